@@ -1,0 +1,449 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see oracle.hpp).
+// Plain C entry points over the restatement so that tests/, smoke() and bench.py's cpu_baseline leg can drive it with ctypes.
+// The record layouts mirror include/isaac_gpu.h byte for byte (checked by tests/test_abi.py) but are declared independently.
+#include "oracle.hpp"
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <algorithm>
+
+using namespace oracle;
+
+extern "C" {
+
+typedef struct
+{
+    int32_t gap_match, gap_mismatch, gap_open, gap_extend, min_gap_extend;
+    uint32_t repeat_threshold, gapped_mismatches_max, semialigned_gap_limit, base_quality_cutoff;
+    uint32_t ignore_neighbors, clip_semialigned, clip_overlapping, scatter_repeats;
+    int32_t dodgy_alignment_score; uint32_t mapq_threshold; uint32_t keep_unaligned; int32_t mate_drift_range;
+    uint32_t first_pass_seeds, seed_length;
+    uint32_t n_reads; uint32_t read_length[2];
+    uint32_t n_seeds;
+    struct { uint16_t offset, length; uint32_t read_index; } seeds[16];
+} oracle_params;
+
+typedef struct { uint32_t min, max, median, low_std_dev, high_std_dev; int32_t best_model[2]; uint32_t stable, mate_min, mate_max; } oracle_tls;
+
+typedef struct
+{
+    int64_t position; double log_probability;
+    uint32_t cluster, read_index, contig_id, observed_length, reverse, mismatch_count, matches_in_a_row, gap_count, edit_distance,
+             smith_waterman_score, unique_seed_count, non_unique_first, non_unique_second, repeat_seeds_count, cigar_offset, cigar_length,
+             low_clipped, high_clipped;
+    int32_t first_seed_index; uint32_t reserved;
+} oracle_candidate;
+
+static thread_local std::string g_error;
+const char *oracle_last_error() { return g_error.c_str(); }
+
+static Params toParams(const oracle_params *c)
+{
+    Params p;
+    p.gapMatchScore = c->gap_match; p.gapMismatchScore = c->gap_mismatch; p.gapOpenScore = c->gap_open; p.gapExtendScore = c->gap_extend; p.minGapExtendScore = c->min_gap_extend;
+    p.repeatThreshold = c->repeat_threshold; p.gappedMismatchesMax = c->gapped_mismatches_max; p.semialignedGapLimit = c->semialigned_gap_limit;
+    p.baseQualityCutoff = c->base_quality_cutoff; p.ignoreNeighbors = c->ignore_neighbors; p.clipSemialigned = c->clip_semialigned; p.clipOverlapping = c->clip_overlapping;
+    p.scatterRepeats = c->scatter_repeats; p.dodgyAlignmentScore = c->dodgy_alignment_score; p.mapqThreshold = c->mapq_threshold; p.keepUnaligned = c->keep_unaligned;
+    p.mateDriftRange = c->mate_drift_range; p.firstPassSeeds = c->first_pass_seeds; p.seedLength = c->seed_length;
+    unsigned offset = 0, firstCycle = 1;
+    for (unsigned r = 0; r < c->n_reads; ++r)
+    {
+        ReadMetadata rm = { c->read_length[r], r, offset, firstCycle }; p.reads.push_back(rm);
+        offset += c->read_length[r]; firstCycle += c->read_length[r];
+    }
+    for (unsigned s = 0; s < c->n_seeds; ++s) { SeedMetadata sm = { c->seeds[s].offset, c->seeds[s].length, c->seeds[s].read_index, s }; p.seeds.push_back(sm); }
+    return p;
+}
+
+// default parameters for the given read geometry (AlignOptions.cpp:77-160 + "auto" seeds)
+int oracle_default_params(uint32_t n_reads, uint32_t len1, uint32_t len2, oracle_params *out)
+{
+    try
+    {
+        const Params p = makeParams(n_reads, len1, len2);
+        memset(out, 0, sizeof(*out));
+        out->gap_match = p.gapMatchScore; out->gap_mismatch = p.gapMismatchScore; out->gap_open = p.gapOpenScore; out->gap_extend = p.gapExtendScore; out->min_gap_extend = p.minGapExtendScore;
+        out->repeat_threshold = p.repeatThreshold; out->gapped_mismatches_max = p.gappedMismatchesMax; out->semialigned_gap_limit = p.semialignedGapLimit;
+        out->base_quality_cutoff = p.baseQualityCutoff; out->ignore_neighbors = p.ignoreNeighbors; out->clip_semialigned = p.clipSemialigned; out->clip_overlapping = p.clipOverlapping;
+        out->scatter_repeats = p.scatterRepeats; out->dodgy_alignment_score = p.dodgyAlignmentScore; out->mapq_threshold = p.mapqThreshold; out->keep_unaligned = p.keepUnaligned;
+        out->mate_drift_range = p.mateDriftRange; out->first_pass_seeds = p.firstPassSeeds; out->seed_length = p.seedLength;
+        out->n_reads = n_reads; out->read_length[0] = len1; out->read_length[1] = n_reads > 1 ? len2 : 0;
+        if (p.seeds.size() > 16) throw std::runtime_error("too many seeds");
+        out->n_seeds = uint32_t(p.seeds.size());
+        for (size_t s = 0; s < p.seeds.size(); ++s) { out->seeds[s].offset = uint16_t(p.seeds[s].offset); out->seeds[s].length = uint16_t(p.seeds[s].length); out->seeds[s].read_index = p.seeds[s].readIndex; }
+        return 0;
+    }
+    catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+
+// ---- banded smith-waterman leaf (BandedSmithWaterman.hh:75-86)
+int oracle_bsw_align(int match, int mismatch, int gap_open, int gap_extend, int max_read_length,
+                     const char *query, uint32_t query_length, const char *database /* query_length + 15 bytes */,
+                     uint32_t *cigar_out, uint32_t cigar_capacity, uint32_t *n_ops, uint32_t *offset)
+{
+    try
+    {
+        BandedSmithWaterman bsw(match, mismatch, gap_open, gap_extend, max_read_length);
+        Cigar cigar;
+        *offset = bsw.align(query, query + query_length, database, database + query_length + 15, cigar);
+        *n_ops = uint32_t(cigar.size());
+        if (cigar.size() > cigar_capacity) throw std::runtime_error("cigar capacity");
+        memcpy(cigar_out, cigar.data(), cigar.size() * 4);
+        return 0;
+    }
+    catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+// constructor overflow rule only (BandedSmithWaterman.cpp:47-53): returns 1 when the reference would throw
+int oracle_bsw_check(int match, int mismatch, int gap_open, int gap_extend, int max_read_length)
+{
+    try { BandedSmithWaterman bsw(match, mismatch, gap_open, gap_extend, max_read_length); return 0; }
+    catch (const std::exception &) { return 1; }
+}
+
+// ---- reference handle: contigs + sorted index
+struct oracle_ref { ContigList contigs; SortedReference index; std::vector<uint8_t> contigHasMatches; };
+
+oracle_ref *oracle_ref_create(const char *bases, const uint64_t *offsets /* n+1 */, uint32_t n_contigs)
+{
+    oracle_ref *r = new oracle_ref;
+    for (uint32_t c = 0; c < n_contigs; ++c)
+    {
+        Contig contig; contig.index = c; contig.name = "c" + std::to_string(c);
+        contig.forward.assign(bases + offsets[c], bases + offsets[c + 1]);
+        r->contigs.push_back(contig);
+        r->index.karyotype.push_back(c);
+    }
+    r->contigHasMatches.assign(n_contigs, 0);
+    return r;
+}
+void oracle_ref_destroy(oracle_ref *r) { delete r; }
+int oracle_ref_build_index(oracle_ref *r, uint32_t repeat_threshold, int annotate_neighbors, uint32_t neighborhood_width)
+{
+    try { r->index = buildSortedReference(r->contigs, 32, repeat_threshold, annotate_neighbors != 0, neighborhood_width); return 0; }
+    catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+// load an index in mask-file layout ({u64 kmer, u64 position} sorted by kmer)
+void oracle_ref_set_index(oracle_ref *r, const uint64_t *kmer_pos_pairs, uint64_t n)
+{
+    r->index.kmers.resize(n);
+    memcpy(r->index.kmers.data(), kmer_pos_pairs, n * 16);
+}
+uint64_t oracle_ref_index_size(const oracle_ref *r) { return r->index.kmers.size(); }
+void oracle_ref_get_index(const oracle_ref *r, uint64_t *kmer_pos_pairs) { memcpy(kmer_pos_pairs, r->index.kmers.data(), r->index.kmers.size() * 16); }
+
+// ---- find matches for one tile (both seed passes), sorted by (cluster, location, seed, reverse)
+int oracle_find_matches(oracle_ref *r, const oracle_params *cp, const uint8_t *bcl, uint32_t n_clusters, uint32_t tile,
+                        uint64_t *matches_out /* pairs {seedId, location} */, uint64_t capacity, uint64_t *n_out, uint8_t *contig_has_matches)
+{
+    try
+    {
+        const Params p = toParams(cp);
+        std::vector<Match> matches;
+        std::vector<uint8_t> hits(r->contigs.size(), 0);
+        findTileMatches(p, r->index, bcl, n_clusters, tile, matches, hits);
+        *n_out = matches.size();
+        if (matches.size() > capacity) throw std::runtime_error("match capacity");
+        memcpy(matches_out, matches.data(), matches.size() * 16);
+        for (size_t i = 0; i < hits.size(); ++i) { if (contig_has_matches) contig_has_matches[i] |= hits[i]; }
+        return 0;
+    }
+    catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+
+static ContigList filteredContigs(const oracle_ref *r, const uint8_t *contig_loaded)
+{
+    // MatchSelector.cpp:85-90,138: contigs without any match are not loaded (empty sequence, length 0)
+    ContigList c = r->contigs;
+    if (contig_loaded) for (size_t i = 0; i < c.size(); ++i) if (!contig_loaded[i]) c[i].forward.clear();
+    return c;
+}
+
+static void fillCandidate(oracle_candidate &o, const FragmentMetadata &f, uint32_t cluster, uint32_t cigarOffset)
+{
+    memset(&o, 0, sizeof(o));
+    o.position = f.position; o.log_probability = f.logProbability; o.cluster = cluster; o.read_index = f.readIndex; o.contig_id = f.contigId;
+    o.observed_length = f.observedLength; o.reverse = f.reverse; o.mismatch_count = f.mismatchCount; o.matches_in_a_row = f.matchesInARow; o.gap_count = f.gapCount;
+    o.edit_distance = f.editDistance; o.smith_waterman_score = f.smithWatermanScore; o.unique_seed_count = f.uniqueSeedCount;
+    o.non_unique_first = f.nonUniqueSeedOffsets.first; o.non_unique_second = f.nonUniqueSeedOffsets.second; o.repeat_seeds_count = f.repeatSeedsCount;
+    o.cigar_offset = cigarOffset; o.cigar_length = f.cigarLength; o.low_clipped = f.lowClipped; o.high_clipped = f.highClipped; o.first_seed_index = f.firstSeedIndex;
+}
+
+// ---- FragmentBuilder::build for every cluster of the match list (FragmentBuilder.hh:62-70); candidates in (cluster, read, list order)
+int oracle_build_fragments(oracle_ref *r, const oracle_params *cp, const uint8_t *contig_loaded, const uint8_t *bcl, uint32_t tile,
+                           const uint64_t *matches, uint64_t n_matches, int with_gaps, int trim,
+                           oracle_candidate *out, uint64_t capacity, uint64_t *n_out, uint32_t *cigar_out, uint64_t cigar_capacity, uint64_t *n_cigar)
+{
+    try
+    {
+        const Params p = toParams(cp);
+        const ContigList contigs = filteredContigs(r, contig_loaded);
+        FragmentBuilder fb(p);
+        Cluster cluster;
+        const Match *mb = reinterpret_cast<const Match *>(matches), *me = mb + n_matches;
+        uint64_t n = 0, nc = 0;
+        const unsigned clusterLength = p.clusterLength();
+        while (mb != me)
+        {
+            const uint64_t clusterId = SeedId(mb->seedId).getCluster();
+            const Match *mn = mb; while (mn != me && SeedId(mn->seedId).getCluster() == clusterId) ++mn;
+            if (!ReferencePosition::fromValue(mb->location).isNoMatch())
+            {
+                cluster.init(p.reads, bcl + clusterId * clusterLength, tile, clusterId, true);
+                if (trim) trimLowQualityEnds(cluster, p.baseQualityCutoff);
+                fb.build(contigs, p.reads, p.seeds, mb, mn, cluster, with_gaps != 0);
+                for (unsigned rd = 0; rd < 2; ++rd) for (size_t i = 0; i < fb.fragments[rd].size(); ++i)
+                {
+                    const FragmentMetadata &f = fb.fragments[rd][i];
+                    if (n >= capacity || nc + f.cigarLength > cigar_capacity) throw std::runtime_error("candidate capacity");
+                    fillCandidate(out[n], f, uint32_t(clusterId), uint32_t(nc));
+                    if (f.cigarLength) memcpy(cigar_out + nc, f.cigarBuffer->data() + f.cigarOffset, f.cigarLength * 4);
+                    nc += f.cigarLength; ++n;
+                }
+            }
+            mb = mn;
+        }
+        *n_out = n; *n_cigar = nc;
+        return 0;
+    }
+    catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+
+static void toTls(const TemplateLengthStatistics &t, oracle_tls *o)
+{
+    o->min = t.min; o->max = t.max; o->median = t.median; o->low_std_dev = t.lowStdDev; o->high_std_dev = t.highStdDev;
+    o->best_model[0] = t.bestModels[0]; o->best_model[1] = t.bestModels[1]; o->stable = t.stable; o->mate_min = t.mateMin; o->mate_max = t.mateMax;
+}
+static TemplateLengthStatistics fromTls(const oracle_tls *o)
+{
+    TemplateLengthStatistics t;
+    t.min = o->min; t.max = o->max; t.median = o->median; t.lowStdDev = o->low_std_dev; t.highStdDev = o->high_std_dev;
+    t.bestModels[0] = TemplateLengthStatistics::AlignmentModel(o->best_model[0]); t.bestModels[1] = TemplateLengthStatistics::AlignmentModel(o->best_model[1]);
+    t.stable = o->stable; t.mateMin = o->mate_min; t.mateMax = o->mate_max;
+    return t;
+}
+
+// ---- MatchSelector::determineTemplateLength (MatchSelector.cpp:188-256)
+int oracle_determine_tls(oracle_ref *r, const oracle_params *cp, const uint8_t *contig_loaded, const uint8_t *bcl, uint32_t tile,
+                         const uint64_t *matches, uint64_t n_matches, oracle_tls *out)
+{
+    try
+    {
+        const Params p = toParams(cp);
+        const ContigList contigs = filteredContigs(r, contig_loaded);
+        MatchSelector ms(p, contigs);
+        const Match *mb = reinterpret_cast<const Match *>(matches);
+        toTls(ms.determineTemplateLength(mb, mb + n_matches, bcl, tile), out);
+        return 0;
+    }
+    catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+
+// ---- MatchSelector::processMatchList for the whole tile (MatchSelector.cpp:258-368); n_threads > 1 splits the match list
+// at cluster boundaries (records are concatenated in cluster order; counters[0..1] = rescue calls, rescue candidate positions)
+int oracle_select(oracle_ref *r, const oracle_params *cp, const uint8_t *contig_loaded, const uint8_t *bcl, uint32_t tile,
+                  const uint64_t *matches, uint64_t n_matches, const oracle_tls *tls, uint32_t n_threads,
+                  void *records_out /* FragmentRecord */, uint64_t capacity, uint64_t *n_out, uint32_t *cigar_out, uint64_t cigar_capacity, uint64_t *n_cigar,
+                  uint64_t *counters)
+{
+    try
+    {
+        const Params p = toParams(cp);
+        const ContigList contigs = filteredContigs(r, contig_loaded);
+        const TemplateLengthStatistics t = fromTls(tls);
+        const Match *mb = reinterpret_cast<const Match *>(matches), *me = mb + n_matches;
+        if (!n_threads) n_threads = 1;
+        std::vector<const Match *> bounds(1, mb);
+        for (uint32_t i = 1; i < n_threads; ++i)
+        {
+            const Match *b = mb + n_matches * i / n_threads;
+            while (b != me && b != mb && SeedId(b->seedId).getCluster() == SeedId((b - 1)->seedId).getCluster()) ++b;
+            if (b < bounds.back()) b = bounds.back();
+            bounds.push_back(b);
+        }
+        bounds.push_back(me);
+        std::vector<std::vector<FragmentRecord> > recs(n_threads);
+        std::vector<std::vector<uint32_t> > cigs(n_threads);
+        std::vector<std::string> errors(n_threads);
+        std::vector<uint64_t> calls(n_threads, 0), cands(n_threads, 0);
+        std::vector<std::thread> threads;
+        for (uint32_t i = 0; i < n_threads; ++i)
+            threads.push_back(std::thread([&, i]()
+            {
+                try
+                {
+                    MatchSelector ms(p, contigs);
+                    ms.selectTile(bounds[i], bounds[i + 1], bcl, tile, t, recs[i], cigs[i]);
+                    calls[i] = ms.templateBuilder.rescueCalls; cands[i] = ms.templateBuilder.rescueCandidates;
+                }
+                catch (const std::exception &e) { errors[i] = e.what(); if (errors[i].empty()) errors[i] = "error"; }
+            }));
+        for (auto &th : threads) th.join();
+        uint64_t n = 0, nc = 0;
+        FragmentRecord *out = reinterpret_cast<FragmentRecord *>(records_out);
+        if (counters) { counters[0] = 0; counters[1] = 0; }
+        for (uint32_t i = 0; i < n_threads; ++i)
+        {
+            if (!errors[i].empty()) throw std::runtime_error(errors[i]);
+            if (n + recs[i].size() > capacity || nc + cigs[i].size() > cigar_capacity) throw std::runtime_error("record capacity");
+            for (size_t k = 0; k < recs[i].size(); ++k) { out[n] = recs[i][k]; out[n].cigarOffset += uint32_t(nc); ++n; }
+            memcpy(cigar_out + nc, cigs[i].data(), cigs[i].size() * 4); nc += cigs[i].size();
+            if (counters) { counters[0] += calls[i]; counters[1] += cands[i]; }
+        }
+        *n_out = n; *n_cigar = nc;
+        return 0;
+    }
+    catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+
+// ---- unit-test hooks for the golden vectors --------------------------------------------------------------------
+// SeedId bit layout and overflow rule (testSeedId.cpp)
+int oracle_seed_id(uint64_t tile, uint64_t barcode, uint64_t cluster, uint64_t seed, uint64_t reverse, uint64_t *value)
+{
+    try { *value = SeedId(tile, barcode, cluster, seed, reverse).value; return 0; }
+    catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+
+// Runs FragmentBuilder::build on literal inputs the way testSimpleIndelAligner.cpp:146-262 / testFragmentBuilder2.cpp do:
+// one contig, reads given as ASCII ('n' allowed) with quality 30 (':'-'!' in the tests' getBcl), explicit seed list and
+// explicit matches (seed index, reverse, contig, seed position).
+int oracle_align_literal(const oracle_params *cp, const char *contig_bases, uint32_t contig_length,
+                         const uint8_t *bcl, const uint64_t *matches, uint64_t n_matches, int with_gaps,
+                         oracle_candidate *out, uint64_t capacity, uint64_t *n_out, uint32_t *cigar_out, uint64_t cigar_capacity, uint64_t *n_cigar)
+{
+    try
+    {
+        const uint64_t offsets[2] = { 0, contig_length };
+        oracle_ref *r = oracle_ref_create(contig_bases, offsets, 1);
+        const int rc = oracle_build_fragments(r, cp, 0, bcl, 0, matches, n_matches, with_gaps, 0, out, capacity, n_out, cigar_out, cigar_capacity, n_cigar);
+        oracle_ref_destroy(r);
+        return rc;
+    }
+    catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+
+// Test harness of testSimpleIndelAligner.cpp:146-262 restated: two ungapped candidates for the same read are built by hand
+// (head at the read's own offset, tail right-aligned to the reference end), then SimpleIndelAligner::alignSimpleIndels runs.
+// Scores 0:-1:-2:-1:-5, gap limit 20000 (testSimpleIndelAligner.cpp:139-158).  Reverse strand of the test reads is the plain
+// reversal (no complement), qualities are the test's "irrelevantQualities" string minus 33.
+int oracle_simple_indel_literal(const char *read, const char *reference, int have_seeds, const uint32_t *seed_offsets /*2*/,
+                                uint32_t left_clip0, uint32_t right_clip1,
+                                oracle_candidate *out /*2*/, uint32_t *cigar_out, uint64_t cigar_capacity, uint64_t *n_cigar)
+{
+    try
+    {
+        static const std::string irrelevantQualities("CFCEEBFHEHDGBDBEDDEGEHHFHEGBHHDDDB<F>FGGBFGGFGCGGGDGGDDFHHHFEGGBGDGGBGGBEGEGGBGEHDHHHGGGGGDGGGG?GGGGCFCEEBFHEHDGBDBEDDEGEHHFHEGBHHDDDBCFCEEBFHEHDGBDBEDDEGEHHFHEGBHHDDDB");
+        const std::string readS(read), referenceS(reference);
+        const long referenceOffset = long(referenceS.find_first_not_of(' '));
+        const std::string referenceWithoutSpaces = referenceS.substr(referenceOffset);
+        const long pos = long(readS.find_first_not_of(' '));
+        const std::string readWithoutSpaces = readS.substr(pos);
+        Cluster cluster; cluster.nReads = 1;
+        Read &rd = cluster[0];
+        rd.forwardSequence.assign(readWithoutSpaces.begin(), readWithoutSpaces.end());
+        rd.forwardQuality.assign(irrelevantQualities.begin(), irrelevantQualities.end());
+        rd.forwardQuality.resize(rd.forwardSequence.size());
+        for (size_t i = 0; i < rd.forwardQuality.size(); ++i) rd.forwardQuality[i] -= 33;
+        rd.reverseSequence = rd.forwardSequence; rd.reverseQuality = rd.forwardQuality;
+        std::reverse(rd.reverseSequence.begin(), rd.reverseSequence.end()); std::reverse(rd.reverseQuality.begin(), rd.reverseQuality.end());
+        std::vector<ReadMetadata> reads; { ReadMetadata rm = { rd.getLength(), 0, 0, 1 }; reads.push_back(rm); }
+        std::vector<SeedMetadata> seeds;
+        if (have_seeds) { SeedMetadata a = { seed_offsets[0], 32, 0, 0 }, b = { seed_offsets[1], 32, 0, 1 }; seeds.push_back(a); seeds.push_back(b); }
+        else
+        {
+            const unsigned readLength = unsigned(std::min<long>(long(readWithoutSpaces.length()), long(referenceS.length()) - pos));
+            SeedMetadata a = { 0, 32, 0, 0 }, b = { readLength - 32 - 1, 32, 0, 1 }; seeds.push_back(a); seeds.push_back(b);
+        }
+        FragmentMetadataList list(2);
+        list[0].lowClipped = (unsigned short)left_clip0; list[1].highClipped = (unsigned short)right_clip1;
+        list[0].readIndex = 0; list[0].contigId = 0; list[0].position = pos - referenceOffset; list[0].firstSeedIndex = 0;
+        list[1].readIndex = 0; list[1].contigId = 0; list[1].position = long(referenceS.length()) - long(readWithoutSpaces.length()) - referenceOffset; list[1].firstSeedIndex = 1;
+        const SimpleIndelAligner aligner(0, -1, -2, -1, -5, 20000);
+        Contig contig; contig.index = 0; contig.name = "vasja"; contig.forward.assign(referenceWithoutSpaces.begin(), referenceWithoutSpaces.end());
+        ContigList contigs(1, contig);
+        const std::vector<char> &referenceV = contigs[0].forward;
+        Cigar cigarBuffer; cigarBuffer.reserve(1024);
+        for (size_t k = 0; k < 2; ++k)
+        {
+            FragmentMetadata &f = list[k];
+            f.cluster = &cluster; f.cigarBuffer = &cigarBuffer; f.cigarOffset = unsigned(cigarBuffer.size()); f.observedLength = rd.getLength();
+            if (0 > f.position)
+            {
+                const long c = std::max<long>(-f.position, f.leftClipped());
+                cigarBuffer.push_back(cigarEncode(unsigned(c), SOFT_CLIP)); ++f.cigarLength; f.observedLength -= unsigned(c); f.position += c;
+            }
+            else if (f.leftClipped())
+            {
+                cigarBuffer.push_back(cigarEncode(f.leftClipped(), SOFT_CLIP)); ++f.cigarLength; f.observedLength -= f.leftClipped(); f.position += f.leftClipped();
+            }
+            long rightClip = 0;
+            if (f.rightClipped() || (f.position + long(f.observedLength) > long(referenceV.size())))
+            {
+                rightClip = std::max<long>(f.rightClipped(), f.position + long(f.observedLength) - long(referenceV.size()));
+                f.observedLength -= unsigned(rightClip);
+            }
+            cigarBuffer.push_back(cigarEncode(f.observedLength, ALIGN)); ++f.cigarLength;
+            if (rightClip) { cigarBuffer.push_back(cigarEncode(unsigned(rightClip), SOFT_CLIP)); ++f.cigarLength; }
+            aligner.updateFragmentCigar(reads, referenceV, f, f.position, cigarBuffer, f.cigarOffset);
+        }
+        if (list[1].getUnclippedPosition() < list[0].getUnclippedPosition()) std::swap(list[0], list[1]);
+        aligner.alignSimpleIndels(cigarBuffer, contigs, reads, seeds, list);
+        uint64_t nc = 0;
+        for (size_t k = 0; k < 2; ++k)
+        {
+            fillCandidate(out[k], list[k], 0, uint32_t(nc));
+            if (nc + list[k].cigarLength > cigar_capacity) throw std::runtime_error("cigar capacity");
+            memcpy(cigar_out + nc, list[k].cigarBuffer->data() + list[k].cigarOffset, list[k].cigarLength * 4); nc += list[k].cigarLength;
+        }
+        *n_cigar = nc;
+        return 0;
+    }
+    catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+
+// Test harness of testFragmentBuilder2.cpp:146-180 restated: ungapped alignment of one read against one contig, optionally followed
+// by the gapped retry with the test's own accept rule.  ELAND scores 2:-1:-15:-3:25.
+int oracle_fragment_builder2_literal(const char *read, const char *reference, int reverse, int have_position, int64_t position, int gapped,
+                                     oracle_candidate *out, uint32_t *cigar_out, uint64_t cigar_capacity, uint64_t *n_cigar, uint32_t *first_mismatch_cycle)
+{
+    try
+    {
+        static const std::string irrelevantQualities("CFCEEBFHEHDGBDBEDDEGEHHFHEGBHHDDDB<F>FGGBFGGFGCGGGDGGDDFHHHFEGGBGDGGBGGBEGEGGBGEHDHHHGGGGGDGGGG?GGGG");
+        std::string r(read); if (reverse) std::reverse(r.begin(), r.end());
+        Cluster cluster; cluster.nReads = 1;
+        Read &rd = cluster[0];
+        rd.forwardSequence.assign(r.begin(), r.end());
+        rd.forwardQuality.assign(irrelevantQualities.begin(), irrelevantQualities.end());
+        if (rd.forwardQuality.size() != rd.forwardSequence.size()) throw std::runtime_error("sequence and quality must be of equal lengths");
+        for (size_t i = 0; i < rd.forwardQuality.size(); ++i) rd.forwardQuality[i] -= 33;
+        rd.reverseSequence = rd.forwardSequence; rd.reverseQuality = rd.forwardQuality;
+        std::reverse(rd.reverseSequence.begin(), rd.reverseSequence.end()); std::reverse(rd.reverseQuality.begin(), rd.reverseQuality.end());
+        std::vector<ReadMetadata> reads; { ReadMetadata a = { 100, 0, 0, 1 }, b = { 100, 1, 100, 101 }; reads.push_back(a); reads.push_back(b); }
+        FragmentMetadata f; f.reverse = reverse != 0;
+        if (have_position) { f.contigId = 0; f.position = position; }
+        if (f.isNoMatch()) { f.contigId = 0; f.position = 0; }
+        Cigar cigarBuffer; cigarBuffer.reserve(1024);
+        f.cluster = &cluster; f.cigarBuffer = &cigarBuffer;
+        Contig contig; contig.index = 0; contig.name = "vasja"; contig.forward.assign(reference, reference + strlen(reference));
+        const UngappedAligner ungapped(2, -1, -15, -3, 25);
+        ungapped.alignUngapped(f, cigarBuffer, reads, contig);
+        if (gapped)
+        {
+            const GappedAligner gappedAligner(200, 2, -1, -15, -3, 25);
+            FragmentMetadata tmp = f;
+            const unsigned matchCount = gappedAligner.alignGapped(tmp, cigarBuffer, reads, contig);
+            if (matchCount + BandedSmithWaterman::WIDEST_GAP_SIZE > f.getObservedLength() && (tmp.mismatchCount <= 5) &&
+                (f.mismatchCount > tmp.mismatchCount) && f.logProbability < tmp.logProbability)
+                f = tmp;
+        }
+        fillCandidate(*out, f, 0, 0);
+        if (f.cigarLength > cigar_capacity) throw std::runtime_error("cigar capacity");
+        if (f.cigarLength) memcpy(cigar_out, f.cigarBuffer->data() + f.cigarOffset, f.cigarLength * 4);
+        *n_cigar = f.cigarLength;
+        *first_mismatch_cycle = f.mismatchCycles.empty() ? 0 : f.mismatchCycles[0];
+        return 0;
+    }
+    catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+
+} // extern "C"

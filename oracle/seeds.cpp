@@ -1,0 +1,322 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see oracle.hpp).
+// Seed descriptor, seed generation, the reference's sort-merge-join match finder and the match sort.
+// Parity unpinned by reference tests (nothing in the reference tests MatchFinder/ExactMaskMatcher directly).
+#include "oracle.hpp"
+#include <algorithm>
+#include <stdexcept>
+#include <map>
+#include <cstring>
+
+namespace oracle
+{
+
+// lib/options/alignOptions/SeedDescriptorOption.cpp:90-151
+unsigned parseAutoSeedDescriptor(bool /*detectSimpleIndels*/, const ReadMetadata &read, unsigned seedLength, std::vector<SeedMetadata> &out)
+{
+    unsigned ret = 1, generated = 0, offset = 0, endOffset = read.length;
+    if (read.length > seedLength)
+    {
+        SeedMetadata s0 = { 0, seedLength, read.index, unsigned(out.size()) }; out.push_back(s0);
+        offset = seedLength;
+        endOffset = read.length - seedLength;
+        SeedMetadata s1 = { endOffset, seedLength, read.index, unsigned(out.size()) }; out.push_back(s1);
+        generated = 2; ret = 2;
+    }
+    while (offset + seedLength <= endOffset)
+    {
+        SeedMetadata s = { offset, seedLength, read.index, unsigned(out.size()) }; out.push_back(s);
+        ++generated; offset += seedLength;
+    }
+    offset = seedLength / 2;
+    if (endOffset > seedLength / 2)
+    {
+        endOffset -= seedLength / 2;
+        while (generated < 4 && offset + seedLength <= endOffset)
+        {
+            SeedMetadata s = { offset, seedLength, read.index, unsigned(out.size()) }; out.push_back(s);
+            ++generated; offset += seedLength;
+        }
+    }
+    return ret;
+}
+
+// SeedDescriptorOption.cpp:209-245
+std::vector<SeedMetadata> autoSeeds(bool detectSimpleIndels, const std::vector<ReadMetadata> &reads, unsigned seedLength, unsigned &firstPassSeeds)
+{
+    std::vector<SeedMetadata> ret;
+    for (size_t i = 0; i < reads.size(); ++i)
+        firstPassSeeds = std::min(firstPassSeeds, parseAutoSeedDescriptor(detectSimpleIndels, reads[i], seedLength, ret));
+    return ret;
+}
+
+// lib/workflow/alignWorkflow/FindMatchesTransition.cpp:90-110
+std::vector<std::vector<unsigned> > seedIndexListPerIteration(const std::vector<SeedMetadata> &seeds, unsigned nReads, unsigned firstPassSeeds)
+{
+    std::vector<std::vector<unsigned> > ret(2);
+    std::vector<unsigned> countsPerRead(nReads, 0);
+    for (size_t i = 0; i < seeds.size(); ++i)
+    {
+        const unsigned iteration = (firstPassSeeds > countsPerRead[seeds[i].readIndex]) ? 0 : 1;
+        ret[iteration].push_back(seeds[i].index);
+        ++countsPerRead[seeds[i].readIndex];
+    }
+    while (!ret.empty() && ret.back().empty()) ret.resize(ret.size() - 1);
+    return ret;
+}
+
+// AlignOptions.cpp:77-160 defaults, :1165-1171 (firstPassSeeds = 2 for "auto" when semialigned-gap-limit != 0)
+Params makeParams(unsigned nReads, unsigned len1, unsigned len2)
+{
+    Params p;
+    unsigned firstCycle = 1, offset = 0;
+    const unsigned lens[2] = { len1, len2 };
+    for (unsigned r = 0; r < nReads; ++r)
+    {
+        ReadMetadata rm = { lens[r], r, offset, firstCycle };
+        p.reads.push_back(rm);
+        offset += lens[r]; firstCycle += lens[r];
+    }
+    p.firstPassSeeds = p.semialignedGapLimit ? 2 : 1;
+    p.seeds = autoSeeds(0 != p.semialignedGapLimit, p.reads, p.seedLength, p.firstPassSeeds);
+    return p;
+}
+
+// include/alignment/SeedMetadata.hh:103-108
+static bool firstCycleLess(const SeedMetadata &l, const SeedMetadata &r)
+{ return l.readIndex < r.readIndex || (l.readIndex == r.readIndex && l.offset < r.offset); }
+
+// include/alignment/Seed.hh:88-93
+static bool orderByKmerSeedIndex(const Seed &l, const Seed &r)
+{ return l.kmer < r.kmer || (l.kmer == r.kmer && SeedId(l.seedId).getSeed() < SeedId(r.seedId).getSeed()); }
+
+// lib/alignment/ClusterSeedGenerator.cpp:138-192 (one barcode, index 0) + SeedGeneratorBase.cpp:71-94
+void generateSeeds(const Params &p, const std::vector<unsigned> &seedIndexList, const uint8_t *bcl, unsigned nClusters,
+                   unsigned tile, const ClusterInfo &complete, std::vector<Seed> &seeds)
+{
+    std::vector<SeedMetadata> ordered;
+    for (size_t i = 0; i < seedIndexList.size(); ++i) ordered.push_back(p.seeds.at(seedIndexList[i]));
+    std::sort(ordered.begin(), ordered.end(), firstCycleLess);
+    const unsigned clusterLength = p.clusterLength();
+    seeds.clear();
+    for (unsigned clusterId = 0; clusterId < nClusters; ++clusterId)
+    {
+        const uint8_t *clusterIt = bcl + size_t(clusterId) * clusterLength;
+        for (size_t s = 0; s < ordered.size(); ++s)
+        {
+            const SeedMetadata &sm = ordered[s];
+            if ((complete[clusterId] >> sm.readIndex) & 1) continue;
+            Seed fw = { 0, SeedId(tile, 0, clusterId, sm.index, 0).value };
+            Seed rv = { 0, SeedId(tile, 0, clusterId, sm.index, 1).value };
+            const uint8_t *baseIt = clusterIt + sm.offset + p.reads.at(sm.readIndex).offset;
+            for (unsigned len = 32; len; --len, ++baseIt)
+            {
+                const uint8_t base = *baseIt;
+                if (base & 0xfc)
+                {
+                    const uint64_t f = base & 3, r = (~f) & 3;
+                    fw.kmer <<= 2; fw.kmer |= f;
+                    rv.kmer >>= 2; rv.kmer |= r << 62;
+                }
+                else
+                {
+                    // Seed.hh:80-85 makeNSeed(tile, barcode, cluster, lowestSeedId): reverse bit = !lowest
+                    const bool lowest = (0 == sm.index);
+                    fw.kmer = ~uint64_t(0); fw.seedId = SeedId(tile, 0, clusterId, SeedId::SEED_MASK, !lowest).value;
+                    rv = fw;
+                    break;
+                }
+            }
+            seeds.push_back(fw); seeds.push_back(rv);
+        }
+    }
+    std::sort(seeds.begin(), seeds.end(), orderByKmerSeedIndex);
+}
+
+// lib/alignment/matchFinder/ExactMaskMatcher.cpp:83-184 over the concatenation of all mask files, plus the N-seed handling of
+// MatchFinder.cpp:213-249.  The reference reads `isReadComplete` in generateNoMatches while other mask threads may be
+// setting it (benign race); this restatement resolves it by evaluating NoMatch emission after the whole pass.
+void findMatchesExact(const Params &p, const SortedReference &ref, const std::vector<Seed> &seeds, bool closeRepeats, bool storeNoMatches,
+                      ClusterInfo &complete, std::vector<Match> &out, std::vector<uint8_t> &contigHasMatches)
+{
+    const ReferencePosition tooMany(ReferencePosition::TooManyMatch), noMatch(ReferencePosition::NoMatch);
+    std::vector<Seed> pendingNoMatch;
+    size_t nextSeed = 0, nextRef = 0;
+    const size_t nRef = ref.kmers.size();
+    std::vector<ReferenceKmer> repeatList;
+    // seeds are sorted by (kmer, seed index); N-seeds (kmer ~0, seed index 255) are at the very end
+    size_t endSeeds = seeds.size();
+    while (endSeeds && SeedId(seeds[endSeeds - 1].seedId).isNSeedId()) --endSeeds;
+    while (endSeeds != nextSeed)
+    {
+        const size_t currentSeed = nextSeed;
+        while (endSeeds != nextSeed && seeds[currentSeed].kmer == seeds[nextSeed].kmer) ++nextSeed;
+        while (nextRef < nRef && seeds[currentSeed].kmer > ref.kmers[nextRef].kmer) ++nextRef;
+        repeatList.clear();
+        while (nextRef < nRef && seeds[currentSeed].kmer == ref.kmers[nextRef].kmer)
+        {
+            if (repeatList.size() < p.repeatThreshold)
+            {
+                ReferenceKmer rk = { ref.kmers[nextRef].kmer, ReferencePosition::fromValue(ref.kmers[nextRef].position).translateContig(ref.karyotype).value };
+                repeatList.push_back(rk);
+            }
+            ++nextRef;
+        }
+        if (repeatList.empty())
+        {
+            if (storeNoMatches) for (size_t s = currentSeed; s < nextSeed; ++s) pendingNoMatch.push_back(seeds[s]);
+        }
+        else if (repeatList.size() >= p.repeatThreshold || ReferencePosition::fromValue(repeatList.front().position).isTooManyMatch())
+        {
+            for (size_t s = currentSeed; s < nextSeed; ++s)
+            {
+                const SeedId id(seeds[s].seedId);
+                Match m = { id.value, tooMany.value }; out.push_back(m);
+                if (closeRepeats) complete[id.getCluster()] |= uint8_t(1 << p.seeds[id.getSeed()].readIndex);
+            }
+        }
+        else
+        {
+            const ReferencePosition anyPosition = ReferencePosition::fromValue(repeatList.front().position);
+            for (size_t s = currentSeed; s < nextSeed; ++s)
+            {
+                const SeedId id(seeds[s].seedId);
+                for (size_t r = 0; r < repeatList.size(); ++r) { Match m = { id.value, repeatList[r].position }; out.push_back(m); }
+                if (p.ignoreNeighbors || !anyPosition.hasNeighbors()) complete[id.getCluster()] |= uint8_t(1 << p.seeds[id.getSeed()].readIndex);
+            }
+            for (size_t r = 0; r < repeatList.size(); ++r) // MatchDistribution::addMatches (>= 1 per repeat) -> "contig has matches"
+                contigHasMatches.at(ReferencePosition::fromValue(repeatList[r].position).getContigId()) = 1;
+        }
+    }
+    for (size_t i = 0; i < pendingNoMatch.size(); ++i)
+    {
+        const SeedId id(pendingNoMatch[i].seedId);
+        if (!((complete[id.getCluster()] >> p.seeds[id.getSeed()].readIndex) & 1)) { Match m = { id.value, noMatch.value }; out.push_back(m); }
+    }
+    if (storeNoMatches) // MatchFinder.cpp:231-246
+        for (size_t s = endSeeds; s < seeds.size(); ++s) { Match m = { seeds[s].seedId, noMatch.value }; out.push_back(m); }
+}
+
+// lib/workflow/alignWorkflow/SelectMatchesTransition.cpp:242-254
+bool sortByTileBarcodeClusterLocation(const Match &l, const Match &r)
+{
+    const SeedId ls(l.seedId), rs(r.seedId);
+    return ls.getTileBarcodeCluster() < rs.getTileBarcodeCluster() ||
+        (ls.getTileBarcodeCluster() == rs.getTileBarcodeCluster() && (l.location < r.location ||
+            (l.location == r.location && ls.getSeed() < rs.getSeed())));
+}
+
+// FindMatchesTransition.cpp:391-427 for one tile, default options (no neighbor pass).  The final sort adds the reverse bit as
+// the last key: the reference's parallelSort leaves the order of (cluster, location, seed)-equal matches unspecified.
+void findTileMatches(const Params &p, const SortedReference &ref, const uint8_t *bcl, unsigned nClusters, unsigned tile,
+                     std::vector<Match> &matches, std::vector<uint8_t> &contigHasMatches)
+{
+    const std::vector<std::vector<unsigned> > perIteration = seedIndexListPerIteration(p.seeds, unsigned(p.reads.size()), p.firstPassSeeds);
+    ClusterInfo complete(nClusters, 0);
+    matches.clear();
+    std::vector<Seed> seeds;
+    generateSeeds(p, perIteration.at(0), bcl, nClusters, tile, complete, seeds);
+    findMatchesExact(p, ref, seeds, false, 1 == perIteration.size(), complete, matches, contigHasMatches);
+    if (2 == perIteration.size())
+    {
+        generateSeeds(p, perIteration.at(1), bcl, nClusters, tile, complete, seeds);
+        findMatchesExact(p, ref, seeds, true, true, complete, matches, contigHasMatches);
+    }
+    std::sort(matches.begin(), matches.end(), [](const Match &l, const Match &r)
+    {
+        if (sortByTileBarcodeClusterLocation(l, r)) return true;
+        if (sortByTileBarcodeClusterLocation(r, l)) return false;
+        return (l.seedId & 1) < (r.seedId & 1);
+    });
+}
+
+// ---------------------------------------------------------------- index builder
+// lib/reference/ReferenceSorter.cpp:105-261: forward-strand k-mers are stored; reverse-complement k-mers only take part in the
+// repeat count.  A k-mer with more than `repeatThreshold` (fwd+rc) occurrences is stored as a single TooManyMatch entry.
+// Neighbor flag (NeighborsFinder.cpp:395-446): set when another distinct reference k-mer (either strand) exists within Hamming
+// distance 1..neighborhoodWidth.  Computed here by the same pigeonhole idea (8 blocks of 4 bases, any 4 blocks equal) but with
+// hashing instead of 70 sorted permutations; small genomes only.
+static unsigned hamming2bit(uint64_t a, uint64_t b)
+{
+    uint64_t x = a ^ b;
+    x = (x | (x >> 1)) & 0x5555555555555555ULL;
+    return unsigned(__builtin_popcountll(x));
+}
+
+SortedReference buildSortedReference(const ContigList &contigs, unsigned seedLength, unsigned repeatThreshold, bool annotateNeighbors, unsigned neighborhoodWidth)
+{
+    if (32 != seedLength) throw std::invalid_argument("only 32-mers are supported");
+    struct Entry { uint64_t kmer; uint64_t pos; bool fwd; };
+    std::vector<Entry> all;
+    for (size_t c = 0; c < contigs.size(); ++c)
+    {
+        const std::vector<char> &s = contigs[c].forward;
+        uint64_t forward = 0, reverse = 0; unsigned bad = 32;
+        for (size_t position = 0; position < s.size(); ++position)
+        {
+            if (bad) --bad;
+            unsigned v;
+            switch (s[position]) { case 'A': case 'a': v = 0; break; case 'C': case 'c': v = 1; break; case 'G': case 'g': v = 2; break; case 'T': case 't': v = 3; break; default: v = 4; }
+            if (v >> 2) bad = 32;
+            forward <<= 2; forward |= (v & 3);
+            reverse >>= 2; reverse |= uint64_t((~v) & 3) << 62;
+            if (0 == bad)
+            {
+                const uint64_t kmerPosition = position + 1 - 32;
+                Entry f = { forward, ReferencePosition(c, kmerPosition, false).value, true }; all.push_back(f);
+                Entry r = { reverse, ReferencePosition(c, kmerPosition, true).value, false }; all.push_back(r);
+            }
+        }
+    }
+    std::stable_sort(all.begin(), all.end(), [](const Entry &a, const Entry &b) { return a.kmer < b.kmer; });
+    // distinct k-mers (both strands) for the neighbor search
+    std::vector<uint64_t> distinct;
+    for (size_t i = 0; i < all.size(); ++i) if (distinct.empty() || distinct.back() != all[i].kmer) distinct.push_back(all[i].kmer);
+    std::vector<uint8_t> hasNeighbor(distinct.size(), 0);
+    if (annotateNeighbors && neighborhoodWidth)
+    {
+        // choose 4 of 8 4-base blocks as the exact-match key (C(8,4) = 70 choices)
+        for (unsigned mask = 0; mask < 256; ++mask)
+        {
+            if (__builtin_popcount(mask) != 4) continue;
+            uint64_t keep = 0;
+            for (unsigned b = 0; b < 8; ++b) if ((mask >> b) & 1) keep |= uint64_t(0xff) << (8 * b);
+            std::vector<std::pair<uint64_t, unsigned> > keyed(distinct.size());
+            for (size_t i = 0; i < distinct.size(); ++i) keyed[i] = std::make_pair(distinct[i] & keep, unsigned(i));
+            std::sort(keyed.begin(), keyed.end());
+            for (size_t i = 0; i < keyed.size();)
+            {
+                size_t j = i; while (j < keyed.size() && keyed[j].first == keyed[i].first) ++j;
+                for (size_t a = i; a < j; ++a) for (size_t b = a + 1; b < j; ++b)
+                {
+                    const unsigned d = hamming2bit(distinct[keyed[a].second], distinct[keyed[b].second]);
+                    if (d && d <= neighborhoodWidth) { hasNeighbor[keyed[a].second] = 1; hasNeighbor[keyed[b].second] = 1; }
+                }
+                i = j;
+            }
+        }
+    }
+    SortedReference ret;
+    for (size_t c = 0; c < contigs.size(); ++c) ret.karyotype.push_back(unsigned(c));
+    size_t d = 0;
+    for (size_t i = 0; i < all.size();)
+    {
+        size_t j = i; while (j < all.size() && all[j].kmer == all[i].kmer) ++j;
+        while (distinct[d] != all[i].kmer) ++d;
+        bool anyFwd = false; for (size_t a = i; a < j; ++a) anyFwd |= all[a].fwd;
+        if (anyFwd)
+        {
+            if (repeatThreshold < j - i)
+            {
+                ReferenceKmer rk = { all[i].kmer, ReferencePosition(ReferencePosition::TooManyMatch).value }; ret.kmers.push_back(rk);
+            }
+            else for (size_t a = i; a < j; ++a) if (all[a].fwd)
+            {
+                ReferenceKmer rk = { all[a].kmer, ReferencePosition::fromValue(all[a].pos).setNeighbors(hasNeighbor[d]).value }; ret.kmers.push_back(rk);
+            }
+        }
+        i = j;
+    }
+    return ret;
+}
+
+} // namespace oracle

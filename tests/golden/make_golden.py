@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures under tests/golden/ from the reference's own cppunit known-answer tests.
+
+Run in the build container only (it reads /root/reference, which does not exist on the GPU box):
+
+    python tests/golden/make_golden.py
+
+What is extracted is DATA: the literal inputs and the asserted outputs of
+  * lib/alignment/cppunit/testSimpleIndelAligner.cpp:264-615   -> simple_indel.json
+  * lib/alignment/cppunit/testFragmentBuilder2.cpp:183-307     -> fragment_builder2.json
+  * lib/alignment/cppunit/testBandedSmithWaterman.cpp:79-225   -> bsw.json (the construction recipe of the test is re-run here
+    on genomes drawn with glibc rand() exactly like getGenome() at :33-43; the asserted CIGARs are the test's literals)
+  * lib/alignment/cppunit/testSeedId.cpp                        -> seed_id.json
+No reference source text is stored.
+"""
+import ctypes
+import json
+import os
+import re
+
+REF = "/root/reference/src/c++/lib/alignment/cppunit"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def strip_comments(s):
+    s = re.sub(r"/\*.*?\*/", "", s, flags=re.S)
+    s = re.sub(r"//[^\n]*", "", s)
+    return s
+
+
+def split_args(argtext):
+    """split a C++ argument list at top-level commas; adjacent string literals are concatenated"""
+    args, cur, depth, i, in_str = [], "", 0, 0, False
+    while i < len(argtext):
+        c = argtext[i]
+        if in_str:
+            cur += c
+            if c == "\\":
+                cur += argtext[i + 1]
+                i += 1
+            elif c == '"':
+                in_str = False
+        else:
+            if c == '"':
+                in_str = True
+                cur += c
+            elif c in "([{":
+                depth += 1
+                cur += c
+            elif c in ")]}":
+                depth -= 1
+                cur += c
+            elif c == "," and depth == 0:
+                args.append(cur.strip())
+                cur = ""
+            else:
+                cur += c
+        i += 1
+    if cur.strip():
+        args.append(cur.strip())
+    out = []
+    for a in args:
+        lits = re.findall(r'"((?:[^"\\]|\\.)*)"', a)
+        if lits and re.fullmatch(r'(\s*"(?:[^"\\]|\\.)*"\s*)+', a):
+            out.append(("str", "".join(lits)))
+        else:
+            out.append(("id", a))
+    return out
+
+
+def find_call(text, start):
+    """text[start] is just after 'align(' ; returns (argtext, end index after ')')"""
+    depth, i, in_str = 1, start, False
+    while depth:
+        c = text[i]
+        if in_str:
+            if c == "\\":
+                i += 1
+            elif c == '"':
+                in_str = False
+        else:
+            if c == '"':
+                in_str = True
+            elif c == "(":
+                depth += 1
+            elif c == ")":
+                depth -= 1
+        i += 1
+    return text[start:i - 1], i
+
+
+def enclosing_block(text, pos):
+    depth, i = 0, pos
+    while i >= 0:
+        if text[i] == "}":
+            depth += 1
+        elif text[i] == "{":
+            if depth == 0:
+                break
+            depth -= 1
+        i -= 1
+    begin = i
+    depth, j = 0, pos
+    while j < len(text):
+        if text[j] == "{":
+            depth += 1
+        elif text[j] == "}":
+            if depth == 0:
+                break
+            depth -= 1
+        j += 1
+    return begin, j
+
+
+def make_simple_indel():
+    text = strip_comments(open(os.path.join(REF, "testSimpleIndelAligner.cpp")).read())
+    body = text[text.index("void TestSimpleIndelAligner::testEverything()"):]
+    cases = []
+    for m in re.finditer(r"\balign\(", body):
+        argtext, end = find_call(body, m.end())
+        args = split_args(argtext)
+        b, e = enclosing_block(body, m.start())
+        before, after = body[b:m.start()], body[end:e]
+        case = {"read": args[0][1], "reference": args[1][1], "seeds": None, "left_clip0": 0, "right_clip1": 0, "expect": {}}
+        if len(args) == 4:
+            seeds = re.findall(r"SeedMetadata\(\s*(\d+)\s*,\s*(\d+)\s*,\s*(\d+)\s*,\s*(\d+)\s*\)", before)
+            assert len(seeds) == 2 and all(s[1] == "32" and s[2] == "0" for s in seeds) and [s[3] for s in seeds] == ["0", "1"], seeds
+            case["seeds"] = [int(seeds[0][0]), int(seeds[1][0])]
+        lc = re.search(r"fragmentMetadataList\[0\]\.leftClipped\(\)\s*=\s*(\d+)", before)
+        rc = re.search(r"fragmentMetadataList\[1\]\.rightClipped\(\)\s*=\s*(\d+)", before)
+        if lc:
+            case["left_clip0"] = int(lc.group(1))
+        if rc:
+            case["right_clip1"] = int(rc.group(1))
+        for am in re.finditer(r"CPPUNIT_ASSERT_EQUAL\((.*?),\s*(?:unsigned\()?fragmentMetadataList\[0\]\.(\w+)\(\)(?:\.getPosition\(\))?\)?\);", after):
+            expected, what = am.group(1).strip(), am.group(2)
+            sm = re.match(r'std::string\("(.*)"\)', expected)
+            case["expect"][what] = sm.group(1) if sm else int(re.match(r"(\d+)", expected).group(1))
+        assert "getCigarString" in case["expect"], after
+        cases.append(case)
+    assert len(cases) == 22, len(cases)
+    json.dump({"source": "lib/alignment/cppunit/testSimpleIndelAligner.cpp:264-615", "scores": [0, -1, -2, -1, -5], "gap_limit": 20000, "cases": cases},
+              open(os.path.join(OUT, "simple_indel.json"), "w"), indent=1)
+    return len(cases)
+
+
+def make_fragment_builder2():
+    text = strip_comments(open(os.path.join(REF, "testFragmentBuilder2.cpp")).read())
+    cases = []
+    for fm in re.finditer(r"void TestFragmentBuilder2::(test\w+)\(\)\s*\{", text):
+        name = fm.group(1)
+        if name == "testEverything":
+            continue
+        b = fm.end()
+        _, e = enclosing_block(text, b)
+        body = text[b:e]
+        m = re.search(r"\balign\(", body)
+        argtext, end = find_call(body, m.end())
+        args = split_args(argtext)
+        case = {"name": name, "read": args[0][1], "reference": args[1][1], "reverse": "reverse = true" in body[:m.start()],
+                "position": None, "gapped": len(args) == 5 and args[4][1] == "true", "expect": {}}
+        pm = re.search(r"fragmentMetadata\.position\s*=\s*(-?\d+)", body[:m.start()])
+        if pm:
+            case["position"] = int(pm.group(1))
+        after = body[end:]
+        for am in re.finditer(r"CPPUNIT_ASSERT_EQUAL\((.*?),\s*(?:unsigned\(\*)?fragmentMetadata\.(\w+)\(\)\)?\);", after):
+            expected, what = am.group(1).strip(), am.group(2)
+            sm = re.match(r'std::string\("(.*)"\)', expected)
+            rp = re.match(r"isaac::reference::ReferencePosition\((\d+),\s*(\d+)U?\)", expected)
+            case["expect"][what] = sm.group(1) if sm else [int(rp.group(1)), int(rp.group(2))] if rp else int(re.match(r"(\d+)", expected).group(1))
+        cases.append(case)
+    assert len(cases) == 5, len(cases)
+    json.dump({"source": "lib/alignment/cppunit/testFragmentBuilder2.cpp:183-307", "scores": [2, -1, -15, -3, 25], "cases": cases},
+              open(os.path.join(OUT, "fragment_builder2.json"), "w"), indent=1)
+    return len(cases)
+
+
+def make_bsw():
+    """testBandedSmithWaterman.cpp: the genome is 1000 draws of "ACGT"[rand() % 4].  The rand() state at the time the fixture
+    is constructed depends on how many draws other cppunit fixtures made before it, so the recipe is evaluated on the first
+    eight consecutive 1000-base genomes of the glibc rand() stream (default seed 1); the asserted CIGARs hold for any of them
+    (the test is written to be genome independent: "no Ts to ensure constant location")."""
+    libc = ctypes.CDLL("libc.so.6")
+    libc.srand(1)
+    genomes = ["".join("ACGT"[libc.rand() % 4] for _ in range(1000)) for _ in range(8)]
+    cases = []
+    for gi, genome in enumerate(genomes):
+        # testUngapped :79-103
+        database = genome[100:215]
+        for i in range(0, 16):
+            cases.append({"name": "ungapped", "genome": gi, "query": database[i:i + 100], "database": database, "cigar": [1600]})
+        # testSingleDeletion :105-131
+        left = right = 40
+        deletion = "AGAGCAGCGAGCGACAGCAGCAGCAAA"
+        for dlen in range(1, 14):
+            dl = 7 - (dlen // 2)
+            dlS = genome[100:100 + dl]
+            leftS = genome[100 + dl:100 + dl + left - 1] + "T"
+            rightS = genome[100 + dl + left:100 + dl + left + right]
+            delS = deletion[:dlen]
+            drD = 15 - dl - len(delS)
+            drDS = genome[100 + dl + left + right:100 + dl + left + right + drD]
+            cases.append({"name": "single_deletion", "genome": gi, "query": leftS + rightS, "database": dlS + leftS + delS + rightS + drDS,
+                          "cigar": [(left << 4) | 0, (len(delS) << 4) | 2, (right << 4) | 0]})
+        # testSingleInsertion :133-154
+        database = genome[100:320]
+        qlen = len(database) - 15
+        for ilen in range(1, 10):
+            if database[9 + 100 - 1] == "T":
+                # the inserted bases are Ts: when the base in front of the insertion point is a T as well, "99M<n>I" scores
+                # the same as the asserted "100M<n>I" and the recipe has no unique answer -> not a known-answer vector
+                continue
+            left = 100
+            right = qlen - left - ilen
+            dl = 9
+            query = database[dl:dl + left] + "T" * ilen + database[left + dl:left + dl + right]
+            cases.append({"name": "single_insertion", "genome": gi, "query": query, "database": database,
+                          "cigar": [(left << 4) | 0, (ilen << 4) | 1, (right << 4) | 0]})
+        # testMultipleIndels :156-212
+        left = center = right = 20
+        dl = 6
+        dlS = genome[100:100 + dl]
+        leftS = genome[100 + dl:100 + dl + left - 1] + "T"
+        ins1, ins2 = "A", "CG"
+        centerS = genome[100 + dl + left:100 + dl + left + center - 1] + "T"
+        del1, del2 = "AAG", "ACAG"
+        rightS = genome[100 + dl + left + center:100 + dl + left + center + right]
+        tail = 100 + dl + left + center + right
+        drID = 15 - dl + len(ins1) - len(del2)
+        cases.append({"name": "ins_del", "genome": gi, "query": leftS + ins1 + centerS + rightS, "database": dlS + leftS + centerS + del2 + rightS + genome[tail:tail + drID],
+                      "cigar": [(left << 4) | 0, (len(ins1) << 4) | 1, (center << 4) | 0, (len(del2) << 4) | 2, (right << 4) | 0]})
+        drI2 = 15 - dl + len(ins1) + len(ins2)
+        cases.append({"name": "ins_ins", "genome": gi, "query": leftS + ins1 + centerS + ins2 + rightS, "database": dlS + leftS + centerS + rightS + genome[tail:tail + drI2],
+                      "cigar": [(left << 4) | 0, (len(ins1) << 4) | 1, (center << 4) | 0, (len(ins2) << 4) | 1, (right << 4) | 0]})
+        drD2 = 15 - dl - len(del1) - len(del2)
+        cases.append({"name": "del_del", "genome": gi, "query": leftS + centerS + rightS, "database": dlS + leftS + del1 + centerS + del2 + rightS + genome[tail:tail + drD2],
+                      "cigar": [(left << 4) | 0, (len(del1) << 4) | 2, (center << 4) | 0, (len(del2) << 4) | 2, (right << 4) | 0]})
+    for c in cases:
+        assert len(c["database"]) == len(c["query"]) + 15, c["name"]
+    overflow = [  # testOverflow :214-225: (match, mismatch, open, extend, maxReadLength, throws)
+        [2, -1, 6, 3, 5460, False], [2, -1, 7, 3, 4681, True], [2, -1, 17, 3, 3681, True], [2, -1, 11, 3, 13681, True]]
+    json.dump({"source": "lib/alignment/cppunit/testBandedSmithWaterman.cpp:45-225", "scores": [2, -1, 15, 3], "max_read_length": 300,
+               "cases": cases, "overflow": overflow}, open(os.path.join(OUT, "bsw.json"), "w"))
+    return len(cases)
+
+
+def make_seed_id():
+    """testSeedId.cpp:35-122: the test is written against the symbolic masks; the data below are those masks spelled out
+    (widths tile 12 / barcode 12 / cluster 31 / seed 8 / reverse 1, SeedId.hh:64-68) plus the literal `other` case."""
+    masks = {"tile": (1 << 12) - 1, "barcode": (1 << 12) - 1, "cluster": (1 << 31) - 1, "seed": (1 << 8) - 1, "reverse": 1}
+    order = ["tile", "barcode", "cluster", "seed", "reverse"]
+    valid = [[0, 0, 0, 0, 0], [masks[k] for k in order], [4020, 1234, 1234567, 3, 1]]
+    for i, k in enumerate(order):
+        v = [0] * 5
+        v[i] = masks[k]
+        valid.append(v)
+    throws = []
+    for i, k in enumerate(order):
+        v = [0] * 5
+        v[i] = masks[k] + 1
+        throws.append(v)
+    json.dump({"source": "lib/alignment/cppunit/testSeedId.cpp:35-122", "order": order, "valid": valid, "throws": throws},
+              open(os.path.join(OUT, "seed_id.json"), "w"), indent=1)
+    return len(valid), len(throws)
+
+
+if __name__ == "__main__":
+    print("simple_indel cases:", make_simple_indel())
+    print("fragment_builder2 cases:", make_fragment_builder2())
+    print("bsw cases:", make_bsw())
+    print("seed_id:", make_seed_id())

@@ -1,0 +1,202 @@
+"""ctypes binding of oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.  The product package
+(isaac_aligner_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+
+class Seed(C.Structure):
+    _fields_ = [("offset", C.c_uint16), ("length", C.c_uint16), ("read_index", C.c_uint32)]
+
+
+class Params(C.Structure):
+    _fields_ = [("gap_match", C.c_int32), ("gap_mismatch", C.c_int32), ("gap_open", C.c_int32), ("gap_extend", C.c_int32), ("min_gap_extend", C.c_int32),
+                ("repeat_threshold", C.c_uint32), ("gapped_mismatches_max", C.c_uint32), ("semialigned_gap_limit", C.c_uint32), ("base_quality_cutoff", C.c_uint32),
+                ("ignore_neighbors", C.c_uint32), ("clip_semialigned", C.c_uint32), ("clip_overlapping", C.c_uint32), ("scatter_repeats", C.c_uint32),
+                ("dodgy_alignment_score", C.c_int32), ("mapq_threshold", C.c_uint32), ("keep_unaligned", C.c_uint32), ("mate_drift_range", C.c_int32),
+                ("first_pass_seeds", C.c_uint32), ("seed_length", C.c_uint32),
+                ("n_reads", C.c_uint32), ("read_length", C.c_uint32 * 2), ("n_seeds", C.c_uint32), ("seeds", Seed * 16)]
+
+
+class Tls(C.Structure):
+    _fields_ = [("min", C.c_uint32), ("max", C.c_uint32), ("median", C.c_uint32), ("low_std_dev", C.c_uint32), ("high_std_dev", C.c_uint32),
+                ("best_model", C.c_int32 * 2), ("stable", C.c_uint32), ("mate_min", C.c_uint32), ("mate_max", C.c_uint32)]
+
+    def astuple(self):
+        return (self.min, self.max, self.median, self.low_std_dev, self.high_std_dev, self.best_model[0], self.best_model[1], self.stable, self.mate_min, self.mate_max)
+
+
+CANDIDATE_DTYPE = np.dtype([("position", "<i8"), ("log_probability", "<f8"), ("cluster", "<u4"), ("read_index", "<u4"), ("contig_id", "<u4"),
+                            ("observed_length", "<u4"), ("reverse", "<u4"), ("mismatch_count", "<u4"), ("matches_in_a_row", "<u4"), ("gap_count", "<u4"),
+                            ("edit_distance", "<u4"), ("smith_waterman_score", "<u4"), ("unique_seed_count", "<u4"), ("non_unique_first", "<u4"),
+                            ("non_unique_second", "<u4"), ("repeat_seeds_count", "<u4"), ("cigar_offset", "<u4"), ("cigar_length", "<u4"),
+                            ("low_clipped", "<u4"), ("high_clipped", "<u4"), ("first_seed_index", "<i4"), ("reserved", "<u4")])
+assert CANDIDATE_DTYPE.itemsize == 96
+
+RECORD_DTYPE = np.dtype([("f_strand_position", "<u8"), ("mate_f_strand_position", "<u8"), ("bam_tlen", "<i4"), ("observed_length", "<u4"),
+                         ("low_clipped", "<u2"), ("high_clipped", "<u2"), ("alignment_score", "<u2"), ("template_alignment_score", "<u2"),
+                         ("read_length", "<u2"), ("cigar_length", "<u2"), ("gap_count", "<u2"), ("edit_distance", "<u2"),
+                         ("flags", "<u4"), ("cigar_offset", "<u4"), ("tile", "<u4"), ("cluster_id", "<u4"), ("mapq", "<u4"), ("reserved", "<u4")])
+assert RECORD_DTYPE.itemsize == 64
+
+MATCH_DTYPE = np.dtype([("seed_id", "<u8"), ("location", "<u8")])
+INDEX_DTYPE = np.dtype([("kmer", "<u8"), ("position", "<u8")])
+
+CIGAR_OPS = "MIDNSHP=X?"
+
+
+def cigar_string(words):
+    return "".join("%d%s" % (int(w) >> 4, CIGAR_OPS[min(int(w) & 0xF, 9)]) for w in words)
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.lib = lib
+        lib.oracle_last_error.restype = C.c_char_p
+        lib.oracle_ref_create.restype = C.c_void_p
+        lib.oracle_ref_index_size.restype = C.c_uint64
+
+    def check(self, rc):
+        if rc:
+            raise RuntimeError(self.lib.oracle_last_error().decode())
+
+    def default_params(self, n_reads, len1, len2=0):
+        p = Params()
+        self.check(self.lib.oracle_default_params(C.c_uint32(n_reads), C.c_uint32(len1), C.c_uint32(len2), C.byref(p)))
+        return p
+
+    def bsw_align(self, scores, max_read_length, query, database):
+        q, d = query.encode() if isinstance(query, str) else bytes(query), database.encode() if isinstance(database, str) else bytes(database)
+        assert len(d) == len(q) + 15
+        cig = np.zeros(1024, np.uint32)
+        n, off = C.c_uint32(), C.c_uint32()
+        self.check(self.lib.oracle_bsw_align(scores[0], scores[1], scores[2], scores[3], max_read_length, q, C.c_uint32(len(q)), d, ptr(cig), C.c_uint32(1024), C.byref(n), C.byref(off)))
+        return cig[:n.value].copy(), off.value
+
+    def bsw_check(self, match, mismatch, gap_open, gap_extend, max_read_length):
+        return bool(self.lib.oracle_bsw_check(match, mismatch, gap_open, gap_extend, max_read_length))
+
+    def seed_id(self, tile, barcode, cluster, seed, reverse):
+        v = C.c_uint64()
+        self.check(self.lib.oracle_seed_id(C.c_uint64(tile), C.c_uint64(barcode), C.c_uint64(cluster), C.c_uint64(seed), C.c_uint64(reverse), C.byref(v)))
+        return v.value
+
+    def simple_indel_literal(self, read, reference, seeds, left_clip0, right_clip1):
+        out = np.zeros(2, CANDIDATE_DTYPE)
+        cig = np.zeros(256, np.uint32)
+        n = C.c_uint64()
+        so = (C.c_uint32 * 2)(*(seeds or [0, 0]))
+        self.check(self.lib.oracle_simple_indel_literal(read.encode(), reference.encode(), 1 if seeds else 0, so, C.c_uint32(left_clip0), C.c_uint32(right_clip1),
+                                                        ptr(out), ptr(cig), C.c_uint64(256), C.byref(n)))
+        return out, cig[:n.value].copy()
+
+    def fragment_builder2_literal(self, read, reference, reverse, position, gapped):
+        out = np.zeros(1, CANDIDATE_DTYPE)
+        cig = np.zeros(256, np.uint32)
+        n, cyc = C.c_uint64(), C.c_uint32()
+        self.check(self.lib.oracle_fragment_builder2_literal(read.encode(), reference.encode(), int(reverse), int(position is not None), C.c_int64(position or 0), int(gapped),
+                                                             ptr(out), ptr(cig), C.c_uint64(256), C.byref(n), C.byref(cyc)))
+        return out[0], cig[:n.value].copy(), cyc.value
+
+    def reference(self, contigs):
+        return OracleReference(self, contigs)
+
+
+class OracleReference:
+    """contigs (list of bytes/str, ASCII ACGTN) + sorted 32-mer index"""
+
+    def __init__(self, oracle, contigs):
+        self.o = oracle
+        self.contigs = [c.encode() if isinstance(c, str) else bytes(c) for c in contigs]
+        self.bases = np.frombuffer(b"".join(self.contigs), np.uint8).copy()
+        self.offsets = np.zeros(len(self.contigs) + 1, np.uint64)
+        self.offsets[1:] = np.cumsum([len(c) for c in self.contigs])
+        self.h = C.c_void_p(oracle.lib.oracle_ref_create(ptr(self.bases), ptr(self.offsets), C.c_uint32(len(self.contigs))))
+
+    def __del__(self):
+        try:
+            self.o.lib.oracle_ref_destroy(self.h)
+        except Exception:
+            pass
+
+    def build_index(self, repeat_threshold=1000, annotate_neighbors=True, neighborhood_width=4):
+        self.o.check(self.o.lib.oracle_ref_build_index(self.h, C.c_uint32(repeat_threshold), int(annotate_neighbors), C.c_uint32(neighborhood_width)))
+        return self.index()
+
+    def index(self):
+        n = self.o.lib.oracle_ref_index_size(self.h)
+        out = np.zeros(n, INDEX_DTYPE)
+        self.o.lib.oracle_ref_get_index(self.h, ptr(out))
+        return out
+
+    def set_index(self, index):
+        index = np.ascontiguousarray(index, INDEX_DTYPE)
+        self.o.lib.oracle_ref_set_index(self.h, ptr(index), C.c_uint64(len(index)))
+
+    def find_matches(self, params, bcl, n_clusters, tile=0):
+        cap = int(n_clusters) * 16 * 10 + 1024
+        out = np.zeros(cap, MATCH_DTYPE)
+        n = C.c_uint64()
+        hits = np.zeros(len(self.contigs), np.uint8)
+        self.o.check(self.o.lib.oracle_find_matches(self.h, C.byref(params), ptr(bcl), C.c_uint32(n_clusters), C.c_uint32(tile), ptr(out), C.c_uint64(cap), C.byref(n), ptr(hits)))
+        return out[:n.value].copy(), hits
+
+    def build_fragments(self, params, bcl, matches, contig_loaded=None, tile=0, with_gaps=True, trim=True):
+        cap = max(len(matches), 16) + 1024
+        out = np.zeros(cap, CANDIDATE_DTYPE)
+        cig = np.zeros(cap * 8, np.uint32)
+        n, nc = C.c_uint64(), C.c_uint64()
+        matches = np.ascontiguousarray(matches, MATCH_DTYPE)
+        cl = ptr(np.ascontiguousarray(contig_loaded, np.uint8)) if contig_loaded is not None else None
+        self.o.check(self.o.lib.oracle_build_fragments(self.h, C.byref(params), cl, ptr(bcl), C.c_uint32(tile), ptr(matches), C.c_uint64(len(matches)), int(with_gaps), int(trim),
+                                                       ptr(out), C.c_uint64(cap), C.byref(n), ptr(cig), C.c_uint64(len(cig)), C.byref(nc)))
+        return out[:n.value].copy(), cig[:nc.value].copy()
+
+    def determine_tls(self, params, bcl, matches, contig_loaded=None, tile=0):
+        t = Tls()
+        matches = np.ascontiguousarray(matches, MATCH_DTYPE)
+        cl = ptr(np.ascontiguousarray(contig_loaded, np.uint8)) if contig_loaded is not None else None
+        self.o.check(self.o.lib.oracle_determine_tls(self.h, C.byref(params), cl, ptr(bcl), C.c_uint32(tile), ptr(matches), C.c_uint64(len(matches)), C.byref(t)))
+        return t
+
+    def select(self, params, bcl, matches, tls, contig_loaded=None, tile=0, n_threads=1, n_clusters_hint=None):
+        matches = np.ascontiguousarray(matches, MATCH_DTYPE)
+        cap = 2 * (int(n_clusters_hint) if n_clusters_hint else len(matches)) + 64
+        out = np.zeros(cap, RECORD_DTYPE)
+        cig = np.zeros(cap * 8, np.uint32)
+        n, nc = C.c_uint64(), C.c_uint64()
+        counters = (C.c_uint64 * 2)()
+        cl = ptr(np.ascontiguousarray(contig_loaded, np.uint8)) if contig_loaded is not None else None
+        self.o.check(self.o.lib.oracle_select(self.h, C.byref(params), cl, ptr(bcl), C.c_uint32(tile), ptr(matches), C.c_uint64(len(matches)), C.byref(tls), C.c_uint32(n_threads),
+                                              ptr(out), C.c_uint64(cap), C.byref(n), ptr(cig), C.c_uint64(len(cig)), C.byref(nc), counters))
+        return out[:n.value].copy(), cig[:nc.value].copy(), (counters[0], counters[1])
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "-j8"])
+
+
+_cached = None
+
+
+def load():
+    global _cached
+    if _cached is None:
+        so = os.path.join(ORACLE_DIR, "liboracle.so")
+        srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".cpp", ".hpp"))]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            build()
+        _cached = Oracle(C.CDLL(so))
+    return _cached
