@@ -1,0 +1,199 @@
+/*
+ * isaac_gpu.h -- C ABI of the MI355X (gfx950) implementation of Isaac's seed-and-extend hot path.
+ *
+ * The reference (sequencing/isaac_aligner, iSAAC-01.15.04.01) has no plugin/FFI seam: the path is reached by direct C++
+ * calls inside one static binary.  The entry points below replace the narrowest C++ seams of that path; each one cites
+ * the reference interface it stands in for (paths relative to /root/reference/src/c++).  A maintainer binds them from
+ * the two workflow transitions.
+ *
+ * Conventions
+ *   - plain C, opaque context, caller-owned buffers, no exceptions across the boundary: every call returns 0 on success
+ *     or an ISAAC_GPU_E* code; isaac_gpu_last_error() gives the text.
+ *   - one context per device; calls on one context are serialised by the caller, different contexts are independent.
+ *   - bulk buffers (`*_dev` parameters) are DEVICE pointers (hipMalloc'ed or owned by a framework that shares the HIP
+ *     context, e.g. torch tensors); everything else is host memory.  isaac_gpu_malloc/upload/download exist so that a
+ *     host with no other GPU runtime can use the library.
+ *   - all kernels run on the stream given at context creation (0 = the default stream).
+ *   - there is no CPU fallback: without a usable HIP device isaac_gpu_create fails.
+ */
+#ifndef ISAAC_GPU_H
+#define ISAAC_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISAAC_GPU_OK 0
+#define ISAAC_GPU_EINVAL 1     /* bad argument (where the reference throws PreConditionException / InvalidOptionException) */
+#define ISAAC_GPU_ENOMEM 2     /* device allocation failed (reference: common::MemoryException) */
+#define ISAAC_GPU_EHIP 3       /* HIP runtime error */
+#define ISAAC_GPU_ECAPACITY 4  /* an output buffer supplied by the caller is too small */
+#define ISAAC_GPU_EOVERFLOW 5  /* an internal fixed-capacity work list overflowed; results of the flagged clusters are not exact */
+
+#define ISAAC_GPU_MAX_SEEDS 16
+#define ISAAC_GPU_MAX_CIGAR_OPS 40
+
+/* alignment::SeedMetadata (include/alignment/SeedMetadata.hh:43-101): index in the list == seed index of SeedId */
+typedef struct { uint16_t offset, length; uint32_t read_index; } isaac_seed;
+
+/* The subset of options::AlignOptions (lib/options/AlignOptions.cpp:77-160) that parameterises the path, plus the read
+ * geometry of flowcell::ReadMetadataList and the seed list of --seeds (alignOptions/SeedDescriptorOption.cpp:90-151). */
+typedef struct
+{
+    int32_t gap_match, gap_mismatch, gap_open, gap_extend, min_gap_extend; /* --gap-scoring, bwa = 0:-3:-11:-4:-20 */
+    uint32_t repeat_threshold;         /* --repeat-threshold 10 */
+    uint32_t gapped_mismatches_max;    /* --gapped-mismatches 5 */
+    uint32_t semialigned_gap_limit;    /* --semialigned-gap-limit 100 */
+    uint32_t base_quality_cutoff;      /* --base-quality-cutoff 25 */
+    uint32_t ignore_neighbors;         /* --ignore-neighbors 0 */
+    uint32_t clip_semialigned;         /* --clip-semialigned 1 */
+    uint32_t clip_overlapping;         /* --clip-overlapping 1 */
+    uint32_t scatter_repeats;          /* --scatter-repeats 0 */
+    int32_t dodgy_alignment_score;     /* --dodgy-alignment-score 0 (255 = Unknown, -1 = Unaligned) */
+    uint32_t mapq_threshold;           /* --mapq-threshold 0 */
+    uint32_t keep_unaligned;           /* --keep-unaligned back|front => 1 */
+    int32_t mate_drift_range;          /* --shadow-scan-range -1 */
+    uint32_t first_pass_seeds;         /* --first-pass-seeds (2 with --seeds auto and a non-zero gap limit) */
+    uint32_t seed_length;              /* --seed-length: only 32 is implemented */
+    uint32_t n_reads;                  /* 1 or 2 */
+    uint32_t read_length[2];
+    uint32_t n_seeds;
+    isaac_seed seeds[ISAAC_GPU_MAX_SEEDS];
+} isaac_params;
+
+/* alignment::Match (include/alignment/Match.hh:38-73): SeedId (SeedId.hh:60-127) + ReferencePosition value
+ * (ReferencePosition.hh:51-188), exactly the 16 bytes io::TileMatchWriter::write appends (lib/io/MatchWriter.cpp:79-94) */
+typedef struct { uint64_t seed_id; uint64_t location; } isaac_match;
+
+/* reference::ReferenceKmer<unsigned long> (include/reference/ReferenceKmer.hh:37-54): the record of the mask files */
+typedef struct { uint64_t kmer; uint64_t position; } isaac_reference_kmer;
+
+/* one candidate alignment of one read: the observable fields of alignment::FragmentMetadata
+ * (include/alignment/FragmentMetadata.hh:330-414) after FragmentBuilder::build */
+typedef struct
+{
+    int64_t position; double log_probability;
+    uint32_t cluster, read_index, contig_id, observed_length, reverse, mismatch_count, matches_in_a_row, gap_count, edit_distance,
+             smith_waterman_score, unique_seed_count, non_unique_first, non_unique_second, repeat_seeds_count, cigar_offset, cigar_length,
+             low_clipped, high_clipped;
+    int32_t first_seed_index; uint32_t reserved;
+} isaac_candidate;
+
+/* alignment::TemplateLengthStatistics (include/alignment/TemplateLengthStatistics.hh:44-239) */
+typedef struct { uint32_t min, max, median, low_std_dev, high_std_dev; int32_t best_model[2]; uint32_t stable, mate_min, mate_max; } isaac_tls;
+
+/* What the reference persists per read: io::FragmentHeader (include/io/Fragment.hh:73-330), plus the BAM MAPQ that
+ * build::FragmentAccessorBamAdapter::mapq() derives from it (include/build/FragmentAccessorBamAdapter.hh:250-265). */
+typedef struct
+{
+    uint64_t f_strand_position, mate_f_strand_position;   /* ReferencePosition values */
+    int32_t bam_tlen; uint32_t observed_length;
+    uint16_t low_clipped, high_clipped, alignment_score, template_alignment_score;
+    uint16_t read_length, cigar_length, gap_count, edit_distance;
+    uint32_t flags;        /* bit0 paired,1 unmapped,2 mateUnmapped,3 reverse,4 mateReverse,5 firstRead,6 secondRead,7 failFilter,8 properPair */
+    uint32_t cigar_offset; /* into the cigar pool of the same call */
+    uint32_t tile, cluster_id;
+    uint32_t mapq;
+    uint32_t reserved;
+} isaac_fragment;
+
+/* one banded Smith-Waterman problem: query = ASCII ACGTn, database = query_length + 15 ASCII ACGTN bytes */
+typedef struct { uint64_t query_offset, database_offset; uint32_t query_length; uint32_t reserved; } isaac_bsw_job;
+typedef struct { uint32_t n_ops, offset; uint32_t cigar[ISAAC_GPU_MAX_CIGAR_OPS]; } isaac_bsw_result;
+
+/* work counters of the last isaac_gpu_align_tile call; they feed the bytes/pair formula of SURVEY.md §8d */
+typedef struct
+{
+    uint64_t clusters, probes, probe_steps, matches, candidates, ungapped_scans, bsw_jobs, bsw_accepted, simple_indels,
+             rescue_calls, rescue_window_bases, rescue_candidates, rescue_bsw, overflow_clusters, mapq_near_integer;
+} isaac_counters;
+
+typedef struct isaac_gpu_ctx isaac_gpu_ctx;
+
+const char *isaac_gpu_last_error(void);
+
+/* Replaces the construction of alignment::MatchFinder / MatchSelector / TemplateBuilder for one device
+ * (lib/alignment/MatchFinder.cpp:74-112, MatchSelector.cpp:92-168).  `stream` is a hipStream_t or NULL. */
+int isaac_gpu_create(int device, const isaac_params *params, void *stream, isaac_gpu_ctx **out);
+void isaac_gpu_destroy(isaac_gpu_ctx *ctx);
+
+/* plain device memory helpers for hosts without another GPU runtime */
+int isaac_gpu_malloc(isaac_gpu_ctx *ctx, uint64_t bytes, void **dev_out);
+int isaac_gpu_free(isaac_gpu_ctx *ctx, void *dev);
+int isaac_gpu_upload(isaac_gpu_ctx *ctx, void *dev, const void *host, uint64_t bytes);
+int isaac_gpu_download(isaac_gpu_ctx *ctx, void *host, const void *dev, uint64_t bytes);
+int isaac_gpu_synchronize(isaac_gpu_ctx *ctx);
+
+/* Replaces reference::loadContigs (include/reference/ContigLoader.hh:84-140, lib/reference/ContigLoader.cpp:29-66):
+ * ASCII ACGTN, exactly reference::Contig::forward_, all contigs concatenated in karyotype order;
+ * offsets has n_contigs + 1 entries.  The bytes are copied to HBM once and stay resident. */
+int isaac_gpu_load_contigs(isaac_gpu_ctx *ctx, const char *bases_host, const uint64_t *offsets_host, uint32_t n_contigs);
+int isaac_gpu_load_contigs_dev(isaac_gpu_ctx *ctx, const char *bases_dev, const uint64_t *offsets_host, uint32_t n_contigs);
+
+/* Replaces the streaming of the mask files of sorted-reference.xml by matchFinder::ExactMaskMatcher::matchMask
+ * (lib/alignment/matchFinder/ExactMaskMatcher.cpp:83-126, MatchFinder.cpp:251-316): the masks (host pointers to the
+ * mmap'ed *.dat files, in mask order, which is global k-mer order) are concatenated into one resident sorted table.
+ * karyotype_of_contig is SortedReferenceMetadata::Contig::karyotypeIndex_ (MatchFinder.cpp:51-66), NULL = identity. */
+int isaac_gpu_load_index(isaac_gpu_ctx *ctx, const isaac_reference_kmer *const *masks_host, const uint64_t *mask_sizes, uint32_t n_masks,
+                         const uint32_t *karyotype_of_contig, uint32_t n_contigs);
+
+/* Replaces isaac-sort-reference (lib/reference/ReferenceSorter.cpp:105-261 + NeighborsFinder.cpp:193-446) for the
+ * contigs already loaded: builds the sorted 32-mer table on the device (repeat_threshold = 1000, neighborhood 4).
+ * n_entries_out may be NULL. */
+int isaac_gpu_build_index(isaac_gpu_ctx *ctx, uint32_t repeat_threshold, int annotate_neighbors, uint64_t *n_entries_out);
+/* copies the resident table back in mask-file record layout (capacity in records) */
+int isaac_gpu_get_index(isaac_gpu_ctx *ctx, isaac_reference_kmer *out_host, uint64_t capacity, uint64_t *n_out);
+
+/* Replaces one tile's worth of alignWorkflow::FindMatchesTransition::findLaneMatches (both seed iterations;
+ * lib/workflow/alignWorkflow/FindMatchesTransition.cpp:391-427): alignment::ClusterSeedGenerator::generateThread
+ * (lib/alignment/ClusterSeedGenerator.cpp:138-192) + MatchFinder<KmerT>::findMatches (include/alignment/MatchFinder.hh:100-104).
+ *   bcl_dev          n_clusters x (read_length[0] + read_length[1]) BCL bytes (base | quality << 2, 0 = N)
+ *   matches_dev      optional: receives what io::TileMatchWriter::write(SeedId, ReferencePosition) would have been called
+ *                    with (include/io/MatchWriter.hh:72), grouped by cluster (ascending), unordered inside a cluster (the
+ *                    reference's file order is thread-interleaved; SelectMatchesTransition sorts later).  A cluster without
+ *                    any match gets one NoMatch record.
+ *   contig_has_matches_host  n_contigs bytes, OR-ed: the "MatchDistribution::isEmptyContig" fact (MatchDistribution.hh:96-101)
+ * The per-cluster match lists also stay resident in the context for isaac_gpu_build_fragments / isaac_gpu_select. */
+int isaac_gpu_find_matches(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t n_clusters, uint32_t tile,
+                           isaac_match *matches_dev, uint64_t capacity, uint64_t *n_matches_out, uint8_t *contig_has_matches_host);
+
+/* Tells the extend stage which contigs the reference would have loaded (MatchSelector.cpp:85-90,138): the OR of
+ * contig_has_matches over the whole run (all devices).  Lengths of the others count as 0 in the rest-of-genome
+ * correction (include/alignment/RestOfGenomeCorrection.hh:44-55). NULL = all loaded. */
+int isaac_gpu_set_loaded_contigs(isaac_gpu_ctx *ctx, const uint8_t *contig_loaded_host, uint32_t n_contigs);
+
+/* Replaces alignment::FragmentBuilder::build for every cluster of the last isaac_gpu_find_matches call
+ * (include/alignment/FragmentBuilder.hh:62-70; getFragments()/getCigarBuffer() :71-72): candidates in (cluster, read,
+ * list order); with_gaps and trim select the two ways MatchSelector calls it (MatchSelector.cpp:233-245 vs :298-312).
+ * Outputs are optional (NULL) device buffers. */
+int isaac_gpu_build_fragments(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t n_clusters, uint32_t tile, int with_gaps, int trim,
+                              isaac_candidate *candidates_dev, uint64_t capacity, uint64_t *n_candidates_out,
+                              uint32_t *cigar_dev, uint64_t cigar_capacity, uint64_t *n_cigar_out);
+
+/* Replaces MatchSelector::determineTemplateLength (lib/alignment/MatchSelector.cpp:188-256) on the clusters of the last
+ * isaac_gpu_find_matches call, in cluster order, until the statistics are stable. */
+int isaac_gpu_determine_tls(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t n_clusters, uint32_t tile, isaac_tls *tls_out);
+
+/* Replaces MatchSelector::processMatchList for the tile (lib/alignment/MatchSelector.cpp:258-368): fragment building with
+ * gaps, TemplateBuilder::buildTemplate (shadow rescue, alignment scores), the semialigned / overlapping end clippers, and
+ * the io::FragmentHeader fields FragmentCollector would store.  One record per read, in cluster order. */
+int isaac_gpu_select(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t n_clusters, uint32_t tile, const isaac_tls *tls,
+                     isaac_fragment *fragments_dev /* n_clusters * n_reads */, uint32_t *cigar_dev, uint64_t cigar_capacity, uint64_t *n_cigar_out);
+
+/* The leaf: alignment::BandedSmithWaterman::align (include/alignment/BandedSmithWaterman.hh:75-86) for a batch;
+ * scores as the reference constructor takes them (GappedAligner.cpp:41-42: match, mismatch, -gapOpen, -gapExtend). */
+int isaac_gpu_bsw_batch(isaac_gpu_ctx *ctx, int match, int mismatch, int gap_open, int gap_extend,
+                        const char *sequences_dev, const isaac_bsw_job *jobs_dev, uint32_t n_jobs, isaac_bsw_result *results_dev);
+
+int isaac_gpu_get_counters(isaac_gpu_ctx *ctx, isaac_counters *out);
+/* average device time (ms) of the named kernel over the launches since the last reset, measured with HIP events on the
+ * context's stream; names: "find_matches", "build_fragments", "bsw", "select" */
+int isaac_gpu_kernel_time_ms(isaac_gpu_ctx *ctx, const char *kernel, double *avg_ms, uint64_t *launches);
+int isaac_gpu_reset_timers(isaac_gpu_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

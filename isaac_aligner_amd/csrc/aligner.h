@@ -1,0 +1,681 @@
+// Thread-serial extend arithmetic: read decoding and trimming, CIGAR scan, ungapped / gapped / single-indel aligners and
+// the per-cluster fragment builder.  One GPU thread runs these for one cluster; the 16-lane cooperative banded
+// Smith-Waterman of bsw_kernel.h is the wavefront form of bswAlignSerial below.
+//
+// Behaviour follows (paths relative to /root/reference/src/c++):
+//   lib/alignment/Read.cpp:32-73, Quality.cpp:72-120, fragmentBuilder/AlignerBase.cpp:50-227, UngappedAligner.cpp:39-92,
+//   GappedAligner.cpp:51-82,167-249, BandedSmithWaterman.cpp:84-462, SimpleIndelAligner.cpp:50-518, FragmentBuilder.cpp:82-343
+#pragma once
+#include "types.h"
+#include "sort.h"
+
+namespace isaac
+{
+
+// ------------------------------------------------------------------------------------------------------------------
+// reads straight from the BCL bytes (no decoded copy is kept): Read::decodeBcl semantics
+struct ReadView
+{
+    const u8 *bcl;          // first cycle of this read
+    u32 length;
+    u32 endCyclesMasked;    // Read::endCyclesMasked_ (quality trimming), 0 when not trimmed
+    u32 firstCycle;         // flowcell::ReadMetadata::getFirstCycle (1-based)
+};
+ISAAC_HD char strandBase(const ReadView &r, bool reverse, u32 i)
+{
+    const u8 b = reverse ? r.bcl[r.length - 1 - i] : r.bcl[i];
+    if (!(b & 0xfc)) return 'n';                         // oligo::isBclN: any quality-0 byte is an N
+    const u32 code = reverse ? (~u32(b)) & 3 : u32(b) & 3;
+    return char(0x54474341u >> (8 * code));              // "ACGT"
+}
+ISAAC_HD u32 strandQuality(const ReadView &r, bool reverse, u32 i)
+{
+    const u8 b = reverse ? r.bcl[r.length - 1 - i] : r.bcl[i];
+    return (b & 0xfc) ? u32(b >> 2) : 2u;
+}
+// include/alignment/Alignment.hh:44-47
+ISAAC_HD bool isMatch(char readBase, char referenceBase) { return readBase == 'n' || (readBase == referenceBase && referenceBase != 'N'); }
+
+// lib/alignment/Quality.cpp:72-105 (BWA-style 3' trimming); returns Read::endCyclesMasked_
+ISAAC_HD u32 trimLowQualityEnd(const u8 *bcl, u32 length, u32 baseQualityCutoff)
+{
+    const u32 MASK_READ_LENGTH_MIN = 35;
+    if (!baseQualityCutoff || length < MASK_READ_LENGTH_MIN) return 0;
+    i32 qscoreSum = 0, peakSum = 0; bool trimPosSet = false; u32 trimPos = 0;
+    for (u32 it = 0; length - MASK_READ_LENGTH_MIN != it; ++it)
+    {
+        const u8 b = bcl[length - 1 - it];
+        const i32 q = (b & 0xfc) ? i32(b >> 2) : 2;
+        qscoreSum += i32(baseQualityCutoff) - q;
+        if (qscoreSum < 0) break;
+        if (qscoreSum > peakSum) { peakSum = qscoreSum; trimPos = it; trimPosSet = true; }
+    }
+    return trimPosSet ? trimPos + 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// per-cluster cigar pool (alignment::Cigar buffer of FragmentBuilder / TemplateBuilder, fixed capacity here)
+struct CigarPool
+{
+    u32 *words; u32 used; u32 capacity; u32 overflow;
+    ISAAC_HD void push(u32 w) { if (used < capacity) words[used++] = w; else overflow = 1; }
+    ISAAC_HD void addOperation(u32 len, u32 op) { push(cigarOp(len, op)); }
+};
+
+ISAAC_HD i64 candBeginClipped(const Cand &c, const u32 *pool)
+{ return (c.cigarLength && OP_SOFT_CLIP == cigarCode(pool[c.cigarOffset])) ? i64(cigarLen(pool[c.cigarOffset])) : 0; }
+ISAAC_HD i64 candEndClipped(const Cand &c, const u32 *pool)
+{ const u32 w = pool[c.cigarOffset + (c.cigarLength ? c.cigarLength - 1 : 0)]; return (c.cigarLength && OP_SOFT_CLIP == cigarCode(w)) ? i64(cigarLen(w)) : 0; }
+ISAAC_HD i64 candUnclippedPosition(const Cand &c, const u32 *pool) { return c.position - candBeginClipped(c, pool); }
+ISAAC_HD u32 candMappedLength(const Cand &c, const u32 *pool)
+{ u32 r = 0; for (u32 i = 0; i < c.cigarLength; ++i) if (OP_ALIGN == cigarCode(pool[c.cigarOffset + i])) r += cigarLen(pool[c.cigarOffset + i]); return r; }
+// FragmentMetadata::resetAlignment + resetClipping (FragmentMetadata.hh:352-375)
+ISAAC_HD void candResetAlignment(Cand &c, const CigarPool &pool)
+{
+    c.position = candUnclippedPosition(c, pool.words);
+    c.cigarOffset = pool.used; c.cigarLength = 0; c.observedLength = 0; c.mismatchCount = 0; c.matchesInARow = 0; c.gapCount = 0; c.editDistance = 0;
+    c.logProbability = 0.0; c.alignmentScore = 0xffffffffu; c.smithWatermanScore = 0;
+}
+
+// AlignerBase::updateFragmentCigar (AlignerBase.cpp:121-227).  logProbability is a running fp64 sum in base order: the
+// order of the additions is part of the result, so this loop is deliberately serial.
+ISAAC_HD u32 updateFragmentCigar(const DevParams &P, const DevReference &R, const ReadView &read, Cand &f, i64 strandPosition, const CigarPool &pool, u32 cigarOffset)
+{
+    const bool reverse = f.reverse;
+    const char *reference = R.bases + R.contigOffset[f.contigId];
+    const char *currentReference = reference + strandPosition;
+    f.cigarOffset = cigarOffset;
+    f.cigarLength = u16(pool.used - cigarOffset);
+    u32 currentBase = 0, matchCount = 0;
+    double lp = f.logProbability;
+    u32 mismatchCount = f.mismatchCount, best = f.matchesInARow, editDistance = f.editDistance, gapCount = f.gapCount, sws = f.smithWatermanScore;
+    for (u32 i = 0; f.cigarLength > i; ++i)
+    {
+        const u32 w = pool.words[cigarOffset + i];
+        const u32 length = cigarLen(w), op = cigarCode(w);
+        if (OP_ALIGN == op)
+        {
+            u32 matchesInARow = 0;
+            for (u32 j = 0; length > j; ++j)
+            {
+                const char s = strandBase(read, reverse, currentBase);
+                const u32 q = strandQuality(read, reverse, currentBase);
+                const char r = *currentReference;
+                if (isMatch(s, r)) { ++matchCount; ++matchesInARow; lp += R.logMatch[q]; }
+                else
+                {
+                    best = imax(best, matchesInARow); matchesInARow = 0;
+                    ++mismatchCount; lp += R.logMismatch[q]; sws += P.normalizedMismatchScore;
+                }
+                if (s != r) ++editDistance;
+                ++currentReference; ++currentBase;
+            }
+            best = imax(best, matchesInARow);
+        }
+        else if (OP_INSERT == op)
+        {
+            currentBase += length; editDistance += length; ++gapCount;
+            sws += P.normalizedGapOpenScore + imin(P.normalizedMaxGapExtendScore, (length - 1) * P.normalizedGapExtendScore);
+        }
+        else if (OP_DELETE == op)
+        {
+            currentReference += length; editDistance += length; ++gapCount;
+            sws += P.normalizedGapOpenScore + imin(P.normalizedMaxGapExtendScore, (length - 1) * P.normalizedGapExtendScore);
+        }
+        else // OP_SOFT_CLIP
+        {
+            for (u32 j = 0; j < length; ++j) lp += R.logMatch[strandQuality(read, reverse, currentBase + j)];
+            currentBase += length;
+        }
+    }
+    f.logProbability = lp; f.mismatchCount = u16(mismatchCount); f.matchesInARow = u16(best); f.editDistance = u16(editDistance);
+    f.gapCount = u16(gapCount); f.smithWatermanScore = sws;
+    f.observedLength = u32(currentReference - reference - strandPosition);
+    f.position = strandPosition;
+    return matchCount;
+}
+
+// AlignerBase::clipReadMasking + clipReference (AlignerBase.cpp:50-119) on [begin, end) indices of the strand sequence.
+// Returns false for the "position past the contig end" case (AlignerBase.cpp:74-81), which no seed or rescue candidate can
+// produce (positions are always < contig length) and which is undefined behaviour in the reference.
+ISAAC_HD bool clipSequence(const ReadView &read, Cand &f, i64 referenceSize, i64 &begin, i64 &end)
+{
+    begin = 0; end = read.length;
+    const i64 maskedBegin = f.reverse ? i64(read.endCyclesMasked) : 0;
+    const i64 maskedEnd = f.reverse ? i64(read.length) : i64(read.length) - i64(read.endCyclesMasked);
+    if (maskedBegin > begin) { candIncrementClipLeft(f, u32(maskedBegin - begin)); begin = maskedBegin; }
+    if (maskedEnd < end) { candIncrementClipRight(f, u32(end - maskedEnd)); end = maskedEnd; }
+    const i64 referenceLeft = referenceSize - f.position;
+    if (referenceLeft < 0) return false;
+    if (referenceLeft < end - begin) end = begin + referenceLeft;
+    if (0 > f.position) { begin -= f.position; f.position = 0; }
+    end = imax(end, begin);
+    return true;
+}
+
+// UngappedAligner::alignUngapped (UngappedAligner.cpp:39-92), no sequencing adapters
+ISAAC_HD u32 alignUngapped(const DevParams &P, const DevReference &R, const ReadView &read, Cand &f, CigarPool &pool)
+{
+    const u32 cigarOffset = pool.used;
+    candResetAlignment(f, pool);
+    f.lowClipped = 0; f.highClipped = 0;
+    i64 begin, end;
+    if (!clipSequence(read, f, i64(contigLength(R, f.contigId)), begin, end)) { candSetUnaligned(f); return 0; }
+    if (begin > i64(read.length)) { candSetUnaligned(f); return 0; }
+    if (begin) pool.addOperation(u32(begin), OP_SOFT_CLIP);
+    if (end - begin) pool.addOperation(u32(end - begin), OP_ALIGN);
+    if (i64(read.length) - end) pool.addOperation(u32(i64(read.length) - end), OP_SOFT_CLIP);
+    const u32 ret = updateFragmentCigar(P, R, read, f, f.position, pool, cigarOffset);
+    if (!ret) candSetUnaligned(f);
+    return ret;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// BandedSmithWaterman::align (BandedSmithWaterman.cpp:84-462), one thread, the 16 lanes of the SSE registers as arrays.
+// The traceback flags are packed 2 bits each: 3 words per query row (TG, TE, TF) in `tflags` (3 * queryLength words).
+static const u32 BSW_WIDEST_GAP_SIZE = 16, BSW_DISTANCE_CUTOFF = 7, BSW_MISMATCHES_CUTOFF = 5;
+ISAAC_HD i16 w16(i32 v) { return i16(u16(v)); }
+
+template <typename QueryF>
+ISAAC_HD u32 bswAlignSerial(const DevParams &P, QueryF query, u32 querySize, const char *database, u32 *tflags, CigarPool &cigar)
+{
+    const i32 matchScore = P.gapMatch, mismatchScore = P.gapMismatch, gapOpenScore = -P.gapOpen, gapExtendScore = -P.gapExtend; // GappedAligner.cpp:41-42
+    const i16 initialValue = i16(-32768 + gapOpenScore);
+    const i16 open = i16(gapOpenScore), ext = i16(gapExtendScore);
+    const u32 originalCigarSize = cigar.used;
+    i16 E[16], F[16], G[16];
+    for (u32 k = 0; k < 16; ++k) { E[k] = initialValue; F[k] = 0; G[k] = initialValue; }
+    G[0] = 0;
+    for (u32 i = 0; i < querySize; ++i)
+    {
+        i16 newF[16], newG[16];
+        u32 TF = 0, TG = 0, TE = 0;
+        for (u32 k = 1; k < 16; ++k)
+        {
+            const i16 g = G[k - 1], e = E[k - 1];
+            u32 tf = (g < e) ? 1 : 0;
+            const i16 v = w16(i32(imax(g, e)) - open);
+            const i16 fe = w16(i32(F[k - 1]) - ext);
+            if (v < fe) tf = 2;
+            newF[k] = imax(v, fe);
+            TF |= tf << (2 * k);
+        }
+        newF[0] = initialValue;
+        u32 fE = 0, fF = 0; // one bit per lane
+        for (u32 k = 0; k < 16; ++k)
+        {
+            if (G[k] < E[k]) fE |= 1u << k;
+            const i16 m = imax(G[k], E[k]);
+            if (m < F[k]) fF |= 1u << k;
+            newG[k] = imax(m, F[k]);
+        }
+        // _mm_max_epi16 over (even, odd) byte pairs of the F-flags (0/2) and E-flags (0/1): BandedSmithWaterman.cpp:197
+        for (u32 m = 0; m < 8; ++m)
+        {
+            const u32 e0 = (fE >> (2 * m)) & 1, e1 = (fE >> (2 * m + 1)) & 1, f0 = (fF >> (2 * m)) & 1, f1 = (fF >> (2 * m + 1)) & 1;
+            const u32 a = (2 * f1) * 256 + 2 * f0, b = e1 * 256 + e0;
+            const u32 r = a > b ? a : b;
+            TG |= (r & 0xff) << (4 * m); TG |= (r >> 8) << (4 * m + 2);
+        }
+        const char q = query(i);
+        for (u32 k = 0; k < 16; ++k)
+        {
+            const bool diff = q != database[i + 15 - k];
+            const u16 w = diff ? u16(0xff00u | u8(mismatchScore)) : u16(u8(matchScore));
+            newG[k] = w16(i32(newG[k]) + i32(i16(w)));
+        }
+        {
+            i16 g = initialValue, e = initialValue, f = initialValue;
+            for (u32 j = 0; j < 16; ++j)
+            {
+                const u32 k = 15 - j;
+                i16 mx = g; u32 tMax = 0;
+                if (e > g && e > f) { mx = e; tMax = 1; }
+                else if (f > g) { mx = f; tMax = 2; }
+                TE |= tMax << (2 * k);
+                E[k] = mx;
+                g = w16(i32(newG[k]) - open);
+                e = w16(i32(mx) - gapExtendScore);
+                f = w16(i32(newF[k]) - open);
+            }
+        }
+        for (u32 k = 0; k < 16; ++k) { G[k] = newG[k]; F[k] = newF[k]; }
+        tflags[3 * i] = TG; tflags[3 * i + 1] = TE; tflags[3 * i + 2] = TF;
+    }
+    i16 mx = w16(i32(u16(G[15])) - 1);
+    i32 ii = i32(querySize) - 1, jj = ii; u32 maxType = 0;
+    for (i32 k = 15; k >= 0; --k)
+    {
+        if (G[k] > mx) { mx = G[k]; jj = k; maxType = 0; }
+        if (E[k] > mx) { mx = E[k]; jj = k; maxType = 1; }
+        if (F[k] > mx) { mx = F[k]; jj = k; maxType = 2; }
+    }
+    u32 opLength = 0;
+    if (jj > 0) cigar.addOperation(u32(jj), OP_DELETE);
+    while (ii >= 0 && jj >= 0 && jj <= 15)
+    {
+        ++opLength;
+        const u32 nextMaxType = (tflags[3 * ii + maxType] >> (2 * jj)) & 3;
+        const u32 op = maxType == 0 ? OP_ALIGN : maxType == 1 ? OP_DELETE : OP_INSERT;
+        if (nextMaxType != maxType) { cigar.addOperation(opLength, op); opLength = 0; }
+        ii += (maxType == 1) ? 0 : -1;
+        jj += (maxType == 1) ? 1 : (maxType == 2) ? -1 : 0;
+        maxType = nextMaxType;
+    }
+    if (1 != maxType && opLength) { cigar.addOperation(opLength, maxType == 0 ? OP_ALIGN : OP_INSERT); opLength = 0; }
+    if (15 > jj) { cigar.addOperation(opLength + 15 - u32(jj), OP_DELETE); opLength = 0; }
+    u32 ret = 0;
+    if (cigar.used > originalCigarSize && OP_DELETE == cigarCode(cigar.words[cigar.used - 1])) { ret = cigarLen(cigar.words[cigar.used - 1]); --cigar.used; }
+    for (u32 lo = originalCigarSize, hi = cigar.used; lo + 1 < hi; ++lo) { --hi; const u32 t = cigar.words[lo]; cigar.words[lo] = cigar.words[hi]; cigar.words[hi] = t; }
+    if (cigar.used > originalCigarSize && OP_DELETE == cigarCode(cigar.words[cigar.used - 1])) --cigar.used;
+    return ret;
+}
+
+// GappedAligner::getFlanks (GappedAligner.cpp:51-82)
+ISAAC_HD void getFlanks(i64 strandPosition, u32 readLength, u64 referenceSize, u32 &left, u32 &right)
+{
+    const u32 w = BSW_WIDEST_GAP_SIZE;
+    if (strandPosition >= i64(w / 2))
+    {
+        if (strandPosition + i64(readLength) + i64(w - w / 2) < i64(referenceSize)) { left = w / 2; right = w - left - 1; }
+        else { right = u32(referenceSize - readLength - u64(strandPosition)); left = w - right - 1; }
+    }
+    else { left = u32(strandPosition); right = w - left - 1; }
+}
+
+struct StrandQuery
+{
+    const ReadView *read; bool reverse; u32 offset;
+    ISAAC_HD char operator()(u32 i) const { return strandBase(*read, reverse, offset + i); }
+};
+
+// GappedAligner::alignGapped (GappedAligner.cpp:167-249), --avoid-smith-waterman 0
+ISAAC_HD u32 alignGapped(const DevParams &P, const DevReference &R, const ReadView &read, Cand &f, CigarPool &pool, u32 *tflags)
+{
+    const u32 cigarOffset = pool.used;
+    candResetAlignment(f, pool);
+    f.lowClipped = 0; f.highClipped = 0;
+    const u64 referenceSize = contigLength(R, f.contigId);
+    i64 begin, end;
+    if (!clipSequence(read, f, i64(referenceSize), begin, end)) return 0;
+    if (begin) pool.addOperation(u32(begin), OP_SOFT_CLIP);
+    const u32 sequenceLength = u32(end - begin);
+    i64 strandPosition = f.position;
+    if (i64(referenceSize) < i64(sequenceLength) + strandPosition + i64(BSW_WIDEST_GAP_SIZE)) return 0;
+    if (!sequenceLength) return 0; // the reference would read cigar.back() of an empty alignment here; cannot happen for seeded candidates
+    u32 left, right;
+    getFlanks(strandPosition, sequenceLength, referenceSize, left, right);
+    const char *database = R.bases + R.contigOffset[f.contigId] + strandPosition - left;
+    StrandQuery q; q.read = &read; q.reverse = f.reverse; q.offset = u32(begin);
+    strandPosition += bswAlignSerial(P, q, sequenceLength, database, tflags, pool);
+    const u32 clipEndBases = u32(i64(read.length) - end);
+    if (clipEndBases) pool.addOperation(clipEndBases, OP_SOFT_CLIP);
+    strandPosition -= left;
+    return updateFragmentCigar(P, R, read, f, strandPosition, pool, cigarOffset);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// SimpleIndelAligner (SimpleIndelAligner.cpp:50-438)
+static const u32 GAP_FLANK_BASES = 32, GAP_FLANK_MISMATCHES_MAX = 8;
+
+// countMismatches(seq + seqOffset, ref + refOffset .. refEnd, length) of Alignment.hh:115-157
+ISAAC_HD u32 countMismatches(const ReadView &read, bool reverse, i64 seqOffset, const char *reference, i64 refOffset, i64 refSize, u32 length)
+{
+    u32 ret = 0;
+    for (u32 i = 0; i < length && refOffset + i64(i) < refSize; ++i) ret += !isMatch(strandBase(read, reverse, u32(seqOffset + i)), reference[refOffset + i]);
+    return ret;
+}
+
+ISAAC_HD void alignSimpleDeletion(const DevParams &P, const DevReference &R, const ReadView &read, CigarPool &pool, Cand &head, u32 headSeedOffset,
+                                  Cand &tail, u32 tailSeedOffset, u32 tailSeedLength, u32 &simpleIndels)
+{
+    const u32 *cw = pool.words;
+    if (i64(headSeedOffset) < candBeginClipped(head, cw)) return;
+    if (candBeginClipped(tail, cw) + i64(candObservedLength(tail)) < i64(tailSeedOffset + tailSeedLength)) return;
+    const u32 tailOffset = headSeedOffset;
+    const bool reverse = head.reverse;
+    const char *reference = R.bases + R.contigOffset[head.contigId];
+    const i64 refSize = i64(contigLength(R, head.contigId));
+    const i64 headUnclipped = candUnclippedPosition(head, cw), tailUnclipped = candUnclippedPosition(tail, cw);
+    i64 tailIt = tailOffset;                                          // index into the strand sequence
+    u32 tailLength = u32(candBeginClipped(tail, cw) + i64(candObservedLength(tail)) - i64(tailOffset));
+    const u32 tailMismatches = countMismatches(read, reverse, tailIt, reference, headUnclipped + tailOffset, refSize, tailLength);
+    if (!tailMismatches) return;
+    const i64 deletionLengthL = tailUnclipped - headUnclipped;
+    if (deletionLengthL < 0) return;                                  // boost::numeric_cast would throw; unreachable for ordered lists
+    const u32 deletionLength = u32(deletionLengthL);
+    u32 rightRealignedMismatches = countMismatches(read, reverse, tailIt, reference, tailUnclipped + tailOffset, refSize, tailLength);
+    u32 leftRealignedMismatches = 0;
+    const u32 lf = imin(GAP_FLANK_BASES, tailOffset);
+    u32 leftFlankMismatches = countMismatches(read, reverse, tailIt - lf, reference, headUnclipped + tailOffset - imin(32u, tailOffset), refSize, lf);
+    u32 rightFlankMismatches = countMismatches(read, reverse, tailIt, reference, tailUnclipped + tailOffset, refSize, imin(GAP_FLANK_BASES, tailLength));
+    i64 refIt = headUnclipped + tailOffset;
+    u32 bestMismatches = tailMismatches, bestLeftFlankMismatches = leftFlankMismatches, bestRightFlankMismatches = rightFlankMismatches;
+    u32 bestOffset = 0xffffffffu;
+    for (u32 deletionOffset = tailOffset; bestMismatches && deletionOffset <= tailSeedOffset; ++deletionOffset, ++tailIt, ++refIt, --tailLength)
+    {
+        const u32 thisOffsetMismatches = leftRealignedMismatches + rightRealignedMismatches;
+        if (bestMismatches > thisOffsetMismatches)
+        {
+            bestOffset = deletionOffset; bestMismatches = thisOffsetMismatches;
+            bestLeftFlankMismatches = leftFlankMismatches; bestRightFlankMismatches = rightFlankMismatches;
+        }
+        const char tb = strandBase(read, reverse, u32(tailIt));
+        const bool newLeftMismatch = !isMatch(tb, reference[refIt]);
+        leftRealignedMismatches += newLeftMismatch; leftFlankMismatches += newLeftMismatch;
+        if (deletionOffset >= GAP_FLANK_BASES)
+            leftFlankMismatches -= !isMatch(strandBase(read, reverse, u32(tailIt - GAP_FLANK_BASES)), reference[refIt - GAP_FLANK_BASES]);
+        const bool disappearingRightMismatch = !isMatch(tb, reference[refIt + deletionLength]);
+        rightRealignedMismatches -= disappearingRightMismatch; rightFlankMismatches -= disappearingRightMismatch;
+        if (tailLength > GAP_FLANK_BASES)
+            rightFlankMismatches += !isMatch(strandBase(read, reverse, u32(tailIt + GAP_FLANK_BASES)), reference[refIt + deletionLength + GAP_FLANK_BASES]);
+    }
+    if (bestLeftFlankMismatches <= GAP_FLANK_MISMATCHES_MAX && bestRightFlankMismatches <= GAP_FLANK_MISMATCHES_MAX && 0xffffffffu != bestOffset)
+    {
+        const i64 clippingPositionOffset = candBeginClipped(head, cw);
+        const u32 leftMapped = u32(i64(bestOffset) - clippingPositionOffset);
+        const u32 headMismatches = countMismatches(read, reverse, clippingPositionOffset, reference, head.position, refSize, leftMapped);
+        const u32 newMismatches = headMismatches + bestMismatches;
+        const u32 sws = P.normalizedMismatchScore * newMismatches + P.normalizedGapOpenScore +
+            imin(P.normalizedMaxGapExtendScore, (deletionLength - 1) * P.normalizedGapExtendScore);
+        if (head.smithWatermanScore > sws || (head.smithWatermanScore == sws && head.mismatchCount > newMismatches))
+        {
+            const u32 cigarOffset = pool.used;
+            if (clippingPositionOffset) pool.addOperation(u32(clippingPositionOffset), OP_SOFT_CLIP);
+            if (leftMapped) { pool.addOperation(leftMapped, OP_ALIGN); pool.addOperation(deletionLength, OP_DELETE); }
+            else head.position += deletionLength;
+            const u32 tailEndClipped = u32(candEndClipped(tail, cw));
+            const u32 rightMapped = u32(i64(candObservedLength(head)) + candEndClipped(head, cw) - i64(leftMapped) - i64(tailEndClipped));
+            if (rightMapped) pool.addOperation(rightMapped, OP_ALIGN);
+            if (tailEndClipped) pool.addOperation(tailEndClipped, OP_SOFT_CLIP);
+            const u16 tailRightClipped = tail.reverse ? tail.lowClipped : tail.highClipped;
+            // resetAlignment reads the OLD cigar for the unclipped position, then points at the new one
+            const i64 unclipped = candUnclippedPosition(head, cw);
+            CigarPool view = pool; view.used = cigarOffset;
+            candResetAlignment(head, view);
+            head.position = unclipped;
+            if (head.reverse) head.lowClipped = tailRightClipped; else head.highClipped = tailRightClipped;
+            updateFragmentCigar(P, R, read, head, head.position + clippingPositionOffset, pool, cigarOffset);
+            ++simpleIndels;
+        }
+    }
+}
+
+ISAAC_HD void alignSimpleInsertion(const DevParams &P, const DevReference &R, const ReadView &read, CigarPool &pool, Cand &head, u32 headSeedOffset, u32 headSeedLength,
+                                   Cand &tail, u32 tailSeedOffset, u32 tailSeedLength, u32 &simpleIndels)
+{
+    const u32 *cw = pool.words;
+    if (i64(headSeedOffset) < candBeginClipped(head, cw)) return;
+    if (candBeginClipped(tail, cw) + i64(candObservedLength(tail)) < i64(tailSeedOffset + tailSeedLength)) return;
+    const u32 tailOffset = headSeedOffset + headSeedLength;
+    const u32 observedEnd = u32(candBeginClipped(tail, cw) + i64(candObservedLength(tail)));
+    const i64 headUnclipped = candUnclippedPosition(head, cw), tailUnclipped = candUnclippedPosition(tail, cw);
+    const i64 insertionLengthL = headUnclipped - tailUnclipped;
+    if (insertionLengthL < 0) return;
+    const u32 insertionLength = u32(insertionLengthL);
+    if (tailSeedOffset - headSeedOffset < insertionLength + headSeedLength) return;   // unsigned arithmetic as in the reference
+    const bool reverse = head.reverse;
+    const char *reference = R.bases + R.contigOffset[head.contigId];
+    const i64 refSize = i64(contigLength(R, head.contigId));
+    i64 tailIt = i64(tailOffset) + insertionLength;
+    u32 tailLength = observedEnd - tailOffset - insertionLength;
+    const u32 tailMismatches = countMismatches(read, reverse, tailIt, reference, headUnclipped + tailOffset, refSize, tailLength);
+    u32 leftFlankMismatches = countMismatches(read, reverse, tailIt - insertionLength - GAP_FLANK_BASES, reference, headUnclipped + tailOffset - GAP_FLANK_BASES, refSize, GAP_FLANK_BASES);
+    u32 rightFlankMismatches = countMismatches(read, reverse, tailIt, reference, headUnclipped + tailOffset, refSize, imin(GAP_FLANK_BASES, tailLength));
+    u32 rightRealignedMismatches = tailMismatches, leftRealignedMismatches = 0;
+    i64 refIt = headUnclipped + tailOffset;
+    u32 bestMismatches = tailMismatches, bestOffset = tailOffset, bestLeftFlankMismatches = leftFlankMismatches, bestRightFlankMismatches = rightFlankMismatches;
+    for (u32 insertionOffset = tailOffset; bestMismatches && insertionOffset <= tailSeedOffset - insertionLength; ++insertionOffset, ++tailIt, ++refIt, --tailLength)
+    {
+        const u32 thisOffsetMismatches = leftRealignedMismatches + rightRealignedMismatches;
+        if (bestMismatches > thisOffsetMismatches)
+        {
+            bestOffset = insertionOffset; bestMismatches = thisOffsetMismatches;
+            bestLeftFlankMismatches = leftFlankMismatches; bestRightFlankMismatches = rightFlankMismatches;
+        }
+        const bool newLeftMismatch = !isMatch(strandBase(read, reverse, u32(tailIt - insertionLength)), reference[refIt]);
+        leftRealignedMismatches += newLeftMismatch; leftFlankMismatches += newLeftMismatch;
+        if (insertionOffset >= GAP_FLANK_BASES)
+            leftFlankMismatches -= !isMatch(strandBase(read, reverse, u32(tailIt - insertionLength - GAP_FLANK_BASES)), reference[refIt - GAP_FLANK_BASES]);
+        const bool disappearingRightMismatch = !isMatch(strandBase(read, reverse, u32(tailIt)), reference[refIt]);
+        rightRealignedMismatches -= disappearingRightMismatch; rightFlankMismatches -= disappearingRightMismatch;
+        if (tailLength > GAP_FLANK_BASES)
+            rightFlankMismatches += !isMatch(strandBase(read, reverse, u32(tailIt + GAP_FLANK_BASES)), reference[refIt + GAP_FLANK_BASES]);
+    }
+    const i64 clippingPositionOffset = candBeginClipped(head, cw);
+    const u32 leftMapped = u32(i64(bestOffset) - clippingPositionOffset);
+    if (!leftMapped) return;   // ISAAC_ASSERT in the reference
+    const u32 headMismatches = countMismatches(read, reverse, clippingPositionOffset, reference, head.position, refSize, leftMapped);
+    const u32 newMismatches = headMismatches + bestMismatches;
+    const u32 sws = P.normalizedMismatchScore * newMismatches + P.normalizedGapOpenScore +
+        imin(P.normalizedMaxGapExtendScore, (insertionLength - 1) * P.normalizedGapExtendScore);
+    if (bestLeftFlankMismatches <= GAP_FLANK_MISMATCHES_MAX && bestRightFlankMismatches <= GAP_FLANK_MISMATCHES_MAX)
+    {
+        if (tail.smithWatermanScore > sws || (tail.smithWatermanScore == sws && tail.mismatchCount > newMismatches))
+        {
+            const u32 tailEndClipped = u32(candEndClipped(tail, cw));
+            const u32 rightMapped = u32(i64(candObservedLength(head)) + candEndClipped(head, cw) - i64(leftMapped) - i64(tailEndClipped) - i64(insertionLength));
+            if (!rightMapped) return; // ISAAC_ASSERT in the reference
+            const u32 cigarOffset = pool.used;
+            if (clippingPositionOffset) pool.addOperation(u32(clippingPositionOffset), OP_SOFT_CLIP);
+            pool.addOperation(leftMapped, OP_ALIGN);
+            pool.addOperation(insertionLength, OP_INSERT);
+            pool.addOperation(rightMapped, OP_ALIGN);
+            if (tailEndClipped) pool.addOperation(tailEndClipped, OP_SOFT_CLIP);
+            const u16 headLeftClipped = head.reverse ? head.highClipped : head.lowClipped;
+            const i64 unclipped = candUnclippedPosition(tail, cw);
+            CigarPool view = pool; view.used = cigarOffset;
+            candResetAlignment(tail, view);
+            tail.position = unclipped;
+            if (tail.reverse) tail.highClipped = headLeftClipped; else tail.lowClipped = headLeftClipped;
+            updateFragmentCigar(P, R, read, tail, head.position, pool, cigarOffset);
+            ++simpleIndels;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// candidate list of one read: elements never move, the list is an index array (see sort.h)
+struct CandList
+{
+    Cand *store; u8 *order; u32 n; u32 stored; u32 capacity; u32 overflow;
+    ISAAC_HD Cand &at(u32 i) { return store[order[i]]; }
+    ISAAC_HD const Cand &at(u32 i) const { return store[order[i]]; }
+};
+
+struct CandLessByPosition
+{
+    const Cand *store;
+    ISAAC_HD bool operator()(u8 a, u8 b) const { return candLess(store[a], store[b]); }
+};
+// SimpleIndelAligner.cpp:443-449
+struct CandLessByUnclippedPosition
+{
+    const Cand *store; const u32 *pool;
+    ISAAC_HD bool operator()(u8 a, u8 b) const
+    {
+        const Cand &l = store[a], &r = store[b];
+        return l.contigId < r.contigId || (l.contigId == r.contigId && candUnclippedPosition(l, pool) < candUnclippedPosition(r, pool));
+    }
+};
+
+// FragmentBuilder::consolidateDuplicateFragments (FragmentBuilder.cpp:279-324)
+ISAAC_HD void consolidateDuplicateFragments(CandList &l, bool removeUnaligned)
+{
+    CandLessByPosition less; less.store = l.store;
+    exactSort(l.order, i32(l.n), less);
+    u32 first = 0;
+    while (first != l.n && removeUnaligned && !candAligned(l.at(first))) ++first;
+    if (first) { for (u32 i = first; i < l.n; ++i) l.order[i - first] = l.order[i]; l.n -= first; }
+    if (2 > l.n) return;
+    u32 last = 0;
+    for (u32 current = 1; current != l.n; ++current)
+    {
+        if (removeUnaligned && !candAligned(l.at(current))) { }
+        else if (candEqual(l.at(last), l.at(current)))
+        {
+            Cand &a = l.at(last); const Cand &b = l.at(current);
+            a.uniqueSeedCount = u16(a.uniqueSeedCount + b.uniqueSeedCount);
+            a.nonUniqueFirst = imin(a.nonUniqueFirst, b.nonUniqueFirst);
+            a.nonUniqueSecond = imax(a.nonUniqueSecond, b.nonUniqueSecond);
+        }
+        else { ++last; if (last != current) l.order[last] = l.order[current]; }
+    }
+    l.n = last + 1;
+}
+
+// SimpleIndelAligner::alignSimpleIndels (SimpleIndelAligner.cpp:460-518)
+ISAAC_HD void alignSimpleIndels(const DevParams &P, const DevReference &R, const ReadView &read, CigarPool &pool, CandList &l, u32 &simpleIndels)
+{
+    if (l.n < 2) return;
+    CandLessByUnclippedPosition less; less.store = l.store; less.pool = pool.words;
+    exactSort(l.order, i32(l.n), less);
+    for (u32 t = 1; t != l.n; ++t)
+    {
+        Cand &head = l.at(t - 1); Cand &tail = l.at(t);
+        if (head.contigId == tail.contigId && head.reverse == tail.reverse)
+        {
+            const DevSeed &headSeed = P.seeds[head.firstSeedIndex]; const DevSeed &tailSeed = P.seeds[tail.firstSeedIndex];
+            const i64 distance = candUnclippedPosition(tail, pool.words) - candUnclippedPosition(head, pool.words);
+            if (!distance) continue;  // ISAAC_ASSERT in the reference
+            if ((distance < 0 ? -distance : distance) < i64(P.semialignedGapLimit))
+            {
+                const i64 readLength = read.length;
+                const i64 headSeedOffset = head.reverse ? readLength - headSeed.offset - headSeed.length : i64(headSeed.offset);
+                const i64 tailSeedOffset = head.reverse ? readLength - tailSeed.offset - tailSeed.length : i64(tailSeed.offset);
+                if (0 < tailSeedOffset - headSeedOffset)
+                    alignSimpleDeletion(P, R, read, pool, head, u32(headSeedOffset), tail, u32(tailSeedOffset), tailSeed.length, simpleIndels);
+                else
+                    alignSimpleInsertion(P, R, read, pool, tail, u32(tailSeedOffset), tailSeed.length, head, u32(headSeedOffset), headSeed.length, simpleIndels);
+            }
+        }
+    }
+}
+
+// per-thread scratch of the fragment stage
+struct FragmentWork
+{
+    Cand store[CAND_CAP];
+    u8 order[CAND_CAP];
+    u8 matchOrder[MATCH_CAP_MAX];
+    u32 tflags[3 * 512];          // banded SW traceback flags, reads up to 512 cycles
+};
+
+struct MatchLess
+{
+    const Match *m;
+    // SelectMatchesTransition.cpp:242-254 within one cluster: (location, seed index); the reverse bit makes the order total
+    ISAAC_HD bool operator()(u8 a, u8 b) const
+    {
+        const Match &l = m[a], &r = m[b];
+        if (l.location != r.location) return l.location < r.location;
+        const u32 ls = seedIdSeed(l.seedId), rs = seedIdSeed(r.seedId);
+        if (ls != rs) return ls < rs;
+        return (l.seedId & 1) < (r.seedId & 1);
+    }
+};
+
+// FragmentBuilder::build (FragmentBuilder.cpp:82-145) + alignFragments (:147-217) for one cluster.
+// `matches` are the cluster's Match records in any order.  Results go to `out` (lists compacted in final order).
+ISAAC_HD bool buildFragments(const DevParams &P, const DevReference &R, const u8 *clusterBcl, const Match *matches, u32 nMatches,
+                             bool withGaps, bool trim, FragmentWork &work, ClusterFragments &out, Counters &cnt)
+{
+    out.nCands[0] = out.nCands[1] = 0; out.cigarUsed = 0; out.flags = 0; out.repeatSeedsCount = 0; out.built = 0;
+    ReadView reads[2];
+    for (u32 r = 0; r < 2; ++r)
+    {
+        reads[r].bcl = clusterBcl + P.readOffset[r]; reads[r].length = r < P.nReads ? P.readLength[r] : 0; reads[r].firstCycle = P.firstCycle[r];
+        reads[r].endCyclesMasked = (trim && r < P.nReads) ? trimLowQualityEnd(reads[r].bcl, reads[r].length, P.baseQualityCutoff) : 0;
+        out.endCyclesMasked[r] = reads[r].endCyclesMasked;
+    }
+    if (!nMatches || nMatches > MATCH_CAP_MAX) { if (nMatches > MATCH_CAP_MAX) out.flags |= CLUSTER_OVERFLOW; return false; }
+    // seedMatchCounts_ / repeatSeedsCount_ (FragmentBuilder.cpp:99-126): order independent once stated per seed index
+    u32 counts[MAX_SEEDS]; bool tooMany[MAX_SEEDS];
+    for (u32 s = 0; s < MAX_SEEDS; ++s) { counts[s] = 0; tooMany[s] = false; }
+    bool any = false;
+    for (u32 i = 0; i < nMatches; ++i)
+    {
+        if (refposIsNoMatch(matches[i].location)) continue;
+        any = true;
+        const u32 s = seedIdSeed(matches[i].seedId);
+        if (refposIsTooMany(matches[i].location)) tooMany[s] = true; else ++counts[s];
+    }
+    if (!any) return false;
+    u32 repeatSeedsCount = 0;
+    for (u32 s = 0; s < P.nSeeds; ++s) if (tooMany[s] || counts[s] >= P.repeatThreshold) ++repeatSeedsCount;
+    out.repeatSeedsCount = repeatSeedsCount;
+    // the reference adds candidates in sorted match order; that order is the input order of the first std::sort
+    for (u32 i = 0; i < nMatches; ++i) work.matchOrder[i] = u8(i);
+    { MatchLess ml; ml.m = matches; exactSort(work.matchOrder, i32(nMatches), ml); }
+    CigarPool pool; pool.words = out.cigarPool; pool.used = 0; pool.capacity = CIGAR_POOL; pool.overflow = 0;
+    bool built = false;
+    for (u32 r = 0; r < P.nReads; ++r)
+    {
+        CandList l; l.store = work.store; l.order = work.order; l.n = 0; l.stored = 0; l.capacity = CAND_CAP; l.overflow = 0;
+        for (u32 k = 0; k < nMatches; ++k)
+        {
+            const Match &m = matches[work.matchOrder[k]];
+            if (refposIsNoMatch(m.location) || refposIsTooMany(m.location)) continue;
+            const u32 s = seedIdSeed(m.seedId);
+            const DevSeed &seed = P.seeds[s];
+            if (seed.readIndex != r || tooMany[s] || counts[s] >= P.repeatThreshold) continue;
+            if (l.stored == l.capacity) { l.overflow = 1; break; }
+            // FragmentBuilder::addMatch (:219-249) + getReadPosition (:326-343)
+            Cand &f = l.store[l.stored];
+            candInit(f, r);
+            const bool reverse = m.seedId & 1;
+            const i64 seedPosition = i64(refposPosition(m.location));
+            f.firstSeedIndex = (signed char)s;
+            f.contigId = refposContig(m.location);
+            f.position = reverse ? seedPosition + seed.length + seed.offset - i64(P.readLength[r]) : seedPosition - seed.offset;
+            f.reverse = reverse;
+            if (seed.length != 64 && (m.location & 1)) { f.nonUniqueFirst = seed.offset; f.nonUniqueSecond = seed.offset; }
+            else f.uniqueSeedCount = 1;
+            l.order[l.n++] = u8(l.stored++);
+        }
+        if (l.overflow) out.flags |= CLUSTER_OVERFLOW;
+        if (!l.n) continue;
+        built = true;
+        // alignFragments (:147-217)
+        consolidateDuplicateFragments(l, false);
+        for (u32 i = 0; i < l.n; ++i)
+        {
+            Cand &f = l.at(i);
+            f.repeatSeedsCount = u16(repeatSeedsCount);
+            alignUngapped(P, R, reads[r], f, pool);
+            ++cnt.ungappedScans;
+        }
+        consolidateDuplicateFragments(l, true);
+        if (P.semialignedGapLimit)
+        {
+            u32 si = 0;
+            alignSimpleIndels(P, R, reads[r], pool, l, si);
+            cnt.simpleIndels += si;
+            consolidateDuplicateFragments(l, true);
+        }
+        for (u32 i = 0; i < l.n; ++i)
+        {
+            Cand &f = l.at(i);
+            if (withGaps && BSW_MISMATCHES_CUTOFF < f.mismatchCount)
+            {
+                Cand tmp = f;
+                ++cnt.bswJobs;
+                const u32 matchCount = alignGapped(P, R, reads[r], tmp, pool, work.tflags);
+                if (matchCount && matchCount + BSW_WIDEST_GAP_SIZE > candObservedLength(f) && (tmp.mismatchCount <= P.gappedMismatchesMax) &&
+                    (f.mismatchCount > tmp.mismatchCount) && lpLess(f.logProbability, tmp.logProbability))
+                { f = tmp; ++cnt.bswAccepted; }
+            }
+        }
+        consolidateDuplicateFragments(l, true);
+        if (l.n > CAND_CAP) l.n = CAND_CAP;
+        for (u32 i = 0; i < l.n; ++i) out.cands[r][i] = l.at(i);
+        out.nCands[r] = l.n;
+        cnt.candidates += l.n;
+    }
+    out.cigarUsed = pool.used;
+    if (pool.overflow) out.flags |= CLUSTER_OVERFLOW;
+    out.built = built;
+    return built;
+}
+
+} // namespace isaac

@@ -1,0 +1,153 @@
+// Shared plain-data layouts of the MI355X seed-and-extend pipeline.
+//
+// Everything in csrc/*.h is written as ISAAC_HD functions over plain pointers: hipcc compiles them into the gfx950 kernels
+// of the product library; tests/hostemu compiles the very same headers with g++ so that the thread-serial device logic can
+// be stepped against the oracle in the CPU-only container (a debugging harness, never a product path).
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define ISAAC_HD __host__ __device__ inline
+#else
+#define ISAAC_HD inline
+#endif
+
+namespace isaac
+{
+
+typedef uint8_t u8; typedef uint16_t u16; typedef uint32_t u32; typedef uint64_t u64; typedef int16_t i16; typedef int32_t i32; typedef int64_t i64;
+
+// ---- reference formats (cited in include/isaac_gpu.h) -------------------------------------------------------------
+// ReferencePosition (include/reference/ReferencePosition.hh:51-188): bit 0 neighbors, bits 1..40 position, bits 41..63 contig+1
+static const u64 REFPOS_NOMATCH = ((~u64(0)) >> 41) << 41;
+static const u32 MAX_CONTIG_ID = u32((~u64(0)) >> 41);
+ISAAC_HD u64 refpos(u64 contig, u64 position, bool neighbors = false) { return ((((contig + 1) << 40) | position) << 1) | u64(neighbors); }
+ISAAC_HD u32 refposContig(u64 v) { return u32(v >> 41) - 1; }
+ISAAC_HD u64 refposPosition(u64 v) { return (v >> 1) & ((u64(1) << 40) - 1); }
+ISAAC_HD bool refposIsTooMany(u64 v) { return (v >> 1) == 0; }
+ISAAC_HD bool refposIsNoMatch(u64 v) { return v == REFPOS_NOMATCH; }
+// SeedId (include/alignment/SeedId.hh:60-127)
+ISAAC_HD u64 seedId(u64 tile, u64 barcode, u64 cluster, u64 seed, u64 reverse) { return (tile << 52) | (barcode << 40) | (cluster << 9) | (seed << 1) | reverse; }
+ISAAC_HD u32 seedIdSeed(u64 v) { return u32(v >> 1) & 0xff; }
+ISAAC_HD u32 seedIdCluster(u64 v) { return u32(v >> 9) & 0x7fffffffu; }
+// Cigar (include/alignment/Cigar.hh:52-70,156-168)
+enum { OP_ALIGN = 0, OP_INSERT = 1, OP_DELETE = 2, OP_SOFT_CLIP = 4 };
+ISAAC_HD u32 cigarOp(u32 len, u32 op) { return (len << 4) | op; }
+ISAAC_HD u32 cigarLen(u32 w) { return w >> 4; }
+ISAAC_HD u32 cigarCode(u32 w) { u32 c = w & 0xf; return c > 9 ? 9 : c; }
+
+struct Match { u64 seedId; u64 location; };
+
+// ---- parameters as the kernels see them ---------------------------------------------------------------------------
+static const u32 MAX_SEEDS = 16;
+struct DevSeed { u16 offset, length; u32 readIndex; };
+struct DevParams
+{
+    i32 gapMatch, gapMismatch, gapOpen, gapExtend, minGapExtend;
+    // AlignerBase (lib/alignment/fragmentBuilder/AlignerBase.cpp:32-44)
+    u32 normalizedMismatchScore, normalizedGapOpenScore, normalizedGapExtendScore, normalizedMaxGapExtendScore;
+    u32 repeatThreshold, gappedMismatchesMax, semialignedGapLimit, baseQualityCutoff;
+    u32 ignoreNeighbors, clipSemialigned, clipOverlapping, scatterRepeats;
+    i32 dodgyAlignmentScore; u32 mapqThreshold, keepUnaligned; i32 mateDriftRange;
+    u32 nReads, readLength[2], readOffset[2], firstCycle[2], clusterLength;
+    u32 nSeeds; DevSeed seeds[MAX_SEEDS];
+    u32 nPass[2]; u8 passSeeds[2][MAX_SEEDS];  // FindMatchesTransition.cpp:90-110, each list ordered by (read, offset)
+    u32 maxSeedsPerRead;
+};
+
+// reference sequence + sorted k-mer table resident in HBM
+struct DevReference
+{
+    const char *bases;        // all contigs, ASCII ACGTN, concatenated
+    const u64 *contigOffset;  // n_contigs + 1
+    const u8 *contigLoaded;   // MatchSelector.cpp:85-90: contigs without any seed match count as empty
+    u32 nContigs;
+    const u64 *kmers;         // sorted 32-mers (all masks concatenated)
+    const u64 *positions;     // ReferencePosition values, parallel to kmers
+    u64 nKmers;
+    const u32 *karyotype;     // contig id translation of ReferenceKmer::getTranslatedPosition, NULL = identity
+    const u32 *prefixTable;   // optional: first table index of every PREFIX_BITS-bit k-mer prefix (+ end sentinel)
+    u32 prefixBits;
+    const double *logMatch;   // Quality::logMatchLookup / logMismatchLookup (lib/alignment/Quality.cpp:34-66), 100 entries each
+    const double *logMismatch;
+};
+ISAAC_HD u64 contigLength(const DevReference &r, u32 contig) { return r.contigOffset[contig + 1] - r.contigOffset[contig]; }
+
+// ---- candidates (alignment::FragmentMetadata reduced to what the path reads) -------------------------------------
+static const u16 NON_UNIQUE_NONE = 0xffff;
+struct Cand
+{
+    i64 position;
+    double logProbability;
+    u32 contigId;
+    u32 observedLength;
+    u32 smithWatermanScore;
+    u32 cigarOffset;      // into the cluster's cigar pool
+    u32 alignmentScore;
+    u16 cigarLength, mismatchCount, matchesInARow, gapCount, editDistance, lowClipped, highClipped;
+    u16 uniqueSeedCount, nonUniqueFirst, nonUniqueSecond, repeatSeedsCount;
+    u8 reverse, readIndex; signed char firstSeedIndex; u8 pad;
+};
+static_assert(sizeof(Cand) == 64, "Cand layout");
+
+ISAAC_HD void candInit(Cand &c, u32 readIndex)
+{
+    c.position = 0; c.logProbability = 0.0; c.contigId = MAX_CONTIG_ID; c.observedLength = 0; c.smithWatermanScore = 0; c.cigarOffset = 0;
+    c.alignmentScore = 0xffffffffu; c.cigarLength = 0; c.mismatchCount = 0; c.matchesInARow = 0; c.gapCount = 0; c.editDistance = 0;
+    c.lowClipped = 0; c.highClipped = 0; c.uniqueSeedCount = 0; c.nonUniqueFirst = NON_UNIQUE_NONE; c.nonUniqueSecond = 0; c.repeatSeedsCount = 0;
+    c.reverse = 0; c.readIndex = u8(readIndex); c.firstSeedIndex = -1; c.pad = 0;
+}
+ISAAC_HD bool candAligned(const Cand &c) { return 0 != c.cigarLength; }
+ISAAC_HD u32 candObservedLength(const Cand &c) { return candAligned(c) ? c.observedLength : 0; }
+ISAAC_HD bool candNoMatch(const Cand &c) { return MAX_CONTIG_ID == c.contigId; }
+// FragmentMetadata::isWellAnchored (FragmentMetadata.hh:477-483)
+ISAAC_HD bool candWellAnchored(const Cand &c)
+{ return c.uniqueSeedCount || (c.nonUniqueFirst != NON_UNIQUE_NONE && c.nonUniqueSecond > c.nonUniqueFirst && u32(c.nonUniqueSecond - c.nonUniqueFirst) >= 32); }
+ISAAC_HD void candSetUnaligned(Cand &c) { c.cigarLength = 0; c.alignmentScore = 0xffffffffu; }
+ISAAC_HD void candSetNoMatch(Cand &c) { candSetUnaligned(c); c.contigId = MAX_CONTIG_ID; c.position = 0; }
+ISAAC_HD void candIncrementClipLeft(Cand &c, u32 bases) { c.position += bases; if (c.reverse) c.highClipped += u16(bases); else c.lowClipped += u16(bases); }
+ISAAC_HD void candIncrementClipRight(Cand &c, u32 bases) { if (c.reverse) c.lowClipped += u16(bases); else c.highClipped += u16(bases); }
+// FragmentMetadata::operator< / == (FragmentMetadata.hh:419-448)
+ISAAC_HD bool candLess(const Cand &a, const Cand &b)
+{
+    return a.contigId < b.contigId || (a.contigId == b.contigId && (a.position < b.position ||
+           (a.position == b.position && (a.reverse < b.reverse || (a.reverse == b.reverse && a.observedLength < b.observedLength)))));
+}
+ISAAC_HD bool candEqual(const Cand &a, const Cand &b) { return a.position == b.position && a.contigId == b.contigId && a.reverse == b.reverse && a.observedLength == b.observedLength; }
+
+// ---- per-cluster state that lives in HBM between the kernels of one tile -----------------------------------------
+static const u32 CAND_CAP = 128;         // per read; 2 strands x seeds/read x (repeatThreshold - 1) = 72 for 4 seeds (2x150), 126 for 7 (2x250)
+static const u32 CIGAR_POOL = 1024;      // cigar words per cluster (fragment stage)
+static const u32 MATCH_CAP_MAX = 320;
+struct ClusterFragments
+{
+    Cand cands[2][CAND_CAP];
+    u32 nCands[2];
+    u32 cigarUsed;
+    u32 flags;              // bit0: a fixed-capacity list overflowed
+    u32 endCyclesMasked[2]; // Read::endCyclesMasked_ after trimLowQualityEnds
+    u32 repeatSeedsCount;
+    u32 built;              // FragmentBuilder::build returned true
+    u32 cigarPool[CIGAR_POOL];
+};
+enum { CLUSTER_OVERFLOW = 1 };
+
+struct Counters
+{
+    u64 clusters, probes, probeSteps, matches, candidates, ungappedScans, bswJobs, bswAccepted, simpleIndels,
+        rescueCalls, rescueWindowBases, rescueCandidates, rescueBsw, overflowClusters, mapqNearInteger;
+};
+
+// per-cluster facts TemplateLengthDistribution::addTemplate looks at (TemplateLengthStatistics.cpp:275-314)
+struct TlsSample { u32 n0, n1; u32 contig0, contig1; i64 pos0, pos1; u32 obs0, obs1; u8 rev0, rev1; u8 insertEnd; u8 valid; };
+
+// Quality.hh:104-112
+ISAAC_HD bool lpEquals(double l, double r) { double d = l - r; if (d < 0) d = -d; return 0.0000001 >= d; }
+ISAAC_HD bool lpLess(double l, double r) { return !lpEquals(l, r) && l < r; }
+
+template <typename T> ISAAC_HD T imin(T a, T b) { return a < b ? a : b; }
+template <typename T> ISAAC_HD T imax(T a, T b) { return a > b ? a : b; }
+
+} // namespace isaac

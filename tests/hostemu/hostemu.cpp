@@ -1,0 +1,174 @@
+// CPU debugging harness for the thread-serial device logic of isaac_aligner_amd/csrc/*.h.
+//
+// TEST INFRASTRUCTURE ONLY.  The container that builds this repository has no GPU; this file compiles the very headers the
+// gfx950 kernels are made of with g++ and runs the per-cluster functions in a plain loop, so that their logic can be checked
+// against the oracle before a GPU box is spent on them.  It is not part of the product library and the product has no CPU path.
+#include "../../isaac_aligner_amd/csrc/cluster_ops.h"
+#include "../../isaac_aligner_amd/csrc/host_util.h"
+#include <string>
+#include <vector>
+#include <cstring>
+#include <algorithm>
+
+using namespace isaac;
+
+namespace {
+thread_local std::string g_error;
+
+struct Emu
+{
+    DevParams P; DevReference R;
+    std::vector<char> bases; std::vector<u64> offsets; std::vector<u8> loaded;
+    std::vector<double> logMatch, logMismatch;
+    std::vector<ClusterFragments> frags;
+    std::vector<Match> matches; std::vector<u32> counts; u32 stride;
+    Counters cnt;
+};
+}
+
+extern "C" {
+
+const char *emu_last_error() { return g_error.c_str(); }
+
+Emu *emu_create(const isaac_params *p, const char *bases, const u64 *offsets, u32 nContigs, const u8 *loaded)
+{
+    try
+    {
+        Emu *e = new Emu;
+        e->P = makeDevParams(*p);
+        e->bases.assign(bases, bases + offsets[nContigs]); e->offsets.assign(offsets, offsets + nContigs + 1);
+        e->loaded.assign(nContigs, 1); if (loaded) e->loaded.assign(loaded, loaded + nContigs);
+        e->logMatch.resize(100); e->logMismatch.resize(100); makeQualityTables(e->logMatch.data(), e->logMismatch.data());
+        std::memset(&e->R, 0, sizeof(e->R));
+        e->R.bases = e->bases.data(); e->R.contigOffset = e->offsets.data(); e->R.contigLoaded = e->loaded.data(); e->R.nContigs = nContigs;
+        e->R.logMatch = e->logMatch.data(); e->R.logMismatch = e->logMismatch.data();
+        std::memset(&e->cnt, 0, sizeof(e->cnt));
+        e->stride = 2 * e->P.nSeeds * std::max(1u, e->P.repeatThreshold - 1);
+        return e;
+    }
+    catch (const std::exception &ex) { g_error = ex.what(); return 0; }
+}
+void emu_destroy(Emu *e) { delete e; }
+
+// matches: any order inside a cluster, clusters ascending (as isaac_gpu_find_matches delivers them)
+int emu_set_matches(Emu *e, const isaac_match *m, u64 n, u32 nClusters)
+{
+    e->matches.assign(size_t(nClusters) * e->stride, Match()); e->counts.assign(nClusters, 0);
+    for (u64 i = 0; i < n; ++i)
+    {
+        const u32 c = seedIdCluster(m[i].seed_id);
+        if (c >= nClusters) { g_error = "cluster id out of range"; return 1; }
+        if (refposIsNoMatch(m[i].location)) continue;
+        if (e->counts[c] >= e->stride) { g_error = "match capacity"; return 1; }
+        Match &d = e->matches[size_t(c) * e->stride + e->counts[c]++]; d.seedId = m[i].seed_id; d.location = m[i].location;
+    }
+    return 0;
+}
+
+int emu_build_fragments(Emu *e, const u8 *bcl, u32 nClusters, int withGaps, int trim,
+                        isaac_candidate *out, u64 capacity, u64 *nOut, u32 *cigarOut, u64 cigarCapacity, u64 *nCigar)
+{
+    e->frags.resize(nClusters);
+    std::vector<FragmentWork> work(1);
+    u64 n = 0, nc = 0;
+    for (u32 c = 0; c < nClusters; ++c)
+    {
+        ClusterFragments &f = e->frags[c];
+        clusterBuildFragments(e->P, e->R, bcl, c, e->matches.data(), e->counts.data(), e->stride, withGaps != 0, trim != 0, work[0], f, e->cnt);
+        if (!out) continue;
+        for (u32 r = 0; r < 2; ++r) for (u32 i = 0; i < f.nCands[r]; ++i)
+        {
+            const Cand &k = f.cands[r][i];
+            if (n >= capacity || nc + k.cigarLength > cigarCapacity) { g_error = "capacity"; return 1; }
+            isaac_candidate &o = out[n++]; std::memset(&o, 0, sizeof(o));
+            o.position = k.position; o.log_probability = k.logProbability; o.cluster = c; o.read_index = k.readIndex; o.contig_id = k.contigId;
+            o.observed_length = k.observedLength; o.reverse = k.reverse; o.mismatch_count = k.mismatchCount; o.matches_in_a_row = k.matchesInARow; o.gap_count = k.gapCount;
+            o.edit_distance = k.editDistance; o.smith_waterman_score = k.smithWatermanScore; o.unique_seed_count = k.uniqueSeedCount;
+            o.non_unique_first = k.nonUniqueFirst == NON_UNIQUE_NONE ? 0xffffffffu : k.nonUniqueFirst; o.non_unique_second = k.nonUniqueSecond;
+            o.repeat_seeds_count = k.repeatSeedsCount; o.cigar_offset = u32(nc); o.cigar_length = k.cigarLength; o.low_clipped = k.lowClipped; o.high_clipped = k.highClipped;
+            o.first_seed_index = k.firstSeedIndex;
+            std::memcpy(cigarOut + nc, f.cigarPool + k.cigarOffset, k.cigarLength * 4); nc += k.cigarLength;
+        }
+    }
+    if (nOut) *nOut = n; if (nCigar) *nCigar = nc;
+    return 0;
+}
+
+int emu_determine_tls(Emu *e, const u8 *bcl, u32 nClusters, isaac_tls *out)
+{
+    int rc = emu_build_fragments(e, bcl, nClusters, 0, 0, 0, 0, 0, 0, 0, 0);
+    if (rc) return rc;
+    TlsLearner learner(e->P.mateDriftRange);
+    if (2 == e->P.nReads)
+    {
+        for (u32 c = 0; c < nClusters && !learner.stats.stable; ++c)
+        {
+            TlsSample s; clusterTlsSample(e->frags[c], e->counts[c], s);
+            learner.add(s);
+        }
+        if (!learner.stats.stable) learner.finalize();
+    }
+    std::memcpy(out, &learner.stats, sizeof(*out));
+    return 0;
+}
+
+int emu_select(Emu *e, const u8 *bcl, u32 nClusters, u32 tile, const isaac_tls *tls, isaac_fragment *records, u32 *cigars)
+{
+    int rc = emu_build_fragments(e, bcl, nClusters, 1, 1, 0, 0, 0, 0, 0, 0);
+    if (rc) return rc;
+    DevTls t; std::memcpy(&t, tls, sizeof(t));
+    const RogCorrection rog = makeRogCorrection(e->P, e->offsets.data(), e->loaded.data(), e->R.nContigs);
+    FragmentRecord *recs = reinterpret_cast<FragmentRecord *>(records);
+    // main pass with the light per-thread capacities, then the flagged clusters again with the reference's own limits
+    for (int tier = 0; tier < 2; ++tier)
+    {
+        const TemplateCaps caps = tier ? heavyCaps() : lightCaps();
+        std::vector<u8> arena(templateWorkBytes(caps) + 16, 0);
+        TemplateWork work;
+        void *base = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(arena.data()) + 15) & ~uintptr_t(15));
+        templateWorkBind(work, base, caps);
+        for (u32 c = 0; c < nClusters; ++c)
+        {
+            if (tier && !(recs[u64(c) * e->P.nReads].reserved & RECORD_TEMPLATE_OVERFLOW)) continue;
+            if (tier) ++e->cnt.overflowClusters;
+            clusterSelect(e->P, e->R, t, rog, logMismatchQ40(), bcl, c, tile, e->frags[c], work, recs, cigars, e->cnt);
+        }
+    }
+    return 0;
+}
+
+void emu_get_counters(Emu *e, isaac_counters *out) { std::memcpy(out, &e->cnt, sizeof(*out)); }
+
+// banded SW leaf through the serial device function
+int emu_bsw(int match, int mismatch, int gapOpen, int gapExtend, const char *query, u32 queryLength, const char *database, u32 *cigarOut, u32 *nOps, u32 *offset)
+{
+    DevParams P; std::memset(&P, 0, sizeof(P));
+    P.gapMatch = match; P.gapMismatch = mismatch; P.gapOpen = -gapOpen; P.gapExtend = -gapExtend;
+    std::vector<u32> tflags(3 * queryLength + 3);
+    u32 words[256]; CigarPool pool; pool.words = words; pool.used = 0; pool.capacity = 256; pool.overflow = 0;
+    struct Q { const char *q; char operator()(u32 i) const { return q[i]; } } q; q.q = query;
+    *offset = bswAlignSerial(P, q, queryLength, database, tflags.data(), pool);
+    *nOps = pool.used; std::memcpy(cigarOut, words, pool.used * 4);
+    return 0;
+}
+
+// exactSort versus std::sort: sorts n records by key only and returns the permutation
+void emu_exact_sort(const u32 *keys, u32 n, u16 *perm)
+{
+    for (u32 i = 0; i < n; ++i) perm[i] = u16(i);
+    struct L { const u32 *k; bool operator()(u16 a, u16 b) const { return k[a] < k[b]; } } less; less.k = keys;
+    exactSort(perm, int(n), less);
+}
+void emu_std_sort(const u32 *keys, u32 n, u16 *perm)
+{
+    for (u32 i = 0; i < n; ++i) perm[i] = u16(i);
+    std::sort(perm, perm + n, [&](u16 a, u16 b) { return keys[a] < keys[b]; });
+}
+
+uint32_t emu_sizeof(int what)
+{
+    switch (what) { case 0: return sizeof(Cand); case 1: return sizeof(ClusterFragments); case 2: return sizeof(FragmentWork); case 3: return sizeof(TemplateWork);
+                    case 4: return sizeof(FragmentRecord); case 5: return sizeof(DevParams); case 6: return sizeof(isaac_params); default: return 0; }
+}
+
+} // extern "C"
