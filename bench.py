@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- paired-end reads aligned per second on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): a chr21-sized reference (46.7 Mbp; synthetic, because no genome ships with the image),
+2x150 bp synthetic pairs, default 10 steps x 1 M pairs = 10 M pairs per GPU.  A step = one pass of the hot path over one
+batch of pairs already resident in HBM: isaac_gpu_find_matches (seed extraction + index lookup) followed by
+isaac_gpu_select (fragment building, banded Smith-Waterman, mate rescue, MAPQ, clipping, FragmentHeader records).  As in the
+reference the two halves run as two phases over all batches, with the loaded-contig set and the template-length statistics
+(learnt from the first batch during warm-up, then frozen: MatchSelector.cpp:402-417) fixed in between.
+With N > 1 every rank aligns its own K batches on its own GPU (static shard, no data-path collective); the ranks OR-reduce the
+per-contig hit flags between the phases and rank 0 gathers the fixed-size alignment records once at the end (RCCL).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs-per-step", type=int, default=1_000_000)
+    ap.add_argument("--genome-bases", type=int, default=46_700_000)
+    ap.add_argument("--read-length", type=int, default=150)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=100_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-neighbors", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    from isaac_aligner_amd import abi, gpu, options, synth
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    L = args.read_length
+    params = options.default_params(L, L)
+
+    # ---- setup (untimed): reference, index, reads resident in HBM ---------------------------------------------------
+    t0 = time.time()
+    contigs = synth.make_genome(args.genome_bases, seed=2, device=dev, n_contigs=1)
+    al = gpu.Aligner(params, local_rank, contigs)
+    n_index = al.build_index(repeat_threshold=1000, annotate_neighbors=not args.no_neighbors)
+    t_index = time.time() - t0
+    n_batches = args.warmup + args.steps
+    batches = []
+    for b in range(n_batches):
+        bcl, _ = synth.make_read_pairs(contigs, args.pairs_per_step, L, seed=1000 * (rank + 1) + b, device=dev)
+        batches.append(bcl)
+    torch.cuda.synchronize()
+    t_setup = time.time() - t0
+
+    n_rec = args.pairs_per_step * 2
+    records = [torch.empty((n_rec, abi.FRAGMENT_DTYPE.itemsize), dtype=torch.uint8, device=dev) for _ in range(args.steps)]
+    cigars = torch.empty(n_rec * abi.MAX_CIGAR_OPS, dtype=torch.int32, device=dev)   # reused: only the records are gathered
+
+    def reduce_hits(h):
+        if dist is None:
+            return h
+        t = torch.from_numpy(h.astype(np.int32)).to(dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.cpu().numpy().astype(np.uint8)
+
+    # ---- warm-up: also learns the template length statistics from the first batch (as tile 1 of the reference does) ---
+    tls = None
+    for b in range(args.warmup):
+        m, o, hits = al.find_matches(batches[b])
+        al.set_loaded_contigs(reduce_hits(hits))
+        if tls is None:
+            tls = al.determine_tls(batches[b], m, o)
+        al.select(batches[b], m, o, tls, out=(records[0], cigars))
+    if tls is None:
+        m, o, hits = al.find_matches(batches[0])
+        al.set_loaded_contigs(reduce_hits(hits))
+        tls = al.determine_tls(batches[0], m, o)
+    if dist is not None:   # rank 0's statistics are the run's statistics
+        t = torch.tensor(list(tls.astuple()), dtype=torch.int64, device=dev)
+        dist.broadcast(t, 0)
+        v = t.cpu().tolist()
+        tls.min, tls.max, tls.median, tls.low_std_dev, tls.high_std_dev = v[0:5]
+        tls.best_model[0], tls.best_model[1], tls.stable, tls.mate_min, tls.mate_max = v[5:10]
+    al.reset_timers()
+
+    # ---- timed region: exactly K steps ---------------------------------------------------------------------------------
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    found = []
+    all_hits = np.zeros(al.n_contigs, np.uint8)
+    for s in range(args.steps):                       # phase 1: FindMatchesTransition
+        m, o, hits = al.find_matches(batches[args.warmup + s])
+        found.append((m, o))
+        all_hits |= hits
+    al.set_loaded_contigs(reduce_hits(all_hits))      # MatchSelector loads only contigs that received matches
+    for s in range(args.steps):                       # phase 2: SelectMatchesTransition
+        m, o = found[s]
+        al.select(batches[args.warmup + s], m, o, tls, out=(records[s], cigars))
+    if dist is not None:                              # single gather of the per-GPU records at the end
+        mine = torch.cat(records)
+        gathered = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine, gathered, dst=0)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    counters = al.counters()
+    timers = {k: al.kernel_time_ms(k) for k in ("find_matches", "build_fragments", "select", "select_heavy")}
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    pairs_total = args.pairs_per_step * args.steps * world
+    reads_per_s = 2.0 * pairs_total / elapsed
+
+    # ---- roofline of the dominant kernel: algorithmic bytes (stated per kernel in DESIGN.md) / event-timed duration
+    pairs_rank = args.pairs_per_step * args.steps
+    log2n = max(1, math.ceil(math.log2(max(2, n_index))))
+    per_kernel_bytes = {
+        # BCL in + P * ceil(log2 n) * 16 B index probes + match records out
+        "find_matches": 2 * L * pairs_rank + counters["probes"] * log2n * 16 + counters["matches"] * 16,
+        # match records in + BCL + one (L + 15)-byte reference window per seeded scan / banded SW + candidate records out
+        "build_fragments": counters["matches"] * 16 + 2 * L * pairs_rank + 0,
+        # candidate records in + rescue windows + one reference window per rescue scan + 2 records out
+        "select": counters["candidates"] * 64 + counters["rescue_window_bases"] + 2 * pairs_rank * (64 + 4 * 3),
+    }
+    seeded_scans = max(0, counters["ungapped_scans"] - counters["rescue_candidates"])
+    per_kernel_bytes["build_fragments"] += (seeded_scans + counters["bsw_jobs"]) * (L + 15) + counters["candidates"] * 64
+    per_kernel_bytes["select"] += (counters["rescue_candidates"] + counters["rescue_bsw"]) * (L + 15)
+    total_ms = {k: v[0] * v[1] for k, v in timers.items()}
+    dominant = max(("find_matches", "build_fragments", "select"), key=lambda k: total_ms[k])
+    launches = max(1, timers[dominant][1])
+    avg_s = timers[dominant][0] / 1e3
+    achieved = per_kernel_bytes[dominant] / launches / avg_s / 1e9 if avg_s > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "k_" + dominant, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 6), "traffic": None,
+                "avg_launch_ms": round(timers[dominant][0], 4), "launches": int(launches),
+                "algorithmic_bytes_per_launch": int(per_kernel_bytes[dominant] / launches),
+                "kernel_ms_total": {k: round(v, 2) for k, v in total_ms.items()},
+                "bytes_per_pair": round(sum(per_kernel_bytes.values()) / pairs_rank, 1)}
+
+    # ---- CPU baseline: the oracle (a port of the reference path) on a bounded sample of the same workload, host cores -------
+    cpu = None
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        o = oracle_lib.load()
+        cores = os.cpu_count() or 1
+        sample = min(args.cpu_sample_pairs, args.pairs_per_step)
+        host_bcl = batches[args.warmup][:sample].cpu().numpy()
+        ref = o.reference([bytes(c.cpu().numpy()) for c in contigs])
+        ref.set_index(al.get_index())
+        p = o.default_params(2, L, L)
+        tc = time.perf_counter()
+        om, ohits = ref.find_matches(p, host_bcl, sample)
+        t_find = time.perf_counter() - tc
+        otls = oracle_lib.Tls()
+        for name in ("min", "max", "median", "low_std_dev", "high_std_dev", "stable", "mate_min", "mate_max"):
+            setattr(otls, name, getattr(tls, name))
+        otls.best_model[0], otls.best_model[1] = tls.best_model[0], tls.best_model[1]
+        tc = time.perf_counter()
+        ref.select(p, host_bcl, om, otls, ohits, n_threads=cores, n_clusters_hint=sample)
+        t_select = time.perf_counter() - tc
+        cpu = {"value": round(2.0 * sample / (t_find + t_select), 1), "unit": "reads/s", "cores": cores, "kind": "port",
+               "sample": "%d pairs of the same workload; oracle/ (CPU restatement of the reference path): merge-join seed lookup on 1 thread "
+                         "(%.2f s) + match selection on %d threads (%.2f s)" % (sample, t_find, cores, t_select)}
+
+    out = {"metric": "paired-end reads aligned/sec (2x%dbp)" % L, "value": round(reads_per_s, 1), "unit": "reads/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "u8/int16 (+f64 log-probabilities)", "data": "synthetic",
+           "config": {"workload": "chr21-sized synthetic reference (%d bp, 32-mer index %d entries), %d synthetic 2x%d bp pairs per GPU "
+                                  "(%d steps x %d pairs)" % (args.genome_bases, n_index, pairs_rank, L, args.steps, args.pairs_per_step),
+                      "pairs_per_step": args.pairs_per_step, "read_length": L, "genome_bases": args.genome_bases, "index_entries": int(n_index),
+                      "parallelism": "read shards x%d, records gathered once" % world, "setup_s": round(t_setup, 1), "index_build_s": round(t_index, 1),
+                      "tls": list(tls.astuple())},
+           "roofline": roofline, "cpu_baseline": cpu,
+           "counters": {k: int(v) for k, v in counters.items()}}
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -149,47 +149,58 @@ int isaac_gpu_get_index(isaac_gpu_ctx *ctx, isaac_reference_kmer *out_host, uint
 /* Replaces one tile's worth of alignWorkflow::FindMatchesTransition::findLaneMatches (both seed iterations;
  * lib/workflow/alignWorkflow/FindMatchesTransition.cpp:391-427): alignment::ClusterSeedGenerator::generateThread
  * (lib/alignment/ClusterSeedGenerator.cpp:138-192) + MatchFinder<KmerT>::findMatches (include/alignment/MatchFinder.hh:100-104).
- *   bcl_dev          n_clusters x (read_length[0] + read_length[1]) BCL bytes (base | quality << 2, 0 = N)
- *   matches_dev      optional: receives what io::TileMatchWriter::write(SeedId, ReferencePosition) would have been called
- *                    with (include/io/MatchWriter.hh:72), grouped by cluster (ascending), unordered inside a cluster (the
- *                    reference's file order is thread-interleaved; SelectMatchesTransition sorts later).  A cluster without
- *                    any match gets one NoMatch record.
+ *   bcl_dev              n_clusters x (read_length[0] + read_length[1]) BCL bytes (base | quality << 2, 0 = N)
+ *   matches_dev          receives what io::TileMatchWriter::write(SeedId, ReferencePosition) would have been called with
+ *                        (include/io/MatchWriter.hh:72; the <Temp>/..._matches.dat files of lib/io/MatchWriter.cpp:79-94),
+ *                        grouped by cluster; the order inside a cluster is unspecified, as in the reference's files
+ *                        (thread-interleaved appends; SelectMatchesTransition.cpp:242-254 sorts them later).
+ *   cluster_offsets_dev  n_clusters + 1 entries: cluster c owns matches_dev[offsets[c] .. offsets[c + 1]).  An empty range is
+ *                        a cluster for which the reference stores only NoMatch records.
  *   contig_has_matches_host  n_contigs bytes, OR-ed: the "MatchDistribution::isEmptyContig" fact (MatchDistribution.hh:96-101)
- * The per-cluster match lists also stay resident in the context for isaac_gpu_build_fragments / isaac_gpu_select. */
+ * The two buffers are the hand-over between the two halves of the path, exactly like the match files of the reference. */
 int isaac_gpu_find_matches(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t n_clusters, uint32_t tile,
-                           isaac_match *matches_dev, uint64_t capacity, uint64_t *n_matches_out, uint8_t *contig_has_matches_host);
+                           isaac_match *matches_dev, uint64_t capacity, uint64_t *cluster_offsets_dev, uint64_t *n_matches_out,
+                           uint8_t *contig_has_matches_host);
 
 /* Tells the extend stage which contigs the reference would have loaded (MatchSelector.cpp:85-90,138): the OR of
  * contig_has_matches over the whole run (all devices).  Lengths of the others count as 0 in the rest-of-genome
  * correction (include/alignment/RestOfGenomeCorrection.hh:44-55). NULL = all loaded. */
 int isaac_gpu_set_loaded_contigs(isaac_gpu_ctx *ctx, const uint8_t *contig_loaded_host, uint32_t n_contigs);
 
-/* Replaces alignment::FragmentBuilder::build for every cluster of the last isaac_gpu_find_matches call
- * (include/alignment/FragmentBuilder.hh:62-70; getFragments()/getCigarBuffer() :71-72): candidates in (cluster, read,
- * list order); with_gaps and trim select the two ways MatchSelector calls it (MatchSelector.cpp:233-245 vs :298-312).
- * Outputs are optional (NULL) device buffers. */
-int isaac_gpu_build_fragments(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t n_clusters, uint32_t tile, int with_gaps, int trim,
+/* Replaces alignment::FragmentBuilder::build for every cluster of the tile (include/alignment/FragmentBuilder.hh:62-70;
+ * getFragments()/getCigarBuffer() :71-72): candidates in (cluster, read, list order); with_gaps and trim select the two ways
+ * MatchSelector calls it (MatchSelector.cpp:233-245 vs :298-312).  candidates_dev / cigar_dev may be NULL. */
+int isaac_gpu_build_fragments(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t n_clusters, uint32_t tile,
+                              const isaac_match *matches_dev, const uint64_t *cluster_offsets_dev, int with_gaps, int trim,
                               isaac_candidate *candidates_dev, uint64_t capacity, uint64_t *n_candidates_out,
                               uint32_t *cigar_dev, uint64_t cigar_capacity, uint64_t *n_cigar_out);
 
-/* Replaces MatchSelector::determineTemplateLength (lib/alignment/MatchSelector.cpp:188-256) on the clusters of the last
- * isaac_gpu_find_matches call, in cluster order, until the statistics are stable. */
-int isaac_gpu_determine_tls(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t n_clusters, uint32_t tile, isaac_tls *tls_out);
+/* Replaces MatchSelector::determineTemplateLength (lib/alignment/MatchSelector.cpp:188-256): learns the template length
+ * statistics from the clusters of the tile, in cluster order, until they are stable. */
+int isaac_gpu_determine_tls(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t n_clusters, uint32_t tile,
+                            const isaac_match *matches_dev, const uint64_t *cluster_offsets_dev, isaac_tls *tls_out);
 
 /* Replaces MatchSelector::processMatchList for the tile (lib/alignment/MatchSelector.cpp:258-368): fragment building with
  * gaps, TemplateBuilder::buildTemplate (shadow rescue, alignment scores), the semialigned / overlapping end clippers, and
- * the io::FragmentHeader fields FragmentCollector would store.  One record per read, in cluster order. */
-int isaac_gpu_select(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t n_clusters, uint32_t tile, const isaac_tls *tls,
-                     isaac_fragment *fragments_dev /* n_clusters * n_reads */, uint32_t *cigar_dev, uint64_t cigar_capacity, uint64_t *n_cigar_out);
+ * the io::FragmentHeader fields FragmentCollector would store.  One record per read, in cluster order:
+ * fragments_dev[cluster * n_reads + read]; its CIGAR is cigar_dev[cigar_offset .. + cigar_length);
+ * cigar_dev must hold n_clusters * n_reads * ISAAC_GPU_MAX_CIGAR_OPS words.
+ * isaac_fragment::reserved: bit 2 = a fixed internal capacity was exceeded for this cluster (result not exact; counted in
+ * isaac_counters::overflow_clusters), bit 1 = the reference would not have stored the template (only without --keep-unaligned). */
+int isaac_gpu_select(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t n_clusters, uint32_t tile,
+                     const isaac_match *matches_dev, const uint64_t *cluster_offsets_dev, const isaac_tls *tls,
+                     isaac_fragment *fragments_dev, uint32_t *cigar_dev, uint64_t cigar_capacity);
 
 /* The leaf: alignment::BandedSmithWaterman::align (include/alignment/BandedSmithWaterman.hh:75-86) for a batch;
- * scores as the reference constructor takes them (GappedAligner.cpp:41-42: match, mismatch, -gapOpen, -gapExtend). */
+ * scores as the reference constructor takes them (GappedAligner.cpp:41-42: match, mismatch, -gapOpen, -gapExtend).
+ * results[i].n_ops == 0xffffffff flags a CIGAR longer than ISAAC_GPU_MAX_CIGAR_OPS. */
 int isaac_gpu_bsw_batch(isaac_gpu_ctx *ctx, int match, int mismatch, int gap_open, int gap_extend,
-                        const char *sequences_dev, const isaac_bsw_job *jobs_dev, uint32_t n_jobs, isaac_bsw_result *results_dev);
+                        const char *sequences_dev, const isaac_bsw_job *jobs_dev, uint32_t n_jobs, uint32_t max_query_length,
+                        isaac_bsw_result *results_dev);
 
 int isaac_gpu_get_counters(isaac_gpu_ctx *ctx, isaac_counters *out);
 /* average device time (ms) of the named kernel over the launches since the last reset, measured with HIP events on the
- * context's stream; names: "find_matches", "build_fragments", "bsw", "select" */
+ * context's stream; names: "find_matches", "build_fragments", "bsw", "select", "select_heavy" */
 int isaac_gpu_kernel_time_ms(isaac_gpu_ctx *ctx, const char *kernel, double *avg_ms, uint64_t *launches);
 int isaac_gpu_reset_timers(isaac_gpu_ctx *ctx);
 

@@ -12,11 +12,12 @@ enum { RECORD_TEMPLATE_OVERFLOW = 1,   // a template-stage work list overflowed:
        RECORD_NOT_STORED = 2,          // the reference would not have stored this template (only without --keep-unaligned)
        RECORD_FRAGMENT_OVERFLOW = 4 }; // a fragment-stage capacity was exceeded: the cluster's result is not exact
 
-// FragmentBuilder::build for cluster `cluster` of the tile; the cluster's matches are matches[cluster * stride .. + counts[cluster])
-ISAAC_HD void clusterBuildFragments(const DevParams &P, const DevReference &R, const u8 *bcl, u32 cluster, const Match *matches, const u32 *counts, u32 stride,
+// FragmentBuilder::build for cluster `cluster` of the tile; its matches are matches[offsets[cluster] .. offsets[cluster + 1])
+ISAAC_HD void clusterBuildFragments(const DevParams &P, const DevReference &R, const u8 *bcl, u32 cluster, const Match *matches, const u64 *offsets,
                                     bool withGaps, bool trim, FragmentWork &work, ClusterFragments &out, Counters &cnt)
 {
-    buildFragments(P, R, bcl + u64(cluster) * P.clusterLength, matches + u64(cluster) * stride, counts[cluster], withGaps, trim, work, out, cnt);
+    const u64 begin = offsets[cluster], end = offsets[cluster + 1];
+    buildFragments(P, R, bcl + u64(cluster) * P.clusterLength, matches + begin, u32(end - begin), withGaps, trim, work, out, cnt);
     if (out.flags & CLUSTER_OVERFLOW) ++cnt.overflowClusters;
 }
 

@@ -1,0 +1,870 @@
+// MI355X (gfx950) kernels and the C ABI of include/isaac_gpu.h.
+//
+// Kernels
+//   k_find_matches      8 lanes per cluster, one lane per seed probe: 2-bit k-mer extraction from LDS-staged BCL bytes,
+//                       binary search of the resident sorted 32-mer table, ExactMaskMatcher's match rules
+//   k_compact_matches   fixed-stride staging -> compact per-cluster ranges
+//   k_build_fragments   one thread per cluster: FragmentBuilder::build (aligner.h)
+//   k_bsw_batch         16 lanes per alignment: banded Smith-Waterman leaf (bsw_kernel.h)
+//   k_tls_samples       one thread per cluster: the facts TemplateLengthDistribution::addTemplate needs
+//   k_select            one thread per cluster: TemplateBuilder::buildTemplate + clippers + FragmentHeader records (template.h)
+//   index builder       k-mer enumeration + hipCUB radix sort + run analysis (+ 70-permutation neighbour annotation)
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+#include "cluster_ops.h"
+#include "host_util.h"
+#include "bsw_kernel.h"
+
+using namespace isaac;
+
+namespace
+{
+thread_local std::string g_error;
+
+struct HipError : std::runtime_error { hipError_t code; HipError(hipError_t c, const std::string &w) : std::runtime_error(w), code(c) {} };
+#define HIP_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw HipError(e_, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+template <typename T> struct DevBuf
+{
+    T *p = nullptr; size_t n = 0;
+    void reserve(size_t count) { if (count > n) { release(); HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T))); n = count; } }
+    void release() { if (p) { hipFree(p); p = nullptr; n = 0; } }
+    ~DevBuf() { release(); }
+};
+
+struct KernelTimer { double ms = 0; uint64_t launches = 0; };
+} // namespace
+
+struct isaac_gpu_ctx
+{
+    int device = 0; hipStream_t stream = nullptr;
+    isaac_params params; DevParams P;
+    // reference
+    DevBuf<char> basesOwned; const char *bases = nullptr;
+    DevBuf<u64> contigOffset; std::vector<u64> hContigOffset; DevBuf<u8> contigLoaded; std::vector<u8> hContigLoaded; u32 nContigs = 0;
+    DevBuf<u64> kmers, positions; u64 nKmers = 0; DevBuf<u32> karyotype; bool hasKaryotype = false;
+    DevBuf<double> logTables;
+    // work
+    DevBuf<Match> staging; DevBuf<u32> counts, chunkOffsets; DevBuf<u8> cubTemp; DevBuf<u32> contigHits;
+    DevBuf<ClusterFragments> frags; DevBuf<FragmentWork> fragWork;
+    DevBuf<u8> lightArena, heavyArena; DevBuf<u32> overflowList; DevBuf<u32> overflowCount;
+    DevBuf<TlsSample> tlsSamples;
+    DevBuf<Counters> counters;
+    std::map<std::string, KernelTimer> timers;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    u32 chunkClusters = 131072;
+
+    DevReference ref() const
+    {
+        DevReference r; std::memset(&r, 0, sizeof(r));
+        r.bases = bases; r.contigOffset = contigOffset.p; r.contigLoaded = contigLoaded.p; r.nContigs = nContigs;
+        r.kmers = kmers.p; r.positions = positions.p; r.nKmers = nKmers; r.karyotype = hasKaryotype ? karyotype.p : nullptr;
+        r.logMatch = logTables.p; r.logMismatch = logTables.p + 100;
+        return r;
+    }
+};
+
+namespace
+{
+// times one kernel launch sequence with HIP events on the context's stream
+struct ScopedTimer
+{
+    isaac_gpu_ctx *c; const char *name;
+    ScopedTimer(isaac_gpu_ctx *ctx, const char *n) : c(ctx), name(n) { hipEventRecord(c->ev0, c->stream); }
+    ~ScopedTimer()
+    {
+        hipEventRecord(c->ev1, c->stream); hipEventSynchronize(c->ev1);
+        float ms = 0; hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        KernelTimer &t = c->timers[name]; t.ms += ms; ++t.launches;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// wave-level reduction of the work counters, one atomic per field per wave
+__device__ inline void flushCounters(const Counters &local, Counters *global)
+{
+    const u64 *src = reinterpret_cast<const u64 *>(&local);
+    u64 *dst = reinterpret_cast<u64 *>(global);
+    for (u32 f = 0; f < sizeof(Counters) / sizeof(u64); ++f)
+    {
+        u64 v = src[f];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(reinterpret_cast<unsigned long long *>(dst + f), static_cast<unsigned long long>(v));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_find_matches: ClusterSeedGenerator::generateThread (ClusterSeedGenerator.cpp:138-192) + ExactMaskMatcher::matchMask
+// (ExactMaskMatcher.cpp:83-184) for both seed iterations of FindMatchesTransition::findLaneMatches (:391-427).
+// 8 lanes cooperate on one cluster; each lane owns one (seed, strand) probe per round.
+static const u32 FIND_GROUP = 8, FIND_BLOCK = 256, FIND_CLUSTERS_PER_BLOCK = FIND_BLOCK / FIND_GROUP;
+
+__device__ inline u64 lowerBound(const u64 *kmers, u64 n, u64 key, u32 &steps)
+{
+    u64 lo = 0, hi = n;
+    while (lo < hi)
+    {
+        const u64 mid = (lo + hi) >> 1;
+        if (kmers[mid] < key) lo = mid + 1; else hi = mid;
+        ++steps;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(FIND_BLOCK) void k_find_matches(DevParams P, DevReference R, const u8 *bcl, u32 nClusters, u32 clusterBase, u32 tile,
+                                                             Match *staging, u32 *counts, u32 stride, u32 *contigHits, Counters *counters)
+{
+    extern __shared__ __align__(16) u8 sbcl[];
+    const u32 CL = P.clusterLength;
+    const u32 firstCluster = blockIdx.x * FIND_CLUSTERS_PER_BLOCK;
+    {   // stage the block's clusters (contiguous bytes) through LDS with coalesced loads
+        const u64 base = u64(firstCluster) * CL;
+        const u32 nBytes = imin<u32>(FIND_CLUSTERS_PER_BLOCK, nClusters - firstCluster) * CL;
+        const u8 *src = bcl + base;
+        if (((reinterpret_cast<uintptr_t>(src)) & 15) == 0)
+        {
+            const u32 nVec = nBytes / 16;
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(src); uint4 *d4 = reinterpret_cast<uint4 *>(sbcl);
+            for (u32 i = threadIdx.x; i < nVec; i += FIND_BLOCK) d4[i] = s4[i];
+            for (u32 i = nVec * 16 + threadIdx.x; i < nBytes; i += FIND_BLOCK) sbcl[i] = src[i];
+        }
+        else for (u32 i = threadIdx.x; i < nBytes; i += FIND_BLOCK) sbcl[i] = src[i];
+    }
+    __syncthreads();
+    const u32 group = threadIdx.x / FIND_GROUP, lane = threadIdx.x % FIND_GROUP;
+    const u32 cluster = firstCluster + group;
+    const bool active = cluster < nClusters;
+    const u8 *cb = sbcl + group * CL;
+    Counters local; memset(&local, 0, sizeof(local));
+    u32 complete = 0;      // bit r: read r complete (TileClusterInfo.hh:65-209)
+    u32 written = 0;       // records of this cluster so far (uniform over the group)
+    Match *out = staging + u64(cluster) * stride;
+    for (u32 pass = 0; pass < 2; ++pass)
+    {
+        const u32 nProbes = 2 * P.nPass[pass];
+        u32 completeNext = complete;
+        for (u32 base = 0; base < nProbes; base += FIND_GROUP)
+        {
+            const u32 p = base + lane;
+            bool probe = active && p < nProbes;
+            u32 seedIdx = 0, strand = 0, readIdx = 0;
+            if (probe)
+            {
+                seedIdx = P.passSeeds[pass][p >> 1]; strand = p & 1; readIdx = P.seeds[seedIdx].readIndex;
+                if ((complete >> readIdx) & 1) probe = false;      // ClusterSeedGenerator.cpp:148
+            }
+            u32 nrec = 0; u64 first = 0; bool tooMany = false; bool completes = false;
+            if (probe)
+            {
+                // k-mer of the seed: forward MSB-first, reverse complement built from the other end (ClusterSeedGenerator.cpp:162-176)
+                const u8 *b = cb + P.readOffset[readIdx] + P.seeds[seedIdx].offset;
+                u64 kmer = 0; bool isN = false;
+                #pragma unroll 8
+                for (u32 i = 0; i < 32; ++i)
+                {
+                    const u32 v = b[i];
+                    isN |= !(v & 0xfc);
+                    if (strand) kmer = (kmer >> 2) | (u64((~v) & 3) << 62); else kmer = (kmer << 2) | (v & 3);
+                }
+                if (!isN)
+                {
+                    ++local.probes;
+                    u32 steps = 0;
+                    first = lowerBound(R.kmers, R.nKmers, kmer, steps);
+                    local.probeSteps += steps;
+                    // ExactMaskMatcher.cpp:118-126: reference entries with the same k-mer, at most repeatThreshold of them
+                    u32 r = 0;
+                    while (first + r < R.nKmers && r < P.repeatThreshold && R.kmers[first + r] == kmer) ++r;
+                    if (r)
+                    {
+                        const u64 pos0 = R.positions[first];
+                        if (r >= P.repeatThreshold || refposIsTooMany(pos0))
+                        {   // :135-154 generateTooManyMatches; the second iteration closes the read (MatchFinder.cpp:299)
+                            tooMany = true; nrec = 1;
+                            if (pass == 1) completes = true;
+                        }
+                        else
+                        {   // :157-170
+                            nrec = r;
+                            completes = P.ignoreNeighbors || !(pos0 & 1);
+                        }
+                    }
+                }
+            }
+            // exclusive prefix of nrec over the 8 lanes of the group
+            u32 incl = nrec;
+            for (u32 o = 1; o < FIND_GROUP; o <<= 1) { const u32 t = __shfl_up(incl, o, FIND_GROUP); if (lane >= o) incl += t; }
+            const u32 total = __shfl(incl, FIND_GROUP - 1, FIND_GROUP);
+            u32 at = written + incl - nrec;
+            if (nrec)
+            {
+                const u64 sid = seedId(tile, 0, clusterBase + cluster, seedIdx, strand);
+                if (tooMany) { if (at < stride) { out[at].seedId = sid; out[at].location = 0; } }
+                else for (u32 i = 0; i < nrec; ++i, ++at)
+                {
+                    u64 pos = R.positions[first + i];
+                    if (R.karyotype) { const u32 c = u32(pos >> 41); pos = (u64(R.karyotype[c - 1] + 1) << 41) | (pos & ((u64(1) << 41) - 1)); }
+                    if (at < stride) { out[at].seedId = sid; out[at].location = pos; }
+                    contigHits[refposContig(pos)] = 1;      // MatchDistribution::addMatches (:173-181): the contig is not empty
+                }
+                local.matches += nrec;
+            }
+            written += total;
+            u32 c = completes ? (1u << readIdx) : 0;
+            for (u32 o = 1; o < FIND_GROUP; o <<= 1) c |= __shfl_xor(c, o, FIND_GROUP);
+            completeNext |= c;
+        }
+        complete = completeNext;
+    }
+    if (active && lane == 0) { counts[cluster] = imin(written, stride); ++local.clusters; }
+    flushCounters(local, counters);
+}
+
+__global__ void k_compact_matches(const Match *staging, const u32 *counts, const u32 *chunkOffsets, u32 nClusters, u32 stride, u64 base,
+                                  Match *out, u64 capacity, u64 *offsetsOut)
+{
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nClusters) return;
+    const u64 at = base + chunkOffsets[c];
+    offsetsOut[c] = at;
+    const u32 n = counts[c];
+    const Match *src = staging + u64(c) * stride;
+    for (u32 i = 0; i < n; ++i) if (at + i < capacity) out[at + i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_build_fragments(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, u32 nChunk, const Match *matches, const u64 *offsets,
+                                                        int withGaps, int trim, FragmentWork *work, ClusterFragments *frags, Counters *counters)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    Counters local; memset(&local, 0, sizeof(local));
+    if (t < nChunk) clusterBuildFragments(P, R, bcl, clusterBase + t, matches, offsets, withGaps != 0, trim != 0, work[t], frags[t], local);
+    flushCounters(local, counters);
+}
+
+__global__ void k_tls_samples(const ClusterFragments *frags, const u64 *offsets, u32 clusterBase, u32 nChunk, TlsSample *samples)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nChunk) return;
+    clusterTlsSample(frags[t], u32(offsets[clusterBase + t + 1] - offsets[clusterBase + t]), samples[t]);
+}
+
+// candidates of the chunk -> compact ABI records; one thread per cluster, offsets from an exclusive scan of the counts
+__global__ void k_count_candidates(const ClusterFragments *frags, u32 nChunk, u32 *nCands, u32 *nCigar)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nChunk) return;
+    const ClusterFragments &f = frags[t];
+    u32 n = f.nCands[0] + f.nCands[1], c = 0;
+    for (u32 r = 0; r < 2; ++r) for (u32 i = 0; i < f.nCands[r]; ++i) c += f.cands[r][i].cigarLength;
+    nCands[t] = n; nCigar[t] = c;
+}
+__global__ void k_write_candidates(const ClusterFragments *frags, u32 clusterBase, u32 nChunk, const u32 *candOffsets, const u32 *cigarOffsets, u64 candBase, u64 cigarBase,
+                                   isaac_candidate *out, u64 capacity, u32 *cigarOut, u64 cigarCapacity)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nChunk) return;
+    const ClusterFragments &f = frags[t];
+    u64 at = candBase + candOffsets[t], cat = cigarBase + cigarOffsets[t];
+    for (u32 r = 0; r < 2; ++r) for (u32 i = 0; i < f.nCands[r]; ++i, ++at)
+    {
+        const Cand &k = f.cands[r][i];
+        if (at < capacity && cat + k.cigarLength <= cigarCapacity)
+        {
+            isaac_candidate o; memset(&o, 0, sizeof(o));
+            o.position = k.position; o.log_probability = k.logProbability; o.cluster = clusterBase + t; o.read_index = k.readIndex; o.contig_id = k.contigId;
+            o.observed_length = k.observedLength; o.reverse = k.reverse; o.mismatch_count = k.mismatchCount; o.matches_in_a_row = k.matchesInARow; o.gap_count = k.gapCount;
+            o.edit_distance = k.editDistance; o.smith_waterman_score = k.smithWatermanScore; o.unique_seed_count = k.uniqueSeedCount;
+            o.non_unique_first = k.nonUniqueFirst == NON_UNIQUE_NONE ? 0xffffffffu : k.nonUniqueFirst; o.non_unique_second = k.nonUniqueSecond;
+            o.repeat_seeds_count = k.repeatSeedsCount; o.cigar_offset = u32(cat); o.cigar_length = k.cigarLength; o.low_clipped = k.lowClipped; o.high_clipped = k.highClipped;
+            o.first_seed_index = k.firstSeedIndex;
+            out[at] = o;
+            for (u32 w = 0; w < k.cigarLength; ++w) cigarOut[cat + w] = f.cigarPool[k.cigarOffset + w];
+        }
+        cat += k.cigarLength;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_select: clusters [clusterBase, clusterBase + nChunk) with per-thread arenas of `arenaBytes`; clusters whose light work
+// lists overflow are appended to overflowList.  With `list` given, thread t redoes cluster list[t] (heavy capacities).
+__global__ __launch_bounds__(64) void k_select(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk, u32 tile,
+                                               const ClusterFragments *frags, u8 *arena, u64 arenaBytes, TemplateCaps caps, const u32 *list,
+                                               FragmentRecord *records, u32 *cigars, u32 *overflowList, u32 *overflowCount, u32 overflowCapacity, Counters *counters)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    Counters local; memset(&local, 0, sizeof(local));
+    if (t < nChunk)
+    {
+        const u32 inChunk = list ? list[t] : t;
+        TemplateWork work;
+        templateWorkBind(work, arena + u64(t) * arenaBytes, caps);
+        clusterSelect(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + inChunk, tile, frags[inChunk], work, records, cigars, local);
+        if (work.overflow)
+        {
+            if (!list) { const u32 at = atomicAdd(overflowCount, 1u); if (at < overflowCapacity) overflowList[at] = inChunk; }
+            else ++local.overflowClusters;   // even the reference's own capacities were exceeded
+        }
+        if (!list) ++local.clusters;
+    }
+    flushCounters(local, counters);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// index builder (ReferenceSorter.cpp:105-261, NeighborsFinder.cpp:193-446)
+__global__ void k_kmer_flags(const char *bases, const u64 *contigOffset, u32 nContigs, u64 totalBases, u32 *valid)
+{
+    // position p (global) ends a valid 32-mer iff the last 32 bases are ACGT and lie in one contig; computed naively per position
+    const u64 p = u64(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (p >= totalBases) return;
+    // contig of p by binary search
+    u32 lo = 0, hi = nContigs;
+    while (lo + 1 < hi) { const u32 mid = (lo + hi) >> 1; if (contigOffset[mid] <= p) lo = mid; else hi = mid; }
+    const u64 start = contigOffset[lo];
+    u32 ok = (p + 1 >= start + 32);
+    if (ok) for (u32 i = 0; i < 32; ++i) { const char c = bases[p - i]; if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T')) { ok = 0; break; } }
+    valid[p] = ok;
+}
+__global__ void k_kmer_emit(const char *bases, const u64 *contigOffset, u32 nContigs, u64 totalBases, const u32 *valid, const u32 *slot, u64 *keys, u64 *vals)
+{
+    const u64 p = u64(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (p >= totalBases || !valid[p]) return;
+    u32 lo = 0, hi = nContigs;
+    while (lo + 1 < hi) { const u32 mid = (lo + hi) >> 1; if (contigOffset[mid] <= p) lo = mid; else hi = mid; }
+    u64 fwd = 0, rc = 0;
+    for (u32 i = 0; i < 32; ++i)
+    {
+        const char c = bases[p - 31 + i];
+        const u64 v = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3;
+        fwd = (fwd << 2) | v; rc = (rc >> 2) | (((~v) & 3) << 62);
+    }
+    const u64 kmerPosition = p - 31 - contigOffset[lo];
+    const u64 s = u64(slot[p]) * 2;
+    keys[s] = fwd; vals[s] = refpos(lo, kmerPosition, false);      // forward strand entries are the ones that get stored
+    keys[s + 1] = rc; vals[s + 1] = refpos(lo, kmerPosition, true); // reverse-complement entries only take part in the repeat count
+}
+__global__ void k_run_heads(const u64 *keys, u64 n, u32 *head, u32 *isFwd, const u64 *vals)
+{
+    const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+    isFwd[i] = (vals[i] & 1) ? 0 : 1;
+}
+// runId = inclusive scan of head - 1; per run: start index, total count, forward count (atomics on small arrays are avoided:
+// the last element of a run writes the totals using the prefix sums)
+__global__ void k_run_totals(const u64 *keys, u64 n, const u32 *runIdIncl, const u32 *fwdExcl, const u32 *isFwd, u32 *runStart, u32 *runTotal, u32 *runFwd)
+{
+    const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 run = runIdIncl[i] - 1;
+    if (i == 0 || keys[i] != keys[i - 1]) runStart[run] = u32(i);
+    if (i + 1 == n || keys[i] != keys[i + 1])
+    {
+        // start may be written by another thread: recompute it from the run totals written later; use a second kernel for the totals
+        runTotal[run] = u32(i);          // temporarily the index of the last element
+        runFwd[run] = fwdExcl[i] + isFwd[i]; // temporarily the inclusive forward prefix at the end
+    }
+}
+__global__ void k_run_finish(u32 nRuns, const u32 *fwdExcl, const u32 *runStart, u32 *runTotal, u32 *runFwd)
+{
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nRuns) return;
+    const u32 start = runStart[r];
+    runTotal[r] = runTotal[r] - start + 1;
+    runFwd[r] = runFwd[r] - fwdExcl[start];
+}
+__global__ void k_emit_flags(const u64 *keys, u64 n, const u32 *runIdIncl, const u32 *isFwd, const u32 *runStart, const u32 *runTotal, const u32 *runFwd, u32 repeatThreshold, u32 *emit)
+{
+    const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 run = runIdIncl[i] - 1;
+    u32 e = 0;
+    if (runFwd[run])
+    {
+        if (repeatThreshold < runTotal[run]) e = (runStart[run] == i) ? 1 : 0;   // a single TooManyMatch entry (ReferenceSorter.cpp:201-222)
+        else e = isFwd[i];
+    }
+    emit[i] = e;
+}
+__global__ void k_emit_entries(const u64 *keys, const u64 *vals, u64 n, const u32 *runIdIncl, const u32 *runTotal, u32 repeatThreshold, const u32 *emit, const u32 *emitSlot,
+                               const u8 *runHasNeighbors, u64 *outKmers, u64 *outPositions)
+{
+    const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n || !emit[i]) return;
+    const u32 run = runIdIncl[i] - 1;
+    const u32 s = emitSlot[i];
+    outKmers[s] = keys[i];
+    if (repeatThreshold < runTotal[run]) outPositions[s] = 0;
+    else outPositions[s] = (vals[i] & ~u64(1)) | u64(runHasNeighbors ? runHasNeighbors[run] : 0);
+}
+// neighbour annotation: distinct k-mers (both strands) = run heads
+__global__ void k_distinct(const u64 *keys, u64 n, const u32 *head, const u32 *runIdIncl, u64 *distinct)
+{
+    const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n || !head[i]) return;
+    distinct[runIdIncl[i] - 1] = keys[i];
+}
+__global__ void k_mask_keys(const u64 *distinct, u32 n, u64 keep, u64 *keys, u32 *vals)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = distinct[i] & keep; vals[i] = i;
+}
+__device__ inline u32 hamming2bit(u64 a, u64 b) { u64 x = a ^ b; x = (x | (x >> 1)) & 0x5555555555555555ULL; return u32(__popcll(x)); }
+__global__ void k_mark_neighbors(const u64 *sortedKeys, const u32 *sortedVals, u32 n, const u64 *distinct, u8 *hasNeighbors)
+{
+    // NeighborsFinder::markNeighbors (:395-446): inside a block of k-mers sharing the 16 kept bases, every pair within
+    // Hamming distance 1..4 marks both members
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 key = sortedKeys[i]; const u64 mine = distinct[sortedVals[i]];
+    bool any = false;
+    for (u32 j = i + 1; j < n && sortedKeys[j] == key; ++j)
+    {
+        const u32 d = hamming2bit(mine, distinct[sortedVals[j]]);
+        if (d && d <= 4) { hasNeighbors[sortedVals[j]] = 1; any = true; }
+    }
+    if (any) hasNeighbors[sortedVals[i]] = 1;
+}
+
+u32 gridFor(u64 n, u32 block) { return u32((n + block - 1) / block); }
+
+template <typename T> void exclusiveSum(isaac_gpu_ctx *c, const T *in, T *out, size_t n)
+{
+    size_t bytes = 0;
+    HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, int(n), c->stream));
+    c->cubTemp.reserve(bytes + 16);
+    HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(c->cubTemp.p, bytes, in, out, int(n), c->stream));
+}
+template <typename T> void inclusiveSum(isaac_gpu_ctx *c, const T *in, T *out, size_t n)
+{
+    size_t bytes = 0;
+    HIP_CHECK(hipcub::DeviceScan::InclusiveSum(nullptr, bytes, in, out, int(n), c->stream));
+    c->cubTemp.reserve(bytes + 16);
+    HIP_CHECK(hipcub::DeviceScan::InclusiveSum(c->cubTemp.p, bytes, in, out, int(n), c->stream));
+}
+template <typename K, typename V> void sortPairs(isaac_gpu_ctx *c, const K *kin, K *kout, const V *vin, V *vout, size_t n)
+{
+    size_t bytes = 0;
+    HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kin, kout, vin, vout, int(n), 0, int(sizeof(K) * 8), c->stream));
+    c->cubTemp.reserve(bytes + 16);
+    HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->cubTemp.p, bytes, kin, kout, vin, vout, int(n), 0, int(sizeof(K) * 8), c->stream));
+}
+
+int fail(int code, const std::string &what) { g_error = what; return code; }
+#define ISAAC_TRY try {
+#define ISAAC_CATCH } catch (const HipError &e) { return fail(e.code == hipErrorOutOfMemory ? ISAAC_GPU_ENOMEM : ISAAC_GPU_EHIP, e.what()); } \
+                      catch (const std::invalid_argument &e) { return fail(ISAAC_GPU_EINVAL, e.what()); } \
+                      catch (const std::exception &e) { return fail(ISAAC_GPU_EHIP, e.what()); }
+} // namespace
+
+extern "C" {
+
+const char *isaac_gpu_last_error(void) { return g_error.c_str(); }
+
+int isaac_gpu_create(int device, const isaac_params *params, void *stream, isaac_gpu_ctx **out)
+{
+    ISAAC_TRY
+    if (!params || !out) return fail(ISAAC_GPU_EINVAL, "null argument");
+    int nDevices = 0;
+    HIP_CHECK(hipGetDeviceCount(&nDevices));
+    if (device < 0 || device >= nDevices) return fail(ISAAC_GPU_EINVAL, "no such HIP device (this library has no CPU path)");
+    HIP_CHECK(hipSetDevice(device));
+    std::unique_ptr<isaac_gpu_ctx> c(new isaac_gpu_ctx);
+    c->device = device; c->stream = static_cast<hipStream_t>(stream);
+    c->params = *params; c->P = makeDevParams(*params);
+    if (-params->gap_open < -params->gap_extend) return fail(ISAAC_GPU_EINVAL, "gap open penalty below gap extend penalty is not supported by the banded Smith-Waterman scan");
+    double tables[200]; makeQualityTables(tables, tables + 100);
+    c->logTables.reserve(200);
+    HIP_CHECK(hipMemcpy(c->logTables.p, tables, sizeof(tables), hipMemcpyHostToDevice));
+    c->counters.reserve(1);
+    HIP_CHECK(hipMemset(c->counters.p, 0, sizeof(Counters)));
+    c->overflowCount.reserve(1);
+    HIP_CHECK(hipEventCreate(&c->ev0)); HIP_CHECK(hipEventCreate(&c->ev1));
+    if (const char *e = getenv("ISAAC_GPU_CHUNK_CLUSTERS")) c->chunkClusters = u32(std::max(1024, atoi(e)));
+    *out = c.release();
+    return ISAAC_GPU_OK;
+    ISAAC_CATCH
+}
+
+void isaac_gpu_destroy(isaac_gpu_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    delete c;
+}
+
+int isaac_gpu_malloc(isaac_gpu_ctx *c, uint64_t bytes, void **dev) { ISAAC_TRY HIP_CHECK(hipSetDevice(c->device)); HIP_CHECK(hipMalloc(dev, bytes ? bytes : 16)); return 0; ISAAC_CATCH }
+int isaac_gpu_free(isaac_gpu_ctx *c, void *dev) { ISAAC_TRY HIP_CHECK(hipSetDevice(c->device)); HIP_CHECK(hipFree(dev)); return 0; ISAAC_CATCH }
+int isaac_gpu_upload(isaac_gpu_ctx *c, void *dev, const void *host, uint64_t bytes)
+{ ISAAC_TRY HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
+int isaac_gpu_download(isaac_gpu_ctx *c, void *host, const void *dev, uint64_t bytes)
+{ ISAAC_TRY HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
+int isaac_gpu_synchronize(isaac_gpu_ctx *c) { ISAAC_TRY HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
+
+static void setContigs(isaac_gpu_ctx *c, const uint64_t *offsets, uint32_t n)
+{
+    c->nContigs = n; c->hContigOffset.assign(offsets, offsets + n + 1);
+    c->contigOffset.reserve(n + 1);
+    HIP_CHECK(hipMemcpy(c->contigOffset.p, offsets, (n + 1) * sizeof(u64), hipMemcpyHostToDevice));
+    c->hContigLoaded.assign(n, 1); c->contigLoaded.reserve(n);
+    HIP_CHECK(hipMemcpy(c->contigLoaded.p, c->hContigLoaded.data(), n, hipMemcpyHostToDevice));
+    c->contigHits.reserve(n);
+}
+
+int isaac_gpu_load_contigs(isaac_gpu_ctx *c, const char *bases, const uint64_t *offsets, uint32_t n)
+{
+    ISAAC_TRY
+    if (!n || !bases || !offsets) return fail(ISAAC_GPU_EINVAL, "no contigs");
+    HIP_CHECK(hipSetDevice(c->device));
+    c->basesOwned.reserve(offsets[n] + 64);
+    HIP_CHECK(hipMemset(c->basesOwned.p, 'N', offsets[n] + 64));
+    HIP_CHECK(hipMemcpy(c->basesOwned.p, bases, offsets[n], hipMemcpyHostToDevice));
+    c->bases = c->basesOwned.p;
+    setContigs(c, offsets, n);
+    return 0;
+    ISAAC_CATCH
+}
+int isaac_gpu_load_contigs_dev(isaac_gpu_ctx *c, const char *bases_dev, const uint64_t *offsets, uint32_t n)
+{
+    ISAAC_TRY
+    if (!n || !bases_dev || !offsets) return fail(ISAAC_GPU_EINVAL, "no contigs");
+    HIP_CHECK(hipSetDevice(c->device));
+    c->bases = bases_dev;
+    setContigs(c, offsets, n);
+    return 0;
+    ISAAC_CATCH
+}
+
+int isaac_gpu_load_index(isaac_gpu_ctx *c, const isaac_reference_kmer *const *masks, const uint64_t *sizes, uint32_t nMasks, const uint32_t *karyotype, uint32_t nContigs)
+{
+    ISAAC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    u64 total = 0; for (u32 m = 0; m < nMasks; ++m) total += sizes[m];
+    std::vector<u64> k(total), p(total);
+    u64 at = 0;
+    for (u32 m = 0; m < nMasks; ++m) for (u64 i = 0; i < sizes[m]; ++i, ++at)
+    {
+        k[at] = masks[m][i].kmer; p[at] = masks[m][i].position;
+        if (at && k[at] < k[at - 1]) return fail(ISAAC_GPU_EINVAL, "mask files are not in global k-mer order");
+    }
+    c->kmers.reserve(total + 1); c->positions.reserve(total + 1); c->nKmers = total;
+    if (total) { HIP_CHECK(hipMemcpy(c->kmers.p, k.data(), total * 8, hipMemcpyHostToDevice)); HIP_CHECK(hipMemcpy(c->positions.p, p.data(), total * 8, hipMemcpyHostToDevice)); }
+    c->hasKaryotype = false;
+    if (karyotype)
+    {
+        bool identity = true; for (u32 i = 0; i < nContigs; ++i) identity &= karyotype[i] == i;
+        if (!identity) { c->karyotype.reserve(nContigs); HIP_CHECK(hipMemcpy(c->karyotype.p, karyotype, nContigs * 4, hipMemcpyHostToDevice)); c->hasKaryotype = true; }
+    }
+    return 0;
+    ISAAC_CATCH
+}
+
+int isaac_gpu_build_index(isaac_gpu_ctx *c, uint32_t repeatThreshold, int annotateNeighbors, uint64_t *nEntriesOut)
+{
+    ISAAC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    if (!c->bases) return fail(ISAAC_GPU_EINVAL, "load the contigs first");
+    const u64 totalBases = c->hContigOffset[c->nContigs];
+    if (totalBases >= (u64(1) << 30)) return fail(ISAAC_GPU_EINVAL, "the device index builder handles references below 2^30 bases (bigger ones: build per mask and isaac_gpu_load_index)");
+    hipStream_t st = c->stream;
+    DevBuf<u32> valid, slot; valid.reserve(totalBases + 1); slot.reserve(totalBases + 1);
+    k_kmer_flags<<<gridFor(totalBases, 256), 256, 0, st>>>(c->bases, c->contigOffset.p, c->nContigs, totalBases, valid.p);
+    exclusiveSum(c, valid.p, slot.p, totalBases);
+    u32 lastSlot = 0, lastValid = 0;
+    HIP_CHECK(hipMemcpyAsync(&lastSlot, slot.p + totalBases - 1, 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(&lastValid, valid.p + totalBases - 1, 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    const u64 n = 2 * u64(lastSlot + lastValid);
+    if (!n) { c->nKmers = 0; c->kmers.reserve(1); c->positions.reserve(1); if (nEntriesOut) *nEntriesOut = 0; return 0; }
+    DevBuf<u64> keys0, vals0, keys, vals; keys0.reserve(n); vals0.reserve(n); keys.reserve(n); vals.reserve(n);
+    k_kmer_emit<<<gridFor(totalBases, 256), 256, 0, st>>>(c->bases, c->contigOffset.p, c->nContigs, totalBases, valid.p, slot.p, keys0.p, vals0.p);
+    sortPairs(c, keys0.p, keys.p, vals0.p, vals.p, n);
+    keys0.release(); vals0.release(); valid.release(); slot.release();
+    DevBuf<u32> head, isFwd, runId, fwdExcl; head.reserve(n); isFwd.reserve(n); runId.reserve(n); fwdExcl.reserve(n);
+    k_run_heads<<<gridFor(n, 256), 256, 0, st>>>(keys.p, n, head.p, isFwd.p, vals.p);
+    inclusiveSum(c, head.p, runId.p, n);
+    exclusiveSum(c, isFwd.p, fwdExcl.p, n);
+    u32 nRuns = 0;
+    HIP_CHECK(hipMemcpyAsync(&nRuns, runId.p + n - 1, 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    DevBuf<u32> runStart, runTotal, runFwd; runStart.reserve(nRuns); runTotal.reserve(nRuns); runFwd.reserve(nRuns);
+    k_run_totals<<<gridFor(n, 256), 256, 0, st>>>(keys.p, n, runId.p, fwdExcl.p, isFwd.p, runStart.p, runTotal.p, runFwd.p);
+    k_run_finish<<<gridFor(nRuns, 256), 256, 0, st>>>(nRuns, fwdExcl.p, runStart.p, runTotal.p, runFwd.p);
+    DevBuf<u8> runNeighbors;
+    if (annotateNeighbors)
+    {
+        runNeighbors.reserve(nRuns);
+        HIP_CHECK(hipMemsetAsync(runNeighbors.p, 0, nRuns, st));
+        DevBuf<u64> distinct, mkeys, mkeysSorted; DevBuf<u32> mvals, mvalsSorted;
+        distinct.reserve(nRuns); mkeys.reserve(nRuns); mkeysSorted.reserve(nRuns); mvals.reserve(nRuns); mvalsSorted.reserve(nRuns);
+        k_distinct<<<gridFor(n, 256), 256, 0, st>>>(keys.p, n, head.p, runId.p, distinct.p);
+        for (u32 mask = 0; mask < 256; ++mask)
+        {   // any 4 of the 8 blocks of 4 bases are kept (oligo/Permutate.cpp:94-145: C(8,4) = 70 permutations)
+            if (__builtin_popcount(mask) != 4) continue;
+            u64 keep = 0; for (u32 b = 0; b < 8; ++b) if ((mask >> b) & 1) keep |= u64(0xff) << (8 * b);
+            k_mask_keys<<<gridFor(nRuns, 256), 256, 0, st>>>(distinct.p, nRuns, keep, mkeys.p, mvals.p);
+            sortPairs(c, mkeys.p, mkeysSorted.p, mvals.p, mvalsSorted.p, nRuns);
+            k_mark_neighbors<<<gridFor(nRuns, 256), 256, 0, st>>>(mkeysSorted.p, mvalsSorted.p, nRuns, distinct.p, runNeighbors.p);
+        }
+    }
+    DevBuf<u32> emit, emitSlot; emit.reserve(n); emitSlot.reserve(n);
+    k_emit_flags<<<gridFor(n, 256), 256, 0, st>>>(keys.p, n, runId.p, isFwd.p, runStart.p, runTotal.p, runFwd.p, repeatThreshold, emit.p);
+    exclusiveSum(c, emit.p, emitSlot.p, n);
+    u32 lastE = 0, lastS = 0;
+    HIP_CHECK(hipMemcpyAsync(&lastE, emit.p + n - 1, 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(&lastS, emitSlot.p + n - 1, 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    const u64 nOut = u64(lastE) + lastS;
+    c->kmers.reserve(nOut + 1); c->positions.reserve(nOut + 1); c->nKmers = nOut;
+    k_emit_entries<<<gridFor(n, 256), 256, 0, st>>>(keys.p, vals.p, n, runId.p, runTotal.p, repeatThreshold, emit.p, emitSlot.p,
+                                                      annotateNeighbors ? runNeighbors.p : nullptr, c->kmers.p, c->positions.p);
+    HIP_CHECK(hipStreamSynchronize(st));
+    c->hasKaryotype = false;
+    if (nEntriesOut) *nEntriesOut = nOut;
+    return 0;
+    ISAAC_CATCH
+}
+
+int isaac_gpu_get_index(isaac_gpu_ctx *c, isaac_reference_kmer *out, uint64_t capacity, uint64_t *nOut)
+{
+    ISAAC_TRY
+    if (nOut) *nOut = c->nKmers;
+    if (!out) return 0;
+    if (capacity < c->nKmers) return fail(ISAAC_GPU_ECAPACITY, "index buffer too small");
+    std::vector<u64> k(c->nKmers), p(c->nKmers);
+    if (c->nKmers) { HIP_CHECK(hipMemcpy(k.data(), c->kmers.p, c->nKmers * 8, hipMemcpyDeviceToHost)); HIP_CHECK(hipMemcpy(p.data(), c->positions.p, c->nKmers * 8, hipMemcpyDeviceToHost)); }
+    for (u64 i = 0; i < c->nKmers; ++i) { out[i].kmer = k[i]; out[i].position = p[i]; }
+    return 0;
+    ISAAC_CATCH
+}
+
+int isaac_gpu_find_matches(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, uint32_t tile, isaac_match *matchesOut, uint64_t capacity,
+                           uint64_t *clusterOffsets, uint64_t *nMatchesOut, uint8_t *contigHasMatches)
+{
+    ISAAC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    if (!c->kmers.p || !c->bases) return fail(ISAAC_GPU_EINVAL, "load the contigs and the index first");
+    if (!matchesOut || !clusterOffsets) return fail(ISAAC_GPU_EINVAL, "matches_dev and cluster_offsets_dev are required");
+    if (nClusters > 0x7fffffffu || tile > 0xfff) return fail(ISAAC_GPU_EINVAL, "SeedId overflow (SeedId.hh:95-109)");
+    hipStream_t st = c->stream;
+    const DevParams &P = c->P;
+    const u32 stride = 2 * P.nSeeds * std::max(1u, P.repeatThreshold - 1);
+    const u32 chunk = c->chunkClusters;
+    c->staging.reserve(size_t(chunk) * stride); c->counts.reserve(chunk); c->chunkOffsets.reserve(chunk);
+    HIP_CHECK(hipMemsetAsync(c->contigHits.p, 0, c->nContigs * 4, st));
+    const DevReference R = c->ref();
+    u64 base = 0;
+    for (u32 done = 0; done < nClusters; done += chunk)
+    {
+        const u32 n = std::min(chunk, nClusters - done);
+        {
+            ScopedTimer t(c, "find_matches");
+            const size_t lds = size_t(FIND_CLUSTERS_PER_BLOCK) * P.clusterLength + 16;
+            k_find_matches<<<gridFor(n, FIND_CLUSTERS_PER_BLOCK), FIND_BLOCK, lds, st>>>(P, R, bcl + u64(done) * P.clusterLength, n, done, tile,
+                                                                                          c->staging.p, c->counts.p, stride, c->contigHits.p, c->counters.p);
+            HIP_CHECK(hipGetLastError());
+        }
+        exclusiveSum(c, c->counts.p, c->chunkOffsets.p, n);
+        k_compact_matches<<<gridFor(n, 256), 256, 0, st>>>(c->staging.p, c->counts.p, c->chunkOffsets.p, n, stride, base,
+                                                            reinterpret_cast<Match *>(matchesOut), capacity, clusterOffsets + done);
+        u32 lastOff = 0, lastCount = 0;
+        HIP_CHECK(hipMemcpyAsync(&lastOff, c->chunkOffsets.p + n - 1, 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(&lastCount, c->counts.p + n - 1, 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        base += u64(lastOff) + lastCount;
+    }
+    HIP_CHECK(hipMemcpyAsync(clusterOffsets + nClusters, &base, 8, hipMemcpyHostToDevice, st));
+    if (contigHasMatches)
+    {
+        std::vector<u32> hits(c->nContigs);
+        HIP_CHECK(hipMemcpyAsync(hits.data(), c->contigHits.p, c->nContigs * 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        for (u32 i = 0; i < c->nContigs; ++i) contigHasMatches[i] |= u8(hits[i] != 0);
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (nMatchesOut) *nMatchesOut = base;
+    if (base > capacity) return fail(ISAAC_GPU_ECAPACITY, "matches_dev is too small");
+    return 0;
+    ISAAC_CATCH
+}
+
+int isaac_gpu_set_loaded_contigs(isaac_gpu_ctx *c, const uint8_t *loaded, uint32_t n)
+{
+    ISAAC_TRY
+    if (n != c->nContigs) return fail(ISAAC_GPU_EINVAL, "contig count mismatch");
+    if (loaded) c->hContigLoaded.assign(loaded, loaded + n); else c->hContigLoaded.assign(n, 1);
+    HIP_CHECK(hipMemcpy(c->contigLoaded.p, c->hContigLoaded.data(), n, hipMemcpyHostToDevice));
+    return 0;
+    ISAAC_CATCH
+}
+
+static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clusterBase, u32 n, const isaac_match *matches, const uint64_t *offsets, int withGaps, int trim)
+{
+    c->frags.reserve(c->chunkClusters); c->fragWork.reserve(c->chunkClusters);
+    ScopedTimer t(c, "build_fragments");
+    k_build_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, reinterpret_cast<const Match *>(matches), offsets,
+                                                             withGaps, trim, c->fragWork.p, c->frags.p, c->counters.p);
+    HIP_CHECK(hipGetLastError());
+}
+
+int isaac_gpu_build_fragments(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, uint32_t tile, const isaac_match *matches, const uint64_t *offsets,
+                              int withGaps, int trim, isaac_candidate *candidates, uint64_t capacity, uint64_t *nCandidatesOut,
+                              uint32_t *cigar, uint64_t cigarCapacity, uint64_t *nCigarOut)
+{
+    ISAAC_TRY
+    (void)tile;
+    HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const u32 chunk = c->chunkClusters;
+    DevBuf<u32> nc, ng, oc, og; nc.reserve(chunk); ng.reserve(chunk); oc.reserve(chunk); og.reserve(chunk);
+    u64 candBase = 0, cigarBase = 0;
+    for (u32 done = 0; done < nClusters; done += chunk)
+    {
+        const u32 n = std::min(chunk, nClusters - done);
+        launchBuildFragments(c, bcl, done, n, matches, offsets, withGaps, trim);
+        if (!candidates) continue;
+        k_count_candidates<<<gridFor(n, 256), 256, 0, st>>>(c->frags.p, n, nc.p, ng.p);
+        exclusiveSum(c, nc.p, oc.p, n); exclusiveSum(c, ng.p, og.p, n);
+        k_write_candidates<<<gridFor(n, 256), 256, 0, st>>>(c->frags.p, done, n, oc.p, og.p, candBase, cigarBase, candidates, capacity, cigar, cigarCapacity);
+        u32 a[4];
+        HIP_CHECK(hipMemcpyAsync(a + 0, oc.p + n - 1, 4, hipMemcpyDeviceToHost, st)); HIP_CHECK(hipMemcpyAsync(a + 1, nc.p + n - 1, 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(a + 2, og.p + n - 1, 4, hipMemcpyDeviceToHost, st)); HIP_CHECK(hipMemcpyAsync(a + 3, ng.p + n - 1, 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        candBase += u64(a[0]) + a[1]; cigarBase += u64(a[2]) + a[3];
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (nCandidatesOut) *nCandidatesOut = candBase;
+    if (nCigarOut) *nCigarOut = cigarBase;
+    if (candidates && (candBase > capacity || cigarBase > cigarCapacity)) return fail(ISAAC_GPU_ECAPACITY, "candidate buffers are too small");
+    return 0;
+    ISAAC_CATCH
+}
+
+int isaac_gpu_determine_tls(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, uint32_t tile, const isaac_match *matches, const uint64_t *offsets, isaac_tls *out)
+{
+    ISAAC_TRY
+    (void)tile;
+    HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    TlsLearner learner(c->P.mateDriftRange);
+    if (2 == c->P.nReads)
+    {
+        const u32 chunk = std::min<u32>(c->chunkClusters, 65536);
+        c->tlsSamples.reserve(chunk);
+        std::vector<TlsSample> h(chunk);
+        for (u32 done = 0; done < nClusters && !learner.stats.stable; done += chunk)
+        {
+            const u32 n = std::min(chunk, nClusters - done);
+            launchBuildFragments(c, bcl, done, n, matches, offsets, 0, 0);     // MatchSelector.cpp:233-245: no gaps, no quality trimming
+            k_tls_samples<<<gridFor(n, 256), 256, 0, st>>>(c->frags.p, offsets, done, n, c->tlsSamples.p);
+            HIP_CHECK(hipMemcpyAsync(h.data(), c->tlsSamples.p, size_t(n) * sizeof(TlsSample), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            for (u32 i = 0; i < n && !learner.stats.stable; ++i) learner.add(h[i]);
+        }
+        if (!learner.stats.stable) learner.finalize();
+    }
+    std::memcpy(out, &learner.stats, sizeof(*out));
+    return 0;
+    ISAAC_CATCH
+}
+
+int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, uint32_t tile, const isaac_match *matches, const uint64_t *offsets, const isaac_tls *tls,
+                     isaac_fragment *fragments, uint32_t *cigar, uint64_t cigarCapacity)
+{
+    ISAAC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    if (cigarCapacity < u64(nClusters) * c->P.nReads * OUT_CIGAR_CAP) return fail(ISAAC_GPU_ECAPACITY, "cigar_dev needs n_clusters * n_reads * ISAAC_GPU_MAX_CIGAR_OPS words");
+    hipStream_t st = c->stream;
+    DevTls t; std::memcpy(&t, tls, sizeof(t));
+    const RogCorrection rog = makeRogCorrection(c->P, c->hContigOffset.data(), c->hContigLoaded.data(), c->nContigs);
+    const double lmq40 = logMismatchQ40();
+    const TemplateCaps light = lightCaps(), heavy = heavyCaps();
+    const u64 lightBytes = templateWorkBytes(light), heavyBytes = templateWorkBytes(heavy);
+    const u32 chunk = c->chunkClusters;
+    const u32 heavyThreads = 1024;
+    c->lightArena.reserve(size_t(chunk) * lightBytes);
+    c->overflowList.reserve(chunk);
+    const DevReference R = c->ref();
+    for (u32 done = 0; done < nClusters; done += chunk)
+    {
+        const u32 n = std::min(chunk, nClusters - done);
+        launchBuildFragments(c, bcl, done, n, matches, offsets, 1, 1);
+        HIP_CHECK(hipMemsetAsync(c->overflowCount.p, 0, 4, st));
+        {
+            ScopedTimer tm(c, "select");
+            k_select<<<gridFor(n, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, n, tile, c->frags.p, c->lightArena.p, lightBytes, light, nullptr,
+                                                     reinterpret_cast<FragmentRecord *>(fragments), cigar, c->overflowList.p, c->overflowCount.p, chunk, c->counters.p);
+            HIP_CHECK(hipGetLastError());
+        }
+        u32 nOverflow = 0;
+        HIP_CHECK(hipMemcpyAsync(&nOverflow, c->overflowCount.p, 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        nOverflow = std::min(nOverflow, chunk);
+        for (u32 od = 0; od < nOverflow; od += heavyThreads)
+        {   // the few clusters whose work lists did not fit: again, with the reference's own capacities
+            const u32 m = std::min(heavyThreads, nOverflow - od);
+            c->heavyArena.reserve(size_t(heavyThreads) * heavyBytes);
+            ScopedTimer tm(c, "select_heavy");
+            k_select<<<gridFor(m, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, m, tile, c->frags.p, c->heavyArena.p, heavyBytes, heavy, c->overflowList.p + od,
+                                                     reinterpret_cast<FragmentRecord *>(fragments), cigar, nullptr, nullptr, 0, c->counters.p);
+            HIP_CHECK(hipGetLastError());
+        }
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+    ISAAC_CATCH
+}
+
+int isaac_gpu_bsw_batch(isaac_gpu_ctx *c, int match, int mismatch, int gapOpen, int gapExtend, const char *sequences, const isaac_bsw_job *jobs, uint32_t nJobs,
+                        uint32_t maxQueryLength, isaac_bsw_result *results)
+{
+    ISAAC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    if (!nJobs) return 0;
+    if (!maxQueryLength || maxQueryLength > 512) return fail(ISAAC_GPU_EINVAL, "query lengths 1..512 are supported");
+    const int maxScore = std::max(std::max(std::abs(match), std::abs(mismatch)), std::max(std::abs(gapOpen), std::abs(gapExtend)));
+    if (int(maxQueryLength) * maxScore >= std::abs(-32768 + gapOpen)) return fail(ISAAC_GPU_EINVAL, "BandedSmithWaterman: unsupported read length for these scores");
+    const size_t lds = size_t(16) * bswGroupLdsBytes(maxQueryLength);
+    ScopedTimer t(c, "bsw");
+    k_bsw_batch<<<gridFor(nJobs, 16), 256, lds, c->stream>>>(match, mismatch, gapOpen, gapExtend, sequences, jobs, nJobs, maxQueryLength, results);
+    HIP_CHECK(hipGetLastError());
+    return 0;
+    ISAAC_CATCH
+}
+
+int isaac_gpu_get_counters(isaac_gpu_ctx *c, isaac_counters *out)
+{
+    ISAAC_TRY
+    static_assert(sizeof(isaac_counters) == sizeof(Counters), "counter layouts");
+    HIP_CHECK(hipMemcpy(out, c->counters.p, sizeof(Counters), hipMemcpyDeviceToHost));
+    return 0;
+    ISAAC_CATCH
+}
+
+int isaac_gpu_kernel_time_ms(isaac_gpu_ctx *c, const char *kernel, double *avgMs, uint64_t *launches)
+{
+    const auto it = c->timers.find(kernel);
+    if (it == c->timers.end() || !it->second.launches) { if (avgMs) *avgMs = 0; if (launches) *launches = 0; return 0; }
+    if (avgMs) *avgMs = it->second.ms / double(it->second.launches);
+    if (launches) *launches = it->second.launches;
+    return 0;
+}
+int isaac_gpu_reset_timers(isaac_gpu_ctx *c)
+{
+    ISAAC_TRY
+    c->timers.clear();
+    HIP_CHECK(hipMemset(c->counters.p, 0, sizeof(Counters)));
+    return 0;
+    ISAAC_CATCH
+}
+
+} // extern "C"

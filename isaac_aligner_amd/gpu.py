@@ -1,0 +1,225 @@
+"""Host-side mirror of the reference's interface for the hot path, over the C ABI of include/isaac_gpu.h.
+
+`Aligner.find_matches` stands where alignWorkflow::FindMatchesTransition::perform drives MatchFinder
+(lib/workflow/alignWorkflow/FindMatchesTransition.cpp:538-604), `Aligner.select` where SelectMatchesTransition drives
+MatchSelector::parallelSelect (lib/alignment/MatchSelector.cpp:370-443).  torch is used for device memory and the stream.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi, build as _build
+
+_lib = None
+
+
+class IsaacGpuError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """dlopens libisaac_gpu.so; never falls back to anything else"""
+    global _lib
+    if _lib is None:
+        path = path or _build.LIB
+        if not os.path.exists(path):
+            raise IsaacGpuError("libisaac_gpu.so is missing: run `python -m isaac_aligner_amd.build` (hipcc --offload-arch=gfx950)")
+        lib = C.CDLL(path)
+        lib.isaac_gpu_last_error.restype = C.c_char_p
+        _lib = lib
+    return _lib
+
+
+EXPORTS = ["isaac_gpu_last_error", "isaac_gpu_create", "isaac_gpu_destroy", "isaac_gpu_malloc", "isaac_gpu_free", "isaac_gpu_upload", "isaac_gpu_download",
+           "isaac_gpu_synchronize", "isaac_gpu_load_contigs", "isaac_gpu_load_contigs_dev", "isaac_gpu_load_index", "isaac_gpu_build_index", "isaac_gpu_get_index",
+           "isaac_gpu_find_matches", "isaac_gpu_set_loaded_contigs", "isaac_gpu_build_fragments", "isaac_gpu_determine_tls", "isaac_gpu_select", "isaac_gpu_bsw_batch",
+           "isaac_gpu_get_counters", "isaac_gpu_kernel_time_ms", "isaac_gpu_reset_timers"]
+
+
+def _p(t):
+    """device (or host) pointer of a torch tensor / numpy array / None"""
+    if t is None:
+        return None
+    if isinstance(t, np.ndarray):
+        return t.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(t.data_ptr())
+
+
+class Aligner:
+    """one context on one device"""
+
+    def __init__(self, params, device=0, contigs=None, use_current_stream=True):
+        import torch
+        self.torch = torch
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise IsaacGpuError("no HIP device is visible: this package has no CPU path")
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.params = params
+        stream = torch.cuda.current_stream(self.device).cuda_stream if use_current_stream else 0
+        h = C.c_void_p()
+        self._check(self.lib.isaac_gpu_create(int(device), C.byref(params), C.c_void_p(stream), C.byref(h)))
+        self.h = h
+        self.n_reads = params.n_reads
+        self.cluster_length = params.read_length[0] + params.read_length[1]
+        self.n_contigs = 0
+        self._keep = []
+        if contigs is not None:
+            self.load_contigs(contigs)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.isaac_gpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise IsaacGpuError("isaac_gpu error %d: %s" % (rc, self.lib.isaac_gpu_last_error().decode()))
+
+    # ---- reference ------------------------------------------------------------------------------------------------
+    def load_contigs(self, contigs):
+        """contigs: list of bytes / uint8 tensors (ASCII ACGTN).  Device tensors are used in place."""
+        torch = self.torch
+        lengths = [len(c) if isinstance(c, (bytes, bytearray)) else c.numel() for c in contigs]
+        offsets = np.zeros(len(contigs) + 1, np.uint64)
+        offsets[1:] = np.cumsum(lengths)
+        parts = [torch.frombuffer(bytearray(c), dtype=torch.uint8) if isinstance(c, (bytes, bytearray)) else c for c in contigs]
+        bases = torch.cat([p.to(self.device) for p in parts] + [torch.full((64,), 78, dtype=torch.uint8, device=self.device)])
+        self._bases = bases
+        self.contig_offsets = offsets
+        self.n_contigs = len(contigs)
+        self._check(self.lib.isaac_gpu_load_contigs_dev(self.h, _p(bases), _p(offsets), C.c_uint32(self.n_contigs)))
+
+    def build_index(self, repeat_threshold=1000, annotate_neighbors=True):
+        n = C.c_uint64()
+        self._check(self.lib.isaac_gpu_build_index(self.h, C.c_uint32(repeat_threshold), int(annotate_neighbors), C.byref(n)))
+        return n.value
+
+    def load_index(self, masks):
+        """masks: list of REFERENCE_KMER_DTYPE arrays (the mask files in mask order)"""
+        masks = [np.ascontiguousarray(m, abi.REFERENCE_KMER_DTYPE) for m in masks]
+        ptrs = (C.c_void_p * len(masks))(*[m.ctypes.data for m in masks])
+        sizes = (C.c_uint64 * len(masks))(*[len(m) for m in masks])
+        self._check(self.lib.isaac_gpu_load_index(self.h, ptrs, sizes, C.c_uint32(len(masks)), None, C.c_uint32(self.n_contigs)))
+
+    def get_index(self):
+        n = C.c_uint64()
+        self._check(self.lib.isaac_gpu_get_index(self.h, None, C.c_uint64(0), C.byref(n)))
+        out = np.zeros(n.value, abi.REFERENCE_KMER_DTYPE)
+        self._check(self.lib.isaac_gpu_get_index(self.h, _p(out), C.c_uint64(n.value), C.byref(n)))
+        return out
+
+    def set_loaded_contigs(self, loaded):
+        loaded = np.ascontiguousarray(loaded, np.uint8) if loaded is not None else None
+        self._check(self.lib.isaac_gpu_set_loaded_contigs(self.h, _p(loaded), C.c_uint32(self.n_contigs)))
+
+    # ---- find -----------------------------------------------------------------------------------------------------
+    def find_matches(self, bcl, tile=0, capacity=None):
+        """bcl: uint8 device tensor [n_clusters, cluster_length].  Returns (matches tensor [n,2] int64, offsets tensor, contig_has_matches)"""
+        torch = self.torch
+        n_clusters = bcl.shape[0]
+        per = 2 * self.params.n_seeds * max(1, self.params.repeat_threshold - 1)
+        capacity = capacity or min(n_clusters * per, max(1024, n_clusters * 24))
+        while True:
+            matches = torch.empty((capacity, 2), dtype=torch.int64, device=self.device)
+            offsets = torch.empty(n_clusters + 1, dtype=torch.int64, device=self.device)
+            hits = np.zeros(self.n_contigs, np.uint8)
+            n = C.c_uint64()
+            rc = self.lib.isaac_gpu_find_matches(self.h, _p(bcl), C.c_uint32(n_clusters), C.c_uint32(tile), _p(matches), C.c_uint64(capacity), _p(offsets), C.byref(n), _p(hits))
+            if rc == 4 and capacity < n_clusters * per:   # ISAAC_GPU_ECAPACITY
+                capacity = min(n_clusters * per, max(n.value, capacity * 2))
+                continue
+            self._check(rc)
+            return matches[:n.value], offsets, hits
+
+    # ---- extend ---------------------------------------------------------------------------------------------------
+    def build_fragments(self, bcl, matches, offsets, tile=0, with_gaps=True, trim=True, want_output=True):
+        torch = self.torch
+        n_clusters = bcl.shape[0]
+        nc, ng = C.c_uint64(), C.c_uint64()
+        if not want_output:
+            self._check(self.lib.isaac_gpu_build_fragments(self.h, _p(bcl), C.c_uint32(n_clusters), C.c_uint32(tile), _p(matches), _p(offsets), int(with_gaps), int(trim),
+                                                           None, C.c_uint64(0), C.byref(nc), None, C.c_uint64(0), C.byref(ng)))
+            return None, None
+        cap = n_clusters * 8 + 1024
+        while True:
+            cands = torch.empty(cap * abi.CANDIDATE_DTYPE.itemsize, dtype=torch.uint8, device=self.device)
+            cig = torch.empty(cap * 6, dtype=torch.int32, device=self.device)
+            rc = self.lib.isaac_gpu_build_fragments(self.h, _p(bcl), C.c_uint32(n_clusters), C.c_uint32(tile), _p(matches), _p(offsets), int(with_gaps), int(trim),
+                                                    _p(cands), C.c_uint64(cap), C.byref(nc), _p(cig), C.c_uint64(cap * 6), C.byref(ng))
+            if rc == 4:
+                cap = max(cap * 2, nc.value + 16, (ng.value + 5) // 6 + 16)
+                continue
+            self._check(rc)
+            c = cands.cpu().numpy().view(abi.CANDIDATE_DTYPE)[:nc.value].copy()
+            g = cig.cpu().numpy().view(np.uint32)[:ng.value].copy()
+            return c, g
+
+    def determine_tls(self, bcl, matches, offsets, tile=0):
+        t = abi.Tls()
+        self._check(self.lib.isaac_gpu_determine_tls(self.h, _p(bcl), C.c_uint32(bcl.shape[0]), C.c_uint32(tile), _p(matches), _p(offsets), C.byref(t)))
+        return t
+
+    def select(self, bcl, matches, offsets, tls, tile=0, out=None):
+        """returns (records tensor uint8 [n_clusters*n_reads, 64], cigar tensor int32)"""
+        torch = self.torch
+        n_clusters = bcl.shape[0]
+        n_rec = n_clusters * self.n_reads
+        if out is None:
+            records = torch.empty((n_rec, abi.FRAGMENT_DTYPE.itemsize), dtype=torch.uint8, device=self.device)
+            cigars = torch.empty(n_rec * abi.MAX_CIGAR_OPS, dtype=torch.int32, device=self.device)
+        else:
+            records, cigars = out
+        self._check(self.lib.isaac_gpu_select(self.h, _p(bcl), C.c_uint32(n_clusters), C.c_uint32(tile), _p(matches), _p(offsets), C.byref(tls),
+                                              _p(records), _p(cigars), C.c_uint64(cigars.numel())))
+        return records, cigars
+
+    @staticmethod
+    def records_to_numpy(records, cigars):
+        return records.cpu().numpy().view(abi.FRAGMENT_DTYPE).reshape(-1).copy(), cigars.cpu().numpy().view(np.uint32).copy()
+
+    # ---- leaf -----------------------------------------------------------------------------------------------------
+    def bsw_batch(self, scores, queries, databases):
+        """scores = (match, mismatch, gapOpen > 0, gapExtend > 0) as BandedSmithWaterman's constructor takes them"""
+        torch = self.torch
+        blob = bytearray()
+        jobs = np.zeros(len(queries), abi.BSW_JOB_DTYPE)
+        for i, (q, d) in enumerate(zip(queries, databases)):
+            q = q.encode() if isinstance(q, str) else bytes(q)
+            d = d.encode() if isinstance(d, str) else bytes(d)
+            assert len(d) == len(q) + 15
+            jobs[i] = (len(blob), len(blob) + len(q), len(q), 0)
+            blob += q + d
+        seq = torch.frombuffer(blob + bytearray(32), dtype=torch.uint8).to(self.device)
+        jobs_d = torch.from_numpy(jobs.view(np.uint8)).to(self.device)
+        res = torch.zeros(len(queries) * abi.BSW_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=self.device)
+        max_len = int(jobs["query_length"].max()) if len(jobs) else 1
+        self._check(self.lib.isaac_gpu_bsw_batch(self.h, int(scores[0]), int(scores[1]), int(scores[2]), int(scores[3]), _p(seq), _p(jobs_d), C.c_uint32(len(queries)),
+                                                 C.c_uint32(max_len), _p(res)))
+        self.synchronize()
+        return res.cpu().numpy().view(abi.BSW_RESULT_DTYPE)
+
+    # ---- bookkeeping ----------------------------------------------------------------------------------------------
+    def synchronize(self):
+        self._check(self.lib.isaac_gpu_synchronize(self.h))
+
+    def counters(self):
+        c = abi.Counters()
+        self._check(self.lib.isaac_gpu_get_counters(self.h, C.byref(c)))
+        return c.asdict()
+
+    def kernel_time_ms(self, name):
+        ms, n = C.c_double(), C.c_uint64()
+        self._check(self.lib.isaac_gpu_kernel_time_ms(self.h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def reset_timers(self):
+        self._check(self.lib.isaac_gpu_reset_timers(self.h))

@@ -21,7 +21,7 @@ struct Emu
     std::vector<char> bases; std::vector<u64> offsets; std::vector<u8> loaded;
     std::vector<double> logMatch, logMismatch;
     std::vector<ClusterFragments> frags;
-    std::vector<Match> matches; std::vector<u32> counts; u32 stride;
+    std::vector<Match> matches; std::vector<u64> matchOffsets;
     Counters cnt;
 };
 }
@@ -43,25 +43,27 @@ Emu *emu_create(const isaac_params *p, const char *bases, const u64 *offsets, u3
         e->R.bases = e->bases.data(); e->R.contigOffset = e->offsets.data(); e->R.contigLoaded = e->loaded.data(); e->R.nContigs = nContigs;
         e->R.logMatch = e->logMatch.data(); e->R.logMismatch = e->logMismatch.data();
         std::memset(&e->cnt, 0, sizeof(e->cnt));
-        e->stride = 2 * e->P.nSeeds * std::max(1u, e->P.repeatThreshold - 1);
         return e;
     }
     catch (const std::exception &ex) { g_error = ex.what(); return 0; }
 }
 void emu_destroy(Emu *e) { delete e; }
 
-// matches: any order inside a cluster, clusters ascending (as isaac_gpu_find_matches delivers them)
+// matches: grouped by cluster (ascending), any order inside a cluster, as isaac_gpu_find_matches delivers them; NoMatch records are dropped
 int emu_set_matches(Emu *e, const isaac_match *m, u64 n, u32 nClusters)
 {
-    e->matches.assign(size_t(nClusters) * e->stride, Match()); e->counts.assign(nClusters, 0);
+    e->matches.clear(); e->matchOffsets.assign(size_t(nClusters) + 1, 0);
+    u32 last = 0;
     for (u64 i = 0; i < n; ++i)
     {
         const u32 c = seedIdCluster(m[i].seed_id);
-        if (c >= nClusters) { g_error = "cluster id out of range"; return 1; }
+        if (c >= nClusters || c < last) { g_error = "matches must be grouped by ascending cluster"; return 1; }
+        last = c;
         if (refposIsNoMatch(m[i].location)) continue;
-        if (e->counts[c] >= e->stride) { g_error = "match capacity"; return 1; }
-        Match &d = e->matches[size_t(c) * e->stride + e->counts[c]++]; d.seedId = m[i].seed_id; d.location = m[i].location;
+        Match d; d.seedId = m[i].seed_id; d.location = m[i].location; e->matches.push_back(d);
+        ++e->matchOffsets[c + 1];
     }
+    for (u32 c = 0; c < nClusters; ++c) e->matchOffsets[c + 1] += e->matchOffsets[c];
     return 0;
 }
 
@@ -74,7 +76,7 @@ int emu_build_fragments(Emu *e, const u8 *bcl, u32 nClusters, int withGaps, int 
     for (u32 c = 0; c < nClusters; ++c)
     {
         ClusterFragments &f = e->frags[c];
-        clusterBuildFragments(e->P, e->R, bcl, c, e->matches.data(), e->counts.data(), e->stride, withGaps != 0, trim != 0, work[0], f, e->cnt);
+        clusterBuildFragments(e->P, e->R, bcl, c, e->matches.data(), e->matchOffsets.data(), withGaps != 0, trim != 0, work[0], f, e->cnt);
         if (!out) continue;
         for (u32 r = 0; r < 2; ++r) for (u32 i = 0; i < f.nCands[r]; ++i)
         {
@@ -103,7 +105,7 @@ int emu_determine_tls(Emu *e, const u8 *bcl, u32 nClusters, isaac_tls *out)
     {
         for (u32 c = 0; c < nClusters && !learner.stats.stable; ++c)
         {
-            TlsSample s; clusterTlsSample(e->frags[c], e->counts[c], s);
+            TlsSample s; clusterTlsSample(e->frags[c], u32(e->matchOffsets[c + 1] - e->matchOffsets[c]), s);
             learner.add(s);
         }
         if (!learner.stats.stable) learner.finalize();

@@ -1,0 +1,213 @@
+"""Parity of the HIP path against the oracle, through the C ABI, on seeded inputs (run with -m gpu on an MI355X)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from isaac_aligner_amd import abi, options
+from parity_util import compare_candidates, compare_records, make_inputs, sort_matches
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    return torch
+
+
+def gpu_matches_numpy(matches):
+    m = matches.cpu().numpy().view(np.uint64).reshape(-1, 2)
+    return np.rec.fromarrays([m[:, 0], m[:, 1]], dtype=oracle_lib.MATCH_DTYPE)
+
+
+def canonical_index(idx):
+    return np.sort(idx, order=["kmer", "position"])
+
+
+def test_bsw_kernel_known_answers(torch):
+    from isaac_aligner_amd import gpu
+    g = json.load(open(os.path.join(GOLDEN, "bsw.json")))
+    al = gpu.Aligner(options.default_params(150, 150), 0)
+    res = al.bsw_batch(g["scores"], [c["query"] for c in g["cases"]], [c["database"] for c in g["cases"]])
+    bad = [(c["name"], abi.cigar_string(r["cigar"][:r["n_ops"]]), abi.cigar_string(c["cigar"])) for c, r in zip(g["cases"], res) if list(r["cigar"][:r["n_ops"]]) != c["cigar"]]
+    assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize("scores", [(0, -3, 11, 4), (2, -1, 15, 3)])
+def test_bsw_kernel_vs_oracle_random(torch, oracle, scores):
+    from isaac_aligner_amd import gpu
+    rng = np.random.default_rng(7)
+    queries, dbs = [], []
+    for i in range(6000):
+        L = int(rng.integers(35, 251))
+        db = rng.choice(list(b"ACGT"), L + 15).astype(np.uint8)
+        if rng.random() < 0.1:
+            db[rng.integers(0, L + 15, 3)] = ord("N")
+        off = int(rng.integers(0, 16))
+        src = np.concatenate([db, rng.choice(list(b"ACGT"), 40).astype(np.uint8)])
+        q = src[off:off + L].copy()
+        kind = rng.random()
+        if kind < 0.35:      # deletion from the read
+            p, n = int(rng.integers(5, L - 20)), int(rng.integers(1, 9))
+            q = np.concatenate([q[:p], src[off + p + n:off + L + n]])[:L]
+        elif kind < 0.7:     # insertion into the read
+            p, n = int(rng.integers(5, L - 20)), int(rng.integers(1, 9))
+            q = np.concatenate([q[:p], rng.choice(list(b"ACGT"), n).astype(np.uint8), q[p:]])[:L]
+        mut = rng.random(L) < 0.03
+        q[mut] = rng.choice(list(b"ACGT"), int(mut.sum()))
+        q[rng.random(L) < 0.005] = ord("n")
+        queries.append(bytes(q))
+        dbs.append(bytes(db))
+    al = gpu.Aligner(options.default_params(150, 150), 0)
+    res = al.bsw_batch(scores, queries, dbs)
+    gapped = 0
+    for q, d, r in zip(queries, dbs, res):
+        cig, off = oracle.bsw_align(scores, 300, q, d)
+        assert list(r["cigar"][:r["n_ops"]]) == list(cig) and r["offset"] == off, (q, d, abi.cigar_string(cig), abi.cigar_string(r["cigar"][:r["n_ops"]]))
+        gapped += len(cig) > 1
+    assert gapped > 1000
+
+
+@pytest.fixture(scope="module", params=[
+    dict(read_length=150, n_pairs=4000, seed=1, genome_bases=400000),
+    dict(read_length=100, n_pairs=3000, seed=5, genome_bases=300000),
+    dict(read_length=250, n_pairs=1500, seed=9, genome_bases=300000, indel_read_fraction=0.2, indel_max=10),
+])
+def case(request, torch, oracle):
+    """one synthetic data set pushed through both implementations up to the match lists"""
+    from isaac_aligner_amd import gpu
+    cfg = request.param
+    contigs, bcl, truth = make_inputs(**cfg)
+    L = cfg["read_length"]
+    p = options.default_params(L, L)
+    al = gpu.Aligner(p, 0, contigs)
+    al.build_index(annotate_neighbors=True)
+    ref = oracle.reference(contigs)
+    oidx = ref.build_index()
+    gidx = al.get_index()
+    dev_bcl = torch.from_numpy(bcl).to(al.device)
+    matches, offsets, hits = al.find_matches(dev_bcl)
+    om, ohits = ref.find_matches(p, bcl, len(bcl))
+    return dict(cfg=cfg, p=p, al=al, ref=ref, bcl=bcl, dev_bcl=dev_bcl, oidx=oidx, gidx=gidx, matches=matches, offsets=offsets, hits=hits, om=om, ohits=ohits, truth=truth)
+
+
+def test_index_builder(case):
+    a, b = canonical_index(case["oidx"]), canonical_index(case["gidx"].view(oracle_lib.INDEX_DTYPE))
+    assert len(a) == len(b)
+    assert (a["kmer"] == b["kmer"]).all()
+    assert (a["position"] == b["position"]).all()
+    assert (case["gidx"]["kmer"][1:] >= case["gidx"]["kmer"][:-1]).all()
+
+
+def test_find_matches(case):
+    gm = gpu_matches_numpy(case["matches"])
+    a, b = sort_matches(case["om"]), sort_matches(gm)
+    assert len(a) == len(b)
+    assert (a["seed_id"] == b["seed_id"]).all() and (a["location"] == b["location"]).all()
+    assert (case["hits"] == case["ohits"]).all()
+    off = case["offsets"].cpu().numpy()
+    cl = ((gm["seed_id"] >> np.uint64(9)) & np.uint64(0x7fffffff)).astype(np.int64)
+    assert (np.repeat(np.arange(len(off) - 1), np.diff(off)) == cl).all()     # grouped by cluster, offsets consistent
+
+
+@pytest.mark.parametrize("with_gaps,trim", [(True, True), (False, False)])
+def test_build_fragments(case, with_gaps, trim):
+    al, ref = case["al"], case["ref"]
+    al.set_loaded_contigs(case["hits"])
+    gc, gcig = al.build_fragments(case["dev_bcl"], case["matches"], case["offsets"], with_gaps=with_gaps, trim=trim)
+    oc, ocig = ref.build_fragments(case["p"], case["bcl"], case["om"], case["ohits"], with_gaps=with_gaps, trim=trim)
+    assert not compare_candidates(oc, ocig, gc, gcig)
+
+
+def test_tls_and_records(case):
+    al, ref = case["al"], case["ref"]
+    al.set_loaded_contigs(case["hits"])
+    al.reset_timers()
+    gtls = al.determine_tls(case["dev_bcl"], case["matches"], case["offsets"])
+    otls = ref.determine_tls(case["p"], case["bcl"], case["om"], case["ohits"])
+    assert gtls.astuple() == otls.astuple()
+    rec, cig = al.records_to_numpy(*al.select(case["dev_bcl"], case["matches"], case["offsets"], gtls))
+    orec, ocig, _ = ref.select(case["p"], case["bcl"], case["om"], otls, case["ohits"], n_clusters_hint=len(case["bcl"]))
+    assert not (rec["reserved"] & 5).any()
+    assert not compare_records(orec, ocig, rec, cig)
+    counters = al.counters()
+    assert counters["mapq_near_integer"] == 0
+    assert counters["clusters"] == len(case["bcl"])
+
+
+def test_single_ended_and_edge_inputs(torch, oracle):
+    """single-ended data, all-N reads, reads hanging over contig ends, an empty batch is rejected cleanly"""
+    from isaac_aligner_amd import gpu
+    contigs, bcl, _ = make_inputs(genome_bases=120000, n_pairs=600, read_length=100, seed=21, n_contigs=3)
+    bcl = bcl[:, :100].copy()
+    bcl[5] = 0                                   # all N
+    for i, c in enumerate(contigs[:2]):          # reads that start before / end after a contig
+        codes = np.frombuffer(c[:100], np.uint8)
+        code = np.zeros(100, np.uint8)
+        code[codes == ord("C")], code[codes == ord("G")], code[codes == ord("T")] = 1, 2, 3
+        bcl[10 + i, :] = np.concatenate([np.full(8, 3 | (30 << 2), np.uint8), (code | (35 << 2))[:92]])
+        tail = np.frombuffer(c[-95:], np.uint8)
+        code = np.zeros(95, np.uint8)
+        code[tail == ord("C")], code[tail == ord("G")], code[tail == ord("T")] = 1, 2, 3
+        bcl[20 + i, :] = np.concatenate([(code | (35 << 2)), np.full(5, 0 | (30 << 2), np.uint8)])
+    p = options.default_params(100)
+    al = gpu.Aligner(p, 0, contigs)
+    al.build_index()
+    ref = oracle.reference(contigs)
+    ref.set_index(al.get_index())
+    dev_bcl = torch.from_numpy(bcl).to(al.device)
+    matches, offsets, hits = al.find_matches(dev_bcl)
+    om, ohits = ref.find_matches(p, bcl, len(bcl))
+    assert (sort_matches(om) == sort_matches(gpu_matches_numpy(matches))).all()
+    al.set_loaded_contigs(hits)
+    gtls = al.determine_tls(dev_bcl, matches, offsets)
+    otls = ref.determine_tls(p, bcl, om, ohits)
+    assert gtls.astuple() == otls.astuple()
+    rec, cig = al.records_to_numpy(*al.select(dev_bcl, matches, offsets, gtls))
+    orec, ocig, _ = ref.select(p, bcl, om, otls, ohits, n_clusters_hint=len(bcl))
+    assert not compare_records(orec, ocig, rec, cig)
+
+
+def test_full_size_properties(torch):
+    """BASELINE-sized batch (no oracle): size-independent properties of the output"""
+    from isaac_aligner_amd import gpu, synth
+    contigs = synth.make_genome(4_000_000, seed=11, device="cuda", n_contigs=2)
+    bcl, truth = synth.make_read_pairs(contigs, 300_000, 150, seed=12, device="cuda")
+    p = options.default_params(150, 150)
+    al = gpu.Aligner(p, 0, contigs)
+    al.build_index(annotate_neighbors=False)
+    matches, offsets, hits = al.find_matches(bcl)
+    al.set_loaded_contigs(hits)
+    tls = al.determine_tls(bcl, matches, offsets)
+    assert tls.stable == 1 and 250 < tls.median < 450
+    rec_t, cig_t = al.select(bcl, matches, offsets, tls)
+    rec, cig = al.records_to_numpy(rec_t, cig_t)
+    # idempotence: the same call again gives the same bytes
+    rec2, cig2 = al.records_to_numpy(*al.select(bcl, matches, offsets, tls))
+    assert (rec.view(np.uint8) == rec2.view(np.uint8)).all()
+    # every aligned record's CIGAR consumes exactly the read
+    aligned = (rec["flags"] & 2) == 0
+    assert aligned.mean() > 0.97
+    ops = cig.reshape(len(rec), abi.MAX_CIGAR_OPS)
+    lens, codes = ops >> 4, ops & 0xF
+    valid = np.arange(abi.MAX_CIGAR_OPS)[None, :] < rec["cigar_length"][:, None]
+    consumed = (lens * np.isin(codes, [0, 1, 4]) * valid).sum(1)
+    assert (consumed[aligned] == 150).all()
+    ref_span = (lens * np.isin(codes, [0, 2]) * valid).sum(1)
+    assert (ref_span[aligned] == rec["observed_length"][aligned]).all()
+    # accuracy against the simulation truth for confidently placed first reads
+    r1 = rec[0::2]
+    ok = ((r1["flags"] & 2) == 0) & (r1["mapq"] >= 30) & ~truth["random"].cpu().numpy()
+    pos = abi.refpos_position(r1["f_strand_position"])
+    ctg = abi.refpos_contig(r1["f_strand_position"])
+    left = truth["r1_left"].cpu().numpy()
+    close = (np.abs(pos - left) <= 60) & (ctg == truth["contig"].cpu().numpy())
+    assert close[ok].mean() > 0.995
+    assert not (rec["reserved"] & 4).any()
+    assert al.counters()["mapq_near_integer"] == 0
