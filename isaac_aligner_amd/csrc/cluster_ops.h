@@ -70,7 +70,6 @@ ISAAC_HD void clusterSelect(const DevParams &P, const DevReference &R, const Dev
         if (frags.flags & CLUSTER_OVERFLOW) r.reserved |= RECORD_FRAGMENT_OVERFLOW;
         if (!store) r.reserved |= RECORD_NOT_STORED;
     }
-    ++cnt.clusters;
 }
 
 } // namespace isaac

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(FIND_BLOCK) void k_find_matches(DevParams P, DevRef
         }
         complete = completeNext;
     }
-    if (active && lane == 0) { counts[cluster] = imin(written, stride); ++local.clusters; }
+    if (active && lane == 0) counts[cluster] = imin(written, stride);
     flushCounters(local, counters);
 }
 

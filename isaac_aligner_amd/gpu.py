@@ -22,6 +22,7 @@ def load_library(path=None):
     """dlopens libisaac_gpu.so; never falls back to anything else"""
     global _lib
     if _lib is None:
+        import torch  # noqa: F401  -- first: the library must bind to the HIP runtime torch ships, not to a second copy
         path = path or _build.LIB
         if not os.path.exists(path):
             raise IsaacGpuError("libisaac_gpu.so is missing: run `python -m isaac_aligner_amd.build` (hipcc --offload-arch=gfx950)")

@@ -134,6 +134,7 @@ int emu_select(Emu *e, const u8 *bcl, u32 nClusters, u32 tile, const isaac_tls *
             if (tier && !(recs[u64(c) * e->P.nReads].reserved & RECORD_TEMPLATE_OVERFLOW)) continue;
             if (tier) ++e->cnt.overflowClusters;
             clusterSelect(e->P, e->R, t, rog, logMismatchQ40(), bcl, c, tile, e->frags[c], work, recs, cigars, e->cnt);
+            if (!tier) ++e->cnt.clusters;
         }
     }
     return 0;

@@ -14,8 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_exports_every_declared_symbol():
-    lib_path = build.build()
-    lib = C.CDLL(lib_path)
+    build.build()
+    lib = gpu.load_library()
     header = open(os.path.join(ROOT, "include", "isaac_gpu.h")).read()
     declared = set(re.findall(r"\b(isaac_gpu_\w+)\s*\(", header))
     declared.discard("isaac_gpu_ctx")
