@@ -12,6 +12,9 @@
 #if !defined(__HIPCC__)
 #include <cmath>
 #endif
+#ifdef ISAAC_DEBUG_MAPQ
+#include <cstdio>
+#endif
 
 namespace isaac
 {
@@ -196,7 +199,13 @@ ISAAC_HD u32 mapqFloor(TemplateCtx &x, double ratio)
     // only if v sits within that distance of an integer.  Such cases are counted (generously, 1e-11) so that a run can
     // prove it had none; v in [0, 1e-11) is safe because v cannot be negative.
     const double d = v - fl;
-    if (d > 1.0 - 1e-11 || (d < 1e-11 && fl >= 1.0)) ++x.cnt->mapqNearInteger;
+    if (d > 1.0 - 1e-11 || (d < 1e-11 && fl >= 1.0))
+    {
+        ++x.cnt->mapqNearInteger;
+#ifdef ISAAC_DEBUG_MAPQ
+        printf("mapq near integer: ratio=%.17g v=%.17g floor=%.17g cluster=%u\n", ratio, v, fl, x.clusterId);
+#endif
+    }
     return u32(fl);
 }
 
