@@ -107,7 +107,7 @@ typedef struct { uint32_t n_ops, offset; uint32_t cigar[ISAAC_GPU_MAX_CIGAR_OPS]
 typedef struct
 {
     uint64_t clusters, probes, probe_steps, matches, candidates, ungapped_scans, bsw_jobs, bsw_accepted, simple_indels,
-             rescue_calls, rescue_window_bases, rescue_candidates, rescue_bsw, overflow_clusters, mapq_near_integer;
+             rescue_calls, rescue_window_bases, rescue_candidates, rescue_bsw, overflow_clusters, mapq_near_integer, heavy_clusters;
 } isaac_counters;
 
 typedef struct isaac_gpu_ctx isaac_gpu_ctx;
@@ -200,7 +200,7 @@ int isaac_gpu_bsw_batch(isaac_gpu_ctx *ctx, int match, int mismatch, int gap_ope
 
 int isaac_gpu_get_counters(isaac_gpu_ctx *ctx, isaac_counters *out);
 /* average device time (ms) of the named kernel over the launches since the last reset, measured with HIP events on the
- * context's stream; names: "find_matches", "build_fragments", "bsw", "select", "select_heavy" */
+ * context's stream; names: "find_matches", "build_fragments", "plan_rescue", "rescue_windows", "rescue_align", "select", "select_heavy", "bsw" */
 int isaac_gpu_kernel_time_ms(isaac_gpu_ctx *ctx, const char *kernel, double *avg_ms, uint64_t *launches);
 int isaac_gpu_reset_timers(isaac_gpu_ctx *ctx);
 

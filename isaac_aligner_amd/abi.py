@@ -33,7 +33,7 @@ class Tls(C.Structure):
 class Counters(C.Structure):
     """isaac_counters"""
     _fields_ = [(n, C.c_uint64) for n in ("clusters", "probes", "probe_steps", "matches", "candidates", "ungapped_scans", "bsw_jobs", "bsw_accepted", "simple_indels",
-                                          "rescue_calls", "rescue_window_bases", "rescue_candidates", "rescue_bsw", "overflow_clusters", "mapq_near_integer")]
+                                          "rescue_calls", "rescue_window_bases", "rescue_candidates", "rescue_bsw", "overflow_clusters", "mapq_near_integer", "heavy_clusters")]
 
     def asdict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -552,6 +552,12 @@ ISAAC_HD void alignSimpleIndels(const DevParams &P, const DevReference &R, const
     }
 }
 
+// One gapped (banded Smith-Waterman) re-alignment problem: GappedAligner::alignGapped of a candidate.  Problems are collected
+// per chunk and executed 16 lanes per problem (k_gapped_jobs); results come back to the cluster's thread.
+struct GappedJob { Cand in; u32 cluster; u32 endCyclesMasked; u32 tag; u32 pad; };
+struct GappedResult { Cand out; u32 matchCount; u32 nCigar; u32 cigar[40]; };
+static_assert(sizeof(GappedJob) == 80 && sizeof(GappedResult) == 232, "gapped job layouts");
+
 // per-thread scratch of the fragment stage
 struct FragmentWork
 {
@@ -653,29 +659,96 @@ ISAAC_HD bool buildFragments(const DevParams &P, const DevReference &R, const u8
             cnt.simpleIndels += si;
             consolidateDuplicateFragments(l, true);
         }
-        for (u32 i = 0; i < l.n; ++i)
-        {
-            Cand &f = l.at(i);
-            if (withGaps && BSW_MISMATCHES_CUTOFF < f.mismatchCount)
-            {
-                Cand tmp = f;
-                ++cnt.bswJobs;
-                const u32 matchCount = alignGapped(P, R, reads[r], tmp, pool, work.tflags);
-                if (matchCount && matchCount + BSW_WIDEST_GAP_SIZE > candObservedLength(f) && (tmp.mismatchCount <= P.gappedMismatchesMax) &&
-                    (f.mismatchCount > tmp.mismatchCount) && lpLess(f.logProbability, tmp.logProbability))
-                { f = tmp; ++cnt.bswAccepted; }
-            }
-        }
-        consolidateDuplicateFragments(l, true);
+        // the candidates stay in list order; the gapped retries (FragmentBuilder.cpp:187-214) follow in finishFragments
         if (l.n > CAND_CAP) l.n = CAND_CAP;
         for (u32 i = 0; i < l.n; ++i) out.cands[r][i] = l.at(i);
         out.nCands[r] = l.n;
-        cnt.candidates += l.n;
     }
     out.cigarUsed = pool.used;
     if (pool.overflow) out.flags |= CLUSTER_OVERFLOW;
     out.built = built;
     return built;
 }
+
+// the candidates FragmentBuilder::alignFragments would hand to GappedAligner (FragmentBuilder.cpp:197): list order, read 0 first
+ISAAC_HD u32 countGappedJobs(const ClusterFragments &f, bool withGaps)
+{
+    u32 n = 0;
+    if (withGaps && f.built) for (u32 r = 0; r < 2; ++r) for (u32 i = 0; i < f.nCands[r]; ++i) n += BSW_MISMATCHES_CUTOFF < f.cands[r][i].mismatchCount;
+    return n;
+}
+ISAAC_HD void makeGappedJob(const ClusterFragments &f, u32 r, u32 i, u32 chunkCluster, GappedJob &j)
+{
+    j.in = f.cands[r][i]; j.cluster = chunkCluster; j.endCyclesMasked = f.endCyclesMasked[r]; j.tag = (r << 16) | i; j.pad = 0;
+    // FragmentMetadata::resetAlignment starts from the unclipped position; the job does not carry the old CIGAR
+    j.in.position = candUnclippedPosition(f.cands[r][i], f.cigarPool); j.in.cigarLength = 0; j.in.cigarOffset = 0;
+}
+ISAAC_HD void writeGappedJobs(const ClusterFragments &f, u32 chunkCluster, GappedJob *jobs)
+{
+    u32 n = 0;
+    for (u32 r = 0; r < 2; ++r) for (u32 i = 0; i < f.nCands[r]; ++i) if (BSW_MISMATCHES_CUTOFF < f.cands[r][i].mismatchCount)
+        makeGappedJob(f, r, i, chunkCluster, jobs[n++]);
+}
+
+// one gapped problem in the calling thread (serial form of k_gapped_jobs)
+ISAAC_HD void runGappedJobSerial(const DevParams &P, const DevReference &R, const u8 *clusterBcl, const GappedJob &job, u32 *tflags, GappedResult &res)
+{
+    ReadView read; const u32 r = job.in.readIndex;
+    read.bcl = clusterBcl + P.readOffset[r]; read.length = P.readLength[r]; read.firstCycle = P.firstCycle[r]; read.endCyclesMasked = job.endCyclesMasked;
+    res.out = job.in;
+    CigarPool pool; pool.words = res.cigar; pool.used = 0; pool.capacity = 40; pool.overflow = 0;
+    res.matchCount = alignGapped(P, R, read, res.out, pool, tflags);
+    res.nCigar = pool.overflow ? 0xffffffffu : pool.used;
+}
+
+// second half of FragmentBuilder::alignFragments (FragmentBuilder.cpp:187-216): accept rule for the gapped retries, then the
+// final consolidation.
+// `provider(r, i)` returns the GappedResult of candidate i of read r (called in countGappedJobs order) or NULL for "no gapped alignment"
+template <typename ProviderF>
+ISAAC_HD void finishFragments(const DevParams &P, ClusterFragments &out, ProviderF &provider, u8 *order, Counters &cnt)
+{
+    if (!out.built) return;
+    CigarPool pool; pool.words = out.cigarPool; pool.used = out.cigarUsed; pool.capacity = CIGAR_POOL; pool.overflow = 0;
+    for (u32 r = 0; r < P.nReads; ++r)
+    {
+        const u32 n = out.nCands[r];
+        for (u32 i = 0; i < n; ++i)
+        {
+            Cand &f = out.cands[r][i];
+            const GappedResult *pg = (BSW_MISMATCHES_CUTOFF < f.mismatchCount) ? provider(r, i) : 0;
+            if (pg)
+            {
+                const GappedResult &g = *pg;
+                ++cnt.bswJobs;
+                if (0xffffffffu == g.nCigar) { out.flags |= CLUSTER_OVERFLOW; continue; }
+                const Cand &tmp = g.out;
+                if (g.matchCount && g.matchCount + BSW_WIDEST_GAP_SIZE > candObservedLength(f) && (tmp.mismatchCount <= P.gappedMismatchesMax) &&
+                    (f.mismatchCount > tmp.mismatchCount) && lpLess(f.logProbability, tmp.logProbability))
+                {
+                    f = tmp;
+                    f.cigarOffset = pool.used;
+                    for (u32 w = 0; w < g.nCigar; ++w) pool.push(g.cigar[w]);
+                    ++cnt.bswAccepted;
+                }
+            }
+        }
+        CandList l; l.store = out.cands[r]; l.order = order; l.n = n; l.stored = n; l.capacity = CAND_CAP; l.overflow = 0;
+        for (u32 i = 0; i < n; ++i) order[i] = u8(i);
+        consolidateDuplicateFragments(l, true);
+        // apply the permutation in place (cycle following); order[i] = index of the element that belongs at i
+        for (u32 i = 0; i < l.n; ++i)
+        {
+            u32 src = order[i];
+            while (src < i) src = order[src];       // already moved: follow where it went
+            if (src != i) { const Cand t = out.cands[r][i]; out.cands[r][i] = out.cands[r][src]; out.cands[r][src] = t; }
+            order[i] = u8(src);
+        }
+        out.nCands[r] = l.n;
+        cnt.candidates += l.n;
+    }
+    out.cigarUsed = pool.used;
+    if (pool.overflow) out.flags |= CLUSTER_OVERFLOW;
+}
+
 
 } // namespace isaac

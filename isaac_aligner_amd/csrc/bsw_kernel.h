@@ -7,7 +7,7 @@
 // the chain computes for in-range scores); the traceback flags (one byte per lane per row) are staged in LDS and walked by
 // lane 0 of the group.  Integer DP: no MFMA.
 #pragma once
-#include "types.h"
+#include "aligner.h"
 #include "../../include/isaac_gpu.h"
 
 namespace isaac
@@ -20,20 +20,14 @@ __device__ inline int s16(int v) { return int(short(v)); }
 // LDS bytes per alignment group
 __host__ __device__ inline u32 bswGroupLdsBytes(u32 maxQueryLength) { return ((maxQueryLength * 16 + 15) & ~15u) + 128; }
 
-__global__ __launch_bounds__(256) void k_bsw_batch(int matchScore, int mismatchScore, int gapOpenScore, int gapExtendScore,
-                                                  const char *sequences, const isaac_bsw_job *jobs, u32 nJobs, u32 maxQueryLength,
-                                                  isaac_bsw_result *results)
+// The DP of one alignment on the 16 lanes of a group, then traceback and CIGAR on lane 0.  `cig[n..)` receives the operations
+// (reference order); the return value (lane 0 only) is BandedSmithWaterman::align's: the length of the stripped leading
+// deletion.  T: L*16 bytes of LDS, endVals: 48 shorts of LDS, both private to the group.  The 16 lanes are part of one
+// wave, so LDS traffic between them needs no workgroup barrier.
+template <typename QueryF>
+__device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapOpenScore, int gapExtendScore, QueryF query, u32 L, const char *database,
+                                     u8 *T, short *endVals, u32 k, u32 *cig, u32 cap, u32 &n, bool &overflow)
 {
-    extern __shared__ __align__(16) u8 lds[];
-    const u32 group = threadIdx.x >> 4, k = threadIdx.x & 15;
-    const u32 job = blockIdx.x * 16 + group;
-    if (job >= nJobs) return;
-    u8 *T = lds + group * bswGroupLdsBytes(maxQueryLength);
-    short *endVals = reinterpret_cast<short *>(T + ((maxQueryLength * 16 + 15) & ~15u));
-    const isaac_bsw_job jb = jobs[job];
-    const u32 L = jb.query_length;
-    const char *query = sequences + jb.query_offset;
-    const char *database = sequences + jb.database_offset;
     const int initialValue = s16(-32768 + gapOpenScore);
     const int open = gapOpenScore, ext = gapExtendScore;
     const int wMatch = matchScore & 0xff, wMismatch = s16(0xff00 | (mismatchScore & 0xff));
@@ -58,7 +52,7 @@ __global__ __launch_bounds__(256) void k_bsw_batch(int matchScore, int mismatchS
         if (k & 1) tg = fF ? 2 : fE;
         else tg = pfF ? 2 * fF : (pfE ? fE : max(2 * fF, fE));
         // W (:200-244): byte compare, so read 'n' never equals reference 'N'
-        const char q = query[i];
+        const char q = query(i);
         newG = s16(newG + ((q != d) ? wMismatch : wMatch));
         // E (:246-297) as an exclusive max-plus suffix scan over the lanes
         const int g = s16(newG - open), f = s16(newF - open);
@@ -82,41 +76,124 @@ __global__ __launch_bounds__(256) void k_bsw_batch(int matchScore, int mismatchS
         d = (k == 0) ? ((i + 1 < L) ? database[i + 16] : char(0)) : dn;
     }
     endVals[k] = short(G); endVals[16 + k] = short(E); endVals[32 + k] = short(F);
-    __syncthreads();   // flags and end values written by the 16 lanes become visible to lane 0 of the group
-    if (k != 0) return;
-    // end-cell scan (:349-379), traceback (:381-435), stripping of the terminal deletions (:437-453)
-    isaac_bsw_result &res = results[job];
-    int mx = s16(int(u16(endVals[15])) - 1);
-    int ii = int(L) - 1, jj = ii; u32 maxType = 0;
-    for (int lane = 15; lane >= 0; --lane)
-        for (u32 type = 0; type < 3; ++type)
-        {
-            const int value = endVals[16 * type + lane];
-            if (value > mx) { mx = value; jj = lane; maxType = type; }
-        }
-    u32 n = 0, opLength = 0;
-    u32 *cig = res.cigar;
-    bool overflow = false;
-#define ISAAC_BSW_PUSH(len, op) do { if (n < ISAAC_GPU_MAX_CIGAR_OPS) cig[n++] = cigarOp(u32(len), op); else overflow = true; } while (0)
-    if (jj > 0) ISAAC_BSW_PUSH(jj, OP_DELETE);
-    while (ii >= 0 && jj >= 0 && jj <= 15)
-    {
-        ++opLength;
-        const u32 nextMaxType = (T[ii * 16 + jj] >> (2 * maxType)) & 3;
-        if (nextMaxType != maxType) { ISAAC_BSW_PUSH(opLength, maxType == 0 ? OP_ALIGN : maxType == 1 ? OP_DELETE : OP_INSERT); opLength = 0; }
-        ii += (maxType == 1) ? 0 : -1;
-        jj += (maxType == 1) ? 1 : (maxType == 2) ? -1 : 0;
-        maxType = nextMaxType;
-    }
-    if (1 != maxType && opLength) { ISAAC_BSW_PUSH(opLength, maxType == 0 ? OP_ALIGN : OP_INSERT); opLength = 0; }
-    if (15 > jj) { ISAAC_BSW_PUSH(opLength + 15 - u32(jj), OP_DELETE); opLength = 0; }
-#undef ISAAC_BSW_PUSH
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     u32 ret = 0;
-    if (n && OP_DELETE == cigarCode(cig[n - 1])) { ret = cigarLen(cig[n - 1]); --n; }
-    for (u32 lo = 0, hi = n; lo + 1 < hi; ++lo) { --hi; const u32 tt = cig[lo]; cig[lo] = cig[hi]; cig[hi] = tt; }
-    if (n && OP_DELETE == cigarCode(cig[n - 1])) --n;
-    res.n_ops = overflow ? 0xffffffffu : n;
-    res.offset = ret;
+    if (k == 0)
+    {
+        // end-cell scan (:349-379), traceback (:381-435), stripping of the terminal deletions (:437-453)
+        const u32 first = n;
+        int mx = s16(int(u16(endVals[15])) - 1);
+        int ii = int(L) - 1, jj = ii; u32 maxType = 0;
+        for (int lane = 15; lane >= 0; --lane)
+            for (u32 type = 0; type < 3; ++type)
+            {
+                const int value = endVals[16 * type + lane];
+                if (value > mx) { mx = value; jj = lane; maxType = type; }
+            }
+        u32 opLength = 0;
+#define ISAAC_BSW_PUSH(len, op) do { if (n < cap) cig[n++] = cigarOp(u32(len), op); else overflow = true; } while (0)
+        if (jj > 0) ISAAC_BSW_PUSH(jj, OP_DELETE);
+        while (ii >= 0 && jj >= 0 && jj <= 15)
+        {
+            ++opLength;
+            const u32 nextMaxType = (T[ii * 16 + jj] >> (2 * maxType)) & 3;
+            if (nextMaxType != maxType) { ISAAC_BSW_PUSH(opLength, maxType == 0 ? OP_ALIGN : maxType == 1 ? OP_DELETE : OP_INSERT); opLength = 0; }
+            ii += (maxType == 1) ? 0 : -1;
+            jj += (maxType == 1) ? 1 : (maxType == 2) ? -1 : 0;
+            maxType = nextMaxType;
+        }
+        if (1 != maxType && opLength) { ISAAC_BSW_PUSH(opLength, maxType == 0 ? OP_ALIGN : OP_INSERT); opLength = 0; }
+        if (15 > jj) { ISAAC_BSW_PUSH(opLength + 15 - u32(jj), OP_DELETE); opLength = 0; }
+#undef ISAAC_BSW_PUSH
+        if (n > first && OP_DELETE == cigarCode(cig[n - 1])) { ret = cigarLen(cig[n - 1]); --n; }
+        for (u32 lo = first, hi = n; lo + 1 < hi; ++lo) { --hi; const u32 tt = cig[lo]; cig[lo] = cig[hi]; cig[hi] = tt; }
+        if (n > first && OP_DELETE == cigarCode(cig[n - 1])) --n;
+    }
+    // the group's LDS is reused by the next problem only after lane 0 is done with it
+    __builtin_amdgcn_wave_barrier();
+    return ret;
+}
+
+struct PlainQuery { const char *q; __device__ char operator()(u32 i) const { return q[i]; } };
+
+__global__ __launch_bounds__(256) void k_bsw_batch(int matchScore, int mismatchScore, int gapOpenScore, int gapExtendScore,
+                                                  const char *sequences, const isaac_bsw_job *jobs, u32 nJobs, u32 maxQueryLength,
+                                                  isaac_bsw_result *results)
+{
+    extern __shared__ __align__(16) u8 lds[];
+    const u32 group = threadIdx.x >> 4, k = threadIdx.x & 15;
+    const u32 job = blockIdx.x * 16 + group;
+    if (job >= nJobs) return;
+    u8 *T = lds + group * bswGroupLdsBytes(maxQueryLength);
+    short *endVals = reinterpret_cast<short *>(T + ((maxQueryLength * 16 + 15) & ~15u));
+    const isaac_bsw_job jb = jobs[job];
+    PlainQuery q; q.q = sequences + jb.query_offset;
+    isaac_bsw_result &res = results[job];
+    u32 n = 0; bool overflow = false;
+    const u32 ret = bswCooperative(matchScore, mismatchScore, gapOpenScore, gapExtendScore, q, jb.query_length, sequences + jb.database_offset, T, endVals, k,
+                                   res.cigar, ISAAC_GPU_MAX_CIGAR_OPS, n, overflow);
+    if (k == 0) { res.n_ops = overflow ? 0xffffffffu : n; res.offset = ret; }
+}
+
+struct StrandQueryDev { ReadView read; bool reverse; u32 offset; __device__ char operator()(u32 i) const { return strandBase(read, reverse, offset + i); } };
+
+// GappedAligner::alignGapped (GappedAligner.cpp:167-249) for a list of candidates, 16 lanes per candidate: the statements of
+// alignGapped() in aligner.h with the DP on the group and everything else on its lane 0.  `bcl` is the tile, the job's
+// cluster index is relative to clusterBase.  Grid-stride over the jobs, so the launch does not need the job count on the host.
+__global__ __launch_bounds__(256) void k_gapped_jobs(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap,
+                                                    u32 maxReadLength, GappedResult *results)
+{
+    extern __shared__ __align__(16) u8 lds[];
+    const u32 group = threadIdx.x >> 4, k = threadIdx.x & 15;
+    u8 *T = lds + group * bswGroupLdsBytes(maxReadLength);
+    short *endVals = reinterpret_cast<short *>(T + ((maxReadLength * 16 + 15) & ~15u));
+    const u32 nJobs = imin(*jobCounter, jobsCap);
+    for (u32 j = blockIdx.x * 16 + group; j < nJobs; j += gridDim.x * 16)
+    {
+        const GappedJob &jb = jobs[j];
+        GappedResult &res = results[j];
+        Cand f = jb.in;
+        const u32 r = f.readIndex;
+        ReadView read;
+        read.bcl = bcl + u64(clusterBase + jb.cluster) * P.clusterLength + P.readOffset[r]; read.length = P.readLength[r];
+        read.firstCycle = P.firstCycle[r]; read.endCyclesMasked = jb.endCyclesMasked;
+        CigarPool pool; pool.words = res.cigar; pool.used = 0; pool.capacity = 40; pool.overflow = 0;
+        candResetAlignment(f, pool);
+        f.lowClipped = 0; f.highClipped = 0;
+        const u64 referenceSize = contigLength(R, f.contigId);
+        i64 begin, end;
+        bool go = clipSequence(read, f, i64(referenceSize), begin, end);
+        u32 n = 0, matchCount = 0; bool overflow = false;
+        u32 sequenceLength = 0; i64 strandPosition = 0;
+        if (go)
+        {
+            if (begin) { if (k == 0) res.cigar[0] = cigarOp(u32(begin), OP_SOFT_CLIP); n = 1; }
+            sequenceLength = u32(end - begin);
+            strandPosition = f.position;
+            if (i64(referenceSize) < i64(sequenceLength) + strandPosition + i64(BSW_WIDEST_GAP_SIZE)) go = false;
+            if (!sequenceLength || sequenceLength > maxReadLength) go = false;
+        }
+        if (go)
+        {
+            u32 left, right;
+            getFlanks(strandPosition, sequenceLength, referenceSize, left, right);
+            const char *database = R.bases + R.contigOffset[f.contigId] + strandPosition - left;
+            StrandQueryDev q; q.read = read; q.reverse = f.reverse; q.offset = u32(begin);
+            const u32 ret = bswCooperative(P.gapMatch, P.gapMismatch, -P.gapOpen, -P.gapExtend, q, sequenceLength, database, T, endVals, k, res.cigar, 40u, n, overflow);
+            if (k == 0)
+            {
+                strandPosition += ret;
+                const u32 clipEndBases = u32(i64(read.length) - end);
+                if (clipEndBases) { if (n < 40) res.cigar[n++] = cigarOp(clipEndBases, OP_SOFT_CLIP); else overflow = true; }
+                strandPosition -= left;
+                pool.used = n;
+                matchCount = updateFragmentCigar(P, R, read, f, strandPosition, pool, 0);
+            }
+        }
+        if (k == 0) { res.out = f; res.matchCount = matchCount; res.nCigar = overflow ? 0xffffffffu : n; }
+    }
 }
 
 #endif // __HIPCC__

@@ -18,6 +18,33 @@ ISAAC_HD void clusterBuildFragments(const DevParams &P, const DevReference &R, c
 {
     const u64 begin = offsets[cluster], end = offsets[cluster + 1];
     buildFragments(P, R, bcl + u64(cluster) * P.clusterLength, matches + begin, u32(end - begin), withGaps, trim, work, out, cnt);
+}
+
+// second half: the gapped retries' results (in countGappedJobs order) are applied and the lists consolidated.  results == NULL
+// with withGaps: the retries run here, one after the other (capacity fallback of the flat pass and the plain serial form).
+struct FlatGappedProvider { const GappedResult *next; ISAAC_HD const GappedResult *operator()(u32, u32) { return next++; } };
+struct NoGappedProvider { ISAAC_HD const GappedResult *operator()(u32, u32) { return 0; } };
+struct SerialGappedProvider
+{
+    const DevParams *P; const DevReference *R; const u8 *clusterBcl; const ClusterFragments *frags; u32 *tflags; GappedResult result;
+    ISAAC_HD const GappedResult *operator()(u32 r, u32 i)
+    {
+        GappedJob job;
+        makeGappedJob(*frags, r, i, 0, job);
+        runGappedJobSerial(*P, *R, clusterBcl, job, tflags, result);
+        return &result;
+    }
+};
+ISAAC_HD void clusterFinishFragments(const DevParams &P, const DevReference &R, const u8 *bcl, u32 cluster, bool withGaps, const GappedResult *results,
+                                     FragmentWork &work, ClusterFragments &out, Counters &cnt)
+{
+    if (!withGaps) { NoGappedProvider p; finishFragments(P, out, p, work.order, cnt); }
+    else if (results) { FlatGappedProvider p; p.next = results; finishFragments(P, out, p, work.order, cnt); }
+    else
+    {
+        SerialGappedProvider p; p.P = &P; p.R = &R; p.clusterBcl = bcl + u64(cluster) * P.clusterLength; p.frags = &out; p.tflags = work.tflags;
+        finishFragments(P, out, p, work.order, cnt);
+    }
     if (out.flags & CLUSTER_OVERFLOW) ++cnt.overflowClusters;
 }
 
@@ -38,20 +65,69 @@ ISAAC_HD void clusterTlsSample(const ClusterFragments &f, u32 nMatches, TlsSampl
     }
 }
 
-// MatchSelector::processMatchList for one cluster: template building, clipping, io::FragmentHeader records.
-// records: P.nReads per cluster; cigars: P.nReads * OUT_CIGAR_CAP words per cluster
-ISAAC_HD void clusterSelect(const DevParams &P, const DevReference &R, const DevTls &tls, const RogCorrection &rog, double logMismatchQ40,
-                            const u8 *bcl, u32 cluster, u32 tile, const ClusterFragments &frags, TemplateWork &work,
-                            FragmentRecord *records, u32 *cigars, Counters &cnt)
+ISAAC_HD void templateCtxInit(TemplateCtx &x, const DevParams &P, const DevReference &R, const DevTls &tls, const RogCorrection &rog, const u8 *bcl, u32 cluster,
+                               const ClusterFragments &frags, TemplateWork &work, Counters &cnt)
 {
-    TemplateCtx x;
     x.P = &P; x.R = &R; x.tls = &tls; x.frags = &frags; x.w = &work; x.cnt = &cnt; x.clusterId = cluster;
     x.rogRead[0] = rog.read[0]; x.rogRead[1] = rog.read[1]; x.rog = rog.pair;
+    x.rescueMode = RESCUE_SERIAL; x.jobNext = 0; x.jobCount = 0; x.jobs = 0; x.planWrite = false; x.serialFallbackAllowed = true;
+    x.candPositions = 0; x.shadowCands = 0; x.shadowCigars = 0; x.gappedResults = 0;
     const u8 *clusterBcl = bcl + u64(cluster) * P.clusterLength;
     for (u32 r = 0; r < 2; ++r)
     {
         x.reads[r].bcl = clusterBcl + P.readOffset[r]; x.reads[r].length = r < P.nReads ? P.readLength[r] : 0;
         x.reads[r].firstCycle = P.firstCycle[r]; x.reads[r].endCyclesMasked = frags.endCyclesMasked[r];
+    }
+}
+
+// The mate-rescue problems of one cluster, in the order TemplateBuilder would call ShadowAligner::rescueShadow.  The order
+// and the windows depend only on the seeded candidates, never on rescue results, so the template logic is simply run with a
+// stub rescue.  jobs == NULL: count only.  `cluster` is the index in the tile, `chunkCluster` the index inside the chunk.
+ISAAC_HD u32 clusterPlanRescue(const DevParams &P, const DevReference &R, const DevTls &tls, const RogCorrection &rog, double logMismatchQ40,
+                               const u8 *bcl, u32 cluster, u32 chunkCluster, const ClusterFragments &frags, TemplateWork &work, RescueJob *jobs)
+{
+    if (!frags.built) return 0;
+    Counters scratch;
+    TemplateCtx x;
+    templateCtxInit(x, P, R, tls, rog, bcl, cluster, frags, work, scratch);
+    x.rescueMode = RESCUE_PLAN; x.jobs = jobs; x.planWrite = jobs != 0;
+    BamTemplate t;
+    work.overflow = 0;
+    buildTemplate(x, t, logMismatchQ40);
+    if (jobs) for (u32 i = 0; i < x.jobNext; ++i) jobs[i].cluster = chunkCluster;
+    return x.jobNext;
+}
+
+// ungapped alignment of one rescue candidate position (the body of the loop at ShadowAligner.cpp:206-231)
+ISAAC_HD void rescueAlignCandidate(const DevParams &P, const DevReference &R, const u8 *bcl, u32 cluster, const ClusterFragments &frags, const RescueJob &job, i32 relativePosition,
+                                   Cand &out, u32 *cigar3)
+{
+    ReadView shadowRead;
+    const u32 r = job.shadowReadIndex;
+    shadowRead.bcl = bcl + u64(cluster) * P.clusterLength + P.readOffset[r]; shadowRead.length = P.readLength[r];
+    shadowRead.firstCycle = P.firstCycle[r]; shadowRead.endCyclesMasked = frags.endCyclesMasked[r];
+    CigarPool pool; pool.words = cigar3; pool.used = 0; pool.capacity = 3; pool.overflow = 0;
+    candInit(out, r);
+    out.reverse = job.shadowReverse; out.contigId = job.contigId; out.position = i64(relativePosition) + job.windowBegin;
+    alignUngapped(P, R, shadowRead, out, pool);
+}
+
+// What the flat kernels hand to clusterSelect: the cluster's jobs and the aligned candidates of the chunk
+struct RescueInputs { RescueJob *jobs; u32 jobCount; const Cand *shadowCands; const u32 *shadowCigars; const GappedResult *gappedResults; bool serialFallbackAllowed; };
+
+// MatchSelector::processMatchList for one cluster: template building, clipping, io::FragmentHeader records.
+// records: P.nReads per cluster; cigars: P.nReads * OUT_CIGAR_CAP words per cluster
+ISAAC_HD void clusterSelect(const DevParams &P, const DevReference &R, const DevTls &tls, const RogCorrection &rog, double logMismatchQ40,
+                            const u8 *bcl, u32 cluster, u32 tile, const ClusterFragments &frags, TemplateWork &work,
+                            FragmentRecord *records, u32 *cigars, Counters &cnt, const RescueInputs *rescue = 0)
+{
+    TemplateCtx x;
+    templateCtxInit(x, P, R, tls, rog, bcl, cluster, frags, work, cnt);
+    if (rescue)
+    {
+        x.rescueMode = RESCUE_LOOKUP; x.jobs = rescue->jobs; x.jobCount = rescue->jobCount; x.shadowCands = rescue->shadowCands; x.shadowCigars = rescue->shadowCigars;
+        x.gappedResults = rescue->gappedResults;
+        x.serialFallbackAllowed = rescue->serialFallbackAllowed;
     }
     BamTemplate t;
     const bool store = selectCluster(x, t, logMismatchQ40);

@@ -53,8 +53,11 @@ struct isaac_gpu_ctx
     // work
     DevBuf<Match> staging; DevBuf<u32> counts, chunkOffsets; DevBuf<u8> cubTemp; DevBuf<u32> contigHits;
     DevBuf<ClusterFragments> frags; DevBuf<FragmentWork> fragWork;
+    DevBuf<GappedJob> gappedJobs; DevBuf<GappedResult> gappedResults; DevBuf<u32> gappedBase, gappedCounters;
     DevBuf<u8> lightArena, heavyArena; DevBuf<u32> overflowList; DevBuf<u32> overflowCount;
     DevBuf<TlsSample> tlsSamples;
+    DevBuf<RescueJob> jobs; DevBuf<u32> rescueCounters, bitmaps, candJob, shadowCigars, jobBase, jobCount; DevBuf<i32> candPositions; DevBuf<Cand> shadowCands;
+    bool flatRescue = true;
     DevBuf<Counters> counters;
     std::map<std::string, KernelTimer> timers;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -239,12 +242,40 @@ __global__ void k_compact_matches(const Match *staging, const u32 *counts, const
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// the chunk's gapped (banded Smith-Waterman) problems: written by the per-cluster threads, run by k_gapped_jobs
+struct GappedBuffers { GappedJob *jobs; GappedResult *results; u32 cap; u32 *counter; u32 *base; };
+
 __global__ __launch_bounds__(64) void k_build_fragments(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, u32 nChunk, const Match *matches, const u64 *offsets,
-                                                        int withGaps, int trim, FragmentWork *work, ClusterFragments *frags, Counters *counters)
+                                                        int withGaps, int trim, FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     Counters local; memset(&local, 0, sizeof(local));
-    if (t < nChunk) clusterBuildFragments(P, R, bcl, clusterBase + t, matches, offsets, withGaps != 0, trim != 0, work[t], frags[t], local);
+    if (t < nChunk)
+    {
+        clusterBuildFragments(P, R, bcl, clusterBase + t, matches, offsets, withGaps != 0, trim != 0, work[t], frags[t], local);
+        u32 base = 0;
+        const u32 n = countGappedJobs(frags[t], withGaps != 0);
+        if (n)
+        {
+            base = atomicAdd(gb.counter, n);
+            if (base + n > gb.cap) base = 0xffffffffu;   // k_finish_fragments runs this cluster's retries itself
+            else writeGappedJobs(frags[t], t, gb.jobs + base);
+        }
+        gb.base[t] = base;
+    }
+    flushCounters(local, counters);
+}
+
+__global__ __launch_bounds__(64) void k_finish_fragments(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, u32 nChunk, int withGaps,
+                                                         FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    Counters local; memset(&local, 0, sizeof(local));
+    if (t < nChunk)
+    {
+        const GappedResult *res = (withGaps && gb.base[t] != 0xffffffffu) ? gb.results + gb.base[t] : nullptr;
+        clusterFinishFragments(P, R, bcl, clusterBase + t, withGaps != 0, res, work[t], frags[t], local);
+    }
     flushCounters(local, counters);
 }
 
@@ -292,10 +323,211 @@ __global__ void k_write_candidates(const ClusterFragments *frags, u32 clusterBas
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Template stage.  Mate rescue (ShadowAligner::rescueShadow) is the bulk of the work of the select phase: a 7-mer scan of
+// a window of several hundred reference bases plus one 150-base ungapped alignment per candidate start, for ~1.5 orphans
+// per cluster.  It is planned per cluster, then executed flat:
+//   k_plan_rescue     one thread per cluster: the rescue problems TemplateBuilder would pose (result independent)
+//   k_rescue_windows  one wavefront per problem: the mate's 7-mer table in LDS, the window scanned 64 positions at a time,
+//                     candidate starts collected in a per-problem bitmap (sorted + unique for free)
+//   k_rescue_align    one thread per candidate start: UngappedAligner::alignUngapped
+//   k_select          one thread per cluster: consumes the aligned candidates, pair / orphan selection, alignment scores,
+//                     clippers, FragmentHeader records
+struct RescueBuffers
+{
+    RescueJob *jobs; u32 jobsCap; u32 *jobCounter;
+    u32 *bitmaps; u32 bitmapCap; u32 *bitmapCounter;
+    i32 *candPositions; u32 *candJob; Cand *shadowCands; u32 *shadowCigars; u32 candCap; u32 *candCounter;
+    u32 *jobBase; u32 *jobCount;   // per cluster of the chunk; jobBase == 0xffffffff: the cluster runs its rescues itself
+};
+
+__global__ __launch_bounds__(64) void k_plan_rescue(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk,
+                                                    const ClusterFragments *frags, u8 *arena, u64 arenaBytes, TemplateCaps caps, RescueBuffers rb)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nChunk) return;
+    TemplateWork work;
+    templateWorkBind(work, arena + u64(t) * arenaBytes, caps);
+    const u32 n = clusterPlanRescue(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + t, t, frags[t], work, nullptr);
+    u32 base = 0;
+    if (n)
+    {
+        base = atomicAdd(rb.jobCounter, n);
+        if (base + n > rb.jobsCap) base = 0xffffffffu;
+        else
+        {
+            RescueJob *jobs = rb.jobs + base;
+            clusterPlanRescue(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + t, t, frags[t], work, jobs);
+            for (u32 i = 0; i < n; ++i)
+            {
+                if (!jobs[i].valid) continue;
+                const u32 words = (jobs[i].windowLen + P.readLength[jobs[i].shadowReadIndex] + 31) / 32;
+                const u32 at = atomicAdd(rb.bitmapCounter, words);
+                if (at + words > rb.bitmapCap) jobs[i].fallback = 1; else { jobs[i].bitmapBase = at; jobs[i].bitmapWords = words; }
+            }
+        }
+    }
+    rb.jobBase[t] = base; rb.jobCount[t] = n;
+}
+
+static const u32 KMER_EMPTY = 0xffffffffu;
+
+__global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, RescueBuffers rb, Counters *counters)
+{
+    __shared__ u32 tables[4][KMER_TABLE];
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 j = blockIdx.x * 4 + wave;
+    const u32 nJobs = imin(*rb.jobCounter, rb.jobsCap);
+    if (j >= nJobs) return;
+    RescueJob job = rb.jobs[j];
+    if (!job.valid || job.fallback) return;
+    u32 *tab = tables[wave];
+    for (u32 i = lane; i < KMER_TABLE; i += 64) tab[i] = KMER_EMPTY;
+    u32 *bitmap = rb.bitmaps + job.bitmapBase;
+    for (u32 i = lane; i < job.bitmapWords; i += 64) bitmap[i] = 0;
+    __threadfence();
+    __builtin_amdgcn_wave_barrier();
+    // the mate's 7-mers: first read position of every k-mer (ShadowAligner::hashShadowKmers, :53-72)
+    const u32 r = job.shadowReadIndex, L = P.readLength[r];
+    ReadView read; read.bcl = bcl + u64(clusterBase + job.cluster) * P.clusterLength + P.readOffset[r]; read.length = L; read.endCyclesMasked = 0; read.firstCycle = 0;
+    const bool reverse = job.shadowReverse != 0;
+    for (u32 i = lane; i + 7 <= L; i += 64)
+    {
+        u32 kmer = 0; bool ok = true;
+        for (u32 k = 0; k < 7; ++k) { const char c = strandBase(read, reverse, i + k); ok &= c != 'n'; kmer = (kmer << 2) | baseCode(c); }
+        if (!ok) continue;
+        kmer &= 0x3fff;
+        const u32 val = (kmer << 10) | i;
+        u32 h = (kmer * 2654435761u) >> 22;
+        while (true)
+        {
+            const u32 old = atomicCAS(&tab[h], KMER_EMPTY, val);
+            if (old == KMER_EMPTY) break;
+            if ((old >> 10) == kmer) { atomicMin(&tab[h], val); break; }
+            h = (h + 1) & (KMER_TABLE - 1);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    // window scan (ShadowAligner::findShadowCandidatePositions, :74-112), 64 start positions per step, in window order
+    const char *window = R.bases + R.contigOffset[job.contigId] + job.windowBegin;
+    u32 pushes = 0; i32 carry = 0; bool haveCarry = false;
+    const i32 bias = i32(L) - 7;
+    for (u32 base = 0; base + 7 <= job.windowLen; base += 64)
+    {
+        const u32 p = base + lane;
+        bool hit = false; i32 cand = 0;
+        if (p + 7 <= job.windowLen)
+        {
+            u32 kmer = 0; bool ok = true;
+            for (u32 k = 0; k < 7; ++k) { const u32 v = baseCode(window[p + k]); ok &= v < 4; kmer = (kmer << 2) | (v & 3); }
+            if (ok)
+            {
+                u32 h = (kmer * 2654435761u) >> 22;
+                while (true)
+                {
+                    const u32 e = tab[h];
+                    if (e == KMER_EMPTY) break;
+                    if ((e >> 10) == kmer) { hit = true; cand = i32(p) - i32(e & 0x3ff); break; }
+                    h = (h + 1) & (KMER_TABLE - 1);
+                }
+            }
+        }
+        const unsigned long long hitMask = __ballot(hit);
+        const unsigned long long below = hitMask & ((1ull << lane) - 1ull);
+        const int prevLane = below ? 63 - __clzll(below) : 0;
+        const i32 prevCand = __shfl(cand, prevLane, 64);
+        const bool push = hit && (below ? prevCand != cand : (!haveCarry || carry != cand));
+        pushes += u32(__popcll(__ballot(push)));
+        if (push) { const u32 bit = u32(cand + bias); atomicOr(&bitmap[bit >> 5], 1u << (bit & 31)); }
+        if (hitMask) { carry = __shfl(cand, 63 - __clzll(hitMask), 64); haveCarry = true; }
+    }
+    __threadfence();
+    __builtin_amdgcn_wave_barrier();
+    // enumerate the set bits in ascending order = the sorted unique candidate list
+    u32 total = 0;
+    for (u32 w0 = 0; w0 < job.bitmapWords; w0 += 64)
+    {
+        const u32 w = w0 + lane;
+        const u32 word = w < job.bitmapWords ? __hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        u32 c = u32(__popc(word));
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+        total += c;
+    }
+    bool fallback = pushes > SHADOW_POSITIONS_MAX;
+    u32 candBase = 0;
+    if (!fallback && total)
+    {
+        if (lane == 0) candBase = atomicAdd(rb.candCounter, total);
+        candBase = __shfl(candBase, 0, 64);
+        if (candBase + total > rb.candCap) fallback = true;
+    }
+    if (!fallback && total)
+    {
+        u32 running = 0;
+        for (u32 w0 = 0; w0 < job.bitmapWords; w0 += 64)
+        {
+            const u32 w = w0 + lane;
+            u32 word = w < job.bitmapWords ? __hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            const u32 c = u32(__popc(word));
+            u32 incl = c;
+            for (u32 o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+            u32 at = candBase + running + incl - c;
+            while (word)
+            {
+                const u32 b = u32(__ffs(word)) - 1; word &= word - 1;
+                rb.candPositions[at] = i32(w * 32 + b) - bias; rb.candJob[at] = j; ++at;
+            }
+            running += __shfl(incl, 63, 64);
+        }
+    }
+    if (lane == 0)
+    {
+        RescueJob &out = rb.jobs[j];
+        out.pushes = pushes; out.fallback = fallback ? 1 : 0; out.candBase = candBase; out.nCands = fallback ? 0 : total;
+        atomicAdd(reinterpret_cast<unsigned long long *>(&counters->rescueCalls), 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&counters->rescueWindowBases), static_cast<unsigned long long>(job.windowLen));
+        atomicAdd(reinterpret_cast<unsigned long long *>(&counters->rescueCandidates), static_cast<unsigned long long>(fallback ? 0 : total));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, const ClusterFragments *frags, RescueBuffers rb, Counters *counters)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 n = imin(*rb.candCounter, rb.candCap);
+    Counters local; memset(&local, 0, sizeof(local));
+    if (i < n)
+    {
+        const RescueJob &job = rb.jobs[rb.candJob[i]];
+        rescueAlignCandidate(P, R, bcl, clusterBase + job.cluster, frags[job.cluster], job, rb.candPositions[i], rb.shadowCands[i], rb.shadowCigars + u64(i) * 3);
+        ++local.ungappedScans;
+    }
+    flushCounters(local, counters);
+}
+
+// one thread per rescue problem: which of its aligned candidates get a gapped retry (ShadowAligner.cpp:232-262)
+__global__ __launch_bounds__(256) void k_rescue_gapped_plan(const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb)
+{
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 nJobs = imin(*rb.jobCounter, rb.jobsCap);
+    if (j >= nJobs) return;
+    RescueJob &job = rb.jobs[j];
+    if (!job.valid || job.fallback) return;
+    const u32 ecm = frags[job.cluster].endCyclesMasked[job.shadowReadIndex];
+    const u32 n = planRescueGapped(job, rb.shadowCands, rb.shadowCigars, ecm, nullptr);
+    u32 base = 0;
+    if (n)
+    {
+        base = atomicAdd(gb.counter, n);
+        if (base + n > gb.cap) base = 0xffffffffu;     // the cluster's thread runs them itself
+        else planRescueGapped(job, rb.shadowCands, rb.shadowCigars, ecm, gb.jobs + base);
+    }
+    job.gappedBase = base; job.nGapped = n;
+}
+
 // k_select: clusters [clusterBase, clusterBase + nChunk) with per-thread arenas of `arenaBytes`; clusters whose light work
 // lists overflow are appended to overflowList.  With `list` given, thread t redoes cluster list[t] (heavy capacities).
 __global__ __launch_bounds__(64) void k_select(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk, u32 tile,
-                                               const ClusterFragments *frags, u8 *arena, u64 arenaBytes, TemplateCaps caps, const u32 *list,
+                                               const ClusterFragments *frags, u8 *arena, u64 arenaBytes, TemplateCaps caps, const u32 *list, RescueBuffers rb, const GappedResult *gappedResults,
                                                FragmentRecord *records, u32 *cigars, u32 *overflowList, u32 *overflowCount, u32 overflowCapacity, Counters *counters)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -305,13 +537,20 @@ __global__ __launch_bounds__(64) void k_select(DevParams P, DevReference R, DevT
         const u32 inChunk = list ? list[t] : t;
         TemplateWork work;
         templateWorkBind(work, arena + u64(t) * arenaBytes, caps);
-        clusterSelect(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + inChunk, tile, frags[inChunk], work, records, cigars, local);
+        RescueInputs in; const RescueInputs *pin = nullptr;
+        if (rb.jobBase && rb.jobBase[inChunk] != 0xffffffffu)
+        {
+            in.jobs = rb.jobs + rb.jobBase[inChunk]; in.jobCount = rb.jobCount[inChunk]; in.shadowCands = rb.shadowCands; in.shadowCigars = rb.shadowCigars;
+            in.gappedResults = gappedResults; in.serialFallbackAllowed = list != nullptr;
+            pin = &in;
+        }
+        clusterSelect(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + inChunk, tile, frags[inChunk], work, records, cigars, local, pin);
         if (work.overflow)
         {
             if (!list) { const u32 at = atomicAdd(overflowCount, 1u); if (at < overflowCapacity) overflowList[at] = inChunk; }
             else ++local.overflowClusters;   // even the reference's own capacities were exceeded
         }
-        if (!list) ++local.clusters;
+        if (!list) ++local.clusters; else ++local.heavyClusters;
     }
     flushCounters(local, counters);
 }
@@ -488,6 +727,7 @@ int isaac_gpu_create(int device, const isaac_params *params, void *stream, isaac
     c->overflowCount.reserve(1);
     HIP_CHECK(hipEventCreate(&c->ev0)); HIP_CHECK(hipEventCreate(&c->ev1));
     if (const char *e = getenv("ISAAC_GPU_CHUNK_CLUSTERS")) c->chunkClusters = u32(std::max(1024, atoi(e)));
+    if (const char *e = getenv("ISAAC_GPU_FLAT_RESCUE")) c->flatRescue = atoi(e) != 0;
     *out = c.release();
     return ISAAC_GPU_OK;
     ISAAC_CATCH
@@ -707,13 +947,41 @@ int isaac_gpu_set_loaded_contigs(isaac_gpu_ctx *c, const uint8_t *loaded, uint32
     ISAAC_CATCH
 }
 
+static GappedBuffers gappedBuffers(isaac_gpu_ctx *c, u32 which)
+{
+    GappedBuffers gb;
+    gb.cap = 2 * c->chunkClusters;
+    c->gappedJobs.reserve(gb.cap); c->gappedResults.reserve(gb.cap); c->gappedBase.reserve(c->chunkClusters); c->gappedCounters.reserve(4);
+    gb.jobs = c->gappedJobs.p; gb.results = c->gappedResults.p; gb.base = c->gappedBase.p; gb.counter = c->gappedCounters.p + which;
+    return gb;
+}
+
+static void launchGappedJobs(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clusterBase, const GappedBuffers &gb, const char *timer)
+{
+    const u32 maxReadLength = std::max(c->P.readLength[0], c->P.nReads > 1 ? c->P.readLength[1] : 0u);
+    const size_t lds = size_t(16) * bswGroupLdsBytes(maxReadLength);
+    ScopedTimer t(c, timer);
+    k_gapped_jobs<<<1024, 256, lds, c->stream>>>(c->P, c->ref(), bcl, clusterBase, gb.jobs, gb.counter, gb.cap, maxReadLength, gb.results);
+    HIP_CHECK(hipGetLastError());
+}
+
 static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clusterBase, u32 n, const isaac_match *matches, const uint64_t *offsets, int withGaps, int trim)
 {
     c->frags.reserve(c->chunkClusters); c->fragWork.reserve(c->chunkClusters);
-    ScopedTimer t(c, "build_fragments");
-    k_build_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, reinterpret_cast<const Match *>(matches), offsets,
-                                                             withGaps, trim, c->fragWork.p, c->frags.p, c->counters.p);
-    HIP_CHECK(hipGetLastError());
+    const GappedBuffers gb = gappedBuffers(c, 0);
+    HIP_CHECK(hipMemsetAsync(c->gappedCounters.p, 0, 16, c->stream));
+    {
+        ScopedTimer t(c, "build_fragments");
+        k_build_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, reinterpret_cast<const Match *>(matches), offsets,
+                                                                 withGaps, trim, c->fragWork.p, c->frags.p, gb, c->counters.p);
+        HIP_CHECK(hipGetLastError());
+    }
+    if (withGaps) launchGappedJobs(c, bcl, clusterBase, gb, "gapped_fragments");
+    {
+        ScopedTimer t(c, "finish_fragments");
+        k_finish_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, withGaps, c->fragWork.p, c->frags.p, gb, c->counters.p);
+        HIP_CHECK(hipGetLastError());
+    }
 }
 
 int isaac_gpu_build_fragments(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, uint32_t tile, const isaac_match *matches, const uint64_t *offsets,
@@ -787,21 +1055,63 @@ int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, u
     DevTls t; std::memcpy(&t, tls, sizeof(t));
     const RogCorrection rog = makeRogCorrection(c->P, c->hContigOffset.data(), c->hContigLoaded.data(), c->nContigs);
     const double lmq40 = logMismatchQ40();
-    const TemplateCaps light = lightCaps(), heavy = heavyCaps();
+    TemplateCaps light = lightCaps(); const TemplateCaps heavy = heavyCaps();
+    if (const char *e = getenv("ISAAC_GPU_LIGHT_CAPS"))
+    {   // shadow,shadowCigar,pos,prob,pair,best,templateCigar
+        unsigned v[7];
+        if (7 == sscanf(e, "%u,%u,%u,%u,%u,%u,%u", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6))
+        { light.shadow = v[0]; light.shadowCigar = v[1]; light.pos = v[2]; light.prob = v[3]; light.pair = v[4]; light.best = v[5]; light.templateCigar = v[6]; }
+    }
     const u64 lightBytes = templateWorkBytes(light), heavyBytes = templateWorkBytes(heavy);
     const u32 chunk = c->chunkClusters;
     const u32 heavyThreads = 1024;
     c->lightArena.reserve(size_t(chunk) * lightBytes);
     c->overflowList.reserve(chunk);
+    RescueBuffers rb; std::memset(&rb, 0, sizeof(rb));
+    if (c->flatRescue)
+    {
+        rb.jobsCap = 4 * chunk; rb.bitmapCap = 64 * rb.jobsCap; rb.candCap = 24 * chunk;
+        c->jobs.reserve(rb.jobsCap); c->bitmaps.reserve(rb.bitmapCap); c->candPositions.reserve(rb.candCap); c->candJob.reserve(rb.candCap);
+        c->shadowCands.reserve(rb.candCap); c->shadowCigars.reserve(size_t(rb.candCap) * 3); c->jobBase.reserve(chunk); c->jobCount.reserve(chunk); c->rescueCounters.reserve(4);
+        rb.jobs = c->jobs.p; rb.bitmaps = c->bitmaps.p; rb.candPositions = c->candPositions.p; rb.candJob = c->candJob.p; rb.shadowCands = c->shadowCands.p;
+        rb.shadowCigars = c->shadowCigars.p; rb.jobBase = c->jobBase.p; rb.jobCount = c->jobCount.p;
+        rb.jobCounter = c->rescueCounters.p; rb.bitmapCounter = c->rescueCounters.p + 1; rb.candCounter = c->rescueCounters.p + 2;
+    }
     const DevReference R = c->ref();
+    const GappedBuffers gbRescue = gappedBuffers(c, 1);   // counter 1; the job and result arrays are the fragment stage's, free again by then
     for (u32 done = 0; done < nClusters; done += chunk)
     {
         const u32 n = std::min(chunk, nClusters - done);
         launchBuildFragments(c, bcl, done, n, matches, offsets, 1, 1);
         HIP_CHECK(hipMemsetAsync(c->overflowCount.p, 0, 4, st));
+        if (c->flatRescue)
+        {
+            HIP_CHECK(hipMemsetAsync(c->rescueCounters.p, 0, 16, st));
+            {
+                ScopedTimer tm(c, "plan_rescue");
+                k_plan_rescue<<<gridFor(n, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, n, c->frags.p, c->lightArena.p, lightBytes, light, rb);
+                HIP_CHECK(hipGetLastError());
+            }
+            {
+                ScopedTimer tm(c, "rescue_windows");
+                k_rescue_windows<<<gridFor(rb.jobsCap, 4), 256, 0, st>>>(c->P, R, bcl, done, rb, c->counters.p);
+                HIP_CHECK(hipGetLastError());
+            }
+            {
+                ScopedTimer tm(c, "rescue_align");
+                k_rescue_align<<<gridFor(rb.candCap, 256), 256, 0, st>>>(c->P, R, bcl, done, c->frags.p, rb, c->counters.p);
+                HIP_CHECK(hipGetLastError());
+            }
+            {
+                ScopedTimer tm(c, "rescue_gapped_plan");
+                k_rescue_gapped_plan<<<gridFor(rb.jobsCap, 256), 256, 0, st>>>(c->frags.p, rb, gbRescue);
+                HIP_CHECK(hipGetLastError());
+            }
+            launchGappedJobs(c, bcl, done, gbRescue, "gapped_rescue");
+        }
         {
             ScopedTimer tm(c, "select");
-            k_select<<<gridFor(n, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, n, tile, c->frags.p, c->lightArena.p, lightBytes, light, nullptr,
+            k_select<<<gridFor(n, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, n, tile, c->frags.p, c->lightArena.p, lightBytes, light, nullptr, rb, c->flatRescue ? gbRescue.results : nullptr,
                                                      reinterpret_cast<FragmentRecord *>(fragments), cigar, c->overflowList.p, c->overflowCount.p, chunk, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }
@@ -814,7 +1124,7 @@ int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, u
             const u32 m = std::min(heavyThreads, nOverflow - od);
             c->heavyArena.reserve(size_t(heavyThreads) * heavyBytes);
             ScopedTimer tm(c, "select_heavy");
-            k_select<<<gridFor(m, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, m, tile, c->frags.p, c->heavyArena.p, heavyBytes, heavy, c->overflowList.p + od,
+            k_select<<<gridFor(m, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, m, tile, c->frags.p, c->heavyArena.p, heavyBytes, heavy, c->overflowList.p + od, rb, c->flatRescue ? gbRescue.results : nullptr,
                                                      reinterpret_cast<FragmentRecord *>(fragments), cigar, nullptr, nullptr, 0, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }

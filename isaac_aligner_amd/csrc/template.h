@@ -141,6 +141,7 @@ struct TemplateWork
     u32 *tflags;
     BestPairInfo bestCombination, bestRescued;
     u32 overflow;
+    u32 lastPushes, lastTruncated;   // of the last findShadowCandidatePositions: list length before sort/unique, capacity hit
 };
 ISAAC_HD u64 alignUp(u64 v) { return (v + 15) & ~u64(15); }
 ISAAC_HD u64 templateWorkBytes(const TemplateCaps &c)
@@ -179,9 +180,31 @@ ISAAC_HD void templateWorkBind(TemplateWork &w, void *base, const TemplateCaps &
 struct Frag { Cand c; const u32 *pool; };
 struct BamTemplate { Frag f[2]; u32 n; u32 alignmentScore; bool properPair; };
 
+// One mate-rescue problem (ShadowAligner::rescueShadow call): planned by the cluster's thread, its window scanned by a
+// wavefront (k_rescue_windows), its candidate positions aligned one per thread (k_rescue_align), consumed by the cluster again.
+struct RescueJob
+{
+    i64 windowBegin;        // first reference base of the scanned window (candidatePositionOffset of ShadowAligner.cpp:190)
+    u32 windowLen;          // bases in [windowBegin, windowEnd)
+    u32 cluster;            // index inside the chunk
+    u32 contigId;
+    u32 candBase, nCands;   // slots of the unique candidate start positions (ascending)
+    u32 pushes;             // entries shadowCandidatePositions_ would have held before sort/unique (capacity 10000)
+    u32 bitmapBase, bitmapWords;
+    u8 shadowReadIndex, shadowReverse, valid, fallback;   // fallback: redo this job serially (capacity exceeded)
+    u32 gappedBase, nGapped; // the job's gapped retries in the chunk's GappedResult array; gappedBase 0xffffffff: run them serially
+    u32 pad;
+};
+static_assert(sizeof(RescueJob) == 56, "RescueJob layout");
+enum { RESCUE_SERIAL = 0, RESCUE_PLAN = 1, RESCUE_LOOKUP = 2 };
+static const u32 SHADOW_POSITIONS_MAX = 10000;   // ShadowAligner.hh:91
+
 struct TemplateCtx
 {
     const DevParams *P; const DevReference *R; const DevTls *tls;
+    u32 rescueMode; u32 jobNext, jobCount; RescueJob *jobs; bool planWrite; bool serialFallbackAllowed;
+    const i32 *candPositions; const Cand *shadowCands; const u32 *shadowCigars;   // RESCUE_LOOKUP inputs
+    const GappedResult *gappedResults;                                            // RESCUE_LOOKUP: the chunk's gapped retries, or NULL
     ReadView reads[2];
     const ClusterFragments *frags;
     TemplateWork *w;
@@ -268,7 +291,8 @@ ISAAC_HD u32 findShadowCandidatePositions(TemplateCtx &x, const char *reference,
         }
         if (truncated) break;
     }
-    if (truncated) w.overflow = 1;  // the reference keeps up to 10000 positions
+    if (truncated && w.caps.pos < SHADOW_POSITIONS_MAX) w.overflow = 1;  // the reference itself stops at 10000 positions
+    w.lastPushes = n; w.lastTruncated = truncated ? 1 : 0;
     if (n)
     {
         for (u32 i = 0; i < n; ++i) w.sortIdx[i] = u16(i);
@@ -302,45 +326,35 @@ ISAAC_HD void calculateShadowRescueRange(const TemplateCtx &x, const Cand &orpha
     first = shadowMinPosition - 10; second = shadowMaxPosition + 10;
 }
 
-// ShadowAligner::rescueShadow (ShadowAligner.cpp:155-291).  Fills w.shadowList (best first when true is returned).
-ISAAC_HD bool shadowRescue(TemplateCtx &x, const Cand &orphan, i64 bestTemplateLength)
+// first half of ShadowAligner::rescueShadow (ShadowAligner.cpp:155-197): where the mate is expected
+ISAAC_HD bool planRescue(const TemplateCtx &x, const Cand &orphan, i64 bestTemplateLength, RescueJob &job)
 {
-    TemplateWork &w = *x.w;
-    const DevParams &P = *x.P; const DevReference &R = *x.R;
-    w.nShadows = 0;
+    job.windowBegin = 0; job.windowLen = 0; job.cluster = x.clusterId; job.contigId = orphan.contigId; job.candBase = 0; job.nCands = 0; job.pushes = 0;
+    job.bitmapBase = 0; job.bitmapWords = 0; job.valid = 0; job.fallback = 0; job.gappedBase = 0xffffffffu; job.nGapped = 0; job.pad = 0;
+    job.shadowReadIndex = u8((orphan.readIndex + 1) % 2);
+    job.shadowReverse = 0;
     if (!tlsIsCoherent(*x.tls)) return false;
-    const u32 shadowReadIndex = (orphan.readIndex + 1) % 2;
-    const ReadView &shadowRead = x.reads[shadowReadIndex];
-    const bool shadowReverse = tlsMateOrientation(*x.tls, orphan.readIndex, orphan.reverse);
+    job.shadowReverse = u8(tlsMateOrientation(*x.tls, orphan.readIndex, orphan.reverse));
     i64 rangeFirst, rangeSecond;
     calculateShadowRescueRange(x, orphan, bestTemplateLength, rangeFirst, rangeSecond);
     if (rangeSecond < rangeFirst) return false;
-    if (rangeSecond + 1 + i64(shadowRead.length) < 0) return false;
-    const i64 referenceSize = i64(contigLength(R, orphan.contigId));
-    const char *reference = R.bases + R.contigOffset[orphan.contigId];
-    const i64 candidatePositionOffset = imax<i64>(0, rangeFirst);
+    if (rangeSecond + 1 + i64(x.reads[job.shadowReadIndex].length) < 0) return false;
+    const i64 referenceSize = i64(contigLength(*x.R, orphan.contigId));
+    job.windowBegin = imax<i64>(0, rangeFirst);
     const i64 windowEnd = imin(referenceSize, rangeSecond + 1);
-    ++x.cnt->rescueCalls;
-    if (windowEnd > candidatePositionOffset) x.cnt->rescueWindowBases += u64(windowEnd - candidatePositionOffset);
-    const u32 nPositions = findShadowCandidatePositions(x, reference, candidatePositionOffset, windowEnd, shadowRead, shadowReverse);
-    x.cnt->rescueCandidates += nPositions;
-    CigarPool pool; pool.words = w.shadowCigar; pool.used = 0; pool.capacity = w.caps.shadowCigar; pool.overflow = 0;
-    i32 best = -1;
-    for (u32 c = 0; c < nPositions; ++c)
-    {
-        if (w.nShadows == w.caps.shadow) { w.overflow = 1; return false; } // reference: capacity 1000 -> return false
-        Cand &fragment = w.shadowList[w.nShadows];
-        candInit(fragment, shadowReadIndex);
-        fragment.reverse = shadowReverse; fragment.contigId = orphan.contigId;
-        fragment.position = w.candidatePositions[w.sortIdx[c]] + candidatePositionOffset;
-        ++x.cnt->ungappedScans;
-        if (alignUngapped(P, R, shadowRead, fragment, pool))
-        {
-            if (best < 0 || lpLess(w.shadowList[best].logProbability, fragment.logProbability)) best = i32(w.nShadows);
-            ++w.nShadows;
-        }
-    }
+    job.windowLen = windowEnd > job.windowBegin ? u32(windowEnd - job.windowBegin) : 0;
+    job.valid = 1;
+    return true;
+}
+
+// second half (ShadowAligner.cpp:232-291): gapped retries next to close candidates, best shadow to the front
+// `gapped`: results of the retries in list order when the flat pass already ran them (planRescueGapped), else NULL
+ISAAC_HD bool finishRescue(TemplateCtx &x, CigarPool &pool, i32 best, const GappedResult *gapped = 0)
+{
+    TemplateWork &w = *x.w;
+    const DevParams &P = *x.P; const DevReference &R = *x.R;
     if (best < 0) { if (pool.overflow) w.overflow = 1; return false; }
+    const ReadView &shadowRead = x.reads[w.shadowList[0].readIndex];
     if (BSW_MISMATCHES_CUTOFF < w.shadowList[best].mismatchCount)
     {
         for (u32 i = 0; i < w.nShadows; ++i)
@@ -352,7 +366,15 @@ ISAAC_HD bool shadowRescue(TemplateCtx &x, const Cand &orphan, i64 bestTemplateL
                 {
                     Cand tmp = fragment;
                     ++x.cnt->rescueBsw;
-                    const u32 matchCount = alignGapped(P, R, shadowRead, tmp, pool, w.tflags);
+                    u32 matchCount;
+                    if (gapped)
+                    {
+                        const GappedResult &g = *gapped++;
+                        tmp = g.out; matchCount = g.matchCount; tmp.cigarOffset = pool.used;
+                        if (0xffffffffu == g.nCigar) { w.overflow = 1; matchCount = 0; }
+                        else for (u32 k = 0; k < g.nCigar; ++k) pool.push(g.cigar[k]);
+                    }
+                    else matchCount = alignGapped(P, R, shadowRead, tmp, pool, w.tflags);
                     if (matchCount && matchCount + BSW_WIDEST_GAP_SIZE > candObservedLength(fragment) && (tmp.mismatchCount <= P.gappedMismatchesMax) &&
                         (fragment.mismatchCount > tmp.mismatchCount) && lpLess(fragment.logProbability, tmp.logProbability))
                     {
@@ -366,6 +388,123 @@ ISAAC_HD bool shadowRescue(TemplateCtx &x, const Cand &orphan, i64 bestTemplateL
     if (pool.overflow) w.overflow = 1;
     if (best != 0) { const Cand t = w.shadowList[0]; w.shadowList[0] = w.shadowList[best]; w.shadowList[best] = t; }
     return true;
+}
+
+// ShadowAligner::rescueShadow, everything in this thread (RESCUE_SERIAL)
+ISAAC_HD bool shadowRescueSerial(TemplateCtx &x, const Cand &orphan, const RescueJob &job)
+{
+    TemplateWork &w = *x.w;
+    const DevParams &P = *x.P; const DevReference &R = *x.R;
+    const ReadView &shadowRead = x.reads[job.shadowReadIndex];
+    const char *reference = R.bases + R.contigOffset[orphan.contigId];
+    const u32 nPositions = findShadowCandidatePositions(x, reference, job.windowBegin, job.windowBegin + job.windowLen, shadowRead, job.shadowReverse != 0);
+    x.cnt->rescueCandidates += nPositions;
+    CigarPool pool; pool.words = w.shadowCigar; pool.used = 0; pool.capacity = w.caps.shadowCigar; pool.overflow = 0;
+    i32 best = -1;
+    for (u32 c = 0; c < nPositions; ++c)
+    {
+        if (w.nShadows == w.caps.shadow) { w.overflow = 1; return false; } // reference: capacity 1000 -> return false
+        Cand &fragment = w.shadowList[w.nShadows];
+        candInit(fragment, job.shadowReadIndex);
+        fragment.reverse = job.shadowReverse; fragment.contigId = orphan.contigId;
+        fragment.position = w.candidatePositions[w.sortIdx[c]] + job.windowBegin;
+        ++x.cnt->ungappedScans;
+        if (alignUngapped(P, R, shadowRead, fragment, pool))
+        {
+            if (best < 0 || lpLess(w.shadowList[best].logProbability, fragment.logProbability)) best = i32(w.nShadows);
+            ++w.nShadows;
+        }
+    }
+    return finishRescue(x, pool, best);
+}
+
+// ShadowAligner::rescueShadow with the window scan and the ungapped alignments already done by the flat kernels (RESCUE_LOOKUP)
+ISAAC_HD bool shadowRescueLookup(TemplateCtx &x, const Cand &orphan, const RescueJob &job)
+{
+    TemplateWork &w = *x.w;
+    if (job.fallback)
+    {   // a capacity of the flat pass was exceeded for this job: exact serial path, which needs the reference-sized lists
+        if (!x.serialFallbackAllowed) { w.overflow = 1; return false; }
+        return shadowRescueSerial(x, orphan, job);
+    }
+    CigarPool pool; pool.words = w.shadowCigar; pool.used = 0; pool.capacity = w.caps.shadowCigar; pool.overflow = 0;
+    i32 best = -1;
+    for (u32 c = 0; c < job.nCands; ++c)
+    {
+        if (w.nShadows == w.caps.shadow) { w.overflow = 1; return false; }
+        const Cand &src = x.shadowCands[job.candBase + c];
+        if (!candAligned(src)) continue;
+        Cand &fragment = w.shadowList[w.nShadows];
+        fragment = src;
+        fragment.cigarOffset = pool.used;
+        for (u32 k = 0; k < src.cigarLength; ++k) pool.push(x.shadowCigars[u64(job.candBase + c) * 3 + k]);
+        if (best < 0 || lpLess(w.shadowList[best].logProbability, fragment.logProbability)) best = i32(w.nShadows);
+        ++w.nShadows;
+    }
+    return finishRescue(x, pool, best, (0xffffffffu != job.gappedBase && x.gappedResults) ? x.gappedResults + job.gappedBase : 0);
+}
+
+// Which shadows of a job ShadowAligner.cpp:232-262 hands to the gapped aligner.  The choice reads only the ungapped results
+// (the loop compares each element with its not yet modified successor), so the retries can run before the cluster's thread
+// consumes them.  out == NULL: count only.
+ISAAC_HD u32 planRescueGapped(const RescueJob &job, const Cand *shadowCands, const u32 *shadowCigars, u32 endCyclesMasked, GappedJob *out)
+{
+    i32 best = -1;
+    for (u32 c = 0; c < job.nCands; ++c)
+    {
+        const Cand &f = shadowCands[job.candBase + c];
+        if (!candAligned(f)) continue;
+        if (best < 0 || lpLess(shadowCands[job.candBase + best].logProbability, f.logProbability)) best = i32(c);
+    }
+    if (best < 0 || !(BSW_MISMATCHES_CUTOFF < shadowCands[job.candBase + best].mismatchCount)) return 0;
+    u32 n = 0; i32 prev = -1;
+    for (u32 c = 0; c < job.nCands; ++c)
+    {
+        const Cand &next = shadowCands[job.candBase + c];
+        if (!candAligned(next)) continue;
+        if (prev >= 0)
+        {
+            const Cand &f = shadowCands[job.candBase + prev];
+            if (next.position - f.position < i64(BSW_DISTANCE_CUTOFF) && BSW_MISMATCHES_CUTOFF < f.mismatchCount)
+            {
+                if (out)
+                {
+                    GappedJob &g = out[n]; g.in = f; g.cluster = job.cluster; g.endCyclesMasked = endCyclesMasked; g.tag = job.candBase + u32(prev); g.pad = 0;
+                    g.in.cigarOffset = 0;
+                    g.in.position = candUnclippedPosition(g.in, shadowCigars + u64(job.candBase + u32(prev)) * 3); g.in.cigarLength = 0;
+                }
+                ++n;
+            }
+        }
+        prev = i32(c);
+    }
+    return n;
+}
+
+// ShadowAligner::rescueShadow (ShadowAligner.cpp:155-291).  Fills w.shadowList (best first when true is returned).
+ISAAC_HD bool shadowRescue(TemplateCtx &x, const Cand &orphan, i64 bestTemplateLength)
+{
+    TemplateWork &w = *x.w;
+    w.nShadows = 0;
+    if (RESCUE_PLAN == x.rescueMode)
+    {   // only the sequence of rescue problems is wanted: it does not depend on their results
+        RescueJob job;
+        planRescue(x, orphan, bestTemplateLength, job);
+        if (x.planWrite) x.jobs[x.jobNext] = job;
+        ++x.jobNext;
+        return false;
+    }
+    if (RESCUE_LOOKUP == x.rescueMode)
+    {
+        const RescueJob &job = x.jobs[x.jobNext++];
+        if (!job.valid) return false;
+        return shadowRescueLookup(x, orphan, job);
+    }
+    RescueJob job;
+    if (!planRescue(x, orphan, bestTemplateLength, job)) return false;
+    ++x.cnt->rescueCalls; x.cnt->rescueWindowBases += job.windowLen;
+    const bool ret = shadowRescueSerial(x, orphan, job);
+    return ret;
 }
 
 // ------------------------------------------------------------------------------------------------------------------

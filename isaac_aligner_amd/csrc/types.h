@@ -137,7 +137,7 @@ enum { CLUSTER_OVERFLOW = 1 };
 struct Counters
 {
     u64 clusters, probes, probeSteps, matches, candidates, ungappedScans, bswJobs, bswAccepted, simpleIndels,
-        rescueCalls, rescueWindowBases, rescueCandidates, rescueBsw, overflowClusters, mapqNearInteger;
+        rescueCalls, rescueWindowBases, rescueCandidates, rescueBsw, overflowClusters, mapqNearInteger, heavyClusters;
 };
 
 // per-cluster facts TemplateLengthDistribution::addTemplate looks at (TemplateLengthStatistics.cpp:275-314)

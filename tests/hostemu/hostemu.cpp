@@ -22,7 +22,7 @@ struct Emu
     std::vector<double> logMatch, logMismatch;
     std::vector<ClusterFragments> frags;
     std::vector<Match> matches; std::vector<u64> matchOffsets;
-    Counters cnt;
+    Counters cnt; bool flatRescue = true;
 };
 }
 
@@ -77,6 +77,15 @@ int emu_build_fragments(Emu *e, const u8 *bcl, u32 nClusters, int withGaps, int 
     {
         ClusterFragments &f = e->frags[c];
         clusterBuildFragments(e->P, e->R, bcl, c, e->matches.data(), e->matchOffsets.data(), withGaps != 0, trim != 0, work[0], f, e->cnt);
+        if (e->flatRescue && withGaps)
+        {   // k_build_fragments -> k_gapped_jobs -> k_finish_fragments
+            const u32 nj = countGappedJobs(f, true);
+            std::vector<GappedJob> jobs(nj + 1); std::vector<GappedResult> results(nj + 1);
+            if (nj) writeGappedJobs(f, c, jobs.data());
+            for (u32 j = 0; j < nj; ++j) runGappedJobSerial(e->P, e->R, bcl + u64(jobs[j].cluster) * e->P.clusterLength, jobs[j], work[0].tflags, results[j]);
+            clusterFinishFragments(e->P, e->R, bcl, c, true, results.data(), work[0], f, e->cnt);
+        }
+        else clusterFinishFragments(e->P, e->R, bcl, c, withGaps != 0, 0, work[0], f, e->cnt);
         if (!out) continue;
         for (u32 r = 0; r < 2; ++r) for (u32 i = 0; i < f.nCands[r]; ++i)
         {
@@ -121,24 +130,97 @@ int emu_select(Emu *e, const u8 *bcl, u32 nClusters, u32 tile, const isaac_tls *
     DevTls t; std::memcpy(&t, tls, sizeof(t));
     const RogCorrection rog = makeRogCorrection(e->P, e->offsets.data(), e->loaded.data(), e->R.nContigs);
     FragmentRecord *recs = reinterpret_cast<FragmentRecord *>(records);
-    // main pass with the light per-thread capacities, then the flagged clusters again with the reference's own limits
-    for (int tier = 0; tier < 2; ++tier)
+    const double lmq40 = logMismatchQ40();
+    auto makeWork = [](const TemplateCaps &caps, std::vector<u8> &arena, TemplateWork &work)
     {
-        const TemplateCaps caps = tier ? heavyCaps() : lightCaps();
-        std::vector<u8> arena(templateWorkBytes(caps) + 16, 0);
-        TemplateWork work;
-        void *base = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(arena.data()) + 15) & ~uintptr_t(15));
-        templateWorkBind(work, base, caps);
+        arena.assign(templateWorkBytes(caps) + 16, 0);
+        templateWorkBind(work, reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(arena.data()) + 15) & ~uintptr_t(15)), caps);
+    };
+    std::vector<u8> lightArena, heavyArena; TemplateWork light, heavy;
+    makeWork(lightCaps(), lightArena, light); makeWork(heavyCaps(), heavyArena, heavy);
+    if (!e->flatRescue)
+    {   // everything in the cluster's own thread (the round-1 baseline design)
+        for (int tier = 0; tier < 2; ++tier)
+            for (u32 c = 0; c < nClusters; ++c)
+            {
+                if (tier && !(recs[u64(c) * e->P.nReads].reserved & RECORD_TEMPLATE_OVERFLOW)) continue;
+                clusterSelect(e->P, e->R, t, rog, lmq40, bcl, c, tile, e->frags[c], tier ? heavy : light, recs, cigars, e->cnt);
+                if (!tier) ++e->cnt.clusters;
+            }
+        return 0;
+    }
+    // flat rescue: the same sequence of kernels as isaac_gpu_select, as plain loops
+    // k_plan_rescue
+    std::vector<u32> jobBase(nClusters + 1, 0);
+    std::vector<RescueJob> jobs;
+    for (u32 c = 0; c < nClusters; ++c)
+    {
+        const u32 n = clusterPlanRescue(e->P, e->R, t, rog, lmq40, bcl, c, c, e->frags[c], light, 0);
+        jobBase[c + 1] = jobBase[c] + n;
+    }
+    jobs.resize(jobBase[nClusters]);
+    for (u32 c = 0; c < nClusters; ++c) clusterPlanRescue(e->P, e->R, t, rog, lmq40, bcl, c, c, e->frags[c], light, jobs.data() + jobBase[c]);
+    // k_rescue_windows
+    std::vector<i32> candPositions;
+    {
+        Counters scratch; std::memset(&scratch, 0, sizeof(scratch));
+        for (size_t j = 0; j < jobs.size(); ++j)
+        {
+            RescueJob &job = jobs[j];
+            if (!job.valid) continue;
+            ++e->cnt.rescueCalls; e->cnt.rescueWindowBases += job.windowLen;
+            TemplateCtx x; templateCtxInit(x, e->P, e->R, t, rog, bcl, job.cluster, e->frags[job.cluster], heavy, scratch);
+            const u32 n = findShadowCandidatePositions(x, e->R.bases + e->R.contigOffset[job.contigId], job.windowBegin, job.windowBegin + job.windowLen,
+                                                       x.reads[job.shadowReadIndex], job.shadowReverse != 0);
+            job.pushes = heavy.lastPushes + heavy.lastTruncated;
+            if (heavy.lastTruncated) { job.fallback = 1; continue; }
+            job.candBase = u32(candPositions.size()); job.nCands = n;
+            for (u32 i = 0; i < n; ++i) candPositions.push_back(i32(heavy.candidatePositions[heavy.sortIdx[i]]));
+            e->cnt.rescueCandidates += n;
+        }
+    }
+    // k_rescue_align
+    std::vector<Cand> shadowCands(candPositions.size()); std::vector<u32> shadowCigars(candPositions.size() * 3 + 3);
+    for (size_t j = 0; j < jobs.size(); ++j)
+        for (u32 i = 0; i < jobs[j].nCands; ++i)
+        {
+            const u32 slot = jobs[j].candBase + i;
+            rescueAlignCandidate(e->P, e->R, bcl, jobs[j].cluster, e->frags[jobs[j].cluster], jobs[j], candPositions[slot], shadowCands[slot], &shadowCigars[size_t(slot) * 3]);
+            ++e->cnt.ungappedScans;
+        }
+    // k_rescue_gapped_plan + k_gapped_jobs
+    std::vector<GappedResult> gapped;
+    {
+        std::vector<u32> tflags(3 * 512);
+        std::vector<GappedJob> gj;
+        for (size_t j = 0; j < jobs.size(); ++j)
+        {
+            RescueJob &job = jobs[j];
+            if (!job.valid || job.fallback) continue;
+            const u32 ecm = e->frags[job.cluster].endCyclesMasked[job.shadowReadIndex];
+            const u32 n = planRescueGapped(job, shadowCands.data(), shadowCigars.data(), ecm, 0);
+            job.gappedBase = u32(gj.size()); job.nGapped = n;
+            gj.resize(gj.size() + n);
+            if (n) planRescueGapped(job, shadowCands.data(), shadowCigars.data(), ecm, gj.data() + job.gappedBase);
+        }
+        gapped.resize(gj.size() + 1);
+        for (size_t j = 0; j < gj.size(); ++j) runGappedJobSerial(e->P, e->R, bcl + u64(gj[j].cluster) * e->P.clusterLength, gj[j], tflags.data(), gapped[j]);
+    }
+    // k_select (light capacities), then the flagged clusters with the reference's own capacities
+    for (int tier = 0; tier < 2; ++tier)
         for (u32 c = 0; c < nClusters; ++c)
         {
             if (tier && !(recs[u64(c) * e->P.nReads].reserved & RECORD_TEMPLATE_OVERFLOW)) continue;
-            if (tier) ++e->cnt.overflowClusters;
-            clusterSelect(e->P, e->R, t, rog, logMismatchQ40(), bcl, c, tile, e->frags[c], work, recs, cigars, e->cnt);
+            RescueInputs in; in.jobs = jobs.data() + jobBase[c]; in.jobCount = jobBase[c + 1] - jobBase[c]; in.shadowCands = shadowCands.data(); in.shadowCigars = shadowCigars.data();
+            in.gappedResults = gapped.data();
+            in.serialFallbackAllowed = tier != 0;
+            clusterSelect(e->P, e->R, t, rog, lmq40, bcl, c, tile, e->frags[c], tier ? heavy : light, recs, cigars, e->cnt, &in);
             if (!tier) ++e->cnt.clusters;
         }
-    }
     return 0;
 }
+
+void emu_set_flat_rescue(Emu *e, int on) { e->flatRescue = on != 0; }
 
 void emu_get_counters(Emu *e, isaac_counters *out) { std::memcpy(out, &e->cnt, sizeof(*out)); }
 
