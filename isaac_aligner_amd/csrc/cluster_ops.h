@@ -72,6 +72,7 @@ ISAAC_HD void templateCtxInit(TemplateCtx &x, const DevParams &P, const DevRefer
     x.rogRead[0] = rog.read[0]; x.rogRead[1] = rog.read[1]; x.rog = rog.pair;
     x.rescueMode = RESCUE_SERIAL; x.jobNext = 0; x.jobCount = 0; x.jobs = 0; x.planWrite = false; x.serialFallbackAllowed = true;
     x.candPositions = 0; x.shadowCands = 0; x.shadowCigars = 0; x.gappedResults = 0;
+    x.lanes = 1; x.lane = 0; x.fastSort = false; x.ldsSort = 0; x.ldsSortCap = 0;
     const u8 *clusterBcl = bcl + u64(cluster) * P.clusterLength;
     for (u32 r = 0; r < 2; ++r)
     {
@@ -114,15 +115,18 @@ ISAAC_HD void rescueAlignCandidate(const DevParams &P, const DevReference &R, co
 
 // What the flat kernels hand to clusterSelect: the cluster's jobs and the aligned candidates of the chunk
 struct RescueInputs { RescueJob *jobs; u32 jobCount; const Cand *shadowCands; const u32 *shadowCigars; const GappedResult *gappedResults; bool serialFallbackAllowed; };
+// wave-cooperative execution (k_select_heavy) and the fast probability sort; see TemplateCtx
+struct CoopInputs { u32 lanes, lane; bool fastSort; u16 *ldsSort; u32 ldsSortCap; };
 
 // MatchSelector::processMatchList for one cluster: template building, clipping, io::FragmentHeader records.
 // records: P.nReads per cluster; cigars: P.nReads * OUT_CIGAR_CAP words per cluster
 ISAAC_HD void clusterSelect(const DevParams &P, const DevReference &R, const DevTls &tls, const RogCorrection &rog, double logMismatchQ40,
                             const u8 *bcl, u32 cluster, u32 tile, const ClusterFragments &frags, TemplateWork &work,
-                            FragmentRecord *records, u32 *cigars, Counters &cnt, const RescueInputs *rescue = 0)
+                            FragmentRecord *records, u32 *cigars, Counters &cnt, const RescueInputs *rescue = 0, const CoopInputs *coop = 0)
 {
     TemplateCtx x;
     templateCtxInit(x, P, R, tls, rog, bcl, cluster, frags, work, cnt);
+    if (coop) { x.lanes = coop->lanes; x.lane = coop->lane; x.fastSort = coop->fastSort; x.ldsSort = coop->ldsSort; x.ldsSortCap = coop->ldsSortCap; }
     if (rescue)
     {
         x.rescueMode = RESCUE_LOOKUP; x.jobs = rescue->jobs; x.jobCount = rescue->jobCount; x.shadowCands = rescue->shadowCands; x.shadowCigars = rescue->shadowCigars;

@@ -61,7 +61,7 @@ struct isaac_gpu_ctx
     DevBuf<Counters> counters;
     std::map<std::string, KernelTimer> timers;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    u32 chunkClusters = 131072;
+    u32 chunkClusters = 524288;
 
     DevReference ref() const
     {
@@ -552,6 +552,35 @@ __global__ __launch_bounds__(64) void k_select(DevParams P, DevReference R, DevT
         }
         if (!list) ++local.clusters; else ++local.heavyClusters;
     }
+    flushCounters(local, counters);
+}
+
+// k_select_heavy: one wave per cluster of the overflow list.  All 64 lanes execute the template logic together on one arena
+// (same statements, same data), which costs what one thread costs; the bulk steps (probability sorts) are spread over the lanes.
+static const u32 HEAVY_SORT_LDS = 32768;   // u16 indices: heavyCaps().prob / .pair entries
+__global__ __launch_bounds__(64) void k_select_heavy(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nList, u32 tile,
+                                                     const ClusterFragments *frags, u8 *arena, u64 arenaBytes, TemplateCaps caps, const u32 *list, RescueBuffers rb, const GappedResult *gappedResults,
+                                                     FragmentRecord *records, u32 *cigars, Counters *counters)
+{
+    extern __shared__ __align__(16) u8 heavyLds[];
+    const u32 t = blockIdx.x;
+    if (t >= nList) return;
+    Counters local; memset(&local, 0, sizeof(local));
+    const u32 inChunk = list[t];
+    TemplateWork work;
+    templateWorkBind(work, arena + u64(t) * arenaBytes, caps);
+    RescueInputs in; const RescueInputs *pin = nullptr;
+    if (rb.jobBase && rb.jobBase[inChunk] != 0xffffffffu)
+    {
+        in.jobs = rb.jobs + rb.jobBase[inChunk]; in.jobCount = rb.jobCount[inChunk]; in.shadowCands = rb.shadowCands; in.shadowCigars = rb.shadowCigars;
+        in.gappedResults = gappedResults; in.serialFallbackAllowed = true;
+        pin = &in;
+    }
+    CoopInputs coop; coop.lanes = 64; coop.lane = threadIdx.x; coop.fastSort = true; coop.ldsSort = reinterpret_cast<u16 *>(heavyLds); coop.ldsSortCap = HEAVY_SORT_LDS;
+    clusterSelect(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + inChunk, tile, frags[inChunk], work, records, cigars, local, pin, &coop);
+    if (work.overflow) ++local.overflowClusters;   // even the reference's own capacities were exceeded
+    ++local.heavyClusters;
+    if (0 != threadIdx.x) memset(&local, 0, sizeof(local));   // every lane counted the same events
     flushCounters(local, counters);
 }
 
@@ -1124,8 +1153,8 @@ int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, u
             const u32 m = std::min(heavyThreads, nOverflow - od);
             c->heavyArena.reserve(size_t(heavyThreads) * heavyBytes);
             ScopedTimer tm(c, "select_heavy");
-            k_select<<<gridFor(m, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, m, tile, c->frags.p, c->heavyArena.p, heavyBytes, heavy, c->overflowList.p + od, rb, c->flatRescue ? gbRescue.results : nullptr,
-                                                     reinterpret_cast<FragmentRecord *>(fragments), cigar, nullptr, nullptr, 0, c->counters.p);
+            k_select_heavy<<<m, 64, HEAVY_SORT_LDS * 2, st>>>(c->P, R, t, rog, lmq40, bcl, done, m, tile, c->frags.p, c->heavyArena.p, heavyBytes, heavy, c->overflowList.p + od, rb,
+                                                              c->flatRescue ? gbRescue.results : nullptr, reinterpret_cast<FragmentRecord *>(fragments), cigar, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }
     }

@@ -113,6 +113,34 @@ ISAAC_HD bool pairProbEqual(const PairProb &a, const PairProb &b)
 { return a.r1.pos == b.r1.pos && a.r2.pos == b.r2.pos && lpEquals(pairLp(a), pairLp(b)) && a.r1.observedLength == b.r1.observedLength && a.r2.observedLength == b.r2.observedLength; }
 struct ShadowProbIdxLess { const ShadowProb *v; ISAAC_HD bool operator()(u16 a, u16 b) const { return shadowProbLess(v[a], v[b]); } };
 struct PairProbIdxLess { const PairProb *v; ISAAC_HD bool operator()(u16 a, u16 b) const { return pairProbLess(v[a], v[b]); } };
+// total orders refining shadowProbLess / pairProbLess (exact comparisons, index as the last key): see sumUnique*Probabilities
+struct ShadowProbTotalLess
+{
+    const ShadowProb *v;
+    ISAAC_HD bool operator()(u16 a, u16 b) const
+    {
+        const ShadowProb &x = v[a], &y = v[b];
+        if (x.pos != y.pos) return x.pos < y.pos;
+        if (x.logProbability != y.logProbability) return x.logProbability < y.logProbability;
+        if (x.observedLength != y.observedLength) return x.observedLength < y.observedLength;
+        return a < b;
+    }
+};
+struct PairProbTotalLess
+{
+    const PairProb *v;
+    ISAAC_HD bool operator()(u16 a, u16 b) const
+    {
+        const PairProb &x = v[a], &y = v[b];
+        if (x.r1.pos != y.r1.pos) return x.r1.pos < y.r1.pos;
+        if (x.r2.pos != y.r2.pos) return x.r2.pos < y.r2.pos;
+        const double lx = pairLp(x), ly = pairLp(y);
+        if (lx != ly) return ly < lx;                                   // higher probability first
+        if (x.r1.observedLength != y.r1.observedLength) return x.r1.observedLength < y.r1.observedLength;
+        if (x.r2.observedLength != y.r2.observedLength) return x.r2.observedLength < y.r2.observedLength;
+        return a < b;
+    }
+};
 struct PosIdxLess { const i64 *v; ISAAC_HD bool operator()(u16 a, u16 b) const { return v[a] < v[b]; } };
 
 struct BestPairInfo
@@ -211,7 +239,65 @@ struct TemplateCtx
     double rogRead[2], rog;
     u32 clusterId;
     Counters *cnt;
+    // wave-cooperative form (k_select_heavy): all `lanes` lanes of the wave run the same statements on the same arena; the bulk
+    // loops are strided by `lane`.  lanes == 1: plain thread-serial execution.  fastSort: large probability lists are sorted by a
+    // total order that refines the reference's comparators, with the exact std::sort replica as fallback for ambiguous data.
+    u32 lanes, lane; bool fastSort; u16 *ldsSort; u32 ldsSortCap;
 };
+
+// wave-level helpers of the cooperative form; identities in the thread-serial form
+ISAAC_HD bool coopAny(const TemplateCtx &x, bool v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (x.lanes > 1) return __ballot(v) != 0;
+#endif
+    (void)x; return v;
+}
+ISAAC_HD void coopSync(const TemplateCtx &x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (x.lanes > 1) __syncthreads();   // the workgroup is this one wave: orders the lanes' global and LDS traffic
+#endif
+    (void)x;
+}
+
+// Sorts idx[0..n) by a strict TOTAL order.  Cooperative form: bitonic network over the indices in LDS, keys stay where they are.
+template <typename LessT>
+ISAAC_HD void sortTotal(TemplateCtx &x, u16 *idx, u32 n, LessT less)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (x.lanes > 1)
+    {
+        u32 m = 1; while (m < n) m <<= 1;
+        if (m <= x.ldsSortCap)
+        {
+            u16 *l = x.ldsSort;
+            for (u32 i = x.lane; i < m; i += x.lanes) l[i] = i < n ? idx[i] : u16(0xffff);
+            __syncthreads();
+            for (u32 k = 2; k <= m; k <<= 1)
+                for (u32 j = k >> 1; j > 0; j >>= 1)
+                {
+                    for (u32 t = x.lane; t < (m >> 1); t += x.lanes)
+                    {
+                        const u32 i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                        const u16 a = l[i], b = l[i + j];
+                        // 0xffff pads the network: greater than every element
+                        const bool aLessB = (a != 0xffff) && (b == 0xffff || less(a, b));
+                        const bool bLessA = (b != 0xffff) && (a == 0xffff || less(b, a));
+                        const bool swap = (0 == (i & k)) ? bLessA : aLessB;
+                        if (swap) { l[i] = b; l[i + j] = a; }
+                    }
+                    __syncthreads();
+                }
+            for (u32 i = x.lane; i < n; i += x.lanes) idx[i] = l[i];
+            __syncthreads();
+            return;
+        }
+    }
+#endif
+    (void)x;
+    exactSort(idx, i32(n), less);   // any correct algorithm will do for a total order
+}
 
 ISAAC_HD u32 mapqFloor(TemplateCtx &x, double ratio)
 {
@@ -643,12 +729,38 @@ ISAAC_HD void pushShadowProb(TemplateWork &w, u32 side, const Cand &s)
 
 // sumUniqueShadowProbabilities / sumUniquePairProbabilities (TemplateBuilder.cpp:694-714): std::sort, then the first element of
 // every run of elements equal to it (std::unique_copy over forward iterators), summed in sorted order
-ISAAC_HD double sumUniqueShadowProbabilities(TemplateWork &w, u32 side)
+//
+// The reference's comparators use |a - b| <= 1e-7 for the probabilities, so they are strict weak orders only on data without
+// "near ties" (same position, probabilities different but within 1e-7).  Without near ties the sorted sequence is unique up to
+// the order of elements with identical keys, and those contribute the same term whichever of them std::unique_copy keeps: any
+// correct sort gives the reference's sum.  The fast path therefore sorts by a total order, checks for near ties (adjacent
+// elements suffice once sorted) and only falls back to the instruction-exact std::sort replica if it finds one.
+static const u32 FAST_SORT_MIN = 192;
+ISAAC_HD double sumUniqueShadowProbabilities(TemplateCtx &x, u32 side)
 {
+    TemplateWork &w = *x.w;
     const u32 n = w.nShadowProbs[side]; const ShadowProb *v = w.shadowProbs[side];
-    for (u32 i = 0; i < n; ++i) w.sortIdx[i] = u16(i);
-    ShadowProbIdxLess less; less.v = v;
-    exactSort(w.sortIdx, i32(n), less);
+    bool exact = true;
+    if (x.fastSort && n >= FAST_SORT_MIN)
+    {
+        for (u32 i = x.lane; i < n; i += x.lanes) w.sortIdx[i] = u16(i);
+        coopSync(x);
+        ShadowProbTotalLess tl; tl.v = v;
+        sortTotal(x, w.sortIdx, n, tl);
+        bool nearTie = false;
+        for (u32 i = 1 + x.lane; i < n; i += x.lanes)
+        {
+            const ShadowProb &a = v[w.sortIdx[i - 1]], &b = v[w.sortIdx[i]];
+            if (a.pos == b.pos && a.logProbability != b.logProbability && lpEquals(a.logProbability, b.logProbability)) nearTie = true;
+        }
+        exact = coopAny(x, nearTie);
+    }
+    if (exact)
+    {
+        for (u32 i = 0; i < n; ++i) w.sortIdx[i] = u16(i);
+        ShadowProbIdxLess less; less.v = v;
+        exactSort(w.sortIdx, i32(n), less);
+    }
     double ret = 0.0;
     for (u32 i = 0; i < n;)
     {
@@ -659,12 +771,32 @@ ISAAC_HD double sumUniqueShadowProbabilities(TemplateWork &w, u32 side)
     }
     return ret;
 }
-ISAAC_HD double sumUniquePairProbabilities(TemplateWork &w)
+ISAAC_HD double sumUniquePairProbabilities(TemplateCtx &x)
 {
+    TemplateWork &w = *x.w;
     const u32 n = w.nPairProbs; const PairProb *v = w.pairProbs;
-    for (u32 i = 0; i < n; ++i) w.sortIdx[i] = u16(i);
-    PairProbIdxLess less; less.v = v;
-    exactSort(w.sortIdx, i32(n), less);
+    bool exact = true;
+    if (x.fastSort && n >= FAST_SORT_MIN)
+    {
+        for (u32 i = x.lane; i < n; i += x.lanes) w.sortIdx[i] = u16(i);
+        coopSync(x);
+        PairProbTotalLess tl; tl.v = v;
+        sortTotal(x, w.sortIdx, n, tl);
+        bool nearTie = false;
+        for (u32 i = 1 + x.lane; i < n; i += x.lanes)
+        {
+            const PairProb &a = v[w.sortIdx[i - 1]], &b = v[w.sortIdx[i]];
+            const double la = pairLp(a), lb = pairLp(b);
+            if (a.r1.pos == b.r1.pos && a.r2.pos == b.r2.pos && la != lb && lpEquals(la, lb)) nearTie = true;
+        }
+        exact = coopAny(x, nearTie);
+    }
+    if (exact)
+    {
+        for (u32 i = 0; i < n; ++i) w.sortIdx[i] = u16(i);
+        PairProbIdxLess less; less.v = v;
+        exactSort(w.sortIdx, i32(n), less);
+    }
     double ret = 0.0;
     for (u32 i = 0; i < n;)
     {
@@ -723,7 +855,7 @@ ISAAC_HD bool templateRescueShadow(TemplateCtx &x, BamTemplate &t, double logMis
             bestPair.totalTemplateProbability += exp(orphan.logProbability + w.shadowList[s].logProbability);
         }
     }
-    const double totalShadowProbability = (0 < bestPair.resolvedTemplateCount) ? sumUniqueShadowProbabilities(w, orphanIndex) : 0.0;
+    const double totalShadowProbability = (0 < bestPair.resolvedTemplateCount) ? sumUniqueShadowProbabilities(x, orphanIndex) : 0.0;
     bool ret = true;
     Frag &orphanF = t.f[orphanIndex]; Frag &shadowF = t.f[shadowIndex];
     if (0 < bestPair.resolvedTemplateCount)
@@ -914,10 +1046,10 @@ ISAAC_HD bool buildDisjoinedTemplate(TemplateCtx &x, BamTemplate &t, const BestP
     if (0 < bestOrphans.resolvedTemplateCount)
     {
         for (u32 i = 0; i < x.frags->nCands[bestShadowIndex]; ++i) pushShadowProb(w, bestOrphanIndex, x.frags->cands[bestShadowIndex][i]);
-        totalShadowProbability = sumUniqueShadowProbabilities(w, bestOrphanIndex);
+        totalShadowProbability = sumUniqueShadowProbabilities(x, bestOrphanIndex);
         for (u32 i = 0; i < x.frags->nCands[bestOrphanIndex]; ++i) pushShadowProb(w, bestShadowIndex, x.frags->cands[bestOrphanIndex][i]);
-        totalOrphanProbability = sumUniqueShadowProbabilities(w, bestShadowIndex);
-        bestOrphans.totalTemplateProbability += sumUniquePairProbabilities(w);
+        totalOrphanProbability = sumUniqueShadowProbabilities(x, bestShadowIndex);
+        bestOrphans.totalTemplateProbability += sumUniquePairProbabilities(x);
     }
     if (bestOrphans.overflow) w.overflow = 1;
     return scoreDisjoinedTemplate(x, t, bestOrphans, knownBestPair, bestOrphanIndex, totalShadowProbability, totalOrphanProbability, bestDisjoinedFragments);

@@ -7,6 +7,7 @@
 #include "../../isaac_aligner_amd/csrc/host_util.h"
 #include <string>
 #include <vector>
+#include <chrono>
 #include <cstring>
 #include <algorithm>
 
@@ -22,7 +23,7 @@ struct Emu
     std::vector<double> logMatch, logMismatch;
     std::vector<ClusterFragments> frags;
     std::vector<Match> matches; std::vector<u64> matchOffsets;
-    Counters cnt; bool flatRescue = true;
+    Counters cnt; bool flatRescue = true; double *clusterTimes = nullptr; bool fastSort = true; std::vector<u32> dbgJobBase; std::vector<RescueJob> dbgJobs;
 };
 }
 
@@ -144,7 +145,8 @@ int emu_select(Emu *e, const u8 *bcl, u32 nClusters, u32 tile, const isaac_tls *
             for (u32 c = 0; c < nClusters; ++c)
             {
                 if (tier && !(recs[u64(c) * e->P.nReads].reserved & RECORD_TEMPLATE_OVERFLOW)) continue;
-                clusterSelect(e->P, e->R, t, rog, lmq40, bcl, c, tile, e->frags[c], tier ? heavy : light, recs, cigars, e->cnt);
+                { CoopInputs coop; coop.lanes = 1; coop.lane = 0; coop.fastSort = e->fastSort && tier; coop.ldsSort = 0; coop.ldsSortCap = 0;
+                  clusterSelect(e->P, e->R, t, rog, lmq40, bcl, c, tile, e->frags[c], tier ? heavy : light, recs, cigars, e->cnt, 0, &coop); }
                 if (!tier) ++e->cnt.clusters;
             }
         return 0;
@@ -206,6 +208,7 @@ int emu_select(Emu *e, const u8 *bcl, u32 nClusters, u32 tile, const isaac_tls *
         gapped.resize(gj.size() + 1);
         for (size_t j = 0; j < gj.size(); ++j) runGappedJobSerial(e->P, e->R, bcl + u64(gj[j].cluster) * e->P.clusterLength, gj[j], tflags.data(), gapped[j]);
     }
+    e->dbgJobBase = jobBase; e->dbgJobs = jobs;
     // k_select (light capacities), then the flagged clusters with the reference's own capacities
     for (int tier = 0; tier < 2; ++tier)
         for (u32 c = 0; c < nClusters; ++c)
@@ -213,14 +216,30 @@ int emu_select(Emu *e, const u8 *bcl, u32 nClusters, u32 tile, const isaac_tls *
             if (tier && !(recs[u64(c) * e->P.nReads].reserved & RECORD_TEMPLATE_OVERFLOW)) continue;
             RescueInputs in; in.jobs = jobs.data() + jobBase[c]; in.jobCount = jobBase[c + 1] - jobBase[c]; in.shadowCands = shadowCands.data(); in.shadowCigars = shadowCigars.data();
             in.gappedResults = gapped.data();
+            const auto t0 = std::chrono::steady_clock::now();
             in.serialFallbackAllowed = tier != 0;
-            clusterSelect(e->P, e->R, t, rog, lmq40, bcl, c, tile, e->frags[c], tier ? heavy : light, recs, cigars, e->cnt, &in);
+            CoopInputs coop; coop.lanes = 1; coop.lane = 0; coop.fastSort = e->fastSort && tier; coop.ldsSort = 0; coop.ldsSortCap = 0;
+            clusterSelect(e->P, e->R, t, rog, lmq40, bcl, c, tile, e->frags[c], tier ? heavy : light, recs, cigars, e->cnt, &in, &coop);
+            if (e->clusterTimes) e->clusterTimes[c] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (!tier) ++e->cnt.clusters;
         }
     return 0;
 }
 
 void emu_set_flat_rescue(Emu *e, int on) { e->flatRescue = on != 0; }
+void emu_set_fast_sort(Emu *e, int on) { e->fastSort = on != 0; }
+void emu_set_cluster_times(Emu *e, double *t) { e->clusterTimes = t; }
+// debugging: out = { jobs, valid jobs, total candidates, max candidates, gapped retries, fallback jobs, total window bases }
+void emu_cluster_job_stats(Emu *e, u32 c, u64 *out)
+{
+    for (int i = 0; i < 7; ++i) out[i] = 0;
+    if (c + 1 >= e->dbgJobBase.size()) return;
+    for (u32 j = e->dbgJobBase[c]; j < e->dbgJobBase[c + 1]; ++j)
+    {
+        const RescueJob &job = e->dbgJobs[j];
+        ++out[0]; out[1] += job.valid; out[2] += job.nCands; out[3] = std::max<u64>(out[3], job.nCands); out[4] += job.nGapped; out[5] += job.fallback; out[6] += job.windowLen;
+    }
+}
 
 void emu_get_counters(Emu *e, isaac_counters *out) { std::memcpy(out, &e->cnt, sizeof(*out)); }
 
