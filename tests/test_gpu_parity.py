@@ -210,4 +210,32 @@ def test_full_size_properties(torch):
     close = (np.abs(pos - left) <= 60) & (ctg == truth["contig"].cpu().numpy())
     assert close[ok].mean() > 0.995
     assert not (rec["reserved"] & 4).any()
-    assert al.counters()["mapq_near_integer"] == 0
+    # MAPQ hazard counter: templates whose -10 log10(ratio) sits within 1e-11 of an integer (probability ratios that are
+    # mathematically 10^-k).  They exist in any large input; test_full_size_parity checks them against the oracle.
+    assert al.counters()["mapq_near_integer"] < 1e-4 * len(rec)
+
+
+def test_full_size_parity(torch, oracle):
+    """300K pairs against the oracle: every FragmentHeader field, MAPQ and CIGAR.  The index is handed over from the GPU
+    builder (itself checked against the oracle's in test_index_builder) and the oracle's match selection uses all host cores."""
+    import os
+    from isaac_aligner_amd import gpu, synth
+    contigs = synth.make_genome(4_000_000, seed=11, device="cuda", n_contigs=2)
+    bcl, truth = synth.make_read_pairs(contigs, 300_000, 150, seed=12, device="cuda")
+    p = options.default_params(150, 150)
+    al = gpu.Aligner(p, 0, contigs)
+    al.build_index(annotate_neighbors=False)
+    matches, offsets, hits = al.find_matches(bcl)
+    al.set_loaded_contigs(hits)
+    tls = al.determine_tls(bcl, matches, offsets)
+    rec, cig = al.records_to_numpy(*al.select(bcl, matches, offsets, tls))
+    assert al.counters()["heavy_clusters"] > 0          # the wave-cooperative path for overflowing clusters is exercised
+    ref = oracle.reference([bytes(c.cpu().numpy()) for c in contigs])
+    ref.set_index(al.get_index())
+    host_bcl = bcl.cpu().numpy()
+    om, ohits = ref.find_matches(p, host_bcl, len(host_bcl))
+    assert (ohits == hits).all()
+    otls = ref.determine_tls(p, host_bcl, om, ohits)
+    assert otls.astuple() == tls.astuple()
+    orec, ocig, _ = ref.select(p, host_bcl, om, otls, ohits, n_threads=os.cpu_count() or 1, n_clusters_hint=len(host_bcl))
+    assert not compare_records(orec, ocig, rec, cig)
