@@ -332,6 +332,11 @@ __global__ void k_write_candidates(const ClusterFragments *frags, u32 clusterBas
 //   k_rescue_align    one thread per candidate start: UngappedAligner::alignUngapped
 //   k_select          one thread per cluster: consumes the aligned candidates, pair / orphan selection, alignment scores,
 //                     clippers, FragmentHeader records
+static const u32 KMER_EMPTY = 0xffffffffu;
+static const u32 RW_TABLE = 512;          // hash slots for the mate's <= 250-odd 7-mers
+static const u32 RW_LDS_BITMAP = 64;      // words: windows up to ~1900 bases keep their candidate bitmap in LDS
+static const u32 RW_PER_LANE = 16;        // consecutive window positions per lane and tile
+
 struct RescueBuffers
 {
     RescueJob *jobs; u32 jobsCap; u32 *jobCounter;
@@ -361,6 +366,7 @@ __global__ __launch_bounds__(64) void k_plan_rescue(DevParams P, DevReference R,
             {
                 if (!jobs[i].valid) continue;
                 const u32 words = (jobs[i].windowLen + P.readLength[jobs[i].shadowReadIndex] + 31) / 32;
+                if (words <= RW_LDS_BITMAP) continue;               // k_rescue_windows keeps short bitmaps in LDS
                 const u32 at = atomicAdd(rb.bitmapCounter, words);
                 if (at + words > rb.bitmapCap) jobs[i].fallback = 1; else { jobs[i].bitmapBase = at; jobs[i].bitmapWords = words; }
             }
@@ -369,105 +375,180 @@ __global__ __launch_bounds__(64) void k_plan_rescue(DevParams P, DevReference R,
     rb.jobBase[t] = base; rb.jobCount[t] = n;
 }
 
-static const u32 KMER_EMPTY = 0xffffffffu;
 
-__global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, RescueBuffers rb, Counters *counters)
+// 16 reference bytes at a 16-byte aligned address, zero where the address leaves [lo, hi)
+__device__ inline uint4 loadChunkGuarded(const char *at, const char *lo, const char *hi)
 {
-    __shared__ u32 tables[4][KMER_TABLE];
-    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const u32 j = blockIdx.x * 4 + wave;
-    const u32 nJobs = imin(*rb.jobCounter, rb.jobsCap);
-    if (j >= nJobs) return;
-    RescueJob job = rb.jobs[j];
-    if (!job.valid || job.fallback) return;
-    u32 *tab = tables[wave];
-    for (u32 i = lane; i < KMER_TABLE; i += 64) tab[i] = KMER_EMPTY;
-    u32 *bitmap = rb.bitmaps + job.bitmapBase;
-    for (u32 i = lane; i < job.bitmapWords; i += 64) bitmap[i] = 0;
-    __threadfence();
-    __builtin_amdgcn_wave_barrier();
-    // the mate's 7-mers: first read position of every k-mer (ShadowAligner::hashShadowKmers, :53-72)
-    const u32 r = job.shadowReadIndex, L = P.readLength[r];
-    ReadView read; read.bcl = bcl + u64(clusterBase + job.cluster) * P.clusterLength + P.readOffset[r]; read.length = L; read.endCyclesMasked = 0; read.firstCycle = 0;
-    const bool reverse = job.shadowReverse != 0;
-    for (u32 i = lane; i + 7 <= L; i += 64)
-    {
-        u32 kmer = 0; bool ok = true;
-        for (u32 k = 0; k < 7; ++k) { const char c = strandBase(read, reverse, i + k); ok &= c != 'n'; kmer = (kmer << 2) | baseCode(c); }
-        if (!ok) continue;
-        kmer &= 0x3fff;
-        const u32 val = (kmer << 10) | i;
-        u32 h = (kmer * 2654435761u) >> 22;
-        while (true)
-        {
-            const u32 old = atomicCAS(&tab[h], KMER_EMPTY, val);
-            if (old == KMER_EMPTY) break;
-            if ((old >> 10) == kmer) { atomicMin(&tab[h], val); break; }
-            h = (h + 1) & (KMER_TABLE - 1);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    // window scan (ShadowAligner::findShadowCandidatePositions, :74-112), 64 start positions per step, in window order
+    if (at >= lo && at + 16 <= hi) return *reinterpret_cast<const uint4 *>(at);
+    u32 w[4] = {0, 0, 0, 0};
+    for (u32 i = 0; i < 16; ++i) if (at + i >= lo && at + i < hi) w[i >> 2] |= u32(u8(at[i])) << (8 * (i & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+// any fixed bijection ACGT -> 0..3 will do for the 7-mer table; 4 = not a base
+__device__ inline u32 rwCode(u32 c) { const u32 d = c - 0x41u; return (d < 32u && ((0x80045u >> d) & 1u)) ? ((c >> 1) & 3u) : 4u; }
+
+// k_rescue_windows: one wave per rescue problem (ShadowAligner::findShadowCandidatePositions, ShadowAligner.cpp:53-112).
+// The mate's 7-mers go to an LDS hash table (first read position per k-mer).  The window is walked in tiles of 1024 bases:
+// every lane takes 16 consecutive positions from two aligned 16-byte loads, rolls the 7-mer along them and looks each one
+// up.  "Push unless equal to the previous hit's candidate" needs the previous hit in window order: inside a lane that is
+// sequential, across lanes one ballot + shuffle, across tiles a carried value.  Pushed candidates set bits in a bitmap
+// (LDS for ordinary windows, global for the long ones), whose ascending enumeration is the reference's sort + unique.
+template <bool LDS_BITMAP>
+__device__ inline void rescueWindowScan(const DevReference &R, u64 totalBases, const RescueJob &job, u32 L, const u32 *tab, u32 *bitmap, u32 lane, u32 &pushes)
+{
     const char *window = R.bases + R.contigOffset[job.contigId] + job.windowBegin;
-    u32 pushes = 0; i32 carry = 0; bool haveCarry = false;
+    const char *lo = R.bases, *hi = R.bases + totalBases;
+    const uintptr_t A = reinterpret_cast<uintptr_t>(window);
+    const char *alignedBase = reinterpret_cast<const char *>(A & ~uintptr_t(15));
+    const i32 off = i32(A & 15);                        // window[0] sits `off` bytes into the first chunk
     const i32 bias = i32(L) - 7;
-    for (u32 base = 0; base + 7 <= job.windowLen; base += 64)
+    const i32 lastStart = i32(job.windowLen) - 7;       // last valid k-mer start
+    i32 carry = 0; bool haveCarry = false;
+    for (i32 tile = 0; tile * 1024 - off <= lastStart; ++tile)
     {
-        const u32 p = base + lane;
-        bool hit = false; i32 cand = 0;
-        if (p + 7 <= job.windowLen)
+        const char *chunk = alignedBase + tile * 1024 + lane * 16;
+        const uint4 c0 = loadChunkGuarded(chunk, lo, hi), c1 = loadChunkGuarded(chunk + 16, lo, hi);
+        const u32 words[6] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y };
+        const i32 p0 = tile * 1024 + i32(lane) * 16 - off;          // window position of this lane's first byte
+        i32 cand[RW_PER_LANE]; u32 hitMask = 0;
+        u32 kmer = 0, valid = 0;
+#pragma unroll
+        for (u32 b = 0; b < RW_PER_LANE + 6; ++b)
         {
-            u32 kmer = 0; bool ok = true;
-            for (u32 k = 0; k < 7; ++k) { const u32 v = baseCode(window[p + k]); ok &= v < 4; kmer = (kmer << 2) | (v & 3); }
-            if (ok)
+            const u32 code = rwCode((words[b >> 2] >> (8 * (b & 3))) & 0xffu);
+            if (code > 3) { valid = 0; kmer = 0; } else { kmer = ((kmer << 2) | code) & 0x3fffu; ++valid; }
+            if (b >= 6)
             {
-                u32 h = (kmer * 2654435761u) >> 22;
-                while (true)
+                const u32 k = b - 6;                                   // the 7-mer starting at this lane's byte k
+                const i32 p = p0 + i32(k);
+                cand[k] = 0;
+                if (valid >= 7 && p >= 0 && p <= lastStart)
                 {
-                    const u32 e = tab[h];
-                    if (e == KMER_EMPTY) break;
-                    if ((e >> 10) == kmer) { hit = true; cand = i32(p) - i32(e & 0x3ff); break; }
-                    h = (h + 1) & (KMER_TABLE - 1);
+                    u32 h = (kmer * 2654435761u) >> 23;
+                    while (true)
+                    {
+                        const u32 e = tab[h];
+                        if (e == KMER_EMPTY) break;
+                        if ((e >> 10) == kmer) { hitMask |= 1u << k; cand[k] = p - i32(e & 0x3ffu); break; }
+                        h = (h + 1) & (RW_TABLE - 1);
+                    }
                 }
             }
         }
-        const unsigned long long hitMask = __ballot(hit);
-        const unsigned long long below = hitMask & ((1ull << lane) - 1ull);
+        // previous hit in window order for this lane's first hit
+        i32 lastCand = 0;
+#pragma unroll
+        for (u32 k = 0; k < RW_PER_LANE; ++k) if (hitMask & (1u << k)) lastCand = cand[k];
+        const unsigned long long lanesWithHits = __ballot(hitMask != 0);
+        const unsigned long long below = lanesWithHits & ((1ull << lane) - 1ull);
         const int prevLane = below ? 63 - __clzll(below) : 0;
-        const i32 prevCand = __shfl(cand, prevLane, 64);
-        const bool push = hit && (below ? prevCand != cand : (!haveCarry || carry != cand));
-        pushes += u32(__popcll(__ballot(push)));
-        if (push) { const u32 bit = u32(cand + bias); atomicOr(&bitmap[bit >> 5], 1u << (bit & 31)); }
-        if (hitMask) { carry = __shfl(cand, 63 - __clzll(hitMask), 64); haveCarry = true; }
+        const i32 prevCand = __shfl(lastCand, prevLane, 64);
+        bool havePrev = below ? true : haveCarry;
+        i32 prev = below ? prevCand : carry;
+        u32 localPushes = 0;
+#pragma unroll
+        for (u32 k = 0; k < RW_PER_LANE; ++k)
+            if (hitMask & (1u << k))
+            {
+                if (!havePrev || prev != cand[k])
+                {
+                    ++localPushes;
+                    const u32 bit = u32(cand[k] + bias);
+                    atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
+                }
+                prev = cand[k]; havePrev = true;
+            }
+        for (int o = 32; o > 0; o >>= 1) localPushes += __shfl_xor(localPushes, o, 64);
+        pushes += localPushes;
+        if (lanesWithHits) { carry = __shfl(lastCand, 63 - __clzll(lanesWithHits), 64); haveCarry = true; }
     }
-    __threadfence();
-    __builtin_amdgcn_wave_barrier();
-    // enumerate the set bits in ascending order = the sorted unique candidate list
-    u32 total = 0;
-    for (u32 w0 = 0; w0 < job.bitmapWords; w0 += 64)
+}
+
+__global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReference R, u64 totalBases, const u8 *bcl, u32 clusterBase, RescueBuffers rb)
+{
+    __shared__ u32 tables[4][RW_TABLE];
+    __shared__ u32 ldsBitmaps[4][RW_LDS_BITMAP];
+    __shared__ u32 waveTotals[4], blockBase;
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 j = blockIdx.x * 4 + wave;
+    const u32 nJobs = imin(*rb.jobCounter, rb.jobsCap);
+    RescueJob job;
+    bool active = j < nJobs;
+    if (active) { job = rb.jobs[j]; active = job.valid && !job.fallback; }
+    u32 pushes = 0, total = 0, bitmapWords = 0, L = 0;
+    bool small = true;
+    u32 *bitmap = ldsBitmaps[wave];
+    if (active)
     {
-        const u32 w = w0 + lane;
-        const u32 word = w < job.bitmapWords ? __hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        u32 c = u32(__popc(word));
-        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
-        total += c;
-    }
-    bool fallback = pushes > SHADOW_POSITIONS_MAX;
-    u32 candBase = 0;
-    if (!fallback && total)
-    {
-        if (lane == 0) candBase = atomicAdd(rb.candCounter, total);
-        candBase = __shfl(candBase, 0, 64);
-        if (candBase + total > rb.candCap) fallback = true;
-    }
-    if (!fallback && total)
-    {
-        u32 running = 0;
-        for (u32 w0 = 0; w0 < job.bitmapWords; w0 += 64)
+        u32 *tab = tables[wave];
+        for (u32 i = lane; i < RW_TABLE; i += 64) tab[i] = KMER_EMPTY;
+        const u32 r = job.shadowReadIndex;
+        L = P.readLength[r];
+        bitmapWords = (job.windowLen + L + 31) / 32;
+        small = bitmapWords <= RW_LDS_BITMAP;
+        if (!small) bitmap = rb.bitmaps + job.bitmapBase;
+        for (u32 i = lane; i < bitmapWords; i += 64) bitmap[i] = 0;
+        if (!small) __threadfence();
+        __builtin_amdgcn_wave_barrier();
+        // the mate's 7-mers: first read position of every k-mer (ShadowAligner::hashShadowKmers, :53-72)
+        ReadView read; read.bcl = bcl + u64(clusterBase + job.cluster) * P.clusterLength + P.readOffset[r]; read.length = L; read.endCyclesMasked = 0; read.firstCycle = 0;
+        const bool reverse = job.shadowReverse != 0;
+        for (u32 i = lane; i + 7 <= L; i += 64)
+        {
+            u32 kmer = 0; bool ok = true;
+            for (u32 k = 0; k < 7; ++k) { const u32 code = rwCode(u32(u8(strandBase(read, reverse, i + k)))); ok &= code < 4; kmer = (kmer << 2) | (code & 3); }
+            if (!ok) continue;
+            const u32 val = (kmer << 10) | i;
+            u32 h = (kmer * 2654435761u) >> 23;
+            while (true)
+            {
+                const u32 old = atomicCAS(&tab[h], KMER_EMPTY, val);
+                if (old == KMER_EMPTY) break;
+                if ((old >> 10) == kmer) { atomicMin(&tab[h], val); break; }
+                h = (h + 1) & (RW_TABLE - 1);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (small) rescueWindowScan<true>(R, totalBases, job, L, tab, ldsBitmaps[wave], lane, pushes);
+        else { rescueWindowScan<false>(R, totalBases, job, L, tab, bitmap, lane, pushes); __threadfence(); }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the set bits in ascending order are the sorted unique candidate list: count them first
+        for (u32 w0 = 0; w0 < bitmapWords; w0 += 64)
         {
             const u32 w = w0 + lane;
-            u32 word = w < job.bitmapWords ? __hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            const u32 word = w < bitmapWords ? (small ? bitmap[w] : __hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0u;
+            u32 c = u32(__popc(word));
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+            total += c;
+        }
+    }
+    bool fallback = pushes > SHADOW_POSITIONS_MAX;
+    if (fallback) total = 0;
+    // one allocation per workgroup: a single counter serves every rescue problem of the chunk
+    if (lane == 0) waveTotals[wave] = total;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        const u32 sum = waveTotals[0] + waveTotals[1] + waveTotals[2] + waveTotals[3];
+        blockBase = sum ? atomicAdd(rb.candCounter, sum) : 0u;
+    }
+    __syncthreads();
+    if (!active) return;
+    u32 candBase = blockBase;
+    for (u32 w = 0; w < wave; ++w) candBase += waveTotals[w];
+    if (total && candBase + total > rb.candCap) fallback = true;
+    if (!fallback && total)
+    {
+        const i32 bias = i32(L) - 7;
+        u32 running = 0;
+        for (u32 w0 = 0; w0 < bitmapWords; w0 += 64)
+        {
+            const u32 w = w0 + lane;
+            u32 word = w < bitmapWords ? (small ? bitmap[w] : __hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0u;
             const u32 c = u32(__popc(word));
             u32 incl = c;
             for (u32 o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
@@ -484,9 +565,6 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
     {
         RescueJob &out = rb.jobs[j];
         out.pushes = pushes; out.fallback = fallback ? 1 : 0; out.candBase = candBase; out.nCands = fallback ? 0 : total;
-        atomicAdd(reinterpret_cast<unsigned long long *>(&counters->rescueCalls), 1ull);
-        atomicAdd(reinterpret_cast<unsigned long long *>(&counters->rescueWindowBases), static_cast<unsigned long long>(job.windowLen));
-        atomicAdd(reinterpret_cast<unsigned long long *>(&counters->rescueCandidates), static_cast<unsigned long long>(fallback ? 0 : total));
     }
 }
 
@@ -505,23 +583,28 @@ __global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference 
 }
 
 // one thread per rescue problem: which of its aligned candidates get a gapped retry (ShadowAligner.cpp:232-262)
-__global__ __launch_bounds__(256) void k_rescue_gapped_plan(const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb)
+__global__ __launch_bounds__(256) void k_rescue_gapped_plan(const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, Counters *counters)
 {
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     const u32 nJobs = imin(*rb.jobCounter, rb.jobsCap);
-    if (j >= nJobs) return;
-    RescueJob &job = rb.jobs[j];
-    if (!job.valid || job.fallback) return;
-    const u32 ecm = frags[job.cluster].endCyclesMasked[job.shadowReadIndex];
-    const u32 n = planRescueGapped(job, rb.shadowCands, rb.shadowCigars, ecm, nullptr);
-    u32 base = 0;
-    if (n)
+    Counters local; memset(&local, 0, sizeof(local));
+    if (j < nJobs && rb.jobs[j].valid && !rb.jobs[j].fallback)
     {
-        base = atomicAdd(gb.counter, n);
-        if (base + n > gb.cap) base = 0xffffffffu;     // the cluster's thread runs them itself
-        else planRescueGapped(job, rb.shadowCands, rb.shadowCigars, ecm, gb.jobs + base);
+        RescueJob &job = rb.jobs[j];
+        // the flat pass's rescue statistics are counted here, one wave reduction instead of one atomic per problem
+        ++local.rescueCalls; local.rescueWindowBases += job.windowLen; local.rescueCandidates += job.nCands;
+        const u32 ecm = frags[job.cluster].endCyclesMasked[job.shadowReadIndex];
+        const u32 n = planRescueGapped(job, rb.shadowCands, rb.shadowCigars, ecm, nullptr);
+        u32 base = 0;
+        if (n)
+        {
+            base = atomicAdd(gb.counter, n);
+            if (base + n > gb.cap) base = 0xffffffffu;     // the cluster's thread runs them itself
+            else planRescueGapped(job, rb.shadowCands, rb.shadowCigars, ecm, gb.jobs + base);
+        }
+        job.gappedBase = base; job.nGapped = n;
     }
-    job.gappedBase = base; job.nGapped = n;
+    flushCounters(local, counters);
 }
 
 // k_select: clusters [clusterBase, clusterBase + nChunk) with per-thread arenas of `arenaBytes`; clusters whose light work
@@ -1123,7 +1206,7 @@ int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, u
             }
             {
                 ScopedTimer tm(c, "rescue_windows");
-                k_rescue_windows<<<gridFor(rb.jobsCap, 4), 256, 0, st>>>(c->P, R, bcl, done, rb, c->counters.p);
+                k_rescue_windows<<<gridFor(rb.jobsCap, 4), 256, 0, st>>>(c->P, R, c->hContigOffset[c->nContigs], bcl, done, rb);
                 HIP_CHECK(hipGetLastError());
             }
             {
@@ -1133,7 +1216,7 @@ int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, u
             }
             {
                 ScopedTimer tm(c, "rescue_gapped_plan");
-                k_rescue_gapped_plan<<<gridFor(rb.jobsCap, 256), 256, 0, st>>>(c->frags.p, rb, gbRescue);
+                k_rescue_gapped_plan<<<gridFor(rb.jobsCap, 256), 256, 0, st>>>(c->frags.p, rb, gbRescue, c->counters.p);
                 HIP_CHECK(hipGetLastError());
             }
             launchGappedJobs(c, bcl, done, gbRescue, "gapped_rescue");
