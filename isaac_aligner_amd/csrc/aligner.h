@@ -6,6 +6,7 @@
 //   lib/alignment/Read.cpp:32-73, Quality.cpp:72-120, fragmentBuilder/AlignerBase.cpp:50-227, UngappedAligner.cpp:39-92,
 //   GappedAligner.cpp:51-82,167-249, BandedSmithWaterman.cpp:84-462, SimpleIndelAligner.cpp:50-518, FragmentBuilder.cpp:82-343
 #pragma once
+#include <cstring>
 #include "types.h"
 #include "sort.h"
 
@@ -77,16 +78,63 @@ ISAAC_HD void candResetAlignment(Cand &c, const CigarPool &pool)
     c.logProbability = 0.0; c.alignmentScore = 0xffffffffu; c.smithWatermanScore = 0;
 }
 
+// Sequential readers: the strand sequence of a read and the reference, 8 bytes per load instead of one.  A thread that
+// walks 150 bases is bound by the latency of its loads, not by their size.
+struct ReadStream
+{
+    const u8 *bcl; u32 length; bool reverse; u32 pos; u64 buf; u32 avail;
+    ISAAC_HD void init(const ReadView &r, bool rev, u32 start) { bcl = r.bcl; length = r.length; reverse = rev; pos = start; avail = 0; buf = 0; }
+    ISAAC_HD void refill()
+    {
+        const u32 left = pos < length ? length - pos : 0;
+        if (left >= 8) { memcpy(&buf, reverse ? bcl + (length - pos - 8) : bcl + pos, 8); avail = 8; }
+        else
+        {
+            buf = 0;
+            for (u32 k = 0; k < left; ++k) { const u64 b = reverse ? bcl[length - 1 - pos - k] : bcl[pos + k]; buf |= reverse ? b << (8 * (7 - k)) : b << (8 * k); }
+            avail = left ? left : 8;   // past the end (never for a valid CIGAR): zero bytes, i.e. 'n' with quality 2
+        }
+    }
+    // the BCL byte of the next strand position; reverse strand: the caller complements (strandBaseOf)
+    ISAAC_HD u8 next() { if (!avail) refill(); const u8 b = reverse ? u8(buf >> 56) : u8(buf); buf = reverse ? buf << 8 : buf >> 8; --avail; ++pos; return b; }
+    ISAAC_HD void skip(u32 n) { if (n < avail) { buf = reverse ? buf << (8 * n) : buf >> (8 * n); avail -= n; } else avail = 0; pos += n; }
+};
+ISAAC_HD char strandBaseOf(u8 b, bool reverse)
+{
+    if (!(b & 0xfc)) return 'n';
+    const u32 code = reverse ? (~u32(b)) & 3 : u32(b) & 3;
+    return char(0x54474341u >> (8 * code));
+}
+ISAAC_HD u32 qualityOf(u8 b) { return (b & 0xfc) ? u32(b >> 2) : 2u; }
+struct RefStream
+{
+    const char *p, *end; u64 buf; u32 avail;
+    ISAAC_HD void init(const char *at, const char *basesEnd) { p = at; end = basesEnd; avail = 0; buf = 0; }
+    ISAAC_HD char next()
+    {
+        if (!avail)
+        {
+            if (p + 8 <= end) { memcpy(&buf, p, 8); avail = 8; }
+            else { buf = 0; u32 k = 0; for (; p + k < end; ++k) buf |= u64(u8(p[k])) << (8 * k); avail = k ? k : 8; }
+        }
+        const char c = char(u8(buf)); buf >>= 8; --avail; ++p;
+        return c;
+    }
+    ISAAC_HD void skip(u32 n) { if (n < avail) { buf >>= 8 * n; avail -= n; } else avail = 0; p += n; }
+};
+
 // AlignerBase::updateFragmentCigar (AlignerBase.cpp:121-227).  logProbability is a running fp64 sum in base order: the
 // order of the additions is part of the result, so this loop is deliberately serial.
 ISAAC_HD u32 updateFragmentCigar(const DevParams &P, const DevReference &R, const ReadView &read, Cand &f, i64 strandPosition, const CigarPool &pool, u32 cigarOffset)
 {
     const bool reverse = f.reverse;
     const char *reference = R.bases + R.contigOffset[f.contigId];
-    const char *currentReference = reference + strandPosition;
     f.cigarOffset = cigarOffset;
     f.cigarLength = u16(pool.used - cigarOffset);
-    u32 currentBase = 0, matchCount = 0;
+    ReadStream rs; rs.init(read, reverse, 0);
+    RefStream fs; fs.init(reference + strandPosition, R.bases + R.totalBases);
+    u32 matchCount = 0;
+    i64 referenceAdvance = 0;
     double lp = f.logProbability;
     u32 mismatchCount = f.mismatchCount, best = f.matchesInARow, editDistance = f.editDistance, gapCount = f.gapCount, sws = f.smithWatermanScore;
     for (u32 i = 0; f.cigarLength > i; ++i)
@@ -98,9 +146,10 @@ ISAAC_HD u32 updateFragmentCigar(const DevParams &P, const DevReference &R, cons
             u32 matchesInARow = 0;
             for (u32 j = 0; length > j; ++j)
             {
-                const char s = strandBase(read, reverse, currentBase);
-                const u32 q = strandQuality(read, reverse, currentBase);
-                const char r = *currentReference;
+                const u8 b = rs.next();
+                const char s = strandBaseOf(b, reverse);
+                const u32 q = qualityOf(b);
+                const char r = fs.next();
                 if (isMatch(s, r)) { ++matchCount; ++matchesInARow; lp += R.logMatch[q]; }
                 else
                 {
@@ -108,29 +157,28 @@ ISAAC_HD u32 updateFragmentCigar(const DevParams &P, const DevReference &R, cons
                     ++mismatchCount; lp += R.logMismatch[q]; sws += P.normalizedMismatchScore;
                 }
                 if (s != r) ++editDistance;
-                ++currentReference; ++currentBase;
             }
+            referenceAdvance += length;
             best = imax(best, matchesInARow);
         }
         else if (OP_INSERT == op)
         {
-            currentBase += length; editDistance += length; ++gapCount;
+            rs.skip(length); editDistance += length; ++gapCount;
             sws += P.normalizedGapOpenScore + imin(P.normalizedMaxGapExtendScore, (length - 1) * P.normalizedGapExtendScore);
         }
         else if (OP_DELETE == op)
         {
-            currentReference += length; editDistance += length; ++gapCount;
+            fs.skip(length); referenceAdvance += length; editDistance += length; ++gapCount;
             sws += P.normalizedGapOpenScore + imin(P.normalizedMaxGapExtendScore, (length - 1) * P.normalizedGapExtendScore);
         }
         else // OP_SOFT_CLIP
         {
-            for (u32 j = 0; j < length; ++j) lp += R.logMatch[strandQuality(read, reverse, currentBase + j)];
-            currentBase += length;
+            for (u32 j = 0; j < length; ++j) lp += R.logMatch[qualityOf(rs.next())];
         }
     }
     f.logProbability = lp; f.mismatchCount = u16(mismatchCount); f.matchesInARow = u16(best); f.editDistance = u16(editDistance);
     f.gapCount = u16(gapCount); f.smithWatermanScore = sws;
-    f.observedLength = u32(currentReference - reference - strandPosition);
+    f.observedLength = u32(referenceAdvance);
     f.position = strandPosition;
     return matchCount;
 }

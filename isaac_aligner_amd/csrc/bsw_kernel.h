@@ -142,10 +142,14 @@ struct StrandQueryDev { ReadView read; bool reverse; u32 offset; __device__ char
 // GappedAligner::alignGapped (GappedAligner.cpp:167-249) for a list of candidates, 16 lanes per candidate: the statements of
 // alignGapped() in aligner.h with the DP on the group and everything else on its lane 0.  `bcl` is the tile, the job's
 // cluster index is relative to clusterBase.  Grid-stride over the jobs, so the launch does not need the job count on the host.
-__global__ __launch_bounds__(256) void k_gapped_jobs(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap,
+__global__ __launch_bounds__(256) void k_gapped_jobs(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap,
                                                     u32 maxReadLength, GappedResult *results)
 {
     extern __shared__ __align__(16) u8 lds[];
+    __shared__ double qualityTables[128];
+    for (u32 qi = threadIdx.x; qi < 128; qi += blockDim.x) qualityTables[qi] = qi < 64 ? Rg.logMatch[qi] : Rg.logMismatch[qi - 64];
+    __syncthreads();
+    DevReference R = Rg; R.logMatch = qualityTables; R.logMismatch = qualityTables + 64;
     const u32 group = threadIdx.x >> 4, k = threadIdx.x & 15;
     u8 *T = lds + group * bswGroupLdsBytes(maxReadLength);
     short *endVals = reinterpret_cast<short *>(T + ((maxReadLength * 16 + 15) & ~15u));

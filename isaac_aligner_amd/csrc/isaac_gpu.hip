@@ -66,7 +66,7 @@ struct isaac_gpu_ctx
     DevReference ref() const
     {
         DevReference r; std::memset(&r, 0, sizeof(r));
-        r.bases = bases; r.contigOffset = contigOffset.p; r.contigLoaded = contigLoaded.p; r.nContigs = nContigs;
+        r.bases = bases; r.totalBases = hContigOffset.empty() ? 0 : hContigOffset[nContigs]; r.contigOffset = contigOffset.p; r.contigLoaded = contigLoaded.p; r.nContigs = nContigs;
         r.kmers = kmers.p; r.positions = positions.p; r.nKmers = nKmers; r.karyotype = hasKaryotype ? karyotype.p : nullptr;
         r.logMatch = logTables.p; r.logMismatch = logTables.p + 100;
         return r;
@@ -242,12 +242,20 @@ __global__ void k_compact_matches(const Match *staging, const u32 *counts, const
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Quality::logMatchLookup / logMismatchLookup staged in LDS: every base of every alignment reads one of the two
+#define ISAAC_STAGE_QUALITY_TABLES(R_IN, R_OUT)                                                                              \
+    __shared__ double qualityTables[128];                                                                                    \
+    for (u32 qi = threadIdx.x; qi < 128; qi += blockDim.x) qualityTables[qi] = qi < 64 ? (R_IN).logMatch[qi] : (R_IN).logMismatch[qi - 64]; \
+    __syncthreads();                                                                                                         \
+    DevReference R_OUT = (R_IN); R_OUT.logMatch = qualityTables; R_OUT.logMismatch = qualityTables + 64;
+
 // the chunk's gapped (banded Smith-Waterman) problems: written by the per-cluster threads, run by k_gapped_jobs
 struct GappedBuffers { GappedJob *jobs; GappedResult *results; u32 cap; u32 *counter; u32 *base; };
 
-__global__ __launch_bounds__(64) void k_build_fragments(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, u32 nChunk, const Match *matches, const u64 *offsets,
+__global__ __launch_bounds__(64) void k_build_fragments(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, u32 nChunk, const Match *matches, const u64 *offsets,
                                                         int withGaps, int trim, FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters)
 {
+    ISAAC_STAGE_QUALITY_TABLES(Rg, R)
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     Counters local; memset(&local, 0, sizeof(local));
     if (t < nChunk)
@@ -568,8 +576,9 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
     }
 }
 
-__global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, const ClusterFragments *frags, RescueBuffers rb, Counters *counters)
+__global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const ClusterFragments *frags, RescueBuffers rb, Counters *counters)
 {
+    ISAAC_STAGE_QUALITY_TABLES(Rg, R)
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     const u32 n = imin(*rb.candCounter, rb.candCap);
     Counters local; memset(&local, 0, sizeof(local));

@@ -61,6 +61,7 @@ struct DevParams
 struct DevReference
 {
     const char *bases;        // all contigs, ASCII ACGTN, concatenated
+    u64 totalBases;           // contigOffset[nContigs]
     const u64 *contigOffset;  // n_contigs + 1
     const u8 *contigLoaded;   // MatchSelector.cpp:85-90: contigs without any seed match count as empty
     u32 nContigs;
