@@ -157,11 +157,11 @@ def main():
         # candidate records + gapped results in, consolidated candidate records out
         "finish_fragments": counters["candidates"] * 128 + counters["bsw_jobs"] * 232,
         # one pass over the aligned rescue candidates
-        "rescue_gapped_plan": counters["rescue_candidates"] * 64 + jobs * 56,
+        "rescue_gapped_plan": counters["rescue_candidates"] * 64 + jobs * 72,
         # candidate records in, rescue problems out
-        "plan_rescue": counters["candidates"] * 64 + jobs * 56,
+        "plan_rescue": counters["candidates"] * 64 + jobs * 72,
         # the mate's bases + the window bases in, candidate start positions out
-        "rescue_windows": jobs * (56 + L) + counters["rescue_window_bases"] + counters["rescue_candidates"] * 8,
+        "rescue_windows": jobs * (72 + L) + counters["rescue_window_bases"] + counters["rescue_candidates"] * 8,
         # per candidate start: the mate (L BCL bytes) + L reference bytes in, one candidate record + 3 cigar words out
         "rescue_align": counters["rescue_candidates"] * (2 * L + 64 + 12),
         # seeded + rescued candidate records in, 2 FragmentHeader records + cigars out

@@ -71,8 +71,9 @@ ISAAC_HD void templateCtxInit(TemplateCtx &x, const DevParams &P, const DevRefer
     x.P = &P; x.R = &R; x.tls = &tls; x.frags = &frags; x.w = &work; x.cnt = &cnt; x.clusterId = cluster;
     x.rogRead[0] = rog.read[0]; x.rogRead[1] = rog.read[1]; x.rog = rog.pair;
     x.rescueMode = RESCUE_SERIAL; x.jobNext = 0; x.jobCount = 0; x.jobs = 0; x.planWrite = false; x.serialFallbackAllowed = true;
-    x.candPositions = 0; x.shadowCands = 0; x.shadowCigars = 0; x.gappedResults = 0;
+    x.candPositions = 0; x.shadowCands = 0; x.shadowCigars = 0; x.gappedResults = 0; x.candRank = 0;
     x.lanes = 1; x.lane = 0; x.fastSort = false; x.ldsSort = 0; x.ldsSortCap = 0;
+    for (u32 i = 0; i < 8; ++i) x.prof[i] = 0;
     const u8 *clusterBcl = bcl + u64(cluster) * P.clusterLength;
     for (u32 r = 0; r < 2; ++r)
     {
@@ -114,7 +115,7 @@ ISAAC_HD void rescueAlignCandidate(const DevParams &P, const DevReference &R, co
 }
 
 // What the flat kernels hand to clusterSelect: the cluster's jobs and the aligned candidates of the chunk
-struct RescueInputs { RescueJob *jobs; u32 jobCount; const Cand *shadowCands; const u32 *shadowCigars; const GappedResult *gappedResults; bool serialFallbackAllowed; };
+struct RescueInputs { RescueJob *jobs; u32 jobCount; const Cand *shadowCands; const u32 *shadowCigars; const u32 *candRank; const GappedResult *gappedResults; bool serialFallbackAllowed; };
 // wave-cooperative execution (k_select_heavy) and the fast probability sort; see TemplateCtx
 struct CoopInputs { u32 lanes, lane; bool fastSort; u16 *ldsSort; u32 ldsSortCap; };
 
@@ -130,11 +131,18 @@ ISAAC_HD void clusterSelect(const DevParams &P, const DevReference &R, const Dev
     if (rescue)
     {
         x.rescueMode = RESCUE_LOOKUP; x.jobs = rescue->jobs; x.jobCount = rescue->jobCount; x.shadowCands = rescue->shadowCands; x.shadowCigars = rescue->shadowCigars;
-        x.gappedResults = rescue->gappedResults;
+        x.gappedResults = rescue->gappedResults; x.candRank = rescue->candRank;
         x.serialFallbackAllowed = rescue->serialFallbackAllowed;
     }
     BamTemplate t;
+    ISAAC_PROF_T0(x);
     const bool store = selectCluster(x, t, logMismatchQ40);
+    ISAAC_PROF_ADD(x, 6);
+#if defined(ISAAC_PROFILE_HEAVY) && defined(__HIP_DEVICE_COMPILE__)
+    if (coop && 0 == x.lane)
+        printf("heavy cluster %u jobs %u: copy %lld finish %lld push %lld sortS %lld sortP %lld sums %lld total %lld\n", cluster, x.jobCount,
+               x.prof[0], x.prof[1], x.prof[2], x.prof[3], x.prof[4], x.prof[5], x.prof[6]);
+#endif
     for (u32 i = 0; i < P.nReads; ++i)
     {
         FragmentRecord &r = records[u64(cluster) * P.nReads + i];

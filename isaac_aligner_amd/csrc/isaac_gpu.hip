@@ -56,7 +56,7 @@ struct isaac_gpu_ctx
     DevBuf<GappedJob> gappedJobs; DevBuf<GappedResult> gappedResults; DevBuf<u32> gappedBase, gappedCounters;
     DevBuf<u8> lightArena, heavyArena; DevBuf<u32> overflowList; DevBuf<u32> overflowCount;
     DevBuf<TlsSample> tlsSamples;
-    DevBuf<RescueJob> jobs; DevBuf<u32> rescueCounters, bitmaps, candJob, shadowCigars, jobBase, jobCount; DevBuf<i32> candPositions; DevBuf<Cand> shadowCands;
+    DevBuf<RescueJob> jobs; DevBuf<u32> rescueCounters, bitmaps, candJob, shadowCigars, jobBase, jobCount; DevBuf<i32> candPositions; DevBuf<Cand> shadowCands; DevBuf<u32> candRank;
     bool flatRescue = true;
     DevBuf<Counters> counters;
     std::map<std::string, KernelTimer> timers;
@@ -349,7 +349,7 @@ struct RescueBuffers
 {
     RescueJob *jobs; u32 jobsCap; u32 *jobCounter;
     u32 *bitmaps; u32 bitmapCap; u32 *bitmapCounter;
-    i32 *candPositions; u32 *candJob; Cand *shadowCands; u32 *shadowCigars; u32 candCap; u32 *candCounter;
+    i32 *candPositions; u32 *candJob; Cand *shadowCands; u32 *shadowCigars; u32 *candRank; u32 candCap; u32 *candCounter;
     u32 *jobBase; u32 *jobCount;   // per cluster of the chunk; jobBase == 0xffffffff: the cluster runs its rescues itself
 };
 
@@ -602,6 +602,7 @@ __global__ __launch_bounds__(256) void k_rescue_gapped_plan(const ClusterFragmen
         RescueJob &job = rb.jobs[j];
         // the flat pass's rescue statistics are counted here, one wave reduction instead of one atomic per problem
         ++local.rescueCalls; local.rescueWindowBases += job.windowLen; local.rescueCandidates += job.nCands;
+        summarizeRescueJob(job, rb.shadowCands, rb.candRank);
         const u32 ecm = frags[job.cluster].endCyclesMasked[job.shadowReadIndex];
         const u32 n = planRescueGapped(job, rb.shadowCands, rb.shadowCigars, ecm, nullptr);
         u32 base = 0;
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(64) void k_select(DevParams P, DevReference R, DevT
         RescueInputs in; const RescueInputs *pin = nullptr;
         if (rb.jobBase && rb.jobBase[inChunk] != 0xffffffffu)
         {
-            in.jobs = rb.jobs + rb.jobBase[inChunk]; in.jobCount = rb.jobCount[inChunk]; in.shadowCands = rb.shadowCands; in.shadowCigars = rb.shadowCigars;
+            in.jobs = rb.jobs + rb.jobBase[inChunk]; in.jobCount = rb.jobCount[inChunk]; in.shadowCands = rb.shadowCands; in.shadowCigars = rb.shadowCigars; in.candRank = rb.candRank;
             in.gappedResults = gappedResults; in.serialFallbackAllowed = list != nullptr;
             pin = &in;
         }
@@ -664,7 +665,7 @@ __global__ __launch_bounds__(64) void k_select_heavy(DevParams P, DevReference R
     RescueInputs in; const RescueInputs *pin = nullptr;
     if (rb.jobBase && rb.jobBase[inChunk] != 0xffffffffu)
     {
-        in.jobs = rb.jobs + rb.jobBase[inChunk]; in.jobCount = rb.jobCount[inChunk]; in.shadowCands = rb.shadowCands; in.shadowCigars = rb.shadowCigars;
+        in.jobs = rb.jobs + rb.jobBase[inChunk]; in.jobCount = rb.jobCount[inChunk]; in.shadowCands = rb.shadowCands; in.shadowCigars = rb.shadowCigars; in.candRank = rb.candRank;
         in.gappedResults = gappedResults; in.serialFallbackAllowed = true;
         pin = &in;
     }
@@ -1193,8 +1194,8 @@ int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, u
     {
         rb.jobsCap = 4 * chunk; rb.bitmapCap = 64 * rb.jobsCap; rb.candCap = 24 * chunk;
         c->jobs.reserve(rb.jobsCap); c->bitmaps.reserve(rb.bitmapCap); c->candPositions.reserve(rb.candCap); c->candJob.reserve(rb.candCap);
-        c->shadowCands.reserve(rb.candCap); c->shadowCigars.reserve(size_t(rb.candCap) * 3); c->jobBase.reserve(chunk); c->jobCount.reserve(chunk); c->rescueCounters.reserve(4);
-        rb.jobs = c->jobs.p; rb.bitmaps = c->bitmaps.p; rb.candPositions = c->candPositions.p; rb.candJob = c->candJob.p; rb.shadowCands = c->shadowCands.p;
+        c->shadowCands.reserve(rb.candCap); c->candRank.reserve(rb.candCap); c->shadowCigars.reserve(size_t(rb.candCap) * 3); c->jobBase.reserve(chunk); c->jobCount.reserve(chunk); c->rescueCounters.reserve(4);
+        rb.jobs = c->jobs.p; rb.bitmaps = c->bitmaps.p; rb.candPositions = c->candPositions.p; rb.candJob = c->candJob.p; rb.shadowCands = c->shadowCands.p; rb.candRank = c->candRank.p;
         rb.shadowCigars = c->shadowCigars.p; rb.jobBase = c->jobBase.p; rb.jobCount = c->jobCount.p;
         rb.jobCounter = c->rescueCounters.p; rb.bitmapCounter = c->rescueCounters.p + 1; rb.candCounter = c->rescueCounters.p + 2;
     }

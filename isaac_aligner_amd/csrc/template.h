@@ -221,9 +221,11 @@ struct RescueJob
     u32 bitmapBase, bitmapWords;
     u8 shadowReadIndex, shadowReverse, valid, fallback;   // fallback: redo this job serially (capacity exceeded)
     u32 gappedBase, nGapped; // the job's gapped retries in the chunk's GappedResult array; gappedBase 0xffffffff: run them serially
+    u32 nAligned, bestRank, bestSlot, lastAligned;   // summarizeRescueJob: aligned candidates, the best of them, "the last candidate aligned"
     u32 pad;
 };
-static_assert(sizeof(RescueJob) == 56, "RescueJob layout");
+static_assert(sizeof(RescueJob) == 72, "RescueJob layout");
+static const u32 SHADOW_LIST_MAX = 1000;          // ShadowAligner.hh: shadowList_ capacity, TemplateBuilder.hh:TRACKED_REPEATS_MAX_ONE_READ
 enum { RESCUE_SERIAL = 0, RESCUE_PLAN = 1, RESCUE_LOOKUP = 2 };
 static const u32 SHADOW_POSITIONS_MAX = 10000;   // ShadowAligner.hh:91
 
@@ -233,6 +235,7 @@ struct TemplateCtx
     u32 rescueMode; u32 jobNext, jobCount; RescueJob *jobs; bool planWrite; bool serialFallbackAllowed;
     const i32 *candPositions; const Cand *shadowCands; const u32 *shadowCigars;   // RESCUE_LOOKUP inputs
     const GappedResult *gappedResults;                                            // RESCUE_LOOKUP: the chunk's gapped retries, or NULL
+    const u32 *candRank;                                                          // RESCUE_LOOKUP: aligned candidates before each slot (summarizeRescueJob)
     ReadView reads[2];
     const ClusterFragments *frags;
     TemplateWork *w;
@@ -243,7 +246,17 @@ struct TemplateCtx
     // loops are strided by `lane`.  lanes == 1: plain thread-serial execution.  fastSort: large probability lists are sorted by a
     // total order that refines the reference's comparators, with the exact std::sort replica as fallback for ambiguous data.
     u32 lanes, lane; bool fastSort; u16 *ldsSort; u32 ldsSortCap;
+    long long prof[8];
 };
+
+// optional section timers of the heavy path (-DISAAC_PROFILE_HEAVY): shader clock ticks per section, printed per cluster
+#if defined(ISAAC_PROFILE_HEAVY) && defined(__HIP_DEVICE_COMPILE__)
+#define ISAAC_PROF_T0(x) const long long prof_t0 = clock64()
+#define ISAAC_PROF_ADD(x, slot) (x).prof[slot] += clock64() - prof_t0
+#else
+#define ISAAC_PROF_T0(x)
+#define ISAAC_PROF_ADD(x, slot)
+#endif
 
 // wave-level helpers of the cooperative form; identities in the thread-serial form
 ISAAC_HD bool coopAny(const TemplateCtx &x, bool v)
@@ -416,7 +429,7 @@ ISAAC_HD void calculateShadowRescueRange(const TemplateCtx &x, const Cand &orpha
 ISAAC_HD bool planRescue(const TemplateCtx &x, const Cand &orphan, i64 bestTemplateLength, RescueJob &job)
 {
     job.windowBegin = 0; job.windowLen = 0; job.cluster = x.clusterId; job.contigId = orphan.contigId; job.candBase = 0; job.nCands = 0; job.pushes = 0;
-    job.bitmapBase = 0; job.bitmapWords = 0; job.valid = 0; job.fallback = 0; job.gappedBase = 0xffffffffu; job.nGapped = 0; job.pad = 0;
+    job.bitmapBase = 0; job.bitmapWords = 0; job.valid = 0; job.fallback = 0; job.gappedBase = 0xffffffffu; job.nGapped = 0; job.nAligned = 0; job.bestRank = 0; job.bestSlot = 0; job.lastAligned = 0; job.pad = 0;
     job.shadowReadIndex = u8((orphan.readIndex + 1) % 2);
     job.shadowReverse = 0;
     if (!tlsIsCoherent(*x.tls)) return false;
@@ -440,6 +453,7 @@ ISAAC_HD bool finishRescue(TemplateCtx &x, CigarPool &pool, i32 best, const Gapp
     TemplateWork &w = *x.w;
     const DevParams &P = *x.P; const DevReference &R = *x.R;
     if (best < 0) { if (pool.overflow) w.overflow = 1; return false; }
+    ISAAC_PROF_T0(x);
     const ReadView &shadowRead = x.reads[w.shadowList[0].readIndex];
     if (BSW_MISMATCHES_CUTOFF < w.shadowList[best].mismatchCount)
     {
@@ -473,6 +487,7 @@ ISAAC_HD bool finishRescue(TemplateCtx &x, CigarPool &pool, i32 best, const Gapp
     }
     if (pool.overflow) w.overflow = 1;
     if (best != 0) { const Cand t = w.shadowList[0]; w.shadowList[0] = w.shadowList[best]; w.shadowList[best] = t; }
+    ISAAC_PROF_ADD(x, 1);
     return true;
 }
 
@@ -489,7 +504,7 @@ ISAAC_HD bool shadowRescueSerial(TemplateCtx &x, const Cand &orphan, const Rescu
     i32 best = -1;
     for (u32 c = 0; c < nPositions; ++c)
     {
-        if (w.nShadows == w.caps.shadow) { w.overflow = 1; return false; } // reference: capacity 1000 -> return false
+        if (w.nShadows == w.caps.shadow) { if (w.caps.shadow < SHADOW_LIST_MAX) w.overflow = 1; return false; } // reference: capacity 1000 -> return false
         Cand &fragment = w.shadowList[w.nShadows];
         candInit(fragment, job.shadowReadIndex);
         fragment.reverse = job.shadowReverse; fragment.contigId = orphan.contigId;
@@ -508,26 +523,58 @@ ISAAC_HD bool shadowRescueSerial(TemplateCtx &x, const Cand &orphan, const Rescu
 ISAAC_HD bool shadowRescueLookup(TemplateCtx &x, const Cand &orphan, const RescueJob &job)
 {
     TemplateWork &w = *x.w;
-    if (job.fallback)
+    if (job.fallback || (job.nGapped && (0xffffffffu == job.gappedBase || !x.gappedResults)))
     {   // a capacity of the flat pass was exceeded for this job: exact serial path, which needs the reference-sized lists
         if (!x.serialFallbackAllowed) { w.overflow = 1; return false; }
         return shadowRescueSerial(x, orphan, job);
     }
     CigarPool pool; pool.words = w.shadowCigar; pool.used = 0; pool.capacity = w.caps.shadowCigar; pool.overflow = 0;
+    ISAAC_PROF_T0(x);
+    // The reference appends the aligned candidates one by one and gives up ("return false", list kept) when the list is full
+    // and another candidate turns up.  With the ranks known (summarizeRescueJob) the copies are independent of each other.
+    const u32 K = w.caps.shadow;
+    const bool full = job.nAligned - job.lastAligned >= K && job.nCands != 0;
+    const u32 take = imin(job.nAligned, K);
+    for (u32 c = x.lane; c < job.nCands; c += x.lanes)
+    {
+        const u32 slot = job.candBase + c;
+        const u32 rank = x.candRank[slot];
+        const Cand &src = x.shadowCands[slot];
+        if (rank >= take || !candAligned(src)) continue;
+        Cand &fragment = w.shadowList[rank];
+        fragment = src;
+        fragment.cigarOffset = 0; fragment.cigarLength = src.cigarLength;   // only the best shadow's CIGAR is ever read: it is put in place below
+    }
+    coopSync(x);
+    w.nShadows = take;
+    if (full) { if (K < SHADOW_LIST_MAX) w.overflow = 1; ISAAC_PROF_ADD(x, 0); return false; }
     i32 best = -1;
+    if (job.nAligned)
+    {
+        best = i32(job.bestRank);
+        Cand &b = w.shadowList[best];
+        b.cigarOffset = pool.used;
+        for (u32 k = 0; k < b.cigarLength; ++k) pool.push(x.shadowCigars[u64(job.bestSlot) * 3 + k]);
+    }
+    ISAAC_PROF_ADD(x, 0);
+    return finishRescue(x, pool, best, job.nGapped ? x.gappedResults + job.gappedBase : 0);
+}
+
+// One pass over a job's aligned candidates (in candidate order): how many there are before each slot, which is the best
+// (the running choice of ShadowAligner.cpp:216-230) and whether the last candidate aligned.
+ISAAC_HD void summarizeRescueJob(RescueJob &job, const Cand *shadowCands, u32 *candRank)
+{
+    u32 n = 0; i32 best = -1; u32 bestRank = 0; bool last = false;
     for (u32 c = 0; c < job.nCands; ++c)
     {
-        if (w.nShadows == w.caps.shadow) { w.overflow = 1; return false; }
-        const Cand &src = x.shadowCands[job.candBase + c];
-        if (!candAligned(src)) continue;
-        Cand &fragment = w.shadowList[w.nShadows];
-        fragment = src;
-        fragment.cigarOffset = pool.used;
-        for (u32 k = 0; k < src.cigarLength; ++k) pool.push(x.shadowCigars[u64(job.candBase + c) * 3 + k]);
-        if (best < 0 || lpLess(w.shadowList[best].logProbability, fragment.logProbability)) best = i32(w.nShadows);
-        ++w.nShadows;
+        const Cand &f = shadowCands[job.candBase + c];
+        candRank[job.candBase + c] = n;
+        last = candAligned(f);
+        if (!last) continue;
+        if (best < 0 || lpLess(shadowCands[job.candBase + best].logProbability, f.logProbability)) { best = i32(c); bestRank = n; }
+        ++n;
     }
-    return finishRescue(x, pool, best, (0xffffffffu != job.gappedBase && x.gappedResults) ? x.gappedResults + job.gappedBase : 0);
+    job.nAligned = n; job.bestRank = bestRank; job.bestSlot = best < 0 ? 0 : job.candBase + u32(best); job.lastAligned = last ? 1 : 0;
 }
 
 // Which shadows of a job ShadowAligner.cpp:232-262 hands to the gapped aligner.  The choice reads only the ungapped results
@@ -741,6 +788,7 @@ ISAAC_HD double sumUniqueShadowProbabilities(TemplateCtx &x, u32 side)
     TemplateWork &w = *x.w;
     const u32 n = w.nShadowProbs[side]; const ShadowProb *v = w.shadowProbs[side];
     bool exact = true;
+    ISAAC_PROF_T0(x);
     if (x.fastSort && n >= FAST_SORT_MIN)
     {
         for (u32 i = x.lane; i < n; i += x.lanes) w.sortIdx[i] = u16(i);
@@ -751,7 +799,13 @@ ISAAC_HD double sumUniqueShadowProbabilities(TemplateCtx &x, u32 side)
         for (u32 i = 1 + x.lane; i < n; i += x.lanes)
         {
             const ShadowProb &a = v[w.sortIdx[i - 1]], &b = v[w.sortIdx[i]];
-            if (a.pos == b.pos && a.logProbability != b.logProbability && lpEquals(a.logProbability, b.logProbability)) nearTie = true;
+            if (a.pos == b.pos && a.logProbability != b.logProbability && lpEquals(a.logProbability, b.logProbability))
+            {
+                nearTie = true;
+#if defined(ISAAC_DEBUG_NEARTIE) && !defined(__HIP_DEVICE_COMPILE__)
+                printf("near tie cluster %u n %u: pos %llu lp %.17g %.17g obs %lld %lld\n", x.clusterId, n, (unsigned long long)a.pos, a.logProbability, b.logProbability, (long long)a.observedLength, (long long)b.observedLength);
+#endif
+            }
         }
         exact = coopAny(x, nearTie);
     }
@@ -761,6 +815,7 @@ ISAAC_HD double sumUniqueShadowProbabilities(TemplateCtx &x, u32 side)
         ShadowProbIdxLess less; less.v = v;
         exactSort(w.sortIdx, i32(n), less);
     }
+    ISAAC_PROF_ADD(x, 3);
     double ret = 0.0;
     for (u32 i = 0; i < n;)
     {
@@ -769,6 +824,7 @@ ISAAC_HD double sumUniqueShadowProbabilities(TemplateCtx &x, u32 side)
         while (j < n && shadowProbEqual(v[w.sortIdx[i]], v[w.sortIdx[j]])) ++j;
         i = j;
     }
+    ISAAC_PROF_ADD(x, 5);
     return ret;
 }
 ISAAC_HD double sumUniquePairProbabilities(TemplateCtx &x)
@@ -776,6 +832,7 @@ ISAAC_HD double sumUniquePairProbabilities(TemplateCtx &x)
     TemplateWork &w = *x.w;
     const u32 n = w.nPairProbs; const PairProb *v = w.pairProbs;
     bool exact = true;
+    ISAAC_PROF_T0(x);
     if (x.fastSort && n >= FAST_SORT_MIN)
     {
         for (u32 i = x.lane; i < n; i += x.lanes) w.sortIdx[i] = u16(i);
@@ -797,6 +854,7 @@ ISAAC_HD double sumUniquePairProbabilities(TemplateCtx &x)
         PairProbIdxLess less; less.v = v;
         exactSort(w.sortIdx, i32(n), less);
     }
+    ISAAC_PROF_ADD(x, 4);
     double ret = 0.0;
     for (u32 i = 0; i < n;)
     {
@@ -849,10 +907,14 @@ ISAAC_HD bool templateRescueShadow(TemplateCtx &x, BamTemplate &t, double logMis
                 ++bestPair.resolvedTemplateCount;
             }
         }
-        for (u32 s = 0; s < w.nShadows; ++s)
         {
-            pushShadowProb(w, orphanIndex, w.shadowList[s]);
-            bestPair.totalTemplateProbability += exp(orphan.logProbability + w.shadowList[s].logProbability);
+            const u32 probBase = w.nShadowProbs[orphanIndex], probRoom = w.caps.prob - probBase;
+            for (u32 s = x.lane; s < w.nShadows; s += x.lanes) if (s < probRoom) w.shadowProbs[orphanIndex][probBase + s] = makeShadowProb(w.shadowList[s]);
+            coopSync(x);
+            if (w.nShadows > probRoom) w.overflow = 1;
+            w.nShadowProbs[orphanIndex] = probBase + imin(w.nShadows, probRoom);
+            // a running fp64 sum in list order: the order of the additions is part of the result
+            for (u32 s = 0; s < w.nShadows; ++s) bestPair.totalTemplateProbability += exp(orphan.logProbability + w.shadowList[s].logProbability);
         }
     }
     const double totalShadowProbability = (0 < bestPair.resolvedTemplateCount) ? sumUniqueShadowProbabilities(x, orphanIndex) : 0.0;
@@ -1028,17 +1090,26 @@ ISAAC_HD bool buildDisjoinedTemplate(TemplateCtx &x, BamTemplate &t, const BestP
                     ++bestOrphans.resolvedTemplateCount;
                 }
             }
-            for (u32 s = 0; s < w.nShadows; ++s)
-            {
-                const Cand &shadow = w.shadowList[s];
-                if (w.nPairProbs < w.caps.pair)
+            ISAAC_PROF_T0(x);
+            {   // every shadow contributes one pair and one shadow probability entry; the entries are independent of each other
+                const u32 pairBase = w.nPairProbs, pairRoom = w.caps.pair - pairBase;
+                const u32 probBase = w.nShadowProbs[orphanIndex], probRoom = w.caps.prob - probBase;
+                for (u32 s = x.lane; s < w.nShadows; s += x.lanes)
                 {
-                    PairProb &pp = w.pairProbs[w.nPairProbs++];
-                    pp.r1 = makeShadowProb(0 == orphanIndex ? orphan : shadow); pp.r2 = makeShadowProb(0 == orphanIndex ? shadow : orphan);
+                    const Cand &shadow = w.shadowList[s];
+                    if (s < pairRoom)
+                    {
+                        PairProb &pp = w.pairProbs[pairBase + s];
+                        pp.r1 = makeShadowProb(0 == orphanIndex ? orphan : shadow); pp.r2 = makeShadowProb(0 == orphanIndex ? shadow : orphan);
+                    }
+                    if (s < probRoom) w.shadowProbs[orphanIndex][probBase + s] = makeShadowProb(shadow);
                 }
-                else w.overflow = 1;
-                pushShadowProb(w, orphanIndex, shadow);
+                coopSync(x);
+                if (w.nShadows > pairRoom || w.nShadows > probRoom) w.overflow = 1;
+                w.nPairProbs = pairBase + imin(w.nShadows, pairRoom);
+                w.nShadowProbs[orphanIndex] = probBase + imin(w.nShadows, probRoom);
             }
+            ISAAC_PROF_ADD(x, 2);
         }
     }
     const u32 bestShadowIndex = (bestOrphanIndex + 1) % 2;

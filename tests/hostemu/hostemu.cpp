@@ -191,7 +191,7 @@ int emu_select(Emu *e, const u8 *bcl, u32 nClusters, u32 tile, const isaac_tls *
             ++e->cnt.ungappedScans;
         }
     // k_rescue_gapped_plan + k_gapped_jobs
-    std::vector<GappedResult> gapped;
+    std::vector<GappedResult> gapped; std::vector<u32> candRank(shadowCands.size() + 1);
     {
         std::vector<u32> tflags(3 * 512);
         std::vector<GappedJob> gj;
@@ -200,6 +200,7 @@ int emu_select(Emu *e, const u8 *bcl, u32 nClusters, u32 tile, const isaac_tls *
             RescueJob &job = jobs[j];
             if (!job.valid || job.fallback) continue;
             const u32 ecm = e->frags[job.cluster].endCyclesMasked[job.shadowReadIndex];
+            summarizeRescueJob(job, shadowCands.data(), candRank.data());
             const u32 n = planRescueGapped(job, shadowCands.data(), shadowCigars.data(), ecm, 0);
             job.gappedBase = u32(gj.size()); job.nGapped = n;
             gj.resize(gj.size() + n);
@@ -215,7 +216,7 @@ int emu_select(Emu *e, const u8 *bcl, u32 nClusters, u32 tile, const isaac_tls *
         {
             if (tier && !(recs[u64(c) * e->P.nReads].reserved & RECORD_TEMPLATE_OVERFLOW)) continue;
             RescueInputs in; in.jobs = jobs.data() + jobBase[c]; in.jobCount = jobBase[c + 1] - jobBase[c]; in.shadowCands = shadowCands.data(); in.shadowCigars = shadowCigars.data();
-            in.gappedResults = gapped.data();
+            in.gappedResults = gapped.data(); in.candRank = candRank.data();
             const auto t0 = std::chrono::steady_clock::now();
             in.serialFallbackAllowed = tier != 0;
             CoopInputs coop; coop.lanes = 1; coop.lane = 0; coop.fastSort = e->fastSort && tier; coop.ldsSort = 0; coop.ldsSortCap = 0;
