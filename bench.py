@@ -43,7 +43,7 @@ def parse():
 
 def main():
     args = parse()
-    from isaac_aligner_amd import abi, gpu, options, synth
+    from isaac_aligner_amd import abi, gpu, options, shard, synth
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -76,11 +76,7 @@ def main():
     cigars = torch.empty(n_rec * abi.MAX_CIGAR_OPS, dtype=torch.int32, device=dev)   # reused: only the records are gathered
 
     def reduce_hits(h):
-        if dist is None:
-            return h
-        t = torch.from_numpy(h.astype(np.int32)).to(dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return t.cpu().numpy().astype(np.uint8)
+        return shard.reduce_contig_hits(h, dist, dev)
 
     # ---- warm-up: also learns the template length statistics from the first batch (as tile 1 of the reference does) ---
     tls = None
@@ -94,12 +90,7 @@ def main():
         m, o, hits = al.find_matches(batches[0])
         al.set_loaded_contigs(reduce_hits(hits))
         tls = al.determine_tls(batches[0], m, o)
-    if dist is not None:   # rank 0's statistics are the run's statistics
-        t = torch.tensor(list(tls.astuple()), dtype=torch.int64, device=dev)
-        dist.broadcast(t, 0)
-        v = t.cpu().tolist()
-        tls.min, tls.max, tls.median, tls.low_std_dev, tls.high_std_dev = v[0:5]
-        tls.best_model[0], tls.best_model[1], tls.stable, tls.mate_min, tls.mate_max = v[5:10]
+    shard.broadcast_tls(tls, dist, dev)   # rank 0's statistics are the run's statistics
     al.reset_timers()
 
     # ---- timed region: exactly K steps ---------------------------------------------------------------------------------
@@ -118,9 +109,7 @@ def main():
         m, o = found[s]
         al.select(batches[args.warmup + s], m, o, tls, out=(records[s], cigars))
     if dist is not None:                              # single gather of the per-GPU records at the end
-        mine = torch.cat(records)
-        gathered = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
-        dist.gather(mine, gathered, dst=0)
+        shard.gather_records(torch.cat(records), dist, rank, world)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

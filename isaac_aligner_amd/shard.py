@@ -1,0 +1,69 @@
+"""Read-sharded multi-GPU execution of the path: one process per GPU, every rank aligns its own clusters.
+
+The reference shards the same way inside one process (FindMatchesTransition / SelectMatchesTransition hand tiles to worker
+threads; MatchSelector::parallelSelect, lib/alignment/MatchSelector.cpp:372-460): clusters are independent once three pieces
+of run-wide state are fixed, and those are the only things the ranks exchange:
+
+  * the set of contigs that received any seed match (MatchSelector.cpp:85-90 loads only those; the rest-of-genome
+    correction depends on it): OR over the ranks                      -> all_reduce(MAX)
+  * the template length statistics, learnt from the first tile only (MatchSelector.cpp:402-417)  -> broadcast from rank 0
+  * the FragmentHeader records, collected once at the end             -> gather to rank 0, rank order = cluster order
+
+No collective sits on the per-cluster data path.  `dist` is torch.distributed (backend "nccl" = RCCL on the GPUs, "gloo" in
+the CPU tests) or None for a single process.
+"""
+import numpy as np
+import torch
+
+
+def shard_bounds(n_items, rank, world):
+    """contiguous static shard [begin, end) of n_items for this rank (sizes differ by at most one)"""
+    base, extra = divmod(int(n_items), int(world))
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def reduce_contig_hits(hits, dist, device="cpu"):
+    """OR of the per-contig hit flags over all ranks"""
+    h = np.ascontiguousarray(hits, np.uint8)
+    if dist is None:
+        return h
+    t = torch.from_numpy(h.astype(np.int32)).to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.cpu().numpy().astype(np.uint8)
+
+
+TLS_FIELDS = ("min", "max", "median", "low_std_dev", "high_std_dev")
+
+
+def broadcast_tls(tls, dist, device="cpu", src=0):
+    """rank `src`'s template length statistics become everybody's (in place); tls: abi.Tls-like ctypes structure"""
+    if dist is None:
+        return tls
+    t = torch.tensor([int(v) for v in tls.astuple()], dtype=torch.int64, device=device)
+    dist.broadcast(t, src)
+    v = t.cpu().tolist()
+    tls.min, tls.max, tls.median, tls.low_std_dev, tls.high_std_dev = v[0:5]
+    tls.best_model[0], tls.best_model[1], tls.stable, tls.mate_min, tls.mate_max = v[5:10]
+    return tls
+
+
+def gather_records(records, dist, rank, world, dst=0):
+    """records: (n, record_bytes) uint8 tensor of this rank; returns the list of all ranks' tensors on `dst`, else None.
+    Shards may differ in size by one cluster: sizes are exchanged first and the payload is padded for the gather."""
+    if dist is None:
+        return [records]
+    n = torch.tensor([records.shape[0]], dtype=torch.int64, device=records.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    width = max(sizes)
+    mine = records
+    if records.shape[0] < width:
+        mine = torch.zeros((width,) + tuple(records.shape[1:]), dtype=records.dtype, device=records.device)
+        mine[:records.shape[0]] = records
+    out = [torch.empty_like(mine) for _ in range(world)] if rank == dst else None
+    dist.gather(mine, out, dst=dst)
+    if rank != dst:
+        return None
+    return [t[:s] for t, s in zip(out, sizes)]
