@@ -18,8 +18,10 @@ def is_stale():
 def build(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
+    # -amdgpu-function-calls=false: everything is inlined into the kernels, so that their occupancy targets
+    # (amdgpu_waves_per_eu in isaac_gpu.hip) bind the whole call tree and not just the kernel body
     cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wno-unused-value",
-           "-I", CSRC, "-o", LIB, os.path.join(CSRC, "isaac_gpu.hip")]
+           "-mllvm", "-amdgpu-function-calls=false", "-I", CSRC, "-o", LIB, os.path.join(CSRC, "isaac_gpu.hip")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -21,6 +21,14 @@
 #include "host_util.h"
 #include "bsw_kernel.h"
 
+// occupancy targets (waves per SIMD) of the two thread-per-cluster kernels; the register allocator spills to meet them
+#ifndef ISAAC_SELECT_WAVES
+#define ISAAC_SELECT_WAVES 4
+#endif
+#ifndef ISAAC_FRAGMENT_WAVES
+#define ISAAC_FRAGMENT_WAVES 6
+#endif
+
 using namespace isaac;
 
 namespace
@@ -60,7 +68,10 @@ struct isaac_gpu_ctx
     bool flatRescue = true;
     DevBuf<Counters> counters;
     std::map<std::string, KernelTimer> timers;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    struct PendingTimer { std::string name; hipEvent_t e0, e1; };
+    std::vector<PendingTimer> pendingTimers; std::vector<hipEvent_t> eventPool;
+    hipStream_t heavyStream = nullptr; hipEvent_t evPredicted = nullptr, evHeavyDone = nullptr;
+    DevBuf<u32> heavyList, heavyCount; DevBuf<u8> heavyFlag;
     u32 chunkClusters = 524288;
 
     DevReference ref() const
@@ -75,18 +86,32 @@ struct isaac_gpu_ctx
 
 namespace
 {
-// times one kernel launch sequence with HIP events on the context's stream
+// times one kernel launch sequence with HIP events on the stream it is launched on.  The events are only read when the
+// timers are queried (resolveTimers), so timing does not put a host synchronisation between the launches.
+static hipEvent_t takeEvent(isaac_gpu_ctx *c)
+{
+    if (!c->eventPool.empty()) { hipEvent_t e = c->eventPool.back(); c->eventPool.pop_back(); return e; }
+    hipEvent_t e = nullptr; hipEventCreate(&e); return e;
+}
+static void resolveTimers(isaac_gpu_ctx *c);
 struct ScopedTimer
 {
-    isaac_gpu_ctx *c; const char *name;
-    ScopedTimer(isaac_gpu_ctx *ctx, const char *n) : c(ctx), name(n) { hipEventRecord(c->ev0, c->stream); }
-    ~ScopedTimer()
-    {
-        hipEventRecord(c->ev1, c->stream); hipEventSynchronize(c->ev1);
-        float ms = 0; hipEventElapsedTime(&ms, c->ev0, c->ev1);
-        KernelTimer &t = c->timers[name]; t.ms += ms; ++t.launches;
-    }
+    isaac_gpu_ctx *c; const char *name; hipStream_t st; hipEvent_t e0, e1;
+    ScopedTimer(isaac_gpu_ctx *ctx, const char *n, hipStream_t stream = nullptr) : c(ctx), name(n), st(stream ? stream : ctx->stream)
+    { e0 = takeEvent(c); e1 = takeEvent(c); hipEventRecord(e0, st); }
+    ~ScopedTimer() { hipEventRecord(e1, st); c->pendingTimers.push_back({name, e0, e1}); if (c->pendingTimers.size() > 4096) resolveTimers(c); }
 };
+static void resolveTimers(isaac_gpu_ctx *c)
+{
+    for (auto &p : c->pendingTimers)
+    {
+        hipEventSynchronize(p.e1);
+        float ms = 0; hipEventElapsedTime(&ms, p.e0, p.e1);
+        KernelTimer &t = c->timers[p.name]; t.ms += ms; ++t.launches;
+        c->eventPool.push_back(p.e0); c->eventPool.push_back(p.e1);
+    }
+    c->pendingTimers.clear();
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // wave-level reduction of the work counters, one atomic per field per wave
@@ -252,7 +277,7 @@ __global__ void k_compact_matches(const Match *staging, const u32 *counts, const
 // the chunk's gapped (banded Smith-Waterman) problems: written by the per-cluster threads, run by k_gapped_jobs
 struct GappedBuffers { GappedJob *jobs; GappedResult *results; u32 cap; u32 *counter; u32 *base; };
 
-__global__ __launch_bounds__(64) void k_build_fragments(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, u32 nChunk, const Match *matches, const u64 *offsets,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_build_fragments(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, u32 nChunk, const Match *matches, const u64 *offsets,
                                                         int withGaps, int trim, FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters)
 {
     ISAAC_STAGE_QUALITY_TABLES(Rg, R)
@@ -617,15 +642,41 @@ __global__ __launch_bounds__(256) void k_rescue_gapped_plan(const ClusterFragmen
     flushCounters(local, counters);
 }
 
+// Which clusters cannot fit the light work lists of k_select: known from the rescue summaries before k_select runs, so the
+// wave-per-cluster pass can start at the same time on its own stream.  The test is a superset of the real overflow
+// conditions (a cluster sent here needlessly is still processed exactly); what it misses, k_select reports afterwards.
+__global__ __launch_bounds__(256) void k_predict_heavy(const ClusterFragments *frags, u32 nChunk, RescueBuffers rb, TemplateCaps light, u8 *heavyFlag, u32 *heavyList, u32 *heavyCount)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nChunk) return;
+    bool heavy = false;
+    if (rb.jobBase[t] != 0xffffffffu)
+    {
+        const RescueJob *jobs = rb.jobs + rb.jobBase[t];
+        const u32 n = rb.jobCount[t];
+        u32 total = 0;
+        for (u32 j = 0; j < n; ++j)
+        {
+            if (!jobs[j].valid) continue;
+            if (jobs[j].fallback || jobs[j].nAligned >= light.shadow) heavy = true;
+            total += jobs[j].nAligned;
+        }
+        const u32 seeded = frags[t].nCands[0] + frags[t].nCands[1];
+        if (total + seeded > light.prob || total > light.pair) heavy = true;
+    }
+    heavyFlag[t] = heavy ? 1 : 0;
+    if (heavy) heavyList[atomicAdd(heavyCount, 1u)] = t;
+}
+
 // k_select: clusters [clusterBase, clusterBase + nChunk) with per-thread arenas of `arenaBytes`; clusters whose light work
 // lists overflow are appended to overflowList.  With `list` given, thread t redoes cluster list[t] (heavy capacities).
-__global__ __launch_bounds__(64) void k_select(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk, u32 tile,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_SELECT_WAVES))) void k_select(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk, u32 tile,
                                                const ClusterFragments *frags, u8 *arena, u64 arenaBytes, TemplateCaps caps, const u32 *list, RescueBuffers rb, const GappedResult *gappedResults,
-                                               FragmentRecord *records, u32 *cigars, u32 *overflowList, u32 *overflowCount, u32 overflowCapacity, Counters *counters)
+                                               FragmentRecord *records, u32 *cigars, u32 *overflowList, u32 *overflowCount, u32 overflowCapacity, const u8 *skip, Counters *counters)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     Counters local; memset(&local, 0, sizeof(local));
-    if (t < nChunk)
+    if (t < nChunk && !(skip && skip[t]))
     {
         const u32 inChunk = list ? list[t] : t;
         TemplateWork work;
@@ -643,25 +694,27 @@ __global__ __launch_bounds__(64) void k_select(DevParams P, DevReference R, DevT
             if (!list) { const u32 at = atomicAdd(overflowCount, 1u); if (at < overflowCapacity) overflowList[at] = inChunk; }
             else ++local.overflowClusters;   // even the reference's own capacities were exceeded
         }
-        if (!list) ++local.clusters; else ++local.heavyClusters;
+        if (list) ++local.heavyClusters;
     }
+    if (t < nChunk && !list) ++local.clusters;   // including the ones the wave-per-cluster pass takes
     flushCounters(local, counters);
 }
 
 // k_select_heavy: one wave per cluster of the overflow list.  All 64 lanes execute the template logic together on one arena
 // (same statements, same data), which costs what one thread costs; the bulk steps (probability sorts) are spread over the lanes.
 static const u32 HEAVY_SORT_LDS = 32768;   // u16 indices: heavyCaps().prob / .pair entries
-__global__ __launch_bounds__(64) void k_select_heavy(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nList, u32 tile,
+__global__ __launch_bounds__(64) void k_select_heavy(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nList, const u32 *nListDev, u32 tile,
                                                      const ClusterFragments *frags, u8 *arena, u64 arenaBytes, TemplateCaps caps, const u32 *list, RescueBuffers rb, const GappedResult *gappedResults,
                                                      FragmentRecord *records, u32 *cigars, Counters *counters)
 {
     extern __shared__ __align__(16) u8 heavyLds[];
-    const u32 t = blockIdx.x;
-    if (t >= nList) return;
     Counters local; memset(&local, 0, sizeof(local));
+    const u32 n = nListDev ? *nListDev : nList;
+    for (u32 t = blockIdx.x; t < n; t += gridDim.x)
+    {
     const u32 inChunk = list[t];
     TemplateWork work;
-    templateWorkBind(work, arena + u64(t) * arenaBytes, caps);
+    templateWorkBind(work, arena + u64(blockIdx.x) * arenaBytes, caps);
     RescueInputs in; const RescueInputs *pin = nullptr;
     if (rb.jobBase && rb.jobBase[inChunk] != 0xffffffffu)
     {
@@ -673,6 +726,8 @@ __global__ __launch_bounds__(64) void k_select_heavy(DevParams P, DevReference R
     clusterSelect(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + inChunk, tile, frags[inChunk], work, records, cigars, local, pin, &coop);
     if (work.overflow) ++local.overflowClusters;   // even the reference's own capacities were exceeded
     ++local.heavyClusters;
+    __syncthreads();                                 // the arena is reused by the block's next cluster
+    }
     if (0 != threadIdx.x) memset(&local, 0, sizeof(local));   // every lane counted the same events
     flushCounters(local, counters);
 }
@@ -847,7 +902,8 @@ int isaac_gpu_create(int device, const isaac_params *params, void *stream, isaac
     c->counters.reserve(1);
     HIP_CHECK(hipMemset(c->counters.p, 0, sizeof(Counters)));
     c->overflowCount.reserve(1);
-    HIP_CHECK(hipEventCreate(&c->ev0)); HIP_CHECK(hipEventCreate(&c->ev1));
+    HIP_CHECK(hipStreamCreateWithFlags(&c->heavyStream, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&c->evPredicted, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&c->evHeavyDone, hipEventDisableTiming));
     if (const char *e = getenv("ISAAC_GPU_CHUNK_CLUSTERS")) c->chunkClusters = u32(std::max(1024, atoi(e)));
     if (const char *e = getenv("ISAAC_GPU_FLAT_RESCUE")) c->flatRescue = atoi(e) != 0;
     *out = c.release();
@@ -859,8 +915,11 @@ void isaac_gpu_destroy(isaac_gpu_ctx *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
-    if (c->ev0) hipEventDestroy(c->ev0);
-    if (c->ev1) hipEventDestroy(c->ev1);
+    resolveTimers(c);
+    for (hipEvent_t e : c->eventPool) hipEventDestroy(e);
+    if (c->evPredicted) hipEventDestroy(c->evPredicted);
+    if (c->evHeavyDone) hipEventDestroy(c->evHeavyDone);
+    if (c->heavyStream) hipStreamDestroy(c->heavyStream);
     delete c;
 }
 
@@ -1186,7 +1245,7 @@ int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, u
     }
     const u64 lightBytes = templateWorkBytes(light), heavyBytes = templateWorkBytes(heavy);
     const u32 chunk = c->chunkClusters;
-    const u32 heavyThreads = 1024;
+    const u32 heavyThreads = 1024, residualThreads = 256;
     c->lightArena.reserve(size_t(chunk) * lightBytes);
     c->overflowList.reserve(chunk);
     RescueBuffers rb; std::memset(&rb, 0, sizeof(rb));
@@ -1231,25 +1290,45 @@ int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, u
             }
             launchGappedJobs(c, bcl, done, gbRescue, "gapped_rescue");
         }
+        const bool predicted = c->flatRescue;
+        if (predicted)
+        {   // clusters that cannot fit the light lists start on their own stream now, next to k_select
+            c->heavyArena.reserve(size_t(heavyThreads + residualThreads) * heavyBytes);
+            c->heavyList.reserve(chunk); c->heavyCount.reserve(1); c->heavyFlag.reserve(chunk);
+            HIP_CHECK(hipMemsetAsync(c->heavyCount.p, 0, 4, st));
+            k_predict_heavy<<<gridFor(n, 256), 256, 0, st>>>(c->frags.p, n, rb, light, c->heavyFlag.p, c->heavyList.p, c->heavyCount.p);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipEventRecord(c->evPredicted, st));
+            HIP_CHECK(hipStreamWaitEvent(c->heavyStream, c->evPredicted, 0));
+            {
+                ScopedTimer tm(c, "select_heavy", c->heavyStream);
+                k_select_heavy<<<heavyThreads, 64, HEAVY_SORT_LDS * 2, c->heavyStream>>>(c->P, R, t, rog, lmq40, bcl, done, 0, c->heavyCount.p, tile, c->frags.p, c->heavyArena.p, heavyBytes, heavy,
+                                                                                         c->heavyList.p, rb, gbRescue.results, reinterpret_cast<FragmentRecord *>(fragments), cigar, c->counters.p);
+                HIP_CHECK(hipGetLastError());
+            }
+            HIP_CHECK(hipEventRecord(c->evHeavyDone, c->heavyStream));
+        }
         {
             ScopedTimer tm(c, "select");
             k_select<<<gridFor(n, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, n, tile, c->frags.p, c->lightArena.p, lightBytes, light, nullptr, rb, c->flatRescue ? gbRescue.results : nullptr,
-                                                     reinterpret_cast<FragmentRecord *>(fragments), cigar, c->overflowList.p, c->overflowCount.p, chunk, c->counters.p);
+                                                     reinterpret_cast<FragmentRecord *>(fragments), cigar, c->overflowList.p, c->overflowCount.p, chunk, predicted ? c->heavyFlag.p : nullptr, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }
         u32 nOverflow = 0;
         HIP_CHECK(hipMemcpyAsync(&nOverflow, c->overflowCount.p, 4, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         nOverflow = std::min(nOverflow, chunk);
-        for (u32 od = 0; od < nOverflow; od += heavyThreads)
-        {   // the few clusters whose work lists did not fit: again, with the reference's own capacities
-            const u32 m = std::min(heavyThreads, nOverflow - od);
-            c->heavyArena.reserve(size_t(heavyThreads) * heavyBytes);
+        for (u32 od = 0; od < nOverflow; od += residualThreads)
+        {   // what the prediction missed: again, with the reference's own capacities
+            const u32 m = std::min(residualThreads, nOverflow - od);
+            c->heavyArena.reserve(size_t(heavyThreads + residualThreads) * heavyBytes);
             ScopedTimer tm(c, "select_heavy");
-            k_select_heavy<<<m, 64, HEAVY_SORT_LDS * 2, st>>>(c->P, R, t, rog, lmq40, bcl, done, m, tile, c->frags.p, c->heavyArena.p, heavyBytes, heavy, c->overflowList.p + od, rb,
-                                                              c->flatRescue ? gbRescue.results : nullptr, reinterpret_cast<FragmentRecord *>(fragments), cigar, c->counters.p);
+            k_select_heavy<<<m, 64, HEAVY_SORT_LDS * 2, st>>>(c->P, R, t, rog, lmq40, bcl, done, m, nullptr, tile, c->frags.p, c->heavyArena.p + size_t(heavyThreads) * heavyBytes, heavyBytes, heavy,
+                                                              c->overflowList.p + od, rb, c->flatRescue ? gbRescue.results : nullptr, reinterpret_cast<FragmentRecord *>(fragments), cigar, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }
+        // the chunk's buffers are reused by the next chunk: its first kernel waits for the wave-per-cluster pass
+        if (predicted) HIP_CHECK(hipStreamWaitEvent(st, c->evHeavyDone, 0));
     }
     HIP_CHECK(hipStreamSynchronize(st));
     return 0;
@@ -1284,6 +1363,7 @@ int isaac_gpu_get_counters(isaac_gpu_ctx *c, isaac_counters *out)
 
 int isaac_gpu_kernel_time_ms(isaac_gpu_ctx *c, const char *kernel, double *avgMs, uint64_t *launches)
 {
+    resolveTimers(c);
     const auto it = c->timers.find(kernel);
     if (it == c->timers.end() || !it->second.launches) { if (avgMs) *avgMs = 0; if (launches) *launches = 0; return 0; }
     if (avgMs) *avgMs = it->second.ms / double(it->second.launches);
@@ -1293,6 +1373,7 @@ int isaac_gpu_kernel_time_ms(isaac_gpu_ctx *c, const char *kernel, double *avgMs
 int isaac_gpu_reset_timers(isaac_gpu_ctx *c)
 {
     ISAAC_TRY
+    resolveTimers(c);
     c->timers.clear();
     HIP_CHECK(hipMemset(c->counters.p, 0, sizeof(Counters)));
     return 0;

@@ -23,7 +23,7 @@ def load_library(path=None):
     global _lib
     if _lib is None:
         import torch  # noqa: F401  -- first: the library must bind to the HIP runtime torch ships, not to a second copy
-        path = path or _build.LIB
+        path = path or os.environ.get("ISAAC_GPU_LIBRARY") or _build.LIB   # the variable selects another build of the same library
         if not os.path.exists(path):
             raise IsaacGpuError("libisaac_gpu.so is missing: run `python -m isaac_aligner_amd.build` (hipcc --offload-arch=gfx950)")
         lib = C.CDLL(path)
