@@ -671,7 +671,7 @@ __global__ __launch_bounds__(256) void k_predict_heavy(const ClusterFragments *f
 // k_select: clusters [clusterBase, clusterBase + nChunk) with per-thread arenas of `arenaBytes`; clusters whose light work
 // lists overflow are appended to overflowList.  With `list` given, thread t redoes cluster list[t] (heavy capacities).
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_SELECT_WAVES))) void k_select(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk, u32 tile,
-                                               const ClusterFragments *frags, u8 *arena, u64 arenaBytes, TemplateCaps caps, const u32 *list, RescueBuffers rb, const GappedResult *gappedResults,
+                                               const ClusterFragments *frags, u8 *arena, u64 arenaBytes, TemplateCaps caps, const u32 *list, RescueBuffers rb, const GappedResult *gappedResults, const GappedJob *gappedJobs,
                                                FragmentRecord *records, u32 *cigars, u32 *overflowList, u32 *overflowCount, u32 overflowCapacity, const u8 *skip, Counters *counters)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_SELECT
         if (rb.jobBase && rb.jobBase[inChunk] != 0xffffffffu)
         {
             in.jobs = rb.jobs + rb.jobBase[inChunk]; in.jobCount = rb.jobCount[inChunk]; in.shadowCands = rb.shadowCands; in.shadowCigars = rb.shadowCigars; in.candRank = rb.candRank;
-            in.gappedResults = gappedResults; in.serialFallbackAllowed = list != nullptr;
+            in.gappedResults = gappedResults; in.gappedJobs = gappedJobs; in.serialFallbackAllowed = list != nullptr;
             pin = &in;
         }
         clusterSelect(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + inChunk, tile, frags[inChunk], work, records, cigars, local, pin);
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_SELECT
 // (same statements, same data), which costs what one thread costs; the bulk steps (probability sorts) are spread over the lanes.
 static const u32 HEAVY_SORT_LDS = 32768;   // u16 indices: heavyCaps().prob / .pair entries
 __global__ __launch_bounds__(64) void k_select_heavy(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nList, const u32 *nListDev, u32 tile,
-                                                     const ClusterFragments *frags, u8 *arena, u64 arenaBytes, TemplateCaps caps, const u32 *list, RescueBuffers rb, const GappedResult *gappedResults,
+                                                     const ClusterFragments *frags, u8 *arena, u64 arenaBytes, TemplateCaps caps, const u32 *list, RescueBuffers rb, const GappedResult *gappedResults, const GappedJob *gappedJobs,
                                                      FragmentRecord *records, u32 *cigars, Counters *counters)
 {
     extern __shared__ __align__(16) u8 heavyLds[];
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(64) void k_select_heavy(DevParams P, DevReference R
     if (rb.jobBase && rb.jobBase[inChunk] != 0xffffffffu)
     {
         in.jobs = rb.jobs + rb.jobBase[inChunk]; in.jobCount = rb.jobCount[inChunk]; in.shadowCands = rb.shadowCands; in.shadowCigars = rb.shadowCigars; in.candRank = rb.candRank;
-        in.gappedResults = gappedResults; in.serialFallbackAllowed = true;
+        in.gappedResults = gappedResults; in.gappedJobs = gappedJobs; in.serialFallbackAllowed = true;
         pin = &in;
     }
     CoopInputs coop; coop.lanes = 64; coop.lane = threadIdx.x; coop.fastSort = true; coop.ldsSort = reinterpret_cast<u16 *>(heavyLds); coop.ldsSortCap = HEAVY_SORT_LDS;
@@ -1303,14 +1303,14 @@ int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, u
             {
                 ScopedTimer tm(c, "select_heavy", c->heavyStream);
                 k_select_heavy<<<heavyThreads, 64, HEAVY_SORT_LDS * 2, c->heavyStream>>>(c->P, R, t, rog, lmq40, bcl, done, 0, c->heavyCount.p, tile, c->frags.p, c->heavyArena.p, heavyBytes, heavy,
-                                                                                         c->heavyList.p, rb, gbRescue.results, reinterpret_cast<FragmentRecord *>(fragments), cigar, c->counters.p);
+                                                                                         c->heavyList.p, rb, gbRescue.results, gbRescue.jobs, reinterpret_cast<FragmentRecord *>(fragments), cigar, c->counters.p);
                 HIP_CHECK(hipGetLastError());
             }
             HIP_CHECK(hipEventRecord(c->evHeavyDone, c->heavyStream));
         }
         {
             ScopedTimer tm(c, "select");
-            k_select<<<gridFor(n, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, n, tile, c->frags.p, c->lightArena.p, lightBytes, light, nullptr, rb, c->flatRescue ? gbRescue.results : nullptr,
+            k_select<<<gridFor(n, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, n, tile, c->frags.p, c->lightArena.p, lightBytes, light, nullptr, rb, c->flatRescue ? gbRescue.results : nullptr, c->flatRescue ? gbRescue.jobs : nullptr,
                                                      reinterpret_cast<FragmentRecord *>(fragments), cigar, c->overflowList.p, c->overflowCount.p, chunk, predicted ? c->heavyFlag.p : nullptr, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }
@@ -1324,7 +1324,7 @@ int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, u
             c->heavyArena.reserve(size_t(heavyThreads + residualThreads) * heavyBytes);
             ScopedTimer tm(c, "select_heavy");
             k_select_heavy<<<m, 64, HEAVY_SORT_LDS * 2, st>>>(c->P, R, t, rog, lmq40, bcl, done, m, nullptr, tile, c->frags.p, c->heavyArena.p + size_t(heavyThreads) * heavyBytes, heavyBytes, heavy,
-                                                              c->overflowList.p + od, rb, c->flatRescue ? gbRescue.results : nullptr, reinterpret_cast<FragmentRecord *>(fragments), cigar, c->counters.p);
+                                                              c->overflowList.p + od, rb, c->flatRescue ? gbRescue.results : nullptr, c->flatRescue ? gbRescue.jobs : nullptr, reinterpret_cast<FragmentRecord *>(fragments), cigar, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }
         // the chunk's buffers are reused by the next chunk: its first kernel waits for the wave-per-cluster pass

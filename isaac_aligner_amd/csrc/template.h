@@ -164,6 +164,7 @@ struct TemplateWork
     ShadowProb *shadowProbs[2]; u32 nShadowProbs[2];
     PairProb *pairProbs; u32 nPairProbs;
     u16 *sortIdx;
+    double *terms;            // exp() of the sorted probabilities (fast path of sumUnique*Probabilities)
     Cand *bestOrphanShadows[2]; u32 nBestOrphanShadows[2];
     u32 *templateCigar; u32 templateCigarUsed;
     u32 *tflags;
@@ -176,7 +177,7 @@ ISAAC_HD u64 templateWorkBytes(const TemplateCaps &c)
 {
     const u64 sortN = imax(imax(c.pos, c.prob), c.pair);
     return alignUp(u64(c.shadow) * sizeof(Cand)) + alignUp(u64(c.shadowCigar) * 4) + alignUp(u64(c.pos) * 8) + alignUp(u64(KMER_TABLE) * 4) +
-           2 * alignUp(u64(c.prob) * sizeof(ShadowProb)) + alignUp(u64(c.pair) * sizeof(PairProb)) + alignUp(sortN * 2) + 2 * alignUp(u64(c.best) * sizeof(Cand)) +
+           2 * alignUp(u64(c.prob) * sizeof(ShadowProb)) + alignUp(u64(c.pair) * sizeof(PairProb)) + alignUp(sortN * 2) + alignUp(sortN * 8) + 2 * alignUp(u64(c.best) * sizeof(Cand)) +
            alignUp(u64(c.templateCigar) * 4) + alignUp(u64(3 * 512) * 4) + 4 * alignUp(u64(c.best));
 }
 // binds the pointers of `w` into the arena at `base` (16-byte aligned, templateWorkBytes(caps) long); the k-mer table must be
@@ -193,6 +194,7 @@ ISAAC_HD void templateWorkBind(TemplateWork &w, void *base, const TemplateCaps &
     for (u32 i = 0; i < 2; ++i) { w.shadowProbs[i] = reinterpret_cast<ShadowProb *>(p); p += alignUp(u64(c.prob) * sizeof(ShadowProb)); }
     w.pairProbs = reinterpret_cast<PairProb *>(p); p += alignUp(u64(c.pair) * sizeof(PairProb));
     w.sortIdx = reinterpret_cast<u16 *>(p); p += alignUp(sortN * 2);
+    w.terms = reinterpret_cast<double *>(p); p += alignUp(sortN * 8);
     for (u32 i = 0; i < 2; ++i) { w.bestOrphanShadows[i] = reinterpret_cast<Cand *>(p); p += alignUp(u64(c.best) * sizeof(Cand)); }
     w.templateCigar = reinterpret_cast<u32 *>(p); p += alignUp(u64(c.templateCigar) * 4);
     w.tflags = reinterpret_cast<u32 *>(p); p += alignUp(u64(3 * 512) * 4);
@@ -234,7 +236,7 @@ struct TemplateCtx
     const DevParams *P; const DevReference *R; const DevTls *tls;
     u32 rescueMode; u32 jobNext, jobCount; RescueJob *jobs; bool planWrite; bool serialFallbackAllowed;
     const i32 *candPositions; const Cand *shadowCands; const u32 *shadowCigars;   // RESCUE_LOOKUP inputs
-    const GappedResult *gappedResults;                                            // RESCUE_LOOKUP: the chunk's gapped retries, or NULL
+    const GappedResult *gappedResults; const GappedJob *gappedJobs;               // RESCUE_LOOKUP: the chunk's gapped retries, or NULL
     const u32 *candRank;                                                          // RESCUE_LOOKUP: aligned candidates before each slot (summarizeRescueJob)
     ReadView reads[2];
     const ClusterFragments *frags;
@@ -491,6 +493,36 @@ ISAAC_HD bool finishRescue(TemplateCtx &x, CigarPool &pool, i32 best, const Gapp
     return true;
 }
 
+// finishRescue when the retries were planned and run by the flat pass: only the planned elements are visited (in list
+// order, like the loop above), found through the rank of their candidate slot
+ISAAC_HD bool finishRescueLookup(TemplateCtx &x, CigarPool &pool, i32 best, const RescueJob &job)
+{
+    TemplateWork &w = *x.w;
+    const DevParams &P = *x.P;
+    if (best < 0) { if (pool.overflow) w.overflow = 1; return false; }
+    ISAAC_PROF_T0(x);
+    for (u32 k = 0; k < job.nGapped; ++k)
+    {
+        const GappedResult &g = x.gappedResults[job.gappedBase + k];
+        const u32 i = x.candRank[x.gappedJobs[job.gappedBase + k].tag];
+        Cand &fragment = w.shadowList[i];
+        ++x.cnt->rescueBsw;
+        Cand tmp = g.out; u32 matchCount = g.matchCount; tmp.cigarOffset = pool.used;
+        if (0xffffffffu == g.nCigar) { w.overflow = 1; matchCount = 0; }
+        else for (u32 c = 0; c < g.nCigar; ++c) pool.push(g.cigar[c]);
+        if (matchCount && matchCount + BSW_WIDEST_GAP_SIZE > candObservedLength(fragment) && (tmp.mismatchCount <= P.gappedMismatchesMax) &&
+            (fragment.mismatchCount > tmp.mismatchCount) && lpLess(fragment.logProbability, tmp.logProbability))
+        {
+            fragment = tmp;
+            if (lpLess(w.shadowList[best].logProbability, fragment.logProbability)) best = i32(i);
+        }
+    }
+    if (pool.overflow) w.overflow = 1;
+    if (best != 0) { const Cand t = w.shadowList[0]; w.shadowList[0] = w.shadowList[best]; w.shadowList[best] = t; }
+    ISAAC_PROF_ADD(x, 1);
+    return true;
+}
+
 // ShadowAligner::rescueShadow, everything in this thread (RESCUE_SERIAL)
 ISAAC_HD bool shadowRescueSerial(TemplateCtx &x, const Cand &orphan, const RescueJob &job)
 {
@@ -523,7 +555,7 @@ ISAAC_HD bool shadowRescueSerial(TemplateCtx &x, const Cand &orphan, const Rescu
 ISAAC_HD bool shadowRescueLookup(TemplateCtx &x, const Cand &orphan, const RescueJob &job)
 {
     TemplateWork &w = *x.w;
-    if (job.fallback || (job.nGapped && (0xffffffffu == job.gappedBase || !x.gappedResults)))
+    if (job.fallback || (job.nGapped && (0xffffffffu == job.gappedBase || !x.gappedResults || !x.gappedJobs)))
     {   // a capacity of the flat pass was exceeded for this job: exact serial path, which needs the reference-sized lists
         if (!x.serialFallbackAllowed) { w.overflow = 1; return false; }
         return shadowRescueSerial(x, orphan, job);
@@ -557,7 +589,7 @@ ISAAC_HD bool shadowRescueLookup(TemplateCtx &x, const Cand &orphan, const Rescu
         for (u32 k = 0; k < b.cigarLength; ++k) pool.push(x.shadowCigars[u64(job.bestSlot) * 3 + k]);
     }
     ISAAC_PROF_ADD(x, 0);
-    return finishRescue(x, pool, best, job.nGapped ? x.gappedResults + job.gappedBase : 0);
+    return finishRescueLookup(x, pool, best, job);
 }
 
 // One pass over a job's aligned candidates (in candidate order): how many there are before each slot, which is the best
@@ -817,7 +849,15 @@ ISAAC_HD double sumUniqueShadowProbabilities(TemplateCtx &x, u32 side)
     }
     ISAAC_PROF_ADD(x, 3);
     double ret = 0.0;
-    for (u32 i = 0; i < n;)
+    if (!exact)
+    {   // without near ties "equal to the first element of the run" is "equal to the predecessor": every element decides alone
+        // whether it contributes, the exps run side by side and only the additions stay in sequence (x + 0.0 == x)
+        for (u32 i = x.lane; i < n; i += x.lanes)
+            w.terms[i] = (i && shadowProbEqual(v[w.sortIdx[i - 1]], v[w.sortIdx[i]])) ? 0.0 : exp(v[w.sortIdx[i]].logProbability);
+        coopSync(x);
+        for (u32 i = 0; i < n; ++i) ret += w.terms[i];
+    }
+    else for (u32 i = 0; i < n;)
     {
         ret += exp(v[w.sortIdx[i]].logProbability);
         u32 j = i + 1;
@@ -856,7 +896,14 @@ ISAAC_HD double sumUniquePairProbabilities(TemplateCtx &x)
     }
     ISAAC_PROF_ADD(x, 4);
     double ret = 0.0;
-    for (u32 i = 0; i < n;)
+    if (!exact)
+    {
+        for (u32 i = x.lane; i < n; i += x.lanes)
+            w.terms[i] = (i && pairProbEqual(v[w.sortIdx[i - 1]], v[w.sortIdx[i]])) ? 0.0 : exp(pairLp(v[w.sortIdx[i]]));
+        coopSync(x);
+        for (u32 i = 0; i < n; ++i) ret += w.terms[i];
+    }
+    else for (u32 i = 0; i < n;)
     {
         ret += exp(pairLp(v[w.sortIdx[i]]));
         u32 j = i + 1;

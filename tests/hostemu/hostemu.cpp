@@ -192,9 +192,9 @@ int emu_select(Emu *e, const u8 *bcl, u32 nClusters, u32 tile, const isaac_tls *
         }
     // k_rescue_gapped_plan + k_gapped_jobs
     std::vector<GappedResult> gapped; std::vector<u32> candRank(shadowCands.size() + 1);
+    std::vector<GappedJob> gj;
     {
         std::vector<u32> tflags(3 * 512);
-        std::vector<GappedJob> gj;
         for (size_t j = 0; j < jobs.size(); ++j)
         {
             RescueJob &job = jobs[j];
@@ -216,7 +216,7 @@ int emu_select(Emu *e, const u8 *bcl, u32 nClusters, u32 tile, const isaac_tls *
         {
             if (tier && !(recs[u64(c) * e->P.nReads].reserved & RECORD_TEMPLATE_OVERFLOW)) continue;
             RescueInputs in; in.jobs = jobs.data() + jobBase[c]; in.jobCount = jobBase[c + 1] - jobBase[c]; in.shadowCands = shadowCands.data(); in.shadowCigars = shadowCigars.data();
-            in.gappedResults = gapped.data(); in.candRank = candRank.data();
+            in.gappedResults = gapped.data(); in.gappedJobs = gj.data(); in.candRank = candRank.data();
             const auto t0 = std::chrono::steady_clock::now();
             in.serialFallbackAllowed = tier != 0;
             CoopInputs coop; coop.lanes = 1; coop.lane = 0; coop.fastSort = e->fastSort && tier; coop.ldsSort = 0; coop.ldsSortCap = 0;
