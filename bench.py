@@ -120,7 +120,7 @@ def main():
         elapsed = float(t.item())
 
     counters = al.counters()
-    timers = {k: al.kernel_time_ms(k) for k in ("find_matches", "build_fragments", "gapped_fragments", "finish_fragments", "plan_rescue", "rescue_windows", "rescue_align",
+    timers = {k: al.kernel_time_ms(k) for k in ("find_matches", "order_fragments", "build_fragments", "gapped_fragments", "finish_fragments", "plan_rescue", "rescue_windows", "rescue_align", "order_select",
                                                  "rescue_gapped_plan", "gapped_rescue", "select", "select_heavy")}
     if rank != 0:
         if dist is not None:
@@ -162,8 +162,19 @@ def main():
     launches = max(1, timers[dominant][1])
     avg_s = total_ms[dominant] / launches / 1e3
     achieved = per_kernel_bytes[dominant] / launches / avg_s / 1e9 if avg_s > 0 else 0.0
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure comes from the
+    # committed rocprofv3 --pmc passes over this same workload (profiles/r1_d_pmc_summary.json, made by scripts/pmc_summary.py;
+    # FETCH_SIZE doubled as the MI355X guide prescribes for gfx950), scaled from that run's clusters per launch to this run's
+    traffic, traffic_source = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "r1_d_pmc_summary.json")
+    if os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path)).get("k_" + dominant)
+        if pmc and "hbm_bytes_per_launch" in pmc:
+            pmc_pairs_per_launch = 500_000.0
+            traffic = int(pmc["hbm_bytes_per_launch"] / pmc_pairs_per_launch * (pairs_rank / launches))
+            traffic_source = "profiles/r1_d_pmc_summary.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes, 500000 pairs per launch), scaled per pair"
     roofline = {"bound": "hbm", "kernel": "k_" + dominant, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 6), "traffic": None,
+                "frac": round(achieved / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_ms": round(total_ms[dominant] / launches, 4), "launches": int(launches),
                 "algorithmic_bytes_per_launch": int(per_kernel_bytes[dominant] / launches),
                 "kernel_ms_total": dict({k: round(v, 2) for k, v in total_ms.items()}, select_heavy=round(heavy_ms, 2)),

@@ -72,7 +72,8 @@ struct isaac_gpu_ctx
     std::vector<PendingTimer> pendingTimers; std::vector<hipEvent_t> eventPool;
     hipStream_t heavyStream = nullptr; hipEvent_t evPredicted = nullptr, evHeavyDone = nullptr;
     DevBuf<u32> heavyList, heavyCount; DevBuf<u8> heavyFlag;
-    u32 chunkClusters = 524288;
+    DevBuf<u32> classKeys, classKeysSorted, classIdx, fragmentOrder, selectOrder;   // clusters ordered by work class (see k_match_class)
+    u32 chunkClusters = 524288; bool workClasses = false;   // lane order by work class: measured slower (locality of neighbouring clusters matters more), kept as ISAAC_GPU_WORK_CLASSES=1
 
     DevReference ref() const
     {
@@ -274,40 +275,53 @@ __global__ void k_compact_matches(const Match *staging, const u32 *counts, const
     __syncthreads();                                                                                                         \
     DevReference R_OUT = (R_IN); R_OUT.logMatch = qualityTables; R_OUT.logMismatch = qualityTables + 64;
 
+// Work classes.  The per-cluster kernels run one cluster per lane, and a wave takes as long as the union of its lanes' paths:
+// clusters are therefore handed to the lanes in the order of a cheap work estimate (stable radix sort of small keys), so
+// that a wave holds clusters of similar cost.  The results stay indexed by cluster.
+__global__ void k_match_class(const u64 *offsets, u32 clusterBase, u32 n, u32 *keys, u32 *idx)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u64 m = offsets[clusterBase + t + 1] - offsets[clusterBase + t];
+    keys[t] = m < 63 ? u32(m) : 63u; idx[t] = t;
+}
+
 // the chunk's gapped (banded Smith-Waterman) problems: written by the per-cluster threads, run by k_gapped_jobs
 struct GappedBuffers { GappedJob *jobs; GappedResult *results; u32 cap; u32 *counter; u32 *base; };
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_build_fragments(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, u32 nChunk, const Match *matches, const u64 *offsets,
-                                                        int withGaps, int trim, FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters)
+                                                        int withGaps, int trim, const u32 *order, FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters)
 {
     ISAAC_STAGE_QUALITY_TABLES(Rg, R)
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     Counters local; memset(&local, 0, sizeof(local));
     if (t < nChunk)
     {
-        clusterBuildFragments(P, R, bcl, clusterBase + t, matches, offsets, withGaps != 0, trim != 0, work[t], frags[t], local);
+        const u32 cl = order ? order[t] : t;     // neighbouring lanes take clusters of the same work class
+        clusterBuildFragments(P, R, bcl, clusterBase + cl, matches, offsets, withGaps != 0, trim != 0, work[t], frags[cl], local);
         u32 base = 0;
-        const u32 n = countGappedJobs(frags[t], withGaps != 0);
+        const u32 n = countGappedJobs(frags[cl], withGaps != 0);
         if (n)
         {
             base = atomicAdd(gb.counter, n);
             if (base + n > gb.cap) base = 0xffffffffu;   // k_finish_fragments runs this cluster's retries itself
-            else writeGappedJobs(frags[t], t, gb.jobs + base);
+            else writeGappedJobs(frags[cl], cl, gb.jobs + base);
         }
-        gb.base[t] = base;
+        gb.base[cl] = base;
     }
     flushCounters(local, counters);
 }
 
-__global__ __launch_bounds__(64) void k_finish_fragments(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, u32 nChunk, int withGaps,
+__global__ __launch_bounds__(64) void k_finish_fragments(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, u32 nChunk, int withGaps, const u32 *order,
                                                          FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     Counters local; memset(&local, 0, sizeof(local));
     if (t < nChunk)
     {
-        const GappedResult *res = (withGaps && gb.base[t] != 0xffffffffu) ? gb.results + gb.base[t] : nullptr;
-        clusterFinishFragments(P, R, bcl, clusterBase + t, withGaps != 0, res, work[t], frags[t], local);
+        const u32 cl = order ? order[t] : t;
+        const GappedResult *res = (withGaps && gb.base[cl] != 0xffffffffu) ? gb.results + gb.base[cl] : nullptr;
+        clusterFinishFragments(P, R, bcl, clusterBase + cl, withGaps != 0, res, work[t], frags[cl], local);
     }
     flushCounters(local, counters);
 }
@@ -645,11 +659,11 @@ __global__ __launch_bounds__(256) void k_rescue_gapped_plan(const ClusterFragmen
 // Which clusters cannot fit the light work lists of k_select: known from the rescue summaries before k_select runs, so the
 // wave-per-cluster pass can start at the same time on its own stream.  The test is a superset of the real overflow
 // conditions (a cluster sent here needlessly is still processed exactly); what it misses, k_select reports afterwards.
-__global__ __launch_bounds__(256) void k_predict_heavy(const ClusterFragments *frags, u32 nChunk, RescueBuffers rb, TemplateCaps light, u8 *heavyFlag, u32 *heavyList, u32 *heavyCount)
+__global__ __launch_bounds__(256) void k_predict_heavy(const ClusterFragments *frags, u32 nChunk, RescueBuffers rb, TemplateCaps light, u8 *heavyFlag, u32 *heavyList, u32 *heavyCount, u32 *classKeys, u32 *classIdx)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nChunk) return;
-    bool heavy = false;
+    bool heavy = false; u32 work = 4 * (frags[t].nCands[0] + frags[t].nCands[1]);
     if (rb.jobBase[t] != 0xffffffffu)
     {
         const RescueJob *jobs = rb.jobs + rb.jobBase[t];
@@ -661,10 +675,12 @@ __global__ __launch_bounds__(256) void k_predict_heavy(const ClusterFragments *f
             if (jobs[j].fallback || jobs[j].nAligned >= light.shadow) heavy = true;
             total += jobs[j].nAligned;
         }
+        work += total + 8 * n;
         const u32 seeded = frags[t].nCands[0] + frags[t].nCands[1];
         if (total + seeded > light.prob || total > light.pair) heavy = true;
     }
     heavyFlag[t] = heavy ? 1 : 0;
+    if (classKeys) { classKeys[t] = heavy ? 255u : (work < 254 ? work : 254u); classIdx[t] = t; }   // work class for k_select's lane order
     if (heavy) heavyList[atomicAdd(heavyCount, 1u)] = t;
 }
 
@@ -672,13 +688,13 @@ __global__ __launch_bounds__(256) void k_predict_heavy(const ClusterFragments *f
 // lists overflow are appended to overflowList.  With `list` given, thread t redoes cluster list[t] (heavy capacities).
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_SELECT_WAVES))) void k_select(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk, u32 tile,
                                                const ClusterFragments *frags, u8 *arena, u64 arenaBytes, TemplateCaps caps, const u32 *list, RescueBuffers rb, const GappedResult *gappedResults, const GappedJob *gappedJobs,
-                                               FragmentRecord *records, u32 *cigars, u32 *overflowList, u32 *overflowCount, u32 overflowCapacity, const u8 *skip, Counters *counters)
+                                               FragmentRecord *records, u32 *cigars, u32 *overflowList, u32 *overflowCount, u32 overflowCapacity, const u8 *skip, const u32 *order, Counters *counters)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     Counters local; memset(&local, 0, sizeof(local));
-    if (t < nChunk && !(skip && skip[t]))
+    const u32 inChunk = t < nChunk ? (list ? list[t] : (order ? order[t] : t)) : 0;
+    if (t < nChunk && !(skip && skip[inChunk]))
     {
-        const u32 inChunk = list ? list[t] : t;
         TemplateWork work;
         templateWorkBind(work, arena + u64(t) * arenaBytes, caps);
         RescueInputs in; const RescueInputs *pin = nullptr;
@@ -865,12 +881,12 @@ template <typename T> void inclusiveSum(isaac_gpu_ctx *c, const T *in, T *out, s
     c->cubTemp.reserve(bytes + 16);
     HIP_CHECK(hipcub::DeviceScan::InclusiveSum(c->cubTemp.p, bytes, in, out, int(n), c->stream));
 }
-template <typename K, typename V> void sortPairs(isaac_gpu_ctx *c, const K *kin, K *kout, const V *vin, V *vout, size_t n)
+template <typename K, typename V> void sortPairs(isaac_gpu_ctx *c, const K *kin, K *kout, const V *vin, V *vout, size_t n, int endBit = int(sizeof(K) * 8))
 {
     size_t bytes = 0;
-    HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kin, kout, vin, vout, int(n), 0, int(sizeof(K) * 8), c->stream));
+    HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kin, kout, vin, vout, int(n), 0, endBit, c->stream));
     c->cubTemp.reserve(bytes + 16);
-    HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->cubTemp.p, bytes, kin, kout, vin, vout, int(n), 0, int(sizeof(K) * 8), c->stream));
+    HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->cubTemp.p, bytes, kin, kout, vin, vout, int(n), 0, endBit, c->stream));
 }
 
 int fail(int code, const std::string &what) { g_error = what; return code; }
@@ -906,6 +922,7 @@ int isaac_gpu_create(int device, const isaac_params *params, void *stream, isaac
     HIP_CHECK(hipEventCreateWithFlags(&c->evPredicted, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&c->evHeavyDone, hipEventDisableTiming));
     if (const char *e = getenv("ISAAC_GPU_CHUNK_CLUSTERS")) c->chunkClusters = u32(std::max(1024, atoi(e)));
     if (const char *e = getenv("ISAAC_GPU_FLAT_RESCUE")) c->flatRescue = atoi(e) != 0;
+    if (const char *e = getenv("ISAAC_GPU_WORK_CLASSES")) c->workClasses = atoi(e) != 0;
     *out = c.release();
     return ISAAC_GPU_OK;
     ISAAC_CATCH
@@ -1151,16 +1168,25 @@ static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clust
     c->frags.reserve(c->chunkClusters); c->fragWork.reserve(c->chunkClusters);
     const GappedBuffers gb = gappedBuffers(c, 0);
     HIP_CHECK(hipMemsetAsync(c->gappedCounters.p, 0, 16, c->stream));
+    const u32 *order = nullptr;
+    if (c->workClasses)
+    {
+        ScopedTimer t(c, "order_fragments");
+        c->classKeys.reserve(c->chunkClusters); c->classKeysSorted.reserve(c->chunkClusters); c->classIdx.reserve(c->chunkClusters); c->fragmentOrder.reserve(c->chunkClusters);
+        k_match_class<<<gridFor(n, 256), 256, 0, c->stream>>>(offsets, clusterBase, n, c->classKeys.p, c->classIdx.p);
+        sortPairs(c, c->classKeys.p, c->classKeysSorted.p, c->classIdx.p, c->fragmentOrder.p, n, 6);
+        order = c->fragmentOrder.p;
+    }
     {
         ScopedTimer t(c, "build_fragments");
         k_build_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, reinterpret_cast<const Match *>(matches), offsets,
-                                                                 withGaps, trim, c->fragWork.p, c->frags.p, gb, c->counters.p);
+                                                                 withGaps, trim, order, c->fragWork.p, c->frags.p, gb, c->counters.p);
         HIP_CHECK(hipGetLastError());
     }
     if (withGaps) launchGappedJobs(c, bcl, clusterBase, gb, "gapped_fragments");
     {
         ScopedTimer t(c, "finish_fragments");
-        k_finish_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, withGaps, c->fragWork.p, c->frags.p, gb, c->counters.p);
+        k_finish_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, withGaps, order, c->fragWork.p, c->frags.p, gb, c->counters.p);
         HIP_CHECK(hipGetLastError());
     }
 }
@@ -1295,8 +1321,10 @@ int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, u
         {   // clusters that cannot fit the light lists start on their own stream now, next to k_select
             c->heavyArena.reserve(size_t(heavyThreads + residualThreads) * heavyBytes);
             c->heavyList.reserve(chunk); c->heavyCount.reserve(1); c->heavyFlag.reserve(chunk);
+            c->classKeys.reserve(chunk); c->classKeysSorted.reserve(chunk); c->classIdx.reserve(chunk); c->selectOrder.reserve(chunk);
             HIP_CHECK(hipMemsetAsync(c->heavyCount.p, 0, 4, st));
-            k_predict_heavy<<<gridFor(n, 256), 256, 0, st>>>(c->frags.p, n, rb, light, c->heavyFlag.p, c->heavyList.p, c->heavyCount.p);
+            k_predict_heavy<<<gridFor(n, 256), 256, 0, st>>>(c->frags.p, n, rb, light, c->heavyFlag.p, c->heavyList.p, c->heavyCount.p,
+                                                             c->workClasses ? c->classKeys.p : nullptr, c->classIdx.p);
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipEventRecord(c->evPredicted, st));
             HIP_CHECK(hipStreamWaitEvent(c->heavyStream, c->evPredicted, 0));
@@ -1308,10 +1336,17 @@ int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, u
             }
             HIP_CHECK(hipEventRecord(c->evHeavyDone, c->heavyStream));
         }
+        const u32 *selectOrder = nullptr;
+        if (predicted && c->workClasses)
+        {
+            ScopedTimer tm(c, "order_select");
+            sortPairs(c, c->classKeys.p, c->classKeysSorted.p, c->classIdx.p, c->selectOrder.p, n, 8);
+            selectOrder = c->selectOrder.p;
+        }
         {
             ScopedTimer tm(c, "select");
             k_select<<<gridFor(n, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, n, tile, c->frags.p, c->lightArena.p, lightBytes, light, nullptr, rb, c->flatRescue ? gbRescue.results : nullptr, c->flatRescue ? gbRescue.jobs : nullptr,
-                                                     reinterpret_cast<FragmentRecord *>(fragments), cigar, c->overflowList.p, c->overflowCount.p, chunk, predicted ? c->heavyFlag.p : nullptr, c->counters.p);
+                                                     reinterpret_cast<FragmentRecord *>(fragments), cigar, c->overflowList.p, c->overflowCount.p, chunk, predicted ? c->heavyFlag.p : nullptr, selectOrder, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }
         u32 nOverflow = 0;

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Per-kernel summary of rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_*) -> JSON for profiles/.
+
+    python scripts/pmc_summary.py OUT.json name=counter_collection.csv [name=...]
+
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KB.  Following /opt/skills/guides/MI355X_MICROARCH.md (HBM section), on
+gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes, so hbm_read_bytes = 2 x FETCH_SIZE; WRITE_SIZE is taken as is.  The
+guide calibrates this on wide streaming accesses; the kernels here issue narrow scattered ones, so the raw values are kept
+next to the corrected ones."""
+import collections, csv, json, re, sys
+
+def main():
+    out = sys.argv[1]
+    kernels = collections.defaultdict(lambda: {"launches": 0})
+    for arg in sys.argv[2:]:
+        _, path = arg.split("=", 1)
+        seen = set()
+        for r in csv.DictReader(open(path)):
+            m = re.search(r"(k_\w+)", r["Kernel_Name"])
+            if not m:
+                continue
+            k = kernels[m.group(1)]
+            k[r["Counter_Name"]] = k.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            key = (path, r["Dispatch_Id"])
+            if key not in seen:
+                seen.add(key)
+                k.setdefault("_launches_" + path, 0)
+                k["_launches_" + path] += 1
+    res = {}
+    for name, k in sorted(kernels.items()):
+        launches = max(v for kk, v in k.items() if kk.startswith("_launches_"))
+        e = {"launches": launches}
+        for c, v in k.items():
+            if c.startswith("_") or c == "launches":
+                continue
+            e[c] = v
+        if "FETCH_SIZE" in e:
+            e["hbm_read_bytes_per_launch"] = 2.0 * e["FETCH_SIZE"] * 1024 / launches
+        if "WRITE_SIZE" in e:
+            e["hbm_write_bytes_per_launch"] = e["WRITE_SIZE"] * 1024 / launches
+        if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+            e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
+        if "SQ_WAVE_CYCLES" in e and e["SQ_WAVE_CYCLES"]:
+            wc = e["SQ_WAVE_CYCLES"]
+            e["wait_any_frac"] = e.get("SQ_WAIT_ANY", 0) / wc
+            e["active_inst_frac"] = e.get("SQ_ACTIVE_INST_ANY", 0) / wc
+            if e.get("SQ_ACTIVE_INST_VALU"):
+                e["valu_lane_utilisation"] = e.get("SQ_THREAD_CYCLES_VALU", 0) / (64.0 * e["SQ_ACTIVE_INST_VALU"])
+        res[name] = e
+    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+    print("wrote", out, "kernels:", ", ".join(res))
+
+if __name__ == "__main__":
+    main()
