@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--pairs-per-step", type=int, default=1_000_000)
     ap.add_argument("--genome-bases", type=int, default=46_700_000)
     ap.add_argument("--read-length", type=int, default=150)
-    ap.add_argument("--cpu-sample-pairs", type=int, default=100_000)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-neighbors", action="store_true")
     return ap.parse_args()
