@@ -57,6 +57,7 @@ struct isaac_gpu_ctx
     DevBuf<char> basesOwned; const char *bases = nullptr;
     DevBuf<u64> contigOffset; std::vector<u64> hContigOffset; DevBuf<u8> contigLoaded; std::vector<u8> hContigLoaded; u32 nContigs = 0;
     DevBuf<u64> kmers, positions; u64 nKmers = 0; DevBuf<u32> karyotype; bool hasKaryotype = false;
+    DevBuf<u32> prefixTable; u32 prefixBits = 0;
     DevBuf<double> logTables;
     // work
     DevBuf<Match> staging; DevBuf<u32> counts, chunkOffsets; DevBuf<u8> cubTemp; DevBuf<u32> contigHits;
@@ -81,6 +82,7 @@ struct isaac_gpu_ctx
         r.bases = bases; r.totalBases = hContigOffset.empty() ? 0 : hContigOffset[nContigs]; r.contigOffset = contigOffset.p; r.contigLoaded = contigLoaded.p; r.nContigs = nContigs;
         r.kmers = kmers.p; r.positions = positions.p; r.nKmers = nKmers; r.karyotype = hasKaryotype ? karyotype.p : nullptr;
         r.logMatch = logTables.p; r.logMismatch = logTables.p + 100;
+        r.prefixTable = prefixBits ? prefixTable.p : nullptr; r.prefixBits = prefixBits;
         return r;
     }
 };
@@ -134,9 +136,8 @@ __device__ inline void flushCounters(const Counters &local, Counters *global)
 // 8 lanes cooperate on one cluster; each lane owns one (seed, strand) probe per round.
 static const u32 FIND_GROUP = 8, FIND_BLOCK = 256, FIND_CLUSTERS_PER_BLOCK = FIND_BLOCK / FIND_GROUP;
 
-__device__ inline u64 lowerBound(const u64 *kmers, u64 n, u64 key, u32 &steps)
+__device__ inline u64 lowerBound(const u64 *kmers, u64 lo, u64 hi, u64 key, u32 &steps)
 {
-    u64 lo = 0, hi = n;
     while (lo < hi)
     {
         const u64 mid = (lo + hi) >> 1;
@@ -144,6 +145,15 @@ __device__ inline u64 lowerBound(const u64 *kmers, u64 n, u64 key, u32 &steps)
         ++steps;
     }
     return lo;
+}
+
+// prefixTable[b] = first table index whose k-mer has leading bits >= b (b = 0 .. 2^bits, the last one = n)
+__global__ void k_prefix_table(const u64 *kmers, u64 n, u32 bits, u32 *table)
+{
+    const u64 b = u64(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (b > (u64(1) << bits)) return;
+    u32 steps = 0;
+    table[b] = (b >> bits) ? u32(n) : u32(lowerBound(kmers, 0, n, b << (64 - bits), steps));
 }
 
 __global__ __launch_bounds__(FIND_BLOCK) void k_find_matches(DevParams P, DevReference R, const u8 *bcl, u32 nClusters, u32 clusterBase, u32 tile,
@@ -205,7 +215,14 @@ __global__ __launch_bounds__(FIND_BLOCK) void k_find_matches(DevParams P, DevRef
                 {
                     ++local.probes;
                     u32 steps = 0;
-                    first = lowerBound(R.kmers, R.nKmers, kmer, steps);
+                    if (R.prefixTable)
+                    {   // the k-mer's leading bits select a slice of the table: one 8-byte read instead of most of the bisection
+                        const u64 bucket = kmer >> (64 - R.prefixBits);
+                        const uint2 range = *reinterpret_cast<const uint2 *>(R.prefixTable + bucket);   // [bucket], [bucket + 1]
+                        ++steps;
+                        first = lowerBound(R.kmers, range.x, range.y, kmer, steps);
+                    }
+                    else first = lowerBound(R.kmers, 0, R.nKmers, kmer, steps);
                     local.probeSteps += steps;
                     // ExactMaskMatcher.cpp:118-126: reference entries with the same k-mer, at most repeatThreshold of them
                     u32 r = 0;
@@ -890,6 +907,21 @@ template <typename K, typename V> void sortPairs(isaac_gpu_ctx *c, const K *kin,
 }
 
 int fail(int code, const std::string &what) { g_error = what; return code; }
+
+// after the table changed: the prefix directory of k_find_matches (tables of 2^32 entries and more go without)
+void buildPrefixTable(isaac_gpu_ctx *c)
+{
+    c->prefixBits = 0;
+    if (!c->nKmers || c->nKmers >= (u64(1) << 32) || getenv("ISAAC_GPU_NO_PREFIX_TABLE")) return;
+    u32 bits = 16; while (bits < 28 && (u64(1) << bits) < c->nKmers) ++bits;     // about one entry per bucket, 256 KB .. 1 GB
+    const u64 entries = (u64(1) << bits) + 1;
+    c->prefixTable.reserve(entries + 1);                                            // + 1: the last bucket reads a pair
+    k_prefix_table<<<gridFor(entries, 256), 256, 0, c->stream>>>(c->kmers.p, c->nKmers, bits, c->prefixTable.p);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemsetAsync(c->prefixTable.p + entries, 0xff, 4, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->prefixBits = bits;
+}
 #define ISAAC_TRY try {
 #define ISAAC_CATCH } catch (const HipError &e) { return fail(e.code == hipErrorOutOfMemory ? ISAAC_GPU_ENOMEM : ISAAC_GPU_EHIP, e.what()); } \
                       catch (const std::invalid_argument &e) { return fail(ISAAC_GPU_EINVAL, e.what()); } \
@@ -996,6 +1028,7 @@ int isaac_gpu_load_index(isaac_gpu_ctx *c, const isaac_reference_kmer *const *ma
     }
     c->kmers.reserve(total + 1); c->positions.reserve(total + 1); c->nKmers = total;
     if (total) { HIP_CHECK(hipMemcpy(c->kmers.p, k.data(), total * 8, hipMemcpyHostToDevice)); HIP_CHECK(hipMemcpy(c->positions.p, p.data(), total * 8, hipMemcpyHostToDevice)); }
+    buildPrefixTable(c);
     c->hasKaryotype = false;
     if (karyotype)
     {
@@ -1022,7 +1055,7 @@ int isaac_gpu_build_index(isaac_gpu_ctx *c, uint32_t repeatThreshold, int annota
     HIP_CHECK(hipMemcpyAsync(&lastValid, valid.p + totalBases - 1, 4, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     const u64 n = 2 * u64(lastSlot + lastValid);
-    if (!n) { c->nKmers = 0; c->kmers.reserve(1); c->positions.reserve(1); if (nEntriesOut) *nEntriesOut = 0; return 0; }
+    if (!n) { c->nKmers = 0; c->prefixBits = 0; c->kmers.reserve(1); c->positions.reserve(1); if (nEntriesOut) *nEntriesOut = 0; return 0; }
     DevBuf<u64> keys0, vals0, keys, vals; keys0.reserve(n); vals0.reserve(n); keys.reserve(n); vals.reserve(n);
     k_kmer_emit<<<gridFor(totalBases, 256), 256, 0, st>>>(c->bases, c->contigOffset.p, c->nContigs, totalBases, valid.p, slot.p, keys0.p, vals0.p);
     sortPairs(c, keys0.p, keys.p, vals0.p, vals.p, n);
@@ -1067,6 +1100,7 @@ int isaac_gpu_build_index(isaac_gpu_ctx *c, uint32_t repeatThreshold, int annota
                                                       annotateNeighbors ? runNeighbors.p : nullptr, c->kmers.p, c->positions.p);
     HIP_CHECK(hipStreamSynchronize(st));
     c->hasKaryotype = false;
+    buildPrefixTable(c);
     if (nEntriesOut) *nEntriesOut = nOut;
     return 0;
     ISAAC_CATCH
