@@ -121,7 +121,7 @@ def main():
 
     counters = al.counters()
     timers = {k: al.kernel_time_ms(k) for k in ("find_matches", "order_fragments", "build_fragments", "gapped_fragments", "finish_fragments", "plan_rescue", "rescue_windows", "rescue_align", "order_select",
-                                                 "rescue_gapped_plan", "gapped_rescue", "select", "select_heavy")}
+                                                 "rescue_gapped_plan", "gapped_rescue", "select", "select_heavy", "select_residual", "compact_matches")}
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()

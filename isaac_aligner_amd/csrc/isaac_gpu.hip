@@ -58,11 +58,12 @@ struct isaac_gpu_ctx
     DevBuf<u64> contigOffset; std::vector<u64> hContigOffset; DevBuf<u8> contigLoaded; std::vector<u8> hContigLoaded; u32 nContigs = 0;
     DevBuf<u64> kmers, positions; u64 nKmers = 0; DevBuf<u32> karyotype; bool hasKaryotype = false;
     DevBuf<u32> prefixTable; u32 prefixBits = 0;
+    DevBuf<u64> matchBase;
     DevBuf<double> logTables;
     // work
     DevBuf<Match> staging; DevBuf<u32> counts, chunkOffsets; DevBuf<u8> cubTemp; DevBuf<u32> contigHits;
-    DevBuf<ClusterFragments> frags; DevBuf<FragmentWork> fragWork;
-    DevBuf<GappedJob> gappedJobs; DevBuf<GappedResult> gappedResults; DevBuf<u32> gappedBase, gappedCounters;
+    DevBuf<ClusterFragments> frags, fragsAlt; ClusterFragments *fragsCur = nullptr; DevBuf<FragmentWork> fragWork;   // fragsAlt: see isaac_gpu_select
+    DevBuf<GappedJob> gappedJobs, rescueGappedJobs; DevBuf<GappedResult> gappedResults, rescueGappedResults; DevBuf<u32> gappedBase, gappedCounters;
     DevBuf<u8> lightArena, heavyArena; DevBuf<u32> overflowList; DevBuf<u32> overflowCount;
     DevBuf<TlsSample> tlsSamples;
     DevBuf<RescueJob> jobs; DevBuf<u32> rescueCounters, bitmaps, candJob, shadowCigars, jobBase, jobCount; DevBuf<i32> candPositions; DevBuf<Cand> shadowCands; DevBuf<u32> candRank;
@@ -272,12 +273,19 @@ __global__ __launch_bounds__(FIND_BLOCK) void k_find_matches(DevParams P, DevRef
     flushCounters(local, counters);
 }
 
-__global__ void k_compact_matches(const Match *staging, const u32 *counts, const u32 *chunkOffsets, u32 nClusters, u32 stride, u64 base,
+// the running output offset stays on the device: no host round trip between the chunks of a tile
+__global__ void k_advance_match_base(u64 *baseDev, const u32 *chunkOffsets, const u32 *counts, u32 nClusters, u64 *offsetsEnd)
+{
+    *baseDev += u64(chunkOffsets[nClusters - 1]) + counts[nClusters - 1];
+    *offsetsEnd = *baseDev;
+}
+
+__global__ void k_compact_matches(const Match *staging, const u32 *counts, const u32 *chunkOffsets, u32 nClusters, u32 stride, const u64 *baseDev,
                                   Match *out, u64 capacity, u64 *offsetsOut)
 {
     const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nClusters) return;
-    const u64 at = base + chunkOffsets[c];
+    const u64 at = *baseDev + chunkOffsets[c];
     offsetsOut[c] = at;
     const u32 n = counts[c];
     const Match *src = staging + u64(c) * stride;
@@ -1134,7 +1142,8 @@ int isaac_gpu_find_matches(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClust
     c->staging.reserve(size_t(chunk) * stride); c->counts.reserve(chunk); c->chunkOffsets.reserve(chunk);
     HIP_CHECK(hipMemsetAsync(c->contigHits.p, 0, c->nContigs * 4, st));
     const DevReference R = c->ref();
-    u64 base = 0;
+    c->matchBase.reserve(1);
+    HIP_CHECK(hipMemsetAsync(c->matchBase.p, 0, 8, st));
     for (u32 done = 0; done < nClusters; done += chunk)
     {
         const u32 n = std::min(chunk, nClusters - done);
@@ -1145,16 +1154,16 @@ int isaac_gpu_find_matches(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClust
                                                                                           c->staging.p, c->counts.p, stride, c->contigHits.p, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }
+        ScopedTimer t(c, "compact_matches");
         exclusiveSum(c, c->counts.p, c->chunkOffsets.p, n);
-        k_compact_matches<<<gridFor(n, 256), 256, 0, st>>>(c->staging.p, c->counts.p, c->chunkOffsets.p, n, stride, base,
+        k_compact_matches<<<gridFor(n, 256), 256, 0, st>>>(c->staging.p, c->counts.p, c->chunkOffsets.p, n, stride, c->matchBase.p,
                                                             reinterpret_cast<Match *>(matchesOut), capacity, clusterOffsets + done);
-        u32 lastOff = 0, lastCount = 0;
-        HIP_CHECK(hipMemcpyAsync(&lastOff, c->chunkOffsets.p + n - 1, 4, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipMemcpyAsync(&lastCount, c->counts.p + n - 1, 4, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        base += u64(lastOff) + lastCount;
+        k_advance_match_base<<<1, 1, 0, st>>>(c->matchBase.p, c->chunkOffsets.p, c->counts.p, n, clusterOffsets + done + n);
+        HIP_CHECK(hipGetLastError());
     }
-    HIP_CHECK(hipMemcpyAsync(clusterOffsets + nClusters, &base, 8, hipMemcpyHostToDevice, st));
+    u64 base = 0;
+    if (!nClusters) HIP_CHECK(hipMemcpyAsync(clusterOffsets, &base, 8, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(&base, c->matchBase.p, 8, hipMemcpyDeviceToHost, st));
     if (contigHasMatches)
     {
         std::vector<u32> hits(c->nContigs);
@@ -1183,8 +1192,10 @@ static GappedBuffers gappedBuffers(isaac_gpu_ctx *c, u32 which)
 {
     GappedBuffers gb;
     gb.cap = 2 * c->chunkClusters;
-    c->gappedJobs.reserve(gb.cap); c->gappedResults.reserve(gb.cap); c->gappedBase.reserve(c->chunkClusters); c->gappedCounters.reserve(4);
-    gb.jobs = c->gappedJobs.p; gb.results = c->gappedResults.p; gb.base = c->gappedBase.p; gb.counter = c->gappedCounters.p + which;
+    // the rescue stage has its own arrays: the wave-per-cluster pass still reads them while the next chunk's fragment stage runs
+    DevBuf<GappedJob> &jobs = which ? c->rescueGappedJobs : c->gappedJobs; DevBuf<GappedResult> &results = which ? c->rescueGappedResults : c->gappedResults;
+    jobs.reserve(gb.cap); results.reserve(gb.cap); c->gappedBase.reserve(c->chunkClusters); c->gappedCounters.reserve(4);
+    gb.jobs = jobs.p; gb.results = results.p; gb.base = c->gappedBase.p; gb.counter = c->gappedCounters.p + which;
     return gb;
 }
 
@@ -1200,6 +1211,7 @@ static void launchGappedJobs(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clusterBa
 static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clusterBase, u32 n, const isaac_match *matches, const uint64_t *offsets, int withGaps, int trim)
 {
     c->frags.reserve(c->chunkClusters); c->fragWork.reserve(c->chunkClusters);
+    if (!c->fragsCur) c->fragsCur = c->frags.p;
     const GappedBuffers gb = gappedBuffers(c, 0);
     HIP_CHECK(hipMemsetAsync(c->gappedCounters.p, 0, 16, c->stream));
     const u32 *order = nullptr;
@@ -1214,13 +1226,13 @@ static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clust
     {
         ScopedTimer t(c, "build_fragments");
         k_build_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, reinterpret_cast<const Match *>(matches), offsets,
-                                                                 withGaps, trim, order, c->fragWork.p, c->frags.p, gb, c->counters.p);
+                                                                 withGaps, trim, order, c->fragWork.p, c->fragsCur, gb, c->counters.p);
         HIP_CHECK(hipGetLastError());
     }
     if (withGaps) launchGappedJobs(c, bcl, clusterBase, gb, "gapped_fragments");
     {
         ScopedTimer t(c, "finish_fragments");
-        k_finish_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, withGaps, order, c->fragWork.p, c->frags.p, gb, c->counters.p);
+        k_finish_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, withGaps, order, c->fragWork.p, c->fragsCur, gb, c->counters.p);
         HIP_CHECK(hipGetLastError());
     }
 }
@@ -1241,9 +1253,9 @@ int isaac_gpu_build_fragments(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nCl
         const u32 n = std::min(chunk, nClusters - done);
         launchBuildFragments(c, bcl, done, n, matches, offsets, withGaps, trim);
         if (!candidates) continue;
-        k_count_candidates<<<gridFor(n, 256), 256, 0, st>>>(c->frags.p, n, nc.p, ng.p);
+        k_count_candidates<<<gridFor(n, 256), 256, 0, st>>>(c->fragsCur, n, nc.p, ng.p);
         exclusiveSum(c, nc.p, oc.p, n); exclusiveSum(c, ng.p, og.p, n);
-        k_write_candidates<<<gridFor(n, 256), 256, 0, st>>>(c->frags.p, done, n, oc.p, og.p, candBase, cigarBase, candidates, capacity, cigar, cigarCapacity);
+        k_write_candidates<<<gridFor(n, 256), 256, 0, st>>>(c->fragsCur, done, n, oc.p, og.p, candBase, cigarBase, candidates, capacity, cigar, cigarCapacity);
         u32 a[4];
         HIP_CHECK(hipMemcpyAsync(a + 0, oc.p + n - 1, 4, hipMemcpyDeviceToHost, st)); HIP_CHECK(hipMemcpyAsync(a + 1, nc.p + n - 1, 4, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipMemcpyAsync(a + 2, og.p + n - 1, 4, hipMemcpyDeviceToHost, st)); HIP_CHECK(hipMemcpyAsync(a + 3, ng.p + n - 1, 4, hipMemcpyDeviceToHost, st));
@@ -1274,7 +1286,7 @@ int isaac_gpu_determine_tls(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         {
             const u32 n = std::min(chunk, nClusters - done);
             launchBuildFragments(c, bcl, done, n, matches, offsets, 0, 0);     // MatchSelector.cpp:233-245: no gaps, no quality trimming
-            k_tls_samples<<<gridFor(n, 256), 256, 0, st>>>(c->frags.p, offsets, done, n, c->tlsSamples.p);
+            k_tls_samples<<<gridFor(n, 256), 256, 0, st>>>(c->fragsCur, offsets, done, n, c->tlsSamples.p);
             HIP_CHECK(hipMemcpyAsync(h.data(), c->tlsSamples.p, size_t(n) * sizeof(TlsSample), hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
             for (u32 i = 0; i < n && !learner.stats.stable; ++i) learner.add(h[i]);
@@ -1319,18 +1331,24 @@ int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, u
         rb.jobCounter = c->rescueCounters.p; rb.bitmapCounter = c->rescueCounters.p + 1; rb.candCounter = c->rescueCounters.p + 2;
     }
     const DevReference R = c->ref();
-    const GappedBuffers gbRescue = gappedBuffers(c, 1);   // counter 1; the job and result arrays are the fragment stage's, free again by then
+    const GappedBuffers gbRescue = gappedBuffers(c, 1);
+    c->frags.reserve(chunk); c->fragsAlt.reserve(chunk);
+    bool heavyPending = false; u32 chunkIndex = 0;
     for (u32 done = 0; done < nClusters; done += chunk)
     {
         const u32 n = std::min(chunk, nClusters - done);
+        // two ClusterFragments buffers take turns: the fragment stage of this chunk runs while the wave-per-cluster pass of the
+        // previous chunk is still reading its own; everything else that pass reads is rewritten only after the wait below
+        c->fragsCur = (chunkIndex++ & 1) ? c->fragsAlt.p : c->frags.p;
         launchBuildFragments(c, bcl, done, n, matches, offsets, 1, 1);
+        if (heavyPending) { HIP_CHECK(hipStreamWaitEvent(st, c->evHeavyDone, 0)); heavyPending = false; }
         HIP_CHECK(hipMemsetAsync(c->overflowCount.p, 0, 4, st));
         if (c->flatRescue)
         {
             HIP_CHECK(hipMemsetAsync(c->rescueCounters.p, 0, 16, st));
             {
                 ScopedTimer tm(c, "plan_rescue");
-                k_plan_rescue<<<gridFor(n, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, n, c->frags.p, c->lightArena.p, lightBytes, light, rb);
+                k_plan_rescue<<<gridFor(n, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, n, c->fragsCur, c->lightArena.p, lightBytes, light, rb);
                 HIP_CHECK(hipGetLastError());
             }
             {
@@ -1340,35 +1358,35 @@ int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, u
             }
             {
                 ScopedTimer tm(c, "rescue_align");
-                k_rescue_align<<<gridFor(rb.candCap, 256), 256, 0, st>>>(c->P, R, bcl, done, c->frags.p, rb, c->counters.p);
+                k_rescue_align<<<gridFor(rb.candCap, 256), 256, 0, st>>>(c->P, R, bcl, done, c->fragsCur, rb, c->counters.p);
                 HIP_CHECK(hipGetLastError());
             }
             {
                 ScopedTimer tm(c, "rescue_gapped_plan");
-                k_rescue_gapped_plan<<<gridFor(rb.jobsCap, 256), 256, 0, st>>>(c->frags.p, rb, gbRescue, c->counters.p);
+                k_rescue_gapped_plan<<<gridFor(rb.jobsCap, 256), 256, 0, st>>>(c->fragsCur, rb, gbRescue, c->counters.p);
                 HIP_CHECK(hipGetLastError());
             }
             launchGappedJobs(c, bcl, done, gbRescue, "gapped_rescue");
         }
         const bool predicted = c->flatRescue;
+        c->heavyArena.reserve(size_t(heavyThreads + residualThreads) * heavyBytes);
         if (predicted)
         {   // clusters that cannot fit the light lists start on their own stream now, next to k_select
-            c->heavyArena.reserve(size_t(heavyThreads + residualThreads) * heavyBytes);
             c->heavyList.reserve(chunk); c->heavyCount.reserve(1); c->heavyFlag.reserve(chunk);
             c->classKeys.reserve(chunk); c->classKeysSorted.reserve(chunk); c->classIdx.reserve(chunk); c->selectOrder.reserve(chunk);
             HIP_CHECK(hipMemsetAsync(c->heavyCount.p, 0, 4, st));
-            k_predict_heavy<<<gridFor(n, 256), 256, 0, st>>>(c->frags.p, n, rb, light, c->heavyFlag.p, c->heavyList.p, c->heavyCount.p,
+            k_predict_heavy<<<gridFor(n, 256), 256, 0, st>>>(c->fragsCur, n, rb, light, c->heavyFlag.p, c->heavyList.p, c->heavyCount.p,
                                                              c->workClasses ? c->classKeys.p : nullptr, c->classIdx.p);
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipEventRecord(c->evPredicted, st));
             HIP_CHECK(hipStreamWaitEvent(c->heavyStream, c->evPredicted, 0));
             {
                 ScopedTimer tm(c, "select_heavy", c->heavyStream);
-                k_select_heavy<<<heavyThreads, 64, HEAVY_SORT_LDS * 2, c->heavyStream>>>(c->P, R, t, rog, lmq40, bcl, done, 0, c->heavyCount.p, tile, c->frags.p, c->heavyArena.p, heavyBytes, heavy,
+                k_select_heavy<<<heavyThreads, 64, HEAVY_SORT_LDS * 2, c->heavyStream>>>(c->P, R, t, rog, lmq40, bcl, done, 0, c->heavyCount.p, tile, c->fragsCur, c->heavyArena.p, heavyBytes, heavy,
                                                                                          c->heavyList.p, rb, gbRescue.results, gbRescue.jobs, reinterpret_cast<FragmentRecord *>(fragments), cigar, c->counters.p);
                 HIP_CHECK(hipGetLastError());
             }
-            HIP_CHECK(hipEventRecord(c->evHeavyDone, c->heavyStream));
+            HIP_CHECK(hipEventRecord(c->evHeavyDone, c->heavyStream)); heavyPending = true;
         }
         const u32 *selectOrder = nullptr;
         if (predicted && c->workClasses)
@@ -1379,26 +1397,21 @@ int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, u
         }
         {
             ScopedTimer tm(c, "select");
-            k_select<<<gridFor(n, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, n, tile, c->frags.p, c->lightArena.p, lightBytes, light, nullptr, rb, c->flatRescue ? gbRescue.results : nullptr, c->flatRescue ? gbRescue.jobs : nullptr,
+            k_select<<<gridFor(n, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, n, tile, c->fragsCur, c->lightArena.p, lightBytes, light, nullptr, rb, c->flatRescue ? gbRescue.results : nullptr, c->flatRescue ? gbRescue.jobs : nullptr,
                                                      reinterpret_cast<FragmentRecord *>(fragments), cigar, c->overflowList.p, c->overflowCount.p, chunk, predicted ? c->heavyFlag.p : nullptr, selectOrder, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }
-        u32 nOverflow = 0;
-        HIP_CHECK(hipMemcpyAsync(&nOverflow, c->overflowCount.p, 4, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        nOverflow = std::min(nOverflow, chunk);
-        for (u32 od = 0; od < nOverflow; od += residualThreads)
-        {   // what the prediction missed: again, with the reference's own capacities
-            const u32 m = std::min(residualThreads, nOverflow - od);
-            c->heavyArena.reserve(size_t(heavyThreads + residualThreads) * heavyBytes);
-            ScopedTimer tm(c, "select_heavy");
-            k_select_heavy<<<m, 64, HEAVY_SORT_LDS * 2, st>>>(c->P, R, t, rog, lmq40, bcl, done, m, nullptr, tile, c->frags.p, c->heavyArena.p + size_t(heavyThreads) * heavyBytes, heavyBytes, heavy,
-                                                              c->overflowList.p + od, rb, c->flatRescue ? gbRescue.results : nullptr, c->flatRescue ? gbRescue.jobs : nullptr, reinterpret_cast<FragmentRecord *>(fragments), cigar, c->counters.p);
+        {   // what the prediction missed (normally nothing): again, with the reference's own capacities; the count stays on the device
+            ScopedTimer tm(c, "select_residual");
+            k_select_heavy<<<residualThreads, 64, HEAVY_SORT_LDS * 2, st>>>(c->P, R, t, rog, lmq40, bcl, done, 0, c->overflowCount.p, tile, c->fragsCur,
+                                                                            c->heavyArena.p + size_t(heavyThreads) * heavyBytes, heavyBytes, heavy, c->overflowList.p, rb,
+                                                                            c->flatRescue ? gbRescue.results : nullptr, c->flatRescue ? gbRescue.jobs : nullptr,
+                                                                            reinterpret_cast<FragmentRecord *>(fragments), cigar, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }
-        // the chunk's buffers are reused by the next chunk: its first kernel waits for the wave-per-cluster pass
-        if (predicted) HIP_CHECK(hipStreamWaitEvent(st, c->evHeavyDone, 0));
     }
+    if (heavyPending) HIP_CHECK(hipStreamWaitEvent(st, c->evHeavyDone, 0));
+    c->fragsCur = c->frags.p;
     HIP_CHECK(hipStreamSynchronize(st));
     return 0;
     ISAAC_CATCH
