@@ -17,6 +17,14 @@ namespace isaac
 
 __device__ inline int s16(int v) { return int(short(v)); }
 
+// Lane exchange inside the 16-lane group of one alignment.  The group is one DPP row, so neighbour shifts are register
+// operations (row_shr / row_shl / quad_perm) instead of trips through the LDS crossbar (ds_bpermute).  Lanes whose source
+// falls outside the row keep their own value, as __shfl_up / __shfl_down do.
+template <int CTRL> __device__ inline int dpp16(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+__device__ inline int rowUp1(int v) { return dpp16<0x111>(v); }          // lane k <- lane k - 1   (row_shr:1)
+__device__ inline int rowXor1(int v) { return dpp16<0xB1>(v); }          // lane k <- lane k ^ 1   (quad_perm [1,0,3,2])
+template <int N> __device__ inline int rowDown(int v) { return dpp16<0x100 + N>(v); }   // lane k <- lane k + N (row_shl:N)
+
 // LDS bytes per alignment group
 __host__ __device__ inline u32 bswGroupLdsBytes(u32 maxQueryLength) { return ((maxQueryLength * 16 + 15) & ~15u) + 128; }
 
@@ -36,7 +44,7 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
     for (u32 i = 0; i < L; ++i)
     {
         // F: lane k from lane k-1 of the previous row (:130-173)
-        const int gp = __shfl_up(G, 1, 16), ep = __shfl_up(E, 1, 16), fp = __shfl_up(F, 1, 16);
+        const int gp = rowUp1(G), ep = rowUp1(E), fp = rowUp1(F);
         int tf = (gp < ep) ? 1 : 0;
         const int v = s16(max(gp, ep) - open), fe = s16(fp - ext);
         if (v < fe) tf = 2;
@@ -47,7 +55,7 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
         const int m = max(G, E);
         const int fF = (m < F) ? 1 : 0;
         int newG = max(m, F);
-        const int pfE = __shfl_xor(fE, 1, 16), pfF = __shfl_xor(fF, 1, 16);
+        const int pfE = rowXor1(fE), pfF = rowXor1(fF);
         int tg;
         if (k & 1) tg = fF ? 2 : fE;
         else tg = pfF ? 2 * fF : (pfE ? fE : max(2 * fF, fE));
@@ -58,21 +66,21 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
         const int g = s16(newG - open), f = s16(newF - open);
         const int NEG = -(1 << 28);
         int c = max(g, f) - int(k) * ext;
-        int s = __shfl_down(c, 1, 16); if (k + 1 > 15) s = NEG;
+        int s = rowDown<1>(c); if (k + 1 > 15) s = NEG;
         int t;
-        t = __shfl_down(s, 1, 16); if (k + 1 <= 15) s = max(s, t);
-        t = __shfl_down(s, 2, 16); if (k + 2 <= 15) s = max(s, t);
-        t = __shfl_down(s, 4, 16); if (k + 4 <= 15) s = max(s, t);
-        t = __shfl_down(s, 8, 16); if (k + 8 <= 15) s = max(s, t);
+        t = rowDown<1>(s); if (k + 1 <= 15) s = max(s, t);
+        t = rowDown<2>(s); if (k + 2 <= 15) s = max(s, t);
+        t = rowDown<4>(s); if (k + 4 <= 15) s = max(s, t);
+        t = rowDown<8>(s); if (k + 8 <= 15) s = max(s, t);
         const int newE = (k == 15) ? initialValue : s16(s + int(k + 1) * ext);
         // TE from lane k+1's (g, E - ext, f) with the reference's tie rules
-        const int g1 = __shfl_down(g, 1, 16), f1 = __shfl_down(f, 1, 16), e1 = s16(__shfl_down(newE, 1, 16) - ext);
+        const int g1 = rowDown<1>(g), f1 = rowDown<1>(f), e1 = s16(rowDown<1>(newE) - ext);
         int te = 0;
         if (k < 15) { if (e1 > g1 && e1 > f1) te = 1; else if (f1 > g1) te = 2; }
         T[i * 16 + k] = u8(tg | (te << 2) | (tf << 4));
         G = newG; E = newE; F = newF;
         // slide the database window: lane k takes lane k-1's base, lane 0 loads the next one
-        const char dn = char(__shfl_up(int(d), 1, 16));
+        const char dn = char(rowUp1(int(d)));
         d = (k == 0) ? ((i + 1 < L) ? database[i + 16] : char(0)) : dn;
     }
     endVals[k] = short(G); endVals[16 + k] = short(E); endVals[32 + k] = short(F);
