@@ -635,6 +635,7 @@ ISAAC_HD bool buildFragments(const DevParams &P, const DevReference &R, const u8
                              bool withGaps, bool trim, FragmentWork &work, ClusterFragments &out, Counters &cnt)
 {
     out.nCands[0] = out.nCands[1] = 0; out.cigarUsed = 0; out.flags = 0; out.repeatSeedsCount = 0; out.built = 0;
+    STAMP_BEGIN();
     ReadView reads[2];
     for (u32 r = 0; r < 2; ++r)
     {
@@ -642,6 +643,7 @@ ISAAC_HD bool buildFragments(const DevParams &P, const DevReference &R, const u8
         reads[r].endCyclesMasked = (trim && r < P.nReads) ? trimLowQualityEnd(reads[r].bcl, reads[r].length, P.baseQualityCutoff) : 0;
         out.endCyclesMasked[r] = reads[r].endCyclesMasked;
     }
+    STAMP(20);
     if (!nMatches || nMatches > MATCH_CAP_MAX) { if (nMatches > MATCH_CAP_MAX) out.flags |= CLUSTER_OVERFLOW; return false; }
     // seedMatchCounts_ / repeatSeedsCount_ (FragmentBuilder.cpp:99-126): order independent once stated per seed index
     u32 counts[MAX_SEEDS]; bool tooMany[MAX_SEEDS];
@@ -658,9 +660,11 @@ ISAAC_HD bool buildFragments(const DevParams &P, const DevReference &R, const u8
     u32 repeatSeedsCount = 0;
     for (u32 s = 0; s < P.nSeeds; ++s) if (tooMany[s] || counts[s] >= P.repeatThreshold) ++repeatSeedsCount;
     out.repeatSeedsCount = repeatSeedsCount;
+    STAMP(21);
     // the reference adds candidates in sorted match order; that order is the input order of the first std::sort
     for (u32 i = 0; i < nMatches; ++i) work.matchOrder[i] = u8(i);
     { MatchLess ml; ml.m = matches; exactSort(work.matchOrder, i32(nMatches), ml); }
+    STAMP(22);
     CigarPool pool; pool.words = out.cigarPool; pool.used = 0; pool.capacity = CIGAR_POOL; pool.overflow = 0;
     bool built = false;
     for (u32 r = 0; r < P.nReads; ++r)
@@ -688,10 +692,12 @@ ISAAC_HD bool buildFragments(const DevParams &P, const DevReference &R, const u8
             l.order[l.n++] = u8(l.stored++);
         }
         if (l.overflow) out.flags |= CLUSTER_OVERFLOW;
+        STAMP(23);
         if (!l.n) continue;
         built = true;
         // alignFragments (:147-217)
         consolidateDuplicateFragments(l, false);
+        STAMP(24);
         for (u32 i = 0; i < l.n; ++i)
         {
             Cand &f = l.at(i);
@@ -699,7 +705,9 @@ ISAAC_HD bool buildFragments(const DevParams &P, const DevReference &R, const u8
             alignUngapped(P, R, reads[r], f, pool);
             ++cnt.ungappedScans;
         }
+        STAMP(25);
         consolidateDuplicateFragments(l, true);
+        STAMP(26);
         if (P.semialignedGapLimit)
         {
             u32 si = 0;
@@ -707,10 +715,12 @@ ISAAC_HD bool buildFragments(const DevParams &P, const DevReference &R, const u8
             cnt.simpleIndels += si;
             consolidateDuplicateFragments(l, true);
         }
+        STAMP(27);
         // the candidates stay in list order; the gapped retries (FragmentBuilder.cpp:187-214) follow in finishFragments
         if (l.n > CAND_CAP) l.n = CAND_CAP;
         for (u32 i = 0; i < l.n; ++i) out.cands[r][i] = l.at(i);
         out.nCands[r] = l.n;
+        STAMP(28);
     }
     out.cigarUsed = pool.used;
     if (pool.overflow) out.flags |= CLUSTER_OVERFLOW;

@@ -125,6 +125,7 @@ ISAAC_HD void clusterSelect(const DevParams &P, const DevReference &R, const Dev
                             const u8 *bcl, u32 cluster, u32 tile, const ClusterFragments &frags, TemplateWork &work,
                             FragmentRecord *records, u32 *cigars, Counters &cnt, const RescueInputs *rescue = 0, const CoopInputs *coop = 0)
 {
+    STAMP_BEGIN();
     TemplateCtx x;
     templateCtxInit(x, P, R, tls, rog, bcl, cluster, frags, work, cnt);
     if (coop) { x.lanes = coop->lanes; x.lane = coop->lane; x.fastSort = coop->fastSort; x.ldsSort = coop->ldsSort; x.ldsSortCap = coop->ldsSortCap; }
@@ -136,7 +137,9 @@ ISAAC_HD void clusterSelect(const DevParams &P, const DevReference &R, const Dev
     }
     BamTemplate t;
     ISAAC_PROF_T0(x);
+    STAMP(30);
     const bool store = selectCluster(x, t, logMismatchQ40);
+    STAMP(31);
     ISAAC_PROF_ADD(x, 6);
 #if defined(ISAAC_PROFILE_HEAVY) && defined(__HIP_DEVICE_COMPILE__)
     if (coop && 0 == x.lane)
@@ -158,6 +161,7 @@ ISAAC_HD void clusterSelect(const DevParams &P, const DevReference &R, const Dev
         if (frags.flags & CLUSTER_OVERFLOW) r.reserved |= RECORD_FRAGMENT_OVERFLOW;
         if (!store) r.reserved |= RECORD_NOT_STORED;
     }
+    STAMP(32);
 }
 
 } // namespace isaac

@@ -21,6 +21,10 @@
 #include "host_util.h"
 #include "bsw_kernel.h"
 
+#if defined(ISAAC_KERNEL_STAMPS)
+__device__ unsigned long long g_stamps[64];
+#endif
+
 // occupancy targets (waves per SIMD) of the two thread-per-cluster kernels; the register allocator spills to meet them
 #ifndef ISAAC_SELECT_WAVES
 #define ISAAC_SELECT_WAVES 4
@@ -163,6 +167,7 @@ __global__ __launch_bounds__(FIND_BLOCK) void k_find_matches(DevParams P, DevRef
     extern __shared__ __align__(16) u8 sbcl[];
     const u32 CL = P.clusterLength;
     const u32 firstCluster = blockIdx.x * FIND_CLUSTERS_PER_BLOCK;
+    STAMP_BEGIN();
     {   // stage the block's clusters (contiguous bytes) through LDS with coalesced loads
         const u64 base = u64(firstCluster) * CL;
         const u32 nBytes = imin<u32>(FIND_CLUSTERS_PER_BLOCK, nClusters - firstCluster) * CL;
@@ -177,6 +182,7 @@ __global__ __launch_bounds__(FIND_BLOCK) void k_find_matches(DevParams P, DevRef
         else for (u32 i = threadIdx.x; i < nBytes; i += FIND_BLOCK) sbcl[i] = src[i];
     }
     __syncthreads();
+    STAMP(10);
     const u32 group = threadIdx.x / FIND_GROUP, lane = threadIdx.x % FIND_GROUP;
     const u32 cluster = firstCluster + group;
     const bool active = cluster < nClusters;
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(FIND_BLOCK) void k_find_matches(DevParams P, DevRef
                 seedIdx = P.passSeeds[pass][p >> 1]; strand = p & 1; readIdx = P.seeds[seedIdx].readIndex;
                 if ((complete >> readIdx) & 1) probe = false;      // ClusterSeedGenerator.cpp:148
             }
-            u32 nrec = 0; u64 first = 0; bool tooMany = false; bool completes = false;
+            u32 nrec = 0; u64 first = 0, pos0 = 0; bool tooMany = false; bool completes = false;
             if (probe)
             {
                 // k-mer of the seed: forward MSB-first, reverse complement built from the other end (ClusterSeedGenerator.cpp:162-176)
@@ -212,6 +218,7 @@ __global__ __launch_bounds__(FIND_BLOCK) void k_find_matches(DevParams P, DevRef
                     isN |= !(v & 0xfc);
                     if (strand) kmer = (kmer >> 2) | (u64((~v) & 3) << 62); else kmer = (kmer << 2) | (v & 3);
                 }
+                STAMP(11);
                 if (!isN)
                 {
                     ++local.probes;
@@ -225,12 +232,21 @@ __global__ __launch_bounds__(FIND_BLOCK) void k_find_matches(DevParams P, DevRef
                     }
                     else first = lowerBound(R.kmers, 0, R.nKmers, kmer, steps);
                     local.probeSteps += steps;
-                    // ExactMaskMatcher.cpp:118-126: reference entries with the same k-mer, at most repeatThreshold of them
+                    STAMP(12);
+                    // ExactMaskMatcher.cpp:118-126: reference entries with the same k-mer, at most repeatThreshold of them.
+                    // The first two table entries and the first position are fetched together: most hits are single entries,
+                    // and three loads in flight cost one latency instead of three.
                     u32 r = 0;
-                    while (first + r < R.nKmers && r < P.repeatThreshold && R.kmers[first + r] == kmer) ++r;
+                    const bool in0 = first < R.nKmers, in1 = first + 1 < R.nKmers;
+                    const u64 k0 = in0 ? R.kmers[first] : 0, k1 = in1 ? R.kmers[first + 1] : 0;
+                    pos0 = in0 ? R.positions[first] : 0;
+                    if (in0 && k0 == kmer)
+                    {
+                        r = 1;
+                        if (in1 && k1 == kmer) { r = 2; while (first + r < R.nKmers && r < P.repeatThreshold && R.kmers[first + r] == kmer) ++r; }
+                    }
                     if (r)
                     {
-                        const u64 pos0 = R.positions[first];
                         if (r >= P.repeatThreshold || refposIsTooMany(pos0))
                         {   // :135-154 generateTooManyMatches; the second iteration closes the read (MatchFinder.cpp:299)
                             tooMany = true; nrec = 1;
@@ -244,6 +260,7 @@ __global__ __launch_bounds__(FIND_BLOCK) void k_find_matches(DevParams P, DevRef
                     }
                 }
             }
+            STAMP(13);
             // exclusive prefix of nrec over the 8 lanes of the group
             u32 incl = nrec;
             for (u32 o = 1; o < FIND_GROUP; o <<= 1) { const u32 t = __shfl_up(incl, o, FIND_GROUP); if (lane >= o) incl += t; }
@@ -255,13 +272,16 @@ __global__ __launch_bounds__(FIND_BLOCK) void k_find_matches(DevParams P, DevRef
                 if (tooMany) { if (at < stride) { out[at].seedId = sid; out[at].location = 0; } }
                 else for (u32 i = 0; i < nrec; ++i, ++at)
                 {
-                    u64 pos = R.positions[first + i];
+                    u64 pos = i ? R.positions[first + i] : pos0;
                     if (R.karyotype) { const u32 c = u32(pos >> 41); pos = (u64(R.karyotype[c - 1] + 1) << 41) | (pos & ((u64(1) << 41) - 1)); }
                     if (at < stride) { out[at].seedId = sid; out[at].location = pos; }
-                    contigHits[refposContig(pos)] = 1;      // MatchDistribution::addMatches (:173-181): the contig is not empty
+                    // MatchDistribution::addMatches (:173-181): the contig is not empty.  Read before write: millions of stores to
+                    // the same word serialise in L2, reads of it do not
+                    if (!contigHits[refposContig(pos)]) contigHits[refposContig(pos)] = 1;
                 }
                 local.matches += nrec;
             }
+            STAMP(14);
             written += total;
             u32 c = completes ? (1u << readIdx) : 0;
             for (u32 o = 1; o < FIND_GROUP; o <<= 1) c |= __shfl_xor(c, o, FIND_GROUP);
@@ -270,7 +290,9 @@ __global__ __launch_bounds__(FIND_BLOCK) void k_find_matches(DevParams P, DevRef
         complete = completeNext;
     }
     if (active && lane == 0) counts[cluster] = imin(written, stride);
+    STAMP(15);
     flushCounters(local, counters);
+    STAMP(16);
 }
 
 // the running output offset stays on the device: no host round trip between the chunks of a tile
@@ -408,12 +430,16 @@ static const u32 KMER_EMPTY = 0xffffffffu;
 static const u32 RW_TABLE = 512;          // hash slots for the mate's <= 250-odd 7-mers
 static const u32 RW_LDS_BITMAP = 64;      // words: windows up to ~1900 bases keep their candidate bitmap in LDS
 static const u32 RW_PER_LANE = 16;        // consecutive window positions per lane and tile
+static const u32 CAND_REGIONS = 256;
 
 struct RescueBuffers
 {
     RescueJob *jobs; u32 jobsCap; u32 *jobCounter;
     u32 *bitmaps; u32 bitmapCap; u32 *bitmapCounter;
     i32 *candPositions; u32 *candJob; Cand *shadowCands; u32 *shadowCigars; u32 *candRank; u32 candCap; u32 *candCounter;
+    // candidate slots are handed out from CAND_REGIONS equal regions, each with its own counter (candCounter[region]): one
+    // counter for every workgroup of a chunk serialises at ~8 ns per atomic
+    u32 candRegionSize;
     u32 *jobBase; u32 *jobCount;   // per cluster of the chunk; jobBase == 0xffffffff: the cluster runs its rescues itself
 };
 
@@ -546,7 +572,9 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
     const u32 nJobs = imin(*rb.jobCounter, rb.jobsCap);
     RescueJob job;
     bool active = j < nJobs;
+    STAMP_BEGIN();
     if (active) { job = rb.jobs[j]; active = job.valid && !job.fallback; }
+    STAMP(0);
     u32 pushes = 0, total = 0, bitmapWords = 0, L = 0;
     bool small = true;
     u32 *bitmap = ldsBitmaps[wave];
@@ -562,13 +590,25 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
         for (u32 i = lane; i < bitmapWords; i += 64) bitmap[i] = 0;
         if (!small) __threadfence();
         __builtin_amdgcn_wave_barrier();
+        STAMP(1);
         // the mate's 7-mers: first read position of every k-mer (ShadowAligner::hashShadowKmers, :53-72)
         ReadView read; read.bcl = bcl + u64(clusterBase + job.cluster) * P.clusterLength + P.readOffset[r]; read.length = L; read.endCyclesMasked = 0; read.firstCycle = 0;
         const bool reverse = job.shadowReverse != 0;
         for (u32 i = lane; i + 7 <= L; i += 64)
         {
+            // the 7 BCL bytes of strand positions i .. i+6 sit in 7 consecutive bytes of the read either way: one 8-byte load
+            const u32 first = reverse ? L - 7 - i : i;           // lowest BCL index of the k-mer
+            u64 bytes = 0;
+            if (first + 8 <= L) memcpy(&bytes, read.bcl + first, 8);
+            else { memcpy(&bytes, read.bcl + L - 8, 8); bytes >>= 8 * (first + 8 - L); }
             u32 kmer = 0; bool ok = true;
-            for (u32 k = 0; k < 7; ++k) { const u32 code = rwCode(u32(u8(strandBase(read, reverse, i + k)))); ok &= code < 4; kmer = (kmer << 2) | (code & 3); }
+#pragma unroll
+            for (u32 k = 0; k < 7; ++k)
+            {
+                const u8 b = u8(bytes >> (8 * (reverse ? 6 - k : k)));
+                const u32 code = rwCode(u32(u8(strandBaseOf(b, reverse))));
+                ok &= code < 4; kmer = (kmer << 2) | (code & 3);
+            }
             if (!ok) continue;
             const u32 val = (kmer << 10) | i;
             u32 h = (kmer * 2654435761u) >> 23;
@@ -583,8 +623,10 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        STAMP(2);
         if (small) rescueWindowScan<true>(R, totalBases, job, L, tab, ldsBitmaps[wave], lane, pushes);
         else { rescueWindowScan<false>(R, totalBases, job, L, tab, bitmap, lane, pushes); __threadfence(); }
+        STAMP(3);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -598,21 +640,31 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
             total += c;
         }
     }
+    STAMP(4);
     bool fallback = pushes > SHADOW_POSITIONS_MAX;
     if (fallback) total = 0;
     // one allocation per workgroup: a single counter serves every rescue problem of the chunk
     if (lane == 0) waveTotals[wave] = total;
     __syncthreads();
+    STAMP(5);
     if (threadIdx.x == 0)
     {
         const u32 sum = waveTotals[0] + waveTotals[1] + waveTotals[2] + waveTotals[3];
-        blockBase = sum ? atomicAdd(rb.candCounter, sum) : 0u;
+        const u32 region = blockIdx.x % CAND_REGIONS;
+        u32 base = 0xffffffffu;
+        if (sum)
+        {
+            const u32 at = atomicAdd(rb.candCounter + region, sum);
+            if (at + sum <= rb.candRegionSize) base = region * rb.candRegionSize + at;   // else: the region is full, these problems fall back
+        }
+        blockBase = base;
     }
     __syncthreads();
+    STAMP(6);
     if (!active) return;
     u32 candBase = blockBase;
+    if (total && candBase == 0xffffffffu) fallback = true;
     for (u32 w = 0; w < wave; ++w) candBase += waveTotals[w];
-    if (total && candBase + total > rb.candCap) fallback = true;
     if (!fallback && total)
     {
         const i32 bias = i32(L) - 7;
@@ -638,15 +690,15 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
         RescueJob &out = rb.jobs[j];
         out.pushes = pushes; out.fallback = fallback ? 1 : 0; out.candBase = candBase; out.nCands = fallback ? 0 : total;
     }
+    STAMP(7);
 }
 
 __global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const ClusterFragments *frags, RescueBuffers rb, Counters *counters)
 {
     ISAAC_STAGE_QUALITY_TABLES(Rg, R)
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    const u32 n = imin(*rb.candCounter, rb.candCap);
     Counters local; memset(&local, 0, sizeof(local));
-    if (i < n)
+    if (i < rb.candCap && i % rb.candRegionSize < imin(rb.candCounter[i / rb.candRegionSize], rb.candRegionSize))
     {
         const RescueJob &job = rb.jobs[rb.candJob[i]];
         rescueAlignCandidate(P, R, bcl, clusterBase + job.cluster, frags[job.cluster], job, rb.candPositions[i], rb.shadowCands[i], rb.shadowCigars + u64(i) * 3);
@@ -973,6 +1025,12 @@ void isaac_gpu_destroy(isaac_gpu_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     resolveTimers(c);
+#if defined(ISAAC_KERNEL_STAMPS)
+    {
+        unsigned long long h[64]; hipDeviceSynchronize(); hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof(h));
+        for (int i = 0; i < 64; ++i) if (h[i]) fprintf(stderr, "stamp %2d: %llu\n", i, h[i]);
+    }
+#endif
     for (hipEvent_t e : c->eventPool) hipEventDestroy(e);
     if (c->evPredicted) hipEventDestroy(c->evPredicted);
     if (c->evHeavyDone) hipEventDestroy(c->evHeavyDone);
@@ -1323,12 +1381,12 @@ int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, u
     RescueBuffers rb; std::memset(&rb, 0, sizeof(rb));
     if (c->flatRescue)
     {
-        rb.jobsCap = 4 * chunk; rb.bitmapCap = 64 * rb.jobsCap; rb.candCap = 24 * chunk;
+        rb.jobsCap = 4 * chunk; rb.bitmapCap = 64 * rb.jobsCap; rb.candRegionSize = (24 * chunk + CAND_REGIONS - 1) / CAND_REGIONS; rb.candCap = rb.candRegionSize * CAND_REGIONS;
         c->jobs.reserve(rb.jobsCap); c->bitmaps.reserve(rb.bitmapCap); c->candPositions.reserve(rb.candCap); c->candJob.reserve(rb.candCap);
-        c->shadowCands.reserve(rb.candCap); c->candRank.reserve(rb.candCap); c->shadowCigars.reserve(size_t(rb.candCap) * 3); c->jobBase.reserve(chunk); c->jobCount.reserve(chunk); c->rescueCounters.reserve(4);
+        c->shadowCands.reserve(rb.candCap); c->candRank.reserve(rb.candCap); c->shadowCigars.reserve(size_t(rb.candCap) * 3); c->jobBase.reserve(chunk); c->jobCount.reserve(chunk); c->rescueCounters.reserve(4 + CAND_REGIONS);
         rb.jobs = c->jobs.p; rb.bitmaps = c->bitmaps.p; rb.candPositions = c->candPositions.p; rb.candJob = c->candJob.p; rb.shadowCands = c->shadowCands.p; rb.candRank = c->candRank.p;
         rb.shadowCigars = c->shadowCigars.p; rb.jobBase = c->jobBase.p; rb.jobCount = c->jobCount.p;
-        rb.jobCounter = c->rescueCounters.p; rb.bitmapCounter = c->rescueCounters.p + 1; rb.candCounter = c->rescueCounters.p + 2;
+        rb.jobCounter = c->rescueCounters.p; rb.bitmapCounter = c->rescueCounters.p + 1; rb.candCounter = c->rescueCounters.p + 4;
     }
     const DevReference R = c->ref();
     const GappedBuffers gbRescue = gappedBuffers(c, 1);
@@ -1345,7 +1403,7 @@ int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, u
         HIP_CHECK(hipMemsetAsync(c->overflowCount.p, 0, 4, st));
         if (c->flatRescue)
         {
-            HIP_CHECK(hipMemsetAsync(c->rescueCounters.p, 0, 16, st));
+            HIP_CHECK(hipMemsetAsync(c->rescueCounters.p, 0, (4 + CAND_REGIONS) * 4, st));
             {
                 ScopedTimer tm(c, "plan_rescue");
                 k_plan_rescue<<<gridFor(n, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, n, c->fragsCur, c->lightArena.p, lightBytes, light, rb);

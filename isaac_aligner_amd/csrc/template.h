@@ -1110,7 +1110,10 @@ ISAAC_HD bool buildDisjoinedTemplate(TemplateCtx &x, BamTemplate &t, const BestP
                 u32(orphan.editDistance) > (knownBestPair.bestPairEditDistance + SKIP_ORPHAN_EDIT_DISTANCE) :
                 lpLess(orphan.logProbability + 100.0, orphans[bestDisjoinedFragments[orphanIndex]].logProbability);
             w.nShadows = 0;
-            if (!skipThisOrphan && shadowRescue(x, orphan, bestTemplateLength))
+            STAMP_BEGIN();
+            const bool rescued = !skipThisOrphan && shadowRescue(x, orphan, bestTemplateLength);
+            STAMP(39);
+            if (rescued)
             {
                 const Cand &bestRescued = w.shadowList[0];
                 const double currentTemplateLogProbability = orphan.logProbability + bestRescued.logProbability;
@@ -1161,6 +1164,7 @@ ISAAC_HD bool buildDisjoinedTemplate(TemplateCtx &x, BamTemplate &t, const BestP
     }
     const u32 bestShadowIndex = (bestOrphanIndex + 1) % 2;
     double totalShadowProbability = 0.0, totalOrphanProbability = 0.0;
+    STAMP_BEGIN();
     if (0 < bestOrphans.resolvedTemplateCount)
     {
         for (u32 i = 0; i < x.frags->nCands[bestShadowIndex]; ++i) pushShadowProb(w, bestOrphanIndex, x.frags->cands[bestShadowIndex][i]);
@@ -1170,7 +1174,10 @@ ISAAC_HD bool buildDisjoinedTemplate(TemplateCtx &x, BamTemplate &t, const BestP
         bestOrphans.totalTemplateProbability += sumUniquePairProbabilities(x);
     }
     if (bestOrphans.overflow) w.overflow = 1;
-    return scoreDisjoinedTemplate(x, t, bestOrphans, knownBestPair, bestOrphanIndex, totalShadowProbability, totalOrphanProbability, bestDisjoinedFragments);
+    STAMP(40);
+    const bool scored = scoreDisjoinedTemplate(x, t, bestOrphans, knownBestPair, bestOrphanIndex, totalShadowProbability, totalOrphanProbability, bestDisjoinedFragments);
+    STAMP(41);
+    return scored;
 }
 
 // pickBestFragment (TemplateBuilder.cpp:1035-1058): single-ended data
@@ -1225,10 +1232,16 @@ ISAAC_HD bool buildTemplate(TemplateCtx &x, BamTemplate &t, double logMismatchQ4
     {
         if (n0 && n1)
         {
+            STAMP_BEGIN();
             locateBestPair(x, w.bestCombination);
+            STAMP(36);
             if (w.bestCombination.overflow) w.overflow = 1;
             if (!w.bestCombination.resolvedTemplateCount || !buildPairedEndTemplate(x, t, w.bestCombination) || w.bestCombination.bestPairEditDistance)
+            {
+                STAMP(37);
                 ret = buildDisjoinedTemplate(x, t, w.bestCombination, logMismatchQ40);
+                STAMP(38);
+            }
             else ret = true;
         }
         else if (n0 || n1) ret = templateRescueShadow(x, t, logMismatchQ40);
@@ -1472,11 +1485,15 @@ ISAAC_HD bool selectCluster(TemplateCtx &x, BamTemplate &t, double logMismatchQ4
     bool store;
     if (x.frags->built)
     {
+        STAMP_BEGIN();
         store = buildTemplate(x, t, logMismatchQ40) || x.P->keepUnaligned;
+        STAMP(33);
         if (store)
         {
             if (x.P->clipSemialigned) semialignedClip(x, t);
+            STAMP(34);
             if (x.P->clipOverlapping) overlappingClip(x, t);
+            STAMP(35);
         }
     }
     else { bamTemplateInitialize(x, t); store = x.P->keepUnaligned; }

@@ -14,6 +14,18 @@
 #define ISAAC_HD inline
 #endif
 
+// optional in-kernel section stamps (-DISAAC_KERNEL_STAMPS): shader-clock ticks per section, summed over the sampled waves
+// (lane 0 of every wave of every 256th workgroup), printed when the context is destroyed.  A measuring aid, compiled out of
+// the product build.
+#if defined(ISAAC_KERNEL_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+extern __device__ unsigned long long g_stamps[64];
+#define STAMP_BEGIN() long long stamp_t = clock64()
+#define STAMP(slot) do { if ((threadIdx.x & 63) == 0 && (blockIdx.x & 255) == 0) { const long long stamp_n = clock64(); atomicAdd(&g_stamps[slot], (unsigned long long)(stamp_n - stamp_t)); stamp_t = stamp_n; } } while (0)
+#else
+#define STAMP_BEGIN()
+#define STAMP(slot)
+#endif
+
 namespace isaac
 {
 
