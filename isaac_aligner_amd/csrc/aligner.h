@@ -366,37 +366,47 @@ ISAAC_HD u32 alignGapped(const DevParams &P, const DevReference &R, const ReadVi
 // SimpleIndelAligner (SimpleIndelAligner.cpp:50-438)
 static const u32 GAP_FLANK_BASES = 32, GAP_FLANK_MISMATCHES_MAX = 8;
 
+// a contig, or a copy of a stretch of it that is addressed with the contig's own offsets (k_indel_fragments keeps one in LDS)
+struct RefView { const char *p; i64 base; ISAAC_HD char operator[](i64 i) const { return p[i - base]; } };
+
 // countMismatches(seq + seqOffset, ref + refOffset .. refEnd, length) of Alignment.hh:115-157
-ISAAC_HD u32 countMismatches(const ReadView &read, bool reverse, i64 seqOffset, const char *reference, i64 refOffset, i64 refSize, u32 length)
+// `lanes` > 1 (wave-per-cluster form, every lane calling with the same arguments): the positions are spread over the lanes and
+// the counts summed across the wave, so every lane returns the total
+ISAAC_HD u32 countMismatches(const ReadView &read, bool reverse, i64 seqOffset, const RefView &reference, i64 refOffset, i64 refSize, u32 length, u32 lanes = 1, u32 lane = 0)
 {
     u32 ret = 0;
-    for (u32 i = 0; i < length && refOffset + i64(i) < refSize; ++i) ret += !isMatch(strandBase(read, reverse, u32(seqOffset + i)), reference[refOffset + i]);
+    for (u32 i = lane; i < length && refOffset + i64(i) < refSize; i += lanes) ret += !isMatch(strandBase(read, reverse, u32(seqOffset + i)), reference[refOffset + i]);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (lanes > 1) for (int o = 32; o > 0; o >>= 1) ret += __shfl_xor(ret, o, 64);
+#endif
     return ret;
 }
 
+// `referenceOverride`: a copy of the contig around the two candidates, addressed like the contig itself (k_indel_fragments
+// stages it in LDS); the CIGAR rescan of an accepted indel reads the real contig
 ISAAC_HD void alignSimpleDeletion(const DevParams &P, const DevReference &R, const ReadView &read, CigarPool &pool, Cand &head, u32 headSeedOffset,
-                                  Cand &tail, u32 tailSeedOffset, u32 tailSeedLength, u32 &simpleIndels)
+                                  Cand &tail, u32 tailSeedOffset, u32 tailSeedLength, u32 &simpleIndels, const RefView *referenceOverride = 0, const ReadView *scanRead = 0, u32 lanes = 1, u32 lane = 0)
 {
     const u32 *cw = pool.words;
     if (i64(headSeedOffset) < candBeginClipped(head, cw)) return;
     if (candBeginClipped(tail, cw) + i64(candObservedLength(tail)) < i64(tailSeedOffset + tailSeedLength)) return;
     const u32 tailOffset = headSeedOffset;
     const bool reverse = head.reverse;
-    const char *reference = R.bases + R.contigOffset[head.contigId];
+    RefView reference; if (referenceOverride) reference = *referenceOverride; else { reference.p = R.bases + R.contigOffset[head.contigId]; reference.base = 0; }
     const i64 refSize = i64(contigLength(R, head.contigId));
     const i64 headUnclipped = candUnclippedPosition(head, cw), tailUnclipped = candUnclippedPosition(tail, cw);
     i64 tailIt = tailOffset;                                          // index into the strand sequence
     u32 tailLength = u32(candBeginClipped(tail, cw) + i64(candObservedLength(tail)) - i64(tailOffset));
-    const u32 tailMismatches = countMismatches(read, reverse, tailIt, reference, headUnclipped + tailOffset, refSize, tailLength);
+    const u32 tailMismatches = countMismatches(read, reverse, tailIt, reference, headUnclipped + tailOffset, refSize, tailLength, lanes, lane);
     if (!tailMismatches) return;
     const i64 deletionLengthL = tailUnclipped - headUnclipped;
     if (deletionLengthL < 0) return;                                  // boost::numeric_cast would throw; unreachable for ordered lists
     const u32 deletionLength = u32(deletionLengthL);
-    u32 rightRealignedMismatches = countMismatches(read, reverse, tailIt, reference, tailUnclipped + tailOffset, refSize, tailLength);
+    u32 rightRealignedMismatches = countMismatches(read, reverse, tailIt, reference, tailUnclipped + tailOffset, refSize, tailLength, lanes, lane);
     u32 leftRealignedMismatches = 0;
     const u32 lf = imin(GAP_FLANK_BASES, tailOffset);
-    u32 leftFlankMismatches = countMismatches(read, reverse, tailIt - lf, reference, headUnclipped + tailOffset - imin(32u, tailOffset), refSize, lf);
-    u32 rightFlankMismatches = countMismatches(read, reverse, tailIt, reference, tailUnclipped + tailOffset, refSize, imin(GAP_FLANK_BASES, tailLength));
+    u32 leftFlankMismatches = countMismatches(read, reverse, tailIt - lf, reference, headUnclipped + tailOffset - imin(32u, tailOffset), refSize, lf, lanes, lane);
+    u32 rightFlankMismatches = countMismatches(read, reverse, tailIt, reference, tailUnclipped + tailOffset, refSize, imin(GAP_FLANK_BASES, tailLength), lanes, lane);
     i64 refIt = headUnclipped + tailOffset;
     u32 bestMismatches = tailMismatches, bestLeftFlankMismatches = leftFlankMismatches, bestRightFlankMismatches = rightFlankMismatches;
     u32 bestOffset = 0xffffffffu;
@@ -422,7 +432,7 @@ ISAAC_HD void alignSimpleDeletion(const DevParams &P, const DevReference &R, con
     {
         const i64 clippingPositionOffset = candBeginClipped(head, cw);
         const u32 leftMapped = u32(i64(bestOffset) - clippingPositionOffset);
-        const u32 headMismatches = countMismatches(read, reverse, clippingPositionOffset, reference, head.position, refSize, leftMapped);
+        const u32 headMismatches = countMismatches(read, reverse, clippingPositionOffset, reference, head.position, refSize, leftMapped, lanes, lane);
         const u32 newMismatches = headMismatches + bestMismatches;
         const u32 sws = P.normalizedMismatchScore * newMismatches + P.normalizedGapOpenScore +
             imin(P.normalizedMaxGapExtendScore, (deletionLength - 1) * P.normalizedGapExtendScore);
@@ -443,14 +453,14 @@ ISAAC_HD void alignSimpleDeletion(const DevParams &P, const DevReference &R, con
             candResetAlignment(head, view);
             head.position = unclipped;
             if (head.reverse) head.lowClipped = tailRightClipped; else head.highClipped = tailRightClipped;
-            updateFragmentCigar(P, R, read, head, head.position + clippingPositionOffset, pool, cigarOffset);
+            updateFragmentCigar(P, R, scanRead ? *scanRead : read, head, head.position + clippingPositionOffset, pool, cigarOffset);
             ++simpleIndels;
         }
     }
 }
 
 ISAAC_HD void alignSimpleInsertion(const DevParams &P, const DevReference &R, const ReadView &read, CigarPool &pool, Cand &head, u32 headSeedOffset, u32 headSeedLength,
-                                   Cand &tail, u32 tailSeedOffset, u32 tailSeedLength, u32 &simpleIndels)
+                                   Cand &tail, u32 tailSeedOffset, u32 tailSeedLength, u32 &simpleIndels, const RefView *referenceOverride = 0, const ReadView *scanRead = 0, u32 lanes = 1, u32 lane = 0)
 {
     const u32 *cw = pool.words;
     if (i64(headSeedOffset) < candBeginClipped(head, cw)) return;
@@ -463,13 +473,13 @@ ISAAC_HD void alignSimpleInsertion(const DevParams &P, const DevReference &R, co
     const u32 insertionLength = u32(insertionLengthL);
     if (tailSeedOffset - headSeedOffset < insertionLength + headSeedLength) return;   // unsigned arithmetic as in the reference
     const bool reverse = head.reverse;
-    const char *reference = R.bases + R.contigOffset[head.contigId];
+    RefView reference; if (referenceOverride) reference = *referenceOverride; else { reference.p = R.bases + R.contigOffset[head.contigId]; reference.base = 0; }
     const i64 refSize = i64(contigLength(R, head.contigId));
     i64 tailIt = i64(tailOffset) + insertionLength;
     u32 tailLength = observedEnd - tailOffset - insertionLength;
-    const u32 tailMismatches = countMismatches(read, reverse, tailIt, reference, headUnclipped + tailOffset, refSize, tailLength);
-    u32 leftFlankMismatches = countMismatches(read, reverse, tailIt - insertionLength - GAP_FLANK_BASES, reference, headUnclipped + tailOffset - GAP_FLANK_BASES, refSize, GAP_FLANK_BASES);
-    u32 rightFlankMismatches = countMismatches(read, reverse, tailIt, reference, headUnclipped + tailOffset, refSize, imin(GAP_FLANK_BASES, tailLength));
+    const u32 tailMismatches = countMismatches(read, reverse, tailIt, reference, headUnclipped + tailOffset, refSize, tailLength, lanes, lane);
+    u32 leftFlankMismatches = countMismatches(read, reverse, tailIt - insertionLength - GAP_FLANK_BASES, reference, headUnclipped + tailOffset - GAP_FLANK_BASES, refSize, GAP_FLANK_BASES, lanes, lane);
+    u32 rightFlankMismatches = countMismatches(read, reverse, tailIt, reference, headUnclipped + tailOffset, refSize, imin(GAP_FLANK_BASES, tailLength), lanes, lane);
     u32 rightRealignedMismatches = tailMismatches, leftRealignedMismatches = 0;
     i64 refIt = headUnclipped + tailOffset;
     u32 bestMismatches = tailMismatches, bestOffset = tailOffset, bestLeftFlankMismatches = leftFlankMismatches, bestRightFlankMismatches = rightFlankMismatches;
@@ -493,7 +503,7 @@ ISAAC_HD void alignSimpleInsertion(const DevParams &P, const DevReference &R, co
     const i64 clippingPositionOffset = candBeginClipped(head, cw);
     const u32 leftMapped = u32(i64(bestOffset) - clippingPositionOffset);
     if (!leftMapped) return;   // ISAAC_ASSERT in the reference
-    const u32 headMismatches = countMismatches(read, reverse, clippingPositionOffset, reference, head.position, refSize, leftMapped);
+    const u32 headMismatches = countMismatches(read, reverse, clippingPositionOffset, reference, head.position, refSize, leftMapped, lanes, lane);
     const u32 newMismatches = headMismatches + bestMismatches;
     const u32 sws = P.normalizedMismatchScore * newMismatches + P.normalizedGapOpenScore +
         imin(P.normalizedMaxGapExtendScore, (insertionLength - 1) * P.normalizedGapExtendScore);
@@ -516,7 +526,7 @@ ISAAC_HD void alignSimpleInsertion(const DevParams &P, const DevReference &R, co
             candResetAlignment(tail, view);
             tail.position = unclipped;
             if (tail.reverse) tail.highClipped = headLeftClipped; else tail.lowClipped = headLeftClipped;
-            updateFragmentCigar(P, R, read, tail, head.position, pool, cigarOffset);
+            updateFragmentCigar(P, R, scanRead ? *scanRead : read, tail, head.position, pool, cigarOffset);
             ++simpleIndels;
         }
     }
@@ -573,31 +583,80 @@ ISAAC_HD void consolidateDuplicateFragments(CandList &l, bool removeUnaligned)
 }
 
 // SimpleIndelAligner::alignSimpleIndels (SimpleIndelAligner.cpp:460-518)
-ISAAC_HD void alignSimpleIndels(const DevParams &P, const DevReference &R, const ReadView &read, CigarPool &pool, CandList &l, u32 &simpleIndels)
+// SimpleIndelAligner::alignSimpleIndels (SimpleIndelAligner.cpp:460-518) in three parts, so that the expensive middle one can
+// run in a kernel of its own over just the reads that need it: sort by unclipped position, "is there a pair to look at",
+// the pairs.
+ISAAC_HD void sortForSimpleIndels(CandList &l, const CigarPool &pool)
 {
-    if (l.n < 2) return;
     CandLessByUnclippedPosition less; less.store = l.store; less.pool = pool.words;
     exactSort(l.order, i32(l.n), less);
+}
+ISAAC_HD bool simpleIndelPairQualifies(const DevParams &P, const Cand &head, const Cand &tail, const u32 *pool)
+{
+    if (head.contigId != tail.contigId || head.reverse != tail.reverse) return false;
+    const i64 distance = candUnclippedPosition(tail, pool) - candUnclippedPosition(head, pool);
+    if (!distance) return false;  // ISAAC_ASSERT in the reference
+    return (distance < 0 ? -distance : distance) < i64(P.semialignedGapLimit);
+}
+ISAAC_HD bool hasSimpleIndelPair(const DevParams &P, const CandList &l, const CigarPool &pool)
+{
+    for (u32 t = 1; t < l.n; ++t) if (simpleIndelPairQualifies(P, l.at(t - 1), l.at(t), pool.words)) return true;
+    return false;
+}
+// LDS staging area of the wave-per-cluster form: the read's BCL bytes and a window of the contig around a candidate pair
+struct IndelStage { u8 *bcl; u32 bclCap; char *window; u32 windowCap; u32 lane; };
+static const i64 INDEL_WINDOW_MARGIN = 256;   // the detector looks at most gap limit + read length + 2 flanks around the candidates
+
+ISAAC_HD void simpleIndelPairs(const DevParams &P, const DevReference &R, const ReadView &readIn, CigarPool &pool, CandList &l, u32 &simpleIndels, const IndelStage *stage = 0)
+{
+    ReadView read = readIn;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (stage && read.length <= stage->bclCap)
+    {
+        __syncthreads();                                           // nobody still reads the previous read's copy
+        for (u32 i = stage->lane; i < read.length; i += 64) stage->bcl[i] = readIn.bcl[i];
+        __syncthreads();
+        read.bcl = stage->bcl;
+    }
+#endif
     for (u32 t = 1; t != l.n; ++t)
     {
         Cand &head = l.at(t - 1); Cand &tail = l.at(t);
-        if (head.contigId == tail.contigId && head.reverse == tail.reverse)
+        if (simpleIndelPairQualifies(P, head, tail, pool.words))
         {
-            const DevSeed &headSeed = P.seeds[head.firstSeedIndex]; const DevSeed &tailSeed = P.seeds[tail.firstSeedIndex];
-            const i64 distance = candUnclippedPosition(tail, pool.words) - candUnclippedPosition(head, pool.words);
-            if (!distance) continue;  // ISAAC_ASSERT in the reference
-            if ((distance < 0 ? -distance : distance) < i64(P.semialignedGapLimit))
+            RefView windowView; const RefView *window = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (stage)
             {
-                const i64 readLength = read.length;
-                const i64 headSeedOffset = head.reverse ? readLength - headSeed.offset - headSeed.length : i64(headSeed.offset);
-                const i64 tailSeedOffset = head.reverse ? readLength - tailSeed.offset - tailSeed.length : i64(tailSeed.offset);
-                if (0 < tailSeedOffset - headSeedOffset)
-                    alignSimpleDeletion(P, R, read, pool, head, u32(headSeedOffset), tail, u32(tailSeedOffset), tailSeed.length, simpleIndels);
-                else
-                    alignSimpleInsertion(P, R, read, pool, tail, u32(tailSeedOffset), tailSeed.length, head, u32(headSeedOffset), headSeed.length, simpleIndels);
+                const i64 hu = candUnclippedPosition(head, pool.words), tu = candUnclippedPosition(tail, pool.words);
+                const i64 lo = imin(hu, tu) - INDEL_WINDOW_MARGIN, hi = imax(hu, tu) + i64(read.length) + INDEL_WINDOW_MARGIN;
+                if (hi - lo <= i64(stage->windowCap))
+                {
+                    const char *contig = R.bases + R.contigOffset[head.contigId];
+                    const char *first = R.bases, *last = R.bases + R.totalBases;
+                    __syncthreads();                                   // the previous pair's readers are done with the window
+                    for (i64 i = stage->lane; i < hi - lo; i += 64) { const char *g = contig + lo + i; stage->window[i] = (g >= first && g < last) ? *g : char(0); }
+                    __syncthreads();
+                    windowView.p = stage->window; windowView.base = lo; window = &windowView;
+                }
             }
+#endif
+            const DevSeed &headSeed = P.seeds[head.firstSeedIndex]; const DevSeed &tailSeed = P.seeds[tail.firstSeedIndex];
+            const i64 readLength = read.length;
+            const i64 headSeedOffset = head.reverse ? readLength - headSeed.offset - headSeed.length : i64(headSeed.offset);
+            const i64 tailSeedOffset = head.reverse ? readLength - tailSeed.offset - tailSeed.length : i64(tailSeed.offset);
+            if (0 < tailSeedOffset - headSeedOffset)
+                alignSimpleDeletion(P, R, read, pool, head, u32(headSeedOffset), tail, u32(tailSeedOffset), tailSeed.length, simpleIndels, window, &readIn, stage ? 64u : 1u, stage ? stage->lane : 0u);
+            else
+                alignSimpleInsertion(P, R, read, pool, tail, u32(tailSeedOffset), tailSeed.length, head, u32(headSeedOffset), headSeed.length, simpleIndels, window, &readIn, stage ? 64u : 1u, stage ? stage->lane : 0u);
         }
     }
+}
+ISAAC_HD void alignSimpleIndels(const DevParams &P, const DevReference &R, const ReadView &read, CigarPool &pool, CandList &l, u32 &simpleIndels)
+{
+    if (l.n < 2) return;
+    sortForSimpleIndels(l, pool);
+    simpleIndelPairs(P, R, read, pool, l, simpleIndels);
 }
 
 // One gapped (banded Smith-Waterman) re-alignment problem: GappedAligner::alignGapped of a candidate.  Problems are collected
@@ -632,7 +691,7 @@ struct MatchLess
 // FragmentBuilder::build (FragmentBuilder.cpp:82-145) + alignFragments (:147-217) for one cluster.
 // `matches` are the cluster's Match records in any order.  Results go to `out` (lists compacted in final order).
 ISAAC_HD bool buildFragments(const DevParams &P, const DevReference &R, const u8 *clusterBcl, const Match *matches, u32 nMatches,
-                             bool withGaps, bool trim, FragmentWork &work, ClusterFragments &out, Counters &cnt)
+                             bool withGaps, bool trim, FragmentWork &work, ClusterFragments &out, Counters &cnt, bool deferSimpleIndels = false)
 {
     out.nCands[0] = out.nCands[1] = 0; out.cigarUsed = 0; out.flags = 0; out.repeatSeedsCount = 0; out.built = 0;
     STAMP_BEGIN();
@@ -710,10 +769,16 @@ ISAAC_HD bool buildFragments(const DevParams &P, const DevReference &R, const u8
         STAMP(26);
         if (P.semialignedGapLimit)
         {
-            u32 si = 0;
-            alignSimpleIndels(P, R, reads[r], pool, l, si);
-            cnt.simpleIndels += si;
-            consolidateDuplicateFragments(l, true);
+            if (l.n >= 2)
+            {
+                sortForSimpleIndels(l, pool);
+                if (hasSimpleIndelPair(P, l, pool))
+                {
+                    if (deferSimpleIndels) out.flags |= CLUSTER_INDEL_PENDING << r;   // the list is left in this order for finishSimpleIndels
+                    else { u32 si = 0; simpleIndelPairs(P, R, reads[r], pool, l, si); cnt.simpleIndels += si; }
+                }
+            }
+            if (!(out.flags & (CLUSTER_INDEL_PENDING << r))) consolidateDuplicateFragments(l, true);
         }
         STAMP(27);
         // the candidates stay in list order; the gapped retries (FragmentBuilder.cpp:187-214) follow in finishFragments
@@ -726,6 +791,36 @@ ISAAC_HD bool buildFragments(const DevParams &P, const DevReference &R, const u8
     if (pool.overflow) out.flags |= CLUSTER_OVERFLOW;
     out.built = built;
     return built;
+}
+
+// The single-indel stage of the reads buildFragments left pending: the pair loop of alignSimpleIndels and the consolidation
+// that follows it (FragmentBuilder.cpp:176-185).  The list was stored sorted by unclipped position.
+ISAAC_HD void finishSimpleIndels(const DevParams &P, const DevReference &R, const u8 *clusterBcl, ClusterFragments &out, u8 *order, Counters &cnt, const IndelStage *stage = 0)
+{
+    CigarPool pool; pool.words = out.cigarPool; pool.used = out.cigarUsed; pool.capacity = CIGAR_POOL; pool.overflow = 0;
+    for (u32 r = 0; r < P.nReads; ++r)
+    {
+        if (!(out.flags & (CLUSTER_INDEL_PENDING << r))) continue;
+        out.flags &= ~(CLUSTER_INDEL_PENDING << r);
+        ReadView read; read.bcl = clusterBcl + P.readOffset[r]; read.length = P.readLength[r]; read.firstCycle = P.firstCycle[r]; read.endCyclesMasked = out.endCyclesMasked[r];
+        const u32 n = out.nCands[r];
+        CandList l; l.store = out.cands[r]; l.order = order; l.n = n; l.stored = n; l.capacity = CAND_CAP; l.overflow = 0;
+        for (u32 i = 0; i < n; ++i) order[i] = u8(i);
+        u32 si = 0;
+        simpleIndelPairs(P, R, read, pool, l, si, stage);
+        cnt.simpleIndels += si;
+        consolidateDuplicateFragments(l, true);
+        for (u32 i = 0; i < l.n; ++i)      // the permutation in place (cycle following), as in finishFragments
+        {
+            u32 src = order[i];
+            while (src < i) src = order[src];
+            if (src != i) { const Cand t = out.cands[r][i]; out.cands[r][i] = out.cands[r][src]; out.cands[r][src] = t; }
+            order[i] = u8(src);
+        }
+        out.nCands[r] = l.n;
+    }
+    out.cigarUsed = pool.used;
+    if (pool.overflow) out.flags |= CLUSTER_OVERFLOW;
 }
 
 // the candidates FragmentBuilder::alignFragments would hand to GappedAligner (FragmentBuilder.cpp:197): list order, read 0 first

@@ -14,10 +14,17 @@ enum { RECORD_TEMPLATE_OVERFLOW = 1,   // a template-stage work list overflowed:
 
 // FragmentBuilder::build for cluster `cluster` of the tile; its matches are matches[offsets[cluster] .. offsets[cluster + 1])
 ISAAC_HD void clusterBuildFragments(const DevParams &P, const DevReference &R, const u8 *bcl, u32 cluster, const Match *matches, const u64 *offsets,
-                                    bool withGaps, bool trim, FragmentWork &work, ClusterFragments &out, Counters &cnt)
+                                    bool withGaps, bool trim, FragmentWork &work, ClusterFragments &out, Counters &cnt, bool deferSimpleIndels = false)
 {
     const u64 begin = offsets[cluster], end = offsets[cluster + 1];
-    buildFragments(P, R, bcl + u64(cluster) * P.clusterLength, matches + begin, u32(end - begin), withGaps, trim, work, out, cnt);
+    buildFragments(P, R, bcl + u64(cluster) * P.clusterLength, matches + begin, u32(end - begin), withGaps, trim, work, out, cnt, deferSimpleIndels);
+}
+ISAAC_HD bool clusterSimpleIndelsPending(const ClusterFragments &f) { return 0 != (f.flags & (CLUSTER_INDEL_PENDING | (CLUSTER_INDEL_PENDING << 1))); }
+// the deferred single-indel stage of a cluster (k_indel_fragments)
+ISAAC_HD void clusterFinishSimpleIndels(const DevParams &P, const DevReference &R, const u8 *bcl, u32 cluster, FragmentWork &work, ClusterFragments &out, Counters &cnt,
+                                        const IndelStage *stage = 0)
+{
+    finishSimpleIndels(P, R, bcl + u64(cluster) * P.clusterLength, out, work.order, cnt, stage);
 }
 
 // second half: the gapped retries' results (in countGappedJobs order) are applied and the lists consolidated.  results == NULL

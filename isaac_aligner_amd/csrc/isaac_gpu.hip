@@ -77,7 +77,7 @@ struct isaac_gpu_ctx
     struct PendingTimer { std::string name; hipEvent_t e0, e1; };
     std::vector<PendingTimer> pendingTimers; std::vector<hipEvent_t> eventPool;
     hipStream_t heavyStream = nullptr; hipEvent_t evPredicted = nullptr, evHeavyDone = nullptr;
-    DevBuf<u32> heavyList, heavyCount; DevBuf<u8> heavyFlag;
+    DevBuf<u32> heavyList, heavyCount, indelList; DevBuf<u8> heavyFlag;
     DevBuf<u32> classKeys, classKeysSorted, classIdx, fragmentOrder, selectOrder;   // clusters ordered by work class (see k_match_class)
     u32 chunkClusters = 524288; bool workClasses = false;   // lane order by work class: measured slower (locality of neighbouring clusters matters more), kept as ISAAC_GPU_WORK_CLASSES=1
 
@@ -336,8 +336,21 @@ __global__ void k_match_class(const u64 *offsets, u32 clusterBase, u32 n, u32 *k
 // the chunk's gapped (banded Smith-Waterman) problems: written by the per-cluster threads, run by k_gapped_jobs
 struct GappedBuffers { GappedJob *jobs; GappedResult *results; u32 cap; u32 *counter; u32 *base; };
 
+__device__ inline void emitGappedJobs(const ClusterFragments &f, u32 cl, bool withGaps, const GappedBuffers &gb)
+{
+    u32 base = 0;
+    const u32 n = countGappedJobs(f, withGaps);
+    if (n)
+    {
+        base = atomicAdd(gb.counter, n);
+        if (base + n > gb.cap) base = 0xffffffffu;   // k_finish_fragments runs this cluster's retries itself
+        else writeGappedJobs(f, cl, gb.jobs + base);
+    }
+    gb.base[cl] = base;
+}
+
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_build_fragments(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, u32 nChunk, const Match *matches, const u64 *offsets,
-                                                        int withGaps, int trim, const u32 *order, FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters)
+                                                        int withGaps, int trim, const u32 *order, u32 *indelList, u32 *indelCount, FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters)
 {
     ISAAC_STAGE_QUALITY_TABLES(Rg, R)
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -345,17 +358,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGME
     if (t < nChunk)
     {
         const u32 cl = order ? order[t] : t;     // neighbouring lanes take clusters of the same work class
-        clusterBuildFragments(P, R, bcl, clusterBase + cl, matches, offsets, withGaps != 0, trim != 0, work[t], frags[cl], local);
-        u32 base = 0;
-        const u32 n = countGappedJobs(frags[cl], withGaps != 0);
-        if (n)
-        {
-            base = atomicAdd(gb.counter, n);
-            if (base + n > gb.cap) base = 0xffffffffu;   // k_finish_fragments runs this cluster's retries itself
-            else writeGappedJobs(frags[cl], cl, gb.jobs + base);
-        }
-        gb.base[cl] = base;
+        clusterBuildFragments(P, R, bcl, clusterBase + cl, matches, offsets, withGaps != 0, trim != 0, work[t], frags[cl], local, indelList != nullptr);
+        // a read with candidate pairs for the single-indel detector (3-4 % of the clusters) goes to k_indel_fragments: inside this
+        // kernel nearly every wave would hold one such lane and wait for it
+        if (clusterSimpleIndelsPending(frags[cl])) indelList[atomicAdd(indelCount, 1u)] = cl;
+        else emitGappedJobs(frags[cl], cl, withGaps != 0, gb);
     }
+    flushCounters(local, counters);
+}
+
+// The deferred single-indel stage (SimpleIndelAligner) for the clusters k_build_fragments listed, then their gapped problems.
+// One wave per cluster, every lane executing the same statements (as in k_select_heavy): the detector is a chain of dependent
+// byte loads, and 64 different clusters per wave would spread them over more cache lines than the L1 holds.
+__global__ __launch_bounds__(64) void k_indel_fragments(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, int withGaps, const u32 *indelList, const u32 *indelCount,
+                                                        FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters)
+{
+    ISAAC_STAGE_QUALITY_TABLES(Rg, R)
+    __shared__ __align__(16) u8 stageBcl[512];
+    __shared__ __align__(16) char stageWindow[1536];
+    IndelStage stage; stage.bcl = stageBcl; stage.bclCap = sizeof(stageBcl); stage.window = stageWindow; stage.windowCap = sizeof(stageWindow); stage.lane = threadIdx.x;
+    Counters local; memset(&local, 0, sizeof(local));
+    const u32 n = *indelCount;
+    for (u32 t = blockIdx.x; t < n; t += gridDim.x)
+    {
+        const u32 cl = indelList[t];
+        clusterFinishSimpleIndels(P, R, bcl, clusterBase + cl, work[blockIdx.x], frags[cl], local, &stage);
+        __syncthreads();
+        if (0 == threadIdx.x) emitGappedJobs(frags[cl], cl, withGaps != 0, gb);
+    }
+    if (0 != threadIdx.x) memset(&local, 0, sizeof(local));   // every lane counted the same events
     flushCounters(local, counters);
 }
 
@@ -1268,7 +1299,7 @@ static void launchGappedJobs(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clusterBa
 
 static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clusterBase, u32 n, const isaac_match *matches, const uint64_t *offsets, int withGaps, int trim)
 {
-    c->frags.reserve(c->chunkClusters); c->fragWork.reserve(c->chunkClusters);
+    c->frags.reserve(c->chunkClusters); c->fragWork.reserve(c->chunkClusters); c->indelList.reserve(c->chunkClusters);
     if (!c->fragsCur) c->fragsCur = c->frags.p;
     const GappedBuffers gb = gappedBuffers(c, 0);
     HIP_CHECK(hipMemsetAsync(c->gappedCounters.p, 0, 16, c->stream));
@@ -1284,7 +1315,12 @@ static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clust
     {
         ScopedTimer t(c, "build_fragments");
         k_build_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, reinterpret_cast<const Match *>(matches), offsets,
-                                                                 withGaps, trim, order, c->fragWork.p, c->fragsCur, gb, c->counters.p);
+                                                                 withGaps, trim, order, c->indelList.p, c->gappedCounters.p + 2, c->fragWork.p, c->fragsCur, gb, c->counters.p);
+        HIP_CHECK(hipGetLastError());
+    }
+    {
+        ScopedTimer t(c, "indel_fragments");
+        k_indel_fragments<<<8192, 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, withGaps, c->indelList.p, c->gappedCounters.p + 2, c->fragWork.p, c->fragsCur, gb, c->counters.p);
         HIP_CHECK(hipGetLastError());
     }
     if (withGaps) launchGappedJobs(c, bcl, clusterBase, gb, "gapped_fragments");

@@ -145,7 +145,8 @@ struct ClusterFragments
     u32 built;              // FragmentBuilder::build returned true
     u32 cigarPool[CIGAR_POOL];
 };
-enum { CLUSTER_OVERFLOW = 1 };
+enum { CLUSTER_OVERFLOW = 1,
+       CLUSTER_INDEL_PENDING = 2 };   // << read index: the single-indel stage of this read is still to run (finishSimpleIndels)
 
 struct Counters
 {

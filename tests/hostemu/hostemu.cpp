@@ -77,7 +77,8 @@ int emu_build_fragments(Emu *e, const u8 *bcl, u32 nClusters, int withGaps, int 
     for (u32 c = 0; c < nClusters; ++c)
     {
         ClusterFragments &f = e->frags[c];
-        clusterBuildFragments(e->P, e->R, bcl, c, e->matches.data(), e->matchOffsets.data(), withGaps != 0, trim != 0, work[0], f, e->cnt);
+        clusterBuildFragments(e->P, e->R, bcl, c, e->matches.data(), e->matchOffsets.data(), withGaps != 0, trim != 0, work[0], f, e->cnt, e->flatRescue);
+        if (clusterSimpleIndelsPending(f)) clusterFinishSimpleIndels(e->P, e->R, bcl, c, work[0], f, e->cnt);   // k_indel_fragments
         if (e->flatRescue && withGaps)
         {   // k_build_fragments -> k_gapped_jobs -> k_finish_fragments
             const u32 nj = countGappedJobs(f, true);
