@@ -193,8 +193,9 @@ def main():
         ref = o.reference([bytes(c.cpu().numpy()) for c in contigs])
         ref.set_index(al.get_index())
         p = o.default_params(2, L, L)
+        find_threads = min(cores, 32)      # every thread streams the whole index for its clusters: more threads only add memory traffic
         tc = time.perf_counter()
-        om, ohits = ref.find_matches(p, host_bcl, sample)
+        om, ohits = ref.find_matches(p, host_bcl, sample, n_threads=find_threads)
         t_find = time.perf_counter() - tc
         otls = oracle_lib.Tls()
         for name in ("min", "max", "median", "low_std_dev", "high_std_dev", "stable", "mate_min", "mate_max"):
@@ -204,8 +205,8 @@ def main():
         ref.select(p, host_bcl, om, otls, ohits, n_threads=cores, n_clusters_hint=sample)
         t_select = time.perf_counter() - tc
         cpu = {"value": round(2.0 * sample / (t_find + t_select), 1), "unit": "reads/s", "cores": cores, "kind": "port",
-               "sample": "%d pairs of the same workload; oracle/ (CPU restatement of the reference path): merge-join seed lookup on 1 thread "
-                         "(%.2f s) + match selection on %d threads (%.2f s)" % (sample, t_find, cores, t_select)}
+               "sample": "%d pairs of the same workload; oracle/ (CPU restatement of the reference path): merge-join seed lookup on %d threads "
+                         "(%.2f s) + match selection on %d threads (%.2f s)" % (sample, find_threads, t_find, cores, t_select)}
 
     out = {"metric": "paired-end reads aligned/sec (2x%dbp)" % L, "value": round(reads_per_s, 1), "unit": "reads/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,

@@ -151,6 +151,49 @@ int oracle_find_matches(oracle_ref *r, const oracle_params *cp, const uint8_t *b
     catch (const std::exception &e) { g_error = e.what(); return 1; }
 }
 
+// The same on n_threads host threads, for the CPU baseline of bench.py: the tile is cut into contiguous cluster ranges, every
+// thread runs the unchanged single-tile function (its own merge-join over the whole index, as every mask thread of the
+// reference streams whole mask files) on its range, and the cluster numbers are put back into the SeedIds afterwards.
+int oracle_find_matches_mt(oracle_ref *r, const oracle_params *cp, const uint8_t *bcl, uint32_t n_clusters, uint32_t tile, uint32_t n_threads,
+                           uint64_t *matches_out, uint64_t capacity, uint64_t *n_out, uint8_t *contig_has_matches)
+{
+    try
+    {
+        const Params p = toParams(cp);
+        if (!n_threads) n_threads = 1;
+        if (n_threads > n_clusters) n_threads = n_clusters ? n_clusters : 1;
+        std::vector<std::vector<Match> > parts(n_threads);
+        std::vector<std::vector<uint8_t> > hits(n_threads, std::vector<uint8_t>(r->contigs.size(), 0));
+        std::vector<std::string> errors(n_threads);
+        std::vector<std::thread> threads;
+        const unsigned clusterLength = p.clusterLength();
+        for (uint32_t t = 0; t < n_threads; ++t)
+            threads.emplace_back([&, t]()
+            {
+                try
+                {
+                    const uint64_t begin = uint64_t(n_clusters) * t / n_threads, end = uint64_t(n_clusters) * (t + 1) / n_threads;
+                    findTileMatches(p, r->index, bcl + begin * clusterLength, unsigned(end - begin), tile, parts[t], hits[t]);
+                    for (size_t i = 0; i < parts[t].size(); ++i) parts[t][i].seedId += begin << 9;       // SeedId.hh: cluster field at bit 9
+                }
+                catch (const std::exception &e) { errors[t] = e.what(); }
+            });
+        for (size_t t = 0; t < threads.size(); ++t) threads[t].join();
+        uint64_t n = 0;
+        for (uint32_t t = 0; t < n_threads; ++t)
+        {
+            if (!errors[t].empty()) throw std::runtime_error(errors[t]);
+            if (n + parts[t].size() > capacity) throw std::runtime_error("match capacity");
+            memcpy(matches_out + 2 * n, parts[t].data(), parts[t].size() * 16);
+            n += parts[t].size();
+            for (size_t i = 0; i < hits[t].size(); ++i) if (contig_has_matches) contig_has_matches[i] |= hits[t][i];
+        }
+        *n_out = n;
+        return 0;
+    }
+    catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+
 static ContigList filteredContigs(const oracle_ref *r, const uint8_t *contig_loaded)
 {
     // MatchSelector.cpp:85-90,138: contigs without any match are not loaded (empty sequence, length 0)

@@ -145,12 +145,16 @@ class OracleReference:
         index = np.ascontiguousarray(index, INDEX_DTYPE)
         self.o.lib.oracle_ref_set_index(self.h, ptr(index), C.c_uint64(len(index)))
 
-    def find_matches(self, params, bcl, n_clusters, tile=0):
+    def find_matches(self, params, bcl, n_clusters, tile=0, n_threads=1):
         cap = int(n_clusters) * 16 * 10 + 1024
         out = np.zeros(cap, MATCH_DTYPE)
         n = C.c_uint64()
         hits = np.zeros(len(self.contigs), np.uint8)
-        self.o.check(self.o.lib.oracle_find_matches(self.h, C.byref(params), ptr(bcl), C.c_uint32(n_clusters), C.c_uint32(tile), ptr(out), C.c_uint64(cap), C.byref(n), ptr(hits)))
+        if n_threads > 1:
+            self.o.check(self.o.lib.oracle_find_matches_mt(self.h, C.byref(params), ptr(bcl), C.c_uint32(n_clusters), C.c_uint32(tile), C.c_uint32(n_threads),
+                                                           ptr(out), C.c_uint64(cap), C.byref(n), ptr(hits)))
+        else:
+            self.o.check(self.o.lib.oracle_find_matches(self.h, C.byref(params), ptr(bcl), C.c_uint32(n_clusters), C.c_uint32(tile), ptr(out), C.c_uint64(cap), C.byref(n), ptr(hits)))
         return out[:n.value].copy(), hits
 
     def build_fragments(self, params, bcl, matches, contig_loaded=None, tile=0, with_gaps=True, trim=True):

@@ -83,3 +83,16 @@ def test_fragment_builder2(oracle):
             assert [f["contig_id"], f["position"]] == e["getStrandReferencePosition"], c["name"]
         if "getMismatchCyclesBegin" in e:
             assert cyc == e["getMismatchCyclesBegin"], c["name"]
+
+
+def test_threaded_seed_lookup_equals_single_thread(oracle):
+    """oracle_find_matches_mt (the CPU-baseline form: cluster ranges on host threads) returns the single-thread result"""
+    from parity_util import make_inputs
+    from isaac_aligner_amd import options
+    contigs, bcl, _ = make_inputs(genome_bases=200000, n_pairs=3001, seed=9)
+    ref = oracle.reference(contigs)
+    ref.build_index()
+    p = options.default_params(150, 150)
+    m1, h1 = ref.find_matches(p, bcl, len(bcl))
+    m7, h7 = ref.find_matches(p, bcl, len(bcl), n_threads=7)
+    assert len(m1) == len(m7) and (m1 == m7).all() and (h1 == h7).all()
