@@ -31,6 +31,8 @@ extern "C" {
 #define ISAAC_GPU_EHIP 3       /* HIP runtime error */
 #define ISAAC_GPU_ECAPACITY 4  /* an output buffer supplied by the caller is too small */
 #define ISAAC_GPU_EOVERFLOW 5  /* an internal fixed-capacity work list overflowed; results of the flagged clusters are not exact */
+#define ISAAC_GPU_EFORMAT 6    /* malformed FASTQ (reference: io::FastqFormatException) */
+#define ISAAC_GPU_EREADLEN 7   /* FASTQ read shorter than the configured read length (reference: common::IoException, EINVAL) */
 
 #define ISAAC_GPU_MAX_SEEDS 16
 #define ISAAC_GPU_MAX_CIGAR_OPS 40
@@ -197,6 +199,23 @@ int isaac_gpu_select(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t n_clus
 int isaac_gpu_bsw_batch(isaac_gpu_ctx *ctx, int match, int mismatch, int gap_open, int gap_extend,
                         const char *sequences_dev, const isaac_bsw_job *jobs_dev, uint32_t n_jobs, uint32_t max_query_length,
                         isaac_bsw_result *results_dev);
+
+/* The data format on the input side of the path: io::FastqReader::next / extractBcl (lib/io/FastqReader.cpp:120-283,
+ * include/io/FastqReader.hh:144-210) and io::FastqLoader::loadSingleRead (include/io/FastqLoader.hh) for one read of a lane.
+ * fastq_dev: n_bytes of uncompressed FASTQ text resident in HBM (gzip inflation stays with the caller).  The records are
+ * parsed with the reference's tolerance (any run of \r / \n separates lines, the '+' line may repeat the header, a sequence
+ * line that starts with '+' is a zero-length read) and converted to BCL bytes (base | quality << 2, 0 for N), cluster k at
+ * bcl_dev[k * cluster_length + offset of read read_index], at most max_clusters of them.
+ * final = 0: the text is a piece of a longer file; a record not yet followed by a newline is left for the next call and
+ * *consumed_bytes_out is where that call's text has to start.  final = 1: the text ends at the end of the file.
+ * Errors as the reference throws them, first in file order: ISAAC_GPU_EFORMAT (bad structure, base or quality; quality
+ * must be in [0, 63]) or ISAAC_GPU_EREADLEN (record shorter than the read length unless allow_variable_length, which pads
+ * with N); *n_clusters_out then counts the records before the bad one and *error_offset_out is the byte offset the
+ * reference would report.  Reads longer than the read length are cut.  Non-contiguous cycle lists (use-bases masks) are
+ * not supported. */
+int isaac_gpu_fastq_to_bcl(isaac_gpu_ctx *ctx, const char *fastq_dev, uint64_t n_bytes, uint32_t read_index,
+                           int allow_variable_length, int final, uint8_t *bcl_dev, uint32_t max_clusters,
+                           uint32_t *n_clusters_out, uint64_t *consumed_bytes_out, uint64_t *error_offset_out);
 
 int isaac_gpu_get_counters(isaac_gpu_ctx *ctx, isaac_counters *out);
 /* average device time (ms) of the named kernel over the launches since the last reset, measured with HIP events on the

@@ -20,6 +20,7 @@
 #include "cluster_ops.h"
 #include "host_util.h"
 #include "bsw_kernel.h"
+#include "fastq_kernel.h"
 
 #if defined(ISAAC_KERNEL_STAMPS)
 __device__ unsigned long long g_stamps[64];
@@ -63,6 +64,8 @@ struct isaac_gpu_ctx
     DevBuf<u64> kmers, positions; u64 nKmers = 0; DevBuf<u32> karyotype; bool hasKaryotype = false;
     DevBuf<u32> prefixTable; u32 prefixBits = 0;
     DevBuf<u64> matchBase;
+    // isaac_gpu_fastq_to_bcl scratch, kept between calls (hipMalloc costs more than the conversion)
+    DevBuf<u8> fqIsStart; DevBuf<u64> fqLineStart, fqLineEnd; DevBuf<int> fqSelected; DevBuf<u32> fqLineMap, fqMapBefore, fqIsHeader, fqRecordIndex, fqFirstBad; DevBuf<FqRecord> fqRecords;
     DevBuf<double> logTables;
     // work
     DevBuf<Match> staging; DevBuf<u32> counts, chunkOffsets; DevBuf<u8> cubTemp; DevBuf<u32> contigHits;
@@ -1524,6 +1527,88 @@ int isaac_gpu_bsw_batch(isaac_gpu_ctx *c, int match, int mismatch, int gapOpen, 
     ScopedTimer t(c, "bsw");
     k_bsw_batch<<<gridFor(nJobs, 16), 256, lds, c->stream>>>(match, mismatch, gapOpen, gapExtend, sequences, jobs, nJobs, maxQueryLength, results);
     HIP_CHECK(hipGetLastError());
+    return 0;
+    ISAAC_CATCH
+}
+
+int isaac_gpu_fastq_to_bcl(isaac_gpu_ctx *c, const char *fastq, uint64_t nBytes, uint32_t readIndex, int allowVariableLength, int final, uint8_t *bcl,
+                           uint32_t maxClusters, uint32_t *nClustersOut, uint64_t *consumedOut, uint64_t *errorOffsetOut)
+{
+    ISAAC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    if (!nClustersOut || !consumedOut) return fail(ISAAC_GPU_EINVAL, "n_clusters_out and consumed_bytes_out are required");
+    *nClustersOut = 0; *consumedOut = 0; if (errorOffsetOut) *errorOffsetOut = 0;
+    if (readIndex >= c->P.nReads) return fail(ISAAC_GPU_EINVAL, "read_index");
+    if (nBytes >= (u64(1) << 31)) return fail(ISAAC_GPU_EINVAL, "pieces of FASTQ text below 2 GiB per call");
+    if (!nBytes) return 0;
+    if (!fastq || !bcl) return fail(ISAAC_GPU_EINVAL, "fastq_dev and bcl_dev are required");
+    hipStream_t st = c->stream;
+    const u32 readLength = c->P.readLength[readIndex];
+    // 1. lines
+    DevBuf<u8> &isStart = c->fqIsStart; isStart.reserve(nBytes);
+    DevBuf<u64> &lineStart = c->fqLineStart; lineStart.reserve(nBytes / 2 + 2);
+    DevBuf<int> &nSelected = c->fqSelected; nSelected.reserve(1);
+    k_fq_line_starts<<<gridFor(nBytes, 256), 256, 0, st>>>(fastq, nBytes, isStart.p);
+    {
+        hipcub::CountingInputIterator<u64> positions(0);
+        size_t bytes = 0;
+        HIP_CHECK(hipcub::DeviceSelect::Flagged(nullptr, bytes, positions, isStart.p, lineStart.p, nSelected.p, int(nBytes), st));
+        c->cubTemp.reserve(bytes + 16);
+        HIP_CHECK(hipcub::DeviceSelect::Flagged(c->cubTemp.p, bytes, positions, isStart.p, lineStart.p, nSelected.p, int(nBytes), st));
+    }
+    int nLinesHost = 0;
+    HIP_CHECK(hipMemcpyAsync(&nLinesHost, nSelected.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    const u32 nLines = u32(nLinesHost);
+    if (!nLines) { *consumedOut = nBytes; return 0; }        // nothing but newlines
+    // 2. the role of every line
+    DevBuf<u64> &lineEnd = c->fqLineEnd; DevBuf<u32> &lineMap = c->fqLineMap, &mapBefore = c->fqMapBefore, &isHeader = c->fqIsHeader, &recordIndex = c->fqRecordIndex;
+    lineEnd.reserve(nLines); lineMap.reserve(nLines); mapBefore.reserve(nLines); isHeader.reserve(nLines); recordIndex.reserve(nLines);
+    k_fq_lines<<<gridFor(nLines, 256), 256, 0, st>>>(fastq, nBytes, lineStart.p, nLines, lineEnd.p, lineMap.p);
+    {
+        size_t bytes = 0;
+        HIP_CHECK(hipcub::DeviceScan::ExclusiveScan(nullptr, bytes, lineMap.p, mapBefore.p, FqCompose(), FQ_IDENTITY, int(nLines), st));
+        c->cubTemp.reserve(bytes + 16);
+        HIP_CHECK(hipcub::DeviceScan::ExclusiveScan(c->cubTemp.p, bytes, lineMap.p, mapBefore.p, FqCompose(), FQ_IDENTITY, int(nLines), st));
+    }
+    k_fq_headers<<<gridFor(nLines, 256), 256, 0, st>>>(mapBefore.p, nLines, isHeader.p);
+    exclusiveSum(c, isHeader.p, recordIndex.p, nLines);
+    u32 lastIndex = 0, lastFlag = 0;
+    HIP_CHECK(hipMemcpyAsync(&lastIndex, recordIndex.p + nLines - 1, 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(&lastFlag, isHeader.p + nLines - 1, 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    const u32 nRecords = lastIndex + lastFlag;
+    const u32 nTried = std::min(nRecords, maxClusters);
+    if (!nTried) { *consumedOut = nRecords ? 0 : nBytes; return 0; }
+    // 3. the records
+    DevBuf<FqRecord> &records = c->fqRecords; records.reserve(nTried);
+    DevBuf<u32> &firstBad = c->fqFirstBad; firstBad.reserve(1);
+    HIP_CHECK(hipMemsetAsync(firstBad.p, 0xff, 4, st));
+    {
+        ScopedTimer t(c, "fastq_to_bcl");
+        k_fq_records<<<gridFor(nLines, 256), 256, 0, st>>>(fastq, nBytes, final, allowVariableLength, readLength, lineStart.p, lineEnd.p, lineMap.p, isHeader.p, recordIndex.p, nLines,
+                                                            bcl + c->P.readOffset[readIndex], c->P.clusterLength, maxClusters, records.p);
+        HIP_CHECK(hipGetLastError());
+    }
+    k_fq_first_bad<<<gridFor(nTried, 256), 256, 0, st>>>(records.p, nTried, firstBad.p);
+    u32 bad = 0;
+    HIP_CHECK(hipMemcpyAsync(&bad, firstBad.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    const u32 nGood = std::min(bad, nTried);
+    *nClustersOut = nGood;
+    FqRecord lastGood, firstBadRecord;
+    if (nGood) HIP_CHECK(hipMemcpy(&lastGood, records.p + nGood - 1, sizeof(FqRecord), hipMemcpyDeviceToHost));
+    *consumedOut = (nGood == nRecords) ? nBytes : (nGood ? lastGood.recordEnd : 0);
+    if (bad < nTried)
+    {
+        HIP_CHECK(hipMemcpy(&firstBadRecord, records.p + bad, sizeof(FqRecord), hipMemcpyDeviceToHost));
+        if (FQ_INCOMPLETE != firstBadRecord.status)
+        {
+            if (errorOffsetOut) *errorOffsetOut = firstBadRecord.errorOffset;
+            return FQ_BAD_LENGTH == firstBadRecord.status ? fail(ISAAC_GPU_EREADLEN, "FASTQ read length is different from expected (common::IoException)")
+                                                          : fail(ISAAC_GPU_EFORMAT, "malformed FASTQ record (io::FastqFormatException)");
+        }
+    }
     return 0;
     ISAAC_CATCH
 }

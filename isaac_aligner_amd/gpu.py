@@ -15,7 +15,9 @@ _lib = None
 
 
 class IsaacGpuError(RuntimeError):
-    pass
+    code = 0          # the ISAAC_GPU_E* value
+    error_offset = 0  # isaac_gpu_fastq_to_bcl: byte offset of the malformed record
+    n_clusters = 0    # isaac_gpu_fastq_to_bcl: records converted before it
 
 
 def load_library(path=None):
@@ -35,7 +37,7 @@ def load_library(path=None):
 EXPORTS = ["isaac_gpu_last_error", "isaac_gpu_create", "isaac_gpu_destroy", "isaac_gpu_malloc", "isaac_gpu_free", "isaac_gpu_upload", "isaac_gpu_download",
            "isaac_gpu_synchronize", "isaac_gpu_load_contigs", "isaac_gpu_load_contigs_dev", "isaac_gpu_load_index", "isaac_gpu_build_index", "isaac_gpu_get_index",
            "isaac_gpu_find_matches", "isaac_gpu_set_loaded_contigs", "isaac_gpu_build_fragments", "isaac_gpu_determine_tls", "isaac_gpu_select", "isaac_gpu_bsw_batch",
-           "isaac_gpu_get_counters", "isaac_gpu_kernel_time_ms", "isaac_gpu_reset_timers"]
+           "isaac_gpu_fastq_to_bcl", "isaac_gpu_get_counters", "isaac_gpu_kernel_time_ms", "isaac_gpu_reset_timers"]
 
 
 def _p(t):
@@ -186,6 +188,27 @@ class Aligner:
     @staticmethod
     def records_to_numpy(records, cigars):
         return records.cpu().numpy().view(abi.FRAGMENT_DTYPE).reshape(-1).copy(), cigars.cpu().numpy().view(np.uint32).copy()
+
+    # ---- input format ---------------------------------------------------------------------------------------------
+    def fastq_to_bcl(self, text, read_index, bcl=None, max_clusters=None, allow_variable_length=False, final=True):
+        """io::FastqReader / FastqLoader::loadSingleRead on the device.  text: bytes or a uint8 device tensor of FASTQ text.
+        Returns (bcl tensor [max_clusters, cluster_length], n_clusters, consumed_bytes); raises IsaacGpuError for malformed input."""
+        torch = self.torch
+        if isinstance(text, (bytes, bytearray)):
+            text = torch.frombuffer(bytearray(text) + bytearray(16), dtype=torch.uint8)[:len(text)].to(self.device)
+        n = int(text.numel())
+        if max_clusters is None:
+            max_clusters = n // 4 + 1 if bcl is None else int(bcl.shape[0])
+        if bcl is None:
+            bcl = torch.zeros((max_clusters, self.cluster_length), dtype=torch.uint8, device=self.device)
+        nc, consumed, err = C.c_uint32(), C.c_uint64(), C.c_uint64()
+        rc = self.lib.isaac_gpu_fastq_to_bcl(self.h, _p(text), C.c_uint64(n), C.c_uint32(read_index), int(allow_variable_length), int(final), _p(bcl),
+                                             C.c_uint32(max_clusters), C.byref(nc), C.byref(consumed), C.byref(err))
+        if rc:
+            e = IsaacGpuError("isaac_gpu error %d: %s" % (rc, self.lib.isaac_gpu_last_error().decode()))
+            e.code, e.error_offset, e.n_clusters = rc, err.value, nc.value
+            raise e
+        return bcl, nc.value, consumed.value
 
     # ---- leaf -----------------------------------------------------------------------------------------------------
     def bsw_batch(self, scores, queries, databases):

@@ -128,3 +128,18 @@ def make_read_pairs(contigs, n_pairs, read_length=150, seed=2, device=None, inse
     bcl = torch.where(is_n, torch.zeros_like(code), code | (qual << 2))
     truth = {"contig": contig, "r1_left": r1_left, "r2_left": r2_left, "flip": flip, "random": rnd_pair}
     return bcl.contiguous(), truth
+
+
+def bcl_to_fastq(bcl, read_offset, read_length, name="r", newline=b"\n", plus_header=False):
+    """FASTQ text of one read of a BCL tile (numpy uint8 [n, cluster_length]); N for quality-0 bytes.  The inverse of
+    isaac_gpu_fastq_to_bcl for bytes whose quality is not 0."""
+    import numpy as np
+    b = np.asarray(bcl)[:, read_offset:read_offset + read_length]
+    is_n = (b & 0xFC) == 0
+    bases = np.where(is_n, ord("N"), np.frombuffer(b"ACGT", np.uint8)[b & 3]).astype(np.uint8)
+    quals = np.where(is_n, 33 + 2, 33 + (b >> 2)).astype(np.uint8)
+    out = bytearray()
+    for i in range(len(b)):
+        header = b"@%s:%d" % (name.encode(), i)
+        out += header + newline + bases[i].tobytes() + newline + b"+" + (header[1:] if plus_header else b"") + newline + quals[i].tobytes() + newline
+    return bytes(out)

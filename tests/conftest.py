@@ -18,3 +18,12 @@ def oracle():
     """the CPU restatement (test infrastructure); built on demand with the recipe committed under oracle/"""
     import oracle_lib
     return oracle_lib.load()
+
+
+@pytest.fixture(scope="session")
+def torch():
+    """for the -m gpu tests: torch with a visible GPU (they fail, not skip, without one)"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    return torch

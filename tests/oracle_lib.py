@@ -88,6 +88,20 @@ class Oracle:
     def bsw_check(self, match, mismatch, gap_open, gap_extend, max_read_length):
         return bool(self.lib.oracle_bsw_check(match, mismatch, gap_open, gap_extend, max_read_length))
 
+    def fastq_to_bcl(self, text, read_length, allow_variable_length=False, final=True, max_clusters=None, bcl=None, cluster_stride=None, offset=0):
+        """io::FastqReader + FastqLoader::loadSingleRead over a memory buffer.  Returns (rc, bcl[n, stride], n_clusters, consumed, error_offset)"""
+        data = np.frombuffer(text, np.uint8) if isinstance(text, (bytes, bytearray)) else np.ascontiguousarray(text, np.uint8)
+        if max_clusters is None:
+            max_clusters = len(data) // 4 + 1
+        stride = cluster_stride or read_length
+        if bcl is None:
+            bcl = np.full((max_clusters, stride), 0xEE, np.uint8)
+        n, consumed, err = C.c_uint32(), C.c_uint64(), C.c_uint64()
+        self.lib.oracle_fastq_to_bcl.restype = C.c_int
+        rc = self.lib.oracle_fastq_to_bcl(ptr(data), C.c_uint64(len(data)), C.c_uint32(read_length), int(allow_variable_length), int(final),
+                                          C.c_void_p(bcl.ctypes.data + offset), C.c_uint64(stride), C.c_uint32(max_clusters), C.byref(n), C.byref(consumed), C.byref(err))
+        return rc, bcl, n.value, consumed.value, err.value
+
     def seed_id(self, tile, barcode, cluster, seed, reverse):
         v = C.c_uint64()
         self.check(self.lib.oracle_seed_id(C.c_uint64(tile), C.c_uint64(barcode), C.c_uint64(cluster), C.c_uint64(seed), C.c_uint64(reverse), C.byref(v)))

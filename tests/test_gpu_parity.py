@@ -13,14 +13,6 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.fixture(scope="module")
-def torch():
-    import torch
-    if not torch.cuda.is_available():
-        pytest.fail("-m gpu tests need a GPU")
-    return torch
-
-
 def gpu_matches_numpy(matches):
     m = matches.cpu().numpy().view(np.uint64).reshape(-1, 2)
     return np.rec.fromarrays([m[:, 0], m[:, 1]], dtype=oracle_lib.MATCH_DTYPE)
