@@ -27,6 +27,8 @@ template <int N> __device__ inline int rowDown(int v) { return dpp16<0x100 + N>(
 
 // LDS bytes per alignment group
 __host__ __device__ inline u32 bswGroupLdsBytes(u32 maxQueryLength) { return ((maxQueryLength * 16 + 15) & ~15u) + 128; }
+// k_gapped_jobs also keeps the query and the database window of the group there (the DP loop then reads LDS, not global memory)
+__host__ __device__ inline u32 gappedGroupLdsBytes(u32 maxQueryLength) { return bswGroupLdsBytes(maxQueryLength) + 2 * ((maxQueryLength + 31) & ~15u); }
 
 // The DP of one alignment on the 16 lanes of a group, then traceback and CIGAR on lane 0.  `cig[n..)` receives the operations
 // (reference order); the return value (lane 0 only) is BandedSmithWaterman::align's: the length of the stripped leading
@@ -159,8 +161,10 @@ __global__ __launch_bounds__(256) void k_gapped_jobs(DevParams P, DevReference R
     __syncthreads();
     DevReference R = Rg; R.logMatch = qualityTables; R.logMismatch = qualityTables + 64;
     const u32 group = threadIdx.x >> 4, k = threadIdx.x & 15;
-    u8 *T = lds + group * bswGroupLdsBytes(maxReadLength);
+    u8 *T = lds + group * gappedGroupLdsBytes(maxReadLength);
     short *endVals = reinterpret_cast<short *>(T + ((maxReadLength * 16 + 15) & ~15u));
+    char *stagedQuery = reinterpret_cast<char *>(T + bswGroupLdsBytes(maxReadLength));
+    char *stagedDatabase = stagedQuery + ((maxReadLength + 31) & ~15u);
     const u32 nJobs = imin(*jobCounter, jobsCap);
     for (u32 j = blockIdx.x * 16 + group; j < nJobs; j += gridDim.x * 16)
     {
@@ -192,8 +196,14 @@ __global__ __launch_bounds__(256) void k_gapped_jobs(DevParams P, DevReference R
             u32 left, right;
             getFlanks(strandPosition, sequenceLength, referenceSize, left, right);
             const char *database = R.bases + R.contigOffset[f.contigId] + strandPosition - left;
-            StrandQueryDev q; q.read = read; q.reverse = f.reverse; q.offset = u32(begin);
-            const u32 ret = bswCooperative(P.gapMatch, P.gapMismatch, -P.gapOpen, -P.gapExtend, q, sequenceLength, database, T, endVals, k, res.cigar, 40u, n, overflow);
+            // the group's 16 lanes bring the query and the window into LDS side by side; the DP rows then read one byte of each
+            for (u32 i = k; i < sequenceLength; i += 16) stagedQuery[i] = strandBase(read, f.reverse, u32(begin) + i);
+            for (u32 i = k; i < sequenceLength + 16; i += 16) stagedDatabase[i] = (i < sequenceLength + 15) ? database[i] : char(0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            PlainQuery q; q.q = stagedQuery;
+            const u32 ret = bswCooperative(P.gapMatch, P.gapMismatch, -P.gapOpen, -P.gapExtend, q, sequenceLength, stagedDatabase, T, endVals, k, res.cigar, 40u, n, overflow);
             if (k == 0)
             {
                 strandPosition += ret;

@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256) void k_rescue_gapped_plan(const ClusterFragmen
         ++local.rescueCalls; local.rescueWindowBases += job.windowLen; local.rescueCandidates += job.nCands;
         summarizeRescueJob(job, rb.shadowCands, rb.candRank);
         const u32 ecm = frags[job.cluster].endCyclesMasked[job.shadowReadIndex];
-        const u32 n = planRescueGapped(job, rb.shadowCands, rb.shadowCigars, ecm, nullptr);
+        const u32 n = job.nGapped;      // counted by the summary pass; the candidates are walked again only to write the problems
         u32 base = 0;
         if (n)
         {
@@ -1294,7 +1294,7 @@ static GappedBuffers gappedBuffers(isaac_gpu_ctx *c, u32 which)
 static void launchGappedJobs(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clusterBase, const GappedBuffers &gb, const char *timer)
 {
     const u32 maxReadLength = std::max(c->P.readLength[0], c->P.nReads > 1 ? c->P.readLength[1] : 0u);
-    const size_t lds = size_t(16) * bswGroupLdsBytes(maxReadLength);
+    const size_t lds = size_t(16) * gappedGroupLdsBytes(maxReadLength);
     ScopedTimer t(c, timer);
     k_gapped_jobs<<<1024, 256, lds, c->stream>>>(c->P, c->ref(), bcl, clusterBase, gb.jobs, gb.counter, gb.cap, maxReadLength, gb.results);
     HIP_CHECK(hipGetLastError());

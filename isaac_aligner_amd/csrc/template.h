@@ -596,17 +596,23 @@ ISAAC_HD bool shadowRescueLookup(TemplateCtx &x, const Cand &orphan, const Rescu
 // (the running choice of ShadowAligner.cpp:216-230) and whether the last candidate aligned.
 ISAAC_HD void summarizeRescueJob(RescueJob &job, const Cand *shadowCands, u32 *candRank)
 {
-    u32 n = 0; i32 best = -1; u32 bestRank = 0; bool last = false;
+    u32 n = 0; i32 best = -1; u32 bestRank = 0, bestMismatches = 0; bool last = false;
+    double bestLp = 0.0;
+    u32 nClose = 0; i64 prevPosition = 0; u32 prevMismatches = 0;     // the pairs planRescueGapped would pick, counted on the way
     for (u32 c = 0; c < job.nCands; ++c)
     {
         const Cand &f = shadowCands[job.candBase + c];
         candRank[job.candBase + c] = n;
         last = candAligned(f);
         if (!last) continue;
-        if (best < 0 || lpLess(shadowCands[job.candBase + best].logProbability, f.logProbability)) { best = i32(c); bestRank = n; }
+        const double lp = f.logProbability; const i64 position = f.position; const u32 mismatches = f.mismatchCount;
+        if (best < 0 || lpLess(bestLp, lp)) { best = i32(c); bestRank = n; bestLp = lp; bestMismatches = mismatches; }
+        if (n && position - prevPosition < i64(BSW_DISTANCE_CUTOFF) && BSW_MISMATCHES_CUTOFF < prevMismatches) ++nClose;
+        prevPosition = position; prevMismatches = mismatches;
         ++n;
     }
     job.nAligned = n; job.bestRank = bestRank; job.bestSlot = best < 0 ? 0 : job.candBase + u32(best); job.lastAligned = last ? 1 : 0;
+    job.nGapped = (best >= 0 && BSW_MISMATCHES_CUTOFF < bestMismatches) ? nClose : 0;   // == planRescueGapped(job, ..., NULL)
 }
 
 // Which shadows of a job ShadowAligner.cpp:232-262 hands to the gapped aligner.  The choice reads only the ungapped results

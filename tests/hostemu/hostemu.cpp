@@ -202,7 +202,8 @@ int emu_select(Emu *e, const u8 *bcl, u32 nClusters, u32 tile, const isaac_tls *
             if (!job.valid || job.fallback) continue;
             const u32 ecm = e->frags[job.cluster].endCyclesMasked[job.shadowReadIndex];
             summarizeRescueJob(job, shadowCands.data(), candRank.data());
-            const u32 n = planRescueGapped(job, shadowCands.data(), shadowCigars.data(), ecm, 0);
+            const u32 n = job.nGapped;
+            if (n != planRescueGapped(job, shadowCands.data(), shadowCigars.data(), ecm, 0)) { g_error = "summarizeRescueJob and planRescueGapped disagree"; return 1; }
             job.gappedBase = u32(gj.size()); job.nGapped = n;
             gj.resize(gj.size() + n);
             if (n) planRescueGapped(job, shadowCands.data(), shadowCigars.data(), ecm, gj.data() + job.gappedBase);
