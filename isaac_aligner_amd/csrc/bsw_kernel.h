@@ -38,6 +38,7 @@ template <typename QueryF>
 __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapOpenScore, int gapExtendScore, QueryF query, u32 L, const char *database,
                                      u8 *T, short *endVals, u32 k, u32 *cig, u32 cap, u32 &n, bool &overflow)
 {
+    STAMP_BEGIN();
     const int initialValue = s16(-32768 + gapOpenScore);
     const int open = gapOpenScore, ext = gapExtendScore;
     const int wMatch = matchScore & 0xff, wMismatch = s16(0xff00 | (mismatchScore & 0xff));
@@ -86,6 +87,7 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
         d = (k == 0) ? ((i + 1 < L) ? database[i + 16] : char(0)) : dn;
     }
     endVals[k] = short(G); endVals[16 + k] = short(E); endVals[32 + k] = short(F);
+    STAMP(55);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -121,6 +123,7 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
         for (u32 lo = first, hi = n; lo + 1 < hi; ++lo) { --hi; const u32 tt = cig[lo]; cig[lo] = cig[hi]; cig[hi] = tt; }
         if (n > first && OP_DELETE == cigarCode(cig[n - 1])) --n;
     }
+    STAMP(56);
     // the group's LDS is reused by the next problem only after lane 0 is done with it
     __builtin_amdgcn_wave_barrier();
     return ret;
@@ -168,6 +171,7 @@ __global__ __launch_bounds__(256) void k_gapped_jobs(DevParams P, DevReference R
     const u32 nJobs = imin(*jobCounter, jobsCap);
     for (u32 j = blockIdx.x * 16 + group; j < nJobs; j += gridDim.x * 16)
     {
+        STAMP_BEGIN();
         const GappedJob &jb = jobs[j];
         GappedResult &res = results[j];
         Cand f = jb.in;
@@ -196,25 +200,58 @@ __global__ __launch_bounds__(256) void k_gapped_jobs(DevParams P, DevReference R
             u32 left, right;
             getFlanks(strandPosition, sequenceLength, referenceSize, left, right);
             const char *database = R.bases + R.contigOffset[f.contigId] + strandPosition - left;
+            STAMP(50);
             // the group's 16 lanes bring the query and the window into LDS side by side; the DP rows then read one byte of each
             for (u32 i = k; i < sequenceLength; i += 16) stagedQuery[i] = strandBase(read, f.reverse, u32(begin) + i);
             for (u32 i = k; i < sequenceLength + 16; i += 16) stagedDatabase[i] = (i < sequenceLength + 15) ? database[i] : char(0);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            STAMP(51);
             PlainQuery q; q.q = stagedQuery;
             const u32 ret = bswCooperative(P.gapMatch, P.gapMismatch, -P.gapOpen, -P.gapExtend, q, sequenceLength, stagedDatabase, T, endVals, k, res.cigar, 40u, n, overflow);
+            STAMP(52);
             if (k == 0)
             {
                 strandPosition += ret;
                 const u32 clipEndBases = u32(i64(read.length) - end);
                 if (clipEndBases) { if (n < 40) res.cigar[n++] = cigarOp(clipEndBases, OP_SOFT_CLIP); else overflow = true; }
                 strandPosition -= left;
-                pool.used = n;
-                matchCount = updateFragmentCigar(P, R, read, f, strandPosition, pool, 0);
+                // the rescan of the CIGAR (a serial fp64 chain per alignment) is k_gapped_rescan's, one thread per problem:
+                // here it would occupy one lane in sixteen.  Handed over: the strand position and "aligned" in matchCount.
+                f.position = strandPosition;
+                matchCount = 1;
             }
         }
+        STAMP(53);
         if (k == 0) { res.out = f; res.matchCount = matchCount; res.nCigar = overflow ? 0xffffffffu : n; }
+        STAMP(54);
+    }
+}
+
+// AlignerBase::updateFragmentCigar for the alignments k_gapped_jobs produced: one thread per problem
+__global__ __launch_bounds__(256) void k_gapped_rescan(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap,
+                                                      GappedResult *results)
+{
+    __shared__ double qualityTables[128];
+    for (u32 qi = threadIdx.x; qi < 128; qi += blockDim.x) qualityTables[qi] = qi < 64 ? Rg.logMatch[qi] : Rg.logMismatch[qi - 64];
+    __syncthreads();
+    DevReference R = Rg; R.logMatch = qualityTables; R.logMismatch = qualityTables + 64;
+    const u32 nJobs = imin(*jobCounter, jobsCap);
+    for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < nJobs; j += gridDim.x * blockDim.x)
+    {
+        GappedResult &res = results[j];
+        if (!res.matchCount || 0xffffffffu == res.nCigar) continue;      // refused by the aligner, or the CIGAR did not fit
+        const GappedJob &jb = jobs[j];
+        Cand f = res.out;
+        const u32 r = f.readIndex;
+        ReadView read;
+        read.bcl = bcl + u64(clusterBase + jb.cluster) * P.clusterLength + P.readOffset[r]; read.length = P.readLength[r];
+        read.firstCycle = P.firstCycle[r]; read.endCyclesMasked = jb.endCyclesMasked;
+        CigarPool pool; pool.words = res.cigar; pool.used = res.nCigar; pool.capacity = 40; pool.overflow = 0;
+        const i64 strandPosition = f.position;
+        res.matchCount = updateFragmentCigar(P, R, read, f, strandPosition, pool, 0);
+        res.out = f;
     }
 }
 

@@ -1298,6 +1298,8 @@ static void launchGappedJobs(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clusterBa
     ScopedTimer t(c, timer);
     k_gapped_jobs<<<1024, 256, lds, c->stream>>>(c->P, c->ref(), bcl, clusterBase, gb.jobs, gb.counter, gb.cap, maxReadLength, gb.results);
     HIP_CHECK(hipGetLastError());
+    k_gapped_rescan<<<1024, 256, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, gb.jobs, gb.counter, gb.cap, gb.results);
+    HIP_CHECK(hipGetLastError());
 }
 
 static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clusterBase, u32 n, const isaac_match *matches, const uint64_t *offsets, int withGaps, int trim)
