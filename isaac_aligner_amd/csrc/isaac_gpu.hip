@@ -689,7 +689,8 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
         if (sum)
         {
             const u32 at = atomicAdd(rb.candCounter + region, sum);
-            if (at + sum <= rb.candRegionSize) base = region * rb.candRegionSize + at;   // else: the region is full, these problems fall back
+            if (at + sum <= rb.candRegionSize) base = region * rb.candRegionSize + at;
+            else atomicMin(rb.candCounter + CAND_REGIONS + region, at);   // the region is full from here on: these problems fall back
         }
         blockBase = base;
     }
@@ -732,7 +733,8 @@ __global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference 
     ISAAC_STAGE_QUALITY_TABLES(Rg, R)
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     Counters local; memset(&local, 0, sizeof(local));
-    if (i < rb.candCap && i % rb.candRegionSize < imin(rb.candCounter[i / rb.candRegionSize], rb.candRegionSize))
+    // slots in use: below the region's counter and below the first request the region could not serve
+    if (i < rb.candCap && i % rb.candRegionSize < imin(imin(rb.candCounter[i / rb.candRegionSize], rb.candCounter[CAND_REGIONS + i / rb.candRegionSize]), rb.candRegionSize))
     {
         const RescueJob &job = rb.jobs[rb.candJob[i]];
         rescueAlignCandidate(P, R, bcl, clusterBase + job.cluster, frags[job.cluster], job, rb.candPositions[i], rb.shadowCands[i], rb.shadowCigars + u64(i) * 3);
@@ -1424,7 +1426,7 @@ int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, u
     {
         rb.jobsCap = 4 * chunk; rb.bitmapCap = 64 * rb.jobsCap; rb.candRegionSize = (24 * chunk + CAND_REGIONS - 1) / CAND_REGIONS; rb.candCap = rb.candRegionSize * CAND_REGIONS;
         c->jobs.reserve(rb.jobsCap); c->bitmaps.reserve(rb.bitmapCap); c->candPositions.reserve(rb.candCap); c->candJob.reserve(rb.candCap);
-        c->shadowCands.reserve(rb.candCap); c->candRank.reserve(rb.candCap); c->shadowCigars.reserve(size_t(rb.candCap) * 3); c->jobBase.reserve(chunk); c->jobCount.reserve(chunk); c->rescueCounters.reserve(4 + CAND_REGIONS);
+        c->shadowCands.reserve(rb.candCap); c->candRank.reserve(rb.candCap); c->shadowCigars.reserve(size_t(rb.candCap) * 3); c->jobBase.reserve(chunk); c->jobCount.reserve(chunk); c->rescueCounters.reserve(4 + 2 * CAND_REGIONS);
         rb.jobs = c->jobs.p; rb.bitmaps = c->bitmaps.p; rb.candPositions = c->candPositions.p; rb.candJob = c->candJob.p; rb.shadowCands = c->shadowCands.p; rb.candRank = c->candRank.p;
         rb.shadowCigars = c->shadowCigars.p; rb.jobBase = c->jobBase.p; rb.jobCount = c->jobCount.p;
         rb.jobCounter = c->rescueCounters.p; rb.bitmapCounter = c->rescueCounters.p + 1; rb.candCounter = c->rescueCounters.p + 4;
@@ -1445,6 +1447,7 @@ int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, u
         if (c->flatRescue)
         {
             HIP_CHECK(hipMemsetAsync(c->rescueCounters.p, 0, (4 + CAND_REGIONS) * 4, st));
+            HIP_CHECK(hipMemsetAsync(c->rescueCounters.p + 4 + CAND_REGIONS, 0xff, CAND_REGIONS * 4, st));   // per region: first request that did not fit
             {
                 ScopedTimer tm(c, "plan_rescue");
                 k_plan_rescue<<<gridFor(n, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, n, c->fragsCur, c->lightArena.p, lightBytes, light, rb);

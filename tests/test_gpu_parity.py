@@ -231,3 +231,50 @@ def test_full_size_parity(torch, oracle):
     assert otls.astuple() == tls.astuple()
     orec, ocig, _ = ref.select(p, host_bcl, om, otls, ohits, n_threads=os.cpu_count() or 1, n_clusters_hint=len(host_bcl))
     assert not compare_records(orec, ocig, rec, cig)
+
+
+def _repeat_genome(seed=77):
+    """one contig: unique flanks around eight copies of a 3 kb unit 2 kb apart (all within reach of the mate-rescue window
+    once a cross-copy pair sets the best template length), a dinucleotide run and a homopolymer run"""
+    rng = np.random.default_rng(seed)
+    rnd = lambda n: rng.choice(list(b"ACGT"), n).astype(np.uint8)
+    unit = rnd(3000)
+    parts = [rnd(20000)]
+    for i in range(8):
+        copy = unit.copy()
+        mut = rng.random(len(copy)) < 0.002           # copies differ a little
+        copy[mut] = rng.choice(list(b"ACGT"), int(mut.sum()))
+        parts += [copy, rnd(2000)]
+    parts += [np.frombuffer(b"AC" * 1500, np.uint8), rnd(3000), np.full(2500, ord("A"), np.uint8), rnd(20000)]
+    return [bytes(np.concatenate(parts))]
+
+
+@pytest.mark.parametrize("chunk", [None, "1024"])
+def test_repeat_family_stress(torch, oracle, chunk, monkeypatch):
+    """reads from a repeat family: thousands of rescue candidates per cluster, the wave-per-cluster pass, the reference's own
+    capacities (1000 shadows, 10000 window positions); with a 1024-cluster chunk also every capacity fallback of the flat pass"""
+    from isaac_aligner_amd import gpu, synth
+    if chunk:
+        monkeypatch.setenv("ISAAC_GPU_CHUNK_CLUSTERS", chunk)
+    contigs = _repeat_genome()
+    dev_contigs = [torch.frombuffer(bytearray(c), dtype=torch.uint8).to("cuda") for c in contigs]
+    bcl, _ = synth.make_read_pairs(dev_contigs, 2500, 150, seed=78, device="cuda")
+    p = options.default_params(150, 150)
+    al = gpu.Aligner(p, 0, contigs)
+    al.build_index()
+    matches, offsets, hits = al.find_matches(bcl)
+    al.set_loaded_contigs(hits)
+    tls = al.determine_tls(bcl, matches, offsets)
+    rec, cig = al.records_to_numpy(*al.select(bcl, matches, offsets, tls))
+    counters = al.counters()
+    assert counters["heavy_clusters"] > 0 and counters["overflow_clusters"] == 0
+    ref = oracle.reference(contigs)
+    ref.set_index(al.get_index())
+    host_bcl = bcl.cpu().numpy()
+    om, ohits = ref.find_matches(p, host_bcl, len(host_bcl))
+    assert (sort_matches(om) == sort_matches(gpu_matches_numpy(matches))).all()
+    otls = ref.determine_tls(p, host_bcl, om, ohits)
+    assert otls.astuple() == tls.astuple()
+    import os
+    orec, ocig, _ = ref.select(p, host_bcl, om, otls, ohits, n_threads=os.cpu_count() or 1, n_clusters_hint=len(host_bcl))
+    assert not compare_records(orec, ocig, rec, cig)
