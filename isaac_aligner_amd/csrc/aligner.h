@@ -690,18 +690,29 @@ struct MatchLess
 
 // FragmentBuilder::build (FragmentBuilder.cpp:82-145) + alignFragments (:147-217) for one cluster.
 // `matches` are the cluster's Match records in any order.  Results go to `out` (lists compacted in final order).
-ISAAC_HD bool buildFragments(const DevParams &P, const DevReference &R, const u8 *clusterBcl, const Match *matches, u32 nMatches,
-                             bool withGaps, bool trim, FragmentWork &work, ClusterFragments &out, Counters &cnt, bool deferSimpleIndels = false)
+// the list order l.order applied to l.store in place (cycle following); the first l.n elements end up in list order
+ISAAC_HD void applyOrderInPlace(Cand *store, u8 *order, u32 n)
+{
+    for (u32 i = 0; i < n; ++i)
+    {
+        u32 src = order[i];
+        while (src < i) src = order[src];       // already moved: follow where it went
+        if (src != i) { const Cand t = store[i]; store[i] = store[src]; store[src] = t; }
+        order[i] = u8(src);
+    }
+}
+
+// FragmentBuilder::build (FragmentBuilder.cpp:82-145) + alignFragments (:147-217) in three steps, so that the ungapped scans can
+// run one per thread (k_align_candidates) instead of one cluster's worth per thread:
+//   buildCandidates   matches -> candidate positions of both reads, duplicates merged (list order in out.cands)
+//   alignCandidate    UngappedAligner::alignUngapped for one candidate; its CIGAR takes a fixed 3-word slot of the cluster's pool
+//   finishCandidates  consolidation, the single-indel stage (or its deferral), lists compacted in place
+ISAAC_HD bool buildCandidates(const DevParams &P, const u8 *clusterBcl, const Match *matches, u32 nMatches, bool trim, FragmentWork &work, ClusterFragments &out)
 {
     out.nCands[0] = out.nCands[1] = 0; out.cigarUsed = 0; out.flags = 0; out.repeatSeedsCount = 0; out.built = 0;
     STAMP_BEGIN();
-    ReadView reads[2];
     for (u32 r = 0; r < 2; ++r)
-    {
-        reads[r].bcl = clusterBcl + P.readOffset[r]; reads[r].length = r < P.nReads ? P.readLength[r] : 0; reads[r].firstCycle = P.firstCycle[r];
-        reads[r].endCyclesMasked = (trim && r < P.nReads) ? trimLowQualityEnd(reads[r].bcl, reads[r].length, P.baseQualityCutoff) : 0;
-        out.endCyclesMasked[r] = reads[r].endCyclesMasked;
-    }
+        out.endCyclesMasked[r] = (trim && r < P.nReads) ? trimLowQualityEnd(clusterBcl + P.readOffset[r], P.readLength[r], P.baseQualityCutoff) : 0;
     STAMP(20);
     if (!nMatches || nMatches > MATCH_CAP_MAX) { if (nMatches > MATCH_CAP_MAX) out.flags |= CLUSTER_OVERFLOW; return false; }
     // seedMatchCounts_ / repeatSeedsCount_ (FragmentBuilder.cpp:99-126): order independent once stated per seed index
@@ -724,7 +735,6 @@ ISAAC_HD bool buildFragments(const DevParams &P, const DevReference &R, const u8
     for (u32 i = 0; i < nMatches; ++i) work.matchOrder[i] = u8(i);
     { MatchLess ml; ml.m = matches; exactSort(work.matchOrder, i32(nMatches), ml); }
     STAMP(22);
-    CigarPool pool; pool.words = out.cigarPool; pool.used = 0; pool.capacity = CIGAR_POOL; pool.overflow = 0;
     bool built = false;
     for (u32 r = 0; r < P.nReads; ++r)
     {
@@ -746,6 +756,7 @@ ISAAC_HD bool buildFragments(const DevParams &P, const DevReference &R, const u8
             f.contigId = refposContig(m.location);
             f.position = reverse ? seedPosition + seed.length + seed.offset - i64(P.readLength[r]) : seedPosition - seed.offset;
             f.reverse = reverse;
+            f.repeatSeedsCount = u16(repeatSeedsCount);
             if (seed.length != 64 && (m.location & 1)) { f.nonUniqueFirst = seed.offset; f.nonUniqueSecond = seed.offset; }
             else f.uniqueSeedCount = 1;
             l.order[l.n++] = u8(l.stored++);
@@ -754,17 +765,36 @@ ISAAC_HD bool buildFragments(const DevParams &P, const DevReference &R, const u8
         STAMP(23);
         if (!l.n) continue;
         built = true;
-        // alignFragments (:147-217)
-        consolidateDuplicateFragments(l, false);
+        consolidateDuplicateFragments(l, false);       // alignFragments (:147-217) starts with this
         STAMP(24);
-        for (u32 i = 0; i < l.n; ++i)
-        {
-            Cand &f = l.at(i);
-            f.repeatSeedsCount = u16(repeatSeedsCount);
-            alignUngapped(P, R, reads[r], f, pool);
-            ++cnt.ungappedScans;
-        }
-        STAMP(25);
+        for (u32 i = 0; i < l.n; ++i) out.cands[r][i] = l.at(i);
+        out.nCands[r] = l.n;
+    }
+    out.built = built;
+    return built;
+}
+
+ISAAC_HD void alignCandidate(const DevParams &P, const DevReference &R, const u8 *clusterBcl, ClusterFragments &out, u32 r, u32 i, Counters &cnt)
+{
+    ReadView read; read.bcl = clusterBcl + P.readOffset[r]; read.length = P.readLength[r]; read.firstCycle = P.firstCycle[r]; read.endCyclesMasked = out.endCyclesMasked[r];
+    const u32 slot = 3 * ((r ? out.nCands[0] : 0) + i);
+    CigarPool pool; pool.words = out.cigarPool; pool.used = slot; pool.capacity = slot + 3; pool.overflow = 0;
+    alignUngapped(P, R, read, out.cands[r][i], pool);
+    ++cnt.ungappedScans;
+}
+
+ISAAC_HD void finishCandidates(const DevParams &P, const DevReference &R, const u8 *clusterBcl, FragmentWork &work, ClusterFragments &out, Counters &cnt, bool deferSimpleIndels)
+{
+    if (!out.built) return;
+    STAMP_BEGIN();
+    CigarPool pool; pool.words = out.cigarPool; pool.used = 3 * (out.nCands[0] + out.nCands[1]); pool.capacity = CIGAR_POOL; pool.overflow = 0;
+    for (u32 r = 0; r < P.nReads; ++r)
+    {
+        const u32 n = out.nCands[r];
+        if (!n) continue;
+        ReadView read; read.bcl = clusterBcl + P.readOffset[r]; read.length = P.readLength[r]; read.firstCycle = P.firstCycle[r]; read.endCyclesMasked = out.endCyclesMasked[r];
+        CandList l; l.store = out.cands[r]; l.order = work.order; l.n = n; l.stored = n; l.capacity = CAND_CAP; l.overflow = 0;
+        for (u32 i = 0; i < n; ++i) work.order[i] = u8(i);
         consolidateDuplicateFragments(l, true);
         STAMP(26);
         if (P.semialignedGapLimit)
@@ -775,22 +805,30 @@ ISAAC_HD bool buildFragments(const DevParams &P, const DevReference &R, const u8
                 if (hasSimpleIndelPair(P, l, pool))
                 {
                     if (deferSimpleIndels) out.flags |= CLUSTER_INDEL_PENDING << r;   // the list is left in this order for finishSimpleIndels
-                    else { u32 si = 0; simpleIndelPairs(P, R, reads[r], pool, l, si); cnt.simpleIndels += si; }
+                    else { u32 si = 0; simpleIndelPairs(P, R, read, pool, l, si); cnt.simpleIndels += si; }
                 }
             }
             if (!(out.flags & (CLUSTER_INDEL_PENDING << r))) consolidateDuplicateFragments(l, true);
         }
         STAMP(27);
         // the candidates stay in list order; the gapped retries (FragmentBuilder.cpp:187-214) follow in finishFragments
-        if (l.n > CAND_CAP) l.n = CAND_CAP;
-        for (u32 i = 0; i < l.n; ++i) out.cands[r][i] = l.at(i);
+        applyOrderInPlace(out.cands[r], work.order, l.n);
         out.nCands[r] = l.n;
         STAMP(28);
     }
     out.cigarUsed = pool.used;
     if (pool.overflow) out.flags |= CLUSTER_OVERFLOW;
-    out.built = built;
-    return built;
+}
+
+// the three steps one after the other in this thread (serial form)
+ISAAC_HD bool buildFragments(const DevParams &P, const DevReference &R, const u8 *clusterBcl, const Match *matches, u32 nMatches,
+                             bool withGaps, bool trim, FragmentWork &work, ClusterFragments &out, Counters &cnt, bool deferSimpleIndels = false)
+{
+    (void)withGaps;
+    if (!buildCandidates(P, clusterBcl, matches, nMatches, trim, work, out)) return false;
+    for (u32 r = 0; r < P.nReads; ++r) for (u32 i = 0; i < out.nCands[r]; ++i) alignCandidate(P, R, clusterBcl, out, r, i, cnt);
+    finishCandidates(P, R, clusterBcl, work, out, cnt, deferSimpleIndels);
+    return true;
 }
 
 // The single-indel stage of the reads buildFragments left pending: the pair loop of alignSimpleIndels and the consolidation

@@ -80,7 +80,7 @@ struct isaac_gpu_ctx
     struct PendingTimer { std::string name; hipEvent_t e0, e1; };
     std::vector<PendingTimer> pendingTimers; std::vector<hipEvent_t> eventPool;
     hipStream_t heavyStream = nullptr; hipEvent_t evPredicted = nullptr, evHeavyDone = nullptr;
-    DevBuf<u32> heavyList, heavyCount, indelList; DevBuf<u8> heavyFlag;
+    DevBuf<u32> heavyList, heavyCount, indelList, alignList; DevBuf<u8> heavyFlag;
     DevBuf<u32> classKeys, classKeysSorted, classIdx, fragmentOrder, selectOrder;   // clusters ordered by work class (see k_match_class)
     u32 chunkClusters = 524288; bool workClasses = false;   // lane order by work class: measured slower (locality of neighbouring clusters matters more), kept as ISAAC_GPU_WORK_CLASSES=1
 
@@ -352,20 +352,79 @@ __device__ inline void emitGappedJobs(const ClusterFragments &f, u32 cl, bool wi
     gb.base[cl] = base;
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_build_fragments(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, u32 nChunk, const Match *matches, const u64 *offsets,
-                                                        int withGaps, int trim, const u32 *order, u32 *indelList, u32 *indelCount, FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters)
+// the chunk's ungapped alignment problems: (cluster << 8) | (read << 7) | index in the read's candidate list
+struct AlignList { u32 *entries; u32 cap; u32 *counter; };
+
+// Fragment stage, step 1: matches -> candidate positions (buildCandidates), and one entry per candidate in the flat list
+// k_align_candidates works through.  The list space of a wave is taken with one atomic.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_build_fragments(DevParams P, const u8 *bcl, u32 clusterBase, u32 nChunk, const Match *matches, const u64 *offsets,
+                                                        int trim, const u32 *order, FragmentWork *work, ClusterFragments *frags, AlignList al)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 cl = 0, n = 0;
+    if (t < nChunk)
+    {
+        cl = order ? order[t] : t;     // neighbouring lanes take clusters of the same work class
+        const u64 begin = offsets[clusterBase + cl], end = offsets[clusterBase + cl + 1];
+        buildCandidates(P, bcl + u64(clusterBase + cl) * P.clusterLength, matches + begin, u32(end - begin), trim != 0, work[t], frags[cl]);
+        n = frags[cl].nCands[0] + frags[cl].nCands[1];
+    }
+    // exclusive prefix of n over the wave, one allocation for all of it
+    u32 incl = n;
+    for (u32 o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o, 64); if ((threadIdx.x & 63) >= o) incl += v; }
+    const u32 total = __shfl(incl, 63, 64);
+    u32 base = 0;
+    if ((threadIdx.x & 63) == 63 && total) base = atomicAdd(al.counter, total);
+    base = __shfl(base, 63, 64);
+    if (n)
+    {
+        u32 at = base + incl - n;
+        if (base + total > al.cap)
+        {   // no room: the cluster aligns its own candidates later; what the wave took of the list is marked unused
+            frags[cl].flags |= CLUSTER_ALIGN_PENDING;
+            for (u32 k = 0; k < n; ++k) if (at + k < al.cap) al.entries[at + k] = 0xffffffffu;
+        }
+        else for (u32 r = 0; r < 2; ++r) for (u32 i = 0; i < frags[cl].nCands[r]; ++i) al.entries[at++] = (cl << 8) | (r << 7) | i;
+    }
+}
+
+// step 2: UngappedAligner::alignUngapped, one candidate per thread
+__global__ __launch_bounds__(256) void k_align_candidates(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, ClusterFragments *frags, AlignList al, Counters *counters)
+{
+    ISAAC_STAGE_QUALITY_TABLES(Rg, R)
+    Counters local; memset(&local, 0, sizeof(local));
+    const u32 n = imin(*al.counter, al.cap);
+    for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+    {
+        const u32 e = al.entries[j], cl = e >> 8;
+        if (0xffffffffu == e) continue;
+        alignCandidate(P, R, bcl + u64(clusterBase + cl) * P.clusterLength, frags[cl], (e >> 7) & 1, e & 127, local);
+    }
+    flushCounters(local, counters);
+}
+
+// step 3: consolidation and the single-indel stage (finishCandidates), then either the cluster's gapped problems or, for the
+// 3-4 % of clusters with a candidate pair for the single-indel detector, an entry for k_indel_fragments: inside this kernel
+// nearly every wave would hold one such lane and wait for it
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_finish_candidates(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, u32 nChunk,
+                                                        int withGaps, const u32 *order, u32 *indelList, u32 *indelCount, FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters)
 {
     ISAAC_STAGE_QUALITY_TABLES(Rg, R)
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     Counters local; memset(&local, 0, sizeof(local));
     if (t < nChunk)
     {
-        const u32 cl = order ? order[t] : t;     // neighbouring lanes take clusters of the same work class
-        clusterBuildFragments(P, R, bcl, clusterBase + cl, matches, offsets, withGaps != 0, trim != 0, work[t], frags[cl], local, indelList != nullptr);
-        // a read with candidate pairs for the single-indel detector (3-4 % of the clusters) goes to k_indel_fragments: inside this
-        // kernel nearly every wave would hold one such lane and wait for it
-        if (clusterSimpleIndelsPending(frags[cl])) indelList[atomicAdd(indelCount, 1u)] = cl;
-        else emitGappedJobs(frags[cl], cl, withGaps != 0, gb);
+        const u32 cl = order ? order[t] : t;
+        ClusterFragments &f = frags[cl];
+        const u8 *clusterBcl = bcl + u64(clusterBase + cl) * P.clusterLength;
+        if (f.flags & CLUSTER_ALIGN_PENDING)
+        {
+            f.flags &= ~u32(CLUSTER_ALIGN_PENDING);
+            for (u32 r = 0; r < P.nReads; ++r) for (u32 i = 0; i < f.nCands[r]; ++i) alignCandidate(P, R, clusterBcl, f, r, i, local);
+        }
+        finishCandidates(P, R, clusterBcl, work[t], f, local, true);
+        if (clusterSimpleIndelsPending(f)) indelList[atomicAdd(indelCount, 1u)] = cl;
+        else emitGappedJobs(f, cl, withGaps != 0, gb);
     }
     flushCounters(local, counters);
 }
@@ -1319,10 +1378,20 @@ static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clust
         sortPairs(c, c->classKeys.p, c->classKeysSorted.p, c->classIdx.p, c->fragmentOrder.p, n, 6);
         order = c->fragmentOrder.p;
     }
+    AlignList al; al.cap = 8 * c->chunkClusters; c->alignList.reserve(al.cap); al.entries = c->alignList.p; al.counter = c->gappedCounters.p + 3;
     {
         ScopedTimer t(c, "build_fragments");
-        k_build_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, reinterpret_cast<const Match *>(matches), offsets,
-                                                                 withGaps, trim, order, c->indelList.p, c->gappedCounters.p + 2, c->fragWork.p, c->fragsCur, gb, c->counters.p);
+        k_build_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, bcl, clusterBase, n, reinterpret_cast<const Match *>(matches), offsets, trim, order, c->fragWork.p, c->fragsCur, al);
+        HIP_CHECK(hipGetLastError());
+    }
+    {
+        ScopedTimer t(c, "align_candidates");
+        k_align_candidates<<<4096, 256, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, c->fragsCur, al, c->counters.p);
+        HIP_CHECK(hipGetLastError());
+    }
+    {
+        ScopedTimer t(c, "finish_candidates");
+        k_finish_candidates<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, withGaps, order, c->indelList.p, c->gappedCounters.p + 2, c->fragWork.p, c->fragsCur, gb, c->counters.p);
         HIP_CHECK(hipGetLastError());
     }
     {

@@ -146,7 +146,8 @@ struct ClusterFragments
     u32 cigarPool[CIGAR_POOL];
 };
 enum { CLUSTER_OVERFLOW = 1,
-       CLUSTER_INDEL_PENDING = 2 };   // << read index: the single-indel stage of this read is still to run (finishSimpleIndels)
+       CLUSTER_INDEL_PENDING = 2,     // << read index (bits 1, 2)
+       CLUSTER_ALIGN_PENDING = 8 };   // the flat alignment list was full: k_finish_candidates runs the cluster's ungapped scans itself   // << read index: the single-indel stage of this read is still to run (finishSimpleIndels)
 
 struct Counters
 {
