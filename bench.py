@@ -120,7 +120,7 @@ def main():
         elapsed = float(t.item())
 
     counters = al.counters()
-    timers = {k: al.kernel_time_ms(k) for k in ("find_matches", "order_fragments", "build_fragments", "align_candidates", "finish_candidates", "indel_fragments", "gapped_fragments", "finish_fragments", "plan_rescue", "rescue_windows", "rescue_align", "order_select",
+    timers = {k: al.kernel_time_ms(k) for k in ("find_matches", "build_fragments", "align_candidates", "finish_candidates", "indel_fragments", "gapped_fragments", "finish_fragments", "plan_rescue", "rescue_windows", "rescue_align",
                                                  "rescue_gapped_plan", "gapped_rescue", "select", "select_heavy", "select_residual", "compact_matches")}
     if rank != 0:
         if dist is not None:

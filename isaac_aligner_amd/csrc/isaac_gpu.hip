@@ -64,6 +64,9 @@ struct isaac_gpu_ctx
     DevBuf<u64> kmers, positions; u64 nKmers = 0; DevBuf<u32> karyotype; bool hasKaryotype = false;
     DevBuf<u32> prefixTable; u32 prefixBits = 0;
     DevBuf<u64> matchBase;
+    // run constants of the template kernels in device memory: passed by value they end up as private copies (dynamic indexing)
+    struct TemplateConstants { DevParams P; DevTls tls; RogCorrection rog; };
+    DevBuf<TemplateConstants> templateConstants;
     // isaac_gpu_fastq_to_bcl scratch, kept between calls (hipMalloc costs more than the conversion)
     DevBuf<u8> fqIsStart; DevBuf<u64> fqLineStart, fqLineEnd; DevBuf<int> fqSelected; DevBuf<u32> fqLineMap, fqMapBefore, fqIsHeader, fqRecordIndex, fqFirstBad; DevBuf<FqRecord> fqRecords;
     DevBuf<double> logTables;
@@ -81,8 +84,7 @@ struct isaac_gpu_ctx
     std::vector<PendingTimer> pendingTimers; std::vector<hipEvent_t> eventPool;
     hipStream_t heavyStream = nullptr; hipEvent_t evPredicted = nullptr, evHeavyDone = nullptr;
     DevBuf<u32> heavyList, heavyCount, indelList, alignList; DevBuf<u8> heavyFlag;
-    DevBuf<u32> classKeys, classKeysSorted, classIdx, fragmentOrder, selectOrder;   // clusters ordered by work class (see k_match_class)
-    u32 chunkClusters = 524288; bool workClasses = false;   // lane order by work class: measured slower (locality of neighbouring clusters matters more), kept as ISAAC_GPU_WORK_CLASSES=1
+    u32 chunkClusters = 524288;
 
     DevReference ref() const
     {
@@ -325,17 +327,6 @@ __global__ void k_compact_matches(const Match *staging, const u32 *counts, const
     __syncthreads();                                                                                                         \
     DevReference R_OUT = (R_IN); R_OUT.logMatch = qualityTables; R_OUT.logMismatch = qualityTables + 64;
 
-// Work classes.  The per-cluster kernels run one cluster per lane, and a wave takes as long as the union of its lanes' paths:
-// clusters are therefore handed to the lanes in the order of a cheap work estimate (stable radix sort of small keys), so
-// that a wave holds clusters of similar cost.  The results stay indexed by cluster.
-__global__ void k_match_class(const u64 *offsets, u32 clusterBase, u32 n, u32 *keys, u32 *idx)
-{
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const u64 m = offsets[clusterBase + t + 1] - offsets[clusterBase + t];
-    keys[t] = m < 63 ? u32(m) : 63u; idx[t] = t;
-}
-
 // the chunk's gapped (banded Smith-Waterman) problems: written by the per-cluster threads, run by k_gapped_jobs
 struct GappedBuffers { GappedJob *jobs; GappedResult *results; u32 cap; u32 *counter; u32 *base; };
 
@@ -358,13 +349,13 @@ struct AlignList { u32 *entries; u32 cap; u32 *counter; };
 // Fragment stage, step 1: matches -> candidate positions (buildCandidates), and one entry per candidate in the flat list
 // k_align_candidates works through.  The list space of a wave is taken with one atomic.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_build_fragments(DevParams P, const u8 *bcl, u32 clusterBase, u32 nChunk, const Match *matches, const u64 *offsets,
-                                                        int trim, const u32 *order, FragmentWork *work, ClusterFragments *frags, AlignList al)
+                                                        int trim, FragmentWork *work, ClusterFragments *frags, AlignList al)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     u32 cl = 0, n = 0;
     if (t < nChunk)
     {
-        cl = order ? order[t] : t;     // neighbouring lanes take clusters of the same work class
+        cl = t;
         const u64 begin = offsets[clusterBase + cl], end = offsets[clusterBase + cl + 1];
         buildCandidates(P, bcl + u64(clusterBase + cl) * P.clusterLength, matches + begin, u32(end - begin), trim != 0, work[t], frags[cl]);
         n = frags[cl].nCands[0] + frags[cl].nCands[1];
@@ -407,14 +398,14 @@ __global__ __launch_bounds__(256) void k_align_candidates(DevParams P, DevRefere
 // 3-4 % of clusters with a candidate pair for the single-indel detector, an entry for k_indel_fragments: inside this kernel
 // nearly every wave would hold one such lane and wait for it
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_finish_candidates(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, u32 nChunk,
-                                                        int withGaps, const u32 *order, u32 *indelList, u32 *indelCount, FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters)
+                                                        int withGaps, u32 *indelList, u32 *indelCount, FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters)
 {
     ISAAC_STAGE_QUALITY_TABLES(Rg, R)
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     Counters local; memset(&local, 0, sizeof(local));
     if (t < nChunk)
     {
-        const u32 cl = order ? order[t] : t;
+        const u32 cl = t;
         ClusterFragments &f = frags[cl];
         const u8 *clusterBcl = bcl + u64(clusterBase + cl) * P.clusterLength;
         if (f.flags & CLUSTER_ALIGN_PENDING)
@@ -452,14 +443,14 @@ __global__ __launch_bounds__(64) void k_indel_fragments(DevParams P, DevReferenc
     flushCounters(local, counters);
 }
 
-__global__ __launch_bounds__(64) void k_finish_fragments(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, u32 nChunk, int withGaps, const u32 *order,
+__global__ __launch_bounds__(64) void k_finish_fragments(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, u32 nChunk, int withGaps,
                                                          FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     Counters local; memset(&local, 0, sizeof(local));
     if (t < nChunk)
     {
-        const u32 cl = order ? order[t] : t;
+        const u32 cl = t;
         const GappedResult *res = (withGaps && gb.base[cl] != 0xffffffffu) ? gb.results + gb.base[cl] : nullptr;
         clusterFinishFragments(P, R, bcl, clusterBase + cl, withGaps != 0, res, work[t], frags[cl], local);
     }
@@ -831,11 +822,11 @@ __global__ __launch_bounds__(256) void k_rescue_gapped_plan(const ClusterFragmen
 // Which clusters cannot fit the light work lists of k_select: known from the rescue summaries before k_select runs, so the
 // wave-per-cluster pass can start at the same time on its own stream.  The test is a superset of the real overflow
 // conditions (a cluster sent here needlessly is still processed exactly); what it misses, k_select reports afterwards.
-__global__ __launch_bounds__(256) void k_predict_heavy(const ClusterFragments *frags, u32 nChunk, RescueBuffers rb, TemplateCaps light, u8 *heavyFlag, u32 *heavyList, u32 *heavyCount, u32 *classKeys, u32 *classIdx)
+__global__ __launch_bounds__(256) void k_predict_heavy(const ClusterFragments *frags, u32 nChunk, RescueBuffers rb, TemplateCaps light, u8 *heavyFlag, u32 *heavyList, u32 *heavyCount)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nChunk) return;
-    bool heavy = false; u32 work = 4 * (frags[t].nCands[0] + frags[t].nCands[1]);
+    bool heavy = false;
     if (rb.jobBase[t] != 0xffffffffu)
     {
         const RescueJob *jobs = rb.jobs + rb.jobBase[t];
@@ -847,24 +838,23 @@ __global__ __launch_bounds__(256) void k_predict_heavy(const ClusterFragments *f
             if (jobs[j].fallback || jobs[j].nAligned >= light.shadow) heavy = true;
             total += jobs[j].nAligned;
         }
-        work += total + 8 * n;
         const u32 seeded = frags[t].nCands[0] + frags[t].nCands[1];
         if (total + seeded > light.prob || total > light.pair) heavy = true;
     }
     heavyFlag[t] = heavy ? 1 : 0;
-    if (classKeys) { classKeys[t] = heavy ? 255u : (work < 254 ? work : 254u); classIdx[t] = t; }   // work class for k_select's lane order
     if (heavy) heavyList[atomicAdd(heavyCount, 1u)] = t;
 }
 
 // k_select: clusters [clusterBase, clusterBase + nChunk) with per-thread arenas of `arenaBytes`; clusters whose light work
 // lists overflow are appended to overflowList.  With `list` given, thread t redoes cluster list[t] (heavy capacities).
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_SELECT_WAVES))) void k_select(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk, u32 tile,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_SELECT_WAVES))) void k_select(const isaac_gpu_ctx::TemplateConstants *constants, DevReference R, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk, u32 tile,
                                                const ClusterFragments *frags, u8 *arena, u64 arenaBytes, TemplateCaps caps, const u32 *list, RescueBuffers rb, const GappedResult *gappedResults, const GappedJob *gappedJobs,
-                                               FragmentRecord *records, u32 *cigars, u32 *overflowList, u32 *overflowCount, u32 overflowCapacity, const u8 *skip, const u32 *order, Counters *counters)
+                                               FragmentRecord *records, u32 *cigars, u32 *overflowList, u32 *overflowCount, u32 overflowCapacity, const u8 *skip, Counters *counters)
 {
+    const DevParams &P = constants->P; const DevTls &tls = constants->tls; const RogCorrection &rog = constants->rog;
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     Counters local; memset(&local, 0, sizeof(local));
-    const u32 inChunk = t < nChunk ? (list ? list[t] : (order ? order[t] : t)) : 0;
+    const u32 inChunk = t < nChunk ? (list ? list[t] : t) : 0;
     if (t < nChunk && !(skip && skip[inChunk]))
     {
         TemplateWork work;
@@ -1109,7 +1099,6 @@ int isaac_gpu_create(int device, const isaac_params *params, void *stream, isaac
     HIP_CHECK(hipEventCreateWithFlags(&c->evPredicted, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&c->evHeavyDone, hipEventDisableTiming));
     if (const char *e = getenv("ISAAC_GPU_CHUNK_CLUSTERS")) c->chunkClusters = u32(std::max(1024, atoi(e)));
     if (const char *e = getenv("ISAAC_GPU_FLAT_RESCUE")) c->flatRescue = atoi(e) != 0;
-    if (const char *e = getenv("ISAAC_GPU_WORK_CLASSES")) c->workClasses = atoi(e) != 0;
     *out = c.release();
     return ISAAC_GPU_OK;
     ISAAC_CATCH
@@ -1369,19 +1358,10 @@ static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clust
     if (!c->fragsCur) c->fragsCur = c->frags.p;
     const GappedBuffers gb = gappedBuffers(c, 0);
     HIP_CHECK(hipMemsetAsync(c->gappedCounters.p, 0, 16, c->stream));
-    const u32 *order = nullptr;
-    if (c->workClasses)
-    {
-        ScopedTimer t(c, "order_fragments");
-        c->classKeys.reserve(c->chunkClusters); c->classKeysSorted.reserve(c->chunkClusters); c->classIdx.reserve(c->chunkClusters); c->fragmentOrder.reserve(c->chunkClusters);
-        k_match_class<<<gridFor(n, 256), 256, 0, c->stream>>>(offsets, clusterBase, n, c->classKeys.p, c->classIdx.p);
-        sortPairs(c, c->classKeys.p, c->classKeysSorted.p, c->classIdx.p, c->fragmentOrder.p, n, 6);
-        order = c->fragmentOrder.p;
-    }
     AlignList al; al.cap = 8 * c->chunkClusters; c->alignList.reserve(al.cap); al.entries = c->alignList.p; al.counter = c->gappedCounters.p + 3;
     {
         ScopedTimer t(c, "build_fragments");
-        k_build_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, bcl, clusterBase, n, reinterpret_cast<const Match *>(matches), offsets, trim, order, c->fragWork.p, c->fragsCur, al);
+        k_build_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, bcl, clusterBase, n, reinterpret_cast<const Match *>(matches), offsets, trim, c->fragWork.p, c->fragsCur, al);
         HIP_CHECK(hipGetLastError());
     }
     {
@@ -1391,7 +1371,7 @@ static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clust
     }
     {
         ScopedTimer t(c, "finish_candidates");
-        k_finish_candidates<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, withGaps, order, c->indelList.p, c->gappedCounters.p + 2, c->fragWork.p, c->fragsCur, gb, c->counters.p);
+        k_finish_candidates<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, withGaps, c->indelList.p, c->gappedCounters.p + 2, c->fragWork.p, c->fragsCur, gb, c->counters.p);
         HIP_CHECK(hipGetLastError());
     }
     {
@@ -1402,7 +1382,7 @@ static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clust
     if (withGaps) launchGappedJobs(c, bcl, clusterBase, gb, "gapped_fragments");
     {
         ScopedTimer t(c, "finish_fragments");
-        k_finish_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, withGaps, order, c->fragWork.p, c->fragsCur, gb, c->counters.p);
+        k_finish_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, withGaps, c->fragWork.p, c->fragsCur, gb, c->counters.p);
         HIP_CHECK(hipGetLastError());
     }
 }
@@ -1501,6 +1481,12 @@ int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, u
         rb.jobCounter = c->rescueCounters.p; rb.bitmapCounter = c->rescueCounters.p + 1; rb.candCounter = c->rescueCounters.p + 4;
     }
     const DevReference R = c->ref();
+    {
+        isaac_gpu_ctx::TemplateConstants k; k.P = c->P; k.tls = t; k.rog = rog;
+        c->templateConstants.reserve(1);
+        HIP_CHECK(hipMemcpyAsync(c->templateConstants.p, &k, sizeof(k), hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipStreamSynchronize(st));       // k is on the stack
+    }
     const GappedBuffers gbRescue = gappedBuffers(c, 1);
     c->frags.reserve(chunk); c->fragsAlt.reserve(chunk);
     bool heavyPending = false; u32 chunkIndex = 0;
@@ -1544,10 +1530,8 @@ int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, u
         if (predicted)
         {   // clusters that cannot fit the light lists start on their own stream now, next to k_select
             c->heavyList.reserve(chunk); c->heavyCount.reserve(1); c->heavyFlag.reserve(chunk);
-            c->classKeys.reserve(chunk); c->classKeysSorted.reserve(chunk); c->classIdx.reserve(chunk); c->selectOrder.reserve(chunk);
             HIP_CHECK(hipMemsetAsync(c->heavyCount.p, 0, 4, st));
-            k_predict_heavy<<<gridFor(n, 256), 256, 0, st>>>(c->fragsCur, n, rb, light, c->heavyFlag.p, c->heavyList.p, c->heavyCount.p,
-                                                             c->workClasses ? c->classKeys.p : nullptr, c->classIdx.p);
+            k_predict_heavy<<<gridFor(n, 256), 256, 0, st>>>(c->fragsCur, n, rb, light, c->heavyFlag.p, c->heavyList.p, c->heavyCount.p);
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipEventRecord(c->evPredicted, st));
             HIP_CHECK(hipStreamWaitEvent(c->heavyStream, c->evPredicted, 0));
@@ -1559,17 +1543,10 @@ int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, u
             }
             HIP_CHECK(hipEventRecord(c->evHeavyDone, c->heavyStream)); heavyPending = true;
         }
-        const u32 *selectOrder = nullptr;
-        if (predicted && c->workClasses)
-        {
-            ScopedTimer tm(c, "order_select");
-            sortPairs(c, c->classKeys.p, c->classKeysSorted.p, c->classIdx.p, c->selectOrder.p, n, 8);
-            selectOrder = c->selectOrder.p;
-        }
         {
             ScopedTimer tm(c, "select");
-            k_select<<<gridFor(n, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, n, tile, c->fragsCur, c->lightArena.p, lightBytes, light, nullptr, rb, c->flatRescue ? gbRescue.results : nullptr, c->flatRescue ? gbRescue.jobs : nullptr,
-                                                     reinterpret_cast<FragmentRecord *>(fragments), cigar, c->overflowList.p, c->overflowCount.p, chunk, predicted ? c->heavyFlag.p : nullptr, selectOrder, c->counters.p);
+            k_select<<<gridFor(n, 64), 64, 0, st>>>(c->templateConstants.p, R, lmq40, bcl, done, n, tile, c->fragsCur, c->lightArena.p, lightBytes, light, nullptr, rb, c->flatRescue ? gbRescue.results : nullptr, c->flatRescue ? gbRescue.jobs : nullptr,
+                                                     reinterpret_cast<FragmentRecord *>(fragments), cigar, c->overflowList.p, c->overflowCount.p, chunk, predicted ? c->heavyFlag.p : nullptr, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }
         {   // what the prediction missed (normally nothing): again, with the reference's own capacities; the count stays on the device
