@@ -72,9 +72,20 @@ ISAAC_HD void clusterTlsSample(const ClusterFragments &f, u32 nMatches, TlsSampl
     }
 }
 
+// privateCands: room for 2 * PRIVATE_CANDS candidates in the caller's private memory.  Short candidate lists (the usual case) are
+// copied there once, 16 bytes at a time; the template logic reads their fields many times over, and private memory is
+// interleaved by lane, so a wave's reads of "field f of candidate i" share cache lines instead of touching one line per lane.
+static const u32 PRIVATE_CANDS = 6;
 ISAAC_HD void templateCtxInit(TemplateCtx &x, const DevParams &P, const DevReference &R, const DevTls &tls, const RogCorrection &rog, const u8 *bcl, u32 cluster,
-                               const ClusterFragments &frags, TemplateWork &work, Counters &cnt)
+                               const ClusterFragments &frags, TemplateWork &work, Counters &cnt, Cand *privateCands = 0)
 {
+    for (u32 r = 0; r < 2; ++r) { x.cands[r] = frags.cands[r]; x.nCands[r] = frags.nCands[r]; }
+    if (privateCands && x.nCands[0] <= PRIVATE_CANDS && x.nCands[1] <= PRIVATE_CANDS)
+        for (u32 r = 0; r < 2; ++r)
+        {
+            for (u32 i = 0; i < x.nCands[r]; ++i) privateCands[r * PRIVATE_CANDS + i] = frags.cands[r][i];
+            x.cands[r] = privateCands + r * PRIVATE_CANDS;
+        }
     x.P = &P; x.R = &R; x.tls = &tls; x.frags = &frags; x.w = &work; x.cnt = &cnt; x.clusterId = cluster;
     x.rogRead[0] = rog.read[0]; x.rogRead[1] = rog.read[1]; x.rog = rog.pair;
     x.rescueMode = RESCUE_SERIAL; x.jobNext = 0; x.jobCount = 0; x.jobs = 0; x.planWrite = false; x.serialFallbackAllowed = true;
@@ -93,12 +104,12 @@ ISAAC_HD void templateCtxInit(TemplateCtx &x, const DevParams &P, const DevRefer
 // and the windows depend only on the seeded candidates, never on rescue results, so the template logic is simply run with a
 // stub rescue.  jobs == NULL: count only.  `cluster` is the index in the tile, `chunkCluster` the index inside the chunk.
 ISAAC_HD u32 clusterPlanRescue(const DevParams &P, const DevReference &R, const DevTls &tls, const RogCorrection &rog, double logMismatchQ40,
-                               const u8 *bcl, u32 cluster, u32 chunkCluster, const ClusterFragments &frags, TemplateWork &work, RescueJob *jobs)
+                               const u8 *bcl, u32 cluster, u32 chunkCluster, const ClusterFragments &frags, TemplateWork &work, RescueJob *jobs, Cand *privateCands = 0)
 {
     if (!frags.built) return 0;
     Counters scratch;
     TemplateCtx x;
-    templateCtxInit(x, P, R, tls, rog, bcl, cluster, frags, work, scratch);
+    templateCtxInit(x, P, R, tls, rog, bcl, cluster, frags, work, scratch, privateCands);
     x.rescueMode = RESCUE_PLAN; x.jobs = jobs; x.planWrite = jobs != 0;
     BamTemplate t;
     work.overflow = 0;
@@ -130,11 +141,11 @@ struct CoopInputs { u32 lanes, lane; bool fastSort; u16 *ldsSort; u32 ldsSortCap
 // records: P.nReads per cluster; cigars: P.nReads * OUT_CIGAR_CAP words per cluster
 ISAAC_HD void clusterSelect(const DevParams &P, const DevReference &R, const DevTls &tls, const RogCorrection &rog, double logMismatchQ40,
                             const u8 *bcl, u32 cluster, u32 tile, const ClusterFragments &frags, TemplateWork &work,
-                            FragmentRecord *records, u32 *cigars, Counters &cnt, const RescueInputs *rescue = 0, const CoopInputs *coop = 0)
+                            FragmentRecord *records, u32 *cigars, Counters &cnt, const RescueInputs *rescue = 0, const CoopInputs *coop = 0, Cand *privateCands = 0)
 {
     STAMP_BEGIN();
     TemplateCtx x;
-    templateCtxInit(x, P, R, tls, rog, bcl, cluster, frags, work, cnt);
+    templateCtxInit(x, P, R, tls, rog, bcl, cluster, frags, work, cnt, privateCands);
     if (coop) { x.lanes = coop->lanes; x.lane = coop->lane; x.fastSort = coop->fastSort; x.ldsSort = coop->ldsSort; x.ldsSortCap = coop->ldsSortCap; }
     if (rescue)
     {

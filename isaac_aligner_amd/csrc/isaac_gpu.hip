@@ -534,7 +534,8 @@ __global__ __launch_bounds__(64) void k_plan_rescue(DevParams P, DevReference R,
     if (t >= nChunk) return;
     TemplateWork work;
     templateWorkBind(work, arena + u64(t) * arenaBytes, caps);
-    const u32 n = clusterPlanRescue(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + t, t, frags[t], work, nullptr);
+    Cand privateCands[2 * PRIVATE_CANDS];
+    const u32 n = clusterPlanRescue(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + t, t, frags[t], work, nullptr, privateCands);
     u32 base = 0;
     if (n)
     {
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(64) void k_plan_rescue(DevParams P, DevReference R,
         else
         {
             RescueJob *jobs = rb.jobs + base;
-            clusterPlanRescue(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + t, t, frags[t], work, jobs);
+            clusterPlanRescue(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + t, t, frags[t], work, jobs, privateCands);
             for (u32 i = 0; i < n; ++i)
             {
                 if (!jobs[i].valid) continue;
@@ -866,7 +867,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_SELECT
             in.gappedResults = gappedResults; in.gappedJobs = gappedJobs; in.serialFallbackAllowed = list != nullptr;
             pin = &in;
         }
-        clusterSelect(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + inChunk, tile, frags[inChunk], work, records, cigars, local, pin);
+        Cand privateCands[2 * PRIVATE_CANDS];
+        clusterSelect(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + inChunk, tile, frags[inChunk], work, records, cigars, local, pin, nullptr, privateCands);
         if (work.overflow)
         {
             if (!list) { const u32 at = atomicAdd(overflowCount, 1u); if (at < overflowCapacity) overflowList[at] = inChunk; }

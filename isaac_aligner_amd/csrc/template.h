@@ -240,6 +240,7 @@ struct TemplateCtx
     const u32 *candRank;                                                          // RESCUE_LOOKUP: aligned candidates before each slot (summarizeRescueJob)
     ReadView reads[2];
     const ClusterFragments *frags;
+    const Cand *cands[2]; u32 nCands[2];      // the cluster's candidate lists: frags->cands, or a private copy of short lists (templateCtxInit)
     TemplateWork *w;
     double rogRead[2], rog;
     u32 clusterId;
@@ -691,7 +692,7 @@ ISAAC_HD bool isVeryBadAlignment(const Cand &f, const u32 *pool, double logMisma
 // (clusterId % count)-th with --scatter-repeats
 ISAAC_HD u32 getBestFragment(const TemplateCtx &x, u32 r)
 {
-    const Cand *list = x.frags->cands[r]; const u32 n = x.frags->nCands[r];
+    const Cand *list = x.cands[r]; const u32 n = x.nCands[r];
     u32 bestScore = 0xffffffffu; double bestLp = -1.7976931348623157e308;
     u32 first = 0, count = 0;
     for (u32 i = 0; i < n; ++i)
@@ -713,7 +714,7 @@ ISAAC_HD bool updateMappingScore(TemplateCtx &x, Cand &fragment, u32 r, u32 list
 {
     if (forceWellAnchored || candWellAnchored(fragment))
     {
-        const Cand *list = x.frags->cands[r]; const u32 n = x.frags->nCands[r];
+        const Cand *list = x.cands[r]; const u32 n = x.nCands[r];
         double neighborProbability = x.rogRead[list[listIndex].readIndex];
         for (u32 i = 0; i < n; ++i) if (listIndex != i) neighborProbability += exp(list[i].logProbability);
         fragment.alignmentScore = mapqFloor(x, neighborProbability / (neighborProbability + exp(list[listIndex].logProbability)));
@@ -726,8 +727,8 @@ ISAAC_HD bool updateMappingScore(TemplateCtx &x, Cand &fragment, u32 r, u32 list
 // locateBestPair (TemplateBuilder.cpp:287-391)
 ISAAC_HD void locateBestPair(TemplateCtx &x, BestPairInfo &ret)
 {
-    const Cand *l0 = x.frags->cands[0], *l1 = x.frags->cands[1];
-    const u32 n0 = x.frags->nCands[0], n1 = x.frags->nCands[1];
+    const Cand *l0 = x.cands[0], *l1 = x.cands[1];
+    const u32 n0 = x.nCands[0], n1 = x.nCands[1];
     ret.init(0, 0);
     u32 b0 = 0, b1 = 0;
     while (b0 != n0 && b1 != n1)
@@ -761,7 +762,7 @@ ISAAC_HD void locateBestPair(TemplateCtx &x, BestPairInfo &ret)
     if (ret.resolvedTemplateCount) ret.bestPairEditDistance = u32(l0[ret.frags[0][0]].editDistance) + u32(l1[ret.frags[1][0]].editDistance);
 }
 
-ISAAC_HD void fragFromList(const TemplateCtx &x, Frag &f, u32 r, u32 idx) { f.c = x.frags->cands[r][idx]; f.pool = x.frags->cigarPool; }
+ISAAC_HD void fragFromList(const TemplateCtx &x, Frag &f, u32 r, u32 idx) { f.c = x.cands[r][idx]; f.pool = x.frags->cigarPool; }
 
 // buildPairedEndTemplate (TemplateBuilder.cpp:398-465)
 ISAAC_HD bool buildPairedEndTemplate(TemplateCtx &x, BamTemplate &t, BestPairInfo &best)
@@ -923,9 +924,9 @@ ISAAC_HD double sumUniquePairProbabilities(TemplateCtx &x)
 ISAAC_HD bool templateRescueShadow(TemplateCtx &x, BamTemplate &t, double logMismatchQ40)
 {
     TemplateWork &w = *x.w;
-    const u32 orphanIndex = x.frags->nCands[0] ? 0 : 1;
+    const u32 orphanIndex = x.nCands[0] ? 0 : 1;
     const u32 shadowIndex = (orphanIndex + 1) % 2;
-    const Cand *orphans = x.frags->cands[orphanIndex]; const u32 nOrphans = x.frags->nCands[orphanIndex];
+    const Cand *orphans = x.cands[orphanIndex]; const u32 nOrphans = x.nCands[orphanIndex];
     const u32 bestOrphanIt = getBestFragment(x, orphanIndex);
     BestPairInfo &bestPair = w.bestRescued;
     bestPair.clear();
@@ -1022,7 +1023,7 @@ ISAAC_HD bool templateRescueShadow(TemplateCtx &x, BamTemplate &t, double logMis
 ISAAC_HD i64 getBestTemplateLength(const TemplateCtx &x, const BestPairInfo &b)
 {
     if (!b.resolvedTemplateCount) return 0;
-    const Cand &a = x.frags->cands[0][b.frags[0][0]], &c = x.frags->cands[1][b.frags[1][0]];
+    const Cand &a = x.cands[0][b.frags[0][0]], &c = x.cands[1][b.frags[1][0]];
     const u64 templateStart = imin(candFStrandPos(a), candFStrandPos(c));
     const u64 templateEnd = imax(candRStrandPos(a), candRStrandPos(c));
     return i64(refposPosition(templateEnd)) - i64(refposPosition(templateStart));
@@ -1038,16 +1039,16 @@ ISAAC_HD bool scoreDisjoinedTemplate(TemplateCtx &x, BamTemplate &t, const BestP
     {
         const u32 repeatIndex = x.P->scatterRepeats ? x.clusterId % bestOrphans.n[bestOrphanIndex] : 0;
         const u32 orphanListIdx = bestOrphans.frags[bestOrphanIndex][repeatIndex];
-        const Cand &bestOrphan = x.frags->cands[bestOrphanIndex][orphanListIdx];
+        const Cand &bestOrphan = x.cands[bestOrphanIndex][orphanListIdx];
         Cand &bestShadow = w.bestOrphanShadows[bestOrphanIndex][repeatIndex];
         const u32 orphanRead = bestOrphan.readIndex, shadowRead = bestShadow.readIndex;
         const bool rediscovered = !repeatIndex && knownBestPair.resolvedTemplateCount &&
-            candEqual(x.frags->cands[orphanRead][knownBestPair.frags[orphanRead][0]], bestOrphan) &&
-            candEqual(x.frags->cands[shadowRead][knownBestPair.frags[shadowRead][0]], bestShadow);
+            candEqual(x.cands[orphanRead][knownBestPair.frags[orphanRead][0]], bestOrphan) &&
+            candEqual(x.cands[shadowRead][knownBestPair.frags[shadowRead][0]], bestShadow);
         Frag &orphanF = t.f[orphanRead];
         fragFromList(x, orphanF, bestOrphanIndex, orphanListIdx);
         Cand &orphan = orphanF.c;
-        const bool shadowWellAnchored = rediscovered && candWellAnchored(x.frags->cands[shadowRead][knownBestPair.frags[shadowRead][0]]);
+        const bool shadowWellAnchored = rediscovered && candWellAnchored(x.cands[shadowRead][knownBestPair.frags[shadowRead][0]]);
         const bool assumeWellAnchored = updateMappingScore(x, orphan, orphanRead, bestOrphans.frags[orphanRead][repeatIndex],
                                                            0 == u32(orphan.editDistance) + u32(bestShadow.editDistance) || shadowWellAnchored);
         t.properPair = TLS_NOMINAL == tlsCheckModel(*x.tls, orphan, bestShadow);
@@ -1108,7 +1109,7 @@ ISAAC_HD bool buildDisjoinedTemplate(TemplateCtx &x, BamTemplate &t, const BestP
     {
         w.nShadowProbs[orphanIndex] = 0;
         w.nBestOrphanShadows[orphanIndex] = 0;
-        const Cand *orphans = x.frags->cands[orphanIndex]; const u32 nOrphans = x.frags->nCands[orphanIndex];
+        const Cand *orphans = x.cands[orphanIndex]; const u32 nOrphans = x.nCands[orphanIndex];
         for (u32 oi = 0; oi < nOrphans; ++oi)
         {
             const Cand &orphan = orphans[oi];
@@ -1173,9 +1174,9 @@ ISAAC_HD bool buildDisjoinedTemplate(TemplateCtx &x, BamTemplate &t, const BestP
     STAMP_BEGIN();
     if (0 < bestOrphans.resolvedTemplateCount)
     {
-        for (u32 i = 0; i < x.frags->nCands[bestShadowIndex]; ++i) pushShadowProb(w, bestOrphanIndex, x.frags->cands[bestShadowIndex][i]);
+        for (u32 i = 0; i < x.nCands[bestShadowIndex]; ++i) pushShadowProb(w, bestOrphanIndex, x.cands[bestShadowIndex][i]);
         totalShadowProbability = sumUniqueShadowProbabilities(x, bestOrphanIndex);
-        for (u32 i = 0; i < x.frags->nCands[bestOrphanIndex]; ++i) pushShadowProb(w, bestShadowIndex, x.frags->cands[bestOrphanIndex][i]);
+        for (u32 i = 0; i < x.nCands[bestOrphanIndex]; ++i) pushShadowProb(w, bestShadowIndex, x.cands[bestOrphanIndex][i]);
         totalOrphanProbability = sumUniqueShadowProbabilities(x, bestShadowIndex);
         bestOrphans.totalTemplateProbability += sumUniquePairProbabilities(x);
     }
@@ -1189,7 +1190,7 @@ ISAAC_HD bool buildDisjoinedTemplate(TemplateCtx &x, BamTemplate &t, const BestP
 // pickBestFragment (TemplateBuilder.cpp:1035-1058): single-ended data
 ISAAC_HD bool pickBestFragment(TemplateCtx &x, BamTemplate &t)
 {
-    if (!x.frags->nCands[0]) return false;
+    if (!x.nCands[0]) return false;
     const u32 best = getBestFragment(x, 0);
     fragFromList(x, t.f[0], 0, best);
     if (!updateMappingScore(x, t.f[0].c, 0, best, false))
@@ -1233,7 +1234,7 @@ ISAAC_HD bool buildTemplate(TemplateCtx &x, BamTemplate &t, double logMismatchQ4
     w.templateCigarUsed = 0;
     bamTemplateInitialize(x, t);
     bool ret;
-    const u32 n0 = x.frags->nCands[0], n1 = x.frags->nCands[1];
+    const u32 n0 = x.nCands[0], n1 = x.nCands[1];
     if (2 == x.P->nReads)
     {
         if (n0 && n1)
