@@ -489,4 +489,135 @@ int oracle_fragment_builder2_literal(const char *read, const char *reference, in
     catch (const std::exception &e) { g_error = e.what(); return 1; }
 }
 
+// ---- literal entry points for lib/alignment/cppunit/testSemialignedClipper.cpp and testOverlappingEndsClipper.cpp
+static void literalRead(Read &rd, const std::string &sequence, const std::string &quality)
+{
+    rd.forwardSequence.assign(sequence.begin(), sequence.end());
+    rd.forwardQuality.assign(quality.begin(), quality.end());
+    if (rd.forwardQuality.size() != rd.forwardSequence.size()) throw std::runtime_error("sequence and quality must be of equal lengths");
+    for (size_t i = 0; i < rd.forwardQuality.size(); ++i) rd.forwardQuality[i] -= 33;
+    rd.reverseSequence = rd.forwardSequence; rd.reverseQuality = rd.forwardQuality;
+    std::reverse(rd.reverseSequence.begin(), rd.reverseSequence.end()); std::reverse(rd.reverseQuality.begin(), rd.reverseQuality.end());
+}
+static Contig literalContig(const std::string &forward, long &firstPosOffset)   // makeContig of the tests: leading spaces shift the start
+{
+    const size_t begin = std::min(forward.find_first_not_of(' '), forward.size());
+    Contig c; c.index = 0; c.name = "vasja"; c.forward.assign(forward.begin() + begin, forward.end());
+    firstPosOffset = -long(begin);
+    return c;
+}
+// TestSemialignedClipper::align (testSemialignedClipper.cpp:163-187): ungapped alignment at the position the reference string implies,
+// then SemialignedEndsClipper::clip.  out: CIGAR words and the strand position
+int oracle_semialigned_clip_literal(const char *read, const char *reference, int reverse, uint32_t *cigar_out, uint64_t cigar_capacity, uint64_t *n_cigar, int64_t *position_out)
+{
+    try
+    {
+        static const std::string irrelevantQualities("CFCEEBFHEHDGBDBEDDEGEHHFHEGBHHDDDB<F>FGGBFGGFGCGGGDGGDDFHHHFEGGBGDGGBGGBEGEGGBGEHDHHHGGGGGDGGGG?GGGG");
+        std::string r(read); if (reverse) std::reverse(r.begin(), r.end());
+        Cluster cluster; cluster.nReads = 1;
+        literalRead(cluster[0], r, irrelevantQualities);
+        std::vector<ReadMetadata> reads; { ReadMetadata a = { 100, 0, 0, 1 }, b = { 100, 1, 100, 101 }; reads.push_back(a); reads.push_back(b); }
+        FragmentMetadata f; f.reverse = reverse != 0;
+        if (f.isNoMatch()) { f.contigId = 0; f.position = 0; }
+        Cigar cigarBuffer; cigarBuffer.reserve(1024);
+        f.cluster = &cluster; f.cigarBuffer = &cigarBuffer;
+        ContigList contigs; long offset = 0;
+        contigs.push_back(literalContig(reference, offset));
+        f.position = offset;
+        const UngappedAligner ungapped(2, -1, -15, -3, 25);
+        ungapped.alignUngapped(f, cigarBuffer, reads, contigs[0]);
+        SemialignedEndsClipper clipper; clipper.cigarBuffer.reserve(1024);
+        clipper.clip(contigs, f);
+        if (f.cigarLength > cigar_capacity) throw std::runtime_error("cigar capacity");
+        if (f.cigarLength) memcpy(cigar_out, f.cigarBuffer->data() + f.cigarOffset, f.cigarLength * 4);
+        *n_cigar = f.cigarLength; *position_out = f.position;
+        return 0;
+    }
+    catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+// TestOverlappingEndsClipper::init + clip (testOverlappingEndsClipper.cpp:109-222): both reads placed as "xM" at the columns the
+// strings imply, then OverlappingEndsClipper::clip.  out per read: CIGAR words (capacity 8), count, position
+int oracle_overlapping_clip_literal(const char *read1, const char *quality1, int reverse1, const char *read2, const char *quality2, int reverse2, const char *reference,
+                                    uint32_t *cigar_out /* 2 x 8 */, uint32_t *n_cigar /* 2 */, int64_t *position_out /* 2 */)
+{
+    try
+    {
+        const std::string r[2] = { read1, read2 }, q[2] = { quality1, quality2 };
+        const bool rev[2] = { reverse1 != 0, reverse2 != 0 };
+        ContigList contigs; long offset = 0;
+        contigs.push_back(literalContig(reference, offset));
+        Cluster cluster; cluster.nReads = 2;
+        size_t start[2]; std::vector<ReadMetadata> reads;
+        for (unsigned i = 0; i < 2; ++i)
+        {
+            start[i] = r[i].find_first_not_of(' ');
+            std::string s = r[i].substr(start[i]); if (rev[i]) std::reverse(s.begin(), s.end());     // ReadInit reverses the string of a reverse read
+            std::string ql = q[i]; if (!rev[i]) std::reverse(ql.begin(), ql.end());                  // ... and, as written there, the qualities of a forward one
+            literalRead(cluster[i], s, ql);
+            ReadMetadata m = { unsigned(s.size()), i, i ? reads[0].length : 0u, i ? reads[0].length + 1 : 1u }; reads.push_back(m);
+        }
+        Cigar cigarBuffer; cigarBuffer.reserve(1024);
+        BamTemplate templ(cigarBuffer);
+        templ.initialize(reads, cluster);
+        for (unsigned i = 0; i < 2; ++i)
+        {
+            FragmentMetadata &f = templ.getFragmentMetadata(i);
+            f.reverse = rev[i]; f.cigarBuffer = &cigarBuffer; f.cigarOffset = unsigned(cigarBuffer.size());
+            cigarBuffer.push_back(cigarEncode(reads[i].length, ALIGN));
+            f.cigarLength = unsigned(cigarBuffer.size()) - f.cigarOffset;
+            f.contigId = 0; f.position = long(start[i]); f.observedLength = reads[i].length;
+        }
+        OverlappingEndsClipper clipper; clipper.cigarBuffer.reserve(1024);
+        clipper.clip(contigs, templ);
+        for (unsigned i = 0; i < 2; ++i)
+        {
+            const FragmentMetadata &f = templ.getFragmentMetadata(i);
+            if (f.cigarLength > 8) throw std::runtime_error("cigar capacity");
+            memcpy(cigar_out + 8 * i, f.cigarBuffer->data() + f.cigarOffset, f.cigarLength * 4);
+            n_cigar[i] = f.cigarLength; position_out[i] = f.position;
+        }
+        return 0;
+    }
+    catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+
+// ---- literal entry points for the known-answer vectors of lib/alignment/cppunit/testTemplateLengthStatistics.cpp
+int oracle_tls_alignment_model(int64_t pos1, int reverse1, int64_t pos2, int reverse2)
+{
+    FragmentMetadata f1, f2; f1.position = pos1; f1.reverse = reverse1 != 0; f2.position = pos2; f2.reverse = reverse2 != 0;
+    return int(TemplateLengthStatistics::alignmentModel(f1, f2));
+}
+int oracle_tls_alignment_class(int model) { return int(TemplateLengthStatistics::alignmentClass(TemplateLengthStatistics::AlignmentModel(model))); }
+// out: { mateOrientation, mateMinPosition, mateMaxPosition }
+void oracle_tls_mate(uint32_t mn, uint32_t mx, uint32_t median, uint32_t low, uint32_t high, int model0, int model1, int drift,
+                     uint32_t read_index, int reverse, int64_t position, uint32_t len0, uint32_t len1, int64_t *out)
+{
+    const TemplateLengthStatistics tls(mn, mx, median, low, high, TemplateLengthStatistics::AlignmentModel(model0), TemplateLengthStatistics::AlignmentModel(model1), drift);
+    const unsigned readLengths[2] = { len0, len1 };
+    out[0] = tls.mateOrientation(read_index, reverse != 0);
+    out[1] = tls.mateMinPosition(read_index, reverse != 0, position, readLengths);
+    out[2] = tls.mateMaxPosition(read_index, reverse != 0, position, readLengths);
+}
+// TestTemplateLengthStatistics::addTemplates (:98-128): the literal sequence of templates.  out: after the first 10000 templates
+// { min, median, max, lowStdDev, highStdDev, mateMin, mateMax }, then { value returned by the last addTemplate, stable }
+void oracle_tls_add_templates_sequence(int drift, uint32_t *out)
+{
+    TemplateLengthDistribution tls(drift);
+    const std::vector<uint32_t> cigarBuffer(1, 16);
+    std::vector<FragmentMetadataList> f(2, FragmentMetadataList(1));
+    f[0][0].contigId = 0; f[0][0].position = 0; f[0][0].observedLength = 1; f[0][0].reverse = false;
+    f[0][0].cigarBuffer = &cigarBuffer; f[0][0].cigarOffset = 0; f[0][0].cigarLength = 1;
+    f[1][0] = f[0][0]; f[1][0].reverse = true;
+    bool any = false;
+    for (unsigned i = 1; i < 10000; ++i) { any |= tls.addTemplate(f); ++f[1][0].position; }
+    std::swap(f[0], f[1]);
+    any |= tls.addTemplate(f);
+    out[0] = tls.stats.min; out[1] = tls.stats.median; out[2] = tls.stats.max; out[3] = tls.stats.lowStdDev; out[4] = tls.stats.highStdDev;
+    out[5] = tls.stats.mateMin; out[6] = tls.stats.mateMax; out[7] = any;
+    std::swap(f[0], f[1]);
+    f[1][0].position = f[0][0].position;
+    for (unsigned i = 1; i < 10000; ++i) { any |= tls.addTemplate(f); ++f[1][0].position; }
+    out[8] = tls.addTemplate(f); out[9] = tls.isStable();
+}
+
 } // extern "C"

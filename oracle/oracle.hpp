@@ -7,10 +7,10 @@
 // directory.  The product path (isaac_aligner_amd/) never includes it.
 //
 // Pinning status: see oracle/README.md.  BandedSmithWaterman, SimpleIndelAligner,
-// FragmentBuilder (gapped/ungapped decision), SeedId, ReferencePosition and the
-// clippers are pinned by the reference's own cppunit known-answer vectors
-// (tests/golden/).  Seed lookup (MatchFinder/ExactMaskMatcher) and the MAPQ
-// numerics have no reference vectors: "parity unpinned" for those rows.
+// FragmentBuilder (gapped/ungapped decision), SeedId, TemplateLengthStatistics and the
+// two end clippers are pinned by the reference's own cppunit known-answer vectors
+// (tests/golden/).  Seed lookup (MatchFinder/ExactMaskMatcher), the MAPQ numerics and
+// the FASTQ reader have no reference vectors: "parity unpinned" for those rows.
 #pragma once
 #include <stdint.h>
 #include <string>

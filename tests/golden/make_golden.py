@@ -11,6 +11,8 @@ What is extracted is DATA: the literal inputs and the asserted outputs of
   * lib/alignment/cppunit/testBandedSmithWaterman.cpp:79-225   -> bsw.json (the construction recipe of the test is re-run here
     on genomes drawn with glibc rand() exactly like getGenome() at :33-43; the asserted CIGARs are the test's literals)
   * lib/alignment/cppunit/testSeedId.cpp                        -> seed_id.json
+  * lib/alignment/cppunit/testTemplateLengthStatistics.cpp:42-367 -> template_length_statistics.json (asserted literals only)
+  * lib/alignment/cppunit/testSemialignedClipper.cpp:189-251, testOverlappingEndsClipper.cpp:109-157 -> clippers.json
 No reference source text is stored.
 """
 import ctypes
@@ -264,7 +266,79 @@ def make_seed_id():
     return len(valid), len(throws)
 
 
+def make_template_length_statistics():
+    """every CPPUNIT_ASSERT_EQUAL of testTemplateLengthStatistics.cpp as data: alignment models / classes by name, mate orientation and
+    mate position windows for the eight model pairs, and the statistics the literal addTemplates() sequence must produce"""
+    text = strip_comments(open(os.path.join(REF, "testTemplateLengthStatistics.cpp")).read())
+    models = {"FFp": 0, "FRp": 1, "RFp": 2, "RRp": 3, "FFm": 4, "FRm": 5, "RFm": 6, "RRm": 7}
+    out = {"source": "lib/alignment/cppunit/testTemplateLengthStatistics.cpp:42-367", "models": models}
+    # testAlignmentModels: the eight (position, reverse) settings in source order, each followed by the asserted name
+    names = re.findall(r'std::string\("([FR]{2}[+-])"\), alignmentModelName\(alignmentModel\(f1, f2\)\)', text)
+    assert names == ["FF+", "FR+", "RR+", "RF+", "FF-", "FR-", "RR-", "RF-"], names
+    settings = [(0, 0, 1, 0), (0, 0, 1, 1), (0, 1, 1, 1), (0, 1, 1, 0), (2, 0, 1, 0), (2, 0, 1, 1), (2, 1, 1, 1), (2, 1, 1, 0)]   # f1.position, f1.reverse, f2.position, f2.reverse as the test sets them
+    out["alignment_models"] = [{"f1": [a, b], "f2": [c, d], "name": n} for (a, b, c, d), n in zip(settings, names)]
+    out["alignment_classes"] = [{"model": m, "name": n} for n, m in re.findall(r'std::string\("([FR][+-])"\), alignmentClassName\(alignmentClass\(TemplateLengthStatistics::(\w+)\)\)', text)]
+    assert len(out["alignment_classes"]) == 8
+    # mateOrientation / mateMinPosition / mateMaxPosition: blocks "TemplateLengthStatistics tls(100, 200, 170, 160, 175, M0, M1, -1);" + asserts
+    mates = []
+    for fn, key in (("mateOrientation", "orientation"), ("mateMinPosition", "min_position"), ("mateMaxPosition", "max_position")):
+        body = text[text.index("::test" + fn[0].upper() + fn[1:] + "()"):]
+        body = body[:body.index("\nvoid ", 10)] if "\nvoid " in body[10:] else body
+        blocks = re.split(r'TemplateLengthStatistics tls\(', body)[1:]
+        assert len(blocks) == 8, (fn, len(blocks))
+        for blk in blocks:
+            args = [a.strip() for a in blk[:blk.index(")")].split(",")]
+            stats = [int(a) for a in args[:5]]
+            m0, m1 = args[5].split("::")[1], args[6].split("::")[1]
+            drift = int(args[7])
+            lens = re.search(r'readLengths\[\] = \{(\d+), (\d+)\}', blk)
+            for exp, ri, rev, rest in re.findall(r'CPPUNIT_ASSERT_EQUAL\((\w+), tls\.' + fn + r'\((\d), (true|false)([^)]*)\)\)', blk):
+                e = {"stats": stats, "models": [m0, m1], "drift": drift, "what": key, "read_index": int(ri), "reverse": rev == "true",
+                     "expected": {"true": 1, "false": 0}.get(exp, None) if exp in ("true", "false") else int(exp.rstrip("L"))}
+                if lens:
+                    e["read_lengths"] = [int(lens.group(1)), int(lens.group(2))]
+                    e["position"] = int(rest.split(",")[1])
+                mates.append(e)
+    assert len(mates) == 3 * 8 * 4, len(mates)
+    out["mates"] = mates
+    # addTemplates(): the asserted statistics after the first 10000 templates, and the drift variants
+    seq = {k: int(v) for k, v in re.findall(r'CPPUNIT_ASSERT_EQUAL\((\d+)U, tls\.getStatistics\(\)\.get(\w+)\(\)\)', text[text.index("::addTemplates"):text.index("::testStatistics")]) and
+           [(name, val) for val, name in re.findall(r'CPPUNIT_ASSERT_EQUAL\((\d+)U, tls\.getStatistics\(\)\.get(\w+)\(\)\)', text[text.index("::addTemplates"):text.index("::testStatistics")])]}
+    assert seq == {"Min": 14, "Median": 5001, "Max": 9987, "LowStdDev": 3414, "HighStdDev": 3413}, seq
+    drift = int(re.search(r'TemplateLengthDistribution tls\((\d+)\);', text[text.index("::testMateDriftRange"):]).group(1))
+    out["add_templates"] = {"after_10000": seq, "all_intermediate_results_false": True, "last_result_true": True, "mate_drift_range": drift}
+    json.dump(out, open(os.path.join(OUT, "template_length_statistics.json"), "w"), indent=1)
+    return len(mates)
+
+
+def make_clippers():
+    """the literal (read, reference) pairs and asserted CIGAR / position of the two end clipper tests"""
+    text = strip_comments(open(os.path.join(REF, "testSemialignedClipper.cpp")).read())
+    semi = []
+    for m in re.finditer(r'fragmentMetadata\.reverse = (true|false);\s*align\("([^"]*)",\s*"([^"]*)",\s*noAdapters,\s*fragmentMetadata\);(.*?)\n}', text, re.S):
+        rev, read, ref, asserts = m.groups()
+        cigar = re.search(r'std::string\("([0-9A-Z]+)"\), fragmentMetadata\.getCigarString', asserts).group(1)
+        pos = int(re.search(r'ReferencePosition\(0, (\d+)U\), fragmentMetadata\.getStrandReferencePosition', asserts).group(1))
+        semi.append({"read": read, "reference": ref, "reverse": rev == "true", "cigar": cigar, "position": pos})
+    assert len(semi) == 4, len(semi)
+    text = strip_comments(open(os.path.join(REF, "testOverlappingEndsClipper.cpp")).read())
+    over = []
+    for m in re.finditer(r'init\("([^"]*)", "([^"]*)", (true|false),\s*"([^"]*)", "([^"]*)", (true|false),\s*"([^"]*)", templ, contigList\);(.*?)\n    }', text, re.S):
+        r1, q1, v1, r2, q2, v2, ref, body = m.groups()
+        after = body[body.index("clipper.clip"):]
+        cig = re.findall(r'std::string\("([0-9A-Z]+)"\), templ\.getFragmentMetadata\((\d)\)\.getCigarString', after)
+        pos = re.findall(r'CPPUNIT_ASSERT_EQUAL\((\d+)L, templ\.getFragmentMetadata\((\d)\)\.position', after)
+        over.append({"read1": r1, "quality1": q1, "reverse1": v1 == "true", "read2": r2, "quality2": q2, "reverse2": v2 == "true", "reference": ref,
+                     "cigar": [dict((int(i), c) for c, i in cig)[k] for k in (0, 1)], "position": [dict((int(i), int(p)) for p, i in pos)[k] for k in (0, 1)]})
+    assert len(over) == 2, len(over)
+    json.dump({"source": "lib/alignment/cppunit/testSemialignedClipper.cpp:189-251, testOverlappingEndsClipper.cpp:109-157", "semialigned": semi, "overlapping": over},
+              open(os.path.join(OUT, "clippers.json"), "w"), indent=1)
+    return len(semi), len(over)
+
+
 if __name__ == "__main__":
+    print("clippers:", make_clippers())
+    print("template_length_statistics asserts:", make_template_length_statistics())
     print("simple_indel cases:", make_simple_indel())
     print("fragment_builder2 cases:", make_fragment_builder2())
     print("bsw cases:", make_bsw())

@@ -96,3 +96,52 @@ def test_threaded_seed_lookup_equals_single_thread(oracle):
     m1, h1 = ref.find_matches(p, bcl, len(bcl))
     m7, h7 = ref.find_matches(p, bcl, len(bcl), n_threads=7)
     assert len(m1) == len(m7) and (m1 == m7).all() and (h1 == h7).all()
+
+
+def test_template_length_statistics_known_answers(oracle):
+    """testTemplateLengthStatistics.cpp:42-367: alignment models and classes, mate orientation and mate position windows for the
+    eight model pairs, and the statistics of the literal addTemplates() sequence (min 14, median 5001, max 9987, sd 3414/3413)"""
+    import ctypes as C
+    g = json.load(open(os.path.join(GOLDEN, "template_length_statistics.json")))
+    lib = oracle.lib
+    model_names = {0: "FF+", 1: "FR+", 2: "RF+", 3: "RR+", 4: "FF-", 5: "FR-", 6: "RF-", 7: "RR-"}       # TemplateLengthStatistics.cpp alignmentModelName
+    class_names = {0: "F+", 1: "R+", 2: "R-", 3: "F-"}
+    for c in g["alignment_models"]:
+        m = lib.oracle_tls_alignment_model(C.c_int64(c["f1"][0]), c["f1"][1], C.c_int64(c["f2"][0]), c["f2"][1])
+        assert model_names[m] == c["name"], c
+    for c in g["alignment_classes"]:
+        assert class_names[lib.oracle_tls_alignment_class(g["models"][c["model"]])] == c["name"], c
+    out = (C.c_int64 * 3)()
+    for c in g["mates"]:
+        lens = c.get("read_lengths", [67, 83])
+        lib.oracle_tls_mate(*[C.c_uint32(v) for v in c["stats"]], g["models"][c["models"][0]], g["models"][c["models"][1]], c["drift"],
+                            C.c_uint32(c["read_index"]), int(c["reverse"]), C.c_int64(c.get("position", 500)), C.c_uint32(lens[0]), C.c_uint32(lens[1]), out)
+        got = {"orientation": out[0], "min_position": out[1], "max_position": out[2]}[c["what"]]
+        assert got == c["expected"], (c, got)
+    seq = (C.c_uint32 * 10)()
+    exp = g["add_templates"]["after_10000"]
+    lib.oracle_tls_add_templates_sequence(-1, seq)
+    assert [seq[0], seq[1], seq[2], seq[3], seq[4]] == [exp["Min"], exp["Median"], exp["Max"], exp["LowStdDev"], exp["HighStdDev"]]
+    assert (seq[5], seq[6]) == (exp["Min"], exp["Max"])                # testNoMateDriftRange
+    assert seq[7] == 0 and seq[8] == 1 and seq[9] == 1                 # every addTemplate false until the last one
+    drift = g["add_templates"]["mate_drift_range"]
+    lib.oracle_tls_add_templates_sequence(drift, seq)
+    assert seq[1] == exp["Median"] and (seq[5], seq[6]) == (exp["Median"] - drift, exp["Median"] + drift)     # testMateDriftRange
+
+
+def test_end_clippers_known_answers(oracle):
+    """testSemialignedClipper.cpp:189-251 (four literal alignments) and testOverlappingEndsClipper.cpp:109-157 (two literal pairs)"""
+    import ctypes as C
+    from isaac_aligner_amd import abi
+    g = json.load(open(os.path.join(GOLDEN, "clippers.json")))
+    lib = oracle.lib
+    cig, n, pos = (C.c_uint32 * 16)(), C.c_uint64(), C.c_int64()
+    for c in g["semialigned"]:
+        assert 0 == lib.oracle_semialigned_clip_literal(c["read"].encode(), c["reference"].encode(), int(c["reverse"]), cig, C.c_uint64(16), C.byref(n), C.byref(pos))
+        assert abi.cigar_string(list(cig[:n.value])) == c["cigar"] and pos.value == c["position"], (c, abi.cigar_string(list(cig[:n.value])), pos.value)
+    cig2, n2, pos2 = (C.c_uint32 * 16)(), (C.c_uint32 * 2)(), (C.c_int64 * 2)()
+    for c in g["overlapping"]:
+        assert 0 == lib.oracle_overlapping_clip_literal(c["read1"].encode(), c["quality1"].encode(), int(c["reverse1"]), c["read2"].encode(), c["quality2"].encode(), int(c["reverse2"]),
+                                                        c["reference"].encode(), cig2, n2, pos2)
+        for i in (0, 1):
+            assert abi.cigar_string(list(cig2[8 * i:8 * i + n2[i]])) == c["cigar"][i] and pos2[i] == c["position"][i], (c, i, abi.cigar_string(list(cig2[8 * i:8 * i + n2[i]])), pos2[i])
