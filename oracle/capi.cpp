@@ -581,6 +581,66 @@ int oracle_overlapping_clip_literal(const char *read1, const char *quality1, int
     catch (const std::exception &e) { g_error = e.what(); return 1; }
 }
 
+// ---- the fixture of lib/alignment/cppunit/testTemplateBuilder.cpp (:57-137 and BuilderInit.hh): five contigs, a cluster copied from
+// contig `bcl_contig` (read 1 forward at offset0, read 2 from the reverse strand at offset1, all Q40), the dummy template length
+// statistics (150/190/250, 20/30, FR+/RF-), ELAND scores and an explicit candidate list per read.
+typedef struct
+{
+    uint32_t contig_id; int64_t position; uint32_t observed_length, read_index, reverse, cigar_offset, cigar_length, mismatch_count;
+    double log_probability; uint32_t unique_seed_count, alignment_score, no_match;
+} oracle_literal_fragment;
+int oracle_template_builder_literal(const char *const *contig_bases, uint32_t n_contigs, uint32_t bcl_contig, int32_t offset0, int32_t offset1,
+                                    const oracle_literal_fragment *frags0, uint32_t n0, const oracle_literal_fragment *frags1, uint32_t n1,
+                                    uint32_t repeats /* buildTemplate calls with the same input */, uint32_t *template_score_out, oracle_literal_fragment *out /* 2 */)
+{
+    try
+    {
+        ContigList contigs;
+        for (uint32_t i = 0; i < n_contigs; ++i) { Contig c; c.index = 0; c.name = "c"; c.forward.assign(contig_bases[i], contig_bases[i] + strlen(contig_bases[i])); contigs.push_back(c); }
+        Params p;
+        p.gapMatchScore = 2; p.gapMismatchScore = -1; p.gapOpenScore = -15; p.gapExtendScore = -3; p.minGapExtendScore = 25;     // ELAND_* of the test
+        p.repeatThreshold = 10; p.gappedMismatchesMax = 8; p.semialignedGapLimit = 20000; p.scatterRepeats = false;
+        p.dodgyAlignmentScore = TemplateBuilder::DODGY_ALIGNMENT_SCORE_UNALIGNED;
+        { ReadMetadata a = { 100, 0, 0, 1 }, b = { 100, 1, 100, 101 }; p.reads.push_back(a); p.reads.push_back(b); }
+        // getBcl (BuilderInit.hh:141-169)
+        const std::vector<char> &forward = contigs.at(bcl_contig).forward;
+        std::vector<char> reverse;
+        for (size_t i = forward.size(); i-- > 0;) { const char b = forward[i]; reverse.push_back(b == 'A' ? 'T' : b == 'C' ? 'G' : b == 'G' ? 'C' : b == 'T' ? 'A' : 'N'); }
+        std::string bases(forward.begin() + offset0, forward.begin() + offset0 + 100);
+        bases += std::string(reverse.begin() + offset1, reverse.begin() + offset1 + 100);
+        std::vector<uint8_t> bcl;
+        for (size_t i = 0; i < bases.size(); ++i) { const char b = bases[i]; bcl.push_back(uint8_t((40 << 2) | (b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : 3))); }
+        Cluster cluster; cluster.init(p.reads, bcl.data(), 32, 1234, true);
+        const RestOfGenomeCorrection rog(contigs, p.reads);
+        const TemplateLengthStatistics tls(150, 250, 190, 20, 30, TemplateLengthStatistics::FRp, TemplateLengthStatistics::RFm, -1);
+        const std::vector<uint32_t> cigarBuffer(1000, 1600);
+        std::vector<FragmentMetadataList> fragments(2);
+        const oracle_literal_fragment *in[2] = { frags0, frags1 }; const uint32_t n[2] = { n0, n1 };
+        for (unsigned r = 0; r < 2; ++r) for (uint32_t i = 0; i < n[r]; ++i)
+        {
+            const oracle_literal_fragment &l = in[r][i];
+            FragmentMetadata f;
+            f.contigId = l.contig_id; f.position = l.position; f.observedLength = l.observed_length; f.readIndex = l.read_index; f.reverse = l.reverse != 0;
+            f.cigarOffset = l.cigar_offset; f.cigarLength = l.cigar_length; f.cigarBuffer = &cigarBuffer; f.mismatchCount = l.mismatch_count;
+            f.logProbability = l.log_probability; f.uniqueSeedCount = l.unique_seed_count; f.alignmentScore = l.alignment_score; f.cluster = &cluster;
+            fragments[r].push_back(f);
+        }
+        TemplateBuilder builder(p);
+        for (uint32_t k = 0; k < (repeats ? repeats : 1); ++k) builder.buildTemplate(contigs, rog, p.reads, fragments, cluster, tls);
+        *template_score_out = builder.bamTemplate.getAlignmentScore();
+        for (unsigned i = 0; i < 2; ++i)
+        {
+            const FragmentMetadata &f = builder.bamTemplate.getFragmentMetadata(i);
+            oracle_literal_fragment &o = out[i];
+            o.contig_id = f.contigId; o.position = f.position; o.observed_length = f.observedLength; o.read_index = f.readIndex; o.reverse = f.reverse;
+            o.cigar_offset = f.cigarOffset; o.cigar_length = f.cigarLength; o.mismatch_count = f.mismatchCount; o.log_probability = f.logProbability;
+            o.unique_seed_count = f.uniqueSeedCount; o.alignment_score = f.alignmentScore; o.no_match = f.isNoMatch();
+        }
+        return 0;
+    }
+    catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+
 // ---- literal entry points for the known-answer vectors of lib/alignment/cppunit/testTemplateLengthStatistics.cpp
 int oracle_tls_alignment_model(int64_t pos1, int reverse1, int64_t pos2, int reverse2)
 {

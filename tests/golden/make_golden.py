@@ -13,6 +13,7 @@ What is extracted is DATA: the literal inputs and the asserted outputs of
   * lib/alignment/cppunit/testSeedId.cpp                        -> seed_id.json
   * lib/alignment/cppunit/testTemplateLengthStatistics.cpp:42-367 -> template_length_statistics.json (asserted literals only)
   * lib/alignment/cppunit/testSemialignedClipper.cpp:189-251, testOverlappingEndsClipper.cpp:109-157 -> clippers.json
+  * lib/alignment/cppunit/testTemplateBuilder.cpp:96-373 (+ BuilderInit.hh fixture recipe) -> template_builder.json
 No reference source text is stored.
 """
 import ctypes
@@ -336,7 +337,101 @@ def make_clippers():
     return len(semi), len(over)
 
 
+def make_template_builder():
+    """testTemplateBuilder.cpp: the candidate lists each test hands to TemplateBuilder::buildTemplate and every value it asserts
+    afterwards (template and fragment alignment scores = the MAPQ arithmetic, positions, CIGAR references ...).
+    Fixture (BuilderInit.hh:122-132): contigs c0..c4 drawn with glibc rand() in the order c2(230), c4(60), c1(220), c0(210),
+    c3 = "AAAAA" + c2.  The stream position at which the fixture is constructed depends on the other fixtures of the test
+    binary, so the recipe is evaluated at several positions of the default-seed stream; the asserted values do not depend on it."""
+    text = strip_comments(open(os.path.join(REF, "testTemplateBuilder.cpp")).read())
+    libc = ctypes.CDLL("libc.so.6")
+    libc.srand(1)
+    fixtures = []
+    for _ in range(4):
+        draw = lambda n: "".join("ACGT"[libc.rand() % 4] for _ in range(n))
+        c2 = draw(230); c4 = draw(60); c1 = draw(220); c0 = draw(210)
+        fixtures.append([c0, c1, c2, "AAAAA" + c2, c4])
+    # the two literal candidates of the fixture (:121-122)
+    def literal(name):
+        m = re.search(name + r'\(getFragmentMetadata\(([^)]*)\)\)', text)
+        a = [x.strip() for x in m.group(1).split(",")]
+        return {"contig_id": int(a[0]), "position": int(a[1]), "observed_length": int(a[2]), "read_index": int(a[3]), "reverse": a[4] == "true",
+                "cigar_offset": int(a[5]), "cigar_length": int(a[6]), "mismatch_count": int(a[8]), "log_probability": float(a[9]),
+                "unique_seed_count": int(a[10]), "alignment_score": int(a[11])}
+    f0_0, f0_1 = literal("f0_0"), literal("f0_1")
+    assert (f0_0["position"], f0_0["log_probability"], f0_1["position"], f0_1["log_probability"]) == (2, -8.0, 107, -12.0)
+    bcl = re.search(r'bcl0\(getBcl\(readMetadataList, contigList, (\d+), (\d+), (\d+)\)\)', text)
+    out = {"source": "lib/alignment/cppunit/testTemplateBuilder.cpp:96-373, BuilderInit.hh:122-169", "fixtures": fixtures,
+           "bcl": {"contig": int(bcl.group(1)), "offset0": int(bcl.group(2)), "offset1": int(bcl.group(3))}, "f0_0": f0_0, "f0_1": f0_1, "cases": []}
+
+    def asserts(body):
+        """{(fragment index or 't', field): literal} for the CPPUNIT_ASSERT_EQUALs of one stretch of test code"""
+        exp = {}
+        for lit, who, field in re.findall(r'CPPUNIT_ASSERT_EQUAL\(([^,]+), bamTemplate\.(?:getFragmentMetadata\((\d)\)\.)?(\w+)(?:\(\))?\)', body):
+            exp[(who if who else "t", field)] = lit.strip()
+        return exp
+    def value(lit, best):
+        lit = lit.strip()
+        m = re.match(r'^(-?\d+)[UL]*$', lit)
+        if m: return int(m.group(1))
+        if lit in ("true", "false"): return lit == "true"
+        m = re.match(r'^(f0_0|f0_1)\.logProbability$', lit)
+        if m: return {"f0_0": f0_0, "f0_1": f0_1}[m.group(1)]["log_probability"]
+        m = re.match(r'^(?:unsigned|long)?\(?(best[01])\.(\w+)', lit)
+        if m:
+            b = best[m.group(1)]
+            key = {"getFStrandReferencePosition": None, "getObservedLength": "observed_length", "getReadIndex": "read_index", "isReverse": "reverse", "cigarOffset": "cigar_offset",
+                   "getCigarLength": "cigar_length", "getMismatchCount": "mismatch_count", "logProbability": "log_probability", "uniqueSeedCount": "unique_seed_count"}[m.group(2)]
+            if key is None: return b["contig_id"] if "getContigId" in lit else b["position"]
+            return b[key]
+        raise ValueError(lit)
+    names = {"contigId": "contig_id", "position": "position", "observedLength": "observed_length", "readIndex": "read_index", "reverse": "reverse", "cigarOffset": "cigar_offset",
+             "cigarLength": "cigar_length", "mismatchCount": "mismatch_count", "logProbability": "log_probability", "uniqueSeedCount": "unique_seed_count",
+             "alignmentScore": "alignment_score", "getAlignmentScore": "alignment_score"}
+    def case(name, frags0, frags1, body, best=None):
+        exp = {"template_score": None, "fragments": [{}, {}]}
+        for (who, field), lit in asserts(body).items():
+            if who == "t": exp["template_score"] = value(lit, best)
+            else: exp["fragments"][int(who)][names[field]] = value(lit, best)
+        out["cases"].append({"name": name, "fragments0": frags0, "fragments1": frags1, "expected": exp})
+    fn = lambda n: text[text.index("::" + n + "()"):text.index("\nvoid ", text.index("::" + n + "()") + 10)] if "\nvoid " in text[text.index("::" + n + "()") + 10:] else text[text.index("::" + n + "()"):]
+    # testEmptyMatchList: checkUnalignedTemplate + score 0
+    unaligned = {"no_match": True, "observed_length": 0, "reverse": False, "cigar_offset": 0, "cigar_length": 0, "mismatch_count": 0, "log_probability": 0.0,
+                 "unique_seed_count": 0, "alignment_score": 0xffffffff}
+    assert "CPPUNIT_ASSERT_EQUAL(-1U, bamTemplate.getFragmentMetadata(i).alignmentScore)" in text
+    out["cases"].append({"name": "empty", "fragments0": [], "fragments1": [], "expected": {"template_score": 0, "fragments": [dict(unaligned, read_index=0), dict(unaligned, read_index=1)]}})
+    orphan = fn("testOrphan")
+    first, second = orphan.split("// align on the second read only") if "// align on the second read only" in orphan else (None, None)
+    if first is None:   # comments were stripped: split at the second buildTemplate call
+        idx = [m.start() for m in re.finditer(r'templateBuilder->buildTemplate', orphan)]
+        first, second = orphan[idx[0]:idx[1]], orphan[idx[1]:]
+    case("orphan_read1", [f0_0], [], first)
+    case("orphan_read2", [], [f0_1], second)
+    uniq = fn("testUnique")
+    case("unique_pair", [f0_0], [f0_1], uniq[uniq.index("templateBuilder->buildTemplate"):])
+    # testMultiple: the list construction of :283-336 transcribed
+    fr0, fr1 = [], []
+    t0, t1 = dict(f0_0), dict(f0_1)
+    for _ in range(2):
+        fr0.append(dict(t0)); t0["position"] += 56; fr0.append(dict(t0)); t0["position"] += 65; fr1.append(dict(t1)); t1["position"] += 300
+    t0, t1 = dict(f0_0, contig_id=1), dict(f0_1, contig_id=1)
+    for _ in range(2):
+        t0["position"] += 56; fr0.append(dict(t0)); t0["position"] += 65; fr0.append(dict(t0)); t1["position"] += 401; fr1.append(dict(t1))
+    t0, t1 = dict(f0_0, contig_id=1), dict(f0_1, contig_id=1)
+    t0["log_probability"] += 2; t1["log_probability"] += 2
+    fr0.append(dict(t0)); best0 = dict(t0); fr1.append(dict(t1)); best1 = dict(t1)
+    t0["log_probability"] -= 2; t1["log_probability"] -= 2
+    for _ in range(2):
+        t0["position"] += 36; fr0.append(dict(t0)); t0["position"] += 45; fr0.append(dict(t0)); t1["position"] += 402; fr1.append(dict(t1))
+    mult = fn("testMultiple")
+    assert mult.count("t0.position += 56") == 2 and "t1.position += 401" in mult and "t1.position += 402" in mult and "t0.position += 36" in mult
+    case("multiple", fr0, fr1, mult[mult.index("templateBuilder->buildTemplate"):], {"best0": best0, "best1": best1})
+    json.dump(out, open(os.path.join(OUT, "template_builder.json"), "w"), indent=1)
+    return len(out["cases"]), sum(len(f) for c in out["cases"] for f in c["expected"]["fragments"])
+
+
 if __name__ == "__main__":
+    print("template_builder cases, asserted fragment fields:", make_template_builder())
     print("clippers:", make_clippers())
     print("template_length_statistics asserts:", make_template_length_statistics())
     print("simple_indel cases:", make_simple_indel())

@@ -145,3 +145,39 @@ def test_end_clippers_known_answers(oracle):
                                                         c["reference"].encode(), cig2, n2, pos2)
         for i in (0, 1):
             assert abi.cigar_string(list(cig2[8 * i:8 * i + n2[i]])) == c["cigar"][i] and pos2[i] == c["position"][i], (c, i, abi.cigar_string(list(cig2[8 * i:8 * i + n2[i]])), pos2[i])
+
+
+def test_template_builder_known_answers(oracle):
+    """testTemplateBuilder.cpp:149-373: the candidate lists of every test through TemplateBuilder::buildTemplate; every asserted
+    value must come out, notably the alignment scores (1136 / 534 / 569, 1119 / 517, 1084, 2 / 2 / 3): the MAPQ arithmetic
+    (rest-of-genome correction, exp / log10, shadow rescue probabilities) against the reference's own numbers"""
+    import ctypes as C
+    g = json.load(open(os.path.join(GOLDEN, "template_builder.json")))
+
+    class Frag(C.Structure):
+        _fields_ = [("contig_id", C.c_uint32), ("position", C.c_int64), ("observed_length", C.c_uint32), ("read_index", C.c_uint32), ("reverse", C.c_uint32),
+                    ("cigar_offset", C.c_uint32), ("cigar_length", C.c_uint32), ("mismatch_count", C.c_uint32), ("log_probability", C.c_double),
+                    ("unique_seed_count", C.c_uint32), ("alignment_score", C.c_uint32), ("no_match", C.c_uint32)]
+
+    def pack(frags):
+        a = (Frag * max(1, len(frags)))()
+        for i, f in enumerate(frags):
+            for k, v in f.items():
+                setattr(a[i], k, int(v) if isinstance(v, bool) else v)
+        return a
+
+    lib = oracle.lib
+    for fixture in g["fixtures"]:
+        contigs = (C.c_char_p * len(fixture))(*[c.encode() for c in fixture])
+        for case in g["cases"]:
+            out, score = (Frag * 2)(), C.c_uint32()
+            rc = lib.oracle_template_builder_literal(contigs, C.c_uint32(len(fixture)), C.c_uint32(g["bcl"]["contig"]), g["bcl"]["offset0"], g["bcl"]["offset1"],
+                                                     pack(case["fragments0"]), C.c_uint32(len(case["fragments0"])), pack(case["fragments1"]), C.c_uint32(len(case["fragments1"])),
+                                                     C.c_uint32(1), C.byref(score), out)
+            assert rc == 0
+            exp = case["expected"]
+            assert score.value == exp["template_score"], (case["name"], score.value, exp["template_score"])
+            for i in (0, 1):
+                for k, v in exp["fragments"][i].items():
+                    got = getattr(out[i], k)
+                    assert got == (int(v) if isinstance(v, bool) else v), (case["name"], i, k, got, v)
