@@ -7,10 +7,11 @@
 // directory.  The product path (isaac_aligner_amd/) never includes it.
 //
 // Pinning status: see oracle/README.md.  BandedSmithWaterman, SimpleIndelAligner,
-// FragmentBuilder (gapped/ungapped decision), SeedId, TemplateLengthStatistics and the
-// two end clippers are pinned by the reference's own cppunit known-answer vectors
-// (tests/golden/).  Seed lookup (MatchFinder/ExactMaskMatcher), the MAPQ numerics and
-// the FASTQ reader have no reference vectors: "parity unpinned" for those rows.
+// FragmentBuilder (gapped/ungapped decision), SeedId, TemplateLengthStatistics, the two
+// end clippers and TemplateBuilder::buildTemplate (MAPQ arithmetic, orphan rescue) are
+// pinned by the reference's own cppunit known-answer vectors (tests/golden/).  Seed
+// lookup (MatchFinder/ExactMaskMatcher) and the FASTQ reader have no reference vectors:
+// "parity unpinned" for those rows.
 #pragma once
 #include <stdint.h>
 #include <string>
