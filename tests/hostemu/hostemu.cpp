@@ -229,6 +229,44 @@ int emu_select(Emu *e, const u8 *bcl, u32 nClusters, u32 tile, const isaac_tls *
     return 0;
 }
 
+// The candidate lists of lib/alignment/cppunit/testTemplateBuilder.cpp pushed through the product's template code (thread-serial
+// form): ClusterFragments filled from literals, then clusterSelect.  Same record layout as tests/oracle capi's oracle_literal_fragment.
+struct LiteralFragment
+{
+    u32 contigId; i64 position; u32 observedLength, readIndex, reverse, cigarOffset, cigarLength, mismatchCount;
+    double logProbability; u32 uniqueSeedCount, alignmentScore, noMatch;
+};
+int emu_select_literal(Emu *e, const u8 *bcl, const LiteralFragment *f0, u32 n0, const LiteralFragment *f1, u32 n1, const isaac_tls *tls, isaac_fragment *records, u32 *cigars)
+{
+    if (n0 > CAND_CAP || n1 > CAND_CAP) { g_error = "too many candidates"; return 1; }
+    std::vector<ClusterFragments> frags(1);
+    ClusterFragments &f = frags[0];
+    std::memset(&f, 0, sizeof(f));
+    for (u32 k = 0; k < 16; ++k) f.cigarPool[k] = cigarOp(100, OP_ALIGN);     // cigarBuffer(1000, 1600) of the fixture
+    f.cigarUsed = 16; f.built = (n0 || n1) ? 1 : 0;
+    const LiteralFragment *in[2] = { f0, f1 }; const u32 n[2] = { n0, n1 };
+    for (u32 r = 0; r < 2; ++r)
+    {
+        f.nCands[r] = n[r];
+        for (u32 i = 0; i < n[r]; ++i)
+        {
+            const LiteralFragment &l = in[r][i];
+            Cand &c = f.cands[r][i];
+            candInit(c, l.readIndex);
+            c.contigId = l.contigId; c.position = l.position; c.observedLength = l.observedLength; c.reverse = l.reverse != 0;
+            c.cigarOffset = l.cigarOffset; c.cigarLength = u16(l.cigarLength); c.mismatchCount = u16(l.mismatchCount);
+            c.logProbability = l.logProbability; c.uniqueSeedCount = u16(l.uniqueSeedCount); c.alignmentScore = l.alignmentScore;
+        }
+    }
+    DevTls t; std::memcpy(&t, tls, sizeof(t));
+    const RogCorrection rog = makeRogCorrection(e->P, e->offsets.data(), e->loaded.data(), e->R.nContigs);
+    std::vector<u8> arena(templateWorkBytes(heavyCaps()) + 16, 0);
+    TemplateWork work;
+    templateWorkBind(work, reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(arena.data()) + 15) & ~uintptr_t(15)), heavyCaps());
+    clusterSelect(e->P, e->R, t, rog, logMismatchQ40(), bcl, 0, 32, f, work, reinterpret_cast<FragmentRecord *>(records), cigars, e->cnt);
+    return 0;
+}
+
 void emu_set_flat_rescue(Emu *e, int on) { e->flatRescue = on != 0; }
 void emu_set_fast_sort(Emu *e, int on) { e->fastSort = on != 0; }
 void emu_set_cluster_times(Emu *e, double *t) { e->clusterTimes = t; }

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import hostemu_lib
-from isaac_aligner_amd import options
+from isaac_aligner_amd import abi, options
 from parity_util import compare_candidates, compare_records, make_inputs
 
 
@@ -68,3 +68,60 @@ def test_fragments_tls_and_records(oracle, emulib, cfg):
     assert not (erec["reserved"] & 5).any()
     assert not compare_records(orec, ocig, erec, ecig)
     assert emu.counters()["mapq_near_integer"] == 0
+
+
+def test_template_code_reproduces_reference_known_answers(emulib):
+    """the product's template code (device headers, thread-serial form) on the candidate lists of testTemplateBuilder.cpp: the
+    reference's own alignment scores (1136 / 534 / 569, 1119 / 517, 1084, 2 / 2 / 3) and placements must come out"""
+    import ctypes as C
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "template_builder.json")))
+
+    class Frag(C.Structure):
+        _fields_ = [("contig_id", C.c_uint32), ("position", C.c_int64), ("observed_length", C.c_uint32), ("read_index", C.c_uint32), ("reverse", C.c_uint32),
+                    ("cigar_offset", C.c_uint32), ("cigar_length", C.c_uint32), ("mismatch_count", C.c_uint32), ("log_probability", C.c_double),
+                    ("unique_seed_count", C.c_uint32), ("alignment_score", C.c_uint32), ("no_match", C.c_uint32)]
+
+    def pack(frags):
+        a = (Frag * max(1, len(frags)))()
+        for i, f in enumerate(frags):
+            for k, v in f.items():
+                setattr(a[i], k, int(v) if isinstance(v, bool) else v)
+        return a
+
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    # TemplateBuilder(flowcells, 10, 4, false, 8, false, ELAND scores, 20000, DODGY_ALIGNMENT_SCORE_UNALIGNED), no clipping in buildTemplate
+    p = options.default_params(100, 100, gap_scoring="eland", gapped_mismatches_max=8, semialigned_gap_limit=20000, dodgy_alignment_score=-1,
+                               clip_semialigned=0, clip_overlapping=0)
+    tls = abi.Tls()
+    tls.min, tls.max, tls.median, tls.low_std_dev, tls.high_std_dev, tls.stable, tls.mate_min, tls.mate_max = 150, 250, 190, 20, 30, 1, 150, 250
+    tls.best_model[0], tls.best_model[1] = 1, 6       # FR+, RF-
+    for fixture in g["fixtures"]:
+        emu = hostemu_lib.Emu(emulib, p, [c.encode() for c in fixture])
+        forward = fixture[g["bcl"]["contig"]]
+        reverse = "".join(comp[b] for b in reversed(forward))
+        bases = forward[g["bcl"]["offset0"]:g["bcl"]["offset0"] + 100] + reverse[g["bcl"]["offset1"]:g["bcl"]["offset1"] + 100]
+        bcl = np.array([(40 << 2) | "ACGT".index(b) for b in bases], np.uint8)
+        for case in g["cases"]:
+            rec = np.zeros(2, abi.FRAGMENT_DTYPE)
+            cig = np.zeros(2 * abi.MAX_CIGAR_OPS, np.uint32)
+            rc = emulib.emu_select_literal(emu.h, hostemu_lib.ptr(bcl), pack(case["fragments0"]), C.c_uint32(len(case["fragments0"])), pack(case["fragments1"]),
+                                           C.c_uint32(len(case["fragments1"])), C.byref(tls), hostemu_lib.ptr(rec), hostemu_lib.ptr(cig))
+            assert rc == 0
+            exp = case["expected"]
+            if case["fragments0"] or case["fragments1"]:      # without candidates the cluster never reaches buildTemplate in the product path
+                assert rec["template_alignment_score"][0] == (exp["template_score"] & 0xffff), (case["name"], rec["template_alignment_score"], exp["template_score"])
+            for i in (0, 1):
+                e = exp["fragments"][i]
+                if "alignment_score" in e:
+                    assert rec["alignment_score"][i] == (e["alignment_score"] & 0xffff), (case["name"], i, rec["alignment_score"][i], e["alignment_score"])
+                if e.get("no_match"):
+                    assert rec["flags"][i] & 2                      # unaligned
+                    continue
+                if "position" in e:
+                    assert abi.refpos_position(rec["f_strand_position"][i:i + 1])[0] == e["position"], (case["name"], i)
+                if "contig_id" in e:
+                    assert abi.refpos_contig(rec["f_strand_position"][i:i + 1])[0] == e["contig_id"], (case["name"], i)
+                if "observed_length" in e:
+                    assert rec["observed_length"][i] == e["observed_length"], (case["name"], i)
