@@ -193,6 +193,17 @@ int isaac_gpu_select(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t n_clus
                      const isaac_match *matches_dev, const uint64_t *cluster_offsets_dev, const isaac_tls *tls,
                      isaac_fragment *fragments_dev, uint32_t *cigar_dev, uint64_t cigar_capacity);
 
+/* The same from explicit candidate lists instead of match lists: TemplateBuilder::buildTemplate(contigList, restOfGenomeCorrection,
+ * readMetadataList, sequencingAdapters, fragments, cluster, templateLengthStatistics) (include/alignment/TemplateBuilder.hh, the
+ * overload the reference's own unit tests drive, lib/alignment/cppunit/testTemplateBuilder.cpp:149-373) followed by the clippers
+ * and the record conversion of isaac_gpu_select.  candidates_dev: as isaac_gpu_build_fragments writes them, cluster by cluster,
+ * read 0's list before read 1's, each in list order; candidate_offsets_dev[k] .. [k + 1]: the candidates of cluster k
+ * (n_clusters + 1 entries); candidate_cigars_dev: the words isaac_candidate::cigar_offset / cigar_length refer to.
+ * isaac_gpu_build_fragments(with_gaps = 1, trim = 1) followed by this call is isaac_gpu_select. */
+int isaac_gpu_select_candidates(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t n_clusters, uint32_t tile,
+                                const isaac_candidate *candidates_dev, const uint64_t *candidate_offsets_dev, const uint32_t *candidate_cigars_dev,
+                                const isaac_tls *tls, isaac_fragment *fragments_dev, uint32_t *cigar_dev, uint64_t cigar_capacity);
+
 /* The leaf: alignment::BandedSmithWaterman::align (include/alignment/BandedSmithWaterman.hh:75-86) for a batch;
  * scores as the reference constructor takes them (GappedAligner.cpp:41-42: match, mismatch, -gapOpen, -gapExtend).
  * results[i].n_ops == 0xffffffff flags a CIGAR longer than ISAAC_GPU_MAX_CIGAR_OPS. */

@@ -500,6 +500,40 @@ __global__ void k_write_candidates(const ClusterFragments *frags, u32 clusterBas
     }
 }
 
+// the inverse of k_write_candidates: ClusterFragments from caller-supplied candidate lists (isaac_gpu_select_candidates)
+__global__ void k_load_candidates(DevParams P, const u8 *bcl, u32 clusterBase, u32 nChunk, const isaac_candidate *cands, const u64 *candOffsets, const u32 *cigarIn, int trim,
+                                  ClusterFragments *frags)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nChunk) return;
+    ClusterFragments &f = frags[t];
+    f.nCands[0] = f.nCands[1] = 0; f.cigarUsed = 0; f.flags = 0; f.repeatSeedsCount = 0; f.built = 0;
+    const u8 *clusterBcl = bcl + u64(clusterBase + t) * P.clusterLength;
+    for (u32 r = 0; r < 2; ++r)
+        f.endCyclesMasked[r] = (trim && r < P.nReads) ? trimLowQualityEnd(clusterBcl + P.readOffset[r], P.readLength[r], P.baseQualityCutoff) : 0;
+    const u64 begin = candOffsets[clusterBase + t], end = candOffsets[clusterBase + t + 1];
+    CigarPool pool; pool.words = f.cigarPool; pool.used = 0; pool.capacity = CIGAR_POOL; pool.overflow = 0;
+    for (u64 i = begin; i < end; ++i)
+    {
+        const isaac_candidate &o = cands[i];
+        const u32 r = o.read_index & 1;
+        if (f.nCands[r] == CAND_CAP) { f.flags |= CLUSTER_OVERFLOW; continue; }
+        Cand &k = f.cands[r][f.nCands[r]++];
+        candInit(k, r);
+        k.position = o.position; k.logProbability = o.log_probability; k.contigId = o.contig_id; k.observedLength = o.observed_length; k.reverse = o.reverse != 0;
+        k.mismatchCount = u16(o.mismatch_count); k.matchesInARow = u16(o.matches_in_a_row); k.gapCount = u16(o.gap_count); k.editDistance = u16(o.edit_distance);
+        k.smithWatermanScore = o.smith_waterman_score; k.uniqueSeedCount = u16(o.unique_seed_count);
+        k.nonUniqueFirst = o.non_unique_first == 0xffffffffu ? NON_UNIQUE_NONE : u16(o.non_unique_first); k.nonUniqueSecond = u16(o.non_unique_second);
+        k.repeatSeedsCount = u16(o.repeat_seeds_count); k.lowClipped = u16(o.low_clipped); k.highClipped = u16(o.high_clipped); k.firstSeedIndex = (signed char)o.first_seed_index;
+        k.cigarOffset = pool.used; k.cigarLength = u16(o.cigar_length);
+        for (u32 w = 0; w < o.cigar_length; ++w) pool.push(cigarIn[o.cigar_offset + w]);
+        f.repeatSeedsCount = o.repeat_seeds_count;
+        f.built = 1;
+    }
+    f.cigarUsed = pool.used;
+    if (pool.overflow) f.flags |= CLUSTER_OVERFLOW;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Template stage.  Mate rescue (ShadowAligner::rescueShadow) is the bulk of the work of the select phase: a 7-mer scan of
 // a window of several hundred reference bases plus one 150-base ungapped alignment per candidate start, for ~1.5 orphans
@@ -1450,8 +1484,11 @@ int isaac_gpu_determine_tls(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
     ISAAC_CATCH
 }
 
-int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, uint32_t tile, const isaac_match *matches, const uint64_t *offsets, const isaac_tls *tls,
-                     isaac_fragment *fragments, uint32_t *cigar, uint64_t cigarCapacity)
+// what fills the chunk's ClusterFragments: the fragment stage on match lists (isaac_gpu_select) or caller-supplied candidates
+struct FragmentSource { const isaac_match *matches; const uint64_t *offsets; const isaac_candidate *candidates; const uint64_t *candidateOffsets; const uint32_t *candidateCigars; };
+} // extern "C"
+static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, uint32_t tile, const FragmentSource &source, const isaac_tls *tls,
+                            isaac_fragment *fragments, uint32_t *cigar, uint64_t cigarCapacity)
 {
     ISAAC_TRY
     HIP_CHECK(hipSetDevice(c->device));
@@ -1498,7 +1535,15 @@ int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, u
         // two ClusterFragments buffers take turns: the fragment stage of this chunk runs while the wave-per-cluster pass of the
         // previous chunk is still reading its own; everything else that pass reads is rewritten only after the wait below
         c->fragsCur = (chunkIndex++ & 1) ? c->fragsAlt.p : c->frags.p;
-        launchBuildFragments(c, bcl, done, n, matches, offsets, 1, 1);
+        if (source.candidates)
+        {
+            gappedBuffers(c, 0);
+            HIP_CHECK(hipMemsetAsync(c->gappedCounters.p, 0, 16, st));      // launchBuildFragments does this on the other path
+            ScopedTimer tm(c, "load_candidates");
+            k_load_candidates<<<gridFor(n, 256), 256, 0, st>>>(c->P, bcl, done, n, source.candidates, source.candidateOffsets, source.candidateCigars, 1, c->fragsCur);
+            HIP_CHECK(hipGetLastError());
+        }
+        else launchBuildFragments(c, bcl, done, n, source.matches, source.offsets, 1, 1);
         if (heavyPending) { HIP_CHECK(hipStreamWaitEvent(st, c->evHeavyDone, 0)); heavyPending = false; }
         HIP_CHECK(hipMemsetAsync(c->overflowCount.p, 0, 4, st));
         if (c->flatRescue)
@@ -1565,6 +1610,20 @@ int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, u
     HIP_CHECK(hipStreamSynchronize(st));
     return 0;
     ISAAC_CATCH
+}
+extern "C" {
+int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, uint32_t tile, const isaac_match *matches, const uint64_t *offsets, const isaac_tls *tls,
+                     isaac_fragment *fragments, uint32_t *cigar, uint64_t cigarCapacity)
+{
+    FragmentSource source; std::memset(&source, 0, sizeof(source)); source.matches = matches; source.offsets = offsets;
+    return selectFromSource(c, bcl, nClusters, tile, source, tls, fragments, cigar, cigarCapacity);
+}
+int isaac_gpu_select_candidates(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, uint32_t tile, const isaac_candidate *candidates, const uint64_t *candidateOffsets,
+                                const uint32_t *candidateCigars, const isaac_tls *tls, isaac_fragment *fragments, uint32_t *cigar, uint64_t cigarCapacity)
+{
+    if (!candidates || !candidateOffsets) return fail(ISAAC_GPU_EINVAL, "candidates_dev and candidate_offsets_dev are required");
+    FragmentSource source; std::memset(&source, 0, sizeof(source)); source.candidates = candidates; source.candidateOffsets = candidateOffsets; source.candidateCigars = candidateCigars;
+    return selectFromSource(c, bcl, nClusters, tile, source, tls, fragments, cigar, cigarCapacity);
 }
 
 int isaac_gpu_bsw_batch(isaac_gpu_ctx *c, int match, int mismatch, int gapOpen, int gapExtend, const char *sequences, const isaac_bsw_job *jobs, uint32_t nJobs,

@@ -36,7 +36,8 @@ def load_library(path=None):
 
 EXPORTS = ["isaac_gpu_last_error", "isaac_gpu_create", "isaac_gpu_destroy", "isaac_gpu_malloc", "isaac_gpu_free", "isaac_gpu_upload", "isaac_gpu_download",
            "isaac_gpu_synchronize", "isaac_gpu_load_contigs", "isaac_gpu_load_contigs_dev", "isaac_gpu_load_index", "isaac_gpu_build_index", "isaac_gpu_get_index",
-           "isaac_gpu_find_matches", "isaac_gpu_set_loaded_contigs", "isaac_gpu_build_fragments", "isaac_gpu_determine_tls", "isaac_gpu_select", "isaac_gpu_bsw_batch",
+           "isaac_gpu_find_matches", "isaac_gpu_set_loaded_contigs", "isaac_gpu_build_fragments", "isaac_gpu_determine_tls", "isaac_gpu_select", "isaac_gpu_select_candidates",
+           "isaac_gpu_bsw_batch",
            "isaac_gpu_fastq_to_bcl", "isaac_gpu_get_counters", "isaac_gpu_kernel_time_ms", "isaac_gpu_reset_timers"]
 
 
@@ -183,6 +184,24 @@ class Aligner:
             records, cigars = out
         self._check(self.lib.isaac_gpu_select(self.h, _p(bcl), C.c_uint32(n_clusters), C.c_uint32(tile), _p(matches), _p(offsets), C.byref(tls),
                                               _p(records), _p(cigars), C.c_uint64(cigars.numel())))
+        return records, cigars
+
+    def select_candidates(self, bcl, candidates, candidate_cigars, tls, tile=0):
+        """TemplateBuilder::buildTemplate on explicit candidate lists.  candidates: abi.CANDIDATE_DTYPE numpy array ordered by
+        (cluster, read, list position); returns (records tensor, cigars tensor) like select()"""
+        torch = self.torch
+        n = int(bcl.shape[0])
+        cands = np.ascontiguousarray(candidates, abi.CANDIDATE_DTYPE)
+        counts = np.bincount(cands["cluster"].astype(np.int64), minlength=n) if len(cands) else np.zeros(n, np.int64)
+        offsets = np.zeros(n + 1, np.uint64); offsets[1:] = np.cumsum(counts)
+        cand_d = torch.from_numpy(cands.view(np.uint8).reshape(-1).copy() if len(cands) else np.zeros(abi.CANDIDATE_DTYPE.itemsize, np.uint8)).to(self.device)
+        off_d = torch.from_numpy(offsets.view(np.int64)).to(self.device)
+        cig_in = torch.from_numpy(np.ascontiguousarray(candidate_cigars, np.uint32).view(np.int32) if len(candidate_cigars) else np.zeros(1, np.int32)).to(self.device)
+        n_rec = n * self.n_reads
+        records = torch.empty((n_rec, abi.FRAGMENT_DTYPE.itemsize), dtype=torch.uint8, device=self.device)
+        cigars = torch.empty(n_rec * abi.MAX_CIGAR_OPS, dtype=torch.int32, device=self.device)
+        self._check(self.lib.isaac_gpu_select_candidates(self.h, _p(bcl), C.c_uint32(n), C.c_uint32(tile), _p(cand_d), _p(off_d), _p(cig_in), C.byref(tls),
+                                                         _p(records), _p(cigars), C.c_uint64(cigars.numel())))
         return records, cigars
 
     @staticmethod

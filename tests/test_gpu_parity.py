@@ -278,3 +278,60 @@ def test_repeat_family_stress(torch, oracle, chunk, monkeypatch):
     import os
     orec, ocig, _ = ref.select(p, host_bcl, om, otls, ohits, n_threads=os.cpu_count() or 1, n_clusters_hint=len(host_bcl))
     assert not compare_records(orec, ocig, rec, cig)
+
+
+def test_select_candidates_round_trip(case):
+    """isaac_gpu_build_fragments -> isaac_gpu_select_candidates gives the records of isaac_gpu_select"""
+    al = case["al"]
+    al.set_loaded_contigs(case["hits"])
+    tls = al.determine_tls(case["dev_bcl"], case["matches"], case["offsets"])
+    rec, cig = al.records_to_numpy(*al.select(case["dev_bcl"], case["matches"], case["offsets"], tls))
+    cands, ccig = al.build_fragments(case["dev_bcl"], case["matches"], case["offsets"], with_gaps=True, trim=True)
+    rec2, cig2 = al.records_to_numpy(*al.select_candidates(case["dev_bcl"], cands, ccig, tls))
+    assert not compare_records(rec, cig, rec2, cig2)
+
+
+def test_template_builder_known_answers_on_the_gpu(torch):
+    """lib/alignment/cppunit/testTemplateBuilder.cpp:149-373 through isaac_gpu_select_candidates: the reference's own asserted
+    alignment scores (1136 / 534 / 569, 1119 / 517, 1084, 2 / 2 / 3) and placements, computed by the kernels with the device
+    maths library"""
+    import json
+    import os
+    from isaac_aligner_amd import gpu
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "template_builder.json")))
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    p = options.default_params(100, 100, gap_scoring="eland", gapped_mismatches_max=8, semialigned_gap_limit=20000, dodgy_alignment_score=-1,
+                               clip_semialigned=0, clip_overlapping=0)
+    tls = abi.Tls()
+    tls.min, tls.max, tls.median, tls.low_std_dev, tls.high_std_dev, tls.stable, tls.mate_min, tls.mate_max = 150, 250, 190, 20, 30, 1, 150, 250
+    tls.best_model[0], tls.best_model[1] = 1, 6       # FR+, RF-
+    for fixture in g["fixtures"]:
+        al = gpu.Aligner(p, 0, [c.encode() for c in fixture])
+        forward = fixture[g["bcl"]["contig"]]
+        reverse = "".join(comp[b] for b in reversed(forward))
+        bases = forward[g["bcl"]["offset0"]:g["bcl"]["offset0"] + 100] + reverse[g["bcl"]["offset1"]:g["bcl"]["offset1"] + 100]
+        one = np.array([(40 << 2) | "ACGT".index(b) for b in bases], np.uint8)
+        cases = [c for c in g["cases"] if c["fragments0"] or c["fragments1"]]
+        bcl = torch.from_numpy(np.tile(one, (len(cases), 1))).to(al.device)           # one cluster per test case
+        cands = []
+        for k, case in enumerate(cases):
+            for f in case["fragments0"] + case["fragments1"]:
+                c = np.zeros(1, abi.CANDIDATE_DTYPE)[0]
+                c["cluster"], c["position"], c["log_probability"], c["read_index"], c["contig_id"] = k, f["position"], f["log_probability"], f["read_index"], f["contig_id"]
+                c["observed_length"], c["reverse"], c["mismatch_count"], c["unique_seed_count"] = f["observed_length"], int(f["reverse"]), f["mismatch_count"], f["unique_seed_count"]
+                c["non_unique_first"] = 0xffffffff
+                c["cigar_offset"], c["cigar_length"] = f["cigar_offset"], f["cigar_length"]        # into the fixture's cigarBuffer(1000, 1600)
+                cands.append(c)
+        cands = np.array(cands, abi.CANDIDATE_DTYPE)
+        rec, _ = al.records_to_numpy(*al.select_candidates(bcl, cands, np.full(16, 1600, np.uint32), tls))
+        for k, case in enumerate(cases):
+            exp = case["expected"]
+            r = rec[2 * k:2 * k + 2]
+            assert r["template_alignment_score"][0] == exp["template_score"], (case["name"], r["template_alignment_score"], exp["template_score"])
+            for i in (0, 1):
+                e = exp["fragments"][i]
+                assert r["alignment_score"][i] == e["alignment_score"], (case["name"], i, r["alignment_score"][i], e["alignment_score"])
+                if "position" in e:
+                    assert abi.refpos_position(r["f_strand_position"][i:i + 1])[0] == e["position"] and abi.refpos_contig(r["f_strand_position"][i:i + 1])[0] == e["contig_id"]
+                if "observed_length" in e:
+                    assert r["observed_length"][i] == e["observed_length"]
