@@ -229,8 +229,11 @@ int isaac_gpu_fastq_to_bcl(isaac_gpu_ctx *ctx, const char *fastq_dev, uint64_t n
                            uint32_t *n_clusters_out, uint64_t *consumed_bytes_out, uint64_t *error_offset_out);
 
 int isaac_gpu_get_counters(isaac_gpu_ctx *ctx, isaac_counters *out);
-/* average device time (ms) of the named kernel over the launches since the last reset, measured with HIP events on the
- * context's stream; names: "find_matches", "build_fragments", "plan_rescue", "rescue_windows", "rescue_align", "select", "select_heavy", "bsw" */
+/* average device time (ms) of the named launch sequence over the launches since the last reset, measured with HIP events on the
+ * stream it runs on; names: "find_matches", "compact_matches", "build_fragments", "align_candidates", "finish_candidates",
+ * "indel_fragments", "gapped_fragments", "finish_fragments", "load_candidates", "plan_rescue", "rescue_windows", "rescue_align",
+ * "rescue_gapped_plan", "gapped_rescue", "select", "select_heavy" (own stream, overlaps "select"), "select_residual",
+ * "fastq_to_bcl", "bsw" */
 int isaac_gpu_kernel_time_ms(isaac_gpu_ctx *ctx, const char *kernel, double *avg_ms, uint64_t *launches);
 int isaac_gpu_reset_timers(isaac_gpu_ctx *ctx);
 
