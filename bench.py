@@ -43,6 +43,7 @@ def parse():
 
 def main():
     args = parse()
+    os.environ.setdefault("ISAAC_GPU_DEFERRED_COMPLETION", "1")   # read by isaac_gpu_create: select calls pipeline, isaac_gpu_synchronize completes them
     from isaac_aligner_amd import abi, gpu, options, shard, synth
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -73,7 +74,9 @@ def main():
 
     n_rec = args.pairs_per_step * 2
     records = [torch.empty((n_rec, abi.FRAGMENT_DTYPE.itemsize), dtype=torch.uint8, device=dev) for _ in range(args.steps)]
-    cigars = torch.empty(n_rec * abi.MAX_CIGAR_OPS, dtype=torch.int32, device=dev)   # reused: only the records are gathered
+    # only the records are gathered; two CIGAR buffers take turns because the tail of one select call (its wave-per-cluster pass)
+    # overlaps the start of the next one (ISAAC_GPU_DEFERRED_COMPLETION, set below)
+    cigars = [torch.empty(n_rec * abi.MAX_CIGAR_OPS, dtype=torch.int32, device=dev) for _ in range(2)]
 
     def reduce_hits(h):
         return shard.reduce_contig_hits(h, dist, dev)
@@ -85,7 +88,7 @@ def main():
         al.set_loaded_contigs(reduce_hits(hits))
         if tls is None:
             tls = al.determine_tls(batches[b], m, o)
-        al.select(batches[b], m, o, tls, out=(records[0], cigars))
+        al.select(batches[b], m, o, tls, out=(records[0], cigars[0]))
     if tls is None:
         m, o, hits = al.find_matches(batches[0])
         al.set_loaded_contigs(reduce_hits(hits))
@@ -107,7 +110,8 @@ def main():
     al.set_loaded_contigs(reduce_hits(all_hits))      # MatchSelector loads only contigs that received matches
     for s in range(args.steps):                       # phase 2: SelectMatchesTransition
         m, o = found[s]
-        al.select(batches[args.warmup + s], m, o, tls, out=(records[s], cigars))
+        al.select(batches[args.warmup + s], m, o, tls, out=(records[s], cigars[s & 1]))
+    al.synchronize()                                  # completes the last call's wave-per-cluster pass
     if dist is not None:                              # single gather of the per-GPU records at the end
         shard.gather_records(torch.cat(records), dist, rank, world)
     torch.cuda.synchronize()

@@ -187,6 +187,9 @@ int isaac_gpu_determine_tls(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t
  * the io::FragmentHeader fields FragmentCollector would store.  One record per read, in cluster order:
  * fragments_dev[cluster * n_reads + read]; its CIGAR is cigar_dev[cigar_offset .. + cigar_length);
  * cigar_dev must hold n_clusters * n_reads * ISAAC_GPU_MAX_CIGAR_OPS words.
+ * The call returns when the records are complete.  With ISAAC_GPU_DEFERRED_COMPLETION=1 in the environment of isaac_gpu_create it
+ * returns while its last wave-per-cluster pass is still running on an internal stream, so that back-to-back calls overlap; the
+ * outputs of all calls are then complete after isaac_gpu_synchronize(), and calls in flight need distinct output buffers.
  * isaac_fragment::reserved: bit 2 = a fixed internal capacity was exceeded for this cluster (result not exact; counted in
  * isaac_counters::overflow_clusters), bit 1 = the reference would not have stored the template (only without --keep-unaligned). */
 int isaac_gpu_select(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t n_clusters, uint32_t tile,

@@ -83,6 +83,9 @@ struct isaac_gpu_ctx
     struct PendingTimer { std::string name; hipEvent_t e0, e1; };
     std::vector<PendingTimer> pendingTimers; std::vector<hipEvent_t> eventPool;
     hipStream_t heavyStream = nullptr; hipEvent_t evPredicted = nullptr, evHeavyDone = nullptr;
+    // a wave-per-cluster pass is still running on heavyStream (it reads the chunk buffers of the chunk it belongs to); with
+    // deferredCompletion the last one of a select call is left running when the call returns (see isaac_gpu_select)
+    bool heavyPending = false, deferredCompletion = false; u32 chunkParity = 0;
     DevBuf<u32> heavyList, heavyCount, indelList, alignList; DevBuf<u8> heavyFlag;
     u32 chunkClusters = 524288;
 
@@ -124,6 +127,12 @@ static void resolveTimers(isaac_gpu_ctx *c)
         c->eventPool.push_back(p.e0); c->eventPool.push_back(p.e1);
     }
     c->pendingTimers.clear();
+}
+
+// the caller's stream waits for a wave-per-cluster pass that may still be running
+static void joinHeavy(isaac_gpu_ctx *c)
+{
+    if (c->heavyPending) { hipStreamWaitEvent(c->stream, c->evHeavyDone, 0); c->heavyPending = false; }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1135,6 +1144,7 @@ int isaac_gpu_create(int device, const isaac_params *params, void *stream, isaac
     HIP_CHECK(hipEventCreateWithFlags(&c->evPredicted, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&c->evHeavyDone, hipEventDisableTiming));
     if (const char *e = getenv("ISAAC_GPU_CHUNK_CLUSTERS")) c->chunkClusters = u32(std::max(1024, atoi(e)));
     if (const char *e = getenv("ISAAC_GPU_FLAT_RESCUE")) c->flatRescue = atoi(e) != 0;
+    if (const char *e = getenv("ISAAC_GPU_DEFERRED_COMPLETION")) c->deferredCompletion = atoi(e) != 0;
     *out = c.release();
     return ISAAC_GPU_OK;
     ISAAC_CATCH
@@ -1144,6 +1154,7 @@ void isaac_gpu_destroy(isaac_gpu_ctx *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
+    joinHeavy(c); hipStreamSynchronize(c->stream); if (c->heavyStream) hipStreamSynchronize(c->heavyStream);
     resolveTimers(c);
 #if defined(ISAAC_KERNEL_STAMPS)
     {
@@ -1164,7 +1175,7 @@ int isaac_gpu_upload(isaac_gpu_ctx *c, void *dev, const void *host, uint64_t byt
 { ISAAC_TRY HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
 int isaac_gpu_download(isaac_gpu_ctx *c, void *host, const void *dev, uint64_t bytes)
 { ISAAC_TRY HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
-int isaac_gpu_synchronize(isaac_gpu_ctx *c) { ISAAC_TRY HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
+int isaac_gpu_synchronize(isaac_gpu_ctx *c) { ISAAC_TRY joinHeavy(c); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
 
 static void setContigs(isaac_gpu_ctx *c, const uint64_t *offsets, uint32_t n)
 {
@@ -1430,6 +1441,7 @@ int isaac_gpu_build_fragments(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nCl
     ISAAC_TRY
     (void)tile;
     HIP_CHECK(hipSetDevice(c->device));
+    joinHeavy(c);      // a wave-per-cluster pass of an earlier select call may still read the buffers written below
     hipStream_t st = c->stream;
     const u32 chunk = c->chunkClusters;
     DevBuf<u32> nc, ng, oc, og; nc.reserve(chunk); ng.reserve(chunk); oc.reserve(chunk); og.reserve(chunk);
@@ -1461,6 +1473,7 @@ int isaac_gpu_determine_tls(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
     ISAAC_TRY
     (void)tile;
     HIP_CHECK(hipSetDevice(c->device));
+    joinHeavy(c);      // a wave-per-cluster pass of an earlier select call may still read the buffers written below
     hipStream_t st = c->stream;
     TlsLearner learner(c->P.mateDriftRange);
     if (2 == c->P.nReads)
@@ -1528,13 +1541,12 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
     }
     const GappedBuffers gbRescue = gappedBuffers(c, 1);
     c->frags.reserve(chunk); c->fragsAlt.reserve(chunk);
-    bool heavyPending = false; u32 chunkIndex = 0;
     for (u32 done = 0; done < nClusters; done += chunk)
     {
         const u32 n = std::min(chunk, nClusters - done);
         // two ClusterFragments buffers take turns: the fragment stage of this chunk runs while the wave-per-cluster pass of the
         // previous chunk is still reading its own; everything else that pass reads is rewritten only after the wait below
-        c->fragsCur = (chunkIndex++ & 1) ? c->fragsAlt.p : c->frags.p;
+        c->fragsCur = (c->chunkParity++ & 1) ? c->fragsAlt.p : c->frags.p;
         if (source.candidates)
         {
             gappedBuffers(c, 0);
@@ -1544,7 +1556,7 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
             HIP_CHECK(hipGetLastError());
         }
         else launchBuildFragments(c, bcl, done, n, source.matches, source.offsets, 1, 1);
-        if (heavyPending) { HIP_CHECK(hipStreamWaitEvent(st, c->evHeavyDone, 0)); heavyPending = false; }
+        joinHeavy(c);
         HIP_CHECK(hipMemsetAsync(c->overflowCount.p, 0, 4, st));
         if (c->flatRescue)
         {
@@ -1588,7 +1600,7 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
                                                                                          c->heavyList.p, rb, gbRescue.results, gbRescue.jobs, reinterpret_cast<FragmentRecord *>(fragments), cigar, c->counters.p);
                 HIP_CHECK(hipGetLastError());
             }
-            HIP_CHECK(hipEventRecord(c->evHeavyDone, c->heavyStream)); heavyPending = true;
+            HIP_CHECK(hipEventRecord(c->evHeavyDone, c->heavyStream)); c->heavyPending = true;
         }
         {
             ScopedTimer tm(c, "select");
@@ -1605,8 +1617,8 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
             HIP_CHECK(hipGetLastError());
         }
     }
-    if (heavyPending) HIP_CHECK(hipStreamWaitEvent(st, c->evHeavyDone, 0));
-    c->fragsCur = c->frags.p;
+    if (c->deferredCompletion) return 0;      // the last wave-per-cluster pass overlaps whatever the caller enqueues next; isaac_gpu_synchronize completes it
+    joinHeavy(c);
     HIP_CHECK(hipStreamSynchronize(st));
     return 0;
     ISAAC_CATCH

@@ -335,3 +335,39 @@ def test_template_builder_known_answers_on_the_gpu(torch):
                     assert abi.refpos_position(r["f_strand_position"][i:i + 1])[0] == e["position"] and abi.refpos_contig(r["f_strand_position"][i:i + 1])[0] == e["contig_id"]
                 if "observed_length" in e:
                     assert r["observed_length"][i] == e["observed_length"]
+
+
+def test_deferred_completion_pipelines_select_calls(torch, monkeypatch):
+    """ISAAC_GPU_DEFERRED_COMPLETION=1: isaac_gpu_select returns with its last wave-per-cluster pass still running, the next call
+    overlaps it, isaac_gpu_synchronize completes everything.  Same records as the synchronous calls, batch for batch."""
+    from isaac_aligner_amd import gpu, synth
+    contigs = _repeat_genome()
+    dev_contigs = [torch.frombuffer(bytearray(c), dtype=torch.uint8).to("cuda") for c in contigs]
+    batches = [synth.make_read_pairs(dev_contigs, 3000, 150, seed=90 + i, device="cuda")[0] for i in range(4)]
+    p = options.default_params(150, 150)
+
+    def run(deferred):
+        if deferred:
+            monkeypatch.setenv("ISAAC_GPU_DEFERRED_COMPLETION", "1")
+            monkeypatch.setenv("ISAAC_GPU_CHUNK_CLUSTERS", "1024")       # several chunks per call as well
+        else:
+            monkeypatch.delenv("ISAAC_GPU_DEFERRED_COMPLETION", raising=False)
+            monkeypatch.delenv("ISAAC_GPU_CHUNK_CLUSTERS", raising=False)
+        al = gpu.Aligner(p, 0, contigs)
+        al.build_index()
+        found = [al.find_matches(b) for b in batches]
+        hits = found[0][2]
+        for f in found[1:]:
+            hits = hits | f[2]
+        al.set_loaded_contigs(hits)
+        tls = al.determine_tls(batches[0], found[0][0], found[0][1])
+        outs = [al.select(b, m, o, tls) for b, (m, o, _) in zip(batches, found)]       # enqueued back to back
+        al.synchronize()
+        heavy = al.counters()["heavy_clusters"]
+        return [al.records_to_numpy(r, c) for r, c in outs], heavy
+
+    deferred, heavy = run(True)
+    assert heavy > 0
+    plain, _ = run(False)
+    for (r1, c1), (r2, c2) in zip(deferred, plain):
+        assert not compare_records(r2, c2, r1, c1)
