@@ -123,6 +123,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    hbm_used_gb = round((total_b - free_b) / 1e9, 1)      # everything resident at the end of the run: index, reads, records, chunk scratch
     counters = al.counters()
     timers = {k: al.kernel_time_ms(k) for k in ("find_matches", "build_fragments", "align_candidates", "finish_candidates", "indel_fragments", "gapped_fragments", "finish_fragments", "plan_rescue", "rescue_windows", "rescue_align",
                                                  "rescue_gapped_plan", "gapped_rescue", "select", "select_heavy", "select_residual", "compact_matches")}
@@ -218,7 +220,7 @@ def main():
            "config": {"workload": "chr21-sized synthetic reference (%d bp, 32-mer index %d entries), %d synthetic 2x%d bp pairs per GPU "
                                   "(%d steps x %d pairs)" % (args.genome_bases, n_index, pairs_rank, L, args.steps, args.pairs_per_step),
                       "pairs_per_step": args.pairs_per_step, "read_length": L, "genome_bases": args.genome_bases, "index_entries": int(n_index),
-                      "parallelism": "read shards x%d, records gathered once" % world, "setup_s": round(t_setup, 1), "index_build_s": round(t_index, 1),
+                      "parallelism": "read shards x%d, records gathered once" % world, "hbm_used_gb": hbm_used_gb, "setup_s": round(t_setup, 1), "index_build_s": round(t_index, 1),
                       "tls": list(tls.astuple())},
            "roofline": roofline, "cpu_baseline": cpu,
            "counters": {k: int(v) for k, v in counters.items()}}
