@@ -1,14 +1,16 @@
 // MI355X (gfx950) kernels and the C ABI of include/isaac_gpu.h.
 //
-// Kernels
-//   k_find_matches      8 lanes per cluster, one lane per seed probe: 2-bit k-mer extraction from LDS-staged BCL bytes,
-//                       binary search of the resident sorted 32-mer table, ExactMaskMatcher's match rules
-//   k_compact_matches   fixed-stride staging -> compact per-cluster ranges
-//   k_build_fragments   one thread per cluster: FragmentBuilder::build (aligner.h)
-//   k_bsw_batch         16 lanes per alignment: banded Smith-Waterman leaf (bsw_kernel.h)
-//   k_tls_samples       one thread per cluster: the facts TemplateLengthDistribution::addTemplate needs
-//   k_select            one thread per cluster: TemplateBuilder::buildTemplate + clippers + FragmentHeader records (template.h)
-//   index builder       k-mer enumeration + hipCUB radix sort + run analysis (+ 70-permutation neighbour annotation)
+// Kernels (DESIGN.md §4 has the mapping, the bound and the algorithmic bytes of each)
+//   seed lookup      k_find_matches (8 lanes per cluster, prefix directory + bisection of the resident 32-mer table, ExactMaskMatcher's
+//                    rules), k_compact_matches
+//   fragment stage   k_build_fragments (candidate positions per cluster) -> k_align_candidates (ungapped alignment per candidate) ->
+//                    k_finish_candidates (consolidation per cluster) -> k_indel_fragments (single-indel detector, wave per listed
+//                    cluster) -> k_gapped_jobs + k_gapped_rescan (banded Smith-Waterman, 16 lanes per problem; bsw_kernel.h) ->
+//                    k_finish_fragments (accept rule, final consolidation)
+//   template stage   k_plan_rescue -> k_rescue_windows -> k_rescue_align -> k_rescue_gapped_plan -> k_gapped_jobs ->
+//                    k_predict_heavy -> k_select (thread per cluster) || k_select_heavy (wave per cluster, own stream); template.h
+//   leaves / formats k_bsw_batch, k_tls_samples, k_load_candidates / k_write_candidates, k_fq_* (fastq_kernel.h)
+//   index builder    k-mer enumeration + hipCUB radix sort + run analysis (+ 70-permutation neighbour annotation), k_prefix_table
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <cstdio>
@@ -547,12 +549,16 @@ __global__ void k_load_candidates(DevParams P, const u8 *bcl, u32 clusterBase, u
 // Template stage.  Mate rescue (ShadowAligner::rescueShadow) is the bulk of the work of the select phase: a 7-mer scan of
 // a window of several hundred reference bases plus one 150-base ungapped alignment per candidate start, for ~1.5 orphans
 // per cluster.  It is planned per cluster, then executed flat:
-//   k_plan_rescue     one thread per cluster: the rescue problems TemplateBuilder would pose (result independent)
-//   k_rescue_windows  one wavefront per problem: the mate's 7-mer table in LDS, the window scanned 64 positions at a time,
-//                     candidate starts collected in a per-problem bitmap (sorted + unique for free)
-//   k_rescue_align    one thread per candidate start: UngappedAligner::alignUngapped
-//   k_select          one thread per cluster: consumes the aligned candidates, pair / orphan selection, alignment scores,
-//                     clippers, FragmentHeader records
+//   k_plan_rescue         one thread per cluster: the rescue problems TemplateBuilder would pose (result independent)
+//   k_rescue_windows      one wavefront per problem: the mate's 7-mer table in LDS, the window scanned 1024 positions at a time
+//                         (16 per lane), candidate starts collected in a per-problem bitmap (sorted + unique for free)
+//   k_rescue_align        one thread per candidate start: UngappedAligner::alignUngapped
+//   k_rescue_gapped_plan  one thread per problem: rank of every aligned candidate, the best one, which get a gapped retry
+//   k_gapped_jobs         16 lanes per retry (bsw_kernel.h)
+//   k_predict_heavy       one thread per cluster: which clusters cannot fit the light work lists
+//   k_select              one thread per cluster: consumes the rescue results, pair / orphan selection, alignment scores,
+//                         clippers, FragmentHeader records
+//   k_select_heavy        one wave per predicted cluster, on its own stream next to k_select
 static const u32 KMER_EMPTY = 0xffffffffu;
 static const u32 RW_TABLE = 512;          // hash slots for the mate's <= 250-odd 7-mers
 static const u32 RW_LDS_BITMAP = 64;      // words: windows up to ~1900 bases keep their candidate bitmap in LDS
