@@ -641,6 +641,53 @@ int oracle_template_builder_literal(const char *const *contig_bases, uint32_t n_
     catch (const std::exception &e) { g_error = e.what(); return 1; }
 }
 
+// ---- lib/alignment/cppunit/testShadowAligner.cpp:56-252: reads of 81 and 92 bases copied from a contig (getBcl of BuilderInit.hh with
+// explicit strands), an orphan on read 1 at position 0, its mate rescued; then the mate found is used as the orphan and read 1 rescued.
+// out[0] = the rescued mate, out[1] = read 1 rescued back; ok[k] = what rescueShadow returned
+int oracle_shadow_aligner_literal(const char *const *contig_bases, uint32_t n_contigs, uint32_t bcl_contig, int32_t offset0, int32_t offset1, int reverse0, int reverse1,
+                                  uint32_t tls_min, uint32_t tls_max, uint32_t tls_median, uint32_t tls_low, uint32_t tls_high, int model0, int model1,
+                                  int orphan_reverse, oracle_literal_fragment *out /* 2 */, uint32_t *first_cigar_word /* 2 */, uint32_t *ok /* 2 */)
+{
+    try
+    {
+        ContigList contigs;
+        for (uint32_t i = 0; i < n_contigs; ++i) { Contig c; c.index = 0; c.name = "c"; c.forward.assign(contig_bases[i], contig_bases[i] + strlen(contig_bases[i])); contigs.push_back(c); }
+        Params p;
+        p.gapMatchScore = 2; p.gapMismatchScore = -1; p.gapOpenScore = -15; p.gapExtendScore = -3; p.minGapExtendScore = 25; p.gappedMismatchesMax = 8;
+        { ReadMetadata a = { 81, 0, 0, 1 }, b = { 92, 1, 81, 82 }; p.reads.push_back(a); p.reads.push_back(b); }
+        const std::vector<char> &forward = contigs.at(bcl_contig).forward;
+        std::vector<char> reverse;
+        for (size_t i = forward.size(); i-- > 0;) { const char b = forward[i]; reverse.push_back(b == 'A' ? 'T' : b == 'C' ? 'G' : b == 'G' ? 'C' : b == 'T' ? 'A' : 'N'); }
+        const std::vector<char> &s0 = reverse0 ? reverse : forward, &s1 = reverse1 ? reverse : forward;
+        std::string bases(s0.begin() + offset0, s0.begin() + offset0 + 81);
+        bases += std::string(s1.begin() + offset1, s1.begin() + offset1 + 92);
+        std::vector<uint8_t> bcl;
+        for (size_t i = 0; i < bases.size(); ++i) { const char b = bases[i]; bcl.push_back(uint8_t((40 << 2) | (b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : 3))); }
+        Cluster cluster; cluster.init(p.reads, bcl.data(), 1101, 999, true);
+        const TemplateLengthStatistics tls(tls_min, tls_max, tls_median, tls_low, tls_high, TemplateLengthStatistics::AlignmentModel(model0), TemplateLengthStatistics::AlignmentModel(model1), -1);
+        ShadowAligner shadowAligner(p);
+        FragmentMetadataList shadowList; shadowList.reserve(50);
+        FragmentMetadata orphan; orphan.cluster = &cluster; orphan.readIndex = 0; orphan.contigId = bcl_contig; orphan.position = 0; orphan.reverse = orphan_reverse != 0;
+        for (unsigned k = 0; k < 2; ++k)
+        {
+            shadowList.clear();
+            ok[k] = shadowAligner.rescueShadow(contigs, orphan, shadowList, 50, p.reads, tls, 0);
+            if (!ok[k] || shadowList.empty()) { ok[k] = 0; break; }
+            const FragmentMetadata f = shadowList[0];
+            oracle_literal_fragment &o = out[k];
+            o.contig_id = f.contigId; o.position = f.position; o.observed_length = f.observedLength; o.read_index = f.readIndex; o.reverse = f.reverse;
+            o.cigar_offset = f.cigarOffset; o.cigar_length = f.cigarLength; o.mismatch_count = f.mismatchCount; o.log_probability = f.logProbability;
+            o.unique_seed_count = f.uniqueSeedCount; o.alignment_score = f.alignmentScore; o.no_match = f.isNoMatch();
+            // the test reads getCigarBuffer()[0]: on its own genome the mate is the first candidate of the window.  With other draws of
+            // the contigs chance 7-mer hits come first, so the word reported is the rescued fragment's own first CIGAR word
+            first_cigar_word[k] = f.cigarLength ? shadowAligner.shadowCigarBuffer.at(f.cigarOffset) : 0;
+            orphan = f;
+        }
+        return 0;
+    }
+    catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+
 // ---- literal entry points for the known-answer vectors of lib/alignment/cppunit/testTemplateLengthStatistics.cpp
 int oracle_tls_alignment_model(int64_t pos1, int reverse1, int64_t pos2, int reverse2)
 {

@@ -14,6 +14,7 @@ What is extracted is DATA: the literal inputs and the asserted outputs of
   * lib/alignment/cppunit/testTemplateLengthStatistics.cpp:42-367 -> template_length_statistics.json (asserted literals only)
   * lib/alignment/cppunit/testSemialignedClipper.cpp:189-251, testOverlappingEndsClipper.cpp:109-157 -> clippers.json
   * lib/alignment/cppunit/testTemplateBuilder.cpp:96-373 (+ BuilderInit.hh fixture recipe) -> template_builder.json
+  * lib/alignment/cppunit/testShadowAligner.cpp:56-252 -> shadow_aligner.json
 No reference source text is stored.
 """
 import ctypes
@@ -430,7 +431,54 @@ def make_template_builder():
     return len(out["cases"]), sum(len(f) for c in out["cases"] for f in c["expected"]["fragments"])
 
 
+def make_shadow_aligner():
+    """testShadowAligner.cpp: four blocks (two tests x two orientations); in each an orphan on read 1 rescues its mate and the mate
+    found rescues read 1 back.  Inputs: the getBcl() arguments, the template length statistics and the orphan's strand; expected:
+    every asserted field of the two rescued fragments.  Contigs as in the fixture (getContigList(190, 300, 422)), evaluated at four
+    positions of the glibc rand() stream."""
+    text = strip_comments(open(os.path.join(REF, "testShadowAligner.cpp")).read())
+    m = re.search(r'readMetadataList\(getReadMetadataList\((\d+), (\d+)\)\)', text)
+    lens = (int(m.group(1)), int(m.group(2)))
+    m = re.search(r'contigList\(getContigList\((\d+), (\d+), (\d+)\)\)', text)
+    l0, l1, l4 = int(m.group(1)), int(m.group(2)), int(m.group(3))
+    libc = ctypes.CDLL("libc.so.6")
+    libc.srand(1)
+    fixtures = []
+    for _ in range(4):
+        draw = lambda n: "".join("ACGT"[libc.rand() % 4] for _ in range(n))
+        c2 = draw(230); c4 = draw(l4); c1 = draw(l1); c0 = draw(l0)
+        fixtures.append([c0, c1, c2, "AAAAA" + c2, c4])
+    models = {"FFp": 0, "FRp": 1, "RFp": 2, "RRp": 3, "FFm": 4, "FRm": 5, "RFm": 6, "RRm": 7}
+    blocks = []
+    for blk in re.split(r'const TemplateLengthStatistics tls\(', text)[1:]:
+        a = [x.strip() for x in blk[:blk.index(")")].split(",")]
+        tls = {"min": int(a[0]), "max": int(a[1]), "median": int(a[2]), "low_std_dev": int(a[3]), "high_std_dev": int(a[4]),
+               "model0": models[a[5].split("::")[1]], "model1": models[a[6].split("::")[1]]}
+        b = re.search(r'getBcl\(readMetadataList, contigList, (\d+), (\d+), (\d+), (true|false), (true|false)\)', blk)
+        orphan_reverse = re.search(r'fragment0\.reverse = (true|false);', blk).group(1) == "true"
+        halves = re.split(r'fragment0 = fragment1;', blk)
+        exp = []
+        for half, who in ((halves[0], "fragment1"), (halves[1], "fragment0")):
+            g = lambda pat, conv=int: conv(re.search(pat, half).group(1))
+            exp.append({"position": g(r'CPPUNIT_ASSERT_EQUAL\((\d+)L, ' + who + r'\.position\)'),
+                        "reverse": re.search(r'CPPUNIT_ASSERT_EQUAL\((true|false), ' + who + r'\.reverse\)', half).group(1) == "true",
+                        "observed_length": g(r'CPPUNIT_ASSERT_EQUAL\((\d+)U, ' + who + r'\.observedLength\)'),
+                        "mismatch_count": g(r'CPPUNIT_ASSERT_EQUAL\((\d+)U, ' + who + r'\.mismatchCount\)'),
+                        "cigar_offset": g(r'CPPUNIT_ASSERT_EQUAL\((\d+)U, ' + who + r'\.cigarOffset\)'),
+                        "cigar_length": g(r'CPPUNIT_ASSERT_EQUAL\((\d+)U, ' + who + r'\.cigarLength\)'),
+                        "first_cigar_word": g(r'CPPUNIT_ASSERT_EQUAL\((\d+)U << 4, shadowAligner\.getCigarBuffer\(\)\[0\]\)') << 4,
+                        "log_probability": g(r'CPPUNIT_ASSERT_DOUBLES_EQUAL\((-[0-9.]+), ' + who + r'\.logProbability', float),
+                        "log_probability_tolerance": g(r'CPPUNIT_ASSERT_DOUBLES_EQUAL\(-[0-9.]+, ' + who + r'\.logProbability, ([0-9.]+)\)', float)})
+        blocks.append({"tls": tls, "bcl": {"contig": int(b.group(1)), "offset0": int(b.group(2)), "offset1": int(b.group(3)), "reverse0": b.group(4) == "true", "reverse1": b.group(5) == "true"},
+                       "orphan_reverse": orphan_reverse, "expected": exp})
+    assert len(blocks) == 4, len(blocks)
+    json.dump({"source": "lib/alignment/cppunit/testShadowAligner.cpp:56-252, BuilderInit.hh:122-169", "read_lengths": lens, "fixtures": fixtures, "blocks": blocks},
+              open(os.path.join(OUT, "shadow_aligner.json"), "w"), indent=1)
+    return len(blocks)
+
+
 if __name__ == "__main__":
+    print("shadow_aligner blocks:", make_shadow_aligner())
     print("template_builder cases, asserted fragment fields:", make_template_builder())
     print("clippers:", make_clippers())
     print("template_length_statistics asserts:", make_template_length_statistics())

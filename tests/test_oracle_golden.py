@@ -181,3 +181,34 @@ def test_template_builder_known_answers(oracle):
                 for k, v in exp["fragments"][i].items():
                     got = getattr(out[i], k)
                     assert got == (int(v) if isinstance(v, bool) else v), (case["name"], i, k, got, v)
+
+
+def test_shadow_aligner_known_answers(oracle):
+    """testShadowAligner.cpp:56-252: an orphan rescues its mate, the mate rescues the orphan back, in both orientations and on a
+    short and a long contig: position, strand, observed length, CIGAR and log probability as asserted there"""
+    import ctypes as C
+    g = json.load(open(os.path.join(GOLDEN, "shadow_aligner.json")))
+    assert tuple(g["read_lengths"]) == (81, 92)
+
+    class Frag(C.Structure):
+        _fields_ = [("contig_id", C.c_uint32), ("position", C.c_int64), ("observed_length", C.c_uint32), ("read_index", C.c_uint32), ("reverse", C.c_uint32),
+                    ("cigar_offset", C.c_uint32), ("cigar_length", C.c_uint32), ("mismatch_count", C.c_uint32), ("log_probability", C.c_double),
+                    ("unique_seed_count", C.c_uint32), ("alignment_score", C.c_uint32), ("no_match", C.c_uint32)]
+    lib = oracle.lib
+    for fixture in g["fixtures"]:
+        contigs = (C.c_char_p * len(fixture))(*[c.encode() for c in fixture])
+        for blk in g["blocks"]:
+            out, words, ok = (Frag * 2)(), (C.c_uint32 * 2)(), (C.c_uint32 * 2)()
+            t, b = blk["tls"], blk["bcl"]
+            rc = lib.oracle_shadow_aligner_literal(contigs, C.c_uint32(len(fixture)), C.c_uint32(b["contig"]), b["offset0"], b["offset1"], int(b["reverse0"]), int(b["reverse1"]),
+                                                   C.c_uint32(t["min"]), C.c_uint32(t["max"]), C.c_uint32(t["median"]), C.c_uint32(t["low_std_dev"]), C.c_uint32(t["high_std_dev"]),
+                                                   t["model0"], t["model1"], int(blk["orphan_reverse"]), out, words, ok)
+            assert rc == 0 and list(ok) == [1, 1], (blk, list(ok))
+            for k, e in enumerate(blk["expected"]):
+                f = out[k]
+                assert f.contig_id == b["contig"] and f.read_index == (1 - k)
+                # cigarOffset is 0 in the reference's run because the mate happens to be the first candidate of its window there; on
+                # other draws of the rand() contigs chance 7-mer hits precede it, so the fragment's own CIGAR word is compared instead
+                assert (f.position, bool(f.reverse), f.observed_length, f.mismatch_count, f.cigar_length, words[k]) == (
+                    e["position"], e["reverse"], e["observed_length"], e["mismatch_count"], e["cigar_length"], e["first_cigar_word"]), (blk, k)
+                assert abs(f.log_probability - e["log_probability"]) <= e["log_probability_tolerance"]
