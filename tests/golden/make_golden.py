@@ -15,6 +15,7 @@ What is extracted is DATA: the literal inputs and the asserted outputs of
   * lib/alignment/cppunit/testSemialignedClipper.cpp:189-251, testOverlappingEndsClipper.cpp:109-157 -> clippers.json
   * lib/alignment/cppunit/testTemplateBuilder.cpp:96-373 (+ BuilderInit.hh fixture recipe) -> template_builder.json
   * lib/alignment/cppunit/testShadowAligner.cpp:56-252 -> shadow_aligner.json
+  * lib/alignment/cppunit/testFragmentBuilder.cpp:33-598 (seed matches -> candidates) -> fragment_builder.json
 No reference source text is stored.
 """
 import ctypes
@@ -477,7 +478,102 @@ def make_shadow_aligner():
     return len(blocks)
 
 
+def make_fragment_builder():
+    """testFragmentBuilder.cpp: seed matches (SeedId, ReferencePosition) in, FragmentBuilder::build candidates out.  For every test:
+    the match list it pushes, the cluster it builds for, and every asserted value (list sizes, CIGAR buffer words, fragment fields,
+    log probabilities with the test's tolerance).  Fixture (BuilderInit.hh:122-132, getContigList() defaults): contigs drawn with
+    glibc rand() at eight positions of the default-seed stream; the clusters' BCL bytes are evaluated per fixture from the
+    constructor's recipes (:41-52).  testMismatches presumes bases of the drawn contig (its own sanity asserts at :383-390, :447);
+    `mismatch_fixtures` lists the fixtures for which they hold."""
+    text = strip_comments(open(os.path.join(REF, "testFragmentBuilder.cpp")).read())
+    libc = ctypes.CDLL("libc.so.6")
+    libc.srand(1)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    rc = lambda s: "".join(comp[b] for b in reversed(s))
+    enc = lambda bases: [(40 << 2) | "ACGT".index(b) for b in bases]
+    m = re.search(r'bcl0\(getBcl\(readMetadataList, contigList, (\d+), (\d+), (\d+)\)\)', text); b0 = [int(x) for x in m.groups()]
+    m = re.search(r'bcl2\(getBcl\(readMetadataList, contigList, (\d+), (\d+), (\d+)\)\)', text); b2 = [int(x) for x in m.groups()]
+    m = re.search(r'bcl3\(subv\(bcl0, 0,(\d+)\) \+\s*"(.)" \+\s*subv\(bcl0, (\d+), (\d+)\) \+\s*"(.)" \+\s*subv\(bcl0, (\d+)\)\)', text)
+    assert m and int(m.group(3)) == int(m.group(1)) + 1 and int(m.group(6)) == int(m.group(3)) + int(m.group(4)) + 1
+    at0, ch0, at1, ch1 = int(m.group(1)), ord(m.group(2)), int(m.group(3)) + int(m.group(4)), ord(m.group(5))
+    assert re.search(r'bcl4l\(getBcl\(substr\(contigList\[4\]\.forward_, 0, 44\) \+ substr\(contigList\[4\]\.forward_, 0, 56\) \+\s*substr\(reverseComplement\(contigList\[4\]\.forward_\), 0, 42\) \+ substr\(reverseComplement\(contigList\[4\]\.forward_\), 0, 58\)\)\)', text)
+    assert re.search(r'bcl4t\(getBcl\(substr\(contigList\[4\]\.forward_, 16, 44\) \+ substr\(contigList\[4\]\.forward_, 0, 56\) \+\s*substr\(reverseComplement\(contigList\[4\]\.forward_\), 18, 42\) \+ substr\(reverseComplement\(contigList\[4\]\.forward_\), 0, 58\)\)\)', text)
+    assert re.search(r"bcl4lt\(getBcl\(std::vector<char>\(10, 'A'\) \+ contigList\[4\]\.forward_ \+ std::vector<char>\(30, 'C'\) \+\s*std::vector<char>\(15, 'G'\) \+ reverseComplement\(contigList\[4\]\.forward_\) \+ std::vector<char>\(25, 'T'\)\)\)", text)
+    tiles = {"tile0": int(re.search(r'tile0\((\d+)\)', text).group(1)), "tile2": int(re.search(r'tile2\((\d+)\)', text).group(1))}
+    cluster_ids = {"clusterId0": int(re.search(r'clusterId0\((\d+)\)', text).group(1)), "clusterId2": int(re.search(r'clusterId2\((\d+)\)', text).group(1))}
+    fixtures, mismatch_fixtures = [], []
+    for k in range(8):
+        draw = lambda n: "".join("ACGT"[libc.rand() % 4] for _ in range(n))
+        c2 = draw(230); c4 = draw(60); c1 = draw(220); c0 = draw(210)
+        contigs = [c0, c1, c2, "AAAAA" + c2, c4]
+        def get_bcl(contig, o0, o1):
+            f = contigs[contig]
+            return enc(f[o0:o0 + 100] + rc(f)[o1:o1 + 100])
+        bcl0 = get_bcl(*b0)
+        bcl3 = list(bcl0); bcl3[at0] = ch0; bcl3[at1] = ch1
+        r4 = rc(c4)
+        clusters = {"cluster0": bcl0, "cluster2": get_bcl(*b2), "cluster3": bcl3,
+                    "cluster4l": enc(c4[0:44] + c4[0:56] + r4[0:42] + r4[0:58]),
+                    "cluster4t": enc(c4[16:60] + c4[0:56] + r4[18:60] + r4[0:58]),
+                    "cluster4lt": enc("A" * 10 + c4 + "C" * 30 + "G" * 15 + r4 + "T" * 25)}
+        assert all(len(v) == 200 for v in clusters.values())
+        fixtures.append({"contigs": contigs, "clusters": {n: bytes(v).hex() for n, v in clusters.items()}})
+        # the sanity asserts of testMismatches
+        if (bcl0[at0] & 3) != (bcl3[at0] & 3) and (bcl0[at1] & 3) != (bcl3[at1] & 3) and (bcl3[at0] & 3) == 0:
+            mismatch_fixtures.append(k)
+    assert mismatch_fixtures
+    seed_offsets = [0, 32, 64, 0, 32, 64]          # BuilderInit.hh:33-45
+    ctor = re.search(r'FragmentBuilder fragmentBuilder\(flowcells, (\d+), seedMetadataList\.size\(\)/2, (\d+), (true|false),', text)
+    ops = {"ALIGN": 0, "SOFT_CLIP": 4}
+    cases = []
+    def body_of(name):
+        a = text.index("::" + name + "(")
+        b = text.find("\nvoid ", a + 10)
+        return text[a:b if b >= 0 else len(text)]
+    def one(name, body, env):
+        ev = lambda e: int(eval(e, {}, env))
+        matches = [{"tile": tiles[t], "cluster": cluster_ids[c], "seed": ev(s), "reverse": r == "true", "contig": int(ct), "position": ev(pos)}
+                   for t, c, s, r, ct, pos in re.findall(r'SeedId\((tile\d), 0, (clusterId\d), (\w+), (true|false)\s*\), ReferencePosition\((\d+), ([^)]+)\)', body)]
+        cl = re.search(r'matchList\.begin\(\), matchList\.end\(\), (cluster\w+), (true|false)\)', body)
+        threshold = int(re.search(r'FragmentBuilder fragmentBuilder\(flowcells, (\d+),', body).group(1))
+        exp = {"fragments": {}, "cigar_words": {}, "list_sizes": {}, "cigar_buffer_size": None}
+        for n, i in re.findall(r'CPPUNIT_ASSERT_EQUAL\(\(size_t\)(\d+), fragmentBuilder\.getFragments\(\)\[(\d)\]\.size\(\)\)', body): exp["list_sizes"][i] = int(n)
+        m = re.search(r'CPPUNIT_ASSERT_EQUAL\(\(size_t\)(\d+), fragmentBuilder\.getCigarBuffer\(\)\.size\(\)\)', body)
+        if m: exp["cigar_buffer_size"] = int(m.group(1))
+        for ln, op, k in re.findall(r'CPPUNIT_ASSERT_EQUAL\(\(unsigned\)\(\((\d+)<<4\)\|Cigar::(\w+)\), fragmentBuilder\.getCigarBuffer\(\)\[(\d+)\]\)', body):
+            w = (int(ln) << 4) | ops[op]
+            assert exp["cigar_words"].get(k, w) == w
+            exp["cigar_words"][k] = w
+        for lit, i, j, field in re.findall(r'CPPUNIT_ASSERT_EQUAL\((?:\(\w+ ?\w*\s?\))?(\w+), fragmentBuilder\.getFragments\(\)\[(\d)\]\[(\d)\]\.(\w+)\)', body):
+            v = {"true": 1, "false": 0}.get(lit)
+            if v is None: v = int(re.match(r'^(\d+)[UL]*$', lit).group(1))
+            exp["fragments"].setdefault(i + "," + j, {})[field] = v
+        for lit, i, j, tol in re.findall(r'CPPUNIT_ASSERT_DOUBLES_EQUAL\(\(double\)(-[0-9.]+), fragmentBuilder\.getFragments\(\)\[(\d)\]\[(\d)\]\.logProbability, \(double\)([0-9.]+)\)', body):
+            exp["fragments"].setdefault(i + "," + j, {})["logProbability"] = [float(lit), float(tol)]
+        cases.append({"name": name, "matches": matches, "cluster": cl.group(1) if cl else None, "with_gaps": (cl.group(2) == "true") if cl else True,
+                      "repeat_threshold": threshold, "expected": exp})
+    aux = body_of("auxSingleSeed")
+    for name in ("testSingleSeed", "testSeedOffset"):
+        s0, s1 = [int(x) for x in re.search(r'auxSingleSeed\((\d+), (\d+)\)', body_of(name)).groups()]
+        one(name, aux, {"s0": s0, "s1": s1, "offset0": seed_offsets[s0], "offset1": seed_offsets[s1]})
+    for name in ("testMultiSeed", "testRepeats", "testMismatches", "testLeadingSoftClips", "testTrailingSoftClips", "testLeadingAndTrailingSoftClips"):
+        body = body_of(name)
+        env = {}
+        for var, val in re.findall(r'const unsigned (s[01]) = (\d+);', body): env[var] = int(val)
+        if "s0" in env: env.update(offset0=seed_offsets[env["s0"]], offset1=seed_offsets[env["s1"]])
+        one(name, body, env)
+    for c in cases:
+        assert c["matches"] and c["cluster"] and c["expected"]["fragments"], c["name"]
+    n_asserts = sum(len(f) for c in cases for f in c["expected"]["fragments"].values()) + sum(len(c["expected"]["cigar_words"]) + len(c["expected"]["list_sizes"]) for c in cases)
+    json.dump({"source": "lib/alignment/cppunit/testFragmentBuilder.cpp:33-598, BuilderInit.hh:33-169", "read_lengths": [100, 100], "seed_offsets": seed_offsets, "seed_length": 32,
+               "gapped_mismatches_max": int(ctor.group(2)), "scores": [2, -1, -15, -3, 25], "gap_limit": 20000,
+               "fixtures": fixtures, "mismatch_fixtures": mismatch_fixtures, "cases": cases},
+              open(os.path.join(OUT, "fragment_builder.json"), "w"), indent=1)
+    return len(cases), n_asserts
+
+
 if __name__ == "__main__":
+    print("fragment_builder cases, asserted values:", make_fragment_builder())
     print("shadow_aligner blocks:", make_shadow_aligner())
     print("template_builder cases, asserted fragment fields:", make_template_builder())
     print("clippers:", make_clippers())

@@ -54,3 +54,56 @@ def sort_matches(m):
     cluster = (m["seed_id"] >> np.uint64(9)) & np.uint64(0x7fffffff)
     order = np.lexsort((m["seed_id"] & np.uint64(0x1ff), m["location"], cluster))
     return m[order]
+
+
+# ---- lib/alignment/cppunit/testFragmentBuilder.cpp vectors (tests/golden/fragment_builder.json)
+CANDIDATE_FIELD = {"contigId": "contig_id", "uniqueSeedCount": "unique_seed_count", "position": "position", "observedLength": "observed_length", "readIndex": "read_index",
+                   "reverse": "reverse", "cigarOffset": "cigar_offset", "cigarLength": "cigar_length", "mismatchCount": "mismatch_count"}
+
+
+def fragment_builder_params(g, repeat_threshold, device_limits=False):
+    """the FragmentBuilder the test constructs (:92-94): 100 + 100 cycles, three 32-mer seeds per read at 0 / 32 / 64.
+    device_limits: the test's repeat thresholds (123, 456) are above what the device library accepts (1..16, its fixed candidate
+    capacity); no case has more than two candidates per read, so the largest accepted value gives the same lists."""
+    if device_limits:
+        repeat_threshold = min(repeat_threshold, 16)
+    from isaac_aligner_amd import options
+    p = options.default_params(*g["read_lengths"], gap_scoring="eland", gapped_mismatches_max=g["gapped_mismatches_max"], semialigned_gap_limit=g["gap_limit"],
+                               repeat_threshold=repeat_threshold, min_gap_extend=g["scores"][4])
+    assert [p.gap_match, p.gap_mismatch, p.gap_open, p.gap_extend, p.min_gap_extend] == g["scores"]
+    p.n_seeds = len(g["seed_offsets"])
+    for i, offset in enumerate(g["seed_offsets"]):
+        p.seeds[i].offset, p.seeds[i].length, p.seeds[i].read_index = offset, g["seed_length"], i // 3
+    return p
+
+
+def fragment_builder_inputs(case, fixture, seed_id):
+    """(bcl [n_clusters, 200] with the test's cluster at its own id, match records, tile) for one test of the suite"""
+    cluster = case["matches"][0]["cluster"]
+    bcl = np.zeros((cluster + 1, 200), np.uint8)
+    bcl[cluster] = np.frombuffer(bytes.fromhex(fixture["clusters"][case["cluster"]]), np.uint8)
+    m = np.zeros(len(case["matches"]), abi.MATCH_DTYPE)
+    for k, x in enumerate(case["matches"]):
+        m["seed_id"][k] = seed_id(x["tile"], 0, x["cluster"], x["seed"], int(x["reverse"]))
+        m["location"][k] = ((x["contig"] + 1) << 41) | (x["position"] << 1)
+    return bcl, m, case["matches"][0]["tile"]
+
+
+def check_fragment_builder_case(case, cands, cigars):
+    """every value the reference test asserts, on candidates in (read, list order) with CIGAR offsets into `cigars`"""
+    exp = case["expected"]
+    lists = [cands[cands["read_index"] == r] for r in (0, 1)]
+    for r, n in exp["list_sizes"].items():
+        assert len(lists[int(r)]) == n, (case["name"], r, len(lists[int(r)]), n)
+    if exp["cigar_buffer_size"] is not None:
+        assert len(cigars) == exp["cigar_buffer_size"], (case["name"], len(cigars))
+    for k, w in exp["cigar_words"].items():
+        assert int(cigars[int(k)]) == w, (case["name"], k, int(cigars[int(k)]), w)
+    for key, fields in exp["fragments"].items():
+        r, j = [int(x) for x in key.split(",")]
+        f = lists[r][j]
+        for name, v in fields.items():
+            if name == "logProbability":
+                assert abs(float(f["log_probability"]) - v[0]) <= v[1], (case["name"], key, float(f["log_probability"]), v)
+            else:
+                assert int(f[CANDIDATE_FIELD[name]]) == v, (case["name"], key, name, int(f[CANDIDATE_FIELD[name]]), v)

@@ -337,6 +337,33 @@ def test_template_builder_known_answers_on_the_gpu(torch):
                     assert r["observed_length"][i] == e["observed_length"]
 
 
+def test_fragment_builder_known_answers_on_the_gpu(torch, oracle):
+    """lib/alignment/cppunit/testFragmentBuilder.cpp:33-598 through isaac_gpu_build_fragments: the reference's hand-made seed match
+    lists in, the candidate lists, CIGAR words and log probabilities its test asserts out (clusters at the test's own ids 1234 and
+    12345 of the tile)"""
+    import json
+    import os
+    from isaac_aligner_amd import gpu
+    from parity_util import check_fragment_builder_case, fragment_builder_inputs, fragment_builder_params
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fragment_builder.json")))
+    for k, fixture in enumerate(g["fixtures"]):
+        for case in g["cases"]:
+            if case["name"] == "testMismatches" and k not in g["mismatch_fixtures"]:
+                continue
+            p = fragment_builder_params(g, case["repeat_threshold"], device_limits=True)
+            al = gpu.Aligner(p, 0, [c.encode() for c in fixture["contigs"]])
+            bcl, matches, tile = fragment_builder_inputs(case, fixture, oracle.seed_id)
+            cluster = len(bcl) - 1
+            offsets = np.zeros(len(bcl) + 1, np.int64)
+            offsets[cluster + 1:] = len(matches)
+            dev_matches = torch.from_numpy(matches.view(np.uint64).view(np.int64).reshape(-1, 2).copy()).to(al.device)
+            cands, cigars = al.build_fragments(torch.from_numpy(bcl).to(al.device), dev_matches, torch.from_numpy(offsets).to(al.device), tile=tile,
+                                               with_gaps=case["with_gaps"], trim=False)
+            assert (cands["cluster"] == cluster).all()
+            check_fragment_builder_case(case, cands, cigars)
+            al.close()
+
+
 def test_deferred_completion_pipelines_select_calls(torch, monkeypatch):
     """ISAAC_GPU_DEFERRED_COMPLETION=1: isaac_gpu_select returns with its last wave-per-cluster pass still running, the next call
     overlaps it, isaac_gpu_synchronize completes everything.  Same records as the synchronous calls, batch for batch."""

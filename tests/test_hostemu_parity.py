@@ -125,3 +125,22 @@ def test_template_code_reproduces_reference_known_answers(emulib):
                     assert abi.refpos_contig(rec["f_strand_position"][i:i + 1])[0] == e["contig_id"], (case["name"], i)
                 if "observed_length" in e:
                     assert rec["observed_length"][i] == e["observed_length"], (case["name"], i)
+
+
+def test_fragment_code_reproduces_reference_known_answers(oracle, emulib):
+    """lib/alignment/cppunit/testFragmentBuilder.cpp:33-598 through the device headers (candidate building, ungapped alignment,
+    contig-end soft clips, consolidation): the values the reference's test asserts, not only agreement with the oracle"""
+    import json
+    import os
+    from parity_util import check_fragment_builder_case, fragment_builder_inputs, fragment_builder_params
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fragment_builder.json")))
+    for k in g["mismatch_fixtures"][:2]:              # two draws of the contigs on which every test of the suite applies
+        fixture = g["fixtures"][k]
+        contigs = [c.encode() for c in fixture["contigs"]]
+        for case in g["cases"]:
+            p = fragment_builder_params(g, case["repeat_threshold"], device_limits=True)
+            bcl, matches, _ = fragment_builder_inputs(case, fixture, oracle.seed_id)
+            emu = hostemu_lib.Emu(emulib, p, contigs)
+            emu.set_matches(matches, len(bcl))
+            cands, cigars = emu.build_fragments(bcl, len(bcl), with_gaps=case["with_gaps"], trim=False)
+            check_fragment_builder_case(case, cands, cigars)

@@ -212,3 +212,23 @@ def test_shadow_aligner_known_answers(oracle):
                 assert (f.position, bool(f.reverse), f.observed_length, f.mismatch_count, f.cigar_length, words[k]) == (
                     e["position"], e["reverse"], e["observed_length"], e["mismatch_count"], e["cigar_length"], e["first_cigar_word"]), (blk, k)
                 assert abs(f.log_probability - e["log_probability"]) <= e["log_probability_tolerance"]
+
+
+def test_fragment_builder_known_answers(oracle):
+    """testFragmentBuilder.cpp:33-598: hand-made seed match lists -> FragmentBuilder::build candidates (single seed, seed offsets,
+    several seeds of one alignment, repeats on two contigs, mismatches and their log probabilities, alignments hanging over
+    either end of a short contig and the soft clips they get)"""
+    from parity_util import check_fragment_builder_case, fragment_builder_inputs, fragment_builder_params
+    g = load("fragment_builder.json")
+    for k, fixture in enumerate(g["fixtures"]):
+        ref = oracle.reference([c.encode() for c in fixture["contigs"]])
+        for case in g["cases"]:
+            if case["name"] == "testMismatches" and k not in g["mismatch_fixtures"]:
+                continue
+            p = fragment_builder_params(g, case["repeat_threshold"])
+            bcl, matches, tile = fragment_builder_inputs(case, fixture, oracle.seed_id)
+            cands, cigars = ref.build_fragments(p, bcl, matches, tile=tile, with_gaps=case["with_gaps"], trim=False)
+            check_fragment_builder_case(case, cands, cigars)
+    # testEmptyMatchList (:84-104): nothing in, nothing out
+    cands, cigars = ref.build_fragments(p, bcl, matches[:0], tile=tile, with_gaps=True, trim=False)
+    assert len(cands) == 0 and len(cigars) == 0
