@@ -727,4 +727,116 @@ void oracle_tls_add_templates_sequence(int drift, uint32_t *out)
     out[8] = tls.addTemplate(f); out[9] = tls.isStable();
 }
 
+
+// ---- bit layouts and oligo helpers behind the seed lookup and the index builder, as the reference's small unit tests drive them
+// matchFinder::ClusterInfo (testMatchFinderClusterInfo.cpp:38-91).  ops: 0 = markReadComplete(arg), 1 = setBarcodeIndex(arg),
+// 2 = unmarkComplete; state_out: { getBarcodeIndex, isBarcodeSet, isReadComplete(0), isReadComplete(1), byte1, byte2 }
+int oracle_cluster_info(int mark_complete_ctor /* -1: default constructor */, const uint32_t *ops, const uint32_t *args, uint32_t n_ops, uint32_t *state_out)
+{
+    try
+    {
+        matchFinder::ClusterInfo c = mark_complete_ctor < 0 ? matchFinder::ClusterInfo() : matchFinder::ClusterInfo(mark_complete_ctor != 0);
+        for (uint32_t i = 0; i < n_ops; ++i)
+        {
+            if (0 == ops[i]) c.markReadComplete(args[i]);
+            else if (1 == ops[i]) c.setBarcodeIndex(args[i]);
+            else c.unmarkComplete();
+        }
+        state_out[0] = c.getBarcodeIndex(); state_out[1] = c.isBarcodeSet(); state_out[2] = c.isReadComplete(0); state_out[3] = c.isReadComplete(1);
+        state_out[4] = c.byte(0); state_out[5] = c.byte(1);
+        return 0;
+    }
+    catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+
+// oligo::KmerGenerator<unsigned>::next until exhausted (testKmerGenerator.cpp:37-77)
+int oracle_kmer_generator(const char *sequence, uint64_t length, uint32_t kmer_length, uint32_t *kmers_out, int64_t *positions_out, uint64_t capacity, uint64_t *n_out)
+{
+    KmerGenerator<unsigned> g(sequence, sequence + length, kmer_length);
+    unsigned kmer; const char *position; uint64_t n = 0;
+    while (g.next(kmer, position))
+    {
+        if (n >= capacity) { g_error = "k-mer capacity"; return 1; }
+        kmers_out[n] = kmer; positions_out[n] = position - sequence; ++n;
+    }
+    *n_out = n;
+    return 0;
+}
+// oligo::generateKmer / getMaxKmer<unsigned long> (testKmerGenerator.cpp:80-97)
+int oracle_generate_kmer(uint32_t kmer_length, const char *sequence, uint64_t length, uint32_t *kmer_out)
+{ unsigned kmer = 0; const bool ok = generateKmer<unsigned>(kmer_length, kmer, sequence, sequence + length); *kmer_out = kmer; return ok; }
+uint64_t oracle_max_kmer(uint32_t kmer_length) { return getMaxKmer<uint64_t>(kmer_length); }
+
+} // extern "C"
+typedef unsigned __int128 u128;
+static u128 make128(uint64_t hi, uint64_t lo) { return (u128(hi) << 64) | lo; }
+template <typename F> static void withKmerType(uint32_t kmer_bases, uint64_t hi, uint64_t lo, uint64_t *out_hi, uint64_t *out_lo, const F &f)
+{
+    if (16 == kmer_bases) { *out_hi = 0; *out_lo = f(uint32_t(lo)); }
+    else if (32 == kmer_bases) { *out_hi = 0; *out_lo = f(uint64_t(lo)); }
+    else { const u128 r = f(make128(hi, lo)); *out_hi = uint64_t(r >> 64); *out_lo = uint64_t(r); }
+}
+struct ApplyPermutate { const Permutate &p; bool reorder; template <typename K> K operator()(K k) const { return reorder ? p.reorder(k) : p(k); } };
+extern "C" {
+// oligo::Permutate(blockLength, from, to)(kmer) or .reorder(kmer) (testPermutate.cpp:41-103); k-mers of 16, 32 or 64 bases as (hi, lo)
+int oracle_permutate(uint32_t block_length, const uint32_t *from, const uint32_t *to, uint32_t count, uint32_t kmer_bases, int reorder, uint64_t hi, uint64_t lo, uint64_t *out_hi, uint64_t *out_lo)
+{
+    try
+    {
+        const Permutate p(block_length, std::vector<unsigned>(from, from + count), std::vector<unsigned>(to, to + count));
+        const ApplyPermutate f = { p, reorder != 0 };
+        withKmerType(kmer_bases, hi, lo, out_hi, out_lo, f);
+        return 0;
+    }
+    catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+} // extern "C"
+// the walk of testPermutate.cpp:105-118 through getPermutateList<KmerT>(errorCount): the k-mer after every permutation applied in
+// turn; ok_out = every intermediate value reorders to the original, and the first permutation is the identity both ways
+struct WalkPermutateList
+{
+    const std::vector<Permutate> &list; mutable bool ok;
+    template <typename K> K operator()(K original) const
+    {
+        ok = original == list.front()(original) && original == list.front().reorder(original);
+        K permuted = original;
+        for (size_t i = 0; i < list.size(); ++i) { permuted = list[i](permuted); ok = ok && original == list[i].reorder(permuted); }
+        ok = ok && original == list.back().reorder(permuted);
+        return permuted;
+    }
+};
+extern "C" {
+int oracle_permutate_list_walk(uint32_t kmer_bases, uint32_t error_count, uint64_t hi, uint64_t lo, uint64_t *list_size, uint64_t *out_hi, uint64_t *out_lo, int *ok_out)
+{
+    try
+    {
+        const std::vector<Permutate> list = getPermutateList(kmer_bases, error_count);
+        const WalkPermutateList w = { list, false };
+        withKmerType(kmer_bases, hi, lo, out_hi, out_lo, w);
+        *list_size = list.size(); *ok_out = w.ok;
+        return 0;
+    }
+    catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+// reference::NeighborsFinder<KmerT>::findNeighbors(kmerList, jobs) on the list as given (testNeighborsFinder.cpp:44-97); 32- or 64-base k-mers
+int oracle_find_neighbors(uint32_t kmer_bases, const uint64_t *hi, const uint64_t *lo, uint64_t n, uint32_t jobs, uint8_t *has_neighbors_out)
+{
+    if (32 == kmer_bases)
+    {
+        std::vector<AnnotatedKmer<uint64_t> > l(n);
+        for (uint64_t i = 0; i < n; ++i) { l[i].value = lo[i]; l[i].hasNeighbors = false; }
+        findNeighbors(l, jobs);
+        for (uint64_t i = 0; i < n; ++i) has_neighbors_out[i] = l[i].hasNeighbors;
+    }
+    else if (64 == kmer_bases)
+    {
+        std::vector<AnnotatedKmer<u128> > l(n);
+        for (uint64_t i = 0; i < n; ++i) { l[i].value = make128(hi[i], lo[i]); l[i].hasNeighbors = false; }
+        findNeighbors(l, jobs);
+        for (uint64_t i = 0; i < n; ++i) has_neighbors_out[i] = l[i].hasNeighbors;
+    }
+    else { g_error = "k-mers of 32 or 64 bases"; return 1; }
+    return 0;
+}
+
 } // extern "C"

@@ -7,11 +7,13 @@
 // directory.  The product path (isaac_aligner_amd/) never includes it.
 //
 // Pinning status: see oracle/README.md.  BandedSmithWaterman, SimpleIndelAligner,
-// FragmentBuilder (gapped/ungapped decision), SeedId, TemplateLengthStatistics, the two
-// end clippers and TemplateBuilder::buildTemplate (MAPQ arithmetic, orphan rescue) are
-// pinned by the reference's own cppunit known-answer vectors (tests/golden/).  Seed
-// lookup (MatchFinder/ExactMaskMatcher) and the FASTQ reader have no reference vectors:
-// "parity unpinned" for those rows.
+// FragmentBuilder (from seed match lists; gapped/ungapped decision), SeedId, ClusterInfo,
+// KmerGenerator, Permutate, NeighborsFinder::findNeighbors, TemplateLengthStatistics, the
+// two end clippers, ShadowAligner::rescueShadow and TemplateBuilder::buildTemplate (MAPQ
+// arithmetic, orphan rescue) are pinned by the reference's own cppunit known-answer
+// vectors (tests/golden/).  The seed lookup proper (ClusterSeedGenerator, MatchFinder /
+// ExactMaskMatcher) and the FASTQ reader have no reference vectors: "parity unpinned"
+// for those rows.
 #pragma once
 #include <stdint.h>
 #include <string>
@@ -20,6 +22,7 @@
 #include <limits>
 #include <cmath>
 #include <algorithm>
+#include <stdexcept>
 
 namespace oracle
 {
@@ -350,9 +353,112 @@ struct FragmentBuilder
     static void consolidateDuplicateFragments(FragmentMetadataList &list, bool removeUnaligned);
 };
 
+// ---------------------------------------------------------------- oligo helpers
+// include/oligo/KmerGenerator.hpp:39-131: successive N-free k-mers of an ASCII sequence (any non-ACGT byte restarts the k-mer).
+// Used by ShadowAligner (7-mers of the shadow and of the rescue window, ShadowAligner.cpp:59,82).
+template <typename T = unsigned>
+struct KmerGenerator
+{
+    const char *current, *end; unsigned kmerLength; T mask; T kmer;
+    static unsigned value(char c) { switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; } }
+    KmerGenerator(const char *b, const char *e, unsigned k) : current(b), end(e), kmerLength(k), mask(T(~((~T(0)) << (2 * k)))), kmer(0) { initialize(); }
+    void initialize()
+    {
+        unsigned currentLength = 0;
+        while ((current < end) && currentLength + 1 < kmerLength)
+        {
+            const unsigned v = value(*current);
+            if (4 > v) { kmer <<= 2; kmer |= v; ++currentLength; } else { currentLength = 0; kmer = 0; }
+            ++current;
+        }
+    }
+    bool next(T &out, const char *&position)
+    {
+        while ((current < end) && (4 <= value(*current))) initialize();
+        if (current < end)
+        {
+            kmer <<= 2; kmer |= value(*current); kmer &= mask; out = kmer; ++current; position = current - kmerLength;
+            return true;
+        }
+        return false;
+    }
+};
+// KmerGenerator.hpp:133-168
+template <typename T> inline T getMaxKmer(unsigned kmerLength) { return T(~(~T(0) << 2 * kmerLength)); }
+template <typename T> inline bool generateKmer(unsigned kmerLength, T &kmer, const char *current, const char *end)
+{
+    for (unsigned todo = kmerLength; todo; --todo, ++current)
+    {
+        if (current == end) return false;
+        kmer <<= 2; kmer |= KmerGenerator<T>::value(*current);
+    }
+    kmer &= getMaxKmer<T>(kmerLength);
+    return true;
+}
+
+// include/oligo/Permutate.hh:43-100, lib/oligo/Permutate.cpp:32-170: a k-mer as `count` blocks of `blockLength` bases (block 0 = the
+// most significant); operator() takes a k-mer from the block order `from` to the block order `to`, reorder() from `to` back to
+// the natural order
+class Permutate
+{
+    unsigned blockLength_, count_;
+    uint64_t order_, absoluteReverseOrder_;
+    static uint64_t encode(const std::vector<unsigned> &from, const std::vector<unsigned> &to);
+    template <typename KmerT> KmerT transform(KmerT kmer, uint64_t order) const
+    {
+        const unsigned blockBits = 2 * blockLength_;
+        const KmerT blockMask = KmerT(~((~KmerT(0)) << blockBits));
+        KmerT ret = 0;
+        for (unsigned origin = 0; origin < count_; ++origin)
+        {
+            const unsigned target = unsigned((order >> ((count_ - origin - 1) * 4)) & 0xf);
+            ret |= KmerT(((kmer >> ((count_ - origin - 1) * blockBits)) & blockMask) << ((count_ - target - 1) * blockBits));
+        }
+        return ret;
+    }
+public:
+    Permutate(unsigned blockLength, const std::vector<unsigned> &from, const std::vector<unsigned> &to);
+    template <typename KmerT> KmerT operator()(KmerT kmer) const { return transform(kmer, order_); }
+    template <typename KmerT> KmerT reorder(KmerT kmer) const { return transform(kmer, absoluteReverseOrder_); }
+};
+// Permutate.cpp:94-145: for `errorCount` tolerated mismatches the k-mer is cut into 2 * errorCount blocks; every choice of
+// errorCount blocks (ascending) becomes the prefix once.  Each Permutate leads from the previous order to the next one.
+std::vector<Permutate> getPermutateList(unsigned kmerBases, unsigned errorCount);
+
+// lib/reference/NeighborsFinder.cpp:286-383: in a list sorted by value, k-mers sharing the upper half are compared on the lower
+// half; both ends of a pair 1..4 mismatches apart get the flag.
+template <typename KmerT> struct AnnotatedKmer { KmerT value; bool hasNeighbors; bool operator<(const AnnotatedKmer &o) const { return value < o.value; } };
+template <typename KmerT> void findNeighbors(std::vector<AnnotatedKmer<KmerT> > &kmerList, unsigned jobs);
+
 // ---------------------------------------------------------------- seeds + matches
-// include/alignment/matchFinder/TileClusterInfo.hh:65-209: per cluster, bit r = read r complete
-typedef std::vector<uint8_t> ClusterInfo;
+// include/alignment/matchFinder/TileClusterInfo.hh:65-143: two bytes per cluster; bit 0 of byte r = read r+1 complete, the six bits
+// above it = one half of the 12-bit barcode index (all ones = no barcode assigned yet)
+namespace matchFinder
+{
+class ClusterInfo
+{
+    uint8_t byte1_, byte2_;
+    static const unsigned FOUND_MASK = 1, BARCODE_HALF_BITS = 6, BARCODE_HALF_MASK = ((1u << BARCODE_HALF_BITS) - 1) << 1;
+public:
+    static const unsigned MAX_BARCODE_VALUE = (1u << (2 * BARCODE_HALF_BITS)) - 1;
+    ClusterInfo() : byte1_(0xff & ~FOUND_MASK), byte2_(0xff & ~FOUND_MASK) {}
+    explicit ClusterInfo(bool markComplete) : byte1_(markComplete ? FOUND_MASK : 0), byte2_(markComplete ? FOUND_MASK : 0) {}
+    unsigned getBarcodeIndex() const { return ((byte1_ & BARCODE_HALF_MASK) >> 1) | (((byte2_ & BARCODE_HALF_MASK) >> 1) << BARCODE_HALF_BITS); }
+    bool isBarcodeSet() const { return MAX_BARCODE_VALUE != getBarcodeIndex(); }
+    void setBarcodeIndex(unsigned barcodeIndex)
+    {
+        if (barcodeIndex >= MAX_BARCODE_VALUE) throw std::invalid_argument("Barcode does not fit in the allowed bit range");
+        byte1_ = uint8_t((byte1_ & FOUND_MASK) | ((barcodeIndex << 1) & BARCODE_HALF_MASK));
+        byte2_ = uint8_t((byte2_ & FOUND_MASK) | (((barcodeIndex >> BARCODE_HALF_BITS) << 1) & BARCODE_HALF_MASK));
+    }
+    bool isReadComplete(unsigned readIndex) const { return ((0 == readIndex) ? byte1_ : byte2_) & FOUND_MASK; }
+    void markReadComplete(unsigned readIndex) { ((0 == readIndex) ? byte1_ : byte2_) |= FOUND_MASK; }
+    void unmarkComplete() { byte1_ &= uint8_t(~FOUND_MASK); byte2_ &= uint8_t(~FOUND_MASK); }
+    uint8_t byte(unsigned i) const { return i ? byte2_ : byte1_; }
+};
+}
+// one tile of matchFinder::TileClusterInfo (:160-209)
+typedef std::vector<matchFinder::ClusterInfo> ClusterInfo;
 // lib/alignment/ClusterSeedGenerator.cpp:138-192 + SeedGeneratorBase.cpp:71-94 (sorted by (kmer, seedIndex))
 void generateSeeds(const Params &p, const std::vector<unsigned> &seedIndexList, const uint8_t *bcl, unsigned nClusters,
                    unsigned tile, const ClusterInfo &complete, std::vector<Seed> &seeds);

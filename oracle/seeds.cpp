@@ -104,7 +104,7 @@ void generateSeeds(const Params &p, const std::vector<unsigned> &seedIndexList, 
         for (size_t s = 0; s < ordered.size(); ++s)
         {
             const SeedMetadata &sm = ordered[s];
-            if ((complete[clusterId] >> sm.readIndex) & 1) continue;
+            if (complete[clusterId].isReadComplete(sm.readIndex)) continue;
             Seed fw = { 0, SeedId(tile, 0, clusterId, sm.index, 0).value };
             Seed rv = { 0, SeedId(tile, 0, clusterId, sm.index, 1).value };
             const uint8_t *baseIt = clusterIt + sm.offset + p.reads.at(sm.readIndex).offset;
@@ -171,7 +171,7 @@ void findMatchesExact(const Params &p, const SortedReference &ref, const std::ve
             {
                 const SeedId id(seeds[s].seedId);
                 Match m = { id.value, tooMany.value }; out.push_back(m);
-                if (closeRepeats) complete[id.getCluster()] |= uint8_t(1 << p.seeds[id.getSeed()].readIndex);
+                if (closeRepeats) complete[id.getCluster()].markReadComplete(p.seeds[id.getSeed()].readIndex);
             }
         }
         else
@@ -181,7 +181,7 @@ void findMatchesExact(const Params &p, const SortedReference &ref, const std::ve
             {
                 const SeedId id(seeds[s].seedId);
                 for (size_t r = 0; r < repeatList.size(); ++r) { Match m = { id.value, repeatList[r].position }; out.push_back(m); }
-                if (p.ignoreNeighbors || !anyPosition.hasNeighbors()) complete[id.getCluster()] |= uint8_t(1 << p.seeds[id.getSeed()].readIndex);
+                if (p.ignoreNeighbors || !anyPosition.hasNeighbors()) complete[id.getCluster()].markReadComplete(p.seeds[id.getSeed()].readIndex);
             }
             for (size_t r = 0; r < repeatList.size(); ++r) // MatchDistribution::addMatches (>= 1 per repeat) -> "contig has matches"
                 contigHasMatches.at(ReferencePosition::fromValue(repeatList[r].position).getContigId()) = 1;
@@ -190,7 +190,7 @@ void findMatchesExact(const Params &p, const SortedReference &ref, const std::ve
     for (size_t i = 0; i < pendingNoMatch.size(); ++i)
     {
         const SeedId id(pendingNoMatch[i].seedId);
-        if (!((complete[id.getCluster()] >> p.seeds[id.getSeed()].readIndex) & 1)) { Match m = { id.value, noMatch.value }; out.push_back(m); }
+        if (!complete[id.getCluster()].isReadComplete(p.seeds[id.getSeed()].readIndex)) { Match m = { id.value, noMatch.value }; out.push_back(m); }
     }
     if (storeNoMatches) // MatchFinder.cpp:231-246
         for (size_t s = endSeeds; s < seeds.size(); ++s) { Match m = { seeds[s].seedId, noMatch.value }; out.push_back(m); }
@@ -211,7 +211,7 @@ void findTileMatches(const Params &p, const SortedReference &ref, const uint8_t 
                      std::vector<Match> &matches, std::vector<uint8_t> &contigHasMatches)
 {
     const std::vector<std::vector<unsigned> > perIteration = seedIndexListPerIteration(p.seeds, unsigned(p.reads.size()), p.firstPassSeeds);
-    ClusterInfo complete(nClusters, 0);
+    ClusterInfo complete(nClusters);      // nothing complete, no barcode (TileClusterInfo.hh:177-184)
     matches.clear();
     std::vector<Seed> seeds;
     generateSeeds(p, perIteration.at(0), bcl, nClusters, tile, complete, seeds);
@@ -232,15 +232,8 @@ void findTileMatches(const Params &p, const SortedReference &ref, const uint8_t 
 // ---------------------------------------------------------------- index builder
 // lib/reference/ReferenceSorter.cpp:105-261: forward-strand k-mers are stored; reverse-complement k-mers only take part in the
 // repeat count.  A k-mer with more than `repeatThreshold` (fwd+rc) occurrences is stored as a single TooManyMatch entry.
-// Neighbor flag (NeighborsFinder.cpp:395-446): set when another distinct reference k-mer (either strand) exists within Hamming
-// distance 1..neighborhoodWidth.  Computed here by the same pigeonhole idea (8 blocks of 4 bases, any 4 blocks equal) but with
-// hashing instead of 70 sorted permutations; small genomes only.
-static unsigned hamming2bit(uint64_t a, uint64_t b)
-{
-    uint64_t x = a ^ b;
-    x = (x | (x >> 1)) & 0x5555555555555555ULL;
-    return unsigned(__builtin_popcountll(x));
-}
+// Neighbor flag (NeighborsFinder.cpp:192-244,395-446): set when another distinct reference k-mer (either strand) exists within
+// Hamming distance 1..4; found as the reference finds it (neighbors.cpp).  Small genomes only.
 
 SortedReference buildSortedReference(const ContigList &contigs, unsigned seedLength, unsigned repeatThreshold, bool annotateNeighbors, unsigned neighborhoodWidth)
 {
@@ -274,25 +267,24 @@ SortedReference buildSortedReference(const ContigList &contigs, unsigned seedLen
     std::vector<uint8_t> hasNeighbor(distinct.size(), 0);
     if (annotateNeighbors && neighborhoodWidth)
     {
-        // choose 4 of 8 4-base blocks as the exact-match key (C(8,4) = 70 choices)
-        for (unsigned mask = 0; mask < 256; ++mask)
+        // NeighborsFinder::generateNeighbors (NeighborsFinder.cpp:192-244): the distinct k-mers of both strands go through the 70
+        // block orders of getPermutateList(4); under each they are sorted and compared inside the blocks of equal prefix
+        if (4 != neighborhoodWidth) throw std::invalid_argument("the neighbour search is defined for 4 mismatches (NeighborsFinder.cpp:196,343-383)");
+        std::vector<AnnotatedKmer<uint64_t> > kmerList(distinct.size());
+        for (size_t i = 0; i < distinct.size(); ++i) { kmerList[i].value = distinct[i]; kmerList[i].hasNeighbors = false; }
+        const std::vector<Permutate> permutateList = getPermutateList(32, neighborhoodWidth);
+        for (size_t k = 0; k < permutateList.size(); ++k)
         {
-            if (__builtin_popcount(mask) != 4) continue;
-            uint64_t keep = 0;
-            for (unsigned b = 0; b < 8; ++b) if ((mask >> b) & 1) keep |= uint64_t(0xff) << (8 * b);
-            std::vector<std::pair<uint64_t, unsigned> > keyed(distinct.size());
-            for (size_t i = 0; i < distinct.size(); ++i) keyed[i] = std::make_pair(distinct[i] & keep, unsigned(i));
-            std::sort(keyed.begin(), keyed.end());
-            for (size_t i = 0; i < keyed.size();)
-            {
-                size_t j = i; while (j < keyed.size() && keyed[j].first == keyed[i].first) ++j;
-                for (size_t a = i; a < j; ++a) for (size_t b = a + 1; b < j; ++b)
-                {
-                    const unsigned d = hamming2bit(distinct[keyed[a].second], distinct[keyed[b].second]);
-                    if (d && d <= neighborhoodWidth) { hasNeighbor[keyed[a].second] = 1; hasNeighbor[keyed[b].second] = 1; }
-                }
-                i = j;
-            }
+            for (size_t i = 0; i < kmerList.size(); ++i) kmerList[i].value = permutateList[k](kmerList[i].value);
+            std::sort(kmerList.begin(), kmerList.end());
+            findNeighbors(kmerList, 1);
+        }
+        for (size_t i = 0; i < kmerList.size(); ++i) kmerList[i].value = permutateList.back().reorder(kmerList[i].value);
+        std::sort(kmerList.begin(), kmerList.end());
+        for (size_t i = 0; i < kmerList.size(); ++i)
+        {
+            if (kmerList[i].value != distinct[i]) throw std::logic_error("neighbour list out of step with the k-mer list");
+            hasNeighbor[i] = kmerList[i].hasNeighbors;
         }
     }
     SortedReference ret;

@@ -221,46 +221,16 @@ ShadowAligner::ShadowAligner(const Params &p)
     shadowCigarBuffer.reserve(1 << 20);
 }
 
-// oligo/KmerGenerator.hpp:39-131 for unsigned k-mers over ASCII (any non-ACGT byte restarts the k-mer)
-namespace {
-struct KmerGenerator
-{
-    const char *current, *end; unsigned kmerLength; unsigned mask; unsigned kmer;
-    static unsigned value(char c) { switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; } }
-    KmerGenerator(const char *b, const char *e, unsigned k) : current(b), end(e), kmerLength(k), mask(~((~0U) << (2 * k))), kmer(0) { initialize(); }
-    void initialize()
-    {
-        unsigned currentLength = 0;
-        while ((current < end) && currentLength + 1 < kmerLength)
-        {
-            const unsigned v = value(*current);
-            if (4 > v) { kmer <<= 2; kmer |= v; ++currentLength; } else { currentLength = 0; kmer = 0; }
-            ++current;
-        }
-    }
-    bool next(unsigned &out, const char *&position)
-    {
-        while ((current < end) && (4 <= value(*current))) initialize();
-        if (current < end)
-        {
-            kmer <<= 2; kmer |= value(*current); kmer &= mask; out = kmer; ++current; position = current - kmerLength;
-            return true;
-        }
-        return false;
-    }
-};
-}
-
 // ShadowAligner.cpp:53-112
 void ShadowAligner::findShadowCandidatePositions(const char *referenceBegin, const char *referenceEnd, const std::vector<char> &shadowSequence)
 {
     shadowKmerPositions.assign(shadowKmerCount, -1);
     {
-        KmerGenerator g(shadowSequence.data(), shadowSequence.data() + shadowSequence.size(), shadowKmerLength);
+        KmerGenerator<unsigned> g(shadowSequence.data(), shadowSequence.data() + shadowSequence.size(), shadowKmerLength);
         unsigned kmer; const char *position;
         while (g.next(kmer, position)) if (-1 == shadowKmerPositions[kmer]) shadowKmerPositions[kmer] = short(position - shadowSequence.data());
     }
-    KmerGenerator g(referenceBegin, referenceEnd, shadowKmerLength);
+    KmerGenerator<unsigned> g(referenceBegin, referenceEnd, shadowKmerLength);
     unsigned kmer; const char *position;
     while (g.next(kmer, position))
     {

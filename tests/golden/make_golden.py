@@ -16,6 +16,8 @@ What is extracted is DATA: the literal inputs and the asserted outputs of
   * lib/alignment/cppunit/testTemplateBuilder.cpp:96-373 (+ BuilderInit.hh fixture recipe) -> template_builder.json
   * lib/alignment/cppunit/testShadowAligner.cpp:56-252 -> shadow_aligner.json
   * lib/alignment/cppunit/testFragmentBuilder.cpp:33-598 (seed matches -> candidates) -> fragment_builder.json
+  * testMatchFinderClusterInfo.cpp, oligo/cppunit/testKmerGenerator.cpp, oligo/cppunit/testPermutate.cpp,
+    reference/cppunit/testNeighborsFinder.cpp -> oligo.json
 No reference source text is stored.
 """
 import ctypes
@@ -572,7 +574,105 @@ def make_fragment_builder():
     return len(cases), n_asserts
 
 
+def make_oligo():
+    """The small bit-layout / k-mer tests behind the seed lookup, mate rescue and the index builder:
+    testMatchFinderClusterInfo.cpp (ClusterInfo's two bytes), testKmerGenerator.cpp (N-skipping k-mer stream, generateKmer,
+    getMaxKmer), testPermutate.cpp (block permutations, the 6 / 70 permutation lists) and testNeighborsFinder.cpp (the 16 k-mer list
+    and the flags findNeighbors must set).  Statements are replayed as data: operations in source order with the asserted values."""
+    lib = os.path.join(os.path.dirname(REF), "..")
+    out = {"source": "lib/alignment/cppunit/testMatchFinderClusterInfo.cpp:38-91, lib/oligo/cppunit/testKmerGenerator.cpp:37-97, "
+                     "lib/oligo/cppunit/testPermutate.cpp:41-170, lib/reference/cppunit/testNeighborsFinder.cpp:44-113"}
+    # ---- ClusterInfo: a script of constructions, mutations and asserts
+    text = strip_comments(open(os.path.join(REF, "testMatchFinderClusterInfo.cpp")).read())
+    body = text[text.index("::testFields()"):]
+    script = []
+    for st in body.split(";"):
+        st = " ".join(st.split())
+        m = re.search(r'ClusterInfo (\w+)$', st)
+        if m and "using" not in st: script.append({"op": "new", "var": m.group(1)}); continue
+        m = re.search(r'(\w+)\.markReadComplete\((\d+)\)$', st)
+        if m: script.append({"op": "markReadComplete", "var": m.group(1), "arg": int(m.group(2))}); continue
+        m = re.search(r'(\w+)\.setBarcodeIndex\((\d+)U\)$', st)
+        if m: script.append({"op": "setBarcodeIndex", "var": m.group(1), "arg": int(m.group(2))}); continue
+        m = re.search(r'CPPUNIT_ASSERT\((!?)(\w+)\.isBarcodeSet\(\)\)$', st)
+        if m: script.append({"op": "assert", "var": m.group(2), "what": "isBarcodeSet", "expected": m.group(1) != "!"}); continue
+        m = re.search(r'CPPUNIT_ASSERT_EQUAL\((true|false), (\w+)\.isReadComplete\((\d)\)\)$', st)
+        if m: script.append({"op": "assert", "var": m.group(2), "what": "isReadComplete", "arg": int(m.group(3)), "expected": m.group(1) == "true"}); continue
+        m = re.search(r'CPPUNIT_ASSERT_EQUAL\((\d+)U, (\w+)\.getBarcodeIndex\(\)\)$', st)
+        if m: script.append({"op": "assert", "var": m.group(2), "what": "getBarcodeIndex", "expected": int(m.group(1))}); continue
+    assert sum(1 for x in script if x["op"] == "assert") == body.count("CPPUNIT_ASSERT"), (sum(1 for x in script if x["op"] == "assert"), body.count("CPPUNIT_ASSERT"))
+    out["cluster_info"] = script
+    # ---- KmerGenerator
+    text = strip_comments(open(os.path.join(lib, "oligo", "cppunit", "testKmerGenerator.cpp")).read())
+    uns = text[text.index("::testUnsigned()"):text.index("::testConstMethods()")]
+    streams = []
+    for blk in re.findall(r'\{\s*const std::string s(?:\(| = std::string\()"(\w+)"\);(.*?)\n    \}', uns, flags=re.S):
+        k = int(re.search(r'kmerGenerator\(v\.begin\(\), v\.end\(\), (\d+)\)', blk[1]).group(1))
+        kmers = [int(x, 16) for x in re.findall(r'CPPUNIT_ASSERT_EQUAL\(kmer, (0x[0-9A-Fa-f]+)U\)', blk[1])]
+        positions = [int(x) for x in re.findall(r'CPPUNIT_ASSERT_EQUAL\(position - v\.begin\(\), (\d+)L\)', blk[1])]
+        n_true = len(re.findall(r'CPPUNIT_ASSERT\(kmerGenerator\.next', blk[1])); n_false = len(re.findall(r'CPPUNIT_ASSERT\(!kmerGenerator\.next', blk[1]))
+        assert len(kmers) == len(positions) == n_true and n_false == 1
+        streams.append({"sequence": blk[0], "k": k, "kmers": kmers, "positions": positions})
+    assert len(streams) == 3
+    const = text[text.index("::testConstMethods()"):]
+    max_kmers = [[int(k), int(v)] for v, k in re.findall(r'CPPUNIT_ASSERT_EQUAL\((\d+)UL, isaac::oligo::getMaxKmer<unsigned long>\((\d+)\)\)', const)]
+    gen = []
+    for blk in re.findall(r'\{\s*const std::string s(?:\(| = std::string\()"(\w+)"\);(.*?)\n    \}', const, flags=re.S):
+        m = re.search(r'CPPUNIT_ASSERT\((!?)isaac::oligo::generateKmer\((\d+), kmer, s\.begin\(\), s\.end\(\)\)\)', blk[1])
+        e = {"sequence": blk[0], "k": int(m.group(2)), "ok": m.group(1) != "!"}
+        b = re.search(r'BOOST_BINARY\(([01 ]+)\)', blk[1])
+        if b: e["kmer"] = int(b.group(1).replace(" ", ""), 2)
+        gen.append(e)
+    assert len(max_kmers) == 2 and len(gen) == 2 and "kmer" in gen[1]
+    out["kmer_generator"] = {"streams": streams, "max_kmer": max_kmers, "generate_kmer": gen}
+    # ---- Permutate
+    text = strip_comments(open(os.path.join(lib, "oligo", "cppunit", "testPermutate.cpp")).read())
+    blocks = []
+    for name in ("testFourBlocks", "testEightBlocks"):
+        a = text.index("::" + name + "()"); body = text[a:text.index("\n}", a)]
+        consts = {n: int(v, 16) for n, v in re.findall(r'const unsigned long (\w+) = (0x[0-9A-F]+)UL;', body)}
+        orders = {n: [int(x) for x in re.findall(r'\((\d+)\)', v)] for n, v in re.findall(r'const std::vector<unsigned> (\w+) = list_of((?:\(\d+\))+);', body)}
+        perms = {n: (f, t) for n, f, t in re.findall(r'const oligo::Permutate (\w+)\(blockLength, (\w+), (\w+)\);', body)}
+        block_length = int(re.search(r'const unsigned blockLength = (\d+);', body).group(1))
+        val = lambda x: consts[x] if x in consts else int(x.rstrip("UL"), 16)
+        checks = []
+        for pn, ro, arg, exp in re.findall(r'CPPUNIT_ASSERT_EQUAL\((\w+)(\.reorder)?\((\w+)\), (\w+)\);', body):
+            checks.append({"from": orders[perms[pn][0]], "to": orders[perms[pn][1]], "reorder": bool(ro), "kmer": "%016x" % val(arg), "expected": "%016x" % val(exp)})
+        assert len(checks) == body.count("CPPUNIT_ASSERT_EQUAL"), (name, len(checks))
+        blocks.append({"name": name, "block_length": block_length, "checks": checks})
+    hexs = lambda x: "%x" % x
+    g = lambda pat: re.search(pat, text)
+    o16, e16 = int(g(r'ORIGINAL16\((0x[0-9A-F]+)U\)').group(1), 16), int(g(r'EXPECTED16\((0x[0-9A-F]+)U\)').group(1), 16)
+    o32, e32 = int(g(r'ORIGINAL\((0x[0-9A-F]+)UL\)').group(1), 16), int(g(r'EXPECTED\((0x[0-9A-F]+)UL\)').group(1), 16)
+    m = g(r'ORIGINAL64\(isaac::oligo::LongKmerType\((0x[0-9A-F]+)UL\) << 64 \| isaac::oligo::LongKmerType\((0x[0-9A-F]+)UL\)\)'); o64 = (int(m.group(1), 16) << 64) | int(m.group(2), 16)
+    m = g(r'EXPECTED64\(isaac::oligo::LongKmerType\((0x[0-9A-F]+)UL\) << 64 \| isaac::oligo::LongKmerType\((0x[0-9A-F]+)UL\)\)'); e64 = (int(m.group(1), 16) << 64) | int(m.group(2), 16)
+    lists = []
+    for name in ("testTwoErrors", "testFourErrors"):
+        a = text.index("::" + name + "()"); body = text[a:text.index("\n}", a)]
+        for kt, errors in re.findall(r'getPermutateList<oligo::(\w+)>\((\d)\)', body):
+            size = int(re.search(r'CPPUNIT_ASSERT_EQUAL\((\d+)UL, permutateList\.size\(\)\)', body).group(1))
+            bases, o, e = {"ShortKmerType": (16, o16, e16), "KmerType": (32, o32, e32), "LongKmerType": (64, o64, e64)}[kt]
+            lists.append({"kmer_bases": bases, "error_count": int(errors), "size": size, "original": hexs(o), "expected": hexs(e)})
+    assert len(lists) == 6
+    out["permutate"] = {"blocks": blocks, "lists": lists}
+    # ---- NeighborsFinder
+    text = strip_comments(open(os.path.join(lib, "reference", "cppunit", "testNeighborsFinder.cpp")).read())
+    aux = re.findall(r'\((MASK[01])(?:\|(0x[0-9A-F]+)UL)?\)\s*\n', text[text.index("kmerListAux = list_of"):text.index("KmerList kmerList;")])
+    flags = {int(i): v == "true" for v, i in re.findall(r'CPPUNIT_ASSERT_EQUAL\((true|false), kmerList\[(\d+)\]\.hasNeighbors\)', text)}
+    jobs = int(re.search(r'findNeighbors\(kmerList, (\d+)\)', text).group(1))
+    masks = re.findall(r'const isaac::oligo::(\w+) (MASK[01]) = isaac::oligo::\w+\((0x[0-9A-F]+)UL\)( << 64)?;', text)
+    assert len(aux) == 16 and len(flags) == 16 and len(masks) == 4
+    runs = []
+    for kt in ("KmerType", "LongKmerType"):
+        mk = {n: int(v, 16) << (64 if sh else 0) for t, n, v, sh in masks if t == kt}
+        runs.append({"kmer_bases": 32 if kt == "KmerType" else 64, "kmers": [hexs(mk[n] | (int(lit, 16) if lit else 0)) for n, lit in aux]})
+    out["neighbors_finder"] = {"jobs": jobs, "expected": [flags[i] for i in range(16)], "runs": runs}
+    json.dump(out, open(os.path.join(OUT, "oligo.json"), "w"), indent=1)
+    return len(script), len(streams), sum(len(b["checks"]) for b in blocks), len(lists), len(runs)
+
+
 if __name__ == "__main__":
+    print("oligo (cluster info steps, k-mer streams, permutate checks, permutation lists, neighbour runs):", make_oligo())
     print("fragment_builder cases, asserted values:", make_fragment_builder())
     print("shadow_aligner blocks:", make_shadow_aligner())
     print("template_builder cases, asserted fragment fields:", make_template_builder())

@@ -232,3 +232,66 @@ def test_fragment_builder_known_answers(oracle):
     # testEmptyMatchList (:84-104): nothing in, nothing out
     cands, cigars = ref.build_fragments(p, bcl, matches[:0], tile=tile, with_gaps=True, trim=False)
     assert len(cands) == 0 and len(cigars) == 0
+
+
+def test_cluster_info_kmer_generator_permutate_and_neighbors_finder(oracle):
+    """The reference's small unit tests behind the seed lookup (ClusterInfo: which reads still get seeds), the mate rescue (7-mer
+    streams of KmerGenerator) and the index builder's neighbour annotation (Permutate, the 70-permutation list, findNeighbors):
+    testMatchFinderClusterInfo.cpp, testKmerGenerator.cpp, testPermutate.cpp, testNeighborsFinder.cpp"""
+    import ctypes as C
+    import numpy as np
+    g = load("oligo.json")
+    lib = oracle.lib
+    lib.oracle_max_kmer.restype = C.c_uint64
+    # ---- ClusterInfo: replay the statements of the test in order
+    objects = {}
+
+    def state(var):
+        ops = objects[var]
+        st = (C.c_uint32 * 6)()
+        oracle.check(lib.oracle_cluster_info(-1, (C.c_uint32 * len(ops))(*[o for o, _ in ops]), (C.c_uint32 * len(ops))(*[a for _, a in ops]), C.c_uint32(len(ops)), st))
+        return {"getBarcodeIndex": st[0], "isBarcodeSet": bool(st[1]), "isReadComplete": [bool(st[2]), bool(st[3])], "bytes": (st[4], st[5])}
+    for step in g["cluster_info"]:
+        if step["op"] == "new": objects[step["var"]] = []
+        elif step["op"] == "markReadComplete": objects[step["var"]].append((0, step["arg"]))
+        elif step["op"] == "setBarcodeIndex": objects[step["var"]].append((1, step["arg"]))
+        else:
+            got = state(step["var"])[step["what"]]
+            if step["what"] == "isReadComplete": got = got[step["arg"]]
+            assert got == step["expected"], step
+    assert state("none")["bytes"] == (0xfe, 0xfe) and state("all")["bytes"] == (0xff, 0xff)       # the layout drawn at TileClusterInfo.hh:55-64
+    # ---- KmerGenerator
+    for s in g["kmer_generator"]["streams"]:
+        kmers, positions, n = np.zeros(64, np.uint32), np.zeros(64, np.int64), C.c_uint64()
+        oracle.check(lib.oracle_kmer_generator(s["sequence"].encode(), C.c_uint64(len(s["sequence"])), C.c_uint32(s["k"]), kmers.ctypes.data_as(C.c_void_p),
+                                               positions.ctypes.data_as(C.c_void_p), C.c_uint64(64), C.byref(n)))
+        assert list(kmers[:n.value]) == s["kmers"] and list(positions[:n.value]) == s["positions"], s
+    for k, v in g["kmer_generator"]["max_kmer"]:
+        assert lib.oracle_max_kmer(C.c_uint32(k)) == v
+    for c in g["kmer_generator"]["generate_kmer"]:
+        kmer = C.c_uint32()
+        ok = lib.oracle_generate_kmer(C.c_uint32(c["k"]), c["sequence"].encode(), C.c_uint64(len(c["sequence"])), C.byref(kmer))
+        assert bool(ok) == c["ok"] and (not c["ok"] or kmer.value == c["kmer"]), c
+    # ---- Permutate
+    hi_lo = lambda v: (C.c_uint64(v >> 64), C.c_uint64(v & (2 ** 64 - 1)))
+    for b in g["permutate"]["blocks"]:
+        for c in b["checks"]:
+            n = len(c["from"])
+            hi, lo = C.c_uint64(), C.c_uint64()
+            oracle.check(lib.oracle_permutate(C.c_uint32(b["block_length"]), (C.c_uint32 * n)(*c["from"]), (C.c_uint32 * n)(*c["to"]), C.c_uint32(n), C.c_uint32(32), int(c["reorder"]),
+                                              *hi_lo(int(c["kmer"], 16)), C.byref(hi), C.byref(lo)))
+            assert lo.value == int(c["expected"], 16), (b["name"], c, hex(lo.value))
+    for c in g["permutate"]["lists"]:
+        size, hi, lo, ok = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int()
+        oracle.check(lib.oracle_permutate_list_walk(C.c_uint32(c["kmer_bases"]), C.c_uint32(c["error_count"]), *hi_lo(int(c["original"], 16)), C.byref(size), C.byref(hi), C.byref(lo), C.byref(ok)))
+        assert size.value == c["size"] and ok.value == 1 and ((hi.value << 64) | lo.value) == int(c["expected"], 16), c
+    # ---- NeighborsFinder::findNeighbors
+    nf = g["neighbors_finder"]
+    for run in nf["runs"]:
+        values = [int(k, 16) for k in run["kmers"]]
+        hi = np.array([v >> 64 for v in values], np.uint64); lo = np.array([v & (2 ** 64 - 1) for v in values], np.uint64)
+        for jobs in (nf["jobs"], 1, 16):
+            flags = np.zeros(len(values), np.uint8)
+            oracle.check(lib.oracle_find_neighbors(C.c_uint32(run["kmer_bases"]), hi.ctypes.data_as(C.c_void_p), lo.ctypes.data_as(C.c_void_p), C.c_uint64(len(values)), C.c_uint32(jobs),
+                                                   flags.ctypes.data_as(C.c_void_p)))
+            assert [bool(f) for f in flags] == nf["expected"], (run["kmer_bases"], jobs, list(flags))
