@@ -550,7 +550,7 @@ __global__ void k_load_candidates(DevParams P, const u8 *bcl, u32 clusterBase, u
 // a window of several hundred reference bases plus one 150-base ungapped alignment per candidate start, for ~1.5 orphans
 // per cluster.  It is planned per cluster, then executed flat:
 //   k_plan_rescue         one thread per cluster: the rescue problems TemplateBuilder would pose (result independent)
-//   k_rescue_windows      one wavefront per problem: the mate's 7-mer table in LDS, the window scanned 1024 positions at a time
+//   k_rescue_windows      one wavefront per problem: the mate's 7-mer table in LDS, the window scanned 64 x RW_PER_LANE positions at a time
 //                         (16 per lane), candidate starts collected in a per-problem bitmap (sorted + unique for free)
 //   k_rescue_align        one thread per candidate start: UngappedAligner::alignUngapped
 //   k_rescue_gapped_plan  one thread per problem: rank of every aligned candidate, the best one, which get a gapped retry
@@ -562,7 +562,12 @@ __global__ void k_load_candidates(DevParams P, const u8 *bcl, u32 clusterBase, u
 static const u32 KMER_EMPTY = 0xffffffffu;
 static const u32 RW_TABLE = 512;          // hash slots for the mate's <= 250-odd 7-mers
 static const u32 RW_LDS_BITMAP = 64;      // words: windows up to ~1900 bases keep their candidate bitmap in LDS
-static const u32 RW_PER_LANE = 16;        // consecutive window positions per lane and tile
+#ifndef ISAAC_RW_PER_LANE
+#define ISAAC_RW_PER_LANE 8
+#endif
+static const u32 RW_PER_LANE = ISAAC_RW_PER_LANE;        // consecutive window positions per lane and tile (a multiple of 8)
+static const i32 RW_TILE = 64 * RW_PER_LANE;              // window positions per wave and tile
+static const u32 RW_LOADS = (RW_PER_LANE + 6 + 7) / 8;    // 8-byte loads covering a lane's positions and the 6 bases after them
 static const u32 CAND_REGIONS = 256;
 
 struct RescueBuffers
@@ -608,27 +613,26 @@ __global__ __launch_bounds__(64) void k_plan_rescue(DevParams P, DevReference R,
 }
 
 
-// 16 reference bytes at a 16-byte aligned address, zero where the address leaves [lo, hi)
-__device__ inline uint4 loadChunkGuarded(const char *at, const char *lo, const char *hi)
+// 8 reference bytes at an 8-byte aligned address, zero where the address leaves [lo, hi)
+__device__ inline u64 loadWordGuarded(const char *at, const char *lo, const char *hi)
 {
-    if (at >= lo && at + 16 <= hi) return *reinterpret_cast<const uint4 *>(at);
-    u32 w[4] = {0, 0, 0, 0};
-    for (u32 i = 0; i < 16; ++i) if (at + i >= lo && at + i < hi) w[i >> 2] |= u32(u8(at[i])) << (8 * (i & 3));
-    return make_uint4(w[0], w[1], w[2], w[3]);
+    if (at >= lo && at + 8 <= hi) return *reinterpret_cast<const u64 *>(at);
+    u64 w = 0;
+    for (u32 i = 0; i < 8; ++i) if (at + i >= lo && at + i < hi) w |= u64(u8(at[i])) << (8 * i);
+    return w;
 }
 // any fixed bijection ACGT -> 0..3 will do for the 7-mer table; 4 = not a base
 __device__ inline u32 rwCode(u32 c) { const u32 d = c - 0x41u; return (d < 32u && ((0x80045u >> d) & 1u)) ? ((c >> 1) & 3u) : 4u; }
 
 // k_rescue_windows: one wave per rescue problem (ShadowAligner::findShadowCandidatePositions, ShadowAligner.cpp:53-112).
-// The mate's 7-mers go to an LDS hash table (first read position per k-mer).  The window is walked in tiles of 1024 bases:
-// every lane takes 16 consecutive positions from two aligned 16-byte loads, rolls the 7-mer along them and looks each one
+// The mate's 7-mers go to an LDS hash table (first read position per k-mer).  The window is walked in tiles of 64 x RW_PER_LANE bases:
+// every lane takes RW_PER_LANE consecutive positions from aligned 8-byte loads, rolls the 7-mer along them and looks each one
 // up.  "Push unless equal to the previous hit's candidate" needs the previous hit in window order: inside a lane that is
 // sequential, across lanes one ballot + shuffle, across tiles a carried value.  Pushed candidates set bits in a bitmap
 // (LDS for ordinary windows, global for the long ones), whose ascending enumeration is the reference's sort + unique.
 template <bool LDS_BITMAP>
-__device__ inline void rescueWindowScan(const DevReference &R, u64 totalBases, const RescueJob &job, u32 L, const u32 *tab, u32 *bitmap, u32 lane, u32 &pushes)
+__device__ inline void rescueWindowScan(const DevReference &R, u64 totalBases, const RescueJob &job, const char *window, const u64 *firstTile, u32 L, const u32 *tab, u32 *bitmap, u32 lane, u32 &pushes)
 {
-    const char *window = R.bases + R.contigOffset[job.contigId] + job.windowBegin;
     const char *lo = R.bases, *hi = R.bases + totalBases;
     const uintptr_t A = reinterpret_cast<uintptr_t>(window);
     const char *alignedBase = reinterpret_cast<const char *>(A & ~uintptr_t(15));
@@ -636,18 +640,19 @@ __device__ inline void rescueWindowScan(const DevReference &R, u64 totalBases, c
     const i32 bias = i32(L) - 7;
     const i32 lastStart = i32(job.windowLen) - 7;       // last valid k-mer start
     i32 carry = 0; bool haveCarry = false;
-    for (i32 tile = 0; tile * 1024 - off <= lastStart; ++tile)
+    for (i32 tile = 0; tile * RW_TILE - off <= lastStart; ++tile)
     {
-        const char *chunk = alignedBase + tile * 1024 + lane * 16;
-        const uint4 c0 = loadChunkGuarded(chunk, lo, hi), c1 = loadChunkGuarded(chunk + 16, lo, hi);
-        const u32 words[6] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y };
-        const i32 p0 = tile * 1024 + i32(lane) * 16 - off;          // window position of this lane's first byte
+        const char *chunk = alignedBase + tile * RW_TILE + lane * RW_PER_LANE;
+        u64 words[RW_LOADS];
+#pragma unroll
+        for (u32 w = 0; w < RW_LOADS; ++w) words[w] = tile ? loadWordGuarded(chunk + 8 * w, lo, hi) : firstTile[w];
+        const i32 p0 = tile * RW_TILE + i32(lane) * i32(RW_PER_LANE) - off;          // window position of this lane's first byte
         i32 cand[RW_PER_LANE]; u32 hitMask = 0;
         u32 kmer = 0, valid = 0;
 #pragma unroll
         for (u32 b = 0; b < RW_PER_LANE + 6; ++b)
         {
-            const u32 code = rwCode((words[b >> 2] >> (8 * (b & 3))) & 0xffu);
+            const u32 code = rwCode(u32(words[b >> 3] >> (8 * (b & 7))) & 0xffu);
             if (code > 3) { valid = 0; kmer = 0; } else { kmer = ((kmer << 2) | code) & 0x3fffu; ++valid; }
             if (b >= 6)
             {
@@ -700,7 +705,6 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
 {
     __shared__ u32 tables[4][RW_TABLE];
     __shared__ u32 ldsBitmaps[4][RW_LDS_BITMAP];
-    __shared__ u32 waveTotals[4], blockBase;
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 j = blockIdx.x * 4 + wave;
     const u32 nJobs = imin(*rb.jobCounter, rb.jobsCap);
@@ -714,6 +718,15 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
     u32 *bitmap = ldsBitmaps[wave];
     if (active)
     {
+        // the lane's bytes of the first window tile are requested now and used after the k-mer table is built: one memory
+        // latency instead of two in a row
+        const char *window = R.bases + R.contigOffset[job.contigId] + job.windowBegin;
+        u64 firstTile[RW_LOADS];
+        {
+            const char *chunk = reinterpret_cast<const char *>(reinterpret_cast<uintptr_t>(window) & ~uintptr_t(15)) + lane * RW_PER_LANE;
+#pragma unroll
+            for (u32 w = 0; w < RW_LOADS; ++w) firstTile[w] = loadWordGuarded(chunk + 8 * w, R.bases, R.bases + totalBases);
+        }
         u32 *tab = tables[wave];
         for (u32 i = lane; i < RW_TABLE; i += 64) tab[i] = KMER_EMPTY;
         const u32 r = job.shadowReadIndex;
@@ -758,8 +771,8 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         STAMP(2);
-        if (small) rescueWindowScan<true>(R, totalBases, job, L, tab, ldsBitmaps[wave], lane, pushes);
-        else { rescueWindowScan<false>(R, totalBases, job, L, tab, bitmap, lane, pushes); __threadfence(); }
+        if (small) rescueWindowScan<true>(R, totalBases, job, window, firstTile, L, tab, ldsBitmaps[wave], lane, pushes);
+        else { rescueWindowScan<false>(R, totalBases, job, window, firstTile, L, tab, bitmap, lane, pushes); __threadfence(); }
         STAMP(3);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -775,31 +788,25 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
         }
     }
     STAMP(4);
+    if (!active) return;
     bool fallback = pushes > SHADOW_POSITIONS_MAX;
     if (fallback) total = 0;
-    // one allocation per workgroup: a single counter serves every rescue problem of the chunk
-    if (lane == 0) waveTotals[wave] = total;
-    __syncthreads();
-    STAMP(5);
-    if (threadIdx.x == 0)
+    // one allocation per problem from the block's region: the regions keep the atomics on different addresses, and the waves of
+    // a block stay independent of each other (no barrier: their windows differ in length)
+    u32 candBase = 0xffffffffu;
+    if (total)
     {
-        const u32 sum = waveTotals[0] + waveTotals[1] + waveTotals[2] + waveTotals[3];
-        const u32 region = blockIdx.x % CAND_REGIONS;
-        u32 base = 0xffffffffu;
-        if (sum)
+        if (lane == 0)
         {
-            const u32 at = atomicAdd(rb.candCounter + region, sum);
-            if (at + sum <= rb.candRegionSize) base = region * rb.candRegionSize + at;
+            const u32 region = blockIdx.x % CAND_REGIONS;
+            const u32 at = atomicAdd(rb.candCounter + region, total);
+            if (at + total <= rb.candRegionSize) candBase = region * rb.candRegionSize + at;
             else atomicMin(rb.candCounter + CAND_REGIONS + region, at);   // the region is full from here on: these problems fall back
         }
-        blockBase = base;
+        candBase = __shfl(candBase, 0, 64);
+        if (candBase == 0xffffffffu) fallback = true;
     }
-    __syncthreads();
     STAMP(6);
-    if (!active) return;
-    u32 candBase = blockBase;
-    if (total && candBase == 0xffffffffu) fallback = true;
-    for (u32 w = 0; w < wave; ++w) candBase += waveTotals[w];
     if (!fallback && total)
     {
         const i32 bias = i32(L) - 7;
@@ -823,7 +830,7 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
     if (lane == 0)
     {
         RescueJob &out = rb.jobs[j];
-        out.pushes = pushes; out.fallback = fallback ? 1 : 0; out.candBase = candBase; out.nCands = fallback ? 0 : total;
+        out.pushes = pushes; out.fallback = fallback ? 1 : 0; out.candBase = (fallback || !total) ? 0 : candBase; out.nCands = fallback ? 0 : total;
     }
     STAMP(7);
 }

@@ -822,10 +822,68 @@ ISAAC_HD void pushShadowProb(TemplateWork &w, u32 side, const Cand &s)
 // correct sort gives the reference's sum.  The fast path therefore sorts by a total order, checks for near ties (adjacent
 // elements suffice once sorted) and only falls back to the instruction-exact std::sort replica if it finds one.
 static const u32 FAST_SORT_MIN = 192;
+// Lists of up to four entries (the usual case: one or two candidates per read and what they rescued) never touch the work
+// arrays: the entries are fetched side by side, ordered by the same total order in registers, and summed in that order; a
+// near tie sends the list through the exact sort like any other.
+static const u32 SMALL_SUM_MAX = 4;
+struct ShadowKey { u64 pos; double lp; i64 obs; u32 idx; };
+struct PairKey { u64 pos1, pos2; double lp; i64 obs1, obs2; u32 idx; };
+ISAAC_HD bool keyLess(const ShadowKey &a, const ShadowKey &b)
+{ if (a.pos != b.pos) return a.pos < b.pos; if (a.lp != b.lp) return a.lp < b.lp; if (a.obs != b.obs) return a.obs < b.obs; return a.idx < b.idx; }
+ISAAC_HD bool keyNearTie(const ShadowKey &a, const ShadowKey &b) { return a.pos == b.pos && a.lp != b.lp && lpEquals(a.lp, b.lp); }
+ISAAC_HD bool keyEqual(const ShadowKey &a, const ShadowKey &b) { return a.pos == b.pos && lpEquals(a.lp, b.lp) && a.obs == b.obs; }
+ISAAC_HD bool keyLess(const PairKey &a, const PairKey &b)
+{
+    if (a.pos1 != b.pos1) return a.pos1 < b.pos1;
+    if (a.pos2 != b.pos2) return a.pos2 < b.pos2;
+    if (a.lp != b.lp) return b.lp < a.lp;                                // higher probability first
+    if (a.obs1 != b.obs1) return a.obs1 < b.obs1;
+    if (a.obs2 != b.obs2) return a.obs2 < b.obs2;
+    return a.idx < b.idx;
+}
+ISAAC_HD bool keyNearTie(const PairKey &a, const PairKey &b) { return a.pos1 == b.pos1 && a.pos2 == b.pos2 && a.lp != b.lp && lpEquals(a.lp, b.lp); }
+ISAAC_HD bool keyEqual(const PairKey &a, const PairKey &b) { return a.pos1 == b.pos1 && a.pos2 == b.pos2 && lpEquals(a.lp, b.lp) && a.obs1 == b.obs1 && a.obs2 == b.obs2; }
+template <typename K> ISAAC_HD void keyOrder(K &a, K &b) { if (keyLess(b, a)) { const K t = a; a = b; b = t; } }
+// k0..k3: the list's n entries, the rest padded with keys that sort last.  false: a near tie, nothing decided.
+template <typename K> ISAAC_HD bool smallUniqueSum(K k0, K k1, K k2, K k3, u32 n, double &ret)
+{
+    keyOrder(k0, k1); keyOrder(k2, k3); keyOrder(k0, k2); keyOrder(k1, k3); keyOrder(k1, k2);
+    if ((1 < n && keyNearTie(k0, k1)) || (2 < n && keyNearTie(k1, k2)) || (3 < n && keyNearTie(k2, k3))) return false;
+    ret = 0.0;
+    K prev = k0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma nounroll
+#endif
+    for (u32 i = 0; i < n; ++i)
+    {
+        const K cur = k0; k0 = k1; k1 = k2; k2 = k3;
+        if (!(i && keyEqual(prev, cur))) ret += exp(cur.lp);
+        prev = cur;
+    }
+    return true;
+}
+ISAAC_HD ShadowKey shadowKey(const ShadowProb *v, u32 i, u32 n)
+{
+    ShadowKey k; k.idx = i;
+    if (i < n) { const ShadowProb p = v[i]; k.pos = p.pos; k.lp = p.logProbability; k.obs = p.observedLength; } else { k.pos = ~u64(0); k.lp = 0.0; k.obs = 0; }
+    return k;
+}
+ISAAC_HD PairKey pairKey(const PairProb *v, u32 i, u32 n)
+{
+    PairKey k; k.idx = i;
+    if (i < n) { const PairProb p = v[i]; k.pos1 = p.r1.pos; k.pos2 = p.r2.pos; k.lp = pairLp(p); k.obs1 = p.r1.observedLength; k.obs2 = p.r2.observedLength; }
+    else { k.pos1 = ~u64(0); k.pos2 = ~u64(0); k.lp = 0.0; k.obs1 = 0; k.obs2 = 0; }
+    return k;
+}
 ISAAC_HD double sumUniqueShadowProbabilities(TemplateCtx &x, u32 side)
 {
     TemplateWork &w = *x.w;
     const u32 n = w.nShadowProbs[side]; const ShadowProb *v = w.shadowProbs[side];
+    if (n <= SMALL_SUM_MAX)
+    {
+        double sum;
+        if (smallUniqueSum(shadowKey(v, 0, n), shadowKey(v, 1, n), shadowKey(v, 2, n), shadowKey(v, 3, n), n, sum)) return sum;
+    }
     bool exact = true;
     ISAAC_PROF_T0(x);
     if (x.fastSort && n >= FAST_SORT_MIN)
@@ -878,6 +936,11 @@ ISAAC_HD double sumUniquePairProbabilities(TemplateCtx &x)
 {
     TemplateWork &w = *x.w;
     const u32 n = w.nPairProbs; const PairProb *v = w.pairProbs;
+    if (n <= SMALL_SUM_MAX)
+    {
+        double sum;
+        if (smallUniqueSum(pairKey(v, 0, n), pairKey(v, 1, n), pairKey(v, 2, n), pairKey(v, 3, n), n, sum)) return sum;
+    }
     bool exact = true;
     ISAAC_PROF_T0(x);
     if (x.fastSort && n >= FAST_SORT_MIN)
