@@ -138,14 +138,18 @@ static void joinHeavy(isaac_gpu_ctx *c)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// wave-level reduction of the work counters, one atomic per field per wave
+// wave-level reduction of the work counters, one atomic per field per wave.  The totals are kept in COUNTER_SHARDS copies
+// (a block adds to the copy of its index; isaac_gpu_get_counters sums them): atomics on one address execute one after the
+// other in L2, and a grid of small waves can spend longer queueing there than working.  Fields no lane touched cost a vote.
+static const u32 COUNTER_SHARDS = 64;
 __device__ inline void flushCounters(const Counters &local, Counters *global)
 {
     const u64 *src = reinterpret_cast<const u64 *>(&local);
-    u64 *dst = reinterpret_cast<u64 *>(global);
+    u64 *dst = reinterpret_cast<u64 *>(global + (blockIdx.x & (COUNTER_SHARDS - 1)));
     for (u32 f = 0; f < sizeof(Counters) / sizeof(u64); ++f)
     {
         u64 v = src[f];
+        if (!__any(v != 0)) continue;
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         if ((threadIdx.x & 63) == 0 && v) atomicAdd(reinterpret_cast<unsigned long long *>(dst + f), static_cast<unsigned long long>(v));
     }
@@ -1150,8 +1154,8 @@ int isaac_gpu_create(int device, const isaac_params *params, void *stream, isaac
     double tables[200]; makeQualityTables(tables, tables + 100);
     c->logTables.reserve(200);
     HIP_CHECK(hipMemcpy(c->logTables.p, tables, sizeof(tables), hipMemcpyHostToDevice));
-    c->counters.reserve(1);
-    HIP_CHECK(hipMemset(c->counters.p, 0, sizeof(Counters)));
+    c->counters.reserve(COUNTER_SHARDS);
+    HIP_CHECK(hipMemset(c->counters.p, 0, COUNTER_SHARDS * sizeof(Counters)));
     c->overflowCount.reserve(1);
     HIP_CHECK(hipStreamCreateWithFlags(&c->heavyStream, hipStreamNonBlocking));
     HIP_CHECK(hipEventCreateWithFlags(&c->evPredicted, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&c->evHeavyDone, hipEventDisableTiming));
@@ -1754,7 +1758,14 @@ int isaac_gpu_get_counters(isaac_gpu_ctx *c, isaac_counters *out)
 {
     ISAAC_TRY
     static_assert(sizeof(isaac_counters) == sizeof(Counters), "counter layouts");
-    HIP_CHECK(hipMemcpy(out, c->counters.p, sizeof(Counters), hipMemcpyDeviceToHost));
+    std::vector<Counters> shards(COUNTER_SHARDS);
+    HIP_CHECK(hipMemcpy(shards.data(), c->counters.p, COUNTER_SHARDS * sizeof(Counters), hipMemcpyDeviceToHost));
+    u64 *sum = reinterpret_cast<u64 *>(out);
+    for (u32 f = 0; f < sizeof(Counters) / sizeof(u64); ++f)
+    {
+        sum[f] = 0;
+        for (u32 i = 0; i < COUNTER_SHARDS; ++i) sum[f] += reinterpret_cast<const u64 *>(&shards[i])[f];
+    }
     return 0;
     ISAAC_CATCH
 }
@@ -1773,7 +1784,7 @@ int isaac_gpu_reset_timers(isaac_gpu_ctx *c)
     ISAAC_TRY
     resolveTimers(c);
     c->timers.clear();
-    HIP_CHECK(hipMemset(c->counters.p, 0, sizeof(Counters)));
+    HIP_CHECK(hipMemset(c->counters.p, 0, COUNTER_SHARDS * sizeof(Counters)));
     return 0;
     ISAAC_CATCH
 }

@@ -595,22 +595,42 @@ ISAAC_HD bool shadowRescueLookup(TemplateCtx &x, const Cand &orphan, const Rescu
 
 // One pass over a job's aligned candidates (in candidate order): how many there are before each slot, which is the best
 // (the running choice of ShadowAligner.cpp:216-230) and whether the last candidate aligned.
+static const u32 SUMMARY_BATCH = 8;
 ISAAC_HD void summarizeRescueJob(RescueJob &job, const Cand *shadowCands, u32 *candRank)
 {
     u32 n = 0; i32 best = -1; u32 bestRank = 0, bestMismatches = 0; bool last = false;
     double bestLp = 0.0;
     u32 nClose = 0; i64 prevPosition = 0; u32 prevMismatches = 0;     // the pairs planRescueGapped would pick, counted on the way
-    for (u32 c = 0; c < job.nCands; ++c)
+    // the candidates' fields are fetched SUMMARY_BATCH at a time before any of them is looked at: one thread walks the whole
+    // list (thousands of entries in repeat families), and loads that wait for the previous element's branches cost a memory
+    // latency each
+    for (u32 c0 = 0; c0 < job.nCands; c0 += SUMMARY_BATCH)
     {
-        const Cand &f = shadowCands[job.candBase + c];
-        candRank[job.candBase + c] = n;
-        last = candAligned(f);
-        if (!last) continue;
-        const double lp = f.logProbability; const i64 position = f.position; const u32 mismatches = f.mismatchCount;
-        if (best < 0 || lpLess(bestLp, lp)) { best = i32(c); bestRank = n; bestLp = lp; bestMismatches = mismatches; }
-        if (n && position - prevPosition < i64(BSW_DISTANCE_CUTOFF) && BSW_MISMATCHES_CUTOFF < prevMismatches) ++nClose;
-        prevPosition = position; prevMismatches = mismatches;
-        ++n;
+        double lps[SUMMARY_BATCH]; i64 positions[SUMMARY_BATCH]; u32 mismatchCounts[SUMMARY_BATCH]; bool aligned[SUMMARY_BATCH];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (u32 k = 0; k < SUMMARY_BATCH; ++k)
+        {
+            const Cand &f = shadowCands[job.candBase + imin(c0 + k, job.nCands - 1)];
+            lps[k] = f.logProbability; positions[k] = f.position; mismatchCounts[k] = f.mismatchCount; aligned[k] = candAligned(f);
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (u32 k = 0; k < SUMMARY_BATCH; ++k)
+        {
+            const u32 c = c0 + k;
+            if (c >= job.nCands) break;
+            candRank[job.candBase + c] = n;
+            last = aligned[k];
+            if (!last) continue;
+            const double lp = lps[k]; const i64 position = positions[k]; const u32 mismatches = mismatchCounts[k];
+            if (best < 0 || lpLess(bestLp, lp)) { best = i32(c); bestRank = n; bestLp = lp; bestMismatches = mismatches; }
+            if (n && position - prevPosition < i64(BSW_DISTANCE_CUTOFF) && BSW_MISMATCHES_CUTOFF < prevMismatches) ++nClose;
+            prevPosition = position; prevMismatches = mismatches;
+            ++n;
+        }
     }
     job.nAligned = n; job.bestRank = bestRank; job.bestSlot = best < 0 ? 0 : job.candBase + u32(best); job.lastAligned = last ? 1 : 0;
     job.nGapped = (best >= 0 && BSW_MISMATCHES_CUTOFF < bestMismatches) ? nClose : 0;   // == planRescueGapped(job, ..., NULL)
