@@ -65,6 +65,7 @@ struct isaac_gpu_ctx
     DevBuf<u64> contigOffset; std::vector<u64> hContigOffset; DevBuf<u8> contigLoaded; std::vector<u8> hContigLoaded; u32 nContigs = 0;
     DevBuf<u64> kmers, positions; u64 nKmers = 0; DevBuf<u32> karyotype; bool hasKaryotype = false;
     DevBuf<u32> prefixTable; u32 prefixBits = 0;
+    DevBuf<u32> packedBases, notBase;   // 2-bit copy of the contigs + not-ACGT bitmap (k_rescue_windows reads these)
     DevBuf<u64> matchBase;
     // run constants of the template kernels in device memory: passed by value they end up as private copies (dynamic indexing)
     struct TemplateConstants { DevParams P; DevTls tls; RogCorrection rog; };
@@ -98,6 +99,7 @@ struct isaac_gpu_ctx
         r.kmers = kmers.p; r.positions = positions.p; r.nKmers = nKmers; r.karyotype = hasKaryotype ? karyotype.p : nullptr;
         r.logMatch = logTables.p; r.logMismatch = logTables.p + 100;
         r.prefixTable = prefixBits ? prefixTable.p : nullptr; r.prefixBits = prefixBits;
+        r.packedBases = packedBases.p; r.notBase = notBase.p;
         return r;
     }
 };
@@ -571,7 +573,6 @@ static const u32 RW_LDS_BITMAP = 64;      // words: windows up to ~1900 bases ke
 #endif
 static const u32 RW_PER_LANE = ISAAC_RW_PER_LANE;        // consecutive window positions per lane and tile (a multiple of 8)
 static const i32 RW_TILE = 64 * RW_PER_LANE;              // window positions per wave and tile
-static const u32 RW_LOADS = (RW_PER_LANE + 6 + 7) / 8;    // 8-byte loads covering a lane's positions and the 6 bases after them
 static const u32 CAND_REGIONS = 256;
 
 struct RescueBuffers
@@ -617,62 +618,56 @@ __global__ __launch_bounds__(64) void k_plan_rescue(DevParams P, DevReference R,
 }
 
 
-// 8 reference bytes at an 8-byte aligned address, zero where the address leaves [lo, hi)
-__device__ inline u64 loadWordGuarded(const char *at, const char *lo, const char *hi)
+// The bases of window positions [g, g + RW_PER_LANE + 6) for one lane: their 2-bit codes (position g in the low bits) and their
+// not-ACGT flags, from the packed copy of the reference.  g is an index into the concatenated contigs.
+struct WindowBits { u64 codes; u32 notBase; };
+__device__ inline WindowBits loadWindowBits(const DevReference &R, u64 g)
 {
-    if (at >= lo && at + 8 <= hi) return *reinterpret_cast<const u64 *>(at);
-    u64 w = 0;
-    for (u32 i = 0; i < 8; ++i) if (at + i >= lo && at + i < hi) w |= u64(u8(at[i])) << (8 * i);
+    WindowBits w;
+    g = g < R.totalBases ? g : R.totalBases;          // lanes past the end of a window that ends the reference: read the spare words
+    const u32 *pw = R.packedBases + (g >> 4);
+    const u32 shift = 2 * u32(g & 15);
+    const u64 lo = u64(pw[0]) | (u64(pw[1]) << 32);
+    w.codes = shift ? (lo >> shift) | (u64(pw[2]) << (64 - shift)) : lo;             // 2 * (RW_PER_LANE + 6) bits wanted, up to 30 shifted out
+    const u32 *pn = R.notBase + (g >> 5);
+    const u32 ns = u32(g & 31);
+    w.notBase = u32((u64(pn[0]) | (u64(pn[1]) << 32)) >> ns);
     return w;
 }
-// any fixed bijection ACGT -> 0..3 will do for the 7-mer table; 4 = not a base
-__device__ inline u32 rwCode(u32 c) { const u32 d = c - 0x41u; return (d < 32u && ((0x80045u >> d) & 1u)) ? ((c >> 1) & 3u) : 4u; }
+static_assert(2 * (RW_PER_LANE + 6) <= 64 && RW_PER_LANE + 6 <= 32, "a lane's window bases fit the two words loadWindowBits returns");
 
 // k_rescue_windows: one wave per rescue problem (ShadowAligner::findShadowCandidatePositions, ShadowAligner.cpp:53-112).
 // The mate's 7-mers go to an LDS hash table (first read position per k-mer).  The window is walked in tiles of 64 x RW_PER_LANE bases:
-// every lane takes RW_PER_LANE consecutive positions from aligned 8-byte loads, rolls the 7-mer along them and looks each one
-// up.  "Push unless equal to the previous hit's candidate" needs the previous hit in window order: inside a lane that is
+// every lane takes RW_PER_LANE consecutive positions; with the reference 2 bits per base a 7-mer is a shift and a mask of the
+// lane's word (and seven zero bits of the not-ACGT map), and each one is looked up.  "Push unless equal to the previous hit's candidate" needs the previous hit in window order: inside a lane that is
 // sequential, across lanes one ballot + shuffle, across tiles a carried value.  Pushed candidates set bits in a bitmap
 // (LDS for ordinary windows, global for the long ones), whose ascending enumeration is the reference's sort + unique.
 template <bool LDS_BITMAP>
-__device__ inline void rescueWindowScan(const DevReference &R, u64 totalBases, const RescueJob &job, const char *window, const u64 *firstTile, u32 L, const u32 *tab, u32 *bitmap, u32 lane, u32 &pushes)
+__device__ inline void rescueWindowScan(const DevReference &R, const RescueJob &job, u64 windowBase, const WindowBits &firstTile, u32 L, const u32 *tab, u32 *bitmap, u32 lane, u32 &pushes)
 {
-    const char *lo = R.bases, *hi = R.bases + totalBases;
-    const uintptr_t A = reinterpret_cast<uintptr_t>(window);
-    const char *alignedBase = reinterpret_cast<const char *>(A & ~uintptr_t(15));
-    const i32 off = i32(A & 15);                        // window[0] sits `off` bytes into the first chunk
     const i32 bias = i32(L) - 7;
     const i32 lastStart = i32(job.windowLen) - 7;       // last valid k-mer start
     i32 carry = 0; bool haveCarry = false;
-    for (i32 tile = 0; tile * RW_TILE - off <= lastStart; ++tile)
+    for (i32 tile = 0; tile * RW_TILE <= lastStart; ++tile)
     {
-        const char *chunk = alignedBase + tile * RW_TILE + lane * RW_PER_LANE;
-        u64 words[RW_LOADS];
-#pragma unroll
-        for (u32 w = 0; w < RW_LOADS; ++w) words[w] = tile ? loadWordGuarded(chunk + 8 * w, lo, hi) : firstTile[w];
-        const i32 p0 = tile * RW_TILE + i32(lane) * i32(RW_PER_LANE) - off;          // window position of this lane's first byte
+        const i32 p0 = tile * RW_TILE + i32(lane) * i32(RW_PER_LANE);          // window position of this lane's first base
+        const WindowBits wb = tile ? loadWindowBits(R, windowBase + u64(p0)) : firstTile;
         i32 cand[RW_PER_LANE]; u32 hitMask = 0;
-        u32 kmer = 0, valid = 0;
 #pragma unroll
-        for (u32 b = 0; b < RW_PER_LANE + 6; ++b)
+        for (u32 k = 0; k < RW_PER_LANE; ++k)
         {
-            const u32 code = rwCode(u32(words[b >> 3] >> (8 * (b & 7))) & 0xffu);
-            if (code > 3) { valid = 0; kmer = 0; } else { kmer = ((kmer << 2) | code) & 0x3fffu; ++valid; }
-            if (b >= 6)
+            const i32 p = p0 + i32(k);
+            cand[k] = 0;
+            if (p <= lastStart && !((wb.notBase >> k) & 0x7fu))
             {
-                const u32 k = b - 6;                                   // the 7-mer starting at this lane's byte k
-                const i32 p = p0 + i32(k);
-                cand[k] = 0;
-                if (valid >= 7 && p >= 0 && p <= lastStart)
+                const u32 kmer = u32(wb.codes >> (2 * k)) & 0x3fffu;
+                u32 h = (kmer * 2654435761u) >> 23;
+                while (true)
                 {
-                    u32 h = (kmer * 2654435761u) >> 23;
-                    while (true)
-                    {
-                        const u32 e = tab[h];
-                        if (e == KMER_EMPTY) break;
-                        if ((e >> 10) == kmer) { hitMask |= 1u << k; cand[k] = p - i32(e & 0x3ffu); break; }
-                        h = (h + 1) & (RW_TABLE - 1);
-                    }
+                    const u32 e = tab[h];
+                    if (e == KMER_EMPTY) break;
+                    if ((e >> 10) == kmer) { hitMask |= 1u << k; cand[k] = p - i32(e & 0x3ffu); break; }
+                    h = (h + 1) & (RW_TABLE - 1);
                 }
             }
         }
@@ -724,13 +719,8 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
     {
         // the lane's bytes of the first window tile are requested now and used after the k-mer table is built: one memory
         // latency instead of two in a row
-        const char *window = R.bases + R.contigOffset[job.contigId] + job.windowBegin;
-        u64 firstTile[RW_LOADS];
-        {
-            const char *chunk = reinterpret_cast<const char *>(reinterpret_cast<uintptr_t>(window) & ~uintptr_t(15)) + lane * RW_PER_LANE;
-#pragma unroll
-            for (u32 w = 0; w < RW_LOADS; ++w) firstTile[w] = loadWordGuarded(chunk + 8 * w, R.bases, R.bases + totalBases);
-        }
+        const u64 windowBase = R.contigOffset[job.contigId] + u64(job.windowBegin);      // windowBegin >= 0 (planRescue)
+        const WindowBits firstTile = loadWindowBits(R, windowBase + lane * RW_PER_LANE);
         u32 *tab = tables[wave];
         for (u32 i = lane; i < RW_TABLE; i += 64) tab[i] = KMER_EMPTY;
         const u32 r = job.shadowReadIndex;
@@ -756,9 +746,10 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
 #pragma unroll
             for (u32 k = 0; k < 7; ++k)
             {
-                const u8 b = u8(bytes >> (8 * (reverse ? 6 - k : k)));
-                const u32 code = rwCode(u32(u8(strandBaseOf(b, reverse))));
-                ok &= code < 4; kmer = (kmer << 2) | (code & 3);
+                // BCL byte -> the code the packed reference has for the same base of the strand (A 0, C 1, G 3, T 2); a byte without quality bits is an N (Read.cpp:56-69)
+                const u32 b = u32(bytes >> (8 * (reverse ? 6 - k : k))) & 0xffu;
+                const u32 base = (b & 3u) ^ (reverse ? 3u : 0u);
+                ok &= (b & 0xfcu) != 0; kmer |= (base ^ (base >> 1)) << (2 * k);             // base k of the k-mer at bits 2k, as loadWindowBits lays them out
             }
             if (!ok) continue;
             const u32 val = (kmer << 10) | i;
@@ -775,8 +766,8 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         STAMP(2);
-        if (small) rescueWindowScan<true>(R, totalBases, job, window, firstTile, L, tab, ldsBitmaps[wave], lane, pushes);
-        else { rescueWindowScan<false>(R, totalBases, job, window, firstTile, L, tab, bitmap, lane, pushes); __threadfence(); }
+        if (small) rescueWindowScan<true>(R, job, windowBase, firstTile, L, tab, ldsBitmaps[wave], lane, pushes);
+        else { rescueWindowScan<false>(R, job, windowBase, firstTile, L, tab, bitmap, lane, pushes); __threadfence(); }
         STAMP(3);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1194,6 +1185,25 @@ int isaac_gpu_download(isaac_gpu_ctx *c, void *host, const void *dev, uint64_t b
 { ISAAC_TRY HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
 int isaac_gpu_synchronize(isaac_gpu_ctx *c) { ISAAC_TRY joinHeavy(c); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
 
+// 32 bases per thread: two words of 2-bit codes and one word of not-ACGT flags
+__global__ void k_pack_reference(const char *bases, u64 totalBases, u32 *packed, u32 *notBase, u64 nWords32)
+{
+    const u64 w = u64(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (w >= nWords32) return;
+    u32 lo = 0, hi = 0, bad = 0;
+    for (u32 i = 0; i < 32; ++i)
+    {
+        const u64 at = w * 32 + i;
+        const u32 ch = at < totalBases ? u32(u8(bases[at])) : u32('N');
+        const u32 d = ch - 0x41u;
+        const bool isBase = d < 32u && ((0x80045u >> d) & 1u);           // A C G T, upper case
+        const u32 code = isBase ? ((ch >> 1) & 3u) : 0u;
+        if (i < 16) lo |= code << (2 * i); else hi |= code << (2 * (i - 16));
+        bad |= (isBase ? 0u : 1u) << i;
+    }
+    packed[2 * w] = lo; packed[2 * w + 1] = hi; notBase[w] = bad;
+}
+
 static void setContigs(isaac_gpu_ctx *c, const uint64_t *offsets, uint32_t n)
 {
     c->nContigs = n; c->hContigOffset.assign(offsets, offsets + n + 1);
@@ -1202,6 +1212,11 @@ static void setContigs(isaac_gpu_ctx *c, const uint64_t *offsets, uint32_t n)
     c->hContigLoaded.assign(n, 1); c->contigLoaded.reserve(n);
     HIP_CHECK(hipMemcpy(c->contigLoaded.p, c->hContigLoaded.data(), n, hipMemcpyHostToDevice));
     c->contigHits.reserve(n);
+    const u64 nWords32 = (offsets[n] + 31) / 32 + 4;                       // + spare words: a lane reads two words past its first
+    c->packedBases.reserve(2 * nWords32); c->notBase.reserve(nWords32);
+    k_pack_reference<<<gridFor(nWords32, 256), 256, 0, c->stream>>>(c->bases, offsets[n], c->packedBases.p, c->notBase.p, nWords32);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(c->stream));
 }
 
 int isaac_gpu_load_contigs(isaac_gpu_ctx *c, const char *bases, const uint64_t *offsets, uint32_t n)

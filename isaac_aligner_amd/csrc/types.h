@@ -83,6 +83,8 @@ struct DevReference
     const u32 *karyotype;     // contig id translation of ReferenceKmer::getTranslatedPosition, NULL = identity
     const u32 *prefixTable;   // optional: first table index of every PREFIX_BITS-bit k-mer prefix (+ end sentinel)
     u32 prefixBits;
+    const u32 *packedBases;   // the same bases 2 bits each, 16 per word, base i of a word at bits 2i: A 0, C 1, T 2, G 3 ((ASCII >> 1) & 3)
+    const u32 *notBase;       // 1 bit per base: set where it is not one of ACGT (32 per word); both arrays end with spare words
     const double *logMatch;   // Quality::logMatchLookup / logMismatchLookup (lib/alignment/Quality.cpp:34-66), 100 entries each
     const double *logMismatch;
 };
