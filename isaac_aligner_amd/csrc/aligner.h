@@ -123,6 +123,53 @@ struct RefStream
     ISAAC_HD void skip(u32 n) { if (n < avail) { buf >>= 8 * n; avail -= n; } else avail = 0; p += n; }
 };
 
+// ---- eight bases of an ALIGN stretch at a time.  What depends on the order of the bases (the running fp64 sum, the length of
+// the current run of matches) stays a loop over the eight; everything else -- strand bases, N handling, the comparison with the
+// reference, the counters -- is done on all eight bytes of a 64-bit word at once.
+static const u64 BYTES_01 = 0x0101010101010101ull;
+// 0x80 in every byte of x that is zero, 0 elsewhere (exact: no carries between bytes)
+ISAAC_HD u64 zeroBytes(u64 x) { const u64 m = 0x7f * BYTES_01; return ~(((x & m) + m) | x | m); }
+// 'A' 'C' 'G' 'T' for the codes 0..3 in the bytes of `codes`
+ISAAC_HD u64 asciiOfCodes(u64 codes)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    // v_perm_b32 as a four-entry byte table: selector bytes 0..3 pick the bytes of the second operand
+    const u32 lo = __builtin_amdgcn_perm(0u, 0x54474341u, u32(codes)), hi = __builtin_amdgcn_perm(0u, 0x54474341u, u32(codes >> 32));
+    return u64(lo) | (u64(hi) << 32);
+#else
+    u64 r = 0;
+    for (u32 k = 0; k < 8; ++k) r |= u64((0x54474341u >> (8 * u32((codes >> (8 * k)) & 3))) & 0xffu) << (8 * k);
+    return r;
+#endif
+}
+struct AlignBlock { u64 quality; u64 matchFlags; u64 differFlags; };   // byte k: strand position k of the block; flags are 0x80 or 0
+// readBytes: the BCL bytes of eight consecutive strand positions (lowest position in the lowest byte); referenceBytes: the eight
+// reference bytes under them.  isMatch (Alignment.hh:44-47), strandBaseOf and qualityOf for all eight.
+ISAAC_HD AlignBlock alignBlock(u64 readBytes, bool reverse, u64 referenceBytes)
+{
+    AlignBlock b;
+    const u64 nFlags = zeroBytes(readBytes & (0xfc * BYTES_01));                       // no quality bits: the base is an N
+    u64 codes = readBytes & (0x03 * BYTES_01);
+    if (reverse) codes ^= 0x03 * BYTES_01;
+    const u64 nBytes = (nFlags >> 7) * 0xff;
+    const u64 strand = (asciiOfCodes(codes) & ~nBytes) | ((0x6e * BYTES_01) & nBytes);   // 'n' for N
+    const u64 equalFlags = zeroBytes(strand ^ referenceBytes);
+    const u64 referenceNFlags = zeroBytes(referenceBytes ^ (0x4e * BYTES_01));
+    b.matchFlags = nFlags | (equalFlags & ~referenceNFlags);
+    b.differFlags = ~equalFlags & (0x80 * BYTES_01);
+    b.quality = ((readBytes >> 2) & (0x3f * BYTES_01)) | (nFlags >> 6);                  // N: quality 2
+    return b;
+}
+ISAAC_HD u32 flagCount(u64 flags)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return u32(__popcll(flags));
+#else
+    return u32(__builtin_popcountll(flags));
+#endif
+}
+ISAAC_HD u64 reverseBytes(u64 x) { return __builtin_bswap64(x); }
+
 // AlignerBase::updateFragmentCigar (AlignerBase.cpp:121-227).  logProbability is a running fp64 sum in base order: the
 // order of the additions is part of the result, so this loop is deliberately serial.
 ISAAC_HD u32 updateFragmentCigar(const DevParams &P, const DevReference &R, const ReadView &read, Cand &f, i64 strandPosition, const CigarPool &pool, u32 cigarOffset)
@@ -144,7 +191,33 @@ ISAAC_HD u32 updateFragmentCigar(const DevParams &P, const DevReference &R, cons
         if (OP_ALIGN == op)
         {
             u32 matchesInARow = 0;
-            for (u32 j = 0; length > j; ++j)
+            u32 j = 0;
+            // whole blocks of eight while the read and the reference both have eight bytes left
+            while (j + 8 <= length && rs.pos + 8 <= rs.length && fs.p + 8 <= fs.end)
+            {
+                u64 readBytes, referenceBytes;
+                if (reverse) { memcpy(&readBytes, rs.bcl + (rs.length - rs.pos - 8), 8); readBytes = reverseBytes(readBytes); }
+                else memcpy(&readBytes, rs.bcl + rs.pos, 8);
+                memcpy(&referenceBytes, fs.p, 8);
+                const AlignBlock blk = alignBlock(readBytes, reverse, referenceBytes);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+                for (u32 k = 0; k < 8; ++k)
+                {
+                    const u32 q = u32(blk.quality >> (8 * k)) & 0xffu;
+                    const bool match = (blk.matchFlags >> (8 * k + 7)) & 1;
+                    lp += match ? R.logMatch[q] : R.logMismatch[q];
+                    matchesInARow = match ? matchesInARow + 1 : 0;
+                    best = imax(best, matchesInARow);
+                }
+                const u32 matches = flagCount(blk.matchFlags);
+                matchCount += matches; mismatchCount += 8 - matches; sws += (8 - matches) * P.normalizedMismatchScore;
+                editDistance += flagCount(blk.differFlags);
+                rs.pos += 8; rs.avail = 0; fs.p += 8; fs.avail = 0;
+                j += 8;
+            }
+            for (; length > j; ++j)
             {
                 const u8 b = rs.next();
                 const char s = strandBaseOf(b, reverse);
