@@ -594,16 +594,23 @@ __global__ __launch_bounds__(64) void k_plan_rescue(DevParams P, DevReference R,
     TemplateWork work;
     templateWorkBind(work, arena + u64(t) * arenaBytes, caps);
     Cand privateCands[2 * PRIVATE_CANDS];
-    const u32 n = clusterPlanRescue(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + t, t, frags[t], work, nullptr, privateCands);
-    u32 base = 0;
-    if (n)
+    // Every seeded candidate is an orphan at most once, so their number bounds the cluster's rescue problems: the slots are
+    // reserved first and the template logic runs once, writing the problems as it meets them (unused slots stay invalid)
+    const u32 reserve = frags[t].built ? frags[t].nCands[0] + frags[t].nCands[1] : 0;
+    u32 base = 0, n = 0;
+    if (reserve)
     {
-        base = atomicAdd(rb.jobCounter, n);
-        if (base + n > rb.jobsCap) base = 0xffffffffu;
+        base = atomicAdd(rb.jobCounter, reserve);
+        if (base + reserve > rb.jobsCap)
+        {   // the cluster's thread runs its rescues itself (k_select, wave-per-cluster capacities)
+            base = 0xffffffffu;
+            n = clusterPlanRescue(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + t, t, frags[t], work, nullptr, privateCands);
+        }
         else
         {
             RescueJob *jobs = rb.jobs + base;
-            clusterPlanRescue(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + t, t, frags[t], work, jobs, privateCands);
+            n = clusterPlanRescue(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + t, t, frags[t], work, jobs, privateCands);
+            for (u32 i = n; i < reserve; ++i) { jobs[i].valid = 0; jobs[i].fallback = 0; jobs[i].nCands = 0; jobs[i].nGapped = 0; }
             for (u32 i = 0; i < n; ++i)
             {
                 if (!jobs[i].valid) continue;
