@@ -169,16 +169,17 @@ def main():
     avg_s = total_ms[dominant] / launches / 1e3
     achieved = per_kernel_bytes[dominant] / launches / avg_s / 1e9 if avg_s > 0 else 0.0
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure comes from the
-    # committed rocprofv3 --pmc passes over this same workload (profiles/r1_d_pmc_summary.json, made by scripts/pmc_summary.py;
+    # committed rocprofv3 --pmc passes over this same workload (profiles/r1_j_pmc_summary.json, made by scripts/pmc_traffic.sh + pmc_summary.py;
     # FETCH_SIZE doubled as the MI355X guide prescribes for gfx950), scaled from that run's clusters per launch to this run's
     traffic, traffic_source = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "r1_d_pmc_summary.json")
+    pmc_name = next((n for n in ("r1_j_pmc_summary.json", "r1_d_pmc_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), "r1_d_pmc_summary.json")
+    pmc_path = os.path.join(ROOT, "profiles", pmc_name)
     if os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path)).get("k_" + dominant)
         if pmc and "hbm_bytes_per_launch" in pmc:
             pmc_pairs_per_launch = 500_000.0
             traffic = int(pmc["hbm_bytes_per_launch"] / pmc_pairs_per_launch * (pairs_rank / launches))
-            traffic_source = "profiles/r1_d_pmc_summary.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes, 500000 pairs per launch), scaled per pair"
+            traffic_source = "profiles/%s (separate --pmc FETCH_SIZE / WRITE_SIZE passes, 500000 pairs per launch), scaled per pair" % pmc_name
     roofline = {"bound": "hbm", "kernel": "k_" + dominant, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_ms": round(total_ms[dominant] / launches, 4), "launches": int(launches),
