@@ -75,7 +75,10 @@ ISAAC_HD void clusterTlsSample(const ClusterFragments &f, u32 nMatches, TlsSampl
 // privateCands: room for 2 * PRIVATE_CANDS candidates in the caller's private memory.  Short candidate lists (the usual case) are
 // copied there once, 16 bytes at a time; the template logic reads their fields many times over, and private memory is
 // interleaved by lane, so a wave's reads of "field f of candidate i" share cache lines instead of touching one line per lane.
-static const u32 PRIVATE_CANDS = 6;
+#ifndef ISAAC_PRIVATE_CANDS
+#define ISAAC_PRIVATE_CANDS 2
+#endif
+static const u32 PRIVATE_CANDS = ISAAC_PRIVATE_CANDS;
 ISAAC_HD void templateCtxInit(TemplateCtx &x, const DevParams &P, const DevReference &R, const DevTls &tls, const RogCorrection &rog, const u8 *bcl, u32 cluster,
                                const ClusterFragments &frags, TemplateWork &work, Counters &cnt, Cand *privateCands = 0)
 {
