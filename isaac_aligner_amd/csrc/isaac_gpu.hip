@@ -90,7 +90,8 @@ struct isaac_gpu_ctx
     // deferredCompletion the last one of a select call is left running when the call returns (see isaac_gpu_select)
     bool heavyPending = false, deferredCompletion = false; u32 chunkParity = 0;
     DevBuf<u32> heavyList, heavyCount, indelList, alignList; DevBuf<u8> heavyFlag;
-    u32 chunkClusters = 524288;
+    u32 chunkClusters = 1048576;   // upper bound of a chunk (ISAAC_GPU_CHUNK_CLUSTERS)
+    u32 chunkNow = 0;              // the chunk size in use: the largest call so far, rounded up, at most chunkClusters; sizes the chunk-private buffers
 
     DevReference ref() const
     {
@@ -1113,6 +1114,15 @@ template <typename K, typename V> void sortPairs(isaac_gpu_ctx *c, const K *kin,
 
 int fail(int code, const std::string &what) { g_error = what; return code; }
 
+// Chunk size for a call over nClusters clusters.  Kernel durations end in a tail set by their slowest waves, so fewer, larger
+// launches are faster; the buffers grow with the largest call seen instead of being sized for the upper bound at once.
+u32 chunkFor(isaac_gpu_ctx *c, u32 nClusters)
+{
+    const u32 wanted = std::min<u32>(c->chunkClusters, std::max<u32>(1024u, u32((u64(nClusters) + 65535) / 65536 * 65536)));
+    c->chunkNow = std::max(c->chunkNow, std::min(wanted, c->chunkClusters));
+    return c->chunkNow;
+}
+
 // after the table changed: the prefix directory of k_find_matches (tables of 2^32 entries and more go without)
 void buildPrefixTable(isaac_gpu_ctx *c)
 {
@@ -1366,7 +1376,7 @@ int isaac_gpu_find_matches(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClust
     hipStream_t st = c->stream;
     const DevParams &P = c->P;
     const u32 stride = 2 * P.nSeeds * std::max(1u, P.repeatThreshold - 1);
-    const u32 chunk = c->chunkClusters;
+    const u32 chunk = chunkFor(c, nClusters);
     c->staging.reserve(size_t(chunk) * stride); c->counts.reserve(chunk); c->chunkOffsets.reserve(chunk);
     HIP_CHECK(hipMemsetAsync(c->contigHits.p, 0, c->nContigs * 4, st));
     const DevReference R = c->ref();
@@ -1419,10 +1429,10 @@ int isaac_gpu_set_loaded_contigs(isaac_gpu_ctx *c, const uint8_t *loaded, uint32
 static GappedBuffers gappedBuffers(isaac_gpu_ctx *c, u32 which)
 {
     GappedBuffers gb;
-    gb.cap = 2 * c->chunkClusters;
+    gb.cap = 2 * c->chunkNow;
     // the rescue stage has its own arrays: the wave-per-cluster pass still reads them while the next chunk's fragment stage runs
     DevBuf<GappedJob> &jobs = which ? c->rescueGappedJobs : c->gappedJobs; DevBuf<GappedResult> &results = which ? c->rescueGappedResults : c->gappedResults;
-    jobs.reserve(gb.cap); results.reserve(gb.cap); c->gappedBase.reserve(c->chunkClusters); c->gappedCounters.reserve(4);
+    jobs.reserve(gb.cap); results.reserve(gb.cap); c->gappedBase.reserve(c->chunkNow); c->gappedCounters.reserve(4);
     gb.jobs = jobs.p; gb.results = results.p; gb.base = c->gappedBase.p; gb.counter = c->gappedCounters.p + which;
     return gb;
 }
@@ -1440,11 +1450,11 @@ static void launchGappedJobs(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clusterBa
 
 static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clusterBase, u32 n, const isaac_match *matches, const uint64_t *offsets, int withGaps, int trim)
 {
-    c->frags.reserve(c->chunkClusters); c->fragWork.reserve(c->chunkClusters); c->indelList.reserve(c->chunkClusters);
-    if (!c->fragsCur) c->fragsCur = c->frags.p;
+    c->frags.reserve(c->chunkNow); c->fragWork.reserve(c->chunkNow); c->indelList.reserve(c->chunkNow);
+    if (c->fragsCur != c->frags.p && (!c->fragsAlt.p || c->fragsCur != c->fragsAlt.p)) c->fragsCur = c->frags.p;   // first use, or the buffers grew
     const GappedBuffers gb = gappedBuffers(c, 0);
     HIP_CHECK(hipMemsetAsync(c->gappedCounters.p, 0, 16, c->stream));
-    AlignList al; al.cap = 8 * c->chunkClusters; c->alignList.reserve(al.cap); al.entries = c->alignList.p; al.counter = c->gappedCounters.p + 3;
+    AlignList al; al.cap = 8 * c->chunkNow; c->alignList.reserve(al.cap); al.entries = c->alignList.p; al.counter = c->gappedCounters.p + 3;
     {
         ScopedTimer t(c, "build_fragments");
         k_build_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, bcl, clusterBase, n, reinterpret_cast<const Match *>(matches), offsets, trim, c->fragWork.p, c->fragsCur, al);
@@ -1482,7 +1492,7 @@ int isaac_gpu_build_fragments(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nCl
     HIP_CHECK(hipSetDevice(c->device));
     joinHeavy(c);      // a wave-per-cluster pass of an earlier select call may still read the buffers written below
     hipStream_t st = c->stream;
-    const u32 chunk = c->chunkClusters;
+    const u32 chunk = chunkFor(c, nClusters);
     DevBuf<u32> nc, ng, oc, og; nc.reserve(chunk); ng.reserve(chunk); oc.reserve(chunk); og.reserve(chunk);
     u64 candBase = 0, cigarBase = 0;
     for (u32 done = 0; done < nClusters; done += chunk)
@@ -1517,7 +1527,7 @@ int isaac_gpu_determine_tls(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
     TlsLearner learner(c->P.mateDriftRange);
     if (2 == c->P.nReads)
     {
-        const u32 chunk = std::min<u32>(c->chunkClusters, 65536);
+        const u32 chunk = std::min<u32>(chunkFor(c, std::min<u32>(nClusters, 65536)), 65536);
         c->tlsSamples.reserve(chunk);
         std::vector<TlsSample> h(chunk);
         for (u32 done = 0; done < nClusters && !learner.stats.stable; done += chunk)
@@ -1557,7 +1567,7 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         { light.shadow = v[0]; light.shadowCigar = v[1]; light.pos = v[2]; light.prob = v[3]; light.pair = v[4]; light.best = v[5]; light.templateCigar = v[6]; }
     }
     const u64 lightBytes = templateWorkBytes(light), heavyBytes = templateWorkBytes(heavy);
-    const u32 chunk = c->chunkClusters;
+    const u32 chunk = chunkFor(c, nClusters);
     const u32 heavyThreads = 1024, residualThreads = 256;
     c->lightArena.reserve(size_t(chunk) * lightBytes);
     c->overflowList.reserve(chunk);
