@@ -1549,6 +1549,8 @@ int isaac_gpu_determine_tls(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
 // what fills the chunk's ClusterFragments: the fragment stage on match lists (isaac_gpu_select) or caller-supplied candidates
 struct FragmentSource { const isaac_match *matches; const uint64_t *offsets; const isaac_candidate *candidates; const uint64_t *candidateOffsets; const uint32_t *candidateCigars; };
 } // extern "C"
+__global__ void k_set_template_constants(isaac_gpu_ctx::TemplateConstants k, isaac_gpu_ctx::TemplateConstants *dst) { *dst = k; }
+
 static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, uint32_t tile, const FragmentSource &source, const isaac_tls *tls,
                             isaac_fragment *fragments, uint32_t *cigar, uint64_t cigarCapacity)
 {
@@ -1585,8 +1587,8 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
     {
         isaac_gpu_ctx::TemplateConstants k; k.P = c->P; k.tls = t; k.rog = rog;
         c->templateConstants.reserve(1);
-        HIP_CHECK(hipMemcpyAsync(c->templateConstants.p, &k, sizeof(k), hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipStreamSynchronize(st));       // k is on the stack
+        k_set_template_constants<<<1, 1, 0, st>>>(k, c->templateConstants.p);      // by value: no host buffer to keep alive, no host wait
+        HIP_CHECK(hipGetLastError());
     }
     const GappedBuffers gbRescue = gappedBuffers(c, 1);
     c->frags.reserve(chunk); c->fragsAlt.reserve(chunk);
