@@ -169,10 +169,11 @@ def main():
     avg_s = total_ms[dominant] / launches / 1e3
     achieved = per_kernel_bytes[dominant] / launches / avg_s / 1e9 if avg_s > 0 else 0.0
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure comes from the
-    # committed rocprofv3 --pmc passes over this same workload (profiles/r1_j_pmc_summary.json, made by scripts/pmc_traffic.sh + pmc_summary.py;
+    # committed rocprofv3 --pmc passes over this same workload (the latest profiles/*_pmc_summary.json, made by scripts/pmc_traffic.sh + pmc_summary.py;
     # FETCH_SIZE doubled as the MI355X guide prescribes for gfx950), scaled from that run's clusters per launch to this run's
     traffic, traffic_source = None, None
-    pmc_name = next((n for n in ("r1_j_pmc_summary.json", "r1_d_pmc_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), "r1_d_pmc_summary.json")
+    pmc_files = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_pmc_summary.json")) if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+    pmc_name = pmc_files[-1] if pmc_files else "r1_k_pmc_summary.json"     # the latest committed passes
     pmc_path = os.path.join(ROOT, "profiles", pmc_name)
     if os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path)).get("k_" + dominant)
