@@ -65,6 +65,7 @@ struct isaac_gpu_ctx
     DevBuf<u64> contigOffset; std::vector<u64> hContigOffset; DevBuf<u8> contigLoaded; std::vector<u8> hContigLoaded; u32 nContigs = 0;
     DevBuf<u64> kmers, positions; u64 nKmers = 0; DevBuf<u32> karyotype; bool hasKaryotype = false;
     DevBuf<u32> prefixTable; u32 prefixBits = 0;
+    DevBuf<u8> classFlag; DevBuf<u32> classOrder; u32 selectOrder = 2;      // work classes of k_select, most work first (ISAAC_GPU_SELECT_ORDER: 0 = chunk order, 2..4 classes)   // longest-first order of the light select pass
     DevBuf<u32> packedBases, notBase;   // 2-bit copy of the contigs + not-ACGT bitmap (k_rescue_windows reads these)
     DevBuf<u64> matchBase;
     // run constants of the template kernels in device memory: passed by value they end up as private copies (dynamic indexing)
@@ -905,16 +906,40 @@ __global__ __launch_bounds__(256) void k_predict_heavy(const ClusterFragments *f
     if (heavy) heavyList[atomicAdd(heavyCount, 1u)] = t;
 }
 
+// A kernel ends when its slowest waves do.  Clusters with mate-rescue problems take several times longer than those without, so
+// they are handed out first (longest work first) and the quick ones fill the end of the launch: a stable partition of the chunk.
+__global__ void k_select_classes(RescueBuffers rb, u32 nChunk, u32 nClasses, u8 *workClass, u32 *identity)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nChunk) return;
+    u32 cls = 0;
+    if (rb.jobCount[t])
+    {
+        cls = 1;
+        if (nClasses > 2 && rb.jobBase[t] != 0xffffffffu)
+        {
+            u32 total = 0;
+            for (u32 j = 0; j < rb.jobCount[t]; ++j) total += rb.jobs[rb.jobBase[t] + j].nCands;
+            if (total > 4) cls = 2;
+            if (total > 16 && nClasses > 3) cls = 3;
+        }
+    }
+    workClass[t] = u8(3 - cls);       // ascending sort = most work first
+    identity[t] = t;
+}
+
 // k_select: clusters [clusterBase, clusterBase + nChunk) with per-thread arenas of `arenaBytes`; clusters whose light work
 // lists overflow are appended to overflowList.  With `list` given, thread t redoes cluster list[t] (heavy capacities).
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_SELECT_WAVES))) void k_select(const isaac_gpu_ctx::TemplateConstants *constants, DevReference R, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk, u32 tile,
                                                const ClusterFragments *frags, u8 *arena, u64 arenaBytes, TemplateCaps caps, const u32 *list, RescueBuffers rb, const GappedResult *gappedResults, const GappedJob *gappedJobs,
-                                               FragmentRecord *records, u32 *cigars, u32 *overflowList, u32 *overflowCount, u32 overflowCapacity, const u8 *skip, Counters *counters)
+                                               FragmentRecord *records, u32 *cigars, u32 *overflowList, u32 *overflowCount, u32 overflowCapacity, const u8 *skip, Counters *counters,
+                                               const u32 *order)
 {
     const DevParams &P = constants->P; const DevTls &tls = constants->tls; const RogCorrection &rog = constants->rog;
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     Counters local; memset(&local, 0, sizeof(local));
-    const u32 inChunk = t < nChunk ? (list ? list[t] : t) : 0;
+    // `order`: a permutation of the chunk's clusters, the ones with mate-rescue problems first (see k_select_classes)
+    const u32 inChunk = t < nChunk ? (order ? order[t] : list ? list[t] : t) : 0;
     if (t < nChunk && !(skip && skip[inChunk]))
     {
         TemplateWork work;
@@ -1170,6 +1195,7 @@ int isaac_gpu_create(int device, const isaac_params *params, void *stream, isaac
     if (const char *e = getenv("ISAAC_GPU_CHUNK_CLUSTERS")) c->chunkClusters = u32(std::max(1024, atoi(e)));
     if (const char *e = getenv("ISAAC_GPU_FLAT_RESCUE")) c->flatRescue = atoi(e) != 0;
     if (const char *e = getenv("ISAAC_GPU_DEFERRED_COMPLETION")) c->deferredCompletion = atoi(e) != 0;
+    if (const char *e = getenv("ISAAC_GPU_SELECT_ORDER")) c->selectOrder = u32(std::max(0, atoi(e)));
     *out = c.release();
     return ISAAC_GPU_OK;
     ISAAC_CATCH
@@ -1655,8 +1681,20 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         }
         {
             ScopedTimer tm(c, "select");
+            const u32 *order = nullptr;
+            if (c->selectOrder && c->flatRescue)
+            {
+                c->classFlag.reserve(2 * size_t(chunk)); c->classOrder.reserve(2 * size_t(chunk));
+                u8 *keysIn = c->classFlag.p, *keysOut = c->classFlag.p + chunk; u32 *idIn = c->classOrder.p, *idOut = c->classOrder.p + chunk;
+                k_select_classes<<<gridFor(n, 256), 256, 0, st>>>(rb, n, c->selectOrder, keysIn, idIn);
+                size_t bytes = 0;
+                HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keysIn, keysOut, idIn, idOut, int(n), 0, 2, st));   // stable: the chunk's order inside a class
+                c->cubTemp.reserve(bytes + 16);
+                HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->cubTemp.p, bytes, keysIn, keysOut, idIn, idOut, int(n), 0, 2, st));
+                order = idOut;
+            }
             k_select<<<gridFor(n, 64), 64, 0, st>>>(c->templateConstants.p, R, lmq40, bcl, done, n, tile, c->fragsCur, c->lightArena.p, lightBytes, light, nullptr, rb, c->flatRescue ? gbRescue.results : nullptr, c->flatRescue ? gbRescue.jobs : nullptr,
-                                                     reinterpret_cast<FragmentRecord *>(fragments), cigar, c->overflowList.p, c->overflowCount.p, chunk, predicted ? c->heavyFlag.p : nullptr, c->counters.p);
+                                                     reinterpret_cast<FragmentRecord *>(fragments), cigar, c->overflowList.p, c->overflowCount.p, chunk, predicted ? c->heavyFlag.p : nullptr, c->counters.p, order);
             HIP_CHECK(hipGetLastError());
         }
         {   // what the prediction missed (normally nothing): again, with the reference's own capacities; the count stays on the device
