@@ -127,7 +127,7 @@ def main():
     hbm_used_gb = round((total_b - free_b) / 1e9, 1)      # everything resident at the end of the run: index, reads, records, chunk scratch
     counters = al.counters()
     timers = {k: al.kernel_time_ms(k) for k in ("find_matches", "build_fragments", "align_candidates", "finish_candidates", "indel_fragments", "gapped_fragments", "finish_fragments", "plan_rescue", "rescue_windows", "rescue_align",
-                                                 "rescue_gapped_plan", "gapped_rescue", "select", "select_heavy", "select_residual", "compact_matches")}
+                                                 "rescue_gapped_plan", "gapped_rescue", "select_order", "select", "select_heavy", "select_residual", "compact_matches")}
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()

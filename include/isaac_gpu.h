@@ -235,7 +235,7 @@ int isaac_gpu_get_counters(isaac_gpu_ctx *ctx, isaac_counters *out);
 /* average device time (ms) of the named launch sequence over the launches since the last reset, measured with HIP events on the
  * stream it runs on; names: "find_matches", "compact_matches", "build_fragments", "align_candidates", "finish_candidates",
  * "indel_fragments", "gapped_fragments", "finish_fragments", "load_candidates", "plan_rescue", "rescue_windows", "rescue_align",
- * "rescue_gapped_plan", "gapped_rescue", "select", "select_heavy" (own stream, overlaps "select"), "select_residual",
+ * "rescue_gapped_plan", "gapped_rescue", "select_order", "select", "select_heavy" (own stream, overlaps "select"), "select_residual",
  * "fastq_to_bcl", "bsw" */
 int isaac_gpu_kernel_time_ms(isaac_gpu_ctx *ctx, const char *kernel, double *avg_ms, uint64_t *launches);
 int isaac_gpu_reset_timers(isaac_gpu_ctx *ctx);

@@ -1680,10 +1680,10 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
             HIP_CHECK(hipEventRecord(c->evHeavyDone, c->heavyStream)); c->heavyPending = true;
         }
         {
-            ScopedTimer tm(c, "select");
             const u32 *order = nullptr;
             if (c->selectOrder && c->flatRescue)
             {
+                ScopedTimer tmOrder(c, "select_order");
                 c->classFlag.reserve(2 * size_t(chunk)); c->classOrder.reserve(2 * size_t(chunk));
                 u8 *keysIn = c->classFlag.p, *keysOut = c->classFlag.p + chunk; u32 *idIn = c->classOrder.p, *idOut = c->classOrder.p + chunk;
                 k_select_classes<<<gridFor(n, 256), 256, 0, st>>>(rb, n, c->selectOrder, keysIn, idIn);
@@ -1693,6 +1693,7 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
                 HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->cubTemp.p, bytes, keysIn, keysOut, idIn, idOut, int(n), 0, 2, st));
                 order = idOut;
             }
+            ScopedTimer tm(c, "select");
             k_select<<<gridFor(n, 64), 64, 0, st>>>(c->templateConstants.p, R, lmq40, bcl, done, n, tile, c->fragsCur, c->lightArena.p, lightBytes, light, nullptr, rb, c->flatRescue ? gbRescue.results : nullptr, c->flatRescue ? gbRescue.jobs : nullptr,
                                                      reinterpret_cast<FragmentRecord *>(fragments), cigar, c->overflowList.p, c->overflowCount.p, chunk, predicted ? c->heavyFlag.p : nullptr, c->counters.p, order);
             HIP_CHECK(hipGetLastError());
