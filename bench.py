@@ -187,6 +187,9 @@ def main():
                 "algorithmic_bytes_per_launch": int(per_kernel_bytes[dominant] / launches),
                 "kernel_ms_total": dict({k: round(v, 2) for k, v in total_ms.items()}, select_heavy=round(heavy_ms, 2)),
                 "bytes_per_pair": round(sum(per_kernel_bytes.values()) / pairs_rank, 1),
+                # the whole path of this GPU against the same peak (pairs/s x algorithmic bytes per pair)
+                "path_achieved": round(sum(per_kernel_bytes.values()) / elapsed / 1e9, 2),
+                "path_frac": round(sum(per_kernel_bytes.values()) / elapsed / 1e9 / 8000.0, 6),
                 "heavy_clusters": int(counters.get("heavy_clusters", 0))}
 
     # ---- CPU baseline: the oracle (a port of the reference path) on a bounded sample of the same workload, host cores -------
