@@ -398,3 +398,43 @@ def test_deferred_completion_pipelines_select_calls(torch, monkeypatch):
     plain, _ = run(False)
     for (r1, c1), (r2, c2) in zip(deferred, plain):
         assert not compare_records(r2, c2, r1, c1)
+
+
+def test_chunk_buffers_grow_with_the_calls(torch, monkeypatch):
+    """The chunk-private buffers are sized by the largest call so far: a context that has served small calls serves a larger one
+    (buffers reallocated, also while deferred completion has work in flight) and a small one again, with the records a fresh
+    context produces for each"""
+    from isaac_aligner_amd import gpu, synth
+    monkeypatch.setenv("ISAAC_GPU_DEFERRED_COMPLETION", "1")
+    contigs = _repeat_genome()
+    dev_contigs = [torch.frombuffer(bytearray(c), dtype=torch.uint8).to("cuda") for c in contigs]
+    sizes = [3000, 70000, 2000, 140000, 3000]           # 65536-cluster granules: one, two, one, three, one
+    batches = [synth.make_read_pairs(dev_contigs, n, 150, seed=300 + i, device="cuda")[0] for i, n in enumerate(sizes)]
+    p = options.default_params(150, 150)
+
+    def run(al, b, hits, tls):
+        m, o, _ = al.find_matches(b)
+        al.set_loaded_contigs(hits)
+        out = al.select(b, m, o, tls)
+        return out
+
+    first = gpu.Aligner(p, 0, contigs)
+    first.build_index()
+    m, o, hits = first.find_matches(batches[1])
+    tls = first.determine_tls(batches[1], m, o)
+    hits[:] = 1
+    first.close()
+    reused = gpu.Aligner(p, 0, contigs)
+    reused.build_index()
+    outs = [run(reused, b, hits, tls) for b in batches]                 # back to back, growing and shrinking
+    reused.synchronize()
+    got = [reused.records_to_numpy(r, c) for r, c in outs]
+    reused.close()
+    for b, (r1, c1) in zip(batches, got):
+        fresh = gpu.Aligner(p, 0, contigs)
+        fresh.build_index()
+        out = run(fresh, b, hits, tls)
+        fresh.synchronize()
+        r2, c2 = fresh.records_to_numpy(*out)
+        fresh.close()
+        assert not compare_records(r2, c2, r1, c1)
