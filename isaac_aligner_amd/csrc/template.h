@@ -882,6 +882,32 @@ template <typename K> ISAAC_HD bool smallUniqueSum(K k0, K k1, K k2, K k3, u32 n
     }
     return true;
 }
+// the same for up to eight entries (19-comparator network); used for the shadow lists, whose keys are small enough
+static const u32 SMALL_SHADOW_SUM_MAX = 8;
+template <typename K> ISAAC_HD bool smallUniqueSum8(K k0, K k1, K k2, K k3, K k4, K k5, K k6, K k7, u32 n, double &ret)
+{
+    keyOrder(k0, k1); keyOrder(k2, k3); keyOrder(k4, k5); keyOrder(k6, k7);
+    keyOrder(k0, k2); keyOrder(k1, k3); keyOrder(k4, k6); keyOrder(k5, k7);
+    keyOrder(k1, k2); keyOrder(k5, k6); keyOrder(k0, k4); keyOrder(k3, k7);
+    keyOrder(k1, k5); keyOrder(k2, k6);
+    keyOrder(k1, k4); keyOrder(k3, k6);
+    keyOrder(k2, k4); keyOrder(k3, k5);
+    keyOrder(k3, k4);
+    if ((1 < n && keyNearTie(k0, k1)) || (2 < n && keyNearTie(k1, k2)) || (3 < n && keyNearTie(k2, k3)) || (4 < n && keyNearTie(k3, k4)) ||
+        (5 < n && keyNearTie(k4, k5)) || (6 < n && keyNearTie(k5, k6)) || (7 < n && keyNearTie(k6, k7))) return false;
+    ret = 0.0;
+    K prev = k0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma nounroll
+#endif
+    for (u32 i = 0; i < n; ++i)
+    {
+        const K cur = k0; k0 = k1; k1 = k2; k2 = k3; k3 = k4; k4 = k5; k5 = k6; k6 = k7;
+        if (!(i && keyEqual(prev, cur))) ret += exp(cur.lp);
+        prev = cur;
+    }
+    return true;
+}
 ISAAC_HD ShadowKey shadowKey(const ShadowProb *v, u32 i, u32 n)
 {
     ShadowKey k; k.idx = i;
@@ -903,6 +929,11 @@ ISAAC_HD double sumUniqueShadowProbabilities(TemplateCtx &x, u32 side)
     {
         double sum;
         if (smallUniqueSum(shadowKey(v, 0, n), shadowKey(v, 1, n), shadowKey(v, 2, n), shadowKey(v, 3, n), n, sum)) return sum;
+    }
+    else if (n <= SMALL_SHADOW_SUM_MAX && 1 == x.lanes)
+    {
+        double sum;
+        if (smallUniqueSum8(shadowKey(v, 0, n), shadowKey(v, 1, n), shadowKey(v, 2, n), shadowKey(v, 3, n), shadowKey(v, 4, n), shadowKey(v, 5, n), shadowKey(v, 6, n), shadowKey(v, 7, n), n, sum)) return sum;
     }
     bool exact = true;
     ISAAC_PROF_T0(x);
@@ -961,6 +992,7 @@ ISAAC_HD double sumUniquePairProbabilities(TemplateCtx &x)
         double sum;
         if (smallUniqueSum(pairKey(v, 0, n), pairKey(v, 1, n), pairKey(v, 2, n), pairKey(v, 3, n), n, sum)) return sum;
     }
+
     bool exact = true;
     ISAAC_PROF_T0(x);
     if (x.fastSort && n >= FAST_SORT_MIN)
