@@ -127,6 +127,12 @@ int isaac_gpu_free(isaac_gpu_ctx *ctx, void *dev);
 int isaac_gpu_upload(isaac_gpu_ctx *ctx, void *dev, const void *host, uint64_t bytes);
 int isaac_gpu_download(isaac_gpu_ctx *ctx, void *host, const void *dev, uint64_t bytes);
 int isaac_gpu_synchronize(isaac_gpu_ctx *ctx);
+/* Deferred completion (off by default).  When on, isaac_gpu_select / isaac_gpu_select_candidates return while their last
+ * wave-per-cluster pass (the clusters of repeat families) is still running on an internal stream, so that back-to-back calls
+ * overlap.  The caller then owns the hazard: every buffer handed to such a call (bcl, matches, offsets, fragments, cigar) must
+ * stay allocated and unmodified, and its outputs unread, until isaac_gpu_synchronize() returns; calls in flight need distinct
+ * output buffers.  Every other entry point of the context first waits for that pass.  Turning it off completes what is pending. */
+int isaac_gpu_set_deferred_completion(isaac_gpu_ctx *ctx, int enabled);
 
 /* Replaces reference::loadContigs (include/reference/ContigLoader.hh:84-140, lib/reference/ContigLoader.cpp:29-66):
  * ASCII ACGTN, exactly reference::Contig::forward_, all contigs concatenated in karyotype order;
@@ -136,17 +142,24 @@ int isaac_gpu_load_contigs_dev(isaac_gpu_ctx *ctx, const char *bases_dev, const 
 
 /* Replaces the streaming of the mask files of sorted-reference.xml by matchFinder::ExactMaskMatcher::matchMask
  * (lib/alignment/matchFinder/ExactMaskMatcher.cpp:83-126, MatchFinder.cpp:251-316): the masks (host pointers to the
- * mmap'ed *.dat files, in mask order, which is global k-mer order) are concatenated into one resident sorted table.
- * karyotype_of_contig is SortedReferenceMetadata::Contig::karyotypeIndex_ (MatchFinder.cpp:51-66), NULL = identity. */
+ * mmap'ed *.dat files, in mask order, which is global k-mer order) are concatenated into one resident sorted table, streamed
+ * through device staging buffers 256 MB at a time (no host copy is made; GRCh38: 46 GB).  karyotype_of_contig is
+ * SortedReferenceMetadata::Contig::karyotypeIndex_ (MatchFinder.cpp:51-66: stored contig index -> position in karyotype order,
+ * which is the order of isaac_gpu_load_contigs), n_contigs entries, NULL = identity.  Tables below 2^32 entries. */
 int isaac_gpu_load_index(isaac_gpu_ctx *ctx, const isaac_reference_kmer *const *masks_host, const uint64_t *mask_sizes, uint32_t n_masks,
                          const uint32_t *karyotype_of_contig, uint32_t n_contigs);
 
 /* Replaces isaac-sort-reference (lib/reference/ReferenceSorter.cpp:105-261 + NeighborsFinder.cpp:193-446) for the
- * contigs already loaded: builds the sorted 32-mer table on the device (repeat_threshold = 1000, neighborhood 4).
- * n_entries_out may be NULL. */
+ * contigs already loaded: builds the sorted 32-mer table on the device, one mask (top 6 bits of the k-mer, --mask-width 6) after
+ * the other exactly as the 64 mask files are laid out (repeat_threshold = 1000, neighborhood 4).  Sized for a human genome:
+ * 64-bit positions and counts throughout, below 2^32 table entries.  n_entries_out may be NULL. */
 int isaac_gpu_build_index(isaac_gpu_ctx *ctx, uint32_t repeat_threshold, int annotate_neighbors, uint64_t *n_entries_out);
 /* copies the resident table back in mask-file record layout (capacity in records) */
 int isaac_gpu_get_index(isaac_gpu_ctx *ctx, isaac_reference_kmer *out_host, uint64_t capacity, uint64_t *n_out);
+/* offsets_out[m] = table entries before mask m, m = 0 .. n_masks (the <File> elements of sorted-reference.xml,
+ * lib/reference/SortedReferenceXml.cpp:312-324: one mask file = entries [offsets[m], offsets[m + 1])); n_masks must be the
+ * number of masks the table was loaded or built with (64 for a built one) */
+int isaac_gpu_get_mask_offsets(isaac_gpu_ctx *ctx, uint64_t *offsets_out, uint32_t n_masks);
 
 /* Replaces one tile's worth of alignWorkflow::FindMatchesTransition::findLaneMatches (both seed iterations;
  * lib/workflow/alignWorkflow/FindMatchesTransition.cpp:391-427): alignment::ClusterSeedGenerator::generateThread
@@ -187,9 +200,7 @@ int isaac_gpu_determine_tls(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t
  * the io::FragmentHeader fields FragmentCollector would store.  One record per read, in cluster order:
  * fragments_dev[cluster * n_reads + read]; its CIGAR is cigar_dev[cigar_offset .. + cigar_length);
  * cigar_dev must hold n_clusters * n_reads * ISAAC_GPU_MAX_CIGAR_OPS words.
- * The call returns when the records are complete.  With ISAAC_GPU_DEFERRED_COMPLETION=1 in the environment of isaac_gpu_create it
- * returns while its last wave-per-cluster pass is still running on an internal stream, so that back-to-back calls overlap; the
- * outputs of all calls are then complete after isaac_gpu_synchronize(), and calls in flight need distinct output buffers.
+ * The call returns when the records are complete, unless isaac_gpu_set_deferred_completion(ctx, 1) was called: see there.
  * isaac_fragment::reserved: bit 2 = a fixed internal capacity was exceeded for this cluster (result not exact; counted in
  * isaac_counters::overflow_clusters), bit 1 = the reference would not have stored the template (only without --keep-unaligned). */
 int isaac_gpu_select(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t n_clusters, uint32_t tile,

@@ -13,6 +13,7 @@
 //   index builder    k-mer enumeration + hipCUB radix sort + run analysis (+ 70-permutation neighbour annotation), k_prefix_table
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -23,6 +24,7 @@
 #include "host_util.h"
 #include "bsw_kernel.h"
 #include "fastq_kernel.h"
+#include "index_kernels.h"
 
 #if defined(ISAAC_KERNEL_STAMPS)
 __device__ unsigned long long g_stamps[64];
@@ -48,6 +50,7 @@ struct HipError : std::runtime_error { hipError_t code; HipError(hipError_t c, c
 template <typename T> struct DevBuf
 {
     T *p = nullptr; size_t n = 0;
+    DevBuf() = default; DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
     void reserve(size_t count) { if (count > n) { release(); HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T))); n = count; } }
     void release() { if (p) { hipFree(p); p = nullptr; n = 0; } }
     ~DevBuf() { release(); }
@@ -64,7 +67,7 @@ struct isaac_gpu_ctx
     DevBuf<char> basesOwned; const char *bases = nullptr;
     DevBuf<u64> contigOffset; std::vector<u64> hContigOffset; DevBuf<u8> contigLoaded; std::vector<u8> hContigLoaded; u32 nContigs = 0;
     DevBuf<u64> kmers, positions; u64 nKmers = 0; DevBuf<u32> karyotype; bool hasKaryotype = false;
-    DevBuf<u32> prefixTable; u32 prefixBits = 0;
+    DevBuf<u32> prefixTable; u32 prefixBits = 0; std::vector<u64> maskOffsets;   // entries before each mask of the table (load_index / build_index)
     DevBuf<u8> classFlag; DevBuf<u32> classOrder; u32 selectOrder = 2;      // work classes of k_select, most work first (ISAAC_GPU_SELECT_ORDER: 0 = chunk order, 2..4 classes)   // longest-first order of the light select pass
     DevBuf<u32> packedBases, notBase;   // 2-bit copy of the contigs + not-ACGT bitmap (k_rescue_windows reads these)
     DevBuf<u64> matchBase;
@@ -996,123 +999,6 @@ __global__ __launch_bounds__(64) void k_select_heavy(DevParams P, DevReference R
     flushCounters(local, counters);
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// index builder (ReferenceSorter.cpp:105-261, NeighborsFinder.cpp:193-446)
-__global__ void k_kmer_flags(const char *bases, const u64 *contigOffset, u32 nContigs, u64 totalBases, u32 *valid)
-{
-    // position p (global) ends a valid 32-mer iff the last 32 bases are ACGT and lie in one contig; computed naively per position
-    const u64 p = u64(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (p >= totalBases) return;
-    // contig of p by binary search
-    u32 lo = 0, hi = nContigs;
-    while (lo + 1 < hi) { const u32 mid = (lo + hi) >> 1; if (contigOffset[mid] <= p) lo = mid; else hi = mid; }
-    const u64 start = contigOffset[lo];
-    u32 ok = (p + 1 >= start + 32);
-    if (ok) for (u32 i = 0; i < 32; ++i) { const char c = bases[p - i]; if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T')) { ok = 0; break; } }
-    valid[p] = ok;
-}
-__global__ void k_kmer_emit(const char *bases, const u64 *contigOffset, u32 nContigs, u64 totalBases, const u32 *valid, const u32 *slot, u64 *keys, u64 *vals)
-{
-    const u64 p = u64(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (p >= totalBases || !valid[p]) return;
-    u32 lo = 0, hi = nContigs;
-    while (lo + 1 < hi) { const u32 mid = (lo + hi) >> 1; if (contigOffset[mid] <= p) lo = mid; else hi = mid; }
-    u64 fwd = 0, rc = 0;
-    for (u32 i = 0; i < 32; ++i)
-    {
-        const char c = bases[p - 31 + i];
-        const u64 v = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3;
-        fwd = (fwd << 2) | v; rc = (rc >> 2) | (((~v) & 3) << 62);
-    }
-    const u64 kmerPosition = p - 31 - contigOffset[lo];
-    const u64 s = u64(slot[p]) * 2;
-    keys[s] = fwd; vals[s] = refpos(lo, kmerPosition, false);      // forward strand entries are the ones that get stored
-    keys[s + 1] = rc; vals[s + 1] = refpos(lo, kmerPosition, true); // reverse-complement entries only take part in the repeat count
-}
-__global__ void k_run_heads(const u64 *keys, u64 n, u32 *head, u32 *isFwd, const u64 *vals)
-{
-    const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
-    isFwd[i] = (vals[i] & 1) ? 0 : 1;
-}
-// runId = inclusive scan of head - 1; per run: start index, total count, forward count (atomics on small arrays are avoided:
-// the last element of a run writes the totals using the prefix sums)
-__global__ void k_run_totals(const u64 *keys, u64 n, const u32 *runIdIncl, const u32 *fwdExcl, const u32 *isFwd, u32 *runStart, u32 *runTotal, u32 *runFwd)
-{
-    const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const u32 run = runIdIncl[i] - 1;
-    if (i == 0 || keys[i] != keys[i - 1]) runStart[run] = u32(i);
-    if (i + 1 == n || keys[i] != keys[i + 1])
-    {
-        // start may be written by another thread: recompute it from the run totals written later; use a second kernel for the totals
-        runTotal[run] = u32(i);          // temporarily the index of the last element
-        runFwd[run] = fwdExcl[i] + isFwd[i]; // temporarily the inclusive forward prefix at the end
-    }
-}
-__global__ void k_run_finish(u32 nRuns, const u32 *fwdExcl, const u32 *runStart, u32 *runTotal, u32 *runFwd)
-{
-    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nRuns) return;
-    const u32 start = runStart[r];
-    runTotal[r] = runTotal[r] - start + 1;
-    runFwd[r] = runFwd[r] - fwdExcl[start];
-}
-__global__ void k_emit_flags(const u64 *keys, u64 n, const u32 *runIdIncl, const u32 *isFwd, const u32 *runStart, const u32 *runTotal, const u32 *runFwd, u32 repeatThreshold, u32 *emit)
-{
-    const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const u32 run = runIdIncl[i] - 1;
-    u32 e = 0;
-    if (runFwd[run])
-    {
-        if (repeatThreshold < runTotal[run]) e = (runStart[run] == i) ? 1 : 0;   // a single TooManyMatch entry (ReferenceSorter.cpp:201-222)
-        else e = isFwd[i];
-    }
-    emit[i] = e;
-}
-__global__ void k_emit_entries(const u64 *keys, const u64 *vals, u64 n, const u32 *runIdIncl, const u32 *runTotal, u32 repeatThreshold, const u32 *emit, const u32 *emitSlot,
-                               const u8 *runHasNeighbors, u64 *outKmers, u64 *outPositions)
-{
-    const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n || !emit[i]) return;
-    const u32 run = runIdIncl[i] - 1;
-    const u32 s = emitSlot[i];
-    outKmers[s] = keys[i];
-    if (repeatThreshold < runTotal[run]) outPositions[s] = 0;
-    else outPositions[s] = (vals[i] & ~u64(1)) | u64(runHasNeighbors ? runHasNeighbors[run] : 0);
-}
-// neighbour annotation: distinct k-mers (both strands) = run heads
-__global__ void k_distinct(const u64 *keys, u64 n, const u32 *head, const u32 *runIdIncl, u64 *distinct)
-{
-    const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n || !head[i]) return;
-    distinct[runIdIncl[i] - 1] = keys[i];
-}
-__global__ void k_mask_keys(const u64 *distinct, u32 n, u64 keep, u64 *keys, u32 *vals)
-{
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    keys[i] = distinct[i] & keep; vals[i] = i;
-}
-__device__ inline u32 hamming2bit(u64 a, u64 b) { u64 x = a ^ b; x = (x | (x >> 1)) & 0x5555555555555555ULL; return u32(__popcll(x)); }
-__global__ void k_mark_neighbors(const u64 *sortedKeys, const u32 *sortedVals, u32 n, const u64 *distinct, u8 *hasNeighbors)
-{
-    // NeighborsFinder::markNeighbors (:395-446): inside a block of k-mers sharing the 16 kept bases, every pair within
-    // Hamming distance 1..4 marks both members
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const u64 key = sortedKeys[i]; const u64 mine = distinct[sortedVals[i]];
-    bool any = false;
-    for (u32 j = i + 1; j < n && sortedKeys[j] == key; ++j)
-    {
-        const u32 d = hamming2bit(mine, distinct[sortedVals[j]]);
-        if (d && d <= 4) { hasNeighbors[sortedVals[j]] = 1; any = true; }
-    }
-    if (any) hasNeighbors[sortedVals[i]] = 1;
-}
-
 u32 gridFor(u64 n, u32 block) { return u32((n + block - 1) / block); }
 
 template <typename T> void exclusiveSum(isaac_gpu_ctx *c, const T *in, T *out, size_t n)
@@ -1153,7 +1039,7 @@ void buildPrefixTable(isaac_gpu_ctx *c)
 {
     c->prefixBits = 0;
     if (!c->nKmers || c->nKmers >= (u64(1) << 32) || getenv("ISAAC_GPU_NO_PREFIX_TABLE")) return;
-    u32 bits = 16; while (bits < 28 && (u64(1) << bits) < c->nKmers) ++bits;     // about one entry per bucket, 256 KB .. 1 GB
+    u32 bits = 16; while (bits < 30 && (u64(1) << bits) < c->nKmers) ++bits;     // about one entry per bucket (human: 2.7), 256 KB .. 4 GB
     const u64 entries = (u64(1) << bits) + 1;
     c->prefixTable.reserve(entries + 1);                                            // + 1: the last bucket reads a pair
     k_prefix_table<<<gridFor(entries, 256), 256, 0, c->stream>>>(c->kmers.p, c->nKmers, bits, c->prefixTable.p);
@@ -1194,7 +1080,6 @@ int isaac_gpu_create(int device, const isaac_params *params, void *stream, isaac
     HIP_CHECK(hipEventCreateWithFlags(&c->evPredicted, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&c->evHeavyDone, hipEventDisableTiming));
     if (const char *e = getenv("ISAAC_GPU_CHUNK_CLUSTERS")) c->chunkClusters = u32(std::max(1024, atoi(e)));
     if (const char *e = getenv("ISAAC_GPU_FLAT_RESCUE")) c->flatRescue = atoi(e) != 0;
-    if (const char *e = getenv("ISAAC_GPU_DEFERRED_COMPLETION")) c->deferredCompletion = atoi(e) != 0;
     if (const char *e = getenv("ISAAC_GPU_SELECT_ORDER")) c->selectOrder = u32(std::max(0, atoi(e)));
     *out = c.release();
     return ISAAC_GPU_OK;
@@ -1225,8 +1110,16 @@ int isaac_gpu_free(isaac_gpu_ctx *c, void *dev) { ISAAC_TRY HIP_CHECK(hipSetDevi
 int isaac_gpu_upload(isaac_gpu_ctx *c, void *dev, const void *host, uint64_t bytes)
 { ISAAC_TRY HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
 int isaac_gpu_download(isaac_gpu_ctx *c, void *host, const void *dev, uint64_t bytes)
-{ ISAAC_TRY HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
+{ ISAAC_TRY joinHeavy(c); HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
 int isaac_gpu_synchronize(isaac_gpu_ctx *c) { ISAAC_TRY joinHeavy(c); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
+int isaac_gpu_set_deferred_completion(isaac_gpu_ctx *c, int enabled)
+{
+    ISAAC_TRY
+    if (!enabled) { joinHeavy(c); HIP_CHECK(hipStreamSynchronize(c->stream)); }
+    c->deferredCompletion = enabled != 0;
+    return 0;
+    ISAAC_CATCH
+}
 
 // 32 bases per thread: two words of 2-bit codes and one word of not-ACGT flags
 __global__ void k_pack_reference(const char *bases, u64 totalBases, u32 *packed, u32 *notBase, u64 nWords32)
@@ -1286,20 +1179,56 @@ int isaac_gpu_load_contigs_dev(isaac_gpu_ctx *c, const char *bases_dev, const ui
     ISAAC_CATCH
 }
 
+// The mask files are streamed in mask order through two device staging buffers (the copy of one chunk overlaps the split of the
+// previous one); the host never holds more than the caller's own mappings.
 int isaac_gpu_load_index(isaac_gpu_ctx *c, const isaac_reference_kmer *const *masks, const uint64_t *sizes, uint32_t nMasks, const uint32_t *karyotype, uint32_t nContigs)
 {
     ISAAC_TRY
     HIP_CHECK(hipSetDevice(c->device));
+    if (nMasks && (!masks || !sizes)) return fail(ISAAC_GPU_EINVAL, "masks_host and mask_sizes are required");
+    if (karyotype && nContigs != c->nContigs) return fail(ISAAC_GPU_EINVAL, "karyotype_of_contig needs one entry per loaded contig");
     u64 total = 0; for (u32 m = 0; m < nMasks; ++m) total += sizes[m];
-    std::vector<u64> k(total), p(total);
-    u64 at = 0;
-    for (u32 m = 0; m < nMasks; ++m) for (u64 i = 0; i < sizes[m]; ++i, ++at)
+    if (total >= (u64(1) << 32)) return fail(ISAAC_GPU_EINVAL, "tables of 2^32 entries and more are not supported");
+    hipStream_t st = c->stream;
+    c->kmers.reserve(total + 1); c->positions.reserve(total + 1); c->nKmers = 0; c->prefixBits = 0;
+    const u64 chunk = 1u << 24;      // records per staging buffer (256 MB)
+    DevBuf<ReferenceKmerRecord> staging[2]; DevBuf<u32> disorder; disorder.reserve(1);
+    HIP_CHECK(hipMemsetAsync(disorder.p, 0, 4, st));
+    hipStream_t copyStream; HIP_CHECK(hipStreamCreateWithFlags(&copyStream, hipStreamNonBlocking));
+    hipEvent_t copied[2], split[2];
+    for (u32 i = 0; i < 2; ++i) { HIP_CHECK(hipEventCreateWithFlags(&copied[i], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&split[i], hipEventDisableTiming)); }
+    c->maskOffsets.assign(1, 0);
+    u64 at = 0; u32 turn = 0; bool used[2] = { false, false };
+    try
     {
-        k[at] = masks[m][i].kmer; p[at] = masks[m][i].position;
-        if (at && k[at] < k[at - 1]) return fail(ISAAC_GPU_EINVAL, "mask files are not in global k-mer order");
+        HIP_CHECK(hipStreamSynchronize(st));
+        for (u32 m = 0; m < nMasks; ++m)
+        {
+            for (u64 done = 0; done < sizes[m]; done += chunk, turn ^= 1)
+            {
+                const u64 n = std::min(chunk, sizes[m] - done);
+                staging[turn].reserve(chunk);
+                if (used[turn]) HIP_CHECK(hipStreamWaitEvent(copyStream, split[turn], 0));     // its previous contents have been split
+                HIP_CHECK(hipMemcpyAsync(staging[turn].p, masks[m] + done, n * sizeof(ReferenceKmerRecord), hipMemcpyHostToDevice, copyStream));
+                HIP_CHECK(hipEventRecord(copied[turn], copyStream));
+                HIP_CHECK(hipStreamWaitEvent(st, copied[turn], 0));
+                k_split_records<<<gridFor(n, 256), 256, 0, st>>>(staging[turn].p, n, at, c->kmers.p, c->positions.p, disorder.p);
+                k_check_boundary<<<1, 1, 0, st>>>(c->kmers.p, at, disorder.p);
+                HIP_CHECK(hipGetLastError());
+                HIP_CHECK(hipEventRecord(split[turn], st)); used[turn] = true;
+                at += n;
+            }
+            c->maskOffsets.push_back(at);
+        }
+        u32 bad = 0;
+        HIP_CHECK(hipMemcpyAsync(&bad, disorder.p, 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st)); HIP_CHECK(hipStreamSynchronize(copyStream));
+        for (u32 i = 0; i < 2; ++i) { hipEventDestroy(copied[i]); hipEventDestroy(split[i]); }
+        hipStreamDestroy(copyStream);
+        if (bad) return fail(ISAAC_GPU_EINVAL, "mask files are not in global k-mer order");
     }
-    c->kmers.reserve(total + 1); c->positions.reserve(total + 1); c->nKmers = total;
-    if (total) { HIP_CHECK(hipMemcpy(c->kmers.p, k.data(), total * 8, hipMemcpyHostToDevice)); HIP_CHECK(hipMemcpy(c->positions.p, p.data(), total * 8, hipMemcpyHostToDevice)); }
+    catch (...) { hipStreamSynchronize(copyStream); hipStreamDestroy(copyStream); for (u32 i = 0; i < 2; ++i) { hipEventDestroy(copied[i]); hipEventDestroy(split[i]); } throw; }
+    c->nKmers = total;
     buildPrefixTable(c);
     c->hasKaryotype = false;
     if (karyotype)
@@ -1311,67 +1240,155 @@ int isaac_gpu_load_index(isaac_gpu_ctx *c, const isaac_reference_kmer *const *ma
     ISAAC_CATCH
 }
 
+namespace
+{
+// One mask of the table (see index_kernels.h): its k-mers emitted in position order, sorted, analysed and appended.
+struct IndexScratch
+{
+    DevBuf<u64> keys0, vals0, keys, vals, blockBase;
+    DevBuf<u32> head, isFwd, runId, fwdExcl, runStart, runTotal, runFwd, emit, emitSlot;
+    void release()
+    {
+        keys0.release(); vals0.release(); keys.release(); vals.release(); blockBase.release(); head.release(); isFwd.release(); runId.release(); fwdExcl.release();
+        runStart.release(); runTotal.release(); runFwd.release(); emit.release(); emitSlot.release();
+    }
+};
+
+// out byte j of the shuffled key = key byte src[j] (byte 0 = least significant)
+ByteShuffle makeShuffle(const u32 src[8])
+{
+    ByteShuffle s; s.selLo = 0; s.selHi = 0;
+    for (u32 j = 0; j < 4; ++j) { s.selLo |= src[j] << (8 * j); s.selHi |= src[4 + j] << (8 * j); }
+    return s;
+}
+// layout of the key under a choice of 4 of the 8 four-base blocks: the chosen bytes in the low half (the sorted half, see
+// k_mark_neighbors), the others above, both in descending significance.  at[b] = where byte b of the k-mer sits.
+void blockLayout(u32 chosen, u32 at[8])
+{
+    u32 hi = 7, lo = 3;
+    for (int b = 7; b >= 0; --b) { if ((chosen >> b) & 1) at[b] = lo--; else at[b] = hi--; }
+}
+} // namespace
+
 int isaac_gpu_build_index(isaac_gpu_ctx *c, uint32_t repeatThreshold, int annotateNeighbors, uint64_t *nEntriesOut)
 {
     ISAAC_TRY
     HIP_CHECK(hipSetDevice(c->device));
     if (!c->bases) return fail(ISAAC_GPU_EINVAL, "load the contigs first");
+    joinHeavy(c);
     const u64 totalBases = c->hContigOffset[c->nContigs];
-    if (totalBases >= (u64(1) << 30)) return fail(ISAAC_GPU_EINVAL, "the device index builder handles references below 2^30 bases (bigger ones: build per mask and isaac_gpu_load_index)");
     hipStream_t st = c->stream;
-    DevBuf<u32> valid, slot; valid.reserve(totalBases + 1); slot.reserve(totalBases + 1);
-    k_kmer_flags<<<gridFor(totalBases, 256), 256, 0, st>>>(c->bases, c->contigOffset.p, c->nContigs, totalBases, valid.p);
-    exclusiveSum(c, valid.p, slot.p, totalBases);
-    u32 lastSlot = 0, lastValid = 0;
-    HIP_CHECK(hipMemcpyAsync(&lastSlot, slot.p + totalBases - 1, 4, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(&lastValid, valid.p + totalBases - 1, 4, hipMemcpyDeviceToHost, st));
+    const u32 *packed = c->packedBases.p, *notBase = c->notBase.p;
+    const u64 nBlocks = (totalBases + INDEX_TILE - 1) / INDEX_TILE;
+    if (nBlocks >= (u64(1) << 31)) return fail(ISAAC_GPU_EINVAL, "reference too long");
+    c->nKmers = 0; c->prefixBits = 0; c->hasKaryotype = false; c->maskOffsets.assign(1, 0);
+    // 1. how many k-mers of each mask every block of positions holds
+    DevBuf<u32> counts; counts.reserve(size_t(INDEX_MASKS) * nBlocks);
+    DevBuf<unsigned long long> validCount; validCount.reserve(1);
+    HIP_CHECK(hipMemsetAsync(validCount.p, 0, 8, st));
+    k_index_count<<<u32(nBlocks), INDEX_THREADS, 0, st>>>(packed, notBase, c->contigOffset.p, c->nContigs, totalBases, nBlocks, counts.p, validCount.p);
+    HIP_CHECK(hipGetLastError());
+    unsigned long long nValid = 0;
+    HIP_CHECK(hipMemcpyAsync(&nValid, validCount.p, 8, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    const u64 n = 2 * u64(lastSlot + lastValid);
-    if (!n) { c->nKmers = 0; c->prefixBits = 0; c->kmers.reserve(1); c->positions.reserve(1); if (nEntriesOut) *nEntriesOut = 0; return 0; }
-    DevBuf<u64> keys0, vals0, keys, vals; keys0.reserve(n); vals0.reserve(n); keys.reserve(n); vals.reserve(n);
-    k_kmer_emit<<<gridFor(totalBases, 256), 256, 0, st>>>(c->bases, c->contigOffset.p, c->nContigs, totalBases, valid.p, slot.p, keys0.p, vals0.p);
-    sortPairs(c, keys0.p, keys.p, vals0.p, vals.p, n);
-    keys0.release(); vals0.release(); valid.release(); slot.release();
-    DevBuf<u32> head, isFwd, runId, fwdExcl; head.reserve(n); isFwd.reserve(n); runId.reserve(n); fwdExcl.reserve(n);
-    k_run_heads<<<gridFor(n, 256), 256, 0, st>>>(keys.p, n, head.p, isFwd.p, vals.p);
-    inclusiveSum(c, head.p, runId.p, n);
-    exclusiveSum(c, isFwd.p, fwdExcl.p, n);
-    u32 nRuns = 0;
-    HIP_CHECK(hipMemcpyAsync(&nRuns, runId.p + n - 1, 4, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    DevBuf<u32> runStart, runTotal, runFwd; runStart.reserve(nRuns); runTotal.reserve(nRuns); runFwd.reserve(nRuns);
-    k_run_totals<<<gridFor(n, 256), 256, 0, st>>>(keys.p, n, runId.p, fwdExcl.p, isFwd.p, runStart.p, runTotal.p, runFwd.p);
-    k_run_finish<<<gridFor(nRuns, 256), 256, 0, st>>>(nRuns, fwdExcl.p, runStart.p, runTotal.p, runFwd.p);
-    DevBuf<u8> runNeighbors;
-    if (annotateNeighbors)
+    if (nValid >= (u64(1) << 32)) return fail(ISAAC_GPU_EINVAL, "tables of 2^32 entries and more are not supported");
+    // every stored entry is a forward-strand occurrence: nValid bounds the table, 2 * nValid the distinct k-mers of both strands
+    c->kmers.reserve(nValid + 1); c->positions.reserve(nValid + 1);
+    DevBuf<u64> distinct; DevBuf<u32> entryRun;
+    if (annotateNeighbors) { distinct.reserve(2 * nValid + 1); entryRun.reserve(nValid + 1); }
+    std::vector<u64> distinctBase(1, 0);
+    IndexScratch w;
+    w.blockBase.reserve(nBlocks + 1);
+    u64 nOut = 0, nDistinct = 0;
+    for (u32 mask = 0; mask < INDEX_MASKS; ++mask)
     {
-        runNeighbors.reserve(nRuns);
-        HIP_CHECK(hipMemsetAsync(runNeighbors.p, 0, nRuns, st));
-        DevBuf<u64> distinct, mkeys, mkeysSorted; DevBuf<u32> mvals, mvalsSorted;
-        distinct.reserve(nRuns); mkeys.reserve(nRuns); mkeysSorted.reserve(nRuns); mvals.reserve(nRuns); mvalsSorted.reserve(nRuns);
-        k_distinct<<<gridFor(n, 256), 256, 0, st>>>(keys.p, n, head.p, runId.p, distinct.p);
-        for (u32 mask = 0; mask < 256; ++mask)
-        {   // any 4 of the 8 blocks of 4 bases are kept (oligo/Permutate.cpp:94-145: C(8,4) = 70 permutations)
-            if (__builtin_popcount(mask) != 4) continue;
-            u64 keep = 0; for (u32 b = 0; b < 8; ++b) if ((mask >> b) & 1) keep |= u64(0xff) << (8 * b);
-            k_mask_keys<<<gridFor(nRuns, 256), 256, 0, st>>>(distinct.p, nRuns, keep, mkeys.p, mvals.p);
-            sortPairs(c, mkeys.p, mkeysSorted.p, mvals.p, mvalsSorted.p, nRuns);
-            k_mark_neighbors<<<gridFor(nRuns, 256), 256, 0, st>>>(mkeysSorted.p, mvalsSorted.p, nRuns, distinct.p, runNeighbors.p);
+        // 2. the mask's k-mers in position order
+        k_index_widen<<<gridFor(nBlocks, 256), 256, 0, st>>>(counts.p + size_t(mask) * nBlocks, nBlocks, w.blockBase.p);
+        u64 lastCount = 0, lastBase = 0;
+        HIP_CHECK(hipMemcpyAsync(&lastCount, w.blockBase.p + nBlocks - 1, 8, hipMemcpyDeviceToHost, st));
+        exclusiveSum(c, w.blockBase.p, w.blockBase.p, nBlocks);
+        HIP_CHECK(hipMemcpyAsync(&lastBase, w.blockBase.p + nBlocks - 1, 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        const u64 n = lastBase + lastCount;
+        if (n >= (u64(1) << 31)) return fail(ISAAC_GPU_EINVAL, "more than 2^31 k-mers in one mask (a degenerate reference)");
+        if (n)
+        {
+            w.keys0.reserve(n); w.vals0.reserve(n); w.keys.reserve(n); w.vals.reserve(n);
+            k_index_emit<<<u32(nBlocks), INDEX_THREADS, 0, st>>>(packed, notBase, c->contigOffset.p, c->nContigs, totalBases, mask, w.blockBase.p, w.keys0.p, w.vals0.p);
+            HIP_CHECK(hipGetLastError());
+            // 3. sorted by k-mer (stable: position order inside a run, forward strand first); the mask bits are equal
+            sortPairs(c, w.keys0.p, w.keys.p, w.vals0.p, w.vals.p, n, 64 - int(INDEX_MASK_BITS));
+            // 4. runs of equal k-mers: ReferenceSorter.cpp:179-252
+            w.head.reserve(n); w.isFwd.reserve(n); w.runId.reserve(n); w.fwdExcl.reserve(n); w.emit.reserve(n); w.emitSlot.reserve(n);
+            k_run_heads<<<gridFor(n, 256), 256, 0, st>>>(w.keys.p, n, w.head.p, w.isFwd.p, w.vals.p);
+            inclusiveSum(c, w.head.p, w.runId.p, n);
+            exclusiveSum(c, w.isFwd.p, w.fwdExcl.p, n);
+            u32 nRuns = 0;
+            HIP_CHECK(hipMemcpyAsync(&nRuns, w.runId.p + n - 1, 4, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            w.runStart.reserve(nRuns); w.runTotal.reserve(nRuns); w.runFwd.reserve(nRuns);
+            k_run_totals<<<gridFor(n, 256), 256, 0, st>>>(w.keys.p, n, w.runId.p, w.fwdExcl.p, w.isFwd.p, w.runStart.p, w.runTotal.p, w.runFwd.p);
+            k_run_finish<<<gridFor(nRuns, 256), 256, 0, st>>>(nRuns, w.fwdExcl.p, w.runStart.p, w.runTotal.p, w.runFwd.p);
+            k_emit_flags<<<gridFor(n, 256), 256, 0, st>>>(n, w.runId.p, w.isFwd.p, w.runStart.p, w.runTotal.p, w.runFwd.p, repeatThreshold, w.emit.p);
+            exclusiveSum(c, w.emit.p, w.emitSlot.p, n);
+            u32 lastE = 0, lastS = 0;
+            HIP_CHECK(hipMemcpyAsync(&lastE, w.emit.p + n - 1, 4, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipMemcpyAsync(&lastS, w.emitSlot.p + n - 1, 4, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            k_emit_entries<<<gridFor(n, 256), 256, 0, st>>>(w.keys.p, w.vals.p, n, w.runId.p, w.runTotal.p, repeatThreshold, w.emit.p, w.emitSlot.p, nOut, c->kmers.p, c->positions.p,
+                                                              annotateNeighbors ? entryRun.p : nullptr);
+            if (annotateNeighbors) k_distinct<<<gridFor(n, 256), 256, 0, st>>>(w.keys.p, n, w.head.p, w.runId.p, nDistinct, distinct.p);
+            HIP_CHECK(hipGetLastError());
+            nOut += u64(lastE) + lastS; nDistinct += nRuns;
         }
+        c->maskOffsets.push_back(nOut); distinctBase.push_back(nDistinct);
     }
-    DevBuf<u32> emit, emitSlot; emit.reserve(n); emitSlot.reserve(n);
-    k_emit_flags<<<gridFor(n, 256), 256, 0, st>>>(keys.p, n, runId.p, isFwd.p, runStart.p, runTotal.p, runFwd.p, repeatThreshold, emit.p);
-    exclusiveSum(c, emit.p, emitSlot.p, n);
-    u32 lastE = 0, lastS = 0;
-    HIP_CHECK(hipMemcpyAsync(&lastE, emit.p + n - 1, 4, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(&lastS, emitSlot.p + n - 1, 4, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    const u64 nOut = u64(lastE) + lastS;
-    c->kmers.reserve(nOut + 1); c->positions.reserve(nOut + 1); c->nKmers = nOut;
-    k_emit_entries<<<gridFor(n, 256), 256, 0, st>>>(keys.p, vals.p, n, runId.p, runTotal.p, repeatThreshold, emit.p, emitSlot.p,
-                                                      annotateNeighbors ? runNeighbors.p : nullptr, c->kmers.p, c->positions.p);
-    HIP_CHECK(hipStreamSynchronize(st));
-    c->hasKaryotype = false;
+    w.release(); counts.release();
+    if (annotateNeighbors && nDistinct)
+    {
+        // 5. NeighborsFinder::generateNeighbors: 70 groupings of the distinct k-mers of both strands
+        DevBuf<u64> keysAlt; DevBuf<u8> flags, flagsAlt;
+        keysAlt.reserve(nDistinct); flags.reserve(nDistinct); flagsAlt.reserve(nDistinct);
+        HIP_CHECK(hipMemsetAsync(flags.p, 0, nDistinct, st));
+        hipcub::DoubleBuffer<u64> dk(distinct.p, keysAlt.p); hipcub::DoubleBuffer<u8> df(flags.p, flagsAlt.p);
+        u32 at[8]; for (u32 b = 0; b < 8; ++b) at[b] = b;           // where byte b of the k-mer sits in the keys right now
+        auto shuffleTo = [&](const u32 next[8])
+        {
+            u32 src[8];                                                // out byte next[b] = current byte at[b]
+            for (u32 b = 0; b < 8; ++b) src[next[b]] = at[b];
+            k_shuffle_keys<<<gridFor(nDistinct, 256), 256, 0, st>>>(dk.Current(), nDistinct, makeShuffle(src));
+            for (u32 b = 0; b < 8; ++b) at[b] = next[b];
+        };
+        auto sortKeys = [&](int endBit)
+        {
+            size_t bytes = 0;
+            HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dk, df, size_t(nDistinct), 0, endBit, st));
+            c->cubTemp.reserve(bytes + 16);
+            HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->cubTemp.p, bytes, dk, df, size_t(nDistinct), 0, endBit, st));
+        };
+        for (u32 chosen = 0; chosen < 256; ++chosen)
+        {   // any 4 of the 8 blocks of 4 bases (oligo/Permutate.cpp:94-145, getPermutateList(4) at NeighborsFinder.cpp:196)
+            if (__builtin_popcount(chosen) != 4) continue;
+            u32 next[8]; blockLayout(chosen, next);
+            shuffleTo(next);
+            sortKeys(32);                                              // groups of equal chosen blocks
+            k_mark_neighbors<<<gridFor(nDistinct, 256), 256, 0, st>>>(dk.Current(), df.Current(), nDistinct);
+            HIP_CHECK(hipGetLastError());
+        }
+        u32 identity[8]; for (u32 b = 0; b < 8; ++b) identity[b] = b;
+        shuffleTo(identity);
+        sortKeys(64);                                                  // back in the order of `distinct`: flags[i] belongs to distinct k-mer i
+        for (u32 mask = 0; mask < INDEX_MASKS; ++mask)
+        {
+            const u64 first = c->maskOffsets[mask], n = c->maskOffsets[mask + 1] - first;
+            if (n) k_apply_neighbors<<<gridFor(n, 256), 256, 0, st>>>(c->positions.p, entryRun.p, first, n, distinctBase[mask], df.Current());
+        }
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
+    c->cubTemp.release();
+    c->nKmers = nOut;
     buildPrefixTable(c);
     if (nEntriesOut) *nEntriesOut = nOut;
     return 0;
@@ -1381,12 +1398,32 @@ int isaac_gpu_build_index(isaac_gpu_ctx *c, uint32_t repeatThreshold, int annota
 int isaac_gpu_get_index(isaac_gpu_ctx *c, isaac_reference_kmer *out, uint64_t capacity, uint64_t *nOut)
 {
     ISAAC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
     if (nOut) *nOut = c->nKmers;
     if (!out) return 0;
     if (capacity < c->nKmers) return fail(ISAAC_GPU_ECAPACITY, "index buffer too small");
-    std::vector<u64> k(c->nKmers), p(c->nKmers);
-    if (c->nKmers) { HIP_CHECK(hipMemcpy(k.data(), c->kmers.p, c->nKmers * 8, hipMemcpyDeviceToHost)); HIP_CHECK(hipMemcpy(p.data(), c->positions.p, c->nKmers * 8, hipMemcpyDeviceToHost)); }
-    for (u64 i = 0; i < c->nKmers; ++i) { out[i].kmer = k[i]; out[i].position = p[i]; }
+    static_assert(sizeof(ReferenceKmerRecord) == sizeof(isaac_reference_kmer), "mask file record");
+    const u64 chunk = 1u << 24;
+    DevBuf<ReferenceKmerRecord> staging; staging.reserve(std::min<u64>(chunk, std::max<u64>(c->nKmers, 1)));
+    for (u64 done = 0; done < c->nKmers; done += chunk)
+    {
+        const u64 n = std::min(chunk, c->nKmers - done);
+        k_join_records<<<gridFor(n, 256), 256, 0, c->stream>>>(c->kmers.p, c->positions.p, done, n, staging.p);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(out + done, staging.p, n * sizeof(ReferenceKmerRecord), hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+    ISAAC_CATCH
+}
+
+// entries of the resident table before each mask (n_masks + 1 values, mask = the k-mer's top 6 bits): where a writer of
+// sorted-reference mask files cuts it
+int isaac_gpu_get_mask_offsets(isaac_gpu_ctx *c, uint64_t *offsetsOut, uint32_t nMasks)
+{
+    ISAAC_TRY
+    if (!offsetsOut || nMasks + 1 != c->maskOffsets.size()) return fail(ISAAC_GPU_EINVAL, "the resident table has a different number of masks");
+    std::copy(c->maskOffsets.begin(), c->maskOffsets.end(), offsetsOut);
     return 0;
     ISAAC_CATCH
 }
@@ -1474,10 +1511,13 @@ static void launchGappedJobs(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clusterBa
     HIP_CHECK(hipGetLastError());
 }
 
+// the calls that run the fragment stage alone write the first of the two ClusterFragments buffers, sized for the chunk in use
+static void useFragments(isaac_gpu_ctx *c) { c->frags.reserve(c->chunkNow); c->fragsCur = c->frags.p; }
+
 static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clusterBase, u32 n, const isaac_match *matches, const uint64_t *offsets, int withGaps, int trim)
 {
-    c->frags.reserve(c->chunkNow); c->fragWork.reserve(c->chunkNow); c->indelList.reserve(c->chunkNow);
-    if (c->fragsCur != c->frags.p && (!c->fragsAlt.p || c->fragsCur != c->fragsAlt.p)) c->fragsCur = c->frags.p;   // first use, or the buffers grew
+    // c->fragsCur (the ClusterFragments buffer of this chunk) is the caller's choice: see useFragments / selectFromSource
+    c->fragWork.reserve(c->chunkNow); c->indelList.reserve(c->chunkNow);
     const GappedBuffers gb = gappedBuffers(c, 0);
     HIP_CHECK(hipMemsetAsync(c->gappedCounters.p, 0, 16, c->stream));
     AlignList al; al.cap = 8 * c->chunkNow; c->alignList.reserve(al.cap); al.entries = c->alignList.p; al.counter = c->gappedCounters.p + 3;
@@ -1519,6 +1559,7 @@ int isaac_gpu_build_fragments(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nCl
     joinHeavy(c);      // a wave-per-cluster pass of an earlier select call may still read the buffers written below
     hipStream_t st = c->stream;
     const u32 chunk = chunkFor(c, nClusters);
+    useFragments(c);
     DevBuf<u32> nc, ng, oc, og; nc.reserve(chunk); ng.reserve(chunk); oc.reserve(chunk); og.reserve(chunk);
     u64 candBase = 0, cigarBase = 0;
     for (u32 done = 0; done < nClusters; done += chunk)
@@ -1555,6 +1596,7 @@ int isaac_gpu_determine_tls(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
     {
         const u32 chunk = std::min<u32>(chunkFor(c, std::min<u32>(nClusters, 65536)), 65536);
         c->tlsSamples.reserve(chunk);
+        useFragments(c);
         std::vector<TlsSample> h(chunk);
         for (u32 done = 0; done < nClusters && !learner.stats.stable; done += chunk)
         {
@@ -1832,6 +1874,7 @@ int isaac_gpu_get_counters(isaac_gpu_ctx *c, isaac_counters *out)
     ISAAC_TRY
     static_assert(sizeof(isaac_counters) == sizeof(Counters), "counter layouts");
     std::vector<Counters> shards(COUNTER_SHARDS);
+    joinHeavy(c); HIP_CHECK(hipStreamSynchronize(c->stream));     // a deferred wave-per-cluster pass still counts
     HIP_CHECK(hipMemcpy(shards.data(), c->counters.p, COUNTER_SHARDS * sizeof(Counters), hipMemcpyDeviceToHost));
     u64 *sum = reinterpret_cast<u64 *>(out);
     for (u32 f = 0; f < sizeof(Counters) / sizeof(u64); ++f)
@@ -1855,6 +1898,7 @@ int isaac_gpu_kernel_time_ms(isaac_gpu_ctx *c, const char *kernel, double *avgMs
 int isaac_gpu_reset_timers(isaac_gpu_ctx *c)
 {
     ISAAC_TRY
+    joinHeavy(c); HIP_CHECK(hipStreamSynchronize(c->stream));
     resolveTimers(c);
     c->timers.clear();
     HIP_CHECK(hipMemset(c->counters.p, 0, COUNTER_SHARDS * sizeof(Counters)));

@@ -35,7 +35,7 @@ def load_library(path=None):
 
 
 EXPORTS = ["isaac_gpu_last_error", "isaac_gpu_create", "isaac_gpu_destroy", "isaac_gpu_malloc", "isaac_gpu_free", "isaac_gpu_upload", "isaac_gpu_download",
-           "isaac_gpu_synchronize", "isaac_gpu_load_contigs", "isaac_gpu_load_contigs_dev", "isaac_gpu_load_index", "isaac_gpu_build_index", "isaac_gpu_get_index",
+           "isaac_gpu_synchronize", "isaac_gpu_set_deferred_completion", "isaac_gpu_load_contigs", "isaac_gpu_load_contigs_dev", "isaac_gpu_load_index", "isaac_gpu_build_index", "isaac_gpu_get_index", "isaac_gpu_get_mask_offsets",
            "isaac_gpu_find_matches", "isaac_gpu_set_loaded_contigs", "isaac_gpu_build_fragments", "isaac_gpu_determine_tls", "isaac_gpu_select", "isaac_gpu_select_candidates",
            "isaac_gpu_bsw_batch",
            "isaac_gpu_fastq_to_bcl", "isaac_gpu_get_counters", "isaac_gpu_kernel_time_ms", "isaac_gpu_reset_timers"]
@@ -53,7 +53,7 @@ def _p(t):
 class Aligner:
     """one context on one device"""
 
-    def __init__(self, params, device=0, contigs=None, use_current_stream=True):
+    def __init__(self, params, device=0, contigs=None, use_current_stream=True, deferred_completion=False):
         import torch
         self.torch = torch
         self.lib = load_library()
@@ -69,7 +69,10 @@ class Aligner:
         self.n_reads = params.n_reads
         self.cluster_length = params.read_length[0] + params.read_length[1]
         self.n_contigs = 0
-        self._keep = []
+        self._inflight = []          # tensors of select calls whose last pass may still be running (deferred completion)
+        self.deferred_completion = bool(deferred_completion)
+        if self.deferred_completion:
+            self._check(self.lib.isaac_gpu_set_deferred_completion(self.h, 1))
         if contigs is not None:
             self.load_contigs(contigs)
 
@@ -92,6 +95,11 @@ class Aligner:
     def load_contigs(self, contigs):
         """contigs: list of bytes / uint8 tensors (ASCII ACGTN).  Device tensors are used in place."""
         torch = self.torch
+        if getattr(contigs, "padded", None) is not None and contigs.padded.device == self.device:     # synth.Genome already resident: used in place
+            offsets = np.asarray(contigs.offsets, np.uint64)
+            self._bases, self.contig_offsets, self.n_contigs = contigs.padded, offsets, len(offsets) - 1
+            self._check(self.lib.isaac_gpu_load_contigs_dev(self.h, _p(self._bases), _p(offsets), C.c_uint32(self.n_contigs)))
+            return
         lengths = [len(c) if isinstance(c, (bytes, bytearray)) else c.numel() for c in contigs]
         offsets = np.zeros(len(contigs) + 1, np.uint64)
         offsets[1:] = np.cumsum(lengths)
@@ -107,12 +115,19 @@ class Aligner:
         self._check(self.lib.isaac_gpu_build_index(self.h, C.c_uint32(repeat_threshold), int(annotate_neighbors), C.byref(n)))
         return n.value
 
-    def load_index(self, masks):
-        """masks: list of REFERENCE_KMER_DTYPE arrays (the mask files in mask order)"""
+    def load_index(self, masks, karyotype=None):
+        """masks: list of REFERENCE_KMER_DTYPE arrays (the mask files in mask order; np.memmap works);
+        karyotype: SortedReferenceMetadata::Contig::karyotypeIndex_ per stored contig index, None = identity"""
         masks = [np.ascontiguousarray(m, abi.REFERENCE_KMER_DTYPE) for m in masks]
         ptrs = (C.c_void_p * len(masks))(*[m.ctypes.data for m in masks])
         sizes = (C.c_uint64 * len(masks))(*[len(m) for m in masks])
-        self._check(self.lib.isaac_gpu_load_index(self.h, ptrs, sizes, C.c_uint32(len(masks)), None, C.c_uint32(self.n_contigs)))
+        kar = np.ascontiguousarray(karyotype, np.uint32) if karyotype is not None else None
+        self._check(self.lib.isaac_gpu_load_index(self.h, ptrs, sizes, C.c_uint32(len(masks)), _p(kar), C.c_uint32(self.n_contigs)))
+
+    def mask_offsets(self, n_masks=64):
+        out = np.zeros(n_masks + 1, np.uint64)
+        self._check(self.lib.isaac_gpu_get_mask_offsets(self.h, _p(out), C.c_uint32(n_masks)))
+        return out
 
     def get_index(self):
         n = C.c_uint64()
@@ -131,7 +146,7 @@ class Aligner:
         torch = self.torch
         n_clusters = bcl.shape[0]
         per = 2 * self.params.n_seeds * max(1, self.params.repeat_threshold - 1)
-        capacity = capacity or min(n_clusters * per, max(1024, n_clusters * 24))
+        capacity = max(1, capacity or min(n_clusters * per, max(1024, n_clusters * 24)))
         while True:
             matches = torch.empty((capacity, 2), dtype=torch.int64, device=self.device)
             offsets = torch.empty(n_clusters + 1, dtype=torch.int64, device=self.device)
@@ -184,6 +199,10 @@ class Aligner:
             records, cigars = out
         self._check(self.lib.isaac_gpu_select(self.h, _p(bcl), C.c_uint32(n_clusters), C.c_uint32(tile), _p(matches), _p(offsets), C.byref(tls),
                                               _p(records), _p(cigars), C.c_uint64(cigars.numel())))
+        if self.deferred_completion:
+            # the call's last pass may still read the inputs and write the outputs on the library's own stream: the tensors stay
+            # referenced (the caching allocator must not hand their memory out) until synchronize()
+            self._inflight.append((bcl, matches, offsets, records, cigars))
         return records, cigars
 
     def select_candidates(self, bcl, candidates, candidate_cigars, tls, tile=0):
@@ -204,8 +223,9 @@ class Aligner:
                                                          _p(records), _p(cigars), C.c_uint64(cigars.numel())))
         return records, cigars
 
-    @staticmethod
-    def records_to_numpy(records, cigars):
+    def records_to_numpy(self, records, cigars):
+        if self.deferred_completion:
+            self.synchronize()
         return records.cpu().numpy().view(abi.FRAGMENT_DTYPE).reshape(-1).copy(), cigars.cpu().numpy().view(np.uint32).copy()
 
     # ---- input format ---------------------------------------------------------------------------------------------
@@ -253,6 +273,7 @@ class Aligner:
     # ---- bookkeeping ----------------------------------------------------------------------------------------------
     def synchronize(self):
         self._check(self.lib.isaac_gpu_synchronize(self.h))
+        self._inflight.clear()
 
     def counters(self):
         c = abi.Counters()

@@ -52,25 +52,42 @@ def make_genome(n_bases, seed=1, device="cpu", n_contigs=1, repeat_families=True
 
 def make_read_pairs(contigs, n_pairs, read_length=150, seed=2, device=None, insert_mean=350.0, insert_sd=50.0,
                     subst_rate=0.003, indel_read_fraction=0.03, indel_max=5, n_rate=0.001, low_quality_tail_fraction=0.1,
-                    random_pair_fraction=0.002, read_length2=None):
+                    random_pair_fraction=0.002, read_length2=None, avoid_gaps=False):
     """FR-oriented pairs drawn uniformly from the contigs; returns (bcl uint8 [n_pairs, L1+L2], truth dict).
-    indel_read_fraction = fraction of reads carrying one indel of 1..indel_max bases (0.02 %/base at 150 bp ~ 3 %)."""
+    indel_read_fraction = fraction of reads carrying one indel of 1..indel_max bases (0.02 %/base at 150 bp ~ 3 %).
+    contigs: list of uint8 tensors or a Genome (used in place).  avoid_gaps: fragments that touch a run of N are drawn again
+    (a sequencer produces no reads from assembly gaps)."""
     device = device or contigs[0].device
     L1 = read_length
     L2 = read_length2 or read_length
     g = torch.Generator(device=device).manual_seed(seed)
     lens = torch.tensor([c.numel() for c in contigs], dtype=torch.float64)
-    genome = torch.cat([c.to(device) for c in contigs])
+    genome = contigs.bases.to(device) if isinstance(contigs, Genome) else torch.cat([c.to(device) for c in contigs])
     starts = torch.zeros(len(contigs) + 1, dtype=torch.long)
     starts[1:] = torch.cumsum(lens, 0).long()
     starts = starts.to(device)
-    # contig choice proportional to length, fragment inside the contig
-    contig = torch.multinomial(lens.float().to(device), n_pairs, replacement=True, generator=g)
-    clen = lens.long().to(device)[contig]
-    insert = (torch.randn(n_pairs, generator=g, device=device) * insert_sd + insert_mean).round().long()
-    insert = insert.clamp(min=max(L1, L2) + 10)
-    insert = torch.minimum(insert, clen - 2 * indel_max - 2)
-    frag_start = (torch.rand(n_pairs, generator=g, device=device, dtype=torch.float64) * (clen - insert - 2 * indel_max).double()).long()
+
+    def draw(n):
+        # contig choice proportional to length, fragment inside the contig
+        contig = torch.multinomial(lens.float().to(device), n, replacement=True, generator=g)
+        clen = lens.long().to(device)[contig]
+        insert = (torch.randn(n, generator=g, device=device) * insert_sd + insert_mean).round().long()
+        insert = insert.clamp(min=max(L1, L2) + 10)
+        insert = torch.minimum(insert, clen - 2 * indel_max - 2)
+        frag_start = (torch.rand(n, generator=g, device=device, dtype=torch.float64) * (clen - insert - 2 * indel_max).double()).long()
+        return contig, clen, insert, frag_start
+
+    contig, clen, insert, frag_start = draw(n_pairs)
+    if avoid_gaps:
+        for _ in range(8):
+            probe = torch.linspace(0.0, 1.0, 12, device=device).unsqueeze(0)
+            at = (starts[contig] + frag_start).unsqueeze(1) + (probe * (insert + indel_max).unsqueeze(1).float()).long()
+            bad = (genome[at.clamp(max=genome.numel() - 1)] == 78).any(1)
+            n_bad = int(bad.sum())
+            if not n_bad:
+                break
+            c2, l2, i2, f2 = draw(n_bad)
+            contig[bad], clen[bad], insert[bad], frag_start[bad] = c2, l2, i2, f2
     flip = torch.rand(n_pairs, generator=g, device=device) < 0.5          # fragment taken from the reverse strand
     comp = torch.full((256,), 78, dtype=torch.uint8, device=device)
     comp[65], comp[67], comp[71], comp[84] = 84, 71, 67, 65
@@ -143,3 +160,167 @@ def bcl_to_fastq(bcl, read_offset, read_length, name="r", newline=b"\n", plus_he
         header = b"@%s:%d" % (name.encode(), i)
         out += header + newline + bases[i].tobytes() + newline + b"+" + (header[1:] if plus_header else b"") + newline + quals[i].tobytes() + newline
     return bytes(out)
+
+
+# ---- a human-like reference (BASELINE.json configs 2-4: "GRCh38") ---------------------------------------------------------
+# Relative lengths of GRCh38's chr1..22, X, Y, M (Mbp): the contig list of the synthetic genome follows them.
+_GRCH38_MBP = [248.96, 242.19, 198.30, 190.21, 181.54, 170.81, 159.35, 145.14, 138.39, 133.80, 135.09, 133.28, 114.36, 107.04, 101.99,
+               90.34, 83.26, 80.37, 58.62, 64.44, 46.71, 50.82, 156.04, 57.23, 0.0166]
+
+
+class Genome:
+    """contigs concatenated in one uint8 tensor (ASCII ACGTN) + their offsets; `contigs` are views of it"""
+
+    def __init__(self, bases, offsets, padded=None):
+        self.bases = bases
+        self.padded = padded            # the same storage followed by >= 64 bytes of 'N' (what isaac_gpu_load_contigs_dev wants), or None
+        self.offsets = [int(o) for o in offsets]
+        self.contigs = [bases[self.offsets[i]:self.offsets[i + 1]] for i in range(len(self.offsets) - 1)]
+
+    def __len__(self):
+        return len(self.contigs)
+
+    def __iter__(self):
+        return iter(self.contigs)
+
+    def __getitem__(self, i):
+        return self.contigs[i]
+
+
+def _expand(starts, lengths):
+    """for segments (starts[i], lengths[i]): flat tensors (segment index, offset inside the segment) of all their elements"""
+    seg = torch.repeat_interleave(torch.arange(len(lengths), device=lengths.device), lengths)
+    first = torch.cumsum(lengths, 0) - lengths
+    off = torch.arange(int(lengths.sum()), device=lengths.device) - first[seg]
+    return seg, off
+
+
+def _mutate(codes, rate, g):
+    """substitutions at per-element probability `rate` (tensor or float); codes 0..3"""
+    mut = torch.rand(codes.shape, generator=g, device=codes.device) < rate
+    shift = torch.randint(1, 4, codes.shape, generator=g, device=codes.device, dtype=torch.uint8)
+    return torch.where(mut, (codes + shift) % 4, codes)
+
+
+def make_human_like_genome(n_bases, seed=3, device="cpu", n_contigs=25, chunk=1 << 26):
+    """A synthetic stand-in for GRCh38 (no genome ships with the image): `n_contigs` contigs with the relative lengths of the
+    human chromosomes and the repeat spectrum the seed-and-extend path reacts to, as fractions of the genome:
+       * Alu-like SINEs: ~300 bp, one copy per 3 kbp (10 %), six subfamilies, 2-16 % divergence from their consensus, A-rich tails;
+       * L1-like LINEs: 6 kbp consensus, 5'-truncated copies (mean ~1 kbp), one per 6 kbp (16 %), 3-20 % divergence;
+       * segmental duplications: 5-50 kbp copies of other places at 0.5-3 % divergence (~4 %);
+       * centromeric satellites: per contig an array of a 171-bp monomer in higher-order repeats (~1 %), 1-2 % between copies;
+       * microsatellites and homopolymer runs; a short element present > 1000 times;
+       * N: telomeres, one centromeric gap per contig and scattered assembly gaps.
+    Everything is vectorised torch on `device` (3.1 Gbp take seconds on the GPU).  Returns a Genome."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    rel = _GRCH38_MBP[:n_contigs] if n_contigs <= len(_GRCH38_MBP) else _GRCH38_MBP + [1.0] * (n_contigs - len(_GRCH38_MBP))
+    lens = [max(200, int(n_bases * r / sum(rel))) for r in rel]
+    lens[0] += n_bases - sum(lens) if n_bases > sum(lens) else 0
+    offsets = [0]
+    for n in lens:
+        offsets.append(offsets[-1] + n)
+    total = offsets[-1]
+    codes = torch.empty(total, dtype=torch.uint8, device=device)
+    for a in range(0, total, chunk):
+        codes[a:min(total, a + chunk)] = torch.randint(0, 4, (min(total, a + chunk) - a,), generator=g, device=device, dtype=torch.uint8)
+    off_t = torch.tensor(offsets, dtype=torch.long, device=device)
+
+    def rand_int(lo, hi, n):
+        return torch.randint(int(lo), int(hi), (n,), generator=g, device=device)
+
+    def place(lengths):
+        """a random place for every segment that does not cross a contig end"""
+        n = len(lengths)
+        contig = torch.multinomial(torch.tensor(lens, dtype=torch.float, device=device), n, replacement=True, generator=g)
+        room = (off_t[contig + 1] - off_t[contig] - lengths).clamp(min=1)
+        return off_t[contig] + (torch.rand(n, generator=g, device=device, dtype=torch.float64) * room.double()).long()
+
+    def paste(src_of, dst, lengths, divergence):
+        """codes[dst[i] + j] = mutate(src_of(i, j)) for j < lengths[i], in pieces of at most `chunk` elements"""
+        n = len(lengths)
+        csum = torch.cumsum(lengths, 0)
+        a = 0
+        while a < n:
+            base = int(csum[a - 1]) if a else 0
+            b = int(torch.searchsorted(csum, torch.tensor(base + chunk, device=device), right=True))
+            b = max(a + 1, min(n, b))
+            seg, off = _expand(dst[a:b], lengths[a:b])
+            vals = _mutate(src_of(seg + a, off), divergence[a:b][seg] if torch.is_tensor(divergence) else divergence, g)
+            idx = dst[a:b][seg] + off
+            ok = idx < total
+            codes[idx[ok]] = vals[ok]
+            a = b
+
+    # segmental duplications first (they copy whatever is there; later elements land inside them as in a real genome)
+    n_sd = total // 600_000
+    if n_sd:
+        length = rand_int(5_000, 50_000, n_sd).clamp(max=max(200, min(lens) // 4))
+        src, dst = place(length), place(length)
+        snapshot_free = True  # sources are read while destinations are written: harmless for a synthetic genome
+        paste(lambda i, j: codes[(src[i] + j).clamp(max=total - 1)], dst, length, torch.rand(n_sd, generator=g, device=device) * 0.025 + 0.005)
+    # L1-like
+    n_l1 = total // 6_000
+    if n_l1:
+        consensus = torch.randint(0, 4, (6_000,), generator=g, device=device, dtype=torch.uint8)
+        u = torch.rand(n_l1, generator=g, device=device)
+        length = (6_000 * u * u * 0.5 + 100).long().clamp(max=6_000)            # 5'-truncated: the 3' end is what is left
+        length = torch.where(torch.rand(n_l1, generator=g, device=device) < 0.03, torch.full_like(length, 6_000), length).clamp(max=max(100, min(lens) // 4))
+        start = 6_000 - length
+        paste(lambda i, j: consensus[start[i] + j], place(length), length, torch.rand(n_l1, generator=g, device=device) * 0.17 + 0.03)
+    # Alu-like
+    n_alu = total // 3_000
+    if n_alu:
+        master = torch.randint(0, 4, (282,), generator=g, device=device, dtype=torch.uint8)
+        sub = torch.stack([_mutate(master, 0.03, g) for _ in range(6)])
+        tail = torch.zeros((6, 30), dtype=torch.uint8, device=device)                 # A-rich tail
+        sub = torch.cat([sub, tail], 1)                                                # 312 columns
+        fam = rand_int(0, 6, n_alu)
+        length = rand_int(280, 313, n_alu).clamp(max=max(50, min(lens) // 4))
+        paste(lambda i, j: sub[fam[i], j], place(length), length, torch.rand(n_alu, generator=g, device=device) * 0.14 + 0.02)
+    # a short element present more than 1000 times (a single TooManyMatch entry of the index, ReferenceSorter.cpp:201-222)
+    if total >= 200_000:
+        element = torch.randint(0, 4, (40,), generator=g, device=device, dtype=torch.uint8)
+        n_el = max(1100, total // 2_000_000)
+        length = torch.full((n_el,), 40, dtype=torch.long, device=device)
+        paste(lambda i, j: element[j], place(length), length, 0.0)
+    # microsatellites / homopolymers
+    n_ms = total // 20_000
+    if n_ms:
+        unit_len = rand_int(1, 5, n_ms)
+        unit = torch.randint(0, 4, (n_ms, 4), generator=g, device=device, dtype=torch.uint8)
+        length = rand_int(15, 120, n_ms)
+        paste(lambda i, j: unit[i, j % unit_len[i]], place(length), length, 0.01)
+    # centromeric satellite array + gap per contig; telomeres; scattered gaps
+    is_n = torch.zeros(0, dtype=torch.bool, device=device)
+    n_starts, n_lengths = [], []
+    for c, n in enumerate(lens):
+        if n < 20_000:
+            continue
+        mono = torch.randint(0, 4, (171,), generator=g, device=device, dtype=torch.uint8)
+        k = int(torch.randint(4, 13, (1,), generator=g, device=device))
+        hor = torch.cat([_mutate(mono, 0.2, g) for _ in range(k)])                     # higher-order repeat of k diverged monomers
+        array_len = max(2 * len(hor), n // 100)
+        centre = offsets[c] + int(n * (0.35 + 0.3 * float(torch.rand(1, generator=g, device=device))))
+        a0 = centre - array_len // 2
+        for a in range(a0, a0 + array_len, chunk):
+            m = min(a0 + array_len, a + chunk) - a
+            j = torch.arange(a - a0, a - a0 + m, device=device)
+            codes[a:a + m] = _mutate(hor[j % len(hor)], 0.015, g)
+        n_starts += [offsets[c], offsets[c + 1] - max(10, n // 20_000), centre + array_len // 2]
+        n_lengths += [max(10, n // 20_000), max(10, n // 20_000), max(50, n // 30)]
+    n_gaps = total // 5_000_000
+    if n_gaps:
+        gl = rand_int(50, 2_000, n_gaps)
+        gs = place(gl)
+        n_starts += gs.tolist(); n_lengths += gl.tolist()
+    # to ASCII, then the N runs
+    bases = torch.empty(total + 64, dtype=torch.uint8, device=device)
+    lut = _ASCII.to(device)
+    for a in range(0, total, chunk):
+        b = min(total, a + chunk)
+        bases[a:b] = lut[codes[a:b].long()]
+    bases[total:] = 78
+    del codes
+    for s, n in zip(n_starts, n_lengths):
+        bases[max(0, s):min(total, s + n)] = 78
+    return Genome(bases[:total], offsets, padded=bases)

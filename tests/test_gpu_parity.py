@@ -375,12 +375,10 @@ def test_deferred_completion_pipelines_select_calls(torch, monkeypatch):
 
     def run(deferred):
         if deferred:
-            monkeypatch.setenv("ISAAC_GPU_DEFERRED_COMPLETION", "1")
             monkeypatch.setenv("ISAAC_GPU_CHUNK_CLUSTERS", "1024")       # several chunks per call as well
         else:
-            monkeypatch.delenv("ISAAC_GPU_DEFERRED_COMPLETION", raising=False)
             monkeypatch.delenv("ISAAC_GPU_CHUNK_CLUSTERS", raising=False)
-        al = gpu.Aligner(p, 0, contigs)
+        al = gpu.Aligner(p, 0, contigs, deferred_completion=deferred)
         al.build_index()
         found = [al.find_matches(b) for b in batches]
         hits = found[0][2]
@@ -405,7 +403,6 @@ def test_chunk_buffers_grow_with_the_calls(torch, monkeypatch):
     (buffers reallocated, also while deferred completion has work in flight) and a small one again, with the records a fresh
     context produces for each"""
     from isaac_aligner_amd import gpu, synth
-    monkeypatch.setenv("ISAAC_GPU_DEFERRED_COMPLETION", "1")
     contigs = _repeat_genome()
     dev_contigs = [torch.frombuffer(bytearray(c), dtype=torch.uint8).to("cuda") for c in contigs]
     sizes = [3000, 70000, 2000, 140000, 3000]           # 65536-cluster granules: one, two, one, three, one
@@ -424,7 +421,7 @@ def test_chunk_buffers_grow_with_the_calls(torch, monkeypatch):
     tls = first.determine_tls(batches[1], m, o)
     hits[:] = 1
     first.close()
-    reused = gpu.Aligner(p, 0, contigs)
+    reused = gpu.Aligner(p, 0, contigs, deferred_completion=True)
     reused.build_index()
     outs = [run(reused, b, hits, tls) for b in batches]                 # back to back, growing and shrinking
     reused.synchronize()
