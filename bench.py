@@ -1,30 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py -- paired-end reads aligned per second on MI355X (BASELINE.json metric).
+"""bench.py -- paired-end reads aligned per second on MI355X (BASELINE.json metric: 2x150 bp, GRCh38).
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): a chr21-sized reference (46.7 Mbp; synthetic, because no genome ships with the image),
-2x150 bp synthetic pairs, default 10 steps x 1 M pairs = 10 M pairs per GPU.  A step = one pass of the hot path over one
-batch of pairs already resident in HBM: isaac_gpu_find_matches (seed extraction + index lookup) followed by
-isaac_gpu_select (fragment building, banded Smith-Waterman, mate rescue, MAPQ, clipping, FragmentHeader records).  As in the
-reference the two halves run as two phases over all batches, with the loaded-contig set and the template-length statistics
-(learnt from the first batch during warm-up, then frozen: MatchSelector.cpp:402-417) fixed in between.
-With N > 1 every rank aligns its own K batches on its own GPU (static shard, no data-path collective); the ranks OR-reduce the
-per-contig hit flags between the phases and rank 0 gathers the fixed-size alignment records once at the end (RCCL).
+Workload (BASELINE.json configs[2]/[3]): a GRCh38-sized reference -- 3.1 Gbp in 25 contigs with a human-like repeat spectrum,
+synthetic because no genome ships with the image (isaac_aligner_amd/synth.py) -- indexed on the device in the sorted-reference
+format (2.9 G 32-mer entries, neighbour-annotated), and synthetic 2x150 bp pairs, default 10 steps x 1 M pairs per GPU.
+A step = one pass of the hot path over one batch of pairs already resident in HBM: isaac_gpu_find_matches (seed extraction +
+index lookup) followed by isaac_gpu_select (fragment building, banded Smith-Waterman, mate rescue, MAPQ, clipping,
+FragmentHeader records) and isaac_gpu_compact_cigars.  As in the reference the two halves run as two phases over all batches,
+with the loaded-contig set and the template-length statistics (learnt from the first batch during warm-up, then frozen:
+MatchSelector.cpp:402-417) fixed in between.
+
+N > 1: one process per GPU.  Started without a launcher (WORLD_SIZE unset), this script starts `torch.distributed.run` with N
+ranks itself -- as a child process, before anything touches a GPU -- and exits with its code.  Every rank builds the index on
+its own GPU and aligns its own shard of the read batches (no collective on the data path); the ranks OR-reduce the per-contig
+hit flags between the phases and rank 0 gathers the alignment records and CIGARs once at the end (RCCL).
+--scaling weak (default): every rank aligns K batches of its own; strong: one read set of K batches cut N ways.
 """
 import argparse
 import json
-import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 
 def parse():
@@ -33,21 +36,73 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs-per-step", type=int, default=1_000_000)
-    ap.add_argument("--genome-bases", type=int, default=46_700_000)
+    ap.add_argument("--genome-bases", type=int, default=3_100_000_000)
     ap.add_argument("--read-length", type=int, default=150)
+    ap.add_argument("--indel-read-fraction", type=float, default=None, help="fraction of reads with one indel (default 0.03; config 4: 0.05)")
+    ap.add_argument("--indel-max", type=int, default=None, help="longest simulated indel (default 5; config 4: 10)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--cpu-sample-pairs", type=int, default=1_000_000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="also skips the parity check, which uses the same oracle records")
+    ap.add_argument("--no-pcie-pass", action="store_true")
     ap.add_argument("--no-neighbors", action="store_true")
+    ap.add_argument("--launch-check", action="store_true", help="GPU-less check of the launcher and the collectives (gloo): no alignment")
     return ap.parse_args()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    """N > 1 without a launcher: the ranks are started as a child process tree of this one (never an exec after GPU init)"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(args, rank, world):
+    """the run's three collectives on fake data over gloo (CPU): what tests/test_bench_launch.py drives"""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from isaac_aligner_amd import abi, shard
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo")
+    hits = np.zeros(8, np.uint8); hits[rank % 8] = 1
+    merged = shard.reduce_contig_hits(hits, dist)
+    tls = abi.Tls(); tls.min, tls.max, tls.median = 100 + rank, 500 + rank, 300 + rank
+    shard.broadcast_tls(tls, dist)
+    begin, end = shard.shard_bounds(1001, rank, world)
+    records = torch.full((end - begin, 4), rank, dtype=torch.uint8)
+    got = shard.gather_records(records, dist, rank, world)
+    dist.barrier()
+    if rank == 0:
+        ok = int(merged.sum()) == min(world, 8) and tls.min == 100 and sum(len(g) for g in got) == 1001 and all(int(g[0, 0]) == r for r, g in enumerate(got))
+        print(json.dumps({"launch_check": bool(ok), "n_gpus": world, "gpus_requested": args.gpus}))
+    dist.destroy_process_group()
 
 
 def main():
     args = parse()
-    os.environ.setdefault("ISAAC_GPU_DEFERRED_COMPLETION", "1")   # read by isaac_gpu_create: select calls pipeline, isaac_gpu_synchronize completes them
-    from isaac_aligner_amd import abi, gpu, options, shard, synth
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    if args.launch_check:
+        return launch_check(args, rank, world)
+
+    import numpy as np
+    import torch
+    from isaac_aligner_amd import abi, gpu, options, shard, synth
     dist = None
     if world > 1 or os.environ.get("ISAAC_BENCH_FORCE_DIST"):      # the variable: run the collectives with one rank too (1-GPU check of the RCCL path)
         import torch.distributed as dist
@@ -57,43 +112,60 @@ def main():
     dev = torch.device("cuda", local_rank)
     L = args.read_length
     params = options.default_params(L, L)
+    read_kw = {}
+    if args.indel_read_fraction is not None:
+        read_kw["indel_read_fraction"] = args.indel_read_fraction
+    if args.indel_max is not None:
+        read_kw["indel_max"] = args.indel_max
 
     # ---- setup (untimed): reference, index, reads resident in HBM ---------------------------------------------------
     t0 = time.time()
-    contigs = synth.make_genome(args.genome_bases, seed=2, device=dev, n_contigs=1)
-    al = gpu.Aligner(params, local_rank, contigs)
+    genome = synth.make_human_like_genome(args.genome_bases, seed=3, device=dev)
+    torch.cuda.empty_cache()
+    al = gpu.Aligner(params, local_rank, genome, deferred_completion=True)   # back-to-back select calls overlap; al.synchronize() completes them
+    t_genome = time.time() - t0
     n_index = al.build_index(repeat_threshold=1000, annotate_neighbors=not args.no_neighbors)
-    t_index = time.time() - t0
+    t_index = time.time() - t0 - t_genome
     n_batches = args.warmup + args.steps
+    per_rank = args.pairs_per_step
     batches = []
     for b in range(n_batches):
-        bcl, _ = synth.make_read_pairs(contigs, args.pairs_per_step, L, seed=1000 * (rank + 1) + b, device=dev)
+        if args.scaling == "strong" and b >= args.warmup:   # one read set for the whole job, cut N ways (every rank draws it, keeps its shard)
+            bcl = synth.make_read_pairs(genome, args.pairs_per_step, L, seed=1000 + b, device=dev, avoid_gaps=True, **read_kw)[0]
+            begin, end = shard.shard_bounds(args.pairs_per_step, rank, world)
+            bcl = bcl[begin:end].contiguous()
+            per_rank = end - begin
+        else:
+            bcl = synth.make_read_pairs(genome, args.pairs_per_step, L, seed=1000 * (rank + 1) + b, device=dev, avoid_gaps=True, **read_kw)[0]
         batches.append(bcl)
     torch.cuda.synchronize()
     t_setup = time.time() - t0
 
-    n_rec = args.pairs_per_step * 2
-    records = [torch.empty((n_rec, abi.FRAGMENT_DTYPE.itemsize), dtype=torch.uint8, device=dev) for _ in range(args.steps)]
-    # only the records are gathered; two CIGAR buffers take turns because the tail of one select call (its wave-per-cluster pass)
-    # overlaps the start of the next one (ISAAC_GPU_DEFERRED_COMPLETION, set below)
-    cigars = [torch.empty(n_rec * abi.MAX_CIGAR_OPS, dtype=torch.int32, device=dev) for _ in range(2)]
+    def buffers(n_pairs):
+        n_rec = n_pairs * 2
+        return (torch.empty((n_rec, abi.FRAGMENT_DTYPE.itemsize), dtype=torch.uint8, device=dev), torch.empty(n_rec * abi.MAX_CIGAR_OPS, dtype=torch.int32, device=dev),
+                torch.empty(n_rec * 4, dtype=torch.int32, device=dev))
+    out = [buffers(batches[args.warmup + s].shape[0]) for s in range(args.steps)]     # records, 40-word CIGAR slots, packed CIGARs of every step
+    tile_of = lambda s: 1 + rank * args.steps + s          # every (rank, step) batch is a tile of its own, as FASTQ tiles are (SeedId.hh: 12 bits)
 
     def reduce_hits(h):
         return shard.reduce_contig_hits(h, dist, dev)
 
     # ---- warm-up: also learns the template length statistics from the first batch (as tile 1 of the reference does) ---
     tls = None
-    for b in range(args.warmup):
+    for b in range(max(1, args.warmup)):
         m, o, hits = al.find_matches(batches[b])
         al.set_loaded_contigs(reduce_hits(hits))
         if tls is None:
             tls = al.determine_tls(batches[b], m, o)
-        al.select(batches[b], m, o, tls, out=(records[0], cigars[0]))
-    if tls is None:
-        m, o, hits = al.find_matches(batches[0])
-        al.set_loaded_contigs(reduce_hits(hits))
-        tls = al.determine_tls(batches[0], m, o)
+        if b < args.warmup:
+            w = buffers(batches[b].shape[0])
+            al.select(batches[b], m, o, tls, out=w[:2])
+            al.synchronize()
+            al.compact_cigars(w[0], w[1], w[2])
+            del w
     shard.broadcast_tls(tls, dist, dev)   # rank 0's statistics are the run's statistics
+    al.synchronize()
     al.reset_timers()
 
     # ---- timed region: exactly K steps ---------------------------------------------------------------------------------
@@ -104,16 +176,18 @@ def main():
     found = []
     all_hits = np.zeros(al.n_contigs, np.uint8)
     for s in range(args.steps):                       # phase 1: FindMatchesTransition
-        m, o, hits = al.find_matches(batches[args.warmup + s])
+        m, o, hits = al.find_matches(batches[args.warmup + s], tile=tile_of(s))
         found.append((m, o))
         all_hits |= hits
     al.set_loaded_contigs(reduce_hits(all_hits))      # MatchSelector loads only contigs that received matches
     for s in range(args.steps):                       # phase 2: SelectMatchesTransition
         m, o = found[s]
-        al.select(batches[args.warmup + s], m, o, tls, out=(records[s], cigars[s & 1]))
+        al.select(batches[args.warmup + s], m, o, tls, tile=tile_of(s), out=out[s][:2])
     al.synchronize()                                  # completes the last call's wave-per-cluster pass
-    if dist is not None:                              # single gather of the per-GPU records at the end
-        shard.gather_records(torch.cat(records), dist, rank, world)
+    packed = [al.compact_cigars(out[s][0], out[s][1], out[s][2])[0] for s in range(args.steps)]
+    if dist is not None:                              # single gather of the per-GPU records and CIGARs at the end
+        shard.gather_records(torch.cat([o_[0] for o_ in out]), dist, rank, world)
+        shard.gather_records(torch.cat(packed).view(-1, 1), dist, rank, world)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -122,114 +196,178 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        n_pairs_all = torch.tensor([sum(b.shape[0] for b in batches[args.warmup:])], dtype=torch.int64, device=dev)
+        dist.all_reduce(n_pairs_all)
+        pairs_total = int(n_pairs_all.item())
+    else:
+        pairs_total = sum(b.shape[0] for b in batches[args.warmup:])
 
     free_b, total_b = torch.cuda.mem_get_info(dev)
     hbm_used_gb = round((total_b - free_b) / 1e9, 1)      # everything resident at the end of the run: index, reads, records, chunk scratch
     counters = al.counters()
-    timers = {k: al.kernel_time_ms(k) for k in ("find_matches", "build_fragments", "align_candidates", "finish_candidates", "indel_fragments", "gapped_fragments", "finish_fragments", "plan_rescue", "rescue_windows", "rescue_align",
-                                                 "rescue_gapped_plan", "gapped_rescue", "select_order", "select", "select_heavy", "select_residual", "compact_matches")}
+    timer_names = ("find_matches", "compact_matches", "build_fragments", "align_candidates", "finish_candidates", "indel_fragments", "gapped_fragments", "finish_fragments",
+                   "plan_rescue", "rescue_windows", "rescue_align", "rescue_gapped_plan", "gapped_rescue", "rescue_finish", "probability_sums", "select_order", "select",
+                   "select_heavy", "select_residual")
+    timers = {k: al.kernel_time_ms(k) for k in timer_names}
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    pairs_total = args.pairs_per_step * args.steps * world
     reads_per_s = 2.0 * pairs_total / elapsed
+    pairs_rank = sum(b.shape[0] for b in batches[args.warmup:])
+
+    # ---- the same K steps with the reads arriving over PCIe and the results leaving over it (reported next to `value`, never as it)
+    pcie = None
+    if not args.no_pcie_pass and dist is None:
+        host_in = [torch.empty(b.shape, dtype=torch.uint8).pin_memory() for b in batches[args.warmup:]]
+        for h, b in zip(host_in, batches[args.warmup:]):
+            h.copy_(b)
+        host_rec = [torch.empty(o_[0].shape, dtype=torch.uint8).pin_memory() for o_ in out]
+        host_cig = [torch.empty(p_.shape, dtype=torch.int32).pin_memory() for p_ in packed]
+        copy_stream = torch.cuda.Stream(dev)
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        found = []
+        dev_in = []
+        for s in range(args.steps):
+            with torch.cuda.stream(copy_stream):          # uploads run ahead of the lookups on their own stream
+                d = host_in[s].to(dev, non_blocking=True)
+                ev = torch.cuda.Event(); ev.record(copy_stream)
+            dev_in.append((d, ev))
+        for s in range(args.steps):
+            d, ev = dev_in[s]
+            torch.cuda.current_stream(dev).wait_event(ev)
+            m, o, hits = al.find_matches(d, tile=tile_of(s))
+            found.append((m, o))
+        for s in range(args.steps):
+            m, o = found[s]
+            al.select(dev_in[s][0], m, o, tls, tile=tile_of(s), out=out[s][:2])
+            if s:                                           # the previous step's results leave while this step computes
+                al.synchronize()
+                p_ = al.compact_cigars(out[s - 1][0], out[s - 1][1], out[s - 1][2])[0]
+                done = torch.cuda.Event(); done.record()
+                with torch.cuda.stream(copy_stream):
+                    copy_stream.wait_event(done)
+                    host_rec[s - 1].copy_(out[s - 1][0], non_blocking=True)
+                    host_cig[s - 1][:p_.numel()].copy_(p_, non_blocking=True)
+        al.synchronize()
+        p_ = al.compact_cigars(out[-1][0], out[-1][1], out[-1][2])[0]
+        host_rec[-1].copy_(out[-1][0], non_blocking=True)
+        host_cig[-1][:p_.numel()].copy_(p_, non_blocking=True)
+        torch.cuda.synchronize()
+        t_pcie = time.perf_counter() - tp
+        pcie = {"reads_per_s": round(2.0 * pairs_rank / t_pcie, 1), "ms_per_step": round(1e3 * t_pcie / args.steps, 3),
+                "bytes_in_per_pair": 2 * L, "bytes_out_per_pair": round((sum(r.numel() for r in host_rec) + 4 * sum(int(p.numel()) for p in packed)) / pairs_rank, 1),
+                "note": "BCL bytes uploaded from pinned host memory ahead of the lookups, records + packed CIGARs downloaded while the next step computes"}
 
     # ---- roofline of the dominant kernel: algorithmic bytes (stated per kernel in DESIGN.md) / event-timed duration
-    pairs_rank = args.pairs_per_step * args.steps
-    log2n = max(1, math.ceil(math.log2(max(2, n_index))))
-    seeded_scans = max(0, counters["ungapped_scans"] - counters["rescue_candidates"])
-    jobs = counters["rescue_calls"]
+    c = counters
+    seeded_scans = max(0, c["ungapped_scans"] - c["rescue_candidates"])
+    jobs = c["rescue_calls"]
     per_kernel_bytes = {
-        # BCL in + P * ceil(log2 n) * 16 B index probes + match records out
-        "find_matches": 2 * L * pairs_rank + counters["probes"] * log2n * 16 + counters["matches"] * 16,
-        # match records in + BCL + one (L + 15)-byte reference window per seeded scan / banded SW + candidate records out
-        "build_fragments": counters["matches"] * 16 + 2 * L * pairs_rank + seeded_scans * (L + 15) + counters["candidates"] * 64,
+        # BCL in + 16 B per probe step actually taken (prefix directory entry or table entry) + match records out
+        "find_matches": 2 * L * pairs_rank + c["probe_steps"] * 16 + c["matches"] * 16,
+        # match records in + BCL + candidate records out
+        "build_fragments": c["matches"] * 16 + 2 * L * pairs_rank + c["candidates"] * 64,
+        # per seeded candidate: the read + an L-base reference window in, the candidate record + 3 cigar words out
+        "align_candidates": seeded_scans * (2 * L + 64 + 12),
+        "finish_candidates": c["candidates"] * 128,
+        "indel_fragments": c["simple_indels"] * (2 * L + 256 + 128),
         # per banded Smith-Waterman problem: job record in, read + (L + 15)-base reference window in, result record out
-        "gapped_fragments": counters["bsw_jobs"] * (80 + 2 * L + 15 + 232),
-        "gapped_rescue": counters["rescue_bsw"] * (80 + 2 * L + 15 + 232),
-        # candidate records + gapped results in, consolidated candidate records out
-        "finish_fragments": counters["candidates"] * 128 + counters["bsw_jobs"] * 232,
-        # one pass over the aligned rescue candidates
-        "rescue_gapped_plan": counters["rescue_candidates"] * 64 + jobs * 72,
-        # candidate records in, rescue problems out
-        "plan_rescue": counters["candidates"] * 64 + jobs * 72,
-        # the mate's bases + the window bases in, candidate start positions out
-        "rescue_windows": jobs * (72 + L) + counters["rescue_window_bases"] + counters["rescue_candidates"] * 8,
+        "gapped_fragments": c["bsw_jobs"] * (80 + 2 * L + 15 + 232),
+        "gapped_rescue": c["rescue_bsw"] * (80 + 2 * L + 15 + 232),
+        "finish_fragments": c["candidates"] * 128 + c["bsw_jobs"] * 232,
+        "plan_rescue": c["candidates"] * 64 + jobs * 72,
+        # the mate's bases + the window bases (2 bits + 1 bit each) in, candidate start positions out
+        "rescue_windows": jobs * (72 + L) + c["rescue_window_bases"] * 3 // 8 + c["rescue_candidates"] * 8,
         # per candidate start: the mate (L BCL bytes) + L reference bytes in, one candidate record + 3 cigar words out
-        "rescue_align": counters["rescue_candidates"] * (2 * L + 64 + 12),
+        "rescue_align": c["rescue_candidates"] * (2 * L + 64 + 12),
+        "rescue_gapped_plan": c["rescue_candidates"] * 64 + jobs * 72,
+        "rescue_finish": c["rescue_candidates"] * 64 + jobs * 72,
+        "probability_sums": c["rescue_candidates"] * 2 * 24 + c["candidates"] * 24,
         # seeded + rescued candidate records in, 2 FragmentHeader records + cigars out
-        "select": counters["candidates"] * 64 + counters["rescue_candidates"] * (64 + 12) + 2 * pairs_rank * (64 + 4 * 3),
+        "select": c["candidates"] * 64 + c["rescue_candidates"] * (64 + 12) + 2 * pairs_rank * (64 + 4 * 3),
+        "select_heavy": c["heavy_clusters"] * 64 * 1000,
     }
     total_ms = {k: v[0] * v[1] for k, v in timers.items()}
-    heavy_ms = total_ms.pop("select_heavy", 0.0)              # wave-per-cluster pass for clusters that overflow the light work lists
-    dominant = max(per_kernel_bytes, key=lambda k: total_ms[k])
+    dominant = max(per_kernel_bytes, key=lambda k: total_ms.get(k, 0.0))
     launches = max(1, timers[dominant][1])
     avg_s = total_ms[dominant] / launches / 1e3
     achieved = per_kernel_bytes[dominant] / launches / avg_s / 1e9 if avg_s > 0 else 0.0
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure comes from the
-    # committed rocprofv3 --pmc passes over this same workload (the latest profiles/*_pmc_summary.json, made by scripts/pmc_traffic.sh + pmc_summary.py;
-    # FETCH_SIZE doubled as the MI355X guide prescribes for gfx950), scaled from that run's clusters per launch to this run's
-    traffic, traffic_source = None, None
-    pmc_files = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_pmc_summary.json")) if os.path.isdir(os.path.join(ROOT, "profiles")) else []
-    pmc_name = pmc_files[-1] if pmc_files else "r1_k_pmc_summary.json"     # the latest committed passes
-    pmc_path = os.path.join(ROOT, "profiles", pmc_name)
-    if os.path.exists(pmc_path):
-        pmc = json.load(open(pmc_path)).get("k_" + dominant)
-        if pmc and "hbm_bytes_per_launch" in pmc:
-            pmc_pairs_per_launch = 500_000.0
-            traffic = int(pmc["hbm_bytes_per_launch"] / pmc_pairs_per_launch * (pairs_rank / launches))
-            traffic_source = "profiles/%s (separate --pmc FETCH_SIZE / WRITE_SIZE passes, 500000 pairs per launch), scaled per pair" % pmc_name
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process.  The figure is taken from a
+    # committed rocprofv3 --pmc summary (scripts/pmc_traffic.sh + pmc_summary.py) only when that summary was made on this
+    # workload at this many pairs per launch; otherwise null.
+    traffic, traffic_source = None, "no profiles/*_pmc_summary.json for this workload (genome_bases, read_length, pairs_per_launch)"
+    prof_dir = os.path.join(ROOT, "profiles")
+    for name in sorted((n for n in os.listdir(prof_dir) if n.endswith("_pmc_summary.json")), reverse=True) if os.path.isdir(prof_dir) else []:
+        summary = json.load(open(os.path.join(prof_dir, name)))
+        w = summary.get("workload", {})
+        k = summary.get("k_" + dominant)
+        if k and "hbm_bytes_per_launch" in k and w.get("genome_bases") == args.genome_bases and w.get("read_length") == L and w.get("pairs_per_launch") == args.pairs_per_step:
+            traffic, traffic_source = int(k["hbm_bytes_per_launch"]), "profiles/%s (separate rocprofv3 --pmc passes over the same workload, per launch)" % name
+            break
+    # SURVEY.md §8d's bytes per pair with the run's own counters (probe steps as measured, not ceil(log2 n))
+    bytes_pair = (2 * L + (c["probe_steps"] * 16 + c["matches"] * 16 + seeded_scans * (L + 15) + c["bsw_jobs"] * (L + 15) + c["rescue_window_bases"] +
+                           c["rescue_candidates"] * L) / pairs_rank + 2 * (64 + 12))
+    elapsed_rank = elapsed
     roofline = {"bound": "hbm", "kernel": "k_" + dominant, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_ms": round(total_ms[dominant] / launches, 4), "launches": int(launches),
                 "algorithmic_bytes_per_launch": int(per_kernel_bytes[dominant] / launches),
-                "kernel_ms_total": dict({k: round(v, 2) for k, v in total_ms.items()}, select_heavy=round(heavy_ms, 2)),
-                "bytes_per_pair": round(sum(per_kernel_bytes.values()) / pairs_rank, 1),
+                "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in total_ms.items() if v},
+                "bytes_per_pair": round(bytes_pair, 1),
                 # the whole path of this GPU against the same peak (pairs/s x algorithmic bytes per pair)
-                "path_achieved": round(sum(per_kernel_bytes.values()) / elapsed / 1e9, 2),
-                "path_frac": round(sum(per_kernel_bytes.values()) / elapsed / 1e9 / 8000.0, 6),
-                "heavy_clusters": int(counters.get("heavy_clusters", 0))}
+                "path_achieved": round(pairs_rank * bytes_pair / elapsed_rank / 1e9, 2),
+                "path_frac": round(pairs_rank * bytes_pair / elapsed_rank / 1e9 / 8000.0, 6),
+                "heavy_clusters": int(c.get("heavy_clusters", 0))}
 
-    # ---- CPU baseline: the oracle (a port of the reference path) on a bounded sample of the same workload, host cores -------
-    cpu = None
+    # ---- CPU baseline + parity: the oracle (a port of the reference path) on a bounded sample of the same workload, host cores ---
+    cpu, parity = None, {"parity_checked_pairs": 0, "parity_diffs": None}
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
-        o = oracle_lib.load()
+        from parity_util import count_record_diffs
+        orc = oracle_lib.load()
         cores = os.cpu_count() or 1
-        sample = min(args.cpu_sample_pairs, args.pairs_per_step)
+        sample = min(args.cpu_sample_pairs, batches[args.warmup].shape[0])
         host_bcl = batches[args.warmup][:sample].cpu().numpy()
-        ref = o.reference([bytes(c.cpu().numpy()) for c in contigs])
+        ref = orc.reference([c_.cpu().numpy().tobytes() for c_ in genome.contigs])
         ref.set_index(al.get_index())
-        p = o.default_params(2, L, L)
-        find_threads = min(cores, 32)      # every thread streams the whole index for its clusters: more threads only add memory traffic
+        p = orc.default_params(2, L, L)
+        find_threads = min(cores, 64)      # as MatchFinder: one mask of the table per thread at a time (64 masks)
         tc = time.perf_counter()
-        om, ohits = ref.find_matches(p, host_bcl, sample, n_threads=find_threads)
+        om, ohits = ref.find_matches(p, host_bcl, sample, tile=tile_of(0), n_threads=find_threads)
         t_find = time.perf_counter() - tc
         otls = oracle_lib.Tls()
         for name in ("min", "max", "median", "low_std_dev", "high_std_dev", "stable", "mate_min", "mate_max"):
             setattr(otls, name, getattr(tls, name))
         otls.best_model[0], otls.best_model[1] = tls.best_model[0], tls.best_model[1]
         tc = time.perf_counter()
-        ref.select(p, host_bcl, om, otls, ohits, n_threads=cores, n_clusters_hint=sample)
+        orec, ocig, _ = ref.select(p, host_bcl, om, otls, all_hits, tile=tile_of(0), n_threads=cores, n_clusters_hint=sample)
         t_select = time.perf_counter() - tc
         cpu = {"value": round(2.0 * sample / (t_find + t_select), 1), "unit": "reads/s", "cores": cores, "kind": "port",
-               "sample": "%d pairs of the same workload; oracle/ (CPU restatement of the reference path): merge-join seed lookup on %d threads "
-                         "(%.2f s) + match selection on %d threads (%.2f s)" % (sample, find_threads, t_find, cores, t_select)}
+               "sample": "the first %d pairs of the first timed batch; oracle/ (CPU restatement of the reference path): merge-join seed lookup against the %d-entry table on %d "
+                         "threads (%.2f s) + match selection on %d threads (%.2f s)" % (sample, n_index, find_threads, t_find, cores, t_select)}
+        # the GPU records of the same pairs (first timed step) against the oracle's, field for field + CIGARs
+        grec = out[0][0][:2 * sample].cpu().numpy().view(abi.FRAGMENT_DTYPE).reshape(-1)
+        gcig = packed[0].cpu().numpy().view(np.uint32)
+        n_diff, text = count_record_diffs(orec, ocig, grec, gcig)
+        parity = {"parity_checked_pairs": int(sample), "parity_diffs": int(n_diff)}
+        if text:
+            parity["first_diffs"] = text[:3]
 
-    out = {"metric": "paired-end reads aligned/sec (2x%dbp)" % L, "value": round(reads_per_s, 1), "unit": "reads/s", "n_gpus": world,
-           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "u8/int16 (+f64 log-probabilities)", "data": "synthetic",
-           "config": {"workload": "chr21-sized synthetic reference (%d bp, 32-mer index %d entries), %d synthetic 2x%d bp pairs per GPU "
-                                  "(%d steps x %d pairs)" % (args.genome_bases, n_index, pairs_rank, L, args.steps, args.pairs_per_step),
-                      "pairs_per_step": args.pairs_per_step, "read_length": L, "genome_bases": args.genome_bases, "index_entries": int(n_index),
-                      "parallelism": "read shards x%d, records gathered once" % world, "hbm_used_gb": hbm_used_gb, "setup_s": round(t_setup, 1), "index_build_s": round(t_index, 1),
-                      "tls": list(tls.astuple())},
-           "roofline": roofline, "cpu_baseline": cpu,
-           "counters": {k: int(v) for k, v in counters.items()}}
-    print(json.dumps(out))
+    workload = "GRCh38-sized synthetic human-like reference (%d bp in %d contigs, 32-mer index %d entries), %d synthetic 2x%d bp pairs per GPU (%d steps x %d pairs)" % (
+        args.genome_bases, len(genome), n_index, pairs_rank, L, args.steps, per_rank)
+    result = {"metric": "paired-end reads aligned/sec (2x%dbp, GRCh38)" % L, "value": round(reads_per_s, 1), "unit": "reads/s", "n_gpus": world,
+              "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+              "scaling": args.scaling, "vs_baseline": None, "dtype": "u8/int16 (+f64 log-probabilities)", "data": "synthetic",
+              "config": {"workload": workload, "pairs_per_step": args.pairs_per_step, "read_length": L, "genome_bases": args.genome_bases, "index_entries": int(n_index),
+                         "parallelism": "read shards x%d, records and CIGARs gathered once" % world, "hbm_used_gb": hbm_used_gb, "setup_s": round(t_setup, 1),
+                         "genome_s": round(t_genome, 1), "index_build_s": round(t_index, 1), "tls": list(tls.astuple()), "pcie_inclusive": pcie},
+              "roofline": roofline, "cpu_baseline": cpu, "counters": {k: int(v) for k, v in counters.items()}}
+    result.update(parity)
+    print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -218,6 +218,13 @@ int isaac_gpu_select_candidates(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint
                                 const isaac_candidate *candidates_dev, const uint64_t *candidate_offsets_dev, const uint32_t *candidate_cigars_dev,
                                 const isaac_tls *tls, isaac_fragment *fragments_dev, uint32_t *cigar_dev, uint64_t cigar_capacity);
 
+/* Packs the CIGARs of isaac_gpu_select's fixed 40-word slots back to back, in record order, and rewrites cigar_offset of every
+ * record accordingly: the form in which io::FragmentHeader records are followed by their CIGAR in the reference's bin files
+ * (include/io/Fragment.hh:73-100) and in which a tile's result crosses PCIe or xGMI (about 2 words per read instead of 40).
+ * cigar_out_dev must not overlap cigar_in_dev; *n_words_out receives the packed length (also when it exceeds capacity). */
+int isaac_gpu_compact_cigars(isaac_gpu_ctx *ctx, isaac_fragment *fragments_dev, uint64_t n_records, const uint32_t *cigar_in_dev,
+                             uint32_t *cigar_out_dev, uint64_t capacity, uint64_t *n_words_out);
+
 /* The leaf: alignment::BandedSmithWaterman::align (include/alignment/BandedSmithWaterman.hh:75-86) for a batch;
  * scores as the reference constructor takes them (GappedAligner.cpp:41-42: match, mismatch, -gapOpen, -gapExtend).
  * results[i].n_ops == 0xffffffff flags a CIGAR longer than ISAAC_GPU_MAX_CIGAR_OPS. */

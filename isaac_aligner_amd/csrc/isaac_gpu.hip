@@ -82,7 +82,7 @@ struct isaac_gpu_ctx
     DevBuf<ClusterFragments> frags, fragsAlt; ClusterFragments *fragsCur = nullptr; DevBuf<FragmentWork> fragWork;   // fragsAlt: see isaac_gpu_select
     DevBuf<GappedJob> gappedJobs, rescueGappedJobs; DevBuf<GappedResult> gappedResults, rescueGappedResults; DevBuf<u32> gappedBase, gappedCounters;
     DevBuf<u8> lightArena, heavyArena; DevBuf<u32> overflowList; DevBuf<u32> overflowCount;
-    DevBuf<TlsSample> tlsSamples;
+    DevBuf<TlsSample> tlsSamples; DevBuf<u32> cigarLengths, cigarOffsets;
     DevBuf<RescueJob> jobs; DevBuf<u32> rescueCounters, bitmaps, candJob, shadowCigars, jobBase, jobCount; DevBuf<i32> candPositions; DevBuf<Cand> shadowCands; DevBuf<u32> candRank;
     bool flatRescue = true;
     DevBuf<Counters> counters;
@@ -1768,6 +1768,49 @@ int isaac_gpu_select_candidates(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t n
     if (!candidates || !candidateOffsets) return fail(ISAAC_GPU_EINVAL, "candidates_dev and candidate_offsets_dev are required");
     FragmentSource source; std::memset(&source, 0, sizeof(source)); source.candidates = candidates; source.candidateOffsets = candidateOffsets; source.candidateCigars = candidateCigars;
     return selectFromSource(c, bcl, nClusters, tile, source, tls, fragments, cigar, cigarCapacity);
+}
+
+} // extern "C"
+// the CIGARs of a tile's records packed back to back (isaac_gpu_compact_cigars)
+__global__ void k_cigar_lengths(const FragmentRecord *records, u64 n, u32 *lengths)
+{
+    const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) lengths[i] = records[i].cigarLength;
+}
+__global__ void k_cigar_pack(FragmentRecord *records, u64 n, const u32 *offsets, const u32 *cigarIn, u32 *cigarOut, u64 capacity)
+{
+    const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 from = records[i].cigarOffset, to = offsets[i], len = records[i].cigarLength;
+    if (u64(to) + len <= capacity) for (u32 k = 0; k < len; ++k) cigarOut[to + k] = cigarIn[from + k];
+    records[i].cigarOffset = to;
+}
+extern "C" {
+int isaac_gpu_compact_cigars(isaac_gpu_ctx *c, isaac_fragment *fragments, uint64_t nRecords, const uint32_t *cigarIn, uint32_t *cigarOut, uint64_t capacity, uint64_t *nWordsOut)
+{
+    ISAAC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    if (nWordsOut) *nWordsOut = 0;
+    if (!nRecords) return 0;
+    if (!fragments || !cigarIn || !cigarOut) return fail(ISAAC_GPU_EINVAL, "fragments_dev, cigar_in_dev and cigar_out_dev are required");
+    if (nRecords >= (u64(1) << 31)) return fail(ISAAC_GPU_EINVAL, "at most 2^31 - 1 records per call");
+    joinHeavy(c);
+    hipStream_t st = c->stream;
+    DevBuf<u32> &len = c->cigarLengths, &off = c->cigarOffsets; len.reserve(nRecords); off.reserve(nRecords);
+    FragmentRecord *records = reinterpret_cast<FragmentRecord *>(fragments);
+    k_cigar_lengths<<<gridFor(nRecords, 256), 256, 0, st>>>(records, nRecords, len.p);
+    exclusiveSum(c, len.p, off.p, nRecords);
+    k_cigar_pack<<<gridFor(nRecords, 256), 256, 0, st>>>(records, nRecords, off.p, cigarIn, cigarOut, capacity);
+    HIP_CHECK(hipGetLastError());
+    u32 lastLen = 0, lastOff = 0;
+    HIP_CHECK(hipMemcpyAsync(&lastLen, len.p + nRecords - 1, 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(&lastOff, off.p + nRecords - 1, 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    const u64 total = u64(lastLen) + lastOff;
+    if (nWordsOut) *nWordsOut = total;
+    if (total > capacity) return fail(ISAAC_GPU_ECAPACITY, "cigar_out_dev is too small");
+    return 0;
+    ISAAC_CATCH
 }
 
 int isaac_gpu_bsw_batch(isaac_gpu_ctx *c, int match, int mismatch, int gapOpen, int gapExtend, const char *sequences, const isaac_bsw_job *jobs, uint32_t nJobs,

@@ -37,7 +37,7 @@ def load_library(path=None):
 EXPORTS = ["isaac_gpu_last_error", "isaac_gpu_create", "isaac_gpu_destroy", "isaac_gpu_malloc", "isaac_gpu_free", "isaac_gpu_upload", "isaac_gpu_download",
            "isaac_gpu_synchronize", "isaac_gpu_set_deferred_completion", "isaac_gpu_load_contigs", "isaac_gpu_load_contigs_dev", "isaac_gpu_load_index", "isaac_gpu_build_index", "isaac_gpu_get_index", "isaac_gpu_get_mask_offsets",
            "isaac_gpu_find_matches", "isaac_gpu_set_loaded_contigs", "isaac_gpu_build_fragments", "isaac_gpu_determine_tls", "isaac_gpu_select", "isaac_gpu_select_candidates",
-           "isaac_gpu_bsw_batch",
+           "isaac_gpu_bsw_batch", "isaac_gpu_compact_cigars",
            "isaac_gpu_fastq_to_bcl", "isaac_gpu_get_counters", "isaac_gpu_kernel_time_ms", "isaac_gpu_reset_timers"]
 
 
@@ -222,6 +222,20 @@ class Aligner:
         self._check(self.lib.isaac_gpu_select_candidates(self.h, _p(bcl), C.c_uint32(n), C.c_uint32(tile), _p(cand_d), _p(off_d), _p(cig_in), C.byref(tls),
                                                          _p(records), _p(cigars), C.c_uint64(cigars.numel())))
         return records, cigars
+
+    def compact_cigars(self, records, cigars, out=None):
+        """packs the 40-word CIGAR slots of select() back to back; rewrites the records' cigar_offset in place.
+        Returns (packed cigar tensor view, number of words)"""
+        n_rec = records.shape[0]
+        if out is None:
+            out = self.torch.empty(max(1, n_rec * 4), dtype=self.torch.int32, device=self.device)
+        n = C.c_uint64()
+        rc = self.lib.isaac_gpu_compact_cigars(self.h, _p(records), C.c_uint64(n_rec), _p(cigars), _p(out), C.c_uint64(out.numel()), C.byref(n))
+        if rc == 4:
+            out = self.torch.empty(n.value, dtype=self.torch.int32, device=self.device)
+            rc = self.lib.isaac_gpu_compact_cigars(self.h, _p(records), C.c_uint64(n_rec), _p(cigars), _p(out), C.c_uint64(out.numel()), C.byref(n))
+        self._check(rc)
+        return out[:n.value], n.value
 
     def records_to_numpy(self, records, cigars):
         if self.deferred_completion:

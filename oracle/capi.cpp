@@ -129,6 +129,8 @@ void oracle_ref_set_index(oracle_ref *r, const uint64_t *kmer_pos_pairs, uint64_
     r->index.kmers.resize(n);
     memcpy(r->index.kmers.data(), kmer_pos_pairs, n * 16);
 }
+// SortedReferenceMetadata::Contig::karyotypeIndex_ of every stored contig index (MatchFinder.cpp:51-66)
+void oracle_ref_set_karyotype(oracle_ref *r, const uint32_t *karyotype, uint32_t n) { r->index.karyotype.assign(karyotype, karyotype + n); }
 uint64_t oracle_ref_index_size(const oracle_ref *r) { return r->index.kmers.size(); }
 void oracle_ref_get_index(const oracle_ref *r, uint64_t *kmer_pos_pairs) { memcpy(kmer_pos_pairs, r->index.kmers.data(), r->index.kmers.size() * 16); }
 
@@ -160,35 +162,13 @@ int oracle_find_matches_mt(oracle_ref *r, const oracle_params *cp, const uint8_t
     try
     {
         const Params p = toParams(cp);
-        if (!n_threads) n_threads = 1;
-        if (n_threads > n_clusters) n_threads = n_clusters ? n_clusters : 1;
-        std::vector<std::vector<Match> > parts(n_threads);
-        std::vector<std::vector<uint8_t> > hits(n_threads, std::vector<uint8_t>(r->contigs.size(), 0));
-        std::vector<std::string> errors(n_threads);
-        std::vector<std::thread> threads;
-        const unsigned clusterLength = p.clusterLength();
-        for (uint32_t t = 0; t < n_threads; ++t)
-            threads.emplace_back([&, t]()
-            {
-                try
-                {
-                    const uint64_t begin = uint64_t(n_clusters) * t / n_threads, end = uint64_t(n_clusters) * (t + 1) / n_threads;
-                    findTileMatches(p, r->index, bcl + begin * clusterLength, unsigned(end - begin), tile, parts[t], hits[t]);
-                    for (size_t i = 0; i < parts[t].size(); ++i) parts[t][i].seedId += begin << 9;       // SeedId.hh: cluster field at bit 9
-                }
-                catch (const std::exception &e) { errors[t] = e.what(); }
-            });
-        for (size_t t = 0; t < threads.size(); ++t) threads[t].join();
-        uint64_t n = 0;
-        for (uint32_t t = 0; t < n_threads; ++t)
-        {
-            if (!errors[t].empty()) throw std::runtime_error(errors[t]);
-            if (n + parts[t].size() > capacity) throw std::runtime_error("match capacity");
-            memcpy(matches_out + 2 * n, parts[t].data(), parts[t].size() * 16);
-            n += parts[t].size();
-            for (size_t i = 0; i < hits[t].size(); ++i) if (contig_has_matches) contig_has_matches[i] |= hits[t][i];
-        }
-        *n_out = n;
+        std::vector<Match> matches;
+        std::vector<uint8_t> hits(r->contigs.size(), 0);
+        findTileMatchesParallel(p, r->index, bcl, n_clusters, tile, n_threads ? n_threads : 1, matches, hits);
+        if (matches.size() > capacity) throw std::runtime_error("match capacity");
+        memcpy(matches_out, matches.data(), matches.size() * 16);
+        *n_out = matches.size();
+        for (size_t i = 0; i < hits.size(); ++i) if (contig_has_matches) contig_has_matches[i] |= hits[i];
         return 0;
     }
     catch (const std::exception &e) { g_error = e.what(); return 1; }

@@ -470,6 +470,9 @@ void findMatchesExact(const Params &p, const SortedReference &ref, const std::ve
 void findTileMatches(const Params &p, const SortedReference &ref, const uint8_t *bcl, unsigned nClusters, unsigned tile,
                      std::vector<Match> &sortedMatches, std::vector<uint8_t> &contigHasMatches);
 bool sortByTileBarcodeClusterLocation(const Match &l, const Match &r);
+// the same on nThreads threads, each taking a range of the k-mer space as MatchFinder::matchMaskParallel hands out masks (MatchFinder.cpp:251-316)
+void findTileMatchesParallel(const Params &p, const SortedReference &ref, const uint8_t *bcl, unsigned nClusters, unsigned tile, unsigned nThreads,
+                             std::vector<Match> &sortedMatches, std::vector<uint8_t> &contigHasMatches);
 
 // ---------------------------------------------------------------- template stage
 // include/alignment/TemplateLengthStatistics.hh, lib/alignment/TemplateLengthStatistics.cpp

@@ -6,6 +6,8 @@
 #include <stdexcept>
 #include <map>
 #include <cstring>
+#include <thread>
+#include <string>
 
 namespace oracle
 {
@@ -227,6 +229,180 @@ void findTileMatches(const Params &p, const SortedReference &ref, const uint8_t 
         if (sortByTileBarcodeClusterLocation(r, l)) return false;
         return (l.seedId & 1) < (r.seedId & 1);
     });
+}
+
+// ---------------------------------------------------------------- the same, on several threads
+// MatchFinder::matchMaskParallel (lib/alignment/MatchFinder.cpp:251-316): every thread takes whole masks, i.e. a range of the
+// k-mer space -- its share of the sorted seeds and the part of the sorted reference they can meet -- so the table is streamed
+// once per iteration in total, not once per thread.  Read-complete marks are collected per thread and applied when all threads
+// have finished: the merge join only reads them after the pass (NoMatch emission), which is also how the serial form resolves
+// the reference's benign race.
+namespace
+{
+struct PartialFind
+{
+    std::vector<Match> matches; std::vector<Seed> pendingNoMatch; std::vector<std::pair<unsigned, unsigned> > marks; std::vector<uint8_t> hits;
+};
+
+void joinRange(const Params &p, const SortedReference &ref, const std::vector<Seed> &seeds, size_t nextSeed, const size_t endSeeds, bool closeRepeats, bool storeNoMatches, PartialFind &out)
+{
+    const ReferencePosition tooMany(ReferencePosition::TooManyMatch);
+    const size_t nRef = ref.kmers.size();
+    if (nextSeed == endSeeds) return;
+    // where a mask file that starts with this thread's first k-mer would begin
+    size_t nextRef = size_t(std::lower_bound(ref.kmers.begin(), ref.kmers.end(), seeds[nextSeed].kmer,
+                                             [](const ReferenceKmer &r, uint64_t k) { return r.kmer < k; }) - ref.kmers.begin());
+    std::vector<ReferenceKmer> repeatList;
+    while (endSeeds != nextSeed)
+    {
+        const size_t currentSeed = nextSeed;
+        while (endSeeds != nextSeed && seeds[currentSeed].kmer == seeds[nextSeed].kmer) ++nextSeed;
+        while (nextRef < nRef && seeds[currentSeed].kmer > ref.kmers[nextRef].kmer) ++nextRef;
+        repeatList.clear();
+        while (nextRef < nRef && seeds[currentSeed].kmer == ref.kmers[nextRef].kmer)
+        {
+            if (repeatList.size() < p.repeatThreshold)
+            {
+                ReferenceKmer rk = { ref.kmers[nextRef].kmer, ReferencePosition::fromValue(ref.kmers[nextRef].position).translateContig(ref.karyotype).value };
+                repeatList.push_back(rk);
+            }
+            ++nextRef;
+        }
+        if (repeatList.empty())
+        {
+            if (storeNoMatches) for (size_t s = currentSeed; s < nextSeed; ++s) out.pendingNoMatch.push_back(seeds[s]);
+        }
+        else if (repeatList.size() >= p.repeatThreshold || ReferencePosition::fromValue(repeatList.front().position).isTooManyMatch())
+        {
+            for (size_t s = currentSeed; s < nextSeed; ++s)
+            {
+                const SeedId id(seeds[s].seedId);
+                Match m = { id.value, tooMany.value }; out.matches.push_back(m);
+                if (closeRepeats) out.marks.push_back(std::make_pair(unsigned(id.getCluster()), p.seeds[id.getSeed()].readIndex));
+            }
+        }
+        else
+        {
+            const ReferencePosition anyPosition = ReferencePosition::fromValue(repeatList.front().position);
+            for (size_t s = currentSeed; s < nextSeed; ++s)
+            {
+                const SeedId id(seeds[s].seedId);
+                for (size_t r = 0; r < repeatList.size(); ++r) { Match m = { id.value, repeatList[r].position }; out.matches.push_back(m); }
+                if (p.ignoreNeighbors || !anyPosition.hasNeighbors()) out.marks.push_back(std::make_pair(unsigned(id.getCluster()), p.seeds[id.getSeed()].readIndex));
+            }
+            for (size_t r = 0; r < repeatList.size(); ++r) out.hits.at(ReferencePosition::fromValue(repeatList[r].position).getContigId()) = 1;
+        }
+    }
+}
+
+// seeds of one iteration in (kmer, seed index) order: the clusters are cut into ranges, every thread extracts and sorts its own,
+// the sorted pieces are merged pairwise (SeedGeneratorBase.cpp:182-206 sorts with parallelSort)
+void generateSeedsParallel(const Params &p, const std::vector<unsigned> &seedIndexList, const uint8_t *bcl, unsigned nClusters, unsigned tile, const ClusterInfo &complete,
+                           unsigned nThreads, std::vector<Seed> &seeds)
+{
+    std::vector<std::vector<Seed> > parts(nThreads);
+    std::vector<std::thread> threads;
+    const unsigned clusterLength = p.clusterLength();
+    for (unsigned t = 0; t < nThreads; ++t)
+        threads.emplace_back([&, t]()
+        {
+            const uint64_t begin = uint64_t(nClusters) * t / nThreads, end = uint64_t(nClusters) * (t + 1) / nThreads;
+            ClusterInfo part(complete.begin() + begin, complete.begin() + end);
+            generateSeeds(p, seedIndexList, bcl + begin * clusterLength, unsigned(end - begin), tile, part, parts[t]);
+            for (size_t i = 0; i < parts[t].size(); ++i) parts[t][i].seedId += begin << 9;       // SeedId.hh: cluster field at bit 9
+        });
+    for (size_t t = 0; t < threads.size(); ++t) threads[t].join();
+    // (kmer, seed index) leaves seeds of different clusters with equal keys in unspecified order, as the reference's sort does
+    for (unsigned width = 1; width < nThreads; width *= 2)
+    {
+        threads.clear();
+        for (unsigned t = 0; t + width < nThreads; t += 2 * width)
+            threads.emplace_back([&, t]()
+            {
+                std::vector<Seed> merged(parts[t].size() + parts[t + width].size());
+                std::merge(parts[t].begin(), parts[t].end(), parts[t + width].begin(), parts[t + width].end(), merged.begin(),
+                           [](const Seed &l, const Seed &r) { return l.kmer < r.kmer || (l.kmer == r.kmer && SeedId(l.seedId).getSeed() < SeedId(r.seedId).getSeed()); });
+                parts[t].swap(merged); std::vector<Seed>().swap(parts[t + width]);
+            });
+        for (size_t t = 0; t < threads.size(); ++t) threads[t].join();
+    }
+    seeds.swap(parts[0]);
+}
+
+void findMatchesExactParallel(const Params &p, const SortedReference &ref, const std::vector<Seed> &seeds, bool closeRepeats, bool storeNoMatches, unsigned nThreads,
+                              ClusterInfo &complete, std::vector<Match> &out, std::vector<uint8_t> &contigHasMatches)
+{
+    const ReferencePosition noMatch(ReferencePosition::NoMatch);
+    size_t endSeeds = seeds.size();
+    while (endSeeds && SeedId(seeds[endSeeds - 1].seedId).isNSeedId()) --endSeeds;
+    // thread t takes the seeds of k-mer range t: cut points moved forward to the next change of k-mer
+    std::vector<size_t> cut(nThreads + 1, endSeeds);
+    cut[0] = 0;
+    for (unsigned t = 1; t < nThreads; ++t)
+    {
+        size_t at = std::max(cut[t - 1], endSeeds * t / nThreads);
+        while (at < endSeeds && at && seeds[at].kmer == seeds[at - 1].kmer) ++at;
+        cut[t] = at;
+    }
+    std::vector<PartialFind> parts(nThreads);
+    std::vector<std::string> errors(nThreads);
+    std::vector<std::thread> threads;
+    for (unsigned t = 0; t < nThreads; ++t)
+        threads.emplace_back([&, t]()
+        {
+            try { parts[t].hits.assign(contigHasMatches.size(), 0); joinRange(p, ref, seeds, cut[t], cut[t + 1], closeRepeats, storeNoMatches, parts[t]); }
+            catch (const std::exception &e) { errors[t] = e.what(); }
+        });
+    for (size_t t = 0; t < threads.size(); ++t) threads[t].join();
+    for (unsigned t = 0; t < nThreads; ++t)
+    {
+        if (!errors[t].empty()) throw std::runtime_error(errors[t]);
+        out.insert(out.end(), parts[t].matches.begin(), parts[t].matches.end());
+        for (size_t i = 0; i < parts[t].marks.size(); ++i) complete[parts[t].marks[i].first].markReadComplete(parts[t].marks[i].second);
+        for (size_t i = 0; i < contigHasMatches.size(); ++i) contigHasMatches[i] |= parts[t].hits[i];
+    }
+    for (unsigned t = 0; t < nThreads; ++t)
+        for (size_t i = 0; i < parts[t].pendingNoMatch.size(); ++i)
+        {
+            const SeedId id(parts[t].pendingNoMatch[i].seedId);
+            if (!complete[id.getCluster()].isReadComplete(p.seeds[id.getSeed()].readIndex)) { Match m = { id.value, noMatch.value }; out.push_back(m); }
+        }
+    if (storeNoMatches) for (size_t s = endSeeds; s < seeds.size(); ++s) { Match m = { seeds[s].seedId, noMatch.value }; out.push_back(m); }
+}
+} // namespace
+
+void findTileMatchesParallel(const Params &p, const SortedReference &ref, const uint8_t *bcl, unsigned nClusters, unsigned tile, unsigned nThreads,
+                             std::vector<Match> &matches, std::vector<uint8_t> &contigHasMatches)
+{
+    if (nThreads < 2 || nClusters < nThreads) { findTileMatches(p, ref, bcl, nClusters, tile, matches, contigHasMatches); return; }
+    const std::vector<std::vector<unsigned> > perIteration = seedIndexListPerIteration(p.seeds, unsigned(p.reads.size()), p.firstPassSeeds);
+    ClusterInfo complete(nClusters);
+    matches.clear();
+    std::vector<Seed> seeds;
+    generateSeedsParallel(p, perIteration.at(0), bcl, nClusters, tile, complete, nThreads, seeds);
+    findMatchesExactParallel(p, ref, seeds, false, 1 == perIteration.size(), nThreads, complete, matches, contigHasMatches);
+    if (2 == perIteration.size())
+    {
+        generateSeedsParallel(p, perIteration.at(1), bcl, nClusters, tile, complete, nThreads, seeds);
+        findMatchesExactParallel(p, ref, seeds, true, true, nThreads, complete, matches, contigHasMatches);
+    }
+    // the final order (SelectMatchesTransition.cpp:242-254 + the reverse bit) by cluster ranges on the same threads
+    std::vector<std::vector<Match> > byRange(nThreads);
+    for (size_t i = 0; i < matches.size(); ++i) byRange[size_t(SeedId(matches[i].seedId).getCluster()) * nThreads / nClusters].push_back(matches[i]);
+    std::vector<std::thread> threads;
+    for (unsigned t = 0; t < nThreads; ++t)
+        threads.emplace_back([&, t]()
+        {
+            std::sort(byRange[t].begin(), byRange[t].end(), [](const Match &l, const Match &r)
+            {
+                if (sortByTileBarcodeClusterLocation(l, r)) return true;
+                if (sortByTileBarcodeClusterLocation(r, l)) return false;
+                return (l.seedId & 1) < (r.seedId & 1);
+            });
+        });
+    for (size_t t = 0; t < threads.size(); ++t) threads[t].join();
+    matches.clear();
+    for (unsigned t = 0; t < nThreads; ++t) matches.insert(matches.end(), byRange[t].begin(), byRange[t].end());
 }
 
 // ---------------------------------------------------------------- index builder

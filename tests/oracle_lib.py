@@ -159,6 +159,10 @@ class OracleReference:
         index = np.ascontiguousarray(index, INDEX_DTYPE)
         self.o.lib.oracle_ref_set_index(self.h, ptr(index), C.c_uint64(len(index)))
 
+    def set_karyotype(self, karyotype):
+        k = np.ascontiguousarray(karyotype, np.uint32)
+        self.o.lib.oracle_ref_set_karyotype(self.h, ptr(k), C.c_uint32(len(k)))
+
     def find_matches(self, params, bcl, n_clusters, tile=0, n_threads=1):
         cap = int(n_clusters) * 16 * 10 + 1024
         out = np.zeros(cap, MATCH_DTYPE)

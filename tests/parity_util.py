@@ -107,3 +107,28 @@ def check_fragment_builder_case(case, cands, cigars):
                 assert abs(float(f["log_probability"]) - v[0]) <= v[1], (case["name"], key, float(f["log_probability"]), v)
             else:
                 assert int(f[CANDIDATE_FIELD[name]]) == v, (case["name"], key, name, int(f[CANDIDATE_FIELD[name]]), v)
+
+
+def count_record_diffs(a, acig, b, bcig, limit=5):
+    """vectorised compare_records for full-size batches: (number of differing records, first few as text)"""
+    n = min(len(a), len(b))
+    names = [f for f in a.dtype.names if f not in ("cigar_offset", "reserved")]
+    eq = np.ones(n, bool)
+    for f in names:
+        eq &= a[f][:n] == b[f][:n]
+    # CIGARs: word k of every record side by side, for as many words as the longest one has
+    la = a["cigar_length"][:n].astype(np.int64)
+    oa, ob = a["cigar_offset"][:n].astype(np.int64), b["cigar_offset"][:n].astype(np.int64)
+    for k in range(int(la.max()) if n else 0):
+        has = eq & (la > k)
+        idx = np.nonzero(has)[0]
+        if not len(idx):
+            break
+        eq[idx] &= acig[oa[idx] + k] == bcig[ob[idx] + k]
+    bad = np.nonzero(~eq)[0]
+    text = []
+    for i in bad[:limit]:
+        x, y = a[i], b[i]
+        text.append("record %d:\n  %s %s\n  %s %s" % (i, x, abi.cigar_string(acig[x["cigar_offset"]:x["cigar_offset"] + x["cigar_length"]]),
+                                                      y, abi.cigar_string(bcig[y["cigar_offset"]:y["cigar_offset"] + y["cigar_length"]])))
+    return int(len(bad)) + abs(len(a) - len(b)), text
