@@ -92,7 +92,8 @@ ISAAC_HD void templateCtxInit(TemplateCtx &x, const DevParams &P, const DevRefer
     x.P = &P; x.R = &R; x.tls = &tls; x.frags = &frags; x.w = &work; x.cnt = &cnt; x.clusterId = cluster;
     x.rogRead[0] = rog.read[0]; x.rogRead[1] = rog.read[1]; x.rog = rog.pair;
     x.rescueMode = RESCUE_SERIAL; x.jobNext = 0; x.jobCount = 0; x.jobs = 0; x.planWrite = false; x.serialFallbackAllowed = true;
-    x.candPositions = 0; x.shadowCands = 0; x.shadowCigars = 0; x.gappedResults = 0; x.gappedJobs = 0; x.candRank = 0;
+    x.candPositions = 0; x.shadowCands = 0; x.shadowCigars = 0; x.gappedResults = 0; x.gappedJobs = 0; x.candRank = 0; x.sums = 0;
+    x.bestRescued = work.shadowList; x.bestRescuedPool = work.shadowCigar;
     x.lanes = 1; x.lane = 0; x.fastSort = false; x.ldsSort = 0; x.ldsSortCap = 0;
     for (u32 i = 0; i < 8; ++i) x.prof[i] = 0;
     const u8 *clusterBcl = bcl + u64(cluster) * P.clusterLength;
@@ -136,7 +137,9 @@ ISAAC_HD void rescueAlignCandidate(const DevParams &P, const DevReference &R, co
 }
 
 // What the flat kernels hand to clusterSelect: the cluster's jobs and the aligned candidates of the chunk
-struct RescueInputs { RescueJob *jobs; u32 jobCount; const Cand *shadowCands; const u32 *shadowCigars; const u32 *candRank; const GappedResult *gappedResults; const GappedJob *gappedJobs; bool serialFallbackAllowed; };
+// sums != NULL: the jobs carry their outcome and the cluster's probability sums are given (RESCUE_PRECOMPUTED, after k_cluster_sums)
+struct RescueInputs { RescueJob *jobs; u32 jobCount; const Cand *shadowCands; const u32 *shadowCigars; const u32 *candRank; const GappedResult *gappedResults; const GappedJob *gappedJobs; bool serialFallbackAllowed;
+                      const ClusterSums *sums; };
 // wave-cooperative execution (k_select_heavy) and the fast probability sort; see TemplateCtx
 struct CoopInputs { u32 lanes, lane; bool fastSort; u16 *ldsSort; u32 ldsSortCap; };
 
@@ -155,6 +158,7 @@ ISAAC_HD void clusterSelect(const DevParams &P, const DevReference &R, const Dev
         x.rescueMode = RESCUE_LOOKUP; x.jobs = rescue->jobs; x.jobCount = rescue->jobCount; x.shadowCands = rescue->shadowCands; x.shadowCigars = rescue->shadowCigars;
         x.gappedResults = rescue->gappedResults; x.gappedJobs = rescue->gappedJobs; x.candRank = rescue->candRank;
         x.serialFallbackAllowed = rescue->serialFallbackAllowed;
+        if (rescue->sums) { x.rescueMode = RESCUE_PRECOMPUTED; x.sums = rescue->sums; }
     }
     BamTemplate t;
     ISAAC_PROF_T0(x);

@@ -21,6 +21,7 @@
 #include <string>
 #include <vector>
 #include "cluster_ops.h"
+#include "sums.h"
 #include "host_util.h"
 #include "bsw_kernel.h"
 #include "fastq_kernel.h"
@@ -68,7 +69,6 @@ struct isaac_gpu_ctx
     DevBuf<u64> contigOffset; std::vector<u64> hContigOffset; DevBuf<u8> contigLoaded; std::vector<u8> hContigLoaded; u32 nContigs = 0;
     DevBuf<u64> kmers, positions; u64 nKmers = 0; DevBuf<u32> karyotype; bool hasKaryotype = false;
     DevBuf<u32> prefixTable; u32 prefixBits = 0; std::vector<u64> maskOffsets;   // entries before each mask of the table (load_index / build_index)
-    DevBuf<u8> classFlag; DevBuf<u32> classOrder; u32 selectOrder = 2;      // work classes of k_select, most work first (ISAAC_GPU_SELECT_ORDER: 0 = chunk order, 2..4 classes)   // longest-first order of the light select pass
     DevBuf<u32> packedBases, notBase;   // 2-bit copy of the contigs + not-ACGT bitmap (k_rescue_windows reads these)
     DevBuf<u64> matchBase;
     // run constants of the template kernels in device memory: passed by value they end up as private copies (dynamic indexing)
@@ -81,10 +81,9 @@ struct isaac_gpu_ctx
     DevBuf<Match> staging; DevBuf<u32> counts, chunkOffsets; DevBuf<u8> cubTemp; DevBuf<u32> contigHits;
     DevBuf<ClusterFragments> frags, fragsAlt; ClusterFragments *fragsCur = nullptr; DevBuf<FragmentWork> fragWork;   // fragsAlt: see isaac_gpu_select
     DevBuf<GappedJob> gappedJobs, rescueGappedJobs; DevBuf<GappedResult> gappedResults, rescueGappedResults; DevBuf<u32> gappedBase, gappedCounters;
-    DevBuf<u8> lightArena, heavyArena; DevBuf<u32> overflowList; DevBuf<u32> overflowCount;
+    DevBuf<u8> heavyArena; DevBuf<u32> overflowList; DevBuf<u32> overflowCount; DevBuf<ClusterSums> clusterSums; DevBuf<u32> largeList;
     DevBuf<TlsSample> tlsSamples; DevBuf<u32> cigarLengths, cigarOffsets;
     DevBuf<RescueJob> jobs; DevBuf<u32> rescueCounters, bitmaps, candJob, shadowCigars, jobBase, jobCount; DevBuf<i32> candPositions; DevBuf<Cand> shadowCands; DevBuf<u32> candRank;
-    bool flatRescue = true;
     DevBuf<Counters> counters;
     std::map<std::string, KernelTimer> timers;
     struct PendingTimer { std::string name; hipEvent_t e0, e1; };
@@ -591,13 +590,17 @@ struct RescueBuffers
     u32 *jobBase; u32 *jobCount;   // per cluster of the chunk; jobBase == 0xffffffff: the cluster runs its rescues itself
 };
 
+// the main pass's template work area (tinyCaps) lives in private memory
+static const u32 TINY_WORK_BYTES = 1024;
+
 __global__ __launch_bounds__(64) void k_plan_rescue(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk,
-                                                    const ClusterFragments *frags, u8 *arena, u64 arenaBytes, TemplateCaps caps, RescueBuffers rb)
+                                                    const ClusterFragments *frags, RescueBuffers rb)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nChunk) return;
+    __attribute__((aligned(16))) u8 workBytes[TINY_WORK_BYTES];
     TemplateWork work;
-    templateWorkBind(work, arena + u64(t) * arenaBytes, caps);
+    templateWorkBind(work, workBytes, tinyCaps());
     Cand privateCands[2 * PRIVATE_CANDS];
     // Every seeded candidate is an orphan at most once, so their number bounds the cluster's rescue problems: the slots are
     // reserved first and the template logic runs once, writing the problems as it meets them (unused slots stay invalid)
@@ -607,7 +610,7 @@ __global__ __launch_bounds__(64) void k_plan_rescue(DevParams P, DevReference R,
     {
         base = atomicAdd(rb.jobCounter, reserve);
         if (base + reserve > rb.jobsCap)
-        {   // the cluster's thread runs its rescues itself (k_select, wave-per-cluster capacities)
+        {   // the cluster runs its rescues itself in the wave-per-cluster pass
             base = 0xffffffffu;
             n = clusterPlanRescue(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + t, t, frags[t], work, nullptr, privateCands);
         }
@@ -883,87 +886,88 @@ __global__ __launch_bounds__(256) void k_rescue_gapped_plan(const ClusterFragmen
     flushCounters(local, counters);
 }
 
-// Which clusters cannot fit the light work lists of k_select: known from the rescue summaries before k_select runs, so the
-// wave-per-cluster pass can start at the same time on its own stream.  The test is a superset of the real overflow
-// conditions (a cluster sent here needlessly is still processed exactly); what it misses, k_select reports afterwards.
-__global__ __launch_bounds__(256) void k_predict_heavy(const ClusterFragments *frags, u32 nChunk, RescueBuffers rb, TemplateCaps light, u8 *heavyFlag, u32 *heavyList, u32 *heavyCount)
-{
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nChunk) return;
-    bool heavy = false;
-    if (rb.jobBase[t] != 0xffffffffu)
-    {
-        const RescueJob *jobs = rb.jobs + rb.jobBase[t];
-        const u32 n = rb.jobCount[t];
-        u32 total = 0;
-        for (u32 j = 0; j < n; ++j)
-        {
-            if (!jobs[j].valid) continue;
-            if (jobs[j].fallback || jobs[j].nAligned >= light.shadow) heavy = true;
-            total += jobs[j].nAligned;
-        }
-        const u32 seeded = frags[t].nCands[0] + frags[t].nCands[1];
-        if (total + seeded > light.prob || total > light.pair) heavy = true;
-    }
-    heavyFlag[t] = heavy ? 1 : 0;
-    if (heavy) heavyList[atomicAdd(heavyCount, 1u)] = t;
-}
+// k_cluster_sums: the outcome of every rescue problem of a cluster and its probability sums (sums.h), one wavefront per cluster
+// with room for 64 list entries in LDS; clusters with longer lists are listed for the workgroup-per-cluster form (1024 entries),
+// and what neither can do (near ties, lists beyond that, capacity misses of the flat pass) for the wave-per-cluster pass.
+static const u32 SUMS_WAVE_CAP = 64, SUMS_BLOCK_CAP = 1024;
+struct SumsBuffers { ClusterSums *sums; u8 *residualFlag; u32 *residualList, *residualCount, *largeList, *largeCount; };
 
-// A kernel ends when its slowest waves do.  Clusters with mate-rescue problems take several times longer than those without, so
-// they are handed out first (longest work first) and the quick ones fill the end of the launch: a stable partition of the chunk.
-__global__ void k_select_classes(RescueBuffers rb, u32 nChunk, u32 nClasses, u8 *workClass, u32 *identity)
+__device__ inline SumInputs sumInputs(const RescueBuffers &rb, u32 t, const GappedBuffers &gb)
 {
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nChunk) return;
-    u32 cls = 0;
-    if (rb.jobCount[t])
+    SumInputs in; in.jobs = rb.jobs + rb.jobBase[t]; in.nJobs = rb.jobCount[t]; in.shadowCands = rb.shadowCands; in.candRank = rb.candRank; in.gappedResults = gb.results; in.gappedJobs = gb.jobs;
+    return in;
+}
+__device__ inline void markResidual(const SumsBuffers &sb, u32 t) { sb.residualFlag[t] = 1; sb.residualList[atomicAdd(sb.residualCount, 1u)] = t; }
+
+__global__ __launch_bounds__(256) void k_cluster_sums(DevParams P, const ClusterFragments *frags, u32 nChunk, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters)
+{
+    __shared__ __align__(16) u8 keyBytes[4][SUMS_WAVE_CAP * 42];
+    static_assert(SUMS_WAVE_CAP * 42 % 16 == 0, "key arrays stay aligned");
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 t = blockIdx.x * 4 + wave;
+    Counters local; memset(&local, 0, sizeof(local));
+    if (t < nChunk)
     {
-        cls = 1;
-        if (nClasses > 2 && rb.jobBase[t] != 0xffffffffu)
+        if (0xffffffffu == rb.jobBase[t]) { if (0 == lane) markResidual(sb, t); }
+        else if (rb.jobCount[t])
         {
-            u32 total = 0;
-            for (u32 j = 0; j < rb.jobCount[t]; ++j) total += rb.jobs[rb.jobBase[t] + j].nCands;
-            if (total > 4) cls = 2;
-            if (total > 16 && nClasses > 3) cls = 3;
+            SumKeys keys; sumKeysBind(keys, keyBytes[wave], SUMS_WAVE_CAP);
+            SumGroup g; g.lanes = 64; g.lane = lane; g.block = false;
+            ClusterSums out;
+            const u32 status = clusterSums(P, frags[t], sumInputs(rb, t, gb), keys, g, nullptr, true, out, local);
+            if (0 == lane)
+            {
+                if (SUMS_DONE == status) sb.sums[t] = out;
+                else if (SUMS_TOO_LARGE == status) sb.largeList[atomicAdd(sb.largeCount, 1u)] = t;
+                else markResidual(sb, t);
+            }
         }
     }
-    workClass[t] = u8(3 - cls);       // ascending sort = most work first
-    identity[t] = t;
+    flushCounters(local, counters);
 }
 
-// k_select: clusters [clusterBase, clusterBase + nChunk) with per-thread arenas of `arenaBytes`; clusters whose light work
-// lists overflow are appended to overflowList.  With `list` given, thread t redoes cluster list[t] (heavy capacities).
+__global__ __launch_bounds__(256) void k_cluster_sums_large(DevParams P, const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters)
+{
+    __shared__ __align__(16) u8 keyBytes[SUMS_BLOCK_CAP * 42];
+    __shared__ u32 scratch;
+    Counters local; memset(&local, 0, sizeof(local));
+    const u32 n = *sb.largeCount;
+    for (u32 i = blockIdx.x; i < n; i += gridDim.x)
+    {
+        const u32 t = sb.largeList[i];
+        SumKeys keys; sumKeysBind(keys, keyBytes, SUMS_BLOCK_CAP);
+        SumGroup g; g.lanes = 256; g.lane = threadIdx.x; g.block = true;
+        ClusterSums out;
+        const u32 status = clusterSums(P, frags[t], sumInputs(rb, t, gb), keys, g, &scratch, false, out, local);
+        if (0 == threadIdx.x) { if (SUMS_DONE == status) sb.sums[t] = out; else markResidual(sb, t); }
+        __syncthreads();
+    }
+    flushCounters(local, counters);
+}
+
+// k_select: TemplateBuilder::buildTemplate on the precomputed rescue outcomes and sums, the clippers and the FragmentHeader records,
+// one thread per cluster of the chunk; `skip`: clusters the wave-per-cluster pass takes.  Clusters whose private work area overflows
+// (more equally good placements than it holds) are appended to overflowList and redone by that pass as well.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_SELECT_WAVES))) void k_select(const isaac_gpu_ctx::TemplateConstants *constants, DevReference R, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk, u32 tile,
-                                               const ClusterFragments *frags, u8 *arena, u64 arenaBytes, TemplateCaps caps, const u32 *list, RescueBuffers rb, const GappedResult *gappedResults, const GappedJob *gappedJobs,
-                                               FragmentRecord *records, u32 *cigars, u32 *overflowList, u32 *overflowCount, u32 overflowCapacity, const u8 *skip, Counters *counters,
-                                               const u32 *order)
+                                               const ClusterFragments *frags, RescueBuffers rb, const GappedResult *gappedResults, const GappedJob *gappedJobs, const ClusterSums *sums,
+                                               FragmentRecord *records, u32 *cigars, u32 *overflowList, u32 *overflowCount, const u8 *skip, Counters *counters)
 {
     const DevParams &P = constants->P; const DevTls &tls = constants->tls; const RogCorrection &rog = constants->rog;
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     Counters local; memset(&local, 0, sizeof(local));
-    // `order`: a permutation of the chunk's clusters, the ones with mate-rescue problems first (see k_select_classes)
-    const u32 inChunk = t < nChunk ? (order ? order[t] : list ? list[t] : t) : 0;
-    if (t < nChunk && !(skip && skip[inChunk]))
+    if (t < nChunk && !skip[t])
     {
+        __attribute__((aligned(16))) u8 workBytes[TINY_WORK_BYTES];
         TemplateWork work;
-        templateWorkBind(work, arena + u64(t) * arenaBytes, caps);
-        RescueInputs in; const RescueInputs *pin = nullptr;
-        if (rb.jobBase && rb.jobBase[inChunk] != 0xffffffffu)
-        {
-            in.jobs = rb.jobs + rb.jobBase[inChunk]; in.jobCount = rb.jobCount[inChunk]; in.shadowCands = rb.shadowCands; in.shadowCigars = rb.shadowCigars; in.candRank = rb.candRank;
-            in.gappedResults = gappedResults; in.gappedJobs = gappedJobs; in.serialFallbackAllowed = list != nullptr;
-            pin = &in;
-        }
+        templateWorkBind(work, workBytes, tinyCaps());
+        RescueInputs in;
+        in.jobs = rb.jobs + rb.jobBase[t]; in.jobCount = rb.jobCount[t]; in.shadowCands = rb.shadowCands; in.shadowCigars = rb.shadowCigars; in.candRank = rb.candRank;
+        in.gappedResults = gappedResults; in.gappedJobs = gappedJobs; in.serialFallbackAllowed = false; in.sums = sums + t;
         Cand privateCands[2 * PRIVATE_CANDS];
-        clusterSelect(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + inChunk, tile, frags[inChunk], work, records, cigars, local, pin, nullptr, privateCands);
-        if (work.overflow)
-        {
-            if (!list) { const u32 at = atomicAdd(overflowCount, 1u); if (at < overflowCapacity) overflowList[at] = inChunk; }
-            else ++local.overflowClusters;   // even the reference's own capacities were exceeded
-        }
-        if (list) ++local.heavyClusters;
+        clusterSelect(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + t, tile, frags[t], work, records, cigars, local, &in, nullptr, privateCands);
+        if (work.overflow) overflowList[atomicAdd(overflowCount, 1u)] = t;
     }
-    if (t < nChunk && !list) ++local.clusters;   // including the ones the wave-per-cluster pass takes
+    if (t < nChunk) ++local.clusters;   // including the ones the wave-per-cluster pass takes
     flushCounters(local, counters);
 }
 
@@ -986,7 +990,7 @@ __global__ __launch_bounds__(64) void k_select_heavy(DevParams P, DevReference R
     if (rb.jobBase && rb.jobBase[inChunk] != 0xffffffffu)
     {
         in.jobs = rb.jobs + rb.jobBase[inChunk]; in.jobCount = rb.jobCount[inChunk]; in.shadowCands = rb.shadowCands; in.shadowCigars = rb.shadowCigars; in.candRank = rb.candRank;
-        in.gappedResults = gappedResults; in.gappedJobs = gappedJobs; in.serialFallbackAllowed = true;
+        in.gappedResults = gappedResults; in.gappedJobs = gappedJobs; in.serialFallbackAllowed = true; in.sums = nullptr;
         pin = &in;
     }
     CoopInputs coop; coop.lanes = 64; coop.lane = threadIdx.x; coop.fastSort = true; coop.ldsSort = reinterpret_cast<u16 *>(heavyLds); coop.ldsSortCap = HEAVY_SORT_LDS;
@@ -1079,8 +1083,6 @@ int isaac_gpu_create(int device, const isaac_params *params, void *stream, isaac
     HIP_CHECK(hipStreamCreateWithFlags(&c->heavyStream, hipStreamNonBlocking));
     HIP_CHECK(hipEventCreateWithFlags(&c->evPredicted, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&c->evHeavyDone, hipEventDisableTiming));
     if (const char *e = getenv("ISAAC_GPU_CHUNK_CLUSTERS")) c->chunkClusters = u32(std::max(1024, atoi(e)));
-    if (const char *e = getenv("ISAAC_GPU_FLAT_RESCUE")) c->flatRescue = atoi(e) != 0;
-    if (const char *e = getenv("ISAAC_GPU_SELECT_ORDER")) c->selectOrder = u32(std::max(0, atoi(e)));
     *out = c.release();
     return ISAAC_GPU_OK;
     ISAAC_CATCH
@@ -1629,28 +1631,22 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
     DevTls t; std::memcpy(&t, tls, sizeof(t));
     const RogCorrection rog = makeRogCorrection(c->P, c->hContigOffset.data(), c->hContigLoaded.data(), c->nContigs);
     const double lmq40 = logMismatchQ40();
-    TemplateCaps light = lightCaps(); const TemplateCaps heavy = heavyCaps();
-    if (const char *e = getenv("ISAAC_GPU_LIGHT_CAPS"))
-    {   // shadow,shadowCigar,pos,prob,pair,best,templateCigar
-        unsigned v[7];
-        if (7 == sscanf(e, "%u,%u,%u,%u,%u,%u,%u", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6))
-        { light.shadow = v[0]; light.shadowCigar = v[1]; light.pos = v[2]; light.prob = v[3]; light.pair = v[4]; light.best = v[5]; light.templateCigar = v[6]; }
-    }
-    const u64 lightBytes = templateWorkBytes(light), heavyBytes = templateWorkBytes(heavy);
+    const TemplateCaps heavy = heavyCaps();
+    if (templateWorkBytes(tinyCaps()) > TINY_WORK_BYTES) return fail(ISAAC_GPU_EHIP, "TINY_WORK_BYTES is smaller than the work area of tinyCaps()");
+    const u64 heavyBytes = templateWorkBytes(heavy);
     const u32 chunk = chunkFor(c, nClusters);
     const u32 heavyThreads = 1024, residualThreads = 256;
-    c->lightArena.reserve(size_t(chunk) * lightBytes);
     c->overflowList.reserve(chunk);
     RescueBuffers rb; std::memset(&rb, 0, sizeof(rb));
-    if (c->flatRescue)
-    {
-        rb.jobsCap = 4 * chunk; rb.bitmapCap = 64 * rb.jobsCap; rb.candRegionSize = (24 * chunk + CAND_REGIONS - 1) / CAND_REGIONS; rb.candCap = rb.candRegionSize * CAND_REGIONS;
-        c->jobs.reserve(rb.jobsCap); c->bitmaps.reserve(rb.bitmapCap); c->candPositions.reserve(rb.candCap); c->candJob.reserve(rb.candCap);
-        c->shadowCands.reserve(rb.candCap); c->candRank.reserve(rb.candCap); c->shadowCigars.reserve(size_t(rb.candCap) * 3); c->jobBase.reserve(chunk); c->jobCount.reserve(chunk); c->rescueCounters.reserve(4 + 2 * CAND_REGIONS);
-        rb.jobs = c->jobs.p; rb.bitmaps = c->bitmaps.p; rb.candPositions = c->candPositions.p; rb.candJob = c->candJob.p; rb.shadowCands = c->shadowCands.p; rb.candRank = c->candRank.p;
-        rb.shadowCigars = c->shadowCigars.p; rb.jobBase = c->jobBase.p; rb.jobCount = c->jobCount.p;
-        rb.jobCounter = c->rescueCounters.p; rb.bitmapCounter = c->rescueCounters.p + 1; rb.candCounter = c->rescueCounters.p + 4;
-    }
+    rb.jobsCap = 4 * chunk; rb.bitmapCap = 64 * rb.jobsCap; rb.candRegionSize = (24 * chunk + CAND_REGIONS - 1) / CAND_REGIONS; rb.candCap = rb.candRegionSize * CAND_REGIONS;
+    c->jobs.reserve(rb.jobsCap); c->bitmaps.reserve(rb.bitmapCap); c->candPositions.reserve(rb.candCap); c->candJob.reserve(rb.candCap);
+    c->shadowCands.reserve(rb.candCap); c->candRank.reserve(rb.candCap); c->shadowCigars.reserve(size_t(rb.candCap) * 3); c->jobBase.reserve(chunk); c->jobCount.reserve(chunk); c->rescueCounters.reserve(4 + 2 * CAND_REGIONS);
+    rb.jobs = c->jobs.p; rb.bitmaps = c->bitmaps.p; rb.candPositions = c->candPositions.p; rb.candJob = c->candJob.p; rb.shadowCands = c->shadowCands.p; rb.candRank = c->candRank.p;
+    rb.shadowCigars = c->shadowCigars.p; rb.jobBase = c->jobBase.p; rb.jobCount = c->jobCount.p;
+    rb.jobCounter = c->rescueCounters.p; rb.bitmapCounter = c->rescueCounters.p + 1; rb.candCounter = c->rescueCounters.p + 4;
+    c->clusterSums.reserve(chunk); c->heavyList.reserve(chunk); c->largeList.reserve(chunk); c->heavyCount.reserve(2); c->heavyFlag.reserve(chunk);
+    SumsBuffers sb; sb.sums = c->clusterSums.p; sb.residualFlag = c->heavyFlag.p; sb.residualList = c->heavyList.p; sb.residualCount = c->heavyCount.p;
+    sb.largeList = c->largeList.p; sb.largeCount = c->heavyCount.p + 1;
     const DevReference R = c->ref();
     {
         isaac_gpu_ctx::TemplateConstants k; k.P = c->P; k.tls = t; k.rog = rog;
@@ -1660,6 +1656,7 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
     }
     const GappedBuffers gbRescue = gappedBuffers(c, 1);
     c->frags.reserve(chunk); c->fragsAlt.reserve(chunk);
+    c->heavyArena.reserve(size_t(heavyThreads + residualThreads) * heavyBytes);
     for (u32 done = 0; done < nClusters; done += chunk)
     {
         const u32 n = std::min(chunk, nClusters - done);
@@ -1677,40 +1674,38 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         else launchBuildFragments(c, bcl, done, n, source.matches, source.offsets, 1, 1);
         joinHeavy(c);
         HIP_CHECK(hipMemsetAsync(c->overflowCount.p, 0, 4, st));
-        if (c->flatRescue)
+        HIP_CHECK(hipMemsetAsync(c->rescueCounters.p, 0, (4 + CAND_REGIONS) * 4, st));
+        HIP_CHECK(hipMemsetAsync(c->rescueCounters.p + 4 + CAND_REGIONS, 0xff, CAND_REGIONS * 4, st));   // per region: first request that did not fit
+        HIP_CHECK(hipMemsetAsync(c->heavyCount.p, 0, 8, st));
+        HIP_CHECK(hipMemsetAsync(c->heavyFlag.p, 0, n, st));
         {
-            HIP_CHECK(hipMemsetAsync(c->rescueCounters.p, 0, (4 + CAND_REGIONS) * 4, st));
-            HIP_CHECK(hipMemsetAsync(c->rescueCounters.p + 4 + CAND_REGIONS, 0xff, CAND_REGIONS * 4, st));   // per region: first request that did not fit
-            {
-                ScopedTimer tm(c, "plan_rescue");
-                k_plan_rescue<<<gridFor(n, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, n, c->fragsCur, c->lightArena.p, lightBytes, light, rb);
-                HIP_CHECK(hipGetLastError());
-            }
-            {
-                ScopedTimer tm(c, "rescue_windows");
-                k_rescue_windows<<<gridFor(rb.jobsCap, 4), 256, 0, st>>>(c->P, R, c->hContigOffset[c->nContigs], bcl, done, rb);
-                HIP_CHECK(hipGetLastError());
-            }
-            {
-                ScopedTimer tm(c, "rescue_align");
-                k_rescue_align<<<gridFor(rb.candCap, 256), 256, 0, st>>>(c->P, R, bcl, done, c->fragsCur, rb, c->counters.p);
-                HIP_CHECK(hipGetLastError());
-            }
-            {
-                ScopedTimer tm(c, "rescue_gapped_plan");
-                k_rescue_gapped_plan<<<gridFor(rb.jobsCap, 256), 256, 0, st>>>(c->fragsCur, rb, gbRescue, c->counters.p);
-                HIP_CHECK(hipGetLastError());
-            }
-            launchGappedJobs(c, bcl, done, gbRescue, "gapped_rescue");
-        }
-        const bool predicted = c->flatRescue;
-        c->heavyArena.reserve(size_t(heavyThreads + residualThreads) * heavyBytes);
-        if (predicted)
-        {   // clusters that cannot fit the light lists start on their own stream now, next to k_select
-            c->heavyList.reserve(chunk); c->heavyCount.reserve(1); c->heavyFlag.reserve(chunk);
-            HIP_CHECK(hipMemsetAsync(c->heavyCount.p, 0, 4, st));
-            k_predict_heavy<<<gridFor(n, 256), 256, 0, st>>>(c->fragsCur, n, rb, light, c->heavyFlag.p, c->heavyList.p, c->heavyCount.p);
+            ScopedTimer tm(c, "plan_rescue");
+            k_plan_rescue<<<gridFor(n, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, n, c->fragsCur, rb);
             HIP_CHECK(hipGetLastError());
+        }
+        {
+            ScopedTimer tm(c, "rescue_windows");
+            k_rescue_windows<<<gridFor(rb.jobsCap, 4), 256, 0, st>>>(c->P, R, c->hContigOffset[c->nContigs], bcl, done, rb);
+            HIP_CHECK(hipGetLastError());
+        }
+        {
+            ScopedTimer tm(c, "rescue_align");
+            k_rescue_align<<<gridFor(rb.candCap, 256), 256, 0, st>>>(c->P, R, bcl, done, c->fragsCur, rb, c->counters.p);
+            HIP_CHECK(hipGetLastError());
+        }
+        {
+            ScopedTimer tm(c, "rescue_gapped_plan");
+            k_rescue_gapped_plan<<<gridFor(rb.jobsCap, 256), 256, 0, st>>>(c->fragsCur, rb, gbRescue, c->counters.p);
+            HIP_CHECK(hipGetLastError());
+        }
+        launchGappedJobs(c, bcl, done, gbRescue, "gapped_rescue");
+        {
+            ScopedTimer tm(c, "probability_sums");
+            k_cluster_sums<<<gridFor(n, 4), 256, 0, st>>>(c->P, c->fragsCur, n, rb, gbRescue, sb, c->counters.p);
+            k_cluster_sums_large<<<2048, 256, 0, st>>>(c->P, c->fragsCur, rb, gbRescue, sb, c->counters.p);
+            HIP_CHECK(hipGetLastError());
+        }
+        {   // what the sums stage could not do starts on its own stream now, next to k_select, with the reference's own capacities
             HIP_CHECK(hipEventRecord(c->evPredicted, st));
             HIP_CHECK(hipStreamWaitEvent(c->heavyStream, c->evPredicted, 0));
             {
@@ -1722,29 +1717,15 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
             HIP_CHECK(hipEventRecord(c->evHeavyDone, c->heavyStream)); c->heavyPending = true;
         }
         {
-            const u32 *order = nullptr;
-            if (c->selectOrder && c->flatRescue)
-            {
-                ScopedTimer tmOrder(c, "select_order");
-                c->classFlag.reserve(2 * size_t(chunk)); c->classOrder.reserve(2 * size_t(chunk));
-                u8 *keysIn = c->classFlag.p, *keysOut = c->classFlag.p + chunk; u32 *idIn = c->classOrder.p, *idOut = c->classOrder.p + chunk;
-                k_select_classes<<<gridFor(n, 256), 256, 0, st>>>(rb, n, c->selectOrder, keysIn, idIn);
-                size_t bytes = 0;
-                HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keysIn, keysOut, idIn, idOut, int(n), 0, 2, st));   // stable: the chunk's order inside a class
-                c->cubTemp.reserve(bytes + 16);
-                HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->cubTemp.p, bytes, keysIn, keysOut, idIn, idOut, int(n), 0, 2, st));
-                order = idOut;
-            }
             ScopedTimer tm(c, "select");
-            k_select<<<gridFor(n, 64), 64, 0, st>>>(c->templateConstants.p, R, lmq40, bcl, done, n, tile, c->fragsCur, c->lightArena.p, lightBytes, light, nullptr, rb, c->flatRescue ? gbRescue.results : nullptr, c->flatRescue ? gbRescue.jobs : nullptr,
-                                                     reinterpret_cast<FragmentRecord *>(fragments), cigar, c->overflowList.p, c->overflowCount.p, chunk, predicted ? c->heavyFlag.p : nullptr, c->counters.p, order);
+            k_select<<<gridFor(n, 64), 64, 0, st>>>(c->templateConstants.p, R, lmq40, bcl, done, n, tile, c->fragsCur, rb, gbRescue.results, gbRescue.jobs, c->clusterSums.p,
+                                                     reinterpret_cast<FragmentRecord *>(fragments), cigar, c->overflowList.p, c->overflowCount.p, c->heavyFlag.p, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }
-        {   // what the prediction missed (normally nothing): again, with the reference's own capacities; the count stays on the device
+        {   // clusters whose private work area overflowed (normally none): again, with the reference's own capacities; the count stays on the device
             ScopedTimer tm(c, "select_residual");
             k_select_heavy<<<residualThreads, 64, HEAVY_SORT_LDS * 2, st>>>(c->P, R, t, rog, lmq40, bcl, done, 0, c->overflowCount.p, tile, c->fragsCur,
-                                                                            c->heavyArena.p + size_t(heavyThreads) * heavyBytes, heavyBytes, heavy, c->overflowList.p, rb,
-                                                                            c->flatRescue ? gbRescue.results : nullptr, c->flatRescue ? gbRescue.jobs : nullptr,
+                                                                            c->heavyArena.p + size_t(heavyThreads) * heavyBytes, heavyBytes, heavy, c->overflowList.p, rb, gbRescue.results, gbRescue.jobs,
                                                                             reinterpret_cast<FragmentRecord *>(fragments), cigar, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }

@@ -1,0 +1,251 @@
+// The probability sums of TemplateBuilder (sumUniqueShadowProbabilities / sumUniquePairProbabilities, TemplateBuilder.cpp:694-714,
+// and the running sum of rescueShadow, :552-560) and the outcome of every ShadowAligner::rescueShadow call of a cluster
+// (ShadowAligner.cpp:232-291), computed by a group of lanes per cluster from what the flat rescue kernels left in HBM.
+// k_select then runs the template logic on numbers (RESCUE_PRECOMPUTED) instead of building, copying and sorting lists per thread.
+//
+// A list is never materialised: element r of the shadow list of rescue problem j is the aligned candidate of rank r (its gapped
+// retry where ShadowAligner accepted one), so the sort keys are gathered straight into the group's LDS arrays, ordered by a
+// bitonic network over 16-bit indices, and summed in sorted order by the reference's rule (the first of every run of equal
+// elements).  The order used is the total order that refines the reference's epsilon comparators; a list with a "near tie"
+// (same position, probabilities different but within 1e-7), where the two can disagree, sends the cluster to the
+// wave-per-cluster pass, which has the instruction-exact std::sort replica.  So do clusters whose lists exceed the group's
+// capacity and clusters for which a capacity of the flat pass was exceeded.
+#pragma once
+#include "template.h"
+
+namespace isaac
+{
+
+// `cap` entries each, in LDS on the device
+struct SumKeys { u64 *pos1, *pos2; double *lp, *term; u32 *obs1, *obs2; u16 *idx; u32 cap; };
+ISAAC_HD u64 sumKeysBytes(u32 cap) { return u64(cap) * (8 + 8 + 8 + 8 + 4 + 4 + 2); }
+ISAAC_HD void sumKeysBind(SumKeys &k, void *base, u32 cap)
+{
+    u8 *p = static_cast<u8 *>(base);
+    k.cap = cap;
+    k.pos1 = reinterpret_cast<u64 *>(p); p += u64(cap) * 8; k.pos2 = reinterpret_cast<u64 *>(p); p += u64(cap) * 8;
+    k.lp = reinterpret_cast<double *>(p); p += u64(cap) * 8; k.term = reinterpret_cast<double *>(p); p += u64(cap) * 8;
+    k.obs1 = reinterpret_cast<u32 *>(p); p += u64(cap) * 4; k.obs2 = reinterpret_cast<u32 *>(p); p += u64(cap) * 4;
+    k.idx = reinterpret_cast<u16 *>(p);
+}
+
+// the lanes working on one cluster: one wavefront, or a whole workgroup (block = true)
+struct SumGroup { u32 lanes, lane; bool block; };
+ISAAC_HD void groupSync(const SumGroup &g)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (g.block) __syncthreads();
+    else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+#endif
+    (void)g;
+}
+ISAAC_HD bool groupAny(const SumGroup &g, bool v, u32 *scratch)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (!g.block) return __ballot(v) != 0;
+    if (0 == g.lane) *scratch = 0;
+    __syncthreads();
+    if (v) *scratch = 1;
+    __syncthreads();
+    const bool r = 0 != *scratch;
+    __syncthreads();
+    return r;
+#else
+    (void)g; (void)scratch; return v;
+#endif
+}
+
+// total orders refining shadowProbLess / pairProbLess (keyLess of template.h), on entries of the key arrays
+ISAAC_HD bool sumKeyLess(const SumKeys &k, bool pairs, u32 a, u32 b)
+{
+    if (k.pos1[a] != k.pos1[b]) return k.pos1[a] < k.pos1[b];
+    if (k.pos2[a] != k.pos2[b]) return k.pos2[a] < k.pos2[b];
+    if (k.lp[a] != k.lp[b]) return pairs ? k.lp[b] < k.lp[a] : k.lp[a] < k.lp[b];      // pairs: higher probability first
+    if (k.obs1[a] != k.obs1[b]) return k.obs1[a] < k.obs1[b];
+    if (k.obs2[a] != k.obs2[b]) return k.obs2[a] < k.obs2[b];
+    return a < b;
+}
+ISAAC_HD bool sumKeyNearTie(const SumKeys &k, u32 a, u32 b) { return k.pos1[a] == k.pos1[b] && k.pos2[a] == k.pos2[b] && k.lp[a] != k.lp[b] && lpEquals(k.lp[a], k.lp[b]); }
+ISAAC_HD bool sumKeyEqual(const SumKeys &k, u32 a, u32 b)
+{ return k.pos1[a] == k.pos1[b] && k.pos2[a] == k.pos2[b] && lpEquals(k.lp[a], k.lp[b]) && k.obs1[a] == k.obs1[b] && k.obs2[a] == k.obs2[b]; }
+
+// Sum of exp(lp) over the first element of every run of equal keys of entries [0, n), in sorted order.  false: a near tie.
+ISAAC_HD bool uniqueSortedSum(SumKeys &k, u32 n, bool pairs, const SumGroup &g, u32 *scratch, double &sum)
+{
+    sum = 0.0;
+    if (!n) return true;
+    u32 m = 1; while (m < n) m <<= 1;
+    for (u32 i = g.lane; i < m; i += g.lanes) k.idx[i] = i < n ? u16(i) : u16(0xffff);
+    groupSync(g);
+    for (u32 kk = 2; kk <= m; kk <<= 1)
+        for (u32 j = kk >> 1; j > 0; j >>= 1)
+        {
+            for (u32 t = g.lane; t < (m >> 1); t += g.lanes)
+            {
+                const u32 i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const u16 a = k.idx[i], b = k.idx[i + j];
+                // 0xffff pads the network: greater than every element
+                const bool aLessB = (a != 0xffff) && (b == 0xffff || sumKeyLess(k, pairs, a, b));
+                const bool bLessA = (b != 0xffff) && (a == 0xffff || sumKeyLess(k, pairs, b, a));
+                if ((0 == (i & kk)) ? bLessA : aLessB) { k.idx[i] = b; k.idx[i + j] = a; }
+            }
+            groupSync(g);
+        }
+    bool nearTie = false;
+    for (u32 i = g.lane; i < n; i += g.lanes)
+    {
+        const u32 cur = k.idx[i];
+        bool dup = false;
+        if (i) { const u32 prev = k.idx[i - 1]; nearTie |= sumKeyNearTie(k, prev, cur); dup = sumKeyEqual(k, prev, cur); }
+        k.term[i] = dup ? 0.0 : exp(k.lp[cur]);       // without near ties "equal to the first of the run" is "equal to the predecessor"; x + 0.0 == x
+    }
+    if (groupAny(g, nearTie, scratch)) return false;
+    groupSync(g);
+    for (u32 i = 0; i < n; ++i) sum += k.term[i];     // the additions in sequence: their order is part of the result (every lane: same value)
+    groupSync(g);
+    return true;
+}
+
+ISAAC_HD void sumKeyFromCand(SumKeys &k, u32 at, const Cand &c)
+{ const ShadowProb p = makeShadowProb(c); k.pos1[at] = p.pos; k.pos2[at] = 0; k.lp[at] = p.logProbability; k.obs1[at] = u32(p.observedLength); k.obs2[at] = 0; }
+
+enum { SUMS_DONE = 0, SUMS_TOO_LARGE = 1, SUMS_RESIDUAL = 2 };
+
+// what the flat rescue kernels left for one cluster
+struct SumInputs { RescueJob *jobs; u32 nJobs; const Cand *shadowCands; const u32 *candRank; const GappedResult *gappedResults; GappedJob *gappedJobs; };
+
+// second half of ShadowAligner::rescueShadow (ShadowAligner.cpp:232-291) for one problem, on numbers only: how long the list is,
+// whether the call succeeds, which retries are accepted (GappedJob::pad = 1) and which shadow ends up in front.  false: the
+// wave-per-cluster pass has to do it (a capacity of the flat pass was exceeded).
+ISAAC_HD bool finishRescueFlat(const DevParams &P, RescueJob &job, const SumInputs &in, u32 &retries)
+{
+    job.take = 0; job.rescued = 0; job.finalBestRank = 0; job.finalBestSlot = 0; job.finalBestGapped = 0xffffffffu;
+    if (!job.valid) return true;
+    if (job.fallback || (job.nGapped && 0xffffffffu == job.gappedBase)) return false;
+    const bool full = job.nAligned - job.lastAligned >= SHADOW_LIST_MAX && job.nCands != 0;   // the reference gives up when the list is full and another candidate aligns
+    job.take = imin(job.nAligned, SHADOW_LIST_MAX);
+    if (full || !job.nAligned) return true;
+    u32 best = job.bestRank, bestSlot = job.bestSlot, bestGapped = 0xffffffffu;
+    double bestLp = in.shadowCands[job.bestSlot].logProbability;
+    for (u32 kk = 0; kk < job.nGapped; ++kk)
+    {
+        const GappedResult &g = in.gappedResults[job.gappedBase + kk];
+        GappedJob &gj = in.gappedJobs[job.gappedBase + kk];
+        const u32 slot = gj.tag, i = in.candRank[slot];
+        const Cand &fragment = in.shadowCands[slot];
+        ++retries;
+        gj.pad = 0;
+        if (0xffffffffu == g.nCigar) return false;        // CIGAR longer than the result record holds
+        const Cand &tmp = g.out;
+        if (g.matchCount && g.matchCount + BSW_WIDEST_GAP_SIZE > candObservedLength(fragment) && (tmp.mismatchCount <= P.gappedMismatchesMax) &&
+            (fragment.mismatchCount > tmp.mismatchCount) && lpLess(fragment.logProbability, tmp.logProbability))
+        {
+            gj.pad = 1;
+            if (i == best) { bestLp = tmp.logProbability; bestGapped = job.gappedBase + kk; bestSlot = slot; }
+            else if (lpLess(bestLp, tmp.logProbability)) { best = i; bestLp = tmp.logProbability; bestGapped = job.gappedBase + kk; bestSlot = slot; }
+        }
+    }
+    job.rescued = 1; job.finalBestRank = best; job.finalBestSlot = bestSlot; job.finalBestGapped = bestGapped;
+    return true;
+}
+
+// the shadows of one problem, f(rank, cand) for every element of its list (any order; all lanes of the group take part)
+template <typename F>
+ISAAC_HD void forEachShadow(const RescueJob &job, const SumInputs &in, const SumGroup &g, F f)
+{
+    for (u32 c = g.lane; c < job.nCands; c += g.lanes)
+    {
+        const u32 slot = job.candBase + c;
+        const Cand &cand = in.shadowCands[slot];
+        if (!candAligned(cand)) continue;
+        const u32 r = in.candRank[slot];
+        if (r < job.take) f(r, cand, false);
+    }
+    if (!job.rescued) return;
+    groupSync(g);                                         // the accepted retries replace what the loop above wrote
+    for (u32 kk = g.lane; kk < job.nGapped; kk += g.lanes)
+    {
+        const GappedJob &gj = in.gappedJobs[job.gappedBase + kk];
+        if (!gj.pad) continue;
+        const u32 r = in.candRank[gj.tag];
+        if (r < job.take) f(r, in.gappedResults[job.gappedBase + kk].out, true);
+    }
+}
+
+// Everything k_select needs to know about the mate rescues of one cluster.  `first`: the jobs have not been finished yet (the
+// larger group that retries a SUMS_TOO_LARGE cluster skips that step).
+ISAAC_HD u32 clusterSums(const DevParams &P, const ClusterFragments &f, const SumInputs &in, SumKeys &k, const SumGroup &g, u32 *scratch, bool first, ClusterSums &out, Counters &cnt)
+{
+    out.shadow[0] = out.shadow[1] = out.pair = out.ordered = 0.0;
+    if (first)
+    {   // every lane does this for itself (the same loads, the same stores of the same values): nothing to hand from lane to lane
+        bool ok = true; u32 retries = 0;
+        for (u32 j = 0; j < in.nJobs && ok; ++j) ok = finishRescueFlat(P, in.jobs[j], in, retries);
+        if (!ok) return SUMS_RESIDUAL;
+        if (0 == g.lane) cnt.rescueBsw += retries;
+    }
+    const u32 nCands[2] = { f.nCands[0], f.nCands[1] };
+    u32 shadows[2] = { 0, 0 };
+    for (u32 j = 0; j < in.nJobs; ++j) shadows[(in.jobs[j].shadowReadIndex + 1) % 2] += in.jobs[j].take;
+    const bool bothReads = nCands[0] && nCands[1];
+    if (shadows[0] + nCands[1] > k.cap || shadows[1] + nCands[0] > k.cap || shadows[0] + shadows[1] > k.cap) return SUMS_TOO_LARGE;
+    // sumUniqueShadowProbabilities of either side: the shadows its orphans rescued + the seeded candidates of the other read
+    for (u32 side = 0; side < 2; ++side)
+    {
+        u32 base = 0;
+        for (u32 j = 0; j < in.nJobs; ++j)
+        {
+            const RescueJob &job = in.jobs[j];
+            if ((job.shadowReadIndex + 1u) % 2 != side || !job.take) continue;
+            forEachShadow(job, in, g, [&](u32 r, const Cand &c, bool) { sumKeyFromCand(k, base + r, c); });
+            base += job.take;
+        }
+        for (u32 i = g.lane; i < nCands[1 - side]; i += g.lanes) sumKeyFromCand(k, base + i, f.cands[1 - side][i]);
+        groupSync(g);
+        if (!uniqueSortedSum(k, base + nCands[1 - side], false, g, scratch, out.shadow[side])) return SUMS_RESIDUAL;
+    }
+    if (bothReads)
+    {   // sumUniquePairProbabilities: every orphan with every shadow it rescued, read 1's alignment first
+        u32 base = 0;
+        for (u32 j = 0; j < in.nJobs; ++j)
+        {
+            const RescueJob &job = in.jobs[j];
+            if (!job.take) continue;
+            const u32 side = (job.shadowReadIndex + 1u) % 2;
+            const ShadowProb o = makeShadowProb(f.cands[side][job.orphanListIndex]);
+            forEachShadow(job, in, g, [&](u32 r, const Cand &c, bool)
+            {
+                const ShadowProb s = makeShadowProb(c);
+                const ShadowProb &r1 = side ? s : o, &r2 = side ? o : s;
+                const u32 at = base + r;
+                k.pos1[at] = r1.pos; k.pos2[at] = r2.pos; k.lp[at] = r1.logProbability + r2.logProbability; k.obs1[at] = u32(r1.observedLength); k.obs2[at] = u32(r2.observedLength);
+            });
+            base += job.take;
+        }
+        groupSync(g);
+        if (!uniqueSortedSum(k, base, true, g, scratch, out.pair)) return SUMS_RESIDUAL;
+    }
+    else
+    {   // TemplateBuilder::rescueShadow's running sum over the shadow lists in list order: the best shadow of a successful rescue
+        // has changed places with the first one
+        u32 base = 0;
+        for (u32 j = 0; j < in.nJobs; ++j)
+        {
+            const RescueJob &job = in.jobs[j];
+            if (!job.take) continue;
+            const u32 side = (job.shadowReadIndex + 1u) % 2;
+            const double orphanLp = f.cands[side][job.orphanListIndex].logProbability;
+            const u32 best = job.rescued ? job.finalBestRank : 0;
+            forEachShadow(job, in, g, [&](u32 r, const Cand &c, bool) { k.term[base + (r == best ? 0 : 0 == r ? best : r)] = exp(orphanLp + c.logProbability); });
+            base += job.take;
+        }
+        groupSync(g);
+        double sum = 0.0;
+        for (u32 i = 0; i < base; ++i) sum += k.term[i];
+        out.ordered = sum;
+        groupSync(g);
+    }
+    return SUMS_DONE;
+}
+
+} // namespace isaac

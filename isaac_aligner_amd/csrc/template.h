@@ -86,10 +86,14 @@ ISAAC_HD i64 tlsMateMaxPosition(const DevTls &t, u32 readIndex, bool reverse, i6
 // Work-list capacities are runtime values: the main pass runs with small per-thread lists (LIGHT); the rare clusters that
 // overflow them are redone by a second launch with the reference's own limits (HEAVY: 10000 candidate positions and 1000
 // tracked shadows, ShadowAligner.hh:91 / TemplateBuilder.hh:149).
-struct TemplateCaps { u32 shadow, shadowCigar, pos, prob, pair, best, templateCigar; };
-ISAAC_HD TemplateCaps lightCaps() { TemplateCaps c; c.shadow = 48; c.shadowCigar = 512; c.pos = 384; c.prob = 256; c.pair = 256; c.best = 12; c.templateCigar = 768; return c; }
-ISAAC_HD TemplateCaps heavyCaps() { TemplateCaps c; c.shadow = 1000; c.shadowCigar = 16384; c.pos = 10000; c.prob = 32768; c.pair = 32768; c.best = 1000; c.templateCigar = 65536; return c; }
+struct TemplateCaps { u32 shadow, shadowCigar, pos, prob, pair, best, templateCigar, kmerTable, tflags; };   // kmerTable / tflags: only the serial rescue needs them
 static const u32 KMER_TABLE = 1024;
+ISAAC_HD TemplateCaps lightCaps() { TemplateCaps c; c.shadow = 48; c.shadowCigar = 512; c.pos = 384; c.prob = 256; c.pair = 256; c.best = 12; c.templateCigar = 768; c.kmerTable = KMER_TABLE; c.tflags = 3 * 512; return c; }
+// the main pass (k_select, k_plan_rescue): rescue results and probability sums arrive precomputed (RESCUE_PRECOMPUTED), so a thread
+// keeps only the tie lists of the best pairs, the clones of the best rescued shadows and the template's CIGAR buffer -- in
+// private memory.  What does not fit goes to the wave-per-cluster pass with the reference's own limits.
+ISAAC_HD TemplateCaps tinyCaps() { TemplateCaps c; c.shadow = 0; c.shadowCigar = 0; c.pos = 0; c.prob = 0; c.pair = 0; c.best = 4; c.templateCigar = 96; c.kmerTable = 0; c.tflags = 0; return c; }
+ISAAC_HD TemplateCaps heavyCaps() { TemplateCaps c; c.shadow = 1000; c.shadowCigar = 16384; c.pos = 10000; c.prob = 32768; c.pair = 32768; c.best = 1000; c.templateCigar = 65536; c.kmerTable = KMER_TABLE; c.tflags = 3 * 512; return c; }
 static const u32 TRACKED_REPEATS_MAX_ONE_READ = 1000;
 static const u32 SKIP_ORPHAN_EDIT_DISTANCE = 3, DODGY_BUT_CLEAN_ALIGNMENT_SCORE = 10;
 
@@ -176,9 +180,9 @@ ISAAC_HD u64 alignUp(u64 v) { return (v + 15) & ~u64(15); }
 ISAAC_HD u64 templateWorkBytes(const TemplateCaps &c)
 {
     const u64 sortN = imax(imax(c.pos, c.prob), c.pair);
-    return alignUp(u64(c.shadow) * sizeof(Cand)) + alignUp(u64(c.shadowCigar) * 4) + alignUp(u64(c.pos) * 8) + alignUp(u64(KMER_TABLE) * 4) +
+    return alignUp(u64(c.shadow) * sizeof(Cand)) + alignUp(u64(c.shadowCigar) * 4) + alignUp(u64(c.pos) * 8) + alignUp(u64(c.kmerTable) * 4) +
            2 * alignUp(u64(c.prob) * sizeof(ShadowProb)) + alignUp(u64(c.pair) * sizeof(PairProb)) + alignUp(sortN * 2) + alignUp(sortN * 8) + 2 * alignUp(u64(c.best) * sizeof(Cand)) +
-           alignUp(u64(c.templateCigar) * 4) + alignUp(u64(3 * 512) * 4) + 4 * alignUp(u64(c.best));
+           alignUp(u64(c.templateCigar) * 4) + alignUp(u64(c.tflags) * 4) + 4 * alignUp(u64(c.best));
 }
 // binds the pointers of `w` into the arena at `base` (16-byte aligned, templateWorkBytes(caps) long); the k-mer table must be
 // zero at first use (generation 0)
@@ -190,14 +194,14 @@ ISAAC_HD void templateWorkBind(TemplateWork &w, void *base, const TemplateCaps &
     w.shadowList = reinterpret_cast<Cand *>(p); p += alignUp(u64(c.shadow) * sizeof(Cand));
     w.shadowCigar = reinterpret_cast<u32 *>(p); p += alignUp(u64(c.shadowCigar) * 4);
     w.candidatePositions = reinterpret_cast<i64 *>(p); p += alignUp(u64(c.pos) * 8);
-    w.kmerTable = reinterpret_cast<u32 *>(p); p += alignUp(u64(KMER_TABLE) * 4);
+    w.kmerTable = reinterpret_cast<u32 *>(p); p += alignUp(u64(c.kmerTable) * 4);
     for (u32 i = 0; i < 2; ++i) { w.shadowProbs[i] = reinterpret_cast<ShadowProb *>(p); p += alignUp(u64(c.prob) * sizeof(ShadowProb)); }
     w.pairProbs = reinterpret_cast<PairProb *>(p); p += alignUp(u64(c.pair) * sizeof(PairProb));
     w.sortIdx = reinterpret_cast<u16 *>(p); p += alignUp(sortN * 2);
     w.terms = reinterpret_cast<double *>(p); p += alignUp(sortN * 8);
     for (u32 i = 0; i < 2; ++i) { w.bestOrphanShadows[i] = reinterpret_cast<Cand *>(p); p += alignUp(u64(c.best) * sizeof(Cand)); }
     w.templateCigar = reinterpret_cast<u32 *>(p); p += alignUp(u64(c.templateCigar) * 4);
-    w.tflags = reinterpret_cast<u32 *>(p); p += alignUp(u64(3 * 512) * 4);
+    w.tflags = reinterpret_cast<u32 *>(p); p += alignUp(u64(c.tflags) * 4);
     for (u32 i = 0; i < 2; ++i) { w.bestCombination.frags[i] = p; p += alignUp(u64(c.best)); }
     for (u32 i = 0; i < 2; ++i) { w.bestRescued.frags[i] = p; p += alignUp(u64(c.best)); }
     w.bestCombination.cap = c.best; w.bestRescued.cap = c.best;
@@ -224,11 +228,23 @@ struct RescueJob
     u8 shadowReadIndex, shadowReverse, valid, fallback;   // fallback: redo this job serially (capacity exceeded)
     u32 gappedBase, nGapped; // the job's gapped retries in the chunk's GappedResult array; gappedBase 0xffffffff: run them serially
     u32 nAligned, bestRank, bestSlot, lastAligned;   // summarizeRescueJob: aligned candidates, the best of them, "the last candidate aligned"
+    // finishRescueFlat (k_cluster_sums): what ShadowAligner::rescueShadow leaves behind, without the list itself
+    u32 take;               // shadows in the list (min(nAligned, 1000))
+    u32 finalBestRank;      // rank of the best shadow after the gapped retries (it is swapped to the front of the list)
+    u32 finalBestSlot;      // its candidate slot
+    u32 finalBestGapped;    // index of the retry that produced it in the chunk's GappedResult array, 0xffffffff: its ungapped alignment stands
+    u8 orphanListIndex;     // the orphan is candidate orphanListIndex of read 1 - shadowReadIndex
+    u8 rescued;             // rescueShadow's return value
+    u8 pad8[2];
     u32 pad;
 };
-static_assert(sizeof(RescueJob) == 72, "RescueJob layout");
+static_assert(sizeof(RescueJob) == 96, "RescueJob layout");
 static const u32 SHADOW_LIST_MAX = 1000;          // ShadowAligner.hh: shadowList_ capacity, TemplateBuilder.hh:TRACKED_REPEATS_MAX_ONE_READ
-enum { RESCUE_SERIAL = 0, RESCUE_PLAN = 1, RESCUE_LOOKUP = 2 };
+enum { RESCUE_SERIAL = 0, RESCUE_PLAN = 1, RESCUE_LOOKUP = 2, RESCUE_PRECOMPUTED = 3 };
+// Per cluster, from k_cluster_sums: sumUniqueShadowProbabilities of either side (the shadows rescued by the orphans of read `side`
+// plus the seeded candidates of the other read), sumUniquePairProbabilities, and the running sum of TemplateBuilder::rescueShadow
+// (TemplateBuilder.cpp:552-560: exp(orphan + shadow) over every shadow of every orphan, in list order).
+struct ClusterSums { double shadow[2]; double pair; double ordered; };
 static const u32 SHADOW_POSITIONS_MAX = 10000;   // ShadowAligner.hh:91
 
 struct TemplateCtx
@@ -238,6 +254,10 @@ struct TemplateCtx
     const i32 *candPositions; const Cand *shadowCands; const u32 *shadowCigars;   // RESCUE_LOOKUP inputs
     const GappedResult *gappedResults; const GappedJob *gappedJobs;               // RESCUE_LOOKUP: the chunk's gapped retries, or NULL
     const u32 *candRank;                                                          // RESCUE_LOOKUP: aligned candidates before each slot (summarizeRescueJob)
+    const ClusterSums *sums;                                                      // RESCUE_PRECOMPUTED
+    // the best shadow of the last successful shadowRescue and the buffer its CIGAR lives in (shadowList[0] / shadowCigar in the
+    // list-building modes, a private copy / the flat pass's arrays in RESCUE_PRECOMPUTED)
+    const Cand *bestRescued; const u32 *bestRescuedPool; Cand bestRescuedCopy;
     ReadView reads[2];
     const ClusterFragments *frags;
     const Cand *cands[2]; u32 nCands[2];      // the cluster's candidate lists: frags->cands, or a private copy of short lists (templateCtxInit)
@@ -432,7 +452,9 @@ ISAAC_HD void calculateShadowRescueRange(const TemplateCtx &x, const Cand &orpha
 ISAAC_HD bool planRescue(const TemplateCtx &x, const Cand &orphan, i64 bestTemplateLength, RescueJob &job)
 {
     job.windowBegin = 0; job.windowLen = 0; job.cluster = x.clusterId; job.contigId = orphan.contigId; job.candBase = 0; job.nCands = 0; job.pushes = 0;
-    job.bitmapBase = 0; job.bitmapWords = 0; job.valid = 0; job.fallback = 0; job.gappedBase = 0xffffffffu; job.nGapped = 0; job.nAligned = 0; job.bestRank = 0; job.bestSlot = 0; job.lastAligned = 0; job.pad = 0;
+    job.bitmapBase = 0; job.bitmapWords = 0; job.valid = 0; job.fallback = 0; job.gappedBase = 0xffffffffu; job.nGapped = 0; job.nAligned = 0; job.bestRank = 0; job.bestSlot = 0; job.lastAligned = 0;
+    job.take = 0; job.finalBestRank = 0; job.finalBestSlot = 0; job.finalBestGapped = 0xffffffffu; job.rescued = 0; job.pad8[0] = job.pad8[1] = 0; job.pad = 0;
+    job.orphanListIndex = u8(&orphan - x.cands[orphan.readIndex]);
     job.shadowReadIndex = u8((orphan.readIndex + 1) % 2);
     job.shadowReverse = 0;
     if (!tlsIsCoherent(*x.tls)) return false;
@@ -673,11 +695,13 @@ ISAAC_HD u32 planRescueGapped(const RescueJob &job, const Cand *shadowCands, con
     return n;
 }
 
-// ShadowAligner::rescueShadow (ShadowAligner.cpp:155-291).  Fills w.shadowList (best first when true is returned).
+// ShadowAligner::rescueShadow (ShadowAligner.cpp:155-291).  Fills w.shadowList (best first when true is returned); in
+// RESCUE_PRECOMPUTED there is no list: the flat pass left the outcome in the job.  x.bestRescued / x.bestRescuedPool: the best shadow.
 ISAAC_HD bool shadowRescue(TemplateCtx &x, const Cand &orphan, i64 bestTemplateLength)
 {
     TemplateWork &w = *x.w;
     w.nShadows = 0;
+    x.bestRescued = w.shadowList; x.bestRescuedPool = w.shadowCigar;
     if (RESCUE_PLAN == x.rescueMode)
     {   // only the sequence of rescue problems is wanted: it does not depend on their results
         RescueJob job;
@@ -685,6 +709,20 @@ ISAAC_HD bool shadowRescue(TemplateCtx &x, const Cand &orphan, i64 bestTemplateL
         if (x.planWrite) x.jobs[x.jobNext] = job;
         ++x.jobNext;
         return false;
+    }
+    if (RESCUE_PRECOMPUTED == x.rescueMode)
+    {
+        const RescueJob &job = x.jobs[x.jobNext++];
+        if (!job.valid || !job.rescued) return false;
+        if (0xffffffffu != job.finalBestGapped)
+        {
+            const GappedResult &g = x.gappedResults[job.finalBestGapped];
+            x.bestRescuedCopy = g.out; x.bestRescuedCopy.cigarLength = u16(g.nCigar); x.bestRescuedPool = g.cigar;
+        }
+        else { x.bestRescuedCopy = x.shadowCands[job.finalBestSlot]; x.bestRescuedPool = x.shadowCigars + u64(job.finalBestSlot) * 3; }
+        x.bestRescuedCopy.cigarOffset = 0;
+        x.bestRescued = &x.bestRescuedCopy;
+        return true;
     }
     if (RESCUE_LOOKUP == x.rescueMode)
     {
@@ -923,6 +961,7 @@ ISAAC_HD PairKey pairKey(const PairProb *v, u32 i, u32 n)
 }
 ISAAC_HD double sumUniqueShadowProbabilities(TemplateCtx &x, u32 side)
 {
+    if (RESCUE_PRECOMPUTED == x.rescueMode) return x.sums->shadow[side];
     TemplateWork &w = *x.w;
     const u32 n = w.nShadowProbs[side]; const ShadowProb *v = w.shadowProbs[side];
     if (n <= SMALL_SUM_MAX)
@@ -985,6 +1024,7 @@ ISAAC_HD double sumUniqueShadowProbabilities(TemplateCtx &x, u32 side)
 }
 ISAAC_HD double sumUniquePairProbabilities(TemplateCtx &x)
 {
+    if (RESCUE_PRECOMPUTED == x.rescueMode) return x.sums->pair;
     TemplateWork &w = *x.w;
     const u32 n = w.nPairProbs; const PairProb *v = w.pairProbs;
     if (n <= SMALL_SUM_MAX)
@@ -1054,10 +1094,10 @@ ISAAC_HD bool templateRescueShadow(TemplateCtx &x, BamTemplate &t, double logMis
         if (lpLess(orphan.logProbability + 100.0, orphans[bestOrphanIt].logProbability)) { }
         else if (shadowRescue(x, orphan, 0))
         {
-            const Cand &bestRescued = w.shadowList[0];
+            const Cand &bestRescued = *x.bestRescued;
             const double currentTemplateLogProbability = orphan.logProbability + bestRescued.logProbability;
             const u64 templateScore = u64(orphan.smithWatermanScore + bestRescued.smithWatermanScore);
-            if (!isVeryBadAlignment(bestRescued, w.shadowCigar, logMismatchQ40))
+            if (!isVeryBadAlignment(bestRescued, x.bestRescuedPool, logMismatchQ40))
             {
                 if (0 == bestPair.resolvedTemplateCount || templateScore < bestPair.bestTemplateScore ||
                     (templateScore == bestPair.bestTemplateScore && lpLess(bestPair.bestTemplateLogProbability, currentTemplateLogProbability)))
@@ -1065,17 +1105,18 @@ ISAAC_HD bool templateRescueShadow(TemplateCtx &x, BamTemplate &t, double logMis
                     bestPair.bestTemplateLogProbability = currentTemplateLogProbability; bestPair.bestTemplateScore = templateScore;
                     bestPair.n[orphanIndex] = 0; bestPair.push(orphanIndex, oi);
                     w.nBestOrphanShadows[orphanIndex] = 0;
-                    w.bestOrphanShadows[orphanIndex][w.nBestOrphanShadows[orphanIndex]++] = cloneWithCigar(w, bestRescued, w.shadowCigar);
+                    w.bestOrphanShadows[orphanIndex][w.nBestOrphanShadows[orphanIndex]++] = cloneWithCigar(w, bestRescued, x.bestRescuedPool);
                 }
                 else if (templateScore == bestPair.bestTemplateScore && lpEquals(currentTemplateLogProbability, bestPair.bestTemplateLogProbability))
                 {
                     bestPair.push(orphanIndex, oi);
-                    if (w.nBestOrphanShadows[orphanIndex] < w.caps.best) w.bestOrphanShadows[orphanIndex][w.nBestOrphanShadows[orphanIndex]++] = cloneWithCigar(w, bestRescued, w.shadowCigar);
+                    if (w.nBestOrphanShadows[orphanIndex] < w.caps.best) w.bestOrphanShadows[orphanIndex][w.nBestOrphanShadows[orphanIndex]++] = cloneWithCigar(w, bestRescued, x.bestRescuedPool);
                     else w.overflow = 1;
                 }
                 ++bestPair.resolvedTemplateCount;
             }
         }
+        if (RESCUE_PRECOMPUTED != x.rescueMode)
         {
             const u32 probBase = w.nShadowProbs[orphanIndex], probRoom = w.caps.prob - probBase;
             for (u32 s = x.lane; s < w.nShadows; s += x.lanes) if (s < probRoom) w.shadowProbs[orphanIndex][probBase + s] = makeShadowProb(w.shadowList[s]);
@@ -1086,6 +1127,8 @@ ISAAC_HD bool templateRescueShadow(TemplateCtx &x, BamTemplate &t, double logMis
             for (u32 s = 0; s < w.nShadows; ++s) bestPair.totalTemplateProbability += exp(orphan.logProbability + w.shadowList[s].logProbability);
         }
     }
+    if (RESCUE_PRECOMPUTED == x.rescueMode) bestPair.totalTemplateProbability = x.sums->ordered;      // the loop's running sum, made by k_cluster_sums
+    if (bestPair.overflow) w.overflow = 1;
     const double totalShadowProbability = (0 < bestPair.resolvedTemplateCount) ? sumUniqueShadowProbabilities(x, orphanIndex) : 0.0;
     bool ret = true;
     Frag &orphanF = t.f[orphanIndex]; Frag &shadowF = t.f[shadowIndex];
@@ -1237,10 +1280,10 @@ ISAAC_HD bool buildDisjoinedTemplate(TemplateCtx &x, BamTemplate &t, const BestP
             STAMP(39);
             if (rescued)
             {
-                const Cand &bestRescued = w.shadowList[0];
+                const Cand &bestRescued = *x.bestRescued;
                 const double currentTemplateLogProbability = orphan.logProbability + bestRescued.logProbability;
                 const u32 rescuedEditDistance = u32(orphan.editDistance) + u32(bestRescued.editDistance);
-                if (isVeryBadAlignment(bestRescued, w.shadowCigar, logMismatchQ40)) { }
+                if (isVeryBadAlignment(bestRescued, x.bestRescuedPool, logMismatchQ40)) { }
                 else if (!knownBestPair.resolvedTemplateCount || (knownBestPair.bestPairEditDistance + SKIP_ORPHAN_EDIT_DISTANCE) >= rescuedEditDistance)
                 {
                     const u64 templateScore = u64(orphan.smithWatermanScore + bestRescued.smithWatermanScore);
@@ -1250,19 +1293,20 @@ ISAAC_HD bool buildDisjoinedTemplate(TemplateCtx &x, BamTemplate &t, const BestP
                         bestOrphans.bestTemplateLogProbability = currentTemplateLogProbability; bestOrphans.bestTemplateScore = templateScore;
                         bestOrphans.n[orphanIndex] = 0; bestOrphans.push(orphanIndex, oi);
                         w.nBestOrphanShadows[orphanIndex] = 0;
-                        w.bestOrphanShadows[orphanIndex][w.nBestOrphanShadows[orphanIndex]++] = cloneWithCigar(w, bestRescued, w.shadowCigar);
+                        w.bestOrphanShadows[orphanIndex][w.nBestOrphanShadows[orphanIndex]++] = cloneWithCigar(w, bestRescued, x.bestRescuedPool);
                         bestOrphanIndex = orphanIndex;
                     }
                     else if (templateScore == bestOrphans.bestTemplateScore && lpEquals(currentTemplateLogProbability, bestOrphans.bestTemplateLogProbability))
                     {
                         bestOrphans.push(orphanIndex, oi);
-                        if (w.nBestOrphanShadows[orphanIndex] < w.caps.best) w.bestOrphanShadows[orphanIndex][w.nBestOrphanShadows[orphanIndex]++] = cloneWithCigar(w, bestRescued, w.shadowCigar);
+                        if (w.nBestOrphanShadows[orphanIndex] < w.caps.best) w.bestOrphanShadows[orphanIndex][w.nBestOrphanShadows[orphanIndex]++] = cloneWithCigar(w, bestRescued, x.bestRescuedPool);
                         else w.overflow = 1;
                     }
                     ++bestOrphans.resolvedTemplateCount;
                 }
             }
             ISAAC_PROF_T0(x);
+            if (RESCUE_PRECOMPUTED != x.rescueMode)
             {   // every shadow contributes one pair and one shadow probability entry; the entries are independent of each other
                 const u32 pairBase = w.nPairProbs, pairRoom = w.caps.pair - pairBase;
                 const u32 probBase = w.nShadowProbs[orphanIndex], probRoom = w.caps.prob - probBase;
@@ -1289,9 +1333,9 @@ ISAAC_HD bool buildDisjoinedTemplate(TemplateCtx &x, BamTemplate &t, const BestP
     STAMP_BEGIN();
     if (0 < bestOrphans.resolvedTemplateCount)
     {
-        for (u32 i = 0; i < x.nCands[bestShadowIndex]; ++i) pushShadowProb(w, bestOrphanIndex, x.cands[bestShadowIndex][i]);
+        if (RESCUE_PRECOMPUTED != x.rescueMode) for (u32 i = 0; i < x.nCands[bestShadowIndex]; ++i) pushShadowProb(w, bestOrphanIndex, x.cands[bestShadowIndex][i]);
         totalShadowProbability = sumUniqueShadowProbabilities(x, bestOrphanIndex);
-        for (u32 i = 0; i < x.nCands[bestOrphanIndex]; ++i) pushShadowProb(w, bestShadowIndex, x.cands[bestOrphanIndex][i]);
+        if (RESCUE_PRECOMPUTED != x.rescueMode) for (u32 i = 0; i < x.nCands[bestOrphanIndex]; ++i) pushShadowProb(w, bestShadowIndex, x.cands[bestOrphanIndex][i]);
         totalOrphanProbability = sumUniqueShadowProbabilities(x, bestShadowIndex);
         bestOrphans.totalTemplateProbability += sumUniquePairProbabilities(x);
     }

@@ -4,6 +4,7 @@
 // gfx950 kernels are made of with g++ and runs the per-cluster functions in a plain loop, so that their logic can be checked
 // against the oracle before a GPU box is spent on them.  It is not part of the product library and the product has no CPU path.
 #include "../../isaac_aligner_amd/csrc/cluster_ops.h"
+#include "../../isaac_aligner_amd/csrc/sums.h"
 #include "../../isaac_aligner_amd/csrc/host_util.h"
 #include <string>
 #include <vector>
@@ -23,7 +24,7 @@ struct Emu
     std::vector<double> logMatch, logMismatch;
     std::vector<ClusterFragments> frags;
     std::vector<Match> matches; std::vector<u64> matchOffsets;
-    Counters cnt; bool flatRescue = true; double *clusterTimes = nullptr; bool fastSort = true; std::vector<u32> dbgJobBase; std::vector<RescueJob> dbgJobs;
+    Counters cnt; bool flatRescue = true; double *clusterTimes = nullptr; bool fastSort = true; u32 sumsCap = 0; std::vector<u32> dbgJobBase; std::vector<RescueJob> dbgJobs;
 };
 }
 
@@ -212,20 +213,37 @@ int emu_select(Emu *e, const u8 *bcl, u32 nClusters, u32 tile, const isaac_tls *
         for (size_t j = 0; j < gj.size(); ++j) runGappedJobSerial(e->P, e->R, bcl + u64(gj[j].cluster) * e->P.clusterLength, gj[j], tflags.data(), gapped[j]);
     }
     e->dbgJobBase = jobBase; e->dbgJobs = jobs;
-    // k_select (light capacities), then the flagged clusters with the reference's own capacities
-    for (int tier = 0; tier < 2; ++tier)
-        for (u32 c = 0; c < nClusters; ++c)
+    // k_cluster_sums, then k_select on the precomputed results (private-memory work area); what either of them cannot do goes to
+    // the wave-per-cluster pass with the reference's own capacities
+    std::vector<u8> keyBytes(sumKeysBytes(1024) + 16);
+    SumKeys keys; sumKeysBind(keys, keyBytes.data(), e->sumsCap ? e->sumsCap : 1024);
+    std::vector<u8> tinyArena(templateWorkBytes(tinyCaps()) + 16, 0);
+    TemplateWork tiny; templateWorkBind(tiny, reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(tinyArena.data()) + 15) & ~uintptr_t(15)), tinyCaps());
+    for (u32 c = 0; c < nClusters; ++c)
+    {
+        RescueInputs in; in.jobs = jobs.data() + jobBase[c]; in.jobCount = jobBase[c + 1] - jobBase[c]; in.shadowCands = shadowCands.data(); in.shadowCigars = shadowCigars.data();
+        in.gappedResults = gapped.data(); in.gappedJobs = gj.data(); in.candRank = candRank.data(); in.sums = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        SumInputs si; si.jobs = in.jobs; si.nJobs = in.jobCount; si.shadowCands = shadowCands.data(); si.candRank = candRank.data(); si.gappedResults = gapped.data(); si.gappedJobs = gj.data();
+        SumGroup g; g.lanes = 1; g.lane = 0; g.block = false;
+        ClusterSums sums; u32 scratch = 0;
+        bool residual = SUMS_DONE != clusterSums(e->P, e->frags[c], si, keys, g, &scratch, true, sums, e->cnt);
+        CoopInputs coop; coop.lanes = 1; coop.lane = 0; coop.fastSort = false; coop.ldsSort = 0; coop.ldsSortCap = 0;
+        if (!residual)
         {
-            if (tier && !(recs[u64(c) * e->P.nReads].reserved & RECORD_TEMPLATE_OVERFLOW)) continue;
-            RescueInputs in; in.jobs = jobs.data() + jobBase[c]; in.jobCount = jobBase[c + 1] - jobBase[c]; in.shadowCands = shadowCands.data(); in.shadowCigars = shadowCigars.data();
-            in.gappedResults = gapped.data(); in.gappedJobs = gj.data(); in.candRank = candRank.data();
-            const auto t0 = std::chrono::steady_clock::now();
-            in.serialFallbackAllowed = tier != 0;
-            CoopInputs coop; coop.lanes = 1; coop.lane = 0; coop.fastSort = e->fastSort && tier; coop.ldsSort = 0; coop.ldsSortCap = 0;
-            clusterSelect(e->P, e->R, t, rog, lmq40, bcl, c, tile, e->frags[c], tier ? heavy : light, recs, cigars, e->cnt, &in, &coop);
-            if (e->clusterTimes) e->clusterTimes[c] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            if (!tier) ++e->cnt.clusters;
+            in.sums = &sums; in.serialFallbackAllowed = false;
+            clusterSelect(e->P, e->R, t, rog, lmq40, bcl, c, tile, e->frags[c], tiny, recs, cigars, e->cnt, &in, &coop);
+            residual = 0 != (recs[u64(c) * e->P.nReads].reserved & RECORD_TEMPLATE_OVERFLOW);
         }
+        if (residual)
+        {
+            in.sums = 0; in.serialFallbackAllowed = true; coop.fastSort = e->fastSort;
+            clusterSelect(e->P, e->R, t, rog, lmq40, bcl, c, tile, e->frags[c], heavy, recs, cigars, e->cnt, &in, &coop);
+            ++e->cnt.heavyClusters;
+        }
+        if (e->clusterTimes) e->clusterTimes[c] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        ++e->cnt.clusters;
+    }
     return 0;
 }
 
@@ -269,6 +287,7 @@ int emu_select_literal(Emu *e, const u8 *bcl, const LiteralFragment *f0, u32 n0,
 
 void emu_set_flat_rescue(Emu *e, int on) { e->flatRescue = on != 0; }
 void emu_set_fast_sort(Emu *e, int on) { e->fastSort = on != 0; }
+void emu_set_sums_capacity(Emu *e, uint32_t cap) { e->sumsCap = cap > 1024 ? 1024 : cap; }   // entries of the probability-sum key arrays (k_cluster_sums tiers)
 void emu_set_cluster_times(Emu *e, double *t) { e->clusterTimes = t; }
 // debugging: out = { jobs, valid jobs, total candidates, max candidates, gapped retries, fallback jobs, total window bases }
 void emu_cluster_job_stats(Emu *e, u32 c, u64 *out)

@@ -144,3 +144,31 @@ def test_fragment_code_reproduces_reference_known_answers(oracle, emulib):
             emu.set_matches(matches, len(bcl))
             cands, cigars = emu.build_fragments(bcl, len(bcl), with_gaps=case["with_gaps"], trim=False)
             check_fragment_builder_case(case, cands, cigars)
+
+
+@pytest.mark.parametrize("sums_cap", [1024, 24])
+def test_repeat_rich_reference_through_the_precomputed_sums(oracle, emulib, sums_cap):
+    """a small human-like reference (Alu / L1-like families, satellites, segmental duplications): clusters with dozens of seeded
+    candidates and hundreds of rescued shadows go through the probability-sum stage (sums.h); with a small key capacity most of
+    them take the wave-per-cluster route instead, and the records must not depend on the route"""
+    from isaac_aligner_amd import synth
+    g = synth.make_human_like_genome(1_500_000, seed=11)
+    contigs = [bytes(c.numpy()) for c in g.contigs]
+    bcl = synth.make_read_pairs(g, 1500, 150, seed=12, avoid_gaps=True)[0].numpy()
+    n = len(bcl)
+    p = options.default_params(150, 150)
+    ref = oracle.reference(contigs)
+    ref.build_index()
+    matches, hits = ref.find_matches(p, bcl, n)
+    emu = hostemu_lib.Emu(emulib, p, contigs, hits)
+    emu.set_matches(matches, n)
+    emulib.emu_set_sums_capacity(emu.h, C.c_uint32(sums_cap))
+    otls = ref.determine_tls(p, bcl, matches, hits)
+    etls = emu.determine_tls(bcl, n)
+    assert otls.astuple() == etls.astuple()
+    orec, ocig, _ = ref.select(p, bcl, matches, otls, hits, n_clusters_hint=n)
+    erec, ecig = emu.select(bcl, n, etls)
+    assert not (erec["reserved"] & 5).any()
+    assert not compare_records(orec, ocig, erec, ecig)
+    heavy = emu.counters()["heavy_clusters"]
+    assert (heavy > 20) if sums_cap < 100 else (heavy < 20), heavy
