@@ -206,7 +206,7 @@ def main():
     hbm_used_gb = round((total_b - free_b) / 1e9, 1)      # everything resident at the end of the run: index, reads, records, chunk scratch
     counters = al.counters()
     timer_names = ("find_matches", "compact_matches", "build_fragments", "align_candidates", "finish_candidates", "indel_fragments", "gapped_fragments", "finish_fragments",
-                   "plan_rescue", "rescue_windows", "rescue_align", "rescue_gapped_plan", "gapped_rescue", "rescue_finish", "probability_sums", "select_order", "select",
+                   "plan_rescue", "rescue_windows", "rescue_align", "rescue_gapped_plan", "gapped_rescue", "sums_wave", "sums_large", "sums_xl", "sums_huge", "select",
                    "select_heavy", "select_residual")
     timers = {k: al.kernel_time_ms(k) for k in timer_names}
     if rank != 0:
@@ -284,8 +284,8 @@ def main():
         # per candidate start: the mate (L BCL bytes) + L reference bytes in, one candidate record + 3 cigar words out
         "rescue_align": c["rescue_candidates"] * (2 * L + 64 + 12),
         "rescue_gapped_plan": c["rescue_candidates"] * 64 + jobs * 72,
-        "rescue_finish": c["rescue_candidates"] * 64 + jobs * 72,
-        "probability_sums": c["rescue_candidates"] * 2 * 24 + c["candidates"] * 24,
+        # per rescued shadow: its candidate record in (twice: its own list and the pair list), 32 B of sums per cluster out
+        "sums_wave": c["rescue_candidates"] * 2 * 64 + jobs * 96 + pairs_rank * 32,
         # seeded + rescued candidate records in, 2 FragmentHeader records + cigars out
         "select": c["candidates"] * 64 + c["rescue_candidates"] * (64 + 12) + 2 * pairs_rank * (64 + 4 * 3),
         "select_heavy": c["heavy_clusters"] * 64 * 1000,

@@ -109,7 +109,8 @@ typedef struct { uint32_t n_ops, offset; uint32_t cigar[ISAAC_GPU_MAX_CIGAR_OPS]
 typedef struct
 {
     uint64_t clusters, probes, probe_steps, matches, candidates, ungapped_scans, bsw_jobs, bsw_accepted, simple_indels,
-             rescue_calls, rescue_window_bases, rescue_candidates, rescue_bsw, overflow_clusters, mapq_near_integer, heavy_clusters;
+             rescue_calls, rescue_window_bases, rescue_candidates, rescue_bsw, overflow_clusters, mapq_near_integer, heavy_clusters,
+             residual_capacity, residual_near_tie, residual_oversize, large_sums;   /* heavy_clusters by cause; clusters whose probability sums took a whole workgroup */
 } isaac_counters;
 
 typedef struct isaac_gpu_ctx isaac_gpu_ctx;
@@ -253,8 +254,8 @@ int isaac_gpu_get_counters(isaac_gpu_ctx *ctx, isaac_counters *out);
 /* average device time (ms) of the named launch sequence over the launches since the last reset, measured with HIP events on the
  * stream it runs on; names: "find_matches", "compact_matches", "build_fragments", "align_candidates", "finish_candidates",
  * "indel_fragments", "gapped_fragments", "finish_fragments", "load_candidates", "plan_rescue", "rescue_windows", "rescue_align",
- * "rescue_gapped_plan", "gapped_rescue", "select_order", "select", "select_heavy" (own stream, overlaps "select"), "select_residual",
- * "fastq_to_bcl", "bsw" */
+ * "rescue_gapped_plan", "gapped_rescue", "sums_wave", "sums_large", "sums_xl", "sums_huge", "select", "select_heavy", "select_residual" (the last two
+ * only when a cluster needed the wave-per-cluster pass), "fastq_to_bcl", "bsw" */
 int isaac_gpu_kernel_time_ms(isaac_gpu_ctx *ctx, const char *kernel, double *avg_ms, uint64_t *launches);
 int isaac_gpu_reset_timers(isaac_gpu_ctx *ctx);
 

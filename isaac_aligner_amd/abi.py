@@ -33,7 +33,8 @@ class Tls(C.Structure):
 class Counters(C.Structure):
     """isaac_counters"""
     _fields_ = [(n, C.c_uint64) for n in ("clusters", "probes", "probe_steps", "matches", "candidates", "ungapped_scans", "bsw_jobs", "bsw_accepted", "simple_indels",
-                                          "rescue_calls", "rescue_window_bases", "rescue_candidates", "rescue_bsw", "overflow_clusters", "mapq_near_integer", "heavy_clusters")]
+                                          "rescue_calls", "rescue_window_bases", "rescue_candidates", "rescue_bsw", "overflow_clusters", "mapq_near_integer", "heavy_clusters",
+                                          "residual_capacity", "residual_near_tie", "residual_oversize", "large_sums")]
 
     def asdict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -1,14 +1,28 @@
-"""Builds libisaac_gpu.so (the only native artefact of the product) with hipcc for gfx950, in-tree."""
+"""Builds libisaac_gpu.so (the only native artefact of the product) with hipcc for gfx950, in-tree: every csrc/*.hip is a
+translation unit of its own (kernel families + the host side), compiled in parallel and linked into one shared library."""
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libisaac_gpu.so")
+# -amdgpu-function-calls=false: everything is inlined into the kernels, so that their occupancy targets
+# (amdgpu_waves_per_eu in kernels.h) bind the whole call tree and not just the kernel body
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-value", "-mllvm", "-amdgpu-function-calls=false", "-I", CSRC]
+
+
+def units():
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+
+
+def headers():
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "isaac_gpu.h")]
 
 
 def sources():
-    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(HERE, "..", "include", "isaac_gpu.h")]
+    return units() + headers()
 
 
 def is_stale():
@@ -18,12 +32,24 @@ def is_stale():
 def build(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
-    # -amdgpu-function-calls=false: everything is inlined into the kernels, so that their occupancy targets
-    # (amdgpu_waves_per_eu in isaac_gpu.hip) bind the whole call tree and not just the kernel body
-    cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wno-unused-value",
-           "-mllvm", "-amdgpu-function-calls=false", "-I", CSRC, "-o", LIB, os.path.join(CSRC, "isaac_gpu.hip")]
+    os.makedirs(OBJ, exist_ok=True)
+    newest_header = max(os.path.getmtime(h) for h in headers())
+
+    def compile_unit(src):
+        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_header):
+            return obj
+        cmd = ["hipcc"] + FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_unit, units()))
+    cmd = ["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + objs
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return LIB
 

@@ -26,9 +26,7 @@ __device__ inline int rowXor1(int v) { return dpp16<0xB1>(v); }          // lane
 template <int N> __device__ inline int rowDown(int v) { return dpp16<0x100 + N>(v); }   // lane k <- lane k + N (row_shl:N)
 
 // LDS bytes per alignment group
-__host__ __device__ inline u32 bswGroupLdsBytes(u32 maxQueryLength) { return ((maxQueryLength * 16 + 15) & ~15u) + 128; }
-// k_gapped_jobs also keeps the query and the database window of the group there (the DP loop then reads LDS, not global memory)
-__host__ __device__ inline u32 gappedGroupLdsBytes(u32 maxQueryLength) { return bswGroupLdsBytes(maxQueryLength) + 2 * ((maxQueryLength + 31) & ~15u); }
+// bswGroupLdsBytes / gappedGroupLdsBytes: kernels.h (the host sizes the launches with them)
 
 // The DP of one alignment on the 16 lanes of a group, then traceback and CIGAR on lane 0.  `cig[n..)` receives the operations
 // (reference order); the return value (lane 0 only) is BandedSmithWaterman::align's: the length of the stripped leading

@@ -20,26 +20,14 @@
 #include <memory>
 #include <string>
 #include <vector>
-#include "cluster_ops.h"
-#include "sums.h"
+#include "kernels.h"
 #include "host_util.h"
-#include "bsw_kernel.h"
 #include "fastq_kernel.h"
 #include "index_kernels.h"
 
 #if defined(ISAAC_KERNEL_STAMPS)
 __device__ unsigned long long g_stamps[64];
 #endif
-
-// occupancy targets (waves per SIMD) of the two thread-per-cluster kernels; the register allocator spills to meet them
-#ifndef ISAAC_SELECT_WAVES
-#define ISAAC_SELECT_WAVES 4
-#endif
-#ifndef ISAAC_FRAGMENT_WAVES
-#define ISAAC_FRAGMENT_WAVES 6
-#endif
-
-using namespace isaac;
 
 namespace
 {
@@ -72,7 +60,6 @@ struct isaac_gpu_ctx
     DevBuf<u32> packedBases, notBase;   // 2-bit copy of the contigs + not-ACGT bitmap (k_rescue_windows reads these)
     DevBuf<u64> matchBase;
     // run constants of the template kernels in device memory: passed by value they end up as private copies (dynamic indexing)
-    struct TemplateConstants { DevParams P; DevTls tls; RogCorrection rog; };
     DevBuf<TemplateConstants> templateConstants;
     // isaac_gpu_fastq_to_bcl scratch, kept between calls (hipMalloc costs more than the conversion)
     DevBuf<u8> fqIsStart; DevBuf<u64> fqLineStart, fqLineEnd; DevBuf<int> fqSelected; DevBuf<u32> fqLineMap, fqMapBefore, fqIsHeader, fqRecordIndex, fqFirstBad; DevBuf<FqRecord> fqRecords;
@@ -81,17 +68,22 @@ struct isaac_gpu_ctx
     DevBuf<Match> staging; DevBuf<u32> counts, chunkOffsets; DevBuf<u8> cubTemp; DevBuf<u32> contigHits;
     DevBuf<ClusterFragments> frags, fragsAlt; ClusterFragments *fragsCur = nullptr; DevBuf<FragmentWork> fragWork;   // fragsAlt: see isaac_gpu_select
     DevBuf<GappedJob> gappedJobs, rescueGappedJobs; DevBuf<GappedResult> gappedResults, rescueGappedResults; DevBuf<u32> gappedBase, gappedCounters;
-    DevBuf<u8> heavyArena; DevBuf<u32> overflowList; DevBuf<u32> overflowCount; DevBuf<ClusterSums> clusterSums; DevBuf<u32> largeList;
+    DevBuf<u8> heavyArena; DevBuf<u32> overflowList; DevBuf<u32> overflowCount; DevBuf<ClusterSums> clusterSums; DevBuf<u32> largeList, xlList, hugeList; DevBuf<u8> hugeKeys;
     DevBuf<TlsSample> tlsSamples; DevBuf<u32> cigarLengths, cigarOffsets;
     DevBuf<RescueJob> jobs; DevBuf<u32> rescueCounters, bitmaps, candJob, shadowCigars, jobBase, jobCount; DevBuf<i32> candPositions; DevBuf<Cand> shadowCands; DevBuf<u32> candRank;
     DevBuf<Counters> counters;
     std::map<std::string, KernelTimer> timers;
     struct PendingTimer { std::string name; hipEvent_t e0, e1; };
     std::vector<PendingTimer> pendingTimers; std::vector<hipEvent_t> eventPool;
-    hipStream_t heavyStream = nullptr; hipEvent_t evPredicted = nullptr, evHeavyDone = nullptr;
-    // a wave-per-cluster pass is still running on heavyStream (it reads the chunk buffers of the chunk it belongs to); with
-    // deferredCompletion the last one of a select call is left running when the call returns (see isaac_gpu_select)
-    bool heavyPending = false, deferredCompletion = false; u32 chunkParity = 0;
+    // The wave-per-cluster pass (k_select_heavy, the reference's own capacities) runs only for the clusters the flat kernels could
+    // not finish, which is rare enough to ask: the two counts come back through pinned memory.  The count of k_cluster_sums is
+    // read while k_select runs; the count of k_select itself when the next chunk (or call) has enqueued its fragment stage, which
+    // is why the chunk's pointers are kept (`pending`).
+    hipEvent_t evSums = nullptr, evSelect = nullptr; u32 *hostCounts = nullptr;
+    struct Pending { bool active = false; const uint8_t *bcl = nullptr; u32 clusterBase = 0, tile = 0; ClusterFragments *frags = nullptr; FragmentRecord *records = nullptr; u32 *cigars = nullptr;
+                     DevTls tls; RogCorrection rog; } pending;
+    bool deferredCompletion = false; u32 chunkParity = 0;
+    u32 selectCapacity = 0;        // chunk size the buffers of the select stage were last sized for
     DevBuf<u32> heavyList, heavyCount, indelList, alignList; DevBuf<u8> heavyFlag;
     u32 chunkClusters = 1048576;   // upper bound of a chunk (ISAAC_GPU_CHUNK_CLUSTERS)
     u32 chunkNow = 0;              // the chunk size in use: the largest call so far, rounded up, at most chunkClusters; sizes the chunk-private buffers
@@ -107,6 +99,9 @@ struct isaac_gpu_ctx
         return r;
     }
 };
+
+// completes the last chunk of a select call: if k_select listed clusters for the wave-per-cluster pass, that pass is launched now
+static void resolvePending(isaac_gpu_ctx *c);
 
 namespace
 {
@@ -137,29 +132,6 @@ static void resolveTimers(isaac_gpu_ctx *c)
     c->pendingTimers.clear();
 }
 
-// the caller's stream waits for a wave-per-cluster pass that may still be running
-static void joinHeavy(isaac_gpu_ctx *c)
-{
-    if (c->heavyPending) { hipStreamWaitEvent(c->stream, c->evHeavyDone, 0); c->heavyPending = false; }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// wave-level reduction of the work counters, one atomic per field per wave.  The totals are kept in COUNTER_SHARDS copies
-// (a block adds to the copy of its index; isaac_gpu_get_counters sums them): atomics on one address execute one after the
-// other in L2, and a grid of small waves can spend longer queueing there than working.  Fields no lane touched cost a vote.
-static const u32 COUNTER_SHARDS = 64;
-__device__ inline void flushCounters(const Counters &local, Counters *global)
-{
-    const u64 *src = reinterpret_cast<const u64 *>(&local);
-    u64 *dst = reinterpret_cast<u64 *>(global + (blockIdx.x & (COUNTER_SHARDS - 1)));
-    for (u32 f = 0; f < sizeof(Counters) / sizeof(u64); ++f)
-    {
-        u64 v = src[f];
-        if (!__any(v != 0)) continue;
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if ((threadIdx.x & 63) == 0 && v) atomicAdd(reinterpret_cast<unsigned long long *>(dst + f), static_cast<unsigned long long>(v));
-    }
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // k_find_matches: ClusterSeedGenerator::generateThread (ClusterSeedGenerator.cpp:138-192) + ExactMaskMatcher::matchMask
@@ -340,144 +312,6 @@ __global__ void k_compact_matches(const Match *staging, const u32 *counts, const
     for (u32 i = 0; i < n; ++i) if (at + i < capacity) out[at + i] = src[i];
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Quality::logMatchLookup / logMismatchLookup staged in LDS: every base of every alignment reads one of the two
-#define ISAAC_STAGE_QUALITY_TABLES(R_IN, R_OUT)                                                                              \
-    __shared__ double qualityTables[128];                                                                                    \
-    for (u32 qi = threadIdx.x; qi < 128; qi += blockDim.x) qualityTables[qi] = qi < 64 ? (R_IN).logMatch[qi] : (R_IN).logMismatch[qi - 64]; \
-    __syncthreads();                                                                                                         \
-    DevReference R_OUT = (R_IN); R_OUT.logMatch = qualityTables; R_OUT.logMismatch = qualityTables + 64;
-
-// the chunk's gapped (banded Smith-Waterman) problems: written by the per-cluster threads, run by k_gapped_jobs
-struct GappedBuffers { GappedJob *jobs; GappedResult *results; u32 cap; u32 *counter; u32 *base; };
-
-__device__ inline void emitGappedJobs(const ClusterFragments &f, u32 cl, bool withGaps, const GappedBuffers &gb)
-{
-    u32 base = 0;
-    const u32 n = countGappedJobs(f, withGaps);
-    if (n)
-    {
-        base = atomicAdd(gb.counter, n);
-        if (base + n > gb.cap) base = 0xffffffffu;   // k_finish_fragments runs this cluster's retries itself
-        else writeGappedJobs(f, cl, gb.jobs + base);
-    }
-    gb.base[cl] = base;
-}
-
-// the chunk's ungapped alignment problems: (cluster << 8) | (read << 7) | index in the read's candidate list
-struct AlignList { u32 *entries; u32 cap; u32 *counter; };
-
-// Fragment stage, step 1: matches -> candidate positions (buildCandidates), and one entry per candidate in the flat list
-// k_align_candidates works through.  The list space of a wave is taken with one atomic.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_build_fragments(DevParams P, const u8 *bcl, u32 clusterBase, u32 nChunk, const Match *matches, const u64 *offsets,
-                                                        int trim, FragmentWork *work, ClusterFragments *frags, AlignList al)
-{
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 cl = 0, n = 0;
-    if (t < nChunk)
-    {
-        cl = t;
-        const u64 begin = offsets[clusterBase + cl], end = offsets[clusterBase + cl + 1];
-        buildCandidates(P, bcl + u64(clusterBase + cl) * P.clusterLength, matches + begin, u32(end - begin), trim != 0, work[t], frags[cl]);
-        n = frags[cl].nCands[0] + frags[cl].nCands[1];
-    }
-    // exclusive prefix of n over the wave, one allocation for all of it
-    u32 incl = n;
-    for (u32 o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o, 64); if ((threadIdx.x & 63) >= o) incl += v; }
-    const u32 total = __shfl(incl, 63, 64);
-    u32 base = 0;
-    if ((threadIdx.x & 63) == 63 && total) base = atomicAdd(al.counter, total);
-    base = __shfl(base, 63, 64);
-    if (n)
-    {
-        u32 at = base + incl - n;
-        if (base + total > al.cap)
-        {   // no room: the cluster aligns its own candidates later; what the wave took of the list is marked unused
-            frags[cl].flags |= CLUSTER_ALIGN_PENDING;
-            for (u32 k = 0; k < n; ++k) if (at + k < al.cap) al.entries[at + k] = 0xffffffffu;
-        }
-        else for (u32 r = 0; r < 2; ++r) for (u32 i = 0; i < frags[cl].nCands[r]; ++i) al.entries[at++] = (cl << 8) | (r << 7) | i;
-    }
-}
-
-// step 2: UngappedAligner::alignUngapped, one candidate per thread
-__global__ __launch_bounds__(256) void k_align_candidates(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, ClusterFragments *frags, AlignList al, Counters *counters)
-{
-    ISAAC_STAGE_QUALITY_TABLES(Rg, R)
-    Counters local; memset(&local, 0, sizeof(local));
-    const u32 n = imin(*al.counter, al.cap);
-    for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
-    {
-        const u32 e = al.entries[j], cl = e >> 8;
-        if (0xffffffffu == e) continue;
-        alignCandidate(P, R, bcl + u64(clusterBase + cl) * P.clusterLength, frags[cl], (e >> 7) & 1, e & 127, local);
-    }
-    flushCounters(local, counters);
-}
-
-// step 3: consolidation and the single-indel stage (finishCandidates), then either the cluster's gapped problems or, for the
-// 3-4 % of clusters with a candidate pair for the single-indel detector, an entry for k_indel_fragments: inside this kernel
-// nearly every wave would hold one such lane and wait for it
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_finish_candidates(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, u32 nChunk,
-                                                        int withGaps, u32 *indelList, u32 *indelCount, FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters)
-{
-    ISAAC_STAGE_QUALITY_TABLES(Rg, R)
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    Counters local; memset(&local, 0, sizeof(local));
-    if (t < nChunk)
-    {
-        const u32 cl = t;
-        ClusterFragments &f = frags[cl];
-        const u8 *clusterBcl = bcl + u64(clusterBase + cl) * P.clusterLength;
-        if (f.flags & CLUSTER_ALIGN_PENDING)
-        {
-            f.flags &= ~u32(CLUSTER_ALIGN_PENDING);
-            for (u32 r = 0; r < P.nReads; ++r) for (u32 i = 0; i < f.nCands[r]; ++i) alignCandidate(P, R, clusterBcl, f, r, i, local);
-        }
-        finishCandidates(P, R, clusterBcl, work[t], f, local, true);
-        if (clusterSimpleIndelsPending(f)) indelList[atomicAdd(indelCount, 1u)] = cl;
-        else emitGappedJobs(f, cl, withGaps != 0, gb);
-    }
-    flushCounters(local, counters);
-}
-
-// The deferred single-indel stage (SimpleIndelAligner) for the clusters k_build_fragments listed, then their gapped problems.
-// One wave per cluster, every lane executing the same statements (as in k_select_heavy): the detector is a chain of dependent
-// byte loads, and 64 different clusters per wave would spread them over more cache lines than the L1 holds.
-__global__ __launch_bounds__(64) void k_indel_fragments(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, int withGaps, const u32 *indelList, const u32 *indelCount,
-                                                        FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters)
-{
-    ISAAC_STAGE_QUALITY_TABLES(Rg, R)
-    __shared__ __align__(16) u8 stageBcl[512];
-    __shared__ __align__(16) char stageWindow[1536];
-    IndelStage stage; stage.bcl = stageBcl; stage.bclCap = sizeof(stageBcl); stage.window = stageWindow; stage.windowCap = sizeof(stageWindow); stage.lane = threadIdx.x;
-    Counters local; memset(&local, 0, sizeof(local));
-    const u32 n = *indelCount;
-    for (u32 t = blockIdx.x; t < n; t += gridDim.x)
-    {
-        const u32 cl = indelList[t];
-        clusterFinishSimpleIndels(P, R, bcl, clusterBase + cl, work[blockIdx.x], frags[cl], local, &stage);
-        __syncthreads();
-        if (0 == threadIdx.x) emitGappedJobs(frags[cl], cl, withGaps != 0, gb);
-    }
-    if (0 != threadIdx.x) memset(&local, 0, sizeof(local));   // every lane counted the same events
-    flushCounters(local, counters);
-}
-
-__global__ __launch_bounds__(64) void k_finish_fragments(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, u32 nChunk, int withGaps,
-                                                         FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters)
-{
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    Counters local; memset(&local, 0, sizeof(local));
-    if (t < nChunk)
-    {
-        const u32 cl = t;
-        const GappedResult *res = (withGaps && gb.base[cl] != 0xffffffffu) ? gb.results + gb.base[cl] : nullptr;
-        clusterFinishFragments(P, R, bcl, clusterBase + cl, withGaps != 0, res, work[t], frags[cl], local);
-    }
-    flushCounters(local, counters);
-}
-
 __global__ void k_tls_samples(const ClusterFragments *frags, const u64 *offsets, u32 clusterBase, u32 nChunk, TlsSample *samples)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -553,454 +387,6 @@ __global__ void k_load_candidates(DevParams P, const u8 *bcl, u32 clusterBase, u
     }
     f.cigarUsed = pool.used;
     if (pool.overflow) f.flags |= CLUSTER_OVERFLOW;
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Template stage.  Mate rescue (ShadowAligner::rescueShadow) is the bulk of the work of the select phase: a 7-mer scan of
-// a window of several hundred reference bases plus one 150-base ungapped alignment per candidate start, for ~1.5 orphans
-// per cluster.  It is planned per cluster, then executed flat:
-//   k_plan_rescue         one thread per cluster: the rescue problems TemplateBuilder would pose (result independent)
-//   k_rescue_windows      one wavefront per problem: the mate's 7-mer table in LDS, the window scanned 64 x RW_PER_LANE positions at a time
-//                         (16 per lane), candidate starts collected in a per-problem bitmap (sorted + unique for free)
-//   k_rescue_align        one thread per candidate start: UngappedAligner::alignUngapped
-//   k_rescue_gapped_plan  one thread per problem: rank of every aligned candidate, the best one, which get a gapped retry
-//   k_gapped_jobs         16 lanes per retry (bsw_kernel.h)
-//   k_predict_heavy       one thread per cluster: which clusters cannot fit the light work lists
-//   k_select              one thread per cluster: consumes the rescue results, pair / orphan selection, alignment scores,
-//                         clippers, FragmentHeader records
-//   k_select_heavy        one wave per predicted cluster, on its own stream next to k_select
-static const u32 KMER_EMPTY = 0xffffffffu;
-static const u32 RW_TABLE = 512;          // hash slots for the mate's <= 250-odd 7-mers
-static const u32 RW_LDS_BITMAP = 64;      // words: windows up to ~1900 bases keep their candidate bitmap in LDS
-#ifndef ISAAC_RW_PER_LANE
-#define ISAAC_RW_PER_LANE 8
-#endif
-static const u32 RW_PER_LANE = ISAAC_RW_PER_LANE;        // consecutive window positions per lane and tile (a multiple of 8)
-static const i32 RW_TILE = 64 * RW_PER_LANE;              // window positions per wave and tile
-static const u32 CAND_REGIONS = 256;
-
-struct RescueBuffers
-{
-    RescueJob *jobs; u32 jobsCap; u32 *jobCounter;
-    u32 *bitmaps; u32 bitmapCap; u32 *bitmapCounter;
-    i32 *candPositions; u32 *candJob; Cand *shadowCands; u32 *shadowCigars; u32 *candRank; u32 candCap; u32 *candCounter;
-    // candidate slots are handed out from CAND_REGIONS equal regions, each with its own counter (candCounter[region]): one
-    // counter for every workgroup of a chunk serialises at ~8 ns per atomic
-    u32 candRegionSize;
-    u32 *jobBase; u32 *jobCount;   // per cluster of the chunk; jobBase == 0xffffffff: the cluster runs its rescues itself
-};
-
-// the main pass's template work area (tinyCaps) lives in private memory
-static const u32 TINY_WORK_BYTES = 1024;
-
-__global__ __launch_bounds__(64) void k_plan_rescue(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk,
-                                                    const ClusterFragments *frags, RescueBuffers rb)
-{
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nChunk) return;
-    __attribute__((aligned(16))) u8 workBytes[TINY_WORK_BYTES];
-    TemplateWork work;
-    templateWorkBind(work, workBytes, tinyCaps());
-    Cand privateCands[2 * PRIVATE_CANDS];
-    // Every seeded candidate is an orphan at most once, so their number bounds the cluster's rescue problems: the slots are
-    // reserved first and the template logic runs once, writing the problems as it meets them (unused slots stay invalid)
-    const u32 reserve = frags[t].built ? frags[t].nCands[0] + frags[t].nCands[1] : 0;
-    u32 base = 0, n = 0;
-    if (reserve)
-    {
-        base = atomicAdd(rb.jobCounter, reserve);
-        if (base + reserve > rb.jobsCap)
-        {   // the cluster runs its rescues itself in the wave-per-cluster pass
-            base = 0xffffffffu;
-            n = clusterPlanRescue(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + t, t, frags[t], work, nullptr, privateCands);
-        }
-        else
-        {
-            RescueJob *jobs = rb.jobs + base;
-            n = clusterPlanRescue(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + t, t, frags[t], work, jobs, privateCands);
-            for (u32 i = n; i < reserve; ++i) { jobs[i].valid = 0; jobs[i].fallback = 0; jobs[i].nCands = 0; jobs[i].nGapped = 0; }
-            for (u32 i = 0; i < n; ++i)
-            {
-                if (!jobs[i].valid) continue;
-                const u32 words = (jobs[i].windowLen + P.readLength[jobs[i].shadowReadIndex] + 31) / 32;
-                if (words <= RW_LDS_BITMAP) continue;               // k_rescue_windows keeps short bitmaps in LDS
-                const u32 at = atomicAdd(rb.bitmapCounter, words);
-                if (at + words > rb.bitmapCap) jobs[i].fallback = 1; else { jobs[i].bitmapBase = at; jobs[i].bitmapWords = words; }
-            }
-        }
-    }
-    rb.jobBase[t] = base; rb.jobCount[t] = n;
-}
-
-
-// The bases of window positions [g, g + RW_PER_LANE + 6) for one lane: their 2-bit codes (position g in the low bits) and their
-// not-ACGT flags, from the packed copy of the reference.  g is an index into the concatenated contigs.
-struct WindowBits { u64 codes; u32 notBase; };
-__device__ inline WindowBits loadWindowBits(const DevReference &R, u64 g)
-{
-    WindowBits w;
-    g = g < R.totalBases ? g : R.totalBases;          // lanes past the end of a window that ends the reference: read the spare words
-    const u32 *pw = R.packedBases + (g >> 4);
-    const u32 shift = 2 * u32(g & 15);
-    const u64 lo = u64(pw[0]) | (u64(pw[1]) << 32);
-    w.codes = shift ? (lo >> shift) | (u64(pw[2]) << (64 - shift)) : lo;             // 2 * (RW_PER_LANE + 6) bits wanted, up to 30 shifted out
-    const u32 *pn = R.notBase + (g >> 5);
-    const u32 ns = u32(g & 31);
-    w.notBase = u32((u64(pn[0]) | (u64(pn[1]) << 32)) >> ns);
-    return w;
-}
-static_assert(2 * (RW_PER_LANE + 6) <= 64 && RW_PER_LANE + 6 <= 32, "a lane's window bases fit the two words loadWindowBits returns");
-
-// k_rescue_windows: one wave per rescue problem (ShadowAligner::findShadowCandidatePositions, ShadowAligner.cpp:53-112).
-// The mate's 7-mers go to an LDS hash table (first read position per k-mer).  The window is walked in tiles of 64 x RW_PER_LANE bases:
-// every lane takes RW_PER_LANE consecutive positions; with the reference 2 bits per base a 7-mer is a shift and a mask of the
-// lane's word (and seven zero bits of the not-ACGT map), and each one is looked up.  "Push unless equal to the previous hit's candidate" needs the previous hit in window order: inside a lane that is
-// sequential, across lanes one ballot + shuffle, across tiles a carried value.  Pushed candidates set bits in a bitmap
-// (LDS for ordinary windows, global for the long ones), whose ascending enumeration is the reference's sort + unique.
-template <bool LDS_BITMAP>
-__device__ inline void rescueWindowScan(const DevReference &R, const RescueJob &job, u64 windowBase, const WindowBits &firstTile, u32 L, const u32 *tab, u32 *bitmap, u32 lane, u32 &pushes)
-{
-    const i32 bias = i32(L) - 7;
-    const i32 lastStart = i32(job.windowLen) - 7;       // last valid k-mer start
-    i32 carry = 0; bool haveCarry = false;
-    for (i32 tile = 0; tile * RW_TILE <= lastStart; ++tile)
-    {
-        const i32 p0 = tile * RW_TILE + i32(lane) * i32(RW_PER_LANE);          // window position of this lane's first base
-        const WindowBits wb = tile ? loadWindowBits(R, windowBase + u64(p0)) : firstTile;
-        i32 cand[RW_PER_LANE]; u32 hitMask = 0;
-#pragma unroll
-        for (u32 k = 0; k < RW_PER_LANE; ++k)
-        {
-            const i32 p = p0 + i32(k);
-            cand[k] = 0;
-            if (p <= lastStart && !((wb.notBase >> k) & 0x7fu))
-            {
-                const u32 kmer = u32(wb.codes >> (2 * k)) & 0x3fffu;
-                u32 h = (kmer * 2654435761u) >> 23;
-                while (true)
-                {
-                    const u32 e = tab[h];
-                    if (e == KMER_EMPTY) break;
-                    if ((e >> 10) == kmer) { hitMask |= 1u << k; cand[k] = p - i32(e & 0x3ffu); break; }
-                    h = (h + 1) & (RW_TABLE - 1);
-                }
-            }
-        }
-        // previous hit in window order for this lane's first hit
-        i32 lastCand = 0;
-#pragma unroll
-        for (u32 k = 0; k < RW_PER_LANE; ++k) if (hitMask & (1u << k)) lastCand = cand[k];
-        const unsigned long long lanesWithHits = __ballot(hitMask != 0);
-        const unsigned long long below = lanesWithHits & ((1ull << lane) - 1ull);
-        const int prevLane = below ? 63 - __clzll(below) : 0;
-        const i32 prevCand = __shfl(lastCand, prevLane, 64);
-        bool havePrev = below ? true : haveCarry;
-        i32 prev = below ? prevCand : carry;
-        u32 localPushes = 0;
-#pragma unroll
-        for (u32 k = 0; k < RW_PER_LANE; ++k)
-            if (hitMask & (1u << k))
-            {
-                if (!havePrev || prev != cand[k])
-                {
-                    ++localPushes;
-                    const u32 bit = u32(cand[k] + bias);
-                    atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
-                }
-                prev = cand[k]; havePrev = true;
-            }
-        for (int o = 32; o > 0; o >>= 1) localPushes += __shfl_xor(localPushes, o, 64);
-        pushes += localPushes;
-        if (lanesWithHits) { carry = __shfl(lastCand, 63 - __clzll(lanesWithHits), 64); haveCarry = true; }
-    }
-}
-
-__global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReference R, u64 totalBases, const u8 *bcl, u32 clusterBase, RescueBuffers rb)
-{
-    __shared__ u32 tables[4][RW_TABLE];
-    __shared__ u32 ldsBitmaps[4][RW_LDS_BITMAP];
-    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const u32 j = blockIdx.x * 4 + wave;
-    const u32 nJobs = imin(*rb.jobCounter, rb.jobsCap);
-    RescueJob job;
-    bool active = j < nJobs;
-    STAMP_BEGIN();
-    if (active) { job = rb.jobs[j]; active = job.valid && !job.fallback; }
-    STAMP(0);
-    u32 pushes = 0, total = 0, bitmapWords = 0, L = 0;
-    bool small = true;
-    u32 *bitmap = ldsBitmaps[wave];
-    if (active)
-    {
-        // the lane's bytes of the first window tile are requested now and used after the k-mer table is built: one memory
-        // latency instead of two in a row
-        const u64 windowBase = R.contigOffset[job.contigId] + u64(job.windowBegin);      // windowBegin >= 0 (planRescue)
-        const WindowBits firstTile = loadWindowBits(R, windowBase + lane * RW_PER_LANE);
-        u32 *tab = tables[wave];
-        for (u32 i = lane; i < RW_TABLE; i += 64) tab[i] = KMER_EMPTY;
-        const u32 r = job.shadowReadIndex;
-        L = P.readLength[r];
-        bitmapWords = (job.windowLen + L + 31) / 32;
-        small = bitmapWords <= RW_LDS_BITMAP;
-        if (!small) bitmap = rb.bitmaps + job.bitmapBase;
-        for (u32 i = lane; i < bitmapWords; i += 64) bitmap[i] = 0;
-        if (!small) __threadfence();
-        __builtin_amdgcn_wave_barrier();
-        STAMP(1);
-        // the mate's 7-mers: first read position of every k-mer (ShadowAligner::hashShadowKmers, :53-72)
-        ReadView read; read.bcl = bcl + u64(clusterBase + job.cluster) * P.clusterLength + P.readOffset[r]; read.length = L; read.endCyclesMasked = 0; read.firstCycle = 0;
-        const bool reverse = job.shadowReverse != 0;
-        for (u32 i = lane; i + 7 <= L; i += 64)
-        {
-            // the 7 BCL bytes of strand positions i .. i+6 sit in 7 consecutive bytes of the read either way: one 8-byte load
-            const u32 first = reverse ? L - 7 - i : i;           // lowest BCL index of the k-mer
-            u64 bytes = 0;
-            if (first + 8 <= L) memcpy(&bytes, read.bcl + first, 8);
-            else { memcpy(&bytes, read.bcl + L - 8, 8); bytes >>= 8 * (first + 8 - L); }
-            u32 kmer = 0; bool ok = true;
-#pragma unroll
-            for (u32 k = 0; k < 7; ++k)
-            {
-                // BCL byte -> the code the packed reference has for the same base of the strand (A 0, C 1, G 3, T 2); a byte without quality bits is an N (Read.cpp:56-69)
-                const u32 b = u32(bytes >> (8 * (reverse ? 6 - k : k))) & 0xffu;
-                const u32 base = (b & 3u) ^ (reverse ? 3u : 0u);
-                ok &= (b & 0xfcu) != 0; kmer |= (base ^ (base >> 1)) << (2 * k);             // base k of the k-mer at bits 2k, as loadWindowBits lays them out
-            }
-            if (!ok) continue;
-            const u32 val = (kmer << 10) | i;
-            u32 h = (kmer * 2654435761u) >> 23;
-            while (true)
-            {
-                const u32 old = atomicCAS(&tab[h], KMER_EMPTY, val);
-                if (old == KMER_EMPTY) break;
-                if ((old >> 10) == kmer) { atomicMin(&tab[h], val); break; }
-                h = (h + 1) & (RW_TABLE - 1);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        STAMP(2);
-        if (small) rescueWindowScan<true>(R, job, windowBase, firstTile, L, tab, ldsBitmaps[wave], lane, pushes);
-        else { rescueWindowScan<false>(R, job, windowBase, firstTile, L, tab, bitmap, lane, pushes); __threadfence(); }
-        STAMP(3);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // the set bits in ascending order are the sorted unique candidate list: count them first
-        for (u32 w0 = 0; w0 < bitmapWords; w0 += 64)
-        {
-            const u32 w = w0 + lane;
-            const u32 word = w < bitmapWords ? (small ? bitmap[w] : __hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0u;
-            u32 c = u32(__popc(word));
-            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-            total += c;
-        }
-    }
-    STAMP(4);
-    if (!active) return;
-    bool fallback = pushes > SHADOW_POSITIONS_MAX;
-    if (fallback) total = 0;
-    // one allocation per problem from the block's region: the regions keep the atomics on different addresses, and the waves of
-    // a block stay independent of each other (no barrier: their windows differ in length)
-    u32 candBase = 0xffffffffu;
-    if (total)
-    {
-        if (lane == 0)
-        {
-            const u32 region = blockIdx.x % CAND_REGIONS;
-            const u32 at = atomicAdd(rb.candCounter + region, total);
-            if (at + total <= rb.candRegionSize) candBase = region * rb.candRegionSize + at;
-            else atomicMin(rb.candCounter + CAND_REGIONS + region, at);   // the region is full from here on: these problems fall back
-        }
-        candBase = __shfl(candBase, 0, 64);
-        if (candBase == 0xffffffffu) fallback = true;
-    }
-    STAMP(6);
-    if (!fallback && total)
-    {
-        const i32 bias = i32(L) - 7;
-        u32 running = 0;
-        for (u32 w0 = 0; w0 < bitmapWords; w0 += 64)
-        {
-            const u32 w = w0 + lane;
-            u32 word = w < bitmapWords ? (small ? bitmap[w] : __hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0u;
-            const u32 c = u32(__popc(word));
-            u32 incl = c;
-            for (u32 o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-            u32 at = candBase + running + incl - c;
-            while (word)
-            {
-                const u32 b = u32(__ffs(word)) - 1; word &= word - 1;
-                rb.candPositions[at] = i32(w * 32 + b) - bias; rb.candJob[at] = j; ++at;
-            }
-            running += __shfl(incl, 63, 64);
-        }
-    }
-    if (lane == 0)
-    {
-        RescueJob &out = rb.jobs[j];
-        out.pushes = pushes; out.fallback = fallback ? 1 : 0; out.candBase = (fallback || !total) ? 0 : candBase; out.nCands = fallback ? 0 : total;
-    }
-    STAMP(7);
-}
-
-__global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const ClusterFragments *frags, RescueBuffers rb, Counters *counters)
-{
-    ISAAC_STAGE_QUALITY_TABLES(Rg, R)
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    Counters local; memset(&local, 0, sizeof(local));
-    // slots in use: below the region's counter and below the first request the region could not serve
-    if (i < rb.candCap && i % rb.candRegionSize < imin(imin(rb.candCounter[i / rb.candRegionSize], rb.candCounter[CAND_REGIONS + i / rb.candRegionSize]), rb.candRegionSize))
-    {
-        const RescueJob &job = rb.jobs[rb.candJob[i]];
-        rescueAlignCandidate(P, R, bcl, clusterBase + job.cluster, frags[job.cluster], job, rb.candPositions[i], rb.shadowCands[i], rb.shadowCigars + u64(i) * 3);
-        ++local.ungappedScans;
-    }
-    flushCounters(local, counters);
-}
-
-// one thread per rescue problem: which of its aligned candidates get a gapped retry (ShadowAligner.cpp:232-262)
-__global__ __launch_bounds__(256) void k_rescue_gapped_plan(const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, Counters *counters)
-{
-    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
-    const u32 nJobs = imin(*rb.jobCounter, rb.jobsCap);
-    Counters local; memset(&local, 0, sizeof(local));
-    if (j < nJobs && rb.jobs[j].valid && !rb.jobs[j].fallback)
-    {
-        RescueJob &job = rb.jobs[j];
-        // the flat pass's rescue statistics are counted here, one wave reduction instead of one atomic per problem
-        ++local.rescueCalls; local.rescueWindowBases += job.windowLen; local.rescueCandidates += job.nCands;
-        summarizeRescueJob(job, rb.shadowCands, rb.candRank);
-        const u32 ecm = frags[job.cluster].endCyclesMasked[job.shadowReadIndex];
-        const u32 n = job.nGapped;      // counted by the summary pass; the candidates are walked again only to write the problems
-        u32 base = 0;
-        if (n)
-        {
-            base = atomicAdd(gb.counter, n);
-            if (base + n > gb.cap) base = 0xffffffffu;     // the cluster's thread runs them itself
-            else planRescueGapped(job, rb.shadowCands, rb.shadowCigars, ecm, gb.jobs + base);
-        }
-        job.gappedBase = base; job.nGapped = n;
-    }
-    flushCounters(local, counters);
-}
-
-// k_cluster_sums: the outcome of every rescue problem of a cluster and its probability sums (sums.h), one wavefront per cluster
-// with room for 64 list entries in LDS; clusters with longer lists are listed for the workgroup-per-cluster form (1024 entries),
-// and what neither can do (near ties, lists beyond that, capacity misses of the flat pass) for the wave-per-cluster pass.
-static const u32 SUMS_WAVE_CAP = 64, SUMS_BLOCK_CAP = 1024;
-struct SumsBuffers { ClusterSums *sums; u8 *residualFlag; u32 *residualList, *residualCount, *largeList, *largeCount; };
-
-__device__ inline SumInputs sumInputs(const RescueBuffers &rb, u32 t, const GappedBuffers &gb)
-{
-    SumInputs in; in.jobs = rb.jobs + rb.jobBase[t]; in.nJobs = rb.jobCount[t]; in.shadowCands = rb.shadowCands; in.candRank = rb.candRank; in.gappedResults = gb.results; in.gappedJobs = gb.jobs;
-    return in;
-}
-__device__ inline void markResidual(const SumsBuffers &sb, u32 t) { sb.residualFlag[t] = 1; sb.residualList[atomicAdd(sb.residualCount, 1u)] = t; }
-
-__global__ __launch_bounds__(256) void k_cluster_sums(DevParams P, const ClusterFragments *frags, u32 nChunk, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters)
-{
-    __shared__ __align__(16) u8 keyBytes[4][SUMS_WAVE_CAP * 42];
-    static_assert(SUMS_WAVE_CAP * 42 % 16 == 0, "key arrays stay aligned");
-    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const u32 t = blockIdx.x * 4 + wave;
-    Counters local; memset(&local, 0, sizeof(local));
-    if (t < nChunk)
-    {
-        if (0xffffffffu == rb.jobBase[t]) { if (0 == lane) markResidual(sb, t); }
-        else if (rb.jobCount[t])
-        {
-            SumKeys keys; sumKeysBind(keys, keyBytes[wave], SUMS_WAVE_CAP);
-            SumGroup g; g.lanes = 64; g.lane = lane; g.block = false;
-            ClusterSums out;
-            const u32 status = clusterSums(P, frags[t], sumInputs(rb, t, gb), keys, g, nullptr, true, out, local);
-            if (0 == lane)
-            {
-                if (SUMS_DONE == status) sb.sums[t] = out;
-                else if (SUMS_TOO_LARGE == status) sb.largeList[atomicAdd(sb.largeCount, 1u)] = t;
-                else markResidual(sb, t);
-            }
-        }
-    }
-    flushCounters(local, counters);
-}
-
-__global__ __launch_bounds__(256) void k_cluster_sums_large(DevParams P, const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters)
-{
-    __shared__ __align__(16) u8 keyBytes[SUMS_BLOCK_CAP * 42];
-    __shared__ u32 scratch;
-    Counters local; memset(&local, 0, sizeof(local));
-    const u32 n = *sb.largeCount;
-    for (u32 i = blockIdx.x; i < n; i += gridDim.x)
-    {
-        const u32 t = sb.largeList[i];
-        SumKeys keys; sumKeysBind(keys, keyBytes, SUMS_BLOCK_CAP);
-        SumGroup g; g.lanes = 256; g.lane = threadIdx.x; g.block = true;
-        ClusterSums out;
-        const u32 status = clusterSums(P, frags[t], sumInputs(rb, t, gb), keys, g, &scratch, false, out, local);
-        if (0 == threadIdx.x) { if (SUMS_DONE == status) sb.sums[t] = out; else markResidual(sb, t); }
-        __syncthreads();
-    }
-    flushCounters(local, counters);
-}
-
-// k_select: TemplateBuilder::buildTemplate on the precomputed rescue outcomes and sums, the clippers and the FragmentHeader records,
-// one thread per cluster of the chunk; `skip`: clusters the wave-per-cluster pass takes.  Clusters whose private work area overflows
-// (more equally good placements than it holds) are appended to overflowList and redone by that pass as well.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_SELECT_WAVES))) void k_select(const isaac_gpu_ctx::TemplateConstants *constants, DevReference R, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk, u32 tile,
-                                               const ClusterFragments *frags, RescueBuffers rb, const GappedResult *gappedResults, const GappedJob *gappedJobs, const ClusterSums *sums,
-                                               FragmentRecord *records, u32 *cigars, u32 *overflowList, u32 *overflowCount, const u8 *skip, Counters *counters)
-{
-    const DevParams &P = constants->P; const DevTls &tls = constants->tls; const RogCorrection &rog = constants->rog;
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    Counters local; memset(&local, 0, sizeof(local));
-    if (t < nChunk && !skip[t])
-    {
-        __attribute__((aligned(16))) u8 workBytes[TINY_WORK_BYTES];
-        TemplateWork work;
-        templateWorkBind(work, workBytes, tinyCaps());
-        RescueInputs in;
-        in.jobs = rb.jobs + rb.jobBase[t]; in.jobCount = rb.jobCount[t]; in.shadowCands = rb.shadowCands; in.shadowCigars = rb.shadowCigars; in.candRank = rb.candRank;
-        in.gappedResults = gappedResults; in.gappedJobs = gappedJobs; in.serialFallbackAllowed = false; in.sums = sums + t;
-        Cand privateCands[2 * PRIVATE_CANDS];
-        clusterSelect(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + t, tile, frags[t], work, records, cigars, local, &in, nullptr, privateCands);
-        if (work.overflow) overflowList[atomicAdd(overflowCount, 1u)] = t;
-    }
-    if (t < nChunk) ++local.clusters;   // including the ones the wave-per-cluster pass takes
-    flushCounters(local, counters);
-}
-
-// k_select_heavy: one wave per cluster of the overflow list.  All 64 lanes execute the template logic together on one arena
-// (same statements, same data), which costs what one thread costs; the bulk steps (probability sorts) are spread over the lanes.
-static const u32 HEAVY_SORT_LDS = 32768;   // u16 indices: heavyCaps().prob / .pair entries
-__global__ __launch_bounds__(64) void k_select_heavy(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nList, const u32 *nListDev, u32 tile,
-                                                     const ClusterFragments *frags, u8 *arena, u64 arenaBytes, TemplateCaps caps, const u32 *list, RescueBuffers rb, const GappedResult *gappedResults, const GappedJob *gappedJobs,
-                                                     FragmentRecord *records, u32 *cigars, Counters *counters)
-{
-    extern __shared__ __align__(16) u8 heavyLds[];
-    Counters local; memset(&local, 0, sizeof(local));
-    const u32 n = nListDev ? *nListDev : nList;
-    for (u32 t = blockIdx.x; t < n; t += gridDim.x)
-    {
-    const u32 inChunk = list[t];
-    TemplateWork work;
-    templateWorkBind(work, arena + u64(blockIdx.x) * arenaBytes, caps);
-    RescueInputs in; const RescueInputs *pin = nullptr;
-    if (rb.jobBase && rb.jobBase[inChunk] != 0xffffffffu)
-    {
-        in.jobs = rb.jobs + rb.jobBase[inChunk]; in.jobCount = rb.jobCount[inChunk]; in.shadowCands = rb.shadowCands; in.shadowCigars = rb.shadowCigars; in.candRank = rb.candRank;
-        in.gappedResults = gappedResults; in.gappedJobs = gappedJobs; in.serialFallbackAllowed = true; in.sums = nullptr;
-        pin = &in;
-    }
-    CoopInputs coop; coop.lanes = 64; coop.lane = threadIdx.x; coop.fastSort = true; coop.ldsSort = reinterpret_cast<u16 *>(heavyLds); coop.ldsSortCap = HEAVY_SORT_LDS;
-    clusterSelect(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + inChunk, tile, frags[inChunk], work, records, cigars, local, pin, &coop);
-    if (work.overflow) ++local.overflowClusters;   // even the reference's own capacities were exceeded
-    ++local.heavyClusters;
-    __syncthreads();                                 // the arena is reused by the block's next cluster
-    }
-    if (0 != threadIdx.x) memset(&local, 0, sizeof(local));   // every lane counted the same events
-    flushCounters(local, counters);
 }
 
 u32 gridFor(u64 n, u32 block) { return u32((n + block - 1) / block); }
@@ -1080,8 +466,9 @@ int isaac_gpu_create(int device, const isaac_params *params, void *stream, isaac
     c->counters.reserve(COUNTER_SHARDS);
     HIP_CHECK(hipMemset(c->counters.p, 0, COUNTER_SHARDS * sizeof(Counters)));
     c->overflowCount.reserve(1);
-    HIP_CHECK(hipStreamCreateWithFlags(&c->heavyStream, hipStreamNonBlocking));
-    HIP_CHECK(hipEventCreateWithFlags(&c->evPredicted, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&c->evHeavyDone, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&c->evSums, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&c->evSelect, hipEventDisableTiming));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->hostCounts), 16, hipHostMallocDefault));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cluster_sums_xl), hipFuncAttributeMaxDynamicSharedMemorySize, int(SUMS_XL_LDS)));
     if (const char *e = getenv("ISAAC_GPU_CHUNK_CLUSTERS")) c->chunkClusters = u32(std::max(1024, atoi(e)));
     *out = c.release();
     return ISAAC_GPU_OK;
@@ -1092,7 +479,8 @@ void isaac_gpu_destroy(isaac_gpu_ctx *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
-    joinHeavy(c); hipStreamSynchronize(c->stream); if (c->heavyStream) hipStreamSynchronize(c->heavyStream);
+    try { resolvePending(c); } catch (...) { }
+    hipStreamSynchronize(c->stream);
     resolveTimers(c);
 #if defined(ISAAC_KERNEL_STAMPS)
     {
@@ -1101,9 +489,9 @@ void isaac_gpu_destroy(isaac_gpu_ctx *c)
     }
 #endif
     for (hipEvent_t e : c->eventPool) hipEventDestroy(e);
-    if (c->evPredicted) hipEventDestroy(c->evPredicted);
-    if (c->evHeavyDone) hipEventDestroy(c->evHeavyDone);
-    if (c->heavyStream) hipStreamDestroy(c->heavyStream);
+    if (c->evSums) hipEventDestroy(c->evSums);
+    if (c->evSelect) hipEventDestroy(c->evSelect);
+    if (c->hostCounts) hipHostFree(c->hostCounts);
     delete c;
 }
 
@@ -1112,12 +500,12 @@ int isaac_gpu_free(isaac_gpu_ctx *c, void *dev) { ISAAC_TRY HIP_CHECK(hipSetDevi
 int isaac_gpu_upload(isaac_gpu_ctx *c, void *dev, const void *host, uint64_t bytes)
 { ISAAC_TRY HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
 int isaac_gpu_download(isaac_gpu_ctx *c, void *host, const void *dev, uint64_t bytes)
-{ ISAAC_TRY joinHeavy(c); HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
-int isaac_gpu_synchronize(isaac_gpu_ctx *c) { ISAAC_TRY joinHeavy(c); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
+{ ISAAC_TRY resolvePending(c); HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
+int isaac_gpu_synchronize(isaac_gpu_ctx *c) { ISAAC_TRY resolvePending(c); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
 int isaac_gpu_set_deferred_completion(isaac_gpu_ctx *c, int enabled)
 {
     ISAAC_TRY
-    if (!enabled) { joinHeavy(c); HIP_CHECK(hipStreamSynchronize(c->stream)); }
+    if (!enabled) { resolvePending(c); HIP_CHECK(hipStreamSynchronize(c->stream)); }
     c->deferredCompletion = enabled != 0;
     return 0;
     ISAAC_CATCH
@@ -1277,7 +665,7 @@ int isaac_gpu_build_index(isaac_gpu_ctx *c, uint32_t repeatThreshold, int annota
     ISAAC_TRY
     HIP_CHECK(hipSetDevice(c->device));
     if (!c->bases) return fail(ISAAC_GPU_EINVAL, "load the contigs first");
-    joinHeavy(c);
+    resolvePending(c);
     const u64 totalBases = c->hContigOffset[c->nContigs];
     hipStream_t st = c->stream;
     const u32 *packed = c->packedBases.p, *notBase = c->notBase.p;
@@ -1558,7 +946,7 @@ int isaac_gpu_build_fragments(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nCl
     ISAAC_TRY
     (void)tile;
     HIP_CHECK(hipSetDevice(c->device));
-    joinHeavy(c);      // a wave-per-cluster pass of an earlier select call may still read the buffers written below
+    resolvePending(c);      // a wave-per-cluster pass of an earlier select call may still read the buffers written below
     hipStream_t st = c->stream;
     const u32 chunk = chunkFor(c, nClusters);
     useFragments(c);
@@ -1591,7 +979,7 @@ int isaac_gpu_determine_tls(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
     ISAAC_TRY
     (void)tile;
     HIP_CHECK(hipSetDevice(c->device));
-    joinHeavy(c);      // a wave-per-cluster pass of an earlier select call may still read the buffers written below
+    resolvePending(c);      // a wave-per-cluster pass of an earlier select call may still read the buffers written below
     hipStream_t st = c->stream;
     TlsLearner learner(c->P.mateDriftRange);
     if (2 == c->P.nReads)
@@ -1619,7 +1007,29 @@ int isaac_gpu_determine_tls(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
 // what fills the chunk's ClusterFragments: the fragment stage on match lists (isaac_gpu_select) or caller-supplied candidates
 struct FragmentSource { const isaac_match *matches; const uint64_t *offsets; const isaac_candidate *candidates; const uint64_t *candidateOffsets; const uint32_t *candidateCigars; };
 } // extern "C"
-__global__ void k_set_template_constants(isaac_gpu_ctx::TemplateConstants k, isaac_gpu_ctx::TemplateConstants *dst) { *dst = k; }
+__global__ void k_set_template_constants(TemplateConstants k, TemplateConstants *dst) { *dst = k; }
+
+// the wave-per-cluster pass over `list` (count on the device) for the chunk described by `p`, on the context's stream
+static void launchHeavy(isaac_gpu_ctx *c, const isaac_gpu_ctx::Pending &p, const u32 *list, const u32 *countDev, u32 blocks, const char *timer)
+{
+    const TemplateCaps heavy = heavyCaps();
+    const u64 heavyBytes = templateWorkBytes(heavy);
+    c->heavyArena.reserve(size_t(1024) * heavyBytes);
+    RescueBuffers rb; std::memset(&rb, 0, sizeof(rb));
+    rb.jobs = c->jobs.p; rb.shadowCands = c->shadowCands.p; rb.candRank = c->candRank.p; rb.shadowCigars = c->shadowCigars.p; rb.jobBase = c->jobBase.p; rb.jobCount = c->jobCount.p;
+    ScopedTimer tm(c, timer);
+    k_select_heavy<<<std::max(1u, blocks), 64, HEAVY_SORT_LDS * 2, c->stream>>>(c->P, c->ref(), p.tls, p.rog, logMismatchQ40(), p.bcl, p.clusterBase, 0, countDev, p.tile, p.frags, c->heavyArena.p, heavyBytes, heavy,
+                                                                                 list, rb, c->rescueGappedResults.p, c->rescueGappedJobs.p, p.records, p.cigars, c->counters.p);
+    HIP_CHECK(hipGetLastError());
+}
+
+static void resolvePending(isaac_gpu_ctx *c)
+{
+    if (!c->pending.active) return;
+    c->pending.active = false;
+    HIP_CHECK(hipEventSynchronize(c->evSelect));
+    if (c->hostCounts[1]) launchHeavy(c, c->pending, c->overflowList.p, c->overflowCount.p, std::min<u32>(c->hostCounts[1], 1024u), "select_residual");
+}
 
 static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, uint32_t tile, const FragmentSource &source, const isaac_tls *tls,
                             isaac_fragment *fragments, uint32_t *cigar, uint64_t cigarCapacity)
@@ -1631,11 +1041,13 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
     DevTls t; std::memcpy(&t, tls, sizeof(t));
     const RogCorrection rog = makeRogCorrection(c->P, c->hContigOffset.data(), c->hContigLoaded.data(), c->nContigs);
     const double lmq40 = logMismatchQ40();
-    const TemplateCaps heavy = heavyCaps();
     if (templateWorkBytes(tinyCaps()) > TINY_WORK_BYTES) return fail(ISAAC_GPU_EHIP, "TINY_WORK_BYTES is smaller than the work area of tinyCaps()");
-    const u64 heavyBytes = templateWorkBytes(heavy);
     const u32 chunk = chunkFor(c, nClusters);
-    const u32 heavyThreads = 1024, residualThreads = 256;
+    if (chunk > c->selectCapacity)
+    {   // the chunk buffers are about to be reallocated: nothing may be left that reads them
+        resolvePending(c); HIP_CHECK(hipStreamSynchronize(st));
+        c->selectCapacity = chunk;
+    }
     c->overflowList.reserve(chunk);
     RescueBuffers rb; std::memset(&rb, 0, sizeof(rb));
     rb.jobsCap = 4 * chunk; rb.bitmapCap = 64 * rb.jobsCap; rb.candRegionSize = (24 * chunk + CAND_REGIONS - 1) / CAND_REGIONS; rb.candCap = rb.candRegionSize * CAND_REGIONS;
@@ -1644,19 +1056,19 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
     rb.jobs = c->jobs.p; rb.bitmaps = c->bitmaps.p; rb.candPositions = c->candPositions.p; rb.candJob = c->candJob.p; rb.shadowCands = c->shadowCands.p; rb.candRank = c->candRank.p;
     rb.shadowCigars = c->shadowCigars.p; rb.jobBase = c->jobBase.p; rb.jobCount = c->jobCount.p;
     rb.jobCounter = c->rescueCounters.p; rb.bitmapCounter = c->rescueCounters.p + 1; rb.candCounter = c->rescueCounters.p + 4;
-    c->clusterSums.reserve(chunk); c->heavyList.reserve(chunk); c->largeList.reserve(chunk); c->heavyCount.reserve(2); c->heavyFlag.reserve(chunk);
+    c->clusterSums.reserve(chunk); c->heavyList.reserve(chunk); c->largeList.reserve(chunk); c->hugeList.reserve(chunk); c->xlList.reserve(chunk); c->heavyCount.reserve(4); c->heavyFlag.reserve(chunk);
+    c->hugeKeys.reserve(size_t(SUMS_HUGE_BLOCKS) * SUMS_HUGE_CAP * 42);
     SumsBuffers sb; sb.sums = c->clusterSums.p; sb.residualFlag = c->heavyFlag.p; sb.residualList = c->heavyList.p; sb.residualCount = c->heavyCount.p;
-    sb.largeList = c->largeList.p; sb.largeCount = c->heavyCount.p + 1;
+    sb.largeList = c->largeList.p; sb.largeCount = c->heavyCount.p + 1; sb.hugeList = c->hugeList.p; sb.hugeCount = c->heavyCount.p + 2; sb.xlList = c->xlList.p; sb.xlCount = c->heavyCount.p + 3; sb.hugeKeys = c->hugeKeys.p;
     const DevReference R = c->ref();
     {
-        isaac_gpu_ctx::TemplateConstants k; k.P = c->P; k.tls = t; k.rog = rog;
+        TemplateConstants k; k.P = c->P; k.tls = t; k.rog = rog;
         c->templateConstants.reserve(1);
         k_set_template_constants<<<1, 1, 0, st>>>(k, c->templateConstants.p);      // by value: no host buffer to keep alive, no host wait
         HIP_CHECK(hipGetLastError());
     }
     const GappedBuffers gbRescue = gappedBuffers(c, 1);
     c->frags.reserve(chunk); c->fragsAlt.reserve(chunk);
-    c->heavyArena.reserve(size_t(heavyThreads + residualThreads) * heavyBytes);
     for (u32 done = 0; done < nClusters; done += chunk)
     {
         const u32 n = std::min(chunk, nClusters - done);
@@ -1672,11 +1084,11 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
             HIP_CHECK(hipGetLastError());
         }
         else launchBuildFragments(c, bcl, done, n, source.matches, source.offsets, 1, 1);
-        joinHeavy(c);
+        resolvePending(c);      // the previous chunk's leftovers still read the rescue buffers this chunk is about to overwrite
         HIP_CHECK(hipMemsetAsync(c->overflowCount.p, 0, 4, st));
         HIP_CHECK(hipMemsetAsync(c->rescueCounters.p, 0, (4 + CAND_REGIONS) * 4, st));
         HIP_CHECK(hipMemsetAsync(c->rescueCounters.p + 4 + CAND_REGIONS, 0xff, CAND_REGIONS * 4, st));   // per region: first request that did not fit
-        HIP_CHECK(hipMemsetAsync(c->heavyCount.p, 0, 8, st));
+        HIP_CHECK(hipMemsetAsync(c->heavyCount.p, 0, 16, st));
         HIP_CHECK(hipMemsetAsync(c->heavyFlag.p, 0, n, st));
         {
             ScopedTimer tm(c, "plan_rescue");
@@ -1700,38 +1112,44 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         }
         launchGappedJobs(c, bcl, done, gbRescue, "gapped_rescue");
         {
-            ScopedTimer tm(c, "probability_sums");
+            ScopedTimer tm(c, "sums_wave");
             k_cluster_sums<<<gridFor(n, 4), 256, 0, st>>>(c->P, c->fragsCur, n, rb, gbRescue, sb, c->counters.p);
+            HIP_CHECK(hipGetLastError());
+        }
+        {
+            ScopedTimer tm(c, "sums_large");
             k_cluster_sums_large<<<2048, 256, 0, st>>>(c->P, c->fragsCur, rb, gbRescue, sb, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }
-        {   // what the sums stage could not do starts on its own stream now, next to k_select, with the reference's own capacities
-            HIP_CHECK(hipEventRecord(c->evPredicted, st));
-            HIP_CHECK(hipStreamWaitEvent(c->heavyStream, c->evPredicted, 0));
-            {
-                ScopedTimer tm(c, "select_heavy", c->heavyStream);
-                k_select_heavy<<<heavyThreads, 64, HEAVY_SORT_LDS * 2, c->heavyStream>>>(c->P, R, t, rog, lmq40, bcl, done, 0, c->heavyCount.p, tile, c->fragsCur, c->heavyArena.p, heavyBytes, heavy,
-                                                                                         c->heavyList.p, rb, gbRescue.results, gbRescue.jobs, reinterpret_cast<FragmentRecord *>(fragments), cigar, c->counters.p);
-                HIP_CHECK(hipGetLastError());
-            }
-            HIP_CHECK(hipEventRecord(c->evHeavyDone, c->heavyStream)); c->heavyPending = true;
+        {
+            ScopedTimer tm(c, "sums_xl");
+            k_cluster_sums_xl<<<256, 1024, SUMS_XL_LDS, st>>>(c->P, c->fragsCur, rb, gbRescue, sb, c->counters.p);
+            HIP_CHECK(hipGetLastError());
         }
+        {
+            ScopedTimer tm(c, "sums_huge");
+            k_cluster_sums_huge<<<SUMS_HUGE_BLOCKS, 1024, 0, st>>>(c->P, c->fragsCur, rb, gbRescue, sb, c->counters.p);
+            HIP_CHECK(hipGetLastError());
+        }
+        HIP_CHECK(hipMemcpyAsync(c->hostCounts, c->heavyCount.p, 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipEventRecord(c->evSums, st));
         {
             ScopedTimer tm(c, "select");
             k_select<<<gridFor(n, 64), 64, 0, st>>>(c->templateConstants.p, R, lmq40, bcl, done, n, tile, c->fragsCur, rb, gbRescue.results, gbRescue.jobs, c->clusterSums.p,
                                                      reinterpret_cast<FragmentRecord *>(fragments), cigar, c->overflowList.p, c->overflowCount.p, c->heavyFlag.p, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }
-        {   // clusters whose private work area overflowed (normally none): again, with the reference's own capacities; the count stays on the device
-            ScopedTimer tm(c, "select_residual");
-            k_select_heavy<<<residualThreads, 64, HEAVY_SORT_LDS * 2, st>>>(c->P, R, t, rog, lmq40, bcl, done, 0, c->overflowCount.p, tile, c->fragsCur,
-                                                                            c->heavyArena.p + size_t(heavyThreads) * heavyBytes, heavyBytes, heavy, c->overflowList.p, rb, gbRescue.results, gbRescue.jobs,
-                                                                            reinterpret_cast<FragmentRecord *>(fragments), cigar, c->counters.p);
-            HIP_CHECK(hipGetLastError());
-        }
+        HIP_CHECK(hipMemcpyAsync(c->hostCounts + 1, c->overflowCount.p, 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipEventRecord(c->evSelect, st));
+        c->pending.active = true; c->pending.bcl = bcl; c->pending.clusterBase = done; c->pending.tile = tile; c->pending.frags = c->fragsCur;
+        c->pending.records = reinterpret_cast<FragmentRecord *>(fragments); c->pending.cigars = cigar; c->pending.tls = t; c->pending.rog = rog;
+        // what the sums stage could not do (near ties, lists beyond the reference's own capacities, capacity misses of the flat pass):
+        // the wave-per-cluster pass, after k_select.  The host learns the count while k_select runs.
+        HIP_CHECK(hipEventSynchronize(c->evSums));
+        if (c->hostCounts[0]) launchHeavy(c, c->pending, c->heavyList.p, c->heavyCount.p, std::min<u32>(c->hostCounts[0], 1024u), "select_heavy");
     }
-    if (c->deferredCompletion) return 0;      // the last wave-per-cluster pass overlaps whatever the caller enqueues next; isaac_gpu_synchronize completes it
-    joinHeavy(c);
+    if (c->deferredCompletion) return 0;      // the caller enqueues its next call behind this one's k_select; isaac_gpu_synchronize completes the last one
+    resolvePending(c);
     HIP_CHECK(hipStreamSynchronize(st));
     return 0;
     ISAAC_CATCH
@@ -1775,7 +1193,7 @@ int isaac_gpu_compact_cigars(isaac_gpu_ctx *c, isaac_fragment *fragments, uint64
     if (!nRecords) return 0;
     if (!fragments || !cigarIn || !cigarOut) return fail(ISAAC_GPU_EINVAL, "fragments_dev, cigar_in_dev and cigar_out_dev are required");
     if (nRecords >= (u64(1) << 31)) return fail(ISAAC_GPU_EINVAL, "at most 2^31 - 1 records per call");
-    joinHeavy(c);
+    resolvePending(c);
     hipStream_t st = c->stream;
     DevBuf<u32> &len = c->cigarLengths, &off = c->cigarOffsets; len.reserve(nRecords); off.reserve(nRecords);
     FragmentRecord *records = reinterpret_cast<FragmentRecord *>(fragments);
@@ -1898,7 +1316,7 @@ int isaac_gpu_get_counters(isaac_gpu_ctx *c, isaac_counters *out)
     ISAAC_TRY
     static_assert(sizeof(isaac_counters) == sizeof(Counters), "counter layouts");
     std::vector<Counters> shards(COUNTER_SHARDS);
-    joinHeavy(c); HIP_CHECK(hipStreamSynchronize(c->stream));     // a deferred wave-per-cluster pass still counts
+    resolvePending(c); HIP_CHECK(hipStreamSynchronize(c->stream));     // a deferred wave-per-cluster pass still counts
     HIP_CHECK(hipMemcpy(shards.data(), c->counters.p, COUNTER_SHARDS * sizeof(Counters), hipMemcpyDeviceToHost));
     u64 *sum = reinterpret_cast<u64 *>(out);
     for (u32 f = 0; f < sizeof(Counters) / sizeof(u64); ++f)
@@ -1922,7 +1340,7 @@ int isaac_gpu_kernel_time_ms(isaac_gpu_ctx *c, const char *kernel, double *avgMs
 int isaac_gpu_reset_timers(isaac_gpu_ctx *c)
 {
     ISAAC_TRY
-    joinHeavy(c); HIP_CHECK(hipStreamSynchronize(c->stream));
+    resolvePending(c); HIP_CHECK(hipStreamSynchronize(c->stream));
     resolveTimers(c);
     c->timers.clear();
     HIP_CHECK(hipMemset(c->counters.p, 0, COUNTER_SHARDS * sizeof(Counters)));

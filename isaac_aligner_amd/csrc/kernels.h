@@ -1,0 +1,128 @@
+// What the translation units of the library share: buffer descriptors handed to the kernels, launch constants, the work-counter
+// reduction, and the prototypes of the kernels that live in kernels_*.hip (each kernel family is compiled on its own, so that a
+// change to one does not rebuild the others and the build runs in parallel).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/isaac_gpu.h"
+#include "cluster_ops.h"
+#include "sums.h"
+
+// occupancy targets (waves per SIMD) of the two thread-per-cluster kernels; the register allocator spills to meet them
+#ifndef ISAAC_SELECT_WAVES
+#define ISAAC_SELECT_WAVES 4
+#endif
+#ifndef ISAAC_FRAGMENT_WAVES
+#define ISAAC_FRAGMENT_WAVES 6
+#endif
+
+using namespace isaac;
+
+// run constants of the template kernels in device memory: passed by value they end up as private copies (dynamic indexing)
+struct TemplateConstants { DevParams P; DevTls tls; RogCorrection rog; };
+
+// ------------------------------------------------------------------------------------------------------------------
+// wave-level reduction of the work counters, one atomic per field per wave.  The totals are kept in COUNTER_SHARDS copies
+// (a block adds to the copy of its index; isaac_gpu_get_counters sums them): atomics on one address execute one after the
+// other in L2, and a grid of small waves can spend longer queueing there than working.  Fields no lane touched cost a vote.
+static const u32 COUNTER_SHARDS = 64;
+__device__ inline void flushCounters(const Counters &local, Counters *global)
+{
+    const u64 *src = reinterpret_cast<const u64 *>(&local);
+    u64 *dst = reinterpret_cast<u64 *>(global + (blockIdx.x & (COUNTER_SHARDS - 1)));
+    for (u32 f = 0; f < sizeof(Counters) / sizeof(u64); ++f)
+    {
+        u64 v = src[f];
+        if (!__any(v != 0)) continue;
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(reinterpret_cast<unsigned long long *>(dst + f), static_cast<unsigned long long>(v));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Quality::logMatchLookup / logMismatchLookup staged in LDS: every base of every alignment reads one of the two
+#define ISAAC_STAGE_QUALITY_TABLES(R_IN, R_OUT)                                                                              \
+    __shared__ double qualityTables[128];                                                                                    \
+    for (u32 qi = threadIdx.x; qi < 128; qi += blockDim.x) qualityTables[qi] = qi < 64 ? (R_IN).logMatch[qi] : (R_IN).logMismatch[qi - 64]; \
+    __syncthreads();                                                                                                         \
+    DevReference R_OUT = (R_IN); R_OUT.logMatch = qualityTables; R_OUT.logMismatch = qualityTables + 64;
+
+// the chunk's gapped (banded Smith-Waterman) problems: written by the per-cluster threads, run by k_gapped_jobs
+struct GappedBuffers { GappedJob *jobs; GappedResult *results; u32 cap; u32 *counter; u32 *base; };
+
+// the chunk's ungapped alignment problems: (cluster << 8) | (read << 7) | index in the read's candidate list
+struct AlignList { u32 *entries; u32 cap; u32 *counter; };
+
+// ------------------------------------------------------------------------------------------------------------------
+// Template stage.  Mate rescue (ShadowAligner::rescueShadow) is the bulk of the work of the select phase: a 7-mer scan of
+// a window of several hundred reference bases plus one 150-base ungapped alignment per candidate start, for ~1.5 orphans
+// per cluster.  It is planned per cluster, then executed flat:
+//   k_plan_rescue         one thread per cluster: the rescue problems TemplateBuilder would pose (result independent)
+//   k_rescue_windows      one wavefront per problem: the mate's 7-mer table in LDS, the window scanned 64 x RW_PER_LANE positions at a time
+//                         (16 per lane), candidate starts collected in a per-problem bitmap (sorted + unique for free)
+//   k_rescue_align        one thread per candidate start: UngappedAligner::alignUngapped
+//   k_rescue_gapped_plan  one thread per problem: rank of every aligned candidate, the best one, which get a gapped retry
+//   k_gapped_jobs         16 lanes per retry (bsw_kernel.h)
+//   k_predict_heavy       one thread per cluster: which clusters cannot fit the light work lists
+//   k_select              one thread per cluster: consumes the rescue results, pair / orphan selection, alignment scores,
+//                         clippers, FragmentHeader records
+//   k_select_heavy        one wave per predicted cluster, on its own stream next to k_select
+static const u32 KMER_EMPTY = 0xffffffffu;
+static const u32 RW_TABLE = 512;          // hash slots for the mate's <= 250-odd 7-mers
+static const u32 RW_LDS_BITMAP = 64;      // words: windows up to ~1900 bases keep their candidate bitmap in LDS
+#ifndef ISAAC_RW_PER_LANE
+#define ISAAC_RW_PER_LANE 8
+#endif
+static const u32 RW_PER_LANE = ISAAC_RW_PER_LANE;        // consecutive window positions per lane and tile (a multiple of 8)
+static const i32 RW_TILE = 64 * RW_PER_LANE;              // window positions per wave and tile
+static const u32 CAND_REGIONS = 256;
+
+struct RescueBuffers
+{
+    RescueJob *jobs; u32 jobsCap; u32 *jobCounter;
+    u32 *bitmaps; u32 bitmapCap; u32 *bitmapCounter;
+    i32 *candPositions; u32 *candJob; Cand *shadowCands; u32 *shadowCigars; u32 *candRank; u32 candCap; u32 *candCounter;
+    // candidate slots are handed out from CAND_REGIONS equal regions, each with its own counter (candCounter[region]): one
+    // counter for every workgroup of a chunk serialises at ~8 ns per atomic
+    u32 candRegionSize;
+    u32 *jobBase; u32 *jobCount;   // per cluster of the chunk; jobBase == 0xffffffff: the cluster runs its rescues itself
+};
+
+// the main pass's template work area (tinyCaps) lives in private memory
+static const u32 TINY_WORK_BYTES = 1024;
+
+// k_cluster_sums: the outcome of every rescue problem of a cluster and its probability sums (sums.h), one wavefront per cluster
+// with room for 64 list entries in LDS; clusters with longer lists are listed for the workgroup-per-cluster form (1024 entries),
+// and what neither can do (near ties, lists beyond that, capacity misses of the flat pass) for the wave-per-cluster pass.
+// SUMS_XL_CAP is not a power of two: its index array is padded to the next one for the sorting network (SUMS_XL_LDS)
+static const u32 SUMS_XL_LDS = 3584 * 42 + (4096 - 3584) * 2;
+static const u32 SUMS_WAVE_CAP = 64, SUMS_BLOCK_CAP = 1024, SUMS_XL_CAP = 3584, SUMS_HUGE_CAP = 32768 /* heavyCaps().prob / .pair */, SUMS_HUGE_BLOCKS = 512;
+struct SumsBuffers { ClusterSums *sums; u8 *residualFlag; u32 *residualList, *residualCount, *largeList, *largeCount, *xlList, *xlCount, *hugeList, *hugeCount; u8 *hugeKeys; };
+
+static const u32 HEAVY_SORT_LDS = 32768;   // u16 indices: heavyCaps().prob / .pair entries
+
+// LDS bytes of one 16-lane banded Smith-Waterman group (bsw_kernel.h)
+__host__ __device__ inline u32 bswGroupLdsBytes(u32 maxQueryLength) { return ((maxQueryLength * 16 + 15) & ~15u) + 128; }
+// k_gapped_jobs also keeps the query and the database window of the group there (the DP loop then reads LDS, not global memory)
+__host__ __device__ inline u32 gappedGroupLdsBytes(u32 maxQueryLength) { return bswGroupLdsBytes(maxQueryLength) + 2 * ((maxQueryLength + 31) & ~15u); }
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_build_fragments(DevParams P, const u8 *bcl, u32 clusterBase, u32 nChunk, const Match *matches, const u64 *offsets, int trim, FragmentWork *work, ClusterFragments *frags, AlignList al);
+__global__ __launch_bounds__(256) void k_align_candidates(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, ClusterFragments *frags, AlignList al, Counters *counters);
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_finish_candidates(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, u32 nChunk, int withGaps, u32 *indelList, u32 *indelCount, FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters);
+__global__ __launch_bounds__(64) void k_indel_fragments(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, int withGaps, const u32 *indelList, const u32 *indelCount, FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters);
+__global__ __launch_bounds__(64) void k_finish_fragments(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, u32 nChunk, int withGaps, FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters);
+__global__ __launch_bounds__(64) void k_plan_rescue(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk, const ClusterFragments *frags, RescueBuffers rb);
+__global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReference R, u64 totalBases, const u8 *bcl, u32 clusterBase, RescueBuffers rb);
+__global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const ClusterFragments *frags, RescueBuffers rb, Counters *counters);
+__global__ __launch_bounds__(256) void k_rescue_gapped_plan(const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, Counters *counters);
+__global__ __launch_bounds__(256) void k_cluster_sums(DevParams P, const ClusterFragments *frags, u32 nChunk, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);
+__global__ __launch_bounds__(256) void k_cluster_sums_large(DevParams P, const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);
+__global__ __launch_bounds__(1024) void k_cluster_sums_xl(DevParams P, const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);
+__global__ __launch_bounds__(1024) void k_cluster_sums_huge(DevParams P, const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_SELECT_WAVES))) void k_select(const TemplateConstants *constants, DevReference R, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk, u32 tile, const ClusterFragments *frags, RescueBuffers rb, const GappedResult *gappedResults, const GappedJob *gappedJobs, const ClusterSums *sums, FragmentRecord *records, u32 *cigars, u32 *overflowList, u32 *overflowCount, const u8 *skip, Counters *counters);
+__global__ __launch_bounds__(64) void k_select_heavy(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nList, const u32 *nListDev, u32 tile, const ClusterFragments *frags, u8 *arena, u64 arenaBytes, TemplateCaps caps, const u32 *list, RescueBuffers rb, const GappedResult *gappedResults, const GappedJob *gappedJobs, FragmentRecord *records, u32 *cigars, Counters *counters);
+namespace isaac
+{
+__global__ __launch_bounds__(256) void k_bsw_batch(int matchScore, int mismatchScore, int gapOpenScore, int gapExtendScore, const char *sequences, const isaac_bsw_job *jobs, u32 nJobs, u32 maxQueryLength, isaac_bsw_result *results);
+__global__ __launch_bounds__(256) void k_gapped_jobs(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap, u32 maxReadLength, GappedResult *results);
+__global__ __launch_bounds__(256) void k_gapped_rescan(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap, GappedResult *results);
+}

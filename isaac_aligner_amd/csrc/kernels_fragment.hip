@@ -1,0 +1,129 @@
+// kernels_fragment.hip: see kernels.h and DESIGN.md §4
+#include "kernels.h"
+#include "bsw_kernel.h"
+
+__device__ inline void emitGappedJobs(const ClusterFragments &f, u32 cl, bool withGaps, const GappedBuffers &gb)
+{
+    u32 base = 0;
+    const u32 n = countGappedJobs(f, withGaps);
+    if (n)
+    {
+        base = atomicAdd(gb.counter, n);
+        if (base + n > gb.cap) base = 0xffffffffu;   // k_finish_fragments runs this cluster's retries itself
+        else writeGappedJobs(f, cl, gb.jobs + base);
+    }
+    gb.base[cl] = base;
+}
+
+
+// Fragment stage, step 1: matches -> candidate positions (buildCandidates), and one entry per candidate in the flat list
+// k_align_candidates works through.  The list space of a wave is taken with one atomic.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_build_fragments(DevParams P, const u8 *bcl, u32 clusterBase, u32 nChunk, const Match *matches, const u64 *offsets,
+                                                        int trim, FragmentWork *work, ClusterFragments *frags, AlignList al)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 cl = 0, n = 0;
+    if (t < nChunk)
+    {
+        cl = t;
+        const u64 begin = offsets[clusterBase + cl], end = offsets[clusterBase + cl + 1];
+        buildCandidates(P, bcl + u64(clusterBase + cl) * P.clusterLength, matches + begin, u32(end - begin), trim != 0, work[t], frags[cl]);
+        n = frags[cl].nCands[0] + frags[cl].nCands[1];
+    }
+    // exclusive prefix of n over the wave, one allocation for all of it
+    u32 incl = n;
+    for (u32 o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o, 64); if ((threadIdx.x & 63) >= o) incl += v; }
+    const u32 total = __shfl(incl, 63, 64);
+    u32 base = 0;
+    if ((threadIdx.x & 63) == 63 && total) base = atomicAdd(al.counter, total);
+    base = __shfl(base, 63, 64);
+    if (n)
+    {
+        u32 at = base + incl - n;
+        if (base + total > al.cap)
+        {   // no room: the cluster aligns its own candidates later; what the wave took of the list is marked unused
+            frags[cl].flags |= CLUSTER_ALIGN_PENDING;
+            for (u32 k = 0; k < n; ++k) if (at + k < al.cap) al.entries[at + k] = 0xffffffffu;
+        }
+        else for (u32 r = 0; r < 2; ++r) for (u32 i = 0; i < frags[cl].nCands[r]; ++i) al.entries[at++] = (cl << 8) | (r << 7) | i;
+    }
+}
+
+// step 2: UngappedAligner::alignUngapped, one candidate per thread
+__global__ __launch_bounds__(256) void k_align_candidates(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, ClusterFragments *frags, AlignList al, Counters *counters)
+{
+    ISAAC_STAGE_QUALITY_TABLES(Rg, R)
+    Counters local; memset(&local, 0, sizeof(local));
+    const u32 n = imin(*al.counter, al.cap);
+    for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+    {
+        const u32 e = al.entries[j], cl = e >> 8;
+        if (0xffffffffu == e) continue;
+        alignCandidate(P, R, bcl + u64(clusterBase + cl) * P.clusterLength, frags[cl], (e >> 7) & 1, e & 127, local);
+    }
+    flushCounters(local, counters);
+}
+
+// step 3: consolidation and the single-indel stage (finishCandidates), then either the cluster's gapped problems or, for the
+// 3-4 % of clusters with a candidate pair for the single-indel detector, an entry for k_indel_fragments: inside this kernel
+// nearly every wave would hold one such lane and wait for it
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_finish_candidates(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, u32 nChunk,
+                                                        int withGaps, u32 *indelList, u32 *indelCount, FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters)
+{
+    ISAAC_STAGE_QUALITY_TABLES(Rg, R)
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    Counters local; memset(&local, 0, sizeof(local));
+    if (t < nChunk)
+    {
+        const u32 cl = t;
+        ClusterFragments &f = frags[cl];
+        const u8 *clusterBcl = bcl + u64(clusterBase + cl) * P.clusterLength;
+        if (f.flags & CLUSTER_ALIGN_PENDING)
+        {
+            f.flags &= ~u32(CLUSTER_ALIGN_PENDING);
+            for (u32 r = 0; r < P.nReads; ++r) for (u32 i = 0; i < f.nCands[r]; ++i) alignCandidate(P, R, clusterBcl, f, r, i, local);
+        }
+        finishCandidates(P, R, clusterBcl, work[t], f, local, true);
+        if (clusterSimpleIndelsPending(f)) indelList[atomicAdd(indelCount, 1u)] = cl;
+        else emitGappedJobs(f, cl, withGaps != 0, gb);
+    }
+    flushCounters(local, counters);
+}
+
+// The deferred single-indel stage (SimpleIndelAligner) for the clusters k_build_fragments listed, then their gapped problems.
+// One wave per cluster, every lane executing the same statements (as in k_select_heavy): the detector is a chain of dependent
+// byte loads, and 64 different clusters per wave would spread them over more cache lines than the L1 holds.
+__global__ __launch_bounds__(64) void k_indel_fragments(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, int withGaps, const u32 *indelList, const u32 *indelCount,
+                                                        FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters)
+{
+    ISAAC_STAGE_QUALITY_TABLES(Rg, R)
+    __shared__ __align__(16) u8 stageBcl[512];
+    __shared__ __align__(16) char stageWindow[1536];
+    IndelStage stage; stage.bcl = stageBcl; stage.bclCap = sizeof(stageBcl); stage.window = stageWindow; stage.windowCap = sizeof(stageWindow); stage.lane = threadIdx.x;
+    Counters local; memset(&local, 0, sizeof(local));
+    const u32 n = *indelCount;
+    for (u32 t = blockIdx.x; t < n; t += gridDim.x)
+    {
+        const u32 cl = indelList[t];
+        clusterFinishSimpleIndels(P, R, bcl, clusterBase + cl, work[blockIdx.x], frags[cl], local, &stage);
+        __syncthreads();
+        if (0 == threadIdx.x) emitGappedJobs(frags[cl], cl, withGaps != 0, gb);
+    }
+    if (0 != threadIdx.x) memset(&local, 0, sizeof(local));   // every lane counted the same events
+    flushCounters(local, counters);
+}
+
+__global__ __launch_bounds__(64) void k_finish_fragments(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, u32 nChunk, int withGaps,
+                                                         FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    Counters local; memset(&local, 0, sizeof(local));
+    if (t < nChunk)
+    {
+        const u32 cl = t;
+        const GappedResult *res = (withGaps && gb.base[cl] != 0xffffffffu) ? gb.results + gb.base[cl] : nullptr;
+        clusterFinishFragments(P, R, bcl, clusterBase + cl, withGaps != 0, res, work[t], frags[cl], local);
+    }
+    flushCounters(local, counters);
+}
+

@@ -1,0 +1,296 @@
+// kernels_rescue.hip: see kernels.h and DESIGN.md §4
+#include "kernels.h"
+
+__global__ __launch_bounds__(64) void k_plan_rescue(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk,
+                                                    const ClusterFragments *frags, RescueBuffers rb)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nChunk) return;
+    __attribute__((aligned(16))) u8 workBytes[TINY_WORK_BYTES];
+    TemplateWork work;
+    templateWorkBind(work, workBytes, tinyCaps());
+    Cand privateCands[2 * PRIVATE_CANDS];
+    // Every seeded candidate is an orphan at most once, so their number bounds the cluster's rescue problems: the slots are
+    // reserved first and the template logic runs once, writing the problems as it meets them (unused slots stay invalid)
+    const u32 reserve = frags[t].built ? frags[t].nCands[0] + frags[t].nCands[1] : 0;
+    u32 base = 0, n = 0;
+    if (reserve)
+    {
+        base = atomicAdd(rb.jobCounter, reserve);
+        if (base + reserve > rb.jobsCap)
+        {   // the cluster runs its rescues itself in the wave-per-cluster pass
+            base = 0xffffffffu;
+            n = clusterPlanRescue(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + t, t, frags[t], work, nullptr, privateCands);
+        }
+        else
+        {
+            RescueJob *jobs = rb.jobs + base;
+            n = clusterPlanRescue(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + t, t, frags[t], work, jobs, privateCands);
+            for (u32 i = n; i < reserve; ++i) { jobs[i].valid = 0; jobs[i].fallback = 0; jobs[i].nCands = 0; jobs[i].nGapped = 0; }
+            for (u32 i = 0; i < n; ++i)
+            {
+                if (!jobs[i].valid) continue;
+                const u32 words = (jobs[i].windowLen + P.readLength[jobs[i].shadowReadIndex] + 31) / 32;
+                if (words <= RW_LDS_BITMAP) continue;               // k_rescue_windows keeps short bitmaps in LDS
+                const u32 at = atomicAdd(rb.bitmapCounter, words);
+                if (at + words > rb.bitmapCap) jobs[i].fallback = 1; else { jobs[i].bitmapBase = at; jobs[i].bitmapWords = words; }
+            }
+        }
+    }
+    rb.jobBase[t] = base; rb.jobCount[t] = n;
+}
+
+
+// The bases of window positions [g, g + RW_PER_LANE + 6) for one lane: their 2-bit codes (position g in the low bits) and their
+// not-ACGT flags, from the packed copy of the reference.  g is an index into the concatenated contigs.
+struct WindowBits { u64 codes; u32 notBase; };
+__device__ inline WindowBits loadWindowBits(const DevReference &R, u64 g)
+{
+    WindowBits w;
+    g = g < R.totalBases ? g : R.totalBases;          // lanes past the end of a window that ends the reference: read the spare words
+    const u32 *pw = R.packedBases + (g >> 4);
+    const u32 shift = 2 * u32(g & 15);
+    const u64 lo = u64(pw[0]) | (u64(pw[1]) << 32);
+    w.codes = shift ? (lo >> shift) | (u64(pw[2]) << (64 - shift)) : lo;             // 2 * (RW_PER_LANE + 6) bits wanted, up to 30 shifted out
+    const u32 *pn = R.notBase + (g >> 5);
+    const u32 ns = u32(g & 31);
+    w.notBase = u32((u64(pn[0]) | (u64(pn[1]) << 32)) >> ns);
+    return w;
+}
+static_assert(2 * (RW_PER_LANE + 6) <= 64 && RW_PER_LANE + 6 <= 32, "a lane's window bases fit the two words loadWindowBits returns");
+
+// k_rescue_windows: one wave per rescue problem (ShadowAligner::findShadowCandidatePositions, ShadowAligner.cpp:53-112).
+// The mate's 7-mers go to an LDS hash table (first read position per k-mer).  The window is walked in tiles of 64 x RW_PER_LANE bases:
+// every lane takes RW_PER_LANE consecutive positions; with the reference 2 bits per base a 7-mer is a shift and a mask of the
+// lane's word (and seven zero bits of the not-ACGT map), and each one is looked up.  "Push unless equal to the previous hit's candidate" needs the previous hit in window order: inside a lane that is
+// sequential, across lanes one ballot + shuffle, across tiles a carried value.  Pushed candidates set bits in a bitmap
+// (LDS for ordinary windows, global for the long ones), whose ascending enumeration is the reference's sort + unique.
+template <bool LDS_BITMAP>
+__device__ inline void rescueWindowScan(const DevReference &R, const RescueJob &job, u64 windowBase, const WindowBits &firstTile, u32 L, const u32 *tab, u32 *bitmap, u32 lane, u32 &pushes)
+{
+    const i32 bias = i32(L) - 7;
+    const i32 lastStart = i32(job.windowLen) - 7;       // last valid k-mer start
+    i32 carry = 0; bool haveCarry = false;
+    for (i32 tile = 0; tile * RW_TILE <= lastStart; ++tile)
+    {
+        const i32 p0 = tile * RW_TILE + i32(lane) * i32(RW_PER_LANE);          // window position of this lane's first base
+        const WindowBits wb = tile ? loadWindowBits(R, windowBase + u64(p0)) : firstTile;
+        i32 cand[RW_PER_LANE]; u32 hitMask = 0;
+#pragma unroll
+        for (u32 k = 0; k < RW_PER_LANE; ++k)
+        {
+            const i32 p = p0 + i32(k);
+            cand[k] = 0;
+            if (p <= lastStart && !((wb.notBase >> k) & 0x7fu))
+            {
+                const u32 kmer = u32(wb.codes >> (2 * k)) & 0x3fffu;
+                u32 h = (kmer * 2654435761u) >> 23;
+                while (true)
+                {
+                    const u32 e = tab[h];
+                    if (e == KMER_EMPTY) break;
+                    if ((e >> 10) == kmer) { hitMask |= 1u << k; cand[k] = p - i32(e & 0x3ffu); break; }
+                    h = (h + 1) & (RW_TABLE - 1);
+                }
+            }
+        }
+        // previous hit in window order for this lane's first hit
+        i32 lastCand = 0;
+#pragma unroll
+        for (u32 k = 0; k < RW_PER_LANE; ++k) if (hitMask & (1u << k)) lastCand = cand[k];
+        const unsigned long long lanesWithHits = __ballot(hitMask != 0);
+        const unsigned long long below = lanesWithHits & ((1ull << lane) - 1ull);
+        const int prevLane = below ? 63 - __clzll(below) : 0;
+        const i32 prevCand = __shfl(lastCand, prevLane, 64);
+        bool havePrev = below ? true : haveCarry;
+        i32 prev = below ? prevCand : carry;
+        u32 localPushes = 0;
+#pragma unroll
+        for (u32 k = 0; k < RW_PER_LANE; ++k)
+            if (hitMask & (1u << k))
+            {
+                if (!havePrev || prev != cand[k])
+                {
+                    ++localPushes;
+                    const u32 bit = u32(cand[k] + bias);
+                    atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
+                }
+                prev = cand[k]; havePrev = true;
+            }
+        for (int o = 32; o > 0; o >>= 1) localPushes += __shfl_xor(localPushes, o, 64);
+        pushes += localPushes;
+        if (lanesWithHits) { carry = __shfl(lastCand, 63 - __clzll(lanesWithHits), 64); haveCarry = true; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReference R, u64 totalBases, const u8 *bcl, u32 clusterBase, RescueBuffers rb)
+{
+    __shared__ u32 tables[4][RW_TABLE];
+    __shared__ u32 ldsBitmaps[4][RW_LDS_BITMAP];
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 j = blockIdx.x * 4 + wave;
+    const u32 nJobs = imin(*rb.jobCounter, rb.jobsCap);
+    RescueJob job;
+    bool active = j < nJobs;
+    STAMP_BEGIN();
+    if (active) { job = rb.jobs[j]; active = job.valid && !job.fallback; }
+    STAMP(0);
+    u32 pushes = 0, total = 0, bitmapWords = 0, L = 0;
+    bool small = true;
+    u32 *bitmap = ldsBitmaps[wave];
+    if (active)
+    {
+        // the lane's bytes of the first window tile are requested now and used after the k-mer table is built: one memory
+        // latency instead of two in a row
+        const u64 windowBase = R.contigOffset[job.contigId] + u64(job.windowBegin);      // windowBegin >= 0 (planRescue)
+        const WindowBits firstTile = loadWindowBits(R, windowBase + lane * RW_PER_LANE);
+        u32 *tab = tables[wave];
+        for (u32 i = lane; i < RW_TABLE; i += 64) tab[i] = KMER_EMPTY;
+        const u32 r = job.shadowReadIndex;
+        L = P.readLength[r];
+        bitmapWords = (job.windowLen + L + 31) / 32;
+        small = bitmapWords <= RW_LDS_BITMAP;
+        if (!small) bitmap = rb.bitmaps + job.bitmapBase;
+        for (u32 i = lane; i < bitmapWords; i += 64) bitmap[i] = 0;
+        if (!small) __threadfence();
+        __builtin_amdgcn_wave_barrier();
+        STAMP(1);
+        // the mate's 7-mers: first read position of every k-mer (ShadowAligner::hashShadowKmers, :53-72)
+        ReadView read; read.bcl = bcl + u64(clusterBase + job.cluster) * P.clusterLength + P.readOffset[r]; read.length = L; read.endCyclesMasked = 0; read.firstCycle = 0;
+        const bool reverse = job.shadowReverse != 0;
+        for (u32 i = lane; i + 7 <= L; i += 64)
+        {
+            // the 7 BCL bytes of strand positions i .. i+6 sit in 7 consecutive bytes of the read either way: one 8-byte load
+            const u32 first = reverse ? L - 7 - i : i;           // lowest BCL index of the k-mer
+            u64 bytes = 0;
+            if (first + 8 <= L) memcpy(&bytes, read.bcl + first, 8);
+            else { memcpy(&bytes, read.bcl + L - 8, 8); bytes >>= 8 * (first + 8 - L); }
+            u32 kmer = 0; bool ok = true;
+#pragma unroll
+            for (u32 k = 0; k < 7; ++k)
+            {
+                // BCL byte -> the code the packed reference has for the same base of the strand (A 0, C 1, G 3, T 2); a byte without quality bits is an N (Read.cpp:56-69)
+                const u32 b = u32(bytes >> (8 * (reverse ? 6 - k : k))) & 0xffu;
+                const u32 base = (b & 3u) ^ (reverse ? 3u : 0u);
+                ok &= (b & 0xfcu) != 0; kmer |= (base ^ (base >> 1)) << (2 * k);             // base k of the k-mer at bits 2k, as loadWindowBits lays them out
+            }
+            if (!ok) continue;
+            const u32 val = (kmer << 10) | i;
+            u32 h = (kmer * 2654435761u) >> 23;
+            while (true)
+            {
+                const u32 old = atomicCAS(&tab[h], KMER_EMPTY, val);
+                if (old == KMER_EMPTY) break;
+                if ((old >> 10) == kmer) { atomicMin(&tab[h], val); break; }
+                h = (h + 1) & (RW_TABLE - 1);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        STAMP(2);
+        if (small) rescueWindowScan<true>(R, job, windowBase, firstTile, L, tab, ldsBitmaps[wave], lane, pushes);
+        else { rescueWindowScan<false>(R, job, windowBase, firstTile, L, tab, bitmap, lane, pushes); __threadfence(); }
+        STAMP(3);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the set bits in ascending order are the sorted unique candidate list: count them first
+        for (u32 w0 = 0; w0 < bitmapWords; w0 += 64)
+        {
+            const u32 w = w0 + lane;
+            const u32 word = w < bitmapWords ? (small ? bitmap[w] : __hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0u;
+            u32 c = u32(__popc(word));
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+            total += c;
+        }
+    }
+    STAMP(4);
+    if (!active) return;
+    bool fallback = pushes > SHADOW_POSITIONS_MAX;
+    if (fallback) total = 0;
+    // one allocation per problem from the block's region: the regions keep the atomics on different addresses, and the waves of
+    // a block stay independent of each other (no barrier: their windows differ in length)
+    u32 candBase = 0xffffffffu;
+    if (total)
+    {
+        if (lane == 0)
+        {
+            const u32 region = blockIdx.x % CAND_REGIONS;
+            const u32 at = atomicAdd(rb.candCounter + region, total);
+            if (at + total <= rb.candRegionSize) candBase = region * rb.candRegionSize + at;
+            else atomicMin(rb.candCounter + CAND_REGIONS + region, at);   // the region is full from here on: these problems fall back
+        }
+        candBase = __shfl(candBase, 0, 64);
+        if (candBase == 0xffffffffu) fallback = true;
+    }
+    STAMP(6);
+    if (!fallback && total)
+    {
+        const i32 bias = i32(L) - 7;
+        u32 running = 0;
+        for (u32 w0 = 0; w0 < bitmapWords; w0 += 64)
+        {
+            const u32 w = w0 + lane;
+            u32 word = w < bitmapWords ? (small ? bitmap[w] : __hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0u;
+            const u32 c = u32(__popc(word));
+            u32 incl = c;
+            for (u32 o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+            u32 at = candBase + running + incl - c;
+            while (word)
+            {
+                const u32 b = u32(__ffs(word)) - 1; word &= word - 1;
+                rb.candPositions[at] = i32(w * 32 + b) - bias; rb.candJob[at] = j; ++at;
+            }
+            running += __shfl(incl, 63, 64);
+        }
+    }
+    if (lane == 0)
+    {
+        RescueJob &out = rb.jobs[j];
+        out.pushes = pushes; out.fallback = fallback ? 1 : 0; out.candBase = (fallback || !total) ? 0 : candBase; out.nCands = fallback ? 0 : total;
+    }
+    STAMP(7);
+}
+
+__global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const ClusterFragments *frags, RescueBuffers rb, Counters *counters)
+{
+    ISAAC_STAGE_QUALITY_TABLES(Rg, R)
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    Counters local; memset(&local, 0, sizeof(local));
+    // slots in use: below the region's counter and below the first request the region could not serve
+    if (i < rb.candCap && i % rb.candRegionSize < imin(imin(rb.candCounter[i / rb.candRegionSize], rb.candCounter[CAND_REGIONS + i / rb.candRegionSize]), rb.candRegionSize))
+    {
+        const RescueJob &job = rb.jobs[rb.candJob[i]];
+        rescueAlignCandidate(P, R, bcl, clusterBase + job.cluster, frags[job.cluster], job, rb.candPositions[i], rb.shadowCands[i], rb.shadowCigars + u64(i) * 3);
+        ++local.ungappedScans;
+    }
+    flushCounters(local, counters);
+}
+
+// one thread per rescue problem: which of its aligned candidates get a gapped retry (ShadowAligner.cpp:232-262)
+__global__ __launch_bounds__(256) void k_rescue_gapped_plan(const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, Counters *counters)
+{
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 nJobs = imin(*rb.jobCounter, rb.jobsCap);
+    Counters local; memset(&local, 0, sizeof(local));
+    if (j < nJobs && rb.jobs[j].valid && !rb.jobs[j].fallback)
+    {
+        RescueJob &job = rb.jobs[j];
+        // the flat pass's rescue statistics are counted here, one wave reduction instead of one atomic per problem
+        ++local.rescueCalls; local.rescueWindowBases += job.windowLen; local.rescueCandidates += job.nCands;
+        summarizeRescueJob(job, rb.shadowCands, rb.candRank);
+        const u32 ecm = frags[job.cluster].endCyclesMasked[job.shadowReadIndex];
+        const u32 n = job.nGapped;      // counted by the summary pass; the candidates are walked again only to write the problems
+        u32 base = 0;
+        if (n)
+        {
+            base = atomicAdd(gb.counter, n);
+            if (base + n > gb.cap) base = 0xffffffffu;     // the cluster's thread runs them itself
+            else planRescueGapped(job, rb.shadowCands, rb.shadowCigars, ecm, gb.jobs + base);
+        }
+        job.gappedBase = base; job.nGapped = n;
+    }
+    flushCounters(local, counters);
+}
+

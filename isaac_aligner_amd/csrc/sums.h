@@ -74,6 +74,27 @@ ISAAC_HD bool uniqueSortedSum(SumKeys &k, u32 n, bool pairs, const SumGroup &g, 
 {
     sum = 0.0;
     if (!n) return true;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (!g.block && n <= g.lanes)
+    {   // one entry per lane: its place in the order is the number of entries before it, counted against every entry in turn (the
+        // LDS reads of entry j are the same address for all lanes); a fraction of the instructions of the network below
+        const u32 i = g.lane < n ? g.lane : 0;
+        const u64 p1 = k.pos1[i], p2 = k.pos2[i]; const double lp = k.lp[i]; const u32 o1 = k.obs1[i], o2 = k.obs2[i];
+        u32 rank = 0;
+        for (u32 j = 0; j < n; ++j)
+        {
+            const u64 q1 = k.pos1[j], q2 = k.pos2[j]; const double ql = k.lp[j]; const u32 r1 = k.obs1[j], r2 = k.obs2[j];
+            const bool lpBefore = pairs ? lp < ql : ql < lp;
+            const bool tail = r1 < o1 || (r1 == o1 && (r2 < o2 || (r2 == o2 && j < i)));
+            const bool mid = q2 < p2 || (q2 == p2 && (lpBefore || (ql == lp && tail)));
+            rank += (q1 < p1 || (q1 == p1 && mid)) ? 1u : 0u;
+        }
+        if (g.lane < n) k.idx[rank] = u16(i);
+        groupSync(g);
+    }
+    else
+#endif
+    {
     u32 m = 1; while (m < n) m <<= 1;
     for (u32 i = g.lane; i < m; i += g.lanes) k.idx[i] = i < n ? u16(i) : u16(0xffff);
     groupSync(g);
@@ -91,6 +112,7 @@ ISAAC_HD bool uniqueSortedSum(SumKeys &k, u32 n, bool pairs, const SumGroup &g, 
             }
             groupSync(g);
         }
+    }
     bool nearTie = false;
     for (u32 i = g.lane; i < n; i += g.lanes)
     {
@@ -109,7 +131,7 @@ ISAAC_HD bool uniqueSortedSum(SumKeys &k, u32 n, bool pairs, const SumGroup &g, 
 ISAAC_HD void sumKeyFromCand(SumKeys &k, u32 at, const Cand &c)
 { const ShadowProb p = makeShadowProb(c); k.pos1[at] = p.pos; k.pos2[at] = 0; k.lp[at] = p.logProbability; k.obs1[at] = u32(p.observedLength); k.obs2[at] = 0; }
 
-enum { SUMS_DONE = 0, SUMS_TOO_LARGE = 1, SUMS_RESIDUAL = 2 };
+enum { SUMS_DONE = 0, SUMS_TOO_LARGE = 1, SUMS_RESIDUAL = 2 /* a capacity of the flat pass was exceeded */, SUMS_NEAR_TIE = 3 };
 
 // what the flat rescue kernels left for one cluster
 struct SumInputs { RescueJob *jobs; u32 nJobs; const Cand *shadowCands; const u32 *candRank; const GappedResult *gappedResults; GappedJob *gappedJobs; };
@@ -202,7 +224,7 @@ ISAAC_HD u32 clusterSums(const DevParams &P, const ClusterFragments &f, const Su
         }
         for (u32 i = g.lane; i < nCands[1 - side]; i += g.lanes) sumKeyFromCand(k, base + i, f.cands[1 - side][i]);
         groupSync(g);
-        if (!uniqueSortedSum(k, base + nCands[1 - side], false, g, scratch, out.shadow[side])) return SUMS_RESIDUAL;
+        if (!uniqueSortedSum(k, base + nCands[1 - side], false, g, scratch, out.shadow[side])) return SUMS_NEAR_TIE;
     }
     if (bothReads)
     {   // sumUniquePairProbabilities: every orphan with every shadow it rescued, read 1's alignment first
@@ -223,7 +245,7 @@ ISAAC_HD u32 clusterSums(const DevParams &P, const ClusterFragments &f, const Su
             base += job.take;
         }
         groupSync(g);
-        if (!uniqueSortedSum(k, base, true, g, scratch, out.pair)) return SUMS_RESIDUAL;
+        if (!uniqueSortedSum(k, base, true, g, scratch, out.pair)) return SUMS_NEAR_TIE;
     }
     else
     {   // TemplateBuilder::rescueShadow's running sum over the shadow lists in list order: the best shadow of a successful rescue

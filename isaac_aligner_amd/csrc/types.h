@@ -154,7 +154,9 @@ enum { CLUSTER_OVERFLOW = 1,
 struct Counters
 {
     u64 clusters, probes, probeSteps, matches, candidates, ungappedScans, bswJobs, bswAccepted, simpleIndels,
-        rescueCalls, rescueWindowBases, rescueCandidates, rescueBsw, overflowClusters, mapqNearInteger, heavyClusters;
+        rescueCalls, rescueWindowBases, rescueCandidates, rescueBsw, overflowClusters, mapqNearInteger, heavyClusters,
+        // why clusters went to the wave-per-cluster pass (k_cluster_sums) and how many took the workgroup-per-cluster sums
+        residualCapacity, residualNearTie, residualOversize, largeSums;
 };
 
 // per-cluster facts TemplateLengthDistribution::addTemplate looks at (TemplateLengthStatistics.cpp:275-314)
