@@ -1057,7 +1057,7 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
     rb.shadowCigars = c->shadowCigars.p; rb.jobBase = c->jobBase.p; rb.jobCount = c->jobCount.p;
     rb.jobCounter = c->rescueCounters.p; rb.bitmapCounter = c->rescueCounters.p + 1; rb.candCounter = c->rescueCounters.p + 4;
     c->clusterSums.reserve(chunk); c->heavyList.reserve(chunk); c->largeList.reserve(chunk); c->hugeList.reserve(chunk); c->xlList.reserve(chunk); c->heavyCount.reserve(4); c->heavyFlag.reserve(chunk);
-    c->hugeKeys.reserve(size_t(SUMS_HUGE_BLOCKS) * SUMS_HUGE_CAP * 42);
+    c->hugeKeys.reserve(size_t(SUMS_HUGE_BLOCKS) * SUMS_HUGE_CAP * SUMS_HUGE_ENTRY);
     SumsBuffers sb; sb.sums = c->clusterSums.p; sb.residualFlag = c->heavyFlag.p; sb.residualList = c->heavyList.p; sb.residualCount = c->heavyCount.p;
     sb.largeList = c->largeList.p; sb.largeCount = c->heavyCount.p + 1; sb.hugeList = c->hugeList.p; sb.hugeCount = c->heavyCount.p + 2; sb.xlList = c->xlList.p; sb.xlCount = c->heavyCount.p + 3; sb.hugeKeys = c->hugeKeys.p;
     const DevReference R = c->ref();

@@ -93,6 +93,7 @@ static const u32 TINY_WORK_BYTES = 1024;
 // k_cluster_sums: the outcome of every rescue problem of a cluster and its probability sums (sums.h), one wavefront per cluster
 // with room for 64 list entries in LDS; clusters with longer lists are listed for the workgroup-per-cluster form (1024 entries),
 // and what neither can do (near ties, lists beyond that, capacity misses of the flat pass) for the wave-per-cluster pass.
+static const u32 SUMS_HUGE_ENTRY = 44;   // bytes per list entry of the HBM tier: the key arrays (42) + the second index array of the radix ordering
 // SUMS_XL_CAP is not a power of two: its index array is padded to the next one for the sorting network (SUMS_XL_LDS)
 static const u32 SUMS_XL_LDS = 3584 * 42 + (4096 - 3584) * 2;
 static const u32 SUMS_WAVE_CAP = 64, SUMS_BLOCK_CAP = 1024, SUMS_XL_CAP = 3584, SUMS_HUGE_CAP = 32768 /* heavyCaps().prob / .pair */, SUMS_HUGE_BLOCKS = 512;

@@ -30,7 +30,12 @@ ISAAC_HD void sumKeysBind(SumKeys &k, void *base, u32 cap)
 }
 
 // the lanes working on one cluster: one wavefront, or a whole workgroup (block = true)
-struct SumGroup { u32 lanes, lane; bool block; };
+// radix: work area of the radix ordering used for long lists (counts: 16 x lanes, totals: lanes, vary: 2, alt: as many entries as the
+// key arrays), or all NULL
+struct SumRadix { u16 *counts; u32 *totals; u64 *vary; u16 *alt; };
+// sumTile: LDS room for sumTileCap terms when the key arrays are not in LDS themselves (the final additions are a chain of
+// dependent loads otherwise), or NULL
+struct SumGroup { u32 lanes, lane; bool block; SumRadix radix; u32 radixMin; double *sumTile; u32 sumTileCap; };
 ISAAC_HD void groupSync(const SumGroup &g)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -69,11 +74,97 @@ ISAAC_HD bool sumKeyNearTie(const SumKeys &k, u32 a, u32 b) { return k.pos1[a] =
 ISAAC_HD bool sumKeyEqual(const SumKeys &k, u32 a, u32 b)
 { return k.pos1[a] == k.pos1[b] && k.pos2[a] == k.pos2[b] && lpEquals(k.lp[a], k.lp[b]) && k.obs1[a] == k.obs1[b] && k.obs2[a] == k.obs2[b]; }
 
+// what follows the positions in the total order
+ISAAC_HD bool sumKeyRestLess(const SumKeys &k, bool pairs, u32 a, u32 b)
+{
+    if (k.lp[a] != k.lp[b]) return pairs ? k.lp[b] < k.lp[a] : k.lp[a] < k.lp[b];
+    if (k.obs1[a] != k.obs1[b]) return k.obs1[a] < k.obs1[b];
+    if (k.obs2[a] != k.obs2[b]) return k.obs2[a] < k.obs2[b];
+    return a < b;
+}
+
+// The same order as the bitonic network of uniqueSortedSum for lists of thousands of entries: stable least-significant-digit radix
+// passes (4 bits, every lane a contiguous slice of the list, digit-major counts) over the two positions -- only over the nibbles that
+// differ inside the list, typically six to ten of the 32 -- then every entry finds its place inside its run of equal positions by
+// counting.  A few dozen passes with independent, mostly coalesced loads instead of 120 dependent exchange steps.
+// Returns the array that holds the order (k.idx or g.radix.alt).
+ISAAC_HD const u16 *radixOrder(SumKeys &k, u32 n, bool pairs, const SumGroup &g)
+{
+    const SumRadix &r = g.radix;
+    const u32 per = (n + g.lanes - 1) / g.lanes, begin = imin(n, g.lane * per), end = imin(n, begin + per);
+    u16 *src = k.idx, *dst = r.alt;
+    for (u32 i = begin; i < end; ++i) src[i] = u16(i);
+    if (0 == g.lane) { r.vary[0] = 0; r.vary[1] = 0; }
+    groupSync(g);
+    {   // bits that differ somewhere in the list
+        u64 v1 = 0, v2 = 0; const u64 f1 = k.pos1[0], f2 = k.pos2[0];
+        for (u32 i = begin; i < end; ++i) { v1 |= k.pos1[i] ^ f1; v2 |= k.pos2[i] ^ f2; }
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (v1) atomicOr(reinterpret_cast<unsigned long long *>(&r.vary[0]), (unsigned long long)v1);
+        if (v2) atomicOr(reinterpret_cast<unsigned long long *>(&r.vary[1]), (unsigned long long)v2);
+#else
+        r.vary[0] |= v1; r.vary[1] |= v2;
+#endif
+    }
+    groupSync(g);
+    for (u32 word = 0; word < 2; ++word)
+    {
+        const u64 *key = word ? k.pos1 : k.pos2;         // least significant key first
+        const u64 vary = r.vary[word ? 0 : 1];
+        for (u32 shift = 0; shift < 64; shift += 4)
+        {
+            if (!((vary >> shift) & 15)) continue;
+            for (u32 d = 0; d < 16; ++d) r.counts[d * g.lanes + g.lane] = 0;
+            for (u32 i = begin; i < end; ++i) ++r.counts[u32((key[src[i]] >> shift) & 15) * g.lanes + g.lane];
+            groupSync(g);
+            {   // exclusive prefix over the 16 x lanes counts, digit-major: a lane sums 16 consecutive ones, the lanes' sums are scanned in steps
+                u32 sum = 0;
+                for (u32 e = 0; e < 16; ++e) sum += r.counts[g.lane * 16 + e];
+                r.totals[g.lane] = sum;
+                groupSync(g);
+                for (u32 step = 1; step < g.lanes; step <<= 1)
+                {
+                    const u32 add = g.lane >= step ? r.totals[g.lane - step] : 0;
+                    groupSync(g);
+                    r.totals[g.lane] += add;
+                    groupSync(g);
+                }
+                u32 running = r.totals[g.lane] - sum;
+                for (u32 e = 0; e < 16; ++e) { const u32 c = r.counts[g.lane * 16 + e]; r.counts[g.lane * 16 + e] = u16(running); running += c; }
+            }
+            groupSync(g);
+            for (u32 i = begin; i < end; ++i) { const u16 e = src[i]; dst[r.counts[u32((key[e] >> shift) & 15) * g.lanes + g.lane]++] = e; }
+            groupSync(g);
+            u16 *t = src; src = dst; dst = t;
+        }
+    }
+    // inside a run of equal positions: the place of an entry is the number of the run's entries before it
+    for (u32 i = begin; i < end; ++i)
+    {
+        const u32 e = src[i];
+        const u64 p1 = k.pos1[e], p2 = k.pos2[e];
+        u32 lo = i; while (lo && k.pos1[src[lo - 1]] == p1 && k.pos2[src[lo - 1]] == p2) --lo;
+        u32 before = 0;
+        for (u32 j = lo; j < n; ++j)
+        {
+            const u32 o = src[j];
+            if (k.pos1[o] != p1 || k.pos2[o] != p2) break;
+            before += sumKeyRestLess(k, pairs, o, e) ? 1u : 0u;
+        }
+        dst[lo + before] = u16(e);
+    }
+    groupSync(g);
+    return dst;
+}
+
 // Sum of exp(lp) over the first element of every run of equal keys of entries [0, n), in sorted order.  false: a near tie.
 ISAAC_HD bool uniqueSortedSum(SumKeys &k, u32 n, bool pairs, const SumGroup &g, u32 *scratch, double &sum)
 {
     sum = 0.0;
     if (!n) return true;
+    const u16 *order = k.idx;
+    if (g.radix.counts && n >= g.radixMin) order = radixOrder(k, n, pairs, g);
+    else
 #if defined(__HIP_DEVICE_COMPILE__)
     if (!g.block && n <= g.lanes)
     {   // one entry per lane: its place in the order is the number of entries before it, counted against every entry in turn (the
@@ -116,13 +207,30 @@ ISAAC_HD bool uniqueSortedSum(SumKeys &k, u32 n, bool pairs, const SumGroup &g, 
     bool nearTie = false;
     for (u32 i = g.lane; i < n; i += g.lanes)
     {
-        const u32 cur = k.idx[i];
+        const u32 cur = order[i];
         bool dup = false;
-        if (i) { const u32 prev = k.idx[i - 1]; nearTie |= sumKeyNearTie(k, prev, cur); dup = sumKeyEqual(k, prev, cur); }
+        if (i) { const u32 prev = order[i - 1]; nearTie |= sumKeyNearTie(k, prev, cur); dup = sumKeyEqual(k, prev, cur); }
         k.term[i] = dup ? 0.0 : exp(k.lp[cur]);       // without near ties "equal to the first of the run" is "equal to the predecessor"; x + 0.0 == x
     }
     if (groupAny(g, nearTie, scratch)) return false;
     groupSync(g);
+    if (g.sumTile)
+    {   // the terms pass through LDS a tile at a time; the first wavefront adds them up, the others wait
+        double acc = 0.0;
+        for (u32 base = 0; base < n; base += g.sumTileCap)
+        {
+            const u32 m = imin(g.sumTileCap, n - base);
+            for (u32 i = g.lane; i < m; i += g.lanes) g.sumTile[i] = k.term[base + i];
+            groupSync(g);
+            if (g.lane < 64) for (u32 i = 0; i < m; ++i) acc += g.sumTile[i];
+            groupSync(g);
+        }
+        if (0 == g.lane) g.sumTile[0] = acc;
+        groupSync(g);
+        sum = g.sumTile[0];
+        groupSync(g);
+        return true;
+    }
     for (u32 i = 0; i < n; ++i) sum += k.term[i];     // the additions in sequence: their order is part of the result (every lane: same value)
     groupSync(g);
     return true;
@@ -263,7 +371,21 @@ ISAAC_HD u32 clusterSums(const DevParams &P, const ClusterFragments &f, const Su
         }
         groupSync(g);
         double sum = 0.0;
-        for (u32 i = 0; i < base; ++i) sum += k.term[i];
+        if (g.sumTile)
+        {
+            for (u32 b0 = 0; b0 < base; b0 += g.sumTileCap)
+            {
+                const u32 m = imin(g.sumTileCap, base - b0);
+                for (u32 i = g.lane; i < m; i += g.lanes) g.sumTile[i] = k.term[b0 + i];
+                groupSync(g);
+                if (g.lane < 64) for (u32 i = 0; i < m; ++i) sum += g.sumTile[i];
+                groupSync(g);
+            }
+            if (0 == g.lane) g.sumTile[0] = sum;
+            groupSync(g);
+            sum = g.sumTile[0];
+        }
+        else for (u32 i = 0; i < base; ++i) sum += k.term[i];
         out.ordered = sum;
         groupSync(g);
     }

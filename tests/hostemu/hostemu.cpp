@@ -24,7 +24,7 @@ struct Emu
     std::vector<double> logMatch, logMismatch;
     std::vector<ClusterFragments> frags;
     std::vector<Match> matches; std::vector<u64> matchOffsets;
-    Counters cnt; bool flatRescue = true; double *clusterTimes = nullptr; bool fastSort = true; u32 sumsCap = 0; std::vector<u32> dbgJobBase; std::vector<RescueJob> dbgJobs;
+    Counters cnt; bool flatRescue = true; double *clusterTimes = nullptr; bool fastSort = true; u32 sumsCap = 0; int sumsRadixMin = -1; std::vector<u32> dbgJobBase; std::vector<RescueJob> dbgJobs;
 };
 }
 
@@ -225,7 +225,10 @@ int emu_select(Emu *e, const u8 *bcl, u32 nClusters, u32 tile, const isaac_tls *
         in.gappedResults = gapped.data(); in.gappedJobs = gj.data(); in.candRank = candRank.data(); in.sums = 0;
         const auto t0 = std::chrono::steady_clock::now();
         SumInputs si; si.jobs = in.jobs; si.nJobs = in.jobCount; si.shadowCands = shadowCands.data(); si.candRank = candRank.data(); si.gappedResults = gapped.data(); si.gappedJobs = gj.data();
-        SumGroup g; g.lanes = 1; g.lane = 0; g.block = false;
+        SumGroup g; g.lanes = 1; g.lane = 0; g.block = false; g.radix = SumRadix{nullptr, nullptr, nullptr, nullptr}; g.radixMin = 0; g.sumTile = nullptr; g.sumTileCap = 0;
+        double sumTile[7]; if (e->sumsRadixMin >= 0) { g.sumTile = sumTile; g.sumTileCap = 7; }
+        u16 radixCounts[16]; u32 radixTotals[1]; u64 radixVary[2]; std::vector<u16> radixAlt(1024);
+        if (e->sumsRadixMin >= 0) { g.radix.counts = radixCounts; g.radix.totals = radixTotals; g.radix.vary = radixVary; g.radix.alt = radixAlt.data(); g.radixMin = u32(e->sumsRadixMin); }
         ClusterSums sums; u32 scratch = 0;
         bool residual = SUMS_DONE != clusterSums(e->P, e->frags[c], si, keys, g, &scratch, true, sums, e->cnt);
         CoopInputs coop; coop.lanes = 1; coop.lane = 0; coop.fastSort = false; coop.ldsSort = 0; coop.ldsSortCap = 0;
@@ -287,6 +290,7 @@ int emu_select_literal(Emu *e, const u8 *bcl, const LiteralFragment *f0, u32 n0,
 
 void emu_set_flat_rescue(Emu *e, int on) { e->flatRescue = on != 0; }
 void emu_set_fast_sort(Emu *e, int on) { e->fastSort = on != 0; }
+void emu_set_sums_radix(Emu *e, int minEntries) { e->sumsRadixMin = minEntries; }   // lists of at least this many entries are ordered by radixOrder (sums.h); -1: never
 void emu_set_sums_capacity(Emu *e, uint32_t cap) { e->sumsCap = cap > 1024 ? 1024 : cap; }   // entries of the probability-sum key arrays (k_cluster_sums tiers)
 void emu_set_cluster_times(Emu *e, double *t) { e->clusterTimes = t; }
 // debugging: out = { jobs, valid jobs, total candidates, max candidates, gapped retries, fallback jobs, total window bases }

@@ -146,8 +146,8 @@ def test_fragment_code_reproduces_reference_known_answers(oracle, emulib):
             check_fragment_builder_case(case, cands, cigars)
 
 
-@pytest.mark.parametrize("sums_cap", [1024, 24])
-def test_repeat_rich_reference_through_the_precomputed_sums(oracle, emulib, sums_cap):
+@pytest.mark.parametrize("sums_cap,radix_min", [(1024, -1), (24, -1), (1024, 0), (1024, 20)])
+def test_repeat_rich_reference_through_the_precomputed_sums(oracle, emulib, sums_cap, radix_min):
     """a small human-like reference (Alu / L1-like families, satellites, segmental duplications): clusters with dozens of seeded
     candidates and hundreds of rescued shadows go through the probability-sum stage (sums.h); with a small key capacity most of
     them take the wave-per-cluster route instead, and the records must not depend on the route"""
@@ -163,6 +163,7 @@ def test_repeat_rich_reference_through_the_precomputed_sums(oracle, emulib, sums
     emu = hostemu_lib.Emu(emulib, p, contigs, hits)
     emu.set_matches(matches, n)
     emulib.emu_set_sums_capacity(emu.h, C.c_uint32(sums_cap))
+    emulib.emu_set_sums_radix(emu.h, C.c_int(radix_min))        # the radix ordering of the HBM tier (device: lists beyond 3584 entries)
     otls = ref.determine_tls(p, bcl, matches, hits)
     etls = emu.determine_tls(bcl, n)
     assert otls.astuple() == etls.astuple()
