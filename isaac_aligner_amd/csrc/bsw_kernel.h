@@ -90,9 +90,11 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     u32 ret = 0;
-    if (k == 0)
     {
-        // end-cell scan (:349-379), traceback (:381-435), stripping of the terminal deletions (:437-453)
+        // end-cell scan (:349-379), traceback (:381-435), stripping of the terminal deletions (:437-453).  All 16 lanes of the group
+        // walk the traceback together (the same values in every lane; lane 0 does the stores): a stretch of ALIGN cells whose flags
+        // say "came from ALIGN" -- nearly all of a typical alignment -- is crossed 16 rows at a time, every lane looking at one row,
+        // instead of one dependent LDS read per row.
         const u32 first = n;
         int mx = s16(int(u16(endVals[15])) - 1);
         int ii = int(L) - 1, jj = ii; u32 maxType = 0;
@@ -102,11 +104,22 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
                 const int value = endVals[16 * type + lane];
                 if (value > mx) { mx = value; jj = lane; maxType = type; }
             }
-        u32 opLength = 0;
-#define ISAAC_BSW_PUSH(len, op) do { if (n < cap) cig[n++] = cigarOp(u32(len), op); else overflow = true; } while (0)
+        u32 opLength = 0, firstOp = 0, lastOp = 0;
+        const u32 groupShift = (threadIdx.x & 63u) & ~15u;
+#define ISAAC_BSW_PUSH(len, op) do { if (n < cap) { lastOp = cigarOp(u32(len), op); if (n == first) firstOp = lastOp; if (k == 0) cig[n] = lastOp; ++n; } else overflow = true; } while (0)
         if (jj > 0) ISAAC_BSW_PUSH(jj, OP_DELETE);
         while (ii >= 0 && jj >= 0 && jj <= 15)
         {
+            if (0 == maxType)
+            {
+                const int row = ii - int(k);
+                const bool stop = row < 0 || 0 != (T[row * 16 + jj] & 3);
+                const u32 mask = u32(__ballot(stop) >> groupShift) & 0xffffu;
+                const u32 run = mask ? u32(__ffs(int(mask))) - 1 : 16u;
+                opLength += run; ii -= int(run);
+                if (!mask) continue;
+                if (ii < 0) break;
+            }
             ++opLength;
             const u32 nextMaxType = (T[ii * 16 + jj] >> (2 * maxType)) & 3;
             if (nextMaxType != maxType) { ISAAC_BSW_PUSH(opLength, maxType == 0 ? OP_ALIGN : maxType == 1 ? OP_DELETE : OP_INSERT); opLength = 0; }
@@ -117,9 +130,10 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
         if (1 != maxType && opLength) { ISAAC_BSW_PUSH(opLength, maxType == 0 ? OP_ALIGN : OP_INSERT); opLength = 0; }
         if (15 > jj) { ISAAC_BSW_PUSH(opLength + 15 - u32(jj), OP_DELETE); opLength = 0; }
 #undef ISAAC_BSW_PUSH
-        if (n > first && OP_DELETE == cigarCode(cig[n - 1])) { ret = cigarLen(cig[n - 1]); --n; }
-        for (u32 lo = first, hi = n; lo + 1 < hi; ++lo) { --hi; const u32 tt = cig[lo]; cig[lo] = cig[hi]; cig[hi] = tt; }
-        if (n > first && OP_DELETE == cigarCode(cig[n - 1])) --n;
+        // the operations were pushed back to front: the last one is the alignment's leading deletion, the first one its trailing one
+        if (n > first && OP_DELETE == cigarCode(lastOp)) { ret = cigarLen(lastOp); --n; }
+        if (k == 0) for (u32 lo = first, hi = n; lo + 1 < hi; ++lo) { --hi; const u32 tt = cig[lo]; cig[lo] = cig[hi]; cig[hi] = tt; }
+        if (n > first && OP_DELETE == cigarCode(firstOp)) --n;
     }
     STAMP(56);
     // the group's LDS is reused by the next problem only after lane 0 is done with it
