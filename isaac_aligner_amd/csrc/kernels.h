@@ -114,7 +114,8 @@ __global__ __launch_bounds__(64) void k_finish_fragments(DevParams P, DevReferen
 __global__ __launch_bounds__(64) void k_plan_rescue(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk, const ClusterFragments *frags, RescueBuffers rb);
 __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReference R, u64 totalBases, const u8 *bcl, u32 clusterBase, RescueBuffers rb);
 __global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const ClusterFragments *frags, RescueBuffers rb, Counters *counters);
-__global__ __launch_bounds__(256) void k_rescue_gapped_plan(const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, Counters *counters);
+__global__ __launch_bounds__(256) void k_rescue_gapped_plan(const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, u32 *longList, u32 *longCount, Counters *counters);
+__global__ __launch_bounds__(256) void k_rescue_gapped_plan_long(const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, const u32 *longList, const u32 *longCount);
 __global__ __launch_bounds__(256) void k_cluster_sums(DevParams P, const ClusterFragments *frags, u32 nChunk, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);
 __global__ __launch_bounds__(256) void k_cluster_sums_large(DevParams P, const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);
 __global__ __launch_bounds__(1024) void k_cluster_sums_xl(DevParams P, const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);

@@ -123,17 +123,12 @@ __device__ inline void rescueWindowScan(const DevReference &R, const RescueJob &
     }
 }
 
-__global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReference R, u64 totalBases, const u8 *bcl, u32 clusterBase, RescueBuffers rb)
+__device__ inline void rescueWindowsOfJob(const DevParams &P, const DevReference &R, const u8 *bcl, u32 clusterBase, const RescueBuffers &rb, u32 j, u32 (*tables)[RW_TABLE], u32 (*ldsBitmaps)[RW_LDS_BITMAP],
+                                          u32 wave, u32 lane)
 {
-    __shared__ u32 tables[4][RW_TABLE];
-    __shared__ u32 ldsBitmaps[4][RW_LDS_BITMAP];
-    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const u32 j = blockIdx.x * 4 + wave;
-    const u32 nJobs = imin(*rb.jobCounter, rb.jobsCap);
-    RescueJob job;
-    bool active = j < nJobs;
+    RescueJob job = rb.jobs[j];
+    bool active = job.valid && !job.fallback;
     STAMP_BEGIN();
-    if (active) { job = rb.jobs[j]; active = job.valid && !job.fallback; }
     STAMP(0);
     u32 pushes = 0, total = 0, bitmapWords = 0, L = 0;
     bool small = true;
@@ -253,6 +248,22 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
     STAMP(7);
 }
 
+// One wavefront per problem slot (two slots in three are empty: they are reserved per seeded candidate, see k_plan_rescue).  A resident
+// grid of 16 K wavefronts striding over the slots was measured slower (8.0 against 6.4 ms per 1 M clusters): the windows differ in
+// length and the hardware's own wave scheduling balances them better.  The loop stays so that any grid size is correct.
+__global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReference R, u64 totalBases, const u8 *bcl, u32 clusterBase, RescueBuffers rb)
+{
+    __shared__ u32 tables[4][RW_TABLE];
+    __shared__ u32 ldsBitmaps[4][RW_LDS_BITMAP];
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 nJobs = imin(*rb.jobCounter, rb.jobsCap);
+    for (u32 j = blockIdx.x * 4 + wave; j < nJobs; j += gridDim.x * 4)
+    {
+        rescueWindowsOfJob(P, R, bcl, clusterBase, rb, j, tables, ldsBitmaps, wave, lane);
+        __builtin_amdgcn_wave_barrier();      // the wave's table and bitmap are rewritten by its next problem
+    }
+}
+
 __global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const ClusterFragments *frags, RescueBuffers rb, Counters *counters)
 {
     ISAAC_STAGE_QUALITY_TABLES(Rg, R)
@@ -268,8 +279,11 @@ __global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference 
     flushCounters(local, counters);
 }
 
-// one thread per rescue problem: which of its aligned candidates get a gapped retry (ShadowAligner.cpp:232-262)
-__global__ __launch_bounds__(256) void k_rescue_gapped_plan(const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, Counters *counters)
+// one thread per rescue problem: which of its aligned candidates get a gapped retry (ShadowAligner.cpp:232-262).  Problems with
+// long candidate lists (repeat families: thousands of entries) would keep one thread walking them long after the rest of the
+// grid has finished; they are listed for k_rescue_gapped_plan_long instead.
+static const u32 GAPPED_PLAN_LONG = 48;
+__global__ __launch_bounds__(256) void k_rescue_gapped_plan(const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, u32 *longList, u32 *longCount, Counters *counters)
 {
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     const u32 nJobs = imin(*rb.jobCounter, rb.jobsCap);
@@ -279,18 +293,107 @@ __global__ __launch_bounds__(256) void k_rescue_gapped_plan(const ClusterFragmen
         RescueJob &job = rb.jobs[j];
         // the flat pass's rescue statistics are counted here, one wave reduction instead of one atomic per problem
         ++local.rescueCalls; local.rescueWindowBases += job.windowLen; local.rescueCandidates += job.nCands;
-        summarizeRescueJob(job, rb.shadowCands, rb.candRank);
-        const u32 ecm = frags[job.cluster].endCyclesMasked[job.shadowReadIndex];
-        const u32 n = job.nGapped;      // counted by the summary pass; the candidates are walked again only to write the problems
-        u32 base = 0;
-        if (n)
+        if (job.nCands > GAPPED_PLAN_LONG) longList[atomicAdd(longCount, 1u)] = j;
+        else
         {
-            base = atomicAdd(gb.counter, n);
-            if (base + n > gb.cap) base = 0xffffffffu;     // the cluster's thread runs them itself
-            else planRescueGapped(job, rb.shadowCands, rb.shadowCigars, ecm, gb.jobs + base);
+            summarizeRescueJob(job, rb.shadowCands, rb.candRank);
+            const u32 ecm = frags[job.cluster].endCyclesMasked[job.shadowReadIndex];
+            const u32 n = job.nGapped;      // counted by the summary pass; the candidates are walked again only to write the problems
+            u32 base = 0;
+            if (n)
+            {
+                base = atomicAdd(gb.counter, n);
+                if (base + n > gb.cap) base = 0xffffffffu;     // the cluster's thread runs them itself
+                else planRescueGapped(job, rb.shadowCands, rb.shadowCigars, ecm, gb.jobs + base);
+            }
+            job.gappedBase = base; job.nGapped = n;
         }
-        job.gappedBase = base; job.nGapped = n;
     }
     flushCounters(local, counters);
 }
 
+// value of lane `k` (the same k in every lane)
+__device__ inline u32 laneValue(u32 v, int k) { return u32(__builtin_amdgcn_readlane(int(v), k)); }
+__device__ inline u64 laneValue(u64 v, int k) { return u64(laneValue(u32(v), k)) | (u64(laneValue(u32(v >> 32), k)) << 32); }
+__device__ inline double laneValue(double v, int k) { return __longlong_as_double((long long)laneValue(u64(__double_as_longlong(v)), k)); }
+
+// summarizeRescueJob + planRescueGapped (template.h) by one wavefront: 64 candidates are fetched at a time, the statements that
+// depend on the order of the list run over register values instead of one memory round trip per candidate.
+__global__ __launch_bounds__(256) void k_rescue_gapped_plan_long(const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, const u32 *longList, const u32 *longCount)
+{
+    const u32 lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
+    const u32 nLong = *longCount;
+    const u64 below = (1ull << lane) - 1ull;
+    for (u32 t = wave; t < nLong; t += nWaves)
+    {
+        RescueJob &job = rb.jobs[longList[t]];
+        const Cand *cands = rb.shadowCands + job.candBase;
+        // ---- summarizeRescueJob
+        u32 n = 0; i32 best = -1; u32 bestRank = 0, bestMismatches = 0; bool last = false; double bestLp = 0.0;
+        u32 nClose = 0; i64 prevPosition = 0; u32 prevMismatches = 0;
+        for (u32 c0 = 0; c0 < job.nCands; c0 += 64)
+        {
+            const u32 c = c0 + lane; const bool in = c < job.nCands;
+            double lp = 0.0; i64 position = 0; u32 mismatches = 0; bool aligned = false;
+            if (in) { const Cand &f = cands[c]; lp = f.logProbability; position = f.position; mismatches = f.mismatchCount; aligned = candAligned(f); }
+            const u64 mask = __ballot(aligned);
+            if (in) rb.candRank[job.candBase + c] = n + u32(__popcll(mask & below));
+            for (u64 m = mask; m; m &= m - 1)
+            {
+                const int k = __ffsll((long long)m) - 1;
+                const double lpk = laneValue(lp, k); const i64 pk = i64(laneValue(u64(position), k)); const u32 mk = laneValue(mismatches, k);
+                if (best < 0 || lpLess(bestLp, lpk)) { best = i32(c0) + k; bestRank = n; bestLp = lpk; bestMismatches = mk; }
+                if (n && pk - prevPosition < i64(BSW_DISTANCE_CUTOFF) && BSW_MISMATCHES_CUTOFF < prevMismatches) ++nClose;
+                prevPosition = pk; prevMismatches = mk; ++n;
+            }
+            if (c0 + 64 >= job.nCands) last = 0 != ((mask >> (job.nCands - 1 - c0)) & 1);
+        }
+        const u32 nGapped = (best >= 0 && BSW_MISMATCHES_CUTOFF < bestMismatches) ? nClose : 0;
+        // ---- planRescueGapped: every aligned candidate with its aligned predecessor
+        u32 base = 0;
+        if (nGapped)
+        {
+            if (0 == lane) base = atomicAdd(gb.counter, nGapped);
+            base = laneValue(base, 0);
+            if (base + nGapped > gb.cap) base = 0xffffffffu;
+        }
+        if (nGapped && 0xffffffffu != base)
+        {
+            const u32 ecm = frags[job.cluster].endCyclesMasked[job.shadowReadIndex];
+            u32 emitted = 0; bool havePrev = false; u32 carryC = 0; i64 carryPosition = 0; u32 carryMismatches = 0;
+            for (u32 c0 = 0; c0 < job.nCands; c0 += 64)
+            {
+                const u32 c = c0 + lane; const bool in = c < job.nCands;
+                i64 position = 0; u32 mismatches = 0; bool aligned = false;
+                if (in) { const Cand &f = cands[c]; position = f.position; mismatches = f.mismatchCount; aligned = candAligned(f); }
+                const u64 mask = __ballot(aligned);
+                const u64 before = mask & below;
+                const int pl = before ? 63 - __clzll((long long)before) : 0;
+                const i64 shiftedPosition = i64(__shfl(position, pl, 64)); const u32 shiftedMismatches = __shfl(mismatches, pl, 64);
+                const bool mine = before ? true : havePrev;
+                const u32 prevC = before ? c0 + u32(pl) : carryC;
+                const i64 pPosition = before ? shiftedPosition : carryPosition; const u32 pMismatches = before ? shiftedMismatches : carryMismatches;
+                const bool flag = aligned && mine && position - pPosition < i64(BSW_DISTANCE_CUTOFF) && BSW_MISMATCHES_CUTOFF < pMismatches;
+                const u64 fmask = __ballot(flag);
+                if (flag)
+                {
+                    GappedJob &g = gb.jobs[base + emitted + u32(__popcll(fmask & below))];
+                    g.in = cands[prevC]; g.cluster = job.cluster; g.endCyclesMasked = ecm; g.tag = job.candBase + prevC; g.pad = 0;
+                    g.in.cigarOffset = 0;
+                    g.in.position = candUnclippedPosition(g.in, rb.shadowCigars + u64(job.candBase + prevC) * 3); g.in.cigarLength = 0;
+                }
+                emitted += u32(__popcll(fmask));
+                if (mask)
+                {
+                    const int hi = 63 - __clzll((long long)mask);
+                    havePrev = true; carryC = c0 + u32(hi); carryPosition = i64(laneValue(u64(position), hi)); carryMismatches = laneValue(mismatches, hi);
+                }
+            }
+        }
+        if (0 == lane)
+        {
+            job.nAligned = n; job.bestRank = bestRank; job.bestSlot = best < 0 ? 0 : job.candBase + u32(best); job.lastAligned = last ? 1 : 0;
+            job.gappedBase = base; job.nGapped = nGapped;
+        }
+    }
+}
