@@ -6,11 +6,14 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "build")
-LIB = os.path.join(HERE, "libisaac_gpu.so")
+# ISAAC_GPU_BUILD_TAG / ISAAC_GPU_BUILD_FLAGS: a variant of the library for A/B measurements (libisaac_gpu_<tag>.so, extra -D flags);
+# gpu.load_library() takes it through ISAAC_GPU_LIBRARY
+TAG = os.environ.get("ISAAC_GPU_BUILD_TAG", "")
+OBJ = os.path.join(HERE, "build" + ("_" + TAG if TAG else ""))
+LIB = os.path.join(HERE, "libisaac_gpu%s.so" % ("_" + TAG if TAG else ""))
 # -amdgpu-function-calls=false: everything is inlined into the kernels, so that their occupancy targets
 # (amdgpu_waves_per_eu in kernels.h) bind the whole call tree and not just the kernel body
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-value", "-mllvm", "-amdgpu-function-calls=false", "-I", CSRC]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-value", "-mllvm", "-amdgpu-function-calls=false", "-I", CSRC] + os.environ.get("ISAAC_GPU_BUILD_FLAGS", "").split()
 
 
 def units():

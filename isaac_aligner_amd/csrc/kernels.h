@@ -9,7 +9,10 @@
 
 // occupancy targets (waves per SIMD) of the two thread-per-cluster kernels; the register allocator spills to meet them
 #ifndef ISAAC_SELECT_WAVES
-#define ISAAC_SELECT_WAVES 4
+#define ISAAC_SELECT_WAVES 6
+#endif
+#ifndef ISAAC_PLAN_WAVES
+#define ISAAC_PLAN_WAVES 6
 #endif
 #ifndef ISAAC_FRAGMENT_WAVES
 #define ISAAC_FRAGMENT_WAVES 6
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256) void k_align_candidates(DevParams P, DevRefere
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_finish_candidates(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, u32 nChunk, int withGaps, u32 *indelList, u32 *indelCount, FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters);
 __global__ __launch_bounds__(64) void k_indel_fragments(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, int withGaps, const u32 *indelList, const u32 *indelCount, FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters);
 __global__ __launch_bounds__(64) void k_finish_fragments(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, u32 nChunk, int withGaps, FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters);
-__global__ __launch_bounds__(64) void k_plan_rescue(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk, const ClusterFragments *frags, RescueBuffers rb);
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_PLAN_WAVES))) void k_plan_rescue(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk, const ClusterFragments *frags, RescueBuffers rb);
 __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReference R, u64 totalBases, const u8 *bcl, u32 clusterBase, RescueBuffers rb);
 __global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const ClusterFragments *frags, RescueBuffers rb, Counters *counters);
 __global__ __launch_bounds__(256) void k_rescue_gapped_plan(const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, u32 *longList, u32 *longCount, Counters *counters);

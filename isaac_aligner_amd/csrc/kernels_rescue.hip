@@ -1,7 +1,7 @@
 // kernels_rescue.hip: see kernels.h and DESIGN.md §4
 #include "kernels.h"
 
-__global__ __launch_bounds__(64) void k_plan_rescue(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_PLAN_WAVES))) void k_plan_rescue(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk,
                                                     const ClusterFragments *frags, RescueBuffers rb)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
