@@ -123,12 +123,20 @@ __device__ inline void rescueWindowScan(const DevReference &R, const RescueJob &
     }
 }
 
-__device__ inline void rescueWindowsOfJob(const DevParams &P, const DevReference &R, const u8 *bcl, u32 clusterBase, const RescueBuffers &rb, u32 j, u32 (*tables)[RW_TABLE], u32 (*ldsBitmaps)[RW_LDS_BITMAP],
-                                          u32 wave, u32 lane)
+// (A resident grid of 16 K wavefronts striding over the problem slots -- two slots in three are empty, they are reserved per seeded
+// candidate -- was measured slower, 8.0 against 6.4 ms per 1 M clusters: the windows differ in length and the hardware's own wave
+// scheduling balances them better.)
+__global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReference R, u64 totalBases, const u8 *bcl, u32 clusterBase, RescueBuffers rb)
 {
-    RescueJob job = rb.jobs[j];
-    bool active = job.valid && !job.fallback;
+    __shared__ u32 tables[4][RW_TABLE];
+    __shared__ u32 ldsBitmaps[4][RW_LDS_BITMAP];
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 j = blockIdx.x * 4 + wave;
+    const u32 nJobs = imin(*rb.jobCounter, rb.jobsCap);
+    RescueJob job;
+    bool active = j < nJobs;
     STAMP_BEGIN();
+    if (active) { job = rb.jobs[j]; active = job.valid && !job.fallback; }
     STAMP(0);
     u32 pushes = 0, total = 0, bitmapWords = 0, L = 0;
     bool small = true;
@@ -246,22 +254,6 @@ __device__ inline void rescueWindowsOfJob(const DevParams &P, const DevReference
         out.pushes = pushes; out.fallback = fallback ? 1 : 0; out.candBase = (fallback || !total) ? 0 : candBase; out.nCands = fallback ? 0 : total;
     }
     STAMP(7);
-}
-
-// One wavefront per problem slot (two slots in three are empty: they are reserved per seeded candidate, see k_plan_rescue).  A resident
-// grid of 16 K wavefronts striding over the slots was measured slower (8.0 against 6.4 ms per 1 M clusters): the windows differ in
-// length and the hardware's own wave scheduling balances them better.  The loop stays so that any grid size is correct.
-__global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReference R, u64 totalBases, const u8 *bcl, u32 clusterBase, RescueBuffers rb)
-{
-    __shared__ u32 tables[4][RW_TABLE];
-    __shared__ u32 ldsBitmaps[4][RW_LDS_BITMAP];
-    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const u32 nJobs = imin(*rb.jobCounter, rb.jobsCap);
-    for (u32 j = blockIdx.x * 4 + wave; j < nJobs; j += gridDim.x * 4)
-    {
-        rescueWindowsOfJob(P, R, bcl, clusterBase, rb, j, tables, ldsBitmaps, wave, lane);
-        __builtin_amdgcn_wave_barrier();      // the wave's table and bitmap are rewritten by its next problem
-    }
 }
 
 __global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const ClusterFragments *frags, RescueBuffers rb, Counters *counters)

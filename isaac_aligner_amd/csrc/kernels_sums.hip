@@ -8,9 +8,116 @@ __device__ inline SumInputs sumInputs(const RescueBuffers &rb, u32 t, const Gapp
 }
 __device__ inline void markResidual(const SumsBuffers &sb, u32 t) { sb.residualFlag[t] = 1; sb.residualList[atomicAdd(sb.residualCount, 1u)] = t; }
 
+// clusterSums (sums.h) for one wavefront and lists of at most 64 entries, arranged for latency instead of generality: lane j
+// finishes rescue problem j (the problems' memory round trips overlap), every rescued shadow is fetched once into a table in
+// LDS, and the three lists are assembled from that table.  The orders, the near-tie rule and the sums are uniqueSortedSum's.
+struct ShadowTable { u64 *pos; double *lp; u32 *obs; u8 *job; };      // SUMS_WAVE_CAP entries each, in LDS
+
+__device__ inline u32 clusterSumsWave(const DevParams &P, const ClusterFragments &f, const SumInputs &in, SumKeys &k, const ShadowTable &tab, const SumGroup &g, ClusterSums &out, Counters &cnt)
+{
+    const u32 lane = g.lane, nJobs = in.nJobs;
+    if (nJobs > 64) return clusterSums(P, f, in, k, g, nullptr, true, out, cnt);
+    out.shadow[0] = out.shadow[1] = out.pair = out.ordered = 0.0;
+    // the rescue problems, one per lane
+    u32 take = 0, side = 0, best = 0, rescued = 0, nGapped = 0, gappedBase = 0, candBase = 0, nCands = 0, retries = 0;
+    bool ok = true; double orphanLp = 0.0; ShadowProb orphan; orphan.pos = 0; orphan.logProbability = 0.0; orphan.observedLength = 0;
+    if (lane < nJobs)
+    {
+        RescueJob &job = in.jobs[lane];
+        ok = finishRescueFlat(P, job, in, retries);
+        take = job.take; side = (job.shadowReadIndex + 1u) % 2; rescued = job.rescued; best = job.rescued ? job.finalBestRank : 0;
+        nGapped = job.nGapped; gappedBase = job.gappedBase; candBase = job.candBase; nCands = job.nCands;
+        if (take) { const Cand &o = f.cands[side][job.orphanListIndex]; orphan = makeShadowProb(o); orphanLp = o.logProbability; }
+    }
+    if (__any(!ok)) return SUMS_RESIDUAL;
+    cnt.rescueBsw += retries;
+    u32 incl = take;
+    for (u32 o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    const u32 base = incl - take, total = __shfl(incl, 63, 64);
+    u32 side0 = side ? 0 : take;
+    for (int o = 32; o > 0; o >>= 1) side0 += __shfl_xor(side0, o, 64);
+    const u32 nSeeded[2] = { f.nCands[0], f.nCands[1] };
+    const u32 shadows[2] = { side0, total - side0 };
+    if (shadows[0] + nSeeded[1] > k.cap || shadows[1] + nSeeded[0] > k.cap || total > k.cap) return SUMS_TOO_LARGE;
+    // every shadow once: entry base + rank of its problem (the problems of read 1's orphans come first: TemplateBuilder.cpp:737-757)
+    for (u32 j = 0; j < nJobs; ++j)
+    {
+        const u32 tj = __shfl(take, j, 64);
+        if (!tj) continue;
+        const u32 cb = __shfl(candBase, j, 64), nc = __shfl(nCands, j, 64), bj = __shfl(base, j, 64);
+        for (u32 c = lane; c < nc; c += 64)
+        {
+            const Cand &cand = in.shadowCands[cb + c];
+            if (!candAligned(cand)) continue;
+            const u32 r = in.candRank[cb + c];
+            if (r >= tj) continue;
+            const ShadowProb p = makeShadowProb(cand);
+            tab.pos[bj + r] = p.pos; tab.lp[bj + r] = p.logProbability; tab.obs[bj + r] = u32(p.observedLength); tab.job[bj + r] = u8(j);
+        }
+        const u32 ng = __shfl(nGapped, j, 64);
+        if (__shfl(rescued, j, 64) && ng)
+        {
+            groupSync(g);                                         // the accepted retries replace what the loop above wrote
+            const u32 gbase = __shfl(gappedBase, j, 64);
+            for (u32 kk = lane; kk < ng; kk += 64)
+            {
+                // GappedJob::pad was written a moment ago by the problem's lane: the rule is evaluated again rather than read through memory
+                const u32 slot = in.gappedJobs[gbase + kk].tag;
+                if (!gappedRetryAccepted(P, in.shadowCands[slot], in.gappedResults[gbase + kk])) continue;
+                const u32 r = in.candRank[slot];
+                if (r >= tj) continue;
+                const ShadowProb p = makeShadowProb(in.gappedResults[gbase + kk].out);
+                tab.pos[bj + r] = p.pos; tab.lp[bj + r] = p.logProbability; tab.obs[bj + r] = u32(p.observedLength);
+            }
+        }
+    }
+    groupSync(g);
+    // sumUniqueShadowProbabilities of either side: its shadows (a contiguous stretch of the table) + the seeded candidates of the other read
+    for (u32 s = 0; s < 2; ++s)
+    {
+        const u32 first = s ? shadows[0] : 0, n = shadows[s] + nSeeded[1 - s];
+        if (lane < shadows[s]) { k.pos1[lane] = tab.pos[first + lane]; k.pos2[lane] = 0; k.lp[lane] = tab.lp[first + lane]; k.obs1[lane] = tab.obs[first + lane]; k.obs2[lane] = 0; }
+        else if (lane < n) sumKeyFromCand(k, lane, f.cands[1 - s][lane - shadows[s]]);
+        groupSync(g);
+        if (!uniqueSortedSum(k, n, false, g, nullptr, out.shadow[s])) return SUMS_NEAR_TIE;
+    }
+    const u32 myJob = lane < total ? tab.job[lane] : 0;
+    if (nSeeded[0] && nSeeded[1])
+    {   // sumUniquePairProbabilities: every orphan with every shadow it rescued, read 1's alignment first
+        const u64 oPos = __shfl(orphan.pos, myJob, 64); const double oLp = __shfl(orphan.logProbability, myJob, 64);
+        const u32 oObs = __shfl(u32(orphan.observedLength), myJob, 64), oSide = __shfl(side, myJob, 64);
+        if (lane < total)
+        {
+            const u64 sPos = tab.pos[lane]; const double sLp = tab.lp[lane]; const u32 sObs = tab.obs[lane];
+            k.pos1[lane] = oSide ? sPos : oPos; k.pos2[lane] = oSide ? oPos : sPos;
+            k.lp[lane] = oSide ? sLp + oLp : oLp + sLp;
+            k.obs1[lane] = oSide ? sObs : oObs; k.obs2[lane] = oSide ? oObs : sObs;
+        }
+        groupSync(g);
+        if (!uniqueSortedSum(k, total, true, g, nullptr, out.pair)) return SUMS_NEAR_TIE;
+    }
+    else
+    {   // TemplateBuilder::rescueShadow's running sum in list order: the best shadow of a successful rescue has changed places with the first
+        const double oLp = __shfl(orphanLp, myJob, 64);
+        const u32 jBase = __shfl(base, myJob, 64), jBest = __shfl(best, myJob, 64);
+        if (lane < total)
+        {
+            const u32 r = lane - jBase;
+            k.term[jBase + (r == jBest ? 0 : 0 == r ? jBest : r)] = exp(oLp + tab.lp[lane]);
+        }
+        groupSync(g);
+        double sum = 0.0;
+        for (u32 i = 0; i < total; ++i) sum += k.term[i];
+        out.ordered = sum;
+        groupSync(g);
+    }
+    return SUMS_DONE;
+}
+
 __global__ __launch_bounds__(256) void k_cluster_sums(DevParams P, const ClusterFragments *frags, u32 nChunk, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters)
 {
     __shared__ __align__(16) u8 keyBytes[4][SUMS_WAVE_CAP * 42];
+    __shared__ u64 tabPos[4][SUMS_WAVE_CAP]; __shared__ double tabLp[4][SUMS_WAVE_CAP]; __shared__ u32 tabObs[4][SUMS_WAVE_CAP]; __shared__ u8 tabJob[4][SUMS_WAVE_CAP];
     static_assert(SUMS_WAVE_CAP * 42 % 16 == 0, "key arrays stay aligned");
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 t = blockIdx.x * 4 + wave;
@@ -23,7 +130,13 @@ __global__ __launch_bounds__(256) void k_cluster_sums(DevParams P, const Cluster
             SumKeys keys; sumKeysBind(keys, keyBytes[wave], SUMS_WAVE_CAP);
             SumGroup g; g.lanes = 64; g.lane = lane; g.block = false; g.radix = SumRadix{nullptr, nullptr, nullptr, nullptr}; g.radixMin = 0; g.sumTile = nullptr; g.sumTileCap = 0;
             ClusterSums out;
+            ShadowTable tab; tab.pos = tabPos[wave]; tab.lp = tabLp[wave]; tab.obs = tabObs[wave]; tab.job = tabJob[wave];
+#if defined(ISAAC_SUMS_GENERIC_WAVE)      // A/B aid: the general form of sums.h on the wavefront
+            (void)tab;
             const u32 status = clusterSums(P, frags[t], sumInputs(rb, t, gb), keys, g, nullptr, true, out, local);
+#else
+            const u32 status = clusterSumsWave(P, frags[t], sumInputs(rb, t, gb), keys, tab, g, out, local);
+#endif
             if (0 == lane)
             {
                 if (SUMS_DONE == status) sb.sums[t] = out;

@@ -244,6 +244,14 @@ enum { SUMS_DONE = 0, SUMS_TOO_LARGE = 1, SUMS_RESIDUAL = 2 /* a capacity of the
 // what the flat rescue kernels left for one cluster
 struct SumInputs { RescueJob *jobs; u32 nJobs; const Cand *shadowCands; const u32 *candRank; const GappedResult *gappedResults; GappedJob *gappedJobs; };
 
+// the accept rule of ShadowAligner.cpp:243-262 for the gapped retry `g` of the shadow `fragment`
+ISAAC_HD bool gappedRetryAccepted(const DevParams &P, const Cand &fragment, const GappedResult &g)
+{
+    const Cand &tmp = g.out;
+    return 0xffffffffu != g.nCigar && g.matchCount && g.matchCount + BSW_WIDEST_GAP_SIZE > candObservedLength(fragment) && (tmp.mismatchCount <= P.gappedMismatchesMax) &&
+           (fragment.mismatchCount > tmp.mismatchCount) && lpLess(fragment.logProbability, tmp.logProbability);
+}
+
 // second half of ShadowAligner::rescueShadow (ShadowAligner.cpp:232-291) for one problem, on numbers only: how long the list is,
 // whether the call succeeds, which retries are accepted (GappedJob::pad = 1) and which shadow ends up in front.  false: the
 // wave-per-cluster pass has to do it (a capacity of the flat pass was exceeded).
@@ -267,8 +275,7 @@ ISAAC_HD bool finishRescueFlat(const DevParams &P, RescueJob &job, const SumInpu
         gj.pad = 0;
         if (0xffffffffu == g.nCigar) return false;        // CIGAR longer than the result record holds
         const Cand &tmp = g.out;
-        if (g.matchCount && g.matchCount + BSW_WIDEST_GAP_SIZE > candObservedLength(fragment) && (tmp.mismatchCount <= P.gappedMismatchesMax) &&
-            (fragment.mismatchCount > tmp.mismatchCount) && lpLess(fragment.logProbability, tmp.logProbability))
+        if (gappedRetryAccepted(P, fragment, g))
         {
             gj.pad = 1;
             if (i == best) { bestLp = tmp.logProbability; bestGapped = job.gappedBase + kk; bestSlot = slot; }

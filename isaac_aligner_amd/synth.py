@@ -248,7 +248,12 @@ def make_human_like_genome(n_bases, seed=3, device="cpu", n_contigs=25, chunk=1 
             vals = _mutate(src_of(seg + a, off), divergence[a:b][seg] if torch.is_tensor(divergence) else divergence, g)
             idx = dst[a:b][seg] + off
             ok = idx < total
-            codes[idx[ok]] = vals[ok]
+            idx, vals = idx[ok], vals[ok]
+            # copies overlap: the later one wins, whatever the device (a scatter with repeated indices is not ordered on a GPU)
+            idx, perm = torch.sort(idx, stable=True)
+            last = torch.ones_like(idx, dtype=torch.bool)
+            last[:-1] = idx[1:] != idx[:-1]
+            codes[idx[last]] = vals[perm][last]
             a = b
 
     # segmental duplications first (they copy whatever is there; later elements land inside them as in a real genome)
