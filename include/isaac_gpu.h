@@ -157,10 +157,39 @@ int isaac_gpu_load_index(isaac_gpu_ctx *ctx, const isaac_reference_kmer *const *
 int isaac_gpu_build_index(isaac_gpu_ctx *ctx, uint32_t repeat_threshold, int annotate_neighbors, uint64_t *n_entries_out);
 /* copies the resident table back in mask-file record layout (capacity in records) */
 int isaac_gpu_get_index(isaac_gpu_ctx *ctx, isaac_reference_kmer *out_host, uint64_t capacity, uint64_t *n_out);
+/* entries [first, first + n) of the resident table, e.g. one mask at a time */
+int isaac_gpu_get_index_range(isaac_gpu_ctx *ctx, uint64_t first, uint64_t n, isaac_reference_kmer *out_host);
 /* offsets_out[m] = table entries before mask m, m = 0 .. n_masks (the <File> elements of sorted-reference.xml,
  * lib/reference/SortedReferenceXml.cpp:312-324: one mask file = entries [offsets[m], offsets[m + 1])); n_masks must be the
  * number of masks the table was loaded or built with (64 for a built one) */
 int isaac_gpu_get_mask_offsets(isaac_gpu_ctx *ctx, uint64_t *offsets_out, uint32_t n_masks);
+
+/* sorted-reference.xml: reference::SortedReferenceMetadata::Contig / ::MaskFile (include/reference/SortedReferenceMetadata.hh:44-98) as
+ * plain records.  strings are NUL-terminated. */
+typedef struct
+{
+    uint64_t genomic_position, offset, size, total_bases, acgt_bases;
+    uint32_t index, karyotype_index;
+    char name[256], file[1024], bam_sq_as[256], bam_sq_ur[1024], bam_m5[64];
+} isaac_reference_contig;
+typedef struct { uint64_t kmers; uint32_t mask_width, mask, seed_length, reserved; char file[1024]; } isaac_reference_mask_file;
+
+/* reference::loadSortedReferenceXml / saveSortedReferenceXml (lib/reference/SortedReferenceXml.cpp:193-213,216-330) on memory buffers;
+ * no GPU involved.  parse: contigs / masks may be NULL to count; *format_version receives the version the metadata carries after
+ * loading (the current one, as the reference bumps it).  format: xml_out may be NULL to size it; the text ends with a NUL that
+ * *n_bytes_out does not count.  Errors: ISAAC_GPU_EFORMAT with the reader's message in isaac_gpu_sorted_reference_last_error(). */
+int isaac_gpu_sorted_reference_parse(const char *xml_text, uint64_t n_bytes, isaac_reference_contig *contigs, uint32_t contig_capacity, uint32_t *n_contigs,
+                                     isaac_reference_mask_file *masks, uint32_t mask_capacity, uint32_t *n_masks, uint32_t *format_version);
+int isaac_gpu_sorted_reference_format(const isaac_reference_contig *contigs, uint32_t n_contigs, const isaac_reference_mask_file *masks, uint32_t n_masks,
+                                      char *xml_out, uint64_t capacity, uint64_t *n_bytes_out);
+const char *isaac_gpu_sorted_reference_last_error(void);
+/* isaac-align -r <sorted-reference.xml>: maps the 32-mer mask files the XML names (relative paths: relative to the XML) and loads
+ * them with the contig translation of <Index> / <KaryotypeIndex> (isaac_gpu_load_index).  The contigs must be loaded already, in
+ * karyotype order. */
+int isaac_gpu_load_sorted_reference(isaac_gpu_ctx *ctx, const char *xml_path);
+/* isaac-sort-reference's output for the resident table (64 masks): <directory>/<genome_name>-32mer-6bit-ABCD-NN.dat and
+ * <directory>/sorted-reference.xml with the given contig metadata */
+int isaac_gpu_save_sorted_reference(isaac_gpu_ctx *ctx, const char *directory, const char *genome_name, const isaac_reference_contig *contigs, uint32_t n_contigs);
 
 /* Replaces one tile's worth of alignWorkflow::FindMatchesTransition::findLaneMatches (both seed iterations;
  * lib/workflow/alignWorkflow/FindMatchesTransition.cpp:391-427): alignment::ClusterSeedGenerator::generateThread

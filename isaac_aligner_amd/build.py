@@ -17,7 +17,7 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-val
 
 
 def units():
-    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".cpp"))]
 
 
 def headers():
@@ -39,10 +39,10 @@ def build(force=False, verbose=False):
     newest_header = max(os.path.getmtime(h) for h in headers())
 
     def compile_unit(src):
-        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+        obj = os.path.join(OBJ, os.path.splitext(os.path.basename(src))[0] + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_header):
             return obj
-        cmd = ["hipcc"] + FLAGS + ["-c", src, "-o", obj]
+        cmd = (["hipcc"] + FLAGS if src.endswith(".hip") else ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall"]) + ["-c", src, "-o", obj]      # .cpp: host code on the C ABI
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

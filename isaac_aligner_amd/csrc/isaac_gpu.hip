@@ -807,6 +807,27 @@ int isaac_gpu_get_index(isaac_gpu_ctx *c, isaac_reference_kmer *out, uint64_t ca
     ISAAC_CATCH
 }
 
+int isaac_gpu_get_index_range(isaac_gpu_ctx *c, uint64_t first, uint64_t n, isaac_reference_kmer *out)
+{
+    ISAAC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    if (first > c->nKmers || n > c->nKmers - first) return fail(ISAAC_GPU_EINVAL, "range outside the table");
+    if (!n) return 0;
+    if (!out) return fail(ISAAC_GPU_EINVAL, "out_host is required");
+    const u64 chunk = 1u << 24;
+    DevBuf<ReferenceKmerRecord> staging; staging.reserve(std::min<u64>(chunk, n));
+    for (u64 done = 0; done < n; done += chunk)
+    {
+        const u64 m = std::min(chunk, n - done);
+        k_join_records<<<gridFor(m, 256), 256, 0, c->stream>>>(c->kmers.p, c->positions.p, first + done, m, staging.p);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(out + done, staging.p, m * sizeof(ReferenceKmerRecord), hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+    ISAAC_CATCH
+}
+
 // entries of the resident table before each mask (n_masks + 1 values, mask = the k-mer's top 6 bits): where a writer of
 // sorted-reference mask files cuts it
 int isaac_gpu_get_mask_offsets(isaac_gpu_ctx *c, uint64_t *offsetsOut, uint32_t nMasks)

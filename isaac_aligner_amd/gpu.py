@@ -35,7 +35,9 @@ def load_library(path=None):
 
 
 EXPORTS = ["isaac_gpu_last_error", "isaac_gpu_create", "isaac_gpu_destroy", "isaac_gpu_malloc", "isaac_gpu_free", "isaac_gpu_upload", "isaac_gpu_download",
-           "isaac_gpu_synchronize", "isaac_gpu_set_deferred_completion", "isaac_gpu_load_contigs", "isaac_gpu_load_contigs_dev", "isaac_gpu_load_index", "isaac_gpu_build_index", "isaac_gpu_get_index", "isaac_gpu_get_mask_offsets",
+           "isaac_gpu_synchronize", "isaac_gpu_set_deferred_completion", "isaac_gpu_load_contigs", "isaac_gpu_load_contigs_dev", "isaac_gpu_load_index", "isaac_gpu_build_index", "isaac_gpu_get_index", "isaac_gpu_get_index_range", "isaac_gpu_get_mask_offsets",
+           "isaac_gpu_sorted_reference_parse", "isaac_gpu_sorted_reference_format", "isaac_gpu_sorted_reference_last_error", "isaac_gpu_load_sorted_reference",
+           "isaac_gpu_save_sorted_reference",
            "isaac_gpu_find_matches", "isaac_gpu_set_loaded_contigs", "isaac_gpu_build_fragments", "isaac_gpu_determine_tls", "isaac_gpu_select", "isaac_gpu_select_candidates",
            "isaac_gpu_bsw_batch", "isaac_gpu_compact_cigars",
            "isaac_gpu_fastq_to_bcl", "isaac_gpu_get_counters", "isaac_gpu_kernel_time_ms", "isaac_gpu_reset_timers"]
@@ -123,6 +125,21 @@ class Aligner:
         sizes = (C.c_uint64 * len(masks))(*[len(m) for m in masks])
         kar = np.ascontiguousarray(karyotype, np.uint32) if karyotype is not None else None
         self._check(self.lib.isaac_gpu_load_index(self.h, ptrs, sizes, C.c_uint32(len(masks)), _p(kar), C.c_uint32(self.n_contigs)))
+
+    def load_sorted_reference(self, xml_path):
+        """isaac-align -r: the mask files named by sorted-reference.xml, with its karyotype translation"""
+        from . import sorted_reference
+        rc = self.lib.isaac_gpu_load_sorted_reference(self.h, os.fsencode(xml_path))
+        if rc:
+            raise IsaacGpuError("isaac_gpu error %d: %s" % (rc, sorted_reference.last_error(self.lib)))
+
+    def save_sorted_reference(self, directory, genome_name, contigs):
+        """isaac-sort-reference's output for the resident table; contigs: list of sorted_reference.Contig"""
+        from . import sorted_reference
+        arr = (sorted_reference.Contig * max(1, len(contigs)))(*contigs)
+        rc = self.lib.isaac_gpu_save_sorted_reference(self.h, os.fsencode(directory), genome_name.encode(), arr, C.c_uint32(len(contigs)))
+        if rc:
+            raise IsaacGpuError("isaac_gpu error %d: %s" % (rc, sorted_reference.last_error(self.lib)))
 
     def mask_offsets(self, n_masks=64):
         out = np.zeros(n_masks + 1, np.uint64)

@@ -671,7 +671,29 @@ def make_oligo():
     return len(script), len(streams), sum(len(b["checks"]) for b in blocks), len(lists), len(runs)
 
 
+def make_sorted_reference():
+    """reference/cppunit/testSortedReferenceXml.cpp:30-199: the XML document of the fixture and every value checkContigs / checkMasks
+    assert after loading it"""
+    text = open(os.path.join(REF, "../../reference/cppunit/testSortedReferenceXml.cpp")).read()
+    a = text.index(": xmlString(") + len(": xmlString(")
+    literal = text[a:text.index(")\n{", a)]
+    xml = "".join(bytes(m, "utf-8").decode("unicode_escape") for m in re.findall(r'"((?:[^"\\]|\\.)*)"', literal))
+    field = {"genomicPosition_": "genomic_position", "index_": "index", "name_": "name", "filePath_": "file", "offset_": "offset", "size_": "size", "totalBases_": "total_bases",
+             "acgtBases_": "acgt_bases", "karyotypeIndex_": "karyotype_index", "bamSqAs_": "bam_sq_as", "bamSqUr_": "bam_sq_ur", "bamM5_": "bam_m5"}
+    contigs = [{}, {}]
+    for value, i, name in re.findall(r'CPPUNIT_ASSERT_EQUAL\((.+?), sortedReferenceMetadata\.getContigs\(\)\.at\((\d)\)\.(\w+)\);', text):
+        m = re.search(r'"(.*)"', value)
+        contigs[int(i)][field[name]] = m.group(1) if m else int(re.match(r"\d+", value).group(0))
+    masks = {"count": int(re.search(r"CPPUNIT_ASSERT_EQUAL\((\d+)U, unsigned\(list\.size\(\)\)\)", text).group(1)),
+             "last_file": re.search(r'boost::filesystem::path\("([^"]+ABCD-02\.dat)"\),\s*list\.back\(\)\.path', text).group(1),
+             "mask_width": int(re.search(r"CPPUNIT_ASSERT_EQUAL\((\d+)U, sortedReferenceMetadata\.getDefaultMaskWidth\(\)\)", text).group(1)), "seed_length": 32}
+    out = {"source": "lib/reference/cppunit/testSortedReferenceXml.cpp:30-199 (xmlString and the values checkContigs / checkMasks assert)", "xml": xml, "contigs": contigs, "masks": masks}
+    json.dump(out, open(os.path.join(OUT, "sorted_reference.json"), "w"), indent=1)
+    return len(contigs), sum(len(c) for c in contigs), masks["count"]
+
+
 if __name__ == "__main__":
+    print("sorted_reference contigs, asserted contig fields, masks:", make_sorted_reference())
     print("oligo (cluster info steps, k-mer streams, permutate checks, permutation lists, neighbour runs):", make_oligo())
     print("fragment_builder cases, asserted values:", make_fragment_builder())
     print("shadow_aligner blocks:", make_shadow_aligner())

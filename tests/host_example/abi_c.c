@@ -7,7 +7,9 @@ any_function isaac_gpu_entry_points[] = {
     (any_function)isaac_gpu_last_error, (any_function)isaac_gpu_create, (any_function)isaac_gpu_destroy, (any_function)isaac_gpu_malloc, (any_function)isaac_gpu_free,
     (any_function)isaac_gpu_upload, (any_function)isaac_gpu_download, (any_function)isaac_gpu_synchronize, (any_function)isaac_gpu_set_deferred_completion,
     (any_function)isaac_gpu_load_contigs, (any_function)isaac_gpu_load_contigs_dev, (any_function)isaac_gpu_load_index, (any_function)isaac_gpu_build_index,
-    (any_function)isaac_gpu_get_index, (any_function)isaac_gpu_get_mask_offsets, (any_function)isaac_gpu_find_matches, (any_function)isaac_gpu_set_loaded_contigs,
+    (any_function)isaac_gpu_get_index, (any_function)isaac_gpu_get_index_range, (any_function)isaac_gpu_get_mask_offsets,
+    (any_function)isaac_gpu_sorted_reference_parse, (any_function)isaac_gpu_sorted_reference_format, (any_function)isaac_gpu_sorted_reference_last_error,
+    (any_function)isaac_gpu_load_sorted_reference, (any_function)isaac_gpu_save_sorted_reference, (any_function)isaac_gpu_find_matches, (any_function)isaac_gpu_set_loaded_contigs,
     (any_function)isaac_gpu_build_fragments, (any_function)isaac_gpu_determine_tls, (any_function)isaac_gpu_select, (any_function)isaac_gpu_select_candidates,
     (any_function)isaac_gpu_compact_cigars, (any_function)isaac_gpu_bsw_batch, (any_function)isaac_gpu_fastq_to_bcl, (any_function)isaac_gpu_get_counters,
     (any_function)isaac_gpu_kernel_time_ms, (any_function)isaac_gpu_reset_timers,
