@@ -31,27 +31,25 @@ size_t genomeLength(const ContigList &c) { size_t r = 0; for (size_t i = 0; i < 
 
 // ---------------------------------------------------------------- Quality (lib/alignment/Quality.cpp:34-66)
 double Quality::getLogMismatch(unsigned q) { const double mismatch = pow(10.0, (double)q / -10.0); return log(mismatch / 3.0); }
-const std::vector<double> &Quality::logMatchLookup()
+// (function-local statics initialised by a call: thread-safe in C++11.  Filling them lazily under `if (lookup.empty())` let the worker
+// threads of oracle_select race on the first call of a process: a thread could read a table another one was still growing.)
+static std::vector<double> makeLogMatchLookup()
 {
-    static std::vector<double> lookup;
-    if (lookup.empty())
-    {
-        const double nMismatch = pow(10.0, 1.0 / -10.0);
-        lookup.push_back(log(1.0 - nMismatch));
-        for (int i = 1; i < 100; ++i) { const double mismatch = pow(10.0, (double)i / -10.0); lookup.push_back(log(1.0 - mismatch)); }
-    }
+    std::vector<double> lookup;
+    const double nMismatch = pow(10.0, 1.0 / -10.0);
+    lookup.push_back(log(1.0 - nMismatch));
+    for (int i = 1; i < 100; ++i) { const double mismatch = pow(10.0, (double)i / -10.0); lookup.push_back(log(1.0 - mismatch)); }
     return lookup;
 }
-const std::vector<double> &Quality::logMismatchLookup()
+static std::vector<double> makeLogMismatchLookup()
 {
-    static std::vector<double> lookup;
-    if (lookup.empty())
-    {
-        lookup.push_back(log(1.0 - pow(10.0, 1.0 / -10.0)));
-        for (unsigned q = 1; q < 100U; ++q) lookup.push_back(getLogMismatch(q));
-    }
+    std::vector<double> lookup;
+    lookup.push_back(log(1.0 - pow(10.0, 1.0 / -10.0)));
+    for (unsigned q = 1; q < 100U; ++q) lookup.push_back(Quality::getLogMismatch(q));
     return lookup;
 }
+const std::vector<double> &Quality::logMatchLookup() { static const std::vector<double> lookup = makeLogMatchLookup(); return lookup; }
+const std::vector<double> &Quality::logMismatchLookup() { static const std::vector<double> lookup = makeLogMismatchLookup(); return lookup; }
 // include/alignment/Quality.hh:87-91 (genomeLength is passed through `unsigned`)
 double Quality::restOfGenomeCorrection(unsigned genomeLength, unsigned readLength)
 {

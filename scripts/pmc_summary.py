@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Per-kernel summary of rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_*) -> JSON for profiles/.
 
-    python scripts/pmc_summary.py OUT.json name=counter_collection.csv [name=...]
+    python scripts/pmc_summary.py OUT.json name=counter_collection.csv [name=...] [workload=bench_line.json]
+
+workload=: the bench.py line of one of the passes; its genome size, read length and pairs per launch are recorded so that bench.py
+only quotes these figures for the same workload.
 
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KB.  Following /opt/skills/guides/MI355X_MICROARCH.md (HBM section), on
 gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes, so hbm_read_bytes = 2 x FETCH_SIZE; WRITE_SIZE is taken as is.  The
@@ -12,8 +15,14 @@ import collections, csv, json, re, sys
 def main():
     out = sys.argv[1]
     kernels = collections.defaultdict(lambda: {"launches": 0})
+    workload = None
     for arg in sys.argv[2:]:
-        _, path = arg.split("=", 1)
+        name, path = arg.split("=", 1)
+        if name == "workload":
+            line = [l for l in open(path).read().splitlines() if l.startswith("{")][-1]
+            cfg = json.loads(line)["config"]
+            workload = {"genome_bases": cfg["genome_bases"], "read_length": cfg["read_length"], "pairs_per_launch": cfg["pairs_per_step"], "index_entries": cfg["index_entries"]}
+            continue
         seen = set()
         for r in csv.DictReader(open(path)):
             m = re.search(r"(k_\w+)", r["Kernel_Name"])
@@ -47,6 +56,8 @@ def main():
             if e.get("SQ_ACTIVE_INST_VALU"):
                 e["valu_lane_utilisation"] = e.get("SQ_THREAD_CYCLES_VALU", 0) / (64.0 * e["SQ_ACTIVE_INST_VALU"])
         res[name] = e
+    if workload:
+        res["workload"] = workload
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     print("wrote", out, "kernels:", ", ".join(res))
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic and SQ activity per kernel: three separate rocprofv3 --pmc passes (never combined with tracing) over a short bench
-# run with 500000 pairs per launch, reduced by scripts/pmc_summary.py into gpurun_out/pmc_summary.json
+# run with the default 1 M pairs per launch, reduced by scripts/pmc_summary.py into gpurun_out/pmc_summary.json
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie-pass"
@@ -8,4 +8,6 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_j_fetch -- $
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_j_write -- $B > $R/gpurun_out/pmc_j_write.log 2>&1; echo "write rc=$?"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d $R/gpurun_out/pmc_j_sq -- $B > $R/gpurun_out/pmc_j_sq.log 2>&1; echo "sq rc=$?"
 cd $R
-python3 scripts/pmc_summary.py gpurun_out/pmc_summary.json fetch=$(find gpurun_out/pmc_j_fetch -name "*counter_collection.csv" | head -1) write=$(find gpurun_out/pmc_j_write -name "*counter_collection.csv" | head -1) sq=$(find gpurun_out/pmc_j_sq -name "*counter_collection.csv" | head -1)
+python3 scripts/pmc_summary.py gpurun_out/pmc_summary.json workload=gpurun_out/pmc_j_sq.log fetch=$(find gpurun_out/pmc_j_fetch -name "*counter_collection.csv" | head -1) write=$(find gpurun_out/pmc_j_write -name "*counter_collection.csv" | head -1) sq=$(find gpurun_out/pmc_j_sq -name "*counter_collection.csv" | head -1)
+
+rm -rf gpurun_out/pmc_j_fetch gpurun_out/pmc_j_write gpurun_out/pmc_j_sq      # the per-dispatch CSVs: tens of MB
