@@ -255,6 +255,46 @@ int isaac_gpu_select_candidates(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint
 int isaac_gpu_compact_cigars(isaac_gpu_ctx *ctx, isaac_fragment *fragments_dev, uint64_t n_records, const uint32_t *cigar_in_dev,
                              uint32_t *cigar_out_dev, uint64_t capacity, uint64_t *n_words_out);
 
+/* The output side of the path for --realign-gaps no --mark-duplicates 0: the BAM alignment records build::Build writes
+ * (lib/build/Build.cpp, lib/build/BinSorter.cpp) from what isaac_gpu_select produced, computed where the records already are.
+ *   order    PackedFragmentBuffer::orderForBam (include/build/PackedFragmentBuffer.hh:149-176): bin position, global cluster id
+ *            (tile * 1000000000 + cluster, include/build/FragmentIndex.hh:33), mapped before unmapped (a shadow follows its
+ *            singleton), first read before second; templates with both reads unaligned last, in (tile, cluster, read) order
+ *            (--keep-unaligned back); records flagged "not stored" (isaac_fragment::reserved bit 1) are left out
+ *   record   bam::serializeAlignment over build::FragmentAccessorBamAdapter (include/bam/Bam.hh:257-345,
+ *            include/build/FragmentAccessorBamAdapter.hh:127-377) with the default tag set SM AS RG NM BC (--bam-exclude-tags ZX,ZY);
+ *            bases and qualities as FragmentCollector::storeBclAndCigar keeps them (lib/alignment/matchSelector/FragmentCollector.cpp:84-111)
+ * One tile = the buffers of one isaac_gpu_select call (bcl_dev as given to it, its records and cigar pool, fixed slots or packed);
+ * read_name_prefix = "<flowcell id>:<lane>:<tile>:" (FragmentAccessorBamAdapter::readName), at most 63 characters.  Contig ids are
+ * written as they are (the BAM header must list the contigs in the order of isaac_gpu_load_contigs).
+ * bam_dev receives the uncompressed records back to back; *n_bytes_out their length (also when it exceeds capacity),
+ * *n_records_out their number, *unaligned_offset_out the offset of the first record of the unaligned bin (= *n_bytes_out if none). */
+typedef struct { const uint8_t *bcl_dev; const isaac_fragment *fragments_dev; const uint32_t *cigar_dev; uint64_t n_records; const char *read_name_prefix; } isaac_bam_tile;
+typedef struct
+{
+    uint32_t forced_dodgy_alignment_score;  /* MAPQ of alignments whose score is unknown (0xffff): --dodgy-alignment-score */
+    uint32_t pessimistic_mapq;               /* --pessimistic-mapq: min instead of max of SM and AS for proper pairs */
+    const char *read_group;                  /* RG:Z value: the barcode index (FragmentAccessorBamAdapter.hh:283-299); NULL = "0" */
+    const char *barcode;                     /* BC:Z value: the sample sheet barcode name (:307-335); NULL = "none" */
+} isaac_bam_options;
+int isaac_gpu_bam_records(isaac_gpu_ctx *ctx, const isaac_bam_tile *tiles, uint32_t n_tiles, const isaac_bam_options *options /* NULL = defaults */,
+                          uint8_t *bam_dev, uint64_t capacity, uint64_t *n_bytes_out, uint64_t *n_records_out, uint64_t *unaligned_offset_out);
+
+/* Host-only pieces of the BAM file (no context, no GPU).  Errors: isaac_gpu_bam_last_error().
+ * isaac_gpu_bam_header: bam::serializeHeader (include/bam/Bam.hh:153-235): magic, the text (@HD VN:1.0 SO:coordinate, @PG ID:iSAAC
+ * with CL / DS / VN, header_lines such as --bam-header-tag and the @RG lines verbatim, one @SQ SN LN per contig), the contig table.
+ * isaac_gpu_bgzf_compress: the BGZF framing of bgzf::BgzfCompressor (include/bgzf/BgzfCompressor.hh:36-176): blocks of at most
+ * 0xFFFF - 41 input bytes, each a gzip member with the BC extra field, deflated with zlib at `level` (--bam-gzip-level) on
+ * n_threads threads; eof_block != 0 appends the 28-byte empty block of bam::serializeBgzfFooter (lib/bam/Bam.cpp:38-45).
+ * out_host must hold isaac_gpu_bgzf_bound(n_bytes) bytes. */
+const char *isaac_gpu_bam_last_error(void);
+int isaac_gpu_bam_header(const char *command_line, const char *description, const char *version, const char *const *header_lines, uint32_t n_header_lines,
+                         const char *const *contig_names, const uint32_t *contig_lengths, uint32_t n_contigs,
+                         uint8_t *out_host, uint64_t capacity, uint64_t *n_bytes_out);
+uint64_t isaac_gpu_bgzf_bound(uint64_t n_bytes);
+int isaac_gpu_bgzf_compress(const uint8_t *data_host, uint64_t n_bytes, int level, uint32_t n_threads, int eof_block,
+                            uint8_t *out_host, uint64_t capacity, uint64_t *n_bytes_out);
+
 /* The leaf: alignment::BandedSmithWaterman::align (include/alignment/BandedSmithWaterman.hh:75-86) for a batch;
  * scores as the reference constructor takes them (GappedAligner.cpp:41-42: match, mismatch, -gapOpen, -gapExtend).
  * results[i].n_ops == 0xffffffff flags a CIGAR longer than ISAAC_GPU_MAX_CIGAR_OPS. */
@@ -284,7 +324,7 @@ int isaac_gpu_get_counters(isaac_gpu_ctx *ctx, isaac_counters *out);
  * stream it runs on; names: "find_matches", "compact_matches", "build_fragments", "align_candidates", "finish_candidates",
  * "indel_fragments", "gapped_fragments", "finish_fragments", "load_candidates", "plan_rescue", "rescue_windows", "rescue_align",
  * "rescue_gapped_plan", "gapped_rescue", "sums_wave", "sums_large", "sums_xl", "sums_huge", "select", "select_heavy", "select_residual" (the last two
- * only when a cluster needed the wave-per-cluster pass), "fastq_to_bcl", "bsw" */
+ * only when a cluster needed the wave-per-cluster pass), "fastq_to_bcl", "bsw", "bam_order", "bam_encode" */
 int isaac_gpu_kernel_time_ms(isaac_gpu_ctx *ctx, const char *kernel, double *avg_ms, uint64_t *launches);
 int isaac_gpu_reset_timers(isaac_gpu_ctx *ctx);
 

@@ -1,0 +1,97 @@
+"""Host-side mirror of the BAM output boundary (include/isaac_gpu.h: isaac_gpu_bam_records / isaac_gpu_bam_header /
+isaac_gpu_bgzf_compress): what build::Build writes for --realign-gaps no --mark-duplicates 0
+(reference: lib/build/Build.cpp, include/bam/Bam.hh, include/bgzf/BgzfCompressor.hh)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+
+class BamTile(C.Structure):
+    _fields_ = [("bcl_dev", C.c_void_p), ("fragments_dev", C.c_void_p), ("cigar_dev", C.c_void_p), ("n_records", C.c_uint64), ("read_name_prefix", C.c_char_p)]
+
+
+class BamOptions(C.Structure):
+    _fields_ = [("forced_dodgy_alignment_score", C.c_uint32), ("pessimistic_mapq", C.c_uint32), ("read_group", C.c_char_p), ("barcode", C.c_char_p)]
+
+
+class BamError(RuntimeError):
+    pass
+
+
+def _lib():
+    from . import gpu
+    lib = gpu.load_library()
+    lib.isaac_gpu_bam_last_error.restype = C.c_char_p
+    lib.isaac_gpu_bgzf_bound.restype = C.c_uint64
+    lib.isaac_gpu_bgzf_bound.argtypes = [C.c_uint64]
+    return lib
+
+
+def _check(lib, rc):
+    if rc:
+        raise BamError("%d: %s" % (rc, lib.isaac_gpu_bam_last_error().decode()))
+
+
+def header(command_line, version, contigs, description="", header_lines=()):
+    """bam::serializeHeader; contigs: [(name, length)] in reference order; header_lines: --bam-header-tag lines and @RG lines"""
+    lib = _lib()
+    lines = (C.c_char_p * max(1, len(header_lines)))(*[l.encode() for l in header_lines])
+    names = (C.c_char_p * max(1, len(contigs)))(*[n.encode() for n, _ in contigs])
+    lengths = (C.c_uint32 * max(1, len(contigs)))(*[l for _, l in contigs])
+    n = C.c_uint64()
+    capacity = 4096 + len(command_line) + len(description) + sum(len(l) + 1 for l in header_lines) + sum(2 * len(nm) + 64 for nm, _ in contigs)
+    out = np.empty(capacity, np.uint8)
+    _check(lib, lib.isaac_gpu_bam_header(command_line.encode(), description.encode(), version.encode(), lines, C.c_uint32(len(header_lines)), names, lengths,
+                                         C.c_uint32(len(contigs)), out.ctypes.data_as(C.c_void_p), C.c_uint64(capacity), C.byref(n)))
+    return out[:n.value].tobytes()
+
+
+def bgzf_compress(data, level=1, n_threads=None, eof_block=False):
+    """bgzf::BgzfCompressor framing of `data` (bytes or a uint8 numpy array); returns bytes"""
+    lib = _lib()
+    a = np.frombuffer(data, np.uint8) if isinstance(data, (bytes, bytearray, memoryview)) else np.ascontiguousarray(data, np.uint8)
+    capacity = lib.isaac_gpu_bgzf_bound(C.c_uint64(a.size))
+    out = np.empty(capacity, np.uint8)
+    n = C.c_uint64()
+    _check(lib, lib.isaac_gpu_bgzf_compress(a.ctypes.data_as(C.c_void_p), C.c_uint64(a.size), C.c_int(level), C.c_uint32(n_threads or os.cpu_count() or 1), C.c_int(int(eof_block)),
+                                            out.ctypes.data_as(C.c_void_p), C.c_uint64(capacity), C.byref(n)))
+    return out[:n.value].tobytes()
+
+
+def write_bam(path, header_bytes, record_bytes, level=1, n_threads=None):
+    """header, records and the empty end-of-file block, each flushed as the reference's filter chain flushes them"""
+    with open(path, "wb") as f:
+        f.write(bgzf_compress(header_bytes, level, n_threads))
+        f.write(bgzf_compress(record_bytes, level, n_threads, eof_block=True))
+
+
+def parse_records(data):
+    """decodes an uncompressed BAM record stream into dicts (for tests and examples)"""
+    out, at = [], 0
+    data = bytes(data)
+    while at < len(data):
+        size = int.from_bytes(data[at:at + 4], "little")
+        b = data[at + 4:at + 4 + size]
+        ref_id, pos, bin_mq_nl, flag_nc, l_seq, next_ref, next_pos, tlen = np.frombuffer(b[:32], "<i4")
+        nl, mq, bn = bin_mq_nl & 0xff, (bin_mq_nl >> 8) & 0xff, (int(bin_mq_nl) >> 16) & 0xffff
+        nc, flag = flag_nc & 0xffff, (int(flag_nc) >> 16) & 0xffff
+        p = 32
+        name = b[p:p + nl - 1].decode(); p += nl
+        cigar = np.frombuffer(b[p:p + 4 * nc], "<u4"); p += 4 * nc
+        seq4 = np.frombuffer(b[p:p + (l_seq + 1) // 2], np.uint8); p += (l_seq + 1) // 2
+        seq = "".join("=ACMGRSVTWYHKDBN"[(seq4[i // 2] >> (4 if i % 2 == 0 else 0)) & 15] for i in range(l_seq))
+        qual = np.frombuffer(b[p:p + l_seq], np.uint8); p += l_seq
+        tags = {}
+        while p < len(b):
+            tag, typ = b[p:p + 2].decode(), chr(b[p + 2]); p += 3
+            if typ == "i":
+                tags[tag] = int.from_bytes(b[p:p + 4], "little", signed=True); p += 4
+            elif typ == "Z":
+                e = b.index(0, p); tags[tag] = b[p:e].decode(); p = e + 1
+            else:
+                raise ValueError("tag type " + typ)
+        out.append(dict(ref_id=int(ref_id), pos=int(pos), bin=bn, mapq=int(mq), flag=flag, name=name, cigar=cigar, seq=seq, qual=qual, next_ref_id=int(next_ref), next_pos=int(next_pos),
+                        tlen=int(tlen), tags=tags))
+        at += 4 + size
+    return out

@@ -50,7 +50,7 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
         objs = list(pool.map(compile_unit, units()))
-    cmd = ["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + objs
+    cmd = ["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + objs + ["-lz"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

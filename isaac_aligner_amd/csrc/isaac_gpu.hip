@@ -24,6 +24,7 @@
 #include "host_util.h"
 #include "fastq_kernel.h"
 #include "index_kernels.h"
+#include "bam_kernels.h"
 
 #if defined(ISAAC_KERNEL_STAMPS)
 __device__ unsigned long long g_stamps[64];
@@ -70,6 +71,8 @@ struct isaac_gpu_ctx
     DevBuf<GappedJob> gappedJobs, rescueGappedJobs; DevBuf<GappedResult> gappedResults, rescueGappedResults; DevBuf<u32> gappedBase, gappedCounters;
     DevBuf<u8> heavyArena; DevBuf<u32> overflowList; DevBuf<u32> overflowCount; DevBuf<ClusterSums> clusterSums; DevBuf<u32> largeList, xlList, hugeList, longJobs; DevBuf<u8> hugeKeys;
     DevBuf<TlsSample> tlsSamples; DevBuf<u32> cigarLengths, cigarOffsets;
+    // isaac_gpu_bam_records scratch
+    DevBuf<BamTile> bamTiles; DevBuf<u64> bamKeyHi, bamKeyLo, bamKeyAlt, bamOffsets, bamBytes64, bamBounds; DevBuf<u32> bamIndex, bamIndexAlt, bamBytes;
     DevBuf<RescueJob> jobs; DevBuf<u32> rescueCounters, bitmaps, candJob, shadowCigars, jobBase, jobCount; DevBuf<i32> candPositions; DevBuf<Cand> shadowCands; DevBuf<u32> candRank;
     DevBuf<Counters> counters;
     std::map<std::string, KernelTimer> timers;
@@ -1230,6 +1233,79 @@ int isaac_gpu_compact_cigars(isaac_gpu_ctx *c, isaac_fragment *fragments, uint64
     const u64 total = u64(lastLen) + lastOff;
     if (nWordsOut) *nWordsOut = total;
     if (total > capacity) return fail(ISAAC_GPU_ECAPACITY, "cigar_out_dev is too small");
+    return 0;
+    ISAAC_CATCH
+}
+
+// The BAM alignment records of a set of tiles in file order (bam_kernels.h)
+int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_t nTiles, const isaac_bam_options *options, uint8_t *bam, uint64_t capacity,
+                          uint64_t *nBytesOut, uint64_t *nRecordsOut, uint64_t *unalignedOffsetOut)
+{
+    ISAAC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    if (nBytesOut) *nBytesOut = 0;
+    if (nRecordsOut) *nRecordsOut = 0;
+    if (unalignedOffsetOut) *unalignedOffsetOut = 0;
+    if (nTiles && !tiles) return fail(ISAAC_GPU_EINVAL, "tiles is required");
+    BamOptions o; std::memset(&o, 0, sizeof(o));
+    o.nReads = c->params.n_reads;
+    for (u32 r = 0; r < o.nReads; ++r) { o.readLength[r] = c->params.read_length[r]; o.readOffset[r] = o.clusterLength; o.clusterLength += o.readLength[r]; }
+    const char *readGroup = options && options->read_group ? options->read_group : "0", *barcode = options && options->barcode ? options->barcode : "none";
+    if (std::strlen(readGroup) >= sizeof(o.readGroup) || std::strlen(barcode) >= sizeof(o.barcode)) return fail(ISAAC_GPU_EINVAL, "read_group and barcode: at most 63 characters");
+    std::strcpy(o.readGroup, readGroup); o.readGroupLength = u32(std::strlen(readGroup)); std::strcpy(o.barcode, barcode); o.barcodeLength = u32(std::strlen(barcode));
+    o.forcedDodgyAlignmentScore = options ? (options->forced_dodgy_alignment_score & 0xff) : (u32(c->params.dodgy_alignment_score) & 0xff);
+    o.pessimisticMapQ = options ? options->pessimistic_mapq : 0;
+    std::vector<BamTile> h(nTiles);
+    u64 n = 0;
+    for (u32 t = 0; t < nTiles; ++t)
+    {
+        const isaac_bam_tile &in = tiles[t];
+        if (in.n_records && (!in.bcl_dev || !in.fragments_dev || !in.cigar_dev)) return fail(ISAAC_GPU_EINVAL, "bcl_dev, fragments_dev and cigar_dev are required for every tile");
+        const char *prefix = in.read_name_prefix ? in.read_name_prefix : "";
+        if (std::strlen(prefix) >= sizeof(h[t].name)) return fail(ISAAC_GPU_EINVAL, "read_name_prefix: at most 63 characters");
+        std::memset(&h[t], 0, sizeof(BamTile));
+        h[t].bcl = in.bcl_dev; h[t].records = reinterpret_cast<const FragmentRecord *>(in.fragments_dev); h[t].cigars = in.cigar_dev; h[t].firstRecord = n;
+        h[t].nRecords = u32(in.n_records); h[t].nameLength = u32(std::strlen(prefix)); std::memcpy(h[t].name, prefix, h[t].nameLength);
+        n += in.n_records;
+    }
+    if (n >= (u64(1) << 31)) return fail(ISAAC_GPU_EINVAL, "at most 2^31 - 1 records per call");
+    if (!n) return 0;
+    if (!bam && capacity) return fail(ISAAC_GPU_EINVAL, "bam_dev is required");
+    resolvePending(c);
+    hipStream_t st = c->stream;
+    c->bamTiles.reserve(nTiles); c->bamKeyHi.reserve(n); c->bamKeyLo.reserve(n); c->bamKeyAlt.reserve(n); c->bamOffsets.reserve(n); c->bamBytes64.reserve(n);
+    c->bamIndex.reserve(n); c->bamIndexAlt.reserve(n); c->bamBytes.reserve(n); c->bamBounds.reserve(2);
+    HIP_CHECK(hipMemcpyAsync(c->bamTiles.p, h.data(), sizeof(BamTile) * nTiles, hipMemcpyHostToDevice, st));
+    const u64 bounds0[2] = { n, n };
+    HIP_CHECK(hipMemcpyAsync(c->bamBounds.p, bounds0, sizeof(bounds0), hipMemcpyHostToDevice, st));
+    {
+        ScopedTimer t(c, "bam_order");
+        k_bam_keys<<<gridFor(n, 256), 256, 0, st>>>(c->bamTiles.p, nTiles, n, o, c->bamKeyHi.p, c->bamKeyLo.p, c->bamIndex.p, c->bamBytes.p);
+        // two stable passes: by (global cluster id, unmapped, second read), then by bin position
+        sortPairs(c, c->bamKeyLo.p, c->bamKeyAlt.p, c->bamIndex.p, c->bamIndexAlt.p, n);
+        k_bam_gather_hi<<<gridFor(n, 256), 256, 0, st>>>(c->bamKeyHi.p, c->bamIndexAlt.p, n, c->bamKeyLo.p);
+        sortPairs(c, c->bamKeyLo.p, c->bamKeyAlt.p, c->bamIndexAlt.p, c->bamIndex.p, n);
+        k_bam_gather_bytes<<<gridFor(n, 256), 256, 0, st>>>(c->bamBytes.p, c->bamIndex.p, n, c->bamBytes64.p);
+        exclusiveSum(c, c->bamBytes64.p, c->bamOffsets.p, n);
+        k_bam_bounds<<<gridFor(n, 256), 256, 0, st>>>(c->bamKeyAlt.p, n, c->bamBounds.p);
+    }
+    {
+        ScopedTimer t(c, "bam_encode");
+        k_bam_encode<<<gridFor(n, 64), 64, 0, st>>>(c->bamTiles.p, nTiles, n, o, c->bamIndex.p, c->bamOffsets.p, bam, capacity);
+    }
+    HIP_CHECK(hipGetLastError());
+    u64 lastOffset = 0, lastBytes = 0, bounds[2] = { 0, 0 };
+    HIP_CHECK(hipMemcpyAsync(&lastOffset, c->bamOffsets.p + n - 1, 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(&lastBytes, c->bamBytes64.p + n - 1, 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(bounds, c->bamBounds.p, 16, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    const u64 total = lastOffset + lastBytes;
+    u64 unalignedOffset = total;
+    if (bounds[0] < n) HIP_CHECK(hipMemcpy(&unalignedOffset, c->bamOffsets.p + bounds[0], 8, hipMemcpyDeviceToHost));
+    if (nBytesOut) *nBytesOut = total;
+    if (nRecordsOut) *nRecordsOut = bounds[1];
+    if (unalignedOffsetOut) *unalignedOffsetOut = unalignedOffset;
+    if (total > capacity) return fail(ISAAC_GPU_ECAPACITY, "bam_dev is too small");
     return 0;
     ISAAC_CATCH
 }

@@ -40,6 +40,7 @@ EXPORTS = ["isaac_gpu_last_error", "isaac_gpu_create", "isaac_gpu_destroy", "isa
            "isaac_gpu_save_sorted_reference",
            "isaac_gpu_find_matches", "isaac_gpu_set_loaded_contigs", "isaac_gpu_build_fragments", "isaac_gpu_determine_tls", "isaac_gpu_select", "isaac_gpu_select_candidates",
            "isaac_gpu_bsw_batch", "isaac_gpu_compact_cigars",
+           "isaac_gpu_bam_records", "isaac_gpu_bam_last_error", "isaac_gpu_bam_header", "isaac_gpu_bgzf_bound", "isaac_gpu_bgzf_compress",
            "isaac_gpu_fastq_to_bcl", "isaac_gpu_get_counters", "isaac_gpu_kernel_time_ms", "isaac_gpu_reset_timers"]
 
 
@@ -222,6 +223,13 @@ class Aligner:
             self._inflight.append((bcl, matches, offsets, records, cigars))
         return records, cigars
 
+    def align_tile(self, bcl, tile=0, tls=None):
+        """find_matches -> determine_tls (unless given) -> select for one tile; returns (records, cigars)"""
+        matches, offsets, _ = self.find_matches(bcl, tile=tile)
+        if tls is None:
+            tls = self.determine_tls(bcl, matches, offsets, tile=tile)
+        return self.select(bcl, matches, offsets, tls, tile=tile)
+
     def select_candidates(self, bcl, candidates, candidate_cigars, tls, tile=0):
         """TemplateBuilder::buildTemplate on explicit candidate lists.  candidates: abi.CANDIDATE_DTYPE numpy array ordered by
         (cluster, read, list position); returns (records tensor, cigars tensor) like select()"""
@@ -253,6 +261,45 @@ class Aligner:
             rc = self.lib.isaac_gpu_compact_cigars(self.h, _p(records), C.c_uint64(n_rec), _p(cigars), _p(out), C.c_uint64(out.numel()), C.byref(n))
         self._check(rc)
         return out[:n.value], n.value
+
+    # ---- output format --------------------------------------------------------------------------------------------
+    def bam_records(self, tiles, out=None, read_group=None, barcode=None, forced_dodgy_alignment_score=None, pessimistic_mapq=False):
+        """build::Build's BAM alignment records (--realign-gaps no --mark-duplicates 0) of one or more tiles, in file order.
+        tiles: [(bcl, records, cigars, read_name_prefix)] as given to / returned by select().  Returns (uint8 device tensor of the
+        uncompressed records, number of records, offset of the unaligned bin)."""
+        from . import bam
+        arr = (bam.BamTile * len(tiles))()
+        keep = []
+        n_rec = 0
+        for i, (bcl, records, cigars, prefix) in enumerate(tiles):
+            name = prefix.encode() if isinstance(prefix, str) else prefix
+            keep.append(name)
+            arr[i].bcl_dev = _p(bcl).value if _p(bcl) is not None else None
+            arr[i].fragments_dev = _p(records).value if _p(records) is not None else None
+            arr[i].cigar_dev = _p(cigars).value if _p(cigars) is not None else None
+            arr[i].n_records = records.shape[0]
+            arr[i].read_name_prefix = name
+            n_rec += records.shape[0]
+        options = None
+        if read_group is not None or barcode is not None or forced_dodgy_alignment_score is not None or pessimistic_mapq:
+            options = bam.BamOptions()
+            options.forced_dodgy_alignment_score = (self.params.dodgy_alignment_score & 0xff) if forced_dodgy_alignment_score is None else forced_dodgy_alignment_score
+            options.pessimistic_mapq = int(bool(pessimistic_mapq))
+            options.read_group = None if read_group is None else read_group.encode()
+            options.barcode = None if barcode is None else barcode.encode()
+        if out is None:
+            out = self.torch.empty(max(1, n_rec * (96 + 2 * max(self.params.read_length[0], self.params.read_length[1]))), dtype=self.torch.uint8, device=self.device)
+        nb, nr, un = C.c_uint64(), C.c_uint64(), C.c_uint64()
+
+        def call(buf):
+            return self.lib.isaac_gpu_bam_records(self.h, arr, C.c_uint32(len(tiles)), C.byref(options) if options is not None else None, _p(buf), C.c_uint64(buf.numel()),
+                                                  C.byref(nb), C.byref(nr), C.byref(un))
+        rc = call(out)
+        if rc == 4:
+            out = self.torch.empty(nb.value, dtype=self.torch.uint8, device=self.device)
+            rc = call(out)
+        self._check(rc)
+        return out[:nb.value], nr.value, un.value
 
     def records_to_numpy(self, records, cigars):
         if self.deferred_completion:

@@ -1,0 +1,174 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see oracle/README.md).  CPU restatement of the BAM side of the path for
+// --realign-gaps no --mark-duplicates 0 and the default tag set (--bam-exclude-tags ZX,ZY):
+//   what FragmentCollector keeps per read      lib/alignment/matchSelector/FragmentCollector.cpp:43-111
+//   the order of a bin                         include/build/PackedFragmentBuffer.hh:149-176 (orderForBam), lib/build/BinSorter.cpp
+//   the record adapter                         include/build/FragmentAccessorBamAdapter.hh:127-377
+//   record and header serialisation            include/bam/Bam.hh:147-345, lib/bam/Bam.cpp:38-45
+// Bins follow each other in position order and the unaligned bin is written last (--keep-unaligned back), so one sort over
+// all aligned records and shadows followed by the unaligned templates in storage order is the record stream of the file.
+#include "oracle.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+
+namespace oracle
+{
+namespace
+{
+
+const uint64_t CLUSTERS_PER_TILE_FACTOR = 1000000000UL;     // include/build/FragmentIndex.hh INSANELY_HIGH_NUMBER_OF_CLUSTERS_PER_TILE
+const uint16_t DODGY = 0xffff;
+const uint64_t NO_MATCH_VALUE = ReferencePosition(ReferencePosition::NoMatch).value;
+
+// the stored form of one read: header fields, bases as stored (FragmentCollector::storeBclAndCigar), CIGAR
+struct Stored
+{
+    const FragmentRecord *header; std::vector<unsigned char> bases; const uint32_t *cigarBegin, *cigarEnd; const std::string *namePrefix;
+    bool paired() const { return header->flags & 1; }
+    bool unmapped() const { return header->flags & 2; }
+    bool mateUnmapped() const { return header->flags & 4; }
+    bool reverse() const { return header->flags & 8; }
+    bool secondRead() const { return header->flags & 64; }
+    bool properPair() const { return header->flags & 256; }
+};
+
+inline bool isBclN(unsigned char b) { return !(b & 0xfc); }                                   // oligo/Nucleotides.hh:91-94
+inline unsigned char reverseBcl(unsigned char b) { return !isBclN(b) ? (b & 0xfc) | (3 - (b & 3)) : 0; }   // :153-156
+
+void put(std::vector<char> &os, const void *p, size_t n) { const char *c = static_cast<const char *>(p); os.insert(os.end(), c, c + n); }
+void putInt(std::vector<char> &os, int v) { put(os, &v, 4); }
+void putUnsigned(std::vector<char> &os, unsigned v) { put(os, &v, 4); }
+
+int reg2bin(unsigned beg, unsigned end)                                                       // Bam.hh:237-246
+{
+    --end;
+    if (beg >> 14 == end >> 14) return 4681 + (beg >> 14);
+    if (beg >> 17 == end >> 17) return 585 + (beg >> 17);
+    if (beg >> 20 == end >> 20) return 73 + (beg >> 20);
+    if (beg >> 23 == end >> 23) return 9 + (beg >> 23);
+    if (beg >> 26 == end >> 26) return 1 + (beg >> 26);
+    return 0;
+}
+
+struct Adapter                                                                                 // FragmentAccessorBamAdapter
+{
+    const Stored &s; uint64_t pos; bool withCigar; const BamOptions &o;
+    bool noMatch() const { return pos == NO_MATCH_VALUE; }
+    int refId() const { return noMatch() ? -1 : int(ReferencePosition::fromValue(pos).getContigId()); }
+    int position() const { return noMatch() ? -1 : int(ReferencePosition::fromValue(pos).getPosition()); }
+    std::string readName() const { return *s.namePrefix + std::to_string(s.header->clusterId) + ":0"; }
+    unsigned char mapq() const
+    {
+        const FragmentRecord &h = *s.header;
+        if (s.properPair())
+        {
+            if (DODGY == h.templateAlignmentScore) return o.forcedDodgyAlignmentScore;
+            return std::min<unsigned>(60U, o.pessimisticMapQ ? std::min(h.alignmentScore, h.templateAlignmentScore) : std::max(h.alignmentScore, h.templateAlignmentScore));
+        }
+        return DODGY == h.alignmentScore ? o.forcedDodgyAlignmentScore : std::min<unsigned>(60U, h.alignmentScore);
+    }
+    unsigned flag() const
+    {
+        unsigned bs = 0;
+        bs |= unsigned(s.paired()) << 0; bs |= unsigned(s.properPair()) << 1; bs |= unsigned(s.unmapped()) << 2; bs |= unsigned(s.paired() && s.mateUnmapped()) << 3;
+        bs |= unsigned(s.reverse()) << 4; bs |= unsigned(bool(s.header->flags & 16)) << 5; bs |= unsigned(s.paired() && (s.header->flags & 32)) << 6;
+        bs |= unsigned(s.paired() && s.secondRead()) << 7; bs |= unsigned(bool(s.header->flags & 128)) << 9;
+        return bs;
+    }
+    int nextRefId() const { return s.paired() ? (s.unmapped() && s.mateUnmapped() ? -1 : int(ReferencePosition::fromValue(s.header->mateFStrandPosition).getContigId())) : -1; }
+    int nextPos() const { return s.paired() ? (s.unmapped() && s.mateUnmapped() ? -1 : int(ReferencePosition::fromValue(s.header->mateFStrandPosition).getPosition())) : -1; }
+};
+
+unsigned char bamBase(unsigned char b) { return !isBclN(b) ? 1 << (b & 3) : 15; }              // bamBaseFromBclByte
+
+// bam::serializeAlignment
+void serializeAlignment(std::vector<char> &os, const Adapter &a)
+{
+    const FragmentRecord &h = *a.s.header;
+    const int refID = a.refId(), pos = a.position();
+    const std::string name = a.readName();
+    const unsigned observedLength = h.observedLength;
+    const unsigned bin_mq_nl = unsigned(reg2bin(pos, pos + (observedLength ? observedLength : 1))) << 16 | unsigned(a.mapq()) << 8 | unsigned(name.size() + 1);
+    const size_t cigarLength = a.withCigar ? a.s.cigarEnd - a.s.cigarBegin : 0;
+    const unsigned flag_nc = a.flag() << 16 | (unsigned(cigarLength) & 0xFFFF);
+    const int l_seq = h.readLength;
+    std::vector<unsigned char> seq((l_seq + 1) / 2, 15), qual;
+    for (int i = 0; i + 1 < l_seq; i += 2) seq[i / 2] = bamBase(a.s.bases[i]) << 4 | bamBase(a.s.bases[i + 1]);
+    if (l_seq % 2) seq[l_seq / 2] = bamBase(a.s.bases[l_seq - 1]) << 4;
+    for (int i = 0; i < l_seq; ++i) qual.push_back(a.s.bases[i] >> 2);
+    const bool sm = DODGY != h.alignmentScore, as = a.s.properPair() && DODGY != h.templateAlignmentScore;
+    const int block_size = 32 + int(name.size()) + 1 + int(cigarLength) * 4 + int(seq.size()) + int(qual.size()) + (sm ? 7 : 0) + (as ? 7 : 0) + 7 +
+                           (3 + int(a.o.barcode.size()) + 1) + (3 + int(a.o.readGroup.size()) + 1);
+    putInt(os, block_size); putInt(os, refID); putInt(os, pos); putUnsigned(os, bin_mq_nl); putUnsigned(os, flag_nc);
+    putInt(os, l_seq); putInt(os, a.nextRefId()); putInt(os, a.nextPos()); putInt(os, h.bamTlen);
+    put(os, name.c_str(), name.size() + 1);
+    put(os, a.s.cigarBegin, cigarLength * 4);
+    put(os, seq.data(), seq.size()); put(os, qual.data(), qual.size());
+    if (sm) { put(os, "SMi", 3); putInt(os, h.alignmentScore); }
+    if (as) { put(os, "ASi", 3); putInt(os, h.templateAlignmentScore); }
+    put(os, "RGZ", 3); put(os, a.o.readGroup.c_str(), a.o.readGroup.size() + 1);
+    put(os, "NMi", 3); putInt(os, h.editDistance);
+    put(os, "BCZ", 3); put(os, a.o.barcode.c_str(), a.o.barcode.size() + 1);
+}
+
+} // namespace
+
+void bamRecords(const std::vector<BamTileInput> &tiles, const BamOptions &o, std::vector<char> &os, uint64_t &nRecords, uint64_t &unalignedOffset)
+{
+    std::vector<Stored> stored;
+    for (const BamTileInput &t : tiles)
+        for (uint64_t i = 0; i < t.nRecords; ++i)
+        {
+            const FragmentRecord &h = t.records[i];
+            if (h.reserved & 2) continue;                                     // MatchSelector.cpp:345-357: the template was not stored
+            Stored s; s.header = &h; s.namePrefix = &t.namePrefix;
+            const unsigned readIndex = (h.flags & 1) && (h.flags & 64) ? 1 : 0;
+            const uint8_t *bcl = t.bcl + uint64_t(h.clusterId) * o.clusterLength + o.readOffset[readIndex];
+            s.bases.assign(bcl, bcl + h.readLength);
+            if (s.reverse()) { std::reverse(s.bases.begin(), s.bases.end()); for (unsigned char &b : s.bases) b = reverseBcl(b); }
+            s.cigarBegin = t.cigars + h.cigarOffset; s.cigarEnd = s.cigarBegin + ((h.flags & 2) ? 0 : h.cigarLength);
+            stored.push_back(s);
+        }
+    // aligned bins: everything with a bin position; the unaligned bin keeps storage order
+    std::vector<const Stored *> aligned, unaligned;
+    for (const Stored &s : stored) (s.header->fStrandPosition == NO_MATCH_VALUE ? unaligned : aligned).push_back(&s);
+    std::sort(aligned.begin(), aligned.end(), [](const Stored *l, const Stored *r)
+    {
+        // Index::pos_ is a ReferencePosition; those compare by value (ReferencePosition.hh operator<)
+        const uint64_t lp = l->header->fStrandPosition, rp = r->header->fStrandPosition;
+        if (lp < rp) return true;
+        if (lp == rp)
+        {
+            const uint64_t lc = l->header->tile * CLUSTERS_PER_TILE_FACTOR + l->header->clusterId, rc = r->header->tile * CLUSTERS_PER_TILE_FACTOR + r->header->clusterId;
+            return lc < rc || (lc == rc && (l->unmapped() < r->unmapped() || (l->unmapped() == r->unmapped() && l->secondRead() < r->secondRead())));
+        }
+        return false;
+    });
+    // The unaligned bin is written as stored (Build.cpp: no sort for bin 0).  MatchSelector stores tile after tile in the order of the tile
+    // indexes (FragmentHeader::tile_ is that index) and, within a tile, cluster after cluster when one thread does the work; with several
+    // threads the reference's order inside a tile varies from run to run.  The single-threaded order is the one restated here.
+    std::stable_sort(unaligned.begin(), unaligned.end(), [](const Stored *l, const Stored *r)
+    {
+        return l->header->tile * CLUSTERS_PER_TILE_FACTOR + l->header->clusterId < r->header->tile * CLUSTERS_PER_TILE_FACTOR + r->header->clusterId;
+    });
+    nRecords = 0;
+    for (const Stored *s : aligned) { Adapter a = { *s, s->header->fStrandPosition, true, o }; serializeAlignment(os, a); ++nRecords; }
+    unalignedOffset = os.size();
+    for (const Stored *s : unaligned) { Adapter a = { *s, NO_MATCH_VALUE, false, o }; serializeAlignment(os, a); ++nRecords; }
+}
+
+// bam::serializeHeader (Bam.hh:153-235)
+void bamHeader(const std::string &commandLine, const std::string &description, const std::string &version, const std::vector<std::string> &headerLines,
+               const std::vector<std::pair<std::string, uint32_t> > &refSeqs, std::vector<char> &os)
+{
+    std::string text = "@HD\tVN:1.0\tSO:coordinate\n@PG\tID:iSAAC\tPN:iSAAC\tCL:" + commandLine + "\t" + (description.empty() ? std::string() : ("DS:" + description + "\t")) +
+                       "VN:" + version + "\n";
+    for (const std::string &l : headerLines) text += l + "\n";
+    for (const auto &r : refSeqs) text += "@SQ\tSN:" + r.first + "\tLN:" + std::to_string(r.second) + "\n";
+    put(os, "BAM\1", 4); putInt(os, int(text.size())); put(os, text.data(), text.size());
+    putInt(os, int(refSeqs.size()));
+    for (const auto &r : refSeqs) { putInt(os, int(r.first.size() + 1)); put(os, r.first.c_str(), r.first.size() + 1); putInt(os, int(r.second)); }
+}
+
+} // namespace oracle

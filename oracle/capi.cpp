@@ -820,3 +820,51 @@ int oracle_find_neighbors(uint32_t kmer_bases, const uint64_t *hi, const uint64_
 }
 
 } // extern "C"
+
+// ---- BAM records and header (bam.cpp) ---------------------------------------------------------------------------
+extern "C" {
+typedef struct { const uint8_t *bcl; const void *records; const uint32_t *cigars; uint64_t n_records; const char *read_name_prefix; } oracle_bam_tile;
+
+int oracle_bam_records(const oracle_bam_tile *tiles, uint32_t n_tiles, uint32_t n_reads, const uint32_t *read_lengths, uint32_t forced_dodgy_alignment_score,
+                       int pessimistic_mapq, const char *read_group, const char *barcode, uint8_t *out, uint64_t capacity, uint64_t *n_bytes,
+                       uint64_t *n_records, uint64_t *unaligned_offset)
+{
+    try
+    {
+        std::vector<BamTileInput> in;
+        for (uint32_t i = 0; i < n_tiles; ++i)
+        {
+            BamTileInput t = { tiles[i].bcl, static_cast<const FragmentRecord *>(tiles[i].records), tiles[i].cigars, tiles[i].n_records, tiles[i].read_name_prefix };
+            in.push_back(t);
+        }
+        BamOptions o; o.clusterLength = 0; o.readOffset[0] = o.readOffset[1] = 0;
+        for (uint32_t r = 0; r < n_reads; ++r) { o.readOffset[r] = o.clusterLength; o.clusterLength += read_lengths[r]; }
+        o.forcedDodgyAlignmentScore = (unsigned char)forced_dodgy_alignment_score; o.pessimisticMapQ = pessimistic_mapq; o.readGroup = read_group; o.barcode = barcode;
+        std::vector<char> os;
+        bamRecords(in, o, os, *n_records, *unaligned_offset);
+        *n_bytes = os.size();
+        if (os.size() > capacity) throw std::runtime_error("bam capacity");
+        memcpy(out, os.data(), os.size());
+        return 0;
+    }
+    catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+
+int oracle_bam_header(const char *command_line, const char *description, const char *version, const char *const *header_lines, uint32_t n_header_lines,
+                      const char *const *contig_names, const uint32_t *contig_lengths, uint32_t n_contigs, uint8_t *out, uint64_t capacity, uint64_t *n_bytes)
+{
+    try
+    {
+        std::vector<std::string> lines(header_lines, header_lines + n_header_lines);
+        std::vector<std::pair<std::string, uint32_t> > refs;
+        for (uint32_t i = 0; i < n_contigs; ++i) refs.push_back(std::make_pair(std::string(contig_names[i]), contig_lengths[i]));
+        std::vector<char> os;
+        bamHeader(command_line, description, version, lines, refs, os);
+        *n_bytes = os.size();
+        if (os.size() > capacity) throw std::runtime_error("bam capacity");
+        memcpy(out, os.data(), os.size());
+        return 0;
+    }
+    catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+} // extern "C"

@@ -680,4 +680,11 @@ struct MatchSelector
                     std::vector<FragmentRecord> &records, std::vector<uint32_t> &cigarPool);
 };
 
+// bam.cpp: the BAM record stream of a set of tiles (build::Build with --realign-gaps no --mark-duplicates 0) and the BAM header
+struct BamTileInput { const uint8_t *bcl; const FragmentRecord *records; const uint32_t *cigars; uint64_t nRecords; std::string namePrefix; };
+struct BamOptions { unsigned clusterLength, readOffset[2]; unsigned char forcedDodgyAlignmentScore; bool pessimisticMapQ; std::string readGroup, barcode; };
+void bamRecords(const std::vector<BamTileInput> &tiles, const BamOptions &o, std::vector<char> &os, uint64_t &nRecords, uint64_t &unalignedOffset);
+void bamHeader(const std::string &commandLine, const std::string &description, const std::string &version, const std::vector<std::string> &headerLines,
+               const std::vector<std::pair<std::string, uint32_t> > &refSeqs, std::vector<char> &os);
+
 } // namespace oracle

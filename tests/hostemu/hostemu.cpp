@@ -5,6 +5,7 @@
 // against the oracle before a GPU box is spent on them.  It is not part of the product library and the product has no CPU path.
 #include "../../isaac_aligner_amd/csrc/cluster_ops.h"
 #include "../../isaac_aligner_amd/csrc/sums.h"
+#include "../../isaac_aligner_amd/csrc/bam_kernels.h"
 #include "../../isaac_aligner_amd/csrc/host_util.h"
 #include <string>
 #include <vector>
@@ -331,6 +332,48 @@ void emu_std_sort(const u32 *keys, u32 n, u16 *perm)
 {
     for (u32 i = 0; i < n; ++i) perm[i] = u16(i);
     std::sort(perm, perm + n, [&](u16 a, u16 b) { return keys[a] < keys[b]; });
+}
+
+// the device logic of isaac_gpu_bam_records (bam_kernels.h: keys, record sizes, record bytes) with std::stable_sort in place of the radix passes
+int emu_bam_records(const isaac_bam_tile *tiles, u32 nTiles, u32 nReads, const u32 *readLengths, u32 forcedDodgy, int pessimistic, const char *readGroup, const char *barcode,
+                    u8 *out, u64 capacity, u64 *nBytes, u64 *nRecords, u64 *unalignedOffset)
+{
+    BamOptions o; std::memset(&o, 0, sizeof(o));
+    o.nReads = nReads;
+    for (u32 r = 0; r < nReads; ++r) { o.readLength[r] = readLengths[r]; o.readOffset[r] = o.clusterLength; o.clusterLength += readLengths[r]; }
+    std::strcpy(o.readGroup, readGroup); o.readGroupLength = u32(std::strlen(readGroup)); std::strcpy(o.barcode, barcode); o.barcodeLength = u32(std::strlen(barcode));
+    o.forcedDodgyAlignmentScore = forcedDodgy; o.pessimisticMapQ = pessimistic;
+    std::vector<BamTile> t(nTiles);
+    struct Key { u64 hi, lo; u32 tile; u64 index; };
+    std::vector<Key> keys;
+    for (u32 i = 0; i < nTiles; ++i)
+    {
+        std::memset(&t[i], 0, sizeof(BamTile));
+        t[i].bcl = tiles[i].bcl_dev; t[i].records = reinterpret_cast<const FragmentRecord *>(tiles[i].fragments_dev); t[i].cigars = tiles[i].cigar_dev;
+        t[i].nRecords = u32(tiles[i].n_records); t[i].nameLength = u32(std::strlen(tiles[i].read_name_prefix)); std::memcpy(t[i].name, tiles[i].read_name_prefix, t[i].nameLength);
+        for (u64 k = 0; k < tiles[i].n_records; ++k)
+        {
+            const FragmentRecord &r = t[i].records[k];
+            Key key; key.tile = i; key.index = k;
+            key.hi = !bamStored(r) ? ~u64(0) : bamUnalignedBin(r) ? ~u64(0) - 1 : r.fStrandPosition;
+            key.lo = ((u64(r.tile) * INSANELY_HIGH_NUMBER_OF_CLUSTERS_PER_TILE + r.clusterId) << 2) | ((r.flags & 2) ? 2u : 0u) | ((r.flags & 64) ? 1u : 0u);
+            keys.push_back(key);
+        }
+    }
+    std::stable_sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); });
+    u64 at = 0; *nRecords = 0; *unalignedOffset = ~u64(0);
+    for (const Key &k : keys)
+    {
+        if (k.hi == ~u64(0)) break;
+        if (k.hi == ~u64(0) - 1 && *unalignedOffset == ~u64(0)) *unalignedOffset = at;
+        const FragmentRecord &r = t[k.tile].records[k.index];
+        const u32 n = bamRecordBytes(t[k.tile], r, o);
+        if (at + n <= capacity) bamWriteRecord(t[k.tile], r, o, out + at);
+        at += n; ++*nRecords;
+    }
+    if (*unalignedOffset == ~u64(0)) *unalignedOffset = at;
+    *nBytes = at;
+    return at <= capacity ? 0 : 4;
 }
 
 uint32_t emu_sizeof(int what)

@@ -53,6 +53,10 @@ INDEX_DTYPE = np.dtype([("kmer", "<u8"), ("position", "<u8")])
 CIGAR_OPS = "MIDNSHP=X?"
 
 
+class BamTile(C.Structure):
+    _fields_ = [("bcl", C.c_void_p), ("records", C.c_void_p), ("cigars", C.c_void_p), ("n_records", C.c_uint64), ("read_name_prefix", C.c_char_p)]
+
+
 def cigar_string(words):
     return "".join("%d%s" % (int(w) >> 4, CIGAR_OPS[min(int(w) & 0xF, 9)]) for w in words)
 
@@ -71,6 +75,35 @@ class Oracle:
     def check(self, rc):
         if rc:
             raise RuntimeError(self.lib.oracle_last_error().decode())
+
+    def bam_records(self, tiles, read_lengths, forced_dodgy_alignment_score=0, pessimistic_mapq=False, read_group="0", barcode="none"):
+        """tiles: [(bcl, records, cigars, read_name_prefix)] as numpy arrays; returns (bytes, n_records, unaligned_offset)"""
+        arr = (BamTile * len(tiles))()
+        keep = []
+        total = 0
+        for i, (bcl, records, cigars, prefix) in enumerate(tiles):
+            bcl, records, cigars = np.ascontiguousarray(bcl, np.uint8), np.ascontiguousarray(records), np.ascontiguousarray(cigars, np.uint32)
+            keep.append((bcl, records, cigars, prefix.encode()))
+            arr[i].bcl = bcl.ctypes.data; arr[i].records = records.ctypes.data; arr[i].cigars = cigars.ctypes.data
+            arr[i].n_records = len(records); arr[i].read_name_prefix = keep[-1][3]
+            total += len(records)
+        lengths = (C.c_uint32 * 2)(*(list(read_lengths) + [0])[:2])
+        cap = max(1, total * (128 + 2 * max(read_lengths) + 4 * 64))
+        out = np.empty(cap, np.uint8)
+        nb, nr, un = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self.check(self.lib.oracle_bam_records(arr, C.c_uint32(len(tiles)), C.c_uint32(len(read_lengths)), lengths, C.c_uint32(forced_dodgy_alignment_score), C.c_int(int(pessimistic_mapq)),
+                                               read_group.encode(), barcode.encode(), ptr(out), C.c_uint64(cap), C.byref(nb), C.byref(nr), C.byref(un)))
+        return out[:nb.value].tobytes(), nr.value, un.value
+
+    def bam_header(self, command_line, version, contigs, description="", header_lines=()):
+        lines = (C.c_char_p * max(1, len(header_lines)))(*[l.encode() for l in header_lines])
+        names = (C.c_char_p * max(1, len(contigs)))(*[n.encode() for n, _ in contigs])
+        lengths = (C.c_uint32 * max(1, len(contigs)))(*[l for _, l in contigs])
+        out = np.empty(1 << 20, np.uint8)
+        n = C.c_uint64()
+        self.check(self.lib.oracle_bam_header(command_line.encode(), description.encode(), version.encode(), lines, C.c_uint32(len(header_lines)), names, lengths, C.c_uint32(len(contigs)),
+                                              ptr(out), C.c_uint64(out.size), C.byref(n)))
+        return out[:n.value].tobytes()
 
     def default_params(self, n_reads, len1, len2=0):
         p = Params()

@@ -1,0 +1,245 @@
+"""The output side of the path: BAM records, header and BGZF framing against the oracle's restatement of
+build::Build / bam::serializeAlignment / bgzf::BgzfCompressor."""
+import ctypes as C
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+import hostemu_lib
+import oracle_lib
+from isaac_aligner_amd import abi, bam, options, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def noisy_mates(bcl, read_length, step, rng):
+    """every step-th cluster gets a random second read: singletons with shadows"""
+    for k in range(0, len(bcl), step):
+        bcl[k, read_length:] = (rng.integers(0, 4, bcl.shape[1] - read_length) | (30 << 2)).astype(np.uint8)
+
+
+def make_tiles(n_tiles=2, n_clusters=600, read_length=100, seed=5, keep_unaligned=True):
+    """oracle results for a few small tiles: (params, contigs, [(bcl, records, cigars, prefix)])"""
+    o = oracle_lib.load()
+    rng = np.random.default_rng(seed)
+    contigs = [bytes(c.numpy()) for c in synth.make_genome(60000, seed=seed, n_contigs=3)]
+    params = options.default_params(read_length, read_length)
+    params.keep_unaligned = int(keep_unaligned)
+    ref = o.reference(contigs)
+    ref.build_index()
+    tiles = []
+    for t in range(n_tiles):
+        bcl = synth.make_read_pairs([__import__("torch").from_numpy(np.frombuffer(c, np.uint8).copy()) for c in contigs], n_clusters, read_length, seed=seed + 10 + t,
+                                    indel_read_fraction=0.1, n_rate=0.004, random_pair_fraction=0.06)[0].numpy()
+        noisy_mates(bcl, read_length, 23, rng)
+        tile = 1101 + 7 * t
+        matches, hits = ref.find_matches(params, bcl, n_clusters, tile=tile)
+        tls = ref.determine_tls(params, bcl, matches, hits, tile=tile)
+        records, cigars, _ = ref.select(params, bcl, matches, tls, hits, tile=tile, n_clusters_hint=n_clusters)
+        tiles.append((bcl, records, cigars, "FC%d:%d:%d:" % (t, 1 + t, tile)))
+    return params, contigs, tiles
+
+
+def emu_bam_records(tiles, read_lengths, forced=0, pessimistic=False, read_group="0", barcode="none"):
+    lib = hostemu_lib.load()
+    arr = (bam.BamTile * len(tiles))()
+    keep = []
+    total = 0
+    for i, (bcl, records, cigars, prefix) in enumerate(tiles):
+        keep.append((np.ascontiguousarray(bcl, np.uint8), np.ascontiguousarray(records), np.ascontiguousarray(cigars, np.uint32), prefix.encode()))
+        arr[i].bcl_dev, arr[i].fragments_dev, arr[i].cigar_dev = keep[-1][0].ctypes.data, keep[-1][1].ctypes.data, keep[-1][2].ctypes.data
+        arr[i].n_records, arr[i].read_name_prefix = len(records), keep[-1][3]
+        total += len(records)
+    cap = total * (400 + 2 * max(read_lengths))
+    out = np.empty(cap, np.uint8)
+    nb, nr, un = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    lengths = (C.c_uint32 * 2)(*read_lengths)
+    rc = lib.emu_bam_records(arr, C.c_uint32(len(tiles)), C.c_uint32(2), lengths, C.c_uint32(forced), C.c_int(int(pessimistic)), read_group.encode(), barcode.encode(),
+                             out.ctypes.data_as(C.c_void_p), C.c_uint64(cap), C.byref(nb), C.byref(nr), C.byref(un))
+    assert rc == 0
+    return out[:nb.value].tobytes(), nr.value, un.value
+
+
+def check_stream(stream, tiles, n_records):
+    """properties of the record stream that do not need the oracle: sorted by (ref, pos), unaligned last, every stored read once"""
+    recs = bam.parse_records(stream)
+    assert len(recs) == n_records
+    aligned = [r for r in recs if r["ref_id"] >= 0]
+    assert recs[:len(aligned)] == aligned or all(r["ref_id"] < 0 for r in recs[len(aligned):])
+    keys = [(r["ref_id"], r["pos"]) for r in aligned]
+    assert keys == sorted(keys)
+    names = {}
+    for r in recs:
+        names[(r["name"], r["flag"] & 0xc0)] = names.get((r["name"], r["flag"] & 0xc0), 0) + 1
+    assert all(v == 1 for v in names.values())
+    return recs
+
+
+@pytest.mark.parametrize("keep_unaligned", [True, False])
+def test_device_record_logic_matches_the_oracle_on_cpu(keep_unaligned):
+    """bam_kernels.h compiled for the host (tests/hostemu) against oracle/bam.cpp: byte-identical record streams"""
+    params, contigs, tiles = make_tiles(keep_unaligned=keep_unaligned)
+    o = oracle_lib.load()
+    lengths = [params.read_length[0], params.read_length[1]]
+    for kwargs in (dict(), dict(forced_dodgy_alignment_score=255, pessimistic_mapq=True, read_group="7", barcode="ACGTTG-NNAC")):
+        want, want_n, want_un = o.bam_records(tiles, lengths, **kwargs)
+        assert o.bam_records(tiles[::-1], lengths, **kwargs)[0] == want          # the order in which the tiles are handed over does not matter
+        got, got_n, got_un = emu_bam_records(tiles[::-1], lengths, kwargs.get("forced_dodgy_alignment_score", 0), kwargs.get("pessimistic_mapq", False), kwargs.get("read_group", "0"),
+                                             kwargs.get("barcode", "none"))
+        assert (got_n, got_un) == (want_n, want_un)
+        assert got == want
+    recs = check_stream(want, tiles, want_n)
+    stored = sum(int(((t[1]["reserved"] & 2) == 0).sum()) for t in tiles)
+    assert want_n == stored
+    if keep_unaligned:
+        assert any(r["ref_id"] < 0 for r in recs) and want_un < len(want)
+    # a shadow follows its singleton at the singleton's position
+    shadows = [i for i, r in enumerate(recs) if (r["flag"] & 4) and r["ref_id"] >= 0]
+    assert shadows
+    for i in shadows:
+        assert recs[i - 1]["name"] == recs[i]["name"] and not (recs[i - 1]["flag"] & 4) and recs[i - 1]["pos"] == recs[i]["pos"] and (recs[i - 1]["flag"] & 8)
+
+
+def test_record_fields_follow_the_adapter():
+    """spot checks of serializeAlignment's fields on the oracle's stream: flags, MAPQ, bin, sequence orientation, tags"""
+    params, contigs, tiles = make_tiles(n_tiles=1, n_clusters=300)
+    o = oracle_lib.load()
+    L = params.read_length[0]
+    stream, n, _ = o.bam_records(tiles, [L, L])
+    recs = bam.parse_records(stream)
+    bcl, records, cigars, prefix = tiles[0]
+    by_key = {(int(r["cluster_id"]), int(bool(r["flags"] & 64))): r for r in records}
+    checked = 0
+    for r in recs:
+        cluster = int(r["name"][len(prefix):-2])
+        assert r["name"].startswith(prefix) and r["name"].endswith(":0")
+        h = by_key[(cluster, int(bool(r["flag"] & 128)))]
+        assert r["mapq"] == int(h["mapq"])
+        assert r["tlen"] == int(h["bam_tlen"])
+        assert r["tags"]["NM"] == int(h["edit_distance"]) and r["tags"]["RG"] == "0" and r["tags"]["BC"] == "none"
+        assert ("AS" in r["tags"]) == (bool(h["flags"] & 256) and int(h["template_alignment_score"]) != 0xffff)
+        assert ("SM" in r["tags"]) == (int(h["alignment_score"]) != 0xffff)
+        if not (r["flag"] & 4):
+            assert r["ref_id"] == int(abi.refpos_contig(h["f_strand_position"])) and r["pos"] == int(abi.refpos_position(h["f_strand_position"]))
+            assert abi.cigar_string(r["cigar"]) == abi.cigar_string(cigars[int(h["cigar_offset"]):int(h["cigar_offset"]) + int(h["cigar_length"])])
+            # the sequence is the forward-strand one: it matches the reference where the CIGAR says so, for a clean read
+            if int(h["edit_distance"]) == 0 and abi.cigar_string(r["cigar"]) == "%dM" % L:
+                assert r["seq"] == contigs[r["ref_id"]][r["pos"]:r["pos"] + L].decode()
+                checked += 1
+        else:
+            assert len(r["cigar"]) == 0
+    assert checked > 50
+
+
+def test_header_matches_the_oracle():
+    o = oracle_lib.load()
+    contigs = [("chr1", 248956422), ("chrUn_KI270302v1", 2274), ("phiX", 5386)]
+    lines = ["@CO\tmade by a test", "@RG\tID:0\tPL:ILLUMINA\tSM:s1\tPU:FC0:1:none"]
+    for description in ("", "a run"):
+        want = o.bam_header("isaac-align -r ref.xml -b Data", "iSAAC-01.15", contigs, description, lines)
+        got = bam.header("isaac-align -r ref.xml -b Data", "iSAAC-01.15", contigs, description, lines)
+        assert got == want
+    text_len = int.from_bytes(got[4:8], "little")
+    text = got[8:8 + text_len].decode()
+    assert got[:4] == b"BAM\x01" and text.startswith("@HD\tVN:1.0\tSO:coordinate\n@PG\tID:iSAAC\tPN:iSAAC\tCL:isaac-align") and "DS:a run\tVN:iSAAC-01.15\n" in text
+    assert text.count("@SQ") == 3 and "@SQ\tSN:phiX\tLN:5386\n" in text
+    assert bam.header("", "", []) == o.bam_header("", "", [])
+
+
+@pytest.mark.parametrize("level", [0, 1, 6])
+def test_bgzf_blocks_round_trip(level, tmp_path):
+    rng = np.random.default_rng(3)
+    data = (rng.integers(0, 4, 300000) + 65).astype(np.uint8).tobytes() + bytes(rng.integers(0, 256, 100000, dtype=np.uint8))
+    z = bam.bgzf_compress(data, level=level, n_threads=3, eof_block=True)
+    assert gzip.decompress(z) == data                      # a BGZF file is a series of gzip members
+    # block structure: BC extra field, BSIZE, at most 0xFFFF - 41 input bytes per block, the 28-byte end-of-file block last
+    at, sizes = 0, []
+    while at < len(z):
+        assert z[at:at + 4] == b"\x1f\x8b\x08\x04" and z[at + 10:at + 16] == b"\x06\x00BC\x02\x00"
+        bsize = int.from_bytes(z[at + 16:at + 18], "little") + 1
+        sizes.append(int.from_bytes(z[at + bsize - 4:at + bsize], "little"))
+        at += bsize
+    assert at == len(z) and sizes[-1] == 0 and all(s == 0xFFFF - 41 for s in sizes[:-2]) and sum(sizes) == len(data)
+    assert z[-28:] == bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    assert bam.bgzf_compress(b"", level=level) == b""
+    # the same bytes whatever the number of threads
+    assert bam.bgzf_compress(data, level=level, n_threads=1, eof_block=True) == z
+    path = tmp_path / "x.bam"
+    bam.write_bam(str(path), b"BAM\x01" + bytes(8), data, level=level)
+    assert gzip.open(str(path)).read() == b"BAM\x01" + bytes(8) + data
+
+
+@pytest.mark.gpu
+def test_gpu_bam_records_match_the_oracle():
+    """isaac_gpu_bam_records on the records the GPU path itself produced == oracle/bam.cpp on the same records, byte for byte;
+    with fixed-slot and with packed CIGAR pools, one tile and several"""
+    import torch
+    from isaac_aligner_amd import gpu
+    o = oracle_lib.load()
+    rng = np.random.default_rng(11)
+    L = 100
+    genome = synth.make_genome(150000, seed=11, n_contigs=3)
+    contigs = [bytes(c.numpy()) for c in genome]
+    params = options.default_params(L, L)
+    a = gpu.Aligner(params, 0, contigs)
+    a.build_index()
+    dev_tiles, host_tiles = [], []
+    for t in range(3):
+        bcl = synth.make_read_pairs(genome, 5000, L, seed=20 + t, indel_read_fraction=0.1, n_rate=0.004, random_pair_fraction=0.05)[0].numpy()
+        noisy_mates(bcl, L, 19, rng)
+        tile = 2101 + t
+        d_bcl = torch.from_numpy(bcl).cuda()
+        records, cigars = a.align_tile(d_bcl, tile=tile)
+        if t == 1:
+            cigars, _ = a.compact_cigars(records, cigars)
+        prefix = "HFC%d:2:%d:" % (t, tile)
+        dev_tiles.append((d_bcl, records, cigars, prefix))
+        r, c = a.records_to_numpy(records, cigars)
+        host_tiles.append((bcl, r, c, prefix))
+    for subset in ([0], [0, 1, 2], [2, 1]):
+        for kwargs in (dict(), dict(read_group="3", barcode="ACGT", forced_dodgy_alignment_score=255, pessimistic_mapq=True)):
+            got, n, un = a.bam_records([dev_tiles[i] for i in subset], **kwargs)
+            okw = dict(kwargs)
+            okw.setdefault("forced_dodgy_alignment_score", params.dodgy_alignment_score & 0xff)
+            want, want_n, want_un = o.bam_records([host_tiles[i] for i in subset], [L, L], **okw)
+            assert (n, un) == (want_n, want_un)
+            assert got.cpu().numpy().tobytes() == want
+    check_stream(want, host_tiles, want_n)
+    # too small a buffer reports the size it needs
+    small = torch.empty(1000, dtype=torch.uint8, device="cuda")
+    nb = C.c_uint64()
+    arr = (bam.BamTile * 1)()
+    arr[0].bcl_dev, arr[0].fragments_dev, arr[0].cigar_dev = dev_tiles[0][0].data_ptr(), dev_tiles[0][1].data_ptr(), dev_tiles[0][2].data_ptr()
+    arr[0].n_records, arr[0].read_name_prefix = dev_tiles[0][1].shape[0], b"x:"
+    rc = a.lib.isaac_gpu_bam_records(a.h, arr, C.c_uint32(1), None, C.c_void_p(small.data_ptr()), C.c_uint64(1000), C.byref(nb), None, None)
+    assert rc == 4 and nb.value > 1000
+    # no records at all
+    got, n, un = a.bam_records([(dev_tiles[0][0], dev_tiles[0][1][:0], dev_tiles[0][2], "x:")])
+    assert got.numel() == 0 and n == 0
+
+
+@pytest.mark.gpu
+def test_gpu_bam_file_is_readable(tmp_path):
+    """end to end: tile -> records -> BAM file; the file inflates to header + records and its records are sorted"""
+    import torch
+    from isaac_aligner_amd import gpu
+    L = 150
+    genome = synth.make_genome(200000, seed=12, n_contigs=2)
+    contigs = [bytes(c.numpy()) for c in genome]
+    a = gpu.Aligner(options.default_params(L, L), 0, contigs)
+    a.build_index()
+    bcl = synth.make_read_pairs(genome, 20000, L, seed=13)[0].numpy()
+    d_bcl = torch.from_numpy(bcl).cuda()
+    records, cigars = a.align_tile(d_bcl, tile=1101)
+    stream, n, un = a.bam_records([(d_bcl, records, cigars, "FC:1:1101:")])
+    header = bam.header("test", "0", [("c%d" % i, len(c)) for i, c in enumerate(contigs)])
+    path = str(tmp_path / "sorted.bam")
+    bam.write_bam(path, header, stream.cpu().numpy(), level=1)
+    raw = gzip.open(path).read()
+    assert raw[:len(header)] == header
+    recs = bam.parse_records(raw[len(header):])
+    assert len(recs) == n == 40000
+    keys = [(r["ref_id"], r["pos"]) for r in recs if r["ref_id"] >= 0]
+    assert keys == sorted(keys) and len(keys) > 39000
