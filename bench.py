@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--cpu-sample-pairs", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="also skips the parity check, which uses the same oracle records")
     ap.add_argument("--no-pcie-pass", action="store_true")
+    ap.add_argument("--no-bam-pass", action="store_true")
     ap.add_argument("--no-neighbors", action="store_true")
     ap.add_argument("--launch-check", action="store_true", help="GPU-less check of the launcher and the collectives (gloo): no alignment")
     return ap.parse_args()
@@ -264,6 +265,24 @@ def main():
                 "bytes_in_per_pair": 2 * L, "bytes_out_per_pair": round((sum(r.numel() for r in host_rec) + 4 * sum(int(p.numel()) for p in packed)) / pairs_rank, 1),
                 "note": "BCL bytes uploaded from pinned host memory ahead of the lookups, records + packed CIGARs downloaded while the next step computes"}
 
+    # ---- the output side: all steps' records as one position-sorted BAM record stream, resident in HBM; reported beside `value`
+    bam_info = None
+    if not args.no_bam_pass and dist is None:
+        tiles = [(batches[args.warmup + s], out[s][0], out[s][2], "SYNTH:1:%d:" % tile_of(s)) for s in range(args.steps)]
+        bam_buf = torch.empty(sum(o_[0].shape[0] for o_ in out) * (100 + L + (L + 1) // 2 + 8), dtype=torch.uint8, device=dev)
+        al.bam_records(tiles, out=bam_buf)               # warm-up: scratch allocation
+        al.reset_timers()
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        stream_bytes, n_bam, unaligned_at = al.bam_records(tiles, out=bam_buf)
+        torch.cuda.synchronize()
+        t_bam = time.perf_counter() - tb
+        bam_info = {"records": int(n_bam), "bytes": int(stream_bytes.numel()), "ms": round(1e3 * t_bam, 3), "records_per_s": round(n_bam / t_bam, 1),
+                    "GB_per_s_written": round(stream_bytes.numel() / t_bam / 1e9, 2), "order_ms": round(al.kernel_time_ms("bam_order")[0], 3),
+                    "encode_ms": round(al.kernel_time_ms("bam_encode")[0], 3), "unaligned_bin_offset": int(unaligned_at),
+                    "note": "isaac_gpu_bam_records over the records of all %d steps (two radix passes + one encode launch); BGZF deflate stays on the host" % args.steps}
+        del bam_buf, stream_bytes
+
     # ---- roofline of the dominant kernel: algorithmic bytes (stated per kernel in DESIGN.md) / event-timed duration
     c = counters
     seeded_scans = max(0, c["ungapped_scans"] - c["rescue_candidates"])
@@ -359,6 +378,16 @@ def main():
         parity = {"parity_checked_pairs": int(sample), "parity_diffs": int(n_diff)}
         if text:
             parity["first_diffs"] = text[:3]
+        if bam_info is not None:
+            # the BAM record stream of the same pairs: GPU path on its own records against oracle/bam.cpp on the oracle's records, byte for byte
+            prefix = "SYNTH:1:%d:" % tile_of(0)
+            gbam = al.bam_records([(batches[args.warmup][:sample], checked_records[:2 * sample], checked_cigars, prefix)])[0].cpu().numpy().tobytes()
+            obam = orc.bam_records([(host_bcl, orec, ocig, prefix)], [L, L], forced_dodgy_alignment_score=p.dodgy_alignment_score & 0xff)[0]
+            bam_info.update({"parity_checked_bytes": len(obam), "parity_identical": gbam == obam})
+            if gbam != obam:
+                m_ = min(len(gbam), len(obam))
+                d_ = np.flatnonzero(np.frombuffer(gbam, np.uint8)[:m_] != np.frombuffer(obam, np.uint8)[:m_])
+                bam_info["first_difference_at"] = int(d_[0]) if len(d_) else m_
 
     workload = "GRCh38-sized synthetic human-like reference (%d bp in %d contigs, 32-mer index %d entries), %d synthetic 2x%d bp pairs per GPU (%d steps x %d pairs)" % (
         args.genome_bases, len(genome), n_index, pairs_rank, L, args.steps, per_rank)
@@ -367,7 +396,7 @@ def main():
               "scaling": args.scaling, "vs_baseline": None, "dtype": "u8/int16 (+f64 log-probabilities)", "data": "synthetic",
               "config": {"workload": workload, "pairs_per_step": args.pairs_per_step, "read_length": L, "genome_bases": args.genome_bases, "index_entries": int(n_index),
                          "parallelism": "read shards x%d, records and CIGARs gathered once" % world, "hbm_used_gb": hbm_used_gb, "setup_s": round(t_setup, 1),
-                         "genome_s": round(t_genome, 1), "index_build_s": round(t_index, 1), "tls": list(tls.astuple()), "pcie_inclusive": pcie},
+                         "genome_s": round(t_genome, 1), "index_build_s": round(t_index, 1), "tls": list(tls.astuple()), "pcie_inclusive": pcie, "bam_output": bam_info},
               "roofline": roofline, "cpu_baseline": cpu, "counters": {k: int(v) for k, v in counters.items()}}
     result.update(parity)
     print(json.dumps(result))

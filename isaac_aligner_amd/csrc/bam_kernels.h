@@ -68,58 +68,90 @@ ISAAC_HD u32 bamRecordBytes(const BamTile &t, const FragmentRecord &r, const Bam
     return n;
 }
 
-struct BamWriter
+// Where the parts of one record lie and the values that are the same for all of its bytes.  A record is written by a whole wave, lane j
+// producing bytes j, j + 64, ...: every store instruction covers 64 consecutive bytes.
+struct BamLayout
 {
-    u8 *p;
-    ISAAC_HD void u32le(u32 v) { p[0] = u8(v); p[1] = u8(v >> 8); p[2] = u8(v >> 16); p[3] = u8(v >> 24); p += 4; }
-    ISAAC_HD void byte(u8 v) { *p++ = v; }
-    ISAAC_HD void iTag(char a, char b, u32 v) { byte(u8(a)); byte(u8(b)); byte(u8('i')); u32le(v); }
-    ISAAC_HD void zTag(char a, char b, const char *s, u32 n) { byte(u8(a)); byte(u8(b)); byte(u8('Z')); for (u32 i = 0; i < n; ++i) byte(u8(s[i])); byte(0); }
+    u32 words[9];                                    // block_size, refID, pos, bin_mq_nl, flag_nc, l_seq, next_refID, next_pos, tlen
+    u32 nameBegin, digitsBegin, nameTail, cigarBegin, seqBegin, qualBegin, tagBegin, total;
+    u32 digits, clusterId, nCigar, readLength, reverse, smAt, asAt, rgAt, nmAt, bcAt;   // tag offsets relative to tagBegin (~0u: absent)
+    u32 sm, as, nm;
+    const u8 *bcl; const u32 *cigar;
 };
 
-// bam::serializeAlignment (Bam.hh:257-345) for one record; `out` has bamRecordBytes() bytes
-ISAAC_HD void bamWriteRecord(const BamTile &t, const FragmentRecord &r, const BamOptions &o, u8 *out)
+// bam::serializeAlignment (Bam.hh:257-345): the fixed part and the section boundaries
+ISAAC_HD void bamLayout(const BamTile &t, const FragmentRecord &r, const BamOptions &o, BamLayout &l)
 {
-    BamWriter w; w.p = out;
     const bool aligned = !(r.flags & 2), unalignedBin = bamUnalignedBin(r), paired = r.flags & 1;
     // FragmentAccessorBamAdapter::operator(): aligned fragments and shadows carry the bin index position, unaligned templates NoMatch
     const i32 refId = unalignedBin ? -1 : i32(refposContig(r.fStrandPosition)), pos = unalignedBin ? -1 : i32(refposPosition(r.fStrandPosition));
-    const u32 nameLength = bamReadNameLength(t, r);
-    const u32 nCigar = aligned ? r.cigarLength : 0;
-    const u32 observed = r.observedLength;
-    w.u32le(bamRecordBytes(t, r, o) - 4);
-    w.u32le(u32(refId)); w.u32le(u32(pos));
-    w.u32le((bamReg2bin(u32(pos), u32(pos) + (observed ? observed : 1)) << 16) | (bamMapq(r, o) << 8) | (nameLength + 1));
-    w.u32le((bamFlag(r) << 16) | (nCigar & 0xffff));
-    w.u32le(r.readLength);
+    const u32 nameLength = bamReadNameLength(t, r), observed = r.observedLength;
+    l.nCigar = aligned ? r.cigarLength : 0;
+    l.total = bamRecordBytes(t, r, o);
     const bool noMate = !paired || ((r.flags & 2) && (r.flags & 4));
-    w.u32le(noMate ? u32(-1) : u32(refposContig(r.mateFStrandPosition)));
-    w.u32le(noMate ? u32(-1) : u32(refposPosition(r.mateFStrandPosition)));
-    w.u32le(u32(r.bamTlen));
-    for (u32 i = 0; i < t.nameLength; ++i) w.byte(u8(t.name[i]));
-    { u32 digits = decimalDigits(r.clusterId), v = r.clusterId; for (u32 i = 0; i < digits; ++i) { w.p[digits - 1 - i] = u8('0' + v % 10); v /= 10; } w.p += digits; }
-    w.byte(u8(':')); w.byte(u8('0')); w.byte(0);
-    const u32 *cigar = t.cigars + r.cigarOffset;
-    for (u32 i = 0; i < nCigar; ++i) w.u32le(cigar[i]);
-    // the bases as FragmentCollector::storeBclAndCigar keeps them (reverse-complemented for reverse alignments, :84-96), 4 bits each
-    // (bamBaseFromBclByte :218-221), then the qualities (bamQualFromBclByte :228-230)
-    const u32 readIndex = (r.flags & 64) && paired ? 1u : 0u, L = r.readLength;
-    const u8 *bcl = t.bcl + u64(r.clusterId) * o.clusterLength + o.readOffset[readIndex];
-    const bool reverse = r.flags & 8;
-    u32 packed = 0;
-    for (u32 i = 0; i < L; ++i)
+    l.words[0] = l.total - 4; l.words[1] = u32(refId); l.words[2] = u32(pos);
+    l.words[3] = (bamReg2bin(u32(pos), u32(pos) + (observed ? observed : 1)) << 16) | (bamMapq(r, o) << 8) | (nameLength + 1);
+    l.words[4] = (bamFlag(r) << 16) | (l.nCigar & 0xffff);
+    l.words[5] = r.readLength;
+    l.words[6] = noMate ? u32(-1) : u32(refposContig(r.mateFStrandPosition));
+    l.words[7] = noMate ? u32(-1) : u32(refposPosition(r.mateFStrandPosition));
+    l.words[8] = u32(r.bamTlen);
+    l.digits = decimalDigits(r.clusterId); l.clusterId = r.clusterId; l.readLength = r.readLength; l.reverse = (r.flags & 8) ? 1 : 0;
+    l.nameBegin = 36; l.digitsBegin = l.nameBegin + t.nameLength; l.nameTail = l.digitsBegin + l.digits; l.cigarBegin = l.nameTail + 3;
+    l.seqBegin = l.cigarBegin + 4 * l.nCigar; l.qualBegin = l.seqBegin + (l.readLength + 1) / 2; l.tagBegin = l.qualBegin + l.readLength;
+    u32 at = 0;
+    const bool sm = DODGY_ALIGNMENT_SCORE != r.alignmentScore, as = (r.flags & 256) && DODGY_ALIGNMENT_SCORE != r.templateAlignmentScore;
+    l.smAt = sm ? at : ~0u; at += sm ? 7 : 0;
+    l.asAt = as ? at : ~0u; at += as ? 7 : 0;
+    l.rgAt = at; at += 3 + o.readGroupLength + 1;
+    l.nmAt = at; at += 7;
+    l.bcAt = at;
+    l.sm = r.alignmentScore; l.as = r.templateAlignmentScore; l.nm = r.editDistance;
+    const u32 readIndex = (r.flags & 64) && paired ? 1u : 0u;
+    l.bcl = t.bcl + u64(r.clusterId) * o.clusterLength + o.readOffset[readIndex];
+    l.cigar = t.cigars + r.cigarOffset;
+}
+
+// the base as FragmentCollector::storeBclAndCigar keeps it (reverse-complemented for reverse alignments, FragmentCollector.cpp:84-96) ...
+ISAAC_HD u8 bamStoredBcl(const BamLayout &l, u32 i) { const u8 b = l.reverse ? l.bcl[l.readLength - 1 - i] : l.bcl[i]; return (b & 0xfc) ? (l.reverse ? u8((b & 0xfc) | (3 - (b & 3))) : b) : u8(0); }
+// ... and as the adapter converts it (bamBaseFromBclByte :218-221)
+ISAAC_HD u32 bamBase4(u8 stored) { return (stored & 0xfc) ? 1u << (stored & 3) : 15u; }
+ISAAC_HD u8 bamIntTagByte(char a, char b, u32 v, u32 k) { return k == 0 ? u8(a) : k == 1 ? u8(b) : k == 2 ? u8('i') : u8(v >> (8 * (k - 3))); }
+ISAAC_HD u8 bamStringTagByte(char a, char b, const char *s, u32 n, u32 k) { return k == 0 ? u8(a) : k == 1 ? u8(b) : k == 2 ? u8('Z') : k - 3 < n ? u8(s[k - 3]) : u8(0); }
+
+// byte j of the record; `text`: the strings that go into it; `stored` (optional): the read's bases as bamStoredBcl gives them, staged by the caller; `cigar`: l.cigar or a staged copy
+struct BamStrings { const char *namePrefix, *readGroup, *barcode; u32 readGroupLength, barcodeLength; };   // BamTile::name, BamOptions strings or staged copies
+ISAAC_HD u8 bamRecordByte(const BamStrings &text, const BamLayout &l, u32 j, const u8 *stored, const u32 *cigar)
+{
+    if (j < l.nameBegin)
     {
-        const u8 b = reverse ? bcl[L - 1 - i] : bcl[i];
-        const u32 base = (b & 0xfc) ? 1u << (reverse ? 3u - (b & 3u) : (b & 3u)) : 15u;
-        if (i & 1) w.byte(u8((packed << 4) | base)); else packed = base;
+        const u32 w = j >> 2;
+        u32 v = l.words[0];
+        for (u32 k = 1; k < 9; ++k) v = (w == k) ? l.words[k] : v;
+        return u8(v >> (8 * (j & 3)));
     }
-    if (L & 1) w.byte(u8(packed << 4));
-    for (u32 i = 0; i < L; ++i) { const u8 b = reverse ? bcl[L - 1 - i] : bcl[i]; w.byte((b & 0xfc) ? u8(b >> 2) : u8(0)); }
-    if (DODGY_ALIGNMENT_SCORE != r.alignmentScore) w.iTag('S', 'M', r.alignmentScore);
-    if ((r.flags & 256) && DODGY_ALIGNMENT_SCORE != r.templateAlignmentScore) w.iTag('A', 'S', r.templateAlignmentScore);
-    w.zTag('R', 'G', o.readGroup, o.readGroupLength);
-    w.iTag('N', 'M', r.editDistance);
-    w.zTag('B', 'C', o.barcode, o.barcodeLength);
+    if (j < l.digitsBegin) return u8(text.namePrefix[j - l.nameBegin]);
+    if (j < l.nameTail)
+    {
+        u32 v = l.clusterId;
+        for (u32 k = l.nameTail - 1 - j; k; --k) v /= 10;
+        return u8('0' + v % 10);
+    }
+    if (j < l.cigarBegin) return j == l.nameTail ? u8(':') : j == l.nameTail + 1 ? u8('0') : u8(0);
+    if (j < l.seqBegin) { const u32 k = j - l.cigarBegin; return u8(cigar[k >> 2] >> (8 * (k & 3))); }
+    if (j < l.qualBegin)
+    {
+        const u32 i = 2 * (j - l.seqBegin);
+        const u32 hi = bamBase4(stored ? stored[i] : bamStoredBcl(l, i)), lo = i + 1 < l.readLength ? bamBase4(stored ? stored[i + 1] : bamStoredBcl(l, i + 1)) : 0u;
+        return u8((hi << 4) | lo);
+    }
+    if (j < l.tagBegin) return u8((stored ? stored[j - l.qualBegin] : bamStoredBcl(l, j - l.qualBegin)) >> 2);               // bamQualFromBclByte :228-230
+    const u32 k = j - l.tagBegin;
+    if (k >= l.bcAt) return bamStringTagByte('B', 'C', text.barcode, text.barcodeLength, k - l.bcAt);
+    if (k >= l.nmAt) return bamIntTagByte('N', 'M', l.nm, k - l.nmAt);
+    if (k >= l.rgAt) return bamStringTagByte('R', 'G', text.readGroup, text.readGroupLength, k - l.rgAt);
+    if (l.asAt != ~0u && k >= l.asAt) return bamIntTagByte('A', 'S', l.as, k - l.asAt);
+    return bamIntTagByte('S', 'M', l.sm, k);
 }
 
 #if defined(__HIPCC__)
@@ -151,16 +183,119 @@ __global__ void k_bam_bounds(const u64 *sortedHi, u64 n, u64 *bounds)
     if (hi >= UNALIGNED && (0 == k || before < UNALIGNED)) bounds[0] = k;
     if (hi == DROPPED && (0 == k || before < DROPPED)) bounds[1] = k;
 }
-__global__ void k_bam_encode(const BamTile *tiles, u32 nTiles, u64 nRecords, BamOptions o, const u32 *order, const u64 *offsets, u8 *out, u64 capacity)
+// One workgroup per BAM_CHUNK_RECORDS consecutive records of the file, in four phases so that memory latency is paid per chunk, not per record:
+//   A  a thread per record: order entry -> record -> layout (LDS)
+//   B  a thread per 16 bases: the reads' bases as they are stored (reverse-complemented for reverse alignments) and the first CIGAR words
+//      into LDS, every thread's loads in flight together
+//   C  a wave per record at a time: the record's bytes from LDS into the chunk's image in LDS
+//   D  the image, a contiguous piece of the file, leaves with 16-byte stores on 16-byte boundaries
+// The first version (a wave per record writing bytes straight to HBM) ran at 115 GB/s: about six dependent memory round trips per record
+// and 16 partial-line write requests per store instruction.
+static const u32 BAM_STAGE_CIGAR = 8, BAM_STAGE_TILES = 128, BAM_CHUNK_RECORDS = 64;
+struct BamChunkLds { u32 chunkBytes, basesStride; };     // dynamic LDS: image[chunkBytes + 16] | bases[64][basesStride] ; the rest is static
+ISAAC_HD u32 bamChunkImageBytes(u32 maxReadLength, u32 nameBytes, u32 tagBytes) { return BAM_CHUNK_RECORDS * (36 + nameBytes + 4 * 40 + (maxReadLength + 1) / 2 + maxReadLength + tagBytes); }
+__global__ void __launch_bounds__(256) k_bam_encode(const BamTile *tiles, u32 nTiles, u64 nRecords, BamOptions o, const u32 *order, const u64 *offsets, const u64 *bytes,
+                                                    u8 *out, u64 capacity, BamChunkLds lds)
 {
-    const u64 k = u64(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (k >= nRecords) return;
-    const u64 i = order[k];
-    const u32 t = bamTileOf(tiles, nTiles, i);
-    const FragmentRecord &r = tiles[t].records[i - tiles[t].firstRecord];
-    if (!bamStored(r)) return;
-    const u32 n = bamRecordBytes(tiles[t], r, o);
-    if (offsets[k] + n <= capacity) bamWriteRecord(tiles[t], r, o, out + offsets[k]);
+    extern __shared__ __attribute__((aligned(16))) u8 dynamicLds[];
+    u8 *image = dynamicLds, *bases = dynamicLds + ((lds.chunkBytes + 16 + 15) & ~15u);
+    __shared__ BamLayout layouts[BAM_CHUNK_RECORDS];
+    __shared__ u32 tileOfRecord[BAM_CHUNK_RECORDS];            // ~0u: no bytes for this record
+    __shared__ u32 stageCigar[BAM_CHUNK_RECORDS][BAM_STAGE_CIGAR];
+    __shared__ u64 tileFirst[BAM_STAGE_TILES];
+    __shared__ u32 imageAt[BAM_CHUNK_RECORDS];                 // where the record starts in the chunk
+    __shared__ char optionText[2][64];
+    const u32 lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool tilesStaged = nTiles <= BAM_STAGE_TILES;
+    if (tilesStaged) for (u32 t = threadIdx.x; t < nTiles; t += blockDim.x) tileFirst[t] = tiles[t].firstRecord;
+    if (threadIdx.x < 64) optionText[0][threadIdx.x] = o.readGroup[threadIdx.x]; else if (threadIdx.x < 128) optionText[1][threadIdx.x - 64] = o.barcode[threadIdx.x - 64];
+    const u64 k0 = u64(blockIdx.x) * BAM_CHUNK_RECORDS, k1 = k0 + BAM_CHUNK_RECORDS < nRecords ? k0 + BAM_CHUNK_RECORDS : nRecords;
+    const u32 count = u32(k1 - k0);
+    // the chunk's piece of the file: [begin, end); records that are left out have no bytes and sort last
+    const u64 begin = offsets[k0], end = offsets[k1 - 1] + bytes[k1 - 1];
+    const u32 shift = u32((reinterpret_cast<u64>(out) + begin) & 15);        // image[shift + x] mirrors file byte begin + x: equal alignment mod 16
+    const bool viaLds = end - begin <= lds.chunkBytes;
+    __syncthreads();
+    // ---- A
+    if (threadIdx.x < count)
+    {
+        const u64 i = order[k0 + threadIdx.x], at = offsets[k0 + threadIdx.x];
+        u32 t;
+        if (tilesStaged) { u32 lo = 0, hi = nTiles; while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (tileFirst[mid] <= i) lo = mid; else hi = mid; } t = lo; }
+        else t = bamTileOf(tiles, nTiles, i);
+        const FragmentRecord r = tiles[t].records[i - tiles[t].firstRecord];
+        BamLayout l;
+        bool write = bamStored(r);
+        if (write) { bamLayout(tiles[t], r, o, l); write = at + l.total <= capacity && l.readLength <= lds.basesStride; }
+        if (write)
+        {
+            layouts[threadIdx.x] = l; imageAt[threadIdx.x] = u32(at - begin);
+        }
+        tileOfRecord[threadIdx.x] = write ? t : ~0u;
+    }
+    __syncthreads();
+    // ---- B
+    const u32 segments = (lds.basesStride + 15) / 16;
+    for (u32 x = threadIdx.x; x < count * segments; x += blockDim.x)
+    {
+        const u32 rec = x / segments, first = 16 * (x % segments);
+        if (~0u == tileOfRecord[rec]) continue;
+        const BamLayout &l = layouts[rec];
+        u8 v[16];
+#pragma unroll
+        for (u32 b = 0; b < 16; ++b) v[b] = first + b < l.readLength ? l.bcl[first + b] : u8(0);
+#pragma unroll
+        for (u32 b = 0; b < 16; ++b)
+            if (first + b < l.readLength)
+            {
+                const u8 c = v[b];
+                bases[rec * lds.basesStride + (l.reverse ? l.readLength - 1 - (first + b) : first + b)] = (c & 0xfc) ? (l.reverse ? u8((c & 0xfc) | (3 - (c & 3))) : c) : u8(0);
+            }
+    }
+    for (u32 x = threadIdx.x; x < count * BAM_STAGE_CIGAR; x += blockDim.x)
+    {
+        const u32 rec = x / BAM_STAGE_CIGAR, word = x % BAM_STAGE_CIGAR;
+        if (~0u != tileOfRecord[rec] && word < layouts[rec].nCigar) stageCigar[rec][word] = layouts[rec].cigar[word];
+    }
+    __syncthreads();
+    // ---- C: no global memory in this phase
+    for (u32 rec = w; rec < count; rec += 4)
+    {
+        if (~0u == tileOfRecord[rec]) continue;
+        const BamLayout &l = layouts[rec];
+        const u8 *stored = bases + rec * lds.basesStride;
+        BamStrings text = { tiles[tileOfRecord[rec]].name, optionText[0], optionText[1], o.readGroupLength, o.barcodeLength };
+        if (viaLds && l.nCigar <= BAM_STAGE_CIGAR)
+        {
+            u8 *to = image + shift + imageAt[rec];
+            for (u32 j = lane; j < l.total; j += 64) to[j] = bamRecordByte(text, l, j, stored, stageCigar[rec]);
+        }
+        else if (viaLds)
+        {
+            u8 *to = image + shift + imageAt[rec];
+            for (u32 j = lane; j < l.total; j += 64) to[j] = bamRecordByte(text, l, j, stored, l.cigar);
+        }
+        else
+        {
+            u8 *to = out + begin + imageAt[rec];
+            for (u32 j = lane; j < l.total; j += 64) to[j] = bamRecordByte(text, l, j, stored, l.cigar);
+        }
+    }
+    if (!viaLds) return;
+    __syncthreads();
+    // ---- D: the part of [begin, end) that fits the caller's buffer: records are whole or absent, and the ones that did not fit lie at the end
+    u64 stop = end <= capacity ? end : begin;
+    if (end > capacity) for (u64 k = k0; k < k1; ++k) { const u64 e = offsets[k] + bytes[k]; if (e <= capacity) stop = e; }
+    const u32 n = u32(stop - begin);
+    u8 *g = out + begin;
+    const u32 head = n < ((16 - shift) & 15) ? n : ((16 - shift) & 15);      // bytes before the first 16-byte boundary
+    if (threadIdx.x < head) g[threadIdx.x] = image[shift + threadIdx.x];
+    const u32 body = (n - head) / 16;
+    const uint4 *from = reinterpret_cast<const uint4 *>(image + shift + head);
+    uint4 *gto = reinterpret_cast<uint4 *>(g + head);
+    for (u32 x = threadIdx.x; x < body; x += blockDim.x) gto[x] = from[x];
+    const u32 tail = n - head - 16 * body;
+    if (threadIdx.x < tail) g[head + 16 * body + threadIdx.x] = image[shift + head + 16 * body + threadIdx.x];
 }
 #endif
 
