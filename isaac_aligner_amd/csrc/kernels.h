@@ -71,6 +71,7 @@ struct AlignList { u32 *entries; u32 cap; u32 *counter; };
 //   k_select_heavy        one wave per predicted cluster, on its own stream next to k_select
 static const u32 KMER_EMPTY = 0xffffffffu;
 static const u32 RW_TABLE = 512;          // hash slots for the mate's <= 250-odd 7-mers
+static const u32 RW_PRESENT_WORDS = 512;  // one bit per possible 7-mer: does the mate have it?
 static const u32 RW_LDS_BITMAP = 64;      // words: windows up to ~1900 bases keep their candidate bitmap in LDS
 #ifndef ISAAC_RW_PER_LANE
 #define ISAAC_RW_PER_LANE 8

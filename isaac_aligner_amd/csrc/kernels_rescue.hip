@@ -123,6 +123,44 @@ __device__ inline void rescueWindowScan(const DevReference &R, const RescueJob &
     }
 }
 
+// The ordinary window (candidate bitmap in LDS, far fewer than SHADOW_POSITIONS_MAX positions): which 7-mers the mate has at all is a
+// 16384-bit map, so a window position costs one LDS word and a bit test, and only the positions whose 7-mer does occur in the mate (about
+// 1 % of a window outside the mate's own place) go on to the hash table for the read offset.  The probe loops of the general form run
+// once per position and lane *for the whole wave*; here they run for the few hits.  The reference's "push unless equal to the previous
+// candidate" only decides how many entries its position list holds before sort + unique; that number cannot reach the list's capacity in
+// a window this short, and the set of candidates is the same without it.
+__device__ inline void rescueWindowScanShort(const DevReference &R, const RescueJob &job, u64 windowBase, const WindowBits &firstTile, u32 L, const u32 *tab, const u32 *present,
+                                             u32 *bitmap, u32 lane)
+{
+    const i32 bias = i32(L) - 7;
+    const i32 lastStart = i32(job.windowLen) - 7;       // last valid k-mer start
+    for (i32 tile = 0; tile * RW_TILE <= lastStart; ++tile)
+    {
+        const i32 p0 = tile * RW_TILE + i32(lane) * i32(RW_PER_LANE);          // window position of this lane's first base
+        const WindowBits wb = tile ? loadWindowBits(R, windowBase + u64(p0)) : firstTile;
+        u32 words[RW_PER_LANE];
+#pragma unroll
+        for (u32 k = 0; k < RW_PER_LANE; ++k) words[k] = present[(u32(wb.codes >> (2 * k)) & 0x3fffu) >> 5];
+        u32 hitMask = 0;
+#pragma unroll
+        for (u32 k = 0; k < RW_PER_LANE; ++k)
+        {
+            const u32 kmer = u32(wb.codes >> (2 * k)) & 0x3fffu;
+            const bool valid = p0 + i32(k) <= lastStart && !((wb.notBase >> k) & 0x7fu);
+            hitMask |= (valid && ((words[k] >> (kmer & 31u)) & 1u)) ? 1u << k : 0u;
+        }
+        while (hitMask)
+        {
+            const u32 k = u32(__ffs(hitMask)) - 1; hitMask &= hitMask - 1;
+            const u32 kmer = u32(wb.codes >> (2 * k)) & 0x3fffu;
+            u32 h = (kmer * 2654435761u) >> 23, e = tab[h];
+            while ((e >> 10) != kmer) { h = (h + 1) & (RW_TABLE - 1); e = tab[h]; }            // the k-mer is in the table
+            const u32 bit = u32(p0 + i32(k) - i32(e & 0x3ffu) + bias);
+            atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
+        }
+    }
+}
+
 // (A resident grid of 16 K wavefronts striding over the problem slots -- two slots in three are empty, they are reserved per seeded
 // candidate -- was measured slower, 8.0 against 6.4 ms per 1 M clusters: the windows differ in length and the hardware's own wave
 // scheduling balances them better.)
@@ -130,6 +168,7 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
 {
     __shared__ u32 tables[4][RW_TABLE];
     __shared__ u32 ldsBitmaps[4][RW_LDS_BITMAP];
+    __shared__ __align__(16) u32 presentMaps[4][RW_PRESENT_WORDS];
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 j = blockIdx.x * 4 + wave;
     const u32 nJobs = imin(*rb.jobCounter, rb.jobsCap);
@@ -154,6 +193,8 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
         bitmapWords = (job.windowLen + L + 31) / 32;
         small = bitmapWords <= RW_LDS_BITMAP;
         if (!small) bitmap = rb.bitmaps + job.bitmapBase;
+        u32 *present = presentMaps[wave];
+        if (small) for (u32 i = lane; i < RW_PRESENT_WORDS / 4; i += 64) reinterpret_cast<uint4 *>(present)[i] = make_uint4(0, 0, 0, 0);
         for (u32 i = lane; i < bitmapWords; i += 64) bitmap[i] = 0;
         if (!small) __threadfence();
         __builtin_amdgcn_wave_barrier();
@@ -179,6 +220,7 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
             }
             if (!ok) continue;
             const u32 val = (kmer << 10) | i;
+            if (small) atomicOr(&present[kmer >> 5], 1u << (kmer & 31u));
             u32 h = (kmer * 2654435761u) >> 23;
             while (true)
             {
@@ -192,7 +234,7 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         STAMP(2);
-        if (small) rescueWindowScan<true>(R, job, windowBase, firstTile, L, tab, ldsBitmaps[wave], lane, pushes);
+        if (small) rescueWindowScanShort(R, job, windowBase, firstTile, L, tab, present, ldsBitmaps[wave], lane);
         else { rescueWindowScan<false>(R, job, windowBase, firstTile, L, tab, bitmap, lane, pushes); __threadfence(); }
         STAMP(3);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
