@@ -342,7 +342,9 @@ def main():
                 # the whole path of this GPU against the same peak (pairs/s x algorithmic bytes per pair)
                 "path_achieved": round(pairs_rank * bytes_pair / elapsed_rank / 1e9, 2),
                 "path_frac": round(pairs_rank * bytes_pair / elapsed_rank / 1e9 / 8000.0, 6),
-                "heavy_clusters": int(c.get("heavy_clusters", 0))}
+                "heavy_clusters": int(c.get("heavy_clusters", 0)),
+                # the banded Smith-Waterman kernels are VALU-bound: 16 band cells per row and problem (report cell updates/s)
+                "band_cell_updates_per_s": round((c["bsw_jobs"] + c["rescue_bsw"]) * L * 16 / max(1e-9, (total_ms.get("gapped_fragments", 0.0) + total_ms.get("gapped_rescue", 0.0)) / 1e3), 1)}
 
     # ---- CPU baseline + parity: the oracle (a port of the reference path) on a bounded sample of the same workload, host cores ---
     cpu, parity = None, {"parity_checked_pairs": 0, "parity_diffs": None}

@@ -8,4 +8,7 @@ python bench.py > gpurun_out/bench_default_$TAG.json 2> gpurun_out/bench_default
 bash scripts/prof_trace.sh $TAG > gpurun_out/prof_trace_$TAG.log 2>&1
 bash scripts/pmc_traffic.sh > gpurun_out/pmc_traffic_$TAG.log 2>&1
 cp gpurun_out/pmc_summary.json gpurun_out/pmc_summary_$TAG.json
+TAG=$TAG bash scripts/pmc_kernels.sh > gpurun_out/pmc_kernels_$TAG.log 2>&1
+KERNEL="k_gapped_jobs|k_gapped_rescan" TAG=${TAG}sw BENCH_ARGS="--read-length 250 --indel-read-fraction 0.05 --indel-max 10" bash scripts/pmc_kernels.sh > gpurun_out/pmc_kernels_${TAG}sw.log 2>&1
+rm -rf gpurun_out/pmc_${TAG}_? gpurun_out/pmc_${TAG}sw_?
 tail -2 gpurun_out/smoke_$TAG.log; cat gpurun_out/gputests_$TAG.log; tail -c 1500 gpurun_out/bench_default_$TAG.json; tail -3 gpurun_out/pmc_traffic_$TAG.log

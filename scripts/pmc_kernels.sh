@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 run() { # name, counters...
   local name=$1; shift
   rm -rf $R/gpurun_out/pmc_${TAG}_$name
-  rocprofv3 --pmc "$@" --kernel-include-regex "$KERNEL" --output-format csv -d $R/gpurun_out/pmc_${TAG}_$name -- python3 $R/${PROGRAM:-bench.py} ${PROGRAM_ARGS:---steps 2 --warmup 1 --no-cpu-baseline --no-pcie-pass} $BENCH_ARGS > $R/gpurun_out/pmc_${TAG}_$name.log 2>&1
+  rocprofv3 --pmc "$@" --kernel-include-regex "$KERNEL" --output-format csv -d $R/gpurun_out/pmc_${TAG}_$name -- python3 $R/${PROGRAM:-bench.py} ${PROGRAM_ARGS:---steps 2 --warmup 1 --no-cpu-baseline --no-pcie-pass --no-bam-pass} $BENCH_ARGS > $R/gpurun_out/pmc_${TAG}_$name.log 2>&1
   echo "pass $name rc=$?"
 }
 run a SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
