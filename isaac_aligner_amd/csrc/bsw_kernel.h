@@ -21,6 +21,10 @@ __device__ inline int s16(int v) { return int(short(v)); }
 // operations (row_shr / row_shl / quad_perm) instead of trips through the LDS crossbar (ds_bpermute).  Lanes whose source
 // falls outside the row keep their own value, as __shfl_up / __shfl_down do.
 template <int CTRL> __device__ inline int dpp16(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+// lane k <- lane k + 1, the last lane of the row <- `outside` (a lane without a source keeps the `old` operand of the DPP move).
+// Written as `last ? outside : rowDown<1>(v)` the exchange would sit in the untaken arm of a branch for lane 15 -- and lane 14, reading a
+// lane that is switched off, would keep its own value.
+__device__ inline int rowDown1Or(int v, int outside) { return __builtin_amdgcn_update_dpp(outside, v, 0x101, 0xf, 0xf, false); }
 __device__ inline int rowUp1(int v) { return dpp16<0x111>(v); }          // lane k <- lane k - 1   (row_shr:1)
 __device__ inline int rowXor1(int v) { return dpp16<0xB1>(v); }          // lane k <- lane k ^ 1   (quad_perm [1,0,3,2])
 template <int N> __device__ inline int rowDown(int v) { return dpp16<0x100 + N>(v); }   // lane k <- lane k + N (row_shl:N)
@@ -41,48 +45,57 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
     const int open = gapOpenScore, ext = gapExtendScore;
     const int wMatch = matchScore & 0xff, wMismatch = s16(0xff00 | (mismatchScore & 0xff));
     int G = (k == 0) ? 0 : initialValue, E = initialValue, F = 0;
-    char d = database[15 - k];                      // lane k of row i looks at database[i + 15 - k]
+    const bool first = k == 0, last = k == 15, odd = (k & 1) != 0;
+    const int kExt = int(k) * ext, k1Ext = int(k + 1) * ext;
+    int d = u8(database[15 - k]);                   // lane k of row i looks at database[i + 15 - k]
+    // the next row's query base and the database base that enters the band with it are requested a row ahead (every lane reads the same
+    // bytes: one broadcast access, no branch), so that their latency lies behind the row's arithmetic
+    int qNext = u8(query(0)), dNext = u8(database[L > 1 ? 16 : 15]);
     for (u32 i = 0; i < L; ++i)
     {
+        const int q = qNext, dIn = dNext;
+        {
+            const u32 ahead = i + 1 < L ? i + 1 : i;                  // the values fetched in the last row are not used
+            qNext = u8(query(ahead));
+            dNext = u8(database[ahead + 1 < L ? ahead + 16 : ahead + 15]);
+        }
         // F: lane k from lane k-1 of the previous row (:130-173)
         const int gp = rowUp1(G), ep = rowUp1(E), fp = rowUp1(F);
-        int tf = (gp < ep) ? 1 : 0;
         const int v = s16(max(gp, ep) - open), fe = s16(fp - ext);
-        if (v < fe) tf = 2;
+        int tf = (v < fe) ? 2 : ((gp < ep) ? 1 : 0);
         int newF = max(v, fe);
-        if (k == 0) { newF = initialValue; tf = 0; }
+        newF = first ? initialValue : newF; tf = first ? 0 : tf;
         // G (:174-197) with the 16-bit max over byte pairs of the flag vectors
         const int fE = (G < E) ? 1 : 0;
         const int m = max(G, E);
         const int fF = (m < F) ? 1 : 0;
         int newG = max(m, F);
         const int pfE = rowXor1(fE), pfF = rowXor1(fF);
-        int tg;
-        if (k & 1) tg = fF ? 2 : fE;
-        else tg = pfF ? 2 * fF : (pfE ? fE : max(2 * fF, fE));
+        const int tgOdd = fF ? 2 : fE;
+        const int tgEven = pfF ? 2 * fF : (pfE ? fE : max(2 * fF, fE));
+        const int tg = odd ? tgOdd : tgEven;
         // W (:200-244): byte compare, so read 'n' never equals reference 'N'
-        const char q = query(i);
         newG = s16(newG + ((q != d) ? wMismatch : wMatch));
-        // E (:246-297) as an exclusive max-plus suffix scan over the lanes
+        // E (:246-297) as an exclusive max-plus suffix scan over the lanes.  A lane whose source lies outside the row gets its own value
+        // back from the row shift, and max(s, s) = s: only the first step needs to know where the row ends
         const int g = s16(newG - open), f = s16(newF - open);
         const int NEG = -(1 << 28);
-        int c = max(g, f) - int(k) * ext;
-        int s = rowDown<1>(c); if (k + 1 > 15) s = NEG;
-        int t;
-        t = rowDown<1>(s); if (k + 1 <= 15) s = max(s, t);
-        t = rowDown<2>(s); if (k + 2 <= 15) s = max(s, t);
-        t = rowDown<4>(s); if (k + 4 <= 15) s = max(s, t);
-        t = rowDown<8>(s); if (k + 8 <= 15) s = max(s, t);
-        const int newE = (k == 15) ? initialValue : s16(s + int(k + 1) * ext);
+        const int c = max(g, f) - kExt;
+        int s = rowDown1Or(c, NEG);
+        s = max(s, rowDown<1>(s));
+        s = max(s, rowDown<2>(s));
+        s = max(s, rowDown<4>(s));
+        s = max(s, rowDown<8>(s));
+        const int newE = last ? initialValue : s16(s + k1Ext);
         // TE from lane k+1's (g, E - ext, f) with the reference's tie rules
         const int g1 = rowDown<1>(g), f1 = rowDown<1>(f), e1 = s16(rowDown<1>(newE) - ext);
-        int te = 0;
-        if (k < 15) { if (e1 > g1 && e1 > f1) te = 1; else if (f1 > g1) te = 2; }
+        int te = (e1 > g1 && e1 > f1) ? 1 : ((f1 > g1) ? 2 : 0);
+        te = last ? 0 : te;
         T[i * 16 + k] = u8(tg | (te << 2) | (tf << 4));
         G = newG; E = newE; F = newF;
-        // slide the database window: lane k takes lane k-1's base, lane 0 loads the next one
-        const char dn = char(rowUp1(int(d)));
-        d = (k == 0) ? ((i + 1 < L) ? database[i + 16] : char(0)) : dn;
+        // slide the database window: lane k takes lane k-1's base, lane 0 the next one (0 past the end, as the reference pads)
+        const int dn = rowUp1(d);
+        d = first ? ((i + 1 < L) ? dIn : 0) : dn;
     }
     endVals[k] = short(G); endVals[16 + k] = short(E); endVals[32 + k] = short(F);
     STAMP(55);
