@@ -18,12 +18,22 @@ namespace isaac
 __device__ inline int s16(int v) { return int(short(v)); }
 
 // Lane exchange inside the 16-lane group of one alignment.  The group is one DPP row, so neighbour shifts are register
-// operations (row_shr / row_shl / quad_perm) instead of trips through the LDS crossbar (ds_bpermute).  Lanes whose source
-// falls outside the row keep their own value, as __shfl_up / __shfl_down do.
-template <int CTRL> __device__ inline int dpp16(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+// operations (row_shr / row_shl / quad_perm) instead of trips through the LDS crossbar (ds_bpermute).
+// (bound_ctrl: a lane whose source falls outside the row reads 0 -- every use below overrides that lane's result -- which leaves the move
+// without an `old` operand to copy first)
+template <int CTRL> __device__ inline int dpp16(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
 // lane k <- lane k + 1, the last lane of the row <- `outside` (a lane without a source keeps the `old` operand of the DPP move).
 // Written as `last ? outside : rowDown<1>(v)` the exchange would sit in the untaken arm of a branch for lane 15 -- and lane 14, reading a
 // lane that is switched off, would keep its own value.
+// s = max(s, s of lane k + N) in one instruction: the DPP operand of v_max itself (the compiler emits v_mov, v_mov_dpp, v_max and the
+// wait states between them).  Lanes without a source keep s.  The wait states a DPP read needs after a vector write are in the string:
+// inline assembly is opaque to the hazard recogniser.
+template <int N> __device__ inline int maxRowDown(int s)
+{
+    int r = s;
+    asm("s_nop 1\n\tv_max_i32_dpp %0, %1, %1 row_shl:%2 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(s), "n"(N));
+    return r;
+}
 __device__ inline int rowDown1Or(int v, int outside) { return __builtin_amdgcn_update_dpp(outside, v, 0x101, 0xf, 0xf, false); }
 __device__ inline int rowUp1(int v) { return dpp16<0x111>(v); }          // lane k <- lane k - 1   (row_shr:1)
 __device__ inline int rowXor1(int v) { return dpp16<0xB1>(v); }          // lane k <- lane k ^ 1   (quad_perm [1,0,3,2])
@@ -82,10 +92,10 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
         const int NEG = -(1 << 28);
         const int c = max(g, f) - kExt;
         int s = rowDown1Or(c, NEG);
-        s = max(s, rowDown<1>(s));
-        s = max(s, rowDown<2>(s));
-        s = max(s, rowDown<4>(s));
-        s = max(s, rowDown<8>(s));
+        s = maxRowDown<1>(s);
+        s = maxRowDown<2>(s);
+        s = maxRowDown<4>(s);
+        s = maxRowDown<8>(s);
         const int newE = last ? initialValue : s16(s + k1Ext);
         // TE from lane k+1's (g, E - ext, f) with the reference's tie rules
         const int g1 = rowDown<1>(g), f1 = rowDown<1>(f), e1 = s16(rowDown<1>(newE) - ext);
