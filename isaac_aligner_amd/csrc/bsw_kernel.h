@@ -46,7 +46,8 @@ template <int N> __device__ inline int rowDown(int v) { return dpp16<0x100 + N>(
 // (reference order); the return value (lane 0 only) is BandedSmithWaterman::align's: the length of the stripped leading
 // deletion.  T: L*16 bytes of LDS, endVals: 48 shorts of LDS, both private to the group.  The 16 lanes are part of one
 // wave, so LDS traffic between them needs no workgroup barrier.
-template <typename QueryF>
+// PADDED: query[L] and database[L + 16] may be read (staged copies with room behind them): the look-ahead then needs no clamping
+template <bool PADDED = false, typename QueryF>
 __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapOpenScore, int gapExtendScore, QueryF query, u32 L, const char *database,
                                      u8 *T, short *endVals, u32 k, u32 *cig, u32 cap, u32 &n, bool &overflow)
 {
@@ -64,6 +65,8 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
     for (u32 i = 0; i < L; ++i)
     {
         const int q = qNext, dIn = dNext;
+        if (PADDED) { qNext = u8(query(i + 1)); dNext = u8(database[i + 17]); }
+        else
         {
             const u32 ahead = i + 1 < L ? i + 1 : i;                  // the values fetched in the last row are not used
             qNext = u8(query(ahead));
@@ -103,9 +106,9 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
         te = last ? 0 : te;
         T[i * 16 + k] = u8(tg | (te << 2) | (tf << 4));
         G = newG; E = newE; F = newF;
-        // slide the database window: lane k takes lane k-1's base, lane 0 the next one (0 past the end, as the reference pads)
+        // slide the database window: lane k takes lane k-1's base, lane 0 the next one (what it takes in the last row is not looked at)
         const int dn = rowUp1(d);
-        d = first ? ((i + 1 < L) ? dIn : 0) : dn;
+        d = first ? dIn : dn;
     }
     endVals[k] = short(G); endVals[16 + k] = short(E); endVals[32 + k] = short(F);
     STAMP(55);
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(256) void k_gapped_jobs(DevParams P, DevReference R
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             STAMP(51);
             PlainQuery q; q.q = stagedQuery;
-            const u32 ret = bswCooperative(P.gapMatch, P.gapMismatch, -P.gapOpen, -P.gapExtend, q, sequenceLength, stagedDatabase, T, endVals, k, res.cigar, 40u, n, overflow);
+            const u32 ret = bswCooperative<true>(P.gapMatch, P.gapMismatch, -P.gapOpen, -P.gapExtend, q, sequenceLength, stagedDatabase, T, endVals, k, res.cigar, 40u, n, overflow);
             STAMP(52);
             if (k == 0)
             {
