@@ -32,7 +32,7 @@ ISAAC_HD void sumKeysBind(SumKeys &k, void *base, u32 cap)
 // the lanes working on one cluster: one wavefront, or a whole workgroup (block = true)
 // radix: work area of the radix ordering used for long lists (counts: 16 x lanes, totals: lanes, vary: 2, alt: as many entries as the
 // key arrays), or all NULL
-struct SumRadix { u16 *counts; u32 *totals; u64 *vary; u16 *alt; };
+struct SumRadix { u16 *counts; u32 *totals; u64 *vary; u16 *alt; u8 *digits; };   // digits (optional, one byte per entry, close memory): see radixOrder
 // sumTile: LDS room for sumTileCap terms when the key arrays are not in LDS themselves (the final additions are a chain of
 // dependent loads otherwise), or NULL
 struct SumGroup { u32 lanes, lane; bool block; SumRadix radix; u32 radixMin; double *sumTile; u32 sumTileCap; };
@@ -115,7 +115,10 @@ ISAAC_HD const u16 *radixOrder(SumKeys &k, u32 n, bool pairs, const SumGroup &g)
         {
             if (!((vary >> shift) & 15)) continue;
             for (u32 d = 0; d < 16; ++d) r.counts[d * g.lanes + g.lane] = 0;
-            for (u32 i = begin; i < end; ++i) ++r.counts[u32((key[src[i]] >> shift) & 15) * g.lanes + g.lane];
+            // The digit of every entry, in entry order: one coalesced pass over the key word.  The two passes below then look the digit of
+            // src[i] up in close memory instead of gathering key[src[i]] from the (HBM-resident) key array, twice.
+            if (r.digits) { for (u32 i = g.lane; i < n; i += g.lanes) r.digits[i] = u8((key[i] >> shift) & 15); groupSync(g); }
+            for (u32 i = begin; i < end; ++i) ++r.counts[(r.digits ? u32(r.digits[src[i]]) : u32((key[src[i]] >> shift) & 15)) * g.lanes + g.lane];
             groupSync(g);
             {   // exclusive prefix over the 16 x lanes counts, digit-major: a lane sums 16 consecutive ones, the lanes' sums are scanned in steps
                 u32 sum = 0;
@@ -133,15 +136,28 @@ ISAAC_HD const u16 *radixOrder(SumKeys &k, u32 n, bool pairs, const SumGroup &g)
                 for (u32 e = 0; e < 16; ++e) { const u32 c = r.counts[g.lane * 16 + e]; r.counts[g.lane * 16 + e] = u16(running); running += c; }
             }
             groupSync(g);
-            for (u32 i = begin; i < end; ++i) { const u16 e = src[i]; dst[r.counts[u32((key[e] >> shift) & 15) * g.lanes + g.lane]++] = e; }
+            for (u32 i = begin; i < end; ++i) { const u16 e = src[i]; dst[r.counts[(r.digits ? u32(r.digits[e]) : u32((key[e] >> shift) & 15)) * g.lanes + g.lane]++] = e; }
             groupSync(g);
             u16 *t = src; src = dst; dst = t;
         }
     }
-    // inside a run of equal positions: the place of an entry is the number of the run's entries before it
+    // inside a run of equal positions: the place of an entry is the number of the run's entries before it.  With the digit array at hand
+    // it first records which entries share their positions with their predecessor (independent loads, a lane per entry): the entries that
+    // are runs of their own -- nearly all -- are in place already and need none of the dependent look-ups below
+    u8 *same = r.digits;
+    if (same)
+    {
+        for (u32 i = g.lane; i < n; i += g.lanes)
+        {
+            const u32 e = src[i], p = i ? src[i - 1] : e;
+            same[i] = (i && k.pos1[e] == k.pos1[p] && k.pos2[e] == k.pos2[p]) ? 1 : 0;
+        }
+        groupSync(g);
+    }
     for (u32 i = begin; i < end; ++i)
     {
         const u32 e = src[i];
+        if (same && !same[i] && !(i + 1 < n && same[i + 1])) { dst[i] = u16(e); continue; }
         const u64 p1 = k.pos1[e], p2 = k.pos2[e];
         u32 lo = i; while (lo && k.pos1[src[lo - 1]] == p1 && k.pos2[src[lo - 1]] == p2) --lo;
         u32 before = 0;
@@ -157,13 +173,28 @@ ISAAC_HD const u16 *radixOrder(SumKeys &k, u32 n, bool pairs, const SumGroup &g)
     return dst;
 }
 
+// acc + t[0] + t[1] + ... in exactly that order.  Eight terms are fetched before they are added: the chain of dependent additions then
+// waits for one load latency per eight terms instead of one per term.
+ISAAC_HD double addInOrder(double acc, const double *t, u32 n)
+{
+    u32 i = 0;
+    for (; i + 8 <= n; i += 8)
+    {
+        const double t0 = t[i], t1 = t[i + 1], t2 = t[i + 2], t3 = t[i + 3], t4 = t[i + 4], t5 = t[i + 5], t6 = t[i + 6], t7 = t[i + 7];
+        acc += t0; acc += t1; acc += t2; acc += t3; acc += t4; acc += t5; acc += t6; acc += t7;
+    }
+    for (; i < n; ++i) acc += t[i];
+    return acc;
+}
+
 // Sum of exp(lp) over the first element of every run of equal keys of entries [0, n), in sorted order.  false: a near tie.
 ISAAC_HD bool uniqueSortedSum(SumKeys &k, u32 n, bool pairs, const SumGroup &g, u32 *scratch, double &sum)
 {
     sum = 0.0;
     if (!n) return true;
     const u16 *order = k.idx;
-    if (g.radix.counts && n >= g.radixMin) order = radixOrder(k, n, pairs, g);
+    const u8 *same = nullptr;                 // radixOrder leaves "same positions as the predecessor in the order" per entry when it has room for it
+    if (g.radix.counts && n >= g.radixMin) { order = radixOrder(k, n, pairs, g); same = g.radix.digits; }
     else
 #if defined(__HIP_DEVICE_COMPILE__)
     if (!g.block && n <= g.lanes)
@@ -209,7 +240,7 @@ ISAAC_HD bool uniqueSortedSum(SumKeys &k, u32 n, bool pairs, const SumGroup &g, 
     {
         const u32 cur = order[i];
         bool dup = false;
-        if (i) { const u32 prev = order[i - 1]; nearTie |= sumKeyNearTie(k, prev, cur); dup = sumKeyEqual(k, prev, cur); }
+        if (i && (!same || same[i])) { const u32 prev = order[i - 1]; nearTie |= sumKeyNearTie(k, prev, cur); dup = sumKeyEqual(k, prev, cur); }   // both need equal positions
         k.term[i] = dup ? 0.0 : exp(k.lp[cur]);       // without near ties "equal to the first of the run" is "equal to the predecessor"; x + 0.0 == x
     }
     if (groupAny(g, nearTie, scratch)) return false;
@@ -222,7 +253,7 @@ ISAAC_HD bool uniqueSortedSum(SumKeys &k, u32 n, bool pairs, const SumGroup &g, 
             const u32 m = imin(g.sumTileCap, n - base);
             for (u32 i = g.lane; i < m; i += g.lanes) g.sumTile[i] = k.term[base + i];
             groupSync(g);
-            if (g.lane < 64) for (u32 i = 0; i < m; ++i) acc += g.sumTile[i];
+            if (g.lane < 64) acc = addInOrder(acc, g.sumTile, m);
             groupSync(g);
         }
         if (0 == g.lane) g.sumTile[0] = acc;
@@ -231,7 +262,7 @@ ISAAC_HD bool uniqueSortedSum(SumKeys &k, u32 n, bool pairs, const SumGroup &g, 
         groupSync(g);
         return true;
     }
-    for (u32 i = 0; i < n; ++i) sum += k.term[i];     // the additions in sequence: their order is part of the result (every lane: same value)
+    sum = addInOrder(sum, k.term, n);                 // the additions in sequence: their order is part of the result (every lane: same value)
     groupSync(g);
     return true;
 }
@@ -385,14 +416,14 @@ ISAAC_HD u32 clusterSums(const DevParams &P, const ClusterFragments &f, const Su
                 const u32 m = imin(g.sumTileCap, base - b0);
                 for (u32 i = g.lane; i < m; i += g.lanes) g.sumTile[i] = k.term[b0 + i];
                 groupSync(g);
-                if (g.lane < 64) for (u32 i = 0; i < m; ++i) sum += g.sumTile[i];
+                if (g.lane < 64) sum = addInOrder(sum, g.sumTile, m);
                 groupSync(g);
             }
             if (0 == g.lane) g.sumTile[0] = sum;
             groupSync(g);
             sum = g.sumTile[0];
         }
-        else for (u32 i = 0; i < base; ++i) sum += k.term[i];
+        else sum = addInOrder(sum, k.term, base);
         out.ordered = sum;
         groupSync(g);
     }
