@@ -209,14 +209,21 @@ ISAAC_HD bool uniqueSortedSum(SumKeys &k, u32 n, bool pairs, const SumGroup &g, 
         const u32 i = g.lane < n ? g.lane : 0;
         const u64 p1 = k.pos1[i], p2 = k.pos2[i]; const double lp = k.lp[i]; const u32 o1 = k.obs1[i], o2 = k.obs2[i];
         u32 rank = 0;
-        for (u32 j = 0; j < n; ++j)
-        {
-            const u64 q1 = k.pos1[j], q2 = k.pos2[j]; const double ql = k.lp[j]; const u32 r1 = k.obs1[j], r2 = k.obs2[j];
-            const bool lpBefore = pairs ? lp < ql : ql < lp;
-            const bool tail = r1 < o1 || (r1 == o1 && (r2 < o2 || (r2 == o2 && j < i)));
-            const bool mid = q2 < p2 || (q2 == p2 && (lpBefore || (ql == lp && tail)));
-            rank += (q1 < p1 || (q1 == p1 && mid)) ? 1u : 0u;
-        }
+        if (pairs)
+            for (u32 j = 0; j < n; ++j)
+            {
+                const u64 q1 = k.pos1[j], q2 = k.pos2[j]; const double ql = k.lp[j]; const u32 r1 = k.obs1[j], r2 = k.obs2[j];
+                const bool tail = r1 < o1 || (r1 == o1 && (r2 < o2 || (r2 == o2 && j < i)));
+                const bool mid = q2 < p2 || (q2 == p2 && (lp < ql || (ql == lp && tail)));
+                rank += (q1 < p1 || (q1 == p1 && mid)) ? 1u : 0u;
+            }
+        else
+            for (u32 j = 0; j < n; ++j)
+            {   // shadow lists: the second position and the second length are 0 in every entry (sumKeyFromCand)
+                const u64 q1 = k.pos1[j]; const double ql = k.lp[j]; const u32 r1 = k.obs1[j];
+                const bool tail = r1 < o1 || (r1 == o1 && j < i);
+                rank += (q1 < p1 || (q1 == p1 && (ql < lp || (ql == lp && tail)))) ? 1u : 0u;
+            }
         if (g.lane < n) k.idx[rank] = u16(i);
         groupSync(g);
     }
