@@ -202,22 +202,42 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
         // the mate's 7-mers: first read position of every k-mer (ShadowAligner::hashShadowKmers, :53-72)
         ReadView read; read.bcl = bcl + u64(clusterBase + job.cluster) * P.clusterLength + P.readOffset[r]; read.length = L; read.endCyclesMasked = 0; read.firstCycle = 0;
         const bool reverse = job.shadowReverse != 0;
-        for (u32 i = lane; i + 7 <= L; i += 64)
+        // The mate in the strand's order, packed once: lane l holds strand positions 8l .. 8l+7 as 2-bit codes (the code the packed reference
+        // has for the same base: A 0, C 1, G 3, T 2) in bits 0-15 and their N flags in bits 16-23 (a BCL byte without quality bits is an N,
+        // Read.cpp:56-69; so is what lies past the end of the read).  A 7-mer is then 14 bits of two neighbouring lanes' words.
+        u32 packedMate = 0x00ff0000u;
+        if (lane * 8 < L)
         {
-            // the 7 BCL bytes of strand positions i .. i+6 sit in 7 consecutive bytes of the read either way: one 8-byte load
-            const u32 first = reverse ? L - 7 - i : i;           // lowest BCL index of the k-mer
+            const u32 s0 = lane * 8;                                 // first strand position of this lane
             u64 bytes = 0;
-            if (first + 8 <= L) memcpy(&bytes, read.bcl + first, 8);
-            else { memcpy(&bytes, read.bcl + L - 8, 8); bytes >>= 8 * (first + 8 - L); }
-            u32 kmer = 0; bool ok = true;
-#pragma unroll
-            for (u32 k = 0; k < 7; ++k)
-            {
-                // BCL byte -> the code the packed reference has for the same base of the strand (A 0, C 1, G 3, T 2); a byte without quality bits is an N (Read.cpp:56-69)
-                const u32 b = u32(bytes >> (8 * (reverse ? 6 - k : k))) & 0xffu;
-                const u32 base = (b & 3u) ^ (reverse ? 3u : 0u);
-                ok &= (b & 0xfcu) != 0; kmer |= (base ^ (base >> 1)) << (2 * k);             // base k of the k-mer at bits 2k, as loadWindowBits lays them out
+            if (!reverse)
+            {   // BCL bytes s0 .. s0+7
+                if (s0 + 8 <= L) memcpy(&bytes, read.bcl + s0, 8);
+                else { memcpy(&bytes, read.bcl + L - 8, 8); bytes >>= 8 * (s0 + 8 - L); }
             }
+            else
+            {   // BCL bytes L-8-s0 .. L-1-s0: strand position s0+t is byte 7-t
+                if (s0 + 8 <= L) memcpy(&bytes, read.bcl + (L - 8 - s0), 8);
+                else { memcpy(&bytes, read.bcl, 8); bytes <<= 8 * (s0 + 8 - L); }
+            }
+            u32 codes = 0, ns = 0;
+#pragma unroll
+            for (u32 t = 0; t < 8; ++t)
+            {
+                const u32 b = u32(bytes >> (8 * (reverse ? 7 - t : t))) & 0xffu;
+                const u32 base = (b & 3u) ^ (reverse ? 3u : 0u);
+                codes |= (base ^ (base >> 1)) << (2 * t);
+                ns |= ((b & 0xfcu) == 0 ? 1u : 0u) << t;
+            }
+            packedMate = codes | (ns << 16);
+        }
+        for (u32 i = lane; i < ((L + 63) & ~63u); i += 64)              // every lane takes part in the exchanges
+        {
+            const u32 w0 = __shfl(packedMate, i >> 3, 64), w1 = __shfl(packedMate, ((i >> 3) + 1) & 63, 64);
+            if (i + 7 > L) continue;
+            const u32 shift = i & 7;
+            const u32 kmer = (((w0 & 0xffffu) | (w1 << 16)) >> (2 * shift)) & 0x3fffu;   // base k of the k-mer at bits 2k, as loadWindowBits lays them out
+            const bool ok = 0 == (((((w0 >> 16) & 0xffu) | (((w1 >> 16) & 0xffu) << 8)) >> shift) & 0x7fu);
             if (!ok) continue;
             const u32 val = (kmer << 10) | i;
             if (small) atomicOr(&present[kmer >> 5], 1u << (kmer & 31u));
