@@ -319,6 +319,15 @@ int isaac_gpu_fastq_to_bcl(isaac_gpu_ctx *ctx, const char *fastq_dev, uint64_t n
                            int allow_variable_length, int final, uint8_t *bcl_dev, uint32_t max_clusters,
                            uint32_t *n_clusters_out, uint64_t *consumed_bytes_out, uint64_t *error_offset_out);
 
+/* How the clusters of one load of a lane's FASTQ files become tiles (host-only, no context): FastqSeedSource's tileClustersMax_
+ * (lib/workflow/alignWorkflow/FastqDataSource.cpp:82-84: min(--clusters-at-a-time, 40000000 / #seeds), or the latter alone when the
+ * option is 0) and the tile breakdown of discoverTiles (:153-173).  first_tile is 1 for a lane's first load and *next_tile_out of the
+ * previous load afterwards; cluster ids restart at 0 in every tile (the tile number and the id inside it are what isaac_gpu_find_matches /
+ * isaac_gpu_select take and what the BAM read name shows).  Returns ISAAC_GPU_ECAPACITY (with *n_tiles_out set) when the arrays are short. */
+uint32_t isaac_gpu_fastq_tile_clusters_max(uint32_t clusters_at_a_time, uint32_t n_seeds);
+int isaac_gpu_fastq_tiles(uint32_t clusters_loaded, uint32_t clusters_at_a_time, uint32_t n_seeds, uint32_t first_tile,
+                          uint32_t *tile_numbers, uint32_t *tile_clusters, uint32_t capacity, uint32_t *n_tiles_out, uint32_t *next_tile_out);
+
 int isaac_gpu_get_counters(isaac_gpu_ctx *ctx, isaac_counters *out);
 /* average device time (ms) of the named launch sequence over the launches since the last reset, measured with HIP events on the
  * stream it runs on; names: "find_matches", "compact_matches", "build_fragments", "align_candidates", "finish_candidates",

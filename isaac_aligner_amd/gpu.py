@@ -41,7 +41,19 @@ EXPORTS = ["isaac_gpu_last_error", "isaac_gpu_create", "isaac_gpu_destroy", "isa
            "isaac_gpu_find_matches", "isaac_gpu_set_loaded_contigs", "isaac_gpu_build_fragments", "isaac_gpu_determine_tls", "isaac_gpu_select", "isaac_gpu_select_candidates",
            "isaac_gpu_bsw_batch", "isaac_gpu_compact_cigars",
            "isaac_gpu_bam_records", "isaac_gpu_bam_last_error", "isaac_gpu_bam_header", "isaac_gpu_bgzf_bound", "isaac_gpu_bgzf_compress",
-           "isaac_gpu_fastq_to_bcl", "isaac_gpu_get_counters", "isaac_gpu_kernel_time_ms", "isaac_gpu_reset_timers"]
+           "isaac_gpu_fastq_to_bcl", "isaac_gpu_fastq_tile_clusters_max", "isaac_gpu_fastq_tiles", "isaac_gpu_get_counters", "isaac_gpu_kernel_time_ms", "isaac_gpu_reset_timers"]
+
+
+def fastq_tiles(clusters_loaded, n_seeds, clusters_at_a_time=0, first_tile=1):
+    """FastqSeedSource::discoverTiles' breakdown of one load: ([(tile number, clusters)], next tile number)"""
+    lib = load_library()
+    n, nxt = C.c_uint32(), C.c_uint32()
+    lib.isaac_gpu_fastq_tiles(C.c_uint32(clusters_loaded), C.c_uint32(clusters_at_a_time), C.c_uint32(n_seeds), C.c_uint32(first_tile), None, None, C.c_uint32(0), C.byref(n), C.byref(nxt))
+    numbers, sizes = (C.c_uint32 * max(1, n.value))(), (C.c_uint32 * max(1, n.value))()
+    rc = lib.isaac_gpu_fastq_tiles(C.c_uint32(clusters_loaded), C.c_uint32(clusters_at_a_time), C.c_uint32(n_seeds), C.c_uint32(first_tile), numbers, sizes, C.c_uint32(n.value), C.byref(n), C.byref(nxt))
+    if rc:
+        raise IsaacGpuError("isaac_gpu_fastq_tiles: %d" % rc)
+    return [(numbers[i], sizes[i]) for i in range(n.value)], nxt.value
 
 
 def _p(t):

@@ -868,3 +868,18 @@ int oracle_bam_header(const char *command_line, const char *description, const c
     catch (const std::exception &e) { g_error = e.what(); return 1; }
 }
 } // extern "C"
+
+extern "C" {
+// FastqSeedSource's tile rule (fastq.cpp)
+int oracle_fastq_tiles(uint32_t clusters_loaded, uint32_t clusters_at_a_time, uint32_t n_seeds, uint32_t first_tile, uint32_t *numbers, uint32_t *sizes, uint32_t capacity,
+                       uint32_t *n_tiles, uint32_t *next_tile)
+{
+    std::vector<std::pair<unsigned, unsigned> > tiles;
+    unsigned current = first_tile;
+    fastqDiscoverTiles(clusters_loaded, fastqTileClustersMax(clusters_at_a_time, n_seeds), current, tiles);
+    *n_tiles = uint32_t(tiles.size()); *next_tile = current;
+    for (size_t i = 0; i < tiles.size() && i < capacity; ++i) { numbers[i] = tiles[i].first; sizes[i] = tiles[i].second; }
+    return 0;
+}
+} // extern "C"
+

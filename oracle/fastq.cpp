@@ -115,3 +115,23 @@ int oracle_fastq_to_bcl(const char *text, uint64_t n_bytes, uint32_t read_length
 }
 
 } // extern "C"
+
+// FastqSeedSource: tileClustersMax_ (FastqDataSource.cpp:82-84) and the tile breakdown of discoverTiles (:153-173): full tiles, then one
+// partial tile for what is left; a load that is a whole number of tiles ends without a partial one
+#include <algorithm>
+#include <utility>
+#include <vector>
+namespace oracle
+{
+unsigned fastqTileClustersMax(unsigned clustersAtATimeMax, unsigned seedCount)
+{
+    const unsigned seedBound = 40000000 / seedCount;
+    return (clustersAtATimeMax && clustersAtATimeMax < seedBound) ? clustersAtATimeMax : seedBound;
+}
+void fastqDiscoverTiles(unsigned clustersLoaded, unsigned tileClustersMax, unsigned &currentTile, std::vector<std::pair<unsigned, unsigned> > &loadedTiles)
+{
+    const unsigned fullTiles = clustersLoaded / tileClustersMax, rest = clustersLoaded % tileClustersMax;
+    for (unsigned t = 0; t < fullTiles; ++t) loadedTiles.push_back(std::make_pair(currentTile++, tileClustersMax));
+    if (rest) loadedTiles.push_back(std::make_pair(currentTile++, rest));
+}
+} // namespace oracle

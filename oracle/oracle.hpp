@@ -680,6 +680,10 @@ struct MatchSelector
                     std::vector<FragmentRecord> &records, std::vector<uint32_t> &cigarPool);
 };
 
+// fastq.cpp: FastqSeedSource's tile rule
+unsigned fastqTileClustersMax(unsigned clustersAtATimeMax, unsigned seedCount);
+void fastqDiscoverTiles(unsigned clustersLoaded, unsigned tileClustersMax, unsigned &currentTile, std::vector<std::pair<unsigned, unsigned> > &loadedTiles);
+
 // bam.cpp: the BAM record stream of a set of tiles (build::Build with --realign-gaps no --mark-duplicates 0) and the BAM header
 struct BamTileInput { const uint8_t *bcl; const FragmentRecord *records; const uint32_t *cigars; uint64_t nRecords; std::string namePrefix; };
 struct BamOptions { unsigned clusterLength, readOffset[2]; unsigned char forcedDodgyAlignmentScore; bool pessimisticMapQ; std::string readGroup, barcode; };

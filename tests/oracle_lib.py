@@ -105,6 +105,13 @@ class Oracle:
                                               ptr(out), C.c_uint64(out.size), C.byref(n)))
         return out[:n.value].tobytes()
 
+    def fastq_tiles(self, clusters_loaded, n_seeds, clusters_at_a_time=0, first_tile=1):
+        numbers, sizes = (C.c_uint32 * 4096)(), (C.c_uint32 * 4096)()
+        n, nxt = C.c_uint32(), C.c_uint32()
+        self.check(self.lib.oracle_fastq_tiles(C.c_uint32(clusters_loaded), C.c_uint32(clusters_at_a_time), C.c_uint32(n_seeds), C.c_uint32(first_tile), numbers, sizes, C.c_uint32(4096),
+                                               C.byref(n), C.byref(nxt)))
+        return [(numbers[i], sizes[i]) for i in range(n.value)], nxt.value
+
     def default_params(self, n_reads, len1, len2=0):
         p = Params()
         self.check(self.lib.oracle_default_params(C.c_uint32(n_reads), C.c_uint32(len1), C.c_uint32(len2), C.byref(p)))

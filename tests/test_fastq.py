@@ -114,3 +114,23 @@ def test_gpu_fastq_parity(torch, oracle):
     for text in cases:
         for kw in ({}, {"final": False}, {"allow_variable_length": True}):
             _gpu_vs_oracle(all_, oracle, text, 1, L, 2 * L, L, **kw)
+
+
+def test_fastq_tile_rule():
+    """FastqSeedSource's tile breakdown (FastqDataSource.cpp:82-84,153-173): product (host code of the C ABI) against the oracle's restatement
+    and against the numbers the rule gives by hand"""
+    import oracle_lib
+    from isaac_aligner_amd import gpu
+    o = oracle_lib.load()
+    # 2x150 with --seeds auto: 8 seeds -> 5 000 000 clusters per tile; a load of 12 M clusters is tiles 1, 2 (full) and 3 (2 M)
+    assert gpu.fastq_tiles(12_000_000, 8) == ([(1, 5_000_000), (2, 5_000_000), (3, 2_000_000)], 4)
+    # a whole number of tiles: no empty tile at the end; numbering goes on in the lane's next load
+    assert gpu.fastq_tiles(10_000_000, 8, first_tile=4) == ([(4, 5_000_000), (5, 5_000_000)], 6)
+    # --clusters-at-a-time below the seed bound caps the tile size
+    assert gpu.fastq_tiles(2_500_000, 8, clusters_at_a_time=1_000_000) == ([(1, 1_000_000), (2, 1_000_000), (3, 500_000)], 4)
+    assert gpu.fastq_tiles(0, 8) == ([], 1)
+    rng = np.random.default_rng(5)
+    for _ in range(300):
+        loaded = int(rng.integers(0, 60_000_000)); seeds = int(rng.integers(1, 17)); at = int(rng.choice([0, 200_000, 3_000_000, 50_000_000])); first = int(rng.integers(1, 100))
+        assert gpu.fastq_tiles(loaded, seeds, at, first) == o.fastq_tiles(loaded, seeds, at, first)
+
