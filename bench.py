@@ -67,6 +67,27 @@ def launch_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+_RESULT_FD = None
+
+
+def claim_stdout():
+    """The result is the only thing this process writes to its standard output: libraries that print there (RCCL writes a version banner
+    when a process group comes up) are sent to standard error, and emit() writes the one JSON line to the real descriptor."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(result):
+    data = (json.dumps(result) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(data.decode()); sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, data)
+
+
 def launch_check(args, rank, world):
     """the run's three collectives on fake data over gloo (CPU): what tests/test_bench_launch.py drives"""
     import numpy as np
@@ -82,10 +103,15 @@ def launch_check(args, rank, world):
     begin, end = shard.shard_bounds(1001, rank, world)
     records = torch.full((end - begin, 4), rank, dtype=torch.uint8)
     got = shard.gather_records(records, dist, rank, world)
+    gatherer = shard.StepGather(dist, rank, world)                 # what the timed loop does per step
+    for step in range(2):
+        gatherer.add(records + step, torch.full((3 * (end - begin) + rank,), 16 * rank + step, dtype=torch.int32))
+    steps = gatherer.finish()
     dist.barrier()
     if rank == 0:
         ok = int(merged.sum()) == min(world, 8) and tls.min == 100 and sum(len(g) for g in got) == 1001 and all(int(g[0, 0]) == r for r, g in enumerate(got))
-        print(json.dumps({"launch_check": bool(ok), "n_gpus": world, "gpus_requested": args.gpus}))
+        ok = ok and len(steps) == 2 and all(sum(len(r_) for r_ in recs) == 1001 and all(int(c_[0]) == 16 * r + st for r, c_ in enumerate(cigs)) for st, (recs, cigs) in enumerate(steps))
+        emit({"launch_check": bool(ok), "n_gpus": world, "gpus_requested": args.gpus})
     dist.destroy_process_group()
 
 
@@ -98,6 +124,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    claim_stdout()
     if args.launch_check:
         return launch_check(args, rank, world)
 
@@ -166,6 +193,12 @@ def main():
             al.compact_cigars(w[0], w[1], w[2])
             del w
     shard.broadcast_tls(tls, dist, dev)   # rank 0's statistics are the run's statistics
+    if dist is not None:
+        # the first gather of a process group sets up its point-to-point channels (most of a second): not part of the steps
+        warm = shard.StepGather(dist, rank, world)
+        warm.add(torch.zeros((64, abi.FRAGMENT_DTYPE.itemsize), dtype=torch.uint8, device=dev), torch.zeros(256, dtype=torch.int32, device=dev))
+        warm.finish()
+        del warm
     al.synchronize()
     al.reset_timers()
 
@@ -181,14 +214,21 @@ def main():
         found.append((m, o))
         all_hits |= hits
     al.set_loaded_contigs(reduce_hits(all_hits))      # MatchSelector loads only contigs that received matches
+    # with several GPUs every step's records and packed CIGARs leave for rank 0 as soon as they are final, behind the later steps
+    # (shard.StepGather); one GPU packs the CIGARs of all steps at the end
+    gatherer = shard.StepGather(dist, rank, world) if dist is not None else None
+    packed = []
     for s in range(args.steps):                       # phase 2: SelectMatchesTransition
         m, o = found[s]
         al.select(batches[args.warmup + s], m, o, tls, tile=tile_of(s), out=out[s][:2])
+        if gatherer is not None:
+            packed.append(al.compact_cigars(out[s][0], out[s][1], out[s][2])[0])      # completes the step, its residual pass included
+            gatherer.add(out[s][0], packed[-1])
     al.synchronize()                                  # completes the last call's wave-per-cluster pass
-    packed = [al.compact_cigars(out[s][0], out[s][1], out[s][2])[0] for s in range(args.steps)]
-    if dist is not None:                              # single gather of the per-GPU records and CIGARs at the end
-        shard.gather_records(torch.cat([o_[0] for o_ in out]), dist, rank, world)
-        shard.gather_records(torch.cat(packed).view(-1, 1), dist, rank, world)
+    if gatherer is None:
+        packed = [al.compact_cigars(out[s][0], out[s][1], out[s][2])[0] for s in range(args.steps)]
+    else:
+        gatherer.finish()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -397,11 +437,11 @@ def main():
               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
               "scaling": args.scaling, "vs_baseline": None, "dtype": "u8/int16 (+f64 log-probabilities)", "data": "synthetic",
               "config": {"workload": workload, "pairs_per_step": args.pairs_per_step, "read_length": L, "genome_bases": args.genome_bases, "index_entries": int(n_index),
-                         "parallelism": "read shards x%d, records and CIGARs gathered once" % world, "hbm_used_gb": hbm_used_gb, "setup_s": round(t_setup, 1),
+                         "parallelism": "read shards x%d, every step's records and packed CIGARs gathered to rank 0 behind the later steps" % world, "hbm_used_gb": hbm_used_gb, "setup_s": round(t_setup, 1),
                          "genome_s": round(t_genome, 1), "index_build_s": round(t_index, 1), "tls": list(tls.astuple()), "pcie_inclusive": pcie, "bam_output": bam_info},
               "roofline": roofline, "cpu_baseline": cpu, "counters": {k: int(v) for k, v in counters.items()}}
     result.update(parity)
-    print(json.dumps(result))
+    emit(result)
     if dist is not None:
         dist.destroy_process_group()
 

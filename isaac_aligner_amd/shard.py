@@ -67,3 +67,52 @@ def gather_records(records, dist, rank, world, dst=0):
     if rank != dst:
         return None
     return [t[:s] for t, s in zip(out, sizes)]
+
+
+class StepGather:
+    """Collects every step's records and packed CIGARs on rank `dst` while the later steps compute: the payload of a step is handed to
+    an asynchronous gather as soon as it is final, and only finish() waits.  Per rank and step 138 B per pair cross one xGMI link
+    (about 48 GB/s): left to the end of a run that is 8-9 % of the run's time on its own, spread over the steps it hides behind them.
+    Shards may differ in size: the sizes of a step are exchanged first (a tiny all-gather) and the payloads padded to the largest."""
+
+    def __init__(self, dist, rank, world, dst=0):
+        self.dist, self.rank, self.world, self.dst = dist, rank, world, dst
+        self.pending, self.steps = [], []
+
+    def _pad(self, t, n):
+        if t.shape[0] == n:
+            return t.contiguous()
+        out = torch.zeros((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        out[:t.shape[0]] = t
+        return out
+
+    def add(self, records, cigars):
+        """records: (n, record_bytes) uint8, cigars: 1-D packed CIGAR words of this rank for one step (both final)"""
+        if self.dist is None:
+            self.steps.append(([records], [cigars]))
+            return
+        dist = self.dist
+        n = torch.tensor([records.shape[0], cigars.shape[0]], dtype=torch.int64, device=records.device)
+        sizes = [torch.zeros_like(n) for _ in range(self.world)]
+        dist.all_gather(sizes, n)
+        sizes = [[int(v) for v in s.tolist()] for s in sizes]
+        rec = self._pad(records, max(s[0] for s in sizes))
+        cig = self._pad(cigars, max(1, max(s[1] for s in sizes)))
+        on_dst = self.rank == self.dst
+        out_r = [torch.empty_like(rec) for _ in range(self.world)] if on_dst else None
+        out_c = [torch.empty_like(cig) for _ in range(self.world)] if on_dst else None
+        h_r = dist.gather(rec, out_r, dst=self.dst, async_op=True)
+        h_c = dist.gather(cig, out_c, dst=self.dst, async_op=True)
+        self.pending.append((h_r, h_c, rec, cig, out_r, out_c, sizes))        # the tensors stay referenced until finish()
+
+    def finish(self):
+        """waits for every gather; on `dst`: [(list of record tensors by rank, list of CIGAR tensors by rank)] per step, else None"""
+        for h_r, h_c, rec, cig, out_r, out_c, sizes in self.pending:
+            h_r.wait()
+            h_c.wait()
+            if self.rank == self.dst:
+                self.steps.append(([t[:s[0]] for t, s in zip(out_r, sizes)], [t[:s[1]] for t, s in zip(out_c, sizes)]))
+        self.pending = []
+        if self.dist is not None and self.rank != self.dst:
+            return None
+        return self.steps

@@ -85,3 +85,55 @@ def test_shard_bounds_cover_everything():
             assert edges[0][0] == 0 and edges[-1][1] == n
             assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
             assert max(e - b for b, e in edges) - min(e - b for b, e in edges) <= 1
+
+
+def _step_gather_worker(rank, world, port, result_path):
+    import torch.distributed as dist
+    from isaac_aligner_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        g = shard.StepGather(dist, rank, world)
+        mine = []
+        for step in range(3):
+            rng = np.random.default_rng(100 * step + rank)
+            n = 50 + 7 * rank + step                                      # shards of different sizes
+            rec = torch.from_numpy(rng.integers(0, 256, (n, 64), dtype=np.uint8))
+            cig = torch.from_numpy(rng.integers(0, 1 << 20, 2 * n + rank, dtype=np.int64).astype(np.int32))
+            if step == 2 and rank == 1:
+                cig = cig[:0]                                              # a rank without CIGAR words in a step
+            mine.append((rec, cig))
+            g.add(rec, cig)
+        steps = g.finish()
+        if rank == 0:
+            assert len(steps) == 3
+            for step, (recs, cigs) in enumerate(steps):
+                assert len(recs) == world and len(cigs) == world
+                for r in range(world):
+                    rng = np.random.default_rng(100 * step + r)
+                    n = 50 + 7 * r + step
+                    want_rec = rng.integers(0, 256, (n, 64), dtype=np.uint8)
+                    want_cig = rng.integers(0, 1 << 20, 2 * n + r, dtype=np.int64).astype(np.int32)
+                    if step == 2 and r == 1:
+                        want_cig = want_cig[:0]
+                    assert (recs[r].numpy() == want_rec).all() and (cigs[r].numpy() == want_cig).all()
+            open(result_path, "w").write("ok")
+        else:
+            assert steps is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_step_gather_collects_every_step_on_rank_0(tmp_path):
+    """shard.StepGather (what bench.py --gpus N uses to move records and CIGARs while later steps compute): asynchronous gathers of
+    padded payloads, sizes differing by rank and step, two gloo ranks"""
+    result = str(tmp_path / "result")
+    mp.spawn(_step_gather_worker, args=(2, _free_port(), result), nprocs=2, join=True)
+    assert open(result).read() == "ok"
+    from isaac_aligner_amd import shard
+    g = shard.StepGather(None, 0, 1)                                       # single process: nothing to exchange
+    r, c = torch.zeros((3, 64), dtype=torch.uint8), torch.zeros(5, dtype=torch.int32)
+    g.add(r, c)
+    assert g.finish() == [([r], [c])]
+
