@@ -388,7 +388,7 @@ def main():
 
     # ---- CPU baseline + parity: the oracle (a port of the reference path) on a bounded sample of the same workload, host cores ---
     cpu, parity = None, {"parity_checked_pairs": 0, "parity_diffs": None}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:          # the CPU leg and the parity check: rank 0 of a one-GPU run only
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
         from parity_util import count_record_diffs
