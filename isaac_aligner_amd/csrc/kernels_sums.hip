@@ -39,36 +39,44 @@ __device__ inline u32 clusterSumsWave(const DevParams &P, const ClusterFragments
     const u32 nSeeded[2] = { f.nCands[0], f.nCands[1] };
     const u32 shadows[2] = { side0, total - side0 };
     if (shadows[0] + nSeeded[1] > k.cap || shadows[1] + nSeeded[0] > k.cap || total > k.cap) return SUMS_TOO_LARGE;
-    // every shadow once: entry base + rank of its problem (the problems of read 1's orphans come first: TemplateBuilder.cpp:737-757)
+    // every shadow once: entry base + rank of its problem (the problems of read 1's orphans come first: TemplateBuilder.cpp:737-757).
+    // The candidates of all problems are spread over the lanes together -- (problem, candidate) pairs in one sequence -- so that a
+    // cluster with several problems pays one memory round trip for their candidate records, not one per problem.
+    u32 inclCands = nCands;
+    for (u32 o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(inclCands, o, 64); if (lane >= o) inclCands += v; }
+    const u32 totalCands = __shfl(inclCands, 63, 64);
+    for (u32 idx = lane; idx < ((totalCands + 63) & ~63u); idx += 64)
+    {
+        u32 j = 0;                                             // the problem of candidate idx: the number of problems that end at or before it
+        for (u32 q = 0; q < nJobs; ++q) j += (__shfl(inclCands, q, 64) <= idx) ? 1u : 0u;
+        const u32 jj = j < nJobs ? j : 0;
+        const u32 tj = __shfl(take, jj, 64), cb = __shfl(candBase, jj, 64), bj = __shfl(base, jj, 64), endJ = __shfl(inclCands, jj, 64), nc = __shfl(nCands, jj, 64);
+        if (idx >= totalCands || !tj) continue;
+        const u32 c = idx - (endJ - nc);
+        const Cand &cand = in.shadowCands[cb + c];
+        if (!candAligned(cand)) continue;
+        const u32 r = in.candRank[cb + c];
+        if (r >= tj) continue;
+        const ShadowProb p = makeShadowProb(cand);
+        tab.pos[bj + r] = p.pos; tab.lp[bj + r] = p.logProbability; tab.obs[bj + r] = u32(p.observedLength); tab.job[bj + r] = u8(jj);
+    }
     for (u32 j = 0; j < nJobs; ++j)
     {
         const u32 tj = __shfl(take, j, 64);
-        if (!tj) continue;
-        const u32 cb = __shfl(candBase, j, 64), nc = __shfl(nCands, j, 64), bj = __shfl(base, j, 64);
-        for (u32 c = lane; c < nc; c += 64)
-        {
-            const Cand &cand = in.shadowCands[cb + c];
-            if (!candAligned(cand)) continue;
-            const u32 r = in.candRank[cb + c];
-            if (r >= tj) continue;
-            const ShadowProb p = makeShadowProb(cand);
-            tab.pos[bj + r] = p.pos; tab.lp[bj + r] = p.logProbability; tab.obs[bj + r] = u32(p.observedLength); tab.job[bj + r] = u8(j);
-        }
         const u32 ng = __shfl(nGapped, j, 64);
-        if (__shfl(rescued, j, 64) && ng)
+        if (!tj || !__shfl(rescued, j, 64) || !ng) continue;
+        const u32 bj = __shfl(base, j, 64);
+        groupSync(g);                                         // the accepted retries replace what the loop above wrote
+        const u32 gbase = __shfl(gappedBase, j, 64);
+        for (u32 kk = lane; kk < ng; kk += 64)
         {
-            groupSync(g);                                         // the accepted retries replace what the loop above wrote
-            const u32 gbase = __shfl(gappedBase, j, 64);
-            for (u32 kk = lane; kk < ng; kk += 64)
-            {
-                // GappedJob::pad was written a moment ago by the problem's lane: the rule is evaluated again rather than read through memory
-                const u32 slot = in.gappedJobs[gbase + kk].tag;
-                if (!gappedRetryAccepted(P, in.shadowCands[slot], in.gappedResults[gbase + kk])) continue;
-                const u32 r = in.candRank[slot];
-                if (r >= tj) continue;
-                const ShadowProb p = makeShadowProb(in.gappedResults[gbase + kk].out);
-                tab.pos[bj + r] = p.pos; tab.lp[bj + r] = p.logProbability; tab.obs[bj + r] = u32(p.observedLength);
-            }
+            // GappedJob::pad was written a moment ago by the problem's lane: the rule is evaluated again rather than read through memory
+            const u32 slot = in.gappedJobs[gbase + kk].tag;
+            if (!gappedRetryAccepted(P, in.shadowCands[slot], in.gappedResults[gbase + kk])) continue;
+            const u32 r = in.candRank[slot];
+            if (r >= tj) continue;
+            const ShadowProb p = makeShadowProb(in.gappedResults[gbase + kk].out);
+            tab.pos[bj + r] = p.pos; tab.lp[bj + r] = p.logProbability; tab.obs[bj + r] = u32(p.observedLength);
         }
     }
     groupSync(g);
