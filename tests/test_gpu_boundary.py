@@ -128,3 +128,34 @@ def test_bench_geometry(torch, oracle):
     for f in rec.dtype.names:
         if f not in ("cigar_offset", "cluster_id", "reserved"):
             assert (srec[f] == whole[f]).all(), f
+
+
+def test_build_fragments_after_smaller_selects(torch):
+    """A context that has served an even number of small isaac_gpu_select calls (its second ClusterFragments buffer was the last one
+    in use, sized for those calls) is then asked for isaac_gpu_build_fragments on a far larger tile: the candidates must be what a
+    fresh context produces (the call must not write through the small buffer)"""
+    from isaac_aligner_amd import gpu, synth
+    contigs = synth.make_genome(600000, seed=41, n_contigs=2)
+    host_contigs = [bytes(c.numpy()) for c in contigs]
+    p = options.default_params(150, 150)
+    small = [synth.make_read_pairs(contigs, 3000, 150, seed=50 + i)[0].cuda() for i in range(2)]
+    large = synth.make_read_pairs(contigs, 200000, 150, seed=60)[0].cuda()
+
+    def candidates(al):
+        m, o, _ = al.find_matches(large)
+        return al.build_fragments(large, m, o)
+
+    used = gpu.Aligner(p, 0, host_contigs)
+    used.build_index()
+    m, o, hits = used.find_matches(small[0])
+    tls = used.determine_tls(small[0], m, o)
+    for b in small:                                        # two chunks: the buffers alternate, the second one ends up current
+        m, o, _ = used.find_matches(b)
+        used.select(b, m, o, tls)
+    got_c, got_g = candidates(used)
+    used.close()
+    fresh = gpu.Aligner(p, 0, host_contigs)
+    fresh.build_index()
+    want_c, want_g = candidates(fresh)
+    fresh.close()
+    assert len(got_c) == len(want_c) > 300000 and got_c.tobytes() == want_c.tobytes() and (got_g == want_g).all()
