@@ -183,31 +183,87 @@ __global__ void k_bam_bounds(const u64 *sortedHi, u64 n, u64 *bounds)
     if (hi >= UNALIGNED && (0 == k || before < UNALIGNED)) bounds[0] = k;
     if (hi == DROPPED && (0 == k || before < DROPPED)) bounds[1] = k;
 }
-// One workgroup per BAM_CHUNK_RECORDS consecutive records of the file, in four phases so that memory latency is paid per chunk, not per record:
+// One workgroup per BAM_CHUNK_RECORDS consecutive records of the file.  Everything is done by threads that each own a small piece of a
+// record, so that a vector instruction works on 64 pieces at once (the first versions gave a record to a whole wave, which then issued the
+// few hundred instructions of its irregular parts -- name, tags -- for that one record: 1.4 ns per record, instruction issue bound):
 //   A  a thread per record: order entry -> record -> layout (LDS)
-//   B  a thread per 16 bases: the reads' bases as they are stored (reverse-complemented for reverse alignments) and the first CIGAR words
-//      into LDS, every thread's loads in flight together
-//   C  a wave per record at a time: the record's bytes from LDS into the chunk's image in LDS
-//   D  the image, a contiguous piece of the file, leaves with 16-byte stores on 16-byte boundaries
-// The first version (a wave per record writing bytes straight to HBM) ran at 115 GB/s: about six dependent memory round trips per record
-// and 16 partial-line write requests per store instruction.
-static const u32 BAM_STAGE_CIGAR = 8, BAM_STAGE_TILES = 128, BAM_CHUNK_RECORDS = 64;
-struct BamChunkLds { u32 chunkBytes, basesStride; };     // dynamic LDS: image[chunkBytes + 16] | bases[64][basesStride] ; the rest is static
+//   B  a thread per piece: the fixed part | the read name | CIGAR + SM + AS | RG + NM + BC | every 16 bases (sequence nibbles and
+//      qualities, straight from the BCL bytes, reverse-complemented for reverse alignments), written into the chunk's image in LDS
+//   C  the image, a contiguous piece of the file, leaves with 16-byte stores on 16-byte boundaries
+// Chunks whose records do not fit the image (CIGARs far beyond the usual) are written byte by byte with bamRecordByte.
+static const u32 BAM_STAGE_TILES = 128, BAM_CHUNK_RECORDS = 64, BAM_SMALL_PIECES = 4;
+struct BamChunkLds { u32 chunkBytes, segments; };     // dynamic LDS: image[chunkBytes + 16]; segments: 16-base pieces of the longest read
 ISAAC_HD u32 bamChunkImageBytes(u32 maxReadLength, u32 nameBytes, u32 tagBytes) { return BAM_CHUNK_RECORDS * (36 + nameBytes + 4 * 40 + (maxReadLength + 1) / 2 + maxReadLength + tagBytes); }
+
+__device__ inline void bamPut32(u8 *to, u32 v) { to[0] = u8(v); to[1] = u8(v >> 8); to[2] = u8(v >> 16); to[3] = u8(v >> 24); }
+__device__ inline void bamPutIntTag(u8 *to, char a, char b, u32 v) { to[0] = u8(a); to[1] = u8(b); to[2] = u8('i'); bamPut32(to + 3, v); }
+__device__ inline void bamPutStringTag(u8 *to, char a, char b, const char *s, u32 n) { to[0] = u8(a); to[1] = u8(b); to[2] = u8('Z'); for (u32 i = 0; i < n; ++i) to[3 + i] = u8(s[i]); to[3 + n] = 0; }
+
+// one of the small pieces of a record (the same bytes bamRecordByte gives for those positions)
+__device__ inline void bamWriteSmallPiece(u32 piece, const BamLayout &l, const char *name, const char *readGroup, u32 readGroupLength, const char *barcode, u32 barcodeLength, u8 *to)
+{
+    if (0 == piece) { for (u32 w = 0; w < 9; ++w) bamPut32(to + 4 * w, l.words[w]); }
+    else if (1 == piece)
+    {
+        const u32 nameBegin = l.nameBegin, digitsBegin = l.digitsBegin, nameTail = l.nameTail;
+        for (u32 i = nameBegin; i < digitsBegin; ++i) to[i] = u8(name[i - nameBegin]);
+        u32 v = l.clusterId;
+        for (u32 i = nameTail; i > digitsBegin; --i) { to[i - 1] = u8('0' + v % 10); v /= 10; }
+        to[nameTail] = u8(':'); to[nameTail + 1] = u8('0'); to[nameTail + 2] = 0;
+    }
+    else if (2 == piece)
+    {
+        const u32 n = l.nCigar, cigarBegin = l.cigarBegin; const u32 *cigar = l.cigar;
+        for (u32 i = 0; i < n; ++i) bamPut32(to + cigarBegin + 4 * i, cigar[i]);
+        const u32 tagBegin = l.tagBegin, smAt = l.smAt, asAt = l.asAt;
+        if (~0u != smAt) bamPutIntTag(to + tagBegin + smAt, 'S', 'M', l.sm);
+        if (~0u != asAt) bamPutIntTag(to + tagBegin + asAt, 'A', 'S', l.as);
+    }
+    else
+    {
+        const u32 tagBegin = l.tagBegin;
+        bamPutStringTag(to + tagBegin + l.rgAt, 'R', 'G', readGroup, readGroupLength);
+        bamPutIntTag(to + tagBegin + l.nmAt, 'N', 'M', l.nm);
+        bamPutStringTag(to + tagBegin + l.bcAt, 'B', 'C', barcode, barcodeLength);
+    }
+}
+
+// stored positions [16 * segment, 16 * segment + 16) of the read: their qualities and the eight sequence bytes they make
+__device__ inline void bamWriteBases(u32 segment, const BamLayout &l, u8 *to)
+{
+    const u32 L = l.readLength, s0 = 16 * segment;
+    if (s0 >= L) return;
+    const bool reverse = 0 != l.reverse;
+    const u8 *bcl = l.bcl;
+    u8 v[16];
+#pragma unroll
+    for (u32 b = 0; b < 16; ++b) v[b] = s0 + b < L ? (reverse ? bcl[L - 1 - s0 - b] : bcl[s0 + b]) : u8(0);
+    u8 *qual = to + l.qualBegin + s0, *seq = to + l.seqBegin + s0 / 2;
+#pragma unroll
+    for (u32 b = 0; b < 16; b += 2)
+    {
+        // FragmentCollector::storeBclAndCigar (reverse complement for reverse alignments), then bamBaseFromBclByte / bamQualFromBclByte
+        const u8 c0 = v[b], c1 = v[b + 1];
+        const u8 st0 = (c0 & 0xfc) ? (reverse ? u8((c0 & 0xfc) | (3 - (c0 & 3))) : c0) : u8(0);
+        const u8 st1 = (c1 & 0xfc) ? (reverse ? u8((c1 & 0xfc) | (3 - (c1 & 3))) : c1) : u8(0);
+        if (s0 + b < L) { qual[b] = u8(st0 >> 2); seq[b / 2] = u8((bamBase4(st0) << 4) | (s0 + b + 1 < L ? bamBase4(st1) : 0u)); }
+        if (s0 + b + 1 < L) qual[b + 1] = u8(st1 >> 2);
+    }
+}
+
 __global__ void __launch_bounds__(256) k_bam_encode(const BamTile *tiles, u32 nTiles, u64 nRecords, BamOptions o, const u32 *order, const u64 *offsets, const u64 *bytes,
                                                     u8 *out, u64 capacity, BamChunkLds lds)
 {
-    extern __shared__ __attribute__((aligned(16))) u8 dynamicLds[];
-    u8 *image = dynamicLds, *bases = dynamicLds + ((lds.chunkBytes + 16 + 15) & ~15u);
+    extern __shared__ __attribute__((aligned(16))) u8 image[];
     __shared__ BamLayout layouts[BAM_CHUNK_RECORDS];
     __shared__ u32 tileOfRecord[BAM_CHUNK_RECORDS];            // ~0u: no bytes for this record
-    __shared__ u32 stageCigar[BAM_CHUNK_RECORDS][BAM_STAGE_CIGAR];
     __shared__ u64 tileFirst[BAM_STAGE_TILES];
     __shared__ u32 imageAt[BAM_CHUNK_RECORDS];                 // where the record starts in the chunk
     __shared__ char optionText[2][64];
-    const u32 lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __shared__ u32 tileNames[BAM_STAGE_TILES][16];             // BamTile::name of every tile (when there are few enough)
     const bool tilesStaged = nTiles <= BAM_STAGE_TILES;
     if (tilesStaged) for (u32 t = threadIdx.x; t < nTiles; t += blockDim.x) tileFirst[t] = tiles[t].firstRecord;
+    if (tilesStaged) for (u32 x = threadIdx.x; x < nTiles * 16; x += blockDim.x) tileNames[x / 16][x % 16] = reinterpret_cast<const u32 *>(tiles[x / 16].name)[x % 16];
     if (threadIdx.x < 64) optionText[0][threadIdx.x] = o.readGroup[threadIdx.x]; else if (threadIdx.x < 128) optionText[1][threadIdx.x - 64] = o.barcode[threadIdx.x - 64];
     const u64 k0 = u64(blockIdx.x) * BAM_CHUNK_RECORDS, k1 = k0 + BAM_CHUNK_RECORDS < nRecords ? k0 + BAM_CHUNK_RECORDS : nRecords;
     const u32 count = u32(k1 - k0);
@@ -226,64 +282,38 @@ __global__ void __launch_bounds__(256) k_bam_encode(const BamTile *tiles, u32 nT
         const FragmentRecord r = tiles[t].records[i - tiles[t].firstRecord];
         BamLayout l;
         bool write = bamStored(r);
-        if (write) { bamLayout(tiles[t], r, o, l); write = at + l.total <= capacity && l.readLength <= lds.basesStride; }
-        if (write)
-        {
-            layouts[threadIdx.x] = l; imageAt[threadIdx.x] = u32(at - begin);
-        }
+        if (write) { bamLayout(tiles[t], r, o, l); write = at + l.total <= capacity; }
+        if (write) { layouts[threadIdx.x] = l; imageAt[threadIdx.x] = u32(at - begin); }
         tileOfRecord[threadIdx.x] = write ? t : ~0u;
     }
     __syncthreads();
-    // ---- B
-    const u32 segments = (lds.basesStride + 15) / 16;
-    for (u32 x = threadIdx.x; x < count * segments; x += blockDim.x)
-    {
-        const u32 rec = x / segments, first = 16 * (x % segments);
-        if (~0u == tileOfRecord[rec]) continue;
-        const BamLayout &l = layouts[rec];
-        u8 v[16];
-#pragma unroll
-        for (u32 b = 0; b < 16; ++b) v[b] = first + b < l.readLength ? l.bcl[first + b] : u8(0);
-#pragma unroll
-        for (u32 b = 0; b < 16; ++b)
-            if (first + b < l.readLength)
-            {
-                const u8 c = v[b];
-                bases[rec * lds.basesStride + (l.reverse ? l.readLength - 1 - (first + b) : first + b)] = (c & 0xfc) ? (l.reverse ? u8((c & 0xfc) | (3 - (c & 3))) : c) : u8(0);
-            }
-    }
-    for (u32 x = threadIdx.x; x < count * BAM_STAGE_CIGAR; x += blockDim.x)
-    {
-        const u32 rec = x / BAM_STAGE_CIGAR, word = x % BAM_STAGE_CIGAR;
-        if (~0u != tileOfRecord[rec] && word < layouts[rec].nCigar) stageCigar[rec][word] = layouts[rec].cigar[word];
-    }
-    __syncthreads();
-    // ---- C: no global memory in this phase
-    for (u32 rec = w; rec < count; rec += 4)
-    {
-        if (~0u == tileOfRecord[rec]) continue;
-        const BamLayout &l = layouts[rec];
-        const u8 *stored = bases + rec * lds.basesStride;
-        BamStrings text = { tiles[tileOfRecord[rec]].name, optionText[0], optionText[1], o.readGroupLength, o.barcodeLength };
-        if (viaLds && l.nCigar <= BAM_STAGE_CIGAR)
+    if (!viaLds)
+    {   // the general form: a wave per record at a time, byte j of the record by lane j, j + 64, ...
+        const u32 lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        for (u32 rec = w; rec < count; rec += 4)
         {
-            u8 *to = image + shift + imageAt[rec];
-            for (u32 j = lane; j < l.total; j += 64) to[j] = bamRecordByte(text, l, j, stored, stageCigar[rec]);
-        }
-        else if (viaLds)
-        {
-            u8 *to = image + shift + imageAt[rec];
-            for (u32 j = lane; j < l.total; j += 64) to[j] = bamRecordByte(text, l, j, stored, l.cigar);
-        }
-        else
-        {
+            if (~0u == tileOfRecord[rec]) continue;
+            const BamLayout &l = layouts[rec];
+            BamStrings text = { tiles[tileOfRecord[rec]].name, optionText[0], optionText[1], o.readGroupLength, o.barcodeLength };
             u8 *to = out + begin + imageAt[rec];
-            for (u32 j = lane; j < l.total; j += 64) to[j] = bamRecordByte(text, l, j, stored, l.cigar);
+            for (u32 j = lane; j < l.total; j += 64) to[j] = bamRecordByte(text, l, j, nullptr, l.cigar);
         }
+        return;
     }
-    if (!viaLds) return;
+    // ---- B
+    const u32 pieces = BAM_SMALL_PIECES + lds.segments;
+    for (u32 x = threadIdx.x; x < count * pieces; x += blockDim.x)
+    {
+        const u32 rec = x / pieces, piece = x % pieces;
+        const u32 t = tileOfRecord[rec];
+        if (~0u == t) continue;
+        u8 *to = image + shift + imageAt[rec];
+        if (piece < BAM_SMALL_PIECES)
+            bamWriteSmallPiece(piece, layouts[rec], tilesStaged ? reinterpret_cast<const char *>(tileNames[t]) : tiles[t].name, optionText[0], o.readGroupLength, optionText[1], o.barcodeLength, to);
+        else bamWriteBases(piece - BAM_SMALL_PIECES, layouts[rec], to);
+    }
     __syncthreads();
-    // ---- D: the part of [begin, end) that fits the caller's buffer: records are whole or absent, and the ones that did not fit lie at the end
+    // ---- C: the part of [begin, end) that fits the caller's buffer: records are whole or absent, and the ones that did not fit lie at the end
     u64 stop = end <= capacity ? end : begin;
     if (end > capacity) for (u64 k = k0; k < k1; ++k) { const u64 e = offsets[k] + bytes[k]; if (e <= capacity) stop = e; }
     const u32 n = u32(stop - begin);

@@ -1296,9 +1296,9 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
         for (u32 r = 0; r < o.nReads; ++r) maxRead = std::max(maxRead, o.readLength[r]);
         for (u32 t = 0; t < nTiles; ++t) maxName = std::max(maxName, h[t].nameLength);
         BamChunkLds lds;
-        lds.basesStride = (maxRead + 15) & ~15u;
+        lds.segments = (maxRead + 15) / 16;
         lds.chunkBytes = std::min<u32>(bamChunkImageBytes(maxRead, maxName + 13, 28 + o.readGroupLength + o.barcodeLength), 96 * 1024);
-        const size_t dynamicBytes = ((lds.chunkBytes + 16 + 15) & ~15u) + size_t(BAM_CHUNK_RECORDS) * lds.basesStride;
+        const size_t dynamicBytes = (lds.chunkBytes + 16 + 15) & ~15u;
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bam_encode), hipFuncAttributeMaxDynamicSharedMemorySize, int(dynamicBytes)));
         k_bam_encode<<<gridFor(n, BAM_CHUNK_RECORDS), 256, dynamicBytes, st>>>(c->bamTiles.p, nTiles, n, o, c->bamIndex.p, c->bamOffsets.p, c->bamBytes64.p, bam, capacity, lds);
     }
