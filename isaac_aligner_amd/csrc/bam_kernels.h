@@ -191,7 +191,10 @@ __global__ void k_bam_bounds(const u64 *sortedHi, u64 n, u64 *bounds)
 //      qualities, straight from the BCL bytes, reverse-complemented for reverse alignments), written into the chunk's image in LDS
 //   C  the image, a contiguous piece of the file, leaves with 16-byte stores on 16-byte boundaries
 // Chunks whose records do not fit the image (CIGARs far beyond the usual) are written byte by byte with bamRecordByte.
-static const u32 BAM_STAGE_TILES = 128, BAM_CHUNK_RECORDS = 64, BAM_SMALL_PIECES = 4;
+#ifndef ISAAC_BAM_CHUNK_RECORDS
+#define ISAAC_BAM_CHUNK_RECORDS 32
+#endif
+static const u32 BAM_STAGE_TILES = 32, BAM_CHUNK_RECORDS = ISAAC_BAM_CHUNK_RECORDS, BAM_SMALL_PIECES = 4;
 struct BamChunkLds { u32 chunkBytes, segments; };     // dynamic LDS: image[chunkBytes + 16]; segments: 16-base pieces of the longest read
 ISAAC_HD u32 bamChunkImageBytes(u32 maxReadLength, u32 nameBytes, u32 tagBytes) { return BAM_CHUNK_RECORDS * (36 + nameBytes + 4 * 40 + (maxReadLength + 1) / 2 + maxReadLength + tagBytes); }
 
