@@ -173,26 +173,6 @@ ISAAC_HD const u16 *radixOrder(SumKeys &k, u32 n, bool pairs, const SumGroup &g)
     return dst;
 }
 
-// acc + t[0] + t[1] + ... in exactly that order.  Eight terms are fetched before they are added: the chain of dependent additions then
-// does not wait for loads.
-ISAAC_HD double addInOrder(double acc, const double *t, u32 n)
-{
-    u32 i = 0;
-    if (n >= 8)
-    {   // the next eight terms are on their way while the current eight are added
-        double a0 = t[0], a1 = t[1], a2 = t[2], a3 = t[3], a4 = t[4], a5 = t[5], a6 = t[6], a7 = t[7];
-        for (i = 8; i + 8 <= n; i += 8)
-        {
-            const double b0 = t[i], b1 = t[i + 1], b2 = t[i + 2], b3 = t[i + 3], b4 = t[i + 4], b5 = t[i + 5], b6 = t[i + 6], b7 = t[i + 7];
-            acc += a0; acc += a1; acc += a2; acc += a3; acc += a4; acc += a5; acc += a6; acc += a7;
-            a0 = b0; a1 = b1; a2 = b2; a3 = b3; a4 = b4; a5 = b5; a6 = b6; a7 = b7;
-        }
-        acc += a0; acc += a1; acc += a2; acc += a3; acc += a4; acc += a5; acc += a6; acc += a7;
-    }
-    for (; i < n; ++i) acc += t[i];
-    return acc;
-}
-
 // Sum of exp(lp) over the first element of every run of equal keys of entries [0, n), in sorted order.  false: a near tie.
 ISAAC_HD bool uniqueSortedSum(SumKeys &k, u32 n, bool pairs, const SumGroup &g, u32 *scratch, double &sum)
 {

@@ -871,6 +871,26 @@ ISAAC_HD Cand cloneWithCigar(TemplateWork &w, const Cand &right, const u32 *righ
 ISAAC_HD void pushShadowProb(TemplateWork &w, u32 side, const Cand &s)
 { if (w.nShadowProbs[side] < w.caps.prob) w.shadowProbs[side][w.nShadowProbs[side]++] = makeShadowProb(s); else w.overflow = 1; }
 
+// acc + t[0] + t[1] + ... in exactly that order.  Eight terms are fetched before they are added: the chain of dependent additions then
+// does not wait for loads.
+ISAAC_HD double addInOrder(double acc, const double *t, u32 n)
+{
+    u32 i = 0;
+    if (n >= 8)
+    {   // the next eight terms are on their way while the current eight are added
+        double a0 = t[0], a1 = t[1], a2 = t[2], a3 = t[3], a4 = t[4], a5 = t[5], a6 = t[6], a7 = t[7];
+        for (i = 8; i + 8 <= n; i += 8)
+        {
+            const double b0 = t[i], b1 = t[i + 1], b2 = t[i + 2], b3 = t[i + 3], b4 = t[i + 4], b5 = t[i + 5], b6 = t[i + 6], b7 = t[i + 7];
+            acc += a0; acc += a1; acc += a2; acc += a3; acc += a4; acc += a5; acc += a6; acc += a7;
+            a0 = b0; a1 = b1; a2 = b2; a3 = b3; a4 = b4; a5 = b5; a6 = b6; a7 = b7;
+        }
+        acc += a0; acc += a1; acc += a2; acc += a3; acc += a4; acc += a5; acc += a6; acc += a7;
+    }
+    for (; i < n; ++i) acc += t[i];
+    return acc;
+}
+
 // sumUniqueShadowProbabilities / sumUniquePairProbabilities (TemplateBuilder.cpp:694-714): std::sort, then the first element of
 // every run of elements equal to it (std::unique_copy over forward iterators), summed in sorted order
 //
@@ -1010,7 +1030,7 @@ ISAAC_HD double sumUniqueShadowProbabilities(TemplateCtx &x, u32 side)
         for (u32 i = x.lane; i < n; i += x.lanes)
             w.terms[i] = (i && shadowProbEqual(v[w.sortIdx[i - 1]], v[w.sortIdx[i]])) ? 0.0 : exp(v[w.sortIdx[i]].logProbability);
         coopSync(x);
-        for (u32 i = 0; i < n; ++i) ret += w.terms[i];
+        ret = addInOrder(ret, w.terms, n);
     }
     else for (u32 i = 0; i < n;)
     {
@@ -1063,7 +1083,7 @@ ISAAC_HD double sumUniquePairProbabilities(TemplateCtx &x)
         for (u32 i = x.lane; i < n; i += x.lanes)
             w.terms[i] = (i && pairProbEqual(v[w.sortIdx[i - 1]], v[w.sortIdx[i]])) ? 0.0 : exp(pairLp(v[w.sortIdx[i]]));
         coopSync(x);
-        for (u32 i = 0; i < n; ++i) ret += w.terms[i];
+        ret = addInOrder(ret, w.terms, n);
     }
     else for (u32 i = 0; i < n;)
     {
@@ -1124,7 +1144,15 @@ ISAAC_HD bool templateRescueShadow(TemplateCtx &x, BamTemplate &t, double logMis
             if (w.nShadows > probRoom) w.overflow = 1;
             w.nShadowProbs[orphanIndex] = probBase + imin(w.nShadows, probRoom);
             // a running fp64 sum in list order: the order of the additions is part of the result
-            for (u32 s = 0; s < w.nShadows; ++s) bestPair.totalTemplateProbability += exp(orphan.logProbability + w.shadowList[s].logProbability);
+            // (the terms side by side when the term array has room for them, the additions one after the other)
+            if (w.nShadows <= imax(imax(w.caps.pos, w.caps.prob), w.caps.pair))
+            {
+                for (u32 s = x.lane; s < w.nShadows; s += x.lanes) w.terms[s] = exp(orphan.logProbability + w.shadowList[s].logProbability);
+                coopSync(x);
+                bestPair.totalTemplateProbability = addInOrder(bestPair.totalTemplateProbability, w.terms, w.nShadows);
+                coopSync(x);
+            }
+            else for (u32 s = 0; s < w.nShadows; ++s) bestPair.totalTemplateProbability += exp(orphan.logProbability + w.shadowList[s].logProbability);
         }
     }
     if (RESCUE_PRECOMPUTED == x.rescueMode) bestPair.totalTemplateProbability = x.sums->ordered;      // the loop's running sum, made by k_cluster_sums
