@@ -1034,7 +1034,7 @@ struct FragmentSource { const isaac_match *matches; const uint64_t *offsets; con
 __global__ void k_set_template_constants(TemplateConstants k, TemplateConstants *dst) { *dst = k; }
 
 // the wave-per-cluster pass over `list` (count on the device) for the chunk described by `p`, on the context's stream
-static void launchHeavy(isaac_gpu_ctx *c, const isaac_gpu_ctx::Pending &p, const u32 *list, const u32 *countDev, u32 blocks, const char *timer)
+static void launchHeavy(isaac_gpu_ctx *c, const isaac_gpu_ctx::Pending &p, const u32 *list, const u32 *countDev, u32 blocks, const char *timer, bool sumsKnown)
 {
     const TemplateCaps heavy = heavyCaps();
     const u64 heavyBytes = templateWorkBytes(heavy);
@@ -1043,7 +1043,7 @@ static void launchHeavy(isaac_gpu_ctx *c, const isaac_gpu_ctx::Pending &p, const
     rb.jobs = c->jobs.p; rb.shadowCands = c->shadowCands.p; rb.candRank = c->candRank.p; rb.shadowCigars = c->shadowCigars.p; rb.jobBase = c->jobBase.p; rb.jobCount = c->jobCount.p;
     ScopedTimer tm(c, timer);
     k_select_heavy<<<std::max(1u, blocks), 64, HEAVY_SORT_LDS * 2, c->stream>>>(c->P, c->ref(), p.tls, p.rog, logMismatchQ40(), p.bcl, p.clusterBase, 0, countDev, p.tile, p.frags, c->heavyArena.p, heavyBytes, heavy,
-                                                                                 list, rb, c->rescueGappedResults.p, c->rescueGappedJobs.p, p.records, p.cigars, c->counters.p);
+                                                                                 list, rb, c->rescueGappedResults.p, c->rescueGappedJobs.p, sumsKnown ? c->clusterSums.p : nullptr, p.records, p.cigars, c->counters.p);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1052,7 +1052,7 @@ static void resolvePending(isaac_gpu_ctx *c)
     if (!c->pending.active) return;
     c->pending.active = false;
     HIP_CHECK(hipEventSynchronize(c->evSelect));
-    if (c->hostCounts[1]) launchHeavy(c, c->pending, c->overflowList.p, c->overflowCount.p, std::min<u32>(c->hostCounts[1], 1024u), "select_residual");
+    if (c->hostCounts[1]) launchHeavy(c, c->pending, c->overflowList.p, c->overflowCount.p, std::min<u32>(c->hostCounts[1], 1024u), "select_residual", true);
 }
 
 static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, uint32_t tile, const FragmentSource &source, const isaac_tls *tls,
@@ -1171,7 +1171,7 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         // what the sums stage could not do (near ties, lists beyond the reference's own capacities, capacity misses of the flat pass):
         // the wave-per-cluster pass, after k_select.  The host learns the count while k_select runs.
         HIP_CHECK(hipEventSynchronize(c->evSums));
-        if (c->hostCounts[0]) launchHeavy(c, c->pending, c->heavyList.p, c->heavyCount.p, std::min<u32>(c->hostCounts[0], 1024u), "select_heavy");
+        if (c->hostCounts[0]) launchHeavy(c, c->pending, c->heavyList.p, c->heavyCount.p, std::min<u32>(c->hostCounts[0], 1024u), "select_heavy", false);
     }
     if (c->deferredCompletion) return 0;      // the caller enqueues its next call behind this one's k_select; isaac_gpu_synchronize completes the last one
     resolvePending(c);

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_cluster_sums_large(DevParams P, const C
 __global__ __launch_bounds__(1024) void k_cluster_sums_xl(DevParams P, const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);
 __global__ __launch_bounds__(1024) void k_cluster_sums_huge(DevParams P, const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_SELECT_WAVES))) void k_select(const TemplateConstants *constants, DevReference R, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk, u32 tile, const ClusterFragments *frags, RescueBuffers rb, const GappedResult *gappedResults, const GappedJob *gappedJobs, const ClusterSums *sums, FragmentRecord *records, u32 *cigars, u32 *overflowList, u32 *overflowCount, const u8 *skip, Counters *counters);
-__global__ __launch_bounds__(64) void k_select_heavy(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nList, const u32 *nListDev, u32 tile, const ClusterFragments *frags, u8 *arena, u64 arenaBytes, TemplateCaps caps, const u32 *list, RescueBuffers rb, const GappedResult *gappedResults, const GappedJob *gappedJobs, FragmentRecord *records, u32 *cigars, Counters *counters);
+__global__ __launch_bounds__(64) void k_select_heavy(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nList, const u32 *nListDev, u32 tile, const ClusterFragments *frags, u8 *arena, u64 arenaBytes, TemplateCaps caps, const u32 *list, RescueBuffers rb, const GappedResult *gappedResults, const GappedJob *gappedJobs, const ClusterSums *sums, FragmentRecord *records, u32 *cigars, Counters *counters);
 namespace isaac
 {
 __global__ __launch_bounds__(256) void k_bsw_batch(int matchScore, int mismatchScore, int gapOpenScore, int gapExtendScore, const char *sequences, const isaac_bsw_job *jobs, u32 nJobs, u32 maxQueryLength, isaac_bsw_result *results);

@@ -1,11 +1,12 @@
 // kernels_heavy.hip: see kernels.h and DESIGN.md §4
 #include "kernels.h"
 
-// k_select_heavy: one wave per cluster of the overflow list.  All 64 lanes execute the template logic together on one arena
+// k_select_heavy: one wave per cluster of the overflow list (sums == NULL: the clusters the sums kernels could not finish; else the
+// clusters whose placements overflowed k_select's private lists).  All 64 lanes execute the template logic together on one arena
 // (same statements, same data), which costs what one thread costs; the bulk steps (probability sorts) are spread over the lanes.
 __global__ __launch_bounds__(64) void k_select_heavy(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nList, const u32 *nListDev, u32 tile,
                                                      const ClusterFragments *frags, u8 *arena, u64 arenaBytes, TemplateCaps caps, const u32 *list, RescueBuffers rb, const GappedResult *gappedResults, const GappedJob *gappedJobs,
-                                                     FragmentRecord *records, u32 *cigars, Counters *counters)
+                                                     const ClusterSums *sums, FragmentRecord *records, u32 *cigars, Counters *counters)
 {
     extern __shared__ __align__(16) u8 heavyLds[];
     Counters local; memset(&local, 0, sizeof(local));
@@ -19,7 +20,9 @@ __global__ __launch_bounds__(64) void k_select_heavy(DevParams P, DevReference R
     if (rb.jobBase && rb.jobBase[inChunk] != 0xffffffffu)
     {
         in.jobs = rb.jobs + rb.jobBase[inChunk]; in.jobCount = rb.jobCount[inChunk]; in.shadowCands = rb.shadowCands; in.shadowCigars = rb.shadowCigars; in.candRank = rb.candRank;
-        in.gappedResults = gappedResults; in.gappedJobs = gappedJobs; in.serialFallbackAllowed = true; in.sums = nullptr;
+        in.gappedResults = gappedResults; in.gappedJobs = gappedJobs; in.serialFallbackAllowed = true;
+        // sums: the cluster's rescue outcomes and probability sums are there already (it is here because k_select's small lists overflowed)
+        in.sums = sums ? sums + inChunk : nullptr;
         pin = &in;
     }
     CoopInputs coop; coop.lanes = 64; coop.lane = threadIdx.x; coop.fastSort = true; coop.ldsSort = reinterpret_cast<u16 *>(heavyLds); coop.ldsSortCap = HEAVY_SORT_LDS;

@@ -92,7 +92,10 @@ ISAAC_HD TemplateCaps lightCaps() { TemplateCaps c; c.shadow = 48; c.shadowCigar
 // the main pass (k_select, k_plan_rescue): rescue results and probability sums arrive precomputed (RESCUE_PRECOMPUTED), so a thread
 // keeps only the tie lists of the best pairs, the clones of the best rescued shadows and the template's CIGAR buffer -- in
 // private memory.  What does not fit goes to the wave-per-cluster pass with the reference's own limits.
-ISAAC_HD TemplateCaps tinyCaps() { TemplateCaps c; c.shadow = 0; c.shadowCigar = 0; c.pos = 0; c.prob = 0; c.pair = 0; c.best = 4; c.templateCigar = 96; c.kmerTable = 0; c.tflags = 0; return c; }
+#ifndef ISAAC_TINY_BEST
+#define ISAAC_TINY_BEST 4           // equally good placements k_select keeps per read (a test build sets 1: most clusters then take the residual pass)
+#endif
+ISAAC_HD TemplateCaps tinyCaps() { TemplateCaps c; c.shadow = 0; c.shadowCigar = 0; c.pos = 0; c.prob = 0; c.pair = 0; c.best = ISAAC_TINY_BEST; c.templateCigar = 96; c.kmerTable = 0; c.tflags = 0; return c; }
 ISAAC_HD TemplateCaps heavyCaps() { TemplateCaps c; c.shadow = 1000; c.shadowCigar = 16384; c.pos = 10000; c.prob = 32768; c.pair = 32768; c.best = 1000; c.templateCigar = 65536; c.kmerTable = KMER_TABLE; c.tflags = 3 * 512; return c; }
 static const u32 TRACKED_REPEATS_MAX_ONE_READ = 1000;
 static const u32 SKIP_ORPHAN_EDIT_DISTANCE = 3, DODGY_BUT_CLEAN_ALIGNMENT_SCORE = 10;
