@@ -1,0 +1,44 @@
+"""Run with ISAAC_GPU_LIBRARY pointing at the -DISAAC_TINY_BEST=1 build: k_select then keeps one placement per read, most clusters overflow
+its lists and are redone by the residual wave-per-cluster pass from the rescue outcomes and sums that exist already.  The records must be
+the oracle's all the same.  (A process of its own: the product library is loaded once per process.)"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+import oracle_lib                                                        # noqa: E402
+from isaac_aligner_amd import gpu, options, synth                        # noqa: E402
+from parity_util import compare_records                                  # noqa: E402
+
+n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 60000
+g = synth.make_human_like_genome(6_000_000, seed=21)
+contigs = [bytes(c.numpy()) for c in g.contigs]
+bcl = synth.make_read_pairs(g, n_pairs, 150, seed=22, avoid_gaps=True)[0]
+p = options.default_params(150, 150)
+al = gpu.Aligner(p, 0, contigs)
+al.build_index()
+dev_bcl = bcl.cuda()
+m, o, hits = al.find_matches(dev_bcl)
+al.set_loaded_contigs(hits)
+tls = al.determine_tls(dev_bcl, m, o)
+rec, cig = al.records_to_numpy(*al.select(dev_bcl, m, o, tls))
+counters = al.counters()
+orc = oracle_lib.load()
+ref = orc.reference(contigs)
+ref.set_index(al.get_index())
+host = bcl.numpy()
+om, ohits = ref.find_matches(p, host, n_pairs)
+otls = oracle_lib.Tls()
+for name in ("min", "max", "median", "low_std_dev", "high_std_dev", "stable", "mate_min", "mate_max"):
+    setattr(otls, name, getattr(tls, name))
+otls.best_model[0], otls.best_model[1] = tls.best_model[0], tls.best_model[1]
+orec, ocig, _ = ref.select(p, host, om, otls, ohits, n_threads=8, n_clusters_hint=n_pairs)
+diffs = compare_records(orec, ocig, rec, cig)
+print("residual clusters %d of %d, differences %d" % (counters["heavy_clusters"], n_pairs, len(diffs)))
+for d in diffs[:3]:
+    print(d)
+sys.exit(1 if diffs or counters["heavy_clusters"] < n_pairs // 20 else 0)

@@ -435,3 +435,17 @@ def test_chunk_buffers_grow_with_the_calls(torch, monkeypatch):
         r2, c2 = fresh.records_to_numpy(*out)
         fresh.close()
         assert not compare_records(r2, c2, r1, c1)
+
+
+def test_residual_pass_on_most_clusters(torch):
+    """the -DISAAC_TINY_BEST=1 build of the library (made by __graft_entry__.build()): most clusters overflow k_select's private lists and
+    go through the residual wave-per-cluster pass, which takes their rescue outcomes and probability sums as k_cluster_sums left them;
+    records against the oracle in a process of its own"""
+    import subprocess
+    import sys
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "isaac_aligner_amd", "libisaac_gpu_residual.so")
+    if not os.path.exists(lib):
+        pytest.skip("the residual test build is not there (python __graft_entry__.py builds it)")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "residual_variant_check.py"), "60000"],
+                       env=dict(os.environ, ISAAC_GPU_LIBRARY=lib), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
