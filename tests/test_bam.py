@@ -243,3 +243,69 @@ def test_gpu_bam_file_is_readable(tmp_path):
     assert len(recs) == n == 40000
     keys = [(r["ref_id"], r["pos"]) for r in recs if r["ref_id"] >= 0]
     assert keys == sorted(keys) and len(keys) > 39000
+
+
+@pytest.mark.gpu
+def test_gpu_fastq_to_bam_end_to_end(tmp_path):
+    """The rows on either side of the path joined up, through the C ABI only: a lane's FASTQ text -> tiles (FastqSeedSource's rule) ->
+    BCL bytes on the device -> seed lookup, template length statistics, match selection per tile -> one position-sorted BAM file.
+    The uncompressed record stream must be the oracle's, computed from the same FASTQ text by the oracle's reader, aligner and
+    BAM writer; the file must inflate to header + records."""
+    import torch
+    from isaac_aligner_amd import gpu
+    o = oracle_lib.load()
+    L, n_pairs, at_a_time = 100, 9000, 4000                        # --clusters-at-a-time 4000: tiles of 4000, 4000, 1000
+    genome = synth.make_genome(300000, seed=31, n_contigs=3)
+    contigs = [bytes(c.numpy()) for c in genome]
+    bcl = synth.make_read_pairs(genome, n_pairs, L, seed=32, indel_read_fraction=0.05, n_rate=0.002)[0].numpy()
+    text = [synth.bcl_to_fastq(bcl, r * L, L, name="FC1:1:r%d" % (r + 1)) for r in range(2)]
+    params = options.default_params(L, L)
+    tiles, next_tile = gpu.fastq_tiles(n_pairs, params.n_seeds, clusters_at_a_time=at_a_time)
+    assert [c for _, c in tiles] == [4000, 4000, 1000] and [t for t, _ in tiles] == [1, 2, 3] and next_tile == 4
+    a = gpu.Aligner(params, 0, contigs)
+    a.build_index()
+    # the whole load goes through the converter once per read, then the tiles are slices of it
+    lane = None
+    for r in range(2):
+        lane, n, _ = a.fastq_to_bcl(text[r], r, bcl=lane, max_clusters=n_pairs)
+        assert n == n_pairs
+    ref = o.reference(contigs)
+    ref.set_index(a.get_index())
+    o_lane = None
+    for r in range(2):
+        rc, o_lane, n, _, _ = o.fastq_to_bcl(text[r], L, bcl=o_lane, cluster_stride=2 * L, offset=r * L, max_clusters=n_pairs)
+        assert rc == 0 and n == n_pairs
+    assert (lane.cpu().numpy() == o_lane).all()
+    dev_tiles, host_tiles, tls, first = [], [], None, 0
+    all_hits = np.zeros(len(contigs), np.uint8)
+    found = []
+    for tile, count in tiles:                                            # phase 1 over all tiles, then the loaded contigs are known
+        d = lane[first:first + count]
+        m, off, hits = a.find_matches(d, tile=tile)
+        om, ohits = ref.find_matches(params, o_lane[first:first + count], count, tile=tile)
+        all_hits |= hits
+        found.append((d, m, off, om, first, count, tile))
+        first += count
+    a.set_loaded_contigs(all_hits)
+    for d, m, off, om, first, count, tile in found:
+        if tls is None:
+            tls = a.determine_tls(d, m, off, tile=tile)                  # the first tile teaches the template length statistics
+            otls = ref.determine_tls(params, o_lane[first:first + count], om, all_hits, tile=tile)
+            assert otls.astuple() == tls.astuple()
+        rec, cig = a.select(d, m, off, tls, tile=tile)
+        prefix = "FC1:1:%d:" % tile
+        dev_tiles.append((d, rec, cig, prefix))
+        orec, ocig, _ = ref.select(params, o_lane[first:first + count], om, otls, all_hits, tile=tile, n_clusters_hint=count)
+        host_tiles.append((o_lane[first:first + count], orec, ocig, prefix))
+    stream, n_rec, _ = a.bam_records(dev_tiles)
+    want, want_n, _ = o.bam_records(host_tiles, [L, L], forced_dodgy_alignment_score=params.dodgy_alignment_score & 0xff)
+    assert n_rec == want_n == 2 * n_pairs
+    assert stream.cpu().numpy().tobytes() == want
+    header = bam.header("isaac-align (test)", "0", [("c%d" % i, len(c)) for i, c in enumerate(contigs)], header_lines=["@RG\tID:0\tPL:ILLUMINA\tSM:s"])
+    path = str(tmp_path / "sorted.bam")
+    bam.write_bam(path, header, stream.cpu().numpy(), level=1)
+    raw = gzip.open(path).read()
+    assert raw == header + want
+    recs = bam.parse_records(want)
+    assert {r["name"].split(":")[2] for r in recs} == {"1", "2", "3"}   # read names carry the tile of the rule, cluster ids restart per tile
+    assert max(int(r["name"].split(":")[3]) for r in recs) == 3999
