@@ -100,7 +100,8 @@ static const u32 TINY_WORK_BYTES = 1024;
 static const u32 SUMS_HUGE_ENTRY = 44;   // bytes per list entry of the HBM tier: the key arrays (42) + the second index array of the radix ordering
 // SUMS_XL_CAP is not a power of two: its index array is padded to the next one for the sorting network (SUMS_XL_LDS)
 static const u32 SUMS_XL_LDS = 3584 * 42 + (4096 - 3584) * 2;
-static const u32 SUMS_WAVE_CAP = 64, SUMS_BLOCK_CAP = 1024, SUMS_XL_CAP = 3584, SUMS_HUGE_CAP = 32768 /* heavyCaps().prob / .pair */, SUMS_HUGE_BLOCKS = 512;
+static const u32 SUMS_WAVE_CAP = 64, SUMS_BLOCK_CAP = 1024, SUMS_XL_CAP = 3584, SUMS_HUGE_CAP = 65528 /* what 16-bit entry indexes allow; the reference reserves seeds x repeat threshold x 2000 pairs */,
+                 SUMS_HUGE_DIGITS = 32768 /* entries whose radix digits fit the LDS array */, SUMS_HUGE_BLOCKS = 512;
 struct SumsBuffers { ClusterSums *sums; u8 *residualFlag; u32 *residualList, *residualCount, *largeList, *largeCount, *xlList, *xlCount, *hugeList, *hugeCount; u8 *hugeKeys; };
 
 static const u32 HEAVY_SORT_LDS = 32768;   // u16 indices: heavyCaps().prob / .pair entries

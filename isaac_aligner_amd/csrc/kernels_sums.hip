@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void k_cluster_sums(DevParams P, const Cluster
         else if (rb.jobCount[t])
         {
             SumKeys keys; sumKeysBind(keys, keyBytes[wave], SUMS_WAVE_CAP);
-            SumGroup g; g.lanes = 64; g.lane = lane; g.block = false; g.radix = SumRadix{nullptr, nullptr, nullptr, nullptr, nullptr}; g.radixMin = 0; g.sumTile = nullptr; g.sumTileCap = 0;
+            SumGroup g; g.lanes = 64; g.lane = lane; g.block = false; g.radix = SumRadix{nullptr, nullptr, nullptr, nullptr, nullptr, 0}; g.radixMin = 0; g.sumTile = nullptr; g.sumTileCap = 0;
             ClusterSums out;
             ShadowTable tab; tab.pos = tabPos[wave]; tab.lp = tabLp[wave]; tab.obs = tabObs[wave]; tab.job = tabJob[wave];
 #if defined(ISAAC_SUMS_GENERIC_WAVE)      // A/B aid: the general form of sums.h on the wavefront
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void k_cluster_sums_large(DevParams P, const C
     {
         const u32 t = sb.largeList[i];
         SumKeys keys; sumKeysBind(keys, keyBytes, SUMS_BLOCK_CAP);
-        SumGroup g; g.lanes = 256; g.lane = threadIdx.x; g.block = true; g.radix = SumRadix{nullptr, nullptr, nullptr, nullptr, nullptr}; g.radixMin = 0; g.sumTile = nullptr; g.sumTileCap = 0;
+        SumGroup g; g.lanes = 256; g.lane = threadIdx.x; g.block = true; g.radix = SumRadix{nullptr, nullptr, nullptr, nullptr, nullptr, 0}; g.radixMin = 0; g.sumTile = nullptr; g.sumTileCap = 0;
         ClusterSums out;
         const u32 status = clusterSums(P, frags[t], sumInputs(rb, t, gb), keys, g, &scratch, false, out, local);
         if (0 == threadIdx.x)
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(1024) void k_cluster_sums_xl(DevParams P, const Clu
     for (u32 i = blockIdx.x; i < n; i += gridDim.x)
     {
         const u32 t = sb.xlList[i];
-        SumGroup g; g.lanes = 1024; g.lane = threadIdx.x; g.block = true; g.radix = SumRadix{nullptr, nullptr, nullptr, nullptr, nullptr}; g.radixMin = 0; g.sumTile = nullptr; g.sumTileCap = 0;
+        SumGroup g; g.lanes = 1024; g.lane = threadIdx.x; g.block = true; g.radix = SumRadix{nullptr, nullptr, nullptr, nullptr, nullptr, 0}; g.radixMin = 0; g.sumTile = nullptr; g.sumTileCap = 0;
         ClusterSums out;
         const u32 status = clusterSums(P, frags[t], sumInputs(rb, t, gb), keys, g, &scratch, false, out, local);
         if (0 == threadIdx.x)
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(1024) void k_cluster_sums_huge(DevParams P, const C
     __shared__ __align__(16) u16 radixCounts[16 * 1024];
     __shared__ u32 radixTotals[1024];
     __shared__ u64 radixVary[2];
-    __shared__ u8 radixDigits[SUMS_HUGE_CAP];
+    __shared__ u8 radixDigits[SUMS_HUGE_DIGITS];
     Counters local; memset(&local, 0, sizeof(local));
     const u32 n = *sb.hugeCount;
     u8 *mine = sb.hugeKeys + size_t(blockIdx.x) * SUMS_HUGE_CAP * SUMS_HUGE_ENTRY;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(1024) void k_cluster_sums_huge(DevParams P, const C
         const u32 t = sb.hugeList[i];
         SumGroup g; g.lanes = 1024; g.lane = threadIdx.x; g.block = true; g.radixMin = 0;
         g.sumTile = reinterpret_cast<double *>(radixCounts); g.sumTileCap = sizeof(radixCounts) / 8;        // the counts are idle by then
-        g.radix.counts = radixCounts; g.radix.totals = radixTotals; g.radix.vary = radixVary; g.radix.alt = reinterpret_cast<u16 *>(mine + size_t(SUMS_HUGE_CAP) * 42); g.radix.digits = radixDigits;
+        g.radix.counts = radixCounts; g.radix.totals = radixTotals; g.radix.vary = radixVary; g.radix.alt = reinterpret_cast<u16 *>(mine + size_t(SUMS_HUGE_CAP) * 42); g.radix.digits = radixDigits; g.radix.digitsCap = SUMS_HUGE_DIGITS;
         ClusterSums out;
         const u32 status = clusterSums(P, frags[t], sumInputs(rb, t, gb), keys, g, &scratch, false, out, local);
         if (0 == threadIdx.x)

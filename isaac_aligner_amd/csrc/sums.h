@@ -32,7 +32,7 @@ ISAAC_HD void sumKeysBind(SumKeys &k, void *base, u32 cap)
 // the lanes working on one cluster: one wavefront, or a whole workgroup (block = true)
 // radix: work area of the radix ordering used for long lists (counts: 16 x lanes, totals: lanes, vary: 2, alt: as many entries as the
 // key arrays), or all NULL
-struct SumRadix { u16 *counts; u32 *totals; u64 *vary; u16 *alt; u8 *digits; };   // digits (optional, one byte per entry, close memory): see radixOrder
+struct SumRadix { u16 *counts; u32 *totals; u64 *vary; u16 *alt; u8 *digits; u32 digitsCap; };   // digits (optional, one byte per entry, close memory): see radixOrder
 // sumTile: LDS room for sumTileCap terms when the key arrays are not in LDS themselves (the final additions are a chain of
 // dependent loads otherwise), or NULL
 struct SumGroup { u32 lanes, lane; bool block; SumRadix radix; u32 radixMin; double *sumTile; u32 sumTileCap; };
@@ -90,7 +90,8 @@ ISAAC_HD bool sumKeyRestLess(const SumKeys &k, bool pairs, u32 a, u32 b)
 // Returns the array that holds the order (k.idx or g.radix.alt).
 ISAAC_HD const u16 *radixOrder(SumKeys &k, u32 n, bool pairs, const SumGroup &g)
 {
-    const SumRadix &r = g.radix;
+    SumRadix r = g.radix;
+    if (n > r.digitsCap) r.digits = nullptr;          // the close array holds digitsCap entries: longer lists gather from the key arrays
     const u32 per = (n + g.lanes - 1) / g.lanes, begin = imin(n, g.lane * per), end = imin(n, begin + per);
     u16 *src = k.idx, *dst = r.alt;
     for (u32 i = begin; i < end; ++i) src[i] = u16(i);
@@ -180,7 +181,7 @@ ISAAC_HD bool uniqueSortedSum(SumKeys &k, u32 n, bool pairs, const SumGroup &g, 
     if (!n) return true;
     const u16 *order = k.idx;
     const u8 *same = nullptr;                 // radixOrder leaves "same positions as the predecessor in the order" per entry when it has room for it
-    if (g.radix.counts && n >= g.radixMin) { order = radixOrder(k, n, pairs, g); same = g.radix.digits; }
+    if (g.radix.counts && n >= g.radixMin) { order = radixOrder(k, n, pairs, g); same = n <= g.radix.digitsCap ? g.radix.digits : nullptr; }
     else
 #if defined(__HIP_DEVICE_COMPILE__)
     if (!g.block && n <= g.lanes)

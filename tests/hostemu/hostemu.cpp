@@ -226,10 +226,10 @@ int emu_select(Emu *e, const u8 *bcl, u32 nClusters, u32 tile, const isaac_tls *
         in.gappedResults = gapped.data(); in.gappedJobs = gj.data(); in.candRank = candRank.data(); in.sums = 0;
         const auto t0 = std::chrono::steady_clock::now();
         SumInputs si; si.jobs = in.jobs; si.nJobs = in.jobCount; si.shadowCands = shadowCands.data(); si.candRank = candRank.data(); si.gappedResults = gapped.data(); si.gappedJobs = gj.data();
-        SumGroup g; g.lanes = 1; g.lane = 0; g.block = false; g.radix = SumRadix{nullptr, nullptr, nullptr, nullptr, nullptr}; g.radixMin = 0; g.sumTile = nullptr; g.sumTileCap = 0;
+        SumGroup g; g.lanes = 1; g.lane = 0; g.block = false; g.radix = SumRadix{nullptr, nullptr, nullptr, nullptr, nullptr, 0}; g.radixMin = 0; g.sumTile = nullptr; g.sumTileCap = 0;
         double sumTile[7]; if (e->sumsRadixMin >= 0) { g.sumTile = sumTile; g.sumTileCap = 7; }
         u16 radixCounts[16]; u32 radixTotals[1]; u64 radixVary[2]; std::vector<u16> radixAlt(1024); std::vector<u8> radixDigits(1024);
-        if (e->sumsRadixMin >= 0) { g.radix.digits = (c & 1) ? radixDigits.data() : nullptr; g.radix.counts = radixCounts; g.radix.totals = radixTotals; g.radix.vary = radixVary; g.radix.alt = radixAlt.data(); g.radixMin = u32(e->sumsRadixMin); }
+        if (e->sumsRadixMin >= 0) { g.radix.digits = (c & 1) ? radixDigits.data() : nullptr; g.radix.digitsCap = (c & 2) ? 1024 : 24; g.radix.counts = radixCounts; g.radix.totals = radixTotals; g.radix.vary = radixVary; g.radix.alt = radixAlt.data(); g.radixMin = u32(e->sumsRadixMin); }
         ClusterSums sums; u32 scratch = 0;
         bool residual = SUMS_DONE != clusterSums(e->P, e->frags[c], si, keys, g, &scratch, true, sums, e->cnt);
         CoopInputs coop; coop.lanes = 1; coop.lane = 0; coop.fastSort = false; coop.ldsSort = 0; coop.ldsSortCap = 0;
