@@ -69,7 +69,7 @@ struct isaac_gpu_ctx
     DevBuf<Match> staging; DevBuf<u32> counts, chunkOffsets; DevBuf<u8> cubTemp; DevBuf<u32> contigHits;
     DevBuf<ClusterFragments> frags, fragsAlt; ClusterFragments *fragsCur = nullptr; DevBuf<FragmentWork> fragWork;   // fragsAlt: see isaac_gpu_select
     DevBuf<GappedJob> gappedJobs, rescueGappedJobs; DevBuf<GappedResult> gappedResults, rescueGappedResults; DevBuf<u32> gappedBase, gappedCounters;
-    DevBuf<u8> heavyArena; DevBuf<u32> overflowList; DevBuf<u32> overflowCount; DevBuf<ClusterSums> clusterSums; DevBuf<u32> largeList, xlList, hugeList, longJobs; DevBuf<u8> hugeKeys;
+    DevBuf<u8> heavyArena; DevBuf<u32> overflowList; DevBuf<u32> overflowCount; DevBuf<ClusterSums> clusterSums; DevBuf<u32> mediumList, largeList, xlList, hugeList, longJobs; DevBuf<u8> hugeKeys;
     DevBuf<TlsSample> tlsSamples; DevBuf<u32> cigarLengths, cigarOffsets;
     // isaac_gpu_bam_records scratch
     DevBuf<BamTile> bamTiles; DevBuf<u64> bamKeyHi, bamKeyLo, bamKeyAlt, bamOffsets, bamBytes64, bamBounds; DevBuf<u32> bamIndex, bamIndexAlt, bamBytes;
@@ -1080,10 +1080,10 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
     rb.jobs = c->jobs.p; rb.bitmaps = c->bitmaps.p; rb.candPositions = c->candPositions.p; rb.candJob = c->candJob.p; rb.shadowCands = c->shadowCands.p; rb.candRank = c->candRank.p;
     rb.shadowCigars = c->shadowCigars.p; rb.jobBase = c->jobBase.p; rb.jobCount = c->jobCount.p;
     rb.jobCounter = c->rescueCounters.p; rb.bitmapCounter = c->rescueCounters.p + 1; rb.candCounter = c->rescueCounters.p + 4;
-    c->clusterSums.reserve(chunk); c->heavyList.reserve(chunk); c->largeList.reserve(chunk); c->hugeList.reserve(chunk); c->xlList.reserve(chunk); c->heavyCount.reserve(4); c->heavyFlag.reserve(chunk);
+    c->clusterSums.reserve(chunk); c->heavyList.reserve(chunk); c->mediumList.reserve(chunk); c->largeList.reserve(chunk); c->hugeList.reserve(chunk); c->xlList.reserve(chunk); c->heavyCount.reserve(8); c->heavyFlag.reserve(chunk);
     c->hugeKeys.reserve(size_t(SUMS_HUGE_BLOCKS) * SUMS_HUGE_CAP * SUMS_HUGE_ENTRY);
     SumsBuffers sb; sb.sums = c->clusterSums.p; sb.residualFlag = c->heavyFlag.p; sb.residualList = c->heavyList.p; sb.residualCount = c->heavyCount.p;
-    sb.largeList = c->largeList.p; sb.largeCount = c->heavyCount.p + 1; sb.hugeList = c->hugeList.p; sb.hugeCount = c->heavyCount.p + 2; sb.xlList = c->xlList.p; sb.xlCount = c->heavyCount.p + 3; sb.hugeKeys = c->hugeKeys.p;
+    sb.mediumList = c->mediumList.p; sb.mediumCount = c->heavyCount.p + 4; sb.largeList = c->largeList.p; sb.largeCount = c->heavyCount.p + 1; sb.hugeList = c->hugeList.p; sb.hugeCount = c->heavyCount.p + 2; sb.xlList = c->xlList.p; sb.xlCount = c->heavyCount.p + 3; sb.hugeKeys = c->hugeKeys.p;
     const DevReference R = c->ref();
     {
         TemplateConstants k; k.P = c->P; k.tls = t; k.rog = rog;
@@ -1112,7 +1112,7 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         HIP_CHECK(hipMemsetAsync(c->overflowCount.p, 0, 4, st));
         HIP_CHECK(hipMemsetAsync(c->rescueCounters.p, 0, (4 + CAND_REGIONS) * 4, st));
         HIP_CHECK(hipMemsetAsync(c->rescueCounters.p + 4 + CAND_REGIONS, 0xff, CAND_REGIONS * 4, st));   // per region: first request that did not fit
-        HIP_CHECK(hipMemsetAsync(c->heavyCount.p, 0, 16, st));
+        HIP_CHECK(hipMemsetAsync(c->heavyCount.p, 0, 32, st));
         HIP_CHECK(hipMemsetAsync(c->heavyFlag.p, 0, n, st));
         {
             ScopedTimer tm(c, "plan_rescue");
@@ -1138,7 +1138,8 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         launchGappedJobs(c, bcl, done, gbRescue, "gapped_rescue");
         {
             ScopedTimer tm(c, "sums_wave");
-            k_cluster_sums<<<gridFor(n, 4), 256, 0, st>>>(c->P, c->fragsCur, n, rb, gbRescue, sb, c->counters.p);
+            k_cluster_sums16<<<gridFor(n, 16), 256, 0, st>>>(c->P, c->fragsCur, n, rb, gbRescue, sb, c->counters.p);
+            k_cluster_sums<<<8192, 256, 0, st>>>(c->P, c->fragsCur, rb, gbRescue, sb, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }
         {

@@ -100,9 +100,9 @@ static const u32 TINY_WORK_BYTES = 1024;
 static const u32 SUMS_HUGE_ENTRY = 44;   // bytes per list entry of the HBM tier: the key arrays (42) + the second index array of the radix ordering
 // SUMS_XL_CAP is not a power of two: its index array is padded to the next one for the sorting network (SUMS_XL_LDS)
 static const u32 SUMS_XL_LDS = 3584 * 42 + (4096 - 3584) * 2;
-static const u32 SUMS_WAVE_CAP = 64, SUMS_BLOCK_CAP = 1024, SUMS_XL_CAP = 3584, SUMS_HUGE_CAP = 65528 /* what 16-bit entry indexes allow; the reference reserves seeds x repeat threshold x 2000 pairs */,
+static const u32 SUMS_QUARTER_CAP = 16, SUMS_WAVE_CAP = 64, SUMS_BLOCK_CAP = 1024, SUMS_XL_CAP = 3584, SUMS_HUGE_CAP = 65528 /* what 16-bit entry indexes allow; the reference reserves seeds x repeat threshold x 2000 pairs */,
                  SUMS_HUGE_DIGITS = 32768 /* entries whose radix digits fit the LDS array */, SUMS_HUGE_BLOCKS = 512;
-struct SumsBuffers { ClusterSums *sums; u8 *residualFlag; u32 *residualList, *residualCount, *largeList, *largeCount, *xlList, *xlCount, *hugeList, *hugeCount; u8 *hugeKeys; };
+struct SumsBuffers { ClusterSums *sums; u8 *residualFlag; u32 *residualList, *residualCount, *mediumList, *mediumCount, *largeList, *largeCount, *xlList, *xlCount, *hugeList, *hugeCount; u8 *hugeKeys; };
 
 static const u32 HEAVY_SORT_LDS = 32768;   // u16 indices: heavyCaps().prob / .pair entries
 
@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
 __global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const ClusterFragments *frags, RescueBuffers rb, Counters *counters);
 __global__ __launch_bounds__(256) void k_rescue_gapped_plan(const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, u32 *longList, u32 *longCount, Counters *counters);
 __global__ __launch_bounds__(256) void k_rescue_gapped_plan_long(const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, const u32 *longList, const u32 *longCount);
-__global__ __launch_bounds__(256) void k_cluster_sums(DevParams P, const ClusterFragments *frags, u32 nChunk, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);
+__global__ __launch_bounds__(256) void k_cluster_sums16(DevParams P, const ClusterFragments *frags, u32 nChunk, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);
+__global__ __launch_bounds__(256) void k_cluster_sums(DevParams P, const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);
 __global__ __launch_bounds__(256) void k_cluster_sums_large(DevParams P, const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);
 __global__ __launch_bounds__(1024) void k_cluster_sums_xl(DevParams P, const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);
 __global__ __launch_bounds__(1024) void k_cluster_sums_huge(DevParams P, const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);

@@ -13,10 +13,12 @@ __device__ inline void markResidual(const SumsBuffers &sb, u32 t) { sb.residualF
 // LDS, and the three lists are assembled from that table.  The orders, the near-tie rule and the sums are uniqueSortedSum's.
 struct ShadowTable { u64 *pos; double *lp; u32 *obs; u8 *job; };      // SUMS_WAVE_CAP entries each, in LDS
 
-__device__ inline u32 clusterSumsWave(const DevParams &P, const ClusterFragments &f, const SumInputs &in, SumKeys &k, const ShadowTable &tab, const SumGroup &g, ClusterSums &out, Counters &cnt)
+// W lanes of a wavefront per cluster (64, or 16: four clusters per wavefront for the many clusters whose lists are that short); W entries
+// per key array and table.  Exchanges stay inside the group: shuffles of width W, votes masked to the group's lanes.
+template <u32 W> __device__ inline u32 clusterSumsWave(const DevParams &P, const ClusterFragments &f, const SumInputs &in, SumKeys &k, const ShadowTable &tab, const SumGroup &g, ClusterSums &out, Counters &cnt)
 {
     const u32 lane = g.lane, nJobs = in.nJobs;
-    if (nJobs > 64) return clusterSums(P, f, in, k, g, nullptr, true, out, cnt);
+    if (nJobs > W) { if (W < 64) return SUMS_TOO_LARGE; return clusterSums(P, f, in, k, g, nullptr, true, out, cnt); }
     out.shadow[0] = out.shadow[1] = out.pair = out.ordered = 0.0;
     // the rescue problems, one per lane
     u32 take = 0, side = 0, best = 0, rescued = 0, nGapped = 0, gappedBase = 0, candBase = 0, nCands = 0, retries = 0;
@@ -29,13 +31,17 @@ __device__ inline u32 clusterSumsWave(const DevParams &P, const ClusterFragments
         nGapped = job.nGapped; gappedBase = job.gappedBase; candBase = job.candBase; nCands = job.nCands;
         if (take) { const Cand &o = f.cands[side][job.orphanListIndex]; orphan = makeShadowProb(o); orphanLp = o.logProbability; }
     }
-    if (__any(!ok)) return SUMS_RESIDUAL;
+    {
+        const u32 groupBase = (threadIdx.x & 63u) & ~(W - 1);
+        const unsigned long long groupMask = W < 64 ? ((1ull << W) - 1) << groupBase : ~0ull;
+        if (__ballot(!ok) & groupMask) return SUMS_RESIDUAL;
+    }
     cnt.rescueBsw += retries;
     u32 incl = take;
-    for (u32 o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
-    const u32 base = incl - take, total = __shfl(incl, 63, 64);
+    for (u32 o = 1; o < W; o <<= 1) { const u32 v = __shfl_up(incl, o, W); if (lane >= o) incl += v; }
+    const u32 base = incl - take, total = __shfl(incl, W - 1, W);
     u32 side0 = side ? 0 : take;
-    for (int o = 32; o > 0; o >>= 1) side0 += __shfl_xor(side0, o, 64);
+    for (int o = W / 2; o > 0; o >>= 1) side0 += __shfl_xor(side0, o, W);
     const u32 nSeeded[2] = { f.nCands[0], f.nCands[1] };
     const u32 shadows[2] = { side0, total - side0 };
     if (shadows[0] + nSeeded[1] > k.cap || shadows[1] + nSeeded[0] > k.cap || total > k.cap) return SUMS_TOO_LARGE;
@@ -43,14 +49,14 @@ __device__ inline u32 clusterSumsWave(const DevParams &P, const ClusterFragments
     // The candidates of all problems are spread over the lanes together -- (problem, candidate) pairs in one sequence -- so that a
     // cluster with several problems pays one memory round trip for their candidate records, not one per problem.
     u32 inclCands = nCands;
-    for (u32 o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(inclCands, o, 64); if (lane >= o) inclCands += v; }
-    const u32 totalCands = __shfl(inclCands, 63, 64);
-    for (u32 idx = lane; idx < ((totalCands + 63) & ~63u); idx += 64)
+    for (u32 o = 1; o < W; o <<= 1) { const u32 v = __shfl_up(inclCands, o, W); if (lane >= o) inclCands += v; }
+    const u32 totalCands = __shfl(inclCands, W - 1, W);
+    for (u32 idx = lane; idx < ((totalCands + W - 1) & ~(W - 1)); idx += W)
     {
         u32 j = 0;                                             // the problem of candidate idx: the number of problems that end at or before it
-        for (u32 q = 0; q < nJobs; ++q) j += (__shfl(inclCands, q, 64) <= idx) ? 1u : 0u;
+        for (u32 q = 0; q < nJobs; ++q) j += (__shfl(inclCands, q, W) <= idx) ? 1u : 0u;
         const u32 jj = j < nJobs ? j : 0;
-        const u32 tj = __shfl(take, jj, 64), cb = __shfl(candBase, jj, 64), bj = __shfl(base, jj, 64), endJ = __shfl(inclCands, jj, 64), nc = __shfl(nCands, jj, 64);
+        const u32 tj = __shfl(take, jj, W), cb = __shfl(candBase, jj, W), bj = __shfl(base, jj, W), endJ = __shfl(inclCands, jj, W), nc = __shfl(nCands, jj, W);
         if (idx >= totalCands || !tj) continue;
         const u32 c = idx - (endJ - nc);
         const Cand &cand = in.shadowCands[cb + c];
@@ -62,13 +68,13 @@ __device__ inline u32 clusterSumsWave(const DevParams &P, const ClusterFragments
     }
     for (u32 j = 0; j < nJobs; ++j)
     {
-        const u32 tj = __shfl(take, j, 64);
-        const u32 ng = __shfl(nGapped, j, 64);
-        if (!tj || !__shfl(rescued, j, 64) || !ng) continue;
-        const u32 bj = __shfl(base, j, 64);
+        const u32 tj = __shfl(take, j, W);
+        const u32 ng = __shfl(nGapped, j, W);
+        if (!tj || !__shfl(rescued, j, W) || !ng) continue;
+        const u32 bj = __shfl(base, j, W);
         groupSync(g);                                         // the accepted retries replace what the loop above wrote
-        const u32 gbase = __shfl(gappedBase, j, 64);
-        for (u32 kk = lane; kk < ng; kk += 64)
+        const u32 gbase = __shfl(gappedBase, j, W);
+        for (u32 kk = lane; kk < ng; kk += W)
         {
             // GappedJob::pad was written a moment ago by the problem's lane: the rule is evaluated again rather than read through memory
             const u32 slot = in.gappedJobs[gbase + kk].tag;
@@ -92,8 +98,8 @@ __device__ inline u32 clusterSumsWave(const DevParams &P, const ClusterFragments
     const u32 myJob = lane < total ? tab.job[lane] : 0;
     if (nSeeded[0] && nSeeded[1])
     {   // sumUniquePairProbabilities: every orphan with every shadow it rescued, read 1's alignment first
-        const u64 oPos = __shfl(orphan.pos, myJob, 64); const double oLp = __shfl(orphan.logProbability, myJob, 64);
-        const u32 oObs = __shfl(u32(orphan.observedLength), myJob, 64), oSide = __shfl(side, myJob, 64);
+        const u64 oPos = __shfl(orphan.pos, myJob, W); const double oLp = __shfl(orphan.logProbability, myJob, W);
+        const u32 oObs = __shfl(u32(orphan.observedLength), myJob, W), oSide = __shfl(side, myJob, W);
         if (lane < total)
         {
             const u64 sPos = tab.pos[lane]; const double sLp = tab.lp[lane]; const u32 sObs = tab.obs[lane];
@@ -106,8 +112,8 @@ __device__ inline u32 clusterSumsWave(const DevParams &P, const ClusterFragments
     }
     else
     {   // TemplateBuilder::rescueShadow's running sum in list order: the best shadow of a successful rescue has changed places with the first
-        const double oLp = __shfl(orphanLp, myJob, 64);
-        const u32 jBase = __shfl(base, myJob, 64), jBest = __shfl(best, myJob, 64);
+        const double oLp = __shfl(orphanLp, myJob, W);
+        const u32 jBase = __shfl(base, myJob, W), jBest = __shfl(best, myJob, W);
         if (lane < total)
         {
             const u32 r = lane - jBase;
@@ -122,36 +128,59 @@ __device__ inline u32 clusterSumsWave(const DevParams &P, const ClusterFragments
     return SUMS_DONE;
 }
 
-__global__ __launch_bounds__(256) void k_cluster_sums(DevParams P, const ClusterFragments *frags, u32 nChunk, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters)
+// lists of up to 16 entries (most clusters): a quarter of a wavefront per cluster.  What does not fit goes to k_cluster_sums.
+__global__ __launch_bounds__(256) void k_cluster_sums16(DevParams P, const ClusterFragments *frags, u32 nChunk, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters)
 {
-    __shared__ __align__(16) u8 keyBytes[4][SUMS_WAVE_CAP * 42];
-    __shared__ u64 tabPos[4][SUMS_WAVE_CAP]; __shared__ double tabLp[4][SUMS_WAVE_CAP]; __shared__ u32 tabObs[4][SUMS_WAVE_CAP]; __shared__ u8 tabJob[4][SUMS_WAVE_CAP];
-    static_assert(SUMS_WAVE_CAP * 42 % 16 == 0, "key arrays stay aligned");
-    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const u32 t = blockIdx.x * 4 + wave;
+    __shared__ __align__(16) u8 keyBytes[16][SUMS_QUARTER_CAP * 42 + 16];
+    __shared__ u64 tabPos[16][SUMS_QUARTER_CAP]; __shared__ double tabLp[16][SUMS_QUARTER_CAP]; __shared__ u32 tabObs[16][SUMS_QUARTER_CAP]; __shared__ u8 tabJob[16][SUMS_QUARTER_CAP];
+    const u32 group = threadIdx.x >> 4, lane = threadIdx.x & 15;
+    const u32 t = blockIdx.x * 16 + group;
     Counters local; memset(&local, 0, sizeof(local));
     if (t < nChunk)
     {
         if (0xffffffffu == rb.jobBase[t]) { if (0 == lane) { markResidual(sb, t); ++local.residualCapacity; } }
         else if (rb.jobCount[t])
         {
-            SumKeys keys; sumKeysBind(keys, keyBytes[wave], SUMS_WAVE_CAP);
-            SumGroup g; g.lanes = 64; g.lane = lane; g.block = false; g.radix = SumRadix{nullptr, nullptr, nullptr, nullptr, nullptr, 0}; g.radixMin = 0; g.sumTile = nullptr; g.sumTileCap = 0;
+            SumKeys keys; sumKeysBind(keys, keyBytes[group], SUMS_QUARTER_CAP);
+            SumGroup g; g.lanes = 16; g.lane = lane; g.block = false; g.radix = SumRadix{nullptr, nullptr, nullptr, nullptr, nullptr, 0}; g.radixMin = 0; g.sumTile = nullptr; g.sumTileCap = 0;
             ClusterSums out;
-            ShadowTable tab; tab.pos = tabPos[wave]; tab.lp = tabLp[wave]; tab.obs = tabObs[wave]; tab.job = tabJob[wave];
-#if defined(ISAAC_SUMS_GENERIC_WAVE)      // A/B aid: the general form of sums.h on the wavefront
-            (void)tab;
-            const u32 status = clusterSums(P, frags[t], sumInputs(rb, t, gb), keys, g, nullptr, true, out, local);
-#else
-            const u32 status = clusterSumsWave(P, frags[t], sumInputs(rb, t, gb), keys, tab, g, out, local);
-#endif
+            ShadowTable tab; tab.pos = tabPos[group]; tab.lp = tabLp[group]; tab.obs = tabObs[group]; tab.job = tabJob[group];
+            const u32 status = clusterSumsWave<16>(P, frags[t], sumInputs(rb, t, gb), keys, tab, g, out, local);
             if (0 == lane)
             {
                 if (SUMS_DONE == status) sb.sums[t] = out;
-                else if (SUMS_TOO_LARGE == status) sb.largeList[atomicAdd(sb.largeCount, 1u)] = t;
+                else if (SUMS_TOO_LARGE == status) sb.mediumList[atomicAdd(sb.mediumCount, 1u)] = t;
                 else { markResidual(sb, t); if (SUMS_NEAR_TIE == status) ++local.residualNearTie; else ++local.residualCapacity; }
             }
         }
+    }
+    flushCounters(local, counters);
+}
+
+// lists of up to 64 entries: a wavefront per cluster of the list k_cluster_sums16 left
+__global__ __launch_bounds__(256) void k_cluster_sums(DevParams P, const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters)
+{
+    __shared__ __align__(16) u8 keyBytes[4][SUMS_WAVE_CAP * 42];
+    __shared__ u64 tabPos[4][SUMS_WAVE_CAP]; __shared__ double tabLp[4][SUMS_WAVE_CAP]; __shared__ u32 tabObs[4][SUMS_WAVE_CAP]; __shared__ u8 tabJob[4][SUMS_WAVE_CAP];
+    static_assert(SUMS_WAVE_CAP * 42 % 16 == 0, "key arrays stay aligned");
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    Counters local; memset(&local, 0, sizeof(local));
+    const u32 n = *sb.mediumCount;
+    for (u32 i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4)
+    {
+        const u32 t = sb.mediumList[i];
+        SumKeys keys; sumKeysBind(keys, keyBytes[wave], SUMS_WAVE_CAP);
+        SumGroup g; g.lanes = 64; g.lane = lane; g.block = false; g.radix = SumRadix{nullptr, nullptr, nullptr, nullptr, nullptr, 0}; g.radixMin = 0; g.sumTile = nullptr; g.sumTileCap = 0;
+        ClusterSums out;
+        ShadowTable tab; tab.pos = tabPos[wave]; tab.lp = tabLp[wave]; tab.obs = tabObs[wave]; tab.job = tabJob[wave];
+        const u32 status = clusterSumsWave<64>(P, frags[t], sumInputs(rb, t, gb), keys, tab, g, out, local);
+        if (0 == lane)
+        {
+            if (SUMS_DONE == status) sb.sums[t] = out;
+            else if (SUMS_TOO_LARGE == status) sb.largeList[atomicAdd(sb.largeCount, 1u)] = t;
+            else { markResidual(sb, t); if (SUMS_NEAR_TIE == status) ++local.residualNearTie; else ++local.residualCapacity; }
+        }
+        groupSync(g);
     }
     flushCounters(local, counters);
 }

@@ -47,7 +47,12 @@ ISAAC_HD void groupSync(const SumGroup &g)
 ISAAC_HD bool groupAny(const SumGroup &g, bool v, u32 *scratch)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (!g.block) return __ballot(v) != 0;
+    if (!g.block)
+    {
+        if (g.lanes >= 64) return __ballot(v) != 0;
+        const u32 groupBase = (threadIdx.x & 63u) & ~(g.lanes - 1);            // a part of a wavefront: its lanes' votes only
+        return 0 != ((__ballot(v) >> groupBase) & ((1ull << g.lanes) - 1));
+    }
     if (0 == g.lane) *scratch = 0;
     __syncthreads();
     if (v) *scratch = 1;
