@@ -174,6 +174,9 @@ def main():
         return (torch.empty((n_rec, abi.FRAGMENT_DTYPE.itemsize), dtype=torch.uint8, device=dev), torch.empty(n_rec * abi.MAX_CIGAR_OPS, dtype=torch.int32, device=dev),
                 torch.empty(n_rec * 4, dtype=torch.int32, device=dev))
     out = [buffers(batches[args.warmup + s].shape[0]) for s in range(args.steps)]     # records, 40-word CIGAR slots, packed CIGARs of every step
+    # ... and the match lists of every step (the hand-over between the two phases): nothing is allocated inside the timed steps
+    match_bufs = [(torch.empty((al.match_capacity(batches[args.warmup + s].shape[0]), 2), dtype=torch.int64, device=dev),
+                   torch.empty(batches[args.warmup + s].shape[0] + 1, dtype=torch.int64, device=dev)) for s in range(args.steps)]
     tile_of = lambda s: 1 + rank * args.steps + s          # every (rank, step) batch is a tile of its own, as FASTQ tiles are (SeedId.hh: 12 bits)
 
     def reduce_hits(h):
@@ -199,6 +202,12 @@ def main():
         warm.add(torch.zeros((64, abi.FRAGMENT_DTYPE.itemsize), dtype=torch.uint8, device=dev), torch.zeros(256, dtype=torch.int32, device=dev))
         warm.finish()
         del warm
+        if rank == 0:
+            # rank 0 receives world x (records + packed CIGARs) per step: the blocks are taken from the driver once, here, and handed back to
+            # torch's caching allocator, so that the timed steps find them there (a fresh hipMalloc of 100s of MB costs milliseconds)
+            pool = [torch.empty_like(out[s][0]) for s in range(args.steps) for _ in range(world)]
+            pool += [torch.empty(out[s][2].shape[0] // 2, dtype=torch.int32, device=dev) for s in range(args.steps) for _ in range(world)]
+            del pool
     al.synchronize()
     al.reset_timers()
 
@@ -210,7 +219,7 @@ def main():
     found = []
     all_hits = np.zeros(al.n_contigs, np.uint8)
     for s in range(args.steps):                       # phase 1: FindMatchesTransition
-        m, o, hits = al.find_matches(batches[args.warmup + s], tile=tile_of(s))
+        m, o, hits = al.find_matches(batches[args.warmup + s], tile=tile_of(s), out=match_bufs[s])
         found.append((m, o))
         all_hits |= hits
     al.set_loaded_contigs(reduce_hits(all_hits))      # MatchSelector loads only contigs that received matches
@@ -281,7 +290,7 @@ def main():
         for s in range(args.steps):
             d, ev = dev_in[s]
             torch.cuda.current_stream(dev).wait_event(ev)
-            m, o, hits = al.find_matches(d, tile=tile_of(s))
+            m, o, hits = al.find_matches(d, tile=tile_of(s), out=match_bufs[s])
             found.append((m, o))
         for s in range(args.steps):
             m, o = found[s]

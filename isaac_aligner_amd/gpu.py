@@ -171,20 +171,31 @@ class Aligner:
         self._check(self.lib.isaac_gpu_set_loaded_contigs(self.h, _p(loaded), C.c_uint32(self.n_contigs)))
 
     # ---- find -----------------------------------------------------------------------------------------------------
-    def find_matches(self, bcl, tile=0, capacity=None):
-        """bcl: uint8 device tensor [n_clusters, cluster_length].  Returns (matches tensor [n,2] int64, offsets tensor, contig_has_matches)"""
+    def match_capacity(self, n_clusters):
+        """match records isaac_gpu_find_matches is given room for by default (it reports the number it needs when that is not enough)"""
+        per = 2 * self.params.n_seeds * max(1, self.params.repeat_threshold - 1)
+        return max(1, min(n_clusters * per, max(1024, n_clusters * 24)))
+
+    def find_matches(self, bcl, tile=0, capacity=None, out=None):
+        """bcl: uint8 device tensor [n_clusters, cluster_length].  Returns (matches tensor [n,2] int64, offsets tensor, contig_has_matches).
+        out: (matches [capacity, 2] int64, offsets [n_clusters + 1] int64) tensors to write into instead of fresh ones"""
         torch = self.torch
         n_clusters = bcl.shape[0]
         per = 2 * self.params.n_seeds * max(1, self.params.repeat_threshold - 1)
-        capacity = max(1, capacity or min(n_clusters * per, max(1024, n_clusters * 24)))
+        capacity = max(1, capacity or self.match_capacity(n_clusters))
         while True:
-            matches = torch.empty((capacity, 2), dtype=torch.int64, device=self.device)
-            offsets = torch.empty(n_clusters + 1, dtype=torch.int64, device=self.device)
+            if out is not None and out[0].shape[0] >= capacity and out[1].shape[0] >= n_clusters + 1:
+                matches, offsets = out[0], out[1][:n_clusters + 1]
+                capacity = matches.shape[0]
+            else:
+                matches = torch.empty((capacity, 2), dtype=torch.int64, device=self.device)
+                offsets = torch.empty(n_clusters + 1, dtype=torch.int64, device=self.device)
             hits = np.zeros(self.n_contigs, np.uint8)
             n = C.c_uint64()
             rc = self.lib.isaac_gpu_find_matches(self.h, _p(bcl), C.c_uint32(n_clusters), C.c_uint32(tile), _p(matches), C.c_uint64(capacity), _p(offsets), C.byref(n), _p(hits))
             if rc == 4 and capacity < n_clusters * per:   # ISAAC_GPU_ECAPACITY
                 capacity = min(n_clusters * per, max(n.value, capacity * 2))
+                out = None
                 continue
             self._check(rc)
             return matches[:n.value], offsets, hits
