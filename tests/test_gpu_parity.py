@@ -449,3 +449,38 @@ def test_residual_pass_on_most_clusters(torch):
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "residual_variant_check.py"), "60000"],
                        env=dict(os.environ, ISAAC_GPU_LIBRARY=lib), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_phix_sized_reference(torch, oracle):
+    """BASELINE configuration 0 (the reference's own plumbing case): one 5 386-base contig, 2x100 reads at a coverage of hundreds --
+    index, match sets, template length statistics and every record against the oracle; then the same tile as BAM records"""
+    from isaac_aligner_amd import gpu, synth
+    contigs = synth.make_genome(5386, seed=7, n_contigs=1, repeat_families=False)
+    host_contigs = [bytes(c.numpy()) for c in contigs]
+    n = 20000
+    bcl = synth.make_read_pairs(contigs, n, 100, seed=8, insert_mean=300.0, insert_sd=30.0, subst_rate=0.005)[0].numpy()
+    p = options.default_params(100, 100)
+    al = gpu.Aligner(p, 0, host_contigs)
+    al.build_index()
+    ref = oracle.reference(host_contigs)
+    oidx = ref.build_index()
+    gidx = al.get_index()
+    assert len(oidx) == len(gidx) and (oidx["kmer"] == gidx["kmer"]).all() and (oidx["position"] == gidx["position"]).all()
+    dev_bcl = torch.from_numpy(bcl).cuda()
+    m, o, hits = al.find_matches(dev_bcl, tile=1)
+    om, ohits = ref.find_matches(p, bcl, n, tile=1)
+    gm = m.cpu().numpy().view(np.uint64).reshape(-1, 2)
+    gm = np.rec.fromarrays([gm[:, 0], gm[:, 1]], dtype=oracle_lib.MATCH_DTYPE)
+    assert (sort_matches(om) == sort_matches(gm)).all() and (ohits == hits).all()
+    al.set_loaded_contigs(hits)
+    tls = al.determine_tls(dev_bcl, m, o, tile=1)
+    otls = ref.determine_tls(p, bcl, om, ohits, tile=1)
+    assert tls.astuple() == otls.astuple()
+    records, cigars = al.select(dev_bcl, m, o, tls, tile=1)
+    rec, cig = al.records_to_numpy(records, cigars)
+    orec, ocig, _ = ref.select(p, bcl, om, otls, ohits, tile=1, n_clusters_hint=n)
+    assert not compare_records(orec, ocig, rec, cig)
+    assert (rec["flags"] & 2 == 0).mean() > 0.95
+    got = al.bam_records([(dev_bcl, records, cigars, "PHIX:1:1:")])[0].cpu().numpy().tobytes()
+    want = oracle.bam_records([(bcl, orec, ocig, "PHIX:1:1:")], [100, 100], forced_dodgy_alignment_score=p.dodgy_alignment_score & 0xff)[0]
+    assert got == want
