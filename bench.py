@@ -330,7 +330,16 @@ def main():
                     "GB_per_s_written": round(stream_bytes.numel() / t_bam / 1e9, 2), "order_ms": round(al.kernel_time_ms("bam_order")[0], 3),
                     "encode_ms": round(al.kernel_time_ms("bam_encode")[0], 3), "unaligned_bin_offset": int(unaligned_at),
                     "note": "isaac_gpu_bam_records over the records of all %d steps (two radix passes + one encode launch); BGZF deflate stays on the host" % args.steps}
-        del bam_buf, stream_bytes
+        # the host side of the file writer: BGZF deflate (zlib level 1, as --bam-gzip-level defaults) of a bounded sample on all host threads
+        from isaac_aligner_amd import bam as bam_host
+        sample_bytes = min(int(stream_bytes.numel()), 512 << 20)
+        host_sample = stream_bytes[:sample_bytes].cpu().numpy()
+        tz = time.perf_counter()
+        z = bam_host.bgzf_compress(host_sample, level=1, n_threads=os.cpu_count() or 1)
+        t_z = time.perf_counter() - tz
+        bam_info.update({"bgzf_sample_bytes": sample_bytes, "bgzf_threads": os.cpu_count() or 1, "bgzf_GB_per_s": round(sample_bytes / t_z / 1e9, 2),
+                         "bgzf_ratio": round(len(z) / sample_bytes, 3)})
+        del bam_buf, stream_bytes, host_sample, z
 
     # ---- roofline of the dominant kernel: algorithmic bytes (stated per kernel in DESIGN.md) / event-timed duration
     c = counters
