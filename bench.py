@@ -330,6 +330,14 @@ def main():
                     "GB_per_s_written": round(stream_bytes.numel() / t_bam / 1e9, 2), "order_ms": round(al.kernel_time_ms("bam_order")[0], 3),
                     "encode_ms": round(al.kernel_time_ms("bam_encode")[0], 3), "unaligned_bin_offset": int(unaligned_at),
                     "note": "isaac_gpu_bam_records over the records of all %d steps (two radix passes + one encode launch); BGZF deflate stays on the host" % args.steps}
+        # --bam-gzip-level 0 entirely on the device: BGZF framing with stored blocks, CRC-32 per block computed by the GPU
+        framed = al.bgzf_store(stream_bytes, eof_block=True)
+        al.reset_timers()
+        framed = al.bgzf_store(stream_bytes, eof_block=True, out=framed)
+        torch.cuda.synchronize()
+        t_store = al.kernel_time_ms("bgzf_store")[0]
+        bam_info.update({"bgzf_store_ms": round(t_store, 3), "bgzf_store_GB_per_s": round(stream_bytes.numel() / max(1e-9, t_store) / 1e6, 1), "bgzf_store_bytes": int(framed.numel())})
+        del framed
         # the host side of the file writer: BGZF deflate (zlib level 1, as --bam-gzip-level defaults) of a bounded sample on all host threads
         from isaac_aligner_amd import bam as bam_host
         sample_bytes = min(int(stream_bytes.numel()), 512 << 20)

@@ -295,6 +295,14 @@ uint64_t isaac_gpu_bgzf_bound(uint64_t n_bytes);
 int isaac_gpu_bgzf_compress(const uint8_t *data_host, uint64_t n_bytes, int level, uint32_t n_threads, int eof_block,
                             uint8_t *out_host, uint64_t capacity, uint64_t *n_bytes_out);
 
+/* BGZF framing without compression on the device, for --bam-gzip-level 0: what bgzf::BgzfCompressor produces at gzip level 0
+ * (include/bgzf/BgzfCompressor.hh:36-176: blocks of at most 0xFFFF - 41 input bytes, each a gzip member with the BC extra field around
+ * one stored deflate block, CRC-32 and length behind it), byte for byte what isaac_gpu_bgzf_compress(level 0) writes.  data_dev: n_bytes
+ * of an uncompressed BAM stream in HBM (header or records); out_dev must hold isaac_gpu_bgzf_store_bound(n_bytes) bytes; eof_block != 0
+ * appends the 28-byte empty block.  The CRC-32 of every block is computed on the device. */
+uint64_t isaac_gpu_bgzf_store_bound(uint64_t n_bytes);
+int isaac_gpu_bgzf_store(isaac_gpu_ctx *ctx, const uint8_t *data_dev, uint64_t n_bytes, int eof_block, uint8_t *out_dev, uint64_t capacity, uint64_t *n_bytes_out);
+
 /* The leaf: alignment::BandedSmithWaterman::align (include/alignment/BandedSmithWaterman.hh:75-86) for a batch;
  * scores as the reference constructor takes them (GappedAligner.cpp:41-42: match, mismatch, -gapOpen, -gapExtend).
  * results[i].n_ops == 0xffffffff flags a CIGAR longer than ISAAC_GPU_MAX_CIGAR_OPS. */
@@ -333,7 +341,7 @@ int isaac_gpu_get_counters(isaac_gpu_ctx *ctx, isaac_counters *out);
  * stream it runs on; names: "find_matches", "compact_matches", "build_fragments", "align_candidates", "finish_candidates",
  * "indel_fragments", "gapped_fragments", "finish_fragments", "load_candidates", "plan_rescue", "rescue_windows", "rescue_align",
  * "rescue_gapped_plan", "gapped_rescue", "sums_wave", "sums_large", "sums_xl", "sums_huge", "select", "select_heavy", "select_residual" (the last two
- * only when a cluster needed the wave-per-cluster pass), "fastq_to_bcl", "bsw", "bam_order", "bam_encode" */
+ * only when a cluster needed the wave-per-cluster pass), "fastq_to_bcl", "bsw", "bam_order", "bam_encode", "bgzf_store" */
 int isaac_gpu_kernel_time_ms(isaac_gpu_ctx *ctx, const char *kernel, double *avg_ms, uint64_t *launches);
 int isaac_gpu_reset_timers(isaac_gpu_ctx *ctx);
 

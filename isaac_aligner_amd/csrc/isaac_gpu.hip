@@ -25,6 +25,7 @@
 #include "fastq_kernel.h"
 #include "index_kernels.h"
 #include "bam_kernels.h"
+#include "bgzf_kernels.h"
 
 #if defined(ISAAC_KERNEL_STAMPS)
 __device__ unsigned long long g_stamps[64];
@@ -71,6 +72,7 @@ struct isaac_gpu_ctx
     DevBuf<GappedJob> gappedJobs, rescueGappedJobs; DevBuf<GappedResult> gappedResults, rescueGappedResults; DevBuf<u32> gappedBase, gappedCounters;
     DevBuf<u8> heavyArena; DevBuf<u32> overflowList; DevBuf<u32> overflowCount; DevBuf<ClusterSums> clusterSums; DevBuf<u32> mediumList, largeList, xlList, hugeList, longJobs; DevBuf<u8> hugeKeys;
     DevBuf<TlsSample> tlsSamples; DevBuf<u32> cigarLengths, cigarOffsets;
+    DevBuf<CrcConstants> crcConstants; bool crcReady = false;    // isaac_gpu_bgzf_store
     // isaac_gpu_bam_records scratch
     DevBuf<BamTile> bamTiles; DevBuf<u64> bamKeyHi, bamKeyLo, bamKeyAlt, bamOffsets, bamBytes64, bamBounds; DevBuf<u32> bamIndex, bamIndexAlt, bamBytes;
     DevBuf<RescueJob> jobs; DevBuf<u32> rescueCounters, bitmaps, candJob, shadowCigars, jobBase, jobCount; DevBuf<i32> candPositions; DevBuf<Cand> shadowCands; DevBuf<u32> candRank;
@@ -1316,6 +1318,44 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
     if (nRecordsOut) *nRecordsOut = bounds[1];
     if (unalignedOffsetOut) *unalignedOffsetOut = unalignedOffset;
     if (total > capacity) return fail(ISAAC_GPU_ECAPACITY, "bam_dev is too small");
+    return 0;
+    ISAAC_CATCH
+}
+
+// BGZF without compression on the device (bgzf_kernels.h)
+uint64_t isaac_gpu_bgzf_store_bound(uint64_t nBytes) { return ((nBytes + BGZF_BLOCK_INPUT - 1) / BGZF_BLOCK_INPUT) * u64(BGZF_BLOCK_INPUT + BGZF_STORED_OVERHEAD) + 28; }
+int isaac_gpu_bgzf_store(isaac_gpu_ctx *c, const uint8_t *data, uint64_t nBytes, int eofBlock, uint8_t *out, uint64_t capacity, uint64_t *nBytesOut)
+{
+    ISAAC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    if (nBytesOut) *nBytesOut = 0;
+    if (nBytes && (!data || !out)) return fail(ISAAC_GPU_EINVAL, "data_dev and out_dev are required");
+    const u64 nBlocks = (nBytes + BGZF_BLOCK_INPUT - 1) / BGZF_BLOCK_INPUT;
+    const u64 total = nBytes + nBlocks * BGZF_STORED_OVERHEAD + (eofBlock ? 28 : 0);
+    if (nBytesOut) *nBytesOut = total;
+    if (total > capacity) return fail(ISAAC_GPU_ECAPACITY, "out_dev is too small (isaac_gpu_bgzf_store_bound)");
+    if (nBlocks >= (u64(1) << 31)) return fail(ISAAC_GPU_EINVAL, "at most 2^31 - 1 blocks per call");
+    resolvePending(c);
+    hipStream_t st = c->stream;
+    if (!c->crcReady)
+    {
+        CrcConstants h; makeCrcConstants(h);
+        c->crcConstants.reserve(1);
+        HIP_CHECK(hipMemcpy(c->crcConstants.p, &h, sizeof(h), hipMemcpyHostToDevice));
+        c->crcReady = true;
+    }
+    if (nBlocks)
+    {
+        ScopedTimer t(c, "bgzf_store");
+        k_bgzf_store<<<u32(nBlocks), 256, 0, st>>>(data, nBytes, c->crcConstants.p, out);
+        HIP_CHECK(hipGetLastError());
+    }
+    if (eofBlock)
+    {
+        static const unsigned char eof[28] = { 0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+        HIP_CHECK(hipMemcpyAsync(out + total - 28, eof, 28, hipMemcpyHostToDevice, st));
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
     return 0;
     ISAAC_CATCH
 }

@@ -40,7 +40,7 @@ EXPORTS = ["isaac_gpu_last_error", "isaac_gpu_create", "isaac_gpu_destroy", "isa
            "isaac_gpu_save_sorted_reference",
            "isaac_gpu_find_matches", "isaac_gpu_set_loaded_contigs", "isaac_gpu_build_fragments", "isaac_gpu_determine_tls", "isaac_gpu_select", "isaac_gpu_select_candidates",
            "isaac_gpu_bsw_batch", "isaac_gpu_compact_cigars",
-           "isaac_gpu_bam_records", "isaac_gpu_bam_last_error", "isaac_gpu_bam_header", "isaac_gpu_bgzf_bound", "isaac_gpu_bgzf_compress",
+           "isaac_gpu_bam_records", "isaac_gpu_bam_last_error", "isaac_gpu_bam_header", "isaac_gpu_bgzf_bound", "isaac_gpu_bgzf_compress", "isaac_gpu_bgzf_store_bound", "isaac_gpu_bgzf_store",
            "isaac_gpu_fastq_to_bcl", "isaac_gpu_fastq_tile_clusters_max", "isaac_gpu_fastq_tiles", "isaac_gpu_get_counters", "isaac_gpu_kernel_time_ms", "isaac_gpu_reset_timers"]
 
 
@@ -323,6 +323,16 @@ class Aligner:
             rc = call(out)
         self._check(rc)
         return out[:nb.value], nr.value, un.value
+
+    def bgzf_store(self, data, eof_block=False, out=None):
+        """BGZF framing without compression (--bam-gzip-level 0) of a uint8 device tensor, CRC-32 on the device; returns a uint8 device tensor"""
+        self.lib.isaac_gpu_bgzf_store_bound.restype = C.c_uint64
+        bound = self.lib.isaac_gpu_bgzf_store_bound(C.c_uint64(data.numel()))
+        if out is None:
+            out = self.torch.empty(bound, dtype=self.torch.uint8, device=self.device)
+        n = C.c_uint64()
+        self._check(self.lib.isaac_gpu_bgzf_store(self.h, _p(data), C.c_uint64(data.numel()), C.c_int(int(eof_block)), _p(out), C.c_uint64(out.numel()), C.byref(n)))
+        return out[:n.value]
 
     def records_to_numpy(self, records, cigars):
         if self.deferred_completion:

@@ -6,6 +6,7 @@
 #include "../../isaac_aligner_amd/csrc/cluster_ops.h"
 #include "../../isaac_aligner_amd/csrc/sums.h"
 #include "../../isaac_aligner_amd/csrc/bam_kernels.h"
+#include "../../isaac_aligner_amd/csrc/bgzf_kernels.h"
 #include "../../isaac_aligner_amd/csrc/host_util.h"
 #include <string>
 #include <vector>
@@ -374,6 +375,31 @@ int emu_bam_records(const isaac_bam_tile *tiles, u32 nTiles, u32 nReads, const u
     if (*unalignedOffset == ~u64(0)) *unalignedOffset = at;
     *nBytes = at;
     return at <= capacity ? 0 : 4;
+}
+
+// the CRC-32 arithmetic of k_bgzf_store (bgzf_kernels.h) in the kernel's own order: remainders of 260-byte pieces from a zero register, folded
+// pairwise, the initial register value carried over the whole length at the end
+uint32_t emu_crc32_folded(const u8 *data, u32 n)
+{
+    CrcConstants c; makeCrcConstants(c);
+    std::vector<u32> partial(256, 0), lengths(256, 0);
+    for (u32 t = 0; t < 256; ++t)
+    {
+        const u32 begin = t * 260, end = std::min(begin + 260, n);
+        u32 crc = 0;
+        u32 i = begin;
+        for (; i + 4 <= end; i += 4)
+        {
+            u32 w; std::memcpy(&w, data + i, 4); w ^= crc;
+            crc = c.table[3][w & 0xff] ^ c.table[2][(w >> 8) & 0xff] ^ c.table[1][(w >> 16) & 0xff] ^ c.table[0][w >> 24];
+        }
+        for (; i < end; ++i) crc = c.table[0][(crc ^ data[i]) & 0xff] ^ (crc >> 8);
+        partial[t] = crc; lengths[t] = begin < n ? end - begin : 0;
+    }
+    for (u32 step = 1; step < 256; step <<= 1)
+        for (u32 t = 0; t < 256; t += 2 * step)
+            if (lengths[t + step]) { partial[t] = crcMultiply(partial[t], crcShiftOperator(c.squares, lengths[t + step])) ^ partial[t + step]; lengths[t] += lengths[t + step]; }
+    return ~(crcMultiply(0xffffffffu, crcShiftOperator(c.squares, n)) ^ partial[0]);
 }
 
 uint32_t emu_sizeof(int what)

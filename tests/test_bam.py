@@ -171,6 +171,41 @@ def test_bgzf_blocks_round_trip(level, tmp_path):
     assert gzip.open(str(path)).read() == b"BAM\x01" + bytes(8) + data
 
 
+def test_folded_crc32_is_zlibs():
+    """the CRC-32 arithmetic of k_bgzf_store (pieces from a zero register, pairwise folds, the initial value carried at the end), on the CPU"""
+    import zlib
+    lib = hostemu_lib.load()
+    lib.emu_crc32_folded.restype = C.c_uint32
+    rng = np.random.default_rng(9)
+    for n in [0, 1, 2, 255, 256, 257, 511, 512, 513, 1000, 4096, 65493, 65494]:
+        data = rng.integers(0, 256, max(n, 1), dtype=np.uint8)[:n].copy()
+        got = lib.emu_crc32_folded(data.ctypes.data_as(C.c_void_p) if n else None, C.c_uint32(n))
+        assert got == (zlib.crc32(data.tobytes()) & 0xffffffff), n
+
+
+@pytest.mark.gpu
+def test_gpu_bgzf_store_is_level_0():
+    """isaac_gpu_bgzf_store: byte for byte what the host framing writes at gzip level 0, and a series of gzip members that inflate to the input"""
+    import torch
+    from isaac_aligner_amd import gpu
+    a = gpu.Aligner(options.default_params(100, 100), 0)
+    rng = np.random.default_rng(10)
+    for n in [0, 1, 1000, 65494, 65495, 3 * 65494, 1_000_003]:
+        data = rng.integers(0, 256, max(n, 1), dtype=np.uint8)[:n].copy()
+        dev = torch.from_numpy(data).cuda() if n else torch.empty(0, dtype=torch.uint8, device="cuda")
+        for eof in (False, True):
+            got = a.bgzf_store(dev, eof_block=eof).cpu().numpy().tobytes()
+            want = bam.bgzf_compress(data.tobytes(), level=0, n_threads=4, eof_block=eof)
+            assert got == want, (n, eof)
+            if n or eof:
+                assert gzip.decompress(got) == data.tobytes()
+    # input on an odd address, on an address that is 2 mod 4
+    data = rng.integers(0, 256, 200_003, dtype=np.uint8)
+    dev = torch.from_numpy(data).cuda()
+    for skip in (1, 2, 3):
+        assert a.bgzf_store(dev[skip:], eof_block=True).cpu().numpy().tobytes() == bam.bgzf_compress(data[skip:].tobytes(), level=0, eof_block=True)
+
+
 @pytest.mark.gpu
 def test_gpu_bam_records_match_the_oracle():
     """isaac_gpu_bam_records on the records the GPU path itself produced == oracle/bam.cpp on the same records, byte for byte;
