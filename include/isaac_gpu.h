@@ -129,8 +129,8 @@ int isaac_gpu_upload(isaac_gpu_ctx *ctx, void *dev, const void *host, uint64_t b
 int isaac_gpu_download(isaac_gpu_ctx *ctx, void *host, const void *dev, uint64_t bytes);
 int isaac_gpu_synchronize(isaac_gpu_ctx *ctx);
 /* Deferred completion (off by default).  When on, isaac_gpu_select / isaac_gpu_select_candidates return while their last
- * wave-per-cluster pass (the clusters of repeat families) is still running on an internal stream, so that back-to-back calls
- * overlap.  The caller then owns the hazard: every buffer handed to such a call (bcl, matches, offsets, fragments, cigar) must
+ * kernels are still running on the context's stream (the call only enqueues; nothing inside it waits for the GPU), so that the
+ * host can prepare and enqueue the next call meanwhile.  The caller then owns the hazard: every buffer handed to such a call (bcl, matches, offsets, fragments, cigar) must
  * stay allocated and unmodified, and its outputs unread, until isaac_gpu_synchronize() returns; calls in flight need distinct
  * output buffers.  Every other entry point of the context first waits for that pass.  Turning it off completes what is pending. */
 int isaac_gpu_set_deferred_completion(isaac_gpu_ctx *ctx, int enabled);

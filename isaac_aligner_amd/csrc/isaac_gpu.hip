@@ -1159,22 +1159,21 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
             k_cluster_sums_huge<<<SUMS_HUGE_BLOCKS, 1024, 0, st>>>(c->P, c->fragsCur, rb, gbRescue, sb, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }
-        HIP_CHECK(hipMemcpyAsync(c->hostCounts, c->heavyCount.p, 4, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipEventRecord(c->evSums, st));
         {
             ScopedTimer tm(c, "select");
             k_select<<<gridFor(n, 64), 64, 0, st>>>(c->templateConstants.p, R, lmq40, bcl, done, n, tile, c->fragsCur, rb, gbRescue.results, gbRescue.jobs, c->clusterSums.p,
                                                      reinterpret_cast<FragmentRecord *>(fragments), cigar, c->overflowList.p, c->overflowCount.p, c->heavyFlag.p, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }
-        HIP_CHECK(hipMemcpyAsync(c->hostCounts + 1, c->overflowCount.p, 4, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipEventRecord(c->evSelect, st));
-        c->pending.active = true; c->pending.bcl = bcl; c->pending.clusterBase = done; c->pending.tile = tile; c->pending.frags = c->fragsCur;
-        c->pending.records = reinterpret_cast<FragmentRecord *>(fragments); c->pending.cigars = cigar; c->pending.tls = t; c->pending.rog = rog;
-        // what the sums stage could not do (near ties, lists beyond the reference's own capacities, capacity misses of the flat pass):
-        // the wave-per-cluster pass, after k_select.  The host learns the count while k_select runs.
-        HIP_CHECK(hipEventSynchronize(c->evSums));
-        if (c->hostCounts[0]) launchHeavy(c, c->pending, c->heavyList.p, c->heavyCount.p, std::min<u32>(c->hostCounts[0], 1024u), "select_heavy", false);
+        // The wave-per-cluster pass, twice, behind k_select on the same stream: for what the sums stage could not do (near ties, lists beyond
+        // its capacities, capacity misses of the flat pass) and for the clusters whose placements overflowed k_select's private lists.  Both
+        // read their count on the device and are launched whatever it is -- nearly always zero, a few microseconds -- so that the host never
+        // waits for the GPU inside a call: it used to read the two counts back and decide, which cost an idle gap per call.
+        isaac_gpu_ctx::Pending chunkDesc;
+        chunkDesc.bcl = bcl; chunkDesc.clusterBase = done; chunkDesc.tile = tile; chunkDesc.frags = c->fragsCur;
+        chunkDesc.records = reinterpret_cast<FragmentRecord *>(fragments); chunkDesc.cigars = cigar; chunkDesc.tls = t; chunkDesc.rog = rog;
+        launchHeavy(c, chunkDesc, c->heavyList.p, c->heavyCount.p, 1024u, "select_heavy", false);
+        launchHeavy(c, chunkDesc, c->overflowList.p, c->overflowCount.p, 1024u, "select_residual", true);
     }
     if (c->deferredCompletion) return 0;      // the caller enqueues its next call behind this one's k_select; isaac_gpu_synchronize completes the last one
     resolvePending(c);
