@@ -132,7 +132,7 @@ int isaac_gpu_synchronize(isaac_gpu_ctx *ctx);
  * kernels are still running on the context's stream (the call only enqueues; nothing inside it waits for the GPU), so that the
  * host can prepare and enqueue the next call meanwhile.  The caller then owns the hazard: every buffer handed to such a call (bcl, matches, offsets, fragments, cigar) must
  * stay allocated and unmodified, and its outputs unread, until isaac_gpu_synchronize() returns; calls in flight need distinct
- * output buffers.  Every other entry point of the context first waits for that pass.  Turning it off completes what is pending. */
+ * output buffers.  Every other entry point of the context is ordered behind those kernels on the same stream.  Turning it off completes what is in flight. */
 int isaac_gpu_set_deferred_completion(isaac_gpu_ctx *ctx, int enabled);
 
 /* Replaces reference::loadContigs (include/reference/ContigLoader.hh:84-140, lib/reference/ContigLoader.cpp:29-66):
