@@ -232,7 +232,11 @@ int isaac_gpu_determine_tls(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t
  * cigar_dev must hold n_clusters * n_reads * ISAAC_GPU_MAX_CIGAR_OPS words.
  * The call returns when the records are complete, unless isaac_gpu_set_deferred_completion(ctx, 1) was called: see there.
  * isaac_fragment::reserved: bit 2 = a fixed internal capacity was exceeded for this cluster (result not exact; counted in
- * isaac_counters::overflow_clusters), bit 1 = the reference would not have stored the template (only without --keep-unaligned). */
+ * isaac_counters::overflow_clusters), bit 1 = the reference would not have stored the template (only without --keep-unaligned),
+ * bit 3 = one of the cluster's alignment scores is unsigned(floor(-10 * log10(x))) (TemplateBuilder.cpp:273,437,604-608,912-920) with the
+ * argument of floor within 1e-11 of an integer: the device's log10 / exp agree with glibc's to the last ulp or so, which can move the
+ * floor only there.  A host that has to be certain re-derives exactly these clusters (counted in isaac_counters::mapq_near_integer;
+ * a handful per million pairs). */
 int isaac_gpu_select(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t n_clusters, uint32_t tile,
                      const isaac_match *matches_dev, const uint64_t *cluster_offsets_dev, const isaac_tls *tls,
                      isaac_fragment *fragments_dev, uint32_t *cigar_dev, uint64_t cigar_capacity);
@@ -251,9 +255,14 @@ int isaac_gpu_select_candidates(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint
 /* Packs the CIGARs of isaac_gpu_select's fixed 40-word slots back to back, in record order, and rewrites cigar_offset of every
  * record accordingly: the form in which io::FragmentHeader records are followed by their CIGAR in the reference's bin files
  * (include/io/Fragment.hh:73-100) and in which a tile's result crosses PCIe or xGMI (about 2 words per read instead of 40).
- * cigar_out_dev must not overlap cigar_in_dev; *n_words_out receives the packed length (also when it exceeds capacity). */
+ * cigar_out_dev must not overlap cigar_in_dev; *n_words_out receives the packed length (also when it exceeds capacity: the call then
+ * returns ISAAC_GPU_ECAPACITY and has changed nothing, the records still refer to their slots, so it can be repeated with a larger pool).
+ * isaac_gpu_compact_cigars_async is the same without the host wait: the packed length is written to the DEVICE word *n_words_out_dev
+ * behind the kernels on the context's stream, and a pool that is too small shows as *n_words_out_dev > capacity with nothing changed. */
 int isaac_gpu_compact_cigars(isaac_gpu_ctx *ctx, isaac_fragment *fragments_dev, uint64_t n_records, const uint32_t *cigar_in_dev,
                              uint32_t *cigar_out_dev, uint64_t capacity, uint64_t *n_words_out);
+int isaac_gpu_compact_cigars_async(isaac_gpu_ctx *ctx, isaac_fragment *fragments_dev, uint64_t n_records, const uint32_t *cigar_in_dev,
+                                   uint32_t *cigar_out_dev, uint64_t capacity, uint64_t *n_words_out_dev);
 
 /* The output side of the path for --realign-gaps no --mark-duplicates 0: the BAM alignment records build::Build writes
  * (lib/build/Build.cpp, lib/build/BinSorter.cpp) from what isaac_gpu_select produced, computed where the records already are.
@@ -282,15 +291,16 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *ctx, const isaac_bam_tile *tiles, uint3
 
 /* Host-only pieces of the BAM file (no context, no GPU).  Errors: isaac_gpu_bam_last_error().
  * isaac_gpu_bam_header: bam::serializeHeader (include/bam/Bam.hh:153-235): magic, the text (@HD VN:1.0 SO:coordinate, @PG ID:iSAAC
- * with CL / DS / VN, header_lines such as --bam-header-tag and the @RG lines verbatim, one @SQ SN LN per contig), the contig table.
+ * with CL / DS / VN, header_lines such as --bam-header-tag and the @RG lines verbatim, one @SQ SN LN [AS] [UR] [M5] per contig -- the three
+ * optional tags from isaac_reference_contig::bam_sq_as / bam_sq_ur / bam_m5, arrays or entries may be NULL or empty --), the contig table.
  * isaac_gpu_bgzf_compress: the BGZF framing of bgzf::BgzfCompressor (include/bgzf/BgzfCompressor.hh:36-176): blocks of at most
  * 0xFFFF - 41 input bytes, each a gzip member with the BC extra field, deflated with zlib at `level` (--bam-gzip-level) on
  * n_threads threads; eof_block != 0 appends the 28-byte empty block of bam::serializeBgzfFooter (lib/bam/Bam.cpp:38-45).
  * out_host must hold isaac_gpu_bgzf_bound(n_bytes) bytes. */
 const char *isaac_gpu_bam_last_error(void);
 int isaac_gpu_bam_header(const char *command_line, const char *description, const char *version, const char *const *header_lines, uint32_t n_header_lines,
-                         const char *const *contig_names, const uint32_t *contig_lengths, uint32_t n_contigs,
-                         uint8_t *out_host, uint64_t capacity, uint64_t *n_bytes_out);
+                         const char *const *contig_names, const uint32_t *contig_lengths, const char *const *contig_as, const char *const *contig_ur,
+                         const char *const *contig_m5, uint32_t n_contigs, uint8_t *out_host, uint64_t capacity, uint64_t *n_bytes_out);
 uint64_t isaac_gpu_bgzf_bound(uint64_t n_bytes);
 int isaac_gpu_bgzf_compress(const uint8_t *data_host, uint64_t n_bytes, int level, uint32_t n_threads, int eof_block,
                             uint8_t *out_host, uint64_t capacity, uint64_t *n_bytes_out);
@@ -341,7 +351,8 @@ int isaac_gpu_get_counters(isaac_gpu_ctx *ctx, isaac_counters *out);
  * stream it runs on; names: "find_matches", "compact_matches", "build_fragments", "align_candidates", "finish_candidates",
  * "indel_fragments", "gapped_fragments", "finish_fragments", "load_candidates", "plan_rescue", "rescue_windows", "rescue_align",
  * "rescue_gapped_plan", "gapped_rescue", "sums_wave", "sums_large", "sums_xl", "sums_huge", "select", "select_heavy", "select_residual" (the last two
- * only when a cluster needed the wave-per-cluster pass), "fastq_to_bcl", "bsw", "bam_order", "bam_encode", "bgzf_store" */
+ * are launched for every chunk and read their cluster count on the device: a few microseconds when it is zero), "fastq_to_bcl", "bsw",
+ * "bam_order", "bam_encode", "bgzf_store" */
 int isaac_gpu_kernel_time_ms(isaac_gpu_ctx *ctx, const char *kernel, double *avg_ms, uint64_t *launches);
 int isaac_gpu_reset_timers(isaac_gpu_ctx *ctx);
 

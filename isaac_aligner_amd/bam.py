@@ -33,17 +33,27 @@ def _check(lib, rc):
         raise BamError("%d: %s" % (rc, lib.isaac_gpu_bam_last_error().decode()))
 
 
+def _sq_tags(contigs):
+    """the optional (AS, UR, M5) of every contig as three char* arrays; contigs: (name, length[, as, ur, m5])"""
+    arrays = []
+    for k in (2, 3, 4):
+        arrays.append((C.c_char_p * max(1, len(contigs)))(*[(c[k].encode() if len(c) > k and c[k] else None) for c in contigs]))
+    return arrays
+
+
 def header(command_line, version, contigs, description="", header_lines=()):
-    """bam::serializeHeader; contigs: [(name, length)] in reference order; header_lines: --bam-header-tag lines and @RG lines"""
+    """bam::serializeHeader; contigs: [(name, length[, AS, UR, M5])] in reference order; header_lines: --bam-header-tag lines and @RG lines"""
     lib = _lib()
+    sq_as, sq_ur, sq_m5 = _sq_tags(contigs)
+    contigs = [(c[0], c[1]) for c in contigs]
     lines = (C.c_char_p * max(1, len(header_lines)))(*[l.encode() for l in header_lines])
     names = (C.c_char_p * max(1, len(contigs)))(*[n.encode() for n, _ in contigs])
     lengths = (C.c_uint32 * max(1, len(contigs)))(*[l for _, l in contigs])
     n = C.c_uint64()
-    capacity = 4096 + len(command_line) + len(description) + sum(len(l) + 1 for l in header_lines) + sum(2 * len(nm) + 64 for nm, _ in contigs)
+    capacity = 4096 + len(command_line) + len(description) + sum(len(l) + 1 for l in header_lines) + sum(2 * len(nm) + 64 + 1400 for nm, _ in contigs)
     out = np.empty(capacity, np.uint8)
     _check(lib, lib.isaac_gpu_bam_header(command_line.encode(), description.encode(), version.encode(), lines, C.c_uint32(len(header_lines)), names, lengths,
-                                         C.c_uint32(len(contigs)), out.ctypes.data_as(C.c_void_p), C.c_uint64(capacity), C.byref(n)))
+                                         sq_as, sq_ur, sq_m5, C.c_uint32(len(contigs)), out.ctypes.data_as(C.c_void_p), C.c_uint64(capacity), C.byref(n)))
     return out[:n.value].tobytes()
 
 

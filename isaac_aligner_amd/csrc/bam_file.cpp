@@ -54,7 +54,8 @@ extern "C" {
 const char *isaac_gpu_bam_last_error(void) { return g_bamError.c_str(); }
 
 int isaac_gpu_bam_header(const char *commandLine, const char *description, const char *version, const char *const *headerLines, uint32_t nHeaderLines,
-                         const char *const *contigNames, const uint32_t *contigLengths, uint32_t nContigs, uint8_t *out, uint64_t capacity, uint64_t *nBytesOut)
+                         const char *const *contigNames, const uint32_t *contigLengths, const char *const *contigAs, const char *const *contigUr, const char *const *contigM5,
+                         uint32_t nContigs, uint8_t *out, uint64_t capacity, uint64_t *nBytesOut)
 {
     if (nBytesOut) *nBytesOut = 0;
     if ((nContigs && (!contigNames || !contigLengths)) || (nHeaderLines && !headerLines)) return bamFail(ISAAC_GPU_EINVAL, "contig names, lengths and header lines are required");
@@ -63,7 +64,14 @@ int isaac_gpu_bam_header(const char *commandLine, const char *description, const
     if (description && *description) { text += "DS:"; text += description; text += "\t"; }
     text += "VN:"; text += version ? version : ""; text += "\n";
     for (uint32_t i = 0; i < nHeaderLines; ++i) { text += headerLines[i]; text += "\n"; }
-    for (uint32_t i = 0; i < nContigs; ++i) { text += "@SQ\tSN:"; text += contigNames[i]; text += "\tLN:"; text += std::to_string(contigLengths[i]); text += "\n"; }
+    for (uint32_t i = 0; i < nContigs; ++i)
+    {   // Bam.hh:196-213: AS, UR and M5 follow when the sorted-reference metadata carries them, in this order
+        text += "@SQ\tSN:"; text += contigNames[i]; text += "\tLN:"; text += std::to_string(contigLengths[i]);
+        if (contigAs && contigAs[i] && *contigAs[i]) { text += "\tAS:"; text += contigAs[i]; }
+        if (contigUr && contigUr[i] && *contigUr[i]) { text += "\tUR:"; text += contigUr[i]; }
+        if (contigM5 && contigM5[i] && *contigM5[i]) { text += "\tM5:"; text += contigM5[i]; }
+        text += "\n";
+    }
     std::string bin("BAM\1", 4);
     putLe32(bin, uint32_t(text.size())); bin += text; putLe32(bin, nContigs);
     for (uint32_t i = 0; i < nContigs; ++i)

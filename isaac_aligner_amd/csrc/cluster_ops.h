@@ -10,7 +10,9 @@ static const u32 OUT_CIGAR_CAP = 40;   // ISAAC_GPU_MAX_CIGAR_OPS words per read
 // isaac_fragment::reserved
 enum { RECORD_TEMPLATE_OVERFLOW = 1,   // a template-stage work list overflowed: redo the cluster with heavyCaps()
        RECORD_NOT_STORED = 2,          // the reference would not have stored this template (only without --keep-unaligned)
-       RECORD_FRAGMENT_OVERFLOW = 4 }; // a fragment-stage capacity was exceeded: the cluster's result is not exact
+       RECORD_FRAGMENT_OVERFLOW = 4,   // a fragment-stage capacity was exceeded: the cluster's result is not exact
+       RECORD_MAPQ_NEAR_INTEGER = 8 }; // a MAPQ of this cluster is floor(v) with v within 1e-11 of an integer (mapqFloor): a host that must be sure
+                                       // the device's log10/exp rounded like glibc's re-derives exactly these clusters
 
 // FragmentBuilder::build for cluster `cluster` of the tile; its matches are matches[offsets[cluster] .. offsets[cluster + 1])
 ISAAC_HD void clusterBuildFragments(const DevParams &P, const DevReference &R, const u8 *bcl, u32 cluster, const Match *matches, const u64 *offsets,
@@ -94,7 +96,7 @@ ISAAC_HD void templateCtxInit(TemplateCtx &x, const DevParams &P, const DevRefer
     x.rescueMode = RESCUE_SERIAL; x.jobNext = 0; x.jobCount = 0; x.jobs = 0; x.planWrite = false; x.serialFallbackAllowed = true;
     x.candPositions = 0; x.shadowCands = 0; x.shadowCigars = 0; x.gappedResults = 0; x.gappedJobs = 0; x.candRank = 0; x.sums = 0;
     x.bestRescued = work.shadowList; x.bestRescuedPool = work.shadowCigar;
-    x.lanes = 1; x.lane = 0; x.fastSort = false; x.ldsSort = 0; x.ldsSortCap = 0;
+    x.lanes = 1; x.lane = 0; x.fastSort = false; x.ldsSort = 0; x.ldsSortCap = 0; x.mapqNearInteger = 0;
     for (u32 i = 0; i < 8; ++i) x.prof[i] = 0;
     const u8 *clusterBcl = bcl + u64(cluster) * P.clusterLength;
     for (u32 r = 0; r < 2; ++r)
@@ -185,6 +187,7 @@ ISAAC_HD void clusterSelect(const DevParams &P, const DevReference &R, const Dev
         if (work.overflow) r.reserved |= RECORD_TEMPLATE_OVERFLOW;
         if (frags.flags & CLUSTER_OVERFLOW) r.reserved |= RECORD_FRAGMENT_OVERFLOW;
         if (!store) r.reserved |= RECORD_NOT_STORED;
+        if (x.mapqNearInteger) r.reserved |= RECORD_MAPQ_NEAR_INTEGER;
     }
     STAMP(32);
 }

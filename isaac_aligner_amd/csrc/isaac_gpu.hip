@@ -8,7 +8,7 @@
 //                    cluster) -> k_gapped_jobs + k_gapped_rescan (banded Smith-Waterman, 16 lanes per problem; bsw_kernel.h) ->
 //                    k_finish_fragments (accept rule, final consolidation)
 //   template stage   k_plan_rescue -> k_rescue_windows -> k_rescue_align -> k_rescue_gapped_plan -> k_gapped_jobs ->
-//                    k_predict_heavy -> k_select (thread per cluster) || k_select_heavy (wave per cluster, own stream); template.h
+//                    k_cluster_sums* -> k_select (thread per cluster) -> k_select_heavy (wave per cluster, twice, counts read on the device); template.h
 //   leaves / formats k_bsw_batch, k_tls_samples, k_load_candidates / k_write_candidates, k_fq_* (fastq_kernel.h)
 //   index builder    k-mer enumeration + hipCUB radix sort + run analysis (+ 70-permutation neighbour annotation), k_prefix_table
 #include <hip/hip_runtime.h>
@@ -67,11 +67,11 @@ struct isaac_gpu_ctx
     DevBuf<u8> fqIsStart; DevBuf<u64> fqLineStart, fqLineEnd; DevBuf<int> fqSelected; DevBuf<u32> fqLineMap, fqMapBefore, fqIsHeader, fqRecordIndex, fqFirstBad; DevBuf<FqRecord> fqRecords;
     DevBuf<double> logTables;
     // work
-    DevBuf<Match> staging; DevBuf<u32> counts, chunkOffsets; DevBuf<u8> cubTemp; DevBuf<u32> contigHits;
-    DevBuf<ClusterFragments> frags, fragsAlt; ClusterFragments *fragsCur = nullptr; DevBuf<FragmentWork> fragWork;   // fragsAlt: see isaac_gpu_select
+    DevBuf<Match> staging; DevBuf<u32> counts, chunkOffsets; DevBuf<u8> cubTemp; DevBuf<u32> contigHits; std::vector<u32> hContigHits;
+    DevBuf<ClusterFragments> frags; ClusterFragments *fragsCur = nullptr; DevBuf<FragmentWork> fragWork;
     DevBuf<GappedJob> gappedJobs, rescueGappedJobs; DevBuf<GappedResult> gappedResults, rescueGappedResults; DevBuf<u32> gappedBase, gappedCounters;
     DevBuf<u8> heavyArena; DevBuf<u32> overflowList; DevBuf<u32> overflowCount; DevBuf<ClusterSums> clusterSums; DevBuf<u32> mediumList, largeList, xlList, hugeList, longJobs; DevBuf<u8> hugeKeys;
-    DevBuf<TlsSample> tlsSamples; DevBuf<u32> cigarLengths, cigarOffsets;
+    DevBuf<TlsSample> tlsSamples; DevBuf<u32> cigarLengths, cigarOffsets; DevBuf<u64> cigarTotal;
     DevBuf<CrcConstants> crcConstants; bool crcReady = false;    // isaac_gpu_bgzf_store
     // isaac_gpu_bam_records scratch
     DevBuf<BamTile> bamTiles; DevBuf<u64> bamKeyHi, bamKeyLo, bamKeyAlt, bamOffsets, bamBytes64, bamBounds; DevBuf<u32> bamIndex, bamIndexAlt, bamBytes;
@@ -80,14 +80,9 @@ struct isaac_gpu_ctx
     std::map<std::string, KernelTimer> timers;
     struct PendingTimer { std::string name; hipEvent_t e0, e1; };
     std::vector<PendingTimer> pendingTimers; std::vector<hipEvent_t> eventPool;
-    // The wave-per-cluster pass (k_select_heavy, the reference's own capacities) runs only for the clusters the flat kernels could
-    // not finish, which is rare enough to ask: the two counts come back through pinned memory.  The count of k_cluster_sums is
-    // read while k_select runs; the count of k_select itself when the next chunk (or call) has enqueued its fragment stage, which
-    // is why the chunk's pointers are kept (`pending`).
-    hipEvent_t evSums = nullptr, evSelect = nullptr; u32 *hostCounts = nullptr;
-    struct Pending { bool active = false; const uint8_t *bcl = nullptr; u32 clusterBase = 0, tile = 0; ClusterFragments *frags = nullptr; FragmentRecord *records = nullptr; u32 *cigars = nullptr;
-                     DevTls tls; RogCorrection rog; } pending;
-    bool deferredCompletion = false; u32 chunkParity = 0;
+    // one chunk of a select call as the wave-per-cluster pass (k_select_heavy) sees it
+    struct ChunkDesc { const uint8_t *bcl = nullptr; u32 clusterBase = 0, tile = 0; ClusterFragments *frags = nullptr; FragmentRecord *records = nullptr; u32 *cigars = nullptr; DevTls tls; RogCorrection rog; };
+    bool deferredCompletion = false;
     u32 selectCapacity = 0;        // chunk size the buffers of the select stage were last sized for
     DevBuf<u32> heavyList, heavyCount, indelList, alignList; DevBuf<u8> heavyFlag;
     u32 chunkClusters = 1048576;   // upper bound of a chunk (ISAAC_GPU_CHUNK_CLUSTERS)
@@ -104,9 +99,6 @@ struct isaac_gpu_ctx
         return r;
     }
 };
-
-// completes the last chunk of a select call: if k_select listed clusters for the wave-per-cluster pass, that pass is launched now
-static void resolvePending(isaac_gpu_ctx *c);
 
 namespace
 {
@@ -471,8 +463,6 @@ int isaac_gpu_create(int device, const isaac_params *params, void *stream, isaac
     c->counters.reserve(COUNTER_SHARDS);
     HIP_CHECK(hipMemset(c->counters.p, 0, COUNTER_SHARDS * sizeof(Counters)));
     c->overflowCount.reserve(1);
-    HIP_CHECK(hipEventCreateWithFlags(&c->evSums, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&c->evSelect, hipEventDisableTiming));
-    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->hostCounts), 16, hipHostMallocDefault));
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cluster_sums_xl), hipFuncAttributeMaxDynamicSharedMemorySize, int(SUMS_XL_LDS)));
     if (const char *e = getenv("ISAAC_GPU_CHUNK_CLUSTERS")) c->chunkClusters = u32(std::max(1024, atoi(e)));
     *out = c.release();
@@ -484,7 +474,6 @@ void isaac_gpu_destroy(isaac_gpu_ctx *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
-    try { resolvePending(c); } catch (...) { }
     hipStreamSynchronize(c->stream);
     resolveTimers(c);
 #if defined(ISAAC_KERNEL_STAMPS)
@@ -494,9 +483,6 @@ void isaac_gpu_destroy(isaac_gpu_ctx *c)
     }
 #endif
     for (hipEvent_t e : c->eventPool) hipEventDestroy(e);
-    if (c->evSums) hipEventDestroy(c->evSums);
-    if (c->evSelect) hipEventDestroy(c->evSelect);
-    if (c->hostCounts) hipHostFree(c->hostCounts);
     delete c;
 }
 
@@ -505,12 +491,12 @@ int isaac_gpu_free(isaac_gpu_ctx *c, void *dev) { ISAAC_TRY HIP_CHECK(hipSetDevi
 int isaac_gpu_upload(isaac_gpu_ctx *c, void *dev, const void *host, uint64_t bytes)
 { ISAAC_TRY HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
 int isaac_gpu_download(isaac_gpu_ctx *c, void *host, const void *dev, uint64_t bytes)
-{ ISAAC_TRY resolvePending(c); HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
-int isaac_gpu_synchronize(isaac_gpu_ctx *c) { ISAAC_TRY resolvePending(c); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
+{ ISAAC_TRY HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
+int isaac_gpu_synchronize(isaac_gpu_ctx *c) { ISAAC_TRY HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
 int isaac_gpu_set_deferred_completion(isaac_gpu_ctx *c, int enabled)
 {
     ISAAC_TRY
-    if (!enabled) { resolvePending(c); HIP_CHECK(hipStreamSynchronize(c->stream)); }
+    if (!enabled) HIP_CHECK(hipStreamSynchronize(c->stream));
     c->deferredCompletion = enabled != 0;
     return 0;
     ISAAC_CATCH
@@ -670,7 +656,6 @@ int isaac_gpu_build_index(isaac_gpu_ctx *c, uint32_t repeatThreshold, int annota
     ISAAC_TRY
     HIP_CHECK(hipSetDevice(c->device));
     if (!c->bases) return fail(ISAAC_GPU_EINVAL, "load the contigs first");
-    resolvePending(c);
     const u64 totalBases = c->hContigOffset[c->nContigs];
     hipStream_t st = c->stream;
     const u32 *packed = c->packedBases.p, *notBase = c->notBase.p;
@@ -881,14 +866,9 @@ int isaac_gpu_find_matches(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClust
     u64 base = 0;
     if (!nClusters) HIP_CHECK(hipMemcpyAsync(clusterOffsets, &base, 8, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(&base, c->matchBase.p, 8, hipMemcpyDeviceToHost, st));
-    if (contigHasMatches)
-    {
-        std::vector<u32> hits(c->nContigs);
-        HIP_CHECK(hipMemcpyAsync(hits.data(), c->contigHits.p, c->nContigs * 4, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        for (u32 i = 0; i < c->nContigs; ++i) contigHasMatches[i] |= u8(hits[i] != 0);
-    }
-    HIP_CHECK(hipStreamSynchronize(st));
+    if (contigHasMatches) { c->hContigHits.resize(c->nContigs); HIP_CHECK(hipMemcpyAsync(c->hContigHits.data(), c->contigHits.p, c->nContigs * 4, hipMemcpyDeviceToHost, st)); }
+    HIP_CHECK(hipStreamSynchronize(st));      // the one host wait of the call: the match count and the hit flags
+    if (contigHasMatches) for (u32 i = 0; i < c->nContigs; ++i) contigHasMatches[i] |= u8(c->hContigHits[i] != 0);
     if (nMatchesOut) *nMatchesOut = base;
     if (base > capacity) return fail(ISAAC_GPU_ECAPACITY, "matches_dev is too small");
     return 0;
@@ -909,7 +889,7 @@ static GappedBuffers gappedBuffers(isaac_gpu_ctx *c, u32 which)
 {
     GappedBuffers gb;
     gb.cap = 2 * c->chunkNow;
-    // the rescue stage has its own arrays: the wave-per-cluster pass still reads them while the next chunk's fragment stage runs
+    // the rescue stage has its own arrays (its results are read by k_select and the wave-per-cluster pass at the end of the chunk)
     DevBuf<GappedJob> &jobs = which ? c->rescueGappedJobs : c->gappedJobs; DevBuf<GappedResult> &results = which ? c->rescueGappedResults : c->gappedResults;
     jobs.reserve(gb.cap); results.reserve(gb.cap); c->gappedBase.reserve(c->chunkNow); c->gappedCounters.reserve(4);
     gb.jobs = jobs.p; gb.results = results.p; gb.base = c->gappedBase.p; gb.counter = c->gappedCounters.p + which;
@@ -972,7 +952,6 @@ int isaac_gpu_build_fragments(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nCl
     ISAAC_TRY
     (void)tile;
     HIP_CHECK(hipSetDevice(c->device));
-    resolvePending(c);      // a wave-per-cluster pass of an earlier select call may still read the buffers written below
     hipStream_t st = c->stream;
     const u32 chunk = chunkFor(c, nClusters);
     useFragments(c);
@@ -1005,7 +984,6 @@ int isaac_gpu_determine_tls(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
     ISAAC_TRY
     (void)tile;
     HIP_CHECK(hipSetDevice(c->device));
-    resolvePending(c);      // a wave-per-cluster pass of an earlier select call may still read the buffers written below
     hipStream_t st = c->stream;
     TlsLearner learner(c->P.mateDriftRange);
     if (2 == c->P.nReads)
@@ -1036,7 +1014,7 @@ struct FragmentSource { const isaac_match *matches; const uint64_t *offsets; con
 __global__ void k_set_template_constants(TemplateConstants k, TemplateConstants *dst) { *dst = k; }
 
 // the wave-per-cluster pass over `list` (count on the device) for the chunk described by `p`, on the context's stream
-static void launchHeavy(isaac_gpu_ctx *c, const isaac_gpu_ctx::Pending &p, const u32 *list, const u32 *countDev, u32 blocks, const char *timer, bool sumsKnown)
+static void launchHeavy(isaac_gpu_ctx *c, const isaac_gpu_ctx::ChunkDesc &p, const u32 *list, const u32 *countDev, u32 blocks, const char *timer, bool sumsKnown)
 {
     const TemplateCaps heavy = heavyCaps();
     const u64 heavyBytes = templateWorkBytes(heavy);
@@ -1047,14 +1025,6 @@ static void launchHeavy(isaac_gpu_ctx *c, const isaac_gpu_ctx::Pending &p, const
     k_select_heavy<<<std::max(1u, blocks), 64, HEAVY_SORT_LDS * 2, c->stream>>>(c->P, c->ref(), p.tls, p.rog, logMismatchQ40(), p.bcl, p.clusterBase, 0, countDev, p.tile, p.frags, c->heavyArena.p, heavyBytes, heavy,
                                                                                  list, rb, c->rescueGappedResults.p, c->rescueGappedJobs.p, sumsKnown ? c->clusterSums.p : nullptr, p.records, p.cigars, c->counters.p);
     HIP_CHECK(hipGetLastError());
-}
-
-static void resolvePending(isaac_gpu_ctx *c)
-{
-    if (!c->pending.active) return;
-    c->pending.active = false;
-    HIP_CHECK(hipEventSynchronize(c->evSelect));
-    if (c->hostCounts[1]) launchHeavy(c, c->pending, c->overflowList.p, c->overflowCount.p, std::min<u32>(c->hostCounts[1], 1024u), "select_residual", true);
 }
 
 static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, uint32_t tile, const FragmentSource &source, const isaac_tls *tls,
@@ -1071,7 +1041,7 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
     const u32 chunk = chunkFor(c, nClusters);
     if (chunk > c->selectCapacity)
     {   // the chunk buffers are about to be reallocated: nothing may be left that reads them
-        resolvePending(c); HIP_CHECK(hipStreamSynchronize(st));
+        HIP_CHECK(hipStreamSynchronize(st));
         c->selectCapacity = chunk;
     }
     c->overflowList.reserve(chunk);
@@ -1094,13 +1064,10 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         HIP_CHECK(hipGetLastError());
     }
     const GappedBuffers gbRescue = gappedBuffers(c, 1);
-    c->frags.reserve(chunk); c->fragsAlt.reserve(chunk);
+    c->frags.reserve(chunk); c->fragsCur = c->frags.p;
     for (u32 done = 0; done < nClusters; done += chunk)
     {
         const u32 n = std::min(chunk, nClusters - done);
-        // two ClusterFragments buffers take turns: the fragment stage of this chunk runs while the wave-per-cluster pass of the
-        // previous chunk is still reading its own; everything else that pass reads is rewritten only after the wait below
-        c->fragsCur = (c->chunkParity++ & 1) ? c->fragsAlt.p : c->frags.p;
         if (source.candidates)
         {
             gappedBuffers(c, 0);
@@ -1110,7 +1077,6 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
             HIP_CHECK(hipGetLastError());
         }
         else launchBuildFragments(c, bcl, done, n, source.matches, source.offsets, 1, 1);
-        resolvePending(c);      // the previous chunk's leftovers still read the rescue buffers this chunk is about to overwrite
         HIP_CHECK(hipMemsetAsync(c->overflowCount.p, 0, 4, st));
         HIP_CHECK(hipMemsetAsync(c->rescueCounters.p, 0, (4 + CAND_REGIONS) * 4, st));
         HIP_CHECK(hipMemsetAsync(c->rescueCounters.p + 4 + CAND_REGIONS, 0xff, CAND_REGIONS * 4, st));   // per region: first request that did not fit
@@ -1169,14 +1135,13 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         // its capacities, capacity misses of the flat pass) and for the clusters whose placements overflowed k_select's private lists.  Both
         // read their count on the device and are launched whatever it is -- nearly always zero, a few microseconds -- so that the host never
         // waits for the GPU inside a call: it used to read the two counts back and decide, which cost an idle gap per call.
-        isaac_gpu_ctx::Pending chunkDesc;
+        isaac_gpu_ctx::ChunkDesc chunkDesc;
         chunkDesc.bcl = bcl; chunkDesc.clusterBase = done; chunkDesc.tile = tile; chunkDesc.frags = c->fragsCur;
         chunkDesc.records = reinterpret_cast<FragmentRecord *>(fragments); chunkDesc.cigars = cigar; chunkDesc.tls = t; chunkDesc.rog = rog;
         launchHeavy(c, chunkDesc, c->heavyList.p, c->heavyCount.p, 1024u, "select_heavy", false);
         launchHeavy(c, chunkDesc, c->overflowList.p, c->overflowCount.p, 1024u, "select_residual", true);
     }
-    if (c->deferredCompletion) return 0;      // the caller enqueues its next call behind this one's k_select; isaac_gpu_synchronize completes the last one
-    resolvePending(c);
+    if (c->deferredCompletion) return 0;      // the caller enqueues its next call behind this one; isaac_gpu_synchronize waits for the last one
     HIP_CHECK(hipStreamSynchronize(st));
     return 0;
     ISAAC_CATCH
@@ -1203,13 +1168,30 @@ __global__ void k_cigar_lengths(const FragmentRecord *records, u64 n, u32 *lengt
     const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i < n) lengths[i] = records[i].cigarLength;
 }
-__global__ void k_cigar_pack(FragmentRecord *records, u64 n, const u32 *offsets, const u32 *cigarIn, u32 *cigarOut, u64 capacity)
+// nothing is touched when the packed pool would not fit: the records keep their slot offsets, so that the call can be repeated
+// with a larger pool (the total is offsets[n - 1] + lengths[n - 1], known on the device before this kernel starts)
+__global__ void k_cigar_pack(FragmentRecord *records, u64 n, const u32 *offsets, const u32 *lengths, const u32 *cigarIn, u32 *cigarOut, u64 capacity, u64 *totalOut)
 {
     const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const u32 from = records[i].cigarOffset, to = offsets[i], len = records[i].cigarLength;
-    if (u64(to) + len <= capacity) for (u32 k = 0; k < len; ++k) cigarOut[to + k] = cigarIn[from + k];
+    const u64 total = u64(offsets[n - 1]) + lengths[n - 1];
+    if (0 == i && totalOut) *totalOut = total;
+    if (i >= n || total > capacity) return;
+    const u32 from = records[i].cigarOffset, to = offsets[i], len = lengths[i];
+    for (u32 k = 0; k < len; ++k) cigarOut[to + k] = cigarIn[from + k];
     records[i].cigarOffset = to;
+}
+static int compactCigars(isaac_gpu_ctx *c, isaac_fragment *fragments, uint64_t nRecords, const uint32_t *cigarIn, uint32_t *cigarOut, uint64_t capacity, u64 *totalDev)
+{
+    if (!fragments || !cigarIn || !cigarOut) return fail(ISAAC_GPU_EINVAL, "fragments_dev, cigar_in_dev and cigar_out_dev are required");
+    if (nRecords >= (u64(1) << 31)) return fail(ISAAC_GPU_EINVAL, "at most 2^31 - 1 records per call");
+    hipStream_t st = c->stream;
+    DevBuf<u32> &len = c->cigarLengths, &off = c->cigarOffsets; len.reserve(nRecords); off.reserve(nRecords);
+    FragmentRecord *records = reinterpret_cast<FragmentRecord *>(fragments);
+    k_cigar_lengths<<<gridFor(nRecords, 256), 256, 0, st>>>(records, nRecords, len.p);
+    exclusiveSum(c, len.p, off.p, nRecords);
+    k_cigar_pack<<<gridFor(nRecords, 256), 256, 0, st>>>(records, nRecords, off.p, len.p, cigarIn, cigarOut, capacity, totalDev);
+    HIP_CHECK(hipGetLastError());
+    return 0;
 }
 extern "C" {
 int isaac_gpu_compact_cigars(isaac_gpu_ctx *c, isaac_fragment *fragments, uint64_t nRecords, const uint32_t *cigarIn, uint32_t *cigarOut, uint64_t capacity, uint64_t *nWordsOut)
@@ -1218,24 +1200,23 @@ int isaac_gpu_compact_cigars(isaac_gpu_ctx *c, isaac_fragment *fragments, uint64
     HIP_CHECK(hipSetDevice(c->device));
     if (nWordsOut) *nWordsOut = 0;
     if (!nRecords) return 0;
-    if (!fragments || !cigarIn || !cigarOut) return fail(ISAAC_GPU_EINVAL, "fragments_dev, cigar_in_dev and cigar_out_dev are required");
-    if (nRecords >= (u64(1) << 31)) return fail(ISAAC_GPU_EINVAL, "at most 2^31 - 1 records per call");
-    resolvePending(c);
-    hipStream_t st = c->stream;
-    DevBuf<u32> &len = c->cigarLengths, &off = c->cigarOffsets; len.reserve(nRecords); off.reserve(nRecords);
-    FragmentRecord *records = reinterpret_cast<FragmentRecord *>(fragments);
-    k_cigar_lengths<<<gridFor(nRecords, 256), 256, 0, st>>>(records, nRecords, len.p);
-    exclusiveSum(c, len.p, off.p, nRecords);
-    k_cigar_pack<<<gridFor(nRecords, 256), 256, 0, st>>>(records, nRecords, off.p, cigarIn, cigarOut, capacity);
-    HIP_CHECK(hipGetLastError());
-    u32 lastLen = 0, lastOff = 0;
-    HIP_CHECK(hipMemcpyAsync(&lastLen, len.p + nRecords - 1, 4, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(&lastOff, off.p + nRecords - 1, 4, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    const u64 total = u64(lastLen) + lastOff;
+    c->cigarTotal.reserve(1);
+    if (const int rc = compactCigars(c, fragments, nRecords, cigarIn, cigarOut, capacity, c->cigarTotal.p)) return rc;
+    u64 total = 0;
+    HIP_CHECK(hipMemcpyAsync(&total, c->cigarTotal.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
     if (nWordsOut) *nWordsOut = total;
     if (total > capacity) return fail(ISAAC_GPU_ECAPACITY, "cigar_out_dev is too small");
     return 0;
+    ISAAC_CATCH
+}
+int isaac_gpu_compact_cigars_async(isaac_gpu_ctx *c, isaac_fragment *fragments, uint64_t nRecords, const uint32_t *cigarIn, uint32_t *cigarOut, uint64_t capacity, uint64_t *nWordsOutDev)
+{
+    ISAAC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    if (!nWordsOutDev) return fail(ISAAC_GPU_EINVAL, "n_words_out_dev is required");
+    if (!nRecords) { HIP_CHECK(hipMemsetAsync(nWordsOutDev, 0, 8, c->stream)); return 0; }
+    return compactCigars(c, fragments, nRecords, cigarIn, cigarOut, capacity, reinterpret_cast<u64 *>(nWordsOutDev));
     ISAAC_CATCH
 }
 
@@ -1273,7 +1254,6 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
     if (n >= (u64(1) << 31)) return fail(ISAAC_GPU_EINVAL, "at most 2^31 - 1 records per call");
     if (!n) return 0;
     if (!bam && capacity) return fail(ISAAC_GPU_EINVAL, "bam_dev is required");
-    resolvePending(c);
     hipStream_t st = c->stream;
     c->bamTiles.reserve(nTiles); c->bamKeyHi.reserve(n); c->bamKeyLo.reserve(n); c->bamKeyAlt.reserve(n); c->bamOffsets.reserve(n); c->bamBytes64.reserve(n);
     c->bamIndex.reserve(n); c->bamIndexAlt.reserve(n); c->bamBytes.reserve(n); c->bamBounds.reserve(2);
@@ -1334,7 +1314,6 @@ int isaac_gpu_bgzf_store(isaac_gpu_ctx *c, const uint8_t *data, uint64_t nBytes,
     if (nBytesOut) *nBytesOut = total;
     if (total > capacity) return fail(ISAAC_GPU_ECAPACITY, "out_dev is too small (isaac_gpu_bgzf_store_bound)");
     if (nBlocks >= (u64(1) << 31)) return fail(ISAAC_GPU_EINVAL, "at most 2^31 - 1 blocks per call");
-    resolvePending(c);
     hipStream_t st = c->stream;
     if (!c->crcReady)
     {
@@ -1463,7 +1442,7 @@ int isaac_gpu_get_counters(isaac_gpu_ctx *c, isaac_counters *out)
     ISAAC_TRY
     static_assert(sizeof(isaac_counters) == sizeof(Counters), "counter layouts");
     std::vector<Counters> shards(COUNTER_SHARDS);
-    resolvePending(c); HIP_CHECK(hipStreamSynchronize(c->stream));     // a deferred wave-per-cluster pass still counts
+    HIP_CHECK(hipStreamSynchronize(c->stream));     // kernels in flight still count
     HIP_CHECK(hipMemcpy(shards.data(), c->counters.p, COUNTER_SHARDS * sizeof(Counters), hipMemcpyDeviceToHost));
     u64 *sum = reinterpret_cast<u64 *>(out);
     for (u32 f = 0; f < sizeof(Counters) / sizeof(u64); ++f)
@@ -1487,7 +1466,7 @@ int isaac_gpu_kernel_time_ms(isaac_gpu_ctx *c, const char *kernel, double *avgMs
 int isaac_gpu_reset_timers(isaac_gpu_ctx *c)
 {
     ISAAC_TRY
-    resolvePending(c); HIP_CHECK(hipStreamSynchronize(c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
     resolveTimers(c);
     c->timers.clear();
     HIP_CHECK(hipMemset(c->counters.p, 0, COUNTER_SHARDS * sizeof(Counters)));

@@ -78,6 +78,7 @@ struct Parser
             n->text += unescape(std::string(b, p));
             if (p == end) fail("unterminated element " + n->name);
             if (starts("<!--")) { skipTo("-->"); continue; }
+            if (starts("<![CDATA[")) { const char *cb = p + 9; skipTo("]]>"); n->text += std::string(cb, p - 3); continue; }
             if (starts("</")) { p += 2; const std::string c = name(); if (c != n->name) fail("</" + c + "> closes <" + n->name + ">"); skipSpace(); if (p == end || *p != '>') fail("'>' expected"); ++p; break; }
             n->children.push_back(element());
         }
@@ -100,7 +101,10 @@ uint64_t numberAttribute(const Node &n, const char *a, bool optional, uint64_t f
 {
     const auto it = n.attributes.find(a);
     if (it == n.attributes.end()) { if (optional) return fallback; throw std::runtime_error(std::string("sorted-reference.xml: attribute ") + a + " of " + n.name + " is missing"); }
-    return std::strtoull(it->second.c_str(), nullptr, 10);
+    char *e = nullptr; errno = 0;
+    const unsigned long long v = std::strtoull(it->second.c_str(), &e, 10);
+    if (errno || e == it->second.c_str() || *e) throw std::runtime_error(std::string("sorted-reference.xml: attribute ") + a + " of " + n.name + " is not a number: " + it->second);
+    return v;
 }
 void copyText(char *dst, size_t cap, const std::string &s, const char *what)
 {
@@ -294,10 +298,14 @@ int isaac_gpu_load_sorted_reference(isaac_gpu_ctx *ctx, const char *xmlPath)
             close(fd);
             pointers[i] = MAP_FAILED == mappings[i].p ? nullptr : static_cast<const isaac_reference_kmer *>(mappings[i].p); sizes[i] = wanted[i].kmers;
         }
+        // <Index> and <KaryotypeIndex> must each name every contig once: a duplicate would leave another contig translated to 0
         std::vector<uint32_t> karyotype(nContigs);
+        std::vector<char> seenIndex(nContigs, 0), seenKaryotype(nContigs, 0);
         for (const auto &c : contigs)
         {
             if (c.index >= nContigs || c.karyotype_index >= nContigs) return xmlFail(ISAAC_GPU_EFORMAT, "contig Index / KaryotypeIndex out of range");
+            if (seenIndex[c.index]++ || seenKaryotype[c.karyotype_index]++)
+                return xmlFail(ISAAC_GPU_EFORMAT, std::string("contig Index / KaryotypeIndex values are not a permutation of 0..n-1 (contig ") + c.name + ")");
             karyotype[c.index] = c.karyotype_index;
         }
         rc = isaac_gpu_load_index(ctx, pointers.data(), sizes.data(), uint32_t(wanted.size()), nContigs ? karyotype.data() : nullptr, nContigs);

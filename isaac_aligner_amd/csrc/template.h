@@ -272,6 +272,7 @@ struct TemplateCtx
     // loops are strided by `lane`.  lanes == 1: plain thread-serial execution.  fastSort: large probability lists are sorted by a
     // total order that refines the reference's comparators, with the exact std::sort replica as fallback for ambiguous data.
     u32 lanes, lane; bool fastSort; u16 *ldsSort; u32 ldsSortCap;
+    u32 mapqNearInteger;      // mapqFloor met an argument within 1e-11 of an integer for this cluster (RECORD_MAPQ_NEAR_INTEGER)
     long long prof[8];
 };
 
@@ -349,7 +350,7 @@ ISAAC_HD u32 mapqFloor(TemplateCtx &x, double ratio)
     const double d = v - fl;
     if (d > 1.0 - 1e-11 || (d < 1e-11 && fl >= 1.0))
     {
-        ++x.cnt->mapqNearInteger;
+        ++x.cnt->mapqNearInteger; x.mapqNearInteger = 1;
 #ifdef ISAAC_DEBUG_MAPQ
         printf("mapq near integer: ratio=%.17g v=%.17g floor=%.17g cluster=%u\n", ratio, v, fl, x.clusterId);
 #endif

@@ -39,7 +39,7 @@ EXPORTS = ["isaac_gpu_last_error", "isaac_gpu_create", "isaac_gpu_destroy", "isa
            "isaac_gpu_sorted_reference_parse", "isaac_gpu_sorted_reference_format", "isaac_gpu_sorted_reference_last_error", "isaac_gpu_load_sorted_reference",
            "isaac_gpu_save_sorted_reference",
            "isaac_gpu_find_matches", "isaac_gpu_set_loaded_contigs", "isaac_gpu_build_fragments", "isaac_gpu_determine_tls", "isaac_gpu_select", "isaac_gpu_select_candidates",
-           "isaac_gpu_bsw_batch", "isaac_gpu_compact_cigars",
+           "isaac_gpu_bsw_batch", "isaac_gpu_compact_cigars", "isaac_gpu_compact_cigars_async",
            "isaac_gpu_bam_records", "isaac_gpu_bam_last_error", "isaac_gpu_bam_header", "isaac_gpu_bgzf_bound", "isaac_gpu_bgzf_compress", "isaac_gpu_bgzf_store_bound", "isaac_gpu_bgzf_store",
            "isaac_gpu_fastq_to_bcl", "isaac_gpu_fastq_tile_clusters_max", "isaac_gpu_fastq_tiles", "isaac_gpu_get_counters", "isaac_gpu_kernel_time_ms", "isaac_gpu_reset_timers"]
 
@@ -241,8 +241,7 @@ class Aligner:
         self._check(self.lib.isaac_gpu_select(self.h, _p(bcl), C.c_uint32(n_clusters), C.c_uint32(tile), _p(matches), _p(offsets), C.byref(tls),
                                               _p(records), _p(cigars), C.c_uint64(cigars.numel())))
         if self.deferred_completion:
-            # the call's last pass may still read the inputs and write the outputs on the library's own stream: the tensors stay
-            # referenced (the caching allocator must not hand their memory out) until synchronize()
+            # the call's kernels may still be queued: the tensors stay referenced until synchronize()
             self._inflight.append((bcl, matches, offsets, records, cigars))
         return records, cigars
 
@@ -284,6 +283,13 @@ class Aligner:
             rc = self.lib.isaac_gpu_compact_cigars(self.h, _p(records), C.c_uint64(n_rec), _p(cigars), _p(out), C.c_uint64(out.numel()), C.byref(n))
         self._check(rc)
         return out[:n.value], n.value
+
+    def compact_cigars_async(self, records, cigars, out, n_words_dev):
+        """compact_cigars without the host wait: n_words_dev (1-element int64 device tensor) receives the packed length behind the kernels;
+        `out` must be large enough (a pool that is too small leaves everything as it was and shows as n_words_dev > out.numel())"""
+        self._check(self.lib.isaac_gpu_compact_cigars_async(self.h, _p(records), C.c_uint64(records.shape[0]), _p(cigars), _p(out), C.c_uint64(out.numel()), _p(n_words_dev)))
+        if self.deferred_completion:
+            self._inflight.append((records, cigars, out, n_words_dev))
 
     # ---- output format --------------------------------------------------------------------------------------------
     def bam_records(self, tiles, out=None, read_group=None, barcode=None, forced_dodgy_alignment_score=None, pessimistic_mapq=False):

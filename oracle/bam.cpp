@@ -160,12 +160,19 @@ void bamRecords(const std::vector<BamTileInput> &tiles, const BamOptions &o, std
 
 // bam::serializeHeader (Bam.hh:153-235)
 void bamHeader(const std::string &commandLine, const std::string &description, const std::string &version, const std::vector<std::string> &headerLines,
-               const std::vector<std::pair<std::string, uint32_t> > &refSeqs, std::vector<char> &os)
+               const std::vector<std::pair<std::string, uint32_t> > &refSeqs, std::vector<char> &os, const std::vector<SqTags> *tags)
 {
     std::string text = "@HD\tVN:1.0\tSO:coordinate\n@PG\tID:iSAAC\tPN:iSAAC\tCL:" + commandLine + "\t" + (description.empty() ? std::string() : ("DS:" + description + "\t")) +
                        "VN:" + version + "\n";
     for (const std::string &l : headerLines) text += l + "\n";
-    for (const auto &r : refSeqs) text += "@SQ\tSN:" + r.first + "\tLN:" + std::to_string(r.second) + "\n";
+    for (size_t i = 0; i < refSeqs.size(); ++i)
+    {   // Bam.hh:194-213
+        std::string sq = "@SQ\tSN:" + refSeqs[i].first + "\tLN:" + std::to_string(refSeqs[i].second);
+        if (tags && (*tags)[i].as.length()) sq += "\tAS:" + (*tags)[i].as;
+        if (tags && !(*tags)[i].ur.empty()) sq += "\tUR:" + (*tags)[i].ur;
+        if (tags && !(*tags)[i].m5.empty()) sq += "\tM5:" + (*tags)[i].m5;
+        text += sq + "\n";
+    }
     put(os, "BAM\1", 4); putInt(os, int(text.size())); put(os, text.data(), text.size());
     putInt(os, int(refSeqs.size()));
     for (const auto &r : refSeqs) { putInt(os, int(r.first.size() + 1)); put(os, r.first.c_str(), r.first.size() + 1); putInt(os, int(r.second)); }

@@ -851,15 +851,23 @@ int oracle_bam_records(const oracle_bam_tile *tiles, uint32_t n_tiles, uint32_t 
 }
 
 int oracle_bam_header(const char *command_line, const char *description, const char *version, const char *const *header_lines, uint32_t n_header_lines,
-                      const char *const *contig_names, const uint32_t *contig_lengths, uint32_t n_contigs, uint8_t *out, uint64_t capacity, uint64_t *n_bytes)
+                      const char *const *contig_names, const uint32_t *contig_lengths, const char *const *contig_as, const char *const *contig_ur, const char *const *contig_m5,
+                      uint32_t n_contigs, uint8_t *out, uint64_t capacity, uint64_t *n_bytes)
 {
     try
     {
         std::vector<std::string> lines(header_lines, header_lines + n_header_lines);
         std::vector<std::pair<std::string, uint32_t> > refs;
-        for (uint32_t i = 0; i < n_contigs; ++i) refs.push_back(std::make_pair(std::string(contig_names[i]), contig_lengths[i]));
+        std::vector<SqTags> tags(n_contigs);
+        for (uint32_t i = 0; i < n_contigs; ++i)
+        {
+            refs.push_back(std::make_pair(std::string(contig_names[i]), contig_lengths[i]));
+            if (contig_as && contig_as[i]) tags[i].as = contig_as[i];
+            if (contig_ur && contig_ur[i]) tags[i].ur = contig_ur[i];
+            if (contig_m5 && contig_m5[i]) tags[i].m5 = contig_m5[i];
+        }
         std::vector<char> os;
-        bamHeader(command_line, description, version, lines, refs, os);
+        bamHeader(command_line, description, version, lines, refs, os, &tags);
         *n_bytes = os.size();
         if (os.size() > capacity) throw std::runtime_error("bam capacity");
         memcpy(out, os.data(), os.size());

@@ -688,7 +688,8 @@ void fastqDiscoverTiles(unsigned clustersLoaded, unsigned tileClustersMax, unsig
 struct BamTileInput { const uint8_t *bcl; const FragmentRecord *records; const uint32_t *cigars; uint64_t nRecords; std::string namePrefix; };
 struct BamOptions { unsigned clusterLength, readOffset[2]; unsigned char forcedDodgyAlignmentScore; bool pessimisticMapQ; std::string readGroup, barcode; };
 void bamRecords(const std::vector<BamTileInput> &tiles, const BamOptions &o, std::vector<char> &os, uint64_t &nRecords, uint64_t &unalignedOffset);
+struct SqTags { std::string as, ur, m5; };    // SortedReferenceMetadata::Contig::bamSqAs_ / bamSqUr_ / bamM5_
 void bamHeader(const std::string &commandLine, const std::string &description, const std::string &version, const std::vector<std::string> &headerLines,
-               const std::vector<std::pair<std::string, uint32_t> > &refSeqs, std::vector<char> &os);
+               const std::vector<std::pair<std::string, uint32_t> > &refSeqs, std::vector<char> &os, const std::vector<SqTags> *tags = 0);
 
 } // namespace oracle

@@ -97,11 +97,13 @@ class Oracle:
 
     def bam_header(self, command_line, version, contigs, description="", header_lines=()):
         lines = (C.c_char_p * max(1, len(header_lines)))(*[l.encode() for l in header_lines])
-        names = (C.c_char_p * max(1, len(contigs)))(*[n.encode() for n, _ in contigs])
-        lengths = (C.c_uint32 * max(1, len(contigs)))(*[l for _, l in contigs])
+        names = (C.c_char_p * max(1, len(contigs)))(*[c[0].encode() for c in contigs])
+        lengths = (C.c_uint32 * max(1, len(contigs)))(*[c[1] for c in contigs])
+        tags = [(C.c_char_p * max(1, len(contigs)))(*[(c[k].encode() if len(c) > k and c[k] else None) for c in contigs]) for k in (2, 3, 4)]
         out = np.empty(1 << 20, np.uint8)
         n = C.c_uint64()
-        self.check(self.lib.oracle_bam_header(command_line.encode(), description.encode(), version.encode(), lines, C.c_uint32(len(header_lines)), names, lengths, C.c_uint32(len(contigs)),
+        self.check(self.lib.oracle_bam_header(command_line.encode(), description.encode(), version.encode(), lines, C.c_uint32(len(header_lines)), names, lengths, tags[0], tags[1], tags[2],
+                                              C.c_uint32(len(contigs)),
                                               ptr(out), C.c_uint64(out.size), C.byref(n)))
         return out[:n.value].tobytes()
 

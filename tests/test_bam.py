@@ -146,6 +146,16 @@ def test_header_matches_the_oracle():
     assert got[:4] == b"BAM\x01" and text.startswith("@HD\tVN:1.0\tSO:coordinate\n@PG\tID:iSAAC\tPN:iSAAC\tCL:isaac-align") and "DS:a run\tVN:iSAAC-01.15\n" in text
     assert text.count("@SQ") == 3 and "@SQ\tSN:phiX\tLN:5386\n" in text
     assert bam.header("", "", []) == o.bam_header("", "", [])
+    # @SQ lines of a sorted reference that carries AS / UR / M5 (Bam.hh:196-213: appended in this order, each only when present)
+    tagged = [("chr1", 1000, "GRCh38", "file:///ref/chr1.fa", "6aef897c3d6ff0c78aff06ac189178dd"), ("chr2", 500, "", "http://x/y", ""), ("chr3", 7, None, None, "0123")]
+    want = o.bam_header("cl", "v", tagged)
+    got = bam.header("cl", "v", tagged)
+    assert got == want
+    literal = ("@HD\tVN:1.0\tSO:coordinate\n@PG\tID:iSAAC\tPN:iSAAC\tCL:cl\tVN:v\n"
+               "@SQ\tSN:chr1\tLN:1000\tAS:GRCh38\tUR:file:///ref/chr1.fa\tM5:6aef897c3d6ff0c78aff06ac189178dd\n"
+               "@SQ\tSN:chr2\tLN:500\tUR:http://x/y\n@SQ\tSN:chr3\tLN:7\tM5:0123\n").encode()
+    table = b"".join(len(n) .to_bytes(4, "little")[:0] + (len(n) + 1).to_bytes(4, "little") + n.encode() + b"\0" + l.to_bytes(4, "little") for n, l in (("chr1", 1000), ("chr2", 500), ("chr3", 7)))
+    assert got == b"BAM\x01" + len(literal).to_bytes(4, "little") + literal + (3).to_bytes(4, "little") + table
 
 
 @pytest.mark.parametrize("level", [0, 1, 6])

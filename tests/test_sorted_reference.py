@@ -62,6 +62,19 @@ def test_reader_errors_as_the_reference_raises_them():
         sr.parse(GOLDEN["xml"][:len(GOLDEN["xml"]) // 2])
     with pytest.raises(sr.FormatError):
         sr.parse(GOLDEN["xml"].replace("<Total>107990454</Total>", "<Total>many</Total>"))
+    # numbers in attributes are validated like numbers in elements (the reference's reader throws on lexical_cast)
+    first_position = GOLDEN["xml"].index('Position="')
+    with pytest.raises(sr.FormatError, match="Position"):
+        sr.parse(GOLDEN["xml"][:first_position] + 'Position="abc' + GOLDEN["xml"][first_position + len('Position="'):])
+    with pytest.raises(sr.FormatError, match="Mask"):
+        sr.parse(GOLDEN["xml"].replace('Mask="1"', 'Mask="x1"', 1))
+
+
+def test_reader_takes_cdata_sections():
+    name = GOLDEN["contigs"][0]["name"]
+    text = GOLDEN["xml"].replace("<Name>%s</Name>" % name, "<Name><![CDATA[%s]]></Name>" % name, 1)
+    assert text != GOLDEN["xml"]
+    check_content(*sr.parse(text)[:2])
 
 
 @pytest.mark.gpu
@@ -107,3 +120,9 @@ def test_table_round_trip_through_mask_files(torch, tmp_path):
     assert mb.shape == mc.shape and (np.sort(mb.view(np.uint64).reshape(-1, 2), axis=0) == np.sort(mc.view(np.uint64).reshape(-1, 2), axis=0)).all()
     with pytest.raises(gpu.IsaacGpuError):
         b.load_sorted_reference(str(tmp_path / "missing.xml"))
+    # <Index> / <KaryotypeIndex> that are not permutations are refused instead of silently translating a contig to 0
+    text = open(tmp_path / "sorted-reference.xml").read()
+    assert "<KaryotypeIndex>2</KaryotypeIndex>" in text
+    open(tmp_path / "duplicate.xml", "w").write(text.replace("<KaryotypeIndex>2</KaryotypeIndex>", "<KaryotypeIndex>1</KaryotypeIndex>"))
+    with pytest.raises(gpu.IsaacGpuError, match="permutation"):
+        b.load_sorted_reference(str(tmp_path / "duplicate.xml"))
