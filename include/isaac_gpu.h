@@ -121,6 +121,8 @@ const char *isaac_gpu_last_error(void);
  * (lib/alignment/MatchFinder.cpp:74-112, MatchSelector.cpp:92-168).  `stream` is a hipStream_t or NULL. */
 int isaac_gpu_create(int device, const isaac_params *params, void *stream, isaac_gpu_ctx **out);
 void isaac_gpu_destroy(isaac_gpu_ctx *ctx);
+/* Replaces the options and the read geometry of the context; contigs and table stay resident.  Waits for what is in flight. */
+int isaac_gpu_set_params(isaac_gpu_ctx *ctx, const isaac_params *params);
 
 /* plain device memory helpers for hosts without another GPU runtime */
 int isaac_gpu_malloc(isaac_gpu_ctx *ctx, uint64_t bytes, void **dev_out);
@@ -163,6 +165,15 @@ int isaac_gpu_get_index_range(isaac_gpu_ctx *ctx, uint64_t first, uint64_t n, is
  * lib/reference/SortedReferenceXml.cpp:312-324: one mask file = entries [offsets[m], offsets[m + 1])); n_masks must be the
  * number of masks the table was loaded or built with (64 for a built one) */
 int isaac_gpu_get_mask_offsets(isaac_gpu_ctx *ctx, uint64_t *offsets_out, uint32_t n_masks);
+
+/* The resident table as it lies in HBM: kmers_dev[i] / positions_dev[i] = the i-th record of the concatenated mask files, split into two arrays
+ * (read-only device pointers, valid until the table is rebuilt or reloaded or the context destroyed).  isaac_gpu_set_index_dev adopts such a
+ * pair owned by the caller instead of loading one -- several contexts on one device share one table that way, and the ranks of a multi-GPU
+ * job can receive rank 0's table over xGMI instead of building or reading their own.  mask_offsets (n_masks + 1 entries) may be NULL
+ * when nobody will ask for the mask cuts.  The contig translation of isaac_gpu_load_index does not apply (positions are used as stored). */
+int isaac_gpu_index_dev(isaac_gpu_ctx *ctx, const uint64_t **kmers_dev_out, const uint64_t **positions_dev_out, uint64_t *n_entries_out);
+int isaac_gpu_set_index_dev(isaac_gpu_ctx *ctx, const uint64_t *kmers_dev, const uint64_t *positions_dev, uint64_t n_entries,
+                            const uint64_t *mask_offsets, uint32_t n_masks);
 
 /* sorted-reference.xml: reference::SortedReferenceMetadata::Contig / ::MaskFile (include/reference/SortedReferenceMetadata.hh:44-98) as
  * plain records.  strings are NUL-terminated. */

@@ -58,6 +58,9 @@ struct isaac_gpu_ctx
     DevBuf<char> basesOwned; const char *bases = nullptr;
     DevBuf<u64> contigOffset; std::vector<u64> hContigOffset; DevBuf<u8> contigLoaded; std::vector<u8> hContigLoaded; u32 nContigs = 0;
     DevBuf<u64> kmers, positions; u64 nKmers = 0; DevBuf<u32> karyotype; bool hasKaryotype = false;
+    const u64 *kmersBorrowed = nullptr, *positionsBorrowed = nullptr;   // isaac_gpu_set_index_dev: a table owned by the caller (another context, an RCCL receive buffer)
+    const u64 *tableKmers() const { return kmersBorrowed ? kmersBorrowed : kmers.p; }
+    const u64 *tablePositions() const { return positionsBorrowed ? positionsBorrowed : positions.p; }
     DevBuf<u32> prefixTable; u32 prefixBits = 0; std::vector<u64> maskOffsets;   // entries before each mask of the table (load_index / build_index)
     DevBuf<u32> packedBases, notBase;   // 2-bit copy of the contigs + not-ACGT bitmap (k_rescue_windows reads these)
     DevBuf<u64> matchBase;
@@ -92,7 +95,7 @@ struct isaac_gpu_ctx
     {
         DevReference r; std::memset(&r, 0, sizeof(r));
         r.bases = bases; r.totalBases = hContigOffset.empty() ? 0 : hContigOffset[nContigs]; r.contigOffset = contigOffset.p; r.contigLoaded = contigLoaded.p; r.nContigs = nContigs;
-        r.kmers = kmers.p; r.positions = positions.p; r.nKmers = nKmers; r.karyotype = hasKaryotype ? karyotype.p : nullptr;
+        r.kmers = tableKmers(); r.positions = tablePositions(); r.nKmers = nKmers; r.karyotype = hasKaryotype ? karyotype.p : nullptr;
         r.logMatch = logTables.p; r.logMismatch = logTables.p + 100;
         r.prefixTable = prefixBits ? prefixTable.p : nullptr; r.prefixBits = prefixBits;
         r.packedBases = packedBases.p; r.notBase = notBase.p;
@@ -429,7 +432,7 @@ void buildPrefixTable(isaac_gpu_ctx *c)
     u32 bits = 16; while (bits < 30 && (u64(1) << bits) < c->nKmers) ++bits;     // about one entry per bucket (human: 2.7), 256 KB .. 4 GB
     const u64 entries = (u64(1) << bits) + 1;
     c->prefixTable.reserve(entries + 1);                                            // + 1: the last bucket reads a pair
-    k_prefix_table<<<gridFor(entries, 256), 256, 0, c->stream>>>(c->kmers.p, c->nKmers, bits, c->prefixTable.p);
+    k_prefix_table<<<gridFor(entries, 256), 256, 0, c->stream>>>(c->tableKmers(), c->nKmers, bits, c->prefixTable.p);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemsetAsync(c->prefixTable.p + entries, 0xff, 4, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -571,6 +574,7 @@ int isaac_gpu_load_index(isaac_gpu_ctx *c, const isaac_reference_kmer *const *ma
     u64 total = 0; for (u32 m = 0; m < nMasks; ++m) total += sizes[m];
     if (total >= (u64(1) << 32)) return fail(ISAAC_GPU_EINVAL, "tables of 2^32 entries and more are not supported");
     hipStream_t st = c->stream;
+    c->kmersBorrowed = c->positionsBorrowed = nullptr;
     c->kmers.reserve(total + 1); c->positions.reserve(total + 1); c->nKmers = 0; c->prefixBits = 0;
     const u64 chunk = 1u << 24;      // records per staging buffer (256 MB)
     DevBuf<ReferenceKmerRecord> staging[2]; DevBuf<u32> disorder; disorder.reserve(1);
@@ -661,6 +665,7 @@ int isaac_gpu_build_index(isaac_gpu_ctx *c, uint32_t repeatThreshold, int annota
     const u32 *packed = c->packedBases.p, *notBase = c->notBase.p;
     const u64 nBlocks = (totalBases + INDEX_TILE - 1) / INDEX_TILE;
     if (nBlocks >= (u64(1) << 31)) return fail(ISAAC_GPU_EINVAL, "reference too long");
+    c->kmersBorrowed = c->positionsBorrowed = nullptr;
     c->nKmers = 0; c->prefixBits = 0; c->hasKaryotype = false; c->maskOffsets.assign(1, 0);
     // 1. how many k-mers of each mask every block of positions holds
     DevBuf<u32> counts; counts.reserve(size_t(INDEX_MASKS) * nBlocks);
@@ -788,7 +793,7 @@ int isaac_gpu_get_index(isaac_gpu_ctx *c, isaac_reference_kmer *out, uint64_t ca
     for (u64 done = 0; done < c->nKmers; done += chunk)
     {
         const u64 n = std::min(chunk, c->nKmers - done);
-        k_join_records<<<gridFor(n, 256), 256, 0, c->stream>>>(c->kmers.p, c->positions.p, done, n, staging.p);
+        k_join_records<<<gridFor(n, 256), 256, 0, c->stream>>>(c->tableKmers(), c->tablePositions(), done, n, staging.p);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(out + done, staging.p, n * sizeof(ReferenceKmerRecord), hipMemcpyDeviceToHost, c->stream));
         HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -809,7 +814,7 @@ int isaac_gpu_get_index_range(isaac_gpu_ctx *c, uint64_t first, uint64_t n, isaa
     for (u64 done = 0; done < n; done += chunk)
     {
         const u64 m = std::min(chunk, n - done);
-        k_join_records<<<gridFor(m, 256), 256, 0, c->stream>>>(c->kmers.p, c->positions.p, first + done, m, staging.p);
+        k_join_records<<<gridFor(m, 256), 256, 0, c->stream>>>(c->tableKmers(), c->tablePositions(), first + done, m, staging.p);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(out + done, staging.p, m * sizeof(ReferenceKmerRecord), hipMemcpyDeviceToHost, c->stream));
         HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -829,12 +834,56 @@ int isaac_gpu_get_mask_offsets(isaac_gpu_ctx *c, uint64_t *offsetsOut, uint32_t 
     ISAAC_CATCH
 }
 
+// the resident table as device pointers (read-only; valid until the table is rebuilt, reloaded or its owner destroyed)
+int isaac_gpu_index_dev(isaac_gpu_ctx *c, const uint64_t **kmersOut, const uint64_t **positionsOut, uint64_t *nOut)
+{
+    ISAAC_TRY
+    if (kmersOut) *kmersOut = c->tableKmers();
+    if (positionsOut) *positionsOut = c->tablePositions();
+    if (nOut) *nOut = c->nKmers;
+    return 0;
+    ISAAC_CATCH
+}
+
+// adopts a table that lives in the caller's device memory (another context's, or what an RCCL broadcast delivered): nothing is
+// copied; only the prefix directory is built
+int isaac_gpu_set_index_dev(isaac_gpu_ctx *c, const uint64_t *kmers, const uint64_t *positions, uint64_t n, const uint64_t *maskOffsets, uint32_t nMasks)
+{
+    ISAAC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    if (n && (!kmers || !positions)) return fail(ISAAC_GPU_EINVAL, "kmers_dev and positions_dev are required");
+    if (n >= (u64(1) << 32)) return fail(ISAAC_GPU_EINVAL, "tables of 2^32 entries and more are not supported");
+    if (maskOffsets && (maskOffsets[0] != 0 || maskOffsets[nMasks] != n)) return fail(ISAAC_GPU_EINVAL, "mask_offsets must run from 0 to n_entries");
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->kmers.release(); c->positions.release();
+    c->kmersBorrowed = kmers; c->positionsBorrowed = positions; c->nKmers = n; c->hasKaryotype = false;
+    if (maskOffsets) c->maskOffsets.assign(maskOffsets, maskOffsets + nMasks + 1); else { c->maskOffsets.assign(1, 0); c->maskOffsets.push_back(n); }
+    buildPrefixTable(c);
+    return 0;
+    ISAAC_CATCH
+}
+
+// other options / read geometry for the same reference and table (the reference constructs its MatchFinder / MatchSelector once per
+// run; a service that aligns runs of different read lengths against one resident genome does not reload 50 GB for that)
+int isaac_gpu_set_params(isaac_gpu_ctx *c, const isaac_params *params)
+{
+    ISAAC_TRY
+    if (!params) return fail(ISAAC_GPU_EINVAL, "null argument");
+    if (-params->gap_open < -params->gap_extend) return fail(ISAAC_GPU_EINVAL, "gap open penalty below gap extend penalty is not supported by the banded Smith-Waterman scan");
+    const DevParams P = makeDevParams(*params);
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->params = *params; c->P = P;
+    return 0;
+    ISAAC_CATCH
+}
+
 int isaac_gpu_find_matches(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, uint32_t tile, isaac_match *matchesOut, uint64_t capacity,
                            uint64_t *clusterOffsets, uint64_t *nMatchesOut, uint8_t *contigHasMatches)
 {
     ISAAC_TRY
     HIP_CHECK(hipSetDevice(c->device));
-    if (!c->kmers.p || !c->bases) return fail(ISAAC_GPU_EINVAL, "load the contigs and the index first");
+    if (!c->tableKmers() || !c->bases) return fail(ISAAC_GPU_EINVAL, "load the contigs and the index first");
     if (!matchesOut || !clusterOffsets) return fail(ISAAC_GPU_EINVAL, "matches_dev and cluster_offsets_dev are required");
     if (nClusters > 0x7fffffffu || tile > 0xfff) return fail(ISAAC_GPU_EINVAL, "SeedId overflow (SeedId.hh:95-109)");
     hipStream_t st = c->stream;

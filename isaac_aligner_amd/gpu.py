@@ -34,7 +34,7 @@ def load_library(path=None):
     return _lib
 
 
-EXPORTS = ["isaac_gpu_last_error", "isaac_gpu_create", "isaac_gpu_destroy", "isaac_gpu_malloc", "isaac_gpu_free", "isaac_gpu_upload", "isaac_gpu_download",
+EXPORTS = ["isaac_gpu_last_error", "isaac_gpu_create", "isaac_gpu_destroy", "isaac_gpu_set_params", "isaac_gpu_index_dev", "isaac_gpu_set_index_dev", "isaac_gpu_malloc", "isaac_gpu_free", "isaac_gpu_upload", "isaac_gpu_download",
            "isaac_gpu_synchronize", "isaac_gpu_set_deferred_completion", "isaac_gpu_load_contigs", "isaac_gpu_load_contigs_dev", "isaac_gpu_load_index", "isaac_gpu_build_index", "isaac_gpu_get_index", "isaac_gpu_get_index_range", "isaac_gpu_get_mask_offsets",
            "isaac_gpu_sorted_reference_parse", "isaac_gpu_sorted_reference_format", "isaac_gpu_sorted_reference_last_error", "isaac_gpu_load_sorted_reference",
            "isaac_gpu_save_sorted_reference",
@@ -165,6 +165,33 @@ class Aligner:
         out = np.zeros(n.value, abi.REFERENCE_KMER_DTYPE)
         self._check(self.lib.isaac_gpu_get_index(self.h, _p(out), C.c_uint64(n.value), C.byref(n)))
         return out
+
+    def set_params(self, params):
+        """other options / read lengths against the same resident reference and table"""
+        self._check(self.lib.isaac_gpu_set_params(self.h, C.byref(params)))
+        self.params = params
+        self.n_reads = params.n_reads
+        self.cluster_length = params.read_length[0] + params.read_length[1]
+
+    def index_tensors(self):
+        """the resident table as two int64 device tensors (k-mers, positions) that alias the library's memory: no copy"""
+        k, p, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self._check(self.lib.isaac_gpu_index_dev(self.h, C.byref(k), C.byref(p), C.byref(n)))
+
+        class _View:                      # __cuda_array_interface__: torch wraps the pointer without copying
+            def __init__(self, ptr, count):
+                self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<i8", "data": (ptr, False), "version": 2}
+        if not n.value:
+            e = self.torch.empty(0, dtype=self.torch.int64, device=self.device)
+            return e, e
+        return self.torch.as_tensor(_View(k.value, n.value), device=self.device), self.torch.as_tensor(_View(p.value, n.value), device=self.device)
+
+    def set_index_tensors(self, kmers, positions, mask_offsets=None):
+        """adopts a table held in two int64 device tensors (they are kept referenced); mask_offsets: the cuts of the mask files or None"""
+        assert kmers.dtype == self.torch.int64 and positions.dtype == self.torch.int64 and kmers.numel() == positions.numel()
+        self._borrowed_index = (kmers, positions)
+        mo = np.ascontiguousarray(mask_offsets, np.uint64) if mask_offsets is not None else None
+        self._check(self.lib.isaac_gpu_set_index_dev(self.h, _p(kmers), _p(positions), C.c_uint64(kmers.numel()), _p(mo), C.c_uint32(len(mo) - 1 if mo is not None else 0)))
 
     def set_loaded_contigs(self, loaded):
         loaded = np.ascontiguousarray(loaded, np.uint8) if loaded is not None else None

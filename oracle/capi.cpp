@@ -123,6 +123,11 @@ int oracle_ref_build_index(oracle_ref *r, uint32_t repeat_threshold, int annotat
     try { r->index = buildSortedReference(r->contigs, 32, repeat_threshold, annotate_neighbors != 0, neighborhood_width); return 0; }
     catch (const std::exception &e) { g_error = e.what(); return 1; }
 }
+int oracle_ref_build_index_mt(oracle_ref *r, uint32_t repeat_threshold, int annotate_neighbors, uint32_t neighborhood_width, uint32_t n_threads)
+{
+    try { r->index = buildSortedReference(r->contigs, 32, repeat_threshold, annotate_neighbors != 0, neighborhood_width, n_threads); return 0; }
+    catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
 // load an index in mask-file layout ({u64 kmer, u64 position} sorted by kmer)
 void oracle_ref_set_index(oracle_ref *r, const uint64_t *kmer_pos_pairs, uint64_t n)
 {

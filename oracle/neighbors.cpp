@@ -7,7 +7,9 @@
 #include "oracle.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <stdexcept>
+#include <thread>
 
 namespace oracle
 {
@@ -106,10 +108,12 @@ static void findNeighborsRange(typename std::vector<AnnotatedKmer<KmerT> >::iter
 }
 
 // NeighborsFinder.cpp:286-309: the list is cut into `jobs` stretches ending on prefix boundaries (one thread each in the
-// reference; the stretches are independent, so they are simply done one after another here)
+// reference).  The stretches are independent: they are done one after another, or by `nThreads` threads taking them in turn.
 template <typename KmerT>
-void findNeighbors(std::vector<AnnotatedKmer<KmerT> > &kmerList, unsigned jobs)
+void findNeighbors(std::vector<AnnotatedKmer<KmerT> > &kmerList, unsigned jobs, unsigned nThreads)
 {
+    typedef typename std::vector<AnnotatedKmer<KmerT> >::iterator It;
+    std::vector<std::pair<It, It> > stretches;
     const unsigned prefixShift = sizeof(KmerT) * 4;
     typename std::vector<AnnotatedKmer<KmerT> >::iterator begin = kmerList.begin();
     unsigned started = 0;
@@ -122,13 +126,19 @@ void findNeighbors(std::vector<AnnotatedKmer<KmerT> > &kmerList, unsigned jobs)
             const KmerT prefix = end->value >> prefixShift;
             while (kmerList.end() != end && prefix == (end->value >> prefixShift)) ++end;
         }
-        findNeighborsRange<KmerT>(begin, end);
+        stretches.push_back(std::make_pair(begin, end));
         begin = end; ++started;
     }
+    if (nThreads <= 1) { for (size_t i = 0; i < stretches.size(); ++i) findNeighborsRange<KmerT>(stretches[i].first, stretches[i].second); return; }
+    std::atomic<size_t> next(0);
+    std::vector<std::thread> threads;
+    for (unsigned t = 0; t < nThreads; ++t)
+        threads.emplace_back([&]() { for (size_t i = next++; i < stretches.size(); i = next++) findNeighborsRange<KmerT>(stretches[i].first, stretches[i].second); });
+    for (size_t t = 0; t < threads.size(); ++t) threads[t].join();
 }
 
-template void findNeighbors<uint32_t>(std::vector<AnnotatedKmer<uint32_t> > &, unsigned);
-template void findNeighbors<uint64_t>(std::vector<AnnotatedKmer<uint64_t> > &, unsigned);
-template void findNeighbors<unsigned __int128>(std::vector<AnnotatedKmer<unsigned __int128> > &, unsigned);
+template void findNeighbors<uint32_t>(std::vector<AnnotatedKmer<uint32_t> > &, unsigned, unsigned);
+template void findNeighbors<uint64_t>(std::vector<AnnotatedKmer<uint64_t> > &, unsigned, unsigned);
+template void findNeighbors<unsigned __int128>(std::vector<AnnotatedKmer<unsigned __int128> > &, unsigned, unsigned);
 
 } // namespace oracle

@@ -147,7 +147,7 @@ struct SortedReference
 };
 // lib/reference/ReferenceSorter.cpp:105-261 (+ neighbor flag semantics of NeighborsFinder.cpp:395-446, computed by
 // brute-force Hamming search over the permutation blocks; small genomes only)
-SortedReference buildSortedReference(const ContigList &contigs, unsigned seedLength, unsigned repeatThreshold /*1000*/, bool annotateNeighbors, unsigned neighborhoodWidth /*4*/);
+SortedReference buildSortedReference(const ContigList &contigs, unsigned seedLength, unsigned repeatThreshold /*1000*/, bool annotateNeighbors, unsigned neighborhoodWidth /*4*/, unsigned nThreads = 1);
 
 // ---------------------------------------------------------------- banded smith-waterman
 // lib/alignment/BandedSmithWaterman.cpp:36-54,84-462
@@ -428,7 +428,7 @@ std::vector<Permutate> getPermutateList(unsigned kmerBases, unsigned errorCount)
 // lib/reference/NeighborsFinder.cpp:286-383: in a list sorted by value, k-mers sharing the upper half are compared on the lower
 // half; both ends of a pair 1..4 mismatches apart get the flag.
 template <typename KmerT> struct AnnotatedKmer { KmerT value; bool hasNeighbors; bool operator<(const AnnotatedKmer &o) const { return value < o.value; } };
-template <typename KmerT> void findNeighbors(std::vector<AnnotatedKmer<KmerT> > &kmerList, unsigned jobs);
+template <typename KmerT> void findNeighbors(std::vector<AnnotatedKmer<KmerT> > &kmerList, unsigned jobs, unsigned nThreads = 1);
 
 // ---------------------------------------------------------------- seeds + matches
 // include/alignment/matchFinder/TileClusterInfo.hh:65-143: two bytes per cluster; bit 0 of byte r = read r+1 complete, the six bits

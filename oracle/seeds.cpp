@@ -2,6 +2,9 @@
 // Seed descriptor, seed generation, the reference's sort-merge-join match finder and the match sort.
 // Parity unpinned by reference tests (nothing in the reference tests MatchFinder/ExactMaskMatcher directly).
 #include "oracle.hpp"
+
+#include <omp.h>
+#include <parallel/algorithm>
 #include <algorithm>
 #include <stdexcept>
 #include <map>
@@ -411,8 +414,12 @@ void findTileMatchesParallel(const Params &p, const SortedReference &ref, const 
 // Neighbor flag (NeighborsFinder.cpp:192-244,395-446): set when another distinct reference k-mer (either strand) exists within
 // Hamming distance 1..4; found as the reference finds it (neighbors.cpp).  Small genomes only.
 
-SortedReference buildSortedReference(const ContigList &contigs, unsigned seedLength, unsigned repeatThreshold, bool annotateNeighbors, unsigned neighborhoodWidth)
+// nThreads > 1: the sorts run on that many threads (the k-mers of the neighbour lists are distinct and the first sort is stable, so the sorted
+// sequences do not depend on the algorithm) and findNeighbors works on its stretches concurrently, as the reference's
+// findNeighborsParallel does (NeighborsFinder.cpp:286-309).  The result is the same for any thread count.
+SortedReference buildSortedReference(const ContigList &contigs, unsigned seedLength, unsigned repeatThreshold, bool annotateNeighbors, unsigned neighborhoodWidth, unsigned nThreads)
 {
+    if (nThreads > 1) omp_set_num_threads(int(nThreads));
     if (32 != seedLength) throw std::invalid_argument("only 32-mers are supported");
     struct Entry { uint64_t kmer; uint64_t pos; bool fwd; };
     std::vector<Entry> all;
@@ -436,7 +443,8 @@ SortedReference buildSortedReference(const ContigList &contigs, unsigned seedLen
             }
         }
     }
-    std::stable_sort(all.begin(), all.end(), [](const Entry &a, const Entry &b) { return a.kmer < b.kmer; });
+    if (nThreads > 1) __gnu_parallel::stable_sort(all.begin(), all.end(), [](const Entry &a, const Entry &b) { return a.kmer < b.kmer; });
+    else std::stable_sort(all.begin(), all.end(), [](const Entry &a, const Entry &b) { return a.kmer < b.kmer; });
     // distinct k-mers (both strands) for the neighbor search
     std::vector<uint64_t> distinct;
     for (size_t i = 0; i < all.size(); ++i) if (distinct.empty() || distinct.back() != all[i].kmer) distinct.push_back(all[i].kmer);
@@ -451,12 +459,14 @@ SortedReference buildSortedReference(const ContigList &contigs, unsigned seedLen
         const std::vector<Permutate> permutateList = getPermutateList(32, neighborhoodWidth);
         for (size_t k = 0; k < permutateList.size(); ++k)
         {
-            for (size_t i = 0; i < kmerList.size(); ++i) kmerList[i].value = permutateList[k](kmerList[i].value);
-            std::sort(kmerList.begin(), kmerList.end());
-            findNeighbors(kmerList, 1);
+            const Permutate &permutate = permutateList[k];
+            #pragma omp parallel for if (nThreads > 1) schedule(static)
+            for (size_t i = 0; i < kmerList.size(); ++i) kmerList[i].value = permutate(kmerList[i].value);
+            if (nThreads > 1) __gnu_parallel::sort(kmerList.begin(), kmerList.end()); else std::sort(kmerList.begin(), kmerList.end());
+            findNeighbors(kmerList, nThreads > 1 ? 4 * nThreads : 1, nThreads);
         }
         for (size_t i = 0; i < kmerList.size(); ++i) kmerList[i].value = permutateList.back().reorder(kmerList[i].value);
-        std::sort(kmerList.begin(), kmerList.end());
+        if (nThreads > 1) __gnu_parallel::sort(kmerList.begin(), kmerList.end()); else std::sort(kmerList.begin(), kmerList.end());
         for (size_t i = 0; i < kmerList.size(); ++i)
         {
             if (kmerList[i].value != distinct[i]) throw std::logic_error("neighbour list out of step with the k-mer list");

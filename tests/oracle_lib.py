@@ -187,7 +187,11 @@ class OracleReference:
         except Exception:
             pass
 
-    def build_index(self, repeat_threshold=1000, annotate_neighbors=True, neighborhood_width=4):
+    def build_index(self, repeat_threshold=1000, annotate_neighbors=True, neighborhood_width=4, n_threads=1):
+        """ReferenceSorter + NeighborsFinder restated; n_threads > 1 only changes how fast (sorts and neighbour stretches in parallel)"""
+        if n_threads > 1:
+            self.o.check(self.o.lib.oracle_ref_build_index_mt(self.h, C.c_uint32(repeat_threshold), int(annotate_neighbors), C.c_uint32(neighborhood_width), C.c_uint32(n_threads)))
+            return self.index()
         self.o.check(self.o.lib.oracle_ref_build_index(self.h, C.c_uint32(repeat_threshold), int(annotate_neighbors), C.c_uint32(neighborhood_width)))
         return self.index()
 
