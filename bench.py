@@ -103,14 +103,17 @@ def launch_check(args, rank, world):
     begin, end = shard.shard_bounds(1001, rank, world)
     records = torch.full((end - begin, 4), rank, dtype=torch.uint8)
     got = shard.gather_records(records, dist, rank, world)
-    gatherer = shard.StepGather(dist, rank, world)                 # what the timed loop does per step
+    counts = [shard.shard_bounds(1001, r, world)[1] - shard.shard_bounds(1001, r, world)[0] for r in range(world)]
+    gatherer = shard.StepGather(dist, rank, world, record_counts=counts)       # what the timed loop does per step
     for step in range(2):
-        gatherer.add(records + step, torch.full((3 * (end - begin) + rank,), 16 * rank + step, dtype=torch.int32))
+        pool = torch.full((4 * (end - begin),), 16 * rank + step, dtype=torch.int32)
+        gatherer.add(records + step, pool, torch.tensor([3 * (end - begin) + rank], dtype=torch.int64))
     steps = gatherer.finish()
     dist.barrier()
     if rank == 0:
         ok = int(merged.sum()) == min(world, 8) and tls.min == 100 and sum(len(g) for g in got) == 1001 and all(int(g[0, 0]) == r for r, g in enumerate(got))
-        ok = ok and len(steps) == 2 and all(sum(len(r_) for r_ in recs) == 1001 and all(int(c_[0]) == 16 * r + st for r, c_ in enumerate(cigs)) for st, (recs, cigs) in enumerate(steps))
+        ok = ok and len(steps) == 2 and all(sum(len(r_) for r_ in recs) == 1001 and all(int(c_[0]) == 16 * r + st and len(c_) == 3 * counts[r] + r for r, c_ in enumerate(cigs))
+                                            for st, (recs, cigs) in enumerate(steps))
         emit({"launch_check": bool(ok), "n_gpus": world, "gpus_requested": args.gpus})
     dist.destroy_process_group()
 
@@ -172,8 +175,8 @@ def main():
     def buffers(n_pairs):
         n_rec = n_pairs * 2
         return (torch.empty((n_rec, abi.FRAGMENT_DTYPE.itemsize), dtype=torch.uint8, device=dev), torch.empty(n_rec * abi.MAX_CIGAR_OPS, dtype=torch.int32, device=dev),
-                torch.empty(n_rec * 4, dtype=torch.int32, device=dev))
-    out = [buffers(batches[args.warmup + s].shape[0]) for s in range(args.steps)]     # records, 40-word CIGAR slots, packed CIGARs of every step
+                torch.empty(n_rec * 4, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int64, device=dev))
+    out = [buffers(batches[args.warmup + s].shape[0]) for s in range(args.steps)]     # records, 40-word CIGAR slots, packed CIGARs of every step + their length
     # ... and the match lists of every step (the hand-over between the two phases): nothing is allocated inside the timed steps
     match_bufs = [(torch.empty((al.match_capacity(batches[args.warmup + s].shape[0]), 2), dtype=torch.int64, device=dev),
                    torch.empty(batches[args.warmup + s].shape[0] + 1, dtype=torch.int64, device=dev)) for s in range(args.steps)]
@@ -199,14 +202,14 @@ def main():
     if dist is not None:
         # the first gather of a process group sets up its point-to-point channels (most of a second): not part of the steps
         warm = shard.StepGather(dist, rank, world)
-        warm.add(torch.zeros((64, abi.FRAGMENT_DTYPE.itemsize), dtype=torch.uint8, device=dev), torch.zeros(256, dtype=torch.int32, device=dev))
+        warm.add(torch.zeros((64, abi.FRAGMENT_DTYPE.itemsize), dtype=torch.uint8, device=dev), torch.zeros(256, dtype=torch.int32, device=dev), torch.full((1,), 200, dtype=torch.int64, device=dev))
         warm.finish()
         del warm
         if rank == 0:
             # rank 0 receives world x (records + packed CIGARs) per step: the blocks are taken from the driver once, here, and handed back to
             # torch's caching allocator, so that the timed steps find them there (a fresh hipMalloc of 100s of MB costs milliseconds)
             pool = [torch.empty_like(out[s][0]) for s in range(args.steps) for _ in range(world)]
-            pool += [torch.empty(out[s][2].shape[0] // 2, dtype=torch.int32, device=dev) for s in range(args.steps) for _ in range(world)]
+            pool += [torch.empty_like(out[s][2]) for s in range(args.steps) for _ in range(world)]
             del pool
     al.synchronize()
     al.reset_timers()
@@ -223,21 +226,23 @@ def main():
         found.append((m, o))
         all_hits |= hits
     al.set_loaded_contigs(reduce_hits(all_hits))      # MatchSelector loads only contigs that received matches
-    # with several GPUs every step's records and packed CIGARs leave for rank 0 as soon as they are final, behind the later steps
-    # (shard.StepGather); one GPU packs the CIGARs of all steps at the end
-    gatherer = shard.StepGather(dist, rank, world) if dist is not None else None
-    packed = []
+    # Every step's CIGARs are packed behind its selection without a host wait (isaac_gpu_compact_cigars_async: the packed length stays on the
+    # device); with several GPUs the step's records and CIGAR pool then leave for rank 0 behind the later steps (shard.StepGather: nothing
+    # in the loop waits for the GPU or for another rank -- every rank's record count is known from the static split)
+    if dist is not None:
+        if args.scaling == "strong":
+            rec_counts = [2 * (shard.shard_bounds(args.pairs_per_step, r, world)[1] - shard.shard_bounds(args.pairs_per_step, r, world)[0]) for r in range(world)]
+        else:
+            rec_counts = [2 * args.pairs_per_step] * world
+    gatherer = shard.StepGather(dist, rank, world, record_counts=rec_counts) if dist is not None else None
     for s in range(args.steps):                       # phase 2: SelectMatchesTransition
         m, o = found[s]
         al.select(batches[args.warmup + s], m, o, tls, tile=tile_of(s), out=out[s][:2])
+        al.compact_cigars_async(out[s][0], out[s][1], out[s][2], out[s][3])
         if gatherer is not None:
-            packed.append(al.compact_cigars(out[s][0], out[s][1], out[s][2])[0])      # completes the step, its residual pass included
-            gatherer.add(out[s][0], packed[-1])
-    al.synchronize()                                  # completes the last call's wave-per-cluster pass
-    if gatherer is None:
-        packed = [al.compact_cigars(out[s][0], out[s][1], out[s][2])[0] for s in range(args.steps)]
-    else:
-        gatherer.finish()
+            gatherer.add(out[s][0], out[s][2], out[s][3])
+    al.synchronize()
+    gathered = gatherer.finish() if gatherer is not None else None
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -252,8 +257,23 @@ def main():
     else:
         pairs_total = sum(b.shape[0] for b in batches[args.warmup:])
 
+    packed = [out[s][2][:int(out[s][3].item())] for s in range(args.steps)]
+    assert all(int(out[s][3].item()) <= out[s][2].numel() for s in range(args.steps)), "a CIGAR pool of 4 words per record was too small"
     # the first timed step's result, kept for the parity check below (the PCIe-inclusive pass writes the same buffers again)
     checked_records, checked_cigars = out[0][0].clone(), packed[0].clone()
+    gather_identical = None
+    if gathered is not None and rank == 0:          # rank 0's own step as it came back through the gather
+        gather_identical = bool((gathered[0][0][0] == checked_records).all()) and bool((gathered[0][1][0] == checked_cigars).all())
+    del gathered
+    # clusters whose MAPQ arithmetic sat within 1e-11 of an integer (isaac_fragment::reserved bit 3), of every step: re-derived by the oracle below
+    flagged = []
+    for s in range(args.steps):
+        pairs_s = torch.nonzero((out[s][0].view(torch.int32)[:, 15] & 8) != 0).flatten() // 2
+        pairs_s = torch.unique(pairs_s)
+        if pairs_s.numel():
+            flagged.append((s, batches[args.warmup + s][pairs_s].cpu().numpy(),
+                            out[s][0].view(-1, 2, abi.FRAGMENT_DTYPE.itemsize)[pairs_s].reshape(-1, abi.FRAGMENT_DTYPE.itemsize).cpu().numpy()))
+    flagged_cigars = {s: packed[s].cpu().numpy().view(np.uint32) for s, _, _ in flagged}
     free_b, total_b = torch.cuda.mem_get_info(dev)
     hbm_used_gb = round((total_b - free_b) / 1e9, 1)      # everything resident at the end of the run: index, reads, records, chunk scratch
     counters = al.counters()
@@ -292,27 +312,34 @@ def main():
             torch.cuda.current_stream(dev).wait_event(ev)
             m, o, hits = al.find_matches(d, tile=tile_of(s), out=match_bufs[s])
             found.append((m, o))
+        host_n = [torch.zeros(1, dtype=torch.int64).pin_memory() for _ in range(args.steps)]
+        left = [None] * args.steps
+
+        def download_cigars(k):
+            left[k].synchronize()                         # step k is complete (the step after it is queued already: the GPU stays busy)
+            n_k = int(host_n[k].item())
+            with torch.cuda.stream(copy_stream):
+                host_cig[k][:n_k].copy_(out[k][2][:n_k], non_blocking=True)
         for s in range(args.steps):
             m, o = found[s]
             al.select(dev_in[s][0], m, o, tls, tile=tile_of(s), out=out[s][:2])
-            if s:                                           # the previous step's results leave while this step computes
-                al.synchronize()
-                p_ = al.compact_cigars(out[s - 1][0], out[s - 1][1], out[s - 1][2])[0]
-                done = torch.cuda.Event(); done.record()
-                with torch.cuda.stream(copy_stream):
-                    copy_stream.wait_event(done)
-                    host_rec[s - 1].copy_(out[s - 1][0], non_blocking=True)
-                    host_cig[s - 1][:p_.numel()].copy_(p_, non_blocking=True)
+            al.compact_cigars_async(out[s][0], out[s][1], out[s][2], out[s][3])
+            done = torch.cuda.Event(); done.record()
+            if s:
+                download_cigars(s - 1)
+            with torch.cuda.stream(copy_stream):          # the step's records and the length of its CIGAR pool leave as soon as they are final
+                copy_stream.wait_event(done)
+                host_rec[s].copy_(out[s][0], non_blocking=True)
+                host_n[s].copy_(out[s][3], non_blocking=True)
+                left[s] = torch.cuda.Event(); left[s].record(copy_stream)
+        download_cigars(args.steps - 1)
         al.synchronize()
-        p_ = al.compact_cigars(out[-1][0], out[-1][1], out[-1][2])[0]
-        host_rec[-1].copy_(out[-1][0], non_blocking=True)
-        host_cig[-1][:p_.numel()].copy_(p_, non_blocking=True)
         torch.cuda.synchronize()
         t_pcie = time.perf_counter() - tp
         same = bool((out[0][0] == checked_records).all()) and bool((out[0][2][:checked_cigars.numel()] == checked_cigars).all())
         pcie = {"reads_per_s": round(2.0 * pairs_rank / t_pcie, 1), "records_identical_to_resident_pass": same, "ms_per_step": round(1e3 * t_pcie / args.steps, 3),
                 "bytes_in_per_pair": 2 * L, "bytes_out_per_pair": round((sum(r.numel() for r in host_rec) + 4 * sum(int(p.numel()) for p in packed)) / pairs_rank, 1),
-                "note": "BCL bytes uploaded from pinned host memory ahead of the lookups, records + packed CIGARs downloaded while the next step computes"}
+                "note": "BCL bytes uploaded from pinned host memory ahead of the lookups; a step's records + packed CIGARs are downloaded on a copy stream while the next step, already queued, computes"}
 
     # ---- the output side: all steps' records as one position-sorted BAM record stream, resident in HBM; reported beside `value`
     bam_info = None
@@ -446,6 +473,23 @@ def main():
         parity = {"parity_checked_pairs": int(sample), "parity_diffs": int(n_diff)}
         if text:
             parity["first_diffs"] = text[:3]
+        # Every cluster of every step whose MAPQ arithmetic sat within 1e-11 of an integer -- the only place where the device's log10 / exp and
+        # glibc's could round a score differently -- re-derived by the oracle (glibc) from its BCL bytes and compared with the GPU's records
+        n_flagged = sum(len(b_) for _, b_, _ in flagged)
+        parity.update({"mapq_near_integer_pairs": int(n_flagged), "mapq_near_integer_checked": 0, "mapq_near_integer_diffs": 0 if not n_flagged else None})
+        if n_flagged:
+            f_bcl = np.ascontiguousarray(np.concatenate([b_ for _, b_, _ in flagged]))
+            fm, _ = ref.find_matches(p, f_bcl, len(f_bcl), tile=0, n_threads=find_threads)
+            frec, fcig, _ = ref.select(p, f_bcl, fm, otls, all_hits, tile=0, n_threads=min(cores, 16), n_clusters_hint=len(f_bcl))
+            pools, g_parts, base = [], [], 0
+            for s_, _, r_ in flagged:
+                r_ = r_.view(abi.FRAGMENT_DTYPE).reshape(-1).copy()
+                r_["cigar_offset"] += base
+                g_parts.append(r_); pools.append(flagged_cigars[s_]); base += len(flagged_cigars[s_])
+            f_diff, f_text = count_record_diffs(frec, fcig, np.concatenate(g_parts), np.concatenate(pools), ignore=("tile", "cluster_id"))
+            parity.update({"mapq_near_integer_checked": int(n_flagged), "mapq_near_integer_diffs": int(f_diff)})
+            if f_text:
+                parity["mapq_first_diffs"] = f_text[:3]
         if bam_info is not None:
             # the BAM record stream of the same pairs: GPU path on its own records against oracle/bam.cpp on the oracle's records, byte for byte
             prefix = "SYNTH:1:%d:" % tile_of(0)
@@ -467,6 +511,10 @@ def main():
                          "genome_s": round(t_genome, 1), "index_build_s": round(t_index, 1), "tls": list(tls.astuple()), "pcie_inclusive": pcie, "bam_output": bam_info},
               "roofline": roofline, "cpu_baseline": cpu, "counters": {k: int(v) for k, v in counters.items()}}
     result.update(parity)
+    import hashlib
+    result["records_sha1"] = hashlib.sha1(checked_records.cpu().numpy().tobytes() + checked_cigars.cpu().numpy().tobytes()).hexdigest()   # first timed step of rank 0
+    if gather_identical is not None:
+        result["gather_identical"] = gather_identical
     emit(result)
     if dist is not None:
         dist.destroy_process_group()

@@ -245,7 +245,8 @@ int isaac_gpu_determine_tls(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t
  * isaac_fragment::reserved: bit 2 = a fixed internal capacity was exceeded for this cluster (result not exact; counted in
  * isaac_counters::overflow_clusters), bit 1 = the reference would not have stored the template (only without --keep-unaligned),
  * bit 3 = one of the cluster's alignment scores is unsigned(floor(-10 * log10(x))) (TemplateBuilder.cpp:273,437,604-608,912-920) with the
- * argument of floor within 1e-11 of an integer: the device's log10 / exp agree with glibc's to the last ulp or so, which can move the
+ * bits 16-31 = BamTemplate::getAlignmentScore as 16 bits (0xffff: unknown), which the duplicate ranking of the BAM stage needs;
+ * [bit 3, continued] argument of floor within 1e-11 of an integer: the device's log10 / exp agree with glibc's to the last ulp or so, which can move the
  * floor only there.  A host that has to be certain re-derives exactly these clusters (counted in isaac_counters::mapq_near_integer;
  * a handful per million pairs). */
 int isaac_gpu_select(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t n_clusters, uint32_t tile,
@@ -275,12 +276,17 @@ int isaac_gpu_compact_cigars(isaac_gpu_ctx *ctx, isaac_fragment *fragments_dev, 
 int isaac_gpu_compact_cigars_async(isaac_gpu_ctx *ctx, isaac_fragment *fragments_dev, uint64_t n_records, const uint32_t *cigar_in_dev,
                                    uint32_t *cigar_out_dev, uint64_t capacity, uint64_t *n_words_out_dev);
 
-/* The output side of the path for --realign-gaps no --mark-duplicates 0: the BAM alignment records build::Build writes
+/* The output side of the path for --realign-gaps no: the BAM alignment records build::Build writes
  * (lib/build/Build.cpp, lib/build/BinSorter.cpp) from what isaac_gpu_select produced, computed where the records already are.
  *   order    PackedFragmentBuffer::orderForBam (include/build/PackedFragmentBuffer.hh:149-176): bin position, global cluster id
  *            (tile * 1000000000 + cluster, include/build/FragmentIndex.hh:33), mapped before unmapped (a shadow follows its
  *            singleton), first read before second; templates with both reads unaligned last, in (tile, cluster, read) order
  *            (--keep-unaligned back); records flagged "not stored" (isaac_fragment::reserved bit 1) are left out
+ *   duplicates  BinSorter::resolveDuplicates (lib/build/BinSorter.cpp:293-330) with DuplicatePairEndFilter over FDuplicateFilter / RSDuplicateFilter
+ *            (include/build/DuplicatePairEndFilter.hh, DuplicateFragmentIndexFiltering.hh) when isaac_bam_options asks for it: one library
+ *            (--single-library-samples with one barcode), all the tiles of the call compared with each other as if every contig were one
+ *            bin of the reference (its result depends on where its bins end); the template's rank of io::getTemplateDuplicateRank is
+ *            derived from the BCL qualities, the two records and isaac_fragment::reserved bits 16-31 (the template's alignment score)
  *   record   bam::serializeAlignment over build::FragmentAccessorBamAdapter (include/bam/Bam.hh:257-345,
  *            include/build/FragmentAccessorBamAdapter.hh:127-377) with the default tag set SM AS RG NM BC (--bam-exclude-tags ZX,ZY);
  *            bases and qualities as FragmentCollector::storeBclAndCigar keeps them (lib/alignment/matchSelector/FragmentCollector.cpp:84-111)
@@ -296,6 +302,8 @@ typedef struct
     uint32_t pessimistic_mapq;               /* --pessimistic-mapq: min instead of max of SM and AS for proper pairs */
     const char *read_group;                  /* RG:Z value: the barcode index (FragmentAccessorBamAdapter.hh:283-299); NULL = "0" */
     const char *barcode;                     /* BC:Z value: the sample sheet barcode name (:307-335); NULL = "none" */
+    uint32_t mark_duplicates;                /* --mark-duplicates (reference default 1): duplicates get BAM flag 0x400 */
+    uint32_t keep_duplicates;                /* --keep-duplicates (reference default 1): 0 leaves duplicates out of the file */
 } isaac_bam_options;
 int isaac_gpu_bam_records(isaac_gpu_ctx *ctx, const isaac_bam_tile *tiles, uint32_t n_tiles, const isaac_bam_options *options /* NULL = defaults */,
                           uint8_t *bam_dev, uint64_t capacity, uint64_t *n_bytes_out, uint64_t *n_records_out, uint64_t *unaligned_offset_out);

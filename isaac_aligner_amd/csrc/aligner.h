@@ -741,7 +741,6 @@ static_assert(sizeof(GappedJob) == 80 && sizeof(GappedResult) == 232, "gapped jo
 // per-thread scratch of the fragment stage
 struct FragmentWork
 {
-    Cand store[CAND_CAP];
     u8 order[CAND_CAP];
     u8 matchOrder[MATCH_CAP_MAX];
     u32 tflags[3 * 512];          // banded SW traceback flags, reads up to 512 cycles
@@ -783,6 +782,7 @@ ISAAC_HD void applyOrderInPlace(Cand *store, u8 *order, u32 n)
 ISAAC_HD bool buildCandidates(const DevParams &P, const u8 *clusterBcl, const Match *matches, u32 nMatches, bool trim, FragmentWork &work, ClusterFragments &out)
 {
     out.nCands[0] = out.nCands[1] = 0; out.cigarUsed = 0; out.flags = 0; out.repeatSeedsCount = 0; out.built = 0;
+    out.cands[1] = out.cands[0]; out.candCap[1] = out.candCap[0];
     STAMP_BEGIN();
     for (u32 r = 0; r < 2; ++r)
         out.endCyclesMasked[r] = (trim && r < P.nReads) ? trimLowQualityEnd(clusterBcl + P.readOffset[r], P.readLength[r], P.baseQualityCutoff) : 0;
@@ -811,7 +811,9 @@ ISAAC_HD bool buildCandidates(const DevParams &P, const u8 *clusterBcl, const Ma
     bool built = false;
     for (u32 r = 0; r < P.nReads; ++r)
     {
-        CandList l; l.store = work.store; l.order = work.order; l.n = 0; l.stored = 0; l.capacity = CAND_CAP; l.overflow = 0;
+        // the candidates are made where they stay: read 0's from the cluster's first slot, read 1's behind read 0's consolidated list
+        if (r) { out.cands[1] = out.cands[0] + out.nCands[0]; out.candCap[1] = out.candCap[0] - out.nCands[0]; }
+        CandList l; l.store = out.cands[r]; l.order = work.order; l.n = 0; l.stored = 0; l.capacity = imin(CAND_CAP, out.candCap[r]); l.overflow = 0;
         for (u32 k = 0; k < nMatches; ++k)
         {
             const Match &m = matches[work.matchOrder[k]];
@@ -840,7 +842,7 @@ ISAAC_HD bool buildCandidates(const DevParams &P, const u8 *clusterBcl, const Ma
         built = true;
         consolidateDuplicateFragments(l, false);       // alignFragments (:147-217) starts with this
         STAMP(24);
-        for (u32 i = 0; i < l.n; ++i) out.cands[r][i] = l.at(i);
+        applyOrderInPlace(out.cands[r], work.order, l.n);
         out.nCands[r] = l.n;
     }
     out.built = built;
@@ -860,7 +862,7 @@ ISAAC_HD void finishCandidates(const DevParams &P, const DevReference &R, const 
 {
     if (!out.built) return;
     STAMP_BEGIN();
-    CigarPool pool; pool.words = out.cigarPool; pool.used = 3 * (out.nCands[0] + out.nCands[1]); pool.capacity = CIGAR_POOL; pool.overflow = 0;
+    CigarPool pool; pool.words = out.cigarPool; pool.used = 3 * (out.nCands[0] + out.nCands[1]); pool.capacity = out.cigarCap; pool.overflow = 0;
     for (u32 r = 0; r < P.nReads; ++r)
     {
         const u32 n = out.nCands[r];
@@ -908,7 +910,7 @@ ISAAC_HD bool buildFragments(const DevParams &P, const DevReference &R, const u8
 // that follows it (FragmentBuilder.cpp:176-185).  The list was stored sorted by unclipped position.
 ISAAC_HD void finishSimpleIndels(const DevParams &P, const DevReference &R, const u8 *clusterBcl, ClusterFragments &out, u8 *order, Counters &cnt, const IndelStage *stage = 0)
 {
-    CigarPool pool; pool.words = out.cigarPool; pool.used = out.cigarUsed; pool.capacity = CIGAR_POOL; pool.overflow = 0;
+    CigarPool pool; pool.words = out.cigarPool; pool.used = out.cigarUsed; pool.capacity = out.cigarCap; pool.overflow = 0;
     for (u32 r = 0; r < P.nReads; ++r)
     {
         if (!(out.flags & (CLUSTER_INDEL_PENDING << r))) continue;
@@ -972,7 +974,7 @@ template <typename ProviderF>
 ISAAC_HD void finishFragments(const DevParams &P, ClusterFragments &out, ProviderF &provider, u8 *order, Counters &cnt)
 {
     if (!out.built) return;
-    CigarPool pool; pool.words = out.cigarPool; pool.used = out.cigarUsed; pool.capacity = CIGAR_POOL; pool.overflow = 0;
+    CigarPool pool; pool.words = out.cigarPool; pool.used = out.cigarUsed; pool.capacity = out.cigarCap; pool.overflow = 0;
     for (u32 r = 0; r < P.nReads; ++r)
     {
         const u32 n = out.nCands[r];

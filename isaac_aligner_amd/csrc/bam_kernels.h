@@ -17,7 +17,8 @@ struct BamTile
     const u8 *bcl; const FragmentRecord *records; const u32 *cigars; u64 firstRecord;   // index of the tile's first record among all records of the call
     u32 nRecords, nameLength; char name[64];                                             // "<flowcell>:<lane>:<tile>:" (FragmentAccessorBamAdapter::readName)
 };
-struct BamOptions { u32 nReads, readLength[2], readOffset[2], clusterLength, forcedDodgyAlignmentScore, pessimisticMapQ, barcodeLength, readGroupLength; char barcode[64], readGroup[64]; };
+struct BamOptions { u32 nReads, readLength[2], readOffset[2], clusterLength, forcedDodgyAlignmentScore, pessimisticMapQ, barcodeLength, readGroupLength; char barcode[64], readGroup[64];
+                    u32 markDuplicates, keepDuplicates; };
 
 static const u64 INSANELY_HIGH_NUMBER_OF_CLUSTERS_PER_TILE = 1000000000ull;   // include/build/FragmentIndex.hh:33
 static const u16 DODGY_ALIGNMENT_SCORE = 0xffff;                               // io::FragmentHeader::DODGY_ALIGNMENT_SCORE
@@ -80,7 +81,7 @@ struct BamLayout
 };
 
 // bam::serializeAlignment (Bam.hh:257-345): the fixed part and the section boundaries
-ISAAC_HD void bamLayout(const BamTile &t, const FragmentRecord &r, const BamOptions &o, BamLayout &l)
+ISAAC_HD void bamLayout(const BamTile &t, const FragmentRecord &r, const BamOptions &o, BamLayout &l, bool duplicate = false)
 {
     const bool aligned = !(r.flags & 2), unalignedBin = bamUnalignedBin(r), paired = r.flags & 1;
     // FragmentAccessorBamAdapter::operator(): aligned fragments and shadows carry the bin index position, unaligned templates NoMatch
@@ -91,7 +92,7 @@ ISAAC_HD void bamLayout(const BamTile &t, const FragmentRecord &r, const BamOpti
     const bool noMate = !paired || ((r.flags & 2) && (r.flags & 4));
     l.words[0] = l.total - 4; l.words[1] = u32(refId); l.words[2] = u32(pos);
     l.words[3] = (bamReg2bin(u32(pos), u32(pos) + (observed ? observed : 1)) << 16) | (bamMapq(r, o) << 8) | (nameLength + 1);
-    l.words[4] = (bamFlag(r) << 16) | (l.nCigar & 0xffff);
+    l.words[4] = ((bamFlag(r) | (duplicate ? 1024u : 0u)) << 16) | (l.nCigar & 0xffff);      // bit 10: FragmentAccessorBamAdapter.hh:357
     l.words[5] = r.readLength;
     l.words[6] = noMate ? u32(-1) : u32(refposContig(r.mateFStrandPosition));
     l.words[7] = noMate ? u32(-1) : u32(refposPosition(r.mateFStrandPosition));
@@ -160,13 +161,14 @@ __device__ inline u32 bamTileOf(const BamTile *tiles, u32 nTiles, u64 i) { u32 t
 
 // orderForBam as a 128-bit key: hi = the bin index position (unaligned templates and dropped records last), lo = global cluster id,
 // unmapped, second read
-__global__ void k_bam_keys(const BamTile *tiles, u32 nTiles, u64 nRecords, BamOptions o, u64 *keyHi, u64 *keyLo, u32 *index, u32 *bytes)
+// duplicate: the verdicts of k_dup_mark, or NULL; a duplicate is left out like a record that was never stored when --keep-duplicates is off
+__global__ void k_bam_keys(const BamTile *tiles, u32 nTiles, u64 nRecords, BamOptions o, const u8 *duplicate, u64 *keyHi, u64 *keyLo, u32 *index, u32 *bytes)
 {
     const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= nRecords) return;
     const u32 t = bamTileOf(tiles, nTiles, i);
     const FragmentRecord &r = tiles[t].records[i - tiles[t].firstRecord];
-    const bool stored = bamStored(r);
+    const bool stored = bamStored(r) && !(duplicate && duplicate[i] && !o.keepDuplicates);
     keyHi[i] = !stored ? ~u64(0) : bamUnalignedBin(r) ? ~u64(0) - 1 : r.fStrandPosition;
     keyLo[i] = ((u64(r.tile) * INSANELY_HIGH_NUMBER_OF_CLUSTERS_PER_TILE + r.clusterId) << 2) | ((r.flags & 2) ? 2u : 0u) | ((r.flags & 64) ? 1u : 0u);
     index[i] = u32(i);
@@ -183,6 +185,73 @@ __global__ void k_bam_bounds(const u64 *sortedHi, u64 n, u64 *bounds)
     if (hi >= UNALIGNED && (0 == k || before < UNALIGNED)) bounds[0] = k;
     if (hi == DROPPED && (0 == k || before < DROPPED)) bounds[1] = k;
 }
+// ---- duplicate marking (--mark-duplicates 1, --keep-duplicates): BinSorter::resolveDuplicates (lib/build/BinSorter.cpp:293-330) over all
+// records of the call.  The ends of pairs that have a bin position are ranked by the reference's comparators (include/build/
+// DuplicateFragmentIndexFiltering.hh:37-208: forward-strand ends by f-strand position, reverse-strand ends and shadows by their anchor; then
+// the mate's anchor and orientation, the library, the template's rank descending, the global cluster id) and every end that equals the
+// best one before it in position, mate anchor, mate orientation and library -- but belongs to another cluster -- is a duplicate
+// (DuplicatePairEndFilter.hh:45-107).  One library (one barcode); bins as wide as a contig, so that mates with equal anchors share a
+// storage bin.  Here: five key arrays, five stable radix passes, one pass over the sorted ends.
+// io::FragmentIndexAnchor (include/io/Fragment.hh:490-506)
+__device__ inline u64 dupAnchor(const FragmentRecord &h, const u8 *readBcl)
+{
+    if (!(h.flags & 2)) return (h.flags & 8) ? h.fStrandPosition + (u64(imax(h.observedLength, 1u) - 1) << 1) : h.fStrandPosition;
+    u64 packed = 0;                                                        // oligo::pack32BclBases of a shadow
+    for (u32 i = 0; i < 32 && i < h.readLength; ++i) packed |= u64(readBcl[i] & 3) << (2 * i);
+    return packed;
+}
+// keySmall: 0 for records that take no part, else 4 | 8 (reverse-strand end or shadow) | mate_.info_ (shadow | reverse << 1)
+__global__ void k_dup_keys(const BamTile *tiles, u32 nTiles, u64 nRecords, BamOptions o, u64 *keyPrimary, u64 *keyMate, u64 *keyRank, u64 *keyCluster, u64 *keySmall, u32 *index)
+{
+    const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= nRecords) return;
+    const u32 t = bamTileOf(tiles, nTiles, i);
+    const u64 local = i - tiles[t].firstRecord;
+    const FragmentRecord &h = tiles[t].records[local];
+    index[i] = u32(i);
+    u64 primary = 0, mate = 0, rank = 0, cluster = 0, small = 0;
+    if (bamStored(h) && (h.flags & 1) && !bamUnalignedBin(h))
+    {
+        const FragmentRecord &m = tiles[t].records[local ^ 1];          // records come in cluster order, read 0 before read 1
+        const u8 *clusterBcl = tiles[t].bcl + u64(h.clusterId) * o.clusterLength;
+        const u32 readIndex = (h.flags & 64) ? 1u : 0u;
+        // io::getTemplateDuplicateRank (Fragment.hh:66-71); an N has quality 2 (Read.cpp:56-69)
+        u32 quality = 0;
+        for (u32 b = 0; b < o.clusterLength; ++b) { const u8 v = clusterBcl[b]; quality += (v & 0xfc) ? u32(v >> 2) : 2u; }
+        const u32 score = (h.reserved >> 16) == 0xffffu ? 0xffffffffu : (h.reserved >> 16);
+        rank = (u64(quality) << 32) | u64(((u32(h.readLength) + m.readLength - (u32(h.editDistance) + m.editDistance)) << 16) | score);
+        mate = dupAnchor(m, clusterBcl + o.readOffset[1 - readIndex]);
+        const bool rs = (h.flags & 8) || (h.flags & 2);
+        primary = rs ? dupAnchor(h, clusterBcl + o.readOffset[readIndex]) : h.fStrandPosition;
+        cluster = u64(h.tile) * INSANELY_HIGH_NUMBER_OF_CLUSTERS_PER_TILE + h.clusterId;
+        small = 4u | (rs ? 8u : 0u) | ((h.flags & 4) ? 1u : 0u) | ((h.flags & 16) ? 2u : 0u);
+    }
+    keyPrimary[i] = primary; keyMate[i] = mate; keyRank[i] = ~rank /* higher rank first */; keyCluster[i] = cluster; keySmall[i] = small;
+}
+__global__ void k_dup_gather(const u64 *key, const u32 *order, u64 n, u64 *out) { const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x; if (i < n) out[i] = key[order[i]]; }
+// order: the ends sorted by (small, primary, mate anchor | rank descending, cluster).  The first end of a group is the best; the walk is
+// DuplicatePairEndFilter's loop: an end of another cluster than the last survivor is a duplicate, an end of the same cluster survives
+// and takes over ("both ends of a pair facing the same way at the same position").
+__global__ void k_dup_mark(const u32 *order, u64 n, const u64 *keyPrimary, const u64 *keyMate, const u64 *keyCluster, const u64 *keySmall, u8 *duplicate)
+{
+    const u64 k = u64(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const u32 i = order[k];
+    const u64 small = keySmall[i];
+    duplicate[i] = 0;
+    if (!small) return;
+    const u64 primary = keyPrimary[i], mate = keyMate[i];
+    if (k) { const u32 p = order[k - 1]; if (keySmall[p] == small && keyPrimary[p] == primary && keyMate[p] == mate) return; }     // not the head of its group
+    u64 last = keyCluster[i];
+    for (u64 j = k + 1; j < n; ++j)
+    {
+        const u32 e = order[j];
+        if (keySmall[e] != small || keyPrimary[e] != primary || keyMate[e] != mate) break;
+        const u64 c = keyCluster[e];
+        if (c != last) duplicate[e] = 1; else last = c;
+    }
+}
+
 // One workgroup per BAM_CHUNK_RECORDS consecutive records of the file.  Everything is done by threads that each own a small piece of a
 // record, so that a vector instruction works on 64 pieces at once (the first versions gave a record to a whole wave, which then issued the
 // few hundred instructions of its irregular parts -- name, tags -- for that one record: 1.4 ns per record, instruction issue bound):
@@ -255,7 +324,7 @@ __device__ inline void bamWriteBases(u32 segment, const BamLayout &l, u8 *to)
 }
 
 __global__ void __launch_bounds__(256) k_bam_encode(const BamTile *tiles, u32 nTiles, u64 nRecords, BamOptions o, const u32 *order, const u64 *offsets, const u64 *bytes,
-                                                    u8 *out, u64 capacity, BamChunkLds lds)
+                                                    const u8 *duplicate, u8 *out, u64 capacity, BamChunkLds lds)
 {
     extern __shared__ __attribute__((aligned(16))) u8 image[];
     __shared__ BamLayout layouts[BAM_CHUNK_RECORDS];
@@ -284,8 +353,9 @@ __global__ void __launch_bounds__(256) k_bam_encode(const BamTile *tiles, u32 nT
         else t = bamTileOf(tiles, nTiles, i);
         const FragmentRecord r = tiles[t].records[i - tiles[t].firstRecord];
         BamLayout l;
-        bool write = bamStored(r);
-        if (write) { bamLayout(tiles[t], r, o, l); write = at + l.total <= capacity; }
+        const bool dup = duplicate && duplicate[i];
+        bool write = bamStored(r) && !(dup && !o.keepDuplicates);
+        if (write) { bamLayout(tiles[t], r, o, l, dup && o.markDuplicates); write = at + l.total <= capacity; }
         if (write) { layouts[threadIdx.x] = l; imageAt[threadIdx.x] = u32(at - begin); }
         tileOfRecord[threadIdx.x] = write ? t : ~0u;
     }

@@ -125,13 +125,13 @@ ISAAC_HD u32 clusterPlanRescue(const DevParams &P, const DevReference &R, const 
 }
 
 // ungapped alignment of one rescue candidate position (the body of the loop at ShadowAligner.cpp:206-231)
-ISAAC_HD void rescueAlignCandidate(const DevParams &P, const DevReference &R, const u8 *bcl, u32 cluster, const ClusterFragments &frags, const RescueJob &job, i32 relativePosition,
+ISAAC_HD void rescueAlignCandidate(const DevParams &P, const DevReference &R, const u8 *bcl, u32 cluster, u32 endCyclesMasked, const RescueJob &job, i32 relativePosition,
                                    Cand &out, u32 *cigar3)
 {
     ReadView shadowRead;
     const u32 r = job.shadowReadIndex;
     shadowRead.bcl = bcl + u64(cluster) * P.clusterLength + P.readOffset[r]; shadowRead.length = P.readLength[r];
-    shadowRead.firstCycle = P.firstCycle[r]; shadowRead.endCyclesMasked = frags.endCyclesMasked[r];
+    shadowRead.firstCycle = P.firstCycle[r]; shadowRead.endCyclesMasked = endCyclesMasked;
     CigarPool pool; pool.words = cigar3; pool.used = 0; pool.capacity = 3; pool.overflow = 0;
     candInit(out, r);
     out.reverse = job.shadowReverse; out.contigId = job.contigId; out.position = i64(relativePosition) + job.windowBegin;
@@ -188,6 +188,7 @@ ISAAC_HD void clusterSelect(const DevParams &P, const DevReference &R, const Dev
         if (frags.flags & CLUSTER_OVERFLOW) r.reserved |= RECORD_FRAGMENT_OVERFLOW;
         if (!store) r.reserved |= RECORD_NOT_STORED;
         if (x.mapqNearInteger) r.reserved |= RECORD_MAPQ_NEAR_INTEGER;
+        r.reserved |= (t.alignmentScore >= 0xffffu ? 0xffffu : t.alignmentScore) << 16;      // BamTemplate::getAlignmentScore for io::getTemplateDuplicateRank (bam_kernels.h)
     }
     STAMP(32);
 }

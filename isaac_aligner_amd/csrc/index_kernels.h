@@ -200,13 +200,15 @@ __global__ void k_distinct(const u64 *keys, u64 n, const u32 *head, const u32 *r
 // ---- neighbour annotation ------------------------------------------------------------------------------------------
 // out byte j = in byte sel[j] (sel packed 4 bits per byte, byte 0 = least significant)
 struct ByteShuffle { u32 selLo, selHi; };   // v_perm_b32 selectors over {hi word, lo word} of the key
+// (grid-stride: a human genome has 5.8 G distinct k-mers, and a launch holds fewer than 2^32 work-items)
 __global__ void k_shuffle_keys(u64 *keys, u64 n, ByteShuffle s)
 {
-    const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const u64 v = keys[i];
-    const u32 lo = __builtin_amdgcn_perm(u32(v >> 32), u32(v), s.selLo), hi = __builtin_amdgcn_perm(u32(v >> 32), u32(v), s.selHi);
-    keys[i] = u64(lo) | (u64(hi) << 32);
+    for (u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += u64(gridDim.x) * blockDim.x)
+    {
+        const u64 v = keys[i];
+        const u32 lo = __builtin_amdgcn_perm(u32(v >> 32), u32(v), s.selLo), hi = __builtin_amdgcn_perm(u32(v >> 32), u32(v), s.selHi);
+        keys[i] = u64(lo) | (u64(hi) << 32);
+    }
 }
 __device__ inline u32 baseDistance32(u32 a, u32 b) { u32 x = a ^ b; x = (x | (x >> 1)) & 0x55555555u; return u32(__popc(x)); }
 // NeighborsFinder::markNeighbors (:395-446) for keys grouped by their LOW 32 bits (the chosen blocks; rocPRIM 4.2 missorts small
@@ -215,23 +217,27 @@ __device__ inline u32 baseDistance32(u32 a, u32 b) { u32 x = a ^ b; x = (x | (x 
 // the first hit.
 __global__ void k_mark_neighbors(const u64 *keys, u8 *flags, u64 n)
 {
-    const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n || flags[i]) return;
-    const u64 mine = keys[i];
-    const u32 group = u32(mine), rest = u32(mine >> 32);
-    for (u64 j = i + 1; j < n; ++j)
+    for (u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += u64(gridDim.x) * blockDim.x)
     {
-        const u64 o = keys[j];
-        if (u32(o) != group) break;
-        const u32 d = baseDistance32(rest, u32(o >> 32));
-        if (d && d <= 4) { flags[i] = 1; return; }
-    }
-    for (u64 j = i; j-- > 0;)
-    {
-        const u64 o = keys[j];
-        if (u32(o) != group) break;
-        const u32 d = baseDistance32(rest, u32(o >> 32));
-        if (d && d <= 4) { flags[i] = 1; return; }
+        if (flags[i]) continue;
+        const u64 mine = keys[i];
+        const u32 group = u32(mine), rest = u32(mine >> 32);
+        bool found = false;
+        for (u64 j = i + 1; j < n && !found; ++j)
+        {
+            const u64 o = keys[j];
+            if (u32(o) != group) break;
+            const u32 d = baseDistance32(rest, u32(o >> 32));
+            found = d && d <= 4;
+        }
+        for (u64 j = i; !found && j-- > 0;)
+        {
+            const u64 o = keys[j];
+            if (u32(o) != group) break;
+            const u32 d = baseDistance32(rest, u32(o >> 32));
+            found = d && d <= 4;
+        }
+        if (found) flags[i] = 1;
     }
 }
 // table entries take the flag of their k-mer: entry i of mask m belongs to distinct k-mer distinctBase[m] + entryRun[i]

@@ -71,20 +71,23 @@ struct isaac_gpu_ctx
     DevBuf<double> logTables;
     // work
     DevBuf<Match> staging; DevBuf<u32> counts, chunkOffsets; DevBuf<u8> cubTemp; DevBuf<u32> contigHits; std::vector<u32> hContigHits;
-    DevBuf<ClusterFragments> frags; ClusterFragments *fragsCur = nullptr; DevBuf<FragmentWork> fragWork;
+    // the chunk's candidates: 32 B of ClusterMeta per cluster, one slot per seed match in the candidate pool, the cigar arena (types.h)
+    DevBuf<ClusterMeta> clusterMeta; DevBuf<Cand> candPool; DevBuf<u32> cigarArena, cigarNext; ClusterPools pools; DevBuf<FragmentWork> fragWork;
+    struct KnownTotal { const void *offsets; u32 nClusters; u64 total; }; std::vector<KnownTotal> knownTotals;   // match counts of recent isaac_gpu_find_matches calls, by offsets buffer
     DevBuf<GappedJob> gappedJobs, rescueGappedJobs; DevBuf<GappedResult> gappedResults, rescueGappedResults; DevBuf<u32> gappedBase, gappedCounters;
     DevBuf<u8> heavyArena; DevBuf<u32> overflowList; DevBuf<u32> overflowCount; DevBuf<ClusterSums> clusterSums; DevBuf<u32> mediumList, largeList, xlList, hugeList, longJobs; DevBuf<u8> hugeKeys;
     DevBuf<TlsSample> tlsSamples; DevBuf<u32> cigarLengths, cigarOffsets; DevBuf<u64> cigarTotal;
     DevBuf<CrcConstants> crcConstants; bool crcReady = false;    // isaac_gpu_bgzf_store
     // isaac_gpu_bam_records scratch
     DevBuf<BamTile> bamTiles; DevBuf<u64> bamKeyHi, bamKeyLo, bamKeyAlt, bamOffsets, bamBytes64, bamBounds; DevBuf<u32> bamIndex, bamIndexAlt, bamBytes;
+    DevBuf<u64> dupPrimary, dupMate, dupRank, dupCluster, dupSmall; DevBuf<u8> dupFlag;        // duplicate marking
     DevBuf<RescueJob> jobs; DevBuf<u32> rescueCounters, bitmaps, candJob, shadowCigars, jobBase, jobCount; DevBuf<i32> candPositions; DevBuf<Cand> shadowCands; DevBuf<u32> candRank;
     DevBuf<Counters> counters;
     std::map<std::string, KernelTimer> timers;
     struct PendingTimer { std::string name; hipEvent_t e0, e1; };
     std::vector<PendingTimer> pendingTimers; std::vector<hipEvent_t> eventPool;
     // one chunk of a select call as the wave-per-cluster pass (k_select_heavy) sees it
-    struct ChunkDesc { const uint8_t *bcl = nullptr; u32 clusterBase = 0, tile = 0; ClusterFragments *frags = nullptr; FragmentRecord *records = nullptr; u32 *cigars = nullptr; DevTls tls; RogCorrection rog; };
+    struct ChunkDesc { const uint8_t *bcl = nullptr; u32 clusterBase = 0, tile = 0; FragmentRecord *records = nullptr; u32 *cigars = nullptr; DevTls tls; RogCorrection rog; };
     bool deferredCompletion = false;
     u32 selectCapacity = 0;        // chunk size the buffers of the select stage were last sized for
     DevBuf<u32> heavyList, heavyCount, indelList, alignList; DevBuf<u8> heavyFlag;
@@ -312,29 +315,29 @@ __global__ void k_compact_matches(const Match *staging, const u32 *counts, const
     for (u32 i = 0; i < n; ++i) if (at + i < capacity) out[at + i] = src[i];
 }
 
-__global__ void k_tls_samples(const ClusterFragments *frags, const u64 *offsets, u32 clusterBase, u32 nChunk, TlsSample *samples)
+__global__ void k_tls_samples(ClusterPools pools, const u64 *offsets, u32 clusterBase, u32 nChunk, TlsSample *samples)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nChunk) return;
-    clusterTlsSample(frags[t], u32(offsets[clusterBase + t + 1] - offsets[clusterBase + t]), samples[t]);
+    clusterTlsSample(clusterView(pools.meta[t], pools.cands, pools.cigars), u32(offsets[clusterBase + t + 1] - offsets[clusterBase + t]), samples[t]);
 }
 
 // candidates of the chunk -> compact ABI records; one thread per cluster, offsets from an exclusive scan of the counts
-__global__ void k_count_candidates(const ClusterFragments *frags, u32 nChunk, u32 *nCands, u32 *nCigar)
+__global__ void k_count_candidates(ClusterPools pools, u32 nChunk, u32 *nCands, u32 *nCigar)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nChunk) return;
-    const ClusterFragments &f = frags[t];
+    const ClusterFragments f = clusterView(pools.meta[t], pools.cands, pools.cigars);
     u32 n = f.nCands[0] + f.nCands[1], c = 0;
     for (u32 r = 0; r < 2; ++r) for (u32 i = 0; i < f.nCands[r]; ++i) c += f.cands[r][i].cigarLength;
     nCands[t] = n; nCigar[t] = c;
 }
-__global__ void k_write_candidates(const ClusterFragments *frags, u32 clusterBase, u32 nChunk, const u32 *candOffsets, const u32 *cigarOffsets, u64 candBase, u64 cigarBase,
+__global__ void k_write_candidates(ClusterPools pools, u32 clusterBase, u32 nChunk, const u32 *candOffsets, const u32 *cigarOffsets, u64 candBase, u64 cigarBase,
                                    isaac_candidate *out, u64 capacity, u32 *cigarOut, u64 cigarCapacity)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nChunk) return;
-    const ClusterFragments &f = frags[t];
+    const ClusterFragments f = clusterView(pools.meta[t], pools.cands, pools.cigars);
     u64 at = candBase + candOffsets[t], cat = cigarBase + cigarOffsets[t];
     for (u32 r = 0; r < 2; ++r) for (u32 i = 0; i < f.nCands[r]; ++i, ++at)
     {
@@ -355,41 +358,60 @@ __global__ void k_write_candidates(const ClusterFragments *frags, u32 clusterBas
     }
 }
 
-// the inverse of k_write_candidates: ClusterFragments from caller-supplied candidate lists (isaac_gpu_select_candidates)
+// the inverse of k_write_candidates: the chunk's pools from caller-supplied candidate lists (isaac_gpu_select_candidates): a cluster owns
+// as many slots as the caller lists candidates for it, read 0's before read 1's
 __global__ void k_load_candidates(DevParams P, const u8 *bcl, u32 clusterBase, u32 nChunk, const isaac_candidate *cands, const u64 *candOffsets, const u32 *cigarIn, int trim,
-                                  ClusterFragments *frags)
+                                  ClusterPools pools)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nChunk) return;
-    ClusterFragments &f = frags[t];
-    f.nCands[0] = f.nCands[1] = 0; f.cigarUsed = 0; f.flags = 0; f.repeatSeedsCount = 0; f.built = 0;
+    const u64 chunkBegin = candOffsets[clusterBase], begin = candOffsets[clusterBase + t], end = candOffsets[clusterBase + t + 1];
+    const u32 first = u32(begin - chunkBegin);
+    const u32 cap = (u64(first) + (end - begin) <= pools.candCap && end - begin <= 2 * CAND_CAP) ? u32(end - begin) : 0u;
+    ClusterFragments f = clusterViewNew(first, cap, pools.cands, pools.cigars);
+    if (cap != end - begin) f.flags |= CLUSTER_OVERFLOW;
     const u8 *clusterBcl = bcl + u64(clusterBase + t) * P.clusterLength;
     for (u32 r = 0; r < 2; ++r)
         f.endCyclesMasked[r] = (trim && r < P.nReads) ? trimLowQualityEnd(clusterBcl + P.readOffset[r], P.readLength[r], P.baseQualityCutoff) : 0;
-    const u64 begin = candOffsets[clusterBase + t], end = candOffsets[clusterBase + t + 1];
-    CigarPool pool; pool.words = f.cigarPool; pool.used = 0; pool.capacity = CIGAR_POOL; pool.overflow = 0;
-    for (u64 i = begin; i < end; ++i)
+    u32 words = 0;
+    for (u64 i = begin; i < begin + cap; ++i) words += cands[i].cigar_length;
+    if (words > f.cigarCap) clusterCigarExtra(f, pools.cigars, 3 * pools.candCap + atomicAdd(pools.cigarNext, words), words, pools.cigarCap);
+    CigarPool pool; pool.words = f.cigarPool; pool.used = f.cigarUsed; pool.capacity = f.cigarCap; pool.overflow = 0;
+    for (u32 r = 0; r < 2; ++r)
     {
-        const isaac_candidate &o = cands[i];
-        const u32 r = o.read_index & 1;
-        if (f.nCands[r] == CAND_CAP) { f.flags |= CLUSTER_OVERFLOW; continue; }
-        Cand &k = f.cands[r][f.nCands[r]++];
-        candInit(k, r);
-        k.position = o.position; k.logProbability = o.log_probability; k.contigId = o.contig_id; k.observedLength = o.observed_length; k.reverse = o.reverse != 0;
-        k.mismatchCount = u16(o.mismatch_count); k.matchesInARow = u16(o.matches_in_a_row); k.gapCount = u16(o.gap_count); k.editDistance = u16(o.edit_distance);
-        k.smithWatermanScore = o.smith_waterman_score; k.uniqueSeedCount = u16(o.unique_seed_count);
-        k.nonUniqueFirst = o.non_unique_first == 0xffffffffu ? NON_UNIQUE_NONE : u16(o.non_unique_first); k.nonUniqueSecond = u16(o.non_unique_second);
-        k.repeatSeedsCount = u16(o.repeat_seeds_count); k.lowClipped = u16(o.low_clipped); k.highClipped = u16(o.high_clipped); k.firstSeedIndex = (signed char)o.first_seed_index;
-        k.cigarOffset = pool.used; k.cigarLength = u16(o.cigar_length);
-        for (u32 w = 0; w < o.cigar_length; ++w) pool.push(cigarIn[o.cigar_offset + w]);
-        f.repeatSeedsCount = o.repeat_seeds_count;
-        f.built = 1;
+        if (r) { f.cands[1] = f.cands[0] + f.nCands[0]; f.candCap[1] = f.candCap[0] - f.nCands[0]; }
+        for (u64 i = begin; i < begin + cap; ++i)
+        {
+            const isaac_candidate &o = cands[i];
+            if ((o.read_index & 1) != r) continue;
+            if (f.nCands[r] == CAND_CAP) { f.flags |= CLUSTER_OVERFLOW; continue; }
+            Cand &k = f.cands[r][f.nCands[r]++];
+            candInit(k, r);
+            k.position = o.position; k.logProbability = o.log_probability; k.contigId = o.contig_id; k.observedLength = o.observed_length; k.reverse = o.reverse != 0;
+            k.mismatchCount = u16(o.mismatch_count); k.matchesInARow = u16(o.matches_in_a_row); k.gapCount = u16(o.gap_count); k.editDistance = u16(o.edit_distance);
+            k.smithWatermanScore = o.smith_waterman_score; k.uniqueSeedCount = u16(o.unique_seed_count);
+            k.nonUniqueFirst = o.non_unique_first == 0xffffffffu ? NON_UNIQUE_NONE : u16(o.non_unique_first); k.nonUniqueSecond = u16(o.non_unique_second);
+            k.repeatSeedsCount = u16(o.repeat_seeds_count); k.lowClipped = u16(o.low_clipped); k.highClipped = u16(o.high_clipped); k.firstSeedIndex = (signed char)o.first_seed_index;
+            k.cigarOffset = pool.used; k.cigarLength = u16(o.cigar_length);
+            for (u32 w = 0; w < o.cigar_length; ++w) pool.push(cigarIn[o.cigar_offset + w]);
+            f.repeatSeedsCount = o.repeat_seeds_count;
+            f.built = 1;
+        }
     }
     f.cigarUsed = pool.used;
     if (pool.overflow) f.flags |= CLUSTER_OVERFLOW;
+    clusterViewStore(f, pools.cands, pools.meta[t]);
 }
 
-u32 gridFor(u64 n, u32 block) { return u32((n + block - 1) / block); }
+u32 gridFor(u64 n, u32 block)
+{
+    // a launch holds fewer than 2^32 work-items (the dispatch packet counts them in 32 bits): anything that can be larger must use gridStrided
+    const u64 blocks = (n + block - 1) / block;
+    if (blocks * block >= (u64(1) << 32)) throw std::invalid_argument("launch of 2^32 work-items or more");
+    return u32(blocks);
+}
+// for grid-stride kernels over arrays that may hold 2^32 elements and more
+u32 gridStrided(u64 n, u32 block) { return u32(std::min<u64>((n + block - 1) / block, (u64(1) << 22))); }
 
 template <typename T> void exclusiveSum(isaac_gpu_ctx *c, const T *in, T *out, size_t n)
 {
@@ -742,7 +764,7 @@ int isaac_gpu_build_index(isaac_gpu_ctx *c, uint32_t repeatThreshold, int annota
         {
             u32 src[8];                                                // out byte next[b] = current byte at[b]
             for (u32 b = 0; b < 8; ++b) src[next[b]] = at[b];
-            k_shuffle_keys<<<gridFor(nDistinct, 256), 256, 0, st>>>(dk.Current(), nDistinct, makeShuffle(src));
+            k_shuffle_keys<<<gridStrided(nDistinct, 256), 256, 0, st>>>(dk.Current(), nDistinct, makeShuffle(src));
             for (u32 b = 0; b < 8; ++b) at[b] = next[b];
         };
         auto sortKeys = [&](int endBit)
@@ -758,7 +780,7 @@ int isaac_gpu_build_index(isaac_gpu_ctx *c, uint32_t repeatThreshold, int annota
             u32 next[8]; blockLayout(chosen, next);
             shuffleTo(next);
             sortKeys(32);                                              // groups of equal chosen blocks
-            k_mark_neighbors<<<gridFor(nDistinct, 256), 256, 0, st>>>(dk.Current(), df.Current(), nDistinct);
+            k_mark_neighbors<<<gridStrided(nDistinct, 256), 256, 0, st>>>(dk.Current(), df.Current(), nDistinct);
             HIP_CHECK(hipGetLastError());
         }
         u32 identity[8]; for (u32 b = 0; b < 8; ++b) identity[b] = b;
@@ -920,6 +942,12 @@ int isaac_gpu_find_matches(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClust
     if (contigHasMatches) for (u32 i = 0; i < c->nContigs; ++i) contigHasMatches[i] |= u8(c->hContigHits[i] != 0);
     if (nMatchesOut) *nMatchesOut = base;
     if (base > capacity) return fail(ISAAC_GPU_ECAPACITY, "matches_dev is too small");
+    {   // isaac_gpu_select sizes its candidate pool by this without asking the device
+        auto &known = c->knownTotals;
+        known.erase(std::remove_if(known.begin(), known.end(), [&](const isaac_gpu_ctx::KnownTotal &k) { return k.offsets == clusterOffsets; }), known.end());
+        if (known.size() >= 64) known.erase(known.begin());
+        known.push_back({ clusterOffsets, nClusters, base });
+    }
     return 0;
     ISAAC_CATCH
 }
@@ -957,39 +985,61 @@ static void launchGappedJobs(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clusterBa
 }
 
 // the calls that run the fragment stage alone write the first of the two ClusterFragments buffers, sized for the chunk in use
-static void useFragments(isaac_gpu_ctx *c) { c->frags.reserve(c->chunkNow); c->fragsCur = c->frags.p; }
+// The candidate pools of the chunk in use (types.h: ClusterMeta, candidate pool, cigar arena).  `slots` bounds the seed matches (or
+// caller-supplied candidates) of any chunk of the call; 0 = not known, the hard bound of seeds x strands x (repeat threshold - 1)
+// per cluster is taken then (4.6 KB per cluster at 2x150 -- still a fifth of the fixed records this replaced).
+static void preparePools(isaac_gpu_ctx *c, u64 slots)
+{
+    const u64 perCluster = 2 * u64(c->P.nSeeds) * std::max(1u, c->P.repeatThreshold - 1);
+    const u64 hard = u64(c->chunkNow) * perCluster;
+    const u64 cap = std::max<u64>(slots ? slots : hard, 64);
+    if (3 * cap + 32 * u64(c->chunkNow) >= (u64(1) << 32)) throw std::invalid_argument("too many candidates in one chunk");
+    c->clusterMeta.reserve(c->chunkNow); c->candPool.reserve(cap); c->cigarArena.reserve(3 * cap + 32 * u64(c->chunkNow)); c->cigarNext.reserve(1);
+    c->pools.meta = c->clusterMeta.p; c->pools.cands = c->candPool.p; c->pools.cigars = c->cigarArena.p; c->pools.candCap = u32(cap);
+    c->pools.cigarCap = u32(3 * cap + 32 * u64(c->chunkNow)); c->pools.cigarNext = c->cigarNext.p;
+}
+// entries [0] and [n] of a device array of offsets (a host wait: only the calls outside the timed path use it)
+static u64 offsetsSpan(isaac_gpu_ctx *c, const uint64_t *offsetsDev, u32 n)
+{
+    u64 ends[2] = { 0, 0 };
+    HIP_CHECK(hipMemcpyAsync(&ends[0], offsetsDev, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipMemcpyAsync(&ends[1], offsetsDev + n, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return ends[1] - ends[0];
+}
 
 static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clusterBase, u32 n, const isaac_match *matches, const uint64_t *offsets, int withGaps, int trim)
 {
-    // c->fragsCur (the ClusterFragments buffer of this chunk) is the caller's choice: see useFragments / selectFromSource
+    // c->pools: see preparePools
+    HIP_CHECK(hipMemsetAsync(c->cigarNext.p, 0, 4, c->stream));
     c->fragWork.reserve(c->chunkNow); c->indelList.reserve(c->chunkNow);
     const GappedBuffers gb = gappedBuffers(c, 0);
     HIP_CHECK(hipMemsetAsync(c->gappedCounters.p, 0, 16, c->stream));
     AlignList al; al.cap = 8 * c->chunkNow; c->alignList.reserve(al.cap); al.entries = c->alignList.p; al.counter = c->gappedCounters.p + 3;
     {
         ScopedTimer t(c, "build_fragments");
-        k_build_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, bcl, clusterBase, n, reinterpret_cast<const Match *>(matches), offsets, trim, c->fragWork.p, c->fragsCur, al);
+        k_build_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, bcl, clusterBase, n, reinterpret_cast<const Match *>(matches), offsets, trim, c->fragWork.p, c->pools, al);
         HIP_CHECK(hipGetLastError());
     }
     {
         ScopedTimer t(c, "align_candidates");
-        k_align_candidates<<<4096, 256, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, c->fragsCur, al, c->counters.p);
+        k_align_candidates<<<4096, 256, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, c->pools, al, c->counters.p);
         HIP_CHECK(hipGetLastError());
     }
     {
         ScopedTimer t(c, "finish_candidates");
-        k_finish_candidates<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, withGaps, c->indelList.p, c->gappedCounters.p + 2, c->fragWork.p, c->fragsCur, gb, c->counters.p);
+        k_finish_candidates<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, withGaps, c->indelList.p, c->gappedCounters.p + 2, c->fragWork.p, c->pools, gb, c->counters.p);
         HIP_CHECK(hipGetLastError());
     }
     {
         ScopedTimer t(c, "indel_fragments");
-        k_indel_fragments<<<8192, 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, withGaps, c->indelList.p, c->gappedCounters.p + 2, c->fragWork.p, c->fragsCur, gb, c->counters.p);
+        k_indel_fragments<<<8192, 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, withGaps, c->indelList.p, c->gappedCounters.p + 2, c->fragWork.p, c->pools, gb, c->counters.p);
         HIP_CHECK(hipGetLastError());
     }
     if (withGaps) launchGappedJobs(c, bcl, clusterBase, gb, "gapped_fragments");
     {
         ScopedTimer t(c, "finish_fragments");
-        k_finish_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, withGaps, c->fragWork.p, c->fragsCur, gb, c->counters.p);
+        k_finish_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, withGaps, c->fragWork.p, c->pools, gb, c->counters.p);
         HIP_CHECK(hipGetLastError());
     }
 }
@@ -1003,7 +1053,7 @@ int isaac_gpu_build_fragments(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nCl
     HIP_CHECK(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const u32 chunk = chunkFor(c, nClusters);
-    useFragments(c);
+    preparePools(c, nClusters ? offsetsSpan(c, offsets, nClusters) : 0);
     DevBuf<u32> nc, ng, oc, og; nc.reserve(chunk); ng.reserve(chunk); oc.reserve(chunk); og.reserve(chunk);
     u64 candBase = 0, cigarBase = 0;
     for (u32 done = 0; done < nClusters; done += chunk)
@@ -1011,9 +1061,9 @@ int isaac_gpu_build_fragments(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nCl
         const u32 n = std::min(chunk, nClusters - done);
         launchBuildFragments(c, bcl, done, n, matches, offsets, withGaps, trim);
         if (!candidates) continue;
-        k_count_candidates<<<gridFor(n, 256), 256, 0, st>>>(c->fragsCur, n, nc.p, ng.p);
+        k_count_candidates<<<gridFor(n, 256), 256, 0, st>>>(c->pools, n, nc.p, ng.p);
         exclusiveSum(c, nc.p, oc.p, n); exclusiveSum(c, ng.p, og.p, n);
-        k_write_candidates<<<gridFor(n, 256), 256, 0, st>>>(c->fragsCur, done, n, oc.p, og.p, candBase, cigarBase, candidates, capacity, cigar, cigarCapacity);
+        k_write_candidates<<<gridFor(n, 256), 256, 0, st>>>(c->pools, done, n, oc.p, og.p, candBase, cigarBase, candidates, capacity, cigar, cigarCapacity);
         u32 a[4];
         HIP_CHECK(hipMemcpyAsync(a + 0, oc.p + n - 1, 4, hipMemcpyDeviceToHost, st)); HIP_CHECK(hipMemcpyAsync(a + 1, nc.p + n - 1, 4, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipMemcpyAsync(a + 2, og.p + n - 1, 4, hipMemcpyDeviceToHost, st)); HIP_CHECK(hipMemcpyAsync(a + 3, ng.p + n - 1, 4, hipMemcpyDeviceToHost, st));
@@ -1039,13 +1089,13 @@ int isaac_gpu_determine_tls(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
     {
         const u32 chunk = std::min<u32>(chunkFor(c, std::min<u32>(nClusters, 65536)), 65536);
         c->tlsSamples.reserve(chunk);
-        useFragments(c);
+        preparePools(c, 0);
         std::vector<TlsSample> h(chunk);
         for (u32 done = 0; done < nClusters && !learner.stats.stable; done += chunk)
         {
             const u32 n = std::min(chunk, nClusters - done);
             launchBuildFragments(c, bcl, done, n, matches, offsets, 0, 0);     // MatchSelector.cpp:233-245: no gaps, no quality trimming
-            k_tls_samples<<<gridFor(n, 256), 256, 0, st>>>(c->fragsCur, offsets, done, n, c->tlsSamples.p);
+            k_tls_samples<<<gridFor(n, 256), 256, 0, st>>>(c->pools, offsets, done, n, c->tlsSamples.p);
             HIP_CHECK(hipMemcpyAsync(h.data(), c->tlsSamples.p, size_t(n) * sizeof(TlsSample), hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
             for (u32 i = 0; i < n && !learner.stats.stable; ++i) learner.add(h[i]);
@@ -1071,7 +1121,7 @@ static void launchHeavy(isaac_gpu_ctx *c, const isaac_gpu_ctx::ChunkDesc &p, con
     RescueBuffers rb; std::memset(&rb, 0, sizeof(rb));
     rb.jobs = c->jobs.p; rb.shadowCands = c->shadowCands.p; rb.candRank = c->candRank.p; rb.shadowCigars = c->shadowCigars.p; rb.jobBase = c->jobBase.p; rb.jobCount = c->jobCount.p;
     ScopedTimer tm(c, timer);
-    k_select_heavy<<<std::max(1u, blocks), 64, HEAVY_SORT_LDS * 2, c->stream>>>(c->P, c->ref(), p.tls, p.rog, logMismatchQ40(), p.bcl, p.clusterBase, 0, countDev, p.tile, p.frags, c->heavyArena.p, heavyBytes, heavy,
+    k_select_heavy<<<std::max(1u, blocks), 64, HEAVY_SORT_LDS * 2, c->stream>>>(c->P, c->ref(), p.tls, p.rog, logMismatchQ40(), p.bcl, p.clusterBase, 0, countDev, p.tile, c->pools, c->heavyArena.p, heavyBytes, heavy,
                                                                                  list, rb, c->rescueGappedResults.p, c->rescueGappedJobs.p, sumsKnown ? c->clusterSums.p : nullptr, p.records, p.cigars, c->counters.p);
     HIP_CHECK(hipGetLastError());
 }
@@ -1113,7 +1163,13 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         HIP_CHECK(hipGetLastError());
     }
     const GappedBuffers gbRescue = gappedBuffers(c, 1);
-    c->frags.reserve(chunk); c->fragsCur = c->frags.p;
+    {   // how many candidate slots a chunk can need: the tile's match count when a recent isaac_gpu_find_matches call on this offsets buffer
+        // told (no host wait), the caller's candidate count for explicit lists, else the hard per-cluster bound
+        u64 slots = 0;
+        if (source.candidates) slots = nClusters ? offsetsSpan(c, source.candidateOffsets, nClusters) : 0;
+        else for (const auto &k : c->knownTotals) if (k.offsets == source.offsets && k.nClusters == nClusters) slots = std::max<u64>(k.total, 1);
+        preparePools(c, slots);
+    }
     for (u32 done = 0; done < nClusters; done += chunk)
     {
         const u32 n = std::min(chunk, nClusters - done);
@@ -1121,8 +1177,9 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         {
             gappedBuffers(c, 0);
             HIP_CHECK(hipMemsetAsync(c->gappedCounters.p, 0, 16, st));      // launchBuildFragments does this on the other path
+            HIP_CHECK(hipMemsetAsync(c->cigarNext.p, 0, 4, st));
             ScopedTimer tm(c, "load_candidates");
-            k_load_candidates<<<gridFor(n, 256), 256, 0, st>>>(c->P, bcl, done, n, source.candidates, source.candidateOffsets, source.candidateCigars, 1, c->fragsCur);
+            k_load_candidates<<<gridFor(n, 256), 256, 0, st>>>(c->P, bcl, done, n, source.candidates, source.candidateOffsets, source.candidateCigars, 1, c->pools);
             HIP_CHECK(hipGetLastError());
         }
         else launchBuildFragments(c, bcl, done, n, source.matches, source.offsets, 1, 1);
@@ -1133,7 +1190,7 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         HIP_CHECK(hipMemsetAsync(c->heavyFlag.p, 0, n, st));
         {
             ScopedTimer tm(c, "plan_rescue");
-            k_plan_rescue<<<gridFor(n, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, n, c->fragsCur, rb);
+            k_plan_rescue<<<gridFor(n, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, n, c->pools, rb);
             HIP_CHECK(hipGetLastError());
         }
         {
@@ -1143,40 +1200,40 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         }
         {
             ScopedTimer tm(c, "rescue_align");
-            k_rescue_align<<<gridFor(rb.candCap, 256), 256, 0, st>>>(c->P, R, bcl, done, c->fragsCur, rb, c->counters.p);
+            k_rescue_align<<<gridFor(rb.candCap, 256), 256, 0, st>>>(c->P, R, bcl, done, c->pools, rb, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }
         {
             ScopedTimer tm(c, "rescue_gapped_plan");
-            k_rescue_gapped_plan<<<gridFor(rb.jobsCap, 256), 256, 0, st>>>(c->fragsCur, rb, gbRescue, c->longJobs.p, c->rescueCounters.p + 2, c->counters.p);
-            k_rescue_gapped_plan_long<<<2048, 256, 0, st>>>(c->fragsCur, rb, gbRescue, c->longJobs.p, c->rescueCounters.p + 2);
+            k_rescue_gapped_plan<<<gridFor(rb.jobsCap, 256), 256, 0, st>>>(c->pools, rb, gbRescue, c->longJobs.p, c->rescueCounters.p + 2, c->counters.p);
+            k_rescue_gapped_plan_long<<<2048, 256, 0, st>>>(c->pools, rb, gbRescue, c->longJobs.p, c->rescueCounters.p + 2);
             HIP_CHECK(hipGetLastError());
         }
         launchGappedJobs(c, bcl, done, gbRescue, "gapped_rescue");
         {
             ScopedTimer tm(c, "sums_wave");
-            k_cluster_sums16<<<gridFor(n, 16), 256, 0, st>>>(c->P, c->fragsCur, n, rb, gbRescue, sb, c->counters.p);
-            k_cluster_sums<<<8192, 256, 0, st>>>(c->P, c->fragsCur, rb, gbRescue, sb, c->counters.p);
+            k_cluster_sums16<<<gridFor(n, 16), 256, 0, st>>>(c->P, c->pools, n, rb, gbRescue, sb, c->counters.p);
+            k_cluster_sums<<<8192, 256, 0, st>>>(c->P, c->pools, rb, gbRescue, sb, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }
         {
             ScopedTimer tm(c, "sums_large");
-            k_cluster_sums_large<<<2048, 256, 0, st>>>(c->P, c->fragsCur, rb, gbRescue, sb, c->counters.p);
+            k_cluster_sums_large<<<2048, 256, 0, st>>>(c->P, c->pools, rb, gbRescue, sb, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }
         {
             ScopedTimer tm(c, "sums_xl");
-            k_cluster_sums_xl<<<256, 1024, SUMS_XL_LDS, st>>>(c->P, c->fragsCur, rb, gbRescue, sb, c->counters.p);
+            k_cluster_sums_xl<<<256, 1024, SUMS_XL_LDS, st>>>(c->P, c->pools, rb, gbRescue, sb, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }
         {
             ScopedTimer tm(c, "sums_huge");
-            k_cluster_sums_huge<<<SUMS_HUGE_BLOCKS, 1024, 0, st>>>(c->P, c->fragsCur, rb, gbRescue, sb, c->counters.p);
+            k_cluster_sums_huge<<<SUMS_HUGE_BLOCKS, 1024, 0, st>>>(c->P, c->pools, rb, gbRescue, sb, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }
         {
             ScopedTimer tm(c, "select");
-            k_select<<<gridFor(n, 64), 64, 0, st>>>(c->templateConstants.p, R, lmq40, bcl, done, n, tile, c->fragsCur, rb, gbRescue.results, gbRescue.jobs, c->clusterSums.p,
+            k_select<<<gridFor(n, 64), 64, 0, st>>>(c->templateConstants.p, R, lmq40, bcl, done, n, tile, c->pools, rb, gbRescue.results, gbRescue.jobs, c->clusterSums.p,
                                                      reinterpret_cast<FragmentRecord *>(fragments), cigar, c->overflowList.p, c->overflowCount.p, c->heavyFlag.p, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }
@@ -1185,7 +1242,7 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         // read their count on the device and are launched whatever it is -- nearly always zero, a few microseconds -- so that the host never
         // waits for the GPU inside a call: it used to read the two counts back and decide, which cost an idle gap per call.
         isaac_gpu_ctx::ChunkDesc chunkDesc;
-        chunkDesc.bcl = bcl; chunkDesc.clusterBase = done; chunkDesc.tile = tile; chunkDesc.frags = c->fragsCur;
+        chunkDesc.bcl = bcl; chunkDesc.clusterBase = done; chunkDesc.tile = tile; 
         chunkDesc.records = reinterpret_cast<FragmentRecord *>(fragments); chunkDesc.cigars = cigar; chunkDesc.tls = t; chunkDesc.rog = rog;
         launchHeavy(c, chunkDesc, c->heavyList.p, c->heavyCount.p, 1024u, "select_heavy", false);
         launchHeavy(c, chunkDesc, c->overflowList.p, c->overflowCount.p, 1024u, "select_residual", true);
@@ -1287,6 +1344,7 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
     std::strcpy(o.readGroup, readGroup); o.readGroupLength = u32(std::strlen(readGroup)); std::strcpy(o.barcode, barcode); o.barcodeLength = u32(std::strlen(barcode));
     o.forcedDodgyAlignmentScore = options ? (options->forced_dodgy_alignment_score & 0xff) : (u32(c->params.dodgy_alignment_score) & 0xff);
     o.pessimisticMapQ = options ? options->pessimistic_mapq : 0;
+    o.markDuplicates = options ? (options->mark_duplicates != 0) : 0; o.keepDuplicates = options ? (options->keep_duplicates != 0) : 1;
     std::vector<BamTile> h(nTiles);
     u64 n = 0;
     for (u32 t = 0; t < nTiles; ++t)
@@ -1309,9 +1367,28 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
     HIP_CHECK(hipMemcpyAsync(c->bamTiles.p, h.data(), sizeof(BamTile) * nTiles, hipMemcpyHostToDevice, st));
     const u64 bounds0[2] = { n, n };
     HIP_CHECK(hipMemcpyAsync(c->bamBounds.p, bounds0, sizeof(bounds0), hipMemcpyHostToDevice, st));
+    const u8 *duplicate = nullptr;
+    if (o.markDuplicates || !o.keepDuplicates)
+    {   // BinSorter::resolveDuplicates: the verdict per record, before the records are ordered (bam_kernels.h)
+        ScopedTimer t(c, "bam_duplicates");
+        c->dupPrimary.reserve(n); c->dupMate.reserve(n); c->dupRank.reserve(n); c->dupCluster.reserve(n); c->dupSmall.reserve(n); c->dupFlag.reserve(n);
+        k_dup_keys<<<gridFor(n, 256), 256, 0, st>>>(c->bamTiles.p, nTiles, n, o, c->dupPrimary.p, c->dupMate.p, c->dupRank.p, c->dupCluster.p, c->dupSmall.p, c->bamIndex.p);
+        // stable passes from the least significant key up; the keys of a pass are gathered in the order the previous one left
+        u32 *from = c->bamIndex.p, *to = c->bamIndexAlt.p;
+        const struct { const u64 *key; int bits; } passes[5] = { { c->dupCluster.p, 64 }, { c->dupRank.p, 64 }, { c->dupMate.p, 64 }, { c->dupPrimary.p, 64 }, { c->dupSmall.p, 4 } };
+        for (const auto &pass : passes)
+        {
+            k_dup_gather<<<gridFor(n, 256), 256, 0, st>>>(pass.key, from, n, c->bamKeyLo.p);
+            sortPairs(c, c->bamKeyLo.p, c->bamKeyAlt.p, from, to, n, pass.bits);
+            std::swap(from, to);
+        }
+        k_dup_mark<<<gridFor(n, 256), 256, 0, st>>>(from, n, c->dupPrimary.p, c->dupMate.p, c->dupCluster.p, c->dupSmall.p, c->dupFlag.p);
+        HIP_CHECK(hipGetLastError());
+        duplicate = c->dupFlag.p;
+    }
     {
         ScopedTimer t(c, "bam_order");
-        k_bam_keys<<<gridFor(n, 256), 256, 0, st>>>(c->bamTiles.p, nTiles, n, o, c->bamKeyHi.p, c->bamKeyLo.p, c->bamIndex.p, c->bamBytes.p);
+        k_bam_keys<<<gridFor(n, 256), 256, 0, st>>>(c->bamTiles.p, nTiles, n, o, duplicate, c->bamKeyHi.p, c->bamKeyLo.p, c->bamIndex.p, c->bamBytes.p);
         // two stable passes: by (global cluster id, unmapped, second read), then by bin position
         sortPairs(c, c->bamKeyLo.p, c->bamKeyAlt.p, c->bamIndex.p, c->bamIndexAlt.p, n);
         k_bam_gather_hi<<<gridFor(n, 256), 256, 0, st>>>(c->bamKeyHi.p, c->bamIndexAlt.p, n, c->bamKeyLo.p);
@@ -1331,7 +1408,7 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
         lds.chunkBytes = std::min<u32>(bamChunkImageBytes(maxRead, maxName + 13, 28 + o.readGroupLength + o.barcodeLength), 96 * 1024);
         const size_t dynamicBytes = (lds.chunkBytes + 16 + 15) & ~15u;
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bam_encode), hipFuncAttributeMaxDynamicSharedMemorySize, int(dynamicBytes)));
-        k_bam_encode<<<gridFor(n, BAM_CHUNK_RECORDS), 256, dynamicBytes, st>>>(c->bamTiles.p, nTiles, n, o, c->bamIndex.p, c->bamOffsets.p, c->bamBytes64.p, bam, capacity, lds);
+        k_bam_encode<<<gridFor(n, BAM_CHUNK_RECORDS), 256, dynamicBytes, st>>>(c->bamTiles.p, nTiles, n, o, c->bamIndex.p, c->bamOffsets.p, c->bamBytes64.p, duplicate, bam, capacity, lds);
     }
     HIP_CHECK(hipGetLastError());
     u64 lastOffset = 0, lastBytes = 0, bounds[2] = { 0, 0 };

@@ -19,16 +19,21 @@ __device__ inline void emitGappedJobs(const ClusterFragments &f, u32 cl, bool wi
 // Fragment stage, step 1: matches -> candidate positions (buildCandidates), and one entry per candidate in the flat list
 // k_align_candidates works through.  The list space of a wave is taken with one atomic.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_build_fragments(DevParams P, const u8 *bcl, u32 clusterBase, u32 nChunk, const Match *matches, const u64 *offsets,
-                                                        int trim, FragmentWork *work, ClusterFragments *frags, AlignList al)
+                                                        int trim, FragmentWork *work, ClusterPools pools, AlignList al)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     u32 cl = 0, n = 0;
+    ClusterFragments f;
     if (t < nChunk)
     {
         cl = t;
-        const u64 begin = offsets[clusterBase + cl], end = offsets[clusterBase + cl + 1];
-        buildCandidates(P, bcl + u64(clusterBase + cl) * P.clusterLength, matches + begin, u32(end - begin), trim != 0, work[t], frags[cl]);
-        n = frags[cl].nCands[0] + frags[cl].nCands[1];
+        // the cluster's slots: one per seed match, at the offset of its first match in the chunk
+        const u64 chunkBegin = offsets[clusterBase], begin = offsets[clusterBase + cl], end = offsets[clusterBase + cl + 1];
+        const u32 first = u32(begin - chunkBegin);
+        const u32 cap = (u64(first) + (end - begin) <= pools.candCap) ? u32(end - begin) : 0u;     // a pool that is too small shows as CLUSTER_OVERFLOW
+        f = clusterViewNew(first, cap, pools.cands, pools.cigars);
+        buildCandidates(P, bcl + u64(clusterBase + cl) * P.clusterLength, matches + begin, u32(end - begin), trim != 0, work[t], f);
+        n = f.nCands[0] + f.nCands[1];
     }
     // exclusive prefix of n over the wave, one allocation for all of it
     u32 incl = n;
@@ -42,15 +47,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGME
         u32 at = base + incl - n;
         if (base + total > al.cap)
         {   // no room: the cluster aligns its own candidates later; what the wave took of the list is marked unused
-            frags[cl].flags |= CLUSTER_ALIGN_PENDING;
+            f.flags |= CLUSTER_ALIGN_PENDING;
             for (u32 k = 0; k < n; ++k) if (at + k < al.cap) al.entries[at + k] = 0xffffffffu;
         }
-        else for (u32 r = 0; r < 2; ++r) for (u32 i = 0; i < frags[cl].nCands[r]; ++i) al.entries[at++] = (cl << 8) | (r << 7) | i;
+        else for (u32 r = 0; r < 2; ++r) for (u32 i = 0; i < f.nCands[r]; ++i) al.entries[at++] = (cl << 8) | (r << 7) | i;
     }
+    if (t < nChunk) clusterViewStore(f, pools.cands, pools.meta[cl]);
 }
 
 // step 2: UngappedAligner::alignUngapped, one candidate per thread
-__global__ __launch_bounds__(256) void k_align_candidates(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, ClusterFragments *frags, AlignList al, Counters *counters)
+__global__ __launch_bounds__(256) void k_align_candidates(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, ClusterPools pools, AlignList al, Counters *counters)
 {
     ISAAC_STAGE_QUALITY_TABLES(Rg, R)
     Counters local; memset(&local, 0, sizeof(local));
@@ -59,7 +65,8 @@ __global__ __launch_bounds__(256) void k_align_candidates(DevParams P, DevRefere
     {
         const u32 e = al.entries[j], cl = e >> 8;
         if (0xffffffffu == e) continue;
-        alignCandidate(P, R, bcl + u64(clusterBase + cl) * P.clusterLength, frags[cl], (e >> 7) & 1, e & 127, local);
+        ClusterFragments f = clusterView(pools.meta[cl], pools.cands, pools.cigars);      // the candidate and its three cigar words are written in place; the cluster's state is not touched
+        alignCandidate(P, R, bcl + u64(clusterBase + cl) * P.clusterLength, f, (e >> 7) & 1, e & 127, local);
     }
     flushCounters(local, counters);
 }
@@ -68,7 +75,7 @@ __global__ __launch_bounds__(256) void k_align_candidates(DevParams P, DevRefere
 // 3-4 % of clusters with a candidate pair for the single-indel detector, an entry for k_indel_fragments: inside this kernel
 // nearly every wave would hold one such lane and wait for it
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_finish_candidates(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, u32 nChunk,
-                                                        int withGaps, u32 *indelList, u32 *indelCount, FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters)
+                                                        int withGaps, u32 *indelList, u32 *indelCount, FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters)
 {
     ISAAC_STAGE_QUALITY_TABLES(Rg, R)
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -76,7 +83,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGME
     if (t < nChunk)
     {
         const u32 cl = t;
-        ClusterFragments &f = frags[cl];
+        ClusterFragments f = clusterView(pools.meta[cl], pools.cands, pools.cigars);
         const u8 *clusterBcl = bcl + u64(clusterBase + cl) * P.clusterLength;
         if (f.flags & CLUSTER_ALIGN_PENDING)
         {
@@ -86,6 +93,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGME
         finishCandidates(P, R, clusterBcl, work[t], f, local, true);
         if (clusterSimpleIndelsPending(f)) indelList[atomicAdd(indelCount, 1u)] = cl;
         else emitGappedJobs(f, cl, withGaps != 0, gb);
+        clusterViewStore(f, pools.cands, pools.meta[cl]);
     }
     flushCounters(local, counters);
 }
@@ -94,7 +102,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGME
 // One wave per cluster, every lane executing the same statements (as in k_select_heavy): the detector is a chain of dependent
 // byte loads, and 64 different clusters per wave would spread them over more cache lines than the L1 holds.
 __global__ __launch_bounds__(64) void k_indel_fragments(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, int withGaps, const u32 *indelList, const u32 *indelCount,
-                                                        FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters)
+                                                        FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters)
 {
     ISAAC_STAGE_QUALITY_TABLES(Rg, R)
     __shared__ __align__(16) u8 stageBcl[512];
@@ -105,24 +113,50 @@ __global__ __launch_bounds__(64) void k_indel_fragments(DevParams P, DevReferenc
     for (u32 t = blockIdx.x; t < n; t += gridDim.x)
     {
         const u32 cl = indelList[t];
-        clusterFinishSimpleIndels(P, R, bcl, clusterBase + cl, work[blockIdx.x], frags[cl], local, &stage);
+        ClusterFragments f = clusterView(pools.meta[cl], pools.cands, pools.cigars);       // the same view in every lane
+        // an accepted single indel writes a CIGAR of up to five words; there is at most one per neighbouring pair of a list
+        const u32 need = 5 * (f.nCands[0] + f.nCands[1]);
+        u32 at = 0;
+        if (0 == threadIdx.x) at = 3 * pools.candCap + atomicAdd(pools.cigarNext, need);
+        at = __shfl(at, 0, 64);
+        clusterCigarExtra(f, pools.cigars, at, need, pools.cigarCap);
+        clusterFinishSimpleIndels(P, R, bcl, clusterBase + cl, work[blockIdx.x], f, local, &stage);
         __syncthreads();
-        if (0 == threadIdx.x) emitGappedJobs(frags[cl], cl, withGaps != 0, gb);
+        if (0 == threadIdx.x) { emitGappedJobs(f, cl, withGaps != 0, gb); clusterViewStore(f, pools.cands, pools.meta[cl]); }
     }
     if (0 != threadIdx.x) memset(&local, 0, sizeof(local));   // every lane counted the same events
     flushCounters(local, counters);
 }
 
 __global__ __launch_bounds__(64) void k_finish_fragments(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, u32 nChunk, int withGaps,
-                                                         FragmentWork *work, ClusterFragments *frags, GappedBuffers gb, Counters *counters)
+                                                         FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     Counters local; memset(&local, 0, sizeof(local));
+    ClusterFragments f;
+    const GappedResult *res = nullptr;
+    u32 need = 0;
     if (t < nChunk)
     {
-        const u32 cl = t;
-        const GappedResult *res = (withGaps && gb.base[cl] != 0xffffffffu) ? gb.results + gb.base[cl] : nullptr;
-        clusterFinishFragments(P, R, bcl, clusterBase + cl, withGaps != 0, res, work[t], frags[cl], local);
+        f = clusterView(pools.meta[t], pools.cands, pools.cigars);
+        const u32 nJobs = countGappedJobs(f, withGaps != 0);
+        res = (nJobs && gb.base[t] != 0xffffffffu) ? gb.results + gb.base[t] : nullptr;
+        // room for the CIGARs of the gapped alignments that may be accepted (all of them at most; 40 words each when they are still to run)
+        if (res) for (u32 k = 0; k < nJobs; ++k) { const u32 w = res[k].nCigar; need += (0xffffffffu == w) ? 0u : w; }
+        else need = 40 * nJobs;
+    }
+    // one bump of the arena's counter per wave
+    u32 incl = need;
+    for (u32 o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o, 64); if ((threadIdx.x & 63) >= o) incl += v; }
+    const u32 total = __shfl(incl, 63, 64);
+    u32 base = 0;
+    if ((threadIdx.x & 63) == 63 && total) base = atomicAdd(pools.cigarNext, total);
+    base = __shfl(base, 63, 64);
+    if (t < nChunk)
+    {
+        if (need) clusterCigarExtra(f, pools.cigars, 3 * pools.candCap + base + incl - need, need, pools.cigarCap);
+        clusterFinishFragments(P, R, bcl, clusterBase + t, withGaps != 0, res, work[t], f, local);
+        clusterViewStore(f, pools.cands, pools.meta[t]);
     }
     flushCounters(local, counters);
 }

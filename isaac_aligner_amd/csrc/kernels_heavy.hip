@@ -5,7 +5,7 @@
 // clusters whose placements overflowed k_select's private lists).  All 64 lanes execute the template logic together on one arena
 // (same statements, same data), which costs what one thread costs; the bulk steps (probability sorts) are spread over the lanes.
 __global__ __launch_bounds__(64) void k_select_heavy(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nList, const u32 *nListDev, u32 tile,
-                                                     const ClusterFragments *frags, u8 *arena, u64 arenaBytes, TemplateCaps caps, const u32 *list, RescueBuffers rb, const GappedResult *gappedResults, const GappedJob *gappedJobs,
+                                                     ClusterPools pools, u8 *arena, u64 arenaBytes, TemplateCaps caps, const u32 *list, RescueBuffers rb, const GappedResult *gappedResults, const GappedJob *gappedJobs,
                                                      const ClusterSums *sums, FragmentRecord *records, u32 *cigars, Counters *counters)
 {
     extern __shared__ __align__(16) u8 heavyLds[];
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(64) void k_select_heavy(DevParams P, DevReference R
         pin = &in;
     }
     CoopInputs coop; coop.lanes = 64; coop.lane = threadIdx.x; coop.fastSort = true; coop.ldsSort = reinterpret_cast<u16 *>(heavyLds); coop.ldsSortCap = HEAVY_SORT_LDS;
-    clusterSelect(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + inChunk, tile, frags[inChunk], work, records, cigars, local, pin, &coop);
+    clusterSelect(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + inChunk, tile, clusterView(pools.meta[inChunk], pools.cands, pools.cigars), work, records, cigars, local, pin, &coop);
     if (work.overflow) ++local.overflowClusters;   // even the reference's own capacities were exceeded
     ++local.heavyClusters;
     __syncthreads();                                 // the arena is reused by the block's next cluster

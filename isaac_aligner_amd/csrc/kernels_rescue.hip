@@ -2,17 +2,18 @@
 #include "kernels.h"
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_PLAN_WAVES))) void k_plan_rescue(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk,
-                                                    const ClusterFragments *frags, RescueBuffers rb)
+                                                    ClusterPools pools, RescueBuffers rb)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nChunk) return;
+    const ClusterFragments f = clusterView(pools.meta[t], pools.cands, pools.cigars);
     __attribute__((aligned(16))) u8 workBytes[TINY_WORK_BYTES];
     TemplateWork work;
     templateWorkBind(work, workBytes, tinyCaps());
     Cand privateCands[2 * PRIVATE_CANDS];
     // Every seeded candidate is an orphan at most once, so their number bounds the cluster's rescue problems: the slots are
     // reserved first and the template logic runs once, writing the problems as it meets them (unused slots stay invalid)
-    const u32 reserve = frags[t].built ? frags[t].nCands[0] + frags[t].nCands[1] : 0;
+    const u32 reserve = f.built ? f.nCands[0] + f.nCands[1] : 0;
     u32 base = 0, n = 0;
     if (reserve)
     {
@@ -20,12 +21,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_PLAN_W
         if (base + reserve > rb.jobsCap)
         {   // the cluster runs its rescues itself in the wave-per-cluster pass
             base = 0xffffffffu;
-            n = clusterPlanRescue(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + t, t, frags[t], work, nullptr, privateCands);
+            n = clusterPlanRescue(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + t, t, f, work, nullptr, privateCands);
         }
         else
         {
             RescueJob *jobs = rb.jobs + base;
-            n = clusterPlanRescue(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + t, t, frags[t], work, jobs, privateCands);
+            n = clusterPlanRescue(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + t, t, f, work, jobs, privateCands);
             for (u32 i = n; i < reserve; ++i) { jobs[i].valid = 0; jobs[i].fallback = 0; jobs[i].nCands = 0; jobs[i].nGapped = 0; }
             for (u32 i = 0; i < n; ++i)
             {
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
     STAMP(7);
 }
 
-__global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const ClusterFragments *frags, RescueBuffers rb, Counters *counters)
+__global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, ClusterPools pools, RescueBuffers rb, Counters *counters)
 {
     ISAAC_STAGE_QUALITY_TABLES(Rg, R)
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference 
     if (i < rb.candCap && i % rb.candRegionSize < imin(imin(rb.candCounter[i / rb.candRegionSize], rb.candCounter[CAND_REGIONS + i / rb.candRegionSize]), rb.candRegionSize))
     {
         const RescueJob &job = rb.jobs[rb.candJob[i]];
-        rescueAlignCandidate(P, R, bcl, clusterBase + job.cluster, frags[job.cluster], job, rb.candPositions[i], rb.shadowCands[i], rb.shadowCigars + u64(i) * 3);
+        rescueAlignCandidate(P, R, bcl, clusterBase + job.cluster, pools.meta[job.cluster].endCyclesMasked[job.shadowReadIndex], job, rb.candPositions[i], rb.shadowCands[i], rb.shadowCigars + u64(i) * 3);
         ++local.ungappedScans;
     }
     flushCounters(local, counters);
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference 
 // long candidate lists (repeat families: thousands of entries) would keep one thread walking them long after the rest of the
 // grid has finished; they are listed for k_rescue_gapped_plan_long instead.
 static const u32 GAPPED_PLAN_LONG = 48;
-__global__ __launch_bounds__(256) void k_rescue_gapped_plan(const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, u32 *longList, u32 *longCount, Counters *counters)
+__global__ __launch_bounds__(256) void k_rescue_gapped_plan(ClusterPools pools, RescueBuffers rb, GappedBuffers gb, u32 *longList, u32 *longCount, Counters *counters)
 {
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     const u32 nJobs = imin(*rb.jobCounter, rb.jobsCap);
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(256) void k_rescue_gapped_plan(const ClusterFragmen
         else
         {
             summarizeRescueJob(job, rb.shadowCands, rb.candRank);
-            const u32 ecm = frags[job.cluster].endCyclesMasked[job.shadowReadIndex];
+            const u32 ecm = pools.meta[job.cluster].endCyclesMasked[job.shadowReadIndex];
             const u32 n = job.nGapped;      // counted by the summary pass; the candidates are walked again only to write the problems
             u32 base = 0;
             if (n)
@@ -373,7 +374,7 @@ __device__ inline double laneValue(double v, int k) { return __longlong_as_doubl
 
 // summarizeRescueJob + planRescueGapped (template.h) by one wavefront: 64 candidates are fetched at a time, the statements that
 // depend on the order of the list run over register values instead of one memory round trip per candidate.
-__global__ __launch_bounds__(256) void k_rescue_gapped_plan_long(const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, const u32 *longList, const u32 *longCount)
+__global__ __launch_bounds__(256) void k_rescue_gapped_plan_long(ClusterPools pools, RescueBuffers rb, GappedBuffers gb, const u32 *longList, const u32 *longCount)
 {
     const u32 lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
     const u32 nLong = *longCount;
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(256) void k_rescue_gapped_plan_long(const ClusterFr
         }
         if (nGapped && 0xffffffffu != base)
         {
-            const u32 ecm = frags[job.cluster].endCyclesMasked[job.shadowReadIndex];
+            const u32 ecm = pools.meta[job.cluster].endCyclesMasked[job.shadowReadIndex];
             u32 emitted = 0; bool havePrev = false; u32 carryC = 0; i64 carryPosition = 0; u32 carryMismatches = 0;
             for (u32 c0 = 0; c0 < job.nCands; c0 += 64)
             {

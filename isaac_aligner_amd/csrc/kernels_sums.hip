@@ -129,7 +129,7 @@ template <u32 W> __device__ inline u32 clusterSumsWave(const DevParams &P, const
 }
 
 // lists of up to 16 entries (most clusters): a quarter of a wavefront per cluster.  What does not fit goes to k_cluster_sums.
-__global__ __launch_bounds__(256) void k_cluster_sums16(DevParams P, const ClusterFragments *frags, u32 nChunk, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters)
+__global__ __launch_bounds__(256) void k_cluster_sums16(DevParams P, ClusterPools pools, u32 nChunk, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters)
 {
     __shared__ __align__(16) u8 keyBytes[16][SUMS_QUARTER_CAP * 42 + 16];
     __shared__ u64 tabPos[16][SUMS_QUARTER_CAP]; __shared__ double tabLp[16][SUMS_QUARTER_CAP]; __shared__ u32 tabObs[16][SUMS_QUARTER_CAP]; __shared__ u8 tabJob[16][SUMS_QUARTER_CAP];
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_cluster_sums16(DevParams P, const Clust
             SumGroup g; g.lanes = 16; g.lane = lane; g.block = false; g.radix = SumRadix{nullptr, nullptr, nullptr, nullptr, nullptr, 0}; g.radixMin = 0; g.sumTile = nullptr; g.sumTileCap = 0;
             ClusterSums out;
             ShadowTable tab; tab.pos = tabPos[group]; tab.lp = tabLp[group]; tab.obs = tabObs[group]; tab.job = tabJob[group];
-            const u32 status = clusterSumsWave<16>(P, frags[t], sumInputs(rb, t, gb), keys, tab, g, out, local);
+            const u32 status = clusterSumsWave<16>(P, clusterView(pools.meta[t], pools.cands, pools.cigars), sumInputs(rb, t, gb), keys, tab, g, out, local);
             if (0 == lane)
             {
                 if (SUMS_DONE == status) sb.sums[t] = out;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void k_cluster_sums16(DevParams P, const Clust
 }
 
 // lists of up to 64 entries: a wavefront per cluster of the list k_cluster_sums16 left
-__global__ __launch_bounds__(256) void k_cluster_sums(DevParams P, const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters)
+__global__ __launch_bounds__(256) void k_cluster_sums(DevParams P, ClusterPools pools, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters)
 {
     __shared__ __align__(16) u8 keyBytes[4][SUMS_WAVE_CAP * 42];
     __shared__ u64 tabPos[4][SUMS_WAVE_CAP]; __shared__ double tabLp[4][SUMS_WAVE_CAP]; __shared__ u32 tabObs[4][SUMS_WAVE_CAP]; __shared__ u8 tabJob[4][SUMS_WAVE_CAP];
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void k_cluster_sums(DevParams P, const Cluster
         SumGroup g; g.lanes = 64; g.lane = lane; g.block = false; g.radix = SumRadix{nullptr, nullptr, nullptr, nullptr, nullptr, 0}; g.radixMin = 0; g.sumTile = nullptr; g.sumTileCap = 0;
         ClusterSums out;
         ShadowTable tab; tab.pos = tabPos[wave]; tab.lp = tabLp[wave]; tab.obs = tabObs[wave]; tab.job = tabJob[wave];
-        const u32 status = clusterSumsWave<64>(P, frags[t], sumInputs(rb, t, gb), keys, tab, g, out, local);
+        const u32 status = clusterSumsWave<64>(P, clusterView(pools.meta[t], pools.cands, pools.cigars), sumInputs(rb, t, gb), keys, tab, g, out, local);
         if (0 == lane)
         {
             if (SUMS_DONE == status) sb.sums[t] = out;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void k_cluster_sums(DevParams P, const Cluster
     flushCounters(local, counters);
 }
 
-__global__ __launch_bounds__(256) void k_cluster_sums_large(DevParams P, const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters)
+__global__ __launch_bounds__(256) void k_cluster_sums_large(DevParams P, ClusterPools pools, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters)
 {
     __shared__ __align__(16) u8 keyBytes[SUMS_BLOCK_CAP * 42];
     __shared__ u32 scratch;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void k_cluster_sums_large(DevParams P, const C
         SumKeys keys; sumKeysBind(keys, keyBytes, SUMS_BLOCK_CAP);
         SumGroup g; g.lanes = 256; g.lane = threadIdx.x; g.block = true; g.radix = SumRadix{nullptr, nullptr, nullptr, nullptr, nullptr, 0}; g.radixMin = 0; g.sumTile = nullptr; g.sumTileCap = 0;
         ClusterSums out;
-        const u32 status = clusterSums(P, frags[t], sumInputs(rb, t, gb), keys, g, &scratch, false, out, local);
+        const u32 status = clusterSums(P, clusterView(pools.meta[t], pools.cands, pools.cigars), sumInputs(rb, t, gb), keys, g, &scratch, false, out, local);
         if (0 == threadIdx.x)
         {
             if (SUMS_DONE == status) { sb.sums[t] = out; ++local.largeSums; }
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void k_cluster_sums_large(DevParams P, const C
 }
 
 // lists of up to 3584 entries: 1024 lanes per cluster, the keys in 147 KB of the CU's 160 KB of LDS
-__global__ __launch_bounds__(1024) void k_cluster_sums_xl(DevParams P, const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters)
+__global__ __launch_bounds__(1024) void k_cluster_sums_xl(DevParams P, ClusterPools pools, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters)
 {
     extern __shared__ __align__(16) u8 xlKeyBytes[];
     __shared__ u32 scratch;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(1024) void k_cluster_sums_xl(DevParams P, const Clu
         const u32 t = sb.xlList[i];
         SumGroup g; g.lanes = 1024; g.lane = threadIdx.x; g.block = true; g.radix = SumRadix{nullptr, nullptr, nullptr, nullptr, nullptr, 0}; g.radixMin = 0; g.sumTile = nullptr; g.sumTileCap = 0;
         ClusterSums out;
-        const u32 status = clusterSums(P, frags[t], sumInputs(rb, t, gb), keys, g, &scratch, false, out, local);
+        const u32 status = clusterSums(P, clusterView(pools.meta[t], pools.cands, pools.cigars), sumInputs(rb, t, gb), keys, g, &scratch, false, out, local);
         if (0 == threadIdx.x)
         {
             if (SUMS_DONE == status) { sb.sums[t] = out; ++local.largeSums; }
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(1024) void k_cluster_sums_xl(DevParams P, const Clu
 
 // the clusters of repeat families: lists of thousands of entries (up to the reference's own 32768), keys in HBM (L2-resident: 1.4 MB
 // per workgroup), 1024 lanes per cluster
-__global__ __launch_bounds__(1024) void k_cluster_sums_huge(DevParams P, const ClusterFragments *frags, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters)
+__global__ __launch_bounds__(1024) void k_cluster_sums_huge(DevParams P, ClusterPools pools, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters)
 {
     __shared__ u32 scratch;
     __shared__ __align__(16) u16 radixCounts[16 * 1024];
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(1024) void k_cluster_sums_huge(DevParams P, const C
         g.sumTile = reinterpret_cast<double *>(radixCounts); g.sumTileCap = sizeof(radixCounts) / 8;        // the counts are idle by then
         g.radix.counts = radixCounts; g.radix.totals = radixTotals; g.radix.vary = radixVary; g.radix.alt = reinterpret_cast<u16 *>(mine + size_t(SUMS_HUGE_CAP) * 42); g.radix.digits = radixDigits; g.radix.digitsCap = SUMS_HUGE_DIGITS;
         ClusterSums out;
-        const u32 status = clusterSums(P, frags[t], sumInputs(rb, t, gb), keys, g, &scratch, false, out, local);
+        const u32 status = clusterSums(P, clusterView(pools.meta[t], pools.cands, pools.cigars), sumInputs(rb, t, gb), keys, g, &scratch, false, out, local);
         if (0 == threadIdx.x)
         {
             if (SUMS_DONE == status) { sb.sums[t] = out; ++local.largeSums; }

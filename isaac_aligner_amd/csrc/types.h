@@ -133,19 +133,87 @@ ISAAC_HD bool candLess(const Cand &a, const Cand &b)
 ISAAC_HD bool candEqual(const Cand &a, const Cand &b) { return a.position == b.position && a.contigId == b.contigId && a.reverse == b.reverse && a.observedLength == b.observedLength; }
 
 // ---- per-cluster state that lives in HBM between the kernels of one tile -----------------------------------------
-static const u32 CAND_CAP = 128;         // per read; 2 strands x seeds/read x (repeatThreshold - 1) = 72 for 4 seeds (2x150), 126 for 7 (2x250)
-static const u32 CIGAR_POOL = 1024;      // cigar words per cluster (fragment stage)
+// The candidates of a chunk lie back to back in one pool, CSR fashion: a cluster owns as many slots as it has seed matches (every
+// candidate starts as a match and the lists only shrink afterwards), at the offset of its first match in the chunk -- no count /
+// scan pass is needed, the match offsets are the row pointers.  Read 0's list starts at the cluster's first slot, read 1's behind
+// what read 0's held after its first consolidation.  CIGAR words live in one arena per chunk: three words per candidate slot for
+// the ungapped alignment at 3 x slot, and extra regions handed out by a bump counter to the few clusters that need more (single
+// indels, accepted gapped alignments).  Per cluster 32 bytes of ClusterMeta say where everything is; a typical cluster touches
+// 32 + 2.7 x 64 B instead of a fixed 20.5 KB record.
+static const u32 CAND_CAP = 128;         // per read (u8 list indexes): 2 strands x seeds/read x (repeatThreshold - 1) = 72 for 4 seeds (2x150), 126 for 7 (2x250)
+static const u32 CIGAR_POOL = 1024;      // cigar words of a fixed-capacity ClusterStore (host harness)
 static const u32 MATCH_CAP_MAX = 320;
+struct ClusterMeta
+{
+    u32 first;              // first candidate slot (and 3 x first = first cigar word) of the cluster in the chunk's pools
+    u32 cigarUsed;          // append cursor of the cluster's cigar words, relative to 3 x first
+    u32 cigarCap;           // end of the region the cursor is in, relative to 3 x first
+    u16 second, cap;        // read 1's list starts `second` slots in; slots owned
+    u16 nCands[2];
+    u16 endCyclesMasked[2]; // Read::endCyclesMasked_ after trimLowQualityEnds
+    u16 flags;              // CLUSTER_* below
+    u8 repeatSeedsCount, built;
+    u32 pad;
+};
+static_assert(sizeof(ClusterMeta) == 32, "ClusterMeta layout");
+
+// What the per-cluster functions work on: a view of the cluster's lists and cigar words (pointers into the pools, or into a
+// ClusterStore) plus its small state, kept in registers for the duration of a kernel and written back as ClusterMeta.
 struct ClusterFragments
 {
-    Cand cands[2][CAND_CAP];
+    Cand *cands[2];
+    u32 candCap[2];         // slots available to each list
     u32 nCands[2];
     u32 cigarUsed;
+    u32 cigarCap;
     u32 flags;              // bit0: a fixed-capacity list overflowed
-    u32 endCyclesMasked[2]; // Read::endCyclesMasked_ after trimLowQualityEnds
+    u32 endCyclesMasked[2];
     u32 repeatSeedsCount;
     u32 built;              // FragmentBuilder::build returned true
-    u32 cigarPool[CIGAR_POOL];
+    u32 *cigarPool;         // cigarPool[Cand::cigarOffset ...]: the cluster's words
+};
+ISAAC_HD ClusterFragments clusterView(const ClusterMeta &m, Cand *candPool, u32 *cigarArena)
+{
+    ClusterFragments f;
+    f.cands[0] = candPool + m.first; f.cands[1] = f.cands[0] + m.second;
+    f.candCap[0] = m.cap; f.candCap[1] = m.cap - m.second;
+    f.nCands[0] = m.nCands[0]; f.nCands[1] = m.nCands[1];
+    f.cigarUsed = m.cigarUsed; f.cigarCap = m.cigarCap; f.flags = m.flags;
+    f.endCyclesMasked[0] = m.endCyclesMasked[0]; f.endCyclesMasked[1] = m.endCyclesMasked[1];
+    f.repeatSeedsCount = m.repeatSeedsCount; f.built = m.built;
+    f.cigarPool = cigarArena + 3 * u64(m.first);
+    return f;
+}
+// a fresh view for a cluster that owns `cap` slots from `first` on
+ISAAC_HD ClusterFragments clusterViewNew(u32 first, u32 cap, Cand *candPool, u32 *cigarArena)
+{
+    ClusterMeta m; m.first = first; m.cigarUsed = 0; m.cigarCap = 3 * cap; m.second = 0; m.cap = u16(cap); m.nCands[0] = m.nCands[1] = 0;
+    m.endCyclesMasked[0] = m.endCyclesMasked[1] = 0; m.flags = 0; m.repeatSeedsCount = 0; m.built = 0; m.pad = 0;
+    return clusterView(m, candPool, cigarArena);
+}
+ISAAC_HD void clusterViewStore(const ClusterFragments &f, Cand *candPool, ClusterMeta &m)
+{
+    m.first = u32(f.cands[0] - candPool); m.second = u16(f.cands[1] - f.cands[0]); m.cap = u16(f.candCap[0]);
+    m.nCands[0] = u16(f.nCands[0]); m.nCands[1] = u16(f.nCands[1]); m.cigarUsed = f.cigarUsed; m.cigarCap = f.cigarCap; m.flags = u16(f.flags);
+    m.endCyclesMasked[0] = u16(f.endCyclesMasked[0]); m.endCyclesMasked[1] = u16(f.endCyclesMasked[1]);
+    m.repeatSeedsCount = u8(f.repeatSeedsCount); m.built = u8(f.built); m.pad = 0;
+}
+// the chunk's pools as the kernels receive them
+struct ClusterPools { ClusterMeta *meta; Cand *cands; u32 *cigars; u32 candCap /* slots */; u32 cigarCap /* words */; u32 *cigarNext /* bump counter of the extra regions */; };
+// `words` more cigar words for a cluster whose cursor region is full or not the right size: a fresh region from the arena's
+// bump counter; the cluster's earlier words stay where they are (offsets are relative to its first word).  No room: the view's
+// capacity stays as it is and the pool's own overflow flag does the rest.
+ISAAC_HD void clusterCigarExtra(ClusterFragments &f, u32 *cigarArena, u32 at, u32 words, u32 arenaCap)
+{
+    if (u64(at) + words > arenaCap) return;
+    const u32 base = u32(f.cigarPool - cigarArena);
+    f.cigarUsed = at - base; f.cigarCap = f.cigarUsed + words;
+}
+// fixed-capacity backing of one cluster's view (tests/hostemu; the serial forms)
+struct ClusterStore
+{
+    Cand cands[2 * CAND_CAP]; u32 cigarPool[CIGAR_POOL];
+    ISAAC_HD ClusterFragments view() { ClusterFragments f = clusterViewNew(0, 2 * CAND_CAP, cands, cigarPool); f.cigarCap = CIGAR_POOL; return f; }
 };
 enum { CLUSTER_OVERFLOW = 1,
        CLUSTER_INDEL_PENDING = 2,     // << read index (bits 1, 2)

@@ -71,12 +71,15 @@ def gather_records(records, dist, rank, world, dst=0):
 
 class StepGather:
     """Collects every step's records and packed CIGARs on rank `dst` while the later steps compute: the payload of a step is handed to
-    an asynchronous gather as soon as it is final, and only finish() waits.  Per rank and step 138 B per pair cross one xGMI link
-    (about 48 GB/s): left to the end of a run that is 8-9 % of the run's time on its own, spread over the steps it hides behind them.
-    Shards may differ in size: the sizes of a step are exchanged first (a tiny all-gather) and the payloads padded to the largest."""
+    asynchronous gathers as soon as its kernels are queued, and only finish() waits.  Per rank and step about 140 B per pair cross one
+    xGMI link (about 48 GB/s): left to the end of a run that is 8-9 % of the run's time on its own, spread over the steps it hides
+    behind them.  Nothing in add() waits for the GPU or for another rank: the record count of every rank is known beforehand
+    (`record_counts`, e.g. 2 x shard_bounds), the CIGAR pool travels at its fixed capacity and its fill level as a third, tiny gather
+    of the device word isaac_gpu_compact_cigars_async wrote."""
 
-    def __init__(self, dist, rank, world, dst=0):
+    def __init__(self, dist, rank, world, dst=0, record_counts=None):
         self.dist, self.rank, self.world, self.dst = dist, rank, world, dst
+        self.record_counts = None if record_counts is None else [int(c) for c in record_counts]
         self.pending, self.steps = [], []
 
     def _pad(self, t, n):
@@ -86,32 +89,41 @@ class StepGather:
         out[:t.shape[0]] = t
         return out
 
-    def add(self, records, cigars):
-        """records: (n, record_bytes) uint8, cigars: 1-D packed CIGAR words of this rank for one step (both final)"""
+    def add(self, records, cigars, n_words=None, record_counts=None):
+        """records: (n, record_bytes) uint8 of this rank for one step; cigars: its CIGAR pool (1-D int32, at most 4 words per record of the
+        largest shard), n_words: 1-element int64 tensor holding the number of pool words in use (may still be in flight on the device),
+        or None when all of `cigars` is meant; record_counts: this step's record count of every rank when it differs from the constructor's"""
+        if n_words is None:
+            n_words = torch.tensor([cigars.shape[0]], dtype=torch.int64, device=cigars.device)
         if self.dist is None:
-            self.steps.append(([records], [cigars]))
+            self.pending.append((None, None, None, records, cigars, n_words, None, None, None))
             return
         dist = self.dist
-        n = torch.tensor([records.shape[0], cigars.shape[0]], dtype=torch.int64, device=records.device)
-        sizes = [torch.zeros_like(n) for _ in range(self.world)]
-        dist.all_gather(sizes, n)
-        sizes = [[int(v) for v in s.tolist()] for s in sizes]
-        rec = self._pad(records, max(s[0] for s in sizes))
-        cig = self._pad(cigars, max(1, max(s[1] for s in sizes)))
+        counts = [int(c) for c in record_counts] if record_counts is not None else self.record_counts if self.record_counts is not None else [records.shape[0]] * self.world
+        assert counts[self.rank] == records.shape[0], "record_counts disagrees with this rank's records"
+        assert cigars.shape[0] <= 4 * max(counts), "the CIGAR pool is larger than 4 words per record"
+        width = max(counts)
+        rec = self._pad(records, width)
+        cig = self._pad(cigars, 4 * width)                # the pool's capacity is 4 words per record everywhere (bench.py: buffers())
         on_dst = self.rank == self.dst
         out_r = [torch.empty_like(rec) for _ in range(self.world)] if on_dst else None
         out_c = [torch.empty_like(cig) for _ in range(self.world)] if on_dst else None
+        out_n = [torch.empty_like(n_words) for _ in range(self.world)] if on_dst else None
         h_r = dist.gather(rec, out_r, dst=self.dst, async_op=True)
         h_c = dist.gather(cig, out_c, dst=self.dst, async_op=True)
-        self.pending.append((h_r, h_c, rec, cig, out_r, out_c, sizes))        # the tensors stay referenced until finish()
+        h_n = dist.gather(n_words, out_n, dst=self.dst, async_op=True)
+        self.pending.append((h_r, h_c, h_n, rec, cig, n_words, out_r, out_c, (out_n, counts)))     # the tensors stay referenced until finish()
 
     def finish(self):
         """waits for every gather; on `dst`: [(list of record tensors by rank, list of CIGAR tensors by rank)] per step, else None"""
-        for h_r, h_c, rec, cig, out_r, out_c, sizes in self.pending:
-            h_r.wait()
-            h_c.wait()
+        for h_r, h_c, h_n, rec, cig, n_words, out_r, out_c, out_n in self.pending:
+            if self.dist is None:
+                self.steps.append(([rec], [cig[:int(n_words.item())]]))
+                continue
+            h_r.wait(); h_c.wait(); h_n.wait()
             if self.rank == self.dst:
-                self.steps.append(([t[:s[0]] for t, s in zip(out_r, sizes)], [t[:s[1]] for t, s in zip(out_c, sizes)]))
+                out_n, counts = out_n
+                self.steps.append(([t[:c] for t, c in zip(out_r, counts)], [t[:int(n.item())] for t, n in zip(out_c, out_n)]))
         self.pending = []
         if self.dist is not None and self.rank != self.dst:
             return None

@@ -1,5 +1,7 @@
 // ORACLE -- TEST INFRASTRUCTURE ONLY (see oracle/README.md).  CPU restatement of the BAM side of the path for
-// --realign-gaps no --mark-duplicates 0 and the default tag set (--bam-exclude-tags ZX,ZY):
+// --realign-gaps no, --mark-duplicates 0 | 1, --keep-duplicates 0 | 1 and the default tag set (--bam-exclude-tags ZX,ZY):
+//   duplicate marking                          lib/build/BinSorter.cpp:293-330, include/build/DuplicateFragmentIndexFiltering.hh:37-208,
+//                                              include/build/DuplicatePairEndFilter.hh:45-107, include/io/Fragment.hh:66-71,490-506
 //   what FragmentCollector keeps per read      lib/alignment/matchSelector/FragmentCollector.cpp:43-111
 //   the order of a bin                         include/build/PackedFragmentBuffer.hh:149-176 (orderForBam), lib/build/BinSorter.cpp
 //   the record adapter                         include/build/FragmentAccessorBamAdapter.hh:127-377
@@ -25,6 +27,7 @@ const uint64_t NO_MATCH_VALUE = ReferencePosition(ReferencePosition::NoMatch).va
 struct Stored
 {
     const FragmentRecord *header; std::vector<unsigned char> bases; const uint32_t *cigarBegin, *cigarEnd; const std::string *namePrefix;
+    const uint8_t *clusterBcl = 0; const FragmentRecord *mate = 0; bool duplicate = false;
     bool paired() const { return header->flags & 1; }
     bool unmapped() const { return header->flags & 2; }
     bool mateUnmapped() const { return header->flags & 4; }
@@ -74,6 +77,7 @@ struct Adapter                                                                  
         bs |= unsigned(s.paired()) << 0; bs |= unsigned(s.properPair()) << 1; bs |= unsigned(s.unmapped()) << 2; bs |= unsigned(s.paired() && s.mateUnmapped()) << 3;
         bs |= unsigned(s.reverse()) << 4; bs |= unsigned(bool(s.header->flags & 16)) << 5; bs |= unsigned(s.paired() && (s.header->flags & 32)) << 6;
         bs |= unsigned(s.paired() && s.secondRead()) << 7; bs |= unsigned(bool(s.header->flags & 128)) << 9;
+        bs |= unsigned(s.duplicate) << 10;                                                       // FragmentAccessorBamAdapter.hh:357
         return bs;
     }
     int nextRefId() const { return s.paired() ? (s.unmapped() && s.mateUnmapped() ? -1 : int(ReferencePosition::fromValue(s.header->mateFStrandPosition).getContigId())) : -1; }
@@ -112,7 +116,67 @@ void serializeAlignment(std::vector<char> &os, const Adapter &a)
     put(os, "BCZ", 3); put(os, a.o.barcode.c_str(), a.o.barcode.size() + 1);
 }
 
+// oligo::pack32BclBases (include/oligo/Nucleotides.hh:241-280)
+uint64_t pack32BclBases(const uint8_t *bcl, unsigned available)
+{
+    uint64_t ret = 0;
+    for (unsigned i = 0; i < 32 && i < available; ++i) ret |= uint64_t(bcl[i] & 3) << (2 * i);
+    return ret;
+}
+// ReferencePosition value of the position `offset` bases further on the same contig
+uint64_t advance(uint64_t positionValue, uint64_t offset) { return positionValue + (offset << 1); }
+// io::FragmentIndexAnchor (Fragment.hh:490-506): aligned reads are anchored at their lowest cycle (f-strand position of forward reads, r-strand
+// position of reverse ones), shadows at their first 32 bases
+uint64_t anchorOf(const FragmentRecord &h, const uint8_t *readBcl)
+{
+    if (!(h.flags & 2)) return (h.flags & 8) ? advance(h.fStrandPosition, std::max(h.observedLength, 1U) - 1) : h.fStrandPosition;
+    return pack32BclBases(readBcl, h.readLength);
+}
+
 } // namespace
+
+// FDuplicateFilter::less / RSDuplicateFilter::less (DuplicateFragmentIndexFiltering.hh:42-88,126-175)
+static bool duplicateLess(const PairEndIndex &left, const PairEndIndex &right)
+{
+    if (left.primary < right.primary) return true;
+    if (left.primary == right.primary)
+    {
+        if (left.mateAnchor < right.mateAnchor) return true;
+        if (left.mateAnchor == right.mateAnchor)
+        {
+            if (left.mateInfo < right.mateInfo) return true;
+            if (left.mateInfo == right.mateInfo)
+            {
+                if (left.library < right.library) return true;
+                if (left.library == right.library)
+                {
+                    if (left.duplicateClusterRank > right.duplicateClusterRank) return true;      // higher alignment score on top
+                    if (left.duplicateClusterRank == right.duplicateClusterRank && left.globalClusterId < right.globalClusterId) return true;
+                }
+            }
+        }
+    }
+    return false;
+}
+// ::equal_to (:89-115,176-206): both ends of one cluster are never duplicates of each other
+static bool duplicateEqual(const PairEndIndex &left, const PairEndIndex &right)
+{
+    if (left.primary == right.primary && left.mateAnchor == right.mateAnchor && left.mateInfo == right.mateInfo)
+        if (left.globalClusterId != right.globalClusterId) return left.library == right.library;
+    return false;
+}
+void filterDuplicates(std::vector<PairEndIndex> &ends, std::vector<char> &isDuplicate)
+{
+    isDuplicate.assign(ends.size(), 0);
+    if (ends.empty()) return;
+    std::sort(ends.begin(), ends.end(), duplicateLess);
+    size_t last = 0;
+    for (size_t it = 1; it < ends.size(); ++it)
+    {
+        if (!duplicateEqual(ends[last], ends[it])) last = it;
+        else isDuplicate[it] = 1;
+    }
+}
 
 void bamRecords(const std::vector<BamTileInput> &tiles, const BamOptions &o, std::vector<char> &os, uint64_t &nRecords, uint64_t &unalignedOffset)
 {
@@ -128,8 +192,44 @@ void bamRecords(const std::vector<BamTileInput> &tiles, const BamOptions &o, std
             s.bases.assign(bcl, bcl + h.readLength);
             if (s.reverse()) { std::reverse(s.bases.begin(), s.bases.end()); for (unsigned char &b : s.bases) b = reverseBcl(b); }
             s.cigarBegin = t.cigars + h.cigarOffset; s.cigarEnd = s.cigarBegin + ((h.flags & 2) ? 0 : h.cigarLength);
+            s.clusterBcl = t.bcl + uint64_t(h.clusterId) * o.clusterLength;
+            if (h.flags & 1) s.mate = &t.records[i ^ 1];                      // records come in cluster order, read 0 before read 1
             stored.push_back(s);
         }
+    if (o.markDuplicates || !o.keepDuplicates)
+    {
+        // BinSorter::loadAlignedData (:214-291) + resolveDuplicates (:293-330): the ends of pairs with a bin position, forward-strand ones apart
+        // from reverse-strand ones and shadows; single-ended reads and the unaligned bin are never filtered.  One library (one barcode), and bins
+        // as wide as a contig: mates with equal anchors then share a storage bin, so mate_.info_.storageBin_ is the same everywhere
+        std::vector<PairEndIndex> ends[2];
+        for (size_t k = 0; k < stored.size(); ++k)
+        {
+            const Stored &s = stored[k]; const FragmentRecord &h = *s.header;
+            if (!s.paired() || h.fStrandPosition == NO_MATCH_VALUE) continue;
+            const FragmentRecord &m = *s.mate;
+            const unsigned readIndex = (h.flags & 64) ? 1 : 0;
+            // getTemplateDuplicateRank (Fragment.hh:66-71): template quality << 32 | (total read length - edit distance) << 16 | template alignment score
+            unsigned quality = 0;
+            for (unsigned b = 0; b < o.clusterLength; ++b) quality += isBclN(s.clusterBcl[b]) ? 2 : s.clusterBcl[b] >> 2;    // Read.cpp:56-69: an N has quality 2
+            const unsigned templateAlignmentScore = (h.reserved >> 16) == 0xffffu ? 0xffffffffu : (h.reserved >> 16);
+            PairEndIndex e;
+            e.duplicateClusterRank = uint64_t(quality) << 32 | (unsigned(h.readLength) + m.readLength - (unsigned(h.editDistance) + m.editDistance)) << 16 | templateAlignmentScore;
+            e.mateAnchor = anchorOf(m, s.clusterBcl + o.readOffset[1 - readIndex]);
+            e.mateInfo = unsigned(bool(h.flags & 4)) | unsigned(bool(h.flags & 16)) << 1;
+            e.library = 0; e.globalClusterId = uint64_t(h.tile) * CLUSTERS_PER_TILE_FACTOR + h.clusterId; e.tag = k;
+            const bool rs = s.reverse() || s.unmapped();
+            e.primary = rs ? anchorOf(h, s.clusterBcl + o.readOffset[readIndex]) : h.fStrandPosition;
+            ends[rs].push_back(e);
+        }
+        for (int rs = 1; rs >= 0; --rs)
+        {
+            std::vector<char> dup;
+            filterDuplicates(ends[rs], dup);
+            for (size_t k = 0; k < ends[rs].size(); ++k) if (dup[k]) stored[ends[rs][k].tag].duplicate = true;
+        }
+        if (!o.keepDuplicates) stored.erase(std::remove_if(stored.begin(), stored.end(), [](const Stored &s) { return s.duplicate; }), stored.end());
+        else if (!o.markDuplicates) for (Stored &s : stored) s.duplicate = false;
+    }
     // aligned bins: everything with a bin position; the unaligned bin keeps storage order
     std::vector<const Stored *> aligned, unaligned;
     for (const Stored &s : stored) (s.header->fStrandPosition == NO_MATCH_VALUE ? unaligned : aligned).push_back(&s);

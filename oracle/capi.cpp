@@ -830,8 +830,24 @@ int oracle_find_neighbors(uint32_t kmer_bases, const uint64_t *hi, const uint64_
 extern "C" {
 typedef struct { const uint8_t *bcl; const void *records; const uint32_t *cigars; uint64_t n_records; const char *read_name_prefix; } oracle_bam_tile;
 
+// the literal index entries of lib/build/cppunit/testDuplicateFiltering.cpp through the filter: is_duplicate_out[i] for entry i as given
+int oracle_filter_duplicates(uint64_t n, const uint64_t *primary, const uint64_t *mate_anchor, const uint32_t *mate_info, const uint64_t *rank, const uint64_t *cluster_id,
+                             uint8_t *is_duplicate_out)
+{
+    try
+    {
+        std::vector<PairEndIndex> ends(n);
+        for (uint64_t i = 0; i < n; ++i) { PairEndIndex e = { primary[i], mate_anchor[i], mate_info[i], 0, rank[i], cluster_id[i], i }; ends[i] = e; }
+        std::vector<char> dup;
+        filterDuplicates(ends, dup);
+        for (uint64_t i = 0; i < n; ++i) is_duplicate_out[ends[i].tag] = uint8_t(dup[i]);
+        return 0;
+    }
+    catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+
 int oracle_bam_records(const oracle_bam_tile *tiles, uint32_t n_tiles, uint32_t n_reads, const uint32_t *read_lengths, uint32_t forced_dodgy_alignment_score,
-                       int pessimistic_mapq, const char *read_group, const char *barcode, uint8_t *out, uint64_t capacity, uint64_t *n_bytes,
+                       int pessimistic_mapq, const char *read_group, const char *barcode, int mark_duplicates, int keep_duplicates, uint8_t *out, uint64_t capacity, uint64_t *n_bytes,
                        uint64_t *n_records, uint64_t *unaligned_offset)
 {
     try
@@ -844,7 +860,7 @@ int oracle_bam_records(const oracle_bam_tile *tiles, uint32_t n_tiles, uint32_t 
         }
         BamOptions o; o.clusterLength = 0; o.readOffset[0] = o.readOffset[1] = 0;
         for (uint32_t r = 0; r < n_reads; ++r) { o.readOffset[r] = o.clusterLength; o.clusterLength += read_lengths[r]; }
-        o.forcedDodgyAlignmentScore = (unsigned char)forced_dodgy_alignment_score; o.pessimisticMapQ = pessimistic_mapq; o.readGroup = read_group; o.barcode = barcode;
+        o.forcedDodgyAlignmentScore = (unsigned char)forced_dodgy_alignment_score; o.pessimisticMapQ = pessimistic_mapq; o.readGroup = read_group; o.barcode = barcode; o.markDuplicates = mark_duplicates != 0; o.keepDuplicates = keep_duplicates != 0;
         std::vector<char> os;
         bamRecords(in, o, os, *n_records, *unaligned_offset);
         *n_bytes = os.size();

@@ -686,7 +686,22 @@ void fastqDiscoverTiles(unsigned clustersLoaded, unsigned tileClustersMax, unsig
 
 // bam.cpp: the BAM record stream of a set of tiles (build::Build with --realign-gaps no --mark-duplicates 0) and the BAM header
 struct BamTileInput { const uint8_t *bcl; const FragmentRecord *records; const uint32_t *cigars; uint64_t nRecords; std::string namePrefix; };
-struct BamOptions { unsigned clusterLength, readOffset[2]; unsigned char forcedDodgyAlignmentScore; bool pessimisticMapQ; std::string readGroup, barcode; };
+struct BamOptions { unsigned clusterLength, readOffset[2]; unsigned char forcedDodgyAlignmentScore; bool pessimisticMapQ; std::string readGroup, barcode;
+                    bool markDuplicates = false, keepDuplicates = true; };       // --mark-duplicates / --keep-duplicates (BinSorter.cpp:293-330)
+// One end of a pair as the duplicate filter sees it: build::FStrandFragmentIndex / RStrandOrShadowFragmentIndex (include/build/FragmentIndex.hh:101-192)
+// with the fields of the fragment its comparators look up (library = barcode or sample index, tile * 10^9 + cluster).
+struct PairEndIndex
+{
+    uint64_t primary;        // fStrandPos_ (forward-strand ends) or anchor_.value_ (reverse-strand ends and shadows)
+    uint64_t mateAnchor;     // mate_.anchor_.value_
+    uint32_t mateInfo;       // mate_.info_.value_: shadow | reverse << 1 | storageBin << 2
+    uint64_t library, duplicateClusterRank, globalClusterId;
+    uint64_t tag;            // caller's handle
+};
+// DuplicatePairEndFilter::filterInput (include/build/DuplicatePairEndFilter.hh:45-107) with FDuplicateFilter / RSDuplicateFilter's less and
+// equal_to (DuplicateFragmentIndexFiltering.hh:37-208; the two differ only in what `primary` is): sorts `ends` and flags every end
+// that the reference would discard (or mark, with --keep-duplicates) as a duplicate of the best one before it
+void filterDuplicates(std::vector<PairEndIndex> &ends, std::vector<char> &isDuplicate);
 void bamRecords(const std::vector<BamTileInput> &tiles, const BamOptions &o, std::vector<char> &os, uint64_t &nRecords, uint64_t &unalignedOffset);
 struct SqTags { std::string as, ur, m5; };    // SortedReferenceMetadata::Contig::bamSqAs_ / bamSqUr_ / bamM5_
 void bamHeader(const std::string &commandLine, const std::string &description, const std::string &version, const std::vector<std::string> &headerLines,

@@ -1075,6 +1075,9 @@ FragmentRecord makeFragmentRecord(const BamTemplate &t, const FragmentMetadata &
     r.gapCount = uint16_t(f.getGapCount());
     r.editDistance = uint16_t(f.getEditDistance());
     r.tile = f.cluster->tile; r.clusterId = uint32_t(f.cluster->id);
+    // bits 16-31: BamTemplate::getAlignmentScore as 16 bits (0xffff = unknown, -1U): the one input of io::getTemplateDuplicateRank
+    // (Fragment.hh:66-71) that is neither in the FragmentHeader fields above nor in the reads
+    r.reserved = uint32_t(uint16_t(t.getAlignmentScore())) << 16;
     const unsigned forced = unsigned(dodgyAlignmentScore) & 0xff;
     if (r.flags & (1u << 8))
         r.mapq = (DODGY == r.templateAlignmentScore) ? forced : std::min<unsigned>(60U, std::max(r.alignmentScore, r.templateAlignmentScore));

@@ -16,6 +16,7 @@ What is extracted is DATA: the literal inputs and the asserted outputs of
   * lib/alignment/cppunit/testTemplateBuilder.cpp:96-373 (+ BuilderInit.hh fixture recipe) -> template_builder.json
   * lib/alignment/cppunit/testShadowAligner.cpp:56-252 -> shadow_aligner.json
   * lib/alignment/cppunit/testFragmentBuilder.cpp:33-598 (seed matches -> candidates) -> fragment_builder.json
+  * lib/build/cppunit/testDuplicateFiltering.cpp:131-399 -> duplicate_filtering.json
   * testMatchFinderClusterInfo.cpp, oligo/cppunit/testKmerGenerator.cpp, oligo/cppunit/testPermutate.cpp,
     reference/cppunit/testNeighborsFinder.cpp -> oligo.json
 No reference source text is stored.
@@ -692,7 +693,33 @@ def make_sorted_reference():
     return len(contigs), sum(len(c) for c in contigs), masks["count"]
 
 
+def make_duplicate_filtering():
+    """lib/build/cppunit/testDuplicateFiltering.cpp: the index entries of the fixture (constructor initialisers :131-205, dataOffset_ :207-258) and,
+    per test, the entries handed to DuplicatePairEndFilter(false) and the ones expected to survive (:268-399).  The fake fragment buffer gives
+    the fragment at dataOffset the cluster id dataOffset (fillWithUniqueClusterIdPattern :40-47), tile 0 and barcode 0."""
+    text = strip_comments(open(os.path.join(REF, "../../build/cppunit/testDuplicateFiltering.cpp")).read())
+    entries = {}
+    refpos = lambda contig, position: ((contig + 1) << 41) | (position << 1)           # ReferencePosition(contig, position).value
+    mate = r"FragmentIndexMate\(\s*(true|false)\s*,\s*(true|false)\s*,\s*(\d+)\s*,\s*FragmentIndexAnchor\((0x[0-9a-fA-F]+|\d+)\)\)"
+    for name, c, pos, anchor, shadow, reverse, storage_bin, mate_anchor, rank in re.findall(
+            r"(\w+_)\(ReferencePosition\((\d+),\s*(\d+)\),\s*(?:FragmentIndexAnchor\((0x[0-9a-fA-F]+|\d+)\),\s*)?" + mate + r",\s*(\d+)\)", text):
+        entries[name] = {"kind": "rs" if anchor else "f", "f_strand_pos": refpos(int(c), int(pos)), "anchor": int(anchor, 0) if anchor else None,
+                         "mate_info": int(shadow == "true") | int(reverse == "true") << 1 | int(storage_bin) << 2, "mate_anchor": int(mate_anchor, 0), "rank": int(rank)}
+    for name, n in re.findall(r"(\w+_)\.dataOffset_\s*=\s*(\d+)\s*\*\s*sizeof", text):
+        entries[name]["cluster_id"] = int(n)        # dataOffset / sizeof(FragmentHeader) would do as well: only equality and order matter
+    assert all("cluster_id" in e for e in entries.values()) and len(entries) == 36
+    tests = []
+    for test_name, body in re.findall(r"void TestDuplicateFiltering::(test\w+)\(\)\s*\{(.*?)\n\}", text, flags=re.S):
+        lists = {v: re.findall(r"\((\w+_)\)", items) for v, items in re.findall(r"std::vector<[^>]+>\s+(\w+)\s*=\s*boost::assign::list_of(.*?);", body, flags=re.S)}
+        for inp, exp in re.findall(r"testNoDifferences\((\w+),\s*(\w+)\)", body):
+            tests.append({"test": test_name, "input": lists[inp], "expected_unique": lists[exp]})
+    out = {"source": "lib/build/cppunit/testDuplicateFiltering.cpp:131-399", "entries": entries, "cases": tests}
+    json.dump(out, open(os.path.join(OUT, "duplicate_filtering.json"), "w"), indent=1)
+    return len(entries), len(tests)
+
+
 if __name__ == "__main__":
+    print("duplicate_filtering entries, filter runs:", make_duplicate_filtering())
     print("sorted_reference contigs, asserted contig fields, masks:", make_sorted_reference())
     print("oligo (cluster info steps, k-mer streams, permutate checks, permutation lists, neighbour runs):", make_oligo())
     print("fragment_builder cases, asserted values:", make_fragment_builder())

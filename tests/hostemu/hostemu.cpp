@@ -24,6 +24,7 @@ struct Emu
     DevParams P; DevReference R;
     std::vector<char> bases; std::vector<u64> offsets; std::vector<u8> loaded;
     std::vector<double> logMatch, logMismatch;
+    std::vector<ClusterStore> stores;       // fixed-capacity backing of the views below (the device keeps compact pools instead)
     std::vector<ClusterFragments> frags;
     std::vector<Match> matches; std::vector<u64> matchOffsets;
     Counters cnt; bool flatRescue = true; double *clusterTimes = nullptr; bool fastSort = true; u32 sumsCap = 0; int sumsRadixMin = -1; std::vector<u32> dbgJobBase; std::vector<RescueJob> dbgJobs;
@@ -74,7 +75,8 @@ int emu_set_matches(Emu *e, const isaac_match *m, u64 n, u32 nClusters)
 int emu_build_fragments(Emu *e, const u8 *bcl, u32 nClusters, int withGaps, int trim,
                         isaac_candidate *out, u64 capacity, u64 *nOut, u32 *cigarOut, u64 cigarCapacity, u64 *nCigar)
 {
-    e->frags.resize(nClusters);
+    e->stores.resize(nClusters); e->frags.resize(nClusters);
+    for (u32 c = 0; c < nClusters; ++c) e->frags[c] = e->stores[c].view();
     std::vector<FragmentWork> work(1);
     u64 n = 0, nc = 0;
     for (u32 c = 0; c < nClusters; ++c)
@@ -191,7 +193,7 @@ int emu_select(Emu *e, const u8 *bcl, u32 nClusters, u32 tile, const isaac_tls *
         for (u32 i = 0; i < jobs[j].nCands; ++i)
         {
             const u32 slot = jobs[j].candBase + i;
-            rescueAlignCandidate(e->P, e->R, bcl, jobs[j].cluster, e->frags[jobs[j].cluster], jobs[j], candPositions[slot], shadowCands[slot], &shadowCigars[size_t(slot) * 3]);
+            rescueAlignCandidate(e->P, e->R, bcl, jobs[j].cluster, e->frags[jobs[j].cluster].endCyclesMasked[jobs[j].shadowReadIndex], jobs[j], candPositions[slot], shadowCands[slot], &shadowCigars[size_t(slot) * 3]);
             ++e->cnt.ungappedScans;
         }
     // k_rescue_gapped_plan + k_gapped_jobs
@@ -262,9 +264,9 @@ struct LiteralFragment
 int emu_select_literal(Emu *e, const u8 *bcl, const LiteralFragment *f0, u32 n0, const LiteralFragment *f1, u32 n1, const isaac_tls *tls, isaac_fragment *records, u32 *cigars)
 {
     if (n0 > CAND_CAP || n1 > CAND_CAP) { g_error = "too many candidates"; return 1; }
-    std::vector<ClusterFragments> frags(1);
-    ClusterFragments &f = frags[0];
-    std::memset(&f, 0, sizeof(f));
+    std::vector<ClusterStore> stores(1);
+    ClusterFragments f = stores[0].view();
+    f.cands[1] = f.cands[0] + n0; f.candCap[1] = f.candCap[0] - n0;
     for (u32 k = 0; k < 16; ++k) f.cigarPool[k] = cigarOp(100, OP_ALIGN);     // cigarBuffer(1000, 1600) of the fixture
     f.cigarUsed = 16; f.built = (n0 || n1) ? 1 : 0;
     const LiteralFragment *in[2] = { f0, f1 }; const u32 n[2] = { n0, n1 };
@@ -404,7 +406,7 @@ uint32_t emu_crc32_folded(const u8 *data, u32 n)
 
 uint32_t emu_sizeof(int what)
 {
-    switch (what) { case 0: return sizeof(Cand); case 1: return sizeof(ClusterFragments); case 2: return sizeof(FragmentWork); case 3: return sizeof(TemplateWork);
+    switch (what) { case 0: return sizeof(Cand); case 1: return sizeof(ClusterMeta); case 2: return sizeof(FragmentWork); case 3: return sizeof(TemplateWork);
                     case 4: return sizeof(FragmentRecord); case 5: return sizeof(DevParams); case 6: return sizeof(isaac_params); default: return 0; }
 }
 

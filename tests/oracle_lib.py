@@ -76,7 +76,15 @@ class Oracle:
         if rc:
             raise RuntimeError(self.lib.oracle_last_error().decode())
 
-    def bam_records(self, tiles, read_lengths, forced_dodgy_alignment_score=0, pessimistic_mapq=False, read_group="0", barcode="none"):
+    def filter_duplicates(self, primary, mate_anchor, mate_info, rank, cluster_id):
+        """DuplicatePairEndFilter over literal index entries; returns a bool array: entry i is a duplicate of a better one"""
+        arrays = [np.ascontiguousarray(primary, np.uint64), np.ascontiguousarray(mate_anchor, np.uint64), np.ascontiguousarray(mate_info, np.uint32),
+                  np.ascontiguousarray(rank, np.uint64), np.ascontiguousarray(cluster_id, np.uint64)]
+        out = np.zeros(len(arrays[0]), np.uint8)
+        self.check(self.lib.oracle_filter_duplicates(C.c_uint64(len(out)), *[ptr(a) for a in arrays], ptr(out)))
+        return out.astype(bool)
+
+    def bam_records(self, tiles, read_lengths, forced_dodgy_alignment_score=0, pessimistic_mapq=False, read_group="0", barcode="none", mark_duplicates=False, keep_duplicates=True):
         """tiles: [(bcl, records, cigars, read_name_prefix)] as numpy arrays; returns (bytes, n_records, unaligned_offset)"""
         arr = (BamTile * len(tiles))()
         keep = []
@@ -92,7 +100,7 @@ class Oracle:
         out = np.empty(cap, np.uint8)
         nb, nr, un = C.c_uint64(), C.c_uint64(), C.c_uint64()
         self.check(self.lib.oracle_bam_records(arr, C.c_uint32(len(tiles)), C.c_uint32(len(read_lengths)), lengths, C.c_uint32(forced_dodgy_alignment_score), C.c_int(int(pessimistic_mapq)),
-                                               read_group.encode(), barcode.encode(), ptr(out), C.c_uint64(cap), C.byref(nb), C.byref(nr), C.byref(un)))
+                                               read_group.encode(), barcode.encode(), C.c_int(int(mark_duplicates)), C.c_int(int(keep_duplicates)), ptr(out), C.c_uint64(cap), C.byref(nb), C.byref(nr), C.byref(un)))
         return out[:nb.value].tobytes(), nr.value, un.value
 
     def bam_header(self, command_line, version, contigs, description="", header_lines=()):

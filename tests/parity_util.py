@@ -109,10 +109,10 @@ def check_fragment_builder_case(case, cands, cigars):
                 assert int(f[CANDIDATE_FIELD[name]]) == v, (case["name"], key, name, int(f[CANDIDATE_FIELD[name]]), v)
 
 
-def count_record_diffs(a, acig, b, bcig, limit=5):
+def count_record_diffs(a, acig, b, bcig, limit=5, ignore=()):
     """vectorised compare_records for full-size batches: (number of differing records, first few as text)"""
     n = min(len(a), len(b))
-    names = [f for f in a.dtype.names if f not in ("cigar_offset", "reserved")]
+    names = [f for f in a.dtype.names if f not in ("cigar_offset", "reserved") + tuple(ignore)]
     eq = np.ones(n, bool)
     for f in names:
         eq &= a[f][:n] == b[f][:n]

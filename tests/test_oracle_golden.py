@@ -295,3 +295,18 @@ def test_cluster_info_kmer_generator_permutate_and_neighbors_finder(oracle):
             oracle.check(lib.oracle_find_neighbors(C.c_uint32(run["kmer_bases"]), hi.ctypes.data_as(C.c_void_p), lo.ctypes.data_as(C.c_void_p), C.c_uint64(len(values)), C.c_uint32(jobs),
                                                    flags.ctypes.data_as(C.c_void_p)))
             assert [bool(f) for f in flags] == nf["expected"], (run["kmer_bases"], jobs, list(flags))
+
+
+def test_duplicate_filter_reproduces_the_reference_test(oracle):
+    """lib/build/cppunit/testDuplicateFiltering.cpp: every filterInput run of the suite (FDuplicateFilter / RSDuplicateFilter, keepDuplicates false)
+    leaves exactly the entries the test expects"""
+    g = json.load(open(os.path.join(GOLDEN, "duplicate_filtering.json")))
+    assert len(g["cases"]) == 13
+    for case in g["cases"]:
+        entries = [g["entries"][name] for name in case["input"]]
+        kinds = {e["kind"] for e in entries}
+        assert len(kinds) == 1
+        primary = [e["anchor"] if e["kind"] == "rs" else e["f_strand_pos"] for e in entries]
+        dup = oracle.filter_duplicates(primary, [e["mate_anchor"] for e in entries], [e["mate_info"] for e in entries], [e["rank"] for e in entries], [e["cluster_id"] for e in entries])
+        kept = sorted(name for name, d in zip(case["input"], dup) if not d)
+        assert kept == sorted(case["expected_unique"]), (case["test"], kept, case["expected_unique"])

@@ -104,7 +104,11 @@ def _step_gather_worker(rank, world, port, result_path):
             if step == 2 and rank == 1:
                 cig = cig[:0]                                              # a rank without CIGAR words in a step
             mine.append((rec, cig))
-            g.add(rec, cig)
+            # as bench.py hands a step over: the pool at its fixed capacity of 4 words per record, its fill level in a tensor, every rank's
+            # record count known without asking (here 50 + 7 * rank + step)
+            pool = torch.full((4 * n,), -1, dtype=torch.int32)
+            pool[:cig.shape[0]] = cig
+            g.add(rec, pool, torch.tensor([cig.shape[0]], dtype=torch.int64), record_counts=[50 + 7 * r + step for r in range(world)])
         steps = g.finish()
         if rank == 0:
             assert len(steps) == 3
@@ -135,5 +139,7 @@ def test_step_gather_collects_every_step_on_rank_0(tmp_path):
     g = shard.StepGather(None, 0, 1)                                       # single process: nothing to exchange
     r, c = torch.zeros((3, 64), dtype=torch.uint8), torch.zeros(5, dtype=torch.int32)
     g.add(r, c)
-    assert g.finish() == [([r], [c])]
+    g.add(r, c, torch.tensor([2]))
+    (r0, c0), (r1, c1) = g.finish()
+    assert r0[0] is r and (c0[0] == c).all() and c1[0].shape[0] == 2
 
