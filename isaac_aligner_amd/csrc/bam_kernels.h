@@ -237,8 +237,7 @@ __global__ void k_dup_mark(const u32 *order, u64 n, const u64 *keyPrimary, const
     const u64 k = u64(blockIdx.x) * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const u32 i = order[k];
-    const u64 small = keySmall[i];
-    duplicate[i] = 0;
+    const u64 small = keySmall[i];           // (the verdicts are zeroed before the launch: a group's head writes the flags of its followers)
     if (!small) return;
     const u64 primary = keyPrimary[i], mate = keyMate[i];
     if (k) { const u32 p = order[k - 1]; if (keySmall[p] == small && keyPrimary[p] == primary && keyMate[p] == mate) return; }     // not the head of its group

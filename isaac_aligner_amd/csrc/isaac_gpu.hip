@@ -1382,6 +1382,7 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
             sortPairs(c, c->bamKeyLo.p, c->bamKeyAlt.p, from, to, n, pass.bits);
             std::swap(from, to);
         }
+        HIP_CHECK(hipMemsetAsync(c->dupFlag.p, 0, n, st));
         k_dup_mark<<<gridFor(n, 256), 256, 0, st>>>(from, n, c->dupPrimary.p, c->dupMate.p, c->dupCluster.p, c->dupSmall.p, c->dupFlag.p);
         HIP_CHECK(hipGetLastError());
         duplicate = c->dupFlag.p;

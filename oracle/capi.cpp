@@ -826,6 +826,47 @@ int oracle_find_neighbors(uint32_t kmer_bases, const uint64_t *hi, const uint64_
 
 } // extern "C"
 
+// ---- gap realigner (realign.cpp): one case of lib/build/cppunit/testGapRealigner.cpp (realign() at :353-424 of the test)
+extern "C" int oracle_realign_case(const char *contig, uint64_t contig_length, const uint8_t *read_bcl, uint32_t read_length, uint64_t f_strand_position, const uint32_t *cigar, uint32_t cigar_length,
+                                   uint32_t observed_length, uint32_t edit_distance, uint32_t low_clipped, uint32_t high_clipped, const int64_t *gap_positions, const int32_t *gap_lengths, uint32_t n_gaps,
+                                   uint32_t mismatch_cost, uint32_t gap_open_cost, uint32_t gap_extend_cost, int vigorous, int dodgy, uint32_t gaps_per_fragment, int clip_semialigned,
+                                   uint64_t bin_start, int64_t bin_end /* < 0: bin_start + contig length */,
+                                   uint64_t *realigned_position, uint32_t *realigned_cigar, uint32_t *realigned_cigar_length, uint32_t *realigned_edit_distance, uint32_t *realigned_observed_length,
+                                   uint32_t *overlaps, uint32_t *n_overlaps)
+{
+    try
+    {
+        ContigList contigs(1);
+        contigs[0].index = 0; contigs[0].name = "testContig"; contigs[0].forward.assign(contig, contig + contig_length);
+        const ReferencePosition binStartPos(0, bin_start);
+        const ReferencePosition binEndPos = bin_end < 0 ? ReferencePosition(0, bin_start + contig_length) : ReferencePosition(0, uint64_t(bin_end));
+        RealignerGaps realignerGaps;
+        for (uint32_t i = 0; i < n_gaps; ++i) realignerGaps.gapGroups.push_back(RealignGap(ReferencePosition(0, uint64_t(gap_positions[i])), gap_lengths[i]));
+        realignerGaps.finalizeGaps();
+        std::vector<RealignGap> all;
+        realignerGaps.findGaps(binStartPos, binEndPos, all, 100000);
+        const OverlappingGapsFilter filter(all);
+        *n_overlaps = uint32_t(filter.overlappingGaps.size());
+        for (size_t i = 0; i < filter.overlappingGaps.size() && i < 32; ++i) overlaps[i] = filter.overlappingGaps[i];
+        RealignFragment fragment = RealignFragment();
+        fragment.fStrandPosition = ReferencePosition(0, f_strand_position); fragment.mateFStrandPosition = fragment.fStrandPosition.value; fragment.observedLength = observed_length;
+        fragment.lowClipped = uint16_t(low_clipped); fragment.highClipped = uint16_t(high_clipped); fragment.alignmentScore = 1; fragment.templateAlignmentScore = 0;
+        fragment.readLength = uint16_t(read_length); fragment.editDistance = uint16_t(edit_distance); fragment.flags = 0; fragment.bases = read_bcl;
+        RealignIndex index = { fragment.fStrandPosition, cigar, cigar + cigar_length };
+        const GapRealigner realigner = { vigorous != 0, dodgy != 0, gaps_per_fragment, mismatch_cost, gap_open_cost, gap_extend_cost, clip_semialigned != 0, contigs };
+        std::vector<uint32_t> realignedCigars; realignedCigars.reserve(1 << 20);
+        bool changed = false;
+        realigner.realign(realignerGaps, binStartPos, binEndPos, index, fragment, realignedCigars, changed);
+        *realigned_position = index.pos.getPosition();
+        if (index.pos != fragment.fStrandPosition) throw std::logic_error("index.pos_ and fragment.fStrandPosition_ differ after realignment");
+        *realigned_cigar_length = uint32_t(index.cigarEnd - index.cigarBegin);
+        for (const uint32_t *it = index.cigarBegin; it != index.cigarEnd; ++it) *realigned_cigar++ = *it;
+        *realigned_edit_distance = fragment.editDistance; *realigned_observed_length = fragment.observedLength;
+        return 0;
+    }
+    catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+
 // ---- BAM records and header (bam.cpp) ---------------------------------------------------------------------------
 extern "C" {
 typedef struct { const uint8_t *bcl; const void *records; const uint32_t *cigars; uint64_t n_records; const char *read_name_prefix; } oracle_bam_tile;

@@ -707,4 +707,56 @@ struct SqTags { std::string as, ur, m5; };    // SortedReferenceMetadata::Contig
 void bamHeader(const std::string &commandLine, const std::string &description, const std::string &version, const std::vector<std::string> &headerLines,
                const std::vector<std::pair<std::string, uint32_t> > &refSeqs, std::vector<char> &os, const std::vector<SqTags> *tags = 0);
 
+// ---- gap realigner (realign.cpp)
+// gapRealigner::Gap (include/build/gapRealigner/Gap.hh:31-78): length > 0 deletion from the reference, < 0 insertion
+struct RealignGap
+{
+    ReferencePosition pos; int length;
+    RealignGap(ReferencePosition p, int l) : pos(p), length(l) {}
+    unsigned getLength() const { return unsigned(length < 0 ? -length : length); }
+    bool isInsertion() const { return 0 > length; }
+    bool isDeletion() const { return 0 < length; }
+    ReferencePosition endPos(bool fatInsertions) const;
+    ReferencePosition deletionEndPos() const;
+};
+// build::RealignerGaps (include/build/GapRealigner.hh:37-128)
+struct RealignerGaps
+{
+    std::vector<RealignGap> gapGroups, deletionEndGroups;
+    void addGaps(ReferencePosition fStrandPosition, const uint32_t *cigarBegin, const uint32_t *cigarEnd);
+    void finalizeGaps();
+    void findGaps(ReferencePosition rangeBegin, ReferencePosition rangeEnd, std::vector<RealignGap> &foundGaps, size_t capacity) const;
+};
+// gapRealigner::OverlappingGapsFilter (OverlappingGapsFilter.hh:32-92)
+struct OverlappingGapsFilter
+{
+    static const unsigned MAX_TRACKED_OVERLAPS = 30, MAX_TRACKED_DELETIONS = 30;
+    unsigned maxChoice; std::vector<unsigned> overlappingGaps;
+    explicit OverlappingGapsFilter(const std::vector<RealignGap> &gaps);
+    unsigned findOverlaps(unsigned combination) const;
+    unsigned next(unsigned combination) const;
+private:
+    void findOverlaps(const std::vector<RealignGap> &gaps);
+};
+// the fields of io::FragmentAccessor the realigner reads and writes; bases: the read as FragmentCollector stored it (forward-strand BCL bytes)
+struct RealignFragment
+{
+    ReferencePosition fStrandPosition; uint64_t mateFStrandPosition; unsigned observedLength; uint16_t lowClipped, highClipped, alignmentScore, templateAlignmentScore, readLength, editDistance;
+    uint32_t flags; const unsigned char *bases;
+    unsigned leftClipped() const { return (flags & 8) ? highClipped : lowClipped; }
+    unsigned rightClipped() const { return (flags & 8) ? lowClipped : highClipped; }
+};
+struct RealignIndex { ReferencePosition pos; const uint32_t *cigarBegin, *cigarEnd; };       // PackedFragmentBuffer::Index
+struct GapRealigner
+{
+    static const unsigned MAX_GAPS_AT_A_TIME = 10;
+    bool realignGapsVigorously, realignDodgyFragments; unsigned realignedGapsPerFragment, mismatchCost, gapOpenCost, gapExtendCost; bool clipSemialigned;
+    const ContigList &reference;
+    // realignedCigars must have room (capacity) for everything the call appends: indexes of other fragments point into it
+    void realign(const RealignerGaps &realignerGaps, ReferencePosition binStartPos, ReferencePosition binEndPos, RealignIndex &index, RealignFragment &fragment,
+                 std::vector<uint32_t> &realignedCigars, bool &changed) const;
+    unsigned getAlignmentCost(const RealignFragment &fragment, const RealignIndex &index, unsigned &editDistance, int &mismatchesPercent) const;
+    struct Impl;
+};
+
 } // namespace oracle

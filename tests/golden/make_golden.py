@@ -17,6 +17,7 @@ What is extracted is DATA: the literal inputs and the asserted outputs of
   * lib/alignment/cppunit/testShadowAligner.cpp:56-252 -> shadow_aligner.json
   * lib/alignment/cppunit/testFragmentBuilder.cpp:33-598 (seed matches -> candidates) -> fragment_builder.json
   * lib/build/cppunit/testDuplicateFiltering.cpp:131-399 -> duplicate_filtering.json
+  * lib/build/cppunit/testGapRealigner.cpp:53-1733 -> gap_realigner.json (the fixture recipe re-run on the test's strings; asserted literals)
   * testMatchFinderClusterInfo.cpp, oligo/cppunit/testKmerGenerator.cpp, oligo/cppunit/testPermutate.cpp,
     reference/cppunit/testNeighborsFinder.cpp -> oligo.json
 No reference source text is stored.
@@ -718,7 +719,143 @@ def make_duplicate_filtering():
     return len(entries), len(tests)
 
 
+def _realign_fixture(read, ref, gaps, low_clipped, high_clipped):
+    """initFragment (testGapRealigner.cpp:175-289) and addGaps (:291-351) of the test fixture, re-run on the test's strings: the concrete
+    fragment (forward-strand read, position, CIGAR, observed length, edit distance), reference and gap list GapRealigner::realign is given"""
+    ALIGN, INSERT, DELETE, SOFT_CLIP = 0, 1, 2, 4
+    left_clipped, right_clipped = low_clipped, high_clipped            # the test's fragments are forward-strand
+    unclipped_pos = next(i for i, ch in enumerate(read) if ch != " ")
+    left_overhang = next(i for i, ch in enumerate(ref) if ch != " ")
+    f_strand_pos = left_clipped + unclipped_pos
+    assert f_strand_pos < len(ref)
+    cigar = []
+    ri = fi = unclipped_pos                                             # readIterator, refIterator as indexes
+    edit_distance = 0
+    if left_clipped + left_overhang:
+        cigar.append((left_clipped + left_overhang, SOFT_CLIP))
+        while ri != f_strand_pos + left_overhang and fi != len(ref):
+            ri += 1; fi += 1
+    observed = 0
+    bit = [0, ALIGN]
+    read_end = len(read) - right_clipped
+    while ri != read_end and fi != len(ref):
+        if read[ri] == "-":
+            if bit[1] == DELETE:
+                bit[0] += 1
+            else:
+                cigar.append(tuple(bit)); bit = [1, DELETE]
+            assert ref[fi] != "*"
+            edit_distance += 1; observed += 1
+        elif ref[fi] == "*":
+            if bit[1] == INSERT:
+                bit[0] += 1
+            else:
+                if bit[0]:
+                    cigar.append(tuple(bit))
+                bit = [1, INSERT]
+            edit_distance += 1
+        else:
+            if bit[1] == ALIGN:
+                bit[0] += 1
+            else:
+                cigar.append(tuple(bit)); bit = [1, ALIGN]
+            edit_distance += ref[fi] != read[ri]
+            observed += 1
+        ri += 1; fi += 1
+    if bit[0]:
+        cigar.append(tuple(bit))
+    if fi == len(ref):
+        if ri != len(read):
+            cigar.append((len(read) - ri, SOFT_CLIP))
+    elif right_clipped:
+        cigar.append((right_clipped, SOFT_CLIP))
+    bases = [ch for ch in read if ch in "ACGTN"]                        # TestFragmentAccessor (:116-151)
+    contig = "".join(ch for ch in ref if ch not in "* ")
+    # addGaps: positions count reference characters that are not '*'
+    found = []
+    pos, length = 0, 0
+    fi = 0
+    for gi, g in enumerate(gaps):
+        if fi == len(ref):
+            if length:
+                found.append((pos - abs(length), length))
+            pos, length, fi = 0, 0, 0
+        if ref[fi] == "*":
+            assert g == " "
+            fi += 1
+            continue
+        if g != "*":
+            if length < 0:
+                found.append((pos + length, length)); length = 0
+        else:
+            length -= 1
+        if g != "-":
+            if length > 0:
+                found.append((pos - length, length)); length = 0
+        else:
+            length += 1
+        pos += 1
+        fi += 1
+    if length:
+        found.append((pos - abs(length), length))
+    return {"read_bases": "".join(bases), "contig": contig, "f_strand_position": f_strand_pos, "cigar": [(n << 4) | op for n, op in cigar], "observed_length": observed,
+            "edit_distance": int(edit_distance), "low_clipped": low_clipped, "high_clipped": high_clipped, "gaps": found}
+
+
+def make_gap_realigner():
+    """lib/build/cppunit/testGapRealigner.cpp:456-1733: every realign(...) call of testFull / testMore with the values asserted on its result"""
+    text = strip_comments(open(os.path.join(REF, "../../build/cppunit/testGapRealigner.cpp")).read())
+    cases = []
+    for m in re.finditer(r"const RealignResult result = realign\(", text):
+        args_text, end = find_call(text, m.end())
+        args = split_args(args_text)
+        block_start, block_end = enclosing_block(text, m.start())
+        block = text[block_start:block_end]
+        costs = (1, 0)
+        if args[0][0] != "str":
+            costs = (int(args[0][1]), int(args[1][1])); args = args[2:]
+        assert all(a[0] == "str" for a in args[:3])
+        read, ref, gaps = args[0][1], args[1][1], args[2][1]
+        args = [a[1] for a in args]
+        low = high = 0
+        bin_start, bin_end = 0, None
+        if len(args) > 3:
+            init = args[3].strip()
+            if init != "io::FragmentHeader()":
+                before = text[block_start:m.start()]
+                for field, value in re.findall(re.escape(init) + r"\.(lowClipped_|highClipped_)\s*=\s*(\d+)", before):
+                    if field == "lowClipped_":
+                        low = int(value)
+                    else:
+                        high = int(value)
+            if len(args) > 4:
+                bin_start = int(re.search(r"ReferencePosition\(0,\s*(\d+)\)", args[4]).group(1))
+            if len(args) > 5:
+                bin_end = int(re.search(r"ReferencePosition\(0,\s*(\d+)\)", args[5]).group(1))
+        after = text[m.end():block_end]
+        nxt = after.find("const RealignResult result = realign(")
+        if nxt >= 0:
+            after = after[:nxt]
+        expected = {}
+        for value, field in re.findall(r"CPPUNIT_ASSERT_EQUAL\((.+?),\s*(?:int\()?result\.(\w+(?:\.\w+\(\d*\))?)\)?\);", after):
+            value = value.strip()
+            if "std::string" in value:
+                expected[field] = re.search(r'"(.*)"', value).group(1)
+            elif "ReferencePosition" in value:
+                expected[field] = int(re.search(r"ReferencePosition\(0,\s*(\d+)\)", value).group(1))
+            else:
+                expected[field] = int(value.rstrip("U"), 0)
+        case = _realign_fixture(read, ref, gaps, low, high)
+        case.update({"mismatch_cost": costs[0], "gap_open_cost": costs[1], "bin_start": bin_start, "bin_end": bin_end, "expected": expected})
+        cases.append(case)
+    out = {"source": "lib/build/cppunit/testGapRealigner.cpp:456-1733 (fixture recipe :53-424 re-run on the test's strings)",
+           "realigner": {"vigorous": True, "dodgy": False, "gaps_per_fragment": 8, "gap_extend_cost": 0, "clip_semialigned": False}, "cases": cases}
+    json.dump(out, open(os.path.join(OUT, "gap_realigner.json"), "w"), indent=1)
+    return len(cases), sum(len(c["expected"]) for c in cases)
+
+
 if __name__ == "__main__":
+    print("gap_realigner cases, asserted values:", make_gap_realigner())
     print("duplicate_filtering entries, filter runs:", make_duplicate_filtering())
     print("sorted_reference contigs, asserted contig fields, masks:", make_sorted_reference())
     print("oligo (cluster info steps, k-mer streams, permutate checks, permutation lists, neighbour runs):", make_oligo())

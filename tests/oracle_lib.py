@@ -76,6 +76,23 @@ class Oracle:
         if rc:
             raise RuntimeError(self.lib.oracle_last_error().decode())
 
+    def realign_case(self, case, realigner):
+        """one testGapRealigner case (tests/golden/gap_realigner.json) through GapRealigner::realign; returns a dict of what the test looks at"""
+        code = {"A": 0, "C": 1, "G": 2, "T": 3}
+        bcl = np.array([(code[b] | 0x20) if b != "N" else 0 for b in case["read_bases"]], np.uint8)      # TestFragmentAccessor: quality 8, N = 0
+        contig = case["contig"].encode()
+        cigar = np.array(case["cigar"], np.uint32)
+        gp = np.array([g[0] for g in case["gaps"]], np.int64); gl = np.array([g[1] for g in case["gaps"]], np.int32)
+        pos, ncig, ed, obs, nov = C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        out_cigar, overlaps = np.zeros(4096, np.uint32), np.zeros(32, np.uint32)
+        self.check(self.lib.oracle_realign_case(contig, C.c_uint64(len(contig)), ptr(bcl), C.c_uint32(len(bcl)), C.c_uint64(case["f_strand_position"]), ptr(cigar), C.c_uint32(len(cigar)),
+                                                C.c_uint32(case["observed_length"]), C.c_uint32(case["edit_distance"]), C.c_uint32(case["low_clipped"]), C.c_uint32(case["high_clipped"]),
+                                                ptr(gp), ptr(gl), C.c_uint32(len(gp)), C.c_uint32(case["mismatch_cost"]), C.c_uint32(case["gap_open_cost"]), C.c_uint32(realigner["gap_extend_cost"]),
+                                                C.c_int(int(realigner["vigorous"])), C.c_int(int(realigner["dodgy"])), C.c_uint32(realigner["gaps_per_fragment"]), C.c_int(int(realigner["clip_semialigned"])),
+                                                C.c_uint64(case["bin_start"]), C.c_int64(-1 if case["bin_end"] is None else case["bin_end"]),
+                                                C.byref(pos), ptr(out_cigar), C.byref(ncig), C.byref(ed), C.byref(obs), ptr(overlaps), C.byref(nov)))
+        return {"position": pos.value, "cigar": cigar_string(out_cigar[:ncig.value]), "edit_distance": ed.value, "observed_length": obs.value, "overlaps": [int(x) for x in overlaps[:nov.value]]}
+
     def filter_duplicates(self, primary, mate_anchor, mate_info, rank, cluster_id):
         """DuplicatePairEndFilter over literal index entries; returns a bool array: entry i is a duplicate of a better one"""
         arrays = [np.ascontiguousarray(primary, np.uint64), np.ascontiguousarray(mate_anchor, np.uint64), np.ascontiguousarray(mate_info, np.uint32),

@@ -37,6 +37,7 @@ def compare_records(a, acig, b, bcig, limit=5):
     eq = np.ones(n, bool)
     for f in names:
         eq &= a[f][:n] == b[f][:n]
+    eq &= (a["reserved"][:n] >> 16) == (b["reserved"][:n] >> 16)          # the template's alignment score (bits 16-31; the low bits are diagnostics)
     for i in range(n):
         x, y = a[i], b[i]
         cx = acig[x["cigar_offset"]:x["cigar_offset"] + x["cigar_length"]]
@@ -116,6 +117,7 @@ def count_record_diffs(a, acig, b, bcig, limit=5, ignore=()):
     eq = np.ones(n, bool)
     for f in names:
         eq &= a[f][:n] == b[f][:n]
+    eq &= (a["reserved"][:n] >> 16) == (b["reserved"][:n] >> 16)          # the template's alignment score (bits 16-31; the low bits are diagnostics)
     # CIGARs: word k of every record side by side, for as many words as the longest one has
     la = a["cigar_length"][:n].astype(np.int64)
     oa, ob = a["cigar_offset"][:n].astype(np.int64), b["cigar_offset"][:n].astype(np.int64)

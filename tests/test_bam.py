@@ -266,6 +266,74 @@ def test_gpu_bam_records_match_the_oracle():
 
 
 @pytest.mark.gpu
+def test_gpu_duplicate_marking_matches_the_oracle():
+    """--mark-duplicates 1 / --keep-duplicates 0|1 (BinSorter::resolveDuplicates): tiles in which a fifth of the templates were sequenced
+    twice or three times (same fragment, other qualities and errors, some with an unaligned mate, some across tiles) through
+    isaac_gpu_bam_records and through the oracle's restatement of the filter (pinned by the reference's testDuplicateFiltering vectors):
+    the same bytes, flag 0x400 on the same records, the same records left out"""
+    import torch
+    from isaac_aligner_amd import gpu
+    o = oracle_lib.load()
+    rng = np.random.default_rng(5)
+    L = 100
+    genome = synth.make_genome(200000, seed=41, n_contigs=2)
+    contigs = [bytes(c.numpy()) for c in genome]
+    params = options.default_params(L, L)
+    a = gpu.Aligner(params, 0, contigs)
+    a.build_index()
+    base = synth.make_read_pairs(genome, 6000, L, seed=42, indel_read_fraction=0.05, n_rate=0.002)[0].numpy()
+    dev_tiles, host_tiles = [], []
+    for t in range(2):
+        own = synth.make_read_pairs(genome, 3000, L, seed=50 + t)[0].numpy()
+        copies = base[rng.integers(0, len(base), 1500)].copy()           # fragments seen before: same bases ...
+        q = copies >> 2
+        requal = np.clip(q.astype(np.int64) + rng.integers(-6, 3, q.shape), 2, 40).astype(np.uint8)
+        copies = np.where(q > 0, (requal << 2) | (copies & 3), 0).astype(np.uint8)                     # ... other qualities (another rank)
+        flip = rng.random(copies.shape) < 0.004
+        copies = np.where(flip & (copies > 0), (copies & 0xfc) | ((copies + 1) & 3), copies).astype(np.uint8)     # ... and a few other errors
+        bcl = np.concatenate([base if t == 0 else base[:2000], own, copies])
+        noisy_mates(bcl, L, 29, rng)                                      # some mates become shadows
+        bcl = np.ascontiguousarray(bcl[rng.permutation(len(bcl))])
+        tile = 11 + t
+        d_bcl = torch.from_numpy(bcl).cuda()
+        records, cigars = a.align_tile(d_bcl, tile=tile)
+        prefix = "DUP:1:%d:" % tile
+        dev_tiles.append((d_bcl, records, cigars, prefix))
+        r, c = a.records_to_numpy(records, cigars)
+        host_tiles.append((bcl, r, c, prefix))
+    plain, n_plain, _ = a.bam_records(dev_tiles)
+    sizes = {}
+    for mark, keep in ((True, True), (True, False), (False, False)):
+        got, n, un = a.bam_records(dev_tiles, mark_duplicates=mark, keep_duplicates=keep)
+        want, want_n, want_un = o.bam_records(host_tiles, [L, L], forced_dodgy_alignment_score=params.dodgy_alignment_score & 0xff, mark_duplicates=mark, keep_duplicates=keep)
+        assert (n, un) == (want_n, want_un)
+        assert got.cpu().numpy().tobytes() == want
+        sizes[(mark, keep)] = (n, want)
+    marked = bam.parse_records(sizes[(True, True)][1])
+    n_dup = sum(1 for r in marked if r["flag"] & 0x400)
+    assert sizes[(True, True)][0] == n_plain and 1500 < n_dup < 8000          # every record is still there, the copies are flagged
+    assert sizes[(True, False)][0] == n_plain - n_dup == sizes[(False, False)][0]
+    assert not any(r["flag"] & 0x400 for r in bam.parse_records(sizes[(True, False)][1]))
+    assert not any(r["flag"] & 0x400 for r in bam.parse_records(plain.cpu().numpy().tobytes()))
+    # the template's alignment score travels in the record for the duplicate rank: the same on both sides
+    for (_, r, _, _), (_, records, _, _) in zip(host_tiles, dev_tiles):
+        assert len(r) and ((r["reserved"] >> 16) <= 0xffff).all()
+    ref = o.reference(contigs)
+    ref.set_index(a.get_index())
+    bcl = host_tiles[0][0]
+    om, ohits = ref.find_matches(params, bcl, len(bcl), tile=11)
+    d_bcl = dev_tiles[0][0]
+    matches, offsets, hits = a.find_matches(d_bcl, tile=11)
+    tls = a.determine_tls(d_bcl, matches, offsets, tile=11)
+    otls = ref.determine_tls(params, bcl, om, ohits, tile=11)
+    assert otls.astuple() == tls.astuple()
+    orec, _, _ = ref.select(params, bcl, om, otls, ohits, tile=11, n_clusters_hint=len(bcl))
+    a.set_loaded_contigs(hits)
+    grec = a.records_to_numpy(*a.select(d_bcl, matches, offsets, tls, tile=11))[0]
+    assert ((orec["reserved"] >> 16) == (grec["reserved"] >> 16)).all()
+
+
+@pytest.mark.gpu
 def test_gpu_bam_file_is_readable(tmp_path):
     """end to end: tile -> records -> BAM file; the file inflates to header + records and its records are sorted"""
     import torch

@@ -310,3 +310,28 @@ def test_duplicate_filter_reproduces_the_reference_test(oracle):
         dup = oracle.filter_duplicates(primary, [e["mate_anchor"] for e in entries], [e["mate_info"] for e in entries], [e["rank"] for e in entries], [e["cluster_id"] for e in entries])
         kept = sorted(name for name, d in zip(case["input"], dup) if not d)
         assert kept == sorted(case["expected_unique"]), (case["test"], kept, case["expected_unique"])
+
+
+def test_gap_realigner_reproduces_the_reference_test(oracle):
+    """lib/build/cppunit/testGapRealigner.cpp (testFull, testMore): the fragment, reference and gaps the fixture builds from the test's strings go
+    through the oracle's GapRealigner::realign; original CIGAR / position / edit distance are the fixture's, realigned ones and the overlap masks
+    of OverlappingGapsFilter are what the test asserts"""
+    g = json.load(open(os.path.join(GOLDEN, "gap_realigner.json")))
+    assert len(g["cases"]) == 62
+    for k, case in enumerate(g["cases"]):
+        e = case["expected"]
+        assert cigar_string(case["cigar"]) == e["originalCigar_"], k
+        if "originalPos_" in e:
+            assert case["f_strand_position"] == e["originalPos_"], k
+        if "originalEditDistance_" in e:
+            assert case["edit_distance"] == e["originalEditDistance_"], k
+        got = oracle.realign_case(case, g["realigner"])
+        assert got["position"] == e["realignedPos_"], (k, got, e)
+        if "realignedCigar_" in e:
+            assert got["cigar"] == e["realignedCigar_"], (k, got, e)
+        assert got["edit_distance"] == e["realignedEditDistance_"], (k, got, e)
+        if "overlappingGapsFilter_.overlapsCount()" in e:
+            assert len(got["overlaps"]) == e["overlappingGapsFilter_.overlapsCount()"], (k, got, e)
+        for n in (0, 1):
+            if "overlappingGapsFilter_.overlap(%d)" % n in e:
+                assert got["overlaps"][n] == e["overlappingGapsFilter_.overlap(%d)" % n], (k, got, e)
