@@ -282,6 +282,11 @@ int isaac_gpu_compact_cigars_async(isaac_gpu_ctx *ctx, isaac_fragment *fragments
  *            (tile * 1000000000 + cluster, include/build/FragmentIndex.hh:33), mapped before unmapped (a shadow follows its
  *            singleton), first read before second; templates with both reads unaligned last, in (tile, cluster, read) order
  *            (--keep-unaligned back); records flagged "not stored" (isaac_fragment::reserved bit 1) are left out
+ *   realignment BinSorter::collectGaps / realignGaps (lib/build/BinSorter.cpp:387-417) with build::GapRealigner (lib/build/GapRealigner.cpp) and
+ *            build::SemialignedEndsClipper when isaac_bam_options::realign_gaps is set: every fragment is tried against the gaps the other
+ *            fragments of its contig carry (mismatch 3, gap open 4, gap extend 0; at most ten gaps in reach), positions, CIGARs, edit
+ *            distances, TLEN, mate positions and proper-pair flags change on a private copy of the records before they are ordered;
+ *            every contig is one bin (the reference's bins, whose ends limit what it realigns, depend on its memory settings)
  *   duplicates  BinSorter::resolveDuplicates (lib/build/BinSorter.cpp:293-330) with DuplicatePairEndFilter over FDuplicateFilter / RSDuplicateFilter
  *            (include/build/DuplicatePairEndFilter.hh, DuplicateFragmentIndexFiltering.hh) when isaac_bam_options asks for it: one library
  *            (--single-library-samples with one barcode), all the tiles of the call compared with each other as if every contig were one
@@ -304,6 +309,11 @@ typedef struct
     const char *barcode;                     /* BC:Z value: the sample sheet barcode name (:307-335); NULL = "none" */
     uint32_t mark_duplicates;                /* --mark-duplicates (reference default 1): duplicates get BAM flag 0x400 */
     uint32_t keep_duplicates;                /* --keep-duplicates (reference default 1): 0 leaves duplicates out of the file */
+    uint32_t realign_gaps;                   /* --realign-gaps: 0 = no, 1 = sample / project / all (one gap group: the call's records are one sample) */
+    uint32_t realign_vigorously;             /* --realign-vigorously (reference default 0): only 0 is implemented */
+    uint32_t realign_dodgy;                  /* --realign-dodgy (reference default 0) */
+    const isaac_tls *tls;                    /* the template length statistics isaac_gpu_select ran with: GapRealigner::updatePairDetails re-derives the
+                                                proper-pair flag of realigned pairs from them; required with realign_gaps and paired reads */
 } isaac_bam_options;
 int isaac_gpu_bam_records(isaac_gpu_ctx *ctx, const isaac_bam_tile *tiles, uint32_t n_tiles, const isaac_bam_options *options /* NULL = defaults */,
                           uint8_t *bam_dev, uint64_t capacity, uint64_t *n_bytes_out, uint64_t *n_records_out, uint64_t *unaligned_offset_out);

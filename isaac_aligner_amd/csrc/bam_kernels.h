@@ -7,6 +7,7 @@
 // two stable radix passes; record sizes are scanned in that order; every record is then written where it belongs, one thread each.
 #pragma once
 #include "cluster_ops.h"
+#include "realign.h"
 
 namespace isaac
 {
@@ -16,9 +17,10 @@ struct BamTile
 {
     const u8 *bcl; const FragmentRecord *records; const u32 *cigars; u64 firstRecord;   // index of the tile's first record among all records of the call
     u32 nRecords, nameLength; char name[64];                                             // "<flowcell>:<lane>:<tile>:" (FragmentAccessorBamAdapter::readName)
+    const u32 *cigarsAlt;                                                                // CIGARs of realigned records (RECORD_CIGAR_REALIGNED), else NULL
 };
 struct BamOptions { u32 nReads, readLength[2], readOffset[2], clusterLength, forcedDodgyAlignmentScore, pessimisticMapQ, barcodeLength, readGroupLength; char barcode[64], readGroup[64];
-                    u32 markDuplicates, keepDuplicates; };
+                    u32 markDuplicates, keepDuplicates, realignGaps; RealignParams realign; DevTls tls; };
 
 static const u64 INSANELY_HIGH_NUMBER_OF_CLUSTERS_PER_TILE = 1000000000ull;   // include/build/FragmentIndex.hh:33
 static const u16 DODGY_ALIGNMENT_SCORE = 0xffff;                               // io::FragmentHeader::DODGY_ALIGNMENT_SCORE
@@ -110,7 +112,7 @@ ISAAC_HD void bamLayout(const BamTile &t, const FragmentRecord &r, const BamOpti
     l.sm = r.alignmentScore; l.as = r.templateAlignmentScore; l.nm = r.editDistance;
     const u32 readIndex = (r.flags & 64) && paired ? 1u : 0u;
     l.bcl = t.bcl + u64(r.clusterId) * o.clusterLength + o.readOffset[readIndex];
-    l.cigar = t.cigars + r.cigarOffset;
+    l.cigar = ((r.reserved & RECORD_CIGAR_REALIGNED) ? t.cigarsAlt : t.cigars) + r.cigarOffset;
 }
 
 // the base as FragmentCollector::storeBclAndCigar keeps it (reverse-complemented for reverse alignments, FragmentCollector.cpp:84-96) ...
@@ -249,6 +251,116 @@ __global__ void k_dup_mark(const u32 *order, u64 n, const u64 *keyPrimary, const
         const u64 c = keyCluster[e];
         if (c != last) duplicate[e] = 1; else last = c;
     }
+}
+
+// ---- gap realignment (--realign-gaps sample): BinSorter::collectGaps / realignGaps (lib/build/BinSorter.cpp:387-417) over the call's records,
+// every contig one bin.  The records are the stage's private copy (the caller's stay as they are).
+//   k_realign_count / k_realign_collect   the gaps of every stored aligned fragment (duplicates included, as the reference walks the bin's data)
+//   host                                  RealignerGaps::finalizeGaps with std::sort of the same libstdc++, contig by contig (ties among deletions
+//                                         that end at the same place keep the order the reference's sort gives them)
+//   k_realign                             GapRealigner::realign per kept fragment (realign.h)
+//   k_realign_pairs                       GapRealigner::updatePairDetails once both ends are final
+__device__ inline const u32 *bamRecordCigar(const BamTile &t, const FragmentRecord &r) { return ((r.reserved & RECORD_CIGAR_REALIGNED) ? t.cigarsAlt : t.cigars) + r.cigarOffset; }
+__device__ inline bool realignHasGaps(const FragmentRecord &r) { return bamStored(r) && !(r.flags & 2) && !bamUnalignedBin(r) && r.gapCount; }
+__global__ void k_realign_count(const BamTile *tiles, u32 nTiles, u64 nRecords, u32 *counts)
+{
+    const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= nRecords) return;
+    const u32 t = bamTileOf(tiles, nTiles, i);
+    const FragmentRecord &r = tiles[t].records[i - tiles[t].firstRecord];
+    u32 n = 0;
+    if (realignHasGaps(r)) { const u32 *c = bamRecordCigar(tiles[t], r); for (u32 k = 0; k < r.cigarLength; ++k) { const u32 code = cigarCode(c[k]); n += (OP_INSERT == code || OP_DELETE == code); } }
+    counts[i] = n;
+}
+// RealignerGaps::addGaps (GapRealigner.hh:54-104)
+__global__ void k_realign_collect(const BamTile *tiles, u32 nTiles, u64 nRecords, const u32 *offsets, RealignGap *gaps)
+{
+    const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= nRecords) return;
+    const u32 t = bamTileOf(tiles, nTiles, i);
+    const FragmentRecord &r = tiles[t].records[i - tiles[t].firstRecord];
+    if (!realignHasGaps(r)) return;
+    const u32 *c = bamRecordCigar(tiles[t], r);
+    u64 pos = r.fStrandPosition; u32 at = offsets[i];
+    for (u32 k = 0; k < r.cigarLength; ++k)
+    {
+        const u32 length = cigarLen(c[k]), code = cigarCode(c[k]);
+        if (OP_ALIGN == code) pos = rpPlus(pos, length);
+        else if (OP_INSERT == code) { RealignGap g; g.pos = pos; g.length = -i32(length); g.pad = 0; gaps[at++] = g; }
+        else if (OP_DELETE == code) { RealignGap g; g.pos = pos; g.length = i32(length); g.pad = 0; gaps[at++] = g; pos = rpPlus(pos, length); }
+    }
+}
+// changed[i]: the fragment was realigned; its new CIGAR took words from the pool's bump counter
+__global__ void k_realign(BamTile *tiles, u32 nTiles, u64 nRecords, BamOptions o, DevReference R, RealignerGapsView gapsView, const u8 *duplicate, FragmentRecord *records /* the copy */,
+                          u32 *pool, u32 poolCap, u32 *poolNext, u8 *changed)
+{
+    const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= nRecords) return;
+    changed[i] = 0;
+    const u32 t = bamTileOf(tiles, nTiles, i);
+    FragmentRecord &r = records[i];
+    if (!bamStored(r) || (r.flags & 2) || bamUnalignedBin(r) || !r.editDistance) return;
+    if (duplicate && duplicate[i] && !o.keepDuplicates) return;                 // not in the bin's index any more
+    RealignCtx x; x.R = &R; x.P = o.realign;
+    RealignFragment f;
+    f.fStrandPosition = r.fStrandPosition; f.mateFStrandPosition = r.mateFStrandPosition; f.observedLength = r.observedLength; f.flags = r.flags;
+    f.lowClipped = r.lowClipped; f.highClipped = r.highClipped; f.alignmentScore = r.alignmentScore; f.templateAlignmentScore = r.templateAlignmentScore;
+    f.readLength = r.readLength; f.editDistance = r.editDistance;
+    const u32 readIndex = ((r.flags & 64) && (r.flags & 1)) ? 1u : 0u;
+    f.bcl = tiles[t].bcl + u64(r.clusterId) * o.clusterLength + o.readOffset[readIndex];
+    const u32 *cigar = bamRecordCigar(tiles[t], r);
+    RealignIndex index = { r.fStrandPosition, cigar, cigar + r.cigarLength };
+    const u32 contig = refposContig(r.fStrandPosition);
+    RealignCigar result;
+    if (!realignFragment(x, gapsView, refpos(contig, 0), refpos(contig, contigLength(R, contig)), index, f, result)) return;
+    const u32 at = atomicAdd(poolNext, result.n);
+    if (at + result.n > poolCap) return;                                         // no room: the fragment keeps its alignment (sized so that this does not happen)
+    for (u32 k = 0; k < result.n; ++k) pool[at + k] = result.words[k];
+    r.fStrandPosition = f.fStrandPosition; r.observedLength = f.observedLength; r.editDistance = f.editDistance; r.cigarLength = u16(result.n); r.cigarOffset = at;
+    r.reserved |= RECORD_CIGAR_REALIGNED;
+    changed[i] = 1;
+}
+// GapRealigner::updatePairDetails (:267-318).  The reference brings a pair up to date whenever one of its ends has been realigned, the ends of a
+// bin in the order of its index: reverse-strand ends and shadows first, then forward-strand ends, each list in the duplicate filter's order.
+// With both ends final that is: TLEN and mate positions from the final alignments, proper-pair from checkModel(end realigned last, its mate).
+__global__ void k_realign_pairs(const BamTile *tiles, u32 nTiles, u64 nRecords, BamOptions o, FragmentRecord *records, const u8 *changed)
+{
+    const u64 unit = u64(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (1 == o.nReads)
+    {   // single-ended: !index.hasMate() (:272-276)
+        if (unit < nRecords && changed[unit]) { FragmentRecord &r = records[unit]; r.bamTlen = r.bamTlen < 0 ? -i32(r.observedLength) + 1 : i32(r.observedLength) - 1; }
+        return;
+    }
+    const u64 i = 2 * unit;                       // a pair: records 2k (read 1) and 2k + 1 (read 2) of a tile
+    if (i + 1 >= nRecords) return;
+    FragmentRecord &a = records[i];
+    FragmentRecord &b = records[i + 1];
+    if (!changed[i] && !changed[i + 1]) return;
+    const u32 t = bamTileOf(tiles, nTiles, i);
+    // which end was realigned last
+    bool aLast = changed[i] && !changed[i + 1];
+    if (changed[i] && changed[i + 1])
+    {
+        const bool aForward = !(a.flags & 8), bForward = !(b.flags & 8);
+        if (aForward != bForward) aLast = aForward;
+        else
+        {
+            const u8 *clusterBcl = tiles[t].bcl + u64(a.clusterId) * o.clusterLength;
+            const u64 pa = aForward ? a.fStrandPosition : dupAnchor(a, clusterBcl), pb = bForward ? b.fStrandPosition : dupAnchor(b, clusterBcl + o.readOffset[1]);
+            aLast = pa > pb;      // later in the list's order; equal keys: the second read
+        }
+    }
+    FragmentRecord &f = aLast ? a : b, &m = aLast ? b : a;
+    const u64 fragmentBeginPos = f.fStrandPosition, fragmentEndPos = rpPlus(fragmentBeginPos, f.observedLength), mateBeginPos = m.fStrandPosition, mateEndPos = rpPlus(mateBeginPos, m.observedLength);
+    f.mateFStrandPosition = m.fStrandPosition;
+    f.bamTlen = rgTlen(fragmentBeginPos, fragmentEndPos, mateBeginPos, mateEndPos, 0 != (f.flags & 32));
+    m.bamTlen = -f.bamTlen;
+    m.mateFStrandPosition = f.fStrandPosition;
+    Cand cf, cm; candInit(cf, 0); candInit(cm, 1);
+    cf.contigId = refposContig(f.fStrandPosition); cf.position = i64(refposPosition(f.fStrandPosition)); cf.reverse = (f.flags & 8) ? 1 : 0; cf.observedLength = f.observedLength; cf.cigarLength = 1;
+    cm.contigId = refposContig(m.fStrandPosition); cm.position = i64(refposPosition(m.fStrandPosition)); cm.reverse = (m.flags & 8) ? 1 : 0; cm.observedLength = m.observedLength; cm.cigarLength = 1;
+    const bool proper = TLS_NOMINAL == tlsCheckModel(o.tls, cf, cm);
+    f.flags = (f.flags & ~256u) | (proper ? 256u : 0u); m.flags = (m.flags & ~256u) | (proper ? 256u : 0u);
 }
 
 // One workgroup per BAM_CHUNK_RECORDS consecutive records of the file.  Everything is done by threads that each own a small piece of a

@@ -11,7 +11,8 @@ static const u32 OUT_CIGAR_CAP = 40;   // ISAAC_GPU_MAX_CIGAR_OPS words per read
 enum { RECORD_TEMPLATE_OVERFLOW = 1,   // a template-stage work list overflowed: redo the cluster with heavyCaps()
        RECORD_NOT_STORED = 2,          // the reference would not have stored this template (only without --keep-unaligned)
        RECORD_FRAGMENT_OVERFLOW = 4,   // a fragment-stage capacity was exceeded: the cluster's result is not exact
-       RECORD_MAPQ_NEAR_INTEGER = 8 }; // a MAPQ of this cluster is floor(v) with v within 1e-11 of an integer (mapqFloor): a host that must be sure
+       RECORD_MAPQ_NEAR_INTEGER = 8,
+       RECORD_CIGAR_REALIGNED = 16 };  // BAM stage, on its private copy of the records: the CIGAR lies in the gap realigner's pool (BamTile::cigarsAlt) // a MAPQ of this cluster is floor(v) with v within 1e-11 of an integer (mapqFloor): a host that must be sure
                                        // the device's log10/exp rounded like glibc's re-derives exactly these clusters
 
 // FragmentBuilder::build for cluster `cluster` of the tile; its matches are matches[offsets[cluster] .. offsets[cluster + 1])

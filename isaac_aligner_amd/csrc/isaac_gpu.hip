@@ -81,6 +81,7 @@ struct isaac_gpu_ctx
     // isaac_gpu_bam_records scratch
     DevBuf<BamTile> bamTiles; DevBuf<u64> bamKeyHi, bamKeyLo, bamKeyAlt, bamOffsets, bamBytes64, bamBounds; DevBuf<u32> bamIndex, bamIndexAlt, bamBytes;
     DevBuf<u64> dupPrimary, dupMate, dupRank, dupCluster, dupSmall; DevBuf<u8> dupFlag;        // duplicate marking
+    DevBuf<FragmentRecord> realignRecords; DevBuf<RealignGap> realignGaps, realignDeletionEnds; DevBuf<u32> realignPool, realignNext; DevBuf<u8> realignChanged;   // gap realignment
     DevBuf<RescueJob> jobs; DevBuf<u32> rescueCounters, bitmaps, candJob, shadowCigars, jobBase, jobCount; DevBuf<i32> candPositions; DevBuf<Cand> shadowCands; DevBuf<u32> candRank;
     DevBuf<Counters> counters;
     std::map<std::string, KernelTimer> timers;
@@ -1345,6 +1346,15 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
     o.forcedDodgyAlignmentScore = options ? (options->forced_dodgy_alignment_score & 0xff) : (u32(c->params.dodgy_alignment_score) & 0xff);
     o.pessimisticMapQ = options ? options->pessimistic_mapq : 0;
     o.markDuplicates = options ? (options->mark_duplicates != 0) : 0; o.keepDuplicates = options ? (options->keep_duplicates != 0) : 1;
+    o.realignGaps = options ? (options->realign_gaps != 0) : 0;
+    if (o.realignGaps)
+    {
+        if (options->realign_vigorously) return fail(ISAAC_GPU_EINVAL, "--realign-vigorously is not implemented");
+        if (2 == o.nReads && !options->tls) return fail(ISAAC_GPU_EINVAL, "gap realignment of paired reads needs the template length statistics (isaac_bam_options::tls)");
+        // BinSorter.hh:96-98: GapRealigner(realignGapsVigorously, realignDodgyFragments, realignedGapsPerFragment, 3, 4, 0, clipSemialigned, ...)
+        o.realign.mismatchCost = 3; o.realign.gapOpenCost = 4; o.realign.gapExtendCost = 0; o.realign.realignDodgyFragments = options->realign_dodgy != 0; o.realign.clipSemialigned = c->params.clip_semialigned != 0;
+        if (options->tls) std::memcpy(&o.tls, options->tls, sizeof(o.tls));
+    }
     std::vector<BamTile> h(nTiles);
     u64 n = 0;
     for (u32 t = 0; t < nTiles; ++t)
@@ -1364,6 +1374,15 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
     hipStream_t st = c->stream;
     c->bamTiles.reserve(nTiles); c->bamKeyHi.reserve(n); c->bamKeyLo.reserve(n); c->bamKeyAlt.reserve(n); c->bamOffsets.reserve(n); c->bamBytes64.reserve(n);
     c->bamIndex.reserve(n); c->bamIndexAlt.reserve(n); c->bamBytes.reserve(n); c->bamBounds.reserve(2);
+    if (o.realignGaps)
+    {   // the realigner works on a copy of the records: positions, CIGARs, TLEN and proper-pair flags change, the caller's buffers do not
+        c->realignRecords.reserve(n); c->realignPool.reserve(n + 1024); c->realignNext.reserve(1); c->realignChanged.reserve(n);
+        for (u32 t = 0; t < nTiles; ++t)
+        {
+            if (h[t].nRecords) HIP_CHECK(hipMemcpyAsync(c->realignRecords.p + h[t].firstRecord, h[t].records, sizeof(FragmentRecord) * h[t].nRecords, hipMemcpyDeviceToDevice, st));
+            h[t].records = c->realignRecords.p + h[t].firstRecord; h[t].cigarsAlt = c->realignPool.p;
+        }
+    }
     HIP_CHECK(hipMemcpyAsync(c->bamTiles.p, h.data(), sizeof(BamTile) * nTiles, hipMemcpyHostToDevice, st));
     const u64 bounds0[2] = { n, n };
     HIP_CHECK(hipMemcpyAsync(c->bamBounds.p, bounds0, sizeof(bounds0), hipMemcpyHostToDevice, st));
@@ -1386,6 +1405,44 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
         k_dup_mark<<<gridFor(n, 256), 256, 0, st>>>(from, n, c->dupPrimary.p, c->dupMate.p, c->dupCluster.p, c->dupSmall.p, c->dupFlag.p);
         HIP_CHECK(hipGetLastError());
         duplicate = c->dupFlag.p;
+    }
+    if (o.realignGaps)
+    {   // BinSorter::collectGaps + realignGaps with every contig as one bin (bam_kernels.h, realign.h)
+        ScopedTimer t(c, "bam_realign");
+        u32 *counts = c->bamBytes.p, *offsets = c->bamIndexAlt.p;
+        k_realign_count<<<gridFor(n, 256), 256, 0, st>>>(c->bamTiles.p, nTiles, n, counts);
+        exclusiveSum(c, counts, offsets, n);
+        u32 lastCount = 0, lastOffset = 0;
+        HIP_CHECK(hipMemcpyAsync(&lastCount, counts + n - 1, 4, hipMemcpyDeviceToHost, st)); HIP_CHECK(hipMemcpyAsync(&lastOffset, offsets + n - 1, 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        const u64 nGaps = u64(lastCount) + lastOffset;
+        std::vector<RealignGap> gaps(nGaps), deletionEnds;
+        if (nGaps)
+        {
+            c->realignGaps.reserve(nGaps); c->realignDeletionEnds.reserve(nGaps);
+            k_realign_collect<<<gridFor(n, 256), 256, 0, st>>>(c->bamTiles.p, nTiles, n, offsets, c->realignGaps.p);
+            HIP_CHECK(hipMemcpyAsync(gaps.data(), c->realignGaps.p, nGaps * sizeof(RealignGap), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            // RealignerGaps::finalizeGaps (GapRealigner.cpp:86-94) with the host's std::sort, one contig (bin) at a time for the deletion ends
+            std::sort(gaps.begin(), gaps.end(), [](const RealignGap &l, const RealignGap &r) { return rgLess(l, r); });
+            gaps.erase(std::unique(gaps.begin(), gaps.end(), [](const RealignGap &l, const RealignGap &r) { return l.pos == r.pos && l.length == r.length; }), gaps.end());
+            for (size_t b = 0; b < gaps.size();)
+            {
+                size_t e = b; while (e < gaps.size() && refposContig(gaps[e].pos) == refposContig(gaps[b].pos)) ++e;
+                const size_t first = deletionEnds.size();
+                for (size_t k = b; k < e; ++k) if (rgIsDeletion(gaps[k])) deletionEnds.push_back(gaps[k]);
+                std::sort(deletionEnds.begin() + first, deletionEnds.end(), [](const RealignGap &l, const RealignGap &r) { return rgEndPos(l, false) < rgEndPos(r, false); });
+                b = e;
+            }
+            HIP_CHECK(hipMemcpyAsync(c->realignGaps.p, gaps.data(), gaps.size() * sizeof(RealignGap), hipMemcpyHostToDevice, st));
+            if (!deletionEnds.empty()) HIP_CHECK(hipMemcpyAsync(c->realignDeletionEnds.p, deletionEnds.data(), deletionEnds.size() * sizeof(RealignGap), hipMemcpyHostToDevice, st));
+        }
+        RealignerGapsView view = { c->realignGaps.p, u32(gaps.size()), c->realignDeletionEnds.p, u32(deletionEnds.size()) };
+        HIP_CHECK(hipMemsetAsync(c->realignNext.p, 0, 4, st));
+        k_realign<<<gridFor(n, 128), 128, 0, st>>>(c->bamTiles.p, nTiles, n, o, c->ref(), view, duplicate, c->realignRecords.p, c->realignPool.p, u32(n), c->realignNext.p, c->realignChanged.p);
+        k_realign_pairs<<<gridFor(n, 256), 256, 0, st>>>(c->bamTiles.p, nTiles, n, o, c->realignRecords.p, c->realignChanged.p);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(st));         // the host vectors above are read by the copies
     }
     {
         ScopedTimer t(c, "bam_order");

@@ -319,7 +319,7 @@ class Aligner:
             self._inflight.append((records, cigars, out, n_words_dev))
 
     # ---- output format --------------------------------------------------------------------------------------------
-    def bam_records(self, tiles, out=None, read_group=None, barcode=None, forced_dodgy_alignment_score=None, pessimistic_mapq=False, mark_duplicates=False, keep_duplicates=True):
+    def bam_records(self, tiles, out=None, read_group=None, barcode=None, forced_dodgy_alignment_score=None, pessimistic_mapq=False, mark_duplicates=False, keep_duplicates=True, realign_gaps=False, tls=None):
         """build::Build's BAM alignment records (--realign-gaps no --mark-duplicates 0) of one or more tiles, in file order.
         tiles: [(bcl, records, cigars, read_name_prefix)] as given to / returned by select().  Returns (uint8 device tensor of the
         uncompressed records, number of records, offset of the unaligned bin)."""
@@ -337,9 +337,11 @@ class Aligner:
             arr[i].read_name_prefix = name
             n_rec += records.shape[0]
         options = None
-        if read_group is not None or barcode is not None or forced_dodgy_alignment_score is not None or pessimistic_mapq or mark_duplicates or not keep_duplicates:
+        if read_group is not None or barcode is not None or forced_dodgy_alignment_score is not None or pessimistic_mapq or mark_duplicates or not keep_duplicates or realign_gaps:
             options = bam.BamOptions()
             options.mark_duplicates, options.keep_duplicates = int(bool(mark_duplicates)), int(bool(keep_duplicates))
+            options.realign_gaps = int(bool(realign_gaps))
+            options.tls = C.cast(C.pointer(tls), C.c_void_p) if tls is not None else None
             options.forced_dodgy_alignment_score = (self.params.dodgy_alignment_score & 0xff) if forced_dodgy_alignment_score is None else forced_dodgy_alignment_score
             options.pessimistic_mapq = int(bool(pessimistic_mapq))
             options.read_group = None if read_group is None else read_group.encode()

@@ -1,5 +1,6 @@
 // ORACLE -- TEST INFRASTRUCTURE ONLY (see oracle/README.md).  CPU restatement of the BAM side of the path for
 // --realign-gaps no, --mark-duplicates 0 | 1, --keep-duplicates 0 | 1 and the default tag set (--bam-exclude-tags ZX,ZY):
+//   gap realignment (--realign-gaps sample)    lib/build/BinSorter.cpp:387-417 around realign.cpp (GapRealigner), every contig one bin
 //   duplicate marking                          lib/build/BinSorter.cpp:293-330, include/build/DuplicateFragmentIndexFiltering.hh:37-208,
 //                                              include/build/DuplicatePairEndFilter.hh:45-107, include/io/Fragment.hh:66-71,490-506
 //   what FragmentCollector keeps per read      lib/alignment/matchSelector/FragmentCollector.cpp:43-111
@@ -26,8 +27,8 @@ const uint64_t NO_MATCH_VALUE = ReferencePosition(ReferencePosition::NoMatch).va
 // the stored form of one read: header fields, bases as stored (FragmentCollector::storeBclAndCigar), CIGAR
 struct Stored
 {
-    const FragmentRecord *header; std::vector<unsigned char> bases; const uint32_t *cigarBegin, *cigarEnd; const std::string *namePrefix;
-    const uint8_t *clusterBcl = 0; const FragmentRecord *mate = 0; bool duplicate = false;
+    FragmentRecord *header; std::vector<unsigned char> bases; const uint32_t *cigarBegin, *cigarEnd; const std::string *namePrefix;
+    const uint8_t *clusterBcl = 0; FragmentRecord *mate = 0; bool duplicate = false;
     bool paired() const { return header->flags & 1; }
     bool unmapped() const { return header->flags & 2; }
     bool mateUnmapped() const { return header->flags & 4; }
@@ -180,11 +181,17 @@ void filterDuplicates(std::vector<PairEndIndex> &ends, std::vector<char> &isDupl
 
 void bamRecords(const std::vector<BamTileInput> &tiles, const BamOptions &o, std::vector<char> &os, uint64_t &nRecords, uint64_t &unalignedOffset)
 {
+    // the realigner changes records: everything below works on copies
+    std::vector<std::vector<FragmentRecord> > copies;
+    for (const BamTileInput &t : tiles) copies.push_back(std::vector<FragmentRecord>(t.records, t.records + t.nRecords));
+    std::vector<uint32_t> realignedCigars;
     std::vector<Stored> stored;
-    for (const BamTileInput &t : tiles)
+    for (size_t tileIndex = 0; tileIndex < tiles.size(); ++tileIndex)
+    {
+        const BamTileInput &t = tiles[tileIndex];
         for (uint64_t i = 0; i < t.nRecords; ++i)
         {
-            const FragmentRecord &h = t.records[i];
+            FragmentRecord &h = copies[tileIndex][i];
             if (h.reserved & 2) continue;                                     // MatchSelector.cpp:345-357: the template was not stored
             Stored s; s.header = &h; s.namePrefix = &t.namePrefix;
             const unsigned readIndex = (h.flags & 1) && (h.flags & 64) ? 1 : 0;
@@ -193,15 +200,20 @@ void bamRecords(const std::vector<BamTileInput> &tiles, const BamOptions &o, std
             if (s.reverse()) { std::reverse(s.bases.begin(), s.bases.end()); for (unsigned char &b : s.bases) b = reverseBcl(b); }
             s.cigarBegin = t.cigars + h.cigarOffset; s.cigarEnd = s.cigarBegin + ((h.flags & 2) ? 0 : h.cigarLength);
             s.clusterBcl = t.bcl + uint64_t(h.clusterId) * o.clusterLength;
-            if (h.flags & 1) s.mate = &t.records[i ^ 1];                      // records come in cluster order, read 0 before read 1
+            if (h.flags & 1) s.mate = &copies[tileIndex][i ^ 1];              // records come in cluster order, read 0 before read 1
             stored.push_back(s);
         }
-    if (o.markDuplicates || !o.keepDuplicates)
+    }
+    // the ends of pairs in the order of the bin's index after BinSorter::resolveDuplicates: reverse-strand ends and shadows, then forward-strand
+    // ends, each list as the duplicate filter's sort leaves it (without filtering the reference keeps the order of its bin files, which is the
+    // order its threads happened to store fragments in; the sorted order stands in for it)
+    std::vector<PairEndIndex> ends[2];
+    const bool filtering = o.markDuplicates || !o.keepDuplicates;
+    if (filtering || o.realignGaps)
     {
         // BinSorter::loadAlignedData (:214-291) + resolveDuplicates (:293-330): the ends of pairs with a bin position, forward-strand ones apart
         // from reverse-strand ones and shadows; single-ended reads and the unaligned bin are never filtered.  One library (one barcode), and bins
         // as wide as a contig: mates with equal anchors then share a storage bin, so mate_.info_.storageBin_ is the same everywhere
-        std::vector<PairEndIndex> ends[2];
         for (size_t k = 0; k < stored.size(); ++k)
         {
             const Stored &s = stored[k]; const FragmentRecord &h = *s.header;
@@ -225,11 +237,76 @@ void bamRecords(const std::vector<BamTileInput> &tiles, const BamOptions &o, std
         {
             std::vector<char> dup;
             filterDuplicates(ends[rs], dup);
-            for (size_t k = 0; k < ends[rs].size(); ++k) if (dup[k]) stored[ends[rs][k].tag].duplicate = true;
+            if (filtering) for (size_t k = 0; k < ends[rs].size(); ++k) if (dup[k]) stored[ends[rs][k].tag].duplicate = true;
         }
-        if (!o.keepDuplicates) stored.erase(std::remove_if(stored.begin(), stored.end(), [](const Stored &s) { return s.duplicate; }), stored.end());
-        else if (!o.markDuplicates) for (Stored &s : stored) s.duplicate = false;
     }
+    if (o.realignGaps)
+    {
+        // BinSorter::collectGaps (:387-403): the gaps of every fragment of the bin's data (discarded duplicates included), a bin = a contig
+        const ContigList &contigs = *o.contigs;
+        std::vector<RealignerGaps> binGaps(contigs.size());
+        for (const Stored &s : stored)
+        {
+            const FragmentRecord &h = *s.header;
+            if (h.fStrandPosition == NO_MATCH_VALUE || (h.flags & 2) || !h.gapCount) continue;
+            binGaps.at(ReferencePosition::fromValue(h.fStrandPosition).getContigId()).addGaps(ReferencePosition::fromValue(h.fStrandPosition), s.cigarBegin, s.cigarEnd);
+        }
+        for (RealignerGaps &g : binGaps) g.finalizeGaps();
+        // BinSorter::realignGaps (:405-417): the index in order (single-ended, reverse-strand ends and shadows, forward-strand ends), duplicates that were dropped are not in it
+        const GapRealigner realigner = { false, o.realignDodgy, 1, 3, 4, 0, o.clipSemialigned, contigs };
+        realignedCigars.reserve(size_t(1) << 26);
+        std::vector<size_t> order;
+        for (size_t k = 0; k < stored.size(); ++k) if (!stored[k].paired() && stored[k].header->fStrandPosition != NO_MATCH_VALUE) order.push_back(k);
+        for (int rs = 1; rs >= 0; --rs) for (const PairEndIndex &e : ends[rs]) order.push_back(size_t(e.tag));
+        for (const size_t k : order)
+        {
+            Stored &s = stored[k];
+            if (s.duplicate && !o.keepDuplicates) continue;
+            FragmentRecord &h = *s.header;
+            if (h.flags & 2) continue;
+            const ReferencePosition pos = ReferencePosition::fromValue(h.fStrandPosition);
+            const ReferencePosition binStartPos(pos.getContigId(), 0), binEndPos(pos.getContigId(), contigs.at(pos.getContigId()).forward.size());
+            RealignFragment f = RealignFragment();
+            f.fStrandPosition = pos; f.mateFStrandPosition = h.mateFStrandPosition; f.observedLength = h.observedLength; f.lowClipped = h.lowClipped; f.highClipped = h.highClipped;
+            f.alignmentScore = h.alignmentScore; f.templateAlignmentScore = h.templateAlignmentScore; f.readLength = h.readLength; f.editDistance = h.editDistance; f.flags = h.flags; f.bases = s.bases.data();
+            RealignIndex index = { pos, s.cigarBegin, s.cigarEnd };
+            bool changed = false;
+            realigner.realign(binGaps.at(pos.getContigId()), binStartPos, binEndPos, index, f, realignedCigars, changed);
+            if (!changed) continue;
+            h.fStrandPosition = f.fStrandPosition.value; h.observedLength = f.observedLength; h.editDistance = f.editDistance;
+            s.cigarBegin = index.cigarBegin; s.cigarEnd = index.cigarEnd; h.cigarLength = uint16_t(index.cigarEnd - index.cigarBegin);
+            // GapRealigner::updatePairDetails (GapRealigner.cpp:267-318); index.hasMate(): the mate is in the same bin
+            const bool hasMate = s.paired() && ReferencePosition::fromValue(h.mateFStrandPosition).getContigId() == pos.getContigId();
+            if (!hasMate || (h.flags & 4)) { h.bamTlen = h.bamTlen < 0 ? -int(h.observedLength) + 1 : int(h.observedLength) - 1; continue; }
+            FragmentRecord &mate = *s.mate;
+            const ReferencePosition fragmentBeginPos = f.fStrandPosition, fragmentEndPos = ReferencePosition::fromValue(advance(h.fStrandPosition, h.observedLength));
+            const ReferencePosition mateBeginPos = ReferencePosition::fromValue(h.mateFStrandPosition), mateEndPos = ReferencePosition::fromValue(advance(h.mateFStrandPosition, mate.observedLength));
+            // io::FragmentHeader::getTlen (Fragment.hh:199-212)
+            const uint64_t distance = std::max(fragmentEndPos, mateEndPos).getLocation() - std::min(fragmentBeginPos, mateBeginPos).getLocation();
+            const bool firstRead = h.flags & 32;
+            const long tlen = fragmentBeginPos < mateBeginPos ? long(distance) : (mateBeginPos < fragmentBeginPos || !firstRead) ? -long(distance) : long(distance);
+            h.bamTlen = int(tlen); mate.bamTlen = -h.bamTlen;
+            mate.mateFStrandPosition = h.fStrandPosition;
+            // TemplateLengthStatistics::checkModel(fragment, mate) (TemplateLengthStatistics.hh:104-118) on the two FragmentAccessors
+            bool proper = false;
+            {
+                const TemplateLengthStatistics &tls = *o.tls;
+                const ReferencePosition mp = ReferencePosition::fromValue(mate.fStrandPosition);
+                if (pos.getContigId() == mp.getContigId())
+                {
+                    const long p1 = long(f.fStrandPosition.getPosition()), p2 = long(mp.getPosition());
+                    const unsigned model = ((p1 <= p2) ? 0 : 4) | ((h.flags & 8) ? 2 : 0) | ((mate.flags & 8) ? 1 : 0);
+                    if (model == unsigned(tls.bestModels[0]) || model == unsigned(tls.bestModels[1]))
+                    {
+                        const unsigned long length = p1 < p2 ? (unsigned long)std::max<long>(p2 + mate.observedLength - p1, h.observedLength) : (unsigned long)std::max<long>(p1 + h.observedLength - p2, mate.observedLength);
+                        proper = !(length > tls.max) && !(length < tls.min);
+                    }
+                }
+            }
+            h.flags = (h.flags & ~256u) | (proper ? 256u : 0u); mate.flags = (mate.flags & ~256u) | (proper ? 256u : 0u);
+        }
+    }
+    if (!o.keepDuplicates) stored.erase(std::remove_if(stored.begin(), stored.end(), [](const Stored &s) { return s.duplicate; }), stored.end());
     // aligned bins: everything with a bin position; the unaligned bin keeps storage order
     std::vector<const Stored *> aligned, unaligned;
     for (const Stored &s : stored) (s.header->fStrandPosition == NO_MATCH_VALUE ? unaligned : aligned).push_back(&s);

@@ -888,8 +888,9 @@ int oracle_filter_duplicates(uint64_t n, const uint64_t *primary, const uint64_t
 }
 
 int oracle_bam_records(const oracle_bam_tile *tiles, uint32_t n_tiles, uint32_t n_reads, const uint32_t *read_lengths, uint32_t forced_dodgy_alignment_score,
-                       int pessimistic_mapq, const char *read_group, const char *barcode, int mark_duplicates, int keep_duplicates, uint8_t *out, uint64_t capacity, uint64_t *n_bytes,
-                       uint64_t *n_records, uint64_t *unaligned_offset)
+                       int pessimistic_mapq, const char *read_group, const char *barcode, int mark_duplicates, int keep_duplicates,
+                       int realign_gaps, int realign_dodgy, int clip_semialigned, const oracle_ref *reference, const oracle_tls *tls,
+                       uint8_t *out, uint64_t capacity, uint64_t *n_bytes, uint64_t *n_records, uint64_t *unaligned_offset)
 {
     try
     {
@@ -902,6 +903,9 @@ int oracle_bam_records(const oracle_bam_tile *tiles, uint32_t n_tiles, uint32_t 
         BamOptions o; o.clusterLength = 0; o.readOffset[0] = o.readOffset[1] = 0;
         for (uint32_t r = 0; r < n_reads; ++r) { o.readOffset[r] = o.clusterLength; o.clusterLength += read_lengths[r]; }
         o.forcedDodgyAlignmentScore = (unsigned char)forced_dodgy_alignment_score; o.pessimisticMapQ = pessimistic_mapq; o.readGroup = read_group; o.barcode = barcode; o.markDuplicates = mark_duplicates != 0; o.keepDuplicates = keep_duplicates != 0;
+        TemplateLengthStatistics stats; if (tls) stats = fromTls(tls);
+        o.realignGaps = realign_gaps != 0; o.realignDodgy = realign_dodgy != 0; o.clipSemialigned = clip_semialigned != 0; o.contigs = reference ? &reference->contigs : 0; o.tls = tls ? &stats : 0;
+        if (o.realignGaps && !o.contigs) throw std::runtime_error("gap realignment needs the reference");
         std::vector<char> os;
         bamRecords(in, o, os, *n_records, *unaligned_offset);
         *n_bytes = os.size();

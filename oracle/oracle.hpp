@@ -687,7 +687,8 @@ void fastqDiscoverTiles(unsigned clustersLoaded, unsigned tileClustersMax, unsig
 // bam.cpp: the BAM record stream of a set of tiles (build::Build with --realign-gaps no --mark-duplicates 0) and the BAM header
 struct BamTileInput { const uint8_t *bcl; const FragmentRecord *records; const uint32_t *cigars; uint64_t nRecords; std::string namePrefix; };
 struct BamOptions { unsigned clusterLength, readOffset[2]; unsigned char forcedDodgyAlignmentScore; bool pessimisticMapQ; std::string readGroup, barcode;
-                    bool markDuplicates = false, keepDuplicates = true; };       // --mark-duplicates / --keep-duplicates (BinSorter.cpp:293-330)
+                    bool markDuplicates = false, keepDuplicates = true;          // --mark-duplicates / --keep-duplicates (BinSorter.cpp:293-330)
+                    bool realignGaps = false, realignDodgy = false, clipSemialigned = true; const ContigList *contigs = 0; const TemplateLengthStatistics *tls = 0; };   // --realign-gaps sample
 // One end of a pair as the duplicate filter sees it: build::FStrandFragmentIndex / RStrandOrShadowFragmentIndex (include/build/FragmentIndex.hh:101-192)
 // with the fields of the fragment its comparators look up (library = barcode or sample index, tile * 10^9 + cluster).
 struct PairEndIndex

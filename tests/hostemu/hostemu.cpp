@@ -7,6 +7,7 @@
 #include "../../isaac_aligner_amd/csrc/sums.h"
 #include "../../isaac_aligner_amd/csrc/bam_kernels.h"
 #include "../../isaac_aligner_amd/csrc/bgzf_kernels.h"
+#include "../../isaac_aligner_amd/csrc/realign.h"
 #include "../../isaac_aligner_amd/csrc/host_util.h"
 #include <string>
 #include <vector>
@@ -289,6 +290,39 @@ int emu_select_literal(Emu *e, const u8 *bcl, const LiteralFragment *f0, u32 n0,
     TemplateWork work;
     templateWorkBind(work, reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(arena.data()) + 15) & ~uintptr_t(15)), heavyCaps());
     clusterSelect(e->P, e->R, t, rog, logMismatchQ40(), bcl, 0, 32, f, work, reinterpret_cast<FragmentRecord *>(records), cigars, e->cnt);
+    return 0;
+}
+
+// realign.h (the BAM stage's gap realigner, thread-serial) on one fragment: the same inputs and outputs as the oracle's oracle_realign_case
+int emu_realign_case(const char *contig, uint64_t contigLength, const uint8_t *readBcl, uint32_t readLength, uint64_t fStrandPosition, const uint32_t *cigar, uint32_t cigarLength,
+                     uint32_t observedLength, uint32_t editDistance, uint32_t lowClipped, uint32_t highClipped, const int64_t *gapPositions, const int32_t *gapLengths, uint32_t nGaps,
+                     uint32_t mismatchCost, uint32_t gapOpenCost, uint32_t gapExtendCost, int dodgy, int clipSemialigned, uint64_t binStart, int64_t binEnd,
+                     uint64_t *realignedPosition, uint32_t *realignedCigar, uint32_t *realignedCigarLength, uint32_t *realignedEditDistance, uint32_t *realignedObservedLength)
+{
+    DevReference R; std::memset(&R, 0, sizeof(R));
+    const u64 offsets[2] = { 0, contigLength };
+    R.bases = contig; R.totalBases = contigLength; R.contigOffset = offsets; R.nContigs = 1;
+    // RealignerGaps::finalizeGaps
+    std::vector<RealignGap> gaps(nGaps);
+    for (u32 i = 0; i < nGaps; ++i) { gaps[i].pos = refpos(0, u64(gapPositions[i])); gaps[i].length = gapLengths[i]; gaps[i].pad = 0; }
+    std::sort(gaps.begin(), gaps.end(), [](const RealignGap &l, const RealignGap &r) { return rgLess(l, r); });
+    gaps.erase(std::unique(gaps.begin(), gaps.end(), [](const RealignGap &l, const RealignGap &r) { return l.pos == r.pos && l.length == r.length; }), gaps.end());
+    std::vector<RealignGap> ends;
+    for (const RealignGap &g : gaps) if (rgIsDeletion(g)) ends.push_back(g);
+    std::stable_sort(ends.begin(), ends.end(), [](const RealignGap &l, const RealignGap &r) { return rgEndPos(l, false) < rgEndPos(r, false); });
+    RealignerGapsView view = { gaps.data(), u32(gaps.size()), ends.data(), u32(ends.size()) };
+    RealignCtx x; x.R = &R; x.P.mismatchCost = mismatchCost; x.P.gapOpenCost = gapOpenCost; x.P.gapExtendCost = gapExtendCost; x.P.realignDodgyFragments = dodgy != 0; x.P.clipSemialigned = clipSemialigned != 0;
+    RealignFragment f; std::memset(&f, 0, sizeof(f));
+    f.fStrandPosition = refpos(0, fStrandPosition); f.mateFStrandPosition = f.fStrandPosition; f.observedLength = observedLength; f.flags = 0;
+    f.lowClipped = u16(lowClipped); f.highClipped = u16(highClipped); f.alignmentScore = 1; f.templateAlignmentScore = 0; f.readLength = u16(readLength); f.editDistance = u16(editDistance); f.bcl = readBcl;
+    RealignIndex index = { f.fStrandPosition, cigar, cigar + cigarLength };
+    RealignCigar result; result.n = 0; result.overflow = false;
+    const u64 binStartPos = refpos(0, binStart), binEndPos = binEnd < 0 ? refpos(0, binStart + contigLength) : refpos(0, u64(binEnd));
+    realignFragment(x, view, binStartPos, binEndPos, index, f, result);
+    *realignedPosition = refposPosition(index.pos);
+    *realignedCigarLength = u32(index.cigarEnd - index.cigarBegin);
+    for (const u32 *it = index.cigarBegin; it != index.cigarEnd; ++it) *realignedCigar++ = *it;
+    *realignedEditDistance = f.editDistance; *realignedObservedLength = f.observedLength;
     return 0;
 }
 

@@ -101,7 +101,8 @@ class Oracle:
         self.check(self.lib.oracle_filter_duplicates(C.c_uint64(len(out)), *[ptr(a) for a in arrays], ptr(out)))
         return out.astype(bool)
 
-    def bam_records(self, tiles, read_lengths, forced_dodgy_alignment_score=0, pessimistic_mapq=False, read_group="0", barcode="none", mark_duplicates=False, keep_duplicates=True):
+    def bam_records(self, tiles, read_lengths, forced_dodgy_alignment_score=0, pessimistic_mapq=False, read_group="0", barcode="none", mark_duplicates=False, keep_duplicates=True,
+                    realign_gaps=False, realign_dodgy=False, clip_semialigned=True, reference=None, tls=None):
         """tiles: [(bcl, records, cigars, read_name_prefix)] as numpy arrays; returns (bytes, n_records, unaligned_offset)"""
         arr = (BamTile * len(tiles))()
         keep = []
@@ -117,7 +118,9 @@ class Oracle:
         out = np.empty(cap, np.uint8)
         nb, nr, un = C.c_uint64(), C.c_uint64(), C.c_uint64()
         self.check(self.lib.oracle_bam_records(arr, C.c_uint32(len(tiles)), C.c_uint32(len(read_lengths)), lengths, C.c_uint32(forced_dodgy_alignment_score), C.c_int(int(pessimistic_mapq)),
-                                               read_group.encode(), barcode.encode(), C.c_int(int(mark_duplicates)), C.c_int(int(keep_duplicates)), ptr(out), C.c_uint64(cap), C.byref(nb), C.byref(nr), C.byref(un)))
+                                               read_group.encode(), barcode.encode(), C.c_int(int(mark_duplicates)), C.c_int(int(keep_duplicates)),
+                                               C.c_int(int(realign_gaps)), C.c_int(int(realign_dodgy)), C.c_int(int(clip_semialigned)), (reference.h if reference is not None else None),
+                                               C.byref(tls) if tls is not None else None, ptr(out), C.c_uint64(cap), C.byref(nb), C.byref(nr), C.byref(un)))
         return out[:nb.value].tobytes(), nr.value, un.value
 
     def bam_header(self, command_line, version, contigs, description="", header_lines=()):

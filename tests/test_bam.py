@@ -334,6 +334,78 @@ def test_gpu_duplicate_marking_matches_the_oracle():
 
 
 @pytest.mark.gpu
+def test_gpu_gap_realignment_matches_the_oracle():
+    """--realign-gaps sample (BinSorter::collectGaps / realignGaps, GapRealigner): reads of a sample that carries indels against the reference,
+    30-fold coverage, so that reads which cross an indel near one of their ends (aligned without the gap, with mismatches) can borrow the
+    gap from reads that show it.  isaac_gpu_bam_records with realign_gaps (and with the reference's default duplicate marking) against the
+    oracle's restatement, which the reference's testGapRealigner cases pin: the same bytes; a good number of records do change."""
+    import torch
+    from isaac_aligner_amd import gpu
+    o = oracle_lib.load()
+    rng = np.random.default_rng(17)
+    L = 100
+    genome = synth.make_genome(200000, seed=61, n_contigs=2, repeat_families=False)
+    contigs = [bytes(c.numpy()) for c in genome]
+    sample = []
+    for c in genome:                                                     # the sample's chromosomes: an indel of 1-8 bases every ~400 bases
+        seq = c.numpy().copy()
+        pieces, at = [], 0
+        while at < len(seq):
+            step = int(rng.integers(250, 550))
+            pieces.append(seq[at:at + step]); at += step
+            if at >= len(seq):
+                break
+            n = int(rng.integers(1, 9))
+            if rng.random() < 0.5:
+                at += n                                                  # deletion from the reference
+            else:
+                pieces.append(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)])     # insertion
+        sample.append(torch.from_numpy(np.concatenate(pieces)))
+    params = options.default_params(L, L)
+    a = gpu.Aligner(params, 0, contigs)
+    a.build_index()
+    ref = o.reference(contigs)
+    ref.set_index(a.get_index())
+    dev_tiles, host_tiles, tls = [], [], None
+    for t in range(2):
+        bcl = synth.make_read_pairs(sample, 15000, L, seed=70 + t, indel_read_fraction=0.0, subst_rate=0.004)[0].numpy()
+        d_bcl = torch.from_numpy(bcl).cuda()
+        matches, offsets, hits = a.find_matches(d_bcl, tile=5 + t)
+        a.set_loaded_contigs(np.ones(len(contigs), np.uint8))
+        if tls is None:
+            tls = a.determine_tls(d_bcl, matches, offsets, tile=5 + t)
+        records, cigars = a.select(d_bcl, matches, offsets, tls, tile=5 + t)
+        prefix = "RG:1:%d:" % (5 + t)
+        dev_tiles.append((d_bcl, records, cigars, prefix))
+        r, c = a.records_to_numpy(records, cigars)
+        host_tiles.append((bcl, r, c, prefix))
+    otls = oracle_lib.Tls()
+    for name in ("min", "max", "median", "low_std_dev", "high_std_dev", "stable", "mate_min", "mate_max"):
+        setattr(otls, name, getattr(tls, name))
+    otls.best_model[0], otls.best_model[1] = tls.best_model[0], tls.best_model[1]
+    before = a.bam_records(dev_tiles)[0].cpu().numpy().tobytes()
+    keep = [t[1].clone() for t in dev_tiles]
+    for mark, keep_dups in ((False, True), (True, True), (True, False)):
+        got, n, un = a.bam_records(dev_tiles, mark_duplicates=mark, keep_duplicates=keep_dups, realign_gaps=True, tls=tls)
+        want, want_n, want_un = o.bam_records(host_tiles, [L, L], forced_dodgy_alignment_score=params.dodgy_alignment_score & 0xff, mark_duplicates=mark, keep_duplicates=keep_dups,
+                                              realign_gaps=True, clip_semialigned=True, reference=ref, tls=otls)
+        assert (n, un) == (want_n, want_un)
+        got = got.cpu().numpy().tobytes()
+        if got != want:
+            ga, wa = bam.parse_records(got), bam.parse_records(want)
+            bad = [(x["name"], x["flag"], x["pos"], abi.cigar_string(x["cigar"]), y["pos"], abi.cigar_string(y["cigar"]), x["tlen"], y["tlen"]) for x, y in zip(ga, wa)
+                   if (x["name"], x["flag"], x["pos"], list(x["cigar"]), x["tlen"], x["tags"]) != (y["name"], y["flag"], y["pos"], list(y["cigar"]), y["tlen"], y["tags"])]
+            assert not bad, (len(bad), bad[:5])
+        assert got == want
+    assert all((k == t[1]).all() for k, t in zip(keep, dev_tiles))       # the caller's records are not touched
+    plain, realigned = bam.parse_records(before), bam.parse_records(o.bam_records(host_tiles, [L, L], forced_dodgy_alignment_score=params.dodgy_alignment_score & 0xff, realign_gaps=True,
+                                                                                 reference=ref, tls=otls)[0])
+    by_name = {(r["name"], r["flag"] & 0xc0): r for r in plain}
+    changed = [r for r in realigned if list(by_name[(r["name"], r["flag"] & 0xc0)]["cigar"]) != list(r["cigar"])]
+    assert len(changed) > 50, len(changed)          # most reads across an indel are gapped already; the realigner moves the ones at read ends and trades mismatches for known gaps
+
+
+@pytest.mark.gpu
 def test_gpu_bam_file_is_readable(tmp_path):
     """end to end: tile -> records -> BAM file; the file inflates to header + records and its records are sorted"""
     import torch

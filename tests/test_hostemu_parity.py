@@ -2,11 +2,13 @@
 oracle, on seeded synthetic inputs.  This validates the host logic and the kernels' per-cluster functions without a GPU;
 the same comparisons run on the real kernels in test_gpu_parity.py."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 
 import hostemu_lib
+import oracle_lib
 from isaac_aligner_amd import abi, options
 from parity_util import compare_candidates, compare_records, make_inputs
 
@@ -173,3 +175,78 @@ def test_repeat_rich_reference_through_the_precomputed_sums(oracle, emulib, sums
     assert not compare_records(orec, ocig, erec, ecig)
     heavy = emu.counters()["heavy_clusters"]
     assert (heavy > 20) if sums_cap < 100 else (heavy < 20), heavy
+
+
+def test_gap_realigner_device_code_against_the_oracle():
+    """realign.h (what the BAM stage's realign kernel runs per fragment) compiled for the CPU against oracle/realign.cpp, which the reference's
+    testGapRealigner cases pin: those cases' inputs without --realign-vigorously (the device has no vigorous mode), with the semialigned
+    clipper off and on, with the test's costs and the BinSorter's (3, 4, 0); and random reads with planted indels against gap sets that hold
+    the true gaps and decoys"""
+    import ctypes as C
+    import json
+    lib = hostemu_lib.load()
+    o = oracle_lib.load()
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gap_realigner.json")))
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+
+    def emu(case, realigner):
+        bcl = np.array([(code[b] | 0x20) if b != "N" else 0 for b in case["read_bases"]], np.uint8)
+        contig = case["contig"].encode()
+        cigar = np.array(case["cigar"], np.uint32)
+        gp = np.array([x[0] for x in case["gaps"]], np.int64); gl = np.array([x[1] for x in case["gaps"]], np.int32)
+        pos, ncig, ed, obs = C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        out = np.zeros(4096, np.uint32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        rc = lib.emu_realign_case(contig, C.c_uint64(len(contig)), p(bcl), C.c_uint32(len(bcl)), C.c_uint64(case["f_strand_position"]), p(cigar), C.c_uint32(len(cigar)),
+                                  C.c_uint32(case["observed_length"]), C.c_uint32(case["edit_distance"]), C.c_uint32(case["low_clipped"]), C.c_uint32(case["high_clipped"]),
+                                  p(gp), p(gl), C.c_uint32(len(gp)), C.c_uint32(case["mismatch_cost"]), C.c_uint32(case["gap_open_cost"]), C.c_uint32(realigner["gap_extend_cost"]),
+                                  C.c_int(int(realigner["dodgy"])), C.c_int(int(realigner["clip_semialigned"])), C.c_uint64(case["bin_start"]),
+                                  C.c_int64(-1 if case["bin_end"] is None else case["bin_end"]), C.byref(pos), p(out), C.byref(ncig), C.byref(ed), C.byref(obs))
+        assert rc == 0
+        return {"position": pos.value, "cigar": oracle_lib.cigar_string(out[:ncig.value]), "edit_distance": ed.value, "observed_length": obs.value}
+
+    changed = 0
+    for clip in (False, True):
+        for costs in (None, (3, 4)):
+            realigner = dict(g["realigner"], vigorous=False, clip_semialigned=clip)
+            for k, case in enumerate(g["cases"]):
+                c = dict(case)
+                if costs:
+                    c["mismatch_cost"], c["gap_open_cost"] = costs
+                want = o.realign_case(c, realigner)
+                want.pop("overlaps")
+                got = emu(c, realigner)
+                assert got == want, (k, clip, costs, got, want)
+                changed += got["cigar"] != oracle_lib.cigar_string(case["cigar"])
+    assert changed > 100
+    # random cases: a read copied from the contig with substitutions and one or two indels, aligned ungapped where it was taken from
+    rng = np.random.default_rng(8)
+    realigner = dict(g["realigner"], vigorous=False, clip_semialigned=True)
+    n_changed = 0
+    for trial in range(400):
+        contig = "".join("ACGT"[x] for x in rng.integers(0, 4, 400))
+        start, L = int(rng.integers(20, 150)), 100
+        read = list(contig[start:start + L + 30])
+        gaps, at = [], int(rng.integers(15, 40))
+        for _ in range(int(rng.integers(1, 3))):
+            n = int(rng.integers(1, 6))
+            if rng.random() < 0.5:                      # deletion from the read: the reference keeps n bases the read lacks
+                gaps.append((start + at, n)); del read[at:at + n]
+            else:                                       # insertion into the read
+                gaps.append((start + at, -n)); read[at:at] = list("ACGT"[x] for x in rng.integers(0, 4, n))
+            at += int(rng.integers(15, 35))
+        read = read[:L]
+        for i in rng.integers(0, L, int(rng.integers(0, 3))):
+            read[i] = "ACGT"[(code[read[i]] + 1) % 4]
+        # decoys and the true gaps shifted into place (gap positions are those of the ungapped read's frame only for the first gap; the rest is what a real run has too: gaps of other reads)
+        for _ in range(int(rng.integers(0, 4))):
+            gaps.append((int(rng.integers(start, start + L)), int(rng.choice([-3, -1, 1, 2, 4]))))
+        ed = sum(1 for i in range(L) if read[i] != contig[start + i])
+        case = {"read_bases": "".join(read), "contig": contig, "f_strand_position": start, "cigar": [(L << 4) | 0], "observed_length": L, "edit_distance": ed, "low_clipped": 0, "high_clipped": 0,
+                "gaps": gaps, "mismatch_cost": 3, "gap_open_cost": 4, "bin_start": 0, "bin_end": None}
+        want = o.realign_case(case, realigner)
+        want.pop("overlaps")
+        got = emu(case, realigner)
+        assert got == want, (trial, case, got, want)
+        n_changed += got["cigar"] != "100M"
+    assert n_changed > 100
