@@ -293,14 +293,20 @@ int isaac_gpu_compact_cigars_async(isaac_gpu_ctx *ctx, isaac_fragment *fragments
  *            bin of the reference (its result depends on where its bins end); the template's rank of io::getTemplateDuplicateRank is
  *            derived from the BCL qualities, the two records and isaac_fragment::reserved bits 16-31 (the template's alignment score)
  *   record   bam::serializeAlignment over build::FragmentAccessorBamAdapter (include/bam/Bam.hh:257-345,
- *            include/build/FragmentAccessorBamAdapter.hh:127-377) with the default tag set SM AS RG NM BC (--bam-exclude-tags ZX,ZY);
+ *            include/build/FragmentAccessorBamAdapter.hh:127-377) with the default tag set SM AS RG NM BC OC (--bam-exclude-tags ZX,ZY; OC, the CIGAR before
+ *            realignment, only on records the gap realigner changed);
  *            bases and qualities as FragmentCollector::storeBclAndCigar keeps them (lib/alignment/matchSelector/FragmentCollector.cpp:84-111)
  * One tile = the buffers of one isaac_gpu_select call (bcl_dev as given to it, its records and cigar pool, fixed slots or packed);
  * read_name_prefix = "<flowcell id>:<lane>:<tile>:" (FragmentAccessorBamAdapter::readName), at most 63 characters.  Contig ids are
  * written as they are (the BAM header must list the contigs in the order of isaac_gpu_load_contigs).
  * bam_dev receives the uncompressed records back to back; *n_bytes_out their length (also when it exceeds capacity),
  * *n_records_out their number, *unaligned_offset_out the offset of the first record of the unaligned bin (= *n_bytes_out if none). */
-typedef struct { const uint8_t *bcl_dev; const isaac_fragment *fragments_dev; const uint32_t *cigar_dev; uint64_t n_records; const char *read_name_prefix; } isaac_bam_tile;
+typedef struct
+{
+    const uint8_t *bcl_dev; const isaac_fragment *fragments_dev; const uint32_t *cigar_dev; uint64_t n_records; const char *read_name_prefix;
+    const char *read_group;   /* RG:Z of this tile's records when lanes differ (one 'none' barcode per lane without a sample sheet,
+                                 lib/demultiplexing/SampleSheetCsv.cpp:101-112); NULL = isaac_bam_options::read_group; at most 27 characters */
+} isaac_bam_tile;
 typedef struct
 {
     uint32_t forced_dodgy_alignment_score;  /* MAPQ of alignments whose score is unknown (0xffff): --dodgy-alignment-score */

@@ -8,7 +8,7 @@ import numpy as np
 
 
 class BamTile(C.Structure):
-    _fields_ = [("bcl_dev", C.c_void_p), ("fragments_dev", C.c_void_p), ("cigar_dev", C.c_void_p), ("n_records", C.c_uint64), ("read_name_prefix", C.c_char_p)]
+    _fields_ = [("bcl_dev", C.c_void_p), ("fragments_dev", C.c_void_p), ("cigar_dev", C.c_void_p), ("n_records", C.c_uint64), ("read_name_prefix", C.c_char_p), ("read_group", C.c_char_p)]
 
 
 class BamOptions(C.Structure):

@@ -18,6 +18,8 @@ struct BamTile
     const u8 *bcl; const FragmentRecord *records; const u32 *cigars; u64 firstRecord;   // index of the tile's first record among all records of the call
     u32 nRecords, nameLength; char name[64];                                             // "<flowcell>:<lane>:<tile>:" (FragmentAccessorBamAdapter::readName)
     const u32 *cigarsAlt;                                                                // CIGARs of realigned records (RECORD_CIGAR_REALIGNED), else NULL
+    const FragmentRecord *recordsOriginal;                                               // with gap realignment: the records as the caller gave them (`records` is the stage's copy), else NULL
+    char readGroup[28]; u32 readGroupLength;                                             // RG:Z of the tile's records: the barcode index of its lane (FragmentAccessorBamAdapter.hh:283-299)
 };
 struct BamOptions { u32 nReads, readLength[2], readOffset[2], clusterLength, forcedDodgyAlignmentScore, pessimisticMapQ, barcodeLength, readGroupLength; char barcode[64], readGroup[64];
                     u32 markDuplicates, keepDuplicates, realignGaps; RealignParams realign; DevTls tls; };
@@ -59,15 +61,30 @@ ISAAC_HD bool bamStored(const FragmentRecord &r) { return 0 == (r.reserved & REC
 ISAAC_HD bool bamUnalignedBin(const FragmentRecord &r) { return refposIsNoMatch(r.fStrandPosition); }
 
 ISAAC_HD u32 bamReadNameLength(const BamTile &t, const FragmentRecord &r) { return t.nameLength + decimalDigits(r.clusterId) + 2; }   // + ":0"
-ISAAC_HD u32 bamRecordBytes(const BamTile &t, const FragmentRecord &r, const BamOptions &o)
+// Cigar::toString (include/alignment/Cigar.hh:74-95) of n operations: its length, and its character k (0 at and past the end)
+ISAAC_HD u32 bamCigarStringLength(const u32 *c, u32 n) { u32 chars = 0; for (u32 k = 0; k < n; ++k) chars += decimalDigits(c[k] >> 4) + 1; return chars; }
+ISAAC_HD u8 bamCigarStringChar(const u32 *c, u32 n, u32 at)
+{
+    for (u32 k = 0; k < n; ++k)
+    {
+        const u32 digits = decimalDigits(c[k] >> 4);
+        if (at < digits) { u32 v = c[k] >> 4; for (u32 d = digits - 1 - at; d; --d) v /= 10; return u8('0' + v % 10); }
+        if (at == digits) { const u32 code = c[k] & 15; return u8("MIDNSHP=X?"[code < 9 ? code : 9]); }
+        at -= digits + 1;
+    }
+    return 0;
+}
+// original: the record before gap realignment (BamTile::recordsOriginal), or NULL
+ISAAC_HD u32 bamRecordBytes(const BamTile &t, const FragmentRecord &r, const BamOptions &o, const FragmentRecord *original = nullptr)
 {
     const bool aligned = !(r.flags & 2);
     u32 n = 4 + 32 + bamReadNameLength(t, r) + 1 + (aligned ? 4 * u32(r.cigarLength) : 0) + (r.readLength + 1) / 2 + r.readLength;
     if (DODGY_ALIGNMENT_SCORE != r.alignmentScore) n += 7;                                                    // SM:i
     if ((r.flags & 256) && DODGY_ALIGNMENT_SCORE != r.templateAlignmentScore) n += 7;                        // AS:i
-    n += 3 + o.readGroupLength + 1;                                                                            // RG:Z
+    n += 3 + t.readGroupLength + 1;                                                                            // RG:Z
     n += 7;                                                                                                    // NM:i
     n += 3 + o.barcodeLength + 1;                                                                              // BC:Z
+    if (original && (r.reserved & RECORD_CIGAR_REALIGNED)) n += 3 + bamCigarStringLength(t.cigars + original->cigarOffset, original->cigarLength) + 1;   // OC:Z
     return n;
 }
 
@@ -77,20 +94,21 @@ struct BamLayout
 {
     u32 words[9];                                    // block_size, refID, pos, bin_mq_nl, flag_nc, l_seq, next_refID, next_pos, tlen
     u32 nameBegin, digitsBegin, nameTail, cigarBegin, seqBegin, qualBegin, tagBegin, total;
-    u32 digits, clusterId, nCigar, readLength, reverse, smAt, asAt, rgAt, nmAt, bcAt;   // tag offsets relative to tagBegin (~0u: absent)
-    u32 sm, as, nm;
-    const u8 *bcl; const u32 *cigar;
+    u32 digits, clusterId, nCigar, readLength, reverse, smAt, asAt, rgAt, nmAt, bcAt, ocAt;   // tag offsets relative to tagBegin (~0u: absent)
+    u32 sm, as, nm, nOriginalCigar;
+    const char *readGroup; u32 readGroupLength;                                          // BamTile::readGroup
+    const u8 *bcl; const u32 *cigar, *originalCigar;                                     // originalCigar: getFragmentOC (FragmentAccessorBamAdapter.hh:182-198), realigned fragments only
 };
 
 // bam::serializeAlignment (Bam.hh:257-345): the fixed part and the section boundaries
-ISAAC_HD void bamLayout(const BamTile &t, const FragmentRecord &r, const BamOptions &o, BamLayout &l, bool duplicate = false)
+ISAAC_HD void bamLayout(const BamTile &t, const FragmentRecord &r, const BamOptions &o, BamLayout &l, bool duplicate = false, const FragmentRecord *original = nullptr)
 {
     const bool aligned = !(r.flags & 2), unalignedBin = bamUnalignedBin(r), paired = r.flags & 1;
     // FragmentAccessorBamAdapter::operator(): aligned fragments and shadows carry the bin index position, unaligned templates NoMatch
     const i32 refId = unalignedBin ? -1 : i32(refposContig(r.fStrandPosition)), pos = unalignedBin ? -1 : i32(refposPosition(r.fStrandPosition));
     const u32 nameLength = bamReadNameLength(t, r), observed = r.observedLength;
     l.nCigar = aligned ? r.cigarLength : 0;
-    l.total = bamRecordBytes(t, r, o);
+    l.total = bamRecordBytes(t, r, o, original);
     const bool noMate = !paired || ((r.flags & 2) && (r.flags & 4));
     l.words[0] = l.total - 4; l.words[1] = u32(refId); l.words[2] = u32(pos);
     l.words[3] = (bamReg2bin(u32(pos), u32(pos) + (observed ? observed : 1)) << 16) | (bamMapq(r, o) << 8) | (nameLength + 1);
@@ -106,9 +124,11 @@ ISAAC_HD void bamLayout(const BamTile &t, const FragmentRecord &r, const BamOpti
     const bool sm = DODGY_ALIGNMENT_SCORE != r.alignmentScore, as = (r.flags & 256) && DODGY_ALIGNMENT_SCORE != r.templateAlignmentScore;
     l.smAt = sm ? at : ~0u; at += sm ? 7 : 0;
     l.asAt = as ? at : ~0u; at += as ? 7 : 0;
-    l.rgAt = at; at += 3 + o.readGroupLength + 1;
+    l.rgAt = at; at += 3 + t.readGroupLength + 1; l.readGroup = t.readGroup; l.readGroupLength = t.readGroupLength;
     l.nmAt = at; at += 7;
-    l.bcAt = at;
+    l.bcAt = at; at += 3 + o.barcodeLength + 1;
+    const bool oc = original && (r.reserved & RECORD_CIGAR_REALIGNED);
+    l.ocAt = oc ? at : ~0u; l.originalCigar = oc ? t.cigars + original->cigarOffset : nullptr; l.nOriginalCigar = oc ? original->cigarLength : 0;
     l.sm = r.alignmentScore; l.as = r.templateAlignmentScore; l.nm = r.editDistance;
     const u32 readIndex = (r.flags & 64) && paired ? 1u : 0u;
     l.bcl = t.bcl + u64(r.clusterId) * o.clusterLength + o.readOffset[readIndex];
@@ -123,7 +143,7 @@ ISAAC_HD u8 bamIntTagByte(char a, char b, u32 v, u32 k) { return k == 0 ? u8(a) 
 ISAAC_HD u8 bamStringTagByte(char a, char b, const char *s, u32 n, u32 k) { return k == 0 ? u8(a) : k == 1 ? u8(b) : k == 2 ? u8('Z') : k - 3 < n ? u8(s[k - 3]) : u8(0); }
 
 // byte j of the record; `text`: the strings that go into it; `stored` (optional): the read's bases as bamStoredBcl gives them, staged by the caller; `cigar`: l.cigar or a staged copy
-struct BamStrings { const char *namePrefix, *readGroup, *barcode; u32 readGroupLength, barcodeLength; };   // BamTile::name, BamOptions strings or staged copies
+struct BamStrings { const char *namePrefix, *barcode; u32 barcodeLength; };   // BamTile::name, BamOptions::barcode or staged copies
 ISAAC_HD u8 bamRecordByte(const BamStrings &text, const BamLayout &l, u32 j, const u8 *stored, const u32 *cigar)
 {
     if (j < l.nameBegin)
@@ -150,9 +170,10 @@ ISAAC_HD u8 bamRecordByte(const BamStrings &text, const BamLayout &l, u32 j, con
     }
     if (j < l.tagBegin) return u8((stored ? stored[j - l.qualBegin] : bamStoredBcl(l, j - l.qualBegin)) >> 2);               // bamQualFromBclByte :228-230
     const u32 k = j - l.tagBegin;
+    if (k >= l.ocAt) return k - l.ocAt == 0 ? u8('O') : k - l.ocAt == 1 ? u8('C') : k - l.ocAt == 2 ? u8('Z') : bamCigarStringChar(l.originalCigar, l.nOriginalCigar, k - l.ocAt - 3);
     if (k >= l.bcAt) return bamStringTagByte('B', 'C', text.barcode, text.barcodeLength, k - l.bcAt);
     if (k >= l.nmAt) return bamIntTagByte('N', 'M', l.nm, k - l.nmAt);
-    if (k >= l.rgAt) return bamStringTagByte('R', 'G', text.readGroup, text.readGroupLength, k - l.rgAt);
+    if (k >= l.rgAt) return bamStringTagByte('R', 'G', l.readGroup, l.readGroupLength, k - l.rgAt);
     if (l.asAt != ~0u && k >= l.asAt) return bamIntTagByte('A', 'S', l.as, k - l.asAt);
     return bamIntTagByte('S', 'M', l.sm, k);
 }
@@ -174,7 +195,7 @@ __global__ void k_bam_keys(const BamTile *tiles, u32 nTiles, u64 nRecords, BamOp
     keyHi[i] = !stored ? ~u64(0) : bamUnalignedBin(r) ? ~u64(0) - 1 : r.fStrandPosition;
     keyLo[i] = ((u64(r.tile) * INSANELY_HIGH_NUMBER_OF_CLUSTERS_PER_TILE + r.clusterId) << 2) | ((r.flags & 2) ? 2u : 0u) | ((r.flags & 64) ? 1u : 0u);
     index[i] = u32(i);
-    bytes[i] = stored ? bamRecordBytes(tiles[t], r, o) : 0;
+    bytes[i] = stored ? bamRecordBytes(tiles[t], r, o, tiles[t].recordsOriginal ? tiles[t].recordsOriginal + (i - tiles[t].firstRecord) : nullptr) : 0;
 }
 __global__ void k_bam_gather_hi(const u64 *keyHi, const u32 *order, u64 n, u64 *out) { const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x; if (i < n) out[i] = keyHi[order[i]]; }
 __global__ void k_bam_gather_bytes(const u32 *bytes, const u32 *order, u64 n, u64 *out) { const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x; if (i < n) out[i] = bytes[order[i]]; }
@@ -383,7 +404,7 @@ __device__ inline void bamPutIntTag(u8 *to, char a, char b, u32 v) { to[0] = u8(
 __device__ inline void bamPutStringTag(u8 *to, char a, char b, const char *s, u32 n) { to[0] = u8(a); to[1] = u8(b); to[2] = u8('Z'); for (u32 i = 0; i < n; ++i) to[3 + i] = u8(s[i]); to[3 + n] = 0; }
 
 // one of the small pieces of a record (the same bytes bamRecordByte gives for those positions)
-__device__ inline void bamWriteSmallPiece(u32 piece, const BamLayout &l, const char *name, const char *readGroup, u32 readGroupLength, const char *barcode, u32 barcodeLength, u8 *to)
+__device__ inline void bamWriteSmallPiece(u32 piece, const BamLayout &l, const char *name, const char *barcode, u32 barcodeLength, u8 *to)
 {
     if (0 == piece) { for (u32 w = 0; w < 9; ++w) bamPut32(to + 4 * w, l.words[w]); }
     else if (1 == piece)
@@ -405,9 +426,15 @@ __device__ inline void bamWriteSmallPiece(u32 piece, const BamLayout &l, const c
     else
     {
         const u32 tagBegin = l.tagBegin;
-        bamPutStringTag(to + tagBegin + l.rgAt, 'R', 'G', readGroup, readGroupLength);
+        bamPutStringTag(to + tagBegin + l.rgAt, 'R', 'G', l.readGroup, l.readGroupLength);
         bamPutIntTag(to + tagBegin + l.nmAt, 'N', 'M', l.nm);
         bamPutStringTag(to + tagBegin + l.bcAt, 'B', 'C', barcode, barcodeLength);
+        if (~0u != l.ocAt)
+        {
+            u8 *oc = to + tagBegin + l.ocAt; const u32 chars = l.total - (tagBegin + l.ocAt) - 4;
+            oc[0] = u8('O'); oc[1] = u8('C'); oc[2] = u8('Z');
+            for (u32 k = 0; k <= chars; ++k) oc[3 + k] = bamCigarStringChar(l.originalCigar, l.nOriginalCigar, k);
+        }
     }
 }
 
@@ -466,7 +493,7 @@ __global__ void __launch_bounds__(256) k_bam_encode(const BamTile *tiles, u32 nT
         BamLayout l;
         const bool dup = duplicate && duplicate[i];
         bool write = bamStored(r) && !(dup && !o.keepDuplicates);
-        if (write) { bamLayout(tiles[t], r, o, l, dup && o.markDuplicates); write = at + l.total <= capacity; }
+        if (write) { bamLayout(tiles[t], r, o, l, dup && o.markDuplicates, tiles[t].recordsOriginal ? tiles[t].recordsOriginal + (i - tiles[t].firstRecord) : nullptr); write = at + l.total <= capacity; }
         if (write) { layouts[threadIdx.x] = l; imageAt[threadIdx.x] = u32(at - begin); }
         tileOfRecord[threadIdx.x] = write ? t : ~0u;
     }
@@ -478,7 +505,7 @@ __global__ void __launch_bounds__(256) k_bam_encode(const BamTile *tiles, u32 nT
         {
             if (~0u == tileOfRecord[rec]) continue;
             const BamLayout &l = layouts[rec];
-            BamStrings text = { tiles[tileOfRecord[rec]].name, optionText[0], optionText[1], o.readGroupLength, o.barcodeLength };
+            BamStrings text = { tiles[tileOfRecord[rec]].name, optionText[1], o.barcodeLength };
             u8 *to = out + begin + imageAt[rec];
             for (u32 j = lane; j < l.total; j += 64) to[j] = bamRecordByte(text, l, j, nullptr, l.cigar);
         }
@@ -493,7 +520,7 @@ __global__ void __launch_bounds__(256) k_bam_encode(const BamTile *tiles, u32 nT
         if (~0u == t) continue;
         u8 *to = image + shift + imageAt[rec];
         if (piece < BAM_SMALL_PIECES)
-            bamWriteSmallPiece(piece, layouts[rec], tilesStaged ? reinterpret_cast<const char *>(tileNames[t]) : tiles[t].name, optionText[0], o.readGroupLength, optionText[1], o.barcodeLength, to);
+            bamWriteSmallPiece(piece, layouts[rec], tilesStaged ? reinterpret_cast<const char *>(tileNames[t]) : tiles[t].name, optionText[1], o.barcodeLength, to);
         else bamWriteBases(piece - BAM_SMALL_PIECES, layouts[rec], to);
     }
     __syncthreads();

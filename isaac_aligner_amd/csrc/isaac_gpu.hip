@@ -1356,7 +1356,7 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
         if (options->tls) std::memcpy(&o.tls, options->tls, sizeof(o.tls));
     }
     std::vector<BamTile> h(nTiles);
-    u64 n = 0;
+    u64 n = 0; u32 maxReadGroup = 0;
     for (u32 t = 0; t < nTiles; ++t)
     {
         const isaac_bam_tile &in = tiles[t];
@@ -1366,6 +1366,10 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
         std::memset(&h[t], 0, sizeof(BamTile));
         h[t].bcl = in.bcl_dev; h[t].records = reinterpret_cast<const FragmentRecord *>(in.fragments_dev); h[t].cigars = in.cigar_dev; h[t].firstRecord = n;
         h[t].nRecords = u32(in.n_records); h[t].nameLength = u32(std::strlen(prefix)); std::memcpy(h[t].name, prefix, h[t].nameLength);
+        const char *tileReadGroup = in.read_group ? in.read_group : readGroup;
+        if (std::strlen(tileReadGroup) >= sizeof(h[t].readGroup)) return fail(ISAAC_GPU_EINVAL, "read_group: at most 27 characters");
+        h[t].readGroupLength = u32(std::strlen(tileReadGroup)); std::memcpy(h[t].readGroup, tileReadGroup, h[t].readGroupLength);
+        maxReadGroup = std::max(maxReadGroup, h[t].readGroupLength);
         n += in.n_records;
     }
     if (n >= (u64(1) << 31)) return fail(ISAAC_GPU_EINVAL, "at most 2^31 - 1 records per call");
@@ -1380,7 +1384,7 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
         for (u32 t = 0; t < nTiles; ++t)
         {
             if (h[t].nRecords) HIP_CHECK(hipMemcpyAsync(c->realignRecords.p + h[t].firstRecord, h[t].records, sizeof(FragmentRecord) * h[t].nRecords, hipMemcpyDeviceToDevice, st));
-            h[t].records = c->realignRecords.p + h[t].firstRecord; h[t].cigarsAlt = c->realignPool.p;
+            h[t].recordsOriginal = h[t].records; h[t].records = c->realignRecords.p + h[t].firstRecord; h[t].cigarsAlt = c->realignPool.p;
         }
     }
     HIP_CHECK(hipMemcpyAsync(c->bamTiles.p, h.data(), sizeof(BamTile) * nTiles, hipMemcpyHostToDevice, st));
@@ -1463,7 +1467,7 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
         for (u32 t = 0; t < nTiles; ++t) maxName = std::max(maxName, h[t].nameLength);
         BamChunkLds lds;
         lds.segments = (maxRead + 15) / 16;
-        lds.chunkBytes = std::min<u32>(bamChunkImageBytes(maxRead, maxName + 13, 28 + o.readGroupLength + o.barcodeLength), 96 * 1024);
+        lds.chunkBytes = std::min<u32>(bamChunkImageBytes(maxRead, maxName + 13, 28 + maxReadGroup + o.barcodeLength), 96 * 1024);
         const size_t dynamicBytes = (lds.chunkBytes + 16 + 15) & ~15u;
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bam_encode), hipFuncAttributeMaxDynamicSharedMemorySize, int(dynamicBytes)));
         k_bam_encode<<<gridFor(n, BAM_CHUNK_RECORDS), 256, dynamicBytes, st>>>(c->bamTiles.p, nTiles, n, o, c->bamIndex.p, c->bamOffsets.p, c->bamBytes64.p, duplicate, bam, capacity, lds);

@@ -321,13 +321,14 @@ class Aligner:
     # ---- output format --------------------------------------------------------------------------------------------
     def bam_records(self, tiles, out=None, read_group=None, barcode=None, forced_dodgy_alignment_score=None, pessimistic_mapq=False, mark_duplicates=False, keep_duplicates=True, realign_gaps=False, tls=None):
         """build::Build's BAM alignment records (--realign-gaps no --mark-duplicates 0) of one or more tiles, in file order.
-        tiles: [(bcl, records, cigars, read_name_prefix)] as given to / returned by select().  Returns (uint8 device tensor of the
+        tiles: [(bcl, records, cigars, read_name_prefix[, read_group])] as given to / returned by select().  Returns (uint8 device tensor of the
         uncompressed records, number of records, offset of the unaligned bin)."""
         from . import bam
         arr = (bam.BamTile * len(tiles))()
         keep = []
         n_rec = 0
-        for i, (bcl, records, cigars, prefix) in enumerate(tiles):
+        for i, tile in enumerate(tiles):
+            bcl, records, cigars, prefix = tile[:4]
             name = prefix.encode() if isinstance(prefix, str) else prefix
             keep.append(name)
             arr[i].bcl_dev = _p(bcl).value if _p(bcl) is not None else None
@@ -335,6 +336,9 @@ class Aligner:
             arr[i].cigar_dev = _p(cigars).value if _p(cigars) is not None else None
             arr[i].n_records = records.shape[0]
             arr[i].read_name_prefix = name
+            if len(tile) > 4 and tile[4] is not None:
+                keep.append(tile[4].encode())
+                arr[i].read_group = keep[-1]
             n_rec += records.shape[0]
         options = None
         if read_group is not None or barcode is not None or forced_dodgy_alignment_score is not None or pessimistic_mapq or mark_duplicates or not keep_duplicates or realign_gaps:

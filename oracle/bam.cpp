@@ -27,7 +27,8 @@ const uint64_t NO_MATCH_VALUE = ReferencePosition(ReferencePosition::NoMatch).va
 // the stored form of one read: header fields, bases as stored (FragmentCollector::storeBclAndCigar), CIGAR
 struct Stored
 {
-    FragmentRecord *header; std::vector<unsigned char> bases; const uint32_t *cigarBegin, *cigarEnd; const std::string *namePrefix;
+    FragmentRecord *header; std::vector<unsigned char> bases; const uint32_t *cigarBegin, *cigarEnd; const std::string *namePrefix; const std::string *readGroup = 0;
+    const uint32_t *originalCigarBegin = 0, *originalCigarEnd = 0;                     // FragmentAccessorBamAdapter::originalCigarBegin_: the fragment's own CIGAR
     const uint8_t *clusterBcl = 0; FragmentRecord *mate = 0; bool duplicate = false;
     bool paired() const { return header->flags & 1; }
     bool unmapped() const { return header->flags & 2; }
@@ -103,8 +104,12 @@ void serializeAlignment(std::vector<char> &os, const Adapter &a)
     if (l_seq % 2) seq[l_seq / 2] = bamBase(a.s.bases[l_seq - 1]) << 4;
     for (int i = 0; i < l_seq; ++i) qual.push_back(a.s.bases[i] >> 2);
     const bool sm = DODGY != h.alignmentScore, as = a.s.properPair() && DODGY != h.templateAlignmentScore;
+    // getFragmentOC (FragmentAccessorBamAdapter.hh:182-198): the CIGAR before realignment, for fragments whose CIGAR now lies in the realigner's buffer
+    std::string oc;
+    const bool realigned = a.s.cigarBegin != a.s.originalCigarBegin;
+    if (realigned) for (const uint32_t *c = a.s.originalCigarBegin; c != a.s.originalCigarEnd; ++c) { oc += std::to_string(*c >> 4); oc += "MIDNSHP=X?"[std::min<uint32_t>(*c & 15, 9)]; }
     const int block_size = 32 + int(name.size()) + 1 + int(cigarLength) * 4 + int(seq.size()) + int(qual.size()) + (sm ? 7 : 0) + (as ? 7 : 0) + 7 +
-                           (3 + int(a.o.barcode.size()) + 1) + (3 + int(a.o.readGroup.size()) + 1);
+                           (3 + int(a.o.barcode.size()) + 1) + (3 + int(a.s.readGroup->size()) + 1) + (realigned ? 3 + int(oc.size()) + 1 : 0);
     putInt(os, block_size); putInt(os, refID); putInt(os, pos); putUnsigned(os, bin_mq_nl); putUnsigned(os, flag_nc);
     putInt(os, l_seq); putInt(os, a.nextRefId()); putInt(os, a.nextPos()); putInt(os, h.bamTlen);
     put(os, name.c_str(), name.size() + 1);
@@ -112,9 +117,10 @@ void serializeAlignment(std::vector<char> &os, const Adapter &a)
     put(os, seq.data(), seq.size()); put(os, qual.data(), qual.size());
     if (sm) { put(os, "SMi", 3); putInt(os, h.alignmentScore); }
     if (as) { put(os, "ASi", 3); putInt(os, h.templateAlignmentScore); }
-    put(os, "RGZ", 3); put(os, a.o.readGroup.c_str(), a.o.readGroup.size() + 1);
+    put(os, "RGZ", 3); put(os, a.s.readGroup->c_str(), a.s.readGroup->size() + 1);
     put(os, "NMi", 3); putInt(os, h.editDistance);
     put(os, "BCZ", 3); put(os, a.o.barcode.c_str(), a.o.barcode.size() + 1);
+    if (realigned) { put(os, "OCZ", 3); put(os, oc.c_str(), oc.size() + 1); }
 }
 
 // oligo::pack32BclBases (include/oligo/Nucleotides.hh:241-280)
@@ -193,12 +199,13 @@ void bamRecords(const std::vector<BamTileInput> &tiles, const BamOptions &o, std
         {
             FragmentRecord &h = copies[tileIndex][i];
             if (h.reserved & 2) continue;                                     // MatchSelector.cpp:345-357: the template was not stored
-            Stored s; s.header = &h; s.namePrefix = &t.namePrefix;
+            Stored s; s.header = &h; s.namePrefix = &t.namePrefix; s.readGroup = t.readGroup.empty() ? &o.readGroup : &t.readGroup;
             const unsigned readIndex = (h.flags & 1) && (h.flags & 64) ? 1 : 0;
             const uint8_t *bcl = t.bcl + uint64_t(h.clusterId) * o.clusterLength + o.readOffset[readIndex];
             s.bases.assign(bcl, bcl + h.readLength);
             if (s.reverse()) { std::reverse(s.bases.begin(), s.bases.end()); for (unsigned char &b : s.bases) b = reverseBcl(b); }
             s.cigarBegin = t.cigars + h.cigarOffset; s.cigarEnd = s.cigarBegin + ((h.flags & 2) ? 0 : h.cigarLength);
+            s.originalCigarBegin = s.cigarBegin; s.originalCigarEnd = s.cigarEnd;
             s.clusterBcl = t.bcl + uint64_t(h.clusterId) * o.clusterLength;
             if (h.flags & 1) s.mate = &copies[tileIndex][i ^ 1];              // records come in cluster order, read 0 before read 1
             stored.push_back(s);

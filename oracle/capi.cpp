@@ -869,7 +869,7 @@ extern "C" int oracle_realign_case(const char *contig, uint64_t contig_length, c
 
 // ---- BAM records and header (bam.cpp) ---------------------------------------------------------------------------
 extern "C" {
-typedef struct { const uint8_t *bcl; const void *records; const uint32_t *cigars; uint64_t n_records; const char *read_name_prefix; } oracle_bam_tile;
+typedef struct { const uint8_t *bcl; const void *records; const uint32_t *cigars; uint64_t n_records; const char *read_name_prefix, *read_group; } oracle_bam_tile;
 
 // the literal index entries of lib/build/cppunit/testDuplicateFiltering.cpp through the filter: is_duplicate_out[i] for entry i as given
 int oracle_filter_duplicates(uint64_t n, const uint64_t *primary, const uint64_t *mate_anchor, const uint32_t *mate_info, const uint64_t *rank, const uint64_t *cluster_id,
@@ -897,7 +897,7 @@ int oracle_bam_records(const oracle_bam_tile *tiles, uint32_t n_tiles, uint32_t 
         std::vector<BamTileInput> in;
         for (uint32_t i = 0; i < n_tiles; ++i)
         {
-            BamTileInput t = { tiles[i].bcl, static_cast<const FragmentRecord *>(tiles[i].records), tiles[i].cigars, tiles[i].n_records, tiles[i].read_name_prefix };
+            BamTileInput t = { tiles[i].bcl, static_cast<const FragmentRecord *>(tiles[i].records), tiles[i].cigars, tiles[i].n_records, tiles[i].read_name_prefix, tiles[i].read_group ? tiles[i].read_group : "" };
             in.push_back(t);
         }
         BamOptions o; o.clusterLength = 0; o.readOffset[0] = o.readOffset[1] = 0;

@@ -685,7 +685,8 @@ unsigned fastqTileClustersMax(unsigned clustersAtATimeMax, unsigned seedCount);
 void fastqDiscoverTiles(unsigned clustersLoaded, unsigned tileClustersMax, unsigned &currentTile, std::vector<std::pair<unsigned, unsigned> > &loadedTiles);
 
 // bam.cpp: the BAM record stream of a set of tiles (build::Build with --realign-gaps no --mark-duplicates 0) and the BAM header
-struct BamTileInput { const uint8_t *bcl; const FragmentRecord *records; const uint32_t *cigars; uint64_t nRecords; std::string namePrefix; };
+struct BamTileInput { const uint8_t *bcl; const FragmentRecord *records; const uint32_t *cigars; uint64_t nRecords; std::string namePrefix;
+                      std::string readGroup; };   // the barcode index of the tile's lane (FragmentAccessorBamAdapter::getFragmentRG); empty: BamOptions::readGroup
 struct BamOptions { unsigned clusterLength, readOffset[2]; unsigned char forcedDodgyAlignmentScore; bool pessimisticMapQ; std::string readGroup, barcode;
                     bool markDuplicates = false, keepDuplicates = true;          // --mark-duplicates / --keep-duplicates (BinSorter.cpp:293-330)
                     bool realignGaps = false, realignDodgy = false, clipSemialigned = true; const ContigList *contigs = 0; const TemplateLengthStatistics *tls = 0; };   // --realign-gaps sample

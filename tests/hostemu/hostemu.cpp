@@ -388,6 +388,7 @@ int emu_bam_records(const isaac_bam_tile *tiles, u32 nTiles, u32 nReads, const u
         std::memset(&t[i], 0, sizeof(BamTile));
         t[i].bcl = tiles[i].bcl_dev; t[i].records = reinterpret_cast<const FragmentRecord *>(tiles[i].fragments_dev); t[i].cigars = tiles[i].cigar_dev;
         t[i].nRecords = u32(tiles[i].n_records); t[i].nameLength = u32(std::strlen(tiles[i].read_name_prefix)); std::memcpy(t[i].name, tiles[i].read_name_prefix, t[i].nameLength);
+        { const char *rg = tiles[i].read_group ? tiles[i].read_group : readGroup; t[i].readGroupLength = u32(std::strlen(rg)); std::memcpy(t[i].readGroup, rg, t[i].readGroupLength); }
         for (u64 k = 0; k < tiles[i].n_records; ++k)
         {
             const FragmentRecord &r = t[i].records[k];
@@ -405,7 +406,7 @@ int emu_bam_records(const isaac_bam_tile *tiles, u32 nTiles, u32 nReads, const u
         if (k.hi == ~u64(0) - 1 && *unalignedOffset == ~u64(0)) *unalignedOffset = at;
         const FragmentRecord &r = t[k.tile].records[k.index];
         const u32 n = bamRecordBytes(t[k.tile], r, o);
-        if (at + n <= capacity) { BamLayout l; bamLayout(t[k.tile], r, o, l); if (l.total != n) return 9; BamStrings text = { t[k.tile].name, o.readGroup, o.barcode, o.readGroupLength, o.barcodeLength }; std::vector<u8> stored(l.readLength); for (u32 b = 0; b < l.readLength; ++b) stored[b] = bamStoredBcl(l, b); for (u32 j = 0; j < n; ++j) out[at + j] = bamRecordByte(text, l, j, (j & 1) ? stored.data() : nullptr, l.cigar); }
+        if (at + n <= capacity) { BamLayout l; bamLayout(t[k.tile], r, o, l); if (l.total != n) return 9; BamStrings text = { t[k.tile].name, o.barcode, o.barcodeLength }; std::vector<u8> stored(l.readLength); for (u32 b = 0; b < l.readLength; ++b) stored[b] = bamStoredBcl(l, b); for (u32 j = 0; j < n; ++j) out[at + j] = bamRecordByte(text, l, j, (j & 1) ? stored.data() : nullptr, l.cigar); }
         at += n; ++*nRecords;
     }
     if (*unalignedOffset == ~u64(0)) *unalignedOffset = at;

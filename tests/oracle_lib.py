@@ -54,7 +54,7 @@ CIGAR_OPS = "MIDNSHP=X?"
 
 
 class BamTile(C.Structure):
-    _fields_ = [("bcl", C.c_void_p), ("records", C.c_void_p), ("cigars", C.c_void_p), ("n_records", C.c_uint64), ("read_name_prefix", C.c_char_p)]
+    _fields_ = [("bcl", C.c_void_p), ("records", C.c_void_p), ("cigars", C.c_void_p), ("n_records", C.c_uint64), ("read_name_prefix", C.c_char_p), ("read_group", C.c_char_p)]
 
 
 def cigar_string(words):
@@ -103,15 +103,18 @@ class Oracle:
 
     def bam_records(self, tiles, read_lengths, forced_dodgy_alignment_score=0, pessimistic_mapq=False, read_group="0", barcode="none", mark_duplicates=False, keep_duplicates=True,
                     realign_gaps=False, realign_dodgy=False, clip_semialigned=True, reference=None, tls=None):
-        """tiles: [(bcl, records, cigars, read_name_prefix)] as numpy arrays; returns (bytes, n_records, unaligned_offset)"""
+        """tiles: [(bcl, records, cigars, read_name_prefix[, read_group])] as numpy arrays; returns (bytes, n_records, unaligned_offset)"""
         arr = (BamTile * len(tiles))()
         keep = []
         total = 0
-        for i, (bcl, records, cigars, prefix) in enumerate(tiles):
+        for i, tile in enumerate(tiles):
+            bcl, records, cigars, prefix = tile[:4]
             bcl, records, cigars = np.ascontiguousarray(bcl, np.uint8), np.ascontiguousarray(records), np.ascontiguousarray(cigars, np.uint32)
             keep.append((bcl, records, cigars, prefix.encode()))
             arr[i].bcl = bcl.ctypes.data; arr[i].records = records.ctypes.data; arr[i].cigars = cigars.ctypes.data
             arr[i].n_records = len(records); arr[i].read_name_prefix = keep[-1][3]
+            if len(tile) > 4 and tile[4] is not None:
+                keep.append(tile[4].encode()); arr[i].read_group = keep[-1]
             total += len(records)
         lengths = (C.c_uint32 * 2)(*(list(read_lengths) + [0])[:2])
         cap = max(1, total * (128 + 2 * max(read_lengths) + 4 * 64))

@@ -47,10 +47,11 @@ def emu_bam_records(tiles, read_lengths, forced=0, pessimistic=False, read_group
     arr = (bam.BamTile * len(tiles))()
     keep = []
     total = 0
-    for i, (bcl, records, cigars, prefix) in enumerate(tiles):
-        keep.append((np.ascontiguousarray(bcl, np.uint8), np.ascontiguousarray(records), np.ascontiguousarray(cigars, np.uint32), prefix.encode()))
+    for i, tile in enumerate(tiles):
+        bcl, records, cigars, prefix = tile[:4]
+        keep.append((np.ascontiguousarray(bcl, np.uint8), np.ascontiguousarray(records), np.ascontiguousarray(cigars, np.uint32), prefix.encode(), tile[4].encode() if len(tile) > 4 else None))
         arr[i].bcl_dev, arr[i].fragments_dev, arr[i].cigar_dev = keep[-1][0].ctypes.data, keep[-1][1].ctypes.data, keep[-1][2].ctypes.data
-        arr[i].n_records, arr[i].read_name_prefix = len(records), keep[-1][3]
+        arr[i].n_records, arr[i].read_name_prefix, arr[i].read_group = len(records), keep[-1][3], keep[-1][4]
         total += len(records)
     cap = total * (400 + 2 * max(read_lengths))
     out = np.empty(cap, np.uint8)
@@ -90,6 +91,11 @@ def test_device_record_logic_matches_the_oracle_on_cpu(keep_unaligned):
                                              kwargs.get("barcode", "none"))
         assert (got_n, got_un) == (want_n, want_un)
         assert got == want
+    # lanes with a read group each (one 'none' barcode per lane): RG:Z follows the tile
+    by_lane = [t + (str(10 * k),) for k, t in enumerate(tiles)]
+    per_lane, per_lane_n, _ = o.bam_records(by_lane, lengths)
+    assert emu_bam_records(by_lane[::-1], lengths)[0] == per_lane and per_lane != want
+    assert {(r["name"].split(":")[0], r["tags"]["RG"]) for r in bam.parse_records(per_lane)} == {(t[3].split(":")[0], t[4]) for t in by_lane}
     recs = check_stream(want, tiles, want_n)
     stored = sum(int(((t[1]["reserved"] & 2) == 0).sum()) for t in tiles)
     assert want_n == stored
@@ -311,7 +317,7 @@ def test_gpu_duplicate_marking_matches_the_oracle():
         sizes[(mark, keep)] = (n, want)
     marked = bam.parse_records(sizes[(True, True)][1])
     n_dup = sum(1 for r in marked if r["flag"] & 0x400)
-    assert sizes[(True, True)][0] == n_plain and 1500 < n_dup < 8000          # every record is still there, the copies are flagged
+    assert sizes[(True, True)][0] == n_plain and 1500 < n_dup < 12000         # every record is still there, the copies are flagged
     assert sizes[(True, False)][0] == n_plain - n_dup == sizes[(False, False)][0]
     assert not any(r["flag"] & 0x400 for r in bam.parse_records(sizes[(True, False)][1]))
     assert not any(r["flag"] & 0x400 for r in bam.parse_records(plain.cpu().numpy().tobytes()))
