@@ -129,6 +129,8 @@ int isaac_gpu_malloc(isaac_gpu_ctx *ctx, uint64_t bytes, void **dev_out);
 int isaac_gpu_free(isaac_gpu_ctx *ctx, void *dev);
 int isaac_gpu_upload(isaac_gpu_ctx *ctx, void *dev, const void *host, uint64_t bytes);
 int isaac_gpu_download(isaac_gpu_ctx *ctx, void *host, const void *dev, uint64_t bytes);
+/* device to device, on the context's stream (ordered with the calls before and after it; no host wait) */
+int isaac_gpu_copy(isaac_gpu_ctx *ctx, void *dst_dev, const void *src_dev, uint64_t bytes);
 int isaac_gpu_synchronize(isaac_gpu_ctx *ctx);
 /* Deferred completion (off by default).  When on, isaac_gpu_select / isaac_gpu_select_candidates return while their last
  * kernels are still running on the context's stream (the call only enqueues; nothing inside it waits for the GPU), so that the
@@ -306,6 +308,8 @@ typedef struct
     const uint8_t *bcl_dev; const isaac_fragment *fragments_dev; const uint32_t *cigar_dev; uint64_t n_records; const char *read_name_prefix;
     const char *read_group;   /* RG:Z of this tile's records when lanes differ (one 'none' barcode per lane without a sample sheet,
                                  lib/demultiplexing/SampleSheetCsv.cpp:101-112); NULL = isaac_bam_options::read_group; at most 27 characters */
+    const isaac_tls *tls;     /* the template length statistics this tile's isaac_gpu_select ran with, when they differ between tiles (the reference
+                                 keeps them per barcode, that is per lane: MatchSelector.cpp:395-412); NULL = isaac_bam_options::tls */
 } isaac_bam_tile;
 typedef struct
 {
@@ -319,7 +323,8 @@ typedef struct
     uint32_t realign_vigorously;             /* --realign-vigorously (reference default 0): only 0 is implemented */
     uint32_t realign_dodgy;                  /* --realign-dodgy (reference default 0) */
     const isaac_tls *tls;                    /* the template length statistics isaac_gpu_select ran with: GapRealigner::updatePairDetails re-derives the
-                                                proper-pair flag of realigned pairs from them; required with realign_gaps and paired reads */
+                                                proper-pair flag of realigned pairs from them; required with realign_gaps and paired reads
+                                                unless every tile brings its own */
 } isaac_bam_options;
 int isaac_gpu_bam_records(isaac_gpu_ctx *ctx, const isaac_bam_tile *tiles, uint32_t n_tiles, const isaac_bam_options *options /* NULL = defaults */,
                           uint8_t *bam_dev, uint64_t capacity, uint64_t *n_bytes_out, uint64_t *n_records_out, uint64_t *unaligned_offset_out);
@@ -339,6 +344,18 @@ int isaac_gpu_bam_header(const char *command_line, const char *description, cons
 uint64_t isaac_gpu_bgzf_bound(uint64_t n_bytes);
 int isaac_gpu_bgzf_compress(const uint8_t *data_host, uint64_t n_bytes, int level, uint32_t n_threads, int eof_block,
                             uint8_t *out_host, uint64_t capacity, uint64_t *n_bytes_out);
+
+/* sorted.bam.bai: bam::BamIndexPart / bam::BamIndex (lib/bam/BamIndexer.cpp:43-126,129-472; constants include/bam/BamIndexer.hh:44-55,646-647), host-only.
+ * The reference indexes its output bin by bin: a bin's records give chunks and 16 kb linear-index entries in offsets of the bin's own
+ * uncompressed bytes, which the BGZF blocks the bin was compressed to turn into virtual file offsets.  A part is that: records_bytes bytes
+ * of the uncompressed record stream at records_offset which were compressed on their own into the bgzf_bytes bytes at bgzf_host (whole
+ * BGZF blocks), the parts following each other in the file behind header_bgzf_bytes bytes of compressed header.  Parts with aligned
+ * records must come in contig order (a contig may have several); the records of the unaligned bin are a part of their own.
+ * bai_out may be NULL with capacity 0 to size the file.  Errors: isaac_gpu_bam_index_last_error(). */
+typedef struct { uint64_t records_offset, records_bytes; const uint8_t *bgzf_host; uint64_t bgzf_bytes; } isaac_bam_index_part;
+const char *isaac_gpu_bam_index_last_error(void);
+int isaac_gpu_bam_index(const uint8_t *records_host, const isaac_bam_index_part *parts, uint32_t n_parts, uint32_t n_contigs, uint64_t header_bgzf_bytes,
+                        uint8_t *bai_out, uint64_t capacity, uint64_t *n_bytes_out);
 
 /* BGZF framing without compression on the device, for --bam-gzip-level 0: what bgzf::BgzfCompressor produces at gzip level 0
  * (include/bgzf/BgzfCompressor.hh:36-176: blocks of at most 0xFFFF - 41 input bytes, each a gzip member with the BC extra field around
@@ -380,6 +397,18 @@ int isaac_gpu_fastq_to_bcl(isaac_gpu_ctx *ctx, const char *fastq_dev, uint64_t n
 uint32_t isaac_gpu_fastq_tile_clusters_max(uint32_t clusters_at_a_time, uint32_t n_seeds);
 int isaac_gpu_fastq_tiles(uint32_t clusters_loaded, uint32_t clusters_at_a_time, uint32_t n_seeds, uint32_t first_tile,
                           uint32_t *tile_numbers, uint32_t *tile_clusters, uint32_t capacity, uint32_t *n_tiles_out, uint32_t *next_tile_out);
+
+/* The option defaults a host starts from (host-only): options::AlignOptions (lib/options/AlignOptions.cpp:77-160) for reads of the given
+ * lengths (read_length2 = 0: single-ended) with --gap-scoring bwa, --seeds auto and the first-pass rule of :1165-1171.
+ * isaac_gpu_parse_gap_scoring: --gap-scoring "bwa" | "eland" | m:mm:go:ge:mge (AlignOptions.cpp:689-743).
+ * isaac_gpu_parse_seeds: --seeds "auto" | "all" | offsets "0:32:64[,0:32]" per read (lib/options/alignOptions/SeedDescriptorOption.cpp:38-244)
+ * for params->n_reads / read_length / seed_length, with --first-pass-seeds as given (it becomes 2 with auto seeds and a non-zero
+ * semialigned_gap_limit, and never exceeds what a read has room for).  ISAAC_GPU_EINVAL with the reference's message in
+ * isaac_gpu_params_last_error(). */
+const char *isaac_gpu_params_last_error(void);
+int isaac_gpu_default_params(uint32_t read_length1, uint32_t read_length2, isaac_params *out);
+int isaac_gpu_parse_gap_scoring(const char *gap_scoring, isaac_params *params);
+int isaac_gpu_parse_seeds(const char *descriptor, uint32_t first_pass_seeds, isaac_params *params);
 
 int isaac_gpu_get_counters(isaac_gpu_ctx *ctx, isaac_counters *out);
 /* average device time (ms) of the named launch sequence over the launches since the last reset, measured with HIP events on the

@@ -8,7 +8,7 @@ import numpy as np
 
 
 class BamTile(C.Structure):
-    _fields_ = [("bcl_dev", C.c_void_p), ("fragments_dev", C.c_void_p), ("cigar_dev", C.c_void_p), ("n_records", C.c_uint64), ("read_name_prefix", C.c_char_p), ("read_group", C.c_char_p)]
+    _fields_ = [("bcl_dev", C.c_void_p), ("fragments_dev", C.c_void_p), ("cigar_dev", C.c_void_p), ("n_records", C.c_uint64), ("read_name_prefix", C.c_char_p), ("read_group", C.c_char_p), ("tls", C.c_void_p)]
 
 
 class BamOptions(C.Structure):
@@ -76,6 +76,68 @@ def write_bam(path, header_bytes, record_bytes, level=1, n_threads=None):
     with open(path, "wb") as f:
         f.write(bgzf_compress(header_bytes, level, n_threads))
         f.write(bgzf_compress(record_bytes, level, n_threads, eof_block=True))
+
+
+class IndexPart(C.Structure):
+    _fields_ = [("records_offset", C.c_uint64), ("records_bytes", C.c_uint64), ("bgzf_host", C.c_void_p), ("bgzf_bytes", C.c_uint64)]
+
+
+def split_parts(record_bytes, unaligned_offset):
+    """the bins of the file as isaac-align makes them: [(offset, bytes)] of every contig's records, then of the unaligned ones"""
+    data = memoryview(record_bytes)
+    parts, at = [], 0
+    while at < unaligned_offset:
+        contig, begin = bytes(data[at + 4:at + 8]), at
+        while at < unaligned_offset and bytes(data[at + 4:at + 8]) == contig:
+            at += 4 + int.from_bytes(data[at:at + 4], "little")
+        parts.append((begin, at - begin))
+    if unaligned_offset < len(data):
+        parts.append((unaligned_offset, len(data) - unaligned_offset))
+    return parts
+
+
+def index(record_bytes, parts, n_contigs, header_bgzf_bytes):
+    """sorted.bam.bai (bam::BamIndex): parts = [(records_offset, records_bytes, bgzf bytes)] in file order; returns the file's bytes"""
+    lib = _lib()
+    lib.isaac_gpu_bam_index_last_error.restype = C.c_char_p
+    records = np.frombuffer(record_bytes, np.uint8) if isinstance(record_bytes, (bytes, bytearray, memoryview)) else np.ascontiguousarray(record_bytes, np.uint8)
+    arr = (IndexPart * max(1, len(parts)))()
+    keep = []
+    for i, (offset, n, bgzf) in enumerate(parts):
+        keep.append(np.frombuffer(bgzf, np.uint8))
+        arr[i].records_offset, arr[i].records_bytes, arr[i].bgzf_host, arr[i].bgzf_bytes = offset, n, keep[-1].ctypes.data, len(bgzf)
+    n = C.c_uint64()
+    lib.isaac_gpu_bam_index(records.ctypes.data_as(C.c_void_p), arr, C.c_uint32(len(parts)), C.c_uint32(n_contigs), C.c_uint64(header_bgzf_bytes), None, C.c_uint64(0), C.byref(n))
+    out = np.empty(max(1, n.value), np.uint8)
+    rc = lib.isaac_gpu_bam_index(records.ctypes.data_as(C.c_void_p), arr, C.c_uint32(len(parts)), C.c_uint32(n_contigs), C.c_uint64(header_bgzf_bytes), out.ctypes.data_as(C.c_void_p),
+                                 C.c_uint64(out.size), C.byref(n))
+    if rc:
+        raise BamError("%d: %s" % (rc, lib.isaac_gpu_bam_index_last_error().decode()))
+    return out[:n.value].tobytes()
+
+
+def parse_index(bai):
+    """decodes a .bai file: (per contig: {"bins": {bin: [(begin, end)]}, "stats": (begin, end, mapped, unmapped) or None, "linear": [offsets]}, n_no_coordinate)"""
+    assert bai[:4] == b"BAI\1"
+    n_ref, at = int.from_bytes(bai[4:8], "little"), 8
+    contigs = []
+    for _ in range(n_ref):
+        n_bin = int.from_bytes(bai[at:at + 4], "little"); at += 4
+        bins, stats = {}, None
+        for _ in range(n_bin):
+            b, n_chunk = int.from_bytes(bai[at:at + 4], "little"), int.from_bytes(bai[at + 4:at + 8], "little"); at += 8
+            chunks = [(int.from_bytes(bai[at + 16 * k:at + 16 * k + 8], "little"), int.from_bytes(bai[at + 16 * k + 8:at + 16 * k + 16], "little")) for k in range(n_chunk)]
+            at += 16 * n_chunk
+            if b == 37450:
+                stats = (chunks[0][0], chunks[0][1], chunks[1][0], chunks[1][1])
+            else:
+                bins[b] = chunks
+        n_intv = int.from_bytes(bai[at:at + 4], "little"); at += 4
+        linear = [int.from_bytes(bai[at + 8 * k:at + 8 * k + 8], "little") for k in range(n_intv)]; at += 8 * n_intv
+        contigs.append(dict(bins=bins, stats=stats, linear=linear))
+    no_coordinate = int.from_bytes(bai[at:at + 8], "little"); at += 8
+    assert at == len(bai)
+    return contigs, no_coordinate
 
 
 def parse_records(data):

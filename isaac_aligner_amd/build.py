@@ -1,5 +1,6 @@
-"""Builds libisaac_gpu.so (the only native artefact of the product) with hipcc for gfx950, in-tree: every csrc/*.hip is a
-translation unit of its own (kernel families + the host side), compiled in parallel and linked into one shared library."""
+"""Builds libisaac_gpu.so with hipcc for gfx950, in-tree: every csrc/*.hip is a translation unit of its own (kernel families + the
+host side), compiled in parallel and linked into one shared library; and bin/isaac-align, the command-line host (host/*.cpp, g++)
+that uses nothing but include/isaac_gpu.h and links against that library."""
 import os
 import subprocess
 from concurrent.futures import ThreadPoolExecutor
@@ -57,5 +58,27 @@ def build(force=False, verbose=False):
     return LIB
 
 
+HOST = os.path.join(HERE, "host")
+HOST_EXE = os.path.join(HERE, "bin", "isaac-align")
+
+
+def build_host(force=False, verbose=False):
+    """bin/isaac-align: plain C++17 on the C ABI; finds the library next to it through its rpath"""
+    build(verbose=verbose)
+    srcs = [os.path.join(HOST, f) for f in sorted(os.listdir(HOST)) if f.endswith(".cpp")]
+    deps = srcs + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")] + [os.path.join(HERE, "..", "include", "isaac_gpu.h"), LIB]
+    if not force and os.path.exists(HOST_EXE) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_EXE) for d in deps):
+        return HOST_EXE
+    os.makedirs(os.path.dirname(HOST_EXE), exist_ok=True)
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-pthread", "-I", os.path.join(HERE, "..", "include"), "-I", HOST] + srcs + \
+          ["-L", HERE, "-l" + os.path.basename(LIB)[3:-3], "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--allow-shlib-undefined", "-lz", "-o", HOST_EXE]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return HOST_EXE
+
+
 if __name__ == "__main__":
     build(force=True, verbose=True)
+    if not TAG:
+        build_host(force=True, verbose=True)

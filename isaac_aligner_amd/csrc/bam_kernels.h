@@ -19,6 +19,7 @@ struct BamTile
     u32 nRecords, nameLength; char name[64];                                             // "<flowcell>:<lane>:<tile>:" (FragmentAccessorBamAdapter::readName)
     const u32 *cigarsAlt;                                                                // CIGARs of realigned records (RECORD_CIGAR_REALIGNED), else NULL
     const FragmentRecord *recordsOriginal;                                               // with gap realignment: the records as the caller gave them (`records` is the stage's copy), else NULL
+    DevTls tls;                                                                          // GapRealigner::updatePairDetails: the statistics of the tile's barcode
     char readGroup[28]; u32 readGroupLength;                                             // RG:Z of the tile's records: the barcode index of its lane (FragmentAccessorBamAdapter.hh:283-299)
 };
 struct BamOptions { u32 nReads, readLength[2], readOffset[2], clusterLength, forcedDodgyAlignmentScore, pessimisticMapQ, barcodeLength, readGroupLength; char barcode[64], readGroup[64];
@@ -380,7 +381,7 @@ __global__ void k_realign_pairs(const BamTile *tiles, u32 nTiles, u64 nRecords, 
     Cand cf, cm; candInit(cf, 0); candInit(cm, 1);
     cf.contigId = refposContig(f.fStrandPosition); cf.position = i64(refposPosition(f.fStrandPosition)); cf.reverse = (f.flags & 8) ? 1 : 0; cf.observedLength = f.observedLength; cf.cigarLength = 1;
     cm.contigId = refposContig(m.fStrandPosition); cm.position = i64(refposPosition(m.fStrandPosition)); cm.reverse = (m.flags & 8) ? 1 : 0; cm.observedLength = m.observedLength; cm.cigarLength = 1;
-    const bool proper = TLS_NOMINAL == tlsCheckModel(o.tls, cf, cm);
+    const bool proper = TLS_NOMINAL == tlsCheckModel(tiles[t].tls, cf, cm);
     f.flags = (f.flags & ~256u) | (proper ? 256u : 0u); m.flags = (m.flags & ~256u) | (proper ? 256u : 0u);
 }
 

@@ -518,6 +518,8 @@ int isaac_gpu_upload(isaac_gpu_ctx *c, void *dev, const void *host, uint64_t byt
 { ISAAC_TRY HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
 int isaac_gpu_download(isaac_gpu_ctx *c, void *host, const void *dev, uint64_t bytes)
 { ISAAC_TRY HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
+int isaac_gpu_copy(isaac_gpu_ctx *c, void *dstDev, const void *srcDev, uint64_t bytes)
+{ ISAAC_TRY if (bytes) HIP_CHECK(hipMemcpyAsync(dstDev, srcDev, bytes, hipMemcpyDeviceToDevice, c->stream)); return 0; ISAAC_CATCH }
 int isaac_gpu_synchronize(isaac_gpu_ctx *c) { ISAAC_TRY HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
 int isaac_gpu_set_deferred_completion(isaac_gpu_ctx *c, int enabled)
 {
@@ -1350,7 +1352,6 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
     if (o.realignGaps)
     {
         if (options->realign_vigorously) return fail(ISAAC_GPU_EINVAL, "--realign-vigorously is not implemented");
-        if (2 == o.nReads && !options->tls) return fail(ISAAC_GPU_EINVAL, "gap realignment of paired reads needs the template length statistics (isaac_bam_options::tls)");
         // BinSorter.hh:96-98: GapRealigner(realignGapsVigorously, realignDodgyFragments, realignedGapsPerFragment, 3, 4, 0, clipSemialigned, ...)
         o.realign.mismatchCost = 3; o.realign.gapOpenCost = 4; o.realign.gapExtendCost = 0; o.realign.realignDodgyFragments = options->realign_dodgy != 0; o.realign.clipSemialigned = c->params.clip_semialigned != 0;
         if (options->tls) std::memcpy(&o.tls, options->tls, sizeof(o.tls));
@@ -1370,6 +1371,9 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
         if (std::strlen(tileReadGroup) >= sizeof(h[t].readGroup)) return fail(ISAAC_GPU_EINVAL, "read_group: at most 27 characters");
         h[t].readGroupLength = u32(std::strlen(tileReadGroup)); std::memcpy(h[t].readGroup, tileReadGroup, h[t].readGroupLength);
         maxReadGroup = std::max(maxReadGroup, h[t].readGroupLength);
+        if (o.realignGaps && 2 == o.nReads && !in.tls && !options->tls)
+            return fail(ISAAC_GPU_EINVAL, "gap realignment of paired reads needs the template length statistics (isaac_bam_options::tls or isaac_bam_tile::tls)");
+        if (in.tls) std::memcpy(&h[t].tls, in.tls, sizeof(h[t].tls)); else h[t].tls = o.tls;
         n += in.n_records;
     }
     if (n >= (u64(1) << 31)) return fail(ISAAC_GPU_EINVAL, "at most 2^31 - 1 records per call");

@@ -35,12 +35,13 @@ def load_library(path=None):
 
 
 EXPORTS = ["isaac_gpu_last_error", "isaac_gpu_create", "isaac_gpu_destroy", "isaac_gpu_set_params", "isaac_gpu_index_dev", "isaac_gpu_set_index_dev", "isaac_gpu_malloc", "isaac_gpu_free", "isaac_gpu_upload", "isaac_gpu_download",
-           "isaac_gpu_synchronize", "isaac_gpu_set_deferred_completion", "isaac_gpu_load_contigs", "isaac_gpu_load_contigs_dev", "isaac_gpu_load_index", "isaac_gpu_build_index", "isaac_gpu_get_index", "isaac_gpu_get_index_range", "isaac_gpu_get_mask_offsets",
+           "isaac_gpu_copy", "isaac_gpu_synchronize", "isaac_gpu_set_deferred_completion", "isaac_gpu_load_contigs", "isaac_gpu_load_contigs_dev", "isaac_gpu_load_index", "isaac_gpu_build_index", "isaac_gpu_get_index", "isaac_gpu_get_index_range", "isaac_gpu_get_mask_offsets",
            "isaac_gpu_sorted_reference_parse", "isaac_gpu_sorted_reference_format", "isaac_gpu_sorted_reference_last_error", "isaac_gpu_load_sorted_reference",
            "isaac_gpu_save_sorted_reference",
            "isaac_gpu_find_matches", "isaac_gpu_set_loaded_contigs", "isaac_gpu_build_fragments", "isaac_gpu_determine_tls", "isaac_gpu_select", "isaac_gpu_select_candidates",
            "isaac_gpu_bsw_batch", "isaac_gpu_compact_cigars", "isaac_gpu_compact_cigars_async",
-           "isaac_gpu_bam_records", "isaac_gpu_bam_last_error", "isaac_gpu_bam_header", "isaac_gpu_bgzf_bound", "isaac_gpu_bgzf_compress", "isaac_gpu_bgzf_store_bound", "isaac_gpu_bgzf_store",
+           "isaac_gpu_bam_records", "isaac_gpu_bam_last_error", "isaac_gpu_bam_header", "isaac_gpu_bgzf_bound", "isaac_gpu_bgzf_compress", "isaac_gpu_bgzf_store_bound", "isaac_gpu_bgzf_store", "isaac_gpu_bam_index", "isaac_gpu_bam_index_last_error",
+           "isaac_gpu_default_params", "isaac_gpu_parse_gap_scoring", "isaac_gpu_parse_seeds", "isaac_gpu_params_last_error",
            "isaac_gpu_fastq_to_bcl", "isaac_gpu_fastq_tile_clusters_max", "isaac_gpu_fastq_tiles", "isaac_gpu_get_counters", "isaac_gpu_kernel_time_ms", "isaac_gpu_reset_timers"]
 
 
@@ -321,7 +322,7 @@ class Aligner:
     # ---- output format --------------------------------------------------------------------------------------------
     def bam_records(self, tiles, out=None, read_group=None, barcode=None, forced_dodgy_alignment_score=None, pessimistic_mapq=False, mark_duplicates=False, keep_duplicates=True, realign_gaps=False, tls=None):
         """build::Build's BAM alignment records (--realign-gaps no --mark-duplicates 0) of one or more tiles, in file order.
-        tiles: [(bcl, records, cigars, read_name_prefix[, read_group])] as given to / returned by select().  Returns (uint8 device tensor of the
+        tiles: [(bcl, records, cigars, read_name_prefix[, read_group[, tls]])] as given to / returned by select().  Returns (uint8 device tensor of the
         uncompressed records, number of records, offset of the unaligned bin)."""
         from . import bam
         arr = (bam.BamTile * len(tiles))()
@@ -339,6 +340,8 @@ class Aligner:
             if len(tile) > 4 and tile[4] is not None:
                 keep.append(tile[4].encode())
                 arr[i].read_group = keep[-1]
+            if len(tile) > 5 and tile[5] is not None:
+                arr[i].tls = C.cast(C.pointer(tile[5]), C.c_void_p)
             n_rec += records.shape[0]
         options = None
         if read_group is not None or barcode is not None or forced_dodgy_alignment_score is not None or pessimistic_mapq or mark_duplicates or not keep_duplicates or realign_gaps:

@@ -27,7 +27,7 @@ const uint64_t NO_MATCH_VALUE = ReferencePosition(ReferencePosition::NoMatch).va
 // the stored form of one read: header fields, bases as stored (FragmentCollector::storeBclAndCigar), CIGAR
 struct Stored
 {
-    FragmentRecord *header; std::vector<unsigned char> bases; const uint32_t *cigarBegin, *cigarEnd; const std::string *namePrefix; const std::string *readGroup = 0;
+    FragmentRecord *header; std::vector<unsigned char> bases; const uint32_t *cigarBegin, *cigarEnd; const std::string *namePrefix; const std::string *readGroup = 0; const TemplateLengthStatistics *tls = 0;
     const uint32_t *originalCigarBegin = 0, *originalCigarEnd = 0;                     // FragmentAccessorBamAdapter::originalCigarBegin_: the fragment's own CIGAR
     const uint8_t *clusterBcl = 0; FragmentRecord *mate = 0; bool duplicate = false;
     bool paired() const { return header->flags & 1; }
@@ -199,7 +199,7 @@ void bamRecords(const std::vector<BamTileInput> &tiles, const BamOptions &o, std
         {
             FragmentRecord &h = copies[tileIndex][i];
             if (h.reserved & 2) continue;                                     // MatchSelector.cpp:345-357: the template was not stored
-            Stored s; s.header = &h; s.namePrefix = &t.namePrefix; s.readGroup = t.readGroup.empty() ? &o.readGroup : &t.readGroup;
+            Stored s; s.header = &h; s.namePrefix = &t.namePrefix; s.readGroup = t.readGroup.empty() ? &o.readGroup : &t.readGroup; s.tls = t.tls ? t.tls : o.tls;
             const unsigned readIndex = (h.flags & 1) && (h.flags & 64) ? 1 : 0;
             const uint8_t *bcl = t.bcl + uint64_t(h.clusterId) * o.clusterLength + o.readOffset[readIndex];
             s.bases.assign(bcl, bcl + h.readLength);
@@ -297,7 +297,7 @@ void bamRecords(const std::vector<BamTileInput> &tiles, const BamOptions &o, std
             // TemplateLengthStatistics::checkModel(fragment, mate) (TemplateLengthStatistics.hh:104-118) on the two FragmentAccessors
             bool proper = false;
             {
-                const TemplateLengthStatistics &tls = *o.tls;
+                const TemplateLengthStatistics &tls = *s.tls;            // barcodeTemplateLengthStatistics_[fragment.barcode_]
                 const ReferencePosition mp = ReferencePosition::fromValue(mate.fStrandPosition);
                 if (pos.getContigId() == mp.getContigId())
                 {

@@ -869,7 +869,7 @@ extern "C" int oracle_realign_case(const char *contig, uint64_t contig_length, c
 
 // ---- BAM records and header (bam.cpp) ---------------------------------------------------------------------------
 extern "C" {
-typedef struct { const uint8_t *bcl; const void *records; const uint32_t *cigars; uint64_t n_records; const char *read_name_prefix, *read_group; } oracle_bam_tile;
+typedef struct { const uint8_t *bcl; const void *records; const uint32_t *cigars; uint64_t n_records; const char *read_name_prefix, *read_group; const oracle_tls *tls; } oracle_bam_tile;
 
 // the literal index entries of lib/build/cppunit/testDuplicateFiltering.cpp through the filter: is_duplicate_out[i] for entry i as given
 int oracle_filter_duplicates(uint64_t n, const uint64_t *primary, const uint64_t *mate_anchor, const uint32_t *mate_info, const uint64_t *rank, const uint64_t *cluster_id,
@@ -895,9 +895,11 @@ int oracle_bam_records(const oracle_bam_tile *tiles, uint32_t n_tiles, uint32_t 
     try
     {
         std::vector<BamTileInput> in;
+        std::vector<TemplateLengthStatistics> tileStats(n_tiles);
         for (uint32_t i = 0; i < n_tiles; ++i)
         {
             BamTileInput t = { tiles[i].bcl, static_cast<const FragmentRecord *>(tiles[i].records), tiles[i].cigars, tiles[i].n_records, tiles[i].read_name_prefix, tiles[i].read_group ? tiles[i].read_group : "" };
+            if (tiles[i].tls) { tileStats[i] = fromTls(tiles[i].tls); t.tls = &tileStats[i]; }
             in.push_back(t);
         }
         BamOptions o; o.clusterLength = 0; o.readOffset[0] = o.readOffset[1] = 0;
@@ -911,6 +913,45 @@ int oracle_bam_records(const oracle_bam_tile *tiles, uint32_t n_tiles, uint32_t 
         *n_bytes = os.size();
         if (os.size() > capacity) throw std::runtime_error("bam capacity");
         memcpy(out, os.data(), os.size());
+        return 0;
+    }
+    catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+
+// records: the uncompressed record stream; part k = records [part_offsets[k], + part_bytes[k]) compressed to bgzf[k] (bgzf_bytes[k] bytes)
+int oracle_bam_index(const uint8_t *records, const uint64_t *part_offsets, const uint64_t *part_bytes, const uint8_t *const *bgzf, const uint64_t *bgzf_bytes, uint32_t n_parts,
+                     uint32_t n_contigs, uint32_t header_compressed_length, uint8_t *out, uint64_t capacity, uint64_t *n_bytes)
+{
+    try
+    {
+        std::vector<BamIndexPartInput> parts(n_parts);
+        for (uint32_t k = 0; k < n_parts; ++k)
+        {
+            parts[k].bgzf.assign(reinterpret_cast<const char *>(bgzf[k]), reinterpret_cast<const char *>(bgzf[k]) + bgzf_bytes[k]);
+            const uint8_t *b = records + part_offsets[k], *end = b + part_bytes[k];
+            while (b < end)
+            {
+                // the fields FragmentAccessorBamAdapter hands to the indexer, read back from the serialised record (Bam.hh:257-345)
+                int32_t blockSize, refId, pos, lSeq; uint32_t binMqNl, flagNc;
+                memcpy(&blockSize, b, 4); memcpy(&refId, b + 4, 4); memcpy(&pos, b + 8, 4); memcpy(&binMqNl, b + 12, 4); memcpy(&flagNc, b + 16, 4); memcpy(&lSeq, b + 20, 4);
+                const uint32_t nameLength = binMqNl & 0xff, nCigar = flagNc & 0xffff;
+                uint32_t observed = 0;
+                for (uint32_t c = 0; c < nCigar; ++c)
+                {
+                    uint32_t w; memcpy(&w, b + 36 + nameLength + 4 * c, 4);
+                    const uint32_t op = w & 15;
+                    if (0 == op || 2 == op || 3 == op || 7 == op || 8 == op) observed += w >> 4;      // M D N = X: the reference bases covered
+                }
+                const BamIndexRecord r = { refId, pos, lSeq, observed, flagNc >> 16, uint32_t(blockSize) + 4 };
+                parts[k].records.push_back(r);
+                b += uint32_t(blockSize) + 4;
+            }
+        }
+        std::vector<char> bai;
+        bamIndex(parts, n_contigs, header_compressed_length, bai);
+        *n_bytes = bai.size();
+        if (bai.size() > capacity) throw std::runtime_error("bai capacity");
+        memcpy(out, bai.data(), bai.size());
         return 0;
     }
     catch (const std::exception &e) { g_error = e.what(); return 1; }

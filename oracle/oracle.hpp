@@ -686,7 +686,8 @@ void fastqDiscoverTiles(unsigned clustersLoaded, unsigned tileClustersMax, unsig
 
 // bam.cpp: the BAM record stream of a set of tiles (build::Build with --realign-gaps no --mark-duplicates 0) and the BAM header
 struct BamTileInput { const uint8_t *bcl; const FragmentRecord *records; const uint32_t *cigars; uint64_t nRecords; std::string namePrefix;
-                      std::string readGroup; };   // the barcode index of the tile's lane (FragmentAccessorBamAdapter::getFragmentRG); empty: BamOptions::readGroup
+                      std::string readGroup;                        // the barcode index of the tile's lane (FragmentAccessorBamAdapter::getFragmentRG); empty: BamOptions::readGroup
+                      const TemplateLengthStatistics *tls = 0; };   // of the tile's barcode; NULL: BamOptions::tls
 struct BamOptions { unsigned clusterLength, readOffset[2]; unsigned char forcedDodgyAlignmentScore; bool pessimisticMapQ; std::string readGroup, barcode;
                     bool markDuplicates = false, keepDuplicates = true;          // --mark-duplicates / --keep-duplicates (BinSorter.cpp:293-330)
                     bool realignGaps = false, realignDodgy = false, clipSemialigned = true; const ContigList *contigs = 0; const TemplateLengthStatistics *tls = 0; };   // --realign-gaps sample
@@ -708,6 +709,13 @@ void bamRecords(const std::vector<BamTileInput> &tiles, const BamOptions &o, std
 struct SqTags { std::string as, ur, m5; };    // SortedReferenceMetadata::Contig::bamSqAs_ / bamSqUr_ / bamM5_
 void bamHeader(const std::string &commandLine, const std::string &description, const std::string &version, const std::vector<std::string> &headerLines,
                const std::vector<std::pair<std::string, uint32_t> > &refSeqs, std::vector<char> &os, const std::vector<SqTags> *tags = 0);
+
+// ---- bam_index.cpp: the .bai file (bam::BamIndexPart / bam::BamIndex, lib/bam/BamIndexer.cpp)
+// what BamIndexPart::processFragment reads from the adapter of one serialised record
+struct BamIndexRecord { int refId, pos, seqLen; uint32_t observedLength, flag, serializedLength; };
+// one bin as build::Build saves it: its records in file order and the BGZF bytes they were compressed to
+struct BamIndexPartInput { std::vector<BamIndexRecord> records; std::vector<char> bgzf; };
+void bamIndex(const std::vector<BamIndexPartInput> &parts, uint32_t nContigs, uint32_t headerCompressedLength, std::vector<char> &bai);
 
 // ---- gap realigner (realign.cpp)
 // gapRealigner::Gap (include/build/gapRealigner/Gap.hh:31-78): length > 0 deletion from the reference, < 0 insertion

@@ -54,7 +54,7 @@ CIGAR_OPS = "MIDNSHP=X?"
 
 
 class BamTile(C.Structure):
-    _fields_ = [("bcl", C.c_void_p), ("records", C.c_void_p), ("cigars", C.c_void_p), ("n_records", C.c_uint64), ("read_name_prefix", C.c_char_p), ("read_group", C.c_char_p)]
+    _fields_ = [("bcl", C.c_void_p), ("records", C.c_void_p), ("cigars", C.c_void_p), ("n_records", C.c_uint64), ("read_name_prefix", C.c_char_p), ("read_group", C.c_char_p), ("tls", C.c_void_p)]
 
 
 def cigar_string(words):
@@ -103,7 +103,7 @@ class Oracle:
 
     def bam_records(self, tiles, read_lengths, forced_dodgy_alignment_score=0, pessimistic_mapq=False, read_group="0", barcode="none", mark_duplicates=False, keep_duplicates=True,
                     realign_gaps=False, realign_dodgy=False, clip_semialigned=True, reference=None, tls=None):
-        """tiles: [(bcl, records, cigars, read_name_prefix[, read_group])] as numpy arrays; returns (bytes, n_records, unaligned_offset)"""
+        """tiles: [(bcl, records, cigars, read_name_prefix[, read_group[, tls]])] as numpy arrays; returns (bytes, n_records, unaligned_offset)"""
         arr = (BamTile * len(tiles))()
         keep = []
         total = 0
@@ -115,6 +115,8 @@ class Oracle:
             arr[i].n_records = len(records); arr[i].read_name_prefix = keep[-1][3]
             if len(tile) > 4 and tile[4] is not None:
                 keep.append(tile[4].encode()); arr[i].read_group = keep[-1]
+            if len(tile) > 5 and tile[5] is not None:
+                arr[i].tls = C.cast(C.pointer(tile[5]), C.c_void_p)
             total += len(records)
         lengths = (C.c_uint32 * 2)(*(list(read_lengths) + [0])[:2])
         cap = max(1, total * (128 + 2 * max(read_lengths) + 4 * 64))
@@ -125,6 +127,20 @@ class Oracle:
                                                C.c_int(int(realign_gaps)), C.c_int(int(realign_dodgy)), C.c_int(int(clip_semialigned)), (reference.h if reference is not None else None),
                                                C.byref(tls) if tls is not None else None, ptr(out), C.c_uint64(cap), C.byref(nb), C.byref(nr), C.byref(un)))
         return out[:nb.value].tobytes(), nr.value, un.value
+
+    def bam_index(self, record_bytes, parts, n_contigs, header_bgzf_bytes):
+        """parts: [(records_offset, records_bytes, bgzf bytes)] in file order; returns the .bai bytes"""
+        records = np.frombuffer(record_bytes, np.uint8)
+        keep = [np.frombuffer(p[2], np.uint8) for p in parts]
+        offsets = (C.c_uint64 * max(1, len(parts)))(*[p[0] for p in parts])
+        sizes = (C.c_uint64 * max(1, len(parts)))(*[p[1] for p in parts])
+        bgzf = (C.c_void_p * max(1, len(parts)))(*[k.ctypes.data for k in keep])
+        bgzf_sizes = (C.c_uint64 * max(1, len(parts)))(*[len(p[2]) for p in parts])
+        out = np.empty(64 + 16 * len(records) // 32 + 400000 * n_contigs, np.uint8)
+        n = C.c_uint64()
+        self.check(self.lib.oracle_bam_index(ptr(records), offsets, sizes, bgzf, bgzf_sizes, C.c_uint32(len(parts)), C.c_uint32(n_contigs), C.c_uint32(header_bgzf_bytes),
+                                             ptr(out), C.c_uint64(out.size), C.byref(n)))
+        return out[:n.value].tobytes()
 
     def bam_header(self, command_line, version, contigs, description="", header_lines=()):
         lines = (C.c_char_p * max(1, len(header_lines)))(*[l.encode() for l in header_lines])

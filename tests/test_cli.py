@@ -1,0 +1,346 @@
+"""isaac-align, the command-line host (isaac_aligner_amd/host, built on include/isaac_gpu.h alone), and the host-only entry points it
+brought: option defaults / --seeds / --gap-scoring (isaac_gpu_default_params, isaac_gpu_parse_seeds, isaac_gpu_parse_gap_scoring) and the
+.bai writer (isaac_gpu_bam_index) against the oracle's restatement of bam::BamIndexPart / bam::BamIndex and against what a BAI must mean.
+On the GPU: a two-lane FASTQ flowcell through the binary, sorted.bam and sorted.bam.bai compared byte for byte with the oracle run on the
+same inputs (reader, seed lookup, template statistics per lane, selection, duplicate marking, gap realignment, record stream, index)."""
+import ctypes as C
+import gzip
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from isaac_aligner_amd import abi, bam, build, gpu, options, sorted_reference as sr, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def host():
+    return build.build_host()
+
+
+def run_host(*args, cwd=None):
+    return subprocess.run([host()] + [str(a) for a in args], capture_output=True, text=True, cwd=cwd)
+
+
+# ---- options ---------------------------------------------------------------------------------------------------------------------------
+
+PARAM_FIELDS = ("gap_match", "gap_mismatch", "gap_open", "gap_extend", "min_gap_extend", "repeat_threshold", "gapped_mismatches_max", "semialigned_gap_limit", "base_quality_cutoff",
+                "ignore_neighbors", "clip_semialigned", "clip_overlapping", "scatter_repeats", "dodgy_alignment_score", "mapq_threshold", "keep_unaligned", "mate_drift_range",
+                "first_pass_seeds", "seed_length", "n_reads", "n_seeds")
+
+
+def seeds_of(p):
+    return [(p.seeds[i].offset, p.seeds[i].length, p.seeds[i].read_index) for i in range(p.n_seeds)]
+
+
+@pytest.mark.parametrize("lengths", [(100, 100), (150, 150), (36, 0), (50, 50), (64, 64), (33, 33), (250, 250), (101, 75), (32, 32)])
+def test_default_params_follow_the_options_rule(lengths):
+    """isaac_gpu_default_params (C, what the command-line host starts from) == options.default_params (Python) == the oracle's"""
+    lib = gpu.load_library()
+    p = abi.Params()
+    assert lib.isaac_gpu_default_params(C.c_uint32(lengths[0]), C.c_uint32(lengths[1]), C.byref(p)) == 0
+    want = options.default_params(*lengths)
+    assert [getattr(p, f) for f in PARAM_FIELDS] == [getattr(want, f) for f in PARAM_FIELDS]
+    assert seeds_of(p) == seeds_of(want) and list(p.read_length) == list(want.read_length)
+    o = oracle_lib.load().default_params(2 if lengths[1] else 1, *lengths)
+    assert seeds_of(p) == seeds_of(o) and p.first_pass_seeds == o.first_pass_seeds
+
+
+def test_seed_descriptors_and_gap_scoring():
+    lib = gpu.load_library()
+    lib.isaac_gpu_params_last_error.restype = C.c_char_p
+    p = options.default_params(100, 100)
+    # SeedDescriptorOption.cpp: a list per read, the last one serves the reads that follow; seeds that do not fit are dropped
+    assert lib.isaac_gpu_parse_seeds(b"0:32:64:90", C.c_uint32(3), C.byref(p)) == 0
+    assert seeds_of(p) == [(0, 32, 0), (32, 32, 0), (64, 32, 0), (0, 32, 1), (32, 32, 1), (64, 32, 1)] and p.first_pass_seeds == 3
+    assert lib.isaac_gpu_parse_seeds(b"0:16,8", C.c_uint32(2), C.byref(p)) == 0
+    assert seeds_of(p) == [(0, 32, 0), (16, 32, 0), (8, 32, 1)] and p.first_pass_seeds == 1
+    p.semialigned_gap_limit = 0
+    assert lib.isaac_gpu_parse_seeds(b"auto", C.c_uint32(1), C.byref(p)) == 0 and p.first_pass_seeds == 1       # 2 only with a gap limit (AlignOptions.cpp:1165-1171)
+    for bad, message in ((b"", b"empty"), (b"0:x", b"Invalid seed offset 'x'"), (b"0,0,0", b"Too many lists-of-seeds"), (b"90", b"At least one seed must be used")):
+        assert lib.isaac_gpu_parse_seeds(bad, C.c_uint32(1), C.byref(p)) == 1 and message in lib.isaac_gpu_params_last_error()
+    assert lib.isaac_gpu_parse_gap_scoring(b"eland", C.byref(p)) == 0 and (p.gap_match, p.gap_mismatch, p.gap_open, p.gap_extend, p.min_gap_extend) == (2, -1, -15, -3, -25)
+    assert lib.isaac_gpu_parse_gap_scoring(b"1:-2:-3:-4:-5", C.byref(p)) == 0 and (p.gap_match, p.gap_mismatch, p.gap_open, p.gap_extend, p.min_gap_extend) == (1, -2, -3, -4, -5)
+    for bad, message in ((b"1:2", b"five components"), (b"-1:-2:-3:-4:-5", b"match score"), (b"1:2:-3:-4:-5", b"mismatch score"), (b"1:-2:-3:-4:5", b"score cap")):
+        assert lib.isaac_gpu_parse_gap_scoring(bad, C.byref(p)) == 1 and message in lib.isaac_gpu_params_last_error()
+
+
+def test_command_line_errors(tmp_path):
+    """what options::AlignOptions rejects, and what this host refuses instead of ignoring; exit code 1 with the message (common::run)"""
+    assert run_host("--version").stdout.strip().startswith("isaac_aligner_amd")
+    assert "--base-calls-format" in run_host("--help").stdout
+    cases = [(["-r", "x.xml"], "At least one 'base-calls' is required"),
+             (["-b", tmp_path], "At least one 'reference-genome' is required"),
+             (["-r", "x.xml", "-b", tmp_path], "this host reads fastq and fastq-gz only"),
+             (["-r", "x.xml", "-b", tmp_path, "--base-calls-format", "fastq", "--frobnicate", "1"], "unrecognised option '--frobnicate'"),
+             (["-r", "x.xml", "-b", tmp_path, "--base-calls-format", "fastq", "--realign-gaps", "maybe"], "The 'realign-gaps' value is invalid maybe"),
+             (["-r", "x.xml", "-b", tmp_path, "--base-calls-format", "fastq", "--keep-unaligned", "sideways"], "must be 'discard', 'front' or 'back'"),
+             (["-r", "x.xml", "-b", tmp_path, "--base-calls-format", "fastq", "--dodgy-alignment-score", "300"], "must be either Unknown, Unaligned or a number 0-255 (300 given)"),
+             (["-r", "x.xml", "-b", tmp_path, "--base-calls-format", "fastq", "--seed-length", "20"], "--seed-length other than 16, 32 or 64 is not supported"),
+             (["-r", "x.xml", "-b", tmp_path, "--base-calls-format", "fastq", "--seed-length", "64"], "32-mer seeds only"),
+             (["-r", "x.xml", "-b", tmp_path, "--base-calls-format", "fastq", "--realign-vigorously", "1"], "--realign-vigorously 1 is not supported"),
+             (["-r", "x.xml", "-b", tmp_path, "--base-calls-format", "fastq", "--mark-duplicates", "perhaps"], "option '--mark-duplicates' is invalid"),
+             (["-r", "x.xml", "-b", tmp_path, "--base-calls-format", "fastq", "--jobs"], "the required argument for option '--jobs' is missing"),
+             (["-r", "x.xml", "-b", tmp_path, "--base-calls-format", "fastq", "-m", "5", "-j4", "-t", tmp_path / "Temp"], "Could not find any fastq lanes in")]
+    for args, message in cases:
+        r = run_host(*args)
+        assert r.returncode == 1 and message in r.stderr, (args, r.stderr)
+    # a flowcell that is there: ids of the two reads must agree, masks must parse and leave a prefix of every read
+    for lane, (h1, h2) in enumerate([("@M1:7:FCA:1:1", "@M1:7:FCB:1:1")], start=1):
+        for read, header in ((1, h1), (2, h2)):
+            (tmp_path / ("lane%d_read%d.fastq" % (lane, read))).write_text("%s\n%s\n+\n%s\n" % (header, "ACGT" * 10, "I" * 40))
+    base = ["-r", "x.xml", "-b", tmp_path, "--base-calls-format", "fastq"]
+    r = run_host(*base)
+    assert r.returncode == 1 and "Flowcell ID mismatch between fastq reads FCA vs FCB" in r.stderr
+    (tmp_path / "lane1_read2.fastq").write_text("@M1:7:FCA:1:1\n%s\n+\n%s\n" % ("ACGT" * 10, "I" * 40))
+    for mask, message in (("y*n,q*", "Could not parse the use-bases-mask 'y*n,q*'"), ("y*", "incompatible with number of reads (2)"), ("n4y*,y*", "is not of that form"),
+                          ("y*n,i*", "index cycles are not supported"), ("y20n*,y*", "is too short: 20 cycle < 32"), ("y0n*,y*", "Could not parse")):
+        r = run_host(*(base + ["--use-bases-mask", mask]))
+        assert r.returncode == 1 and message in r.stderr, (mask, r.stderr)
+    r = run_host(*(base + ["--use-bases-mask", "y36n*,y*n"]))          # a good mask: the run gets as far as the device (or the reference file)
+    assert r.returncode == 1 and ("isaac_gpu_create" in r.stderr or "x.xml" in r.stderr)
+
+
+# ---- the index -------------------------------------------------------------------------------------------------------------------------
+
+def bgzf_blocks(data):
+    """[(offset, compressed size, uncompressed bytes)] of a run of BGZF blocks"""
+    blocks, at = [], 0
+    while at < len(data):
+        assert data[at:at + 4] == b"\x1f\x8b\x08\x04" and data[at + 12:at + 14] == b"BC"
+        size = int.from_bytes(data[at + 16:at + 18], "little") + 1
+        blocks.append((at, size, zlib.decompress(data[at + 18:at + size - 8], -15)))
+        assert int.from_bytes(data[at + size - 4:at + size], "little") == len(blocks[-1][2])
+        at += size
+    return blocks
+
+
+def check_index_semantics(bai, stream, parts, n_contigs, header_bgzf_bytes, read_length):
+    """independent of both implementations: every record with a position is inside a chunk of its bin, the linear index of a 16 kb window is
+    the smallest virtual offset of the records that overlap it, the counts are the records' counts"""
+    contigs, no_coordinate = bam.parse_index(bai)
+    assert len(contigs) == n_contigs
+    voffsets, file_at = {}, header_bgzf_bytes
+    for offset, n, bgzf in parts:
+        starts, raw = [], 0
+        for at, size, data in bgzf_blocks(bgzf):
+            starts.append((raw, file_at + at)); raw += len(data)
+        assert raw == n
+        at = 0
+        while at < n:
+            k = max(i for i, (u, _) in enumerate(starts) if u <= at)
+            voffsets[offset + at] = (starts[k][1] << 16) | (at - starts[k][0])
+            at += 4 + int.from_bytes(stream[offset + at:offset + at + 4], "little")
+        file_at += len(bgzf)
+    recs, at = bam.parse_records(stream), 0
+    windows = [dict() for _ in range(n_contigs)]
+    counts = [[0, 0] for _ in range(n_contigs)]
+    unplaced = 0
+    for r in recs:
+        v = voffsets[at]
+        at += 4 + int.from_bytes(stream[at:at + 4], "little")
+        if r["pos"] < 0:
+            unplaced += 1
+            continue
+        c = contigs[r["ref_id"]]
+        span = sum(int(w) >> 4 for w in r["cigar"] if (int(w) & 15) in (0, 2, 3, 7, 8))
+        index_bin = bam_reg2bin(r["pos"], r["pos"] + len(r["seq"]))               # the read's length, not its span: "samtools is doing it this way"
+        assert any(b <= v < e for b, e in c["bins"][index_bin]), (r["name"], index_bin)
+        for w in {r["pos"] >> 14, (r["pos"] + max(span, 1) - 1) >> 14}:
+            windows[r["ref_id"]][w] = min(windows[r["ref_id"]].get(w, v), v)
+        counts[r["ref_id"]][1 if r["flag"] & 4 else 0] += 1
+    assert no_coordinate == unplaced
+    for k, c in enumerate(contigs):
+        for w, v in windows[k].items():
+            assert c["linear"][w] == v, (k, w)
+        if c["stats"] is None:
+            assert counts[k] == [0, 0] and not c["bins"]
+        else:
+            assert list(c["stats"][2:]) == counts[k]
+            assert c["stats"][0] == min(ch[0][0] for ch in c["bins"].values()) and c["stats"][1] == max(ch[-1][1] for ch in c["bins"].values())
+
+
+def bam_reg2bin(beg, end):
+    end -= 1
+    for shift, first in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        if beg >> shift == end >> shift:
+            return first + (beg >> shift)
+    return 0
+
+
+@pytest.mark.parametrize("level", [0, 1])
+def test_bam_index_matches_the_oracle_and_the_bai_semantics(level):
+    from test_bam import make_tiles
+    params, contigs, tiles = make_tiles(n_tiles=3, n_clusters=1500)
+    o = oracle_lib.load()
+    L = params.read_length[0]
+    stream, n, unaligned = o.bam_records(tiles, [L, L])
+    cuts = bam.split_parts(stream, unaligned)
+    assert len(cuts) == len(contigs) + 1 and sum(c[1] for c in cuts) == len(stream)
+    header_bytes = 977
+    for order in ("back", "front"):
+        ordered = cuts if order == "back" else cuts[-1:] + cuts[:-1]
+        parts = [(off, size, bam.bgzf_compress(stream[off:off + size], level=level, n_threads=2)) for off, size in ordered]
+        got = bam.index(stream, parts, len(contigs), header_bytes)
+        assert got == o.bam_index(stream, parts, len(contigs), header_bytes)
+        check_index_semantics(got, stream, parts, len(contigs), header_bytes, L)
+    # a contig in several parts (the reference's bins are narrower than a contig), a contig without records, nothing at all
+    off, size = cuts[0]
+    half = 0
+    while half < size // 2:
+        half += 4 + int.from_bytes(stream[off + half:off + half + 4], "little")
+    split = [(off, half), (off + half, size - half)] + cuts[1:]
+    parts = [(a, b, bam.bgzf_compress(stream[a:a + b], level=level)) for a, b in split]
+    got = bam.index(stream, parts, len(contigs) + 2, header_bytes)
+    assert got == o.bam_index(stream, parts, len(contigs) + 2, header_bytes)
+    assert bam.parse_index(got)[0][-1] == dict(bins={}, stats=None, linear=[])
+    assert bam.index(b"", [], 2, 100) == o.bam_index(b"", [], 2, 100) == b"BAI\1" + (2).to_bytes(4, "little") + bytes(16) + bytes(8)
+    with pytest.raises(bam.BamError):
+        bam.index(stream, [(cuts[0][0], cuts[0][1], b"not bgzf at all")], len(contigs), 0)
+    with pytest.raises(bam.BamError):
+        bam.index(stream, [(o_, s, bam.bgzf_compress(stream[o_:o_ + s])) for o_, s in (cuts[1], cuts[0])], len(contigs), 0)       # out of contig order
+
+
+# ---- the whole program -----------------------------------------------------------------------------------------------------------------
+
+def write_fasta(path, names, contigs, rng):
+    """contigs with lower case stretches and IUPAC codes in the file; returns (per contig byte offset / size in the file, the contigs as
+    reference::loadContig reads them: upper case, everything that is not ACGT an N)"""
+    meta, loaded = [], []
+    with open(path, "wb") as f:
+        for name, c in zip(names, contigs):
+            text = bytearray(c)
+            for _ in range(5):
+                at = int(rng.integers(0, len(text) - 300))
+                text[at:at + 200] = bytes(text[at:at + 200]).lower()
+            for at in rng.integers(0, len(text), 12):
+                text[int(at)] = b"RYKMswbdhvn"[int(at) % 11]
+            f.write(b">" + name + b" test contig\n")
+            begin = f.tell()
+            for at in range(0, len(text), 60):
+                f.write(text[at:at + 60] + b"\n")
+            meta.append((begin, f.tell() - begin))
+            loaded.append(bytes(b if b in b"ACGT" else ord("N") for b in bytes(text).upper()))
+    return meta, loaded
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compressed", [False, True])
+def test_gpu_isaac_align_end_to_end(tmp_path, compressed):
+    import torch
+    o = oracle_lib.load()
+    rng = np.random.default_rng(17)
+    file_length, L, at_a_time = 101, 100, 4000                             # --use-bases-mask default: y*n, the last cycle of a read is not used
+    genome = synth.make_genome(300000, seed=61, n_contigs=3)
+    names = [b"chrA", b"chrB", b"chrC"]
+    ref_dir = tmp_path / "ref"
+    ref_dir.mkdir()
+    fasta = str(ref_dir / "genome.fa")
+    meta, stored = write_fasta(fasta, names, [bytes(c.numpy()) for c in genome], rng)
+    params = options.default_params(L, L)
+    karyotype = [2, 0, 1]                                                    # stored contig i is the karyotype[i]-th of the karyotype
+    a = gpu.Aligner(params, 0, stored)
+    a.build_index()
+    contig_meta, position = [], 0
+    for i, c in enumerate(stored):
+        m = sr.Contig()
+        m.genomic_position, m.index, m.karyotype_index, m.name, m.file = position, i, karyotype[i], names[i], fasta.encode()
+        m.offset, m.size, m.total_bases, m.acgt_bases = meta[i][0], meta[i][1], len(c), sum(c.count(b) for b in b"ACGT")
+        if i == 1:
+            m.bam_sq_as, m.bam_sq_ur, m.bam_m5 = b"testAssembly", b"http://example.org/chrB.fa", b"0123456789abcdef0123456789abcdef"
+        position += len(c)
+        contig_meta.append(m)
+    a.save_sorted_reference(str(ref_dir), "genome.fa", contig_meta)
+    xml = str(ref_dir / "sorted-reference.xml")
+    ordered = [None] * 3
+    for i, k in enumerate(karyotype):
+        ordered[k] = i
+    contigs = [stored[i] for i in ordered]                                   # karyotype order: the order of contig ids in records and of the header
+    del a
+    # two lanes (1 and 3) of one flowcell; a tenth of the fragments of lane 1 sequenced twice
+    tensors = [torch.from_numpy(np.frombuffer(c, np.uint8).copy()) for c in contigs]
+    lanes = []
+    for lane, n_pairs, seed in ((1, 9000, 62), (3, 5000, 63)):
+        bcl = synth.make_read_pairs(tensors, n_pairs, file_length, seed=seed, indel_read_fraction=0.08, n_rate=0.002)[0].numpy()
+        if lane == 1:
+            bcl[8100:9000] = bcl[rng.integers(0, 8000, 900)]
+        lanes.append((lane, bcl))
+    calls = tmp_path / "calls"
+    calls.mkdir()
+    texts = {}
+    for lane, bcl in lanes:
+        for read in range(2):
+            text = synth.bcl_to_fastq(bcl, read * file_length, file_length, name="M7:15:FCTEST:%d" % lane, plus_header=bool(read))
+            texts[(lane, read)] = text
+            path = calls / ("lane%d_read%d.fastq%s" % (lane, read + 1, ".gz" if compressed else ""))
+            if compressed:
+                half = text.rfind(b"\n@", 0, len(text) // 2) + 1
+                path.write_bytes(gzip.compress(text[:half], 1) + gzip.compress(text[half:], 6))      # concatenated members
+            else:
+                path.write_bytes(text)
+    out = tmp_path / "Aligned"
+    args = ["-r", xml, "-b", str(calls), "--base-calls-format", "fastq-gz" if compressed else "fastq", "-o", str(out), "--clusters-at-a-time", str(at_a_time), "-j", "4",
+            "--bam-header-tag", "@CO\tend to end", "--description", "cli test", "-t", str(tmp_path / "Temp")]
+    r = run_host(*args)
+    assert r.returncode == 0, r.stderr
+    assert not (tmp_path / "Temp").exists()
+    # ---- the oracle on the same inputs
+    b = gpu.Aligner(params, 0, contigs)
+    b.load_sorted_reference(xml)
+    ref = o.reference(contigs)
+    ref.set_index(b.get_index())
+    del b
+    found, all_hits, index = [], np.zeros(3, np.uint8), 0
+    for lane_index, (lane, bcl) in enumerate(lanes):
+        o_lane = None
+        for read in range(2):
+            rc, o_lane, n, _, _ = o.fastq_to_bcl(texts[(lane, read)], L, bcl=o_lane, cluster_stride=2 * L, offset=read * L, max_clusters=len(bcl))
+            assert rc == 0 and n == len(bcl)
+        number = 1
+        for first in range(0, len(bcl), at_a_time):                          # loads of --clusters-at-a-time, each one tile
+            tile_bcl = o_lane[first:first + at_a_time]
+            om, hits = ref.find_matches(params, tile_bcl, len(tile_bcl), tile=index)
+            all_hits |= hits
+            found.append((lane_index, lane, number, index, tile_bcl, om))
+            number += 1; index += 1
+    host_tiles, tls_of_lane = [], {}
+    for lane_index, lane, number, index, tile_bcl, om in found:
+        tls = tls_of_lane.get(lane_index)
+        if tls is None or not tls.stable:
+            tls = tls_of_lane[lane_index] = ref.determine_tls(params, tile_bcl, om, all_hits, tile=index)
+        orec, ocig, _ = ref.select(params, tile_bcl, om, tls, all_hits, tile=index, n_clusters_hint=len(tile_bcl))
+        host_tiles.append((tile_bcl, orec, ocig, "FCTEST:%d:%d:" % (lane, number), str(lane_index), tls))
+    want, want_n, want_unaligned = o.bam_records(host_tiles, [L, L], forced_dodgy_alignment_score=0, mark_duplicates=True, keep_duplicates=True, realign_gaps=True, reference=ref)
+    recs = bam.parse_records(want)
+    assert sum(1 for x in recs if x["flag"] & 0x400) > 500 and sum(1 for x in recs if "OC" in x["tags"]) > 5 and {x["tags"]["RG"] for x in recs} == {"0", "1"}
+    sq = [(names[i].decode(), len(stored[i]), contig_meta[i].bam_sq_as.decode(), contig_meta[i].bam_sq_ur.decode() or fasta, contig_meta[i].bam_m5.decode()) for i in ordered]
+    header = o.bam_header(" ".join([host()] + args), "isaac_aligner_amd-0.3", sq, description="cli test",
+                          header_lines=["@CO\tend to end", "@RG\tID:0\tPL:ILLUMINA\tSM:default\tPU:FCTEST:1:none", "@RG\tID:1\tPL:ILLUMINA\tSM:default\tPU:FCTEST:3:none"])
+    # ---- the files
+    path = out / "Projects" / "default" / "default" / "sorted.bam"
+    data = path.read_bytes()
+    blocks = bgzf_blocks(data)
+    raw = b"".join(x[2] for x in blocks)
+    assert raw[:len(header)] == header
+    assert raw[len(header):] == want
+    assert blocks[-1][1] == 28 and blocks[-1][2] == b""                      # bam::serializeBgzfFooter
+    assert gzip.decompress(data) == raw
+    # the bins of the file: the header, a BGZF run per contig, the unaligned records, the empty block
+    cuts = bam.split_parts(want, want_unaligned)
+    assert len(cuts) == 4
+    starts, at = {}, 0
+    for offset, size, block in blocks:
+        starts.setdefault(at, offset); at += len(block)
+    header_bgzf = starts[len(header)]
+    parts = []
+    for off, size in cuts:
+        begin, end = starts[len(header) + off], starts[len(header) + off + size] if len(header) + off + size in starts else blocks[-1][0]
+        parts.append((off, size, data[begin:end]))
+    assert sum(len(p[2]) for p in parts) + header_bgzf + 28 == len(data)
+    bai = (out / "Projects" / "default" / "default" / "sorted.bam.bai").read_bytes()
+    assert bai == o.bam_index(want, parts, 3, header_bgzf)
+    check_index_semantics(bai, want, parts, 3, header_bgzf, L)
