@@ -413,8 +413,8 @@ int isaac_gpu_parse_seeds(const char *descriptor, uint32_t first_pass_seeds, isa
 int isaac_gpu_get_counters(isaac_gpu_ctx *ctx, isaac_counters *out);
 /* average device time (ms) of the named launch sequence over the launches since the last reset, measured with HIP events on the
  * stream it runs on; names: "find_matches", "compact_matches", "build_fragments", "align_candidates", "finish_candidates",
- * "indel_fragments", "gapped_fragments", "finish_fragments", "load_candidates", "plan_rescue", "rescue_windows", "rescue_align",
- * "rescue_gapped_plan", "gapped_rescue", "sums_wave", "sums_large", "sums_xl", "sums_huge", "select", "select_heavy", "select_residual" (the last two
+ * "indel_fragments", "gapped_fragments" (k_gapped_jobs of the fragment stage) and "gapped_fragments_rescan", "finish_fragments", "load_candidates", "plan_rescue", "rescue_windows", "rescue_align",
+ * "rescue_gapped_plan", "gapped_rescue" / "gapped_rescue_rescan" (the same two kernels for the mate rescue), "sums_wave", "sums_large", "sums_xl", "sums_huge", "select", "select_heavy", "select_residual" (the last two
  * are launched for every chunk and read their cluster count on the device: a few microseconds when it is zero), "fastq_to_bcl", "bsw",
  * "bam_order", "bam_encode", "bgzf_store" */
 int isaac_gpu_kernel_time_ms(isaac_gpu_ctx *ctx, const char *kernel, double *avg_ms, uint64_t *launches);

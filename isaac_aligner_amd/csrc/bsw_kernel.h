@@ -1,11 +1,18 @@
 // Wavefront form of alignment::BandedSmithWaterman::align (lib/alignment/BandedSmithWaterman.cpp:84-462).
 //
-// 16 lanes per alignment (one lane per diagonal of the band, exactly the 16 int16 lanes of the reference's two SSE
-// registers), 4 alignments per wave64, 16 per 256-thread workgroup.  G/E/F live in registers; the F update and the database
-// window move between neighbouring lanes with width-16 wave shuffles; the serial 16-step E chain of the reference
-// (:246-297) becomes a 4-step max-plus suffix scan (E[k] = max_{j>k}(max(G'[j],F'[j]) - open - (j-k-1)*extend), which is what
-// the chain computes for in-range scores); the traceback flags (one byte per lane per row) are staged in LDS and walked by
-// lane 0 of the group.  Integer DP: no MFMA.
+// 8 lanes per alignment, two cells of the 16-wide band per lane: lane l holds cells 2l (low 16 bits) and 2l + 1 (high 16 bits) of G, E
+// and F in one register each, so that the row's arithmetic is packed int16 (v_pk_add / sub / max: the wrapping _mm_*_epi16 of the
+// reference, two cells an instruction) and the reference's "16-bit max over pairs of flag bytes" pairs the two halves of a register.
+// The two alignments of a 16-lane DPP row are interleaved (even lanes one, odd lanes the other): a shift by two lanes moves along one
+// alignment and never crosses into the other, and the row's ends behave as the band's ends.  8 alignments per wave64, 16 per 128-thread
+// workgroup.  A cell's left / right neighbour is the other half of the register or the neighbouring lane's: one DPP move and one
+// v_alignbit.  What a cell passes on -- the F it gives to the cell above it in the next row, the E-traceback flag of the cell below --
+// is computed where its inputs are and then moved, instead of moving the inputs.  The serial 16-step E chain of the reference
+// (:246-297) is an exclusive max-plus suffix scan (E[k] = max_{j>k}(max(G'[j],F'[j]) - open - (j-k-1)*extend)): both cells of a lane in
+// 32 bits (the chain's intermediate values are not wrapped), then three v_max_i32_dpp steps over the 8 lanes.  The traceback flags
+// (one byte per cell and row) are staged in LDS and walked by the group together.  Integer DP: no MFMA.
+// (Round 2's form had one cell per lane, 16 lanes per alignment, 32-bit arithmetic with a sign extension after every operation: ~75
+// issue slots per row for 4 alignments; this one ~80 for 8.)
 #pragma once
 #include "aligner.h"
 #include "../../include/isaac_gpu.h"
@@ -17,15 +24,34 @@ namespace isaac
 
 __device__ inline int s16(int v) { return int(short(v)); }
 
-// Lane exchange inside the 16-lane group of one alignment.  The group is one DPP row, so neighbour shifts are register
-// operations (row_shr / row_shl / quad_perm) instead of trips through the LDS crossbar (ds_bpermute).
-// (bound_ctrl: a lane whose source falls outside the row reads 0 -- every use below overrides that lane's result -- which leaves the move
-// without an `old` operand to copy first)
-template <int CTRL> __device__ inline int dpp16(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
-// lane k <- lane k + 1, the last lane of the row <- `outside` (a lane without a source keeps the `old` operand of the DPP move).
-// Written as `last ? outside : rowDown<1>(v)` the exchange would sit in the untaken arm of a branch for lane 15 -- and lane 14, reading a
-// lane that is switched off, would keep its own value.
-// s = max(s, s of lane k + N) in one instruction: the DPP operand of v_max itself (the compiler emits v_mov, v_mov_dpp, v_max and the
+typedef short S2 __attribute__((ext_vector_type(2)));
+typedef unsigned short U2 __attribute__((ext_vector_type(2)));
+__device__ inline S2 asS2(int v) { return __builtin_bit_cast(S2, v); }
+__device__ inline S2 asS2(U2 v) { return __builtin_bit_cast(S2, v); }
+__device__ inline U2 asU2(int v) { return __builtin_bit_cast(U2, v); }
+__device__ inline int asInt(S2 v) { return __builtin_bit_cast(int, v); }
+__device__ inline int asInt(U2 v) { return __builtin_bit_cast(int, v); }
+__device__ inline S2 pkMax(S2 a, S2 b) { return __builtin_elementwise_max(a, b); }
+__device__ inline U2 pkMaxU(U2 a, U2 b) { return __builtin_elementwise_max(a, b); }
+__device__ inline U2 pkMinU(U2 a, U2 b) { return __builtin_elementwise_min(a, b); }
+// 1 where a < b, per half: the sign of the saturated difference (a plain difference wraps)
+__device__ inline U2 pkLt(S2 a, S2 b) { return __builtin_bit_cast(U2, __builtin_elementwise_sub_sat(a, b)) >> 15; }
+__device__ inline int both(int v) { return int((u32(v) & 0xffffu) | (u32(v) << 16)); }
+// (mask & a) | (~mask & b): v_bfi_b32
+__device__ inline int bfi(int mask, int a, int b) { return (mask & a) | (~mask & b); }
+// keeps a packed 0 / 1 flag pair a value of its own: the optimiser otherwise turns arithmetic on it back into a compare and a select per half
+__device__ inline U2 opaque(U2 v) { int x = asInt(v); asm("" : "+v"(x)); return asU2(x); }
+// 1 where the half is not zero (min(x, 1), which the optimiser would rewrite as a compare and a select per half)
+__device__ inline U2 pkNonZero(int x, int ones) { int r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(ones)); return asU2(r); }
+
+// Lane exchange along one alignment: its lanes are every second lane of a DPP row.  A lane without a source (the row's end) keeps `old`.
+__device__ inline int fromLaneBelow(int v, int old) { return __builtin_amdgcn_update_dpp(old, v, 0x112, 0xf, 0xf, false); }    // lane l <- lane l - 1 (row_shr:2)
+__device__ inline int fromLaneAbove(int v, int old) { return __builtin_amdgcn_update_dpp(old, v, 0x102, 0xf, 0xf, false); }    // lane l <- lane l + 1 (row_shl:2)
+// every cell takes the value of the cell below it (k - 1); cell 0 takes the low half of `first`
+__device__ inline int fromCellBelow(int v, int first) { return int(__builtin_amdgcn_alignbit(u32(v), u32(fromLaneBelow(v, int(u32(first) << 16))), 16)); }
+// every cell takes the value of the cell above it (k + 1); cell 15 takes the low half of `last`
+__device__ inline int fromCellAbove(int v, int last) { return int(__builtin_amdgcn_alignbit(u32(fromLaneAbove(v, last)), u32(v), 16)); }
+// s = max(s, s of lane l + N / 2) in one instruction: the DPP operand of v_max itself (the compiler emits v_mov, v_mov_dpp, v_max and the
 // wait states between them).  Lanes without a source keep s.  The wait states a DPP read needs after a vector write are in the string:
 // inline assembly is opaque to the hazard recogniser.
 template <int N> __device__ inline int maxRowDown(int s)
@@ -34,31 +60,35 @@ template <int N> __device__ inline int maxRowDown(int s)
     asm("s_nop 1\n\tv_max_i32_dpp %0, %1, %1 row_shl:%2 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(s), "n"(N));
     return r;
 }
-__device__ inline int rowDown1Or(int v, int outside) { return __builtin_amdgcn_update_dpp(outside, v, 0x101, 0xf, 0xf, false); }
-__device__ inline int rowUp1(int v) { return dpp16<0x111>(v); }          // lane k <- lane k - 1   (row_shr:1)
-__device__ inline int rowXor1(int v) { return dpp16<0xB1>(v); }          // lane k <- lane k ^ 1   (quad_perm [1,0,3,2])
-template <int N> __device__ inline int rowDown(int v) { return dpp16<0x100 + N>(v); }   // lane k <- lane k + N (row_shl:N)
 
 // LDS bytes per alignment group
 // bswGroupLdsBytes / gappedGroupLdsBytes: kernels.h (the host sizes the launches with them)
 
-// The DP of one alignment on the 16 lanes of a group, then traceback and CIGAR on lane 0.  `cig[n..)` receives the operations
-// (reference order); the return value (lane 0 only) is BandedSmithWaterman::align's: the length of the stripped leading
-// deletion.  T: L*16 bytes of LDS, endVals: 48 shorts of LDS, both private to the group.  The 16 lanes are part of one
+// which alignment group of its workgroup a thread belongs to, and which of the group's 8 lanes it is
+__device__ inline u32 bswGroupOfThread() { return ((threadIdx.x >> 4) << 1) | (threadIdx.x & 1u); }
+__device__ inline u32 bswLaneOfThread() { return (threadIdx.x & 15u) >> 1; }
+static const u32 BSW_GROUP_LANES = 8;
+
+// The DP of one alignment on the 8 lanes of a group, then traceback and CIGAR (the group walks together, lane 0 stores).  `cig[n..)`
+// receives the operations (reference order); the return value is BandedSmithWaterman::align's: the length of the stripped leading
+// deletion.  T: L*16 bytes of LDS, endVals: 48 shorts of LDS, both private to the group.  The 8 lanes are part of one
 // wave, so LDS traffic between them needs no workgroup barrier.
 // PADDED: query[L] and database[L + 16] may be read (staged copies with room behind them): the look-ahead then needs no clamping
 template <bool PADDED = false, typename QueryF>
 __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapOpenScore, int gapExtendScore, QueryF query, u32 L, const char *database,
-                                     u8 *T, short *endVals, u32 k, u32 *cig, u32 cap, u32 &n, bool &overflow)
+                                     u8 *T, short *endVals, u32 l, u32 *cig, u32 cap, u32 &n, bool &overflow)
 {
     STAMP_BEGIN();
     const int initialValue = s16(-32768 + gapOpenScore);
-    const int open = gapOpenScore, ext = gapExtendScore;
-    const int wMatch = matchScore & 0xff, wMismatch = s16(0xff00 | (mismatchScore & 0xff));
-    int G = (k == 0) ? 0 : initialValue, E = initialValue, F = 0;
-    const bool first = k == 0, last = k == 15, odd = (k & 1) != 0;
-    const int kExt = int(k) * ext, k1Ext = int(k + 1) * ext;
-    int d = u8(database[15 - k]);                   // lane k of row i looks at database[i + 15 - k]
+    const S2 open2 = asS2(both(gapOpenScore)), ext2 = asS2(both(gapExtendScore));
+    const U2 wMatch2 = asU2(both(matchScore & 0xff)), wDiff2 = asU2(both((0xff00 | (mismatchScore & 0xff)) - (matchScore & 0xff)));
+    const int init2 = both(initialValue), ones2 = 0x00010001;
+    int G = (l == 0) ? int(u32(initialValue) << 16) : init2, E = init2, F = 0;                 // cell 0 starts at 0 (:110-113)
+    const bool lastLane = l == 7;
+    const int ext = gapExtendScore;
+    const int kExtLo = int(2 * l) * ext, kExtHi = int(2 * l + 1) * ext, k1ExtHi = int(2 * l + 2) * ext;        // k1Ext of the low cell = kExtHi
+    int d2 = int(u8(database[15 - 2 * l])) | (int(u8(database[14 - 2 * l])) << 16);            // cell k of row i looks at database[i + 15 - k]
+    u16 *Trow = reinterpret_cast<u16 *>(T) + l;
     // the next row's query base and the database base that enters the band with it are requested a row ahead (every lane reads the same
     // bytes: one broadcast access, no branch), so that their latency lies behind the row's arithmetic
     int qNext = u8(query(0)), dNext = u8(database[L > 1 ? 16 : 15]);
@@ -72,76 +102,82 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
             qNext = u8(query(ahead));
             dNext = u8(database[ahead + 1 < L ? ahead + 16 : ahead + 15]);
         }
-        // F: lane k from lane k-1 of the previous row (:130-173)
-        const int gp = rowUp1(G), ep = rowUp1(E), fp = rowUp1(F);
-        const int v = s16(max(gp, ep) - open), fe = s16(fp - ext);
-        int tf = (v < fe) ? 2 : ((gp < ep) ? 1 : 0);
-        int newF = max(v, fe);
-        newF = first ? initialValue : newF; tf = first ? 0 : tf;
-        // G (:174-197) with the 16-bit max over byte pairs of the flag vectors
-        const int fE = (G < E) ? 1 : 0;
-        const int m = max(G, E);
-        const int fF = (m < F) ? 1 : 0;
-        int newG = max(m, F);
-        const int pfE = rowXor1(fE), pfF = rowXor1(fF);
-        const int tgOdd = fF ? 2 : fE;
-        const int tgEven = pfF ? 2 * fF : (pfE ? fE : max(2 * fF, fE));
-        const int tg = odd ? tgOdd : tgEven;
+        const S2 Gv = asS2(G), Ev = asS2(E), Fv = asS2(F);
+        // F (:130-173): what cell k hands to cell k + 1 of this row -- max(G - open, E - open, F - extend) and where it came from --
+        // computed in place and moved up one cell; cell 0 gets the initial value
+        const S2 m = pkMax(Gv, Ev);
+        const U2 fE = pkLt(Gv, Ev);
+        const S2 v = m - open2, fe = Fv - ext2;
+        const int newF = fromCellBelow(asInt(pkMax(v, fe)), initialValue);
+        const int tf = fromCellBelow(asInt(pkMaxU(pkLt(v, fe) << 1, fE)), 0);            // v < fe ? 2 : (G < E ? 1 : 0)
+        // G (:174-197) with the 16-bit max over byte pairs of the flag vectors: an odd cell takes fF ? 2 : fE, an even cell looks at its
+        // odd partner's flags first (the other half of the register)
+        const U2 fF = pkLt(m, Fv);
+        const S2 gmax = pkMax(m, Fv);
+        const U2 twoF = fF << 1;
+        const int mx = asInt(pkMaxU(twoF, fE));
+        const int negPartnerF = -int(u32(asInt(fF)) >> 16), negPartnerE = -int(u32(asInt(fE)) >> 16);
+        const int even = bfi(negPartnerF, asInt(twoF), bfi(negPartnerE, asInt(fE), mx));   // pfF ? 2 fF : (pfE ? fE : max(2 fF, fE))
+        const int tg = bfi(0xffff, even, mx);
         // W (:200-244): byte compare, so read 'n' never equals reference 'N'
-        newG = s16(newG + ((q != d) ? wMismatch : wMatch));
-        // E (:246-297) as an exclusive max-plus suffix scan over the lanes.  A lane whose source lies outside the row gets its own value
-        // back from the row shift, and max(s, s) = s: only the first step needs to know where the row ends
-        const int g = s16(newG - open), f = s16(newF - open);
+        const U2 differs = pkNonZero(both(q) ^ d2, ones2);
+        const S2 newG = gmax + asS2(differs * wDiff2 + wMatch2);
+        // E (:246-297) as an exclusive max-plus suffix scan over the cells: the two cells of a lane in 32 bits, then the lanes.  A lane
+        // whose source lies outside the row gets its own value back from the row shift, and max(s, s) = s: only the first step needs to
+        // know where the row ends
+        const S2 g = newG - open2, f = asS2(newF) - open2;
+        const int gf = asInt(pkMax(g, f));
         const int NEG = -(1 << 28);
-        const int c = max(g, f) - kExt;
-        int s = rowDown1Or(c, NEG);
-        s = maxRowDown<1>(s);
+        const int cLo = s16(gf) - kExtLo, cHi = (gf >> 16) - kExtHi;
+        int s = fromLaneAbove(max(cLo, cHi), NEG);
         s = maxRowDown<2>(s);
         s = maxRowDown<4>(s);
         s = maxRowDown<8>(s);
-        const int newE = last ? initialValue : s16(s + k1Ext);
-        // TE from lane k+1's (g, E - ext, f) with the reference's tie rules
-        const int g1 = rowDown<1>(g), f1 = rowDown<1>(f), e1 = s16(rowDown<1>(newE) - ext);
-        int te = (e1 > g1 && e1 > f1) ? 1 : ((f1 > g1) ? 2 : 0);
-        te = last ? 0 : te;
-        T[i * 16 + k] = u8(tg | (te << 2) | (tf << 4));
-        G = newG; E = newE; F = newF;
-        // slide the database window: lane k takes lane k-1's base, lane 0 the next one (what it takes in the last row is not looked at)
-        const int dn = rowUp1(d);
-        d = first ? dIn : dn;
+        const int eLo = max(cHi, s) + kExtHi, eHi = lastLane ? initialValue : s + k1ExtHi;
+        const int newE = int((u32(eLo) & 0xffffu) | (u32(eHi) << 16));
+        // TE: what cell k + 1 tells cell k -- from its (g, E - ext, f) with the reference's tie rules -- moved down one cell; cell 15 gets 0
+        const S2 e1 = asS2(newE) - ext2;
+        const U2 fromE = opaque(pkLt(g, e1) & pkLt(f, e1));
+        const int teOut = bfi(asInt(-asS2(fromE)) /* per half: all ones where the flag is set */, 0x00010001, asInt(pkLt(g, f) << 1));
+        const int te = fromCellAbove(teOut, 0);
+        const int flags = tg | (te << 2) | (tf << 4);
+        Trow[i * 8] = u16((flags & 0xff) | ((flags >> 8) & 0xff00));
+        G = asInt(newG); E = newE; F = newF;
+        // slide the database window: cell k takes cell k - 1's base, cell 0 the next one (what it takes in the last row is not looked at)
+        d2 = fromCellBelow(d2, dIn);
     }
-    endVals[k] = short(G); endVals[16 + k] = short(E); endVals[32 + k] = short(F);
+    reinterpret_cast<int *>(endVals)[l] = G; reinterpret_cast<int *>(endVals)[8 + l] = E; reinterpret_cast<int *>(endVals)[16 + l] = F;
     STAMP(55);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     u32 ret = 0;
     {
-        // end-cell scan (:349-379), traceback (:381-435), stripping of the terminal deletions (:437-453).  All 16 lanes of the group
+        // end-cell scan (:349-379), traceback (:381-435), stripping of the terminal deletions (:437-453).  All 8 lanes of the group
         // walk the traceback together (the same values in every lane; lane 0 does the stores): a stretch of ALIGN cells whose flags
-        // say "came from ALIGN" -- nearly all of a typical alignment -- is crossed 16 rows at a time, every lane looking at one row,
+        // say "came from ALIGN" -- nearly all of a typical alignment -- is crossed 8 rows at a time, every lane looking at one row,
         // instead of one dependent LDS read per row.
         const u32 first = n;
         int mx = s16(int(u16(endVals[15])) - 1);
         int ii = int(L) - 1, jj = ii; u32 maxType = 0;
-        for (int lane = 15; lane >= 0; --lane)
+        for (int cell = 15; cell >= 0; --cell)
             for (u32 type = 0; type < 3; ++type)
             {
-                const int value = endVals[16 * type + lane];
-                if (value > mx) { mx = value; jj = lane; maxType = type; }
+                const int value = endVals[16 * type + cell];
+                if (value > mx) { mx = value; jj = cell; maxType = type; }
             }
         u32 opLength = 0, firstOp = 0, lastOp = 0;
-        const u32 groupShift = (threadIdx.x & 63u) & ~15u;
-#define ISAAC_BSW_PUSH(len, op) do { if (n < cap) { lastOp = cigarOp(u32(len), op); if (n == first) firstOp = lastOp; if (k == 0) cig[n] = lastOp; ++n; } else overflow = true; } while (0)
+        const u32 groupShift = ((threadIdx.x & 63u) & ~15u) | (threadIdx.x & 1u);      // the group's lanes: every second bit from here
+#define ISAAC_BSW_PUSH(len, op) do { if (n < cap) { lastOp = cigarOp(u32(len), op); if (n == first) firstOp = lastOp; if (l == 0) cig[n] = lastOp; ++n; } else overflow = true; } while (0)
         if (jj > 0) ISAAC_BSW_PUSH(jj, OP_DELETE);
         while (ii >= 0 && jj >= 0 && jj <= 15)
         {
             if (0 == maxType)
             {
-                const int row = ii - int(k);
+                const int row = ii - int(l);
                 const bool stop = row < 0 || 0 != (T[row * 16 + jj] & 3);
-                const u32 mask = u32(__ballot(stop) >> groupShift) & 0xffffu;
-                const u32 run = mask ? u32(__ffs(int(mask))) - 1 : 16u;
+                const u32 mask = u32(__ballot(stop) >> groupShift) & 0x5555u;
+                const u32 run = mask ? (u32(__ffs(int(mask))) - 1) >> 1 : 8u;
                 opLength += run; ii -= int(run);
                 if (!mask) continue;
                 if (ii < 0) break;
@@ -158,7 +194,7 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
 #undef ISAAC_BSW_PUSH
         // the operations were pushed back to front: the last one is the alignment's leading deletion, the first one its trailing one
         if (n > first && OP_DELETE == cigarCode(lastOp)) { ret = cigarLen(lastOp); --n; }
-        if (k == 0) for (u32 lo = first, hi = n; lo + 1 < hi; ++lo) { --hi; const u32 tt = cig[lo]; cig[lo] = cig[hi]; cig[hi] = tt; }
+        if (l == 0) for (u32 lo = first, hi = n; lo + 1 < hi; ++lo) { --hi; const u32 tt = cig[lo]; cig[lo] = cig[hi]; cig[hi] = tt; }
         if (n > first && OP_DELETE == cigarCode(firstOp)) --n;
     }
     STAMP(56);
@@ -169,13 +205,13 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
 
 struct PlainQuery { const char *q; __device__ char operator()(u32 i) const { return q[i]; } };
 
-__global__ __launch_bounds__(256) void k_bsw_batch(int matchScore, int mismatchScore, int gapOpenScore, int gapExtendScore,
+__global__ __launch_bounds__(128) void k_bsw_batch(int matchScore, int mismatchScore, int gapOpenScore, int gapExtendScore,
                                                   const char *sequences, const isaac_bsw_job *jobs, u32 nJobs, u32 maxQueryLength,
                                                   isaac_bsw_result *results)
 {
     extern __shared__ __align__(16) u8 lds[];
-    const u32 group = threadIdx.x >> 4, k = threadIdx.x & 15;
-    const u32 job = blockIdx.x * 16 + group;
+    const u32 group = bswGroupOfThread(), k = bswLaneOfThread();
+    const u32 job = blockIdx.x * (blockDim.x / BSW_GROUP_LANES) + group;
     if (job >= nJobs) return;
     u8 *T = lds + group * bswGroupLdsBytes(maxQueryLength);
     short *endVals = reinterpret_cast<short *>(T + ((maxQueryLength * 16 + 15) & ~15u));
@@ -190,10 +226,10 @@ __global__ __launch_bounds__(256) void k_bsw_batch(int matchScore, int mismatchS
 
 struct StrandQueryDev { ReadView read; bool reverse; u32 offset; __device__ char operator()(u32 i) const { return strandBase(read, reverse, offset + i); } };
 
-// GappedAligner::alignGapped (GappedAligner.cpp:167-249) for a list of candidates, 16 lanes per candidate: the statements of
+// GappedAligner::alignGapped (GappedAligner.cpp:167-249) for a list of candidates, 8 lanes per candidate: the statements of
 // alignGapped() in aligner.h with the DP on the group and everything else on its lane 0.  `bcl` is the tile, the job's
 // cluster index is relative to clusterBase.  Grid-stride over the jobs, so the launch does not need the job count on the host.
-__global__ __launch_bounds__(256) void k_gapped_jobs(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap,
+__global__ __launch_bounds__(128) void k_gapped_jobs(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap,
                                                     u32 maxReadLength, GappedResult *results)
 {
     extern __shared__ __align__(16) u8 lds[];
@@ -201,13 +237,13 @@ __global__ __launch_bounds__(256) void k_gapped_jobs(DevParams P, DevReference R
     for (u32 qi = threadIdx.x; qi < 128; qi += blockDim.x) qualityTables[qi] = qi < 64 ? Rg.logMatch[qi] : Rg.logMismatch[qi - 64];
     __syncthreads();
     DevReference R = Rg; R.logMatch = qualityTables; R.logMismatch = qualityTables + 64;
-    const u32 group = threadIdx.x >> 4, k = threadIdx.x & 15;
+    const u32 group = bswGroupOfThread(), k = bswLaneOfThread(), groups = blockDim.x / BSW_GROUP_LANES;
     u8 *T = lds + group * gappedGroupLdsBytes(maxReadLength);
     short *endVals = reinterpret_cast<short *>(T + ((maxReadLength * 16 + 15) & ~15u));
     char *stagedQuery = reinterpret_cast<char *>(T + bswGroupLdsBytes(maxReadLength));
     char *stagedDatabase = stagedQuery + ((maxReadLength + 31) & ~15u);
     const u32 nJobs = imin(*jobCounter, jobsCap);
-    for (u32 j = blockIdx.x * 16 + group; j < nJobs; j += gridDim.x * 16)
+    for (u32 j = blockIdx.x * groups + group; j < nJobs; j += gridDim.x * groups)
     {
         STAMP_BEGIN();
         const GappedJob &jb = jobs[j];
@@ -240,8 +276,8 @@ __global__ __launch_bounds__(256) void k_gapped_jobs(DevParams P, DevReference R
             const char *database = R.bases + R.contigOffset[f.contigId] + strandPosition - left;
             STAMP(50);
             // the group's 16 lanes bring the query and the window into LDS side by side; the DP rows then read one byte of each
-            for (u32 i = k; i < sequenceLength; i += 16) stagedQuery[i] = strandBase(read, f.reverse, u32(begin) + i);
-            for (u32 i = k; i < sequenceLength + 16; i += 16) stagedDatabase[i] = (i < sequenceLength + 15) ? database[i] : char(0);
+            for (u32 i = k; i < sequenceLength; i += BSW_GROUP_LANES) stagedQuery[i] = strandBase(read, f.reverse, u32(begin) + i);
+            for (u32 i = k; i < sequenceLength + 16; i += BSW_GROUP_LANES) stagedDatabase[i] = (i < sequenceLength + 15) ? database[i] : char(0);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

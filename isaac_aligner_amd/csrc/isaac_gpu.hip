@@ -976,13 +976,17 @@ static GappedBuffers gappedBuffers(isaac_gpu_ctx *c, u32 which)
     return gb;
 }
 
-static void launchGappedJobs(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clusterBase, const GappedBuffers &gb, const char *timer)
+// timer: k_gapped_jobs alone (so that the figure can be set against that kernel's duration in a rocprofv3 trace); rescanTimer: k_gapped_rescan
+static void launchGappedJobs(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clusterBase, const GappedBuffers &gb, const char *timer, const char *rescanTimer)
 {
     const u32 maxReadLength = std::max(c->P.readLength[0], c->P.nReads > 1 ? c->P.readLength[1] : 0u);
     const size_t lds = size_t(16) * gappedGroupLdsBytes(maxReadLength);
-    ScopedTimer t(c, timer);
-    k_gapped_jobs<<<1024, 256, lds, c->stream>>>(c->P, c->ref(), bcl, clusterBase, gb.jobs, gb.counter, gb.cap, maxReadLength, gb.results);
+    {
+        ScopedTimer t(c, timer);
+        k_gapped_jobs<<<4096, 128, lds, c->stream>>>(c->P, c->ref(), bcl, clusterBase, gb.jobs, gb.counter, gb.cap, maxReadLength, gb.results);
+    }
     HIP_CHECK(hipGetLastError());
+    ScopedTimer t(c, rescanTimer);
     k_gapped_rescan<<<1024, 256, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, gb.jobs, gb.counter, gb.cap, gb.results);
     HIP_CHECK(hipGetLastError());
 }
@@ -1039,7 +1043,7 @@ static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clust
         k_indel_fragments<<<8192, 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, withGaps, c->indelList.p, c->gappedCounters.p + 2, c->fragWork.p, c->pools, gb, c->counters.p);
         HIP_CHECK(hipGetLastError());
     }
-    if (withGaps) launchGappedJobs(c, bcl, clusterBase, gb, "gapped_fragments");
+    if (withGaps) launchGappedJobs(c, bcl, clusterBase, gb, "gapped_fragments", "gapped_fragments_rescan");
     {
         ScopedTimer t(c, "finish_fragments");
         k_finish_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, withGaps, c->fragWork.p, c->pools, gb, c->counters.p);
@@ -1212,7 +1216,7 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
             k_rescue_gapped_plan_long<<<2048, 256, 0, st>>>(c->pools, rb, gbRescue, c->longJobs.p, c->rescueCounters.p + 2);
             HIP_CHECK(hipGetLastError());
         }
-        launchGappedJobs(c, bcl, done, gbRescue, "gapped_rescue");
+        launchGappedJobs(c, bcl, done, gbRescue, "gapped_rescue", "gapped_rescue_rescan");
         {
             ScopedTimer tm(c, "sums_wave");
             k_cluster_sums16<<<gridFor(n, 16), 256, 0, st>>>(c->P, c->pools, n, rb, gbRescue, sb, c->counters.p);
@@ -1541,7 +1545,7 @@ int isaac_gpu_bsw_batch(isaac_gpu_ctx *c, int match, int mismatch, int gapOpen, 
     if (int(maxQueryLength) * maxScore >= std::abs(-32768 + gapOpen)) return fail(ISAAC_GPU_EINVAL, "BandedSmithWaterman: unsupported read length for these scores");
     const size_t lds = size_t(16) * bswGroupLdsBytes(maxQueryLength);
     ScopedTimer t(c, "bsw");
-    k_bsw_batch<<<gridFor(nJobs, 16), 256, lds, c->stream>>>(match, mismatch, gapOpen, gapExtend, sequences, jobs, nJobs, maxQueryLength, results);
+    k_bsw_batch<<<gridFor(nJobs, 16), 128, lds, c->stream>>>(match, mismatch, gapOpen, gapExtend, sequences, jobs, nJobs, maxQueryLength, results);
     HIP_CHECK(hipGetLastError());
     return 0;
     ISAAC_CATCH

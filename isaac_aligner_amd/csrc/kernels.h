@@ -71,7 +71,7 @@ struct AlignList { u32 *entries; u32 cap; u32 *counter; };
 //   k_select_heavy        one wave per predicted cluster, on its own stream next to k_select
 static const u32 KMER_EMPTY = 0xffffffffu;
 static const u32 RW_TABLE = 512;          // hash slots for the mate's <= 250-odd 7-mers
-static const u32 RW_PRESENT_WORDS = 512;  // one bit per possible 7-mer: does the mate have it?
+static const u32 RW_PRESENT_WORDS = 1024; // a byte per six bases: which 7-mers that begin or end with them does the mate have? (kernels_rescue.hip)
 static const u32 RW_LDS_BITMAP = 64;      // words: windows up to ~1900 bases keep their candidate bitmap in LDS
 #ifndef ISAAC_RW_PER_LANE
 #define ISAAC_RW_PER_LANE 8
@@ -109,7 +109,13 @@ static const u32 HEAVY_SORT_LDS = 32768;   // u16 indices: heavyCaps().prob / .p
 // LDS bytes of one 16-lane banded Smith-Waterman group (bsw_kernel.h)
 __host__ __device__ inline u32 bswGroupLdsBytes(u32 maxQueryLength) { return ((maxQueryLength * 16 + 15) & ~15u) + 128; }
 // k_gapped_jobs also keeps the query and the database window of the group there (the DP loop then reads LDS, not global memory)
-__host__ __device__ inline u32 gappedGroupLdsBytes(u32 maxQueryLength) { return bswGroupLdsBytes(maxQueryLength) + 2 * ((maxQueryLength + 31) & ~15u); }
+// (the eight groups of a wave touch their areas at the same offsets in the same instruction: a stride of 16 bytes modulo 128 spreads them
+// over all LDS banks)
+__host__ __device__ inline u32 gappedGroupLdsBytes(u32 maxQueryLength)
+{
+    const u32 bytes = bswGroupLdsBytes(maxQueryLength) + 2 * ((maxQueryLength + 31) & ~15u);
+    return bytes + ((16u + 128u - (bytes & 127u)) & 127u);
+}
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_build_fragments(DevParams P, const u8 *bcl, u32 clusterBase, u32 nChunk, const Match *matches, const u64 *offsets, int trim, FragmentWork *work, ClusterPools pools, AlignList al);
 __global__ __launch_bounds__(256) void k_align_candidates(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, ClusterPools pools, AlignList al, Counters *counters);
@@ -131,6 +137,6 @@ __global__ __launch_bounds__(64) void k_select_heavy(DevParams P, DevReference R
 namespace isaac
 {
 __global__ __launch_bounds__(256) void k_bsw_batch(int matchScore, int mismatchScore, int gapOpenScore, int gapExtendScore, const char *sequences, const isaac_bsw_job *jobs, u32 nJobs, u32 maxQueryLength, isaac_bsw_result *results);
-__global__ __launch_bounds__(256) void k_gapped_jobs(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap, u32 maxReadLength, GappedResult *results);
+__global__ __launch_bounds__(128) void k_gapped_jobs(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap, u32 maxReadLength, GappedResult *results);
 __global__ __launch_bounds__(256) void k_gapped_rescan(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap, GappedResult *results);
 }

@@ -16,6 +16,7 @@ def main():
     out = sys.argv[1]
     kernels = collections.defaultdict(lambda: {"launches": 0})
     workload = None
+    gapped_order = {}
     for arg in sys.argv[2:]:
         name, path = arg.split("=", 1)
         if name == "workload":
@@ -28,13 +29,20 @@ def main():
             m = re.search(r"(k_\w+)", r["Kernel_Name"])
             if not m:
                 continue
-            k = kernels[m.group(1)]
-            k[r["Counter_Name"]] = k.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-            key = (path, r["Dispatch_Id"])
-            if key not in seen:
-                seen.add(key)
-                k.setdefault("_launches_" + path, 0)
-                k["_launches_" + path] += 1
+            names = [m.group(1)]
+            if m.group(1) == "k_gapped_jobs":
+                # launched twice per select call, for the fragment stage and then for the mate rescue: the dispatches alternate
+                order = gapped_order.setdefault(path, {})
+                stage = order.setdefault(r["Dispatch_Id"], len(order) % 2)
+                names.append("k_gapped_jobs:" + ("rescue" if stage else "fragments"))
+            for name in names:
+                k = kernels[name]
+                k[r["Counter_Name"]] = k.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                key = (path, name, r["Dispatch_Id"])
+                if key not in seen:
+                    seen.add(key)
+                    k.setdefault("_launches_" + path, 0)
+                    k["_launches_" + path] += 1
     res = {}
     for name, k in sorted(kernels.items()):
         launches = max(v for kk, v in k.items() if kk.startswith("_launches_"))

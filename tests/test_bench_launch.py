@@ -27,3 +27,24 @@ def test_bench_starts_its_own_ranks():
 def test_bench_refuses_a_world_size_mismatch():
     r = run(["--gpus", "4", "--launch-check"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "--gpus 4" in (r.stderr + r.stdout)
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_gpu_bench_rccl_path_gives_the_same_records():
+    """One rank through the whole multi-GPU path of bench.py (ISAAC_BENCH_FORCE_DIST=1: process group over RCCL, all-reduce of the contig
+    flags, broadcast of the template statistics, every step's records and CIGARs gathered behind the later steps) against the plain
+    one-GPU run on a small workload: the gathered step is the step that was computed, and both runs produce the same records."""
+    args = ["--gpus", "1", "--steps", "3", "--warmup", "1", "--pairs-per-step", "60000", "--genome-bases", "30000000", "--no-pcie-pass", "--no-bam-pass", "--cpu-sample-pairs", "20000"]
+    lines = []
+    for env in ({}, {"ISAAC_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29617", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"}):
+        r = run(args, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
+    plain, dist = lines
+    assert plain["parity_diffs"] == 0 and dist["parity_diffs"] == 0
+    assert "gather_identical" not in plain and dist["gather_identical"] is True
+    assert plain["records_sha1"] == dist["records_sha1"]
+    assert plain["n_gpus"] == dist["n_gpus"] == 1 and dist["value"] > 0

@@ -261,13 +261,28 @@ def test_gpu_isaac_align_end_to_end(tmp_path, compressed):
         ordered[k] = i
     contigs = [stored[i] for i in ordered]                                   # karyotype order: the order of contig ids in records and of the header
     del a
-    # two lanes (1 and 3) of one flowcell; a tenth of the fragments of lane 1 sequenced twice
-    tensors = [torch.from_numpy(np.frombuffer(c, np.uint8).copy()) for c in contigs]
+    # two lanes (1 and 3) of one flowcell, read from a sample that carries an indel every ~400 bases (reads that cross one near their end
+    # can borrow the gap from the reads that show it: work for the realigner); a tenth of the fragments of lane 1 sequenced twice
+    sample = []
+    for c in contigs:
+        seq = np.frombuffer(c, np.uint8)
+        pieces, at = [], 0
+        while at < len(seq):
+            step = int(rng.integers(250, 550))
+            pieces.append(seq[at:at + step]); at += step
+            if at >= len(seq):
+                break
+            n = int(rng.integers(1, 9))
+            if rng.random() < 0.5:
+                at += n
+            else:
+                pieces.append(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)])
+        sample.append(torch.from_numpy(np.concatenate(pieces)))
     lanes = []
-    for lane, n_pairs, seed in ((1, 9000, 62), (3, 5000, 63)):
-        bcl = synth.make_read_pairs(tensors, n_pairs, file_length, seed=seed, indel_read_fraction=0.08, n_rate=0.002)[0].numpy()
+    for lane, n_pairs, seed in ((1, 14000, 62), (3, 9000, 63)):
+        bcl = synth.make_read_pairs(sample, n_pairs, file_length, seed=seed, indel_read_fraction=0.01, n_rate=0.002)[0].numpy()
         if lane == 1:
-            bcl[8100:9000] = bcl[rng.integers(0, 8000, 900)]
+            bcl[12600:14000] = bcl[rng.integers(0, 12000, 1400)]
         lanes.append((lane, bcl))
     calls = tmp_path / "calls"
     calls.mkdir()
@@ -291,9 +306,15 @@ def test_gpu_isaac_align_end_to_end(tmp_path, compressed):
     # ---- the oracle on the same inputs
     b = gpu.Aligner(params, 0, contigs)
     b.load_sorted_reference(xml)
-    ref = o.reference(contigs)
-    ref.set_index(b.get_index())
+    table = b.get_index()                                                  # as stored in the mask files: contig ids are stored indexes (the lookup translates them)
     del b
+    position = table["position"].copy()
+    located = (position >> np.uint64(1)) != 0                              # not a TooManyMatch entry
+    stored_id = ((position[located] >> np.uint64(41)) - np.uint64(1)).astype(np.int64)
+    position[located] = (position[located] & np.uint64((1 << 41) - 1)) | ((np.array(karyotype, np.uint64)[stored_id] + np.uint64(1)) << np.uint64(41))
+    table["position"] = position
+    ref = o.reference(contigs)
+    ref.set_index(table)
     found, all_hits, index = [], np.zeros(3, np.uint8), 0
     for lane_index, (lane, bcl) in enumerate(lanes):
         o_lane = None
@@ -316,6 +337,9 @@ def test_gpu_isaac_align_end_to_end(tmp_path, compressed):
         host_tiles.append((tile_bcl, orec, ocig, "FCTEST:%d:%d:" % (lane, number), str(lane_index), tls))
     want, want_n, want_unaligned = o.bam_records(host_tiles, [L, L], forced_dodgy_alignment_score=0, mark_duplicates=True, keep_duplicates=True, realign_gaps=True, reference=ref)
     recs = bam.parse_records(want)
+    print("oracle: %d records, %d unmapped, %d with gaps in the CIGAR, %d realigned, tiles %s" % (
+        len(recs), sum(1 for x in recs if x["flag"] & 4), sum(1 for x in recs if any((int(w) & 15) in (1, 2) for w in x["cigar"])), sum(1 for x in recs if "OC" in x["tags"]),
+        [(t[3], t[5].astuple(), int((t[1]["gap_count"] > 0).sum())) for t in host_tiles]))
     assert sum(1 for x in recs if x["flag"] & 0x400) > 500 and sum(1 for x in recs if "OC" in x["tags"]) > 5 and {x["tags"]["RG"] for x in recs} == {"0", "1"}
     sq = [(names[i].decode(), len(stored[i]), contig_meta[i].bam_sq_as.decode(), contig_meta[i].bam_sq_ur.decode() or fasta, contig_meta[i].bam_m5.decode()) for i in ordered]
     header = o.bam_header(" ".join([host()] + args), "isaac_aligner_amd-0.3", sq, description="cli test",
