@@ -9,7 +9,7 @@
 // v_alignbit.  What a cell passes on -- the F it gives to the cell above it in the next row, the E-traceback flag of the cell below --
 // is computed where its inputs are and then moved, instead of moving the inputs.  The serial 16-step E chain of the reference
 // (:246-297) is an exclusive max-plus suffix scan (E[k] = max_{j>k}(max(G'[j],F'[j]) - open - (j-k-1)*extend)): both cells of a lane in
-// 32 bits (the chain's intermediate values are not wrapped), then three v_max_i32_dpp steps over the 8 lanes.  The traceback flags
+// 32 bits (the chain's intermediate values are not wrapped), then the maximum over the lanes above (seven DPP reads of one register).  The traceback flags
 // (one byte per cell and row) are staged in LDS and walked by the group together.  Integer DP: no MFMA.
 // (Round 2's form had one cell per lane, 16 lanes per alignment, 32-bit arithmetic with a sign extension after every operation: ~75
 // issue slots per row for 4 alignments; this one ~80 for 8.)
@@ -51,14 +51,14 @@ __device__ inline int fromLaneAbove(int v, int old) { return __builtin_amdgcn_up
 __device__ inline int fromCellBelow(int v, int first) { return int(__builtin_amdgcn_alignbit(u32(v), u32(fromLaneBelow(v, int(u32(first) << 16))), 16)); }
 // every cell takes the value of the cell above it (k + 1); cell 15 takes the low half of `last`
 __device__ inline int fromCellAbove(int v, int last) { return int(__builtin_amdgcn_alignbit(u32(fromLaneAbove(v, last)), u32(v), 16)); }
-// s = max(s, s of lane l + N / 2) in one instruction: the DPP operand of v_max itself (the compiler emits v_mov, v_mov_dpp, v_max and the
-// wait states between them).  Lanes without a source keep s.  The wait states a DPP read needs after a vector write are in the string:
-// inline assembly is opaque to the hazard recogniser.
-template <int N> __device__ inline int maxRowDown(int s)
+// v_max with the DPP operand in the instruction itself (the compiler emits v_mov, v_mov_dpp, v_max and the wait states between them).
+// Lanes without a source keep s.  Inline assembly is opaque to the hazard recogniser: the wait states a DPP read needs after a vector
+// write of the same register are the caller's business.
+// s = max(s, t of lane l + N / 2): the DPP operand is t, which was written long before, so these need no wait states between them.
+template <int N> __device__ inline int maxWithLaneAbove(int s, int t)
 {
-    int r = s;
-    asm("s_nop 1\n\tv_max_i32_dpp %0, %1, %1 row_shl:%2 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(s), "n"(N));
-    return r;
+    asm("v_max_i32_dpp %0, %1, %0 row_shl:%2 row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(t), "n"(N));
+    return s;
 }
 
 // LDS bytes per alignment group
@@ -71,7 +71,7 @@ static const u32 BSW_GROUP_LANES = 8;
 
 // The DP of one alignment on the 8 lanes of a group, then traceback and CIGAR (the group walks together, lane 0 stores).  `cig[n..)`
 // receives the operations (reference order); the return value is BandedSmithWaterman::align's: the length of the stripped leading
-// deletion.  T: L*16 bytes of LDS, endVals: 48 shorts of LDS, both private to the group.  The 8 lanes are part of one
+// deletion.  T: bswFlagBytes(L) bytes of LDS, endVals: 48 shorts of LDS, both private to the group.  The 8 lanes are part of one
 // wave, so LDS traffic between them needs no workgroup barrier.
 // PADDED: query[L] and database[L + 16] may be read (staged copies with room behind them): the look-ahead then needs no clamping
 template <bool PADDED = false, typename QueryF>
@@ -88,20 +88,23 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
     const int ext = gapExtendScore;
     const int kExtLo = int(2 * l) * ext, kExtHi = int(2 * l + 1) * ext, k1ExtHi = int(2 * l + 2) * ext;        // k1Ext of the low cell = kExtHi
     int d2 = int(u8(database[15 - 2 * l])) | (int(u8(database[14 - 2 * l])) << 16);            // cell k of row i looks at database[i + 15 - k]
-    u16 *Trow = reinterpret_cast<u16 *>(T) + l;
-    // the next row's query base and the database base that enters the band with it are requested a row ahead (every lane reads the same
-    // bytes: one broadcast access, no branch), so that their latency lies behind the row's arithmetic
-    int qNext = u8(query(0)), dNext = u8(database[L > 1 ? 16 : 15]);
-    for (u32 i = 0; i < L; ++i)
+    // Traceback flags: 6 bits per cell (which of G / E / F each of the three came from), 12 per lane and row, four rows of a lane in three
+    // 16-bit stores: 12 bytes of LDS per row and alignment (16 with a byte per cell: a fifth fewer workgroups per CU at 2x150).
+    // Block b (rows 4b .. 4b + 3), lane l: 48 bits at T + 48 b + 6 l, row j's 12 bits at bit 12 j (low cell first).
+    const auto storeFlags = [&](u32 block, u32 f0, u32 f1, u32 f2, u32 f3)
     {
-        const int q = qNext, dIn = dNext;
-        if (PADDED) { qNext = u8(query(i + 1)); dNext = u8(database[i + 17]); }
-        else
-        {
-            const u32 ahead = i + 1 < L ? i + 1 : i;                  // the values fetched in the last row are not used
-            qNext = u8(query(ahead));
-            dNext = u8(database[ahead + 1 < L ? ahead + 16 : ahead + 15]);
-        }
+        u16 *to = reinterpret_cast<u16 *>(T) + block * 24 + l * 3;
+        to[0] = u16(f0 | (f1 << 12)); to[1] = u16((f1 >> 4) | (f2 << 8)); to[2] = u16((f2 >> 8) | (f3 << 4));
+    };
+    const auto flagsAt = [&](int r, int cell) -> u32
+    {
+        const u32 bit = u32(r & 3) * 12 + u32(cell & 1) * 6;
+        const u8 *at = T + u32(r >> 2) * 48 + u32(cell >> 1) * 6 + (bit >> 3);
+        return ((u32(at[0]) | (u32(at[1]) << 8)) >> (bit & 7)) & 0x3fu;
+    };
+    // one row of the band: q = the row's query base, dIn = the database base that enters the band behind it (database[i + 16])
+    const auto bandRow = [&](int q, int dIn) -> u32
+    {
         const S2 Gv = asS2(G), Ev = asS2(E), Fv = asS2(F);
         // F (:130-173): what cell k hands to cell k + 1 of this row -- max(G - open, E - open, F - extend) and where it came from --
         // computed in place and moved up one cell; cell 0 gets the initial value
@@ -129,10 +132,14 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
         const int gf = asInt(pkMax(g, f));
         const int NEG = -(1 << 28);
         const int cLo = s16(gf) - kExtLo, cHi = (gf >> 16) - kExtHi;
-        int s = fromLaneAbove(max(cLo, cHi), NEG);
-        s = maxRowDown<2>(s);
-        s = maxRowDown<4>(s);
-        s = maxRowDown<8>(s);
+        // the maximum over the lanes above: seven v_max whose DPP operand is the same register (a doubling scan is three steps, but each
+        // reads through DPP what the step before has just written and waits for it)
+        // The first is a DPP move the compiler knows (it keeps the wait states between writing t and reading it through DPP, or fills them);
+        // the others come behind it by their dependence on s.
+        const int t = max(cLo, cHi);
+        int s = fromLaneAbove(t, NEG);
+        s = maxWithLaneAbove<4>(s, t); s = maxWithLaneAbove<6>(s, t); s = maxWithLaneAbove<8>(s, t);
+        s = maxWithLaneAbove<10>(s, t); s = maxWithLaneAbove<12>(s, t); s = maxWithLaneAbove<14>(s, t);
         const int eLo = max(cHi, s) + kExtHi, eHi = lastLane ? initialValue : s + k1ExtHi;
         const int newE = int((u32(eLo) & 0xffffu) | (u32(eHi) << 16));
         // TE: what cell k + 1 tells cell k -- from its (g, E - ext, f) with the reference's tie rules -- moved down one cell; cell 15 gets 0
@@ -141,17 +148,64 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
         const int teOut = bfi(asInt(-asS2(fromE)) /* per half: all ones where the flag is set */, 0x00010001, asInt(pkLt(g, f) << 1));
         const int te = fromCellAbove(teOut, 0);
         const int flags = tg | (te << 2) | (tf << 4);
-        Trow[i * 8] = u16((flags & 0xff) | ((flags >> 8) & 0xff00));
         G = asInt(newG); E = newE; F = newF;
         // slide the database window: cell k takes cell k - 1's base, cell 0 the next one (what it takes in the last row is not looked at)
         d2 = fromCellBelow(d2, dIn);
+        return u32((flags & 0x3f) | ((flags >> 10) & 0xfc0));            // the row's 12 bits
+    };
+#if !defined(ISAAC_TIMING_BSW_NO_DP)      // (timing experiments only: builds with these macros give wrong results)
+    if constexpr (PADDED)
+    {   // staged copies (LDS) with room behind them: four rows' bases per 32-bit read, requested four rows ahead.  (A read per row made
+        // every row wait for the row's flag store as well: the waits the compiler places at a loop's head cover everything in flight.)
+        const u32 *q4 = reinterpret_cast<const u32 *>(query.q), *d4 = reinterpret_cast<const u32 *>(database + 16);
+        u32 qw = q4[0], dw = d4[0], i = 0;
+        for (; i + 4 <= L; i += 4)
+        {
+            u32 qn = q4[(i >> 2) + 1], dn = d4[(i >> 2) + 1];
+            const u32 f0 = bandRow(int(qw & 0xffu), int(dw & 0xffu));
+            const u32 f1 = bandRow(int((qw >> 8) & 0xffu), int((dw >> 8) & 0xffu));
+            const u32 f2 = bandRow(int((qw >> 16) & 0xffu), int((dw >> 16) & 0xffu));
+            const u32 f3 = bandRow(int(qw >> 24), int(dw >> 24));
+            storeFlags(i >> 2, f0, f1, f2, f3);
+            // "used" here, so that the wait for the two reads stands here and counts the four stores behind them as allowed to be in
+            // flight; at the loop's head it would wait for everything (three stores now)
+            asm volatile("" : "+v"(qn), "+v"(dn));
+            qw = qn; dw = dn;
+        }
+        if (i < L)
+        {   // the last one to three rows
+            u32 f[4] = { 0, 0, 0, 0 };
+            for (u32 j = 0; i + j < L; ++j) { f[j] = bandRow(int(qw & 0xffu), int(dw & 0xffu)); qw >>= 8; dw >>= 8; }
+            storeFlags(i >> 2, f[0], f[1], f[2], f[3]);
+        }
     }
+    else
+    {
+        // the next row's query base and the database base that enters the band with it are requested a row ahead (every lane reads the
+        // same bytes: one broadcast access, no branch), so that their latency lies behind the row's arithmetic
+        int qNext = u8(query(0)), dNext = u8(database[L > 1 ? 16 : 15]);
+        for (u32 i = 0; i < L; i += 4)
+        {
+            u32 f[4] = { 0, 0, 0, 0 };
+            for (u32 j = 0; j < 4 && i + j < L; ++j)
+            {
+                const int q = qNext, dIn = dNext;
+                const u32 ahead = i + j + 1 < L ? i + j + 1 : i + j;      // the values fetched in the last row are not used
+                qNext = u8(query(ahead));
+                dNext = u8(database[ahead + 1 < L ? ahead + 16 : ahead + 15]);
+                f[j] = bandRow(q, dIn);
+            }
+            storeFlags(i >> 2, f[0], f[1], f[2], f[3]);
+        }
+    }
+#endif
     reinterpret_cast<int *>(endVals)[l] = G; reinterpret_cast<int *>(endVals)[8 + l] = E; reinterpret_cast<int *>(endVals)[16 + l] = F;
     STAMP(55);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     u32 ret = 0;
+#if !defined(ISAAC_TIMING_BSW_NO_TRACEBACK)
     {
         // end-cell scan (:349-379), traceback (:381-435), stripping of the terminal deletions (:437-453).  All 8 lanes of the group
         // walk the traceback together (the same values in every lane; lane 0 does the stores): a stretch of ALIGN cells whose flags
@@ -175,7 +229,7 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
             if (0 == maxType)
             {
                 const int row = ii - int(l);
-                const bool stop = row < 0 || 0 != (T[row * 16 + jj] & 3);
+                const bool stop = row < 0 || 0 != (flagsAt(row, jj) & 3);
                 const u32 mask = u32(__ballot(stop) >> groupShift) & 0x5555u;
                 const u32 run = mask ? (u32(__ffs(int(mask))) - 1) >> 1 : 8u;
                 opLength += run; ii -= int(run);
@@ -183,7 +237,7 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
                 if (ii < 0) break;
             }
             ++opLength;
-            const u32 nextMaxType = (T[ii * 16 + jj] >> (2 * maxType)) & 3;
+            const u32 nextMaxType = (flagsAt(ii, jj) >> (2 * maxType)) & 3;
             if (nextMaxType != maxType) { ISAAC_BSW_PUSH(opLength, maxType == 0 ? OP_ALIGN : maxType == 1 ? OP_DELETE : OP_INSERT); opLength = 0; }
             ii += (maxType == 1) ? 0 : -1;
             jj += (maxType == 1) ? 1 : (maxType == 2) ? -1 : 0;
@@ -197,6 +251,7 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
         if (l == 0) for (u32 lo = first, hi = n; lo + 1 < hi; ++lo) { --hi; const u32 tt = cig[lo]; cig[lo] = cig[hi]; cig[hi] = tt; }
         if (n > first && OP_DELETE == cigarCode(firstOp)) --n;
     }
+#endif
     STAMP(56);
     // the group's LDS is reused by the next problem only after lane 0 is done with it
     __builtin_amdgcn_wave_barrier();
@@ -214,7 +269,7 @@ __global__ __launch_bounds__(128) void k_bsw_batch(int matchScore, int mismatchS
     const u32 job = blockIdx.x * (blockDim.x / BSW_GROUP_LANES) + group;
     if (job >= nJobs) return;
     u8 *T = lds + group * bswGroupLdsBytes(maxQueryLength);
-    short *endVals = reinterpret_cast<short *>(T + ((maxQueryLength * 16 + 15) & ~15u));
+    short *endVals = reinterpret_cast<short *>(T + bswFlagBytes(maxQueryLength));
     const isaac_bsw_job jb = jobs[job];
     PlainQuery q; q.q = sequences + jb.query_offset;
     isaac_bsw_result &res = results[job];
@@ -239,9 +294,9 @@ __global__ __launch_bounds__(128) void k_gapped_jobs(DevParams P, DevReference R
     DevReference R = Rg; R.logMatch = qualityTables; R.logMismatch = qualityTables + 64;
     const u32 group = bswGroupOfThread(), k = bswLaneOfThread(), groups = blockDim.x / BSW_GROUP_LANES;
     u8 *T = lds + group * gappedGroupLdsBytes(maxReadLength);
-    short *endVals = reinterpret_cast<short *>(T + ((maxReadLength * 16 + 15) & ~15u));
+    short *endVals = reinterpret_cast<short *>(T + bswFlagBytes(maxReadLength));
     char *stagedQuery = reinterpret_cast<char *>(T + bswGroupLdsBytes(maxReadLength));
-    char *stagedDatabase = stagedQuery + ((maxReadLength + 31) & ~15u);
+    char *stagedDatabase = stagedQuery + ((maxReadLength + 47) & ~15u);
     const u32 nJobs = imin(*jobCounter, jobsCap);
     for (u32 j = blockIdx.x * groups + group; j < nJobs; j += gridDim.x * groups)
     {
@@ -275,9 +330,60 @@ __global__ __launch_bounds__(128) void k_gapped_jobs(DevParams P, DevReference R
             getFlanks(strandPosition, sequenceLength, referenceSize, left, right);
             const char *database = R.bases + R.contigOffset[f.contigId] + strandPosition - left;
             STAMP(50);
-            // the group's 16 lanes bring the query and the window into LDS side by side; the DP rows then read one byte of each
-            for (u32 i = k; i < sequenceLength; i += BSW_GROUP_LANES) stagedQuery[i] = strandBase(read, f.reverse, u32(begin) + i);
-            for (u32 i = k; i < sequenceLength + 16; i += BSW_GROUP_LANES) stagedDatabase[i] = (i < sequenceLength + 15) ? database[i] : char(0);
+            // the group's 8 lanes bring the query and the window into LDS side by side, eight bases per lane and step, all of a lane's
+            // loads requested before the first is used (a byte per lane and step -- a load, a wait, a store, twenty times over -- cost as
+            // much as the DP itself once fewer waves were there to hide it); the DP rows then read LDS
+            {
+                const u32 queryChunks = (sequenceLength + 7) / 8, window = sequenceLength + 15, windowChunks = (window + 7) / 8;
+                const u8 *bclBytes = read.bcl;
+                const bool reverse = f.reverse != 0;
+                // BCL bytes of strand positions begin + 8c .. + 7 (position t of the chunk in byte t); never reads outside the read's bytes
+                const auto loadQuery = [&](u32 c)
+                {
+                    const u32 s = u32(begin) + 8 * c;
+                    u64 bytes;
+                    if (!reverse) { const u32 at = s + 8 <= read.length ? s : read.length - 8; memcpy(&bytes, bclBytes + at, 8); bytes >>= 8 * (s - at); }
+                    else
+                    {   // strand position p is byte length - 1 - p
+                        const i32 lo = i32(read.length) - 8 - i32(s);
+                        memcpy(&bytes, bclBytes + (lo < 0 ? 0 : lo), 8);
+                        if (lo < 0) bytes <<= 8 * u32(-lo);
+                        bytes = __builtin_bswap64(bytes);
+                    }
+                    return bytes;
+                };
+                const auto loadWindow = [&](u32 c)
+                {
+                    const u32 at = 8 * c + 8 <= window ? 8 * c : window - 8;       // the window is at least 15 bases
+                    u64 bytes; memcpy(&bytes, database + at, 8);
+                    return bytes >> (8 * (8 * c - at));
+                };
+                for (u32 c0 = 0; c0 < windowChunks; c0 += 4 * BSW_GROUP_LANES)
+                {
+                    u64 q[4], w[4];
+#pragma unroll
+                    for (u32 t = 0; t < 4; ++t)
+                    {
+                        const u32 c = c0 + k + BSW_GROUP_LANES * t;
+                        q[t] = loadQuery(c < queryChunks ? c : queryChunks - 1);
+                        w[t] = loadWindow(c < windowChunks ? c : windowChunks - 1);
+                    }
+#pragma unroll
+                    for (u32 t = 0; t < 4; ++t)
+                    {
+                        const u32 c = c0 + k + BSW_GROUP_LANES * t;
+                        if (c < queryChunks)
+                        {   // strandBase for eight positions at once
+                            const u64 nFlags = zeroBytes(q[t] & (0xfc * BYTES_01));
+                            u64 codes = q[t] & (0x03 * BYTES_01);
+                            if (reverse) codes ^= 0x03 * BYTES_01;
+                            const u64 nBytes = (nFlags >> 7) * 0xff;
+                            reinterpret_cast<u64 *>(stagedQuery)[c] = (asciiOfCodes(codes) & ~nBytes) | ((0x6e * BYTES_01) & nBytes);
+                        }
+                        if (c < windowChunks) reinterpret_cast<u64 *>(stagedDatabase)[c] = w[t];
+                    }
+                }
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

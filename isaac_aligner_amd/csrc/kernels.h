@@ -71,7 +71,7 @@ struct AlignList { u32 *entries; u32 cap; u32 *counter; };
 //   k_select_heavy        one wave per predicted cluster, on its own stream next to k_select
 static const u32 KMER_EMPTY = 0xffffffffu;
 static const u32 RW_TABLE = 512;          // hash slots for the mate's <= 250-odd 7-mers
-static const u32 RW_PRESENT_WORDS = 1024; // a byte per six bases: which 7-mers that begin or end with them does the mate have? (kernels_rescue.hip)
+static const u32 RW_PRESENT_WORDS = 512;  // one bit per possible 7-mer: does the mate have it?
 static const u32 RW_LDS_BITMAP = 64;      // words: windows up to ~1900 bases keep their candidate bitmap in LDS
 #ifndef ISAAC_RW_PER_LANE
 #define ISAAC_RW_PER_LANE 8
@@ -107,14 +107,16 @@ struct SumsBuffers { ClusterSums *sums; u8 *residualFlag; u32 *residualList, *re
 static const u32 HEAVY_SORT_LDS = 32768;   // u16 indices: heavyCaps().prob / .pair entries
 
 // LDS bytes of one 16-lane banded Smith-Waterman group (bsw_kernel.h)
-__host__ __device__ inline u32 bswGroupLdsBytes(u32 maxQueryLength) { return ((maxQueryLength * 16 + 15) & ~15u) + 128; }
+// traceback flags: 48 bytes per four rows (bsw_kernel.h)
+__host__ __device__ inline u32 bswFlagBytes(u32 maxQueryLength) { return (((maxQueryLength + 3) / 4) * 48 + 15) & ~15u; }
+__host__ __device__ inline u32 bswGroupLdsBytes(u32 maxQueryLength) { return bswFlagBytes(maxQueryLength) + 128; }
 // k_gapped_jobs also keeps the query and the database window of the group there (the DP loop then reads LDS, not global memory)
-// (the eight groups of a wave touch their areas at the same offsets in the same instruction: a stride of 16 bytes modulo 128 spreads them
-// over all LDS banks)
+// (the eight groups of a wave touch their areas at the same offsets in the same instruction: a stride of an odd number of 16-byte units
+// spreads them over all LDS banks)
 __host__ __device__ inline u32 gappedGroupLdsBytes(u32 maxQueryLength)
 {
-    const u32 bytes = bswGroupLdsBytes(maxQueryLength) + 2 * ((maxQueryLength + 31) & ~15u);
-    return bytes + ((16u + 128u - (bytes & 127u)) & 127u);
+    const u32 bytes = bswGroupLdsBytes(maxQueryLength) + 2 * ((maxQueryLength + 47) & ~15u);     // the staged query and database window, each with room for the look-ahead reads
+    return (((bytes + 15) / 16) | 1u) * 16;
 }
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_build_fragments(DevParams P, const u8 *bcl, u32 clusterBase, u32 nChunk, const Match *matches, const u64 *offsets, int trim, FragmentWork *work, ClusterPools pools, AlignList al);

@@ -125,12 +125,11 @@ __device__ inline void rescueWindowScan(const DevReference &R, const RescueJob &
 }
 
 // The ordinary window (candidate bitmap in LDS, far fewer than SHADOW_POSITIONS_MAX positions): which 7-mers the mate has at all is a
-// presence map, so a window position costs an LDS access and a bit test, and only the positions whose 7-mer does occur in the mate (about
-// 1 % of a window outside the mate's own place) go on to the hash table for the read offset.  The map is addressed by what two
-// neighbouring window positions have in common -- the six bases they share, 4096 values -- and a byte answers both: bits 0-3 "the mate
-// has the 7-mer made of base a followed by these six", bits 4-7 "... of these six followed by base b".  One byte read serves two
-// positions (round 2: one 32-bit word of a 16384-bit map per position; the reads hit random banks, 45 % of the kernel's LDS cycles were
-// conflicts, and halving their number is what helps).  The probe loops of the general form run
+// 16384-bit map, so a window position costs one LDS word and a bit test, and only the positions whose 7-mer does occur in the mate (about
+// 1 % of a window outside the mate's own place) go on to the hash table for the read offset.
+// (Round 3 tried a map addressed by the six bases two neighbouring positions share, a byte answering both -- half the LDS reads, which hit
+// random banks -- and lost: 4.9 -> 6.0 ms per 1 M clusters.  The map doubles to 4 KB per wave, fewer workgroups fit a CU, and the kernel
+// lives on its occupancy: the bank conflicts it removes were hidden behind other waves' arithmetic.)  The probe loops of the general form run
 // once per position and lane *for the whole wave*; here they run for the few hits.  The reference's "push unless equal to the previous
 // candidate" only decides how many entries its position list holds before sort + unique; that number cannot reach the list's capacity in
 // a window this short, and the set of candidates is the same without it.
@@ -143,18 +142,16 @@ __device__ inline void rescueWindowScanShort(const DevReference &R, const Rescue
     {
         const i32 p0 = tile * RW_TILE + i32(lane) * i32(RW_PER_LANE);          // window position of this lane's first base
         const WindowBits wb = tile ? loadWindowBits(R, windowBase + u64(p0)) : firstTile;
-        const u8 *presentBytes = reinterpret_cast<const u8 *>(present);
-        u32 answers[RW_PER_LANE / 2];
+        u32 words[RW_PER_LANE];
 #pragma unroll
-        for (u32 k = 0; k < RW_PER_LANE; k += 2) answers[k / 2] = presentBytes[u32(wb.codes >> (2 * k + 2)) & 0xfffu];      // bases k+1 .. k+6
+        for (u32 k = 0; k < RW_PER_LANE; ++k) words[k] = present[(u32(wb.codes >> (2 * k)) & 0x3fffu) >> 5];
         u32 hitMask = 0;
 #pragma unroll
         for (u32 k = 0; k < RW_PER_LANE; ++k)
         {
+            const u32 kmer = u32(wb.codes >> (2 * k)) & 0x3fffu;
             const bool valid = p0 + i32(k) <= lastStart && !((wb.notBase >> k) & 0x7fu);
-            // position k: its first base in front of the shared six; position k + 1: its last base behind them
-            const u32 bit = (k & 1) ? 4u + (u32(wb.codes >> (2 * k + 12)) & 3u) : u32(wb.codes >> (2 * k)) & 3u;
-            hitMask |= (valid && ((answers[k / 2] >> bit) & 1u)) ? 1u << k : 0u;
+            hitMask |= (valid && ((words[k] >> (kmer & 31u)) & 1u)) ? 1u << k : 0u;
         }
         while (hitMask)
         {
@@ -247,12 +244,7 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
             const bool ok = 0 == (((((w0 >> 16) & 0xffu) | (((w1 >> 16) & 0xffu) << 8)) >> shift) & 0x7fu);
             if (!ok) continue;
             const u32 val = (kmer << 10) | i;
-            if (small)
-            {   // the two bytes that know this 7-mer: by its last six bases (bit = its first base), by its first six (bit 4 + its last base)
-                const u32 byLast = kmer >> 2, byFirst = kmer & 0xfffu;
-                atomicOr(&present[byLast >> 2], (1u << (kmer & 3u)) << (8 * (byLast & 3u)));
-                atomicOr(&present[byFirst >> 2], (16u << (kmer >> 12)) << (8 * (byFirst & 3u)));
-            }
+            if (small) atomicOr(&present[kmer >> 5], 1u << (kmer & 31u));
             u32 h = (kmer * 2654435761u) >> 23;
             while (true)
             {
