@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-pcie-pass", action="store_true")
     ap.add_argument("--no-bam-pass", action="store_true")
     ap.add_argument("--no-neighbors", action="store_true")
+    ap.add_argument("--contexts", type=int, default=3, help="contexts (streams) per GPU that take the steps' selections in turn; they share the contigs and the table")
+    ap.add_argument("--no-single-stream-pass", action="store_true", help="skip the extra pass of the same steps on one context (per-kernel times without sharing)")
     ap.add_argument("--launch-check", action="store_true", help="GPU-less check of the launcher and the collectives (gloo): no alignment")
     return ap.parse_args()
 
@@ -157,6 +159,19 @@ def main():
     t_genome = time.time() - t0
     n_index = al.build_index(repeat_threshold=1000, annotate_neighbors=not args.no_neighbors)
     t_index = time.time() - t0 - t_genome
+    # More contexts on the same GPU, each on a stream of its own, sharing the contigs and the resident table (isaac_gpu_set_index_dev): the
+    # selections of consecutive steps are handed to them in turn, so that kernels of different steps share the GPU -- the tail of a launch,
+    # the few long workgroups of the repeat-family sums and the kernels that wait on memory overlap another step's arithmetic.
+    n_contexts = max(1, args.contexts)
+    als, streams = [al], [torch.cuda.current_stream(dev)]
+    table = al.index_tensors() if n_contexts > 1 else None
+    for _ in range(n_contexts - 1):
+        st = torch.cuda.Stream(dev)
+        with torch.cuda.stream(st):
+            extra = gpu.Aligner(params, local_rank, genome, deferred_completion=True)
+            extra.set_index_tensors(*table)
+        als.append(extra)
+        streams.append(st)
     n_batches = args.warmup + args.steps
     per_rank = args.pairs_per_step
     batches = []
@@ -189,14 +204,18 @@ def main():
     tls = None
     for b in range(max(1, args.warmup)):
         m, o, hits = al.find_matches(batches[b])
-        al.set_loaded_contigs(reduce_hits(hits))
+        warm_loaded = reduce_hits(hits)
+        al.set_loaded_contigs(warm_loaded)
         if tls is None:
             tls = al.determine_tls(batches[b], m, o)
         if b < args.warmup:
             w = buffers(batches[b].shape[0])
-            al.select(batches[b], m, o, tls, out=w[:2])
-            al.synchronize()
-            al.compact_cigars(w[0], w[1], w[2])
+            for ctx in als:                               # every context grows its chunk buffers here, not in the timed steps
+                if ctx is not al:
+                    ctx.set_loaded_contigs(warm_loaded)
+                ctx.select(batches[b], m, o, tls, out=w[:2])
+                ctx.synchronize()
+                ctx.compact_cigars(w[0], w[1], w[2])
             del w
     shard.broadcast_tls(tls, dist, dev)   # rank 0's statistics are the run's statistics
     if dist is not None:
@@ -211,8 +230,9 @@ def main():
             pool = [torch.empty_like(out[s][0]) for s in range(args.steps) for _ in range(world)]
             pool += [torch.empty_like(out[s][2]) for s in range(args.steps) for _ in range(world)]
             del pool
-    al.synchronize()
-    al.reset_timers()
+    for ctx in als:
+        ctx.synchronize()
+        ctx.reset_timers()
 
     # ---- timed region: exactly K steps ---------------------------------------------------------------------------------
     if dist is not None:
@@ -225,7 +245,9 @@ def main():
         m, o, hits = al.find_matches(batches[args.warmup + s], tile=tile_of(s), out=match_bufs[s])
         found.append((m, o))
         all_hits |= hits
-    al.set_loaded_contigs(reduce_hits(all_hits))      # MatchSelector loads only contigs that received matches
+    loaded = reduce_hits(all_hits)
+    for ctx in als:
+        ctx.set_loaded_contigs(loaded)                # MatchSelector loads only contigs that received matches
     # Every step's CIGARs are packed behind its selection without a host wait (isaac_gpu_compact_cigars_async: the packed length stays on the
     # device); with several GPUs the step's records and CIGAR pool then leave for rank 0 behind the later steps (shard.StepGather: nothing
     # in the loop waits for the GPU or for another rank -- every rank's record count is known from the static split)
@@ -237,11 +259,15 @@ def main():
     gatherer = shard.StepGather(dist, rank, world, record_counts=rec_counts) if dist is not None else None
     for s in range(args.steps):                       # phase 2: SelectMatchesTransition
         m, o = found[s]
-        al.select(batches[args.warmup + s], m, o, tls, tile=tile_of(s), out=out[s][:2])
-        al.compact_cigars_async(out[s][0], out[s][1], out[s][2], out[s][3])
+        ctx = als[s % n_contexts]
+        ctx.select(batches[args.warmup + s], m, o, tls, tile=tile_of(s), out=out[s][:2])
+        ctx.compact_cigars_async(out[s][0], out[s][1], out[s][2], out[s][3])
         if gatherer is not None:
+            if ctx is not al:                         # the gather runs on the main stream: behind this step on its context's stream
+                torch.cuda.current_stream(dev).wait_event(streams[s % n_contexts].record_event())
             gatherer.add(out[s][0], out[s][2], out[s][3])
-    al.synchronize()
+    for ctx in als:
+        ctx.synchronize()
     gathered = gatherer.finish() if gatherer is not None else None
     torch.cuda.synchronize()
     if dist is not None:
@@ -277,10 +303,20 @@ def main():
     free_b, total_b = torch.cuda.mem_get_info(dev)
     hbm_used_gb = round((total_b - free_b) / 1e9, 1)      # everything resident at the end of the run: index, reads, records, chunk scratch
     counters = al.counters()
+    for ctx in als[1:]:
+        for key, value in ctx.counters().items():
+            counters[key] += value
     timer_names = ("find_matches", "compact_matches", "build_fragments", "align_candidates", "finish_candidates", "indel_fragments", "gapped_fragments", "gapped_fragments_rescan", "finish_fragments",
                    "plan_rescue", "rescue_windows", "rescue_align", "rescue_gapped_plan", "gapped_rescue", "gapped_rescue_rescan", "sums_wave", "sums_large", "sums_xl", "sums_huge", "select",
                    "select_heavy", "select_residual")
-    timers = {k: al.kernel_time_ms(k) for k in timer_names}
+    def read_timers(contexts):
+        t = {}
+        for k in timer_names:                         # average duration and launches over all contexts
+            per = [ctx.kernel_time_ms(k) for ctx in contexts]
+            launches = sum(n for _, n in per)
+            t[k] = (sum(ms * n for ms, n in per) / launches if launches else 0.0, launches)
+        return t
+    timers = read_timers(als)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -288,6 +324,23 @@ def main():
 
     reads_per_s = 2.0 * pairs_total / elapsed
     pairs_rank = sum(b.shape[0] for b in batches[args.warmup:])
+
+    # ---- the same K selections on ONE context (not `value`): with several contexts the kernels of different steps share the GPU in the
+    # timed region and a kernel's event time includes what it shares; here every kernel has the GPU to itself.  Also shows that the
+    # records do not depend on how the steps were interleaved.
+    single = None
+    if n_contexts > 1 and dist is None and not args.no_single_stream_pass:
+        al.reset_timers()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for s in range(args.steps):
+            al.select(batches[args.warmup + s], found[s][0], found[s][1], tls, tile=tile_of(s), out=out[s][:2])
+            al.compact_cigars_async(out[s][0], out[s][1], out[s][2], out[s][3])
+        al.synchronize()
+        torch.cuda.synchronize()
+        single_elapsed = time.perf_counter() - t1
+        single = {"select_ms_per_step": round(single_elapsed / args.steps * 1e3, 3), "timers": read_timers([al]),
+                  "records_identical_to_timed_region": bool((out[0][0] == checked_records).all()) and bool((packed[0] == checked_cigars).all())}
 
     # ---- the same K steps with the reads arriving over PCIe and the results leaving over it (reported next to `value`, never as it)
     pcie = None
@@ -429,6 +482,15 @@ def main():
     elapsed_rank = elapsed
     # the kernel behind a timer, where the names differ (the banded Smith-Waterman kernel serves the fragment stage and the mate rescue)
     kernel_of = {"gapped_fragments": "k_gapped_jobs", "gapped_rescue": "k_gapped_jobs", "sums_wave": "k_cluster_sums16"}
+    single_stream = None
+    if single is not None:      # the dominant kernel and every kernel's time with the GPU to itself
+        st = single["timers"]
+        st_launches = max(1, st[dominant][1])
+        st_achieved = per_kernel_bytes[dominant] / st_launches / (st[dominant][0] / 1e3) / 1e9 if st[dominant][0] > 0 else 0.0
+        single_stream = {"avg_launch_ms": round(st[dominant][0], 4), "achieved": round(st_achieved, 3), "frac": round(st_achieved / 8000.0, 6),
+                         "select_ms_per_step": single["select_ms_per_step"], "records_identical_to_timed_region": single["records_identical_to_timed_region"],
+                         "kernel_ms_per_step": {k: round(v[0] * v[1] / args.steps, 3) for k, v in st.items() if v[0] * v[1]},
+                         "band_cell_updates_per_s": round((c["bsw_jobs"] + c["rescue_bsw"]) * L * 16 / max(1e-9, (st["gapped_fragments"][0] * st["gapped_fragments"][1] + st["gapped_rescue"][0] * st["gapped_rescue"][1]) / 1e3), 1)}
     roofline = {"bound": "hbm", "kernel": kernel_of.get(dominant, "k_" + dominant), "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_ms": round(total_ms[dominant] / launches, 4), "launches": int(launches),
@@ -439,6 +501,9 @@ def main():
                 "path_achieved": round(pairs_rank * bytes_pair / elapsed_rank / 1e9, 2),
                 "path_frac": round(pairs_rank * bytes_pair / elapsed_rank / 1e9 / 8000.0, 6),
                 "heavy_clusters": int(c.get("heavy_clusters", 0)),
+                # how many steps' kernels share the GPU in the timed region (a kernel's event time then includes what it shares), and the same
+                # kernels with the GPU to themselves
+                "concurrent_contexts": n_contexts, "single_stream": single_stream,
                 # the banded Smith-Waterman kernels are VALU-bound: 16 band cells per row and problem (report cell updates/s)
                 "band_cell_updates_per_s": round((c["bsw_jobs"] + c["rescue_bsw"]) * L * 16 / max(1e-9, (total_ms.get("gapped_fragments", 0.0) + total_ms.get("gapped_rescue", 0.0)) / 1e3), 1)}
 
@@ -510,7 +575,7 @@ def main():
               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
               "scaling": args.scaling, "vs_baseline": None, "dtype": "u8/int16 (+f64 log-probabilities)", "data": "synthetic",
               "config": {"workload": workload, "pairs_per_step": args.pairs_per_step, "read_length": L, "genome_bases": args.genome_bases, "index_entries": int(n_index),
-                         "parallelism": "read shards x%d, every step's records and packed CIGARs gathered to rank 0 behind the later steps" % world, "hbm_used_gb": hbm_used_gb, "setup_s": round(t_setup, 1),
+                         "parallelism": "read shards x%d, %d context(s) per GPU taking the steps' selections in turn (one stream each, contigs and table shared), every step's records and packed CIGARs gathered to rank 0 behind the later steps" % (world, n_contexts), "hbm_used_gb": hbm_used_gb, "setup_s": round(t_setup, 1),
                          "genome_s": round(t_genome, 1), "index_build_s": round(t_index, 1), "tls": list(tls.astuple()), "pcie_inclusive": pcie, "bam_output": bam_info},
               "roofline": roofline, "cpu_baseline": cpu, "counters": {k: int(v) for k, v in counters.items()}}
     result.update(parity)

@@ -3,7 +3,7 @@
 # run with the default 1 M pairs per launch, reduced by scripts/pmc_summary.py into gpurun_out/pmc_summary.json
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie-pass --no-bam-pass"
+B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie-pass --no-bam-pass --no-single-stream-pass"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_j_fetch -- $B > $R/gpurun_out/pmc_j_fetch.log 2>&1; echo "fetch rc=$?"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_j_write -- $B > $R/gpurun_out/pmc_j_write.log 2>&1; echo "write rc=$?"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d $R/gpurun_out/pmc_j_sq -- $B > $R/gpurun_out/pmc_j_sq.log 2>&1; echo "sq rc=$?"

@@ -32,5 +32,13 @@ for s, e, n in rows:
     if end is None or e > end:
         end = e; prev = n
 print("window %.1f ms: busy %.1f ms, idle %.1f ms" % ((t1 - lo) / 1e6, busy / 1e6, idle / 1e6))
+# the kernels of the window (the timed steps only: no warm-up, no set-up): launches and average duration, to set against bench.py's HIP events
+per = collections.defaultdict(list)
+for s, e, n in rows:
+    if s >= lo:
+        per[n].append(e - s)
+print("kernels of the window by total time (launches, average ms, total ms; the totals add up to more than the window when streams overlap):")
+for n, d in sorted(per.items(), key=lambda kv: -sum(kv[1]))[:24]:
+    print("%6d %9.3f %9.2f   %s" % (len(d), sum(d) / len(d) / 1e6, sum(d) / 1e6, n))
 for (a, b), g in gaps.most_common(25):
     print("%8.2f ms in %4d gaps   %s -> %s" % (g / 1e6, counts[(a, b)], a, b))
