@@ -228,22 +228,39 @@ def write_fasta(path, names, contigs, rng):
     return meta, loaded
 
 
+SCENARIOS = {
+    # the reference's defaults: y*n mask (101 -> 100 cycles), duplicates marked, gaps realigned, unaligned records at the back
+    "defaults": dict(compressed=False, lengths=(100, 100), cli=[], paired=True, mark=True, keep=True, realign=True, unaligned="back", dodgy=0, pu="%s:%d:none"),
+    "defaults-gz": dict(compressed=True, lengths=(100, 100), cli=[], paired=True, mark=True, keep=True, realign=True, unaligned="back", dodgy=0, pu="%s:%d:none"),
+    # other masks and options: 75 + 80 cycles, nothing marked or realigned, unaligned records first, stored (level 0) BGZF, MAPQ 255 for unknown scores
+    "options": dict(compressed=False, lengths=(75, 80),
+                    cli=["--use-bases-mask", "y75n*,y80n*", "--keep-unaligned", "front", "--mark-duplicates", "0", "--realign-gaps", "no", "--bam-gzip-level", "0",
+                         "--dodgy-alignment-score", "Unknown", "--bam-pu-format", "%F.%L"],
+                    paired=True, mark=False, keep=True, realign=False, unaligned="front", dodgy=255, pu="%s.%d"),
+    # single-ended lanes, unaligned reads left out
+    "single-ended": dict(compressed=True, lengths=(100,), cli=["--keep-unaligned", "discard"], paired=False, mark=True, keep=True, realign=True, unaligned="discard", dodgy=0, pu="%s:%d:none"),
+}
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("compressed", [False, True])
-def test_gpu_isaac_align_end_to_end(tmp_path, compressed):
+@pytest.mark.parametrize("scenario", sorted(SCENARIOS))
+def test_gpu_isaac_align_end_to_end(tmp_path, scenario):
     import torch
+    sc = SCENARIOS[scenario]
+    compressed, lengths = sc["compressed"], sc["lengths"]
+    n_reads, cluster_length = len(lengths), sum(lengths)
     o = oracle_lib.load()
     rng = np.random.default_rng(17)
-    file_length, L, at_a_time = 101, 100, 4000                             # --use-bases-mask default: y*n, the last cycle of a read is not used
+    file_length, at_a_time = 101, 4000
     genome = synth.make_genome(300000, seed=61, n_contigs=3)
     names = [b"chrA", b"chrB", b"chrC"]
     ref_dir = tmp_path / "ref"
     ref_dir.mkdir()
     fasta = str(ref_dir / "genome.fa")
     meta, stored = write_fasta(fasta, names, [bytes(c.numpy()) for c in genome], rng)
-    params = options.default_params(L, L)
+    params = options.default_params(lengths[0], lengths[1] if n_reads > 1 else 0, dodgy_alignment_score=sc["dodgy"], keep_unaligned=int(sc["unaligned"] != "discard"))
     karyotype = [2, 0, 1]                                                    # stored contig i is the karyotype[i]-th of the karyotype
-    a = gpu.Aligner(params, 0, stored)
+    a = gpu.Aligner(options.default_params(100, 100), 0, stored)
     a.build_index()
     contig_meta, position = [], 0
     for i, c in enumerate(stored):
@@ -288,7 +305,7 @@ def test_gpu_isaac_align_end_to_end(tmp_path, compressed):
     calls.mkdir()
     texts = {}
     for lane, bcl in lanes:
-        for read in range(2):
+        for read in range(n_reads):
             text = synth.bcl_to_fastq(bcl, read * file_length, file_length, name="M7:15:FCTEST:%d" % lane, plus_header=bool(read))
             texts[(lane, read)] = text
             path = calls / ("lane%d_read%d.fastq%s" % (lane, read + 1, ".gz" if compressed else ""))
@@ -299,12 +316,12 @@ def test_gpu_isaac_align_end_to_end(tmp_path, compressed):
                 path.write_bytes(text)
     out = tmp_path / "Aligned"
     args = ["-r", xml, "-b", str(calls), "--base-calls-format", "fastq-gz" if compressed else "fastq", "-o", str(out), "--clusters-at-a-time", str(at_a_time), "-j", "4",
-            "--bam-header-tag", "@CO\tend to end", "--description", "cli test", "-t", str(tmp_path / "Temp")]
+            "--bam-header-tag", "@CO\tend to end", "--description", "cli test", "-t", str(tmp_path / "Temp")] + sc["cli"]
     r = run_host(*args)
     assert r.returncode == 0, r.stderr
     assert not (tmp_path / "Temp").exists()
     # ---- the oracle on the same inputs
-    b = gpu.Aligner(params, 0, contigs)
+    b = gpu.Aligner(options.default_params(100, 100), 0, contigs)
     b.load_sorted_reference(xml)
     table = b.get_index()                                                  # as stored in the mask files: contig ids are stored indexes (the lookup translates them)
     del b
@@ -318,8 +335,8 @@ def test_gpu_isaac_align_end_to_end(tmp_path, compressed):
     found, all_hits, index = [], np.zeros(3, np.uint8), 0
     for lane_index, (lane, bcl) in enumerate(lanes):
         o_lane = None
-        for read in range(2):
-            rc, o_lane, n, _, _ = o.fastq_to_bcl(texts[(lane, read)], L, bcl=o_lane, cluster_stride=2 * L, offset=read * L, max_clusters=len(bcl))
+        for read in range(n_reads):
+            rc, o_lane, n, _, _ = o.fastq_to_bcl(texts[(lane, read)], lengths[read], bcl=o_lane, cluster_stride=cluster_length, offset=sum(lengths[:read]), max_clusters=len(bcl))
             assert rc == 0 and n == len(bcl)
         number = 1
         for first in range(0, len(bcl), at_a_time):                          # loads of --clusters-at-a-time, each one tile
@@ -335,36 +352,44 @@ def test_gpu_isaac_align_end_to_end(tmp_path, compressed):
             tls = tls_of_lane[lane_index] = ref.determine_tls(params, tile_bcl, om, all_hits, tile=index)
         orec, ocig, _ = ref.select(params, tile_bcl, om, tls, all_hits, tile=index, n_clusters_hint=len(tile_bcl))
         host_tiles.append((tile_bcl, orec, ocig, "FCTEST:%d:%d:" % (lane, number), str(lane_index), tls))
-    want, want_n, want_unaligned = o.bam_records(host_tiles, [L, L], forced_dodgy_alignment_score=0, mark_duplicates=True, keep_duplicates=True, realign_gaps=True, reference=ref)
+    want, want_n, want_unaligned = o.bam_records(host_tiles, list(lengths), forced_dodgy_alignment_score=sc["dodgy"] & 0xff, mark_duplicates=sc["mark"], keep_duplicates=sc["keep"],
+                                                 realign_gaps=sc["realign"], reference=ref)
     recs = bam.parse_records(want)
     print("oracle: %d records, %d unmapped, %d with gaps in the CIGAR, %d realigned, tiles %s" % (
         len(recs), sum(1 for x in recs if x["flag"] & 4), sum(1 for x in recs if any((int(w) & 15) in (1, 2) for w in x["cigar"])), sum(1 for x in recs if "OC" in x["tags"]),
         [(t[3], t[5].astuple(), int((t[1]["gap_count"] > 0).sum())) for t in host_tiles]))
-    assert sum(1 for x in recs if x["flag"] & 0x400) > 500 and sum(1 for x in recs if "OC" in x["tags"]) > 5 and {x["tags"]["RG"] for x in recs} == {"0", "1"}
+    assert {x["tags"]["RG"] for x in recs} == {"0", "1"}
+    if scenario.startswith("defaults"):
+        assert sum(1 for x in recs if x["flag"] & 0x400) > 500 and sum(1 for x in recs if "OC" in x["tags"]) > 5
+    if sc["unaligned"] == "discard":
+        assert want_unaligned == len(want) and len(recs) < sum(len(b_) for _, b_ in lanes) * n_reads
+    else:
+        assert want_unaligned < len(want)
     sq = [(names[i].decode(), len(stored[i]), contig_meta[i].bam_sq_as.decode(), contig_meta[i].bam_sq_ur.decode() or fasta, contig_meta[i].bam_m5.decode()) for i in ordered]
     header = o.bam_header(" ".join([host()] + args), "isaac_aligner_amd-0.3", sq, description="cli test",
-                          header_lines=["@CO\tend to end", "@RG\tID:0\tPL:ILLUMINA\tSM:default\tPU:FCTEST:1:none", "@RG\tID:1\tPL:ILLUMINA\tSM:default\tPU:FCTEST:3:none"])
-    # ---- the files
+                          header_lines=["@CO\tend to end"] + ["@RG\tID:%d\tPL:ILLUMINA\tSM:default\tPU:%s" % (k, sc["pu"] % ("FCTEST", lane)) for k, (lane, _) in enumerate(lanes)])
+    # ---- the files: the header, a BGZF run per contig and one for the unaligned records (first with --keep-unaligned front), the empty block
+    cuts = bam.split_parts(want, want_unaligned)
+    if sc["unaligned"] == "front":
+        cuts = cuts[-1:] + cuts[:-1]
+    expected = b"".join(want[off:off + size] for off, size in cuts)
     path = out / "Projects" / "default" / "default" / "sorted.bam"
     data = path.read_bytes()
     blocks = bgzf_blocks(data)
     raw = b"".join(x[2] for x in blocks)
     assert raw[:len(header)] == header
-    assert raw[len(header):] == want
+    assert raw[len(header):] == expected
     assert blocks[-1][1] == 28 and blocks[-1][2] == b""                      # bam::serializeBgzfFooter
     assert gzip.decompress(data) == raw
-    # the bins of the file: the header, a BGZF run per contig, the unaligned records, the empty block
-    cuts = bam.split_parts(want, want_unaligned)
-    assert len(cuts) == 4
     starts, at = {}, 0
     for offset, size, block in blocks:
         starts.setdefault(at, offset); at += len(block)
     header_bgzf = starts[len(header)]
-    parts = []
+    parts, file_at = [], len(header)
     for off, size in cuts:
-        begin, end = starts[len(header) + off], starts[len(header) + off + size] if len(header) + off + size in starts else blocks[-1][0]
-        parts.append((off, size, data[begin:end]))
+        parts.append((off, size, data[starts[file_at]:starts[file_at + size]]))
+        file_at += size
     assert sum(len(p[2]) for p in parts) + header_bgzf + 28 == len(data)
     bai = (out / "Projects" / "default" / "default" / "sorted.bam.bai").read_bytes()
     assert bai == o.bam_index(want, parts, 3, header_bgzf)
-    check_index_semantics(bai, want, parts, 3, header_bgzf, L)
+    check_index_semantics(bai, want, parts, 3, header_bgzf, lengths[0])
