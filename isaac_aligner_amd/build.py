@@ -60,21 +60,25 @@ def build(force=False, verbose=False):
 
 HOST = os.path.join(HERE, "host")
 HOST_EXE = os.path.join(HERE, "bin", "isaac-align")
+SORT_EXE = os.path.join(HERE, "bin", "isaac-sort-reference")
+# the programs of host/: plain C++17 on include/isaac_gpu.h; they find the library next to them through their rpath
+HOST_PROGRAMS = {HOST_EXE: ["isaac_align.cpp", "align_options.cpp", "fastq_flowcell.cpp"], SORT_EXE: ["isaac_sort_reference.cpp"]}
 
 
 def build_host(force=False, verbose=False):
-    """bin/isaac-align: plain C++17 on the C ABI; finds the library next to it through its rpath"""
+    """bin/isaac-align and bin/isaac-sort-reference; returns the path of isaac-align"""
     build(verbose=verbose)
-    srcs = [os.path.join(HOST, f) for f in sorted(os.listdir(HOST)) if f.endswith(".cpp")]
-    deps = srcs + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")] + [os.path.join(HERE, "..", "include", "isaac_gpu.h"), LIB]
-    if not force and os.path.exists(HOST_EXE) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_EXE) for d in deps):
-        return HOST_EXE
-    os.makedirs(os.path.dirname(HOST_EXE), exist_ok=True)
-    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-pthread", "-I", os.path.join(HERE, "..", "include"), "-I", HOST] + srcs + \
-          ["-L", HERE, "-l" + os.path.basename(LIB)[3:-3], "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--allow-shlib-undefined", "-lz", "-o", HOST_EXE]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    headers_ = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")] + [os.path.join(HERE, "..", "include", "isaac_gpu.h"), LIB]
+    for exe, names in HOST_PROGRAMS.items():
+        srcs = [os.path.join(HOST, n) for n in names]
+        if not force and os.path.exists(exe) and all(os.path.getmtime(d) <= os.path.getmtime(exe) for d in srcs + headers_):
+            continue
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-pthread", "-I", os.path.join(HERE, "..", "include"), "-I", HOST] + srcs + \
+              ["-L", HERE, "-l" + os.path.basename(LIB)[3:-3], "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--allow-shlib-undefined", "-lz", "-o", exe]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     return HOST_EXE
 
 

@@ -105,6 +105,27 @@ def test_command_line_errors(tmp_path):
     assert r.returncode == 1 and ("isaac_gpu_create" in r.stderr or "x.xml" in r.stderr)
 
 
+def test_sort_reference_command_line(tmp_path):
+    """bash/bin/isaac-sort-reference's argument handling (exit codes 1 for help / version, 2 for errors) and the contig table it reads;
+    without a GPU it stops at the device with a message"""
+    tool = os.path.join(os.path.dirname(host()), "isaac-sort-reference")
+    run = lambda *a: subprocess.run([tool] + [str(x) for x in a], capture_output=True, text=True)
+    assert run("-v").returncode == 1 and run("-h").returncode == 1 and "--genome-file" in run("-h").stdout
+    for args, code, message in ((["--frob"], 2, "ERROR: unrecognized argument: --frob"), ([], 2, "--output-directory and --genome-file arguments are mandatory"),
+                                (["-g", tmp_path / "missing.fa"], 2, "ERROR: File not found"), (["-g", __file__, "-s", "20"], 2, "--seed-length must be 16, 32 or 64"),
+                                (["-g", __file__, "-s", "64"], 2, "32-mer references only"), (["-g", __file__, "-w", "4"], 2, "--mask-width 6"), (["-g", __file__, "-n"], 2, "--dry-run")):
+        r = run(*args)
+        assert r.returncode == code and message in r.stderr + r.stdout, (args, r.stderr, r.stdout)
+    fasta = tmp_path / "two.fa"
+    fasta.write_bytes(b">c1 first contig\nACGTNNACGTacgtRYACGTTGCA\nACGT\n>c2\nGGGGCCCC\n")
+    r = run("-g", fasta, "-o", tmp_path / "out")
+    if "isaac_gpu_create" in r.stderr:          # no GPU here: the contig table was read, the device was not there
+        assert r.returncode == 2
+    else:
+        assert r.returncode == 0, r.stderr
+    assert "contig c1: 28 bases (24 ACGT) at byte 17, M5 c069df0a1d4472f4a9fbeebe6124a937" in r.stderr and "contig c2: 8 bases (8 ACGT) at byte 51, M5 9b2ef89d932478a21dc98f32c1f2346f" in r.stderr
+
+
 # ---- the index -------------------------------------------------------------------------------------------------------------------------
 
 def bgzf_blocks(data):
@@ -238,7 +259,9 @@ SCENARIOS = {
                          "--dodgy-alignment-score", "Unknown", "--bam-pu-format", "%F.%L"],
                     paired=True, mark=False, keep=True, realign=False, unaligned="front", dodgy=255, pu="%s.%d"),
     # single-ended lanes, unaligned reads left out
-    "single-ended": dict(compressed=True, lengths=(100,), cli=["--keep-unaligned", "discard"], paired=False, mark=True, keep=True, realign=True, unaligned="discard", dodgy=0, pu="%s:%d:none"),
+    # ... on a reference made by bin/isaac-sort-reference from the FASTA file
+    "single-ended": dict(compressed=True, lengths=(100,), cli=["--keep-unaligned", "discard"], paired=False, mark=True, keep=True, realign=True, unaligned="discard", dodgy=0, pu="%s:%d:none",
+                         sort_reference_tool=True),
 }
 
 
@@ -259,20 +282,37 @@ def test_gpu_isaac_align_end_to_end(tmp_path, scenario):
     fasta = str(ref_dir / "genome.fa")
     meta, stored = write_fasta(fasta, names, [bytes(c.numpy()) for c in genome], rng)
     params = options.default_params(lengths[0], lengths[1] if n_reads > 1 else 0, dodgy_alignment_score=sc["dodgy"], keep_unaligned=int(sc["unaligned"] != "discard"))
-    karyotype = [2, 0, 1]                                                    # stored contig i is the karyotype[i]-th of the karyotype
     a = gpu.Aligner(options.default_params(100, 100), 0, stored)
     a.build_index()
-    contig_meta, position = [], 0
-    for i, c in enumerate(stored):
-        m = sr.Contig()
-        m.genomic_position, m.index, m.karyotype_index, m.name, m.file = position, i, karyotype[i], names[i], fasta.encode()
-        m.offset, m.size, m.total_bases, m.acgt_bases = meta[i][0], meta[i][1], len(c), sum(c.count(b) for b in b"ACGT")
-        if i == 1:
-            m.bam_sq_as, m.bam_sq_ur, m.bam_m5 = b"testAssembly", b"http://example.org/chrB.fa", b"0123456789abcdef0123456789abcdef"
-        position += len(c)
-        contig_meta.append(m)
-    a.save_sorted_reference(str(ref_dir), "genome.fa", contig_meta)
     xml = str(ref_dir / "sorted-reference.xml")
+    if sc.get("sort_reference_tool"):
+        # isaac-sort-reference: the contig table of printContigs, the same table as the library builds, in the files isaac-align reads
+        karyotype = [0, 1, 2]
+        r = subprocess.run([os.path.join(os.path.dirname(host()), "isaac-sort-reference"), "-g", fasta, "-o", str(ref_dir), "-j", "4"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        contig_meta, masks, _ = sr.parse(open(xml).read())
+        import hashlib
+        position = 0
+        for i, m in enumerate(contig_meta):
+            sequence = bytes(b for b in open(fasta, "rb").read()[meta[i][0]:meta[i][0] + meta[i][1]].upper() if not chr(b).isspace())
+            assert (m.name, m.index, m.karyotype_index, m.file.decode(), m.offset, m.size, m.total_bases, m.acgt_bases, m.genomic_position, m.bam_m5.decode()) == \
+                   (names[i], i, i, fasta, meta[i][0], meta[i][1], len(stored[i]), sum(stored[i].count(b) for b in b"ACGT"), position, hashlib.md5(sequence).hexdigest())
+            position += len(stored[i])
+        files = sorted(f for f in os.listdir(ref_dir) if f.endswith(".dat"))
+        assert len(files) == 64 and files[5] == "genome.fa-32mer-6bit-05.dat" and [m.file.decode() for m in masks if m.seed_length == 32][5].endswith(files[5])
+        assert np.concatenate([np.fromfile(ref_dir / f, abi.REFERENCE_KMER_DTYPE) for f in files]).tobytes() == a.get_index().tobytes()
+    else:
+        karyotype = [2, 0, 1]                                                # stored contig i is the karyotype[i]-th of the karyotype
+        contig_meta, position = [], 0
+        for i, c in enumerate(stored):
+            m = sr.Contig()
+            m.genomic_position, m.index, m.karyotype_index, m.name, m.file = position, i, karyotype[i], names[i], fasta.encode()
+            m.offset, m.size, m.total_bases, m.acgt_bases = meta[i][0], meta[i][1], len(c), sum(c.count(b) for b in b"ACGT")
+            if i == 1:
+                m.bam_sq_as, m.bam_sq_ur, m.bam_m5 = b"testAssembly", b"http://example.org/chrB.fa", b"0123456789abcdef0123456789abcdef"
+            position += len(c)
+            contig_meta.append(m)
+        a.save_sorted_reference(str(ref_dir), "genome.fa", contig_meta)
     ordered = [None] * 3
     for i, k in enumerate(karyotype):
         ordered[k] = i
