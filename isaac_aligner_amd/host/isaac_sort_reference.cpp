@@ -2,7 +2,7 @@
 // printContigs (lib/reference/ContigsPrinter.cpp:46-141: the contig table of the FASTA file), sortReference once per mask
 // (lib/reference/ReferenceSorter.cpp), mergeReferences, findNeighbors (lib/reference/NeighborsFinder.cpp) -- as one program on
 // include/isaac_gpu.h: the contigs are read as reference::loadContig reads them, the 32-mer table with its neighbour flags is built on the
-// device (isaac_gpu_build_index) and written as <genome>-32mer-6bit-NN.dat + sorted-reference.xml (isaac_gpu_save_sorted_reference).
+// device (isaac_gpu_build_index) and written as <genome>-32mer-6bit-ABCD-NN.dat + sorted-reference.xml (isaac_gpu_save_sorted_reference).
 // Not written: genome-neighbors.1bpb and repeats-<threshold>.1bpb (extractNeighbors; inputs of the reference's reports, not of isaac-align).
 #include "isaac_gpu.h"
 
@@ -242,7 +242,7 @@ int main(int argc, char **argv)
         const std::string genomeName = genomeFile.substr(genomeFile.rfind('/') + 1);
         check(isaac_gpu_save_sorted_reference(ctx, outputDirectory.c_str(), genomeName.c_str(), contigs.data(), uint32_t(contigs.size())), "isaac_gpu_save_sorted_reference");
         isaac_gpu_destroy(ctx);
-        if (!quiet) std::cerr << "isaac-sort-reference: " << nEntries << " entries in " << outputDirectory << "/" << genomeName << "-32mer-6bit-*.dat, " << outputDirectory << "/sorted-reference.xml" << std::endl;
+        if (!quiet) std::cerr << "isaac-sort-reference: " << nEntries << " entries in " << outputDirectory << "/" << genomeName << "-32mer-6bit-ABCD-*.dat, " << outputDirectory << "/sorted-reference.xml" << std::endl;
         return 0;
     }
     catch (const std::exception &e)

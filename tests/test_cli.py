@@ -299,7 +299,7 @@ def test_gpu_isaac_align_end_to_end(tmp_path, scenario):
                    (names[i], i, i, fasta, meta[i][0], meta[i][1], len(stored[i]), sum(stored[i].count(b) for b in b"ACGT"), position, hashlib.md5(sequence).hexdigest())
             position += len(stored[i])
         files = sorted(f for f in os.listdir(ref_dir) if f.endswith(".dat"))
-        assert len(files) == 64 and files[5] == "genome.fa-32mer-6bit-05.dat" and [m.file.decode() for m in masks if m.seed_length == 32][5].endswith(files[5])
+        assert len(files) == 64 and files[5] == "genome.fa-32mer-6bit-ABCD-05.dat" and [m.file.decode() for m in masks if m.seed_length == 32][5].endswith(files[5])
         assert np.concatenate([np.fromfile(ref_dir / f, abi.REFERENCE_KMER_DTYPE) for f in files]).tobytes() == a.get_index().tobytes()
     else:
         karyotype = [2, 0, 1]                                                # stored contig i is the karyotype[i]-th of the karyotype
