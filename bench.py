@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-pcie-pass", action="store_true")
     ap.add_argument("--no-bam-pass", action="store_true")
     ap.add_argument("--no-neighbors", action="store_true")
+    ap.add_argument("--broadcast-index", action="store_true", help="with several GPUs: rank 0 builds the table, the others receive it over RCCL (default: every rank builds its own, in parallel)")
     ap.add_argument("--contexts", type=int, default=3, help="contexts (streams) per GPU that take the steps' selections in turn; they share the contigs and the table")
     ap.add_argument("--no-single-stream-pass", action="store_true", help="skip the extra pass of the same steps on one context (per-kernel times without sharing)")
     ap.add_argument("--launch-check", action="store_true", help="GPU-less check of the launcher and the collectives (gloo): no alignment")
@@ -157,7 +158,16 @@ def main():
     torch.cuda.empty_cache()
     al = gpu.Aligner(params, local_rank, genome, deferred_completion=True)   # back-to-back select calls overlap; al.synchronize() completes them
     t_genome = time.time() - t0
-    n_index = al.build_index(repeat_threshold=1000, annotate_neighbors=not args.no_neighbors)
+    if dist is not None and args.broadcast_index:
+        # one build, N - 1 transfers of the two arrays of the table (47 GB at this size) over xGMI
+        if rank == 0:
+            n_index = al.build_index(repeat_threshold=1000, annotate_neighbors=not args.no_neighbors)
+        shared_table = shard.broadcast_table(*(al.index_tensors() if rank == 0 else (None, None)), dist, rank, dev)
+        if rank != 0:
+            al.set_index_tensors(*shared_table)
+            n_index = int(shared_table[0].numel())
+    else:
+        n_index = al.build_index(repeat_threshold=1000, annotate_neighbors=not args.no_neighbors)
     t_index = time.time() - t0 - t_genome
     # More contexts on the same GPU, each on a stream of its own, sharing the contigs and the resident table (isaac_gpu_set_index_dev): the
     # selections of consecutive steps are handed to them in turn, so that kernels of different steps share the GPU -- the tail of a launch,

@@ -40,7 +40,7 @@ def test_gpu_bench_rccl_path_gives_the_same_records():
     args = ["--gpus", "1", "--steps", "3", "--warmup", "1", "--pairs-per-step", "60000", "--genome-bases", "30000000", "--no-pcie-pass", "--no-bam-pass", "--cpu-sample-pairs", "20000"]
     lines = []
     for env in ({}, {"ISAAC_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29617", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"}):
-        r = run(args, env=env)
+        r = run(args + (["--broadcast-index"] if env else []), env=env)          # the RCCL run also takes its table through shard.broadcast_table
         assert r.returncode == 0, r.stderr[-3000:]
         lines.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
     plain, dist = lines

@@ -143,3 +143,30 @@ def test_step_gather_collects_every_step_on_rank_0(tmp_path):
     (r0, c0), (r1, c1) = g.finish()
     assert r0[0] is r and (c0[0] == c).all() and c1[0].shape[0] == 2
 
+
+
+def _broadcast_table_worker(rank, world, port, result_path):
+    import torch.distributed as dist
+    from isaac_aligner_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(9)
+        want_k, want_p = torch.from_numpy(np.sort(rng.integers(0, 1 << 62, 100003))), torch.from_numpy(rng.integers(0, 1 << 62, 100003))
+        k, p = shard.broadcast_table(want_k if rank == 0 else None, want_p if rank == 0 else None, dist, rank, chunk=4096)      # 25 pieces per array
+        assert k.dtype == torch.int64 and (k == want_k).all() and (p == want_p).all()
+        if rank == 1:
+            open(result_path, "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_table_broadcast_from_rank_0(tmp_path):
+    """shard.broadcast_table (bench.py --broadcast-index: one index build, the two arrays of the table sent to the other ranks in pieces)"""
+    result = str(tmp_path / "result")
+    mp.spawn(_broadcast_table_worker, args=(2, _free_port(), result), nprocs=2, join=True)
+    assert open(result).read() == "ok"
+    from isaac_aligner_amd import shard
+    k = torch.arange(5)
+    assert shard.broadcast_table(k, k, None, 0)[0] is k
