@@ -16,7 +16,8 @@
 
 // optional in-kernel section stamps (-DISAAC_KERNEL_STAMPS): shader-clock ticks per section, summed over the sampled waves
 // (lane 0 of every wave of every 256th workgroup), printed when the context is destroyed.  A measuring aid, compiled out of
-// the product build.
+// the product build.  (The kernels are in several translation units now and g_stamps in one: the build needs -fgpu-rdc to link with this
+// macro; round 3 timed sections by leaving them out instead, -DISAAC_TIMING_BSW_NO_DP / _NO_TRACEBACK in bsw_kernel.h.)
 #if defined(ISAAC_KERNEL_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
 extern __device__ unsigned long long g_stamps[64];
 #define STAMP_BEGIN() long long stamp_t = clock64()
