@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Times the two programs end to end on a mid-sized case: a 100 Mbp human-like genome written as FASTA -> isaac-sort-reference -> 1 M
+synthetic 2x101 pairs written as two FASTQ files (plain) -> isaac-align with the reference's defaults.  Prints the stage lines of both
+programs.  CLI_GENOME_BASES (1e8), CLI_PAIRS (1e6)"""
+import os, subprocess, sys, tempfile, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from isaac_aligner_amd import build, synth
+
+def main():
+    n_bases, n_pairs, L = int(float(os.environ.get("CLI_GENOME_BASES", "1e8"))), int(float(os.environ.get("CLI_PAIRS", "1e6"))), 101
+    work = tempfile.mkdtemp(prefix="isaac_cli_")
+    dev = torch.device("cuda", 0)
+    genome = synth.make_human_like_genome(n_bases, seed=3, device=dev)
+    fasta = os.path.join(work, "genome.fa")
+    with open(fasta, "wb") as f:
+        for i, c in enumerate(genome.contigs if hasattr(genome, "contigs") else genome):
+            seq = c.cpu().numpy()
+            f.write(b">chr%d synthetic\n" % (i + 1))
+            full = len(seq) // 60 * 60
+            f.write(np.concatenate([seq[:full].reshape(-1, 60), np.full((full // 60, 1), 10, np.uint8)], axis=1).tobytes())
+            if len(seq) > full:
+                f.write(seq[full:].tobytes() + b"\n")
+    bcl = synth.make_read_pairs(genome, n_pairs, L, seed=11, device=dev, avoid_gaps=True)[0].cpu().numpy()
+    del genome
+    torch.cuda.empty_cache()
+    calls = os.path.join(work, "calls"); os.makedirs(calls)
+    t0 = time.time()
+    for read in range(2):
+        b = bcl[:, read * L:(read + 1) * L]
+        is_n = (b & 0xFC) == 0
+        bases = np.where(is_n, ord("N"), np.frombuffer(b"ACGT", np.uint8)[b & 3]).astype(np.uint8)
+        quals = np.where(is_n, 35, 33 + (b >> 2)).astype(np.uint8)
+        header = np.frombuffer(b"@M1:7:FCBENCH:1:1101:", np.uint8)
+        rows = []
+        digits = np.char.zfill(np.arange(n_pairs).astype(str), 8).astype("S8").view(np.uint8).reshape(n_pairs, 8)
+        nl = np.full((n_pairs, 1), ord("\n"), np.uint8); plus = np.full((n_pairs, 1), ord("+"), np.uint8)
+        text = np.concatenate([np.tile(header, (n_pairs, 1)), digits, nl, bases, nl, plus, nl, quals, nl], axis=1)
+        text.tofile(os.path.join(calls, "lane1_read%d.fastq" % (read + 1)))
+    print("FASTQ written in %.1f s (%d MB)" % (time.time() - t0, 2 * n_pairs * (21 + 8 + 4 + 2 * L) // 1000000), flush=True)
+    ref_dir = os.path.join(work, "ref")
+    tools = os.path.dirname(build.build_host())
+    for name, cmd in (("isaac-sort-reference", [os.path.join(tools, "isaac-sort-reference"), "-g", fasta, "-o", ref_dir, "-q"]),
+                      ("isaac-align", [os.path.join(tools, "isaac-align"), "-r", os.path.join(ref_dir, "sorted-reference.xml"), "-b", calls, "--base-calls-format", "fastq", "-o", os.path.join(work, "Aligned")])):
+        t0 = time.time()
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        print("%s: rc %d, %.1f s" % (name, r.returncode, time.time() - t0))
+        print("\n".join(l for l in r.stderr.splitlines() if "done in" in l or "records" in l or "clusters in" in l or "error" in l.lower()), flush=True)
+    bam = os.path.join(work, "Aligned", "Projects", "default", "default", "sorted.bam")
+    print("sorted.bam %d MB, .bai %d KB" % (os.path.getsize(bam) // 1000000, os.path.getsize(bam + ".bai") // 1000))
+    subprocess.run(["rm", "-rf", work])
+
+main()
