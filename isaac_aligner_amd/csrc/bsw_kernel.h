@@ -209,7 +209,7 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
     {
         // end-cell scan (:349-379), traceback (:381-435), stripping of the terminal deletions (:437-453).  All 8 lanes of the group
         // walk the traceback together (the same values in every lane; lane 0 does the stores): a stretch of ALIGN cells whose flags
-        // say "came from ALIGN" -- nearly all of a typical alignment -- is crossed 8 rows at a time, every lane looking at one row,
+        // say "came from ALIGN" -- nearly all of a typical alignment -- is crossed 16 rows at a time, every lane looking at two rows,
         // instead of one dependent LDS read per row.
         const u32 first = n;
         int mx = s16(int(u16(endVals[15])) - 1);
@@ -228,10 +228,11 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
         {
             if (0 == maxType)
             {
-                const int row = ii - int(l);
-                const bool stop = row < 0 || 0 != (flagsAt(row, jj) & 3);
-                const u32 mask = u32(__ballot(stop) >> groupShift) & 0x5555u;
-                const u32 run = mask ? (u32(__ffs(int(mask))) - 1) >> 1 : 8u;
+                // lane l looks at rows ii - 2l and ii - 2l - 1: bit t of `mask` says that row ii - t ends the run
+                const int row = ii - 2 * int(l);
+                const bool stop0 = row < 0 || 0 != (flagsAt(row, jj) & 3), stop1 = row < 1 || 0 != (flagsAt(row - 1, jj) & 3);
+                const u32 mask = (u32(__ballot(stop0) >> groupShift) & 0x5555u) | ((u32(__ballot(stop1) >> groupShift) & 0x5555u) << 1);
+                const u32 run = mask ? u32(__ffs(int(mask))) - 1 : 16u;
                 opLength += run; ii -= int(run);
                 if (!mask) continue;
                 if (ii < 0) break;
