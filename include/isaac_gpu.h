@@ -278,7 +278,7 @@ int isaac_gpu_compact_cigars(isaac_gpu_ctx *ctx, isaac_fragment *fragments_dev, 
 int isaac_gpu_compact_cigars_async(isaac_gpu_ctx *ctx, isaac_fragment *fragments_dev, uint64_t n_records, const uint32_t *cigar_in_dev,
                                    uint32_t *cigar_out_dev, uint64_t capacity, uint64_t *n_words_out_dev);
 
-/* The output side of the path for --realign-gaps no: the BAM alignment records build::Build writes
+/* The output side of the path: the BAM alignment records build::Build writes
  * (lib/build/Build.cpp, lib/build/BinSorter.cpp) from what isaac_gpu_select produced, computed where the records already are.
  *   order    PackedFragmentBuffer::orderForBam (include/build/PackedFragmentBuffer.hh:149-176): bin position, global cluster id
  *            (tile * 1000000000 + cluster, include/build/FragmentIndex.hh:33), mapped before unmapped (a shadow follows its

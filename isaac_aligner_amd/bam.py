@@ -1,5 +1,5 @@
 """Host-side mirror of the BAM output boundary (include/isaac_gpu.h: isaac_gpu_bam_records / isaac_gpu_bam_header /
-isaac_gpu_bgzf_compress): what build::Build writes for --realign-gaps no --mark-duplicates 0
+isaac_gpu_bgzf_compress, isaac_gpu_bam_index): what build::Build writes
 (reference: lib/build/Build.cpp, include/bam/Bam.hh, include/bgzf/BgzfCompressor.hh)."""
 import ctypes as C
 import os

@@ -1,7 +1,7 @@
 // BAM alignment records on the device: what build::Build serialises per bin with bam::serializeAlignment over
 // build::FragmentAccessorBamAdapter (include/bam/Bam.hh:257-345, include/build/FragmentAccessorBamAdapter.hh:62-377), in the order of
-// PackedFragmentBuffer::orderForBam (include/build/PackedFragmentBuffer.hh:149-176), for --realign-gaps no --mark-duplicates 0
-// --bam-exclude-tags ZX,ZY (the default tag set: SM AS RG NM BC).
+// PackedFragmentBuffer::orderForBam (include/build/PackedFragmentBuffer.hh:149-176), with duplicate marking and gap realignment when asked
+// for (further down), and --bam-exclude-tags ZX,ZY (the default tag set: SM AS RG NM BC, OC on realigned records).
 //
 // The records of all tiles of a call are ordered together: 128-bit keys (position | global cluster id, unmapped, second read) sorted by
 // two stable radix passes; record sizes are scanned in that order; every record is then written where it belongs, one thread each.

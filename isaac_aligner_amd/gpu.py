@@ -321,7 +321,7 @@ class Aligner:
 
     # ---- output format --------------------------------------------------------------------------------------------
     def bam_records(self, tiles, out=None, read_group=None, barcode=None, forced_dodgy_alignment_score=None, pessimistic_mapq=False, mark_duplicates=False, keep_duplicates=True, realign_gaps=False, tls=None):
-        """build::Build's BAM alignment records (--realign-gaps no --mark-duplicates 0) of one or more tiles, in file order.
+        """build::Build's BAM alignment records of one or more tiles, in file order (mark_duplicates / keep_duplicates / realign_gaps: BinSorter's steps before the order).
         tiles: [(bcl, records, cigars, read_name_prefix[, read_group[, tls]])] as given to / returned by select().  Returns (uint8 device tensor of the
         uncompressed records, number of records, offset of the unaligned bin)."""
         from . import bam

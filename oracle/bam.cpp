@@ -1,5 +1,5 @@
 // ORACLE -- TEST INFRASTRUCTURE ONLY (see oracle/README.md).  CPU restatement of the BAM side of the path for
-// --realign-gaps no, --mark-duplicates 0 | 1, --keep-duplicates 0 | 1 and the default tag set (--bam-exclude-tags ZX,ZY):
+// --realign-gaps no | sample, --mark-duplicates 0 | 1, --keep-duplicates 0 | 1 and the default tag set (--bam-exclude-tags ZX,ZY):
 //   gap realignment (--realign-gaps sample)    lib/build/BinSorter.cpp:387-417 around realign.cpp (GapRealigner), every contig one bin
 //   duplicate marking                          lib/build/BinSorter.cpp:293-330, include/build/DuplicateFragmentIndexFiltering.hh:37-208,
 //                                              include/build/DuplicatePairEndFilter.hh:45-107, include/io/Fragment.hh:66-71,490-506

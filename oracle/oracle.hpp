@@ -684,7 +684,7 @@ struct MatchSelector
 unsigned fastqTileClustersMax(unsigned clustersAtATimeMax, unsigned seedCount);
 void fastqDiscoverTiles(unsigned clustersLoaded, unsigned tileClustersMax, unsigned &currentTile, std::vector<std::pair<unsigned, unsigned> > &loadedTiles);
 
-// bam.cpp: the BAM record stream of a set of tiles (build::Build with --realign-gaps no --mark-duplicates 0) and the BAM header
+// bam.cpp: the BAM record stream of a set of tiles (build::Build: duplicates, gap realignment, order, serialisation) and the BAM header
 struct BamTileInput { const uint8_t *bcl; const FragmentRecord *records; const uint32_t *cigars; uint64_t nRecords; std::string namePrefix;
                       std::string readGroup;                        // the barcode index of the tile's lane (FragmentAccessorBamAdapter::getFragmentRG); empty: BamOptions::readGroup
                       const TemplateLengthStatistics *tls = 0; };   // of the tile's barcode; NULL: BamOptions::tls
