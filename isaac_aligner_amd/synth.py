@@ -147,6 +147,29 @@ def make_read_pairs(contigs, n_pairs, read_length=150, seed=2, device=None, inse
     return bcl.contiguous(), truth
 
 
+def make_sample_with_indels(contigs, rng, spacing=(250, 550), max_indel=8):
+    """A sample's chromosomes: the reference's contigs (ASCII, anything np.frombuffer / np.asarray takes) with an indel of
+    1..max_indel bases every spacing[0]..spacing[1] bases, half deletions and half insertions; reads drawn from it show the indels as
+    gaps, and the ones that cross an indel near one of their ends are the gap realigner's work.  rng is a numpy Generator."""
+    import numpy as np
+    sample = []
+    for c in contigs:
+        seq = np.frombuffer(c, np.uint8) if isinstance(c, (bytes, bytearray)) else np.asarray(c.cpu() if hasattr(c, "cpu") else c, dtype=np.uint8)
+        pieces, at = [], 0
+        while at < len(seq):
+            step = int(rng.integers(spacing[0], spacing[1]))
+            pieces.append(seq[at:at + step]); at += step
+            if at >= len(seq):
+                break
+            n = int(rng.integers(1, max_indel + 1))
+            if rng.random() < 0.5:
+                at += n                                                  # deletion from the reference
+            else:
+                pieces.append(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)])     # insertion
+        sample.append(torch.from_numpy(np.concatenate(pieces)))
+    return sample
+
+
 def bcl_to_fastq(bcl, read_offset, read_length, name="r", newline=b"\n", plus_header=False):
     """FASTQ text of one read of a BCL tile (numpy uint8 [n, cluster_length]); N for quality-0 bytes.  The inverse of
     isaac_gpu_fastq_to_bcl for bytes whose quality is not 0."""

@@ -352,21 +352,7 @@ def test_gpu_gap_realignment_matches_the_oracle():
     L = 100
     genome = synth.make_genome(200000, seed=61, n_contigs=2, repeat_families=False)
     contigs = [bytes(c.numpy()) for c in genome]
-    sample = []
-    for c in genome:                                                     # the sample's chromosomes: an indel of 1-8 bases every ~400 bases
-        seq = c.numpy().copy()
-        pieces, at = [], 0
-        while at < len(seq):
-            step = int(rng.integers(250, 550))
-            pieces.append(seq[at:at + step]); at += step
-            if at >= len(seq):
-                break
-            n = int(rng.integers(1, 9))
-            if rng.random() < 0.5:
-                at += n                                                  # deletion from the reference
-            else:
-                pieces.append(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)])     # insertion
-        sample.append(torch.from_numpy(np.concatenate(pieces)))
+    sample = synth.make_sample_with_indels(genome, rng)                  # the sample's chromosomes: an indel of 1-8 bases every ~400 bases
     params = options.default_params(L, L)
     a = gpu.Aligner(params, 0, contigs)
     a.build_index()

@@ -320,21 +320,7 @@ def test_gpu_isaac_align_end_to_end(tmp_path, scenario):
     del a
     # two lanes (1 and 3) of one flowcell, read from a sample that carries an indel every ~400 bases (reads that cross one near their end
     # can borrow the gap from the reads that show it: work for the realigner); a tenth of the fragments of lane 1 sequenced twice
-    sample = []
-    for c in contigs:
-        seq = np.frombuffer(c, np.uint8)
-        pieces, at = [], 0
-        while at < len(seq):
-            step = int(rng.integers(250, 550))
-            pieces.append(seq[at:at + step]); at += step
-            if at >= len(seq):
-                break
-            n = int(rng.integers(1, 9))
-            if rng.random() < 0.5:
-                at += n
-            else:
-                pieces.append(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)])
-        sample.append(torch.from_numpy(np.concatenate(pieces)))
+    sample = synth.make_sample_with_indels(contigs, rng)
     lanes = []
     for lane, n_pairs, seed in ((1, 14000, 62), (3, 9000, 63)):
         bcl = synth.make_read_pairs(sample, n_pairs, file_length, seed=seed, indel_read_fraction=0.01, n_rate=0.002)[0].numpy()

@@ -92,6 +92,11 @@ def align_and_compare(torch, oracle, human, L, tile, **read_kw):
     gbam = al.bam_records([(bcl, records, packed, prefix)])[0].cpu().numpy().tobytes()
     obam = oracle.bam_records([(host_bcl, orec, ocig, prefix)], [L, L], forced_dodgy_alignment_score=p.dodgy_alignment_score & 0xff)[0]
     assert gbam == obam
+    # the same with the reference's defaults for the BAM stage: --mark-duplicates 1 --keep-duplicates 1 --realign-gaps sample
+    gbam, n, un = al.bam_records([(bcl, records, packed, prefix)], mark_duplicates=True, keep_duplicates=True, realign_gaps=True, tls=tls)
+    obam, on, oun = oracle.bam_records([(host_bcl, orec, ocig, prefix)], [L, L], forced_dodgy_alignment_score=p.dodgy_alignment_score & 0xff, mark_duplicates=True, keep_duplicates=True,
+                                       realign_gaps=True, clip_semialigned=True, reference=ref, tls=otls)
+    assert (n, un) == (on, oun) and gbam.cpu().numpy().tobytes() == obam
     return counters, grec
 
 
@@ -127,6 +132,59 @@ def test_compact_cigars_retry_with_a_pool_that_is_too_small(torch, human):
     got, n_got = al.compact_cigars(records, cigars, out=small)              # the wrapper's retry path: allocates what the first call reported
     assert n_got == n_want and (got == want).all()
     assert isinstance(gpu.IsaacGpuError("x"), RuntimeError)
+
+
+def test_bam_stage_defaults_on_deep_coverage(torch, oracle):
+    """Duplicate marking and gap realignment where they have work to do, at the size of a launch: half a million pairs of a sample that
+    carries an indel every ~400 bases over a 2 Mbp reference (50-fold coverage, so every indel is shown by tens of reads and crossed near
+    a read end by as many; a tenth of the fragments sequenced twice), isaac_gpu_bam_records with the reference's defaults against the oracle,
+    byte for byte."""
+    from isaac_aligner_amd import gpu
+    L, n_pairs = 100, int(os.environ.get("ISAAC_SCALE_DEEP_PAIRS", 500_000))
+    rng = np.random.default_rng(23)
+    genome = synth.make_genome(2_000_000, seed=67, n_contigs=3, repeat_families=True)
+    contigs = [bytes(c.numpy()) for c in genome]
+    sample = synth.make_sample_with_indels(genome, rng)
+    p = options.default_params(L, L)
+    al = gpu.Aligner(p, 0, contigs)
+    al.build_index()
+    ref = oracle.reference(contigs)
+    ref.set_index(al.get_index())
+    host_bcl = synth.make_read_pairs(sample, n_pairs, L, seed=91, indel_read_fraction=0.0, subst_rate=0.004)[0].numpy()
+    twice = n_pairs // 10
+    host_bcl[n_pairs - twice:] = host_bcl[rng.integers(0, n_pairs - twice, twice)]
+    bcl = torch.from_numpy(host_bcl).cuda()
+    matches, offsets, hits = al.find_matches(bcl, tile=2)
+    al.set_loaded_contigs(hits)
+    tls = al.determine_tls(bcl, matches, offsets, tile=2)
+    records, cigars = al.select(bcl, matches, offsets, tls, tile=2)
+    al.synchronize()
+    packed, _ = al.compact_cigars(records, cigars)
+    cores = os.cpu_count() or 1
+    om, ohits = ref.find_matches(p, host_bcl, n_pairs, tile=2, n_threads=min(cores, 64))
+    otls = ref.determine_tls(p, host_bcl, om, ohits, tile=2)
+    assert otls.astuple() == tls.astuple()
+    orec, ocig, _ = ref.select(p, host_bcl, om, otls, ohits, tile=2, n_threads=cores, n_clusters_hint=n_pairs)
+    grec = records.cpu().numpy().view(abi.FRAGMENT_DTYPE).reshape(-1)
+    n_diff, text = count_record_diffs(orec, ocig, grec, packed.cpu().numpy().view(np.uint32))
+    assert n_diff == 0, "\n".join(text)
+    prefix = "DEEP:1:2:"
+    dodgy = p.dodgy_alignment_score & 0xff
+    plain = oracle.bam_records([(host_bcl, orec, ocig, prefix)], [L, L], forced_dodgy_alignment_score=dodgy)[0]
+    for mark, keep in ((True, True), (True, False)):
+        got, n, un = al.bam_records([(bcl, records, packed, prefix)], mark_duplicates=mark, keep_duplicates=keep, realign_gaps=True, tls=tls)
+        want, wn, wun = oracle.bam_records([(host_bcl, orec, ocig, prefix)], [L, L], forced_dodgy_alignment_score=dodgy, mark_duplicates=mark, keep_duplicates=keep,
+                                           realign_gaps=True, clip_semialigned=True, reference=ref, tls=otls)
+        assert (n, un) == (wn, wun)
+        assert got.cpu().numpy().tobytes() == want
+        if keep:
+            from isaac_aligner_amd import bam
+            a, b = bam.parse_records(plain), bam.parse_records(want)
+            by_name = {(r["name"], r["flag"] & 0xc0): r for r in a}
+            n_dup = sum(1 for r in b if r["flag"] & 0x400)
+            n_moved = sum(1 for r in b if list(by_name[(r["name"], r["flag"] & 0xc0)]["cigar"]) != list(r["cigar"]))
+            assert n_dup > twice and n_moved > n_pairs // 500, (n_dup, n_moved)
+    al.close()
 
 
 # ---- the index ------------------------------------------------------------------------------------------------------------------------
