@@ -1202,7 +1202,7 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         }
         {
             ScopedTimer tm(c, "rescue_windows");
-            k_rescue_windows<<<gridFor(rb.jobsCap, 4), 256, 0, st>>>(c->P, R, c->hContigOffset[c->nContigs], bcl, done, rb);
+            k_rescue_windows<<<gridFor(rb.jobsCap, RW_WAVES), 64 * RW_WAVES, 0, st>>>(c->P, R, c->hContigOffset[c->nContigs], bcl, done, rb);
             HIP_CHECK(hipGetLastError());
         }
         {

@@ -72,6 +72,10 @@ struct AlignList { u32 *entries; u32 cap; u32 *counter; };
 static const u32 KMER_EMPTY = 0xffffffffu;
 static const u32 RW_TABLE = 512;          // hash slots for the mate's <= 250-odd 7-mers
 static const u32 RW_PRESENT_WORDS = 512;  // one bit per possible 7-mer: does the mate have it?
+#ifndef ISAAC_RW_WAVES
+#define ISAAC_RW_WAVES 1
+#endif
+static const u32 RW_WAVES = ISAAC_RW_WAVES;   // wavefronts per workgroup of k_rescue_windows
 static const u32 RW_LDS_BITMAP = 64;      // words: windows up to ~1900 bases keep their candidate bitmap in LDS
 #ifndef ISAAC_RW_PER_LANE
 #define ISAAC_RW_PER_LANE 8
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGME
 __global__ __launch_bounds__(64) void k_indel_fragments(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, int withGaps, const u32 *indelList, const u32 *indelCount, FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters);
 __global__ __launch_bounds__(64) void k_finish_fragments(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, u32 nChunk, int withGaps, FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters);
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_PLAN_WAVES))) void k_plan_rescue(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk, ClusterPools pools, RescueBuffers rb);
-__global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReference R, u64 totalBases, const u8 *bcl, u32 clusterBase, RescueBuffers rb);
+__global__ __launch_bounds__(64 * RW_WAVES) void k_rescue_windows(DevParams P, DevReference R, u64 totalBases, const u8 *bcl, u32 clusterBase, RescueBuffers rb);
 __global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, ClusterPools pools, RescueBuffers rb, Counters *counters);
 __global__ __launch_bounds__(256) void k_rescue_gapped_plan(ClusterPools pools, RescueBuffers rb, GappedBuffers gb, u32 *longList, u32 *longCount, Counters *counters);
 __global__ __launch_bounds__(256) void k_rescue_gapped_plan_long(ClusterPools pools, RescueBuffers rb, GappedBuffers gb, const u32 *longList, const u32 *longCount);

@@ -7,10 +7,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_PLAN_W
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nChunk) return;
     const ClusterFragments f = clusterView(pools.meta[t], pools.cands, pools.cigars);
+    // (Round 3 tried this work area -- and the private copies of short candidate lists -- in a per-cluster slice of a global arena, so that a
+    // lane's fields share cache lines instead of lying 256 bytes apart in lane-interleaved scratch: the work area made no difference
+    // (select 3.46 -> 3.48 ms, plan 2.34 -> 2.32), the candidate copies were slower there (3.76 / 2.51): the scratch traffic of these two
+    // kernels is the compiler's own spills and temporaries, not these arrays.)
     __attribute__((aligned(16))) u8 workBytes[TINY_WORK_BYTES];
+    Cand privateCands[2 * PRIVATE_CANDS];
     TemplateWork work;
     templateWorkBind(work, workBytes, tinyCaps());
-    Cand privateCands[2 * PRIVATE_CANDS];
     // Every seeded candidate is an orphan at most once, so their number bounds the cluster's rescue problems: the slots are
     // reserved first and the template logic runs once, writing the problems as it meets them (unused slots stay invalid)
     const u32 reserve = f.built ? f.nCands[0] + f.nCands[1] : 0;
@@ -42,23 +46,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_PLAN_W
 }
 
 
-// The bases of window positions [g, g + RW_PER_LANE + 6) for one lane: their 2-bit codes (position g in the low bits) and their
-// not-ACGT flags, from the packed copy of the reference.  g is an index into the concatenated contigs.
+// The bases of window positions [g, g + 32) for one lane: their 2-bit codes (position g in the low bits) and their not-ACGT flags, from
+// the packed copy of the reference.  g is an index into the concatenated contigs.  (Three words and two funnel shifts: the third
+// word is not needed when g is a multiple of 16, but a branch around one load costs more than the load.)
 struct WindowBits { u64 codes; u32 notBase; };
 __device__ inline WindowBits loadWindowBits(const DevReference &R, u64 g)
 {
     WindowBits w;
     g = g < R.totalBases ? g : R.totalBases;          // lanes past the end of a window that ends the reference: read the spare words
     const u32 *pw = R.packedBases + (g >> 4);
+    const u32 w0 = pw[0], w1 = pw[1], w2 = pw[2];
     const u32 shift = 2 * u32(g & 15);
-    const u64 lo = u64(pw[0]) | (u64(pw[1]) << 32);
-    w.codes = shift ? (lo >> shift) | (u64(pw[2]) << (64 - shift)) : lo;             // 2 * (RW_PER_LANE + 6) bits wanted, up to 30 shifted out
+    w.codes = u64(__builtin_amdgcn_alignbit(w1, w0, shift)) | (u64(__builtin_amdgcn_alignbit(w2, w1, shift)) << 32);
     const u32 *pn = R.notBase + (g >> 5);
-    const u32 ns = u32(g & 31);
-    w.notBase = u32((u64(pn[0]) | (u64(pn[1]) << 32)) >> ns);
+    w.notBase = __builtin_amdgcn_alignbit(pn[1], pn[0], u32(g & 31));
     return w;
 }
-static_assert(2 * (RW_PER_LANE + 6) <= 64 && RW_PER_LANE + 6 <= 32, "a lane's window bases fit the two words loadWindowBits returns");
+static_assert(RW_PER_LANE + 6 <= 32, "a lane's window bases fit the words loadWindowBits returns");
 
 // k_rescue_windows: one wave per rescue problem (ShadowAligner::findShadowCandidatePositions, ShadowAligner.cpp:53-112).
 // The mate's 7-mers go to an LDS hash table (first read position per k-mer).  The window is walked in tiles of 64 x RW_PER_LANE bases:
@@ -133,34 +137,84 @@ __device__ inline void rescueWindowScan(const DevReference &R, const RescueJob &
 // once per position and lane *for the whole wave*; here they run for the few hits.  The reference's "push unless equal to the previous
 // candidate" only decides how many entries its position list holds before sort + unique; that number cannot reach the list's capacity in
 // a window this short, and the set of candidates is the same without it.
+typedef const __attribute__((address_space(3))) u32 LdsWord;
+static const u32 RW_DENSE_HITS = 6;
+// the lane that holds tile position q when every lane holds PL consecutive ones (q < 64 * PL <= 1024)
+template <u32 PL> __device__ inline u32 tileLaneOf(u32 q)
+{
+    static_assert(PL == 8 || PL == 12 || PL == 16, "tile sizes of rescueWindowScanShort");
+    return PL == 8 ? q >> 3 : PL == 16 ? q >> 4 : __umul24(q, 43691u) >> 19;       // q / 12 for q < 2^16
+}
+// one window position whose 7-mer the mate has: the mate's first position with it, and the candidate that puts it there
+__device__ inline void rescueWindowHit(u32 kmer, i32 biasedPosition, const u32 *tab, u32 *bitmap)
+{
+    u32 h = (kmer * 2654435761u) >> 23, e = tab[h];
+    while ((e >> 10) != kmer) { h = (h + 1) & (RW_TABLE - 1); e = tab[h]; }            // the k-mer is in the table
+    const u32 bit = u32(biasedPosition - i32(e & 0x3ffu));
+    atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
+}
+template <u32 PL>
 __device__ inline void rescueWindowScanShort(const DevReference &R, const RescueJob &job, u64 windowBase, const WindowBits &firstTile, u32 L, const u32 *tab, const u32 *present,
                                              u32 *bitmap, u32 lane)
 {
+    static_assert(PL <= 16, "a lane's bit offsets 2k stay below 32");
     const i32 bias = i32(L) - 7;
     const i32 lastStart = i32(job.windowLen) - 7;       // last valid k-mer start
-    for (i32 tile = 0; tile * RW_TILE <= lastStart; ++tile)
+    const u32 presentBase = u32(size_t((LdsWord *)present));               // a multiple of 2048: OR instead of ADD
+    for (i32 tile = 0; tile * i32(64 * PL) <= lastStart; ++tile)
     {
-        const i32 p0 = tile * RW_TILE + i32(lane) * i32(RW_PER_LANE);          // window position of this lane's first base
+        const i32 p0 = tile * i32(64 * PL) + i32(lane * PL);               // window position of this lane's first base
         const WindowBits wb = tile ? loadWindowBits(R, windowBase + u64(p0)) : firstTile;
-        u32 words[RW_PER_LANE];
+        const u32 lo = u32(wb.codes), hi = u32(wb.codes >> 32);
+        // five vector instructions per position: the word's LDS address (bits 2k+5 .. 2k+13 of the codes, times four, into the map's
+        // base), the bit's number (the shifter takes the low five bits of bits 2k ..), the shift, and the bit into the mask
+        u32 words[PL];
 #pragma unroll
-        for (u32 k = 0; k < RW_PER_LANE; ++k) words[k] = present[(u32(wb.codes >> (2 * k)) & 0x3fffu) >> 5];
-        u32 hitMask = 0;
-#pragma unroll
-        for (u32 k = 0; k < RW_PER_LANE; ++k)
+        for (u32 k = 0; k < PL; ++k)
         {
-            const u32 kmer = u32(wb.codes >> (2 * k)) & 0x3fffu;
-            const bool valid = p0 + i32(k) <= lastStart && !((wb.notBase >> k) & 0x7fu);
-            hitMask |= (valid && ((words[k] >> (kmer & 31u)) & 1u)) ? 1u << k : 0u;
+            const u32 s = 2 * k + 3;
+            const u32 x = s + 11 <= 32 ? lo >> s : s < 32 ? __builtin_amdgcn_alignbit(hi, lo, s) : hi >> (s - 32);
+            words[k] = *(LdsWord *)size_t((x & 0x7fcu) | presentBase);
         }
-        while (hitMask)
+        // positions whose seven bases are all ACGT and which start a k-mer inside the window
+        u32 inv = wb.notBase; inv |= inv >> 1; inv |= inv >> 2; inv |= inv >> 3;
+        const i32 nValid = imin(imax(lastStart - p0 + 1, 0), i32(PL));
+        const u32 valid = ~inv & ((1u << nValid) - 1u);
+        u32 h = 0;
+#pragma unroll
+        for (u32 k = 0; k < PL; ++k)
         {
-            const u32 k = u32(__ffs(hitMask)) - 1; hitMask &= hitMask - 1;
-            const u32 kmer = u32(wb.codes >> (2 * k)) & 0x3fffu;
-            u32 h = (kmer * 2654435761u) >> 23, e = tab[h];
-            while ((e >> 10) != kmer) { h = (h + 1) & (RW_TABLE - 1); e = tab[h]; }            // the k-mer is in the table
-            const u32 bit = u32(p0 + i32(k) - i32(e & 0x3ffu) + bias);
-            atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
+            const u32 t = k == 0 ? lo : 2 * k + 5 <= 32 ? lo >> (2 * k) : __builtin_amdgcn_alignbit(hi, lo, 2 * k);
+            h = __builtin_amdgcn_alignbit(words[k] >> (t & 31u), h, 1);    // bit k ends at 32 - PL + k
+        }
+        u32 hitMask = (h >> (32 - PL)) & valid;
+        // Where the mate really lies every position hits: a dozen neighbouring lanes with PL hits each, and a wave that walks its
+        // lanes' hits one by one makes PL passes for them.  Then the hits are dealt out again, lane l taking tile positions l, l + 64,
+        // ...: a run of consecutive hits comes to two or three per lane.
+        if (__ballot(__popc(hitMask) > RW_DENSE_HITS) == 0)
+            while (hitMask)
+            {
+                const u32 k = u32(__ffs(hitMask)) - 1; hitMask &= hitMask - 1;
+                rescueWindowHit(u32(wb.codes >> (2 * k)) & 0x3fffu, p0 + i32(k) + bias, tab, bitmap);
+            }
+        else
+        {
+            u32 mine = 0;                                                  // bit t: tile position t * 64 + lane hits
+#pragma unroll
+            for (u32 t = 0; t < PL; ++t)
+            {
+                const u32 q = t * 64 + lane, l = tileLaneOf<PL>(q), k = q - l * PL;
+                mine = __builtin_amdgcn_alignbit(u32(__shfl(hitMask, l, 64)) >> k, mine, 1);
+            }
+            mine >>= 32 - PL;
+            while (__ballot(mine != 0))                                    // every lane stays in the loop: the exchanges read all lanes
+            {
+                const bool have = mine != 0;
+                const u32 t = have ? u32(__ffs(mine)) - 1 : 0; mine &= mine - 1;
+                const u32 q = t * 64 + lane, l = tileLaneOf<PL>(q), k = q - l * PL;
+                const u64 codes = u64(u32(__shfl(lo, l, 64))) | (u64(u32(__shfl(hi, l, 64))) << 32);
+                if (have) rescueWindowHit(u32(codes >> (2 * k)) & 0x3fffu, tile * i32(64 * PL) + i32(q) + bias, tab, bitmap);
+            }
         }
     }
 }
@@ -171,36 +225,34 @@ __device__ inline void rescueWindowScanShort(const DevReference &R, const Rescue
 // (A resident grid of 16 K wavefronts striding over the problem slots -- two slots in three are empty, they are reserved per seeded
 // candidate -- was measured slower, 8.0 against 6.4 ms per 1 M clusters: the windows differ in length and the hardware's own wave
 // scheduling balances them better.)
-__global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReference R, u64 totalBases, const u8 *bcl, u32 clusterBase, RescueBuffers rb)
+__device__ inline void rescueWindowsProblem(const DevParams &P, const DevReference &R, const u8 *bcl, u32 clusterBase, const RescueBuffers &rb, u32 j, u32 lane,
+                                            u32 *tab, u32 *ldsBitmap, u32 *present)
 {
-    __shared__ u32 tables[4][RW_TABLE];
-    __shared__ u32 ldsBitmaps[4][RW_LDS_BITMAP];
-    __shared__ __align__(16) u32 presentMaps[4][RW_PRESENT_WORDS];
-    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const u32 j = blockIdx.x * 4 + wave;
+    const RescueJob job = rb.jobs[imin(j, rb.jobsCap - 1)];
     const u32 nJobs = imin(*rb.jobCounter, rb.jobsCap);
-    RescueJob job;
-    bool active = j < nJobs;
     STAMP_BEGIN();
-    if (active) { job = rb.jobs[j]; active = job.valid && !job.fallback; }
+    const bool active = j < nJobs && job.valid && !job.fallback;
     STAMP(0);
-    u32 pushes = 0, total = 0, bitmapWords = 0, L = 0;
+    if (!active) return;
+    u32 pushes = 0, total = 0, bitmapWords = 0, L = 0, smallWord = 0, smallIncl = 0;
     bool small = true;
-    u32 *bitmap = ldsBitmaps[wave];
+    u32 *bitmap = ldsBitmap;
     if (active)
     {
         // the lane's bytes of the first window tile are requested now and used after the k-mer table is built: one memory
         // latency instead of two in a row
-        const u64 windowBase = R.contigOffset[job.contigId] + u64(job.windowBegin);      // windowBegin >= 0 (planRescue)
-        const WindowBits firstTile = loadWindowBits(R, windowBase + lane * RW_PER_LANE);
-        u32 *tab = tables[wave];
-        for (u32 i = lane; i < RW_TABLE; i += 64) tab[i] = KMER_EMPTY;
         const u32 r = job.shadowReadIndex;
         L = P.readLength[r];
         bitmapWords = (job.windowLen + L + 31) / 32;
         small = bitmapWords <= RW_LDS_BITMAP;
+        // positions per lane and tile: the windows of a run are nearly all one length (the template length model's), and a tile that
+        // covers the window in one go keeps every lane busy (8 per lane left the second tile of a 710-base window 60 % empty)
+        const u32 nStarts = job.windowLen > 6 ? job.windowLen - 6 : 0;
+        const u32 perLane = __builtin_amdgcn_readfirstlane(!small ? RW_PER_LANE : nStarts <= 64 * 8 ? 8u : nStarts <= 64 * 12 ? 12u : 16u);
+        const u64 windowBase = rescueJobWindowBase(job);
+        const WindowBits firstTile = loadWindowBits(R, windowBase + lane * perLane);
+        for (u32 i = lane; i < RW_TABLE; i += 64) tab[i] = KMER_EMPTY;
         if (!small) bitmap = rb.bitmaps + job.bitmapBase;
-        u32 *present = presentMaps[wave];
         if (small) for (u32 i = lane; i < RW_PRESENT_WORDS / 4; i += 64) reinterpret_cast<uint4 *>(present)[i] = make_uint4(0, 0, 0, 0);
         for (u32 i = lane; i < bitmapWords; i += 64) bitmap[i] = 0;
         if (!small) __threadfence();
@@ -227,17 +279,27 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
                 if (s0 + 8 <= L) memcpy(&bytes, read.bcl + (L - 8 - s0), 8);
                 else { memcpy(&bytes, read.bcl, 8); bytes <<= 8 * (s0 + 8 - L); }
             }
+            // eight bytes at once: strand position s0 + t in byte t, the complement for the reverse strand, then per byte the code
+            // base ^ (base >> 1) and "no quality bits", and the fields of four bytes gathered with shifts
+            if (reverse) bytes = __builtin_bswap64(bytes) ^ 0x0303030303030303ull;
             u32 codes = 0, ns = 0;
 #pragma unroll
-            for (u32 t = 0; t < 8; ++t)
+            for (u32 half = 0; half < 2; ++half)
             {
-                const u32 b = u32(bytes >> (8 * (reverse ? 7 - t : t))) & 0xffu;
-                const u32 base = (b & 3u) ^ (reverse ? 3u : 0u);
-                codes |= (base ^ (base >> 1)) << (2 * t);
-                ns |= ((b & 0xfcu) == 0 ? 1u : 0u) << t;
+                const u32 x = u32(bytes >> (32 * half));
+                const u32 base = x & 0x03030303u;
+                const u32 c = base ^ ((base >> 1) & 0x01010101u);
+                u32 y = (c | (c >> 6)) & 0x000f000fu;                      // bytes 0, 1 -> bits 0-3; bytes 2, 3 -> bits 16-19
+                y = (y | (y >> 12)) & 0xffu;
+                // a byte's quality is 0..63: adding 63 sets bit 6 unless it is 0
+                u32 n = ((((x >> 2) & 0x3f3f3f3fu) + 0x3f3f3f3fu) & 0x40404040u) ^ 0x40404040u;
+                n >>= 6; n |= n >> 7; n = (n | (n >> 14)) & 0xfu;
+                codes |= y << (8 * half); ns |= n << (4 * half);
             }
             packedMate = codes | (ns << 16);
         }
+        // -DISAAC_TIMING_RW_NO_TABLE / _NO_SCAN / _NO_ENUM: builds that leave a section out (wrong results) to time the others, scripts/exp_rw_phases.sh
+#if !defined(ISAAC_TIMING_RW_NO_TABLE)
         for (u32 i = lane; i < ((L + 63) & ~63u); i += 64)              // every lane takes part in the exchanges
         {
             const u32 w0 = __shfl(packedMate, i >> 3, 64), w1 = __shfl(packedMate, ((i >> 3) + 1) & 63, 64);
@@ -257,28 +319,48 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
                 h = (h + 1) & (RW_TABLE - 1);
             }
         }
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         STAMP(2);
-        if (small) rescueWindowScanShort(R, job, windowBase, firstTile, L, tab, present, ldsBitmaps[wave], lane);
+#if !defined(ISAAC_TIMING_RW_NO_TABLE) && !defined(ISAAC_TIMING_RW_NO_SCAN)
+        if (small)
+        {
+            if (perLane == 8) rescueWindowScanShort<8>(R, job, windowBase, firstTile, L, tab, present, ldsBitmap, lane);
+            else if (perLane == 12) rescueWindowScanShort<12>(R, job, windowBase, firstTile, L, tab, present, ldsBitmap, lane);
+            else rescueWindowScanShort<16>(R, job, windowBase, firstTile, L, tab, present, ldsBitmap, lane);
+        }
         else { rescueWindowScan<false>(R, job, windowBase, firstTile, L, tab, bitmap, lane, pushes); __threadfence(); }
+#else
+        if (firstTile.codes == 0x123456789abcull) pushes = 1;             // keeps the early window load alive
+#endif
         STAMP(3);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // the set bits in ascending order are the sorted unique candidate list: count them first
-        for (u32 w0 = 0; w0 < bitmapWords; w0 += 64)
+        // the set bits in ascending order are the sorted unique candidate list: count them first (an LDS bitmap is one word per lane
+        // at most: its words and their running count stay in registers for the enumeration below)
+        if (small)
+        {
+            smallWord = lane < bitmapWords ? bitmap[lane] : 0u;
+            smallIncl = u32(__popc(smallWord));
+            for (u32 o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(smallIncl, o, 64); if (lane >= o) smallIncl += t; }
+            total = __shfl(smallIncl, 63, 64);
+        }
+        else for (u32 w0 = 0; w0 < bitmapWords; w0 += 64)
         {
             const u32 w = w0 + lane;
-            const u32 word = w < bitmapWords ? (small ? bitmap[w] : __hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0u;
+            const u32 word = w < bitmapWords ? __hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
             u32 c = u32(__popc(word));
             for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
             total += c;
         }
     }
     STAMP(4);
-    if (!active) return;
+#if defined(ISAAC_TIMING_RW_NO_ENUM)
+    total = 0;
+#endif
     bool fallback = pushes > SHADOW_POSITIONS_MAX;
     if (fallback) total = 0;
     // one allocation per problem from the block's region: the regions keep the atomics on different addresses, and the waves of
@@ -288,7 +370,7 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
     {
         if (lane == 0)
         {
-            const u32 region = blockIdx.x % CAND_REGIONS;
+            const u32 region = (j / 4) % CAND_REGIONS;
             const u32 at = atomicAdd(rb.candCounter + region, total);
             if (at + total <= rb.candRegionSize) candBase = region * rb.candRegionSize + at;
             else atomicMin(rb.candCounter + CAND_REGIONS + region, at);   // the region is full from here on: these problems fall back
@@ -301,10 +383,19 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
     {
         const i32 bias = i32(L) - 7;
         u32 running = 0;
-        for (u32 w0 = 0; w0 < bitmapWords; w0 += 64)
+        if (small)
+        {
+            u32 at = candBase + smallIncl - u32(__popc(smallWord));
+            while (smallWord)
+            {
+                const u32 b = u32(__ffs(smallWord)) - 1; smallWord &= smallWord - 1;
+                rb.candPositions[at] = i32(lane * 32 + b) - bias; rb.candJob[at] = j; ++at;
+            }
+        }
+        else for (u32 w0 = 0; w0 < bitmapWords; w0 += 64)
         {
             const u32 w = w0 + lane;
-            u32 word = w < bitmapWords ? (small ? bitmap[w] : __hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0u;
+            u32 word = w < bitmapWords ? __hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
             const u32 c = u32(__popc(word));
             u32 incl = c;
             for (u32 o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
@@ -323,6 +414,21 @@ __global__ __launch_bounds__(256) void k_rescue_windows(DevParams P, DevReferenc
         out.pushes = pushes; out.fallback = fallback ? 1 : 0; out.candBase = (fallback || !total) ? 0 : candBase; out.nCands = fallback ? 0 : total;
     }
     STAMP(7);
+}
+
+__global__ __launch_bounds__(64 * RW_WAVES) void k_rescue_windows(DevParams P, DevReference R, u64 totalBases, const u8 *bcl, u32 clusterBase, RescueBuffers rb)
+{
+    __shared__ u32 tables[RW_WAVES][RW_TABLE];
+    __shared__ u32 ldsBitmaps[RW_WAVES][RW_LDS_BITMAP];
+    __shared__ __align__(2048) u32 presentMaps[RW_WAVES][RW_PRESENT_WORDS];      // 2048: rescueWindowScanShort ORs word offsets into the base
+#if defined(ISAAC_TIMING_RW_EXIT)
+    if (clusterBase != 0xffffffffu) return;                                  // timing only: what launching the grid costs
+#endif
+    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // the slot's number in scalar registers: the job record comes through the scalar cache.  (Two or four slots per wavefront, one after
+    // the other, to launch fewer workgroups: 3.8 -> 10.0 / 11.7 ms.  The record loads of the second slot may alias the first one's
+    // record store, so they become vector loads, the record lives in vector registers and the kernel needs 95 of them.)
+    rescueWindowsProblem(P, R, bcl, clusterBase, rb, blockIdx.x * RW_WAVES + wave, lane, tables[wave], ldsBitmaps[wave], presentMaps[wave]);
 }
 
 __global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, ClusterPools pools, RescueBuffers rb, Counters *counters)

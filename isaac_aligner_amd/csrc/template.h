@@ -238,9 +238,10 @@ struct RescueJob
     u32 finalBestGapped;    // index of the retry that produced it in the chunk's GappedResult array, 0xffffffff: its ungapped alignment stands
     u8 orphanListIndex;     // the orphan is candidate orphanListIndex of read 1 - shadowReadIndex
     u8 rescued;             // rescueShadow's return value
-    u8 pad8[2];
-    u32 pad;
+    u16 windowBaseHigh;     // index of the window's first base in the concatenated contigs (contig offset + windowBegin), 48 bits:
+    u32 windowBaseLow;      // k_rescue_windows starts its loads from the job record alone
 };
+ISAAC_HD u64 rescueJobWindowBase(const RescueJob &j) { return (u64(j.windowBaseHigh) << 32) | j.windowBaseLow; }
 static_assert(sizeof(RescueJob) == 96, "RescueJob layout");
 static const u32 SHADOW_LIST_MAX = 1000;          // ShadowAligner.hh: shadowList_ capacity, TemplateBuilder.hh:TRACKED_REPEATS_MAX_ONE_READ
 enum { RESCUE_SERIAL = 0, RESCUE_PLAN = 1, RESCUE_LOOKUP = 2, RESCUE_PRECOMPUTED = 3 };
@@ -457,7 +458,7 @@ ISAAC_HD bool planRescue(const TemplateCtx &x, const Cand &orphan, i64 bestTempl
 {
     job.windowBegin = 0; job.windowLen = 0; job.cluster = x.clusterId; job.contigId = orphan.contigId; job.candBase = 0; job.nCands = 0; job.pushes = 0;
     job.bitmapBase = 0; job.bitmapWords = 0; job.valid = 0; job.fallback = 0; job.gappedBase = 0xffffffffu; job.nGapped = 0; job.nAligned = 0; job.bestRank = 0; job.bestSlot = 0; job.lastAligned = 0;
-    job.take = 0; job.finalBestRank = 0; job.finalBestSlot = 0; job.finalBestGapped = 0xffffffffu; job.rescued = 0; job.pad8[0] = job.pad8[1] = 0; job.pad = 0;
+    job.take = 0; job.finalBestRank = 0; job.finalBestSlot = 0; job.finalBestGapped = 0xffffffffu; job.rescued = 0; job.windowBaseHigh = 0; job.windowBaseLow = 0;
     job.orphanListIndex = u8(&orphan - x.cands[orphan.readIndex]);
     job.shadowReadIndex = u8((orphan.readIndex + 1) % 2);
     job.shadowReverse = 0;
@@ -471,6 +472,8 @@ ISAAC_HD bool planRescue(const TemplateCtx &x, const Cand &orphan, i64 bestTempl
     job.windowBegin = imax<i64>(0, rangeFirst);
     const i64 windowEnd = imin(referenceSize, rangeSecond + 1);
     job.windowLen = windowEnd > job.windowBegin ? u32(windowEnd - job.windowBegin) : 0;
+    const u64 windowBase = x.R->contigOffset[orphan.contigId] + u64(job.windowBegin);
+    job.windowBaseHigh = u16(windowBase >> 32); job.windowBaseLow = u32(windowBase);
     job.valid = 1;
     return true;
 }
