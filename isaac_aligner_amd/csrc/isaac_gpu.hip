@@ -75,7 +75,7 @@ struct isaac_gpu_ctx
     DevBuf<ClusterMeta> clusterMeta; DevBuf<Cand> candPool; DevBuf<u32> cigarArena, cigarNext; ClusterPools pools; DevBuf<FragmentWork> fragWork;
     struct KnownTotal { const void *offsets; u32 nClusters; u64 total; }; std::vector<KnownTotal> knownTotals;   // match counts of recent isaac_gpu_find_matches calls, by offsets buffer
     DevBuf<GappedJob> gappedJobs, rescueGappedJobs; DevBuf<GappedResult> gappedResults, rescueGappedResults; DevBuf<u32> gappedBase, gappedCounters;
-    DevBuf<u8> heavyArena; DevBuf<u32> overflowList; DevBuf<u32> overflowCount; DevBuf<ClusterSums> clusterSums; DevBuf<u32> mediumList, largeList, xlList, hugeList, longJobs; DevBuf<u8> hugeKeys;
+    DevBuf<u8> heavyArena; DevBuf<u32> clusterKinds, clusterIndex; DevBuf<u32> overflowList; DevBuf<u32> overflowCount; DevBuf<ClusterSums> clusterSums; DevBuf<u32> mediumList, largeList, xlList, hugeList, longJobs; DevBuf<u8> hugeKeys;
     DevBuf<TlsSample> tlsSamples; DevBuf<u32> cigarLengths, cigarOffsets; DevBuf<u64> cigarTotal;
     DevBuf<CrcConstants> crcConstants; bool crcReady = false;    // isaac_gpu_bgzf_store
     // isaac_gpu_bam_records scratch
@@ -324,6 +324,27 @@ __global__ void k_tls_samples(ClusterPools pools, const u64 *offsets, u32 cluste
 }
 
 // candidates of the chunk -> compact ABI records; one thread per cluster, offsets from an exclusive scan of the counts
+// k_plan_rescue and k_select give a cluster to a thread, and what a thread does depends on its cluster's candidate lists: a wave of
+// clusters as they come has a quarter of its lanes at work on average, and every lane's private memory access touches a cache line of
+// its own.  The clusters are therefore handed out by kind -- candidates per read and, for k_select, rescue problems -- so that the
+// lanes of a wave mostly take the same branches and make the same number of turns.
+#ifndef ISAAC_CLUSTER_ORDER
+#define ISAAC_CLUSTER_ORDER 1
+#endif
+static const u32 CLUSTER_KIND_BITS = 8, CLUSTER_KIND_MAX = 255;
+__global__ void k_cluster_kinds(ClusterPools pools, u32 nChunk, const u32 *jobCount, u32 *kinds, u32 *index)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nChunk) return;
+    const ClusterMeta m = pools.meta[t];
+    u32 kind = 0;
+    if (m.built) kind = 1 + (imin<u32>(m.nCands[0], 5) * 6 + imin<u32>(m.nCands[1], 5)) * 4 + (jobCount ? imin<u32>(jobCount[t], 3) : 0);
+    // The kinds with most to do first, so that the grid's last waves are short ones (the other way round the order gains half as much, and
+    // k_rescue_windows, whose problem slots follow k_plan_rescue's order, loses).  A finer key -- candidates of both reads together up to 31,
+    // problems up to 7, read 0's candidates up to 15 -- was worse (k_select 3.0 against 2.7 ms): the split between the reads matters most.
+    kinds[t] = CLUSTER_KIND_MAX - kind; index[t] = t;
+}
+
 __global__ void k_count_candidates(ClusterPools pools, u32 nChunk, u32 *nCands, u32 *nCigar)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1195,9 +1216,16 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         HIP_CHECK(hipMemsetAsync(c->rescueCounters.p + 4 + CAND_REGIONS, 0xff, CAND_REGIONS * 4, st));   // per region: first request that did not fit
         HIP_CHECK(hipMemsetAsync(c->heavyCount.p, 0, 32, st));
         HIP_CHECK(hipMemsetAsync(c->heavyFlag.p, 0, n, st));
+        const u32 *order = nullptr;
         {
             ScopedTimer tm(c, "plan_rescue");
-            k_plan_rescue<<<gridFor(n, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, n, c->pools, rb);
+#if ISAAC_CLUSTER_ORDER
+            c->clusterKinds.reserve(2 * size_t(chunk)); c->clusterIndex.reserve(2 * size_t(chunk));
+            k_cluster_kinds<<<gridFor(n, 256), 256, 0, st>>>(c->pools, n, nullptr, c->clusterKinds.p, c->clusterIndex.p);
+            sortPairs(c, c->clusterKinds.p, c->clusterKinds.p + chunk, c->clusterIndex.p, c->clusterIndex.p + chunk, n, int(CLUSTER_KIND_BITS));
+            order = c->clusterIndex.p + chunk;
+#endif
+            k_plan_rescue<<<gridFor(n, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, n, c->pools, rb, order);
             HIP_CHECK(hipGetLastError());
         }
         {
@@ -1240,8 +1268,12 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         }
         {
             ScopedTimer tm(c, "select");
+#if ISAAC_CLUSTER_ORDER
+            k_cluster_kinds<<<gridFor(n, 256), 256, 0, st>>>(c->pools, n, rb.jobCount, c->clusterKinds.p, c->clusterIndex.p);
+            sortPairs(c, c->clusterKinds.p, c->clusterKinds.p + chunk, c->clusterIndex.p, c->clusterIndex.p + chunk, n, int(CLUSTER_KIND_BITS));
+#endif
             k_select<<<gridFor(n, 64), 64, 0, st>>>(c->templateConstants.p, R, lmq40, bcl, done, n, tile, c->pools, rb, gbRescue.results, gbRescue.jobs, c->clusterSums.p,
-                                                     reinterpret_cast<FragmentRecord *>(fragments), cigar, c->overflowList.p, c->overflowCount.p, c->heavyFlag.p, c->counters.p);
+                                                     reinterpret_cast<FragmentRecord *>(fragments), cigar, c->overflowList.p, c->overflowCount.p, c->heavyFlag.p, c->counters.p, order);
             HIP_CHECK(hipGetLastError());
         }
         // The wave-per-cluster pass, twice, behind k_select on the same stream: for what the sums stage could not do (near ties, lists beyond

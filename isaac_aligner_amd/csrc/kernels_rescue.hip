@@ -2,10 +2,11 @@
 #include "kernels.h"
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_PLAN_WAVES))) void k_plan_rescue(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk,
-                                                    ClusterPools pools, RescueBuffers rb)
+                                                    ClusterPools pools, RescueBuffers rb, const u32 *order)
 {
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nChunk) return;
+    const u32 slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= nChunk) return;
+    const u32 t = order ? order[slot] : slot;        // clusters of a kind next to each other: see k_cluster_kinds
     const ClusterFragments f = clusterView(pools.meta[t], pools.cands, pools.cigars);
     // (Round 3 tried this work area -- and the private copies of short candidate lists -- in a per-cluster slice of a global arena, so that a
     // lane's fields share cache lines instead of lying 256 bytes apart in lane-interleaved scratch: the work area made no difference

@@ -6,10 +6,11 @@
 // (more equally good placements than it holds) are appended to overflowList and redone by that pass as well.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_SELECT_WAVES))) void k_select(const TemplateConstants *constants, DevReference R, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk, u32 tile,
                                                ClusterPools pools, RescueBuffers rb, const GappedResult *gappedResults, const GappedJob *gappedJobs, const ClusterSums *sums,
-                                               FragmentRecord *records, u32 *cigars, u32 *overflowList, u32 *overflowCount, const u8 *skip, Counters *counters)
+                                               FragmentRecord *records, u32 *cigars, u32 *overflowList, u32 *overflowCount, const u8 *skip, Counters *counters, const u32 *order)
 {
     const DevParams &P = constants->P; const DevTls &tls = constants->tls; const RogCorrection &rog = constants->rog;
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 t = slot < nChunk ? (order ? order[slot] : slot) : nChunk;        // clusters of a kind next to each other: see k_cluster_kinds
     Counters local; memset(&local, 0, sizeof(local));
     if (t < nChunk && !skip[t])
     {
