@@ -344,7 +344,6 @@ __global__ void k_cluster_kinds(ClusterPools pools, u32 nChunk, const u32 *jobCo
     // problems up to 7, read 0's candidates up to 15 -- was worse (k_select 3.0 against 2.7 ms): the split between the reads matters most.
     kinds[t] = CLUSTER_KIND_MAX - kind; index[t] = t;
 }
-
 __global__ void k_count_candidates(ClusterPools pools, u32 nChunk, u32 *nCands, u32 *nCigar)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1043,10 +1042,13 @@ static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clust
     c->fragWork.reserve(c->chunkNow); c->indelList.reserve(c->chunkNow);
     const GappedBuffers gb = gappedBuffers(c, 0);
     HIP_CHECK(hipMemsetAsync(c->gappedCounters.p, 0, 16, c->stream));
+    const u32 *order = nullptr;
     AlignList al; al.cap = 8 * c->chunkNow; c->alignList.reserve(al.cap); al.entries = c->alignList.p; al.counter = c->gappedCounters.p + 3;
     {
         ScopedTimer t(c, "build_fragments");
-        k_build_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, bcl, clusterBase, n, reinterpret_cast<const Match *>(matches), offsets, trim, c->fragWork.p, c->pools, al);
+        // (in the order of their match counts this kernel is slower, 2.13 -> 2.79 ms, and k_align_candidates behind it 1.37 -> 1.47:
+        // neighbouring threads no longer read neighbouring matches)
+        k_build_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, bcl, clusterBase, n, reinterpret_cast<const Match *>(matches), offsets, trim, c->fragWork.p, c->pools, al, order);
         HIP_CHECK(hipGetLastError());
     }
     {
@@ -1056,7 +1058,13 @@ static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clust
     }
     {
         ScopedTimer t(c, "finish_candidates");
-        k_finish_candidates<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, withGaps, c->indelList.p, c->gappedCounters.p + 2, c->fragWork.p, c->pools, gb, c->counters.p);
+#if ISAAC_CLUSTER_ORDER
+        c->clusterKinds.reserve(2 * size_t(c->chunkNow)); c->clusterIndex.reserve(2 * size_t(c->chunkNow));
+        order = c->clusterIndex.p + c->chunkNow;
+        k_cluster_kinds<<<gridFor(n, 256), 256, 0, c->stream>>>(c->pools, n, nullptr, c->clusterKinds.p, c->clusterIndex.p);
+        sortPairs(c, c->clusterKinds.p, c->clusterKinds.p + c->chunkNow, c->clusterIndex.p, c->clusterIndex.p + c->chunkNow, n, int(CLUSTER_KIND_BITS));
+#endif
+        k_finish_candidates<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, withGaps, c->indelList.p, c->gappedCounters.p + 2, c->fragWork.p, c->pools, gb, c->counters.p, order);
         HIP_CHECK(hipGetLastError());
     }
     {
@@ -1067,7 +1075,7 @@ static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clust
     if (withGaps) launchGappedJobs(c, bcl, clusterBase, gb, "gapped_fragments", "gapped_fragments_rescan");
     {
         ScopedTimer t(c, "finish_fragments");
-        k_finish_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, withGaps, c->fragWork.p, c->pools, gb, c->counters.p);
+        k_finish_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, withGaps, c->fragWork.p, c->pools, gb, c->counters.p, order);
         HIP_CHECK(hipGetLastError());
     }
 }

@@ -123,11 +123,11 @@ __host__ __device__ inline u32 gappedGroupLdsBytes(u32 maxQueryLength)
     return (((bytes + 15) / 16) | 1u) * 16;
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_build_fragments(DevParams P, const u8 *bcl, u32 clusterBase, u32 nChunk, const Match *matches, const u64 *offsets, int trim, FragmentWork *work, ClusterPools pools, AlignList al);
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_build_fragments(DevParams P, const u8 *bcl, u32 clusterBase, u32 nChunk, const Match *matches, const u64 *offsets, int trim, FragmentWork *work, ClusterPools pools, AlignList al, const u32 *order);
 __global__ __launch_bounds__(256) void k_align_candidates(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, ClusterPools pools, AlignList al, Counters *counters);
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_finish_candidates(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, u32 nChunk, int withGaps, u32 *indelList, u32 *indelCount, FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters);
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_finish_candidates(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, u32 nChunk, int withGaps, u32 *indelList, u32 *indelCount, FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *order);
 __global__ __launch_bounds__(64) void k_indel_fragments(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, int withGaps, const u32 *indelList, const u32 *indelCount, FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters);
-__global__ __launch_bounds__(64) void k_finish_fragments(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, u32 nChunk, int withGaps, FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters);
+__global__ __launch_bounds__(64) void k_finish_fragments(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, u32 nChunk, int withGaps, FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *order);
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_PLAN_WAVES))) void k_plan_rescue(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk, ClusterPools pools, RescueBuffers rb, const u32 *order);
 __global__ __launch_bounds__(64 * RW_WAVES) void k_rescue_windows(DevParams P, DevReference R, u64 totalBases, const u8 *bcl, u32 clusterBase, RescueBuffers rb);
 __global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, ClusterPools pools, RescueBuffers rb, Counters *counters);

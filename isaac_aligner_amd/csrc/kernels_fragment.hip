@@ -19,20 +19,20 @@ __device__ inline void emitGappedJobs(const ClusterFragments &f, u32 cl, bool wi
 // Fragment stage, step 1: matches -> candidate positions (buildCandidates), and one entry per candidate in the flat list
 // k_align_candidates works through.  The list space of a wave is taken with one atomic.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_build_fragments(DevParams P, const u8 *bcl, u32 clusterBase, u32 nChunk, const Match *matches, const u64 *offsets,
-                                                        int trim, FragmentWork *work, ClusterPools pools, AlignList al)
+                                                        int trim, FragmentWork *work, ClusterPools pools, AlignList al, const u32 *order)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     u32 cl = 0, n = 0;
     ClusterFragments f;
     if (t < nChunk)
     {
-        cl = t;
+        cl = order ? order[t] : t;                   // clusters with as many matches next to each other: see k_cluster_kinds
         // the cluster's slots: one per seed match, at the offset of its first match in the chunk
         const u64 chunkBegin = offsets[clusterBase], begin = offsets[clusterBase + cl], end = offsets[clusterBase + cl + 1];
         const u32 first = u32(begin - chunkBegin);
         const u32 cap = (u64(first) + (end - begin) <= pools.candCap) ? u32(end - begin) : 0u;     // a pool that is too small shows as CLUSTER_OVERFLOW
         f = clusterViewNew(first, cap, pools.cands, pools.cigars);
-        buildCandidates(P, bcl + u64(clusterBase + cl) * P.clusterLength, matches + begin, u32(end - begin), trim != 0, work[t], f);
+        buildCandidates(P, bcl + u64(clusterBase + cl) * P.clusterLength, matches + begin, u32(end - begin), trim != 0, work[cl], f);
         n = f.nCands[0] + f.nCands[1];
     }
     // exclusive prefix of n over the wave, one allocation for all of it
@@ -75,14 +75,14 @@ __global__ __launch_bounds__(256) void k_align_candidates(DevParams P, DevRefere
 // 3-4 % of clusters with a candidate pair for the single-indel detector, an entry for k_indel_fragments: inside this kernel
 // nearly every wave would hold one such lane and wait for it
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_finish_candidates(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, u32 nChunk,
-                                                        int withGaps, u32 *indelList, u32 *indelCount, FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters)
+                                                        int withGaps, u32 *indelList, u32 *indelCount, FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *order)
 {
     ISAAC_STAGE_QUALITY_TABLES(Rg, R)
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     Counters local; memset(&local, 0, sizeof(local));
     if (t < nChunk)
     {
-        const u32 cl = t;
+        const u32 cl = order ? order[t] : t;
         ClusterFragments f = clusterView(pools.meta[cl], pools.cands, pools.cigars);
         const u8 *clusterBcl = bcl + u64(clusterBase + cl) * P.clusterLength;
         if (f.flags & CLUSTER_ALIGN_PENDING)
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGME
             f.flags &= ~u32(CLUSTER_ALIGN_PENDING);
             for (u32 r = 0; r < P.nReads; ++r) for (u32 i = 0; i < f.nCands[r]; ++i) alignCandidate(P, R, clusterBcl, f, r, i, local);
         }
-        finishCandidates(P, R, clusterBcl, work[t], f, local, true);
+        finishCandidates(P, R, clusterBcl, work[cl], f, local, true);
         if (clusterSimpleIndelsPending(f)) indelList[atomicAdd(indelCount, 1u)] = cl;
         else emitGappedJobs(f, cl, withGaps != 0, gb);
         clusterViewStore(f, pools.cands, pools.meta[cl]);
@@ -129,9 +129,10 @@ __global__ __launch_bounds__(64) void k_indel_fragments(DevParams P, DevReferenc
 }
 
 __global__ __launch_bounds__(64) void k_finish_fragments(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, u32 nChunk, int withGaps,
-                                                         FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters)
+                                                         FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *order)
 {
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 t = slot < nChunk ? (order ? order[slot] : slot) : nChunk;
     Counters local; memset(&local, 0, sizeof(local));
     ClusterFragments f;
     const GappedResult *res = nullptr;
