@@ -1255,7 +1255,12 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         launchGappedJobs(c, bcl, done, gbRescue, "gapped_rescue", "gapped_rescue_rescan");
         {
             ScopedTimer tm(c, "sums_wave");
-            k_cluster_sums16<<<gridFor(n, 16), 256, 0, st>>>(c->P, c->pools, n, rb, gbRescue, sb, c->counters.p);
+#if ISAAC_CLUSTER_ORDER
+            // from here on the kinds know the clusters' rescue problems as well (k_cluster_sums16, k_select)
+            k_cluster_kinds<<<gridFor(n, 256), 256, 0, st>>>(c->pools, n, rb.jobCount, c->clusterKinds.p, c->clusterIndex.p);
+            sortPairs(c, c->clusterKinds.p, c->clusterKinds.p + chunk, c->clusterIndex.p, c->clusterIndex.p + chunk, n, int(CLUSTER_KIND_BITS));
+#endif
+            k_cluster_sums16<<<gridFor(n, 16), 256, 0, st>>>(c->P, c->pools, n, rb, gbRescue, sb, c->counters.p, order);
             k_cluster_sums<<<8192, 256, 0, st>>>(c->P, c->pools, rb, gbRescue, sb, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }
@@ -1276,10 +1281,6 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         }
         {
             ScopedTimer tm(c, "select");
-#if ISAAC_CLUSTER_ORDER
-            k_cluster_kinds<<<gridFor(n, 256), 256, 0, st>>>(c->pools, n, rb.jobCount, c->clusterKinds.p, c->clusterIndex.p);
-            sortPairs(c, c->clusterKinds.p, c->clusterKinds.p + chunk, c->clusterIndex.p, c->clusterIndex.p + chunk, n, int(CLUSTER_KIND_BITS));
-#endif
             k_select<<<gridFor(n, 64), 64, 0, st>>>(c->templateConstants.p, R, lmq40, bcl, done, n, tile, c->pools, rb, gbRescue.results, gbRescue.jobs, c->clusterSums.p,
                                                      reinterpret_cast<FragmentRecord *>(fragments), cigar, c->overflowList.p, c->overflowCount.p, c->heavyFlag.p, c->counters.p, order);
             HIP_CHECK(hipGetLastError());

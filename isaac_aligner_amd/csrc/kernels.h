@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * RW_WAVES) void k_rescue_windows(DevParams P, D
 __global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, ClusterPools pools, RescueBuffers rb, Counters *counters);
 __global__ __launch_bounds__(256) void k_rescue_gapped_plan(ClusterPools pools, RescueBuffers rb, GappedBuffers gb, u32 *longList, u32 *longCount, Counters *counters);
 __global__ __launch_bounds__(256) void k_rescue_gapped_plan_long(ClusterPools pools, RescueBuffers rb, GappedBuffers gb, const u32 *longList, const u32 *longCount);
-__global__ __launch_bounds__(256) void k_cluster_sums16(DevParams P, ClusterPools pools, u32 nChunk, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);
+__global__ __launch_bounds__(256) void k_cluster_sums16(DevParams P, ClusterPools pools, u32 nChunk, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters, const u32 *order);
 __global__ __launch_bounds__(256) void k_cluster_sums(DevParams P, ClusterPools pools, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);
 __global__ __launch_bounds__(256) void k_cluster_sums_large(DevParams P, ClusterPools pools, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);
 __global__ __launch_bounds__(1024) void k_cluster_sums_xl(DevParams P, ClusterPools pools, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);
