@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -42,7 +43,16 @@ template <typename T> struct DevBuf
 {
     T *p = nullptr; size_t n = 0;
     DevBuf() = default; DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
-    void reserve(size_t count) { if (count > n) { release(); HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T))); n = count; } }
+    void reserve(size_t count)
+    {
+        if (count <= n) return;
+        release();
+        HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
+        n = count;
+        // ISAAC_GPU_TRACE_ALLOC=<MB>: device allocations of at least that size on stderr (element size x count)
+        static const long traceFrom = std::getenv("ISAAC_GPU_TRACE_ALLOC") ? std::atol(std::getenv("ISAAC_GPU_TRACE_ALLOC")) : -1;
+        if (traceFrom >= 0 && count * sizeof(T) >= size_t(traceFrom) << 20) std::fprintf(stderr, "isaac_gpu alloc %8.1f MB = %zu x %zu\n", double(count * sizeof(T)) / 1048576.0, sizeof(T), count);
+    }
     void release() { if (p) { hipFree(p); p = nullptr; n = 0; } }
     ~DevBuf() { release(); }
 };
@@ -73,7 +83,7 @@ struct isaac_gpu_ctx
     DevBuf<Match> staging; DevBuf<u32> counts, chunkOffsets; DevBuf<u8> cubTemp; DevBuf<u32> contigHits; std::vector<u32> hContigHits;
     // the chunk's candidates: 32 B of ClusterMeta per cluster, one slot per seed match in the candidate pool, the cigar arena (types.h)
     DevBuf<ClusterMeta> clusterMeta; DevBuf<Cand> candPool; DevBuf<u32> cigarArena, cigarNext; ClusterPools pools; DevBuf<FragmentWork> fragWork;
-    struct KnownTotal { const void *offsets; u32 nClusters; u64 total; }; std::vector<KnownTotal> knownTotals;   // match counts of recent isaac_gpu_find_matches calls, by offsets buffer
+    struct KnownTotal { const void *offsets; u32 nClusters; u64 total; };
     DevBuf<GappedJob> gappedJobs, rescueGappedJobs; DevBuf<GappedResult> gappedResults, rescueGappedResults; DevBuf<u32> gappedBase, gappedCounters;
     DevBuf<u8> heavyArena; DevBuf<u32> clusterKinds, clusterIndex; DevBuf<u32> overflowList; DevBuf<u32> overflowCount; DevBuf<ClusterSums> clusterSums; DevBuf<u32> mediumList, largeList, xlList, hugeList, longJobs; DevBuf<u8> hugeKeys;
     DevBuf<TlsSample> tlsSamples; DevBuf<u32> cigarLengths, cigarOffsets; DevBuf<u64> cigarTotal;
@@ -457,6 +467,25 @@ template <typename K, typename V> void sortPairs(isaac_gpu_ctx *c, const K *kin,
 }
 
 int fail(int code, const std::string &what) { g_error = what; return code; }
+
+// match counts of recent isaac_gpu_find_matches calls, by offsets buffer: isaac_gpu_select sizes its candidate pool by them without asking
+// the device.  One list for the process: the lookups of a run are often made by one context and the selections by others that share its table.
+static std::mutex g_knownTotalsMutex;
+static std::vector<isaac_gpu_ctx::KnownTotal> g_knownTotals;
+static void rememberMatchTotal(const void *offsets, u32 nClusters, u64 total)
+{
+    std::lock_guard<std::mutex> lock(g_knownTotalsMutex);
+    auto &known = g_knownTotals;
+    known.erase(std::remove_if(known.begin(), known.end(), [&](const isaac_gpu_ctx::KnownTotal &k) { return k.offsets == offsets; }), known.end());
+    if (known.size() >= 256) known.erase(known.begin());
+    known.push_back({ offsets, nClusters, total });
+}
+static u64 knownMatchTotal(const void *offsets, u32 nClusters)
+{
+    std::lock_guard<std::mutex> lock(g_knownTotalsMutex);
+    for (const auto &k : g_knownTotals) if (k.offsets == offsets && k.nClusters == nClusters) return std::max<u64>(k.total, 1);
+    return 0;
+}
 
 // Chunk size for a call over nClusters clusters.  Kernel durations end in a tail set by their slowest waves, so fewer, larger
 // launches are faster; the buffers grow with the largest call seen instead of being sized for the upper bound at once.
@@ -965,12 +994,7 @@ int isaac_gpu_find_matches(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClust
     if (contigHasMatches) for (u32 i = 0; i < c->nContigs; ++i) contigHasMatches[i] |= u8(c->hContigHits[i] != 0);
     if (nMatchesOut) *nMatchesOut = base;
     if (base > capacity) return fail(ISAAC_GPU_ECAPACITY, "matches_dev is too small");
-    {   // isaac_gpu_select sizes its candidate pool by this without asking the device
-        auto &known = c->knownTotals;
-        known.erase(std::remove_if(known.begin(), known.end(), [&](const isaac_gpu_ctx::KnownTotal &k) { return k.offsets == clusterOffsets; }), known.end());
-        if (known.size() >= 64) known.erase(known.begin());
-        known.push_back({ clusterOffsets, nClusters, base });
-    }
+    rememberMatchTotal(clusterOffsets, nClusters, base);
     return 0;
     ISAAC_CATCH
 }
@@ -1204,7 +1228,7 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         // told (no host wait), the caller's candidate count for explicit lists, else the hard per-cluster bound
         u64 slots = 0;
         if (source.candidates) slots = nClusters ? offsetsSpan(c, source.candidateOffsets, nClusters) : 0;
-        else for (const auto &k : c->knownTotals) if (k.offsets == source.offsets && k.nClusters == nClusters) slots = std::max<u64>(k.total, 1);
+        else slots = knownMatchTotal(source.offsets, nClusters);
         preparePools(c, slots);
     }
     for (u32 done = 0; done < nClusters; done += chunk)

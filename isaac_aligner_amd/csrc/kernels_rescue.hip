@@ -5,8 +5,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_PLAN_W
                                                     ClusterPools pools, RescueBuffers rb, const u32 *order)
 {
     const u32 slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= nChunk) return;
-    const u32 t = order ? order[slot] : slot;        // clusters of a kind next to each other: see k_cluster_kinds
+    const bool inChunk = slot < nChunk;
+    const u32 t = inChunk ? (order ? order[slot] : slot) : 0;        // clusters of a kind next to each other: see k_cluster_kinds
     const ClusterFragments f = clusterView(pools.meta[t], pools.cands, pools.cigars);
     // (Round 3 tried this work area -- and the private copies of short candidate lists -- in a per-cluster slice of a global arena, so that a
     // lane's fields share cache lines instead of lying 256 bytes apart in lane-interleaved scratch: the work area made no difference
@@ -17,21 +17,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_PLAN_W
     TemplateWork work;
     templateWorkBind(work, workBytes, tinyCaps());
     // Every seeded candidate is an orphan at most once, so their number bounds the cluster's rescue problems: the slots are
-    // reserved first and the template logic runs once, writing the problems as it meets them (unused slots stay invalid)
-    const u32 reserve = f.built ? f.nCands[0] + f.nCands[1] : 0;
+    // reserved first -- one bump of the counter per wavefront -- and the template logic runs once, writing the problems as it meets them
+    // (unused slots stay invalid)
+    const u32 reserve = (inChunk && f.built) ? f.nCands[0] + f.nCands[1] : 0;
+    u32 incl = reserve;
+    for (u32 o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o, 64); if ((threadIdx.x & 63) >= o) incl += v; }
+    const u32 waveTotal = __shfl(incl, 63, 64);
     u32 base = 0, n = 0;
+    if ((threadIdx.x & 63) == 63 && waveTotal) base = atomicAdd(rb.jobCounter, waveTotal);
+    base = __shfl(base, 63, 64) + incl - reserve;
+    if (!inChunk) return;
     if (reserve)
     {
-        base = atomicAdd(rb.jobCounter, reserve);
-        if (base + reserve > rb.jobsCap)
-        {   // the cluster runs its rescues itself in the wave-per-cluster pass
-            base = 0xffffffffu;
-            n = clusterPlanRescue(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + t, t, f, work, nullptr, privateCands);
-        }
-        else
+        // what does not fit: the cluster runs its rescues itself in the wave-per-cluster pass
+        if (base + reserve > rb.jobsCap) base = 0xffffffffu;
+        RescueJob *jobs = 0xffffffffu == base ? nullptr : rb.jobs + base;
+        n = clusterPlanRescue(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + t, t, f, work, jobs, privateCands);
+        if (jobs)
         {
-            RescueJob *jobs = rb.jobs + base;
-            n = clusterPlanRescue(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + t, t, f, work, jobs, privateCands);
             for (u32 i = n; i < reserve; ++i) { jobs[i].valid = 0; jobs[i].fallback = 0; jobs[i].nCands = 0; jobs[i].nGapped = 0; }
             for (u32 i = 0; i < n; ++i)
             {
