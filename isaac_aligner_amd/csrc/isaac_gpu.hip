@@ -85,7 +85,7 @@ struct isaac_gpu_ctx
     DevBuf<ClusterMeta> clusterMeta; DevBuf<Cand> candPool; DevBuf<u32> cigarArena, cigarNext; ClusterPools pools; DevBuf<FragmentWork> fragWork;
     struct KnownTotal { const void *offsets; u32 nClusters; u64 total; };
     DevBuf<GappedJob> gappedJobs, rescueGappedJobs; DevBuf<GappedResult> gappedResults, rescueGappedResults; DevBuf<u32> gappedBase, gappedCounters;
-    DevBuf<u8> heavyArena; DevBuf<u32> clusterKinds, clusterIndex; DevBuf<u32> overflowList; DevBuf<u32> overflowCount; DevBuf<ClusterSums> clusterSums; DevBuf<u32> mediumList, largeList, xlList, hugeList, longJobs; DevBuf<u8> hugeKeys;
+    DevBuf<u8> heavyArena, clusterKinds; DevBuf<u32> clusterOrder, kindCounts; DevBuf<u32> overflowList; DevBuf<u32> overflowCount; DevBuf<ClusterSums> clusterSums; DevBuf<u32> mediumList, largeList, xlList, hugeList, longJobs; DevBuf<u8> hugeKeys;
     DevBuf<TlsSample> tlsSamples; DevBuf<u32> cigarLengths, cigarOffsets; DevBuf<u64> cigarTotal;
     DevBuf<CrcConstants> crcConstants; bool crcReady = false;    // isaac_gpu_bgzf_store
     // isaac_gpu_bam_records scratch
@@ -341,19 +341,54 @@ __global__ void k_tls_samples(ClusterPools pools, const u64 *offsets, u32 cluste
 #ifndef ISAAC_CLUSTER_ORDER
 #define ISAAC_CLUSTER_ORDER 1
 #endif
-static const u32 CLUSTER_KIND_BITS = 8, CLUSTER_KIND_MAX = 255;
-__global__ void k_cluster_kinds(ClusterPools pools, u32 nChunk, const u32 *jobCount, u32 *kinds, u32 *index)
+static const u32 CLUSTER_KINDS = 256, KIND_BLOCK = 1024;
+// A counting sort in two launches (a radix sort of the library is twenty launches and a third of a millisecond for these 1 M keys, four
+// times per step): the kinds and their histogram, then every cluster's place -- the kind's first place, the block's share of the kind
+// (one atomic per block and kind in use), the cluster's rank among the block's clusters of the kind (LDS).  The order inside a kind
+// is the order the blocks arrive in, which nothing depends on.
+__global__ __launch_bounds__(KIND_BLOCK) void k_cluster_kinds(ClusterPools pools, u32 nChunk, const u32 *jobCount, u8 *kinds, u32 *histogram)
 {
+    __shared__ u32 h[CLUSTER_KINDS];
+    if (threadIdx.x < CLUSTER_KINDS) h[threadIdx.x] = 0;
+    __syncthreads();
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nChunk) return;
-    const ClusterMeta m = pools.meta[t];
-    u32 kind = 0;
-    if (m.built) kind = 1 + (imin<u32>(m.nCands[0], 5) * 6 + imin<u32>(m.nCands[1], 5)) * 4 + (jobCount ? imin<u32>(jobCount[t], 3) : 0);
-    // The kinds with most to do first, so that the grid's last waves are short ones (the other way round the order gains half as much, and
-    // k_rescue_windows, whose problem slots follow k_plan_rescue's order, loses).  A finer key -- candidates of both reads together up to 31,
-    // problems up to 7, read 0's candidates up to 15 -- was worse (k_select 3.0 against 2.7 ms): the split between the reads matters most.
-    kinds[t] = CLUSTER_KIND_MAX - kind; index[t] = t;
+    if (t < nChunk)
+    {
+        const ClusterMeta m = pools.meta[t];
+        u32 kind = 0;
+        if (m.built) kind = 1 + (imin<u32>(m.nCands[0], 5) * 6 + imin<u32>(m.nCands[1], 5)) * 4 + (jobCount ? imin<u32>(jobCount[t], 3) : 0);
+        // The kinds with most to do first, so that the grid's last waves are short ones (the other way round the order gains half as much, and
+        // k_rescue_windows, whose problem slots follow k_plan_rescue's order, loses).  A finer key -- candidates of both reads together up to 31,
+        // problems up to 7, read 0's candidates up to 15 -- was worse (k_select 3.0 against 2.7 ms): the split between the reads matters most.
+        kind = CLUSTER_KINDS - 1 - kind;
+        kinds[t] = u8(kind);
+        atomicAdd(&h[kind], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < CLUSTER_KINDS && h[threadIdx.x]) atomicAdd(&histogram[threadIdx.x], h[threadIdx.x]);
 }
+__global__ __launch_bounds__(KIND_BLOCK) void k_cluster_order(const u8 *kinds, u32 nChunk, const u32 *histogram, u32 *cursor, u32 *order)
+{
+    __shared__ u32 first[CLUSTER_KINDS], h[CLUSTER_KINDS], share[CLUSTER_KINDS];
+    if (threadIdx.x < CLUSTER_KINDS) { first[threadIdx.x] = histogram[threadIdx.x]; h[threadIdx.x] = 0; }
+    __syncthreads();
+    for (u32 o = 1; o < CLUSTER_KINDS; o <<= 1)                              // inclusive sums of the histogram
+    {
+        u32 v = 0;
+        if (threadIdx.x < CLUSTER_KINDS && threadIdx.x >= o) v = first[threadIdx.x - o];
+        __syncthreads();
+        if (threadIdx.x < CLUSTER_KINDS) first[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 kind = 0, rank = 0;
+    if (t < nChunk) { kind = kinds[t]; rank = atomicAdd(&h[kind], 1u); }
+    __syncthreads();
+    if (threadIdx.x < CLUSTER_KINDS) share[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]) : 0u;
+    __syncthreads();
+    if (t < nChunk) order[(kind ? first[kind - 1] : 0u) + share[kind] + rank] = t;
+}
+
 __global__ void k_count_candidates(ClusterPools pools, u32 nChunk, u32 *nCands, u32 *nCigar)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -467,6 +502,17 @@ template <typename K, typename V> void sortPairs(isaac_gpu_ctx *c, const K *kin,
 }
 
 int fail(int code, const std::string &what) { g_error = what; return code; }
+
+// the clusters of a chunk by kind (k_cluster_kinds): c->clusterOrder
+static const u32 *orderClustersByKind(isaac_gpu_ctx *c, u32 n, const u32 *jobCount)
+{
+    c->clusterKinds.reserve(c->chunkNow); c->clusterOrder.reserve(c->chunkNow); c->kindCounts.reserve(2 * CLUSTER_KINDS);
+    HIP_CHECK(hipMemsetAsync(c->kindCounts.p, 0, 2 * CLUSTER_KINDS * sizeof(u32), c->stream));
+    k_cluster_kinds<<<gridFor(n, KIND_BLOCK), KIND_BLOCK, 0, c->stream>>>(c->pools, n, jobCount, c->clusterKinds.p, c->kindCounts.p);
+    k_cluster_order<<<gridFor(n, KIND_BLOCK), KIND_BLOCK, 0, c->stream>>>(c->clusterKinds.p, n, c->kindCounts.p, c->kindCounts.p + CLUSTER_KINDS, c->clusterOrder.p);
+    HIP_CHECK(hipGetLastError());
+    return c->clusterOrder.p;
+}
 
 // match counts of recent isaac_gpu_find_matches calls, by offsets buffer: isaac_gpu_select sizes its candidate pool by them without asking
 // the device.  One list for the process: the lookups of a run are often made by one context and the selections by others that share its table.
@@ -1084,10 +1130,7 @@ static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clust
     {
         ScopedTimer t(c, "finish_candidates");
 #if ISAAC_CLUSTER_ORDER
-        c->clusterKinds.reserve(2 * size_t(c->chunkNow)); c->clusterIndex.reserve(2 * size_t(c->chunkNow));
-        order = c->clusterIndex.p + c->chunkNow;
-        k_cluster_kinds<<<gridFor(n, 256), 256, 0, c->stream>>>(c->pools, n, nullptr, c->clusterKinds.p, c->clusterIndex.p);
-        sortPairs(c, c->clusterKinds.p, c->clusterKinds.p + c->chunkNow, c->clusterIndex.p, c->clusterIndex.p + c->chunkNow, n, int(CLUSTER_KIND_BITS));
+        order = orderClustersByKind(c, n, nullptr);
 #endif
         k_finish_candidates<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, withGaps, c->indelList.p, c->gappedCounters.p + 2, c->fragWork.p, c->pools, gb, c->counters.p, order);
         HIP_CHECK(hipGetLastError());
@@ -1253,10 +1296,7 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         {
             ScopedTimer tm(c, "plan_rescue");
 #if ISAAC_CLUSTER_ORDER
-            c->clusterKinds.reserve(2 * size_t(chunk)); c->clusterIndex.reserve(2 * size_t(chunk));
-            k_cluster_kinds<<<gridFor(n, 256), 256, 0, st>>>(c->pools, n, nullptr, c->clusterKinds.p, c->clusterIndex.p);
-            sortPairs(c, c->clusterKinds.p, c->clusterKinds.p + chunk, c->clusterIndex.p, c->clusterIndex.p + chunk, n, int(CLUSTER_KIND_BITS));
-            order = c->clusterIndex.p + chunk;
+            order = orderClustersByKind(c, n, nullptr);
 #endif
             k_plan_rescue<<<gridFor(n, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, n, c->pools, rb, order);
             HIP_CHECK(hipGetLastError());
@@ -1282,8 +1322,7 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
             ScopedTimer tm(c, "sums_wave");
 #if ISAAC_CLUSTER_ORDER
             // from here on the kinds know the clusters' rescue problems as well (k_cluster_sums16, k_select)
-            k_cluster_kinds<<<gridFor(n, 256), 256, 0, st>>>(c->pools, n, rb.jobCount, c->clusterKinds.p, c->clusterIndex.p);
-            sortPairs(c, c->clusterKinds.p, c->clusterKinds.p + chunk, c->clusterIndex.p, c->clusterIndex.p + chunk, n, int(CLUSTER_KIND_BITS));
+            order = orderClustersByKind(c, n, rb.jobCount);
 #endif
             k_cluster_sums16<<<gridFor(n, 16), 256, 0, st>>>(c->P, c->pools, n, rb, gbRescue, sb, c->counters.p, order);
             k_cluster_sums<<<8192, 256, 0, st>>>(c->P, c->pools, rb, gbRescue, sb, c->counters.p);

@@ -63,6 +63,8 @@ def main():
             e["active_inst_frac"] = e.get("SQ_ACTIVE_INST_ANY", 0) / wc
             if e.get("SQ_ACTIVE_INST_VALU"):
                 e["valu_lane_utilisation"] = e.get("SQ_THREAD_CYCLES_VALU", 0) / (64.0 * e["SQ_ACTIVE_INST_VALU"])
+        if e.get("SQ_LDS_IDX_ACTIVE"):
+            e["lds_bank_conflict_frac"] = e.get("SQ_LDS_BANK_CONFLICT", 0) / e["SQ_LDS_IDX_ACTIVE"]
         res[name] = e
     if workload:
         res["workload"] = workload

@@ -1,5 +1,5 @@
 #!/bin/bash
-# HBM traffic and SQ activity per kernel: three separate rocprofv3 --pmc passes (never combined with tracing) over a short bench
+# HBM traffic, SQ activity and LDS bank conflicts per kernel: four separate rocprofv3 --pmc passes (never combined with tracing) over a short bench
 # run with the default 1 M pairs per launch, reduced by scripts/pmc_summary.py into gpurun_out/pmc_summary.json
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
@@ -7,7 +7,8 @@ B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie-pass --n
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_j_fetch -- $B > $R/gpurun_out/pmc_j_fetch.log 2>&1; echo "fetch rc=$?"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_j_write -- $B > $R/gpurun_out/pmc_j_write.log 2>&1; echo "write rc=$?"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d $R/gpurun_out/pmc_j_sq -- $B > $R/gpurun_out/pmc_j_sq.log 2>&1; echo "sq rc=$?"
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU --output-format csv -d $R/gpurun_out/pmc_j_lds -- $B > $R/gpurun_out/pmc_j_lds.log 2>&1; echo "lds rc=$?"
 cd $R
-python3 scripts/pmc_summary.py gpurun_out/pmc_summary.json workload=gpurun_out/pmc_j_sq.log fetch=$(find gpurun_out/pmc_j_fetch -name "*counter_collection.csv" | head -1) write=$(find gpurun_out/pmc_j_write -name "*counter_collection.csv" | head -1) sq=$(find gpurun_out/pmc_j_sq -name "*counter_collection.csv" | head -1)
+python3 scripts/pmc_summary.py gpurun_out/pmc_summary.json workload=gpurun_out/pmc_j_sq.log fetch=$(find gpurun_out/pmc_j_fetch -name "*counter_collection.csv" | head -1) write=$(find gpurun_out/pmc_j_write -name "*counter_collection.csv" | head -1) sq=$(find gpurun_out/pmc_j_sq -name "*counter_collection.csv" | head -1) lds=$(find gpurun_out/pmc_j_lds -name "*counter_collection.csv" | head -1)
 
-rm -rf gpurun_out/pmc_j_fetch gpurun_out/pmc_j_write gpurun_out/pmc_j_sq      # the per-dispatch CSVs: tens of MB
+rm -rf gpurun_out/pmc_j_fetch gpurun_out/pmc_j_write gpurun_out/pmc_j_sq gpurun_out/pmc_j_lds      # the per-dispatch CSVs: tens of MB
