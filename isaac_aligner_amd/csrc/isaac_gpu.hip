@@ -1118,7 +1118,10 @@ static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clust
         ScopedTimer t(c, "build_fragments");
         // (in the order of their match counts this kernel is slower, 2.13 -> 2.79 ms, and k_align_candidates behind it 1.37 -> 1.47:
         // neighbouring threads no longer read neighbouring matches; ordered inside stretches of 1 K / 4 K / 16 K clusters it is slower
-        // still, 5.5 / 4.4 / 3.9 ms)
+        // still, 5.5 / 4.4 / 3.9 ms.  Nor is it the few clusters with hundreds of matches by themselves: leaving those with more than 16 to a
+        // second launch, one per wavefront, most matches first, costs 1.7 ms for the pass in cluster order + 1.0 ms for the heavy ones,
+        // 2.8 ms where one launch takes 2.17: the kernel is a chain of dependent loads per thread (82 % of its wave cycles wait), and what
+        // it needs is the cluster's matches in registers or LDS before the sorts, not a different order.)
         k_build_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, bcl, clusterBase, n, reinterpret_cast<const Match *>(matches), offsets, trim, c->fragWork.p, c->pools, al, order);
         HIP_CHECK(hipGetLastError());
     }
