@@ -433,7 +433,8 @@ __global__ __launch_bounds__(64 * RW_WAVES) void k_rescue_windows(DevParams P, D
     // the other, to launch fewer workgroups: 3.8 -> 10.0 / 11.7 ms.  The record loads of the second slot may alias the first one's
     // record store, so they become vector loads, the record lives in vector registers and the kernel needs 95 of them.  A resident grid of
     // 8 192 wavefronts over a compacted list of the slots in use, the record's fields moved to scalar registers one by one, has the same
-    // 95 registers -- the loop's invariants -- or 64 with spills: 4.7 ms against 3.1.)
+    // 95 registers -- the loop's invariants -- or 64 with spills: 4.7 ms against 3.1 (and that attempt's records differed: a bug that
+    // was not chased once the time was known).)
     rescueWindowsProblem(P, R, bcl, clusterBase, rb, blockIdx.x * RW_WAVES + wave, lane, tables[wave], ldsBitmaps[wave], presentMaps[wave]);
 }
 
