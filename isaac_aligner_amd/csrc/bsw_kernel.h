@@ -67,7 +67,7 @@ template <int N> __device__ inline int maxWithLaneAbove(int s, int t)
 // which alignment group of its workgroup a thread belongs to, and which of the group's 8 lanes it is
 __device__ inline u32 bswGroupOfThread() { return ((threadIdx.x >> 4) << 1) | (threadIdx.x & 1u); }
 __device__ inline u32 bswLaneOfThread() { return (threadIdx.x & 15u) >> 1; }
-static const u32 BSW_GROUP_LANES = 8;
+// BSW_GROUP_LANES, BSW_BLOCK: kernels.h
 
 // The DP of one alignment on the 8 lanes of a group, then traceback and CIGAR (the group walks together, lane 0 stores).  `cig[n..)`
 // receives the operations (reference order); the return value is BandedSmithWaterman::align's: the length of the stripped leading
@@ -285,7 +285,7 @@ struct StrandQueryDev { ReadView read; bool reverse; u32 offset; __device__ char
 // GappedAligner::alignGapped (GappedAligner.cpp:167-249) for a list of candidates, 8 lanes per candidate: the statements of
 // alignGapped() in aligner.h with the DP on the group and everything else on its lane 0.  `bcl` is the tile, the job's
 // cluster index is relative to clusterBase.  Grid-stride over the jobs, so the launch does not need the job count on the host.
-__global__ __launch_bounds__(128) void k_gapped_jobs(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap,
+__global__ __launch_bounds__(BSW_BLOCK) void k_gapped_jobs(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap,
                                                     u32 maxReadLength, GappedResult *results)
 {
     extern __shared__ __align__(16) u8 lds[];

@@ -1070,10 +1070,13 @@ static GappedBuffers gappedBuffers(isaac_gpu_ctx *c, u32 which)
 static void launchGappedJobs(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clusterBase, const GappedBuffers &gb, const char *timer, const char *rescanTimer)
 {
     const u32 maxReadLength = std::max(c->P.readLength[0], c->P.nReads > 1 ? c->P.readLength[1] : 0u);
-    const size_t lds = size_t(16) * gappedGroupLdsBytes(maxReadLength);
+    // one wavefront (eight problems) per workgroup: the LDS of a workgroup is what limits the problems in flight, and at 2 x 250 five
+    // workgroups of eight fit a CU where two of sixteen did
+    // (2 x 250 with 5 % indel reads: 15.5 -> 13.0 ms per 1 M pairs; 2 x 150: 4.46 -> 4.44)
+    const size_t lds = size_t(BSW_BLOCK / BSW_GROUP_LANES) * gappedGroupLdsBytes(maxReadLength);
     {
         ScopedTimer t(c, timer);
-        k_gapped_jobs<<<4096, 128, lds, c->stream>>>(c->P, c->ref(), bcl, clusterBase, gb.jobs, gb.counter, gb.cap, maxReadLength, gb.results);
+        k_gapped_jobs<<<8192, BSW_BLOCK, lds, c->stream>>>(c->P, c->ref(), bcl, clusterBase, gb.jobs, gb.counter, gb.cap, maxReadLength, gb.results);
     }
     HIP_CHECK(hipGetLastError());
     ScopedTimer t(c, rescanTimer);
@@ -1651,9 +1654,9 @@ int isaac_gpu_bsw_batch(isaac_gpu_ctx *c, int match, int mismatch, int gapOpen, 
     if (!maxQueryLength || maxQueryLength > 512) return fail(ISAAC_GPU_EINVAL, "query lengths 1..512 are supported");
     const int maxScore = std::max(std::max(std::abs(match), std::abs(mismatch)), std::max(std::abs(gapOpen), std::abs(gapExtend)));
     if (int(maxQueryLength) * maxScore >= std::abs(-32768 + gapOpen)) return fail(ISAAC_GPU_EINVAL, "BandedSmithWaterman: unsupported read length for these scores");
-    const size_t lds = size_t(16) * bswGroupLdsBytes(maxQueryLength);
+    const size_t lds = size_t(BSW_BLOCK / BSW_GROUP_LANES) * bswGroupLdsBytes(maxQueryLength);
     ScopedTimer t(c, "bsw");
-    k_bsw_batch<<<gridFor(nJobs, 16), 128, lds, c->stream>>>(match, mismatch, gapOpen, gapExtend, sequences, jobs, nJobs, maxQueryLength, results);
+    k_bsw_batch<<<gridFor(nJobs, BSW_BLOCK / BSW_GROUP_LANES), BSW_BLOCK, lds, c->stream>>>(match, mismatch, gapOpen, gapExtend, sequences, jobs, nJobs, maxQueryLength, results);
     HIP_CHECK(hipGetLastError());
     return 0;
     ISAAC_CATCH

@@ -110,7 +110,9 @@ struct SumsBuffers { ClusterSums *sums; u8 *residualFlag; u32 *residualList, *re
 
 static const u32 HEAVY_SORT_LDS = 32768;   // u16 indices: heavyCaps().prob / .pair entries
 
-// LDS bytes of one 16-lane banded Smith-Waterman group (bsw_kernel.h)
+static const u32 BSW_GROUP_LANES = 8;        // lanes that share one banded Smith-Waterman problem (bsw_kernel.h)
+static const u32 BSW_BLOCK = 64;             // threads per workgroup of k_gapped_jobs / k_bsw_batch: one wavefront, eight problems
+// LDS bytes of one banded Smith-Waterman group (bsw_kernel.h)
 // traceback flags: 48 bytes per four rows (bsw_kernel.h)
 __host__ __device__ inline u32 bswFlagBytes(u32 maxQueryLength) { return (((maxQueryLength + 3) / 4) * 48 + 15) & ~15u; }
 __host__ __device__ inline u32 bswGroupLdsBytes(u32 maxQueryLength) { return bswFlagBytes(maxQueryLength) + 128; }
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_SELECT
 __global__ __launch_bounds__(64) void k_select_heavy(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nList, const u32 *nListDev, u32 tile, ClusterPools pools, u8 *arena, u64 arenaBytes, TemplateCaps caps, const u32 *list, RescueBuffers rb, const GappedResult *gappedResults, const GappedJob *gappedJobs, const ClusterSums *sums, FragmentRecord *records, u32 *cigars, Counters *counters);
 namespace isaac
 {
-__global__ __launch_bounds__(256) void k_bsw_batch(int matchScore, int mismatchScore, int gapOpenScore, int gapExtendScore, const char *sequences, const isaac_bsw_job *jobs, u32 nJobs, u32 maxQueryLength, isaac_bsw_result *results);
+__global__ __launch_bounds__(128) void k_bsw_batch(int matchScore, int mismatchScore, int gapOpenScore, int gapExtendScore, const char *sequences, const isaac_bsw_job *jobs, u32 nJobs, u32 maxQueryLength, isaac_bsw_result *results);
 __global__ __launch_bounds__(128) void k_gapped_jobs(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap, u32 maxReadLength, GappedResult *results);
 __global__ __launch_bounds__(256) void k_gapped_rescan(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap, GappedResult *results);
 }
