@@ -59,12 +59,14 @@ struct AlignList { u32 *entries; u32 cap; u32 *counter; };
 // Template stage.  Mate rescue (ShadowAligner::rescueShadow) is the bulk of the work of the select phase: a 7-mer scan of
 // a window of several hundred reference bases plus one 150-base ungapped alignment per candidate start, for ~1.5 orphans
 // per cluster.  It is planned per cluster, then executed flat:
-//   k_plan_rescue         one thread per cluster: the rescue problems TemplateBuilder would pose (result independent)
-//   k_rescue_windows      one wavefront per problem: the mate's 7-mer table in LDS, the window scanned 64 x RW_PER_LANE positions at a time
-//                         (16 per lane), candidate starts collected in a per-problem bitmap (sorted + unique for free)
+//   k_plan_rescue         one thread per cluster: the rescue problems TemplateBuilder would pose (result independent).  It, k_select,
+//                         k_cluster_sums16 and the two finish kernels of the fragment stage take the clusters by kind
+//                         (k_cluster_kinds + k_cluster_order in isaac_gpu.hip), the busiest kinds first
+//   k_rescue_windows      one wavefront (and workgroup) per problem slot: the mate's 7-mer table in LDS, the window scanned 64 x 8, 12 or 16
+//                         positions at a time, candidate starts collected in a per-problem bitmap (sorted + unique for free)
 //   k_rescue_align        one thread per candidate start: UngappedAligner::alignUngapped
 //   k_rescue_gapped_plan  one thread per problem: rank of every aligned candidate, the best one, which get a gapped retry
-//   k_gapped_jobs         16 lanes per retry (bsw_kernel.h)
+//   k_gapped_jobs         8 lanes per retry, one wavefront of 8 retries per workgroup (bsw_kernel.h)
 //   k_predict_heavy       one thread per cluster: which clusters cannot fit the light work lists
 //   k_select              one thread per cluster: consumes the rescue results, pair / orphan selection, alignment scores,
 //                         clippers, FragmentHeader records
