@@ -779,7 +779,23 @@ ISAAC_HD void applyOrderInPlace(Cand *store, u8 *order, u32 n)
 //   buildCandidates   matches -> candidate positions of both reads, duplicates merged (list order in out.cands)
 //   alignCandidate    UngappedAligner::alignUngapped for one candidate; its CIGAR takes a fixed 3-word slot of the cluster's pool
 //   finishCandidates  consolidation, the single-indel stage (or its deferral), lists compacted in place
-ISAAC_HD bool buildCandidates(const DevParams &P, const u8 *clusterBcl, const Match *matches, u32 nMatches, bool trim, FragmentWork &work, ClusterFragments &out)
+// The matches of a cluster with few of them, copied once to fast memory (k_build_fragments: LDS): location, seed and strand are all
+// the fragment stage reads of a match, and it reads them many times -- the counts, every comparison of the sort, the two passes that
+// make the candidates -- each time through a pointer into global memory.  keys / ties are interleaved by `stride` (entry i of this
+// thread at [i * stride]), order is this thread's own bytes.
+struct MatchStage { u64 *keys; u8 *ties; u8 *order; u32 stride; u32 cap; };
+struct StagedMatchLess
+{
+    const u64 *keys; const u8 *ties; u32 stride;
+    ISAAC_HD bool operator()(u8 a, u8 b) const
+    {
+        const u64 l = keys[a * stride], r = keys[b * stride];
+        if (l != r) return l < r;
+        return ties[a * stride] < ties[b * stride];         // (seed index, strand), as MatchLess
+    }
+};
+ISAAC_HD bool buildCandidates(const DevParams &P, const u8 *clusterBcl, const Match *matches, u32 nMatches, bool trim, FragmentWork &work, ClusterFragments &out,
+                              const MatchStage *stage = 0)
 {
     out.nCands[0] = out.nCands[1] = 0; out.cigarUsed = 0; out.flags = 0; out.repeatSeedsCount = 0; out.built = 0;
     out.cands[1] = out.cands[0]; out.candCap[1] = out.candCap[0];
@@ -792,12 +808,15 @@ ISAAC_HD bool buildCandidates(const DevParams &P, const u8 *clusterBcl, const Ma
     u32 counts[MAX_SEEDS]; bool tooMany[MAX_SEEDS];
     for (u32 s = 0; s < MAX_SEEDS; ++s) { counts[s] = 0; tooMany[s] = false; }
     bool any = false;
+    const bool staged = stage && nMatches <= stage->cap;
     for (u32 i = 0; i < nMatches; ++i)
     {
-        if (refposIsNoMatch(matches[i].location)) continue;
+        const u64 location = matches[i].location, seedId = matches[i].seedId;
+        if (staged) { stage->keys[i * stage->stride] = location; stage->ties[i * stage->stride] = u8((seedIdSeed(seedId) << 1) | (seedId & 1)); }
+        if (refposIsNoMatch(location)) continue;
         any = true;
-        const u32 s = seedIdSeed(matches[i].seedId);
-        if (refposIsTooMany(matches[i].location)) tooMany[s] = true; else ++counts[s];
+        const u32 s = seedIdSeed(seedId);
+        if (refposIsTooMany(location)) tooMany[s] = true; else ++counts[s];
     }
     if (!any) return false;
     u32 repeatSeedsCount = 0;
@@ -805,8 +824,10 @@ ISAAC_HD bool buildCandidates(const DevParams &P, const u8 *clusterBcl, const Ma
     out.repeatSeedsCount = repeatSeedsCount;
     STAMP(21);
     // the reference adds candidates in sorted match order; that order is the input order of the first std::sort
-    for (u32 i = 0; i < nMatches; ++i) work.matchOrder[i] = u8(i);
-    { MatchLess ml; ml.m = matches; exactSort(work.matchOrder, i32(nMatches), ml); }
+    u8 *matchOrder = staged ? stage->order : work.matchOrder;
+    for (u32 i = 0; i < nMatches; ++i) matchOrder[i] = u8(i);
+    if (staged) { StagedMatchLess ml; ml.keys = stage->keys; ml.ties = stage->ties; ml.stride = stage->stride; exactSort(matchOrder, i32(nMatches), ml); }
+    else { MatchLess ml; ml.m = matches; exactSort(matchOrder, i32(nMatches), ml); }
     STAMP(22);
     bool built = false;
     for (u32 r = 0; r < P.nReads; ++r)
@@ -816,7 +837,10 @@ ISAAC_HD bool buildCandidates(const DevParams &P, const u8 *clusterBcl, const Ma
         CandList l; l.store = out.cands[r]; l.order = work.order; l.n = 0; l.stored = 0; l.capacity = imin(CAND_CAP, out.candCap[r]); l.overflow = 0;
         for (u32 k = 0; k < nMatches; ++k)
         {
-            const Match &m = matches[work.matchOrder[k]];
+            const u32 at = matchOrder[k];
+            Match m;
+            if (staged) { m.location = stage->keys[at * stage->stride]; m.seedId = u64(stage->ties[at * stage->stride]); }    // seed index and strand: all that is read of seedId below
+            else m = matches[at];
             if (refposIsNoMatch(m.location) || refposIsTooMany(m.location)) continue;
             const u32 s = seedIdSeed(m.seedId);
             const DevSeed &seed = P.seeds[s];

@@ -52,6 +52,11 @@ __device__ inline void flushCounters(const Counters &local, Counters *global)
 // the chunk's gapped (banded Smith-Waterman) problems: written by the per-cluster threads, run by k_gapped_jobs
 struct GappedBuffers { GappedJob *jobs; GappedResult *results; u32 cap; u32 *counter; u32 *base; };
 
+#ifndef ISAAC_BUILD_STAGE_MATCHES
+#define ISAAC_BUILD_STAGE_MATCHES 16
+#endif
+static const u32 BUILD_STAGE_MATCHES = ISAAC_BUILD_STAGE_MATCHES;      // k_build_fragments: clusters with up to this many matches keep them in LDS
+
 // the chunk's ungapped alignment problems: (cluster << 8) | (read << 7) | index in the read's candidate list
 struct AlignList { u32 *entries; u32 cap; u32 *counter; };
 

@@ -21,6 +21,11 @@ __device__ inline void emitGappedJobs(const ClusterFragments &f, u32 cl, bool wi
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_build_fragments(DevParams P, const u8 *bcl, u32 clusterBase, u32 nChunk, const Match *matches, const u64 *offsets,
                                                         int trim, FragmentWork *work, ClusterPools pools, AlignList al, const u32 *order)
 {
+    // the matches of clusters with up to BUILD_STAGE_MATCHES of them are read once and kept in LDS (buildCandidates)
+    __shared__ u64 stageKeys[BUILD_STAGE_MATCHES * 64];
+    __shared__ u8 stageTies[BUILD_STAGE_MATCHES * 64];
+    __shared__ u8 stageOrder[64][BUILD_STAGE_MATCHES];
+    MatchStage stage; stage.keys = stageKeys + threadIdx.x; stage.ties = stageTies + threadIdx.x; stage.order = stageOrder[threadIdx.x]; stage.stride = 64; stage.cap = BUILD_STAGE_MATCHES;
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     u32 cl = 0, n = 0;
     ClusterFragments f;
@@ -32,7 +37,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGME
         const u32 first = u32(begin - chunkBegin);
         const u32 cap = (u64(first) + (end - begin) <= pools.candCap) ? u32(end - begin) : 0u;     // a pool that is too small shows as CLUSTER_OVERFLOW
         f = clusterViewNew(first, cap, pools.cands, pools.cigars);
-        buildCandidates(P, bcl + u64(clusterBase + cl) * P.clusterLength, matches + begin, u32(end - begin), trim != 0, work[cl], f);
+        buildCandidates(P, bcl + u64(clusterBase + cl) * P.clusterLength, matches + begin, u32(end - begin), trim != 0, work[cl], f, &stage);
         n = f.nCands[0] + f.nCands[1];
     }
     // exclusive prefix of n over the wave, one allocation for all of it
