@@ -1330,7 +1330,7 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
             // from here on the kinds know the clusters' rescue problems as well (k_cluster_sums16, k_select)
             order = orderClustersByKind(c, n, rb.jobCount);
 #endif
-            k_cluster_sums16<<<gridFor(n, 16), 256, 0, st>>>(c->P, c->pools, n, rb, gbRescue, sb, c->counters.p, order);
+            k_cluster_sums16<<<gridFor(n, SUMS16_GROUPS), 16 * SUMS16_GROUPS, 0, st>>>(c->P, c->pools, n, rb, gbRescue, sb, c->counters.p, order);
             k_cluster_sums<<<8192, 256, 0, st>>>(c->P, c->pools, rb, gbRescue, sb, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }

@@ -57,6 +57,11 @@ struct GappedBuffers { GappedJob *jobs; GappedResult *results; u32 cap; u32 *cou
 #endif
 static const u32 BUILD_STAGE_MATCHES = ISAAC_BUILD_STAGE_MATCHES;      // k_build_fragments: clusters with up to this many matches keep them in LDS
 
+#ifndef ISAAC_SUMS16_GROUPS
+#define ISAAC_SUMS16_GROUPS 8
+#endif
+static const u32 SUMS16_GROUPS = ISAAC_SUMS16_GROUPS;        // clusters (quarter wavefronts) per workgroup of k_cluster_sums16
+
 // the chunk's ungapped alignment problems: (cluster << 8) | (read << 7) | index in the read's candidate list
 struct AlignList { u32 *entries; u32 cap; u32 *counter; };
 
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(64 * RW_WAVES) void k_rescue_windows(DevParams P, D
 __global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, ClusterPools pools, RescueBuffers rb, Counters *counters);
 __global__ __launch_bounds__(256) void k_rescue_gapped_plan(ClusterPools pools, RescueBuffers rb, GappedBuffers gb, u32 *longList, u32 *longCount, Counters *counters);
 __global__ __launch_bounds__(256) void k_rescue_gapped_plan_long(ClusterPools pools, RescueBuffers rb, GappedBuffers gb, const u32 *longList, const u32 *longCount);
-__global__ __launch_bounds__(256) void k_cluster_sums16(DevParams P, ClusterPools pools, u32 nChunk, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters, const u32 *order);
+__global__ __launch_bounds__(16 * SUMS16_GROUPS) void k_cluster_sums16(DevParams P, ClusterPools pools, u32 nChunk, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters, const u32 *order);
 __global__ __launch_bounds__(256) void k_cluster_sums(DevParams P, ClusterPools pools, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);
 __global__ __launch_bounds__(256) void k_cluster_sums_large(DevParams P, ClusterPools pools, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);
 __global__ __launch_bounds__(1024) void k_cluster_sums_xl(DevParams P, ClusterPools pools, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);

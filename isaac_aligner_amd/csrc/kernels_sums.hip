@@ -129,12 +129,13 @@ template <u32 W> __device__ inline u32 clusterSumsWave(const DevParams &P, const
 }
 
 // lists of up to 16 entries (most clusters): a quarter of a wavefront per cluster.  What does not fit goes to k_cluster_sums.
-__global__ __launch_bounds__(256) void k_cluster_sums16(DevParams P, ClusterPools pools, u32 nChunk, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters, const u32 *order)
+__global__ __launch_bounds__(16 * SUMS16_GROUPS) void k_cluster_sums16(DevParams P, ClusterPools pools, u32 nChunk, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters, const u32 *order)
 {
-    __shared__ __align__(16) u8 keyBytes[16][SUMS_QUARTER_CAP * 42 + 16];
-    __shared__ u64 tabPos[16][SUMS_QUARTER_CAP]; __shared__ double tabLp[16][SUMS_QUARTER_CAP]; __shared__ u32 tabObs[16][SUMS_QUARTER_CAP]; __shared__ u8 tabJob[16][SUMS_QUARTER_CAP];
+    __shared__ __align__(16) u8 keyBytes[SUMS16_GROUPS][SUMS_QUARTER_CAP * 42 + 16];
+    __shared__ u64 tabPos[SUMS16_GROUPS][SUMS_QUARTER_CAP]; __shared__ double tabLp[SUMS16_GROUPS][SUMS_QUARTER_CAP]; __shared__ u32 tabObs[SUMS16_GROUPS][SUMS_QUARTER_CAP];
+    __shared__ u8 tabJob[SUMS16_GROUPS][SUMS_QUARTER_CAP];
     const u32 group = threadIdx.x >> 4, lane = threadIdx.x & 15;
-    const u32 slot = blockIdx.x * 16 + group;
+    const u32 slot = blockIdx.x * SUMS16_GROUPS + group;
     const u32 t = slot < nChunk ? (order ? order[slot] : slot) : nChunk;            // clusters of a kind next to each other (k_cluster_kinds)
     Counters local; memset(&local, 0, sizeof(local));
     if (t < nChunk)
