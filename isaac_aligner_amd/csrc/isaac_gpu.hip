@@ -341,7 +341,7 @@ __global__ void k_tls_samples(ClusterPools pools, const u64 *offsets, u32 cluste
 #ifndef ISAAC_CLUSTER_ORDER
 #define ISAAC_CLUSTER_ORDER 1
 #endif
-static const u32 CLUSTER_KINDS = 256, KIND_BLOCK = 1024;
+static const u32 CLUSTER_KINDS = 256, KIND_BLOCK = 256;         // small workgroups: beside the kernels of other contexts a 1 024-thread workgroup waits long for a CU with 16 free wave slots
 // A counting sort in two launches (a radix sort of the library is twenty launches and a third of a millisecond for these 1 M keys, four
 // times per step): the kinds and their histogram, then every cluster's place -- the kind's first place, the block's share of the kind
 // (one atomic per block and kind in use), the cluster's rank among the block's clusters of the kind (LDS).  The order inside a kind
