@@ -1246,7 +1246,6 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
     DevTls t; std::memcpy(&t, tls, sizeof(t));
     const RogCorrection rog = makeRogCorrection(c->P, c->hContigOffset.data(), c->hContigLoaded.data(), c->nContigs);
     const double lmq40 = logMismatchQ40();
-    if (templateWorkBytes(tinyCaps()) > TINY_WORK_BYTES) return fail(ISAAC_GPU_EHIP, "TINY_WORK_BYTES is smaller than the work area of tinyCaps()");
     const u32 chunk = chunkFor(c, nClusters);
     if (chunk > c->selectCapacity)
     {   // the chunk buffers are about to be reallocated: nothing may be left that reads them
@@ -1304,7 +1303,7 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
 #if ISAAC_CLUSTER_ORDER
             order = orderClustersByKind(c, n, nullptr);
 #endif
-            k_plan_rescue<<<gridFor(n, 64), 64, 0, st>>>(c->P, R, t, rog, lmq40, bcl, done, n, c->pools, rb, order);
+            k_plan_rescue<<<gridFor(n, SELECT_BLOCK), SELECT_BLOCK, 0, st>>>(c->templateConstants.p, R, done, n, c->pools, rb, order);
             HIP_CHECK(hipGetLastError());
         }
         {
@@ -1351,7 +1350,7 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         }
         {
             ScopedTimer tm(c, "select");
-            k_select<<<gridFor(n, 64), 64, 0, st>>>(c->templateConstants.p, R, lmq40, bcl, done, n, tile, c->pools, rb, gbRescue.results, gbRescue.jobs, c->clusterSums.p,
+            k_select<<<gridFor(n, SELECT_BLOCK), SELECT_BLOCK, 0, st>>>(c->templateConstants.p, R, lmq40, bcl, done, n, tile, c->pools, rb, gbRescue.results, c->clusterSums.p,
                                                      reinterpret_cast<FragmentRecord *>(fragments), cigar, c->overflowList.p, c->overflowCount.p, c->heavyFlag.p, c->counters.p, order);
             HIP_CHECK(hipGetLastError());
         }

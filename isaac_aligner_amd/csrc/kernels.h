@@ -7,13 +7,7 @@
 #include "cluster_ops.h"
 #include "sums.h"
 
-// occupancy targets (waves per SIMD) of the two thread-per-cluster kernels; the register allocator spills to meet them
-#ifndef ISAAC_SELECT_WAVES
-#define ISAAC_SELECT_WAVES 6
-#endif
-#ifndef ISAAC_PLAN_WAVES
-#define ISAAC_PLAN_WAVES 6
-#endif
+// occupancy target (waves per SIMD) of the thread-per-cluster kernels of the fragment stage; the register allocator spills to meet it
 #ifndef ISAAC_FRAGMENT_WAVES
 #define ISAAC_FRAGMENT_WAVES 6
 #endif
@@ -39,6 +33,14 @@ __device__ inline void flushCounters(const Counters &local, Counters *global)
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         if ((threadIdx.x & 63) == 0 && v) atomicAdd(reinterpret_cast<unsigned long long *>(dst + f), static_cast<unsigned long long>(v));
     }
+}
+
+// one field, for the kernels that count one or two things (a Counters in registers is forty of them)
+__device__ inline void flushCounter(u64 Counters::*field, u64 v, Counters *global)
+{
+    if (!__any(v != 0)) return;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(reinterpret_cast<unsigned long long *>(&(global[blockIdx.x & (COUNTER_SHARDS - 1)].*field)), static_cast<unsigned long long>(v));
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -107,8 +109,10 @@ struct RescueBuffers
     u32 *jobBase; u32 *jobCount;   // per cluster of the chunk; jobBase == 0xffffffff: the cluster runs its rescues itself
 };
 
-// the main pass's template work area (tinyCaps) lives in private memory
-static const u32 TINY_WORK_BYTES = 1024;
+#ifndef ISAAC_SELECT_BLOCK
+#define ISAAC_SELECT_BLOCK 256
+#endif
+static const u32 SELECT_BLOCK = ISAAC_SELECT_BLOCK;     // threads per workgroup of k_select / k_plan_rescue
 
 // k_cluster_sums: the outcome of every rescue problem of a cluster and its probability sums (sums.h), one wavefront per cluster
 // with room for 64 list entries in LDS; clusters with longer lists are listed for the workgroup-per-cluster form (1024 entries),
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(256) void k_align_candidates(DevParams P, DevRefere
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_finish_candidates(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, u32 nChunk, int withGaps, u32 *indelList, u32 *indelCount, FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *order);
 __global__ __launch_bounds__(64) void k_indel_fragments(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, int withGaps, const u32 *indelList, const u32 *indelCount, FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters);
 __global__ __launch_bounds__(64) void k_finish_fragments(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, u32 nChunk, int withGaps, FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *order);
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_PLAN_WAVES))) void k_plan_rescue(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk, ClusterPools pools, RescueBuffers rb, const u32 *order);
+__global__ __launch_bounds__(SELECT_BLOCK) void k_plan_rescue(const TemplateConstants *__restrict__ constants, DevReference R, u32 clusterBase, u32 nChunk, ClusterPools pools, RescueBuffers rb, const u32 *__restrict__ order);
 __global__ __launch_bounds__(64 * RW_WAVES) void k_rescue_windows(DevParams P, DevReference R, u64 totalBases, const u8 *bcl, u32 clusterBase, RescueBuffers rb);
 __global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, ClusterPools pools, RescueBuffers rb, Counters *counters);
 __global__ __launch_bounds__(256) void k_rescue_gapped_plan(ClusterPools pools, RescueBuffers rb, GappedBuffers gb, u32 *longList, u32 *longCount, Counters *counters);
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(256) void k_cluster_sums(DevParams P, ClusterPools 
 __global__ __launch_bounds__(256) void k_cluster_sums_large(DevParams P, ClusterPools pools, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);
 __global__ __launch_bounds__(1024) void k_cluster_sums_xl(DevParams P, ClusterPools pools, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);
 __global__ __launch_bounds__(1024) void k_cluster_sums_huge(DevParams P, ClusterPools pools, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_SELECT_WAVES))) void k_select(const TemplateConstants *constants, DevReference R, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk, u32 tile, ClusterPools pools, RescueBuffers rb, const GappedResult *gappedResults, const GappedJob *gappedJobs, const ClusterSums *sums, FragmentRecord *records, u32 *cigars, u32 *overflowList, u32 *overflowCount, const u8 *skip, Counters *counters, const u32 *order);
+__global__ __launch_bounds__(SELECT_BLOCK) void k_select(const TemplateConstants *__restrict__ constants, DevReference R, double logMismatchQ40, const u8 *__restrict__ bcl, u32 clusterBase, u32 nChunk, u32 tile, ClusterPools pools, RescueBuffers rb, const GappedResult *__restrict__ gappedResults, const ClusterSums *__restrict__ sums, FragmentRecord *__restrict__ records, u32 *__restrict__ cigars, u32 *overflowList, u32 *overflowCount, const u8 *__restrict__ skip, Counters *counters, const u32 *__restrict__ order);
 __global__ __launch_bounds__(64) void k_select_heavy(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nList, const u32 *nListDev, u32 tile, ClusterPools pools, u8 *arena, u64 arenaBytes, TemplateCaps caps, const u32 *list, RescueBuffers rb, const GappedResult *gappedResults, const GappedJob *gappedJobs, const ClusterSums *sums, FragmentRecord *records, u32 *cigars, Counters *counters);
 namespace isaac
 {

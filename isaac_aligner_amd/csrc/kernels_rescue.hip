@@ -1,25 +1,19 @@
 // kernels_rescue.hip: see kernels.h and DESIGN.md §4
 #include "kernels.h"
+#include "template_lean.h"
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_PLAN_WAVES))) void k_plan_rescue(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nChunk,
-                                                    ClusterPools pools, RescueBuffers rb, const u32 *order)
+// k_plan_rescue: the mate-rescue problems of every cluster (template_lean.h: leanPlanCluster), one thread per cluster
+__global__ __launch_bounds__(SELECT_BLOCK) void k_plan_rescue(const TemplateConstants *__restrict__ constants, DevReference R, u32 clusterBase, u32 nChunk, ClusterPools pools, RescueBuffers rb, const u32 *__restrict__ order)
 {
+    const DevParams &P = constants->P;
     const u32 slot = blockIdx.x * blockDim.x + threadIdx.x;
     const bool inChunk = slot < nChunk;
     const u32 t = inChunk ? (order ? order[slot] : slot) : 0;        // clusters of a kind next to each other: see k_cluster_kinds
-    const ClusterFragments f = clusterView(pools.meta[t], pools.cands, pools.cigars);
-    // (Round 3 tried this work area -- and the private copies of short candidate lists -- in a per-cluster slice of a global arena, so that a
-    // lane's fields share cache lines instead of lying 256 bytes apart in lane-interleaved scratch: the work area made no difference
-    // (select 3.46 -> 3.48 ms, plan 2.34 -> 2.32), the candidate copies were slower there (3.76 / 2.51): the scratch traffic of these two
-    // kernels is the compiler's own spills and temporaries, not these arrays.)
-    __attribute__((aligned(16))) u8 workBytes[TINY_WORK_BYTES];
-    Cand privateCands[2 * PRIVATE_CANDS];
-    TemplateWork work;
-    templateWorkBind(work, workBytes, tinyCaps());
+    const ClusterMeta meta = pools.meta[t];
     // Every seeded candidate is an orphan at most once, so their number bounds the cluster's rescue problems: the slots are
     // reserved first -- one bump of the counter per wavefront -- and the template logic runs once, writing the problems as it meets them
     // (unused slots stay invalid)
-    const u32 reserve = (inChunk && f.built) ? f.nCands[0] + f.nCands[1] : 0;
+    const u32 reserve = (inChunk && meta.built) ? u32(meta.nCands[0]) + meta.nCands[1] : 0;
     u32 incl = reserve;
     for (u32 o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o, 64); if ((threadIdx.x & 63) >= o) incl += v; }
     const u32 waveTotal = __shfl(incl, 63, 64);
@@ -32,7 +26,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_PLAN_W
         // what does not fit: the cluster runs its rescues itself in the wave-per-cluster pass
         if (base + reserve > rb.jobsCap) base = 0xffffffffu;
         RescueJob *jobs = 0xffffffffu == base ? nullptr : rb.jobs + base;
-        n = clusterPlanRescue(P, R, tls, rog, logMismatchQ40, bcl, clusterBase + t, t, f, work, jobs, privateCands);
+        LeanCtx x;
+        x.P = &P; x.R = &R; x.tls = &constants->tls;
+        x.l0 = pools.cands + meta.first; x.l1 = x.l0 + meta.second; x.n0 = meta.nCands[0]; x.n1 = meta.nCands[1];
+        x.pool = pools.cigars + 3 * u64(meta.first);
+        x.rogRead0 = 0.0; x.rogRead1 = 0.0; x.rog = 0.0; x.logMismatchQ40 = 0.0;      // no score is computed here
+        x.clusterId = clusterBase + t; x.mapqNearInteger = 0;
+        n = leanPlanCluster(x, t, jobs);
         if (jobs)
         {
             for (u32 i = n; i < reserve; ++i) { jobs[i].valid = 0; jobs[i].fallback = 0; jobs[i].nCands = 0; jobs[i].nGapped = 0; }

@@ -4,6 +4,7 @@
 // gfx950 kernels are made of with g++ and runs the per-cluster functions in a plain loop, so that their logic can be checked
 // against the oracle before a GPU box is spent on them.  It is not part of the product library and the product has no CPU path.
 #include "../../isaac_aligner_amd/csrc/cluster_ops.h"
+#include "../../isaac_aligner_amd/csrc/template_lean.h"
 #include "../../isaac_aligner_amd/csrc/sums.h"
 #include "../../isaac_aligner_amd/csrc/bam_kernels.h"
 #include "../../isaac_aligner_amd/csrc/bgzf_kernels.h"
@@ -28,7 +29,7 @@ struct Emu
     std::vector<ClusterStore> stores;       // fixed-capacity backing of the views below (the device keeps compact pools instead)
     std::vector<ClusterFragments> frags;
     std::vector<Match> matches; std::vector<u64> matchOffsets;
-    Counters cnt; bool flatRescue = true; double *clusterTimes = nullptr; bool fastSort = true; u32 sumsCap = 0; int sumsRadixMin = -1; std::vector<u32> dbgJobBase; std::vector<RescueJob> dbgJobs;
+    Counters cnt; bool flatRescue = true; bool lean = true; double *clusterTimes = nullptr; bool fastSort = true; u32 sumsCap = 0; int sumsRadixMin = -1; std::vector<u32> dbgJobBase; std::vector<RescueJob> dbgJobs;
 };
 }
 
@@ -162,13 +163,25 @@ int emu_select(Emu *e, const u8 *bcl, u32 nClusters, u32 tile, const isaac_tls *
     // k_plan_rescue
     std::vector<u32> jobBase(nClusters + 1, 0);
     std::vector<RescueJob> jobs;
-    for (u32 c = 0; c < nClusters; ++c)
+    // the lean form (template_lean.h) is what k_plan_rescue runs; the general one is kept for comparison (emu_set_lean)
+    auto leanCtx = [&](u32 c, ClusterMeta &meta)
     {
-        const u32 n = clusterPlanRescue(e->P, e->R, t, rog, lmq40, bcl, c, c, e->frags[c], light, 0);
-        jobBase[c + 1] = jobBase[c] + n;
-    }
+        clusterViewStore(e->frags[c], e->stores[c].cands, meta);
+        LeanCtx x; x.P = &e->P; x.R = &e->R; x.tls = &t;
+        x.l0 = e->frags[c].cands[0]; x.l1 = e->frags[c].cands[1]; x.n0 = meta.nCands[0]; x.n1 = meta.nCands[1]; x.pool = e->frags[c].cigarPool;
+        x.rogRead0 = rog.read[0]; x.rogRead1 = rog.read[1]; x.rog = rog.pair; x.logMismatchQ40 = lmq40; x.clusterId = c; x.mapqNearInteger = 0;
+        return x;
+    };
+    auto plan = [&](u32 c, RescueJob *out) -> u32
+    {
+        if (!e->lean) return clusterPlanRescue(e->P, e->R, t, rog, lmq40, bcl, c, c, e->frags[c], light, out);
+        if (!e->frags[c].built) return 0;
+        ClusterMeta meta; LeanCtx x = leanCtx(c, meta);
+        return leanPlanCluster(x, c, out);
+    };
+    for (u32 c = 0; c < nClusters; ++c) jobBase[c + 1] = jobBase[c] + plan(c, 0);
     jobs.resize(jobBase[nClusters]);
-    for (u32 c = 0; c < nClusters; ++c) clusterPlanRescue(e->P, e->R, t, rog, lmq40, bcl, c, c, e->frags[c], light, jobs.data() + jobBase[c]);
+    for (u32 c = 0; c < nClusters; ++c) plan(c, jobs.data() + jobBase[c]);
     // k_rescue_windows
     std::vector<i32> candPositions;
     {
@@ -237,7 +250,15 @@ int emu_select(Emu *e, const u8 *bcl, u32 nClusters, u32 tile, const isaac_tls *
         ClusterSums sums; u32 scratch = 0;
         bool residual = SUMS_DONE != clusterSums(e->P, e->frags[c], si, keys, g, &scratch, true, sums, e->cnt);
         CoopInputs coop; coop.lanes = 1; coop.lane = 0; coop.fastSort = false; coop.ldsSort = 0; coop.ldsSortCap = 0;
-        if (!residual)
+        if (!residual && e->lean)
+        {   // k_select
+            ClusterMeta meta; clusterViewStore(e->frags[c], e->stores[c].cands, meta);
+            LeanRescue rs; rs.jobs = in.jobs; rs.jobCount = in.jobCount; rs.shadowCands = shadowCands.data(); rs.shadowCigars = shadowCigars.data(); rs.gappedResults = gapped.data(); rs.sums = &sums;
+            u32 near = 0;
+            residual = !leanSelectCluster(e->P, e->R, t, rog, lmq40, bcl, c, tile, meta, e->stores[c].cands, e->frags[c].cigarPool, rs, recs, cigars, near);
+            if (!residual) e->cnt.mapqNearInteger += near;
+        }
+        else if (!residual)
         {
             in.sums = &sums; in.serialFallbackAllowed = false;
             clusterSelect(e->P, e->R, t, rog, lmq40, bcl, c, tile, e->frags[c], tiny, recs, cigars, e->cnt, &in, &coop);
@@ -327,6 +348,7 @@ int emu_realign_case(const char *contig, uint64_t contigLength, const uint8_t *r
 }
 
 void emu_set_flat_rescue(Emu *e, int on) { e->flatRescue = on != 0; }
+void emu_set_lean(Emu *e, int on) { e->lean = on != 0; }
 void emu_set_fast_sort(Emu *e, int on) { e->fastSort = on != 0; }
 void emu_set_sums_radix(Emu *e, int minEntries) { e->sumsRadixMin = minEntries; }   // lists of at least this many entries are ordered by radixOrder (sums.h); -1: never
 void emu_set_sums_capacity(Emu *e, uint32_t cap) { e->sumsCap = cap > 1024 ? 1024 : cap; }   // entries of the probability-sum key arrays (k_cluster_sums tiers)

@@ -177,6 +177,42 @@ def test_repeat_rich_reference_through_the_precomputed_sums(oracle, emulib, sums
     assert (heavy > 20) if sums_cap < 100 else (heavy < 20), heavy
 
 
+@pytest.mark.parametrize("overrides,read_lengths", [
+    (dict(scatter_repeats=1), (150, 150)),
+    (dict(dodgy_alignment_score=-1, mapq_threshold=20, keep_unaligned=0), (150, 150)),
+    (dict(clip_semialigned=0, clip_overlapping=0, dodgy_alignment_score=255, mapq_threshold=3), (100, 100)),
+    (dict(scatter_repeats=1, keep_unaligned=0), (150, 0)),
+])
+def test_lean_template_stage_with_other_options(oracle, emulib, overrides, read_lengths):
+    """template_lean.h (what k_plan_rescue and k_select run) away from the defaults: --scatter-repeats (the tie picked by cluster id),
+    --dodgy-alignment-score Unaligned / a forced value, --mapq-threshold, --keep-unaligned discard, clippers off, single-ended data; on a
+    repeat-rich reference so that ties, rescued ties and low MAPQs occur; every record against the oracle, and the general form of
+    template.h gives the same records"""
+    from isaac_aligner_amd import synth
+    g = synth.make_human_like_genome(1_200_000, seed=31)
+    contigs = [bytes(c.numpy()) for c in g.contigs]
+    bcl = synth.make_read_pairs(g, 1200, read_lengths[0], seed=32, avoid_gaps=True, subst_rate=0.01)[0].numpy()
+    if not read_lengths[1]:
+        bcl = np.ascontiguousarray(bcl[:, :read_lengths[0]])
+    n = len(bcl)
+    p = options.default_params(*read_lengths, **overrides)
+    ref = oracle.reference(contigs)
+    ref.build_index()
+    matches, hits = ref.find_matches(p, bcl, n)
+    otls = ref.determine_tls(p, bcl, matches, hits)
+    orec, ocig, _ = ref.select(p, bcl, matches, otls, hits, n_clusters_hint=n)
+    for lean in (1, 0):
+        emu = hostemu_lib.Emu(emulib, p, contigs, hits)
+        emu.set_matches(matches, n)
+        emulib.emu_set_lean(emu.h, C.c_int(lean))
+        etls = emu.determine_tls(bcl, n)
+        assert otls.astuple() == etls.astuple()
+        erec, ecig = emu.select(bcl, n, etls, n_reads=p.n_reads)
+        assert not (erec["reserved"] & 5).any()
+        erec = erec[(erec["reserved"] & 2) == 0]          # templates the reference does not store (--keep-unaligned discard): the oracle leaves them out
+        assert not compare_records(orec, ocig, erec, ecig), lean
+
+
 def test_gap_realigner_device_code_against_the_oracle():
     """realign.h (what the BAM stage's realign kernel runs per fragment) compiled for the CPU against oracle/realign.cpp, which the reference's
     testGapRealigner cases pin: those cases' inputs without --realign-vigorously (the device has no vigorous mode), with the semialigned
