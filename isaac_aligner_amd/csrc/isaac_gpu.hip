@@ -101,7 +101,7 @@ struct isaac_gpu_ctx
     struct ChunkDesc { const uint8_t *bcl = nullptr; u32 clusterBase = 0, tile = 0; FragmentRecord *records = nullptr; u32 *cigars = nullptr; DevTls tls; RogCorrection rog; };
     bool deferredCompletion = false;
     u32 selectCapacity = 0;        // chunk size the buffers of the select stage were last sized for
-    DevBuf<u32> heavyList, heavyCount, indelList, alignList; DevBuf<u8> heavyFlag;
+    DevBuf<u32> heavyList, heavyCount, indelList, alignList, generalList, generalCount; DevBuf<u8> heavyFlag;
     u32 chunkClusters = 1048576;   // upper bound of a chunk (ISAAC_GPU_CHUNK_CLUSTERS)
     u32 chunkNow = 0;              // the chunk size in use: the largest call so far, rounded up, at most chunkClusters; sizes the chunk-private buffers
 
@@ -1108,24 +1108,27 @@ static u64 offsetsSpan(isaac_gpu_ctx *c, const uint64_t *offsetsDev, u32 n)
     return ends[1] - ends[0];
 }
 
+// The fragment stage of one chunk.  Its three thread-per-cluster steps each run twice: the lean form (fragment_lean.h) over all clusters, which
+// lists the few with a list longer than LEAN_LIST_MAX or a capacity miss, and the general form (aligner.h) over that list, its count read on
+// the device (a launch over an empty list is a few microseconds).
+static const u32 GENERAL_BLOCKS = 2048;
 static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clusterBase, u32 n, const isaac_match *matches, const uint64_t *offsets, int withGaps, int trim)
 {
     // c->pools: see preparePools
     HIP_CHECK(hipMemsetAsync(c->cigarNext.p, 0, 4, c->stream));
     c->fragWork.reserve(c->chunkNow); c->indelList.reserve(c->chunkNow);
+    c->generalList.reserve(size_t(3) * c->chunkNow); c->generalCount.reserve(4);
+    HIP_CHECK(hipMemsetAsync(c->generalCount.p, 0, 16, c->stream));
+    u32 *const list0 = c->generalList.p, *const list1 = list0 + c->chunkNow, *const list2 = list1 + c->chunkNow;
     const GappedBuffers gb = gappedBuffers(c, 0);
     HIP_CHECK(hipMemsetAsync(c->gappedCounters.p, 0, 16, c->stream));
     const u32 *order = nullptr;
     AlignList al; al.cap = 8 * c->chunkNow; c->alignList.reserve(al.cap); al.entries = c->alignList.p; al.counter = c->gappedCounters.p + 3;
     {
         ScopedTimer t(c, "build_fragments");
-        // (in the order of their match counts this kernel is slower, 2.13 -> 2.79 ms, and k_align_candidates behind it 1.37 -> 1.47:
-        // neighbouring threads no longer read neighbouring matches; ordered inside stretches of 1 K / 4 K / 16 K clusters it is slower
-        // still, 5.5 / 4.4 / 3.9 ms.  Nor is it the few clusters with hundreds of matches by themselves: leaving those with more than 16 to a
-        // second launch, one per wavefront, most matches first, costs 1.7 ms for the pass in cluster order + 1.0 ms for the heavy ones,
-        // 2.8 ms where one launch takes 2.17: the kernel is a chain of dependent loads per thread (82 % of its wave cycles wait), and what
-        // it needs is the cluster's matches in registers or LDS before the sorts, not a different order.)
-        k_build_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, bcl, clusterBase, n, reinterpret_cast<const Match *>(matches), offsets, trim, c->fragWork.p, c->pools, al, order);
+        // (in the order of their match counts this kernel is slower: neighbouring threads no longer read neighbouring matches)
+        k_build_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, bcl, clusterBase, n, reinterpret_cast<const Match *>(matches), offsets, trim, c->pools, al, list0, c->generalCount.p);
+        k_build_fragments_general<<<GENERAL_BLOCKS, 64, 0, c->stream>>>(c->P, bcl, clusterBase, reinterpret_cast<const Match *>(matches), offsets, trim, c->fragWork.p, c->pools, al, list0, c->generalCount.p);
         HIP_CHECK(hipGetLastError());
     }
     {
@@ -1138,7 +1141,8 @@ static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clust
 #if ISAAC_CLUSTER_ORDER
         order = orderClustersByKind(c, n, nullptr);
 #endif
-        k_finish_candidates<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, withGaps, c->indelList.p, c->gappedCounters.p + 2, c->fragWork.p, c->pools, gb, c->counters.p, order);
+        k_finish_candidates<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, n, withGaps, c->indelList.p, c->gappedCounters.p + 2, c->pools, gb, order, list1, c->generalCount.p + 1);
+        k_finish_candidates_general<<<GENERAL_BLOCKS, 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, withGaps, c->indelList.p, c->gappedCounters.p + 2, c->fragWork.p, c->pools, gb, c->counters.p, list1, c->generalCount.p + 1);
         HIP_CHECK(hipGetLastError());
     }
     {
@@ -1149,7 +1153,8 @@ static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clust
     if (withGaps) launchGappedJobs(c, bcl, clusterBase, gb, "gapped_fragments", "gapped_fragments_rescan");
     {
         ScopedTimer t(c, "finish_fragments");
-        k_finish_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, withGaps, c->fragWork.p, c->pools, gb, c->counters.p, order);
+        k_finish_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, n, withGaps, c->pools, gb, c->counters.p, order, list2, c->generalCount.p + 2);
+        k_finish_fragments_general<<<GENERAL_BLOCKS, 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, withGaps, c->fragWork.p, c->pools, gb, c->counters.p, list2, c->generalCount.p + 2);
         HIP_CHECK(hipGetLastError());
     }
 }

@@ -141,11 +141,14 @@ __host__ __device__ inline u32 gappedGroupLdsBytes(u32 maxQueryLength)
     return (((bytes + 15) / 16) | 1u) * 16;
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_build_fragments(DevParams P, const u8 *bcl, u32 clusterBase, u32 nChunk, const Match *matches, const u64 *offsets, int trim, FragmentWork *work, ClusterPools pools, AlignList al, const u32 *order);
+__global__ __launch_bounds__(64) void k_build_fragments(DevParams P, const u8 *__restrict__ bcl, u32 clusterBase, u32 nChunk, const Match *__restrict__ matches, const u64 *__restrict__ offsets, int trim, ClusterPools pools, AlignList al, u32 *generalList, u32 *generalCount);
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_build_fragments_general(DevParams P, const u8 *bcl, u32 clusterBase, const Match *matches, const u64 *offsets, int trim, FragmentWork *work, ClusterPools pools, AlignList al, const u32 *list, const u32 *listCount);
 __global__ __launch_bounds__(256) void k_align_candidates(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, ClusterPools pools, AlignList al, Counters *counters);
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_finish_candidates(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, u32 nChunk, int withGaps, u32 *indelList, u32 *indelCount, FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *order);
+__global__ __launch_bounds__(64) void k_finish_candidates(DevParams P, u32 nChunk, int withGaps, u32 *indelList, u32 *indelCount, ClusterPools pools, GappedBuffers gb, const u32 *__restrict__ order, u32 *generalList, u32 *generalCount);
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_finish_candidates_general(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, int withGaps, u32 *indelList, u32 *indelCount, FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *list, const u32 *listCount);
 __global__ __launch_bounds__(64) void k_indel_fragments(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, int withGaps, const u32 *indelList, const u32 *indelCount, FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters);
-__global__ __launch_bounds__(64) void k_finish_fragments(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, u32 nChunk, int withGaps, FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *order);
+__global__ __launch_bounds__(64) void k_finish_fragments(DevParams P, u32 nChunk, int withGaps, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *__restrict__ order, u32 *generalList, u32 *generalCount);
+__global__ __launch_bounds__(64) void k_finish_fragments_general(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, int withGaps, FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *list, const u32 *listCount);
 __global__ __launch_bounds__(SELECT_BLOCK) void k_plan_rescue(const TemplateConstants *__restrict__ constants, DevReference R, u32 clusterBase, u32 nChunk, ClusterPools pools, RescueBuffers rb, const u32 *__restrict__ order);
 __global__ __launch_bounds__(64 * RW_WAVES) void k_rescue_windows(DevParams P, DevReference R, u64 totalBases, const u8 *bcl, u32 clusterBase, RescueBuffers rb);
 __global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, ClusterPools pools, RescueBuffers rb, Counters *counters);

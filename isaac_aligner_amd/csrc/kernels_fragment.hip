@@ -1,6 +1,7 @@
 // kernels_fragment.hip: see kernels.h and DESIGN.md §4
 #include "kernels.h"
 #include "bsw_kernel.h"
+#include "fragment_lean.h"
 
 __device__ inline void emitGappedJobs(const ClusterFragments &f, u32 cl, bool withGaps, const GappedBuffers &gb)
 {
@@ -16,31 +17,30 @@ __device__ inline void emitGappedJobs(const ClusterFragments &f, u32 cl, bool wi
 }
 
 
-// Fragment stage, step 1: matches -> candidate positions (buildCandidates), and one entry per candidate in the flat list
-// k_align_candidates works through.  The list space of a wave is taken with one atomic.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_build_fragments(DevParams P, const u8 *bcl, u32 clusterBase, u32 nChunk, const Match *matches, const u64 *offsets,
-                                                        int trim, FragmentWork *work, ClusterPools pools, AlignList al, const u32 *order)
+// The general form of a step runs over a list of clusters (count on the device): a workgroup of one wavefront takes 64 entries at a time
+#define ISAAC_LIST_LOOP(listCount) for (u32 listBase = blockIdx.x * 64, listN = *(listCount); listBase < listN; listBase += gridDim.x * 64)
+
+// a wavefront's clusters for the general form: one slot of the list per lane that has one
+__device__ inline void pushGeneral(bool mine, u32 cl, u32 *list, u32 *count)
 {
-    // the matches of clusters with up to BUILD_STAGE_MATCHES of them are read once and kept in LDS (buildCandidates)
-    __shared__ u64 stageKeys[BUILD_STAGE_MATCHES * 64];
-    __shared__ u8 stageTies[BUILD_STAGE_MATCHES * 64];
-    __shared__ u8 stageOrder[64][BUILD_STAGE_MATCHES];
-    MatchStage stage; stage.keys = stageKeys + threadIdx.x; stage.ties = stageTies + threadIdx.x; stage.order = stageOrder[threadIdx.x]; stage.stride = 64; stage.cap = BUILD_STAGE_MATCHES;
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 cl = 0, n = 0;
-    ClusterFragments f;
-    if (t < nChunk)
-    {
-        cl = order ? order[t] : t;                   // clusters with as many matches next to each other: see k_cluster_kinds
-        // the cluster's slots: one per seed match, at the offset of its first match in the chunk
-        const u64 chunkBegin = offsets[clusterBase], begin = offsets[clusterBase + cl], end = offsets[clusterBase + cl + 1];
-        const u32 first = u32(begin - chunkBegin);
-        const u32 cap = (u64(first) + (end - begin) <= pools.candCap) ? u32(end - begin) : 0u;     // a pool that is too small shows as CLUSTER_OVERFLOW
-        f = clusterViewNew(first, cap, pools.cands, pools.cigars);
-        buildCandidates(P, bcl + u64(clusterBase + cl) * P.clusterLength, matches + begin, u32(end - begin), trim != 0, work[cl], f, &stage);
-        n = f.nCands[0] + f.nCands[1];
-    }
-    // exclusive prefix of n over the wave, one allocation for all of it
+    const u64 ballot = __ballot(mine);
+    if (!ballot) return;
+    const u32 lane = threadIdx.x & 63;
+    u32 base = 0;
+    if (lane == u32(__ffsll((unsigned long long)ballot)) - 1) base = atomicAdd(count, u32(__popcll(ballot)));
+    base = __shfl(base, __ffsll((unsigned long long)ballot) - 1, 64);
+    if (mine) list[base + u32(__popcll(ballot & ((u64(1) << lane) - 1)))] = cl;
+}
+
+// the per-thread key area of the lean steps (fragment_lean.h): two 64-bit words per list entry, interleaved by lane
+#define ISAAC_LEAN_KEY_AREA(name)                                                     \
+    __shared__ u64 leanKeysA[LEAN_LIST_MAX * 64];                                     \
+    __shared__ u64 leanKeysB[LEAN_LIST_MAX * 64];                                     \
+    LeanKeyArea name; name.a = leanKeysA + (threadIdx.x & 63); name.b = leanKeysB + (threadIdx.x & 63); name.stride = 64;
+
+// one entry per candidate in the flat list k_align_candidates works through; the list space of a wave is taken with one atomic
+__device__ inline void listCandidates(ClusterFragments &f, u32 cl, u32 n, const AlignList &al)
+{
     u32 incl = n;
     for (u32 o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o, 64); if ((threadIdx.x & 63) >= o) incl += v; }
     const u32 total = __shfl(incl, 63, 64);
@@ -57,7 +57,64 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGME
         }
         else for (u32 r = 0; r < 2; ++r) for (u32 i = 0; i < f.nCands[r]; ++i) al.entries[at++] = (cl << 8) | (r << 7) | i;
     }
-    if (t < nChunk) clusterViewStore(f, pools.cands, pools.meta[cl]);
+}
+
+// Fragment stage, step 1: matches -> candidate positions.  Clusters with up to LEAN_LIST_MAX matches (all but a per cent) are done
+// here on keys in LDS (fragment_lean.h: leanBuildCandidates); the others are listed for k_build_fragments_general.
+__global__ __launch_bounds__(64) void k_build_fragments(DevParams P, const u8 *__restrict__ bcl, u32 clusterBase, u32 nChunk, const Match *__restrict__ matches, const u64 *__restrict__ offsets,
+                                                        int trim, ClusterPools pools, AlignList al, u32 *generalList, u32 *generalCount)
+{
+    ISAAC_LEAN_KEY_AREA(keys)
+    const u32 cl = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 n = 0;
+    ClusterFragments f;
+    bool general = false;
+    if (cl < nChunk)
+    {
+        // the cluster's slots: one per seed match, at the offset of its first match in the chunk
+        const u64 chunkBegin = offsets[clusterBase], begin = offsets[clusterBase + cl], end = offsets[clusterBase + cl + 1];
+        const u32 first = u32(begin - chunkBegin);
+        const u32 nMatches = u32(end - begin);
+        general = nMatches > LEAN_LIST_MAX || u64(first) + nMatches > pools.candCap;      // (a pool that is too small shows as CLUSTER_OVERFLOW there)
+        if (!general)
+        {
+            f = clusterViewNew(first, nMatches, pools.cands, pools.cigars);
+            leanBuildCandidates(P, bcl + u64(clusterBase + cl) * P.clusterLength, matches + begin, nMatches, trim != 0, f, keys);
+            n = f.nCands[0] + f.nCands[1];
+        }
+    }
+    pushGeneral(general, cl, generalList, generalCount);
+    listCandidates(f, cl, n, al);
+    if (cl < nChunk && !general) clusterViewStore(f, pools.cands, pools.meta[cl]);
+}
+
+// step 1 in its general form (aligner.h: buildCandidates) for the listed clusters
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_build_fragments_general(DevParams P, const u8 *bcl, u32 clusterBase, const Match *matches, const u64 *offsets,
+                                                        int trim, FragmentWork *work, ClusterPools pools, AlignList al, const u32 *list, const u32 *listCount)
+{
+    // the matches of clusters with up to BUILD_STAGE_MATCHES of them are read once and kept in LDS (buildCandidates)
+    __shared__ u64 stageKeys[BUILD_STAGE_MATCHES * 64];
+    __shared__ u8 stageTies[BUILD_STAGE_MATCHES * 64];
+    __shared__ u8 stageOrder[64][BUILD_STAGE_MATCHES];
+    MatchStage stage; stage.keys = stageKeys + threadIdx.x; stage.ties = stageTies + threadIdx.x; stage.order = stageOrder[threadIdx.x]; stage.stride = 64; stage.cap = BUILD_STAGE_MATCHES;
+    ISAAC_LIST_LOOP(listCount)
+    {
+        const u32 t = listBase + threadIdx.x;
+        u32 cl = 0, n = 0;
+        ClusterFragments f;
+        if (t < listN)
+        {
+            cl = list[t];
+            const u64 chunkBegin = offsets[clusterBase], begin = offsets[clusterBase + cl], end = offsets[clusterBase + cl + 1];
+            const u32 first = u32(begin - chunkBegin);
+            const u32 cap = (u64(first) + (end - begin) <= pools.candCap) ? u32(end - begin) : 0u;     // a pool that is too small shows as CLUSTER_OVERFLOW
+            f = clusterViewNew(first, cap, pools.cands, pools.cigars);
+            buildCandidates(P, bcl + u64(clusterBase + cl) * P.clusterLength, matches + begin, u32(end - begin), trim != 0, work[cl], f, &stage);
+            n = f.nCands[0] + f.nCands[1];
+        }
+        listCandidates(f, cl, n, al);
+        if (t < listN) clusterViewStore(f, pools.cands, pools.meta[cl]);
+    }
 }
 
 // step 2: UngappedAligner::alignUngapped, one candidate per thread
@@ -78,16 +135,41 @@ __global__ __launch_bounds__(256) void k_align_candidates(DevParams P, DevRefere
 
 // step 3: consolidation and the single-indel stage (finishCandidates), then either the cluster's gapped problems or, for the
 // 3-4 % of clusters with a candidate pair for the single-indel detector, an entry for k_indel_fragments: inside this kernel
-// nearly every wave would hold one such lane and wait for it
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_finish_candidates(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, u32 nChunk,
-                                                        int withGaps, u32 *indelList, u32 *indelCount, FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *order)
+// nearly every wave would hold one such lane and wait for it.  Lists of up to LEAN_LIST_MAX candidates are done on keys in LDS
+// (fragment_lean.h: leanFinishCandidates); clusters with a longer one, or whose candidates are still to be aligned, are listed for
+// k_finish_candidates_general.
+__global__ __launch_bounds__(64) void k_finish_candidates(DevParams P, u32 nChunk, int withGaps, u32 *indelList, u32 *indelCount, ClusterPools pools, GappedBuffers gb,
+                                                          const u32 *__restrict__ order, u32 *generalList, u32 *generalCount)
 {
-    ISAAC_STAGE_QUALITY_TABLES(Rg, R)
+    ISAAC_LEAN_KEY_AREA(keys)
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    Counters local; memset(&local, 0, sizeof(local));
+    bool general = false; u32 cl = 0;
     if (t < nChunk)
     {
-        const u32 cl = order ? order[t] : t;
+        cl = order ? order[t] : t;
+        ClusterFragments f = clusterView(pools.meta[cl], pools.cands, pools.cigars);
+        general = f.nCands[0] > LEAN_LIST_MAX || f.nCands[1] > LEAN_LIST_MAX || (f.flags & CLUSTER_ALIGN_PENDING);
+        if (!general)
+        {
+            leanFinishCandidates(P, f, keys);
+            if (clusterSimpleIndelsPending(f)) indelList[atomicAdd(indelCount, 1u)] = cl;
+            else emitGappedJobs(f, cl, withGaps != 0, gb);
+            clusterViewStore(f, pools.cands, pools.meta[cl]);
+        }
+    }
+    pushGeneral(general, cl, generalList, generalCount);
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_finish_candidates_general(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase,
+                                                        int withGaps, u32 *indelList, u32 *indelCount, FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *list, const u32 *listCount)
+{
+    ISAAC_STAGE_QUALITY_TABLES(Rg, R)
+    Counters local; memset(&local, 0, sizeof(local));
+    ISAAC_LIST_LOOP(listCount)
+    {
+        const u32 t = listBase + threadIdx.x;
+        if (t >= listN) continue;
+        const u32 cl = list[t];
         ClusterFragments f = clusterView(pools.meta[cl], pools.cands, pools.cigars);
         const u8 *clusterBcl = bcl + u64(clusterBase + cl) * P.clusterLength;
         if (f.flags & CLUSTER_ALIGN_PENDING)
@@ -133,37 +215,88 @@ __global__ __launch_bounds__(64) void k_indel_fragments(DevParams P, DevReferenc
     flushCounters(local, counters);
 }
 
-__global__ __launch_bounds__(64) void k_finish_fragments(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, u32 nChunk, int withGaps,
-                                                         FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *order)
+// the cluster's share of the cigar arena for the gapped alignments that may be accepted: one bump of the arena's counter per wave
+__device__ inline void reserveGappedCigars(ClusterFragments &f, bool active, u32 need, const ClusterPools &pools)
 {
-    const u32 slot = blockIdx.x * blockDim.x + threadIdx.x;
-    const u32 t = slot < nChunk ? (order ? order[slot] : slot) : nChunk;
-    Counters local; memset(&local, 0, sizeof(local));
-    ClusterFragments f;
-    const GappedResult *res = nullptr;
-    u32 need = 0;
-    if (t < nChunk)
-    {
-        f = clusterView(pools.meta[t], pools.cands, pools.cigars);
-        const u32 nJobs = countGappedJobs(f, withGaps != 0);
-        res = (nJobs && gb.base[t] != 0xffffffffu) ? gb.results + gb.base[t] : nullptr;
-        // room for the CIGARs of the gapped alignments that may be accepted (all of them at most; 40 words each when they are still to run)
-        if (res) for (u32 k = 0; k < nJobs; ++k) { const u32 w = res[k].nCigar; need += (0xffffffffu == w) ? 0u : w; }
-        else need = 40 * nJobs;
-    }
-    // one bump of the arena's counter per wave
     u32 incl = need;
     for (u32 o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o, 64); if ((threadIdx.x & 63) >= o) incl += v; }
     const u32 total = __shfl(incl, 63, 64);
     u32 base = 0;
     if ((threadIdx.x & 63) == 63 && total) base = atomicAdd(pools.cigarNext, total);
     base = __shfl(base, 63, 64);
+    if (active && need) clusterCigarExtra(f, pools.cigars, 3 * pools.candCap + base + incl - need, need, pools.cigarCap);
+}
+
+// step 5: the accept rule for the gapped alignments and the final consolidation.  Lists of up to LEAN_LIST_MAX candidates on keys in LDS
+// (fragment_lean.h: leanFinishFragments); clusters with a longer one, or whose gapped problems found no room in the flat pass, are listed
+// for k_finish_fragments_general.
+__global__ __launch_bounds__(64) void k_finish_fragments(DevParams P, u32 nChunk, int withGaps, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *__restrict__ order,
+                                                         u32 *generalList, u32 *generalCount)
+{
+    ISAAC_LEAN_KEY_AREA(keys)
+    const u32 slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 t = slot < nChunk ? (order ? order[slot] : slot) : nChunk;
+    u32 bswJobs = 0, bswAccepted = 0, candidates = 0;
+    ClusterFragments f;
+    const GappedResult *res = nullptr;
+    u32 need = 0;
+    bool general = false;
     if (t < nChunk)
     {
-        if (need) clusterCigarExtra(f, pools.cigars, 3 * pools.candCap + base + incl - need, need, pools.cigarCap);
-        clusterFinishFragments(P, R, bcl, clusterBase + t, withGaps != 0, res, work[t], f, local);
+        f = clusterView(pools.meta[t], pools.cands, pools.cigars);
+        general = f.nCands[0] > LEAN_LIST_MAX || f.nCands[1] > LEAN_LIST_MAX;
+        if (!general)
+        {
+            const u32 nJobs = countGappedJobs(f, withGaps != 0);
+            if (nJobs && gb.base[t] == 0xffffffffu) general = true;
+            else if (nJobs)
+            {
+                res = gb.results + gb.base[t];
+                for (u32 k = 0; k < nJobs; ++k) { const u32 w = res[k].nCigar; need += (0xffffffffu == w) ? 0u : w; }
+            }
+        }
+    }
+    pushGeneral(general, t, generalList, generalCount);
+    const bool active = t < nChunk && !general;
+    reserveGappedCigars(f, active, need, pools);
+    if (active)
+    {
+        leanFinishFragments(P, f, res, keys, bswJobs, bswAccepted, candidates);
+        if (f.flags & CLUSTER_OVERFLOW) flushCounter(&Counters::overflowClusters, 1, counters);
         clusterViewStore(f, pools.cands, pools.meta[t]);
+    }
+    flushCounter(&Counters::bswJobs, bswJobs, counters);
+    flushCounter(&Counters::bswAccepted, bswAccepted, counters);
+    flushCounter(&Counters::candidates, candidates, counters);
+}
+
+__global__ __launch_bounds__(64) void k_finish_fragments_general(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, int withGaps,
+                                                         FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *list, const u32 *listCount)
+{
+    Counters local; memset(&local, 0, sizeof(local));
+    ISAAC_LIST_LOOP(listCount)
+    {
+        const u32 slot = listBase + threadIdx.x;
+        const bool active = slot < listN;
+        const u32 t = active ? list[slot] : 0;
+        ClusterFragments f;
+        const GappedResult *res = nullptr;
+        u32 need = 0;
+        if (active)
+        {
+            f = clusterView(pools.meta[t], pools.cands, pools.cigars);
+            const u32 nJobs = countGappedJobs(f, withGaps != 0);
+            res = (nJobs && gb.base[t] != 0xffffffffu) ? gb.results + gb.base[t] : nullptr;
+            // room for the CIGARs of the gapped alignments that may be accepted (all of them at most; 40 words each when they are still to run)
+            if (res) for (u32 k = 0; k < nJobs; ++k) { const u32 w = res[k].nCigar; need += (0xffffffffu == w) ? 0u : w; }
+            else need = 40 * nJobs;
+        }
+        reserveGappedCigars(f, active, need, pools);
+        if (active)
+        {
+            clusterFinishFragments(P, R, bcl, clusterBase + t, withGaps != 0, res, work[t], f, local);
+            clusterViewStore(f, pools.cands, pools.meta[t]);
+        }
     }
     flushCounters(local, counters);
 }
-

@@ -5,6 +5,7 @@
 // against the oracle before a GPU box is spent on them.  It is not part of the product library and the product has no CPU path.
 #include "../../isaac_aligner_amd/csrc/cluster_ops.h"
 #include "../../isaac_aligner_amd/csrc/template_lean.h"
+#include "../../isaac_aligner_amd/csrc/fragment_lean.h"
 #include "../../isaac_aligner_amd/csrc/sums.h"
 #include "../../isaac_aligner_amd/csrc/bam_kernels.h"
 #include "../../isaac_aligner_amd/csrc/bgzf_kernels.h"
@@ -84,6 +85,37 @@ int emu_build_fragments(Emu *e, const u8 *bcl, u32 nClusters, int withGaps, int 
     for (u32 c = 0; c < nClusters; ++c)
     {
         ClusterFragments &f = e->frags[c];
+        if (e->flatRescue && e->lean)
+        {   // the kernels' sequence: lean forms for short lists (fragment_lean.h), the general ones for the rest
+            u64 keysA[LEAN_LIST_MAX], keysB[LEAN_LIST_MAX];
+            LeanKeyArea keys; keys.a = keysA; keys.b = keysB; keys.stride = 1;
+            const u8 *clusterBcl = bcl + u64(c) * e->P.clusterLength;
+            const u64 begin = e->matchOffsets[c], end = e->matchOffsets[c + 1];
+            bool built;
+            if (end - begin <= LEAN_LIST_MAX) built = leanBuildCandidates(e->P, clusterBcl, e->matches.data() + begin, u32(end - begin), trim != 0, f, keys);     // k_build_fragments
+            else built = buildCandidates(e->P, clusterBcl, e->matches.data() + begin, u32(end - begin), trim != 0, work[0], f);                                  // k_build_fragments_general
+            if (built)
+            {
+                for (u32 r = 0; r < e->P.nReads; ++r) for (u32 i = 0; i < f.nCands[r]; ++i) alignCandidate(e->P, e->R, clusterBcl, f, r, i, e->cnt);             // k_align_candidates
+                if (f.nCands[0] <= LEAN_LIST_MAX && f.nCands[1] <= LEAN_LIST_MAX) leanFinishCandidates(e->P, f, keys);                                            // k_finish_candidates
+                else finishCandidates(e->P, e->R, clusterBcl, work[0], f, e->cnt, true);
+            }
+            if (clusterSimpleIndelsPending(f)) clusterFinishSimpleIndels(e->P, e->R, bcl, c, work[0], f, e->cnt);   // k_indel_fragments
+            const u32 nj = countGappedJobs(f, withGaps != 0);
+            std::vector<GappedJob> jobs(nj + 1); std::vector<GappedResult> results(nj + 1);
+            if (nj) writeGappedJobs(f, c, jobs.data());
+            for (u32 j = 0; j < nj; ++j) runGappedJobSerial(e->P, e->R, bcl + u64(jobs[j].cluster) * e->P.clusterLength, jobs[j], work[0].tflags, results[j]);
+            if (f.nCands[0] <= LEAN_LIST_MAX && f.nCands[1] <= LEAN_LIST_MAX)
+            {   // k_finish_fragments
+                u32 bswJobs = 0, bswAccepted = 0, candidates = 0;
+                leanFinishFragments(e->P, f, nj ? results.data() : nullptr, keys, bswJobs, bswAccepted, candidates);
+                e->cnt.bswJobs += bswJobs; e->cnt.bswAccepted += bswAccepted; e->cnt.candidates += candidates;
+                if (f.flags & CLUSTER_OVERFLOW) ++e->cnt.overflowClusters;
+            }
+            else clusterFinishFragments(e->P, e->R, bcl, c, withGaps != 0, withGaps ? results.data() : nullptr, work[0], f, e->cnt);
+        }
+        else
+        {
         clusterBuildFragments(e->P, e->R, bcl, c, e->matches.data(), e->matchOffsets.data(), withGaps != 0, trim != 0, work[0], f, e->cnt, e->flatRescue);
         if (clusterSimpleIndelsPending(f)) clusterFinishSimpleIndels(e->P, e->R, bcl, c, work[0], f, e->cnt);   // k_indel_fragments
         if (e->flatRescue && withGaps)
@@ -95,6 +127,7 @@ int emu_build_fragments(Emu *e, const u8 *bcl, u32 nClusters, int withGaps, int 
             clusterFinishFragments(e->P, e->R, bcl, c, true, results.data(), work[0], f, e->cnt);
         }
         else clusterFinishFragments(e->P, e->R, bcl, c, withGaps != 0, 0, work[0], f, e->cnt);
+        }
         if (!out) continue;
         for (u32 r = 0; r < 2; ++r) for (u32 i = 0; i < f.nCands[r]; ++i)
         {

@@ -221,7 +221,8 @@ def test_full_size_parity(torch, oracle):
     al.set_loaded_contigs(hits)
     tls = al.determine_tls(bcl, matches, offsets)
     rec, cig = al.records_to_numpy(*al.select(bcl, matches, offsets, tls))
-    assert al.counters()["heavy_clusters"] > 0          # the wave-cooperative path for overflowing clusters is exercised
+    # (until round 3 a few clusters of this input overflowed k_select's tie lists and took the wave-per-cluster pass; the lean k_select keeps
+    # no lists to overflow.  That pass is exercised by test_residual_pass_on_most_clusters and test_repeat_family_stress.)
     ref = oracle.reference([bytes(c.cpu().numpy()) for c in contigs])
     ref.set_index(al.get_index())
     host_bcl = bcl.cpu().numpy()
