@@ -270,15 +270,19 @@ def main():
         else:
             rec_counts = [2 * args.pairs_per_step] * world
     gatherer = shard.StepGather(dist, rank, world, record_counts=rec_counts) if dist is not None else None
+    # the gathers are issued from a stream of their own that waits for the step's context: issued from the stream a context computes on, that
+    # context's later steps would queue behind the other contexts' steps and the contexts would take turns instead of overlapping
+    gather_stream = torch.cuda.Stream(device=dev) if gatherer is not None else None
     for s in range(args.steps):                       # phase 2: SelectMatchesTransition
         m, o = found[s]
         ctx = als[s % n_contexts]
         ctx.select(batches[args.warmup + s], m, o, tls, tile=tile_of(s), out=out[s][:2])
         ctx.compact_cigars_async(out[s][0], out[s][1], out[s][2], out[s][3])
         if gatherer is not None:
-            if ctx is not al:                         # the gather runs on the main stream: behind this step on its context's stream
-                torch.cuda.current_stream(dev).wait_event(streams[s % n_contexts].record_event())
-            gatherer.add(out[s][0], out[s][2], out[s][3])
+            step_done = (streams[s % n_contexts] if ctx is not al else torch.cuda.current_stream(dev)).record_event()
+            with torch.cuda.stream(gather_stream):
+                gather_stream.wait_event(step_done)
+                gatherer.add(out[s][0], out[s][2], out[s][3])
     for ctx in als:
         ctx.synchronize()
     gathered = gatherer.finish() if gatherer is not None else None
@@ -319,7 +323,8 @@ def main():
     for ctx in als[1:]:
         for key, value in ctx.counters().items():
             counters[key] += value
-    timer_names = ("find_matches", "compact_matches", "build_fragments", "align_candidates", "finish_candidates", "indel_fragments", "gapped_fragments", "gapped_fragments_rescan", "finish_fragments",
+    timer_names = ("find_matches", "compact_matches", "build_fragments", "build_fragments_general", "align_candidates", "finish_candidates", "finish_candidates_general", "indel_fragments", "gapped_fragments",
+                   "gapped_fragments_rescan", "finish_fragments", "finish_fragments_general",
                    "plan_rescue", "rescue_windows", "rescue_align", "rescue_gapped_plan", "gapped_rescue", "gapped_rescue_rescan", "sums_wave", "sums_large", "sums_xl", "sums_huge", "select",
                    "select_heavy", "select_residual")
     def read_timers(contexts):

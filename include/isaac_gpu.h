@@ -254,6 +254,15 @@ int isaac_gpu_determine_tls(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t
 int isaac_gpu_select(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t n_clusters, uint32_t tile,
                      const isaac_match *matches_dev, const uint64_t *cluster_offsets_dev, const isaac_tls *tls,
                      isaac_fragment *fragments_dev, uint32_t *cigar_dev, uint64_t cigar_capacity);
+/* The same when the caller knows the tile's match count (*n_matches_out of isaac_gpu_find_matches): isaac_gpu_select reads it from
+ * cluster_offsets_dev, which is a host wait for everything queued on the context's stream; with deferred completion this form queues its
+ * work without one.  The count sizes the call's candidate pool (one slot per match): if it is smaller than the number of matches under
+ * cluster_offsets_dev, the clusters beyond it get no candidates, are flagged (isaac_fragment::reserved bit 2, overflow_clusters) and the
+ * call -- or, with deferred completion, the next isaac_gpu_synchronize -- returns ISAAC_GPU_ECAPACITY.  (Round 3 kept these counts in a
+ * process-wide table keyed by the offsets pointer, which a recycled device address could make stale.) */
+int isaac_gpu_select_n(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t n_clusters, uint32_t tile,
+                       const isaac_match *matches_dev, uint64_t n_matches, const uint64_t *cluster_offsets_dev, const isaac_tls *tls,
+                       isaac_fragment *fragments_dev, uint32_t *cigar_dev, uint64_t cigar_capacity);
 
 /* The same from explicit candidate lists instead of match lists: TemplateBuilder::buildTemplate(contigList, restOfGenomeCorrection,
  * readMetadataList, sequencingAdapters, fragments, cluster, templateLengthStatistics) (include/alignment/TemplateBuilder.hh, the

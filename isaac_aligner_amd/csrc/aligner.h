@@ -606,10 +606,27 @@ ISAAC_HD void alignSimpleInsertion(const DevParams &P, const DevReference &R, co
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Sort keys of a list in fast memory (LDS in the kernels): entry i at a[i * stride], b[i * stride].  The comparators of the fragment stage
+// are lexicographic orders on a few integer fields of the candidates; stated on two 64-bit words per candidate they give the same answer
+// for every pair, so the same sort makes the same permutation without reading the candidates through their pointers at every comparison.
+struct LeanKeyArea { u64 *a; u64 *b; u32 stride; };
+ISAAC_HD bool leanKeyLess(const LeanKeyArea &k, u32 i, u32 j)
+{
+    const u64 ai = k.a[i * k.stride], aj = k.a[j * k.stride];
+    if (ai != aj) return ai < aj;
+    return k.b[i * k.stride] < k.b[j * k.stride];
+}
+struct KeyLessByIndex { LeanKeyArea k; ISAAC_HD bool operator()(u8 x, u8 y) const { return leanKeyLess(k, x, y); } };
+// FragmentMetadata::operator< as two integers: (contig, position) and (strand, observed length).  Positions of candidates lie within
+// a read length of their contig, and a contig has fewer than 2^40 bases.
+static const i64 LEAN_POSITION_BIAS = 4096;
+ISAAC_HD u64 leanPositionKey(u32 contigId, i64 position) { return (u64(contigId) << 41) | u64(position + LEAN_POSITION_BIAS); }
+
 // candidate list of one read: elements never move, the list is an index array (see sort.h)
 struct CandList
 {
     Cand *store; u8 *order; u32 n; u32 stored; u32 capacity; u32 overflow;
+    const LeanKeyArea *keys; u32 keyCap;        // optional: room for the sort keys of keyCap candidates, indexed like store
     ISAAC_HD Cand &at(u32 i) { return store[order[i]]; }
     ISAAC_HD const Cand &at(u32 i) const { return store[order[i]]; }
 };
@@ -633,8 +650,21 @@ struct CandLessByUnclippedPosition
 // FragmentBuilder::consolidateDuplicateFragments (FragmentBuilder.cpp:279-324)
 ISAAC_HD void consolidateDuplicateFragments(CandList &l, bool removeUnaligned)
 {
-    CandLessByPosition less; less.store = l.store;
-    exactSort(l.order, i32(l.n), less);
+    if (l.keys && l.stored <= l.keyCap)
+    {
+        for (u32 i = 0; i < l.n; ++i)
+        {
+            const u32 at = l.order[i]; const Cand &c = l.store[at];
+            l.keys->a[at * l.keys->stride] = leanPositionKey(c.contigId, c.position); l.keys->b[at * l.keys->stride] = (u64(c.reverse) << 32) | c.observedLength;
+        }
+        KeyLessByIndex less; less.k = *l.keys;
+        exactSort(l.order, i32(l.n), less);
+    }
+    else
+    {
+        CandLessByPosition less; less.store = l.store;
+        exactSort(l.order, i32(l.n), less);
+    }
     u32 first = 0;
     while (first != l.n && removeUnaligned && !candAligned(l.at(first))) ++first;
     if (first) { for (u32 i = first; i < l.n; ++i) l.order[i - first] = l.order[i]; l.n -= first; }
@@ -661,6 +691,17 @@ ISAAC_HD void consolidateDuplicateFragments(CandList &l, bool removeUnaligned)
 // the pairs.
 ISAAC_HD void sortForSimpleIndels(CandList &l, const CigarPool &pool)
 {
+    if (l.keys && l.stored <= l.keyCap)
+    {
+        for (u32 i = 0; i < l.n; ++i)
+        {
+            const u32 at = l.order[i]; const Cand &c = l.store[at];
+            l.keys->a[at * l.keys->stride] = leanPositionKey(c.contigId, candUnclippedPosition(c, pool.words)); l.keys->b[at * l.keys->stride] = 0;
+        }
+        KeyLessByIndex less; less.k = *l.keys;
+        exactSort(l.order, i32(l.n), less);
+        return;
+    }
     CandLessByUnclippedPosition less; less.store = l.store; less.pool = pool.words;
     exactSort(l.order, i32(l.n), less);
 }
@@ -738,12 +779,18 @@ struct GappedJob { Cand in; u32 cluster; u32 endCyclesMasked; u32 tag; u32 pad; 
 struct GappedResult { Cand out; u32 matchCount; u32 nCigar; u32 cigar[40]; };
 static_assert(sizeof(GappedJob) == 80 && sizeof(GappedResult) == 232, "gapped job layouts");
 
-// per-thread scratch of the fragment stage
+// per-thread scratch of the fragment stage's general form: where the index arrays live is the caller's business (LDS in the kernels)
 struct FragmentWork
 {
-    u8 order[CAND_CAP];
-    u8 matchOrder[MATCH_CAP_MAX];
-    u32 tflags[3 * 512];          // banded SW traceback flags, reads up to 512 cycles
+    u8 *order;                    // CAND_CAP entries
+    u8 *matchOrder;               // MATCH_CAP_MAX entries (not needed when every cluster's matches fit the MatchStage)
+    u32 *tflags;                  // 3 * 512 words: banded SW traceback flags, reads up to 512 cycles (serial gapped alignment only)
+    const LeanKeyArea *keys; u32 keyCap;   // optional room for the sort keys of keyCap candidates (CandList::keys)
+};
+struct FragmentWorkStore
+{
+    u8 order[CAND_CAP]; u8 matchOrder[MATCH_CAP_MAX]; u32 tflags[3 * 512];
+    FragmentWork bind() { FragmentWork w; w.order = order; w.matchOrder = matchOrder; w.tflags = tflags; w.keys = 0; w.keyCap = 0; return w; }
 };
 
 struct MatchLess
@@ -834,7 +881,7 @@ ISAAC_HD bool buildCandidates(const DevParams &P, const u8 *clusterBcl, const Ma
     {
         // the candidates are made where they stay: read 0's from the cluster's first slot, read 1's behind read 0's consolidated list
         if (r) { out.cands[1] = out.cands[0] + out.nCands[0]; out.candCap[1] = out.candCap[0] - out.nCands[0]; }
-        CandList l; l.store = out.cands[r]; l.order = work.order; l.n = 0; l.stored = 0; l.capacity = imin(CAND_CAP, out.candCap[r]); l.overflow = 0;
+        CandList l; l.store = out.cands[r]; l.order = work.order; l.n = 0; l.stored = 0; l.capacity = imin(CAND_CAP, out.candCap[r]); l.overflow = 0; l.keys = work.keys; l.keyCap = work.keyCap;
         for (u32 k = 0; k < nMatches; ++k)
         {
             const u32 at = matchOrder[k];
@@ -892,7 +939,7 @@ ISAAC_HD void finishCandidates(const DevParams &P, const DevReference &R, const 
         const u32 n = out.nCands[r];
         if (!n) continue;
         ReadView read; read.bcl = clusterBcl + P.readOffset[r]; read.length = P.readLength[r]; read.firstCycle = P.firstCycle[r]; read.endCyclesMasked = out.endCyclesMasked[r];
-        CandList l; l.store = out.cands[r]; l.order = work.order; l.n = n; l.stored = n; l.capacity = CAND_CAP; l.overflow = 0;
+        CandList l; l.store = out.cands[r]; l.order = work.order; l.n = n; l.stored = n; l.capacity = CAND_CAP; l.overflow = 0; l.keys = work.keys; l.keyCap = work.keyCap;
         for (u32 i = 0; i < n; ++i) work.order[i] = u8(i);
         consolidateDuplicateFragments(l, true);
         STAMP(26);
@@ -941,7 +988,7 @@ ISAAC_HD void finishSimpleIndels(const DevParams &P, const DevReference &R, cons
         out.flags &= ~(CLUSTER_INDEL_PENDING << r);
         ReadView read; read.bcl = clusterBcl + P.readOffset[r]; read.length = P.readLength[r]; read.firstCycle = P.firstCycle[r]; read.endCyclesMasked = out.endCyclesMasked[r];
         const u32 n = out.nCands[r];
-        CandList l; l.store = out.cands[r]; l.order = order; l.n = n; l.stored = n; l.capacity = CAND_CAP; l.overflow = 0;
+        CandList l; l.store = out.cands[r]; l.order = order; l.n = n; l.stored = n; l.capacity = CAND_CAP; l.overflow = 0; l.keys = 0; l.keyCap = 0;
         for (u32 i = 0; i < n; ++i) order[i] = u8(i);
         u32 si = 0;
         simpleIndelPairs(P, R, read, pool, l, si, stage);
@@ -995,7 +1042,7 @@ ISAAC_HD void runGappedJobSerial(const DevParams &P, const DevReference &R, cons
 // final consolidation.
 // `provider(r, i)` returns the GappedResult of candidate i of read r (called in countGappedJobs order) or NULL for "no gapped alignment"
 template <typename ProviderF>
-ISAAC_HD void finishFragments(const DevParams &P, ClusterFragments &out, ProviderF &provider, u8 *order, Counters &cnt)
+ISAAC_HD void finishFragments(const DevParams &P, ClusterFragments &out, ProviderF &provider, u8 *order, Counters &cnt, const LeanKeyArea *keys = 0, u32 keyCap = 0)
 {
     if (!out.built) return;
     CigarPool pool; pool.words = out.cigarPool; pool.used = out.cigarUsed; pool.capacity = out.cigarCap; pool.overflow = 0;
@@ -1022,7 +1069,7 @@ ISAAC_HD void finishFragments(const DevParams &P, ClusterFragments &out, Provide
                 }
             }
         }
-        CandList l; l.store = out.cands[r]; l.order = order; l.n = n; l.stored = n; l.capacity = CAND_CAP; l.overflow = 0;
+        CandList l; l.store = out.cands[r]; l.order = order; l.n = n; l.stored = n; l.capacity = CAND_CAP; l.overflow = 0; l.keys = keys; l.keyCap = keyCap;
         for (u32 i = 0; i < n; ++i) order[i] = u8(i);
         consolidateDuplicateFragments(l, true);
         // apply the permutation in place (cycle following); order[i] = index of the element that belongs at i

@@ -48,12 +48,12 @@ struct SerialGappedProvider
 ISAAC_HD void clusterFinishFragments(const DevParams &P, const DevReference &R, const u8 *bcl, u32 cluster, bool withGaps, const GappedResult *results,
                                      FragmentWork &work, ClusterFragments &out, Counters &cnt)
 {
-    if (!withGaps) { NoGappedProvider p; finishFragments(P, out, p, work.order, cnt); }
-    else if (results) { FlatGappedProvider p; p.next = results; finishFragments(P, out, p, work.order, cnt); }
+    if (!withGaps) { NoGappedProvider p; finishFragments(P, out, p, work.order, cnt, work.keys, work.keyCap); }
+    else if (results) { FlatGappedProvider p; p.next = results; finishFragments(P, out, p, work.order, cnt, work.keys, work.keyCap); }
     else
     {
         SerialGappedProvider p; p.P = &P; p.R = &R; p.clusterBcl = bcl + u64(cluster) * P.clusterLength; p.frags = &out; p.tflags = work.tflags;
-        finishFragments(P, out, p, work.order, cnt);
+        finishFragments(P, out, p, work.order, cnt, work.keys, work.keyCap);
     }
     if (out.flags & CLUSTER_OVERFLOW) ++cnt.overflowClusters;
 }

@@ -30,14 +30,6 @@ struct Nibbles
 };
 static const u64 NIBBLES_IDENTITY = 0xfedcba9876543210ull;
 
-// per-thread key area: entry i at a[i * stride], b[i * stride] (LDS interleaved by lane in the kernels, plain arrays in the CPU harness)
-struct LeanKeyArea { u64 *a; u64 *b; u32 stride; };
-ISAAC_HD bool leanKeyLess(const LeanKeyArea &k, u32 i, u32 j)
-{
-    const u64 ai = k.a[i * k.stride], aj = k.a[j * k.stride];
-    if (ai != aj) return ai < aj;
-    return k.b[i * k.stride] < k.b[j * k.stride];
-}
 // stable insertion sort of order[0 .. n) by the keys of the area
 ISAAC_HD void leanSortOrder(Nibbles &order, u32 n, const LeanKeyArea &k)
 {
@@ -67,11 +59,6 @@ ISAAC_HD void leanApplyOrder(Cand *store, Nibbles order, u32 n)
         order.set(i, src);
     }
 }
-
-// FragmentMetadata::operator< as two integers: (contig, position) and (strand, observed length).  Positions of candidates lie within
-// a read length of their contig, and a contig has fewer than 2^40 bases.
-static const i64 LEAN_POSITION_BIAS = 4096;
-ISAAC_HD u64 leanPositionKey(u32 contigId, i64 position) { return (u64(contigId) << 41) | u64(position + LEAN_POSITION_BIAS); }
 
 // FragmentBuilder::consolidateDuplicateFragments (FragmentBuilder.cpp:279-324) on a list of up to LEAN_LIST_MAX candidates, applied in
 // place: the list ends up sorted, without its unaligned members (removeUnaligned), equal neighbours merged.  Returns the new length.
@@ -116,6 +103,46 @@ ISAAC_HD u32 leanConsolidate(Cand *store, u32 n, bool removeUnaligned, const Lea
     }
     leanApplyOrder(store, order, n);
     return n;
+}
+
+// The sorted candidate keys of one read written as candidates: runs of equal (contig, position, strand) are one candidate, the first of the
+// run with the seeds of all of them (FragmentBuilder::consolidateDuplicateFragments on freshly added matches).  index(at): the key entry at
+// list position `at`.  Key words: a = leanPositionKey, b = strand << 45 | seed position << 5 | seed << 1 | "the table marks the k-mer as having neighbours".
+struct NibbleIndex { Nibbles order; ISAAC_HD u32 operator()(u32 at) const { return order.get(at); } };
+struct ByteIndex { const u8 *order; ISAAC_HD u32 operator()(u32 at) const { return order[at]; } };
+template <typename IndexF>
+ISAAC_HD u32 leanEmitCandidates(const DevParams &P, Cand *store, u32 r, u32 repeatSeedsCount, u32 n, const LeanKeyArea &k, IndexF index)
+{
+    u32 stored = 0;
+    for (u32 at = 0; at < n;)
+    {
+        const u32 i = index(at);
+        const u64 a = k.a[i * k.stride], b = k.b[i * k.stride];
+        const u32 s = u32(b >> 1) & 0xfu;
+        const u16 offset = P.seeds[s].offset;
+        u32 uniqueSeedCount = (b & 1) ? 0u : 1u;
+        u16 nonUniqueFirst = (b & 1) ? offset : NON_UNIQUE_NONE, nonUniqueSecond = (b & 1) ? offset : u16(0);
+        u32 next = at + 1;
+        for (; next < n; ++next)
+        {
+            const u32 j = index(next);
+            const u64 bj = k.b[j * k.stride];
+            if (k.a[j * k.stride] != a || (((bj ^ b) >> 45) & 1)) break;
+            const u16 offsetJ = P.seeds[u32(bj >> 1) & 0xfu].offset;
+            if (bj & 1) { nonUniqueFirst = imin(nonUniqueFirst, offsetJ); nonUniqueSecond = imax(nonUniqueSecond, offsetJ); } else ++uniqueSeedCount;
+        }
+        Cand f;
+        candInit(f, r);
+        f.firstSeedIndex = (signed char)s;
+        f.contigId = u32(a >> 41);
+        f.position = i64(a & ((u64(1) << 41) - 1)) - LEAN_POSITION_BIAS;
+        f.reverse = u8((b >> 45) & 1);
+        f.repeatSeedsCount = u16(repeatSeedsCount);
+        f.uniqueSeedCount = u16(uniqueSeedCount); f.nonUniqueFirst = nonUniqueFirst; f.nonUniqueSecond = nonUniqueSecond;
+        store[stored++] = f;
+        at = next;
+    }
+    return stored;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -181,38 +208,99 @@ ISAAC_HD bool leanBuildCandidates(const DevParams &P, const u8 *clusterBcl, cons
         Nibbles order; order.v = 0; u32 n = 0;
         while (mine) { const u32 i = u32(__builtin_ctz(mine)); mine &= mine - 1; order.set(n++, i); }
         leanSortOrder(order, n, k);
-        // runs of equal (contig, position, strand) are one candidate: the first of the run with the seeds of all of them
-        Cand *store = out.cands[r];
-        u32 stored = 0;
-        for (u32 at = 0; at < n;)
-        {
-            const u32 i = order.get(at);
-            const u64 a = k.a[i * k.stride], b = k.b[i * k.stride];
-            const u32 s = u32(b >> 1) & 0xfu;
-            const u16 offset = P.seeds[s].offset;
-            u32 uniqueSeedCount = (b & 1) ? 0u : 1u;
-            u16 nonUniqueFirst = (b & 1) ? offset : NON_UNIQUE_NONE, nonUniqueSecond = (b & 1) ? offset : u16(0);
-            u32 next = at + 1;
-            for (; next < n; ++next)
-            {
-                const u32 j = order.get(next);
-                const u64 bj = k.b[j * k.stride];
-                if (k.a[j * k.stride] != a || ((bj ^ b) >> 45)) break;
-                const u16 offsetJ = P.seeds[u32(bj >> 1) & 0xfu].offset;
-                if (bj & 1) { nonUniqueFirst = imin(nonUniqueFirst, offsetJ); nonUniqueSecond = imax(nonUniqueSecond, offsetJ); } else ++uniqueSeedCount;
-            }
-            Cand f;
-            candInit(f, r);
-            f.firstSeedIndex = (signed char)s;
-            f.contigId = u32(a >> 41);
-            f.position = i64(a & ((u64(1) << 41) - 1)) - LEAN_POSITION_BIAS;
-            f.reverse = u8(b >> 45);
-            f.repeatSeedsCount = u16(repeatSeedsCount);
-            f.uniqueSeedCount = u16(uniqueSeedCount); f.nonUniqueFirst = nonUniqueFirst; f.nonUniqueSecond = nonUniqueSecond;
-            store[stored++] = f;
-            at = next;
-        }
+        const u32 stored = leanEmitCandidates(P, out.cands[r], r, repeatSeedsCount, n, k, NibbleIndex{order});
         out.nCands[r] = stored;
+    }
+    out.built = built;
+    return built;
+}
+
+// The same for a cluster with any number of matches that its key area holds (the general form of k_build_fragments): the two sorts are the
+// instruction-exact std::sort of sort.h over index arrays -- the match order, then per read the order of the candidates under
+// FragmentMetadata::operator< alone, in which equal candidates keep whatever place std::sort gives them -- on keys in the area instead of
+// on match and candidate records; candidates are written once, in their final order.  matchOrder, candOrder: nMatches bytes each.
+// Precondition: the cluster's slots hold nMatches candidates and a read has at most CAND_CAP of them.
+struct MatchKeyLess
+{
+    LeanKeyArea k;              // a = location, b = seed << 1 | strand
+    ISAAC_HD bool operator()(u8 x, u8 y) const { return leanKeyLess(k, x, y); }
+};
+struct CandKeyLess
+{
+    LeanKeyArea k;              // a = leanPositionKey, b bit 45 = strand
+    ISAAC_HD bool operator()(u8 x, u8 y) const
+    {
+        const u64 ax = k.a[x * k.stride], ay = k.a[y * k.stride];
+        if (ax != ay) return ax < ay;
+        return ((k.b[x * k.stride] >> 45) & 1) < ((k.b[y * k.stride] >> 45) & 1);
+    }
+};
+ISAAC_HD bool keyedBuildCandidates(const DevParams &P, const u8 *clusterBcl, const Match *matches, u32 nMatches, bool trim, ClusterFragments &out, const LeanKeyArea &k, u8 *matchOrder, u8 *candOrder)
+{
+    out.nCands[0] = out.nCands[1] = 0; out.cigarUsed = 0; out.flags = 0; out.repeatSeedsCount = 0; out.built = 0;
+    out.cands[1] = out.cands[0]; out.candCap[1] = out.candCap[0];
+    out.endCyclesMasked[0] = trim ? trimLowQualityEnd(clusterBcl + P.readOffset[0], P.readLength[0], P.baseQualityCutoff) : 0;
+    out.endCyclesMasked[1] = (trim && 1 < P.nReads) ? trimLowQualityEnd(clusterBcl + P.readOffset[1], P.readLength[1], P.baseQualityCutoff) : 0;
+    if (!nMatches) return false;
+    u64 countsLow = 0, countsHigh = 0; u32 tooMany = 0;
+    bool any = false;
+    for (u32 i = 0; i < nMatches; ++i)
+    {
+        const u64 location = matches[i].location, seedId = matches[i].seedId;
+        k.a[i * k.stride] = location; k.b[i * k.stride] = seedId & 0x1ff;
+        matchOrder[i] = u8(i);
+        if (refposIsNoMatch(location)) continue;
+        any = true;
+        const u32 s = seedIdSeed(seedId);
+        if (refposIsTooMany(location)) tooMany |= 1u << s;
+        else if (s & 8) countsHigh += u64(1) << (8 * (s & 7)); else countsLow += u64(1) << (8 * s);
+    }
+    if (!any) return false;
+    u32 skipSeeds = tooMany;
+    u32 repeatSeedsCount = 0;
+    for (u32 s = 0; s < P.nSeeds; ++s)
+    {
+        const u32 count = u32(((s & 8) ? countsHigh : countsLow) >> (8 * (s & 7))) & 0xffu;
+        if (count >= P.repeatThreshold) skipSeeds |= 1u << s;
+        if ((skipSeeds >> s) & 1) ++repeatSeedsCount;
+    }
+    out.repeatSeedsCount = repeatSeedsCount;
+    // the reference adds candidates in sorted match order: that order is the input order of the sort by position
+    { MatchKeyLess ml; ml.k = k; exactSort(matchOrder, i32(nMatches), ml); }
+    // every match becomes its candidate's keys in place; bits 62 / 63 of b: it counts / it belongs to read 1
+    for (u32 i = 0; i < nMatches; ++i)
+    {
+        const u64 location = k.a[i * k.stride]; const u32 tie = u32(k.b[i * k.stride]);
+        k.b[i * k.stride] = 0;
+        if (refposIsNoMatch(location) || refposIsTooMany(location)) continue;
+        const u32 s = tie >> 1;
+        if ((skipSeeds >> s) & 1) continue;
+        const DevSeed &seed = P.seeds[s];
+        const u32 r = seed.readIndex;
+        if (r >= P.nReads) continue;
+        const bool reverse = tie & 1;
+        const i64 seedPosition = i64(refposPosition(location));
+        const i64 position = reverse ? seedPosition + seed.length + seed.offset - i64(P.readLength[r]) : seedPosition - seed.offset;
+        const bool nonUnique = seed.length != 64 && (location & 1);
+        k.a[i * k.stride] = leanPositionKey(refposContig(location), position);
+        k.b[i * k.stride] = (u64(1) << 62) | (u64(r) << 63) | (u64(reverse) << 45) | (u64(seedPosition) << 5) | (u64(s) << 1) | u64(nonUnique);
+    }
+    bool built = false;
+    for (u32 r = 0; r < P.nReads; ++r)
+    {
+        if (r) { out.cands[1] = out.cands[0] + out.nCands[0]; out.candCap[1] = out.candCap[0] - out.nCands[0]; }
+        u32 n = 0;
+        for (u32 at = 0; at < nMatches; ++at)
+        {
+            const u32 i = matchOrder[at];
+            const u64 b = k.b[i * k.stride];
+            if (((b >> 62) & 1) && u32(b >> 63) == r) candOrder[n++] = u8(i);
+        }
+        if (!n) continue;
+        built = true;
+        { CandKeyLess cl; cl.k = k; exactSort(candOrder, i32(n), cl); }
+        ByteIndex index; index.order = candOrder;
+        out.nCands[r] = leanEmitCandidates(P, out.cands[r], r, repeatSeedsCount, n, k, index);
     }
     out.built = built;
     return built;

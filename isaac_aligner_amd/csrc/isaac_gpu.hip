@@ -82,8 +82,7 @@ struct isaac_gpu_ctx
     // work
     DevBuf<Match> staging; DevBuf<u32> counts, chunkOffsets; DevBuf<u8> cubTemp; DevBuf<u32> contigHits; std::vector<u32> hContigHits;
     // the chunk's candidates: 32 B of ClusterMeta per cluster, one slot per seed match in the candidate pool, the cigar arena (types.h)
-    DevBuf<ClusterMeta> clusterMeta; DevBuf<Cand> candPool; DevBuf<u32> cigarArena, cigarNext; ClusterPools pools; DevBuf<FragmentWork> fragWork;
-    struct KnownTotal { const void *offsets; u32 nClusters; u64 total; };
+    DevBuf<ClusterMeta> clusterMeta; DevBuf<Cand> candPool; DevBuf<u32> cigarArena, cigarNext; ClusterPools pools; DevBuf<u32> fragTflags, poolShort; DevBuf<u8> fragMatchOrder;
     DevBuf<GappedJob> gappedJobs, rescueGappedJobs; DevBuf<GappedResult> gappedResults, rescueGappedResults; DevBuf<u32> gappedBase, gappedCounters;
     DevBuf<u8> heavyArena, clusterKinds; DevBuf<u32> clusterOrder, kindCounts; DevBuf<u32> overflowList; DevBuf<u32> overflowCount; DevBuf<ClusterSums> clusterSums; DevBuf<u32> mediumList, largeList, xlList, hugeList, longJobs; DevBuf<u8> hugeKeys;
     DevBuf<TlsSample> tlsSamples; DevBuf<u32> cigarLengths, cigarOffsets; DevBuf<u64> cigarTotal;
@@ -514,25 +513,6 @@ static const u32 *orderClustersByKind(isaac_gpu_ctx *c, u32 n, const u32 *jobCou
     return c->clusterOrder.p;
 }
 
-// match counts of recent isaac_gpu_find_matches calls, by offsets buffer: isaac_gpu_select sizes its candidate pool by them without asking
-// the device.  One list for the process: the lookups of a run are often made by one context and the selections by others that share its table.
-static std::mutex g_knownTotalsMutex;
-static std::vector<isaac_gpu_ctx::KnownTotal> g_knownTotals;
-static void rememberMatchTotal(const void *offsets, u32 nClusters, u64 total)
-{
-    std::lock_guard<std::mutex> lock(g_knownTotalsMutex);
-    auto &known = g_knownTotals;
-    known.erase(std::remove_if(known.begin(), known.end(), [&](const isaac_gpu_ctx::KnownTotal &k) { return k.offsets == offsets; }), known.end());
-    if (known.size() >= 256) known.erase(known.begin());
-    known.push_back({ offsets, nClusters, total });
-}
-static u64 knownMatchTotal(const void *offsets, u32 nClusters)
-{
-    std::lock_guard<std::mutex> lock(g_knownTotalsMutex);
-    for (const auto &k : g_knownTotals) if (k.offsets == offsets && k.nClusters == nClusters) return std::max<u64>(k.total, 1);
-    return 0;
-}
-
 // Chunk size for a call over nClusters clusters.  Kernel durations end in a tail set by their slowest waves, so fewer, larger
 // launches are faster; the buffers grow with the largest call seen instead of being sized for the upper bound at once.
 u32 chunkFor(isaac_gpu_ctx *c, u32 nClusters)
@@ -615,7 +595,19 @@ int isaac_gpu_download(isaac_gpu_ctx *c, void *host, const void *dev, uint64_t b
 { ISAAC_TRY HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
 int isaac_gpu_copy(isaac_gpu_ctx *c, void *dstDev, const void *srcDev, uint64_t bytes)
 { ISAAC_TRY if (bytes) HIP_CHECK(hipMemcpyAsync(dstDev, srcDev, bytes, hipMemcpyDeviceToDevice, c->stream)); return 0; ISAAC_CATCH }
-int isaac_gpu_synchronize(isaac_gpu_ctx *c) { ISAAC_TRY HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
+// the candidate pool of a selection was sized from a match count that was too small (isaac_gpu_select_n): clusters past its end are flagged
+// and counted, and the first wait after the call says so
+static int checkPoolShort(isaac_gpu_ctx *c)
+{
+    if (!c->poolShort.p) return 0;
+    u32 flag = 0;
+    HIP_CHECK(hipMemcpyAsync(&flag, c->poolShort.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (!flag) return 0;
+    HIP_CHECK(hipMemsetAsync(c->poolShort.p, 0, 4, c->stream));
+    return fail(ISAAC_GPU_ECAPACITY, "n_matches given to isaac_gpu_select_n is smaller than the number of matches under cluster_offsets_dev: clusters beyond it have no candidates (overflow_clusters)");
+}
+int isaac_gpu_synchronize(isaac_gpu_ctx *c) { ISAAC_TRY HIP_CHECK(hipStreamSynchronize(c->stream)); return checkPoolShort(c); ISAAC_CATCH }
 int isaac_gpu_set_deferred_completion(isaac_gpu_ctx *c, int enabled)
 {
     ISAAC_TRY
@@ -975,6 +967,7 @@ int isaac_gpu_set_index_dev(isaac_gpu_ctx *c, const uint64_t *kmers, const uint6
     if (n >= (u64(1) << 32)) return fail(ISAAC_GPU_EINVAL, "tables of 2^32 entries and more are not supported");
     if (maskOffsets && (maskOffsets[0] != 0 || maskOffsets[nMasks] != n)) return fail(ISAAC_GPU_EINVAL, "mask_offsets must run from 0 to n_entries");
     HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->kmers.p && kmers == c->kmers.p && positions == c->positions.p && n == c->nKmers) return 0;      // the context's own table handed back to it: nothing to adopt (and nothing to free)
     c->kmers.release(); c->positions.release();
     c->kmersBorrowed = kmers; c->positionsBorrowed = positions; c->nKmers = n; c->hasKaryotype = false;
     if (maskOffsets) c->maskOffsets.assign(maskOffsets, maskOffsets + nMasks + 1); else { c->maskOffsets.assign(1, 0); c->maskOffsets.push_back(n); }
@@ -1040,7 +1033,6 @@ int isaac_gpu_find_matches(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClust
     if (contigHasMatches) for (u32 i = 0; i < c->nContigs; ++i) contigHasMatches[i] |= u8(c->hContigHits[i] != 0);
     if (nMatchesOut) *nMatchesOut = base;
     if (base > capacity) return fail(ISAAC_GPU_ECAPACITY, "matches_dev is too small");
-    rememberMatchTotal(clusterOffsets, nClusters, base);
     return 0;
     ISAAC_CATCH
 }
@@ -1097,6 +1089,8 @@ static void preparePools(isaac_gpu_ctx *c, u64 slots)
     c->clusterMeta.reserve(c->chunkNow); c->candPool.reserve(cap); c->cigarArena.reserve(3 * cap + 32 * u64(c->chunkNow)); c->cigarNext.reserve(1);
     c->pools.meta = c->clusterMeta.p; c->pools.cands = c->candPool.p; c->pools.cigars = c->cigarArena.p; c->pools.candCap = u32(cap);
     c->pools.cigarCap = u32(3 * cap + 32 * u64(c->chunkNow)); c->pools.cigarNext = c->cigarNext.p;
+    if (!c->poolShort.p) { c->poolShort.reserve(1); HIP_CHECK(hipMemsetAsync(c->poolShort.p, 0, 4, c->stream)); }
+    c->pools.shortFlag = c->poolShort.p;
 }
 // entries [0] and [n] of a device array of offsets (a host wait: only the calls outside the timed path use it)
 static u64 offsetsSpan(isaac_gpu_ctx *c, const uint64_t *offsetsDev, u32 n)
@@ -1111,12 +1105,11 @@ static u64 offsetsSpan(isaac_gpu_ctx *c, const uint64_t *offsetsDev, u32 n)
 // The fragment stage of one chunk.  Its three thread-per-cluster steps each run twice: the lean form (fragment_lean.h) over all clusters, which
 // lists the few with a list longer than LEAN_LIST_MAX or a capacity miss, and the general form (aligner.h) over that list, its count read on
 // the device (a launch over an empty list is a few microseconds).
-static const u32 GENERAL_BLOCKS = 2048;
 static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clusterBase, u32 n, const isaac_match *matches, const uint64_t *offsets, int withGaps, int trim)
 {
     // c->pools: see preparePools
     HIP_CHECK(hipMemsetAsync(c->cigarNext.p, 0, 4, c->stream));
-    c->fragWork.reserve(c->chunkNow); c->indelList.reserve(c->chunkNow);
+    c->fragTflags.reserve(size_t(GENERAL_BLOCKS) * 16 * 3 * 512); c->fragMatchOrder.reserve(size_t(GENERAL_BLOCKS) * 16 * (MATCH_CAP_MAX + CAND_CAP)); c->indelList.reserve(c->chunkNow);
     c->generalList.reserve(size_t(3) * c->chunkNow); c->generalCount.reserve(4);
     HIP_CHECK(hipMemsetAsync(c->generalCount.p, 0, 16, c->stream));
     u32 *const list0 = c->generalList.p, *const list1 = list0 + c->chunkNow, *const list2 = list1 + c->chunkNow;
@@ -1128,7 +1121,10 @@ static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clust
         ScopedTimer t(c, "build_fragments");
         // (in the order of their match counts this kernel is slower: neighbouring threads no longer read neighbouring matches)
         k_build_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, bcl, clusterBase, n, reinterpret_cast<const Match *>(matches), offsets, trim, c->pools, al, list0, c->generalCount.p);
-        k_build_fragments_general<<<GENERAL_BLOCKS, 64, 0, c->stream>>>(c->P, bcl, clusterBase, reinterpret_cast<const Match *>(matches), offsets, trim, c->fragWork.p, c->pools, al, list0, c->generalCount.p);
+    }
+    {
+        ScopedTimer t(c, "build_fragments_general");
+        k_build_fragments_general<<<GENERAL_BLOCKS, 64, 0, c->stream>>>(c->P, bcl, clusterBase, reinterpret_cast<const Match *>(matches), offsets, trim, c->fragMatchOrder.p, c->fragMatchOrder.p + size_t(GENERAL_BLOCKS) * 16 * MATCH_CAP_MAX, c->pools, al, list0, c->generalCount.p);
         HIP_CHECK(hipGetLastError());
     }
     {
@@ -1142,19 +1138,25 @@ static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clust
         order = orderClustersByKind(c, n, nullptr);
 #endif
         k_finish_candidates<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, n, withGaps, c->indelList.p, c->gappedCounters.p + 2, c->pools, gb, order, list1, c->generalCount.p + 1);
-        k_finish_candidates_general<<<GENERAL_BLOCKS, 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, withGaps, c->indelList.p, c->gappedCounters.p + 2, c->fragWork.p, c->pools, gb, c->counters.p, list1, c->generalCount.p + 1);
+    }
+    {
+        ScopedTimer t(c, "finish_candidates_general");
+        k_finish_candidates_general<<<GENERAL_BLOCKS, 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, withGaps, c->indelList.p, c->gappedCounters.p + 2, c->pools, gb, c->counters.p, list1, c->generalCount.p + 1);
         HIP_CHECK(hipGetLastError());
     }
     {
         ScopedTimer t(c, "indel_fragments");
-        k_indel_fragments<<<8192, 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, withGaps, c->indelList.p, c->gappedCounters.p + 2, c->fragWork.p, c->pools, gb, c->counters.p);
+        k_indel_fragments<<<8192, 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, withGaps, c->indelList.p, c->gappedCounters.p + 2, c->pools, gb, c->counters.p);
         HIP_CHECK(hipGetLastError());
     }
     if (withGaps) launchGappedJobs(c, bcl, clusterBase, gb, "gapped_fragments", "gapped_fragments_rescan");
     {
         ScopedTimer t(c, "finish_fragments");
         k_finish_fragments<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, n, withGaps, c->pools, gb, c->counters.p, order, list2, c->generalCount.p + 2);
-        k_finish_fragments_general<<<GENERAL_BLOCKS, 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, withGaps, c->fragWork.p, c->pools, gb, c->counters.p, list2, c->generalCount.p + 2);
+    }
+    {
+        ScopedTimer t(c, "finish_fragments_general");
+        k_finish_fragments_general<<<GENERAL_BLOCKS, 64, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, withGaps, c->fragTflags.p, c->pools, gb, c->counters.p, list2, c->generalCount.p + 2);
         HIP_CHECK(hipGetLastError());
     }
 }
@@ -1223,7 +1225,8 @@ int isaac_gpu_determine_tls(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
 }
 
 // what fills the chunk's ClusterFragments: the fragment stage on match lists (isaac_gpu_select) or caller-supplied candidates
-struct FragmentSource { const isaac_match *matches; const uint64_t *offsets; const isaac_candidate *candidates; const uint64_t *candidateOffsets; const uint32_t *candidateCigars; };
+struct FragmentSource { const isaac_match *matches; const uint64_t *offsets; const isaac_candidate *candidates; const uint64_t *candidateOffsets; const uint32_t *candidateCigars;
+                        uint64_t nMatches; bool nMatchesKnown; };
 } // extern "C"
 __global__ void k_set_template_constants(TemplateConstants k, TemplateConstants *dst) { *dst = k; }
 
@@ -1277,12 +1280,13 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         HIP_CHECK(hipGetLastError());
     }
     const GappedBuffers gbRescue = gappedBuffers(c, 1);
-    {   // how many candidate slots a chunk can need: the tile's match count when a recent isaac_gpu_find_matches call on this offsets buffer
-        // told (no host wait), the caller's candidate count for explicit lists, else the hard per-cluster bound
+    {   // how many candidate slots a chunk can need: the tile's match count -- given by the caller (isaac_gpu_select_n: no host wait), or read from
+        // the offsets -- or the caller's candidate count for explicit lists.  A count that is too small shows as ISAAC_GPU_ECAPACITY (poolShort).
         u64 slots = 0;
         if (source.candidates) slots = nClusters ? offsetsSpan(c, source.candidateOffsets, nClusters) : 0;
-        else slots = knownMatchTotal(source.offsets, nClusters);
-        preparePools(c, slots);
+        else if (source.nMatchesKnown) slots = source.nMatches;
+        else slots = nClusters ? offsetsSpan(c, source.offsets, nClusters) : 0;
+        preparePools(c, std::max<u64>(slots, 1));
     }
     for (u32 done = 0; done < nClusters; done += chunk)
     {
@@ -1371,7 +1375,7 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
     }
     if (c->deferredCompletion) return 0;      // the caller enqueues its next call behind this one; isaac_gpu_synchronize waits for the last one
     HIP_CHECK(hipStreamSynchronize(st));
-    return 0;
+    return checkPoolShort(c);
     ISAAC_CATCH
 }
 extern "C" {
@@ -1379,6 +1383,12 @@ int isaac_gpu_select(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, u
                      isaac_fragment *fragments, uint32_t *cigar, uint64_t cigarCapacity)
 {
     FragmentSource source; std::memset(&source, 0, sizeof(source)); source.matches = matches; source.offsets = offsets;
+    return selectFromSource(c, bcl, nClusters, tile, source, tls, fragments, cigar, cigarCapacity);
+}
+int isaac_gpu_select_n(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, uint32_t tile, const isaac_match *matches, uint64_t nMatches, const uint64_t *offsets, const isaac_tls *tls,
+                       isaac_fragment *fragments, uint32_t *cigar, uint64_t cigarCapacity)
+{
+    FragmentSource source; std::memset(&source, 0, sizeof(source)); source.matches = matches; source.offsets = offsets; source.nMatches = nMatches; source.nMatchesKnown = true;
     return selectFromSource(c, bcl, nClusters, tile, source, tls, fragments, cigar, cigarCapacity);
 }
 int isaac_gpu_select_candidates(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, uint32_t tile, const isaac_candidate *candidates, const uint64_t *candidateOffsets,
@@ -1565,11 +1575,32 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
             if (!deletionEnds.empty()) HIP_CHECK(hipMemcpyAsync(c->realignDeletionEnds.p, deletionEnds.data(), deletionEnds.size() * sizeof(RealignGap), hipMemcpyHostToDevice, st));
         }
         RealignerGapsView view = { c->realignGaps.p, u32(gaps.size()), c->realignDeletionEnds.p, u32(deletionEnds.size()) };
-        HIP_CHECK(hipMemsetAsync(c->realignNext.p, 0, 4, st));
-        k_realign<<<gridFor(n, 128), 128, 0, st>>>(c->bamTiles.p, nTiles, n, o, c->ref(), view, duplicate, c->realignRecords.p, c->realignPool.p, u32(n), c->realignNext.p, c->realignChanged.p);
+        // The new CIGARs take words from a pool by a bump counter that keeps counting when the pool is full: a pass that did not fit (deep or
+        // indel-rich bins: more than a word per record on average) is repeated on a fresh copy of the records with a pool of the size it asked for,
+        // so that no realignment is ever dropped and the outcome does not depend on which fragments came first.
+        u64 poolCap = c->realignPool.n;
+        if (const char *small = std::getenv("ISAAC_GPU_REALIGN_POOL_WORDS")) poolCap = std::min<u64>(poolCap, u64(std::atol(small)));     // tests: the second pass
+        for (int attempt = 0; ; ++attempt)
+        {
+            HIP_CHECK(hipMemsetAsync(c->realignNext.p, 0, 4, st));
+            k_realign<<<gridFor(n, 128), 128, 0, st>>>(c->bamTiles.p, nTiles, n, o, c->ref(), view, duplicate, c->realignRecords.p, c->realignPool.p, u32(std::min<u64>(poolCap, 0xffffffffu)), c->realignNext.p, c->realignChanged.p);
+            HIP_CHECK(hipGetLastError());
+            u32 wanted = 0;
+            HIP_CHECK(hipMemcpyAsync(&wanted, c->realignNext.p, 4, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));         // (the host vectors above are read by the copies)
+            if (wanted <= poolCap) break;
+            if (attempt) return fail(ISAAC_GPU_ECAPACITY, "the gap realigner's CIGAR pool overflowed twice");
+            c->realignPool.reserve(size_t(wanted) + 1024); poolCap = c->realignPool.n;
+            for (u32 t = 0; t < nTiles; ++t)
+            {
+                if (h[t].nRecords) HIP_CHECK(hipMemcpyAsync(c->realignRecords.p + h[t].firstRecord, h[t].recordsOriginal, sizeof(FragmentRecord) * h[t].nRecords, hipMemcpyDeviceToDevice, st));
+                h[t].cigarsAlt = c->realignPool.p;
+            }
+            HIP_CHECK(hipMemcpyAsync(c->bamTiles.p, h.data(), sizeof(BamTile) * nTiles, hipMemcpyHostToDevice, st));
+        }
         k_realign_pairs<<<gridFor(n, 256), 256, 0, st>>>(c->bamTiles.p, nTiles, n, o, c->realignRecords.p, c->realignChanged.p);
         HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipStreamSynchronize(st));         // the host vectors above are read by the copies
+        HIP_CHECK(hipStreamSynchronize(st));
     }
     {
         ScopedTimer t(c, "bam_order");

@@ -54,6 +54,18 @@ __device__ inline void flushCounter(u64 Counters::*field, u64 v, Counters *globa
 // the chunk's gapped (banded Smith-Waterman) problems: written by the per-cluster threads, run by k_gapped_jobs
 struct GappedBuffers { GappedJob *jobs; GappedResult *results; u32 cap; u32 *counter; u32 *base; };
 
+// list lengths up to which the lean forms of the fragment stage's steps take a cluster (fragment_lean.h; at most LEAN_LIST_MAX = 16): their
+// key area in LDS is sized by these, and with it the wavefronts a CU holds
+#ifndef ISAAC_BUILD_LEAN_MAX
+#define ISAAC_BUILD_LEAN_MAX 16
+#endif
+#ifndef ISAAC_FINISH_LEAN_MAX
+#define ISAAC_FINISH_LEAN_MAX 8
+#endif
+static const u32 BUILD_LEAN_MAX = ISAAC_BUILD_LEAN_MAX, FINISH_LEAN_MAX = ISAAC_FINISH_LEAN_MAX;
+static const u32 GENERAL_STAGE_MATCHES = 160;         // matches per cluster the general form of k_build_fragments keeps in LDS
+static const u32 GENERAL_BLOCKS = 1024;               // workgroups of the general forms (each with its own banded-SW flag area for the serial fallback)
+
 #ifndef ISAAC_BUILD_STAGE_MATCHES
 #define ISAAC_BUILD_STAGE_MATCHES 16
 #endif
@@ -142,13 +154,13 @@ __host__ __device__ inline u32 gappedGroupLdsBytes(u32 maxQueryLength)
 }
 
 __global__ __launch_bounds__(64) void k_build_fragments(DevParams P, const u8 *__restrict__ bcl, u32 clusterBase, u32 nChunk, const Match *__restrict__ matches, const u64 *__restrict__ offsets, int trim, ClusterPools pools, AlignList al, u32 *generalList, u32 *generalCount);
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_build_fragments_general(DevParams P, const u8 *bcl, u32 clusterBase, const Match *matches, const u64 *offsets, int trim, FragmentWork *work, ClusterPools pools, AlignList al, const u32 *list, const u32 *listCount);
+__global__ __launch_bounds__(64) void k_build_fragments_general(DevParams P, const u8 *bcl, u32 clusterBase, const Match *matches, const u64 *offsets, int trim, u8 *matchOrderArena, u8 *orderArena, ClusterPools pools, AlignList al, const u32 *list, const u32 *listCount);
 __global__ __launch_bounds__(256) void k_align_candidates(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, ClusterPools pools, AlignList al, Counters *counters);
 __global__ __launch_bounds__(64) void k_finish_candidates(DevParams P, u32 nChunk, int withGaps, u32 *indelList, u32 *indelCount, ClusterPools pools, GappedBuffers gb, const u32 *__restrict__ order, u32 *generalList, u32 *generalCount);
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_finish_candidates_general(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, int withGaps, u32 *indelList, u32 *indelCount, FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *list, const u32 *listCount);
-__global__ __launch_bounds__(64) void k_indel_fragments(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, int withGaps, const u32 *indelList, const u32 *indelCount, FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters);
+__global__ __launch_bounds__(64) void k_finish_candidates_general(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, int withGaps, u32 *indelList, u32 *indelCount, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *list, const u32 *listCount);
+__global__ __launch_bounds__(64) void k_indel_fragments(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, int withGaps, const u32 *indelList, const u32 *indelCount, ClusterPools pools, GappedBuffers gb, Counters *counters);
 __global__ __launch_bounds__(64) void k_finish_fragments(DevParams P, u32 nChunk, int withGaps, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *__restrict__ order, u32 *generalList, u32 *generalCount);
-__global__ __launch_bounds__(64) void k_finish_fragments_general(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, int withGaps, FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *list, const u32 *listCount);
+__global__ __launch_bounds__(64) void k_finish_fragments_general(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, int withGaps, u32 *tflagsArena, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *list, const u32 *listCount);
 __global__ __launch_bounds__(SELECT_BLOCK) void k_plan_rescue(const TemplateConstants *__restrict__ constants, DevReference R, u32 clusterBase, u32 nChunk, ClusterPools pools, RescueBuffers rb, const u32 *__restrict__ order);
 __global__ __launch_bounds__(64 * RW_WAVES) void k_rescue_windows(DevParams P, DevReference R, u64 totalBases, const u8 *bcl, u32 clusterBase, RescueBuffers rb);
 __global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, ClusterPools pools, RescueBuffers rb, Counters *counters);

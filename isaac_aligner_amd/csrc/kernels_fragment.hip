@@ -17,8 +17,21 @@ __device__ inline void emitGappedJobs(const ClusterFragments &f, u32 cl, bool wi
 }
 
 
-// The general form of a step runs over a list of clusters (count on the device): a workgroup of one wavefront takes 64 entries at a time
-#define ISAAC_LIST_LOOP(listCount) for (u32 listBase = blockIdx.x * 64, listN = *(listCount); listBase < listN; listBase += gridDim.x * 64)
+// The general form of a step runs over a list of clusters (count on the device).  These are the clusters of repeat families -- dozens of
+// matches and candidates each -- and what a thread does for one is a chain of instruction-exact sorts: a latency chain that only faster memory
+// shortens.  A workgroup (one wavefront) therefore takes GENERAL_LANES entries at a time, one per lane of its first GENERAL_LANES lanes (the
+// others idle along: the wave-level scans count them as clusters without work), so that every cluster's index arrays and sort keys fit in LDS.
+static const u32 GENERAL_LANES = 16;
+#define ISAAC_LIST_LOOP(listCount) for (u32 listBase = blockIdx.x * GENERAL_LANES, listN = *(listCount); listBase < listN; listBase += gridDim.x * GENERAL_LANES)
+// the lane's work area in LDS: list order, sort keys of CAND_CAP candidates (interleaved by lane)
+#define ISAAC_GENERAL_WORK(work, tflagsArena)                                                          \
+    __shared__ u8 generalOrder[GENERAL_LANES][CAND_CAP];                                              \
+    __shared__ u64 generalKeysA[CAND_CAP * GENERAL_LANES];                                            \
+    __shared__ u64 generalKeysB[CAND_CAP * GENERAL_LANES];                                            \
+    const u32 generalLane = threadIdx.x & (GENERAL_LANES - 1);                                         \
+    LeanKeyArea generalKeys; generalKeys.a = generalKeysA + generalLane; generalKeys.b = generalKeysB + generalLane; generalKeys.stride = GENERAL_LANES; \
+    FragmentWork work; work.order = generalOrder[generalLane]; work.matchOrder = 0; work.keys = &generalKeys; work.keyCap = CAND_CAP;    \
+    work.tflags = (tflagsArena) ? (tflagsArena) + (size_t(blockIdx.x) * GENERAL_LANES + generalLane) * 3 * 512 : 0;
 
 // a wavefront's clusters for the general form: one slot of the list per lane that has one
 __device__ inline void pushGeneral(bool mine, u32 cl, u32 *list, u32 *count)
@@ -33,9 +46,9 @@ __device__ inline void pushGeneral(bool mine, u32 cl, u32 *list, u32 *count)
 }
 
 // the per-thread key area of the lean steps (fragment_lean.h): two 64-bit words per list entry, interleaved by lane
-#define ISAAC_LEAN_KEY_AREA(name)                                                     \
-    __shared__ u64 leanKeysA[LEAN_LIST_MAX * 64];                                     \
-    __shared__ u64 leanKeysB[LEAN_LIST_MAX * 64];                                     \
+#define ISAAC_LEAN_KEY_AREA(name, entries)                                            \
+    __shared__ u64 leanKeysA[(entries) * 64];                                         \
+    __shared__ u64 leanKeysB[(entries) * 64];                                         \
     LeanKeyArea name; name.a = leanKeysA + (threadIdx.x & 63); name.b = leanKeysB + (threadIdx.x & 63); name.stride = 64;
 
 // one entry per candidate in the flat list k_align_candidates works through; the list space of a wave is taken with one atomic
@@ -59,12 +72,12 @@ __device__ inline void listCandidates(ClusterFragments &f, u32 cl, u32 n, const 
     }
 }
 
-// Fragment stage, step 1: matches -> candidate positions.  Clusters with up to LEAN_LIST_MAX matches (all but a per cent) are done
+// Fragment stage, step 1: matches -> candidate positions.  Clusters with up to BUILD_LEAN_MAX matches (all but a per cent) are done
 // here on keys in LDS (fragment_lean.h: leanBuildCandidates); the others are listed for k_build_fragments_general.
 __global__ __launch_bounds__(64) void k_build_fragments(DevParams P, const u8 *__restrict__ bcl, u32 clusterBase, u32 nChunk, const Match *__restrict__ matches, const u64 *__restrict__ offsets,
                                                         int trim, ClusterPools pools, AlignList al, u32 *generalList, u32 *generalCount)
 {
-    ISAAC_LEAN_KEY_AREA(keys)
+    ISAAC_LEAN_KEY_AREA(keys, BUILD_LEAN_MAX)
     const u32 cl = blockIdx.x * blockDim.x + threadIdx.x;
     u32 n = 0;
     ClusterFragments f;
@@ -75,7 +88,7 @@ __global__ __launch_bounds__(64) void k_build_fragments(DevParams P, const u8 *_
         const u64 chunkBegin = offsets[clusterBase], begin = offsets[clusterBase + cl], end = offsets[clusterBase + cl + 1];
         const u32 first = u32(begin - chunkBegin);
         const u32 nMatches = u32(end - begin);
-        general = nMatches > LEAN_LIST_MAX || u64(first) + nMatches > pools.candCap;      // (a pool that is too small shows as CLUSTER_OVERFLOW there)
+        general = nMatches > BUILD_LEAN_MAX || u64(first) + nMatches > pools.candCap;      // (a pool that is too small shows as CLUSTER_OVERFLOW there)
         if (!general)
         {
             f = clusterViewNew(first, nMatches, pools.cands, pools.cigars);
@@ -88,32 +101,41 @@ __global__ __launch_bounds__(64) void k_build_fragments(DevParams P, const u8 *_
     if (cl < nChunk && !general) clusterViewStore(f, pools.cands, pools.meta[cl]);
 }
 
-// step 1 in its general form (aligner.h: buildCandidates) for the listed clusters
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_build_fragments_general(DevParams P, const u8 *bcl, u32 clusterBase, const Match *matches, const u64 *offsets,
-                                                        int trim, FragmentWork *work, ClusterPools pools, AlignList al, const u32 *list, const u32 *listCount)
+// step 1 in its general form for the listed clusters: on keys in LDS (fragment_lean.h: keyedBuildCandidates) when the cluster's matches fit
+// there -- GENERAL_STAGE_MATCHES = 2 strands x 8 seeds x repeat threshold 10 -- else where they lie (aligner.h: buildCandidates)
+__global__ __launch_bounds__(64) void k_build_fragments_general(DevParams P, const u8 *bcl, u32 clusterBase, const Match *matches, const u64 *offsets,
+                                                        int trim, u8 *matchOrderArena, u8 *orderArena, ClusterPools pools, AlignList al, const u32 *list, const u32 *listCount)
 {
-    // the matches of clusters with up to BUILD_STAGE_MATCHES of them are read once and kept in LDS (buildCandidates)
-    __shared__ u64 stageKeys[BUILD_STAGE_MATCHES * 64];
-    __shared__ u8 stageTies[BUILD_STAGE_MATCHES * 64];
-    __shared__ u8 stageOrder[64][BUILD_STAGE_MATCHES];
-    MatchStage stage; stage.keys = stageKeys + threadIdx.x; stage.ties = stageTies + threadIdx.x; stage.order = stageOrder[threadIdx.x]; stage.stride = 64; stage.cap = BUILD_STAGE_MATCHES;
+    __shared__ u64 keysA[GENERAL_STAGE_MATCHES * GENERAL_LANES];
+    __shared__ u64 keysB[GENERAL_STAGE_MATCHES * GENERAL_LANES];
+    __shared__ u8 matchOrder[GENERAL_LANES][GENERAL_STAGE_MATCHES];
+    __shared__ u8 candOrder[GENERAL_LANES][GENERAL_STAGE_MATCHES];
+    const u32 generalLane = threadIdx.x & (GENERAL_LANES - 1);
+    LeanKeyArea keys; keys.a = keysA + generalLane; keys.b = keysB + generalLane; keys.stride = GENERAL_LANES;
+    FragmentWork work; work.order = orderArena + (size_t(blockIdx.x) * GENERAL_LANES + generalLane) * CAND_CAP; work.tflags = 0; work.keys = 0; work.keyCap = 0;
+    work.matchOrder = matchOrderArena + (size_t(blockIdx.x) * GENERAL_LANES + generalLane) * MATCH_CAP_MAX;
     ISAAC_LIST_LOOP(listCount)
     {
         const u32 t = listBase + threadIdx.x;
+        const bool active = threadIdx.x < GENERAL_LANES && t < listN;
         u32 cl = 0, n = 0;
         ClusterFragments f;
-        if (t < listN)
+        if (active)
         {
             cl = list[t];
             const u64 chunkBegin = offsets[clusterBase], begin = offsets[clusterBase + cl], end = offsets[clusterBase + cl + 1];
             const u32 first = u32(begin - chunkBegin);
-            const u32 cap = (u64(first) + (end - begin) <= pools.candCap) ? u32(end - begin) : 0u;     // a pool that is too small shows as CLUSTER_OVERFLOW
+            const u32 nMatches = u32(end - begin);
+            const u32 cap = (u64(first) + nMatches <= pools.candCap) ? nMatches : 0u;     // a pool that is too small shows as CLUSTER_OVERFLOW
+            if (!cap && nMatches) *pools.shortFlag = 1;
             f = clusterViewNew(first, cap, pools.cands, pools.cigars);
-            buildCandidates(P, bcl + u64(clusterBase + cl) * P.clusterLength, matches + begin, u32(end - begin), trim != 0, work[cl], f, &stage);
+            const u8 *clusterBcl = bcl + u64(clusterBase + cl) * P.clusterLength;
+            if (cap && nMatches <= GENERAL_STAGE_MATCHES) keyedBuildCandidates(P, clusterBcl, matches + begin, nMatches, trim != 0, f, keys, matchOrder[generalLane], candOrder[generalLane]);
+            else buildCandidates(P, clusterBcl, matches + begin, nMatches, trim != 0, work, f, nullptr);
             n = f.nCands[0] + f.nCands[1];
         }
         listCandidates(f, cl, n, al);
-        if (t < listN) clusterViewStore(f, pools.cands, pools.meta[cl]);
+        if (active) clusterViewStore(f, pools.cands, pools.meta[cl]);
     }
 }
 
@@ -135,20 +157,20 @@ __global__ __launch_bounds__(256) void k_align_candidates(DevParams P, DevRefere
 
 // step 3: consolidation and the single-indel stage (finishCandidates), then either the cluster's gapped problems or, for the
 // 3-4 % of clusters with a candidate pair for the single-indel detector, an entry for k_indel_fragments: inside this kernel
-// nearly every wave would hold one such lane and wait for it.  Lists of up to LEAN_LIST_MAX candidates are done on keys in LDS
+// nearly every wave would hold one such lane and wait for it.  Lists of up to FINISH_LEAN_MAX candidates are done on keys in LDS
 // (fragment_lean.h: leanFinishCandidates); clusters with a longer one, or whose candidates are still to be aligned, are listed for
 // k_finish_candidates_general.
 __global__ __launch_bounds__(64) void k_finish_candidates(DevParams P, u32 nChunk, int withGaps, u32 *indelList, u32 *indelCount, ClusterPools pools, GappedBuffers gb,
                                                           const u32 *__restrict__ order, u32 *generalList, u32 *generalCount)
 {
-    ISAAC_LEAN_KEY_AREA(keys)
+    ISAAC_LEAN_KEY_AREA(keys, FINISH_LEAN_MAX)
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     bool general = false; u32 cl = 0;
     if (t < nChunk)
     {
         cl = order ? order[t] : t;
         ClusterFragments f = clusterView(pools.meta[cl], pools.cands, pools.cigars);
-        general = f.nCands[0] > LEAN_LIST_MAX || f.nCands[1] > LEAN_LIST_MAX || (f.flags & CLUSTER_ALIGN_PENDING);
+        general = f.nCands[0] > FINISH_LEAN_MAX || f.nCands[1] > FINISH_LEAN_MAX || (f.flags & CLUSTER_ALIGN_PENDING);
         if (!general)
         {
             leanFinishCandidates(P, f, keys);
@@ -160,15 +182,16 @@ __global__ __launch_bounds__(64) void k_finish_candidates(DevParams P, u32 nChun
     pushGeneral(general, cl, generalList, generalCount);
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGMENT_WAVES))) void k_finish_candidates_general(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase,
-                                                        int withGaps, u32 *indelList, u32 *indelCount, FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *list, const u32 *listCount)
+__global__ __launch_bounds__(64) void k_finish_candidates_general(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase,
+                                                        int withGaps, u32 *indelList, u32 *indelCount, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *list, const u32 *listCount)
 {
     ISAAC_STAGE_QUALITY_TABLES(Rg, R)
+    ISAAC_GENERAL_WORK(work, (u32 *)nullptr)
     Counters local; memset(&local, 0, sizeof(local));
     ISAAC_LIST_LOOP(listCount)
     {
         const u32 t = listBase + threadIdx.x;
-        if (t >= listN) continue;
+        if (threadIdx.x >= GENERAL_LANES || t >= listN) continue;
         const u32 cl = list[t];
         ClusterFragments f = clusterView(pools.meta[cl], pools.cands, pools.cigars);
         const u8 *clusterBcl = bcl + u64(clusterBase + cl) * P.clusterLength;
@@ -177,7 +200,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGME
             f.flags &= ~u32(CLUSTER_ALIGN_PENDING);
             for (u32 r = 0; r < P.nReads; ++r) for (u32 i = 0; i < f.nCands[r]; ++i) alignCandidate(P, R, clusterBcl, f, r, i, local);
         }
-        finishCandidates(P, R, clusterBcl, work[cl], f, local, true);
+        finishCandidates(P, R, clusterBcl, work, f, local, true);
         if (clusterSimpleIndelsPending(f)) indelList[atomicAdd(indelCount, 1u)] = cl;
         else emitGappedJobs(f, cl, withGaps != 0, gb);
         clusterViewStore(f, pools.cands, pools.meta[cl]);
@@ -189,9 +212,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ISAAC_FRAGME
 // One wave per cluster, every lane executing the same statements (as in k_select_heavy): the detector is a chain of dependent
 // byte loads, and 64 different clusters per wave would spread them over more cache lines than the L1 holds.
 __global__ __launch_bounds__(64) void k_indel_fragments(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, int withGaps, const u32 *indelList, const u32 *indelCount,
-                                                        FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters)
+                                                        ClusterPools pools, GappedBuffers gb, Counters *counters)
 {
     ISAAC_STAGE_QUALITY_TABLES(Rg, R)
+    __shared__ u8 listOrder[CAND_CAP];                  // every lane writes the same values
+    FragmentWork work; work.order = listOrder; work.matchOrder = 0; work.tflags = 0; work.keys = 0; work.keyCap = 0;
     __shared__ __align__(16) u8 stageBcl[512];
     __shared__ __align__(16) char stageWindow[1536];
     IndelStage stage; stage.bcl = stageBcl; stage.bclCap = sizeof(stageBcl); stage.window = stageWindow; stage.windowCap = sizeof(stageWindow); stage.lane = threadIdx.x;
@@ -207,7 +232,7 @@ __global__ __launch_bounds__(64) void k_indel_fragments(DevParams P, DevReferenc
         if (0 == threadIdx.x) at = 3 * pools.candCap + atomicAdd(pools.cigarNext, need);
         at = __shfl(at, 0, 64);
         clusterCigarExtra(f, pools.cigars, at, need, pools.cigarCap);
-        clusterFinishSimpleIndels(P, R, bcl, clusterBase + cl, work[blockIdx.x], f, local, &stage);
+        clusterFinishSimpleIndels(P, R, bcl, clusterBase + cl, work, f, local, &stage);
         __syncthreads();
         if (0 == threadIdx.x) { emitGappedJobs(f, cl, withGaps != 0, gb); clusterViewStore(f, pools.cands, pools.meta[cl]); }
     }
@@ -227,13 +252,13 @@ __device__ inline void reserveGappedCigars(ClusterFragments &f, bool active, u32
     if (active && need) clusterCigarExtra(f, pools.cigars, 3 * pools.candCap + base + incl - need, need, pools.cigarCap);
 }
 
-// step 5: the accept rule for the gapped alignments and the final consolidation.  Lists of up to LEAN_LIST_MAX candidates on keys in LDS
+// step 5: the accept rule for the gapped alignments and the final consolidation.  Lists of up to FINISH_LEAN_MAX candidates on keys in LDS
 // (fragment_lean.h: leanFinishFragments); clusters with a longer one, or whose gapped problems found no room in the flat pass, are listed
 // for k_finish_fragments_general.
 __global__ __launch_bounds__(64) void k_finish_fragments(DevParams P, u32 nChunk, int withGaps, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *__restrict__ order,
                                                          u32 *generalList, u32 *generalCount)
 {
-    ISAAC_LEAN_KEY_AREA(keys)
+    ISAAC_LEAN_KEY_AREA(keys, FINISH_LEAN_MAX)
     const u32 slot = blockIdx.x * blockDim.x + threadIdx.x;
     const u32 t = slot < nChunk ? (order ? order[slot] : slot) : nChunk;
     u32 bswJobs = 0, bswAccepted = 0, candidates = 0;
@@ -244,7 +269,7 @@ __global__ __launch_bounds__(64) void k_finish_fragments(DevParams P, u32 nChunk
     if (t < nChunk)
     {
         f = clusterView(pools.meta[t], pools.cands, pools.cigars);
-        general = f.nCands[0] > LEAN_LIST_MAX || f.nCands[1] > LEAN_LIST_MAX;
+        general = f.nCands[0] > FINISH_LEAN_MAX || f.nCands[1] > FINISH_LEAN_MAX;
         if (!general)
         {
             const u32 nJobs = countGappedJobs(f, withGaps != 0);
@@ -271,13 +296,14 @@ __global__ __launch_bounds__(64) void k_finish_fragments(DevParams P, u32 nChunk
 }
 
 __global__ __launch_bounds__(64) void k_finish_fragments_general(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, int withGaps,
-                                                         FragmentWork *work, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *list, const u32 *listCount)
+                                                         u32 *tflagsArena, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *list, const u32 *listCount)
 {
+    ISAAC_GENERAL_WORK(work, tflagsArena)
     Counters local; memset(&local, 0, sizeof(local));
     ISAAC_LIST_LOOP(listCount)
     {
         const u32 slot = listBase + threadIdx.x;
-        const bool active = slot < listN;
+        const bool active = threadIdx.x < GENERAL_LANES && slot < listN;
         const u32 t = active ? list[slot] : 0;
         ClusterFragments f;
         const GappedResult *res = nullptr;
@@ -294,7 +320,7 @@ __global__ __launch_bounds__(64) void k_finish_fragments_general(DevParams P, De
         reserveGappedCigars(f, active, need, pools);
         if (active)
         {
-            clusterFinishFragments(P, R, bcl, clusterBase + t, withGaps != 0, res, work[t], f, local);
+            clusterFinishFragments(P, R, bcl, clusterBase + t, withGaps != 0, res, work, f, local);
             clusterViewStore(f, pools.cands, pools.meta[t]);
         }
     }

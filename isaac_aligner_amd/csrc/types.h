@@ -143,7 +143,7 @@ ISAAC_HD bool candEqual(const Cand &a, const Cand &b) { return a.position == b.p
 // 32 + 2.7 x 64 B instead of a fixed 20.5 KB record.
 static const u32 CAND_CAP = 128;         // per read (u8 list indexes): 2 strands x seeds/read x (repeatThreshold - 1) = 72 for 4 seeds (2x150), 126 for 7 (2x250)
 static const u32 CIGAR_POOL = 1024;      // cigar words of a fixed-capacity ClusterStore (host harness)
-static const u32 MATCH_CAP_MAX = 320;
+static const u32 MATCH_CAP_MAX = 255;       // list indexes are bytes; a cluster with more matches is flagged (CLUSTER_OVERFLOW)
 struct ClusterMeta
 {
     u32 first;              // first candidate slot (and 3 x first = first cigar word) of the cluster in the chunk's pools
@@ -200,7 +200,8 @@ ISAAC_HD void clusterViewStore(const ClusterFragments &f, Cand *candPool, Cluste
     m.repeatSeedsCount = u8(f.repeatSeedsCount); m.built = u8(f.built); m.pad = 0;
 }
 // the chunk's pools as the kernels receive them
-struct ClusterPools { ClusterMeta *meta; Cand *cands; u32 *cigars; u32 candCap /* slots */; u32 cigarCap /* words */; u32 *cigarNext /* bump counter of the extra regions */; };
+struct ClusterPools { ClusterMeta *meta; Cand *cands; u32 *cigars; u32 candCap /* slots */; u32 cigarCap /* words */; u32 *cigarNext /* bump counter of the extra regions */;
+                      u32 *shortFlag /* set when a cluster's slots lie beyond candCap */; };
 // `words` more cigar words for a cluster whose cursor region is full or not the right size: a fresh region from the arena's
 // bump counter; the cluster's earlier words stay where they are (offsets are relative to its first word).  No room: the view's
 // capacity stays as it is and the pool's own overflow flag does the rest.

@@ -6,6 +6,7 @@ MatchSelector::parallelSelect (lib/alignment/MatchSelector.cpp:370-443).  torch 
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -38,7 +39,7 @@ EXPORTS = ["isaac_gpu_last_error", "isaac_gpu_create", "isaac_gpu_destroy", "isa
            "isaac_gpu_copy", "isaac_gpu_synchronize", "isaac_gpu_set_deferred_completion", "isaac_gpu_load_contigs", "isaac_gpu_load_contigs_dev", "isaac_gpu_load_index", "isaac_gpu_build_index", "isaac_gpu_get_index", "isaac_gpu_get_index_range", "isaac_gpu_get_mask_offsets",
            "isaac_gpu_sorted_reference_parse", "isaac_gpu_sorted_reference_format", "isaac_gpu_sorted_reference_last_error", "isaac_gpu_load_sorted_reference",
            "isaac_gpu_save_sorted_reference",
-           "isaac_gpu_find_matches", "isaac_gpu_set_loaded_contigs", "isaac_gpu_build_fragments", "isaac_gpu_determine_tls", "isaac_gpu_select", "isaac_gpu_select_candidates",
+           "isaac_gpu_find_matches", "isaac_gpu_set_loaded_contigs", "isaac_gpu_build_fragments", "isaac_gpu_determine_tls", "isaac_gpu_select", "isaac_gpu_select_n", "isaac_gpu_select_candidates",
            "isaac_gpu_bsw_batch", "isaac_gpu_compact_cigars", "isaac_gpu_compact_cigars_async",
            "isaac_gpu_bam_records", "isaac_gpu_bam_last_error", "isaac_gpu_bam_header", "isaac_gpu_bgzf_bound", "isaac_gpu_bgzf_compress", "isaac_gpu_bgzf_store_bound", "isaac_gpu_bgzf_store", "isaac_gpu_bam_index", "isaac_gpu_bam_index_last_error",
            "isaac_gpu_default_params", "isaac_gpu_parse_gap_scoring", "isaac_gpu_parse_seeds", "isaac_gpu_params_last_error",
@@ -86,16 +87,27 @@ class Aligner:
         self.cluster_length = params.read_length[0] + params.read_length[1]
         self.n_contigs = 0
         self._inflight = []          # tensors of select calls whose last pass may still be running (deferred completion)
+        self._borrowers = weakref.WeakSet()   # contexts that read this one's table through index_tensors() / set_index_tensors()
+        self._lender = None
         self.deferred_completion = bool(deferred_completion)
         if self.deferred_completion:
             self._check(self.lib.isaac_gpu_set_deferred_completion(self.h, 1))
         if contigs is not None:
             self.load_contigs(contigs)
 
+    def _refuse_while_lent(self, what):
+        open_borrowers = [b for b in getattr(self, "_borrowers", ()) if getattr(b, "h", None)]
+        if open_borrowers:
+            raise IsaacGpuError("%s: %d other context(s) still read this context's table (index_tensors / set_index_tensors); close them first" % (what, len(open_borrowers)))
+
     def close(self):
         if getattr(self, "h", None):
+            self._refuse_while_lent("close")
             self.lib.isaac_gpu_destroy(self.h)
             self.h = None
+            if getattr(self, "_lender", None) is not None:
+                self._lender._borrowers.discard(self)
+                self._lender = None
 
     def __del__(self):
         try:
@@ -127,6 +139,7 @@ class Aligner:
         self._check(self.lib.isaac_gpu_load_contigs_dev(self.h, _p(bases), _p(offsets), C.c_uint32(self.n_contigs)))
 
     def build_index(self, repeat_threshold=1000, annotate_neighbors=True):
+        self._refuse_while_lent("build_index")
         n = C.c_uint64()
         self._check(self.lib.isaac_gpu_build_index(self.h, C.c_uint32(repeat_threshold), int(annotate_neighbors), C.byref(n)))
         return n.value
@@ -134,6 +147,7 @@ class Aligner:
     def load_index(self, masks, karyotype=None):
         """masks: list of REFERENCE_KMER_DTYPE arrays (the mask files in mask order; np.memmap works);
         karyotype: SortedReferenceMetadata::Contig::karyotypeIndex_ per stored contig index, None = identity"""
+        self._refuse_while_lent("load_index")
         masks = [np.ascontiguousarray(m, abi.REFERENCE_KMER_DTYPE) for m in masks]
         ptrs = (C.c_void_p * len(masks))(*[m.ctypes.data for m in masks])
         sizes = (C.c_uint64 * len(masks))(*[len(m) for m in masks])
@@ -143,6 +157,7 @@ class Aligner:
     def load_sorted_reference(self, xml_path):
         """isaac-align -r: the mask files named by sorted-reference.xml, with its karyotype translation"""
         from . import sorted_reference
+        self._refuse_while_lent("load_sorted_reference")
         rc = self.lib.isaac_gpu_load_sorted_reference(self.h, os.fsencode(xml_path))
         if rc:
             raise IsaacGpuError("isaac_gpu error %d: %s" % (rc, sorted_reference.last_error(self.lib)))
@@ -179,18 +194,27 @@ class Aligner:
         k, p, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
         self._check(self.lib.isaac_gpu_index_dev(self.h, C.byref(k), C.byref(p), C.byref(n)))
 
+        owner = self
+
         class _View:                      # __cuda_array_interface__: torch wraps the pointer without copying
             def __init__(self, ptr, count):
                 self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<i8", "data": (ptr, False), "version": 2}
+                self.owner = owner        # the tensors alias the owner's table: they keep it alive (torch keeps the view object referenced)
         if not n.value:
             e = self.torch.empty(0, dtype=self.torch.int64, device=self.device)
             return e, e
-        return self.torch.as_tensor(_View(k.value, n.value), device=self.device), self.torch.as_tensor(_View(p.value, n.value), device=self.device)
+        kt, pt = self.torch.as_tensor(_View(k.value, n.value), device=self.device), self.torch.as_tensor(_View(p.value, n.value), device=self.device)
+        kt._isaac_owner = pt._isaac_owner = self      # set_index_tensors registers the borrower with the owner
+        return kt, pt
 
     def set_index_tensors(self, kmers, positions, mask_offsets=None):
         """adopts a table held in two int64 device tensors (they are kept referenced); mask_offsets: the cuts of the mask files or None"""
         assert kmers.dtype == self.torch.int64 and positions.dtype == self.torch.int64 and kmers.numel() == positions.numel()
         self._borrowed_index = (kmers, positions)
+        owner = getattr(kmers, "_isaac_owner", None)
+        if owner is not None and owner is not self:
+            owner._borrowers.add(self)                # the owner refuses to rebuild, reload or close its table while a borrower is open
+            self._lender = owner
         mo = np.ascontiguousarray(mask_offsets, np.uint64) if mask_offsets is not None else None
         self._check(self.lib.isaac_gpu_set_index_dev(self.h, _p(kmers), _p(positions), C.c_uint64(kmers.numel()), _p(mo), C.c_uint32(len(mo) - 1 if mo is not None else 0)))
 
@@ -266,8 +290,9 @@ class Aligner:
             cigars = torch.empty(n_rec * abi.MAX_CIGAR_OPS, dtype=torch.int32, device=self.device)
         else:
             records, cigars = out
-        self._check(self.lib.isaac_gpu_select(self.h, _p(bcl), C.c_uint32(n_clusters), C.c_uint32(tile), _p(matches), _p(offsets), C.byref(tls),
-                                              _p(records), _p(cigars), C.c_uint64(cigars.numel())))
+        # matches is the slice find_matches returned: its length is the tile's match count, which spares the call a host wait
+        self._check(self.lib.isaac_gpu_select_n(self.h, _p(bcl), C.c_uint32(n_clusters), C.c_uint32(tile), _p(matches), C.c_uint64(matches.shape[0]), _p(offsets), C.byref(tls),
+                                                _p(records), _p(cigars), C.c_uint64(cigars.numel())))
         if self.deferred_completion:
             # the call's kernels may still be queued: the tensors stay referenced until synchronize()
             self._inflight.append((bcl, matches, offsets, records, cigars))

@@ -141,6 +141,8 @@ class StepGather:
             h_r.wait(); h_c.wait(); h_n.wait()
             if self.rank == self.dst:
                 out_n, counts = out_n
+                for r, (t, n) in enumerate(zip(out_c, out_n)):      # a pool that overflowed on its rank would come back clamped by the slice below
+                    assert int(n.item()) <= t.shape[0], "rank %d packed %d CIGAR words into a pool of %d" % (r, int(n.item()), t.shape[0])
                 self.steps.append(([t[:c] for t, c in zip(out_r, counts)], [t[:int(n.item())] for t, n in zip(out_c, out_n)]))
         self.pending = []
         if self.dist is not None and self.rank != self.dst:

@@ -3,6 +3,7 @@
 # run with the default 1 M pairs per launch, reduced by scripts/pmc_summary.py into gpurun_out/pmc_summary.json
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=8      # bench.py sets it for itself, but under rocprofv3 the runtime is up before Python starts
 B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie-pass --no-bam-pass --no-single-stream-pass"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_j_fetch -- $B > $R/gpurun_out/pmc_j_fetch.log 2>&1; echo "fetch rc=$?"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_j_write -- $B > $R/gpurun_out/pmc_j_write.log 2>&1; echo "write rc=$?"

@@ -10,7 +10,7 @@ any_function isaac_gpu_entry_points[] = {
     (any_function)isaac_gpu_get_index, (any_function)isaac_gpu_get_index_range, (any_function)isaac_gpu_get_mask_offsets,
     (any_function)isaac_gpu_sorted_reference_parse, (any_function)isaac_gpu_sorted_reference_format, (any_function)isaac_gpu_sorted_reference_last_error,
     (any_function)isaac_gpu_load_sorted_reference, (any_function)isaac_gpu_save_sorted_reference, (any_function)isaac_gpu_find_matches, (any_function)isaac_gpu_set_loaded_contigs,
-    (any_function)isaac_gpu_build_fragments, (any_function)isaac_gpu_determine_tls, (any_function)isaac_gpu_select, (any_function)isaac_gpu_select_candidates,
+    (any_function)isaac_gpu_build_fragments, (any_function)isaac_gpu_determine_tls, (any_function)isaac_gpu_select, (any_function)isaac_gpu_select_n, (any_function)isaac_gpu_select_candidates,
     (any_function)isaac_gpu_compact_cigars, (any_function)isaac_gpu_compact_cigars_async, (any_function)isaac_gpu_set_params, (any_function)isaac_gpu_index_dev, (any_function)isaac_gpu_set_index_dev, (any_function)isaac_gpu_bsw_batch, (any_function)isaac_gpu_fastq_to_bcl, (any_function)isaac_gpu_get_counters,
     (any_function)isaac_gpu_kernel_time_ms, (any_function)isaac_gpu_reset_timers,
     (any_function)isaac_gpu_bam_records, (any_function)isaac_gpu_bam_last_error, (any_function)isaac_gpu_bam_header, (any_function)isaac_gpu_bgzf_bound,

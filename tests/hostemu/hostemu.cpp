@@ -80,7 +80,9 @@ int emu_build_fragments(Emu *e, const u8 *bcl, u32 nClusters, int withGaps, int 
 {
     e->stores.resize(nClusters); e->frags.resize(nClusters);
     for (u32 c = 0; c < nClusters; ++c) e->frags[c] = e->stores[c].view();
-    std::vector<FragmentWork> work(1);
+    std::vector<FragmentWorkStore> workStore(1); std::vector<FragmentWork> work(1, workStore[0].bind());
+    u64 generalKeysA[CAND_CAP], generalKeysB[CAND_CAP]; LeanKeyArea generalKeys; generalKeys.a = generalKeysA; generalKeys.b = generalKeysB; generalKeys.stride = 1;
+    if (e->lean) { work[0].keys = &generalKeys; work[0].keyCap = CAND_CAP; }      // the general kernels sort on keys in LDS
     u64 n = 0, nc = 0;
     for (u32 c = 0; c < nClusters; ++c)
     {
@@ -93,7 +95,13 @@ int emu_build_fragments(Emu *e, const u8 *bcl, u32 nClusters, int withGaps, int 
             const u64 begin = e->matchOffsets[c], end = e->matchOffsets[c + 1];
             bool built;
             if (end - begin <= LEAN_LIST_MAX) built = leanBuildCandidates(e->P, clusterBcl, e->matches.data() + begin, u32(end - begin), trim != 0, f, keys);     // k_build_fragments
-            else built = buildCandidates(e->P, clusterBcl, e->matches.data() + begin, u32(end - begin), trim != 0, work[0], f);                                  // k_build_fragments_general
+            else if (end - begin <= 160)
+            {   // k_build_fragments_general
+                u64 bigA[160], bigB[160]; u8 matchOrder[160], candOrder[160];
+                LeanKeyArea big; big.a = bigA; big.b = bigB; big.stride = 1;
+                built = keyedBuildCandidates(e->P, clusterBcl, e->matches.data() + begin, u32(end - begin), trim != 0, f, big, matchOrder, candOrder);
+            }
+            else built = buildCandidates(e->P, clusterBcl, e->matches.data() + begin, u32(end - begin), trim != 0, work[0], f);
             if (built)
             {
                 for (u32 r = 0; r < e->P.nReads; ++r) for (u32 i = 0; i < f.nCands[r]; ++i) alignCandidate(e->P, e->R, clusterBcl, f, r, i, e->cnt);             // k_align_candidates

@@ -377,8 +377,14 @@ def test_gpu_gap_realignment_matches_the_oracle():
     otls.best_model[0], otls.best_model[1] = tls.best_model[0], tls.best_model[1]
     before = a.bam_records(dev_tiles)[0].cpu().numpy().tobytes()
     keep = [t[1].clone() for t in dev_tiles]
-    for mark, keep_dups in ((False, True), (True, True), (True, False)):
-        got, n, un = a.bam_records(dev_tiles, mark_duplicates=mark, keep_duplicates=keep_dups, realign_gaps=True, tls=tls)
+    for mark, keep_dups, small_pool in ((False, True, False), (True, True, False), (True, False, False), (True, True, True)):
+        # small_pool: the realigner's CIGAR pool starts at 64 words, overflows, and the pass is repeated with the size it asked for
+        if small_pool:
+            os.environ["ISAAC_GPU_REALIGN_POOL_WORDS"] = "64"
+        try:
+            got, n, un = a.bam_records(dev_tiles, mark_duplicates=mark, keep_duplicates=keep_dups, realign_gaps=True, tls=tls)
+        finally:
+            os.environ.pop("ISAAC_GPU_REALIGN_POOL_WORDS", None)
         want, want_n, want_un = o.bam_records(host_tiles, [L, L], forced_dodgy_alignment_score=params.dodgy_alignment_score & 0xff, mark_duplicates=mark, keep_duplicates=keep_dups,
                                               realign_gaps=True, clip_semialigned=True, reference=ref, tls=otls)
         assert (n, un) == (want_n, want_un)
