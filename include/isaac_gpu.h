@@ -374,6 +374,16 @@ int isaac_gpu_bam_index(const uint8_t *records_host, const isaac_bam_index_part 
 uint64_t isaac_gpu_bgzf_store_bound(uint64_t n_bytes);
 int isaac_gpu_bgzf_store(isaac_gpu_ctx *ctx, const uint8_t *data_dev, uint64_t n_bytes, int eof_block, uint8_t *out_dev, uint64_t capacity, uint64_t *n_bytes_out);
 
+/* BGZF with compression on the device, for --bam-gzip-level 1 and up: replaces bgzf::BgzfCompressor with zlib behind it
+ * (include/bgzf/BgzfCompressor.hh:36-176, wired into the BAM writer at lib/build/Build.cpp:181-254) for streams that are in HBM already.  Same
+ * framing as above (blocks of at most 0xFFFF - 41 input bytes, gzip members with the BC field, CRC-32 and length); inside, one
+ * dynamic-Huffman deflate block per member (hash-table LZ77 over the block, the call's two Huffman tables made from a sample of its blocks),
+ * or a stored block where that is not smaller.  The compressed bytes are not zlib's: what is identical is what they inflate to.  out_dev:
+ * isaac_gpu_bgzf_deflate_bound(n_bytes) bytes are always enough; with less the call fails with ISAAC_GPU_ECAPACITY once the output does not
+ * fit (*n_bytes_out then holds the bound). */
+uint64_t isaac_gpu_bgzf_deflate_bound(uint64_t n_bytes);
+int isaac_gpu_bgzf_deflate(isaac_gpu_ctx *ctx, const uint8_t *data_dev, uint64_t n_bytes, int eof_block, uint8_t *out_dev, uint64_t capacity, uint64_t *n_bytes_out);
+
 /* The leaf: alignment::BandedSmithWaterman::align (include/alignment/BandedSmithWaterman.hh:75-86) for a batch;
  * scores as the reference constructor takes them (GappedAligner.cpp:41-42: match, mismatch, -gapOpen, -gapExtend).
  * results[i].n_ops == 0xffffffff flags a CIGAR longer than ISAAC_GPU_MAX_CIGAR_OPS. */

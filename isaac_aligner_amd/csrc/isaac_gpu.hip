@@ -27,6 +27,7 @@
 #include "index_kernels.h"
 #include "bam_kernels.h"
 #include "bgzf_kernels.h"
+#include "deflate_kernels.h"
 
 #if defined(ISAAC_KERNEL_STAMPS)
 __device__ unsigned long long g_stamps[64];
@@ -87,6 +88,7 @@ struct isaac_gpu_ctx
     DevBuf<u8> heavyArena, clusterKinds; DevBuf<u32> clusterOrder, kindCounts; DevBuf<u32> overflowList; DevBuf<u32> overflowCount; DevBuf<ClusterSums> clusterSums; DevBuf<u32> mediumList, largeList, xlList, hugeList, longJobs; DevBuf<u8> hugeKeys;
     DevBuf<TlsSample> tlsSamples; DevBuf<u32> cigarLengths, cigarOffsets; DevBuf<u64> cigarTotal;
     DevBuf<CrcConstants> crcConstants; bool crcReady = false;    // isaac_gpu_bgzf_store
+    DevBuf<u64> deflateCounts, deflateOffsets; DevBuf<DeflateTables> deflateTables; DevBuf<u8> deflateStaging; DevBuf<u32> deflateSizes;   // isaac_gpu_bgzf_deflate
     // isaac_gpu_bam_records scratch
     DevBuf<BamTile> bamTiles; DevBuf<u64> bamKeyHi, bamKeyLo, bamKeyAlt, bamOffsets, bamBytes64, bamBounds; DevBuf<u32> bamIndex, bamIndexAlt, bamBytes;
     DevBuf<u64> dupPrimary, dupMate, dupRank, dupCluster, dupSmall; DevBuf<u8> dupFlag;        // duplicate marking
@@ -1229,6 +1231,7 @@ struct FragmentSource { const isaac_match *matches; const uint64_t *offsets; con
                         uint64_t nMatches; bool nMatchesKnown; };
 } // extern "C"
 __global__ void k_set_template_constants(TemplateConstants k, TemplateConstants *dst) { *dst = k; }
+__global__ void k_widen_sizes(const u32 *sizes, u64 n, u64 *out) { const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x; if (i < n) out[i] = sizes[i]; }
 
 // the wave-per-cluster pass over `list` (count on the device) for the chunk described by `p`, on the context's stream
 static void launchHeavy(isaac_gpu_ctx *c, const isaac_gpu_ctx::ChunkDesc &p, const u32 *list, const u32 *countDev, u32 blocks, const char *timer, bool sumsKnown)
@@ -1676,6 +1679,79 @@ int isaac_gpu_bgzf_store(isaac_gpu_ctx *c, const uint8_t *data, uint64_t nBytes,
         HIP_CHECK(hipMemcpyAsync(out + total - 28, eof, 28, hipMemcpyHostToDevice, st));
     }
     HIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+    ISAAC_CATCH
+}
+
+uint64_t isaac_gpu_bgzf_deflate_bound(uint64_t nBytes) { return ((nBytes + BGZF_BLOCK_INPUT - 1) / BGZF_BLOCK_INPUT) * u64(0x10000) + 28; }
+int isaac_gpu_bgzf_deflate(isaac_gpu_ctx *c, const uint8_t *data, uint64_t nBytes, int eofBlock, uint8_t *out, uint64_t capacity, uint64_t *nBytesOut)
+{
+    ISAAC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    if (nBytesOut) *nBytesOut = 0;
+    if (nBytes && (!data || !out)) return fail(ISAAC_GPU_EINVAL, "data_dev and out_dev are required");
+    const u64 nBlocks = (nBytes + BGZF_BLOCK_INPUT - 1) / BGZF_BLOCK_INPUT;
+    if (nBlocks >= (u64(1) << 31)) return fail(ISAAC_GPU_EINVAL, "at most 2^31 - 1 blocks per call");
+    hipStream_t st = c->stream;
+    if (!c->crcReady)
+    {
+        CrcConstants h; makeCrcConstants(h);
+        c->crcConstants.reserve(1);
+        HIP_CHECK(hipMemcpy(c->crcConstants.p, &h, sizeof(h), hipMemcpyHostToDevice));
+        c->crcReady = true;
+    }
+    u64 total = 0;
+    if (nBlocks)
+    {
+        ScopedTimer t(c, "bgzf_deflate");
+        // 1. the call's Huffman tables from the symbol counts of a sample of its blocks (every block when there are few)
+        const u64 sampleMax = 2048, stride = (nBlocks + sampleMax - 1) / sampleMax, nSample = (nBlocks + stride - 1) / stride;
+        c->deflateCounts.reserve(DEFLATE_LITLEN_SYMBOLS + DEFLATE_DIST_SYMBOLS); c->deflateTables.reserve(1);
+        HIP_CHECK(hipMemsetAsync(c->deflateCounts.p, 0, sizeof(u64) * (DEFLATE_LITLEN_SYMBOLS + DEFLATE_DIST_SYMBOLS), st));
+        k_deflate_blocks<<<u32(nSample), 64, 0, st>>>(data, nBytes, 0, stride, nBlocks, nullptr, c->crcConstants.p, 1, reinterpret_cast<unsigned long long *>(c->deflateCounts.p), nullptr, nullptr);
+        HIP_CHECK(hipGetLastError());
+        u64 counts[DEFLATE_LITLEN_SYMBOLS + DEFLATE_DIST_SYMBOLS];
+        HIP_CHECK(hipMemcpyAsync(counts, c->deflateCounts.p, sizeof(counts), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        DeflateTables tables;
+        if (!makeDeflateTables(counts, counts + DEFLATE_LITLEN_SYMBOLS, tables)) return fail(ISAAC_GPU_EHIP, "the deflate block header does not fit its buffer");
+        HIP_CHECK(hipMemcpyAsync(c->deflateTables.p, &tables, sizeof(tables), hipMemcpyHostToDevice, st));
+        // 2. the blocks, a slice at a time: every block into its own slot, then closed up behind what is there already
+        const u64 slice = 16384;
+        c->deflateStaging.reserve(size_t(std::min(nBlocks, slice)) * DEFLATE_SLOT); c->deflateSizes.reserve(nBlocks); c->deflateOffsets.reserve(std::min(nBlocks, slice));
+        for (u64 first = 0; first < nBlocks; first += slice)
+        {
+            const u64 n = std::min(slice, nBlocks - first);
+            // (the kernels address slots and sizes by absolute block number: the slice's buffers are offset accordingly)
+            u8 *staging = c->deflateStaging.p - first * DEFLATE_SLOT;
+            k_deflate_blocks<<<u32(n), 64, 0, st>>>(data, nBytes, first, 1, nBlocks, c->deflateTables.p, c->crcConstants.p, 0, nullptr, staging, c->deflateSizes.p);
+            HIP_CHECK(hipGetLastError());
+            k_widen_sizes<<<gridFor(n, 256), 256, 0, st>>>(c->deflateSizes.p + first, n, c->deflateOffsets.p);
+            u64 lastSize = 0, lastOffset = 0;
+            HIP_CHECK(hipMemcpyAsync(&lastSize, c->deflateOffsets.p + n - 1, 8, hipMemcpyDeviceToHost, st));
+            exclusiveSum(c, c->deflateOffsets.p, c->deflateOffsets.p, n);
+            HIP_CHECK(hipMemcpyAsync(&lastOffset, c->deflateOffsets.p + n - 1, 8, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            const u64 sliceBytes = lastOffset + lastSize;
+            if (total + sliceBytes + (eofBlock ? 28 : 0) > capacity)
+            {
+                if (nBytesOut) *nBytesOut = isaac_gpu_bgzf_deflate_bound(nBytes);
+                return fail(ISAAC_GPU_ECAPACITY, "out_dev is too small (isaac_gpu_bgzf_deflate_bound is always enough)");
+            }
+            k_deflate_gather<<<u32(n), 256, 0, st>>>(c->deflateStaging.p, c->deflateSizes.p + first, c->deflateOffsets.p, n, out + total);
+            HIP_CHECK(hipGetLastError());
+            total += sliceBytes;
+        }
+    }
+    if (eofBlock)
+    {
+        static const unsigned char eof[28] = { 0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+        if (total + 28 > capacity) return fail(ISAAC_GPU_ECAPACITY, "out_dev is too small");
+        HIP_CHECK(hipMemcpyAsync(out + total, eof, 28, hipMemcpyHostToDevice, st));
+        total += 28;
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (nBytesOut) *nBytesOut = total;
     return 0;
     ISAAC_CATCH
 }

@@ -41,7 +41,7 @@ EXPORTS = ["isaac_gpu_last_error", "isaac_gpu_create", "isaac_gpu_destroy", "isa
            "isaac_gpu_save_sorted_reference",
            "isaac_gpu_find_matches", "isaac_gpu_set_loaded_contigs", "isaac_gpu_build_fragments", "isaac_gpu_determine_tls", "isaac_gpu_select", "isaac_gpu_select_n", "isaac_gpu_select_candidates",
            "isaac_gpu_bsw_batch", "isaac_gpu_compact_cigars", "isaac_gpu_compact_cigars_async",
-           "isaac_gpu_bam_records", "isaac_gpu_bam_last_error", "isaac_gpu_bam_header", "isaac_gpu_bgzf_bound", "isaac_gpu_bgzf_compress", "isaac_gpu_bgzf_store_bound", "isaac_gpu_bgzf_store", "isaac_gpu_bam_index", "isaac_gpu_bam_index_last_error",
+           "isaac_gpu_bam_records", "isaac_gpu_bam_last_error", "isaac_gpu_bam_header", "isaac_gpu_bgzf_bound", "isaac_gpu_bgzf_compress", "isaac_gpu_bgzf_store_bound", "isaac_gpu_bgzf_store", "isaac_gpu_bgzf_deflate_bound", "isaac_gpu_bgzf_deflate", "isaac_gpu_bam_index", "isaac_gpu_bam_index_last_error",
            "isaac_gpu_default_params", "isaac_gpu_parse_gap_scoring", "isaac_gpu_parse_seeds", "isaac_gpu_params_last_error",
            "isaac_gpu_fastq_to_bcl", "isaac_gpu_fastq_tile_clusters_max", "isaac_gpu_fastq_tiles", "isaac_gpu_get_counters", "isaac_gpu_kernel_time_ms", "isaac_gpu_reset_timers"]
 
@@ -400,6 +400,15 @@ class Aligner:
             out = self.torch.empty(bound, dtype=self.torch.uint8, device=self.device)
         n = C.c_uint64()
         self._check(self.lib.isaac_gpu_bgzf_store(self.h, _p(data), C.c_uint64(data.numel()), C.c_int(int(eof_block)), _p(out), C.c_uint64(out.numel()), C.byref(n)))
+        return out[:n.value]
+
+    def bgzf_deflate(self, data, eof_block=False, out=None):
+        """BGZF with compression on the device (--bam-gzip-level 1) of a uint8 device tensor; returns a uint8 device tensor (a view of `out`)"""
+        self.lib.isaac_gpu_bgzf_deflate_bound.restype = C.c_uint64
+        if out is None:
+            out = self.torch.empty(self.lib.isaac_gpu_bgzf_deflate_bound(C.c_uint64(data.numel())), dtype=self.torch.uint8, device=self.device)
+        n = C.c_uint64()
+        self._check(self.lib.isaac_gpu_bgzf_deflate(self.h, _p(data), C.c_uint64(data.numel()), C.c_int(int(eof_block)), _p(out), C.c_uint64(out.numel()), C.byref(n)))
         return out[:n.value]
 
     def records_to_numpy(self, records, cigars):

@@ -9,6 +9,7 @@
 #include "../../isaac_aligner_amd/csrc/sums.h"
 #include "../../isaac_aligner_amd/csrc/bam_kernels.h"
 #include "../../isaac_aligner_amd/csrc/bgzf_kernels.h"
+#include "../../isaac_aligner_amd/csrc/deflate_common.h"
 #include "../../isaac_aligner_amd/csrc/realign.h"
 #include "../../isaac_aligner_amd/csrc/host_util.h"
 #include <string>
@@ -385,6 +386,60 @@ int emu_realign_case(const char *contig, uint64_t contigLength, const uint8_t *r
     *realignedCigarLength = u32(index.cigarEnd - index.cigarBegin);
     for (const u32 *it = index.cigarBegin; it != index.cigarEnd; ++it) *realignedCigar++ = *it;
     *realignedEditDistance = f.editDistance; *realignedObservedLength = f.observedLength;
+    return 0;
+}
+
+// A CPU model of the device deflate (deflate_kernels.h) for the table builder's sake: a serial greedy parse with the same kind of hash table,
+// the very functions that make a token's bits (deflate_common.h) and the real makeDeflateTables.  One raw deflate block per call.
+// counts (316 entries): in/out symbol statistics; tablesFromCounts: build the tables from `counts` as given, else from this input.
+}
+namespace isaac { bool makeDeflateTables(const u64 *litLenCounts, const u64 *distCounts, DeflateTables &t); }
+extern "C" {
+int emu_deflate(const u8 *data, u32 n, u64 *counts, int tablesFromCounts, u8 *out, u32 capacity, u32 *nOut)
+{
+    struct Token { u32 length, distance, byte; };
+    std::vector<Token> tokens;
+    std::vector<u32> table(1u << 13, 0xffffffffu);
+    for (u32 p = 0; p < n;)
+    {
+        u32 length = 0, distance = 0;
+        if (p + DEFLATE_MIN_MATCH <= n)
+        {
+            u32 w; std::memcpy(&w, data + p, 4);
+            const u32 h = (w * 2654435761u) >> (32 - 13);
+            const u32 candidate = table[h]; table[h] = p;
+            if (candidate != 0xffffffffu && p - candidate <= DEFLATE_WINDOW && 0 == std::memcmp(data + candidate, data + p, 4))
+            {
+                const u32 limit = std::min(n - p, DEFLATE_MAX_MATCH);
+                u32 l = 4; while (l < limit && data[candidate + l] == data[p + l]) ++l;
+                length = l; distance = p - candidate;
+            }
+        }
+        if (length) { tokens.push_back({ length, distance, 0 }); p += length; } else { tokens.push_back({ 0, 0, data[p] }); ++p; }
+    }
+    u64 own[DEFLATE_LITLEN_SYMBOLS + DEFLATE_DIST_SYMBOLS] = { 0 };
+    for (const Token &t : tokens)
+    {
+        u32 xb, xv;
+        if (t.length) { ++own[257 + deflateLengthCode(t.length, xb, xv)]; ++own[DEFLATE_LITLEN_SYMBOLS + deflateDistanceCode(t.distance, xb, xv)]; } else ++own[t.byte];
+    }
+    ++own[DEFLATE_END_OF_BLOCK];
+    if (!tablesFromCounts) std::memcpy(counts, own, sizeof(own));
+    DeflateTables tables;
+    if (!makeDeflateTables(counts, counts + DEFLATE_LITLEN_SYMBOLS, tables)) { g_error = "header overflow"; return 1; }
+    std::vector<u8> bytes; u64 acc = 0; u32 accBits = 0;
+    auto put = [&](u64 bits, u32 nBits) { for (u32 b = 0; b < nBits; ++b) { acc |= ((bits >> b) & 1) << accBits; if (8 == ++accBits) { bytes.push_back(u8(acc)); acc = 0; accBits = 0; } } };
+    for (u32 b = 0; b < tables.headerBits; ++b) put((tables.header[b >> 5] >> (b & 31)) & 1, 1);
+    for (const Token &t : tokens)
+    {
+        u32 nBits; const u64 bits = t.length ? deflateMatchBits(tables.litLen, tables.dist, t.length, t.distance, nBits) : deflateLiteralBits(tables.litLen, t.byte, nBits);
+        put(bits, nBits);
+    }
+    put(tables.litLen[DEFLATE_END_OF_BLOCK] & 0xffffu, tables.litLen[DEFLATE_END_OF_BLOCK] >> 16);
+    if (accBits) bytes.push_back(u8(acc));
+    *nOut = u32(bytes.size());
+    if (bytes.size() > capacity) { g_error = "capacity"; return 1; }
+    std::memcpy(out, bytes.data(), bytes.size());
     return 0;
 }
 

@@ -20,8 +20,10 @@ def load():
     so = os.path.join(DIR, "libhostemu.so")
     srcs = [os.path.join(DIR, "hostemu.cpp")] + [os.path.join(ROOT, "isaac_aligner_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "isaac_aligner_amd", "csrc")) if f.endswith(".h")]
     srcs.append(os.path.join(ROOT, "include", "isaac_gpu.h"))
+    tables = os.path.join(ROOT, "isaac_aligner_amd", "csrc", "deflate_tables.cpp")      # host code of the product: the Huffman tables of the device deflate
+    srcs.append(tables)
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(DIR, "hostemu.cpp")])
+        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(DIR, "hostemu.cpp"), tables])
     lib = C.CDLL(so)
     lib.emu_last_error.restype = C.c_char_p
     lib.emu_create.restype = C.c_void_p

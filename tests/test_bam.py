@@ -222,6 +222,60 @@ def test_gpu_bgzf_store_is_level_0():
         assert a.bgzf_store(dev[skip:], eof_block=True).cpu().numpy().tobytes() == bam.bgzf_compress(data[skip:].tobytes(), level=0, eof_block=True)
 
 
+def _bgzf_members(stream):
+    """(offset, total size, ISIZE) of every BGZF block of `stream`; checks the fixed header bytes"""
+    out, at = [], 0
+    while at < len(stream):
+        assert stream[at:at + 4] == b"\x1f\x8b\x08\x04" and stream[at + 10:at + 16] == b"\x06\x00BC\x02\x00", at
+        total = int.from_bytes(stream[at + 16:at + 18], "little") + 1
+        out.append((at, total, int.from_bytes(stream[at + total - 4:at + total], "little")))
+        at += total
+    assert at == len(stream)
+    return out
+
+
+@pytest.mark.gpu
+def test_gpu_bgzf_deflate_inflates_to_the_input():
+    """isaac_gpu_bgzf_deflate (--bam-gzip-level 1 on the device): whole BGZF blocks of at most 0xFFFF - 41 input bytes whose members zlib
+    inflates to the input, CRC-32 and ISIZE included (gzip checks both); on a BAM record stream the output is within 1.15 x of zlib level 1's size;
+    incompressible blocks are stored; inputs on odd addresses"""
+    import zlib
+    import torch
+    from isaac_aligner_amd import gpu
+    a = gpu.Aligner(options.default_params(100, 100), 0)
+    rng = np.random.default_rng(12)
+    params, contigs, tiles = make_tiles(n_tiles=2, n_clusters=20000)
+    o = oracle_lib.load()
+    stream = np.frombuffer(o.bam_records([(t[0], t[1], t[2], "RG:1:%d:" % k) for k, t in enumerate(tiles)], [100, 100])[0], np.uint8)
+    inputs = {"bam": stream, "random": rng.integers(0, 256, 300_001, dtype=np.uint8), "zeros": np.zeros(200_000, np.uint8), "acgt": np.frombuffer(b"ACGT" * 50_000, np.uint8),
+              "two bits": rng.integers(0, 4, 3 * 65494, dtype=np.uint8), "one": np.frombuffer(b"x", np.uint8), "block": rng.integers(65, 70, 65494, dtype=np.uint8),
+              "block + 1": rng.integers(65, 70, 65495, dtype=np.uint8), "empty": np.zeros(0, np.uint8)}
+    for name, data in inputs.items():
+        dev = torch.from_numpy(data.copy()).cuda() if len(data) else torch.empty(0, dtype=torch.uint8, device="cuda")
+        for eof in (False, True):
+            got = a.bgzf_deflate(dev, eof_block=eof).cpu().numpy().tobytes()
+            members = _bgzf_members(got)
+            assert len(members) == (len(data) + 65493) // 65494 + int(eof), name
+            assert sum(m[2] for m in members) == len(data)
+            if members:
+                assert gzip.decompress(got) == data.tobytes(), name
+        if name == "bam":
+            reference = sum(len(zlib.compress(data[k:k + 65494].tobytes(), 1)) - 6 + 26 for k in range(0, len(data), 65494))
+            assert len(got) <= 1.15 * reference, (len(got), reference, len(data))
+        if name == "random":
+            assert len(got) <= len(data) + 31 * len(members) + 28
+        if name in ("zeros", "acgt"):
+            assert len(got) < 0.02 * len(data) + 2000, (name, len(got))
+    data = rng.integers(0, 8, 400_003, dtype=np.uint8)
+    dev = torch.from_numpy(data).cuda()
+    for skip in (1, 2, 3):
+        assert gzip.decompress(a.bgzf_deflate(dev[skip:], eof_block=True).cpu().numpy().tobytes()) == data[skip:].tobytes()
+    # a small output buffer: ISAAC_GPU_ECAPACITY, nothing written beyond it
+    small = torch.zeros(1000, dtype=torch.uint8, device="cuda")
+    with pytest.raises(gpu.IsaacGpuError):
+        a.bgzf_deflate(torch.from_numpy(inputs["random"]).cuda(), out=small)
+
+
 @pytest.mark.gpu
 def test_gpu_bam_records_match_the_oracle():
     """isaac_gpu_bam_records on the records the GPU path itself produced == oracle/bam.cpp on the same records, byte for byte;
@@ -492,3 +546,33 @@ def test_gpu_fastq_to_bam_end_to_end(tmp_path):
     recs = bam.parse_records(want)
     assert {r["name"].split(":")[2] for r in recs} == {"1", "2", "3"}   # read names carry the tile of the rule, cluster ids restart per tile
     assert max(int(r["name"].split(":")[3]) for r in recs) == 3999
+
+
+def test_deflate_tables_and_token_bits_inflate_with_zlib():
+    """the host half of the device deflate (deflate_tables.cpp: Huffman code lengths, canonical codes, the dynamic block header) and the token
+    bits of deflate_common.h, driven by a serial CPU model of the device's parse (tests/hostemu): zlib inflates every block to its input --
+    with tables made from the block itself, from another block's statistics (every symbol must have a code), and from empty statistics"""
+    import zlib
+    lib = hostemu_lib.load()
+    rng = np.random.default_rng(5)
+    params, contigs, tiles = make_tiles(n_tiles=1, n_clusters=400)
+    o = oracle_lib.load()
+    stream = o.bam_records([(t[0], t[1], t[2], "RG:1:%d:" % k) for k, t in enumerate(tiles)], [100, 100])[0]
+    inputs = [bytes(stream[:60000]), bytes(rng.integers(0, 256, 30000, dtype=np.uint8)), bytes(20000), b"ACGT" * 9000, b"x", b"", bytes(rng.integers(0, 4, 65494, dtype=np.uint8)),
+              b"".join(b"read_%06d/1\tACGTTGCA\n" % i for i in range(2500))]
+    other = np.zeros(316, np.uint64)
+    for k, data in enumerate(inputs):
+        a = np.frombuffer(data, np.uint8).copy() if data else np.zeros(0, np.uint8)
+        for mode in ("own", "other", "empty"):
+            counts = np.zeros(316, np.uint64) if mode != "other" else other.copy()
+            out = np.zeros(len(a) * 2 + 2048, np.uint8)
+            n = C.c_uint32()
+            rc = lib.emu_deflate(hostemu_lib.ptr(a), C.c_uint32(len(a)), hostemu_lib.ptr(counts), C.c_int(0 if mode == "own" else 1), hostemu_lib.ptr(out), C.c_uint32(len(out)), C.byref(n))
+            assert rc == 0, lib.emu_last_error()
+            assert zlib.decompress(bytes(out[:n.value]), -15) == data, (k, mode)
+            if mode == "own":
+                if k == 0:
+                    other = counts.copy()
+                    assert n.value < 0.62 * len(a)                      # BAM records: four-bit bases and few quality values (zlib level 1: about 0.5)
+                if k == 2 or k == 3:
+                    assert n.value < 0.02 * len(a) + 300
