@@ -427,7 +427,7 @@ def main():
         bam_info = {"records": int(n_bam), "bytes": int(stream_bytes.numel()), "ms": round(1e3 * t_bam, 3), "records_per_s": round(n_bam / t_bam, 1),
                     "GB_per_s_written": round(stream_bytes.numel() / t_bam / 1e9, 2), "order_ms": round(al.kernel_time_ms("bam_order")[0], 3),
                     "encode_ms": round(al.kernel_time_ms("bam_encode")[0], 3), "unaligned_bin_offset": int(unaligned_at),
-                    "note": "isaac_gpu_bam_records over the records of all %d steps (two radix passes + one encode launch); BGZF deflate stays on the host" % args.steps}
+                    "note": "isaac_gpu_bam_records over the records of all %d steps (two radix passes + one encode launch)" % args.steps}
         # --bam-gzip-level 0 entirely on the device: BGZF framing with stored blocks, CRC-32 per block computed by the GPU
         framed = al.bgzf_store(stream_bytes, eof_block=True)
         al.reset_timers()
@@ -436,6 +436,29 @@ def main():
         t_store = al.kernel_time_ms("bgzf_store")[0]
         bam_info.update({"bgzf_store_ms": round(t_store, 3), "bgzf_store_GB_per_s": round(stream_bytes.numel() / max(1e-9, t_store) / 1e6, 1), "bgzf_store_bytes": int(framed.numel())})
         del framed
+        # --bam-gzip-level 1 (the reference's default) on the device: isaac_gpu_bgzf_deflate over the whole record stream
+        deflated = al.bgzf_deflate(stream_bytes, eof_block=True)           # warm-up: staging allocation
+        deflate_out = torch.empty(int(deflated.numel()) + (1 << 20), dtype=torch.uint8, device=dev)
+        del deflated
+        torch.cuda.synchronize()
+        td = time.perf_counter()
+        deflated = al.bgzf_deflate(stream_bytes, eof_block=True, out=deflate_out)
+        torch.cuda.synchronize()
+        t_deflate = time.perf_counter() - td
+        import zlib
+        check_bytes = min(int(stream_bytes.numel()), 64 << 20) // 65494 * 65494          # whole blocks: the first of the deflated stream inflate to the first of the records
+        dz = zlib.decompressobj(31)
+        head = deflated[:check_bytes // 2 + (4 << 20)].cpu().numpy().tobytes()
+        inflated = bytearray()
+        while len(inflated) < check_bytes and head:
+            inflated += dz.decompress(head)
+            head = dz.unused_data
+            if dz.eof:
+                dz = zlib.decompressobj(31)
+        bam_info.update({"bgzf_deflate_ms": round(1e3 * t_deflate, 3), "bgzf_deflate_GB_per_s": round(stream_bytes.numel() / t_deflate / 1e9, 2), "bgzf_deflate_bytes": int(deflated.numel()),
+                         "bgzf_deflate_ratio": round(deflated.numel() / stream_bytes.numel(), 4), "bgzf_deflate_checked_bytes": check_bytes,
+                         "bgzf_deflate_inflates_to_records": bytes(inflated[:check_bytes]) == stream_bytes[:check_bytes].cpu().numpy().tobytes()})
+        del deflated, deflate_out, inflated
         # the host side of the file writer: BGZF deflate (zlib level 1, as --bam-gzip-level defaults) of a bounded sample on all host threads
         from isaac_aligner_amd import bam as bam_host
         sample_bytes = min(int(stream_bytes.numel()), 512 << 20)

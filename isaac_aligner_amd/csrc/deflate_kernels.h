@@ -1,6 +1,6 @@
 // BGZF with compression on the device (--bam-gzip-level 1 and up): every block of the output is a gzip member with the BC extra field
 // (include/bgzf/Bgzf.hh:30-85) around one dynamic-Huffman deflate block.  One wavefront per block:
-//   * the block's input (up to BGZF_BLOCK_INPUT bytes) is staged in LDS;
+//   * the block's input (DEFLATE_BLOCK_INPUT bytes) is staged in LDS;
 //   * the wave walks it 64 positions a step: every lane hashes the four bytes at its position, takes the last earlier position with that
 //     hash from a table in LDS (and leaves its own there), checks and extends the match four bytes at a time;
 //   * the greedy parse of the step -- the first match at or beyond the end of the previous one wins, what it covers is skipped, the rest are
@@ -19,7 +19,22 @@ namespace isaac
 
 bool makeDeflateTables(const u64 *litLenCounts, const u64 *distCounts, DeflateTables &t);     // deflate_tables.cpp
 
-static const u32 DEFLATE_HASH_BITS = 13;
+// Input bytes per block.  bgzf::BgzfCompressor takes 0xFFFF - 41 (so that a block fits 16 bits of BSIZE even stored); any smaller size is as
+// valid a BGZF file.  What decides here is LDS: a block's input is staged there, and a CU runs as many blocks side by side as fit.
+// (MI355X, the bench's 2.5 GB record stream, one wavefront per block: 65 494 bytes and 8 192 hash slots, one block per CU: 7.9 GB/s, ratio 0.508;
+// 4 096 slots, two per CU: 16.1 GB/s, 0.510; 32 768 bytes: 24-26 GB/s, 0.512; 24 576 bytes and 2 048 slots, four per CU: 35.3 GB/s, 0.514; 16 384 bytes:
+// 42.1 GB/s, 0.518 -- zlib level 1 on the same stream: 0.520 at 1 GB/s on 256 host threads.  The walk is a chain of LDS round trips that a lone
+// wavefront waits out one by one, so throughput follows the number of blocks in flight; the ratio hardly moves because on BAM records most of
+// the gain is the Huffman coding of four-bit bases and a few quality values, not the matches.  profiles/r4_exp_deflate*.log)
+#ifndef ISAAC_DEFLATE_BLOCK_INPUT
+#define ISAAC_DEFLATE_BLOCK_INPUT 24576
+#endif
+static const u32 DEFLATE_BLOCK_INPUT = ISAAC_DEFLATE_BLOCK_INPUT;
+static_assert(DEFLATE_BLOCK_INPUT <= BGZF_BLOCK_INPUT && 0 == (DEFLATE_BLOCK_INPUT & 1), "block input size");
+#ifndef ISAAC_DEFLATE_HASH_BITS
+#define ISAAC_DEFLATE_HASH_BITS 11
+#endif
+static const u32 DEFLATE_HASH_BITS = ISAAC_DEFLATE_HASH_BITS;
 static const u32 DEFLATE_SLOT = 0x10000 + 64;      // a block's slot in the staging buffer: two bytes of padding (the deflate data then starts on a word), the member
 static const u32 DEFLATE_SLOT_PAD = 2;
 static const u32 DEFLATE_RING_WORDS = 256;         // bit ring: a step adds at most 64 x 48 bits = 96 words
@@ -36,18 +51,17 @@ __device__ inline u32 ldsLoad32(const u8 *base, u32 at)
 __global__ void __launch_bounds__(64) k_deflate_blocks(const u8 *data, u64 nBytes, u64 firstBlock, u64 blockStride, u64 nBlocks, const DeflateTables *tables, const CrcConstants *crcConstants,
                                                        int histogram, unsigned long long *counts, u8 *staging, u32 *sizes)
 {
-    __shared__ __attribute__((aligned(16))) u8 in[BGZF_BLOCK_INPUT + 10];
+    __shared__ __attribute__((aligned(16))) u8 in[DEFLATE_BLOCK_INPUT + 22];
     __shared__ u16 hashTable[1u << DEFLATE_HASH_BITS];
-    __shared__ u32 litLen[DEFLATE_LITLEN_SYMBOLS];
-    __shared__ u32 distCode[DEFLATE_DIST_SYMBOLS];
-    __shared__ u32 ring[DEFLATE_RING_WORDS];
-    __shared__ u32 crcTable[4][256];
-    __shared__ u32 hist[DEFLATE_LITLEN_SYMBOLS + DEFLATE_DIST_SYMBOLS];
+    // coding: the two code tables, the bit ring, the CRC table; counting: the histogram (in the same words)
+    __shared__ u32 small[DEFLATE_LITLEN_SYMBOLS + DEFLATE_DIST_SYMBOLS + DEFLATE_RING_WORDS + 4 * 256];
+    u32 *const litLen = small, *const distCode = small + DEFLATE_LITLEN_SYMBOLS, *const ring = distCode + DEFLATE_DIST_SYMBOLS, *const hist = small;
+    u32 (*const crcTable)[256] = reinterpret_cast<u32 (*)[256]>(ring + DEFLATE_RING_WORDS);
     const u32 lane = threadIdx.x;
     const u64 block = firstBlock + u64(blockIdx.x) * blockStride;
     if (block >= nBlocks) return;
-    const u64 from = block * BGZF_BLOCK_INPUT;
-    const u32 n = u32(nBytes - from < BGZF_BLOCK_INPUT ? nBytes - from : BGZF_BLOCK_INPUT);
+    const u64 from = block * DEFLATE_BLOCK_INPUT;
+    const u32 n = u32(nBytes - from < DEFLATE_BLOCK_INPUT ? nBytes - from : DEFLATE_BLOCK_INPUT);
     const u8 *src = data + from;
     // stage the input (the blocks start on even addresses; every other one on a multiple of four)
     if (0 == (reinterpret_cast<u64>(src) & 3))
@@ -66,7 +80,7 @@ __global__ void __launch_bounds__(64) k_deflate_blocks(const u8 *data, u64 nByte
         for (u32 k = 0; k < 4; ++k) for (u32 i = lane; i < 256; i += 64) crcTable[k][i] = crcConstants->table[k][i];
     }
     __syncthreads();
-    if (lane < 10 && n + lane < sizeof(in)) in[n + lane] = 0;     // the look-ahead reads past the end see zeros (matches are cut at n anyway)
+    if (lane < 22) in[n + lane] = 0;               // the look-ahead reads past the end see zeros (matches are cut at n anyway)
     u32 *out = histogram ? nullptr : reinterpret_cast<u32 *>(staging + block * DEFLATE_SLOT + DEFLATE_SLOT_PAD + 18);       // word aligned: the slot is, 2 + 18 = 20
     u32 bitAt = 0, flushed = 0;                    // bits written so far / whole words already in global memory
     if (!histogram)
@@ -90,12 +104,18 @@ __global__ void __launch_bounds__(64) k_deflate_blocks(const u8 *data, u64 nByte
             if (candidate != 0xffff && candidate < p && p - candidate <= DEFLATE_WINDOW && ldsLoad32(in, candidate) == word)
             {
                 const u32 limit = n - p < DEFLATE_MAX_MATCH ? n - p : DEFLATE_MAX_MATCH;
+                // sixteen bytes a turn: a lone wavefront waits out every LDS round trip, so each one should decide as much as it can
                 u32 l = 4;
                 while (l < limit)
                 {
-                    const u32 x = ldsLoad32(in, p + l) ^ ldsLoad32(in, candidate + l);
-                    if (x) { l += u32(__ffs(int(x)) - 1) >> 3; break; }
-                    l += 4;
+                    const u32 x0 = ldsLoad32(in, p + l) ^ ldsLoad32(in, candidate + l), x1 = ldsLoad32(in, p + l + 4) ^ ldsLoad32(in, candidate + l + 4);
+                    const u32 x2 = ldsLoad32(in, p + l + 8) ^ ldsLoad32(in, candidate + l + 8), x3 = ldsLoad32(in, p + l + 12) ^ ldsLoad32(in, candidate + l + 12);
+                    if (x0 | x1 | x2 | x3)
+                    {
+                        l += x0 ? u32(__ffs(int(x0)) - 1) >> 3 : x1 ? 4 + (u32(__ffs(int(x1)) - 1) >> 3) : x2 ? 8 + (u32(__ffs(int(x2)) - 1) >> 3) : 12 + (u32(__ffs(int(x3)) - 1) >> 3);
+                        break;
+                    }
+                    l += 16;
                 }
                 length = l < limit ? l : limit; distance = p - candidate;
             }
@@ -149,7 +169,7 @@ __global__ void __launch_bounds__(64) k_deflate_blocks(const u8 *data, u64 nByte
         const u32 whole = bitAt >> 5;
         for (u32 w = flushed + lane; w < whole; w += 64)
         {
-            if (4 * w + 4 <= BGZF_BLOCK_INPUT + 8) out[w] = ring[w & (DEFLATE_RING_WORDS - 1)];
+            if (4 * w + 4 <= DEFLATE_BLOCK_INPUT + 8) out[w] = ring[w & (DEFLATE_RING_WORDS - 1)];
             ring[w & (DEFLATE_RING_WORDS - 1)] = 0;
         }
         flushed = whole;
@@ -174,7 +194,7 @@ __global__ void __launch_bounds__(64) k_deflate_blocks(const u8 *data, u64 nByte
     __syncthreads();
     const u32 deflated = (bitAt + 7) / 8;          // bytes of deflate data
     const u32 lastWords = (deflated + 3) / 4;
-    for (u32 w = flushed + lane; w < lastWords; w += 64) if (4 * w + 4 <= BGZF_BLOCK_INPUT + 8) out[w] = ring[w & (DEFLATE_RING_WORDS - 1)];
+    for (u32 w = flushed + lane; w < lastWords; w += 64) if (4 * w + 4 <= DEFLATE_BLOCK_INPUT + 8) out[w] = ring[w & (DEFLATE_RING_WORDS - 1)];
     // CRC-32 of the input: every lane a piece from a zero register, the pieces folded together (bgzf_kernels.h)
     const u32 piece = ((n + 63) / 64 + 3) & ~3u;
     const u32 begin = lane * piece < n ? lane * piece : n, end = begin + piece < n ? begin + piece : n;

@@ -1683,14 +1683,14 @@ int isaac_gpu_bgzf_store(isaac_gpu_ctx *c, const uint8_t *data, uint64_t nBytes,
     ISAAC_CATCH
 }
 
-uint64_t isaac_gpu_bgzf_deflate_bound(uint64_t nBytes) { return ((nBytes + BGZF_BLOCK_INPUT - 1) / BGZF_BLOCK_INPUT) * u64(0x10000) + 28; }
+uint64_t isaac_gpu_bgzf_deflate_bound(uint64_t nBytes) { return ((nBytes + DEFLATE_BLOCK_INPUT - 1) / DEFLATE_BLOCK_INPUT) * u64(DEFLATE_BLOCK_INPUT + 31) + 28; }
 int isaac_gpu_bgzf_deflate(isaac_gpu_ctx *c, const uint8_t *data, uint64_t nBytes, int eofBlock, uint8_t *out, uint64_t capacity, uint64_t *nBytesOut)
 {
     ISAAC_TRY
     HIP_CHECK(hipSetDevice(c->device));
     if (nBytesOut) *nBytesOut = 0;
     if (nBytes && (!data || !out)) return fail(ISAAC_GPU_EINVAL, "data_dev and out_dev are required");
-    const u64 nBlocks = (nBytes + BGZF_BLOCK_INPUT - 1) / BGZF_BLOCK_INPUT;
+    const u64 nBlocks = (nBytes + DEFLATE_BLOCK_INPUT - 1) / DEFLATE_BLOCK_INPUT;
     if (nBlocks >= (u64(1) << 31)) return fail(ISAAC_GPU_EINVAL, "at most 2^31 - 1 blocks per call");
     hipStream_t st = c->stream;
     if (!c->crcReady)
