@@ -334,9 +334,30 @@ typedef struct
     const isaac_tls *tls;                    /* the template length statistics isaac_gpu_select ran with: GapRealigner::updatePairDetails re-derives the
                                                 proper-pair flag of realigned pairs from them; required with realign_gaps and paired reads
                                                 unless every tile brings its own */
+    /* One bin of the file at a time (build::Build works through its bins one by one, lib/build/Build.cpp:509-543,793-900): with bin_filter
+     * set the call writes only the records whose bin position lies on contigs [bin_first_contig, bin_end_contig) -- plus, with bin_unaligned,
+     * the templates without a position -- while every record of the tiles still serves as its mate's mate (duplicate ranks, pair details
+     * after realignment).  The tiles of such a call are what isaac_gpu_bin_tile made for the bin.  Bins of whole contigs written in contig
+     * order, the unaligned one last, give the very bytes of one call over all tiles. */
+    uint32_t bin_filter, bin_first_contig, bin_end_contig, bin_unaligned;
 } isaac_bam_options;
 int isaac_gpu_bam_records(isaac_gpu_ctx *ctx, const isaac_bam_tile *tiles, uint32_t n_tiles, const isaac_bam_options *options /* NULL = defaults */,
                           uint8_t *bam_dev, uint64_t capacity, uint64_t *n_bytes_out, uint64_t *n_records_out, uint64_t *unaligned_offset_out);
+
+/* Replaces alignment::matchSelector::BinningFragmentStorage (lib/alignment/matchSelector/BinningFragmentStorage.cpp, FragmentBinner.cpp): while
+ * the reference selects matches it writes every fragment -- header, bases, CIGAR -- to the file of the bin its position falls into, and builds the
+ * BAM bin by bin from those files, so that a run never has to fit memory.  Here: the output of one isaac_gpu_select call (cigar_dev packed by
+ * isaac_gpu_compact_cigars or not) is cut into one compact tile per bin, each holding the clusters with at least one stored record in the bin:
+ * their BCL bytes, their records (n_reads per cluster, in cluster order; cigar_offset relative to the tile's own words) and their CIGAR words.
+ * A pair whose reads lie in two bins goes to both, whole.  bin_of_contig[c]: the bin of contig c (< n_bins - 1; bins of whole contigs in contig
+ * order); bin n_bins - 1 takes the templates without a position.  out_dev receives, bin after bin, each part starting on a multiple of 64 bytes:
+ *     n_clusters x cluster length bytes of BCL | n_clusters x n_reads records | n_cigar_words words
+ * sizes_out[b]: the two counts of bin b; *n_bytes_out: the bytes written (or needed, with ISAAC_GPU_ECAPACITY).  A part's three arrays, copied
+ * to wherever the bin is kept and back to a device, are the bcl_dev / fragments_dev / cigar_dev of an isaac_bam_tile with the original tile's name
+ * prefix, read group and statistics. */
+typedef struct { uint64_t n_clusters, n_cigar_words; } isaac_bin_size;
+int isaac_gpu_bin_tile(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, const isaac_fragment *fragments_dev, const uint32_t *cigar_dev, uint32_t n_clusters,
+                       const uint32_t *bin_of_contig, uint32_t n_contigs, uint32_t n_bins, uint8_t *out_dev, uint64_t capacity, isaac_bin_size *sizes_out, uint64_t *n_bytes_out);
 
 /* Host-only pieces of the BAM file (no context, no GPU).  Errors: isaac_gpu_bam_last_error().
  * isaac_gpu_bam_header: bam::serializeHeader (include/bam/Bam.hh:153-235): magic, the text (@HD VN:1.0 SO:coordinate, @PG ID:iSAAC

@@ -23,7 +23,8 @@ struct BamTile
     char readGroup[28]; u32 readGroupLength;                                             // RG:Z of the tile's records: the barcode index of its lane (FragmentAccessorBamAdapter.hh:283-299)
 };
 struct BamOptions { u32 nReads, readLength[2], readOffset[2], clusterLength, forcedDodgyAlignmentScore, pessimisticMapQ, barcodeLength, readGroupLength; char barcode[64], readGroup[64];
-                    u32 markDuplicates, keepDuplicates, realignGaps; RealignParams realign; DevTls tls; };
+                    u32 markDuplicates, keepDuplicates, realignGaps; RealignParams realign; DevTls tls;
+                    u32 binFilter, binFirstContig, binEndContig, binUnaligned; };      // isaac_bam_options::bin_*: which records the call writes
 
 static const u64 INSANELY_HIGH_NUMBER_OF_CLUSTERS_PER_TILE = 1000000000ull;   // include/build/FragmentIndex.hh:33
 static const u16 DODGY_ALIGNMENT_SCORE = 0xffff;                               // io::FragmentHeader::DODGY_ALIGNMENT_SCORE
@@ -60,6 +61,19 @@ ISAAC_HD u32 bamFlag(const FragmentRecord &r)
 ISAAC_HD bool bamStored(const FragmentRecord &r) { return 0 == (r.reserved & RECORD_NOT_STORED); }
 // is the record part of the unaligned bin (both reads of the template unplaced)?  Shadows travel with their singleton.
 ISAAC_HD bool bamUnalignedBin(const FragmentRecord &r) { return refposIsNoMatch(r.fStrandPosition); }
+
+// does the record belong to the bin the call writes (isaac_bam_options::bin_*)?  The others are there as mates.
+ISAAC_HD bool bamInBin(const FragmentRecord &r, const BamOptions &o)
+{
+    if (!o.binFilter) return true;
+    if (bamUnalignedBin(r)) return 0 != o.binUnaligned;
+    const u32 contig = refposContig(r.fStrandPosition);
+    return contig >= o.binFirstContig && contig < o.binEndContig;
+}
+// The BCL bytes of the cluster a tile's record `local` belongs to: records come in cluster order, n_reads per cluster, so the cluster's place in
+// the tile's buffers is its records' -- which is its cluster id in the buffers of an isaac_gpu_select call, and stays right for the compacted
+// tiles of isaac_gpu_bin_tile, where the id (the read's name) and the place differ.
+ISAAC_HD const u8 *bamClusterBcl(const BamTile &t, u64 local, const BamOptions &o) { return t.bcl + (local / o.nReads) * o.clusterLength; }
 
 ISAAC_HD u32 bamReadNameLength(const BamTile &t, const FragmentRecord &r) { return t.nameLength + decimalDigits(r.clusterId) + 2; }   // + ":0"
 // Cigar::toString (include/alignment/Cigar.hh:74-95) of n operations: its length, and its character k (0 at and past the end)
@@ -102,7 +116,8 @@ struct BamLayout
 };
 
 // bam::serializeAlignment (Bam.hh:257-345): the fixed part and the section boundaries
-ISAAC_HD void bamLayout(const BamTile &t, const FragmentRecord &r, const BamOptions &o, BamLayout &l, bool duplicate = false, const FragmentRecord *original = nullptr)
+// local: the record's place in the tile
+ISAAC_HD void bamLayout(const BamTile &t, const FragmentRecord &r, u64 local, const BamOptions &o, BamLayout &l, bool duplicate = false, const FragmentRecord *original = nullptr)
 {
     const bool aligned = !(r.flags & 2), unalignedBin = bamUnalignedBin(r), paired = r.flags & 1;
     // FragmentAccessorBamAdapter::operator(): aligned fragments and shadows carry the bin index position, unaligned templates NoMatch
@@ -132,7 +147,7 @@ ISAAC_HD void bamLayout(const BamTile &t, const FragmentRecord &r, const BamOpti
     l.ocAt = oc ? at : ~0u; l.originalCigar = oc ? t.cigars + original->cigarOffset : nullptr; l.nOriginalCigar = oc ? original->cigarLength : 0;
     l.sm = r.alignmentScore; l.as = r.templateAlignmentScore; l.nm = r.editDistance;
     const u32 readIndex = (r.flags & 64) && paired ? 1u : 0u;
-    l.bcl = t.bcl + u64(r.clusterId) * o.clusterLength + o.readOffset[readIndex];
+    l.bcl = bamClusterBcl(t, local, o) + o.readOffset[readIndex];
     l.cigar = ((r.reserved & RECORD_CIGAR_REALIGNED) ? t.cigarsAlt : t.cigars) + r.cigarOffset;
 }
 
@@ -180,8 +195,13 @@ ISAAC_HD u8 bamRecordByte(const BamStrings &text, const BamLayout &l, u32 j, con
 }
 
 #if defined(__HIPCC__)
-// tile of global record index i (tiles are few: linear search over firstRecord)
-__device__ inline u32 bamTileOf(const BamTile *tiles, u32 nTiles, u64 i) { u32 t = 0; while (t + 1 < nTiles && tiles[t + 1].firstRecord <= i) ++t; return t; }
+// tile of global record index i: the last one that starts at or before it (the tiles of a bin are one per tile of the run: bisection)
+__device__ inline u32 bamTileOf(const BamTile *tiles, u32 nTiles, u64 i)
+{
+    u32 lo = 0, hi = nTiles;
+    while (hi - lo > 1) { const u32 mid = (lo + hi) / 2; if (tiles[mid].firstRecord <= i) lo = mid; else hi = mid; }
+    return lo;
+}
 
 // orderForBam as a 128-bit key: hi = the bin index position (unaligned templates and dropped records last), lo = global cluster id,
 // unmapped, second read
@@ -192,7 +212,7 @@ __global__ void k_bam_keys(const BamTile *tiles, u32 nTiles, u64 nRecords, BamOp
     if (i >= nRecords) return;
     const u32 t = bamTileOf(tiles, nTiles, i);
     const FragmentRecord &r = tiles[t].records[i - tiles[t].firstRecord];
-    const bool stored = bamStored(r) && !(duplicate && duplicate[i] && !o.keepDuplicates);
+    const bool stored = bamStored(r) && bamInBin(r, o) && !(duplicate && duplicate[i] && !o.keepDuplicates);
     keyHi[i] = !stored ? ~u64(0) : bamUnalignedBin(r) ? ~u64(0) - 1 : r.fStrandPosition;
     keyLo[i] = ((u64(r.tile) * INSANELY_HIGH_NUMBER_OF_CLUSTERS_PER_TILE + r.clusterId) << 2) | ((r.flags & 2) ? 2u : 0u) | ((r.flags & 64) ? 1u : 0u);
     index[i] = u32(i);
@@ -237,7 +257,7 @@ __global__ void k_dup_keys(const BamTile *tiles, u32 nTiles, u64 nRecords, BamOp
     if (bamStored(h) && (h.flags & 1) && !bamUnalignedBin(h))
     {
         const FragmentRecord &m = tiles[t].records[local ^ 1];          // records come in cluster order, read 0 before read 1
-        const u8 *clusterBcl = tiles[t].bcl + u64(h.clusterId) * o.clusterLength;
+        const u8 *clusterBcl = bamClusterBcl(tiles[t], local, o);
         const u32 readIndex = (h.flags & 64) ? 1u : 0u;
         // io::getTemplateDuplicateRank (Fragment.hh:66-71); an N has quality 2 (Read.cpp:56-69)
         u32 quality = 0;
@@ -329,7 +349,7 @@ __global__ void k_realign(BamTile *tiles, u32 nTiles, u64 nRecords, BamOptions o
     f.lowClipped = r.lowClipped; f.highClipped = r.highClipped; f.alignmentScore = r.alignmentScore; f.templateAlignmentScore = r.templateAlignmentScore;
     f.readLength = r.readLength; f.editDistance = r.editDistance;
     const u32 readIndex = ((r.flags & 64) && (r.flags & 1)) ? 1u : 0u;
-    f.bcl = tiles[t].bcl + u64(r.clusterId) * o.clusterLength + o.readOffset[readIndex];
+    f.bcl = bamClusterBcl(tiles[t], i - tiles[t].firstRecord, o) + o.readOffset[readIndex];
     const u32 *cigar = bamRecordCigar(tiles[t], r);
     RealignIndex index = { r.fStrandPosition, cigar, cigar + r.cigarLength };
     const u32 contig = refposContig(r.fStrandPosition);
@@ -367,7 +387,7 @@ __global__ void k_realign_pairs(const BamTile *tiles, u32 nTiles, u64 nRecords, 
         if (aForward != bForward) aLast = aForward;
         else
         {
-            const u8 *clusterBcl = tiles[t].bcl + u64(a.clusterId) * o.clusterLength;
+            const u8 *clusterBcl = bamClusterBcl(tiles[t], i - tiles[t].firstRecord, o);
             const u64 pa = aForward ? a.fStrandPosition : dupAnchor(a, clusterBcl), pb = bForward ? b.fStrandPosition : dupAnchor(b, clusterBcl + o.readOffset[1]);
             aLast = pa > pb;      // later in the list's order; equal keys: the second read
         }
@@ -493,8 +513,8 @@ __global__ void __launch_bounds__(256) k_bam_encode(const BamTile *tiles, u32 nT
         const FragmentRecord r = tiles[t].records[i - tiles[t].firstRecord];
         BamLayout l;
         const bool dup = duplicate && duplicate[i];
-        bool write = bamStored(r) && !(dup && !o.keepDuplicates);
-        if (write) { bamLayout(tiles[t], r, o, l, dup && o.markDuplicates, tiles[t].recordsOriginal ? tiles[t].recordsOriginal + (i - tiles[t].firstRecord) : nullptr); write = at + l.total <= capacity; }
+        bool write = bamStored(r) && bamInBin(r, o) && !(dup && !o.keepDuplicates);
+        if (write) { bamLayout(tiles[t], r, i - tiles[t].firstRecord, o, l, dup && o.markDuplicates, tiles[t].recordsOriginal ? tiles[t].recordsOriginal + (i - tiles[t].firstRecord) : nullptr); write = at + l.total <= capacity; }
         if (write) { layouts[threadIdx.x] = l; imageAt[threadIdx.x] = u32(at - begin); }
         tileOfRecord[threadIdx.x] = write ? t : ~0u;
     }
@@ -538,6 +558,79 @@ __global__ void __launch_bounds__(256) k_bam_encode(const BamTile *tiles, u32 nT
     for (u32 x = threadIdx.x; x < body; x += blockDim.x) gto[x] = from[x];
     const u32 tail = n - head - 16 * body;
     if (threadIdx.x < tail) g[head + 16 * body + threadIdx.x] = image[shift + head + 16 * body + threadIdx.x];
+}
+#endif
+
+
+// ---- isaac_gpu_bin_tile: the records of a select call cut into one compact tile per bin (BinningFragmentStorage's job) -----------------------
+static const u32 BIN_MAX = 255, BIN_NONE = 255;
+struct BinLayout { u64 firstEntry[BIN_MAX + 2], bclAt[BIN_MAX + 1], recordsAt[BIN_MAX + 1], cigarsAt[BIN_MAX + 1]; };
+#if defined(__HIPCC__)
+__device__ inline u32 binOfRecord(const FragmentRecord &r, const u32 *binOfContig, u32 nContigs, u32 nBins)
+{
+    if (!bamStored(r)) return BIN_NONE;
+    if (bamUnalignedBin(r)) return nBins - 1;
+    const u32 contig = refposContig(r.fStrandPosition);
+    return contig < nContigs ? binOfContig[contig] : BIN_NONE;
+}
+// entries 2c, 2c + 1: the bins cluster c has a stored record in (the second only when it differs from the first), else BIN_NONE
+__global__ void k_bin_entries(const FragmentRecord *records, u32 nClusters, u32 nReads, const u32 *binOfContig, u32 nContigs, u32 nBins, u8 *keys, u32 *values)
+{
+    const u32 cl = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cl >= nClusters) return;
+    const u32 b0 = binOfRecord(records[u64(cl) * nReads], binOfContig, nContigs, nBins);
+    u32 b1 = 2 == nReads ? binOfRecord(records[u64(cl) * 2 + 1], binOfContig, nContigs, nBins) : BIN_NONE;
+    if (b1 == b0) b1 = BIN_NONE;
+    // the smaller bin first, so that BIN_NONE entries sort behind everything
+    keys[2 * u64(cl)] = u8(b0 < b1 ? b0 : b1); keys[2 * u64(cl) + 1] = u8(b0 < b1 ? b1 : b0);
+    values[2 * u64(cl)] = cl; values[2 * u64(cl) + 1] = cl;
+}
+// words[k]: CIGAR words of sorted entry k's cluster (0 for BIN_NONE entries; one more zero at the end for the scan); counts[b], counts[BIN_MAX + b]: entries and words of bin b
+__global__ void k_bin_words(const FragmentRecord *records, u32 nReads, const u8 *sortedKeys, const u32 *sortedValues, u64 nEntries, u64 *words, unsigned long long *counts)
+{
+    __shared__ unsigned long long local[2 * BIN_MAX + 2];
+    for (u32 i = threadIdx.x; i < 2 * BIN_MAX + 2; i += blockDim.x) local[i] = 0;
+    __syncthreads();
+    const u64 k = u64(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k < nEntries)
+    {
+        const u32 bin = sortedKeys[k];
+        u64 w = 0;
+        if (bin != BIN_NONE)
+        {
+            const u32 cl = sortedValues[k];
+            for (u32 r = 0; r < nReads; ++r) w += records[u64(cl) * nReads + r].cigarLength;
+            atomicAdd(&local[bin], 1ull); atomicAdd(&local[BIN_MAX + bin], (unsigned long long)w);
+        }
+        words[k] = w;
+        if (k + 1 == nEntries) words[nEntries] = 0;
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < 2 * BIN_MAX + 2; i += blockDim.x) if (local[i]) atomicAdd(&counts[i], local[i]);
+}
+// 64 threads per entry: the cluster's BCL bytes, its records and their CIGAR words to the entry's place in its bin's part
+__global__ void __launch_bounds__(256) k_bin_gather(const u8 *bcl, const FragmentRecord *records, const u32 *cigars, u32 nReads, u32 clusterLength, const u8 *sortedKeys, const u32 *sortedValues,
+                                                    u64 nEntries, const u64 *wordsBefore, BinLayout layout, u8 *out)
+{
+    const u64 k = u64(blockIdx.x) * 4 + threadIdx.x / 64;
+    const u32 lane = threadIdx.x & 63;
+    if (k >= nEntries) return;
+    const u32 bin = sortedKeys[k], cl = sortedValues[k];
+    const u64 slot = k - layout.firstEntry[bin], wordAt = wordsBefore[k] - wordsBefore[layout.firstEntry[bin]];
+    const u8 *src = bcl + u64(cl) * clusterLength; u8 *dst = out + layout.bclAt[bin] + slot * clusterLength;
+    if (0 == (clusterLength & 3)) { for (u32 i = 4 * lane; i < clusterLength; i += 256) *reinterpret_cast<u32 *>(dst + i) = *reinterpret_cast<const u32 *>(src + i); }
+    else for (u32 i = lane; i < clusterLength; i += 64) dst[i] = src[i];
+    FragmentRecord *recordsOut = reinterpret_cast<FragmentRecord *>(out + layout.recordsAt[bin]) + slot * nReads;
+    u32 *cigarsOut = reinterpret_cast<u32 *>(out + layout.cigarsAt[bin]);
+    u64 w = wordAt;
+    for (u32 r = 0; r < nReads; ++r)
+    {
+        const FragmentRecord &in = records[u64(cl) * nReads + r];
+        const u32 n = in.cigarLength, from = in.cigarOffset;
+        if (lane < 16) reinterpret_cast<u32 *>(recordsOut + r)[lane] = (lane == offsetof(FragmentRecord, cigarOffset) / 4) ? u32(w) : reinterpret_cast<const u32 *>(&in)[lane];
+        for (u32 i = lane; i < n; i += 64) cigarsOut[w + i] = cigars[from + i];
+        w += n;
+    }
 }
 #endif
 

@@ -88,6 +88,7 @@ struct isaac_gpu_ctx
     DevBuf<u8> heavyArena, clusterKinds; DevBuf<u32> clusterOrder, kindCounts; DevBuf<u32> overflowList; DevBuf<u32> overflowCount; DevBuf<ClusterSums> clusterSums; DevBuf<u32> mediumList, largeList, xlList, hugeList, longJobs; DevBuf<u8> hugeKeys;
     DevBuf<TlsSample> tlsSamples; DevBuf<u32> cigarLengths, cigarOffsets; DevBuf<u64> cigarTotal;
     DevBuf<CrcConstants> crcConstants; bool crcReady = false;    // isaac_gpu_bgzf_store
+    DevBuf<u32> binOfContig, binValues, binValuesAlt; DevBuf<u8> binKeys, binKeysAlt; DevBuf<u64> binWords, binCounts;        // isaac_gpu_bin_tile
     DevBuf<u64> deflateCounts, deflateOffsets; DevBuf<DeflateTables> deflateTables; DevBuf<u8> deflateStaging; DevBuf<u32> deflateSizes;   // isaac_gpu_bgzf_deflate
     // isaac_gpu_bam_records scratch
     DevBuf<BamTile> bamTiles; DevBuf<u64> bamKeyHi, bamKeyLo, bamKeyAlt, bamOffsets, bamBytes64, bamBounds; DevBuf<u32> bamIndex, bamIndexAlt, bamBytes;
@@ -1481,6 +1482,7 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
     o.pessimisticMapQ = options ? options->pessimistic_mapq : 0;
     o.markDuplicates = options ? (options->mark_duplicates != 0) : 0; o.keepDuplicates = options ? (options->keep_duplicates != 0) : 1;
     o.realignGaps = options ? (options->realign_gaps != 0) : 0;
+    if (options && options->bin_filter) { o.binFilter = 1; o.binFirstContig = options->bin_first_contig; o.binEndContig = options->bin_end_contig; o.binUnaligned = options->bin_unaligned != 0; }
     if (o.realignGaps)
     {
         if (options->realign_vigorously) return fail(ISAAC_GPU_EINVAL, "--realign-vigorously is not implemented");
@@ -1493,7 +1495,8 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
     for (u32 t = 0; t < nTiles; ++t)
     {
         const isaac_bam_tile &in = tiles[t];
-        if (in.n_records && (!in.bcl_dev || !in.fragments_dev || !in.cigar_dev)) return fail(ISAAC_GPU_EINVAL, "bcl_dev, fragments_dev and cigar_dev are required for every tile");
+        // (cigar_dev may be NULL for a tile without a single CIGAR word: the unaligned bin's tiles)
+        if (in.n_records && (!in.bcl_dev || !in.fragments_dev)) return fail(ISAAC_GPU_EINVAL, "bcl_dev and fragments_dev are required for every tile");
         const char *prefix = in.read_name_prefix ? in.read_name_prefix : "";
         if (std::strlen(prefix) >= sizeof(h[t].name)) return fail(ISAAC_GPU_EINVAL, "read_name_prefix: at most 63 characters");
         std::memset(&h[t], 0, sizeof(BamTile));
@@ -1647,6 +1650,60 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
 }
 
 // BGZF without compression on the device (bgzf_kernels.h)
+// ---- isaac_gpu_bin_tile (bam_kernels.h: k_bin_*)
+int isaac_gpu_bin_tile(isaac_gpu_ctx *c, const uint8_t *bcl, const isaac_fragment *fragments, const uint32_t *cigars, uint32_t nClusters, const uint32_t *binOfContig, uint32_t nContigs, uint32_t nBins,
+                       uint8_t *out, uint64_t capacity, isaac_bin_size *sizesOut, uint64_t *nBytesOut)
+{
+    ISAAC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    if (nBytesOut) *nBytesOut = 0;
+    if (!nBins || nBins > BIN_MAX || !sizesOut || (nContigs && !binOfContig)) return fail(ISAAC_GPU_EINVAL, "1 .. 255 bins, sizes_out and bin_of_contig are required");
+    for (u32 k = 0; k < nContigs; ++k) if (binOfContig[k] + 1 >= nBins) return fail(ISAAC_GPU_EINVAL, "bin_of_contig: bins 0 .. n_bins - 2 (the last bin takes the templates without a position)");
+    for (u32 b = 0; b < nBins; ++b) { sizesOut[b].n_clusters = 0; sizesOut[b].n_cigar_words = 0; }
+    if (!nClusters) return 0;
+    if (!bcl || !fragments || !cigars) return fail(ISAAC_GPU_EINVAL, "bcl_dev, fragments_dev and cigar_dev are required");
+    hipStream_t st = c->stream;
+    const u32 nReads = c->params.n_reads, clusterLength = c->P.clusterLength;
+    const u64 nEntries = u64(nClusters) * 2;
+    c->binOfContig.reserve(std::max(nContigs, 1u)); c->binKeys.reserve(nEntries); c->binKeysAlt.reserve(nEntries); c->binValues.reserve(nEntries); c->binValuesAlt.reserve(nEntries);
+    c->binWords.reserve(nEntries + 1); c->binCounts.reserve(2 * BIN_MAX + 2);
+    if (nContigs) HIP_CHECK(hipMemcpyAsync(c->binOfContig.p, binOfContig, nContigs * 4, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemsetAsync(c->binCounts.p, 0, (2 * BIN_MAX + 2) * 8, st));
+    const FragmentRecord *records = reinterpret_cast<const FragmentRecord *>(fragments);
+    // an entry per (cluster, bin it has a stored record in): at most two; sorted by bin (stable: cluster order inside a bin)
+    k_bin_entries<<<gridFor(nClusters, 256), 256, 0, st>>>(records, nClusters, nReads, c->binOfContig.p, nContigs, nBins, c->binKeys.p, c->binValues.p);
+    sortPairs(c, c->binKeys.p, c->binKeysAlt.p, c->binValues.p, c->binValuesAlt.p, nEntries, 8);
+    // CIGAR words of every entry's cluster, their running sum in sorted order, and per bin the entries and the words
+    k_bin_words<<<gridFor(nEntries, 256), 256, 0, st>>>(records, nReads, c->binKeysAlt.p, c->binValuesAlt.p, nEntries, c->binWords.p, reinterpret_cast<unsigned long long *>(c->binCounts.p));
+    exclusiveSum(c, c->binWords.p, c->binWords.p, nEntries + 1);
+    std::vector<u64> counts(2 * BIN_MAX + 2);
+    HIP_CHECK(hipMemcpyAsync(counts.data(), c->binCounts.p, counts.size() * 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    // the layout of the output: bin after bin, every array on a multiple of 64 bytes
+    BinLayout layout; std::memset(&layout, 0, sizeof(layout));
+    u64 at = 0, firstEntry = 0;
+    auto align64 = [](u64 v) { return (v + 63) & ~u64(63); };
+    for (u32 b = 0; b < nBins; ++b)
+    {
+        const u64 m = counts[b], w = counts[BIN_MAX + b];
+        sizesOut[b].n_clusters = m; sizesOut[b].n_cigar_words = w;
+        layout.firstEntry[b] = firstEntry; layout.bclAt[b] = at;
+        at = align64(at + m * clusterLength); layout.recordsAt[b] = at;
+        at = align64(at + m * nReads * sizeof(FragmentRecord)); layout.cigarsAt[b] = at;
+        at = align64(at + w * 4);
+        firstEntry += m;
+    }
+    layout.firstEntry[nBins] = firstEntry;
+    if (nBytesOut) *nBytesOut = at;
+    if (at > capacity) return fail(ISAAC_GPU_ECAPACITY, "out_dev is too small");
+    if (!out) return fail(ISAAC_GPU_EINVAL, "out_dev is required");
+    if (firstEntry) k_bin_gather<<<gridFor(firstEntry, 4), 256, 0, st>>>(bcl, records, cigars, nReads, clusterLength, c->binKeysAlt.p, c->binValuesAlt.p, firstEntry, c->binWords.p, layout, out);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+    ISAAC_CATCH
+}
+
 uint64_t isaac_gpu_bgzf_store_bound(uint64_t nBytes) { return ((nBytes + BGZF_BLOCK_INPUT - 1) / BGZF_BLOCK_INPUT) * u64(BGZF_BLOCK_INPUT + BGZF_STORED_OVERHEAD) + 28; }
 int isaac_gpu_bgzf_store(isaac_gpu_ctx *c, const uint8_t *data, uint64_t nBytes, int eofBlock, uint8_t *out, uint64_t capacity, uint64_t *nBytesOut)
 {

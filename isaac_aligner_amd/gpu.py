@@ -41,7 +41,7 @@ EXPORTS = ["isaac_gpu_last_error", "isaac_gpu_create", "isaac_gpu_destroy", "isa
            "isaac_gpu_save_sorted_reference",
            "isaac_gpu_find_matches", "isaac_gpu_set_loaded_contigs", "isaac_gpu_build_fragments", "isaac_gpu_determine_tls", "isaac_gpu_select", "isaac_gpu_select_n", "isaac_gpu_select_candidates",
            "isaac_gpu_bsw_batch", "isaac_gpu_compact_cigars", "isaac_gpu_compact_cigars_async",
-           "isaac_gpu_bam_records", "isaac_gpu_bam_last_error", "isaac_gpu_bam_header", "isaac_gpu_bgzf_bound", "isaac_gpu_bgzf_compress", "isaac_gpu_bgzf_store_bound", "isaac_gpu_bgzf_store", "isaac_gpu_bgzf_deflate_bound", "isaac_gpu_bgzf_deflate", "isaac_gpu_bam_index", "isaac_gpu_bam_index_last_error",
+           "isaac_gpu_bam_records", "isaac_gpu_bin_tile", "isaac_gpu_bam_last_error", "isaac_gpu_bam_header", "isaac_gpu_bgzf_bound", "isaac_gpu_bgzf_compress", "isaac_gpu_bgzf_store_bound", "isaac_gpu_bgzf_store", "isaac_gpu_bgzf_deflate_bound", "isaac_gpu_bgzf_deflate", "isaac_gpu_bam_index", "isaac_gpu_bam_index_last_error",
            "isaac_gpu_default_params", "isaac_gpu_parse_gap_scoring", "isaac_gpu_parse_seeds", "isaac_gpu_params_last_error",
            "isaac_gpu_fastq_to_bcl", "isaac_gpu_fastq_tile_clusters_max", "isaac_gpu_fastq_tiles", "isaac_gpu_get_counters", "isaac_gpu_kernel_time_ms", "isaac_gpu_reset_timers"]
 
@@ -345,7 +345,36 @@ class Aligner:
             self._inflight.append((records, cigars, out, n_words_dev))
 
     # ---- output format --------------------------------------------------------------------------------------------
-    def bam_records(self, tiles, out=None, read_group=None, barcode=None, forced_dodgy_alignment_score=None, pessimistic_mapq=False, mark_duplicates=False, keep_duplicates=True, realign_gaps=False, tls=None):
+    def bin_tile(self, bcl, records, cigars, bin_of_contig, n_bins):
+        """isaac_gpu_bin_tile: the output of one select() cut into a compact tile per bin; returns [(bcl, records, cigars)] per bin (device tensors, views of one buffer)"""
+        from . import bam
+        torch = self.torch
+        n_clusters = bcl.shape[0]
+        boc = np.ascontiguousarray(bin_of_contig, np.uint32)
+        sizes = (bam.BinSize * n_bins)()
+        need = C.c_uint64()
+        out = torch.empty(max(64, int(1.2 * (bcl.numel() + records.numel() + 8 * records.shape[0])) + 256 * n_bins), dtype=torch.uint8, device=self.device)
+        args = lambda buf: (self.h, _p(bcl), _p(records), _p(cigars), C.c_uint32(n_clusters), _p(boc), C.c_uint32(len(boc)), C.c_uint32(n_bins), _p(buf), C.c_uint64(buf.numel()), sizes, C.byref(need))
+        rc = self.lib.isaac_gpu_bin_tile(*args(out))
+        if rc == 4:
+            out = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+            rc = self.lib.isaac_gpu_bin_tile(*args(out))
+        self._check(rc)
+        parts, at = [], 0
+        align = lambda v: (v + 63) & ~63
+        for b in range(n_bins):
+            m, w = sizes[b].n_clusters, sizes[b].n_cigar_words
+            bcl_at = at
+            rec_at = align(bcl_at + m * self.cluster_length)
+            cig_at = align(rec_at + m * self.n_reads * abi.FRAGMENT_DTYPE.itemsize)
+            at = align(cig_at + 4 * w)
+            parts.append((out[bcl_at:bcl_at + m * self.cluster_length].view(m, self.cluster_length) if m else out[:0].view(0, self.cluster_length),
+                          out[rec_at:rec_at + m * self.n_reads * abi.FRAGMENT_DTYPE.itemsize].view(m * self.n_reads, abi.FRAGMENT_DTYPE.itemsize),
+                          out[cig_at:cig_at + 4 * w].view(torch.int32)))
+        return parts
+
+    def bam_records(self, tiles, out=None, read_group=None, barcode=None, forced_dodgy_alignment_score=None, pessimistic_mapq=False, mark_duplicates=False, keep_duplicates=True, realign_gaps=False, tls=None,
+                    bin_contigs=None, bin_unaligned=False):
         """build::Build's BAM alignment records of one or more tiles, in file order (mark_duplicates / keep_duplicates / realign_gaps: BinSorter's steps before the order).
         tiles: [(bcl, records, cigars, read_name_prefix[, read_group[, tls]])] as given to / returned by select().  Returns (uint8 device tensor of the
         uncompressed records, number of records, offset of the unaligned bin)."""
@@ -369,8 +398,12 @@ class Aligner:
                 arr[i].tls = C.cast(C.pointer(tile[5]), C.c_void_p)
             n_rec += records.shape[0]
         options = None
-        if read_group is not None or barcode is not None or forced_dodgy_alignment_score is not None or pessimistic_mapq or mark_duplicates or not keep_duplicates or realign_gaps:
+        if read_group is not None or barcode is not None or forced_dodgy_alignment_score is not None or pessimistic_mapq or mark_duplicates or not keep_duplicates or realign_gaps or bin_contigs is not None or bin_unaligned:
             options = bam.BamOptions()
+            if bin_contigs is not None or bin_unaligned:      # one bin of the file: contigs [first, end) and / or the templates without a position
+                options.bin_filter = 1
+                options.bin_first_contig, options.bin_end_contig = bin_contigs if bin_contigs is not None else (0, 0)
+                options.bin_unaligned = int(bool(bin_unaligned))
             options.mark_duplicates, options.keep_duplicates = int(bool(mark_duplicates)), int(bool(keep_duplicates))
             options.realign_gaps = int(bool(realign_gaps))
             options.tls = C.cast(C.pointer(tls), C.c_void_p) if tls is not None else None

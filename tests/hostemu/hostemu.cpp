@@ -524,7 +524,7 @@ int emu_bam_records(const isaac_bam_tile *tiles, u32 nTiles, u32 nReads, const u
         if (k.hi == ~u64(0) - 1 && *unalignedOffset == ~u64(0)) *unalignedOffset = at;
         const FragmentRecord &r = t[k.tile].records[k.index];
         const u32 n = bamRecordBytes(t[k.tile], r, o);
-        if (at + n <= capacity) { BamLayout l; bamLayout(t[k.tile], r, o, l); if (l.total != n) return 9; BamStrings text = { t[k.tile].name, o.barcode, o.barcodeLength }; std::vector<u8> stored(l.readLength); for (u32 b = 0; b < l.readLength; ++b) stored[b] = bamStoredBcl(l, b); for (u32 j = 0; j < n; ++j) out[at + j] = bamRecordByte(text, l, j, (j & 1) ? stored.data() : nullptr, l.cigar); }
+        if (at + n <= capacity) { BamLayout l; bamLayout(t[k.tile], r, u64(&r - t[k.tile].records), o, l); if (l.total != n) return 9; BamStrings text = { t[k.tile].name, o.barcode, o.barcodeLength }; std::vector<u8> stored(l.readLength); for (u32 b = 0; b < l.readLength; ++b) stored[b] = bamStoredBcl(l, b); for (u32 j = 0; j < n; ++j) out[at + j] = bamRecordByte(text, l, j, (j & 1) ? stored.data() : nullptr, l.cigar); }
         at += n; ++*nRecords;
     }
     if (*unalignedOffset == ~u64(0)) *unalignedOffset = at;

@@ -222,6 +222,63 @@ def test_gpu_bgzf_store_is_level_0():
         assert a.bgzf_store(dev[skip:], eof_block=True).cpu().numpy().tobytes() == bam.bgzf_compress(data[skip:].tobytes(), level=0, eof_block=True)
 
 
+@pytest.mark.gpu
+def test_gpu_bins_give_the_bytes_of_one_call():
+    """isaac_gpu_bin_tile + isaac_gpu_bam_records one bin at a time (isaac_bam_options::bin_*) == one isaac_gpu_bam_records call over the whole tiles, byte
+    for byte, with the reference's BAM-stage defaults (duplicates marked, gaps realigned): three tiles of a sample with indels on three contigs, a
+    fifth of the pairs with their second read swapped in from another cluster (reads of one pair on two contigs: such a pair is kept in both bins),
+    some reads unalignable; bins = one contig each, two contigs together, everything in one bin"""
+    import torch
+    from isaac_aligner_amd import gpu
+    rng = np.random.default_rng(23)
+    L = 100
+    genome = synth.make_genome(240000, seed=62, n_contigs=3, repeat_families=False)
+    contigs = [bytes(c.numpy()) for c in genome]
+    sample = synth.make_sample_with_indels(genome, rng)
+    params = options.default_params(L, L)
+    a = gpu.Aligner(params, 0, contigs)
+    a.build_index()
+    tiles, tls = [], None
+    for t in range(3):
+        bcl = synth.make_read_pairs(sample, 9000, L, seed=80 + t, indel_read_fraction=0.0, subst_rate=0.004)[0].numpy().copy()
+        swap = rng.permutation(1800)
+        bcl[:1800, L:] = bcl[swap, L:]                                       # chimeras
+        bcl[1800:1900, :L] = (rng.integers(0, 4, (100, L)) | (30 << 2)).astype(np.uint8)      # random first reads: singletons and shadows
+        bcl[1900:1950] = (rng.integers(0, 4, (50, 2 * L)) | (30 << 2)).astype(np.uint8)      # nothing aligns
+        bcl[2000:2600] = bcl[2600:3200]                                      # duplicates
+        d_bcl = torch.from_numpy(bcl).cuda()
+        matches, offsets, hits = a.find_matches(d_bcl, tile=3 + t)
+        a.set_loaded_contigs(np.ones(len(contigs), np.uint8))
+        if tls is None:
+            tls = a.determine_tls(d_bcl, matches, offsets, tile=3 + t)
+        records, cigars = a.select(d_bcl, matches, offsets, tls, tile=3 + t)
+        if t == 1:                                                            # packed CIGARs too
+            cigars = a.compact_cigars(records, cigars)[0]
+        tiles.append((d_bcl, records, cigars, "FC:1:%d:" % (3 + t)))
+    kw = dict(mark_duplicates=True, keep_duplicates=True, realign_gaps=True, tls=tls)
+    whole, n_whole, unaligned_at = a.bam_records(tiles, **kw)
+    whole = whole.cpu().numpy().tobytes()
+    assert 0 < unaligned_at < len(whole)
+    for bin_of_contig in ([0, 1, 2], [0, 0, 1], [0, 0, 0]):
+        n_bins = max(bin_of_contig) + 2
+        per_bin = [[] for _ in range(n_bins)]
+        for bcl, records, cigars, prefix in tiles:
+            for b, part in enumerate(a.bin_tile(bcl, records, cigars, bin_of_contig, n_bins)):
+                if part[1].shape[0]:
+                    per_bin[b].append((part[0].clone(), part[1].clone(), part[2].clone(), prefix))
+        pieces, n_total = [], 0
+        for b in range(n_bins):
+            if not per_bin[b]:
+                continue
+            mine = [c for c, x in enumerate(bin_of_contig) if x == b]
+            got, n, _ = a.bam_records(per_bin[b], bin_contigs=(mine[0], mine[-1] + 1) if mine else None, bin_unaligned=(b == n_bins - 1), **kw)
+            pieces.append(got.cpu().numpy().tobytes()); n_total += n
+        assert n_total == n_whole
+        assert b"".join(pieces) == whole, bin_of_contig
+        stored_twice = sum(p[1].shape[0] for b in per_bin for p in b) - sum(t[1].shape[0] for t in tiles)
+        assert (stored_twice > 1000) if max(bin_of_contig) else (stored_twice == 0)          # the chimeras, when the contigs are not all one bin
+
+
 def _bgzf_members(stream):
     """(offset, total size, ISIZE) of every BGZF block of `stream`; checks the fixed header bytes"""
     out, at = [], 0
