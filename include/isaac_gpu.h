@@ -117,6 +117,10 @@ typedef struct isaac_gpu_ctx isaac_gpu_ctx;
 
 const char *isaac_gpu_last_error(void);
 
+/* `stream` of isaac_gpu_create: a hipStream_t of the caller's, NULL for the device's default stream, or this value for a stream of the context's
+ * own (created with it, destroyed with it, not synchronised with the default stream): what several contexts on one device want when their
+ * callers are threads of a host that has no HIP runtime of its own. */
+#define ISAAC_GPU_STREAM_OWN ((void *)(uintptr_t)1)
 /* Replaces the construction of alignment::MatchFinder / MatchSelector / TemplateBuilder for one device
  * (lib/alignment/MatchFinder.cpp:74-112, MatchSelector.cpp:92-168).  `stream` is a hipStream_t or NULL. */
 int isaac_gpu_create(int device, const isaac_params *params, void *stream, isaac_gpu_ctx **out);
@@ -386,6 +390,14 @@ typedef struct { uint64_t records_offset, records_bytes; const uint8_t *bgzf_hos
 const char *isaac_gpu_bam_index_last_error(void);
 int isaac_gpu_bam_index(const uint8_t *records_host, const isaac_bam_index_part *parts, uint32_t n_parts, uint32_t n_contigs, uint64_t header_bgzf_bytes,
                         uint8_t *bai_out, uint64_t capacity, uint64_t *n_bytes_out);
+/* The same index made as the reference makes it: one bin at a time while the file is written (bam::BamIndex::processIndexPart per saved bin,
+ * lib/build/Build.cpp), so that the record stream of a whole run never has to be in one place.  add: the part's uncompressed records and the BGZF
+ * blocks they were compressed to (neither is kept); parts in file order, as above.  finish may be called once all parts are in. */
+typedef struct isaac_bam_indexer isaac_bam_indexer;
+isaac_bam_indexer *isaac_gpu_bam_indexer_create(uint32_t n_contigs, uint64_t header_bgzf_bytes);
+int isaac_gpu_bam_indexer_add(isaac_bam_indexer *indexer, const uint8_t *records_host, uint64_t records_bytes, const uint8_t *bgzf_host, uint64_t bgzf_bytes);
+int isaac_gpu_bam_indexer_finish(isaac_bam_indexer *indexer, uint8_t *bai_out, uint64_t capacity, uint64_t *n_bytes_out);
+void isaac_gpu_bam_indexer_destroy(isaac_bam_indexer *indexer);
 
 /* BGZF framing without compression on the device, for --bam-gzip-level 0: what bgzf::BgzfCompressor produces at gzip level 0
  * (include/bgzf/BgzfCompressor.hh:36-176: blocks of at most 0xFFFF - 41 input bytes, each a gzip member with the BC extra field around

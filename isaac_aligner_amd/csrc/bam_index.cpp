@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -95,7 +96,96 @@ void writeContig(std::vector<uint8_t> &out, const ContigIndex &c)
     put32(out, uint32_t(c.linear.size()));
     for (const uint64_t v : c.linear) put64(out, v);
 }
+
+// the state BamIndex keeps between the bins it is given
+struct Indexer
+{
+    std::vector<uint8_t> out; ContigIndex contig; uint32_t nContigs = 0, written = 0; uint64_t noCoordinates = 0, fileOffset = 0; uint32_t parts = 0;
+};
+
+// one part: BamIndexPart::processFragment over its records, BamIndex::processIndexPart with its blocks
+int addPart(Indexer &x, const uint8_t *r, uint64_t recordsBytes, const uint8_t *bgzf, uint64_t bgzfBytes)
+{
+    const uint32_t p = x.parts++;
+    if (!bgzfBytes) return 0;
+    if (!bgzf || (recordsBytes && !r)) return indexFail(ISAAC_GPU_EINVAL, "a part without its bytes");
+    BlockTable blocks;
+    if (!blocks.build(bgzf, bgzfBytes)) return indexFail(ISAAC_GPU_EFORMAT, "part " + std::to_string(p) + ": not a run of BGZF blocks");
+    if (blocks.uncompressed.back() != recordsBytes) return indexFail(ISAAC_GPU_EFORMAT, "part " + std::to_string(p) + ": the BGZF blocks do not hold records_bytes bytes");
+    std::vector<Chunk> chunks;
+    std::vector<uint64_t> linear;
+    uint64_t mapped = 0, unmapped = 0;
+    for (uint64_t at = 0; at < recordsBytes; )
+    {
+        if (at + 36 > recordsBytes) return indexFail(ISAAC_GPU_EFORMAT, "part " + std::to_string(p) + ": truncated record");
+        const uint8_t *b = r + at;
+        const uint64_t length = uint64_t(le32(b)) + 4;
+        if (at + length > recordsBytes) return indexFail(ISAAC_GPU_EFORMAT, "part " + std::to_string(p) + ": truncated record");
+        const int32_t refId = int32_t(le32(b + 4)), pos = int32_t(le32(b + 8));
+        const uint32_t nameLength = b[12], flagNc = le32(b + 16), nCigar = flagNc & 0xffff, flag = flagNc >> 16, seqLength = le32(b + 20);
+        if (pos >= 0)
+        {
+            if (refId < 0 || uint32_t(refId) >= x.nContigs) return indexFail(ISAAC_GPU_EFORMAT, "record with a position on contig " + std::to_string(refId));
+            if (uint32_t(pos) >= 512u * 1024 * 1024) return indexFail(ISAAC_GPU_EINVAL, "alignment position greater than the maximum allowed by BAM index: " + std::to_string(pos));
+            uint32_t observed = 0;                                              // the reference bases the alignment covers
+            for (uint32_t k = 0; k < nCigar; ++k) { const uint32_t w = le32(b + 36 + nameLength + 4 * k), op = w & 15; if (0 == op || 2 == op || 3 == op || 7 == op || 8 == op) observed += w >> 4; }
+            const uint32_t bin = reg2bin(uint32_t(pos), uint32_t(pos) + seqLength);    // "samtools is doing it this way"
+            const uint64_t end = at + length;
+            // addToBinIndexChunks: the chunk grows while the bin stays; a record of the bin before last may still reach back to it
+            if (!chunks.empty() && bin == chunks.back().bin && uint32_t(refId) == chunks.back().refId) chunks.back().end = end;
+            else if (chunks.size() >= 2 && bin == chunks[chunks.size() - 2].bin && uint32_t(refId) == chunks[chunks.size() - 2].refId && chunks[chunks.size() - 2].end + 32768 /* BAM_MIN_CHUNK_GAP */ > end)
+                chunks[chunks.size() - 2].end = end;
+            else chunks.push_back(Chunk{ at, end, bin, uint32_t(refId) });
+            // addToLinearIndex: the first record to reach a 16 kb window claims it, windows skipped on the way repeat the one before
+            const uint32_t windows[2] = { uint32_t(pos) >> 14, observed ? (uint32_t(pos) + observed - 1) >> 14 : uint32_t(pos) >> 14 };
+            for (const uint32_t w : windows)
+                if (linear.size() <= w) { const uint64_t fill = linear.empty() ? UNSET : linear.back(); linear.resize(w + 1, fill); linear[w] = at; }
+        }
+        ++((flag & 4) ? unmapped : mapped);
+        at += length;
+    }
+    if (!chunks.empty())
+    {
+        const uint32_t refId = chunks.front().refId;
+        if (refId < x.written) return indexFail(ISAAC_GPU_EINVAL, "the parts are not in contig order");
+        while (x.written < refId) { writeContig(x.out, x.contig); x.contig = ContigIndex(); ++x.written; }
+        for (const Chunk &c : chunks)
+        {
+            const uint64_t begin = blocks.resolve(c.begin, x.fileOffset), end = blocks.resolve(c.end, x.fileOffset);
+            std::vector<std::pair<uint64_t, uint64_t> > &bin = x.contig.bins[c.bin];
+            if (!bin.empty() && (bin.back().second >> 16) == (begin >> 16)) bin.back().second = end;        // "small chunks reduction"
+            else bin.push_back(std::make_pair(begin, end));
+        }
+        if (x.contig.linear.size() < linear.size()) x.contig.linear.resize(linear.size(), 0);
+        for (size_t w = 0; w < linear.size(); ++w)
+        {
+            if (UNSET == linear[w]) continue;
+            const uint64_t v = blocks.resolve(linear[w], x.fileOffset);
+            if (v < x.contig.linear[w] || !x.contig.linear[w]) x.contig.linear[w] = v;
+        }
+        x.contig.mapped += mapped; x.contig.unmapped += unmapped;
+    }
+    else x.noCoordinates += unmapped;
+    x.fileOffset += bgzfBytes;
+    return 0;
+}
+// BamIndex::outputIndexFile
+int finish(Indexer &x, uint8_t *baiOut, uint64_t capacity, uint64_t *nBytesOut)
+{
+    std::vector<uint8_t> out(x.out);
+    ContigIndex contig = x.contig;
+    for (uint32_t written = x.written; written < x.nContigs; ++written) { writeContig(out, contig); contig = ContigIndex(); }
+    put64(out, x.noCoordinates);
+    *nBytesOut = out.size();
+    if (out.size() > capacity) return indexFail(ISAAC_GPU_ECAPACITY, "bai_out is too small");
+    if (!baiOut) return indexFail(ISAAC_GPU_EINVAL, "bai_out is required");
+    std::memcpy(baiOut, out.data(), out.size());
+    return 0;
+}
+void start(Indexer &x, uint32_t nContigs, uint64_t headerBgzfBytes) { x.nContigs = nContigs; x.fileOffset = headerBgzfBytes; put(x.out, "BAI\1", 4); put32(x.out, nContigs); }
 } // namespace
+
+struct isaac_bam_indexer { Indexer x; };
 
 extern "C" {
 
@@ -106,86 +196,28 @@ int isaac_gpu_bam_index(const uint8_t *records, const isaac_bam_index_part *part
 {
     if (nBytesOut) *nBytesOut = 0;
     if ((nParts && !parts) || !nBytesOut) return indexFail(ISAAC_GPU_EINVAL, "parts and n_bytes_out are required");
-    std::vector<uint8_t> out;
-    put(out, "BAI\1", 4); put32(out, nContigs);
-    ContigIndex contig;
-    uint32_t written = 0;                       // contigs written so far == the contig `contig` belongs to
-    uint64_t noCoordinates = 0, fileOffset = headerBgzfBytes;
+    Indexer x; start(x, nContigs, headerBgzfBytes);
     for (uint32_t p = 0; p < nParts; ++p)
-    {
-        const isaac_bam_index_part &part = parts[p];
-        if (!part.bgzf_bytes) continue;
-        if (!part.bgzf_host || (part.records_bytes && !records)) return indexFail(ISAAC_GPU_EINVAL, "a part without its bytes");
-        BlockTable blocks;
-        if (!blocks.build(part.bgzf_host, part.bgzf_bytes)) return indexFail(ISAAC_GPU_EFORMAT, "part " + std::to_string(p) + ": not a run of BGZF blocks");
-        if (blocks.uncompressed.back() != part.records_bytes) return indexFail(ISAAC_GPU_EFORMAT, "part " + std::to_string(p) + ": the BGZF blocks do not hold records_bytes bytes");
-        // ---- BamIndexPart::processFragment over the part's records
-        std::vector<Chunk> chunks;
-        std::vector<uint64_t> linear;
-        uint64_t mapped = 0, unmapped = 0;
-        const uint8_t *r = records + part.records_offset;
-        for (uint64_t at = 0; at < part.records_bytes; )
-        {
-            if (at + 36 > part.records_bytes) return indexFail(ISAAC_GPU_EFORMAT, "part " + std::to_string(p) + ": truncated record");
-            const uint8_t *b = r + at;
-            const uint64_t length = uint64_t(le32(b)) + 4;
-            if (at + length > part.records_bytes) return indexFail(ISAAC_GPU_EFORMAT, "part " + std::to_string(p) + ": truncated record");
-            const int32_t refId = int32_t(le32(b + 4)), pos = int32_t(le32(b + 8));
-            const uint32_t nameLength = b[12], flagNc = le32(b + 16), nCigar = flagNc & 0xffff, flag = flagNc >> 16, seqLength = le32(b + 20);
-            if (pos >= 0)
-            {
-                if (refId < 0 || uint32_t(refId) >= nContigs) return indexFail(ISAAC_GPU_EFORMAT, "record with a position on contig " + std::to_string(refId));
-                if (uint32_t(pos) >= 512u * 1024 * 1024) return indexFail(ISAAC_GPU_EINVAL, "alignment position greater than the maximum allowed by BAM index: " + std::to_string(pos));
-                uint32_t observed = 0;                                              // the reference bases the alignment covers
-                for (uint32_t k = 0; k < nCigar; ++k) { const uint32_t w = le32(b + 36 + nameLength + 4 * k), op = w & 15; if (0 == op || 2 == op || 3 == op || 7 == op || 8 == op) observed += w >> 4; }
-                const uint32_t bin = reg2bin(uint32_t(pos), uint32_t(pos) + seqLength);    // "samtools is doing it this way"
-                const uint64_t end = at + length;
-                // addToBinIndexChunks: the chunk grows while the bin stays; a record of the bin before last may still reach back to it
-                if (!chunks.empty() && bin == chunks.back().bin && uint32_t(refId) == chunks.back().refId) chunks.back().end = end;
-                else if (chunks.size() >= 2 && bin == chunks[chunks.size() - 2].bin && uint32_t(refId) == chunks[chunks.size() - 2].refId && chunks[chunks.size() - 2].end + 32768 /* BAM_MIN_CHUNK_GAP */ > end)
-                    chunks[chunks.size() - 2].end = end;
-                else chunks.push_back(Chunk{ at, end, bin, uint32_t(refId) });
-                // addToLinearIndex: the first record to reach a 16 kb window claims it, windows skipped on the way repeat the one before
-                const uint32_t windows[2] = { uint32_t(pos) >> 14, observed ? (uint32_t(pos) + observed - 1) >> 14 : uint32_t(pos) >> 14 };
-                for (const uint32_t w : windows)
-                    if (linear.size() <= w) { const uint64_t fill = linear.empty() ? UNSET : linear.back(); linear.resize(w + 1, fill); linear[w] = at; }
-            }
-            ++((flag & 4) ? unmapped : mapped);
-            at += length;
-        }
-        // ---- BamIndex::processIndexPart
-        if (!chunks.empty())
-        {
-            const uint32_t refId = chunks.front().refId;
-            if (refId < written) return indexFail(ISAAC_GPU_EINVAL, "the parts are not in contig order");
-            while (written < refId) { writeContig(out, contig); contig = ContigIndex(); ++written; }
-            for (const Chunk &c : chunks)
-            {
-                const uint64_t begin = blocks.resolve(c.begin, fileOffset), end = blocks.resolve(c.end, fileOffset);
-                std::vector<std::pair<uint64_t, uint64_t> > &bin = contig.bins[c.bin];
-                if (!bin.empty() && (bin.back().second >> 16) == (begin >> 16)) bin.back().second = end;        // "small chunks reduction"
-                else bin.push_back(std::make_pair(begin, end));
-            }
-            if (contig.linear.size() < linear.size()) contig.linear.resize(linear.size(), 0);
-            for (size_t w = 0; w < linear.size(); ++w)
-            {
-                if (UNSET == linear[w]) continue;
-                const uint64_t v = blocks.resolve(linear[w], fileOffset);
-                if (v < contig.linear[w] || !contig.linear[w]) contig.linear[w] = v;
-            }
-            contig.mapped += mapped; contig.unmapped += unmapped;
-        }
-        else noCoordinates += unmapped;
-        fileOffset += part.bgzf_bytes;
-    }
-    // BamIndex::outputIndexFile
-    while (written < nContigs) { writeContig(out, contig); contig = ContigIndex(); ++written; }
-    put64(out, noCoordinates);
-    *nBytesOut = out.size();
-    if (out.size() > capacity) return indexFail(ISAAC_GPU_ECAPACITY, "bai_out is too small");
-    if (!baiOut) return indexFail(ISAAC_GPU_EINVAL, "bai_out is required");
-    std::memcpy(baiOut, out.data(), out.size());
-    return 0;
+        if (const int rc = addPart(x, records ? records + parts[p].records_offset : nullptr, parts[p].records_bytes, parts[p].bgzf_host, parts[p].bgzf_bytes)) return rc;
+    return finish(x, baiOut, capacity, nBytesOut);
 }
+
+isaac_bam_indexer *isaac_gpu_bam_indexer_create(uint32_t nContigs, uint64_t headerBgzfBytes)
+{
+    isaac_bam_indexer *i = new (std::nothrow) isaac_bam_indexer;
+    if (i) start(i->x, nContigs, headerBgzfBytes);
+    return i;
+}
+int isaac_gpu_bam_indexer_add(isaac_bam_indexer *i, const uint8_t *records, uint64_t recordsBytes, const uint8_t *bgzf, uint64_t bgzfBytes)
+{
+    if (!i) return indexFail(ISAAC_GPU_EINVAL, "indexer is required");
+    return addPart(i->x, records, recordsBytes, bgzf, bgzfBytes);
+}
+int isaac_gpu_bam_indexer_finish(isaac_bam_indexer *i, uint8_t *baiOut, uint64_t capacity, uint64_t *nBytesOut)
+{
+    if (!i || !nBytesOut) return indexFail(ISAAC_GPU_EINVAL, "indexer and n_bytes_out are required");
+    return finish(i->x, baiOut, capacity, nBytesOut);
+}
+void isaac_gpu_bam_indexer_destroy(isaac_bam_indexer *i) { delete i; }
 
 } // extern "C"

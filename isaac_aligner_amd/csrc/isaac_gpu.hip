@@ -63,6 +63,7 @@ struct KernelTimer { double ms = 0; uint64_t launches = 0; };
 
 struct isaac_gpu_ctx
 {
+    bool ownsStream = false;
     int device = 0; hipStream_t stream = nullptr;
     isaac_params params; DevParams P;
     // reference
@@ -559,6 +560,7 @@ int isaac_gpu_create(int device, const isaac_params *params, void *stream, isaac
     HIP_CHECK(hipSetDevice(device));
     std::unique_ptr<isaac_gpu_ctx> c(new isaac_gpu_ctx);
     c->device = device; c->stream = static_cast<hipStream_t>(stream);
+    if (ISAAC_GPU_STREAM_OWN == stream) { HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->ownsStream = true; }
     c->params = *params; c->P = makeDevParams(*params);
     if (-params->gap_open < -params->gap_extend) return fail(ISAAC_GPU_EINVAL, "gap open penalty below gap extend penalty is not supported by the banded Smith-Waterman scan");
     double tables[200]; makeQualityTables(tables, tables + 100);
@@ -587,6 +589,7 @@ void isaac_gpu_destroy(isaac_gpu_ctx *c)
     }
 #endif
     for (hipEvent_t e : c->eventPool) hipEventDestroy(e);
+    if (c->ownsStream) hipStreamDestroy(c->stream);
     delete c;
 }
 

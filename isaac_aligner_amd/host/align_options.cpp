@@ -53,6 +53,8 @@ std::string AlignOptions::usage()
         "  -t [ --temp-directory ] arg (=./Temp)   accepted; nothing is written there\n"
         "  -j [ --jobs ] arg                    host threads for BGZF compression and FASTQ inflation\n"
         "  --device arg (=0)                    HIP device\n"
+        "  --devices arg                        HIP devices, comma separated: one worker per entry; the tiles and the bins of the\n"
+        "                                       run are dealt out to them (an entry may repeat: two workers on one device)\n"
         "  --use-bases-mask arg (=default)      y*n per read by default (the last cycle is not used); y<N>n<M> and y* forms\n"
         "  --seeds arg (=auto)                  auto | all | offsets 0:32:64[,...]\n"
         "  --first-pass-seeds arg (=1)\n"
@@ -120,6 +122,7 @@ AlignOptions AlignOptions::parse(int argc, char **argv)
     specs.push_back({ "bam-exclude-tags", 0, false, text(&o.bamExcludeTags), "" });
     specs.push_back({ "description", 0, false, text(&o.description), "" });
     specs.push_back({ "tls", 0, false, text(&o.tls), "" });
+    specs.push_back({ "devices", 0, false, text(&o.devices), "" });
     specs.push_back({ "sample-sheet", 's', true, list(&sampleSheet), "" });
     specs.push_back({ "tiles", 0, true, list(&tiles), "" });
     specs.push_back({ "default-adapters", 0, true, list(&defaultAdapters), "" });
@@ -219,6 +222,23 @@ AlignOptions AlignOptions::parse(int argc, char **argv)
     for (const std::string &s : defaultAdapters) refuse(!s.empty() && s != "none", "--default-adapters");
     (void)pfOnly;       // FASTQ data has no filter files: every cluster passes
     return o;
+}
+
+std::vector<int> AlignOptions::deviceList() const
+{
+    std::vector<int> list;
+    if (devices.empty()) { list.push_back(device); return list; }
+    for (size_t at = 0; at <= devices.size();)
+    {
+        const size_t comma = std::min(devices.find(',', at), devices.size());
+        const std::string item = devices.substr(at, comma - at);
+        char *end = 0;
+        const long v = std::strtol(item.c_str(), &end, 10);
+        if (item.empty() || *end || v < 0) throw InvalidOption("\n   *** --devices: a comma separated list of device numbers is expected (" + devices + " given) ***\n");
+        list.push_back(int(v));
+        at = comma + 1;
+    }
+    return list;
 }
 
 unsigned AlignOptions::forcedDodgyAlignmentScore() const

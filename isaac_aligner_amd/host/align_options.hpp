@@ -24,9 +24,10 @@ struct AlignOptions
     std::vector<std::string> baseCallsFormat;               // fastq | fastq-gz per flowcell (the last one serves the rest)
     std::string referenceGenome;                            // -r sorted-reference.xml
     std::string outputDirectory = "./Aligned";              // -o
-    std::string tempDirectory = "./Temp";                   // -t (nothing is written there)
+    std::string tempDirectory = "./Temp";                   // -t (nothing is written there: the bins are kept in host memory)
     std::string seeds = "auto", gapScoring = "bwa", dodgyAlignmentScore = "0", keepUnaligned = "back", realignGaps = "sample", useBasesMask = "default";
     std::string bamPuFormat = "%F:%L:%B", description, bamExcludeTags = "ZX,ZY", tls;
+    std::string devices;                                    // --devices 0,1,...: one worker (context + thread) per entry; empty: --device alone
     std::vector<std::string> bamHeaderTags;
     unsigned seedLength = 32, firstPassSeeds = 1, jobs = 0, repeatThreshold = 10, laneNumberMax = 8, clustersAtATime = 0, mapqThreshold = 0, baseQualityCutoff = 25,
              semialignedGapLimit = 100, gappedMismatches = 5, realignedGapsPerFragment = 1;
@@ -41,6 +42,7 @@ struct AlignOptions
     isaac_params params(unsigned readLength1, unsigned readLength2) const;
     bool keepUnalignedRecords() const { return "discard" != keepUnaligned; }
     unsigned forcedDodgyAlignmentScore() const;             // the MAPQ of alignments whose score is unknown
+    std::vector<int> deviceList() const;                    // --devices, or --device alone
 };
 
 } // namespace isaac_host

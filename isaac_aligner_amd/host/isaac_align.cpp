@@ -6,9 +6,11 @@
 //   find matches   workflow::alignWorkflow::FindMatchesTransition               isaac_gpu_fastq_to_bcl, isaac_gpu_find_matches (which contigs have matches)
 //   select         workflow::alignWorkflow::SelectMatchesTransition             isaac_gpu_find_matches again (the matches are not kept: 1.3 ms per million
 //                                                                               pairs against 400 bytes per pair), isaac_gpu_determine_tls per lane
-//                                                                               (MatchSelector.cpp:395-412), isaac_gpu_select, isaac_gpu_compact_cigars
-//   build          build::Build                                                 isaac_gpu_bam_records over all tiles, one BGZF run per contig, sorted.bam + .bai
-// Everything a tile needs later stays in HBM: BCL bytes (the BAM records are made from them), 64-byte records, packed CIGARs.
+//                                                                               (MatchSelector.cpp:395-412), isaac_gpu_select_n, isaac_gpu_compact_cigars,
+//                  alignment::matchSelector::BinningFragmentStorage             isaac_gpu_bin_tile: every tile's clusters to the bins (one per contig) in host memory
+//   build          build::Build                                                 per bin: isaac_gpu_bam_records (duplicates, realignment, order, records),
+//                                                                               isaac_gpu_bgzf_deflate / _store, the blocks to sorted.bam, the records to the .bai
+// --devices a,b,...: a worker (context + thread) per entry; loads, tiles and bins are dealt to them; one file comes out, in bin order.
 #include "isaac_gpu.h"
 #include "align_options.hpp"
 #include "fastq_flowcell.hpp"
@@ -25,6 +27,10 @@
 #include <memory>
 #include <sstream>
 #include <sys/stat.h>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 using namespace isaac_host;
 
@@ -128,11 +134,12 @@ Reference loadReference(const std::string &xmlPath)
 }
 
 // ---- the data: lanes, loads, tiles -------------------------------------------------------------------------------------------------------
+struct Worker;
 struct Tile
 {
     unsigned lane = 0, number = 0, index = 0, clusters = 0;     // tile number within the lane (the read name), index over the run (the records)
-    const uint8_t *bcl = 0;                                       // inside its load's buffer
-    DeviceMemory records, cigars;
+    const uint8_t *bcl = 0;                                       // inside its load's buffer, on its worker's device
+    Worker *worker = 0;
     isaac_tls tls;
     std::string namePrefix, readGroup;
 };
@@ -178,10 +185,36 @@ uint32_t loadRead(isaac_gpu_ctx *ctx, ReadStream &stream, unsigned readIndex, bo
     return clusters;
 }
 
-struct Part { uint64_t offset, bytes; std::vector<uint8_t> bgzf; };
+// ---- the bins: what BinningFragmentStorage keeps in files (lib/alignment/matchSelector/BinningFragmentStorage.cpp) kept in host memory ----------
+// One bin per contig and one for the templates without a position: the bins of the BAM stage (duplicates and realignment never look across
+// contigs).  A tile leaves one part in every bin it has records in (isaac_gpu_bin_tile): BCL bytes, records and CIGAR words of the clusters
+// concerned, about 150 + 2 x read length bytes per read.  That is the run's memory model: HBM holds the table, the BCL bytes of the loads
+// until their tiles are selected, one tile's scratch and -- in the build stage -- one bin at a time; host memory holds the bins.
+struct BinPart { const Tile *tile; uint64_t clusters, words, bytes; std::unique_ptr<uint8_t[]> data; };
+struct Bin { std::mutex lock; std::vector<BinPart> parts; uint64_t bytes = 0, records = 0; };
+
+uint64_t align64(uint64_t v) { return (v + 63) & ~uint64_t(63); }
+
+// a device and what runs on it
+struct Worker
+{
+    int device = 0; unsigned id = 0;
+    isaac_gpu_ctx *ctx = 0;
+    std::vector<DeviceMemory> loads;                // the BCL bytes of the loads dealt to this worker
+    std::vector<Tile *> tiles;
+    DeviceMemory matches, offsets, textDev, tableKmers, tablePositions;
+    uint64_t matchCapacity = 0;
+    isaac_counters counters;
+    double selectSeconds = 0, buildSeconds = 0;
+    ~Worker() { loads.clear(); matches.release(); offsets.release(); textDev.release(); if (ctx) { isaac_gpu_destroy(ctx); } tableKmers.release(); tablePositions.release(); }
+};
+
+// what a bin of the file becomes: its BGZF blocks, and its records for the index
+struct BinOutput { bool ready = false; std::vector<uint8_t> bgzf, records; uint64_t nRecords = 0; std::string error; };
 
 int run(const AlignOptions &o)
 {
+    const double runStart = seconds();
     // ---- flowcells (AlignOptions.cpp:1178-1290)
     std::vector<FastqFlowcell> flowcells;
     for (size_t i = 0; i < o.baseCalls.size(); ++i)
@@ -200,44 +233,68 @@ int run(const AlignOptions &o)
     const unsigned nReads = flowcells[0].nReads, clusterLength = flowcells[0].readLength[0] + flowcells[0].readLength[1];
     const isaac_params params = o.params(flowcells[0].readLength[0], 2 == nReads ? flowcells[0].readLength[1] : 0);
 
-    // ---- reference
-    isaac_gpu_ctx *ctx = 0;
-    GPU(isaac_gpu_create(o.device, &params, 0, &ctx));
-    std::unique_ptr<isaac_gpu_ctx, void (*)(isaac_gpu_ctx *)> ctxGuard(ctx, isaac_gpu_destroy);
+    // ---- the workers and the reference: the first context of a device loads the table, the others of that device share it; another device
+    // gets a copy over the link between the two (isaac_gpu_copy)
+    const std::vector<int> devices = o.deviceList();
+    std::vector<std::unique_ptr<Worker> > workers;
     Reference reference;
     {
         Stage stage("loading the reference");
         reference = loadReference(o.referenceGenome);
-        GPU(isaac_gpu_load_contigs(ctx, reference.bases.data(), reference.offsets.data(), uint32_t(reference.contigs.size())));
+        for (size_t k = 0; k < devices.size(); ++k)
+        {
+            workers.emplace_back(new Worker);
+            Worker &w = *workers.back();
+            w.device = devices[k]; w.id = unsigned(k);
+            GPU(isaac_gpu_create(w.device, &params, ISAAC_GPU_STREAM_OWN, &w.ctx));
+            GPU(isaac_gpu_load_contigs(w.ctx, reference.bases.data(), reference.offsets.data(), uint32_t(reference.contigs.size())));
+            if (0 == k) { GPU(isaac_gpu_load_sorted_reference(w.ctx, o.referenceGenome.c_str())); continue; }
+            const uint64_t *kmers = 0, *positions = 0; uint64_t n = 0;
+            GPU(isaac_gpu_index_dev(workers[0]->ctx, &kmers, &positions, &n));
+            std::vector<uint64_t> maskOffsets(65);
+            GPU(isaac_gpu_get_mask_offsets(workers[0]->ctx, maskOffsets.data(), 64));
+            Worker *sameDevice = 0;
+            for (size_t j = 0; j < k && !sameDevice; ++j) if (workers[j]->device == w.device) sameDevice = workers[j].get();
+            if (!sameDevice)
+            {
+                w.tableKmers.reset(w.ctx, n * 8); w.tablePositions.reset(w.ctx, n * 8);
+                GPU(isaac_gpu_copy(w.ctx, w.tableKmers.as<uint64_t>(), kmers, n * 8));
+                GPU(isaac_gpu_copy(w.ctx, w.tablePositions.as<uint64_t>(), positions, n * 8));
+                kmers = w.tableKmers.as<uint64_t>(); positions = w.tablePositions.as<uint64_t>();
+            }
+            else if (sameDevice != workers[0].get()) GPU(isaac_gpu_index_dev(sameDevice->ctx, &kmers, &positions, &n));
+            GPU(isaac_gpu_set_index_dev(w.ctx, kmers, positions, n, maskOffsets.data(), 64));
+        }
         std::string().swap(reference.bases);
-        GPU(isaac_gpu_load_sorted_reference(ctx, o.referenceGenome.c_str()));
     }
     const uint32_t nContigs = uint32_t(reference.contigs.size());
+    if (nContigs + 1 > 255) throw std::runtime_error("this host keeps one bin per contig: at most 254 contigs");
+    const double referenceSeconds = seconds() - runStart;
 
-    // ---- FastqSeedSource: loads of --clusters-at-a-time clusters, tiles of at most tileClustersMax
+    // ---- FastqSeedSource: loads of --clusters-at-a-time clusters, tiles of at most tileClustersMax; the loads are dealt to the workers in turn
     const uint32_t tileClustersMax = isaac_gpu_fastq_tile_clusters_max(o.clustersAtATime, params.n_seeds);
     const uint32_t loadClusters = o.clustersAtATime ? o.clustersAtATime : 4 * tileClustersMax;      // a multiple of the tile size: the tiles come out the same for any such load
     std::deque<Tile> tiles;
-    std::vector<DeviceMemory> loads;
     std::vector<uint8_t> contigHasMatches(nContigs, 0);
-    DeviceMemory matches, offsets(ctx, (uint64_t(tileClustersMax) + 1) * 8), textDev;
-    uint64_t matchCapacity = 0;
-    auto findMatches = [&](const Tile &t, uint64_t &nMatches)
+    auto findMatches = [&](Worker &w, const Tile &t, uint64_t &nMatches, uint8_t *hits)
     {
         const uint64_t worst = uint64_t(t.clusters) * 2 * params.n_seeds * std::max(1u, params.repeat_threshold - 1);
-        if (!matchCapacity) { matchCapacity = std::max<uint64_t>(1024, std::min<uint64_t>(worst, uint64_t(tileClustersMax) * 24)); matches.reset(ctx, matchCapacity * sizeof(isaac_match)); }
+        if (!w.offsets.bytes()) w.offsets.reset(w.ctx, (uint64_t(tileClustersMax) + 1) * 8);
+        if (!w.matchCapacity) { w.matchCapacity = std::max<uint64_t>(1024, std::min<uint64_t>(worst, uint64_t(tileClustersMax) * 24)); w.matches.reset(w.ctx, w.matchCapacity * sizeof(isaac_match)); }
         for (;;)
         {
-            const int rc = isaac_gpu_find_matches(ctx, t.bcl, t.clusters, t.index, matches.as<isaac_match>(), matchCapacity, offsets.as<uint64_t>(), &nMatches, contigHasMatches.data());
+            const int rc = isaac_gpu_find_matches(w.ctx, t.bcl, t.clusters, t.index, w.matches.as<isaac_match>(), w.matchCapacity, w.offsets.as<uint64_t>(), &nMatches, hits);
             if (ISAAC_GPU_ECAPACITY != rc) { check(rc, "isaac_gpu_find_matches"); return; }
-            matchCapacity = std::max(nMatches, 2 * matchCapacity);
-            matches.reset(ctx, matchCapacity * sizeof(isaac_match));
+            w.matchCapacity = std::max(nMatches, 2 * w.matchCapacity);
+            w.matches.reset(w.ctx, w.matchCapacity * sizeof(isaac_match));
         }
     };
+    uint64_t totalClusters = 0;
+    const double loadStart = seconds();
     {
         Stage stage("loading base calls and finding matches");
         unsigned barcodeIndex = 0;
-        uint64_t totalClusters = 0;
+        size_t nextWorker = 0;
         for (const FastqFlowcell &fc : flowcells)
             for (const FastqLane &lane : fc.lanes)
             {
@@ -251,18 +308,19 @@ int run(const AlignOptions &o)
                 uint32_t nextTile = 1;
                 for (;;)
                 {
-                    DeviceMemory bcl(ctx, uint64_t(loadClusters) * clusterLength + 64);
+                    Worker &w = *workers[nextWorker % workers.size()];
+                    DeviceMemory bcl(w.ctx, uint64_t(loadClusters) * clusterLength + 64);
                     uint32_t loaded[2] = { 0, 0 };
                     for (unsigned r = 0; r < nReads; ++r)
-                        loaded[r] = loadRead(ctx, streams[r], r, o.variableReadLength || o.variableFastqReadLength, bcl.as<uint8_t>(), clusterLength, loadClusters, textDev);
+                        loaded[r] = loadRead(w.ctx, streams[r], r, o.variableReadLength || o.variableFastqReadLength, bcl.as<uint8_t>(), clusterLength, loadClusters, w.textDev);
                     if (2 == nReads && loaded[0] != loaded[1])
                         throw std::runtime_error("Mismatching number of clusters in " + lane.readPath[0] + " (" + std::to_string(loaded[0]) + ") and " + lane.readPath[1] + " (" + std::to_string(loaded[1]) + ")");
                     if (!loaded[0]) break;
                     if (loaded[0] < loadClusters / 2)
                     {   // "allocated too much memory for bcl data": the load keeps what it uses
-                        DeviceMemory exact(ctx, uint64_t(loaded[0]) * clusterLength + 64);
-                        GPU(isaac_gpu_copy(ctx, exact.as<uint8_t>(), bcl.as<uint8_t>(), uint64_t(loaded[0]) * clusterLength));
-                        GPU(isaac_gpu_synchronize(ctx));
+                        DeviceMemory exact(w.ctx, uint64_t(loaded[0]) * clusterLength + 64);
+                        GPU(isaac_gpu_copy(w.ctx, exact.as<uint8_t>(), bcl.as<uint8_t>(), uint64_t(loaded[0]) * clusterLength));
+                        GPU(isaac_gpu_synchronize(w.ctx));
                         bcl = std::move(exact);
                     }
                     uint32_t nTiles = 0, next = 0;
@@ -275,99 +333,133 @@ int run(const AlignOptions &o)
                     {
                         tiles.emplace_back();
                         Tile &t = tiles.back();
-                        t.lane = lane.lane; t.number = numbers[k]; t.index = unsigned(tiles.size() - 1); t.clusters = sizes[k]; t.bcl = bcl.as<uint8_t>() + first * clusterLength;
+                        t.lane = lane.lane; t.number = numbers[k]; t.index = unsigned(tiles.size() - 1); t.clusters = sizes[k]; t.bcl = bcl.as<uint8_t>() + first * clusterLength; t.worker = &w;
                         t.namePrefix = fc.flowcellId + ":" + std::to_string(lane.lane) + ":" + std::to_string(t.number) + ":"; t.readGroup = readGroup;
                         std::memset(&t.tls, 0, sizeof(t.tls));
                         first += sizes[k];
                         uint64_t nMatches = 0;
-                        findMatches(t, nMatches);
+                        findMatches(w, t, nMatches, contigHasMatches.data());
+                        w.tiles.push_back(&t);
                     }
                     totalClusters += loaded[0];
-                    loads.push_back(std::move(bcl));
+                    w.loads.push_back(std::move(bcl));
+                    ++nextWorker;
                     if (loaded[0] < loadClusters) break;
                 }
             }
-        textDev.release();
-        std::cerr << "isaac-align: " << totalClusters << " clusters in " << tiles.size() << " tile(s)" << std::endl;
+        for (auto &w : workers) w->textDev.release();
+        std::cerr << "isaac-align: " << totalClusters << " clusters in " << tiles.size() << " tile(s) on " << workers.size() << " worker(s)" << std::endl;
         if (tiles.empty()) throw InvalidOption("No data found to process. Please check your --base-calls.");
     }
+    const double loadSeconds = seconds() - loadStart;
 
-    // ---- SelectMatchesTransition: every tile with the contigs the whole run has matches on
+    // ---- SelectMatchesTransition: every tile with the contigs the whole run has matches on.  The template length statistics of a lane are
+    // learnt tile by tile until a tile gives stable ones, which then serve the rest of the lane (MatchSelector.cpp:395-412): settled first, in tile
+    // order, so that the workers can take their tiles in any order afterwards.
+    std::vector<Bin> bins(nContigs + 1);
+    std::vector<uint32_t> binOfContig(nContigs);
+    for (uint32_t c = 0; c < nContigs; ++c) binOfContig[c] = c;
+    const double selectStart = seconds();
     {
         Stage stage("selecting matches");
-        GPU(isaac_gpu_set_loaded_contigs(ctx, contigHasMatches.data(), nContigs));
-        DeviceMemory slots(ctx, uint64_t(tileClustersMax) * nReads * ISAAC_GPU_MAX_CIGAR_OPS * 4), packed;
-        isaac_tls tls; std::memset(&tls, 0, sizeof(tls));
-        std::string laneKey;
-        for (Tile &t : tiles)
+        for (auto &w : workers) GPU(isaac_gpu_set_loaded_contigs(w->ctx, contigHasMatches.data(), nContigs));
         {
-            uint64_t nMatches = 0;
-            findMatches(t, nMatches);
-            if (laneKey != t.readGroup) { std::memset(&tls, 0, sizeof(tls)); laneKey = t.readGroup; }       // barcodeTemplateLengthStatistics: one per barcode
-            if (!tls.stable || o.perTileTls)
+            isaac_tls tls; std::memset(&tls, 0, sizeof(tls));
+            std::string laneKey;
+            for (Tile &t : tiles)
             {
-                GPU(isaac_gpu_determine_tls(ctx, t.bcl, t.clusters, t.index, matches.as<isaac_match>(), offsets.as<uint64_t>(), &tls));
-                std::cerr << "isaac-align: template length statistics of tile " << t.namePrefix << " min " << tls.min << " median " << tls.median << " max " << tls.max
-                          << (tls.stable ? " (stable)" : " (unstable)") << std::endl;
+                if (laneKey != t.readGroup) { std::memset(&tls, 0, sizeof(tls)); laneKey = t.readGroup; }       // barcodeTemplateLengthStatistics: one per barcode
+                if (!tls.stable || o.perTileTls)
+                {
+                    uint64_t nMatches = 0;
+                    findMatches(*t.worker, t, nMatches, 0);
+                    GPU(isaac_gpu_determine_tls(t.worker->ctx, t.bcl, t.clusters, t.index, t.worker->matches.as<isaac_match>(), t.worker->offsets.as<uint64_t>(), &tls));
+                    std::cerr << "isaac-align: template length statistics of tile " << t.namePrefix << " min " << tls.min << " median " << tls.median << " max " << tls.max
+                              << (tls.stable ? " (stable)" : " (unstable)") << std::endl;
+                }
+                t.tls = tls;
             }
-            t.tls = tls;
-            const uint64_t nRecords = uint64_t(t.clusters) * nReads;
-            t.records.reset(ctx, nRecords * sizeof(isaac_fragment));
-            GPU(isaac_gpu_select(ctx, t.bcl, t.clusters, t.index, matches.as<isaac_match>(), offsets.as<uint64_t>(), &tls, t.records.as<isaac_fragment>(), slots.as<uint32_t>(),
-                                 nRecords * ISAAC_GPU_MAX_CIGAR_OPS));
-            // the CIGARs as the bin files hold them: back to back
-            uint64_t words = 0;
-            if (packed.bytes() < nRecords * 8 * 4) packed.reset(ctx, nRecords * 8 * 4);
-            int rc = isaac_gpu_compact_cigars(ctx, t.records.as<isaac_fragment>(), nRecords, slots.as<uint32_t>(), packed.as<uint32_t>(), packed.bytes() / 4, &words);
-            if (ISAAC_GPU_ECAPACITY == rc)
+        }
+        std::vector<std::string> errors(workers.size());
+        auto selectTiles = [&](Worker &w)
+        {
+            try
             {
-                packed.reset(ctx, words * 4);
-                rc = isaac_gpu_compact_cigars(ctx, t.records.as<isaac_fragment>(), nRecords, slots.as<uint32_t>(), packed.as<uint32_t>(), packed.bytes() / 4, &words);
+                const double start = seconds();
+                DeviceMemory slots(w.ctx, uint64_t(tileClustersMax) * nReads * ISAAC_GPU_MAX_CIGAR_OPS * 4), records(w.ctx, uint64_t(tileClustersMax) * nReads * sizeof(isaac_fragment)), packed, binned;
+                std::vector<isaac_bin_size> sizes(nContigs + 1);
+                for (Tile *tp : w.tiles)
+                {
+                    Tile &t = *tp;
+                    uint64_t nMatches = 0;
+                    findMatches(w, t, nMatches, 0);
+                    const uint64_t nRecords = uint64_t(t.clusters) * nReads;
+                    GPU(isaac_gpu_select_n(w.ctx, t.bcl, t.clusters, t.index, w.matches.as<isaac_match>(), nMatches, w.offsets.as<uint64_t>(), &t.tls, records.as<isaac_fragment>(), slots.as<uint32_t>(),
+                                           nRecords * ISAAC_GPU_MAX_CIGAR_OPS));
+                    // the CIGARs as the bin files hold them: back to back
+                    uint64_t words = 0;
+                    if (packed.bytes() < nRecords * 8 * 4) packed.reset(w.ctx, nRecords * 8 * 4);
+                    int rc = isaac_gpu_compact_cigars(w.ctx, records.as<isaac_fragment>(), nRecords, slots.as<uint32_t>(), packed.as<uint32_t>(), packed.bytes() / 4, &words);
+                    if (ISAAC_GPU_ECAPACITY == rc)
+                    {
+                        packed.reset(w.ctx, words * 4);
+                        rc = isaac_gpu_compact_cigars(w.ctx, records.as<isaac_fragment>(), nRecords, slots.as<uint32_t>(), packed.as<uint32_t>(), packed.bytes() / 4, &words);
+                    }
+                    check(rc, "isaac_gpu_compact_cigars");
+                    // BinningFragmentStorage: the tile's clusters to their bins, every bin's part to host memory
+                    uint64_t need = 0;
+                    const uint64_t guess = align64(uint64_t(t.clusters) * clusterLength + nRecords * sizeof(isaac_fragment) + words * 4) * 5 / 4 + 256 * (nContigs + 1);
+                    if (binned.bytes() < guess) binned.reset(w.ctx, guess);
+                    rc = isaac_gpu_bin_tile(w.ctx, t.bcl, records.as<isaac_fragment>(), packed.as<uint32_t>(), t.clusters, binOfContig.data(), nContigs, nContigs + 1, binned.as<uint8_t>(), binned.bytes(),
+                                            sizes.data(), &need);
+                    if (ISAAC_GPU_ECAPACITY == rc)
+                    {
+                        binned.reset(w.ctx, need);
+                        rc = isaac_gpu_bin_tile(w.ctx, t.bcl, records.as<isaac_fragment>(), packed.as<uint32_t>(), t.clusters, binOfContig.data(), nContigs, nContigs + 1, binned.as<uint8_t>(), binned.bytes(),
+                                                sizes.data(), &need);
+                    }
+                    check(rc, "isaac_gpu_bin_tile");
+                    uint64_t at = 0;
+                    for (uint32_t b = 0; b <= nContigs; ++b)
+                    {
+                        const uint64_t m = sizes[b].n_clusters, cw = sizes[b].n_cigar_words;
+                        const uint64_t bytes = align64(align64(m * clusterLength) + m * nReads * sizeof(isaac_fragment)) + align64(cw * 4);
+                        if (m)
+                        {
+                            BinPart part; part.tile = &t; part.clusters = m; part.words = cw; part.bytes = bytes; part.data.reset(new uint8_t[bytes]);
+                            GPU(isaac_gpu_download(w.ctx, part.data.get(), binned.as<uint8_t>() + at, bytes));
+                            std::lock_guard<std::mutex> guard(bins[b].lock);
+                            bins[b].bytes += bytes; bins[b].records += m * nReads;
+                            bins[b].parts.push_back(std::move(part));
+                        }
+                        at += bytes;
+                    }
+                }
+                GPU(isaac_gpu_synchronize(w.ctx));
+                isaac_gpu_get_counters(w.ctx, &w.counters);
+                w.loads.clear();                        // the BCL bytes are in the bins now
+                w.matches.release(); w.offsets.release();
+                w.selectSeconds = seconds() - start;
             }
-            check(rc, "isaac_gpu_compact_cigars");
-            t.cigars.reset(ctx, words * 4);
-            GPU(isaac_gpu_copy(ctx, t.cigars.as<uint32_t>(), packed.as<uint32_t>(), words * 4));
-        }
-        GPU(isaac_gpu_synchronize(ctx));
-        isaac_counters counters;
-        if (!isaac_gpu_get_counters(ctx, &counters) && counters.overflow_clusters)
-            std::cerr << "WARNING: " << counters.overflow_clusters << " cluster(s) of the last tile exceeded a fixed work list; their records are flagged (isaac_fragment::reserved bit 2)" << std::endl;
+            catch (const std::exception &e) { errors[w.id] = e.what(); }
+        };
+        std::vector<std::thread> threads;
+        for (size_t k = 1; k < workers.size(); ++k) threads.emplace_back(selectTiles, std::ref(*workers[k]));
+        selectTiles(*workers[0]);
+        for (std::thread &t : threads) t.join();
+        for (const std::string &e : errors) if (!e.empty()) throw std::runtime_error(e);
+        uint64_t overflow = 0;
+        for (auto &w : workers) overflow += w->counters.overflow_clusters;
+        if (overflow) std::cerr << "WARNING: " << overflow << " cluster(s) exceeded a fixed work list; their records are flagged (isaac_fragment::reserved bit 2)" << std::endl;
+        // parts in tile order inside a bin, whichever worker was first
+        for (Bin &bin : bins) std::sort(bin.parts.begin(), bin.parts.end(), [](const BinPart &a, const BinPart &b) { return a.tile->index < b.tile->index; });
     }
-    matches.release(); offsets.release();
+    const double selectSeconds = seconds() - selectStart;
 
-    // ---- build::Build: the record stream of the whole run, then one BGZF run per bin (contig) and the index over them
-    std::vector<uint8_t> stream;
-    uint64_t nRecordsWritten = 0, unalignedOffset = 0;
-    {
-        Stage stage("making BAM records");
-        std::vector<isaac_bam_tile> bamTiles(tiles.size());
-        uint64_t nRecords = 0;
-        for (size_t i = 0; i < tiles.size(); ++i)
-        {
-            const Tile &t = tiles[i];
-            isaac_bam_tile &b = bamTiles[i];
-            b.bcl_dev = t.bcl; b.fragments_dev = t.records.as<isaac_fragment>(); b.cigar_dev = t.cigars.as<uint32_t>(); b.n_records = uint64_t(t.clusters) * nReads;
-            b.read_name_prefix = t.namePrefix.c_str(); b.read_group = t.readGroup.c_str(); b.tls = &t.tls;
-            nRecords += b.n_records;
-        }
-        isaac_bam_options bamOptions; std::memset(&bamOptions, 0, sizeof(bamOptions));
-        bamOptions.forced_dodgy_alignment_score = o.forcedDodgyAlignmentScore(); bamOptions.pessimistic_mapq = o.pessimisticMapQ; bamOptions.read_group = "0"; bamOptions.barcode = "none";
-        bamOptions.mark_duplicates = o.markDuplicates; bamOptions.keep_duplicates = o.keepDuplicates; bamOptions.realign_gaps = "no" != o.realignGaps; bamOptions.realign_dodgy = o.realignDodgy;
-        uint64_t capacity = nRecords * (96 + 2 * std::max(params.read_length[0], params.read_length[1])), nBytes = 0;
-        DeviceMemory bam(ctx, capacity);
-        int rc = isaac_gpu_bam_records(ctx, bamTiles.data(), uint32_t(bamTiles.size()), &bamOptions, bam.as<uint8_t>(), capacity, &nBytes, &nRecordsWritten, &unalignedOffset);
-        if (ISAAC_GPU_ECAPACITY == rc)
-        {
-            capacity = nBytes; bam.reset(ctx, capacity);
-            rc = isaac_gpu_bam_records(ctx, bamTiles.data(), uint32_t(bamTiles.size()), &bamOptions, bam.as<uint8_t>(), capacity, &nBytes, &nRecordsWritten, &unalignedOffset);
-        }
-        check(rc, "isaac_gpu_bam_records");
-        stream.resize(nBytes);
-        if (nBytes) GPU(isaac_gpu_download(ctx, stream.data(), bam.as<uint8_t>(), nBytes));
-        std::cerr << "isaac-align: " << nRecordsWritten << " records, " << nBytes << " bytes" << std::endl;
-    }
-
-    Stage stage("writing sorted.bam");
+    // ---- build::Build: one bin at a time -- records, duplicates, realignment, BAM records, BGZF blocks on the device -- the file and its index
+    // in bin order
+    const double buildStart = seconds();
+    Stage stage("building and writing sorted.bam");
     // header (Bam.hh:153-235): --bam-header-tag lines, the read groups in the order of a map keyed by their ids, the contigs in karyotype order
     std::vector<std::string> headerLines = o.bamHeaderTags;
     {
@@ -400,7 +492,7 @@ int run(const AlignOptions &o)
     std::vector<uint8_t> header(headerBytes);
     if (isaac_gpu_bam_header(commandLine.c_str(), o.description.c_str(), VERSION, linePointers.data(), uint32_t(linePointers.size()), names.data(), lengths.data(), as.data(), ur.data(), m5.data(),
                              nContigs, header.data(), header.size(), &headerBytes)) throw std::runtime_error(std::string("isaac_gpu_bam_header: ") + isaac_gpu_bam_last_error());
-    const auto compress = [&o](const uint8_t *data, uint64_t n, int eofBlock)
+    const auto compressOnHost = [&o](const uint8_t *data, uint64_t n, int eofBlock)
     {
         std::vector<uint8_t> out(isaac_gpu_bgzf_bound(n) + 64);
         uint64_t nOut = 0;
@@ -408,46 +500,136 @@ int run(const AlignOptions &o)
         out.resize(nOut);
         return out;
     };
-    const std::vector<uint8_t> headerBgzf = compress(header.data(), header.size(), 0);
-    // the bins: every contig's records, and the unaligned ones
-    std::vector<Part> parts;
-    for (uint64_t at = 0; at < unalignedOffset; )
+    const std::vector<uint8_t> headerBgzf = compressOnHost(header.data(), header.size(), 0);
+    const std::vector<uint8_t> eofBlock = compressOnHost(0, 0, 1);
+
+    // the bins in file order: the contigs, the unaligned templates behind them or (--keep-unaligned front) ahead of them
+    std::vector<uint32_t> fileOrder;
+    if ("front" == o.keepUnaligned) fileOrder.push_back(nContigs);
+    for (uint32_t c = 0; c < nContigs; ++c) fileOrder.push_back(c);
+    if ("front" != o.keepUnaligned) fileOrder.push_back(nContigs);
+    std::vector<BinOutput> outputs(fileOrder.size());
+    std::mutex outputLock; std::condition_variable outputReady;
+    std::atomic<size_t> nextBin(0);
+    isaac_bam_options bamOptions; std::memset(&bamOptions, 0, sizeof(bamOptions));
+    bamOptions.forced_dodgy_alignment_score = o.forcedDodgyAlignmentScore(); bamOptions.pessimistic_mapq = o.pessimisticMapQ; bamOptions.read_group = "0"; bamOptions.barcode = "none";
+    bamOptions.mark_duplicates = o.markDuplicates; bamOptions.keep_duplicates = o.keepDuplicates; bamOptions.realign_gaps = "no" != o.realignGaps; bamOptions.realign_dodgy = o.realignDodgy;
+    bamOptions.bin_filter = 1;
+    const uint32_t maxReadLength = std::max(params.read_length[0], params.read_length[1]);
+    auto buildBins = [&](Worker &w)
     {
-        const auto le32 = [](const uint8_t *p) { return uint32_t(p[0]) | uint32_t(p[1]) << 8 | uint32_t(p[2]) << 16 | uint32_t(p[3]) << 24; };
-        const uint32_t contig = le32(stream.data() + at + 4);
-        const uint64_t begin = at;
-        while (at < unalignedOffset && le32(stream.data() + at + 4) == contig) at += uint64_t(le32(stream.data() + at)) + 4;
-        parts.push_back(Part{ begin, at - begin, {} });
-    }
-    const size_t alignedParts = parts.size();
-    if (unalignedOffset < stream.size()) parts.push_back(Part{ unalignedOffset, stream.size() - unalignedOffset, {} });
-    if ("front" == o.keepUnaligned && parts.size() > alignedParts) std::rotate(parts.begin(), parts.begin() + std::ptrdiff_t(alignedParts), parts.end());    // --keep-unaligned front
-    for (Part &p : parts) p.bgzf = compress(stream.data() + p.offset, p.bytes, 0);
-    const std::vector<uint8_t> eofBlock = compress(0, 0, 1);
+        const double start = seconds();
+        DeviceMemory data, bam, bgzf;
+        for (size_t k = nextBin++; k < fileOrder.size(); k = nextBin++)
+        {
+            BinOutput result;
+            try
+            {
+                Bin &bin = bins[fileOrder[k]];
+                if (!bin.parts.empty())
+                {
+                    // the bin's parts to the device, each the three arrays of a tile
+                    if (data.bytes() < bin.bytes) data.reset(w.ctx, bin.bytes);
+                    std::vector<isaac_bam_tile> bamTiles(bin.parts.size());
+                    uint64_t at = 0;
+                    for (size_t i = 0; i < bin.parts.size(); ++i)
+                    {
+                        BinPart &part = bin.parts[i];
+                        GPU(isaac_gpu_upload(w.ctx, data.as<uint8_t>() + at, part.data.get(), part.bytes));
+                        part.data.reset();
+                        isaac_bam_tile &b = bamTiles[i];
+                        b.bcl_dev = data.as<uint8_t>() + at;
+                        b.fragments_dev = reinterpret_cast<const isaac_fragment *>(data.as<uint8_t>() + at + align64(part.clusters * clusterLength));
+                        b.cigar_dev = reinterpret_cast<const uint32_t *>(data.as<uint8_t>() + at + align64(align64(part.clusters * clusterLength) + part.clusters * nReads * sizeof(isaac_fragment)));
+                        b.n_records = part.clusters * nReads;
+                        b.read_name_prefix = part.tile->namePrefix.c_str(); b.read_group = part.tile->readGroup.c_str(); b.tls = &part.tile->tls;
+                        at += part.bytes;
+                    }
+                    isaac_bam_options options = bamOptions;
+                    if (fileOrder[k] == nContigs) { options.bin_first_contig = 0; options.bin_end_contig = 0; options.bin_unaligned = 1; }
+                    else { options.bin_first_contig = fileOrder[k]; options.bin_end_contig = fileOrder[k] + 1; options.bin_unaligned = 0; }
+                    uint64_t capacity = bin.records * (96 + 2 * uint64_t(maxReadLength)), nBytes = 0, unalignedOffset = 0;
+                    if (bam.bytes() < capacity) bam.reset(w.ctx, capacity);
+                    int rc = isaac_gpu_bam_records(w.ctx, bamTiles.data(), uint32_t(bamTiles.size()), &options, bam.as<uint8_t>(), bam.bytes(), &nBytes, &result.nRecords, &unalignedOffset);
+                    if (ISAAC_GPU_ECAPACITY == rc)
+                    {
+                        bam.reset(w.ctx, nBytes);
+                        rc = isaac_gpu_bam_records(w.ctx, bamTiles.data(), uint32_t(bamTiles.size()), &options, bam.as<uint8_t>(), bam.bytes(), &nBytes, &result.nRecords, &unalignedOffset);
+                    }
+                    check(rc, "isaac_gpu_bam_records");
+                    if (nBytes)
+                    {
+                        // BGZF on the device: stored blocks at level 0 (bgzf::BgzfCompressor's own), deflated ones otherwise
+                        const uint64_t bound = o.bamGzipLevel ? isaac_gpu_bgzf_deflate_bound(nBytes) : isaac_gpu_bgzf_store_bound(nBytes);
+                        if (bgzf.bytes() < bound) bgzf.reset(w.ctx, bound);
+                        uint64_t nOut = 0;
+                        if (o.bamGzipLevel) GPU(isaac_gpu_bgzf_deflate(w.ctx, bam.as<uint8_t>(), nBytes, 0, bgzf.as<uint8_t>(), bgzf.bytes(), &nOut));
+                        else GPU(isaac_gpu_bgzf_store(w.ctx, bam.as<uint8_t>(), nBytes, 0, bgzf.as<uint8_t>(), bgzf.bytes(), &nOut));
+                        result.bgzf.resize(nOut); result.records.resize(nBytes);
+                        GPU(isaac_gpu_download(w.ctx, result.bgzf.data(), bgzf.as<uint8_t>(), nOut));
+                        GPU(isaac_gpu_download(w.ctx, result.records.data(), bam.as<uint8_t>(), nBytes));      // for the index (BamIndexPart reads the records)
+                    }
+                    std::vector<BinPart>().swap(bin.parts);
+                }
+            }
+            catch (const std::exception &e) { result.error = e.what(); }
+            result.ready = true;
+            { std::lock_guard<std::mutex> guard(outputLock); outputs[k] = std::move(result); }
+            outputReady.notify_all();
+        }
+        w.buildSeconds = seconds() - start;
+    };
+    std::vector<std::thread> builders;
+    for (auto &w : workers) builders.emplace_back(buildBins, std::ref(*w));
 
     const std::string directory = o.outputDirectory + "/Projects/default/default";
     makeDirectories(directory);
     const std::string bamPath = directory + "/sorted.bam";
+    uint64_t nRecordsWritten = 0, binsWritten = 0;
+    std::string failure;
     {
         std::ofstream os(bamPath.c_str(), std::ios::binary | std::ios::trunc);
-        if (!os) throw std::runtime_error("Failed to open output BAM file " + bamPath);
+        if (!os) failure = "Failed to open output BAM file " + bamPath;
         os.write(reinterpret_cast<const char *>(headerBgzf.data()), std::streamsize(headerBgzf.size()));
-        for (const Part &p : parts) os.write(reinterpret_cast<const char *>(p.bgzf.data()), std::streamsize(p.bgzf.size()));
+        isaac_bam_indexer *indexer = isaac_gpu_bam_indexer_create(nContigs, headerBgzf.size());
+        for (size_t k = 0; k < outputs.size(); ++k)
+        {
+            BinOutput out;
+            {
+                std::unique_lock<std::mutex> guard(outputLock);
+                outputReady.wait(guard, [&] { return outputs[k].ready; });
+                out = std::move(outputs[k]);
+            }
+            if (!out.error.empty() && failure.empty()) failure = out.error;
+            if (!failure.empty() || out.bgzf.empty()) continue;
+            os.write(reinterpret_cast<const char *>(out.bgzf.data()), std::streamsize(out.bgzf.size()));
+            if (isaac_gpu_bam_indexer_add(indexer, out.records.data(), out.records.size(), out.bgzf.data(), out.bgzf.size())) failure = std::string("isaac_gpu_bam_indexer_add: ") + isaac_gpu_bam_index_last_error();
+            nRecordsWritten += out.nRecords; ++binsWritten;
+        }
+        for (std::thread &t : builders) t.join();
         os.write(reinterpret_cast<const char *>(eofBlock.data()), std::streamsize(eofBlock.size()));
-        if (!os) throw std::runtime_error("Failed to write " + bamPath);
+        if (failure.empty() && !os) failure = "Failed to write " + bamPath;
+        if (failure.empty())
+        {
+            uint64_t baiBytes = 0;
+            isaac_gpu_bam_indexer_finish(indexer, 0, 0, &baiBytes);
+            std::vector<uint8_t> bai(baiBytes);
+            if (isaac_gpu_bam_indexer_finish(indexer, bai.data(), bai.size(), &baiBytes)) failure = std::string("isaac_gpu_bam_indexer_finish: ") + isaac_gpu_bam_index_last_error();
+            else
+            {
+                std::ofstream index((bamPath + ".bai").c_str(), std::ios::binary | std::ios::trunc);
+                if (!index || !index.write(reinterpret_cast<const char *>(bai.data()), std::streamsize(bai.size()))) failure = "Error opening bam index file for writing " + bamPath + ".bai";
+            }
+        }
+        isaac_gpu_bam_indexer_destroy(indexer);
     }
-    std::vector<isaac_bam_index_part> indexParts;
-    for (const Part &p : parts) indexParts.push_back(isaac_bam_index_part{ p.offset, p.bytes, p.bgzf.data(), p.bgzf.size() });
-    uint64_t baiBytes = 0;
-    isaac_gpu_bam_index(stream.data(), indexParts.data(), uint32_t(indexParts.size()), nContigs, headerBgzf.size(), 0, 0, &baiBytes);
-    std::vector<uint8_t> bai(baiBytes);
-    if (isaac_gpu_bam_index(stream.data(), indexParts.data(), uint32_t(indexParts.size()), nContigs, headerBgzf.size(), bai.data(), bai.size(), &baiBytes))
-        throw std::runtime_error(std::string("isaac_gpu_bam_index: ") + isaac_gpu_bam_index_last_error());
-    {
-        std::ofstream os((bamPath + ".bai").c_str(), std::ios::binary | std::ios::trunc);
-        if (!os || !os.write(reinterpret_cast<const char *>(bai.data()), std::streamsize(bai.size()))) throw std::runtime_error("Error opening bam index file for writing " + bamPath + ".bai");
-    }
-    std::cerr << "isaac-align: " << bamPath << ": " << nRecordsWritten << " records in " << parts.size() << " bin(s)" << std::endl;
+    if (!failure.empty()) throw std::runtime_error(failure);
+    const double buildSeconds = seconds() - buildStart, total = seconds() - runStart;
+    std::cerr << "isaac-align: " << bamPath << ": " << nRecordsWritten << " records in " << binsWritten << " bin(s)" << std::endl;
+    // one line for scripts (bench.py): what the run took, stage by stage
+    std::cerr << "isaac-align: timing {\"clusters\": " << totalClusters << ", \"reads\": " << totalClusters * nReads << ", \"records\": " << nRecordsWritten << ", \"workers\": " << workers.size()
+              << ", \"reference_s\": " << referenceSeconds << ", \"load_and_find_s\": " << loadSeconds << ", \"select_and_bin_s\": " << selectSeconds << ", \"build_and_write_s\": " << buildSeconds
+              << ", \"total_s\": " << total << "}" << std::endl;
     return 0;
 }
 

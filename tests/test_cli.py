@@ -258,6 +258,8 @@ SCENARIOS = {
                     cli=["--use-bases-mask", "y75n*,y80n*", "--keep-unaligned", "front", "--mark-duplicates", "0", "--realign-gaps", "no", "--bam-gzip-level", "0",
                          "--dodgy-alignment-score", "Unknown", "--bam-pu-format", "%F.%L"],
                     paired=True, mark=False, keep=True, realign=False, unaligned="front", dodgy=255, pu="%s.%d"),
+    # two workers (contexts, threads) on the one device: loads, tiles and bins dealt between them, one file all the same
+    "two-workers": dict(compressed=False, lengths=(100, 100), cli=["--devices", "0,0"], paired=True, mark=True, keep=True, realign=True, unaligned="back", dodgy=0, pu="%s:%d:none"),
     # single-ended lanes, unaligned reads left out
     # ... on a reference made by bin/isaac-sort-reference from the FASTA file
     "single-ended": dict(compressed=True, lengths=(100,), cli=["--keep-unaligned", "discard"], paired=False, mark=True, keep=True, realign=True, unaligned="discard", dodgy=0, pu="%s:%d:none",
