@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--no-bam-pass", action="store_true")
     ap.add_argument("--no-neighbors", action="store_true")
     ap.add_argument("--broadcast-index", action="store_true", help="with several GPUs: rank 0 builds the table, the others receive it over RCCL (default: every rank builds its own, in parallel)")
+    ap.add_argument("--no-cli-pass", action="store_true", help="skip the isaac-align end-to-end leg (config.cli_end_to_end)")
+    ap.add_argument("--cli-pairs", type=int, default=10_000_000, help="pairs the isaac-align leg aligns (the run's own batches, written as FASTQ)")
     ap.add_argument("--contexts", type=int, default=3, help="contexts (streams) per GPU that take the steps' selections in turn; they share the contigs and the table")
     ap.add_argument("--no-single-stream-pass", action="store_true", help="skip the extra pass of the same steps on one context (per-kernel times without sharing)")
     ap.add_argument("--launch-check", action="store_true", help="GPU-less check of the launcher and the collectives (gloo): no alignment")
@@ -119,6 +121,74 @@ def launch_check(args, rank, world):
                                             for st, (recs, cigs) in enumerate(steps))
         emit({"launch_check": bool(ok), "n_gpus": world, "gpus_requested": args.gpus})
     dist.destroy_process_group()
+
+
+def cli_end_to_end(args, al, genome, batches, L, emit_note):
+    """The drop-in itself, end to end: bin/isaac-align (C++ on the C ABI) on the run's own reference and reads as files -- the synthetic genome as FASTA, the
+    resident table as the 64 mask files + sorted-reference.xml of isaac-sort-reference (isaac_gpu_save_sorted_reference), the batches as two FASTQ files --
+    with the reference's defaults (duplicates marked, gaps realigned, --bam-gzip-level 1).  Files in /dev/shm when there is one (47 GB of mask files).
+    Returns the dict for config.cli_end_to_end: reads per second over the program's wall time and its own stage timers."""
+    import json
+    import shutil
+    import subprocess
+    import tempfile
+    import numpy as np
+    import torch
+    from isaac_aligner_amd import build, sorted_reference as sr, synth
+    t_all = time.perf_counter()
+    work = tempfile.mkdtemp(prefix="isaac_bench_cli_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        ref_dir, calls = os.path.join(work, "ref"), os.path.join(work, "calls")
+        os.makedirs(ref_dir); os.makedirs(calls)
+        fasta = os.path.join(ref_dir, "genome.fa")
+        contigs, position = [], 0
+        t0 = time.perf_counter()
+        for i, (offset, size, bases, acgt) in enumerate(synth.write_fasta(fasta, genome.contigs)):
+            m = sr.Contig()
+            m.genomic_position, m.index, m.karyotype_index, m.name, m.file = position, i, i, b"chr%d" % (i + 1), fasta.encode()
+            m.offset, m.size, m.total_bases, m.acgt_bases = offset, size, bases, acgt
+            position += bases
+            contigs.append(m)
+        t_fasta = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        al.save_sorted_reference(ref_dir, "genome.fa", contigs)
+        t_save = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        n_pairs, files = 0, [open(os.path.join(calls, "lane1_read%d.fastq" % (r + 1)), "wb") for r in range(2)]
+        for batch in batches:
+            if n_pairs >= args.cli_pairs:
+                break
+            bcl = batch[:args.cli_pairs - n_pairs].cpu().numpy()
+            synth.write_fastq(files, bcl, L, name_prefix=b"M1:7:FCBENCH:1:1101:", first_index=n_pairs)
+            n_pairs += len(bcl)
+        for f in files:
+            f.close()
+        t_fastq = time.perf_counter() - t0
+        tool = build.build_host()
+        cmd = [tool, "-r", os.path.join(ref_dir, "sorted-reference.xml"), "-b", calls, "--base-calls-format", "fastq", "-o", os.path.join(work, "Aligned"), "--use-bases-mask", "y*,y*",
+               "--clusters-at-a-time", "2000000"]
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        wall = time.perf_counter() - t0
+        if r.returncode:
+            return {"error": (r.stderr or r.stdout)[-600:]}
+        timing = json.loads([l for l in r.stderr.splitlines() if "timing {" in l][-1].split("timing ", 1)[1])
+        bam = os.path.join(work, "Aligned", "Projects", "default", "default", "sorted.bam")
+        out = {"reads_per_s": round(timing["reads"] / wall, 1), "reads_per_s_without_reference_load": round(timing["reads"] / max(1e-9, timing["total_s"] - timing["reference_s"]), 1),
+               "pairs": n_pairs, "wall_s": round(wall, 2), "stages_s": {k: round(v, 3) for k, v in timing.items() if k.endswith("_s")}, "records": timing["records"], "workers": timing["workers"],
+               "sorted_bam_bytes": os.path.getsize(bam), "bai_bytes": os.path.getsize(bam + ".bai"),
+               "command": "isaac-align -r sorted-reference.xml -b <2 FASTQ files> --base-calls-format fastq --use-bases-mask y*,y* --clusters-at-a-time 2000000 (defaults: --mark-duplicates 1, --realign-gaps sample, --bam-gzip-level 1)",
+               "preparation_s": {"fasta": round(t_fasta, 1), "save_sorted_reference": round(t_save, 1), "fastq": round(t_fastq, 1)},
+               "note": "the program's own wall time from start to finished sorted.bam + .bai, files in %s; reference_s is reading the FASTA and the 64 mask files (%.0f GB) back in" % (os.path.dirname(work), al_table_gb(al))}
+        out["leg_s"] = round(time.perf_counter() - t_all, 1)
+        return out
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def al_table_gb(al):
+    k, _ = al.index_tensors()
+    return 16.0 * k.numel() / 1e9
 
 
 def main():
@@ -470,6 +540,14 @@ def main():
                          "bgzf_ratio": round(len(z) / sample_bytes, 3)})
         del bam_buf, stream_bytes, host_sample, z
 
+    # ---- isaac-align itself, end to end (config.cli_end_to_end)
+    cli_info = None
+    if not args.no_cli_pass and dist is None and rank == 0:
+        try:
+            cli_info = cli_end_to_end(args, al, genome, batches[args.warmup:], L, None)
+        except Exception as e:      # the leg must not cost the run its line
+            cli_info = {"error": repr(e)[:400]}
+
     # ---- roofline of the dominant kernel: algorithmic bytes (stated per kernel in DESIGN.md) / event-timed duration
     c = counters
     seeded_scans = max(0, c["ungapped_scans"] - c["rescue_candidates"])
@@ -562,9 +640,19 @@ def main():
         ref.set_index(al.get_index())
         p = orc.default_params(2, L, L)
         find_threads = min(cores, 64)      # as MatchFinder: one mask of the table per thread at a time (64 masks)
+        # the lookup both ways: entry by entry through the table between two seed k-mers -- the reference's merge join, made for its
+        # batches of millions of clusters, which streams all of the table for this sample -- and by bisection of what is left of it; same matches
+        orc.lib.oracle_set_lookup_mode(1)
+        tc = time.perf_counter()
+        om_bisect, _ = ref.find_matches(p, host_bcl, sample, tile=tile_of(0), n_threads=find_threads)
+        t_find_bisect = time.perf_counter() - tc
+        orc.lib.oracle_set_lookup_mode(0)
         tc = time.perf_counter()
         om, ohits = ref.find_matches(p, host_bcl, sample, tile=tile_of(0), n_threads=find_threads)
-        t_find = time.perf_counter() - tc
+        t_find_merge = time.perf_counter() - tc
+        assert om_bisect.tobytes() == om.tobytes()
+        del om_bisect
+        t_find = min(t_find_merge, t_find_bisect)
         otls = oracle_lib.Tls()
         for name in ("min", "max", "median", "low_std_dev", "high_std_dev", "stable", "mate_min", "mate_max"):
             setattr(otls, name, getattr(tls, name))
@@ -573,8 +661,11 @@ def main():
         orec, ocig, _ = ref.select(p, host_bcl, om, otls, all_hits, tile=tile_of(0), n_threads=cores, n_clusters_hint=sample)
         t_select = time.perf_counter() - tc
         cpu = {"value": round(2.0 * sample / (t_find + t_select), 1), "unit": "reads/s", "cores": cores, "kind": "port",
-               "sample": "the first %d pairs of the first timed batch; oracle/ (CPU restatement of the reference path): merge-join seed lookup against the %d-entry table on %d "
-                         "threads (%.2f s) + match selection on %d threads (%.2f s)" % (sample, n_index, find_threads, t_find, cores, t_select)}
+               "sample": "the first %d pairs of the first timed batch; oracle/ (CPU restatement of the reference path, g++ -O3 -mavx2 -ffp-contract=off): seed lookup against the %d-entry "
+                         "table on %d threads (merge join %.2f s, bisection %.2f s: the faster one counts) + match selection on %d threads (%.2f s; its banded Smith-Waterman is "
+                         "scalar where the reference's is 16-lane SSE2)" % (sample, n_index, find_threads, t_find_merge, t_find_bisect, cores, t_select),
+               "lookup_merge_join_s": round(t_find_merge, 3), "lookup_bisection_s": round(t_find_bisect, 3), "selection_s": round(t_select, 3),
+               "value_with_merge_join": round(2.0 * sample / (t_find_merge + t_select), 1), "value_with_bisection": round(2.0 * sample / (t_find_bisect + t_select), 1)}
         # the GPU records of the same pairs (first timed step) against the oracle's, field for field + CIGARs
         grec = checked_records[:2 * sample].cpu().numpy().view(abi.FRAGMENT_DTYPE).reshape(-1)
         gcig = checked_cigars.cpu().numpy().view(np.uint32)
@@ -617,7 +708,7 @@ def main():
               "scaling": args.scaling, "vs_baseline": None, "dtype": "u8/int16 (+f64 log-probabilities)", "data": "synthetic",
               "config": {"workload": workload, "pairs_per_step": args.pairs_per_step, "read_length": L, "genome_bases": args.genome_bases, "index_entries": int(n_index),
                          "parallelism": "read shards x%d, %d context(s) per GPU taking the steps' selections in turn (one stream each, contigs and table shared), every step's records and packed CIGARs gathered to rank 0 behind the later steps" % (world, n_contexts), "hbm_used_gb": hbm_used_gb, "setup_s": round(t_setup, 1),
-                         "genome_s": round(t_genome, 1), "index_build_s": round(t_index, 1), "tls": list(tls.astuple()), "pcie_inclusive": pcie, "bam_output": bam_info},
+                         "genome_s": round(t_genome, 1), "index_build_s": round(t_index, 1), "tls": list(tls.astuple()), "pcie_inclusive": pcie, "bam_output": bam_info, "cli_end_to_end": cli_info},
               "roofline": roofline, "cpu_baseline": cpu, "counters": {k: int(v) for k, v in counters.items()}}
     result.update(parity)
     import hashlib

@@ -180,6 +180,10 @@ int isaac_gpu_get_mask_offsets(isaac_gpu_ctx *ctx, uint64_t *offsets_out, uint32
 int isaac_gpu_index_dev(isaac_gpu_ctx *ctx, const uint64_t **kmers_dev_out, const uint64_t **positions_dev_out, uint64_t *n_entries_out);
 int isaac_gpu_set_index_dev(isaac_gpu_ctx *ctx, const uint64_t *kmers_dev, const uint64_t *positions_dev, uint64_t n_entries,
                             const uint64_t *mask_offsets, uint32_t n_masks);
+/* The same for two contexts of one process, whole: `ctx` takes `owner`'s table as it is -- entries, mask cuts, karyotype translation -- in place
+ * when both are on one device (nothing is copied; `owner` must outlive `ctx` and keep its table), as a copy over the link between the two devices
+ * when they are not.  Both must have loaded the same contigs.  What a host does for the second and further workers of a run (--devices). */
+int isaac_gpu_share_index(isaac_gpu_ctx *ctx, isaac_gpu_ctx *owner);
 
 /* sorted-reference.xml: reference::SortedReferenceMetadata::Contig / ::MaskFile (include/reference/SortedReferenceMetadata.hh:44-98) as
  * plain records.  strings are NUL-terminated. */
@@ -344,7 +348,12 @@ typedef struct
      * after realignment).  The tiles of such a call are what isaac_gpu_bin_tile made for the bin.  Bins of whole contigs written in contig
      * order, the unaligned one last, give the very bytes of one call over all tiles. */
     uint32_t bin_filter, bin_first_contig, bin_end_contig, bin_unaligned;
+    /* NULL, or room for one entry per record of the call's tiles: the call leaves there, in file order, what the BAM index wants to know about
+     * every record it writes (isaac_gpu_bam_indexer_add_entries), so that a host need not fetch and parse the record stream itself. */
+    struct isaac_bam_index_entry *index_entries_dev;
 } isaac_bam_options;
+/* offset and length of the record in the call's stream, refID, pos, FLAG and l_seq as written, the reference bases its CIGAR covers */
+typedef struct isaac_bam_index_entry { uint64_t offset; uint32_t bytes; int32_t ref_id; int32_t pos; uint32_t flag, seq_length, observed; } isaac_bam_index_entry;
 int isaac_gpu_bam_records(isaac_gpu_ctx *ctx, const isaac_bam_tile *tiles, uint32_t n_tiles, const isaac_bam_options *options /* NULL = defaults */,
                           uint8_t *bam_dev, uint64_t capacity, uint64_t *n_bytes_out, uint64_t *n_records_out, uint64_t *unaligned_offset_out);
 
@@ -396,6 +405,7 @@ int isaac_gpu_bam_index(const uint8_t *records_host, const isaac_bam_index_part 
 typedef struct isaac_bam_indexer isaac_bam_indexer;
 isaac_bam_indexer *isaac_gpu_bam_indexer_create(uint32_t n_contigs, uint64_t header_bgzf_bytes);
 int isaac_gpu_bam_indexer_add(isaac_bam_indexer *indexer, const uint8_t *records_host, uint64_t records_bytes, const uint8_t *bgzf_host, uint64_t bgzf_bytes);
+int isaac_gpu_bam_indexer_add_entries(isaac_bam_indexer *indexer, const isaac_bam_index_entry *entries_host, uint64_t n_entries, uint64_t records_bytes, const uint8_t *bgzf_host, uint64_t bgzf_bytes);
 int isaac_gpu_bam_indexer_finish(isaac_bam_indexer *indexer, uint8_t *bai_out, uint64_t capacity, uint64_t *n_bytes_out);
 void isaac_gpu_bam_indexer_destroy(isaac_bam_indexer *indexer);
 

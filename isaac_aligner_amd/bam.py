@@ -14,7 +14,7 @@ class BamTile(C.Structure):
 class BamOptions(C.Structure):
     _fields_ = [("forced_dodgy_alignment_score", C.c_uint32), ("pessimistic_mapq", C.c_uint32), ("read_group", C.c_char_p), ("barcode", C.c_char_p),
                 ("mark_duplicates", C.c_uint32), ("keep_duplicates", C.c_uint32), ("realign_gaps", C.c_uint32), ("realign_vigorously", C.c_uint32), ("realign_dodgy", C.c_uint32),
-                ("tls", C.c_void_p), ("bin_filter", C.c_uint32), ("bin_first_contig", C.c_uint32), ("bin_end_contig", C.c_uint32), ("bin_unaligned", C.c_uint32)]
+                ("tls", C.c_void_p), ("bin_filter", C.c_uint32), ("bin_first_contig", C.c_uint32), ("bin_end_contig", C.c_uint32), ("bin_unaligned", C.c_uint32), ("index_entries_dev", C.c_void_p)]
 
 
 class BinSize(C.Structure):

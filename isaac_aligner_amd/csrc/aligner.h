@@ -207,7 +207,7 @@ ISAAC_HD u32 updateFragmentCigar(const DevParams &P, const DevReference &R, cons
                 {
                     const u32 q = u32(blk.quality >> (8 * k)) & 0xffu;
                     const bool match = (blk.matchFlags >> (8 * k + 7)) & 1;
-                    lp += match ? R.logMatch[q] : R.logMismatch[q];
+                    lp += match ? R.logMatch[q * R.logStride] : R.logMismatch[q * R.logStride];
                     matchesInARow = match ? matchesInARow + 1 : 0;
                     best = imax(best, matchesInARow);
                 }
@@ -223,11 +223,11 @@ ISAAC_HD u32 updateFragmentCigar(const DevParams &P, const DevReference &R, cons
                 const char s = strandBaseOf(b, reverse);
                 const u32 q = qualityOf(b);
                 const char r = fs.next();
-                if (isMatch(s, r)) { ++matchCount; ++matchesInARow; lp += R.logMatch[q]; }
+                if (isMatch(s, r)) { ++matchCount; ++matchesInARow; lp += R.logMatch[q * R.logStride]; }
                 else
                 {
                     best = imax(best, matchesInARow); matchesInARow = 0;
-                    ++mismatchCount; lp += R.logMismatch[q]; sws += P.normalizedMismatchScore;
+                    ++mismatchCount; lp += R.logMismatch[q * R.logStride]; sws += P.normalizedMismatchScore;
                 }
                 if (s != r) ++editDistance;
             }
@@ -246,7 +246,7 @@ ISAAC_HD u32 updateFragmentCigar(const DevParams &P, const DevReference &R, cons
         }
         else // OP_SOFT_CLIP
         {
-            for (u32 j = 0; j < length; ++j) lp += R.logMatch[qualityOf(rs.next())];
+            for (u32 j = 0; j < length; ++j) lp += R.logMatch[qualityOf(rs.next()) * R.logStride];
         }
     }
     f.logProbability = lp; f.mismatchCount = u16(mismatchCount); f.matchesInARow = u16(best); f.editDistance = u16(editDistance);

@@ -103,47 +103,48 @@ struct Indexer
     std::vector<uint8_t> out; ContigIndex contig; uint32_t nContigs = 0, written = 0; uint64_t noCoordinates = 0, fileOffset = 0; uint32_t parts = 0;
 };
 
-// one part: BamIndexPart::processFragment over its records, BamIndex::processIndexPart with its blocks
-int addPart(Indexer &x, const uint8_t *r, uint64_t recordsBytes, const uint8_t *bgzf, uint64_t bgzfBytes)
+// what BamIndexPart::processFragment reads of a record
+struct RecordFacts { uint64_t at, length; int32_t refId, pos; uint32_t flag, seqLength, observed; };
+
+// one part: BamIndexPart::processFragment over its records (next(facts) hands them over in file order; false at the end, a negative return of
+// error() afterwards means a malformed part), BamIndex::processIndexPart with its blocks
+template <typename NextF>
+int addPartFrom(Indexer &x, uint64_t recordsBytes, const uint8_t *bgzf, uint64_t bgzfBytes, NextF next)
 {
     const uint32_t p = x.parts++;
     if (!bgzfBytes) return 0;
-    if (!bgzf || (recordsBytes && !r)) return indexFail(ISAAC_GPU_EINVAL, "a part without its bytes");
+    if (!bgzf) return indexFail(ISAAC_GPU_EINVAL, "a part without its bytes");
     BlockTable blocks;
     if (!blocks.build(bgzf, bgzfBytes)) return indexFail(ISAAC_GPU_EFORMAT, "part " + std::to_string(p) + ": not a run of BGZF blocks");
     if (blocks.uncompressed.back() != recordsBytes) return indexFail(ISAAC_GPU_EFORMAT, "part " + std::to_string(p) + ": the BGZF blocks do not hold records_bytes bytes");
     std::vector<Chunk> chunks;
     std::vector<uint64_t> linear;
     uint64_t mapped = 0, unmapped = 0;
-    for (uint64_t at = 0; at < recordsBytes; )
+    RecordFacts f;
+    int rc = 0;
+    while (next(f, rc))
     {
-        if (at + 36 > recordsBytes) return indexFail(ISAAC_GPU_EFORMAT, "part " + std::to_string(p) + ": truncated record");
-        const uint8_t *b = r + at;
-        const uint64_t length = uint64_t(le32(b)) + 4;
-        if (at + length > recordsBytes) return indexFail(ISAAC_GPU_EFORMAT, "part " + std::to_string(p) + ": truncated record");
-        const int32_t refId = int32_t(le32(b + 4)), pos = int32_t(le32(b + 8));
-        const uint32_t nameLength = b[12], flagNc = le32(b + 16), nCigar = flagNc & 0xffff, flag = flagNc >> 16, seqLength = le32(b + 20);
+        const int32_t refId = f.refId, pos = f.pos;
+        const uint64_t at = f.at;
         if (pos >= 0)
         {
             if (refId < 0 || uint32_t(refId) >= x.nContigs) return indexFail(ISAAC_GPU_EFORMAT, "record with a position on contig " + std::to_string(refId));
             if (uint32_t(pos) >= 512u * 1024 * 1024) return indexFail(ISAAC_GPU_EINVAL, "alignment position greater than the maximum allowed by BAM index: " + std::to_string(pos));
-            uint32_t observed = 0;                                              // the reference bases the alignment covers
-            for (uint32_t k = 0; k < nCigar; ++k) { const uint32_t w = le32(b + 36 + nameLength + 4 * k), op = w & 15; if (0 == op || 2 == op || 3 == op || 7 == op || 8 == op) observed += w >> 4; }
-            const uint32_t bin = reg2bin(uint32_t(pos), uint32_t(pos) + seqLength);    // "samtools is doing it this way"
-            const uint64_t end = at + length;
+            const uint32_t bin = reg2bin(uint32_t(pos), uint32_t(pos) + f.seqLength);    // "samtools is doing it this way"
+            const uint64_t end = at + f.length;
             // addToBinIndexChunks: the chunk grows while the bin stays; a record of the bin before last may still reach back to it
             if (!chunks.empty() && bin == chunks.back().bin && uint32_t(refId) == chunks.back().refId) chunks.back().end = end;
             else if (chunks.size() >= 2 && bin == chunks[chunks.size() - 2].bin && uint32_t(refId) == chunks[chunks.size() - 2].refId && chunks[chunks.size() - 2].end + 32768 /* BAM_MIN_CHUNK_GAP */ > end)
                 chunks[chunks.size() - 2].end = end;
             else chunks.push_back(Chunk{ at, end, bin, uint32_t(refId) });
             // addToLinearIndex: the first record to reach a 16 kb window claims it, windows skipped on the way repeat the one before
-            const uint32_t windows[2] = { uint32_t(pos) >> 14, observed ? (uint32_t(pos) + observed - 1) >> 14 : uint32_t(pos) >> 14 };
+            const uint32_t windows[2] = { uint32_t(pos) >> 14, f.observed ? (uint32_t(pos) + f.observed - 1) >> 14 : uint32_t(pos) >> 14 };
             for (const uint32_t w : windows)
                 if (linear.size() <= w) { const uint64_t fill = linear.empty() ? UNSET : linear.back(); linear.resize(w + 1, fill); linear[w] = at; }
         }
-        ++((flag & 4) ? unmapped : mapped);
-        at += length;
+        ++((f.flag & 4) ? unmapped : mapped);
     }
+    if (rc) return indexFail(ISAAC_GPU_EFORMAT, "part " + std::to_string(p) + ": truncated record");
     if (!chunks.empty())
     {
         const uint32_t refId = chunks.front().refId;
@@ -168,6 +169,40 @@ int addPart(Indexer &x, const uint8_t *r, uint64_t recordsBytes, const uint8_t *
     else x.noCoordinates += unmapped;
     x.fileOffset += bgzfBytes;
     return 0;
+}
+// the records themselves as the source
+int addPart(Indexer &x, const uint8_t *r, uint64_t recordsBytes, const uint8_t *bgzf, uint64_t bgzfBytes)
+{
+    if (bgzfBytes && recordsBytes && !r) return indexFail(ISAAC_GPU_EINVAL, "a part without its bytes");
+    uint64_t at = 0;
+    return addPartFrom(x, recordsBytes, bgzf, bgzfBytes, [&](RecordFacts &f, int &rc)
+    {
+        if (at >= recordsBytes) return false;
+        if (at + 36 > recordsBytes) { rc = 1; return false; }
+        const uint8_t *b = r + at;
+        const uint64_t length = uint64_t(le32(b)) + 4;
+        if (at + length > recordsBytes) { rc = 1; return false; }
+        const uint32_t nameLength = b[12], flagNc = le32(b + 16), nCigar = flagNc & 0xffff;
+        f.at = at; f.length = length; f.refId = int32_t(le32(b + 4)); f.pos = int32_t(le32(b + 8)); f.flag = flagNc >> 16; f.seqLength = le32(b + 20);
+        f.observed = 0;                                                     // the reference bases the alignment covers
+        for (uint32_t k = 0; k < nCigar; ++k) { const uint32_t w = le32(b + 36 + nameLength + 4 * k), op = w & 15; if (0 == op || 2 == op || 3 == op || 7 == op || 8 == op) f.observed += w >> 4; }
+        at += length;
+        return true;
+    });
+}
+// what isaac_gpu_bam_records left about every record it wrote (isaac_bam_options::index_entries_dev) as the source
+int addPartEntries(Indexer &x, const isaac_bam_index_entry *entries, uint64_t n, uint64_t recordsBytes, const uint8_t *bgzf, uint64_t bgzfBytes)
+{
+    if (n && !entries) return indexFail(ISAAC_GPU_EINVAL, "a part without its entries");
+    uint64_t k = 0;
+    return addPartFrom(x, recordsBytes, bgzf, bgzfBytes, [&](RecordFacts &f, int &rc)
+    {
+        if (k >= n) return false;
+        const isaac_bam_index_entry &e = entries[k++];
+        if (e.offset + e.bytes > recordsBytes) { rc = 1; return false; }
+        f.at = e.offset; f.length = e.bytes; f.refId = e.ref_id; f.pos = e.pos; f.flag = e.flag; f.seqLength = e.seq_length; f.observed = e.observed;
+        return true;
+    });
 }
 // BamIndex::outputIndexFile
 int finish(Indexer &x, uint8_t *baiOut, uint64_t capacity, uint64_t *nBytesOut)
@@ -212,6 +247,11 @@ int isaac_gpu_bam_indexer_add(isaac_bam_indexer *i, const uint8_t *records, uint
 {
     if (!i) return indexFail(ISAAC_GPU_EINVAL, "indexer is required");
     return addPart(i->x, records, recordsBytes, bgzf, bgzfBytes);
+}
+int isaac_gpu_bam_indexer_add_entries(isaac_bam_indexer *i, const isaac_bam_index_entry *entries, uint64_t nEntries, uint64_t recordsBytes, const uint8_t *bgzf, uint64_t bgzfBytes)
+{
+    if (!i) return indexFail(ISAAC_GPU_EINVAL, "indexer is required");
+    return addPartEntries(i->x, entries, nEntries, recordsBytes, bgzf, bgzfBytes);
 }
 int isaac_gpu_bam_indexer_finish(isaac_bam_indexer *i, uint8_t *baiOut, uint64_t capacity, uint64_t *nBytesOut)
 {

@@ -7,6 +7,7 @@
 // two stable radix passes; record sizes are scanned in that order; every record is then written where it belongs, one thread each.
 #pragma once
 #include "cluster_ops.h"
+#include "../../include/isaac_gpu.h"
 #include "realign.h"
 
 namespace isaac
@@ -24,7 +25,8 @@ struct BamTile
 };
 struct BamOptions { u32 nReads, readLength[2], readOffset[2], clusterLength, forcedDodgyAlignmentScore, pessimisticMapQ, barcodeLength, readGroupLength; char barcode[64], readGroup[64];
                     u32 markDuplicates, keepDuplicates, realignGaps; RealignParams realign; DevTls tls;
-                    u32 binFilter, binFirstContig, binEndContig, binUnaligned; };      // isaac_bam_options::bin_*: which records the call writes
+                    u32 binFilter, binFirstContig, binEndContig, binUnaligned;        // isaac_bam_options::bin_*: which records the call writes
+                    isaac_bam_index_entry *indexEntries; };                            // isaac_bam_options::index_entries_dev
 
 static const u64 INSANELY_HIGH_NUMBER_OF_CLUSTERS_PER_TILE = 1000000000ull;   // include/build/FragmentIndex.hh:33
 static const u16 DODGY_ALIGNMENT_SCORE = 0xffff;                               // io::FragmentHeader::DODGY_ALIGNMENT_SCORE
@@ -516,6 +518,12 @@ __global__ void __launch_bounds__(256) k_bam_encode(const BamTile *tiles, u32 nT
         bool write = bamStored(r) && bamInBin(r, o) && !(dup && !o.keepDuplicates);
         if (write) { bamLayout(tiles[t], r, i - tiles[t].firstRecord, o, l, dup && o.markDuplicates, tiles[t].recordsOriginal ? tiles[t].recordsOriginal + (i - tiles[t].firstRecord) : nullptr); write = at + l.total <= capacity; }
         if (write) { layouts[threadIdx.x] = l; imageAt[threadIdx.x] = u32(at - begin); }
+        if (write && o.indexEntries)
+        {
+            isaac_bam_index_entry e;
+            e.offset = at; e.bytes = l.total; e.ref_id = i32(l.words[1]); e.pos = i32(l.words[2]); e.flag = l.words[4] >> 16; e.seq_length = l.words[5]; e.observed = (r.flags & 2) ? 0u : r.observedLength;
+            o.indexEntries[k0 + threadIdx.x] = e;
+        }
         tileOfRecord[threadIdx.x] = write ? t : ~0u;
     }
     __syncthreads();

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(BSW_BLOCK) void k_gapped_jobs(DevParams P, DevRefer
     __shared__ double qualityTables[128];
     for (u32 qi = threadIdx.x; qi < 128; qi += blockDim.x) qualityTables[qi] = qi < 64 ? Rg.logMatch[qi] : Rg.logMismatch[qi - 64];
     __syncthreads();
-    DevReference R = Rg; R.logMatch = qualityTables; R.logMismatch = qualityTables + 64;
+    DevReference R = Rg; R.logMatch = qualityTables; R.logMismatch = qualityTables + 64; R.logStride = 1;
     const u32 group = bswGroupOfThread(), k = bswLaneOfThread(), groups = blockDim.x / BSW_GROUP_LANES;
     u8 *T = lds + group * gappedGroupLdsBytes(maxReadLength);
     short *endVals = reinterpret_cast<short *>(T + bswFlagBytes(maxReadLength));
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void k_gapped_rescan(DevParams P, DevReference
     __shared__ double qualityTables[128];
     for (u32 qi = threadIdx.x; qi < 128; qi += blockDim.x) qualityTables[qi] = qi < 64 ? Rg.logMatch[qi] : Rg.logMismatch[qi - 64];
     __syncthreads();
-    DevReference R = Rg; R.logMatch = qualityTables; R.logMismatch = qualityTables + 64;
+    DevReference R = Rg; R.logMatch = qualityTables; R.logMismatch = qualityTables + 64; R.logStride = 1;
     const u32 nJobs = imin(*jobCounter, jobsCap);
     for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < nJobs; j += gridDim.x * blockDim.x)
     {

@@ -113,7 +113,7 @@ struct isaac_gpu_ctx
         DevReference r; std::memset(&r, 0, sizeof(r));
         r.bases = bases; r.totalBases = hContigOffset.empty() ? 0 : hContigOffset[nContigs]; r.contigOffset = contigOffset.p; r.contigLoaded = contigLoaded.p; r.nContigs = nContigs;
         r.kmers = tableKmers(); r.positions = tablePositions(); r.nKmers = nKmers; r.karyotype = hasKaryotype ? karyotype.p : nullptr;
-        r.logMatch = logTables.p; r.logMismatch = logTables.p + 100;
+        r.logMatch = logTables.p; r.logMismatch = logTables.p + 100; r.logStride = 1;
         r.prefixTable = prefixBits ? prefixTable.p : nullptr; r.prefixBits = prefixBits;
         r.packedBases = packedBases.p; r.notBase = notBase.p;
         return r;
@@ -982,6 +982,43 @@ int isaac_gpu_set_index_dev(isaac_gpu_ctx *c, const uint64_t *kmers, const uint6
     ISAAC_CATCH
 }
 
+// the table of another context for this one: in place when both are on one device, a copy when they are not; the karyotype translation with it
+int isaac_gpu_share_index(isaac_gpu_ctx *c, isaac_gpu_ctx *owner)
+{
+    ISAAC_TRY
+    if (!c || !owner || c == owner) return fail(ISAAC_GPU_EINVAL, "two different contexts are required");
+    if (c->nContigs != owner->nContigs) return fail(ISAAC_GPU_EINVAL, "both contexts must have loaded the same contigs");
+    HIP_CHECK(hipSetDevice(owner->device));
+    HIP_CHECK(hipStreamSynchronize(owner->stream));
+    const u64 n = owner->nKmers;
+    const u64 *kmers = owner->tableKmers(), *positions = owner->tablePositions();
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->kmers.release(); c->positions.release();
+    if (c->device != owner->device && n)
+    {
+        c->kmers.reserve(n); c->positions.reserve(n);
+        HIP_CHECK(hipMemcpy(c->kmers.p, kmers, n * 8, hipMemcpyDefault));
+        HIP_CHECK(hipMemcpy(c->positions.p, positions, n * 8, hipMemcpyDefault));
+        c->kmersBorrowed = nullptr; c->positionsBorrowed = nullptr;
+    }
+    else { c->kmersBorrowed = kmers; c->positionsBorrowed = positions; }
+    c->nKmers = n; c->maskOffsets = owner->maskOffsets;
+    c->hasKaryotype = owner->hasKaryotype;
+    if (owner->hasKaryotype)
+    {
+        std::vector<u32> k(owner->nContigs);
+        HIP_CHECK(hipSetDevice(owner->device));
+        HIP_CHECK(hipMemcpy(k.data(), owner->karyotype.p, k.size() * 4, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipSetDevice(c->device));
+        c->karyotype.reserve(k.size());
+        HIP_CHECK(hipMemcpy(c->karyotype.p, k.data(), k.size() * 4, hipMemcpyHostToDevice));
+    }
+    buildPrefixTable(c);
+    return 0;
+    ISAAC_CATCH
+}
+
 // other options / read geometry for the same reference and table (the reference constructs its MatchFinder / MatchSelector once per
 // run; a service that aligns runs of different read lengths against one resident genome does not reload 50 GB for that)
 int isaac_gpu_set_params(isaac_gpu_ctx *c, const isaac_params *params)
@@ -1485,6 +1522,7 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
     o.pessimisticMapQ = options ? options->pessimistic_mapq : 0;
     o.markDuplicates = options ? (options->mark_duplicates != 0) : 0; o.keepDuplicates = options ? (options->keep_duplicates != 0) : 1;
     o.realignGaps = options ? (options->realign_gaps != 0) : 0;
+    o.indexEntries = options ? options->index_entries_dev : nullptr;
     if (options && options->bin_filter) { o.binFilter = 1; o.binFirstContig = options->bin_first_contig; o.binEndContig = options->bin_end_contig; o.binUnaligned = options->bin_unaligned != 0; }
     if (o.realignGaps)
     {

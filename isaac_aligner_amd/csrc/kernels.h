@@ -49,7 +49,30 @@ __device__ inline void flushCounter(u64 Counters::*field, u64 v, Counters *globa
     __shared__ double qualityTables[128];                                                                                    \
     for (u32 qi = threadIdx.x; qi < 128; qi += blockDim.x) qualityTables[qi] = qi < 64 ? (R_IN).logMatch[qi] : (R_IN).logMismatch[qi - 64]; \
     __syncthreads();                                                                                                         \
-    DevReference R_OUT = (R_IN); R_OUT.logMatch = qualityTables; R_OUT.logMismatch = qualityTables + 64;
+    DevReference R_OUT = (R_IN); R_OUT.logMatch = qualityTables; R_OUT.logMismatch = qualityTables + 64; R_OUT.logStride = 1;
+
+// The same with a copy of the tables per lane of a half wavefront: entry q of copy c at [q * 32 + c].  A ds_read_b64 is served half a wavefront at
+// a time, 64 banks of four bytes: lane l reading copy l % 32 always hits banks 2 (l % 32) and 2 (l % 32) + 1, whatever its q, so the 32 lanes of a
+// half never meet (one shared table: a quarter to two fifths of the LDS cycles of the ungapped scans were conflicts, profiles/r3_zz_pmc_summary.json).
+#ifndef ISAAC_QUALITY_TABLE_COPIES
+#define ISAAC_QUALITY_TABLE_COPIES 32
+#endif
+#ifndef ISAAC_SCAN_TABLES_PER_LANE
+#define ISAAC_SCAN_TABLES_PER_LANE 1
+#endif
+#define ISAAC_STAGE_QUALITY_TABLES_PER_LANE(R_IN, R_OUT)                                                                     \
+    __shared__ double qualityTables[128 * ISAAC_QUALITY_TABLE_COPIES];                                                       \
+    for (u32 qi = threadIdx.x; qi < 128 * ISAAC_QUALITY_TABLE_COPIES; qi += blockDim.x)                                      \
+    { const u32 qe = qi / ISAAC_QUALITY_TABLE_COPIES; qualityTables[qi] = qe < 64 ? (R_IN).logMatch[qe] : (R_IN).logMismatch[qe - 64]; } \
+    __syncthreads();                                                                                                         \
+    DevReference R_OUT = (R_IN); R_OUT.logMatch = qualityTables + (threadIdx.x % ISAAC_QUALITY_TABLE_COPIES);                \
+    R_OUT.logMismatch = R_OUT.logMatch + 64 * ISAAC_QUALITY_TABLE_COPIES; R_OUT.logStride = ISAAC_QUALITY_TABLE_COPIES;
+// the ungapped scans of the fragment stage (k_align_candidates): a thread per alignment, two table reads per base
+#if ISAAC_SCAN_TABLES_PER_LANE
+#define ISAAC_STAGE_SCAN_TABLES(R_IN, R_OUT) ISAAC_STAGE_QUALITY_TABLES_PER_LANE(R_IN, R_OUT)
+#else
+#define ISAAC_STAGE_SCAN_TABLES(R_IN, R_OUT) ISAAC_STAGE_QUALITY_TABLES(R_IN, R_OUT)
+#endif
 
 // the chunk's gapped (banded Smith-Waterman) problems: written by the per-cluster threads, run by k_gapped_jobs
 struct GappedBuffers { GappedJob *jobs; GappedResult *results; u32 cap; u32 *counter; u32 *base; };

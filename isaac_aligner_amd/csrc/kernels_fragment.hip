@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64) void k_build_fragments_general(DevParams P, con
 // step 2: UngappedAligner::alignUngapped, one candidate per thread
 __global__ __launch_bounds__(256) void k_align_candidates(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, ClusterPools pools, AlignList al, Counters *counters)
 {
-    ISAAC_STAGE_QUALITY_TABLES(Rg, R)
+    ISAAC_STAGE_SCAN_TABLES(Rg, R)
     Counters local; memset(&local, 0, sizeof(local));
     const u32 n = imin(*al.counter, al.cap);
     for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)

@@ -440,17 +440,20 @@ __global__ __launch_bounds__(64 * RW_WAVES) void k_rescue_windows(DevParams P, D
 
 __global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, ClusterPools pools, RescueBuffers rb, Counters *counters)
 {
+    // (one shared copy of the quality tables here: with a copy per lane -- k_align_candidates -- this kernel was slower, 2.31 -> 3.37 ms as it is and 2.66 ->
+    // 2.97 ms as a grid that strides over the slots to stage the copies less often; a slot per thread and 94 000 small workgroups stayed the fastest form.
+    // profiles/r4_exp_scan_tables*.log)
     ISAAC_STAGE_QUALITY_TABLES(Rg, R)
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    Counters local; memset(&local, 0, sizeof(local));
+    u32 scans = 0;
     // slots in use: below the region's counter and below the first request the region could not serve
     if (i < rb.candCap && i % rb.candRegionSize < imin(imin(rb.candCounter[i / rb.candRegionSize], rb.candCounter[CAND_REGIONS + i / rb.candRegionSize]), rb.candRegionSize))
     {
         const RescueJob &job = rb.jobs[rb.candJob[i]];
         rescueAlignCandidate(P, R, bcl, clusterBase + job.cluster, pools.meta[job.cluster].endCyclesMasked[job.shadowReadIndex], job, rb.candPositions[i], rb.shadowCands[i], rb.shadowCigars + u64(i) * 3);
-        ++local.ungappedScans;
+        ++scans;
     }
-    flushCounters(local, counters);
+    flushCounter(&Counters::ungappedScans, scans, counters);
 }
 
 // one thread per rescue problem: which of its aligned candidates get a gapped retry (ShadowAligner.cpp:232-262).  Problems with

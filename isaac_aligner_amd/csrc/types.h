@@ -86,8 +86,9 @@ struct DevReference
     u32 prefixBits;
     const u32 *packedBases;   // the same bases 2 bits each, 16 per word, base i of a word at bits 2i: A 0, C 1, T 2, G 3 ((ASCII >> 1) & 3)
     const u32 *notBase;       // 1 bit per base: set where it is not one of ACGT (32 per word); both arrays end with spare words
-    const double *logMatch;   // Quality::logMatchLookup / logMismatchLookup (lib/alignment/Quality.cpp:34-66), 100 entries each
-    const double *logMismatch;
+    const double *logMatch;   // Quality::logMatchLookup / logMismatchLookup (lib/alignment/Quality.cpp:34-66), 100 entries each:
+    const double *logMismatch;//   entry q at [q * logStride] (1 in global memory; kernels.h: the copies in LDS, one per lane of a half wavefront)
+    u32 logStride;
 };
 ISAAC_HD u64 contigLength(const DevReference &r, u32 contig) { return r.contigOffset[contig + 1] - r.contigOffset[contig]; }
 

@@ -202,15 +202,19 @@ struct Worker
     isaac_gpu_ctx *ctx = 0;
     std::vector<DeviceMemory> loads;                // the BCL bytes of the loads dealt to this worker
     std::vector<Tile *> tiles;
-    DeviceMemory matches, offsets, textDev, tableKmers, tablePositions;
+    DeviceMemory matches, offsets, textDev;
     uint64_t matchCapacity = 0;
     isaac_counters counters;
     double selectSeconds = 0, buildSeconds = 0;
-    ~Worker() { loads.clear(); matches.release(); offsets.release(); textDev.release(); if (ctx) { isaac_gpu_destroy(ctx); } tableKmers.release(); tablePositions.release(); }
+    ~Worker() { loads.clear(); matches.release(); offsets.release(); textDev.release(); if (ctx) isaac_gpu_destroy(ctx); }
 };
 
-// what a bin of the file becomes: its BGZF blocks, and its records for the index
-struct BinOutput { bool ready = false; std::vector<uint8_t> bgzf, records; uint64_t nRecords = 0; std::string error; };
+// what a bin of the file becomes: its BGZF blocks, and what the index wants to know about its records (buffers that are not cleared first:
+// they are gigabytes)
+struct BinOutput
+{
+    bool ready = false; std::unique_ptr<uint8_t[]> bgzf; std::unique_ptr<isaac_bam_index_entry[]> entries; uint64_t bgzfBytes = 0, recordsBytes = 0, nRecords = 0; std::string error;
+};
 
 int run(const AlignOptions &o)
 {
@@ -249,21 +253,10 @@ int run(const AlignOptions &o)
             GPU(isaac_gpu_create(w.device, &params, ISAAC_GPU_STREAM_OWN, &w.ctx));
             GPU(isaac_gpu_load_contigs(w.ctx, reference.bases.data(), reference.offsets.data(), uint32_t(reference.contigs.size())));
             if (0 == k) { GPU(isaac_gpu_load_sorted_reference(w.ctx, o.referenceGenome.c_str())); continue; }
-            const uint64_t *kmers = 0, *positions = 0; uint64_t n = 0;
-            GPU(isaac_gpu_index_dev(workers[0]->ctx, &kmers, &positions, &n));
-            std::vector<uint64_t> maskOffsets(65);
-            GPU(isaac_gpu_get_mask_offsets(workers[0]->ctx, maskOffsets.data(), 64));
+            // the first worker of a device that is not the first worker's gets a copy of the table, everybody else reads one that is there
             Worker *sameDevice = 0;
             for (size_t j = 0; j < k && !sameDevice; ++j) if (workers[j]->device == w.device) sameDevice = workers[j].get();
-            if (!sameDevice)
-            {
-                w.tableKmers.reset(w.ctx, n * 8); w.tablePositions.reset(w.ctx, n * 8);
-                GPU(isaac_gpu_copy(w.ctx, w.tableKmers.as<uint64_t>(), kmers, n * 8));
-                GPU(isaac_gpu_copy(w.ctx, w.tablePositions.as<uint64_t>(), positions, n * 8));
-                kmers = w.tableKmers.as<uint64_t>(); positions = w.tablePositions.as<uint64_t>();
-            }
-            else if (sameDevice != workers[0].get()) GPU(isaac_gpu_index_dev(sameDevice->ctx, &kmers, &positions, &n));
-            GPU(isaac_gpu_set_index_dev(w.ctx, kmers, positions, n, maskOffsets.data(), 64));
+            GPU(isaac_gpu_share_index(w.ctx, sameDevice ? sameDevice->ctx : workers[0]->ctx));
         }
         std::string().swap(reference.bases);
     }
@@ -519,7 +512,7 @@ int run(const AlignOptions &o)
     auto buildBins = [&](Worker &w)
     {
         const double start = seconds();
-        DeviceMemory data, bam, bgzf;
+        DeviceMemory data, bam, bgzf, entries;
         for (size_t k = nextBin++; k < fileOrder.size(); k = nextBin++)
         {
             BinOutput result;
@@ -550,6 +543,8 @@ int run(const AlignOptions &o)
                     else { options.bin_first_contig = fileOrder[k]; options.bin_end_contig = fileOrder[k] + 1; options.bin_unaligned = 0; }
                     uint64_t capacity = bin.records * (96 + 2 * uint64_t(maxReadLength)), nBytes = 0, unalignedOffset = 0;
                     if (bam.bytes() < capacity) bam.reset(w.ctx, capacity);
+                    if (entries.bytes() < bin.records * sizeof(isaac_bam_index_entry)) entries.reset(w.ctx, bin.records * sizeof(isaac_bam_index_entry));
+                    options.index_entries_dev = entries.as<isaac_bam_index_entry>();
                     int rc = isaac_gpu_bam_records(w.ctx, bamTiles.data(), uint32_t(bamTiles.size()), &options, bam.as<uint8_t>(), bam.bytes(), &nBytes, &result.nRecords, &unalignedOffset);
                     if (ISAAC_GPU_ECAPACITY == rc)
                     {
@@ -565,9 +560,10 @@ int run(const AlignOptions &o)
                         uint64_t nOut = 0;
                         if (o.bamGzipLevel) GPU(isaac_gpu_bgzf_deflate(w.ctx, bam.as<uint8_t>(), nBytes, 0, bgzf.as<uint8_t>(), bgzf.bytes(), &nOut));
                         else GPU(isaac_gpu_bgzf_store(w.ctx, bam.as<uint8_t>(), nBytes, 0, bgzf.as<uint8_t>(), bgzf.bytes(), &nOut));
-                        result.bgzf.resize(nOut); result.records.resize(nBytes);
-                        GPU(isaac_gpu_download(w.ctx, result.bgzf.data(), bgzf.as<uint8_t>(), nOut));
-                        GPU(isaac_gpu_download(w.ctx, result.records.data(), bam.as<uint8_t>(), nBytes));      // for the index (BamIndexPart reads the records)
+                        result.bgzf.reset(new uint8_t[nOut]); result.bgzfBytes = nOut; result.recordsBytes = nBytes;
+                        result.entries.reset(new isaac_bam_index_entry[result.nRecords]);
+                        GPU(isaac_gpu_download(w.ctx, result.bgzf.get(), bgzf.as<uint8_t>(), nOut));
+                        GPU(isaac_gpu_download(w.ctx, result.entries.get(), entries.as<isaac_bam_index_entry>(), result.nRecords * sizeof(isaac_bam_index_entry)));      // for the index
                     }
                     std::vector<BinPart>().swap(bin.parts);
                 }
@@ -601,9 +597,9 @@ int run(const AlignOptions &o)
                 out = std::move(outputs[k]);
             }
             if (!out.error.empty() && failure.empty()) failure = out.error;
-            if (!failure.empty() || out.bgzf.empty()) continue;
-            os.write(reinterpret_cast<const char *>(out.bgzf.data()), std::streamsize(out.bgzf.size()));
-            if (isaac_gpu_bam_indexer_add(indexer, out.records.data(), out.records.size(), out.bgzf.data(), out.bgzf.size())) failure = std::string("isaac_gpu_bam_indexer_add: ") + isaac_gpu_bam_index_last_error();
+            if (!failure.empty() || !out.bgzfBytes) continue;
+            os.write(reinterpret_cast<const char *>(out.bgzf.get()), std::streamsize(out.bgzfBytes));
+            if (isaac_gpu_bam_indexer_add_entries(indexer, out.entries.get(), out.nRecords, out.recordsBytes, out.bgzf.get(), out.bgzfBytes)) failure = std::string("isaac_gpu_bam_indexer_add_entries: ") + isaac_gpu_bam_index_last_error();
             nRecordsWritten += out.nRecords; ++binsWritten;
         }
         for (std::thread &t : builders) t.join();

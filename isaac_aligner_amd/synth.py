@@ -185,6 +185,43 @@ def bcl_to_fastq(bcl, read_offset, read_length, name="r", newline=b"\n", plus_he
     return bytes(out)
 
 
+def write_fastq(files, bcl, read_length, name_prefix=b"M1:7:FCSYNTH:1:1101:", first_index=0):
+    """appends the FASTQ records of a BCL tile (numpy uint8 [n, 2 * read_length] or [n, read_length]) to the open binary files `files` (one per read), built as
+    one array per read: '@' + name_prefix + a nine-digit number, bases (N for quality-0 bytes), '+', qualities.  The flowcell id the reference's Casava name
+    parser finds is the third ':'-separated field of the name."""
+    import numpy as np
+    bcl = np.asarray(bcl)
+    n = len(bcl)
+    header = np.frombuffer(b"@" + name_prefix, np.uint8)
+    digits = np.char.zfill(np.arange(first_index, first_index + n).astype(str), 9).astype("S9").view(np.uint8).reshape(n, 9)
+    nl, plus = np.full((n, 1), 10, np.uint8), np.full((n, 1), ord("+"), np.uint8)
+    for r, f in enumerate(files):
+        b = bcl[:, r * read_length:(r + 1) * read_length]
+        is_n = (b & 0xFC) == 0
+        bases = np.where(is_n, ord("N"), np.frombuffer(b"ACGT", np.uint8)[b & 3]).astype(np.uint8)
+        quals = np.where(is_n, 35, 33 + (b >> 2)).astype(np.uint8)
+        np.concatenate([np.tile(header, (n, 1)), digits, nl, bases, nl, plus, nl, quals, nl], axis=1).tofile(f)
+
+
+def write_fasta(path, contigs, names=None):
+    """the contigs (uint8 tensors / arrays of ASCII bases) as a FASTA file with 60-base lines; returns [(byte offset, bytes in the file, bases, ACGT bases)] per contig,
+    what isaac_reference_contig wants to know"""
+    import numpy as np
+    meta = []
+    with open(path, "wb") as f:
+        for i, c in enumerate(contigs):
+            seq = c.cpu().numpy() if hasattr(c, "cpu") else np.asarray(c)
+            f.write(b">" + (names[i] if names else b"chr%d" % (i + 1)) + b" synthetic\n")
+            begin = f.tell()
+            full = len(seq) // 60 * 60
+            if full:
+                np.concatenate([seq[:full].reshape(-1, 60), np.full((full // 60, 1), 10, np.uint8)], axis=1).tofile(f)
+            if len(seq) > full:
+                f.write(seq[full:].tobytes() + b"\n")
+            meta.append((begin, f.tell() - begin, len(seq), int(sum(int((seq == b).sum()) for b in b"ACGT"))))
+    return meta
+
+
 # ---- a human-like reference (BASELINE.json configs 2-4: "GRCh38") ---------------------------------------------------------
 # Relative lengths of GRCh38's chr1..22, X, Y, M (Mbp): the contig list of the synthetic genome follows them.
 _GRCH38_MBP = [248.96, 242.19, 198.30, 190.21, 181.54, 170.81, 159.35, 145.14, 138.39, 133.80, 135.09, 133.28, 114.36, 107.04, 101.99,

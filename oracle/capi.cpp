@@ -158,6 +158,8 @@ int oracle_find_matches(oracle_ref *r, const oracle_params *cp, const uint8_t *b
     catch (const std::exception &e) { g_error = e.what(); return 1; }
 }
 
+void oracle_set_lookup_mode(int mode) { setLookupMode(mode); }
+
 // The same on n_threads host threads, for the CPU baseline of bench.py: the tile is cut into contiguous cluster ranges, every
 // thread runs the unchanged single-tile function (its own merge-join over the whole index, as every mask thread of the
 // reference streams whole mask files) on its range, and the cluster numbers are put back into the SeedIds afterwards.

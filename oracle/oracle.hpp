@@ -769,4 +769,6 @@ struct GapRealigner
     struct Impl;
 };
 
+void setLookupMode(int mode);   // seeds.cpp: 0 merge join, 1 bisection between seed k-mers (parallel lookup only)
+
 } // namespace oracle

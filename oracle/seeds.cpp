@@ -15,6 +15,12 @@
 namespace oracle
 {
 
+// How a thread moves through the table between two seed k-mers: 0 = entry by entry (the merge join of ExactMaskMatcher.cpp:83-184, which
+// streams the whole table per pass and is what the reference does with its batches of millions of clusters), 1 = by bisection of what is left
+// (the same matches; less traffic when the seeds are few against the table).  Set by oracle_set_lookup_mode; bench.py times both.
+static int g_lookupMode = 0;
+
+
 // lib/options/alignOptions/SeedDescriptorOption.cpp:90-151
 unsigned parseAutoSeedDescriptor(bool /*detectSimpleIndels*/, const ReadMetadata &read, unsigned seedLength, std::vector<SeedMetadata> &out)
 {
@@ -155,6 +161,8 @@ void findMatchesExact(const Params &p, const SortedReference &ref, const std::ve
     {
         const size_t currentSeed = nextSeed;
         while (endSeeds != nextSeed && seeds[currentSeed].kmer == seeds[nextSeed].kmer) ++nextSeed;
+        if (g_lookupMode && nextRef < nRef && seeds[currentSeed].kmer > ref.kmers[nextRef].kmer)
+            nextRef = size_t(std::lower_bound(ref.kmers.begin() + nextRef, ref.kmers.end(), seeds[currentSeed].kmer, [](const ReferenceKmer &r, uint64_t k) { return r.kmer < k; }) - ref.kmers.begin());
         while (nextRef < nRef && seeds[currentSeed].kmer > ref.kmers[nextRef].kmer) ++nextRef;
         repeatList.clear();
         while (nextRef < nRef && seeds[currentSeed].kmer == ref.kmers[nextRef].kmer)
@@ -260,6 +268,8 @@ void joinRange(const Params &p, const SortedReference &ref, const std::vector<Se
     {
         const size_t currentSeed = nextSeed;
         while (endSeeds != nextSeed && seeds[currentSeed].kmer == seeds[nextSeed].kmer) ++nextSeed;
+        if (g_lookupMode && nextRef < nRef && seeds[currentSeed].kmer > ref.kmers[nextRef].kmer)
+            nextRef = size_t(std::lower_bound(ref.kmers.begin() + nextRef, ref.kmers.end(), seeds[currentSeed].kmer, [](const ReferenceKmer &r, uint64_t k) { return r.kmer < k; }) - ref.kmers.begin());
         while (nextRef < nRef && seeds[currentSeed].kmer > ref.kmers[nextRef].kmer) ++nextRef;
         repeatList.clear();
         while (nextRef < nRef && seeds[currentSeed].kmer == ref.kmers[nextRef].kmer)
@@ -496,5 +506,7 @@ SortedReference buildSortedReference(const ContigList &contigs, unsigned seedLen
     }
     return ret;
 }
+
+void setLookupMode(int mode) { g_lookupMode = mode; }
 
 } // namespace oracle

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Times the two programs end to end on a mid-sized case: a 100 Mbp human-like genome written as FASTA -> isaac-sort-reference -> 1 M
-synthetic 2x101 pairs written as two FASTQ files (plain) -> isaac-align with the reference's defaults.  Prints the stage lines of both
-programs.  CLI_GENOME_BASES (1e8), CLI_PAIRS (1e6)"""
+"""Times the two programs end to end: a human-like genome written as FASTA -> isaac-sort-reference -> synthetic pairs written as two FASTQ
+files (plain) -> isaac-align with the reference's defaults.  Prints the stage lines of both programs and one JSON line (cli_end_to_end).
+CLI_GENOME_BASES (1e8), CLI_PAIRS (1e6), CLI_READ_LENGTH (101), CLI_WORK (a directory to work in: /dev/shm/... keeps the 47 GB of mask files
+of a GRCh38-sized reference off the disk), CLI_ARGS (more isaac-align options, e.g. "--clusters-at-a-time 4000000 --devices 0,0")"""
 import os, subprocess, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,8 +10,8 @@ import torch
 from isaac_aligner_amd import build, synth
 
 def main():
-    n_bases, n_pairs, L = int(float(os.environ.get("CLI_GENOME_BASES", "1e8"))), int(float(os.environ.get("CLI_PAIRS", "1e6"))), 101
-    work = tempfile.mkdtemp(prefix="isaac_cli_")
+    n_bases, n_pairs, L = int(float(os.environ.get("CLI_GENOME_BASES", "1e8"))), int(float(os.environ.get("CLI_PAIRS", "1e6"))), int(os.environ.get("CLI_READ_LENGTH", "101"))
+    work = tempfile.mkdtemp(prefix="isaac_cli_", dir=os.environ.get("CLI_WORK") or None)
     dev = torch.device("cuda", 0)
     genome = synth.make_human_like_genome(n_bases, seed=3, device=dev)
     fasta = os.path.join(work, "genome.fa")
@@ -22,7 +23,7 @@ def main():
             f.write(np.concatenate([seq[:full].reshape(-1, 60), np.full((full // 60, 1), 10, np.uint8)], axis=1).tobytes())
             if len(seq) > full:
                 f.write(seq[full:].tobytes() + b"\n")
-    bcl = synth.make_read_pairs(genome, n_pairs, L, seed=11, device=dev, avoid_gaps=True)[0].cpu().numpy()
+    bcl = torch.cat([synth.make_read_pairs(genome, min(1_000_000, n_pairs - first), L, seed=11 + first, device=dev, avoid_gaps=True)[0].cpu() for first in range(0, n_pairs, 1_000_000)]).numpy()
     del genome
     torch.cuda.empty_cache()
     calls = os.path.join(work, "calls"); os.makedirs(calls)
@@ -42,11 +43,19 @@ def main():
     ref_dir = os.path.join(work, "ref")
     tools = os.path.dirname(build.build_host())
     for name, cmd in (("isaac-sort-reference", [os.path.join(tools, "isaac-sort-reference"), "-g", fasta, "-o", ref_dir, "-q"]),
-                      ("isaac-align", [os.path.join(tools, "isaac-align"), "-r", os.path.join(ref_dir, "sorted-reference.xml"), "-b", calls, "--base-calls-format", "fastq", "-o", os.path.join(work, "Aligned")])):
+                      ("isaac-align", [os.path.join(tools, "isaac-align"), "-r", os.path.join(ref_dir, "sorted-reference.xml"), "-b", calls, "--base-calls-format", "fastq", "-o", os.path.join(work, "Aligned")]
+                       + os.environ.get("CLI_ARGS", "").split())):
         t0 = time.time()
         r = subprocess.run(cmd, capture_output=True, text=True)
-        print("%s: rc %d, %.1f s" % (name, r.returncode, time.time() - t0))
-        print("\n".join(l for l in r.stderr.splitlines() if "done in" in l or "records" in l or "clusters in" in l or "error" in l.lower()), flush=True)
+        wall = time.time() - t0
+        print("%s: rc %d, %.1f s" % (name, r.returncode, wall))
+        print("\n".join(l for l in r.stderr.splitlines() if "done in" in l or "records" in l or "clusters in" in l or "error" in l.lower() or "timing" in l), flush=True)
+        if name == "isaac-align" and r.returncode == 0:
+            import json
+            timing = json.loads([l for l in r.stderr.splitlines() if "timing {" in l][-1].split("timing ", 1)[1])
+            timing.update({"wall_s": round(wall, 2), "reads_per_s": round(timing["reads"] / wall, 1), "reads_per_s_without_reference_load": round(timing["reads"] / (timing["total_s"] - timing["reference_s"]), 1),
+                           "genome_bases": n_bases, "read_length": L})
+            print("cli_end_to_end " + json.dumps(timing), flush=True)
     bam = os.path.join(work, "Aligned", "Projects", "default", "default", "sorted.bam")
     print("sorted.bam %d MB, .bai %d KB" % (os.path.getsize(bam) // 1000000, os.path.getsize(bam + ".bai") // 1000))
     subprocess.run(["rm", "-rf", work])

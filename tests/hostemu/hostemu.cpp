@@ -50,7 +50,7 @@ Emu *emu_create(const isaac_params *p, const char *bases, const u64 *offsets, u3
         e->logMatch.resize(100); e->logMismatch.resize(100); makeQualityTables(e->logMatch.data(), e->logMismatch.data());
         std::memset(&e->R, 0, sizeof(e->R));
         e->R.bases = e->bases.data(); e->R.totalBases = e->bases.size(); e->R.contigOffset = e->offsets.data(); e->R.contigLoaded = e->loaded.data(); e->R.nContigs = nContigs;
-        e->R.logMatch = e->logMatch.data(); e->R.logMismatch = e->logMismatch.data();
+        e->R.logMatch = e->logMatch.data(); e->R.logMismatch = e->logMismatch.data(); e->R.logStride = 1;
         std::memset(&e->cnt, 0, sizeof(e->cnt));
         return e;
     }

@@ -354,3 +354,122 @@ def test_index_entries_against_a_brute_force_scan(torch, human):
         len(wrong), len(bits), int(qh[seg_h[wrong[0]]]), int(bits[wrong[0]]), int(has_neighbor[seg_h[wrong[0]]]))
     assert has_neighbor.any() and not has_neighbor.all() and repeat.any()
     print("k-mers checked %d (entries %d): %d with neighbours, %d repeats" % (m, len(bits), int(has_neighbor.sum()), int(repeat.sum())))
+
+
+def test_isaac_align_on_the_full_size_reference(torch, oracle, human, tmp_path):
+    """bin/isaac-align at real size: the 3.1 Gbp reference as isaac-sort-reference leaves it (FASTA + 64 mask files, 47 GB, read back by
+    isaac_gpu_load_sorted_reference), three lanes of 5.1 M pairs of 2x150 as FASTQ files -- without --clusters-at-a-time a lane is one load cut into
+    two tiles (5 M + 0.1 M clusters: 40 M / 8 seeds per tile) -- aligned with the reference's defaults (duplicates marked, gaps realigned,
+    --bam-gzip-level 1 on the device), binned by contig into host memory and built bin by bin.  sorted.bam must inflate to the header and record
+    stream of the oracle chain on the same reads (lookup, statistics per lane, selection, duplicates, realignment, order, records), and the .bai must
+    be what the oracle's BamIndexer makes of those records and the file's own BGZF blocks."""
+    import shutil
+    import subprocess
+    import tempfile
+    import zlib
+    from isaac_aligner_amd import bam, build, sorted_reference as sr
+    al, genome = human["al"], human["genome"]
+    L = 150
+    pairs_per_lane = int(os.environ.get("ISAAC_SCALE_CLI_PAIRS_PER_LANE", 5_100_000))
+    lanes = (1, 2, 5)
+    p = options.default_params(L, L)
+    al.set_params(p)
+    work = tempfile.mkdtemp(prefix="isaac_scale_cli_", dir="/dev/shm" if os.path.isdir("/dev/shm") else str(tmp_path))
+    try:
+        ref_dir, calls = os.path.join(work, "ref"), os.path.join(work, "calls")
+        os.makedirs(ref_dir); os.makedirs(calls)
+        fasta = os.path.join(ref_dir, "genome.fa")
+        contigs, position = [], 0
+        for i, (offset, size, bases, acgt) in enumerate(synth.write_fasta(fasta, genome.contigs)):
+            m = sr.Contig()
+            m.genomic_position, m.index, m.karyotype_index, m.name, m.file = position, i, i, b"chr%d" % (i + 1), fasta.encode()
+            m.offset, m.size, m.total_bases, m.acgt_bases = offset, size, bases, acgt
+            position += bases
+            contigs.append(m)
+        al.save_sorted_reference(ref_dir, "genome.fa", contigs)
+        # the reads: per lane two FASTQ files; the BCL bytes the oracle gets are the ones the text was written from (the text -> BCL conversion has
+        # tests of its own; a prefix of it is checked here)
+        lane_bcl = {}
+        for lane in lanes:
+            parts = [synth.make_read_pairs(genome, min(1_000_000, pairs_per_lane - first), L, seed=9000 + 100 * lane + first // 1_000_000, device=al.device, avoid_gaps=True)[0].cpu()
+                     for first in range(0, pairs_per_lane, 1_000_000)]
+            bcl = torch.cat(parts).numpy()
+            lane_bcl[lane] = bcl
+            files = [open(os.path.join(calls, "lane%d_read%d.fastq" % (lane, r + 1)), "wb") for r in range(2)]
+            for first in range(0, len(bcl), 1_000_000):
+                synth.write_fastq(files, bcl[first:first + 1_000_000], L, name_prefix=b"M1:7:FCSCALE:%d:1101:" % lane, first_index=first)
+            for f in files:
+                f.close()
+        with open(os.path.join(calls, "lane1_read1.fastq"), "rb") as f:
+            text = f.read(2000 * (2 * L + 40))
+        text = text[:text.rfind(b"\n@") + 1]
+        rc, back, n_back, _, _ = oracle.fastq_to_bcl(text, L, max_clusters=4000)
+        assert rc == 0 and n_back > 1000 and (back[:n_back, :L] == lane_bcl[1][:n_back, :L]).all()
+        out = os.path.join(work, "Aligned")
+        args = [build.build_host(), "-r", os.path.join(ref_dir, "sorted-reference.xml"), "-b", calls, "--base-calls-format", "fastq", "-o", out, "--use-bases-mask", "y*,y*", "-j", "64"]
+        t0 = time.time()
+        r = subprocess.run(args, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        print("isaac-align: %.1f s\n%s" % (time.time() - t0, "\n".join(l for l in r.stderr.splitlines() if "done in" in l or "timing" in l or "tile(s)" in l)))
+        assert "%d clusters in 6 tile(s)" % (3 * pairs_per_lane) in r.stderr
+        # ---- the oracle chain
+        ref = oracle_reference(human, oracle)
+        cores = os.cpu_count() or 1
+        tile_max = 40_000_000 // p.n_seeds
+        found, all_hits, index = [], np.zeros(len(genome.contigs), np.uint8), 0
+        for lane_index, lane in enumerate(lanes):
+            bcl, number = lane_bcl[lane], 1
+            for first in range(0, len(bcl), tile_max):
+                tile_bcl = np.ascontiguousarray(bcl[first:first + tile_max])
+                om, hits = ref.find_matches(p, tile_bcl, len(tile_bcl), tile=index, n_threads=min(cores, 64))
+                all_hits |= hits
+                found.append((lane_index, lane, number, index, tile_bcl, om))
+                number += 1; index += 1
+        host_tiles, tls_of_lane = [], {}
+        for lane_index, lane, number, index, tile_bcl, om in found:
+            tls = tls_of_lane.get(lane_index)
+            if tls is None or not tls.stable:
+                tls = tls_of_lane[lane_index] = ref.determine_tls(p, tile_bcl, om, all_hits, tile=index)
+            orec, ocig, _ = ref.select(p, tile_bcl, om, tls, all_hits, tile=index, n_threads=cores, n_clusters_hint=len(tile_bcl))
+            host_tiles.append((tile_bcl, orec, ocig, "FCSCALE:%d:%d:" % (lane, number), str(lane_index), tls))
+        del found
+        want, want_n, want_unaligned = oracle.bam_records(host_tiles, [L, L], forced_dodgy_alignment_score=p.dodgy_alignment_score & 0xff, mark_duplicates=True, keep_duplicates=True,
+                                                          realign_gaps=True, reference=ref)
+        assert want_n == 2 * 3 * pairs_per_lane
+        sq = [("chr%d" % (i + 1), int(c.total_bases), "", fasta, "") for i, c in enumerate(contigs)]
+        header = oracle.bam_header(" ".join(args), "isaac_aligner_amd-0.3", sq, header_lines=["@RG\tID:%d\tPL:ILLUMINA\tSM:default\tPU:FCSCALE:%d:none" % (k, lane) for k, lane in enumerate(lanes)])
+        # ---- the file: inflated block by block against header + records; its blocks' places for the index
+        path = os.path.join(out, "Projects", "default", "default", "sorted.bam")
+        data = np.fromfile(path, np.uint8)
+        expected_total = len(header) + len(want)
+        blocks, at, raw_at = [], 0, 0
+        view = memoryview(data)
+        hv, wv = memoryview(header), memoryview(want)
+        while at < len(data):
+            assert bytes(view[at:at + 4]) == b"\x1f\x8b\x08\x04" and bytes(view[at + 12:at + 14]) == b"BC"
+            size = int.from_bytes(bytes(view[at + 16:at + 18]), "little") + 1
+            raw = zlib.decompress(view[at + 18:at + size - 8], -15)
+            assert int.from_bytes(bytes(view[at + size - 4:at + size]), "little") == len(raw)
+            for piece_at, piece in ((raw_at, raw),):
+                end = piece_at + len(piece)
+                if end <= len(header):
+                    assert piece == hv[piece_at:end]
+                elif piece_at >= len(header):
+                    assert piece == wv[piece_at - len(header):end - len(header)], "records differ in the block at %d" % at
+                else:
+                    assert piece == bytes(hv[piece_at:]) + bytes(wv[:end - len(header)])
+            blocks.append((at, size, raw_at))
+            raw_at += len(raw); at += size
+        assert raw_at == expected_total and blocks[-1][1] == 28
+        start_of = {b[2]: b[0] for b in blocks[:-1]}
+        start_of[raw_at] = blocks[-1][0]
+        cuts = bam.split_parts(want, want_unaligned)
+        parts, file_at = [], len(header)
+        for off, size in cuts:
+            parts.append((off, size, bytes(view[start_of[file_at]:start_of[file_at + size]])))       # every bin starts a block of its own
+            file_at += size
+        header_bgzf = start_of[len(header)]
+        bai = open(path + ".bai", "rb").read()
+        assert bai == oracle.bam_index(want, parts, len(contigs), header_bgzf)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
