@@ -19,7 +19,9 @@
 #include <cstdlib>
 #include <map>
 #include <memory>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 #include "kernels.h"
 #include "host_util.h"
@@ -694,43 +696,86 @@ int isaac_gpu_load_index(isaac_gpu_ctx *c, const isaac_reference_kmer *const *ma
     hipStream_t st = c->stream;
     c->kmersBorrowed = c->positionsBorrowed = nullptr;
     c->kmers.reserve(total + 1); c->positions.reserve(total + 1); c->nKmers = 0; c->prefixBits = 0;
+    // The mask files arrive as host memory (memory-mapped files, usually): 47 GB for GRCh38.  Copied by the runtime straight from pageable memory they
+    // move at 3-4 GB/s (one thread faulting the pages in and staging them).  Here a few host threads copy 256 MB pieces into a ring of pinned buffers side by
+    // side -- that is where the page faults and the page-cache reads happen -- and the pieces go to the device from there, two in flight, each split into
+    // the two arrays of the table as it lands.
     const u64 chunk = 1u << 24;      // records per staging buffer (256 MB)
+    struct Piece { const ReferenceKmerRecord *src; u64 n, at; };
+    std::vector<Piece> pieces;
+    c->maskOffsets.assign(1, 0);
+    {
+        u64 at = 0;
+        for (u32 m = 0; m < nMasks; ++m)
+        {
+            for (u64 done = 0; done < sizes[m]; done += chunk) { const u64 n = std::min(chunk, sizes[m] - done); pieces.push_back(Piece{ reinterpret_cast<const ReferenceKmerRecord *>(masks[m]) + done, n, at }); at += n; }
+            c->maskOffsets.push_back(at);
+        }
+    }
+    const u32 SLOTS = 6, FILLERS = 8;
     DevBuf<ReferenceKmerRecord> staging[2]; DevBuf<u32> disorder; disorder.reserve(1);
     HIP_CHECK(hipMemsetAsync(disorder.p, 0, 4, st));
     hipStream_t copyStream; HIP_CHECK(hipStreamCreateWithFlags(&copyStream, hipStreamNonBlocking));
-    hipEvent_t copied[2], split[2];
+    hipEvent_t copied[2], split[2], left[SLOTS];
     for (u32 i = 0; i < 2; ++i) { HIP_CHECK(hipEventCreateWithFlags(&copied[i], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&split[i], hipEventDisableTiming)); }
-    c->maskOffsets.assign(1, 0);
-    u64 at = 0; u32 turn = 0; bool used[2] = { false, false };
+    for (u32 i = 0; i < SLOTS; ++i) HIP_CHECK(hipEventCreateWithFlags(&left[i], hipEventDisableTiming));
+    ReferenceKmerRecord *pinned[SLOTS] = { nullptr };
+    std::vector<std::thread> fillers;
+    std::vector<std::atomic<int> > filled(pieces.size());
+    for (auto &f : filled) f.store(0);
+    std::atomic<size_t> nextPiece(0), consumed(0);      // pieces handed to a filler / pieces whose slot may be written again
+    std::atomic<bool> stop(false);
+    auto cleanup = [&]()
+    {
+        stop = true;
+        for (std::thread &t : fillers) t.join();
+        hipStreamSynchronize(copyStream); hipStreamDestroy(copyStream);
+        for (u32 i = 0; i < 2; ++i) { hipEventDestroy(copied[i]); hipEventDestroy(split[i]); }
+        for (u32 i = 0; i < SLOTS; ++i) { hipEventDestroy(left[i]); if (pinned[i]) hipHostFree(pinned[i]); }
+    };
     try
     {
         HIP_CHECK(hipStreamSynchronize(st));
-        for (u32 m = 0; m < nMasks; ++m)
+        if (!pieces.empty())
         {
-            for (u64 done = 0; done < sizes[m]; done += chunk, turn ^= 1)
+            for (u32 i = 0; i < SLOTS; ++i) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&pinned[i]), chunk * sizeof(ReferenceKmerRecord), hipHostMallocDefault));
+            for (u32 t = 0; t < FILLERS; ++t)
+                fillers.emplace_back([&]()
+                {
+                    for (size_t k = nextPiece++; k < pieces.size() && !stop; k = nextPiece++)
+                    {
+                        while (k >= consumed + SLOTS && !stop) std::this_thread::yield();      // the slot's last piece has not left for the device yet
+                        if (stop) return;
+                        std::memcpy(pinned[k % SLOTS], pieces[k].src, pieces[k].n * sizeof(ReferenceKmerRecord));
+                        filled[k].store(1, std::memory_order_release);
+                    }
+                });
+            bool used[2] = { false, false };
+            for (size_t k = 0; k < pieces.size(); ++k)
             {
-                const u64 n = std::min(chunk, sizes[m] - done);
+                const u32 turn = u32(k & 1), slot = u32(k % SLOTS);
+                while (!filled[k].load(std::memory_order_acquire)) std::this_thread::yield();
                 staging[turn].reserve(chunk);
                 if (used[turn]) HIP_CHECK(hipStreamWaitEvent(copyStream, split[turn], 0));     // its previous contents have been split
-                HIP_CHECK(hipMemcpyAsync(staging[turn].p, masks[m] + done, n * sizeof(ReferenceKmerRecord), hipMemcpyHostToDevice, copyStream));
+                HIP_CHECK(hipMemcpyAsync(staging[turn].p, pinned[slot], pieces[k].n * sizeof(ReferenceKmerRecord), hipMemcpyHostToDevice, copyStream));
                 HIP_CHECK(hipEventRecord(copied[turn], copyStream));
+                HIP_CHECK(hipEventRecord(left[slot], copyStream));
                 HIP_CHECK(hipStreamWaitEvent(st, copied[turn], 0));
-                k_split_records<<<gridFor(n, 256), 256, 0, st>>>(staging[turn].p, n, at, c->kmers.p, c->positions.p, disorder.p);
-                k_check_boundary<<<1, 1, 0, st>>>(c->kmers.p, at, disorder.p);
+                k_split_records<<<gridFor(pieces[k].n, 256), 256, 0, st>>>(staging[turn].p, pieces[k].n, pieces[k].at, c->kmers.p, c->positions.p, disorder.p);
+                k_check_boundary<<<1, 1, 0, st>>>(c->kmers.p, pieces[k].at, disorder.p);
                 HIP_CHECK(hipGetLastError());
                 HIP_CHECK(hipEventRecord(split[turn], st)); used[turn] = true;
-                at += n;
+                // two copies may be queued; the slots of everything before them are free again
+                if (k >= 2) { HIP_CHECK(hipEventSynchronize(left[(k - 2) % SLOTS])); consumed = k - 1; }
             }
-            c->maskOffsets.push_back(at);
         }
         u32 bad = 0;
         HIP_CHECK(hipMemcpyAsync(&bad, disorder.p, 4, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st)); HIP_CHECK(hipStreamSynchronize(copyStream));
-        for (u32 i = 0; i < 2; ++i) { hipEventDestroy(copied[i]); hipEventDestroy(split[i]); }
-        hipStreamDestroy(copyStream);
+        cleanup();
         if (bad) return fail(ISAAC_GPU_EINVAL, "mask files are not in global k-mer order");
     }
-    catch (...) { hipStreamSynchronize(copyStream); hipStreamDestroy(copyStream); for (u32 i = 0; i < 2; ++i) { hipEventDestroy(copied[i]); hipEventDestroy(split[i]); } throw; }
+    catch (...) { cleanup(); throw; }
     c->nKmers = total;
     buildPrefixTable(c);
     c->hasKaryotype = false;
