@@ -65,7 +65,7 @@ struct KernelTimer { double ms = 0; uint64_t launches = 0; };
 
 struct isaac_gpu_ctx
 {
-    bool ownsStream = false;
+    bool ownsStream = false; u32 cigarExtra = 32;
     int device = 0; hipStream_t stream = nullptr;
     isaac_params params; DevParams P;
     // reference
@@ -98,7 +98,7 @@ struct isaac_gpu_ctx
     DevBuf<u64> dupPrimary, dupMate, dupRank, dupCluster, dupSmall; DevBuf<u8> dupFlag;        // duplicate marking
     DevBuf<FragmentRecord> realignRecords; DevBuf<RealignGap> realignGaps, realignDeletionEnds; DevBuf<u32> realignPool, realignNext; DevBuf<u8> realignChanged;   // gap realignment
     DevBuf<RescueJob> jobs; DevBuf<u32> rescueCounters, bitmaps, candJob, shadowCigars, jobBase, jobCount; DevBuf<i32> candPositions; DevBuf<Cand> shadowCands; DevBuf<u32> candRank;
-    DevBuf<Counters> counters;
+    DevBuf<Counters> counters, countersSaved;
     std::map<std::string, KernelTimer> timers;
     struct PendingTimer { std::string name; hipEvent_t e0, e1; };
     std::vector<PendingTimer> pendingTimers; std::vector<hipEvent_t> eventPool;
@@ -563,6 +563,7 @@ int isaac_gpu_create(int device, const isaac_params *params, void *stream, isaac
     std::unique_ptr<isaac_gpu_ctx> c(new isaac_gpu_ctx);
     c->device = device; c->stream = static_cast<hipStream_t>(stream);
     if (ISAAC_GPU_STREAM_OWN == stream) { HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->ownsStream = true; }
+    if (const char *small = std::getenv("ISAAC_GPU_CIGAR_EXTRA_WORDS")) c->cigarExtra = std::max<u32>(1, u32(std::atol(small)));      // tests: the repeated call
     c->params = *params; c->P = makeDevParams(*params);
     if (-params->gap_open < -params->gap_extend) return fail(ISAAC_GPU_EINVAL, "gap open penalty below gap extend penalty is not supported by the banded Smith-Waterman scan");
     double tables[200]; makeQualityTables(tables, tables + 100);
@@ -613,6 +614,11 @@ static int checkPoolShort(isaac_gpu_ctx *c)
     HIP_CHECK(hipStreamSynchronize(c->stream));
     if (!flag) return 0;
     HIP_CHECK(hipMemsetAsync(c->poolShort.p, 0, 4, c->stream));
+    if (flag & 2)
+    {   // (with deferred completion the call cannot be repeated here: the next ones get the larger arena)
+        c->cigarExtra = std::min<u32>(c->cigarExtra * 4, 2048);
+        if (!(flag & 1)) return fail(ISAAC_GPU_ECAPACITY, "the CIGAR arena of a selection was used up (many single-indel or gapped alignments): some clusters are flagged (overflow_clusters); repeat the call");
+    }
     return fail(ISAAC_GPU_ECAPACITY, "n_matches given to isaac_gpu_select_n is smaller than the number of matches under cluster_offsets_dev: clusters beyond it have no candidates (overflow_clusters)");
 }
 int isaac_gpu_synchronize(isaac_gpu_ctx *c) { ISAAC_TRY HIP_CHECK(hipStreamSynchronize(c->stream)); return checkPoolShort(c); ISAAC_CATCH }
@@ -1173,10 +1179,13 @@ static void preparePools(isaac_gpu_ctx *c, u64 slots)
     const u64 perCluster = 2 * u64(c->P.nSeeds) * std::max(1u, c->P.repeatThreshold - 1);
     const u64 hard = u64(c->chunkNow) * perCluster;
     const u64 cap = std::max<u64>(slots ? slots : hard, 64);
-    if (3 * cap + 32 * u64(c->chunkNow) >= (u64(1) << 32)) throw std::invalid_argument("too many candidates in one chunk");
-    c->clusterMeta.reserve(c->chunkNow); c->candPool.reserve(cap); c->cigarArena.reserve(3 * cap + 32 * u64(c->chunkNow)); c->cigarNext.reserve(1);
+    // the cigar arena: three words per candidate slot and, for single-indel and accepted gapped alignments, cigarExtra words per cluster on average (32 to
+    // begin with; a call whose chunks use them up is repeated with four times as many: selectFromSource)
+    const u64 arena = 3 * cap + u64(c->cigarExtra) * u64(c->chunkNow);
+    if (arena >= (u64(1) << 32)) throw std::invalid_argument("too many candidates in one chunk");
+    c->clusterMeta.reserve(c->chunkNow); c->candPool.reserve(cap); c->cigarArena.reserve(arena); c->cigarNext.reserve(1);
     c->pools.meta = c->clusterMeta.p; c->pools.cands = c->candPool.p; c->pools.cigars = c->cigarArena.p; c->pools.candCap = u32(cap);
-    c->pools.cigarCap = u32(3 * cap + 32 * u64(c->chunkNow)); c->pools.cigarNext = c->cigarNext.p;
+    c->pools.cigarCap = u32(arena); c->pools.cigarNext = c->cigarNext.p;
     if (!c->poolShort.p) { c->poolShort.reserve(1); HIP_CHECK(hipMemsetAsync(c->poolShort.p, 0, 4, c->stream)); }
     c->pools.shortFlag = c->poolShort.p;
 }
@@ -1369,6 +1378,12 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         HIP_CHECK(hipGetLastError());
     }
     const GappedBuffers gbRescue = gappedBuffers(c, 1);
+    // A call whose CIGAR arena runs out (its extra regions: cigarExtra words per cluster) is repeated with four times as many, the work counters put
+    // back to where they were: the caller sees one call with exact results.  (Not with deferred completion, where nothing is known yet when the call returns.)
+    c->countersSaved.reserve(COUNTER_SHARDS);
+    for (int attempt = 0; ; ++attempt)
+    {
+    if (!c->deferredCompletion) HIP_CHECK(hipMemcpyAsync(c->countersSaved.p, c->counters.p, COUNTER_SHARDS * sizeof(Counters), hipMemcpyDeviceToDevice, st));
     {   // how many candidate slots a chunk can need: the tile's match count -- given by the caller (isaac_gpu_select_n: no host wait), or read from
         // the offsets -- or the caller's candidate count for explicit lists.  A count that is too small shows as ISAAC_GPU_ECAPACITY (poolShort).
         u64 slots = 0;
@@ -1464,6 +1479,14 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
     }
     if (c->deferredCompletion) return 0;      // the caller enqueues its next call behind this one; isaac_gpu_synchronize waits for the last one
     HIP_CHECK(hipStreamSynchronize(st));
+    u32 flag = 0;
+    HIP_CHECK(hipMemcpyAsync(&flag, c->poolShort.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (!(flag & 2) || (flag & 1) || attempt >= 3 || c->cigarExtra >= 2048) break;
+    c->cigarExtra *= 4;
+    HIP_CHECK(hipMemsetAsync(c->poolShort.p, 0, 4, st));
+    HIP_CHECK(hipMemcpyAsync(c->counters.p, c->countersSaved.p, COUNTER_SHARDS * sizeof(Counters), hipMemcpyDeviceToDevice, st));
+    }
     return checkPoolShort(c);
     ISAAC_CATCH
 }

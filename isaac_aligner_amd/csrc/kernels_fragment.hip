@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64) void k_build_fragments_general(DevParams P, con
             const u32 first = u32(begin - chunkBegin);
             const u32 nMatches = u32(end - begin);
             const u32 cap = (u64(first) + nMatches <= pools.candCap) ? nMatches : 0u;     // a pool that is too small shows as CLUSTER_OVERFLOW
-            if (!cap && nMatches) *pools.shortFlag = 1;
+            if (!cap && nMatches) atomicOr(pools.shortFlag, 1u);
             f = clusterViewNew(first, cap, pools.cands, pools.cigars);
             const u8 *clusterBcl = bcl + u64(clusterBase + cl) * P.clusterLength;
             if (cap && nMatches <= GENERAL_STAGE_MATCHES) keyedBuildCandidates(P, clusterBcl, matches + begin, nMatches, trim != 0, f, keys, matchOrder[generalLane], candOrder[generalLane]);
@@ -231,6 +231,7 @@ __global__ __launch_bounds__(64) void k_indel_fragments(DevParams P, DevReferenc
         u32 at = 0;
         if (0 == threadIdx.x) at = 3 * pools.candCap + atomicAdd(pools.cigarNext, need);
         at = __shfl(at, 0, 64);
+        if (0 == threadIdx.x && u64(at) + need > pools.cigarCap) atomicOr(pools.shortFlag, 2u);      // the arena's extra regions are used up: the call is repeated with more (selectFromSource)
         clusterCigarExtra(f, pools.cigars, at, need, pools.cigarCap);
         clusterFinishSimpleIndels(P, R, bcl, clusterBase + cl, work, f, local, &stage);
         __syncthreads();
@@ -249,7 +250,11 @@ __device__ inline void reserveGappedCigars(ClusterFragments &f, bool active, u32
     u32 base = 0;
     if ((threadIdx.x & 63) == 63 && total) base = atomicAdd(pools.cigarNext, total);
     base = __shfl(base, 63, 64);
-    if (active && need) clusterCigarExtra(f, pools.cigars, 3 * pools.candCap + base + incl - need, need, pools.cigarCap);
+    if (active && need)
+    {
+        if (u64(3) * pools.candCap + base + incl > pools.cigarCap) atomicOr(pools.shortFlag, 2u);
+        clusterCigarExtra(f, pools.cigars, 3 * pools.candCap + base + incl - need, need, pools.cigarCap);
+    }
 }
 
 // step 5: the accept rule for the gapped alignments and the final consolidation.  Lists of up to FINISH_LEAN_MAX candidates on keys in LDS

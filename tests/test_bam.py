@@ -49,6 +49,10 @@ def emu_bam_records(tiles, read_lengths, forced=0, pessimistic=False, read_group
     total = 0
     for i, tile in enumerate(tiles):
         bcl, records, cigars, prefix = tile[:4]
+        # the oracle leaves out the clusters it does not store; the device path addresses a tile's BCL by the record's place (two records per
+        # cluster: an isaac_gpu_select call's buffers, or the compacted ones of isaac_gpu_bin_tile), so the BCL goes in compacted the same way
+        assert (records["cluster_id"][0::2] == records["cluster_id"][1::2]).all()
+        bcl = bcl[records["cluster_id"][0::2]]
         keep.append((np.ascontiguousarray(bcl, np.uint8), np.ascontiguousarray(records), np.ascontiguousarray(cigars, np.uint32), prefix.encode(), tile[4].encode() if len(tile) > 4 else None))
         arr[i].bcl_dev, arr[i].fragments_dev, arr[i].cigar_dev = keep[-1][0].ctypes.data, keep[-1][1].ctypes.data, keep[-1][2].ctypes.data
         arr[i].n_records, arr[i].read_name_prefix, arr[i].read_group = len(records), keep[-1][3], keep[-1][4]

@@ -438,6 +438,33 @@ def test_chunk_buffers_grow_with_the_calls(torch, monkeypatch):
         assert not compare_records(r2, c2, r1, c1)
 
 
+def test_cigar_arena_grows_when_a_call_uses_it_up(torch, oracle, monkeypatch):
+    """A context whose CIGAR arena begins with one extra word per cluster (ISAAC_GPU_CIGAR_EXTRA_WORDS; 32 otherwise) and indel-rich reads: the
+    call notices the exhausted arena on the device, repeats itself with a larger one and returns the oracle's records, work counters counted once"""
+    from isaac_aligner_amd import gpu
+    contigs, bcl, _ = make_inputs(read_length=250, n_pairs=1500, seed=9, genome_bases=300000, indel_read_fraction=0.6, indel_max=10)
+    p = options.default_params(250, 250)
+    monkeypatch.setenv("ISAAC_GPU_CIGAR_EXTRA_WORDS", "1")
+    al = gpu.Aligner(p, 0, contigs)
+    monkeypatch.delenv("ISAAC_GPU_CIGAR_EXTRA_WORDS")
+    al.build_index()
+    ref = oracle.reference(contigs)
+    ref.set_index(al.get_index())
+    dev_bcl = torch.from_numpy(bcl).to(al.device)
+    matches, offsets, hits = al.find_matches(dev_bcl)
+    om, ohits = ref.find_matches(p, bcl, len(bcl))
+    al.set_loaded_contigs(hits)
+    gtls = al.determine_tls(dev_bcl, matches, offsets)
+    otls = ref.determine_tls(p, bcl, om, ohits)
+    before = al.counters()["clusters"]
+    rec, cig = al.records_to_numpy(*al.select(dev_bcl, matches, offsets, gtls))
+    orec, ocig, _ = ref.select(p, bcl, om, otls, ohits, n_clusters_hint=len(bcl))
+    assert not (rec["reserved"] & 5).any()
+    assert not compare_records(orec, ocig, rec, cig)
+    assert al.counters()["clusters"] - before == len(bcl)
+    assert (rec["cigar_length"] > 1).sum() > 500
+
+
 def test_residual_pass_on_most_clusters(torch):
     """the -DISAAC_TINY_BEST=1 build of the library (made by __graft_entry__.build()): most clusters overflow k_select's private lists and
     go through the residual wave-per-cluster pass, which takes their rescue outcomes and probability sums as k_cluster_sums left them;
