@@ -231,10 +231,11 @@ __global__ __launch_bounds__(64) void k_indel_fragments(DevParams P, DevReferenc
         u32 at = 0;
         if (0 == threadIdx.x) at = 3 * pools.candCap + atomicAdd(pools.cigarNext, need);
         at = __shfl(at, 0, 64);
-        if (0 == threadIdx.x && u64(at) + need > pools.cigarCap) atomicOr(pools.shortFlag, 2u);      // the arena's extra regions are used up: the call is repeated with more (selectFromSource)
         clusterCigarExtra(f, pools.cigars, at, need, pools.cigarCap);
         clusterFinishSimpleIndels(P, R, bcl, clusterBase + cl, work, f, local, &stage);
         __syncthreads();
+        // a cluster that ran out of CIGAR words after the arena had none left for it: the call is repeated with a larger arena (selectFromSource)
+        if (0 == threadIdx.x && u64(at) + need > pools.cigarCap && (f.flags & CLUSTER_OVERFLOW)) atomicOr(pools.shortFlag, 2u);
         if (0 == threadIdx.x) { emitGappedJobs(f, cl, withGaps != 0, gb); clusterViewStore(f, pools.cands, pools.meta[cl]); }
     }
     if (0 != threadIdx.x) memset(&local, 0, sizeof(local));   // every lane counted the same events
@@ -242,7 +243,8 @@ __global__ __launch_bounds__(64) void k_indel_fragments(DevParams P, DevReferenc
 }
 
 // the cluster's share of the cigar arena for the gapped alignments that may be accepted: one bump of the arena's counter per wave
-__device__ inline void reserveGappedCigars(ClusterFragments &f, bool active, u32 need, const ClusterPools &pools)
+// true: the arena had no room left (the cluster keeps what is left of its own three words per candidate)
+__device__ inline bool reserveGappedCigars(ClusterFragments &f, bool active, u32 need, const ClusterPools &pools)
 {
     u32 incl = need;
     for (u32 o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o, 64); if ((threadIdx.x & 63) >= o) incl += v; }
@@ -250,12 +252,12 @@ __device__ inline void reserveGappedCigars(ClusterFragments &f, bool active, u32
     u32 base = 0;
     if ((threadIdx.x & 63) == 63 && total) base = atomicAdd(pools.cigarNext, total);
     base = __shfl(base, 63, 64);
-    if (active && need)
-    {
-        if (u64(3) * pools.candCap + base + incl > pools.cigarCap) atomicOr(pools.shortFlag, 2u);
-        clusterCigarExtra(f, pools.cigars, 3 * pools.candCap + base + incl - need, need, pools.cigarCap);
-    }
+    if (!active || !need) return false;
+    clusterCigarExtra(f, pools.cigars, 3 * pools.candCap + base + incl - need, need, pools.cigarCap);
+    return u64(3) * pools.candCap + base + incl > pools.cigarCap;
 }
+// a cluster that ran out of CIGAR words after the arena had none left for it: the call is repeated with a larger arena (selectFromSource)
+__device__ inline void arenaShort(bool reservationFailed, const ClusterFragments &f, const ClusterPools &pools) { if (reservationFailed && (f.flags & CLUSTER_OVERFLOW)) atomicOr(pools.shortFlag, 2u); }
 
 // step 5: the accept rule for the gapped alignments and the final consolidation.  Lists of up to FINISH_LEAN_MAX candidates on keys in LDS
 // (fragment_lean.h: leanFinishFragments); clusters with a longer one, or whose gapped problems found no room in the flat pass, are listed
@@ -288,10 +290,11 @@ __global__ __launch_bounds__(64) void k_finish_fragments(DevParams P, u32 nChunk
     }
     pushGeneral(general, t, generalList, generalCount);
     const bool active = t < nChunk && !general;
-    reserveGappedCigars(f, active, need, pools);
+    const bool arenaFull = reserveGappedCigars(f, active, need, pools);
     if (active)
     {
         leanFinishFragments(P, f, res, keys, bswJobs, bswAccepted, candidates);
+        arenaShort(arenaFull, f, pools);
         if (f.flags & CLUSTER_OVERFLOW) flushCounter(&Counters::overflowClusters, 1, counters);
         clusterViewStore(f, pools.cands, pools.meta[t]);
     }
@@ -322,10 +325,11 @@ __global__ __launch_bounds__(64) void k_finish_fragments_general(DevParams P, De
             if (res) for (u32 k = 0; k < nJobs; ++k) { const u32 w = res[k].nCigar; need += (0xffffffffu == w) ? 0u : w; }
             else need = 40 * nJobs;
         }
-        reserveGappedCigars(f, active, need, pools);
+        const bool arenaFull = reserveGappedCigars(f, active, need, pools);
         if (active)
         {
             clusterFinishFragments(P, R, bcl, clusterBase + t, withGaps != 0, res, work, f, local);
+            arenaShort(arenaFull, f, pools);
             clusterViewStore(f, pools.cands, pools.meta[t]);
         }
     }
