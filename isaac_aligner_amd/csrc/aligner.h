@@ -160,6 +160,56 @@ ISAAC_HD AlignBlock alignBlock(u64 readBytes, bool reverse, u64 referenceBytes)
     b.quality = ((readBytes >> 2) & (0x3f * BYTES_01)) | (nFlags >> 6);                  // N: quality 2
     return b;
 }
+ISAAC_HD u64 loadBytes8(const void *p) { u64 v; memcpy(&v, p, 8); return v; }
+// The same for four bases in 32 bits: what the scans use (a 64-bit shift, add or compare is two or more instructions on the device, and nothing
+// here crosses from one byte to the next).  Flags are 0x80 or 0 per byte.
+static const u32 QUAD_01 = 0x01010101u;
+ISAAC_HD u32 zeroBytes32(u32 x) { const u32 m = 0x7f * QUAD_01; return ~(((x & m) + m) | x | m); }
+ISAAC_HD u32 asciiOfCodes32(u32 codes)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(0u, 0x54474341u, codes);
+#else
+    u32 r = 0;
+    for (u32 k = 0; k < 4; ++k) r |= ((0x54474341u >> (8 * ((codes >> (8 * k)) & 3))) & 0xffu) << (8 * k);
+    return r;
+#endif
+}
+struct AlignQuad { u32 termAt; u32 matchFlags; u32 differFlags; };   // byte k: strand position k of the quad; termAt: quality, + 64 for a mismatch
+// readBytes: the BCL bytes of four consecutive strand positions (lowest position in the lowest byte); complement: 0x03030303 for a reverse read, else 0
+ISAAC_HD AlignQuad alignQuad(u32 readBytes, u32 complement, u32 referenceBytes)
+{
+    AlignQuad b;
+    const u32 nFlags = zeroBytes32(readBytes & (0xfc * QUAD_01));                       // no quality bits: the base is an N
+    const u32 codes = (readBytes & (0x03 * QUAD_01)) ^ complement;
+    const u32 nBytes = nFlags | (nFlags - (nFlags >> 7));                                 // 0xff under an N
+    const u32 strand = (asciiOfCodes32(codes) & ~nBytes) | ((0x6e * QUAD_01) & nBytes);   // 'n' for N
+    const u32 equalFlags = zeroBytes32(strand ^ referenceBytes);
+    const u32 referenceNFlags = zeroBytes32(referenceBytes ^ (0x4e * QUAD_01));
+    b.matchFlags = nFlags | (equalFlags & ~referenceNFlags);
+    b.differFlags = ~equalFlags & (0x80 * QUAD_01);
+    b.termAt = ((readBytes >> 2) & (0x3f * QUAD_01)) | (nFlags >> 6) | ((~b.matchFlags & (0x80 * QUAD_01)) >> 1);      // N: quality 2
+    return b;
+}
+// the eight bytes of a block in strand order, as two quads: the bytes as loaded (forward), or last byte first (reverse)
+ISAAC_HD void strandQuads(u64 loaded, bool reverse, u32 &first, u32 &second)
+{
+    const u32 lo = u32(loaded), hi = u32(loaded >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+    first = __builtin_amdgcn_perm(hi, lo, reverse ? 0x04050607u : 0x03020100u);
+    second = __builtin_amdgcn_perm(hi, lo, reverse ? 0x00010203u : 0x07060504u);
+#else
+    first = reverse ? __builtin_bswap32(hi) : lo; second = reverse ? __builtin_bswap32(lo) : hi;
+#endif
+}
+ISAAC_HD u32 flagCount32(u32 flags)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return u32(__popc(flags));
+#else
+    return u32(__builtin_popcount(flags));
+#endif
+}
 ISAAC_HD u32 flagCount(u64 flags)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -192,30 +242,79 @@ ISAAC_HD u32 updateFragmentCigar(const DevParams &P, const DevReference &R, cons
         {
             u32 matchesInARow = 0;
             u32 j = 0;
-            // whole blocks of eight while the read and the reference both have eight bytes left
-            while (j + 8 <= length && rs.pos + 8 <= rs.length && fs.p + 8 <= fs.end)
+            // whole blocks of eight while the read and the reference both have eight bytes left.  Four blocks' loads are in flight ahead of the
+            // arithmetic (a thread that asks for eight bytes, waits, and asks again spends the scan waiting: the kernels that do nothing but this
+            // were issuing instructions a sixth of the time)
+            u32 nBlocks = (length - j) / 8;
+            nBlocks = imin(nBlocks, rs.pos <= rs.length ? (rs.length - rs.pos) / 8 : 0u);
+            nBlocks = fs.p <= fs.end ? u32(imin(u64(nBlocks), u64(fs.end - fs.p) / 8)) : 0u;
+            if (nBlocks)
             {
-                u64 readBytes, referenceBytes;
-                if (reverse) { memcpy(&readBytes, rs.bcl + (rs.length - rs.pos - 8), 8); readBytes = reverseBytes(readBytes); }
-                else memcpy(&readBytes, rs.bcl + rs.pos, 8);
-                memcpy(&referenceBytes, fs.p, 8);
-                const AlignBlock blk = alignBlock(readBytes, reverse, referenceBytes);
+                const u8 *readAt = reverse ? rs.bcl + (rs.length - rs.pos - 8) : rs.bcl + rs.pos;       // block b: 8 b bytes further down (reverse) or up
+                const char *referenceAt = fs.p;
+                // (past the last block: the last block again, so that the load needs no branch; its bytes are not used)
+                const auto load = [&](u32 b, u64 &readBytes, u64 &referenceBytes)
+                {
+                    const size_t at = 8 * size_t(b < nBlocks ? b : nBlocks - 1);
+                    readBytes = loadBytes8(reverse ? readAt - at : readAt + at);
+                    referenceBytes = loadBytes8(referenceAt + at);
+                };
+                const u32 complement = reverse ? 0x03 * QUAD_01 : 0u;
+                // logMismatch behind logMatch in one table (the copies the kernels stage in LDS): a base's term is one read at quality + 64 * mismatch
+                const bool joined = R.logMismatch == R.logMatch + 64 * R.logStride;
+                const auto quad = [&](u32 readBytes, u32 referenceBytes)
+                {
+                    const AlignQuad q = alignQuad(readBytes, complement, referenceBytes);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-                for (u32 k = 0; k < 8; ++k)
+                    for (u32 k = 0; k < 4; ++k)
+                    {
+                        const u32 at = (q.termAt >> (8 * k)) & 0xffu;
+                        lp += joined ? R.logMatch[at * R.logStride] : (at & 64 ? R.logMismatch[(at & 63) * R.logStride] : R.logMatch[at * R.logStride]);
+                        matchesInARow = (matchesInARow + 1) & (0u - ((q.matchFlags >> (8 * k + 7)) & 1u));       // a mismatch: back to 0
+                        best = imax(best, matchesInARow);
+                    }
+                    const u32 matches = flagCount32(q.matchFlags);
+                    matchCount += matches; mismatchCount += 4 - matches;
+                    editDistance += flagCount32(q.differFlags);
+                };
+                const auto block = [&](u64 readBytes, u64 referenceBytes)
                 {
-                    const u32 q = u32(blk.quality >> (8 * k)) & 0xffu;
-                    const bool match = (blk.matchFlags >> (8 * k + 7)) & 1;
-                    lp += match ? R.logMatch[q * R.logStride] : R.logMismatch[q * R.logStride];
-                    matchesInARow = match ? matchesInARow + 1 : 0;
-                    best = imax(best, matchesInARow);
+                    u32 first, second;
+                    strandQuads(readBytes, reverse, first, second);
+                    quad(first, u32(referenceBytes)); quad(second, u32(referenceBytes >> 32));
+                };
+                const u32 mismatchesBefore = mismatchCount;
+#if !defined(ISAAC_SCAN_AHEAD)
+#define ISAAC_SCAN_AHEAD 1
+#endif
+#if ISAAC_SCAN_AHEAD == 4
+                u64 r0 = 0, r1 = 0, r2 = 0, r3 = 0, f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+                load(0, r0, f0); load(1, r1, f1); load(2, r2, f2); load(3, r3, f3);
+                for (u32 b = 0; b < nBlocks; b += 4)
+                {
+                    block(r0, f0); load(b + 4, r0, f0);
+                    if (b + 1 < nBlocks) { block(r1, f1); load(b + 5, r1, f1); }
+                    if (b + 2 < nBlocks) { block(r2, f2); load(b + 6, r2, f2); }
+                    if (b + 3 < nBlocks) { block(r3, f3); load(b + 7, r3, f3); }
                 }
-                const u32 matches = flagCount(blk.matchFlags);
-                matchCount += matches; mismatchCount += 8 - matches; sws += (8 - matches) * P.normalizedMismatchScore;
-                editDistance += flagCount(blk.differFlags);
-                rs.pos += 8; rs.avail = 0; fs.p += 8; fs.avail = 0;
-                j += 8;
+#elif ISAAC_SCAN_AHEAD == 2
+                u64 r0 = 0, r1 = 0, f0 = 0, f1 = 0;
+                load(0, r0, f0); load(1, r1, f1);
+                for (u32 b = 0; b < nBlocks; b += 2)
+                {
+                    block(r0, f0); load(b + 2, r0, f0);
+                    if (b + 1 < nBlocks) { block(r1, f1); load(b + 3, r1, f1); }
+                }
+#else
+                u64 r0 = 0, f0 = 0, r1 = 0, f1 = 0;
+                load(0, r0, f0);
+                for (u32 b = 0; b < nBlocks; ++b) { load(b + 1, r1, f1); block(r0, f0); r0 = r1; f0 = f1; }
+#endif
+                sws += (mismatchCount - mismatchesBefore) * P.normalizedMismatchScore;
+                rs.pos += 8 * nBlocks; rs.avail = 0; fs.p += 8 * size_t(nBlocks); fs.avail = 0;
+                j += 8 * nBlocks;
             }
             for (; length > j; ++j)
             {
