@@ -602,6 +602,17 @@ int isaac_gpu_upload(isaac_gpu_ctx *c, void *dev, const void *host, uint64_t byt
 { ISAAC_TRY HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
 int isaac_gpu_download(isaac_gpu_ctx *c, void *host, const void *dev, uint64_t bytes)
 { ISAAC_TRY HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
+int isaac_gpu_memory_info(isaac_gpu_ctx *c, uint64_t *freeOut, uint64_t *totalOut)
+{
+    ISAAC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    size_t f = 0, t = 0;
+    HIP_CHECK(hipMemGetInfo(&f, &t));
+    if (freeOut) *freeOut = f;
+    if (totalOut) *totalOut = t;
+    return 0;
+    ISAAC_CATCH
+}
 int isaac_gpu_copy(isaac_gpu_ctx *c, void *dstDev, const void *srcDev, uint64_t bytes)
 { ISAAC_TRY if (bytes) HIP_CHECK(hipMemcpyAsync(dstDev, srcDev, bytes, hipMemcpyDeviceToDevice, c->stream)); return 0; ISAAC_CATCH }
 // the candidate pool of a selection was sized from a match count that was too small (isaac_gpu_select_n): clusters past its end are flagged
@@ -621,7 +632,16 @@ static int checkPoolShort(isaac_gpu_ctx *c)
     }
     return fail(ISAAC_GPU_ECAPACITY, "n_matches given to isaac_gpu_select_n is smaller than the number of matches under cluster_offsets_dev: clusters beyond it have no candidates (overflow_clusters)");
 }
-int isaac_gpu_synchronize(isaac_gpu_ctx *c) { ISAAC_TRY HIP_CHECK(hipStreamSynchronize(c->stream)); return checkPoolShort(c); ISAAC_CATCH }
+// ISAAC_GPU_DEBUG_TIERS=1: the last chunk's cluster counts per tier of the probability sums, on stderr (measurement aid)
+static void debugTiers(isaac_gpu_ctx *c)
+{
+    static const bool on = std::getenv("ISAAC_GPU_DEBUG_TIERS") != nullptr;
+    if (!on || !c->heavyCount.p) return;
+    u32 n[8] = { 0 };
+    HIP_CHECK(hipMemcpy(n, c->heavyCount.p, sizeof(n), hipMemcpyDeviceToHost));
+    std::fprintf(stderr, "isaac_gpu tiers (last chunk): residual %u, lists > 16: %u, > 64: %u, > 1024: %u, > 3584: %u\n", n[0], n[4], n[1], n[3], n[2]);
+}
+int isaac_gpu_synchronize(isaac_gpu_ctx *c) { ISAAC_TRY HIP_CHECK(hipStreamSynchronize(c->stream)); debugTiers(c); return checkPoolShort(c); ISAAC_CATCH }
 int isaac_gpu_set_deferred_completion(isaac_gpu_ctx *c, int enabled)
 {
     ISAAC_TRY
@@ -1482,6 +1502,7 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
     u32 flag = 0;
     HIP_CHECK(hipMemcpyAsync(&flag, c->poolShort.p, 4, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
+    debugTiers(c);
     if (!(flag & 2) || (flag & 1) || attempt >= 3 || c->cigarExtra >= 2048) break;
     c->cigarExtra *= 4;
     HIP_CHECK(hipMemsetAsync(c->poolShort.p, 0, 4, st));

@@ -16,6 +16,15 @@
 namespace isaac
 {
 
+// -DISAAC_PROFILE_SUMS: the first clusters of the HBM tier print where their time goes (100 MHz ticks), timing experiments only
+#if defined(ISAAC_PROFILE_SUMS) && defined(__HIP_DEVICE_COMPILE__)
+#define SUMS_T0() long long sums_t = wall_clock64()
+#define SUMS_T(name, n) do { if (g.radix.counts && 0 == g.lane && blockIdx.x < 6) { const long long t = wall_clock64(); printf("sums block %u %s n %u: %lld\n", blockIdx.x, name, u32(n), t - sums_t); sums_t = wall_clock64(); } } while (0)
+#else
+#define SUMS_T0()
+#define SUMS_T(name, n)
+#endif
+
 // `cap` entries each, in LDS on the device
 struct SumKeys { u64 *pos1, *pos2; double *lp, *term; u32 *obs1, *obs2; u16 *idx; u32 cap; };
 ISAAC_HD u64 sumKeysBytes(u32 cap) { return u64(cap) * (8 + 8 + 8 + 8 + 4 + 4 + 2); }
@@ -95,6 +104,7 @@ ISAAC_HD bool sumKeyRestLess(const SumKeys &k, bool pairs, u32 a, u32 b)
 // Returns the array that holds the order (k.idx or g.radix.alt).
 ISAAC_HD const u16 *radixOrder(SumKeys &k, u32 n, bool pairs, const SumGroup &g)
 {
+    SUMS_T0();
     SumRadix r = g.radix;
     if (n > r.digitsCap) r.digits = nullptr;          // the close array holds digitsCap entries: longer lists gather from the key arrays
     const u32 per = (n + g.lanes - 1) / g.lanes, begin = imin(n, g.lane * per), end = imin(n, begin + per);
@@ -126,19 +136,38 @@ ISAAC_HD const u16 *radixOrder(SumKeys &k, u32 n, bool pairs, const SumGroup &g)
             if (r.digits) { for (u32 i = g.lane; i < n; i += g.lanes) r.digits[i] = u8((key[i] >> shift) & 15); groupSync(g); }
             for (u32 i = begin; i < end; ++i) ++r.counts[(r.digits ? u32(r.digits[src[i]]) : u32((key[src[i]] >> shift) & 15)) * g.lanes + g.lane];
             groupSync(g);
-            {   // exclusive prefix over the 16 x lanes counts, digit-major: a lane sums 16 consecutive ones, the lanes' sums are scanned in steps
+            {   // exclusive prefix over the 16 x lanes counts, digit-major: a lane sums 16 consecutive ones, the lanes' sums are scanned
                 u32 sum = 0;
                 for (u32 e = 0; e < 16; ++e) sum += r.counts[g.lane * 16 + e];
-                r.totals[g.lane] = sum;
-                groupSync(g);
-                for (u32 step = 1; step < g.lanes; step <<= 1)
-                {
-                    const u32 add = g.lane >= step ? r.totals[g.lane - step] : 0;
+                u32 running;
+#if defined(__HIP_DEVICE_COMPILE__)
+                if (g.block && 0 == (g.lanes & 63u))
+                {   // inside the wavefronts by shuffles, then the wavefronts' totals (at most 16 of them, read by everyone): two barriers
+                    // instead of the twenty of a scan in steps over 1024 lanes -- a list of thousands of entries has some ten such passes,
+                    // three lists a cluster, and nothing else to do while it waits
+                    u32 incl = sum;
+                    for (u32 o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o, 64); if ((g.lane & 63u) >= o) incl += v; }
+                    if (63u == (g.lane & 63u)) r.totals[g.lane >> 6] = incl;
                     groupSync(g);
-                    r.totals[g.lane] += add;
+                    u32 before = 0;
+                    for (u32 w = 0; w < (g.lane >> 6); ++w) before += r.totals[w];
                     groupSync(g);
+                    running = before + incl - sum;
                 }
-                u32 running = r.totals[g.lane] - sum;
+                else
+#endif
+                {
+                    r.totals[g.lane] = sum;
+                    groupSync(g);
+                    for (u32 step = 1; step < g.lanes; step <<= 1)
+                    {
+                        const u32 add = g.lane >= step ? r.totals[g.lane - step] : 0;
+                        groupSync(g);
+                        r.totals[g.lane] += add;
+                        groupSync(g);
+                    }
+                    running = r.totals[g.lane] - sum;
+                }
                 for (u32 e = 0; e < 16; ++e) { const u32 c = r.counts[g.lane * 16 + e]; r.counts[g.lane * 16 + e] = u16(running); running += c; }
             }
             groupSync(g);
@@ -147,6 +176,7 @@ ISAAC_HD const u16 *radixOrder(SumKeys &k, u32 n, bool pairs, const SumGroup &g)
             u16 *t = src; src = dst; dst = t;
         }
     }
+    SUMS_T("radix passes", n);
     // inside a run of equal positions: the place of an entry is the number of the run's entries before it.  With the digit array at hand
     // it first records which entries share their positions with their predecessor (independent loads, a lane per entry): the entries that
     // are runs of their own -- nearly all -- are in place already and need none of the dependent look-ups below
@@ -176,6 +206,7 @@ ISAAC_HD const u16 *radixOrder(SumKeys &k, u32 n, bool pairs, const SumGroup &g)
         dst[lo + before] = u16(e);
     }
     groupSync(g);
+    SUMS_T("runs", n);
     return dst;
 }
 
@@ -184,6 +215,7 @@ ISAAC_HD bool uniqueSortedSum(SumKeys &k, u32 n, bool pairs, const SumGroup &g, 
 {
     sum = 0.0;
     if (!n) return true;
+    SUMS_T0();
     const u16 *order = k.idx;
     const u8 *same = nullptr;                 // radixOrder leaves "same positions as the predecessor in the order" per entry when it has room for it
     if (g.radix.counts && n >= g.radixMin) { order = radixOrder(k, n, pairs, g); same = n <= g.radix.digitsCap ? g.radix.digits : nullptr; }
@@ -234,6 +266,7 @@ ISAAC_HD bool uniqueSortedSum(SumKeys &k, u32 n, bool pairs, const SumGroup &g, 
             groupSync(g);
         }
     }
+    SUMS_T("order", n);
     bool nearTie = false;
     for (u32 i = g.lane; i < n; i += g.lanes)
     {
@@ -244,6 +277,7 @@ ISAAC_HD bool uniqueSortedSum(SumKeys &k, u32 n, bool pairs, const SumGroup &g, 
     }
     if (groupAny(g, nearTie, scratch)) return false;
     groupSync(g);
+    SUMS_T("terms", n);
     if (g.sumTile)
     {   // the terms pass through LDS a tile at a time; the first wavefront adds them up, the others wait
         double acc = 0.0;
@@ -259,6 +293,7 @@ ISAAC_HD bool uniqueSortedSum(SumKeys &k, u32 n, bool pairs, const SumGroup &g, 
         groupSync(g);
         sum = g.sumTile[0];
         groupSync(g);
+        SUMS_T("add", n);
         return true;
     }
     sum = addInOrder(sum, k.term, n);                 // the additions in sequence: their order is part of the result (every lane: same value)
@@ -351,6 +386,7 @@ ISAAC_HD u32 clusterSums(const DevParams &P, const ClusterFragments &f, const Su
         if (!ok) return SUMS_RESIDUAL;
         if (0 == g.lane) cnt.rescueBsw += retries;
     }
+    SUMS_T0();
     const u32 nCands[2] = { f.nCands[0], f.nCands[1] };
     u32 shadows[2] = { 0, 0 };
     for (u32 j = 0; j < in.nJobs; ++j) shadows[(in.jobs[j].shadowReadIndex + 1) % 2] += in.jobs[j].take;
@@ -369,6 +405,7 @@ ISAAC_HD u32 clusterSums(const DevParams &P, const ClusterFragments &f, const Su
         }
         for (u32 i = g.lane; i < nCands[1 - side]; i += g.lanes) sumKeyFromCand(k, base + i, f.cands[1 - side][i]);
         groupSync(g);
+        SUMS_T("gather", in.nJobs);
         if (!uniqueSortedSum(k, base + nCands[1 - side], false, g, scratch, out.shadow[side])) return SUMS_NEAR_TIE;
     }
     if (bothReads)

@@ -85,7 +85,7 @@ bool fileExists(const std::string &path) { struct stat st; return 0 == ::stat(pa
 struct Reference
 {
     std::vector<isaac_reference_contig> contigs;      // karyotype order: the order of the BAM header and of contig ids in the records
-    std::string bases; std::vector<uint64_t> offsets;
+    std::unique_ptr<char[]> bases; uint64_t totalBases = 0; std::vector<uint64_t> offsets;
 };
 
 Reference loadReference(const std::string &xmlPath)
@@ -102,34 +102,53 @@ Reference loadReference(const std::string &xmlPath)
     if (isaac_gpu_sorted_reference_parse(xml.data(), xml.size(), ref.contigs.data(), nContigs, &nContigs, masks.data(), nMasks, &nMasks, &version))
         throw std::runtime_error(xmlPath + ": " + isaac_gpu_sorted_reference_last_error());
     std::sort(ref.contigs.begin(), ref.contigs.end(), [](const isaac_reference_contig &a, const isaac_reference_contig &b) { return a.karyotype_index < b.karyotype_index; });
-    // reference::loadContig: the alphabetic characters from the contig's offset on, ACGT as they are (upper case), everything else N
+    // reference::loadContig: the alphabetic characters from the contig's offset on, ACGT as they are (upper case), everything else N.
+    // The contigs are read side by side, a thread each at a time (a human genome is three billion bytes to look at: a minute for one
+    // thread pushing them one by one into a string, a second for the machine's cores translating them through a table into place).
     ref.offsets.push_back(0);
-    for (const isaac_reference_contig &c : ref.contigs)
+    for (const isaac_reference_contig &c : ref.contigs) ref.offsets.push_back(ref.offsets.back() + c.total_bases);
+    ref.totalBases = ref.offsets.back();
+    ref.bases.reset(new char[ref.totalBases ? ref.totalBases : 1]);
+    unsigned char translate[256];
+    for (unsigned b = 0; b < 256; ++b)
     {
-        std::string path = c.file;
-        if (!fileExists(path) && '/' != path[0] && fileExists(directoryOf(xmlPath) + "/" + path)) path = directoryOf(xmlPath) + "/" + path;
-        std::ifstream fasta(path.c_str(), std::ios::binary);
-        if (!fasta) throw std::runtime_error("Failed to open reference file " + path);
-        if (!fasta.seekg(std::streamoff(c.offset))) throw std::runtime_error("Failed to reach offset " + std::to_string(c.offset) + " in reference file " + path);
-        const size_t before = ref.bases.size();
-        ref.bases.reserve(before + c.total_bases);
-        std::vector<char> buffer(1 << 20);
-        while (ref.bases.size() - before < c.total_bases && fasta)
-        {
-            fasta.read(buffer.data(), std::streamsize(buffer.size()));
-            const std::streamsize got = fasta.gcount();
-            for (std::streamsize i = 0; i < got && ref.bases.size() - before < c.total_bases; ++i)
-            {
-                const unsigned char b = static_cast<unsigned char>(buffer[size_t(i)]);
-                if (!std::isalpha(b)) continue;
-                const char u = char(std::toupper(b));
-                ref.bases.push_back(('A' == u || 'C' == u || 'G' == u || 'T' == u) ? u : 'N');
-            }
-        }
-        if (ref.bases.size() - before != c.total_bases)
-            throw std::runtime_error("Failed to read " + std::to_string(c.total_bases) + " bases from reference file " + path + ": " + std::to_string(ref.bases.size() - before));
-        ref.offsets.push_back(ref.bases.size());
+        const char u = char(std::toupper(int(b)));
+        translate[b] = !std::isalpha(int(b)) ? 0 : ('A' == u || 'C' == u || 'G' == u || 'T' == u) ? static_cast<unsigned char>(u) : static_cast<unsigned char>('N');
     }
+    std::atomic<size_t> next(0);
+    std::mutex errorLock; std::string error;
+    const auto work = [&]()
+    {
+        std::vector<char> buffer(size_t(4) << 20);
+        for (size_t k = next++; k < ref.contigs.size(); k = next++)
+            try
+            {
+                const isaac_reference_contig &c = ref.contigs[k];
+                std::string path = c.file;
+                if (!fileExists(path) && '/' != path[0] && fileExists(directoryOf(xmlPath) + "/" + path)) path = directoryOf(xmlPath) + "/" + path;
+                std::ifstream fasta(path.c_str(), std::ios::binary);
+                if (!fasta) throw std::runtime_error("Failed to open reference file " + path);
+                if (!fasta.seekg(std::streamoff(c.offset))) throw std::runtime_error("Failed to reach offset " + std::to_string(c.offset) + " in reference file " + path);
+                char *out = ref.bases.get() + ref.offsets[k];
+                uint64_t have = 0;
+                while (have < c.total_bases && fasta)
+                {
+                    fasta.read(buffer.data(), std::streamsize(buffer.size()));
+                    const size_t got = size_t(fasta.gcount());
+                    for (size_t i = 0; i < got && have < c.total_bases; ++i)
+                    {
+                        const unsigned char t = translate[static_cast<unsigned char>(buffer[i])];
+                        out[have] = char(t); have += t ? 1 : 0;
+                    }
+                }
+                if (have != c.total_bases) throw std::runtime_error("Failed to read " + std::to_string(c.total_bases) + " bases from reference file " + path + ": " + std::to_string(have));
+            }
+            catch (const std::exception &e) { std::lock_guard<std::mutex> hold(errorLock); if (error.empty()) error = e.what(); }
+    };
+    std::vector<std::thread> threads;
+    for (unsigned t = 0; t < std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), std::max<size_t>(1, ref.contigs.size())); ++t) threads.emplace_back(work);
+    for (std::thread &t : threads) t.join();
+    if (!error.empty()) throw std::runtime_error(error);
     return ref;
 }
 
@@ -189,8 +208,11 @@ uint32_t loadRead(isaac_gpu_ctx *ctx, ReadStream &stream, unsigned readIndex, bo
 // One bin per contig and one for the templates without a position: the bins of the BAM stage (duplicates and realignment never look across
 // contigs).  A tile leaves one part in every bin it has records in (isaac_gpu_bin_tile): BCL bytes, records and CIGAR words of the clusters
 // concerned, about 150 + 2 x read length bytes per read.  That is the run's memory model: HBM holds the table, the BCL bytes of the loads
-// until their tiles are selected, one tile's scratch and -- in the build stage -- one bin at a time; host memory holds the bins.
-struct BinPart { const Tile *tile; uint64_t clusters, words, bytes; std::unique_ptr<uint8_t[]> data; };
+// until their tiles are selected, one tile's scratch and -- in the build stage -- one bin at a time.  The bins' parts stay where isaac_gpu_bin_tile
+// wrote them, a block of device memory per tile, for as long as the device has room beside what the build stage will want (a quarter of its
+// memory is left alone); the tiles after that leave their parts in host memory.  A part on the device goes into its bin's BAM stage as it
+// lies there, no copy in either direction: on a 288 GB device that is every run of up to some 250 million pairs.
+struct BinPart { const Tile *tile; uint64_t clusters, words, bytes; std::unique_ptr<uint8_t[]> data; std::shared_ptr<DeviceMemory> block; uint64_t offset = 0; int device = -1; };
 struct Bin { std::mutex lock; std::vector<BinPart> parts; uint64_t bytes = 0, records = 0; };
 
 uint64_t align64(uint64_t v) { return (v + 63) & ~uint64_t(63); }
@@ -205,7 +227,8 @@ struct Worker
     DeviceMemory matches, offsets, textDev;
     uint64_t matchCapacity = 0;
     isaac_counters counters;
-    double selectSeconds = 0, buildSeconds = 0;
+    uint64_t tilesKeptOnDevice = 0;
+    double selectSeconds = 0, buildSeconds = 0, uploadSeconds = 0, recordsSeconds = 0, deflateSeconds = 0, downloadSeconds = 0;
     ~Worker() { loads.clear(); matches.release(); offsets.release(); textDev.release(); if (ctx) isaac_gpu_destroy(ctx); }
 };
 
@@ -242,23 +265,27 @@ int run(const AlignOptions &o)
     const std::vector<int> devices = o.deviceList();
     std::vector<std::unique_ptr<Worker> > workers;
     Reference reference;
+    double fastaSeconds = 0, contigSeconds = 0, tableSeconds = 0;
     {
         Stage stage("loading the reference");
         reference = loadReference(o.referenceGenome);
+        fastaSeconds = seconds() - runStart;
         for (size_t k = 0; k < devices.size(); ++k)
         {
             workers.emplace_back(new Worker);
             Worker &w = *workers.back();
             w.device = devices[k]; w.id = unsigned(k);
             GPU(isaac_gpu_create(w.device, &params, ISAAC_GPU_STREAM_OWN, &w.ctx));
-            GPU(isaac_gpu_load_contigs(w.ctx, reference.bases.data(), reference.offsets.data(), uint32_t(reference.contigs.size())));
-            if (0 == k) { GPU(isaac_gpu_load_sorted_reference(w.ctx, o.referenceGenome.c_str())); continue; }
+            const double contigStart = seconds();
+            GPU(isaac_gpu_load_contigs(w.ctx, reference.bases.get(), reference.offsets.data(), uint32_t(reference.contigs.size())));
+            contigSeconds += seconds() - contigStart;
+            if (0 == k) { const double tableStart = seconds(); GPU(isaac_gpu_load_sorted_reference(w.ctx, o.referenceGenome.c_str())); tableSeconds = seconds() - tableStart; continue; }
             // the first worker of a device that is not the first worker's gets a copy of the table, everybody else reads one that is there
             Worker *sameDevice = 0;
             for (size_t j = 0; j < k && !sameDevice; ++j) if (workers[j]->device == w.device) sameDevice = workers[j].get();
             GPU(isaac_gpu_share_index(w.ctx, sameDevice ? sameDevice->ctx : workers[0]->ctx));
         }
-        std::string().swap(reference.bases);
+        reference.bases.reset();
     }
     const uint32_t nContigs = uint32_t(reference.contigs.size());
     if (nContigs + 1 > 255) throw std::runtime_error("this host keeps one bin per contig: at most 254 contigs");
@@ -374,6 +401,7 @@ int run(const AlignOptions &o)
             }
         }
         std::vector<std::string> errors(workers.size());
+        const bool hostBins = 0 != std::getenv("ISAAC_ALIGN_HOST_BINS");          // tests: every part through host memory
         auto selectTiles = [&](Worker &w)
         {
             try
@@ -412,6 +440,14 @@ int run(const AlignOptions &o)
                                                 sizes.data(), &need);
                     }
                     check(rc, "isaac_gpu_bin_tile");
+                    // the tile's parts stay on the device while it has room (see BinPart)
+                    std::shared_ptr<DeviceMemory> block;
+                    {
+                        uint64_t freeBytes = 0, totalBytes = 0;
+                        GPU(isaac_gpu_memory_info(w.ctx, &freeBytes, &totalBytes));
+                        if (!hostBins && freeBytes > totalBytes / 4 + binned.bytes()) { block = std::make_shared<DeviceMemory>(std::move(binned)); ++w.tilesKeptOnDevice; }
+                    }
+                    const uint8_t *binnedBytes = block ? block->as<uint8_t>() : binned.as<uint8_t>();
                     uint64_t at = 0;
                     for (uint32_t b = 0; b <= nContigs; ++b)
                     {
@@ -419,8 +455,13 @@ int run(const AlignOptions &o)
                         const uint64_t bytes = align64(align64(m * clusterLength) + m * nReads * sizeof(isaac_fragment)) + align64(cw * 4);
                         if (m)
                         {
-                            BinPart part; part.tile = &t; part.clusters = m; part.words = cw; part.bytes = bytes; part.data.reset(new uint8_t[bytes]);
-                            GPU(isaac_gpu_download(w.ctx, part.data.get(), binned.as<uint8_t>() + at, bytes));
+                            BinPart part; part.tile = &t; part.clusters = m; part.words = cw; part.bytes = bytes;
+                            if (block) { part.block = block; part.offset = at; part.device = w.device; }
+                            else
+                            {
+                                part.data.reset(new uint8_t[bytes]);
+                                GPU(isaac_gpu_download(w.ctx, part.data.get(), binnedBytes + at, bytes));
+                            }
                             std::lock_guard<std::mutex> guard(bins[b].lock);
                             bins[b].bytes += bytes; bins[b].records += m * nReads;
                             bins[b].parts.push_back(std::move(part));
@@ -516,28 +557,48 @@ int run(const AlignOptions &o)
         for (size_t k = nextBin++; k < fileOrder.size(); k = nextBin++)
         {
             BinOutput result;
+            double mark = seconds();
+            const auto lap = [&mark](double &into) { const double now = seconds(); into += now - mark; mark = now; };
             try
             {
                 Bin &bin = bins[fileOrder[k]];
                 if (!bin.parts.empty())
                 {
                     // the bin's parts to the device, each the three arrays of a tile
-                    if (data.bytes() < bin.bytes) data.reset(w.ctx, bin.bytes);
+                    // parts that lie on this device are used where they are; the others -- in host memory, or on another worker's device --
+                    // come into one buffer
+                    uint64_t foreignBytes = 0;
+                    for (const BinPart &part : bin.parts) if (!part.block || part.device != w.device) foreignBytes += part.bytes;
+                    if (data.bytes() < foreignBytes) data.reset(w.ctx, foreignBytes);
                     std::vector<isaac_bam_tile> bamTiles(bin.parts.size());
+                    std::unique_ptr<uint8_t[]> staging; uint64_t stagingBytes = 0;
                     uint64_t at = 0;
                     for (size_t i = 0; i < bin.parts.size(); ++i)
                     {
                         BinPart &part = bin.parts[i];
-                        GPU(isaac_gpu_upload(w.ctx, data.as<uint8_t>() + at, part.data.get(), part.bytes));
-                        part.data.reset();
+                        uint8_t *base = 0;
+                        if (part.block && part.device == w.device) base = part.block->as<uint8_t>() + part.offset;
+                        else
+                        {
+                            base = data.as<uint8_t>() + at;
+                            if (part.block)
+                            {   // (through the host: the other device's context is busy with bins of its own)
+                                if (stagingBytes < part.bytes) { staging.reset(new uint8_t[part.bytes]); stagingBytes = part.bytes; }
+                                GPU(isaac_gpu_download(part.tile->worker->ctx, staging.get(), part.block->as<uint8_t>() + part.offset, part.bytes));
+                                GPU(isaac_gpu_upload(w.ctx, base, staging.get(), part.bytes));
+                                part.block.reset();
+                            }
+                            else { GPU(isaac_gpu_upload(w.ctx, base, part.data.get(), part.bytes)); part.data.reset(); }
+                            at += part.bytes;
+                        }
                         isaac_bam_tile &b = bamTiles[i];
-                        b.bcl_dev = data.as<uint8_t>() + at;
-                        b.fragments_dev = reinterpret_cast<const isaac_fragment *>(data.as<uint8_t>() + at + align64(part.clusters * clusterLength));
-                        b.cigar_dev = reinterpret_cast<const uint32_t *>(data.as<uint8_t>() + at + align64(align64(part.clusters * clusterLength) + part.clusters * nReads * sizeof(isaac_fragment)));
+                        b.bcl_dev = base;
+                        b.fragments_dev = reinterpret_cast<const isaac_fragment *>(base + align64(part.clusters * clusterLength));
+                        b.cigar_dev = reinterpret_cast<const uint32_t *>(base + align64(align64(part.clusters * clusterLength) + part.clusters * nReads * sizeof(isaac_fragment)));
                         b.n_records = part.clusters * nReads;
                         b.read_name_prefix = part.tile->namePrefix.c_str(); b.read_group = part.tile->readGroup.c_str(); b.tls = &part.tile->tls;
-                        at += part.bytes;
                     }
+                    lap(w.uploadSeconds);
                     isaac_bam_options options = bamOptions;
                     if (fileOrder[k] == nContigs) { options.bin_first_contig = 0; options.bin_end_contig = 0; options.bin_unaligned = 1; }
                     else { options.bin_first_contig = fileOrder[k]; options.bin_end_contig = fileOrder[k] + 1; options.bin_unaligned = 0; }
@@ -552,6 +613,7 @@ int run(const AlignOptions &o)
                         rc = isaac_gpu_bam_records(w.ctx, bamTiles.data(), uint32_t(bamTiles.size()), &options, bam.as<uint8_t>(), bam.bytes(), &nBytes, &result.nRecords, &unalignedOffset);
                     }
                     check(rc, "isaac_gpu_bam_records");
+                    lap(w.recordsSeconds);
                     if (nBytes)
                     {
                         // BGZF on the device: stored blocks at level 0 (bgzf::BgzfCompressor's own), deflated ones otherwise
@@ -560,10 +622,12 @@ int run(const AlignOptions &o)
                         uint64_t nOut = 0;
                         if (o.bamGzipLevel) GPU(isaac_gpu_bgzf_deflate(w.ctx, bam.as<uint8_t>(), nBytes, 0, bgzf.as<uint8_t>(), bgzf.bytes(), &nOut));
                         else GPU(isaac_gpu_bgzf_store(w.ctx, bam.as<uint8_t>(), nBytes, 0, bgzf.as<uint8_t>(), bgzf.bytes(), &nOut));
+                        lap(w.deflateSeconds);
                         result.bgzf.reset(new uint8_t[nOut]); result.bgzfBytes = nOut; result.recordsBytes = nBytes;
                         result.entries.reset(new isaac_bam_index_entry[result.nRecords]);
                         GPU(isaac_gpu_download(w.ctx, result.bgzf.get(), bgzf.as<uint8_t>(), nOut));
                         GPU(isaac_gpu_download(w.ctx, result.entries.get(), entries.as<isaac_bam_index_entry>(), result.nRecords * sizeof(isaac_bam_index_entry)));      // for the index
+                        lap(w.downloadSeconds);
                     }
                     std::vector<BinPart>().swap(bin.parts);
                 }
@@ -582,6 +646,7 @@ int run(const AlignOptions &o)
     makeDirectories(directory);
     const std::string bamPath = directory + "/sorted.bam";
     uint64_t nRecordsWritten = 0, binsWritten = 0;
+    double writeSeconds = 0;
     std::string failure;
     {
         std::ofstream os(bamPath.c_str(), std::ios::binary | std::ios::trunc);
@@ -598,7 +663,9 @@ int run(const AlignOptions &o)
             }
             if (!out.error.empty() && failure.empty()) failure = out.error;
             if (!failure.empty() || !out.bgzfBytes) continue;
+            const double writeStart = seconds();
             os.write(reinterpret_cast<const char *>(out.bgzf.get()), std::streamsize(out.bgzfBytes));
+            writeSeconds += seconds() - writeStart;
             if (isaac_gpu_bam_indexer_add_entries(indexer, out.entries.get(), out.nRecords, out.recordsBytes, out.bgzf.get(), out.bgzfBytes)) failure = std::string("isaac_gpu_bam_indexer_add_entries: ") + isaac_gpu_bam_index_last_error();
             nRecordsWritten += out.nRecords; ++binsWritten;
         }
@@ -621,10 +688,14 @@ int run(const AlignOptions &o)
     }
     if (!failure.empty()) throw std::runtime_error(failure);
     const double buildSeconds = seconds() - buildStart, total = seconds() - runStart;
+    uint64_t tilesOnDevice = 0;
+    for (auto &w : workers) tilesOnDevice += w->tilesKeptOnDevice;
     std::cerr << "isaac-align: " << bamPath << ": " << nRecordsWritten << " records in " << binsWritten << " bin(s)" << std::endl;
     // one line for scripts (bench.py): what the run took, stage by stage
     std::cerr << "isaac-align: timing {\"clusters\": " << totalClusters << ", \"reads\": " << totalClusters * nReads << ", \"records\": " << nRecordsWritten << ", \"workers\": " << workers.size()
-              << ", \"reference_s\": " << referenceSeconds << ", \"load_and_find_s\": " << loadSeconds << ", \"select_and_bin_s\": " << selectSeconds << ", \"build_and_write_s\": " << buildSeconds
+              << ", \"reference_s\": " << referenceSeconds << ", \"reference_fasta_s\": " << fastaSeconds << ", \"reference_contigs_s\": " << contigSeconds << ", \"reference_table_s\": " << tableSeconds << ", \"load_and_find_s\": " << loadSeconds << ", \"select_and_bin_s\": " << selectSeconds << ", \"build_and_write_s\": " << buildSeconds
+              << ", \"tiles_kept_on_device\": " << tilesOnDevice << ", \"build_upload_s\": " << workers[0]->uploadSeconds << ", \"build_records_s\": " << workers[0]->recordsSeconds << ", \"build_deflate_s\": " << workers[0]->deflateSeconds
+              << ", \"build_download_s\": " << workers[0]->downloadSeconds << ", \"file_write_s\": " << writeSeconds
               << ", \"total_s\": " << total << "}" << std::endl;
     return 0;
 }

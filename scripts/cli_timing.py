@@ -2,7 +2,8 @@
 """Times the two programs end to end: a human-like genome written as FASTA -> isaac-sort-reference -> synthetic pairs written as two FASTQ
 files (plain) -> isaac-align with the reference's defaults.  Prints the stage lines of both programs and one JSON line (cli_end_to_end).
 CLI_GENOME_BASES (1e8), CLI_PAIRS (1e6), CLI_READ_LENGTH (101), CLI_WORK (a directory to work in: /dev/shm/... keeps the 47 GB of mask files
-of a GRCh38-sized reference off the disk), CLI_ARGS (more isaac-align options, e.g. "--clusters-at-a-time 4000000 --devices 0,0")"""
+of a GRCh38-sized reference off the disk), CLI_ARGS (more isaac-align options, e.g. "--clusters-at-a-time 4000000 --devices 0,0"; several sets separated
+by ";" run isaac-align once each)"""
 import os, subprocess, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -42,13 +43,15 @@ def main():
     print("FASTQ written in %.1f s (%d MB)" % (time.time() - t0, 2 * n_pairs * (21 + 8 + 4 + 2 * L) // 1000000), flush=True)
     ref_dir = os.path.join(work, "ref")
     tools = os.path.dirname(build.build_host())
-    for name, cmd in (("isaac-sort-reference", [os.path.join(tools, "isaac-sort-reference"), "-g", fasta, "-o", ref_dir, "-q"]),
-                      ("isaac-align", [os.path.join(tools, "isaac-align"), "-r", os.path.join(ref_dir, "sorted-reference.xml"), "-b", calls, "--base-calls-format", "fastq", "-o", os.path.join(work, "Aligned")]
-                       + os.environ.get("CLI_ARGS", "").split())):
+    # CLI_ARGS may hold several option sets separated by ';': isaac-align runs once for each, on the same files
+    runs = [("isaac-sort-reference", [os.path.join(tools, "isaac-sort-reference"), "-g", fasta, "-o", ref_dir, "-q"])]
+    for extra in os.environ.get("CLI_ARGS", "").split(";"):
+        runs.append(("isaac-align", [os.path.join(tools, "isaac-align"), "-r", os.path.join(ref_dir, "sorted-reference.xml"), "-b", calls, "--base-calls-format", "fastq", "-o", os.path.join(work, "Aligned")] + extra.split()))
+    for name, cmd in runs:
         t0 = time.time()
         r = subprocess.run(cmd, capture_output=True, text=True)
         wall = time.time() - t0
-        print("%s: rc %d, %.1f s" % (name, r.returncode, wall))
+        print("%s: rc %d, %.1f s%s" % (name, r.returncode, wall, "  [" + " ".join(cmd[9:]) + "]" if name == "isaac-align" else ""))
         print("\n".join(l for l in r.stderr.splitlines() if "done in" in l or "records" in l or "clusters in" in l or "error" in l.lower() or "timing" in l), flush=True)
         if name == "isaac-align" and r.returncode == 0:
             import json

@@ -5,6 +5,7 @@ On the GPU: a two-lane FASTQ flowcell through the binary, sorted.bam and sorted.
 same inputs (reader, seed lookup, template statistics per lane, selection, duplicate marking, gap realignment, record stream, index)."""
 import ctypes as C
 import gzip
+import json
 import os
 import subprocess
 import zlib
@@ -22,8 +23,8 @@ def host():
     return build.build_host()
 
 
-def run_host(*args, cwd=None):
-    return subprocess.run([host()] + [str(a) for a in args], capture_output=True, text=True, cwd=cwd)
+def run_host(*args, cwd=None, env=None):
+    return subprocess.run([host()] + [str(a) for a in args], capture_output=True, text=True, cwd=cwd, env=dict(os.environ, **env) if env else None)
 
 
 # ---- options ---------------------------------------------------------------------------------------------------------------------------
@@ -260,6 +261,9 @@ SCENARIOS = {
                     paired=True, mark=False, keep=True, realign=False, unaligned="front", dodgy=255, pu="%s.%d"),
     # two workers (contexts, threads) on the one device: loads, tiles and bins dealt between them, one file all the same
     "two-workers": dict(compressed=False, lengths=(100, 100), cli=["--devices", "0,0"], paired=True, mark=True, keep=True, realign=True, unaligned="back", dodgy=0, pu="%s:%d:none"),
+    # the bins' parts through host memory (what a run too large for the device's memory does), two workers
+    "host-bins": dict(compressed=False, lengths=(100, 100), cli=["--devices", "0,0"], paired=True, mark=True, keep=True, realign=True, unaligned="back", dodgy=0, pu="%s:%d:none",
+                      env={"ISAAC_ALIGN_HOST_BINS": "1"}),
     # single-ended lanes, unaligned reads left out
     # ... on a reference made by bin/isaac-sort-reference from the FASTA file
     "single-ended": dict(compressed=True, lengths=(100,), cli=["--keep-unaligned", "discard"], paired=False, mark=True, keep=True, realign=True, unaligned="discard", dodgy=0, pu="%s:%d:none",
@@ -345,9 +349,11 @@ def test_gpu_isaac_align_end_to_end(tmp_path, scenario):
     out = tmp_path / "Aligned"
     args = ["-r", xml, "-b", str(calls), "--base-calls-format", "fastq-gz" if compressed else "fastq", "-o", str(out), "--clusters-at-a-time", str(at_a_time), "-j", "4",
             "--bam-header-tag", "@CO\tend to end", "--description", "cli test", "-t", str(tmp_path / "Temp")] + sc["cli"]
-    r = run_host(*args)
+    r = run_host(*args, env=sc.get("env"))
     assert r.returncode == 0, r.stderr
     assert not (tmp_path / "Temp").exists()
+    kept = json.loads([l for l in r.stderr.splitlines() if "timing {" in l][-1].split("timing ", 1)[1])["tiles_kept_on_device"]
+    assert kept == (0 if sc.get("env") else sum(-(-len(bcl) // at_a_time) for _, bcl in lanes))        # every tile's parts stayed on the device, or none did
     # ---- the oracle on the same inputs
     b = gpu.Aligner(options.default_params(100, 100), 0, contigs)
     b.load_sorted_reference(xml)
