@@ -74,7 +74,10 @@ __device__ inline u32 bswLaneOfThread() { return (threadIdx.x & 15u) >> 1; }
 // deletion.  T: bswFlagBytes(L) bytes of LDS, endVals: 48 shorts of LDS, both private to the group.  The 8 lanes are part of one
 // wave, so LDS traffic between them needs no workgroup barrier.
 // PADDED: query[L] and database[L + 16] may be read (staged copies with room behind them): the look-ahead then needs no clamping
-template <bool PADDED = false, typename QueryF>
+// GLOBAL_FLAGS: T is device memory, not LDS (1.8 KB of flags per problem at 2 x 150 limit the wavefronts a CU holds to two per SIMD, and a row is
+// a chain of dependent packed and DPP instructions that would like more of them to hide behind).  The stores are plain, the traceback's reads go to
+// the L2 (agent scope) behind a release fence: they are other lanes' stores.  An experiment that lost (kernels.h: ISAAC_BSW_GLOBAL_FLAGS).
+template <bool PADDED = false, bool GLOBAL_FLAGS = false, typename QueryF>
 __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapOpenScore, int gapExtendScore, QueryF query, u32 L, const char *database,
                                      u8 *T, short *endVals, u32 l, u32 *cig, u32 cap, u32 &n, bool &overflow)
 {
@@ -88,19 +91,31 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
     const int ext = gapExtendScore;
     const int kExtLo = int(2 * l) * ext, kExtHi = int(2 * l + 1) * ext, k1ExtHi = int(2 * l + 2) * ext;        // k1Ext of the low cell = kExtHi
     int d2 = int(u8(database[15 - 2 * l])) | (int(u8(database[14 - 2 * l])) << 16);            // cell k of row i looks at database[i + 15 - k]
-    // Traceback flags: 6 bits per cell (which of G / E / F each of the three came from), 12 per lane and row, four rows of a lane in three
-    // 16-bit stores: 12 bytes of LDS per row and alignment (16 with a byte per cell: a fifth fewer workgroups per CU at 2x150).
-    // Block b (rows 4b .. 4b + 3), lane l: 48 bits at T + 48 b + 6 l, row j's 12 bits at bit 12 j (low cell first).
-    const auto storeFlags = [&](u32 block, u32 f0, u32 f1, u32 f2, u32 f3)
+    // Traceback flags: 6 bits per cell (which of G / E / F each of the three came from), 12 per lane and row, eight rows of a lane in one
+    // 12-byte store: 12 bytes per row and alignment (16 with a byte per cell).
+    // Block b (rows 8b .. 8b + 7), lane l: 96 bits at T + 96 b + 12 l, row j's 12 bits at bit 12 j (low cell first).
+    const auto storeFlags = [&](u32 block, const u32 (&f)[8])
     {
-        u16 *to = reinterpret_cast<u16 *>(T) + block * 24 + l * 3;
-        to[0] = u16(f0 | (f1 << 12)); to[1] = u16((f1 >> 4) | (f2 << 8)); to[2] = u16((f2 >> 8) | (f3 << 4));
+        const u32 w0 = f[0] | (f[1] << 12) | (f[2] << 24), w1 = (f[2] >> 8) | (f[3] << 4) | (f[4] << 16) | (f[5] << 28), w2 = (f[5] >> 4) | (f[6] << 8) | (f[7] << 20);
+        if constexpr (GLOBAL_FLAGS)
+        {
+            typedef __attribute__((address_space(1))) u32 GlobalU32;
+            GlobalU32 *to = (GlobalU32 *)(reinterpret_cast<u32 *>(T)) + block * 24 + l * 3;
+            to[0] = w0; to[1] = w1; to[2] = w2;
+        }
+        else { u32 *to = reinterpret_cast<u32 *>(T) + block * 24 + l * 3; to[0] = w0; to[1] = w1; to[2] = w2; }
     };
     const auto flagsAt = [&](int r, int cell) -> u32
     {
-        const u32 bit = u32(r & 3) * 12 + u32(cell & 1) * 6;
-        const u8 *at = T + u32(r >> 2) * 48 + u32(cell >> 1) * 6 + (bit >> 3);
-        return ((u32(at[0]) | (u32(at[1]) << 8)) >> (bit & 7)) & 0x3fu;
+        const u32 bit = u32(r & 7) * 12 + u32(cell & 1) * 6;
+        const u8 *at = T + u32(r >> 3) * 96 + u32(cell >> 1) * 12 + (bit >> 3);
+        u32 b0, b1;
+        if constexpr (GLOBAL_FLAGS)
+        {
+            b0 = __hip_atomic_load(at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); b1 = __hip_atomic_load(at + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        else { b0 = at[0]; b1 = at[1]; }
+        return ((b0 | (b1 << 8)) >> (bit & 7)) & 0x3fu;
     };
     // one row of the band: q = the row's query base, dIn = the database base that enters the band behind it (database[i + 16])
     const auto bandRow = [&](int q, int dIn) -> u32
@@ -159,24 +174,41 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
         // every row wait for the row's flag store as well: the waits the compiler places at a loop's head cover everything in flight.)
         const u32 *q4 = reinterpret_cast<const u32 *>(query.q), *d4 = reinterpret_cast<const u32 *>(database + 16);
         u32 qw = q4[0], dw = d4[0], i = 0;
+        u32 f[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
         for (; i + 4 <= L; i += 4)
         {
             u32 qn = q4[(i >> 2) + 1], dn = d4[(i >> 2) + 1];
-            const u32 f0 = bandRow(int(qw & 0xffu), int(dw & 0xffu));
-            const u32 f1 = bandRow(int((qw >> 8) & 0xffu), int((dw >> 8) & 0xffu));
-            const u32 f2 = bandRow(int((qw >> 16) & 0xffu), int((dw >> 16) & 0xffu));
-            const u32 f3 = bandRow(int(qw >> 24), int(dw >> 24));
-            storeFlags(i >> 2, f0, f1, f2, f3);
-            // "used" here, so that the wait for the two reads stands here and counts the four stores behind them as allowed to be in
-            // flight; at the loop's head it would wait for everything (three stores now)
+            const u32 h = i & 4;
+            if (h)
+            {
+                f[4] = bandRow(int(qw & 0xffu), int(dw & 0xffu));
+                f[5] = bandRow(int((qw >> 8) & 0xffu), int((dw >> 8) & 0xffu));
+                f[6] = bandRow(int((qw >> 16) & 0xffu), int((dw >> 16) & 0xffu));
+                f[7] = bandRow(int(qw >> 24), int(dw >> 24));
+                storeFlags(i >> 3, f);
+            }
+            else
+            {
+                f[0] = bandRow(int(qw & 0xffu), int(dw & 0xffu));
+                f[1] = bandRow(int((qw >> 8) & 0xffu), int((dw >> 8) & 0xffu));
+                f[2] = bandRow(int((qw >> 16) & 0xffu), int((dw >> 16) & 0xffu));
+                f[3] = bandRow(int(qw >> 24), int(dw >> 24));
+            }
+            // "used" here, so that the wait for the two reads stands here and counts the stores behind them as allowed to be in
+            // flight; at the loop's head it would wait for everything
             asm volatile("" : "+v"(qn), "+v"(dn));
             qw = qn; dw = dn;
         }
-        if (i < L)
-        {   // the last one to three rows
-            u32 f[4] = { 0, 0, 0, 0 };
-            for (u32 j = 0; i + j < L; ++j) { f[j] = bandRow(int(qw & 0xffu), int(dw & 0xffu)); qw >>= 8; dw >>= 8; }
-            storeFlags(i >> 2, f[0], f[1], f[2], f[3]);
+        if (i < L || (i & 4))
+        {   // the last one to three rows, and a first half of a block that is still to be stored
+            u32 j = i & 7;
+            for (; i < L; ++i, ++j)
+            {
+                const u32 v = bandRow(int(qw & 0xffu), int(dw & 0xffu)); qw >>= 8; dw >>= 8;
+#pragma unroll
+                for (u32 t = 0; t < 8; ++t) if (t == j) f[t] = v;             // (no private array is indexed at run time)
+            }
+            storeFlags((i - 1) >> 3, f);
         }
     }
     else
@@ -184,10 +216,10 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
         // the next row's query base and the database base that enters the band with it are requested a row ahead (every lane reads the
         // same bytes: one broadcast access, no branch), so that their latency lies behind the row's arithmetic
         int qNext = u8(query(0)), dNext = u8(database[L > 1 ? 16 : 15]);
-        for (u32 i = 0; i < L; i += 4)
+        for (u32 i = 0; i < L; i += 8)
         {
-            u32 f[4] = { 0, 0, 0, 0 };
-            for (u32 j = 0; j < 4 && i + j < L; ++j)
+            u32 f[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+            for (u32 j = 0; j < 8 && i + j < L; ++j)
             {
                 const int q = qNext, dIn = dNext;
                 const u32 ahead = i + j + 1 < L ? i + j + 1 : i + j;      // the values fetched in the last row are not used
@@ -195,13 +227,14 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
                 dNext = u8(database[ahead + 1 < L ? ahead + 16 : ahead + 15]);
                 f[j] = bandRow(q, dIn);
             }
-            storeFlags(i >> 2, f[0], f[1], f[2], f[3]);
+            storeFlags(i >> 3, f);
         }
     }
 #endif
     reinterpret_cast<int *>(endVals)[l] = G; reinterpret_cast<int *>(endVals)[8 + l] = E; reinterpret_cast<int *>(endVals)[16 + l] = F;
     STAMP(55);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if constexpr (GLOBAL_FLAGS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     u32 ret = 0;
@@ -286,7 +319,7 @@ struct StrandQueryDev { ReadView read; bool reverse; u32 offset; __device__ char
 // alignGapped() in aligner.h with the DP on the group and everything else on its lane 0.  `bcl` is the tile, the job's
 // cluster index is relative to clusterBase.  Grid-stride over the jobs, so the launch does not need the job count on the host.
 __global__ __launch_bounds__(BSW_BLOCK) void k_gapped_jobs(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap,
-                                                    u32 maxReadLength, GappedResult *results)
+                                                    u32 maxReadLength, GappedResult *results, u8 *flagsArena)
 {
     extern __shared__ __align__(16) u8 lds[];
     __shared__ double qualityTables[128];
@@ -294,9 +327,12 @@ __global__ __launch_bounds__(BSW_BLOCK) void k_gapped_jobs(DevParams P, DevRefer
     __syncthreads();
     DevReference R = Rg; R.logMatch = qualityTables; R.logMismatch = qualityTables + 64; R.logStride = 1;
     const u32 group = bswGroupOfThread(), k = bswLaneOfThread(), groups = blockDim.x / BSW_GROUP_LANES;
-    u8 *T = lds + group * gappedGroupLdsBytes(maxReadLength);
-    short *endVals = reinterpret_cast<short *>(T + bswFlagBytes(maxReadLength));
-    char *stagedQuery = reinterpret_cast<char *>(T + bswGroupLdsBytes(maxReadLength));
+    // the traceback flags of the group's problem: a region of the arena per group of the grid (see bswCooperative); end values and the staged
+    // sequences in LDS
+    u8 *mine = lds + group * gappedGroupLdsBytes(maxReadLength);
+    u8 *T = ISAAC_BSW_GLOBAL_FLAGS ? flagsArena + (size_t(blockIdx.x) * groups + group) * bswFlagBytes(maxReadLength) : mine + 128 + 2 * ((maxReadLength + 47) & ~15u);
+    short *endVals = reinterpret_cast<short *>(mine);
+    char *stagedQuery = reinterpret_cast<char *>(mine + 128);
     char *stagedDatabase = stagedQuery + ((maxReadLength + 47) & ~15u);
     const u32 nJobs = imin(*jobCounter, jobsCap);
     for (u32 j = blockIdx.x * groups + group; j < nJobs; j += gridDim.x * groups)
@@ -390,7 +426,7 @@ __global__ __launch_bounds__(BSW_BLOCK) void k_gapped_jobs(DevParams P, DevRefer
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             STAMP(51);
             PlainQuery q; q.q = stagedQuery;
-            const u32 ret = bswCooperative<true>(P.gapMatch, P.gapMismatch, -P.gapOpen, -P.gapExtend, q, sequenceLength, stagedDatabase, T, endVals, k, res.cigar, 40u, n, overflow);
+            const u32 ret = bswCooperative<true, 0 != ISAAC_BSW_GLOBAL_FLAGS>(P.gapMatch, P.gapMismatch, -P.gapOpen, -P.gapExtend, q, sequenceLength, stagedDatabase, T, endVals, k, res.cigar, 40u, n, overflow);
             STAMP(52);
             if (k == 0)
             {

@@ -98,7 +98,7 @@ struct isaac_gpu_ctx
     DevBuf<u64> dupPrimary, dupMate, dupRank, dupCluster, dupSmall; DevBuf<u8> dupFlag;        // duplicate marking
     DevBuf<FragmentRecord> realignRecords; DevBuf<RealignGap> realignGaps, realignDeletionEnds; DevBuf<u32> realignPool, realignNext; DevBuf<u8> realignChanged;   // gap realignment
     DevBuf<RescueJob> jobs; DevBuf<u32> rescueCounters, bitmaps, candJob, shadowCigars, jobBase, jobCount; DevBuf<i32> candPositions; DevBuf<Cand> shadowCands; DevBuf<u32> candRank;
-    DevBuf<Counters> counters, countersSaved;
+    DevBuf<Counters> counters, countersSaved; DevBuf<u8> bswFlags;
     std::map<std::string, KernelTimer> timers;
     struct PendingTimer { std::string name; hipEvent_t e0, e1; };
     std::vector<PendingTimer> pendingTimers; std::vector<hipEvent_t> eventPool;
@@ -1182,7 +1182,8 @@ static void launchGappedJobs(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clusterBa
     const size_t lds = size_t(BSW_BLOCK / BSW_GROUP_LANES) * gappedGroupLdsBytes(maxReadLength);
     {
         ScopedTimer t(c, timer);
-        k_gapped_jobs<<<8192, BSW_BLOCK, lds, c->stream>>>(c->P, c->ref(), bcl, clusterBase, gb.jobs, gb.counter, gb.cap, maxReadLength, gb.results);
+        if (ISAAC_BSW_GLOBAL_FLAGS) c->bswFlags.reserve(size_t(GAPPED_GRID) * (BSW_BLOCK / BSW_GROUP_LANES) * bswFlagBytes(maxReadLength));
+        k_gapped_jobs<<<GAPPED_GRID, BSW_BLOCK, lds, c->stream>>>(c->P, c->ref(), bcl, clusterBase, gb.jobs, gb.counter, gb.cap, maxReadLength, gb.results, c->bswFlags.p);
     }
     HIP_CHECK(hipGetLastError());
     ScopedTimer t(c, rescanTimer);

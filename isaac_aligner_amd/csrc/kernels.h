@@ -162,17 +162,26 @@ struct SumsBuffers { ClusterSums *sums; u8 *residualFlag; u32 *residualList, *re
 static const u32 HEAVY_SORT_LDS = 32768;   // u16 indices: heavyCaps().prob / .pair entries
 
 static const u32 BSW_GROUP_LANES = 8;        // lanes that share one banded Smith-Waterman problem (bsw_kernel.h)
+#ifndef ISAAC_BSW_GLOBAL_FLAGS
+// 1: the traceback flags of k_gapped_jobs in device memory instead of LDS, five wavefronts per SIMD instead of two.  Measured (2 x 150, 1 M pairs a
+// step): 7.08 ms against 4.27 -- the twelve-byte stores of 64 lanes and the traceback's reads through the L2 cost more than the wavefronts bring
+// (profiles/exp_r4_bsw_global_flags.log).  Kept as a build switch.
+#define ISAAC_BSW_GLOBAL_FLAGS 0
+#endif
+static const u32 GAPPED_GRID = 8192;         // workgroups of k_gapped_jobs (it strides over the problems)
 static const u32 BSW_BLOCK = 64;             // threads per workgroup of k_gapped_jobs / k_bsw_batch: one wavefront, eight problems
 // LDS bytes of one banded Smith-Waterman group (bsw_kernel.h)
 // traceback flags: 48 bytes per four rows (bsw_kernel.h)
-__host__ __device__ inline u32 bswFlagBytes(u32 maxQueryLength) { return (((maxQueryLength + 3) / 4) * 48 + 15) & ~15u; }
+__host__ __device__ inline u32 bswFlagBytes(u32 maxQueryLength) { return ((maxQueryLength + 7) / 8) * 96; }
 __host__ __device__ inline u32 bswGroupLdsBytes(u32 maxQueryLength) { return bswFlagBytes(maxQueryLength) + 128; }
 // k_gapped_jobs also keeps the query and the database window of the group there (the DP loop then reads LDS, not global memory)
 // (the eight groups of a wave touch their areas at the same offsets in the same instruction: a stride of an odd number of 16-byte units
 // spreads them over all LDS banks)
 __host__ __device__ inline u32 gappedGroupLdsBytes(u32 maxQueryLength)
 {
-    const u32 bytes = bswGroupLdsBytes(maxQueryLength) + 2 * ((maxQueryLength + 47) & ~15u);     // the staged query and database window, each with room for the look-ahead reads
+    // the end values (128 bytes) and the staged query and database window, each with room for the look-ahead reads; the traceback flags of
+    // k_gapped_jobs are in device memory (GAPPED_GRID x groups regions of bswFlagBytes)
+    const u32 bytes = 128 + 2 * ((maxQueryLength + 47) & ~15u) + (ISAAC_BSW_GLOBAL_FLAGS ? 0u : bswFlagBytes(maxQueryLength));
     return (((bytes + 15) / 16) | 1u) * 16;
 }
 
@@ -199,6 +208,6 @@ __global__ __launch_bounds__(64) void k_select_heavy(DevParams P, DevReference R
 namespace isaac
 {
 __global__ __launch_bounds__(128) void k_bsw_batch(int matchScore, int mismatchScore, int gapOpenScore, int gapExtendScore, const char *sequences, const isaac_bsw_job *jobs, u32 nJobs, u32 maxQueryLength, isaac_bsw_result *results);
-__global__ __launch_bounds__(128) void k_gapped_jobs(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap, u32 maxReadLength, GappedResult *results);
+__global__ __launch_bounds__(128) void k_gapped_jobs(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap, u32 maxReadLength, GappedResult *results, u8 *flagsArena);
 __global__ __launch_bounds__(256) void k_gapped_rescan(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap, GappedResult *results);
 }
