@@ -176,6 +176,7 @@ def cli_end_to_end(args, al, genome, batches, L, emit_note):
         bam = os.path.join(work, "Aligned", "Projects", "default", "default", "sorted.bam")
         out = {"reads_per_s": round(timing["reads"] / wall, 1), "reads_per_s_without_reference_load": round(timing["reads"] / max(1e-9, timing["total_s"] - timing["reference_s"]), 1),
                "pairs": n_pairs, "wall_s": round(wall, 2), "stages_s": {k: round(v, 3) for k, v in timing.items() if k.endswith("_s")}, "records": timing["records"], "workers": timing["workers"],
+               "tiles_kept_on_device": timing.get("tiles_kept_on_device"),
                "sorted_bam_bytes": os.path.getsize(bam), "bai_bytes": os.path.getsize(bam + ".bai"),
                "command": "isaac-align -r sorted-reference.xml -b <2 FASTQ files> --base-calls-format fastq --use-bases-mask y*,y* --clusters-at-a-time 2000000 (defaults: --mark-duplicates 1, --realign-gaps sample, --bam-gzip-level 1)",
                "preparation_s": {"fasta": round(t_fasta, 1), "save_sorted_reference": round(t_save, 1), "fastq": round(t_fastq, 1)},
@@ -544,6 +545,12 @@ def main():
     cli_info = None
     if not args.no_cli_pass and dist is None and rank == 0:
         try:
+            # the program gets the device as a run of its own would find it, beside this process's table and reads: the extra contexts (their timers
+            # and records have been read) and torch's cached blocks go first
+            for extra in als[1:]:
+                extra.close()
+            del als[1:]
+            torch.cuda.empty_cache()
             cli_info = cli_end_to_end(args, al, genome, batches[args.warmup:], L, None)
         except Exception as e:      # the leg must not cost the run its line
             cli_info = {"error": repr(e)[:400]}
@@ -657,6 +664,9 @@ def main():
         for name in ("min", "max", "median", "low_std_dev", "high_std_dev", "stable", "mate_min", "mate_max"):
             setattr(otls, name, getattr(tls, name))
         otls.best_model[0], otls.best_model[1] = tls.best_model[0], tls.best_model[1]
+        # (an empty call first: the oracle then has its list of loaded contigs, a copy of the genome, as the reference has its contigs in memory before
+        # the first tile; the threads of the timed call take the match list in pieces as they become free)
+        ref.select(p, host_bcl, om[:0], otls, all_hits, tile=tile_of(0), n_threads=1, n_clusters_hint=1)
         tc = time.perf_counter()
         orec, ocig, _ = ref.select(p, host_bcl, om, otls, all_hits, tile=tile_of(0), n_threads=cores, n_clusters_hint=sample)
         t_select = time.perf_counter() - tc

@@ -22,6 +22,7 @@
 #include <cstring>
 #include <deque>
 #include <fstream>
+#include <future>
 #include <iostream>
 #include <map>
 #include <memory>
@@ -164,14 +165,38 @@ struct Tile
 };
 
 // one read of one lane: the file and the text not yet converted
+const size_t TEXT_CHUNK = size_t(64) << 20;
+
+// The next piece of the file is read (and inflated) by a thread of its own while the current one is uploaded and converted: the two reads of a
+// lane and the device then work side by side instead of taking turns.
 struct ReadStream
 {
     std::unique_ptr<FastqFileReader> reader;
     std::vector<char> pending;
     uint64_t consumedBytes = 0;                                   // of the uncompressed text, for error messages
+    std::future<std::vector<char> > ahead;                        // while valid, `reader` belongs to the thread behind it
+    bool ended = false;                                           // the reader was at the end of its file when last looked at
+    ~ReadStream() { if (ahead.valid()) ahead.wait(); }
+    void startAhead()
+    {
+        if (ended || ahead.valid()) return;
+        FastqFileReader *r = reader.get();
+        ahead = std::async(std::launch::async, [r]() { std::vector<char> piece; r->read(piece, TEXT_CHUNK); return piece; });
+    }
+    // more text behind `pending`, at least up to `want` bytes if the file has them
+    void fill(size_t want)
+    {
+        while (pending.size() < want && !ended)
+        {
+            if (!ahead.valid()) startAhead();
+            const std::vector<char> piece = ahead.get();
+            pending.insert(pending.end(), piece.begin(), piece.end());
+            ended = reader->atEnd();
+            startAhead();
+        }
+    }
+    bool atEnd() const { return ended; }
 };
-
-const size_t TEXT_CHUNK = size_t(64) << 20;
 
 // io::FastqLoader::loadSingleRead for up to maxClusters clusters: the text goes to the device in pieces, the converter leaves the incomplete
 // record at the end of a piece for the next one
@@ -181,9 +206,9 @@ uint32_t loadRead(isaac_gpu_ctx *ctx, ReadStream &stream, unsigned readIndex, bo
     size_t chunk = TEXT_CHUNK;
     while (clusters < maxClusters)
     {
-        if (stream.pending.size() < chunk && !stream.reader->atEnd()) stream.reader->read(stream.pending, chunk - stream.pending.size());
+        stream.fill(chunk);
         if (stream.pending.empty()) break;
-        const bool final = stream.reader->atEnd();
+        const bool final = stream.atEnd();
         if (textDev.bytes() < stream.pending.size() + 64) textDev.reset(ctx, stream.pending.size() + 64);
         GPU(isaac_gpu_upload(ctx, textDev.as<char>(), stream.pending.data(), stream.pending.size()));
         uint32_t n = 0; uint64_t consumed = 0, errorOffset = 0;

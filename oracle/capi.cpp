@@ -6,6 +6,9 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <mutex>
+#include <memory>
+#include <atomic>
 #include <algorithm>
 
 using namespace oracle;
@@ -102,7 +105,13 @@ int oracle_bsw_check(int match, int mismatch, int gap_open, int gap_extend, int 
 }
 
 // ---- reference handle: contigs + sorted index
-struct oracle_ref { ContigList contigs; SortedReference index; std::vector<uint8_t> contigHasMatches; };
+struct oracle_ref
+{
+    ContigList contigs; SortedReference index; std::vector<uint8_t> contigHasMatches;
+    // the list a call works on (contigs without matches emptied), kept from call to call: a copy of a human genome per call was a second and a half of
+    // what bench.py's cpu_baseline timed as "selection"
+    std::mutex filteredLock; std::vector<uint8_t> filteredKey; std::shared_ptr<const ContigList> filtered;
+};
 
 oracle_ref *oracle_ref_create(const char *bases, const uint64_t *offsets /* n+1 */, uint32_t n_contigs)
 {
@@ -181,12 +190,19 @@ int oracle_find_matches_mt(oracle_ref *r, const oracle_params *cp, const uint8_t
     catch (const std::exception &e) { g_error = e.what(); return 1; }
 }
 
-static ContigList filteredContigs(const oracle_ref *r, const uint8_t *contig_loaded)
+static std::shared_ptr<const ContigList> filteredContigsShared(oracle_ref *r, const uint8_t *contig_loaded)
 {
     // MatchSelector.cpp:85-90,138: contigs without any match are not loaded (empty sequence, length 0)
-    ContigList c = r->contigs;
-    if (contig_loaded) for (size_t i = 0; i < c.size(); ++i) if (!contig_loaded[i]) c[i].forward.clear();
-    return c;
+    std::vector<uint8_t> key(r->contigs.size(), 1);
+    if (contig_loaded) key.assign(contig_loaded, contig_loaded + r->contigs.size());
+    std::lock_guard<std::mutex> hold(r->filteredLock);
+    if (!r->filtered || key != r->filteredKey)
+    {
+        std::shared_ptr<ContigList> c(new ContigList(r->contigs));
+        for (size_t i = 0; i < c->size(); ++i) if (!key[i]) (*c)[i].forward.clear();
+        r->filtered = c; r->filteredKey = key;
+    }
+    return r->filtered;
 }
 
 static void fillCandidate(oracle_candidate &o, const FragmentMetadata &f, uint32_t cluster, uint32_t cigarOffset)
@@ -207,7 +223,7 @@ int oracle_build_fragments(oracle_ref *r, const oracle_params *cp, const uint8_t
     try
     {
         const Params p = toParams(cp);
-        const ContigList contigs = filteredContigs(r, contig_loaded);
+        const std::shared_ptr<const ContigList> contigsHeld = filteredContigsShared(r, contig_loaded); const ContigList &contigs = *contigsHeld;
         FragmentBuilder fb(p);
         Cluster cluster;
         const Match *mb = reinterpret_cast<const Match *>(matches), *me = mb + n_matches;
@@ -260,7 +276,7 @@ int oracle_determine_tls(oracle_ref *r, const oracle_params *cp, const uint8_t *
     try
     {
         const Params p = toParams(cp);
-        const ContigList contigs = filteredContigs(r, contig_loaded);
+        const std::shared_ptr<const ContigList> contigsHeld = filteredContigsShared(r, contig_loaded); const ContigList &contigs = *contigsHeld;
         MatchSelector ms(p, contigs);
         const Match *mb = reinterpret_cast<const Match *>(matches);
         toTls(ms.determineTemplateLength(mb, mb + n_matches, bcl, tile), out);
@@ -279,23 +295,27 @@ int oracle_select(oracle_ref *r, const oracle_params *cp, const uint8_t *contig_
     try
     {
         const Params p = toParams(cp);
-        const ContigList contigs = filteredContigs(r, contig_loaded);
+        const std::shared_ptr<const ContigList> contigsHeld = filteredContigsShared(r, contig_loaded); const ContigList &contigs = *contigsHeld;
         const TemplateLengthStatistics t = fromTls(tls);
         const Match *mb = reinterpret_cast<const Match *>(matches), *me = mb + n_matches;
         if (!n_threads) n_threads = 1;
+        // pieces of the match list, cut at cluster boundaries, handed out as the threads ask for them: sixteen per thread, so that a thread that meets
+        // a repeat family does not keep the others waiting for its share (a static split into one range per thread did, on 256 threads)
+        const uint32_t n_pieces = 1 == n_threads ? 1 : n_threads * 16;
         std::vector<const Match *> bounds(1, mb);
-        for (uint32_t i = 1; i < n_threads; ++i)
+        for (uint32_t i = 1; i < n_pieces; ++i)
         {
-            const Match *b = mb + n_matches * i / n_threads;
+            const Match *b = mb + n_matches * i / n_pieces;
             while (b != me && b != mb && SeedId(b->seedId).getCluster() == SeedId((b - 1)->seedId).getCluster()) ++b;
             if (b < bounds.back()) b = bounds.back();
             bounds.push_back(b);
         }
         bounds.push_back(me);
-        std::vector<std::vector<FragmentRecord> > recs(n_threads);
-        std::vector<std::vector<uint32_t> > cigs(n_threads);
+        std::vector<std::vector<FragmentRecord> > recs(n_pieces);
+        std::vector<std::vector<uint32_t> > cigs(n_pieces);
         std::vector<std::string> errors(n_threads);
         std::vector<uint64_t> calls(n_threads, 0), cands(n_threads, 0);
+        std::atomic<uint32_t> nextPiece(0);
         std::vector<std::thread> threads;
         for (uint32_t i = 0; i < n_threads; ++i)
             threads.push_back(std::thread([&, i]()
@@ -303,7 +323,8 @@ int oracle_select(oracle_ref *r, const oracle_params *cp, const uint8_t *contig_
                 try
                 {
                     MatchSelector ms(p, contigs);
-                    ms.selectTile(bounds[i], bounds[i + 1], bcl, tile, t, recs[i], cigs[i]);
+                    for (uint32_t piece = nextPiece++; piece < n_pieces; piece = nextPiece++)
+                        ms.selectTile(bounds[piece], bounds[piece + 1], bcl, tile, t, recs[piece], cigs[piece]);
                     calls[i] = ms.templateBuilder.rescueCalls; cands[i] = ms.templateBuilder.rescueCandidates;
                 }
                 catch (const std::exception &e) { errors[i] = e.what(); if (errors[i].empty()) errors[i] = "error"; }
@@ -315,10 +336,13 @@ int oracle_select(oracle_ref *r, const oracle_params *cp, const uint8_t *contig_
         for (uint32_t i = 0; i < n_threads; ++i)
         {
             if (!errors[i].empty()) throw std::runtime_error(errors[i]);
+            if (counters) { counters[0] += calls[i]; counters[1] += cands[i]; }
+        }
+        for (uint32_t i = 0; i < n_pieces; ++i)
+        {
             if (n + recs[i].size() > capacity || nc + cigs[i].size() > cigar_capacity) throw std::runtime_error("record capacity");
             for (size_t k = 0; k < recs[i].size(); ++k) { out[n] = recs[i][k]; out[n].cigarOffset += uint32_t(nc); ++n; }
             memcpy(cigar_out + nc, cigs[i].data(), cigs[i].size() * 4); nc += cigs[i].size();
-            if (counters) { counters[0] += calls[i]; counters[1] += cands[i]; }
         }
         *n_out = n; *n_cigar = nc;
         return 0;
