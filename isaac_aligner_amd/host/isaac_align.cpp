@@ -22,7 +22,6 @@
 #include <cstring>
 #include <deque>
 #include <fstream>
-#include <future>
 #include <iostream>
 #include <map>
 #include <memory>
@@ -166,34 +165,21 @@ struct Tile
 
 // one read of one lane: the file and the text not yet converted
 const size_t TEXT_CHUNK = size_t(64) << 20;
+// where the load phase's time goes (one thread runs it): waiting for text, upload + conversion, first lookup
+double g_textWaitSeconds = 0, g_convertSeconds = 0, g_firstLookupSeconds = 0;
 
-// The next piece of the file is read (and inflated) by a thread of its own while the current one is uploaded and converted: the two reads of a
-// lane and the device then work side by side instead of taking turns.
+// (A thread per read that fetched the next piece ahead of the conversion was measured and taken out again: 1.76 s against 1.3 s for 6.6 GB of text -- the
+// reader's fresh buffers and the extra copy cost more than the overlap brought; profiles/r4_e_cli_timing.log.)
 struct ReadStream
 {
     std::unique_ptr<FastqFileReader> reader;
     std::vector<char> pending;
     uint64_t consumedBytes = 0;                                   // of the uncompressed text, for error messages
-    std::future<std::vector<char> > ahead;                        // while valid, `reader` belongs to the thread behind it
     bool ended = false;                                           // the reader was at the end of its file when last looked at
-    ~ReadStream() { if (ahead.valid()) ahead.wait(); }
-    void startAhead()
-    {
-        if (ended || ahead.valid()) return;
-        FastqFileReader *r = reader.get();
-        ahead = std::async(std::launch::async, [r]() { std::vector<char> piece; r->read(piece, TEXT_CHUNK); return piece; });
-    }
-    // more text behind `pending`, at least up to `want` bytes if the file has them
+    // more text behind `pending`, up to `want` bytes if the file has them
     void fill(size_t want)
     {
-        while (pending.size() < want && !ended)
-        {
-            if (!ahead.valid()) startAhead();
-            const std::vector<char> piece = ahead.get();
-            pending.insert(pending.end(), piece.begin(), piece.end());
-            ended = reader->atEnd();
-            startAhead();
-        }
+        if (pending.size() < want && !ended) { reader->read(pending, want - pending.size()); ended = reader->atEnd(); }
     }
     bool atEnd() const { return ended; }
 };
@@ -206,8 +192,11 @@ uint32_t loadRead(isaac_gpu_ctx *ctx, ReadStream &stream, unsigned readIndex, bo
     size_t chunk = TEXT_CHUNK;
     while (clusters < maxClusters)
     {
+        const double fillStart = seconds();
         stream.fill(chunk);
+        g_textWaitSeconds += seconds() - fillStart;
         if (stream.pending.empty()) break;
+        const double convertStart = seconds();
         const bool final = stream.atEnd();
         if (textDev.bytes() < stream.pending.size() + 64) textDev.reset(ctx, stream.pending.size() + 64);
         GPU(isaac_gpu_upload(ctx, textDev.as<char>(), stream.pending.data(), stream.pending.size()));
@@ -217,6 +206,7 @@ uint32_t loadRead(isaac_gpu_ctx *ctx, ReadStream &stream, unsigned readIndex, bo
         if (rc)
             throw std::runtime_error(stream.reader->path() + ": " + isaac_gpu_last_error() + " (record " + std::to_string(clusters + n) + " of this load, offset " +
                                      std::to_string(stream.consumedBytes + errorOffset) + ")");
+        g_convertSeconds += seconds() - convertStart;
         clusters += n;
         stream.consumedBytes += consumed;
         stream.pending.erase(stream.pending.begin(), stream.pending.begin() + std::ptrdiff_t(consumed));
@@ -383,7 +373,9 @@ int run(const AlignOptions &o)
                         std::memset(&t.tls, 0, sizeof(t.tls));
                         first += sizes[k];
                         uint64_t nMatches = 0;
+                        const double lookupStart = seconds();
                         findMatches(w, t, nMatches, contigHasMatches.data());
+                        g_firstLookupSeconds += seconds() - lookupStart;
                         w.tiles.push_back(&t);
                     }
                     totalClusters += loaded[0];
@@ -718,7 +710,7 @@ int run(const AlignOptions &o)
     std::cerr << "isaac-align: " << bamPath << ": " << nRecordsWritten << " records in " << binsWritten << " bin(s)" << std::endl;
     // one line for scripts (bench.py): what the run took, stage by stage
     std::cerr << "isaac-align: timing {\"clusters\": " << totalClusters << ", \"reads\": " << totalClusters * nReads << ", \"records\": " << nRecordsWritten << ", \"workers\": " << workers.size()
-              << ", \"reference_s\": " << referenceSeconds << ", \"reference_fasta_s\": " << fastaSeconds << ", \"reference_contigs_s\": " << contigSeconds << ", \"reference_table_s\": " << tableSeconds << ", \"load_and_find_s\": " << loadSeconds << ", \"select_and_bin_s\": " << selectSeconds << ", \"build_and_write_s\": " << buildSeconds
+              << ", \"reference_s\": " << referenceSeconds << ", \"reference_fasta_s\": " << fastaSeconds << ", \"reference_contigs_s\": " << contigSeconds << ", \"reference_table_s\": " << tableSeconds << ", \"load_and_find_s\": " << loadSeconds << ", \"load_text_wait_s\": " << g_textWaitSeconds << ", \"load_convert_s\": " << g_convertSeconds << ", \"load_first_lookup_s\": " << g_firstLookupSeconds << ", \"select_and_bin_s\": " << selectSeconds << ", \"build_and_write_s\": " << buildSeconds
               << ", \"tiles_kept_on_device\": " << tilesOnDevice << ", \"build_upload_s\": " << workers[0]->uploadSeconds << ", \"build_records_s\": " << workers[0]->recordsSeconds << ", \"build_deflate_s\": " << workers[0]->deflateSeconds
               << ", \"build_download_s\": " << workers[0]->downloadSeconds << ", \"file_write_s\": " << writeSeconds
               << ", \"total_s\": " << total << "}" << std::endl;
