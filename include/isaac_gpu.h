@@ -133,6 +133,9 @@ int isaac_gpu_malloc(isaac_gpu_ctx *ctx, uint64_t bytes, void **dev_out);
 int isaac_gpu_free(isaac_gpu_ctx *ctx, void *dev);
 int isaac_gpu_upload(isaac_gpu_ctx *ctx, void *dev, const void *host, uint64_t bytes);
 int isaac_gpu_download(isaac_gpu_ctx *ctx, void *host, const void *dev, uint64_t bytes);
+/* page-locked host memory: uploads from it and downloads into it run at the link's rate (pageable memory: a third of it), and nothing clears it first */
+int isaac_gpu_host_malloc(uint64_t bytes, void **host_out);
+int isaac_gpu_host_free(void *host);
 /* free and total memory of the context's device, in bytes (a host that keeps work on the device while there is room: isaac-align's bins) */
 int isaac_gpu_memory_info(isaac_gpu_ctx *ctx, uint64_t *free_bytes_out, uint64_t *total_bytes_out);
 /* device to device, on the context's stream (ordered with the calls before and after it; no host wait) */

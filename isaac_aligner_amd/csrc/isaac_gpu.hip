@@ -602,6 +602,15 @@ int isaac_gpu_upload(isaac_gpu_ctx *c, void *dev, const void *host, uint64_t byt
 { ISAAC_TRY HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
 int isaac_gpu_download(isaac_gpu_ctx *c, void *host, const void *dev, uint64_t bytes)
 { ISAAC_TRY HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
+int isaac_gpu_host_malloc(uint64_t bytes, void **hostOut)
+{
+    ISAAC_TRY
+    if (!hostOut) return fail(ISAAC_GPU_EINVAL, "null argument");
+    HIP_CHECK(hipHostMalloc(hostOut, std::max<uint64_t>(bytes, 64), hipHostMallocDefault));
+    return 0;
+    ISAAC_CATCH
+}
+int isaac_gpu_host_free(void *host) { ISAAC_TRY if (host) HIP_CHECK(hipHostFree(host)); return 0; ISAAC_CATCH }
 int isaac_gpu_memory_info(isaac_gpu_ctx *c, uint64_t *freeOut, uint64_t *totalOut)
 {
     ISAAC_TRY

@@ -35,7 +35,7 @@ def load_library(path=None):
     return _lib
 
 
-EXPORTS = ["isaac_gpu_last_error", "isaac_gpu_create", "isaac_gpu_destroy", "isaac_gpu_set_params", "isaac_gpu_index_dev", "isaac_gpu_set_index_dev", "isaac_gpu_malloc", "isaac_gpu_free", "isaac_gpu_upload", "isaac_gpu_download", "isaac_gpu_memory_info",
+EXPORTS = ["isaac_gpu_last_error", "isaac_gpu_create", "isaac_gpu_destroy", "isaac_gpu_set_params", "isaac_gpu_index_dev", "isaac_gpu_set_index_dev", "isaac_gpu_malloc", "isaac_gpu_free", "isaac_gpu_upload", "isaac_gpu_download", "isaac_gpu_memory_info", "isaac_gpu_host_malloc", "isaac_gpu_host_free",
            "isaac_gpu_copy", "isaac_gpu_synchronize", "isaac_gpu_set_deferred_completion", "isaac_gpu_load_contigs", "isaac_gpu_load_contigs_dev", "isaac_gpu_load_index", "isaac_gpu_build_index", "isaac_gpu_get_index", "isaac_gpu_get_index_range", "isaac_gpu_get_mask_offsets",
            "isaac_gpu_sorted_reference_parse", "isaac_gpu_sorted_reference_format", "isaac_gpu_sorted_reference_last_error", "isaac_gpu_load_sorted_reference",
            "isaac_gpu_save_sorted_reference",

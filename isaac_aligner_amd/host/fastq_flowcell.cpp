@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <cerrno>
 #include <cstring>
+#include <thread>
+#include <unistd.h>
 #include <iostream>
 #include <stdexcept>
 #include <sys/stat.h>
@@ -172,16 +174,43 @@ FastqFileReader::~FastqFileReader()
     if (file_) std::fclose(file_);
 }
 
-size_t FastqFileReader::read(std::vector<char> &to, size_t want)
+size_t FastqFileReader::readInto(char *out, size_t want)
 {
     if (eof_ || !want) return 0;
-    const size_t before = to.size();
-    to.resize(before + want);
     size_t got = 0;
     if (!compressed_)
     {
-        got = std::fread(to.data() + before, 1, want, file_);
-        if (got < want) { if (std::ferror(file_)) throw std::runtime_error("Failed to read " + path_); eof_ = true; }
+        // plain text: a large piece is fetched by a few threads side by side (one thread copies 8 GB/s out of the page cache; the two files of a
+        // lane are 660 bytes per pair)
+        const int fd = fileno(file_);
+        const size_t threads = want >= (size_t(16) << 20) ? 4 : 1, share = (want + threads - 1) / threads;
+        std::vector<size_t> gotPart(threads, 0);
+        std::vector<int> failed(threads, 0);
+        const auto part = [&](size_t t)
+        {
+            const size_t first = t * share, n = first < want ? std::min(share, want - first) : 0;
+            size_t done = 0;
+            while (done < n)
+            {
+                const ssize_t r = ::pread(fd, out + first + done, n - done, off_t(position_ + first + done));
+                if (r < 0) { if (EINTR == errno) continue; failed[t] = errno ? errno : EIO; break; }
+                if (!r) break;
+                done += size_t(r);
+            }
+            gotPart[t] = done;
+        };
+        std::vector<std::thread> workers;
+        for (size_t t = 1; t < threads; ++t) workers.emplace_back(part, t);
+        part(0);
+        for (std::thread &w : workers) w.join();
+        for (size_t t = 0; t < threads; ++t)
+        {
+            if (failed[t]) throw std::runtime_error("Failed to read " + path_ + ": " + std::strerror(failed[t]));
+            got += gotPart[t];
+            if (gotPart[t] < (t * share < want ? std::min(share, want - t * share) : 0)) break;       // the file ends inside this part
+        }
+        position_ += got;
+        if (got < want) eof_ = true;
     }
     else
     {
@@ -203,7 +232,7 @@ size_t FastqFileReader::read(std::vector<char> &to, size_t want)
                 if (Z_OK != inflateInit2(&z_, 15 + 16)) throw std::runtime_error("inflateInit2 failed for " + path_);
                 streamOpen_ = true;
             }
-            z_.next_out = reinterpret_cast<Bytef *>(to.data() + before + got);
+            z_.next_out = reinterpret_cast<Bytef *>(out + got);
             z_.avail_out = uInt(std::min<size_t>(want - got, 1u << 30));
             const uInt room = z_.avail_out;
             const int rc = inflate(&z_, Z_NO_FLUSH);
@@ -218,6 +247,14 @@ size_t FastqFileReader::read(std::vector<char> &to, size_t want)
             else if (Z_OK != rc && Z_BUF_ERROR != rc) throw std::runtime_error("Failed to decompress " + path_ + ": " + (z_.msg ? z_.msg : "zlib error"));
         }
     }
+    return got;
+}
+size_t FastqFileReader::read(std::vector<char> &to, size_t want)
+{
+    if (eof_ || !want) return 0;
+    const size_t before = to.size();
+    to.resize(before + want);
+    const size_t got = readInto(to.data() + before, want);
     to.resize(before + got);
     return got;
 }

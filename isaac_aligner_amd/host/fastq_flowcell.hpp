@@ -41,11 +41,14 @@ public:
     FastqFileReader &operator=(const FastqFileReader &) = delete;
     // appends up to `want` bytes of text to `to`; returns the number appended, 0 at the end of the file
     size_t read(std::vector<char> &to, size_t want);
+    // the same into memory of the caller's: up to `want` bytes at `to`
+    size_t readInto(char *to, size_t want);
     bool atEnd() const { return eof_; }
     const std::string &path() const { return path_; }
 private:
     std::string path_;
     bool compressed_, eof_ = false, streamOpen_ = false;
+    uint64_t position_ = 0;                   // of a plain file: where the next piece begins
     std::FILE *file_ = 0;
     z_stream z_;
     std::vector<unsigned char> in_;

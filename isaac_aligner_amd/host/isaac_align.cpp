@@ -173,13 +173,33 @@ double g_textWaitSeconds = 0, g_convertSeconds = 0, g_firstLookupSeconds = 0;
 struct ReadStream
 {
     std::unique_ptr<FastqFileReader> reader;
-    std::vector<char> pending;
+    // the text not yet converted, [begin, end) of a page-locked buffer: the file is read into it and the device takes it from there at the link's
+    // rate (a std::vector is cleared before it is read into and uploaded through the runtime's own staging: half of the load phase's time)
+    char *text = 0; size_t capacity = 0, begin = 0, end = 0;
     uint64_t consumedBytes = 0;                                   // of the uncompressed text, for error messages
     bool ended = false;                                           // the reader was at the end of its file when last looked at
-    // more text behind `pending`, up to `want` bytes if the file has them
+    ReadStream() {}
+    ReadStream(const ReadStream &) = delete;
+    ReadStream &operator=(const ReadStream &) = delete;
+    ~ReadStream() { if (text) isaac_gpu_host_free(text); }
+    size_t size() const { return end - begin; }
+    const char *data() const { return text + begin; }
+    void consume(size_t n) { begin += n; if (begin == end) begin = end = 0; }
+    // more text behind what is there, up to `want` bytes in all if the file has them
     void fill(size_t want)
     {
-        if (pending.size() < want && !ended) { reader->read(pending, want - pending.size()); ended = reader->atEnd(); }
+        if (size() >= want || ended) return;
+        if (capacity < want)
+        {
+            void *larger = 0;
+            GPU(isaac_gpu_host_malloc(want, &larger));
+            if (size()) std::memcpy(larger, data(), size());
+            if (text) isaac_gpu_host_free(text);
+            text = static_cast<char *>(larger); capacity = want; end = size(); begin = 0;
+        }
+        else if (begin) { std::memmove(text, text + begin, size()); end = size(); begin = 0; }
+        end += reader->readInto(text + end, want - end);
+        ended = reader->atEnd();
     }
     bool atEnd() const { return ended; }
 };
@@ -195,13 +215,13 @@ uint32_t loadRead(isaac_gpu_ctx *ctx, ReadStream &stream, unsigned readIndex, bo
         const double fillStart = seconds();
         stream.fill(chunk);
         g_textWaitSeconds += seconds() - fillStart;
-        if (stream.pending.empty()) break;
+        if (!stream.size()) break;
         const double convertStart = seconds();
         const bool final = stream.atEnd();
-        if (textDev.bytes() < stream.pending.size() + 64) textDev.reset(ctx, stream.pending.size() + 64);
-        GPU(isaac_gpu_upload(ctx, textDev.as<char>(), stream.pending.data(), stream.pending.size()));
+        if (textDev.bytes() < stream.size() + 64) textDev.reset(ctx, stream.size() + 64);
+        GPU(isaac_gpu_upload(ctx, textDev.as<char>(), stream.data(), stream.size()));
         uint32_t n = 0; uint64_t consumed = 0, errorOffset = 0;
-        const int rc = isaac_gpu_fastq_to_bcl(ctx, textDev.as<char>(), stream.pending.size(), readIndex, allowVariableLength, final, bclDev + uint64_t(clusters) * clusterLength,
+        const int rc = isaac_gpu_fastq_to_bcl(ctx, textDev.as<char>(), stream.size(), readIndex, allowVariableLength, final, bclDev + uint64_t(clusters) * clusterLength,
                                               maxClusters - clusters, &n, &consumed, &errorOffset);
         if (rc)
             throw std::runtime_error(stream.reader->path() + ": " + isaac_gpu_last_error() + " (record " + std::to_string(clusters + n) + " of this load, offset " +
@@ -209,7 +229,7 @@ uint32_t loadRead(isaac_gpu_ctx *ctx, ReadStream &stream, unsigned readIndex, bo
         g_convertSeconds += seconds() - convertStart;
         clusters += n;
         stream.consumedBytes += consumed;
-        stream.pending.erase(stream.pending.begin(), stream.pending.begin() + std::ptrdiff_t(consumed));
+        stream.consume(consumed);
         if (!n && !consumed)
         {
             if (final) break;                                     // nothing but line ends left

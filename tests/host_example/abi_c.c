@@ -5,7 +5,7 @@
 typedef void (*any_function)(void);
 any_function isaac_gpu_entry_points[] = {
     (any_function)isaac_gpu_last_error, (any_function)isaac_gpu_create, (any_function)isaac_gpu_destroy, (any_function)isaac_gpu_malloc, (any_function)isaac_gpu_free,
-    (any_function)isaac_gpu_upload, (any_function)isaac_gpu_download, (any_function)isaac_gpu_memory_info, (any_function)isaac_gpu_synchronize, (any_function)isaac_gpu_set_deferred_completion,
+    (any_function)isaac_gpu_upload, (any_function)isaac_gpu_download, (any_function)isaac_gpu_memory_info, (any_function)isaac_gpu_host_malloc, (any_function)isaac_gpu_host_free, (any_function)isaac_gpu_synchronize, (any_function)isaac_gpu_set_deferred_completion,
     (any_function)isaac_gpu_load_contigs, (any_function)isaac_gpu_load_contigs_dev, (any_function)isaac_gpu_load_index, (any_function)isaac_gpu_build_index,
     (any_function)isaac_gpu_get_index, (any_function)isaac_gpu_get_index_range, (any_function)isaac_gpu_get_mask_offsets,
     (any_function)isaac_gpu_sorted_reference_parse, (any_function)isaac_gpu_sorted_reference_format, (any_function)isaac_gpu_sorted_reference_last_error,
