@@ -45,13 +45,18 @@ def main():
     tools = os.path.dirname(build.build_host())
     # CLI_ARGS may hold several option sets separated by ';': isaac-align runs once for each, on the same files
     runs = [("isaac-sort-reference", [os.path.join(tools, "isaac-sort-reference"), "-g", fasta, "-o", ref_dir, "-q"])]
+    envs = {}
     for extra in os.environ.get("CLI_ARGS", "").split(";"):
-        runs.append(("isaac-align", [os.path.join(tools, "isaac-align"), "-r", os.path.join(ref_dir, "sorted-reference.xml"), "-b", calls, "--base-calls-format", "fastq", "-o", os.path.join(work, "Aligned")] + extra.split()))
-    for name, cmd in runs:
+        tokens = extra.split()
+        env = dict(t.split("=", 1) for t in tokens if "=" in t and t.split("=", 1)[0].isupper())          # NAME=value tokens: environment of that run
+        runs.append(("isaac-align", [os.path.join(tools, "isaac-align"), "-r", os.path.join(ref_dir, "sorted-reference.xml"), "-b", calls, "--base-calls-format", "fastq", "-o", os.path.join(work, "Aligned")]
+                     + [t for t in tokens if not ("=" in t and t.split("=", 1)[0].isupper())]))
+        envs[len(runs) - 1] = env
+    for k, (name, cmd) in enumerate(runs):
         t0 = time.time()
-        r = subprocess.run(cmd, capture_output=True, text=True)
+        r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **envs.get(k, {})))
         wall = time.time() - t0
-        print("%s: rc %d, %.1f s%s" % (name, r.returncode, wall, "  [" + " ".join(cmd[9:]) + "]" if name == "isaac-align" else ""))
+        print("%s: rc %d, %.1f s%s" % (name, r.returncode, wall, "  [" + " ".join(cmd[9:] + ["%s=%s" % kv for kv in envs.get(k, {}).items()]) + "]" if name == "isaac-align" else ""))
         print("\n".join(l for l in r.stderr.splitlines() if "done in" in l or "records" in l or "clusters in" in l or "error" in l.lower() or "timing" in l), flush=True)
         if name == "isaac-align" and r.returncode == 0:
             import json
