@@ -343,6 +343,9 @@ __global__ void k_tls_samples(ClusterPools pools, const u64 *offsets, u32 cluste
 // clusters as they come has a quarter of its lanes at work on average, and every lane's private memory access touches a cache line of
 // its own.  The clusters are therefore handed out by kind -- candidates per read and, for k_select, rescue problems -- so that the
 // lanes of a wave mostly take the same branches and make the same number of turns.
+#ifndef ISAAC_PLAN_ORDER
+#define ISAAC_PLAN_ORDER 1      // 0: k_plan_rescue takes the clusters as they come (A/B builds)
+#endif
 #ifndef ISAAC_CLUSTER_ORDER
 #define ISAAC_CLUSTER_ORDER 1
 #endif
@@ -1445,7 +1448,7 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         const u32 *order = nullptr;
         {
             ScopedTimer tm(c, "plan_rescue");
-#if ISAAC_CLUSTER_ORDER
+#if ISAAC_CLUSTER_ORDER && ISAAC_PLAN_ORDER
             order = orderClustersByKind(c, n, nullptr);
 #endif
             k_plan_rescue<<<gridFor(n, SELECT_BLOCK), SELECT_BLOCK, 0, st>>>(c->templateConstants.p, R, done, n, c->pools, rb, order);
