@@ -160,6 +160,12 @@ __global__ __launch_bounds__(16 * SUMS16_GROUPS) void k_cluster_sums16(DevParams
 }
 
 // lists of up to 64 entries: a wavefront per cluster of the list k_cluster_sums16 left
+#ifndef ISAAC_SUMS_WAVES_PER_EU
+#define ISAAC_SUMS_WAVES_PER_EU 0
+#endif
+#if ISAAC_SUMS_WAVES_PER_EU
+__attribute__((amdgpu_waves_per_eu(ISAAC_SUMS_WAVES_PER_EU, ISAAC_SUMS_WAVES_PER_EU)))
+#endif
 __global__ __launch_bounds__(256) void k_cluster_sums(DevParams P, ClusterPools pools, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters)
 {
     __shared__ __align__(16) u8 keyBytes[4][SUMS_WAVE_CAP * 42];
