@@ -161,7 +161,7 @@ __global__ __launch_bounds__(16 * SUMS16_GROUPS) void k_cluster_sums16(DevParams
 
 // lists of up to 64 entries: a wavefront per cluster of the list k_cluster_sums16 left
 #ifndef ISAAC_SUMS_WAVES_PER_EU
-#define ISAAC_SUMS_WAVES_PER_EU 0
+#define ISAAC_SUMS_WAVES_PER_EU 4      // 128 registers: four wavefronts per SIMD instead of three at 129 (1.96 -> 1.85 ms, profiles/exp_r4_sums_waves.log)
 #endif
 #if ISAAC_SUMS_WAVES_PER_EU
 __attribute__((amdgpu_waves_per_eu(ISAAC_SUMS_WAVES_PER_EU, ISAAC_SUMS_WAVES_PER_EU)))
