@@ -3,6 +3,12 @@
 #include "template_lean.h"
 
 // k_plan_rescue: the mate-rescue problems of every cluster (template_lean.h: leanPlanCluster), one thread per cluster
+#ifndef ISAAC_WAVES_PLAN
+#define ISAAC_WAVES_PLAN 0
+#endif
+#if ISAAC_WAVES_PLAN
+__attribute__((amdgpu_waves_per_eu(ISAAC_WAVES_PLAN, ISAAC_WAVES_PLAN)))
+#endif
 __global__ __launch_bounds__(SELECT_BLOCK) void k_plan_rescue(const TemplateConstants *__restrict__ constants, DevReference R, u32 clusterBase, u32 nChunk, ClusterPools pools, RescueBuffers rb, const u32 *__restrict__ order)
 {
     const DevParams &P = constants->P;
@@ -438,6 +444,12 @@ __global__ __launch_bounds__(64 * RW_WAVES) void k_rescue_windows(DevParams P, D
     rescueWindowsProblem(P, R, bcl, clusterBase, rb, blockIdx.x * RW_WAVES + wave, lane, tables[wave], ldsBitmaps[wave], presentMaps[wave]);
 }
 
+#ifndef ISAAC_WAVES_RESCUE_ALIGN
+#define ISAAC_WAVES_RESCUE_ALIGN 0
+#endif
+#if ISAAC_WAVES_RESCUE_ALIGN
+__attribute__((amdgpu_waves_per_eu(ISAAC_WAVES_RESCUE_ALIGN, ISAAC_WAVES_RESCUE_ALIGN)))
+#endif
 __global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, ClusterPools pools, RescueBuffers rb, Counters *counters)
 {
     // (one shared copy of the quality tables here: with a copy per lane -- k_align_candidates -- this kernel was slower, 2.31 -> 3.37 ms as it is and 2.66 ->

@@ -5,6 +5,12 @@
 // k_select: TemplateBuilder::buildTemplate on the precomputed rescue outcomes and sums, the clippers and the FragmentHeader records,
 // one thread per cluster of the chunk (template_lean.h: no work area, no scratch); `skip`: clusters the wave-per-cluster pass takes.
 // Clusters the lean form does not do (leanSelectCluster) are appended to overflowList and redone by that pass as well.
+#ifndef ISAAC_WAVES_SELECT
+#define ISAAC_WAVES_SELECT 0
+#endif
+#if ISAAC_WAVES_SELECT
+__attribute__((amdgpu_waves_per_eu(ISAAC_WAVES_SELECT, ISAAC_WAVES_SELECT)))
+#endif
 __global__ __launch_bounds__(SELECT_BLOCK) void k_select(const TemplateConstants *__restrict__ constants, DevReference R, double logMismatchQ40, const u8 *__restrict__ bcl, u32 clusterBase, u32 nChunk, u32 tile,
                                                ClusterPools pools, RescueBuffers rb, const GappedResult *__restrict__ gappedResults, const ClusterSums *__restrict__ sums,
                                                FragmentRecord *__restrict__ records, u32 *__restrict__ cigars, u32 *overflowList, u32 *overflowCount, const u8 *__restrict__ skip, Counters *counters, const u32 *__restrict__ order)
