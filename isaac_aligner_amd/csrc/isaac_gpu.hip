@@ -602,9 +602,9 @@ void isaac_gpu_destroy(isaac_gpu_ctx *c)
 int isaac_gpu_malloc(isaac_gpu_ctx *c, uint64_t bytes, void **dev) { ISAAC_TRY HIP_CHECK(hipSetDevice(c->device)); HIP_CHECK(hipMalloc(dev, bytes ? bytes : 16)); return 0; ISAAC_CATCH }
 int isaac_gpu_free(isaac_gpu_ctx *c, void *dev) { ISAAC_TRY HIP_CHECK(hipSetDevice(c->device)); HIP_CHECK(hipFree(dev)); return 0; ISAAC_CATCH }
 int isaac_gpu_upload(isaac_gpu_ctx *c, void *dev, const void *host, uint64_t bytes)
-{ ISAAC_TRY HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
+{ ISAAC_TRY HIP_CHECK(hipSetDevice(c->device)); HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
 int isaac_gpu_download(isaac_gpu_ctx *c, void *host, const void *dev, uint64_t bytes)
-{ ISAAC_TRY HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
+{ ISAAC_TRY HIP_CHECK(hipSetDevice(c->device)); HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
 int isaac_gpu_host_malloc(uint64_t bytes, void **hostOut)
 {
     ISAAC_TRY
@@ -626,7 +626,7 @@ int isaac_gpu_memory_info(isaac_gpu_ctx *c, uint64_t *freeOut, uint64_t *totalOu
     ISAAC_CATCH
 }
 int isaac_gpu_copy(isaac_gpu_ctx *c, void *dstDev, const void *srcDev, uint64_t bytes)
-{ ISAAC_TRY if (bytes) HIP_CHECK(hipMemcpyAsync(dstDev, srcDev, bytes, hipMemcpyDeviceToDevice, c->stream)); return 0; ISAAC_CATCH }
+{ ISAAC_TRY HIP_CHECK(hipSetDevice(c->device)); if (bytes) HIP_CHECK(hipMemcpyAsync(dstDev, srcDev, bytes, hipMemcpyDeviceToDevice, c->stream)); return 0; ISAAC_CATCH }
 // the candidate pool of a selection was sized from a match count that was too small (isaac_gpu_select_n): clusters past its end are flagged
 // and counted, and the first wait after the call says so
 static int checkPoolShort(isaac_gpu_ctx *c)
