@@ -64,6 +64,51 @@ def main():
             timing.update({"wall_s": round(wall, 2), "reads_per_s": round(timing["reads"] / wall, 1), "reads_per_s_without_reference_load": round(timing["reads"] / (timing["total_s"] - timing["reference_s"]), 1),
                            "genome_bases": n_bases, "read_length": L})
             print("cli_end_to_end " + json.dumps(timing), flush=True)
+            import hashlib
+            for suffix in ("", ".bai"):
+                h = hashlib.md5()
+                with open(os.path.join(work, "Aligned", "Projects", "default", "default", "sorted.bam" + suffix), "rb") as f:
+                    for block in iter(lambda: f.read(1 << 26), b""):
+                        h.update(block)
+                print("md5 sorted.bam%s %s" % (suffix, h.hexdigest()), flush=True)
+            if os.environ.get("CLI_INFLATE"):
+                # the file's content against the previous run's: the records must not depend on the options that only deal the work out
+                import zlib
+                from isaac_aligner_amd import bam as bam_host
+                raw = open(os.path.join(work, "Aligned", "Projects", "default", "default", "sorted.bam"), "rb").read()
+                parts, at = [], 0
+                while at < len(raw):
+                    size = int.from_bytes(raw[at + 16:at + 18], "little") + 1
+                    parts.append(zlib.decompress(raw[at + 18:at + size - 8], -15))
+                    at += size
+                content = np.frombuffer(b"".join(parts), np.uint8)
+                del raw, parts
+                global previous_content
+                def records_of(arr):                      # behind the header (its @PG line carries the command line, which differs between the runs)
+                    l_text = int.from_bytes(arr[4:8].tobytes(), "little"); p = 8 + l_text
+                    n_ref = int.from_bytes(arr[p:p + 4].tobytes(), "little"); p += 4
+                    for _ in range(n_ref):
+                        l_name = int.from_bytes(arr[p:p + 4].tobytes(), "little"); p += 8 + l_name
+                    return arr[p:]
+                content = records_of(content)
+                if "previous_content" in globals() and previous_content is not None:
+                    same = len(content) == len(previous_content) and bool((content == previous_content).all())
+                    print("inflated records %d bytes, identical to the previous run's: %s" % (len(content), same), flush=True)
+                    if not same:
+                        n = min(len(content), len(previous_content))
+                        first = int(np.argmax(content[:n] != previous_content[:n]))
+                        print("first difference at byte %d of %d / %d" % (first, len(content), len(previous_content)))
+                        p = 0
+                        while p < n:
+                            size = int.from_bytes(previous_content[p:p + 4].tobytes(), "little")
+                            if p + 4 + size > first:
+                                break
+                            p += 4 + size
+                        for arr, label in ((previous_content, "previous"), (content, "this")):
+                            r = bam_host.parse_records(arr[p:p + 4 + int.from_bytes(arr[p:p + 4].tobytes(), "little")].tobytes())[0]
+                            r.pop("qual"); r.pop("seq")
+                            print(label, r)
+                previous_content = content
     bam = os.path.join(work, "Aligned", "Projects", "default", "default", "sorted.bam")
     print("sorted.bam %d MB, .bai %d KB" % (os.path.getsize(bam) // 1000000, os.path.getsize(bam + ".bai") // 1000))
     subprocess.run(["rm", "-rf", work])
