@@ -7,6 +7,35 @@ __device__ inline SumInputs sumInputs(const RescueBuffers &rb, u32 t, const Gapp
     return in;
 }
 __device__ inline void markResidual(const SumsBuffers &sb, u32 t) { sb.residualFlag[t] = 1; sb.residualList[atomicAdd(sb.residualCount, 1u)] = t; }
+// the same when several workgroups (one per list of the cluster) may come to that conclusion: the first one lists the cluster
+__device__ inline bool markResidualOnce(const SumsBuffers &sb, u32 t)
+{
+    u32 *word = reinterpret_cast<u32 *>(sb.residualFlag + (t & ~3u));
+    const u32 bit = 1u << (8 * (t & 3u));
+    if (atomicOr(word, bit) & bit) return false;
+    sb.residualList[atomicAdd(sb.residualCount, 1u)] = t;
+    return true;
+}
+// the next (cluster, list) item of a tier, handed out as the workgroups become free, the pair lists -- the longest -- first: a fixed stride gave
+// the workgroups that began with a long list a second one
+__device__ inline u32 nextItem(u32 *counter, u32 *slot)
+{
+    __syncthreads();                                   // everybody has read the last item's number
+    if (0 == threadIdx.x) *slot = atomicAdd(counter, 1u);
+    __syncthreads();
+    return *slot;
+}
+// what a workgroup that did list `part` of a cluster leaves behind (status: clusterSums')
+__device__ inline void storePart(const SumsBuffers &sb, u32 t, u32 part, u32 status, const ClusterSums &out, u32 *nextList, u32 *nextCount, Counters &local)
+{
+    if (SUMS_DONE == status)
+    {
+        if (part < 2) sb.sums[t].shadow[part] = out.shadow[part]; else { sb.sums[t].pair = out.pair; sb.sums[t].ordered = out.ordered; }
+        if (0 == part) ++local.largeSums;
+    }
+    else if (SUMS_TOO_LARGE == status && nextList) { if (0 == part) nextList[atomicAdd(nextCount, 1u)] = t; }       // every part finds the same: the first one says so
+    else if (markResidualOnce(sb, t)) { if (SUMS_NEAR_TIE == status) ++local.residualNearTie; else if (SUMS_TOO_LARGE == status) ++local.residualOversize; else ++local.residualCapacity; }
+}
 
 // clusterSums (sums.h) for one wavefront and lists of at most 64 entries, arranged for latency instead of generality: lane j
 // finishes rescue problem j (the problems' memory round trips overlap), every rescued shadow is fetched once into a table in
@@ -221,22 +250,17 @@ __global__ __launch_bounds__(256) void k_cluster_sums_large(DevParams P, Cluster
 __global__ __launch_bounds__(1024) void k_cluster_sums_xl(DevParams P, ClusterPools pools, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters)
 {
     extern __shared__ __align__(16) u8 xlKeyBytes[];
-    __shared__ u32 scratch;
+    __shared__ u32 scratch, item;
     Counters local; memset(&local, 0, sizeof(local));
     const u32 n = *sb.xlCount;
     SumKeys keys; sumKeysBind(keys, xlKeyBytes, SUMS_XL_CAP);
-    for (u32 i = blockIdx.x; i < n; i += gridDim.x)
+    for (u32 i = nextItem(sb.xlCount + 3, &item); i < 3 * n; i = nextItem(sb.xlCount + 3, &item))       // a workgroup per list: (cluster, part)
     {
-        const u32 t = sb.xlList[i];
+        const u32 t = sb.xlList[i % n], part = 2 - i / n;
         SumGroup g; g.lanes = 1024; g.lane = threadIdx.x; g.block = true; g.radix = SumRadix{nullptr, nullptr, nullptr, nullptr, nullptr, 0}; g.radixMin = 0; g.sumTile = nullptr; g.sumTileCap = 0;
         ClusterSums out;
-        const u32 status = clusterSums(P, clusterView(pools.meta[t], pools.cands, pools.cigars), sumInputs(rb, t, gb), keys, g, &scratch, false, out, local);
-        if (0 == threadIdx.x)
-        {
-            if (SUMS_DONE == status) { sb.sums[t] = out; ++local.largeSums; }
-            else if (SUMS_TOO_LARGE == status) sb.hugeList[atomicAdd(sb.hugeCount, 1u)] = t;
-            else { markResidual(sb, t); if (SUMS_NEAR_TIE == status) ++local.residualNearTie; else ++local.residualCapacity; }
-        }
+        const u32 status = clusterSums(P, clusterView(pools.meta[t], pools.cands, pools.cigars), sumInputs(rb, t, gb), keys, g, &scratch, false, out, local, part);
+        if (0 == threadIdx.x) storePart(sb, t, part, status, out, sb.hugeList, sb.hugeCount, local);
         __syncthreads();
     }
     flushCounters(local, counters);
@@ -246,7 +270,7 @@ __global__ __launch_bounds__(1024) void k_cluster_sums_xl(DevParams P, ClusterPo
 // per workgroup), 1024 lanes per cluster
 __global__ __launch_bounds__(1024) void k_cluster_sums_huge(DevParams P, ClusterPools pools, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters)
 {
-    __shared__ u32 scratch;
+    __shared__ u32 scratch, item;
     __shared__ __align__(16) u16 radixCounts[16 * 1024];
     __shared__ u32 radixTotals[1024];
     __shared__ u64 radixVary[2];
@@ -255,21 +279,16 @@ __global__ __launch_bounds__(1024) void k_cluster_sums_huge(DevParams P, Cluster
     const u32 n = *sb.hugeCount;
     u8 *mine = sb.hugeKeys + size_t(blockIdx.x) * SUMS_HUGE_CAP * SUMS_HUGE_ENTRY;
     SumKeys keys; sumKeysBind(keys, mine, SUMS_HUGE_CAP);
-    for (u32 i = blockIdx.x; i < n; i += gridDim.x)
+    for (u32 i = nextItem(sb.hugeCount + 3, &item); i < 3 * n; i = nextItem(sb.hugeCount + 3, &item))       // a workgroup per list: (cluster, part)
     {
-        const u32 t = sb.hugeList[i];
+        const u32 t = sb.hugeList[i % n], part = 2 - i / n;
         SumGroup g; g.lanes = 1024; g.lane = threadIdx.x; g.block = true; g.radixMin = 0;
         g.sumTile = reinterpret_cast<double *>(radixCounts); g.sumTileCap = sizeof(radixCounts) / 8;        // the counts are idle by then
         g.radix.counts = radixCounts; g.radix.totals = radixTotals; g.radix.vary = radixVary; g.radix.alt = reinterpret_cast<u16 *>(mine + size_t(SUMS_HUGE_CAP) * 42); g.radix.digits = radixDigits; g.radix.digitsCap = SUMS_HUGE_DIGITS;
         ClusterSums out;
-        const u32 status = clusterSums(P, clusterView(pools.meta[t], pools.cands, pools.cigars), sumInputs(rb, t, gb), keys, g, &scratch, false, out, local);
-        if (0 == threadIdx.x)
-        {
-            if (SUMS_DONE == status) { sb.sums[t] = out; ++local.largeSums; }
-            else { markResidual(sb, t); if (SUMS_NEAR_TIE == status) ++local.residualNearTie; else if (SUMS_TOO_LARGE == status) ++local.residualOversize; else ++local.residualCapacity; }
-        }
+        const u32 status = clusterSums(P, clusterView(pools.meta[t], pools.cands, pools.cigars), sumInputs(rb, t, gb), keys, g, &scratch, false, out, local, part);
+        if (0 == threadIdx.x) storePart(sb, t, part, status, out, nullptr, nullptr, local);
         __syncthreads();
     }
     flushCounters(local, counters);
 }
-

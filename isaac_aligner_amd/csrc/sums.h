@@ -376,7 +376,12 @@ ISAAC_HD void forEachShadow(const RescueJob &job, const SumInputs &in, const Sum
 
 // Everything k_select needs to know about the mate rescues of one cluster.  `first`: the jobs have not been finished yet (the
 // larger group that retries a SUMS_TOO_LARGE cluster skips that step).
-ISAAC_HD u32 clusterSums(const DevParams &P, const ClusterFragments &f, const SumInputs &in, SumKeys &k, const SumGroup &g, u32 *scratch, bool first, ClusterSums &out, Counters &cnt)
+// `part`: one of the cluster's three lists (0, 1: the shadow sums of either side; 2: the pair sum or the running sum) or all of them -- the lists are
+// independent once the problems are finished, and a cluster of a repeat family is a millisecond of barriers and memory round trips per list: the
+// tiers for long lists give every list a workgroup of its own.  The capacity check looks at all three lists whichever part is asked for.
+static const u32 SUMS_ALL_PARTS = 3;
+ISAAC_HD u32 clusterSums(const DevParams &P, const ClusterFragments &f, const SumInputs &in, SumKeys &k, const SumGroup &g, u32 *scratch, bool first, ClusterSums &out, Counters &cnt,
+                         u32 part = SUMS_ALL_PARTS)
 {
     out.shadow[0] = out.shadow[1] = out.pair = out.ordered = 0.0;
     if (first)
@@ -395,6 +400,7 @@ ISAAC_HD u32 clusterSums(const DevParams &P, const ClusterFragments &f, const Su
     // sumUniqueShadowProbabilities of either side: the shadows its orphans rescued + the seeded candidates of the other read
     for (u32 side = 0; side < 2; ++side)
     {
+        if (SUMS_ALL_PARTS != part && side != part) continue;
         u32 base = 0;
         for (u32 j = 0; j < in.nJobs; ++j)
         {
@@ -408,6 +414,7 @@ ISAAC_HD u32 clusterSums(const DevParams &P, const ClusterFragments &f, const Su
         SUMS_T("gather", in.nJobs);
         if (!uniqueSortedSum(k, base + nCands[1 - side], false, g, scratch, out.shadow[side])) return SUMS_NEAR_TIE;
     }
+    if (SUMS_ALL_PARTS != part && 2 != part) return SUMS_DONE;
     if (bothReads)
     {   // sumUniquePairProbabilities: every orphan with every shadow it rescued, read 1's alignment first
         u32 base = 0;
