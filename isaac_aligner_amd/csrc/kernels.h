@@ -155,8 +155,11 @@ static const u32 SELECT_BLOCK = ISAAC_SELECT_BLOCK;     // threads per workgroup
 static const u32 SUMS_HUGE_ENTRY = 44;   // bytes per list entry of the HBM tier: the key arrays (42) + the second index array of the radix ordering
 // SUMS_XL_CAP is not a power of two: its index array is padded to the next one for the sorting network (SUMS_XL_LDS)
 static const u32 SUMS_XL_LDS = 3584 * 42 + (4096 - 3584) * 2;
+#ifndef ISAAC_SUMS_CLOSE_IDX
+#define ISAAC_SUMS_CLOSE_IDX 16384
+#endif
 static const u32 SUMS_QUARTER_CAP = 16, SUMS_WAVE_CAP = 64, SUMS_BLOCK_CAP = 1024, SUMS_XL_CAP = 3584, SUMS_HUGE_CAP = 65528 /* what 16-bit entry indexes allow; the reference reserves seeds x repeat threshold x 2000 pairs */,
-                 SUMS_HUGE_DIGITS = 32768 /* entries whose radix digits fit the LDS array */, SUMS_HUGE_BLOCKS = 512;
+                 SUMS_HUGE_DIGITS = 32768 /* entries whose radix digits fit the LDS array */, SUMS_HUGE_CLOSE_IDX = ISAAC_SUMS_CLOSE_IDX /* entries whose two index arrays fit it too */, SUMS_HUGE_BLOCKS = 512;
 struct SumsBuffers { ClusterSums *sums; u8 *residualFlag; u32 *residualList, *residualCount, *mediumList, *mediumCount, *largeList, *largeCount, *xlList, *xlCount, *hugeList, *hugeCount; u8 *hugeKeys; };
 
 static const u32 HEAVY_SORT_LDS = 32768;   // u16 indices: heavyCaps().prob / .pair entries

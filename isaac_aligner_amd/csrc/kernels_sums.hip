@@ -275,6 +275,7 @@ __global__ __launch_bounds__(1024) void k_cluster_sums_huge(DevParams P, Cluster
     __shared__ u32 radixTotals[1024];
     __shared__ u64 radixVary[2];
     __shared__ u8 radixDigits[SUMS_HUGE_DIGITS];
+    __shared__ u16 closeIdx[2 * SUMS_HUGE_CLOSE_IDX];
     Counters local; memset(&local, 0, sizeof(local));
     const u32 n = *sb.hugeCount;
     u8 *mine = sb.hugeKeys + size_t(blockIdx.x) * SUMS_HUGE_CAP * SUMS_HUGE_ENTRY;
@@ -285,6 +286,7 @@ __global__ __launch_bounds__(1024) void k_cluster_sums_huge(DevParams P, Cluster
         SumGroup g; g.lanes = 1024; g.lane = threadIdx.x; g.block = true; g.radixMin = 0;
         g.sumTile = reinterpret_cast<double *>(radixCounts); g.sumTileCap = sizeof(radixCounts) / 8;        // the counts are idle by then
         g.radix.counts = radixCounts; g.radix.totals = radixTotals; g.radix.vary = radixVary; g.radix.alt = reinterpret_cast<u16 *>(mine + size_t(SUMS_HUGE_CAP) * 42); g.radix.digits = radixDigits; g.radix.digitsCap = SUMS_HUGE_DIGITS;
+        g.radix.closeIdx = closeIdx; g.radix.closeIdxCap = SUMS_HUGE_CLOSE_IDX;
         ClusterSums out;
         const u32 status = clusterSums(P, clusterView(pools.meta[t], pools.cands, pools.cigars), sumInputs(rb, t, gb), keys, g, &scratch, false, out, local, part);
         if (0 == threadIdx.x) storePart(sb, t, part, status, out, nullptr, nullptr, local);
