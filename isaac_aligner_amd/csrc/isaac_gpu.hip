@@ -106,7 +106,7 @@ struct isaac_gpu_ctx
     struct ChunkDesc { const uint8_t *bcl = nullptr; u32 clusterBase = 0, tile = 0; FragmentRecord *records = nullptr; u32 *cigars = nullptr; DevTls tls; RogCorrection rog; };
     bool deferredCompletion = false;
     u32 selectCapacity = 0;        // chunk size the buffers of the select stage were last sized for
-    DevBuf<u32> heavyList, heavyCount, indelList, alignList, generalList, generalCount; DevBuf<u8> heavyFlag;
+    DevBuf<u32> midList, heavyList, heavyCount, indelList, alignList, generalList, generalCount; DevBuf<u8> heavyFlag;
     u32 chunkClusters = 1048576;   // upper bound of a chunk (ISAAC_GPU_CHUNK_CLUSTERS)
     u32 chunkNow = 0;              // the chunk size in use: the largest call so far, rounded up, at most chunkClusters; sizes the chunk-private buffers
 
@@ -649,9 +649,9 @@ static void debugTiers(isaac_gpu_ctx *c)
 {
     static const bool on = std::getenv("ISAAC_GPU_DEBUG_TIERS") != nullptr;
     if (!on || !c->heavyCount.p) return;
-    u32 n[8] = { 0 };
+    u32 n[16] = { 0 };
     HIP_CHECK(hipMemcpy(n, c->heavyCount.p, sizeof(n), hipMemcpyDeviceToHost));
-    std::fprintf(stderr, "isaac_gpu tiers (last chunk): residual %u, lists > 16: %u, > 64: %u, > 1024: %u, > 3584: %u\n", n[0], n[4], n[1], n[3], n[2]);
+    std::fprintf(stderr, "isaac_gpu tiers (last chunk): residual %u, lists > 16: %u, > 64: %u, > 256: %u, > 1024: %u, > 3584: %u\n", n[0], n[4], n[8], n[1], n[3], n[2]);
 }
 int isaac_gpu_synchronize(isaac_gpu_ctx *c) { ISAAC_TRY HIP_CHECK(hipStreamSynchronize(c->stream)); debugTiers(c); return checkPoolShort(c); ISAAC_CATCH }
 int isaac_gpu_set_deferred_completion(isaac_gpu_ctx *c, int enabled)
@@ -1401,10 +1401,10 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
     rb.jobs = c->jobs.p; rb.bitmaps = c->bitmaps.p; rb.candPositions = c->candPositions.p; rb.candJob = c->candJob.p; rb.shadowCands = c->shadowCands.p; rb.candRank = c->candRank.p;
     rb.shadowCigars = c->shadowCigars.p; rb.jobBase = c->jobBase.p; rb.jobCount = c->jobCount.p;
     rb.jobCounter = c->rescueCounters.p; rb.bitmapCounter = c->rescueCounters.p + 1; rb.candCounter = c->rescueCounters.p + 4;
-    c->clusterSums.reserve(chunk); c->heavyList.reserve(chunk); c->mediumList.reserve(chunk); c->largeList.reserve(chunk); c->hugeList.reserve(chunk); c->xlList.reserve(chunk); c->heavyCount.reserve(8); c->heavyFlag.reserve(chunk);
+    c->clusterSums.reserve(chunk); c->heavyList.reserve(chunk); c->mediumList.reserve(chunk); c->largeList.reserve(chunk); c->midList.reserve(chunk); c->hugeList.reserve(chunk); c->xlList.reserve(chunk); c->heavyCount.reserve(16); c->heavyFlag.reserve(chunk);
     c->hugeKeys.reserve(size_t(SUMS_HUGE_BLOCKS) * SUMS_HUGE_CAP * SUMS_HUGE_ENTRY);
     SumsBuffers sb; sb.sums = c->clusterSums.p; sb.residualFlag = c->heavyFlag.p; sb.residualList = c->heavyList.p; sb.residualCount = c->heavyCount.p;
-    sb.mediumList = c->mediumList.p; sb.mediumCount = c->heavyCount.p + 4; sb.largeList = c->largeList.p; sb.largeCount = c->heavyCount.p + 1; sb.hugeList = c->hugeList.p; sb.hugeCount = c->heavyCount.p + 2; sb.xlList = c->xlList.p; sb.xlCount = c->heavyCount.p + 3; sb.hugeKeys = c->hugeKeys.p;
+    sb.mediumList = c->mediumList.p; sb.mediumCount = c->heavyCount.p + 4; sb.midList = c->midList.p; sb.midCount = c->heavyCount.p + 8; sb.largeList = c->largeList.p; sb.largeCount = c->heavyCount.p + 1; sb.hugeList = c->hugeList.p; sb.hugeCount = c->heavyCount.p + 2; sb.xlList = c->xlList.p; sb.xlCount = c->heavyCount.p + 3; sb.hugeKeys = c->hugeKeys.p;
     const DevReference R = c->ref();
     {
         TemplateConstants k; k.P = c->P; k.tls = t; k.rog = rog;
@@ -1443,7 +1443,7 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         HIP_CHECK(hipMemsetAsync(c->overflowCount.p, 0, 4, st));
         HIP_CHECK(hipMemsetAsync(c->rescueCounters.p, 0, (4 + CAND_REGIONS) * 4, st));
         HIP_CHECK(hipMemsetAsync(c->rescueCounters.p + 4 + CAND_REGIONS, 0xff, CAND_REGIONS * 4, st));   // per region: first request that did not fit
-        HIP_CHECK(hipMemsetAsync(c->heavyCount.p, 0, 32, st));
+        HIP_CHECK(hipMemsetAsync(c->heavyCount.p, 0, 64, st));
         HIP_CHECK(hipMemsetAsync(c->heavyFlag.p, 0, n, st));
         const u32 *order = nullptr;
         {
@@ -1483,6 +1483,7 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         }
         {
             ScopedTimer tm(c, "sums_large");
+            k_cluster_sums_mid<<<4096, 256, 0, st>>>(c->P, c->pools, rb, gbRescue, sb, c->counters.p);
             k_cluster_sums_large<<<2048, 256, 0, st>>>(c->P, c->pools, rb, gbRescue, sb, c->counters.p);
             HIP_CHECK(hipGetLastError());
         }

@@ -158,9 +158,9 @@ static const u32 SUMS_XL_LDS = 3584 * 42 + (4096 - 3584) * 2;
 #ifndef ISAAC_SUMS_CLOSE_IDX
 #define ISAAC_SUMS_CLOSE_IDX 16384
 #endif
-static const u32 SUMS_QUARTER_CAP = 16, SUMS_WAVE_CAP = 64, SUMS_BLOCK_CAP = 1024, SUMS_XL_CAP = 3584, SUMS_HUGE_CAP = 65528 /* what 16-bit entry indexes allow; the reference reserves seeds x repeat threshold x 2000 pairs */,
+static const u32 SUMS_QUARTER_CAP = 16, SUMS_WAVE_CAP = 64, SUMS_MID_CAP = 256, SUMS_BLOCK_CAP = 1024, SUMS_XL_CAP = 3584, SUMS_HUGE_CAP = 65528 /* what 16-bit entry indexes allow; the reference reserves seeds x repeat threshold x 2000 pairs */,
                  SUMS_HUGE_DIGITS = 32768 /* entries whose radix digits fit the LDS array */, SUMS_HUGE_CLOSE_IDX = ISAAC_SUMS_CLOSE_IDX /* entries whose two index arrays fit it too */, SUMS_HUGE_BLOCKS = 512;
-struct SumsBuffers { ClusterSums *sums; u8 *residualFlag; u32 *residualList, *residualCount, *mediumList, *mediumCount, *largeList, *largeCount, *xlList, *xlCount, *hugeList, *hugeCount; u8 *hugeKeys; };
+struct SumsBuffers { ClusterSums *sums; u8 *residualFlag; u32 *residualList, *residualCount, *mediumList, *mediumCount, *midList, *midCount, *largeList, *largeCount, *xlList, *xlCount, *hugeList, *hugeCount; u8 *hugeKeys; };
 
 static const u32 HEAVY_SORT_LDS = 32768;   // u16 indices: heavyCaps().prob / .pair entries
 
@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void k_rescue_gapped_plan(ClusterPools pools, 
 __global__ __launch_bounds__(256) void k_rescue_gapped_plan_long(ClusterPools pools, RescueBuffers rb, GappedBuffers gb, const u32 *longList, const u32 *longCount);
 __global__ __launch_bounds__(16 * SUMS16_GROUPS) void k_cluster_sums16(DevParams P, ClusterPools pools, u32 nChunk, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters, const u32 *order);
 __global__ __launch_bounds__(256) void k_cluster_sums(DevParams P, ClusterPools pools, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);
+__global__ __launch_bounds__(256) void k_cluster_sums_mid(DevParams P, ClusterPools pools, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);
 __global__ __launch_bounds__(256) void k_cluster_sums_large(DevParams P, ClusterPools pools, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);
 __global__ __launch_bounds__(1024) void k_cluster_sums_xl(DevParams P, ClusterPools pools, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);
 __global__ __launch_bounds__(1024) void k_cluster_sums_huge(DevParams P, ClusterPools pools, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters);

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void k_cluster_sums(DevParams P, ClusterPools 
         if (0 == lane)
         {
             if (SUMS_DONE == status) sb.sums[t] = out;
-            else if (SUMS_TOO_LARGE == status) sb.largeList[atomicAdd(sb.largeCount, 1u)] = t;
+            else if (SUMS_TOO_LARGE == status) sb.midList[atomicAdd(sb.midCount, 1u)] = t;
             else { markResidual(sb, t); if (SUMS_NEAR_TIE == status) ++local.residualNearTie; else ++local.residualCapacity; }
         }
         groupSync(g);
@@ -222,29 +222,31 @@ __global__ __launch_bounds__(256) void k_cluster_sums(DevParams P, ClusterPools 
     flushCounters(local, counters);
 }
 
-__global__ __launch_bounds__(256) void k_cluster_sums_large(DevParams P, ClusterPools pools, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters)
+// Lists of up to 256 and of up to 1 024 entries: a workgroup of 256 lanes per list, the keys in LDS -- 10.5 KB for the first kind, which is most of them, so
+// that a CU holds twelve such workgroups instead of three.  A cluster whose lists do not fit goes to the next tier's list.
+template <u32 CAP> __device__ inline void clusterSumsBlockTier(const DevParams &P, const ClusterPools &pools, const RescueBuffers &rb, const GappedBuffers &gb, const SumsBuffers &sb, Counters *counters,
+                                                               const u32 *list, const u32 *listCount, u32 *workCounter, u32 *nextList, u32 *nextCount)
 {
-    __shared__ __align__(16) u8 keyBytes[SUMS_BLOCK_CAP * 42];
-    __shared__ u32 scratch;
+    __shared__ __align__(16) u8 keyBytes[CAP * 42];
+    __shared__ u32 scratch, item;
     Counters local; memset(&local, 0, sizeof(local));
-    const u32 n = *sb.largeCount;
-    for (u32 i = blockIdx.x; i < n; i += gridDim.x)
+    const u32 n = *listCount;
+    for (u32 i = nextItem(workCounter, &item); i < 3 * n; i = nextItem(workCounter, &item))       // a workgroup per list, as in the tiers above
     {
-        const u32 t = sb.largeList[i];
-        SumKeys keys; sumKeysBind(keys, keyBytes, SUMS_BLOCK_CAP);
+        const u32 t = list[i % n], part = 2 - i / n;
+        SumKeys keys; sumKeysBind(keys, keyBytes, CAP);
         SumGroup g; g.lanes = 256; g.lane = threadIdx.x; g.block = true; g.radix = SumRadix{nullptr, nullptr, nullptr, nullptr, nullptr, 0}; g.radixMin = 0; g.sumTile = nullptr; g.sumTileCap = 0;
         ClusterSums out;
-        const u32 status = clusterSums(P, clusterView(pools.meta[t], pools.cands, pools.cigars), sumInputs(rb, t, gb), keys, g, &scratch, false, out, local);
-        if (0 == threadIdx.x)
-        {
-            if (SUMS_DONE == status) { sb.sums[t] = out; ++local.largeSums; }
-            else if (SUMS_TOO_LARGE == status) sb.xlList[atomicAdd(sb.xlCount, 1u)] = t;
-            else { markResidual(sb, t); if (SUMS_NEAR_TIE == status) ++local.residualNearTie; else ++local.residualCapacity; }
-        }
+        const u32 status = clusterSums(P, clusterView(pools.meta[t], pools.cands, pools.cigars), sumInputs(rb, t, gb), keys, g, &scratch, false, out, local, part);
+        if (0 == threadIdx.x) storePart(sb, t, part, status, out, nextList, nextCount, local);
         __syncthreads();
     }
     flushCounters(local, counters);
 }
+__global__ __launch_bounds__(256) void k_cluster_sums_mid(DevParams P, ClusterPools pools, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters)
+{ clusterSumsBlockTier<SUMS_MID_CAP>(P, pools, rb, gb, sb, counters, sb.midList, sb.midCount, sb.midCount + 1, sb.largeList, sb.largeCount); }
+__global__ __launch_bounds__(256) void k_cluster_sums_large(DevParams P, ClusterPools pools, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters)
+{ clusterSumsBlockTier<SUMS_BLOCK_CAP>(P, pools, rb, gb, sb, counters, sb.largeList, sb.largeCount, sb.largeCount + 6, sb.xlList, sb.xlCount); }
 
 // lists of up to 3584 entries: 1024 lanes per cluster, the keys in 147 KB of the CU's 160 KB of LDS
 __global__ __launch_bounds__(1024) void k_cluster_sums_xl(DevParams P, ClusterPools pools, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters)

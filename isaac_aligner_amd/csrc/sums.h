@@ -225,7 +225,7 @@ ISAAC_HD bool uniqueSortedSum(SumKeys &k, u32 n, bool pairs, const SumGroup &g, 
     if (g.radix.counts && n >= g.radixMin) { order = radixOrder(k, n, pairs, g); same = n <= g.radix.digitsCap ? g.radix.digits : nullptr; }
     else
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (!g.block && n <= g.lanes)
+    if (n <= g.lanes && !g.sumTile)      // (a wavefront or a workgroup; not the HBM tier, whose keys are not in LDS)
     {   // one entry per lane: its place in the order is the number of entries before it, counted against every entry in turn (the
         // LDS reads of entry j are the same address for all lanes); a fraction of the instructions of the network below
         const u32 i = g.lane < n ? g.lane : 0;
