@@ -16,6 +16,22 @@ __device__ inline bool markResidualOnce(const SumsBuffers &sb, u32 t)
     sb.residualList[atomicAdd(sb.residualCount, 1u)] = t;
     return true;
 }
+// The cluster's problem records in LDS for the workgroup tiers: clusterSums walks them several times, a field at a time, every walk a chain of
+// round trips to the L2 (ten problems: 30 us of a list's 60).  They are only read there (the problems were finished by the first tier).
+static const u32 SUMS_STAGED_JOBS = 64;
+__device__ inline SumInputs stagedInputs(const RescueBuffers &rb, u32 t, const GappedBuffers &gb, RescueJob *staged)
+{
+    SumInputs in = sumInputs(rb, t, gb);
+    __syncthreads();                                   // the last list's readers are done with the copy
+    if (in.nJobs <= SUMS_STAGED_JOBS)
+    {
+        const u32 *from = reinterpret_cast<const u32 *>(in.jobs); u32 *to = reinterpret_cast<u32 *>(staged);
+        for (u32 w = threadIdx.x; w < in.nJobs * u32(sizeof(RescueJob) / 4); w += blockDim.x) to[w] = from[w];
+        in.jobs = staged;
+    }
+    __syncthreads();
+    return in;
+}
 // the next (cluster, list) item of a tier, handed out as the workgroups become free, the pair lists -- the longest -- first: a fixed stride gave
 // the workgroups that began with a long list a second one
 __device__ inline u32 nextItem(u32 *counter, u32 *slot)
@@ -228,6 +244,7 @@ template <u32 CAP> __device__ inline void clusterSumsBlockTier(const DevParams &
                                                                const u32 *list, const u32 *listCount, u32 *workCounter, u32 *nextList, u32 *nextCount)
 {
     __shared__ __align__(16) u8 keyBytes[CAP * 42];
+    __shared__ __align__(16) RescueJob stagedJobs[SUMS_STAGED_JOBS];
     __shared__ u32 scratch, item;
     Counters local; memset(&local, 0, sizeof(local));
     const u32 n = *listCount;
@@ -237,7 +254,7 @@ template <u32 CAP> __device__ inline void clusterSumsBlockTier(const DevParams &
         SumKeys keys; sumKeysBind(keys, keyBytes, CAP);
         SumGroup g; g.lanes = 256; g.lane = threadIdx.x; g.block = true; g.radix = SumRadix{nullptr, nullptr, nullptr, nullptr, nullptr, 0}; g.radixMin = 0; g.sumTile = nullptr; g.sumTileCap = 0;
         ClusterSums out;
-        const u32 status = clusterSums(P, clusterView(pools.meta[t], pools.cands, pools.cigars), sumInputs(rb, t, gb), keys, g, &scratch, false, out, local, part);
+        const u32 status = clusterSums(P, clusterView(pools.meta[t], pools.cands, pools.cigars), stagedInputs(rb, t, gb, stagedJobs), keys, g, &scratch, false, out, local, part);
         if (0 == threadIdx.x) storePart(sb, t, part, status, out, nextList, nextCount, local);
         __syncthreads();
     }
@@ -278,6 +295,7 @@ __global__ __launch_bounds__(1024) void k_cluster_sums_huge(DevParams P, Cluster
     __shared__ u64 radixVary[2];
     __shared__ u8 radixDigits[SUMS_HUGE_DIGITS];
     __shared__ u16 closeIdx[2 * SUMS_HUGE_CLOSE_IDX];
+    __shared__ __align__(16) RescueJob stagedJobs[SUMS_STAGED_JOBS];
     Counters local; memset(&local, 0, sizeof(local));
     const u32 n = *sb.hugeCount;
     u8 *mine = sb.hugeKeys + size_t(blockIdx.x) * SUMS_HUGE_CAP * SUMS_HUGE_ENTRY;
@@ -290,7 +308,7 @@ __global__ __launch_bounds__(1024) void k_cluster_sums_huge(DevParams P, Cluster
         g.radix.counts = radixCounts; g.radix.totals = radixTotals; g.radix.vary = radixVary; g.radix.alt = reinterpret_cast<u16 *>(mine + size_t(SUMS_HUGE_CAP) * 42); g.radix.digits = radixDigits; g.radix.digitsCap = SUMS_HUGE_DIGITS;
         g.radix.closeIdx = closeIdx; g.radix.closeIdxCap = SUMS_HUGE_CLOSE_IDX;
         ClusterSums out;
-        const u32 status = clusterSums(P, clusterView(pools.meta[t], pools.cands, pools.cigars), sumInputs(rb, t, gb), keys, g, &scratch, false, out, local, part);
+        const u32 status = clusterSums(P, clusterView(pools.meta[t], pools.cands, pools.cigars), stagedInputs(rb, t, gb, stagedJobs), keys, g, &scratch, false, out, local, part);
         if (0 == threadIdx.x) storePart(sb, t, part, status, out, nullptr, nullptr, local);
         __syncthreads();
     }
