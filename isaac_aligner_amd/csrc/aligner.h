@@ -181,12 +181,18 @@ ISAAC_HD AlignQuad alignQuad(u32 readBytes, u32 complement, u32 referenceBytes)
 {
     AlignQuad b;
     const u32 nFlags = zeroBytes32(readBytes & (0xfc * QUAD_01));                       // no quality bits: the base is an N
-    const u32 codes = (readBytes & (0x03 * QUAD_01)) ^ complement;
-    const u32 nBytes = nFlags | (nFlags - (nFlags >> 7));                                 // 0xff under an N
-    const u32 strand = (asciiOfCodes32(codes) & ~nBytes) | ((0x6e * QUAD_01) & nBytes);   // 'n' for N
+    // the strand's bytes from an eight-entry table: codes 0..3 are A C G T, 4..7 (an N: its flag moved to bit 2) are 'n'
+    const u32 select = ((readBytes & (0x03 * QUAD_01)) ^ complement) | (nFlags >> 5);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 strand = __builtin_amdgcn_perm(0x6e6e6e6eu, 0x54474341u, select);
+#else
+    u32 strand = 0;
+    for (u32 k = 0; k < 4; ++k) { const u32 c = (select >> (8 * k)) & 7; strand |= (c < 4 ? (0x54474341u >> (8 * c)) & 0xffu : 0x6eu) << (8 * k); }
+#endif
     const u32 equalFlags = zeroBytes32(strand ^ referenceBytes);
-    const u32 referenceNFlags = zeroBytes32(referenceBytes ^ (0x4e * QUAD_01));
-    b.matchFlags = nFlags | (equalFlags & ~referenceNFlags);
+    // isMatch: an N of the read matches anything; otherwise equal bytes -- which are A C G or T, the strand has no upper-case N, so "and the
+    // reference is not N" needs no test of its own
+    b.matchFlags = nFlags | equalFlags;
     b.differFlags = ~equalFlags & (0x80 * QUAD_01);
     b.termAt = ((readBytes >> 2) & (0x3f * QUAD_01)) | (nFlags >> 6) | ((~b.matchFlags & (0x80 * QUAD_01)) >> 1);      // N: quality 2
     return b;
