@@ -293,7 +293,7 @@ ISAAC_HD u32 updateFragmentCigar(const DevParams &P, const DevReference &R, cons
                 };
                 const u32 mismatchesBefore = mismatchCount;
 #if !defined(ISAAC_SCAN_AHEAD)
-#define ISAAC_SCAN_AHEAD 1
+#define ISAAC_SCAN_AHEAD 32
 #endif
 #if ISAAC_SCAN_AHEAD == 4
                 u64 r0 = 0, r1 = 0, r2 = 0, r3 = 0, f0 = 0, f1 = 0, f2 = 0, f3 = 0;
@@ -313,6 +313,51 @@ ISAAC_HD u32 updateFragmentCigar(const DevParams &P, const DevReference &R, cons
                     block(r0, f0); load(b + 2, r0, f0);
                     if (b + 1 < nBlocks) { block(r1, f1); load(b + 3, r1, f1); }
                 }
+#elif ISAAC_SCAN_AHEAD == 32
+                // thirty-two bytes a load pair (measured against sixteen: see ISAAC_SCAN_AHEAD == 16)
+                struct Bytes32 { u64 w0, w1, w2, w3; };
+                const u32 nGroups = nBlocks / 4;
+                const auto loadGroup = [&](u32 g, Bytes32 &readBytes, Bytes32 &referenceBytes)
+                {
+                    const size_t at = 32 * size_t(g < nGroups ? g : nGroups - 1);
+                    memcpy(&readBytes, reverse ? readAt - at - 24 : readAt + at, 32);
+                    memcpy(&referenceBytes, referenceAt + at, 32);
+                };
+                if (nGroups)
+                {
+                    Bytes32 ra, fa, rb, fb;
+                    loadGroup(0, ra, fa);
+                    for (u32 g = 0; g < nGroups; ++g)
+                    {
+                        loadGroup(g + 1, rb, fb);
+                        block(reverse ? ra.w3 : ra.w0, fa.w0); block(reverse ? ra.w2 : ra.w1, fa.w1); block(reverse ? ra.w1 : ra.w2, fa.w2); block(reverse ? ra.w0 : ra.w3, fa.w3);
+                        ra = rb; fa = fb;
+                    }
+                }
+                for (u32 b = 4 * nGroups; b < nBlocks; ++b) { u64 r0 = 0, f0 = 0; load(b, r0, f0); block(r0, f0); }
+#elif ISAAC_SCAN_AHEAD == 16
+                // sixteen bytes a load, the next pair of blocks on its way while the current pair is worked on; an odd last block by itself
+                struct Bytes16 { u64 lo, hi; };
+                const u32 nPairs = nBlocks / 2;
+                const auto loadPair = [&](u32 g, Bytes16 &readBytes, Bytes16 &referenceBytes)
+                {
+                    const size_t at = 16 * size_t(g < nPairs ? g : nPairs - 1);
+                    memcpy(&readBytes, reverse ? readAt - at - 8 : readAt + at, 16);
+                    memcpy(&referenceBytes, referenceAt + at, 16);
+                };
+                if (nPairs)
+                {
+                    Bytes16 ra, fa, rb, fb;
+                    loadPair(0, ra, fa);
+                    for (u32 g = 0; g < nPairs; ++g)
+                    {
+                        loadPair(g + 1, rb, fb);
+                        // reverse: the pair's first block is the upper half of what was loaded
+                        block(reverse ? ra.hi : ra.lo, fa.lo); block(reverse ? ra.lo : ra.hi, fa.hi);
+                        ra = rb; fa = fb;
+                    }
+                }
+                if (nBlocks & 1) { u64 r0 = 0, f0 = 0; load(nBlocks - 1, r0, f0); block(r0, f0); }
 #else
                 u64 r0 = 0, f0 = 0, r1 = 0, f1 = 0;
                 load(0, r0, f0);
