@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void k_rescue_gapped_plan(ClusterPools pools, 
             {
                 base = atomicAdd(gb.counter, n);
                 if (base + n > gb.cap) base = 0xffffffffu;     // the cluster's thread runs them itself
-                else planRescueGapped(job, rb.shadowCands, rb.shadowCigars, ecm, gb.jobs + base);
+                else writeRescueGapped(job, rb.shadowCands, rb.shadowCigars, ecm, gb.jobs + base);
             }
             job.gappedBase = base; job.nGapped = n;
         }

@@ -668,6 +668,43 @@ ISAAC_HD void summarizeRescueJob(RescueJob &job, const Cand *shadowCands, u32 *c
 // Which shadows of a job ShadowAligner.cpp:232-262 hands to the gapped aligner.  The choice reads only the ungapped results
 // (the loop compares each element with its not yet modified successor), so the retries can run before the cluster's thread
 // consumes them.  out == NULL: count only.
+// The second walk of planRescueGapped for a problem whose summary says that there are retries (job.nGapped, so the best candidate's mismatches are
+// known to qualify): positions, mismatch counts and "aligned" fetched SUMMARY_BATCH candidates at a time, as in the summary -- the few threads of a wave
+// that come here would otherwise walk their lists a load at a time, twice, while the others wait.
+ISAAC_HD u32 writeRescueGapped(const RescueJob &job, const Cand *shadowCands, const u32 *shadowCigars, u32 endCyclesMasked, GappedJob *out)
+{
+    u32 n = 0; i32 prev = -1; i64 prevPosition = 0; u32 prevMismatches = 0;
+    for (u32 c0 = 0; c0 < job.nCands; c0 += SUMMARY_BATCH)
+    {
+        i64 positions[SUMMARY_BATCH]; u32 mismatchCounts[SUMMARY_BATCH]; bool aligned[SUMMARY_BATCH];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (u32 k = 0; k < SUMMARY_BATCH; ++k)
+        {
+            const Cand &f = shadowCands[job.candBase + imin(c0 + k, job.nCands - 1)];
+            positions[k] = f.position; mismatchCounts[k] = f.mismatchCount; aligned[k] = candAligned(f);
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (u32 k = 0; k < SUMMARY_BATCH; ++k)
+        {
+            const u32 c = c0 + k;
+            if (c >= job.nCands) break;
+            if (!aligned[k]) continue;
+            if (prev >= 0 && positions[k] - prevPosition < i64(BSW_DISTANCE_CUTOFF) && BSW_MISMATCHES_CUTOFF < prevMismatches)
+            {
+                GappedJob &g = out[n]; g.in = shadowCands[job.candBase + u32(prev)]; g.cluster = job.cluster; g.endCyclesMasked = endCyclesMasked; g.tag = job.candBase + u32(prev); g.pad = 0;
+                g.in.cigarOffset = 0;
+                g.in.position = candUnclippedPosition(g.in, shadowCigars + u64(job.candBase + u32(prev)) * 3); g.in.cigarLength = 0;
+                ++n;
+            }
+            prev = i32(c); prevPosition = positions[k]; prevMismatches = mismatchCounts[k];
+        }
+    }
+    return n;
+}
 ISAAC_HD u32 planRescueGapped(const RescueJob &job, const Cand *shadowCands, const u32 *shadowCigars, u32 endCyclesMasked, GappedJob *out)
 {
     i32 best = -1;

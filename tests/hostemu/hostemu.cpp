@@ -267,7 +267,7 @@ int emu_select(Emu *e, const u8 *bcl, u32 nClusters, u32 tile, const isaac_tls *
             if (n != planRescueGapped(job, shadowCands.data(), shadowCigars.data(), ecm, 0)) { g_error = "summarizeRescueJob and planRescueGapped disagree"; return 1; }
             job.gappedBase = u32(gj.size()); job.nGapped = n;
             gj.resize(gj.size() + n);
-            if (n) planRescueGapped(job, shadowCands.data(), shadowCigars.data(), ecm, gj.data() + job.gappedBase);
+            if (n && n != writeRescueGapped(job, shadowCands.data(), shadowCigars.data(), ecm, gj.data() + job.gappedBase)) { g_error = "summarizeRescueJob and writeRescueGapped disagree"; return 1; }
         }
         gapped.resize(gj.size() + 1);
         for (size_t j = 0; j < gj.size(); ++j) runGappedJobSerial(e->P, e->R, bcl + u64(gj[j].cluster) * e->P.clusterLength, gj[j], tflags.data(), gapped[j]);
