@@ -471,7 +471,10 @@ __global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference 
 // one thread per rescue problem: which of its aligned candidates get a gapped retry (ShadowAligner.cpp:232-262).  Problems with
 // long candidate lists (repeat families: thousands of entries) would keep one thread walking them long after the rest of the
 // grid has finished; they are listed for k_rescue_gapped_plan_long instead.
-static const u32 GAPPED_PLAN_LONG = 48;
+#ifndef ISAAC_GAPPED_PLAN_LONG
+#define ISAAC_GAPPED_PLAN_LONG 48
+#endif
+static const u32 GAPPED_PLAN_LONG = ISAAC_GAPPED_PLAN_LONG;
 __global__ __launch_bounds__(256) void k_rescue_gapped_plan(ClusterPools pools, RescueBuffers rb, GappedBuffers gb, u32 *longList, u32 *longCount, Counters *counters)
 {
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
