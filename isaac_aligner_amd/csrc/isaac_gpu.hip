@@ -156,6 +156,9 @@ static void resolveTimers(isaac_gpu_ctx *c)
 // k_find_matches: ClusterSeedGenerator::generateThread (ClusterSeedGenerator.cpp:138-192) + ExactMaskMatcher::matchMask
 // (ExactMaskMatcher.cpp:83-184) for both seed iterations of FindMatchesTransition::findLaneMatches (:391-427).
 // 8 lanes cooperate on one cluster; each lane owns one (seed, strand) probe per round.
+#ifndef ISAAC_FIND_POSITION_ON_HIT
+#define ISAAC_FIND_POSITION_ON_HIT 1
+#endif
 static const u32 FIND_GROUP = 8, FIND_BLOCK = 256, FIND_CLUSTERS_PER_BLOCK = FIND_BLOCK / FIND_GROUP;
 
 __device__ inline u64 lowerBound(const u64 *kmers, u64 lo, u64 hi, u64 key, u32 &steps)
@@ -256,7 +259,11 @@ __global__ __launch_bounds__(FIND_BLOCK) void k_find_matches(DevParams P, DevRef
                     u32 r = 0;
                     const bool in0 = first < R.nKmers, in1 = first + 1 < R.nKmers;
                     const u64 k0 = in0 ? R.kmers[first] : 0, k1 = in1 ? R.kmers[first + 1] : 0;
+#if ISAAC_FIND_POSITION_ON_HIT
+                    pos0 = (in0 && k0 == kmer) ? R.positions[first] : 0;       // (A/B: the position's cache line only for probes that hit)
+#else
                     pos0 = in0 ? R.positions[first] : 0;
+#endif
                     if (in0 && k0 == kmer)
                     {
                         r = 1;
