@@ -46,7 +46,8 @@ def parse():
     ap.add_argument("--no-pcie-pass", action="store_true")
     ap.add_argument("--no-bam-pass", action="store_true")
     ap.add_argument("--no-neighbors", action="store_true")
-    ap.add_argument("--broadcast-index", action="store_true", help="with several GPUs: rank 0 builds the table, the others receive it over RCCL (default: every rank builds its own, in parallel)")
+    ap.add_argument("--broadcast-index", dest="broadcast_index", action="store_true", default=True, help="with several GPUs: rank 0 builds the table, the others receive it over RCCL (the default)")
+    ap.add_argument("--no-broadcast-index", dest="broadcast_index", action="store_false", help="with several GPUs: every rank builds its own table (N builds side by side)")
     ap.add_argument("--no-cli-pass", action="store_true", help="skip the isaac-align end-to-end leg (config.cli_end_to_end)")
     ap.add_argument("--cli-pairs", type=int, default=10_000_000, help="pairs the isaac-align leg aligns (the run's own batches, written as FASTQ)")
     ap.add_argument("--contexts", type=int, default=3, help="contexts (streams) per GPU that take the steps' selections in turn; they share the contigs and the table")
@@ -188,8 +189,7 @@ def cli_end_to_end(args, al, genome, batches, L, emit_note):
 
 
 def al_table_gb(al):
-    k, _ = al.index_tensors()
-    return 16.0 * k.numel() / 1e9
+    return 16.0 * al.index_tensors().shape[0] / 1e9
 
 
 def main():
@@ -233,13 +233,13 @@ def main():
     al = gpu.Aligner(params, local_rank, genome, deferred_completion=True)   # back-to-back select calls overlap; al.synchronize() completes them
     t_genome = time.time() - t0
     if dist is not None and args.broadcast_index:
-        # one build, N - 1 transfers of the two arrays of the table (47 GB at this size) over xGMI
+        # one build, N - 1 transfers of the table (47 GB at this size) over xGMI
         if rank == 0:
             n_index = al.build_index(repeat_threshold=1000, annotate_neighbors=not args.no_neighbors)
-        shared_table = shard.broadcast_table(*(al.index_tensors() if rank == 0 else (None, None)), dist, rank, dev)
+        shared_table = shard.broadcast_table(al.index_tensors() if rank == 0 else None, dist, rank, dev)
         if rank != 0:
-            al.set_index_tensors(*shared_table)
-            n_index = int(shared_table[0].numel())
+            al.set_index_tensors(shared_table)
+            n_index = int(shared_table.shape[0])
     else:
         n_index = al.build_index(repeat_threshold=1000, annotate_neighbors=not args.no_neighbors)
     t_index = time.time() - t0 - t_genome
@@ -253,7 +253,7 @@ def main():
         st = torch.cuda.Stream(dev)
         with torch.cuda.stream(st):
             extra = gpu.Aligner(params, local_rank, genome, deferred_completion=True)
-            extra.set_index_tensors(*table)
+            extra.set_index_tensors(table)
         als.append(extra)
         streams.append(st)
     n_batches = args.warmup + args.steps
@@ -464,24 +464,28 @@ def main():
                 host_cig[k][:n_k].copy_(out[k][2][:n_k], non_blocking=True)
         for s in range(args.steps):
             m, o = found[s]
-            al.select(dev_in[s][0], m, o, tls, tile=tile_of(s), out=out[s][:2])
-            al.compact_cigars_async(out[s][0], out[s][1], out[s][2], out[s][3])
-            done = torch.cuda.Event(); done.record()
-            if s:
-                download_cigars(s - 1)
+            ctx = als[s % n_contexts]                     # the selections dealt to the contexts in turn, as in the timed region
+            ctx.select(dev_in[s][0], m, o, tls, tile=tile_of(s), out=out[s][:2])
+            ctx.compact_cigars_async(out[s][0], out[s][1], out[s][2], out[s][3])
+            done = (streams[s % n_contexts] if ctx is not al else torch.cuda.current_stream(dev)).record_event()
+            if s >= n_contexts:
+                download_cigars(s - n_contexts)           # the step this context did before: complete by now, or soon; the other contexts keep the GPU busy
             with torch.cuda.stream(copy_stream):          # the step's records and the length of its CIGAR pool leave as soon as they are final
                 copy_stream.wait_event(done)
                 host_rec[s].copy_(out[s][0], non_blocking=True)
                 host_n[s].copy_(out[s][3], non_blocking=True)
                 left[s] = torch.cuda.Event(); left[s].record(copy_stream)
-        download_cigars(args.steps - 1)
-        al.synchronize()
+        for k in range(max(0, args.steps - n_contexts), args.steps):
+            download_cigars(k)
+        for ctx in als:
+            ctx.synchronize()
         torch.cuda.synchronize()
         t_pcie = time.perf_counter() - tp
         same = bool((out[0][0] == checked_records).all()) and bool((out[0][2][:checked_cigars.numel()] == checked_cigars).all())
         pcie = {"reads_per_s": round(2.0 * pairs_rank / t_pcie, 1), "records_identical_to_resident_pass": same, "ms_per_step": round(1e3 * t_pcie / args.steps, 3),
                 "bytes_in_per_pair": 2 * L, "bytes_out_per_pair": round((sum(r.numel() for r in host_rec) + 4 * sum(int(p.numel()) for p in packed)) / pairs_rank, 1),
-                "note": "BCL bytes uploaded from pinned host memory ahead of the lookups; a step's records + packed CIGARs are downloaded on a copy stream while the next step, already queued, computes"}
+                "contexts": n_contexts,
+                "note": "BCL bytes uploaded from pinned host memory ahead of the lookups; the selections dealt to the contexts in turn as in the timed region; a step's records + packed CIGARs are downloaded on a copy stream while the steps queued behind it compute"}
 
     # ---- the output side: all steps' records as one position-sorted BAM record stream, resident in HBM; reported beside `value`
     bam_info = None

@@ -177,14 +177,14 @@ int isaac_gpu_get_index_range(isaac_gpu_ctx *ctx, uint64_t first, uint64_t n, is
  * number of masks the table was loaded or built with (64 for a built one) */
 int isaac_gpu_get_mask_offsets(isaac_gpu_ctx *ctx, uint64_t *offsets_out, uint32_t n_masks);
 
-/* The resident table as it lies in HBM: kmers_dev[i] / positions_dev[i] = the i-th record of the concatenated mask files, split into two arrays
- * (read-only device pointers, valid until the table is rebuilt or reloaded or the context destroyed).  isaac_gpu_set_index_dev adopts such a
- * pair owned by the caller instead of loading one -- several contexts on one device share one table that way, and the ranks of a multi-GPU
+/* The resident table as it lies in HBM: entries_dev[i] = the i-th record of the concatenated mask files, k-mer and position side by side as the files
+ * hold them (a read-only device pointer, valid until the table is rebuilt or reloaded or the context destroyed; rounds 1-4 kept two arrays, which cost every
+ * probe that finds its k-mer a second cache line).  isaac_gpu_set_index_dev adopts such a
+ * table owned by the caller instead of loading one -- several contexts on one device share one table that way, and the ranks of a multi-GPU
  * job can receive rank 0's table over xGMI instead of building or reading their own.  mask_offsets (n_masks + 1 entries) may be NULL
  * when nobody will ask for the mask cuts.  The contig translation of isaac_gpu_load_index does not apply (positions are used as stored). */
-int isaac_gpu_index_dev(isaac_gpu_ctx *ctx, const uint64_t **kmers_dev_out, const uint64_t **positions_dev_out, uint64_t *n_entries_out);
-int isaac_gpu_set_index_dev(isaac_gpu_ctx *ctx, const uint64_t *kmers_dev, const uint64_t *positions_dev, uint64_t n_entries,
-                            const uint64_t *mask_offsets, uint32_t n_masks);
+int isaac_gpu_index_dev(isaac_gpu_ctx *ctx, const isaac_reference_kmer **entries_dev_out, uint64_t *n_entries_out);
+int isaac_gpu_set_index_dev(isaac_gpu_ctx *ctx, const isaac_reference_kmer *entries_dev, uint64_t n_entries, const uint64_t *mask_offsets, uint32_t n_masks);
 /* The same for two contexts of one process, whole: `ctx` takes `owner`'s table as it is -- entries, mask cuts, karyotype translation -- in place
  * when both are on one device (nothing is copied; `owner` must outlive `ctx` and keep its table), as a copy over the link between the two devices
  * when they are not.  Both must have loaded the same contigs.  What a host does for the second and further workers of a run (--devices). */
@@ -352,10 +352,16 @@ typedef struct
      * the templates without a position -- while every record of the tiles still serves as its mate's mate (duplicate ranks, pair details
      * after realignment).  The tiles of such a call are what isaac_gpu_bin_tile made for the bin.  Bins of whole contigs written in contig
      * order, the unaligned one last, give the very bytes of one call over all tiles. */
-    uint32_t bin_filter, bin_first_contig, bin_end_contig, bin_unaligned;
+    uint32_t bin_filter /* 0: no, 1: by contigs, 2: by positions (below) */, bin_first_contig, bin_end_contig, bin_unaligned;
     /* NULL, or room for one entry per record of the call's tiles: the call leaves there, in file order, what the BAM index wants to know about
      * every record it writes (isaac_gpu_bam_indexer_add_entries), so that a host need not fetch and parse the record stream itself. */
     struct isaac_bam_index_entry *index_entries_dev;
+    /* bin_filter 2: the bin is the positions [bin_first_position, bin_end_position), both in the encoding of isaac_fragment::f_strand_position
+     * (reference::ReferencePosition values, which order by contig, then position): a run of small contigs, or a stretch of a large one as
+     * alignment::BinMetadata describes it (the reference cuts its contigs into bins of --target-bin-size, include/alignment/matchSelector/BinIndexMap.hh:44-104).
+     * A bin is sorted, filtered for duplicates and realigned by itself (lib/build/BinSorter.cpp:293-330,387-417): only the bin's own records
+     * take part, gaps are looked for between its first and last position, a pair whose mate lies in another bin is not realigned. */
+    uint64_t bin_first_position, bin_end_position;
 } isaac_bam_options;
 /* offset and length of the record in the call's stream, refID, pos, FLAG and l_seq as written, the reference bases its CIGAR covers */
 typedef struct isaac_bam_index_entry { uint64_t offset; uint32_t bytes; int32_t ref_id; int32_t pos; uint32_t flag, seq_length, observed; } isaac_bam_index_entry;
@@ -368,12 +374,19 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *ctx, const isaac_bam_tile *tiles, uint3
  * isaac_gpu_compact_cigars or not) is cut into one compact tile per bin, each holding the clusters with at least one stored record in the bin:
  * their BCL bytes, their records (n_reads per cluster, in cluster order; cigar_offset relative to the tile's own words) and their CIGAR words.
  * A pair whose reads lie in two bins goes to both, whole.  bin_of_contig[c]: the bin of contig c (< n_bins - 1; bins of whole contigs in contig
- * order); bin n_bins - 1 takes the templates without a position.  out_dev receives, bin after bin, each part starting on a multiple of 64 bytes:
+ * order; isaac_gpu_bin_tile_map: bins that are stretches of a contig as well); bin n_bins - 1 takes the templates without a position.  out_dev receives, bin after bin, each part starting on a multiple of 64 bytes:
  *     n_clusters x cluster length bytes of BCL | n_clusters x n_reads records | n_cigar_words words
  * sizes_out[b]: the two counts of bin b; *n_bytes_out: the bytes written (or needed, with ISAAC_GPU_ECAPACITY).  A part's three arrays, copied
  * to wherever the bin is kept and back to a device, are the bcl_dev / fragments_dev / cigar_dev of an isaac_bam_tile with the original tile's name
  * prefix, read group and statistics. */
 typedef struct { uint64_t n_clusters, n_cigar_words; } isaac_bin_size;
+/* The bins of a run in file order (alignment::matchSelector::BinIndexMap, include/alignment/matchSelector/BinIndexMap.hh:44-104: every contig starts a
+ * bin of its own there and goes on into further bins by the match distribution; here the caller decides): bin_of_contig[c] is the first bin of contig c
+ * -- consecutive small contigs may share one --, and a contig goes on into the next bin at each of its cut_positions (ascending values in the encoding
+ * of isaac_fragment::f_strand_position).  Up to 65535 bins; the last one takes the templates without a position. */
+typedef struct { const uint32_t *bin_of_contig; uint32_t n_contigs; const uint64_t *cut_positions; uint32_t n_cuts; uint32_t n_bins; } isaac_bin_map;
+int isaac_gpu_bin_tile_map(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, const isaac_fragment *fragments_dev, const uint32_t *cigar_dev, uint32_t n_clusters,
+                           const isaac_bin_map *map, uint8_t *out_dev, uint64_t capacity, isaac_bin_size *sizes_out, uint64_t *n_bytes_out);
 int isaac_gpu_bin_tile(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, const isaac_fragment *fragments_dev, const uint32_t *cigar_dev, uint32_t n_clusters,
                        const uint32_t *bin_of_contig, uint32_t n_contigs, uint32_t n_bins, uint8_t *out_dev, uint64_t capacity, isaac_bin_size *sizes_out, uint64_t *n_bytes_out);
 

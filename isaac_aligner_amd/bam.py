@@ -14,11 +14,21 @@ class BamTile(C.Structure):
 class BamOptions(C.Structure):
     _fields_ = [("forced_dodgy_alignment_score", C.c_uint32), ("pessimistic_mapq", C.c_uint32), ("read_group", C.c_char_p), ("barcode", C.c_char_p),
                 ("mark_duplicates", C.c_uint32), ("keep_duplicates", C.c_uint32), ("realign_gaps", C.c_uint32), ("realign_vigorously", C.c_uint32), ("realign_dodgy", C.c_uint32),
-                ("tls", C.c_void_p), ("bin_filter", C.c_uint32), ("bin_first_contig", C.c_uint32), ("bin_end_contig", C.c_uint32), ("bin_unaligned", C.c_uint32), ("index_entries_dev", C.c_void_p)]
+                ("tls", C.c_void_p), ("bin_filter", C.c_uint32), ("bin_first_contig", C.c_uint32), ("bin_end_contig", C.c_uint32), ("bin_unaligned", C.c_uint32), ("index_entries_dev", C.c_void_p),
+                ("bin_first_position", C.c_uint64), ("bin_end_position", C.c_uint64)]
 
 
 class BinSize(C.Structure):
     _fields_ = [("n_clusters", C.c_uint64), ("n_cigar_words", C.c_uint64)]
+
+
+class BinMap(C.Structure):
+    _fields_ = [("bin_of_contig", C.c_void_p), ("n_contigs", C.c_uint32), ("cut_positions", C.c_void_p), ("n_cuts", C.c_uint32), ("n_bins", C.c_uint32)]
+
+
+def reference_position(contig, position):
+    """reference::ReferencePosition::getValue() (include/reference/ReferencePosition.hh:51-188), neighbour bit clear"""
+    return (((contig + 1) << 40) | position) << 1
 
 
 class BamError(RuntimeError):

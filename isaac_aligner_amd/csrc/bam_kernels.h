@@ -26,6 +26,7 @@ struct BamTile
 struct BamOptions { u32 nReads, readLength[2], readOffset[2], clusterLength, forcedDodgyAlignmentScore, pessimisticMapQ, barcodeLength, readGroupLength; char barcode[64], readGroup[64];
                     u32 markDuplicates, keepDuplicates, realignGaps; RealignParams realign; DevTls tls;
                     u32 binFilter, binFirstContig, binEndContig, binUnaligned;        // isaac_bam_options::bin_*: which records the call writes
+                    u64 binFirstPosition, binEndPosition;                             // binFilter 2: the bin is [first, end) in ReferencePosition values
                     isaac_bam_index_entry *indexEntries; };                            // isaac_bam_options::index_entries_dev
 
 static const u64 INSANELY_HIGH_NUMBER_OF_CLUSTERS_PER_TILE = 1000000000ull;   // include/build/FragmentIndex.hh:33
@@ -69,8 +70,16 @@ ISAAC_HD bool bamInBin(const FragmentRecord &r, const BamOptions &o)
 {
     if (!o.binFilter) return true;
     if (bamUnalignedBin(r)) return 0 != o.binUnaligned;
+    if (2 == o.binFilter) return r.fStrandPosition >= o.binFirstPosition && r.fStrandPosition < o.binEndPosition;     // ReferencePosition values order by contig, then position
     const u32 contig = refposContig(r.fStrandPosition);
     return contig >= o.binFirstContig && contig < o.binEndContig;
+}
+// The part of contig `contig` the call's bin covers, as BinSorter hands it to GapRealigner::realign (lib/build/BinSorter.cpp:405-417: binStartPos, binEndPos):
+// the whole contig unless the bin is a range of positions that begins or ends inside it
+ISAAC_HD void bamBinRange(const BamOptions &o, const DevReference &R, u32 contig, u64 &binStartPos, u64 &binEndPos)
+{
+    binStartPos = refpos(contig, 0); binEndPos = refpos(contig, contigLength(R, contig));
+    if (2 == o.binFilter) { binStartPos = imax(binStartPos, o.binFirstPosition); binEndPos = imin(binEndPos, o.binEndPosition); }
 }
 // The BCL bytes of the cluster a tile's record `local` belongs to: records come in cluster order, n_reads per cluster, so the cluster's place in
 // the tile's buffers is its records' -- which is its cluster id in the buffers of an isaac_gpu_select call, and stays right for the compacted
@@ -256,7 +265,8 @@ __global__ void k_dup_keys(const BamTile *tiles, u32 nTiles, u64 nRecords, BamOp
     const FragmentRecord &h = tiles[t].records[local];
     index[i] = u32(i);
     u64 primary = 0, mate = 0, rank = 0, cluster = 0, small = 0;
-    if (bamStored(h) && (h.flags & 1) && !bamUnalignedBin(h))
+    // (a bin is filtered by itself, BinSorter::resolveDuplicates: the records that are in the call's tiles as mates of the bin's own are not part of it)
+    if (bamStored(h) && (h.flags & 1) && !bamUnalignedBin(h) && bamInBin(h, o))
     {
         const FragmentRecord &m = tiles[t].records[local ^ 1];          // records come in cluster order, read 0 before read 1
         const u8 *clusterBcl = bamClusterBcl(tiles[t], local, o);
@@ -305,25 +315,25 @@ __global__ void k_dup_mark(const u32 *order, u64 n, const u64 *keyPrimary, const
 //   k_realign                             GapRealigner::realign per kept fragment (realign.h)
 //   k_realign_pairs                       GapRealigner::updatePairDetails once both ends are final
 __device__ inline const u32 *bamRecordCigar(const BamTile &t, const FragmentRecord &r) { return ((r.reserved & RECORD_CIGAR_REALIGNED) ? t.cigarsAlt : t.cigars) + r.cigarOffset; }
-__device__ inline bool realignHasGaps(const FragmentRecord &r) { return bamStored(r) && !(r.flags & 2) && !bamUnalignedBin(r) && r.gapCount; }
-__global__ void k_realign_count(const BamTile *tiles, u32 nTiles, u64 nRecords, u32 *counts)
+__device__ inline bool realignHasGaps(const FragmentRecord &r, const BamOptions &o) { return bamStored(r) && !(r.flags & 2) && !bamUnalignedBin(r) && r.gapCount && bamInBin(r, o); }
+__global__ void k_realign_count(const BamTile *tiles, u32 nTiles, u64 nRecords, BamOptions o, u32 *counts)
 {
     const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= nRecords) return;
     const u32 t = bamTileOf(tiles, nTiles, i);
     const FragmentRecord &r = tiles[t].records[i - tiles[t].firstRecord];
     u32 n = 0;
-    if (realignHasGaps(r)) { const u32 *c = bamRecordCigar(tiles[t], r); for (u32 k = 0; k < r.cigarLength; ++k) { const u32 code = cigarCode(c[k]); n += (OP_INSERT == code || OP_DELETE == code); } }
+    if (realignHasGaps(r, o)) { const u32 *c = bamRecordCigar(tiles[t], r); for (u32 k = 0; k < r.cigarLength; ++k) { const u32 code = cigarCode(c[k]); n += (OP_INSERT == code || OP_DELETE == code); } }
     counts[i] = n;
 }
 // RealignerGaps::addGaps (GapRealigner.hh:54-104)
-__global__ void k_realign_collect(const BamTile *tiles, u32 nTiles, u64 nRecords, const u32 *offsets, RealignGap *gaps)
+__global__ void k_realign_collect(const BamTile *tiles, u32 nTiles, u64 nRecords, BamOptions o, const u32 *offsets, RealignGap *gaps)
 {
     const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= nRecords) return;
     const u32 t = bamTileOf(tiles, nTiles, i);
     const FragmentRecord &r = tiles[t].records[i - tiles[t].firstRecord];
-    if (!realignHasGaps(r)) return;
+    if (!realignHasGaps(r, o)) return;
     const u32 *c = bamRecordCigar(tiles[t], r);
     u64 pos = r.fStrandPosition; u32 at = offsets[i];
     for (u32 k = 0; k < r.cigarLength; ++k)
@@ -343,7 +353,7 @@ __global__ void k_realign(BamTile *tiles, u32 nTiles, u64 nRecords, BamOptions o
     changed[i] = 0;
     const u32 t = bamTileOf(tiles, nTiles, i);
     FragmentRecord &r = records[i];
-    if (!bamStored(r) || (r.flags & 2) || bamUnalignedBin(r) || !r.editDistance) return;
+    if (!bamStored(r) || (r.flags & 2) || bamUnalignedBin(r) || !r.editDistance || !bamInBin(r, o)) return;
     if (duplicate && duplicate[i] && !o.keepDuplicates) return;                 // not in the bin's index any more
     RealignCtx x; x.R = &R; x.P = o.realign;
     RealignFragment f;
@@ -356,7 +366,9 @@ __global__ void k_realign(BamTile *tiles, u32 nTiles, u64 nRecords, BamOptions o
     RealignIndex index = { r.fStrandPosition, cigar, cigar + r.cigarLength };
     const u32 contig = refposContig(r.fStrandPosition);
     RealignCigar result;
-    if (!realignFragment(x, gapsView, refpos(contig, 0), refpos(contig, contigLength(R, contig)), index, f, result)) return;
+    u64 binStartPos, binEndPos;
+    bamBinRange(o, R, contig, binStartPos, binEndPos);
+    if (!realignFragment(x, gapsView, binStartPos, binEndPos, index, f, result)) return;
     const u32 at = atomicAdd(poolNext, result.n);
     if (at + result.n > poolCap) return;                                         // no room: the fragment keeps its alignment (sized so that this does not happen)
     for (u32 k = 0; k < result.n; ++k) pool[at + k] = result.words[k];
@@ -571,53 +583,92 @@ __global__ void __launch_bounds__(256) k_bam_encode(const BamTile *tiles, u32 nT
 
 
 // ---- isaac_gpu_bin_tile: the records of a select call cut into one compact tile per bin (BinningFragmentStorage's job) -----------------------
-static const u32 BIN_MAX = 255, BIN_NONE = 255;
-struct BinLayout { u64 firstEntry[BIN_MAX + 2], bclAt[BIN_MAX + 1], recordsAt[BIN_MAX + 1], cigarsAt[BIN_MAX + 1]; };
+// Bins are numbered in file order: every contig has a first bin (several small contigs may share one) and a contig too large for one bin goes on
+// into the bins behind it at the cut positions the caller gives; the last bin takes the templates without a position.
+static const u32 BIN_MAX = 65535;        // bins of a call; entries of records without a bin carry the key n_bins and sort behind all others
+struct BinMap { const u32 *binOfContig; u32 nContigs; const u64 *cuts /* ascending ReferencePosition values: a further bin of the cut's contig starts there */; u32 nCuts; u32 nBins; };
+// per bin b: firstEntry[b] (nBins + 1 entries), bclAt / recordsAt / cigarsAt (nBins each): one array of 4 nBins + 1 words in device memory
+struct BinLayout { const u64 *firstEntry, *bclAt, *recordsAt, *cigarsAt; };
 #if defined(__HIPCC__)
-__device__ inline u32 binOfRecord(const FragmentRecord &r, const u32 *binOfContig, u32 nContigs, u32 nBins)
+__device__ inline u32 binOfRecord(const FragmentRecord &r, const BinMap &m)
 {
-    if (!bamStored(r)) return BIN_NONE;
-    if (bamUnalignedBin(r)) return nBins - 1;
+    if (!bamStored(r)) return m.nBins;
+    if (bamUnalignedBin(r)) return m.nBins - 1;
     const u32 contig = refposContig(r.fStrandPosition);
-    return contig < nContigs ? binOfContig[contig] : BIN_NONE;
+    if (contig >= m.nContigs) return m.nBins;
+    u32 bin = m.binOfContig[contig];
+    if (m.nCuts)
+    {   // the cuts of this contig at or before the record: those in [first cut of the contig, first cut beyond the position)
+        const u64 contigStart = refpos(contig, 0), key = r.fStrandPosition & ~u64(1);
+        u32 lo = 0, hi = m.nCuts;
+        while (lo < hi) { const u32 mid = (lo + hi) / 2; if (m.cuts[mid] <= key) lo = mid + 1; else hi = mid; }
+        const u32 upTo = lo;
+        lo = 0; hi = upTo;
+        while (lo < hi) { const u32 mid = (lo + hi) / 2; if (m.cuts[mid] < contigStart) lo = mid + 1; else hi = mid; }
+        bin += upTo - lo;
+    }
+    return bin;
 }
-// entries 2c, 2c + 1: the bins cluster c has a stored record in (the second only when it differs from the first), else BIN_NONE
-__global__ void k_bin_entries(const FragmentRecord *records, u32 nClusters, u32 nReads, const u32 *binOfContig, u32 nContigs, u32 nBins, u8 *keys, u32 *values)
+// entries 2c, 2c + 1: the bins cluster c has a stored record in (the second only when it differs from the first), else n_bins
+__global__ void k_bin_entries(const FragmentRecord *records, u32 nClusters, u32 nReads, BinMap map, u16 *keys, u32 *values)
 {
     const u32 cl = blockIdx.x * blockDim.x + threadIdx.x;
     if (cl >= nClusters) return;
-    const u32 b0 = binOfRecord(records[u64(cl) * nReads], binOfContig, nContigs, nBins);
-    u32 b1 = 2 == nReads ? binOfRecord(records[u64(cl) * 2 + 1], binOfContig, nContigs, nBins) : BIN_NONE;
-    if (b1 == b0) b1 = BIN_NONE;
-    // the smaller bin first, so that BIN_NONE entries sort behind everything
-    keys[2 * u64(cl)] = u8(b0 < b1 ? b0 : b1); keys[2 * u64(cl) + 1] = u8(b0 < b1 ? b1 : b0);
+    const u32 b0 = binOfRecord(records[u64(cl) * nReads], map);
+    u32 b1 = 2 == nReads ? binOfRecord(records[u64(cl) * 2 + 1], map) : map.nBins;
+    if (b1 == b0) b1 = map.nBins;
+    // the smaller bin first, so that the entries without a bin sort behind everything
+    keys[2 * u64(cl)] = u16(b0 < b1 ? b0 : b1); keys[2 * u64(cl) + 1] = u16(b0 < b1 ? b1 : b0);
     values[2 * u64(cl)] = cl; values[2 * u64(cl) + 1] = cl;
 }
-// words[k]: CIGAR words of sorted entry k's cluster (0 for BIN_NONE entries; one more zero at the end for the scan); counts[b], counts[BIN_MAX + b]: entries and words of bin b
-__global__ void k_bin_words(const FragmentRecord *records, u32 nReads, const u8 *sortedKeys, const u32 *sortedValues, u64 nEntries, u64 *words, unsigned long long *counts)
+// words[k]: CIGAR words of sorted entry k's cluster (0 for entries without a bin; one more zero at the end for the scan); counts[b], counts[nBins + b]: entries and words of bin b.
+// Sorted entries: a workgroup's entries are of a few neighbouring bins, one atomic per lane run of equal bins
+__global__ void k_bin_words(const FragmentRecord *records, u32 nReads, const u16 *sortedKeys, const u32 *sortedValues, u64 nEntries, u32 nBins, u64 *words, unsigned long long *counts)
 {
-    __shared__ unsigned long long local[2 * BIN_MAX + 2];
-    for (u32 i = threadIdx.x; i < 2 * BIN_MAX + 2; i += blockDim.x) local[i] = 0;
-    __syncthreads();
     const u64 k = u64(blockIdx.x) * blockDim.x + threadIdx.x;
+    u32 bin = nBins; u64 w = 0;
     if (k < nEntries)
     {
-        const u32 bin = sortedKeys[k];
-        u64 w = 0;
-        if (bin != BIN_NONE)
+        bin = sortedKeys[k];
+        if (bin < nBins)
         {
             const u32 cl = sortedValues[k];
             for (u32 r = 0; r < nReads; ++r) w += records[u64(cl) * nReads + r].cigarLength;
-            atomicAdd(&local[bin], 1ull); atomicAdd(&local[BIN_MAX + bin], (unsigned long long)w);
         }
         words[k] = w;
         if (k + 1 == nEntries) words[nEntries] = 0;
     }
-    __syncthreads();
-    for (u32 i = threadIdx.x; i < 2 * BIN_MAX + 2; i += blockDim.x) if (local[i]) atomicAdd(&counts[i], local[i]);
+    // the entries are sorted by bin: a wavefront's lanes hold runs of equal bins; the last lane of a run adds the run's totals
+    const u32 lane = threadIdx.x & 63;
+    u64 entries = bin < nBins ? 1 : 0, sum = w;
+    for (u32 o = 1; o < 64; o <<= 1)
+    {
+        const u32 otherBin = __shfl_up(bin, o, 64); const u64 otherEntries = __shfl_up(entries, o, 64), otherSum = __shfl_up(sum, o, 64);
+        if (lane >= o && otherBin == bin) { entries += otherEntries; sum += otherSum; }
+    }
+    const u32 nextBin = __shfl_down(bin, 1, 64);
+    if (bin < nBins && (63 == lane || nextBin != bin)) { atomicAdd(&counts[bin], (unsigned long long)entries); atomicAdd(&counts[nBins + bin], (unsigned long long)sum); }
+}
+// the layout of the output: bin after bin, every array on a multiple of 64 bytes (one thread: a few hundred bins at most in practice)
+__global__ void k_bin_layout(const u64 *counts, u32 nBins, u32 nReads, u32 clusterLength, u64 *layout /* firstEntry[nBins + 1] | bclAt | recordsAt | cigarsAt */, u64 *total)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    u64 at = 0, firstEntry = 0;
+    u64 *first = layout, *bclAt = layout + nBins + 1, *recordsAt = bclAt + nBins, *cigarsAt = recordsAt + nBins;
+    for (u32 b = 0; b < nBins; ++b)
+    {
+        const u64 m = counts[b], w = counts[nBins + b];
+        first[b] = firstEntry; bclAt[b] = at;
+        at = (at + m * clusterLength + 63) & ~u64(63); recordsAt[b] = at;
+        at = (at + m * nReads * sizeof(FragmentRecord) + 63) & ~u64(63); cigarsAt[b] = at;
+        at = (at + w * 4 + 63) & ~u64(63);
+        firstEntry += m;
+    }
+    first[nBins] = firstEntry;
+    total[0] = at; total[1] = firstEntry;
 }
 // 64 threads per entry: the cluster's BCL bytes, its records and their CIGAR words to the entry's place in its bin's part
-__global__ void __launch_bounds__(256) k_bin_gather(const u8 *bcl, const FragmentRecord *records, const u32 *cigars, u32 nReads, u32 clusterLength, const u8 *sortedKeys, const u32 *sortedValues,
+__global__ void __launch_bounds__(256) k_bin_gather(const u8 *bcl, const FragmentRecord *records, const u32 *cigars, u32 nReads, u32 clusterLength, const u16 *sortedKeys, const u32 *sortedValues,
                                                     u64 nEntries, const u64 *wordsBefore, BinLayout layout, u8 *out)
 {
     const u64 k = u64(blockIdx.x) * 4 + threadIdx.x / 64;

@@ -179,14 +179,14 @@ __global__ void k_emit_flags(u64 n, const u32 *runIdIncl, const u32 *isFwd, cons
 }
 // entries of the mask appended to the table at outBase; entryRun: the run (distinct k-mer of the mask) an entry belongs to
 __global__ void k_emit_entries(const u64 *keys, const u64 *vals, u64 n, const u32 *runIdIncl, const u32 *runTotal, u32 repeatThreshold, const u32 *emit, const u32 *emitSlot,
-                               u64 outBase, u64 *outKmers, u64 *outPositions, u32 *entryRun)
+                               u64 outBase, TableEntry *out, u32 *entryRun)
 {
     const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n || !emit[i]) return;
     const u32 run = runIdIncl[i] - 1;
     const u64 s = outBase + emitSlot[i];
-    outKmers[s] = keys[i];
-    outPositions[s] = (repeatThreshold < runTotal[run]) ? 0 : (vals[i] & ~u64(1));
+    TableEntry e; e.kmer = keys[i]; e.position = (repeatThreshold < runTotal[run]) ? 0 : (vals[i] & ~u64(1));
+    out[s] = e;
     if (entryRun) entryRun[s] = run;
 }
 // distinct k-mers of the mask (both strands) = run heads, appended at distinctBase
@@ -241,35 +241,26 @@ __global__ void k_mark_neighbors(const u64 *keys, u8 *flags, u64 n)
     }
 }
 // table entries take the flag of their k-mer: entry i of mask m belongs to distinct k-mer distinctBase[m] + entryRun[i]
-__global__ void k_apply_neighbors(u64 *positions, const u32 *entryRun, u64 first, u64 n, u64 distinctBase, const u8 *flags)
+__global__ void k_apply_neighbors(TableEntry *entries, const u32 *entryRun, u64 first, u64 n, u64 distinctBase, const u8 *flags)
 {
     const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const u64 e = first + i;
-    const u64 p = positions[e];
+    const u64 p = entries[e].position;
     if (refposIsTooMany(p)) return;
-    if (flags[distinctBase + entryRun[e]]) positions[e] = p | 1;
+    if (flags[distinctBase + entryRun[e]]) entries[e].position = p | 1;
 }
 
-// ---- mask-file records <-> the resident SoA table ----------------------------------------------------------------
-struct ReferenceKmerRecord { u64 kmer, position; };    // reference::ReferenceKmer<unsigned long> (ReferenceKmer.hh:37-54)
-__global__ void k_split_records(const ReferenceKmerRecord *in, u64 n, u64 at, u64 *kmers, u64 *positions, u32 *disorder)
+// ---- mask-file records are the resident table's entries: a streamed table only has its order checked ----------------------------------
+typedef TableEntry ReferenceKmerRecord;
+// entries [at, at + n) of a table that is being streamed in: ascending k-mers, also across the boundary to the piece before
+__global__ void k_check_order(const TableEntry *entries, u64 at, u64 n, u32 *disorder)
 {
     const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const ReferenceKmerRecord r = in[i];
-    kmers[at + i] = r.kmer; positions[at + i] = r.position;
-    if (i && in[i - 1].kmer > r.kmer) *disorder = 1;
+    const u64 e = at + i;
+    if (e && entries[e - 1].kmer > entries[e].kmer) *disorder = 1;
 }
-__global__ void k_join_records(const u64 *kmers, const u64 *positions, u64 at, u64 n, ReferenceKmerRecord *out)
-{
-    const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    ReferenceKmerRecord r; r.kmer = kmers[at + i]; r.position = positions[at + i];
-    out[i] = r;
-}
-// the boundary between two chunks of a streamed table
-__global__ void k_check_boundary(const u64 *kmers, u64 at, u32 *disorder) { if (at && kmers[at - 1] > kmers[at]) *disorder = 1; }
 
 #endif // __HIPCC__
 

@@ -71,10 +71,9 @@ struct isaac_gpu_ctx
     // reference
     DevBuf<char> basesOwned; const char *bases = nullptr;
     DevBuf<u64> contigOffset; std::vector<u64> hContigOffset; DevBuf<u8> contigLoaded; std::vector<u8> hContigLoaded; u32 nContigs = 0;
-    DevBuf<u64> kmers, positions; u64 nKmers = 0; DevBuf<u32> karyotype; bool hasKaryotype = false;
-    const u64 *kmersBorrowed = nullptr, *positionsBorrowed = nullptr;   // isaac_gpu_set_index_dev: a table owned by the caller (another context, an RCCL receive buffer)
-    const u64 *tableKmers() const { return kmersBorrowed ? kmersBorrowed : kmers.p; }
-    const u64 *tablePositions() const { return positionsBorrowed ? positionsBorrowed : positions.p; }
+    DevBuf<TableEntry> entries; u64 nKmers = 0; DevBuf<u32> karyotype; bool hasKaryotype = false;
+    const TableEntry *entriesBorrowed = nullptr;   // isaac_gpu_set_index_dev: a table owned by the caller (another context, an RCCL receive buffer)
+    const TableEntry *tableEntries() const { return entriesBorrowed ? entriesBorrowed : entries.p; }
     DevBuf<u32> prefixTable; u32 prefixBits = 0; std::vector<u64> maskOffsets;   // entries before each mask of the table (load_index / build_index)
     DevBuf<u32> packedBases, notBase;   // 2-bit copy of the contigs + not-ACGT bitmap (k_rescue_windows reads these)
     DevBuf<u64> matchBase;
@@ -91,7 +90,7 @@ struct isaac_gpu_ctx
     DevBuf<u8> heavyArena, clusterKinds; DevBuf<u32> clusterOrder, kindCounts; DevBuf<u32> overflowList; DevBuf<u32> overflowCount; DevBuf<ClusterSums> clusterSums; DevBuf<u32> mediumList, largeList, xlList, hugeList, longJobs; DevBuf<u8> hugeKeys;
     DevBuf<TlsSample> tlsSamples; DevBuf<u32> cigarLengths, cigarOffsets; DevBuf<u64> cigarTotal;
     DevBuf<CrcConstants> crcConstants; bool crcReady = false;    // isaac_gpu_bgzf_store
-    DevBuf<u32> binOfContig, binValues, binValuesAlt; DevBuf<u8> binKeys, binKeysAlt; DevBuf<u64> binWords, binCounts;        // isaac_gpu_bin_tile
+    DevBuf<u32> binOfContig, binValues, binValuesAlt; DevBuf<u16> binKeys, binKeysAlt; DevBuf<u64> binWords, binCounts, binCuts, binLayout;        // isaac_gpu_bin_tile
     DevBuf<u64> deflateCounts, deflateOffsets; DevBuf<DeflateTables> deflateTables; DevBuf<u8> deflateStaging; DevBuf<u32> deflateSizes;   // isaac_gpu_bgzf_deflate
     // isaac_gpu_bam_records scratch
     DevBuf<BamTile> bamTiles; DevBuf<u64> bamKeyHi, bamKeyLo, bamKeyAlt, bamOffsets, bamBytes64, bamBounds; DevBuf<u32> bamIndex, bamIndexAlt, bamBytes;
@@ -114,7 +113,7 @@ struct isaac_gpu_ctx
     {
         DevReference r; std::memset(&r, 0, sizeof(r));
         r.bases = bases; r.totalBases = hContigOffset.empty() ? 0 : hContigOffset[nContigs]; r.contigOffset = contigOffset.p; r.contigLoaded = contigLoaded.p; r.nContigs = nContigs;
-        r.kmers = tableKmers(); r.positions = tablePositions(); r.nKmers = nKmers; r.karyotype = hasKaryotype ? karyotype.p : nullptr;
+        r.entries = tableEntries(); r.nKmers = nKmers; r.karyotype = hasKaryotype ? karyotype.p : nullptr;
         r.logMatch = logTables.p; r.logMismatch = logTables.p + 100; r.logStride = 1;
         r.prefixTable = prefixBits ? prefixTable.p : nullptr; r.prefixBits = prefixBits;
         r.packedBases = packedBases.p; r.notBase = notBase.p;
@@ -160,20 +159,24 @@ static void resolveTimers(isaac_gpu_ctx *c)
 #define ISAAC_FIND_POSITION_ON_HIT 1
 #endif
 static const u32 FIND_GROUP = 8, FIND_BLOCK = 256, FIND_CLUSTERS_PER_BLOCK = FIND_BLOCK / FIND_GROUP;
+#ifndef ISAAC_FIND_SLICE
+#define ISAAC_FIND_SLICE 4
+#endif
+static const u32 FIND_SLICE = ISAAC_FIND_SLICE;       // slices of the table of up to this many entries are fetched whole (0: always the bisection)
 
-__device__ inline u64 lowerBound(const u64 *kmers, u64 lo, u64 hi, u64 key, u32 &steps)
+__device__ inline u64 lowerBound(const TableEntry *entries, u64 lo, u64 hi, u64 key, u32 &steps)
 {
     while (lo < hi)
     {
         const u64 mid = (lo + hi) >> 1;
-        if (kmers[mid] < key) lo = mid + 1; else hi = mid;
+        if (entries[mid].kmer < key) lo = mid + 1; else hi = mid;
         ++steps;
     }
     return lo;
 }
 
 // prefixTable[b] = first table index whose k-mer has leading bits >= b (b = 0 .. 2^bits, the last one = n)
-__global__ void k_prefix_table(const u64 *kmers, u64 n, u32 bits, u32 *table)
+__global__ void k_prefix_table(const TableEntry *kmers, u64 n, u32 bits, u32 *table)
 {
     const u64 b = u64(blockIdx.x) * blockDim.x + threadIdx.x;
     if (b > (u64(1) << bits)) return;
@@ -243,32 +246,54 @@ __global__ __launch_bounds__(FIND_BLOCK) void k_find_matches(DevParams P, DevRef
                 {
                     ++local.probes;
                     u32 steps = 0;
+                    u32 r = 0;
+                    u64 lo = 0, hi = R.nKmers;
                     if (R.prefixTable)
                     {   // the k-mer's leading bits select a slice of the table: one 8-byte read instead of most of the bisection
                         const u64 bucket = kmer >> (64 - R.prefixBits);
                         const uint2 range = *reinterpret_cast<const uint2 *>(R.prefixTable + bucket);   // [bucket], [bucket + 1]
                         ++steps;
-                        first = lowerBound(R.kmers, range.x, range.y, kmer, steps);
+                        lo = range.x; hi = range.y;
                     }
-                    else first = lowerBound(R.kmers, 0, R.nKmers, kmer, steps);
+                    // ExactMaskMatcher.cpp:118-126: reference entries with the same k-mer, at most repeatThreshold of them.
+                    if (hi - lo <= FIND_SLICE)
+                    {   // The usual slice (the directory has about as many buckets as the table has entries): all of it asked for at once -- k-mers and
+                        // positions, 16 bytes an entry as the mask files hold them -- and searched in registers: one round trip where the bisection, the
+                        // look at the entries behind it and the position were three or four, one after the other
+                        TableEntry e[FIND_SLICE];
+#pragma unroll
+                        for (u32 i = 0; i < FIND_SLICE; ++i)
+                        {
+                            const uint4 v = lo + i < hi ? *reinterpret_cast<const uint4 *>(R.entries + lo + i) : make_uint4(0xffffffffu, 0xffffffffu, 0, 0);
+                            e[i].kmer = u64(v.x) | (u64(v.y) << 32); e[i].position = u64(v.z) | (u64(v.w) << 32);
+                        }
+                        ++steps;
+                        u32 before = 0;                              // entries of the slice below the k-mer (the slice is sorted)
+#pragma unroll
+                        for (u32 i = 0; i < FIND_SLICE; ++i) { const bool in = lo + i < hi; before += (in && e[i].kmer < kmer) ? 1u : 0u; r += (in && e[i].kmer == kmer) ? 1u : 0u; }
+                        first = lo + before;
+#pragma unroll
+                        for (u32 i = 0; i < FIND_SLICE; ++i) if (i == before) pos0 = e[i].position;          // (no register array is indexed at run time)
+                        if (!r) pos0 = 0;
+                    }
+                    else
+                    {
+                        first = lowerBound(R.entries, lo, hi, kmer, steps);
+                        // the first two entries behind the bisection together: most hits are single entries
+                        const bool in0 = first < R.nKmers, in1 = first + 1 < R.nKmers;
+                        uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
+                        if (in0) v0 = *reinterpret_cast<const uint4 *>(R.entries + first);
+                        if (in1) v1 = *reinterpret_cast<const uint4 *>(R.entries + first + 1);
+                        const u64 k0 = u64(v0.x) | (u64(v0.y) << 32), k1 = u64(v1.x) | (u64(v1.y) << 32);
+                        pos0 = (in0 && k0 == kmer) ? (u64(v0.z) | (u64(v0.w) << 32)) : 0;
+                        if (in0 && k0 == kmer)
+                        {
+                            r = 1;
+                            if (in1 && k1 == kmer) { r = 2; while (first + r < R.nKmers && r < P.repeatThreshold && R.entries[first + r].kmer == kmer) ++r; }
+                        }
+                    }
                     local.probeSteps += steps;
                     STAMP(12);
-                    // ExactMaskMatcher.cpp:118-126: reference entries with the same k-mer, at most repeatThreshold of them.
-                    // The first two table entries and the first position are fetched together: most hits are single entries,
-                    // and three loads in flight cost one latency instead of three.
-                    u32 r = 0;
-                    const bool in0 = first < R.nKmers, in1 = first + 1 < R.nKmers;
-                    const u64 k0 = in0 ? R.kmers[first] : 0, k1 = in1 ? R.kmers[first + 1] : 0;
-#if ISAAC_FIND_POSITION_ON_HIT
-                    pos0 = (in0 && k0 == kmer) ? R.positions[first] : 0;       // (A/B: the position's cache line only for probes that hit)
-#else
-                    pos0 = in0 ? R.positions[first] : 0;
-#endif
-                    if (in0 && k0 == kmer)
-                    {
-                        r = 1;
-                        if (in1 && k1 == kmer) { r = 2; while (first + r < R.nKmers && r < P.repeatThreshold && R.kmers[first + r] == kmer) ++r; }
-                    }
                     if (r)
                     {
                         if (r >= P.repeatThreshold || refposIsTooMany(pos0))
@@ -296,7 +321,7 @@ __global__ __launch_bounds__(FIND_BLOCK) void k_find_matches(DevParams P, DevRef
                 if (tooMany) { if (at < stride) { out[at].seedId = sid; out[at].location = 0; } }
                 else for (u32 i = 0; i < nrec; ++i, ++at)
                 {
-                    u64 pos = i ? R.positions[first + i] : pos0;
+                    u64 pos = i ? R.entries[first + i].position : pos0;
                     if (R.karyotype) { const u32 c = u32(pos >> 41); pos = (u64(R.karyotype[c - 1] + 1) << 41) | (pos & ((u64(1) << 41) - 1)); }
                     if (at < stride) { out[at].seedId = sid; out[at].location = pos; }
                     // MatchDistribution::addMatches (:173-181): the contig is not empty.  Read before write: millions of stores to
@@ -546,7 +571,7 @@ void buildPrefixTable(isaac_gpu_ctx *c)
     u32 bits = 16; while (bits < 30 && (u64(1) << bits) < c->nKmers) ++bits;     // about one entry per bucket (human: 2.7), 256 KB .. 4 GB
     const u64 entries = (u64(1) << bits) + 1;
     c->prefixTable.reserve(entries + 1);                                            // + 1: the last bucket reads a pair
-    k_prefix_table<<<gridFor(entries, 256), 256, 0, c->stream>>>(c->tableKmers(), c->nKmers, bits, c->prefixTable.p);
+    k_prefix_table<<<gridFor(entries, 256), 256, 0, c->stream>>>(c->tableEntries(), c->nKmers, bits, c->prefixTable.p);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemsetAsync(c->prefixTable.p + entries, 0xff, 4, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -739,12 +764,12 @@ int isaac_gpu_load_index(isaac_gpu_ctx *c, const isaac_reference_kmer *const *ma
     u64 total = 0; for (u32 m = 0; m < nMasks; ++m) total += sizes[m];
     if (total >= (u64(1) << 32)) return fail(ISAAC_GPU_EINVAL, "tables of 2^32 entries and more are not supported");
     hipStream_t st = c->stream;
-    c->kmersBorrowed = c->positionsBorrowed = nullptr;
-    c->kmers.reserve(total + 1); c->positions.reserve(total + 1); c->nKmers = 0; c->prefixBits = 0;
+    c->entriesBorrowed = nullptr;
+    c->entries.reserve(total + 4); c->nKmers = 0; c->prefixBits = 0;             // + 4: k_find_matches reads four entries from the first candidate on
     // The mask files arrive as host memory (memory-mapped files, usually): 47 GB for GRCh38.  Copied by the runtime straight from pageable memory they
     // move at 3-4 GB/s (one thread faulting the pages in and staging them).  Here a few host threads copy 256 MB pieces into a ring of pinned buffers side by
-    // side -- that is where the page faults and the page-cache reads happen -- and the pieces go to the device from there, two in flight, each split into
-    // the two arrays of the table as it lands.
+    // side -- that is where the page faults and the page-cache reads happen -- and the pieces go from there straight to their place in the table (its
+    // entries are the files' records; rounds 2-4 kept k-mers and positions in two arrays and split every piece on the device).
     const u64 chunk = 1u << 24;      // records per staging buffer (256 MB)
     struct Piece { const ReferenceKmerRecord *src; u64 n, at; };
     std::vector<Piece> pieces;
@@ -760,7 +785,7 @@ int isaac_gpu_load_index(isaac_gpu_ctx *c, const isaac_reference_kmer *const *ma
     const u32 SLOTS = 6;
     // (ISAAC_GPU_LOAD_THREADS: measurement aid)
     const u32 FILLERS = std::getenv("ISAAC_GPU_LOAD_THREADS") ? std::max(1, std::atoi(std::getenv("ISAAC_GPU_LOAD_THREADS"))) : 8;
-    DevBuf<ReferenceKmerRecord> staging[2]; DevBuf<u32> disorder; disorder.reserve(1);
+    DevBuf<u32> disorder; disorder.reserve(1);
     HIP_CHECK(hipMemsetAsync(disorder.p, 0, 4, st));
     hipStream_t copyStream; HIP_CHECK(hipStreamCreateWithFlags(&copyStream, hipStreamNonBlocking));
     hipEvent_t copied[2], split[2], left[SLOTS];
@@ -802,14 +827,11 @@ int isaac_gpu_load_index(isaac_gpu_ctx *c, const isaac_reference_kmer *const *ma
             {
                 const u32 turn = u32(k & 1), slot = u32(k % SLOTS);
                 while (!filled[k].load(std::memory_order_acquire)) std::this_thread::yield();
-                staging[turn].reserve(chunk);
-                if (used[turn]) HIP_CHECK(hipStreamWaitEvent(copyStream, split[turn], 0));     // its previous contents have been split
-                HIP_CHECK(hipMemcpyAsync(staging[turn].p, pinned[slot], pieces[k].n * sizeof(ReferenceKmerRecord), hipMemcpyHostToDevice, copyStream));
+                HIP_CHECK(hipMemcpyAsync(c->entries.p + pieces[k].at, pinned[slot], pieces[k].n * sizeof(ReferenceKmerRecord), hipMemcpyHostToDevice, copyStream));
                 HIP_CHECK(hipEventRecord(copied[turn], copyStream));
                 HIP_CHECK(hipEventRecord(left[slot], copyStream));
                 HIP_CHECK(hipStreamWaitEvent(st, copied[turn], 0));
-                k_split_records<<<gridFor(pieces[k].n, 256), 256, 0, st>>>(staging[turn].p, pieces[k].n, pieces[k].at, c->kmers.p, c->positions.p, disorder.p);
-                k_check_boundary<<<1, 1, 0, st>>>(c->kmers.p, pieces[k].at, disorder.p);
+                k_check_order<<<gridFor(pieces[k].n, 256), 256, 0, st>>>(c->entries.p, pieces[k].at, pieces[k].n, disorder.p);     // (pieces land in order: the entry before a piece is there)
                 HIP_CHECK(hipGetLastError());
                 HIP_CHECK(hipEventRecord(split[turn], st)); used[turn] = true;
                 // two copies may be queued; the slots of everything before them are free again
@@ -875,7 +897,7 @@ int isaac_gpu_build_index(isaac_gpu_ctx *c, uint32_t repeatThreshold, int annota
     const u32 *packed = c->packedBases.p, *notBase = c->notBase.p;
     const u64 nBlocks = (totalBases + INDEX_TILE - 1) / INDEX_TILE;
     if (nBlocks >= (u64(1) << 31)) return fail(ISAAC_GPU_EINVAL, "reference too long");
-    c->kmersBorrowed = c->positionsBorrowed = nullptr;
+    c->entriesBorrowed = nullptr;
     c->nKmers = 0; c->prefixBits = 0; c->hasKaryotype = false; c->maskOffsets.assign(1, 0);
     // 1. how many k-mers of each mask every block of positions holds
     DevBuf<u32> counts; counts.reserve(size_t(INDEX_MASKS) * nBlocks);
@@ -888,7 +910,7 @@ int isaac_gpu_build_index(isaac_gpu_ctx *c, uint32_t repeatThreshold, int annota
     HIP_CHECK(hipStreamSynchronize(st));
     if (nValid >= (u64(1) << 32)) return fail(ISAAC_GPU_EINVAL, "tables of 2^32 entries and more are not supported");
     // every stored entry is a forward-strand occurrence: nValid bounds the table, 2 * nValid the distinct k-mers of both strands
-    c->kmers.reserve(nValid + 1); c->positions.reserve(nValid + 1);
+    c->entries.reserve(nValid + 4);
     DevBuf<u64> distinct; DevBuf<u32> entryRun;
     if (annotateNeighbors) { distinct.reserve(2 * nValid + 1); entryRun.reserve(nValid + 1); }
     std::vector<u64> distinctBase(1, 0);
@@ -930,7 +952,7 @@ int isaac_gpu_build_index(isaac_gpu_ctx *c, uint32_t repeatThreshold, int annota
             HIP_CHECK(hipMemcpyAsync(&lastE, w.emit.p + n - 1, 4, hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipMemcpyAsync(&lastS, w.emitSlot.p + n - 1, 4, hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
-            k_emit_entries<<<gridFor(n, 256), 256, 0, st>>>(w.keys.p, w.vals.p, n, w.runId.p, w.runTotal.p, repeatThreshold, w.emit.p, w.emitSlot.p, nOut, c->kmers.p, c->positions.p,
+            k_emit_entries<<<gridFor(n, 256), 256, 0, st>>>(w.keys.p, w.vals.p, n, w.runId.p, w.runTotal.p, repeatThreshold, w.emit.p, w.emitSlot.p, nOut, c->entries.p,
                                                               annotateNeighbors ? entryRun.p : nullptr);
             if (annotateNeighbors) k_distinct<<<gridFor(n, 256), 256, 0, st>>>(w.keys.p, n, w.head.p, w.runId.p, nDistinct, distinct.p);
             HIP_CHECK(hipGetLastError());
@@ -977,7 +999,7 @@ int isaac_gpu_build_index(isaac_gpu_ctx *c, uint32_t repeatThreshold, int annota
         for (u32 mask = 0; mask < INDEX_MASKS; ++mask)
         {
             const u64 first = c->maskOffsets[mask], n = c->maskOffsets[mask + 1] - first;
-            if (n) k_apply_neighbors<<<gridFor(n, 256), 256, 0, st>>>(c->positions.p, entryRun.p, first, n, distinctBase[mask], df.Current());
+            if (n) k_apply_neighbors<<<gridFor(n, 256), 256, 0, st>>>(c->entries.p, entryRun.p, first, n, distinctBase[mask], df.Current());
         }
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(st));
@@ -998,16 +1020,9 @@ int isaac_gpu_get_index(isaac_gpu_ctx *c, isaac_reference_kmer *out, uint64_t ca
     if (!out) return 0;
     if (capacity < c->nKmers) return fail(ISAAC_GPU_ECAPACITY, "index buffer too small");
     static_assert(sizeof(ReferenceKmerRecord) == sizeof(isaac_reference_kmer), "mask file record");
-    const u64 chunk = 1u << 24;
-    DevBuf<ReferenceKmerRecord> staging; staging.reserve(std::min<u64>(chunk, std::max<u64>(c->nKmers, 1)));
-    for (u64 done = 0; done < c->nKmers; done += chunk)
-    {
-        const u64 n = std::min(chunk, c->nKmers - done);
-        k_join_records<<<gridFor(n, 256), 256, 0, c->stream>>>(c->tableKmers(), c->tablePositions(), done, n, staging.p);
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipMemcpyAsync(out + done, staging.p, n * sizeof(ReferenceKmerRecord), hipMemcpyDeviceToHost, c->stream));
-        HIP_CHECK(hipStreamSynchronize(c->stream));
-    }
+    // the table's entries are the mask files' records
+    if (c->nKmers) HIP_CHECK(hipMemcpyAsync(out, c->tableEntries(), c->nKmers * sizeof(ReferenceKmerRecord), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
     return 0;
     ISAAC_CATCH
 }
@@ -1019,16 +1034,8 @@ int isaac_gpu_get_index_range(isaac_gpu_ctx *c, uint64_t first, uint64_t n, isaa
     if (first > c->nKmers || n > c->nKmers - first) return fail(ISAAC_GPU_EINVAL, "range outside the table");
     if (!n) return 0;
     if (!out) return fail(ISAAC_GPU_EINVAL, "out_host is required");
-    const u64 chunk = 1u << 24;
-    DevBuf<ReferenceKmerRecord> staging; staging.reserve(std::min<u64>(chunk, n));
-    for (u64 done = 0; done < n; done += chunk)
-    {
-        const u64 m = std::min(chunk, n - done);
-        k_join_records<<<gridFor(m, 256), 256, 0, c->stream>>>(c->tableKmers(), c->tablePositions(), first + done, m, staging.p);
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipMemcpyAsync(out + done, staging.p, m * sizeof(ReferenceKmerRecord), hipMemcpyDeviceToHost, c->stream));
-        HIP_CHECK(hipStreamSynchronize(c->stream));
-    }
+    HIP_CHECK(hipMemcpyAsync(out, c->tableEntries() + first, n * sizeof(ReferenceKmerRecord), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
     return 0;
     ISAAC_CATCH
 }
@@ -1045,11 +1052,10 @@ int isaac_gpu_get_mask_offsets(isaac_gpu_ctx *c, uint64_t *offsetsOut, uint32_t 
 }
 
 // the resident table as device pointers (read-only; valid until the table is rebuilt, reloaded or its owner destroyed)
-int isaac_gpu_index_dev(isaac_gpu_ctx *c, const uint64_t **kmersOut, const uint64_t **positionsOut, uint64_t *nOut)
+int isaac_gpu_index_dev(isaac_gpu_ctx *c, const isaac_reference_kmer **entriesOut, uint64_t *nOut)
 {
     ISAAC_TRY
-    if (kmersOut) *kmersOut = c->tableKmers();
-    if (positionsOut) *positionsOut = c->tablePositions();
+    if (entriesOut) *entriesOut = reinterpret_cast<const isaac_reference_kmer *>(c->tableEntries());
     if (nOut) *nOut = c->nKmers;
     return 0;
     ISAAC_CATCH
@@ -1057,17 +1063,18 @@ int isaac_gpu_index_dev(isaac_gpu_ctx *c, const uint64_t **kmersOut, const uint6
 
 // adopts a table that lives in the caller's device memory (another context's, or what an RCCL broadcast delivered): nothing is
 // copied; only the prefix directory is built
-int isaac_gpu_set_index_dev(isaac_gpu_ctx *c, const uint64_t *kmers, const uint64_t *positions, uint64_t n, const uint64_t *maskOffsets, uint32_t nMasks)
+int isaac_gpu_set_index_dev(isaac_gpu_ctx *c, const isaac_reference_kmer *entriesIn, uint64_t n, const uint64_t *maskOffsets, uint32_t nMasks)
 {
     ISAAC_TRY
     HIP_CHECK(hipSetDevice(c->device));
-    if (n && (!kmers || !positions)) return fail(ISAAC_GPU_EINVAL, "kmers_dev and positions_dev are required");
+    const TableEntry *entries = reinterpret_cast<const TableEntry *>(entriesIn);
+    if (n && !entries) return fail(ISAAC_GPU_EINVAL, "entries_dev is required");
     if (n >= (u64(1) << 32)) return fail(ISAAC_GPU_EINVAL, "tables of 2^32 entries and more are not supported");
     if (maskOffsets && (maskOffsets[0] != 0 || maskOffsets[nMasks] != n)) return fail(ISAAC_GPU_EINVAL, "mask_offsets must run from 0 to n_entries");
     HIP_CHECK(hipStreamSynchronize(c->stream));
-    if (c->kmers.p && kmers == c->kmers.p && positions == c->positions.p && n == c->nKmers) return 0;      // the context's own table handed back to it: nothing to adopt (and nothing to free)
-    c->kmers.release(); c->positions.release();
-    c->kmersBorrowed = kmers; c->positionsBorrowed = positions; c->nKmers = n; c->hasKaryotype = false;
+    if (c->entries.p && entries == c->entries.p && n == c->nKmers) return 0;      // the context's own table handed back to it: nothing to adopt (and nothing to free)
+    c->entries.release();
+    c->entriesBorrowed = entries; c->nKmers = n; c->hasKaryotype = false;
     if (maskOffsets) c->maskOffsets.assign(maskOffsets, maskOffsets + nMasks + 1); else { c->maskOffsets.assign(1, 0); c->maskOffsets.push_back(n); }
     buildPrefixTable(c);
     return 0;
@@ -1083,18 +1090,18 @@ int isaac_gpu_share_index(isaac_gpu_ctx *c, isaac_gpu_ctx *owner)
     HIP_CHECK(hipSetDevice(owner->device));
     HIP_CHECK(hipStreamSynchronize(owner->stream));
     const u64 n = owner->nKmers;
-    const u64 *kmers = owner->tableKmers(), *positions = owner->tablePositions();
+    const TableEntry *entries = owner->tableEntries();
     HIP_CHECK(hipSetDevice(c->device));
     HIP_CHECK(hipStreamSynchronize(c->stream));
-    c->kmers.release(); c->positions.release();
-    if (c->device != owner->device && n)
+    c->entries.release();
+    // (ISAAC_GPU_SHARE_BY_COPY: tests on a box with one device take the branch two devices take)
+    if ((c->device != owner->device || std::getenv("ISAAC_GPU_SHARE_BY_COPY")) && n)
     {
-        c->kmers.reserve(n); c->positions.reserve(n);
-        HIP_CHECK(hipMemcpy(c->kmers.p, kmers, n * 8, hipMemcpyDefault));
-        HIP_CHECK(hipMemcpy(c->positions.p, positions, n * 8, hipMemcpyDefault));
-        c->kmersBorrowed = nullptr; c->positionsBorrowed = nullptr;
+        c->entries.reserve(n + 4);
+        HIP_CHECK(hipMemcpy(c->entries.p, entries, n * sizeof(TableEntry), hipMemcpyDefault));
+        c->entriesBorrowed = nullptr;
     }
-    else { c->kmersBorrowed = kmers; c->positionsBorrowed = positions; }
+    else c->entriesBorrowed = entries;
     c->nKmers = n; c->maskOffsets = owner->maskOffsets;
     c->hasKaryotype = owner->hasKaryotype;
     if (owner->hasKaryotype)
@@ -1131,7 +1138,7 @@ int isaac_gpu_find_matches(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClust
 {
     ISAAC_TRY
     HIP_CHECK(hipSetDevice(c->device));
-    if (!c->tableKmers() || !c->bases) return fail(ISAAC_GPU_EINVAL, "load the contigs and the index first");
+    if (!c->tableEntries() || !c->bases) return fail(ISAAC_GPU_EINVAL, "load the contigs and the index first");
     if (!matchesOut || !clusterOffsets) return fail(ISAAC_GPU_EINVAL, "matches_dev and cluster_offsets_dev are required");
     if (nClusters > 0x7fffffffu || tile > 0xfff) return fail(ISAAC_GPU_EINVAL, "SeedId overflow (SeedId.hh:95-109)");
     hipStream_t st = c->stream;
@@ -1635,7 +1642,12 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
     o.markDuplicates = options ? (options->mark_duplicates != 0) : 0; o.keepDuplicates = options ? (options->keep_duplicates != 0) : 1;
     o.realignGaps = options ? (options->realign_gaps != 0) : 0;
     o.indexEntries = options ? options->index_entries_dev : nullptr;
-    if (options && options->bin_filter) { o.binFilter = 1; o.binFirstContig = options->bin_first_contig; o.binEndContig = options->bin_end_contig; o.binUnaligned = options->bin_unaligned != 0; }
+    if (options && options->bin_filter)
+    {
+        o.binFilter = 2 == options->bin_filter ? 2 : 1; o.binFirstContig = options->bin_first_contig; o.binEndContig = options->bin_end_contig; o.binUnaligned = options->bin_unaligned != 0;
+        o.binFirstPosition = options->bin_first_position & ~u64(1); o.binEndPosition = options->bin_end_position & ~u64(1);
+        if (2 == o.binFilter && o.binEndPosition < o.binFirstPosition) return fail(ISAAC_GPU_EINVAL, "bin_filter 2: bin_first_position <= bin_end_position (ReferencePosition values)");
+    }
     if (o.realignGaps)
     {
         if (options->realign_vigorously) return fail(ISAAC_GPU_EINVAL, "--realign-vigorously is not implemented");
@@ -1706,7 +1718,7 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
     {   // BinSorter::collectGaps + realignGaps with every contig as one bin (bam_kernels.h, realign.h)
         ScopedTimer t(c, "bam_realign");
         u32 *counts = c->bamBytes.p, *offsets = c->bamIndexAlt.p;
-        k_realign_count<<<gridFor(n, 256), 256, 0, st>>>(c->bamTiles.p, nTiles, n, counts);
+        k_realign_count<<<gridFor(n, 256), 256, 0, st>>>(c->bamTiles.p, nTiles, n, o, counts);
         exclusiveSum(c, counts, offsets, n);
         u32 lastCount = 0, lastOffset = 0;
         HIP_CHECK(hipMemcpyAsync(&lastCount, counts + n - 1, 4, hipMemcpyDeviceToHost, st)); HIP_CHECK(hipMemcpyAsync(&lastOffset, offsets + n - 1, 4, hipMemcpyDeviceToHost, st));
@@ -1716,7 +1728,7 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
         if (nGaps)
         {
             c->realignGaps.reserve(nGaps); c->realignDeletionEnds.reserve(nGaps);
-            k_realign_collect<<<gridFor(n, 256), 256, 0, st>>>(c->bamTiles.p, nTiles, n, offsets, c->realignGaps.p);
+            k_realign_collect<<<gridFor(n, 256), 256, 0, st>>>(c->bamTiles.p, nTiles, n, o, offsets, c->realignGaps.p);
             HIP_CHECK(hipMemcpyAsync(gaps.data(), c->realignGaps.p, nGaps * sizeof(RealignGap), hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
             // RealignerGaps::finalizeGaps (GapRealigner.cpp:86-94) with the host's std::sort, one contig (bin) at a time for the deletion ends
@@ -1804,57 +1816,73 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
 
 // BGZF without compression on the device (bgzf_kernels.h)
 // ---- isaac_gpu_bin_tile (bam_kernels.h: k_bin_*)
-int isaac_gpu_bin_tile(isaac_gpu_ctx *c, const uint8_t *bcl, const isaac_fragment *fragments, const uint32_t *cigars, uint32_t nClusters, const uint32_t *binOfContig, uint32_t nContigs, uint32_t nBins,
-                       uint8_t *out, uint64_t capacity, isaac_bin_size *sizesOut, uint64_t *nBytesOut)
+int isaac_gpu_bin_tile_map(isaac_gpu_ctx *c, const uint8_t *bcl, const isaac_fragment *fragments, const uint32_t *cigars, uint32_t nClusters, const isaac_bin_map *map,
+                           uint8_t *out, uint64_t capacity, isaac_bin_size *sizesOut, uint64_t *nBytesOut)
 {
     ISAAC_TRY
     HIP_CHECK(hipSetDevice(c->device));
     if (nBytesOut) *nBytesOut = 0;
-    if (!nBins || nBins > BIN_MAX || !sizesOut || (nContigs && !binOfContig)) return fail(ISAAC_GPU_EINVAL, "1 .. 255 bins, sizes_out and bin_of_contig are required");
-    for (u32 k = 0; k < nContigs; ++k) if (binOfContig[k] + 1 >= nBins) return fail(ISAAC_GPU_EINVAL, "bin_of_contig: bins 0 .. n_bins - 2 (the last bin takes the templates without a position)");
+    if (!map || !map->n_bins || map->n_bins > BIN_MAX || !sizesOut || (map->n_contigs && !map->bin_of_contig) || (map->n_cuts && !map->cut_positions))
+        return fail(ISAAC_GPU_EINVAL, "1 .. 65535 bins, sizes_out, bin_of_contig and cut_positions are required");
+    const u32 nBins = map->n_bins, nContigs = map->n_contigs, nCuts = map->n_cuts;
+    {   // every contig's bins end below the last bin (which takes the templates without a position); the cuts ascend
+        std::vector<u32> cutsOf(nContigs, 0);
+        for (u32 k = 0; k < nCuts; ++k)
+        {
+            const u64 v = map->cut_positions[k] & ~u64(1);
+            if (k && v <= (map->cut_positions[k - 1] & ~u64(1))) return fail(ISAAC_GPU_EINVAL, "cut_positions: ascending ReferencePosition values");
+            if (refposContig(v) >= nContigs) return fail(ISAAC_GPU_EINVAL, "cut_positions: a cut on a contig that is not there");
+            ++cutsOf[refposContig(v)];
+        }
+        for (u32 k = 0; k < nContigs; ++k) if (u64(map->bin_of_contig[k]) + cutsOf[k] + 1 >= nBins) return fail(ISAAC_GPU_EINVAL, "bin_of_contig: bins 0 .. n_bins - 2 (the last bin takes the templates without a position)");
+    }
     for (u32 b = 0; b < nBins; ++b) { sizesOut[b].n_clusters = 0; sizesOut[b].n_cigar_words = 0; }
     if (!nClusters) return 0;
     if (!bcl || !fragments || !cigars) return fail(ISAAC_GPU_EINVAL, "bcl_dev, fragments_dev and cigar_dev are required");
     hipStream_t st = c->stream;
     const u32 nReads = c->params.n_reads, clusterLength = c->P.clusterLength;
     const u64 nEntries = u64(nClusters) * 2;
-    c->binOfContig.reserve(std::max(nContigs, 1u)); c->binKeys.reserve(nEntries); c->binKeysAlt.reserve(nEntries); c->binValues.reserve(nEntries); c->binValuesAlt.reserve(nEntries);
-    c->binWords.reserve(nEntries + 1); c->binCounts.reserve(2 * BIN_MAX + 2);
-    if (nContigs) HIP_CHECK(hipMemcpyAsync(c->binOfContig.p, binOfContig, nContigs * 4, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemsetAsync(c->binCounts.p, 0, (2 * BIN_MAX + 2) * 8, st));
+    c->binOfContig.reserve(std::max(nContigs, 1u)); c->binCuts.reserve(std::max(nCuts, 1u)); c->binKeys.reserve(nEntries); c->binKeysAlt.reserve(nEntries); c->binValues.reserve(nEntries); c->binValuesAlt.reserve(nEntries);
+    c->binWords.reserve(nEntries + 1); c->binCounts.reserve(2 * size_t(nBins) + 2); c->binLayout.reserve(4 * size_t(nBins) + 1);
+    if (nContigs) HIP_CHECK(hipMemcpyAsync(c->binOfContig.p, map->bin_of_contig, nContigs * 4, hipMemcpyHostToDevice, st));
+    if (nCuts)
+    {
+        std::vector<u64> cuts(nCuts);
+        for (u32 k = 0; k < nCuts; ++k) cuts[k] = map->cut_positions[k] & ~u64(1);
+        HIP_CHECK(hipMemcpyAsync(c->binCuts.p, cuts.data(), nCuts * 8, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipStreamSynchronize(st));              // `cuts` goes out of scope
+    }
+    HIP_CHECK(hipMemsetAsync(c->binCounts.p, 0, (2 * size_t(nBins) + 2) * 8, st));
     const FragmentRecord *records = reinterpret_cast<const FragmentRecord *>(fragments);
+    BinMap m; m.binOfContig = c->binOfContig.p; m.nContigs = nContigs; m.cuts = c->binCuts.p; m.nCuts = nCuts; m.nBins = nBins;
     // an entry per (cluster, bin it has a stored record in): at most two; sorted by bin (stable: cluster order inside a bin)
-    k_bin_entries<<<gridFor(nClusters, 256), 256, 0, st>>>(records, nClusters, nReads, c->binOfContig.p, nContigs, nBins, c->binKeys.p, c->binValues.p);
-    sortPairs(c, c->binKeys.p, c->binKeysAlt.p, c->binValues.p, c->binValuesAlt.p, nEntries, 8);
+    k_bin_entries<<<gridFor(nClusters, 256), 256, 0, st>>>(records, nClusters, nReads, m, c->binKeys.p, c->binValues.p);
+    int keyBits = 1; while ((1u << keyBits) <= nBins) ++keyBits;             // keys 0 .. n_bins
+    sortPairs(c, c->binKeys.p, c->binKeysAlt.p, c->binValues.p, c->binValuesAlt.p, nEntries, keyBits);
     // CIGAR words of every entry's cluster, their running sum in sorted order, and per bin the entries and the words
-    k_bin_words<<<gridFor(nEntries, 256), 256, 0, st>>>(records, nReads, c->binKeysAlt.p, c->binValuesAlt.p, nEntries, c->binWords.p, reinterpret_cast<unsigned long long *>(c->binCounts.p));
+    k_bin_words<<<gridFor(nEntries, 256), 256, 0, st>>>(records, nReads, c->binKeysAlt.p, c->binValuesAlt.p, nEntries, nBins, c->binWords.p, reinterpret_cast<unsigned long long *>(c->binCounts.p));
     exclusiveSum(c, c->binWords.p, c->binWords.p, nEntries + 1);
-    std::vector<u64> counts(2 * BIN_MAX + 2);
+    k_bin_layout<<<1, 1, 0, st>>>(c->binCounts.p, nBins, nReads, clusterLength, c->binLayout.p, c->binCounts.p + 2 * size_t(nBins));
+    std::vector<u64> counts(2 * size_t(nBins) + 2);
     HIP_CHECK(hipMemcpyAsync(counts.data(), c->binCounts.p, counts.size() * 8, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    // the layout of the output: bin after bin, every array on a multiple of 64 bytes
-    BinLayout layout; std::memset(&layout, 0, sizeof(layout));
-    u64 at = 0, firstEntry = 0;
-    auto align64 = [](u64 v) { return (v + 63) & ~u64(63); };
-    for (u32 b = 0; b < nBins; ++b)
-    {
-        const u64 m = counts[b], w = counts[BIN_MAX + b];
-        sizesOut[b].n_clusters = m; sizesOut[b].n_cigar_words = w;
-        layout.firstEntry[b] = firstEntry; layout.bclAt[b] = at;
-        at = align64(at + m * clusterLength); layout.recordsAt[b] = at;
-        at = align64(at + m * nReads * sizeof(FragmentRecord)); layout.cigarsAt[b] = at;
-        at = align64(at + w * 4);
-        firstEntry += m;
-    }
-    layout.firstEntry[nBins] = firstEntry;
+    for (u32 b = 0; b < nBins; ++b) { sizesOut[b].n_clusters = counts[b]; sizesOut[b].n_cigar_words = counts[nBins + b]; }
+    const u64 at = counts[2 * size_t(nBins)], firstEntry = counts[2 * size_t(nBins) + 1];
     if (nBytesOut) *nBytesOut = at;
     if (at > capacity) return fail(ISAAC_GPU_ECAPACITY, "out_dev is too small");
     if (!out) return fail(ISAAC_GPU_EINVAL, "out_dev is required");
+    BinLayout layout; layout.firstEntry = c->binLayout.p; layout.bclAt = layout.firstEntry + nBins + 1; layout.recordsAt = layout.bclAt + nBins; layout.cigarsAt = layout.recordsAt + nBins;
     if (firstEntry) k_bin_gather<<<gridFor(firstEntry, 4), 256, 0, st>>>(bcl, records, cigars, nReads, clusterLength, c->binKeysAlt.p, c->binValuesAlt.p, firstEntry, c->binWords.p, layout, out);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(st));
     return 0;
     ISAAC_CATCH
+}
+int isaac_gpu_bin_tile(isaac_gpu_ctx *c, const uint8_t *bcl, const isaac_fragment *fragments, const uint32_t *cigars, uint32_t nClusters, const uint32_t *binOfContig, uint32_t nContigs, uint32_t nBins,
+                       uint8_t *out, uint64_t capacity, isaac_bin_size *sizesOut, uint64_t *nBytesOut)
+{
+    isaac_bin_map map; map.bin_of_contig = binOfContig; map.n_contigs = nContigs; map.cut_positions = nullptr; map.n_cuts = 0; map.n_bins = nBins;
+    return isaac_gpu_bin_tile_map(c, bcl, fragments, cigars, nClusters, &map, out, capacity, sizesOut, nBytesOut);
 }
 
 uint64_t isaac_gpu_bgzf_store_bound(uint64_t nBytes) { return ((nBytes + BGZF_BLOCK_INPUT - 1) / BGZF_BLOCK_INPUT) * u64(BGZF_BLOCK_INPUT + BGZF_STORED_OVERHEAD) + 28; }

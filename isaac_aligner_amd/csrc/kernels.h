@@ -145,9 +145,19 @@ struct RescueBuffers
 };
 
 #ifndef ISAAC_SELECT_BLOCK
-#define ISAAC_SELECT_BLOCK 256
+#define ISAAC_SELECT_BLOCK 64
 #endif
 static const u32 SELECT_BLOCK = ISAAC_SELECT_BLOCK;     // threads per workgroup of k_select / k_plan_rescue
+// candidates of both reads together (and rescue problems) up to which k_select / k_plan_rescue copy a cluster's lists to LDS (0: never); the area of
+// one thread in 8-byte words: the candidates, the problems' outcomes (k_select), and a word that makes the count odd
+#ifndef ISAAC_SELECT_STAGE
+#define ISAAC_SELECT_STAGE 4
+#endif
+#ifndef ISAAC_PLAN_STAGE
+#define ISAAC_PLAN_STAGE 6
+#endif
+static const u32 SELECT_STAGE = ISAAC_SELECT_STAGE, SELECT_STAGE_WORDS = (SELECT_STAGE * (64 + 24) / 8) | 1u;
+static const u32 PLAN_STAGE = ISAAC_PLAN_STAGE, PLAN_STAGE_WORDS = PLAN_STAGE * 8 + 1;
 
 // k_cluster_sums: the outcome of every rescue problem of a cluster and its probability sums (sums.h), one wavefront per cluster
 // with room for 64 list entries in LDS; clusters with longer lists are listed for the workgroup-per-cluster form (1024 entries),

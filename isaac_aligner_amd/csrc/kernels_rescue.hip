@@ -11,6 +11,9 @@ __attribute__((amdgpu_waves_per_eu(ISAAC_WAVES_PLAN, ISAAC_WAVES_PLAN)))
 #endif
 __global__ __launch_bounds__(SELECT_BLOCK) void k_plan_rescue(const TemplateConstants *__restrict__ constants, DevReference R, u32 clusterBase, u32 nChunk, ClusterPools pools, RescueBuffers rb, const u32 *__restrict__ order)
 {
+#if ISAAC_PLAN_STAGE
+    __shared__ u64 stage[SELECT_BLOCK * PLAN_STAGE_WORDS];       // the thread's copy of its cluster's candidate lists: see k_select
+#endif
     const DevParams &P = constants->P;
     const u32 slot = blockIdx.x * blockDim.x + threadIdx.x;
     const bool inChunk = slot < nChunk;
@@ -38,6 +41,31 @@ __global__ __launch_bounds__(SELECT_BLOCK) void k_plan_rescue(const TemplateCons
         x.pool = pools.cigars + 3 * u64(meta.first);
         x.rogRead0 = 0.0; x.rogRead1 = 0.0; x.rog = 0.0; x.logMismatchQ40 = 0.0;      // no score is computed here
         x.clusterId = clusterBase + t; x.mapqNearInteger = 0;
+#if ISAAC_PLAN_STAGE
+        if (reserve <= PLAN_STAGE)
+        {
+            Cand *mine = reinterpret_cast<Cand *>(stage + threadIdx.x * PLAN_STAGE_WORDS);
+            uint4 v[PLAN_STAGE][4];
+#pragma unroll
+            for (u32 i = 0; i < PLAN_STAGE; ++i)
+                if (i < reserve)
+                {
+                    const uint4 *from = reinterpret_cast<const uint4 *>(i < x.n0 ? x.l0 + i : x.l1 + (i - x.n0));
+                    v[i][0] = from[0]; v[i][1] = from[1]; v[i][2] = from[2]; v[i][3] = from[3];
+                }
+#pragma unroll
+            for (u32 i = 0; i < PLAN_STAGE; ++i)
+                if (i < reserve)
+                {
+                    uint2 *to = reinterpret_cast<uint2 *>(mine + i);
+                    to[0] = make_uint2(v[i][0].x, v[i][0].y); to[1] = make_uint2(v[i][0].z, v[i][0].w); to[2] = make_uint2(v[i][1].x, v[i][1].y); to[3] = make_uint2(v[i][1].z, v[i][1].w);
+                    to[4] = make_uint2(v[i][2].x, v[i][2].y); to[5] = make_uint2(v[i][2].z, v[i][2].w); to[6] = make_uint2(v[i][3].x, v[i][3].y); to[7] = make_uint2(v[i][3].z, v[i][3].w);
+                }
+            x.l0 = mine; x.l1 = mine + x.n0;
+            n = leanPlanCluster(x, t, jobs);
+        }
+        else
+#endif
         n = leanPlanCluster(x, t, jobs);
         if (jobs)
         {
@@ -170,7 +198,8 @@ __device__ inline void rescueWindowScanShort(const DevReference &R, const Rescue
     static_assert(PL <= 16, "a lane's bit offsets 2k stay below 32");
     const i32 bias = i32(L) - 7;
     const i32 lastStart = i32(job.windowLen) - 7;       // last valid k-mer start
-    const u32 presentBase = u32(size_t((LdsWord *)present));               // a multiple of 2048: OR instead of ADD
+    u32 presentBase = u32(size_t((LdsWord *)present));                     // a multiple of 2048: OR instead of ADD
+    asm("" : "+v"(presentBase));                                           // in a vector register: (x & mask) | base is then one v_and_or_b32 (its mask may be the one scalar operand)
     for (i32 tile = 0; tile * i32(64 * PL) <= lastStart; ++tile)
     {
         const i32 p0 = tile * i32(64 * PL) + i32(lane * PL);               // window position of this lane's first base

@@ -3,7 +3,7 @@
 
 __device__ inline SumInputs sumInputs(const RescueBuffers &rb, u32 t, const GappedBuffers &gb)
 {
-    SumInputs in; in.jobs = rb.jobs + rb.jobBase[t]; in.nJobs = rb.jobCount[t]; in.shadowCands = rb.shadowCands; in.candRank = rb.candRank; in.gappedResults = gb.results; in.gappedJobs = gb.jobs;
+    SumInputs in; in.jobs = rb.jobs + rb.jobBase[t]; in.nJobs = rb.jobCount[t]; in.shadowCands = rb.shadowCands; in.candRank = rb.candRank; in.gappedResults = gb.results; in.gappedJobs = gb.jobs; in.shadowCigars = rb.shadowCigars;
     return in;
 }
 __device__ inline void markResidual(const SumsBuffers &sb, u32 t) { sb.residualFlag[t] = 1; sb.residualList[atomicAdd(sb.residualCount, 1u)] = t; }

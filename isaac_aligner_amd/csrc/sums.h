@@ -311,7 +311,7 @@ ISAAC_HD void sumKeyFromCand(SumKeys &k, u32 at, const Cand &c)
 enum { SUMS_DONE = 0, SUMS_TOO_LARGE = 1, SUMS_RESIDUAL = 2 /* a capacity of the flat pass was exceeded */, SUMS_NEAR_TIE = 3 };
 
 // what the flat rescue kernels left for one cluster
-struct SumInputs { RescueJob *jobs; u32 nJobs; const Cand *shadowCands; const u32 *candRank; const GappedResult *gappedResults; GappedJob *gappedJobs; };
+struct SumInputs { RescueJob *jobs; u32 nJobs; const Cand *shadowCands; const u32 *candRank; const GappedResult *gappedResults; GappedJob *gappedJobs; const u32 *shadowCigars /* 3 words per candidate slot */; };
 
 // the accept rule of ShadowAligner.cpp:243-262 for the gapped retry `g` of the shadow `fragment`
 ISAAC_HD bool gappedRetryAccepted(const DevParams &P, const Cand &fragment, const GappedResult &g)
@@ -327,6 +327,7 @@ ISAAC_HD bool gappedRetryAccepted(const DevParams &P, const Cand &fragment, cons
 ISAAC_HD bool finishRescueFlat(const DevParams &P, RescueJob &job, const SumInputs &in, u32 &retries)
 {
     job.take = 0; job.rescued = 0; job.finalBestRank = 0; job.finalBestSlot = 0; job.finalBestGapped = 0xffffffffu;
+    job.out.logProbability = 0.0; job.out.smithWatermanScore = 0; job.out.editDistance = 0; job.out.mapped = 0; job.out.mismatchCount = 0; job.out.matchesInARow = 0; job.out.rescued = 0;
     if (!job.valid) return true;
     if (job.fallback || (job.nGapped && 0xffffffffu == job.gappedBase)) return false;
     const bool full = job.nAligned - job.lastAligned >= SHADOW_LIST_MAX && job.nCands != 0;   // the reference gives up when the list is full and another candidate aligns
@@ -352,6 +353,16 @@ ISAAC_HD bool finishRescueFlat(const DevParams &P, RescueJob &job, const SumInpu
         }
     }
     job.rescued = 1; job.finalBestRank = best; job.finalBestSlot = bestSlot; job.finalBestGapped = bestGapped;
+    {   // the best shadow as the template stage will ask about it (template_lean.h: leanConsiderRescued)
+        const bool gapped = 0xffffffffu != bestGapped;
+        const Cand &b = gapped ? in.gappedResults[bestGapped].out : in.shadowCands[bestSlot];
+        const u32 *cigar = gapped ? in.gappedResults[bestGapped].cigar : in.shadowCigars + u64(bestSlot) * 3;
+        const u32 n = gapped ? (in.gappedResults[bestGapped].nCigar & 0xffffu) : u32(b.cigarLength);
+        u32 mapped = 0;
+        for (u32 i = 0; i < n; ++i) if (OP_ALIGN == cigarCode(cigar[i])) mapped += cigarLen(cigar[i]);
+        job.out.logProbability = b.logProbability; job.out.smithWatermanScore = b.smithWatermanScore; job.out.editDistance = b.editDistance; job.out.mapped = u16(mapped);
+        job.out.mismatchCount = b.mismatchCount; job.out.matchesInARow = b.matchesInARow; job.out.rescued = 1;
+    }
     return true;
 }
 

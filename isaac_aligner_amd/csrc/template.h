@@ -217,6 +217,12 @@ ISAAC_HD void templateWorkBind(TemplateWork &w, void *base, const TemplateCaps &
 struct Frag { Cand c; const u32 *pool; };
 struct BamTemplate { Frag f[2]; u32 n; u32 alignmentScore; bool properPair; };
 
+// What TemplateBuilder's loops over the orphans (TemplateBuilder.cpp:527-590, :742-824) read of a problem's best shadow: whether there is one
+// (`rescued`: the problem is valid and ShadowAligner::rescueShadow returned true), its logProbability, Smith-Waterman score and edit distance, and
+// what isVeryBadAlignment (TemplateBuilder.cpp:52-62) looks at: the bases its CIGAR maps, its mismatches and its longest run of matches.
+struct RescueOutcome { double logProbability; u32 smithWatermanScore; u16 editDistance, mapped, mismatchCount, matchesInARow; u8 rescued; u8 pad[3]; };
+static_assert(sizeof(RescueOutcome) == 24, "RescueOutcome layout");
+
 // One mate-rescue problem (ShadowAligner::rescueShadow call): planned by the cluster's thread, its window scanned by a
 // wavefront (k_rescue_windows), its candidate positions aligned one per thread (k_rescue_align), consumed by the cluster again.
 struct RescueJob
@@ -240,9 +246,11 @@ struct RescueJob
     u8 rescued;             // rescueShadow's return value
     u16 windowBaseHigh;     // index of the window's first base in the concatenated contigs (contig offset + windowBegin), 48 bits:
     u32 windowBaseLow;      // k_rescue_windows starts its loads from the job record alone
+    RescueOutcome out;      // finishRescueFlat: what the template stage asks about the best shadow, so that it need not follow the record to the shadow
+    u32 pad[2];
 };
 ISAAC_HD u64 rescueJobWindowBase(const RescueJob &j) { return (u64(j.windowBaseHigh) << 32) | j.windowBaseLow; }
-static_assert(sizeof(RescueJob) == 96, "RescueJob layout");
+static_assert(sizeof(RescueJob) == 128 && offsetof(RescueJob, out) == 96, "RescueJob layout");
 static const u32 SHADOW_LIST_MAX = 1000;          // ShadowAligner.hh: shadowList_ capacity, TemplateBuilder.hh:TRACKED_REPEATS_MAX_ONE_READ
 enum { RESCUE_SERIAL = 0, RESCUE_PLAN = 1, RESCUE_LOOKUP = 2, RESCUE_PRECOMPUTED = 3 };
 // Per cluster, from k_cluster_sums: sumUniqueShadowProbabilities of either side (the shadows rescued by the orphans of read `side`

@@ -26,17 +26,23 @@ struct LeanFrag
     u32 contigId, observedLength, alignmentScore;
     u16 cigarLength, editDistance, lowClipped, highClipped, gapCount;
     u8 reverse, readIndex;
+    // while the end clippers work (leanLoadEdges .. leanWriteCigar): the first two and the last two words of the CIGAR, and the bases its first and its
+    // last ALIGN operation have lost to a soft clip since.  The CIGAR itself stays where it is and is written once, clipped, into the record's slot
+    // (round 4 edited it in the slot: every look at a word behind an edit was a round trip to memory)
+    u32 w0, w1, wl, wp; u16 frontClip, backClip;
 };
 ISAAC_HD void leanInit(LeanFrag &f, u32 readIndex)
 {
     f.position = 0; f.cigar = 0; f.contigId = MAX_CONTIG_ID; f.observedLength = 0; f.alignmentScore = 0xffffffffu; f.cigarLength = 0; f.editDistance = 0;
     f.lowClipped = 0; f.highClipped = 0; f.gapCount = 0; f.reverse = 0; f.readIndex = u8(readIndex);
+    f.w0 = f.w1 = f.wl = f.wp = 0; f.frontClip = f.backClip = 0;
 }
 ISAAC_HD void leanLoad(LeanFrag &f, const Cand &c, const u32 *pool)
 {
     f.position = c.position; f.cigar = pool + c.cigarOffset; f.contigId = c.contigId; f.observedLength = c.observedLength; f.alignmentScore = c.alignmentScore;
     f.cigarLength = c.cigarLength; f.editDistance = c.editDistance; f.lowClipped = c.lowClipped; f.highClipped = c.highClipped; f.gapCount = c.gapCount;
     f.reverse = c.reverse; f.readIndex = c.readIndex;
+    f.w0 = f.w1 = f.wl = f.wp = 0; f.frontClip = f.backClip = 0;
 }
 // c ? a : b, field by field: a conditional on the structs themselves is a choice between two addresses, and a fragment whose address
 // is chosen at run time lives in scratch memory instead of registers
@@ -47,6 +53,7 @@ ISAAC_HD LeanFrag leanPick(bool c, const LeanFrag &a, const LeanFrag &b)
     f.alignmentScore = c ? a.alignmentScore : b.alignmentScore; f.cigarLength = c ? a.cigarLength : b.cigarLength; f.editDistance = c ? a.editDistance : b.editDistance;
     f.lowClipped = c ? a.lowClipped : b.lowClipped; f.highClipped = c ? a.highClipped : b.highClipped; f.gapCount = c ? a.gapCount : b.gapCount;
     f.reverse = c ? a.reverse : b.reverse; f.readIndex = c ? a.readIndex : b.readIndex;
+    f.w0 = c ? a.w0 : b.w0; f.w1 = c ? a.w1 : b.w1; f.wl = c ? a.wl : b.wl; f.wp = c ? a.wp : b.wp; f.frontClip = c ? a.frontClip : b.frontClip; f.backClip = c ? a.backClip : b.backClip;
     return f;
 }
 ISAAC_HD ReadView leanPickRead(bool c, const ReadView &a, const ReadView &b)
@@ -325,7 +332,12 @@ ISAAC_HD u32 leanPlanCluster(LeanCtx &x, u32 chunkCluster, RescueJob *jobs)
 struct LeanRescue
 {
     const RescueJob *jobs; u32 jobCount; const Cand *shadowCands; const u32 *shadowCigars; const GappedResult *gappedResults; const ClusterSums *sums;
+    // RescueJob::out of problem k at outcomes + k * outcomeStride bytes: in the records themselves (stride sizeof(RescueJob)), or a copy the
+    // kernel made next to its copy of the candidates (k_select: stride sizeof(RescueOutcome))
+    const u8 *outcomes; u32 outcomeStride;
 };
+ISAAC_HD const RescueOutcome &leanOutcome(const LeanRescue &rs, u32 k) { return *reinterpret_cast<const RescueOutcome *>(rs.outcomes + size_t(k) * rs.outcomeStride); }
+ISAAC_HD void leanOutcomesInPlace(LeanRescue &rs) { rs.outcomes = reinterpret_cast<const u8 *>(rs.jobs) + offsetof(RescueJob, out); rs.outcomeStride = u32(sizeof(RescueJob)); }
 // the best shadow of a successful rescue (template.h: shadowRescue, RESCUE_PRECOMPUTED): where it lies and where its CIGAR words are
 struct LeanShadow { const Cand *c; const u32 *cigar; u32 cigarLength; };
 ISAAC_HD LeanShadow leanShadowOf(const LeanRescue &rs, const RescueJob &job)
@@ -341,6 +353,7 @@ ISAAC_HD void leanLoadShadow(LeanFrag &f, const LeanShadow &s)
     f.position = c.position; f.cigar = s.cigar; f.contigId = c.contigId; f.observedLength = c.observedLength; f.alignmentScore = c.alignmentScore;
     f.cigarLength = u16(s.cigarLength); f.editDistance = c.editDistance; f.lowClipped = c.lowClipped; f.highClipped = c.highClipped; f.gapCount = c.gapCount;
     f.reverse = c.reverse; f.readIndex = c.readIndex;
+    f.w0 = f.w1 = f.wl = f.wp = 0; f.frontClip = f.backClip = 0;
 }
 // isVeryBadAlignment (TemplateBuilder.cpp:52-62) of a rescued shadow / of a list candidate
 ISAAC_HD bool leanVeryBad(const Cand &f, const u32 *cigar, u32 cigarLength, double logMismatchQ40)
@@ -348,6 +361,11 @@ ISAAC_HD bool leanVeryBad(const Cand &f, const u32 *cigar, u32 cigarLength, doub
     u32 mapped = 0;
     for (u32 i = 0; i < cigarLength; ++i) if (OP_ALIGN == cigarCode(cigar[i])) mapped += cigarLen(cigar[i]);
     return f.matchesInARow < 32 && (u32(f.mismatchCount) > mapped / 8 || f.logProbability < logMismatchQ40 / 4 * mapped);
+}
+ISAAC_HD bool leanVeryBad(const RescueOutcome &o, double logMismatchQ40)
+{
+    const u32 mapped = o.mapped;
+    return o.matchesInARow < 32 && (u32(o.mismatchCount) > mapped / 8 || o.logProbability < logMismatchQ40 / 4 * mapped);
 }
 
 // the equally good rescued pairs of one orphan side: list index of the orphan and index of its rescue problem, a byte each
@@ -374,12 +392,12 @@ ISAAC_HD void leanConsiderRescued(const LeanCtx &x, const LeanRescue &rs, const 
                                   LeanRescuedBest &best, bool &newBest)
 {
     newBest = false;
-    const RescueJob &job = rs.jobs[jobIndex];
-    if (!job.valid || !job.rescued) return;
-    const LeanShadow s = leanShadowOf(rs, job);
-    const Cand &bestRescued = *s.c;
+    // (the problem's best shadow through the summary finishRescueFlat left in the record: following the record to the shadow and its CIGAR
+    // is two more memory round trips per orphan, one orphan after the other)
+    const RescueOutcome &bestRescued = leanOutcome(rs, jobIndex);
+    if (!bestRescued.rescued) return;
     const double lp = orphan.logProbability + bestRescued.logProbability;
-    if (leanVeryBad(bestRescued, s.cigar, s.cigarLength, x.logMismatchQ40)) return;
+    if (leanVeryBad(bestRescued, x.logMismatchQ40)) return;
     if (disjoined && knownResolved && !((knownEditDistance + SKIP_ORPHAN_EDIT_DISTANCE) >= u32(orphan.editDistance) + u32(bestRescued.editDistance))) return;
     const u64 templateScore = u64(orphan.smithWatermanScore + bestRescued.smithWatermanScore);
     if (0 == best.resolved || templateScore < best.bestScore || (templateScore == best.bestScore && lpLess(best.bestLp, lp)))
@@ -629,96 +647,179 @@ ISAAC_HD bool leanBuildTemplate(LeanCtx &x, const LeanRescue &rs, LeanTemplate &
     return ret;
 }
 
-// ---- the end clippers on a CIGAR that lies in the record's own slot (cig[0 .. f.cigarLength), room for OUT_CIGAR_CAP words) ----
-// `bases` more bases of the first (last) ALIGN operation become soft clip
-ISAAC_HD void leanClipFront(u32 *cig, LeanFrag &f, u32 bases)
+// ---- the end clippers.  The CIGAR of a template end stays where it is (the cluster's pool, a rescued shadow's three words, a gapped result); the clippers
+// look at its first two and last two words (LeanFrag::w0, w1, wl, wp) and note what they take from its first and last ALIGN operation
+// (frontClip, backClip); leanWriteCigar writes it once, clipped, into the record's output slot.
+ISAAC_HD void leanLoadEdges(LeanFrag &f)
 {
-    u32 n = f.cigarLength;
-    if (OP_SOFT_CLIP == cigarCode(cig[0])) { cig[0] = cigarOp(cigarLen(cig[0]) + bases, OP_SOFT_CLIP); cig[1] = cigarOp(cigarLen(cig[1]) - bases, OP_ALIGN); }
-    else
-    {
-        for (u32 i = n; i > 1; --i) cig[i] = cig[i - 1];
-        cig[1] = cigarOp(cigarLen(cig[0]) - bases, OP_ALIGN); cig[0] = cigarOp(bases, OP_SOFT_CLIP);
-        ++n;
-    }
-    f.cigarLength = u16(n);
+    const u32 n = f.cigarLength;
+    f.w0 = n ? f.cigar[0] : 0u; f.w1 = n > 1 ? f.cigar[1] : 0u; f.wl = n ? f.cigar[n - 1] : 0u; f.wp = n > 1 ? f.cigar[n - 2] : 0u;
+    f.frontClip = 0; f.backClip = 0;
 }
-ISAAC_HD void leanClipBack(u32 *cig, LeanFrag &f, u32 bases)
+ISAAC_HD bool leanSrcFrontClip(const LeanFrag &f) { return f.cigarLength && OP_SOFT_CLIP == cigarCode(f.w0); }
+ISAAC_HD bool leanSrcBackClip(const LeanFrag &f) { return f.cigarLength && OP_SOFT_CLIP == cigarCode(f.wl); }
+// the CIGAR as it stands: its length, its soft clips, and the operations next to them
+ISAAC_HD u32 leanCigarLengthNow(const LeanFrag &f) { return u32(f.cigarLength) + ((f.frontClip && !leanSrcFrontClip(f)) ? 1u : 0u) + ((f.backClip && !leanSrcBackClip(f)) ? 1u : 0u); }
+ISAAC_HD bool leanHasFrontClip(const LeanFrag &f) { return leanSrcFrontClip(f) || f.frontClip; }
+ISAAC_HD bool leanHasBackClip(const LeanFrag &f) { return leanSrcBackClip(f) || f.backClip; }
+ISAAC_HD u32 leanFrontClipBases(const LeanFrag &f) { return (leanSrcFrontClip(f) ? cigarLen(f.w0) : 0u) + f.frontClip; }
+ISAAC_HD u32 leanBackClipBases(const LeanFrag &f) { return (leanSrcBackClip(f) ? cigarLen(f.wl) : 0u) + f.backClip; }
+// index (in the CIGAR where it lies) of the operation behind the leading soft clip / before the trailing one
+ISAAC_HD i32 leanFirstInner(const LeanFrag &f) { return leanSrcFrontClip(f) ? 1 : 0; }
+ISAAC_HD i32 leanLastInner(const LeanFrag &f) { return i32(f.cigarLength) - (leanSrcBackClip(f) ? 2 : 1); }
+// those operations as they stand (0: there is none): an ALIGN operation less what the clippers have taken from it
+ISAAC_HD u32 leanFirstInnerOp(const LeanFrag &f)
 {
-    u32 n = f.cigarLength;
-    if (OP_SOFT_CLIP == cigarCode(cig[n - 1])) { cig[n - 1] = cigarOp(cigarLen(cig[n - 1]) + bases, OP_SOFT_CLIP); cig[n - 2] = cigarOp(cigarLen(cig[n - 2]) - bases, OP_ALIGN); }
-    else { cig[n] = cigarOp(bases, OP_SOFT_CLIP); cig[n - 1] = cigarOp(cigarLen(cig[n - 1]) - bases, OP_ALIGN); ++n; }
-    f.cigarLength = u16(n);
+    const i32 i = leanFirstInner(f), n = i32(f.cigarLength);
+    if (i >= n) return 0;
+    const u32 w = 0 == i ? f.w0 : f.w1;
+    if (OP_ALIGN != cigarCode(w)) return w;
+    return cigarOp(cigarLen(w) - f.frontClip - (i == leanLastInner(f) ? u32(f.backClip) : 0u), OP_ALIGN);
+}
+ISAAC_HD u32 leanLastInnerOp(const LeanFrag &f)
+{
+    const i32 i = leanLastInner(f), n = i32(f.cigarLength);
+    if (i < 0) return 0;
+    const u32 w = n - 1 == i ? f.wl : f.wp;
+    if (OP_ALIGN != cigarCode(w)) return w;
+    return cigarOp(cigarLen(w) - f.backClip - (i == leanFirstInner(f) ? u32(f.frontClip) : 0u), OP_ALIGN);
+}
+// the CIGAR as it stands into the record's slot (room for the source's words + 2); returns its length
+ISAAC_HD u32 leanWriteCigar(const LeanFrag &f, u32 *out)
+{
+    const u32 n = f.cigarLength;
+    if (!f.frontClip && !f.backClip) { for (u32 k = 0; k < n; ++k) out[k] = f.cigar[k]; return n; }
+    const i32 iF = leanFirstInner(f), iL = leanLastInner(f);
+    u32 k = 0;
+    if (leanHasFrontClip(f)) out[k++] = cigarOp(leanFrontClipBases(f), OP_SOFT_CLIP);
+    for (i32 i = iF; i <= iL; ++i)
+    {
+        u32 w = i == iF ? leanFirstInnerOp(f) : i == iL ? leanLastInnerOp(f) : f.cigar[i];
+        out[k++] = w;
+    }
+    if (leanHasBackClip(f)) out[k++] = cigarOp(leanBackClipBases(f), OP_SOFT_CLIP);
+    return k;
 }
 
-// SemialignedEndsClipper::clipLeftSide / clipRightSide (SemialignedEndsClipper.cpp:31-156)
-ISAAC_HD bool leanSemialignedLeft(const LeanCtx &x, const ReadView &read, u32 *cig, LeanFrag &f)
+// clipMismatches<5> (Alignment.hh:55-88; template.h: clipMismatches) with the first eight bases of either side fetched at once: nearly every end
+// is decided by its first five bases, and the loop over single bytes is a memory round trip per base.  A LeanScan is such a scan asked for (leanScanAsk:
+// the two loads are issued) and not yet looked at (leanScanRun): the four scans of a pair -- either end of either read -- are asked for together, one
+// round trip for all of them.  refIdx: position on contig contigId.
+struct LeanScan { u64 readBytes, refBytes; i64 seqIdx, refIdx, b0, blo, a0, alo; i32 dir, bdir; bool reverse, fetched; u32 contigId; };
+ISAAC_HD void leanScanAsk(LeanScan &w, const LeanCtx &x, const ReadView &read, bool reverse, i64 seqIdx, u32 contigId, i64 refIdx, i32 dir)
 {
-    u32 at = 0; u32 op = cig[0];
-    i64 seqBegin = 0;
-    if (OP_SOFT_CLIP == cigarCode(op))
+    w.seqIdx = seqIdx; w.refIdx = refIdx; w.dir = dir; w.reverse = reverse; w.contigId = contigId; w.fetched = false; w.readBytes = 0; w.refBytes = 0;
+    w.b0 = w.blo = w.a0 = w.alo = 0; w.bdir = dir;
+    const i64 total = i64(x.R->totalBases), L = i64(read.length);
+    if (L < 8 || total < 8 || MAX_CONTIG_ID == contigId) return;
+    w.b0 = reverse ? L - 1 - seqIdx : seqIdx;                        // BCL byte of the first base looked at, and which way the bytes go
+    w.bdir = reverse ? -dir : dir;
+    i64 blo = w.bdir > 0 ? w.b0 : w.b0 - 7; blo = blo < 0 ? 0 : blo > L - 8 ? L - 8 : blo;
+    w.a0 = i64(x.R->contigOffset[contigId]) + refIdx;
+    i64 alo = dir > 0 ? w.a0 : w.a0 - 7; alo = alo < 0 ? 0 : alo > total - 8 ? total - 8 : alo;
+    w.blo = blo; w.alo = alo;
+    memcpy(&w.readBytes, read.bcl + blo, 8); memcpy(&w.refBytes, x.R->bases + alo, 8);
+    w.fetched = true;
+}
+ISAAC_HD void leanScanRun(const LeanScan &w, const LeanCtx &x, const ReadView &read, i64 seqCount, i64 refCount, u32 &clipped, u32 &editAdj)
+{
+    if (w.fetched)
     {
-        if (2 > f.cigarLength) return false;
-        at = 1; seqBegin += cigarLen(op); op = cig[1];
+        const u32 MIN = 5;
+        u32 matchesInARow = 0, edMismatches = 0, edUnclipped = 0, k = 0;
+        bool inWindow = true;
+        for (; k < 8 && i64(k) < seqCount && i64(k) < refCount && MIN > matchesInARow; ++k)
+        {
+            const i64 bi = w.b0 + i64(w.bdir) * i64(k) - w.blo, ai = w.a0 + i64(w.dir) * i64(k) - w.alo;
+            if (bi < 0 || bi > 7 || ai < 0 || ai > 7) { inWindow = false; break; }
+            const u8 b = u8(w.readBytes >> (8 * u32(bi))); const char r = char(w.refBytes >> (8 * u32(ai)));
+            const char s = !(b & 0xfc) ? 'n' : char(0x54474341u >> (8 * (w.reverse ? (~u32(b)) & 3u : u32(b) & 3u)));
+            if (isMatch(s, r)) { ++matchesInARow; edUnclipped += (s != r); }
+            else { matchesInARow = 0; edUnclipped = 0; }
+            edMismatches += (s != r);
+        }
+        if (inWindow && !(i64(k) < seqCount && i64(k) < refCount && MIN > matchesInARow))
+        {   // the loop has run to its end
+            if (MIN == matchesInARow) { clipped = k - matchesInARow; editAdj = edMismatches - edUnclipped; }
+            else { clipped = 0; editAdj = 0; }
+            return;
+        }
     }
-    if (OP_ALIGN != cigarCode(op)) return false;
-    const char *reference = x.R->bases + x.R->contigOffset[f.contigId];
+    clipMismatches(read, w.reverse, w.seqIdx, seqCount, x.R->bases + x.R->contigOffset[w.contigId], w.refIdx, refCount, w.dir, clipped, editAdj);
+}
+
+// SemialignedEndsClipper::clipLeftSide / clipRightSide (SemialignedEndsClipper.cpp:31-156).  Where either scan begins does not depend on the other's
+// outcome (a clip at the left moves position and observed length together): leanSemialignedAsk issues the loads of both before either is looked at.
+struct LeanEndScans { LeanScan left, right; };
+ISAAC_HD void leanSemialignedAsk(LeanEndScans &w, const LeanCtx &x, const ReadView &read, const LeanFrag &f)
+{
+    leanScanAsk(w.left, x, read, f.reverse, i64(leanHasFrontClip(f) ? leanFrontClipBases(f) : 0u), f.contigId, f.position, +1);
+    leanScanAsk(w.right, x, read, f.reverse, i64(read.length) - 1 - i64(leanHasBackClip(f) ? leanBackClipBases(f) : 0u), f.contigId, f.position + i64(leanObservedLength(f)) - 1, -1);
+}
+ISAAC_HD bool leanSemialignedLeft(const LeanCtx &x, const ReadView &read, LeanFrag &f, const LeanScan &asked)
+{
+    i64 seqBegin = 0;
+    if (leanHasFrontClip(f))
+    {
+        if (2 > leanCigarLengthNow(f)) return false;
+        seqBegin += leanFrontClipBases(f);
+    }
+    const u32 op = leanFirstInnerOp(f);
+    if (!op || OP_ALIGN != cigarCode(op)) return false;
     const i64 refSize = i64(contigLength(*x.R, f.contigId));
     u32 clipped, editAdj;
-    clipMismatches(read, f.reverse, seqBegin, cigarLen(op), reference, f.position, refSize - f.position, +1, clipped, editAdj);
+    if (asked.seqIdx == seqBegin && asked.refIdx == f.position) leanScanRun(asked, x, read, cigarLen(op), refSize - f.position, clipped, editAdj);
+    else clipMismatches(read, f.reverse, seqBegin, cigarLen(op), x.R->bases + x.R->contigOffset[f.contigId], f.position, refSize - f.position, +1, clipped, editAdj);
     if (!clipped) return false;
     f.observedLength -= clipped; f.position += clipped; f.editDistance = u16(f.editDistance - editAdj);
-    leanClipFront(cig, f, clipped);
-    (void)at;
+    f.frontClip = u16(f.frontClip + clipped);
     return true;
 }
-ISAAC_HD bool leanSemialignedRight(const LeanCtx &x, const ReadView &read, u32 *cig, LeanFrag &f)
+ISAAC_HD bool leanSemialignedRight(const LeanCtx &x, const ReadView &read, LeanFrag &f, const LeanScan &asked)
 {
-    u32 n = f.cigarLength;
-    u32 op = cig[n - 1];
     i64 seqR = i64(read.length) - 1;
-    if (OP_SOFT_CLIP == cigarCode(op))
+    if (leanHasBackClip(f))
     {
-        if (2 > f.cigarLength) return false;
-        --n; seqR -= cigarLen(op); op = cig[n - 1];
+        if (2 > leanCigarLengthNow(f)) return false;
+        seqR -= leanBackClipBases(f);
     }
-    if (OP_ALIGN != cigarCode(op)) return false;
-    const char *reference = x.R->bases + x.R->contigOffset[f.contigId];
+    const u32 op = leanLastInnerOp(f);
+    if (!op || OP_ALIGN != cigarCode(op)) return false;
     const i64 refLast = f.position + i64(leanObservedLength(f)) - 1;
     u32 clipped, editAdj;
-    clipMismatches(read, f.reverse, seqR, cigarLen(op), reference, refLast, refLast + 1, -1, clipped, editAdj);
+    if (asked.seqIdx == seqR && asked.refIdx == refLast) leanScanRun(asked, x, read, cigarLen(op), refLast + 1, clipped, editAdj);
+    else clipMismatches(read, f.reverse, seqR, cigarLen(op), x.R->bases + x.R->contigOffset[f.contigId], refLast, refLast + 1, -1, clipped, editAdj);
     if (!clipped) return false;
     f.observedLength -= clipped; f.editDistance = u16(f.editDistance - editAdj);
-    leanClipBack(cig, f, clipped);
+    f.backClip = u16(f.backClip + clipped);
     return true;
 }
 
 // OverlappingEndsClipper::clip (OverlappingEndsClipper.cpp:46-183); left / right: the template's ends by position (copies: the caller
-// writes the one that changed back, so that nothing here is reached through a pointer chosen at run time), their CIGARs in cigL / cigR.
+// writes the one that changed back, so that nothing here is reached through a pointer chosen at run time).
 // Returns 0: nothing clipped, 1: `right` clipped at its start, 2: `left` clipped at its end.
-ISAAC_HD u32 leanOverlappingClipOrdered(const LeanCtx &x, const ReadView &leftRead, const ReadView &rightRead, LeanFrag &left, u32 *cigL, LeanFrag &right, u32 *cigR)
+ISAAC_HD u32 leanOverlappingClipOrdered(const LeanCtx &x, const ReadView &leftRead, const ReadView &rightRead, LeanFrag &left, LeanFrag &right)
 {
     if (left.reverse) return 0;
     const i64 overlapLength = left.position + i64(leanObservedLength(left)) - right.position;
     if (0 >= overlapLength) return 0;
     u32 leftEndOffset = leftRead.length;
-    u32 leftLastIdx = left.cigarLength - 1;
-    u32 leftLastOp = cigL[leftLastIdx];
-    if (OP_SOFT_CLIP == cigarCode(leftLastOp))
+    if (leanHasBackClip(left))
     {
-        if (left.cigarLength < 2) return 0;
-        leftEndOffset -= cigarLen(leftLastOp); --leftLastIdx; leftLastOp = cigL[leftLastIdx];
+        if (leanCigarLengthNow(left) < 2) return 0;
+        leftEndOffset -= leanBackClipBases(left);
     }
-    if (OP_ALIGN != cigarCode(leftLastOp)) return 0;
+    const u32 leftLastOp = leanLastInnerOp(left);
+    if (!leftLastOp || OP_ALIGN != cigarCode(leftLastOp)) return 0;
     if (overlapLength >= i64(cigarLen(leftLastOp))) return 0;
     u32 rightStartOffset = 0;
-    u32 rightFirstOp = cigR[0];
-    if (OP_SOFT_CLIP == cigarCode(rightFirstOp))
+    if (leanHasFrontClip(right))
     {
-        if (right.cigarLength < 2) return 0;
-        rightStartOffset += cigarLen(rightFirstOp); rightFirstOp = cigR[1];
+        if (leanCigarLengthNow(right) < 2) return 0;
+        rightStartOffset += leanFrontClipBases(right);
     }
-    if (OP_ALIGN != cigarCode(rightFirstOp)) return 0;
+    const u32 rightFirstOp = leanFirstInnerOp(right);
+    if (!rightFirstOp || OP_ALIGN != cigarCode(rightFirstOp)) return 0;
     if (overlapLength >= i64(cigarLen(rightFirstOp))) return 0;
     i32 diff = 0;
     for (i64 i = 0; i < overlapLength; ++i)
@@ -727,7 +828,7 @@ ISAAC_HD u32 leanOverlappingClipOrdered(const LeanCtx &x, const ReadView &leftRe
     {
         const char *reference = x.R->bases + x.R->contigOffset[right.contigId] + right.position;
         u32 ed = 0; for (i64 i = 0; i < overlapLength; ++i) ed += (strandBase(rightRead, true, u32(rightStartOffset + i)) != reference[i]);
-        leanClipFront(cigR, right, u32(overlapLength));
+        right.frontClip = u16(right.frontClip + u32(overlapLength));
         right.position += overlapLength; if (right.reverse) right.highClipped += u16(overlapLength); else right.lowClipped += u16(overlapLength);   // incrementClipLeft
         right.observedLength -= u32(overlapLength);
         right.editDistance = u16(right.editDistance - ed);
@@ -735,7 +836,7 @@ ISAAC_HD u32 leanOverlappingClipOrdered(const LeanCtx &x, const ReadView &leftRe
     }
     const char *reference = x.R->bases + x.R->contigOffset[left.contigId] + left.position + i64(leanObservedLength(left)) - overlapLength;
     u32 ed = 0; for (i64 i = 0; i < overlapLength; ++i) ed += (strandBase(leftRead, false, u32(leftEndOffset - overlapLength + i)) != reference[i]);
-    leanClipBack(cigL, left, u32(overlapLength));
+    left.backClip = u16(left.backClip + u32(overlapLength));
     if (left.reverse) left.lowClipped += u16(overlapLength); else left.highClipped += u16(overlapLength);                                       // incrementClipRight
     left.observedLength -= u32(overlapLength);
     left.editDistance = u16(left.editDistance - ed);
@@ -783,46 +884,59 @@ static const u32 LEAN_OUT_CIGAR_CAP = 40;   // == OUT_CIGAR_CAP (cluster_ops.h)
 // MatchSelector::processMatchList for one cluster on precomputed rescue outcomes (cluster_ops.h: clusterSelect in RESCUE_PRECOMPUTED mode):
 // template, clippers, records.  Returns false when the cluster needs the general form instead (--scatter-repeats picks a rescued placement
 // beyond the LEAN_TIES kept, or a CIGAR is too long to be clipped in its output slot); the records are then not valid.
+// l0, l1: the cluster's two candidate lists -- where they lie in the pool, or a copy of them (k_select: in LDS); their CIGAR offsets are
+// relative to the cluster's words of the arena either way
 ISAAC_HD bool leanSelectCluster(const DevParams &P, const DevReference &R, const DevTls &tls, const RogCorrection &rog, double logMismatchQ40, const u8 *bcl, u32 cluster, u32 tile,
-                                const ClusterMeta &meta, const Cand *candPool, const u32 *cigarArena, const LeanRescue &rs, FragmentRecord *records, u32 *cigars, u32 &mapqNearInteger)
+                                const ClusterMeta &meta, const Cand *l0, const Cand *l1, const u32 *cigarArena, const LeanRescue &rs, FragmentRecord *records, u32 *cigars, u32 &mapqNearInteger)
 {
     LeanCtx x;
     x.P = &P; x.R = &R; x.tls = &tls;
-    x.l0 = candPool + meta.first; x.l1 = x.l0 + meta.second; x.n0 = meta.nCands[0]; x.n1 = meta.nCands[1];
+    x.l0 = l0; x.l1 = l1; x.n0 = meta.nCands[0]; x.n1 = meta.nCands[1];
     x.pool = cigarArena + 3 * u64(meta.first);
     x.rogRead0 = rog.read[0]; x.rogRead1 = rog.read[1]; x.rog = rog.pair; x.logMismatchQ40 = logMismatchQ40;
     x.clusterId = cluster; x.mapqNearInteger = 0;
     LeanTemplate t;
     u32 overflow = 0;
     bool store;
+#if defined(ISAAC_TIMING_SELECT_NO_TEMPLATE)
+    if (meta.built && cluster == 0xfffffff0u) store = leanBuildTemplate(x, rs, t, overflow) || P.keepUnaligned;
+    else if (meta.built) { t.n = P.nReads; t.alignmentScore = 0; t.properPair = false; leanInit(t.f0, 0); leanInit(t.f1, 1); if (x.n0) leanLoad(t.f0, x.l0[0], x.pool); if (x.n1) leanLoad(t.f1, x.l1[0], x.pool); store = true; }
+#else
     if (meta.built) store = leanBuildTemplate(x, rs, t, overflow) || P.keepUnaligned;
+#endif
     else { t.n = P.nReads; t.alignmentScore = 0; t.properPair = false; leanInit(t.f0, 0); leanInit(t.f1, 1); store = 0 != P.keepUnaligned; }
     if (overflow) return false;
     if (!store) { t.n = P.nReads; t.alignmentScore = 0; t.properPair = false; leanInit(t.f0, 0); leanInit(t.f1, 1); }
     if (u32(t.f0.cigarLength) + 2 > LEAN_OUT_CIGAR_CAP || u32(t.f1.cigarLength) + 2 > LEAN_OUT_CIGAR_CAP) return false;
-    // the CIGARs go to their output slots first; the clippers edit them there
     u32 *cig0 = cigars + (u64(cluster) * P.nReads) * LEAN_OUT_CIGAR_CAP, *cig1 = cig0 + LEAN_OUT_CIGAR_CAP;
-    for (u32 k = 0; k < t.f0.cigarLength; ++k) cig0[k] = t.f0.cigar[k];
-    if (2 == t.n) for (u32 k = 0; k < t.f1.cigarLength; ++k) cig1[k] = t.f1.cigar[k];
+    leanLoadEdges(t.f0); leanLoadEdges(t.f1);
     const u8 *clusterBcl = bcl + u64(cluster) * P.clusterLength;
     ReadView read0, read1;
     read0.bcl = clusterBcl + P.readOffset[0]; read0.length = P.readLength[0]; read0.firstCycle = P.firstCycle[0]; read0.endCyclesMasked = meta.endCyclesMasked[0];
     read1.bcl = clusterBcl + P.readOffset[1]; read1.length = 1 < P.nReads ? P.readLength[1] : 0; read1.firstCycle = P.firstCycle[1]; read1.endCyclesMasked = meta.endCyclesMasked[1];
+    // -DISAAC_TIMING_SELECT_NO_CLIP / _NO_TEMPLATE: builds that leave a section out (wrong results) to time the others
+#if defined(ISAAC_TIMING_SELECT_NO_CLIP)
+    if (store && meta.built && cluster == 0xfffffff0u)
+#else
     if (store && meta.built)
+#endif
     {
         if (P.clipSemialigned)
-        {   // SemialignedEndsClipper::clip (SemialignedEndsClipper.cpp:161-205)
+        {   // SemialignedEndsClipper::clip (SemialignedEndsClipper.cpp:161-205); the four scans' first bytes are asked for before any is looked at
+            LeanEndScans scans0, scans1;
+            if (leanAligned(t.f0)) leanSemialignedAsk(scans0, x, read0, t.f0); else { scans0.left.fetched = scans0.right.fetched = false; scans0.left.seqIdx = scans0.right.seqIdx = -1; scans0.left.refIdx = scans0.right.refIdx = 0; }
+            if (2 == t.n && leanAligned(t.f1)) leanSemialignedAsk(scans1, x, read1, t.f1); else { scans1.left.fetched = scans1.right.fetched = false; scans1.left.seqIdx = scans1.right.seqIdx = -1; scans1.left.refIdx = scans1.right.refIdx = 0; }
             bool stop = false;
             if (leanAligned(t.f0))
             {
-                bool changed = leanSemialignedLeft(x, read0, cig0, t.f0);
-                if (leanSemialignedRight(x, read0, cig0, t.f0)) changed = true;
+                bool changed = leanSemialignedLeft(x, read0, t.f0, scans0.left);
+                if (leanSemialignedRight(x, read0, t.f0, scans0.right)) changed = true;
                 if (changed && 2 == t.n && !leanAligned(t.f1)) { t.f1.position = t.f0.position; stop = true; }
             }
             if (!stop && 2 == t.n && leanAligned(t.f1))
             {
-                bool changed = leanSemialignedLeft(x, read1, cig1, t.f1);
-                if (leanSemialignedRight(x, read1, cig1, t.f1)) changed = true;
+                bool changed = leanSemialignedLeft(x, read1, t.f1, scans1.left);
+                if (leanSemialignedRight(x, read1, t.f1, scans1.right)) changed = true;
                 if (changed && !leanAligned(t.f0)) t.f0.position = t.f1.position;
             }
         }
@@ -831,11 +945,14 @@ ISAAC_HD bool leanSelectCluster(const DevParams &P, const DevReference &R, const
             // left: the end that starts first; when both start together OverlappingEndsClipper.cpp:68-69 makes r2 both left and right
             const bool leftIs0 = t.f0.position < t.f1.position, rightIs0 = !(t.f0.position <= t.f1.position);
             LeanFrag left = leanPick(leftIs0, t.f0, t.f1), right = leanPick(rightIs0, t.f0, t.f1);
-            const u32 changed = leanOverlappingClipOrdered(x, leanPickRead(leftIs0, read0, read1), leanPickRead(rightIs0, read0, read1), left, leftIs0 ? cig0 : cig1, right, rightIs0 ? cig0 : cig1);
+            const u32 changed = leanOverlappingClipOrdered(x, leanPickRead(leftIs0, read0, read1), leanPickRead(rightIs0, read0, read1), left, right);
             if (1 == changed) leanPut(t, rightIs0 ? 0 : 1, right);
             else if (2 == changed) leanPut(t, leftIs0 ? 0 : 1, left);
         }
     }
+    // the CIGARs, clipped, into their output slots (an unaligned end has none)
+    if (leanAligned(t.f0)) t.f0.cigarLength = u16(leanWriteCigar(t.f0, cig0));
+    if (2 == t.n && leanAligned(t.f1)) t.f1.cigarLength = u16(leanWriteCigar(t.f1, cig1));
     mapqNearInteger = x.mapqNearInteger;
     const u32 templateScore = (t.alignmentScore >= 0xffffu ? 0xffffu : t.alignmentScore) << 16;
     const u32 reserved = ((meta.flags & CLUSTER_OVERFLOW) ? u32(RECORD_FRAGMENT_OVERFLOW) : 0u) | (store ? 0u : u32(RECORD_NOT_STORED)) | (x.mapqNearInteger ? u32(RECORD_MAPQ_NEAR_INTEGER) : 0u) | templateScore;
@@ -851,6 +968,12 @@ ISAAC_HD bool leanSelectCluster(const DevParams &P, const DevReference &R, const
         r.cigarOffset = u32((u64(cluster) * 2 + 1) * LEAN_OUT_CIGAR_CAP); r.reserved = reserved;
     }
     return true;
+}
+// the same on the lists where they lie in the chunk's pool
+ISAAC_HD bool leanSelectCluster(const DevParams &P, const DevReference &R, const DevTls &tls, const RogCorrection &rog, double logMismatchQ40, const u8 *bcl, u32 cluster, u32 tile,
+                                const ClusterMeta &meta, const Cand *candPool, const u32 *cigarArena, const LeanRescue &rs, FragmentRecord *records, u32 *cigars, u32 &mapqNearInteger)
+{
+    return leanSelectCluster(P, R, tls, rog, logMismatchQ40, bcl, cluster, tile, meta, candPool + meta.first, candPool + meta.first + meta.second, cigarArena, rs, records, cigars, mapqNearInteger);
 }
 
 } // namespace isaac

@@ -70,6 +70,11 @@ struct DevParams
     u32 maxSeedsPerRead;
 };
 
+// reference::ReferenceKmer<unsigned long> (include/reference/ReferenceKmer.hh:37-54): one entry of the sorted table, one record of a mask file.
+// A probe that finds its k-mer has the position in the same 16 bytes (rounds 1-4 kept two arrays: a hit cost a second cache line and a second round trip)
+struct TableEntry { u64 kmer, position; };
+static_assert(sizeof(TableEntry) == 16, "mask file record");
+
 // reference sequence + sorted k-mer table resident in HBM
 struct DevReference
 {
@@ -78,8 +83,7 @@ struct DevReference
     const u64 *contigOffset;  // n_contigs + 1
     const u8 *contigLoaded;   // MatchSelector.cpp:85-90: contigs without any seed match count as empty
     u32 nContigs;
-    const u64 *kmers;         // sorted 32-mers (all masks concatenated)
-    const u64 *positions;     // ReferencePosition values, parallel to kmers
+    const TableEntry *entries;// the sorted 32-mer table (all masks concatenated): k-mer and ReferencePosition side by side, as the mask files hold them
     u64 nKmers;
     const u32 *karyotype;     // contig id translation of ReferenceKmer::getTranslatedPosition, NULL = identity
     const u32 *prefixTable;   // optional: first table index of every PREFIX_BITS-bit k-mer prefix (+ end sentinel)

@@ -41,7 +41,7 @@ EXPORTS = ["isaac_gpu_last_error", "isaac_gpu_create", "isaac_gpu_destroy", "isa
            "isaac_gpu_save_sorted_reference",
            "isaac_gpu_find_matches", "isaac_gpu_set_loaded_contigs", "isaac_gpu_build_fragments", "isaac_gpu_determine_tls", "isaac_gpu_share_index", "isaac_gpu_select", "isaac_gpu_select_n", "isaac_gpu_select_candidates",
            "isaac_gpu_bsw_batch", "isaac_gpu_compact_cigars", "isaac_gpu_compact_cigars_async",
-           "isaac_gpu_bam_records", "isaac_gpu_bin_tile", "isaac_gpu_bam_last_error", "isaac_gpu_bam_header", "isaac_gpu_bgzf_bound", "isaac_gpu_bgzf_compress", "isaac_gpu_bgzf_store_bound", "isaac_gpu_bgzf_store", "isaac_gpu_bgzf_deflate_bound", "isaac_gpu_bgzf_deflate", "isaac_gpu_bam_index", "isaac_gpu_bam_indexer_create", "isaac_gpu_bam_indexer_add", "isaac_gpu_bam_indexer_add_entries", "isaac_gpu_bam_indexer_finish", "isaac_gpu_bam_indexer_destroy", "isaac_gpu_bam_index_last_error",
+           "isaac_gpu_bam_records", "isaac_gpu_bin_tile", "isaac_gpu_bin_tile_map", "isaac_gpu_bam_last_error", "isaac_gpu_bam_header", "isaac_gpu_bgzf_bound", "isaac_gpu_bgzf_compress", "isaac_gpu_bgzf_store_bound", "isaac_gpu_bgzf_store", "isaac_gpu_bgzf_deflate_bound", "isaac_gpu_bgzf_deflate", "isaac_gpu_bam_index", "isaac_gpu_bam_indexer_create", "isaac_gpu_bam_indexer_add", "isaac_gpu_bam_indexer_add_entries", "isaac_gpu_bam_indexer_finish", "isaac_gpu_bam_indexer_destroy", "isaac_gpu_bam_index_last_error",
            "isaac_gpu_default_params", "isaac_gpu_parse_gap_scoring", "isaac_gpu_parse_seeds", "isaac_gpu_params_last_error",
            "isaac_gpu_fastq_to_bcl", "isaac_gpu_fastq_tile_clusters_max", "isaac_gpu_fastq_tiles", "isaac_gpu_get_counters", "isaac_gpu_kernel_time_ms", "isaac_gpu_reset_timers"]
 
@@ -190,33 +190,32 @@ class Aligner:
         self.cluster_length = params.read_length[0] + params.read_length[1]
 
     def index_tensors(self):
-        """the resident table as two int64 device tensors (k-mers, positions) that alias the library's memory: no copy"""
-        k, p, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
-        self._check(self.lib.isaac_gpu_index_dev(self.h, C.byref(k), C.byref(p), C.byref(n)))
+        """the resident table as an [n, 2] int64 device tensor (k-mer, position per entry: the records of the mask files) that aliases the library's memory: no copy"""
+        k, n = C.c_void_p(), C.c_uint64()
+        self._check(self.lib.isaac_gpu_index_dev(self.h, C.byref(k), C.byref(n)))
 
         owner = self
 
         class _View:                      # __cuda_array_interface__: torch wraps the pointer without copying
             def __init__(self, ptr, count):
-                self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<i8", "data": (ptr, False), "version": 2}
-                self.owner = owner        # the tensors alias the owner's table: they keep it alive (torch keeps the view object referenced)
+                self.__cuda_array_interface__ = {"shape": (count, 2), "typestr": "<i8", "data": (ptr, False), "version": 2}
+                self.owner = owner        # the tensor aliases the owner's table: it keeps it alive (torch keeps the view object referenced)
         if not n.value:
-            e = self.torch.empty(0, dtype=self.torch.int64, device=self.device)
-            return e, e
-        kt, pt = self.torch.as_tensor(_View(k.value, n.value), device=self.device), self.torch.as_tensor(_View(p.value, n.value), device=self.device)
-        kt._isaac_owner = pt._isaac_owner = self      # set_index_tensors registers the borrower with the owner
-        return kt, pt
+            return self.torch.empty((0, 2), dtype=self.torch.int64, device=self.device)
+        entries = self.torch.as_tensor(_View(k.value, n.value), device=self.device)
+        entries._isaac_owner = self      # set_index_tensors registers the borrower with the owner
+        return entries
 
-    def set_index_tensors(self, kmers, positions, mask_offsets=None):
-        """adopts a table held in two int64 device tensors (they are kept referenced); mask_offsets: the cuts of the mask files or None"""
-        assert kmers.dtype == self.torch.int64 and positions.dtype == self.torch.int64 and kmers.numel() == positions.numel()
-        self._borrowed_index = (kmers, positions)
-        owner = getattr(kmers, "_isaac_owner", None)
+    def set_index_tensors(self, entries, mask_offsets=None):
+        """adopts a table held in an [n, 2] int64 device tensor (kept referenced); mask_offsets: the cuts of the mask files or None"""
+        assert entries.dtype == self.torch.int64 and entries.dim() == 2 and entries.shape[1] == 2 and entries.is_contiguous()
+        self._borrowed_index = entries
+        owner = getattr(entries, "_isaac_owner", None)
         if owner is not None and owner is not self:
             owner._borrowers.add(self)                # the owner refuses to rebuild, reload or close its table while a borrower is open
             self._lender = owner
         mo = np.ascontiguousarray(mask_offsets, np.uint64) if mask_offsets is not None else None
-        self._check(self.lib.isaac_gpu_set_index_dev(self.h, _p(kmers), _p(positions), C.c_uint64(kmers.numel()), _p(mo), C.c_uint32(len(mo) - 1 if mo is not None else 0)))
+        self._check(self.lib.isaac_gpu_set_index_dev(self.h, _p(entries), C.c_uint64(entries.shape[0]), _p(mo), C.c_uint32(len(mo) - 1 if mo is not None else 0)))
 
     def set_loaded_contigs(self, loaded):
         loaded = np.ascontiguousarray(loaded, np.uint8) if loaded is not None else None
@@ -345,8 +344,9 @@ class Aligner:
             self._inflight.append((records, cigars, out, n_words_dev))
 
     # ---- output format --------------------------------------------------------------------------------------------
-    def bin_tile(self, bcl, records, cigars, bin_of_contig, n_bins):
-        """isaac_gpu_bin_tile: the output of one select() cut into a compact tile per bin; returns [(bcl, records, cigars)] per bin (device tensors, views of one buffer)"""
+    def bin_tile(self, bcl, records, cigars, bin_of_contig, n_bins, cut_positions=None):
+        """isaac_gpu_bin_tile / isaac_gpu_bin_tile_map (with cut_positions: ascending ReferencePosition values at which a contig goes on into its next bin):
+        the output of one select() cut into a compact tile per bin; returns [(bcl, records, cigars)] per bin (device tensors, views of one buffer)"""
         from . import bam
         torch = self.torch
         n_clusters = bcl.shape[0]
@@ -354,11 +354,18 @@ class Aligner:
         sizes = (bam.BinSize * n_bins)()
         need = C.c_uint64()
         out = torch.empty(max(64, int(1.2 * (bcl.numel() + records.numel() + 8 * records.shape[0])) + 256 * n_bins), dtype=torch.uint8, device=self.device)
-        args = lambda buf: (self.h, _p(bcl), _p(records), _p(cigars), C.c_uint32(n_clusters), _p(boc), C.c_uint32(len(boc)), C.c_uint32(n_bins), _p(buf), C.c_uint64(buf.numel()), sizes, C.byref(need))
-        rc = self.lib.isaac_gpu_bin_tile(*args(out))
+        if cut_positions is None:
+            args = lambda buf: (self.h, _p(bcl), _p(records), _p(cigars), C.c_uint32(n_clusters), _p(boc), C.c_uint32(len(boc)), C.c_uint32(n_bins), _p(buf), C.c_uint64(buf.numel()), sizes, C.byref(need))
+            entry = self.lib.isaac_gpu_bin_tile
+        else:
+            cuts = np.ascontiguousarray(cut_positions, np.uint64)
+            bin_map = bam.BinMap(_p(boc), len(boc), _p(cuts), len(cuts), n_bins)
+            args = lambda buf: (self.h, _p(bcl), _p(records), _p(cigars), C.c_uint32(n_clusters), C.byref(bin_map), _p(buf), C.c_uint64(buf.numel()), sizes, C.byref(need))
+            entry = self.lib.isaac_gpu_bin_tile_map
+        rc = entry(*args(out))
         if rc == 4:
             out = torch.empty(need.value, dtype=torch.uint8, device=self.device)
-            rc = self.lib.isaac_gpu_bin_tile(*args(out))
+            rc = entry(*args(out))
         self._check(rc)
         parts, at = [], 0
         align = lambda v: (v + 63) & ~63
@@ -374,7 +381,7 @@ class Aligner:
         return parts
 
     def bam_records(self, tiles, out=None, read_group=None, barcode=None, forced_dodgy_alignment_score=None, pessimistic_mapq=False, mark_duplicates=False, keep_duplicates=True, realign_gaps=False, tls=None,
-                    bin_contigs=None, bin_unaligned=False):
+                    bin_contigs=None, bin_unaligned=False, bin_positions=None):
         """build::Build's BAM alignment records of one or more tiles, in file order (mark_duplicates / keep_duplicates / realign_gaps: BinSorter's steps before the order).
         tiles: [(bcl, records, cigars, read_name_prefix[, read_group[, tls]])] as given to / returned by select().  Returns (uint8 device tensor of the
         uncompressed records, number of records, offset of the unaligned bin)."""
@@ -398,9 +405,13 @@ class Aligner:
                 arr[i].tls = C.cast(C.pointer(tile[5]), C.c_void_p)
             n_rec += records.shape[0]
         options = None
-        if read_group is not None or barcode is not None or forced_dodgy_alignment_score is not None or pessimistic_mapq or mark_duplicates or not keep_duplicates or realign_gaps or bin_contigs is not None or bin_unaligned:
+        if read_group is not None or barcode is not None or forced_dodgy_alignment_score is not None or pessimistic_mapq or mark_duplicates or not keep_duplicates or realign_gaps or bin_contigs is not None or bin_unaligned or bin_positions is not None:
             options = bam.BamOptions()
-            if bin_contigs is not None or bin_unaligned:      # one bin of the file: contigs [first, end) and / or the templates without a position
+            if bin_positions is not None:                       # one bin of the file: the positions [first, end) as ReferencePosition values
+                options.bin_filter = 2
+                options.bin_first_position, options.bin_end_position = bin_positions
+                options.bin_unaligned = int(bool(bin_unaligned))
+            elif bin_contigs is not None or bin_unaligned:      # one bin of the file: contigs [first, end) and / or the templates without a position
                 options.bin_filter = 1
                 options.bin_first_contig, options.bin_end_contig = bin_contigs if bin_contigs is not None else (0, 0)
                 options.bin_unaligned = int(bool(bin_unaligned))

@@ -55,6 +55,8 @@ std::string AlignOptions::usage()
         "  --device arg (=0)                    HIP device\n"
         "  --devices arg                        HIP devices, comma separated: one worker per entry; the tiles and the bins of the\n"
         "                                       run are dealt out to them (an entry may repeat: two workers on one device)\n"
+        "  --bin-records arg (=0)               records a bin of the BAM stage is sized for (0: 8000000): contigs are grouped into or cut\n"
+        "                                       into bins of about that many, each sorted, filtered and realigned by itself\n"
         "  --use-bases-mask arg (=default)      y*n per read by default (the last cycle is not used); y<N>n<M> and y* forms\n"
         "  --seeds arg (=auto)                  auto | all | offsets 0:32:64[,...]\n"
         "  --first-pass-seeds arg (=1)\n"
@@ -134,6 +136,7 @@ AlignOptions AlignOptions::parse(int argc, char **argv)
     number("lane-number-max", 0, &o.laneNumberMax); number("clusters-at-a-time", 0, &o.clustersAtATime); number("mapq-threshold", 0, &o.mapqThreshold);
     number("base-quality-cutoff", 0, &o.baseQualityCutoff); number("semialigned-gap-limit", 0, &o.semialignedGapLimit); number("gapped-mismatches", 0, &o.gappedMismatches);
     number("realigned-gaps-per-fragment", 0, &o.realignedGapsPerFragment); number("neighborhood-size-threshold", 0, &neighborhoodSizeThreshold);
+    number("bin-records", 0, &o.binRecords);
     integer("shadow-scan-range", &o.shadowScanRange); integer("bam-gzip-level", &o.bamGzipLevel); integer("device", &o.device);
     flag("ignore-neighbors", &o.ignoreNeighbors); flag("per-tile-tls", &o.perTileTls); flag("scatter-repeats", &o.scatterRepeats); flag("clip-semialigned", &o.clipSemialigned);
     flag("clip-overlapping", &o.clipOverlapping); flag("realign-vigorously", &o.realignVigorously); flag("realign-dodgy", &o.realignDodgy); flag("keep-duplicates", &o.keepDuplicates);

@@ -31,6 +31,7 @@ struct AlignOptions
     std::vector<std::string> bamHeaderTags;
     unsigned seedLength = 32, firstPassSeeds = 1, jobs = 0, repeatThreshold = 10, laneNumberMax = 8, clustersAtATime = 0, mapqThreshold = 0, baseQualityCutoff = 25,
              semialignedGapLimit = 100, gappedMismatches = 5, realignedGapsPerFragment = 1;
+    unsigned binRecords = 0;                                // --bin-records: records a bin of the BAM stage is sized for (0: 8 million); this host's stand-in for the reference's bin size from --memory-limit
     int shadowScanRange = -1, bamGzipLevel = 1, device = 0;
     bool ignoreNeighbors = false, perTileTls = false, scatterRepeats = false, clipSemialigned = true, clipOverlapping = true, realignVigorously = false, realignDodgy = false,
          keepDuplicates = true, markDuplicates = true, pessimisticMapQ = false, variableReadLength = false, variableFastqReadLength = false, allowEmptyFlowcells = false;

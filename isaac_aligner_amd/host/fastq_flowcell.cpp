@@ -166,6 +166,9 @@ FastqFileReader::FastqFileReader(const std::string &path, bool compressed) : pat
     if (!file_) throw std::runtime_error("Failed to open file " + path + ": " + std::strerror(errno));
     std::memset(&z_, 0, sizeof(z_));
     if (compressed_) in_.resize(1 << 20);
+    struct stat st;
+    seekable_ = 0 == ::fstat(fileno(file_), &st) && S_ISREG(st.st_mode);
+    if (const char *e = std::getenv("ISAAC_ALIGN_READ_THREADS")) readThreads_ = size_t(std::max(1, std::atoi(e)));
 }
 
 FastqFileReader::~FastqFileReader()
@@ -183,7 +186,18 @@ size_t FastqFileReader::readInto(char *out, size_t want)
         // plain text: a large piece is fetched by a few threads side by side (one thread copies 8 GB/s out of the page cache; the two files of a
         // lane are 660 bytes per pair)
         const int fd = fileno(file_);
-        const size_t threads = want >= (size_t(16) << 20) ? 4 : 1, share = (want + threads - 1) / threads;
+        if (!seekable_)
+        {   // a pipe, a process substitution, /dev/stdin: no positions to read from side by side
+            while (got < want)
+            {
+                const size_t r = std::fread(out + got, 1, want - got, file_);
+                if (!r) { if (std::ferror(file_)) throw std::runtime_error("Failed to read " + path_ + ": " + std::strerror(errno)); break; }
+                got += r;
+            }
+            if (got < want) eof_ = true;
+            return got;
+        }
+        const size_t threads = want >= (size_t(16) << 20) ? readThreads_ : 1, share = (want + threads - 1) / threads;
         std::vector<size_t> gotPart(threads, 0);
         std::vector<int> failed(threads, 0);
         const auto part = [&](size_t t)

@@ -47,7 +47,8 @@ public:
     const std::string &path() const { return path_; }
 private:
     std::string path_;
-    bool compressed_, eof_ = false, streamOpen_ = false;
+    bool compressed_, eof_ = false, streamOpen_ = false, seekable_ = true;   // seekable_: a regular file (read at positions, several threads side by side)
+    size_t readThreads_ = 8;
     uint64_t position_ = 0;                   // of a plain file: where the next piece begins
     std::FILE *file_ = 0;
     z_stream z_;

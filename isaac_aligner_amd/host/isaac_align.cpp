@@ -154,117 +154,182 @@ Reference loadReference(const std::string &xmlPath)
 
 // ---- the data: lanes, loads, tiles -------------------------------------------------------------------------------------------------------
 struct Worker;
+struct Load;
 struct Tile
 {
     unsigned lane = 0, number = 0, index = 0, clusters = 0;     // tile number within the lane (the read name), index over the run (the records)
-    const uint8_t *bcl = 0;                                       // inside its load's buffer, on its worker's device
+    Load *load = 0; uint64_t firstCluster = 0;                    // where its BCL bytes are: cluster firstCluster of its load
     Worker *worker = 0;
     isaac_tls tls;
     std::string namePrefix, readGroup;
 };
 
-// one read of one lane: the file and the text not yet converted
-const size_t TEXT_CHUNK = size_t(64) << 20;
-// where the load phase's time goes (one thread runs it): waiting for text, upload + conversion, first lookup
-double g_textWaitSeconds = 0, g_convertSeconds = 0, g_firstLookupSeconds = 0;
-
-// (A thread per read that fetched the next piece ahead of the conversion was measured and taken out again: 1.76 s against 1.3 s for 6.6 GB of text -- the
-// reader's fresh buffers and the extra copy cost more than the overlap brought; profiles/r4_e_cli_timing.log.)
-struct ReadStream
+// --clusters-at-a-time clusters of one lane as FastqSeedSource loads them: the BCL bytes, on the device of the worker the load was dealt to while that
+// has room, in host memory otherwise (back on the device for the time its tiles are selected); gone once the last of its tiles is binned
+struct Load
 {
-    std::unique_ptr<FastqFileReader> reader;
-    // the text not yet converted, [begin, end) of a page-locked buffer: the file is read into it and the device takes it from there at the link's
-    // rate (a std::vector is cleared before it is read into and uploaded through the runtime's own staging: half of the load phase's time)
-    char *text = 0; size_t capacity = 0, begin = 0, end = 0;
-    uint64_t consumedBytes = 0;                                   // of the uncompressed text, for error messages
-    bool ended = false;                                           // the reader was at the end of its file when last looked at
-    ReadStream() {}
-    ReadStream(const ReadStream &) = delete;
-    ReadStream &operator=(const ReadStream &) = delete;
-    ~ReadStream() { if (text) isaac_gpu_host_free(text); }
-    size_t size() const { return end - begin; }
-    const char *data() const { return text + begin; }
-    void consume(size_t n) { begin += n; if (begin == end) begin = end = 0; }
-    // more text behind what is there, up to `want` bytes in all if the file has them
-    void fill(size_t want)
-    {
-        if (size() >= want || ended) return;
-        if (capacity < want)
-        {
-            void *larger = 0;
-            GPU(isaac_gpu_host_malloc(want, &larger));
-            if (size()) std::memcpy(larger, data(), size());
-            if (text) isaac_gpu_host_free(text);
-            text = static_cast<char *>(larger); capacity = want; end = size(); begin = 0;
-        }
-        else if (begin) { std::memmove(text, text + begin, size()); end = size(); begin = 0; }
-        end += reader->readInto(text + end, want - end);
-        ended = reader->atEnd();
-    }
-    bool atEnd() const { return ended; }
+    Worker *worker = 0;
+    uint32_t clusters = 0; uint64_t bytes = 0;
+    DeviceMemory dev; std::unique_ptr<uint8_t[]> host;
+    std::vector<Tile *> tiles;
+    unsigned tilesLeft = 0;
 };
 
-// io::FastqLoader::loadSingleRead for up to maxClusters clusters: the text goes to the device in pieces, the converter leaves the incomplete
-// record at the end of a piece for the next one
-uint32_t loadRead(isaac_gpu_ctx *ctx, ReadStream &stream, unsigned readIndex, bool allowVariableLength, uint8_t *bclDev, unsigned clusterLength, uint32_t maxClusters, DeviceMemory &textDev)
-{
-    uint32_t clusters = 0;
-    size_t chunk = TEXT_CHUNK;
-    while (clusters < maxClusters)
-    {
-        const double fillStart = seconds();
-        stream.fill(chunk);
-        g_textWaitSeconds += seconds() - fillStart;
-        if (!stream.size()) break;
-        const double convertStart = seconds();
-        const bool final = stream.atEnd();
-        if (textDev.bytes() < stream.size() + 64) textDev.reset(ctx, stream.size() + 64);
-        GPU(isaac_gpu_upload(ctx, textDev.as<char>(), stream.data(), stream.size()));
-        uint32_t n = 0; uint64_t consumed = 0, errorOffset = 0;
-        const int rc = isaac_gpu_fastq_to_bcl(ctx, textDev.as<char>(), stream.size(), readIndex, allowVariableLength, final, bclDev + uint64_t(clusters) * clusterLength,
-                                              maxClusters - clusters, &n, &consumed, &errorOffset);
-        if (rc)
-            throw std::runtime_error(stream.reader->path() + ": " + isaac_gpu_last_error() + " (record " + std::to_string(clusters + n) + " of this load, offset " +
-                                     std::to_string(stream.consumedBytes + errorOffset) + ")");
-        g_convertSeconds += seconds() - convertStart;
-        clusters += n;
-        stream.consumedBytes += consumed;
-        stream.consume(consumed);
-        if (!n && !consumed)
-        {
-            if (final) break;                                     // nothing but line ends left
-            chunk *= 2;                                           // a record longer than the piece
-        }
-    }
-    return clusters;
-}
+const size_t TEXT_CHUNK = size_t(64) << 20;          // text per conversion call
+const size_t TEXT_SLACK = size_t(4) << 20;           // what may be left of a piece when the next one is taken: less than a record, unless records are longer than this
+// where the load phase's time goes, summed over its threads: waiting for text, upload + conversion, first lookup
+std::mutex g_timersLock;
+double g_textWaitSeconds = 0, g_convertSeconds = 0, g_firstLookupSeconds = 0;
+void addTime(double &timer, double seconds) { std::lock_guard<std::mutex> hold(g_timersLock); timer += seconds; }
 
-// ---- the bins: what BinningFragmentStorage keeps in files (lib/alignment/matchSelector/BinningFragmentStorage.cpp) kept in host memory ----------
-// One bin per contig and one for the templates without a position: the bins of the BAM stage (duplicates and realignment never look across
-// contigs).  A tile leaves one part in every bin it has records in (isaac_gpu_bin_tile): BCL bytes, records and CIGAR words of the clusters
-// concerned, about 150 + 2 x read length bytes per read.  That is the run's memory model: HBM holds the table, the BCL bytes of the loads
-// until their tiles are selected, one tile's scratch and -- in the build stage -- one bin at a time.  The bins' parts stay where isaac_gpu_bin_tile
-// wrote them, a block of device memory per tile, for as long as the device has room beside what the build stage will want (a quarter of its
-// memory is left alone); the tiles after that leave their parts in host memory.  A part on the device goes into its bin's BAM stage as it
-// lies there, no copy in either direction: on a 288 GB device that is every run of up to some 250 million pairs.
-struct BinPart { const Tile *tile; uint64_t clusters, words, bytes; std::unique_ptr<uint8_t[]> data; std::shared_ptr<DeviceMemory> block; uint64_t offset = 0; int device = -1; };
-struct Bin { std::mutex lock; std::vector<BinPart> parts; uint64_t bytes = 0, records = 0; };
+// One read of one lane: the file's text in pieces of TEXT_CHUNK bytes, each in a page-locked buffer of its own, read ahead of the conversion by a
+// thread of the stream's (the file is read while the device converts the piece before: round 4 read and converted in turn).  The incomplete record a
+// conversion leaves at the end of a piece is moved in front of the next piece -- a few hundred bytes, the only copy the text sees on the host.
+class TextStream
+{
+public:
+    TextStream(const std::string &path, bool compressed) : reader_(path, compressed)
+    {
+        for (Slot &s : slots_) { void *p = 0; GPU(isaac_gpu_host_malloc(TEXT_SLACK + TEXT_CHUNK, &p)); s.base = static_cast<char *>(p); }
+        thread_ = std::thread([this] { readAhead(); });
+    }
+    ~TextStream()
+    {
+        { std::lock_guard<std::mutex> hold(lock_); stop_ = true; }
+        change_.notify_all();
+        if (thread_.joinable()) thread_.join();
+        for (Slot &s : slots_) if (s.base) isaac_gpu_host_free(s.base);
+    }
+    TextStream(const TextStream &) = delete;
+    TextStream &operator=(const TextStream &) = delete;
+    const std::string &path() const { return reader_.path(); }
+    uint64_t consumedBytes = 0;                                   // of the uncompressed text, for error messages
+    // the text at hand: [data(), data() + size()); final(): the file ends with it
+    const char *data() { acquire(); return slots_[current_].base + slots_[current_].begin; }
+    size_t size() { acquire(); return slots_[current_].end - slots_[current_].begin; }
+    bool final() { acquire(); return slots_[current_].last; }
+    void consume(size_t n) { slots_[current_].begin += n; consumedBytes += n; }
+    // what is left of this piece goes in front of the next one, which becomes the text at hand
+    void advance()
+    {
+        acquire();
+        Slot &from = slots_[current_];
+        if (from.last) return;
+        const size_t tail = from.end - from.begin;
+        if (tail > TEXT_SLACK) throw std::runtime_error(reader_.path() + ": a record of more than " + std::to_string(TEXT_SLACK) + " bytes");
+        const size_t next = (current_ + 1) % SLOTS;
+        wait(next);
+        Slot &to = slots_[next];
+        if (tail) std::memcpy(to.base + to.begin - tail, from.base + from.begin, tail);
+        to.begin -= tail;
+        { std::lock_guard<std::mutex> hold(lock_); from.ready = false; }
+        change_.notify_all();
+        current_ = next;
+    }
+private:
+    static const size_t SLOTS = 3;
+    struct Slot { char *base = 0; size_t begin = 0, end = 0; bool last = false, ready = false; };
+    void wait(size_t k)
+    {
+        const double start = seconds();
+        std::unique_lock<std::mutex> hold(lock_);
+        change_.wait(hold, [&] { return slots_[k].ready || !error_.empty(); });
+        if (!slots_[k].ready) throw std::runtime_error(error_);
+        hold.unlock();
+        addTime(g_textWaitSeconds, seconds() - start);
+    }
+    void acquire() { if (!acquired_) { wait(0); acquired_ = true; } }
+    void readAhead()
+    {
+        try
+        {
+            for (size_t k = 0; ; k = (k + 1) % SLOTS)
+            {
+                {
+                    std::unique_lock<std::mutex> hold(lock_);
+                    change_.wait(hold, [&] { return !slots_[k].ready || stop_; });
+                    if (stop_) return;
+                }
+                Slot &s = slots_[k];
+                const size_t got = reader_.readInto(s.base + TEXT_SLACK, TEXT_CHUNK);
+                const bool last = reader_.atEnd();
+                { std::lock_guard<std::mutex> hold(lock_); s.begin = TEXT_SLACK; s.end = TEXT_SLACK + got; s.last = last; s.ready = true; }
+                change_.notify_all();
+                if (last) return;
+            }
+        }
+        catch (const std::exception &e) { { std::lock_guard<std::mutex> hold(lock_); error_ = e.what(); } change_.notify_all(); }
+    }
+    FastqFileReader reader_;
+    Slot slots_[SLOTS];
+    size_t current_ = 0; bool acquired_ = false, stop_ = false;
+    std::mutex lock_; std::condition_variable change_; std::thread thread_; std::string error_;
+};
+
+// ---- the bins: what BinningFragmentStorage keeps in files (lib/alignment/matchSelector/BinningFragmentStorage.cpp) kept in memory ----------
+// The bins of the BAM stage, in file order: a run of small contigs, a contig, or a stretch of a contig too large for one bin (the reference cuts its
+// contigs into bins by the match distribution, include/alignment/matchSelector/BinIndexMap.hh:44-104; here by the reads expected per base), and one
+// for the templates without a position.  Every bin is sorted, filtered for duplicates and realigned by itself (lib/build/BinSorter.cpp).  A tile
+// leaves one part in every bin it has records in (isaac_gpu_bin_tile_map): BCL bytes, records and CIGAR words of the clusters concerned, about
+// 150 + 2 x read length bytes per read.  That is the run's memory model: HBM holds the table, the BCL bytes of the loads until their tiles are
+// selected (host memory beyond what fits), one tile's scratch and -- in the build stage -- one bin at a time.  The bins' parts stay where
+// isaac_gpu_bin_tile_map wrote them, a block of device memory per tile, for as long as the device has room beside what the build stage will want (a
+// quarter of its memory is left alone); the tiles after that leave their parts in host memory.  A part on the device goes into its bin's BAM
+// stage as it lies there, no copy in either direction.
+struct BinPart { const Tile *tile; uint64_t clusters, words, bytes; std::unique_ptr<uint8_t[]> data; std::shared_ptr<DeviceMemory> block; uint64_t offset = 0; int place = -1 /* the worker whose device holds it */; };
+struct Bin { std::mutex lock; std::vector<BinPart> parts; uint64_t bytes = 0, records = 0; uint64_t firstPosition = 0, endPosition = 0; /* ReferencePosition values */ bool unaligned = false; };
 
 uint64_t align64(uint64_t v) { return (v + 63) & ~uint64_t(63); }
+uint64_t referencePosition(uint64_t contig, uint64_t position) { return (((contig + 1) << 40) | position) << 1; }       // reference::ReferencePosition::getValue()
+
+// contigs of `lengths` (in the order of their ids) into bins of about binBases bases: binOfContig, the cuts inside contigs, and every bin's range
+struct BinPlan { std::vector<uint32_t> binOfContig; std::vector<uint64_t> cuts; std::vector<std::pair<uint64_t, uint64_t> > ranges; };
+BinPlan planBins(const std::vector<uint64_t> &lengths, uint64_t binBases)
+{
+    BinPlan plan;
+    const uint64_t GRAIN = 2048;                                  // MatchDistribution::getBinSize: where the reference's bins can begin
+    binBases = std::max<uint64_t>(GRAIN, (binBases + GRAIN - 1) / GRAIN * GRAIN);
+    uint64_t open = 0;                                            // bases in the bin that is being filled with whole contigs
+    for (uint32_t c = 0; c < lengths.size(); ++c)
+    {
+        const uint64_t length = lengths[c];
+        if (length > binBases + binBases / 2)
+        {   // a contig of several bins: equal stretches that begin on the grain
+            const uint64_t pieces = (length + binBases - 1) / binBases;
+            const uint64_t stretch = ((length + pieces - 1) / pieces + GRAIN - 1) / GRAIN * GRAIN;
+            plan.binOfContig.push_back(uint32_t(plan.ranges.size()));
+            for (uint64_t at = 0; at < length; at += stretch)
+            {
+                if (at) plan.cuts.push_back(referencePosition(c, at));
+                plan.ranges.emplace_back(referencePosition(c, at), at + stretch < length ? referencePosition(c, at + stretch) : referencePosition(c + 1, 0));
+            }
+            open = 0;
+            continue;
+        }
+        if (!open || open + length > binBases) { plan.ranges.emplace_back(referencePosition(c, 0), referencePosition(c + 1, 0)); open = 0; }
+        else plan.ranges.back().second = referencePosition(c + 1, 0);
+        plan.binOfContig.push_back(uint32_t(plan.ranges.size() - 1));
+        open += std::max<uint64_t>(length, 1);
+    }
+    return plan;
+}
 
 // a device and what runs on it
 struct Worker
 {
     int device = 0; unsigned id = 0;
+    int place = 0;                                  // which device's memory the worker's blocks are in, as the host sees it: the device, unless a test makes the workers of one device strangers
     isaac_gpu_ctx *ctx = 0;
-    std::vector<DeviceMemory> loads;                // the BCL bytes of the loads dealt to this worker
+    std::mutex ctxLock;                             // load phase: the lanes' threads take turns on the context
     std::vector<Tile *> tiles;
     DeviceMemory matches, offsets, textDev;
     uint64_t matchCapacity = 0;
+    std::vector<uint8_t> contigHasMatches;
     isaac_counters counters;
-    uint64_t tilesKeptOnDevice = 0;
+    uint64_t tilesKeptOnDevice = 0, loadsKeptOnDevice = 0, peakDeviceBytes = 0;
     double selectSeconds = 0, buildSeconds = 0, uploadSeconds = 0, recordsSeconds = 0, deflateSeconds = 0, downloadSeconds = 0;
-    ~Worker() { loads.clear(); matches.release(); offsets.release(); textDev.release(); if (ctx) isaac_gpu_destroy(ctx); }
+    ~Worker() { matches.release(); offsets.release(); textDev.release(); if (ctx) isaac_gpu_destroy(ctx); }
+    void noteMemory() { uint64_t f = 0, t = 0; if (!isaac_gpu_memory_info(ctx, &f, &t)) peakDeviceBytes = std::max(peakDeviceBytes, t - f); }
 };
 
 // what a bin of the file becomes: its BGZF blocks, and what the index wants to know about its records (buffers that are not cleared first:
@@ -273,6 +338,14 @@ struct BinOutput
 {
     bool ready = false; std::unique_ptr<uint8_t[]> bgzf; std::unique_ptr<isaac_bam_index_entry[]> entries; uint64_t bgzfBytes = 0, recordsBytes = 0, nRecords = 0; std::string error;
 };
+
+uint64_t hostResidentBytes()
+{   // VmHWM: the process's peak resident set
+    std::ifstream status("/proc/self/status");
+    std::string line;
+    while (std::getline(status, line)) if (0 == line.compare(0, 6, "VmHWM:")) return uint64_t(std::strtoull(line.c_str() + 6, 0, 10)) * 1024;
+    return 0;
+}
 
 int run(const AlignOptions &o)
 {
@@ -298,6 +371,9 @@ int run(const AlignOptions &o)
     // ---- the workers and the reference: the first context of a device loads the table, the others of that device share it; another device
     // gets a copy over the link between the two (isaac_gpu_copy)
     const std::vector<int> devices = o.deviceList();
+    // ISAAC_ALIGN_STRANGERS (tests on a box with one device): the workers of one device treat each other's memory as another device's -- the table is
+    // copied, a bin's parts on the other worker's blocks are fetched -- which is every line two devices run
+    const bool strangers = 0 != std::getenv("ISAAC_ALIGN_STRANGERS");
     std::vector<std::unique_ptr<Worker> > workers;
     Reference reference;
     double fastaSeconds = 0, contigSeconds = 0, tableSeconds = 0;
@@ -309,113 +385,214 @@ int run(const AlignOptions &o)
         {
             workers.emplace_back(new Worker);
             Worker &w = *workers.back();
-            w.device = devices[k]; w.id = unsigned(k);
+            w.device = devices[k]; w.id = unsigned(k); w.place = strangers ? int(1000 + k) : devices[k];
             GPU(isaac_gpu_create(w.device, &params, ISAAC_GPU_STREAM_OWN, &w.ctx));
             const double contigStart = seconds();
             GPU(isaac_gpu_load_contigs(w.ctx, reference.bases.get(), reference.offsets.data(), uint32_t(reference.contigs.size())));
             contigSeconds += seconds() - contigStart;
             if (0 == k) { const double tableStart = seconds(); GPU(isaac_gpu_load_sorted_reference(w.ctx, o.referenceGenome.c_str())); tableSeconds = seconds() - tableStart; continue; }
             // the first worker of a device that is not the first worker's gets a copy of the table, everybody else reads one that is there
-            Worker *sameDevice = 0;
-            for (size_t j = 0; j < k && !sameDevice; ++j) if (workers[j]->device == w.device) sameDevice = workers[j].get();
-            GPU(isaac_gpu_share_index(w.ctx, sameDevice ? sameDevice->ctx : workers[0]->ctx));
+            Worker *samePlace = 0;
+            for (size_t j = 0; j < k && !samePlace; ++j) if (workers[j]->place == w.place) samePlace = workers[j].get();
+            GPU(isaac_gpu_share_index(w.ctx, samePlace ? samePlace->ctx : workers[0]->ctx));
         }
         reference.bases.reset();
     }
     const uint32_t nContigs = uint32_t(reference.contigs.size());
-    if (nContigs + 1 > 255) throw std::runtime_error("this host keeps one bin per contig: at most 254 contigs");
     const double referenceSeconds = seconds() - runStart;
 
-    // ---- FastqSeedSource: loads of --clusters-at-a-time clusters, tiles of at most tileClustersMax; the loads are dealt to the workers in turn
+    // ---- FastqSeedSource: loads of --clusters-at-a-time clusters, tiles of at most tileClustersMax.  The lanes are read side by side (a thread each, up
+    // to the number of workers + 1 at a time), every load of a lane is dealt to the next worker in turn; a lane's tiles keep the order of the file.
     const uint32_t tileClustersMax = isaac_gpu_fastq_tile_clusters_max(o.clustersAtATime, params.n_seeds);
     const uint32_t loadClusters = o.clustersAtATime ? o.clustersAtATime : 4 * tileClustersMax;      // a multiple of the tile size: the tiles come out the same for any such load
-    std::deque<Tile> tiles;
-    std::vector<uint8_t> contigHasMatches(nContigs, 0);
-    auto findMatches = [&](Worker &w, const Tile &t, uint64_t &nMatches, uint8_t *hits)
+    auto findMatches = [&](Worker &w, const uint8_t *bcl, uint32_t clusters, uint32_t tileIndex, uint64_t &nMatches, uint8_t *hits)
     {
-        const uint64_t worst = uint64_t(t.clusters) * 2 * params.n_seeds * std::max(1u, params.repeat_threshold - 1);
+        const uint64_t worst = uint64_t(clusters) * 2 * params.n_seeds * std::max(1u, params.repeat_threshold - 1);
         if (!w.offsets.bytes()) w.offsets.reset(w.ctx, (uint64_t(tileClustersMax) + 1) * 8);
         if (!w.matchCapacity) { w.matchCapacity = std::max<uint64_t>(1024, std::min<uint64_t>(worst, uint64_t(tileClustersMax) * 24)); w.matches.reset(w.ctx, w.matchCapacity * sizeof(isaac_match)); }
         for (;;)
         {
-            const int rc = isaac_gpu_find_matches(w.ctx, t.bcl, t.clusters, t.index, w.matches.as<isaac_match>(), w.matchCapacity, w.offsets.as<uint64_t>(), &nMatches, hits);
+            const int rc = isaac_gpu_find_matches(w.ctx, bcl, clusters, tileIndex, w.matches.as<isaac_match>(), w.matchCapacity, w.offsets.as<uint64_t>(), &nMatches, hits);
             if (ISAAC_GPU_ECAPACITY != rc) { check(rc, "isaac_gpu_find_matches"); return; }
             w.matchCapacity = std::max(nMatches, 2 * w.matchCapacity);
             w.matches.reset(w.ctx, w.matchCapacity * sizeof(isaac_match));
         }
     };
+    // the BCL bytes of a load stay on the device while it keeps this much free for the selection's scratch and the bins (ISAAC_ALIGN_HOST_LOADS: tests)
+    const bool hostLoads = 0 != std::getenv("ISAAC_ALIGN_HOST_LOADS");
+    auto keepOnDevice = [&](Worker &w, uint64_t bytes)
+    {
+        if (hostLoads) return false;
+        uint64_t freeBytes = 0, totalBytes = 0;
+        GPU(isaac_gpu_memory_info(w.ctx, &freeBytes, &totalBytes));
+        return freeBytes > totalBytes * 2 / 5 + bytes;
+    };
+    // io::FastqLoader::loadSingleRead for up to maxClusters clusters: the text goes to the device in pieces, the converter leaves the incomplete
+    // record at the end of a piece for the next one
+    auto loadRead = [&](Worker &w, TextStream &stream, unsigned readIndex, uint8_t *bclDev, uint32_t maxClusters) -> uint32_t
+    {
+        const bool allowVariableLength = o.variableReadLength || o.variableFastqReadLength;
+        uint32_t clusters = 0;
+        while (clusters < maxClusters)
+        {
+            if (stream.size() < TEXT_SLACK && !stream.final()) stream.advance();
+            if (!stream.size()) break;
+            const bool final = stream.final();
+            const double convertStart = seconds();
+            uint32_t n = 0; uint64_t consumed = 0, errorOffset = 0;
+            int rc;
+            {
+                std::lock_guard<std::mutex> turn(w.ctxLock);
+                if (w.textDev.bytes() < stream.size() + 64) w.textDev.reset(w.ctx, TEXT_SLACK + TEXT_CHUNK + 64);
+                GPU(isaac_gpu_upload(w.ctx, w.textDev.as<char>(), stream.data(), stream.size()));
+                rc = isaac_gpu_fastq_to_bcl(w.ctx, w.textDev.as<char>(), stream.size(), readIndex, allowVariableLength, final, bclDev + uint64_t(clusters) * clusterLength,
+                                            maxClusters - clusters, &n, &consumed, &errorOffset);
+                if (rc)
+                    throw std::runtime_error(stream.path() + ": " + isaac_gpu_last_error() + " (record " + std::to_string(clusters + n) + " of this load, offset " +
+                                             std::to_string(stream.consumedBytes + errorOffset) + ")");
+            }
+            addTime(g_convertSeconds, seconds() - convertStart);
+            clusters += n;
+            stream.consume(consumed);
+            if (!n && !consumed)
+            {
+                if (final) break;                                     // nothing but line ends left
+                if (stream.size() >= TEXT_SLACK) throw std::runtime_error(stream.path() + ": a record of more than " + std::to_string(TEXT_SLACK) + " bytes");
+            }
+        }
+        return clusters;
+    };
+    struct Lane { const FastqFlowcell *flowcell; const FastqLane *lane; std::string readGroup; std::deque<Tile> tiles; std::deque<Load> loads; std::string error; };
+    std::deque<Lane> lanes;
+    for (const FastqFlowcell &fc : flowcells)
+        for (const FastqLane &lane : fc.lanes) { lanes.emplace_back(); lanes.back().flowcell = &fc; lanes.back().lane = &lane; lanes.back().readGroup = std::to_string(lanes.size() - 1); }   // one 'none' barcode per lane, numbered in the order of the lanes
+    for (auto &w : workers) w->contigHasMatches.assign(nContigs, 0);
     uint64_t totalClusters = 0;
     const double loadStart = seconds();
     {
         Stage stage("loading base calls and finding matches");
-        unsigned barcodeIndex = 0;
-        size_t nextWorker = 0;
-        for (const FastqFlowcell &fc : flowcells)
-            for (const FastqLane &lane : fc.lanes)
+        std::atomic<size_t> nextLane(0), nextWorker(0);
+        auto readLanes = [&]()
+        {
+            for (size_t k = nextLane++; k < lanes.size(); k = nextLane++)
             {
-                ReadStream streams[2];
-                for (unsigned r = 0; r < nReads; ++r)
+                Lane &L = lanes[k];
+                try
                 {
-                    if (lane.readPath[r].empty()) throw std::runtime_error("lane " + std::to_string(lane.lane) + " of " + fc.baseCallsDirectory + " has no read " + std::to_string(r + 1));
-                    streams[r].reader.reset(new FastqFileReader(lane.readPath[r], fc.compressed));
-                }
-                const std::string readGroup = std::to_string(barcodeIndex++);         // one 'none' barcode per lane, numbered in the order of the lanes
-                uint32_t nextTile = 1;
-                for (;;)
-                {
-                    Worker &w = *workers[nextWorker % workers.size()];
-                    DeviceMemory bcl(w.ctx, uint64_t(loadClusters) * clusterLength + 64);
-                    uint32_t loaded[2] = { 0, 0 };
+                    const FastqFlowcell &fc = *L.flowcell; const FastqLane &lane = *L.lane;
+                    std::unique_ptr<TextStream> streams[2];
                     for (unsigned r = 0; r < nReads; ++r)
-                        loaded[r] = loadRead(w.ctx, streams[r], r, o.variableReadLength || o.variableFastqReadLength, bcl.as<uint8_t>(), clusterLength, loadClusters, w.textDev);
-                    if (2 == nReads && loaded[0] != loaded[1])
-                        throw std::runtime_error("Mismatching number of clusters in " + lane.readPath[0] + " (" + std::to_string(loaded[0]) + ") and " + lane.readPath[1] + " (" + std::to_string(loaded[1]) + ")");
-                    if (!loaded[0]) break;
-                    if (loaded[0] < loadClusters / 2)
-                    {   // "allocated too much memory for bcl data": the load keeps what it uses
-                        DeviceMemory exact(w.ctx, uint64_t(loaded[0]) * clusterLength + 64);
-                        GPU(isaac_gpu_copy(w.ctx, exact.as<uint8_t>(), bcl.as<uint8_t>(), uint64_t(loaded[0]) * clusterLength));
-                        GPU(isaac_gpu_synchronize(w.ctx));
-                        bcl = std::move(exact);
-                    }
-                    uint32_t nTiles = 0, next = 0;
-                    isaac_gpu_fastq_tiles(loaded[0], o.clustersAtATime, params.n_seeds, nextTile, 0, 0, 0, &nTiles, &next);
-                    std::vector<uint32_t> numbers(nTiles), sizes(nTiles);
-                    GPU(isaac_gpu_fastq_tiles(loaded[0], o.clustersAtATime, params.n_seeds, nextTile, numbers.data(), sizes.data(), nTiles, &nTiles, &next));
-                    nextTile = next;
-                    uint64_t first = 0;
-                    for (uint32_t k = 0; k < nTiles; ++k)
                     {
-                        tiles.emplace_back();
-                        Tile &t = tiles.back();
-                        t.lane = lane.lane; t.number = numbers[k]; t.index = unsigned(tiles.size() - 1); t.clusters = sizes[k]; t.bcl = bcl.as<uint8_t>() + first * clusterLength; t.worker = &w;
-                        t.namePrefix = fc.flowcellId + ":" + std::to_string(lane.lane) + ":" + std::to_string(t.number) + ":"; t.readGroup = readGroup;
-                        std::memset(&t.tls, 0, sizeof(t.tls));
-                        first += sizes[k];
-                        uint64_t nMatches = 0;
-                        const double lookupStart = seconds();
-                        findMatches(w, t, nMatches, contigHasMatches.data());
-                        g_firstLookupSeconds += seconds() - lookupStart;
-                        w.tiles.push_back(&t);
+                        if (lane.readPath[r].empty()) throw std::runtime_error("lane " + std::to_string(lane.lane) + " of " + fc.baseCallsDirectory + " has no read " + std::to_string(r + 1));
+                        streams[r].reset(new TextStream(lane.readPath[r], fc.compressed));
                     }
-                    totalClusters += loaded[0];
-                    w.loads.push_back(std::move(bcl));
-                    ++nextWorker;
-                    if (loaded[0] < loadClusters) break;
+                    uint32_t nextTile = 1;
+                    for (;;)
+                    {
+                        Worker &w = *workers[nextWorker++ % workers.size()];
+                        DeviceMemory bcl;
+                        { std::lock_guard<std::mutex> turn(w.ctxLock); bcl.reset(w.ctx, uint64_t(loadClusters) * clusterLength + 64); }
+                        uint32_t loaded[2] = { 0, 0 };
+                        for (unsigned r = 0; r < nReads; ++r) loaded[r] = loadRead(w, *streams[r], r, bcl.as<uint8_t>(), loadClusters);
+                        if (2 == nReads && loaded[0] != loaded[1])
+                            throw std::runtime_error("Mismatching number of clusters in " + lane.readPath[0] + " (" + std::to_string(loaded[0]) + ") and " + lane.readPath[1] + " (" + std::to_string(loaded[1]) + ")");
+                        if (!loaded[0]) break;
+                        std::lock_guard<std::mutex> turn(w.ctxLock);
+                        const uint64_t bytes = uint64_t(loaded[0]) * clusterLength;
+                        // the lookup that says which contigs have matches (the matches themselves are found again when the tile is selected)
+                        uint32_t nTiles = 0, next = 0;
+                        isaac_gpu_fastq_tiles(loaded[0], o.clustersAtATime, params.n_seeds, nextTile, 0, 0, 0, &nTiles, &next);
+                        std::vector<uint32_t> numbers(nTiles), sizes(nTiles);
+                        GPU(isaac_gpu_fastq_tiles(loaded[0], o.clustersAtATime, params.n_seeds, nextTile, numbers.data(), sizes.data(), nTiles, &nTiles, &next));
+                        nextTile = next;
+                        L.loads.emplace_back();
+                        Load &load = L.loads.back();
+                        load.worker = &w; load.clusters = loaded[0]; load.bytes = bytes;
+                        uint64_t first = 0;
+                        for (uint32_t i = 0; i < nTiles; ++i)
+                        {
+                            L.tiles.emplace_back();
+                            Tile &t = L.tiles.back();
+                            t.lane = lane.lane; t.number = numbers[i]; t.clusters = sizes[i]; t.load = &load; t.firstCluster = first; t.worker = &w;
+                            t.namePrefix = fc.flowcellId + ":" + std::to_string(lane.lane) + ":" + std::to_string(t.number) + ":"; t.readGroup = L.readGroup;
+                            std::memset(&t.tls, 0, sizeof(t.tls));
+                            uint64_t nMatches = 0;
+                            const double lookupStart = seconds();
+                            findMatches(w, bcl.as<uint8_t>() + first * clusterLength, t.clusters, 0, nMatches, w.contigHasMatches.data());
+                            addTime(g_firstLookupSeconds, seconds() - lookupStart);
+                            first += sizes[i];
+                            load.tiles.push_back(&t);
+                        }
+                        load.tilesLeft = unsigned(load.tiles.size());
+                        // where the load waits for the selection: the device while it has room, else host memory; and only the bytes it has
+                        if (keepOnDevice(w, bytes))
+                        {
+                            if (loaded[0] < loadClusters / 2)
+                            {   // "allocated too much memory for bcl data": the load keeps what it uses
+                                DeviceMemory exact(w.ctx, bytes + 64);
+                                GPU(isaac_gpu_copy(w.ctx, exact.as<uint8_t>(), bcl.as<uint8_t>(), bytes));
+                                GPU(isaac_gpu_synchronize(w.ctx));
+                                bcl = std::move(exact);
+                            }
+                            load.dev = std::move(bcl);
+                            ++w.loadsKeptOnDevice;
+                        }
+                        else
+                        {
+                            load.host.reset(new uint8_t[bytes]);
+                            GPU(isaac_gpu_download(w.ctx, load.host.get(), bcl.as<uint8_t>(), bytes));
+                            bcl.release();
+                        }
+                        w.noteMemory();
+                        if (loaded[0] < loadClusters) break;
+                    }
                 }
+                catch (const std::exception &e) { L.error = e.what(); }
             }
+        };
+        std::vector<std::thread> threads;
+        for (size_t k = 1; k < std::min(lanes.size(), workers.size() + 1); ++k) threads.emplace_back(readLanes);
+        readLanes();
+        for (std::thread &t : threads) t.join();
+        for (const Lane &L : lanes) if (!L.error.empty()) throw std::runtime_error(L.error);
         for (auto &w : workers) w->textDev.release();
-        std::cerr << "isaac-align: " << totalClusters << " clusters in " << tiles.size() << " tile(s) on " << workers.size() << " worker(s)" << std::endl;
-        if (tiles.empty()) throw InvalidOption("No data found to process. Please check your --base-calls.");
     }
+    // the tiles of the run in the order of the lanes and of their files: that is their index (FragmentHeader::tile_)
+    std::vector<Tile *> tiles;
+    for (Lane &L : lanes) for (Tile &t : L.tiles) { t.index = unsigned(tiles.size()); tiles.push_back(&t); t.worker->tiles.push_back(&t); totalClusters += t.clusters; }
+    std::cerr << "isaac-align: " << totalClusters << " clusters in " << tiles.size() << " tile(s) on " << workers.size() << " worker(s)" << std::endl;
+    if (tiles.empty()) throw InvalidOption("No data found to process. Please check your --base-calls.");
+    std::vector<uint8_t> contigHasMatches(nContigs, 0);
+    for (auto &w : workers) for (uint32_t c = 0; c < nContigs; ++c) contigHasMatches[c] |= w->contigHasMatches[c];
     const double loadSeconds = seconds() - loadStart;
 
+    // ---- the bins (see BinPart): sized for --bin-records records each, by the reads the run has per base of the reference
+    std::vector<uint64_t> contigLengths;
+    for (const isaac_reference_contig &c : reference.contigs) contigLengths.push_back(c.total_bases);
+    const uint64_t binRecords = o.binRecords ? o.binRecords : 8000000;
+    const double recordsPerBase = double(totalClusters) * nReads / double(std::max<uint64_t>(1, reference.totalBases));
+    const BinPlan plan = planBins(contigLengths, uint64_t(std::min(1e15, double(binRecords) / std::max(recordsPerBase, 1e-9))));
+    const uint32_t nBins = uint32_t(plan.ranges.size()) + 1;
+    if (nBins > 65535) throw std::runtime_error("more than 65534 bins: a larger --bin-records is needed");
+    std::vector<Bin> bins(nBins);
+    for (uint32_t b = 0; b + 1 < nBins; ++b) { bins[b].firstPosition = plan.ranges[b].first; bins[b].endPosition = plan.ranges[b].second; }
+    bins[nBins - 1].unaligned = true;
+    isaac_bin_map binMap; binMap.bin_of_contig = plan.binOfContig.data(); binMap.n_contigs = nContigs; binMap.cut_positions = plan.cuts.data(); binMap.n_cuts = uint32_t(plan.cuts.size()); binMap.n_bins = nBins;
+    std::cerr << "isaac-align: " << nBins - 1 << " bin(s) of about " << binRecords << " records for " << nContigs << " contig(s), " << plan.cuts.size() << " cut(s) inside contigs" << std::endl;
+
+    // a load's BCL bytes on its worker's device (where they may have been all along)
+    auto loadOnDevice = [&](Load &load) -> const uint8_t *
+    {
+        if (!load.dev.bytes())
+        {
+            load.dev.reset(load.worker->ctx, load.bytes + 64);
+            GPU(isaac_gpu_upload(load.worker->ctx, load.dev.as<uint8_t>(), load.host.get(), load.bytes));
+        }
+        return load.dev.as<uint8_t>();
+    };
     // ---- SelectMatchesTransition: every tile with the contigs the whole run has matches on.  The template length statistics of a lane are
     // learnt tile by tile until a tile gives stable ones, which then serve the rest of the lane (MatchSelector.cpp:395-412): settled first, in tile
     // order, so that the workers can take their tiles in any order afterwards.
-    std::vector<Bin> bins(nContigs + 1);
-    std::vector<uint32_t> binOfContig(nContigs);
-    for (uint32_t c = 0; c < nContigs; ++c) binOfContig[c] = c;
     const double selectStart = seconds();
     {
         Stage stage("selecting matches");
@@ -423,14 +600,18 @@ int run(const AlignOptions &o)
         {
             isaac_tls tls; std::memset(&tls, 0, sizeof(tls));
             std::string laneKey;
-            for (Tile &t : tiles)
+            for (Tile *tp : tiles)
             {
+                Tile &t = *tp;
                 if (laneKey != t.readGroup) { std::memset(&tls, 0, sizeof(tls)); laneKey = t.readGroup; }       // barcodeTemplateLengthStatistics: one per barcode
                 if (!tls.stable || o.perTileTls)
                 {
                     uint64_t nMatches = 0;
-                    findMatches(*t.worker, t, nMatches, 0);
-                    GPU(isaac_gpu_determine_tls(t.worker->ctx, t.bcl, t.clusters, t.index, t.worker->matches.as<isaac_match>(), t.worker->offsets.as<uint64_t>(), &tls));
+                    const bool wasOnDevice = 0 != t.load->dev.bytes();
+                    const uint8_t *bcl = loadOnDevice(*t.load) + t.firstCluster * clusterLength;
+                    findMatches(*t.worker, bcl, t.clusters, t.index, nMatches, 0);
+                    GPU(isaac_gpu_determine_tls(t.worker->ctx, bcl, t.clusters, t.index, t.worker->matches.as<isaac_match>(), t.worker->offsets.as<uint64_t>(), &tls));
+                    if (!wasOnDevice) t.load->dev.release();
                     std::cerr << "isaac-align: template length statistics of tile " << t.namePrefix << " min " << tls.min << " median " << tls.median << " max " << tls.max
                               << (tls.stable ? " (stable)" : " (unstable)") << std::endl;
                 }
@@ -445,14 +626,15 @@ int run(const AlignOptions &o)
             {
                 const double start = seconds();
                 DeviceMemory slots(w.ctx, uint64_t(tileClustersMax) * nReads * ISAAC_GPU_MAX_CIGAR_OPS * 4), records(w.ctx, uint64_t(tileClustersMax) * nReads * sizeof(isaac_fragment)), packed, binned;
-                std::vector<isaac_bin_size> sizes(nContigs + 1);
+                std::vector<isaac_bin_size> sizes(nBins);
                 for (Tile *tp : w.tiles)
                 {
                     Tile &t = *tp;
+                    const uint8_t *bcl = loadOnDevice(*t.load) + t.firstCluster * clusterLength;
                     uint64_t nMatches = 0;
-                    findMatches(w, t, nMatches, 0);
+                    findMatches(w, bcl, t.clusters, t.index, nMatches, 0);
                     const uint64_t nRecords = uint64_t(t.clusters) * nReads;
-                    GPU(isaac_gpu_select_n(w.ctx, t.bcl, t.clusters, t.index, w.matches.as<isaac_match>(), nMatches, w.offsets.as<uint64_t>(), &t.tls, records.as<isaac_fragment>(), slots.as<uint32_t>(),
+                    GPU(isaac_gpu_select_n(w.ctx, bcl, t.clusters, t.index, w.matches.as<isaac_match>(), nMatches, w.offsets.as<uint64_t>(), &t.tls, records.as<isaac_fragment>(), slots.as<uint32_t>(),
                                            nRecords * ISAAC_GPU_MAX_CIGAR_OPS));
                     // the CIGARs as the bin files hold them: back to back
                     uint64_t words = 0;
@@ -464,51 +646,60 @@ int run(const AlignOptions &o)
                         rc = isaac_gpu_compact_cigars(w.ctx, records.as<isaac_fragment>(), nRecords, slots.as<uint32_t>(), packed.as<uint32_t>(), packed.bytes() / 4, &words);
                     }
                     check(rc, "isaac_gpu_compact_cigars");
-                    // BinningFragmentStorage: the tile's clusters to their bins, every bin's part to host memory
+                    // BinningFragmentStorage: the tile's clusters to their bins
                     uint64_t need = 0;
-                    const uint64_t guess = align64(uint64_t(t.clusters) * clusterLength + nRecords * sizeof(isaac_fragment) + words * 4) * 5 / 4 + 256 * (nContigs + 1);
+                    const uint64_t guess = align64(uint64_t(t.clusters) * clusterLength + nRecords * sizeof(isaac_fragment) + words * 4) * 5 / 4 + 256 * uint64_t(nBins);
                     if (binned.bytes() < guess) binned.reset(w.ctx, guess);
-                    rc = isaac_gpu_bin_tile(w.ctx, t.bcl, records.as<isaac_fragment>(), packed.as<uint32_t>(), t.clusters, binOfContig.data(), nContigs, nContigs + 1, binned.as<uint8_t>(), binned.bytes(),
-                                            sizes.data(), &need);
+                    rc = isaac_gpu_bin_tile_map(w.ctx, bcl, records.as<isaac_fragment>(), packed.as<uint32_t>(), t.clusters, &binMap, binned.as<uint8_t>(), binned.bytes(), sizes.data(), &need);
                     if (ISAAC_GPU_ECAPACITY == rc)
                     {
                         binned.reset(w.ctx, need);
-                        rc = isaac_gpu_bin_tile(w.ctx, t.bcl, records.as<isaac_fragment>(), packed.as<uint32_t>(), t.clusters, binOfContig.data(), nContigs, nContigs + 1, binned.as<uint8_t>(), binned.bytes(),
-                                                sizes.data(), &need);
+                        rc = isaac_gpu_bin_tile_map(w.ctx, bcl, records.as<isaac_fragment>(), packed.as<uint32_t>(), t.clusters, &binMap, binned.as<uint8_t>(), binned.bytes(), sizes.data(), &need);
                     }
-                    check(rc, "isaac_gpu_bin_tile");
-                    // the tile's parts stay on the device while it has room (see BinPart)
+                    check(rc, "isaac_gpu_bin_tile_map");
+                    // the BCL bytes of a load are in the bins once its last tile is: its memory is free for the tiles that follow
+                    if (0 == --t.load->tilesLeft) { t.load->dev.release(); t.load->host.reset(); }
+                    // the tile's parts stay on the device while it has room (see BinPart); a block that is mostly slack is cut to size first
                     std::shared_ptr<DeviceMemory> block;
                     {
                         uint64_t freeBytes = 0, totalBytes = 0;
                         GPU(isaac_gpu_memory_info(w.ctx, &freeBytes, &totalBytes));
-                        if (!hostBins && freeBytes > totalBytes / 4 + binned.bytes()) { block = std::make_shared<DeviceMemory>(std::move(binned)); ++w.tilesKeptOnDevice; }
+                        if (!hostBins && freeBytes > totalBytes / 4 + binned.bytes())
+                        {
+                            if (need + (need >> 2) < binned.bytes())
+                            {
+                                DeviceMemory exact(w.ctx, need + 64);
+                                GPU(isaac_gpu_copy(w.ctx, exact.as<uint8_t>(), binned.as<uint8_t>(), need));
+                                GPU(isaac_gpu_synchronize(w.ctx));
+                                block = std::make_shared<DeviceMemory>(std::move(exact));
+                            }
+                            else block = std::make_shared<DeviceMemory>(std::move(binned));
+                            ++w.tilesKeptOnDevice;
+                        }
                     }
                     const uint8_t *binnedBytes = block ? block->as<uint8_t>() : binned.as<uint8_t>();
+                    std::unique_ptr<uint8_t[]> whole;
+                    if (!block && need) { whole.reset(new uint8_t[need]); GPU(isaac_gpu_download(w.ctx, whole.get(), binnedBytes, need)); }      // one transfer for the tile, cut up on the host
                     uint64_t at = 0;
-                    for (uint32_t b = 0; b <= nContigs; ++b)
+                    for (uint32_t b = 0; b < nBins; ++b)
                     {
                         const uint64_t m = sizes[b].n_clusters, cw = sizes[b].n_cigar_words;
                         const uint64_t bytes = align64(align64(m * clusterLength) + m * nReads * sizeof(isaac_fragment)) + align64(cw * 4);
                         if (m)
                         {
                             BinPart part; part.tile = &t; part.clusters = m; part.words = cw; part.bytes = bytes;
-                            if (block) { part.block = block; part.offset = at; part.device = w.device; }
-                            else
-                            {
-                                part.data.reset(new uint8_t[bytes]);
-                                GPU(isaac_gpu_download(w.ctx, part.data.get(), binnedBytes + at, bytes));
-                            }
+                            if (block) { part.block = block; part.offset = at; part.place = w.place; }
+                            else { part.data.reset(new uint8_t[bytes]); std::memcpy(part.data.get(), whole.get() + at, bytes); }
                             std::lock_guard<std::mutex> guard(bins[b].lock);
                             bins[b].bytes += bytes; bins[b].records += m * nReads;
                             bins[b].parts.push_back(std::move(part));
                         }
                         at += bytes;
                     }
+                    w.noteMemory();
                 }
                 GPU(isaac_gpu_synchronize(w.ctx));
                 isaac_gpu_get_counters(w.ctx, &w.counters);
-                w.loads.clear();                        // the BCL bytes are in the bins now
                 w.matches.release(); w.offsets.release();
                 w.selectSeconds = seconds() - start;
             }
@@ -519,12 +710,11 @@ int run(const AlignOptions &o)
         selectTiles(*workers[0]);
         for (std::thread &t : threads) t.join();
         for (const std::string &e : errors) if (!e.empty()) throw std::runtime_error(e);
-        uint64_t overflow = 0;
-        for (auto &w : workers) overflow += w->counters.overflow_clusters;
-        if (overflow) std::cerr << "WARNING: " << overflow << " cluster(s) exceeded a fixed work list; their records are flagged (isaac_fragment::reserved bit 2)" << std::endl;
         // parts in tile order inside a bin, whichever worker was first
         for (Bin &bin : bins) std::sort(bin.parts.begin(), bin.parts.end(), [](const BinPart &a, const BinPart &b) { return a.tile->index < b.tile->index; });
     }
+    uint64_t overflowClusters = 0, mapqNearInteger = 0;
+    for (auto &w : workers) { overflowClusters += w->counters.overflow_clusters; mapqNearInteger += w->counters.mapq_near_integer; }
     const double selectSeconds = seconds() - selectStart;
 
     // ---- build::Build: one bin at a time -- records, duplicates, realignment, BAM records, BGZF blocks on the device -- the file and its index
@@ -535,17 +725,14 @@ int run(const AlignOptions &o)
     std::vector<std::string> headerLines = o.bamHeaderTags;
     {
         std::map<std::string, std::string> readGroups;
-        unsigned barcodeIndex = 0;
-        for (const FastqFlowcell &fc : flowcells)
-            for (const FastqLane &lane : fc.lanes)
-            {
-                const std::string id = std::to_string(barcodeIndex++);
-                if (tiles.end() == std::find_if(tiles.begin(), tiles.end(), [&id](const Tile &t) { return t.readGroup == id; })) continue;       // a lane without data has no tiles
-                std::string unit = o.bamPuFormat;
-                const auto replace = [&unit](const std::string &what, const std::string &with) { for (size_t at = unit.find(what); std::string::npos != at; at = unit.find(what, at + with.size())) unit.replace(at, what.size(), with); };
-                replace("%F", fc.flowcellId); replace("%L", std::to_string(lane.lane)); replace("%B", "none");
-                readGroups[id] = "@RG\tID:" + id + "\tPL:ILLUMINA\tSM:default\tPU:" + unit;
-            }
+        for (const Lane &L : lanes)
+        {
+            if (L.tiles.empty()) continue;                                      // a lane without data has no tiles
+            std::string unit = o.bamPuFormat;
+            const auto replace = [&unit](const std::string &what, const std::string &with) { for (size_t at = unit.find(what); std::string::npos != at; at = unit.find(what, at + with.size())) unit.replace(at, what.size(), with); };
+            replace("%F", L.flowcell->flowcellId); replace("%L", std::to_string(L.lane->lane)); replace("%B", "none");
+            readGroups[L.readGroup] = "@RG\tID:" + L.readGroup + "\tPL:ILLUMINA\tSM:default\tPU:" + unit;
+        }
         for (const auto &rg : readGroups) headerLines.push_back(rg.second);
     }
     std::vector<const char *> linePointers, names, as, ur, m5;
@@ -576,16 +763,18 @@ int run(const AlignOptions &o)
 
     // the bins in file order: the contigs, the unaligned templates behind them or (--keep-unaligned front) ahead of them
     std::vector<uint32_t> fileOrder;
-    if ("front" == o.keepUnaligned) fileOrder.push_back(nContigs);
-    for (uint32_t c = 0; c < nContigs; ++c) fileOrder.push_back(c);
-    if ("front" != o.keepUnaligned) fileOrder.push_back(nContigs);
+    if ("front" == o.keepUnaligned) fileOrder.push_back(nBins - 1);
+    for (uint32_t b = 0; b + 1 < nBins; ++b) fileOrder.push_back(b);
+    if ("front" != o.keepUnaligned) fileOrder.push_back(nBins - 1);
     std::vector<BinOutput> outputs(fileOrder.size());
-    std::mutex outputLock; std::condition_variable outputReady;
+    std::mutex outputLock; std::condition_variable outputReady, outputTaken;
     std::atomic<size_t> nextBin(0);
+    size_t binsWrittenSoFar = 0;                        // (under outputLock) the builders stay at most this far ahead of the file: finished bins wait in host memory
+    const size_t BUILD_AHEAD = 8;
     isaac_bam_options bamOptions; std::memset(&bamOptions, 0, sizeof(bamOptions));
     bamOptions.forced_dodgy_alignment_score = o.forcedDodgyAlignmentScore(); bamOptions.pessimistic_mapq = o.pessimisticMapQ; bamOptions.read_group = "0"; bamOptions.barcode = "none";
     bamOptions.mark_duplicates = o.markDuplicates; bamOptions.keep_duplicates = o.keepDuplicates; bamOptions.realign_gaps = "no" != o.realignGaps; bamOptions.realign_dodgy = o.realignDodgy;
-    bamOptions.bin_filter = 1;
+    bamOptions.bin_filter = 2;
     const uint32_t maxReadLength = std::max(params.read_length[0], params.read_length[1]);
     auto buildBins = [&](Worker &w)
     {
@@ -593,6 +782,10 @@ int run(const AlignOptions &o)
         DeviceMemory data, bam, bgzf, entries;
         for (size_t k = nextBin++; k < fileOrder.size(); k = nextBin++)
         {
+            {   // not too far ahead of the writer
+                std::unique_lock<std::mutex> guard(outputLock);
+                outputTaken.wait(guard, [&] { return k < binsWrittenSoFar + BUILD_AHEAD; });
+            }
             BinOutput result;
             double mark = seconds();
             const auto lap = [&mark](double &into) { const double now = seconds(); into += now - mark; mark = now; };
@@ -601,30 +794,24 @@ int run(const AlignOptions &o)
                 Bin &bin = bins[fileOrder[k]];
                 if (!bin.parts.empty())
                 {
-                    // the bin's parts to the device, each the three arrays of a tile
-                    // parts that lie on this device are used where they are; the others -- in host memory, or on another worker's device --
-                    // come into one buffer
+                    // the bin's parts on this device, each the three arrays of a tile: parts in this worker's own blocks are used where they are;
+                    // the others -- in host memory, or in the blocks of a worker on another device -- come into one buffer
                     uint64_t foreignBytes = 0;
-                    for (const BinPart &part : bin.parts) if (!part.block || part.device != w.device) foreignBytes += part.bytes;
+                    for (const BinPart &part : bin.parts) if (!part.block || part.place != w.place) foreignBytes += part.bytes;
                     if (data.bytes() < foreignBytes) data.reset(w.ctx, foreignBytes);
                     std::vector<isaac_bam_tile> bamTiles(bin.parts.size());
-                    std::unique_ptr<uint8_t[]> staging; uint64_t stagingBytes = 0;
                     uint64_t at = 0;
                     for (size_t i = 0; i < bin.parts.size(); ++i)
                     {
                         BinPart &part = bin.parts[i];
                         uint8_t *base = 0;
-                        if (part.block && part.device == w.device) base = part.block->as<uint8_t>() + part.offset;
+                        if (part.block && part.place == w.place) base = part.block->as<uint8_t>() + part.offset;
                         else
                         {
                             base = data.as<uint8_t>() + at;
-                            if (part.block)
-                            {   // (through the host: the other device's context is busy with bins of its own)
-                                if (stagingBytes < part.bytes) { staging.reset(new uint8_t[part.bytes]); stagingBytes = part.bytes; }
-                                GPU(isaac_gpu_download(part.tile->worker->ctx, staging.get(), part.block->as<uint8_t>() + part.offset, part.bytes));
-                                GPU(isaac_gpu_upload(w.ctx, base, staging.get(), part.bytes));
-                                part.block.reset();
-                            }
+                            // (from the other device on this context's own stream: nothing is asked of the context that owns the block, which is busy
+                            // with bins of its own)
+                            if (part.block) GPU(isaac_gpu_copy(w.ctx, base, part.block->as<uint8_t>() + part.offset, part.bytes));
                             else { GPU(isaac_gpu_upload(w.ctx, base, part.data.get(), part.bytes)); part.data.reset(); }
                             at += part.bytes;
                         }
@@ -635,10 +822,11 @@ int run(const AlignOptions &o)
                         b.n_records = part.clusters * nReads;
                         b.read_name_prefix = part.tile->namePrefix.c_str(); b.read_group = part.tile->readGroup.c_str(); b.tls = &part.tile->tls;
                     }
+                    GPU(isaac_gpu_synchronize(w.ctx));
+                    for (BinPart &part : bin.parts) if (part.block && part.place != w.place) part.block.reset();
                     lap(w.uploadSeconds);
                     isaac_bam_options options = bamOptions;
-                    if (fileOrder[k] == nContigs) { options.bin_first_contig = 0; options.bin_end_contig = 0; options.bin_unaligned = 1; }
-                    else { options.bin_first_contig = fileOrder[k]; options.bin_end_contig = fileOrder[k] + 1; options.bin_unaligned = 0; }
+                    options.bin_first_position = bin.firstPosition; options.bin_end_position = bin.endPosition; options.bin_unaligned = bin.unaligned ? 1 : 0;
                     uint64_t capacity = bin.records * (96 + 2 * uint64_t(maxReadLength)), nBytes = 0, unalignedOffset = 0;
                     if (bam.bytes() < capacity) bam.reset(w.ctx, capacity);
                     if (entries.bytes() < bin.records * sizeof(isaac_bam_index_entry)) entries.reset(w.ctx, bin.records * sizeof(isaac_bam_index_entry));
@@ -666,6 +854,7 @@ int run(const AlignOptions &o)
                         GPU(isaac_gpu_download(w.ctx, result.entries.get(), entries.as<isaac_bam_index_entry>(), result.nRecords * sizeof(isaac_bam_index_entry)));      // for the index
                         lap(w.downloadSeconds);
                     }
+                    w.noteMemory();
                     std::vector<BinPart>().swap(bin.parts);
                 }
             }
@@ -697,7 +886,9 @@ int run(const AlignOptions &o)
                 std::unique_lock<std::mutex> guard(outputLock);
                 outputReady.wait(guard, [&] { return outputs[k].ready; });
                 out = std::move(outputs[k]);
+                binsWrittenSoFar = k + 1;
             }
+            outputTaken.notify_all();
             if (!out.error.empty() && failure.empty()) failure = out.error;
             if (!failure.empty() || !out.bgzfBytes) continue;
             const double writeStart = seconds();
@@ -725,15 +916,24 @@ int run(const AlignOptions &o)
     }
     if (!failure.empty()) throw std::runtime_error(failure);
     const double buildSeconds = seconds() - buildStart, total = seconds() - runStart;
-    uint64_t tilesOnDevice = 0;
-    for (auto &w : workers) tilesOnDevice += w->tilesKeptOnDevice;
+    uint64_t tilesOnDevice = 0, loadsOnDevice = 0, peakDevice = 0, nLoads = 0;
+    for (auto &w : workers) { tilesOnDevice += w->tilesKeptOnDevice; loadsOnDevice += w->loadsKeptOnDevice; peakDevice = std::max(peakDevice, w->peakDeviceBytes); }
+    for (const Lane &L : lanes) nLoads += L.loads.size();
     std::cerr << "isaac-align: " << bamPath << ": " << nRecordsWritten << " records in " << binsWritten << " bin(s)" << std::endl;
     // one line for scripts (bench.py): what the run took, stage by stage
     std::cerr << "isaac-align: timing {\"clusters\": " << totalClusters << ", \"reads\": " << totalClusters * nReads << ", \"records\": " << nRecordsWritten << ", \"workers\": " << workers.size()
               << ", \"reference_s\": " << referenceSeconds << ", \"reference_fasta_s\": " << fastaSeconds << ", \"reference_contigs_s\": " << contigSeconds << ", \"reference_table_s\": " << tableSeconds << ", \"load_and_find_s\": " << loadSeconds << ", \"load_text_wait_s\": " << g_textWaitSeconds << ", \"load_convert_s\": " << g_convertSeconds << ", \"load_first_lookup_s\": " << g_firstLookupSeconds << ", \"select_and_bin_s\": " << selectSeconds << ", \"build_and_write_s\": " << buildSeconds
-              << ", \"tiles_kept_on_device\": " << tilesOnDevice << ", \"build_upload_s\": " << workers[0]->uploadSeconds << ", \"build_records_s\": " << workers[0]->recordsSeconds << ", \"build_deflate_s\": " << workers[0]->deflateSeconds
+              << ", \"tiles_kept_on_device\": " << tilesOnDevice << ", \"tiles\": " << tiles.size() << ", \"loads_kept_on_device\": " << loadsOnDevice << ", \"loads\": " << nLoads << ", \"bins\": " << nBins << ", \"bin_cuts\": " << plan.cuts.size()
+              << ", \"build_upload_s\": " << workers[0]->uploadSeconds << ", \"build_records_s\": " << workers[0]->recordsSeconds << ", \"build_deflate_s\": " << workers[0]->deflateSeconds
               << ", \"build_download_s\": " << workers[0]->downloadSeconds << ", \"file_write_s\": " << writeSeconds
+              << ", \"overflow_clusters\": " << overflowClusters << ", \"mapq_near_integer\": " << mapqNearInteger
+              << ", \"peak_device_bytes\": " << peakDevice << ", \"peak_host_bytes\": " << hostResidentBytes()
               << ", \"total_s\": " << total << "}" << std::endl;
+    if (overflowClusters)
+    {   // a fixed work list of the device was too small for these clusters: their records are flagged (isaac_fragment::reserved bit 2) and not exact
+        std::cerr << "ERROR: " << overflowClusters << " cluster(s) exceeded a fixed work list of the device; the records of these clusters in " << bamPath << " are not what the reference writes" << std::endl;
+        return 3;
+    }
     return 0;
 }
 

@@ -48,22 +48,20 @@ def broadcast_tls(tls, dist, device="cpu", src=0):
     return tls
 
 
-def broadcast_table(kmers, positions, dist, rank, device="cpu", src=0, chunk=1 << 28):
-    """The resident table of rank `src` (two int64 arrays: isaac_gpu_index_dev) becomes every rank's: one build and N - 1 transfers over
-    xGMI instead of N builds.  Ranks other than `src` pass None, None and get fresh tensors to hand to isaac_gpu_set_index_dev.  The entry
-    count goes first; the arrays follow in pieces of `chunk` entries (2 GB), so that no single collective carries a count beyond 2^31."""
+def broadcast_table(entries, dist, rank, device="cpu", src=0, chunk=1 << 27):
+    """The resident table of rank `src` (an [n, 2] int64 array: isaac_gpu_index_dev) becomes every rank's: one build and N - 1 transfers over
+    xGMI instead of N builds.  Ranks other than `src` pass None and get a fresh tensor to hand to isaac_gpu_set_index_dev.  The entry
+    count goes first; the table follows in pieces of `chunk` entries (2 GB), so that no single collective carries a count beyond 2^31."""
     if dist is None:
-        return kmers, positions
-    n = torch.tensor([int(kmers.numel()) if rank == src else 0], dtype=torch.int64, device=device)
+        return entries
+    n = torch.tensor([int(entries.shape[0]) if rank == src else 0], dtype=torch.int64, device=device)
     dist.broadcast(n, src)
     n = int(n.item())
     if rank != src:
-        kmers = torch.empty(n, dtype=torch.int64, device=device)
-        positions = torch.empty(n, dtype=torch.int64, device=device)
-    for array in (kmers, positions):
-        for begin in range(0, n, chunk):
-            dist.broadcast(array[begin:begin + chunk], src)
-    return kmers, positions
+        entries = torch.empty((n, 2), dtype=torch.int64, device=device)
+    for begin in range(0, n, chunk):
+        dist.broadcast(entries[begin:begin + chunk], src)
+    return entries
 
 
 def gather_records(records, dist, rank, world, dst=0):

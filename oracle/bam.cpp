@@ -12,6 +12,7 @@
 #include "oracle.hpp"
 
 #include <algorithm>
+#include <map>
 #include <cstring>
 #include <string>
 
@@ -214,6 +215,9 @@ void bamRecords(const std::vector<BamTileInput> &tiles, const BamOptions &o, std
     // the ends of pairs in the order of the bin's index after BinSorter::resolveDuplicates: reverse-strand ends and shadows, then forward-strand
     // ends, each list as the duplicate filter's sort leaves it (without filtering the reference keeps the order of its bin files, which is the
     // order its threads happened to store fragments in; the sorted order stands in for it)
+    // the bin of a position: its contig and the number of cuts at or before it (cuts of earlier contigs count for all positions of this one alike)
+    const auto cutsUpTo = [&o](uint64_t value) { return uint64_t(std::upper_bound(o.binCuts.begin(), o.binCuts.end(), value & ~uint64_t(1)) - o.binCuts.begin()); };
+    const auto binOf = [&cutsUpTo](uint64_t value) { return uint64_t(ReferencePosition::fromValue(value).getContigId()) << 32 | cutsUpTo(value); };
     std::vector<PairEndIndex> ends[2];
     const bool filtering = o.markDuplicates || !o.keepDuplicates;
     if (filtering || o.realignGaps)
@@ -242,23 +246,31 @@ void bamRecords(const std::vector<BamTileInput> &tiles, const BamOptions &o, std
         }
         for (int rs = 1; rs >= 0; --rs)
         {
-            std::vector<char> dup;
-            filterDuplicates(ends[rs], dup);
-            if (filtering) for (size_t k = 0; k < ends[rs].size(); ++k) if (dup[k]) stored[ends[rs][k].tag].duplicate = true;
+            // a bin at a time, the bins in position order
+            std::map<uint64_t, std::vector<PairEndIndex> > byBin;
+            for (const PairEndIndex &e : ends[rs]) byBin[binOf(stored[e.tag].header->fStrandPosition)].push_back(e);
+            ends[rs].clear();
+            for (auto &bin : byBin)
+            {
+                std::vector<char> dup;
+                filterDuplicates(bin.second, dup);
+                if (filtering) for (size_t k = 0; k < bin.second.size(); ++k) if (dup[k]) stored[bin.second[k].tag].duplicate = true;
+                ends[rs].insert(ends[rs].end(), bin.second.begin(), bin.second.end());
+            }
         }
     }
     if (o.realignGaps)
     {
         // BinSorter::collectGaps (:387-403): the gaps of every fragment of the bin's data (discarded duplicates included), a bin = a contig
         const ContigList &contigs = *o.contigs;
-        std::vector<RealignerGaps> binGaps(contigs.size());
+        std::map<uint64_t, RealignerGaps> binGaps;
         for (const Stored &s : stored)
         {
             const FragmentRecord &h = *s.header;
             if (h.fStrandPosition == NO_MATCH_VALUE || (h.flags & 2) || !h.gapCount) continue;
-            binGaps.at(ReferencePosition::fromValue(h.fStrandPosition).getContigId()).addGaps(ReferencePosition::fromValue(h.fStrandPosition), s.cigarBegin, s.cigarEnd);
+            binGaps[binOf(h.fStrandPosition)].addGaps(ReferencePosition::fromValue(h.fStrandPosition), s.cigarBegin, s.cigarEnd);
         }
-        for (RealignerGaps &g : binGaps) g.finalizeGaps();
+        for (auto &g : binGaps) g.second.finalizeGaps();
         // BinSorter::realignGaps (:405-417): the index in order (single-ended, reverse-strand ends and shadows, forward-strand ends), duplicates that were dropped are not in it
         const GapRealigner realigner = { false, o.realignDodgy, 1, 3, 4, 0, o.clipSemialigned, contigs };
         realignedCigars.reserve(size_t(1) << 26);
@@ -272,13 +284,20 @@ void bamRecords(const std::vector<BamTileInput> &tiles, const BamOptions &o, std
             FragmentRecord &h = *s.header;
             if (h.flags & 2) continue;
             const ReferencePosition pos = ReferencePosition::fromValue(h.fStrandPosition);
-            const ReferencePosition binStartPos(pos.getContigId(), 0), binEndPos(pos.getContigId(), contigs.at(pos.getContigId()).forward.size());
+            // the bin: the contig, or the stretch of it between the cuts on either side of the fragment
+            ReferencePosition binStartPos(pos.getContigId(), 0), binEndPos(pos.getContigId(), contigs.at(pos.getContigId()).forward.size());
+            {
+                const uint64_t upTo = cutsUpTo(h.fStrandPosition);
+                if (upTo && ReferencePosition::fromValue(o.binCuts[upTo - 1]).getContigId() == pos.getContigId()) binStartPos = ReferencePosition::fromValue(o.binCuts[upTo - 1]);
+                if (upTo < o.binCuts.size() && ReferencePosition::fromValue(o.binCuts[upTo]).getContigId() == pos.getContigId()) binEndPos = ReferencePosition::fromValue(o.binCuts[upTo]);
+            }
+            const uint64_t bin = binOf(h.fStrandPosition);
             RealignFragment f = RealignFragment();
             f.fStrandPosition = pos; f.mateFStrandPosition = h.mateFStrandPosition; f.observedLength = h.observedLength; f.lowClipped = h.lowClipped; f.highClipped = h.highClipped;
             f.alignmentScore = h.alignmentScore; f.templateAlignmentScore = h.templateAlignmentScore; f.readLength = h.readLength; f.editDistance = h.editDistance; f.flags = h.flags; f.bases = s.bases.data();
             RealignIndex index = { pos, s.cigarBegin, s.cigarEnd };
             bool changed = false;
-            realigner.realign(binGaps.at(pos.getContigId()), binStartPos, binEndPos, index, f, realignedCigars, changed);
+            realigner.realign(binGaps[bin], binStartPos, binEndPos, index, f, realignedCigars, changed);
             if (!changed) continue;
             h.fStrandPosition = f.fStrandPosition.value; h.observedLength = f.observedLength; h.editDistance = f.editDistance;
             s.cigarBegin = index.cigarBegin; s.cigarEnd = index.cigarEnd; h.cigarLength = uint16_t(index.cigarEnd - index.cigarBegin);

@@ -913,10 +913,25 @@ int oracle_filter_duplicates(uint64_t n, const uint64_t *primary, const uint64_t
     catch (const std::exception &e) { g_error = e.what(); return 1; }
 }
 
+// bin_cuts: ascending ReferencePosition values at which a contig goes on into a further bin (BamOptions::binCuts), or NULL
+int oracle_bam_records_cuts(const oracle_bam_tile *tiles, uint32_t n_tiles, uint32_t n_reads, const uint32_t *read_lengths, uint32_t forced_dodgy_alignment_score,
+                            int pessimistic_mapq, const char *read_group, const char *barcode, int mark_duplicates, int keep_duplicates,
+                            int realign_gaps, int realign_dodgy, int clip_semialigned, const oracle_ref *reference, const oracle_tls *tls,
+                            const uint64_t *bin_cuts, uint32_t n_cuts,
+                            uint8_t *out, uint64_t capacity, uint64_t *n_bytes, uint64_t *n_records, uint64_t *unaligned_offset);
 int oracle_bam_records(const oracle_bam_tile *tiles, uint32_t n_tiles, uint32_t n_reads, const uint32_t *read_lengths, uint32_t forced_dodgy_alignment_score,
                        int pessimistic_mapq, const char *read_group, const char *barcode, int mark_duplicates, int keep_duplicates,
                        int realign_gaps, int realign_dodgy, int clip_semialigned, const oracle_ref *reference, const oracle_tls *tls,
                        uint8_t *out, uint64_t capacity, uint64_t *n_bytes, uint64_t *n_records, uint64_t *unaligned_offset)
+{
+    return oracle_bam_records_cuts(tiles, n_tiles, n_reads, read_lengths, forced_dodgy_alignment_score, pessimistic_mapq, read_group, barcode, mark_duplicates, keep_duplicates,
+                                   realign_gaps, realign_dodgy, clip_semialigned, reference, tls, 0, 0, out, capacity, n_bytes, n_records, unaligned_offset);
+}
+int oracle_bam_records_cuts(const oracle_bam_tile *tiles, uint32_t n_tiles, uint32_t n_reads, const uint32_t *read_lengths, uint32_t forced_dodgy_alignment_score,
+                            int pessimistic_mapq, const char *read_group, const char *barcode, int mark_duplicates, int keep_duplicates,
+                            int realign_gaps, int realign_dodgy, int clip_semialigned, const oracle_ref *reference, const oracle_tls *tls,
+                            const uint64_t *bin_cuts, uint32_t n_cuts,
+                            uint8_t *out, uint64_t capacity, uint64_t *n_bytes, uint64_t *n_records, uint64_t *unaligned_offset)
 {
     try
     {
@@ -934,6 +949,8 @@ int oracle_bam_records(const oracle_bam_tile *tiles, uint32_t n_tiles, uint32_t 
         TemplateLengthStatistics stats; if (tls) stats = fromTls(tls);
         o.realignGaps = realign_gaps != 0; o.realignDodgy = realign_dodgy != 0; o.clipSemialigned = clip_semialigned != 0; o.contigs = reference ? &reference->contigs : 0; o.tls = tls ? &stats : 0;
         if (o.realignGaps && !o.contigs) throw std::runtime_error("gap realignment needs the reference");
+        for (uint32_t k = 0; k < n_cuts; ++k) o.binCuts.push_back(bin_cuts[k] & ~uint64_t(1));
+        if (!std::is_sorted(o.binCuts.begin(), o.binCuts.end())) throw std::runtime_error("bin cuts must ascend");
         std::vector<char> os;
         bamRecords(in, o, os, *n_records, *unaligned_offset);
         *n_bytes = os.size();

@@ -690,7 +690,11 @@ struct BamTileInput { const uint8_t *bcl; const FragmentRecord *records; const u
                       const TemplateLengthStatistics *tls = 0; };   // of the tile's barcode; NULL: BamOptions::tls
 struct BamOptions { unsigned clusterLength, readOffset[2]; unsigned char forcedDodgyAlignmentScore; bool pessimisticMapQ; std::string readGroup, barcode;
                     bool markDuplicates = false, keepDuplicates = true;          // --mark-duplicates / --keep-duplicates (BinSorter.cpp:293-330)
-                    bool realignGaps = false, realignDodgy = false, clipSemialigned = true; const ContigList *contigs = 0; const TemplateLengthStatistics *tls = 0; };   // --realign-gaps sample
+                    bool realignGaps = false, realignDodgy = false, clipSemialigned = true; const ContigList *contigs = 0; const TemplateLengthStatistics *tls = 0;   // --realign-gaps sample
+                    // Every contig is a bin of its own unless it is cut: ascending ReferencePosition values at which a contig goes on into a further bin
+                    // (alignment::BinMetadata stretches of --target-bin-size, include/alignment/matchSelector/BinIndexMap.hh:44-104).  build::Build works bin
+                    // by bin: duplicates, gaps and realignment never look beyond the bin (lib/build/BinSorter.cpp:293-330,387-417)
+                    std::vector<uint64_t> binCuts; };
 // One end of a pair as the duplicate filter sees it: build::FStrandFragmentIndex / RStrandOrShadowFragmentIndex (include/build/FragmentIndex.hh:101-192)
 // with the fields of the fragment its comparators look up (library = barcode or sample index, tile * 10^9 + cluster).
 struct PairEndIndex

@@ -16,7 +16,7 @@ def main():
     genome = synth.make_human_like_genome(int(float(os.environ.get("EXP_GENOME_BASES", "3.1e9"))), seed=3, device=dev)
     main_al = gpu.Aligner(params, 0, genome, deferred_completion=True)
     main_al.build_index(repeat_threshold=1000)
-    kmers, positions = main_al.index_tensors()
+    table = main_al.index_tensors()
     batches = [synth.make_read_pairs(genome, pairs, L, seed=1000 + b, device=dev, avoid_gaps=True)[0] for b in range(steps + 1)]
     m, o, hits = main_al.find_matches(batches[0]); main_al.set_loaded_contigs(np.ones_like(hits))
     tls = main_al.determine_tls(batches[0], m, o)
@@ -29,7 +29,7 @@ def main():
         for _ in range(C - 1):
             with torch.cuda.stream(torch.cuda.Stream(dev)):
                 al = gpu.Aligner(params, 0, genome, deferred_completion=True)
-                al.set_index_tensors(kmers, positions)
+                al.set_index_tensors(table)
                 al.set_loaded_contigs(np.ones_like(hits))
                 als.append(al)
         for k, al in enumerate(als):                       # warm-up: every context grows its buffers

@@ -284,7 +284,7 @@ int emu_select(Emu *e, const u8 *bcl, u32 nClusters, u32 tile, const isaac_tls *
         RescueInputs in; in.jobs = jobs.data() + jobBase[c]; in.jobCount = jobBase[c + 1] - jobBase[c]; in.shadowCands = shadowCands.data(); in.shadowCigars = shadowCigars.data();
         in.gappedResults = gapped.data(); in.gappedJobs = gj.data(); in.candRank = candRank.data(); in.sums = 0;
         const auto t0 = std::chrono::steady_clock::now();
-        SumInputs si; si.jobs = in.jobs; si.nJobs = in.jobCount; si.shadowCands = shadowCands.data(); si.candRank = candRank.data(); si.gappedResults = gapped.data(); si.gappedJobs = gj.data();
+        SumInputs si; si.jobs = in.jobs; si.nJobs = in.jobCount; si.shadowCands = shadowCands.data(); si.candRank = candRank.data(); si.gappedResults = gapped.data(); si.gappedJobs = gj.data(); si.shadowCigars = shadowCigars.data();
         SumGroup g; g.lanes = 1; g.lane = 0; g.block = false; g.radix = SumRadix{nullptr, nullptr, nullptr, nullptr, nullptr, 0}; g.radixMin = 0; g.sumTile = nullptr; g.sumTileCap = 0;
         double sumTile[7]; if (e->sumsRadixMin >= 0) { g.sumTile = sumTile; g.sumTileCap = 7; }
         u16 radixCounts[16]; u32 radixTotals[1]; u64 radixVary[2]; std::vector<u16> radixAlt(1024); std::vector<u8> radixDigits(1024);
@@ -295,7 +295,7 @@ int emu_select(Emu *e, const u8 *bcl, u32 nClusters, u32 tile, const isaac_tls *
         if (!residual && e->lean)
         {   // k_select
             ClusterMeta meta; clusterViewStore(e->frags[c], e->stores[c].cands, meta);
-            LeanRescue rs; rs.jobs = in.jobs; rs.jobCount = in.jobCount; rs.shadowCands = shadowCands.data(); rs.shadowCigars = shadowCigars.data(); rs.gappedResults = gapped.data(); rs.sums = &sums;
+            LeanRescue rs; rs.jobs = in.jobs; rs.jobCount = in.jobCount; rs.shadowCands = shadowCands.data(); rs.shadowCigars = shadowCigars.data(); rs.gappedResults = gapped.data(); rs.sums = &sums; leanOutcomesInPlace(rs);
             u32 near = 0;
             residual = !leanSelectCluster(e->P, e->R, t, rog, lmq40, bcl, c, tile, meta, e->stores[c].cands, e->frags[c].cigarPool, rs, recs, cigars, near);
             if (!residual) e->cnt.mapqNearInteger += near;

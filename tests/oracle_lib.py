@@ -102,8 +102,9 @@ class Oracle:
         return out.astype(bool)
 
     def bam_records(self, tiles, read_lengths, forced_dodgy_alignment_score=0, pessimistic_mapq=False, read_group="0", barcode="none", mark_duplicates=False, keep_duplicates=True,
-                    realign_gaps=False, realign_dodgy=False, clip_semialigned=True, reference=None, tls=None):
-        """tiles: [(bcl, records, cigars, read_name_prefix[, read_group[, tls]])] as numpy arrays; returns (bytes, n_records, unaligned_offset)"""
+                    realign_gaps=False, realign_dodgy=False, clip_semialigned=True, reference=None, tls=None, bin_cuts=()):
+        """tiles: [(bcl, records, cigars, read_name_prefix[, read_group[, tls]])] as numpy arrays; bin_cuts: ascending ReferencePosition values at which a
+        contig goes on into a further bin (every bin is filtered and realigned by itself); returns (bytes, n_records, unaligned_offset)"""
         arr = (BamTile * len(tiles))()
         keep = []
         total = 0
@@ -122,10 +123,12 @@ class Oracle:
         cap = max(1, total * (128 + 2 * max(read_lengths) + 4 * 64))
         out = np.empty(cap, np.uint8)
         nb, nr, un = C.c_uint64(), C.c_uint64(), C.c_uint64()
-        self.check(self.lib.oracle_bam_records(arr, C.c_uint32(len(tiles)), C.c_uint32(len(read_lengths)), lengths, C.c_uint32(forced_dodgy_alignment_score), C.c_int(int(pessimistic_mapq)),
-                                               read_group.encode(), barcode.encode(), C.c_int(int(mark_duplicates)), C.c_int(int(keep_duplicates)),
-                                               C.c_int(int(realign_gaps)), C.c_int(int(realign_dodgy)), C.c_int(int(clip_semialigned)), (reference.h if reference is not None else None),
-                                               C.byref(tls) if tls is not None else None, ptr(out), C.c_uint64(cap), C.byref(nb), C.byref(nr), C.byref(un)))
+        cuts = np.ascontiguousarray(list(bin_cuts), np.uint64)
+        self.check(self.lib.oracle_bam_records_cuts(arr, C.c_uint32(len(tiles)), C.c_uint32(len(read_lengths)), lengths, C.c_uint32(forced_dodgy_alignment_score), C.c_int(int(pessimistic_mapq)),
+                                                    read_group.encode(), barcode.encode(), C.c_int(int(mark_duplicates)), C.c_int(int(keep_duplicates)),
+                                                    C.c_int(int(realign_gaps)), C.c_int(int(realign_dodgy)), C.c_int(int(clip_semialigned)), (reference.h if reference is not None else None),
+                                                    C.byref(tls) if tls is not None else None, ptr(cuts) if len(cuts) else None, C.c_uint32(len(cuts)),
+                                                    ptr(out), C.c_uint64(cap), C.byref(nb), C.byref(nr), C.byref(un)))
         return out[:nb.value].tobytes(), nr.value, un.value
 
     def bam_index(self, record_bytes, parts, n_contigs, header_bgzf_bytes):

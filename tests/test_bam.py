@@ -283,6 +283,118 @@ def test_gpu_bins_give_the_bytes_of_one_call():
         assert (stored_twice > 1000) if max(bin_of_contig) else (stored_twice == 0)          # the chimeras, when the contigs are not all one bin
 
 
+@pytest.mark.gpu
+def test_gpu_bins_inside_a_contig_match_the_oracle():
+    """bins that are stretches of a contig (isaac_gpu_bin_tile_map with cut positions, isaac_bam_options::bin_filter 2): every bin is sorted, filtered
+    for duplicates and realigned by itself -- gaps are looked for inside the bin, a pair whose mate lies beyond the cut is not realigned -- and the bins
+    written one after the other are byte for byte what the oracle makes of the same tiles with the same cuts (oracle/bam.cpp: BamOptions::binCuts).  The
+    cuts do change the result: without them some records near a cut come out realigned differently."""
+    import torch
+    from isaac_aligner_amd import gpu
+    rng = np.random.default_rng(29)
+    L = 100
+    genome = synth.make_genome(260000, seed=64, n_contigs=2, repeat_families=False)
+    contigs = [bytes(c.numpy()) for c in genome]
+    sample = synth.make_sample_with_indels(genome, rng)
+    params = options.default_params(L, L)
+    a = gpu.Aligner(params, 0, contigs)
+    a.build_index()
+    o = oracle_lib.load()
+    ref = o.reference(contigs)
+    tiles, host_tiles, tls = [], [], None
+    for t in range(2):
+        bcl = synth.make_read_pairs(sample, 12000, L, seed=90 + t, indel_read_fraction=0.02, subst_rate=0.004)[0].numpy().copy()
+        bcl[2000:2600] = bcl[2600:3200]                                      # duplicates
+        d_bcl = torch.from_numpy(bcl).cuda()
+        matches, offsets, hits = a.find_matches(d_bcl, tile=t)
+        a.set_loaded_contigs(np.ones(len(contigs), np.uint8))
+        if tls is None:
+            tls = a.determine_tls(d_bcl, matches, offsets, tile=t)
+        records, cigars = a.select(d_bcl, matches, offsets, tls, tile=t)
+        tiles.append((d_bcl, records, cigars, "FC:2:%d:" % t))
+        rec, cig = a.records_to_numpy(records, cigars)
+        host_tiles.append((bcl, rec, cig, "FC:2:%d:" % t))
+    kw = dict(mark_duplicates=True, keep_duplicates=True, realign_gaps=True, tls=tls)
+    # every contig in bins of 16 384 positions (cuts at multiples of 2048, the reference's granularity), then the templates without a position
+    lengths = [len(c) for c in contigs]
+    step = 16384
+    cuts, bin_of_contig, bin_range = [], [], []
+    for c, length in enumerate(lengths):
+        bin_of_contig.append(len(bin_range))
+        for at in range(0, length, step):
+            if at:
+                cuts.append(bam.reference_position(c, at))
+            bin_range.append((bam.reference_position(c, at), bam.reference_position(c, at + step) if at + step < length else bam.reference_position(c + 1, 0)))
+    n_bins = len(bin_range) + 1
+    per_bin = [[] for _ in range(n_bins)]
+    for bcl, records, cigars, prefix in tiles:
+        for b, part in enumerate(a.bin_tile(bcl, records, cigars, bin_of_contig, n_bins, cut_positions=cuts)):
+            if part[1].shape[0]:
+                per_bin[b].append((part[0].clone(), part[1].clone(), part[2].clone(), prefix))
+    pieces, n_total = [], 0
+    for b in range(n_bins):
+        if not per_bin[b]:
+            continue
+        if b == n_bins - 1:
+            got, n, _ = a.bam_records(per_bin[b], bin_positions=(0, 0), bin_unaligned=True, **kw)
+        else:
+            got, n, _ = a.bam_records(per_bin[b], bin_positions=bin_range[b], **kw)
+        pieces.append(got.cpu().numpy().tobytes()); n_total += n
+    assert all(per_bin[b] for b in range(n_bins - 1)), "every stretch has records"
+    okw = dict(mark_duplicates=True, keep_duplicates=True, realign_gaps=True, reference=ref, tls=tls)
+    want, want_n, _ = o.bam_records(host_tiles, [L, L], bin_cuts=cuts, **okw)
+    assert n_total == want_n
+    assert b"".join(pieces) == want
+    uncut, _, _ = o.bam_records(host_tiles, [L, L], **okw)
+    assert uncut != want, "the cuts were expected to keep some fragment near them from being realigned"
+    # the same stretches through the contig form of the filter cannot be told apart from whole contigs: the position form is what makes the difference
+    whole, n_whole, _ = a.bam_records(tiles, **kw)
+    assert whole.cpu().numpy().tobytes() == uncut and n_whole == want_n
+
+
+@pytest.mark.gpu
+def test_gpu_bins_of_three_thousand_contigs():
+    """a reference of 3 000 contigs (GRCh38 with its alternate and decoy sequences has 3 366): isaac_gpu_bin_tile with more bins than a byte counts -- one per
+    contig -- and with runs of contigs sharing bins; the bins written in order are the bytes of one isaac_gpu_bam_records call over the whole tiles"""
+    import torch
+    from isaac_aligner_amd import gpu
+    rng = np.random.default_rng(31)
+    L = 100
+    n_contigs = 3000
+    genome = synth.make_genome(2400000, seed=65, n_contigs=n_contigs, repeat_families=False)
+    contigs = [bytes(c.numpy()) for c in genome]
+    assert len(contigs) == n_contigs
+    params = options.default_params(L, L)
+    a = gpu.Aligner(params, 0, contigs)
+    a.build_index()
+    bcl = synth.make_read_pairs(genome, 20000, L, seed=95, indel_read_fraction=0.01)[0].numpy().copy()
+    bcl[:2000, L:] = bcl[rng.permutation(2000), L:]                           # pairs on two contigs
+    d_bcl = torch.from_numpy(bcl).cuda()
+    matches, offsets, hits = a.find_matches(d_bcl, tile=0)
+    a.set_loaded_contigs(np.ones(n_contigs, np.uint8))
+    tls = a.determine_tls(d_bcl, matches, offsets, tile=0)
+    records, cigars = a.select(d_bcl, matches, offsets, tls, tile=0)
+    tile = (d_bcl, records, cigars, "FC:3:0:")
+    kw = dict(mark_duplicates=True, keep_duplicates=True, realign_gaps=True, tls=tls)
+    whole, n_whole, _ = a.bam_records([tile], **kw)
+    whole = whole.cpu().numpy().tobytes()
+    rec = a.records_to_numpy(records, cigars)[0]
+    seen = len(set(int(v >> 41) for v in rec["f_strand_position"] if int(v >> 41)))
+    assert seen > 2000, seen                                                   # records on most contigs
+    for per in (1, 7, 400):                                                    # contigs per bin
+        bin_of_contig = [c // per for c in range(n_contigs)]
+        n_bins = bin_of_contig[-1] + 2
+        parts = a.bin_tile(d_bcl, records, cigars, bin_of_contig, n_bins)
+        pieces, n_total = [], 0
+        for b, part in enumerate(parts):
+            if not part[1].shape[0]:
+                continue
+            mine = (b * per, min(n_contigs, (b + 1) * per))
+            got, n, _ = a.bam_records([(part[0], part[1], part[2], "FC:3:0:")], bin_contigs=mine if b < n_bins - 1 else None, bin_unaligned=(b == n_bins - 1), **kw)
+            pieces.append(got.cpu().numpy().tobytes()); n_total += n
+        assert n_total == n_whole and b"".join(pieces) == whole, per
+
+
 def _bgzf_members(stream):
     """(offset, total size, ISIZE) of every BGZF block of `stream`; checks the fixed header bytes"""
     out, at = [], 0

@@ -250,6 +250,48 @@ def write_fasta(path, names, contigs, rng):
     return meta, loaded
 
 
+def plan_bins(lengths, bin_bases):
+    """host/isaac_align.cpp: planBins -- ([(first, end) ReferencePosition values of every bin with positions], [cut positions inside contigs])"""
+    bin_bases = int(min(1e15, bin_bases))
+    bin_bases = max(2048, -(-bin_bases // 2048) * 2048)
+    ranges, cuts, filled = [], [], 0
+    for c, length in enumerate(lengths):
+        if length > bin_bases + bin_bases // 2:
+            pieces = -(-length // bin_bases)
+            stretch = -(-(-(-length // pieces)) // 2048) * 2048
+            for at in range(0, length, stretch):
+                if at:
+                    cuts.append(bam.reference_position(c, at))
+                ranges.append((bam.reference_position(c, at), bam.reference_position(c, at + stretch) if at + stretch < length else bam.reference_position(c + 1, 0)))
+            filled = 0
+            continue
+        if not filled or filled + length > bin_bases:
+            ranges.append((bam.reference_position(c, 0), bam.reference_position(c + 1, 0))); filled = 0
+        else:
+            ranges[-1] = (ranges[-1][0], bam.reference_position(c + 1, 0))
+        filled += max(length, 1)
+    return ranges, cuts
+
+
+def split_by_bins(record_bytes, unaligned_offset, bin_ranges):
+    """[(offset, bytes)] of the records of every bin that has some, then of the unaligned ones: the runs of BGZF blocks of the file"""
+    data = memoryview(record_bytes)
+    parts, at, b = [], 0, 0
+    while at < unaligned_offset:
+        ref_id, pos = int.from_bytes(data[at + 4:at + 8], "little"), int.from_bytes(data[at + 8:at + 12], "little")
+        key = bam.reference_position(ref_id, pos)
+        while not (bin_ranges[b][0] <= key < bin_ranges[b][1]):
+            b += 1
+        if not parts or parts[-1][2] != b:
+            parts.append([at, 0, b])
+        size = 4 + int.from_bytes(data[at:at + 4], "little")
+        parts[-1][1] += size; at += size
+    parts = [(p[0], p[1]) for p in parts]
+    if unaligned_offset < len(data):
+        parts.append((unaligned_offset, len(data) - unaligned_offset))
+    return parts
+
+
 SCENARIOS = {
     # the reference's defaults: y*n mask (101 -> 100 cycles), duplicates marked, gaps realigned, unaligned records at the back
     "defaults": dict(compressed=False, lengths=(100, 100), cli=[], paired=True, mark=True, keep=True, realign=True, unaligned="back", dodgy=0, pu="%s:%d:none"),
@@ -264,6 +306,16 @@ SCENARIOS = {
     # the bins' parts through host memory (what a run too large for the device's memory does), two workers
     "host-bins": dict(compressed=False, lengths=(100, 100), cli=["--devices", "0,0"], paired=True, mark=True, keep=True, realign=True, unaligned="back", dodgy=0, pu="%s:%d:none",
                       env={"ISAAC_ALIGN_HOST_BINS": "1"}),
+    # what two devices do, on one: the second worker's table is a copy (ISAAC_GPU_SHARE_BY_COPY) and each worker treats the other's blocks of bin parts as
+    # another device's (ISAAC_ALIGN_STRANGERS): isaac_gpu_share_index's copy branch and the fetch of foreign parts in the build stage
+    "strangers": dict(compressed=False, lengths=(100, 100), cli=["--devices", "0,0"], paired=True, mark=True, keep=True, realign=True, unaligned="back", dodgy=0, pu="%s:%d:none",
+                      env={"ISAAC_ALIGN_STRANGERS": "1", "ISAAC_GPU_SHARE_BY_COPY": "1"}),
+    # the loads' BCL bytes wait in host memory for their selection (what a run does whose base calls do not fit the device beside the table)
+    "host-loads": dict(compressed=False, lengths=(100, 100), cli=[], paired=True, mark=True, keep=True, realign=True, unaligned="back", dodgy=0, pu="%s:%d:none",
+                       env={"ISAAC_ALIGN_HOST_LOADS": "1"}, tiles_on_device=True),
+    # bins of about 6 000 records: every contig is cut into several bins, each sorted, filtered and realigned by itself (the oracle with the same cuts)
+    "cut-bins": dict(compressed=False, lengths=(100, 100), cli=["--bin-records", "6000", "--devices", "0,0"], paired=True, mark=True, keep=True, realign=True, unaligned="back", dodgy=0,
+                     pu="%s:%d:none", bin_records=6000),
     # single-ended lanes, unaligned reads left out
     # ... on a reference made by bin/isaac-sort-reference from the FASTA file
     "single-ended": dict(compressed=True, lengths=(100,), cli=["--keep-unaligned", "discard"], paired=False, mark=True, keep=True, realign=True, unaligned="discard", dodgy=0, pu="%s:%d:none",
@@ -352,8 +404,18 @@ def test_gpu_isaac_align_end_to_end(tmp_path, scenario):
     r = run_host(*args, env=sc.get("env"))
     assert r.returncode == 0, r.stderr
     assert not (tmp_path / "Temp").exists()
-    kept = json.loads([l for l in r.stderr.splitlines() if "timing {" in l][-1].split("timing ", 1)[1])["tiles_kept_on_device"]
-    assert kept == (0 if sc.get("env") else sum(-(-len(bcl) // at_a_time) for _, bcl in lanes))        # every tile's parts stayed on the device, or none did
+    timing = json.loads([l for l in r.stderr.splitlines() if "timing {" in l][-1].split("timing ", 1)[1])
+    n_tiles = sum(-(-len(bcl) // at_a_time) for _, bcl in lanes)
+    assert timing["tiles"] == n_tiles and timing["loads"] == n_tiles and timing["overflow_clusters"] == 0
+    host_bins = "ISAAC_ALIGN_HOST_BINS" in sc.get("env", {})
+    assert timing["tiles_kept_on_device"] == (0 if host_bins else n_tiles)                              # every tile's parts stayed on the device, or none did
+    assert timing["loads_kept_on_device"] == (0 if "ISAAC_ALIGN_HOST_LOADS" in sc.get("env", {}) else n_tiles)
+    # the bins the host made (host/isaac_align.cpp: planBins): contigs in karyotype order, grouped or cut by the reads per base of the run
+    total_records = sum(len(b_) for _, b_ in lanes) * n_reads
+    ordered_lengths = [len(stored[i]) for i in sorted(range(3), key=lambda i: karyotype[i])]
+    bin_ranges, cuts = plan_bins(ordered_lengths, sc.get("bin_records", 8000000) / (total_records / sum(ordered_lengths)))
+    assert timing["bin_cuts"] == len(cuts) and timing["bins"] == len(bin_ranges) + 1
+    assert (len(cuts) > 6) if sc.get("bin_records") else (len(bin_ranges) == 1)
     # ---- the oracle on the same inputs
     b = gpu.Aligner(options.default_params(100, 100), 0, contigs)
     b.load_sorted_reference(xml)
@@ -387,7 +449,7 @@ def test_gpu_isaac_align_end_to_end(tmp_path, scenario):
         orec, ocig, _ = ref.select(params, tile_bcl, om, tls, all_hits, tile=index, n_clusters_hint=len(tile_bcl))
         host_tiles.append((tile_bcl, orec, ocig, "FCTEST:%d:%d:" % (lane, number), str(lane_index), tls))
     want, want_n, want_unaligned = o.bam_records(host_tiles, list(lengths), forced_dodgy_alignment_score=sc["dodgy"] & 0xff, mark_duplicates=sc["mark"], keep_duplicates=sc["keep"],
-                                                 realign_gaps=sc["realign"], reference=ref)
+                                                 realign_gaps=sc["realign"], reference=ref, bin_cuts=cuts)
     recs = bam.parse_records(want)
     print("oracle: %d records, %d unmapped, %d with gaps in the CIGAR, %d realigned, tiles %s" % (
         len(recs), sum(1 for x in recs if x["flag"] & 4), sum(1 for x in recs if any((int(w) & 15) in (1, 2) for w in x["cigar"])), sum(1 for x in recs if "OC" in x["tags"]),
@@ -403,8 +465,8 @@ def test_gpu_isaac_align_end_to_end(tmp_path, scenario):
     header = o.bam_header(" ".join([host()] + args), "isaac_aligner_amd-0.3", sq, description="cli test",
                           header_lines=["@CO\tend to end"] + ["@RG\tID:%d\tPL:ILLUMINA\tSM:default\tPU:%s" % (k, sc["pu"] % ("FCTEST", lane)) for k, (lane, _) in enumerate(lanes)])
     # ---- the files: the header, a BGZF run per contig and one for the unaligned records (first with --keep-unaligned front), the empty block
-    cuts = bam.split_parts(want, want_unaligned)
-    if sc["unaligned"] == "front":
+    cuts = split_by_bins(want, want_unaligned, bin_ranges)
+    if sc["unaligned"] == "front" and want_unaligned < len(want):
         cuts = cuts[-1:] + cuts[:-1]
     expected = b"".join(want[off:off + size] for off, size in cuts)
     path = out / "Projects" / "default" / "default" / "sorted.bam"

@@ -242,7 +242,8 @@ def test_index_invariants_at_full_size(torch, human):
     """what must hold for the 2.9 G-entry table whatever built it: global (k-mer, position) order, the mask cuts, entry count against the
     reference's own count of forward 32-mers, TooManyMatch entries single"""
     al, genome, n = human["al"], human["genome"], human["n"]
-    kmers, positions = al.index_tensors()
+    entries = al.index_tensors()
+    kmers, positions = entries[:, 0], entries[:, 1]                       # (strided views of the interleaved table)
     assert kmers.numel() == n == positions.numel()
     cuts = al.mask_offsets()
     assert cuts[0] == 0 and cuts[-1] == n
@@ -293,7 +294,8 @@ def test_index_entries_against_a_brute_force_scan(torch, human):
     right places, all carrying the neighbour bit the scan found."""
     al, genome, n = human["al"], human["genome"], human["n"]
     dev = genome.bases.device
-    kmers, positions = al.index_tensors()
+    entries = al.index_tensors()
+    kmers, positions = entries[:, 0], entries[:, 1]
     g = torch.Generator(device=dev).manual_seed(99)
     n_positions = int(os.environ.get("ISAAC_SCALE_SCAN_SAMPLES", 12288))
     total = genome.offsets[-1]

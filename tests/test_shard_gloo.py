@@ -153,9 +153,9 @@ def _broadcast_table_worker(rank, world, port, result_path):
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     try:
         rng = np.random.default_rng(9)
-        want_k, want_p = torch.from_numpy(np.sort(rng.integers(0, 1 << 62, 100003))), torch.from_numpy(rng.integers(0, 1 << 62, 100003))
-        k, p = shard.broadcast_table(want_k if rank == 0 else None, want_p if rank == 0 else None, dist, rank, chunk=4096)      # 25 pieces per array
-        assert k.dtype == torch.int64 and (k == want_k).all() and (p == want_p).all()
+        want = torch.from_numpy(np.stack([np.sort(rng.integers(0, 1 << 62, 100003)), rng.integers(0, 1 << 62, 100003)], axis=1).copy())
+        got = shard.broadcast_table(want if rank == 0 else None, dist, rank, chunk=4096)      # 25 pieces
+        assert got.dtype == torch.int64 and got.shape == want.shape and (got == want).all()
         if rank == 1:
             open(result_path, "w").write("ok")
     finally:
@@ -163,10 +163,10 @@ def _broadcast_table_worker(rank, world, port, result_path):
 
 
 def test_table_broadcast_from_rank_0(tmp_path):
-    """shard.broadcast_table (bench.py --broadcast-index: one index build, the two arrays of the table sent to the other ranks in pieces)"""
+    """shard.broadcast_table (bench.py --broadcast-index: one index build, the table sent to the other ranks in pieces)"""
     result = str(tmp_path / "result")
     mp.spawn(_broadcast_table_worker, args=(2, _free_port(), result), nprocs=2, join=True)
     assert open(result).read() == "ok"
     from isaac_aligner_amd import shard
-    k = torch.arange(5)
-    assert shard.broadcast_table(k, k, None, 0)[0] is k
+    k = torch.arange(10).view(5, 2)
+    assert shard.broadcast_table(k, None, 0) is k
