@@ -440,52 +440,80 @@ def main():
         host_rec = [torch.empty(o_[0].shape, dtype=torch.uint8).pin_memory() for o_ in out]
         host_cig = [torch.empty(p_.shape, dtype=torch.int32).pin_memory() for p_ in packed]
         copy_stream = torch.cuda.Stream(dev)
+        # the lookups get a context (and stream) of their own, so that the lookup of a later step does not queue behind a selection
+        finder_stream = torch.cuda.Stream(dev)
+        with torch.cuda.stream(finder_stream):
+            finder = gpu.Aligner(params, local_rank, genome, deferred_completion=True)
+            finder.set_index_tensors(al.index_tensors())
+            finder.find_matches(batches[0])                # warm-up: its staging buffers
         torch.cuda.synchronize()
         tp = time.perf_counter()
-        found = []
         dev_in = []
         for s in range(args.steps):
             with torch.cuda.stream(copy_stream):          # uploads run ahead of the lookups on their own stream
                 d = host_in[s].to(dev, non_blocking=True)
                 ev = torch.cuda.Event(); ev.record(copy_stream)
             dev_in.append((d, ev))
-        for s in range(args.steps):
-            d, ev = dev_in[s]
-            torch.cuda.current_stream(dev).wait_event(ev)
-            m, o, hits = al.find_matches(d, tile=tile_of(s), out=match_bufs[s])
-            found.append((m, o))
         host_n = [torch.zeros(1, dtype=torch.int64).pin_memory() for _ in range(args.steps)]
         left = [None] * args.steps
 
         def download_cigars(k):
-            left[k].synchronize()                         # step k is complete (the step after it is queued already: the GPU stays busy)
+            left[k].synchronize()                         # step k is complete (the steps after it are queued already: the GPU stays busy)
             n_k = int(host_n[k].item())
             with torch.cuda.stream(copy_stream):
                 host_cig[k][:n_k].copy_(out[k][2][:n_k], non_blocking=True)
-        for s in range(args.steps):
-            m, o = found[s]
-            ctx = als[s % n_contexts]                     # the selections dealt to the contexts in turn, as in the timed region
-            ctx.select(dev_in[s][0], m, o, tls, tile=tile_of(s), out=out[s][:2])
-            ctx.compact_cigars_async(out[s][0], out[s][1], out[s][2], out[s][3])
-            done = (streams[s % n_contexts] if ctx is not al else torch.cuda.current_stream(dev)).record_event()
-            if s >= n_contexts:
-                download_cigars(s - n_contexts)           # the step this context did before: complete by now, or soon; the other contexts keep the GPU busy
+
+        def select_step(k):
+            m, o = found_p[k]
+            ctx = als[k % n_contexts]                     # the selections dealt to the contexts in turn, as in the timed region
+            ctx_stream = streams[k % n_contexts] if ctx is not al else torch.cuda.current_stream(dev)
+            ctx_stream.wait_event(looked_up[k])
+            ctx.select(dev_in[k][0], m, o, tls, tile=tile_of(k), out=out[k][:2])
+            ctx.compact_cigars_async(out[k][0], out[k][1], out[k][2], out[k][3])
+            done = ctx_stream.record_event()
+            if k >= n_contexts:
+                download_cigars(k - n_contexts)           # the step this context did before: complete by now, or soon; the other contexts keep the GPU busy
             with torch.cuda.stream(copy_stream):          # the step's records and the length of its CIGAR pool leave as soon as they are final
                 copy_stream.wait_event(done)
-                host_rec[s].copy_(out[s][0], non_blocking=True)
-                host_n[s].copy_(out[s][3], non_blocking=True)
-                left[s] = torch.cuda.Event(); left[s].record(copy_stream)
+                host_rec[k].copy_(out[k][0], non_blocking=True)
+                host_n[k].copy_(out[k][3], non_blocking=True)
+                left[k] = torch.cuda.Event(); left[k].record(copy_stream)
+        # FindMatchesTransition comes before SelectMatchesTransition because the selection wants to know which contigs have matches anywhere in the run.
+        # Once every contig has one, no later lookup can change that set: from there on a step is selected as soon as it is looked up, and the uploads
+        # and lookups of the later steps run beside the selections of the earlier ones (a whole-genome run gets there with its first tile)
+        found_p, looked_up, hits_p, streaming, next_select, streaming_from = [], [], np.zeros(al.n_contigs, np.uint8), False, 0, None
+        for s in range(args.steps):
+            d, ev = dev_in[s]
+            with torch.cuda.stream(finder_stream):
+                finder_stream.wait_event(ev)
+                m, o, hits = finder.find_matches(d, tile=tile_of(s), out=match_bufs[s])
+                looked_up.append(finder_stream.record_event())
+            found_p.append((m, o))
+            hits_p |= hits
+            if not streaming and hits_p.all():
+                streaming, streaming_from = True, s
+                for ctx in als:
+                    ctx.set_loaded_contigs(hits_p)
+            while streaming and next_select <= s:
+                select_step(next_select); next_select += 1
+        if not streaming:
+            for ctx in als:
+                ctx.set_loaded_contigs(hits_p)
+        while next_select < args.steps:
+            select_step(next_select); next_select += 1
         for k in range(max(0, args.steps - n_contexts), args.steps):
             download_cigars(k)
         for ctx in als:
             ctx.synchronize()
         torch.cuda.synchronize()
         t_pcie = time.perf_counter() - tp
+        del finder
         same = bool((out[0][0] == checked_records).all()) and bool((out[0][2][:checked_cigars.numel()] == checked_cigars).all())
         pcie = {"reads_per_s": round(2.0 * pairs_rank / t_pcie, 1), "records_identical_to_resident_pass": same, "ms_per_step": round(1e3 * t_pcie / args.steps, 3),
                 "bytes_in_per_pair": 2 * L, "bytes_out_per_pair": round((sum(r.numel() for r in host_rec) + 4 * sum(int(p.numel()) for p in packed)) / pairs_rank, 1),
                 "contexts": n_contexts,
-                "note": "BCL bytes uploaded from pinned host memory ahead of the lookups; the selections dealt to the contexts in turn as in the timed region; a step's records + packed CIGARs are downloaded on a copy stream while the steps queued behind it compute"}
+                "selections_began_after_lookup_of_step": streaming_from,
+                "note": "BCL bytes uploaded from pinned host memory ahead of the lookups (a context and stream of their own); once every contig has a match -- after the first step's lookup here -- no later lookup can change the set of loaded contigs, and a step is selected as soon as it is looked up, the later steps' uploads and lookups running beside it; the selections dealt to the contexts in turn as in the timed region; a step's records + packed CIGARs are downloaded on a copy stream while the steps queued behind it compute"}
 
     # ---- the output side: all steps' records as one position-sorted BAM record stream, resident in HBM; reported beside `value`
     bam_info = None

@@ -267,6 +267,15 @@ int isaac_gpu_determine_tls(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t
 int isaac_gpu_select(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t n_clusters, uint32_t tile,
                      const isaac_match *matches_dev, const uint64_t *cluster_offsets_dev, const isaac_tls *tls,
                      isaac_fragment *fragments_dev, uint32_t *cigar_dev, uint64_t cigar_capacity);
+/* The clusters of a selected tile whose MAPQ arithmetic came within 1e-11 of an integer on the device (isaac_fragment::reserved bit 3; isaac_counters::
+ * mapq_near_integer: a handful per million pairs) redone on the host with glibc's exp / log10 / floor, which is what the reference computes with
+ * (lib/alignment/TemplateBuilder.cpp:270-273,433-439): every such cluster goes through the thread-serial form of the path -- FragmentBuilder::build from its
+ * seed matches, TemplateBuilder::buildTemplate with its mate rescues, clippers, records -- and where a record or CIGAR differs from the device's, the device's
+ * is replaced in fragments_dev / cigar_dev.  To be called after isaac_gpu_select[_n] with the same arguments, before isaac_gpu_compact_cigars (cigar_dev in
+ * slots of ISAAC_GPU_MAX_CIGAR_OPS words).  *n_flagged_out: clusters looked at; *n_changed_out: clusters whose records were replaced (none has ever been
+ * seen to differ; a host that must be certain calls this).  The first call fetches the contigs back into host memory. */
+int isaac_gpu_resolve_flagged(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t n_clusters, uint32_t tile, const isaac_match *matches_dev, const uint64_t *cluster_offsets_dev,
+                              const isaac_tls *tls, isaac_fragment *fragments_dev, uint32_t *cigar_dev, uint64_t *n_flagged_out, uint64_t *n_changed_out);
 /* The same when the caller knows the tile's match count (*n_matches_out of isaac_gpu_find_matches): isaac_gpu_select reads it from
  * cluster_offsets_dev, which is a host wait for everything queued on the context's stream; with deferred completion this form queues its
  * work without one.  The count sizes the call's candidate pool (one slot per match): if it is smaller than the number of matches under

@@ -63,6 +63,8 @@ template <typename T> struct DevBuf
 struct KernelTimer { double ms = 0; uint64_t launches = 0; };
 } // namespace
 
+namespace isaac_host_resolve { struct Resolver; void destroy(Resolver *r); }      // resolve_host.cpp
+
 struct isaac_gpu_ctx
 {
     bool ownsStream = false; u32 cigarExtra = 32;
@@ -74,6 +76,7 @@ struct isaac_gpu_ctx
     DevBuf<TableEntry> entries; u64 nKmers = 0; DevBuf<u32> karyotype; bool hasKaryotype = false;
     const TableEntry *entriesBorrowed = nullptr;   // isaac_gpu_set_index_dev: a table owned by the caller (another context, an RCCL receive buffer)
     const TableEntry *tableEntries() const { return entriesBorrowed ? entriesBorrowed : entries.p; }
+    DevBuf<u32> flaggedList; std::vector<char> hostBases; isaac_host_resolve::Resolver *resolver = nullptr; std::vector<u8> resolverLoaded;      // isaac_gpu_resolve_flagged
     DevBuf<u32> prefixTable; u32 prefixBits = 0; std::vector<u64> maskOffsets;   // entries before each mask of the table (load_index / build_index)
     DevBuf<u32> packedBases, notBase;   // 2-bit copy of the contigs + not-ACGT bitmap (k_rescue_windows reads these)
     DevBuf<u64> matchBase;
@@ -256,6 +259,7 @@ __global__ __launch_bounds__(FIND_BLOCK) void k_find_matches(DevParams P, DevRef
                         lo = range.x; hi = range.y;
                     }
                     // ExactMaskMatcher.cpp:118-126: reference entries with the same k-mer, at most repeatThreshold of them.
+#if ISAAC_FIND_SLICE
                     if (hi - lo <= FIND_SLICE)
                     {   // The usual slice (the directory has about as many buckets as the table has entries): all of it asked for at once -- k-mers and
                         // positions, 16 bytes an entry as the mask files hold them -- and searched in registers: one round trip where the bisection, the
@@ -277,6 +281,7 @@ __global__ __launch_bounds__(FIND_BLOCK) void k_find_matches(DevParams P, DevRef
                         if (!r) pos0 = 0;
                     }
                     else
+#endif
                     {
                         first = lowerBound(R.entries, lo, hi, kmer, steps);
                         // the first two entries behind the bisection together: most hits are single entries
@@ -628,6 +633,7 @@ void isaac_gpu_destroy(isaac_gpu_ctx *c)
 #endif
     for (hipEvent_t e : c->eventPool) hipEventDestroy(e);
     if (c->ownsStream) hipStreamDestroy(c->stream);
+    if (c->resolver) isaac_host_resolve::destroy(c->resolver);
     delete c;
 }
 
@@ -784,7 +790,7 @@ int isaac_gpu_load_index(isaac_gpu_ctx *c, const isaac_reference_kmer *const *ma
     }
     const u32 SLOTS = 6;
     // (ISAAC_GPU_LOAD_THREADS: measurement aid)
-    const u32 FILLERS = std::getenv("ISAAC_GPU_LOAD_THREADS") ? std::max(1, std::atoi(std::getenv("ISAAC_GPU_LOAD_THREADS"))) : 8;
+    const u32 FILLERS = std::getenv("ISAAC_GPU_LOAD_THREADS") ? std::max(1, std::atoi(std::getenv("ISAAC_GPU_LOAD_THREADS"))) : 16;
     DevBuf<u32> disorder; disorder.reserve(1);
     HIP_CHECK(hipMemsetAsync(disorder.p, 0, 4, st));
     hipStream_t copyStream; HIP_CHECK(hipStreamCreateWithFlags(&copyStream, hipStreamNonBlocking));
@@ -1563,6 +1569,99 @@ int isaac_gpu_select_candidates(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t n
 }
 
 } // extern "C"
+// ---- isaac_gpu_resolve_flagged: the clusters whose MAPQ arithmetic came within 1e-11 of an integer, redone on the host with glibc (resolve_host.cpp)
+namespace isaac_host_resolve
+{
+struct Resolver;
+Resolver *create(const isaac_params &params, const char *bases, const u64 *contigOffset, const u8 *contigLoaded, u32 nContigs);
+void destroy(Resolver *r);
+void selectCluster(Resolver *r, const isaac_tls &tls, const u8 *clusterBcl, u32 cluster, u32 tile, const Match *matches, u32 nMatches, FragmentRecord *records, u32 *cigars);
+}
+// the clusters of a tile with RECORD_MAPQ_NEAR_INTEGER on their first record, in any order
+__global__ void k_flagged_clusters(const FragmentRecord *records, u32 nClusters, u32 nReads, u32 *list, u32 capacity, u32 *count)
+{
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nClusters || !(records[u64(c) * nReads].reserved & RECORD_MAPQ_NEAR_INTEGER)) return;
+    const u32 at = atomicAdd(count, 1u);
+    if (at < capacity) list[at] = c;
+}
+extern "C" int isaac_gpu_resolve_flagged(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, uint32_t tile, const isaac_match *matches, const uint64_t *offsets, const isaac_tls *tls,
+                                         isaac_fragment *fragments, uint32_t *cigar, uint64_t *nFlaggedOut, uint64_t *nChangedOut)
+{
+    ISAAC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    if (nFlaggedOut) *nFlaggedOut = 0;
+    if (nChangedOut) *nChangedOut = 0;
+    if (!nClusters) return 0;
+    if (!bcl || !matches || !offsets || !tls || !fragments || !cigar) return fail(ISAAC_GPU_EINVAL, "bcl_dev, matches_dev, cluster_offsets_dev, tls, fragments_dev and cigar_dev are required");
+    hipStream_t st = c->stream;
+    const u32 nReads = c->P.nReads, clusterLength = c->P.clusterLength;
+    const u32 capacity = 1u << 16;
+    c->flaggedList.reserve(capacity + 1);
+    HIP_CHECK(hipMemsetAsync(c->flaggedList.p + capacity, 0, 4, st));
+    FragmentRecord *records = reinterpret_cast<FragmentRecord *>(fragments);
+    k_flagged_clusters<<<gridFor(nClusters, 256), 256, 0, st>>>(records, nClusters, nReads, c->flaggedList.p, capacity, c->flaggedList.p + capacity);
+    HIP_CHECK(hipGetLastError());
+    u32 n = 0;
+    HIP_CHECK(hipMemcpyAsync(&n, c->flaggedList.p + capacity, 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (nFlaggedOut) *nFlaggedOut = n;
+    if (!n) return 0;
+    if (n > capacity) return fail(ISAAC_GPU_ECAPACITY, "more than 65536 flagged clusters in one tile");
+    std::vector<u32> list(n);
+    HIP_CHECK(hipMemcpy(list.data(), c->flaggedList.p, n * 4, hipMemcpyDeviceToHost));
+    std::sort(list.begin(), list.end());
+    // the host's copy of the contigs: fetched once, when the first flagged cluster turns up
+    if (c->hostBases.empty() && c->hContigOffset[c->nContigs])
+    {
+        c->hostBases.resize(c->hContigOffset[c->nContigs]);
+        HIP_CHECK(hipMemcpy(c->hostBases.data(), c->bases, c->hostBases.size(), hipMemcpyDeviceToHost));
+    }
+    if (!c->resolver || c->resolverLoaded != c->hContigLoaded)
+    {   // (the rest-of-genome correction depends on which contigs count as loaded)
+        if (c->resolver) isaac_host_resolve::destroy(c->resolver);
+        c->resolverLoaded = c->hContigLoaded;
+        c->resolver = isaac_host_resolve::create(c->params, c->hostBases.data(), c->hContigOffset.data(), c->resolverLoaded.data(), c->nContigs);
+    }
+    std::vector<u8> clusterBcl(clusterLength);
+    std::vector<Match> clusterMatches;
+    std::vector<FragmentRecord> was(nReads), now(nReads);
+    std::vector<u32> wasCigar(size_t(nReads) * OUT_CIGAR_CAP), nowCigar(size_t(nReads) * OUT_CIGAR_CAP);
+    u64 changed = 0;
+    for (const u32 cluster : list)
+    {
+        u64 range[2];
+        HIP_CHECK(hipMemcpy(range, offsets + cluster, 16, hipMemcpyDeviceToHost));
+        const u64 first = range[0], nMatches = range[1] - range[0];
+        clusterMatches.resize(nMatches + 1);
+        if (nMatches) HIP_CHECK(hipMemcpy(clusterMatches.data(), reinterpret_cast<const Match *>(matches) + first, nMatches * sizeof(Match), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(clusterBcl.data(), bcl + u64(cluster) * clusterLength, clusterLength, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(was.data(), records + u64(cluster) * nReads, nReads * sizeof(FragmentRecord), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(wasCigar.data(), cigar + u64(cluster) * nReads * OUT_CIGAR_CAP, wasCigar.size() * 4, hipMemcpyDeviceToHost));
+        std::fill(nowCigar.begin(), nowCigar.end(), 0u);
+        isaac_host_resolve::selectCluster(c->resolver, *tls, clusterBcl.data(), cluster, tile, clusterMatches.data(), u32(nMatches), now.data(), nowCigar.data());
+        bool differs = false;
+        for (u32 r = 0; r < nReads; ++r)
+        {
+            FragmentRecord a = was[r], b = now[r];
+            // the diagnostic bits apart (the host form does not flag): everything the record says, and its CIGAR
+            b.reserved = (b.reserved & 0xffff0000u) | (a.reserved & 0xffffu) | (b.reserved & (RECORD_NOT_STORED | RECORD_FRAGMENT_OVERFLOW));
+            a.reserved = (a.reserved & ~u32(RECORD_NOT_STORED | RECORD_FRAGMENT_OVERFLOW)) | (a.reserved & (RECORD_NOT_STORED | RECORD_FRAGMENT_OVERFLOW));
+            now[r] = b;
+            if (std::memcmp(&a, &b, sizeof(a))) differs = true;
+            const u32 *ca = wasCigar.data() + (a.cigarOffset - u64(cluster) * nReads * OUT_CIGAR_CAP), *cb = nowCigar.data() + (b.cigarOffset - u64(cluster) * nReads * OUT_CIGAR_CAP);
+            if (a.cigarLength == b.cigarLength && std::memcmp(ca, cb, size_t(a.cigarLength) * 4)) differs = true;
+        }
+        if (!differs) continue;
+        ++changed;
+        HIP_CHECK(hipMemcpy(records + u64(cluster) * nReads, now.data(), nReads * sizeof(FragmentRecord), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(cigar + u64(cluster) * nReads * OUT_CIGAR_CAP, nowCigar.data(), nowCigar.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (nChangedOut) *nChangedOut = changed;
+    return 0;
+    ISAAC_CATCH
+}
+
 // the CIGARs of a tile's records packed back to back (isaac_gpu_compact_cigars)
 __global__ void k_cigar_lengths(const FragmentRecord *records, u64 n, u32 *lengths)
 {

@@ -25,8 +25,11 @@
 #include <iostream>
 #include <map>
 #include <memory>
+#include <set>
 #include <sstream>
 #include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
@@ -326,18 +329,70 @@ struct Worker
     uint64_t matchCapacity = 0;
     std::vector<uint8_t> contigHasMatches;
     isaac_counters counters;
-    uint64_t tilesKeptOnDevice = 0, loadsKeptOnDevice = 0, peakDeviceBytes = 0;
+    uint64_t tilesKeptOnDevice = 0, loadsKeptOnDevice = 0, peakDeviceBytes = 0, mapqResolved = 0, mapqChanged = 0;
     double selectSeconds = 0, buildSeconds = 0, uploadSeconds = 0, recordsSeconds = 0, deflateSeconds = 0, downloadSeconds = 0;
     ~Worker() { matches.release(); offsets.release(); textDev.release(); if (ctx) isaac_gpu_destroy(ctx); }
     void noteMemory() { uint64_t f = 0, t = 0; if (!isaac_gpu_memory_info(ctx, &f, &t)) peakDeviceBytes = std::max(peakDeviceBytes, t - f); }
 };
 
-// what a bin of the file becomes: its BGZF blocks, and what the index wants to know about its records (buffers that are not cleared first:
-// they are gigabytes)
+// Page-locked host buffers handed round between the builders (which fill them from the device at the link's rate: into pageable memory the same copy runs
+// at a third of it) and the writer (which gives them back): pinning memory is slow, so the buffers are kept and grow to the largest request
+class PinnedPool
+{
+public:
+    struct Buffer { void *p = 0; uint64_t bytes = 0; };
+    ~PinnedPool() { for (Buffer &b : free_) if (b.p) isaac_gpu_host_free(b.p); }
+    Buffer take(uint64_t bytes)
+    {
+        Buffer best;
+        {
+            std::lock_guard<std::mutex> hold(lock_);
+            size_t at = free_.size();
+            for (size_t i = 0; i < free_.size(); ++i) if (free_[i].bytes >= bytes && (at == free_.size() || free_[i].bytes < free_[at].bytes)) at = i;
+            if (at == free_.size() && !free_.empty()) { at = 0; for (size_t i = 1; i < free_.size(); ++i) if (free_[i].bytes > free_[at].bytes) at = i; }      // the largest one is replaced
+            if (at < free_.size()) { best = free_[at]; free_.erase(free_.begin() + long(at)); }
+        }
+        if (best.bytes < bytes)
+        {
+            if (best.p) isaac_gpu_host_free(best.p);
+            best.bytes = bytes + bytes / 8 + 4096;
+            GPU(isaac_gpu_host_malloc(best.bytes, &best.p));
+        }
+        return best;
+    }
+    void give(Buffer b) { if (b.p) { std::lock_guard<std::mutex> hold(lock_); free_.push_back(b); } }
+private:
+    std::mutex lock_; std::vector<Buffer> free_;
+};
+// what a bin of the file becomes: its BGZF blocks, and what the index wants to know about its records
 struct BinOutput
 {
-    bool ready = false; std::unique_ptr<uint8_t[]> bgzf; std::unique_ptr<isaac_bam_index_entry[]> entries; uint64_t bgzfBytes = 0, recordsBytes = 0, nRecords = 0; std::string error;
+    bool ready = false; PinnedPool::Buffer bgzf, entries; uint64_t bgzfBytes = 0, recordsBytes = 0, nRecords = 0; std::string error;
 };
+
+// `bytes` at `offset` of the file, by a few threads side by side (one thread writes some 6 GB/s into the page cache)
+void writeAt(int fd, const uint8_t *data, uint64_t bytes, uint64_t offset)
+{
+    const unsigned threads = bytes >= (uint64_t(64) << 20) ? 8 : 1;
+    const uint64_t share = (bytes + threads - 1) / threads;
+    std::vector<int> failed(threads, 0);
+    const auto part = [&](unsigned t)
+    {
+        uint64_t done = std::min<uint64_t>(bytes, t * share);
+        const uint64_t end = std::min<uint64_t>(bytes, done + share);
+        while (done < end)
+        {
+            const ssize_t r = ::pwrite(fd, data + done, size_t(end - done), off_t(offset + done));
+            if (r < 0) { if (EINTR == errno) continue; failed[t] = errno ? errno : EIO; return; }
+            done += uint64_t(r);
+        }
+    };
+    std::vector<std::thread> workers;
+    for (unsigned t = 1; t < threads; ++t) workers.emplace_back(part, t);
+    part(0);
+    for (std::thread &w : workers) w.join();
+    for (int e : failed) if (e) throw std::runtime_error(std::string("Failed to write the BAM file: ") + std::strerror(e));
+}
 
 uint64_t hostResidentBytes()
 {   // VmHWM: the process's peak resident set
@@ -569,7 +624,7 @@ int run(const AlignOptions &o)
     // ---- the bins (see BinPart): sized for --bin-records records each, by the reads the run has per base of the reference
     std::vector<uint64_t> contigLengths;
     for (const isaac_reference_contig &c : reference.contigs) contigLengths.push_back(c.total_bases);
-    const uint64_t binRecords = o.binRecords ? o.binRecords : 8000000;
+    const uint64_t binRecords = o.binRecords ? o.binRecords : 4000000;
     const double recordsPerBase = double(totalClusters) * nReads / double(std::max<uint64_t>(1, reference.totalBases));
     const BinPlan plan = planBins(contigLengths, uint64_t(std::min(1e15, double(binRecords) / std::max(recordsPerBase, 1e-9))));
     const uint32_t nBins = uint32_t(plan.ranges.size()) + 1;
@@ -620,6 +675,17 @@ int run(const AlignOptions &o)
         }
         std::vector<std::string> errors(workers.size());
         const bool hostBins = 0 != std::getenv("ISAAC_ALIGN_HOST_BINS");          // tests: every part through host memory
+        std::set<unsigned> dumpTiles; std::string dumpDirectory;
+        if (const char *e = std::getenv("ISAAC_ALIGN_DUMP_TILES"))
+        {
+            const std::string spec(e);
+            const size_t colon = spec.rfind(':');
+            if (std::string::npos == colon) throw std::runtime_error("ISAAC_ALIGN_DUMP_TILES=<directory>:<tile index>,...");
+            dumpDirectory = spec.substr(0, colon);
+            std::stringstream list(spec.substr(colon + 1));
+            for (std::string item; std::getline(list, item, ','); ) if (!item.empty()) dumpTiles.insert(unsigned(std::stoul(item)));
+            makeDirectories(dumpDirectory);
+        }
         auto selectTiles = [&](Worker &w)
         {
             try
@@ -636,6 +702,13 @@ int run(const AlignOptions &o)
                     const uint64_t nRecords = uint64_t(t.clusters) * nReads;
                     GPU(isaac_gpu_select_n(w.ctx, bcl, t.clusters, t.index, w.matches.as<isaac_match>(), nMatches, w.offsets.as<uint64_t>(), &t.tls, records.as<isaac_fragment>(), slots.as<uint32_t>(),
                                            nRecords * ISAAC_GPU_MAX_CIGAR_OPS));
+                    // the handful of clusters per million whose MAPQ arithmetic came within 1e-11 of an integer on the device take glibc's answer
+                    {
+                        uint64_t flagged = 0, changed = 0;
+                        GPU(isaac_gpu_resolve_flagged(w.ctx, bcl, t.clusters, t.index, w.matches.as<isaac_match>(), w.offsets.as<uint64_t>(), &t.tls, records.as<isaac_fragment>(), slots.as<uint32_t>(),
+                                                      &flagged, &changed));
+                        w.mapqResolved += flagged; w.mapqChanged += changed;
+                    }
                     // the CIGARs as the bin files hold them: back to back
                     uint64_t words = 0;
                     if (packed.bytes() < nRecords * 8 * 4) packed.reset(w.ctx, nRecords * 8 * 4);
@@ -646,6 +719,24 @@ int run(const AlignOptions &o)
                         rc = isaac_gpu_compact_cigars(w.ctx, records.as<isaac_fragment>(), nRecords, slots.as<uint32_t>(), packed.as<uint32_t>(), packed.bytes() / 4, &words);
                     }
                     check(rc, "isaac_gpu_compact_cigars");
+                    if (dumpTiles.count(t.index))
+                    {   // ISAAC_ALIGN_DUMP_TILES=<directory>:<tile index>,...: the tile as it was selected -- BCL bytes, records, packed CIGAR words -- for a checker
+                        const std::string stem = dumpDirectory + "/tile_" + std::to_string(t.index);
+                        const auto dump = [&](const std::string &path, const void *dev, uint64_t bytes)
+                        {
+                            std::vector<uint8_t> host(bytes);
+                            if (bytes) GPU(isaac_gpu_download(w.ctx, host.data(), dev, bytes));
+                            std::ofstream os(path.c_str(), std::ios::binary | std::ios::trunc);
+                            if (!os.write(reinterpret_cast<const char *>(host.data()), std::streamsize(bytes))) throw std::runtime_error("Failed to write " + path);
+                        };
+                        dump(stem + ".bcl", bcl, uint64_t(t.clusters) * clusterLength);
+                        dump(stem + ".records", records.as<isaac_fragment>(), nRecords * sizeof(isaac_fragment));
+                        dump(stem + ".cigars", packed.as<uint32_t>(), words * 4);
+                        std::ofstream meta((stem + ".json").c_str());
+                        meta << "{\"index\": " << t.index << ", \"lane\": " << t.lane << ", \"number\": " << t.number << ", \"clusters\": " << t.clusters << ", \"read_group\": \"" << t.readGroup
+                             << "\", \"tls\": [" << t.tls.min << ", " << t.tls.max << ", " << t.tls.median << ", " << t.tls.low_std_dev << ", " << t.tls.high_std_dev << ", " << t.tls.best_model[0] << ", "
+                             << t.tls.best_model[1] << ", " << t.tls.stable << ", " << t.tls.mate_min << ", " << t.tls.mate_max << "]}" << std::endl;
+                    }
                     // BinningFragmentStorage: the tile's clusters to their bins
                     uint64_t need = 0;
                     const uint64_t guess = align64(uint64_t(t.clusters) * clusterLength + nRecords * sizeof(isaac_fragment) + words * 4) * 5 / 4 + 256 * uint64_t(nBins);
@@ -713,8 +804,8 @@ int run(const AlignOptions &o)
         // parts in tile order inside a bin, whichever worker was first
         for (Bin &bin : bins) std::sort(bin.parts.begin(), bin.parts.end(), [](const BinPart &a, const BinPart &b) { return a.tile->index < b.tile->index; });
     }
-    uint64_t overflowClusters = 0, mapqNearInteger = 0;
-    for (auto &w : workers) { overflowClusters += w->counters.overflow_clusters; mapqNearInteger += w->counters.mapq_near_integer; }
+    uint64_t overflowClusters = 0, mapqNearInteger = 0, mapqResolved = 0, mapqChanged = 0;
+    for (auto &w : workers) { overflowClusters += w->counters.overflow_clusters; mapqNearInteger += w->counters.mapq_near_integer; mapqResolved += w->mapqResolved; mapqChanged += w->mapqChanged; }
     const double selectSeconds = seconds() - selectStart;
 
     // ---- build::Build: one bin at a time -- records, duplicates, realignment, BAM records, BGZF blocks on the device -- the file and its index
@@ -767,6 +858,7 @@ int run(const AlignOptions &o)
     for (uint32_t b = 0; b + 1 < nBins; ++b) fileOrder.push_back(b);
     if ("front" != o.keepUnaligned) fileOrder.push_back(nBins - 1);
     std::vector<BinOutput> outputs(fileOrder.size());
+    PinnedPool pinned;
     std::mutex outputLock; std::condition_variable outputReady, outputTaken;
     std::atomic<size_t> nextBin(0);
     size_t binsWrittenSoFar = 0;                        // (under outputLock) the builders stay at most this far ahead of the file: finished bins wait in host memory
@@ -848,10 +940,10 @@ int run(const AlignOptions &o)
                         if (o.bamGzipLevel) GPU(isaac_gpu_bgzf_deflate(w.ctx, bam.as<uint8_t>(), nBytes, 0, bgzf.as<uint8_t>(), bgzf.bytes(), &nOut));
                         else GPU(isaac_gpu_bgzf_store(w.ctx, bam.as<uint8_t>(), nBytes, 0, bgzf.as<uint8_t>(), bgzf.bytes(), &nOut));
                         lap(w.deflateSeconds);
-                        result.bgzf.reset(new uint8_t[nOut]); result.bgzfBytes = nOut; result.recordsBytes = nBytes;
-                        result.entries.reset(new isaac_bam_index_entry[result.nRecords]);
-                        GPU(isaac_gpu_download(w.ctx, result.bgzf.get(), bgzf.as<uint8_t>(), nOut));
-                        GPU(isaac_gpu_download(w.ctx, result.entries.get(), entries.as<isaac_bam_index_entry>(), result.nRecords * sizeof(isaac_bam_index_entry)));      // for the index
+                        result.bgzf = pinned.take(nOut); result.bgzfBytes = nOut; result.recordsBytes = nBytes;
+                        result.entries = pinned.take(result.nRecords * sizeof(isaac_bam_index_entry));
+                        GPU(isaac_gpu_download(w.ctx, result.bgzf.p, bgzf.as<uint8_t>(), nOut));
+                        GPU(isaac_gpu_download(w.ctx, result.entries.p, entries.as<isaac_bam_index_entry>(), result.nRecords * sizeof(isaac_bam_index_entry)));      // for the index
                         lap(w.downloadSeconds);
                     }
                     w.noteMemory();
@@ -875,9 +967,11 @@ int run(const AlignOptions &o)
     double writeSeconds = 0;
     std::string failure;
     {
-        std::ofstream os(bamPath.c_str(), std::ios::binary | std::ios::trunc);
-        if (!os) failure = "Failed to open output BAM file " + bamPath;
-        os.write(reinterpret_cast<const char *>(headerBgzf.data()), std::streamsize(headerBgzf.size()));
+        const int fd = ::open(bamPath.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+        if (fd < 0) failure = "Failed to open output BAM file " + bamPath;
+        uint64_t fileAt = 0;
+        const auto append = [&](const uint8_t *data, uint64_t bytes) { if (fd >= 0 && bytes) { writeAt(fd, data, bytes, fileAt); fileAt += bytes; } };
+        try { append(headerBgzf.data(), headerBgzf.size()); } catch (const std::exception &e) { failure = e.what(); }
         isaac_bam_indexer *indexer = isaac_gpu_bam_indexer_create(nContigs, headerBgzf.size());
         for (size_t k = 0; k < outputs.size(); ++k)
         {
@@ -890,16 +984,20 @@ int run(const AlignOptions &o)
             }
             outputTaken.notify_all();
             if (!out.error.empty() && failure.empty()) failure = out.error;
-            if (!failure.empty() || !out.bgzfBytes) continue;
-            const double writeStart = seconds();
-            os.write(reinterpret_cast<const char *>(out.bgzf.get()), std::streamsize(out.bgzfBytes));
-            writeSeconds += seconds() - writeStart;
-            if (isaac_gpu_bam_indexer_add_entries(indexer, out.entries.get(), out.nRecords, out.recordsBytes, out.bgzf.get(), out.bgzfBytes)) failure = std::string("isaac_gpu_bam_indexer_add_entries: ") + isaac_gpu_bam_index_last_error();
-            nRecordsWritten += out.nRecords; ++binsWritten;
+            if (failure.empty() && out.bgzfBytes)
+            {
+                const double writeStart = seconds();
+                try { append(static_cast<const uint8_t *>(out.bgzf.p), out.bgzfBytes); } catch (const std::exception &e) { failure = e.what(); }
+                writeSeconds += seconds() - writeStart;
+                if (failure.empty() && isaac_gpu_bam_indexer_add_entries(indexer, static_cast<const isaac_bam_index_entry *>(out.entries.p), out.nRecords, out.recordsBytes, static_cast<const uint8_t *>(out.bgzf.p), out.bgzfBytes))
+                    failure = std::string("isaac_gpu_bam_indexer_add_entries: ") + isaac_gpu_bam_index_last_error();
+                nRecordsWritten += out.nRecords; ++binsWritten;
+            }
+            pinned.give(out.bgzf); pinned.give(out.entries);
         }
         for (std::thread &t : builders) t.join();
-        os.write(reinterpret_cast<const char *>(eofBlock.data()), std::streamsize(eofBlock.size()));
-        if (failure.empty() && !os) failure = "Failed to write " + bamPath;
+        if (failure.empty()) try { append(eofBlock.data(), eofBlock.size()); } catch (const std::exception &e) { failure = e.what(); }
+        if (fd >= 0 && ::close(fd) && failure.empty()) failure = "Failed to write " + bamPath;
         if (failure.empty())
         {
             uint64_t baiBytes = 0;
@@ -926,7 +1024,7 @@ int run(const AlignOptions &o)
               << ", \"tiles_kept_on_device\": " << tilesOnDevice << ", \"tiles\": " << tiles.size() << ", \"loads_kept_on_device\": " << loadsOnDevice << ", \"loads\": " << nLoads << ", \"bins\": " << nBins << ", \"bin_cuts\": " << plan.cuts.size()
               << ", \"build_upload_s\": " << workers[0]->uploadSeconds << ", \"build_records_s\": " << workers[0]->recordsSeconds << ", \"build_deflate_s\": " << workers[0]->deflateSeconds
               << ", \"build_download_s\": " << workers[0]->downloadSeconds << ", \"file_write_s\": " << writeSeconds
-              << ", \"overflow_clusters\": " << overflowClusters << ", \"mapq_near_integer\": " << mapqNearInteger
+              << ", \"overflow_clusters\": " << overflowClusters << ", \"mapq_near_integer\": " << mapqNearInteger << ", \"mapq_resolved_on_host\": " << mapqResolved << ", \"mapq_changed_by_host\": " << mapqChanged
               << ", \"peak_device_bytes\": " << peakDevice << ", \"peak_host_bytes\": " << hostResidentBytes()
               << ", \"total_s\": " << total << "}" << std::endl;
     if (overflowClusters)

@@ -1,0 +1,57 @@
+"""Run with ISAAC_GPU_LIBRARY pointing at the -DISAAC_TEST_MAPQ_SKEW build: that library calls a twentieth of all MAPQ arguments "near an integer" and gets every
+one of them wrong by one on the device.  isaac_gpu_resolve_flagged must put every such cluster right: it redoes the flagged clusters on the host with glibc --
+FragmentBuilder::build from the seed matches, the template with its mate rescues, clippers, records -- and replaces what differs.  Before the call the device's
+records differ from the oracle's in the flagged clusters and nowhere else; after it they are the oracle's.  (A process of its own: the product library is loaded once
+per process.)"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+import oracle_lib                                                        # noqa: E402
+from isaac_aligner_amd import gpu, options, synth                        # noqa: E402
+from parity_util import compare_records                                  # noqa: E402
+
+n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+g = synth.make_human_like_genome(6_000_000, seed=21)
+contigs = [bytes(c.numpy()) for c in g.contigs]
+bcl = synth.make_read_pairs(g, n_pairs, 150, seed=23, avoid_gaps=True)[0]
+p = options.default_params(150, 150)
+al = gpu.Aligner(p, 0, contigs)
+al.build_index()
+dev_bcl = bcl.cuda()
+m, o, hits = al.find_matches(dev_bcl, tile=3)
+al.set_loaded_contigs(hits)
+tls = al.determine_tls(dev_bcl, m, o, tile=3)
+records, cigars = al.select(dev_bcl, m, o, tls, tile=3)
+orc = oracle_lib.load()
+ref = orc.reference(contigs)
+ref.set_index(al.get_index())
+host = bcl.numpy()
+om, ohits = ref.find_matches(p, host, n_pairs, tile=3)
+otls = oracle_lib.Tls()
+for name in ("min", "max", "median", "low_std_dev", "high_std_dev", "stable", "mate_min", "mate_max"):
+    setattr(otls, name, getattr(tls, name))
+otls.best_model[0], otls.best_model[1] = tls.best_model[0], tls.best_model[1]
+orec, ocig, _ = ref.select(p, host, om, otls, ohits, tile=3, n_threads=8, n_clusters_hint=n_pairs)
+
+rec, cig = al.records_to_numpy(records, cigars)
+flagged = (rec["reserved"][0::2] & 8) != 0
+wrong = np.zeros(n_pairs, bool)
+for f in rec.dtype.names:
+    if f not in ("cigar_offset", "reserved"):
+        wrong |= (rec[f] != orec[f]).reshape(-1, 2).any(axis=1)
+print("before: %d clusters flagged, %d differ from the oracle, %d of those not flagged" % (flagged.sum(), wrong.sum(), (wrong & ~flagged).sum()))
+ok = flagged.sum() > n_pairs // 100 and wrong.sum() > flagged.sum() // 4 and not (wrong & ~flagged).any()
+n_flagged, n_changed = al.resolve_flagged(dev_bcl, m, o, tls, records, cigars, tile=3)
+rec, cig = al.records_to_numpy(records, cigars)
+diffs = compare_records(orec, ocig, rec, cig)
+print("resolve_flagged: %d looked at, %d replaced; differences from the oracle afterwards: %d" % (n_flagged, n_changed, len(diffs)))
+for d in diffs[:3]:
+    print(d)
+ok = ok and n_flagged == flagged.sum() and n_changed >= wrong.sum() and not diffs
+sys.exit(0 if ok else 1)

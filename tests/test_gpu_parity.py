@@ -481,6 +481,21 @@ def test_residual_pass_on_most_clusters(torch):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_flagged_clusters_are_resolved_on_the_host(torch):
+    """isaac_gpu_resolve_flagged on the -DISAAC_TEST_MAPQ_SKEW build of the library (made by __graft_entry__.build()), whose device code flags a twentieth of all
+    MAPQ values as 'near an integer' and gets each of them wrong by one: the flagged clusters are redone on the host with glibc and replaced, after which the
+    records are the oracle's (tests/mapq_skew_check.py, a process of its own).  With the product build the same call finds the handful of clusters per million
+    that really are within 1e-11 of an integer and, so far, never a difference."""
+    import subprocess
+    import sys
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "isaac_aligner_amd", "libisaac_gpu_mapqskew.so")
+    if not os.path.exists(lib):
+        pytest.skip("the MAPQ test build is not there (python __graft_entry__.py builds it)")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "mapq_skew_check.py"), "20000"],
+                       env=dict(os.environ, ISAAC_GPU_LIBRARY=lib), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_phix_sized_reference(torch, oracle):
     """BASELINE configuration 0 (the reference's own plumbing case): one 5 386-base contig, 2x100 reads at a coverage of hundreds --
     index, match sets, template length statistics and every record against the oracle; then the same tile as BAM records"""
