@@ -28,6 +28,7 @@
 #include <set>
 #include <sstream>
 #include <sys/stat.h>
+#include <sys/mman.h>
 #include <fcntl.h>
 #include <unistd.h>
 #include <atomic>
@@ -364,34 +365,55 @@ public:
 private:
     std::mutex lock_; std::vector<Buffer> free_;
 };
+// the matches of a tile and where they begin per cluster, grown as isaac_gpu_find_matches asks
+struct Finder { DeviceMemory matches, offsets; uint64_t capacity = 0; };
+// a context per device for the lanes' threads (text upload, conversion, first lookup), beside the workers' own: loading does not wait for a selection
+struct Loader
+{
+    int place = 0; isaac_gpu_ctx *ctx = 0; std::mutex lock; DeviceMemory textDev; Finder finder; std::vector<uint8_t> hits;
+    void close() { textDev.release(); finder.matches.release(); finder.offsets.release(); if (ctx) isaac_gpu_destroy(ctx); ctx = 0; }
+    ~Loader() { close(); }
+};
+
 // what a bin of the file becomes: its BGZF blocks, and what the index wants to know about its records
 struct BinOutput
 {
     bool ready = false; PinnedPool::Buffer bgzf, entries; uint64_t bgzfBytes = 0, recordsBytes = 0, nRecords = 0; std::string error;
+    // a bin of several small contigs is compressed contig by contig: bam::BamIndex takes a run of BGZF blocks per contig (the reference's bins never
+    // span contigs, include/alignment/matchSelector/BinIndexMap.hh:78-83), and so does the index written here
+    struct Segment { uint64_t bgzfOffset, bgzfBytes, recordsOffset, recordsBytes, firstEntry, nEntries; };
+    std::vector<Segment> segments;
 };
 
-// `bytes` at `offset` of the file, by a few threads side by side (one thread writes some 6 GB/s into the page cache)
+// `bytes` at `offset` of the file (its end so far).  A large piece is copied into a shared mapping of the file by several threads side by side: write()
+// calls on one file take turns (the inode's lock), which held a 28 GB sorted.bam to 4 GB/s; page faults on a mapping do not.  Files that cannot be
+// mapped, and small pieces, are written.
 void writeAt(int fd, const uint8_t *data, uint64_t bytes, uint64_t offset)
 {
-    const unsigned threads = bytes >= (uint64_t(64) << 20) ? 8 : 1;
-    const uint64_t share = (bytes + threads - 1) / threads;
-    std::vector<int> failed(threads, 0);
-    const auto part = [&](unsigned t)
+    const auto plain = [&]()
     {
-        uint64_t done = std::min<uint64_t>(bytes, t * share);
-        const uint64_t end = std::min<uint64_t>(bytes, done + share);
-        while (done < end)
+        uint64_t done = 0;
+        while (done < bytes)
         {
-            const ssize_t r = ::pwrite(fd, data + done, size_t(end - done), off_t(offset + done));
-            if (r < 0) { if (EINTR == errno) continue; failed[t] = errno ? errno : EIO; return; }
+            const ssize_t r = ::pwrite(fd, data + done, size_t(bytes - done), off_t(offset + done));
+            if (r < 0) { if (EINTR == errno) continue; throw std::runtime_error(std::string("Failed to write the BAM file: ") + std::strerror(errno)); }
             done += uint64_t(r);
         }
     };
+    if (bytes < (uint64_t(32) << 20) || std::getenv("ISAAC_ALIGN_PLAIN_WRITES")) { plain(); return; }
+    const uint64_t page = uint64_t(::sysconf(_SC_PAGESIZE)), mapFrom = offset / page * page, lead = offset - mapFrom;
+    if (::ftruncate(fd, off_t(offset + bytes))) { plain(); return; }
+    void *map = ::mmap(0, size_t(lead + bytes), PROT_READ | PROT_WRITE, MAP_SHARED, fd, off_t(mapFrom));
+    if (MAP_FAILED == map) { plain(); return; }
+    uint8_t *to = static_cast<uint8_t *>(map) + lead;
+    const unsigned threads = 16;
+    const uint64_t share = ((bytes + threads - 1) / threads + page - 1) / page * page;
     std::vector<std::thread> workers;
+    const auto part = [&](unsigned t) { const uint64_t begin = std::min<uint64_t>(bytes, t * share), end = std::min<uint64_t>(bytes, begin + share); if (end > begin) std::memcpy(to + begin, data + begin, size_t(end - begin)); };
     for (unsigned t = 1; t < threads; ++t) workers.emplace_back(part, t);
     part(0);
     for (std::thread &w : workers) w.join();
-    for (int e : failed) if (e) throw std::runtime_error(std::string("Failed to write the BAM file: ") + std::strerror(e));
+    ::munmap(map, size_t(lead + bytes));
 }
 
 uint64_t hostResidentBytes()
@@ -429,6 +451,7 @@ int run(const AlignOptions &o)
     // ISAAC_ALIGN_STRANGERS (tests on a box with one device): the workers of one device treat each other's memory as another device's -- the table is
     // copied, a bin's parts on the other worker's blocks are fetched -- which is every line two devices run
     const bool strangers = 0 != std::getenv("ISAAC_ALIGN_STRANGERS");
+    std::deque<Loader> loaders;                       // (declared before the workers and the lanes: destroyed after them)
     std::vector<std::unique_ptr<Worker> > workers;
     Reference reference;
     double fastaSeconds = 0, contigSeconds = 0, tableSeconds = 0;
@@ -451,40 +474,58 @@ int run(const AlignOptions &o)
             for (size_t j = 0; j < k && !samePlace; ++j) if (workers[j]->place == w.place) samePlace = workers[j].get();
             GPU(isaac_gpu_share_index(w.ctx, samePlace ? samePlace->ctx : workers[0]->ctx));
         }
+        for (auto &w : workers)
+        {
+            bool have = false;
+            for (Loader &l : loaders) if (l.place == w->place) have = true;
+            if (have) continue;
+            loaders.emplace_back();
+            Loader &l = loaders.back();
+            l.place = w->place; l.hits.assign(reference.contigs.size(), 0);
+            GPU(isaac_gpu_create(w->device, &params, ISAAC_GPU_STREAM_OWN, &l.ctx));
+            GPU(isaac_gpu_load_contigs(l.ctx, reference.bases.get(), reference.offsets.data(), uint32_t(reference.contigs.size())));
+            GPU(isaac_gpu_share_index(l.ctx, w->ctx));
+        }
         reference.bases.reset();
     }
     const uint32_t nContigs = uint32_t(reference.contigs.size());
     const double referenceSeconds = seconds() - runStart;
 
-    // ---- FastqSeedSource: loads of --clusters-at-a-time clusters, tiles of at most tileClustersMax.  The lanes are read side by side (a thread each, up
-    // to the number of workers + 1 at a time), every load of a lane is dealt to the next worker in turn; a lane's tiles keep the order of the file.
+    // ---- FastqSeedSource + FindMatchesTransition + SelectMatchesTransition as one pipeline.  The lanes are read side by side (a thread each): loads of
+    // --clusters-at-a-time clusters, tiles of at most tileClustersMax; every load of a lane is dealt to the next worker in turn and looked up once for the
+    // contigs its matches touch.  The reference finishes that pass over the whole run before it selects anything, because the selection wants to know which
+    // contigs have matches anywhere (MatchSelector loads only those; the rest-of-genome correction counts them).  Once every contig has a match no later
+    // lookup can change that set: from then on a tile is selected -- on its worker's context, by the worker's own thread -- as soon as it is loaded, while
+    // the lanes' threads go on reading and converting on a context of their own (one per device: the loader).  A run that never gets there (a small
+    // reference with untouched contigs) selects after the last load, as the reference does.
     const uint32_t tileClustersMax = isaac_gpu_fastq_tile_clusters_max(o.clustersAtATime, params.n_seeds);
     const uint32_t loadClusters = o.clustersAtATime ? o.clustersAtATime : 4 * tileClustersMax;      // a multiple of the tile size: the tiles come out the same for any such load
-    auto findMatches = [&](Worker &w, const uint8_t *bcl, uint32_t clusters, uint32_t tileIndex, uint64_t &nMatches, uint8_t *hits)
+    auto findMatches = [&](isaac_gpu_ctx *ctx, Finder &f, const uint8_t *bcl, uint32_t clusters, uint32_t tileIndex, uint64_t &nMatches, uint8_t *hits)
     {
         const uint64_t worst = uint64_t(clusters) * 2 * params.n_seeds * std::max(1u, params.repeat_threshold - 1);
-        if (!w.offsets.bytes()) w.offsets.reset(w.ctx, (uint64_t(tileClustersMax) + 1) * 8);
-        if (!w.matchCapacity) { w.matchCapacity = std::max<uint64_t>(1024, std::min<uint64_t>(worst, uint64_t(tileClustersMax) * 24)); w.matches.reset(w.ctx, w.matchCapacity * sizeof(isaac_match)); }
+        if (!f.offsets.bytes()) f.offsets.reset(ctx, (uint64_t(tileClustersMax) + 1) * 8);
+        if (!f.capacity) { f.capacity = std::max<uint64_t>(1024, std::min<uint64_t>(worst, uint64_t(tileClustersMax) * 24)); f.matches.reset(ctx, f.capacity * sizeof(isaac_match)); }
         for (;;)
         {
-            const int rc = isaac_gpu_find_matches(w.ctx, bcl, clusters, tileIndex, w.matches.as<isaac_match>(), w.matchCapacity, w.offsets.as<uint64_t>(), &nMatches, hits);
+            const int rc = isaac_gpu_find_matches(ctx, bcl, clusters, tileIndex & 0xfffu /* SeedId's tile field; nothing reads it back */, f.matches.as<isaac_match>(), f.capacity, f.offsets.as<uint64_t>(), &nMatches, hits);
             if (ISAAC_GPU_ECAPACITY != rc) { check(rc, "isaac_gpu_find_matches"); return; }
-            w.matchCapacity = std::max(nMatches, 2 * w.matchCapacity);
-            w.matches.reset(w.ctx, w.matchCapacity * sizeof(isaac_match));
+            f.capacity = std::max(nMatches, 2 * f.capacity);
+            f.matches.reset(ctx, f.capacity * sizeof(isaac_match));
         }
     };
+    auto loaderOf = [&](const Worker &w) -> Loader & { for (Loader &l : loaders) if (l.place == w.place) return l; throw std::logic_error("no loader"); };
     // the BCL bytes of a load stay on the device while it keeps this much free for the selection's scratch and the bins (ISAAC_ALIGN_HOST_LOADS: tests)
     const bool hostLoads = 0 != std::getenv("ISAAC_ALIGN_HOST_LOADS");
-    auto keepOnDevice = [&](Worker &w, uint64_t bytes)
+    auto keepOnDevice = [&](isaac_gpu_ctx *ctx, uint64_t bytes)
     {
         if (hostLoads) return false;
         uint64_t freeBytes = 0, totalBytes = 0;
-        GPU(isaac_gpu_memory_info(w.ctx, &freeBytes, &totalBytes));
+        GPU(isaac_gpu_memory_info(ctx, &freeBytes, &totalBytes));
         return freeBytes > totalBytes * 2 / 5 + bytes;
     };
     // io::FastqLoader::loadSingleRead for up to maxClusters clusters: the text goes to the device in pieces, the converter leaves the incomplete
     // record at the end of a piece for the next one
-    auto loadRead = [&](Worker &w, TextStream &stream, unsigned readIndex, uint8_t *bclDev, uint32_t maxClusters) -> uint32_t
+    auto loadRead = [&](Loader &l, TextStream &stream, unsigned readIndex, uint8_t *bclDev, uint32_t maxClusters) -> uint32_t
     {
         const bool allowVariableLength = o.variableReadLength || o.variableFastqReadLength;
         uint32_t clusters = 0;
@@ -495,13 +536,12 @@ int run(const AlignOptions &o)
             const bool final = stream.final();
             const double convertStart = seconds();
             uint32_t n = 0; uint64_t consumed = 0, errorOffset = 0;
-            int rc;
             {
-                std::lock_guard<std::mutex> turn(w.ctxLock);
-                if (w.textDev.bytes() < stream.size() + 64) w.textDev.reset(w.ctx, TEXT_SLACK + TEXT_CHUNK + 64);
-                GPU(isaac_gpu_upload(w.ctx, w.textDev.as<char>(), stream.data(), stream.size()));
-                rc = isaac_gpu_fastq_to_bcl(w.ctx, w.textDev.as<char>(), stream.size(), readIndex, allowVariableLength, final, bclDev + uint64_t(clusters) * clusterLength,
-                                            maxClusters - clusters, &n, &consumed, &errorOffset);
+                std::lock_guard<std::mutex> turn(l.lock);
+                if (l.textDev.bytes() < stream.size() + 64) l.textDev.reset(l.ctx, TEXT_SLACK + TEXT_CHUNK + 64);
+                GPU(isaac_gpu_upload(l.ctx, l.textDev.as<char>(), stream.data(), stream.size()));
+                const int rc = isaac_gpu_fastq_to_bcl(l.ctx, l.textDev.as<char>(), stream.size(), readIndex, allowVariableLength, final, bclDev + uint64_t(clusters) * clusterLength,
+                                                      maxClusters - clusters, &n, &consumed, &errorOffset);
                 if (rc)
                     throw std::runtime_error(stream.path() + ": " + isaac_gpu_last_error() + " (record " + std::to_string(clusters + n) + " of this load, offset " +
                                              std::to_string(stream.consumedBytes + errorOffset) + ")");
@@ -517,115 +557,44 @@ int run(const AlignOptions &o)
         }
         return clusters;
     };
-    struct Lane { const FastqFlowcell *flowcell; const FastqLane *lane; std::string readGroup; std::deque<Tile> tiles; std::deque<Load> loads; std::string error; };
+    struct Lane
+    {
+        const FastqFlowcell *flowcell; const FastqLane *lane; unsigned ordinal = 0; std::string readGroup; std::deque<Tile> tiles; std::deque<Load> loads; std::string error;
+        // barcodeTemplateLengthStatistics (one 'none' barcode per lane): learnt tile by tile, in tile order, until a tile gives stable ones (MatchSelector.cpp:395-412)
+        isaac_tls tls; bool tlsStable = false, learning = false; unsigned tlsNext = 0;
+    };
     std::deque<Lane> lanes;
     for (const FastqFlowcell &fc : flowcells)
-        for (const FastqLane &lane : fc.lanes) { lanes.emplace_back(); lanes.back().flowcell = &fc; lanes.back().lane = &lane; lanes.back().readGroup = std::to_string(lanes.size() - 1); }   // one 'none' barcode per lane, numbered in the order of the lanes
-    for (auto &w : workers) w->contigHasMatches.assign(nContigs, 0);
-    uint64_t totalClusters = 0;
-    const double loadStart = seconds();
-    {
-        Stage stage("loading base calls and finding matches");
-        std::atomic<size_t> nextLane(0), nextWorker(0);
-        auto readLanes = [&]()
+        for (const FastqLane &lane : fc.lanes)
         {
-            for (size_t k = nextLane++; k < lanes.size(); k = nextLane++)
-            {
-                Lane &L = lanes[k];
-                try
-                {
-                    const FastqFlowcell &fc = *L.flowcell; const FastqLane &lane = *L.lane;
-                    std::unique_ptr<TextStream> streams[2];
-                    for (unsigned r = 0; r < nReads; ++r)
-                    {
-                        if (lane.readPath[r].empty()) throw std::runtime_error("lane " + std::to_string(lane.lane) + " of " + fc.baseCallsDirectory + " has no read " + std::to_string(r + 1));
-                        streams[r].reset(new TextStream(lane.readPath[r], fc.compressed));
-                    }
-                    uint32_t nextTile = 1;
-                    for (;;)
-                    {
-                        Worker &w = *workers[nextWorker++ % workers.size()];
-                        DeviceMemory bcl;
-                        { std::lock_guard<std::mutex> turn(w.ctxLock); bcl.reset(w.ctx, uint64_t(loadClusters) * clusterLength + 64); }
-                        uint32_t loaded[2] = { 0, 0 };
-                        for (unsigned r = 0; r < nReads; ++r) loaded[r] = loadRead(w, *streams[r], r, bcl.as<uint8_t>(), loadClusters);
-                        if (2 == nReads && loaded[0] != loaded[1])
-                            throw std::runtime_error("Mismatching number of clusters in " + lane.readPath[0] + " (" + std::to_string(loaded[0]) + ") and " + lane.readPath[1] + " (" + std::to_string(loaded[1]) + ")");
-                        if (!loaded[0]) break;
-                        std::lock_guard<std::mutex> turn(w.ctxLock);
-                        const uint64_t bytes = uint64_t(loaded[0]) * clusterLength;
-                        // the lookup that says which contigs have matches (the matches themselves are found again when the tile is selected)
-                        uint32_t nTiles = 0, next = 0;
-                        isaac_gpu_fastq_tiles(loaded[0], o.clustersAtATime, params.n_seeds, nextTile, 0, 0, 0, &nTiles, &next);
-                        std::vector<uint32_t> numbers(nTiles), sizes(nTiles);
-                        GPU(isaac_gpu_fastq_tiles(loaded[0], o.clustersAtATime, params.n_seeds, nextTile, numbers.data(), sizes.data(), nTiles, &nTiles, &next));
-                        nextTile = next;
-                        L.loads.emplace_back();
-                        Load &load = L.loads.back();
-                        load.worker = &w; load.clusters = loaded[0]; load.bytes = bytes;
-                        uint64_t first = 0;
-                        for (uint32_t i = 0; i < nTiles; ++i)
-                        {
-                            L.tiles.emplace_back();
-                            Tile &t = L.tiles.back();
-                            t.lane = lane.lane; t.number = numbers[i]; t.clusters = sizes[i]; t.load = &load; t.firstCluster = first; t.worker = &w;
-                            t.namePrefix = fc.flowcellId + ":" + std::to_string(lane.lane) + ":" + std::to_string(t.number) + ":"; t.readGroup = L.readGroup;
-                            std::memset(&t.tls, 0, sizeof(t.tls));
-                            uint64_t nMatches = 0;
-                            const double lookupStart = seconds();
-                            findMatches(w, bcl.as<uint8_t>() + first * clusterLength, t.clusters, 0, nMatches, w.contigHasMatches.data());
-                            addTime(g_firstLookupSeconds, seconds() - lookupStart);
-                            first += sizes[i];
-                            load.tiles.push_back(&t);
-                        }
-                        load.tilesLeft = unsigned(load.tiles.size());
-                        // where the load waits for the selection: the device while it has room, else host memory; and only the bytes it has
-                        if (keepOnDevice(w, bytes))
-                        {
-                            if (loaded[0] < loadClusters / 2)
-                            {   // "allocated too much memory for bcl data": the load keeps what it uses
-                                DeviceMemory exact(w.ctx, bytes + 64);
-                                GPU(isaac_gpu_copy(w.ctx, exact.as<uint8_t>(), bcl.as<uint8_t>(), bytes));
-                                GPU(isaac_gpu_synchronize(w.ctx));
-                                bcl = std::move(exact);
-                            }
-                            load.dev = std::move(bcl);
-                            ++w.loadsKeptOnDevice;
-                        }
-                        else
-                        {
-                            load.host.reset(new uint8_t[bytes]);
-                            GPU(isaac_gpu_download(w.ctx, load.host.get(), bcl.as<uint8_t>(), bytes));
-                            bcl.release();
-                        }
-                        w.noteMemory();
-                        if (loaded[0] < loadClusters) break;
-                    }
-                }
-                catch (const std::exception &e) { L.error = e.what(); }
-            }
-        };
-        std::vector<std::thread> threads;
-        for (size_t k = 1; k < std::min(lanes.size(), workers.size() + 1); ++k) threads.emplace_back(readLanes);
-        readLanes();
-        for (std::thread &t : threads) t.join();
-        for (const Lane &L : lanes) if (!L.error.empty()) throw std::runtime_error(L.error);
-        for (auto &w : workers) w->textDev.release();
+            lanes.emplace_back();
+            Lane &L = lanes.back();
+            L.flowcell = &fc; L.lane = &lane; L.ordinal = unsigned(lanes.size() - 1); L.readGroup = std::to_string(lanes.size() - 1);   // one 'none' barcode per lane, numbered in the order of the lanes
+            std::memset(&L.tls, 0, sizeof(L.tls));
+        }
+    if (lanes.size() > 4096) throw std::runtime_error("more than 4096 lanes");
+    // How many clusters the run will have, before it has been read: the size of every lane's first file over the length of its first record (compressed
+    // files: taken to hold four times their size).  Only the bins' sizes depend on it; any plan gives a valid file, and the estimate -- unlike the count,
+    // which is known when the last lane is read -- is there when the first tile wants its bins.
+    uint64_t estimatedClusters = 0;
+    for (Lane &L : lanes)
+    {
+        const std::string &path = L.lane->readPath[0];
+        struct stat st;
+        if (path.empty() || ::stat(path.c_str(), &st)) continue;
+        FastqFileReader peek(path, L.flowcell->compressed);
+        std::vector<char> head(1 << 16);
+        const size_t got = peek.readInto(head.data(), head.size());
+        size_t lines = 0, recordBytes = 0;
+        for (size_t i = 0; i < got && lines < 4; ++i) { ++recordBytes; if ('\n' == head[i]) ++lines; }
+        if (lines < 4 || !recordBytes) recordBytes = 2 * size_t(L.flowcell->fileReadLength[0]) + 64;
+        estimatedClusters += uint64_t(st.st_size) * (L.flowcell->compressed ? 4 : 1) / recordBytes;
     }
-    // the tiles of the run in the order of the lanes and of their files: that is their index (FragmentHeader::tile_)
-    std::vector<Tile *> tiles;
-    for (Lane &L : lanes) for (Tile &t : L.tiles) { t.index = unsigned(tiles.size()); tiles.push_back(&t); t.worker->tiles.push_back(&t); totalClusters += t.clusters; }
-    std::cerr << "isaac-align: " << totalClusters << " clusters in " << tiles.size() << " tile(s) on " << workers.size() << " worker(s)" << std::endl;
-    if (tiles.empty()) throw InvalidOption("No data found to process. Please check your --base-calls.");
-    std::vector<uint8_t> contigHasMatches(nContigs, 0);
-    for (auto &w : workers) for (uint32_t c = 0; c < nContigs; ++c) contigHasMatches[c] |= w->contigHasMatches[c];
-    const double loadSeconds = seconds() - loadStart;
-
-    // ---- the bins (see BinPart): sized for --bin-records records each, by the reads the run has per base of the reference
+    // ---- the bins (see BinPart): sized for --bin-records records each, by the reads the run is expected to have per base of the reference
     std::vector<uint64_t> contigLengths;
     for (const isaac_reference_contig &c : reference.contigs) contigLengths.push_back(c.total_bases);
     const uint64_t binRecords = o.binRecords ? o.binRecords : 4000000;
-    const double recordsPerBase = double(totalClusters) * nReads / double(std::max<uint64_t>(1, reference.totalBases));
+    const double recordsPerBase = double(std::max<uint64_t>(estimatedClusters, 1)) * nReads / double(std::max<uint64_t>(1, reference.totalBases));
     const BinPlan plan = planBins(contigLengths, uint64_t(std::min(1e15, double(binRecords) / std::max(recordsPerBase, 1e-9))));
     const uint32_t nBins = uint32_t(plan.ranges.size()) + 1;
     if (nBins > 65535) throw std::runtime_error("more than 65534 bins: a larger --bin-records is needed");
@@ -633,8 +602,41 @@ int run(const AlignOptions &o)
     for (uint32_t b = 0; b + 1 < nBins; ++b) { bins[b].firstPosition = plan.ranges[b].first; bins[b].endPosition = plan.ranges[b].second; }
     bins[nBins - 1].unaligned = true;
     isaac_bin_map binMap; binMap.bin_of_contig = plan.binOfContig.data(); binMap.n_contigs = nContigs; binMap.cut_positions = plan.cuts.data(); binMap.n_cuts = uint32_t(plan.cuts.size()); binMap.n_bins = nBins;
-    std::cerr << "isaac-align: " << nBins - 1 << " bin(s) of about " << binRecords << " records for " << nContigs << " contig(s), " << plan.cuts.size() << " cut(s) inside contigs" << std::endl;
+    std::cerr << "isaac-align: about " << estimatedClusters << " clusters expected: " << nBins - 1 << " bin(s) of about " << binRecords << " records for " << nContigs << " contig(s), " << plan.cuts.size()
+              << " cut(s) inside contigs" << std::endl;
 
+    // ---- what the threads share
+    std::mutex shared; std::condition_variable wake;
+    std::vector<uint8_t> contigHasMatches(nContigs, 0);
+    bool hitsClosed = false, loadingDone = false; std::string pipelineError;
+    std::vector<std::deque<Tile *> > ready(workers.size());          // per worker: its tiles that are loaded and not yet selected, in the order they were loaded
+    std::vector<uint64_t> unselected(workers.size(), 0);             // tiles dealt to the worker and not yet through its selection
+    std::atomic<uint64_t> totalClusters(0), totalTiles(0);
+    const bool hostBins = 0 != std::getenv("ISAAC_ALIGN_HOST_BINS");          // tests: every part through host memory
+    // ISAAC_ALIGN_DUMP_TILES=<directory>:<lane>.<tile>,...: tiles (by lane number and tile number, as in the read names) to write out as they were selected
+    std::set<std::pair<unsigned, unsigned> > dumpTiles; std::string dumpDirectory;
+    if (const char *e = std::getenv("ISAAC_ALIGN_DUMP_TILES"))
+    {
+        const std::string spec(e);
+        const size_t colon = spec.rfind(':');
+        if (std::string::npos == colon) throw std::runtime_error("ISAAC_ALIGN_DUMP_TILES=<directory>:<lane>.<tile>,...");
+        dumpDirectory = spec.substr(0, colon);
+        std::stringstream list(spec.substr(colon + 1));
+        for (std::string item; std::getline(list, item, ','); )
+        {
+            const size_t dot = item.find('.');
+            if (item.empty() || std::string::npos == dot) continue;
+            dumpTiles.insert(std::make_pair(unsigned(std::stoul(item.substr(0, dot))), unsigned(std::stoul(item.substr(dot + 1)))));
+        }
+        makeDirectories(dumpDirectory);
+    }
+    // every contig has a match (or the last load is in): the set is final, the workers' contexts learn it, the selection may begin.  Called with `shared` held.
+    auto closeHits = [&]()
+    {
+        for (auto &w : workers) GPU(isaac_gpu_set_loaded_contigs(w->ctx, contigHasMatches.data(), nContigs));       // (the workers are idle until now)
+        hitsClosed = true;
+        wake.notify_all();
+    };
     // a load's BCL bytes on its worker's device (where they may have been all along)
     auto loadOnDevice = [&](Load &load) -> const uint8_t *
     {
@@ -645,168 +647,294 @@ int run(const AlignOptions &o)
         }
         return load.dev.as<uint8_t>();
     };
-    // ---- SelectMatchesTransition: every tile with the contigs the whole run has matches on.  The template length statistics of a lane are
-    // learnt tile by tile until a tile gives stable ones, which then serve the rest of the lane (MatchSelector.cpp:395-412): settled first, in tile
-    // order, so that the workers can take their tiles in any order afterwards.
-    const double selectStart = seconds();
+
+    // ---- the lanes' threads
+    const double loadStart = seconds();
+    std::atomic<size_t> nextLane(0), nextWorker(0);
+    auto readLanes = [&]()
     {
-        Stage stage("selecting matches");
-        for (auto &w : workers) GPU(isaac_gpu_set_loaded_contigs(w->ctx, contigHasMatches.data(), nContigs));
+        for (size_t k = nextLane++; k < lanes.size(); k = nextLane++)
         {
-            isaac_tls tls; std::memset(&tls, 0, sizeof(tls));
-            std::string laneKey;
-            for (Tile *tp : tiles)
-            {
-                Tile &t = *tp;
-                if (laneKey != t.readGroup) { std::memset(&tls, 0, sizeof(tls)); laneKey = t.readGroup; }       // barcodeTemplateLengthStatistics: one per barcode
-                if (!tls.stable || o.perTileTls)
-                {
-                    uint64_t nMatches = 0;
-                    const bool wasOnDevice = 0 != t.load->dev.bytes();
-                    const uint8_t *bcl = loadOnDevice(*t.load) + t.firstCluster * clusterLength;
-                    findMatches(*t.worker, bcl, t.clusters, t.index, nMatches, 0);
-                    GPU(isaac_gpu_determine_tls(t.worker->ctx, bcl, t.clusters, t.index, t.worker->matches.as<isaac_match>(), t.worker->offsets.as<uint64_t>(), &tls));
-                    if (!wasOnDevice) t.load->dev.release();
-                    std::cerr << "isaac-align: template length statistics of tile " << t.namePrefix << " min " << tls.min << " median " << tls.median << " max " << tls.max
-                              << (tls.stable ? " (stable)" : " (unstable)") << std::endl;
-                }
-                t.tls = tls;
-            }
-        }
-        std::vector<std::string> errors(workers.size());
-        const bool hostBins = 0 != std::getenv("ISAAC_ALIGN_HOST_BINS");          // tests: every part through host memory
-        std::set<unsigned> dumpTiles; std::string dumpDirectory;
-        if (const char *e = std::getenv("ISAAC_ALIGN_DUMP_TILES"))
-        {
-            const std::string spec(e);
-            const size_t colon = spec.rfind(':');
-            if (std::string::npos == colon) throw std::runtime_error("ISAAC_ALIGN_DUMP_TILES=<directory>:<tile index>,...");
-            dumpDirectory = spec.substr(0, colon);
-            std::stringstream list(spec.substr(colon + 1));
-            for (std::string item; std::getline(list, item, ','); ) if (!item.empty()) dumpTiles.insert(unsigned(std::stoul(item)));
-            makeDirectories(dumpDirectory);
-        }
-        auto selectTiles = [&](Worker &w)
-        {
+            Lane &L = lanes[k];
             try
             {
-                const double start = seconds();
-                DeviceMemory slots(w.ctx, uint64_t(tileClustersMax) * nReads * ISAAC_GPU_MAX_CIGAR_OPS * 4), records(w.ctx, uint64_t(tileClustersMax) * nReads * sizeof(isaac_fragment)), packed, binned;
-                std::vector<isaac_bin_size> sizes(nBins);
-                for (Tile *tp : w.tiles)
+                const FastqFlowcell &fc = *L.flowcell; const FastqLane &lane = *L.lane;
+                std::unique_ptr<TextStream> streams[2];
+                for (unsigned r = 0; r < nReads; ++r)
                 {
-                    Tile &t = *tp;
-                    const uint8_t *bcl = loadOnDevice(*t.load) + t.firstCluster * clusterLength;
-                    uint64_t nMatches = 0;
-                    findMatches(w, bcl, t.clusters, t.index, nMatches, 0);
-                    const uint64_t nRecords = uint64_t(t.clusters) * nReads;
-                    GPU(isaac_gpu_select_n(w.ctx, bcl, t.clusters, t.index, w.matches.as<isaac_match>(), nMatches, w.offsets.as<uint64_t>(), &t.tls, records.as<isaac_fragment>(), slots.as<uint32_t>(),
-                                           nRecords * ISAAC_GPU_MAX_CIGAR_OPS));
-                    // the handful of clusters per million whose MAPQ arithmetic came within 1e-11 of an integer on the device take glibc's answer
-                    {
-                        uint64_t flagged = 0, changed = 0;
-                        GPU(isaac_gpu_resolve_flagged(w.ctx, bcl, t.clusters, t.index, w.matches.as<isaac_match>(), w.offsets.as<uint64_t>(), &t.tls, records.as<isaac_fragment>(), slots.as<uint32_t>(),
-                                                      &flagged, &changed));
-                        w.mapqResolved += flagged; w.mapqChanged += changed;
-                    }
-                    // the CIGARs as the bin files hold them: back to back
-                    uint64_t words = 0;
-                    if (packed.bytes() < nRecords * 8 * 4) packed.reset(w.ctx, nRecords * 8 * 4);
-                    int rc = isaac_gpu_compact_cigars(w.ctx, records.as<isaac_fragment>(), nRecords, slots.as<uint32_t>(), packed.as<uint32_t>(), packed.bytes() / 4, &words);
-                    if (ISAAC_GPU_ECAPACITY == rc)
-                    {
-                        packed.reset(w.ctx, words * 4);
-                        rc = isaac_gpu_compact_cigars(w.ctx, records.as<isaac_fragment>(), nRecords, slots.as<uint32_t>(), packed.as<uint32_t>(), packed.bytes() / 4, &words);
-                    }
-                    check(rc, "isaac_gpu_compact_cigars");
-                    if (dumpTiles.count(t.index))
-                    {   // ISAAC_ALIGN_DUMP_TILES=<directory>:<tile index>,...: the tile as it was selected -- BCL bytes, records, packed CIGAR words -- for a checker
-                        const std::string stem = dumpDirectory + "/tile_" + std::to_string(t.index);
-                        const auto dump = [&](const std::string &path, const void *dev, uint64_t bytes)
-                        {
-                            std::vector<uint8_t> host(bytes);
-                            if (bytes) GPU(isaac_gpu_download(w.ctx, host.data(), dev, bytes));
-                            std::ofstream os(path.c_str(), std::ios::binary | std::ios::trunc);
-                            if (!os.write(reinterpret_cast<const char *>(host.data()), std::streamsize(bytes))) throw std::runtime_error("Failed to write " + path);
-                        };
-                        dump(stem + ".bcl", bcl, uint64_t(t.clusters) * clusterLength);
-                        dump(stem + ".records", records.as<isaac_fragment>(), nRecords * sizeof(isaac_fragment));
-                        dump(stem + ".cigars", packed.as<uint32_t>(), words * 4);
-                        std::ofstream meta((stem + ".json").c_str());
-                        meta << "{\"index\": " << t.index << ", \"lane\": " << t.lane << ", \"number\": " << t.number << ", \"clusters\": " << t.clusters << ", \"read_group\": \"" << t.readGroup
-                             << "\", \"tls\": [" << t.tls.min << ", " << t.tls.max << ", " << t.tls.median << ", " << t.tls.low_std_dev << ", " << t.tls.high_std_dev << ", " << t.tls.best_model[0] << ", "
-                             << t.tls.best_model[1] << ", " << t.tls.stable << ", " << t.tls.mate_min << ", " << t.tls.mate_max << "]}" << std::endl;
-                    }
-                    // BinningFragmentStorage: the tile's clusters to their bins
-                    uint64_t need = 0;
-                    const uint64_t guess = align64(uint64_t(t.clusters) * clusterLength + nRecords * sizeof(isaac_fragment) + words * 4) * 5 / 4 + 256 * uint64_t(nBins);
-                    if (binned.bytes() < guess) binned.reset(w.ctx, guess);
-                    rc = isaac_gpu_bin_tile_map(w.ctx, bcl, records.as<isaac_fragment>(), packed.as<uint32_t>(), t.clusters, &binMap, binned.as<uint8_t>(), binned.bytes(), sizes.data(), &need);
-                    if (ISAAC_GPU_ECAPACITY == rc)
-                    {
-                        binned.reset(w.ctx, need);
-                        rc = isaac_gpu_bin_tile_map(w.ctx, bcl, records.as<isaac_fragment>(), packed.as<uint32_t>(), t.clusters, &binMap, binned.as<uint8_t>(), binned.bytes(), sizes.data(), &need);
-                    }
-                    check(rc, "isaac_gpu_bin_tile_map");
-                    // the BCL bytes of a load are in the bins once its last tile is: its memory is free for the tiles that follow
-                    if (0 == --t.load->tilesLeft) { t.load->dev.release(); t.load->host.reset(); }
-                    // the tile's parts stay on the device while it has room (see BinPart); a block that is mostly slack is cut to size first
-                    std::shared_ptr<DeviceMemory> block;
-                    {
-                        uint64_t freeBytes = 0, totalBytes = 0;
-                        GPU(isaac_gpu_memory_info(w.ctx, &freeBytes, &totalBytes));
-                        if (!hostBins && freeBytes > totalBytes / 4 + binned.bytes())
-                        {
-                            if (need + (need >> 2) < binned.bytes())
-                            {
-                                DeviceMemory exact(w.ctx, need + 64);
-                                GPU(isaac_gpu_copy(w.ctx, exact.as<uint8_t>(), binned.as<uint8_t>(), need));
-                                GPU(isaac_gpu_synchronize(w.ctx));
-                                block = std::make_shared<DeviceMemory>(std::move(exact));
-                            }
-                            else block = std::make_shared<DeviceMemory>(std::move(binned));
-                            ++w.tilesKeptOnDevice;
-                        }
-                    }
-                    const uint8_t *binnedBytes = block ? block->as<uint8_t>() : binned.as<uint8_t>();
-                    std::unique_ptr<uint8_t[]> whole;
-                    if (!block && need) { whole.reset(new uint8_t[need]); GPU(isaac_gpu_download(w.ctx, whole.get(), binnedBytes, need)); }      // one transfer for the tile, cut up on the host
-                    uint64_t at = 0;
-                    for (uint32_t b = 0; b < nBins; ++b)
-                    {
-                        const uint64_t m = sizes[b].n_clusters, cw = sizes[b].n_cigar_words;
-                        const uint64_t bytes = align64(align64(m * clusterLength) + m * nReads * sizeof(isaac_fragment)) + align64(cw * 4);
-                        if (m)
-                        {
-                            BinPart part; part.tile = &t; part.clusters = m; part.words = cw; part.bytes = bytes;
-                            if (block) { part.block = block; part.offset = at; part.place = w.place; }
-                            else { part.data.reset(new uint8_t[bytes]); std::memcpy(part.data.get(), whole.get() + at, bytes); }
-                            std::lock_guard<std::mutex> guard(bins[b].lock);
-                            bins[b].bytes += bytes; bins[b].records += m * nReads;
-                            bins[b].parts.push_back(std::move(part));
-                        }
-                        at += bytes;
-                    }
-                    w.noteMemory();
+                    if (lane.readPath[r].empty()) throw std::runtime_error("lane " + std::to_string(lane.lane) + " of " + fc.baseCallsDirectory + " has no read " + std::to_string(r + 1));
+                    streams[r].reset(new TextStream(lane.readPath[r], fc.compressed));
                 }
-                GPU(isaac_gpu_synchronize(w.ctx));
-                isaac_gpu_get_counters(w.ctx, &w.counters);
-                w.matches.release(); w.offsets.release();
-                w.selectSeconds = seconds() - start;
+                uint32_t nextTile = 1;
+                for (;;)
+                {
+                    { std::lock_guard<std::mutex> hold(shared); if (!pipelineError.empty()) break; }
+                    Worker &w = *workers[nextWorker++ % workers.size()];
+                    Loader &l = loaderOf(w);
+                    DeviceMemory bcl;
+                    { std::lock_guard<std::mutex> turn(l.lock); bcl.reset(l.ctx, uint64_t(loadClusters) * clusterLength + 64); }
+                    uint32_t loaded[2] = { 0, 0 };
+                    for (unsigned r = 0; r < nReads; ++r) loaded[r] = loadRead(l, *streams[r], r, bcl.as<uint8_t>(), loadClusters);
+                    if (2 == nReads && loaded[0] != loaded[1])
+                        throw std::runtime_error("Mismatching number of clusters in " + lane.readPath[0] + " (" + std::to_string(loaded[0]) + ") and " + lane.readPath[1] + " (" + std::to_string(loaded[1]) + ")");
+                    if (!loaded[0]) break;
+                    const uint64_t bytes = uint64_t(loaded[0]) * clusterLength;
+                    uint32_t nTiles = 0, next = 0;
+                    isaac_gpu_fastq_tiles(loaded[0], o.clustersAtATime, params.n_seeds, nextTile, 0, 0, 0, &nTiles, &next);
+                    std::vector<uint32_t> numbers(nTiles), sizes(nTiles);
+                    GPU(isaac_gpu_fastq_tiles(loaded[0], o.clustersAtATime, params.n_seeds, nextTile, numbers.data(), sizes.data(), nTiles, &nTiles, &next));
+                    nextTile = next;
+                    L.loads.emplace_back();
+                    Load &load = L.loads.back();
+                    load.worker = &w; load.clusters = loaded[0]; load.bytes = bytes;
+                    {
+                        std::lock_guard<std::mutex> turn(l.lock);
+                        uint64_t first = 0;
+                        for (uint32_t i = 0; i < nTiles; ++i)
+                        {
+                            L.tiles.emplace_back();
+                            Tile &t = L.tiles.back();
+                            // the tile's index over the run (FragmentHeader::tile_): lanes in their order, tiles in the order of the lane's files -- known at once, which a
+                            // running number over the run would not be while the lanes are read side by side.  Only the order of the indexes matters to the output.
+                            t.lane = lane.lane; t.number = numbers[i]; t.index = (L.ordinal << 16) | unsigned(L.tiles.size() - 1); t.clusters = sizes[i]; t.load = &load; t.firstCluster = first; t.worker = &w;
+                            if (L.tiles.size() > 65535) throw std::runtime_error("more than 65535 tiles in a lane");
+                            t.namePrefix = fc.flowcellId + ":" + std::to_string(lane.lane) + ":" + std::to_string(t.number) + ":"; t.readGroup = L.readGroup;
+                            std::memset(&t.tls, 0, sizeof(t.tls));
+                            // the lookup that says which contigs have matches (the matches themselves are found again when the tile is selected)
+                            uint64_t nMatches = 0;
+                            const double lookupStart = seconds();
+                            findMatches(l.ctx, l.finder, bcl.as<uint8_t>() + first * clusterLength, t.clusters, 0, nMatches, l.hits.data());
+                            addTime(g_firstLookupSeconds, seconds() - lookupStart);
+                            first += sizes[i];
+                            load.tiles.push_back(&t);
+                        }
+                        load.tilesLeft = unsigned(load.tiles.size());
+                        // where the load waits for the selection: the device while it has room, else host memory; and only the bytes it has
+                        if (keepOnDevice(l.ctx, bytes))
+                        {
+                            if (loaded[0] < loadClusters / 2)
+                            {   // "allocated too much memory for bcl data": the load keeps what it uses
+                                DeviceMemory exact(l.ctx, bytes + 64);
+                                GPU(isaac_gpu_copy(l.ctx, exact.as<uint8_t>(), bcl.as<uint8_t>(), bytes));
+                                GPU(isaac_gpu_synchronize(l.ctx));
+                                bcl = std::move(exact);
+                            }
+                            load.dev = std::move(bcl);
+                            ++w.loadsKeptOnDevice;
+                        }
+                        else
+                        {
+                            load.host.reset(new uint8_t[bytes]);
+                            GPU(isaac_gpu_download(l.ctx, load.host.get(), bcl.as<uint8_t>(), bytes));
+                            bcl.release();
+                        }
+                    }
+                    totalClusters += loaded[0]; totalTiles += nTiles;
+                    {   // the load's tiles are its worker's to select; the contigs seen so far may complete the set
+                        std::lock_guard<std::mutex> hold(shared);
+                        for (Tile *t : load.tiles) { ready[w.id].push_back(t); ++unselected[w.id]; }
+                        bool all = true;
+                        for (uint32_t c = 0; c < nContigs; ++c) { contigHasMatches[c] |= l.hits[c]; all = all && contigHasMatches[c]; }
+                        if (all && !hitsClosed) closeHits();
+                        wake.notify_all();
+                    }
+                    if (loaded[0] < loadClusters) break;
+                }
             }
-            catch (const std::exception &e) { errors[w.id] = e.what(); }
-        };
-        std::vector<std::thread> threads;
-        for (size_t k = 1; k < workers.size(); ++k) threads.emplace_back(selectTiles, std::ref(*workers[k]));
-        selectTiles(*workers[0]);
-        for (std::thread &t : threads) t.join();
-        for (const std::string &e : errors) if (!e.empty()) throw std::runtime_error(e);
+            catch (const std::exception &e) { L.error = e.what(); std::lock_guard<std::mutex> hold(shared); if (pipelineError.empty()) pipelineError = e.what(); wake.notify_all(); }
+        }
+    };
+
+    // ---- the workers' threads: SelectMatchesTransition for the worker's tiles, then BinningFragmentStorage
+    auto selectTiles = [&](Worker &w)
+    {
+        try
+        {
+            Finder finder;
+            DeviceMemory slots(w.ctx, uint64_t(tileClustersMax) * nReads * ISAAC_GPU_MAX_CIGAR_OPS * 4), records(w.ctx, uint64_t(tileClustersMax) * nReads * sizeof(isaac_fragment)), packed, binned;
+            std::vector<isaac_bin_size> sizes(nBins);
+            for (;;)
+            {
+                // the next tile of this worker that may go: any tile of a lane whose statistics are settled, or the tile a lane learns its statistics from next
+                Tile *tp = 0; Lane *lane = 0; bool learns = false;
+                {
+                    std::unique_lock<std::mutex> hold(shared);
+                    for (;;)
+                    {
+                        if (!pipelineError.empty()) return;
+                        if (hitsClosed)
+                        {
+                            for (auto it = ready[w.id].begin(); it != ready[w.id].end() && !tp; ++it)
+                            {
+                                Lane &L = lanes[(*it)->index >> 16];
+                                const unsigned ordinal = (*it)->index & 0xffffu;
+                                const bool settled = L.tlsStable && !o.perTileTls;
+                                if (settled || (ordinal == L.tlsNext && !L.learning))
+                                {
+                                    tp = *it; lane = &L; learns = !settled;
+                                    if (learns) L.learning = true; else tp->tls = L.tls;
+                                    ready[w.id].erase(it);
+                                    break;
+                                }
+                            }
+                            if (tp) break;
+                            if (loadingDone && !unselected[w.id]) return;
+                        }
+                        wake.wait(hold);
+                    }
+                }
+                Tile &t = *tp;
+                const double start = seconds();
+                const uint8_t *bcl = loadOnDevice(*t.load) + t.firstCluster * clusterLength;
+                uint64_t nMatches = 0;
+                findMatches(w.ctx, finder, bcl, t.clusters, t.index, nMatches, 0);
+                if (learns)
+                {
+                    isaac_tls tls;
+                    { std::lock_guard<std::mutex> hold(shared); tls = lane->tls; }
+                    GPU(isaac_gpu_determine_tls(w.ctx, bcl, t.clusters, t.index, finder.matches.as<isaac_match>(), finder.offsets.as<uint64_t>(), &tls));
+                    std::cerr << "isaac-align: template length statistics of tile " + t.namePrefix + " min " + std::to_string(tls.min) + " median " + std::to_string(tls.median) + " max " + std::to_string(tls.max) +
+                                 (tls.stable ? " (stable)" : " (unstable)") + "\n";
+                    t.tls = tls;
+                    std::lock_guard<std::mutex> hold(shared);
+                    lane->tls = tls; lane->tlsStable = 0 != tls.stable; lane->tlsNext = (t.index & 0xffffu) + 1; lane->learning = false;
+                    wake.notify_all();
+                }
+                const uint64_t nRecords = uint64_t(t.clusters) * nReads;
+                GPU(isaac_gpu_select_n(w.ctx, bcl, t.clusters, t.index, finder.matches.as<isaac_match>(), nMatches, finder.offsets.as<uint64_t>(), &t.tls, records.as<isaac_fragment>(), slots.as<uint32_t>(),
+                                       nRecords * ISAAC_GPU_MAX_CIGAR_OPS));
+                // the handful of clusters per million whose MAPQ arithmetic came within 1e-11 of an integer on the device take glibc's answer
+                {
+                    uint64_t flagged = 0, changed = 0;
+                    GPU(isaac_gpu_resolve_flagged(w.ctx, bcl, t.clusters, t.index, finder.matches.as<isaac_match>(), finder.offsets.as<uint64_t>(), &t.tls, records.as<isaac_fragment>(), slots.as<uint32_t>(),
+                                                  &flagged, &changed));
+                    w.mapqResolved += flagged; w.mapqChanged += changed;
+                }
+                // the CIGARs as the bin files hold them: back to back
+                uint64_t words = 0;
+                if (packed.bytes() < nRecords * 8 * 4) packed.reset(w.ctx, nRecords * 8 * 4);
+                int rc = isaac_gpu_compact_cigars(w.ctx, records.as<isaac_fragment>(), nRecords, slots.as<uint32_t>(), packed.as<uint32_t>(), packed.bytes() / 4, &words);
+                if (ISAAC_GPU_ECAPACITY == rc)
+                {
+                    packed.reset(w.ctx, words * 4);
+                    rc = isaac_gpu_compact_cigars(w.ctx, records.as<isaac_fragment>(), nRecords, slots.as<uint32_t>(), packed.as<uint32_t>(), packed.bytes() / 4, &words);
+                }
+                check(rc, "isaac_gpu_compact_cigars");
+                if (dumpTiles.count(std::make_pair(t.lane, t.number)))
+                {   // the tile as it was selected -- BCL bytes, records, packed CIGAR words -- for a checker
+                    const std::string stem = dumpDirectory + "/tile_" + std::to_string(t.lane) + "_" + std::to_string(t.number);
+                    const auto dump = [&](const std::string &path, const void *dev, uint64_t bytes)
+                    {
+                        std::vector<uint8_t> host(bytes);
+                        if (bytes) GPU(isaac_gpu_download(w.ctx, host.data(), dev, bytes));
+                        std::ofstream os(path.c_str(), std::ios::binary | std::ios::trunc);
+                        if (!os.write(reinterpret_cast<const char *>(host.data()), std::streamsize(bytes))) throw std::runtime_error("Failed to write " + path);
+                    };
+                    dump(stem + ".bcl", bcl, uint64_t(t.clusters) * clusterLength);
+                    dump(stem + ".records", records.as<isaac_fragment>(), nRecords * sizeof(isaac_fragment));
+                    dump(stem + ".cigars", packed.as<uint32_t>(), words * 4);
+                    std::ofstream meta((stem + ".json").c_str());
+                    meta << "{\"index\": " << t.index << ", \"lane\": " << t.lane << ", \"number\": " << t.number << ", \"clusters\": " << t.clusters << ", \"read_group\": \"" << t.readGroup
+                         << "\", \"tls\": [" << t.tls.min << ", " << t.tls.max << ", " << t.tls.median << ", " << t.tls.low_std_dev << ", " << t.tls.high_std_dev << ", " << t.tls.best_model[0] << ", "
+                         << t.tls.best_model[1] << ", " << t.tls.stable << ", " << t.tls.mate_min << ", " << t.tls.mate_max << "]}" << std::endl;
+                }
+                // BinningFragmentStorage: the tile's clusters to their bins
+                uint64_t need = 0;
+                const uint64_t guess = align64(uint64_t(t.clusters) * clusterLength + nRecords * sizeof(isaac_fragment) + words * 4) * 5 / 4 + 256 * uint64_t(nBins);
+                if (binned.bytes() < guess) binned.reset(w.ctx, guess);
+                rc = isaac_gpu_bin_tile_map(w.ctx, bcl, records.as<isaac_fragment>(), packed.as<uint32_t>(), t.clusters, &binMap, binned.as<uint8_t>(), binned.bytes(), sizes.data(), &need);
+                if (ISAAC_GPU_ECAPACITY == rc)
+                {
+                    binned.reset(w.ctx, need);
+                    rc = isaac_gpu_bin_tile_map(w.ctx, bcl, records.as<isaac_fragment>(), packed.as<uint32_t>(), t.clusters, &binMap, binned.as<uint8_t>(), binned.bytes(), sizes.data(), &need);
+                }
+                check(rc, "isaac_gpu_bin_tile_map");
+                // the BCL bytes of a load are in the bins once its last tile is: its memory is free for the loads that follow
+                {
+                    bool last;
+                    { std::lock_guard<std::mutex> hold(shared); last = 0 == --t.load->tilesLeft; }
+                    if (last) { t.load->dev.release(); t.load->host.reset(); }
+                }
+                // the tile's parts stay on the device while it has room (see BinPart); a block that is mostly slack is cut to size first
+                std::shared_ptr<DeviceMemory> block;
+                {
+                    uint64_t freeBytes = 0, totalBytes = 0;
+                    GPU(isaac_gpu_memory_info(w.ctx, &freeBytes, &totalBytes));
+                    if (!hostBins && freeBytes > totalBytes / 4 + binned.bytes())
+                    {
+                        if (need + (need >> 2) < binned.bytes())
+                        {
+                            DeviceMemory exact(w.ctx, need + 64);
+                            GPU(isaac_gpu_copy(w.ctx, exact.as<uint8_t>(), binned.as<uint8_t>(), need));
+                            GPU(isaac_gpu_synchronize(w.ctx));
+                            block = std::make_shared<DeviceMemory>(std::move(exact));
+                        }
+                        else block = std::make_shared<DeviceMemory>(std::move(binned));
+                        ++w.tilesKeptOnDevice;
+                    }
+                }
+                const uint8_t *binnedBytes = block ? block->as<uint8_t>() : binned.as<uint8_t>();
+                std::unique_ptr<uint8_t[]> whole;
+                if (!block && need) { whole.reset(new uint8_t[need]); GPU(isaac_gpu_download(w.ctx, whole.get(), binnedBytes, need)); }      // one transfer for the tile, cut up on the host
+                uint64_t at = 0;
+                for (uint32_t b = 0; b < nBins; ++b)
+                {
+                    const uint64_t m = sizes[b].n_clusters, cw = sizes[b].n_cigar_words;
+                    const uint64_t bytes = align64(align64(m * clusterLength) + m * nReads * sizeof(isaac_fragment)) + align64(cw * 4);
+                    if (m)
+                    {
+                        BinPart part; part.tile = &t; part.clusters = m; part.words = cw; part.bytes = bytes;
+                        if (block) { part.block = block; part.offset = at; part.place = w.place; }
+                        else { part.data.reset(new uint8_t[bytes]); std::memcpy(part.data.get(), whole.get() + at, bytes); }
+                        std::lock_guard<std::mutex> guard(bins[b].lock);
+                        bins[b].bytes += bytes; bins[b].records += m * nReads;
+                        bins[b].parts.push_back(std::move(part));
+                    }
+                    at += bytes;
+                }
+                w.noteMemory();
+                w.selectSeconds += seconds() - start;
+                { std::lock_guard<std::mutex> hold(shared); --unselected[w.id]; wake.notify_all(); }
+            }
+        }
+        catch (const std::exception &e) { std::lock_guard<std::mutex> hold(shared); if (pipelineError.empty()) pipelineError = e.what(); wake.notify_all(); }
+    };
+
+    double loadSeconds = 0;
+    const double selectStart = seconds();
+    {
+        Stage stage("loading base calls, finding and selecting matches");
+        std::vector<std::thread> selectors, readers;
+        for (auto &w : workers) selectors.emplace_back(selectTiles, std::ref(*w));
+        for (size_t k = 0; k < std::min(lanes.size(), workers.size() + 1); ++k) readers.emplace_back(readLanes);
+        for (std::thread &t : readers) t.join();
+        loadSeconds = seconds() - loadStart;
+        {
+            std::lock_guard<std::mutex> hold(shared);
+            loadingDone = true;
+            if (!hitsClosed && pipelineError.empty())
+            {
+                try { closeHits(); } catch (const std::exception &e) { pipelineError = e.what(); }
+            }
+            wake.notify_all();
+        }
+        for (std::thread &t : selectors) t.join();
+        for (const Lane &L : lanes) if (!L.error.empty()) throw std::runtime_error(L.error);
+        if (!pipelineError.empty()) throw std::runtime_error(pipelineError);
+        for (auto &w : workers) { GPU(isaac_gpu_synchronize(w->ctx)); isaac_gpu_get_counters(w->ctx, &w->counters); }
         // parts in tile order inside a bin, whichever worker was first
         for (Bin &bin : bins) std::sort(bin.parts.begin(), bin.parts.end(), [](const BinPart &a, const BinPart &b) { return a.tile->index < b.tile->index; });
     }
+    // every load has been selected and its bytes released: the loaders' contexts -- contigs, directory, buffers -- make room for the build stage
+    for (Lane &L : lanes) for (Load &load : L.loads) { load.dev.release(); load.host.reset(); }
+    for (Loader &l : loaders) l.close();
+    std::vector<Tile *> tiles;
+    for (Lane &L : lanes) for (Tile &t : L.tiles) tiles.push_back(&t);
+    std::cerr << "isaac-align: " << totalClusters.load() << " clusters in " << tiles.size() << " tile(s) on " << workers.size() << " worker(s)" << std::endl;
+    if (tiles.empty()) throw InvalidOption("No data found to process. Please check your --base-calls.");
     uint64_t overflowClusters = 0, mapqNearInteger = 0, mapqResolved = 0, mapqChanged = 0;
     for (auto &w : workers) { overflowClusters += w->counters.overflow_clusters; mapqNearInteger += w->counters.mapq_near_integer; mapqResolved += w->mapqResolved; mapqChanged += w->mapqChanged; }
-    const double selectSeconds = seconds() - selectStart;
+    const double selectSeconds = seconds() - selectStart - loadSeconds;       // what the selection took beyond the loading it ran beside
 
     // ---- build::Build: one bin at a time -- records, duplicates, realignment, BAM records, BGZF blocks on the device -- the file and its index
     // in bin order
@@ -933,17 +1061,35 @@ int run(const AlignOptions &o)
                     lap(w.recordsSeconds);
                     if (nBytes)
                     {
-                        // BGZF on the device: stored blocks at level 0 (bgzf::BgzfCompressor's own), deflated ones otherwise
-                        const uint64_t bound = o.bamGzipLevel ? isaac_gpu_bgzf_deflate_bound(nBytes) : isaac_gpu_bgzf_store_bound(nBytes);
-                        if (bgzf.bytes() < bound) bgzf.reset(w.ctx, bound);
-                        uint64_t nOut = 0;
-                        if (o.bamGzipLevel) GPU(isaac_gpu_bgzf_deflate(w.ctx, bam.as<uint8_t>(), nBytes, 0, bgzf.as<uint8_t>(), bgzf.bytes(), &nOut));
-                        else GPU(isaac_gpu_bgzf_store(w.ctx, bam.as<uint8_t>(), nBytes, 0, bgzf.as<uint8_t>(), bgzf.bytes(), &nOut));
-                        lap(w.deflateSeconds);
-                        result.bgzf = pinned.take(nOut); result.bgzfBytes = nOut; result.recordsBytes = nBytes;
+                        // what the index wants to know about the records, which also says where one contig's records end and the next one's begin
                         result.entries = pinned.take(result.nRecords * sizeof(isaac_bam_index_entry));
-                        GPU(isaac_gpu_download(w.ctx, result.bgzf.p, bgzf.as<uint8_t>(), nOut));
-                        GPU(isaac_gpu_download(w.ctx, result.entries.p, entries.as<isaac_bam_index_entry>(), result.nRecords * sizeof(isaac_bam_index_entry)));      // for the index
+                        GPU(isaac_gpu_download(w.ctx, result.entries.p, entries.as<isaac_bam_index_entry>(), result.nRecords * sizeof(isaac_bam_index_entry)));
+                        lap(w.downloadSeconds);
+                        const isaac_bam_index_entry *e = static_cast<const isaac_bam_index_entry *>(result.entries.p);
+                        for (uint64_t i = 0; i < result.nRecords; )
+                        {
+                            uint64_t j = i + 1;
+                            while (j < result.nRecords && e[j].ref_id == e[i].ref_id) ++j;
+                            const uint64_t begin = e[i].offset, end = j < result.nRecords ? e[j].offset : nBytes;
+                            result.segments.push_back(BinOutput::Segment{ 0, 0, begin, end - begin, i, j - i });
+                            i = j;
+                        }
+                        // BGZF on the device, a run of blocks per contig: stored blocks at level 0 (bgzf::BgzfCompressor's own), deflated ones otherwise
+                        uint64_t bound = 0;
+                        for (const BinOutput::Segment &sg : result.segments) bound += align64(o.bamGzipLevel ? isaac_gpu_bgzf_deflate_bound(sg.recordsBytes) : isaac_gpu_bgzf_store_bound(sg.recordsBytes));
+                        if (bgzf.bytes() < bound) bgzf.reset(w.ctx, bound);
+                        uint64_t at = 0;
+                        for (BinOutput::Segment &sg : result.segments)
+                        {
+                            uint64_t nOut = 0;
+                            if (o.bamGzipLevel) GPU(isaac_gpu_bgzf_deflate(w.ctx, bam.as<uint8_t>() + sg.recordsOffset, sg.recordsBytes, 0, bgzf.as<uint8_t>() + at, bgzf.bytes() - at, &nOut));
+                            else GPU(isaac_gpu_bgzf_store(w.ctx, bam.as<uint8_t>() + sg.recordsOffset, sg.recordsBytes, 0, bgzf.as<uint8_t>() + at, bgzf.bytes() - at, &nOut));
+                            sg.bgzfOffset = at; sg.bgzfBytes = nOut;
+                            at += nOut;                                    // (the runs lie back to back: the file is their concatenation)
+                        }
+                        lap(w.deflateSeconds);
+                        result.bgzf = pinned.take(at); result.bgzfBytes = at; result.recordsBytes = nBytes;
+                        GPU(isaac_gpu_download(w.ctx, result.bgzf.p, bgzf.as<uint8_t>(), at));
                         lap(w.downloadSeconds);
                     }
                     w.noteMemory();
@@ -967,7 +1113,7 @@ int run(const AlignOptions &o)
     double writeSeconds = 0;
     std::string failure;
     {
-        const int fd = ::open(bamPath.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+        const int fd = ::open(bamPath.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0666);
         if (fd < 0) failure = "Failed to open output BAM file " + bamPath;
         uint64_t fileAt = 0;
         const auto append = [&](const uint8_t *data, uint64_t bytes) { if (fd >= 0 && bytes) { writeAt(fd, data, bytes, fileAt); fileAt += bytes; } };
@@ -989,8 +1135,14 @@ int run(const AlignOptions &o)
                 const double writeStart = seconds();
                 try { append(static_cast<const uint8_t *>(out.bgzf.p), out.bgzfBytes); } catch (const std::exception &e) { failure = e.what(); }
                 writeSeconds += seconds() - writeStart;
-                if (failure.empty() && isaac_gpu_bam_indexer_add_entries(indexer, static_cast<const isaac_bam_index_entry *>(out.entries.p), out.nRecords, out.recordsBytes, static_cast<const uint8_t *>(out.bgzf.p), out.bgzfBytes))
-                    failure = std::string("isaac_gpu_bam_indexer_add_entries: ") + isaac_gpu_bam_index_last_error();
+                isaac_bam_index_entry *entries = static_cast<isaac_bam_index_entry *>(out.entries.p);
+                for (const BinOutput::Segment &sg : out.segments)
+                {
+                    if (!failure.empty()) break;
+                    for (uint64_t i = sg.firstEntry; i < sg.firstEntry + sg.nEntries; ++i) entries[i].offset -= sg.recordsOffset;      // offsets inside the run's own records
+                    if (isaac_gpu_bam_indexer_add_entries(indexer, entries + sg.firstEntry, sg.nEntries, sg.recordsBytes, static_cast<const uint8_t *>(out.bgzf.p) + sg.bgzfOffset, sg.bgzfBytes))
+                        failure = std::string("isaac_gpu_bam_indexer_add_entries: ") + isaac_gpu_bam_index_last_error();
+                }
                 nRecordsWritten += out.nRecords; ++binsWritten;
             }
             pinned.give(out.bgzf); pinned.give(out.entries);
@@ -1014,14 +1166,19 @@ int run(const AlignOptions &o)
     }
     if (!failure.empty()) throw std::runtime_error(failure);
     const double buildSeconds = seconds() - buildStart, total = seconds() - runStart;
-    uint64_t tilesOnDevice = 0, loadsOnDevice = 0, peakDevice = 0, nLoads = 0;
+    // the bins' ranges (ReferencePosition values) for whoever checks the file against the same plan
+    std::string binRangesJson = "[";
+    for (size_t b = 0; b < plan.ranges.size(); ++b) binRangesJson += (b ? ", [" : "[") + std::to_string(plan.ranges[b].first) + ", " + std::to_string(plan.ranges[b].second) + "]";
+    binRangesJson += "]";
+    uint64_t tilesOnDevice = 0, loadsOnDevice = 0, peakDevice = 0, nLoads = 0; double selectBusySeconds = 0;
+    for (auto &w : workers) selectBusySeconds += w->selectSeconds;
     for (auto &w : workers) { tilesOnDevice += w->tilesKeptOnDevice; loadsOnDevice += w->loadsKeptOnDevice; peakDevice = std::max(peakDevice, w->peakDeviceBytes); }
     for (const Lane &L : lanes) nLoads += L.loads.size();
     std::cerr << "isaac-align: " << bamPath << ": " << nRecordsWritten << " records in " << binsWritten << " bin(s)" << std::endl;
     // one line for scripts (bench.py): what the run took, stage by stage
     std::cerr << "isaac-align: timing {\"clusters\": " << totalClusters << ", \"reads\": " << totalClusters * nReads << ", \"records\": " << nRecordsWritten << ", \"workers\": " << workers.size()
-              << ", \"reference_s\": " << referenceSeconds << ", \"reference_fasta_s\": " << fastaSeconds << ", \"reference_contigs_s\": " << contigSeconds << ", \"reference_table_s\": " << tableSeconds << ", \"load_and_find_s\": " << loadSeconds << ", \"load_text_wait_s\": " << g_textWaitSeconds << ", \"load_convert_s\": " << g_convertSeconds << ", \"load_first_lookup_s\": " << g_firstLookupSeconds << ", \"select_and_bin_s\": " << selectSeconds << ", \"build_and_write_s\": " << buildSeconds
-              << ", \"tiles_kept_on_device\": " << tilesOnDevice << ", \"tiles\": " << tiles.size() << ", \"loads_kept_on_device\": " << loadsOnDevice << ", \"loads\": " << nLoads << ", \"bins\": " << nBins << ", \"bin_cuts\": " << plan.cuts.size()
+              << ", \"reference_s\": " << referenceSeconds << ", \"reference_fasta_s\": " << fastaSeconds << ", \"reference_contigs_s\": " << contigSeconds << ", \"reference_table_s\": " << tableSeconds << ", \"load_and_find_s\": " << loadSeconds << ", \"load_text_wait_s\": " << g_textWaitSeconds << ", \"load_convert_s\": " << g_convertSeconds << ", \"load_first_lookup_s\": " << g_firstLookupSeconds << ", \"select_and_bin_s\": " << selectSeconds << ", \"select_busy_s\": " << selectBusySeconds << ", \"build_and_write_s\": " << buildSeconds
+              << ", \"tiles_kept_on_device\": " << tilesOnDevice << ", \"tiles\": " << tiles.size() << ", \"loads_kept_on_device\": " << loadsOnDevice << ", \"loads\": " << nLoads << ", \"bins\": " << nBins << ", \"bin_cuts\": " << plan.cuts.size() << ", \"estimated_clusters\": " << estimatedClusters << ", \"bin_ranges\": " << binRangesJson
               << ", \"build_upload_s\": " << workers[0]->uploadSeconds << ", \"build_records_s\": " << workers[0]->recordsSeconds << ", \"build_deflate_s\": " << workers[0]->deflateSeconds
               << ", \"build_download_s\": " << workers[0]->downloadSeconds << ", \"file_write_s\": " << writeSeconds
               << ", \"overflow_clusters\": " << overflowClusters << ", \"mapq_near_integer\": " << mapqNearInteger << ", \"mapq_resolved_on_host\": " << mapqResolved << ", \"mapq_changed_by_host\": " << mapqChanged

@@ -105,21 +105,17 @@ def main():
                 left -= load
             return n
         tiles_per_lane = [tiles_of_lane(w) for w in written]
-        n_tiles = sum(tiles_per_lane)
         rng = np.random.default_rng(7)
-        sample = set(int(x) for x in rng.choice(n_tiles, size=min(args.sample_tiles, n_tiles), replace=False))
+        everything = [(lane + 1, number + 1) for lane, k in enumerate(tiles_per_lane) for number in range(k)]       # (lane number, tile number in the lane): as in the read names
+        sample = set(everything[int(x)] for x in rng.choice(len(everything), size=min(args.sample_tiles, len(everything)), replace=False))
         # ... and the first tile of every lane a sampled tile is in: the lane's template-length statistics come from it
-        first_of_lane, at = {}, 0
-        for lane, k in enumerate(tiles_per_lane):
-            if any(at <= t < at + k for t in sample):
-                first_of_lane[lane] = at
-            at += k
+        first_of_lane = {lane: (lane, 1) for lane, _ in sample}
         sample = sorted(sample | set(first_of_lane.values()))
         dump = os.path.join(work, "dump")
         tool = build.build_host()
         cmd = [tool, "-r", os.path.join(ref_dir, "sorted-reference.xml"), "-b", calls, "--base-calls-format", "fastq", "-o", os.path.join(work, "Aligned"), "--use-bases-mask", "y*,y*",
                "--clusters-at-a-time", str(tile), "--devices", args.devices]
-        env = dict(os.environ, ISAAC_ALIGN_DUMP_TILES="%s:%s" % (dump, ",".join(str(s) for s in sample)))
+        env = dict(os.environ, ISAAC_ALIGN_DUMP_TILES="%s:%s" % (dump, ",".join("%d.%d" % s for s in sample)))
         t0 = time.time()
         r = subprocess.run(cmd, capture_output=True, text=True, env=env)
         wall = time.time() - t0
@@ -151,22 +147,23 @@ def main():
         all_hits = np.ones(len(host_contigs), np.uint8)
         checks, tls_checks = [], []
         for s in sample:
-            meta = json.load(open(os.path.join(dump, "tile_%d.json" % s)))
+            stem = os.path.join(dump, "tile_%d_%d" % s)
+            meta = json.load(open(stem + ".json"))
             n = meta["clusters"]
-            bcl = np.fromfile(os.path.join(dump, "tile_%d.bcl" % s), np.uint8).reshape(n, 2 * L)
-            rec = np.fromfile(os.path.join(dump, "tile_%d.records" % s), abi.FRAGMENT_DTYPE)
-            cig = np.fromfile(os.path.join(dump, "tile_%d.cigars" % s), np.uint32)
+            bcl = np.fromfile(stem + ".bcl", np.uint8).reshape(n, 2 * L)
+            rec = np.fromfile(stem + ".records", abi.FRAGMENT_DTYPE)
+            cig = np.fromfile(stem + ".cigars", np.uint32)
             tls = abi.Tls()
             v = meta["tls"]
             tls.min, tls.max, tls.median, tls.low_std_dev, tls.high_std_dev = v[0:5]
             tls.best_model[0], tls.best_model[1], tls.stable, tls.mate_min, tls.mate_max = v[5:10]
             threads = min(128, os.cpu_count() or 1)
-            om, hits = ref.find_matches(params, bcl, n, tile=s, n_threads=threads)
+            om, hits = ref.find_matches(params, bcl, n, tile=meta["index"] & 0xfff, n_threads=threads)
             if s in first_of_lane.values():
                 # the lane's statistics as the oracle learns them from the lane's first tile: what the program used for every tile of the lane
-                otls = ref.determine_tls(params, bcl, om, all_hits, tile=s)
-                tls_checks.append({"tile": s, "lane": meta["lane"], "oracle": list(otls.astuple()), "program": list(tls.astuple()), "equal": otls.astuple() == tls.astuple()})
-            orec, ocig, _ = ref.select(params, bcl, om, tls, all_hits, tile=s, n_threads=threads, n_clusters_hint=n)
+                otls = ref.determine_tls(params, bcl, om, all_hits, tile=meta["index"])
+                tls_checks.append({"tile": "%d.%d" % s, "lane": meta["lane"], "oracle": list(otls.astuple()), "program": list(tls.astuple()), "equal": otls.astuple() == tls.astuple()})
+            orec, ocig, _ = ref.select(params, bcl, om, tls, all_hits, tile=meta["index"], n_threads=threads, n_clusters_hint=n)
             # every field of every record, and every CIGAR word through each record's own offset (the oracle's CIGARs lie in slots, the program's are packed)
             bad = np.zeros(len(rec), bool) if len(rec) == len(orec) else np.ones(max(len(rec), len(orec)), bool)
             if len(rec) == len(orec):
@@ -183,7 +180,7 @@ def main():
                 if word_bad.any():
                     bad[np.unique(np.repeat(np.arange(len(rec)), lengths)[word_bad])] = True
             first = [int(i) for i in np.flatnonzero(bad)[:3]]
-            checks.append({"tile": s, "lane": meta["lane"], "clusters": n, "records": int(len(rec)), "diffs": int(bad.sum()),
+            checks.append({"tile": "%d.%d" % s, "lane": meta["lane"], "clusters": n, "records": int(len(rec)), "diffs": int(bad.sum()),
                            "first_diffs": compare_records(orec[first], ocig, rec[first], cig) if first and len(rec) == len(orec) else []})
         result["sampled_tiles"] = checks
         result["lane_statistics"] = tls_checks

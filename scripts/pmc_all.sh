@@ -2,7 +2,7 @@
 # VALU / SALU / memory instruction counts of every kernel of a short bench run (one rocprofv3 --pmc pass), next to kernel times
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_FLAT SQ_INSTS_LDS SQ_WAVES SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_all -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie-pass > $R/gpurun_out/pmc_all.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_FLAT SQ_INSTS_LDS SQ_WAVES SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_all -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie-pass --no-cli-pass > $R/gpurun_out/pmc_all.log 2>&1
 cd $R
 f=$(find gpurun_out/pmc_all -name "*counter_collection.csv" | head -1)
 python3 - "$f" <<'PY'

@@ -4,7 +4,7 @@
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=8      # bench.py sets it for itself, but under rocprofv3 the runtime is up before Python starts
-B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie-pass --no-bam-pass --no-single-stream-pass"
+B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie-pass --no-bam-pass --no-single-stream-pass --no-cli-pass"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_j_fetch -- $B > $R/gpurun_out/pmc_j_fetch.log 2>&1; echo "fetch rc=$?"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_j_write -- $B > $R/gpurun_out/pmc_j_write.log 2>&1; echo "write rc=$?"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d $R/gpurun_out/pmc_j_sq -- $B > $R/gpurun_out/pmc_j_sq.log 2>&1; echo "sq rc=$?"

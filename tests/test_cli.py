@@ -274,7 +274,7 @@ def plan_bins(lengths, bin_bases):
 
 
 def split_by_bins(record_bytes, unaligned_offset, bin_ranges):
-    """[(offset, bytes)] of the records of every bin that has some, then of the unaligned ones: the runs of BGZF blocks of the file"""
+    """[(offset, bytes)] of the records of every (bin, contig) that has some, then of the unaligned ones: the runs of BGZF blocks of the file"""
     data = memoryview(record_bytes)
     parts, at, b = [], 0, 0
     while at < unaligned_offset:
@@ -282,8 +282,8 @@ def split_by_bins(record_bytes, unaligned_offset, bin_ranges):
         key = bam.reference_position(ref_id, pos)
         while not (bin_ranges[b][0] <= key < bin_ranges[b][1]):
             b += 1
-        if not parts or parts[-1][2] != b:
-            parts.append([at, 0, b])
+        if not parts or parts[-1][2] != (b, ref_id):          # a run of BGZF blocks per bin and, inside a bin of several contigs, per contig
+            parts.append([at, 0, (b, ref_id)])
         size = 4 + int.from_bytes(data[at:at + 4], "little")
         parts[-1][1] += size; at += size
     parts = [(p[0], p[1]) for p in parts]
@@ -410,11 +410,13 @@ def test_gpu_isaac_align_end_to_end(tmp_path, scenario):
     host_bins = "ISAAC_ALIGN_HOST_BINS" in sc.get("env", {})
     assert timing["tiles_kept_on_device"] == (0 if host_bins else n_tiles)                              # every tile's parts stayed on the device, or none did
     assert timing["loads_kept_on_device"] == (0 if "ISAAC_ALIGN_HOST_LOADS" in sc.get("env", {}) else n_tiles)
-    # the bins the host made (host/isaac_align.cpp: planBins): contigs in karyotype order, grouped or cut by the reads per base of the run
-    total_records = sum(len(b_) for _, b_ in lanes) * n_reads
+    # the bins the host made (host/isaac_align.cpp: planBins): contigs in karyotype order, grouped or cut by the reads the run was expected to have per base
+    # (the host sizes its bins from an estimate of the cluster count -- file size over the length of the first record -- which it reports)
     ordered_lengths = [len(stored[i]) for i in sorted(range(3), key=lambda i: karyotype[i])]
-    bin_ranges, cuts = plan_bins(ordered_lengths, sc.get("bin_records", 4000000) / (total_records / sum(ordered_lengths)))
-    assert timing["bin_cuts"] == len(cuts) and timing["bins"] == len(bin_ranges) + 1
+    total_clusters = sum(len(b_) for _, b_ in lanes)
+    assert 0.5 * total_clusters < timing["estimated_clusters"] < 8 * total_clusters
+    bin_ranges, cuts = plan_bins(ordered_lengths, sc.get("bin_records", 4000000) / (timing["estimated_clusters"] * n_reads / sum(ordered_lengths)))
+    assert timing["bin_cuts"] == len(cuts) and timing["bins"] == len(bin_ranges) + 1 and [tuple(r) for r in timing["bin_ranges"]] == bin_ranges
     assert (len(cuts) >= 6) if sc.get("bin_records") else (len(bin_ranges) == 1)
     # ---- the oracle on the same inputs
     b = gpu.Aligner(options.default_params(100, 100), 0, contigs)
