@@ -77,9 +77,11 @@ __device__ inline u32 bswLaneOfThread() { return (threadIdx.x & 15u) >> 1; }
 // GLOBAL_FLAGS: T is device memory, not LDS (1.8 KB of flags per problem at 2 x 150 limit the wavefronts a CU holds to two per SIMD, and a row is
 // a chain of dependent packed and DPP instructions that would like more of them to hide behind).  The stores are plain, the traceback's reads go to
 // the L2 (agent scope) behind a release fence: they are other lanes' stores.  An experiment that lost (kernels.h: ISAAC_BSW_GLOBAL_FLAGS).
-template <bool PADDED = false, bool GLOBAL_FLAGS = false, typename QueryF>
+struct BswNothingBetween { __device__ void operator()() const {} };
+// between(): called once, behind the last row and before the traceback (k_gapped_jobs asks for its next problem's bases there: they arrive while the group walks back)
+template <bool PADDED = false, bool GLOBAL_FLAGS = false, typename QueryF, typename BetweenF = BswNothingBetween>
 __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapOpenScore, int gapExtendScore, QueryF query, u32 L, const char *database,
-                                     u8 *T, short *endVals, u32 l, u32 *cig, u32 cap, u32 &n, bool &overflow)
+                                     u8 *T, short *endVals, u32 l, u32 *cig, u32 cap, u32 &n, bool &overflow, BetweenF between = BetweenF())
 {
     STAMP_BEGIN();
     const int initialValue = s16(-32768 + gapOpenScore);
@@ -232,6 +234,7 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
     }
 #endif
     reinterpret_cast<int *>(endVals)[l] = G; reinterpret_cast<int *>(endVals)[8 + l] = E; reinterpret_cast<int *>(endVals)[16 + l] = F;
+    between();
     STAMP(55);
     if constexpr (GLOBAL_FLAGS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -335,114 +338,160 @@ __global__ __launch_bounds__(BSW_BLOCK) void k_gapped_jobs(DevParams P, DevRefer
     char *stagedQuery = reinterpret_cast<char *>(mine + 128);
     char *stagedDatabase = stagedQuery + ((maxReadLength + 47) & ~15u);
     const u32 nJobs = imin(*jobCounter, jobsCap);
-    for (u32 j = blockIdx.x * groups + group; j < nJobs; j += gridDim.x * groups)
+    // A problem is set up in two steps that each wait for memory -- its record, then the read's bytes and the window of the contig its record points to --
+    // and a group that does them in front of its rows stands still for both (12 % of the kernel with two wavefronts per SIMD to hide it behind).  So the
+    // group's next problem is fetched beside the current one: its record while the rows run, its bases (into registers) while the group walks the
+    // traceback; the staging into LDS is all that is left in front of the rows.  The loads are volatile so that they stay where they are written: the
+    // compiler otherwise moves a load to the block that uses it, behind the loop it was meant to overlap.
+    struct Prepared
+    {
+        Cand f; ReadView read; i64 begin, end, strandPosition; u32 sequenceLength, left, right, cluster; const char *database; bool go;
+        u32 queryChunks, window, windowChunks;
+    };
+    typedef u64 __attribute__((aligned(1))) UnalignedU64;
+    const auto fetchJob = [&](u32 j, uint4 (&raw)[5])
+    {
+        const volatile uint4 *from = reinterpret_cast<const volatile uint4 *>(jobs + j);
+#pragma unroll
+        for (u32 i = 0; i < 5; ++i) { raw[i].x = from[i].x; raw[i].y = from[i].y; raw[i].z = from[i].z; raw[i].w = from[i].w; }
+    };
+    static_assert(sizeof(GappedJob) == 80, "five 16-byte pieces");
+    const auto prepare = [&](const uint4 (&raw)[5], Prepared &p)
+    {
+        GappedJob jb; memcpy(&jb, raw, sizeof(jb));
+        p.f = jb.in; p.cluster = jb.cluster;
+        const u32 r = p.f.readIndex;
+        p.read.bcl = bcl + u64(clusterBase + jb.cluster) * P.clusterLength + P.readOffset[r]; p.read.length = P.readLength[r];
+        p.read.firstCycle = P.firstCycle[r]; p.read.endCyclesMasked = jb.endCyclesMasked;
+        CigarPool none; none.words = nullptr; none.used = 0; none.capacity = 40; none.overflow = 0;       // (the problem's candidate comes without a CIGAR: nothing is read through it)
+        candResetAlignment(p.f, none);
+        p.f.lowClipped = 0; p.f.highClipped = 0;
+        const u64 referenceSize = contigLength(R, p.f.contigId);
+        p.go = clipSequence(p.read, p.f, i64(referenceSize), p.begin, p.end);
+        p.sequenceLength = 0; p.strandPosition = 0; p.left = 0; p.right = 0; p.database = nullptr; p.queryChunks = 0; p.window = 0; p.windowChunks = 0;
+        if (p.go)
+        {
+            p.sequenceLength = u32(p.end - p.begin);
+            p.strandPosition = p.f.position;
+            if (i64(referenceSize) < i64(p.sequenceLength) + p.strandPosition + i64(BSW_WIDEST_GAP_SIZE)) p.go = false;
+            if (!p.sequenceLength || p.sequenceLength > maxReadLength) p.go = false;
+        }
+        if (p.go)
+        {
+            getFlanks(p.strandPosition, p.sequenceLength, referenceSize, p.left, p.right);
+            p.database = R.bases + R.contigOffset[p.f.contigId] + p.strandPosition - p.left;
+            p.queryChunks = (p.sequenceLength + 7) / 8; p.window = p.sequenceLength + 15; p.windowChunks = (p.window + 7) / 8;
+        }
+    };
+    // the group's 8 lanes bring the query and the window into LDS side by side, eight bases per lane and step, all of a lane's loads requested before
+    // the first is used: chunks c0 + k + 8 t (t < 4) of either sequence
+    const auto fetchChunks = [&](const Prepared &p, u32 c0, u64 (&q)[4], u64 (&w)[4])
+    {
+        const bool reverse = p.f.reverse != 0;
+#pragma unroll
+        for (u32 t = 0; t < 4; ++t)
+        {
+            u32 c = c0 + k + BSW_GROUP_LANES * t;
+            {   // BCL bytes of strand positions begin + 8c .. + 7 (position t of the chunk in byte t); never reads outside the read's bytes
+                const u32 cq = c < p.queryChunks ? c : p.queryChunks - 1;
+                const u32 s0 = u32(p.begin) + 8 * cq;
+                u64 bytes;
+                if (!reverse) { const u32 at = s0 + 8 <= p.read.length ? s0 : p.read.length - 8; bytes = *reinterpret_cast<const volatile UnalignedU64 *>(p.read.bcl + at); bytes >>= 8 * (s0 - at); }
+                else
+                {   // strand position p is byte length - 1 - p
+                    const i32 lo = i32(p.read.length) - 8 - i32(s0);
+                    bytes = *reinterpret_cast<const volatile UnalignedU64 *>(p.read.bcl + (lo < 0 ? 0 : lo));
+                    if (lo < 0) bytes <<= 8 * u32(-lo);
+                    bytes = __builtin_bswap64(bytes);
+                }
+                q[t] = bytes;
+            }
+            {
+                const u32 cw = c < p.windowChunks ? c : p.windowChunks - 1;
+                const u32 at = 8 * cw + 8 <= p.window ? 8 * cw : p.window - 8;       // the window is at least 15 bases
+                w[t] = *reinterpret_cast<const volatile UnalignedU64 *>(p.database + at) >> (8 * (8 * cw - at));
+            }
+        }
+    };
+    const auto stageChunks = [&](const Prepared &p, u32 c0, const u64 (&q)[4], const u64 (&w)[4])
+    {
+        const bool reverse = p.f.reverse != 0;
+#pragma unroll
+        for (u32 t = 0; t < 4; ++t)
+        {
+            const u32 c = c0 + k + BSW_GROUP_LANES * t;
+            if (c < p.queryChunks)
+            {   // strandBase for eight positions at once
+                const u64 nFlags = zeroBytes(q[t] & (0xfc * BYTES_01));
+                u64 codes = q[t] & (0x03 * BYTES_01);
+                if (reverse) codes ^= 0x03 * BYTES_01;
+                const u64 nBytes = (nFlags >> 7) * 0xff;
+                reinterpret_cast<u64 *>(stagedQuery)[c] = (asciiOfCodes(codes) & ~nBytes) | ((0x6e * BYTES_01) & nBytes);
+            }
+            if (c < p.windowChunks) reinterpret_cast<u64 *>(stagedDatabase)[c] = w[t];
+        }
+    };
+    const u32 stride = gridDim.x * groups;
+    u32 j = blockIdx.x * groups + group;
+    Prepared cur; cur.go = false;
+    u64 q[4] = { 0, 0, 0, 0 }, w[4] = { 0, 0, 0, 0 };
+    if (j < nJobs)
+    {
+        uint4 raw[5]; fetchJob(j, raw);
+        prepare(raw, cur);
+        if (cur.go) fetchChunks(cur, 0, q, w);
+    }
+    for (; j < nJobs; j += stride)
     {
         STAMP_BEGIN();
-        const GappedJob &jb = jobs[j];
+        const u32 jn = j + stride;
+        const bool haveNext = jn < nJobs;
+        uint4 rawNext[5];
+        if (haveNext) fetchJob(jn, rawNext);                       // on its way while this problem's rows run
+        Prepared next; next.go = false;
+        u64 qn[4] = { 0, 0, 0, 0 }, wn[4] = { 0, 0, 0, 0 };
+        const auto lookAhead = [&]() { if (haveNext) { prepare(rawNext, next); if (next.go) fetchChunks(next, 0, qn, wn); } };
         GappedResult &res = results[j];
-        Cand f = jb.in;
-        const u32 r = f.readIndex;
-        ReadView read;
-        read.bcl = bcl + u64(clusterBase + jb.cluster) * P.clusterLength + P.readOffset[r]; read.length = P.readLength[r];
-        read.firstCycle = P.firstCycle[r]; read.endCyclesMasked = jb.endCyclesMasked;
-        CigarPool pool; pool.words = res.cigar; pool.used = 0; pool.capacity = 40; pool.overflow = 0;
-        candResetAlignment(f, pool);
-        f.lowClipped = 0; f.highClipped = 0;
-        const u64 referenceSize = contigLength(R, f.contigId);
-        i64 begin, end;
-        bool go = clipSequence(read, f, i64(referenceSize), begin, end);
+        Cand f = cur.f;
         u32 n = 0, matchCount = 0; bool overflow = false;
-        u32 sequenceLength = 0; i64 strandPosition = 0;
-        if (go)
+        if (cur.go)
         {
-            if (begin) { if (k == 0) res.cigar[0] = cigarOp(u32(begin), OP_SOFT_CLIP); n = 1; }
-            sequenceLength = u32(end - begin);
-            strandPosition = f.position;
-            if (i64(referenceSize) < i64(sequenceLength) + strandPosition + i64(BSW_WIDEST_GAP_SIZE)) go = false;
-            if (!sequenceLength || sequenceLength > maxReadLength) go = false;
-        }
-        if (go)
-        {
-            u32 left, right;
-            getFlanks(strandPosition, sequenceLength, referenceSize, left, right);
-            const char *database = R.bases + R.contigOffset[f.contigId] + strandPosition - left;
+            if (cur.begin) { if (k == 0) res.cigar[0] = cigarOp(u32(cur.begin), OP_SOFT_CLIP); n = 1; }
             STAMP(50);
-            // the group's 8 lanes bring the query and the window into LDS side by side, eight bases per lane and step, all of a lane's
-            // loads requested before the first is used (a byte per lane and step -- a load, a wait, a store, twenty times over -- cost as
-            // much as the DP itself once fewer waves were there to hide it); the DP rows then read LDS
-            {
-                const u32 queryChunks = (sequenceLength + 7) / 8, window = sequenceLength + 15, windowChunks = (window + 7) / 8;
-                const u8 *bclBytes = read.bcl;
-                const bool reverse = f.reverse != 0;
-                // BCL bytes of strand positions begin + 8c .. + 7 (position t of the chunk in byte t); never reads outside the read's bytes
-                const auto loadQuery = [&](u32 c)
-                {
-                    const u32 s = u32(begin) + 8 * c;
-                    u64 bytes;
-                    if (!reverse) { const u32 at = s + 8 <= read.length ? s : read.length - 8; memcpy(&bytes, bclBytes + at, 8); bytes >>= 8 * (s - at); }
-                    else
-                    {   // strand position p is byte length - 1 - p
-                        const i32 lo = i32(read.length) - 8 - i32(s);
-                        memcpy(&bytes, bclBytes + (lo < 0 ? 0 : lo), 8);
-                        if (lo < 0) bytes <<= 8 * u32(-lo);
-                        bytes = __builtin_bswap64(bytes);
-                    }
-                    return bytes;
-                };
-                const auto loadWindow = [&](u32 c)
-                {
-                    const u32 at = 8 * c + 8 <= window ? 8 * c : window - 8;       // the window is at least 15 bases
-                    u64 bytes; memcpy(&bytes, database + at, 8);
-                    return bytes >> (8 * (8 * c - at));
-                };
-                for (u32 c0 = 0; c0 < windowChunks; c0 += 4 * BSW_GROUP_LANES)
-                {
-                    u64 q[4], w[4];
-#pragma unroll
-                    for (u32 t = 0; t < 4; ++t)
-                    {
-                        const u32 c = c0 + k + BSW_GROUP_LANES * t;
-                        q[t] = loadQuery(c < queryChunks ? c : queryChunks - 1);
-                        w[t] = loadWindow(c < windowChunks ? c : windowChunks - 1);
-                    }
-#pragma unroll
-                    for (u32 t = 0; t < 4; ++t)
-                    {
-                        const u32 c = c0 + k + BSW_GROUP_LANES * t;
-                        if (c < queryChunks)
-                        {   // strandBase for eight positions at once
-                            const u64 nFlags = zeroBytes(q[t] & (0xfc * BYTES_01));
-                            u64 codes = q[t] & (0x03 * BYTES_01);
-                            if (reverse) codes ^= 0x03 * BYTES_01;
-                            const u64 nBytes = (nFlags >> 7) * 0xff;
-                            reinterpret_cast<u64 *>(stagedQuery)[c] = (asciiOfCodes(codes) & ~nBytes) | ((0x6e * BYTES_01) & nBytes);
-                        }
-                        if (c < windowChunks) reinterpret_cast<u64 *>(stagedDatabase)[c] = w[t];
-                    }
-                }
+            stageChunks(cur, 0, q, w);
+            for (u32 c0 = 4 * BSW_GROUP_LANES; c0 < cur.windowChunks; c0 += 4 * BSW_GROUP_LANES)
+            {   // (reads beyond 241 bases: the rest of the sequences is fetched here)
+                u64 qm[4], wm[4];
+                fetchChunks(cur, c0, qm, wm);
+                stageChunks(cur, c0, qm, wm);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             STAMP(51);
-            PlainQuery q; q.q = stagedQuery;
-            const u32 ret = bswCooperative<true, 0 != ISAAC_BSW_GLOBAL_FLAGS>(P.gapMatch, P.gapMismatch, -P.gapOpen, -P.gapExtend, q, sequenceLength, stagedDatabase, T, endVals, k, res.cigar, 40u, n, overflow);
+            PlainQuery pq; pq.q = stagedQuery;
+            const u32 ret = bswCooperative<true, 0 != ISAAC_BSW_GLOBAL_FLAGS>(P.gapMatch, P.gapMismatch, -P.gapOpen, -P.gapExtend, pq, cur.sequenceLength, stagedDatabase, T, endVals, k, res.cigar, 40u, n, overflow,
+                                                                               lookAhead);
             STAMP(52);
             if (k == 0)
             {
-                strandPosition += ret;
-                const u32 clipEndBases = u32(i64(read.length) - end);
+                i64 strandPosition = cur.strandPosition + ret;
+                const u32 clipEndBases = u32(i64(cur.read.length) - cur.end);
                 if (clipEndBases) { if (n < 40) res.cigar[n++] = cigarOp(clipEndBases, OP_SOFT_CLIP); else overflow = true; }
-                strandPosition -= left;
+                strandPosition -= cur.left;
                 // the rescan of the CIGAR (a serial fp64 chain per alignment) is k_gapped_rescan's, one thread per problem:
                 // here it would occupy one lane in sixteen.  Handed over: the strand position and "aligned" in matchCount.
                 f.position = strandPosition;
                 matchCount = 1;
             }
         }
+        else lookAhead();
         STAMP(53);
         if (k == 0) { res.out = f; res.matchCount = matchCount; res.nCigar = overflow ? 0xffffffffu : n; }
         STAMP(54);
+        cur = next;
+#pragma unroll
+        for (u32 t = 0; t < 4; ++t) { q[t] = qn[t]; w[t] = wn[t]; }
     }
 }
 

@@ -400,7 +400,9 @@ void writeAt(int fd, const uint8_t *data, uint64_t bytes, uint64_t offset)
             done += uint64_t(r);
         }
     };
-    if (bytes < (uint64_t(32) << 20) || std::getenv("ISAAC_ALIGN_PLAIN_WRITES")) { plain(); return; }
+    // (measured on the MI355X host, tmpfs: one writer 6 GB/s, eight writers on one file 4.3 GB/s, sixteen threads through a mapping 2.8 GB/s: the plain write
+    // is the default, ISAAC_ALIGN_MAPPED_WRITES=1 selects the mapping)
+    if (bytes < (uint64_t(32) << 20) || !std::getenv("ISAAC_ALIGN_MAPPED_WRITES")) { plain(); return; }
     const uint64_t page = uint64_t(::sysconf(_SC_PAGESIZE)), mapFrom = offset / page * page, lead = offset - mapFrom;
     if (::ftruncate(fd, off_t(offset + bytes))) { plain(); return; }
     void *map = ::mmap(0, size_t(lead + bytes), PROT_READ | PROT_WRITE, MAP_SHARED, fd, off_t(mapFrom));
@@ -613,6 +615,10 @@ int run(const AlignOptions &o)
     std::vector<uint64_t> unselected(workers.size(), 0);             // tiles dealt to the worker and not yet through its selection
     std::atomic<uint64_t> totalClusters(0), totalTiles(0);
     const bool hostBins = 0 != std::getenv("ISAAC_ALIGN_HOST_BINS");          // tests: every part through host memory
+    // ISAAC_ALIGN_STREAM_SELECTION=1: the selection begins as soon as every contig has a match.  Off by default: on one device the conversion of the base calls
+    // and the selection are both bound by the device, and side by side each took longer than what running them one after the other costs (10 M pairs:
+    // 1.2 + 0.6 s against 0.64 + 0.82 s; profiles/r5_cli_stream.log) -- the pipeline is what a host with a device per stage, or a faster converter, wants
+    const bool streamSelection = 0 != std::getenv("ISAAC_ALIGN_STREAM_SELECTION");
     // ISAAC_ALIGN_DUMP_TILES=<directory>:<lane>.<tile>,...: tiles (by lane number and tile number, as in the read names) to write out as they were selected
     std::set<std::pair<unsigned, unsigned> > dumpTiles; std::string dumpDirectory;
     if (const char *e = std::getenv("ISAAC_ALIGN_DUMP_TILES"))
@@ -735,7 +741,7 @@ int run(const AlignOptions &o)
                         for (Tile *t : load.tiles) { ready[w.id].push_back(t); ++unselected[w.id]; }
                         bool all = true;
                         for (uint32_t c = 0; c < nContigs; ++c) { contigHasMatches[c] |= l.hits[c]; all = all && contigHasMatches[c]; }
-                        if (all && !hitsClosed) closeHits();
+                        if (all && !hitsClosed && streamSelection) closeHits();
                         wake.notify_all();
                     }
                     if (loaded[0] < loadClusters) break;
@@ -900,6 +906,20 @@ int run(const AlignOptions &o)
         catch (const std::exception &e) { std::lock_guard<std::mutex> hold(shared); if (pipelineError.empty()) pipelineError = e.what(); wake.notify_all(); }
     };
 
+    // the page-locked buffers the build stage fills are made while the base calls are loaded (locking pages is slow: a gigabyte takes a tenth of a second and more)
+    PinnedPool pinned;
+    std::thread pinnedWarm([&]()
+    {
+        try
+        {
+            const uint64_t perBin = std::min<uint64_t>(binRecords, std::max<uint64_t>(estimatedClusters * nReads, 1));
+            std::vector<PinnedPool::Buffer> made;
+            for (unsigned i = 0; i < 4; ++i) { made.push_back(pinned.take(perBin * 220)); made.push_back(pinned.take(perBin * sizeof(isaac_bam_index_entry))); }
+            for (PinnedPool::Buffer &b : made) pinned.give(b);
+        }
+        catch (const std::exception &) {}       // (the build stage asks again and reports what fails)
+    });
+    struct JoinWarm { std::thread &t; ~JoinWarm() { if (t.joinable()) t.join(); } } joinWarm{ pinnedWarm };
     double loadSeconds = 0;
     const double selectStart = seconds();
     {
@@ -986,7 +1006,7 @@ int run(const AlignOptions &o)
     for (uint32_t b = 0; b + 1 < nBins; ++b) fileOrder.push_back(b);
     if ("front" != o.keepUnaligned) fileOrder.push_back(nBins - 1);
     std::vector<BinOutput> outputs(fileOrder.size());
-    PinnedPool pinned;
+    if (pinnedWarm.joinable()) pinnedWarm.join();
     std::mutex outputLock; std::condition_variable outputReady, outputTaken;
     std::atomic<size_t> nextBin(0);
     size_t binsWrittenSoFar = 0;                        // (under outputLock) the builders stay at most this far ahead of the file: finished bins wait in host memory

@@ -23,16 +23,11 @@ BandedSmithWaterman::BandedSmithWaterman(int match, int mismatch, int gapOpen, i
         throw std::invalid_argument("BandedSmithWaterman: unsupported read length for these scores");
 }
 
-// BandedSmithWaterman.cpp:84-462.  Lane k (0..15) of row i corresponds to database index i + 15 - k.
-unsigned BandedSmithWaterman::align(const char *queryBegin, const char *queryEnd, const char *dbBegin, const char *dbEnd, Cigar &cigar) const
+// the rows of the band, lane by lane (the restatement the AVX2 form below is checked against: ORACLE_BSW_SCALAR=1 selects it)
+void BandedSmithWaterman::rowsScalar(const char *queryBegin, size_t querySize, const char *dbBegin, int16_t *G, int16_t *E, int16_t *F) const
 {
-    const size_t querySize = queryEnd - queryBegin;
-    assert(querySize + WIDEST_GAP_SIZE - 1 == size_t(dbEnd - dbBegin));
-    assert(querySize <= size_t(maxReadLength));
-    (void)dbEnd;
-    const size_t originalCigarSize = cigar.size();
     const int16_t open = int16_t(gapOpenScore), ext = int16_t(gapExtendScore);
-    int16_t E[16], F[16], G[16];
+    (void)ext;
     for (unsigned k = 0; k < 16; ++k) { E[k] = initialValue; F[k] = 0; G[k] = initialValue; } // :109-114 (F = 0 quirk)
     G[0] = 0;                                                                                  // :115
     uint8_t *t = &T[0];
@@ -100,6 +95,106 @@ unsigned BandedSmithWaterman::align(const char *queryBegin, const char *queryEnd
         for (unsigned k = 0; k < 16; ++k) { t[k] = TG[k]; t[16 + k] = TE[k]; t[32 + k] = TF[k]; } // :306-308
         t += 48;
     }
+}
+
+// The same rows sixteen lanes at a time (AVX2: the whole band of 16 x int16 in one register, where the reference's SSE2 code holds it in two): F, G, the
+// 16-bit max over pairs of flag bytes and W as the reference's vector statements; the E chain, which the reference also walks lane by lane (:246-297),
+// on the lanes stored to memory.  Checked against rowsScalar on the reference's 301 known-answer cases and on random ones (tests/test_oracle_golden.py).
+static thread_local int g_forceScalarRows = 0;
+void bswForceScalarRows(int on) { g_forceScalarRows = on; }
+bool BandedSmithWaterman::useAvx2()
+{
+#if defined(__AVX2__)
+    static const bool scalar = 0 != std::getenv("ORACLE_BSW_SCALAR");
+    return !scalar && !g_forceScalarRows;
+#else
+    return false;
+#endif
+}
+#if defined(__AVX2__)
+} // namespace oracle
+#include <immintrin.h>
+namespace oracle
+{
+void BandedSmithWaterman::rowsAvx2(const char *queryBegin, size_t querySize, const char *dbBegin, int16_t *Gout, int16_t *Eout, int16_t *Fout) const
+{
+    const __m256i open = _mm256_set1_epi16(int16_t(gapOpenScore)), ext = _mm256_set1_epi16(int16_t(gapExtendScore));
+    const __m256i init = _mm256_set1_epi16(initialValue), one = _mm256_set1_epi16(1), two = _mm256_set1_epi16(2);
+    const __m256i lane0 = _mm256_setr_epi16(-1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+    alignas(32) int16_t e0[16], g0[16];
+    for (unsigned k = 0; k < 16; ++k) { e0[k] = initialValue; g0[k] = initialValue; }
+    g0[0] = 0;
+    __m256i E = _mm256_load_si256(reinterpret_cast<const __m256i *>(e0)), F = _mm256_setzero_si256(), G = _mm256_load_si256(reinterpret_cast<const __m256i *>(g0));
+    const __m128i reverse = _mm_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0);
+    const __m256i wMatch = _mm256_set1_epi16(int16_t(uint16_t(uint8_t(matchScore)))), wMismatch = _mm256_set1_epi16(int16_t(uint16_t(0xff00u | uint8_t(mismatchScore))));
+    const int16_t openS = int16_t(gapOpenScore);
+    uint8_t *t = &T[0];
+    alignas(32) int16_t gmo[16], fmo[16], eNew[16];
+    for (size_t i = 0; i < querySize; ++i)
+    {
+        // F (:130-173): computed where its inputs are, then moved up a lane; lane 0 gets the initial value and flag 0
+        const __m256i m = _mm256_max_epi16(G, E);
+        const __m256i gltE = _mm256_cmpgt_epi16(E, G);                                   // G < E
+        const __m256i v = _mm256_sub_epi16(m, open), fe = _mm256_sub_epi16(F, ext);
+        const __m256i vltFe = _mm256_cmpgt_epi16(fe, v);
+        const __m256i tfHere = _mm256_blendv_epi8(_mm256_and_si256(gltE, one), two, vltFe);   // v < fe ? 2 : (G < E ? 1 : 0)
+        const __m256i nfHere = _mm256_max_epi16(v, fe);
+        const __m256i t8 = _mm256_permute2x128_si256(nfHere, nfHere, 0x08), t8f = _mm256_permute2x128_si256(tfHere, tfHere, 0x08);
+        __m256i newF = _mm256_alignr_epi8(nfHere, t8, 14), TF = _mm256_alignr_epi8(tfHere, t8f, 14);
+        newF = _mm256_blendv_epi8(newF, init, lane0); TF = _mm256_andnot_si256(lane0, TF);
+        // G (:174-197) and its flags: fE = G < E, fF = max(G, E) < F
+        const __m256i fE = _mm256_and_si256(gltE, one);
+        const __m256i fF = _mm256_and_si256(_mm256_cmpgt_epi16(F, m), two);
+        __m256i newG = _mm256_max_epi16(m, F);
+        // :197 the 16-bit max over pairs of flag bytes: the flags as sixteen bytes, viewed as eight int16
+        const __m256i packedF = _mm256_permute4x64_epi64(_mm256_packus_epi16(fF, fF), 0xd8), packedE = _mm256_permute4x64_epi64(_mm256_packus_epi16(fE, fE), 0xd8);
+        const __m128i TG = _mm_max_epi16(_mm256_castsi256_si128(packedF), _mm256_castsi256_si128(packedE));
+        // W (:200-244): byte compare of the row's query base against the database bytes of the lanes (lane k: database[i + 15 - k])
+        const __m128i d = _mm_shuffle_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i *>(dbBegin + i)), reverse);
+        const __m128i same = _mm_cmpeq_epi8(d, _mm_set1_epi8(queryBegin[i]));
+        const __m256i same16 = _mm256_cvtepi8_epi16(same);                               // 0xffff where equal
+        newG = _mm256_add_epi16(newG, _mm256_blendv_epi8(wMismatch, wMatch, same16));
+        // E (:246-297): serial from lane 15 down to lane 0
+        _mm256_store_si256(reinterpret_cast<__m256i *>(gmo), _mm256_sub_epi16(newG, open));
+        _mm256_store_si256(reinterpret_cast<__m256i *>(fmo), _mm256_sub_epi16(newF, open));
+        {
+            int16_t g = initialValue, e = initialValue, f = initialValue;
+            for (unsigned j = 0; j < 16; ++j)
+            {
+                const unsigned k = 15 - j;
+                int16_t mx = g; uint8_t tMax = 0;
+                if (e > g && e > f) { mx = e; tMax = 1; }
+                else if (f > g) { mx = f; tMax = 2; }
+                t[16 + k] = tMax;
+                eNew[k] = mx;
+                g = gmo[k]; e = w16(int(mx) - gapExtendScore); f = fmo[k];
+            }
+        }
+        (void)openS;
+        E = _mm256_load_si256(reinterpret_cast<const __m256i *>(eNew));
+        G = newG; F = newF;
+        _mm_storeu_si128(reinterpret_cast<__m128i *>(t), TG);
+        const __m256i packedTF = _mm256_permute4x64_epi64(_mm256_packus_epi16(TF, TF), 0xd8);
+        _mm_storeu_si128(reinterpret_cast<__m128i *>(t + 32), _mm256_castsi256_si128(packedTF));
+        t += 48;
+    }
+    _mm256_store_si256(reinterpret_cast<__m256i *>(Gout), G); _mm256_store_si256(reinterpret_cast<__m256i *>(Eout), E); _mm256_store_si256(reinterpret_cast<__m256i *>(Fout), F);
+}
+#else
+void BandedSmithWaterman::rowsAvx2(const char *queryBegin, size_t querySize, const char *dbBegin, int16_t *G, int16_t *E, int16_t *F) const { rowsScalar(queryBegin, querySize, dbBegin, G, E, F); }
+#endif
+
+// BandedSmithWaterman.cpp:84-462.  Lane k (0..15) of row i corresponds to database index i + 15 - k.
+unsigned BandedSmithWaterman::align(const char *queryBegin, const char *queryEnd, const char *dbBegin, const char *dbEnd, Cigar &cigar) const
+{
+    const size_t querySize = queryEnd - queryBegin;
+    assert(querySize + WIDEST_GAP_SIZE - 1 == size_t(dbEnd - dbBegin));
+    assert(querySize <= size_t(maxReadLength));
+    (void)dbEnd;
+    const size_t originalCigarSize = cigar.size();
+    alignas(32) int16_t E[16], F[16], G[16];
+    if (useAvx2()) rowsAvx2(queryBegin, querySize, dbBegin, G, E, F);
+    else rowsScalar(queryBegin, querySize, dbBegin, G, E, F);
     // :349-379 end-cell scan
     int16_t mx = w16(int(uint16_t(G[15])) - 1);
     int ii = int(querySize) - 1;

@@ -97,6 +97,8 @@ int oracle_bsw_align(int match, int mismatch, int gap_open, int gap_extend, int 
     }
     catch (const std::exception &e) { g_error = e.what(); return 1; }
 }
+// this thread's banded Smith-Waterman rows lane by lane (1) or sixteen lanes at a time (0, where the build has AVX2): the check of the one against the other
+void oracle_bsw_force_scalar(int on) { bswForceScalarRows(on); }
 // constructor overflow rule only (BandedSmithWaterman.cpp:47-53): returns 1 when the reference would throw
 int oracle_bsw_check(int match, int mismatch, int gap_open, int gap_extend, int max_read_length)
 {

@@ -159,7 +159,13 @@ struct BandedSmithWaterman
     mutable std::vector<uint8_t> T; // maxReadLength * 3 * 16 bytes
     BandedSmithWaterman(int match, int mismatch, int gapOpen, int gapExtend, int maxReadLength); // throws std::invalid_argument on overflow bound
     unsigned align(const char *queryBegin, const char *queryEnd, const char *dbBegin, const char *dbEnd, Cigar &cigar) const;
+    // the rows of the band (flags into T, the last row's G / E / F out): lane by lane, or sixteen lanes at a time (AVX2); ORACLE_BSW_SCALAR=1 selects the former
+    void rowsScalar(const char *queryBegin, size_t querySize, const char *dbBegin, int16_t *G, int16_t *E, int16_t *F) const;
+    void rowsAvx2(const char *queryBegin, size_t querySize, const char *dbBegin, int16_t *G, int16_t *E, int16_t *F) const;
+    static bool useAvx2();
 };
+
+void bswForceScalarRows(int on);     // this thread's alignments by the lane-by-lane rows (the check of the AVX2 rows against them)
 
 // ---------------------------------------------------------------- quality
 // lib/alignment/Quality.cpp:34-66, include/alignment/Quality.hh:51-112

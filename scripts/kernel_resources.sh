@@ -35,7 +35,7 @@ seen = set()
 print("%-44s %8s %6s %6s %6s %8s" % ("kernel", "scratch", "vgpr", "agpr", "vspill", "lds"))
 for r in sorted(rows, key=lambda r: -int(r.get("private_segment_fixed_size", 0))):
     sym = r.get("symbol", "?").replace(".kd", "")
-    name = subprocess.run(["c++filt", sym], capture_output=True, text=True).stdout.strip().split("(")[0]
+    name = subprocess.run(["c++filt", sym], capture_output=True, text=True).stdout.strip().replace("(anonymous namespace)::", "").split("(")[0]
     if name in seen: continue
     seen.add(name)
     print("%-44s %8s %6s %6s %6s %8s" % (name[-44:], r.get("private_segment_fixed_size"), r.get("vgpr_count"), r.get("agpr_count", "0"), r.get("vgpr_spill_count"), r.get("group_segment_fixed_size")))

@@ -6,10 +6,13 @@
 workload=: the bench.py line of one of the passes; its genome size, read length and pairs per launch are recorded so that bench.py
 only quotes these figures for the same workload.
 
-FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KB.  Following /opt/skills/guides/MI355X_MICROARCH.md (HBM section), on
-gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes, so hbm_read_bytes = 2 x FETCH_SIZE; WRITE_SIZE is taken as is.  The
-guide calibrates this on wide streaming accesses; the kernels here issue narrow scattered ones, so the raw values are kept
-next to the corrected ones."""
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KB.  /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports half the
+bytes of a wide coalesced streaming read (128-byte requests tallied as 64) and says other access widths are uncalibrated.  Calibrated here
+(scripts/probes/fetch_calib.hip, profiles/r5_fetch_calib.log; 8 GB buffer, 64 M accesses per pattern): random 64-byte records read whole by four lanes,
+one 16-byte load per random line and random 8-byte words all give FETCH_SIZE = 1.000 x the 64-byte lines touched; only the streaming read gives 0.500 x.
+The kernels of the select path read scattered records, so hbm_read_bytes = FETCH_SIZE as reported (every line once); the doubled figure the summaries of
+rounds 1-4 carried is kept as hbm_read_bytes_per_launch_if_streaming (it is the right one only for kernels that stream: BCL staging, sorts, BAM encode,
+deflate)."""
 import collections, csv, json, re, sys
 
 def main():
@@ -52,7 +55,8 @@ def main():
                 continue
             e[c] = v
         if "FETCH_SIZE" in e:
-            e["hbm_read_bytes_per_launch"] = 2.0 * e["FETCH_SIZE"] * 1024 / launches
+            e["hbm_read_bytes_per_launch"] = e["FETCH_SIZE"] * 1024 / launches
+            e["hbm_read_bytes_per_launch_if_streaming"] = 2.0 * e["FETCH_SIZE"] * 1024 / launches
         if "WRITE_SIZE" in e:
             e["hbm_write_bytes_per_launch"] = e["WRITE_SIZE"] * 1024 / launches
         if "FETCH_SIZE" in e and "WRITE_SIZE" in e:

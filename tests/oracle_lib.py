@@ -177,6 +177,10 @@ class Oracle:
         self.check(self.lib.oracle_bsw_align(scores[0], scores[1], scores[2], scores[3], max_read_length, q, C.c_uint32(len(q)), d, ptr(cig), C.c_uint32(1024), C.byref(n), C.byref(off)))
         return cig[:n.value].copy(), off.value
 
+    def bsw_force_scalar(self, on):
+        """this thread's banded Smith-Waterman rows lane by lane (True) or by the AVX2 form (False)"""
+        self.lib.oracle_bsw_force_scalar(C.c_int(int(on)))
+
     def bsw_check(self, match, mismatch, gap_open, gap_extend, max_read_length):
         return bool(self.lib.oracle_bsw_check(match, mismatch, gap_open, gap_extend, max_read_length))
 

@@ -3,6 +3,7 @@ generated from /root/reference by tests/golden/make_golden.py)."""
 import json
 import os
 
+import numpy as np
 import pytest
 
 from oracle_lib import cigar_string
@@ -22,6 +23,41 @@ def test_bsw_known_answers(oracle):
         if list(cigar) != c["cigar"]:
             bad.append((c["name"], c["genome"], cigar_string(cigar), cigar_string(c["cigar"])))
     assert not bad, bad[:10]
+
+
+def test_bsw_avx2_rows_equal_the_lane_by_lane_rows(oracle):
+    """the oracle's banded Smith-Waterman computes its rows sixteen lanes at a time (AVX2: what cpu_baseline times); the lane-by-lane restatement of the
+    reference's statements is the form the known answers above were first pinned with: both on the reference's cases and on random ones, both presets,
+    reads with substitutions, insertions, deletions and N"""
+    g = load("bsw.json")
+    cases = [(g["scores"], g["max_read_length"], c["query"].encode(), c["database"].encode()) for c in g["cases"]]
+    rng = np.random.default_rng(5)
+    for k in range(4000):
+        scores = [[0, -3, 11, 4], [2, -1, 15, 3]][k % 2]
+        L = int(rng.integers(20, 260))
+        db = rng.integers(0, 4, L + 15 + 20)
+        q = list(db[7:7 + L + 12])
+        for _ in range(int(rng.integers(0, 6))):
+            at = int(rng.integers(0, len(q) - 1))
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                q[at] = (q[at] + 1 + int(rng.integers(0, 3))) % 4
+            elif kind == 1:
+                del q[at:at + 1 + int(rng.integers(0, 7))]
+            else:
+                q[at:at] = list(rng.integers(0, 4, 1 + int(rng.integers(0, 7))))
+        q = (q + list(rng.integers(0, 4, L)))[:L]
+        text = bytes(b"ACGT"[v] for v in q)
+        if k % 7 == 0:
+            text = text[:L // 2] + b"n" + text[L // 2 + 1:]
+        data = bytes(b"ACGTN"[v if k % 11 or i != 9 else 4] for i, v in enumerate(db[:L + 15]))
+        cases.append((scores, 300, text, data))
+    for scores, max_len, q, d in cases:
+        oracle.bsw_force_scalar(True)
+        want = oracle.bsw_align(scores, max_len, q, d)
+        oracle.bsw_force_scalar(False)
+        got = oracle.bsw_align(scores, max_len, q, d)
+        assert list(want[0]) == list(got[0]) and want[1] == got[1], (scores, q, d)
 
 
 def test_bsw_overflow_rule(oracle):
