@@ -274,6 +274,9 @@ int isaac_gpu_select(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t n_clus
  * is replaced in fragments_dev / cigar_dev.  To be called after isaac_gpu_select[_n] with the same arguments, before isaac_gpu_compact_cigars (cigar_dev in
  * slots of ISAAC_GPU_MAX_CIGAR_OPS words).  *n_flagged_out: clusters looked at; *n_changed_out: clusters whose records were replaced (none has ever been
  * seen to differ; a host that must be certain calls this).  The first call fetches the contigs back into host memory. */
+/* bases_host: the contigs as isaac_gpu_load_contigs was given them, which the caller keeps for as long as the context lives (NULL: forget them); without it the
+ * first isaac_gpu_resolve_flagged call fetches the contigs back from the device. */
+int isaac_gpu_set_host_contigs(isaac_gpu_ctx *ctx, const char *bases_host);
 int isaac_gpu_resolve_flagged(isaac_gpu_ctx *ctx, const uint8_t *bcl_dev, uint32_t n_clusters, uint32_t tile, const isaac_match *matches_dev, const uint64_t *cluster_offsets_dev,
                               const isaac_tls *tls, isaac_fragment *fragments_dev, uint32_t *cigar_dev, uint64_t *n_flagged_out, uint64_t *n_changed_out);
 /* The same when the caller knows the tile's match count (*n_matches_out of isaac_gpu_find_matches): isaac_gpu_select reads it from

@@ -76,7 +76,7 @@ struct isaac_gpu_ctx
     DevBuf<TableEntry> entries; u64 nKmers = 0; DevBuf<u32> karyotype; bool hasKaryotype = false;
     const TableEntry *entriesBorrowed = nullptr;   // isaac_gpu_set_index_dev: a table owned by the caller (another context, an RCCL receive buffer)
     const TableEntry *tableEntries() const { return entriesBorrowed ? entriesBorrowed : entries.p; }
-    DevBuf<u32> flaggedList; std::vector<char> hostBases; isaac_host_resolve::Resolver *resolver = nullptr; std::vector<u8> resolverLoaded;      // isaac_gpu_resolve_flagged
+    DevBuf<u32> flaggedList; std::vector<char> hostBases; const char *hostBasesGiven = nullptr; std::vector<isaac_host_resolve::Resolver *> resolvers; std::vector<u8> resolverLoaded;      // isaac_gpu_resolve_flagged
     DevBuf<u32> prefixTable; u32 prefixBits = 0; std::vector<u64> maskOffsets;   // entries before each mask of the table (load_index / build_index)
     DevBuf<u32> packedBases, notBase;   // 2-bit copy of the contigs + not-ACGT bitmap (k_rescue_windows reads these)
     DevBuf<u64> matchBase;
@@ -633,7 +633,7 @@ void isaac_gpu_destroy(isaac_gpu_ctx *c)
 #endif
     for (hipEvent_t e : c->eventPool) hipEventDestroy(e);
     if (c->ownsStream) hipStreamDestroy(c->stream);
-    if (c->resolver) isaac_host_resolve::destroy(c->resolver);
+    for (isaac_host_resolve::Resolver *r : c->resolvers) isaac_host_resolve::destroy(r);
     delete c;
 }
 
@@ -1585,6 +1585,17 @@ __global__ void k_flagged_clusters(const FragmentRecord *records, u32 nClusters,
     const u32 at = atomicAdd(count, 1u);
     if (at < capacity) list[at] = c;
 }
+// the caller's own copy of the contigs (as given to isaac_gpu_load_contigs), kept by the caller for as long as the context lives: isaac_gpu_resolve_flagged then
+// has nothing to fetch
+extern "C" int isaac_gpu_set_host_contigs(isaac_gpu_ctx *c, const char *basesHost)
+{
+    ISAAC_TRY
+    c->hostBasesGiven = basesHost;
+    for (isaac_host_resolve::Resolver *r : c->resolvers) isaac_host_resolve::destroy(r);
+    c->resolvers.clear(); c->resolverLoaded.clear();
+    return 0;
+    ISAAC_CATCH
+}
 extern "C" int isaac_gpu_resolve_flagged(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClusters, uint32_t tile, const isaac_match *matches, const uint64_t *offsets, const isaac_tls *tls,
                                          isaac_fragment *fragments, uint32_t *cigar, uint64_t *nFlaggedOut, uint64_t *nChangedOut)
 {
@@ -1611,51 +1622,82 @@ extern "C" int isaac_gpu_resolve_flagged(isaac_gpu_ctx *c, const uint8_t *bcl, u
     std::vector<u32> list(n);
     HIP_CHECK(hipMemcpy(list.data(), c->flaggedList.p, n * 4, hipMemcpyDeviceToHost));
     std::sort(list.begin(), list.end());
-    // the host's copy of the contigs: fetched once, when the first flagged cluster turns up
-    if (c->hostBases.empty() && c->hContigOffset[c->nContigs])
+    // the host's copy of the contigs: the caller's (isaac_gpu_set_host_contigs), or fetched once, when the first flagged cluster turns up
+    const char *hostBases = c->hostBasesGiven;
+    if (!hostBases)
     {
-        c->hostBases.resize(c->hContigOffset[c->nContigs]);
-        HIP_CHECK(hipMemcpy(c->hostBases.data(), c->bases, c->hostBases.size(), hipMemcpyDeviceToHost));
-    }
-    if (!c->resolver || c->resolverLoaded != c->hContigLoaded)
-    {   // (the rest-of-genome correction depends on which contigs count as loaded)
-        if (c->resolver) isaac_host_resolve::destroy(c->resolver);
-        c->resolverLoaded = c->hContigLoaded;
-        c->resolver = isaac_host_resolve::create(c->params, c->hostBases.data(), c->hContigOffset.data(), c->resolverLoaded.data(), c->nContigs);
-    }
-    std::vector<u8> clusterBcl(clusterLength);
-    std::vector<Match> clusterMatches;
-    std::vector<FragmentRecord> was(nReads), now(nReads);
-    std::vector<u32> wasCigar(size_t(nReads) * OUT_CIGAR_CAP), nowCigar(size_t(nReads) * OUT_CIGAR_CAP);
-    u64 changed = 0;
-    for (const u32 cluster : list)
-    {
-        u64 range[2];
-        HIP_CHECK(hipMemcpy(range, offsets + cluster, 16, hipMemcpyDeviceToHost));
-        const u64 first = range[0], nMatches = range[1] - range[0];
-        clusterMatches.resize(nMatches + 1);
-        if (nMatches) HIP_CHECK(hipMemcpy(clusterMatches.data(), reinterpret_cast<const Match *>(matches) + first, nMatches * sizeof(Match), hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(clusterBcl.data(), bcl + u64(cluster) * clusterLength, clusterLength, hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(was.data(), records + u64(cluster) * nReads, nReads * sizeof(FragmentRecord), hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(wasCigar.data(), cigar + u64(cluster) * nReads * OUT_CIGAR_CAP, wasCigar.size() * 4, hipMemcpyDeviceToHost));
-        std::fill(nowCigar.begin(), nowCigar.end(), 0u);
-        isaac_host_resolve::selectCluster(c->resolver, *tls, clusterBcl.data(), cluster, tile, clusterMatches.data(), u32(nMatches), now.data(), nowCigar.data());
-        bool differs = false;
-        for (u32 r = 0; r < nReads; ++r)
+        if (c->hostBases.empty() && c->hContigOffset[c->nContigs])
         {
-            FragmentRecord a = was[r], b = now[r];
-            // the diagnostic bits apart (the host form does not flag): everything the record says, and its CIGAR
-            b.reserved = (b.reserved & 0xffff0000u) | (a.reserved & 0xffffu) | (b.reserved & (RECORD_NOT_STORED | RECORD_FRAGMENT_OVERFLOW));
-            a.reserved = (a.reserved & ~u32(RECORD_NOT_STORED | RECORD_FRAGMENT_OVERFLOW)) | (a.reserved & (RECORD_NOT_STORED | RECORD_FRAGMENT_OVERFLOW));
-            now[r] = b;
-            if (std::memcmp(&a, &b, sizeof(a))) differs = true;
-            const u32 *ca = wasCigar.data() + (a.cigarOffset - u64(cluster) * nReads * OUT_CIGAR_CAP), *cb = nowCigar.data() + (b.cigarOffset - u64(cluster) * nReads * OUT_CIGAR_CAP);
-            if (a.cigarLength == b.cigarLength && std::memcmp(ca, cb, size_t(a.cigarLength) * 4)) differs = true;
+            c->hostBases.resize(c->hContigOffset[c->nContigs]);
+            HIP_CHECK(hipMemcpy(c->hostBases.data(), c->bases, c->hostBases.size(), hipMemcpyDeviceToHost));
         }
-        if (!differs) continue;
+        hostBases = c->hostBases.data();
+    }
+    if (c->resolverLoaded != c->hContigLoaded)
+    {   // (the rest-of-genome correction depends on which contigs count as loaded)
+        for (isaac_host_resolve::Resolver *r : c->resolvers) isaac_host_resolve::destroy(r);
+        c->resolvers.clear();
+        c->resolverLoaded = c->hContigLoaded;
+    }
+    // everything the clusters need, fetched first; then the clusters side by side on host threads (a cluster of a repeat family -- and probability ratios that
+    // are exact powers of ten come from equal placements, i.e. from those -- is milliseconds of serial mate rescue); then what changed goes back
+    struct Item { u32 cluster; std::vector<u8> bcl; std::vector<Match> matches; std::vector<FragmentRecord> was, now; std::vector<u32> wasCigar, nowCigar; bool differs = false; std::string error; };
+    std::vector<Item> items(n);
+    for (u32 k = 0; k < n; ++k)
+    {
+        Item &it = items[k];
+        it.cluster = list[k];
+        u64 range[2];
+        HIP_CHECK(hipMemcpy(range, offsets + it.cluster, 16, hipMemcpyDeviceToHost));
+        const u64 first = range[0], nMatches = range[1] - range[0];
+        it.matches.resize(nMatches + 1);
+        if (nMatches) HIP_CHECK(hipMemcpy(it.matches.data(), reinterpret_cast<const Match *>(matches) + first, nMatches * sizeof(Match), hipMemcpyDeviceToHost));
+        it.matches.resize(nMatches);
+        it.bcl.resize(clusterLength); it.was.resize(nReads); it.now.resize(nReads); it.wasCigar.resize(size_t(nReads) * OUT_CIGAR_CAP); it.nowCigar.assign(size_t(nReads) * OUT_CIGAR_CAP, 0u);
+        HIP_CHECK(hipMemcpy(it.bcl.data(), bcl + u64(it.cluster) * clusterLength, clusterLength, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(it.was.data(), records + u64(it.cluster) * nReads, nReads * sizeof(FragmentRecord), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(it.wasCigar.data(), cigar + u64(it.cluster) * nReads * OUT_CIGAR_CAP, it.wasCigar.size() * 4, hipMemcpyDeviceToHost));
+    }
+    const u32 nThreads = std::min<u32>(n, std::min<u32>(16, std::max(1u, std::thread::hardware_concurrency())));
+    while (c->resolvers.size() < nThreads) c->resolvers.push_back(isaac_host_resolve::create(c->params, hostBases, c->hContigOffset.data(), c->resolverLoaded.data(), c->nContigs));
+    std::atomic<u32> next(0);
+    const auto work = [&](u32 t)
+    {
+        for (u32 k = next++; k < n; k = next++)
+        {
+            Item &it = items[k];
+            try
+            {
+                isaac_host_resolve::selectCluster(c->resolvers[t], *tls, it.bcl.data(), it.cluster, tile, it.matches.data(), u32(it.matches.size()), it.now.data(), it.nowCigar.data());
+                for (u32 r = 0; r < nReads; ++r)
+                {
+                    FragmentRecord a = it.was[r], b = it.now[r];
+                    // the diagnostic bits apart (the host form does not flag): everything the record says, and its CIGAR
+                    b.reserved = (b.reserved & 0xffff0000u) | (a.reserved & 0xffffu & ~u32(RECORD_NOT_STORED | RECORD_FRAGMENT_OVERFLOW)) | (b.reserved & (RECORD_NOT_STORED | RECORD_FRAGMENT_OVERFLOW));
+                    it.now[r] = b;
+                    if (std::memcmp(&a, &b, sizeof(a))) it.differs = true;
+                    const u64 base = u64(it.cluster) * nReads * OUT_CIGAR_CAP;
+                    const u32 *ca = it.wasCigar.data() + (a.cigarOffset - base), *cb = it.nowCigar.data() + (b.cigarOffset - base);
+                    if (a.cigarLength == b.cigarLength && std::memcmp(ca, cb, size_t(a.cigarLength) * 4)) it.differs = true;
+                }
+            }
+            catch (const std::exception &e) { it.error = e.what(); }
+        }
+    };
+    {
+        std::vector<std::thread> threads;
+        for (u32 t = 1; t < nThreads; ++t) threads.emplace_back(work, t);
+        work(0);
+        for (std::thread &t : threads) t.join();
+    }
+    u64 changed = 0;
+    for (Item &it : items)
+    {
+        if (!it.error.empty()) return fail(ISAAC_GPU_EHIP, "isaac_gpu_resolve_flagged: " + it.error);
+        if (!it.differs) continue;
         ++changed;
-        HIP_CHECK(hipMemcpy(records + u64(cluster) * nReads, now.data(), nReads * sizeof(FragmentRecord), hipMemcpyHostToDevice));
-        HIP_CHECK(hipMemcpy(cigar + u64(cluster) * nReads * OUT_CIGAR_CAP, nowCigar.data(), nowCigar.size() * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(records + u64(it.cluster) * nReads, it.now.data(), nReads * sizeof(FragmentRecord), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(cigar + u64(it.cluster) * nReads * OUT_CIGAR_CAP, it.nowCigar.data(), it.nowCigar.size() * 4, hipMemcpyHostToDevice));
     }
     if (nChangedOut) *nChangedOut = changed;
     return 0;

@@ -183,7 +183,7 @@ const size_t TEXT_CHUNK = size_t(64) << 20;          // text per conversion call
 const size_t TEXT_SLACK = size_t(4) << 20;           // what may be left of a piece when the next one is taken: less than a record, unless records are longer than this
 // where the load phase's time goes, summed over its threads: waiting for text, upload + conversion, first lookup
 std::mutex g_timersLock;
-double g_textWaitSeconds = 0, g_convertSeconds = 0, g_firstLookupSeconds = 0;
+double g_textWaitSeconds = 0, g_convertSeconds = 0, g_firstLookupSeconds = 0, g_textOpenSeconds = 0, g_loadMemorySeconds = 0, g_loadPlaceSeconds = 0, g_resolveSeconds = 0;
 void addTime(double &timer, double seconds) { std::lock_guard<std::mutex> hold(g_timersLock); timer += seconds; }
 
 // One read of one lane: the file's text in pieces of TEXT_CHUNK bytes, each in a page-locked buffer of its own, read ahead of the conversion by a
@@ -447,14 +447,62 @@ int run(const AlignOptions &o)
     const unsigned nReads = flowcells[0].nReads, clusterLength = flowcells[0].readLength[0] + flowcells[0].readLength[1];
     const isaac_params params = o.params(flowcells[0].readLength[0], 2 == nReads ? flowcells[0].readLength[1] : 0);
 
+    std::deque<Loader> loaders;                       // (declared before the workers and the lanes: destroyed after them)
+    std::vector<std::unique_ptr<Worker> > workers;
+    struct Lane
+    {
+        const FastqFlowcell *flowcell; const FastqLane *lane; unsigned ordinal = 0; std::string readGroup; std::deque<Tile> tiles; std::deque<Load> loads; std::string error;
+        // barcodeTemplateLengthStatistics (one 'none' barcode per lane): learnt tile by tile, in tile order, until a tile gives stable ones (MatchSelector.cpp:395-412)
+        isaac_tls tls; bool tlsStable = false, learning = false; unsigned tlsNext = 0;
+    };
+    std::deque<Lane> lanes;
+    for (const FastqFlowcell &fc : flowcells)
+        for (const FastqLane &lane : fc.lanes)
+        {
+            lanes.emplace_back();
+            Lane &L = lanes.back();
+            L.flowcell = &fc; L.lane = &lane; L.ordinal = unsigned(lanes.size() - 1); L.readGroup = std::to_string(lanes.size() - 1);   // one 'none' barcode per lane, numbered in the order of the lanes
+            std::memset(&L.tls, 0, sizeof(L.tls));
+        }
+    if (lanes.size() > 4096) throw std::runtime_error("more than 4096 lanes");
+    // How many clusters the run will have, before it has been read: the size of every lane's first file over the length of its first record (compressed
+    // files: taken to hold four times their size).  Only the bins' sizes depend on it; any plan gives a valid file, and the estimate -- unlike the count,
+    // which is known when the last lane is read -- is there when the first tile wants its bins.
+    uint64_t estimatedClusters = 0;
+    for (Lane &L : lanes)
+    {
+        const std::string &path = L.lane->readPath[0];
+        struct stat st;
+        if (path.empty() || ::stat(path.c_str(), &st)) continue;
+        FastqFileReader peek(path, L.flowcell->compressed);
+        std::vector<char> head(1 << 16);
+        const size_t got = peek.readInto(head.data(), head.size());
+        size_t lines = 0, recordBytes = 0;
+        for (size_t i = 0; i < got && lines < 4; ++i) { ++recordBytes; if ('\n' == head[i]) ++lines; }
+        if (lines < 4 || !recordBytes) recordBytes = 2 * size_t(L.flowcell->fileReadLength[0]) + 64;
+        estimatedClusters += uint64_t(st.st_size) * (L.flowcell->compressed ? 4 : 1) / recordBytes;
+    }
+    const uint64_t binRecords = o.binRecords ? o.binRecords : 4000000;
+    // the page-locked buffers the build stage fills are made while the reference is read and its table copied (locking pages is slow -- a gigabyte takes a tenth of a second and more -- and holds other calls of the runtime up: beside the base calls' loading it cost that stage as much as it saved the later one)
+    PinnedPool pinned;
+    std::thread pinnedWarm([&]()
+    {
+        try
+        {
+            const uint64_t perBin = std::min<uint64_t>(binRecords, std::max<uint64_t>(estimatedClusters * nReads, 1));
+            std::vector<PinnedPool::Buffer> made;
+            for (unsigned i = 0; i < 4; ++i) { made.push_back(pinned.take(perBin * 220)); made.push_back(pinned.take(perBin * sizeof(isaac_bam_index_entry))); }
+            for (PinnedPool::Buffer &b : made) pinned.give(b);
+        }
+        catch (const std::exception &) {}       // (the build stage asks again and reports what fails)
+    });
+    struct JoinWarm { std::thread &t; ~JoinWarm() { if (t.joinable()) t.join(); } } joinWarm{ pinnedWarm };
     // ---- the workers and the reference: the first context of a device loads the table, the others of that device share it; another device
     // gets a copy over the link between the two (isaac_gpu_copy)
     const std::vector<int> devices = o.deviceList();
     // ISAAC_ALIGN_STRANGERS (tests on a box with one device): the workers of one device treat each other's memory as another device's -- the table is
     // copied, a bin's parts on the other worker's blocks are fetched -- which is every line two devices run
     const bool strangers = 0 != std::getenv("ISAAC_ALIGN_STRANGERS");
-    std::deque<Loader> loaders;                       // (declared before the workers and the lanes: destroyed after them)
-    std::vector<std::unique_ptr<Worker> > workers;
     Reference reference;
     double fastaSeconds = 0, contigSeconds = 0, tableSeconds = 0;
     {
@@ -488,7 +536,8 @@ int run(const AlignOptions &o)
             GPU(isaac_gpu_load_contigs(l.ctx, reference.bases.get(), reference.offsets.data(), uint32_t(reference.contigs.size())));
             GPU(isaac_gpu_share_index(l.ctx, w->ctx));
         }
-        reference.bases.reset();
+        // the bases stay in host memory: the few clusters per million whose MAPQ arithmetic wants glibc's word (isaac_gpu_resolve_flagged) read them from here
+        for (auto &w : workers) GPU(isaac_gpu_set_host_contigs(w->ctx, reference.bases.get()));
     }
     const uint32_t nContigs = uint32_t(reference.contigs.size());
     const double referenceSeconds = seconds() - runStart;
@@ -518,6 +567,7 @@ int run(const AlignOptions &o)
     auto loaderOf = [&](const Worker &w) -> Loader & { for (Loader &l : loaders) if (l.place == w.place) return l; throw std::logic_error("no loader"); };
     // the BCL bytes of a load stay on the device while it keeps this much free for the selection's scratch and the bins (ISAAC_ALIGN_HOST_LOADS: tests)
     const bool hostLoads = 0 != std::getenv("ISAAC_ALIGN_HOST_LOADS");
+    const bool skipResolution = 0 != std::getenv("ISAAC_ALIGN_TIMING_NO_RESOLUTION");       // (timing only: what isaac_gpu_resolve_flagged costs)
     auto keepOnDevice = [&](isaac_gpu_ctx *ctx, uint64_t bytes)
     {
         if (hostLoads) return false;
@@ -559,43 +609,9 @@ int run(const AlignOptions &o)
         }
         return clusters;
     };
-    struct Lane
-    {
-        const FastqFlowcell *flowcell; const FastqLane *lane; unsigned ordinal = 0; std::string readGroup; std::deque<Tile> tiles; std::deque<Load> loads; std::string error;
-        // barcodeTemplateLengthStatistics (one 'none' barcode per lane): learnt tile by tile, in tile order, until a tile gives stable ones (MatchSelector.cpp:395-412)
-        isaac_tls tls; bool tlsStable = false, learning = false; unsigned tlsNext = 0;
-    };
-    std::deque<Lane> lanes;
-    for (const FastqFlowcell &fc : flowcells)
-        for (const FastqLane &lane : fc.lanes)
-        {
-            lanes.emplace_back();
-            Lane &L = lanes.back();
-            L.flowcell = &fc; L.lane = &lane; L.ordinal = unsigned(lanes.size() - 1); L.readGroup = std::to_string(lanes.size() - 1);   // one 'none' barcode per lane, numbered in the order of the lanes
-            std::memset(&L.tls, 0, sizeof(L.tls));
-        }
-    if (lanes.size() > 4096) throw std::runtime_error("more than 4096 lanes");
-    // How many clusters the run will have, before it has been read: the size of every lane's first file over the length of its first record (compressed
-    // files: taken to hold four times their size).  Only the bins' sizes depend on it; any plan gives a valid file, and the estimate -- unlike the count,
-    // which is known when the last lane is read -- is there when the first tile wants its bins.
-    uint64_t estimatedClusters = 0;
-    for (Lane &L : lanes)
-    {
-        const std::string &path = L.lane->readPath[0];
-        struct stat st;
-        if (path.empty() || ::stat(path.c_str(), &st)) continue;
-        FastqFileReader peek(path, L.flowcell->compressed);
-        std::vector<char> head(1 << 16);
-        const size_t got = peek.readInto(head.data(), head.size());
-        size_t lines = 0, recordBytes = 0;
-        for (size_t i = 0; i < got && lines < 4; ++i) { ++recordBytes; if ('\n' == head[i]) ++lines; }
-        if (lines < 4 || !recordBytes) recordBytes = 2 * size_t(L.flowcell->fileReadLength[0]) + 64;
-        estimatedClusters += uint64_t(st.st_size) * (L.flowcell->compressed ? 4 : 1) / recordBytes;
-    }
     // ---- the bins (see BinPart): sized for --bin-records records each, by the reads the run is expected to have per base of the reference
     std::vector<uint64_t> contigLengths;
     for (const isaac_reference_contig &c : reference.contigs) contigLengths.push_back(c.total_bases);
-    const uint64_t binRecords = o.binRecords ? o.binRecords : 4000000;
     const double recordsPerBase = double(std::max<uint64_t>(estimatedClusters, 1)) * nReads / double(std::max<uint64_t>(1, reference.totalBases));
     const BinPlan plan = planBins(contigLengths, uint64_t(std::min(1e15, double(binRecords) / std::max(recordsPerBase, 1e-9))));
     const uint32_t nBins = uint32_t(plan.ranges.size()) + 1;
@@ -666,8 +682,10 @@ int run(const AlignOptions &o)
             {
                 const FastqFlowcell &fc = *L.flowcell; const FastqLane &lane = *L.lane;
                 std::unique_ptr<TextStream> streams[2];
+                struct OpenTime { double start; ~OpenTime() { addTime(g_textOpenSeconds, seconds() - start); } };
                 for (unsigned r = 0; r < nReads; ++r)
                 {
+                    OpenTime timed{ seconds() };
                     if (lane.readPath[r].empty()) throw std::runtime_error("lane " + std::to_string(lane.lane) + " of " + fc.baseCallsDirectory + " has no read " + std::to_string(r + 1));
                     streams[r].reset(new TextStream(lane.readPath[r], fc.compressed));
                 }
@@ -678,7 +696,7 @@ int run(const AlignOptions &o)
                     Worker &w = *workers[nextWorker++ % workers.size()];
                     Loader &l = loaderOf(w);
                     DeviceMemory bcl;
-                    { std::lock_guard<std::mutex> turn(l.lock); bcl.reset(l.ctx, uint64_t(loadClusters) * clusterLength + 64); }
+                    { const double start = seconds(); std::lock_guard<std::mutex> turn(l.lock); bcl.reset(l.ctx, uint64_t(loadClusters) * clusterLength + 64); addTime(g_loadMemorySeconds, seconds() - start); }
                     uint32_t loaded[2] = { 0, 0 };
                     for (unsigned r = 0; r < nReads; ++r) loaded[r] = loadRead(l, *streams[r], r, bcl.as<uint8_t>(), loadClusters);
                     if (2 == nReads && loaded[0] != loaded[1])
@@ -716,6 +734,8 @@ int run(const AlignOptions &o)
                         }
                         load.tilesLeft = unsigned(load.tiles.size());
                         // where the load waits for the selection: the device while it has room, else host memory; and only the bytes it has
+                        const double placeStart = seconds();
+                        struct PlaceTime { double start; ~PlaceTime() { addTime(g_loadPlaceSeconds, seconds() - start); } } placeTime{ placeStart };
                         if (keepOnDevice(l.ctx, bytes))
                         {
                             if (loaded[0] < loadClusters / 2)
@@ -812,6 +832,9 @@ int run(const AlignOptions &o)
                 // the handful of clusters per million whose MAPQ arithmetic came within 1e-11 of an integer on the device take glibc's answer
                 {
                     uint64_t flagged = 0, changed = 0;
+                    const double resolveStart = seconds();
+                    struct ResolveTime { double start; ~ResolveTime() { addTime(g_resolveSeconds, seconds() - start); } } resolveTime{ resolveStart };
+                    if (!skipResolution)
                     GPU(isaac_gpu_resolve_flagged(w.ctx, bcl, t.clusters, t.index, finder.matches.as<isaac_match>(), finder.offsets.as<uint64_t>(), &t.tls, records.as<isaac_fragment>(), slots.as<uint32_t>(),
                                                   &flagged, &changed));
                     w.mapqResolved += flagged; w.mapqChanged += changed;
@@ -906,20 +929,6 @@ int run(const AlignOptions &o)
         catch (const std::exception &e) { std::lock_guard<std::mutex> hold(shared); if (pipelineError.empty()) pipelineError = e.what(); wake.notify_all(); }
     };
 
-    // the page-locked buffers the build stage fills are made while the base calls are loaded (locking pages is slow: a gigabyte takes a tenth of a second and more)
-    PinnedPool pinned;
-    std::thread pinnedWarm([&]()
-    {
-        try
-        {
-            const uint64_t perBin = std::min<uint64_t>(binRecords, std::max<uint64_t>(estimatedClusters * nReads, 1));
-            std::vector<PinnedPool::Buffer> made;
-            for (unsigned i = 0; i < 4; ++i) { made.push_back(pinned.take(perBin * 220)); made.push_back(pinned.take(perBin * sizeof(isaac_bam_index_entry))); }
-            for (PinnedPool::Buffer &b : made) pinned.give(b);
-        }
-        catch (const std::exception &) {}       // (the build stage asks again and reports what fails)
-    });
-    struct JoinWarm { std::thread &t; ~JoinWarm() { if (t.joinable()) t.join(); } } joinWarm{ pinnedWarm };
     double loadSeconds = 0;
     const double selectStart = seconds();
     {
@@ -1197,7 +1206,7 @@ int run(const AlignOptions &o)
     std::cerr << "isaac-align: " << bamPath << ": " << nRecordsWritten << " records in " << binsWritten << " bin(s)" << std::endl;
     // one line for scripts (bench.py): what the run took, stage by stage
     std::cerr << "isaac-align: timing {\"clusters\": " << totalClusters << ", \"reads\": " << totalClusters * nReads << ", \"records\": " << nRecordsWritten << ", \"workers\": " << workers.size()
-              << ", \"reference_s\": " << referenceSeconds << ", \"reference_fasta_s\": " << fastaSeconds << ", \"reference_contigs_s\": " << contigSeconds << ", \"reference_table_s\": " << tableSeconds << ", \"load_and_find_s\": " << loadSeconds << ", \"load_text_wait_s\": " << g_textWaitSeconds << ", \"load_convert_s\": " << g_convertSeconds << ", \"load_first_lookup_s\": " << g_firstLookupSeconds << ", \"select_and_bin_s\": " << selectSeconds << ", \"select_busy_s\": " << selectBusySeconds << ", \"build_and_write_s\": " << buildSeconds
+              << ", \"reference_s\": " << referenceSeconds << ", \"reference_fasta_s\": " << fastaSeconds << ", \"reference_contigs_s\": " << contigSeconds << ", \"reference_table_s\": " << tableSeconds << ", \"load_and_find_s\": " << loadSeconds << ", \"load_text_wait_s\": " << g_textWaitSeconds << ", \"load_convert_s\": " << g_convertSeconds << ", \"load_first_lookup_s\": " << g_firstLookupSeconds << ", \"load_text_open_s\": " << g_textOpenSeconds << ", \"load_memory_s\": " << g_loadMemorySeconds << ", \"load_place_s\": " << g_loadPlaceSeconds << ", \"select_resolve_s\": " << g_resolveSeconds << ", \"select_and_bin_s\": " << selectSeconds << ", \"select_busy_s\": " << selectBusySeconds << ", \"build_and_write_s\": " << buildSeconds
               << ", \"tiles_kept_on_device\": " << tilesOnDevice << ", \"tiles\": " << tiles.size() << ", \"loads_kept_on_device\": " << loadsOnDevice << ", \"loads\": " << nLoads << ", \"bins\": " << nBins << ", \"bin_cuts\": " << plan.cuts.size() << ", \"estimated_clusters\": " << estimatedClusters << ", \"bin_ranges\": " << binRangesJson
               << ", \"build_upload_s\": " << workers[0]->uploadSeconds << ", \"build_records_s\": " << workers[0]->recordsSeconds << ", \"build_deflate_s\": " << workers[0]->deflateSeconds
               << ", \"build_download_s\": " << workers[0]->downloadSeconds << ", \"file_write_s\": " << writeSeconds
