@@ -189,6 +189,11 @@ int isaac_gpu_set_index_dev(isaac_gpu_ctx *ctx, const isaac_reference_kmer *entr
  * when both are on one device (nothing is copied; `owner` must outlive `ctx` and keep its table), as a copy over the link between the two devices
  * when they are not.  Both must have loaded the same contigs.  What a host does for the second and further workers of a run (--devices). */
 int isaac_gpu_share_index(isaac_gpu_ctx *ctx, isaac_gpu_ctx *owner);
+/* Contigs and table together, for a context that has loaded nothing: on one device `ctx` reads the bases, their packed copy, the table and its prefix directory
+ * where `owner` has them (no byte copied, nothing computed; `owner` must outlive `ctx`); on another device the bases and the table are copied over the link
+ * and the rest is made from them.  The host copy of isaac_gpu_set_host_contigs goes along.  A further worker or loader context of a device costs
+ * milliseconds and no memory this way, against a 3 GB upload and 5.5 GB of directory and packed bases with isaac_gpu_load_contigs + isaac_gpu_share_index. */
+int isaac_gpu_share_reference(isaac_gpu_ctx *ctx, isaac_gpu_ctx *owner);
 
 /* sorted-reference.xml: reference::SortedReferenceMetadata::Contig / ::MaskFile (include/reference/SortedReferenceMetadata.hh:44-98) as
  * plain records.  strings are NUL-terminated. */

@@ -79,6 +79,10 @@ struct isaac_gpu_ctx
     DevBuf<u32> flaggedList; std::vector<char> hostBases; const char *hostBasesGiven = nullptr; std::vector<isaac_host_resolve::Resolver *> resolvers; std::vector<u8> resolverLoaded;      // isaac_gpu_resolve_flagged
     DevBuf<u32> prefixTable; u32 prefixBits = 0; std::vector<u64> maskOffsets;   // entries before each mask of the table (load_index / build_index)
     DevBuf<u32> packedBases, notBase;   // 2-bit copy of the contigs + not-ACGT bitmap (k_rescue_windows reads these)
+    const u32 *packedBorrowed = nullptr, *notBaseBorrowed = nullptr, *prefixBorrowed = nullptr;      // isaac_gpu_share_reference on one device: the owner's
+    const u32 *packedWords() const { return packedBorrowed ? packedBorrowed : packedBases.p; }
+    const u32 *notBaseWords() const { return notBaseBorrowed ? notBaseBorrowed : notBase.p; }
+    const u32 *prefixWords() const { return prefixBorrowed ? prefixBorrowed : prefixTable.p; }
     DevBuf<u64> matchBase;
     // run constants of the template kernels in device memory: passed by value they end up as private copies (dynamic indexing)
     DevBuf<TemplateConstants> templateConstants;
@@ -118,8 +122,8 @@ struct isaac_gpu_ctx
         r.bases = bases; r.totalBases = hContigOffset.empty() ? 0 : hContigOffset[nContigs]; r.contigOffset = contigOffset.p; r.contigLoaded = contigLoaded.p; r.nContigs = nContigs;
         r.entries = tableEntries(); r.nKmers = nKmers; r.karyotype = hasKaryotype ? karyotype.p : nullptr;
         r.logMatch = logTables.p; r.logMismatch = logTables.p + 100; r.logStride = 1;
-        r.prefixTable = prefixBits ? prefixTable.p : nullptr; r.prefixBits = prefixBits;
-        r.packedBases = packedBases.p; r.notBase = notBase.p;
+        r.prefixTable = prefixBits ? prefixWords() : nullptr; r.prefixBits = prefixBits;
+        r.packedBases = packedWords(); r.notBase = notBaseWords();
         return r;
     }
 };
@@ -571,7 +575,7 @@ u32 chunkFor(isaac_gpu_ctx *c, u32 nClusters)
 // after the table changed: the prefix directory of k_find_matches (tables of 2^32 entries and more go without)
 void buildPrefixTable(isaac_gpu_ctx *c)
 {
-    c->prefixBits = 0;
+    c->prefixBits = 0; c->prefixBorrowed = nullptr;
     if (!c->nKmers || c->nKmers >= (u64(1) << 32) || getenv("ISAAC_GPU_NO_PREFIX_TABLE")) return;
     u32 bits = 16; while (bits < 30 && (u64(1) << bits) < c->nKmers) ++bits;     // about one entry per bucket (human: 2.7), 256 KB .. 4 GB
     const u64 entries = (u64(1) << bits) + 1;
@@ -720,7 +724,7 @@ __global__ void k_pack_reference(const char *bases, u64 totalBases, u32 *packed,
     packed[2 * w] = lo; packed[2 * w + 1] = hi; notBase[w] = bad;
 }
 
-static void setContigs(isaac_gpu_ctx *c, const uint64_t *offsets, uint32_t n)
+static void setContigs(isaac_gpu_ctx *c, const uint64_t *offsets, uint32_t n, bool pack = true)
 {
     c->nContigs = n; c->hContigOffset.assign(offsets, offsets + n + 1);
     c->contigOffset.reserve(n + 1);
@@ -728,6 +732,8 @@ static void setContigs(isaac_gpu_ctx *c, const uint64_t *offsets, uint32_t n)
     c->hContigLoaded.assign(n, 1); c->contigLoaded.reserve(n);
     HIP_CHECK(hipMemcpy(c->contigLoaded.p, c->hContigLoaded.data(), n, hipMemcpyHostToDevice));
     c->contigHits.reserve(n);
+    c->packedBorrowed = c->notBaseBorrowed = nullptr;
+    if (!pack) return;
     const u64 nWords32 = (offsets[n] + 31) / 32 + 4;                       // + spare words: a lane reads two words past its first
     c->packedBases.reserve(2 * nWords32); c->notBase.reserve(nWords32);
     k_pack_reference<<<gridFor(nWords32, 256), 256, 0, c->stream>>>(c->bases, offsets[n], c->packedBases.p, c->notBase.p, nWords32);
@@ -900,7 +906,7 @@ int isaac_gpu_build_index(isaac_gpu_ctx *c, uint32_t repeatThreshold, int annota
     if (!c->bases) return fail(ISAAC_GPU_EINVAL, "load the contigs first");
     const u64 totalBases = c->hContigOffset[c->nContigs];
     hipStream_t st = c->stream;
-    const u32 *packed = c->packedBases.p, *notBase = c->notBase.p;
+    const u32 *packed = c->packedWords(), *notBase = c->notBaseWords();
     const u64 nBlocks = (totalBases + INDEX_TILE - 1) / INDEX_TILE;
     if (nBlocks >= (u64(1) << 31)) return fail(ISAAC_GPU_EINVAL, "reference too long");
     c->entriesBorrowed = nullptr;
@@ -1120,6 +1126,52 @@ int isaac_gpu_share_index(isaac_gpu_ctx *c, isaac_gpu_ctx *owner)
         HIP_CHECK(hipMemcpy(c->karyotype.p, k.data(), k.size() * 4, hipMemcpyHostToDevice));
     }
     buildPrefixTable(c);
+    return 0;
+    ISAAC_CATCH
+}
+
+// contigs and table of another context for this one, which need not have loaded anything: on one device everything is read where the owner has it (bases, their
+// packed copy, table, prefix directory: no byte copied, none computed -- the owner must outlive this context or load something else first); on another
+// device the bases and the table are copied over the link and the rest is made from them.  The resolved-on-host copy of the contigs (isaac_gpu_set_host_contigs)
+// goes along.
+int isaac_gpu_share_reference(isaac_gpu_ctx *c, isaac_gpu_ctx *owner)
+{
+    ISAAC_TRY
+    if (!c || !owner || c == owner) return fail(ISAAC_GPU_EINVAL, "two different contexts are required");
+    if (!owner->bases || !owner->nContigs) return fail(ISAAC_GPU_EINVAL, "the owner has no contigs");
+    const bool inPlace = c->device == owner->device && !std::getenv("ISAAC_GPU_SHARE_BY_COPY");
+    HIP_CHECK(hipSetDevice(owner->device));
+    HIP_CHECK(hipStreamSynchronize(owner->stream));
+    HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    const u64 totalBases = owner->hContigOffset[owner->nContigs];
+    if (inPlace)
+    {
+        c->basesOwned.release(); c->packedBases.release(); c->notBase.release();
+        c->bases = owner->bases;
+        setContigs(c, owner->hContigOffset.data(), owner->nContigs, false);
+        c->packedBorrowed = owner->packedWords(); c->notBaseBorrowed = owner->notBaseWords();
+    }
+    else
+    {
+        c->basesOwned.reserve(totalBases + 64);
+        HIP_CHECK(hipMemset(c->basesOwned.p, 'N', totalBases + 64));
+        HIP_CHECK(hipMemcpy(c->basesOwned.p, owner->bases, totalBases, hipMemcpyDefault));
+        c->bases = c->basesOwned.p;
+        setContigs(c, owner->hContigOffset.data(), owner->nContigs);
+    }
+    c->hostBasesGiven = owner->hostBasesGiven;
+    if (!owner->tableEntries()) return 0;
+    if (!inPlace) return isaac_gpu_share_index(c, owner);
+    c->entries.release(); c->prefixTable.release();
+    c->entriesBorrowed = owner->tableEntries(); c->nKmers = owner->nKmers; c->maskOffsets = owner->maskOffsets;
+    c->hasKaryotype = owner->hasKaryotype;
+    if (owner->hasKaryotype)
+    {
+        c->karyotype.reserve(owner->nContigs);
+        HIP_CHECK(hipMemcpy(c->karyotype.p, owner->karyotype.p, size_t(owner->nContigs) * 4, hipMemcpyDeviceToDevice));
+    }
+    c->prefixBits = owner->prefixBits; c->prefixBorrowed = owner->prefixBits ? owner->prefixWords() : nullptr;
     return 0;
     ISAAC_CATCH
 }

@@ -504,7 +504,7 @@ int run(const AlignOptions &o)
     // copied, a bin's parts on the other worker's blocks are fetched -- which is every line two devices run
     const bool strangers = 0 != std::getenv("ISAAC_ALIGN_STRANGERS");
     Reference reference;
-    double fastaSeconds = 0, contigSeconds = 0, tableSeconds = 0;
+    double fastaSeconds = 0, contigSeconds = 0, tableSeconds = 0, shareSeconds = 0;
     {
         Stage stage("loading the reference");
         reference = loadReference(o.referenceGenome);
@@ -515,14 +515,25 @@ int run(const AlignOptions &o)
             Worker &w = *workers.back();
             w.device = devices[k]; w.id = unsigned(k); w.place = strangers ? int(1000 + k) : devices[k];
             GPU(isaac_gpu_create(w.device, &params, ISAAC_GPU_STREAM_OWN, &w.ctx));
-            const double contigStart = seconds();
-            GPU(isaac_gpu_load_contigs(w.ctx, reference.bases.get(), reference.offsets.data(), uint32_t(reference.contigs.size())));
-            contigSeconds += seconds() - contigStart;
-            if (0 == k) { const double tableStart = seconds(); GPU(isaac_gpu_load_sorted_reference(w.ctx, o.referenceGenome.c_str())); tableSeconds = seconds() - tableStart; continue; }
-            // the first worker of a device that is not the first worker's gets a copy of the table, everybody else reads one that is there
+            if (0 == k)
+            {
+                const double contigStart = seconds();
+                GPU(isaac_gpu_load_contigs(w.ctx, reference.bases.get(), reference.offsets.data(), uint32_t(reference.contigs.size())));
+                contigSeconds += seconds() - contigStart;
+                // the bases stay in host memory: the few clusters per million whose MAPQ arithmetic wants glibc's word (isaac_gpu_resolve_flagged) read them from here
+                GPU(isaac_gpu_set_host_contigs(w.ctx, reference.bases.get()));
+                const double tableStart = seconds();
+                GPU(isaac_gpu_load_sorted_reference(w.ctx, o.referenceGenome.c_str()));
+                tableSeconds = seconds() - tableStart;
+                continue;
+            }
+            // everybody else reads what is there: a worker of a device that has one takes that one's contigs and table in place, the first worker of another
+            // device gets copies over the link between the two
+            const double shareStart = seconds();
             Worker *samePlace = 0;
             for (size_t j = 0; j < k && !samePlace; ++j) if (workers[j]->place == w.place) samePlace = workers[j].get();
-            GPU(isaac_gpu_share_index(w.ctx, samePlace ? samePlace->ctx : workers[0]->ctx));
+            GPU(isaac_gpu_share_reference(w.ctx, samePlace ? samePlace->ctx : workers[0]->ctx));
+            shareSeconds += seconds() - shareStart;
         }
         for (auto &w : workers)
         {
@@ -532,12 +543,11 @@ int run(const AlignOptions &o)
             loaders.emplace_back();
             Loader &l = loaders.back();
             l.place = w->place; l.hits.assign(reference.contigs.size(), 0);
+            const double shareStart = seconds();
             GPU(isaac_gpu_create(w->device, &params, ISAAC_GPU_STREAM_OWN, &l.ctx));
-            GPU(isaac_gpu_load_contigs(l.ctx, reference.bases.get(), reference.offsets.data(), uint32_t(reference.contigs.size())));
-            GPU(isaac_gpu_share_index(l.ctx, w->ctx));
+            GPU(isaac_gpu_share_reference(l.ctx, w->ctx));
+            shareSeconds += seconds() - shareStart;
         }
-        // the bases stay in host memory: the few clusters per million whose MAPQ arithmetic wants glibc's word (isaac_gpu_resolve_flagged) read them from here
-        for (auto &w : workers) GPU(isaac_gpu_set_host_contigs(w->ctx, reference.bases.get()));
     }
     const uint32_t nContigs = uint32_t(reference.contigs.size());
     const double referenceSeconds = seconds() - runStart;
@@ -1206,7 +1216,7 @@ int run(const AlignOptions &o)
     std::cerr << "isaac-align: " << bamPath << ": " << nRecordsWritten << " records in " << binsWritten << " bin(s)" << std::endl;
     // one line for scripts (bench.py): what the run took, stage by stage
     std::cerr << "isaac-align: timing {\"clusters\": " << totalClusters << ", \"reads\": " << totalClusters * nReads << ", \"records\": " << nRecordsWritten << ", \"workers\": " << workers.size()
-              << ", \"reference_s\": " << referenceSeconds << ", \"reference_fasta_s\": " << fastaSeconds << ", \"reference_contigs_s\": " << contigSeconds << ", \"reference_table_s\": " << tableSeconds << ", \"load_and_find_s\": " << loadSeconds << ", \"load_text_wait_s\": " << g_textWaitSeconds << ", \"load_convert_s\": " << g_convertSeconds << ", \"load_first_lookup_s\": " << g_firstLookupSeconds << ", \"load_text_open_s\": " << g_textOpenSeconds << ", \"load_memory_s\": " << g_loadMemorySeconds << ", \"load_place_s\": " << g_loadPlaceSeconds << ", \"select_resolve_s\": " << g_resolveSeconds << ", \"select_and_bin_s\": " << selectSeconds << ", \"select_busy_s\": " << selectBusySeconds << ", \"build_and_write_s\": " << buildSeconds
+              << ", \"reference_s\": " << referenceSeconds << ", \"reference_fasta_s\": " << fastaSeconds << ", \"reference_contigs_s\": " << contigSeconds << ", \"reference_table_s\": " << tableSeconds << ", \"reference_share_s\": " << shareSeconds << ", \"load_and_find_s\": " << loadSeconds << ", \"load_text_wait_s\": " << g_textWaitSeconds << ", \"load_convert_s\": " << g_convertSeconds << ", \"load_first_lookup_s\": " << g_firstLookupSeconds << ", \"load_text_open_s\": " << g_textOpenSeconds << ", \"load_memory_s\": " << g_loadMemorySeconds << ", \"load_place_s\": " << g_loadPlaceSeconds << ", \"select_resolve_s\": " << g_resolveSeconds << ", \"select_and_bin_s\": " << selectSeconds << ", \"select_busy_s\": " << selectBusySeconds << ", \"build_and_write_s\": " << buildSeconds
               << ", \"tiles_kept_on_device\": " << tilesOnDevice << ", \"tiles\": " << tiles.size() << ", \"loads_kept_on_device\": " << loadsOnDevice << ", \"loads\": " << nLoads << ", \"bins\": " << nBins << ", \"bin_cuts\": " << plan.cuts.size() << ", \"estimated_clusters\": " << estimatedClusters << ", \"bin_ranges\": " << binRangesJson
               << ", \"build_upload_s\": " << workers[0]->uploadSeconds << ", \"build_records_s\": " << workers[0]->recordsSeconds << ", \"build_deflate_s\": " << workers[0]->deflateSeconds
               << ", \"build_download_s\": " << workers[0]->downloadSeconds << ", \"file_write_s\": " << writeSeconds

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--sample-tiles", type=int, default=3)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r5_cli_headline.json"))
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--extra-env", default="", help="NAME=value[,NAME=value]: the program once more on the same files with these set (timing only); several sets separated by ';'")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -133,6 +134,25 @@ def main():
         bam_path = os.path.join(work, "Aligned", "Projects", "default", "default", "sorted.bam")
         result["sorted_bam_bytes"] = os.path.getsize(bam_path); result["bai_bytes"] = os.path.getsize(bam_path + ".bai")
         result["peak_device_gb"] = round(timing["peak_device_bytes"] / 1e9, 1); result["peak_host_gb"] = round(timing["peak_host_bytes"] / 1e9, 1)
+        # ---- the same files again with other switches: the stage timers only (the first run's output is what is checked)
+        result["extra_runs"] = []
+        for extra in [e for e in args.extra_env.split(";") if e.strip()]:
+            shutil.rmtree(os.path.join(work, "Aligned"), ignore_errors=True)
+            more = dict(kv.split("=", 1) for kv in extra.split(",") if "=" in kv)
+            t0 = time.time()
+            r2 = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **more))
+            w2 = time.time() - t0
+            entry = {"env": more, "rc": r2.returncode, "wall_s": round(w2, 2)}
+            if not r2.returncode:
+                t2 = json.loads([l for l in r2.stderr.splitlines() if "timing {" in l][-1].split("timing ", 1)[1])
+                t2.pop("bin_ranges", None)
+                entry["timing"] = t2
+                entry["reads_per_s"] = round(t2["reads"] / w2, 1)
+                entry["reads_per_s_without_reference_load"] = round(t2["reads"] / max(1e-9, t2["total_s"] - t2["reference_s"]), 1)
+                entry["sorted_bam_bytes"] = os.path.getsize(bam_path)
+            else:
+                entry["stderr_tail"] = r2.stderr[-800:]
+            result["extra_runs"].append(entry)
         # ---- the sampled tiles against the oracle
         import oracle_lib
         from parity_util import compare_records

@@ -306,8 +306,8 @@ SCENARIOS = {
     # the bins' parts through host memory (what a run too large for the device's memory does), two workers
     "host-bins": dict(compressed=False, lengths=(100, 100), cli=["--devices", "0,0"], paired=True, mark=True, keep=True, realign=True, unaligned="back", dodgy=0, pu="%s:%d:none",
                       env={"ISAAC_ALIGN_HOST_BINS": "1"}),
-    # what two devices do, on one: the second worker's table is a copy (ISAAC_GPU_SHARE_BY_COPY) and each worker treats the other's blocks of bin parts as
-    # another device's (ISAAC_ALIGN_STRANGERS): isaac_gpu_share_index's copy branch and the fetch of foreign parts in the build stage
+    # what two devices do, on one: the other contexts' contigs and table are copies (ISAAC_GPU_SHARE_BY_COPY) and each worker treats the other's blocks of bin parts as
+    # another device's (ISAAC_ALIGN_STRANGERS): isaac_gpu_share_reference's copy branch and the fetch of foreign parts in the build stage
     "strangers": dict(compressed=False, lengths=(100, 100), cli=["--devices", "0,0"], paired=True, mark=True, keep=True, realign=True, unaligned="back", dodgy=0, pu="%s:%d:none",
                       env={"ISAAC_ALIGN_STRANGERS": "1", "ISAAC_GPU_SHARE_BY_COPY": "1"}),
     # the loads' BCL bytes wait in host memory for their selection (what a run does whose base calls do not fit the device beside the table)

@@ -367,6 +367,34 @@ def test_fragment_builder_known_answers_on_the_gpu(torch, oracle):
             al.close()
 
 
+@pytest.mark.parametrize("by_copy", [False, True])
+def test_shared_reference_gives_the_same_records(case, by_copy, monkeypatch):
+    """isaac_gpu_share_reference: a context that loaded nothing reads the owner's contigs, packed bases, table and prefix directory in place (or, by_copy: takes the
+    branch two devices take -- bases and table copied, the rest made from them) and finds the same matches and selects the same records"""
+    from isaac_aligner_amd import gpu
+    if by_copy:
+        monkeypatch.setenv("ISAAC_GPU_SHARE_BY_COPY", "1")
+    owner = case["al"]
+    other = gpu.Aligner(case["p"], 0)
+    try:
+        other.share_reference(owner)
+        with pytest.raises(gpu.IsaacGpuError):
+            owner.build_index()                                   # lent: the owner refuses to rebuild under a reader
+        m, o, hits = other.find_matches(case["dev_bcl"])
+        assert (hits == case["hits"]).all()
+        assert (o.cpu() == case["offsets"].cpu()).all()
+        a, b = sort_matches(gpu_matches_numpy(m)), sort_matches(gpu_matches_numpy(case["matches"]))
+        assert (a["seed_id"] == b["seed_id"]).all() and (a["location"] == b["location"]).all()
+        owner.set_loaded_contigs(case["hits"]); other.set_loaded_contigs(case["hits"])
+        tls = owner.determine_tls(case["dev_bcl"], case["matches"], case["offsets"])
+        assert other.determine_tls(case["dev_bcl"], m, o).astuple() == tls.astuple()
+        r1, c1 = owner.records_to_numpy(*owner.select(case["dev_bcl"], case["matches"], case["offsets"], tls))
+        r2, c2 = other.records_to_numpy(*other.select(case["dev_bcl"], m, o, tls))
+        assert not compare_records(r1, c1, r2, c2)
+    finally:
+        other.close()
+
+
 def test_deferred_completion_pipelines_select_calls(torch, monkeypatch):
     """ISAAC_GPU_DEFERRED_COMPLETION=1: isaac_gpu_select returns with its last wave-per-cluster pass still running, the next call
     overlaps it, isaac_gpu_synchronize completes everything.  Same records as the synchronous calls, batch for batch."""
