@@ -29,6 +29,7 @@
 #include <sstream>
 #include <sys/stat.h>
 #include <sys/mman.h>
+#include <sys/statvfs.h>
 #include <fcntl.h>
 #include <unistd.h>
 #include <atomic>
@@ -370,7 +371,7 @@ struct Finder { DeviceMemory matches, offsets; uint64_t capacity = 0; };
 // a context per device for the lanes' threads (text upload, conversion, first lookup), beside the workers' own: loading does not wait for a selection
 struct Loader
 {
-    int place = 0; isaac_gpu_ctx *ctx = 0; std::mutex lock; DeviceMemory textDev; Finder finder; std::vector<uint8_t> hits;
+    int place = 0; unsigned reader = 0, read = 0; isaac_gpu_ctx *ctx = 0; std::mutex lock; DeviceMemory textDev; Finder finder; std::vector<uint8_t> hits;
     void close() { textDev.release(); finder.matches.release(); finder.offsets.release(); if (ctx) isaac_gpu_destroy(ctx); ctx = 0; }
     ~Loader() { close(); }
 };
@@ -417,6 +418,32 @@ void writeAt(int fd, const uint8_t *data, uint64_t bytes, uint64_t offset)
     for (std::thread &w : workers) w.join();
     ::munmap(map, size_t(lead + bytes));
 }
+
+// The output file's blocks, asked for ahead of the data (posix fallocate beyond the end of the file, a quarter of a gigabyte a call so that writes get their turn at
+// the inode): on a disk that reserves extents; on tmpfs -- where the timed runs write -- it takes the page allocation, half of what a write() costs there, out of
+// the writer's way and into the stages before it.  What the estimate asked for beyond the file's end is given back when the file is closed (ftruncate).
+class Preallocator
+{
+public:
+    Preallocator(int fd, uint64_t bytes) : fd_(fd), bytes_(bytes), stop_(false)
+    {
+        if (fd_ < 0 || !bytes_ || std::getenv("ISAAC_ALIGN_NO_PREALLOCATION")) return;
+        struct statvfs fs;
+        if (::fstatvfs(fd_, &fs) || uint64_t(fs.f_bavail) * fs.f_frsize / 2 < bytes_) return;       // never more than half of what is free
+        thread_ = std::thread([this]()
+        {
+            const uint64_t step = uint64_t(256) << 20;
+            for (uint64_t at = 0; at < bytes_ && !stop_.load(); at += step)
+                if (::fallocate(fd_, FALLOC_FL_KEEP_SIZE, off_t(at), off_t(std::min(step, bytes_ - at)))) break;        // (a file system without it: the writes allocate as they go)
+                else done_.store(at + std::min(step, bytes_ - at));
+        });
+    }
+    void finish() { stop_.store(true); if (thread_.joinable()) thread_.join(); }
+    uint64_t done() const { return done_.load(); }
+    ~Preallocator() { finish(); }
+private:
+    int fd_; uint64_t bytes_; std::atomic<bool> stop_; std::atomic<uint64_t> done_{0}; std::thread thread_;
+};
 
 uint64_t hostResidentBytes()
 {   // VmHWM: the process's peak resident set
@@ -465,6 +492,8 @@ int run(const AlignOptions &o)
             std::memset(&L.tls, 0, sizeof(L.tls));
         }
     if (lanes.size() > 4096) throw std::runtime_error("more than 4096 lanes");
+    // the threads that read lanes: one more than there are workers (a lane's text comes from a file at the rate of one file)
+    const unsigned nReaders = unsigned(std::max<size_t>(1, std::min(lanes.size(), o.deviceList().size() + 1)));
     // How many clusters the run will have, before it has been read: the size of every lane's first file over the length of its first record (compressed
     // files: taken to hold four times their size).  Only the bins' sizes depend on it; any plan gives a valid file, and the estimate -- unlike the count,
     // which is known when the last lane is read -- is there when the first tile wants its bins.
@@ -497,6 +526,17 @@ int run(const AlignOptions &o)
         catch (const std::exception &) {}       // (the build stage asks again and reports what fails)
     });
     struct JoinWarm { std::thread &t; ~JoinWarm() { if (t.joinable()) t.join(); } } joinWarm{ pinnedWarm };
+    // ---- the output file, opened now: its blocks are asked for while everything before the first write runs
+    const std::string directory = o.outputDirectory + "/Projects/default/default";
+    makeDirectories(directory);
+    const std::string bamPath = directory + "/sorted.bam";
+    struct OutputFile { int fd = -1; ~OutputFile() { if (fd >= 0) ::close(fd); } } outputFile;
+    outputFile.fd = ::open(bamPath.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0666);
+    if (outputFile.fd < 0) throw std::runtime_error("Failed to open output BAM file " + bamPath);
+    // (a record is some 110 bytes and three halves of its bases; deflated -- base qualities are most of it -- about half of that)
+    const uint64_t expectedBamBytes = uint64_t(double(estimatedClusters) * nReads * (110.0 + 1.5 * clusterLength / nReads) * (o.bamGzipLevel ? 0.55 : 1.02));
+    Preallocator preallocator(outputFile.fd, expectedBamBytes);
+
     // ---- the workers and the reference: the first context of a device loads the table, the others of that device share it; another device
     // gets a copy over the link between the two (isaac_gpu_copy)
     const std::vector<int> devices = o.deviceList();
@@ -535,17 +575,23 @@ int run(const AlignOptions &o)
             GPU(isaac_gpu_share_reference(w.ctx, samePlace ? samePlace->ctx : workers[0]->ctx));
             shareSeconds += seconds() - shareStart;
         }
+        // the loaders: per device a context for every thread that reads lanes and every read of a lane (a context costs a stream and its scratch, the reference
+        // is the worker's) -- one read's text is on the link while the other's is converted, and so are two lanes'
         for (auto &w : workers)
         {
             bool have = false;
             for (Loader &l : loaders) if (l.place == w->place) have = true;
             if (have) continue;
-            loaders.emplace_back();
-            Loader &l = loaders.back();
-            l.place = w->place; l.hits.assign(reference.contigs.size(), 0);
             const double shareStart = seconds();
-            GPU(isaac_gpu_create(w->device, &params, ISAAC_GPU_STREAM_OWN, &l.ctx));
-            GPU(isaac_gpu_share_reference(l.ctx, w->ctx));
+            for (unsigned reader = 0; reader < nReaders; ++reader)
+                for (unsigned read = 0; read < nReads; ++read)
+                {
+                    loaders.emplace_back();
+                    Loader &l = loaders.back();
+                    l.place = w->place; l.reader = reader; l.read = read; l.hits.assign(reference.contigs.size(), 0);
+                    GPU(isaac_gpu_create(w->device, &params, ISAAC_GPU_STREAM_OWN, &l.ctx));
+                    GPU(isaac_gpu_share_reference(l.ctx, w->ctx));
+                }
             shareSeconds += seconds() - shareStart;
         }
     }
@@ -574,7 +620,11 @@ int run(const AlignOptions &o)
             f.matches.reset(ctx, f.capacity * sizeof(isaac_match));
         }
     };
-    auto loaderOf = [&](const Worker &w) -> Loader & { for (Loader &l : loaders) if (l.place == w.place) return l; throw std::logic_error("no loader"); };
+    auto loaderOf = [&](const Worker &w, unsigned reader, unsigned read) -> Loader &
+    {
+        for (Loader &l : loaders) if (l.place == w.place && l.reader == reader && l.read == read) return l;
+        throw std::logic_error("no loader");
+    };
     // the BCL bytes of a load stay on the device while it keeps this much free for the selection's scratch and the bins (ISAAC_ALIGN_HOST_LOADS: tests)
     const bool hostLoads = 0 != std::getenv("ISAAC_ALIGN_HOST_LOADS");
     const bool skipResolution = 0 != std::getenv("ISAAC_ALIGN_TIMING_NO_RESOLUTION");       // (timing only: what isaac_gpu_resolve_flagged costs)
@@ -683,7 +733,7 @@ int run(const AlignOptions &o)
     // ---- the lanes' threads
     const double loadStart = seconds();
     std::atomic<size_t> nextLane(0), nextWorker(0);
-    auto readLanes = [&]()
+    auto readLanes = [&](unsigned reader)
     {
         for (size_t k = nextLane++; k < lanes.size(); k = nextLane++)
         {
@@ -704,11 +754,24 @@ int run(const AlignOptions &o)
                 {
                     { std::lock_guard<std::mutex> hold(shared); if (!pipelineError.empty()) break; }
                     Worker &w = *workers[nextWorker++ % workers.size()];
-                    Loader &l = loaderOf(w);
+                    Loader &l = loaderOf(w, reader, 0);
                     DeviceMemory bcl;
                     { const double start = seconds(); std::lock_guard<std::mutex> turn(l.lock); bcl.reset(l.ctx, uint64_t(loadClusters) * clusterLength + 64); addTime(g_loadMemorySeconds, seconds() - start); }
                     uint32_t loaded[2] = { 0, 0 };
-                    for (unsigned r = 0; r < nReads; ++r) loaded[r] = loadRead(l, *streams[r], r, bcl.as<uint8_t>(), loadClusters);
+                    {   // the second read beside the first, on a context of its own: the bytes of a cluster's two reads do not overlap
+                        std::string secondError;
+                        std::thread second;
+                        if (2 == nReads)
+                            second = std::thread([&]()
+                            {
+                                try { loaded[1] = loadRead(loaderOf(w, reader, 1), *streams[1], 1, bcl.as<uint8_t>(), loadClusters); }
+                                catch (const std::exception &e) { secondError = e.what(); }
+                            });
+                        struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join{ second };
+                        loaded[0] = loadRead(l, *streams[0], 0, bcl.as<uint8_t>(), loadClusters);
+                        if (second.joinable()) second.join();
+                        if (!secondError.empty()) throw std::runtime_error(secondError);
+                    }
                     if (2 == nReads && loaded[0] != loaded[1])
                         throw std::runtime_error("Mismatching number of clusters in " + lane.readPath[0] + " (" + std::to_string(loaded[0]) + ") and " + lane.readPath[1] + " (" + std::to_string(loaded[1]) + ")");
                     if (!loaded[0]) break;
@@ -945,7 +1008,7 @@ int run(const AlignOptions &o)
         Stage stage("loading base calls, finding and selecting matches");
         std::vector<std::thread> selectors, readers;
         for (auto &w : workers) selectors.emplace_back(selectTiles, std::ref(*w));
-        for (size_t k = 0; k < std::min(lanes.size(), workers.size() + 1); ++k) readers.emplace_back(readLanes);
+        for (unsigned k = 0; k < nReaders; ++k) readers.emplace_back(readLanes, k);
         for (std::thread &t : readers) t.join();
         loadSeconds = seconds() - loadStart;
         {
@@ -1145,15 +1208,11 @@ int run(const AlignOptions &o)
     std::vector<std::thread> builders;
     for (auto &w : workers) builders.emplace_back(buildBins, std::ref(*w));
 
-    const std::string directory = o.outputDirectory + "/Projects/default/default";
-    makeDirectories(directory);
-    const std::string bamPath = directory + "/sorted.bam";
     uint64_t nRecordsWritten = 0, binsWritten = 0;
     double writeSeconds = 0;
     std::string failure;
     {
-        const int fd = ::open(bamPath.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0666);
-        if (fd < 0) failure = "Failed to open output BAM file " + bamPath;
+        const int fd = outputFile.fd;
         uint64_t fileAt = 0;
         const auto append = [&](const uint8_t *data, uint64_t bytes) { if (fd >= 0 && bytes) { writeAt(fd, data, bytes, fileAt); fileAt += bytes; } };
         try { append(headerBgzf.data(), headerBgzf.size()); } catch (const std::exception &e) { failure = e.what(); }
@@ -1188,7 +1247,10 @@ int run(const AlignOptions &o)
         }
         for (std::thread &t : builders) t.join();
         if (failure.empty()) try { append(eofBlock.data(), eofBlock.size()); } catch (const std::exception &e) { failure = e.what(); }
-        if (fd >= 0 && ::close(fd) && failure.empty()) failure = "Failed to write " + bamPath;
+        preallocator.finish();
+        if (::ftruncate(fd, off_t(fileAt)) && failure.empty()) failure = "Failed to write " + bamPath;       // (gives back what was asked for beyond the end)
+        outputFile.fd = -1;
+        if (::close(fd) && failure.empty()) failure = "Failed to write " + bamPath;
         if (failure.empty())
         {
             uint64_t baiBytes = 0;
@@ -1219,7 +1281,7 @@ int run(const AlignOptions &o)
               << ", \"reference_s\": " << referenceSeconds << ", \"reference_fasta_s\": " << fastaSeconds << ", \"reference_contigs_s\": " << contigSeconds << ", \"reference_table_s\": " << tableSeconds << ", \"reference_share_s\": " << shareSeconds << ", \"load_and_find_s\": " << loadSeconds << ", \"load_text_wait_s\": " << g_textWaitSeconds << ", \"load_convert_s\": " << g_convertSeconds << ", \"load_first_lookup_s\": " << g_firstLookupSeconds << ", \"load_text_open_s\": " << g_textOpenSeconds << ", \"load_memory_s\": " << g_loadMemorySeconds << ", \"load_place_s\": " << g_loadPlaceSeconds << ", \"select_resolve_s\": " << g_resolveSeconds << ", \"select_and_bin_s\": " << selectSeconds << ", \"select_busy_s\": " << selectBusySeconds << ", \"build_and_write_s\": " << buildSeconds
               << ", \"tiles_kept_on_device\": " << tilesOnDevice << ", \"tiles\": " << tiles.size() << ", \"loads_kept_on_device\": " << loadsOnDevice << ", \"loads\": " << nLoads << ", \"bins\": " << nBins << ", \"bin_cuts\": " << plan.cuts.size() << ", \"estimated_clusters\": " << estimatedClusters << ", \"bin_ranges\": " << binRangesJson
               << ", \"build_upload_s\": " << workers[0]->uploadSeconds << ", \"build_records_s\": " << workers[0]->recordsSeconds << ", \"build_deflate_s\": " << workers[0]->deflateSeconds
-              << ", \"build_download_s\": " << workers[0]->downloadSeconds << ", \"file_write_s\": " << writeSeconds
+              << ", \"build_download_s\": " << workers[0]->downloadSeconds  << ", \"preallocated_bytes\": " << preallocator.done() << ", \"file_write_s\": " << writeSeconds
               << ", \"overflow_clusters\": " << overflowClusters << ", \"mapq_near_integer\": " << mapqNearInteger << ", \"mapq_resolved_on_host\": " << mapqResolved << ", \"mapq_changed_by_host\": " << mapqChanged
               << ", \"peak_device_bytes\": " << peakDevice << ", \"peak_host_bytes\": " << hostResidentBytes()
               << ", \"total_s\": " << total << "}" << std::endl;
