@@ -50,7 +50,9 @@ std::string AlignOptions::usage()
         "  -b [ --base-calls ] arg              directory with lane<N>_read<R>.fastq[.gz]; one per flowcell\n"
         "  --base-calls-format arg              fastq | fastq-gz (bcl, bcl-gz and bam are not read by this host)\n"
         "  -o [ --output-directory ] arg (=./Aligned)\n"
-        "  -t [ --temp-directory ] arg (=./Temp)   accepted; nothing is written there\n"
+        "  -t [ --temp-directory ] arg (=./Temp)   where the bins' parts go that neither the device nor the host's memory hold\n"
+        "  -m [ --memory-limit ] arg (=0)       gigabytes of host memory the bins' parts may take before they go to files under -t\n"
+        "                                       (0: no limit; the reference's limit of its whole process)\n"
         "  -j [ --jobs ] arg                    host threads for BGZF compression and FASTQ inflation\n"
         "  --device arg (=0)                    HIP device\n"
         "  --devices arg                        HIP devices, comma separated: one worker per entry; the tiles and the bins of the\n"
@@ -147,7 +149,7 @@ AlignOptions AlignOptions::parse(int argc, char **argv)
     for (const char *name : { "input-parallel-load", "temp-parallel-load", "temp-parallel-save", "output-parallel-save", "verbosity", "memory-control", "cleanup-intermediary",
                               "expected-bgzf-ratio", "pre-sort-bins", "buffer-bins", "stats-image-format", "ignore-missing-bcls", "ignore-missing-filters" })
         specs.push_back({ name, 0, false, ignored, "" });
-    specs.push_back({ "memory-limit", 'm', false, ignored, "" });
+    number("memory-limit", 'm', &o.memoryLimit);
 
     auto find = [&specs](const std::string &name, bool isShort) -> const OptionSpec *
     {

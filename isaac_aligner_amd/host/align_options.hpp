@@ -24,7 +24,8 @@ struct AlignOptions
     std::vector<std::string> baseCallsFormat;               // fastq | fastq-gz per flowcell (the last one serves the rest)
     std::string referenceGenome;                            // -r sorted-reference.xml
     std::string outputDirectory = "./Aligned";              // -o
-    std::string tempDirectory = "./Temp";                   // -t (nothing is written there: the bins are kept in host memory)
+    std::string tempDirectory = "./Temp";                   // -t: where the bins' parts go that neither the device nor --memory-limit gigabytes of host memory hold
+    unsigned memoryLimit = 0;                               // -m, gigabytes of host memory for the bins' parts (0: as much as the host has)
     std::string seeds = "auto", gapScoring = "bwa", dodgyAlignmentScore = "0", keepUnaligned = "back", realignGaps = "sample", useBasesMask = "default";
     std::string bamPuFormat = "%F:%L:%B", description, bamExcludeTags = "ZX,ZY", tls;
     std::string devices;                                    // --devices 0,1,...: one worker (context + thread) per entry; empty: --device alone

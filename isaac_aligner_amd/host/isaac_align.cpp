@@ -281,8 +281,24 @@ private:
 // isaac_gpu_bin_tile_map wrote them, a block of device memory per tile, for as long as the device has room beside what the build stage will want (a
 // quarter of its memory is left alone); the tiles after that leave their parts in host memory.  A part on the device goes into its bin's BAM
 // stage as it lies there, no copy in either direction.
-struct BinPart { const Tile *tile; uint64_t clusters, words, bytes; std::unique_ptr<uint8_t[]> data; std::shared_ptr<DeviceMemory> block; uint64_t offset = 0; int place = -1 /* the worker whose device holds it */; };
-struct Bin { std::mutex lock; std::vector<BinPart> parts; uint64_t bytes = 0, records = 0; uint64_t firstPosition = 0, endPosition = 0; /* ReferencePosition values */ bool unaligned = false; };
+struct BinPart
+{
+    const Tile *tile; uint64_t clusters, words, bytes;
+    std::unique_ptr<uint8_t[]> data;                             // in host memory
+    std::shared_ptr<DeviceMemory> block; uint64_t offset = 0;    // in a block of device memory (offset: inside the block) ...
+    int place = -1;                                              // ... of this worker's device
+    bool spilled = false; uint64_t fileOffset = 0;               // in the bin's file under --temp-directory
+};
+struct Bin
+{
+    std::mutex lock; std::vector<BinPart> parts; uint64_t bytes = 0, records = 0; uint64_t firstPosition = 0, endPosition = 0; /* ReferencePosition values */ bool unaligned = false;
+    // what host memory has no room for (--memory-limit): a file of the bin's own, as BinningFragmentStorage keeps all of its bins; parts appended under the bin's lock
+    int spillFd = -1; uint64_t spillBytes = 0; std::string spillPath;
+    Bin() {}
+    Bin(const Bin &) = delete;
+    ~Bin() { closeSpill(); }
+    void closeSpill() { if (spillFd >= 0) { ::close(spillFd); ::unlink(spillPath.c_str()); spillFd = -1; } }
+};
 
 uint64_t align64(uint64_t v) { return (v + 63) & ~uint64_t(63); }
 uint64_t referencePosition(uint64_t contig, uint64_t position) { return (((contig + 1) << 40) | position) << 1; }       // reference::ReferencePosition::getValue()
@@ -691,6 +707,10 @@ int run(const AlignOptions &o)
     std::vector<uint64_t> unselected(workers.size(), 0);             // tiles dealt to the worker and not yet through its selection
     std::atomic<uint64_t> totalClusters(0), totalTiles(0);
     const bool hostBins = 0 != std::getenv("ISAAC_ALIGN_HOST_BINS");          // tests: every part through host memory
+    // -m / --memory-limit: gigabytes the parts in host memory may take; what comes after that goes to the bins' files under -t (ISAAC_ALIGN_SPILL_BINS: tests, every such part)
+    const bool spillBins = 0 != std::getenv("ISAAC_ALIGN_SPILL_BINS");
+    const uint64_t hostPartLimit = uint64_t(o.memoryLimit) << 30;
+    std::atomic<uint64_t> hostPartBytes(0), spilledBytes(0);
     // ISAAC_ALIGN_STREAM_SELECTION=1: the selection begins as soon as every contig has a match.  Off by default: on one device the conversion of the base calls
     // and the selection are both bound by the device, and side by side each took longer than what running them one after the other costs (10 M pairs:
     // 1.2 + 0.6 s against 0.64 + 0.82 s; profiles/r5_cli_stream.log) -- the pipeline is what a host with a device per stage, or a faster converter, wants
@@ -987,8 +1007,28 @@ int run(const AlignOptions &o)
                     {
                         BinPart part; part.tile = &t; part.clusters = m; part.words = cw; part.bytes = bytes;
                         if (block) { part.block = block; part.offset = at; part.place = w.place; }
-                        else { part.data.reset(new uint8_t[bytes]); std::memcpy(part.data.get(), whole.get() + at, bytes); }
+                        else if (spillBins || (hostPartLimit && hostPartBytes.load() + bytes > hostPartLimit)) part.spilled = true;
+                        else { part.data.reset(new uint8_t[bytes]); std::memcpy(part.data.get(), whole.get() + at, bytes); hostPartBytes += bytes; }
                         std::lock_guard<std::mutex> guard(bins[b].lock);
+                        if (part.spilled)
+                        {
+                            Bin &bin = bins[b];
+                            if (bin.spillFd < 0)
+                            {
+                                makeDirectories(o.tempDirectory);
+                                bin.spillPath = o.tempDirectory + "/isaac-align-bin-" + std::to_string(b) + "-" + std::to_string(::getpid()) + ".dat";
+                                bin.spillFd = ::open(bin.spillPath.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0600);
+                                if (bin.spillFd < 0) throw std::runtime_error("Failed to create " + bin.spillPath + ": " + std::strerror(errno));
+                            }
+                            part.fileOffset = bin.spillBytes;
+                            for (uint64_t done = 0; done < bytes; )
+                            {
+                                const ssize_t r = ::pwrite(bin.spillFd, whole.get() + at + done, size_t(bytes - done), off_t(part.fileOffset + done));
+                                if (r < 0) { if (EINTR == errno) continue; throw std::runtime_error("Failed to write " + bin.spillPath + ": " + std::strerror(errno)); }
+                                done += uint64_t(r);
+                            }
+                            bin.spillBytes += bytes; spilledBytes += bytes;
+                        }
                         bins[b].bytes += bytes; bins[b].records += m * nReads;
                         bins[b].parts.push_back(std::move(part));
                     }
@@ -1102,6 +1142,7 @@ int run(const AlignOptions &o)
     {
         const double start = seconds();
         DeviceMemory data, bam, bgzf, entries;
+        std::vector<uint8_t> fromFile;                   // a spilled part on its way back
         for (size_t k = nextBin++; k < fileOrder.size(); k = nextBin++)
         {
             {   // not too far ahead of the writer
@@ -1134,7 +1175,18 @@ int run(const AlignOptions &o)
                             // (from the other device on this context's own stream: nothing is asked of the context that owns the block, which is busy
                             // with bins of its own)
                             if (part.block) GPU(isaac_gpu_copy(w.ctx, base, part.block->as<uint8_t>() + part.offset, part.bytes));
-                            else { GPU(isaac_gpu_upload(w.ctx, base, part.data.get(), part.bytes)); part.data.reset(); }
+                            else if (part.spilled)
+                            {
+                                if (fromFile.size() < part.bytes) fromFile.resize(part.bytes);
+                                for (uint64_t done = 0; done < part.bytes; )
+                                {
+                                    const ssize_t r = ::pread(bin.spillFd, fromFile.data() + done, size_t(part.bytes - done), off_t(part.fileOffset + done));
+                                    if (r <= 0) { if (r < 0 && EINTR == errno) continue; throw std::runtime_error("Failed to read " + bin.spillPath); }
+                                    done += uint64_t(r);
+                                }
+                                GPU(isaac_gpu_upload(w.ctx, base, fromFile.data(), part.bytes));
+                            }
+                            else { GPU(isaac_gpu_upload(w.ctx, base, part.data.get(), part.bytes)); part.data.reset(); hostPartBytes -= part.bytes; }
                             at += part.bytes;
                         }
                         isaac_bam_tile &b = bamTiles[i];
@@ -1196,6 +1248,7 @@ int run(const AlignOptions &o)
                     }
                     w.noteMemory();
                     std::vector<BinPart>().swap(bin.parts);
+                    bin.closeSpill();
                 }
             }
             catch (const std::exception &e) { result.error = e.what(); }
@@ -1281,7 +1334,7 @@ int run(const AlignOptions &o)
               << ", \"reference_s\": " << referenceSeconds << ", \"reference_fasta_s\": " << fastaSeconds << ", \"reference_contigs_s\": " << contigSeconds << ", \"reference_table_s\": " << tableSeconds << ", \"reference_share_s\": " << shareSeconds << ", \"load_and_find_s\": " << loadSeconds << ", \"load_text_wait_s\": " << g_textWaitSeconds << ", \"load_convert_s\": " << g_convertSeconds << ", \"load_first_lookup_s\": " << g_firstLookupSeconds << ", \"load_text_open_s\": " << g_textOpenSeconds << ", \"load_memory_s\": " << g_loadMemorySeconds << ", \"load_place_s\": " << g_loadPlaceSeconds << ", \"select_resolve_s\": " << g_resolveSeconds << ", \"select_and_bin_s\": " << selectSeconds << ", \"select_busy_s\": " << selectBusySeconds << ", \"build_and_write_s\": " << buildSeconds
               << ", \"tiles_kept_on_device\": " << tilesOnDevice << ", \"tiles\": " << tiles.size() << ", \"loads_kept_on_device\": " << loadsOnDevice << ", \"loads\": " << nLoads << ", \"bins\": " << nBins << ", \"bin_cuts\": " << plan.cuts.size() << ", \"estimated_clusters\": " << estimatedClusters << ", \"bin_ranges\": " << binRangesJson
               << ", \"build_upload_s\": " << workers[0]->uploadSeconds << ", \"build_records_s\": " << workers[0]->recordsSeconds << ", \"build_deflate_s\": " << workers[0]->deflateSeconds
-              << ", \"build_download_s\": " << workers[0]->downloadSeconds  << ", \"preallocated_bytes\": " << preallocator.done() << ", \"file_write_s\": " << writeSeconds
+              << ", \"build_download_s\": " << workers[0]->downloadSeconds  << ", \"spilled_bytes\": " << spilledBytes.load() << ", \"preallocated_bytes\": " << preallocator.done() << ", \"file_write_s\": " << writeSeconds
               << ", \"overflow_clusters\": " << overflowClusters << ", \"mapq_near_integer\": " << mapqNearInteger << ", \"mapq_resolved_on_host\": " << mapqResolved << ", \"mapq_changed_by_host\": " << mapqChanged
               << ", \"peak_device_bytes\": " << peakDevice << ", \"peak_host_bytes\": " << hostResidentBytes()
               << ", \"total_s\": " << total << "}" << std::endl;

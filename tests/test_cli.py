@@ -306,6 +306,10 @@ SCENARIOS = {
     # the bins' parts through host memory (what a run too large for the device's memory does), two workers
     "host-bins": dict(compressed=False, lengths=(100, 100), cli=["--devices", "0,0"], paired=True, mark=True, keep=True, realign=True, unaligned="back", dodgy=0, pu="%s:%d:none",
                       env={"ISAAC_ALIGN_HOST_BINS": "1"}),
+    # ... and through files under --temp-directory (what a host does whose memory does not hold them: BinningFragmentStorage's bin files), one worker; the
+    # second one by the option itself: -m 0 would mean no limit, so the limit is a gigabyte and nothing spills -- the switch is what the first one tests
+    "spill-bins": dict(compressed=False, lengths=(100, 100), cli=["-m", "1"], paired=True, mark=True, keep=True, realign=True, unaligned="back", dodgy=0, pu="%s:%d:none",
+                       env={"ISAAC_ALIGN_HOST_BINS": "1", "ISAAC_ALIGN_SPILL_BINS": "1"}, spills=True),
     # what two devices do, on one: the other contexts' contigs and table are copies (ISAAC_GPU_SHARE_BY_COPY) and each worker treats the other's blocks of bin parts as
     # another device's (ISAAC_ALIGN_STRANGERS): isaac_gpu_share_reference's copy branch and the fetch of foreign parts in the build stage
     "strangers": dict(compressed=False, lengths=(100, 100), cli=["--devices", "0,0"], paired=True, mark=True, keep=True, realign=True, unaligned="back", dodgy=0, pu="%s:%d:none",
@@ -403,12 +407,14 @@ def test_gpu_isaac_align_end_to_end(tmp_path, scenario):
             "--bam-header-tag", "@CO\tend to end", "--description", "cli test", "-t", str(tmp_path / "Temp")] + sc["cli"]
     r = run_host(*args, env=sc.get("env"))
     assert r.returncode == 0, r.stderr
-    assert not (tmp_path / "Temp").exists()
+    # nothing is left under --temp-directory (the bins' files of a run that spills are removed bin by bin as the file is written)
+    assert not (tmp_path / "Temp").exists() or not list((tmp_path / "Temp").iterdir())
     timing = json.loads([l for l in r.stderr.splitlines() if "timing {" in l][-1].split("timing ", 1)[1])
     n_tiles = sum(-(-len(bcl) // at_a_time) for _, bcl in lanes)
     assert timing["tiles"] == n_tiles and timing["loads"] == n_tiles and timing["overflow_clusters"] == 0
     host_bins = "ISAAC_ALIGN_HOST_BINS" in sc.get("env", {})
     assert timing["tiles_kept_on_device"] == (0 if host_bins else n_tiles)                              # every tile's parts stayed on the device, or none did
+    assert (timing["spilled_bytes"] > 0) == bool(sc.get("spills"))
     assert timing["loads_kept_on_device"] == (0 if "ISAAC_ALIGN_HOST_LOADS" in sc.get("env", {}) else n_tiles)
     # the bins the host made (host/isaac_align.cpp: planBins): contigs in karyotype order, grouped or cut by the reads the run was expected to have per base
     # (the host sizes its bins from an estimate of the cluster count -- file size over the length of the first record -- which it reports)
