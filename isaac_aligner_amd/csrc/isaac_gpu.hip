@@ -799,7 +799,10 @@ int isaac_gpu_load_index(isaac_gpu_ctx *c, const isaac_reference_kmer *const *ma
     const u32 FILLERS = std::getenv("ISAAC_GPU_LOAD_THREADS") ? std::max(1, std::atoi(std::getenv("ISAAC_GPU_LOAD_THREADS"))) : 8;
     DevBuf<u32> disorder; disorder.reserve(1);
     HIP_CHECK(hipMemsetAsync(disorder.p, 0, 4, st));
-    hipStream_t copyStream; HIP_CHECK(hipStreamCreateWithFlags(&copyStream, hipStreamNonBlocking));
+    // (two copy streams, the pieces taken in turn: one stream's copies ran at 28 GB/s of the link's 50 and more; ISAAC_GPU_LOAD_STREAMS=1: measurement aid)
+    const u32 nCopyStreams = std::getenv("ISAAC_GPU_LOAD_STREAMS") && 1 == std::atoi(std::getenv("ISAAC_GPU_LOAD_STREAMS")) ? 1u : 2u;
+    hipStream_t copyStreams[2] = { nullptr, nullptr };
+    for (u32 i = 0; i < nCopyStreams; ++i) HIP_CHECK(hipStreamCreateWithFlags(&copyStreams[i], hipStreamNonBlocking));
     hipEvent_t copied[2], split[2], left[SLOTS];
     for (u32 i = 0; i < 2; ++i) { HIP_CHECK(hipEventCreateWithFlags(&copied[i], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&split[i], hipEventDisableTiming)); }
     for (u32 i = 0; i < SLOTS; ++i) HIP_CHECK(hipEventCreateWithFlags(&left[i], hipEventDisableTiming));
@@ -813,7 +816,7 @@ int isaac_gpu_load_index(isaac_gpu_ctx *c, const isaac_reference_kmer *const *ma
     {
         stop = true;
         for (std::thread &t : fillers) t.join();
-        hipStreamSynchronize(copyStream); hipStreamDestroy(copyStream);
+        for (u32 i = 0; i < nCopyStreams; ++i) { hipStreamSynchronize(copyStreams[i]); hipStreamDestroy(copyStreams[i]); }
         for (u32 i = 0; i < 2; ++i) { hipEventDestroy(copied[i]); hipEventDestroy(split[i]); }
         for (u32 i = 0; i < SLOTS; ++i) { hipEventDestroy(left[i]); if (pinned[i]) hipHostFree(pinned[i]); }
     };
@@ -838,6 +841,7 @@ int isaac_gpu_load_index(isaac_gpu_ctx *c, const isaac_reference_kmer *const *ma
             for (size_t k = 0; k < pieces.size(); ++k)
             {
                 const u32 turn = u32(k & 1), slot = u32(k % SLOTS);
+                hipStream_t copyStream = copyStreams[turn % nCopyStreams];
                 while (!filled[k].load(std::memory_order_acquire)) std::this_thread::yield();
                 HIP_CHECK(hipMemcpyAsync(c->entries.p + pieces[k].at, pinned[slot], pieces[k].n * sizeof(ReferenceKmerRecord), hipMemcpyHostToDevice, copyStream));
                 HIP_CHECK(hipEventRecord(copied[turn], copyStream));
@@ -852,7 +856,7 @@ int isaac_gpu_load_index(isaac_gpu_ctx *c, const isaac_reference_kmer *const *ma
         }
         u32 bad = 0;
         HIP_CHECK(hipMemcpyAsync(&bad, disorder.p, 4, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st)); HIP_CHECK(hipStreamSynchronize(copyStream));
+        HIP_CHECK(hipStreamSynchronize(st)); for (u32 i = 0; i < nCopyStreams; ++i) HIP_CHECK(hipStreamSynchronize(copyStreams[i]));
         cleanup();
         if (bad) return fail(ISAAC_GPU_EINVAL, "mask files are not in global k-mer order");
     }

@@ -711,10 +711,13 @@ int run(const AlignOptions &o)
     const bool spillBins = 0 != std::getenv("ISAAC_ALIGN_SPILL_BINS");
     const uint64_t hostPartLimit = uint64_t(o.memoryLimit) << 30;
     std::atomic<uint64_t> hostPartBytes(0), spilledBytes(0);
-    // ISAAC_ALIGN_STREAM_SELECTION=1: the selection begins as soon as every contig has a match.  Off by default: on one device the conversion of the base calls
-    // and the selection are both bound by the device, and side by side each took longer than what running them one after the other costs (10 M pairs:
-    // 1.2 + 0.6 s against 0.64 + 0.82 s; profiles/r5_cli_stream.log) -- the pipeline is what a host with a device per stage, or a faster converter, wants
-    const bool streamSelection = 0 != std::getenv("ISAAC_ALIGN_STREAM_SELECTION");
+    // The selection may begin as soon as every contig has a match (closeHits).  It does when the run is expected to have many loads (four per worker and more): the selection
+    // of the early loads then runs beside the reading and conversion of the later ones (100 M pairs in 28 loads, two workers: 12.7 s against 18.9 s with the phases one after
+    // the other, profiles/r5_cli_headline_100M_b.json).  A run of a load or two has nothing to run beside, and the two stages -- both bound by the device -- only get in each
+    // other's way (10 M pairs: 1.2 + 0.6 s against 0.64 + 0.82 s): it selects after the last load, as the reference does.  ISAAC_ALIGN_STREAM_SELECTION=1 / 0 forces either.
+    const uint64_t expectedLoads = (estimatedClusters + loadClusters - 1) / std::max<uint64_t>(1, loadClusters);
+    const char *streamSwitch = std::getenv("ISAAC_ALIGN_STREAM_SELECTION");
+    const bool streamSelection = streamSwitch ? 0 != std::atoi(streamSwitch) : expectedLoads >= 4 * workers.size();
     // ISAAC_ALIGN_DUMP_TILES=<directory>:<lane>.<tile>,...: tiles (by lane number and tile number, as in the read names) to write out as they were selected
     std::set<std::pair<unsigned, unsigned> > dumpTiles; std::string dumpDirectory;
     if (const char *e = std::getenv("ISAAC_ALIGN_DUMP_TILES"))
@@ -1331,7 +1334,7 @@ int run(const AlignOptions &o)
     std::cerr << "isaac-align: " << bamPath << ": " << nRecordsWritten << " records in " << binsWritten << " bin(s)" << std::endl;
     // one line for scripts (bench.py): what the run took, stage by stage
     std::cerr << "isaac-align: timing {\"clusters\": " << totalClusters << ", \"reads\": " << totalClusters * nReads << ", \"records\": " << nRecordsWritten << ", \"workers\": " << workers.size()
-              << ", \"reference_s\": " << referenceSeconds << ", \"reference_fasta_s\": " << fastaSeconds << ", \"reference_contigs_s\": " << contigSeconds << ", \"reference_table_s\": " << tableSeconds << ", \"reference_share_s\": " << shareSeconds << ", \"load_and_find_s\": " << loadSeconds << ", \"load_text_wait_s\": " << g_textWaitSeconds << ", \"load_convert_s\": " << g_convertSeconds << ", \"load_first_lookup_s\": " << g_firstLookupSeconds << ", \"load_text_open_s\": " << g_textOpenSeconds << ", \"load_memory_s\": " << g_loadMemorySeconds << ", \"load_place_s\": " << g_loadPlaceSeconds << ", \"select_resolve_s\": " << g_resolveSeconds << ", \"select_and_bin_s\": " << selectSeconds << ", \"select_busy_s\": " << selectBusySeconds << ", \"build_and_write_s\": " << buildSeconds
+              << ", \"reference_s\": " << referenceSeconds << ", \"reference_fasta_s\": " << fastaSeconds << ", \"reference_contigs_s\": " << contigSeconds << ", \"reference_table_s\": " << tableSeconds << ", \"reference_share_s\": " << shareSeconds << ", \"load_and_find_s\": " << loadSeconds << ", \"load_text_wait_s\": " << g_textWaitSeconds << ", \"load_convert_s\": " << g_convertSeconds << ", \"load_first_lookup_s\": " << g_firstLookupSeconds << ", \"load_text_open_s\": " << g_textOpenSeconds << ", \"load_memory_s\": " << g_loadMemorySeconds << ", \"load_place_s\": " << g_loadPlaceSeconds << ", \"select_resolve_s\": " << g_resolveSeconds << ", \"select_and_bin_s\": " << selectSeconds << ", \"select_busy_s\": " << selectBusySeconds << ", \"selection_streamed\": " << (streamSelection ? 1 : 0) << ", \"build_and_write_s\": " << buildSeconds
               << ", \"tiles_kept_on_device\": " << tilesOnDevice << ", \"tiles\": " << tiles.size() << ", \"loads_kept_on_device\": " << loadsOnDevice << ", \"loads\": " << nLoads << ", \"bins\": " << nBins << ", \"bin_cuts\": " << plan.cuts.size() << ", \"estimated_clusters\": " << estimatedClusters << ", \"bin_ranges\": " << binRangesJson
               << ", \"build_upload_s\": " << workers[0]->uploadSeconds << ", \"build_records_s\": " << workers[0]->recordsSeconds << ", \"build_deflate_s\": " << workers[0]->deflateSeconds
               << ", \"build_download_s\": " << workers[0]->downloadSeconds  << ", \"spilled_bytes\": " << spilledBytes.load() << ", \"preallocated_bytes\": " << preallocator.done() << ", \"file_write_s\": " << writeSeconds

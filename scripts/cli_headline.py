@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--sample-tiles", type=int, default=3)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r5_cli_headline.json"))
     ap.add_argument("--keep", action="store_true")
-    ap.add_argument("--extra-env", default="", help="NAME=value[,NAME=value]: the program once more on the same files with these set (timing only); several sets separated by ';'")
+    ap.add_argument("--extra-env", default="", help="NAME=value[,NAME=value][|more options]: the program once more on the same files with these set (timing only); several sets separated by ';'")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -138,11 +138,12 @@ def main():
         result["extra_runs"] = []
         for extra in [e for e in args.extra_env.split(";") if e.strip()]:
             shutil.rmtree(os.path.join(work, "Aligned"), ignore_errors=True)
-            more = dict(kv.split("=", 1) for kv in extra.split(",") if "=" in kv)
+            env_part, _, arg_part = extra.partition("|")             # NAME=value,... | more options (a later option replaces an earlier one)
+            more = dict(kv.split("=", 1) for kv in env_part.split(",") if "=" in kv)
             t0 = time.time()
-            r2 = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **more))
+            r2 = subprocess.run(cmd + arg_part.split(), capture_output=True, text=True, env=dict(os.environ, **more))
             w2 = time.time() - t0
-            entry = {"env": more, "rc": r2.returncode, "wall_s": round(w2, 2)}
+            entry = {"env": more, "args": arg_part.strip(), "rc": r2.returncode, "wall_s": round(w2, 2)}
             if not r2.returncode:
                 t2 = json.loads([l for l in r2.stderr.splitlines() if "timing {" in l][-1].split("timing ", 1)[1])
                 t2.pop("bin_ranges", None)

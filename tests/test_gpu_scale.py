@@ -2,6 +2,7 @@
 entries), 2x150 (configuration 2) and 2x250 with 5 % indel reads (configuration 4), every record and BAM byte against the oracle; and
 the index itself checked against witnesses that do not use it: the oracle's own builder on a 100 Mbp human-like genome, and at
 3.1 Gbp order / mask / count invariants plus a brute-force scan of the reference (tests/gpucheck) for sampled k-mers."""
+import json
 import os
 import time
 
@@ -414,19 +415,26 @@ def test_isaac_align_on_the_full_size_reference(torch, oracle, human, tmp_path):
         assert r.returncode == 0, r.stderr[-3000:]
         print("isaac-align: %.1f s\n%s" % (time.time() - t0, "\n".join(l for l in r.stderr.splitlines() if "done in" in l or "timing" in l or "tile(s)" in l)))
         assert "%d clusters in 6 tile(s)" % (3 * pairs_per_lane) in r.stderr
+        timing = json.loads([l for l in r.stderr.splitlines() if "timing {" in l][-1].split("timing ", 1)[1])
+        assert timing["overflow_clusters"] == 0 and timing["mapq_changed_by_host"] == 0
+        # the bins the program made (about 4 M records each: the long contigs are cut), for the oracle's BAM stage and for the index's parts
+        bin_ranges = [tuple(r_) for r_ in timing["bin_ranges"]]
+        bin_cuts = [first for first, _ in bin_ranges if (first >> 1) & ((1 << 40) - 1)]
+        assert timing["bin_cuts"] == len(bin_cuts) > 0
         # ---- the oracle chain
         ref = oracle_reference(human, oracle)
         cores = os.cpu_count() or 1
         tile_max = 40_000_000 // p.n_seeds
-        found, all_hits, index = [], np.zeros(len(genome.contigs), np.uint8), 0
+        found, all_hits = [], np.zeros(len(genome.contigs), np.uint8)
         for lane_index, lane in enumerate(lanes):
             bcl, number = lane_bcl[lane], 1
             for first in range(0, len(bcl), tile_max):
                 tile_bcl = np.ascontiguousarray(bcl[first:first + tile_max])
-                om, hits = ref.find_matches(p, tile_bcl, len(tile_bcl), tile=index, n_threads=min(cores, 64))
+                index = (lane_index << 16) | (number - 1)              # the program's tile index: lane ordinal, tile ordinal in the lane
+                om, hits = ref.find_matches(p, tile_bcl, len(tile_bcl), tile=index & 0xfff, n_threads=min(cores, 64))
                 all_hits |= hits
                 found.append((lane_index, lane, number, index, tile_bcl, om))
-                number += 1; index += 1
+                number += 1
         host_tiles, tls_of_lane = [], {}
         for lane_index, lane, number, index, tile_bcl, om in found:
             tls = tls_of_lane.get(lane_index)
@@ -436,7 +444,7 @@ def test_isaac_align_on_the_full_size_reference(torch, oracle, human, tmp_path):
             host_tiles.append((tile_bcl, orec, ocig, "FCSCALE:%d:%d:" % (lane, number), str(lane_index), tls))
         del found
         want, want_n, want_unaligned = oracle.bam_records(host_tiles, [L, L], forced_dodgy_alignment_score=p.dodgy_alignment_score & 0xff, mark_duplicates=True, keep_duplicates=True,
-                                                          realign_gaps=True, reference=ref)
+                                                          realign_gaps=True, reference=ref, bin_cuts=bin_cuts)
         assert want_n == 2 * 3 * pairs_per_lane
         sq = [("chr%d" % (i + 1), int(c.total_bases), "", fasta, "") for i, c in enumerate(contigs)]
         header = oracle.bam_header(" ".join(args), "isaac_aligner_amd-0.3", sq, header_lines=["@RG\tID:%d\tPL:ILLUMINA\tSM:default\tPU:FCSCALE:%d:none" % (k, lane) for k, lane in enumerate(lanes)])
@@ -465,7 +473,8 @@ def test_isaac_align_on_the_full_size_reference(torch, oracle, human, tmp_path):
         assert raw_at == expected_total and blocks[-1][1] == 28
         start_of = {b[2]: b[0] for b in blocks[:-1]}
         start_of[raw_at] = blocks[-1][0]
-        cuts = bam.split_parts(want, want_unaligned)
+        from test_cli import split_by_bins
+        cuts = split_by_bins(want, want_unaligned, bin_ranges)          # a BGZF run per bin and contig
         parts, file_at = [], len(header)
         for off, size in cuts:
             parts.append((off, size, bytes(view[start_of[file_at]:start_of[file_at + size]])))       # every bin starts a block of its own
