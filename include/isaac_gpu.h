@@ -133,6 +133,12 @@ int isaac_gpu_malloc(isaac_gpu_ctx *ctx, uint64_t bytes, void **dev_out);
 int isaac_gpu_free(isaac_gpu_ctx *ctx, void *dev);
 int isaac_gpu_upload(isaac_gpu_ctx *ctx, void *dev, const void *host, uint64_t bytes);
 int isaac_gpu_download(isaac_gpu_ctx *ctx, void *host, const void *dev, uint64_t bytes);
+/* The same on a copy stream of the context's own, behind everything the context's stream has been given so far, without waiting: *ticket_out names the copy.
+ * isaac_gpu_download_wait(ctx, ticket) returns when that copy -- and every one begun before it -- has arrived.  The device buffer must stay untouched and the host
+ * buffer unread until then; `host` should be page-locked (isaac_gpu_host_malloc), or the runtime stages the copy and the call waits after all.  What lets a host
+ * fetch one bin's blocks while the next bin is being encoded (isaac-align's build stage). */
+int isaac_gpu_download_async(isaac_gpu_ctx *ctx, void *host, const void *dev, uint64_t bytes, uint64_t *ticket_out);
+int isaac_gpu_download_wait(isaac_gpu_ctx *ctx, uint64_t ticket);
 /* page-locked host memory: uploads from it and downloads into it run at the link's rate (pageable memory: a third of it), and nothing clears it first */
 int isaac_gpu_host_malloc(uint64_t bytes, void **host_out);
 int isaac_gpu_host_free(void *host);

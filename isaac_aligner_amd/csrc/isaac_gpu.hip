@@ -23,6 +23,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <deque>
 #include "kernels.h"
 #include "host_util.h"
 #include "fastq_kernel.h"
@@ -69,6 +70,7 @@ struct isaac_gpu_ctx
 {
     bool ownsStream = false; u32 cigarExtra = 32;
     int device = 0; hipStream_t stream = nullptr;
+    hipStream_t downloadStream = nullptr; std::deque<std::pair<u64, hipEvent_t> > downloads; u64 downloadTicket = 0;      // isaac_gpu_download_async
     isaac_params params; DevParams P;
     // reference
     DevBuf<char> basesOwned; const char *bases = nullptr;
@@ -636,6 +638,7 @@ void isaac_gpu_destroy(isaac_gpu_ctx *c)
     }
 #endif
     for (hipEvent_t e : c->eventPool) hipEventDestroy(e);
+    if (c->downloadStream) { hipStreamSynchronize(c->downloadStream); for (auto &d : c->downloads) hipEventDestroy(d.second); hipStreamDestroy(c->downloadStream); }
     if (c->ownsStream) hipStreamDestroy(c->stream);
     for (isaac_host_resolve::Resolver *r : c->resolvers) isaac_host_resolve::destroy(r);
     delete c;
@@ -647,6 +650,39 @@ int isaac_gpu_upload(isaac_gpu_ctx *c, void *dev, const void *host, uint64_t byt
 { ISAAC_TRY HIP_CHECK(hipSetDevice(c->device)); HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
 int isaac_gpu_download(isaac_gpu_ctx *c, void *host, const void *dev, uint64_t bytes)
 { ISAAC_TRY HIP_CHECK(hipSetDevice(c->device)); HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream)); HIP_CHECK(hipStreamSynchronize(c->stream)); return 0; ISAAC_CATCH }
+int isaac_gpu_download_async(isaac_gpu_ctx *c, void *host, const void *dev, uint64_t bytes, uint64_t *ticketOut)
+{
+    ISAAC_TRY
+    if (!ticketOut) return fail(ISAAC_GPU_EINVAL, "null argument");
+    HIP_CHECK(hipSetDevice(c->device));
+    if (!c->downloadStream) HIP_CHECK(hipStreamCreateWithFlags(&c->downloadStream, hipStreamNonBlocking));
+    hipEvent_t ready, done;
+    HIP_CHECK(hipEventCreateWithFlags(&ready, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(ready, c->stream));                            // what the context's stream has been given so far
+    HIP_CHECK(hipStreamWaitEvent(c->downloadStream, ready, 0));
+    if (bytes) HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->downloadStream));
+    HIP_CHECK(hipEventRecord(done, c->downloadStream));
+    HIP_CHECK(hipEventDestroy(ready));                                      // (destroyed when the work it marks has passed)
+    c->downloads.push_back(std::make_pair(++c->downloadTicket, done));
+    *ticketOut = c->downloadTicket;
+    return 0;
+    ISAAC_CATCH
+}
+int isaac_gpu_download_wait(isaac_gpu_ctx *c, uint64_t ticket)
+{
+    ISAAC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
+    while (!c->downloads.empty() && c->downloads.front().first <= ticket)
+    {
+        const hipEvent_t done = c->downloads.front().second;
+        c->downloads.pop_front();
+        const hipError_t e = hipEventSynchronize(done);
+        hipEventDestroy(done);
+        HIP_CHECK(e);
+    }
+    return 0;
+    ISAAC_CATCH
+}
 int isaac_gpu_host_malloc(uint64_t bytes, void **hostOut)
 {
     ISAAC_TRY
@@ -799,8 +835,9 @@ int isaac_gpu_load_index(isaac_gpu_ctx *c, const isaac_reference_kmer *const *ma
     const u32 FILLERS = std::getenv("ISAAC_GPU_LOAD_THREADS") ? std::max(1, std::atoi(std::getenv("ISAAC_GPU_LOAD_THREADS"))) : 8;
     DevBuf<u32> disorder; disorder.reserve(1);
     HIP_CHECK(hipMemsetAsync(disorder.p, 0, 4, st));
-    // (two copy streams, the pieces taken in turn: one stream's copies ran at 28 GB/s of the link's 50 and more; ISAAC_GPU_LOAD_STREAMS=1: measurement aid)
-    const u32 nCopyStreams = std::getenv("ISAAC_GPU_LOAD_STREAMS") && 1 == std::atoi(std::getenv("ISAAC_GPU_LOAD_STREAMS")) ? 1u : 2u;
+    // (ISAAC_GPU_LOAD_STREAMS=2: the pieces on two copy streams in turn -- measured no faster than one, 1.77 against 1.60 s for 47 GB, nor were 12 or 16 copying
+    // threads: 28 GB/s is what this host's link gives one direction, profiles/r5_l_cli_timing.log)
+    const u32 nCopyStreams = std::getenv("ISAAC_GPU_LOAD_STREAMS") && 2 == std::atoi(std::getenv("ISAAC_GPU_LOAD_STREAMS")) ? 2u : 1u;
     hipStream_t copyStreams[2] = { nullptr, nullptr };
     for (u32 i = 0; i < nCopyStreams; ++i) HIP_CHECK(hipStreamCreateWithFlags(&copyStreams[i], hipStreamNonBlocking));
     hipEvent_t copied[2], split[2], left[SLOTS];

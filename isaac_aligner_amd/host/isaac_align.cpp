@@ -1144,14 +1144,34 @@ int run(const AlignOptions &o)
     auto buildBins = [&](Worker &w)
     {
         const double start = seconds();
-        DeviceMemory data, bam, bgzf, entries;
+        DeviceMemory data, bam, bgzfSets[2], entries;
+        unsigned turn = 0;                               // the blocks of one bin leave for the host (isaac_gpu_download_async) while the next bin is encoded into the other buffer
         std::vector<uint8_t> fromFile;                   // a spilled part on its way back
+        struct Pending { bool active = false; size_t k = 0; uint64_t ticket = 0; BinOutput result; } pending;
+        const auto publish = [&](size_t k, BinOutput &result)
+        {
+            result.ready = true;
+            { std::lock_guard<std::mutex> guard(outputLock); outputs[k] = std::move(result); }
+            outputReady.notify_all();
+        };
+        const auto finishPending = [&]()
+        {
+            if (!pending.active) return;
+            const double waitStart = seconds();
+            if (isaac_gpu_download_wait(w.ctx, pending.ticket) && pending.result.error.empty()) pending.result.error = std::string("isaac_gpu_download_wait: ") + isaac_gpu_last_error();
+            w.downloadSeconds += seconds() - waitStart;
+            publish(pending.k, pending.result);
+            pending.active = false; pending.result = BinOutput();
+        };
         for (size_t k = nextBin++; k < fileOrder.size(); k = nextBin++)
         {
-            {   // not too far ahead of the writer
+            {   // not too far ahead of the writer (which may be waiting for the bin this worker still holds)
                 std::unique_lock<std::mutex> guard(outputLock);
+                if (!(k < binsWrittenSoFar + BUILD_AHEAD)) { guard.unlock(); finishPending(); guard.lock(); }
                 outputTaken.wait(guard, [&] { return k < binsWrittenSoFar + BUILD_AHEAD; });
             }
+            DeviceMemory &bgzf = bgzfSets[turn];
+            bool inFlight = false; uint64_t ticket = 0;
             BinOutput result;
             double mark = seconds();
             const auto lap = [&mark](double &into) { const double now = seconds(); into += now - mark; mark = now; };
@@ -1246,7 +1266,9 @@ int run(const AlignOptions &o)
                         }
                         lap(w.deflateSeconds);
                         result.bgzf = pinned.take(at); result.bgzfBytes = at; result.recordsBytes = nBytes;
-                        GPU(isaac_gpu_download(w.ctx, result.bgzf.p, bgzf.as<uint8_t>(), at));
+                        finishPending();                                   // (the bin before this one: its blocks left while this one was encoded)
+                        GPU(isaac_gpu_download_async(w.ctx, result.bgzf.p, bgzf.as<uint8_t>(), at, &ticket));
+                        inFlight = true;
                         lap(w.downloadSeconds);
                     }
                     w.noteMemory();
@@ -1255,10 +1277,11 @@ int run(const AlignOptions &o)
                 }
             }
             catch (const std::exception &e) { result.error = e.what(); }
-            result.ready = true;
-            { std::lock_guard<std::mutex> guard(outputLock); outputs[k] = std::move(result); }
-            outputReady.notify_all();
+            finishPending();                                               // bins are published in the order this worker took them
+            if (inFlight) { pending.active = true; pending.k = k; pending.ticket = ticket; pending.result = std::move(result); turn ^= 1; }
+            else publish(k, result);
         }
+        finishPending();
         w.buildSeconds = seconds() - start;
     };
     std::vector<std::thread> builders;

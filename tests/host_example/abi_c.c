@@ -14,7 +14,7 @@ any_function isaac_gpu_entry_points[] = {
     (any_function)isaac_gpu_compact_cigars, (any_function)isaac_gpu_compact_cigars_async, (any_function)isaac_gpu_set_params, (any_function)isaac_gpu_index_dev, (any_function)isaac_gpu_set_index_dev, (any_function)isaac_gpu_bsw_batch, (any_function)isaac_gpu_fastq_to_bcl, (any_function)isaac_gpu_get_counters,
     (any_function)isaac_gpu_kernel_time_ms, (any_function)isaac_gpu_reset_timers,
     (any_function)isaac_gpu_bam_records, (any_function)isaac_gpu_bam_last_error, (any_function)isaac_gpu_bam_header, (any_function)isaac_gpu_bgzf_bound,
-    (any_function)isaac_gpu_bgzf_compress, (any_function)isaac_gpu_fastq_tile_clusters_max, (any_function)isaac_gpu_fastq_tiles, (any_function)isaac_gpu_bgzf_store_bound, (any_function)isaac_gpu_bgzf_store, (any_function)isaac_gpu_share_index, (any_function)isaac_gpu_bin_tile, (any_function)isaac_gpu_bin_tile_map, (any_function)isaac_gpu_resolve_flagged, (any_function)isaac_gpu_set_host_contigs, (any_function)isaac_gpu_share_reference, (any_function)isaac_gpu_bam_indexer_create, (any_function)isaac_gpu_bam_indexer_add, (any_function)isaac_gpu_bam_indexer_add_entries, (any_function)isaac_gpu_bam_indexer_finish, (any_function)isaac_gpu_bam_indexer_destroy, (any_function)isaac_gpu_bgzf_deflate_bound, (any_function)isaac_gpu_bgzf_deflate,
+    (any_function)isaac_gpu_bgzf_compress, (any_function)isaac_gpu_fastq_tile_clusters_max, (any_function)isaac_gpu_fastq_tiles, (any_function)isaac_gpu_bgzf_store_bound, (any_function)isaac_gpu_bgzf_store, (any_function)isaac_gpu_share_index, (any_function)isaac_gpu_bin_tile, (any_function)isaac_gpu_bin_tile_map, (any_function)isaac_gpu_resolve_flagged, (any_function)isaac_gpu_set_host_contigs, (any_function)isaac_gpu_download_async, (any_function)isaac_gpu_download_wait, (any_function)isaac_gpu_share_reference, (any_function)isaac_gpu_bam_indexer_create, (any_function)isaac_gpu_bam_indexer_add, (any_function)isaac_gpu_bam_indexer_add_entries, (any_function)isaac_gpu_bam_indexer_finish, (any_function)isaac_gpu_bam_indexer_destroy, (any_function)isaac_gpu_bgzf_deflate_bound, (any_function)isaac_gpu_bgzf_deflate,
     (any_function)isaac_gpu_copy, (any_function)isaac_gpu_bam_index, (any_function)isaac_gpu_bam_index_last_error, (any_function)isaac_gpu_default_params,
     (any_function)isaac_gpu_parse_gap_scoring, (any_function)isaac_gpu_parse_seeds, (any_function)isaac_gpu_params_last_error,
 };

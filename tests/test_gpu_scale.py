@@ -420,7 +420,7 @@ def test_isaac_align_on_the_full_size_reference(torch, oracle, human, tmp_path):
         # the bins the program made (about 4 M records each: the long contigs are cut), for the oracle's BAM stage and for the index's parts
         bin_ranges = [tuple(r_) for r_ in timing["bin_ranges"]]
         bin_cuts = [first for first, _ in bin_ranges if (first >> 1) & ((1 << 40) - 1)]
-        assert timing["bin_cuts"] == len(bin_cuts) > 0
+        assert timing["bin_cuts"] == len(bin_cuts)           # (none at this depth: 30.6 M records in bins of 4 M are 400 Mbp a bin, more than any contig; test_cli cuts)
         # ---- the oracle chain
         ref = oracle_reference(human, oracle)
         cores = os.cpu_count() or 1
