@@ -355,6 +355,7 @@ struct Worker
 
 // Page-locked host buffers handed round between the builders (which fill them from the device at the link's rate: into pageable memory the same copy runs
 // at a third of it) and the writer (which gives them back): pinning memory is slow, so the buffers are kept and grow to the largest request
+const size_t BUILD_AHEAD = 6;            // finished bins that may wait in host memory for the writer
 class PinnedPool
 {
 public:
@@ -536,7 +537,10 @@ int run(const AlignOptions &o)
         {
             const uint64_t perBin = std::min<uint64_t>(binRecords, std::max<uint64_t>(estimatedClusters * nReads, 1));
             std::vector<PinnedPool::Buffer> made;
-            for (unsigned i = 0; i < 4; ++i) { made.push_back(pinned.take(perBin * 220)); made.push_back(pinned.take(perBin * sizeof(isaac_bam_index_entry))); }
+            // as many as the build stage can have in use: the bins that wait for the writer (BUILD_AHEAD), and per worker the one in work and the one whose blocks are on their way
+            const uint64_t expectedBins = (std::max<uint64_t>(estimatedClusters * nReads, 1) + binRecords - 1) / binRecords + 1;
+            const unsigned buffers = unsigned(std::min<uint64_t>(expectedBins, BUILD_AHEAD + 2 * o.deviceList().size()));
+            for (unsigned i = 0; i < buffers; ++i) { made.push_back(pinned.take(perBin * 160)); made.push_back(pinned.take(perBin * sizeof(isaac_bam_index_entry))); }
             for (PinnedPool::Buffer &b : made) pinned.give(b);
         }
         catch (const std::exception &) {}       // (the build stage asks again and reports what fails)
@@ -1135,7 +1139,6 @@ int run(const AlignOptions &o)
     std::mutex outputLock; std::condition_variable outputReady, outputTaken;
     std::atomic<size_t> nextBin(0);
     size_t binsWrittenSoFar = 0;                        // (under outputLock) the builders stay at most this far ahead of the file: finished bins wait in host memory
-    const size_t BUILD_AHEAD = 8;
     isaac_bam_options bamOptions; std::memset(&bamOptions, 0, sizeof(bamOptions));
     bamOptions.forced_dodgy_alignment_score = o.forcedDodgyAlignmentScore(); bamOptions.pessimistic_mapq = o.pessimisticMapQ; bamOptions.read_group = "0"; bamOptions.barcode = "none";
     bamOptions.mark_duplicates = o.markDuplicates; bamOptions.keep_duplicates = o.keepDuplicates; bamOptions.realign_gaps = "no" != o.realignGaps; bamOptions.realign_dodgy = o.realignDodgy;
@@ -1350,6 +1353,15 @@ int run(const AlignOptions &o)
     std::string binRangesJson = "[";
     for (size_t b = 0; b < plan.ranges.size(); ++b) binRangesJson += (b ? ", [" : "[") + std::to_string(plan.ranges[b].first) + ", " + std::to_string(plan.ranges[b].second) + "]";
     binRangesJson += "]";
+    // device time of the build stage's launch sequences on the first worker (HIP events on its stream: isaac_gpu_kernel_time_ms), in seconds over the run
+    std::string buildKernelsJson = "{";
+    for (const char *name : { "bam_duplicates", "bam_realign", "bam_order", "bam_encode", "bgzf_deflate", "bgzf_store" })
+    {
+        double ms = 0; uint64_t launches = 0;
+        if (isaac_gpu_kernel_time_ms(workers[0]->ctx, name, &ms, &launches) || !launches) continue;
+        buildKernelsJson += std::string(buildKernelsJson.size() > 1 ? ", \"" : "\"") + name + "\": " + std::to_string(ms * double(launches) / 1000.0);
+    }
+    buildKernelsJson += "}";
     uint64_t tilesOnDevice = 0, loadsOnDevice = 0, peakDevice = 0, nLoads = 0; double selectBusySeconds = 0;
     for (auto &w : workers) selectBusySeconds += w->selectSeconds;
     for (auto &w : workers) { tilesOnDevice += w->tilesKeptOnDevice; loadsOnDevice += w->loadsKeptOnDevice; peakDevice = std::max(peakDevice, w->peakDeviceBytes); }
@@ -1360,7 +1372,7 @@ int run(const AlignOptions &o)
               << ", \"reference_s\": " << referenceSeconds << ", \"reference_fasta_s\": " << fastaSeconds << ", \"reference_contigs_s\": " << contigSeconds << ", \"reference_table_s\": " << tableSeconds << ", \"reference_share_s\": " << shareSeconds << ", \"load_and_find_s\": " << loadSeconds << ", \"load_text_wait_s\": " << g_textWaitSeconds << ", \"load_convert_s\": " << g_convertSeconds << ", \"load_first_lookup_s\": " << g_firstLookupSeconds << ", \"load_text_open_s\": " << g_textOpenSeconds << ", \"load_memory_s\": " << g_loadMemorySeconds << ", \"load_place_s\": " << g_loadPlaceSeconds << ", \"select_resolve_s\": " << g_resolveSeconds << ", \"select_and_bin_s\": " << selectSeconds << ", \"select_busy_s\": " << selectBusySeconds << ", \"selection_streamed\": " << (streamSelection ? 1 : 0) << ", \"build_and_write_s\": " << buildSeconds
               << ", \"tiles_kept_on_device\": " << tilesOnDevice << ", \"tiles\": " << tiles.size() << ", \"loads_kept_on_device\": " << loadsOnDevice << ", \"loads\": " << nLoads << ", \"bins\": " << nBins << ", \"bin_cuts\": " << plan.cuts.size() << ", \"estimated_clusters\": " << estimatedClusters << ", \"bin_ranges\": " << binRangesJson
               << ", \"build_upload_s\": " << workers[0]->uploadSeconds << ", \"build_records_s\": " << workers[0]->recordsSeconds << ", \"build_deflate_s\": " << workers[0]->deflateSeconds
-              << ", \"build_download_s\": " << workers[0]->downloadSeconds  << ", \"spilled_bytes\": " << spilledBytes.load() << ", \"preallocated_bytes\": " << preallocator.done() << ", \"file_write_s\": " << writeSeconds
+              << ", \"build_download_s\": " << workers[0]->downloadSeconds  << ", \"build_device_s\": " << buildKernelsJson << ", \"spilled_bytes\": " << spilledBytes.load() << ", \"preallocated_bytes\": " << preallocator.done() << ", \"file_write_s\": " << writeSeconds
               << ", \"overflow_clusters\": " << overflowClusters << ", \"mapq_near_integer\": " << mapqNearInteger << ", \"mapq_resolved_on_host\": " << mapqResolved << ", \"mapq_changed_by_host\": " << mapqChanged
               << ", \"peak_device_bytes\": " << peakDevice << ", \"peak_host_bytes\": " << hostResidentBytes()
               << ", \"total_s\": " << total << "}" << std::endl;
