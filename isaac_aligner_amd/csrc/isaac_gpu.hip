@@ -731,7 +731,8 @@ static void debugTiers(isaac_gpu_ctx *c)
     HIP_CHECK(hipMemcpy(n, c->heavyCount.p, sizeof(n), hipMemcpyDeviceToHost));
     std::fprintf(stderr, "isaac_gpu tiers (last chunk): residual %u, lists > 16: %u, > 64: %u, > 256: %u, > 1024: %u, > 3584: %u\n", n[0], n[4], n[8], n[1], n[3], n[2]);
 }
-int isaac_gpu_synchronize(isaac_gpu_ctx *c) { ISAAC_TRY HIP_CHECK(hipStreamSynchronize(c->stream)); debugTiers(c); return checkPoolShort(c); ISAAC_CATCH }
+int isaac_gpu_synchronize(isaac_gpu_ctx *c) { ISAAC_TRY
+    HIP_CHECK(hipSetDevice(c->device)); HIP_CHECK(hipStreamSynchronize(c->stream)); debugTiers(c); return checkPoolShort(c); ISAAC_CATCH }
 int isaac_gpu_set_deferred_completion(isaac_gpu_ctx *c, int enabled)
 {
     ISAAC_TRY
@@ -1281,6 +1282,7 @@ int isaac_gpu_find_matches(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClust
 int isaac_gpu_set_loaded_contigs(isaac_gpu_ctx *c, const uint8_t *loaded, uint32_t n)
 {
     ISAAC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
     if (n != c->nContigs) return fail(ISAAC_GPU_EINVAL, "contig count mismatch");
     if (loaded) c->hContigLoaded.assign(loaded, loaded + n); else c->hContigLoaded.assign(n, 1);
     HIP_CHECK(hipMemcpy(c->contigLoaded.p, c->hContigLoaded.data(), n, hipMemcpyHostToDevice));
@@ -2330,6 +2332,7 @@ int isaac_gpu_fastq_to_bcl(isaac_gpu_ctx *c, const char *fastq, uint64_t nBytes,
 int isaac_gpu_get_counters(isaac_gpu_ctx *c, isaac_counters *out)
 {
     ISAAC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
     static_assert(sizeof(isaac_counters) == sizeof(Counters), "counter layouts");
     std::vector<Counters> shards(COUNTER_SHARDS);
     HIP_CHECK(hipStreamSynchronize(c->stream));     // kernels in flight still count
@@ -2356,6 +2359,7 @@ int isaac_gpu_kernel_time_ms(isaac_gpu_ctx *c, const char *kernel, double *avgMs
 int isaac_gpu_reset_timers(isaac_gpu_ctx *c)
 {
     ISAAC_TRY
+    HIP_CHECK(hipSetDevice(c->device));
     HIP_CHECK(hipStreamSynchronize(c->stream));
     resolveTimers(c);
     c->timers.clear();

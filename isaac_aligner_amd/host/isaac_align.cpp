@@ -348,14 +348,14 @@ struct Worker
     std::vector<uint8_t> contigHasMatches;
     isaac_counters counters;
     uint64_t tilesKeptOnDevice = 0, loadsKeptOnDevice = 0, peakDeviceBytes = 0, mapqResolved = 0, mapqChanged = 0;
-    double selectSeconds = 0, buildSeconds = 0, uploadSeconds = 0, recordsSeconds = 0, deflateSeconds = 0, downloadSeconds = 0;
+    double selectSeconds = 0, buildSeconds = 0, uploadSeconds = 0, recordsSeconds = 0, deflateSeconds = 0, downloadSeconds = 0, writerWaitSeconds = 0, releaseSeconds = 0;
     ~Worker() { matches.release(); offsets.release(); textDev.release(); if (ctx) isaac_gpu_destroy(ctx); }
     void noteMemory() { uint64_t f = 0, t = 0; if (!isaac_gpu_memory_info(ctx, &f, &t)) peakDeviceBytes = std::max(peakDeviceBytes, t - f); }
 };
 
 // Page-locked host buffers handed round between the builders (which fill them from the device at the link's rate: into pageable memory the same copy runs
 // at a third of it) and the writer (which gives them back): pinning memory is slow, so the buffers are kept and grow to the largest request
-const size_t BUILD_AHEAD = 6;            // finished bins that may wait in host memory for the writer
+const size_t BUILD_AHEAD = std::getenv("ISAAC_ALIGN_BUILD_AHEAD") ? size_t(std::max(1, std::atoi(std::getenv("ISAAC_ALIGN_BUILD_AHEAD")))) : 6;            // finished bins that may wait in host memory for the writer (the variable: measurements)
 class PinnedPool
 {
 public:
@@ -539,7 +539,7 @@ int run(const AlignOptions &o)
             std::vector<PinnedPool::Buffer> made;
             // as many as the build stage can have in use: the bins that wait for the writer (BUILD_AHEAD), and per worker the one in work and the one whose blocks are on their way
             const uint64_t expectedBins = (std::max<uint64_t>(estimatedClusters * nReads, 1) + binRecords - 1) / binRecords + 1;
-            const unsigned buffers = unsigned(std::min<uint64_t>(expectedBins, BUILD_AHEAD + 2 * o.deviceList().size()));
+            const unsigned buffers = std::getenv("ISAAC_ALIGN_WARM_BUFFERS") ? unsigned(std::atoi(std::getenv("ISAAC_ALIGN_WARM_BUFFERS"))) : unsigned(std::min<uint64_t>(expectedBins, BUILD_AHEAD + 2 * o.deviceList().size()));
             for (unsigned i = 0; i < buffers; ++i) { made.push_back(pinned.take(perBin * 160)); made.push_back(pinned.take(perBin * sizeof(isaac_bam_index_entry))); }
             for (PinnedPool::Buffer &b : made) pinned.give(b);
         }
@@ -1144,6 +1144,7 @@ int run(const AlignOptions &o)
     bamOptions.mark_duplicates = o.markDuplicates; bamOptions.keep_duplicates = o.keepDuplicates; bamOptions.realign_gaps = "no" != o.realignGaps; bamOptions.realign_dodgy = o.realignDodgy;
     bamOptions.bin_filter = 2;
     const uint32_t maxReadLength = std::max(params.read_length[0], params.read_length[1]);
+    const bool syncDownloads = 0 != std::getenv("ISAAC_ALIGN_SYNC_DOWNLOADS");       // (measurements: a bin's blocks fetched before the next bin is begun)
     auto buildBins = [&](Worker &w)
     {
         const double start = seconds();
@@ -1169,9 +1170,11 @@ int run(const AlignOptions &o)
         for (size_t k = nextBin++; k < fileOrder.size(); k = nextBin++)
         {
             {   // not too far ahead of the writer (which may be waiting for the bin this worker still holds)
+                const double waitStart = seconds();
                 std::unique_lock<std::mutex> guard(outputLock);
                 if (!(k < binsWrittenSoFar + BUILD_AHEAD)) { guard.unlock(); finishPending(); guard.lock(); }
                 outputTaken.wait(guard, [&] { return k < binsWrittenSoFar + BUILD_AHEAD; });
+                w.writerWaitSeconds += seconds() - waitStart;
             }
             DeviceMemory &bgzf = bgzfSets[turn];
             bool inFlight = false; uint64_t ticket = 0;
@@ -1270,13 +1273,14 @@ int run(const AlignOptions &o)
                         lap(w.deflateSeconds);
                         result.bgzf = pinned.take(at); result.bgzfBytes = at; result.recordsBytes = nBytes;
                         finishPending();                                   // (the bin before this one: its blocks left while this one was encoded)
-                        GPU(isaac_gpu_download_async(w.ctx, result.bgzf.p, bgzf.as<uint8_t>(), at, &ticket));
-                        inFlight = true;
+                        if (syncDownloads) GPU(isaac_gpu_download(w.ctx, result.bgzf.p, bgzf.as<uint8_t>(), at));
+                        else { GPU(isaac_gpu_download_async(w.ctx, result.bgzf.p, bgzf.as<uint8_t>(), at, &ticket)); inFlight = true; }
                         lap(w.downloadSeconds);
                     }
                     w.noteMemory();
                     std::vector<BinPart>().swap(bin.parts);
                     bin.closeSpill();
+                    lap(w.releaseSeconds);
                 }
             }
             catch (const std::exception &e) { result.error = e.what(); }
@@ -1372,7 +1376,7 @@ int run(const AlignOptions &o)
               << ", \"reference_s\": " << referenceSeconds << ", \"reference_fasta_s\": " << fastaSeconds << ", \"reference_contigs_s\": " << contigSeconds << ", \"reference_table_s\": " << tableSeconds << ", \"reference_share_s\": " << shareSeconds << ", \"load_and_find_s\": " << loadSeconds << ", \"load_text_wait_s\": " << g_textWaitSeconds << ", \"load_convert_s\": " << g_convertSeconds << ", \"load_first_lookup_s\": " << g_firstLookupSeconds << ", \"load_text_open_s\": " << g_textOpenSeconds << ", \"load_memory_s\": " << g_loadMemorySeconds << ", \"load_place_s\": " << g_loadPlaceSeconds << ", \"select_resolve_s\": " << g_resolveSeconds << ", \"select_and_bin_s\": " << selectSeconds << ", \"select_busy_s\": " << selectBusySeconds << ", \"selection_streamed\": " << (streamSelection ? 1 : 0) << ", \"build_and_write_s\": " << buildSeconds
               << ", \"tiles_kept_on_device\": " << tilesOnDevice << ", \"tiles\": " << tiles.size() << ", \"loads_kept_on_device\": " << loadsOnDevice << ", \"loads\": " << nLoads << ", \"bins\": " << nBins << ", \"bin_cuts\": " << plan.cuts.size() << ", \"estimated_clusters\": " << estimatedClusters << ", \"bin_ranges\": " << binRangesJson
               << ", \"build_upload_s\": " << workers[0]->uploadSeconds << ", \"build_records_s\": " << workers[0]->recordsSeconds << ", \"build_deflate_s\": " << workers[0]->deflateSeconds
-              << ", \"build_download_s\": " << workers[0]->downloadSeconds  << ", \"build_device_s\": " << buildKernelsJson << ", \"spilled_bytes\": " << spilledBytes.load() << ", \"preallocated_bytes\": " << preallocator.done() << ", \"file_write_s\": " << writeSeconds
+              << ", \"build_download_s\": " << workers[0]->downloadSeconds  << ", \"build_writer_wait_s\": " << workers[0]->writerWaitSeconds << ", \"build_release_s\": " << workers[0]->releaseSeconds << ", \"build_device_s\": " << buildKernelsJson << ", \"spilled_bytes\": " << spilledBytes.load() << ", \"preallocated_bytes\": " << preallocator.done() << ", \"file_write_s\": " << writeSeconds
               << ", \"overflow_clusters\": " << overflowClusters << ", \"mapq_near_integer\": " << mapqNearInteger << ", \"mapq_resolved_on_host\": " << mapqResolved << ", \"mapq_changed_by_host\": " << mapqChanged
               << ", \"peak_device_bytes\": " << peakDevice << ", \"peak_host_bytes\": " << hostResidentBytes()
               << ", \"total_s\": " << total << "}" << std::endl;
