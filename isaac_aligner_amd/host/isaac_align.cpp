@@ -355,7 +355,7 @@ struct Worker
 
 // Page-locked host buffers handed round between the builders (which fill them from the device at the link's rate: into pageable memory the same copy runs
 // at a third of it) and the writer (which gives them back): pinning memory is slow, so the buffers are kept and grow to the largest request
-const size_t BUILD_AHEAD = std::getenv("ISAAC_ALIGN_BUILD_AHEAD") ? size_t(std::max(1, std::atoi(std::getenv("ISAAC_ALIGN_BUILD_AHEAD")))) : 6;            // finished bins that may wait in host memory for the writer (the variable: measurements)
+const size_t BUILD_AHEAD = std::getenv("ISAAC_ALIGN_BUILD_AHEAD") ? size_t(std::max(1, std::atoi(std::getenv("ISAAC_ALIGN_BUILD_AHEAD")))) : 8;            // finished bins that may wait in host memory for the writer (the variable: measurements)
 class PinnedPool
 {
 public:
@@ -1295,7 +1295,7 @@ int run(const AlignOptions &o)
     for (auto &w : workers) builders.emplace_back(buildBins, std::ref(*w));
 
     uint64_t nRecordsWritten = 0, binsWritten = 0;
-    double writeSeconds = 0;
+    double writeSeconds = 0, indexBusySeconds = 0;
     std::string failure;
     {
         const int fd = outputFile.fd;
@@ -1303,6 +1303,37 @@ int run(const AlignOptions &o)
         const auto append = [&](const uint8_t *data, uint64_t bytes) { if (fd >= 0 && bytes) { writeAt(fd, data, bytes, fileAt); fileAt += bytes; } };
         try { append(headerBgzf.data(), headerBgzf.size()); } catch (const std::exception &e) { failure = e.what(); }
         isaac_bam_indexer *indexer = isaac_gpu_bam_indexer_create(nContigs, headerBgzf.size());
+        // the index takes its bins on a thread of its own, in the writer's order: going over 32 bytes and a BGZF block table per record costs about as much as
+        // writing the record does (100 M pairs: 2 s beside 3 s of writes), and on the writer's thread it held the builders up
+        std::mutex indexLock; std::condition_variable indexWake;
+        std::deque<BinOutput> indexQueue; bool indexClosed = false; std::string indexFailure; double indexSeconds = 0;
+        std::thread indexThread([&]()
+        {
+            for (;;)
+            {
+                BinOutput out;
+                {
+                    std::unique_lock<std::mutex> guard(indexLock);
+                    indexWake.wait(guard, [&] { return indexClosed || !indexQueue.empty(); });
+                    if (indexQueue.empty()) return;
+                    out = std::move(indexQueue.front()); indexQueue.pop_front();
+                }
+                indexWake.notify_all();
+                const double start = seconds();
+                isaac_bam_index_entry *entries = static_cast<isaac_bam_index_entry *>(out.entries.p);
+                for (const BinOutput::Segment &sg : out.segments)
+                {
+                    if (!indexFailure.empty()) break;
+                    for (uint64_t i = sg.firstEntry; i < sg.firstEntry + sg.nEntries; ++i) entries[i].offset -= sg.recordsOffset;      // offsets inside the run's own records
+                    if (isaac_gpu_bam_indexer_add_entries(indexer, entries + sg.firstEntry, sg.nEntries, sg.recordsBytes, static_cast<const uint8_t *>(out.bgzf.p) + sg.bgzfOffset, sg.bgzfBytes))
+                        indexFailure = std::string("isaac_gpu_bam_indexer_add_entries: ") + isaac_gpu_bam_index_last_error();
+                }
+                indexSeconds += seconds() - start;
+                pinned.give(out.bgzf); pinned.give(out.entries);
+            }
+        });
+        struct CloseIndex { std::mutex &lock; std::condition_variable &wake; bool &closed; std::thread &t; void operator()() { { std::lock_guard<std::mutex> g(lock); closed = true; } wake.notify_all(); if (t.joinable()) t.join(); } ~CloseIndex() { (*this)(); } }
+            closeIndex{ indexLock, indexWake, indexClosed, indexThread };
         for (size_t k = 0; k < outputs.size(); ++k)
         {
             BinOutput out;
@@ -1319,19 +1350,23 @@ int run(const AlignOptions &o)
                 const double writeStart = seconds();
                 try { append(static_cast<const uint8_t *>(out.bgzf.p), out.bgzfBytes); } catch (const std::exception &e) { failure = e.what(); }
                 writeSeconds += seconds() - writeStart;
-                isaac_bam_index_entry *entries = static_cast<isaac_bam_index_entry *>(out.entries.p);
-                for (const BinOutput::Segment &sg : out.segments)
-                {
-                    if (!failure.empty()) break;
-                    for (uint64_t i = sg.firstEntry; i < sg.firstEntry + sg.nEntries; ++i) entries[i].offset -= sg.recordsOffset;      // offsets inside the run's own records
-                    if (isaac_gpu_bam_indexer_add_entries(indexer, entries + sg.firstEntry, sg.nEntries, sg.recordsBytes, static_cast<const uint8_t *>(out.bgzf.p) + sg.bgzfOffset, sg.bgzfBytes))
-                        failure = std::string("isaac_gpu_bam_indexer_add_entries: ") + isaac_gpu_bam_index_last_error();
-                }
                 nRecordsWritten += out.nRecords; ++binsWritten;
+                if (failure.empty())
+                {   // to the index, which keeps the buffers until it is through with them (at most four bins behind the file)
+                    std::unique_lock<std::mutex> guard(indexLock);
+                    indexWake.wait(guard, [&] { return indexQueue.size() < 4; });
+                    indexQueue.push_back(std::move(out));
+                    guard.unlock();
+                    indexWake.notify_all();
+                    continue;
+                }
             }
             pinned.give(out.bgzf); pinned.give(out.entries);
         }
         for (std::thread &t : builders) t.join();
+        closeIndex();
+        if (failure.empty()) failure = indexFailure;
+        indexBusySeconds = indexSeconds;
         if (failure.empty()) try { append(eofBlock.data(), eofBlock.size()); } catch (const std::exception &e) { failure = e.what(); }
         preallocator.finish();
         if (::ftruncate(fd, off_t(fileAt)) && failure.empty()) failure = "Failed to write " + bamPath;       // (gives back what was asked for beyond the end)
@@ -1376,7 +1411,7 @@ int run(const AlignOptions &o)
               << ", \"reference_s\": " << referenceSeconds << ", \"reference_fasta_s\": " << fastaSeconds << ", \"reference_contigs_s\": " << contigSeconds << ", \"reference_table_s\": " << tableSeconds << ", \"reference_share_s\": " << shareSeconds << ", \"load_and_find_s\": " << loadSeconds << ", \"load_text_wait_s\": " << g_textWaitSeconds << ", \"load_convert_s\": " << g_convertSeconds << ", \"load_first_lookup_s\": " << g_firstLookupSeconds << ", \"load_text_open_s\": " << g_textOpenSeconds << ", \"load_memory_s\": " << g_loadMemorySeconds << ", \"load_place_s\": " << g_loadPlaceSeconds << ", \"select_resolve_s\": " << g_resolveSeconds << ", \"select_and_bin_s\": " << selectSeconds << ", \"select_busy_s\": " << selectBusySeconds << ", \"selection_streamed\": " << (streamSelection ? 1 : 0) << ", \"build_and_write_s\": " << buildSeconds
               << ", \"tiles_kept_on_device\": " << tilesOnDevice << ", \"tiles\": " << tiles.size() << ", \"loads_kept_on_device\": " << loadsOnDevice << ", \"loads\": " << nLoads << ", \"bins\": " << nBins << ", \"bin_cuts\": " << plan.cuts.size() << ", \"estimated_clusters\": " << estimatedClusters << ", \"bin_ranges\": " << binRangesJson
               << ", \"build_upload_s\": " << workers[0]->uploadSeconds << ", \"build_records_s\": " << workers[0]->recordsSeconds << ", \"build_deflate_s\": " << workers[0]->deflateSeconds
-              << ", \"build_download_s\": " << workers[0]->downloadSeconds  << ", \"build_writer_wait_s\": " << workers[0]->writerWaitSeconds << ", \"build_release_s\": " << workers[0]->releaseSeconds << ", \"build_device_s\": " << buildKernelsJson << ", \"spilled_bytes\": " << spilledBytes.load() << ", \"preallocated_bytes\": " << preallocator.done() << ", \"file_write_s\": " << writeSeconds
+              << ", \"build_download_s\": " << workers[0]->downloadSeconds  << ", \"build_writer_wait_s\": " << workers[0]->writerWaitSeconds << ", \"build_release_s\": " << workers[0]->releaseSeconds << ", \"build_device_s\": " << buildKernelsJson << ", \"spilled_bytes\": " << spilledBytes.load() << ", \"preallocated_bytes\": " << preallocator.done() << ", \"file_write_s\": " << writeSeconds << ", \"index_s\": " << indexBusySeconds
               << ", \"overflow_clusters\": " << overflowClusters << ", \"mapq_near_integer\": " << mapqNearInteger << ", \"mapq_resolved_on_host\": " << mapqResolved << ", \"mapq_changed_by_host\": " << mapqChanged
               << ", \"peak_device_bytes\": " << peakDevice << ", \"peak_host_bytes\": " << hostResidentBytes()
               << ", \"total_s\": " << total << "}" << std::endl;
