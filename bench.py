@@ -176,7 +176,7 @@ def cli_end_to_end(args, al, genome, batches, L, emit_note):
         timing = json.loads([l for l in r.stderr.splitlines() if "timing {" in l][-1].split("timing ", 1)[1])
         bam = os.path.join(work, "Aligned", "Projects", "default", "default", "sorted.bam")
         out = {"reads_per_s": round(timing["reads"] / wall, 1), "reads_per_s_without_reference_load": round(timing["reads"] / max(1e-9, timing["total_s"] - timing["reference_s"]), 1),
-               "pairs": n_pairs, "wall_s": round(wall, 2), "stages_s": {k: round(v, 3) for k, v in timing.items() if k.endswith("_s")}, "records": timing["records"], "workers": timing["workers"],
+               "pairs": n_pairs, "wall_s": round(wall, 2), "stages_s": {k: (round(v, 3) if not isinstance(v, dict) else {kk: round(vv, 3) for kk, vv in v.items()}) for k, v in timing.items() if k.endswith("_s")}, "records": timing["records"], "workers": timing["workers"],
                "tiles_kept_on_device": timing.get("tiles_kept_on_device"),
                "sorted_bam_bytes": os.path.getsize(bam), "bai_bytes": os.path.getsize(bam + ".bai"),
                "command": "isaac-align -r sorted-reference.xml -b <2 FASTQ files> --base-calls-format fastq --use-bases-mask y*,y* --clusters-at-a-time 2000000 (defaults: --mark-duplicates 1, --realign-gaps sample, --bam-gzip-level 1)",

@@ -104,7 +104,7 @@ struct isaac_gpu_ctx
     // isaac_gpu_bam_records scratch
     DevBuf<BamTile> bamTiles; DevBuf<u64> bamKeyHi, bamKeyLo, bamKeyAlt, bamOffsets, bamBytes64, bamBounds; DevBuf<u32> bamIndex, bamIndexAlt, bamBytes;
     DevBuf<u64> dupPrimary, dupMate, dupRank, dupCluster, dupSmall; DevBuf<u8> dupFlag;        // duplicate marking
-    DevBuf<FragmentRecord> realignRecords; DevBuf<RealignGap> realignGaps, realignDeletionEnds; DevBuf<u32> realignPool, realignNext; DevBuf<u8> realignChanged;   // gap realignment
+    DevBuf<FragmentRecord> realignRecords; DevBuf<RealignGap> realignGaps, realignDeletionEnds; DevBuf<u32> realignPool, realignNext, realignList, realignListCount; DevBuf<u8> realignChanged;   // gap realignment
     DevBuf<RescueJob> jobs; DevBuf<u32> rescueCounters, bitmaps, candJob, shadowCigars, jobBase, jobCount; DevBuf<i32> candPositions; DevBuf<Cand> shadowCands; DevBuf<u32> candRank;
     DevBuf<Counters> counters, countersSaved; DevBuf<u8> bswFlags;
     std::map<std::string, KernelTimer> timers;
@@ -1987,10 +1987,18 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
         // so that no realignment is ever dropped and the outcome does not depend on which fragments came first.
         u64 poolCap = c->realignPool.n;
         if (const char *small = std::getenv("ISAAC_GPU_REALIGN_POOL_WORDS")) poolCap = std::min<u64>(poolCap, u64(std::atol(small)));     // tests: the second pass
-        for (int attempt = 0; ; ++attempt)
+        // the fragments with a gap of the list in their range (k_realign_filter), then the realigner over those
+        c->realignList.reserve(n); c->realignListCount.reserve(1);
+        HIP_CHECK(hipMemsetAsync(c->realignListCount.p, 0, 4, st));
+        k_realign_filter<<<gridFor(n, 256), 256, 0, st>>>(c->bamTiles.p, nTiles, n, o, view, duplicate, c->realignRecords.p, c->realignList.p, c->realignListCount.p, c->realignChanged.p);
+        HIP_CHECK(hipGetLastError());
+        u32 listCount = 0;
+        HIP_CHECK(hipMemcpyAsync(&listCount, c->realignListCount.p, 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));             // (the host vectors above are read by the copies)
+        for (int attempt = 0; listCount; ++attempt)
         {
             HIP_CHECK(hipMemsetAsync(c->realignNext.p, 0, 4, st));
-            k_realign<<<gridFor(n, 128), 128, 0, st>>>(c->bamTiles.p, nTiles, n, o, c->ref(), view, duplicate, c->realignRecords.p, c->realignPool.p, u32(std::min<u64>(poolCap, 0xffffffffu)), c->realignNext.p, c->realignChanged.p);
+            k_realign<<<gridFor(listCount, 128), 128, 0, st>>>(c->bamTiles.p, nTiles, c->realignList.p, listCount, o, c->ref(), view, duplicate, c->realignRecords.p, c->realignPool.p, u32(std::min<u64>(poolCap, 0xffffffffu)), c->realignNext.p, c->realignChanged.p);
             HIP_CHECK(hipGetLastError());
             u32 wanted = 0;
             HIP_CHECK(hipMemcpyAsync(&wanted, c->realignNext.p, 4, hipMemcpyDeviceToHost, st));
@@ -2005,7 +2013,7 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
             }
             HIP_CHECK(hipMemcpyAsync(c->bamTiles.p, h.data(), sizeof(BamTile) * nTiles, hipMemcpyHostToDevice, st));
         }
-        k_realign_pairs<<<gridFor(n, 256), 256, 0, st>>>(c->bamTiles.p, nTiles, n, o, c->realignRecords.p, c->realignChanged.p);
+        if (listCount) k_realign_pairs<<<gridFor(n, 256), 256, 0, st>>>(c->bamTiles.p, nTiles, n, o, c->realignRecords.p, c->realignChanged.p);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(st));
     }

@@ -80,6 +80,16 @@ ISAAC_HD u32 rgFindGaps(const RealignerGapsView &v, u64 rangeBegin, u64 rangeEnd
     return n;
 }
 
+// whether rgFindGaps would find anything at all in the range (the same four bounds, nothing copied): what decides, for nearly every fragment of a bin, that
+// the realigner has nothing to do
+ISAAC_HD bool rgAnyGap(const RealignerGapsView &v, u64 rangeBegin, u64 rangeEnd)
+{
+    const u32 s0 = rgLowerBoundStart(v.gaps, 0, v.nGaps, rangeBegin, -1000000), s1 = rgLowerBoundStart(v.gaps, s0, v.nGaps, rangeEnd, 0);
+    if (s1 > s0) return true;
+    const u32 e0 = rgLowerBoundEnd(v.deletionEnds, 0, v.nDeletionEnds, rpPlus(rangeBegin, 1)), e1 = rgLowerBoundEnd(v.deletionEnds, e0, v.nDeletionEnds, rpPlus(rangeEnd, 1));
+    return e1 > e0;
+}
+
 // gapRealigner::OverlappingGapsFilter (OverlappingGapsFilter.hh:32-92, OverlappingGapsFilter.cpp:30-160) for at most ten gaps
 struct OverlapsFilter { u32 maxChoice, nOverlaps, overlaps[2 * RG_MAX_GAPS_AT_A_TIME + 2]; };
 ISAAC_HD void overlapsFilterInit(OverlapsFilter &f, const RealignGap *gaps, u32 nGaps)
