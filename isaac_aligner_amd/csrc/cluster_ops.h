@@ -134,9 +134,19 @@ ISAAC_HD void rescueAlignCandidate(const DevParams &P, const DevReference &R, co
     shadowRead.bcl = bcl + u64(cluster) * P.clusterLength + P.readOffset[r]; shadowRead.length = P.readLength[r];
     shadowRead.firstCycle = P.firstCycle[r]; shadowRead.endCyclesMasked = endCyclesMasked;
     CigarPool pool; pool.words = cigar3; pool.used = 0; pool.capacity = 3; pool.overflow = 0;
+    // the candidate is made in registers and stored once: initialised in its place and filled in by the scan it reached device memory twice (10.7 M slots a
+    // step do not wait in the L2 for the scan to end: 1.56 GB written per step for 0.8 GB of candidates, profiles/r5_final_pmc_summary.json)
+#if defined(ISAAC_CAND_IN_PLACE)       // (the form of rounds 1-5, for comparison)
     candInit(out, r);
     out.reverse = job.shadowReverse; out.contigId = job.contigId; out.position = i64(relativePosition) + job.windowBegin;
     alignUngapped(P, R, shadowRead, out, pool);
+#else
+    Cand c;
+    candInit(c, r);
+    c.reverse = job.shadowReverse; c.contigId = job.contigId; c.position = i64(relativePosition) + job.windowBegin;
+    alignUngapped(P, R, shadowRead, c, pool);
+    out = c;
+#endif
 }
 
 // What the flat kernels hand to clusterSelect: the cluster's jobs and the aligned candidates of the chunk

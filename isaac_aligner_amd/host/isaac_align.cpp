@@ -716,13 +716,14 @@ int run(const AlignOptions &o)
     const bool spillBins = 0 != std::getenv("ISAAC_ALIGN_SPILL_BINS");
     const uint64_t hostPartLimit = uint64_t(o.memoryLimit) << 30;
     std::atomic<uint64_t> hostPartBytes(0), spilledBytes(0);
-    // The selection may begin as soon as every contig has a match (closeHits).  It does when the run is expected to have many loads (four per worker and more): the selection
-    // of the early loads then runs beside the reading and conversion of the later ones (100 M pairs in 28 loads, two workers: 12.7 s against 18.9 s with the phases one after
-    // the other, profiles/r5_cli_headline_100M_b.json).  A run of a load or two has nothing to run beside, and the two stages -- both bound by the device -- only get in each
-    // other's way (10 M pairs: 1.2 + 0.6 s against 0.64 + 0.82 s): it selects after the last load, as the reference does.  ISAAC_ALIGN_STREAM_SELECTION=1 / 0 forces either.
+    // The selection may begin as soon as every contig has a match (closeHits).  It does when the run is expected to be long (eight loads per worker and more): the selection
+    // of the early loads then runs beside the reading and conversion of the later ones.  Both are bound by the device, so what streaming hides is the shorter of the
+    // two stages, and only where there is enough of a run to hide it in: 100 M pairs in 28 loads on two workers gain between nothing and a second of fourteen
+    // (profiles/r5_cli_headline_100M_*.json); 10 M pairs in five loads gained 0.15 s stand-alone and lost 0.3 s as bench.py's leg (profiles/r5_r_cli_timing.log,
+    // r5_last_bench_default.json against r5_j), where the stages only get in each other's way.  ISAAC_ALIGN_STREAM_SELECTION=1 / 0 forces either.
     const uint64_t expectedLoads = (estimatedClusters + loadClusters - 1) / std::max<uint64_t>(1, loadClusters);
     const char *streamSwitch = std::getenv("ISAAC_ALIGN_STREAM_SELECTION");
-    const bool streamSelection = streamSwitch ? 0 != std::atoi(streamSwitch) : expectedLoads >= 4 * workers.size();
+    const bool streamSelection = streamSwitch ? 0 != std::atoi(streamSwitch) : expectedLoads >= 8 * workers.size();
     // ISAAC_ALIGN_DUMP_TILES=<directory>:<lane>.<tile>,...: tiles (by lane number and tile number, as in the read names) to write out as they were selected
     std::set<std::pair<unsigned, unsigned> > dumpTiles; std::string dumpDirectory;
     if (const char *e = std::getenv("ISAAC_ALIGN_DUMP_TILES"))
