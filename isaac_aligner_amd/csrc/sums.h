@@ -326,33 +326,41 @@ ISAAC_HD bool gappedRetryAccepted(const DevParams &P, const Cand &fragment, cons
 // wave-per-cluster pass has to do it (a capacity of the flat pass was exceeded).
 ISAAC_HD bool finishRescueFlat(const DevParams &P, RescueJob &job, const SumInputs &in, u32 &retries)
 {
-    job.take = 0; job.rescued = 0; job.finalBestRank = 0; job.finalBestSlot = 0; job.finalBestGapped = 0xffffffffu;
-    job.out.logProbability = 0.0; job.out.smithWatermanScore = 0; job.out.editDistance = 0; job.out.mapped = 0; job.out.mismatchCount = 0; job.out.matchesInARow = 0; job.out.rescued = 0;
-    if (!job.valid) return true;
-    if (job.fallback || (job.nGapped && 0xffffffffu == job.gappedBase)) return false;
-    const bool full = job.nAligned - job.lastAligned >= SHADOW_LIST_MAX && job.nCands != 0;   // the reference gives up when the list is full and another candidate aligns
-    job.take = imin(job.nAligned, SHADOW_LIST_MAX);
-    if (full || !job.nAligned) return true;
-    u32 best = job.bestRank, bestSlot = job.bestSlot, bestGapped = 0xffffffffu;
-    double bestLp = in.shadowCands[job.bestSlot].logProbability;
-    for (u32 kk = 0; kk < job.nGapped; ++kk)
+    // What the problem's record gains is put together here and stored once, at the end: written field by field as it became known, the record's two lines
+    // went to device memory more than once (the walk over the retries below is a chain of dependent loads, longer than a line stays in the L2 of a busy kernel).
+    struct Outcome
     {
-        const GappedResult &g = in.gappedResults[job.gappedBase + kk];
-        GappedJob &gj = in.gappedJobs[job.gappedBase + kk];
+        u32 take = 0, rescued = 0, finalBestRank = 0, finalBestSlot = 0, finalBestGapped = 0xffffffffu; RescueOutcome out;
+        ISAAC_HD void store(RescueJob &j) const { j.take = take; j.rescued = rescued; j.finalBestRank = finalBestRank; j.finalBestSlot = finalBestSlot; j.finalBestGapped = finalBestGapped; j.out = out; }
+    } o;
+    o.out.logProbability = 0.0; o.out.smithWatermanScore = 0; o.out.editDistance = 0; o.out.mapped = 0; o.out.mismatchCount = 0; o.out.matchesInARow = 0; o.out.rescued = 0;
+    o.out.pad[0] = o.out.pad[1] = o.out.pad[2] = 0;
+    const u32 valid = job.valid, fallback = job.fallback, nGappedJobs = job.nGapped, gappedBase = job.gappedBase, nAligned = job.nAligned, lastAligned = job.lastAligned, nCands = job.nCands;
+    if (!valid) { o.store(job); return true; }
+    if (fallback || (nGappedJobs && 0xffffffffu == gappedBase)) { o.store(job); return false; }
+    const bool full = nAligned - lastAligned >= SHADOW_LIST_MAX && nCands != 0;   // the reference gives up when the list is full and another candidate aligns
+    o.take = imin(nAligned, SHADOW_LIST_MAX);
+    if (full || !nAligned) { o.store(job); return true; }
+    u32 best = job.bestRank, bestSlot = job.bestSlot, bestGapped = 0xffffffffu;
+    double bestLp = in.shadowCands[bestSlot].logProbability;
+    for (u32 kk = 0; kk < nGappedJobs; ++kk)
+    {
+        const GappedResult &g = in.gappedResults[gappedBase + kk];
+        GappedJob &gj = in.gappedJobs[gappedBase + kk];
         const u32 slot = gj.tag, i = in.candRank[slot];
         const Cand &fragment = in.shadowCands[slot];
         ++retries;
         gj.pad = 0;
-        if (0xffffffffu == g.nCigar) return false;        // CIGAR longer than the result record holds
+        if (0xffffffffu == g.nCigar) { o.store(job); return false; }        // CIGAR longer than the result record holds
         const Cand &tmp = g.out;
         if (gappedRetryAccepted(P, fragment, g))
         {
             gj.pad = 1;
-            if (i == best) { bestLp = tmp.logProbability; bestGapped = job.gappedBase + kk; bestSlot = slot; }
-            else if (lpLess(bestLp, tmp.logProbability)) { best = i; bestLp = tmp.logProbability; bestGapped = job.gappedBase + kk; bestSlot = slot; }
+            if (i == best) { bestLp = tmp.logProbability; bestGapped = gappedBase + kk; bestSlot = slot; }
+            else if (lpLess(bestLp, tmp.logProbability)) { best = i; bestLp = tmp.logProbability; bestGapped = gappedBase + kk; bestSlot = slot; }
         }
     }
-    job.rescued = 1; job.finalBestRank = best; job.finalBestSlot = bestSlot; job.finalBestGapped = bestGapped;
+    o.rescued = 1; o.finalBestRank = best; o.finalBestSlot = bestSlot; o.finalBestGapped = bestGapped;
     {   // the best shadow as the template stage will ask about it (template_lean.h: leanConsiderRescued)
         const bool gapped = 0xffffffffu != bestGapped;
         const Cand &b = gapped ? in.gappedResults[bestGapped].out : in.shadowCands[bestSlot];
@@ -360,9 +368,10 @@ ISAAC_HD bool finishRescueFlat(const DevParams &P, RescueJob &job, const SumInpu
         const u32 n = gapped ? (in.gappedResults[bestGapped].nCigar & 0xffffu) : u32(b.cigarLength);
         u32 mapped = 0;
         for (u32 i = 0; i < n; ++i) if (OP_ALIGN == cigarCode(cigar[i])) mapped += cigarLen(cigar[i]);
-        job.out.logProbability = b.logProbability; job.out.smithWatermanScore = b.smithWatermanScore; job.out.editDistance = b.editDistance; job.out.mapped = u16(mapped);
-        job.out.mismatchCount = b.mismatchCount; job.out.matchesInARow = b.matchesInARow; job.out.rescued = 1;
+        o.out.logProbability = b.logProbability; o.out.smithWatermanScore = b.smithWatermanScore; o.out.editDistance = b.editDistance; o.out.mapped = u16(mapped);
+        o.out.mismatchCount = b.mismatchCount; o.out.matchesInARow = b.matchesInARow; o.out.rescued = 1;
     }
+    o.store(job);
     return true;
 }
 
