@@ -1072,16 +1072,16 @@ ISAAC_HD bool buildCandidates(const DevParams &P, const u8 *clusterBcl, const Ma
 
 ISAAC_HD void alignCandidate(const DevParams &P, const DevReference &R, const u8 *clusterBcl, ClusterFragments &out, u32 r, u32 i, Counters &cnt)
 {
-    ReadView read; read.bcl = clusterBcl + P.readOffset[r]; read.length = P.readLength[r]; read.firstCycle = P.firstCycle[r]; read.endCyclesMasked = out.endCyclesMasked[r];
+    ReadView read; read.bcl = clusterBcl + P.readOffset[r]; read.length = P.readLength[r]; read.firstCycle = P.firstCycle[r]; read.endCyclesMasked = r ? out.endCyclesMasked[1] : out.endCyclesMasked[0];      // (r is known at run time only: selects, not indexes -- ClusterFragments::list)
     const u32 slot = 3 * ((r ? out.nCands[0] : 0) + i);
     CigarPool pool; pool.words = out.cigarPool; pool.used = slot; pool.capacity = slot + 3; pool.overflow = 0;
     // (the candidate in registers while the scan fills it in, one load and one store: updated in its place it went to device memory more than once)
 #if defined(ISAAC_CAND_IN_PLACE)       // (the form of rounds 1-5, for comparison)
-    alignUngapped(P, R, read, out.cands[r][i], pool);
+    alignUngapped(P, R, read, out.list(r)[i], pool);
 #else
-    Cand c = out.cands[r][i];
+    Cand c = out.list(r)[i];
     alignUngapped(P, R, read, c, pool);
-    out.cands[r][i] = c;
+    out.list(r)[i] = c;
 #endif
     ++cnt.ungappedScans;
 }

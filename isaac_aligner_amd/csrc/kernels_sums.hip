@@ -74,7 +74,7 @@ template <u32 W> __device__ inline u32 clusterSumsWave(const DevParams &P, const
         ok = finishRescueFlat(P, job, in, retries);
         take = job.take; side = (job.shadowReadIndex + 1u) % 2; rescued = job.rescued; best = job.rescued ? job.finalBestRank : 0;
         nGapped = job.nGapped; gappedBase = job.gappedBase; candBase = job.candBase; nCands = job.nCands;
-        if (take) { const Cand &o = f.cands[side][job.orphanListIndex]; orphan = makeShadowProb(o); orphanLp = o.logProbability; }
+        if (take) { const Cand &o = f.list(side)[job.orphanListIndex]; orphan = makeShadowProb(o); orphanLp = o.logProbability; }
     }
     {
         const u32 groupBase = (threadIdx.x & 63u) & ~(W - 1);
@@ -136,7 +136,7 @@ template <u32 W> __device__ inline u32 clusterSumsWave(const DevParams &P, const
     {
         const u32 first = s ? shadows[0] : 0, n = shadows[s] + nSeeded[1 - s];
         if (lane < shadows[s]) { k.pos1[lane] = tab.pos[first + lane]; k.pos2[lane] = 0; k.lp[lane] = tab.lp[first + lane]; k.obs1[lane] = tab.obs[first + lane]; k.obs2[lane] = 0; }
-        else if (lane < n) sumKeyFromCand(k, lane, f.cands[1 - s][lane - shadows[s]]);
+        else if (lane < n) sumKeyFromCand(k, lane, f.list(1 - s)[lane - shadows[s]]);
         groupSync(g);
         if (!uniqueSortedSum(k, n, false, g, nullptr, out.shadow[s])) return SUMS_NEAR_TIE;
     }

@@ -433,7 +433,7 @@ ISAAC_HD u32 clusterSums(const DevParams &P, const ClusterFragments &f, const Su
             forEachShadow(job, in, g, [&](u32 r, const Cand &c, bool) { sumKeyFromCand(k, base + r, c); });
             base += job.take;
         }
-        for (u32 i = g.lane; i < nCands[1 - side]; i += g.lanes) sumKeyFromCand(k, base + i, f.cands[1 - side][i]);
+        for (u32 i = g.lane; i < nCands[1 - side]; i += g.lanes) sumKeyFromCand(k, base + i, f.list(1 - side)[i]);
         groupSync(g);
         SUMS_T("gather", in.nJobs);
         if (!uniqueSortedSum(k, base + nCands[1 - side], false, g, scratch, out.shadow[side])) return SUMS_NEAR_TIE;
@@ -447,7 +447,7 @@ ISAAC_HD u32 clusterSums(const DevParams &P, const ClusterFragments &f, const Su
             const RescueJob &job = in.jobs[j];
             if (!job.take) continue;
             const u32 side = (job.shadowReadIndex + 1u) % 2;
-            const ShadowProb o = makeShadowProb(f.cands[side][job.orphanListIndex]);
+            const ShadowProb o = makeShadowProb(f.list(side)[job.orphanListIndex]);
             forEachShadow(job, in, g, [&](u32 r, const Cand &c, bool)
             {
                 const ShadowProb s = makeShadowProb(c);
@@ -469,7 +469,7 @@ ISAAC_HD u32 clusterSums(const DevParams &P, const ClusterFragments &f, const Su
             const RescueJob &job = in.jobs[j];
             if (!job.take) continue;
             const u32 side = (job.shadowReadIndex + 1u) % 2;
-            const double orphanLp = f.cands[side][job.orphanListIndex].logProbability;
+            const double orphanLp = f.list(side)[job.orphanListIndex].logProbability;
             const u32 best = job.rescued ? job.finalBestRank : 0;
             forEachShadow(job, in, g, [&](u32 r, const Cand &c, bool) { k.term[base + (r == best ? 0 : 0 == r ? best : r)] = exp(orphanLp + c.logProbability); });
             base += job.take;

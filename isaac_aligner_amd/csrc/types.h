@@ -177,6 +177,11 @@ struct ClusterFragments
     u32 repeatSeedsCount;
     u32 built;              // FragmentBuilder::build returned true
     u32 *cigarPool;         // cigarPool[Cand::cigarOffset ...]: the cluster's words
+    // the list of read r, r known at run time only: a select between the two pointers.  cands[r] with such an r makes the compiler keep the whole view in
+    // scratch memory -- 80 bytes a thread that every thread of a kernel writes on entry: 1.3 GB a launch of k_cluster_sums16, which reached device memory
+    // as 1 GB of writes (profiles/r5_final_pmc_summary.json) for one pointer read back.
+    ISAAC_HD Cand *list(u32 r) const { return r ? cands[1] : cands[0]; }
+    ISAAC_HD u32 listLength(u32 r) const { return r ? nCands[1] : nCands[0]; }
 };
 ISAAC_HD ClusterFragments clusterView(const ClusterMeta &m, Cand *candPool, u32 *cigarArena)
 {
