@@ -208,8 +208,8 @@ ISAAC_HD bool leanBuildCandidates(const DevParams &P, const u8 *clusterBcl, cons
         Nibbles order; order.v = 0; u32 n = 0;
         while (mine) { const u32 i = u32(__builtin_ctz(mine)); mine &= mine - 1; order.set(n++, i); }
         leanSortOrder(order, n, k);
-        const u32 stored = leanEmitCandidates(P, out.cands[r], r, repeatSeedsCount, n, k, NibbleIndex{order});
-        out.nCands[r] = stored;
+        const u32 stored = leanEmitCandidates(P, out.list(r), r, repeatSeedsCount, n, k, NibbleIndex{order});
+        out.setListLength(r, stored);
     }
     out.built = built;
     return built;
@@ -300,7 +300,7 @@ ISAAC_HD bool keyedBuildCandidates(const DevParams &P, const u8 *clusterBcl, con
         built = true;
         { CandKeyLess cl; cl.k = k; exactSort(candOrder, i32(n), cl); }
         ByteIndex index; index.order = candOrder;
-        out.nCands[r] = leanEmitCandidates(P, out.cands[r], r, repeatSeedsCount, n, k, index);
+        out.setListLength(r, leanEmitCandidates(P, out.list(r), r, repeatSeedsCount, n, k, index));
     }
     out.built = built;
     return built;
@@ -315,9 +315,9 @@ ISAAC_HD void leanFinishCandidates(const DevParams &P, ClusterFragments &out, co
     u32 slotBase = 0;                     // the list's first candidate slot: its ungapped CIGAR is at 3 x slot
     for (u32 r = 0; r < P.nReads; ++r)
     {
-        const u32 n0 = out.nCands[r];
+        const u32 n0 = out.listLength(r);
         if (!n0) continue;
-        Cand *store = out.cands[r];
+        Cand *store = out.list(r);
         u32 n = leanConsolidate(store, n0, true, k);
         if (P.semialignedGapLimit && n >= 2)
         {
@@ -350,7 +350,7 @@ ISAAC_HD void leanFinishCandidates(const DevParams &P, ClusterFragments &out, co
                 if (!sorted) leanApplyOrder(store, order, n);
             }
         }
-        out.nCands[r] = n;
+        out.setListLength(r, n);
         slotBase += n0;
     }
     (void)slotBase;
@@ -366,8 +366,8 @@ ISAAC_HD void leanFinishFragments(const DevParams &P, ClusterFragments &out, con
     CigarPool pool; pool.words = out.cigarPool; pool.used = out.cigarUsed; pool.capacity = out.cigarCap; pool.overflow = 0;
     for (u32 r = 0; r < P.nReads; ++r)
     {
-        const u32 n = out.nCands[r];
-        Cand *store = out.cands[r];
+        const u32 n = out.listLength(r);
+        Cand *store = out.list(r);
         bool changed = false;
         for (u32 i = 0; results && i < n; ++i)
         {
@@ -390,7 +390,7 @@ ISAAC_HD void leanFinishFragments(const DevParams &P, ClusterFragments &out, con
         }
         (void)changed;
         const u32 m = leanConsolidate(store, n, true, k);          // (a list without an accepted gapped alignment is consolidated already: one pass over its keys)
-        out.nCands[r] = m;
+        out.setListLength(r, m);
         candidates += m;
     }
     out.cigarUsed = pool.used;

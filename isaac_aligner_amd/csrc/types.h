@@ -182,6 +182,7 @@ struct ClusterFragments
     // as 1 GB of writes (profiles/r5_final_pmc_summary.json) for one pointer read back.
     ISAAC_HD Cand *list(u32 r) const { return r ? cands[1] : cands[0]; }
     ISAAC_HD u32 listLength(u32 r) const { return r ? nCands[1] : nCands[0]; }
+    ISAAC_HD void setListLength(u32 r, u32 n) { if (r) nCands[1] = n; else nCands[0] = n; }
 };
 ISAAC_HD ClusterFragments clusterView(const ClusterMeta &m, Cand *candPool, u32 *cigarArena)
 {
