@@ -460,8 +460,8 @@ int isaac_gpu_bgzf_store(isaac_gpu_ctx *ctx, const uint8_t *data_dev, uint64_t n
 
 /* BGZF with compression on the device, for --bam-gzip-level 1 and up: replaces bgzf::BgzfCompressor with zlib behind it
  * (include/bgzf/BgzfCompressor.hh:36-176, wired into the BAM writer at lib/build/Build.cpp:181-254) for streams that are in HBM already.  Same
- * framing as above (gzip members with the BC field, CRC-32 and length) around blocks of 24 KB of input -- smaller than the reference's
- * 0xFFFF - 41, which is as valid a BGZF file and lets a compute unit work on four blocks at a time; inside, one
+ * framing as above (gzip members with the BC field, CRC-32 and length) around blocks of 20 KB of input -- smaller than the reference's
+ * 0xFFFF - 41, which is as valid a BGZF file and lets a compute unit work on five blocks at a time; inside, one
  * dynamic-Huffman deflate block per member (hash-table LZ77 over the block, the call's two Huffman tables made from a sample of its blocks),
  * or a stored block where that is not smaller.  The compressed bytes are not zlib's: what is identical is what they inflate to.  out_dev:
  * isaac_gpu_bgzf_deflate_bound(n_bytes) bytes are always enough; with less the call fails with ISAAC_GPU_ECAPACITY once the output does not

@@ -26,8 +26,10 @@ bool makeDeflateTables(const u64 *litLenCounts, const u64 *distCounts, DeflateTa
 // 42.1 GB/s, 0.518 -- zlib level 1 on the same stream: 0.520 at 1 GB/s on 256 host threads.  The walk is a chain of LDS round trips that a lone
 // wavefront waits out one by one, so throughput follows the number of blocks in flight; the ratio hardly moves because on BAM records most of
 // the gain is the Huffman coding of four-bit bases and a few quality values, not the matches.  profiles/r4_exp_deflate*.log)
+// (Round 5, the 6.4 GB record stream of the bench: 24 576 bytes, four blocks per CU: 35.2 GB/s, ratio 0.5138; 20 480 bytes, five per CU: 42.4 GB/s, 0.5158 -- the default
+// since; 16 384 bytes: 41.9 GB/s, 0.5179 (five per CU as well); 16 384 bytes and 1 024 hash slots, six per CU: 53.1 GB/s, 0.5211.  profiles/exp_r5_deflate_block.log)
 #ifndef ISAAC_DEFLATE_BLOCK_INPUT
-#define ISAAC_DEFLATE_BLOCK_INPUT 24576
+#define ISAAC_DEFLATE_BLOCK_INPUT 20480
 #endif
 static const u32 DEFLATE_BLOCK_INPUT = ISAAC_DEFLATE_BLOCK_INPUT;
 static_assert(DEFLATE_BLOCK_INPUT <= BGZF_BLOCK_INPUT && 0 == (DEFLATE_BLOCK_INPUT & 1), "block input size");
