@@ -348,12 +348,16 @@ __global__ void k_realign_collect(const BamTile *tiles, u32 nTiles, u64 nRecords
 // finding none is how the reference leaves nearly every fragment alone).  A thread per record with a few registers; k_realign -- a thread per fragment with
 // the realigner's whole state, ten gaps and three CIGARs of scratch -- then runs over the list only (round 5: it ran over every record, 19 ms for the
 // 3.4 M records of a bin of which a few thousand have anything to try).  changed[] is cleared for every record.
+// (wanted[i] = 1 for the listed records: the list is made from these flags by a scan, in record order -- appended with an atomic counter it came out in the
+// order the waves happened to run, and k_realign's reads of neighbouring records no longer shared lines: at thirty-fold depth, where a third of a bin's
+// fragments have a gap in reach, the stage was slower than without the filter)
 __global__ void k_realign_filter(const BamTile *tiles, u32 nTiles, u64 nRecords, BamOptions o, RealignerGapsView gapsView, const u8 *duplicate, const FragmentRecord *records /* the copy */,
-                                 u32 *list, u32 *listCount, u8 *changed)
+                                 u32 *wanted, u8 *changed)
 {
     const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= nRecords) return;
     changed[i] = 0;
+    wanted[i] = 0;
     const u32 t = bamTileOf(tiles, nTiles, i);
     const FragmentRecord &r = records[i];
     if (!bamStored(r) || (r.flags & 2) || bamUnalignedBin(r) || !r.editDistance || !bamInBin(r, o)) return;
@@ -361,8 +365,12 @@ __global__ void k_realign_filter(const BamTile *tiles, u32 nTiles, u64 nRecords,
     const u32 *cigar = bamRecordCigar(tiles[t], r);
     RealignIndex index = { r.fStrandPosition, cigar, cigar + r.cigarLength };
     const RealignBounds bounds = rgBounds(index);
-    if (!rgAnyGap(gapsView, bounds.beginPos, bounds.endPos)) return;
-    list[atomicAdd(listCount, 1u)] = u32(i);
+    if (rgAnyGap(gapsView, bounds.beginPos, bounds.endPos)) wanted[i] = 1;
+}
+__global__ void k_realign_list(const u32 *wanted, const u32 *offsets, u64 nRecords, u32 *list)
+{
+    const u64 i = u64(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < nRecords && wanted[i]) list[offsets[i]] = u32(i);
 }
 // changed[i]: the fragment was realigned; its new CIGAR took words from the pool's bump counter
 __global__ void k_realign(BamTile *tiles, u32 nTiles, const u32 *list, u32 listCount, BamOptions o, DevReference R, RealignerGapsView gapsView, const u8 *duplicate, FragmentRecord *records /* the copy */,

@@ -104,7 +104,7 @@ struct isaac_gpu_ctx
     // isaac_gpu_bam_records scratch
     DevBuf<BamTile> bamTiles; DevBuf<u64> bamKeyHi, bamKeyLo, bamKeyAlt, bamOffsets, bamBytes64, bamBounds; DevBuf<u32> bamIndex, bamIndexAlt, bamBytes;
     DevBuf<u64> dupPrimary, dupMate, dupRank, dupCluster, dupSmall; DevBuf<u8> dupFlag;        // duplicate marking
-    DevBuf<FragmentRecord> realignRecords; DevBuf<RealignGap> realignGaps, realignDeletionEnds; DevBuf<u32> realignPool, realignNext, realignList, realignListCount; DevBuf<u8> realignChanged;   // gap realignment
+    DevBuf<FragmentRecord> realignRecords; DevBuf<RealignGap> realignGaps, realignDeletionEnds; DevBuf<u32> realignPool, realignNext, realignList; DevBuf<u8> realignChanged;   // gap realignment
     DevBuf<RescueJob> jobs; DevBuf<u32> rescueCounters, bitmaps, candJob, shadowCigars, jobBase, jobCount; DevBuf<i32> candPositions; DevBuf<Cand> shadowCands; DevBuf<u32> candRank;
     DevBuf<Counters> counters, countersSaved; DevBuf<u8> bswFlags;
     std::map<std::string, KernelTimer> timers;
@@ -1988,13 +1988,19 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
         u64 poolCap = c->realignPool.n;
         if (const char *small = std::getenv("ISAAC_GPU_REALIGN_POOL_WORDS")) poolCap = std::min<u64>(poolCap, u64(std::atol(small)));     // tests: the second pass
         // the fragments with a gap of the list in their range (k_realign_filter), then the realigner over those
-        c->realignList.reserve(n); c->realignListCount.reserve(1);
-        HIP_CHECK(hipMemsetAsync(c->realignListCount.p, 0, 4, st));
-        k_realign_filter<<<gridFor(n, 256), 256, 0, st>>>(c->bamTiles.p, nTiles, n, o, view, duplicate, c->realignRecords.p, c->realignList.p, c->realignListCount.p, c->realignChanged.p);
+        c->realignList.reserve(n);
+        k_realign_filter<<<gridFor(n, 256), 256, 0, st>>>(c->bamTiles.p, nTiles, n, o, view, duplicate, c->realignRecords.p, counts, c->realignChanged.p);       // (counts, offsets: free again after the gaps' collection)
+        HIP_CHECK(hipGetLastError());
+        exclusiveSum(c, counts, offsets, n);
+        k_realign_list<<<gridFor(n, 256), 256, 0, st>>>(counts, offsets, n, c->realignList.p);
         HIP_CHECK(hipGetLastError());
         u32 listCount = 0;
-        HIP_CHECK(hipMemcpyAsync(&listCount, c->realignListCount.p, 4, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));             // (the host vectors above are read by the copies)
+        {
+            u32 lastWanted = 0, lastAt = 0;
+            HIP_CHECK(hipMemcpyAsync(&lastWanted, counts + n - 1, 4, hipMemcpyDeviceToHost, st)); HIP_CHECK(hipMemcpyAsync(&lastAt, offsets + n - 1, 4, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));         // (the host vectors above are read by the copies)
+            listCount = lastWanted + lastAt;
+        }
         for (int attempt = 0; listCount; ++attempt)
         {
             HIP_CHECK(hipMemsetAsync(c->realignNext.p, 0, 4, st));

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Round 5, the realigner's list in record order (a scan instead of an atomic append): the GPU tests with the at-scale BAM and CLI tests, the 100 M-pair run twice
+timeout 1500 python -m pytest tests -q -m gpu --deselect tests/test_gpu_scale.py 2>&1 | tail -6 > gpurun_out/gputests_r5_zzz.log
+timeout 2400 python -m pytest tests/test_gpu_scale.py -x -q -m gpu -k "bam_stage or isaac_align" 2>&1 | tail -6 > gpurun_out/scale_r5_zzz.log
+cat gpurun_out/gputests_r5_zzz.log gpurun_out/scale_r5_zzz.log
+timeout 2400 python scripts/cli_headline.py --pairs 100000000 --lanes 4 --devices 0,0 --sample-tiles 3 --extra-env "ISAAC_ALIGN_BUILD_AHEAD=8" --out gpurun_out/r5_cli_headline_100M_h.json > gpurun_out/r5_cli_headline_100M_h.log 2>&1
+echo rc $?
+python3 - <<'PY'
+import json
+d=json.load(open('gpurun_out/r5_cli_headline_100M_h.json'))
+keys=('reference_s','reference_table_s','load_and_find_s','select_and_bin_s','selection_streamed','build_and_write_s','build_records_s','build_deflate_s','build_download_s','build_device_s','index_s','file_write_s','total_s')
+print('first', d['wall_s'], d['sampled_parity_diffs'], d['reads_per_s'], d['reads_per_s_without_reference_load'], d['peak_device_gb'], d['peak_host_gb'], {k:d['timing'].get(k) for k in keys})
+for e in d['extra_runs']: print(e['env'], e['wall_s'], e['reads_per_s'], e['reads_per_s_without_reference_load'], {k:e['timing'].get(k) for k in keys})
+PY
