@@ -638,10 +638,13 @@ ISAAC_HD void summarizeRescueJob(RescueJob &job, const Cand *shadowCands, u32 *c
     u32 n = 0; i32 best = -1; u32 bestRank = 0, bestMismatches = 0; bool last = false;
     double bestLp = 0.0;
     u32 nClose = 0; i64 prevPosition = 0; u32 prevMismatches = 0;     // the pairs planRescueGapped would pick, counted on the way
+    // (the record's two numbers once: read through `job` inside the loops they were fetched again after every store to candRank, which may alias it for all
+    // the compiler knows -- two more dependent loads in front of every batch of a walk that is nothing but dependent loads)
+    const u32 nCands = job.nCands, candBase = job.candBase;
     // the candidates' fields are fetched SUMMARY_BATCH at a time before any of them is looked at: one thread walks the whole
     // list (thousands of entries in repeat families), and loads that wait for the previous element's branches cost a memory
     // latency each
-    for (u32 c0 = 0; c0 < job.nCands; c0 += SUMMARY_BATCH)
+    for (u32 c0 = 0; c0 < nCands; c0 += SUMMARY_BATCH)
     {
         double lps[SUMMARY_BATCH]; i64 positions[SUMMARY_BATCH]; u32 mismatchCounts[SUMMARY_BATCH]; bool aligned[SUMMARY_BATCH];
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -649,7 +652,7 @@ ISAAC_HD void summarizeRescueJob(RescueJob &job, const Cand *shadowCands, u32 *c
 #endif
         for (u32 k = 0; k < SUMMARY_BATCH; ++k)
         {
-            const Cand &f = shadowCands[job.candBase + imin(c0 + k, job.nCands - 1)];
+            const Cand &f = shadowCands[candBase + imin(c0 + k, nCands - 1)];
             lps[k] = f.logProbability; positions[k] = f.position; mismatchCounts[k] = f.mismatchCount; aligned[k] = candAligned(f);
         }
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -658,8 +661,8 @@ ISAAC_HD void summarizeRescueJob(RescueJob &job, const Cand *shadowCands, u32 *c
         for (u32 k = 0; k < SUMMARY_BATCH; ++k)
         {
             const u32 c = c0 + k;
-            if (c >= job.nCands) break;
-            candRank[job.candBase + c] = n;
+            if (c >= nCands) break;
+            candRank[candBase + c] = n;
             last = aligned[k];
             if (!last) continue;
             const double lp = lps[k]; const i64 position = positions[k]; const u32 mismatches = mismatchCounts[k];
@@ -669,7 +672,7 @@ ISAAC_HD void summarizeRescueJob(RescueJob &job, const Cand *shadowCands, u32 *c
             ++n;
         }
     }
-    job.nAligned = n; job.bestRank = bestRank; job.bestSlot = best < 0 ? 0 : job.candBase + u32(best); job.lastAligned = last ? 1 : 0;
+    job.nAligned = n; job.bestRank = bestRank; job.bestSlot = best < 0 ? 0 : candBase + u32(best); job.lastAligned = last ? 1 : 0;
     job.nGapped = (best >= 0 && BSW_MISMATCHES_CUTOFF < bestMismatches) ? nClose : 0;   // == planRescueGapped(job, ..., NULL)
 }
 
@@ -682,7 +685,8 @@ ISAAC_HD void summarizeRescueJob(RescueJob &job, const Cand *shadowCands, u32 *c
 ISAAC_HD u32 writeRescueGapped(const RescueJob &job, const Cand *shadowCands, const u32 *shadowCigars, u32 endCyclesMasked, GappedJob *out)
 {
     u32 n = 0; i32 prev = -1; i64 prevPosition = 0; u32 prevMismatches = 0;
-    for (u32 c0 = 0; c0 < job.nCands; c0 += SUMMARY_BATCH)
+    const u32 nCands = job.nCands, candBase = job.candBase;            // (once: the stores to `out` may alias the record)
+    for (u32 c0 = 0; c0 < nCands; c0 += SUMMARY_BATCH)
     {
         i64 positions[SUMMARY_BATCH]; u32 mismatchCounts[SUMMARY_BATCH]; bool aligned[SUMMARY_BATCH];
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -690,7 +694,7 @@ ISAAC_HD u32 writeRescueGapped(const RescueJob &job, const Cand *shadowCands, co
 #endif
         for (u32 k = 0; k < SUMMARY_BATCH; ++k)
         {
-            const Cand &f = shadowCands[job.candBase + imin(c0 + k, job.nCands - 1)];
+            const Cand &f = shadowCands[candBase + imin(c0 + k, nCands - 1)];
             positions[k] = f.position; mismatchCounts[k] = f.mismatchCount; aligned[k] = candAligned(f);
         }
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -699,13 +703,13 @@ ISAAC_HD u32 writeRescueGapped(const RescueJob &job, const Cand *shadowCands, co
         for (u32 k = 0; k < SUMMARY_BATCH; ++k)
         {
             const u32 c = c0 + k;
-            if (c >= job.nCands) break;
+            if (c >= nCands) break;
             if (!aligned[k]) continue;
             if (prev >= 0 && positions[k] - prevPosition < i64(BSW_DISTANCE_CUTOFF) && BSW_MISMATCHES_CUTOFF < prevMismatches)
             {
-                GappedJob &g = out[n]; g.in = shadowCands[job.candBase + u32(prev)]; g.cluster = job.cluster; g.endCyclesMasked = endCyclesMasked; g.tag = job.candBase + u32(prev); g.pad = 0;
+                GappedJob &g = out[n]; g.in = shadowCands[candBase + u32(prev)]; g.cluster = job.cluster; g.endCyclesMasked = endCyclesMasked; g.tag = candBase + u32(prev); g.pad = 0;
                 g.in.cigarOffset = 0;
-                g.in.position = candUnclippedPosition(g.in, shadowCigars + u64(job.candBase + u32(prev)) * 3); g.in.cigarLength = 0;
+                g.in.position = candUnclippedPosition(g.in, shadowCigars + u64(candBase + u32(prev)) * 3); g.in.cigarLength = 0;
                 ++n;
             }
             prev = i32(c); prevPosition = positions[k]; prevMismatches = mismatchCounts[k];
