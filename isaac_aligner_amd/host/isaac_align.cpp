@@ -94,7 +94,8 @@ struct Reference
     std::unique_ptr<char[]> bases; uint64_t totalBases = 0; std::vector<uint64_t> offsets;
 };
 
-Reference loadReference(const std::string &xmlPath)
+// the contigs of sorted-reference.xml in karyotype order, their places in the concatenated genome; no bases yet
+Reference parseReference(const std::string &xmlPath)
 {
     std::ifstream is(xmlPath.c_str(), std::ios::binary);
     if (!is) throw std::runtime_error("Failed to open sorted reference file " + xmlPath);
@@ -114,6 +115,11 @@ Reference loadReference(const std::string &xmlPath)
     ref.offsets.push_back(0);
     for (const isaac_reference_contig &c : ref.contigs) ref.offsets.push_back(ref.offsets.back() + c.total_bases);
     ref.totalBases = ref.offsets.back();
+    return ref;
+}
+Reference loadReference(const std::string &xmlPath)
+{
+    Reference ref = parseReference(xmlPath);
     ref.bases.reset(new char[ref.totalBases ? ref.totalBases : 1]);
     unsigned char translate[256];
     for (unsigned b = 0; b < 256; ++b)
@@ -530,6 +536,27 @@ int run(const AlignOptions &o)
         estimatedClusters += uint64_t(st.st_size) * (L.flowcell->compressed ? 4 : 1) / recordBytes;
     }
     const uint64_t binRecords = o.binRecords ? o.binRecords : 4000000;
+    if (std::getenv("ISAAC_ALIGN_PLAN_ONLY"))
+    {   // What the run would do, decided before a device is touched -- the threads that read lanes, the loads, whether the selection is streamed, the bins -- as one
+        // line for the tests of the planning (no HIP device is needed for it: sorted-reference.xml and the sizes of the FASTQ files are all it reads).
+        const Reference ref = parseReference(o.referenceGenome);
+        std::vector<uint64_t> lengths;
+        for (const isaac_reference_contig &c : ref.contigs) lengths.push_back(c.total_bases);
+        const double perBase = double(std::max<uint64_t>(estimatedClusters, 1)) * nReads / double(std::max<uint64_t>(1, ref.totalBases));
+        const BinPlan plan = planBins(lengths, uint64_t(std::min(1e15, double(binRecords) / std::max(perBase, 1e-9))));
+        const uint32_t tileMax = isaac_gpu_fastq_tile_clusters_max(o.clustersAtATime, params.n_seeds);
+        const uint32_t load = o.clustersAtATime ? o.clustersAtATime : 4 * tileMax;
+        const uint64_t loads = (estimatedClusters + load - 1) / std::max<uint64_t>(1, load);
+        const char *streamSwitch = std::getenv("ISAAC_ALIGN_STREAM_SELECTION");
+        const size_t nWorkers = o.deviceList().size();
+        std::string ranges = "[";
+        for (size_t b = 0; b < plan.ranges.size(); ++b) ranges += (b ? ", [" : "[") + std::to_string(plan.ranges[b].first) + ", " + std::to_string(plan.ranges[b].second) + "]";
+        std::cout << "{\"estimated_clusters\": " << estimatedClusters << ", \"lanes\": " << lanes.size() << ", \"readers\": " << nReaders << ", \"workers\": " << nWorkers
+                  << ", \"loader_contexts\": " << nReaders * nReads << ", \"tile_clusters_max\": " << tileMax << ", \"load_clusters\": " << load << ", \"expected_loads\": " << loads
+                  << ", \"selection_streamed\": " << ((streamSwitch ? 0 != std::atoi(streamSwitch) : loads >= 8 * nWorkers) ? 1 : 0)
+                  << ", \"bins\": " << plan.ranges.size() + 1 << ", \"bin_cuts\": " << plan.cuts.size() << ", \"bin_ranges\": " << ranges << "]}" << std::endl;
+        return 0;
+    }
     // the page-locked buffers the build stage fills are made while the reference is read and its table copied (locking pages is slow -- a gigabyte takes a tenth of a second and more -- and holds other calls of the runtime up: beside the base calls' loading it cost that stage as much as it saved the later one)
     PinnedPool pinned;
     std::thread pinnedWarm([&]()

@@ -106,6 +106,57 @@ def test_command_line_errors(tmp_path):
     assert r.returncode == 1 and ("isaac_gpu_create" in r.stderr or "x.xml" in r.stderr)
 
 
+def test_run_planning_without_a_device(tmp_path):
+    """ISAAC_ALIGN_PLAN_ONLY: what isaac-align decides before it touches a device -- the threads that read lanes and their loader contexts, the loads, whether the
+    selection is streamed beside the loading, the bins (planBins) -- from sorted-reference.xml and the sizes of the FASTQ files alone"""
+    import json
+    from isaac_aligner_amd import sorted_reference as sr
+    lengths = [50_000_000, 3_000, 700_000, 20_000_000, 5_000]                  # karyotype order below is not the file's order
+    karyotype = [3, 0, 4, 1, 2]
+    contigs, position = [], 0
+    for i, length in enumerate(lengths):
+        c = sr.Contig()
+        c.genomic_position, c.index, c.karyotype_index, c.name, c.file = position, i, karyotype[i], b"c%d" % i, b"genome.fa"
+        c.offset, c.size, c.total_bases, c.acgt_bases = position, length, length, length
+        position += length
+        contigs.append(c)
+    xml = tmp_path / "sorted-reference.xml"
+    xml.write_text(sr.format(contigs, []))
+    calls = tmp_path / "calls"
+    calls.mkdir()
+    record = "@M1:7:FCPLAN:%d:1101:00000001\n" + "A" * 100 + "\n+\n" + "I" * 100 + "\n"
+    lanes_clusters = {1: 30_000, 2: 90_000, 4: 60_000}
+    for lane, n in lanes_clusters.items():
+        one = (record % lane).encode()
+        for read in (1, 2):
+            with open(calls / ("lane%d_read%d.fastq" % (lane, read)), "wb") as f:
+                f.write(one * 1000)
+                f.truncate(len(one) * n)                                        # a sparse file of the size n such records have: only sizes are read here
+    base = ["-r", xml, "-b", calls, "--base-calls-format", "fastq", "-o", tmp_path / "Aligned"]
+    ordered = [lengths[i] for i in sorted(range(len(lengths)), key=lambda i: karyotype[i])]
+    total = sum(lanes_clusters.values())
+
+    def plan(*more, **env):
+        r = run_host(*(base + list(more)), env=dict({"ISAAC_ALIGN_PLAN_ONLY": "1"}, **env))
+        assert r.returncode == 0, r.stderr
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    p = plan("--clusters-at-a-time", "10000", "--bin-records", "40000")
+    assert p["estimated_clusters"] == total and p["lanes"] == 3 and p["workers"] == 1
+    assert p["readers"] == 2 and p["loader_contexts"] == 4                     # one reader more than there are workers; a context per reader and read
+    assert p["load_clusters"] == 10000 and p["expected_loads"] == 18 and p["selection_streamed"] == 1        # eight loads per worker and more: streamed
+    ranges, cuts = plan_bins(ordered, 40000 / (total * 2 / sum(ordered)))
+    assert p["bins"] == len(ranges) + 1 and p["bin_cuts"] == len(cuts) > 0 and [tuple(r) for r in p["bin_ranges"]] == ranges
+    # every bin begins where the one before it ends, a contig's first bin at its first base, and no bin spans two long contigs
+    assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:])) and ranges[0][0] == bam.reference_position(0, 0) and ranges[-1][1] == bam.reference_position(len(ordered), 0)
+    p = plan("--clusters-at-a-time", "10000", "--devices", "0,0,0")
+    assert p["workers"] == 3 and p["readers"] == 3 and p["loader_contexts"] == 6 and p["selection_streamed"] == 0        # 18 loads on three workers: not a long run
+    assert p["bins"] == 2 and p["bin_cuts"] == 0                               # 360 000 records fit one bin of 4 M: every contig in it, and the unaligned bin
+    assert plan("--clusters-at-a-time", "10000", "--devices", "0,0,0", ISAAC_ALIGN_STREAM_SELECTION="1")["selection_streamed"] == 1
+    p = plan()
+    assert p["load_clusters"] == 4 * p["tile_clusters_max"] and p["expected_loads"] == 1 and p["selection_streamed"] == 0
+
+
 def test_sort_reference_command_line(tmp_path):
     """bash/bin/isaac-sort-reference's argument handling (exit codes 1 for help / version, 2 for errors) and the contig table it reads;
     without a GPU it stops at the device with a message"""
