@@ -473,8 +473,9 @@ __global__ __launch_bounds__(64 * RW_WAVES) void k_rescue_windows(DevParams P, D
     rescueWindowsProblem(P, R, bcl, clusterBase, rb, blockIdx.x * RW_WAVES + wave, lane, tables[wave], ldsBitmaps[wave], presentMaps[wave]);
 }
 
+// (six waves per SIMD: with its candidate in registers the kernel took 87 registers, five waves; held to 80 it has 79 and no scratch: 1.45 -> 1.39 ms, profiles/exp_r5_rescue_align_waves.log)
 #ifndef ISAAC_WAVES_RESCUE_ALIGN
-#define ISAAC_WAVES_RESCUE_ALIGN 0
+#define ISAAC_WAVES_RESCUE_ALIGN 6
 #endif
 #if ISAAC_WAVES_RESCUE_ALIGN
 __attribute__((amdgpu_waves_per_eu(ISAAC_WAVES_RESCUE_ALIGN, ISAAC_WAVES_RESCUE_ALIGN)))
