@@ -174,6 +174,12 @@ template <u32 W> __device__ inline u32 clusterSumsWave(const DevParams &P, const
 }
 
 // lists of up to 16 entries (most clusters): a quarter of a wavefront per cluster.  What does not fit goes to k_cluster_sums.
+#ifndef ISAAC_WAVES_SUMS16
+#define ISAAC_WAVES_SUMS16 0
+#endif
+#if ISAAC_WAVES_SUMS16
+__attribute__((amdgpu_waves_per_eu(ISAAC_WAVES_SUMS16, ISAAC_WAVES_SUMS16)))
+#endif
 __global__ __launch_bounds__(16 * SUMS16_GROUPS) void k_cluster_sums16(DevParams P, ClusterPools pools, u32 nChunk, RescueBuffers rb, GappedBuffers gb, SumsBuffers sb, Counters *counters, const u32 *order)
 {
     __shared__ __align__(16) u8 keyBytes[SUMS16_GROUPS][SUMS_QUARTER_CAP * 42 + 16];
