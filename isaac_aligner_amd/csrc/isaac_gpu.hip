@@ -78,7 +78,7 @@ struct isaac_gpu_ctx
     DevBuf<TableEntry> entries; u64 nKmers = 0; DevBuf<u32> karyotype; bool hasKaryotype = false;
     const TableEntry *entriesBorrowed = nullptr;   // isaac_gpu_set_index_dev: a table owned by the caller (another context, an RCCL receive buffer)
     const TableEntry *tableEntries() const { return entriesBorrowed ? entriesBorrowed : entries.p; }
-    DevBuf<u32> flaggedList; std::vector<char> hostBases; const char *hostBasesGiven = nullptr; std::vector<isaac_host_resolve::Resolver *> resolvers; std::vector<u8> resolverLoaded;      // isaac_gpu_resolve_flagged
+    DevBuf<u32> flaggedList, resolveChanged; DevBuf<u8> resolveStaging, resolveBack; DevBuf<u64> resolveRanges; DevBuf<Match> resolveMatches; std::vector<char> hostBases; const char *hostBasesGiven = nullptr; std::vector<isaac_host_resolve::Resolver *> resolvers; std::vector<u8> resolverLoaded;      // isaac_gpu_resolve_flagged
     DevBuf<u32> prefixTable; u32 prefixBits = 0; std::vector<u64> maskOffsets;   // entries before each mask of the table (load_index / build_index)
     DevBuf<u32> packedBases, notBase;   // 2-bit copy of the contigs + not-ACGT bitmap (k_rescue_windows reads these)
     const u32 *packedBorrowed = nullptr, *notBaseBorrowed = nullptr, *prefixBorrowed = nullptr;      // isaac_gpu_share_reference on one device: the owner's
@@ -761,8 +761,18 @@ __global__ void k_pack_reference(const char *bases, u64 totalBases, u32 *packed,
     packed[2 * w] = lo; packed[2 * w + 1] = hi; notBase[w] = bad;
 }
 
+// what isaac_gpu_resolve_flagged keeps between calls is made from the parameters, the contigs and the loaded-contig flags: whoever changes one of them drops it
+static void dropResolvers(isaac_gpu_ctx *c, bool basesToo)
+{
+    for (isaac_host_resolve::Resolver *r : c->resolvers) isaac_host_resolve::destroy(r);
+    c->resolvers.clear(); c->resolverLoaded.clear();
+    if (basesToo) { c->hostBases.clear(); c->hostBases.shrink_to_fit(); }
+}
+
 static void setContigs(isaac_gpu_ctx *c, const uint64_t *offsets, uint32_t n, bool pack = true)
 {
+    dropResolvers(c, true);
+    c->hostBasesGiven = nullptr;                  // (the caller's copy was of the contigs before these)
     c->nContigs = n; c->hContigOffset.assign(offsets, offsets + n + 1);
     c->contigOffset.reserve(n + 1);
     HIP_CHECK(hipMemcpy(c->contigOffset.p, offsets, (n + 1) * sizeof(u64), hipMemcpyHostToDevice));
@@ -1229,6 +1239,7 @@ int isaac_gpu_set_params(isaac_gpu_ctx *c, const isaac_params *params)
     HIP_CHECK(hipSetDevice(c->device));
     HIP_CHECK(hipStreamSynchronize(c->stream));
     c->params = *params; c->P = P;
+    dropResolvers(c, false);                      // they hold the parameters they were made with
     return 0;
     ISAAC_CATCH
 }
@@ -1672,22 +1683,58 @@ Resolver *create(const isaac_params &params, const char *bases, const u64 *conti
 void destroy(Resolver *r);
 void selectCluster(Resolver *r, const isaac_tls &tls, const u8 *clusterBcl, u32 cluster, u32 tile, const Match *matches, u32 nMatches, FragmentRecord *records, u32 *cigars);
 }
-// the clusters of a tile with RECORD_MAPQ_NEAR_INTEGER on their first record, in any order
-__global__ void k_flagged_clusters(const FragmentRecord *records, u32 nClusters, u32 nReads, u32 *list, u32 capacity, u32 *count)
+// the clusters of a tile with RECORD_MAPQ_NEAR_INTEGER on their first record, in any order (the list has room for every cluster of the tile)
+__global__ void k_flagged_clusters(const FragmentRecord *records, u32 nClusters, u32 nReads, u32 *list, u32 *count)
 {
     const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nClusters || !(records[u64(c) * nReads].reserved & RECORD_MAPQ_NEAR_INTEGER)) return;
-    const u32 at = atomicAdd(count, 1u);
-    if (at < capacity) list[at] = c;
+    list[atomicAdd(count, 1u)] = c;
+}
+// What the host wants of the listed clusters, gathered into one staging buffer so that it leaves in one copy: per cluster `stride` bytes --
+// the cluster's match range (16), its BCL bytes (padded to 16), its records, its CIGAR slots.  One workgroup per cluster.
+__global__ void k_gather_flagged(const u32 *list, u32 n, const u8 *bcl, u32 clusterLength, const u64 *offsets, const FragmentRecord *records, const u32 *cigar, u32 nReads, u8 *staging, u32 stride)
+{
+    const u32 k = blockIdx.x;
+    if (k >= n) return;
+    const u32 c = list[k];
+    u8 *to = staging + u64(k) * stride;
+    if (threadIdx.x < 2) reinterpret_cast<u64 *>(to)[threadIdx.x] = offsets[c + threadIdx.x];
+    to += 16;
+    for (u32 i = threadIdx.x; i < clusterLength; i += blockDim.x) to[i] = bcl[u64(c) * clusterLength + i];
+    to += (clusterLength + 15) & ~15u;
+    const u32 recordWords = nReads * u32(sizeof(FragmentRecord) / 4), cigarWords = nReads * OUT_CIGAR_CAP;
+    const u32 *r = reinterpret_cast<const u32 *>(records + u64(c) * nReads), *g = cigar + u64(c) * cigarWords;
+    for (u32 i = threadIdx.x; i < recordWords; i += blockDim.x) reinterpret_cast<u32 *>(to)[i] = r[i];
+    to += recordWords * 4;
+    for (u32 i = threadIdx.x; i < cigarWords; i += blockDim.x) reinterpret_cast<u32 *>(to)[i] = g[i];
+}
+// the listed clusters' seed matches back to back: ranges[2k], ranges[2k + 1] = where cluster k's lie in the tile's array, starts[k] = where they go
+__global__ void k_gather_flagged_matches(const u64 *ranges, const u64 *starts, u32 n, const Match *matches, Match *out)
+{
+    const u32 k = blockIdx.x;
+    if (k >= n) return;
+    const u64 first = ranges[2 * k], count = ranges[2 * k + 1] - first;
+    for (u64 i = threadIdx.x; i < count; i += blockDim.x) out[starts[k] + i] = matches[first + i];
+}
+// ... and the way back for the clusters the host changed: records and CIGAR slots from `staging` (stride bytes per cluster: records, then CIGAR slots)
+__global__ void k_scatter_resolved(const u32 *list, u32 n, const u8 *staging, u32 stride, FragmentRecord *records, u32 *cigar, u32 nReads)
+{
+    const u32 k = blockIdx.x;
+    if (k >= n) return;
+    const u32 c = list[k];
+    const u32 recordWords = nReads * u32(sizeof(FragmentRecord) / 4), cigarWords = nReads * OUT_CIGAR_CAP;
+    const u32 *from = reinterpret_cast<const u32 *>(staging + u64(k) * stride);
+    u32 *r = reinterpret_cast<u32 *>(records + u64(c) * nReads), *g = cigar + u64(c) * cigarWords;
+    for (u32 i = threadIdx.x; i < recordWords; i += blockDim.x) r[i] = from[i];
+    for (u32 i = threadIdx.x; i < cigarWords; i += blockDim.x) g[i] = from[recordWords + i];
 }
 // the caller's own copy of the contigs (as given to isaac_gpu_load_contigs), kept by the caller for as long as the context lives: isaac_gpu_resolve_flagged then
 // has nothing to fetch
 extern "C" int isaac_gpu_set_host_contigs(isaac_gpu_ctx *c, const char *basesHost)
 {
     ISAAC_TRY
+    dropResolvers(c, true);
     c->hostBasesGiven = basesHost;
-    for (isaac_host_resolve::Resolver *r : c->resolvers) isaac_host_resolve::destroy(r);
-    c->resolvers.clear(); c->resolverLoaded.clear();
     return 0;
     ISAAC_CATCH
 }
@@ -1702,21 +1749,21 @@ extern "C" int isaac_gpu_resolve_flagged(isaac_gpu_ctx *c, const uint8_t *bcl, u
     if (!bcl || !matches || !offsets || !tls || !fragments || !cigar) return fail(ISAAC_GPU_EINVAL, "bcl_dev, matches_dev, cluster_offsets_dev, tls, fragments_dev and cigar_dev are required");
     hipStream_t st = c->stream;
     const u32 nReads = c->P.nReads, clusterLength = c->P.clusterLength;
-    const u32 capacity = 1u << 16;
-    c->flaggedList.reserve(capacity + 1);
-    HIP_CHECK(hipMemsetAsync(c->flaggedList.p + capacity, 0, 4, st));
+    c->flaggedList.reserve(size_t(nClusters) + 1);
+    u32 *listCount = c->flaggedList.p + nClusters;
+    HIP_CHECK(hipMemsetAsync(listCount, 0, 4, st));
     FragmentRecord *records = reinterpret_cast<FragmentRecord *>(fragments);
-    k_flagged_clusters<<<gridFor(nClusters, 256), 256, 0, st>>>(records, nClusters, nReads, c->flaggedList.p, capacity, c->flaggedList.p + capacity);
+    k_flagged_clusters<<<gridFor(nClusters, 256), 256, 0, st>>>(records, nClusters, nReads, c->flaggedList.p, listCount);
     HIP_CHECK(hipGetLastError());
-    u32 n = 0;
-    HIP_CHECK(hipMemcpyAsync(&n, c->flaggedList.p + capacity, 4, hipMemcpyDeviceToHost, st));
+    u32 nAll = 0;
+    HIP_CHECK(hipMemcpyAsync(&nAll, listCount, 4, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    if (nFlaggedOut) *nFlaggedOut = n;
-    if (!n) return 0;
-    if (n > capacity) return fail(ISAAC_GPU_ECAPACITY, "more than 65536 flagged clusters in one tile");
-    std::vector<u32> list(n);
-    HIP_CHECK(hipMemcpy(list.data(), c->flaggedList.p, n * 4, hipMemcpyDeviceToHost));
+    if (nFlaggedOut) *nFlaggedOut = nAll;
+    if (!nAll) return 0;
+    std::vector<u32> list(nAll);
+    HIP_CHECK(hipMemcpy(list.data(), c->flaggedList.p, size_t(nAll) * 4, hipMemcpyDeviceToHost));
     std::sort(list.begin(), list.end());
+    HIP_CHECK(hipMemcpy(c->flaggedList.p, list.data(), size_t(nAll) * 4, hipMemcpyHostToDevice));
     // the host's copy of the contigs: the caller's (isaac_gpu_set_host_contigs), or fetched once, when the first flagged cluster turns up
     const char *hostBases = c->hostBasesGiven;
     if (!hostBases)
@@ -1730,69 +1777,103 @@ extern "C" int isaac_gpu_resolve_flagged(isaac_gpu_ctx *c, const uint8_t *bcl, u
     }
     if (c->resolverLoaded != c->hContigLoaded)
     {   // (the rest-of-genome correction depends on which contigs count as loaded)
-        for (isaac_host_resolve::Resolver *r : c->resolvers) isaac_host_resolve::destroy(r);
-        c->resolvers.clear();
+        dropResolvers(c, false);
         c->resolverLoaded = c->hContigLoaded;
     }
-    // everything the clusters need, fetched first; then the clusters side by side on host threads (a cluster of a repeat family -- and probability ratios that
-    // are exact powers of ten come from equal placements, i.e. from those -- is milliseconds of serial mate rescue); then what changed goes back
-    struct Item { u32 cluster; std::vector<u8> bcl; std::vector<Match> matches; std::vector<FragmentRecord> was, now; std::vector<u32> wasCigar, nowCigar; bool differs = false; std::string error; };
-    std::vector<Item> items(n);
-    for (u32 k = 0; k < n; ++k)
-    {
-        Item &it = items[k];
-        it.cluster = list[k];
-        u64 range[2];
-        HIP_CHECK(hipMemcpy(range, offsets + it.cluster, 16, hipMemcpyDeviceToHost));
-        const u64 first = range[0], nMatches = range[1] - range[0];
-        it.matches.resize(nMatches + 1);
-        if (nMatches) HIP_CHECK(hipMemcpy(it.matches.data(), reinterpret_cast<const Match *>(matches) + first, nMatches * sizeof(Match), hipMemcpyDeviceToHost));
-        it.matches.resize(nMatches);
-        it.bcl.resize(clusterLength); it.was.resize(nReads); it.now.resize(nReads); it.wasCigar.resize(size_t(nReads) * OUT_CIGAR_CAP); it.nowCigar.assign(size_t(nReads) * OUT_CIGAR_CAP, 0u);
-        HIP_CHECK(hipMemcpy(it.bcl.data(), bcl + u64(it.cluster) * clusterLength, clusterLength, hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(it.was.data(), records + u64(it.cluster) * nReads, nReads * sizeof(FragmentRecord), hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(it.wasCigar.data(), cigar + u64(it.cluster) * nReads * OUT_CIGAR_CAP, it.wasCigar.size() * 4, hipMemcpyDeviceToHost));
-    }
-    const u32 nThreads = std::min<u32>(n, std::min<u32>(16, std::max(1u, std::thread::hardware_concurrency())));
+    // In batches (a tile rich in ties -- equal placements are what makes probability ratios exact powers of ten -- may flag many): everything the batch's clusters
+    // need is gathered on the device and fetched in two copies; then the clusters side by side on host threads (a cluster of a repeat family is milliseconds of
+    // serial mate rescue); then what changed goes back in one copy and one kernel.
+    const u32 batchMax = 1u << 16;
+    const u32 bclBytes = (clusterLength + 15) & ~15u, recordBytes = nReads * u32(sizeof(FragmentRecord)), cigarBytes = nReads * OUT_CIGAR_CAP * 4;
+    const u32 stride = 16 + bclBytes + recordBytes + cigarBytes, backStride = recordBytes + cigarBytes;
+    DevBuf<u8> &staging = c->resolveStaging, &back = c->resolveBack; DevBuf<u64> &ranges = c->resolveRanges; DevBuf<Match> &gathered = c->resolveMatches; DevBuf<u32> &changedList = c->resolveChanged;
+    const u32 nThreads = std::min<u32>(nAll, std::min<u32>(16, std::max(1u, std::thread::hardware_concurrency())));
     while (c->resolvers.size() < nThreads) c->resolvers.push_back(isaac_host_resolve::create(c->params, hostBases, c->hContigOffset.data(), c->resolverLoaded.data(), c->nContigs));
-    std::atomic<u32> next(0);
-    const auto work = [&](u32 t)
-    {
-        for (u32 k = next++; k < n; k = next++)
-        {
-            Item &it = items[k];
-            try
-            {
-                isaac_host_resolve::selectCluster(c->resolvers[t], *tls, it.bcl.data(), it.cluster, tile, it.matches.data(), u32(it.matches.size()), it.now.data(), it.nowCigar.data());
-                for (u32 r = 0; r < nReads; ++r)
-                {
-                    FragmentRecord a = it.was[r], b = it.now[r];
-                    // the diagnostic bits apart (the host form does not flag): everything the record says, and its CIGAR
-                    b.reserved = (b.reserved & 0xffff0000u) | (a.reserved & 0xffffu & ~u32(RECORD_NOT_STORED | RECORD_FRAGMENT_OVERFLOW)) | (b.reserved & (RECORD_NOT_STORED | RECORD_FRAGMENT_OVERFLOW));
-                    it.now[r] = b;
-                    if (std::memcmp(&a, &b, sizeof(a))) it.differs = true;
-                    const u64 base = u64(it.cluster) * nReads * OUT_CIGAR_CAP;
-                    const u32 *ca = it.wasCigar.data() + (a.cigarOffset - base), *cb = it.nowCigar.data() + (b.cigarOffset - base);
-                    if (a.cigarLength == b.cigarLength && std::memcmp(ca, cb, size_t(a.cigarLength) * 4)) it.differs = true;
-                }
-            }
-            catch (const std::exception &e) { it.error = e.what(); }
-        }
-    };
-    {
-        std::vector<std::thread> threads;
-        for (u32 t = 1; t < nThreads; ++t) threads.emplace_back(work, t);
-        work(0);
-        for (std::thread &t : threads) t.join();
-    }
     u64 changed = 0;
-    for (Item &it : items)
+    for (u32 done = 0; done < nAll; done += batchMax)
     {
-        if (!it.error.empty()) return fail(ISAAC_GPU_EHIP, "isaac_gpu_resolve_flagged: " + it.error);
-        if (!it.differs) continue;
-        ++changed;
-        HIP_CHECK(hipMemcpy(records + u64(it.cluster) * nReads, it.now.data(), nReads * sizeof(FragmentRecord), hipMemcpyHostToDevice));
-        HIP_CHECK(hipMemcpy(cigar + u64(it.cluster) * nReads * OUT_CIGAR_CAP, it.nowCigar.data(), it.nowCigar.size() * 4, hipMemcpyHostToDevice));
+        const u32 n = std::min(batchMax, nAll - done);
+        const u32 *batchList = c->flaggedList.p + done;
+        staging.reserve(size_t(n) * stride);
+        k_gather_flagged<<<n, 64, 0, st>>>(batchList, n, bcl, clusterLength, offsets, records, cigar, nReads, staging.p, stride);
+        HIP_CHECK(hipGetLastError());
+        std::vector<u8> host(size_t(n) * stride);
+        HIP_CHECK(hipMemcpyAsync(host.data(), staging.p, host.size(), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        std::vector<u64> hRanges(2 * size_t(n)), starts(size_t(n) + 1, 0);
+        for (u32 k = 0; k < n; ++k)
+        {
+            std::memcpy(&hRanges[2 * k], host.data() + size_t(k) * stride, 16);
+            starts[k + 1] = starts[k] + (hRanges[2 * k + 1] - hRanges[2 * k]);
+        }
+        std::vector<Match> hMatches(starts[n] + 1);
+        if (starts[n])
+        {
+            ranges.reserve(3 * size_t(n)); gathered.reserve(starts[n]);
+            HIP_CHECK(hipMemcpyAsync(ranges.p, hRanges.data(), 2 * size_t(n) * 8, hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(ranges.p + 2 * size_t(n), starts.data(), size_t(n) * 8, hipMemcpyHostToDevice, st));
+            k_gather_flagged_matches<<<n, 64, 0, st>>>(ranges.p, ranges.p + 2 * size_t(n), n, reinterpret_cast<const Match *>(matches), gathered.p);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipMemcpyAsync(hMatches.data(), gathered.p, starts[n] * sizeof(Match), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+        }
+        std::vector<u8> now(size_t(n) * backStride, 0);
+        std::vector<u8> differs(n, 0); std::vector<std::string> errors(nThreads);
+        std::atomic<u32> next(0);
+        const auto work = [&](u32 t)
+        {
+            for (u32 k = next++; k < n; k = next++)
+            {
+                const u32 cluster = list[done + k];
+                const u8 *item = host.data() + size_t(k) * stride;
+                const u8 *itemBcl = item + 16;
+                const FragmentRecord *was = reinterpret_cast<const FragmentRecord *>(itemBcl + bclBytes);
+                const u32 *wasCigar = reinterpret_cast<const u32 *>(itemBcl + bclBytes + recordBytes);
+                FragmentRecord *nowRecords = reinterpret_cast<FragmentRecord *>(now.data() + size_t(k) * backStride);
+                u32 *nowCigar = reinterpret_cast<u32 *>(now.data() + size_t(k) * backStride + recordBytes);
+                try
+                {
+                    isaac_host_resolve::selectCluster(c->resolvers[t], *tls, itemBcl, cluster, tile, hMatches.data() + starts[k], u32(starts[k + 1] - starts[k]), nowRecords, nowCigar);
+                    for (u32 r = 0; r < nReads; ++r)
+                    {
+                        FragmentRecord a = was[r], b = nowRecords[r];
+                        // the diagnostic bits apart (the host form does not flag): everything the record says, and its CIGAR
+                        b.reserved = (b.reserved & 0xffff0000u) | (a.reserved & 0xffffu & ~u32(RECORD_NOT_STORED | RECORD_FRAGMENT_OVERFLOW)) | (b.reserved & (RECORD_NOT_STORED | RECORD_FRAGMENT_OVERFLOW));
+                        nowRecords[r] = b;
+                        if (std::memcmp(&a, &b, sizeof(a))) differs[k] = 1;
+                        const u64 base = u64(cluster) * nReads * OUT_CIGAR_CAP;
+                        const u32 *ca = wasCigar + (a.cigarOffset - base), *cb = nowCigar + (b.cigarOffset - base);
+                        if (a.cigarLength == b.cigarLength && std::memcmp(ca, cb, size_t(a.cigarLength) * 4)) differs[k] = 1;
+                    }
+                }
+                catch (const std::exception &e) { errors[t] = e.what(); }
+            }
+        };
+        {
+            std::vector<std::thread> threads;
+            for (u32 t = 1; t < nThreads; ++t) threads.emplace_back(work, t);
+            work(0);
+            for (std::thread &t : threads) t.join();
+        }
+        for (const std::string &e : errors) if (!e.empty()) return fail(ISAAC_GPU_EHIP, "isaac_gpu_resolve_flagged: " + e);
+        std::vector<u32> changedClusters; std::vector<u8> changedData;
+        for (u32 k = 0; k < n; ++k)
+            if (differs[k])
+            {
+                changedClusters.push_back(list[done + k]);
+                changedData.insert(changedData.end(), now.begin() + size_t(k) * backStride, now.begin() + size_t(k + 1) * backStride);
+            }
+        if (!changedClusters.empty())
+        {
+            const u32 m = u32(changedClusters.size());
+            changedList.reserve(m); back.reserve(changedData.size());
+            HIP_CHECK(hipMemcpyAsync(changedList.p, changedClusters.data(), size_t(m) * 4, hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(back.p, changedData.data(), changedData.size(), hipMemcpyHostToDevice, st));
+            k_scatter_resolved<<<m, 64, 0, st>>>(changedList.p, m, back.p, backStride, records, cigar, nReads);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipStreamSynchronize(st));
+            changed += m;
+        }
     }
     if (nChangedOut) *nChangedOut = changed;
     return 0;

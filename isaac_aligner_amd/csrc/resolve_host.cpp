@@ -20,6 +20,7 @@ namespace isaac_host_resolve
 struct Resolver
 {
     DevParams P; DevReference R;
+    std::vector<u64> contigOffset; std::vector<u8> contigLoaded;      // copies: the context's vectors may be reassigned while this lives
     std::vector<double> logMatch, logMismatch;
     RogCorrection rog; double lmq40;
     std::vector<u8> arena; TemplateWork work;
@@ -33,6 +34,8 @@ Resolver *create(const isaac_params &params, const char *bases, const u64 *conti
     r->P = makeDevParams(params);
     r->logMatch.resize(100); r->logMismatch.resize(100); makeQualityTables(r->logMatch.data(), r->logMismatch.data());
     std::memset(&r->R, 0, sizeof(r->R));
+    r->contigOffset.assign(contigOffset, contigOffset + nContigs + 1); r->contigLoaded.assign(contigLoaded, contigLoaded + nContigs);
+    contigOffset = r->contigOffset.data(); contigLoaded = r->contigLoaded.data();
     r->R.bases = bases; r->R.totalBases = contigOffset[nContigs]; r->R.contigOffset = contigOffset; r->R.contigLoaded = contigLoaded; r->R.nContigs = nContigs;
     r->R.logMatch = r->logMatch.data(); r->R.logMismatch = r->logMismatch.data(); r->R.logStride = 1;
     r->rog = makeRogCorrection(r->P, contigOffset, contigLoaded, nContigs);

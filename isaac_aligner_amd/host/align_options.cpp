@@ -57,7 +57,7 @@ std::string AlignOptions::usage()
         "  --device arg (=0)                    HIP device\n"
         "  --devices arg                        HIP devices, comma separated: one worker per entry; the tiles and the bins of the\n"
         "                                       run are dealt out to them (an entry may repeat: two workers on one device)\n"
-        "  --bin-records arg (=0)               records a bin of the BAM stage is sized for (0: 8000000): contigs are grouped into or cut\n"
+        "  --bin-records arg (=0)               records a bin of the BAM stage is sized for (0: 4000000): contigs are grouped into or cut\n"
         "                                       into bins of about that many, each sorted, filtered and realigned by itself\n"
         "  --use-bases-mask arg (=default)      y*n per read by default (the last cycle is not used); y<N>n<M> and y* forms\n"
         "  --seeds arg (=auto)                  auto | all | offsets 0:32:64[,...]\n"
@@ -88,7 +88,25 @@ std::string AlignOptions::usage()
         "  --description arg                    @PG DS\n"
         "  --variable-read-length arg           reads shorter than the first one are padded with N\n"
         "  --lane-number-max arg (=8)\n"
-        "  -h [ --help ], -v [ --version ]\n";
+        "  -h [ --help ], -v [ --version ]\n"
+        "\n"
+        "Environment switches (all off by default; none changes a record of the output):\n"
+        "  ISAAC_ALIGN_STREAM_SELECTION=1|0     selections beside the loading (1) or after it (0), whatever the run's length\n"
+        "  ISAAC_ALIGN_PLAN_ONLY=1              print the run's plan (reader threads, loads, bins) and stop before a device is touched\n"
+        "  ISAAC_ALIGN_DUMP_TILES=<dir>:<lane>.<tile>,...   write the named tiles out as they were selected (for parity checks)\n"
+        "  ISAAC_ALIGN_ORDERLY_EXIT=1           run every destructor at the end instead of leaving once the files are complete\n"
+        "  ISAAC_ALIGN_NO_PREALLOCATION=1       no fallocate ahead of the BAM writes\n"
+        "  ISAAC_ALIGN_READ_THREADS=<n>         threads that read lanes side by side (default: devices + 1, at most the lanes)\n"
+        " the routes of a large run, forced on a small one (tests):\n"
+        "  ISAAC_ALIGN_HOST_LOADS=1             base calls through host memory instead of staying on the device\n"
+        "  ISAAC_ALIGN_HOST_BINS=1              bin parts in host memory; ISAAC_ALIGN_SPILL_BINS=1: in files under -t\n"
+        "  ISAAC_ALIGN_STRANGERS=1              the workers of one device treat each other as other devices (with ISAAC_GPU_SHARE_BY_COPY=1)\n"
+        " measurements:\n"
+        "  ISAAC_ALIGN_BUILD_AHEAD=<n>          bins encoded ahead of the file writer\n"
+        "  ISAAC_ALIGN_WARM_BUFFERS=1           touch the page-locked buffers before the clock starts\n"
+        "  ISAAC_ALIGN_SYNC_DOWNLOADS=1         downloads on the work stream instead of the copy stream\n"
+        "  ISAAC_ALIGN_TIMING_NO_RESOLUTION=1   skip isaac_gpu_resolve_flagged (timing only: MAPQs near an integer stay the device's)\n"
+        "  ISAAC_ALIGN_MAPPED_WRITES=1          BAM written through a mapping instead of pwrite\n";
 }
 
 AlignOptions AlignOptions::parse(int argc, char **argv)

@@ -15,6 +15,9 @@ namespace isaac_host
 // common::InvalidOptionException: the program ends with the message and exit code 1 (include/common/Program.hh:60-92)
 struct InvalidOption : std::runtime_error { explicit InvalidOption(const std::string &what) : std::runtime_error(what) {} };
 
+// --bin-records 0: what a bin of the BAM stage is sized for when nothing is said (usage text, plan and run agree on this one number)
+constexpr unsigned long long DEFAULT_BIN_RECORDS = 4000000ULL;
+
 struct AlignOptions
 {
     enum Action { RUN, HELP, VERSION };
@@ -32,7 +35,7 @@ struct AlignOptions
     std::vector<std::string> bamHeaderTags;
     unsigned seedLength = 32, firstPassSeeds = 1, jobs = 0, repeatThreshold = 10, laneNumberMax = 8, clustersAtATime = 0, mapqThreshold = 0, baseQualityCutoff = 25,
              semialignedGapLimit = 100, gappedMismatches = 5, realignedGapsPerFragment = 1;
-    unsigned binRecords = 0;                                // --bin-records: records a bin of the BAM stage is sized for (0: 8 million); this host's stand-in for the reference's bin size from --memory-limit
+    unsigned binRecords = 0;                                // --bin-records: records a bin of the BAM stage is sized for (0: DEFAULT_BIN_RECORDS = 4 million); this host's stand-in for the reference's bin size from --memory-limit
     int shadowScanRange = -1, bamGzipLevel = 1, device = 0;
     bool ignoreNeighbors = false, perTileTls = false, scatterRepeats = false, clipSemialigned = true, clipOverlapping = true, realignVigorously = false, realignDodgy = false,
          keepDuplicates = true, markDuplicates = true, pessimisticMapQ = false, variableReadLength = false, variableFastqReadLength = false, allowEmptyFlowcells = false;

@@ -20,6 +20,10 @@ bool exists(const std::string &path) { struct stat st; return 0 == ::stat(path.c
 // the first record of a lane file: its header line and the length of its sequence line; false for a file without data
 bool firstRecord(const std::string &path, bool compressed, std::string &header, unsigned &sequenceLength)
 {
+    // The flowcell is looked into before it is read (as the reference does: FastqFlowcell.cpp:145-182 opens every lane for its first header), so a lane has to be
+    // a file that can be opened twice: what is peeked from a pipe or /dev/stdin is lost to the reader proper, and records would go missing without an error.
+    struct stat st;
+    if (0 == ::stat(path.c_str(), &st) && !S_ISREG(st.st_mode)) throw std::runtime_error("Fastq lane is not a regular file (pipes and devices are not supported): " + path);
     FastqFileReader reader(path, compressed);
     std::vector<char> text;
     size_t lineEnds = 0;

@@ -527,15 +527,18 @@ int run(const AlignOptions &o)
         const std::string &path = L.lane->readPath[0];
         struct stat st;
         if (path.empty() || ::stat(path.c_str(), &st)) continue;
-        FastqFileReader peek(path, L.flowcell->compressed);
-        std::vector<char> head(1 << 16);
-        const size_t got = peek.readInto(head.data(), head.size());
         size_t lines = 0, recordBytes = 0;
-        for (size_t i = 0; i < got && lines < 4; ++i) { ++recordBytes; if ('\n' == head[i]) ++lines; }
+        if (S_ISREG(st.st_mode))
+        {   // (only a regular file can be looked into twice: bytes peeked from a pipe are lost to the reader proper)
+            FastqFileReader peek(path, L.flowcell->compressed);
+            std::vector<char> head(1 << 16);
+            const size_t got = peek.readInto(head.data(), head.size());
+            for (size_t i = 0; i < got && lines < 4; ++i) { ++recordBytes; if ('\n' == head[i]) ++lines; }
+        }
         if (lines < 4 || !recordBytes) recordBytes = 2 * size_t(L.flowcell->fileReadLength[0]) + 64;
         estimatedClusters += uint64_t(st.st_size) * (L.flowcell->compressed ? 4 : 1) / recordBytes;
     }
-    const uint64_t binRecords = o.binRecords ? o.binRecords : 4000000;
+    const uint64_t binRecords = o.binRecords ? o.binRecords : DEFAULT_BIN_RECORDS;
     if (std::getenv("ISAAC_ALIGN_PLAN_ONLY"))
     {   // What the run would do, decided before a device is touched -- the threads that read lanes, the loads, whether the selection is streamed, the bins -- as one
         // line for the tests of the planning (no HIP device is needed for it: sorted-reference.xml and the sizes of the FASTQ files are all it reads).

@@ -54,4 +54,30 @@ print("resolve_flagged: %d looked at, %d replaced; differences from the oracle a
 for d in diffs[:3]:
     print(d)
 ok = ok and n_flagged == flagged.sum() and n_changed >= wrong.sum() and not diffs
+
+# Other read lengths against the same resident genome (isaac_gpu_set_params), then the call again: what it keeps between calls -- host-side parameters, tables,
+# the contigs' copy -- has to follow the context (it did not; the host then redid 2x100 clusters with 2x150 offsets and overwrote correct records)
+n2 = n_pairs // 2
+bcl2 = synth.make_read_pairs(g, n2, 100, seed=29, avoid_gaps=True)[0]
+p2 = options.default_params(100, 100)
+al.set_params(p2)
+dev2 = bcl2.cuda()
+m2, o2, hits2 = al.find_matches(dev2, tile=4)
+al.set_loaded_contigs(hits2)
+tls2 = al.determine_tls(dev2, m2, o2, tile=4)
+records2, cigars2 = al.select(dev2, m2, o2, tls2, tile=4)
+host2 = bcl2.numpy()
+om2, ohits2 = ref.find_matches(p2, host2, n2, tile=4)
+otls2 = oracle_lib.Tls()
+for name in ("min", "max", "median", "low_std_dev", "high_std_dev", "stable", "mate_min", "mate_max"):
+    setattr(otls2, name, getattr(tls2, name))
+otls2.best_model[0], otls2.best_model[1] = tls2.best_model[0], tls2.best_model[1]
+orec2, ocig2, _ = ref.select(p2, host2, om2, otls2, ohits2, tile=4, n_threads=8, n_clusters_hint=n2)
+n_flagged2, n_changed2 = al.resolve_flagged(dev2, m2, o2, tls2, records2, cigars2, tile=4)
+rec2, cig2 = al.records_to_numpy(records2, cigars2)
+diffs2 = compare_records(orec2, ocig2, rec2, cig2)
+print("after set_params(2x100): %d looked at, %d replaced; differences from the oracle afterwards: %d" % (n_flagged2, n_changed2, len(diffs2)))
+for d in diffs2[:3]:
+    print(d)
+ok = ok and n_flagged2 > n2 // 100 and n_changed2 > 0 and not diffs2
 sys.exit(0 if ok else 1)

@@ -48,3 +48,31 @@ def test_gpu_bench_rccl_path_gives_the_same_records():
     assert "gather_identical" not in plain and dist["gather_identical"] is True
     assert plain["records_sha1"] == dist["records_sha1"]
     assert plain["n_gpus"] == dist["n_gpus"] == 1 and dist["value"] > 0
+
+
+def _device_count():
+    import torch
+    return torch.cuda.device_count()           # (counts without initialising the GPU runtime)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs: RCCL between two ranks (the one-GPU boxes of the pool run the one-rank form above)")
+def test_gpu_bench_two_ranks_rccl():
+    """BASELINE configuration 3 on the smallest scale it exists at: two ranks, one per GPU, started as the driver starts them
+    (`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`), reads sharded statically, the contig flags all-reduced, the template statistics
+    broadcast, the table broadcast over the link, every step's records gathered to rank 0 over RCCL.  Rank 0's first step is the one-GPU run's first step (same
+    seed): same records, and the gathered copy is the computed one; the whole-job value covers both ranks."""
+    args = ["--steps", "2", "--warmup", "1", "--pairs-per-step", "60000", "--genome-bases", "30000000", "--no-pcie-pass", "--no-bam-pass", "--cpu-sample-pairs", "20000"]
+    plain = run(["--gpus", "1"] + args)
+    assert plain.returncode == 0, plain.stderr[-3000:]
+    plain = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29631",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--broadcast-index"] + args, capture_output=True, text=True, env=e, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    two = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and two["parity_diffs"] == 0 and two["gather_identical"] is True
+    assert two["records_sha1"] == plain["records_sha1"]
+    assert two["value"] > 0 and two["scaling"] == "weak"

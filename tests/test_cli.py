@@ -371,6 +371,10 @@ SCENARIOS = {
     # bins of about 6 000 records: every contig is cut into several bins, each sorted, filtered and realigned by itself (the oracle with the same cuts)
     "cut-bins": dict(compressed=False, lengths=(100, 100), cli=["--bin-records", "6000", "--devices", "0,0"], paired=True, mark=True, keep=True, realign=True, unaligned="back", dodgy=0,
                      pu="%s:%d:none", bin_records=6000),
+    # two devices for real (skipped where the box has one): a worker per device, the contigs and the table copied over the link, tiles and bins dealt between
+    # them, foreign bin parts fetched in the build stage -- the same file as one device writes
+    "two-devices": dict(compressed=False, lengths=(100, 100), cli=["--devices", "0,1"], paired=True, mark=True, keep=True, realign=True, unaligned="back", dodgy=0, pu="%s:%d:none",
+                        needs_devices=2),
     # single-ended lanes, unaligned reads left out
     # ... on a reference made by bin/isaac-sort-reference from the FASTA file
     "single-ended": dict(compressed=True, lengths=(100,), cli=["--keep-unaligned", "discard"], paired=False, mark=True, keep=True, realign=True, unaligned="discard", dodgy=0, pu="%s:%d:none",
@@ -383,6 +387,8 @@ SCENARIOS = {
 def test_gpu_isaac_align_end_to_end(tmp_path, scenario):
     import torch
     sc = SCENARIOS[scenario]
+    if sc.get("needs_devices", 1) > torch.cuda.device_count():
+        pytest.skip("needs %d GPUs" % sc["needs_devices"])
     compressed, lengths = sc["compressed"], sc["lengths"]
     n_reads, cluster_length = len(lengths), sum(lengths)
     o = oracle_lib.load()
