@@ -36,9 +36,15 @@ extern "C" {
 
 #define ISAAC_GPU_MAX_SEEDS 16
 #define ISAAC_GPU_MAX_CIGAR_OPS 40
+#define ISAAC_GPU_MAX_ADAPTERS 8
 
 /* alignment::SeedMetadata (include/alignment/SeedMetadata.hh:43-101): index in the list == seed index of SeedId */
 typedef struct { uint16_t offset, length; uint32_t read_index; } isaac_seed;
+
+/* flowcell::SequencingAdapterMetadata (include/flowcell/SequencingAdapterMetadata.hh:33-73): one adapter of --default-adapters, written in the direction of the
+ * reference (5..126 bases of ACGT, NUL-terminated); reverse: the strand it is expected on ("*ACGT" forms); clip_length: 0 for the unbounded forms ("ACGT*",
+ * "*ACGT": everything from the adapter to the read's end goes), the adapter's length for plain sequences. */
+typedef struct { char sequence[128]; uint32_t reverse; uint32_t clip_length; } isaac_adapter;
 
 /* The subset of options::AlignOptions (lib/options/AlignOptions.cpp:77-160) that parameterises the path, plus the read
  * geometry of flowcell::ReadMetadataList and the seed list of --seeds (alignOptions/SeedDescriptorOption.cpp:90-151). */
@@ -63,6 +69,10 @@ typedef struct
     uint32_t read_length[2];
     uint32_t n_seeds;
     isaac_seed seeds[ISAAC_GPU_MAX_SEEDS];
+    /* --default-adapters of the flowcell (lib/options/AlignOptions.cpp:189-207; 0: nothing is clipped, the default): what
+     * matchSelector::FragmentSequencingAdapterClipper clips by in UngappedAligner, GappedAligner and ShadowAligner (isaac_gpu_parse_adapters fills these) */
+    uint32_t n_adapters;
+    isaac_adapter adapters[ISAAC_GPU_MAX_ADAPTERS];
 } isaac_params;
 
 /* alignment::Match (include/alignment/Match.hh:38-73): SeedId (SeedId.hh:60-127) + ReferencePosition value
@@ -513,6 +523,11 @@ const char *isaac_gpu_params_last_error(void);
 int isaac_gpu_default_params(uint32_t read_length1, uint32_t read_length2, isaac_params *out);
 int isaac_gpu_parse_gap_scoring(const char *gap_scoring, isaac_params *params);
 int isaac_gpu_parse_seeds(const char *descriptor, uint32_t first_pass_seeds, isaac_params *params);
+/* options::parseDefaultAdapters (lib/options/alignOptions/DefaultAdaptersOption.cpp:35-60) with flowcell::SequencingAdapterListGrammar
+ * (include/flowcell/SequencingAdapterListGrammar.hpp:52-104): one --default-adapters entry -- "Standard", "Nextera", "NexteraMp"
+ * (lib/flowcell/SequencingAdapterMetadata.cpp:29-39) or a comma-separated list of ACGT / ACGT* / *ACGT -- into params->adapters.
+ * ISAAC_GPU_EINVAL with "Could not parse the default-adapters ..." as isaac_gpu_last_error() for anything else. */
+int isaac_gpu_parse_adapters(const char *descriptor, isaac_params *params);
 
 int isaac_gpu_get_counters(isaac_gpu_ctx *ctx, isaac_counters *out);
 /* average device time (ms) of the named launch sequence over the launches since the last reset, measured with HIP events on the

@@ -5,10 +5,16 @@ import numpy as np
 
 MAX_SEEDS = 16
 MAX_CIGAR_OPS = 40
+MAX_ADAPTERS = 8
 
 
 class Seed(C.Structure):
     _fields_ = [("offset", C.c_uint16), ("length", C.c_uint16), ("read_index", C.c_uint32)]
+
+
+class Adapter(C.Structure):
+    """isaac_adapter"""
+    _fields_ = [("sequence", C.c_char * 128), ("reverse", C.c_uint32), ("clip_length", C.c_uint32)]
 
 
 class Params(C.Structure):
@@ -18,7 +24,8 @@ class Params(C.Structure):
                 ("ignore_neighbors", C.c_uint32), ("clip_semialigned", C.c_uint32), ("clip_overlapping", C.c_uint32), ("scatter_repeats", C.c_uint32),
                 ("dodgy_alignment_score", C.c_int32), ("mapq_threshold", C.c_uint32), ("keep_unaligned", C.c_uint32), ("mate_drift_range", C.c_int32),
                 ("first_pass_seeds", C.c_uint32), ("seed_length", C.c_uint32),
-                ("n_reads", C.c_uint32), ("read_length", C.c_uint32 * 2), ("n_seeds", C.c_uint32), ("seeds", Seed * MAX_SEEDS)]
+                ("n_reads", C.c_uint32), ("read_length", C.c_uint32 * 2), ("n_seeds", C.c_uint32), ("seeds", Seed * MAX_SEEDS),
+                ("n_adapters", C.c_uint32), ("adapters", Adapter * MAX_ADAPTERS)]
 
 
 class Tls(C.Structure):

@@ -131,6 +131,71 @@ int isaac_gpu_parse_seeds(const char *descriptor, uint32_t firstPassSeeds, isaac
     return 0;
 }
 
+// flowcell::SequencingAdapterListGrammar (include/flowcell/SequencingAdapterListGrammar.hpp:52-104) by hand: start_ = macro_ | adapter_list_;
+// adapter_list_ = *(adapter_ >> -','); adapter_ = sequence '*' | sequence | '*' sequence, a sequence being five or more of ACGTacgt (stored upper case).
+// What is left unparsed is an error (DefaultAdaptersOption.cpp:42-47).
+int isaac_gpu_parse_adapters(const char *descriptor, isaac_params *p)
+{
+    if (!descriptor || !p) return paramsFail("descriptor and params are required");
+    const std::string text = descriptor;
+    struct Preset { const char *name; const char *first; bool firstReverse; bool bounded; const char *second; bool secondReverse; };
+    // lib/flowcell/SequencingAdapterMetadata.cpp:29-39; the grammar tries Standard, NexteraMp, Nextera in this order
+    static const Preset presets[] = { { "Standard", "AGATCGGAAGAGC", false, false, "GCTCTTCCGATCT", true },
+                                      { "NexteraMp", "CTGTCTCTTATACACATCT", false, true, "AGATGTGTATAAGAGACAG", false },
+                                      { "Nextera", "CTGTCTCTTATACACATCT", false, false, "AGATGTGTATAAGAGACAG", true } };
+    std::vector<isaac_adapter> list;
+    size_t at = 0;
+    const auto add = [&](const std::string &sequence, bool reverse, bool bounded)
+    {
+        isaac_adapter a; std::memset(&a, 0, sizeof(a));
+        std::memcpy(a.sequence, sequence.data(), std::min(sequence.size(), sizeof(a.sequence) - 1));
+        a.reverse = reverse ? 1 : 0; a.clip_length = bounded ? uint32_t(sequence.size()) : 0;
+        list.push_back(a);
+        return sequence.size() < sizeof(a.sequence) - 1;
+    };
+    bool macro = false, tooLong = false;
+    for (const Preset &preset : presets)
+        if (0 == text.compare(0, std::strlen(preset.name), preset.name))
+        {
+            add(preset.first, preset.firstReverse, preset.bounded); add(preset.second, preset.secondReverse, preset.bounded);
+            at = std::strlen(preset.name); macro = true;
+            break;
+        }
+    const auto sequenceAt = [&](size_t from, std::string &sequence)
+    {
+        sequence.clear();
+        size_t i = from;
+        for (; i < text.size(); ++i)
+        {
+            const char c = text[i];
+            if ('A' == c || 'a' == c) sequence.push_back('A'); else if ('C' == c || 'c' == c) sequence.push_back('C');
+            else if ('G' == c || 'g' == c) sequence.push_back('G'); else if ('T' == c || 't' == c) sequence.push_back('T'); else break;
+        }
+        return sequence.size() >= 5 ? i : from;
+    };
+    while (!macro && at < text.size())
+    {
+        std::string sequence;
+        size_t end = sequenceAt(at, sequence);
+        if (end != at)
+        {
+            if (end < text.size() && '*' == text[end]) { tooLong |= !add(sequence, false, false); ++end; }    // forward_unbounded_adapter_
+            else tooLong |= !add(sequence, false, true);                                                       // simple_adapter_
+        }
+        else if ('*' == text[at] && (end = sequenceAt(at + 1, sequence)) != at + 1) tooLong |= !add(sequence, true, false);   // reverse_unbounded_adapter_
+        else break;
+        at = end;
+        if (at < text.size() && ',' == text[at]) ++at;
+    }
+    if (at != text.size()) return paramsFail("\n   *** Could not parse the default-adapters '" + text + "' at: " + text.substr(at) + " ***\n");
+    if (tooLong) return paramsFail("Adapter sequence is too long");                                             // SequencingAdapter.cpp:35
+    if (list.size() > ISAAC_GPU_MAX_ADAPTERS) return paramsFail("more than " + std::to_string(ISAAC_GPU_MAX_ADAPTERS) + " sequencing adapters");
+    p->n_adapters = uint32_t(list.size());
+    std::memset(p->adapters, 0, sizeof(p->adapters));
+    for (size_t i = 0; i < list.size(); ++i) p->adapters[i] = list[i];
+    return 0;
+}
+
 int isaac_gpu_default_params(uint32_t readLength1, uint32_t readLength2, isaac_params *p)
 {
     if (!p || !readLength1) return paramsFail("params and read_length1 are required");

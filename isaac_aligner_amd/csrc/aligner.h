@@ -406,12 +406,145 @@ ISAAC_HD u32 updateFragmentCigar(const DevParams &P, const DevReference &R, cons
     return matchCount;
 }
 
-// AlignerBase::clipReadMasking + clipReference (AlignerBase.cpp:50-119) on [begin, end) indices of the strand sequence.
+// ------------------------------------------------------------------------------------------------------------------
+// Sequencing adapters: matchSelector::SequencingAdapter::getMatchRange (lib/alignment/matchSelector/SequencingAdapter.cpp:58-141) and
+// FragmentSequencingAdapterClipper (lib/alignment/matchSelector/FragmentSequencingAdapterClipper.cpp:41-282) on offsets into the strand sequence.
+// A strand's adapter range travels as one word: begin | end << 16, 0 = no adapter on this strand (a found range has begin < end).
+ISAAC_HD u32 adapterRangePack(i64 begin, i64 end) { return u32(begin) | (u32(end) << 16); }
+// oligo::generateKmer (KmerGenerator.hpp:149-169) for the 5 bases from `at`: anything but ACGT has the value 4, which spills into the base before it
+ISAAC_HD bool adapterKmer(const ReadView &read, bool reverse, i64 at, i64 end, u32 &kmer)
+{
+    u32 k = 0;
+    for (u32 todo = ADAPTER_MATCH_BASES_MIN; todo; --todo, ++at)
+    {
+        if (at == end) return false;
+        const char c = strandBase(read, reverse, u32(at));
+        const u32 v = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
+        k = ((k << 2) | v) & 0xffffu;                 // (the reference's k-mer is an unsigned short)
+    }
+    kmer = k & ((1u << (2 * ADAPTER_MATCH_BASES_MIN)) - 1);
+    return true;
+}
+ISAAC_HD void adapterMatchRange(const DevAdapter &a, const ReadView &read, bool reverse, i64 sequenceBegin, i64 sequenceEnd, i64 mismatchBase, i64 &first, i64 &second)
+{
+    first = second = mismatchBase;
+    u32 kmer;
+    if (!adapterKmer(read, reverse, mismatchBase, sequenceEnd, kmer)) return;
+    const i32 pos = a.kmerPositions[kmer];
+    if (pos < 0) return;
+    const bool unbounded = 0 == a.clipLength;
+    const u32 mismatchBaseOffset = u32(mismatchBase - sequenceBegin);
+    const u32 adapterBasesBeforeSequence = mismatchBaseOffset < u32(pos) ? u32(pos) - mismatchBaseOffset : 0;
+    if (adapterBasesBeforeSequence && unbounded) return;
+    const i64 testBase = mismatchBase - (i64(pos) - i64(adapterBasesBeforeSequence));
+    const u32 testSequenceLength = u32(sequenceEnd - testBase);
+    const u32 leftClippedAdapterLength = a.length - adapterBasesBeforeSequence;
+    const u32 overlapLength = imin(testSequenceLength, leftClippedAdapterLength);
+    if (overlapLength < leftClippedAdapterLength && unbounded && a.reverse) return;
+    if (overlapLength < ADAPTER_MATCH_BASES_MIN) return;
+    for (u32 i = 0; i < overlapLength; ++i) if (a.sequence[adapterBasesBeforeSequence + i] != strandBase(read, reverse, u32(testBase) + i)) return;
+    if (a.reverse)
+    {
+        first = unbounded ? sequenceBegin : testBase - i64(imin(u32(testBase - sequenceBegin), a.clipLength - a.length));
+        second = testBase + overlapLength;
+    }
+    else
+    {
+        first = testBase;
+        second = unbounded ? sequenceEnd : testBase + i64(imin(overlapLength, a.clipLength));
+    }
+}
+// checkInitStrand (:103-150) for a fragment of `read` on strand `reverse` at `position` of the contig: where the strand's adapter lies
+ISAAC_HD u32 adapterStrandRange(const DevAdapters &A, const DevReference &R, const ReadView &read, bool reverse, u32 contigId, i64 position)
+{
+    const i64 referenceSize = i64(contigLength(R, contigId));
+    i64 sequenceBegin = 0, sequenceEnd = read.length;
+    const i64 referenceLeft = referenceSize - position;
+    if (referenceLeft < sequenceEnd - sequenceBegin) sequenceEnd = sequenceBegin + referenceLeft;
+    i64 newFragmentPos = position;
+    if (0 > position) { sequenceBegin -= position; newFragmentPos = 0; }
+    i64 rangeBegin = sequenceEnd, rangeEnd = sequenceBegin;
+    const char *reference = R.bases + R.contigOffset[contigId];
+    for (u32 k = 0; k < A.n; ++k)
+    {
+        const DevAdapter &a = A.a[k];
+        if (0 == a.clipLength && reverse != (0 != a.reverse)) continue;           // isStrandCompatible
+        if (rangeEnd >= sequenceEnd) continue;
+        // findSequencingAdapter (:76-97) from where the adapters found so far end
+        const i64 searchBegin = rangeEnd;
+        i64 currentReference = newFragmentPos + (searchBegin - sequenceBegin);
+        for (i64 currentBase = searchBegin; currentBase != sequenceEnd; ++currentBase, ++currentReference)
+        {
+            if (isMatch(strandBase(read, reverse, u32(currentBase)), reference[currentReference])) continue;
+            i64 first, second;
+            adapterMatchRange(a, read, reverse, searchBegin, sequenceEnd, currentBase, first, second);
+            if (first != second) { rangeBegin = imin(first, rangeBegin); rangeEnd = imax(second, rangeEnd); break; }
+        }
+    }
+    return sequenceBegin == rangeEnd ? 0u : adapterRangePack(rangeBegin, rangeEnd);
+}
+// countMatches / countMismatches (Alignment.hh:91-146) for decideWhichSideToClip; a reference index outside the contig compares as 'N' (the reference
+// forms reference.begin() + contigPosition unchecked -- undefined for a fragment that hangs over the contig's start and is not the strand's first; the
+// oracle defines it the same way)
+ISAAC_HD u32 adapterCountMatches(const ReadView &read, bool reverse, i64 sequenceBegin, i64 sequenceEnd, const char *reference, i64 referenceSize, i64 referenceBegin, i64 referenceEnd, bool matches)
+{
+    u32 ret = 0;
+    for (; sequenceEnd != sequenceBegin && referenceEnd != referenceBegin; ++sequenceBegin, ++referenceBegin)
+    {
+        const char ref = (referenceBegin < 0 || referenceBegin >= referenceSize) ? 'N' : reference[referenceBegin];
+        ret += matches == isMatch(strandBase(read, reverse, u32(sequenceBegin)), ref);
+    }
+    return ret;
+}
+// FragmentSequencingAdapterClipper::clip with decideWhichSideToClip (:152-278): [begin, end) is the whole strand sequence on entry
+ISAAC_HD void adapterClip(const DevReference &R, const ReadView &read, Cand &f, u32 range, i64 &begin, i64 &end)
+{
+    if (!range) return;
+    const i64 rangeBegin = range & 0xffffu, rangeEnd = range >> 16, sequenceLength = read.length;
+    const bool reverse = 0 != f.reverse;
+    const u32 backwardsClipped = u32(rangeBegin), forwardsClipped = u32(sequenceLength - rangeEnd);
+    bool clipBackwards = backwardsClipped < forwardsClipped, doClip = true;
+    const char *reference = R.bases + R.contigOffset[f.contigId];
+    const i64 referenceSize = i64(contigLength(R, f.contigId)), contigPosition = f.position;
+    const i32 difference = i32(backwardsClipped - forwardsClipped);
+    if (backwardsClipped && forwardsClipped && (difference < 0 ? -difference : difference) < 9)
+    {
+        if (contigPosition >= 0 && u64(referenceSize) >= u64(u32(contigPosition + sequenceLength)))
+        {
+            const i64 referenceBegin = contigPosition, referenceEnd = referenceBegin + sequenceLength;
+            const u32 backwardsMatches = adapterCountMatches(read, reverse, 0, rangeBegin, reference, referenceSize, referenceBegin, referenceBegin + backwardsClipped, true);
+            const u32 forwardsMatches = adapterCountMatches(read, reverse, rangeEnd, sequenceLength, reference, referenceSize, referenceEnd - forwardsClipped, referenceEnd, true);
+            clipBackwards = backwardsMatches < forwardsMatches || (backwardsMatches == forwardsMatches && backwardsClipped < forwardsClipped);
+        }
+    }
+    else if (!backwardsClipped || !forwardsClipped)
+    {
+        const i64 referenceBegin = contigPosition, referenceEnd = referenceBegin + sequenceLength;
+        const u32 TOO_GOOD_READ_MISMATCH_PERCENT = 40;
+        if (clipBackwards && !backwardsClipped)
+        {
+            const u32 basesClipped = u32(rangeEnd);
+            doClip = adapterCountMatches(read, reverse, 0, rangeEnd, reference, referenceSize, referenceBegin, referenceBegin + basesClipped, false) * 100 / basesClipped > TOO_GOOD_READ_MISMATCH_PERCENT;
+        }
+        else if (!clipBackwards && !forwardsClipped)
+        {
+            const u32 basesClipped = u32(sequenceLength - rangeBegin);
+            doClip = adapterCountMatches(read, reverse, rangeBegin, sequenceLength, reference, referenceSize, referenceEnd - basesClipped, referenceEnd, false) * 100 / basesClipped > TOO_GOOD_READ_MISMATCH_PERCENT;
+        }
+    }
+    if (!doClip) return;
+    if (clipBackwards) { candIncrementClipLeft(f, u32(rangeEnd)); begin = rangeEnd; }
+    else { candIncrementClipRight(f, u32(sequenceLength - rangeBegin)); end = rangeBegin; }
+}
+
+// FragmentSequencingAdapterClipper::clip + AlignerBase::clipReadMasking + clipReference (UngappedAligner.cpp:59-62, AlignerBase.cpp:50-119) on [begin, end)
+// indices of the strand sequence.  adapterRange: the strand's adapter (0: none; R is then not looked at).
 // Returns false for the "position past the contig end" case (AlignerBase.cpp:74-81), which no seed or rescue candidate can
 // produce (positions are always < contig length) and which is undefined behaviour in the reference.
-ISAAC_HD bool clipSequence(const ReadView &read, Cand &f, i64 referenceSize, i64 &begin, i64 &end)
+ISAAC_HD bool clipSequence(const ReadView &read, Cand &f, i64 referenceSize, i64 &begin, i64 &end, const DevReference *R = 0, u32 adapterRange = 0)
 {
     begin = 0; end = read.length;
+    if (adapterRange) adapterClip(*R, read, f, adapterRange, begin, end);
     const i64 maskedBegin = f.reverse ? i64(read.endCyclesMasked) : 0;
     const i64 maskedEnd = f.reverse ? i64(read.length) : i64(read.length) - i64(read.endCyclesMasked);
     if (maskedBegin > begin) { candIncrementClipLeft(f, u32(maskedBegin - begin)); begin = maskedBegin; }
@@ -424,14 +557,14 @@ ISAAC_HD bool clipSequence(const ReadView &read, Cand &f, i64 referenceSize, i64
     return true;
 }
 
-// UngappedAligner::alignUngapped (UngappedAligner.cpp:39-92), no sequencing adapters
-ISAAC_HD u32 alignUngapped(const DevParams &P, const DevReference &R, const ReadView &read, Cand &f, CigarPool &pool)
+// UngappedAligner::alignUngapped (UngappedAligner.cpp:39-92)
+ISAAC_HD u32 alignUngapped(const DevParams &P, const DevReference &R, const ReadView &read, Cand &f, CigarPool &pool, u32 adapterRange = 0)
 {
     const u32 cigarOffset = pool.used;
     candResetAlignment(f, pool);
     f.lowClipped = 0; f.highClipped = 0;
     i64 begin, end;
-    if (!clipSequence(read, f, i64(contigLength(R, f.contigId)), begin, end)) { candSetUnaligned(f); return 0; }
+    if (!clipSequence(read, f, i64(contigLength(R, f.contigId)), begin, end, &R, adapterRange)) { candSetUnaligned(f); return 0; }
     if (begin > i64(read.length)) { candSetUnaligned(f); return 0; }
     if (begin) pool.addOperation(u32(begin), OP_SOFT_CLIP);
     if (end - begin) pool.addOperation(u32(end - begin), OP_ALIGN);
@@ -561,14 +694,14 @@ struct StrandQuery
 };
 
 // GappedAligner::alignGapped (GappedAligner.cpp:167-249), --avoid-smith-waterman 0
-ISAAC_HD u32 alignGapped(const DevParams &P, const DevReference &R, const ReadView &read, Cand &f, CigarPool &pool, u32 *tflags)
+ISAAC_HD u32 alignGapped(const DevParams &P, const DevReference &R, const ReadView &read, Cand &f, CigarPool &pool, u32 *tflags, u32 adapterRange = 0)
 {
     const u32 cigarOffset = pool.used;
     candResetAlignment(f, pool);
     f.lowClipped = 0; f.highClipped = 0;
     const u64 referenceSize = contigLength(R, f.contigId);
     i64 begin, end;
-    if (!clipSequence(read, f, i64(referenceSize), begin, end)) return 0;
+    if (!clipSequence(read, f, i64(referenceSize), begin, end, &R, adapterRange)) return 0;
     if (begin) pool.addOperation(u32(begin), OP_SOFT_CLIP);
     const u32 sequenceLength = u32(end - begin);
     i64 strandPosition = f.position;
@@ -888,8 +1021,9 @@ ISAAC_HD void simpleIndelPairs(const DevParams &P, const DevReference &R, const 
         Cand &head = l.at(t - 1); Cand &tail = l.at(t);
         if (simpleIndelPairQualifies(P, head, tail, pool.words))
         {
-            RefView windowView; const RefView *window = 0;
+            const RefView *window = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
+            RefView windowView;
             if (stage)
             {
                 const i64 hu = candUnclippedPosition(head, pool.words), tu = candUnclippedPosition(tail, pool.words);
@@ -925,7 +1059,8 @@ ISAAC_HD void alignSimpleIndels(const DevParams &P, const DevReference &R, const
 
 // One gapped (banded Smith-Waterman) re-alignment problem: GappedAligner::alignGapped of a candidate.  Problems are collected
 // per chunk and executed 16 lanes per problem (k_gapped_jobs); results come back to the cluster's thread.
-struct GappedJob { Cand in; u32 cluster; u32 endCyclesMasked; u32 tag; u32 pad; };
+// accepted: set by the rescue's sums for the retries whose result replaces the ungapped shadow (sums.h); adapterRange: the strand's sequencing adapter (0: none)
+struct GappedJob { Cand in; u32 cluster; u16 endCyclesMasked, accepted; u32 tag; u32 adapterRange; };
 struct GappedResult { Cand out; u32 matchCount; u32 nCigar; u32 cigar[40]; };
 static_assert(sizeof(GappedJob) == 80 && sizeof(GappedResult) == 232, "gapped job layouts");
 
@@ -1070,8 +1205,30 @@ ISAAC_HD bool buildCandidates(const DevParams &P, const u8 *clusterBcl, const Ma
     return built;
 }
 
+// the four adapter ranges (read x strand) of the cluster whose view this is; NULL without adapters
+ISAAC_HD u32 *clusterAdapterRanges(const DevParams &P, const ClusterFragments &f) { return P.adapters ? P.adapterRanges + 4 * size_t(f.cands[0] - P.adapterCandBase) : (u32 *)0; }
+// FragmentSequencingAdapterClipper::checkInitStrand as FragmentBuilder::alignFragments calls it (FragmentBuilder.cpp:164-174): per read a fresh clipper, the
+// first candidate of either strand in list order (the list is consolidated: sorted) decides that strand's range.  Runs on the candidates as built, before
+// any of them is aligned (alignUngapped moves positions).
+ISAAC_HD void clusterInitAdapterRanges(const DevParams &P, const DevReference &R, const u8 *clusterBcl, const ClusterFragments &f, u32 r, u32 strand)
+{
+    u32 *ranges = clusterAdapterRanges(P, f);
+    if (!ranges) return;
+    u32 range = 0;
+    const Cand *list = f.list(r);
+    const u32 n = f.listLength(r);
+    for (u32 i = 0; i < n; ++i)
+    {
+        if (u32(0 != list[i].reverse) != strand) continue;
+        ReadView read; read.bcl = clusterBcl + P.readOffset[r]; read.length = P.readLength[r]; read.firstCycle = P.firstCycle[r]; read.endCyclesMasked = 0;
+        range = adapterStrandRange(*P.adapters, R, read, 0 != strand, list[i].contigId, list[i].position);
+        break;
+    }
+    ranges[2 * r + strand] = range;
+}
 ISAAC_HD void alignCandidate(const DevParams &P, const DevReference &R, const u8 *clusterBcl, ClusterFragments &out, u32 r, u32 i, Counters &cnt)
 {
+    const u32 *ranges = clusterAdapterRanges(P, out);
     ReadView read; read.bcl = clusterBcl + P.readOffset[r]; read.length = P.readLength[r]; read.firstCycle = P.firstCycle[r]; read.endCyclesMasked = r ? out.endCyclesMasked[1] : out.endCyclesMasked[0];      // (r is known at run time only: selects, not indexes -- ClusterFragments::list)
     const u32 slot = 3 * ((r ? out.nCands[0] : 0) + i);
     CigarPool pool; pool.words = out.cigarPool; pool.used = slot; pool.capacity = slot + 3; pool.overflow = 0;
@@ -1080,7 +1237,7 @@ ISAAC_HD void alignCandidate(const DevParams &P, const DevReference &R, const u8
     alignUngapped(P, R, read, out.list(r)[i], pool);
 #else
     Cand c = out.list(r)[i];
-    alignUngapped(P, R, read, c, pool);
+    alignUngapped(P, R, read, c, pool, ranges ? ranges[2 * r + (c.reverse ? 1 : 0)] : 0u);
     out.list(r)[i] = c;
 #endif
     ++cnt.ungappedScans;
@@ -1129,6 +1286,7 @@ ISAAC_HD bool buildFragments(const DevParams &P, const DevReference &R, const u8
 {
     (void)withGaps;
     if (!buildCandidates(P, clusterBcl, matches, nMatches, trim, work, out)) return false;
+    if (P.adapters) for (u32 r = 0; r < P.nReads; ++r) for (u32 strand = 0; strand < 2; ++strand) clusterInitAdapterRanges(P, R, clusterBcl, out, r, strand);
     for (u32 r = 0; r < P.nReads; ++r) for (u32 i = 0; i < out.nCands[r]; ++i) alignCandidate(P, R, clusterBcl, out, r, i, cnt);
     finishCandidates(P, R, clusterBcl, work, out, cnt, deferSimpleIndels);
     return true;
@@ -1171,17 +1329,19 @@ ISAAC_HD u32 countGappedJobs(const ClusterFragments &f, bool withGaps)
     if (withGaps && f.built) for (u32 r = 0; r < 2; ++r) for (u32 i = 0; i < f.nCands[r]; ++i) n += BSW_MISMATCHES_CUTOFF < f.cands[r][i].mismatchCount;
     return n;
 }
-ISAAC_HD void makeGappedJob(const ClusterFragments &f, u32 r, u32 i, u32 chunkCluster, GappedJob &j)
+ISAAC_HD void makeGappedJob(const DevParams &P, const ClusterFragments &f, u32 r, u32 i, u32 chunkCluster, GappedJob &j)
 {
-    j.in = f.cands[r][i]; j.cluster = chunkCluster; j.endCyclesMasked = f.endCyclesMasked[r]; j.tag = (r << 16) | i; j.pad = 0;
+    const u32 *ranges = clusterAdapterRanges(P, f);
+    j.in = f.cands[r][i]; j.cluster = chunkCluster; j.endCyclesMasked = u16(f.endCyclesMasked[r]); j.accepted = 0; j.tag = (r << 16) | i;
+    j.adapterRange = ranges ? ranges[2 * r + (j.in.reverse ? 1 : 0)] : 0u;
     // FragmentMetadata::resetAlignment starts from the unclipped position; the job does not carry the old CIGAR
     j.in.position = candUnclippedPosition(f.cands[r][i], f.cigarPool); j.in.cigarLength = 0; j.in.cigarOffset = 0;
 }
-ISAAC_HD void writeGappedJobs(const ClusterFragments &f, u32 chunkCluster, GappedJob *jobs)
+ISAAC_HD void writeGappedJobs(const DevParams &P, const ClusterFragments &f, u32 chunkCluster, GappedJob *jobs)
 {
     u32 n = 0;
     for (u32 r = 0; r < 2; ++r) for (u32 i = 0; i < f.nCands[r]; ++i) if (BSW_MISMATCHES_CUTOFF < f.cands[r][i].mismatchCount)
-        makeGappedJob(f, r, i, chunkCluster, jobs[n++]);
+        makeGappedJob(P, f, r, i, chunkCluster, jobs[n++]);
 }
 
 // one gapped problem in the calling thread (serial form of k_gapped_jobs)
@@ -1191,7 +1351,7 @@ ISAAC_HD void runGappedJobSerial(const DevParams &P, const DevReference &R, cons
     read.bcl = clusterBcl + P.readOffset[r]; read.length = P.readLength[r]; read.firstCycle = P.firstCycle[r]; read.endCyclesMasked = job.endCyclesMasked;
     res.out = job.in;
     CigarPool pool; pool.words = res.cigar; pool.used = 0; pool.capacity = 40; pool.overflow = 0;
-    res.matchCount = alignGapped(P, R, read, res.out, pool, tflags);
+    res.matchCount = alignGapped(P, R, read, res.out, pool, tflags, job.adapterRange);
     res.nCigar = pool.overflow ? 0xffffffffu : pool.used;
 }
 

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(BSW_BLOCK) void k_gapped_jobs(DevParams P, DevRefer
         candResetAlignment(p.f, none);
         p.f.lowClipped = 0; p.f.highClipped = 0;
         const u64 referenceSize = contigLength(R, p.f.contigId);
-        p.go = clipSequence(p.read, p.f, i64(referenceSize), p.begin, p.end);
+        p.go = clipSequence(p.read, p.f, i64(referenceSize), p.begin, p.end, &R, jb.adapterRange);
         p.sequenceLength = 0; p.strandPosition = 0; p.left = 0; p.right = 0; p.database = nullptr; p.queryChunks = 0; p.window = 0; p.windowChunks = 0;
         if (p.go)
         {

@@ -40,7 +40,7 @@ struct SerialGappedProvider
     ISAAC_HD const GappedResult *operator()(u32 r, u32 i)
     {
         GappedJob job;
-        makeGappedJob(*frags, r, i, 0, job);
+        makeGappedJob(*P, *frags, r, i, 0, job);
         runGappedJobSerial(*P, *R, clusterBcl, job, tflags, result);
         return &result;
     }
@@ -139,12 +139,12 @@ ISAAC_HD void rescueAlignCandidate(const DevParams &P, const DevReference &R, co
 #if defined(ISAAC_CAND_IN_PLACE)       // (the form of rounds 1-5, for comparison)
     candInit(out, r);
     out.reverse = job.shadowReverse; out.contigId = job.contigId; out.position = i64(relativePosition) + job.windowBegin;
-    alignUngapped(P, R, shadowRead, out, pool);
+    alignUngapped(P, R, shadowRead, out, pool, job.adapterRange);
 #else
     Cand c;
     candInit(c, r);
     c.reverse = job.shadowReverse; c.contigId = job.contigId; c.position = i64(relativePosition) + job.windowBegin;
-    alignUngapped(P, R, shadowRead, c, pool);
+    alignUngapped(P, R, shadowRead, c, pool, job.adapterRange);
     out = c;
 #endif
 }

@@ -61,6 +61,39 @@ inline DevParams makeDevParams(const isaac_params &p)
     return d;
 }
 
+// matchSelector::SequencingAdapter's constructor (lib/alignment/matchSelector/SequencingAdapter.cpp:30-56) for every adapter of the list: the position of each
+// 5-mer of the adapter, -1 where there is none, -2 where there are several.  n == 0: no adapters (DevParams::adapters stays NULL).
+inline DevAdapters makeDevAdapters(const isaac_params &p)
+{
+    DevAdapters d;
+    std::memset(&d, 0, sizeof(d));
+    if (p.n_adapters > MAX_ADAPTERS) throw std::invalid_argument("at most 8 sequencing adapters are supported");
+    d.n = p.n_adapters;
+    for (u32 k = 0; k < p.n_adapters; ++k)
+    {
+        const isaac_adapter &in = p.adapters[k];
+        DevAdapter &a = d.a[k];
+        const size_t length = strnlen(in.sequence, sizeof(in.sequence));
+        if (length < ADAPTER_MATCH_BASES_MIN) throw std::invalid_argument("a sequencing adapter has at least 5 bases");              // SequencingAdapterListGrammar.hpp: five adapter_char_ at least
+        if (length > MAX_ADAPTER_LENGTH) throw std::invalid_argument("Adapter sequence is too long");                                 // SequencingAdapter.cpp:35
+        if (in.clip_length && in.clip_length < length) throw std::invalid_argument("Clip length cannot be shorter than the adapter sequence");   // :36-38
+        for (size_t i = 0; i < length; ++i) if (!std::strchr("ACGT", in.sequence[i])) throw std::invalid_argument("adapter sequences are made of A, C, G and T");
+        a.length = u32(length); a.reverse = in.reverse ? 1 : 0; a.clipLength = in.clip_length;
+        std::memcpy(a.sequence, in.sequence, length);
+        std::memset(a.kmerPositions, -1, sizeof(a.kmerPositions));
+        u32 kmer = 0;
+        for (size_t i = 0; i < length; ++i)
+        {
+            kmer = ((kmer << 2) | u32(std::strchr("ACGT", in.sequence[i]) - "ACGT")) & 1023u;
+            if (i + 1 < ADAPTER_MATCH_BASES_MIN) continue;
+            signed char &pos = a.kmerPositions[kmer];
+            if (-1 == pos) pos = (signed char)(i + 1 - ADAPTER_MATCH_BASES_MIN);
+            else if (-2 != pos) pos = -2;
+        }
+    }
+    return d;
+}
+
 // lib/alignment/Quality.cpp:34-66: 100 entries each; entry 0 of BOTH tables is log(1 - 10^-0.1)
 inline void makeQualityTables(double *logMatch, double *logMismatch)
 {

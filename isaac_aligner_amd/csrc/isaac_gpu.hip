@@ -78,6 +78,7 @@ struct isaac_gpu_ctx
     DevBuf<TableEntry> entries; u64 nKmers = 0; DevBuf<u32> karyotype; bool hasKaryotype = false;
     const TableEntry *entriesBorrowed = nullptr;   // isaac_gpu_set_index_dev: a table owned by the caller (another context, an RCCL receive buffer)
     const TableEntry *tableEntries() const { return entriesBorrowed ? entriesBorrowed : entries.p; }
+    DevBuf<DevAdapters> adaptersDev; DevBuf<u32> adapterRanges;      // sequencing adapters (--default-adapters): the list with its 5-mer tables; four ranges per candidate slot's cluster
     DevBuf<u32> flaggedList, resolveChanged; DevBuf<u8> resolveStaging, resolveBack; DevBuf<u64> resolveRanges; DevBuf<Match> resolveMatches; std::vector<char> hostBases; const char *hostBasesGiven = nullptr; std::vector<isaac_host_resolve::Resolver *> resolvers; std::vector<u8> resolverLoaded;      // isaac_gpu_resolve_flagged
     DevBuf<u32> prefixTable; u32 prefixBits = 0; std::vector<u64> maskOffsets;   // entries before each mask of the table (load_index / build_index)
     DevBuf<u32> packedBases, notBase;   // 2-bit copy of the contigs + not-ACGT bitmap (k_rescue_windows reads these)
@@ -598,6 +599,18 @@ extern "C" {
 
 const char *isaac_gpu_last_error(void) { return g_error.c_str(); }
 
+// the adapter list of the parameters on the device; c->P.adapters stays NULL for an empty list (what every kernel's adapter step tests)
+static void setAdapters(isaac_gpu_ctx *c)
+{
+    c->P.adapters = nullptr; c->P.adapterRanges = nullptr; c->P.adapterCandBase = nullptr;
+    if (!c->params.n_adapters) return;
+    const DevAdapters host = makeDevAdapters(c->params);
+    c->adaptersDev.reserve(1);
+    HIP_CHECK(hipMemcpy(c->adaptersDev.p, &host, sizeof(host), hipMemcpyHostToDevice));
+    c->P.adapters = c->adaptersDev.p;
+    if (c->candPool.p) { c->adapterRanges.reserve(4 * c->candPool.n); c->P.adapterRanges = c->adapterRanges.p; c->P.adapterCandBase = c->candPool.p; }
+}
+
 int isaac_gpu_create(int device, const isaac_params *params, void *stream, isaac_gpu_ctx **out)
 {
     ISAAC_TRY
@@ -612,6 +625,7 @@ int isaac_gpu_create(int device, const isaac_params *params, void *stream, isaac
     if (const char *small = std::getenv("ISAAC_GPU_CIGAR_EXTRA_WORDS")) c->cigarExtra = std::max<u32>(1, u32(std::atol(small)));      // tests: the repeated call
     c->params = *params; c->P = makeDevParams(*params);
     if (-params->gap_open < -params->gap_extend) return fail(ISAAC_GPU_EINVAL, "gap open penalty below gap extend penalty is not supported by the banded Smith-Waterman scan");
+    setAdapters(c.get());
     double tables[200]; makeQualityTables(tables, tables + 100);
     c->logTables.reserve(200);
     HIP_CHECK(hipMemcpy(c->logTables.p, tables, sizeof(tables), hipMemcpyHostToDevice));
@@ -1236,9 +1250,11 @@ int isaac_gpu_set_params(isaac_gpu_ctx *c, const isaac_params *params)
     if (!params) return fail(ISAAC_GPU_EINVAL, "null argument");
     if (-params->gap_open < -params->gap_extend) return fail(ISAAC_GPU_EINVAL, "gap open penalty below gap extend penalty is not supported by the banded Smith-Waterman scan");
     const DevParams P = makeDevParams(*params);
+    (void)makeDevAdapters(*params);                // (throws for a bad adapter before anything is changed)
     HIP_CHECK(hipSetDevice(c->device));
     HIP_CHECK(hipStreamSynchronize(c->stream));
     c->params = *params; c->P = P;
+    setAdapters(c);
     dropResolvers(c, false);                      // they hold the parameters they were made with
     return 0;
     ISAAC_CATCH
@@ -1347,6 +1363,7 @@ static void preparePools(isaac_gpu_ctx *c, u64 slots)
     c->clusterMeta.reserve(c->chunkNow); c->candPool.reserve(cap); c->cigarArena.reserve(arena); c->cigarNext.reserve(1);
     c->pools.meta = c->clusterMeta.p; c->pools.cands = c->candPool.p; c->pools.cigars = c->cigarArena.p; c->pools.candCap = u32(cap);
     c->pools.cigarCap = u32(arena); c->pools.cigarNext = c->cigarNext.p;
+    if (c->P.adapters) { c->adapterRanges.reserve(4 * c->candPool.n); c->P.adapterRanges = c->adapterRanges.p; c->P.adapterCandBase = c->candPool.p; }
     if (!c->poolShort.p) { c->poolShort.reserve(1); HIP_CHECK(hipMemsetAsync(c->poolShort.p, 0, 4, c->stream)); }
     c->pools.shortFlag = c->poolShort.p;
 }
@@ -1383,6 +1400,12 @@ static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clust
     {
         ScopedTimer t(c, "build_fragments_general");
         k_build_fragments_general<<<GENERAL_BLOCKS, 64, 0, c->stream>>>(c->P, bcl, clusterBase, reinterpret_cast<const Match *>(matches), offsets, trim, c->fragMatchOrder.p, c->fragMatchOrder.p + size_t(GENERAL_BLOCKS) * 16 * MATCH_CAP_MAX, c->pools, al, list0, c->generalCount.p);
+        HIP_CHECK(hipGetLastError());
+    }
+    if (c->P.adapters)
+    {   // (--default-adapters only: where each read's adapter lies, before any candidate is aligned)
+        ScopedTimer t(c, "adapter_ranges");
+        k_adapter_ranges<<<gridFor(u64(4) * n, 256), 256, 0, c->stream>>>(c->P, c->ref(), bcl, clusterBase, n, c->pools);
         HIP_CHECK(hipGetLastError());
     }
     {
@@ -1583,6 +1606,12 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         {
             ScopedTimer tm(c, "rescue_windows");
             k_rescue_windows<<<gridFor(rb.jobsCap, RW_WAVES), 64 * RW_WAVES, 0, st>>>(c->P, R, c->hContigOffset[c->nContigs], bcl, done, rb);
+            HIP_CHECK(hipGetLastError());
+        }
+        if (c->P.adapters)
+        {   // (--default-adapters only: the shadow strand's adapter of every rescue, from its first candidate position)
+            ScopedTimer tm(c, "rescue_adapter_ranges");
+            k_rescue_adapter_ranges<<<gridFor(rb.jobsCap, 256), 256, 0, st>>>(c->P, R, bcl, done, rb);
             HIP_CHECK(hipGetLastError());
         }
         {

@@ -200,6 +200,8 @@ __host__ __device__ inline u32 gappedGroupLdsBytes(u32 maxQueryLength)
 
 __global__ __launch_bounds__(64) void k_build_fragments(DevParams P, const u8 *__restrict__ bcl, u32 clusterBase, u32 nChunk, const Match *__restrict__ matches, const u64 *__restrict__ offsets, int trim, ClusterPools pools, AlignList al, u32 *generalList, u32 *generalCount);
 __global__ __launch_bounds__(64) void k_build_fragments_general(DevParams P, const u8 *bcl, u32 clusterBase, const Match *matches, const u64 *offsets, int trim, u8 *matchOrderArena, u8 *orderArena, ClusterPools pools, AlignList al, const u32 *list, const u32 *listCount);
+__global__ __launch_bounds__(256) void k_adapter_ranges(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, u32 nChunk, ClusterPools pools);
+__global__ __launch_bounds__(256) void k_rescue_adapter_ranges(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, RescueBuffers rb);
 __global__ __launch_bounds__(256) void k_align_candidates(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, ClusterPools pools, AlignList al, Counters *counters);
 __global__ __launch_bounds__(64) void k_finish_candidates(DevParams P, u32 nChunk, int withGaps, u32 *indelList, u32 *indelCount, ClusterPools pools, GappedBuffers gb, const u32 *__restrict__ order, u32 *generalList, u32 *generalCount);
 __global__ __launch_bounds__(64) void k_finish_candidates_general(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, int withGaps, u32 *indelList, u32 *indelCount, ClusterPools pools, GappedBuffers gb, Counters *counters, const u32 *list, const u32 *listCount);

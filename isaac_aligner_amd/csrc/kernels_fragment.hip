@@ -3,7 +3,7 @@
 #include "bsw_kernel.h"
 #include "fragment_lean.h"
 
-__device__ inline void emitGappedJobs(const ClusterFragments &f, u32 cl, bool withGaps, const GappedBuffers &gb)
+__device__ inline void emitGappedJobs(const DevParams &P, const ClusterFragments &f, u32 cl, bool withGaps, const GappedBuffers &gb)
 {
     u32 base = 0;
     const u32 n = countGappedJobs(f, withGaps);
@@ -11,7 +11,7 @@ __device__ inline void emitGappedJobs(const ClusterFragments &f, u32 cl, bool wi
     {
         base = atomicAdd(gb.counter, n);
         if (base + n > gb.cap) base = 0xffffffffu;   // k_finish_fragments runs this cluster's retries itself
-        else writeGappedJobs(f, cl, gb.jobs + base);
+        else writeGappedJobs(P, f, cl, gb.jobs + base);
     }
     gb.base[cl] = base;
 }
@@ -139,6 +139,20 @@ __global__ __launch_bounds__(64) void k_build_fragments_general(DevParams P, con
     }
 }
 
+// between steps 1 and 2, with sequencing adapters only (--default-adapters): where each read's adapter lies on either strand, decided by the first candidate
+// of that strand in the consolidated list as built (FragmentSequencingAdapterClipper::checkInitStrand, FragmentBuilder.cpp:164-174).  A thread per cluster,
+// read and strand; the four words per cluster are what every later alignment of the cluster clips by.
+__global__ __launch_bounds__(256) void k_adapter_ranges(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, u32 nChunk, ClusterPools pools)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 cl = t >> 2, r = (t >> 1) & 1, strand = t & 1;
+    if (cl >= nChunk || r >= P.nReads) return;
+    const ClusterMeta meta = pools.meta[cl];
+    if (!meta.cap) return;                                   // (a cluster without a match owns no slot: nothing of it is ever aligned)
+    const ClusterFragments f = clusterView(meta, pools.cands, pools.cigars);
+    clusterInitAdapterRanges(P, R, bcl + u64(clusterBase + cl) * P.clusterLength, f, r, strand);
+}
+
 // step 2: UngappedAligner::alignUngapped, one candidate per thread
 __global__ __launch_bounds__(256) void k_align_candidates(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, ClusterPools pools, AlignList al, Counters *counters)
 {
@@ -175,7 +189,7 @@ __global__ __launch_bounds__(64) void k_finish_candidates(DevParams P, u32 nChun
         {
             leanFinishCandidates(P, f, keys);
             if (clusterSimpleIndelsPending(f)) indelList[atomicAdd(indelCount, 1u)] = cl;
-            else emitGappedJobs(f, cl, withGaps != 0, gb);
+            else emitGappedJobs(P, f, cl, withGaps != 0, gb);
             clusterViewStore(f, pools.cands, pools.meta[cl]);
         }
     }
@@ -202,7 +216,7 @@ __global__ __launch_bounds__(64) void k_finish_candidates_general(DevParams P, D
         }
         finishCandidates(P, R, clusterBcl, work, f, local, true);
         if (clusterSimpleIndelsPending(f)) indelList[atomicAdd(indelCount, 1u)] = cl;
-        else emitGappedJobs(f, cl, withGaps != 0, gb);
+        else emitGappedJobs(P, f, cl, withGaps != 0, gb);
         clusterViewStore(f, pools.cands, pools.meta[cl]);
     }
     flushCounters(local, counters);
@@ -236,7 +250,7 @@ __global__ __launch_bounds__(64) void k_indel_fragments(DevParams P, DevReferenc
         __syncthreads();
         // a cluster that ran out of CIGAR words after the arena had none left for it: the call is repeated with a larger arena (selectFromSource)
         if (0 == threadIdx.x && u64(at) + need > pools.cigarCap && (f.flags & CLUSTER_OVERFLOW)) atomicOr(pools.shortFlag, 2u);
-        if (0 == threadIdx.x) { emitGappedJobs(f, cl, withGaps != 0, gb); clusterViewStore(f, pools.cands, pools.meta[cl]); }
+        if (0 == threadIdx.x) { emitGappedJobs(P, f, cl, withGaps != 0, gb); clusterViewStore(f, pools.cands, pools.meta[cl]); }
     }
     if (0 != threadIdx.x) memset(&local, 0, sizeof(local));   // every lane counted the same events
     flushCounters(local, counters);

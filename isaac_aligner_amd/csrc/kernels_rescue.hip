@@ -473,6 +473,22 @@ __global__ __launch_bounds__(64 * RW_WAVES) void k_rescue_windows(DevParams P, D
     rescueWindowsProblem(P, R, bcl, clusterBase, rb, blockIdx.x * RW_WAVES + wave, lane, tables[wave], ldsBitmaps[wave], presentMaps[wave]);
 }
 
+// With sequencing adapters only (--default-adapters): ShadowAligner::rescueShadow makes a fresh FragmentSequencingAdapterClipper per call and its first candidate
+// position initialises the shadow's strand (ShadowAligner.cpp:207,222); the positions of a problem lie ascending from candBase, so that is the first slot.
+// A thread per problem; k_rescue_align and the problem's gapped retries clip by what it leaves in the record.
+__global__ __launch_bounds__(256) void k_rescue_adapter_ranges(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, RescueBuffers rb)
+{
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= imin(*rb.jobCounter, rb.jobsCap)) return;
+    RescueJob &job = rb.jobs[j];
+    if (!job.valid || job.fallback || !job.nCands) return;
+    const u32 r = job.shadowReadIndex;
+    ReadView shadowRead;
+    shadowRead.bcl = bcl + u64(clusterBase + job.cluster) * P.clusterLength + P.readOffset[r]; shadowRead.length = P.readLength[r];
+    shadowRead.firstCycle = P.firstCycle[r]; shadowRead.endCyclesMasked = 0;
+    job.adapterRange = adapterStrandRange(*P.adapters, R, shadowRead, 0 != job.shadowReverse, job.contigId, i64(rb.candPositions[job.candBase]) + job.windowBegin);
+}
+
 // (six waves per SIMD: with its candidate in registers the kernel took 87 registers, five waves; held to 80 it has 79 and no scratch: 1.45 -> 1.39 ms, profiles/exp_r5_rescue_align_waves.log)
 #ifndef ISAAC_WAVES_RESCUE_ALIGN
 #define ISAAC_WAVES_RESCUE_ALIGN 6
@@ -600,7 +616,7 @@ __global__ __launch_bounds__(256) void k_rescue_gapped_plan_long(ClusterPools po
                 if (flag)
                 {
                     GappedJob &g = gb.jobs[base + emitted + u32(__popcll(fmask & below))];
-                    g.in = cands[prevC]; g.cluster = job.cluster; g.endCyclesMasked = ecm; g.tag = job.candBase + prevC; g.pad = 0;
+                    g.in = cands[prevC]; g.cluster = job.cluster; g.endCyclesMasked = u16(ecm); g.accepted = 0; g.tag = job.candBase + prevC; g.adapterRange = job.adapterRange;
                     g.in.cigarOffset = 0;
                     g.in.position = candUnclippedPosition(g.in, rb.shadowCigars + u64(job.candBase + prevC) * 3); g.in.cigarLength = 0;
                 }

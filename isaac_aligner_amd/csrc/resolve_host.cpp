@@ -20,6 +20,7 @@ namespace isaac_host_resolve
 struct Resolver
 {
     DevParams P; DevReference R;
+    DevAdapters adapters; u32 adapterRanges[4];
     std::vector<u64> contigOffset; std::vector<u8> contigLoaded;      // copies: the context's vectors may be reassigned while this lives
     std::vector<double> logMatch, logMismatch;
     RogCorrection rog; double lmq40;
@@ -44,6 +45,8 @@ Resolver *create(const isaac_params &params, const char *bases, const u64 *conti
     r->arena.assign(templateWorkBytes(caps) + 16, 0);
     templateWorkBind(r->work, reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(r->arena.data()) + 15) & ~uintptr_t(15)), caps);
     r->fragmentWork = r->fragmentStore.bind();
+    r->adapters = makeDevAdapters(params);
+    if (r->adapters.n) { r->P.adapters = &r->adapters; r->P.adapterRanges = r->adapterRanges; r->P.adapterCandBase = r->store.cands; }     // (one cluster at a time: its view starts at the store's first slot)
     return r.release();
 }
 void destroy(Resolver *r) { delete r; }

@@ -322,7 +322,7 @@ ISAAC_HD bool gappedRetryAccepted(const DevParams &P, const Cand &fragment, cons
 }
 
 // second half of ShadowAligner::rescueShadow (ShadowAligner.cpp:232-291) for one problem, on numbers only: how long the list is,
-// whether the call succeeds, which retries are accepted (GappedJob::pad = 1) and which shadow ends up in front.  false: the
+// whether the call succeeds, which retries are accepted (GappedJob::accepted = 1) and which shadow ends up in front.  false: the
 // wave-per-cluster pass has to do it (a capacity of the flat pass was exceeded).
 ISAAC_HD bool finishRescueFlat(const DevParams &P, RescueJob &job, const SumInputs &in, u32 &retries)
 {
@@ -350,12 +350,12 @@ ISAAC_HD bool finishRescueFlat(const DevParams &P, RescueJob &job, const SumInpu
         const u32 slot = gj.tag, i = in.candRank[slot];
         const Cand &fragment = in.shadowCands[slot];
         ++retries;
-        gj.pad = 0;
+        gj.accepted = 0;
         if (0xffffffffu == g.nCigar) { o.store(job); return false; }        // CIGAR longer than the result record holds
         const Cand &tmp = g.out;
         if (gappedRetryAccepted(P, fragment, g))
         {
-            gj.pad = 1;
+            gj.accepted = 1;
             if (i == best) { bestLp = tmp.logProbability; bestGapped = gappedBase + kk; bestSlot = slot; }
             else if (lpLess(bestLp, tmp.logProbability)) { best = i; bestLp = tmp.logProbability; bestGapped = gappedBase + kk; bestSlot = slot; }
         }
@@ -392,7 +392,7 @@ ISAAC_HD void forEachShadow(const RescueJob &job, const SumInputs &in, const Sum
     for (u32 kk = g.lane; kk < job.nGapped; kk += g.lanes)
     {
         const GappedJob &gj = in.gappedJobs[job.gappedBase + kk];
-        if (!gj.pad) continue;
+        if (!gj.accepted) continue;
         const u32 r = in.candRank[gj.tag];
         if (r < job.take) f(r, in.gappedResults[job.gappedBase + kk].out, true);
     }

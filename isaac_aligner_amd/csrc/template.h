@@ -247,7 +247,8 @@ struct RescueJob
     u16 windowBaseHigh;     // index of the window's first base in the concatenated contigs (contig offset + windowBegin), 48 bits:
     u32 windowBaseLow;      // k_rescue_windows starts its loads from the job record alone
     RescueOutcome out;      // finishRescueFlat: what the template stage asks about the best shadow, so that it need not follow the record to the shadow
-    u32 pad[2];
+    u32 adapterRange;       // the shadow strand's sequencing adapter, decided by the window's first candidate (ShadowAligner.cpp:207,222); 0: none
+    u32 pad;
 };
 ISAAC_HD u64 rescueJobWindowBase(const RescueJob &j) { return (u64(j.windowBaseHigh) << 32) | j.windowBaseLow; }
 static_assert(sizeof(RescueJob) == 128 && offsetof(RescueJob, out) == 96, "RescueJob layout");
@@ -466,7 +467,7 @@ ISAAC_HD bool planRescue(const TemplateCtx &x, const Cand &orphan, i64 bestTempl
 {
     job.windowBegin = 0; job.windowLen = 0; job.cluster = x.clusterId; job.contigId = orphan.contigId; job.candBase = 0; job.nCands = 0; job.pushes = 0;
     job.bitmapBase = 0; job.bitmapWords = 0; job.valid = 0; job.fallback = 0; job.gappedBase = 0xffffffffu; job.nGapped = 0; job.nAligned = 0; job.bestRank = 0; job.bestSlot = 0; job.lastAligned = 0;
-    job.take = 0; job.finalBestRank = 0; job.finalBestSlot = 0; job.finalBestGapped = 0xffffffffu; job.rescued = 0; job.windowBaseHigh = 0; job.windowBaseLow = 0;
+    job.adapterRange = 0; job.pad = 0; job.take = 0; job.finalBestRank = 0; job.finalBestSlot = 0; job.finalBestGapped = 0xffffffffu; job.rescued = 0; job.windowBaseHigh = 0; job.windowBaseLow = 0;
     job.orphanListIndex = u8(&orphan - x.cands[orphan.readIndex]);
     job.shadowReadIndex = u8((orphan.readIndex + 1) % 2);
     job.shadowReverse = 0;
@@ -488,7 +489,7 @@ ISAAC_HD bool planRescue(const TemplateCtx &x, const Cand &orphan, i64 bestTempl
 
 // second half (ShadowAligner.cpp:232-291): gapped retries next to close candidates, best shadow to the front
 // `gapped`: results of the retries in list order when the flat pass already ran them (planRescueGapped), else NULL
-ISAAC_HD bool finishRescue(TemplateCtx &x, CigarPool &pool, i32 best, const GappedResult *gapped = 0)
+ISAAC_HD bool finishRescue(TemplateCtx &x, CigarPool &pool, i32 best, const GappedResult *gapped = 0, u32 adapterRange = 0)
 {
     TemplateWork &w = *x.w;
     const DevParams &P = *x.P; const DevReference &R = *x.R;
@@ -514,7 +515,7 @@ ISAAC_HD bool finishRescue(TemplateCtx &x, CigarPool &pool, i32 best, const Gapp
                         if (0xffffffffu == g.nCigar) { w.overflow = 1; matchCount = 0; }
                         else for (u32 k = 0; k < g.nCigar; ++k) pool.push(g.cigar[k]);
                     }
-                    else matchCount = alignGapped(P, R, shadowRead, tmp, pool, w.tflags);
+                    else matchCount = alignGapped(P, R, shadowRead, tmp, pool, w.tflags, adapterRange);
                     if (matchCount && matchCount + BSW_WIDEST_GAP_SIZE > candObservedLength(fragment) && (tmp.mismatchCount <= P.gappedMismatchesMax) &&
                         (fragment.mismatchCount > tmp.mismatchCount) && lpLess(fragment.logProbability, tmp.logProbability))
                     {
@@ -572,6 +573,7 @@ ISAAC_HD bool shadowRescueSerial(TemplateCtx &x, const Cand &orphan, const Rescu
     x.cnt->rescueCandidates += nPositions;
     CigarPool pool; pool.words = w.shadowCigar; pool.used = 0; pool.capacity = w.caps.shadowCigar; pool.overflow = 0;
     i32 best = -1;
+    u32 adapterRange = 0;                // a fresh FragmentSequencingAdapterClipper per rescue: the first candidate position decides (ShadowAligner.cpp:207,222)
     for (u32 c = 0; c < nPositions; ++c)
     {
         if (w.nShadows == w.caps.shadow) { if (w.caps.shadow < SHADOW_LIST_MAX) w.overflow = 1; return false; } // reference: capacity 1000 -> return false
@@ -579,14 +581,19 @@ ISAAC_HD bool shadowRescueSerial(TemplateCtx &x, const Cand &orphan, const Rescu
         candInit(fragment, job.shadowReadIndex);
         fragment.reverse = job.shadowReverse; fragment.contigId = orphan.contigId;
         fragment.position = w.candidatePositions[w.sortIdx[c]] + job.windowBegin;
+        if (0 == c && P.adapters)
+        {
+            ReadView whole = shadowRead; whole.endCyclesMasked = 0;
+            adapterRange = adapterStrandRange(*P.adapters, R, whole, 0 != job.shadowReverse, orphan.contigId, fragment.position);
+        }
         ++x.cnt->ungappedScans;
-        if (alignUngapped(P, R, shadowRead, fragment, pool))
+        if (alignUngapped(P, R, shadowRead, fragment, pool, adapterRange))
         {
             if (best < 0 || lpLess(w.shadowList[best].logProbability, fragment.logProbability)) best = i32(w.nShadows);
             ++w.nShadows;
         }
     }
-    return finishRescue(x, pool, best);
+    return finishRescue(x, pool, best, 0, adapterRange);
 }
 
 // ShadowAligner::rescueShadow with the window scan and the ungapped alignments already done by the flat kernels (RESCUE_LOOKUP)
@@ -707,7 +714,7 @@ ISAAC_HD u32 writeRescueGapped(const RescueJob &job, const Cand *shadowCands, co
             if (!aligned[k]) continue;
             if (prev >= 0 && positions[k] - prevPosition < i64(BSW_DISTANCE_CUTOFF) && BSW_MISMATCHES_CUTOFF < prevMismatches)
             {
-                GappedJob &g = out[n]; g.in = shadowCands[candBase + u32(prev)]; g.cluster = job.cluster; g.endCyclesMasked = endCyclesMasked; g.tag = candBase + u32(prev); g.pad = 0;
+                GappedJob &g = out[n]; g.in = shadowCands[candBase + u32(prev)]; g.cluster = job.cluster; g.endCyclesMasked = u16(endCyclesMasked); g.accepted = 0; g.tag = candBase + u32(prev); g.adapterRange = job.adapterRange;
                 g.in.cigarOffset = 0;
                 g.in.position = candUnclippedPosition(g.in, shadowCigars + u64(candBase + u32(prev)) * 3); g.in.cigarLength = 0;
                 ++n;
@@ -739,7 +746,7 @@ ISAAC_HD u32 planRescueGapped(const RescueJob &job, const Cand *shadowCands, con
             {
                 if (out)
                 {
-                    GappedJob &g = out[n]; g.in = f; g.cluster = job.cluster; g.endCyclesMasked = endCyclesMasked; g.tag = job.candBase + u32(prev); g.pad = 0;
+                    GappedJob &g = out[n]; g.in = f; g.cluster = job.cluster; g.endCyclesMasked = u16(endCyclesMasked); g.accepted = 0; g.tag = job.candBase + u32(prev); g.adapterRange = job.adapterRange;
                     g.in.cigarOffset = 0;
                     g.in.position = candUnclippedPosition(g.in, shadowCigars + u64(job.candBase + u32(prev)) * 3); g.in.cigarLength = 0;
                 }

@@ -56,6 +56,13 @@ struct Match { u64 seedId; u64 location; };
 // ---- parameters as the kernels see them ---------------------------------------------------------------------------
 static const u32 MAX_SEEDS = 16;
 struct DevSeed { u16 offset, length; u32 readIndex; };
+// Sequencing adapters of the flowcell (--default-adapters): flowcell::SequencingAdapterMetadata + the 5-mer position table of
+// matchSelector::SequencingAdapter (lib/alignment/matchSelector/SequencingAdapter.cpp:30-56).  Lives in device memory (host memory for the host forms);
+// DevParams::adapters is NULL when the list is empty, and every kernel's adapter step is behind that one uniform test.
+static const u32 MAX_ADAPTERS = 8, ADAPTER_MATCH_BASES_MIN = 5, MAX_ADAPTER_LENGTH = 126;
+struct DevAdapter { u32 length, reverse, clipLength /* 0: unbounded */, pad; char sequence[128]; signed char kmerPositions[1024]; };
+struct DevAdapters { u32 n, pad[3]; DevAdapter a[MAX_ADAPTERS]; };
+struct Cand;
 struct DevParams
 {
     i32 gapMatch, gapMismatch, gapOpen, gapExtend, minGapExtend;
@@ -68,6 +75,11 @@ struct DevParams
     u32 nSeeds; DevSeed seeds[MAX_SEEDS];
     u32 nPass[2]; u8 passSeeds[2][MAX_SEEDS];  // FindMatchesTransition.cpp:90-110, each list ordered by (read, offset)
     u32 maxSeedsPerRead;
+    // sequencing adapters (NULL: none).  Where a read's adapter lies is decided once per read and strand by the first candidate of the list
+    // (FragmentSequencingAdapterClipper::checkInitStrand) and used by every later alignment of that strand: adapterRanges holds those four values per cluster
+    // (read x strand; begin | end << 16 in strand coordinates, 0: none), addressed by the cluster's first candidate slot relative to adapterCandBase.
+    const DevAdapters *adapters;
+    u32 *adapterRanges; const Cand *adapterCandBase;
 };
 
 // reference::ReferenceKmer<unsigned long> (include/reference/ReferenceKmer.hh:37-54): one entry of the sorted table, one record of a mask file.

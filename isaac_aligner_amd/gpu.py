@@ -42,7 +42,7 @@ EXPORTS = ["isaac_gpu_last_error", "isaac_gpu_create", "isaac_gpu_destroy", "isa
            "isaac_gpu_find_matches", "isaac_gpu_set_loaded_contigs", "isaac_gpu_build_fragments", "isaac_gpu_determine_tls", "isaac_gpu_share_index", "isaac_gpu_select", "isaac_gpu_select_n", "isaac_gpu_resolve_flagged", "isaac_gpu_set_host_contigs", "isaac_gpu_download_async", "isaac_gpu_download_wait", "isaac_gpu_share_reference", "isaac_gpu_select_candidates",
            "isaac_gpu_bsw_batch", "isaac_gpu_compact_cigars", "isaac_gpu_compact_cigars_async",
            "isaac_gpu_bam_records", "isaac_gpu_bin_tile", "isaac_gpu_bin_tile_map", "isaac_gpu_bam_last_error", "isaac_gpu_bam_header", "isaac_gpu_bgzf_bound", "isaac_gpu_bgzf_compress", "isaac_gpu_bgzf_store_bound", "isaac_gpu_bgzf_store", "isaac_gpu_bgzf_deflate_bound", "isaac_gpu_bgzf_deflate", "isaac_gpu_bam_index", "isaac_gpu_bam_indexer_create", "isaac_gpu_bam_indexer_add", "isaac_gpu_bam_indexer_add_entries", "isaac_gpu_bam_indexer_finish", "isaac_gpu_bam_indexer_destroy", "isaac_gpu_bam_index_last_error",
-           "isaac_gpu_default_params", "isaac_gpu_parse_gap_scoring", "isaac_gpu_parse_seeds", "isaac_gpu_params_last_error",
+           "isaac_gpu_default_params", "isaac_gpu_parse_gap_scoring", "isaac_gpu_parse_seeds", "isaac_gpu_parse_adapters", "isaac_gpu_params_last_error",
            "isaac_gpu_fastq_to_bcl", "isaac_gpu_fastq_tile_clusters_max", "isaac_gpu_fastq_tiles", "isaac_gpu_get_counters", "isaac_gpu_kernel_time_ms", "isaac_gpu_reset_timers"]
 
 

@@ -65,3 +65,23 @@ def default_params(read_length1, read_length2=0, gap_scoring="bwa", **overrides)
     if "first_pass_seeds" not in overrides:
         p.first_pass_seeds = min(2 if p.semialigned_gap_limit else 1, first_pass)
     return p
+
+
+# lib/flowcell/SequencingAdapterMetadata.cpp:29-39 as (sequence, reverse, clip_length; 0 = unbounded): the macros of --default-adapters
+ADAPTER_PRESETS = {"Standard": [("AGATCGGAAGAGC", False, 0), ("GCTCTTCCGATCT", True, 0)],
+                   "Nextera": [("CTGTCTCTTATACACATCT", False, 0), ("AGATGTGTATAAGAGACAG", True, 0)],
+                   "NexteraMp": [("CTGTCTCTTATACACATCT", False, 19), ("AGATGTGTATAAGAGACAG", False, 19)]}
+
+
+def set_adapters(p, adapters):
+    """isaac_params::adapters from a preset name or a list of (sequence, reverse, clip_length) / dicts with those keys; returns p.
+    (isaac_gpu_parse_adapters of the library parses the full --default-adapters syntax.)"""
+    if isinstance(adapters, str):
+        adapters = ADAPTER_PRESETS[adapters]
+    adapters = [(a["sequence"], a["reverse"], a["clip_length"]) if isinstance(a, dict) else a for a in adapters]
+    if len(adapters) > len(p.adapters):
+        raise ValueError("too many adapters")
+    p.n_adapters = len(adapters)
+    for i, (sequence, reverse, clip_length) in enumerate(adapters):
+        p.adapters[i].sequence, p.adapters[i].reverse, p.adapters[i].clip_length = sequence.encode(), int(reverse), int(clip_length)
+    return p

@@ -25,6 +25,8 @@ typedef struct
     uint32_t n_reads; uint32_t read_length[2];
     uint32_t n_seeds;
     struct { uint16_t offset, length; uint32_t read_index; } seeds[16];
+    uint32_t n_adapters;
+    struct { char sequence[128]; uint32_t reverse, clip_length; } adapters[8];
 } oracle_params;
 
 typedef struct { uint32_t min, max, median, low_std_dev, high_std_dev; int32_t best_model[2]; uint32_t stable, mate_min, mate_max; } oracle_tls;
@@ -56,6 +58,13 @@ static Params toParams(const oracle_params *c)
         offset += c->read_length[r]; firstCycle += c->read_length[r];
     }
     for (unsigned s = 0; s < c->n_seeds; ++s) { SeedMetadata sm = { c->seeds[s].offset, c->seeds[s].length, c->seeds[s].read_index, s }; p.seeds.push_back(sm); }
+    if (c->n_adapters > 8) throw std::runtime_error("at most 8 adapters");
+    for (unsigned a = 0; a < c->n_adapters; ++a)
+    {
+        SequencingAdapterMetadata m; m.sequence.assign(c->adapters[a].sequence, strnlen(c->adapters[a].sequence, sizeof(c->adapters[a].sequence)));
+        m.reverse = 0 != c->adapters[a].reverse; m.clipLength = c->adapters[a].clip_length;
+        p.adapters.push_back(m);
+    }
     return p;
 }
 
@@ -482,12 +491,15 @@ int oracle_fragment_builder2_literal(const char *read, const char *reference, in
         f.cluster = &cluster; f.cigarBuffer = &cigarBuffer;
         Contig contig; contig.index = 0; contig.name = "vasja"; contig.forward.assign(reference, reference + strlen(reference));
         const UngappedAligner ungapped(2, -1, -15, -3, 25);
-        ungapped.alignUngapped(f, cigarBuffer, reads, contig);
+        const SequencingAdapterList noAdapters;
+        FragmentSequencingAdapterClipper adapterClipper(noAdapters);
+        adapterClipper.checkInitStrand(f, contig);
+        ungapped.alignUngapped(f, cigarBuffer, reads, adapterClipper, contig);
         if (gapped)
         {
             const GappedAligner gappedAligner(200, 2, -1, -15, -3, 25);
             FragmentMetadata tmp = f;
-            const unsigned matchCount = gappedAligner.alignGapped(tmp, cigarBuffer, reads, contig);
+            const unsigned matchCount = gappedAligner.alignGapped(tmp, cigarBuffer, reads, adapterClipper, contig);
             if (matchCount + BandedSmithWaterman::WIDEST_GAP_SIZE > f.getObservedLength() && (tmp.mismatchCount <= 5) &&
                 (f.mismatchCount > tmp.mismatchCount) && f.logProbability < tmp.logProbability)
                 f = tmp;
@@ -497,6 +509,50 @@ int oracle_fragment_builder2_literal(const char *read, const char *reference, in
         if (f.cigarLength) memcpy(cigar_out, f.cigarBuffer->data() + f.cigarOffset, f.cigarLength * 4);
         *n_cigar = f.cigarLength;
         *first_mismatch_cycle = f.mismatchCycles.empty() ? 0 : f.mismatchCycles[0];
+        return 0;
+    }
+    catch (const std::exception &e) { g_error = e.what(); return 1; }
+}
+
+// TestSequencingAdapter::align (lib/alignment/cppunit/testSequencingAdapter.cpp:180-203) restated: one read (given in the direction of the reference; a
+// reverse alignment reads it back to front, not complemented -- the test's Read >> operator only reverses) at position 0 of one contig, a fresh
+// FragmentSequencingAdapterClipper over the given adapters, checkInitStrand, alignUngapped.  ELAND scores 2:-1:-15:-3:25.
+int oracle_sequencing_adapter_literal(const char *read, const char *reference, int reverse, uint32_t n_adapters, const char *const *adapter_sequences, const uint32_t *adapter_reverse,
+                                      const uint32_t *adapter_clip_length, oracle_candidate *out, uint32_t *cigar_out, uint64_t cigar_capacity, uint64_t *n_cigar)
+{
+    try
+    {
+        static const std::string irrelevantQualities("CFCEEBFHEHDGBDBEDDEGEHHFHEGBHHDDDB<F>FGGBFGGFGCGGGDGGDDFHHHFEGGBGDGGBGGBEGEGGBGEHDHHHGGGGGDGGGG?GGGGDBEDDEGEHHFHEGBHHDDDB<F>FGGBFGGFGCGGGDGGDDFHHHFEGGBGDGDBEDDEGEHHFHEGBHHDDDB<F>FGGBFGGFGCGGGDGGDDFHHHFEGGBGDG");
+        std::string r(read); if (reverse) std::reverse(r.begin(), r.end());
+        if (r.size() > irrelevantQualities.size()) throw std::runtime_error("read longer than the test's quality string");
+        Cluster cluster; cluster.nReads = 1;
+        Read &rd = cluster[0];
+        rd.forwardSequence.assign(r.begin(), r.end());
+        rd.forwardQuality.assign(irrelevantQualities.begin(), irrelevantQualities.begin() + r.size());
+        for (size_t i = 0; i < rd.forwardQuality.size(); ++i) rd.forwardQuality[i] -= 33;
+        rd.reverseSequence = rd.forwardSequence; rd.reverseQuality = rd.forwardQuality;
+        std::reverse(rd.reverseSequence.begin(), rd.reverseSequence.end()); std::reverse(rd.reverseQuality.begin(), rd.reverseQuality.end());
+        // (the test's ReadMetadata says 100 cycles whatever the read's length: only the mismatch cycle numbers depend on it)
+        std::vector<ReadMetadata> reads; { ReadMetadata a = { 100, 0, 0, 1 }, b = { 100, 1, 100, 101 }; reads.push_back(a); reads.push_back(b); }
+        SequencingAdapterList adapters;
+        for (uint32_t a = 0; a < n_adapters; ++a)
+        {
+            SequencingAdapterMetadata m; m.sequence = adapter_sequences[a]; m.reverse = 0 != adapter_reverse[a]; m.clipLength = adapter_clip_length[a];
+            adapters.push_back(SequencingAdapter(m));
+        }
+        FragmentMetadata f; f.reverse = reverse != 0;
+        f.contigId = 0; f.position = 0;
+        Cigar cigarBuffer; cigarBuffer.reserve(1024);
+        f.cluster = &cluster; f.cigarBuffer = &cigarBuffer;
+        Contig contig; contig.index = 0; contig.name = "vasja"; contig.forward.assign(reference, reference + strlen(reference));
+        const UngappedAligner ungapped(2, -1, -15, -3, 25);
+        FragmentSequencingAdapterClipper adapterClipper(adapters);
+        adapterClipper.checkInitStrand(f, contig);
+        ungapped.alignUngapped(f, cigarBuffer, reads, adapterClipper, contig);
+        fillCandidate(*out, f, 0, 0);
+        if (f.cigarLength > cigar_capacity) throw std::runtime_error("cigar capacity");
+        if (f.cigarLength) memcpy(cigar_out, f.cigarBuffer->data() + f.cigarOffset, f.cigarLength * 4);
+        *n_cigar = f.cigarLength;
         return 0;
     }
     catch (const std::exception &e) { g_error = e.what(); return 1; }
@@ -538,7 +594,10 @@ int oracle_semialigned_clip_literal(const char *read, const char *reference, int
         contigs.push_back(literalContig(reference, offset));
         f.position = offset;
         const UngappedAligner ungapped(2, -1, -15, -3, 25);
-        ungapped.alignUngapped(f, cigarBuffer, reads, contigs[0]);
+        const SequencingAdapterList noAdapters;
+        FragmentSequencingAdapterClipper adapterClipper(noAdapters);
+        adapterClipper.checkInitStrand(f, contigs[0]);
+        ungapped.alignUngapped(f, cigarBuffer, reads, adapterClipper, contigs[0]);
         SemialignedEndsClipper clipper; clipper.cigarBuffer.reserve(1024);
         clipper.clip(contigs, f);
         if (f.cigarLength > cigar_capacity) throw std::runtime_error("cigar capacity");

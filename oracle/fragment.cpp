@@ -129,6 +129,190 @@ unsigned FragmentMetadata::getMappedLength() const
     return ret;
 }
 
+// ---------------------------------------------------------------- sequencing adapters
+// lib/alignment/matchSelector/SequencingAdapter.cpp:30-56: where each 5-mer of the adapter starts; a 5-mer that occurs twice is of no use
+SequencingAdapter::SequencingAdapter(const SequencingAdapterMetadata &m)
+    : metadata(m), kmerPositions(getMaxKmer<unsigned>(adapterMatchBasesMin) + 1, char(UNINITIALIZED_POSITION))
+{
+    if (metadata.sequence.size() >= 127) throw std::logic_error("Adapter sequence is too long");
+    if (!(metadata.isUnbounded() || metadata.sequence.size() <= metadata.clipLength)) throw std::logic_error("Clip length cannot be shorter than the adapter sequence");
+    const char *begin = metadata.sequence.data();
+    KmerGenerator<unsigned short> kmerGenerator(begin, begin + metadata.sequence.size(), adapterMatchBasesMin);
+    const char *position = begin;
+    unsigned short kmer = 0;
+    while (kmerGenerator.next(kmer, position))
+    {
+        char &pos = kmerPositions.at(kmer);
+        if (UNINITIALIZED_POSITION == pos) pos = char(position - begin);
+        else if (NON_UNIQUE_KMER_POSITION != pos) pos = NON_UNIQUE_KMER_POSITION;
+    }
+}
+
+// SequencingAdapter.cpp:58-141.  sequenceBegin is where the caller's search began (not the read's first base): an adapter that starts before it
+// counts as "before the sequence"
+std::pair<long, long> SequencingAdapter::getMatchRange(const char *sequence, const long sequenceBegin, const long sequenceEnd, const long mismatchBase) const
+{
+    unsigned short kmer = 0;
+    if (generateKmer(adapterMatchBasesMin, kmer, sequence + mismatchBase, sequence + sequenceEnd))
+    {
+        const char pos = kmerPositions[kmer];
+        if (0 <= pos)
+        {
+            const unsigned mismatchBaseOffset = unsigned(mismatchBase - sequenceBegin);
+            const unsigned adapterBasesBeforeSequence = mismatchBaseOffset < unsigned(pos) ? pos - mismatchBaseOffset : 0;
+            if (!adapterBasesBeforeSequence || !metadata.isUnbounded())
+            {
+                const long testBase = mismatchBase - (pos - long(adapterBasesBeforeSequence));
+                const unsigned testSequenceLength = unsigned(sequenceEnd - testBase);
+                const unsigned adapterSequenceSize = unsigned(metadata.sequence.size());
+                const unsigned leftClippedAdapterLength = adapterSequenceSize - adapterBasesBeforeSequence;
+                const unsigned overlapLength = std::min<unsigned>(testSequenceLength, leftClippedAdapterLength);
+                if (overlapLength < leftClippedAdapterLength && metadata.isUnbounded() && metadata.reverse)
+                {
+                    // unbounded adapter begins after the reverse sequence: ignored
+                }
+                else if (overlapLength >= adapterMatchBasesMin && !metadata.sequence.compare(adapterBasesBeforeSequence, overlapLength, sequence + testBase, overlapLength))
+                {
+                    if (metadata.reverse)
+                        return metadata.isUnbounded() ?
+                            std::make_pair(sequenceBegin, testBase + long(overlapLength)) :
+                            std::make_pair(testBase - long(std::min<unsigned>(unsigned(testBase - sequenceBegin), metadata.clipLength - adapterSequenceSize)), testBase + long(overlapLength));
+                    return metadata.isUnbounded() ?
+                        std::make_pair(testBase, sequenceEnd) :
+                        std::make_pair(testBase, testBase + long(std::min(overlapLength, metadata.clipLength)));
+                }
+            }
+        }
+    }
+    return std::make_pair(mismatchBase, mismatchBase);
+}
+
+// FragmentSequencingAdapterClipper.cpp:76-97: at every base that does not match the reference, is this where an adapter shows?
+static std::pair<long, long> findSequencingAdapter(const char *sequence, const long sequenceBegin, const long sequenceEnd, const std::vector<char> &reference, long referenceBegin,
+                                                   const SequencingAdapter &adapter)
+{
+    for (long currentBase = sequenceBegin, currentReference = referenceBegin; sequenceEnd != currentBase; ++currentReference, ++currentBase)
+    {
+        if (!isMatch(sequence[currentBase], reference[currentReference]))
+        {
+            const std::pair<long, long> adapterMatchRange = adapter.getMatchRange(sequence, sequenceBegin, sequenceEnd, currentBase);
+            if (adapterMatchRange.first != adapterMatchRange.second) return adapterMatchRange;
+        }
+    }
+    return std::make_pair(sequenceBegin, sequenceBegin);
+}
+
+// FragmentSequencingAdapterClipper.cpp:103-150 (clipReference of :41-58 inlined): the first fragment of a strand that comes by decides where the
+// strand's adapter lies, for every later fragment of that strand as well
+void FragmentSequencingAdapterClipper::checkInitStrand(const FragmentMetadata &fragmentMetadata, const Contig &contig)
+{
+    const bool reverse = fragmentMetadata.reverse;
+    Range &range = strandRange[reverse];
+    if (range.initialized) return;
+    const std::vector<char> &reference = contig.forward;
+    const std::vector<char> &sequence = fragmentMetadata.getRead().getStrandSequence(reverse);
+    long sequenceBegin = 0, sequenceEnd = long(sequence.size());
+    const long referenceLeft = long(reference.size()) - fragmentMetadata.position;
+    if (referenceLeft < sequenceEnd - sequenceBegin) sequenceEnd = sequenceBegin + referenceLeft;
+    long newFragmentPos = fragmentMetadata.position;
+    if (0 > fragmentMetadata.position) { sequenceBegin -= fragmentMetadata.position; newFragmentPos = 0; }
+    range.begin = sequenceEnd;
+    range.end = sequenceBegin;
+    for (const SequencingAdapter &adapter : sequencingAdapters)
+    {
+        if (!adapter.isStrandCompatible(reverse)) continue;
+        // (a read that lies wholly outside the contig: the reference's loop would run off its iterators; no candidate is made like that)
+        if (range.end >= sequenceEnd) continue;
+        const std::pair<long, long> adapterMatchRange = findSequencingAdapter(sequence.data(), range.end, sequenceEnd, reference, newFragmentPos + (range.end - sequenceBegin), adapter);
+        if (adapterMatchRange.first != adapterMatchRange.second)
+        {
+            range.begin = std::min(adapterMatchRange.first, range.begin);
+            range.end = std::max(adapterMatchRange.second, range.end);
+        }
+    }
+    range.initialized = true;
+    range.empty = sequenceBegin == range.end;
+}
+
+// Alignment.hh:91-146 over offsets; a reference index outside the contig compares as 'N'.  (The reference forms reference.begin() + contigPosition
+// without looking: for a fragment other than the strand's first one that hangs over the contig's start it reads what lies in front of the vector --
+// undefined there, defined here, the same way in the device code.)
+static char referenceBaseOrN(const std::vector<char> &reference, long i) { return (i < 0 || i >= long(reference.size())) ? 'N' : reference[i]; }
+static unsigned countAdapterMatches(const char *sequence, long sequenceBegin, long sequenceEnd, const std::vector<char> &reference, long referenceBegin, long referenceEnd, bool matches)
+{
+    unsigned ret = 0;
+    for (; sequenceEnd != sequenceBegin && referenceEnd != referenceBegin; ++sequenceBegin, ++referenceBegin)
+        ret += matches == isMatch(sequence[sequenceBegin], referenceBaseOrN(reference, referenceBegin));
+    return ret;
+}
+static unsigned percentMismatches(const char *sequence, long sequenceBegin, long sequenceEnd, const std::vector<char> &reference, long referenceBegin, long referenceEnd)
+{
+    const unsigned overlapLength = unsigned(std::min(sequenceEnd - sequenceBegin, referenceEnd - referenceBegin));
+    return countAdapterMatches(sequence, sequenceBegin, sequenceEnd, reference, referenceBegin, referenceEnd, false) * 100 / overlapLength;
+}
+
+// FragmentSequencingAdapterClipper.cpp:152-222
+bool FragmentSequencingAdapterClipper::decideWhichSideToClip(const Contig &contig, const long contigPosition, const char *sequence, const long sequenceLengthL, const Range &range,
+                                                             bool &clipBackwards)
+{
+    const unsigned backwardsClipped = unsigned(range.begin);
+    const unsigned forwardsClipped = unsigned(sequenceLengthL - range.end);
+    clipBackwards = backwardsClipped < forwardsClipped;
+    const unsigned sequenceLength = unsigned(sequenceLengthL);
+    const std::vector<char> &reference = contig.forward;
+    // abs(unsigned - unsigned): the only abs in scope in the reference's translation unit is ::abs(int) of <stdlib.h> (with more than one it would not
+    // compile: the call is ambiguous for an unsigned argument), so the difference wraps to int and this is |backwards - forwards| < 9
+    if (backwardsClipped && forwardsClipped && std::abs(int(backwardsClipped - forwardsClipped)) < 9)
+    {
+        if (contigPosition >= 0 && reference.size() >= unsigned(contigPosition + sequenceLength))
+        {
+            const long referenceBegin = contigPosition, referenceEnd = referenceBegin + sequenceLength;
+            const unsigned backwardsMatches = countAdapterMatches(sequence, 0, range.begin, reference, referenceBegin, referenceBegin + backwardsClipped, true);
+            const unsigned forwardsMatches = countAdapterMatches(sequence, range.end, sequenceLengthL, reference, referenceEnd - forwardsClipped, referenceEnd, true);
+            clipBackwards = (backwardsMatches < forwardsMatches || (backwardsMatches == forwardsMatches && backwardsClipped < forwardsClipped));
+        }
+    }
+    else if (!backwardsClipped || !forwardsClipped)
+    {
+        const long referenceBegin = contigPosition, referenceEnd = referenceBegin + sequenceLength;
+        if (clipBackwards && !backwardsClipped)
+        {
+            const unsigned basesClipped = unsigned(range.end);
+            return percentMismatches(sequence, 0, range.end, reference, referenceBegin, referenceBegin + basesClipped) > TOO_GOOD_READ_MISMATCH_PERCENT;
+        }
+        else if (!clipBackwards && !forwardsClipped)
+        {
+            const unsigned basesClipped = unsigned(sequenceLengthL - range.begin);
+            return percentMismatches(sequence, range.begin, sequenceLengthL, reference, referenceEnd - basesClipped, referenceEnd) > TOO_GOOD_READ_MISMATCH_PERCENT;
+        }
+    }
+    return true;
+}
+
+// FragmentSequencingAdapterClipper.cpp:230-278
+void FragmentSequencingAdapterClipper::clip(const Contig &contig, FragmentMetadata &fragment, const char *&sequenceBegin, const char *&sequenceEnd) const
+{
+    const Range &range = strandRange[fragment.reverse];
+    if (!range.initialized) throw std::logic_error("checkInitStrand has not been called");
+    if (range.empty) return;
+    const long sequenceLength = sequenceEnd - sequenceBegin;
+    if (range.begin < 0 || range.begin > sequenceLength || range.end < 0 || range.end > sequenceLength) throw std::logic_error("adapter range is outside the sequence");
+    bool clipBackwards = false;
+    if (decideWhichSideToClip(contig, fragment.position, sequenceBegin, sequenceLength, range, clipBackwards))
+    {
+        if (clipBackwards)
+        {
+            fragment.incrementClipLeft((unsigned short)(range.end));
+            sequenceBegin += range.end;
+        }
+        else
+        {
+            fragment.incrementClipRight((unsigned short)(sequenceLength - range.begin));
+            sequenceEnd = sequenceBegin + range.begin;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- AlignerBase
 // lib/alignment/fragmentBuilder/AlignerBase.cpp:50-82
 void AlignerBase::clipReference(long referenceSize, FragmentMetadata &fragment, const char *&sequenceBegin, const char *&sequenceEnd)
@@ -237,8 +421,9 @@ unsigned AlignerBase::updateFragmentCigar(const std::vector<ReadMetadata> &reads
     return matchCount;
 }
 
-// lib/alignment/fragmentBuilder/UngappedAligner.cpp:39-92 (no sequencing adapters: clip() is a no-op for an empty adapter list)
-unsigned UngappedAligner::alignUngapped(FragmentMetadata &f, Cigar &cigarBuffer, const std::vector<ReadMetadata> &reads, const Contig &contig) const
+// lib/alignment/fragmentBuilder/UngappedAligner.cpp:39-92
+unsigned UngappedAligner::alignUngapped(FragmentMetadata &f, Cigar &cigarBuffer, const std::vector<ReadMetadata> &reads, const FragmentSequencingAdapterClipper &adapterClipper,
+                                        const Contig &contig) const
 {
     const unsigned cigarOffset = unsigned(cigarBuffer.size());
     f.resetAlignment(cigarBuffer);
@@ -248,6 +433,7 @@ unsigned UngappedAligner::alignUngapped(FragmentMetadata &f, Cigar &cigarBuffer,
     const std::vector<char> &reference = contig.forward;
     const char *sequenceBegin = sequence.data();
     const char *sequenceEnd = sequence.data() + sequence.size();
+    adapterClipper.clip(contig, f, sequenceBegin, sequenceEnd);
     clipReadMasking(read, f, sequenceBegin, sequenceEnd);
     clipReference(long(reference.size()), f, sequenceBegin, sequenceEnd);
     const unsigned firstMappedBaseOffset = unsigned(sequenceBegin - sequence.data());
@@ -279,7 +465,8 @@ static std::pair<unsigned, unsigned> getFlanks(long strandPosition, unsigned rea
 }
 
 // GappedAligner.cpp:167-249
-unsigned GappedAligner::alignGapped(FragmentMetadata &f, Cigar &cigarBuffer, const std::vector<ReadMetadata> &reads, const Contig &contig) const
+unsigned GappedAligner::alignGapped(FragmentMetadata &f, Cigar &cigarBuffer, const std::vector<ReadMetadata> &reads, const FragmentSequencingAdapterClipper &adapterClipper,
+                                    const Contig &contig) const
 {
     const unsigned cigarOffset = unsigned(cigarBuffer.size());
     f.resetAlignment(cigarBuffer);
@@ -289,6 +476,7 @@ unsigned GappedAligner::alignGapped(FragmentMetadata &f, Cigar &cigarBuffer, con
     const std::vector<char> &reference = contig.forward;
     const char *sequenceBegin = sequence.data();
     const char *sequenceEnd = sequence.data() + sequence.size();
+    adapterClipper.clip(contig, f, sequenceBegin, sequenceEnd);
     clipReadMasking(read, f, sequenceBegin, sequenceEnd);
     clipReference(long(reference.size()), f, sequenceBegin, sequenceEnd);
     const unsigned firstMappedBaseOffset = unsigned(sequenceBegin - sequence.data());
@@ -529,6 +717,7 @@ FragmentBuilder::FragmentBuilder(const Params &p)
       gappedAligner(int(p.clusterLength()), p.gapMatchScore, p.gapMismatchScore, p.gapOpenScore, p.gapExtendScore, p.minGapExtendScore),
       simpleIndelAligner(p.gapMatchScore, p.gapMismatchScore, p.gapOpenScore, p.gapExtendScore, p.minGapExtendScore, p.semialignedGapLimit)
 {
+    for (const SequencingAdapterMetadata &m : p.adapters) sequencingAdapters.push_back(SequencingAdapter(m));
     // the reference reserves the cigar buffer so that it never reallocates (pointers into it stay valid): FragmentBuilder.cpp:56-58
     cigarBuffer.reserve(1 << 16);
 }
@@ -623,11 +812,13 @@ void FragmentBuilder::alignFragments(const ContigList &contigs, const std::vecto
         FragmentMetadataList &fragmentList = fragments[r];
         if (fragmentList.empty()) continue;
         consolidateDuplicateFragments(fragmentList, false);
+        FragmentSequencingAdapterClipper adapterClipper(sequencingAdapters);      // one per read: FragmentBuilder.cpp:164
         for (size_t i = 0; i < fragmentList.size(); ++i)
         {
             FragmentMetadata &f = fragmentList[i];
             f.repeatSeedsCount = repeatSeedsCount;
-            ungappedAligner.alignUngapped(f, cigarBuffer, reads, contigs.at(f.contigId));
+            adapterClipper.checkInitStrand(f, contigs.at(f.contigId));
+            ungappedAligner.alignUngapped(f, cigarBuffer, reads, adapterClipper, contigs.at(f.contigId));
         }
         consolidateDuplicateFragments(fragmentList, true);
         if (semialignedGapLimit)
@@ -638,10 +829,11 @@ void FragmentBuilder::alignFragments(const ContigList &contigs, const std::vecto
         for (size_t i = 0; i < fragmentList.size(); ++i)
         {
             FragmentMetadata &f = fragmentList[i];
+            adapterClipper.checkInitStrand(f, contigs[f.contigId]);       // (:195; every strand on the list was initialised by the loop above)
             if (withGaps && BandedSmithWaterman::mismatchesCutoff < f.mismatchCount)
             {
                 FragmentMetadata tmp = f;
-                const unsigned matchCount = gappedAligner.alignGapped(tmp, cigarBuffer, reads, contigs[f.contigId]);
+                const unsigned matchCount = gappedAligner.alignGapped(tmp, cigarBuffer, reads, adapterClipper, contigs[f.contigId]);
                 if (matchCount && matchCount + BandedSmithWaterman::WIDEST_GAP_SIZE > f.getObservedLength() &&
                     (tmp.mismatchCount <= gappedMismatchesMax) && (f.mismatchCount > tmp.mismatchCount) &&
                     LP_LESS(f.logProbability, tmp.logProbability))

@@ -113,8 +113,16 @@ std::vector<SeedMetadata> autoSeeds(bool detectSimpleIndels, const std::vector<R
 std::vector<std::vector<unsigned> > seedIndexListPerIteration(const std::vector<SeedMetadata> &seeds, unsigned nReads, unsigned firstPassSeeds);
 
 // ---------------------------------------------------------------- parameters
+// include/flowcell/SequencingAdapterMetadata.hh:33-73: sequence in the direction of the reference; reverse: the strand it is expected on; clipLength 0 = unbounded
+// ("ACGT*" / "*ACGT" of --default-adapters, lib/options/AlignOptions.cpp:189-207)
+struct SequencingAdapterMetadata
+{
+    std::string sequence; bool reverse; unsigned clipLength;
+    bool isUnbounded() const { return !clipLength; }
+};
 struct Params
 {
+    std::vector<SequencingAdapterMetadata> adapters;      // --default-adapters of the flowcell (empty: nothing is clipped)
     int gapMatchScore = 0, gapMismatchScore = -3, gapOpenScore = -11, gapExtendScore = -4, minGapExtendScore = -20; // AlignOptions.cpp:55 "bwa"
     unsigned repeatThreshold = 10;          // AlignOptions.cpp:94
     unsigned gappedMismatchesMax = 5;       // AlignOptions.cpp:124
@@ -302,6 +310,32 @@ struct FragmentMetadata
 };
 typedef std::vector<FragmentMetadata> FragmentMetadataList;
 
+// lib/alignment/matchSelector/SequencingAdapter.cpp:30-141, include/alignment/matchSelector/SequencingAdapter.hh:37-69
+struct SequencingAdapter
+{
+    static constexpr unsigned adapterMatchBasesMin = 5;
+    static constexpr char UNINITIALIZED_POSITION = -1, NON_UNIQUE_KMER_POSITION = -2;
+    SequencingAdapterMetadata metadata;
+    std::vector<char> kmerPositions;
+    explicit SequencingAdapter(const SequencingAdapterMetadata &m);
+    // offsets into the strand sequence instead of iterators: [first, second), first == second: not found
+    std::pair<long, long> getMatchRange(const char *sequence, long sequenceBegin, long sequenceEnd, long mismatchBase) const;
+    bool isStrandCompatible(bool reverse) const { return !metadata.isUnbounded() || reverse == metadata.reverse; }
+};
+typedef std::vector<SequencingAdapter> SequencingAdapterList;
+
+// lib/alignment/matchSelector/FragmentSequencingAdapterClipper.cpp:41-282, include/.../FragmentSequencingAdapterClipper.hh:34-86
+struct FragmentSequencingAdapterClipper
+{
+    static constexpr unsigned TOO_GOOD_READ_MISMATCH_PERCENT = 40;
+    const SequencingAdapterList &sequencingAdapters;
+    struct Range { bool initialized = false, empty = true; long begin = 0, end = 0; } strandRange[2];
+    explicit FragmentSequencingAdapterClipper(const SequencingAdapterList &a) : sequencingAdapters(a) {}
+    void checkInitStrand(const FragmentMetadata &fragmentMetadata, const Contig &contig);
+    void clip(const Contig &contig, FragmentMetadata &fragment, const char *&sequenceBegin, const char *&sequenceEnd) const;
+    static bool decideWhichSideToClip(const Contig &contig, long contigPosition, const char *sequence, long sequenceLength, const Range &range, bool &clipBackwards);
+};
+
 // lib/alignment/fragmentBuilder/AlignerBase.cpp
 struct AlignerBase
 {
@@ -318,14 +352,14 @@ struct AlignerBase
 struct UngappedAligner : AlignerBase
 {
     UngappedAligner(int a, int b, int c, int d, int e) : AlignerBase(a, b, c, d, e) {}
-    unsigned alignUngapped(FragmentMetadata &f, Cigar &cigarBuffer, const std::vector<ReadMetadata> &reads, const Contig &contig) const;
+    unsigned alignUngapped(FragmentMetadata &f, Cigar &cigarBuffer, const std::vector<ReadMetadata> &reads, const FragmentSequencingAdapterClipper &adapterClipper, const Contig &contig) const;
 };
 // lib/alignment/fragmentBuilder/GappedAligner.cpp:51-82,167-249 (--avoid-smith-waterman 0 only)
 struct GappedAligner : AlignerBase
 {
     BandedSmithWaterman bsw;
     GappedAligner(int maxTotalReadLength, int a, int b, int c, int d, int e) : AlignerBase(a, b, c, d, e), bsw(a, b, -c, -d, maxTotalReadLength) {}
-    unsigned alignGapped(FragmentMetadata &f, Cigar &cigarBuffer, const std::vector<ReadMetadata> &reads, const Contig &contig) const;
+    unsigned alignGapped(FragmentMetadata &f, Cigar &cigarBuffer, const std::vector<ReadMetadata> &reads, const FragmentSequencingAdapterClipper &adapterClipper, const Contig &contig) const;
 };
 // lib/alignment/fragmentBuilder/SimpleIndelAligner.cpp
 struct SimpleIndelAligner : AlignerBase
@@ -350,6 +384,7 @@ struct FragmentBuilder
     std::vector<FragmentMetadataList> fragments; // [2]
     Cigar cigarBuffer;
     UngappedAligner ungappedAligner; GappedAligner gappedAligner; SimpleIndelAligner simpleIndelAligner;
+    SequencingAdapterList sequencingAdapters;      // (the reference passes the flowcell's list into build(); one flowcell here)
     FragmentBuilder(const Params &p);
     bool build(const ContigList &contigs, const std::vector<ReadMetadata> &reads, const std::vector<SeedMetadata> &seeds,
                const Match *matchBegin, const Match *matchEnd, const Cluster &cluster, bool withGaps);
@@ -556,6 +591,7 @@ struct ShadowAligner
 {
     static constexpr unsigned shadowKmerLength = 7, shadowKmerCount = 1 << 14, candidatePositionsMax = 10000;
     unsigned gappedMismatchesMax; UngappedAligner ungappedAligner; GappedAligner gappedAligner;
+    SequencingAdapterList sequencingAdapters;
     std::vector<short> shadowKmerPositions; Cigar shadowCigarBuffer; std::vector<long> shadowCandidatePositions;
     ShadowAligner(const Params &p);
     bool rescueShadow(const ContigList &contigs, const FragmentMetadata &orphan, FragmentMetadataList &shadowList, size_t shadowListCapacity,

@@ -218,6 +218,7 @@ ShadowAligner::ShadowAligner(const Params &p)
       ungappedAligner(p.gapMatchScore, p.gapMismatchScore, p.gapOpenScore, p.gapExtendScore, p.minGapExtendScore),
       gappedAligner(int(p.clusterLength()), p.gapMatchScore, p.gapMismatchScore, p.gapOpenScore, p.gapExtendScore, p.minGapExtendScore)
 {
+    for (const SequencingAdapterMetadata &m : p.adapters) sequencingAdapters.push_back(SequencingAdapter(m));
     shadowCigarBuffer.reserve(1 << 20);
 }
 
@@ -291,6 +292,7 @@ bool ShadowAligner::rescueShadow(const ContigList &contigList, const FragmentMet
                                  reference.data() + std::min((long)reference.size(), range.second + 1), shadowSequence);
     shadowList.clear();
     shadowList.reserve(shadowListCapacity); // pointers into the list must stay valid (the reference pre-reserves 1000)
+    FragmentSequencingAdapterClipper adapterClipper(sequencingAdapters);       // ShadowAligner.cpp:207: one per rescue, the first candidate position decides
     FragmentMetadata *bestFragment = 0;
     for (size_t c = 0; c < shadowCandidatePositions.size(); ++c)
     {
@@ -301,7 +303,8 @@ bool ShadowAligner::rescueShadow(const ContigList &contigList, const FragmentMet
         fragment.reverse = shadowReverse;
         fragment.contigId = orphan.contigId;
         fragment.position = strandPosition;
-        if (ungappedAligner.alignUngapped(fragment, shadowCigarBuffer, reads, contig))
+        adapterClipper.checkInitStrand(fragment, contig);
+        if (ungappedAligner.alignUngapped(fragment, shadowCigarBuffer, reads, adapterClipper, contig))
         {
             shadowList.push_back(fragment);
             if (0 == bestFragment || LP_LESS(bestFragment->logProbability, fragment.logProbability)) bestFragment = &shadowList.back();
@@ -318,7 +321,7 @@ bool ShadowAligner::rescueShadow(const ContigList &contigList, const FragmentMet
                 if (BandedSmithWaterman::mismatchesCutoff < fragment.mismatchCount)
                 {
                     FragmentMetadata tmp = fragment;
-                    const unsigned matchCount = gappedAligner.alignGapped(tmp, shadowCigarBuffer, reads, contig);
+                    const unsigned matchCount = gappedAligner.alignGapped(tmp, shadowCigarBuffer, reads, adapterClipper, contig);
                     if (matchCount && matchCount + BandedSmithWaterman::WIDEST_GAP_SIZE > fragment.getObservedLength() &&
                         (tmp.mismatchCount <= gappedMismatchesMax) && (fragment.mismatchCount > tmp.mismatchCount) &&
                         LP_LESS(fragment.logProbability, tmp.logProbability))

@@ -8,6 +8,7 @@ Run in the build container only (it reads /root/reference, which does not exist 
 What is extracted is DATA: the literal inputs and the asserted outputs of
   * lib/alignment/cppunit/testSimpleIndelAligner.cpp:264-615   -> simple_indel.json
   * lib/alignment/cppunit/testFragmentBuilder2.cpp:183-307     -> fragment_builder2.json
+  * lib/alignment/cppunit/testSequencingAdapter.cpp:41-515 (+ the presets of lib/flowcell/SequencingAdapterMetadata.cpp:29-39) -> sequencing_adapter.json
   * lib/alignment/cppunit/testBandedSmithWaterman.cpp:79-225   -> bsw.json (the construction recipe of the test is re-run here
     on genomes drawn with glibc rand() exactly like getGenome() at :33-43; the asserted CIGARs are the test's literals)
   * lib/alignment/cppunit/testSeedId.cpp                        -> seed_id.json
@@ -181,6 +182,55 @@ def make_fragment_builder2():
     assert len(cases) == 5, len(cases)
     json.dump({"source": "lib/alignment/cppunit/testFragmentBuilder2.cpp:183-307", "scores": [2, -1, -15, -3, 25], "cases": cases},
               open(os.path.join(OUT, "fragment_builder2.json"), "w"), indent=1)
+    return len(cases)
+
+
+def make_sequencing_adapter():
+    """testSequencingAdapter.cpp: the adapter pairs the suite constructs, and for each test that testEverything() runs its read, reference, strand, adapter list
+    and every value it asserts; plus the three --default-adapters presets (flowcell/SequencingAdapterMetadata.cpp) as data"""
+    text = strip_comments(open(os.path.join(REF, "testSequencingAdapter.cpp")).read())
+    metadata = {}
+    for m in re.finditer(r"SequencingAdapterMetadata\s+(\w+)\(\s*\"([ACGT]+)\"\s*,\s*(true|false)\s*,\s*(strlen\(\"([ACGT]+)\"\)|\d+)\s*\)", text):
+        name, sequence, reverse, clip = m.group(1), m.group(2), m.group(3) == "true", m.group(4)
+        metadata[name] = {"sequence": sequence, "reverse": reverse, "clip_length": len(m.group(5)) if clip.startswith("strlen") else int(clip)}
+    lists = {}
+    for m in re.finditer(r"(\w+)\s*=\s*boost::assign::list_of\(isaac::alignment::matchSelector::SequencingAdapter\((\w+)\)\)\s*\(isaac::alignment::matchSelector::SequencingAdapter\((\w+)\)\)", text):
+        lists[m.group(1)] = [metadata[m.group(2)], metadata[m.group(3)]]
+    assert sorted(lists) == ["matePairAdapters", "standardAdapters"], lists
+    everything = text[text.index("void TestSequencingAdapter::testEverything()"):]
+    everything = everything[:everything.index("}")]
+    run = re.findall(r"\b(test\w+)\(\);", everything)
+    cases = []
+    for fm in re.finditer(r"void TestSequencingAdapter::(test\w+)\(\)\s*\{", text):
+        name = fm.group(1)
+        if name == "testEverything":
+            continue
+        b = fm.end()
+        _, e = enclosing_block(text, b)
+        body = text[b:e]
+        m = re.search(r"\balign\(", body)
+        argtext, end = find_call(body, m.end())
+        args = split_args(argtext)
+        assert len(args) == 4 and args[2][1] in lists, args
+        case = {"name": name, "read": args[0][1], "reference": args[1][1], "adapters": args[2][1], "reverse": "reverse = true" in body[:m.start()], "expect": {}}
+        for am in re.finditer(r"CPPUNIT_ASSERT_EQUAL\((.*?),\s*fragmentMetadata\.(\w+)\(\)\);", body[end:]):
+            expected, what = am.group(1).strip(), am.group(2)
+            sm = re.match(r'std::string\("(.*)"\)', expected)
+            rp = re.match(r"isaac::reference::ReferencePosition\((\d+),\s*(\d+)U?\)", expected)
+            case["expect"][what] = sm.group(1) if sm else [int(rp.group(1)), int(rp.group(2))] if rp else int(re.match(r"(\d+)", expected).group(1))
+        assert "getCigarString" in case["expect"], body
+        cases.append(case)
+    assert sorted(c["name"] for c in cases) == sorted(run) and len(cases) == 15, (len(cases), run)
+    presets_text = strip_comments(open("/root/reference/src/c++/lib/flowcell/SequencingAdapterMetadata.cpp").read())
+    presets = {}
+    for m in re.finditer(r"SequencingAdapterMetadataList\s+(\w+)\s*=(.*?);", presets_text, flags=re.S):
+        entries = []
+        for a in re.finditer(r"SequencingAdapterMetadata\(\"([ACGT]+)\"\s*,\s*(true|false)\s*(?:,\s*(\d+))?\)", m.group(2)):
+            entries.append({"sequence": a.group(1), "reverse": a.group(2) == "true", "clip_length": len(a.group(1)) if a.group(3) is None else int(a.group(3))})
+        presets[m.group(1)] = entries
+    assert sorted(presets) == ["NEXTERA_MATEPAIR_ADAPTERS", "NEXTERA_STANDARD_ADAPTERS", "STANDARD_ADAPTERS"], presets
+    json.dump({"source": "lib/alignment/cppunit/testSequencingAdapter.cpp:41-515, lib/flowcell/SequencingAdapterMetadata.cpp:29-39", "scores": [2, -1, -15, -3, 25],
+               "adapter_lists": lists, "presets": presets, "cases": cases}, open(os.path.join(OUT, "sequencing_adapter.json"), "w"), indent=1)
     return len(cases)
 
 
@@ -866,5 +916,6 @@ if __name__ == "__main__":
     print("template_length_statistics asserts:", make_template_length_statistics())
     print("simple_indel cases:", make_simple_indel())
     print("fragment_builder2 cases:", make_fragment_builder2())
+    print("sequencing_adapter cases:", make_sequencing_adapter())
     print("bsw cases:", make_bsw())
     print("seed_id:", make_seed_id())

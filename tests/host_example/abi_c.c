@@ -16,7 +16,7 @@ any_function isaac_gpu_entry_points[] = {
     (any_function)isaac_gpu_bam_records, (any_function)isaac_gpu_bam_last_error, (any_function)isaac_gpu_bam_header, (any_function)isaac_gpu_bgzf_bound,
     (any_function)isaac_gpu_bgzf_compress, (any_function)isaac_gpu_fastq_tile_clusters_max, (any_function)isaac_gpu_fastq_tiles, (any_function)isaac_gpu_bgzf_store_bound, (any_function)isaac_gpu_bgzf_store, (any_function)isaac_gpu_share_index, (any_function)isaac_gpu_bin_tile, (any_function)isaac_gpu_bin_tile_map, (any_function)isaac_gpu_resolve_flagged, (any_function)isaac_gpu_set_host_contigs, (any_function)isaac_gpu_download_async, (any_function)isaac_gpu_download_wait, (any_function)isaac_gpu_share_reference, (any_function)isaac_gpu_bam_indexer_create, (any_function)isaac_gpu_bam_indexer_add, (any_function)isaac_gpu_bam_indexer_add_entries, (any_function)isaac_gpu_bam_indexer_finish, (any_function)isaac_gpu_bam_indexer_destroy, (any_function)isaac_gpu_bgzf_deflate_bound, (any_function)isaac_gpu_bgzf_deflate,
     (any_function)isaac_gpu_copy, (any_function)isaac_gpu_bam_index, (any_function)isaac_gpu_bam_index_last_error, (any_function)isaac_gpu_default_params,
-    (any_function)isaac_gpu_parse_gap_scoring, (any_function)isaac_gpu_parse_seeds, (any_function)isaac_gpu_params_last_error,
+    (any_function)isaac_gpu_parse_gap_scoring, (any_function)isaac_gpu_parse_seeds, (any_function)isaac_gpu_parse_adapters, (any_function)isaac_gpu_params_last_error,
 };
 size_t isaac_gpu_entry_point_count(void) { return sizeof(isaac_gpu_entry_points) / sizeof(isaac_gpu_entry_points[0]); }
 int isaac_gpu_struct_sizes_ok(void)

@@ -28,6 +28,7 @@ struct Emu
     DevParams P; DevReference R;
     std::vector<char> bases; std::vector<u64> offsets; std::vector<u8> loaded;
     std::vector<double> logMatch, logMismatch;
+    DevAdapters adapters; std::vector<u32> adapterRanges;        // --default-adapters: the list, and four ranges per cluster (k_adapter_ranges)
     std::vector<ClusterStore> stores;       // fixed-capacity backing of the views below (the device keeps compact pools instead)
     std::vector<ClusterFragments> frags;
     std::vector<Match> matches; std::vector<u64> matchOffsets;
@@ -45,6 +46,8 @@ Emu *emu_create(const isaac_params *p, const char *bases, const u64 *offsets, u3
     {
         Emu *e = new Emu;
         e->P = makeDevParams(*p);
+        e->adapters = makeDevAdapters(*p);
+        if (e->adapters.n) e->P.adapters = &e->adapters;
         e->bases.assign(bases, bases + offsets[nContigs]); e->offsets.assign(offsets, offsets + nContigs + 1);
         e->loaded.assign(nContigs, 1); if (loaded) e->loaded.assign(loaded, loaded + nContigs);
         e->logMatch.resize(100); e->logMismatch.resize(100); makeQualityTables(e->logMatch.data(), e->logMismatch.data());
@@ -85,9 +88,12 @@ int emu_build_fragments(Emu *e, const u8 *bcl, u32 nClusters, int withGaps, int 
     u64 generalKeysA[CAND_CAP], generalKeysB[CAND_CAP]; LeanKeyArea generalKeys; generalKeys.a = generalKeysA; generalKeys.b = generalKeysB; generalKeys.stride = 1;
     if (e->lean) { work[0].keys = &generalKeys; work[0].keyCap = CAND_CAP; }      // the general kernels sort on keys in LDS
     u64 n = 0, nc = 0;
+    e->adapterRanges.assign(size_t(4) * nClusters + 4, 0);
     for (u32 c = 0; c < nClusters; ++c)
     {
         ClusterFragments &f = e->frags[c];
+        // (the device addresses a cluster's ranges by its first candidate slot in the chunk's pool; here every cluster has a store of its own)
+        if (e->P.adapters) { e->P.adapterCandBase = e->stores[c].cands; e->P.adapterRanges = &e->adapterRanges[size_t(4) * c]; }
         if (e->flatRescue && e->lean)
         {   // the kernels' sequence: lean forms for short lists (fragment_lean.h), the general ones for the rest
             u64 keysA[LEAN_LIST_MAX], keysB[LEAN_LIST_MAX];
@@ -105,6 +111,7 @@ int emu_build_fragments(Emu *e, const u8 *bcl, u32 nClusters, int withGaps, int 
             else built = buildCandidates(e->P, clusterBcl, e->matches.data() + begin, u32(end - begin), trim != 0, work[0], f);
             if (built)
             {
+                if (e->P.adapters) for (u32 r = 0; r < e->P.nReads; ++r) for (u32 strand = 0; strand < 2; ++strand) clusterInitAdapterRanges(e->P, e->R, clusterBcl, f, r, strand);   // k_adapter_ranges
                 for (u32 r = 0; r < e->P.nReads; ++r) for (u32 i = 0; i < f.nCands[r]; ++i) alignCandidate(e->P, e->R, clusterBcl, f, r, i, e->cnt);             // k_align_candidates
                 if (f.nCands[0] <= LEAN_LIST_MAX && f.nCands[1] <= LEAN_LIST_MAX) leanFinishCandidates(e->P, f, keys);                                            // k_finish_candidates
                 else finishCandidates(e->P, e->R, clusterBcl, work[0], f, e->cnt, true);
@@ -112,7 +119,7 @@ int emu_build_fragments(Emu *e, const u8 *bcl, u32 nClusters, int withGaps, int 
             if (clusterSimpleIndelsPending(f)) clusterFinishSimpleIndels(e->P, e->R, bcl, c, work[0], f, e->cnt);   // k_indel_fragments
             const u32 nj = countGappedJobs(f, withGaps != 0);
             std::vector<GappedJob> jobs(nj + 1); std::vector<GappedResult> results(nj + 1);
-            if (nj) writeGappedJobs(f, c, jobs.data());
+            if (nj) writeGappedJobs(e->P, f, c, jobs.data());
             for (u32 j = 0; j < nj; ++j) runGappedJobSerial(e->P, e->R, bcl + u64(jobs[j].cluster) * e->P.clusterLength, jobs[j], work[0].tflags, results[j]);
             if (f.nCands[0] <= LEAN_LIST_MAX && f.nCands[1] <= LEAN_LIST_MAX)
             {   // k_finish_fragments
@@ -131,7 +138,7 @@ int emu_build_fragments(Emu *e, const u8 *bcl, u32 nClusters, int withGaps, int 
         {   // k_build_fragments -> k_gapped_jobs -> k_finish_fragments
             const u32 nj = countGappedJobs(f, true);
             std::vector<GappedJob> jobs(nj + 1); std::vector<GappedResult> results(nj + 1);
-            if (nj) writeGappedJobs(f, c, jobs.data());
+            if (nj) writeGappedJobs(e->P, f, c, jobs.data());
             for (u32 j = 0; j < nj; ++j) runGappedJobSerial(e->P, e->R, bcl + u64(jobs[j].cluster) * e->P.clusterLength, jobs[j], work[0].tflags, results[j]);
             clusterFinishFragments(e->P, e->R, bcl, c, true, results.data(), work[0], f, e->cnt);
         }
@@ -243,6 +250,15 @@ int emu_select(Emu *e, const u8 *bcl, u32 nClusters, u32 tile, const isaac_tls *
             e->cnt.rescueCandidates += n;
         }
     }
+    // k_rescue_adapter_ranges
+    if (e->P.adapters)
+        for (RescueJob &job : jobs)
+        {
+            if (!job.valid || job.fallback || !job.nCands) continue;
+            ReadView shadowRead; const u32 r = job.shadowReadIndex;
+            shadowRead.bcl = bcl + u64(job.cluster) * e->P.clusterLength + e->P.readOffset[r]; shadowRead.length = e->P.readLength[r]; shadowRead.firstCycle = e->P.firstCycle[r]; shadowRead.endCyclesMasked = 0;
+            job.adapterRange = adapterStrandRange(*e->P.adapters, e->R, shadowRead, 0 != job.shadowReverse, job.contigId, i64(candPositions[job.candBase]) + job.windowBegin);
+        }
     // k_rescue_align
     std::vector<Cand> shadowCands(candPositions.size()); std::vector<u32> shadowCigars(candPositions.size() * 3 + 3);
     for (size_t j = 0; j < jobs.size(); ++j)
@@ -281,6 +297,7 @@ int emu_select(Emu *e, const u8 *bcl, u32 nClusters, u32 tile, const isaac_tls *
     TemplateWork tiny; templateWorkBind(tiny, reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(tinyArena.data()) + 15) & ~uintptr_t(15)), tinyCaps());
     for (u32 c = 0; c < nClusters; ++c)
     {
+        if (e->P.adapters) { e->P.adapterCandBase = e->stores[c].cands; e->P.adapterRanges = &e->adapterRanges[size_t(4) * c]; }
         RescueInputs in; in.jobs = jobs.data() + jobBase[c]; in.jobCount = jobBase[c + 1] - jobBase[c]; in.shadowCands = shadowCands.data(); in.shadowCigars = shadowCigars.data();
         in.gappedResults = gapped.data(); in.gappedJobs = gj.data(); in.candRank = candRank.data(); in.sums = 0;
         const auto t0 = std::chrono::steady_clock::now();

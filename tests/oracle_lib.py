@@ -17,13 +17,18 @@ class Seed(C.Structure):
     _fields_ = [("offset", C.c_uint16), ("length", C.c_uint16), ("read_index", C.c_uint32)]
 
 
+class Adapter(C.Structure):
+    _fields_ = [("sequence", C.c_char * 128), ("reverse", C.c_uint32), ("clip_length", C.c_uint32)]
+
+
 class Params(C.Structure):
     _fields_ = [("gap_match", C.c_int32), ("gap_mismatch", C.c_int32), ("gap_open", C.c_int32), ("gap_extend", C.c_int32), ("min_gap_extend", C.c_int32),
                 ("repeat_threshold", C.c_uint32), ("gapped_mismatches_max", C.c_uint32), ("semialigned_gap_limit", C.c_uint32), ("base_quality_cutoff", C.c_uint32),
                 ("ignore_neighbors", C.c_uint32), ("clip_semialigned", C.c_uint32), ("clip_overlapping", C.c_uint32), ("scatter_repeats", C.c_uint32),
                 ("dodgy_alignment_score", C.c_int32), ("mapq_threshold", C.c_uint32), ("keep_unaligned", C.c_uint32), ("mate_drift_range", C.c_int32),
                 ("first_pass_seeds", C.c_uint32), ("seed_length", C.c_uint32),
-                ("n_reads", C.c_uint32), ("read_length", C.c_uint32 * 2), ("n_seeds", C.c_uint32), ("seeds", Seed * 16)]
+                ("n_reads", C.c_uint32), ("read_length", C.c_uint32 * 2), ("n_seeds", C.c_uint32), ("seeds", Seed * 16),
+                ("n_adapters", C.c_uint32), ("adapters", Adapter * 8)]
 
 
 class Tls(C.Structure):
@@ -219,6 +224,18 @@ class Oracle:
         self.check(self.lib.oracle_fragment_builder2_literal(read.encode(), reference.encode(), int(reverse), int(position is not None), C.c_int64(position or 0), int(gapped),
                                                              ptr(out), ptr(cig), C.c_uint64(256), C.byref(n), C.byref(cyc)))
         return out[0], cig[:n.value].copy(), cyc.value
+
+    def sequencing_adapter_literal(self, read, reference, reverse, adapters):
+        """adapters: list of dicts sequence / reverse / clip_length (0: unbounded)"""
+        out = np.zeros(1, CANDIDATE_DTYPE)
+        cig = np.zeros(256, np.uint32)
+        n = C.c_uint64()
+        k = len(adapters)
+        sequences = (C.c_char_p * k)(*[a["sequence"].encode() for a in adapters])
+        rev = (C.c_uint32 * k)(*[int(a["reverse"]) for a in adapters])
+        clip = (C.c_uint32 * k)(*[int(a["clip_length"]) for a in adapters])
+        self.check(self.lib.oracle_sequencing_adapter_literal(read.encode(), reference.encode(), int(reverse), C.c_uint32(k), sequences, rev, clip, ptr(out), ptr(cig), C.c_uint64(256), C.byref(n)))
+        return out[0], cig[:n.value].copy()
 
     def reference(self, contigs):
         return OracleReference(self, contigs)

@@ -10,6 +10,32 @@ def make_inputs(genome_bases=300000, n_pairs=2000, read_length=150, read_length2
     return [bytes(c.numpy()) for c in contigs], bcl.numpy(), truth
 
 
+def add_adapters(bcl, read_length, adapter="AGATCGGAAGAGC", fraction=0.3, seed=5, insert_range=(60, 145), adapter2=None):
+    """Short-insert pairs: for `fraction` of the pairs (2 x read_length BCL bytes each) the fragment is cut to an insert shorter than the reads, so that both reads
+    run into the sequencing adapter -- read 1 keeps its first `insert` bases, read 2 becomes the reverse complement of those, and either is followed by the adapter
+    (as the sequencer reads it: the same text at the 3' end of both reads) and by random bases; qualities stay.  Returns (bcl copy, inserts: 0 = untouched)."""
+    rng = np.random.default_rng(seed)
+    out = bcl.copy()
+    n, L = len(out), read_length
+    inserts = np.zeros(n, np.int64)
+    code = {65: 0, 67: 1, 71: 2, 84: 3}
+    tails = [np.array([code[c] for c in a.encode()], np.uint8) for a in (adapter, adapter2 or adapter)]
+    for i in np.nonzero(rng.random(n) < fraction)[0]:
+        insert = int(rng.integers(insert_range[0], insert_range[1] + 1))
+        r1 = out[i, :L].copy()
+        if (r1[:insert] == 0).any():
+            continue                                             # (an N inside the fragment: left alone)
+        inserts[i] = insert
+        fragment = r1[:insert] & 3
+        for read, bases in ((0, fragment), (1, (3 - fragment)[::-1])):
+            tail = np.concatenate([tails[read], rng.integers(0, 4, L, dtype=np.uint8)])
+            seq = np.concatenate([bases, tail])[:L]
+            q = out[i, read * L:(read + 1) * L] >> 2
+            q = np.maximum(q, 1)                                 # (quality 0 would make the base an N)
+            out[i, read * L:(read + 1) * L] = seq | (q << 2)
+    return out, inserts
+
+
 def compare_candidates(a, acig, b, bcig, limit=5):
     """a/b: CANDIDATE_DTYPE arrays in (cluster, read, list) order; returns list of textual differences"""
     diffs = []

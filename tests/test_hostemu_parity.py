@@ -72,6 +72,45 @@ def test_fragments_tls_and_records(oracle, emulib, cfg):
     assert emu.counters()["mapq_near_integer"] == 0
 
 
+@pytest.mark.parametrize("adapters", ["Standard", "Nextera", "NexteraMp"])
+def test_sequencing_adapters_through_the_device_code(oracle, emulib, adapters):
+    """--default-adapters: a third of the pairs have inserts of 60-145 bases at 2 x 150, so both reads run into the adapter.  The device headers (adapter ranges per
+    read and strand from the first candidate, the clip ahead of the ungapped scan, of the gapped window and of the rescue scans) against the oracle's
+    FragmentSequencingAdapterClipper: candidates with and without gaps, template statistics, every record.  The clips must actually happen."""
+    from parity_util import add_adapters
+    text = dict(Standard="AGATCGGAAGAGC", Nextera="CTGTCTCTTATACACATCT", NexteraMp="CTGTCTCTTATACACATCT")[adapters]
+    contigs, bcl, _ = make_inputs(read_length=150, n_pairs=1500, seed=21, indel_read_fraction=0.1)
+    bcl, inserts = add_adapters(bcl, 150, adapter=text, adapter2="AGATGTGTATAAGAGACAG" if adapters == "NexteraMp" else None, fraction=0.35, seed=22)
+    n = len(bcl)
+    p = options.set_adapters(options.default_params(150, 150), adapters)
+    plain = options.default_params(150, 150)
+    ref = oracle.reference(contigs)
+    ref.build_index()
+    matches, hits = ref.find_matches(p, bcl, n)
+    emu = hostemu_lib.Emu(emulib, p, contigs, hits)
+    emu.set_matches(matches, n)
+    for with_gaps, trim in ((True, True), (False, False)):
+        oc, ocig = ref.build_fragments(p, bcl, matches, hits, with_gaps=with_gaps, trim=trim)
+        ec, ecig = emu.build_fragments(bcl, n, with_gaps=with_gaps, trim=trim)
+        assert not compare_candidates(oc, ocig, ec, ecig)
+    otls = ref.determine_tls(p, bcl, matches, hits)
+    etls = emu.determine_tls(bcl, n)
+    assert otls.astuple() == etls.astuple()
+    orec, ocig, _ = ref.select(p, bcl, matches, otls, hits, n_clusters_hint=n)
+    erec, ecig = emu.select(bcl, n, etls)
+    assert not (erec["reserved"] & 5).any()
+    assert not compare_records(orec, ocig, erec, ecig)
+    # the adapters are found: the records differ from a run without them, in the short-insert pairs and (nearly) nowhere else, and most of those are clipped
+    # where the insert ends
+    prec, pcig, _ = ref.select(plain, bcl, matches, ref.determine_tls(plain, bcl, matches, hits), hits, n_clusters_hint=n)
+    differs = ((orec["f_strand_position"] != prec["f_strand_position"]) | (orec["observed_length"] != prec["observed_length"]) | (orec["cigar_length"] != prec["cigar_length"])).reshape(-1, 2).any(1)
+    short = inserts > 0
+    assert differs[short].mean() > 0.25 and differs[~short].mean() < 0.02, (differs[short].mean(), differs[~short].mean())
+    aligned = (orec["flags"] & 4 == 0).reshape(-1, 2)[:, 0] & short
+    at_insert = orec["observed_length"].reshape(-1, 2)[:, 0] == inserts
+    assert (at_insert & aligned).sum() > 0.5 * aligned.sum(), ((at_insert & aligned).sum(), aligned.sum())
+
+
 def test_template_code_reproduces_reference_known_answers(emulib):
     """the product's template code (device headers, thread-serial form) on the candidate lists of testTemplateBuilder.cpp: the
     reference's own alignment scores (1136 / 534 / 569, 1119 / 517, 1084, 2 / 2 / 3) and placements must come out"""

@@ -121,6 +121,24 @@ def test_fragment_builder2(oracle):
             assert cyc == e["getMismatchCyclesBegin"], c["name"]
 
 
+def test_sequencing_adapter_known_answers(oracle):
+    """lib/alignment/cppunit/testSequencingAdapter.cpp: the fifteen cases testEverything() runs -- mate-pair (bounded) and standard (unbounded, strand-bound)
+    Nextera adapters found from the first mismatch on, the side to clip chosen by length / matches / the 40 % rule, adapters that start before the read or
+    end behind it -- through FragmentSequencingAdapterClipper::checkInitStrand + UngappedAligner::alignUngapped of the oracle"""
+    g = load("sequencing_adapter.json")
+    assert len(g["cases"]) == 15
+    for c in g["cases"]:
+        f, cig = oracle.sequencing_adapter_literal(c["read"], c["reference"], c["reverse"], g["adapter_lists"][c["adapters"]])
+        e = c["expect"]
+        assert cigar_string(cig) == e["getCigarString"], (c["name"], cigar_string(cig))
+        for key, field in (("getMismatchCount", "mismatch_count"), ("getEditDistance", "edit_distance"), ("getObservedLength", "observed_length")):
+            if key in e:
+                assert f[field] == e[key], (c["name"], key, f[field])
+        for key in ("getFStrandReferencePosition", "getStrandReferencePosition"):
+            if key in e:
+                assert [f["contig_id"], f["position"]] == e[key], (c["name"], key)
+
+
 def test_threaded_seed_lookup_equals_single_thread(oracle):
     """oracle_find_matches_mt (the CPU-baseline form: cluster ranges on host threads) returns the single-thread result"""
     from parity_util import make_inputs
