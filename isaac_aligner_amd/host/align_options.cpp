@@ -59,6 +59,9 @@ std::string AlignOptions::usage()
         "                                       run are dealt out to them (an entry may repeat: two workers on one device)\n"
         "  --bin-records arg (=0)               records a bin of the BAM stage is sized for (0: 4000000): contigs are grouped into or cut\n"
         "                                       into bins of about that many, each sorted, filtered and realigned by itself\n"
+        "  --default-adapters arg               sequencing adapters to clip, one entry per base-calls directory (the flowcells of a run must agree):\n"
+        "                                       Standard | Nextera | NexteraMp | a comma separated list of ACGT (any strand), ACGT* (forward\n"
+        "                                       alignments, everything from the adapter on) and *ACGT (reverse alignments), in the direction of the reference\n"
         "  --use-bases-mask arg (=default)      y*n per read by default (the last cycle is not used); y<N>n<M> and y* forms\n"
         "  --seeds arg (=auto)                  auto | all | offsets 0:32:64[,...]\n"
         "  --first-pass-seeds arg (=1)\n"
@@ -114,7 +117,7 @@ AlignOptions AlignOptions::parse(int argc, char **argv)
     AlignOptions o;
     o.argv.assign(argv, argv + argc);
     o.jobs = std::max(1u, std::thread::hardware_concurrency());
-    std::vector<std::string> sampleSheet, referenceName, tiles, defaultAdapters, barcodeMismatches, useBasesMaskList;
+    std::vector<std::string> sampleSheet, referenceName, tiles, barcodeMismatches, useBasesMaskList;
     std::string startFrom = "Start", stopAt = "Finish", binRegex = "all", memoryControl, statsImageFormat;
     bool ignoreRepeats = false, avoidSmithWaterman = false, singleLibrarySamples = true, qscoreBin = false, pfOnly = true;
     unsigned neighborhoodSizeThreshold = 0;
@@ -147,7 +150,7 @@ AlignOptions AlignOptions::parse(int argc, char **argv)
     specs.push_back({ "devices", 0, false, text(&o.devices), "" });
     specs.push_back({ "sample-sheet", 's', true, list(&sampleSheet), "" });
     specs.push_back({ "tiles", 0, true, list(&tiles), "" });
-    specs.push_back({ "default-adapters", 0, true, list(&defaultAdapters), "" });
+    specs.push_back({ "default-adapters", 0, true, list(&o.defaultAdapters), "" });
     specs.push_back({ "barcode-mismatches", 0, true, list(&barcodeMismatches), "" });
     specs.push_back({ "start-from", 0, false, text(&startFrom), "" });
     specs.push_back({ "stop-at", 0, false, text(&stopAt), "" });
@@ -242,7 +245,16 @@ AlignOptions AlignOptions::parse(int argc, char **argv)
     for (const std::string &s : sampleSheet) refuse(s != "none", "--sample-sheet (other than none)");
     for (const std::string &s : referenceName) refuse(s != "default", "--reference-name other than default");
     for (const std::string &s : tiles) refuse(!s.empty(), "--tiles");
-    for (const std::string &s : defaultAdapters) refuse(!s.empty() && s != "none", "--default-adapters");
+    // --default-adapters: entry i belongs to base-calls i, a flowcell without one gets nothing clipped (AlignOptions.cpp:189-207,1248-1249).  The run has one set of
+    // parameters on the device, so the flowcells of a run have to agree; each entry is parsed here so that a bad one stops the run before anything is loaded.
+    {
+        isaac_params probe;
+        std::memset(&probe, 0, sizeof(probe));
+        for (const std::string &s : o.defaultAdapters) if (isaac_gpu_parse_adapters(s.c_str(), &probe)) throw InvalidOption(isaac_gpu_params_last_error());
+        const std::string first = o.defaultAdapters.empty() ? std::string() : o.defaultAdapters[0];
+        for (size_t i = 1; i < std::max(o.baseCalls.size(), o.defaultAdapters.size()); ++i)
+            refuse((i < o.defaultAdapters.size() ? o.defaultAdapters[i] : std::string()) != first, "flowcells with different --default-adapters in one run");
+    }
     (void)pfOnly;       // FASTQ data has no filter files: every cluster passes
     return o;
 }
@@ -280,6 +292,7 @@ isaac_params AlignOptions::params(unsigned readLength1, unsigned readLength2) co
     p.dodgy_alignment_score = "Unknown" == dodgyAlignmentScore ? 255 : "Unaligned" == dodgyAlignmentScore ? -1 : std::atoi(dodgyAlignmentScore.c_str());
     p.mapq_threshold = mapqThreshold; p.keep_unaligned = keepUnalignedRecords(); p.mate_drift_range = shadowScanRange; p.seed_length = seedLength;
     if (isaac_gpu_parse_gap_scoring(gapScoring.c_str(), &p) || isaac_gpu_parse_seeds(seeds.c_str(), firstPassSeeds, &p)) throw InvalidOption(isaac_gpu_params_last_error());
+    if (!defaultAdapters.empty() && isaac_gpu_parse_adapters(defaultAdapters[0].c_str(), &p)) throw InvalidOption(isaac_gpu_params_last_error());
     return p;
 }
 

@@ -24,6 +24,7 @@ struct AlignOptions
     Action action = RUN;
     std::vector<std::string> argv;                          // @PG CL
     std::vector<std::string> baseCalls;                     // -b, one flowcell each
+    std::vector<std::string> defaultAdapters;               // --default-adapters, one per flowcell (this host: all the same)
     std::vector<std::string> baseCallsFormat;               // fastq | fastq-gz per flowcell (the last one serves the rest)
     std::string referenceGenome;                            // -r sorted-reference.xml
     std::string outputDirectory = "./Aligned";              // -o

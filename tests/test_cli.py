@@ -70,6 +70,32 @@ def test_seed_descriptors_and_gap_scoring():
         assert lib.isaac_gpu_parse_gap_scoring(bad, C.byref(p)) == 1 and message in lib.isaac_gpu_params_last_error()
 
 
+def test_default_adapters_syntax():
+    """isaac_gpu_parse_adapters: flowcell::SequencingAdapterListGrammar + parseDefaultAdapters (include/flowcell/SequencingAdapterListGrammar.hpp:52-104,
+    lib/options/alignOptions/DefaultAdaptersOption.cpp:35-60) -- the three macros with the reference's own lists (tests/golden/sequencing_adapter.json holds them as
+    data), plain / forward-unbounded / reverse-unbounded sequences, lower case, optional commas, and the error text for what is left unparsed"""
+    import json
+    lib = gpu.load_library()
+    lib.isaac_gpu_params_last_error.restype = C.c_char_p
+    presets = json.load(open(os.path.join(ROOT, "tests", "golden", "sequencing_adapter.json")))["presets"]
+    p = options.default_params(100, 100)
+
+    def parsed(text):
+        assert lib.isaac_gpu_parse_adapters(text.encode(), C.byref(p)) == 0, lib.isaac_gpu_params_last_error()
+        return [(p.adapters[i].sequence.decode(), bool(p.adapters[i].reverse), p.adapters[i].clip_length) for i in range(p.n_adapters)]
+    for macro, name in (("Standard", "STANDARD_ADAPTERS"), ("Nextera", "NEXTERA_STANDARD_ADAPTERS"), ("NexteraMp", "NEXTERA_MATEPAIR_ADAPTERS")):
+        want = [(a["sequence"], a["reverse"], a["clip_length"]) for a in presets[name]]
+        assert parsed(macro) == want, macro
+        assert [tuple(x) for x in options.ADAPTER_PRESETS[macro]] == want, macro
+    assert parsed("ACGTA*,*TGCAT") == [("ACGTA", False, 0), ("TGCAT", True, 0)]
+    assert parsed("acgtac,TGCATG") == [("ACGTAC", False, 6), ("TGCATG", False, 6)]
+    assert parsed("ACGTA*TGCATGG*ACGTT") == [("ACGTA", False, 0), ("TGCATGG", False, 0), ("ACGTT", False, 5)]      # the comma is optional
+    assert parsed("") == []
+    for bad, at in ((b"ACGT", b"at: ACGT "), (b"ACGTA*,x", b"at: x "), (b"Nextera,ACGTA", b"at: ,ACGTA "), (b"*ACGTA*", b"at: * "), (b"ACGTN", b"at: ACGTN ")):
+        assert lib.isaac_gpu_parse_adapters(bad, C.byref(p)) == 1 and b"Could not parse the default-adapters" in lib.isaac_gpu_params_last_error() and at in lib.isaac_gpu_params_last_error(), bad
+    assert lib.isaac_gpu_parse_adapters(b"A" * 127, C.byref(p)) == 1 and b"too long" in lib.isaac_gpu_params_last_error()
+
+
 def test_command_line_errors(tmp_path):
     """what options::AlignOptions rejects, and what this host refuses instead of ignoring; exit code 1 with the message (common::run)"""
     assert run_host("--version").stdout.strip().startswith("isaac_aligner_amd")
@@ -375,6 +401,10 @@ SCENARIOS = {
     # them, foreign bin parts fetched in the build stage -- the same file as one device writes
     "two-devices": dict(compressed=False, lengths=(100, 100), cli=["--devices", "0,1"], paired=True, mark=True, keep=True, realign=True, unaligned="back", dodgy=0, pu="%s:%d:none",
                         needs_devices=2),
+    # --default-adapters: a third of the pairs have inserts shorter than the reads, both reads run into the Nextera adapter and are clipped there
+    # (FragmentSequencingAdapterClipper in the ungapped, gapped and rescue alignments; the oracle with the same list)
+    "adapters": dict(compressed=False, lengths=(100, 100), cli=["--default-adapters", "Nextera"], paired=True, mark=True, keep=True, realign=True, unaligned="back", dodgy=0, pu="%s:%d:none",
+                     adapters="Nextera"),
     # single-ended lanes, unaligned reads left out
     # ... on a reference made by bin/isaac-sort-reference from the FASTA file
     "single-ended": dict(compressed=True, lengths=(100,), cli=["--keep-unaligned", "discard"], paired=False, mark=True, keep=True, realign=True, unaligned="discard", dodgy=0, pu="%s:%d:none",
@@ -401,6 +431,8 @@ def test_gpu_isaac_align_end_to_end(tmp_path, scenario):
     fasta = str(ref_dir / "genome.fa")
     meta, stored = write_fasta(fasta, names, [bytes(c.numpy()) for c in genome], rng)
     params = options.default_params(lengths[0], lengths[1] if n_reads > 1 else 0, dodgy_alignment_score=sc["dodgy"], keep_unaligned=int(sc["unaligned"] != "discard"))
+    if sc.get("adapters"):
+        options.set_adapters(params, sc["adapters"])
     a = gpu.Aligner(options.default_params(100, 100), 0, stored)
     a.build_index()
     xml = str(ref_dir / "sorted-reference.xml")
@@ -445,6 +477,10 @@ def test_gpu_isaac_align_end_to_end(tmp_path, scenario):
         bcl = synth.make_read_pairs(sample, n_pairs, file_length, seed=seed, indel_read_fraction=0.01, n_rate=0.002)[0].numpy()
         if lane == 1:
             bcl[12600:14000] = bcl[rng.integers(0, 12000, 1400)]
+        if sc.get("adapters"):
+            from parity_util import add_adapters
+            bcl, inserts = add_adapters(bcl, file_length, adapter=options.ADAPTER_PRESETS[sc["adapters"]][0][0], fraction=0.35, seed=seed + 7, insert_range=(45, 96))
+            assert (inserts > 0).sum() > 2000
         lanes.append((lane, bcl))
     calls = tmp_path / "calls"
     calls.mkdir()

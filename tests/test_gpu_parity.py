@@ -557,3 +557,87 @@ def test_phix_sized_reference(torch, oracle):
     got = al.bam_records([(dev_bcl, records, cigars, "PHIX:1:1:")])[0].cpu().numpy().tobytes()
     want = oracle.bam_records([(bcl, orec, ocig, "PHIX:1:1:")], [100, 100], forced_dodgy_alignment_score=p.dodgy_alignment_score & 0xff)[0]
     assert got == want
+
+
+def test_sequencing_adapter_known_answers_on_the_gpu(torch, oracle):
+    """lib/alignment/cppunit/testSequencingAdapter.cpp through isaac_gpu_build_fragments: each of the fifteen cases as a one-read cluster with a hand-made seed
+    match that puts it at position 0 of the test's contig (the test's reverse alignments read the literal back to front without complementing it: the BCL bases
+    are chosen so that the reverse strand's sequence is the literal), the test's adapter list in isaac_params -- the CIGAR, mismatch count, edit distance,
+    observed length and position the reference asserts."""
+    from isaac_aligner_amd import gpu
+    g = json.load(open(os.path.join(GOLDEN, "sequencing_adapter.json")))
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    for c in g["cases"]:
+        L = len(c["read"])
+        p = options.set_adapters(options.default_params(L, 0, gap_scoring="eland"), g["adapter_lists"][c["adapters"]])
+        al = gpu.Aligner(p, 0, [c["reference"].encode()])
+        bases = np.array([code[b] for b in c["read"]], np.uint8)
+        if c["reverse"]:
+            bases = (3 - bases)[::-1]                       # forward = reverse complement of the literal: the reverse strand reads the literal
+        bcl = (bases | (30 << 2)).astype(np.uint8).reshape(1, L)
+        m = np.zeros(1, abi.MATCH_DTYPE)
+        seed_position = (L - 32) if c["reverse"] else 0      # FragmentBuilder::getReadPosition: seed 0 (offset 0) of a read at position 0
+        m["seed_id"][0] = oracle.seed_id(1, 0, 0, 0, int(c["reverse"]))
+        m["location"][0] = ((0 + 1) << 41) | (seed_position << 1)
+        offsets = np.array([0, 1], np.int64)
+        dev_matches = torch.from_numpy(m.view(np.uint64).view(np.int64).reshape(-1, 2).copy()).to(al.device)
+        cands, cigars = al.build_fragments(torch.from_numpy(bcl).to(al.device), dev_matches, torch.from_numpy(offsets).to(al.device), tile=1, with_gaps=False, trim=False)
+        assert len(cands) == 1, (c["name"], len(cands))
+        f, e = cands[0], c["expect"]
+        cig = cigars[f["cigar_offset"]:f["cigar_offset"] + f["cigar_length"]]
+        assert abi.cigar_string(cig) == e["getCigarString"], (c["name"], abi.cigar_string(cig))
+        for key, field in (("getMismatchCount", "mismatch_count"), ("getEditDistance", "edit_distance"), ("getObservedLength", "observed_length")):
+            if key in e:
+                assert f[field] == e[key], (c["name"], key, f[field])
+        for key in ("getFStrandReferencePosition", "getStrandReferencePosition"):
+            if key in e:
+                assert [f["contig_id"], f["position"]] == e[key], (c["name"], key)
+        al.close()
+
+
+@pytest.mark.parametrize("adapters", ["Standard", "Nextera", "NexteraMp"])
+def test_sequencing_adapters_on_short_inserts(torch, oracle, adapters):
+    """--default-adapters on the device: a third of the 2 x 150 pairs have inserts of 60-145 bases, so both reads run into the adapter (TruSeq / Nextera text, for
+    NexteraMp the junction adapter's two halves).  k_adapter_ranges and k_rescue_adapter_ranges decide the ranges, every ungapped scan, gapped window and rescue scan
+    clips by them: candidates (with and without gaps), template statistics and every record against the oracle's FragmentSequencingAdapterClipper.  Then the same
+    context without adapters (isaac_gpu_set_params): the default path gives the oracle's default records."""
+    from isaac_aligner_amd import gpu
+    from parity_util import add_adapters
+    text = dict(Standard="AGATCGGAAGAGC", Nextera="CTGTCTCTTATACACATCT", NexteraMp="CTGTCTCTTATACACATCT")[adapters]
+    contigs, bcl, _ = make_inputs(read_length=150, n_pairs=6000, seed=31, genome_bases=500000, indel_read_fraction=0.1)
+    bcl, inserts = add_adapters(bcl, 150, adapter=text, adapter2="AGATGTGTATAAGAGACAG" if adapters == "NexteraMp" else None, fraction=0.35, seed=32)
+    n = len(bcl)
+    plain = options.default_params(150, 150)
+    p = options.set_adapters(options.default_params(150, 150), adapters)
+    al = gpu.Aligner(p, 0, contigs)
+    al.build_index()
+    ref = oracle.reference(contigs)
+    ref.set_index(al.get_index())
+    dev_bcl = torch.from_numpy(bcl).to(al.device)
+    m, o, hits = al.find_matches(dev_bcl)
+    om, ohits = ref.find_matches(p, bcl, n)
+    a, b = sort_matches(om), sort_matches(gpu_matches_numpy(m))
+    assert (a["seed_id"] == b["seed_id"]).all() and (a["location"] == b["location"]).all() and (hits == ohits).all()
+    al.set_loaded_contigs(hits)
+    for with_gaps, trim in ((True, True), (False, False)):
+        gc, gcig = al.build_fragments(dev_bcl, m, o, with_gaps=with_gaps, trim=trim)
+        oc, ocig = ref.build_fragments(p, bcl, om, ohits, with_gaps=with_gaps, trim=trim)
+        assert not compare_candidates(oc, ocig, gc, gcig)
+    tls = al.determine_tls(dev_bcl, m, o)
+    otls = ref.determine_tls(p, bcl, om, ohits)
+    assert tls.astuple() == otls.astuple()
+    rec, cig = al.records_to_numpy(*al.select(dev_bcl, m, o, tls))
+    orec, ocig, _ = ref.select(p, bcl, om, otls, ohits, n_clusters_hint=n)
+    assert not compare_records(orec, ocig, rec, cig)
+    short = inserts > 0
+    aligned = (orec["flags"] & 4 == 0).reshape(-1, 2)[:, 0] & short
+    assert ((orec["observed_length"].reshape(-1, 2)[:, 0] == inserts) & aligned).sum() > 0.5 * aligned.sum()
+    # ... and back to no adapters on the same context
+    al.set_params(plain)
+    tls2 = al.determine_tls(dev_bcl, m, o)
+    ptls = ref.determine_tls(plain, bcl, om, ohits)
+    assert tls2.astuple() == ptls.astuple()
+    rec2, cig2 = al.records_to_numpy(*al.select(dev_bcl, m, o, tls2))
+    prec, pcig, _ = ref.select(plain, bcl, om, ptls, ohits, n_clusters_hint=n)
+    assert not compare_records(prec, pcig, rec2, cig2)
+    assert compare_records(orec, ocig, rec2, cig2)            # (the two runs do differ)
