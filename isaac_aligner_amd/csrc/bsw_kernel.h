@@ -105,12 +105,20 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
             GlobalU32 *to = (GlobalU32 *)(reinterpret_cast<u32 *>(T)) + block * 24 + l * 3;
             to[0] = w0; to[1] = w1; to[2] = w2;
         }
+#if defined(ISAAC_TIMING_BSW_SMALL_LDS)
+        else { u32 *to = reinterpret_cast<u32 *>(T) + (block % 11) * 24 + l * 3; to[0] = w0; to[1] = w1; to[2] = w2; }
+#else
         else { u32 *to = reinterpret_cast<u32 *>(T) + block * 24 + l * 3; to[0] = w0; to[1] = w1; to[2] = w2; }
+#endif
     };
     const auto flagsAt = [&](int r, int cell) -> u32
     {
         const u32 bit = u32(r & 7) * 12 + u32(cell & 1) * 6;
+#if defined(ISAAC_TIMING_BSW_SMALL_LDS)
+        const u8 *at = T + (u32(r >> 3) % 11) * 96 + u32(cell >> 1) * 12 + (bit >> 3);
+#else
         const u8 *at = T + u32(r >> 3) * 96 + u32(cell >> 1) * 12 + (bit >> 3);
+#endif
         u32 b0, b1;
         if constexpr (GLOBAL_FLAGS)
         {

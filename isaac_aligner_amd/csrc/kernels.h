@@ -194,6 +194,9 @@ __host__ __device__ inline u32 gappedGroupLdsBytes(u32 maxQueryLength)
 {
     // the end values (128 bytes) and the staged query and database window, each with room for the look-ahead reads; the traceback flags of
     // k_gapped_jobs are in device memory (GAPPED_GRID x groups regions of bswFlagBytes)
+#if defined(ISAAC_TIMING_BSW_SMALL_LDS)      // (timing experiment only: wrong results -- what a third wavefront per SIMD would buy before the flags are made to fit)
+    return 1616;
+#endif
     const u32 bytes = 128 + 2 * ((maxQueryLength + 47) & ~15u) + (ISAAC_BSW_GLOBAL_FLAGS ? 0u : bswFlagBytes(maxQueryLength));
     return (((bytes + 15) / 16) | 1u) * 16;
 }

@@ -212,7 +212,7 @@ ISAAC_HD void leanPlanRescue(const LeanCtx &x, const LeanOrphan &orphan, i64 bes
     const DevTls &tls = *x.tls;
     job.windowBegin = 0; job.windowLen = 0; job.cluster = chunkCluster; job.contigId = orphan.contigId; job.candBase = 0; job.nCands = 0; job.pushes = 0;
     job.bitmapBase = 0; job.bitmapWords = 0; job.valid = 0; job.fallback = 0; job.gappedBase = 0xffffffffu; job.nGapped = 0; job.nAligned = 0; job.bestRank = 0; job.bestSlot = 0; job.lastAligned = 0;
-    job.take = 0; job.finalBestRank = 0; job.finalBestSlot = 0; job.finalBestGapped = 0xffffffffu; job.rescued = 0; job.windowBaseHigh = 0; job.windowBaseLow = 0;
+    job.adapterRange = 0; job.pad = 0; job.take = 0; job.finalBestRank = 0; job.finalBestSlot = 0; job.finalBestGapped = 0xffffffffu; job.rescued = 0; job.windowBaseHigh = 0; job.windowBaseLow = 0;
     job.orphanListIndex = orphan.listIndex;
     job.shadowReadIndex = u8((orphan.readIndex + 1) % 2);
     job.shadowReverse = 0;
