@@ -10,7 +10,8 @@
 // is computed where its inputs are and then moved, instead of moving the inputs.  The serial 16-step E chain of the reference
 // (:246-297) is an exclusive max-plus suffix scan (E[k] = max_{j>k}(max(G'[j],F'[j]) - open - (j-k-1)*extend)): both cells of a lane in
 // 32 bits (the chain's intermediate values are not wrapped), then the maximum over the lanes above (seven DPP reads of one register).  The traceback flags
-// (one byte per cell and row) are staged in LDS and walked by the group together.  Integer DP: no MFMA.
+// (one of 27 codes per cell and row: which of G / E / F each of the cell's three values came from; five bits, ten bytes per row) are staged in LDS
+// and walked by the group together.  Integer DP: no MFMA.
 // (Round 2's form had one cell per lane, 16 lanes per alignment, 32-bit arithmetic with a sign extension after every operation: ~75
 // issue slots per row for 4 alignments; this one ~80 for 8.)
 #pragma once
@@ -73,14 +74,46 @@ __device__ inline u32 bswLaneOfThread() { return (threadIdx.x & 15u) >> 1; }
 // receives the operations (reference order); the return value is BandedSmithWaterman::align's: the length of the stripped leading
 // deletion.  T: bswFlagBytes(L) bytes of LDS, endVals: 48 shorts of LDS, both private to the group.  The 8 lanes are part of one
 // wave, so LDS traffic between them needs no workgroup barrier.
-// PADDED: query[L] and database[L + 16] may be read (staged copies with room behind them): the look-ahead then needs no clamping
+// Where the row loop takes its bases from (SOURCE):
+// BSW_FROM_FUNCTION: query(i) and database[i], a byte at a time (k_bsw_batch: sequences in device memory)
+// BSW_FROM_LDS (round 5's k_gapped_jobs, kept for reads beyond what the registers hold): query.q and database are staged copies in LDS with room behind them
+//   (query[L] and database[L + 16] may be read): four rows' bases per 32-bit read, requested ahead
+// BSW_FROM_REGISTERS: `query` is a BswRegisterWords -- the group's eight lanes hold the query and the window eight bases per 64-bit register, and a block of
+//   eight rows gets its bases by four lane permutes (ds_bpermute: the LDS crossbar, no LDS memory).  `database` is not looked at.
 // GLOBAL_FLAGS: T is device memory, not LDS (1.8 KB of flags per problem at 2 x 150 limit the wavefronts a CU holds to two per SIMD, and a row is
 // a chain of dependent packed and DPP instructions that would like more of them to hide behind).  The stores are plain, the traceback's reads go to
 // the L2 (agent scope) behind a release fence: they are other lanes' stores.  An experiment that lost (kernels.h: ISAAC_BSW_GLOBAL_FLAGS).
 struct BswNothingBetween { __device__ void operator()() const {} };
 // between(): called once, behind the last row and before the traceback (k_gapped_jobs asks for its next problem's bases there: they arrive while the group walks back)
-template <bool PADDED = false, bool GLOBAL_FLAGS = false, typename QueryF, typename BetweenF = BswNothingBetween>
-__device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapOpenScore, int gapExtendScore, QueryF query, u32 L, const char *database,
+enum { BSW_FROM_FUNCTION = 0, BSW_FROM_LDS = 1, BSW_FROM_REGISTERS = 2 };
+// The sequences of a problem in the registers of its group: chunk c (bases 8c .. 8c + 7; the query as ASCII ACGTn, the window from its first base on) is
+// register c / 8 of lane c % 8.  The blocks are asked for in order, so a register is done with after eight blocks and the arrays move down one place:
+// the permutes always read element 0 and no register is ever indexed at run time.
+template <u32 NCH> struct BswRegisterWords
+{
+    u64 q[NCH], w[NCH];
+    u32 addressBase;         // byte address (lane x 4) of the group's lane 0 for ds_bpermute
+    __device__ static u32 permute(u32 address, u32 value) { return u32(__builtin_amdgcn_ds_bpermute(int(address), int(value))); }
+    // the query's bases of rows 8b .. 8b + 7 (q0: the first four, a byte each) and the window's bases that enter the band behind them (window[8b + 16 ..])
+    __device__ void block(u32 b, u32 &q0, u32 &q1, u32 &d0, u32 &d1)
+    {
+        if (b && !(b & 7)) { _Pragma("unroll") for (u32 t = 0; t + 1 < NCH; ++t) q[t] = q[t + 1]; }
+        if (!((b + 2) & 7)) { _Pragma("unroll") for (u32 t = 0; t + 1 < NCH; ++t) w[t] = w[t + 1]; }
+        const u32 fromQ = addressBase | ((b & 7) << 3), fromD = addressBase | (((b + 2) & 7) << 3);
+        q0 = permute(fromQ, u32(q[0])); q1 = permute(fromQ, u32(q[0] >> 32));
+        d0 = permute(fromD, u32(w[0])); d1 = permute(fromD, u32(w[0] >> 32));
+    }
+    // window[14 - 2l] in the low byte, window[15 - 2l] above it: what lane l's two cells look at in the first row (before any block() call)
+    __device__ u32 firstWindowBases(u32 l) const
+    {
+        const u32 from = addressBase | ((l < 4 ? 1u : 0u) << 3);             // window[8 .. 15] is lane 1's, window[0 .. 7] lane 0's
+        const u32 lo = permute(from, u32(w[0])), hi = permute(from, u32(w[0] >> 32));
+        const u32 at = (6 - 2 * l) & 7;                                     // byte of the chunk where window[14 - 2l] lies
+        return ((at < 4 ? lo : hi) >> (8 * (at & 3))) & 0xffffu;
+    }
+};
+template <int SOURCE = BSW_FROM_FUNCTION, bool GLOBAL_FLAGS = false, typename QueryF, typename BetweenF = BswNothingBetween>
+__device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapOpenScore, int gapExtendScore, QueryF &query, u32 L, const char *database,
                                      u8 *T, short *endVals, u32 l, u32 *cig, u32 cap, u32 &n, bool &overflow, BetweenF between = BetweenF())
 {
     STAMP_BEGIN();
@@ -92,40 +125,48 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
     const bool lastLane = l == 7;
     const int ext = gapExtendScore;
     const int kExtLo = int(2 * l) * ext, kExtHi = int(2 * l + 1) * ext, k1ExtHi = int(2 * l + 2) * ext;        // k1Ext of the low cell = kExtHi
-    int d2 = int(u8(database[15 - 2 * l])) | (int(u8(database[14 - 2 * l])) << 16);            // cell k of row i looks at database[i + 15 - k]
-    // Traceback flags: 6 bits per cell (which of G / E / F each of the three came from), 12 per lane and row, eight rows of a lane in one
-    // 12-byte store: 12 bytes per row and alignment (16 with a byte per cell).
-    // Block b (rows 8b .. 8b + 7), lane l: 96 bits at T + 96 b + 12 l, row j's 12 bits at bit 12 j (low cell first).
+    int d2;                                                                                    // cell k of row i looks at database[i + 15 - k]
+    if constexpr (BSW_FROM_REGISTERS == SOURCE) { const u32 two = query.firstWindowBases(l); d2 = int(two >> 8) | (int(two & 0xffu) << 16); }
+    else d2 = int(u8(database[15 - 2 * l])) | (int(u8(database[14 - 2 * l])) << 16);
+    // Traceback flags: tf + 3 te + 9 tg per cell -- 27 codes, five bits -- ten bits per lane and row, eight rows of a lane in ten bytes: ten bytes per
+    // row and alignment (round 5: six bits per cell, twelve bytes; 16 with a byte per cell).  1.5 KB per alignment at 2 x 150, which with the sequences
+    // in registers (k_gapped_jobs) lets a CU hold three wavefronts per SIMD instead of two.
+    // Block b (rows 8b .. 8b + 7), lane l: 80 bits, row j's ten at bit 10 j (low cell first): the first 64 at T + 80 b + 8 l, the last 16 at T + 80 b + 64 + 2 l.
     const auto storeFlags = [&](u32 block, const u32 (&f)[8])
     {
-        const u32 w0 = f[0] | (f[1] << 12) | (f[2] << 24), w1 = (f[2] >> 8) | (f[3] << 4) | (f[4] << 16) | (f[5] << 28), w2 = (f[5] >> 4) | (f[6] << 8) | (f[7] << 20);
+        const u32 w0 = f[0] | (f[1] << 10) | (f[2] << 20) | (f[3] << 30), w1 = (f[3] >> 2) | (f[4] << 8) | (f[5] << 18) | (f[6] << 28), w2 = (f[6] >> 4) | (f[7] << 6);
         if constexpr (GLOBAL_FLAGS)
         {
             typedef __attribute__((address_space(1))) u32 GlobalU32;
-            GlobalU32 *to = (GlobalU32 *)(reinterpret_cast<u32 *>(T)) + block * 24 + l * 3;
-            to[0] = w0; to[1] = w1; to[2] = w2;
+            typedef __attribute__((address_space(1))) u16 GlobalU16;
+            GlobalU32 *to = (GlobalU32 *)(reinterpret_cast<u32 *>(T + block * 80 + l * 8));
+            to[0] = w0; to[1] = w1; *(GlobalU16 *)(reinterpret_cast<u16 *>(T + block * 80 + 64 + l * 2)) = u16(w2);
         }
-#if defined(ISAAC_TIMING_BSW_SMALL_LDS)
-        else { u32 *to = reinterpret_cast<u32 *>(T) + (block % 11) * 24 + l * 3; to[0] = w0; to[1] = w1; to[2] = w2; }
-#else
-        else { u32 *to = reinterpret_cast<u32 *>(T) + block * 24 + l * 3; to[0] = w0; to[1] = w1; to[2] = w2; }
-#endif
+        else
+        {
+            *reinterpret_cast<uint2 *>(T + block * 80 + l * 8) = make_uint2(w0, w1);
+            *reinterpret_cast<u16 *>(T + block * 80 + 64 + l * 2) = u16(w2);
+        }
     };
+    // the code of cell `cell` in row r
     const auto flagsAt = [&](int r, int cell) -> u32
     {
-        const u32 bit = u32(r & 7) * 12 + u32(cell & 1) * 6;
-#if defined(ISAAC_TIMING_BSW_SMALL_LDS)
-        const u8 *at = T + (u32(r >> 3) % 11) * 96 + u32(cell >> 1) * 12 + (bit >> 3);
-#else
-        const u8 *at = T + u32(r >> 3) * 96 + u32(cell >> 1) * 12 + (bit >> 3);
-#endif
+        const u32 bit = u32(r & 7) * 10 + u32(cell & 1) * 5, n = bit >> 3;
+        const u8 *block = T + u32(r >> 3) * 80, *first = block + u32(cell >> 1) * 8, *second = block + 64 + u32(cell >> 1) * 2 - 8;
+        const u8 *at0 = (n < 8 ? first : second) + n, *at1 = (n < 7 ? first : second) + n + 1;       // (byte 10, past the lane's ten, is read and not looked at)
         u32 b0, b1;
         if constexpr (GLOBAL_FLAGS)
         {
-            b0 = __hip_atomic_load(at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); b1 = __hip_atomic_load(at + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            b0 = __hip_atomic_load(at0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); b1 = __hip_atomic_load(at1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        else { b0 = at[0]; b1 = at[1]; }
-        return ((b0 | (b1 << 8)) >> (bit & 7)) & 0x3fu;
+        else { b0 = *at0; b1 = *at1; }
+        return ((b0 | (b1 << 8)) >> (bit & 7)) & 0x1fu;
+    };
+    // where a value came from (0 G, 1 E, 2 F), by the kind of value: the code's digits, tg the most significant
+    const auto cameFrom = [](u32 code, u32 type) -> u32
+    {
+        const u32 tg = u32(code >= 9) + u32(code >= 18), rest = code - 9 * tg, te = u32(rest >= 3) + u32(rest >= 6), tf = rest - 3 * te;
+        return 0 == type ? tg : 1 == type ? te : tf;
     };
     // one row of the band: q = the row's query base, dIn = the database base that enters the band behind it (database[i + 16])
     const auto bandRow = [&](int q, int dIn) -> u32
@@ -172,14 +213,51 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
         const U2 fromE = opaque(pkLt(g, e1) & pkLt(f, e1));
         const int teOut = bfi(asInt(-asS2(fromE)) /* per half: all ones where the flag is set */, 0x00010001, asInt(pkLt(g, f) << 1));
         const int te = fromCellAbove(teOut, 0);
-        const int flags = tg | (te << 2) | (tf << 4);
+        const U2 nine = { 9, 9 }, three = { 3, 3 };
+        const U2 code = asU2(tg) * nine + (asU2(te) * three + asU2(tf));       // per half: one of 27
+        const int flags = asInt(code);
         G = asInt(newG); E = newE; F = newF;
         // slide the database window: cell k takes cell k - 1's base, cell 0 the next one (what it takes in the last row is not looked at)
         d2 = fromCellBelow(d2, dIn);
-        return u32((flags & 0x3f) | ((flags >> 10) & 0xfc0));            // the row's 12 bits
+        return u32((flags & 0x1f) | ((flags >> 11) & 0x3e0));            // the row's ten bits
     };
 #if !defined(ISAAC_TIMING_BSW_NO_DP)      // (timing experiments only: builds with these macros give wrong results)
-    if constexpr (PADDED)
+    if constexpr (BSW_FROM_REGISTERS == SOURCE)
+    {   // eight rows per step; the next step's bases are asked for before this one's rows run
+        u32 q0, q1, d0, d1;
+        query.block(0, q0, q1, d0, d1);
+        u32 f[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        u32 b = 0;
+        for (; 8 * b + 8 <= L; ++b)
+        {
+            u32 nq0, nq1, nd0, nd1;
+            query.block(b + 1, nq0, nq1, nd0, nd1);
+            f[0] = bandRow(int(q0 & 0xffu), int(d0 & 0xffu));
+            f[1] = bandRow(int((q0 >> 8) & 0xffu), int((d0 >> 8) & 0xffu));
+            f[2] = bandRow(int((q0 >> 16) & 0xffu), int((d0 >> 16) & 0xffu));
+            f[3] = bandRow(int(q0 >> 24), int(d0 >> 24));
+            f[4] = bandRow(int(q1 & 0xffu), int(d1 & 0xffu));
+            f[5] = bandRow(int((q1 >> 8) & 0xffu), int((d1 >> 8) & 0xffu));
+            f[6] = bandRow(int((q1 >> 16) & 0xffu), int((d1 >> 16) & 0xffu));
+            f[7] = bandRow(int(q1 >> 24), int(d1 >> 24));
+            storeFlags(b, f);
+            // "used" here, so that the wait for the permutes stands here and counts the stores behind them as allowed to be in flight
+            asm volatile("" : "+v"(nq0), "+v"(nq1), "+v"(nd0), "+v"(nd1));
+            q0 = nq0; q1 = nq1; d0 = nd0; d1 = nd1;
+        }
+        if (8 * b < L)
+        {   // the last one to seven rows
+            u64 qq = u64(q0) | (u64(q1) << 32), dd = u64(d0) | (u64(d1) << 32);
+            for (u32 j = 0; 8 * b + j < L; ++j)
+            {
+                const u32 v = bandRow(int(u32(qq) & 0xffu), int(u32(dd) & 0xffu)); qq >>= 8; dd >>= 8;
+#pragma unroll
+                for (u32 t = 0; t < 8; ++t) if (t == j) f[t] = v;             // (no private array is indexed at run time)
+            }
+            storeFlags(b, f);
+        }
+    }
+    else if constexpr (BSW_FROM_LDS == SOURCE)
     {   // staged copies (LDS) with room behind them: four rows' bases per 32-bit read, requested four rows ahead.  (A read per row made
         // every row wait for the row's flag store as well: the waits the compiler places at a loop's head cover everything in flight.)
         const u32 *q4 = reinterpret_cast<const u32 *>(query.q), *d4 = reinterpret_cast<const u32 *>(database + 16);
@@ -274,7 +352,7 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
             {
                 // lane l looks at rows ii - 2l and ii - 2l - 1: bit t of `mask` says that row ii - t ends the run
                 const int row = ii - 2 * int(l);
-                const bool stop0 = row < 0 || 0 != (flagsAt(row, jj) & 3), stop1 = row < 1 || 0 != (flagsAt(row - 1, jj) & 3);
+                const bool stop0 = row < 0 || flagsAt(row, jj) >= 9, stop1 = row < 1 || flagsAt(row - 1, jj) >= 9;      // tg != 0
                 const u32 mask = (u32(__ballot(stop0) >> groupShift) & 0x5555u) | ((u32(__ballot(stop1) >> groupShift) & 0x5555u) << 1);
                 const u32 run = mask ? u32(__ffs(int(mask))) - 1 : 16u;
                 opLength += run; ii -= int(run);
@@ -282,7 +360,7 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
                 if (ii < 0) break;
             }
             ++opLength;
-            const u32 nextMaxType = (flagsAt(ii, jj) >> (2 * maxType)) & 3;
+            const u32 nextMaxType = cameFrom(flagsAt(ii, jj), maxType);
             if (nextMaxType != maxType) { ISAAC_BSW_PUSH(opLength, maxType == 0 ? OP_ALIGN : maxType == 1 ? OP_DELETE : OP_INSERT); opLength = 0; }
             ii += (maxType == 1) ? 0 : -1;
             jj += (maxType == 1) ? 1 : (maxType == 2) ? -1 : 0;
@@ -305,7 +383,7 @@ __device__ inline u32 bswCooperative(int matchScore, int mismatchScore, int gapO
 
 struct PlainQuery { const char *q; __device__ char operator()(u32 i) const { return q[i]; } };
 
-__global__ __launch_bounds__(128) void k_bsw_batch(int matchScore, int mismatchScore, int gapOpenScore, int gapExtendScore,
+__global__ __launch_bounds__(BSW_BLOCK) void k_bsw_batch(int matchScore, int mismatchScore, int gapOpenScore, int gapExtendScore,
                                                   const char *sequences, const isaac_bsw_job *jobs, u32 nJobs, u32 maxQueryLength,
                                                   isaac_bsw_result *results)
 {
@@ -319,7 +397,7 @@ __global__ __launch_bounds__(128) void k_bsw_batch(int matchScore, int mismatchS
     PlainQuery q; q.q = sequences + jb.query_offset;
     isaac_bsw_result &res = results[job];
     u32 n = 0; bool overflow = false;
-    const u32 ret = bswCooperative(matchScore, mismatchScore, gapOpenScore, gapExtendScore, q, jb.query_length, sequences + jb.database_offset, T, endVals, k,
+    const u32 ret = bswCooperative<BSW_FROM_FUNCTION>(matchScore, mismatchScore, gapOpenScore, gapExtendScore, q, jb.query_length, sequences + jb.database_offset, T, endVals, k,
                                    res.cigar, ISAAC_GPU_MAX_CIGAR_OPS, n, overflow);
     if (k == 0) { res.n_ops = overflow ? 0xffffffffu : n; res.offset = ret; }
 }
@@ -329,19 +407,19 @@ struct StrandQueryDev { ReadView read; bool reverse; u32 offset; __device__ char
 // GappedAligner::alignGapped (GappedAligner.cpp:167-249) for a list of candidates, 8 lanes per candidate: the statements of
 // alignGapped() in aligner.h with the DP on the group and everything else on its lane 0.  `bcl` is the tile, the job's
 // cluster index is relative to clusterBase.  Grid-stride over the jobs, so the launch does not need the job count on the host.
-__global__ __launch_bounds__(BSW_BLOCK) void k_gapped_jobs(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap,
-                                                    u32 maxReadLength, GappedResult *results, u8 *flagsArena)
+// NCH: 64-bit registers per lane for either sequence (eight bases each, eight lanes: sequences of up to 64 NCH bases stay in registers and the LDS of a
+// group is its traceback flags and end values alone); 0: the sequences are staged in LDS (reads of any length).
+template <u32 NCH>
+__device__ inline void gappedJobsBody(const DevParams &P, const DevReference &R, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap,
+                                      u32 maxReadLength, GappedResult *results, u8 *flagsArena, u8 *lds)
 {
-    extern __shared__ __align__(16) u8 lds[];
-    __shared__ double qualityTables[128];
-    for (u32 qi = threadIdx.x; qi < 128; qi += blockDim.x) qualityTables[qi] = qi < 64 ? Rg.logMatch[qi] : Rg.logMismatch[qi - 64];
-    __syncthreads();
-    DevReference R = Rg; R.logMatch = qualityTables; R.logMismatch = qualityTables + 64; R.logStride = 1;
+    const bool STAGED = 0 == NCH;
+    const u32 FETCH = STAGED ? 4 : NCH;          // chunks per lane a fetch brings
     const u32 group = bswGroupOfThread(), k = bswLaneOfThread(), groups = blockDim.x / BSW_GROUP_LANES;
-    // the traceback flags of the group's problem: a region of the arena per group of the grid (see bswCooperative); end values and the staged
-    // sequences in LDS
-    u8 *mine = lds + group * gappedGroupLdsBytes(maxReadLength);
-    u8 *T = ISAAC_BSW_GLOBAL_FLAGS ? flagsArena + (size_t(blockIdx.x) * groups + group) * bswFlagBytes(maxReadLength) : mine + 128 + 2 * ((maxReadLength + 47) & ~15u);
+    // the group's LDS: end values, [the staged sequences,] the traceback flags of its problem (ISAAC_BSW_GLOBAL_FLAGS: those in a region of the arena per group of the grid)
+    u8 *mine = lds + group * gappedGroupLdsBytes(maxReadLength, STAGED);
+    const u32 stagedBytes = STAGED ? 2 * ((maxReadLength + 47) & ~15u) : 0u;
+    u8 *T = ISAAC_BSW_GLOBAL_FLAGS ? flagsArena + (size_t(blockIdx.x) * groups + group) * bswFlagBytes(maxReadLength) : mine + 128 + stagedBytes;
     short *endVals = reinterpret_cast<short *>(mine);
     char *stagedQuery = reinterpret_cast<char *>(mine + 128);
     char *stagedDatabase = stagedQuery + ((maxReadLength + 47) & ~15u);
@@ -349,8 +427,8 @@ __global__ __launch_bounds__(BSW_BLOCK) void k_gapped_jobs(DevParams P, DevRefer
     // A problem is set up in two steps that each wait for memory -- its record, then the read's bytes and the window of the contig its record points to --
     // and a group that does them in front of its rows stands still for both (12 % of the kernel with two wavefronts per SIMD to hide it behind).  So the
     // group's next problem is fetched beside the current one: its record while the rows run, its bases (into registers) while the group walks the
-    // traceback; the staging into LDS is all that is left in front of the rows.  The loads are volatile so that they stay where they are written: the
-    // compiler otherwise moves a load to the block that uses it, behind the loop it was meant to overlap.
+    // traceback; what is left in front of the rows is the conversion of the read's bytes (and, staged, the stores into LDS).  The loads are volatile so that
+    // they stay where they are written: the compiler otherwise moves a load to the block that uses it, behind the loop it was meant to overlap.
     struct Prepared
     {
         Cand f; ReadView read; i64 begin, end, strandPosition; u32 sequenceLength, left, right, cluster; const char *database; bool go;
@@ -391,13 +469,13 @@ __global__ __launch_bounds__(BSW_BLOCK) void k_gapped_jobs(DevParams P, DevRefer
             p.queryChunks = (p.sequenceLength + 7) / 8; p.window = p.sequenceLength + 15; p.windowChunks = (p.window + 7) / 8;
         }
     };
-    // the group's 8 lanes bring the query and the window into LDS side by side, eight bases per lane and step, all of a lane's loads requested before
-    // the first is used: chunks c0 + k + 8 t (t < 4) of either sequence
-    const auto fetchChunks = [&](const Prepared &p, u32 c0, u64 (&q)[4], u64 (&w)[4])
+    // the group's 8 lanes bring the query and the window in side by side, eight bases per lane and step, all of a lane's loads requested before
+    // the first is used: chunks c0 + k + 8 t (t < FETCH) of either sequence
+    const auto fetchChunks = [&](const Prepared &p, u32 c0, u64 (&q)[FETCH], u64 (&w)[FETCH])
     {
         const bool reverse = p.f.reverse != 0;
 #pragma unroll
-        for (u32 t = 0; t < 4; ++t)
+        for (u32 t = 0; t < FETCH; ++t)
         {
             u32 c = c0 + k + BSW_GROUP_LANES * t;
             {   // BCL bytes of strand positions begin + 8c .. + 7 (position t of the chunk in byte t); never reads outside the read's bytes
@@ -421,28 +499,32 @@ __global__ __launch_bounds__(BSW_BLOCK) void k_gapped_jobs(DevParams P, DevRefer
             }
         }
     };
-    const auto stageChunks = [&](const Prepared &p, u32 c0, const u64 (&q)[4], const u64 (&w)[4])
+    // strandBase for the eight positions of a chunk at once: BCL bytes -> ASCII ACGTn
+    const auto asciiChunk = [](u64 bclBytes, bool reverse) -> u64
+    {
+        const u64 nFlags = zeroBytes(bclBytes & (0xfc * BYTES_01));
+        u64 codes = bclBytes & (0x03 * BYTES_01);
+        if (reverse) codes ^= 0x03 * BYTES_01;
+        const u64 nBytes = (nFlags >> 7) * 0xff;
+        return (asciiOfCodes(codes) & ~nBytes) | ((0x6e * BYTES_01) & nBytes);
+    };
+    const auto stageChunks = [&](const Prepared &p, u32 c0, const u64 (&q)[FETCH], const u64 (&w)[FETCH])
     {
         const bool reverse = p.f.reverse != 0;
 #pragma unroll
-        for (u32 t = 0; t < 4; ++t)
+        for (u32 t = 0; t < FETCH; ++t)
         {
             const u32 c = c0 + k + BSW_GROUP_LANES * t;
-            if (c < p.queryChunks)
-            {   // strandBase for eight positions at once
-                const u64 nFlags = zeroBytes(q[t] & (0xfc * BYTES_01));
-                u64 codes = q[t] & (0x03 * BYTES_01);
-                if (reverse) codes ^= 0x03 * BYTES_01;
-                const u64 nBytes = (nFlags >> 7) * 0xff;
-                reinterpret_cast<u64 *>(stagedQuery)[c] = (asciiOfCodes(codes) & ~nBytes) | ((0x6e * BYTES_01) & nBytes);
-            }
+            if (c < p.queryChunks) reinterpret_cast<u64 *>(stagedQuery)[c] = asciiChunk(q[t], reverse);
             if (c < p.windowChunks) reinterpret_cast<u64 *>(stagedDatabase)[c] = w[t];
         }
     };
     const u32 stride = gridDim.x * groups;
     u32 j = blockIdx.x * groups + group;
     Prepared cur; cur.go = false;
-    u64 q[4] = { 0, 0, 0, 0 }, w[4] = { 0, 0, 0, 0 };
+    u64 q[FETCH], w[FETCH];
+#pragma unroll
+    for (u32 t = 0; t < FETCH; ++t) { q[t] = 0; w[t] = 0; }
     if (j < nJobs)
     {
         uint4 raw[5]; fetchJob(j, raw);
@@ -457,7 +539,9 @@ __global__ __launch_bounds__(BSW_BLOCK) void k_gapped_jobs(DevParams P, DevRefer
         uint4 rawNext[5];
         if (haveNext) fetchJob(jn, rawNext);                       // on its way while this problem's rows run
         Prepared next; next.go = false;
-        u64 qn[4] = { 0, 0, 0, 0 }, wn[4] = { 0, 0, 0, 0 };
+        u64 qn[FETCH], wn[FETCH];
+#pragma unroll
+        for (u32 t = 0; t < FETCH; ++t) { qn[t] = 0; wn[t] = 0; }
         const auto lookAhead = [&]() { if (haveNext) { prepare(rawNext, next); if (next.go) fetchChunks(next, 0, qn, wn); } };
         GappedResult &res = results[j];
         Cand f = cur.f;
@@ -466,20 +550,35 @@ __global__ __launch_bounds__(BSW_BLOCK) void k_gapped_jobs(DevParams P, DevRefer
         {
             if (cur.begin) { if (k == 0) res.cigar[0] = cigarOp(u32(cur.begin), OP_SOFT_CLIP); n = 1; }
             STAMP(50);
-            stageChunks(cur, 0, q, w);
-            for (u32 c0 = 4 * BSW_GROUP_LANES; c0 < cur.windowChunks; c0 += 4 * BSW_GROUP_LANES)
-            {   // (reads beyond 241 bases: the rest of the sequences is fetched here)
-                u64 qm[4], wm[4];
-                fetchChunks(cur, c0, qm, wm);
-                stageChunks(cur, c0, qm, wm);
+            u32 ret;
+            if constexpr (STAGED)
+            {
+                stageChunks(cur, 0, q, w);
+                for (u32 c0 = 4 * BSW_GROUP_LANES; c0 < cur.windowChunks; c0 += 4 * BSW_GROUP_LANES)
+                {   // (reads beyond 241 bases: the rest of the sequences is fetched here)
+                    u64 qm[FETCH], wm[FETCH];
+                    fetchChunks(cur, c0, qm, wm);
+                    stageChunks(cur, c0, qm, wm);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                STAMP(51);
+                PlainQuery pq; pq.q = stagedQuery;
+                ret = bswCooperative<BSW_FROM_LDS, 0 != ISAAC_BSW_GLOBAL_FLAGS>(P.gapMatch, P.gapMismatch, -P.gapOpen, -P.gapExtend, pq, cur.sequenceLength, stagedDatabase, T, endVals, k, res.cigar, 40u, n, overflow,
+                                                                                  lookAhead);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            STAMP(51);
-            PlainQuery pq; pq.q = stagedQuery;
-            const u32 ret = bswCooperative<true, 0 != ISAAC_BSW_GLOBAL_FLAGS>(P.gapMatch, P.gapMismatch, -P.gapOpen, -P.gapExtend, pq, cur.sequenceLength, stagedDatabase, T, endVals, k, res.cigar, 40u, n, overflow,
-                                                                               lookAhead);
+            else
+            {
+                BswRegisterWords<NCH> words;
+                const bool reverse = cur.f.reverse != 0;
+#pragma unroll
+                for (u32 t = 0; t < NCH; ++t) { words.q[t] = asciiChunk(q[t], reverse); words.w[t] = w[t]; }
+                words.addressBase = ((threadIdx.x & 63u) & ~14u) << 2;
+                STAMP(51);
+                ret = bswCooperative<BSW_FROM_REGISTERS, 0 != ISAAC_BSW_GLOBAL_FLAGS>(P.gapMatch, P.gapMismatch, -P.gapOpen, -P.gapExtend, words, cur.sequenceLength, nullptr, T, endVals, k, res.cigar, 40u, n, overflow,
+                                                                                        lookAhead);
+            }
             STAMP(52);
             if (k == 0)
             {
@@ -499,8 +598,29 @@ __global__ __launch_bounds__(BSW_BLOCK) void k_gapped_jobs(DevParams P, DevRefer
         STAMP(54);
         cur = next;
 #pragma unroll
-        for (u32 t = 0; t < 4; ++t) { q[t] = qn[t]; w[t] = wn[t]; }
+        for (u32 t = 0; t < FETCH; ++t) { q[t] = qn[t]; w[t] = wn[t]; }
     }
+}
+// reads of up to 177 bases (2 x 150 and below): three registers per sequence and lane
+__global__ __launch_bounds__(BSW_BLOCK) void k_gapped_jobs(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap,
+                                                    u32 maxReadLength, GappedResult *results, u8 *flagsArena)
+{
+    extern __shared__ __align__(16) u8 lds[];
+    gappedJobsBody<3>(P, R, bcl, clusterBase, jobs, jobCounter, jobsCap, maxReadLength, results, flagsArena, lds);
+}
+// ... of up to 305 bases (2 x 250): five
+__global__ __launch_bounds__(BSW_BLOCK) void k_gapped_jobs_long(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap,
+                                                         u32 maxReadLength, GappedResult *results, u8 *flagsArena)
+{
+    extern __shared__ __align__(16) u8 lds[];
+    gappedJobsBody<5>(P, R, bcl, clusterBase, jobs, jobCounter, jobsCap, maxReadLength, results, flagsArena, lds);
+}
+// ... of any length: the sequences staged in LDS
+__global__ __launch_bounds__(BSW_BLOCK) void k_gapped_jobs_staged(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap,
+                                                           u32 maxReadLength, GappedResult *results, u8 *flagsArena)
+{
+    extern __shared__ __align__(16) u8 lds[];
+    gappedJobsBody<0>(P, R, bcl, clusterBase, jobs, jobCounter, jobsCap, maxReadLength, results, flagsArena, lds);
 }
 
 // AlignerBase::updateFragmentCigar for the alignments k_gapped_jobs produced: one thread per problem

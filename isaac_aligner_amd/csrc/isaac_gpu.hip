@@ -1335,11 +1335,16 @@ static void launchGappedJobs(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clusterBa
     // one wavefront (eight problems) per workgroup: the LDS of a workgroup is what limits the problems in flight, and at 2 x 250 five
     // workgroups of eight fit a CU where two of sixteen did
     // (2 x 250 with 5 % indel reads: 15.5 -> 13.0 ms per 1 M pairs; 2 x 150: 4.46 -> 4.44)
-    const size_t lds = size_t(BSW_BLOCK / BSW_GROUP_LANES) * gappedGroupLdsBytes(maxReadLength);
+    // (round 6) the sequences of a problem stay in the registers of its eight lanes when they fit -- reads of up to 177 bases in three registers per lane and
+    // sequence, of up to 305 in five -- and the traceback flags take ten bytes per row: 1.6 KB of LDS per problem at 2 x 150 where round 5 had 2.3 KB,
+    // three wavefronts per SIMD instead of two
+    const bool staged = maxReadLength > BSW_REGISTER_BASES_LONG;
+    const size_t lds = size_t(BSW_BLOCK / BSW_GROUP_LANES) * gappedGroupLdsBytes(maxReadLength, staged);
     {
         ScopedTimer t(c, timer);
         if (ISAAC_BSW_GLOBAL_FLAGS) c->bswFlags.reserve(size_t(GAPPED_GRID) * (BSW_BLOCK / BSW_GROUP_LANES) * bswFlagBytes(maxReadLength));
-        k_gapped_jobs<<<GAPPED_GRID, BSW_BLOCK, lds, c->stream>>>(c->P, c->ref(), bcl, clusterBase, gb.jobs, gb.counter, gb.cap, maxReadLength, gb.results, c->bswFlags.p);
+        const auto kernel = maxReadLength <= BSW_REGISTER_BASES_SHORT ? k_gapped_jobs : staged ? k_gapped_jobs_staged : k_gapped_jobs_long;
+        kernel<<<GAPPED_GRID, BSW_BLOCK, lds, c->stream>>>(c->P, c->ref(), bcl, clusterBase, gb.jobs, gb.counter, gb.cap, maxReadLength, gb.results, c->bswFlags.p);
     }
     HIP_CHECK(hipGetLastError());
     ScopedTimer t(c, rescanTimer);

@@ -184,22 +184,22 @@ static const u32 BSW_GROUP_LANES = 8;        // lanes that share one banded Smit
 static const u32 GAPPED_GRID = 8192;         // workgroups of k_gapped_jobs (it strides over the problems)
 static const u32 BSW_BLOCK = 64;             // threads per workgroup of k_gapped_jobs / k_bsw_batch: one wavefront, eight problems
 // LDS bytes of one banded Smith-Waterman group (bsw_kernel.h)
-// traceback flags: 48 bytes per four rows (bsw_kernel.h)
-__host__ __device__ inline u32 bswFlagBytes(u32 maxQueryLength) { return ((maxQueryLength + 7) / 8) * 96; }
+// traceback flags: 80 bytes per eight rows (bsw_kernel.h)
+__host__ __device__ inline u32 bswFlagBytes(u32 maxQueryLength) { return ((maxQueryLength + 7) / 8) * 80; }
 __host__ __device__ inline u32 bswGroupLdsBytes(u32 maxQueryLength) { return bswFlagBytes(maxQueryLength) + 128; }
 // k_gapped_jobs also keeps the query and the database window of the group there (the DP loop then reads LDS, not global memory)
 // (the eight groups of a wave touch their areas at the same offsets in the same instruction: a stride of an odd number of 16-byte units
 // spreads them over all LDS banks)
-__host__ __device__ inline u32 gappedGroupLdsBytes(u32 maxQueryLength)
+// staged: the sequences too (k_gapped_jobs_staged); else they are in registers and the group's LDS is its end values and traceback flags
+__host__ __device__ inline u32 gappedGroupLdsBytes(u32 maxQueryLength, bool staged)
 {
-    // the end values (128 bytes) and the staged query and database window, each with room for the look-ahead reads; the traceback flags of
-    // k_gapped_jobs are in device memory (GAPPED_GRID x groups regions of bswFlagBytes)
-#if defined(ISAAC_TIMING_BSW_SMALL_LDS)      // (timing experiment only: wrong results -- what a third wavefront per SIMD would buy before the flags are made to fit)
-    return 1616;
-#endif
-    const u32 bytes = 128 + 2 * ((maxQueryLength + 47) & ~15u) + (ISAAC_BSW_GLOBAL_FLAGS ? 0u : bswFlagBytes(maxQueryLength));
+    // the end values (128 bytes), [the staged query and database window, each with room for the look-ahead reads,] the traceback flags (ISAAC_BSW_GLOBAL_FLAGS:
+    // those in device memory, GAPPED_GRID x groups regions of bswFlagBytes)
+    const u32 bytes = 128 + (staged ? 2 * ((maxQueryLength + 47) & ~15u) : 0u) + (ISAAC_BSW_GLOBAL_FLAGS ? 0u : bswFlagBytes(maxQueryLength));
     return (((bytes + 15) / 16) | 1u) * 16;
 }
+// what the registers of the two forms hold (bsw_kernel.h: gappedJobsBody)
+static const u32 BSW_REGISTER_BASES_SHORT = 177, BSW_REGISTER_BASES_LONG = 305;
 
 __global__ __launch_bounds__(64) void k_build_fragments(DevParams P, const u8 *__restrict__ bcl, u32 clusterBase, u32 nChunk, const Match *__restrict__ matches, const u64 *__restrict__ offsets, int trim, ClusterPools pools, AlignList al, u32 *generalList, u32 *generalCount);
 __global__ __launch_bounds__(64) void k_build_fragments_general(DevParams P, const u8 *bcl, u32 clusterBase, const Match *matches, const u64 *offsets, int trim, u8 *matchOrderArena, u8 *orderArena, ClusterPools pools, AlignList al, const u32 *list, const u32 *listCount);
@@ -226,7 +226,9 @@ __global__ __launch_bounds__(SELECT_BLOCK) void k_select(const TemplateConstants
 __global__ __launch_bounds__(64) void k_select_heavy(DevParams P, DevReference R, DevTls tls, RogCorrection rog, double logMismatchQ40, const u8 *bcl, u32 clusterBase, u32 nList, const u32 *nListDev, u32 tile, ClusterPools pools, u8 *arena, u64 arenaBytes, TemplateCaps caps, const u32 *list, RescueBuffers rb, const GappedResult *gappedResults, const GappedJob *gappedJobs, const ClusterSums *sums, FragmentRecord *records, u32 *cigars, Counters *counters);
 namespace isaac
 {
-__global__ __launch_bounds__(128) void k_bsw_batch(int matchScore, int mismatchScore, int gapOpenScore, int gapExtendScore, const char *sequences, const isaac_bsw_job *jobs, u32 nJobs, u32 maxQueryLength, isaac_bsw_result *results);
-__global__ __launch_bounds__(128) void k_gapped_jobs(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap, u32 maxReadLength, GappedResult *results, u8 *flagsArena);
+__global__ __launch_bounds__(BSW_BLOCK) void k_bsw_batch(int matchScore, int mismatchScore, int gapOpenScore, int gapExtendScore, const char *sequences, const isaac_bsw_job *jobs, u32 nJobs, u32 maxQueryLength, isaac_bsw_result *results);
+__global__ __launch_bounds__(BSW_BLOCK) void k_gapped_jobs(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap, u32 maxReadLength, GappedResult *results, u8 *flagsArena);
+__global__ __launch_bounds__(BSW_BLOCK) void k_gapped_jobs_long(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap, u32 maxReadLength, GappedResult *results, u8 *flagsArena);
+__global__ __launch_bounds__(BSW_BLOCK) void k_gapped_jobs_staged(DevParams P, DevReference R, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap, u32 maxReadLength, GappedResult *results, u8 *flagsArena);
 __global__ __launch_bounds__(256) void k_gapped_rescan(DevParams P, DevReference Rg, const u8 *bcl, u32 clusterBase, const GappedJob *jobs, const u32 *jobCounter, u32 jobsCap, GappedResult *results);
 }

@@ -70,14 +70,26 @@ def test_bsw_kernel_vs_oracle_random(torch, oracle, scores):
     dict(read_length=150, n_pairs=4000, seed=1, genome_bases=400000),
     dict(read_length=100, n_pairs=3000, seed=5, genome_bases=300000),
     dict(read_length=250, n_pairs=1500, seed=9, genome_bases=300000, indel_read_fraction=0.2, indel_max=10),
+    # beyond what the banded-SW kernel keeps in registers (305 bases): its form with the sequences staged in LDS
+    dict(read_length=320, n_pairs=800, seed=11, genome_bases=300000, indel_read_fraction=0.3, indel_max=10, seed_offsets=(0, 288, 64, 128, 192)),
 ])
 def case(request, torch, oracle):
     """one synthetic data set pushed through both implementations up to the match lists"""
     from isaac_aligner_amd import gpu
-    cfg = request.param
+    cfg = dict(request.param)
+    seed_offsets = cfg.pop("seed_offsets", None)
     contigs, bcl, truth = make_inputs(**cfg)
     L = cfg["read_length"]
-    p = options.default_params(L, L)
+    if seed_offsets:
+        # (--seeds auto makes more seeds for reads this long than the library takes: the --seeds 0:288:64:128:192 of a command line instead)
+        p = options.default_params(150, 150)
+        p.read_length[0] = p.read_length[1] = L
+        p.n_seeds = 2 * len(seed_offsets)
+        for i, offset in enumerate(seed_offsets * 2):
+            p.seeds[i].offset, p.seeds[i].length, p.seeds[i].read_index = offset, 32, i // len(seed_offsets)
+        p.first_pass_seeds = 2
+    else:
+        p = options.default_params(L, L)
     al = gpu.Aligner(p, 0, contigs)
     al.build_index(annotate_neighbors=True)
     ref = oracle.reference(contigs)
