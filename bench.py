@@ -631,9 +631,12 @@ def main():
     # workload at this many pairs per launch; otherwise null.
     traffic, traffic_source = None, "no profiles/*_pmc_summary.json for this workload (genome_bases, read_length, pairs_per_launch)"
     prof_dir = os.path.join(ROOT, "profiles")
+    pmc, pmc_name = None, None            # the newest counter summary of this workload (what north_star's rooflines below are made of)
     for name in sorted((n for n in os.listdir(prof_dir) if n.endswith("_pmc_summary.json")), reverse=True) if os.path.isdir(prof_dir) else []:
         summary = json.load(open(os.path.join(prof_dir, name)))
         w = summary.get("workload", {})
+        if pmc is None and w.get("genome_bases") == args.genome_bases and w.get("read_length") == L and w.get("pairs_per_launch") == args.pairs_per_step:
+            pmc, pmc_name = summary, name
         # per (kernel, timer): a kernel that several stages launch has an entry per stage where the summary makes the split
         k = summary.get("k_" + dominant) or (summary.get("k_gapped_jobs:fragments") if dominant == "gapped_fragments" else None)
         if k and "hbm_bytes_per_launch" in k and w.get("genome_bases") == args.genome_bases and w.get("read_length") == L and w.get("pairs_per_launch") == args.pairs_per_step:
@@ -669,6 +672,68 @@ def main():
                 "concurrent_contexts": n_contexts, "single_stream": single_stream,
                 # the banded Smith-Waterman kernels are VALU-bound: 16 band cells per row and problem (report cell updates/s)
                 "band_cell_updates_per_s": round((c["bsw_jobs"] + c["rescue_bsw"]) * L * 16 / max(1e-9, (total_ms.get("gapped_fragments", 0.0) + total_ms.get("gapped_rescue", 0.0)) / 1e3), 1)}
+
+    # ---- what north_star asks to be shown beside the number: achieved HBM GB/s of the seed lookup, LDS / occupancy of the banded SW, and -- the ceiling that
+    # binds an int16 DP and this step -- vector issue.  Durations are this run's (HIP events; the kernels alone where the single-stream pass ran); the counters
+    # are the committed summary's of the same workload (separate rocprofv3 --pmc passes: counters cannot be read from inside this process).
+    SIMDS, CLOCK_HZ = 1024, 2.4e9                    # 256 CUs x 4 SIMDs; one wave instruction issues in 4 clocks (MI355X_MICROARCH.md)
+    alone = single["timers"] if single is not None else timers
+    def duration_s(timer):                            # average launch of a timer's kernel with the GPU to itself, seconds
+        return alone.get(timer, (0.0, 0))[0] / 1e3
+    find_launches = max(1, timers["find_matches"][1])
+    find_s = timers["find_matches"][0] / 1e3         # (the lookups are not part of the single-stream pass: they run one after the other in the timed region too)
+    find_algorithmic = per_kernel_bytes["find_matches"] / find_launches
+    seed_lookup = {"kernel": "k_find_matches", "avg_launch_ms": round(find_s * 1e3, 4), "algorithmic_bytes_per_launch": int(find_algorithmic),
+                   "algorithmic_GBps": round(find_algorithmic / find_s / 1e9, 1) if find_s else None, "frac": round(find_algorithmic / find_s / 1e9 / 8000.0, 5) if find_s else None,
+                   "line_GBps": None, "traffic_ratio": None}
+    sw = {"kernel": "k_gapped_jobs", "cells_per_s": (single_stream or roofline)["band_cell_updates_per_s"], "lanes_per_problem": 8, "lds_bytes_per_wg": None, "waves_per_simd": None,
+          "lds_bank_conflict_frac": None, "valu_issue_frac": None}
+    # LDS per workgroup (csrc/kernels.h: gappedGroupLdsBytes, eight problems per wavefront and workgroup) and what it lets a CU hold
+    sw["lds_bytes_per_wg"] = 8 * ((((128 + (L + 7) // 8 * 80 + 15) // 16) | 1) * 16) if L <= 305 else None
+    vgprs = None
+    for name in sorted((n for n in os.listdir(prof_dir) if n.endswith("kernel_resources.txt")), reverse=True) if os.path.isdir(prof_dir) else []:
+        for line in open(os.path.join(prof_dir, name)):
+            f = line.split()
+            if len(f) >= 3 and f[0].endswith("k_gapped_jobs" if L <= 177 else "k_gapped_jobs_long"):
+                vgprs = int(f[2])
+        if vgprs:
+            sw["vgprs"], sw["resources_source"] = vgprs, "profiles/" + name
+            break
+    if sw["lds_bytes_per_wg"]:
+        by_lds = (160 * 1024 // sw["lds_bytes_per_wg"]) / 4.0
+        sw["waves_per_simd"] = min(by_lds, float(512 // vgprs)) if vgprs else by_lds
+    valu_issue = {"step": None, "dominant": None}
+    if pmc is not None:
+        fm = pmc.get("k_find_matches", {})
+        if fm.get("hbm_bytes_per_launch") and find_s:
+            seed_lookup["line_GBps"] = round(fm["hbm_bytes_per_launch"] / find_s / 1e9, 1)
+            seed_lookup["traffic_ratio"] = round(fm["hbm_bytes_per_launch"] / find_algorithmic, 3)
+            seed_lookup["valu_lane_utilisation"] = round(fm.get("valu_lane_utilisation", 0.0), 3)
+        gj = pmc.get("k_gapped_jobs:fragments") or pmc.get("k_gapped_jobs", {})
+        if gj.get("lds_bank_conflict_frac") is not None:
+            sw["lds_bank_conflict_frac"] = round(gj["lds_bank_conflict_frac"], 4)
+        def issue_s(entry):                           # seconds the chip's SIMDs need to issue one launch's vector instructions
+            return entry["SQ_INSTS_VALU"] / entry["launches"] * 4.0 / (SIMDS * CLOCK_HZ) if entry.get("SQ_INSTS_VALU") and entry.get("launches") else 0.0
+        if gj.get("SQ_INSTS_VALU") and duration_s("gapped_fragments"):
+            sw["valu_issue_frac"] = round(issue_s(gj) / duration_s("gapped_fragments"), 3)
+        # the step: every kernel of one lookup + one selection, launches per step as the timed region made them
+        step_kernels = {"find_matches": ["k_find_matches"], "compact_matches": ["k_compact_matches"], "build_fragments": ["k_build_fragments"], "build_fragments_general": ["k_build_fragments_general"],
+                        "align_candidates": ["k_align_candidates"], "finish_candidates": ["k_finish_candidates", "k_cluster_kinds", "k_cluster_order"], "finish_candidates_general": ["k_finish_candidates_general"],
+                        "indel_fragments": ["k_indel_fragments"], "gapped_fragments": ["k_gapped_jobs:fragments"], "gapped_fragments_rescan": ["k_gapped_rescan"], "finish_fragments": ["k_finish_fragments"],
+                        "finish_fragments_general": ["k_finish_fragments_general"], "plan_rescue": ["k_plan_rescue"], "rescue_windows": ["k_rescue_windows"], "rescue_align": ["k_rescue_align"],
+                        "rescue_gapped_plan": ["k_rescue_gapped_plan", "k_rescue_gapped_plan_long"], "gapped_rescue": ["k_gapped_jobs:rescue"], "gapped_rescue_rescan": ["k_gapped_rescan"],
+                        "sums_wave": ["k_cluster_sums16", "k_cluster_sums"], "sums_large": ["k_cluster_sums_mid", "k_cluster_sums_large"], "sums_xl": ["k_cluster_sums_xl"], "sums_huge": ["k_cluster_sums_huge"],
+                        "select": ["k_select"]}
+        step_issue = sum(issue_s(pmc[k]) for names in step_kernels.values() for k in names if k in pmc)
+        dom_names = step_kernels.get(dominant, [])
+        dom_issue = sum(issue_s(pmc[k]) for k in dom_names if k in pmc)
+        valu_issue = {"step": round(step_issue / (elapsed / args.steps), 3) if step_issue else None, "step_issue_floor_ms": round(step_issue * 1e3, 3),
+                      "dominant": round(dom_issue / duration_s(dominant), 3) if dom_issue and duration_s(dominant) else None,
+                      "dominant_issue_floor_ms": round(dom_issue * 1e3, 3), "source": "profiles/" + pmc_name,
+                      "note": "sum over the kernels of SQ_INSTS_VALU per launch x 4 clocks / (1024 SIMDs x 2.4 GHz), over the measured time: the step's on the timed region, the dominant kernel's with the GPU to itself"}
+    roofline["seed_lookup"] = seed_lookup
+    roofline["sw"] = sw
+    roofline["valu_issue_frac"] = valu_issue
 
     # ---- CPU baseline + parity: the oracle (a port of the reference path) on a bounded sample of the same workload, host cores ---
     cpu, parity = None, {"parity_checked_pairs": 0, "parity_diffs": None}

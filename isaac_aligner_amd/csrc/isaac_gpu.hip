@@ -12,7 +12,12 @@
 //   leaves / formats k_bsw_batch, k_tls_samples, k_load_candidates / k_write_candidates, k_fq_* (fastq_kernel.h)
 //   index builder    k-mer enumeration + hipCUB radix sort + run analysis (+ 70-permutation neighbour annotation), k_prefix_table
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/functional.hpp>
 #include <algorithm>
 #include <mutex>
 #include <cstdio>
@@ -531,26 +536,34 @@ u32 gridFor(u64 n, u32 block)
 // for grid-stride kernels over arrays that may hold 2^32 elements and more
 u32 gridStrided(u64 n, u32 block) { return u32(std::min<u64>((n + block - 1) / block, (u64(1) << 22))); }
 
+// scans and sorts: rocPRIM called directly (rounds 1-5 went through hipCUB, the CUB-shaped wrapper around it, whose entry points take `int` counts)
+inline void checkCount(size_t n, const char *what)
+{   // (nothing on the path comes near: a chunk has at most 2^20 clusters, a mask of the GRCh38 table 46 M entries -- but a count that did would be truncated silently elsewhere)
+    if (n >= (size_t(1) << 31)) throw std::length_error(std::string(what) + ": 2^31 or more items in one device scan / sort");
+}
 template <typename T> void exclusiveSum(isaac_gpu_ctx *c, const T *in, T *out, size_t n)
 {
+    checkCount(n, "exclusiveSum");
     size_t bytes = 0;
-    HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, int(n), c->stream));
+    HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, in, out, T(0), n, rocprim::plus<T>(), c->stream));
     c->cubTemp.reserve(bytes + 16);
-    HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(c->cubTemp.p, bytes, in, out, int(n), c->stream));
+    HIP_CHECK(rocprim::exclusive_scan(c->cubTemp.p, bytes, in, out, T(0), n, rocprim::plus<T>(), c->stream));
 }
 template <typename T> void inclusiveSum(isaac_gpu_ctx *c, const T *in, T *out, size_t n)
 {
+    checkCount(n, "inclusiveSum");
     size_t bytes = 0;
-    HIP_CHECK(hipcub::DeviceScan::InclusiveSum(nullptr, bytes, in, out, int(n), c->stream));
+    HIP_CHECK(rocprim::inclusive_scan(nullptr, bytes, in, out, n, rocprim::plus<T>(), c->stream));
     c->cubTemp.reserve(bytes + 16);
-    HIP_CHECK(hipcub::DeviceScan::InclusiveSum(c->cubTemp.p, bytes, in, out, int(n), c->stream));
+    HIP_CHECK(rocprim::inclusive_scan(c->cubTemp.p, bytes, in, out, n, rocprim::plus<T>(), c->stream));
 }
 template <typename K, typename V> void sortPairs(isaac_gpu_ctx *c, const K *kin, K *kout, const V *vin, V *vout, size_t n, int endBit = int(sizeof(K) * 8))
 {
+    checkCount(n, "sortPairs");
     size_t bytes = 0;
-    HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kin, kout, vin, vout, int(n), 0, endBit, c->stream));
+    HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0u, unsigned(endBit), c->stream));
     c->cubTemp.reserve(bytes + 16);
-    HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->cubTemp.p, bytes, kin, kout, vin, vout, int(n), 0, endBit, c->stream));
+    HIP_CHECK(rocprim::radix_sort_pairs(c->cubTemp.p, bytes, kin, kout, vin, vout, n, 0u, unsigned(endBit), c->stream));
 }
 
 int fail(int code, const std::string &what) { g_error = what; return code; }
@@ -1046,21 +1059,22 @@ int isaac_gpu_build_index(isaac_gpu_ctx *c, uint32_t repeatThreshold, int annota
         DevBuf<u64> keysAlt; DevBuf<u8> flags, flagsAlt;
         keysAlt.reserve(nDistinct); flags.reserve(nDistinct); flagsAlt.reserve(nDistinct);
         HIP_CHECK(hipMemsetAsync(flags.p, 0, nDistinct, st));
-        hipcub::DoubleBuffer<u64> dk(distinct.p, keysAlt.p); hipcub::DoubleBuffer<u8> df(flags.p, flagsAlt.p);
+        rocprim::double_buffer<u64> dk(distinct.p, keysAlt.p); rocprim::double_buffer<u8> df(flags.p, flagsAlt.p);
         u32 at[8]; for (u32 b = 0; b < 8; ++b) at[b] = b;           // where byte b of the k-mer sits in the keys right now
         auto shuffleTo = [&](const u32 next[8])
         {
             u32 src[8];                                                // out byte next[b] = current byte at[b]
             for (u32 b = 0; b < 8; ++b) src[next[b]] = at[b];
-            k_shuffle_keys<<<gridStrided(nDistinct, 256), 256, 0, st>>>(dk.Current(), nDistinct, makeShuffle(src));
+            k_shuffle_keys<<<gridStrided(nDistinct, 256), 256, 0, st>>>(dk.current(), nDistinct, makeShuffle(src));
             for (u32 b = 0; b < 8; ++b) at[b] = next[b];
         };
         auto sortKeys = [&](int endBit)
         {
+            checkCount(nDistinct, "neighbour annotation");
             size_t bytes = 0;
-            HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dk, df, size_t(nDistinct), 0, endBit, st));
+            HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, dk, df, size_t(nDistinct), 0u, unsigned(endBit), st));
             c->cubTemp.reserve(bytes + 16);
-            HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->cubTemp.p, bytes, dk, df, size_t(nDistinct), 0, endBit, st));
+            HIP_CHECK(rocprim::radix_sort_pairs(c->cubTemp.p, bytes, dk, df, size_t(nDistinct), 0u, unsigned(endBit), st));
         };
         for (u32 chosen = 0; chosen < 256; ++chosen)
         {   // any 4 of the 8 blocks of 4 bases (oligo/Permutate.cpp:94-145, getPermutateList(4) at NeighborsFinder.cpp:196)
@@ -1068,7 +1082,7 @@ int isaac_gpu_build_index(isaac_gpu_ctx *c, uint32_t repeatThreshold, int annota
             u32 next[8]; blockLayout(chosen, next);
             shuffleTo(next);
             sortKeys(32);                                              // groups of equal chosen blocks
-            k_mark_neighbors<<<gridStrided(nDistinct, 256), 256, 0, st>>>(dk.Current(), df.Current(), nDistinct);
+            k_mark_neighbors<<<gridStrided(nDistinct, 256), 256, 0, st>>>(dk.current(), df.current(), nDistinct);
             HIP_CHECK(hipGetLastError());
         }
         u32 identity[8]; for (u32 b = 0; b < 8; ++b) identity[b] = b;
@@ -1077,7 +1091,7 @@ int isaac_gpu_build_index(isaac_gpu_ctx *c, uint32_t repeatThreshold, int annota
         for (u32 mask = 0; mask < INDEX_MASKS; ++mask)
         {
             const u64 first = c->maskOffsets[mask], n = c->maskOffsets[mask + 1] - first;
-            if (n) k_apply_neighbors<<<gridFor(n, 256), 256, 0, st>>>(c->entries.p, entryRun.p, first, n, distinctBase[mask], df.Current());
+            if (n) k_apply_neighbors<<<gridFor(n, 256), 256, 0, st>>>(c->entries.p, entryRun.p, first, n, distinctBase[mask], df.current());
         }
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(st));
@@ -2395,11 +2409,12 @@ int isaac_gpu_fastq_to_bcl(isaac_gpu_ctx *c, const char *fastq, uint64_t nBytes,
     DevBuf<int> &nSelected = c->fqSelected; nSelected.reserve(1);
     k_fq_line_starts<<<gridFor(nBytes, 256), 256, 0, st>>>(fastq, nBytes, isStart.p);
     {
-        hipcub::CountingInputIterator<u64> positions(0);
+        checkCount(nBytes, "FASTQ text of one call");
+        rocprim::counting_iterator<u64> positions(0);
         size_t bytes = 0;
-        HIP_CHECK(hipcub::DeviceSelect::Flagged(nullptr, bytes, positions, isStart.p, lineStart.p, nSelected.p, int(nBytes), st));
+        HIP_CHECK(rocprim::select(nullptr, bytes, positions, isStart.p, lineStart.p, nSelected.p, size_t(nBytes), st));
         c->cubTemp.reserve(bytes + 16);
-        HIP_CHECK(hipcub::DeviceSelect::Flagged(c->cubTemp.p, bytes, positions, isStart.p, lineStart.p, nSelected.p, int(nBytes), st));
+        HIP_CHECK(rocprim::select(c->cubTemp.p, bytes, positions, isStart.p, lineStart.p, nSelected.p, size_t(nBytes), st));
     }
     int nLinesHost = 0;
     HIP_CHECK(hipMemcpyAsync(&nLinesHost, nSelected.p, 4, hipMemcpyDeviceToHost, st));
@@ -2412,9 +2427,9 @@ int isaac_gpu_fastq_to_bcl(isaac_gpu_ctx *c, const char *fastq, uint64_t nBytes,
     k_fq_lines<<<gridFor(nLines, 256), 256, 0, st>>>(fastq, nBytes, lineStart.p, nLines, lineEnd.p, lineMap.p);
     {
         size_t bytes = 0;
-        HIP_CHECK(hipcub::DeviceScan::ExclusiveScan(nullptr, bytes, lineMap.p, mapBefore.p, FqCompose(), FQ_IDENTITY, int(nLines), st));
+        HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, lineMap.p, mapBefore.p, FQ_IDENTITY, size_t(nLines), FqCompose(), st));
         c->cubTemp.reserve(bytes + 16);
-        HIP_CHECK(hipcub::DeviceScan::ExclusiveScan(c->cubTemp.p, bytes, lineMap.p, mapBefore.p, FqCompose(), FQ_IDENTITY, int(nLines), st));
+        HIP_CHECK(rocprim::exclusive_scan(c->cubTemp.p, bytes, lineMap.p, mapBefore.p, FQ_IDENTITY, size_t(nLines), FqCompose(), st));
     }
     k_fq_headers<<<gridFor(nLines, 256), 256, 0, st>>>(mapBefore.p, nLines, isHeader.p);
     exclusiveSum(c, isHeader.p, recordIndex.p, nLines);
