@@ -538,7 +538,9 @@ u32 gridStrided(u64 n, u32 block) { return u32(std::min<u64>((n + block - 1) / b
 
 // scans and sorts: rocPRIM called directly (rounds 1-5 went through hipCUB, the CUB-shaped wrapper around it, whose entry points take `int` counts)
 inline void checkCount(size_t n, const char *what)
-{   // (nothing on the path comes near: a chunk has at most 2^20 clusters, a mask of the GRCh38 table 46 M entries -- but a count that did would be truncated silently elsewhere)
+{   // the wrappers below serve per-chunk and per-mask arrays whose elements are addressed with 32-bit indexes by the kernels around them (a chunk has at most 2^20
+    // clusters, a mask of the GRCh38 table 46 M entries): a count that does not fit is refused here, loudly, instead of wrapping there.  (The one sort that is
+    // larger -- the distinct k-mers of the neighbour annotation -- calls rocPRIM with its size_t count itself.)
     if (n >= (size_t(1) << 31)) throw std::length_error(std::string(what) + ": 2^31 or more items in one device scan / sort");
 }
 template <typename T> void exclusiveSum(isaac_gpu_ctx *c, const T *in, T *out, size_t n)
@@ -1070,8 +1072,7 @@ int isaac_gpu_build_index(isaac_gpu_ctx *c, uint32_t repeatThreshold, int annota
         };
         auto sortKeys = [&](int endBit)
         {
-            checkCount(nDistinct, "neighbour annotation");
-            size_t bytes = 0;
+            size_t bytes = 0;                               // (rocPRIM takes the count as size_t: the distinct k-mers of both strands of GRCh38 are more than 2^31)
             HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, dk, df, size_t(nDistinct), 0u, unsigned(endBit), st));
             c->cubTemp.reserve(bytes + 16);
             HIP_CHECK(rocprim::radix_sort_pairs(c->cubTemp.p, bytes, dk, df, size_t(nDistinct), 0u, unsigned(endBit), st));
