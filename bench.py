@@ -50,7 +50,8 @@ def parse():
     ap.add_argument("--no-broadcast-index", dest="broadcast_index", action="store_false", help="with several GPUs: every rank builds its own table (N builds side by side)")
     ap.add_argument("--no-cli-pass", action="store_true", help="skip the isaac-align end-to-end leg (config.cli_end_to_end)")
     ap.add_argument("--cli-pairs", type=int, default=10_000_000, help="pairs the isaac-align leg aligns (the run's own batches, written as FASTQ)")
-    ap.add_argument("--contexts", type=int, default=3, help="contexts (streams) per GPU that take the steps' selections in turn; they share the contigs and the table")
+    ap.add_argument("--contexts", type=int, default=4, help="contexts (streams) per GPU that take the steps' selections in turn; they share the contigs and the table")
+    ap.add_argument("--stream-lookups", action="store_true", help="select a step as soon as it is looked up once every contig has a match (isaac-align's closeHits) instead of all lookups first; measured: no gain with the reads resident -- a lookup that shares the GPU with three selections takes 5.4 ms instead of 1.15 and sits on every step's critical path (profiles/exp_r6_stream.log)")
     ap.add_argument("--no-single-stream-pass", action="store_true", help="skip the extra pass of the same steps on one context (per-kernel times without sharing)")
     ap.add_argument("--launch-check", action="store_true", help="GPU-less check of the launcher and the collectives (gloo): no alignment")
     return ap.parse_args()
@@ -256,6 +257,11 @@ def main():
             extra.set_index_tensors(table)
         als.append(extra)
         streams.append(st)
+    # ... and one for the lookups, so that the lookup of a later step does not queue behind a selection
+    finder_stream = torch.cuda.Stream(dev)
+    with torch.cuda.stream(finder_stream):
+        finder = gpu.Aligner(params, local_rank, genome)
+        finder.set_index_tensors(al.index_tensors())
     n_batches = args.warmup + args.steps
     per_rank = args.pairs_per_step
     batches = []
@@ -314,6 +320,9 @@ def main():
             pool = [torch.empty_like(out[s][0]) for s in range(args.steps) for _ in range(world)]
             pool += [torch.empty_like(out[s][2]) for s in range(args.steps) for _ in range(world)]
             del pool
+    with torch.cuda.stream(finder_stream):           # (the lookup context grows its buffers here, not in the timed steps)
+        finder.find_matches(batches[0], tile=tile_of(0), out=match_bufs[0])
+    finder.synchronize(); finder.reset_timers()
     for ctx in als:
         ctx.synchronize()
         ctx.reset_timers()
@@ -323,15 +332,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
-    found = []
-    all_hits = np.zeros(al.n_contigs, np.uint8)
-    for s in range(args.steps):                       # phase 1: FindMatchesTransition
-        m, o, hits = al.find_matches(batches[args.warmup + s], tile=tile_of(s), out=match_bufs[s])
-        found.append((m, o))
-        all_hits |= hits
-    loaded = reduce_hits(all_hits)
-    for ctx in als:
-        ctx.set_loaded_contigs(loaded)                # MatchSelector loads only contigs that received matches
+    # FindMatchesTransition comes before SelectMatchesTransition because the selection wants to know which contigs have matches anywhere in the run
+    # (MatchSelector loads only those: the rest-of-genome correction, hence MAPQ, depends on the set): all lookups, then all selections.
+    # --stream-lookups: once every contig has a match -- a whole-genome run gets there with its first tile -- no later lookup can change that set, and from
+    # there on a step is selected as soon as it is looked up, the later lookups (a context and stream of their own) beside the selections, as isaac-align itself
+    # does (closeHits).  Same records; with the reads resident it is no faster (see the option's help), so the two phases stay apart by default.  With several GPUs the contig flags are
+    # all-reduced after every lookup until the set is complete -- every rank sees the same reduced set, so every rank takes the same turn.
     # Every step's CIGARs are packed behind its selection without a host wait (isaac_gpu_compact_cigars_async: the packed length stays on the
     # device); with several GPUs the step's records and CIGAR pool then leave for rank 0 behind the later steps (shard.StepGather: nothing
     # in the loop waits for the GPU or for another rank -- every rank's record count is known from the static split)
@@ -344,16 +350,45 @@ def main():
     # the gathers are issued from a stream of their own that waits for the step's context: issued from the stream a context computes on, that
     # context's later steps would queue behind the other contexts' steps and the contexts would take turns instead of overlapping
     gather_stream = torch.cuda.Stream(device=dev) if gatherer is not None else None
-    for s in range(args.steps):                       # phase 2: SelectMatchesTransition
+    found, looked_up = [], []
+    all_hits = np.zeros(al.n_contigs, np.uint8)
+    loaded, streaming, streaming_from, next_select = None, False, None, 0
+
+    def select_step(s):                               # SelectMatchesTransition for step s, on the context whose turn it is
         m, o = found[s]
         ctx = als[s % n_contexts]
-        ctx.select(batches[args.warmup + s], m, o, tls, tile=tile_of(s), out=out[s][:2])
-        ctx.compact_cigars_async(out[s][0], out[s][1], out[s][2], out[s][3])
+        ctx_stream = streams[s % n_contexts]
+        ctx_stream.wait_event(looked_up[s])
+        with torch.cuda.stream(ctx_stream):
+            ctx.select(batches[args.warmup + s], m, o, tls, tile=tile_of(s), out=out[s][:2])
+            ctx.compact_cigars_async(out[s][0], out[s][1], out[s][2], out[s][3])
         if gatherer is not None:
-            step_done = (streams[s % n_contexts] if ctx is not al else torch.cuda.current_stream(dev)).record_event()
+            step_done = ctx_stream.record_event()
             with torch.cuda.stream(gather_stream):
                 gather_stream.wait_event(step_done)
                 gatherer.add(out[s][0], out[s][2], out[s][3])
+    for s in range(args.steps):                       # FindMatchesTransition for step s
+        with torch.cuda.stream(finder_stream):
+            m, o, hits = finder.find_matches(batches[args.warmup + s], tile=tile_of(s), out=match_bufs[s])
+            looked_up.append(finder_stream.record_event())
+        found.append((m, o))
+        all_hits |= hits
+        if not streaming:
+            loaded = reduce_hits(all_hits)
+            if not args.stream_lookups:
+                continue
+            if loaded.all():
+                streaming, streaming_from = True, s
+                for ctx in als:
+                    ctx.set_loaded_contigs(loaded)    # MatchSelector loads only contigs that received matches: all of them from here on
+        while streaming and next_select <= s:
+            select_step(next_select); next_select += 1
+    if not streaming:
+        for ctx in als:
+            ctx.set_loaded_contigs(loaded)
+    while next_select < args.steps:
+        select_step(next_select); next_select += 1
+    finder.synchronize()
     for ctx in als:
         ctx.synchronize()
     gathered = gatherer.finish() if gatherer is not None else None
@@ -361,6 +396,7 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
+    timed_streaming_from = streaming_from
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -405,7 +441,7 @@ def main():
             launches = sum(n for _, n in per)
             t[k] = (sum(ms * n for ms, n in per) / launches if launches else 0.0, launches)
         return t
-    timers = read_timers(als)
+    timers = read_timers(als + [finder])
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -440,12 +476,7 @@ def main():
         host_rec = [torch.empty(o_[0].shape, dtype=torch.uint8).pin_memory() for o_ in out]
         host_cig = [torch.empty(p_.shape, dtype=torch.int32).pin_memory() for p_ in packed]
         copy_stream = torch.cuda.Stream(dev)
-        # the lookups get a context (and stream) of their own, so that the lookup of a later step does not queue behind a selection
-        finder_stream = torch.cuda.Stream(dev)
-        with torch.cuda.stream(finder_stream):
-            finder = gpu.Aligner(params, local_rank, genome, deferred_completion=True)
-            finder.set_index_tensors(al.index_tensors())
-            finder.find_matches(batches[0])                # warm-up: its staging buffers
+        # (the lookups have the context and stream of their own that the timed region gave them)
         torch.cuda.synchronize()
         tp = time.perf_counter()
         dev_in = []
@@ -507,7 +538,6 @@ def main():
             ctx.synchronize()
         torch.cuda.synchronize()
         t_pcie = time.perf_counter() - tp
-        del finder
         same = bool((out[0][0] == checked_records).all()) and bool((out[0][2][:checked_cigars.numel()] == checked_cigars).all())
         pcie = {"reads_per_s": round(2.0 * pairs_rank / t_pcie, 1), "records_identical_to_resident_pass": same, "ms_per_step": round(1e3 * t_pcie / args.steps, 3),
                 "bytes_in_per_pair": 2 * L, "bytes_out_per_pair": round((sum(r.numel() for r in host_rec) + 4 * sum(int(p.numel()) for p in packed)) / pairs_rank, 1),
@@ -579,7 +609,7 @@ def main():
         try:
             # the program gets the device as a run of its own would find it, beside this process's table and reads: the extra contexts (their timers
             # and records have been read) and torch's cached blocks go first
-            for extra in als[1:]:
+            for extra in als[1:] + [finder]:
                 extra.close()
             del als[1:]
             torch.cuda.empty_cache()
@@ -826,7 +856,10 @@ def main():
               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
               "scaling": args.scaling, "vs_baseline": None, "dtype": "u8/int16 (+f64 log-probabilities)", "data": "synthetic",
               "config": {"workload": workload, "pairs_per_step": args.pairs_per_step, "read_length": L, "genome_bases": args.genome_bases, "index_entries": int(n_index),
-                         "parallelism": "read shards x%d, %d context(s) per GPU taking the steps' selections in turn (one stream each, contigs and table shared), every step's records and packed CIGARs gathered to rank 0 behind the later steps" % (world, n_contexts), "hbm_used_gb": hbm_used_gb, "setup_s": round(t_setup, 1),
+                         "parallelism": "read shards x%d, %d context(s) per GPU taking the steps' selections in turn (one stream each, contigs and table shared), every step's records and packed CIGARs gathered to rank 0 behind the later steps; %s" % (
+                             world, n_contexts, "all lookups before the first selection" if timed_streaming_from is None else
+                             "every contig had a match after the lookup of step %d: from there on a step is selected as soon as it is looked up, the later lookups (a context of their own) beside the selections" % timed_streaming_from),
+                         "selections_began_after_lookup_of_step": timed_streaming_from, "hbm_used_gb": hbm_used_gb, "setup_s": round(t_setup, 1),
                          "genome_s": round(t_genome, 1), "index_build_s": round(t_index, 1), "tls": list(tls.astuple()), "pcie_inclusive": pcie, "bam_output": bam_info, "cli_end_to_end": cli_info},
               "roofline": roofline, "cpu_baseline": cpu, "counters": {k: int(v) for k, v in counters.items()}}
     result.update(parity)

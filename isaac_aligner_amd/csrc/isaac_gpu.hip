@@ -1357,9 +1357,10 @@ static void launchGappedJobs(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clusterBa
     const size_t lds = size_t(BSW_BLOCK / BSW_GROUP_LANES) * gappedGroupLdsBytes(maxReadLength, staged);
     {
         ScopedTimer t(c, timer);
-        if (ISAAC_BSW_GLOBAL_FLAGS) c->bswFlags.reserve(size_t(GAPPED_GRID) * (BSW_BLOCK / BSW_GROUP_LANES) * bswFlagBytes(maxReadLength));
+        if (ISAAC_BSW_GLOBAL_FLAGS) c->bswFlags.reserve(size_t(65536) * (BSW_BLOCK / BSW_GROUP_LANES) * bswFlagBytes(maxReadLength));
         const auto kernel = maxReadLength <= BSW_REGISTER_BASES_SHORT ? k_gapped_jobs : staged ? k_gapped_jobs_staged : k_gapped_jobs_long;
-        kernel<<<GAPPED_GRID, BSW_BLOCK, lds, c->stream>>>(c->P, c->ref(), bcl, clusterBase, gb.jobs, gb.counter, gb.cap, maxReadLength, gb.results, c->bswFlags.p);
+        static const u32 grid = std::getenv("ISAAC_GPU_GAPPED_GRID") ? u32(std::max(256, std::atoi(std::getenv("ISAAC_GPU_GAPPED_GRID")))) : GAPPED_GRID;      // (measurements: workgroups the problems are dealt to)
+        kernel<<<grid, BSW_BLOCK, lds, c->stream>>>(c->P, c->ref(), bcl, clusterBase, gb.jobs, gb.counter, gb.cap, maxReadLength, gb.results, c->bswFlags.p);
     }
     HIP_CHECK(hipGetLastError());
     ScopedTimer t(c, rescanTimer);

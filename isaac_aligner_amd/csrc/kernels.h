@@ -181,7 +181,7 @@ static const u32 BSW_GROUP_LANES = 8;        // lanes that share one banded Smit
 // (profiles/exp_r4_bsw_global_flags.log).  Kept as a build switch.
 #define ISAAC_BSW_GLOBAL_FLAGS 0
 #endif
-static const u32 GAPPED_GRID = 8192;         // workgroups of k_gapped_jobs (it strides over the problems)
+static const u32 GAPPED_GRID = 32768;        // workgroups of k_gapped_jobs (it strides over the problems)
 static const u32 BSW_BLOCK = 64;             // threads per workgroup of k_gapped_jobs / k_bsw_batch: one wavefront, eight problems
 // LDS bytes of one banded Smith-Waterman group (bsw_kernel.h)
 // traceback flags: 80 bytes per eight rows (bsw_kernel.h)
