@@ -126,8 +126,9 @@ ISAAC_HD u32 clusterPlanRescue(const DevParams &P, const DevReference &R, const 
 }
 
 // ungapped alignment of one rescue candidate position (the body of the loop at ShadowAligner.cpp:206-231)
+// summary: the 16 bytes of the result that the plan kernels walk (template.h: CandSummary); its position is left to the caller (rescueSummaryPosition)
 ISAAC_HD void rescueAlignCandidate(const DevParams &P, const DevReference &R, const u8 *bcl, u32 cluster, u32 endCyclesMasked, const RescueJob &job, i32 relativePosition,
-                                   Cand &out, u32 *cigar3)
+                                   Cand &out, u32 *cigar3, CandSummary *summary = 0)
 {
     ReadView shadowRead;
     const u32 r = job.shadowReadIndex;
@@ -146,8 +147,14 @@ ISAAC_HD void rescueAlignCandidate(const DevParams &P, const DevReference &R, co
     c.reverse = job.shadowReverse; c.contigId = job.contigId; c.position = i64(relativePosition) + job.windowBegin;
     alignUngapped(P, R, shadowRead, c, pool, job.adapterRange);
     out = c;
+    if (summary) { summary->logProbability = c.logProbability; summary->mismatchCount = c.mismatchCount; summary->cigarLength = c.cigarLength; summary->relativePosition = 0; }
 #endif
 }
+
+// an aligned rescue candidate's position relative to its problem's window: the start that was tried + the leading soft clip (the only way an alignment's
+// position moves; an unaligned candidate's position is not looked at)
+ISAAC_HD i32 rescueSummaryPosition(i32 relativePosition, u32 cigarLength, u32 firstCigarWord)
+{ return relativePosition + ((cigarLength && OP_SOFT_CLIP == cigarCode(firstCigarWord)) ? i32(cigarLen(firstCigarWord)) : 0); }
 
 // What the flat kernels hand to clusterSelect: the cluster's jobs and the aligned candidates of the chunk
 // sums != NULL: the jobs carry their outcome and the cluster's probability sums are given (RESCUE_PRECOMPUTED, after k_cluster_sums)

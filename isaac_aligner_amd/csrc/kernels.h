@@ -137,7 +137,7 @@ struct RescueBuffers
 {
     RescueJob *jobs; u32 jobsCap; u32 *jobCounter;
     u32 *bitmaps; u32 bitmapCap; u32 *bitmapCounter;
-    i32 *candPositions; u32 *candJob; Cand *shadowCands; u32 *shadowCigars; u32 *candRank; u32 candCap; u32 *candCounter;
+    i32 *candPositions; u32 *candJob; Cand *shadowCands; CandSummary *candSummaries; u32 *shadowCigars; u32 *candRank; u32 candCap; u32 *candCounter;
     // candidate slots are handed out from CAND_REGIONS equal regions, each with its own counter (candCounter[region]): one
     // counter for every workgroup of a chunk serialises at ~8 ns per atomic
     u32 candRegionSize;

@@ -508,7 +508,13 @@ __global__ __launch_bounds__(256) void k_rescue_align(DevParams P, DevReference 
     if (i < rb.candCap && i % rb.candRegionSize < imin(imin(rb.candCounter[i / rb.candRegionSize], rb.candCounter[CAND_REGIONS + i / rb.candRegionSize]), rb.candRegionSize))
     {
         const RescueJob &job = rb.jobs[rb.candJob[i]];
-        rescueAlignCandidate(P, R, bcl, clusterBase + job.cluster, pools.meta[job.cluster].endCyclesMasked[job.shadowReadIndex], job, rb.candPositions[i], rb.shadowCands[i], rb.shadowCigars + u64(i) * 3);
+        CandSummary summary;
+        rescueAlignCandidate(P, R, bcl, clusterBase + job.cluster, pools.meta[job.cluster].endCyclesMasked[job.shadowReadIndex], job, rb.candPositions[i], rb.shadowCands[i], rb.shadowCigars + u64(i) * 3, &summary);
+        // the 16 bytes the plan kernels walk.  The tried start and the first CIGAR word are fetched again, through addresses formed here, rather than kept
+        // across the scan: the kernel runs at its register cap (six waves per SIMD)
+        u32 slot = i; asm volatile("" : "+v"(slot));
+        summary.relativePosition = rescueSummaryPosition(*reinterpret_cast<const volatile i32 *>(rb.candPositions + slot), summary.cigarLength, *reinterpret_cast<const volatile u32 *>(rb.shadowCigars + u64(slot) * 3));
+        rb.candSummaries[slot] = summary;
         ++scans;
     }
     flushCounter(&Counters::ungappedScans, scans, counters);
@@ -534,7 +540,7 @@ __global__ __launch_bounds__(256) void k_rescue_gapped_plan(ClusterPools pools, 
         if (job.nCands > GAPPED_PLAN_LONG) longList[atomicAdd(longCount, 1u)] = j;
         else
         {
-            summarizeRescueJob(job, rb.shadowCands, rb.candRank);
+            summarizeRescueJob(job, rb.shadowCands, rb.candRank, rb.candSummaries);
             const u32 ecm = pools.meta[job.cluster].endCyclesMasked[job.shadowReadIndex];
             const u32 n = job.nGapped;      // counted by the summary pass; the candidates are walked again only to write the problems
             u32 base = 0;
@@ -542,7 +548,7 @@ __global__ __launch_bounds__(256) void k_rescue_gapped_plan(ClusterPools pools, 
             {
                 base = atomicAdd(gb.counter, n);
                 if (base + n > gb.cap) base = 0xffffffffu;     // the cluster's thread runs them itself
-                else writeRescueGapped(job, rb.shadowCands, rb.shadowCigars, ecm, gb.jobs + base);
+                else writeRescueGapped(job, rb.shadowCands, rb.shadowCigars, ecm, gb.jobs + base, rb.candSummaries);
             }
             job.gappedBase = base; job.nGapped = n;
         }
@@ -566,6 +572,7 @@ __global__ __launch_bounds__(256) void k_rescue_gapped_plan_long(ClusterPools po
     {
         RescueJob &job = rb.jobs[longList[t]];
         const Cand *cands = rb.shadowCands + job.candBase;
+        const CandSummary *summaries = rb.candSummaries + job.candBase;          // the 16 bytes of each candidate the walks look at
         // ---- summarizeRescueJob
         u32 n = 0; i32 best = -1; u32 bestRank = 0, bestMismatches = 0; bool last = false; double bestLp = 0.0;
         u32 nClose = 0; i64 prevPosition = 0; u32 prevMismatches = 0;
@@ -573,7 +580,7 @@ __global__ __launch_bounds__(256) void k_rescue_gapped_plan_long(ClusterPools po
         {
             const u32 c = c0 + lane; const bool in = c < job.nCands;
             double lp = 0.0; i64 position = 0; u32 mismatches = 0; bool aligned = false;
-            if (in) { const Cand &f = cands[c]; lp = f.logProbability; position = f.position; mismatches = f.mismatchCount; aligned = candAligned(f); }
+            if (in) { const CandSummary f = summaries[c]; lp = f.logProbability; position = f.relativePosition; mismatches = f.mismatchCount; aligned = 0 != f.cigarLength; }
             const u64 mask = __ballot(aligned);
             if (in) rb.candRank[job.candBase + c] = n + u32(__popcll(mask & below));
             for (u64 m = mask; m; m &= m - 1)
@@ -603,7 +610,7 @@ __global__ __launch_bounds__(256) void k_rescue_gapped_plan_long(ClusterPools po
             {
                 const u32 c = c0 + lane; const bool in = c < job.nCands;
                 i64 position = 0; u32 mismatches = 0; bool aligned = false;
-                if (in) { const Cand &f = cands[c]; position = f.position; mismatches = f.mismatchCount; aligned = candAligned(f); }
+                if (in) { const CandSummary f = summaries[c]; position = f.relativePosition; mismatches = f.mismatchCount; aligned = 0 != f.cigarLength; }
                 const u64 mask = __ballot(aligned);
                 const u64 before = mask & below;
                 const int pl = before ? 63 - __clzll((long long)before) : 0;

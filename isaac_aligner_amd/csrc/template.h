@@ -637,10 +637,23 @@ ISAAC_HD bool shadowRescueLookup(TemplateCtx &x, const Cand &orphan, const Rescu
     return finishRescueLookup(x, pool, best, job);
 }
 
+// What the walks below want of a rescue candidate, 16 bytes instead of the 64-byte record (round 6: k_rescue_align writes one beside every candidate; a thread
+// that walks a problem's list read a 64-byte line per candidate for these fields -- 1.1 GB a launch of k_rescue_gapped_plan).  The position is relative to the
+// problem's window (only differences between the candidates of one problem are looked at).
+struct CandSummary { double logProbability; i32 relativePosition; u16 mismatchCount, cigarLength; };
+static_assert(sizeof(CandSummary) == 16, "CandSummary layout");
+ISAAC_HD CandSummary candSummary(const Cand &c, i64 windowBegin)
+{ CandSummary s; s.logProbability = c.logProbability; s.relativePosition = i32(c.position - windowBegin); s.mismatchCount = c.mismatchCount; s.cigarLength = c.cigarLength; return s; }
+// the fields of candidate `slot` whichever way they are kept (summaries == NULL: read from the records, rounds 1-5 and the host forms)
+ISAAC_HD void candSummaryFields(const Cand *shadowCands, const CandSummary *summaries, u32 slot, double &lp, i64 &position, u32 &mismatches, bool &aligned)
+{
+    if (summaries) { const CandSummary s = summaries[slot]; lp = s.logProbability; position = s.relativePosition; mismatches = s.mismatchCount; aligned = 0 != s.cigarLength; }
+    else { const Cand &f = shadowCands[slot]; lp = f.logProbability; position = f.position; mismatches = f.mismatchCount; aligned = candAligned(f); }
+}
 // One pass over a job's aligned candidates (in candidate order): how many there are before each slot, which is the best
 // (the running choice of ShadowAligner.cpp:216-230) and whether the last candidate aligned.
 static const u32 SUMMARY_BATCH = 8;
-ISAAC_HD void summarizeRescueJob(RescueJob &job, const Cand *shadowCands, u32 *candRank)
+ISAAC_HD void summarizeRescueJob(RescueJob &job, const Cand *shadowCands, u32 *candRank, const CandSummary *summaries = 0)
 {
     u32 n = 0; i32 best = -1; u32 bestRank = 0, bestMismatches = 0; bool last = false;
     double bestLp = 0.0;
@@ -657,11 +670,7 @@ ISAAC_HD void summarizeRescueJob(RescueJob &job, const Cand *shadowCands, u32 *c
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (u32 k = 0; k < SUMMARY_BATCH; ++k)
-        {
-            const Cand &f = shadowCands[candBase + imin(c0 + k, nCands - 1)];
-            lps[k] = f.logProbability; positions[k] = f.position; mismatchCounts[k] = f.mismatchCount; aligned[k] = candAligned(f);
-        }
+        for (u32 k = 0; k < SUMMARY_BATCH; ++k) candSummaryFields(shadowCands, summaries, candBase + imin(c0 + k, nCands - 1), lps[k], positions[k], mismatchCounts[k], aligned[k]);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -689,7 +698,7 @@ ISAAC_HD void summarizeRescueJob(RescueJob &job, const Cand *shadowCands, u32 *c
 // The second walk of planRescueGapped for a problem whose summary says that there are retries (job.nGapped, so the best candidate's mismatches are
 // known to qualify): positions, mismatch counts and "aligned" fetched SUMMARY_BATCH candidates at a time, as in the summary -- the few threads of a wave
 // that come here would otherwise walk their lists a load at a time, twice, while the others wait.
-ISAAC_HD u32 writeRescueGapped(const RescueJob &job, const Cand *shadowCands, const u32 *shadowCigars, u32 endCyclesMasked, GappedJob *out)
+ISAAC_HD u32 writeRescueGapped(const RescueJob &job, const Cand *shadowCands, const u32 *shadowCigars, u32 endCyclesMasked, GappedJob *out, const CandSummary *summaries = 0)
 {
     u32 n = 0; i32 prev = -1; i64 prevPosition = 0; u32 prevMismatches = 0;
     const u32 nCands = job.nCands, candBase = job.candBase;            // (once: the stores to `out` may alias the record)
@@ -699,11 +708,7 @@ ISAAC_HD u32 writeRescueGapped(const RescueJob &job, const Cand *shadowCands, co
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (u32 k = 0; k < SUMMARY_BATCH; ++k)
-        {
-            const Cand &f = shadowCands[candBase + imin(c0 + k, nCands - 1)];
-            positions[k] = f.position; mismatchCounts[k] = f.mismatchCount; aligned[k] = candAligned(f);
-        }
+        for (u32 k = 0; k < SUMMARY_BATCH; ++k) { double lp; candSummaryFields(shadowCands, summaries, candBase + imin(c0 + k, nCands - 1), lp, positions[k], mismatchCounts[k], aligned[k]); }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif

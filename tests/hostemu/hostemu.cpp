@@ -261,11 +261,13 @@ int emu_select(Emu *e, const u8 *bcl, u32 nClusters, u32 tile, const isaac_tls *
         }
     // k_rescue_align
     std::vector<Cand> shadowCands(candPositions.size()); std::vector<u32> shadowCigars(candPositions.size() * 3 + 3);
+    std::vector<CandSummary> candSummaries(candPositions.size() + 1);          // the 16 bytes per candidate the plan kernels walk (k_rescue_align writes them)
     for (size_t j = 0; j < jobs.size(); ++j)
         for (u32 i = 0; i < jobs[j].nCands; ++i)
         {
             const u32 slot = jobs[j].candBase + i;
-            rescueAlignCandidate(e->P, e->R, bcl, jobs[j].cluster, e->frags[jobs[j].cluster].endCyclesMasked[jobs[j].shadowReadIndex], jobs[j], candPositions[slot], shadowCands[slot], &shadowCigars[size_t(slot) * 3]);
+            rescueAlignCandidate(e->P, e->R, bcl, jobs[j].cluster, e->frags[jobs[j].cluster].endCyclesMasked[jobs[j].shadowReadIndex], jobs[j], candPositions[slot], shadowCands[slot], &shadowCigars[size_t(slot) * 3], &candSummaries[slot]);
+            candSummaries[slot].relativePosition = rescueSummaryPosition(candPositions[slot], candSummaries[slot].cigarLength, shadowCigars[size_t(slot) * 3]);
             ++e->cnt.ungappedScans;
         }
     // k_rescue_gapped_plan + k_gapped_jobs
@@ -278,12 +280,12 @@ int emu_select(Emu *e, const u8 *bcl, u32 nClusters, u32 tile, const isaac_tls *
             RescueJob &job = jobs[j];
             if (!job.valid || job.fallback) continue;
             const u32 ecm = e->frags[job.cluster].endCyclesMasked[job.shadowReadIndex];
-            summarizeRescueJob(job, shadowCands.data(), candRank.data());
+            summarizeRescueJob(job, shadowCands.data(), candRank.data(), candSummaries.data());
             const u32 n = job.nGapped;
             if (n != planRescueGapped(job, shadowCands.data(), shadowCigars.data(), ecm, 0)) { g_error = "summarizeRescueJob and planRescueGapped disagree"; return 1; }
             job.gappedBase = u32(gj.size()); job.nGapped = n;
             gj.resize(gj.size() + n);
-            if (n && n != writeRescueGapped(job, shadowCands.data(), shadowCigars.data(), ecm, gj.data() + job.gappedBase)) { g_error = "summarizeRescueJob and writeRescueGapped disagree"; return 1; }
+            if (n && n != writeRescueGapped(job, shadowCands.data(), shadowCigars.data(), ecm, gj.data() + job.gappedBase, candSummaries.data())) { g_error = "summarizeRescueJob and writeRescueGapped disagree"; return 1; }
         }
         gapped.resize(gj.size() + 1);
         for (size_t j = 0; j < gj.size(); ++j) runGappedJobSerial(e->P, e->R, bcl + u64(gj[j].cluster) * e->P.clusterLength, gj[j], tflags.data(), gapped[j]);
