@@ -427,7 +427,7 @@ def main():
     free_b, total_b = torch.cuda.mem_get_info(dev)
     hbm_used_gb = round((total_b - free_b) / 1e9, 1)      # everything resident at the end of the run: index, reads, records, chunk scratch
     counters = al.counters()
-    for ctx in als[1:]:
+    for ctx in als[1:] + [finder]:                   # (the lookups' probes and matches are counted by the context that ran them)
         for key, value in ctx.counters().items():
             counters[key] += value
     timer_names = ("find_matches", "compact_matches", "build_fragments", "build_fragments_general", "align_candidates", "finish_candidates", "finish_candidates_general", "indel_fragments", "gapped_fragments",

@@ -190,6 +190,13 @@ __device__ inline u64 lowerBound(const TableEntry *entries, u64 lo, u64 hi, u64 
     return lo;
 }
 
+// Round 6, three attempts on the second seed iteration (16 % of the probes -- the reads the first iteration left open, mostly reads of repeat families whose
+// probes bisect buckets of hundreds of entries -- and 40 % of the kernel: one iteration alone takes 0.69 ms, both 1.15), all measured slower or equal and taken
+// out again: (1) the workgroup's second-iteration probes listed in LDS and dealt out densely, a thread per probe: 1.11 ms -- the waves that have nothing to do
+// still wait at the workgroup's barriers; (2) an eight-way search (seven pivots a round trip) instead of the bisection: 1.40 ms -- the kernel runs at 62 % of
+// the chip's rate of random lines (49.5 G lines/s whatever the access shape, profiles/exp_r6_random_lines.log) and seven lines where the bisection touches
+// one cost more than the shorter chain brings; (3) the second iteration as a kernel of its own over a list of the clusters with an open read: 1.77 ms -- as a
+// second round of this kernel its long chains run beside other workgroups' first rounds, alone they run by themselves.  profiles/exp_r6_find.log
 // prefixTable[b] = first table index whose k-mer has leading bits >= b (b = 0 .. 2^bits, the last one = n)
 __global__ void k_prefix_table(const TableEntry *kmers, u64 n, u32 bits, u32 *table)
 {
