@@ -80,4 +80,30 @@ print("after set_params(2x100): %d looked at, %d replaced; differences from the 
 for d in diffs2[:3]:
     print(d)
 ok = ok and n_flagged2 > n2 // 100 and n_changed2 > 0 and not diffs2
+
+# ... and with sequencing adapters: the host form (csrc/resolve_host.cpp, the product's own headers under g++) decides the adapter ranges itself, per read and per
+# rescue, and has to clip exactly as the kernels did
+from parity_util import add_adapters                                      # noqa: E402
+bcl3, inserts = add_adapters(synth.make_read_pairs(g, n2, 150, seed=31, avoid_gaps=True)[0].numpy(), 150, adapter="AGATCGGAAGAGC", fraction=0.35, seed=32)
+p3 = options.set_adapters(options.default_params(150, 150), "Standard")
+al.set_params(p3)
+dev3 = torch.from_numpy(bcl3).cuda()
+m3, o3, hits3 = al.find_matches(dev3, tile=5)
+al.set_loaded_contigs(hits3)
+tls3 = al.determine_tls(dev3, m3, o3, tile=5)
+records3, cigars3 = al.select(dev3, m3, o3, tls3, tile=5)
+om3, ohits3 = ref.find_matches(p3, bcl3, n2, tile=5)
+otls3 = oracle_lib.Tls()
+for name in ("min", "max", "median", "low_std_dev", "high_std_dev", "stable", "mate_min", "mate_max"):
+    setattr(otls3, name, getattr(tls3, name))
+otls3.best_model[0], otls3.best_model[1] = tls3.best_model[0], tls3.best_model[1]
+orec3, ocig3, _ = ref.select(p3, bcl3, om3, otls3, ohits3, tile=5, n_threads=8, n_clusters_hint=n2)
+n_flagged3, n_changed3 = al.resolve_flagged(dev3, m3, o3, tls3, records3, cigars3, tile=5)
+rec3, cig3 = al.records_to_numpy(records3, cigars3)
+diffs3 = compare_records(orec3, ocig3, rec3, cig3)
+clipped = int(((orec3["observed_length"].reshape(-1, 2)[:, 0] == inserts) & (inserts > 0)).sum())
+print("with adapters: %d looked at, %d replaced, %d reads clipped where the insert ends; differences from the oracle afterwards: %d" % (n_flagged3, n_changed3, clipped, len(diffs3)))
+for d in diffs3[:3]:
+    print(d)
+ok = ok and n_flagged3 > n2 // 100 and n_changed3 > 0 and clipped > n2 // 20 and not diffs3
 sys.exit(0 if ok else 1)
