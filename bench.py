@@ -374,9 +374,9 @@ def main():
         found.append((m, o))
         all_hits |= hits
         if not streaming:
-            loaded = reduce_hits(all_hits)
             if not args.stream_lookups:
-                continue
+                continue                              # (one exchange of the flags behind the last lookup, below)
+            loaded = reduce_hits(all_hits)
             if loaded.all():
                 streaming, streaming_from = True, s
                 for ctx in als:
@@ -384,6 +384,7 @@ def main():
         while streaming and next_select <= s:
             select_step(next_select); next_select += 1
     if not streaming:
+        loaded = reduce_hits(all_hits)
         for ctx in als:
             ctx.set_loaded_contigs(loaded)
     while next_select < args.steps:
