@@ -375,7 +375,7 @@ typedef struct
     uint32_t mark_duplicates;                /* --mark-duplicates (reference default 1): duplicates get BAM flag 0x400 */
     uint32_t keep_duplicates;                /* --keep-duplicates (reference default 1): 0 leaves duplicates out of the file */
     uint32_t realign_gaps;                   /* --realign-gaps: 0 = no, 1 = sample / project / all (one gap group: the call's records are one sample) */
-    uint32_t realign_vigorously;             /* --realign-vigorously (reference default 0): only 0 is implemented */
+    uint32_t realign_vigorously;             /* --realign-vigorously (reference default 0): a realigned fragment is tried again until nothing improves, and fragments with more than ten (up to thirty) gaps in reach are tried too (GapRealigner.cpp:1117,1241) */
     uint32_t realign_dodgy;                  /* --realign-dodgy (reference default 0) */
     const isaac_tls *tls;                    /* the template length statistics isaac_gpu_select ran with: GapRealigner::updatePairDetails re-derives the
                                                 proper-pair flag of realigned pairs from them; required with realign_gaps and paired reads

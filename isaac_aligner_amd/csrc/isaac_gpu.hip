@@ -2024,8 +2024,8 @@ int isaac_gpu_bam_records(isaac_gpu_ctx *c, const isaac_bam_tile *tiles, uint32_
     }
     if (o.realignGaps)
     {
-        if (options->realign_vigorously) return fail(ISAAC_GPU_EINVAL, "--realign-vigorously is not implemented");
         // BinSorter.hh:96-98: GapRealigner(realignGapsVigorously, realignDodgyFragments, realignedGapsPerFragment, 3, 4, 0, clipSemialigned, ...)
+        o.realign.realignGapsVigorously = options->realign_vigorously != 0;
         o.realign.mismatchCost = 3; o.realign.gapOpenCost = 4; o.realign.gapExtendCost = 0; o.realign.realignDodgyFragments = options->realign_dodgy != 0; o.realign.clipSemialigned = c->params.clip_semialigned != 0;
         if (options->tls) std::memcpy(&o.tls, options->tls, sizeof(o.tls));
     }

@@ -1,10 +1,12 @@
-// Gap realignment of the BAM stage (--realign-gaps sample|project|all, not --realign-vigorously): build::GapRealigner::realign
+// Gap realignment of the BAM stage (--realign-gaps sample|project|all, with or without --realign-vigorously): build::GapRealigner::realign
 // (lib/build/GapRealigner.cpp:1053-1268) for one fragment per thread, against the gaps every fragment of the same contig brought in
 // (RealignerGaps, include/build/GapRealigner.hh:37-128; BinSorter::collectGaps, lib/build/BinSorter.cpp:387-403).
 //
 // Thread-serial ISAAC_HD code like aligner.h / template.h: the kernels of bam_kernels.h call it, tests/hostemu compiles it for the CPU.
-// Without --realign-vigorously a fragment with more than MAX_GAPS_AT_A_TIME gaps in reach is left alone (:1116-1120), so ten gaps,
-// 2^10 choices and a CIGAR of a few dozen operations bound everything here; the work areas are small private arrays.
+// Without --realign-vigorously a fragment with more than MAX_GAPS_AT_A_TIME gaps in reach is left alone (:1116-1120): ten gaps and 2^10 choices.  With it
+// (round 6) the fragment is tried against whatever is in reach -- gapRealigner::OverlappingGapsFilter gives up beyond MAX_TRACKED_DELETIONS = 30 gaps
+// (OverlappingGapsFilter.hh:36-43), the choices looked at stay 2^10 -- and a fragment that was realigned is tried again until nothing improves (:1241).  Thirty
+// gaps and a CIGAR of a few dozen operations bound everything here; the work areas are small private arrays.
 #pragma once
 #include "types.h"
 
@@ -27,10 +29,11 @@ ISAAC_HD u64 rgLengthKey(i32 length) { return u64(u32(length) ^ 0x80000000u); }
 struct RealignerGapsView { const RealignGap *gaps; u32 nGaps; const RealignGap *deletionEnds; u32 nDeletionEnds; };
 
 static const u32 RG_MAX_GAPS_AT_A_TIME = 10;       // GapRealigner::MAX_GAPS_AT_A_TIME
-static const u32 RG_FOUND_CAP = 2 * RG_MAX_GAPS_AT_A_TIME;   // starts + ends before the duplicates go: more cannot leave ten or fewer
+static const u32 RG_TRACKED_GAPS_MAX = 30;         // OverlappingGapsFilter::MAX_TRACKED_DELETIONS: more gaps than this and no choice is looked at
+static const u32 RG_FOUND_CAP = 2 * RG_TRACKED_GAPS_MAX;   // starts + ends before the duplicates go: more cannot leave thirty or fewer
 static const u32 RG_CIGAR_CAP = 64;
 
-struct RealignParams { u32 mismatchCost, gapOpenCost, gapExtendCost, realignDodgyFragments, clipSemialigned; };   // BinSorter.hh:96-98: 3, 4, 0
+struct RealignParams { u32 mismatchCost, gapOpenCost, gapExtendCost, realignDodgyFragments, clipSemialigned, realignGapsVigorously; };   // BinSorter.hh:96-98: 3, 4, 0
 
 // the fields of io::FragmentAccessor the realigner reads and changes
 struct RealignFragment
@@ -55,18 +58,18 @@ struct RealignIndex { u64 pos; const u32 *cigarBegin, *cigarEnd; };     // Packe
 ISAAC_HD bool rgIsMatch(char readBase, char referenceBase) { return readBase == 'n' || (readBase == referenceBase && referenceBase != 'N'); }
 
 // RealignerGaps::findGaps (GapRealigner.cpp:99-145) into found[RG_FOUND_CAP]; returns the number of gaps, ~0u when there are more than the
-// caller can use (more than RG_MAX_GAPS_AT_A_TIME after the duplicates are gone)
+// caller can use (more than `most` -- ten, or thirty with --realign-vigorously -- after the duplicates are gone)
 ISAAC_HD u32 rgLowerBoundStart(const RealignGap *g, u32 lo, u32 hi, u64 pos, i32 length)
 { RealignGap key; key.pos = pos; key.length = length; while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (rgLess(g[mid], key)) lo = mid + 1; else hi = mid; } return lo; }
 ISAAC_HD u32 rgLowerBoundEnd(const RealignGap *g, u32 lo, u32 hi, u64 endPos)
 { while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (rpPlus(g[mid].pos, rgLength(g[mid])) < endPos) lo = mid + 1; else hi = mid; } return lo; }
-ISAAC_HD u32 rgFindGaps(const RealignerGapsView &v, u64 rangeBegin, u64 rangeEnd, RealignGap *found)
+ISAAC_HD u32 rgFindGaps(const RealignerGapsView &v, u64 rangeBegin, u64 rangeEnd, RealignGap *found, u32 most = RG_MAX_GAPS_AT_A_TIME)
 {
     const u32 s0 = rgLowerBoundStart(v.gaps, 0, v.nGaps, rangeBegin, -1000000), s1 = rgLowerBoundStart(v.gaps, s0, v.nGaps, rangeEnd, 0);
     // Gap(rangeBegin, 1).getDeletionEndPos() = rangeBegin + 1
     const u32 e0 = rgLowerBoundEnd(v.deletionEnds, 0, v.nDeletionEnds, rpPlus(rangeBegin, 1)), e1 = rgLowerBoundEnd(v.deletionEnds, e0, v.nDeletionEnds, rpPlus(rangeEnd, 1));
     const u32 nStarts = s1 - s0, nEnds = e1 - e0;
-    if (nStarts > RG_MAX_GAPS_AT_A_TIME || nEnds > RG_MAX_GAPS_AT_A_TIME) return ~0u;          // already more distinct gaps than can be used
+    if (nStarts > most || nEnds > most) return ~0u;          // already more distinct gaps than can be used
     u32 n = 0;
     for (u32 i = s0; i < s1; ++i) found[n++] = v.gaps[i];
     for (u32 i = e0; i < e1; ++i) found[n++] = v.deletionEnds[i];
@@ -90,14 +93,14 @@ ISAAC_HD bool rgAnyGap(const RealignerGapsView &v, u64 rangeBegin, u64 rangeEnd)
     return e1 > e0;
 }
 
-// gapRealigner::OverlappingGapsFilter (OverlappingGapsFilter.hh:32-92, OverlappingGapsFilter.cpp:30-160) for at most ten gaps
-struct OverlapsFilter { u32 maxChoice, nOverlaps, overlaps[2 * RG_MAX_GAPS_AT_A_TIME + 2]; };
+// gapRealigner::OverlappingGapsFilter (OverlappingGapsFilter.hh:32-92, OverlappingGapsFilter.cpp:30-160) for at most thirty gaps (more: no choice at all, :42)
+struct OverlapsFilter { u32 maxChoice, nOverlaps, overlaps[2 * RG_TRACKED_GAPS_MAX + 2]; };
 ISAAC_HD void overlapsFilterInit(OverlapsFilter &f, const RealignGap *gaps, u32 nGaps)
 {
-    f.maxChoice = (1u << nGaps) - 1; f.nOverlaps = 0;
+    f.maxChoice = nGaps > RG_TRACKED_GAPS_MAX ? 0u : (1u << nGaps) - 1; f.nOverlaps = 0;
     if (!f.maxChoice) return;
     const u32 DELETION_END_INDEX_OFFSET = 0, DELETION_START_INDEX_OFFSET = 1024, INSERTION_INDEX_OFFSET = 2048;
-    u32 endIndex[2 * RG_MAX_GAPS_AT_A_TIME]; u64 endPos[2 * RG_MAX_GAPS_AT_A_TIME]; u32 nEnds = 0;
+    u32 endIndex[2 * RG_TRACKED_GAPS_MAX]; u64 endPos[2 * RG_TRACKED_GAPS_MAX]; u32 nEnds = 0;
     for (u32 i = 0; i < nGaps; ++i)
     {
         if (rgIsDeletion(gaps[i]))
@@ -481,10 +484,10 @@ ISAAC_HD u32 rgAlignmentCost(const RealignCtx &x, const RealignFragment &fragmen
     return mismatches * x.P.mismatchCost + gapsCount * x.P.gapOpenCost + x.P.gapExtendCost * (totalGapsLength - gapsCount);
 }
 
-// GapRealigner::realign (:1053-1268) without --realign-vigorously and without updatePairDetails (the pair's fields are brought up to date by
-// realignPairDetails once both ends are final).  `index` comes in pointing at the fragment's own CIGAR; on true it points into `result`
-// and fragment.fStrandPosition / observedLength / editDistance are the new ones.
-ISAAC_HD bool realignFragment(const RealignCtx &x, const RealignerGapsView &gapsView, u64 binStartPos, u64 binEndPos, RealignIndex &index, RealignFragment &fragment, RealignCigar &result)
+// One turn of the loop of GapRealigner::realign (:1073-1262) without updatePairDetails (the pair's fields are brought up to date by
+// realignPairDetails once both ends are final: the turns of one fragment's loop do not look at them).  `index` comes in pointing at the fragment's CIGAR -- its own,
+// or `result` after an earlier turn --; on true it points into `result` and fragment.fStrandPosition / observedLength / editDistance are the new ones.
+ISAAC_HD bool realignOnce(const RealignCtx &x, const RealignerGapsView &gapsView, u64 binStartPos, u64 binEndPos, RealignIndex &index, RealignFragment &fragment, RealignCigar &result)
 {
     if (fragment.flags & 2) return false;
     binEndPos = refpos(refposContig(binEndPos), imin<u64>(refposPosition(binEndPos), rgContigLength(x, binEndPos)));
@@ -496,8 +499,11 @@ ISAAC_HD bool realignFragment(const RealignCtx &x, const RealignerGapsView &gaps
     index.pos = fragment.fStrandPosition;
     const RealignBounds bounds = rgBounds(index);
     RealignGap gaps[RG_FOUND_CAP];
-    const u32 nGaps = rgFindGaps(gapsView, bounds.beginPos, bounds.endPos, gaps);
-    if (~0u == nGaps || RG_MAX_GAPS_AT_A_TIME < nGaps || !nGaps) return false;
+    const bool vigorous = 0 != x.P.realignGapsVigorously;
+    const u32 nGaps = rgFindGaps(gapsView, bounds.beginPos, bounds.endPos, gaps, vigorous ? RG_TRACKED_GAPS_MAX : RG_MAX_GAPS_AT_A_TIME);
+    if (~0u == nGaps || !nGaps) return false;
+    if (!vigorous && RG_MAX_GAPS_AT_A_TIME < nGaps) return false;                  // :1117-1121
+    if (RG_TRACKED_GAPS_MAX < nGaps) return false;                                  // OverlappingGapsFilter.hh:42: no choice to look at
     OverlapsFilter filter;
     overlapsFilterInit(filter, gaps, nGaps);
     u32 bestEditDistance = 0; i32 originalMismatchesPercent = 0;
@@ -543,6 +549,17 @@ ISAAC_HD bool realignFragment(const RealignCtx &x, const RealignerGapsView &gaps
     index.pos = tmp.pos; index.cigarBegin = result.words; index.cigarEnd = result.words + result.n;
     fragment = changed;
     return true;
+}
+// GapRealigner::realign (:1053-1268): once, or with --realign-vigorously again and again while a turn finds a better alignment (:1241).  True: the fragment was realigned.
+ISAAC_HD bool realignFragment(const RealignCtx &x, const RealignerGapsView &gapsView, u64 binStartPos, u64 binEndPos, RealignIndex &index, RealignFragment &fragment, RealignCigar &result)
+{
+    bool any = false;
+    while (realignOnce(x, gapsView, binStartPos, binEndPos, index, fragment, result))
+    {
+        any = true;
+        if (!x.P.realignGapsVigorously) break;
+    }
+    return any;
 }
 
 // GapRealigner::updatePairDetails (:267-318) for a pair whose ends are both final; `f` is the end realigned last (the reference runs the

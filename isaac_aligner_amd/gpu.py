@@ -396,7 +396,7 @@ class Aligner:
         return parts
 
     def bam_records(self, tiles, out=None, read_group=None, barcode=None, forced_dodgy_alignment_score=None, pessimistic_mapq=False, mark_duplicates=False, keep_duplicates=True, realign_gaps=False, tls=None,
-                    bin_contigs=None, bin_unaligned=False, bin_positions=None):
+                    bin_contigs=None, bin_unaligned=False, bin_positions=None, realign_vigorously=False):
         """build::Build's BAM alignment records of one or more tiles, in file order (mark_duplicates / keep_duplicates / realign_gaps: BinSorter's steps before the order).
         tiles: [(bcl, records, cigars, read_name_prefix[, read_group[, tls]])] as given to / returned by select().  Returns (uint8 device tensor of the
         uncompressed records, number of records, offset of the unaligned bin)."""
@@ -432,6 +432,7 @@ class Aligner:
                 options.bin_unaligned = int(bool(bin_unaligned))
             options.mark_duplicates, options.keep_duplicates = int(bool(mark_duplicates)), int(bool(keep_duplicates))
             options.realign_gaps = int(bool(realign_gaps))
+            options.realign_vigorously = int(bool(realign_vigorously))
             options.tls = C.cast(C.pointer(tls), C.c_void_p) if tls is not None else None
             options.forced_dodgy_alignment_score = (self.params.dodgy_alignment_score & 0xff) if forced_dodgy_alignment_score is None else forced_dodgy_alignment_score
             options.pessimistic_mapq = int(bool(pessimistic_mapq))

@@ -81,6 +81,7 @@ std::string AlignOptions::usage()
         "  --dodgy-alignment-score arg (=0)     Unknown | Unaligned | 0-254\n"
         "  --keep-unaligned arg (=back)         discard | front | back\n"
         "  --realign-gaps arg (=sample)         no | sample | project | all (one sample: the last three are the same)\n"
+        "  --realign-vigorously arg (=0)        try a realigned fragment again until nothing improves; fragments with up to thirty gaps in reach\n"
         "  --realign-dodgy arg (=0)\n"
         "  --realigned-gaps-per-fragment arg (=1)   taken and not needed (the reference sizes a reservation by it)\n"
         "  --mark-duplicates arg (=1)\n"
@@ -234,7 +235,6 @@ AlignOptions AlignOptions::parse(int argc, char **argv)
     auto refuse = [](bool condition, const std::string &what) { if (condition) throw InvalidOption("\n   *** " + what + " is not supported by this host ***\n"); };
     refuse(o.bamExcludeTags != "ZX,ZY", "--bam-exclude-tags other than ZX,ZY");
     refuse(!o.tls.empty(), "--tls");
-    refuse(o.realignVigorously, "--realign-vigorously 1");
     // --realigned-gaps-per-fragment is "an estimate of how many gaps the realignment will introduce into each fragment" (AlignOptions.cpp:428-429): in the reference it
     // only sizes a reservation (GapRealigner.hh:208-209); the realigner here sizes its CIGAR pool from the bin itself, so any value is taken and none changes a record
     refuse(ignoreRepeats, "--ignore-repeats 1");

@@ -1173,7 +1173,7 @@ int run(const AlignOptions &o)
     size_t binsWrittenSoFar = 0;                        // (under outputLock) the builders stay at most this far ahead of the file: finished bins wait in host memory
     isaac_bam_options bamOptions; std::memset(&bamOptions, 0, sizeof(bamOptions));
     bamOptions.forced_dodgy_alignment_score = o.forcedDodgyAlignmentScore(); bamOptions.pessimistic_mapq = o.pessimisticMapQ; bamOptions.read_group = "0"; bamOptions.barcode = "none";
-    bamOptions.mark_duplicates = o.markDuplicates; bamOptions.keep_duplicates = o.keepDuplicates; bamOptions.realign_gaps = "no" != o.realignGaps; bamOptions.realign_dodgy = o.realignDodgy;
+    bamOptions.mark_duplicates = o.markDuplicates; bamOptions.keep_duplicates = o.keepDuplicates; bamOptions.realign_gaps = "no" != o.realignGaps; bamOptions.realign_vigorously = o.realignVigorously; bamOptions.realign_dodgy = o.realignDodgy;
     bamOptions.bin_filter = 2;
     const uint32_t maxReadLength = std::max(params.read_length[0], params.read_length[1]);
     const bool syncDownloads = 0 != std::getenv("ISAAC_ALIGN_SYNC_DOWNLOADS");       // (measurements: a bin's blocks fetched before the next bin is begun)

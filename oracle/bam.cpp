@@ -272,7 +272,7 @@ void bamRecords(const std::vector<BamTileInput> &tiles, const BamOptions &o, std
         }
         for (auto &g : binGaps) g.second.finalizeGaps();
         // BinSorter::realignGaps (:405-417): the index in order (single-ended, reverse-strand ends and shadows, forward-strand ends), duplicates that were dropped are not in it
-        const GapRealigner realigner = { false, o.realignDodgy, 1, 3, 4, 0, o.clipSemialigned, contigs };
+        const GapRealigner realigner = { o.realignVigorously, o.realignDodgy, 1, 3, 4, 0, o.clipSemialigned, contigs };      // BinSorter.hh:96-98
         realignedCigars.reserve(size_t(1) << 26);
         std::vector<size_t> order;
         for (size_t k = 0; k < stored.size(); ++k) if (!stored[k].paired() && stored[k].header->fStrandPosition != NO_MATCH_VALUE) order.push_back(k);

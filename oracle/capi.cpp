@@ -1008,7 +1008,7 @@ int oracle_bam_records_cuts(const oracle_bam_tile *tiles, uint32_t n_tiles, uint
         for (uint32_t r = 0; r < n_reads; ++r) { o.readOffset[r] = o.clusterLength; o.clusterLength += read_lengths[r]; }
         o.forcedDodgyAlignmentScore = (unsigned char)forced_dodgy_alignment_score; o.pessimisticMapQ = pessimistic_mapq; o.readGroup = read_group; o.barcode = barcode; o.markDuplicates = mark_duplicates != 0; o.keepDuplicates = keep_duplicates != 0;
         TemplateLengthStatistics stats; if (tls) stats = fromTls(tls);
-        o.realignGaps = realign_gaps != 0; o.realignDodgy = realign_dodgy != 0; o.clipSemialigned = clip_semialigned != 0; o.contigs = reference ? &reference->contigs : 0; o.tls = tls ? &stats : 0;
+        o.realignGaps = realign_gaps != 0; o.realignVigorously = 2 == realign_gaps /* --realign-vigorously 1 */; o.realignDodgy = realign_dodgy != 0; o.clipSemialigned = clip_semialigned != 0; o.contigs = reference ? &reference->contigs : 0; o.tls = tls ? &stats : 0;
         if (o.realignGaps && !o.contigs) throw std::runtime_error("gap realignment needs the reference");
         for (uint32_t k = 0; k < n_cuts; ++k) o.binCuts.push_back(bin_cuts[k] & ~uint64_t(1));
         if (!std::is_sorted(o.binCuts.begin(), o.binCuts.end())) throw std::runtime_error("bin cuts must ascend");

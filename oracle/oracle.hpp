@@ -732,7 +732,7 @@ struct BamTileInput { const uint8_t *bcl; const FragmentRecord *records; const u
                       const TemplateLengthStatistics *tls = 0; };   // of the tile's barcode; NULL: BamOptions::tls
 struct BamOptions { unsigned clusterLength, readOffset[2]; unsigned char forcedDodgyAlignmentScore; bool pessimisticMapQ; std::string readGroup, barcode;
                     bool markDuplicates = false, keepDuplicates = true;          // --mark-duplicates / --keep-duplicates (BinSorter.cpp:293-330)
-                    bool realignGaps = false, realignDodgy = false, clipSemialigned = true; const ContigList *contigs = 0; const TemplateLengthStatistics *tls = 0;   // --realign-gaps sample
+                    bool realignGaps = false, realignVigorously = false, realignDodgy = false, clipSemialigned = true; const ContigList *contigs = 0; const TemplateLengthStatistics *tls = 0;   // --realign-gaps sample
                     // Every contig is a bin of its own unless it is cut: ascending ReferencePosition values at which a contig goes on into a further bin
                     // (alignment::BinMetadata stretches of --target-bin-size, include/alignment/matchSelector/BinIndexMap.hh:44-104).  build::Build works bin
                     // by bin: duplicates, gaps and realignment never look beyond the bin (lib/build/BinSorter.cpp:293-330,387-417)

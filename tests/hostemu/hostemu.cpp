@@ -378,7 +378,7 @@ int emu_select_literal(Emu *e, const u8 *bcl, const LiteralFragment *f0, u32 n0,
 // realign.h (the BAM stage's gap realigner, thread-serial) on one fragment: the same inputs and outputs as the oracle's oracle_realign_case
 int emu_realign_case(const char *contig, uint64_t contigLength, const uint8_t *readBcl, uint32_t readLength, uint64_t fStrandPosition, const uint32_t *cigar, uint32_t cigarLength,
                      uint32_t observedLength, uint32_t editDistance, uint32_t lowClipped, uint32_t highClipped, const int64_t *gapPositions, const int32_t *gapLengths, uint32_t nGaps,
-                     uint32_t mismatchCost, uint32_t gapOpenCost, uint32_t gapExtendCost, int dodgy, int clipSemialigned, uint64_t binStart, int64_t binEnd,
+                     uint32_t mismatchCost, uint32_t gapOpenCost, uint32_t gapExtendCost, int dodgy, int clipSemialigned, int vigorous, uint64_t binStart, int64_t binEnd,
                      uint64_t *realignedPosition, uint32_t *realignedCigar, uint32_t *realignedCigarLength, uint32_t *realignedEditDistance, uint32_t *realignedObservedLength)
 {
     DevReference R; std::memset(&R, 0, sizeof(R));
@@ -393,7 +393,7 @@ int emu_realign_case(const char *contig, uint64_t contigLength, const uint8_t *r
     for (const RealignGap &g : gaps) if (rgIsDeletion(g)) ends.push_back(g);
     std::stable_sort(ends.begin(), ends.end(), [](const RealignGap &l, const RealignGap &r) { return rgEndPos(l, false) < rgEndPos(r, false); });
     RealignerGapsView view = { gaps.data(), u32(gaps.size()), ends.data(), u32(ends.size()) };
-    RealignCtx x; x.R = &R; x.P.mismatchCost = mismatchCost; x.P.gapOpenCost = gapOpenCost; x.P.gapExtendCost = gapExtendCost; x.P.realignDodgyFragments = dodgy != 0; x.P.clipSemialigned = clipSemialigned != 0;
+    RealignCtx x; x.R = &R; x.P.mismatchCost = mismatchCost; x.P.gapOpenCost = gapOpenCost; x.P.gapExtendCost = gapExtendCost; x.P.realignDodgyFragments = dodgy != 0; x.P.clipSemialigned = clipSemialigned != 0; x.P.realignGapsVigorously = vigorous != 0;
     RealignFragment f; std::memset(&f, 0, sizeof(f));
     f.fStrandPosition = refpos(0, fStrandPosition); f.mateFStrandPosition = f.fStrandPosition; f.observedLength = observedLength; f.flags = 0;
     f.lowClipped = u16(lowClipped); f.highClipped = u16(highClipped); f.alignmentScore = 1; f.templateAlignmentScore = 0; f.readLength = u16(readLength); f.editDistance = u16(editDistance); f.bcl = readBcl;

@@ -107,7 +107,7 @@ class Oracle:
         return out.astype(bool)
 
     def bam_records(self, tiles, read_lengths, forced_dodgy_alignment_score=0, pessimistic_mapq=False, read_group="0", barcode="none", mark_duplicates=False, keep_duplicates=True,
-                    realign_gaps=False, realign_dodgy=False, clip_semialigned=True, reference=None, tls=None, bin_cuts=()):
+                    realign_gaps=False, realign_dodgy=False, clip_semialigned=True, reference=None, tls=None, bin_cuts=(), realign_vigorously=False):
         """tiles: [(bcl, records, cigars, read_name_prefix[, read_group[, tls]])] as numpy arrays; bin_cuts: ascending ReferencePosition values at which a
         contig goes on into a further bin (every bin is filtered and realigned by itself); returns (bytes, n_records, unaligned_offset)"""
         arr = (BamTile * len(tiles))()
@@ -131,7 +131,7 @@ class Oracle:
         cuts = np.ascontiguousarray(list(bin_cuts), np.uint64)
         self.check(self.lib.oracle_bam_records_cuts(arr, C.c_uint32(len(tiles)), C.c_uint32(len(read_lengths)), lengths, C.c_uint32(forced_dodgy_alignment_score), C.c_int(int(pessimistic_mapq)),
                                                     read_group.encode(), barcode.encode(), C.c_int(int(mark_duplicates)), C.c_int(int(keep_duplicates)),
-                                                    C.c_int(int(realign_gaps)), C.c_int(int(realign_dodgy)), C.c_int(int(clip_semialigned)), (reference.h if reference is not None else None),
+                                                    C.c_int(2 if (realign_gaps and realign_vigorously) else int(realign_gaps)), C.c_int(int(realign_dodgy)), C.c_int(int(clip_semialigned)), (reference.h if reference is not None else None),
                                                     C.byref(tls) if tls is not None else None, ptr(cuts) if len(cuts) else None, C.c_uint32(len(cuts)),
                                                     ptr(out), C.c_uint64(cap), C.byref(nb), C.byref(nr), C.byref(un)))
         return out[:nb.value].tobytes(), nr.value, un.value

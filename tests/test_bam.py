@@ -605,16 +605,19 @@ def test_gpu_gap_realignment_matches_the_oracle():
     otls.best_model[0], otls.best_model[1] = tls.best_model[0], tls.best_model[1]
     before = a.bam_records(dev_tiles)[0].cpu().numpy().tobytes()
     keep = [t[1].clone() for t in dev_tiles]
-    for mark, keep_dups, small_pool in ((False, True, False), (True, True, False), (True, False, False), (True, True, True)):
+    outputs = {}
+    for mark, keep_dups, small_pool, vigorous in ((False, True, False, False), (True, True, False, False), (True, False, False, False), (True, True, True, False), (True, True, False, True), (False, True, True, True)):
         # small_pool: the realigner's CIGAR pool starts at 64 words, overflows, and the pass is repeated with the size it asked for
+        # vigorous: --realign-vigorously 1 (round 6): a realigned fragment is tried again until nothing improves, more than ten gaps in reach are no obstacle
         if small_pool:
             os.environ["ISAAC_GPU_REALIGN_POOL_WORDS"] = "64"
         try:
-            got, n, un = a.bam_records(dev_tiles, mark_duplicates=mark, keep_duplicates=keep_dups, realign_gaps=True, tls=tls)
+            got, n, un = a.bam_records(dev_tiles, mark_duplicates=mark, keep_duplicates=keep_dups, realign_gaps=True, tls=tls, realign_vigorously=vigorous)
         finally:
             os.environ.pop("ISAAC_GPU_REALIGN_POOL_WORDS", None)
         want, want_n, want_un = o.bam_records(host_tiles, [L, L], forced_dodgy_alignment_score=params.dodgy_alignment_score & 0xff, mark_duplicates=mark, keep_duplicates=keep_dups,
-                                              realign_gaps=True, clip_semialigned=True, reference=ref, tls=otls)
+                                              realign_gaps=True, clip_semialigned=True, reference=ref, tls=otls, realign_vigorously=vigorous)
+        outputs[(mark, keep_dups, vigorous)] = want
         assert (n, un) == (want_n, want_un)
         got = got.cpu().numpy().tobytes()
         if got != want:
@@ -624,6 +627,7 @@ def test_gpu_gap_realignment_matches_the_oracle():
             assert not bad, (len(bad), bad[:5])
         assert got == want
     assert all((k == t[1]).all() for k, t in zip(keep, dev_tiles))       # the caller's records are not touched
+    assert outputs[(True, True, True)] != outputs[(True, True, False)]   # the second turns do find something on this sample
     plain, realigned = bam.parse_records(before), bam.parse_records(o.bam_records(host_tiles, [L, L], forced_dodgy_alignment_score=params.dodgy_alignment_score & 0xff, realign_gaps=True,
                                                                                  reference=ref, tls=otls)[0])
     by_name = {(r["name"], r["flag"] & 0xc0): r for r in plain}

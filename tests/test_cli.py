@@ -109,7 +109,7 @@ def test_command_line_errors(tmp_path):
              (["-r", "x.xml", "-b", tmp_path, "--base-calls-format", "fastq", "--dodgy-alignment-score", "300"], "must be either Unknown, Unaligned or a number 0-255 (300 given)"),
              (["-r", "x.xml", "-b", tmp_path, "--base-calls-format", "fastq", "--seed-length", "20"], "--seed-length other than 16, 32 or 64 is not supported"),
              (["-r", "x.xml", "-b", tmp_path, "--base-calls-format", "fastq", "--seed-length", "64"], "32-mer seeds only"),
-             (["-r", "x.xml", "-b", tmp_path, "--base-calls-format", "fastq", "--realign-vigorously", "1"], "--realign-vigorously 1 is not supported"),
+             (["-r", "x.xml", "-b", tmp_path, "--base-calls-format", "fastq", "--avoid-smith-waterman", "1"], "--avoid-smith-waterman 1 is not supported"),
              (["-r", "x.xml", "-b", tmp_path, "--base-calls-format", "fastq", "--mark-duplicates", "perhaps"], "option '--mark-duplicates' is invalid"),
              (["-r", "x.xml", "-b", tmp_path, "--base-calls-format", "fastq", "--jobs"], "the required argument for option '--jobs' is missing"),
              (["-r", "x.xml", "-b", tmp_path, "--base-calls-format", "fastq", "-m", "5", "-j4", "-t", tmp_path / "Temp"], "Could not find any fastq lanes in")]
@@ -405,6 +405,9 @@ SCENARIOS = {
     # (FragmentSequencingAdapterClipper in the ungapped, gapped and rescue alignments; the oracle with the same list)
     "adapters": dict(compressed=False, lengths=(100, 100), cli=["--default-adapters", "Nextera"], paired=True, mark=True, keep=True, realign=True, unaligned="back", dodgy=0, pu="%s:%d:none",
                      adapters="Nextera"),
+    # --realign-vigorously 1: a realigned fragment is tried again until nothing improves (GapRealigner.cpp:1241); the oracle's build stage likewise
+    "vigorous": dict(compressed=False, lengths=(100, 100), cli=["--realign-vigorously", "1"], paired=True, mark=True, keep=True, realign=True, unaligned="back", dodgy=0, pu="%s:%d:none",
+                     vigorous=True),
     # single-ended lanes, unaligned reads left out
     # ... on a reference made by bin/isaac-sort-reference from the FASTA file
     "single-ended": dict(compressed=True, lengths=(100,), cli=["--keep-unaligned", "discard"], paired=False, mark=True, keep=True, realign=True, unaligned="discard", dodgy=0, pu="%s:%d:none",
@@ -550,7 +553,7 @@ def test_gpu_isaac_align_end_to_end(tmp_path, scenario):
         orec, ocig, _ = ref.select(params, tile_bcl, om, tls, all_hits, tile=index, n_clusters_hint=len(tile_bcl))
         host_tiles.append((tile_bcl, orec, ocig, "FCTEST:%d:%d:" % (lane, number), str(lane_index), tls))
     want, want_n, want_unaligned = o.bam_records(host_tiles, list(lengths), forced_dodgy_alignment_score=sc["dodgy"] & 0xff, mark_duplicates=sc["mark"], keep_duplicates=sc["keep"],
-                                                 realign_gaps=sc["realign"], reference=ref, bin_cuts=cuts)
+                                                 realign_gaps=sc["realign"], reference=ref, bin_cuts=cuts, realign_vigorously=bool(sc.get("vigorous")))
     recs = bam.parse_records(want)
     print("oracle: %d records, %d unmapped, %d with gaps in the CIGAR, %d realigned, tiles %s" % (
         len(recs), sum(1 for x in recs if x["flag"] & 4), sum(1 for x in recs if any((int(w) & 15) in (1, 2) for w in x["cigar"])), sum(1 for x in recs if "OC" in x["tags"]),
