@@ -607,8 +607,8 @@ def test_sequencing_adapter_known_answers_on_the_gpu(torch, oracle):
         al.close()
 
 
-@pytest.mark.parametrize("adapters", ["Standard", "Nextera", "NexteraMp"])
-def test_sequencing_adapters_on_short_inserts(torch, oracle, adapters):
+@pytest.mark.parametrize("adapters,L", [("Standard", 150), ("Nextera", 150), ("NexteraMp", 150), ("Nextera", 250)])
+def test_sequencing_adapters_on_short_inserts(torch, oracle, adapters, L):
     """--default-adapters on the device: a third of the 2 x 150 pairs have inserts of 60-145 bases, so both reads run into the adapter (TruSeq / Nextera text, for
     NexteraMp the junction adapter's two halves).  k_adapter_ranges and k_rescue_adapter_ranges decide the ranges, every ungapped scan, gapped window and rescue scan
     clips by them: candidates (with and without gaps), template statistics and every record against the oracle's FragmentSequencingAdapterClipper.  Then the same
@@ -616,11 +616,12 @@ def test_sequencing_adapters_on_short_inserts(torch, oracle, adapters):
     from isaac_aligner_amd import gpu
     from parity_util import add_adapters
     text = dict(Standard="AGATCGGAAGAGC", Nextera="CTGTCTCTTATACACATCT", NexteraMp="CTGTCTCTTATACACATCT")[adapters]
-    contigs, bcl, _ = make_inputs(read_length=150, n_pairs=6000, seed=31, genome_bases=500000, indel_read_fraction=0.1)
-    bcl, inserts = add_adapters(bcl, 150, adapter=text, adapter2="AGATGTGTATAAGAGACAG" if adapters == "NexteraMp" else None, fraction=0.35, seed=32)
+    # (2 x 250: the banded-SW kernel's five-register form and 14 seeds per pair carry the ranges too)
+    contigs, bcl, _ = make_inputs(read_length=L, n_pairs=6000 if L == 150 else 3000, seed=31, genome_bases=500000, indel_read_fraction=0.1)
+    bcl, inserts = add_adapters(bcl, L, adapter=text, adapter2="AGATGTGTATAAGAGACAG" if adapters == "NexteraMp" else None, fraction=0.35, seed=32, insert_range=(60, L - 5))
     n = len(bcl)
-    plain = options.default_params(150, 150)
-    p = options.set_adapters(options.default_params(150, 150), adapters)
+    plain = options.default_params(L, L)
+    p = options.set_adapters(options.default_params(L, L), adapters)
     al = gpu.Aligner(p, 0, contigs)
     al.build_index()
     ref = oracle.reference(contigs)
