@@ -1361,7 +1361,10 @@ static void launchGappedJobs(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clusterBa
     // sequence, of up to 305 in five -- and the traceback flags take ten bytes per row: 1.6 KB of LDS per problem at 2 x 150 where round 5 had 2.3 KB,
     // three wavefronts per SIMD instead of two
     const bool staged = maxReadLength > BSW_REGISTER_BASES_LONG;
-    const size_t lds = size_t(BSW_BLOCK / BSW_GROUP_LANES) * gappedGroupLdsBytes(maxReadLength, staged);
+    size_t lds = size_t(BSW_BLOCK / BSW_GROUP_LANES) * gappedGroupLdsBytes(maxReadLength, staged);
+    // (measurements: ISAAC_GPU_GAPPED_LDS=<bytes> asks for more LDS per workgroup than the kernel uses, i.e. fewer of its wavefronts per CU and room for other contexts' kernels beside them)
+    static const size_t ldsAtLeast = std::getenv("ISAAC_GPU_GAPPED_LDS") ? size_t(std::atol(std::getenv("ISAAC_GPU_GAPPED_LDS"))) : 0;
+    lds = std::max(lds, std::min<size_t>(ldsAtLeast, 65536));
     {
         ScopedTimer t(c, timer);
         if (ISAAC_BSW_GLOBAL_FLAGS) c->bswFlags.reserve(size_t(65536) * (BSW_BLOCK / BSW_GROUP_LANES) * bswFlagBytes(maxReadLength));
