@@ -37,10 +37,6 @@
 #include "bgzf_kernels.h"
 #include "deflate_kernels.h"
 
-#if defined(ISAAC_KERNEL_STAMPS)
-__device__ unsigned long long g_stamps[64];
-#endif
-
 namespace
 {
 thread_local std::string g_error;
@@ -669,8 +665,8 @@ void isaac_gpu_destroy(isaac_gpu_ctx *c)
     resolveTimers(c);
 #if defined(ISAAC_KERNEL_STAMPS)
     {
-        unsigned long long h[64]; hipDeviceSynchronize(); hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof(h));
-        for (int i = 0; i < 64; ++i) if (h[i]) fprintf(stderr, "stamp %2d: %llu\n", i, h[i]);
+        hipDeviceSynchronize();
+        for (void (*print)() : stampPrinters()) print();
     }
 #endif
     for (hipEvent_t e : c->eventPool) hipEventDestroy(e);

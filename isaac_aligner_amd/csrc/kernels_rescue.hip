@@ -183,17 +183,36 @@ template <u32 PL> __device__ inline u32 tileLaneOf(u32 q)
     static_assert(PL == 8 || PL == 12 || PL == 16, "tile sizes of rescueWindowScanShort");
     return PL == 8 ? q >> 3 : PL == 16 ? q >> 4 : __umul24(q, 43691u) >> 19;       // q / 12 for q < 2^16
 }
-// one window position whose 7-mer the mate has: the mate's first position with it, and the candidate that puts it there
-__device__ inline void rescueWindowHit(u32 kmer, i32 biasedPosition, const u32 *tab, u32 *bitmap)
+// The mate's 7-mers of an ordinary window, without a hash table: `present` has one bit per possible 7-mer; a k-mer's rank among the set bits (the set bits in
+// front of its 64-bit block, 256 16-bit counts, plus those below it in the block) is its slot in `firstPosition`, which holds the mate's first position with it
+// (ShadowAligner::hashShadowKmers keeps the first, ShadowAligner.cpp:53-72).  Building it costs no compare-and-swap loops -- the hash table's probe sequences ran
+// for the whole wave as long as its unluckiest lane's -- and a hit reads two words and then one, with no loop either.
+__device__ inline u32 rescueKmerRank(u32 kmer, const u32 *present, const u16 *blockPrefix)
 {
-    u32 h = (kmer * 2654435761u) >> 23, e = tab[h];
-    while ((e >> 10) != kmer) { h = (h + 1) & (RW_TABLE - 1); e = tab[h]; }            // the k-mer is in the table
-    const u32 bit = u32(biasedPosition - i32(e & 0x3ffu));
+    const u32 block = kmer >> 6;
+    const u64 pair = reinterpret_cast<const u64 *>(present)[block];
+    return u32(blockPrefix[block]) + u32(__popcll(pair & ((1ull << (kmer & 63u)) - 1ull)));
+}
+// one window position whose 7-mer the mate has: the mate's first position with it, and the candidate that puts it there
+__device__ inline void rescueWindowHit(u32 kmer, i32 biasedPosition, const u32 *firstPosition, const u32 *present, const u16 *blockPrefix, u32 *bitmap)
+{
+    const u32 bit = u32(biasedPosition - i32(firstPosition[rescueKmerRank(kmer, present, blockPrefix)]));
     atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
 }
+// inclusive prefix sum over the wave's 64 lanes (all of them active): four shifts inside the rows of 16, then the rows' totals handed on
+__device__ inline u32 waveInclusiveAdd(u32 v)
+{
+    v += u32(__builtin_amdgcn_update_dpp(0, int(v), 0x111, 0xf, 0xf, false));      // row_shr:1
+    v += u32(__builtin_amdgcn_update_dpp(0, int(v), 0x112, 0xf, 0xf, false));      // row_shr:2
+    v += u32(__builtin_amdgcn_update_dpp(0, int(v), 0x114, 0xf, 0xf, false));      // row_shr:4
+    v += u32(__builtin_amdgcn_update_dpp(0, int(v), 0x118, 0xf, 0xf, false));      // row_shr:8
+    v += u32(__builtin_amdgcn_update_dpp(0, int(v), 0x142, 0xa, 0xf, false));      // row_bcast:15 into rows 1 and 3
+    v += u32(__builtin_amdgcn_update_dpp(0, int(v), 0x143, 0xc, 0xf, false));      // row_bcast:31 into rows 2 and 3
+    return v;
+}
 template <u32 PL>
-__device__ inline void rescueWindowScanShort(const DevReference &R, const RescueJob &job, u64 windowBase, const WindowBits &firstTile, u32 L, const u32 *tab, const u32 *present,
-                                             u32 *bitmap, u32 lane)
+__device__ inline void rescueWindowScanShort(const DevReference &R, const RescueJob &job, u64 windowBase, const WindowBits &firstTile, u32 L, const u32 *firstPosition, const u32 *present,
+                                             const u16 *blockPrefix, u32 *bitmap, u32 lane STAMP_PARAM)
 {
     static_assert(PL <= 16, "a lane's bit offsets 2k stay below 32");
     const i32 bias = i32(L) - 7;
@@ -227,6 +246,7 @@ __device__ inline void rescueWindowScanShort(const DevReference &R, const Rescue
             h = __builtin_amdgcn_alignbit(words[k] >> (t & 31u), h, 1);    // bit k ends at 32 - PL + k
         }
         u32 hitMask = (h >> (32 - PL)) & valid;
+        STAMP(8);
         // Where the mate really lies every position hits: a dozen neighbouring lanes with PL hits each, and a wave that walks its
         // lanes' hits one by one makes PL passes for them.  Then the hits are dealt out again, lane l taking tile positions l, l + 64,
         // ...: a run of consecutive hits comes to two or three per lane.
@@ -234,7 +254,7 @@ __device__ inline void rescueWindowScanShort(const DevReference &R, const Rescue
             while (hitMask)
             {
                 const u32 k = u32(__ffs(hitMask)) - 1; hitMask &= hitMask - 1;
-                rescueWindowHit(u32(wb.codes >> (2 * k)) & 0x3fffu, p0 + i32(k) + bias, tab, bitmap);
+                rescueWindowHit(u32(wb.codes >> (2 * k)) & 0x3fffu, p0 + i32(k) + bias, firstPosition, present, blockPrefix, bitmap);
             }
         else
         {
@@ -252,9 +272,10 @@ __device__ inline void rescueWindowScanShort(const DevReference &R, const Rescue
                 const u32 t = have ? u32(__ffs(mine)) - 1 : 0; mine &= mine - 1;
                 const u32 q = t * 64 + lane, l = tileLaneOf<PL>(q), k = q - l * PL;
                 const u64 codes = u64(u32(__shfl(lo, l, 64))) | (u64(u32(__shfl(hi, l, 64))) << 32);
-                if (have) rescueWindowHit(u32(codes >> (2 * k)) & 0x3fffu, tile * i32(64 * PL) + i32(q) + bias, tab, bitmap);
+                if (have) rescueWindowHit(u32(codes >> (2 * k)) & 0x3fffu, tile * i32(64 * PL) + i32(q) + bias, firstPosition, present, blockPrefix, bitmap);
             }
         }
+        STAMP(9);
     }
 }
 
@@ -265,10 +286,26 @@ __device__ inline void rescueWindowScanShort(const DevReference &R, const Rescue
 // candidate -- was measured slower, 8.0 against 6.4 ms per 1 M clusters: the windows differ in length and the hardware's own wave
 // scheduling balances them better.)
 __device__ inline void rescueWindowsProblem(const DevParams &P, const DevReference &R, const u8 *bcl, u32 clusterBase, const RescueBuffers &rb, u32 j, u32 lane,
-                                            u32 *tab, u32 *ldsBitmap, u32 *present)
+                                            u32 *tab, u32 *ldsBitmap, u32 *present, u16 *blockPrefix)
 {
-    const RescueJob job = rb.jobs[imin(j, rb.jobsCap - 1)];
-    const u32 nJobs = imin(*rb.jobCounter, rb.jobsCap);
+    // The slot's record and the number of slots in use, asked for together and awaited once: 24 words of the record through the scalar cache.  (Left to the
+    // compiler the byte-sized fields came by vector loads, the two of them that decide whether there is anything to do first and the rest behind the branch, and the
+    // counter in between: three memory latencies in a row before the first useful load was issued.)
+    typedef u32 Words16 __attribute__((ext_vector_type(16)));
+    typedef u32 Words8 __attribute__((ext_vector_type(8)));
+    Words16 head; Words8 tail; u32 slotsInUse;
+    {
+        const RescueJob *record = rb.jobs + imin(j, rb.jobsCap - 1);
+        asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx8 %1, %3, 0x40\n\ts_load_dword %2, %4, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(head), "=&s"(tail), "=&s"(slotsInUse) : "s"(record), "s"(rb.jobCounter) : "memory");
+    }
+    static_assert(offsetof(RescueJob, windowLen) == 8 && offsetof(RescueJob, cluster) == 12 && offsetof(RescueJob, bitmapBase) == 32 && offsetof(RescueJob, shadowReadIndex) == 40 &&
+                  offsetof(RescueJob, fallback) == 43 && offsetof(RescueJob, windowBaseHigh) == 86 && offsetof(RescueJob, windowBaseLow) == 88, "the words picked below");
+    RescueJob job;
+    job.windowLen = head[2]; job.cluster = head[3]; job.bitmapBase = head[8];
+    job.shadowReadIndex = u8(head[10]); job.shadowReverse = u8(head[10] >> 8); job.valid = u8(head[10] >> 16); job.fallback = u8(head[10] >> 24);
+    job.windowBaseHigh = u16(tail[5] >> 16); job.windowBaseLow = tail[6];
+    const u32 nJobs = imin(slotsInUse, rb.jobsCap);
     STAMP_BEGIN();
     const bool active = j < nJobs && job.valid && !job.fallback;
     STAMP(0);
@@ -290,7 +327,23 @@ __device__ inline void rescueWindowsProblem(const DevParams &P, const DevReferen
         const u32 perLane = __builtin_amdgcn_readfirstlane(!small ? RW_PER_LANE : nStarts <= 64 * 8 ? 8u : nStarts <= 64 * 12 ? 12u : 16u);
         const u64 windowBase = rescueJobWindowBase(job);
         const WindowBits firstTile = loadWindowBits(R, windowBase + lane * perLane);
-        for (u32 i = lane; i < RW_TABLE; i += 64) tab[i] = KMER_EMPTY;
+        // ... and so are the lane's eight bytes of the mate: they arrive while the tables are cleared
+        ReadView read; read.bcl = bcl + u64(clusterBase + job.cluster) * P.clusterLength + P.readOffset[r]; read.length = L; read.endCyclesMasked = 0; read.firstCycle = 0;
+        const bool reverse = job.shadowReverse != 0;
+        // (one load from a selected address; the last lane's shift waits until the bytes are used: nothing here may wait for them)
+        // (every lane loads, the ones past the read's end its first bytes: a load under a condition is taken apart, and waited for, where it stands)
+        u64 bytes; u32 shortBy;
+        {
+            const u32 s0 = lane * 8;                                 // first strand position of this lane
+            const bool mine = s0 < L;
+            shortBy = mine && s0 + 8 > L ? s0 + 8 - L : 0;            // strand positions of this lane that lie past the read's end
+            // forward: BCL bytes s0 .. s0+7 (the last lane: L-8 .. L-1, shifted down); reverse: L-8-s0 .. L-1-s0, strand position s0+t is byte 7-t (the last lane: 0 .. 7, shifted up)
+            const u32 from = !mine ? 0 : !reverse ? (shortBy ? L - 8 : s0) : (shortBy ? 0 : L - 8 - s0);
+            memcpy(&bytes, read.bcl + from, 8);
+        }
+        // the slots of the mate's k-mers (an ordinary window: a first position per k-mer in use; a long one: the hash table), all ones either way
+        const u32 nKmers = L > 6 ? L - 6 : 0;
+        for (u32 i = lane; i < (small ? (nKmers + 3) / 4 : RW_TABLE / 4); i += 64) reinterpret_cast<uint4 *>(tab)[i] = make_uint4(KMER_EMPTY, KMER_EMPTY, KMER_EMPTY, KMER_EMPTY);
         if (!small) bitmap = rb.bitmaps + job.bitmapBase;
         if (small) for (u32 i = lane; i < RW_PRESENT_WORDS / 4; i += 64) reinterpret_cast<uint4 *>(present)[i] = make_uint4(0, 0, 0, 0);
         for (u32 i = lane; i < bitmapWords; i += 64) bitmap[i] = 0;
@@ -298,28 +351,16 @@ __device__ inline void rescueWindowsProblem(const DevParams &P, const DevReferen
         __builtin_amdgcn_wave_barrier();
         STAMP(1);
         // the mate's 7-mers: first read position of every k-mer (ShadowAligner::hashShadowKmers, :53-72)
-        ReadView read; read.bcl = bcl + u64(clusterBase + job.cluster) * P.clusterLength + P.readOffset[r]; read.length = L; read.endCyclesMasked = 0; read.firstCycle = 0;
-        const bool reverse = job.shadowReverse != 0;
         // The mate in the strand's order, packed once: lane l holds strand positions 8l .. 8l+7 as 2-bit codes (the code the packed reference
         // has for the same base: A 0, C 1, G 3, T 2) in bits 0-15 and their N flags in bits 16-23 (a BCL byte without quality bits is an N,
         // Read.cpp:56-69; so is what lies past the end of the read).  A 7-mer is then 14 bits of two neighbouring lanes' words.
         u32 packedMate = 0x00ff0000u;
         if (lane * 8 < L)
         {
-            const u32 s0 = lane * 8;                                 // first strand position of this lane
-            u64 bytes = 0;
-            if (!reverse)
-            {   // BCL bytes s0 .. s0+7
-                if (s0 + 8 <= L) memcpy(&bytes, read.bcl + s0, 8);
-                else { memcpy(&bytes, read.bcl + L - 8, 8); bytes >>= 8 * (s0 + 8 - L); }
-            }
-            else
-            {   // BCL bytes L-8-s0 .. L-1-s0: strand position s0+t is byte 7-t
-                if (s0 + 8 <= L) memcpy(&bytes, read.bcl + (L - 8 - s0), 8);
-                else { memcpy(&bytes, read.bcl, 8); bytes <<= 8 * (s0 + 8 - L); }
-            }
             // eight bytes at once: strand position s0 + t in byte t, the complement for the reverse strand, then per byte the code
             // base ^ (base >> 1) and "no quality bits", and the fields of four bytes gathered with shifts
+            asm volatile("" : "+v"(bytes));                                   // (not before: the compiler would start taking the bytes apart right behind the load, and wait for it there)
+            bytes = !reverse ? bytes >> (8 * shortBy) : bytes << (8 * shortBy);
             if (reverse) bytes = __builtin_bswap64(bytes) ^ 0x0303030303030303ull;
             u32 codes = 0, ns = 0;
 #pragma unroll
@@ -337,27 +378,71 @@ __device__ inline void rescueWindowsProblem(const DevParams &P, const DevReferen
             }
             packedMate = codes | (ns << 16);
         }
-        // -DISAAC_TIMING_RW_NO_TABLE / _NO_SCAN / _NO_ENUM: builds that leave a section out (wrong results) to time the others, scripts/exp_rw_phases.sh
-#if !defined(ISAAC_TIMING_RW_NO_TABLE)
-        for (u32 i = lane; i < ((L + 63) & ~63u); i += 64)              // every lane takes part in the exchanges
+        STAMP(10);
+        // the k-mer that starts at the mate's position i (base k of it at bits 2k, as loadWindowBits lays them out), or all ones: past the end, or an N among
+        // its bases.  Every lane takes part in the exchanges.
+        const auto mateKmer = [&](u32 i) -> u32
         {
             const u32 w0 = __shfl(packedMate, i >> 3, 64), w1 = __shfl(packedMate, ((i >> 3) + 1) & 63, 64);
-            if (i + 7 > L) continue;
             const u32 shift = i & 7;
-            const u32 kmer = (((w0 & 0xffffu) | (w1 << 16)) >> (2 * shift)) & 0x3fffu;   // base k of the k-mer at bits 2k, as loadWindowBits lays them out
-            const bool ok = 0 == (((((w0 >> 16) & 0xffu) | (((w1 >> 16) & 0xffu) << 8)) >> shift) & 0x7fu);
-            if (!ok) continue;
-            const u32 val = (kmer << 10) | i;
-            if (small) atomicOr(&present[kmer >> 5], 1u << (kmer & 31u));
-            u32 h = (kmer * 2654435761u) >> 23;
-            while (true)
+            const u32 kmer = (((w0 & 0xffffu) | (w1 << 16)) >> (2 * shift)) & 0x3fffu;
+            const bool ok = i + 7 <= L && 0 == (((((w0 >> 16) & 0xffu) | (((w1 >> 16) & 0xffu) << 8)) >> shift) & 0x7fu);
+            return ok ? kmer : 0xffffffffu;
+        };
+        // -DISAAC_TIMING_RW_NO_TABLE / _NO_SCAN / _NO_ENUM: builds that leave a section out (wrong results) to time the others, scripts/exp_rw_phases.sh
+#if !defined(ISAAC_TIMING_RW_NO_TABLE)
+        if (small)
+        {
+            // which k-mers there are; their ranks; the first position of each.  (Read lengths end at 512: eight rounds of 64 positions at most, the
+            // k-mers of a round kept in a register between the first pass and the third.)
+            u32 held[8];
+#pragma unroll
+            for (u32 t = 0; t < 8; ++t)
             {
-                const u32 old = atomicCAS(&tab[h], KMER_EMPTY, val);
-                if (old == KMER_EMPTY) break;
-                if ((old >> 10) == kmer) { atomicMin(&tab[h], val); break; }
-                h = (h + 1) & (RW_TABLE - 1);
+                held[t] = 0xffffffffu;
+                if (t * 64 < L)
+                {
+                    held[t] = mateKmer(t * 64 + lane);
+                    if (held[t] != 0xffffffffu) atomicOr(&present[held[t] >> 5], 1u << (held[t] & 31u));
+                }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            STAMP(11);
+            {   // lane l counts blocks 2l, 2l+1 (words 4l .. 4l+3) and 128+2l, 128+2l+1: two 16-byte reads a lane, next to each other across the wave
+                const uint4 a = reinterpret_cast<const uint4 *>(present)[lane], b = reinterpret_cast<const uint4 *>(present)[64 + lane];
+                const u32 a0 = u32(__popc(a.x)) + u32(__popc(a.y)), a1 = u32(__popc(a.z)) + u32(__popc(a.w));
+                const u32 b0 = u32(__popc(b.x)) + u32(__popc(b.y)), b1 = u32(__popc(b.z)) + u32(__popc(b.w));
+                const u32 inclusive = waveInclusiveAdd((a0 + a1) | ((b0 + b1) << 16));      // (at most 506 k-mers: the low half never carries)
+                const u32 lowTotal = u32(__builtin_amdgcn_readlane(int(inclusive), 63)) & 0xffffu;
+                const u32 beforeA = (inclusive & 0xffffu) - (a0 + a1), beforeB = (inclusive >> 16) - (b0 + b1) + lowTotal;
+                reinterpret_cast<u32 *>(blockPrefix)[lane] = beforeA | ((beforeA + a0) << 16);
+                reinterpret_cast<u32 *>(blockPrefix)[64 + lane] = beforeB | ((beforeB + b0) << 16);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            STAMP(12);
+#pragma unroll
+            for (u32 t = 0; t < 8; ++t)
+                if (t * 64 < L && held[t] != 0xffffffffu) atomicMin(&tab[rescueKmerRank(held[t], present, blockPrefix)], t * 64 + lane);
         }
+        else
+            for (u32 i = lane; i < ((L + 63) & ~63u); i += 64)
+            {
+                const u32 kmer = mateKmer(i);
+                if (kmer == 0xffffffffu) continue;
+                const u32 val = (kmer << 10) | i;
+                u32 h = (kmer * 2654435761u) >> 23;
+                while (true)
+                {
+                    const u32 old = atomicCAS(&tab[h], KMER_EMPTY, val);
+                    if (old == KMER_EMPTY) break;
+                    if ((old >> 10) == kmer) { atomicMin(&tab[h], val); break; }
+                    h = (h + 1) & (RW_TABLE - 1);
+                }
+            }
 #endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -366,9 +451,9 @@ __device__ inline void rescueWindowsProblem(const DevParams &P, const DevReferen
 #if !defined(ISAAC_TIMING_RW_NO_TABLE) && !defined(ISAAC_TIMING_RW_NO_SCAN)
         if (small)
         {
-            if (perLane == 8) rescueWindowScanShort<8>(R, job, windowBase, firstTile, L, tab, present, ldsBitmap, lane);
-            else if (perLane == 12) rescueWindowScanShort<12>(R, job, windowBase, firstTile, L, tab, present, ldsBitmap, lane);
-            else rescueWindowScanShort<16>(R, job, windowBase, firstTile, L, tab, present, ldsBitmap, lane);
+            if (perLane == 8) rescueWindowScanShort<8>(R, job, windowBase, firstTile, L, tab, present, blockPrefix, ldsBitmap, lane STAMP_ARG);
+            else if (perLane == 12) rescueWindowScanShort<12>(R, job, windowBase, firstTile, L, tab, present, blockPrefix, ldsBitmap, lane STAMP_ARG);
+            else rescueWindowScanShort<16>(R, job, windowBase, firstTile, L, tab, present, blockPrefix, ldsBitmap, lane STAMP_ARG);
         }
         else { rescueWindowScan<false>(R, job, windowBase, firstTile, L, tab, bitmap, lane, pushes); __threadfence(); }
 #else
@@ -383,9 +468,8 @@ __device__ inline void rescueWindowsProblem(const DevParams &P, const DevReferen
         if (small)
         {
             smallWord = lane < bitmapWords ? bitmap[lane] : 0u;
-            smallIncl = u32(__popc(smallWord));
-            for (u32 o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(smallIncl, o, 64); if (lane >= o) smallIncl += t; }
-            total = __shfl(smallIncl, 63, 64);
+            smallIncl = waveInclusiveAdd(u32(__popc(smallWord)));
+            total = u32(__builtin_amdgcn_readlane(int(smallIncl), 63));
         }
         else for (u32 w0 = 0; w0 < bitmapWords; w0 += 64)
         {
@@ -457,9 +541,10 @@ __device__ inline void rescueWindowsProblem(const DevParams &P, const DevReferen
 
 __global__ __launch_bounds__(64 * RW_WAVES) void k_rescue_windows(DevParams P, DevReference R, u64 totalBases, const u8 *bcl, u32 clusterBase, RescueBuffers rb)
 {
-    __shared__ u32 tables[RW_WAVES][RW_TABLE];
+    __shared__ __align__(16) u32 tables[RW_WAVES][RW_TABLE];
     __shared__ u32 ldsBitmaps[RW_WAVES][RW_LDS_BITMAP];
     __shared__ __align__(2048) u32 presentMaps[RW_WAVES][RW_PRESENT_WORDS];      // 2048: rescueWindowScanShort ORs word offsets into the base
+    __shared__ __align__(8) u16 blockPrefixes[RW_WAVES][RW_PRESENT_WORDS / 2];     // set bits in front of each 64-bit block of the map
 #if defined(ISAAC_TIMING_RW_EXIT)
     if (clusterBase != 0xffffffffu) return;                                  // timing only: what launching the grid costs
 #endif
@@ -470,7 +555,7 @@ __global__ __launch_bounds__(64 * RW_WAVES) void k_rescue_windows(DevParams P, D
     // 8 192 wavefronts over a compacted list of the slots in use, the record's fields moved to scalar registers one by one, has the same
     // 95 registers -- the loop's invariants -- or 64 with spills: 4.7 ms against 3.1 (and that attempt's records differed: a bug that
     // was not chased once the time was known).)
-    rescueWindowsProblem(P, R, bcl, clusterBase, rb, blockIdx.x * RW_WAVES + wave, lane, tables[wave], ldsBitmaps[wave], presentMaps[wave]);
+    rescueWindowsProblem(P, R, bcl, clusterBase, rb, blockIdx.x * RW_WAVES + wave, lane, tables[wave], ldsBitmaps[wave], presentMaps[wave], blockPrefixes[wave]);
 }
 
 // With sequencing adapters only (--default-adapters): ShadowAligner::rescueShadow makes a fresh FragmentSequencingAdapterClipper per call and its first candidate

@@ -16,15 +16,37 @@
 
 // optional in-kernel section stamps (-DISAAC_KERNEL_STAMPS): shader-clock ticks per section, summed over the sampled waves
 // (lane 0 of every wave of every 256th workgroup), printed when the context is destroyed.  A measuring aid, compiled out of
-// the product build.  (The kernels are in several translation units now and g_stamps in one: the build needs -fgpu-rdc to link with this
-// macro; round 3 timed sections by leaving them out instead, -DISAAC_TIMING_BSW_NO_DP / _NO_TRACEBACK in bsw_kernel.h.)
+// the product build.  The kernels are in several translation units: each has its own g_stamps and registers a function that prints it
+// (isaac_gpu_destroy calls them all).
+#if defined(ISAAC_KERNEL_STAMPS) && defined(__HIPCC__)
+#include <cstdio>
+#include <vector>
+static __device__ unsigned long long g_stamps[64];
+inline std::vector<void (*)()> &stampPrinters() { static std::vector<void (*)()> v; return v; }
+namespace
+{
+struct StampPrinter
+{
+    StampPrinter() { stampPrinters().push_back(&print); }
+    static void print()
+    {
+        unsigned long long h[64];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof(h)) != hipSuccess) return;
+        for (int i = 0; i < 64; ++i) if (h[i]) fprintf(stderr, "stamp %2d: %llu\n", i, h[i]);
+    }
+} stampPrinter;
+}
+#endif
 #if defined(ISAAC_KERNEL_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
-extern __device__ unsigned long long g_stamps[64];
 #define STAMP_BEGIN() long long stamp_t = clock64()
+#define STAMP_PARAM , long long &stamp_t
+#define STAMP_ARG , stamp_t
 #define STAMP(slot) do { if ((threadIdx.x & 63) == 0 && (blockIdx.x & 255) == 0) { const long long stamp_n = clock64(); atomicAdd(&g_stamps[slot], (unsigned long long)(stamp_n - stamp_t)); stamp_t = stamp_n; } } while (0)
 #else
 #define STAMP_BEGIN()
 #define STAMP(slot)
+#define STAMP_PARAM
+#define STAMP_ARG
 #endif
 
 namespace isaac
