@@ -121,6 +121,8 @@ struct AlignList { u32 *entries; u32 cap; u32 *counter; };
 static const u32 KMER_EMPTY = 0xffffffffu;
 static const u32 RW_TABLE = 512;          // hash slots for the mate's <= 250-odd 7-mers
 static const u32 RW_PRESENT_WORDS = 512;  // one bit per possible 7-mer: does the mate have it?
+static const u32 RW_MATE_WORDS = 36;      // the mate's bases in LDS, 16 a word (512) and what a read from its last word reads on
+static const u32 RW_FLAG_WORDS = 18;      // a bit per mate position, likewise
 #ifndef ISAAC_RW_WAVES
 #define ISAAC_RW_WAVES 1
 #endif

@@ -212,7 +212,7 @@ __device__ inline u32 waveInclusiveAdd(u32 v)
 }
 template <u32 PL>
 __device__ inline void rescueWindowScanShort(const DevReference &R, const RescueJob &job, u64 windowBase, const WindowBits &firstTile, u32 L, const u32 *firstPosition, const u32 *present,
-                                             const u16 *blockPrefix, u32 *bitmap, u32 lane STAMP_PARAM)
+                                             const u16 *blockPrefix, const u32 *mateCodes, const u32 *firstFlags, u32 *bitmap, u32 lane STAMP_PARAM)
 {
     static_assert(PL <= 16, "a lane's bit offsets 2k stay below 32");
     const i32 bias = i32(L) - 7;
@@ -247,9 +247,52 @@ __device__ inline void rescueWindowScanShort(const DevReference &R, const Rescue
         }
         u32 hitMask = (h >> (32 - PL)) & valid;
         STAMP(8);
-        // Where the mate really lies every position hits: a dozen neighbouring lanes with PL hits each, and a wave that walks its
-        // lanes' hits one by one makes PL passes for them.  Then the hits are dealt out again, lane l taking tile positions l, l + 64,
-        // ...: a run of consecutive hits comes to two or three per lane.
+        // Where the mate really lies every position hits, a dozen neighbouring lanes with PL hits each, and all of them name the same candidate: the window
+        // repeats the mate there, base for base.  So every lane looks its first hit up, and asks of the others only whether they continue it: the hit d + 1
+        // positions on names the same candidate if the window's 7-mer there is the mate's at the first hit's mate position + d + 1 and that position is the
+        // first the mate has this 7-mer at (firstFlags) -- a comparison of the lane's window bases with the mate's bases from there, all positions at once.
+        // What that explains is dropped; a lane with a hit it does not explain (another diagonal: an indel, a repeat) keeps all its later hits for the loops below.
+        if (__ballot(hitMask != 0))
+        {
+            const bool have = hitMask != 0;
+            const u32 k0 = have ? u32(__ffs(hitMask)) - 1 : 0;
+            u32 rest = have ? (hitMask >> k0) >> 1 : 0;                    // bit d: position k0 + 1 + d hits
+            u32 first = 0;
+            if (have)
+            {
+                first = firstPosition[rescueKmerRank(u32(wb.codes >> (2 * k0)) & 0x3fffu, present, blockPrefix)];
+                const u32 bit = u32(p0 + i32(k0) + bias - i32(first));
+                atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
+            }
+            if (__ballot(rest != 0))
+            {
+                u32 explained = 0;
+                if (rest)
+                {
+                    const u32 a = first + 1;                               // the mate position that lies against window position k0 + 1
+                    const u64 windowCodes = (wb.codes >> (2 * k0)) >> 2;
+                    const u32 *mw = mateCodes + (a >> 4);
+                    const u32 m0 = mw[0], m1 = mw[1], m2 = mw[2], shift = 2 * (a & 15u);
+                    const u32 xl = u32(windowCodes) ^ __builtin_amdgcn_alignbit(m1, m0, shift), xh = u32(windowCodes >> 32) ^ __builtin_amdgcn_alignbit(m2, m1, shift);
+                    // bit 2j: base j differs; then, bit 2d: one of bases d .. d+6 differs (d <= 14: the low word, which looks at bases up to 20)
+                    const u32 dl = (xl | (xl >> 1)) & 0x55555555u, dh = (xh | (xh >> 1)) & 0x55555555u;
+                    const u32 pl = dl | __builtin_amdgcn_alignbit(dh, dl, 2), ph = dh | (dh >> 2);                          // bases d, d+1
+                    const u32 ql = pl | __builtin_amdgcn_alignbit(ph, pl, 4);                                               // d .. d+3
+                    u32 differs = ql | __builtin_amdgcn_alignbit(ph, pl, 8) | __builtin_amdgcn_alignbit(dh, dl, 12);      // + d+4, d+5 + d+6
+                    // the even bits gathered: bit d
+                    differs = (differs | (differs >> 1)) & 0x33333333u;
+                    differs = (differs | (differs >> 2)) & 0x0f0f0f0fu;
+                    differs = (differs | (differs >> 4)) & 0x00ff00ffu;
+                    differs = (differs | (differs >> 8)) & 0x0000ffffu;
+                    const u32 *fw = firstFlags + (a >> 5);
+                    explained = ~differs & __builtin_amdgcn_alignbit(fw[1], fw[0], a & 31u);
+                }
+                if ((rest & ~explained) == 0) rest = 0;
+            }
+            hitMask = have ? (rest << k0) << 1 : 0;
+        }
+        // What is left is little as a rule.  Should a lane still have many (its hits one by one make as many passes of the whole wave), the hits are
+        // dealt out again, lane l taking tile positions l, l + 64, ...
         if (__ballot(__popc(hitMask) > RW_DENSE_HITS) == 0)
             while (hitMask)
             {
@@ -286,7 +329,7 @@ __device__ inline void rescueWindowScanShort(const DevReference &R, const Rescue
 // candidate -- was measured slower, 8.0 against 6.4 ms per 1 M clusters: the windows differ in length and the hardware's own wave
 // scheduling balances them better.)
 __device__ inline void rescueWindowsProblem(const DevParams &P, const DevReference &R, const u8 *bcl, u32 clusterBase, const RescueBuffers &rb, u32 j, u32 lane,
-                                            u32 *tab, u32 *ldsBitmap, u32 *present, u16 *blockPrefix)
+                                            u32 *tab, u32 *ldsBitmap, u32 *present, u16 *blockPrefix, u32 *mateCodes, u32 *firstFlags)
 {
     // The slot's record and the number of slots in use, asked for together and awaited once: 24 words of the record through the scalar cache.  (Left to the
     // compiler the byte-sized fields came by vector loads, the two of them that decide whether there is anything to do first and the rest behind the branch, and the
@@ -378,6 +421,12 @@ __device__ inline void rescueWindowsProblem(const DevParams &P, const DevReferen
             }
             packedMate = codes | (ns << 16);
         }
+        if (small)
+        {   // the mate's codes in one piece, 16 bases a word (lane l: bases 8l .. 8l+7; past the read's end: zeros, and a spare word for reads that end a word)
+            reinterpret_cast<u16 *>(mateCodes)[lane] = u16(packedMate);
+            if (lane < RW_MATE_WORDS - 32) mateCodes[32 + lane] = 0;
+            if (lane < RW_FLAG_WORDS) firstFlags[lane] = 0;
+        }
         STAMP(10);
         // the k-mer that starts at the mate's position i (base k of it at bits 2k, as loadWindowBits lays them out), or all ones: past the end, or an N among
         // its bases.  Every lane takes part in the exchanges.
@@ -426,7 +475,18 @@ __device__ inline void rescueWindowsProblem(const DevParams &P, const DevReferen
             STAMP(12);
 #pragma unroll
             for (u32 t = 0; t < 8; ++t)
-                if (t * 64 < L && held[t] != 0xffffffffu) atomicMin(&tab[rescueKmerRank(held[t], present, blockPrefix)], t * 64 + lane);
+                if (t * 64 < L && held[t] != 0xffffffffu) { held[t] = rescueKmerRank(held[t], present, blockPrefix); atomicMin(&tab[held[t]], t * 64 + lane); }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // firstFlags, bit i: the mate's position i is the first with its 7-mer (rescueWindowScanShort: where a run of hits may be taken for granted)
+#pragma unroll
+            for (u32 t = 0; t < 8; ++t)
+                if (t * 64 < L)
+                {
+                    const unsigned long long firsts = __ballot(held[t] != 0xffffffffu && tab[held[t] != 0xffffffffu ? held[t] : 0] == t * 64 + lane);
+                    if (lane < 2) firstFlags[2 * t + lane] = lane ? u32(firsts >> 32) : u32(firsts);
+                }
         }
         else
             for (u32 i = lane; i < ((L + 63) & ~63u); i += 64)
@@ -451,9 +511,9 @@ __device__ inline void rescueWindowsProblem(const DevParams &P, const DevReferen
 #if !defined(ISAAC_TIMING_RW_NO_TABLE) && !defined(ISAAC_TIMING_RW_NO_SCAN)
         if (small)
         {
-            if (perLane == 8) rescueWindowScanShort<8>(R, job, windowBase, firstTile, L, tab, present, blockPrefix, ldsBitmap, lane STAMP_ARG);
-            else if (perLane == 12) rescueWindowScanShort<12>(R, job, windowBase, firstTile, L, tab, present, blockPrefix, ldsBitmap, lane STAMP_ARG);
-            else rescueWindowScanShort<16>(R, job, windowBase, firstTile, L, tab, present, blockPrefix, ldsBitmap, lane STAMP_ARG);
+            if (perLane == 8) rescueWindowScanShort<8>(R, job, windowBase, firstTile, L, tab, present, blockPrefix, mateCodes, firstFlags, ldsBitmap, lane STAMP_ARG);
+            else if (perLane == 12) rescueWindowScanShort<12>(R, job, windowBase, firstTile, L, tab, present, blockPrefix, mateCodes, firstFlags, ldsBitmap, lane STAMP_ARG);
+            else rescueWindowScanShort<16>(R, job, windowBase, firstTile, L, tab, present, blockPrefix, mateCodes, firstFlags, ldsBitmap, lane STAMP_ARG);
         }
         else { rescueWindowScan<false>(R, job, windowBase, firstTile, L, tab, bitmap, lane, pushes); __threadfence(); }
 #else
@@ -545,6 +605,8 @@ __global__ __launch_bounds__(64 * RW_WAVES) void k_rescue_windows(DevParams P, D
     __shared__ u32 ldsBitmaps[RW_WAVES][RW_LDS_BITMAP];
     __shared__ __align__(2048) u32 presentMaps[RW_WAVES][RW_PRESENT_WORDS];      // 2048: rescueWindowScanShort ORs word offsets into the base
     __shared__ __align__(8) u16 blockPrefixes[RW_WAVES][RW_PRESENT_WORDS / 2];     // set bits in front of each 64-bit block of the map
+    __shared__ u32 mateWords[RW_WAVES][RW_MATE_WORDS];                               // the mate's bases, 2 bits each
+    __shared__ u32 firstFlagWords[RW_WAVES][RW_FLAG_WORDS];                          // one bit per mate position
 #if defined(ISAAC_TIMING_RW_EXIT)
     if (clusterBase != 0xffffffffu) return;                                  // timing only: what launching the grid costs
 #endif
@@ -555,7 +617,7 @@ __global__ __launch_bounds__(64 * RW_WAVES) void k_rescue_windows(DevParams P, D
     // 8 192 wavefronts over a compacted list of the slots in use, the record's fields moved to scalar registers one by one, has the same
     // 95 registers -- the loop's invariants -- or 64 with spills: 4.7 ms against 3.1 (and that attempt's records differed: a bug that
     // was not chased once the time was known).)
-    rescueWindowsProblem(P, R, bcl, clusterBase, rb, blockIdx.x * RW_WAVES + wave, lane, tables[wave], ldsBitmaps[wave], presentMaps[wave], blockPrefixes[wave]);
+    rescueWindowsProblem(P, R, bcl, clusterBase, rb, blockIdx.x * RW_WAVES + wave, lane, tables[wave], ldsBitmaps[wave], presentMaps[wave], blockPrefixes[wave], mateWords[wave], firstFlagWords[wave]);
 }
 
 // With sequencing adapters only (--default-adapters): ShadowAligner::rescueShadow makes a fresh FragmentSequencingAdapterClipper per call and its first candidate
