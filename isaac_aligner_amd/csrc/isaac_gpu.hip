@@ -107,7 +107,7 @@ struct isaac_gpu_ctx
     DevBuf<BamTile> bamTiles; DevBuf<u64> bamKeyHi, bamKeyLo, bamKeyAlt, bamOffsets, bamBytes64, bamBounds; DevBuf<u32> bamIndex, bamIndexAlt, bamBytes;
     DevBuf<u64> dupPrimary, dupMate, dupRank, dupCluster, dupSmall; DevBuf<u8> dupFlag;        // duplicate marking
     DevBuf<FragmentRecord> realignRecords; DevBuf<RealignGap> realignGaps, realignDeletionEnds; DevBuf<u32> realignPool, realignNext, realignList; DevBuf<u8> realignChanged;   // gap realignment
-    DevBuf<RescueJob> jobs; DevBuf<u32> rescueCounters, bitmaps, candJob, shadowCigars, jobBase, jobCount; DevBuf<i32> candPositions; DevBuf<Cand> shadowCands; DevBuf<CandSummary> candSummaries; DevBuf<u32> candRank;
+    DevBuf<RescueJob> jobs; DevBuf<u8> jobActive; DevBuf<u32> rescueCounters, bitmaps, candJob, shadowCigars, jobBase, jobCount; DevBuf<i32> candPositions; DevBuf<Cand> shadowCands; DevBuf<CandSummary> candSummaries; DevBuf<u32> candRank;
     DevBuf<Counters> counters, countersSaved; DevBuf<u8> bswFlags;
     std::map<std::string, KernelTimer> timers;
     struct PendingTimer { std::string name; hipEvent_t e0, e1; };
@@ -1572,9 +1572,9 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
     c->overflowList.reserve(chunk);
     RescueBuffers rb; std::memset(&rb, 0, sizeof(rb));
     rb.jobsCap = 4 * chunk; rb.bitmapCap = 64 * rb.jobsCap; rb.candRegionSize = (24 * chunk + CAND_REGIONS - 1) / CAND_REGIONS; rb.candCap = rb.candRegionSize * CAND_REGIONS;
-    c->jobs.reserve(rb.jobsCap); c->longJobs.reserve(rb.jobsCap); c->bitmaps.reserve(rb.bitmapCap); c->candPositions.reserve(rb.candCap); c->candJob.reserve(rb.candCap);
+    c->jobs.reserve(rb.jobsCap); c->jobActive.reserve(size_t(rb.jobsCap) + 4); c->longJobs.reserve(rb.jobsCap); c->bitmaps.reserve(rb.bitmapCap); c->candPositions.reserve(rb.candCap); c->candJob.reserve(rb.candCap);
     c->shadowCands.reserve(rb.candCap); c->candSummaries.reserve(rb.candCap); c->candRank.reserve(rb.candCap); c->shadowCigars.reserve(size_t(rb.candCap) * 3); c->jobBase.reserve(chunk); c->jobCount.reserve(chunk); c->rescueCounters.reserve(4 + 2 * CAND_REGIONS);
-    rb.jobs = c->jobs.p; rb.bitmaps = c->bitmaps.p; rb.candPositions = c->candPositions.p; rb.candJob = c->candJob.p; rb.shadowCands = c->shadowCands.p; rb.candSummaries = c->candSummaries.p; rb.candRank = c->candRank.p;
+    rb.jobs = c->jobs.p; rb.jobActive = c->jobActive.p; rb.bitmaps = c->bitmaps.p; rb.candPositions = c->candPositions.p; rb.candJob = c->candJob.p; rb.shadowCands = c->shadowCands.p; rb.candSummaries = c->candSummaries.p; rb.candRank = c->candRank.p;
     rb.shadowCigars = c->shadowCigars.p; rb.jobBase = c->jobBase.p; rb.jobCount = c->jobCount.p;
     rb.jobCounter = c->rescueCounters.p; rb.bitmapCounter = c->rescueCounters.p + 1; rb.candCounter = c->rescueCounters.p + 4;
     c->clusterSums.reserve(chunk); c->heavyList.reserve(chunk); c->mediumList.reserve(chunk); c->largeList.reserve(chunk); c->midList.reserve(chunk); c->hugeList.reserve(chunk); c->xlList.reserve(chunk); c->heavyCount.reserve(16); c->heavyFlag.reserve(chunk);

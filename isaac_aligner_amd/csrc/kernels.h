@@ -138,6 +138,7 @@ static const u32 CAND_REGIONS = 256;
 struct RescueBuffers
 {
     RescueJob *jobs; u32 jobsCap; u32 *jobCounter;
+    u8 *jobActive;                 // per slot: a problem for k_rescue_windows (valid, not given up by the plan).  4 MB a chunk: the kernel's empty wavefronts -- two slots in three -- learn it from L2 instead of the 128-byte record
     u32 *bitmaps; u32 bitmapCap; u32 *bitmapCounter;
     i32 *candPositions; u32 *candJob; Cand *shadowCands; CandSummary *candSummaries; u32 *shadowCigars; u32 *candRank; u32 candCap; u32 *candCounter;
     // candidate slots are handed out from CAND_REGIONS equal regions, each with its own counter (candCounter[region]): one

@@ -78,6 +78,7 @@ __global__ __launch_bounds__(SELECT_BLOCK) void k_plan_rescue(const TemplateCons
                 const u32 at = atomicAdd(rb.bitmapCounter, words);
                 if (at + words > rb.bitmapCap) jobs[i].fallback = 1; else { jobs[i].bitmapBase = at; jobs[i].bitmapWords = words; }
             }
+            for (u32 i = 0; i < reserve; ++i) rb.jobActive[base + i] = i < n && jobs[i].valid && !jobs[i].fallback;
         }
     }
     rb.jobBase[t] = base; rb.jobCount[t] = n;
@@ -331,28 +332,29 @@ __device__ inline void rescueWindowScanShort(const DevReference &R, const Rescue
 __device__ inline void rescueWindowsProblem(const DevParams &P, const DevReference &R, const u8 *bcl, u32 clusterBase, const RescueBuffers &rb, u32 j, u32 lane,
                                             u32 *tab, u32 *ldsBitmap, u32 *present, u16 *blockPrefix, u32 *mateCodes, u32 *firstFlags)
 {
-    // The slot's record and the number of slots in use, asked for together and awaited once: 24 words of the record through the scalar cache.  (Left to the
+    // Is there a problem in the slot?  Two slots in three are empty (they are reserved per seeded candidate): a byte per slot, four megabytes that stay in L2, and
+    // the number of slots in use say so; the empty wavefronts leave on that.  Then the record, 24 words through the scalar cache, awaited once.  (Left to the
     // compiler the byte-sized fields came by vector loads, the two of them that decide whether there is anything to do first and the rest behind the branch, and the
     // counter in between: three memory latencies in a row before the first useful load was issued.)
     typedef u32 Words16 __attribute__((ext_vector_type(16)));
     typedef u32 Words8 __attribute__((ext_vector_type(8)));
-    Words16 head; Words8 tail; u32 slotsInUse;
-    {
-        const RescueJob *record = rb.jobs + imin(j, rb.jobsCap - 1);
-        asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx8 %1, %3, 0x40\n\ts_load_dword %2, %4, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(head), "=&s"(tail), "=&s"(slotsInUse) : "s"(record), "s"(rb.jobCounter) : "memory");
-    }
+    const u32 slot = imin(j, rb.jobsCap - 1);
+    u32 activeBytes, slotsInUse;
+    asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(activeBytes), "=&s"(slotsInUse) : "s"(reinterpret_cast<const u32 *>(rb.jobActive) + (slot >> 2)), "s"(rb.jobCounter) : "memory");
+    const u32 nJobs = imin(slotsInUse, rb.jobsCap);
+    STAMP_BEGIN();
+    if (!(j < nJobs && ((activeBytes >> (8 * (slot & 3u))) & 0xffu))) return;
+    Words16 head; Words8 tail;
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(head), "=&s"(tail) : "s"(rb.jobs + slot) : "memory");
     static_assert(offsetof(RescueJob, windowLen) == 8 && offsetof(RescueJob, cluster) == 12 && offsetof(RescueJob, bitmapBase) == 32 && offsetof(RescueJob, shadowReadIndex) == 40 &&
                   offsetof(RescueJob, fallback) == 43 && offsetof(RescueJob, windowBaseHigh) == 86 && offsetof(RescueJob, windowBaseLow) == 88, "the words picked below");
     RescueJob job;
     job.windowLen = head[2]; job.cluster = head[3]; job.bitmapBase = head[8];
     job.shadowReadIndex = u8(head[10]); job.shadowReverse = u8(head[10] >> 8); job.valid = u8(head[10] >> 16); job.fallback = u8(head[10] >> 24);
     job.windowBaseHigh = u16(tail[5] >> 16); job.windowBaseLow = tail[6];
-    const u32 nJobs = imin(slotsInUse, rb.jobsCap);
-    STAMP_BEGIN();
-    const bool active = j < nJobs && job.valid && !job.fallback;
+    const bool active = true;
     STAMP(0);
-    if (!active) return;
     u32 pushes = 0, total = 0, bitmapWords = 0, L = 0, smallWord = 0, smallIncl = 0;
     bool small = true;
     u32 *bitmap = ldsBitmap;
