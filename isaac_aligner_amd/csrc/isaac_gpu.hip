@@ -70,6 +70,7 @@ namespace isaac_host_resolve { struct Resolver; void destroy(Resolver *r); }    
 struct isaac_gpu_ctx
 {
     bool ownsStream = false; u32 cigarExtra = 32;
+    hipStream_t bswStream = nullptr; hipEvent_t bswBegin = nullptr, bswEnd = nullptr;   // ISAAC_GPU_BSW_SIDE_STREAM: the banded SW on a stream of the lowest priority (a measurement)
     int device = 0; hipStream_t stream = nullptr;
     hipStream_t downloadStream = nullptr; std::deque<std::pair<u64, hipEvent_t> > downloads; u64 downloadTicket = 0;      // isaac_gpu_download_async
     isaac_params params; DevParams P;
@@ -193,13 +194,33 @@ __device__ inline u64 lowerBound(const TableEntry *entries, u64 lo, u64 hi, u64 
 // the chip's rate of random lines (49.5 G lines/s whatever the access shape, profiles/exp_r6_random_lines.log) and seven lines where the bisection touches
 // one cost more than the shorter chain brings; (3) the second iteration as a kernel of its own over a list of the clusters with an open read: 1.77 ms -- as a
 // second round of this kernel its long chains run beside other workgroups' first rounds, alone they run by themselves.  profiles/exp_r6_find.log
-// prefixTable[b] = first table index whose k-mer has leading bits >= b (b = 0 .. 2^bits, the last one = n)
-__global__ void k_prefix_table(const TableEntry *kmers, u64 n, u32 bits, u32 *table)
+// starts[b] = first table index whose k-mer has leading bits >= b (b = 0 .. 2^bits, the last one = n)
+__global__ void k_prefix_table(const TableEntry *kmers, u64 n, u32 bits, u32 *starts)
 {
     const u64 b = u64(blockIdx.x) * blockDim.x + threadIdx.x;
     if (b > (u64(1) << bits)) return;
     u32 steps = 0;
-    table[b] = (b >> bits) ? u32(n) : u32(lowerBound(kmers, 0, n, b << (64 - bits), steps));
+    starts[b] = (b >> bits) ? u32(n) : u32(lowerBound(kmers, 0, n, b << (64 - bits), steps));
+}
+// The directory k_find_matches reads: two words a bucket, the bucket's first table index and a fingerprint of each of its first four entries -- the eight bits of the
+// k-mer behind the bucket's own.  A probe whose fingerprint is not among those of a bucket of up to four entries has no match (the bits differ, so does the k-mer)
+// and ends at the directory's line without touching the table: half the probes and more, every read is looked up on both strands.
+#ifndef ISAAC_FIND_FINGERPRINTS
+#define ISAAC_FIND_FINGERPRINTS 1
+#endif
+__device__ inline u32 kmerFingerprint(u64 kmer, u32 bits) { return u32(kmer >> (56 - bits)) & 0xffu; }
+__global__ void k_prefix_directory(const TableEntry *kmers, u32 bits, const u32 *starts, u32 *directory)
+{
+    const u64 b = u64(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (b > (u64(1) << bits) + 1) return;
+    u32 first = 0xffffffffu, prints = 0;
+    if (b <= (u64(1) << bits))
+    {
+        first = starts[b];
+        const u32 end = (b >> bits) ? first : starts[b + 1];
+        for (u32 i = 0; i < 4 && first + i < end; ++i) prints |= kmerFingerprint(kmers[first + i].kmer, bits) << (8 * i);
+    }
+    directory[2 * b] = first; directory[2 * b + 1] = prints;
 }
 
 __global__ __launch_bounds__(FIND_BLOCK) void k_find_matches(DevParams P, DevReference R, const u8 *bcl, u32 nClusters, u32 clusterBase, u32 tile,
@@ -269,9 +290,18 @@ __global__ __launch_bounds__(FIND_BLOCK) void k_find_matches(DevParams P, DevRef
                     if (R.prefixTable)
                     {   // the k-mer's leading bits select a slice of the table: one 8-byte read instead of most of the bisection
                         const u64 bucket = kmer >> (64 - R.prefixBits);
-                        const uint2 range = *reinterpret_cast<const uint2 *>(R.prefixTable + bucket);   // [bucket], [bucket + 1]
+                        const uint4 range = *reinterpret_cast<const uint4 *>(R.prefixTable + 2 * bucket);   // [bucket], [bucket + 1]: first index, fingerprints
                         ++steps;
-                        lo = range.x; hi = range.y;
+                        lo = range.x; hi = range.z;
+#if ISAAC_FIND_FINGERPRINTS
+                        if (hi - lo <= 4)
+                        {   // is the probe's fingerprint among the bucket's?  (x ^ pattern has a zero byte; bytes past the bucket's end do not count)
+                            const u32 x = range.y ^ (kmerFingerprint(kmer, R.prefixBits) * 0x01010101u);
+                            const u32 zeroBytes = (x - 0x01010101u) & ~x & 0x80808080u;
+                            const u32 inBucket = hi == lo ? 0u : 0x80808080u >> (8 * (4 - u32(hi - lo)));
+                            if (!(zeroBytes & inBucket)) hi = lo;
+                        }
+#endif
                     }
                     // ExactMaskMatcher.cpp:118-126: reference entries with the same k-mer, at most repeatThreshold of them.
 #if ISAAC_FIND_SLICE
@@ -286,7 +316,7 @@ __global__ __launch_bounds__(FIND_BLOCK) void k_find_matches(DevParams P, DevRef
                             const uint4 v = lo + i < hi ? *reinterpret_cast<const uint4 *>(R.entries + lo + i) : make_uint4(0xffffffffu, 0xffffffffu, 0, 0);
                             e[i].kmer = u64(v.x) | (u64(v.y) << 32); e[i].position = u64(v.z) | (u64(v.w) << 32);
                         }
-                        ++steps;
+                        if (hi > lo) ++steps;
                         u32 before = 0;                              // entries of the slice below the k-mer (the slice is sorted)
 #pragma unroll
                         for (u32 i = 0; i < FIND_SLICE; ++i) { const bool in = lo + i < hi; before += (in && e[i].kmer < kmer) ? 1u : 0u; r += (in && e[i].kmer == kmer) ? 1u : 0u; }
@@ -598,12 +628,14 @@ void buildPrefixTable(isaac_gpu_ctx *c)
 {
     c->prefixBits = 0; c->prefixBorrowed = nullptr;
     if (!c->nKmers || c->nKmers >= (u64(1) << 32) || getenv("ISAAC_GPU_NO_PREFIX_TABLE")) return;
-    u32 bits = 16; while (bits < 30 && (u64(1) << bits) < c->nKmers) ++bits;     // about one entry per bucket (human: 2.7), 256 KB .. 4 GB
+    u32 bits = 16; while (bits < 30 && (u64(1) << bits) < c->nKmers) ++bits;     // about one entry per bucket (human: 2.7), 512 KB .. 8 GB
     const u64 entries = (u64(1) << bits) + 1;
-    c->prefixTable.reserve(entries + 1);                                            // + 1: the last bucket reads a pair
-    k_prefix_table<<<gridFor(entries, 256), 256, 0, c->stream>>>(c->tableEntries(), c->nKmers, bits, c->prefixTable.p);
+    DevBuf<u32> starts; starts.reserve(entries);
+    c->prefixTable.reserve(2 * (entries + 1));                                      // + 1: the last bucket reads a pair
+    k_prefix_table<<<gridFor(entries, 256), 256, 0, c->stream>>>(c->tableEntries(), c->nKmers, bits, starts.p);
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipMemsetAsync(c->prefixTable.p + entries, 0xff, 4, c->stream));
+    k_prefix_directory<<<gridFor(entries + 1, 256), 256, 0, c->stream>>>(c->tableEntries(), bits, starts.p, c->prefixTable.p);
+    HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(c->stream));
     c->prefixBits = bits;
 }
@@ -671,6 +703,7 @@ void isaac_gpu_destroy(isaac_gpu_ctx *c)
 #endif
     for (hipEvent_t e : c->eventPool) hipEventDestroy(e);
     if (c->downloadStream) { hipStreamSynchronize(c->downloadStream); for (auto &d : c->downloads) hipEventDestroy(d.second); hipStreamDestroy(c->downloadStream); }
+    if (c->bswStream) { hipStreamSynchronize(c->bswStream); hipStreamDestroy(c->bswStream); hipEventDestroy(c->bswBegin); hipEventDestroy(c->bswEnd); }
     if (c->ownsStream) hipStreamDestroy(c->stream);
     for (isaac_host_resolve::Resolver *r : c->resolvers) isaac_host_resolve::destroy(r);
     delete c;
@@ -1366,7 +1399,24 @@ static void launchGappedJobs(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clusterBa
         if (ISAAC_BSW_GLOBAL_FLAGS) c->bswFlags.reserve(size_t(65536) * (BSW_BLOCK / BSW_GROUP_LANES) * bswFlagBytes(maxReadLength));
         const auto kernel = maxReadLength <= BSW_REGISTER_BASES_SHORT ? k_gapped_jobs : staged ? k_gapped_jobs_staged : k_gapped_jobs_long;
         static const u32 grid = std::getenv("ISAAC_GPU_GAPPED_GRID") ? u32(std::max(256, std::atoi(std::getenv("ISAAC_GPU_GAPPED_GRID")))) : GAPPED_GRID;      // (measurements: workgroups the problems are dealt to)
-        kernel<<<grid, BSW_BLOCK, lds, c->stream>>>(c->P, c->ref(), bcl, clusterBase, gb.jobs, gb.counter, gb.cap, maxReadLength, gb.results, c->bswFlags.p);
+        // (measurements: ISAAC_GPU_BSW_SIDE_STREAM=1 runs the kernel on a stream of the device's lowest priority, between two events: with several contexts on one GPU
+        // the other contexts' short kernels are then dispatched ahead of its workgroups)
+        static const bool sideStream = std::getenv("ISAAC_GPU_BSW_SIDE_STREAM") && std::atoi(std::getenv("ISAAC_GPU_BSW_SIDE_STREAM"));
+        hipStream_t st = c->stream;
+        if (sideStream)
+        {
+            if (!c->bswStream)
+            {
+                int least = 0, greatest = 0;
+                HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+                HIP_CHECK(hipStreamCreateWithPriority(&c->bswStream, hipStreamNonBlocking, least));
+                HIP_CHECK(hipEventCreateWithFlags(&c->bswBegin, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&c->bswEnd, hipEventDisableTiming));
+            }
+            HIP_CHECK(hipEventRecord(c->bswBegin, c->stream)); HIP_CHECK(hipStreamWaitEvent(c->bswStream, c->bswBegin, 0));
+            st = c->bswStream;
+        }
+        kernel<<<grid, BSW_BLOCK, lds, st>>>(c->P, c->ref(), bcl, clusterBase, gb.jobs, gb.counter, gb.cap, maxReadLength, gb.results, c->bswFlags.p);
+        if (sideStream) { HIP_CHECK(hipEventRecord(c->bswEnd, c->bswStream)); HIP_CHECK(hipStreamWaitEvent(c->stream, c->bswEnd, 0)); }
     }
     HIP_CHECK(hipGetLastError());
     ScopedTimer t(c, rescanTimer);

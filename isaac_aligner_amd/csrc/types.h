@@ -120,7 +120,7 @@ struct DevReference
     const TableEntry *entries;// the sorted 32-mer table (all masks concatenated): k-mer and ReferencePosition side by side, as the mask files hold them
     u64 nKmers;
     const u32 *karyotype;     // contig id translation of ReferenceKmer::getTranslatedPosition, NULL = identity
-    const u32 *prefixTable;   // optional: first table index of every PREFIX_BITS-bit k-mer prefix (+ end sentinel)
+    const u32 *prefixTable;   // optional: two words per PREFIX_BITS-bit k-mer prefix (+ end sentinel): its first table index, fingerprints of its first four entries
     u32 prefixBits;
     const u32 *packedBases;   // the same bases 2 bits each, 16 per word, base i of a word at bits 2i: A 0, C 1, T 2, G 3 ((ASCII >> 1) & 3)
     const u32 *notBase;       // 1 bit per base: set where it is not one of ACGT (32 per word); both arrays end with spare words
