@@ -70,6 +70,7 @@ namespace isaac_host_resolve { struct Resolver; void destroy(Resolver *r); }    
 struct isaac_gpu_ctx
 {
     bool ownsStream = false; u32 cigarExtra = 32;
+    u32 orderedClusters = 0; const void *orderedFor = nullptr; u32 orderedBase = 0;   // the chunk c->clusterOrder was last made for by the fragment stage (k_plan_rescue takes it as it is)
     hipStream_t bswStream = nullptr; hipEvent_t bswBegin = nullptr, bswEnd = nullptr;   // ISAAC_GPU_BSW_SIDE_STREAM: the banded SW on a stream of the lowest priority (a measurement)
     int device = 0; hipStream_t stream = nullptr;
     hipStream_t downloadStream = nullptr; std::deque<std::pair<u64, hipEvent_t> > downloads; u64 downloadTicket = 0;      // isaac_gpu_download_async
@@ -170,7 +171,10 @@ static void resolveTimers(isaac_gpu_ctx *c)
 #ifndef ISAAC_FIND_POSITION_ON_HIT
 #define ISAAC_FIND_POSITION_ON_HIT 1
 #endif
-static const u32 FIND_GROUP = 8, FIND_BLOCK = 256, FIND_CLUSTERS_PER_BLOCK = FIND_BLOCK / FIND_GROUP;
+#ifndef ISAAC_FIND_GROUP
+#define ISAAC_FIND_GROUP 8
+#endif
+static const u32 FIND_GROUP = ISAAC_FIND_GROUP, FIND_BLOCK = 256, FIND_CLUSTERS_PER_BLOCK = FIND_BLOCK / FIND_GROUP;      // (lanes per cluster: a power of two)
 #ifndef ISAAC_FIND_SLICE
 #define ISAAC_FIND_SLICE 4
 #endif
@@ -1494,6 +1498,7 @@ static void launchBuildFragments(isaac_gpu_ctx *c, const uint8_t *bcl, u32 clust
         ScopedTimer t(c, "finish_candidates");
 #if ISAAC_CLUSTER_ORDER
         order = orderClustersByKind(c, n, nullptr);
+        c->orderedClusters = n; c->orderedFor = bcl; c->orderedBase = clusterBase;
 #endif
         k_finish_candidates<<<gridFor(n, 64), 64, 0, c->stream>>>(c->P, n, withGaps, c->indelList.p, c->gappedCounters.p + 2, c->pools, gb, order, list1, c->generalCount.p + 1);
     }
@@ -1675,7 +1680,11 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
         {
             ScopedTimer tm(c, "plan_rescue");
 #if ISAAC_CLUSTER_ORDER && ISAAC_PLAN_ORDER
-            order = orderClustersByKind(c, n, nullptr);
+            // the order the fragment stage made for this chunk is taken as it is: what the stage did to the lists since (duplicates dropped, gapped alignments) moves
+            // few clusters to another kind, and nothing but the waves' uniformity depends on the order (ISAAC_GPU_PLAN_REORDER=1 makes it anew: a measurement)
+            static const bool reorder = std::getenv("ISAAC_GPU_PLAN_REORDER") && std::atoi(std::getenv("ISAAC_GPU_PLAN_REORDER"));
+            if (!reorder && c->orderedClusters == n && c->orderedFor == bcl && c->orderedBase == done && c->clusterOrder.p) order = c->clusterOrder.p;
+            else order = orderClustersByKind(c, n, nullptr);
 #endif
             k_plan_rescue<<<gridFor(n, SELECT_BLOCK), SELECT_BLOCK, 0, st>>>(c->templateConstants.p, R, done, n, c->pools, rb, order);
             HIP_CHECK(hipGetLastError());
@@ -1708,6 +1717,7 @@ static int selectFromSource(isaac_gpu_ctx *c, const uint8_t *bcl, uint32_t nClus
 #if ISAAC_CLUSTER_ORDER
             // from here on the kinds know the clusters' rescue problems as well (k_cluster_sums16, k_select)
             order = orderClustersByKind(c, n, rb.jobCount);
+            c->orderedClusters = 0;
 #endif
             k_cluster_sums16<<<gridFor(n, SUMS16_GROUPS), 16 * SUMS16_GROUPS, 0, st>>>(c->P, c->pools, n, rb, gbRescue, sb, c->counters.p, order);
             k_cluster_sums<<<8192, 256, 0, st>>>(c->P, c->pools, rb, gbRescue, sb, c->counters.p);
