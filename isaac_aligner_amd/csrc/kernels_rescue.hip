@@ -102,6 +102,26 @@ __device__ inline WindowBits loadWindowBits(const DevReference &R, u64 g)
     return w;
 }
 static_assert(RW_PER_LANE + 6 <= 32, "a lane's window bases fit the words loadWindowBits returns");
+// The same for window position `offset` of a window whose first base has index `windowBase` in the concatenated contigs, the same in every lane: the 64-bit part
+// of the address arithmetic is the wave's (scalar registers), a lane adds a 32-bit word offset; the clamp at the reference's end is a minimum with what is left
+// of the reference behind the window's first base.  (No branch: two paths that meet again would each have to finish their loads where they stand.)
+__device__ inline WindowBits loadWindowBits(const DevReference &R, u64 windowBase, u32 offset)
+{
+    WindowBits w;
+    const u64 room = R.totalBases - windowBase;                       // (windows begin inside the reference)
+    offset = imin(offset, room > 0xffffffffull ? 0xffffffffu : u32(room));
+    const u32 o = u32(windowBase & 15u) + offset;
+    const u32 *pw = R.packedBases + (windowBase >> 4);
+    const u32 at = o >> 4;
+    const u32 w0 = pw[at], w1 = pw[at + 1], w2 = pw[at + 2];
+    const u32 shift = 2 * (o & 15u);
+    w.codes = u64(__builtin_amdgcn_alignbit(w1, w0, shift)) | (u64(__builtin_amdgcn_alignbit(w2, w1, shift)) << 32);
+    const u32 on = u32(windowBase & 31u) + offset;
+    const u32 *pn = R.notBase + (windowBase >> 5);
+    const u32 atn = on >> 5;
+    w.notBase = __builtin_amdgcn_alignbit(pn[atn + 1], pn[atn], on);
+    return w;
+}
 
 // k_rescue_windows: one wave per rescue problem (ShadowAligner::findShadowCandidatePositions, ShadowAligner.cpp:53-112).
 // The mate's 7-mers go to an LDS hash table (first read position per k-mer).  The window is walked in tiles of 64 x RW_PER_LANE bases:
@@ -223,7 +243,7 @@ __device__ inline void rescueWindowScanShort(const DevReference &R, const Rescue
     for (i32 tile = 0; tile * i32(64 * PL) <= lastStart; ++tile)
     {
         const i32 p0 = tile * i32(64 * PL) + i32(lane * PL);               // window position of this lane's first base
-        const WindowBits wb = tile ? loadWindowBits(R, windowBase + u64(p0)) : firstTile;
+        const WindowBits wb = tile ? loadWindowBits(R, windowBase, u32(p0)) : firstTile;
         const u32 lo = u32(wb.codes), hi = u32(wb.codes >> 32);
         // five vector instructions per position: the word's LDS address (bits 2k+5 .. 2k+13 of the codes, times four, into the map's
         // base), the bit's number (the shifter takes the low five bits of bits 2k ..), the shift, and the bit into the mask
@@ -371,7 +391,7 @@ __device__ inline void rescueWindowsProblem(const DevParams &P, const DevReferen
         const u32 nStarts = job.windowLen > 6 ? job.windowLen - 6 : 0;
         const u32 perLane = __builtin_amdgcn_readfirstlane(!small ? RW_PER_LANE : nStarts <= 64 * 8 ? 8u : nStarts <= 64 * 12 ? 12u : 16u);
         const u64 windowBase = rescueJobWindowBase(job);
-        const WindowBits firstTile = loadWindowBits(R, windowBase + lane * perLane);
+        const WindowBits firstTile = loadWindowBits(R, windowBase, lane * perLane);
         // ... and so are the lane's eight bytes of the mate: they arrive while the tables are cleared
         ReadView read; read.bcl = bcl + u64(clusterBase + job.cluster) * P.clusterLength + P.readOffset[r]; read.length = L; read.endCyclesMasked = 0; read.firstCycle = 0;
         const bool reverse = job.shadowReverse != 0;
@@ -391,8 +411,9 @@ __device__ inline void rescueWindowsProblem(const DevParams &P, const DevReferen
         for (u32 i = lane; i < (small ? (nKmers + 3) / 4 : RW_TABLE / 4); i += 64) reinterpret_cast<uint4 *>(tab)[i] = make_uint4(KMER_EMPTY, KMER_EMPTY, KMER_EMPTY, KMER_EMPTY);
         if (!small) bitmap = rb.bitmaps + job.bitmapBase;
         if (small) for (u32 i = lane; i < RW_PRESENT_WORDS / 4; i += 64) reinterpret_cast<uint4 *>(present)[i] = make_uint4(0, 0, 0, 0);
-        for (u32 i = lane; i < bitmapWords; i += 64) bitmap[i] = 0;
-        if (!small) __threadfence();
+        // (the two address spaces apart: through the one pointer the stores and the count's loads below are flat instructions)
+        if (small) { if (lane < bitmapWords) ldsBitmap[lane] = 0; }
+        else { for (u32 i = lane; i < bitmapWords; i += 64) bitmap[i] = 0; __threadfence(); }
         __builtin_amdgcn_wave_barrier();
         STAMP(1);
         // the mate's 7-mers: first read position of every k-mer (ShadowAligner::hashShadowKmers, :53-72)
@@ -529,7 +550,7 @@ __device__ inline void rescueWindowsProblem(const DevParams &P, const DevReferen
         // at most: its words and their running count stay in registers for the enumeration below)
         if (small)
         {
-            smallWord = lane < bitmapWords ? bitmap[lane] : 0u;
+            smallWord = lane < bitmapWords ? ldsBitmap[lane] : 0u;
             smallIncl = waveInclusiveAdd(u32(__popc(smallWord)));
             total = u32(__builtin_amdgcn_readlane(int(smallIncl), 63));
         }
