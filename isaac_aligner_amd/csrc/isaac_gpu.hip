@@ -227,6 +227,12 @@ __global__ void k_prefix_directory(const TableEntry *kmers, u32 bits, const u32 
     directory[2 * b] = first; directory[2 * b + 1] = prints;
 }
 
+#ifndef ISAAC_WAVES_FIND
+#define ISAAC_WAVES_FIND 0      // (measurements: scripts/exp_r6_find_waves.sh builds the kernel for eight and for four waves per SIMD)
+#endif
+#if ISAAC_WAVES_FIND
+__attribute__((amdgpu_waves_per_eu(ISAAC_WAVES_FIND, ISAAC_WAVES_FIND)))
+#endif
 __global__ __launch_bounds__(FIND_BLOCK) void k_find_matches(DevParams P, DevReference R, const u8 *bcl, u32 nClusters, u32 clusterBase, u32 tile,
                                                              Match *staging, u32 *counts, u32 stride, u32 *contigHits, Counters *counters)
 {

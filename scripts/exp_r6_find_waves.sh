@@ -1,5 +1,6 @@
 #!/bin/bash
 # k_find_matches at 7 (the product: 70 registers), 8 (64 registers, two spilled) and 4 waves per SIMD: how much of its time is waiting that more waves would cover
+# build first:  for w in 8 4; do ISAAC_GPU_BUILD_TAG=find${w}w ISAAC_GPU_BUILD_FLAGS=-DISAAC_WAVES_FIND=$w python -m isaac_aligner_amd.build; done
 mkdir -p gpurun_out
 for v in "" find8w find4w; do
   if [ -n "$v" ]; then export ISAAC_GPU_LIBRARY=$PWD/isaac_aligner_amd/libisaac_gpu_$v.so; else unset ISAAC_GPU_LIBRARY; fi
