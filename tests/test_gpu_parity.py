@@ -654,3 +654,93 @@ def test_sequencing_adapters_on_short_inserts(torch, oracle, adapters, L):
     prec, pcig, _ = ref.select(plain, bcl, om, ptls, ohits, n_clusters_hint=n)
     assert not compare_records(prec, pcig, rec2, cig2)
     assert compare_records(orec, ocig, rec2, cig2)            # (the two runs do differ)
+
+
+def _rescue_window_cases(rng, genome, n, L):
+    """Pairs whose second read cannot be seeded (a substitution in every 32-base seed) and must be rescued from the first, over places that try k_rescue_windows'
+    shortcuts: the mate's locus twice in the window a few hundred bases apart (two diagonals of hits in one lane's positions), tandem repeats and homopolymers under
+    the mate (7-mers that occur more than once in it: no position is "the first" for most of them), Ns in the mate and in the window, an indel in the mate (the
+    run of hits changes its diagonal half way).  Returns BCL bytes [n, 2L]; the genome (a bytearray) is edited in place before the index is built."""
+    code = {65: 0, 67: 1, 71: 2, 84: 3}
+    G = len(genome)
+    places = np.arange(3000, G - 3000, 2000)[:n]
+    places = places + rng.integers(0, 400, len(places))
+    kinds = rng.integers(0, 5, len(places))
+    for x, kind in zip(places, kinds):
+        x = int(x)
+        if kind == 0:      # the stretch under the mate once more, 230-330 bases on, two bases changed
+            d = int(rng.integers(230, 330))
+            copy = bytearray(genome[x:x + 200])
+            for q in rng.integers(0, 200, 2):
+                copy[int(q)] = b"ACGT"[int(rng.integers(0, 4))]
+            genome[x + d:x + d + 200] = copy
+        elif kind == 1:    # a tandem repeat under the mate
+            unit = bytes(rng.choice(list(b"ACGT"), int(rng.integers(2, 9))).astype(np.uint8))
+            genome[x + 40:x + 140] = (unit * 60)[:100]
+        elif kind == 2:    # a homopolymer
+            genome[x + 60:x + 60 + 45] = bytes([b"ACGT"[int(rng.integers(0, 4))]]) * 45
+        elif kind == 3:    # Ns in the window, beside the mate
+            genome[x - 40:x - 40 + int(rng.integers(1, 12))] = b"N" * int(rng.integers(1, 12))
+    rows = []
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    for x, kind in zip(places, kinds):
+        x = int(x)
+        insert = int(rng.integers(330, 420))
+        first = x + L - insert                                  # read 1 forward from here; read 2 is the reverse complement of [x, x + L)
+        if first < 0:
+            continue
+        r1 = bytes(genome[first:first + L])
+        mate = bytearray(genome[x:x + L])
+        if b"N" in r1 or b"N" in mate:
+            continue
+        if kind == 4:      # an insertion or a deletion in the mate
+            q, k = int(rng.integers(40, L - 40)), int(rng.integers(1, 6))
+            if rng.random() < 0.5:
+                mate = (mate[:q] + bytearray(rng.choice(list(b"ACGT"), k).astype(np.uint8).tobytes()) + mate[q:])[:L]
+            else:
+                mate = (mate[:q] + bytearray(genome[x + q + k:x + L + k]))[:L]
+        r2 = bytearray(bytes(mate).translate(comp)[::-1])
+        for s in range(0, L - 31, 32):                          # no seed of read 2 survives
+            q = s + int(rng.integers(4, 28))
+            r2[q] = b"ACGT"[(b"ACGT".index(r2[q]) + 1 + int(rng.integers(0, 3))) % 4]
+        row = np.empty(2 * L, np.uint8)
+        quality = rng.integers(25, 41, 2 * L).astype(np.uint8)
+        bases = np.array([code[c] for c in r1 + bytes(r2)], np.uint8)
+        row[:] = (quality << 2) | bases
+        if rng.random() < 0.3:                                  # a base without quality is an N
+            row[L + int(rng.integers(0, L))] = 0
+        rows.append(row)
+    return np.stack(rows)
+
+
+@pytest.mark.parametrize("L", [100, 150, 250])
+def test_rescue_windows_shortcuts(torch, oracle, L):
+    """mate rescue where k_rescue_windows' first-position-by-rank table and its explained runs of hits have something to get wrong (see _rescue_window_cases)"""
+    from isaac_aligner_amd import gpu, synth
+    rng = np.random.default_rng(100 + L)
+    contigs = synth.make_genome(1000000, seed=31 + L, n_contigs=1)
+    genome = bytearray(bytes(contigs[0].numpy()))
+    crafted = _rescue_window_cases(rng, genome, 1500, L)
+    host_contigs = [bytes(genome)]
+    ordinary = synth.make_read_pairs([torch.frombuffer(bytearray(host_contigs[0]), dtype=torch.uint8)], 3000, L, seed=77, avoid_gaps=True)[0].numpy()
+    bcl = np.concatenate([ordinary, crafted])
+    assert len(crafted) > 250
+    p = options.default_params(L, L)
+    al = gpu.Aligner(p, 0, host_contigs)
+    al.build_index()
+    dev_bcl = torch.from_numpy(bcl).cuda()
+    m, o, hits = al.find_matches(dev_bcl)
+    al.set_loaded_contigs(hits)
+    tls = al.determine_tls(dev_bcl, m, o)
+    rec, cig = al.records_to_numpy(*al.select(dev_bcl, m, o, tls))
+    ref = oracle.reference(host_contigs)
+    ref.set_index(al.get_index())
+    om, ohits = ref.find_matches(p, bcl, len(bcl))
+    assert (sort_matches(om) == sort_matches(gpu_matches_numpy(m))).all()
+    otls = ref.determine_tls(p, bcl, om, ohits)
+    assert otls.astuple() == tls.astuple()
+    orec, ocig, _ = ref.select(p, bcl, om, otls, ohits, n_threads=os.cpu_count() or 1, n_clusters_hint=len(bcl))
+    assert not compare_records(orec, ocig, rec, cig)
+    # the crafted pairs' second reads: unseeded, most of them placed by the rescue all the same
+    second = orec[2 * len(ordinary) + 1::2]
+    assert (second["flags"] & 2 == 0).mean() > 0.5, (second["flags"] & 2 == 0).mean()
