@@ -713,16 +713,18 @@ def _rescue_window_cases(rng, genome, n, L):
     return np.stack(rows)
 
 
-@pytest.mark.parametrize("L", [100, 150, 250])
-def test_rescue_windows_shortcuts(torch, oracle, L):
-    """mate rescue where k_rescue_windows' first-position-by-rank table and its explained runs of hits have something to get wrong (see _rescue_window_cases)"""
+@pytest.mark.parametrize("L,insert_sd", [(100, 50.0), (150, 50.0), (250, 50.0), (150, 170.0)])
+def test_rescue_windows_shortcuts(torch, oracle, L, insert_sd):
+    """mate rescue where k_rescue_windows' first-position-by-rank table and its explained runs of hits have something to get wrong (see _rescue_window_cases);
+    with the wide template length distribution the windows are 1 500 bases and more: two tiles of 64 x 16 positions"""
     from isaac_aligner_amd import gpu, synth
-    rng = np.random.default_rng(100 + L)
+    rng = np.random.default_rng(100 + L + int(insert_sd))
     contigs = synth.make_genome(1000000, seed=31 + L, n_contigs=1)
     genome = bytearray(bytes(contigs[0].numpy()))
     crafted = _rescue_window_cases(rng, genome, 1500, L)
     host_contigs = [bytes(genome)]
-    ordinary = synth.make_read_pairs([torch.frombuffer(bytearray(host_contigs[0]), dtype=torch.uint8)], 3000, L, seed=77, avoid_gaps=True)[0].numpy()
+    ordinary = synth.make_read_pairs([torch.frombuffer(bytearray(host_contigs[0]), dtype=torch.uint8)], 3000, L, seed=77, avoid_gaps=True, insert_mean=450.0 if insert_sd > 100 else 350.0,
+                                     insert_sd=insert_sd)[0].numpy()
     bcl = np.concatenate([ordinary, crafted])
     assert len(crafted) > 250
     p = options.default_params(L, L)
@@ -744,3 +746,5 @@ def test_rescue_windows_shortcuts(torch, oracle, L):
     # the crafted pairs' second reads: unseeded, most of them placed by the rescue all the same
     second = orec[2 * len(ordinary) + 1::2]
     assert (second["flags"] & 2 == 0).mean() > 0.5, (second["flags"] & 2 == 0).mean()
+    if insert_sd > 100:
+        assert otls.max - otls.min > 800, (otls.min, otls.max)
