@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--finders", type=int, default=1, help="contexts that do the lookups of the timed region side by side, a host thread each (a lookup ends with one host wait for its match count and contig flags: a single context leaves the GPU idle for it, 0.09 ms a step; with two or three the lookup phase is that much shorter and the step is not: profiles/exp_r6_finders.log)")
     ap.add_argument("--pairs-per-step", type=int, default=1_000_000)
     ap.add_argument("--genome-bases", type=int, default=3_100_000_000)
     ap.add_argument("--read-length", type=int, default=150)
@@ -262,6 +263,14 @@ def main():
     with torch.cuda.stream(finder_stream):
         finder = gpu.Aligner(params, local_rank, genome)
         finder.set_index_tensors(al.index_tensors())
+    finders, finder_streams = [finder], [finder_stream]
+    for _ in range(1, max(1, args.finders)):
+        st = torch.cuda.Stream(dev)
+        with torch.cuda.stream(st):
+            extra = gpu.Aligner(params, local_rank, genome)
+            extra.set_index_tensors(al.index_tensors())
+        finders.append(extra)
+        finder_streams.append(st)
     n_batches = args.warmup + args.steps
     per_rank = args.pairs_per_step
     batches = []
@@ -320,9 +329,10 @@ def main():
             pool = [torch.empty_like(out[s][0]) for s in range(args.steps) for _ in range(world)]
             pool += [torch.empty_like(out[s][2]) for s in range(args.steps) for _ in range(world)]
             del pool
-    with torch.cuda.stream(finder_stream):           # (the lookup context grows its buffers here, not in the timed steps)
-        finder.find_matches(batches[0], tile=tile_of(0), out=match_bufs[0])
-    finder.synchronize(); finder.reset_timers()
+    for f, st in zip(finders, finder_streams):       # (the lookup contexts grow their buffers here, not in the timed steps)
+        with torch.cuda.stream(st):
+            f.find_matches(batches[0], tile=tile_of(0), out=match_bufs[0])
+        f.synchronize(); f.reset_timers()
     for ctx in als:
         ctx.synchronize()
         ctx.reset_timers()
@@ -367,10 +377,21 @@ def main():
             with torch.cuda.stream(gather_stream):
                 gather_stream.wait_event(step_done)
                 gatherer.add(out[s][0], out[s][2], out[s][3])
-    for s in range(args.steps):                       # FindMatchesTransition for step s
-        with torch.cuda.stream(finder_stream):
-            m, o, hits = finder.find_matches(batches[args.warmup + s], tile=tile_of(s), out=match_bufs[s])
-            looked_up.append(finder_stream.record_event())
+    def look_up(s):                                   # FindMatchesTransition for step s, on the lookup context whose turn it is
+        torch.cuda.set_device(dev)
+        f, st = finders[s % len(finders)], finder_streams[s % len(finders)]
+        with torch.cuda.stream(st):
+            m, o, hits = f.find_matches(batches[args.warmup + s], tile=tile_of(s), out=match_bufs[s])
+            return m, o, hits, st.record_event()
+    ahead = None
+    if len(finders) > 1 and not args.stream_lookups:
+        # the two phases apart (the default): the lookups of the steps side by side, a host thread per lookup context (the calls release the interpreter)
+        import concurrent.futures
+        pool = concurrent.futures.ThreadPoolExecutor(len(finders))
+        ahead = [pool.submit(look_up, s) for s in range(args.steps)]
+    for s in range(args.steps):
+        m, o, hits, event = ahead[s].result() if ahead is not None else look_up(s)
+        looked_up.append(event)
         found.append((m, o))
         all_hits |= hits
         if not streaming:
@@ -383,13 +404,17 @@ def main():
                     ctx.set_loaded_contigs(loaded)    # MatchSelector loads only contigs that received matches: all of them from here on
         while streaming and next_select <= s:
             select_step(next_select); next_select += 1
+    t_lookups_done = time.perf_counter() - t_start    # (host time: every lookup has returned its contig flags by now)
     if not streaming:
         loaded = reduce_hits(all_hits)
         for ctx in als:
             ctx.set_loaded_contigs(loaded)
     while next_select < args.steps:
         select_step(next_select); next_select += 1
-    finder.synchronize()
+    if ahead is not None:
+        pool.shutdown()
+    for f in finders:
+        f.synchronize()
     for ctx in als:
         ctx.synchronize()
     gathered = gatherer.finish() if gatherer is not None else None
@@ -428,7 +453,7 @@ def main():
     free_b, total_b = torch.cuda.mem_get_info(dev)
     hbm_used_gb = round((total_b - free_b) / 1e9, 1)      # everything resident at the end of the run: index, reads, records, chunk scratch
     counters = al.counters()
-    for ctx in als[1:] + [finder]:                   # (the lookups' probes and matches are counted by the context that ran them)
+    for ctx in als[1:] + finders:                    # (the lookups' probes and matches are counted by the context that ran them)
         for key, value in ctx.counters().items():
             counters[key] += value
     timer_names = ("find_matches", "compact_matches", "build_fragments", "build_fragments_general", "align_candidates", "finish_candidates", "finish_candidates_general", "indel_fragments", "gapped_fragments",
@@ -442,7 +467,7 @@ def main():
             launches = sum(n for _, n in per)
             t[k] = (sum(ms * n for ms, n in per) / launches if launches else 0.0, launches)
         return t
-    timers = read_timers(als + [finder])
+    timers = read_timers(als + finders)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -610,7 +635,7 @@ def main():
         try:
             # the program gets the device as a run of its own would find it, beside this process's table and reads: the extra contexts (their timers
             # and records have been read) and torch's cached blocks go first
-            for extra in als[1:] + [finder]:
+            for extra in als[1:] + finders:
                 extra.close()
             del als[1:]
             torch.cuda.empty_cache()
@@ -860,7 +885,7 @@ def main():
                          "parallelism": "read shards x%d, %d context(s) per GPU taking the steps' selections in turn (one stream each, contigs and table shared), every step's records and packed CIGARs gathered to rank 0 behind the later steps; %s" % (
                              world, n_contexts, "all lookups before the first selection" if timed_streaming_from is None else
                              "every contig had a match after the lookup of step %d: from there on a step is selected as soon as it is looked up, the later lookups (a context of their own) beside the selections" % timed_streaming_from),
-                         "selections_began_after_lookup_of_step": timed_streaming_from, "hbm_used_gb": hbm_used_gb, "setup_s": round(t_setup, 1),
+                         "selections_began_after_lookup_of_step": timed_streaming_from, "lookup_phase_ms_per_step": round(1e3 * t_lookups_done / args.steps, 3), "lookup_contexts": len(finders), "hbm_used_gb": hbm_used_gb, "setup_s": round(t_setup, 1),
                          "genome_s": round(t_genome, 1), "index_build_s": round(t_index, 1), "tls": list(tls.astuple()), "pcie_inclusive": pcie, "bam_output": bam_info, "cli_end_to_end": cli_info},
               "roofline": roofline, "cpu_baseline": cpu, "counters": {k: int(v) for k, v in counters.items()}}
     result.update(parity)
