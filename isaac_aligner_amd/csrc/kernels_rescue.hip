@@ -33,7 +33,11 @@ __global__ __launch_bounds__(SELECT_BLOCK) void k_plan_rescue(const TemplateCons
     if (reserve)
     {
         // what does not fit: the cluster runs its rescues itself in the wave-per-cluster pass
-        if (base + reserve > rb.jobsCap) base = 0xffffffffu;
+        if (base + reserve > rb.jobsCap)
+        {   // (the slots of this reservation that do lie below the capacity belong to nobody: the kernels that walk the slots must not take what an earlier chunk left there for problems)
+            for (u32 i = base; i < rb.jobsCap; ++i) { rb.jobActive[i] = 0; rb.jobs[i].valid = 0; }
+            base = 0xffffffffu;
+        }
         RescueJob *jobs = 0xffffffffu == base ? nullptr : rb.jobs + base;
         LeanCtx x;
         x.P = &P; x.R = &R; x.tls = &constants->tls;
